@@ -1,0 +1,142 @@
+"""ctypes binding of oracle/libvaporetto_oracle.so (ORACLE = test infrastructure only).
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this module.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libvaporetto_oracle.so")
+
+
+def build(force: bool = False) -> str:
+    src = os.path.join(HERE, "vaporetto_oracle.c")
+    if force or not os.path.exists(LIB_PATH) or os.path.getmtime(LIB_PATH) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-C", HERE, "-B", "libvaporetto_oracle.so"], stdout=subprocess.DEVNULL)
+    return LIB_PATH
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            build()
+        L = C.CDLL(LIB_PATH)
+        L.vo_predictor_create.argtypes = [C.c_char_p, C.c_size_t, C.c_int, C.POINTER(C.c_void_p), C.c_char_p, C.c_size_t]
+        L.vo_predictor_destroy.argtypes = [C.c_void_p]
+        L.vo_predict.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t, C.c_void_p, C.c_void_p, C.POINTER(C.c_size_t)]
+        L.vo_count_boundaries.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
+        L.vo_predict_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p,
+                                       C.c_void_p, C.c_int, C.POINTER(C.c_uint64)]
+        L.vo_predict_tags.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t, C.c_void_p, C.c_void_p, C.POINTER(C.c_uint32)]
+        L.vo_tag_scores_probe.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t, C.c_int, C.c_uint32, C.c_uint32,
+                                          C.c_void_p, C.c_uint32]
+        L.vo_char_pattern_count.argtypes = [C.c_void_p]
+        L.vo_char_pattern_count.restype = C.c_uint32
+        L.vo_char_pattern_get.argtypes = [C.c_void_p, C.c_uint32, C.POINTER(C.c_int32), C.POINTER(C.c_uint32),
+                                          C.c_void_p, C.c_uint32]
+        L.vo_test_posw_add_assign.argtypes = [C.c_int32, C.c_void_p, C.c_uint32, C.c_int32, C.c_void_p, C.c_uint32,
+                                              C.POINTER(C.c_int32), C.c_void_p, C.POINTER(C.c_uint32), C.c_uint32]
+        _lib = L
+    return _lib
+
+
+class OracleError(Exception):
+    def __init__(self, status, msg):
+        super().__init__("status %d: %s" % (status, msg))
+        self.status = status
+        self.msg = msg
+
+
+class OraclePredictor:
+    """CPU oracle predictor (reference algorithm).  `predict_tags` as in Predictor::new."""
+
+    def __init__(self, model_bytes: bytes, predict_tags: bool = False):
+        self._h = C.c_void_p()
+        err = C.create_string_buffer(256)
+        st = lib().vo_predictor_create(model_bytes, len(model_bytes), int(predict_tags), C.byref(self._h), err, 256)
+        if st != 0:
+            raise OracleError(st, err.value.decode())
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            lib().vo_predictor_destroy(self._h)
+            self._h = None
+
+    def predict(self, text: str):
+        raw = text.encode("utf-8")
+        scores = np.zeros(max(len(raw), 1), dtype=np.int32)
+        labels = np.zeros(max(len(raw), 1), dtype=np.uint8)
+        nb = C.c_size_t()
+        st = lib().vo_predict(self._h, raw, len(raw), scores.ctypes.data, labels.ctypes.data, C.byref(nb))
+        if st != 0:
+            raise OracleError(st, "predict failed")
+        return scores[:nb.value].tolist(), labels[:nb.value].tolist()
+
+    def predict_batch(self, utf8: np.ndarray, byte_offsets: np.ndarray, nthreads: int = 1):
+        """utf8: uint8 array, byte_offsets: uint64[S+1].  Returns (scores, labels, out_offsets, A_char bytes)."""
+        S = len(byte_offsets) - 1
+        utf8 = np.ascontiguousarray(utf8, dtype=np.uint8)
+        byte_offsets = np.ascontiguousarray(byte_offsets, dtype=np.uint64)
+        ooff = np.zeros(S + 1, dtype=np.uint64)
+        st = lib().vo_count_boundaries(utf8.ctypes.data, byte_offsets.ctypes.data, S, ooff.ctypes.data)
+        if st != 0:
+            raise OracleError(st, "count_boundaries failed")
+        nb = int(ooff[S])
+        scores = np.zeros(nb, dtype=np.int32)
+        labels = np.zeros(nb, dtype=np.uint8)
+        ab = C.c_uint64()
+        st = lib().vo_predict_batch(self._h, utf8.ctypes.data, byte_offsets.ctypes.data, S, scores.ctypes.data,
+                                    labels.ctypes.data, ooff.ctypes.data, nthreads, C.byref(ab))
+        if st != 0:
+            raise OracleError(st, "predict_batch failed")
+        return scores, labels, ooff, ab.value
+
+    def predict_tags(self, text: str, labels=None):
+        raw = text.encode("utf-8")
+        n = len(text)
+        nt = C.c_uint32()
+        out = np.full(max(n, 1) * 64, -1, dtype=np.int32)
+        lab = None
+        if labels is not None:
+            lab = np.ascontiguousarray(labels, dtype=np.uint8)
+        st = lib().vo_predict_tags(self._h, raw, len(raw), lab.ctypes.data if lab is not None else None,
+                                   out.ctypes.data, C.byref(nt))
+        if st != 0:
+            raise OracleError(st, "predict_tags failed")
+        return out[:n * nt.value].reshape(n, nt.value) if nt.value else out[:0].reshape(n, 0), nt.value
+
+    def tag_scores_probe(self, text: str, which: int, token_id: int, pos: int, init):
+        raw = text.encode("utf-8")
+        z = np.array(init, dtype=np.int32)
+        st = lib().vo_tag_scores_probe(self._h, raw, len(raw), which, token_id, pos, z.ctypes.data, len(z))
+        if st != 0:
+            raise OracleError(st, "tag probe failed")
+        return z.tolist()
+
+    def char_patterns(self):
+        out = []
+        for i in range(lib().vo_char_pattern_count(self._h)):
+            off, ln = C.c_int32(), C.c_uint32()
+            w = np.zeros(64, dtype=np.int32)
+            lib().vo_char_pattern_get(self._h, i, C.byref(off), C.byref(ln), w.ctypes.data, 64)
+            out.append((off.value, w[:ln.value].tolist()))
+        return out
+
+
+def posw_add_assign(off_a, wa, off_b, wb):
+    a = np.array(wa, dtype=np.int32)
+    b = np.array(wb, dtype=np.int32)
+    out = np.zeros(64, dtype=np.int32)
+    off, ln = C.c_int32(), C.c_uint32()
+    lib().vo_test_posw_add_assign(off_a, a.ctypes.data, len(a), off_b, b.ctypes.data, len(b), C.byref(off),
+                                  out.ctypes.data, C.byref(ln), 64)
+    return off.value, out[:ln.value].tolist()

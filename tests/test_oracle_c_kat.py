@@ -1,0 +1,157 @@
+"""The C oracle (oracle/vaporetto_oracle.c, the reference's own algorithm) against every known-answer
+vector the reference's tests hold for the predict path, and against the brute-force spec oracle."""
+import numpy as np
+import pytest
+
+from oracle import cbind, spec
+from tests import kat
+from vaporetto_amd.modelfmt import ModelData, NgramData, WordWeightRecord, encode_model
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _build():
+    cbind.build()
+
+
+@pytest.mark.parametrize("name,cite,model,text,expected", kat.BOUNDARY_KATS, ids=[k[0] for k in kat.BOUNDARY_KATS])
+def test_boundary_kats(name, cite, model, text, expected):
+    p = cbind.OraclePredictor(encode_model(model))
+    scores, labels = p.predict(text)
+    assert scores == expected, cite
+    assert labels == [1 if s > 0 else 0 for s in expected]
+
+
+def tag_strings(model, text, labels, tags, nt):
+    """candidate indices -> the flat Option<str> array of Sentence::tags()."""
+    flat = []
+    bounds = list(labels) + [1]
+    for i in range(len(text)):
+        start = max([k + 1 for k in range(i) if bounds[k] == 1], default=0)
+        for j in range(nt):
+            idx = tags[i, j]
+            if idx < 0:
+                flat.append(None)
+            else:
+                tm = [t for t in model.tag_models if t.token == text[start:i + 1]][-1]
+                flat.append(tm.tags[j][idx])
+    return flat
+
+
+def test_predict_labels_and_tags():
+    m = kat.predictor_test_model()
+    text = "この人は地球人だ"
+    p = cbind.OraclePredictor(encode_model(m), predict_tags=True)
+    scores, labels = p.predict(text)
+    assert scores == [-22, 54, 58, 43, -54, 68, 48]  # predictor.rs:869
+    assert labels == kat.PREDICT_BOUNDARIES_LABELS
+    tags, nt = p.predict_tags(text)
+    assert nt == 2
+    assert tag_strings(m, text, labels, tags, nt) == kat.PREDICT_TAGS_EXPECTED  # predictor.rs:882-902
+
+
+def test_fill_tags_requires_predict_tags():
+    p = cbind.OraclePredictor(encode_model(kat.predictor_test_model()), predict_tags=False)
+    with pytest.raises(cbind.OracleError):  # predictor.rs:974-983 (#[should_panic])
+        p.predict_tags("この人は地球人だ")
+
+
+def test_char_tag_scores():
+    m = kat.char_tag_test_model()
+    p = cbind.OraclePredictor(encode_model(m), predict_tags=True)
+    assert p.predict(kat.CHAR_TAG_TEXT)[0] == kat.CHAR_TAG_BOUNDARY_SCORES
+    for token_id, pos, expected in kat.CHAR_TAG_SCORES:  # char_scorer.rs:507-524
+        z = p.tag_scores_probe(kat.CHAR_TAG_TEXT, 0, token_id, pos, [1] * 8)
+        assert z == expected + [1] * (8 - len(expected))
+
+
+def test_type_tag_scores():
+    m = kat.type_tag_test_model()
+    p = cbind.OraclePredictor(encode_model(m), predict_tags=True)
+    assert p.predict(kat.TYPE_TAG_TEXT)[0] == kat.TYPE_TAG_BOUNDARY_SCORES
+    for token_id, pos, expected in kat.TYPE_TAG_SCORES:  # type_scorer.rs:456-472
+        z = p.tag_scores_probe(kat.TYPE_TAG_TEXT, 1, token_id, pos, [1] * 8)
+        assert z == expected + [1] * (8 - len(expected))
+
+
+def test_char_weight_merger():
+    """char_scorer.rs:169-185, expressed through a model: n-grams get offset -W (=-3), dict words -len."""
+    m = ModelData(char_ngram_model=[NgramData("東京都", [1, 2, 3, 4]), NgramData("京都", [2, 4, 6, 8, 10])],
+                  dict_model=[WordWeightRecord("京都", [3, 6, 9]), WordWeightRecord("大阪", [4, 8, 12])],
+                  char_window_size=3)
+    p = cbind.OraclePredictor(encode_model(m))
+    assert p.char_patterns() == [(-3, [2, 7, 12, 17, 10]), (-2, [4, 8, 12]), (-3, [3, 9, 15, 21, 10])]
+
+
+@pytest.mark.parametrize("off_b,expected", [
+    (4, (-2, [1, 2, 3, 4, 0, 0, 2, 4, 8])), (2, (-2, [1, 2, 3, 4, 2, 4, 8])), (0, (-2, [1, 2, 5, 8, 8])),
+    (-1, (-2, [1, 4, 7, 12])), (-2, (-2, [3, 6, 11, 4])), (-4, (-4, [2, 4, 9, 2, 3, 4])),
+    (-5, (-5, [2, 4, 8, 1, 2, 3, 4])), (-7, (-7, [2, 4, 8, 0, 0, 1, 2, 3, 4]))])
+def test_positional_weight_add_assign(off_b, expected):
+    """predictor.rs:677-747."""
+    assert cbind.posw_add_assign(-2, [1, 2, 3, 4], off_b, [2, 4, 8]) == expected
+
+
+@pytest.mark.parametrize("fixture,text,expected,cite", kat.FIXTURE_SPLITS)
+def test_fixture_splits(fixture, text, expected, cite):
+    raw, _ = kat.load_fixture(fixture)
+    _, labels = cbind.OraclePredictor(raw).predict(text)
+    assert spec.tokens(text, labels) == expected, cite
+
+
+@pytest.mark.parametrize("fixture,text,expected", kat.FIXTURE_TAGGED)
+def test_fixture_tags(fixture, text, expected):
+    raw, m = kat.load_fixture(fixture)
+    p = cbind.OraclePredictor(raw, predict_tags=True)
+    _, labels = p.predict(text)
+    tags, nt = p.predict_tags(text)
+    out, start = [], 0
+    for i, b in enumerate(labels + [1]):
+        if b == 1:
+            tok = text[start:i + 1]
+            tm = [t for t in m.tag_models if t.token == tok]
+            parts = [tok]
+            for j in range(nt):
+                if tags[i, j] >= 0:
+                    parts.append(tm[-1].tags[j][tags[i, j]])
+            out.append("/".join(parts))
+            start = i + 1
+    assert " ".join(out) == expected
+
+
+@pytest.mark.parametrize("fixture,text,expected", kat.APPENDIX_SCORES)
+def test_appendix_scores(fixture, text, expected):
+    raw, _ = kat.load_fixture(fixture)
+    assert cbind.OraclePredictor(raw).predict(text)[0] == expected
+
+
+def test_text_errors():
+    p = cbind.OraclePredictor(encode_model(kat.predictor_test_model()))
+    for bad in ["", "A1あ\0ア亜"]:  # sentence.rs:1311-1364
+        with pytest.raises(cbind.OracleError) as e:
+            p.predict(bad)
+        assert e.value.status == 2
+
+
+def test_model_errors():
+    with pytest.raises(cbind.OracleError) as e:
+        cbind.OraclePredictor(b"VaporettoTokenizer 0.4.0\n" + b"\0" * 8)
+    assert e.value.status == 1 and "model version mismatch" in e.value.msg
+    dup = ModelData(type_ngram_model=[NgramData(bytes([3]), [1]), NgramData(bytes([3]), [2])], type_window_size=3)
+    with pytest.raises(cbind.OracleError) as e:  # boundary_scorer_cache.rs:23-24
+        cbind.OraclePredictor(encode_model(dup))
+    assert "invalid character type n-grams" in e.value.msg
+
+
+def test_batch_matches_single():
+    raw, _ = kat.load_fixture("model.bin")
+    p = cbind.OraclePredictor(raw)
+    texts = ["まぁ社長は火星猫だ", "まぁ良いだろう", "あ", "火星猫"]
+    enc = [t.encode() for t in texts]
+    utf8 = np.frombuffer(b"".join(enc), dtype=np.uint8)
+    offs = np.cumsum([0] + [len(e) for e in enc]).astype(np.uint64)
+    for nthreads in (1, 3):
+        scores, labels, ooff, _ = p.predict_batch(utf8, offs, nthreads)
+        for i, t in enumerate(texts):
+            s, l = p.predict(t)
+            assert scores[int(ooff[i]):int(ooff[i + 1])].tolist() == s
+            assert labels[int(ooff[i]):int(ooff[i + 1])].tolist() == l
