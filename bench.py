@@ -1,0 +1,187 @@
+#!/usr/bin/env python
+"""bench.py -- boundary scores/sec of the MI355X hot path (BASELINE.json metric).
+
+One "step" = one pass of Predictor::predict over one batch of synthetic sentences that is already resident in
+HBM (configs[1]: bccwj-suw+unidic-shaped model, 100 K sentences x 64 chars per GPU).  With N GPUs every rank
+scores its own batch (sentences shard trivially; no data-path collective) after the model file has been
+broadcast from rank 0 over RCCL -- weak scaling.
+
+    python bench.py --gpus 1 --steps 20 --warmup 3
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import subprocess
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+
+
+def load_model_bytes(kind: int, scale: float):
+    """A real model when $VAPORETTO_MODEL_DIR holds one (zstd, as distributed), else the synthetic stand-in."""
+    from vaporetto_amd import synth
+    name = {1: "bccwj-suw+unidic", 2: "jp-0.4.7-5", 3: "bccwj-suw+unidic_pos+pron"}[kind]
+    d = os.environ.get("VAPORETTO_MODEL_DIR")
+    if d:
+        path = os.path.join(d, name + ".model.zst")
+        if os.path.exists(path):
+            env = dict(os.environ, LD_LIBRARY_PATH="/opt/conda/lib:" + os.environ.get("LD_LIBRARY_PATH", ""))
+            raw = subprocess.check_output(["/opt/conda/bin/zstd", "-d", "-c", path], env=env)
+            return raw, name
+    return synth.synth_model(kind, synth.SEED_BASE + 2, scale), "synthetic-" + {1: "M1", 2: "M2", 3: "M3"}[kind]
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--sentences", type=int, default=100000, help="sentences per GPU per step")
+    ap.add_argument("--min-len", type=int, default=64)
+    ap.add_argument("--max-len", type=int, default=64)
+    ap.add_argument("--model-kind", type=int, default=1, help="1 bccwj-suw+unidic-like, 2 jp-0.4.7-5-like")
+    ap.add_argument("--model-scale", type=float, default=1.0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from vaporetto_amd import api
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world > 1:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    # ---- model: rank 0 loads/synthesises, everyone receives the bytes over RCCL (xGMI)
+    model_name = ""
+    if rank == 0:
+        model_bytes, model_name = load_model_bytes(args.model_kind, args.model_scale)
+        n = torch.tensor([len(model_bytes)], dtype=torch.int64, device=dev)
+    else:
+        model_bytes, n = None, torch.zeros(1, dtype=torch.int64, device=dev)
+    if world > 1:
+        dist.broadcast(n, 0)
+        blob = torch.empty(int(n.item()), dtype=torch.uint8, device=dev)
+        if rank == 0:
+            blob.copy_(torch.frombuffer(bytearray(model_bytes), dtype=torch.uint8))
+        dist.broadcast(blob, 0)
+        model_bytes = blob.cpu().numpy().tobytes()
+    predictor = api.Predictor(api.Model.read_slice(model_bytes)[0], False, device=local_rank)
+    info = predictor.info()
+
+    # ---- this rank's batch, resident in HBM
+    from vaporetto_amd import synth
+    utf8, boff = synth.synth_sentences(model_bytes, args.sentences, args.min_len, args.max_len,
+                                       seed=synth.SEED_BASE + 2 + 1000 * rank)
+    ooff = api.count_boundaries(utf8, boff)
+    S, nb, nbytes = args.sentences, int(ooff[-1]), int(boff[-1])
+    max_bytes = int(np.max(np.diff(boff.astype(np.int64))))
+    d_text = torch.from_numpy(np.concatenate([utf8, np.zeros(64, np.uint8)])).to(dev)
+    d_boff = torch.from_numpy(boff.astype(np.int64)).to(dev)
+    d_ooff = torch.from_numpy(ooff.astype(np.int64)).to(dev)
+    d_scores = torch.empty(nb + 1, dtype=torch.int32, device=dev)
+    d_labels = torch.empty(nb + 1, dtype=torch.uint8, device=dev)
+    batch = api.DeviceBatch(predictor, timing=True)
+    stream = torch.cuda.current_stream().cuda_stream
+
+    def step():
+        batch.predict(d_text.data_ptr(), d_boff.data_ptr(), d_ooff.data_ptr(), S, nb, max_bytes,
+                      d_scores.data_ptr(), d_labels.data_ptr(), stream)
+
+    for _ in range(args.warmup):
+        step()
+    batch.sync()
+    batch.kernel_ms()  # reset the event ring
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    batch.sync()
+    kernel_ms, n_tiles = batch.kernel_ms()
+    el = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    tot = torch.tensor([float(nb)], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(el, op=dist.ReduceOp.MAX)
+        dist.all_reduce(tot, op=dist.ReduceOp.SUM)
+    elapsed = float(el.item())
+    total_boundaries = float(tot.item())
+
+    if rank == 0:
+        out = {
+            "metric": "boundary scores/sec", "value": total_boundaries * args.steps / elapsed, "unit": "boundaries/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "int32", "data": "synthetic",
+            "config": {"workload": "configs[1]: %s model, %d sentences x %d..%d chars per GPU per step, inputs resident in HBM"
+                       % (model_name, S, args.min_len, args.max_len),
+                       "model": model_name, "sentences_per_gpu": S, "boundaries_per_gpu": nb, "text_bytes_per_gpu": nbytes,
+                       "char_ngrams": info["n_char_ngrams"], "dict_words": info["n_dict_words"],
+                       "table_bytes": info["device_table_bytes"], "tiles": n_tiles, "parallelism": "sentence shards x%d" % world},
+        }
+        # ---- roofline of the dominant kernel (score_tiles_kernel): algorithmic bytes per launch / its duration
+        a_stream = nbytes + 5 * nb + 16 * S   # text + i32 score + u8 label per boundary + two u64 offsets per sentence
+        a_type = 4 * nb                        # one type-window table word per boundary (the reference's cache form)
+        a_char = None
+        cpu = None
+        if not args.no_cpu_baseline:
+            from oracle import cbind
+            orc = cbind.OraclePredictor(model_bytes)
+            ncores = os.cpu_count() or 1
+            t = time.perf_counter()
+            o_scores, o_labels, _, a_char = orc.predict_batch(utf8, boff, nthreads=1)
+            t1 = time.perf_counter() - t
+            reps = max(1, min(20, int(10.0 / max(t1 / ncores * 1.5, 1e-3))))
+            t = time.perf_counter()
+            for _ in range(reps):
+                orc.predict_batch(utf8, boff, nthreads=ncores)
+            tn = (time.perf_counter() - t) / reps
+            cpu = {"value": nb / tn, "unit": "boundaries/s", "cores": ncores, "kind": "port",
+                   "single_thread_value": nb / t1,
+                   "sample": "the same %d-sentence batch: 1 pass on 1 thread, %d passes on %d threads (C restatement of the "
+                             "reference algorithm, not the Rust binary)" % (S, reps, ncores)}
+            g_scores = d_scores[:nb].cpu().numpy()
+            g_labels = d_labels[:nb].cpu().numpy()
+            out["parity"] = bool(np.array_equal(g_scores, o_scores) and np.array_equal(g_labels, o_labels))
+        if a_char is not None and kernel_ms > 0:
+            a = a_stream + a_char + a_type
+            achieved = a / (kernel_ms * 1e-3) / 1e9
+            out["roofline"] = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                               "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                               "kernel": "score_tiles_kernel", "kernel_ms": kernel_ms,
+                               "algorithmic_bytes_per_launch": a, "bytes_per_boundary": a / nb,
+                               "a_stream": a_stream, "a_char": a_char, "a_type": a_type}
+        else:
+            out["roofline"] = {"bound": "hbm", "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None,
+                               "traffic": None, "kernel": "score_tiles_kernel", "kernel_ms": kernel_ms}
+        out["cpu_baseline"] = cpu
+        print(json.dumps(out))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,144 @@
+/*
+ * vaporetto_hip.h -- C ABI of the MI355X-native Vaporetto boundary scorer (libvaporetto_hip.so).
+ *
+ * The reference (daac-tools/vaporetto) has no FFI: its boundary is the public Rust API of the `vaporetto`
+ * crate (/root/reference/vaporetto/src/lib.rs:82-91).  Each entry point below names the reference item it
+ * stands in for; INTEGRATION.md shows the Rust `extern "C"` block and the `Predictor`/`Sentence` shim a
+ * maintainer would add on top.  Plain pointers and sizes only; no torch, no C++ types.
+ *
+ * Conventions
+ *   - every function returns a vpt_status; vpt_last_error() gives the message of the calling thread's last
+ *     failure (VaporettoError's Display text where the reference defines one, errors.rs:15-38);
+ *   - a vpt_predictor is immutable after creation and may be shared by any number of host threads
+ *     (mirrors `&self` in Predictor::predict, predictor.rs:518); all mutable state lives in the caller's
+ *     buffers or in a per-caller vpt_batch workspace (mirrors the caller-owned `Sentence`);
+ *   - there is NO CPU fallback: without a usable HIP device every compute entry point fails with
+ *     VPT_RUNTIME_ERROR.
+ */
+#ifndef VAPORETTO_HIP_H
+#define VAPORETTO_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum vpt_status {
+    VPT_OK = 0,
+    VPT_INVALID_MODEL = 1,    /* VaporettoError::InvalidModel / DecodeError   (errors.rs:15-38) */
+    VPT_INVALID_ARGUMENT = 2, /* VaporettoError::InvalidArgument              (errors.rs:15-38) */
+    VPT_RUNTIME_ERROR = 3     /* HIP / device failure, or no device */
+} vpt_status;
+
+/* CharacterBoundary discriminants written to `labels` (sentence.rs:70-82) */
+enum { VPT_NOT_WORD_BOUNDARY = 0, VPT_WORD_BOUNDARY = 1, VPT_BOUNDARY_UNKNOWN = 2 };
+
+typedef struct vpt_predictor vpt_predictor;
+typedef struct vpt_batch vpt_batch;
+
+/* Message of the calling thread's most recent failed call ("" if none). Never NULL. */
+const char *vpt_last_error(void);
+
+/* Library version string. */
+const char *vpt_version(void);
+
+/* ---------------------------------------------------------------------------------------------------------
+ * Model::read_slice + Predictor::new            (model.rs:127-135, predictor.rs:450-508)
+ *
+ * model_bytes : an un-compressed model file: "VaporettoTokenizer 0.5.0\n" + bincode (zstd is outside the
+ *               API in the reference too, README.md:50-63).  The bytes are copied; the caller may free them.
+ * predict_tags: as Predictor::new's flag.  Tag models are parsed and validated; boundary scores are
+ *               identical either way (tag scoring itself is vpt_fill_tags_*, see DESIGN.md "next").
+ * device_id   : HIP device ordinal.
+ * Errors      : VPT_INVALID_MODEL  "model version mismatch" | decode error | "failed to build the automaton"
+ *               (empty pattern) | "invalid character type n-grams" (empty/duplicate type n-gram, cache
+ *               variant, boundary_scorer_cache.rs:23-24) | "words must be shorter than or equal to 32767
+ *               characters" | weight vector longer than its pattern allows (model contract);
+ *               VPT_RUNTIME_ERROR when the device cannot be used.
+ */
+vpt_status vpt_predictor_create(const uint8_t *model_bytes, size_t len, int predict_tags, int device_id,
+                                vpt_predictor **out);
+void vpt_predictor_destroy(vpt_predictor *p);
+
+/* ---------------------------------------------------------------------------------------------------------
+ * Sentence::from_raw's bookkeeping for a batch     (sentence.rs:160-196)
+ *
+ * Sentence i is utf8[byte_offsets[i] .. byte_offsets[i+1]) (valid UTF-8, as a Rust &str always is).
+ * Writes out_offsets[0..S]: out_offsets[i] = sum_{j<i} (chars(j) - 1), i.e. where sentence i's n-1 boundary
+ * scores start in the flat output arrays.  Host-only, no device needed.
+ * Errors: VPT_INVALID_ARGUMENT "text: must contain at least one character" | "text: must not contain NULL".
+ */
+vpt_status vpt_count_boundaries(const uint8_t *utf8, const uint64_t *byte_offsets, size_t n_sentences,
+                                uint64_t *out_offsets);
+
+/* ---------------------------------------------------------------------------------------------------------
+ * Predictor::predict over a batch of sentences, host buffers     (predictor.rs:518-543)
+ *
+ * scores_out[out_offsets[i] + b] = boundary score b of sentence i (what Sentence::boundary_scores() returns,
+ * sentence.rs:1040-1046); labels_out likewise (Sentence::boundaries(), sentence.rs:993).  Either output
+ * pointer may be NULL.  out_offsets must come from vpt_count_boundaries.  Copies H2D, launches, copies D2H,
+ * synchronises.  Thread-safe on a shared predictor.
+ */
+vpt_status vpt_predict_batch(const vpt_predictor *p, const uint8_t *utf8, const uint64_t *byte_offsets,
+                             size_t n_sentences, int32_t *scores_out, uint8_t *labels_out,
+                             const uint64_t *out_offsets);
+
+/* Sentence::from_raw + Predictor::predict for one sentence (same path, batch of one).
+ * scores/labels need room for chars-1 entries (<= len-1). */
+vpt_status vpt_predict_one(const vpt_predictor *p, const uint8_t *utf8, size_t len, int32_t *scores,
+                           uint8_t *labels, size_t *n_boundaries);
+
+/* ---------------------------------------------------------------------------------------------------------
+ * Device-resident variant: inputs and outputs already in HBM, asynchronous on a HIP stream.
+ *
+ * A vpt_batch is the per-caller mutable workspace (what a reused `Sentence` is to the reference's callers,
+ * predict/src/main.rs:122,129): tile tables, the device error word, timing events.  One per host thread /
+ * stream; not shareable between concurrent calls.
+ */
+vpt_status vpt_batch_create(const vpt_predictor *p, vpt_batch **out);
+void vpt_batch_destroy(vpt_batch *b);
+
+/* d_utf8, d_byte_offsets[S+1], d_out_offsets[S+1], d_scores, d_labels are device pointers (d_scores or
+ * d_labels may be NULL).  total_boundaries = out_offsets[S] (the caller sized the outputs with it).
+ * max_sentence_bytes: an upper bound on the byte length of any sentence (sizes the long-sentence scratch).
+ * hip_stream: a hipStream_t (NULL = default stream).  Returns after enqueueing; errors found on the device
+ * (empty sentence, NUL char, offsets inconsistent with the text) are reported by vpt_batch_sync. */
+vpt_status vpt_predict_batch_device(const vpt_predictor *p, vpt_batch *b, const uint8_t *d_utf8,
+                                    const uint64_t *d_byte_offsets, const uint64_t *d_out_offsets,
+                                    size_t n_sentences, uint64_t total_boundaries, uint64_t max_sentence_bytes,
+                                    int32_t *d_scores, uint8_t *d_labels, void *hip_stream);
+
+/* Waits for the batch's last enqueued work and returns its device-side verdict. */
+vpt_status vpt_batch_sync(vpt_batch *b);
+
+/* Optional kernel timing: when enabled, vpt_predict_batch_device brackets the scoring kernel with HIP events
+ * on the launch stream; after vpt_batch_sync, vpt_batch_kernel_ms returns that kernel's AVERAGE duration (ms)
+ * over the calls made since the previous vpt_batch_kernel_ms (at most the 256 most recent) and the number of
+ * workgroups (tiles) of the last call. */
+vpt_status vpt_batch_set_timing(vpt_batch *b, int enabled);
+vpt_status vpt_batch_kernel_ms(vpt_batch *b, float *score_kernel_ms, uint32_t *n_tiles);
+
+/* ---------------------------------------------------------------------------------------------------------
+ * Introspection (host-only; used by tests and the bench's roofline accounting)
+ */
+typedef struct vpt_model_info {
+    uint32_t n_char_ngrams, n_type_ngrams, n_dict_words, n_tag_models;
+    int32_t bias;
+    uint32_t char_window, type_window;
+    uint32_t max_pattern_chars;    /* longest char n-gram / dict word */
+    uint32_t n_short_entries;      /* distinct strings of <= 3 chars (plus 3-char prefixes of longer ones) */
+    uint32_t n_long_nodes;         /* trie nodes for strings of > 3 chars */
+    uint32_t type_kind;            /* 0 none, 1 window table (cache variant), 2 pattern tables */
+    uint64_t device_table_bytes;   /* bytes the tables occupy in HBM */
+} vpt_model_info;
+
+/* Parses + validates + compiles the tables on the host only (no device).  Same errors as create. */
+vpt_status vpt_model_inspect(const uint8_t *model_bytes, size_t len, int predict_tags, vpt_model_info *info);
+vpt_status vpt_predictor_info(const vpt_predictor *p, vpt_model_info *info);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VAPORETTO_HIP_H */

@@ -1,0 +1,235 @@
+"""GPU parity tests (run with -m gpu on an MI355X): the HIP path, called through the C ABI, must reproduce
+bit-exactly (i32 scores, u8 labels) the reference's known-answer vectors and the CPU oracle."""
+import numpy as np
+import pytest
+
+from oracle import cbind, spec
+from tests import kat, randmodel
+from vaporetto_amd import api
+from vaporetto_amd.modelfmt import ModelData, NgramData, WordWeightRecord, encode_model
+
+pytestmark = pytest.mark.gpu
+
+
+def make_predictor(model_data, predict_tags=False):
+    raw = encode_model(model_data) if not isinstance(model_data, (bytes, bytearray)) else bytes(model_data)
+    model, _ = api.Model.read_slice(raw)
+    return api.Predictor(model, predict_tags), cbind.OraclePredictor(raw, predict_tags)
+
+
+def check_batch(pred, orc, texts):
+    """GPU batch vs oracle batch on the same packed input; returns the scores."""
+    utf8, boff = api.pack_texts([t.encode("utf-8") for t in texts])
+    scores, labels, ooff = pred.predict_packed(utf8, boff)
+    o_scores, o_labels, o_ooff, _ = orc.predict_batch(utf8, boff, nthreads=4)
+    assert ooff.tolist() == o_ooff.tolist()
+    if not np.array_equal(scores, o_scores):
+        bad = int(np.nonzero(scores != o_scores)[0][0])
+        sent = int(np.searchsorted(ooff, bad, side="right") - 1)
+        raise AssertionError("first mismatch at boundary %d (sentence %d %r): gpu %d oracle %d"
+                             % (bad, sent, texts[sent][:40], scores[bad], o_scores[bad]))
+    assert np.array_equal(labels, o_labels)
+    return scores, labels, ooff
+
+
+# ------------------------------------------------------------------------------------------------ KATs
+@pytest.mark.parametrize("name,cite,model,text,expected", kat.BOUNDARY_KATS, ids=[k[0] for k in kat.BOUNDARY_KATS])
+def test_boundary_kats(name, cite, model, text, expected):
+    pred, _ = make_predictor(model)
+    s = api.Sentence.from_raw(text)
+    pred.predict(s)
+    assert s.boundary_scores().tolist() == expected, cite
+    assert s.boundaries().tolist() == [1 if v > 0 else 0 for v in expected]
+
+
+def test_predict_boundaries_like_reference():
+    """predictor.rs:840-859, written like the reference test."""
+    model, _ = api.Model.read_slice(encode_model(kat.predictor_test_model()))
+    predictor = api.Predictor(model, False)
+    sentence = api.Sentence.from_raw("この人は地球人だ")
+    predictor.predict(sentence)
+    assert sentence.boundary_scores().tolist() == [-22, 54, 58, 43, -54, 68, 48]
+    B = api.CharacterBoundary
+    assert [B(b) for b in sentence.boundaries()] == [B.NotWordBoundary, B.WordBoundary, B.WordBoundary, B.WordBoundary,
+                                                     B.NotWordBoundary, B.WordBoundary, B.WordBoundary]
+    # predict_tags = true switches the type scorer variant; the scores must not change (predictor.rs:869)
+    predictor = api.Predictor(model, True)
+    predictor.predict(sentence)
+    assert sentence.boundary_scores().tolist() == [-22, 54, 58, 43, -54, 68, 48]
+
+
+@pytest.mark.parametrize("fixture,text,expected,cite", kat.FIXTURE_SPLITS)
+def test_fixture_splits(fixture, text, expected, cite):
+    raw, _ = kat.load_fixture(fixture)
+    predictor = api.Predictor(api.Model.read_slice(raw)[0], False)
+    s = api.Sentence.default()
+    s.update_raw(text)
+    predictor.predict(s)
+    assert list(s.iter_tokens()) == expected, cite
+    assert s.write_tokenized_text() == " ".join(expected)
+
+
+@pytest.mark.parametrize("fixture,text,expected", kat.APPENDIX_SCORES)
+def test_appendix_scores(fixture, text, expected):
+    raw, _ = kat.load_fixture(fixture)
+    predictor = api.Predictor(api.Model.read_slice(raw)[0], False)
+    s = api.Sentence.from_raw(text)
+    predictor.predict(s)
+    assert s.boundary_scores().tolist() == expected
+
+
+def test_sentence_reuse_and_overwrite():
+    """`update_raw` + `predict` on a reused sentence overwrites the previous scores (predict/src/main.rs:122-130)."""
+    raw, _ = kat.load_fixture("model.bin")
+    predictor = api.Predictor(api.Model.read_slice(raw)[0], False)
+    s = api.Sentence.default()
+    for text, expected in [(t, e) for _, t, e in kat.APPENDIX_SCORES[:2]] * 2:
+        s.update_raw(text)
+        predictor.predict(s)
+        assert s.boundary_scores().tolist() == expected
+    s.update_raw("あ")
+    predictor.predict(s)
+    assert len(s.boundary_scores()) == 0 and len(s.boundaries()) == 0
+
+
+# ------------------------------------------------------------------------------------------------ random models
+@pytest.mark.parametrize("seed", range(24))
+def test_random_models_vs_oracle(seed):
+    alphabet = ["mixed", "tiny", "kana"][seed % 3]
+    m = randmodel.rand_model(seed, alphabet=alphabet, max_n=3 + seed % 2, big=(seed % 7 == 0),
+                             max_word=7 + (seed % 4) * 3)
+    pred, orc = make_predictor(m)
+    texts = randmodel.rand_sentences(seed, m, 300, alphabet=alphabet, max_len=60)
+    check_batch(pred, orc, texts)
+
+
+@pytest.mark.parametrize("wc,wt", [(1, 1), (2, 2), (3, 3), (4, 4), (1, 4), (4, 1), (5, 2), (8, 8), (3, 0), (0, 3)])
+def test_window_sizes(wc, wt):
+    m = randmodel.rand_model(100 + wc * 10 + wt, alphabet="tiny", wc=wc, wt=wt, max_n=4, n_char=40, n_type=30)
+    pred, orc = make_predictor(m)
+    texts = randmodel.rand_sentences(wc * 10 + wt, m, 200, alphabet="tiny", max_len=30)
+    check_batch(pred, orc, texts)
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_predict_tags_variant_same_scores(seed):
+    """With tag models and predict_tags = true the reference uses the BoundaryTag scorers (automaton instead of
+    the type window table); boundary scores must be identical to the oracle in that mode too."""
+    m = randmodel.rand_model(500 + seed, alphabet="tiny", n_tag_models=8, max_word=4)
+    pred, orc = make_predictor(m, predict_tags=True)
+    texts = randmodel.rand_sentences(seed, m, 200, alphabet="tiny", max_len=25)
+    check_batch(pred, orc, texts)
+
+
+# ------------------------------------------------------------------------------------------------ shapes
+def test_ragged_and_edge_lengths():
+    m = randmodel.rand_model(7, alphabet="mixed", wc=3, wt=3, max_word=12)
+    pred, orc = make_predictor(m)
+    rng = np.random.RandomState(3)
+    alpha = randmodel.ALPHABETS["mixed"]
+    texts = []
+    for n in [1, 1, 1, 2, 3, 1, 64, 1, 1000, 1, 1, 1017, 1018, 1019, 1020, 1021, 1022, 1023, 1024, 1025, 2, 2047, 2048, 2049,
+              5000, 1, 1, 3, 20000, 1] + [1] * 700 + list(rng.randint(1, 200, size=300)):
+        texts.append("".join(alpha[i] for i in rng.randint(0, len(alpha), size=n)))
+    check_batch(pred, orc, texts)
+
+
+def test_ascii_and_four_byte_text():
+    m = ModelData(char_ngram_model=[NgramData("ab", [1, 2, 3, 4, 5]), NgramData("b", [6, 7, 8, 9, 10, 11]),
+                                    NgramData("🤌🏿", [100, 200, 300, 400, 500]), NgramData("🏿", [7, 7, 7, 7, 7, 7])],
+                  type_ngram_model=[NgramData(bytes([2, 2]), [1, 1, 1, 1, 1]), NgramData(bytes([6]), [3, 2, 1, 1, 2, 3])],
+                  dict_model=[WordWeightRecord("abab", [9, 8, 7, 6, 5]), WordWeightRecord("𠮷🤌🏿𠮷x", [1, 2, 3, 4, 5, 6])],
+                  bias=-3, char_window_size=3, type_window_size=3)
+    pred, orc = make_predictor(m)
+    texts = ["ab" * 40, "b", "abababab", "🤌🏿" * 30, "𠮷🤌🏿𠮷x" * 7, "a🤌b🏿" * 300, "x" * 3000, "🏿" * 2100]
+    check_batch(pred, orc, texts)
+
+
+def test_long_dictionary_words_cross_tile_sized_sentences():
+    words = ["あいうえおかきくけこ" * k for k in (1, 2, 5)] + ["漢字" * 9]
+    m = ModelData(char_ngram_model=[NgramData("あい", [1, 2, 3, 4, 5])],
+                  dict_model=[WordWeightRecord(w, list(range(1, len(w) + 2))) for w in words],
+                  bias=1, char_window_size=3)
+    pred, orc = make_predictor(m)
+    texts = ["あいうえおかきくけこ" * 30, "漢字" * 700, "あいうえおかきくけこ" * 250, "あいうえおかきくけ"]
+    check_batch(pred, orc, texts)
+
+
+def test_many_batches_through_one_predictor():
+    raw, _ = kat.load_fixture("tantivy_model.bin")
+    pred, orc = make_predictor(raw)
+    for k in range(5):
+        texts = ["東京特許許可局" * (1 + (i + k) % 5) for i in range(50 + 100 * k)]
+        check_batch(pred, orc, texts)
+
+
+# ------------------------------------------------------------------------------------------------ errors
+def test_batch_errors():
+    raw, _ = kat.load_fixture("model.bin")
+    pred, _ = make_predictor(raw)
+    utf8, boff = api.pack_texts([b"abc", b"", b"de"])
+    with pytest.raises(api.VaporettoError, match="must contain at least one character") as e:
+        pred.predict_packed(utf8, boff)
+    assert e.value.kind == "InvalidArgument"
+    utf8, boff = api.pack_texts(["A1あ\0ア亜".encode()])
+    with pytest.raises(api.VaporettoError, match="must not contain NULL"):
+        pred.predict_packed(utf8, boff)
+    # the predictor stays usable after an error
+    s = api.Sentence.from_raw("まぁ良いだろう")
+    pred.predict(s)
+    assert s.boundary_scores().tolist() == kat.APPENDIX_SCORES[1][2]
+
+
+def test_device_side_error_flags():
+    """Device-resident entry point: the caller's offsets are trusted, so NUL / empty sentences / inconsistent
+    offsets are detected by the kernel and reported at sync."""
+    import torch
+    raw, _ = kat.load_fixture("model.bin")
+    pred, _ = make_predictor(raw)
+    batch = api.DeviceBatch(pred)
+
+    def run(raws, ooff=None):
+        utf8, boff = api.pack_texts(raws)
+        if ooff is None:
+            ooff = np.cumsum([0] + [max(len(r.decode()) - 1, 0) for r in raws]).astype(np.uint64)
+        d_text = torch.from_numpy(np.concatenate([utf8, np.zeros(16, np.uint8)])).cuda()
+        d_boff = torch.from_numpy(boff.astype(np.int64)).cuda()
+        d_ooff = torch.from_numpy(np.asarray(ooff).astype(np.int64)).cuda()
+        nb = int(ooff[-1])
+        d_scores = torch.zeros(nb + 1, dtype=torch.int32, device="cuda")
+        d_labels = torch.zeros(nb + 1, dtype=torch.uint8, device="cuda")
+        batch.predict(d_text.data_ptr(), d_boff.data_ptr(), d_ooff.data_ptr(), len(raws), nb,
+                      max(len(r) for r in raws), d_scores.data_ptr(), d_labels.data_ptr(),
+                      torch.cuda.current_stream().cuda_stream)
+        batch.sync()
+        return d_scores[:nb].cpu().numpy()
+
+    assert run(["まぁ良いだろう".encode()]).tolist() == kat.APPENDIX_SCORES[1][2]
+    with pytest.raises(api.VaporettoError, match="must not contain NULL"):
+        run([b"ab\0cd"])
+    with pytest.raises(api.VaporettoError, match="must contain at least one character"):
+        run([b"ab", b"", b"cd"], ooff=[0, 1, 1, 2])
+    with pytest.raises(api.VaporettoError, match="do not match the text"):
+        run(["まぁ良いだろう".encode()], ooff=[0, 4])
+    assert run(["まぁ良いだろう".encode()]).tolist() == kat.APPENDIX_SCORES[1][2]
+
+
+def test_concurrent_host_threads_share_a_predictor():
+    """`&self` semantics: one predictor, many caller threads (vaporetto_tantivy/src/lib.rs:62-67)."""
+    import threading
+    raw, _ = kat.load_fixture("tantivy_model.bin")
+    pred, orc = make_predictor(raw)
+    errors = []
+
+    def work(k):
+        try:
+            for r in range(5):
+                texts = ["東京特許許可局" * (1 + (i + k + r) % 7) for i in range(200)]
+                check_batch(pred, orc, texts)
+        except Exception as e:  # noqa
+            errors.append(e)
+
+    th = [threading.Thread(target=work, args=(k,)) for k in range(4)]
+    [t.start() for t in th]
+    [t.join() for t in th]
+    assert not errors, errors[0]

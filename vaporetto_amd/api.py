@@ -1,0 +1,327 @@
+"""Host-side mirror of the reference's public API for the predict path (vaporetto/src/lib.rs:82-91):
+`Model`, `Predictor`, `Sentence`, `CharacterBoundary`, `CharacterType`, `VaporettoError`.
+
+Same names, argument meaning and error behaviour as the Rust crate, over the C ABI of libvaporetto_hip.so.
+All scoring happens in the HIP kernels; this module only parses text and moves buffers.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import enum
+from typing import Iterable, List, Optional, Sequence, Tuple
+
+import numpy as np
+
+from . import _lib, modelfmt
+
+
+class VaporettoError(Exception):
+    """errors.rs:15-38.  `kind` is "InvalidModel", "InvalidArgument" or "Runtime"."""
+
+    def __init__(self, kind: str, message: str):
+        super().__init__(message)
+        self.kind = kind
+
+
+def _raise(status: int):
+    msg = _lib.last_error()
+    kind = {_lib.VPT_INVALID_MODEL: "InvalidModel", _lib.VPT_INVALID_ARGUMENT: "InvalidArgument"}.get(status, "Runtime")
+    raise VaporettoError(kind, msg)
+
+
+class CharacterType(enum.IntEnum):  # sentence.rs:11-29
+    Digit = 1
+    Roman = 2
+    Hiragana = 3
+    Katakana = 4
+    Kanji = 5
+    Other = 6
+
+    @staticmethod
+    def get_type(c: str) -> "CharacterType":  # sentence.rs:50-67
+        return CharacterType(int(_types_of(np.array([ord(c)], dtype=np.uint32))[0]))
+
+
+class CharacterBoundary(enum.IntEnum):  # sentence.rs:70-82
+    NotWordBoundary = 0
+    WordBoundary = 1
+    Unknown = 2
+
+
+_RANGES = [  # (lo, hi, type) -- sentence.rs:52-65
+    (0x30, 0x39, 1), (0xFF10, 0xFF19, 1),
+    (0x41, 0x5A, 2), (0x61, 0x7A, 2), (0xFF21, 0xFF3A, 2), (0xFF41, 0xFF5A, 2),
+    (0x3040, 0x3096, 3),
+    (0x30A0, 0x30FA, 4), (0x30FC, 0x30FF, 4), (0xFF66, 0xFF9F, 4),
+    (0x3400, 0x4DBF, 5), (0x4E00, 0x9FFF, 5), (0xF900, 0xFAFF, 5), (0x20000, 0x2A6DF, 5), (0x2A700, 0x2B73F, 5),
+    (0x2B740, 0x2B81F, 5), (0x2B820, 0x2CEAF, 5), (0x2F800, 0x2FA1F, 5),
+]
+
+
+def _types_of(cps: np.ndarray) -> np.ndarray:
+    out = np.full(cps.shape, 6, dtype=np.uint8)
+    for lo, hi, t in _RANGES:
+        out[(cps >= lo) & (cps <= hi)] = t
+    return out
+
+
+class Model:
+    """model.rs:55-169."""
+
+    def __init__(self, data: modelfmt.ModelData, raw: Optional[bytes] = None):
+        self._data = data
+        self._raw = raw
+
+    @staticmethod
+    def read(rdr) -> "Model":  # model.rs:138-153
+        return Model.read_slice(rdr.read())[0]
+
+    @staticmethod
+    def read_slice(buf: bytes) -> Tuple["Model", bytes]:  # model.rs:127-135
+        try:
+            data, used = modelfmt.decode_model(buf)
+        except modelfmt.ModelFormatError as e:
+            raise VaporettoError("InvalidModel", "InvalidModelError: %s" % e) from e
+        return Model(data, bytes(buf[:used])), bytes(buf[used:])
+
+    def to_vec(self) -> bytes:  # model.rs:99-104
+        if self._raw is None:
+            self._raw = modelfmt.encode_model(self._data)
+        return self._raw
+
+    def write(self, wtr) -> None:  # model.rs:112-121
+        wtr.write(self.to_vec())
+
+    def dictionary(self):  # model.rs:155-158
+        return self._data.dict_model
+
+    def replace_dictionary(self, dict_records) -> None:  # model.rs:160-163
+        self._data.dict_model = list(dict_records)
+        self._raw = None
+
+    def tag_models(self):  # model.rs:165-168
+        return self._data.tag_models
+
+
+class Sentence:
+    """sentence.rs:85-101 (raw-text path).  Holds the text, its character types, and after `predict`
+    the boundary scores and labels."""
+
+    def __init__(self):
+        self._set_default()
+
+    def _set_default(self):  # sentence.rs:140-158: a single space
+        self._text = " "
+        self._utf8 = b" "
+        self._char_types = np.array([6], dtype=np.uint8)
+        self._boundaries = np.zeros(0, dtype=np.uint8)
+        self._scores = np.zeros(0, dtype=np.int32)
+        self._has_scores = False
+
+    @staticmethod
+    def default() -> "Sentence":
+        return Sentence()
+
+    def _parse_raw(self, text: str):  # sentence.rs:160-196
+        if "\0" in text:
+            raise VaporettoError("InvalidArgument", "InvalidArgumentError: text: must not contain NULL")
+        if len(text) == 0:
+            raise VaporettoError("InvalidArgument", "InvalidArgumentError: text: must contain at least one character")
+        cps = np.frombuffer(text.encode("utf-32-le"), dtype=np.uint32)
+        self._text = text
+        self._utf8 = text.encode("utf-8")
+        self._char_types = _types_of(cps)
+        self._boundaries = np.full(len(cps) - 1, CharacterBoundary.Unknown, dtype=np.uint8)
+        self._scores = np.zeros(0, dtype=np.int32)
+        self._has_scores = False
+
+    @staticmethod
+    def from_raw(text: str) -> "Sentence":  # sentence.rs:217-245
+        s = Sentence()
+        s._parse_raw(text)
+        return s
+
+    def update_raw(self, text: str) -> None:  # sentence.rs:264-283: on error the sentence becomes " "
+        try:
+            self._parse_raw(text)
+        except VaporettoError:
+            self._set_default()
+            raise
+
+    def as_raw_text(self) -> str:  # sentence.rs:782
+        return self._text
+
+    def __len__(self) -> int:
+        return len(self._char_types)
+
+    def char_types(self) -> np.ndarray:  # sentence.rs:1034
+        return self._char_types
+
+    def boundaries(self) -> np.ndarray:  # sentence.rs:993
+        return self._boundaries
+
+    def boundaries_mut(self) -> np.ndarray:  # sentence.rs:1016
+        return self._boundaries
+
+    def boundary_scores(self) -> np.ndarray:  # sentence.rs:1040-1046
+        return self._scores if self._has_scores else np.zeros(0, dtype=np.int32)
+
+    def char_to_str_pos(self) -> List[int]:
+        pos, out = 0, [0]
+        for ch in self._text:
+            pos += len(ch.encode("utf-8"))
+            out.append(pos)
+        return out
+
+    def iter_tokens(self) -> Iterable[str]:  # sentence.rs:819 (surfaces only)
+        start = 0
+        for i, b in enumerate(self._boundaries):
+            if b == CharacterBoundary.WordBoundary:
+                yield self._text[start:i + 1]
+                start = i + 1
+        yield self._text[start:]
+
+    def write_tokenized_text(self) -> str:  # sentence.rs:850-886, without tags
+        def esc(tok):
+            return "".join("\\" + c if c in " \\/" else c for c in tok)
+        return " ".join(esc(t) for t in self.iter_tokens())
+
+
+class Predictor:
+    """predictor.rs:433-665 (boundary prediction)."""
+
+    def __init__(self, model: Model, predict_tags: bool = False, device: int = 0):  # Predictor::new, predictor.rs:450
+        raw = model.to_vec()
+        self._h = C.c_void_p()
+        st = _lib.load().vpt_predictor_create(raw, len(raw), int(predict_tags), device, C.byref(self._h))
+        if st != _lib.VPT_OK:
+            self._h = None
+            _raise(st)
+        self.device = device
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            _lib.load().vpt_predictor_destroy(self._h)
+            self._h = None
+
+    @property
+    def handle(self):
+        return self._h
+
+    def info(self) -> dict:
+        mi = _lib.ModelInfo()
+        st = _lib.load().vpt_predictor_info(self._h, C.byref(mi))
+        if st != _lib.VPT_OK:
+            _raise(st)
+        return mi.as_dict()
+
+    def predict(self, sentence: Sentence) -> None:  # predictor.rs:518-543
+        n = len(sentence)
+        scores = np.zeros(max(n - 1, 1), dtype=np.int32)
+        labels = np.zeros(max(n - 1, 1), dtype=np.uint8)
+        nb = C.c_size_t()
+        raw = sentence._utf8
+        st = _lib.load().vpt_predict_one(self._h, raw, len(raw), scores.ctypes.data, labels.ctypes.data, C.byref(nb))
+        if st != _lib.VPT_OK:
+            _raise(st)
+        sentence._scores = scores[:nb.value]
+        sentence._boundaries = labels[:nb.value]
+        sentence._has_scores = True
+
+    def predict_batch(self, sentences: Sequence[Sentence]) -> None:
+        """Predictor::predict for many sentences in one launch."""
+        if not sentences:
+            return
+        utf8, boff = pack_texts([s._utf8 for s in sentences])
+        scores, labels, ooff = self.predict_packed(utf8, boff)
+        for i, s in enumerate(sentences):
+            a, b = int(ooff[i]), int(ooff[i + 1])
+            s._scores = scores[a:b]
+            s._boundaries = labels[a:b]
+            s._has_scores = True
+
+    def predict_packed(self, utf8: np.ndarray, byte_offsets: np.ndarray):
+        """utf8: uint8[total bytes]; byte_offsets: uint64[S+1].  Returns (scores, labels, out_offsets)."""
+        L = _lib.load()
+        utf8 = np.ascontiguousarray(utf8, dtype=np.uint8)
+        byte_offsets = np.ascontiguousarray(byte_offsets, dtype=np.uint64)
+        S = len(byte_offsets) - 1
+        ooff = np.zeros(S + 1, dtype=np.uint64)
+        st = L.vpt_count_boundaries(utf8.ctypes.data, byte_offsets.ctypes.data, S, ooff.ctypes.data)
+        if st != _lib.VPT_OK:
+            _raise(st)
+        nb = int(ooff[S])
+        scores = np.zeros(max(nb, 1), dtype=np.int32)
+        labels = np.zeros(max(nb, 1), dtype=np.uint8)
+        st = L.vpt_predict_batch(self._h, utf8.ctypes.data, byte_offsets.ctypes.data, S, scores.ctypes.data,
+                                 labels.ctypes.data, ooff.ctypes.data)
+        if st != _lib.VPT_OK:
+            _raise(st)
+        return scores[:nb], labels[:nb], ooff
+
+
+class DeviceBatch:
+    """Per-caller workspace for the device-resident entry point (vpt_batch)."""
+
+    def __init__(self, predictor: Predictor, timing: bool = False):
+        self._p = predictor
+        self._h = C.c_void_p()
+        L = _lib.load()
+        st = L.vpt_batch_create(predictor.handle, C.byref(self._h))
+        if st != _lib.VPT_OK:
+            self._h = None
+            _raise(st)
+        if timing:
+            st = L.vpt_batch_set_timing(self._h, 1)
+            if st != _lib.VPT_OK:
+                _raise(st)
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            _lib.load().vpt_batch_destroy(self._h)
+            self._h = None
+
+    def predict(self, d_utf8: int, d_boff: int, d_ooff: int, n_sentences: int, total_boundaries: int,
+                max_sentence_bytes: int, d_scores: int, d_labels: int, stream: int = 0) -> None:
+        """All pointers are raw device addresses (e.g. torch.Tensor.data_ptr()); enqueues and returns."""
+        st = _lib.load().vpt_predict_batch_device(self._p.handle, self._h, d_utf8, d_boff, d_ooff, n_sentences,
+                                                  total_boundaries, max_sentence_bytes, d_scores, d_labels, stream)
+        if st != _lib.VPT_OK:
+            _raise(st)
+
+    def sync(self) -> None:
+        st = _lib.load().vpt_batch_sync(self._h)
+        if st != _lib.VPT_OK:
+            _raise(st)
+
+    def kernel_ms(self) -> Tuple[float, int]:
+        ms, nt = C.c_float(), C.c_uint32()
+        st = _lib.load().vpt_batch_kernel_ms(self._h, C.byref(ms), C.byref(nt))
+        if st != _lib.VPT_OK:
+            _raise(st)
+        return ms.value, nt.value
+
+
+def pack_texts(raws: Sequence[bytes]) -> Tuple[np.ndarray, np.ndarray]:
+    boff = np.zeros(len(raws) + 1, dtype=np.uint64)
+    boff[1:] = np.cumsum([len(r) for r in raws], dtype=np.uint64)
+    return np.frombuffer(b"".join(raws), dtype=np.uint8), boff
+
+
+def count_boundaries(utf8: np.ndarray, byte_offsets: np.ndarray) -> np.ndarray:
+    utf8 = np.ascontiguousarray(utf8, dtype=np.uint8)
+    byte_offsets = np.ascontiguousarray(byte_offsets, dtype=np.uint64)
+    S = len(byte_offsets) - 1
+    ooff = np.zeros(S + 1, dtype=np.uint64)
+    st = _lib.load().vpt_count_boundaries(utf8.ctypes.data, byte_offsets.ctypes.data, S, ooff.ctypes.data)
+    if st != _lib.VPT_OK:
+        _raise(st)
+    return ooff
+
+
+def model_inspect(model_bytes: bytes, predict_tags: bool = False) -> dict:
+    mi = _lib.ModelInfo()
+    st = _lib.load().vpt_model_inspect(model_bytes, len(model_bytes), int(predict_tags), C.byref(mi))
+    if st != _lib.VPT_OK:
+        _raise(st)
+    return mi.as_dict()

@@ -1,0 +1,456 @@
+// C ABI of libvaporetto_hip.so (include/vaporetto_hip.h).  Host side of the drop-in boundary:
+// model loading + table upload (Predictor::new), batch staging and kernel launches (Predictor::predict).
+#include "../../include/vaporetto_hip.h"
+
+#include <hip/hip_runtime_api.h>
+
+#include <algorithm>
+#include <cstring>
+#include <mutex>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "kernels.hpp"
+#include "model.hpp"
+#include "tables.hpp"
+
+namespace {
+
+thread_local std::string g_last_error;
+
+vpt_status fail(vpt_status st, const std::string& msg) {
+    g_last_error = msg;
+    return st;
+}
+
+#define VPT_HIP(expr)                                                                                  \
+    do {                                                                                               \
+        hipError_t e_ = (expr);                                                                        \
+        if (e_ != hipSuccess)                                                                          \
+            return fail(VPT_RUNTIME_ERROR, std::string("HIP error: ") + hipGetErrorString(e_) + " at " #expr); \
+    } while (0)
+
+struct DeviceTable {
+    uint32_t *short_tab = nullptr, *uni = nullptr, *edges = nullptr;
+    int32_t* wdata = nullptr;
+    void release() {
+        (void)hipFree(short_tab); (void)hipFree(uni); (void)hipFree(edges); (void)hipFree(wdata);
+        short_tab = uni = edges = nullptr; wdata = nullptr;
+    }
+};
+
+constexpr size_t kTimingRing = 256;     // timed launches remembered per vpt_batch
+constexpr size_t kTablePadBytes = 256;  // probes read whole 16-byte chunks; keep the tail readable
+
+template <typename T>
+hipError_t upload(const std::vector<T>& v, T** out) {
+    *out = nullptr;
+    size_t bytes = v.size() * sizeof(T);
+    hipError_t e = hipMalloc(reinterpret_cast<void**>(out), bytes + kTablePadBytes);
+    if (e != hipSuccess) return e;
+    e = hipMemset(*out, 0, bytes + kTablePadBytes);
+    if (e != hipSuccess) return e;
+    if (bytes) e = hipMemcpy(*out, v.data(), bytes, hipMemcpyHostToDevice);
+    return e;
+}
+
+vpt::PatternTableView make_view(const vpt::HostPatternTable& h, const DeviceTable& d) {
+    vpt::PatternTableView v{};
+    v.present = h.present ? 1u : 0u;
+    if (!h.present) return v;
+    v.short_tab = d.short_tab; v.uni = d.uni; v.edges = d.edges; v.wdata = d.wdata;
+    v.short_shift = 64 - h.short_bits; v.short_mask = (1u << h.short_bits) - 1;
+    v.edge_shift = 64 - h.edge_bits; v.edge_mask = (1u << h.edge_bits) - 1;
+    v.stride_dw = h.stride_dw; v.uni_dw = h.uni_dw; v.uni_n = h.uni_n; v.ext_slot = h.ext_slot;
+    v.window = h.window;
+    for (int i = 0; i < 3; ++i) { v.lo[i] = h.lo[i]; v.len[i] = h.len[i]; }
+    v.has_long = h.has_long ? 1u : 0u;
+    return v;
+}
+
+void fill_info(const vpt::CompiledModel& c, vpt_model_info* info) {
+    std::memset(info, 0, sizeof(*info));
+    info->n_char_ngrams = c.n_char_ngrams; info->n_type_ngrams = c.n_type_ngrams;
+    info->n_dict_words = c.n_dict_words; info->n_tag_models = c.n_tag_models;
+    info->bias = c.bias;
+    info->char_window = c.chars.present ? uint32_t(c.chars.window) : 0;
+    info->type_window = uint32_t(c.type_window);
+    info->max_pattern_chars = c.chars.max_pattern;
+    info->n_short_entries = c.chars.n_short; info->n_long_nodes = c.chars.n_long_nodes;
+    info->type_kind = uint32_t(c.type_kind);
+    info->device_table_bytes = (c.chars.present ? c.chars.bytes() : 0) + (c.types.present ? c.types.bytes() : 0) +
+                               4ull * c.type_table.size();
+}
+
+}  // namespace
+
+struct vpt_batch {
+    const vpt_predictor* pred = nullptr;
+    int device = 0;
+    // per-call device tables
+    uint32_t* d_tile_first = nullptr; size_t tile_cap = 0;
+    uint32_t* d_slow_list = nullptr;
+    uint32_t* d_ctrl = nullptr;        // [0] status bits, [1] slow tile count
+    unsigned char* d_scratch = nullptr; size_t scratch_bytes = 0;
+    // timing
+    bool timing = false;
+    std::vector<hipEvent_t> ev;        // ring of (start, stop) pairs around the scoring kernel
+    size_t ev_calls = 0;               // timed calls since the last vpt_batch_kernel_ms
+    uint32_t last_tiles = 0;
+    hipStream_t last_stream = nullptr; bool pending = false;
+    // staging for the host-buffer entry points
+    hipStream_t own_stream = nullptr;
+    uint8_t* d_text = nullptr; size_t text_cap = 0;
+    uint64_t *d_boff = nullptr, *d_ooff = nullptr; size_t off_cap = 0;
+    int32_t* d_scores = nullptr; uint8_t* d_labels = nullptr; size_t out_cap = 0;
+};
+
+struct vpt_predictor {
+    int device = 0;
+    vpt_model_info info{};
+    int32_t bias = 0; int pad = 1; int type_kind = 0; int type_window = 0; int chunks = 2;
+    DeviceTable dc, dt;
+    int32_t* d_type_table = nullptr;
+    vpt::PatternTableView ct{}, tt{};
+    mutable std::mutex pool_mu;
+    mutable std::vector<vpt_batch*> pool;  // idle workspaces for the host-buffer entry points
+};
+
+namespace {
+
+vpt_status compile(const uint8_t* bytes, size_t len, int predict_tags, vpt::CompiledModel* out) {
+    if (!bytes) return fail(VPT_INVALID_ARGUMENT, "InvalidArgumentError: model_bytes: must not be NULL");
+    try {
+        vpt::ModelData m = vpt::parse_model(bytes, len, nullptr);
+        *out = vpt::compile_model(m, predict_tags != 0);
+    } catch (const vpt::ModelError& e) {
+        return fail(VPT_INVALID_MODEL, e.what());
+    } catch (const std::bad_alloc&) {
+        return fail(VPT_RUNTIME_ERROR, "out of host memory while compiling the model");
+    }
+    return VPT_OK;
+}
+
+void batch_release(vpt_batch* b) {
+    if (!b) return;
+    (void)hipSetDevice(b->device);
+    (void)hipFree(b->d_tile_first); (void)hipFree(b->d_slow_list); (void)hipFree(b->d_ctrl); (void)hipFree(b->d_scratch);
+    (void)hipFree(b->d_text); (void)hipFree(b->d_boff); (void)hipFree(b->d_ooff); (void)hipFree(b->d_scores); (void)hipFree(b->d_labels);
+    for (hipEvent_t e : b->ev) (void)hipEventDestroy(e);
+    if (b->own_stream) (void)hipStreamDestroy(b->own_stream);
+    delete b;
+}
+
+template <typename T>
+vpt_status grow(T** ptr, size_t* cap, size_t need) {
+    if (need <= *cap && *ptr) return VPT_OK;
+    size_t ncap = std::max<size_t>(need, *cap + *cap / 2);
+    ncap = std::max<size_t>(ncap, 64);
+    (void)hipFree(*ptr);
+    *ptr = nullptr; *cap = 0;
+    VPT_HIP(hipMalloc(reinterpret_cast<void**>(ptr), ncap * sizeof(T) + 64));
+    *cap = ncap;
+    return VPT_OK;
+}
+
+vpt_status status_from_bits(uint32_t bits) {
+    if (bits == 0) return VPT_OK;
+    if (bits & vpt::kErrEmptySentence)
+        return fail(VPT_INVALID_ARGUMENT, "InvalidArgumentError: text: must contain at least one character");
+    if (bits & vpt::kErrNulChar) return fail(VPT_INVALID_ARGUMENT, "InvalidArgumentError: text: must not contain NULL");
+    if (bits & vpt::kErrBadOffsets)
+        return fail(VPT_INVALID_ARGUMENT, "InvalidArgumentError: out_offsets: do not match the text (or the text is not valid UTF-8)");
+    return fail(VPT_INVALID_ARGUMENT, "InvalidArgumentError: max_sentence_bytes: smaller than the longest sentence");
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* vpt_last_error(void) { return g_last_error.c_str(); }
+const char* vpt_version(void) { return "vaporetto_hip 0.1.0 (gfx950)"; }
+
+vpt_status vpt_model_inspect(const uint8_t* model_bytes, size_t len, int predict_tags, vpt_model_info* info) {
+    if (!info) return fail(VPT_INVALID_ARGUMENT, "InvalidArgumentError: info: must not be NULL");
+    vpt::CompiledModel c;
+    vpt_status st = compile(model_bytes, len, predict_tags, &c);
+    if (st != VPT_OK) return st;
+    fill_info(c, info);
+    return VPT_OK;
+}
+
+vpt_status vpt_predictor_create(const uint8_t* model_bytes, size_t len, int predict_tags, int device_id, vpt_predictor** out) {
+    if (!out) return fail(VPT_INVALID_ARGUMENT, "InvalidArgumentError: out: must not be NULL");
+    *out = nullptr;
+    vpt::CompiledModel c;
+    vpt_status st = compile(model_bytes, len, predict_tags, &c);
+    if (st != VPT_OK) return st;
+    int n_dev = 0;
+    if (hipGetDeviceCount(&n_dev) != hipSuccess || n_dev <= 0)
+        return fail(VPT_RUNTIME_ERROR, "no HIP device available (this library has no CPU fallback)");
+    if (device_id < 0 || device_id >= n_dev) return fail(VPT_INVALID_ARGUMENT, "InvalidArgumentError: device_id: no such HIP device");
+    VPT_HIP(hipSetDevice(device_id));
+    vpt_predictor* p = new (std::nothrow) vpt_predictor();
+    if (!p) return fail(VPT_RUNTIME_ERROR, "out of host memory");
+    p->device = device_id;
+    fill_info(c, &p->info);
+    p->bias = c.bias; p->pad = c.pad; p->type_kind = c.type_kind; p->type_window = c.type_window;
+    hipError_t e = hipSuccess;
+    auto up = [&](const vpt::HostPatternTable& h, DeviceTable& d) {
+        if (!h.present) return;
+        if (e == hipSuccess) e = upload(h.short_tab, &d.short_tab);
+        if (e == hipSuccess) e = upload(h.uni, &d.uni);
+        if (e == hipSuccess) e = upload(h.edges, &d.edges);
+        if (e == hipSuccess) e = upload(h.wdata, &d.wdata);
+    };
+    up(c.chars, p->dc);
+    up(c.types, p->dt);
+    if (e == hipSuccess && c.type_kind == vpt::kTypeWindowTable) e = upload(c.type_table, &p->d_type_table);
+    if (e != hipSuccess) {
+        std::string msg = std::string("HIP error while uploading the tables: ") + hipGetErrorString(e);
+        vpt_predictor_destroy(p);
+        return fail(VPT_RUNTIME_ERROR, msg);
+    }
+    p->ct = make_view(c.chars, p->dc);
+    p->tt = make_view(c.types, p->dt);
+    uint32_t stride = 4;
+    if (c.chars.present) stride = std::max(stride, c.chars.stride_dw);
+    if (c.types.present) stride = std::max(stride, c.types.stride_dw);
+    p->chunks = int(std::max<uint32_t>(2, stride / 4));
+    *out = p;
+    return VPT_OK;
+}
+
+void vpt_predictor_destroy(vpt_predictor* p) {
+    if (!p) return;
+    (void)hipSetDevice(p->device);
+    for (vpt_batch* b : p->pool) batch_release(b);
+    p->dc.release(); p->dt.release();
+    (void)hipFree(p->d_type_table);
+    delete p;
+}
+
+vpt_status vpt_predictor_info(const vpt_predictor* p, vpt_model_info* info) {
+    if (!p || !info) return fail(VPT_INVALID_ARGUMENT, "InvalidArgumentError: NULL argument");
+    *info = p->info;
+    return VPT_OK;
+}
+
+vpt_status vpt_count_boundaries(const uint8_t* utf8, const uint64_t* byte_offsets, size_t n_sentences, uint64_t* out_offsets) {
+    if ((!utf8 && n_sentences) || !byte_offsets || !out_offsets) return fail(VPT_INVALID_ARGUMENT, "InvalidArgumentError: NULL argument");
+    uint64_t acc = 0;
+    for (size_t i = 0; i < n_sentences; ++i) {
+        out_offsets[i] = acc;
+        const uint64_t b0 = byte_offsets[i], b1 = byte_offsets[i + 1];
+        if (b1 <= b0) return fail(VPT_INVALID_ARGUMENT, "InvalidArgumentError: text: must contain at least one character");
+        const uint8_t* s = utf8 + b0;
+        const size_t n = size_t(b1 - b0);
+        if (std::memchr(s, 0, n)) return fail(VPT_INVALID_ARGUMENT, "InvalidArgumentError: text: must not contain NULL");
+        uint64_t chars = 0;
+        for (size_t k = 0; k < n; ++k) chars += (s[k] & 0xC0) != 0x80;
+        if (chars == 0) return fail(VPT_INVALID_ARGUMENT, "InvalidArgumentError: text: must contain at least one character");
+        acc += chars - 1;
+    }
+    out_offsets[n_sentences] = acc;
+    return VPT_OK;
+}
+
+vpt_status vpt_batch_create(const vpt_predictor* p, vpt_batch** out) {
+    if (!p || !out) return fail(VPT_INVALID_ARGUMENT, "InvalidArgumentError: NULL argument");
+    *out = nullptr;
+    VPT_HIP(hipSetDevice(p->device));
+    vpt_batch* b = new (std::nothrow) vpt_batch();
+    if (!b) return fail(VPT_RUNTIME_ERROR, "out of host memory");
+    b->pred = p; b->device = p->device;
+    hipError_t e = hipMalloc(reinterpret_cast<void**>(&b->d_ctrl), 64);
+    if (e == hipSuccess) e = hipMemset(b->d_ctrl, 0, 64);
+    if (e != hipSuccess) { batch_release(b); return fail(VPT_RUNTIME_ERROR, std::string("HIP error: ") + hipGetErrorString(e)); }
+    *out = b;
+    return VPT_OK;
+}
+
+void vpt_batch_destroy(vpt_batch* b) { batch_release(b); }
+
+vpt_status vpt_batch_set_timing(vpt_batch* b, int enabled) {
+    if (!b) return fail(VPT_INVALID_ARGUMENT, "InvalidArgumentError: NULL argument");
+    VPT_HIP(hipSetDevice(b->device));
+    if (enabled && b->ev.empty()) {
+        for (size_t i = 0; i < 2 * kTimingRing; ++i) {
+            hipEvent_t e = nullptr;
+            VPT_HIP(hipEventCreate(&e));
+            b->ev.push_back(e);
+        }
+    }
+    b->timing = enabled != 0;
+    b->ev_calls = 0;
+    return VPT_OK;
+}
+
+vpt_status vpt_batch_kernel_ms(vpt_batch* b, float* score_kernel_ms, uint32_t* n_tiles) {
+    if (!b) return fail(VPT_INVALID_ARGUMENT, "InvalidArgumentError: NULL argument");
+    if (n_tiles) *n_tiles = b->last_tiles;
+    if (score_kernel_ms) {
+        *score_kernel_ms = 0.f;
+        if (b->pending) return fail(VPT_INVALID_ARGUMENT, "InvalidArgumentError: batch: call vpt_batch_sync first");
+        const size_t n = std::min(b->ev_calls, kTimingRing);
+        double sum = 0;
+        for (size_t k = 0; k < n; ++k) {
+            const size_t slot = (b->ev_calls - 1 - k) % kTimingRing;
+            float ms = 0.f;
+            VPT_HIP(hipEventElapsedTime(&ms, b->ev[2 * slot], b->ev[2 * slot + 1]));
+            sum += ms;
+        }
+        if (n) *score_kernel_ms = float(sum / double(n));
+        b->ev_calls = 0;
+    }
+    return VPT_OK;
+}
+
+vpt_status vpt_predict_batch_device(const vpt_predictor* p, vpt_batch* b, const uint8_t* d_utf8, const uint64_t* d_byte_offsets,
+                                    const uint64_t* d_out_offsets, size_t n_sentences, uint64_t total_boundaries,
+                                    uint64_t max_sentence_bytes, int32_t* d_scores, uint8_t* d_labels, void* hip_stream) {
+    if (!p || !b || b->pred != p) return fail(VPT_INVALID_ARGUMENT, "InvalidArgumentError: batch: does not belong to this predictor");
+    if (n_sentences == 0) { b->pending = false; b->last_tiles = 0; return VPT_OK; }
+    if (!d_utf8 || !d_byte_offsets || !d_out_offsets) return fail(VPT_INVALID_ARGUMENT, "InvalidArgumentError: NULL device pointer");
+    if (n_sentences >= 0xFFFFFFFFull) return fail(VPT_INVALID_ARGUMENT, "InvalidArgumentError: n_sentences: at most 2^32-2 per call");
+    hipStream_t stream = static_cast<hipStream_t>(hip_stream);
+    VPT_HIP(hipSetDevice(p->device));
+    const uint64_t total_flat = total_boundaries + uint64_t(n_sentences) * uint64_t(1 + p->pad);
+    const uint64_t n_tiles64 = (total_flat + vpt::kTileFlat - 1) / vpt::kTileFlat;
+    if (n_tiles64 >= 0x7FFFFFFFull) return fail(VPT_INVALID_ARGUMENT, "InvalidArgumentError: batch too large for one call");
+    const uint32_t n_tiles = uint32_t(n_tiles64);
+    if (size_t(n_tiles) + 1 > b->tile_cap || !b->d_tile_first) {
+        (void)hipFree(b->d_slow_list); b->d_slow_list = nullptr;
+        size_t cap = b->tile_cap;
+        vpt_status st = grow(&b->d_tile_first, &cap, size_t(n_tiles) + 1);
+        if (st != VPT_OK) return st;
+        b->tile_cap = cap;
+        VPT_HIP(hipMalloc(reinterpret_cast<void**>(&b->d_slow_list), cap * sizeof(uint32_t) + 64));
+    }
+    // long-sentence scratch (only when a sentence might not fit the LDS tile)
+    const bool need_slow = max_sentence_bytes + 2 * uint64_t(p->pad) > uint64_t(vpt::kCap - vpt::kTileFlat);
+    uint32_t slow_blocks = 0, scratch_cap = 0;
+    uint64_t slab = 0;
+    if (need_slow) {
+        const uint64_t cap64 = max_sentence_bytes + 2 * uint64_t(p->pad) + vpt::kMargin + 8;
+        if (cap64 >= 0x7FFFFFF0ull) return fail(VPT_INVALID_ARGUMENT, "InvalidArgumentError: max_sentence_bytes: too large");
+        scratch_cap = uint32_t((cap64 + 15) & ~15ull);
+        slab = (uint64_t(scratch_cap) * 9 + 255) & ~255ull;
+        slow_blocks = uint32_t(std::max<uint64_t>(1, std::min<uint64_t>(64, (8ull << 30) / slab)));
+        const size_t need = size_t(slab) * slow_blocks;
+        if (need > b->scratch_bytes) {
+            (void)hipFree(b->d_scratch); b->d_scratch = nullptr; b->scratch_bytes = 0;
+            VPT_HIP(hipMalloc(reinterpret_cast<void**>(&b->d_scratch), need));
+            b->scratch_bytes = need;
+        }
+    }
+    vpt::ScoreParams P{};
+    P.ct = p->ct; P.tt = p->tt; P.type_table = p->d_type_table;
+    P.type_window = p->type_window; P.type_kind = p->type_kind; P.bias = p->bias; P.pad = p->pad;
+    P.text = d_utf8; P.boff = d_byte_offsets; P.ooff = d_out_offsets; P.tile_first = b->d_tile_first;
+    P.scores = d_scores; P.labels = d_labels; P.status = b->d_ctrl; P.slow_list = b->d_slow_list; P.slow_count = b->d_ctrl + 1;
+    P.scratch = b->d_scratch; P.scratch_stride = slab; P.scratch_cap = scratch_cap;
+
+    VPT_HIP(hipMemsetAsync(b->d_ctrl, 0, 8, stream));
+    VPT_HIP(vpt::launch_assign_tiles(d_out_offsets, n_sentences, p->pad, n_tiles, b->d_tile_first, stream));
+    const size_t slot = b->ev_calls % kTimingRing;
+    if (b->timing) VPT_HIP(hipEventRecord(b->ev[2 * slot], stream));
+    VPT_HIP(vpt::launch_score_tiles(P, p->chunks, n_tiles, stream));
+    if (b->timing) { VPT_HIP(hipEventRecord(b->ev[2 * slot + 1], stream)); ++b->ev_calls; }
+    if (need_slow) VPT_HIP(vpt::launch_score_slow(P, p->chunks, slow_blocks, stream));
+    b->last_tiles = n_tiles; b->last_stream = stream; b->pending = true;
+    return VPT_OK;
+}
+
+vpt_status vpt_batch_sync(vpt_batch* b) {
+    if (!b) return fail(VPT_INVALID_ARGUMENT, "InvalidArgumentError: NULL argument");
+    if (!b->pending) return VPT_OK;
+    VPT_HIP(hipSetDevice(b->device));
+    uint32_t ctrl[2] = {0, 0};
+    VPT_HIP(hipMemcpyAsync(ctrl, b->d_ctrl, sizeof(ctrl), hipMemcpyDeviceToHost, b->last_stream));
+    VPT_HIP(hipStreamSynchronize(b->last_stream));
+    b->pending = false;
+    return status_from_bits(ctrl[0]);
+}
+
+vpt_status vpt_predict_batch(const vpt_predictor* p, const uint8_t* utf8, const uint64_t* byte_offsets, size_t n_sentences,
+                             int32_t* scores_out, uint8_t* labels_out, const uint64_t* out_offsets) {
+    if (!p) return fail(VPT_INVALID_ARGUMENT, "InvalidArgumentError: predictor: must not be NULL");
+    if (n_sentences == 0) return VPT_OK;
+    if (!utf8 || !byte_offsets || !out_offsets) return fail(VPT_INVALID_ARGUMENT, "InvalidArgumentError: NULL argument");
+    VPT_HIP(hipSetDevice(p->device));
+    vpt_batch* b = nullptr;
+    {
+        std::lock_guard<std::mutex> g(p->pool_mu);
+        if (!p->pool.empty()) { b = p->pool.back(); p->pool.pop_back(); }
+    }
+    if (!b) {
+        vpt_status st = vpt_batch_create(p, &b);
+        if (st != VPT_OK) return st;
+        if (hipStreamCreateWithFlags(&b->own_stream, hipStreamNonBlocking) != hipSuccess) {
+            batch_release(b);
+            return fail(VPT_RUNTIME_ERROR, "HIP error: cannot create a stream");
+        }
+    }
+    auto give_back = [&](vpt_status st) {
+        std::lock_guard<std::mutex> g(p->pool_mu);
+        p->pool.push_back(b);
+        return st;
+    };
+    const uint64_t t0 = byte_offsets[0], t1 = byte_offsets[n_sentences];
+    if (t1 < t0) return give_back(fail(VPT_INVALID_ARGUMENT, "InvalidArgumentError: byte_offsets: must be non-decreasing"));
+    const size_t nbytes = size_t(t1 - t0);
+    const uint64_t total_b = out_offsets[n_sentences] - out_offsets[0];
+    uint64_t max_bytes = 0;
+    for (size_t i = 0; i < n_sentences; ++i) {
+        if (byte_offsets[i + 1] <= byte_offsets[i])
+            return give_back(fail(VPT_INVALID_ARGUMENT, "InvalidArgumentError: text: must contain at least one character"));
+        max_bytes = std::max<uint64_t>(max_bytes, byte_offsets[i + 1] - byte_offsets[i]);
+    }
+    vpt_status st;
+    if ((st = grow(&b->d_text, &b->text_cap, nbytes + 32)) != VPT_OK) return give_back(st);
+    {
+        size_t cap = b->off_cap;
+        if ((st = grow(&b->d_boff, &cap, n_sentences + 1)) != VPT_OK) return give_back(st);
+        size_t cap2 = b->off_cap;
+        if ((st = grow(&b->d_ooff, &cap2, n_sentences + 1)) != VPT_OK) return give_back(st);
+        b->off_cap = std::min(cap, cap2);
+    }
+    {
+        size_t cap = b->out_cap;
+        if ((st = grow(&b->d_scores, &cap, size_t(total_b) + 1)) != VPT_OK) return give_back(st);
+        size_t cap2 = b->out_cap;
+        if ((st = grow(&b->d_labels, &cap2, size_t(total_b) + 1)) != VPT_OK) return give_back(st);
+        b->out_cap = std::min(cap, cap2);
+    }
+    // offsets are rebased so that the device sees text starting at 0 and outputs starting at 0
+    std::vector<uint64_t> boff(n_sentences + 1), ooff(n_sentences + 1);
+    for (size_t i = 0; i <= n_sentences; ++i) { boff[i] = byte_offsets[i] - t0; ooff[i] = out_offsets[i] - out_offsets[0]; }
+    hipStream_t s = b->own_stream;
+    auto hip_fail = [&](hipError_t e) { return give_back(fail(VPT_RUNTIME_ERROR, std::string("HIP error: ") + hipGetErrorString(e))); };
+    hipError_t e;
+    if ((e = hipMemcpyAsync(b->d_text, utf8 + t0, nbytes, hipMemcpyHostToDevice, s)) != hipSuccess) return hip_fail(e);
+    if ((e = hipMemcpyAsync(b->d_boff, boff.data(), 8 * (n_sentences + 1), hipMemcpyHostToDevice, s)) != hipSuccess) return hip_fail(e);
+    if ((e = hipMemcpyAsync(b->d_ooff, ooff.data(), 8 * (n_sentences + 1), hipMemcpyHostToDevice, s)) != hipSuccess) return hip_fail(e);
+    st = vpt_predict_batch_device(p, b, b->d_text, b->d_boff, b->d_ooff, n_sentences, total_b, max_bytes,
+                                  scores_out ? b->d_scores : nullptr, labels_out ? b->d_labels : nullptr, s);
+    if (st != VPT_OK) return give_back(st);
+    if (scores_out && total_b &&
+        (e = hipMemcpyAsync(scores_out + out_offsets[0], b->d_scores, 4 * total_b, hipMemcpyDeviceToHost, s)) != hipSuccess) return hip_fail(e);
+    if (labels_out && total_b &&
+        (e = hipMemcpyAsync(labels_out + out_offsets[0], b->d_labels, total_b, hipMemcpyDeviceToHost, s)) != hipSuccess) return hip_fail(e);
+    st = vpt_batch_sync(b);
+    return give_back(st);
+}
+
+vpt_status vpt_predict_one(const vpt_predictor* p, const uint8_t* utf8, size_t len, int32_t* scores, uint8_t* labels, size_t* n_boundaries) {
+    uint64_t boff[2] = {0, uint64_t(len)}, ooff[2] = {0, 0};
+    if (len == 0) return fail(VPT_INVALID_ARGUMENT, "InvalidArgumentError: text: must contain at least one character");
+    vpt_status st = vpt_count_boundaries(utf8, boff, 1, ooff);
+    if (st != VPT_OK) return st;
+    if (n_boundaries) *n_boundaries = size_t(ooff[1]);
+    return vpt_predict_batch(p, utf8, boff, 1, scores, labels, ooff);
+}
+
+}  // extern "C"

@@ -1,0 +1,54 @@
+// Kernel-side parameter block and launchers (kernels.hip), used by the C ABI (capi.cpp).
+#pragma once
+#include <hip/hip_runtime_api.h>
+
+#include <cstddef>
+#include <cstdint>
+
+#include "layout.h"
+#include "tables.hpp"
+
+namespace vpt {
+
+constexpr int kThreads = 256;                    // 4 waves per workgroup
+constexpr int kCap = 2048;                       // flat positions (chars + separators) one LDS tile can hold
+constexpr int kTileFlat = 1024;                  // flat positions a tile is cut at (a tile ends with the sentence
+                                                 // that crosses the cut, so it needs kCap - kTileFlat of slack)
+constexpr int kMargin = 8;                       // zeroed slack past the tile for the s+1, s+2 look-ahead
+constexpr int kBitmapWords = 4 * kCap / 32 + 4;  // one bit per text byte of a tile (UTF-8: <= 4 bytes per char)
+
+// device status word (OR of bits)
+constexpr uint32_t kErrEmptySentence = 1u;    // "text: must contain at least one character" (sentence.rs:181-186)
+constexpr uint32_t kErrNulChar = 2u;          // "text: must not contain NULL"               (sentence.rs:174-179)
+constexpr uint32_t kErrBadOffsets = 4u;       // out_offsets do not match the text (or invalid UTF-8)
+constexpr uint32_t kErrScratchTooSmall = 8u;  // max_sentence_bytes was understated
+
+struct ScoreParams {
+    PatternTableView ct;        // characters: n-grams + dictionary words
+    PatternTableView tt;        // character types, when type_kind == kTypePatternTable
+    const int32_t* type_table;  // 8^(2W) window scores, when type_kind == kTypeWindowTable
+    int32_t type_window;
+    int32_t type_kind;
+    int32_t bias;
+    int32_t pad;
+    const uint8_t* text;
+    const uint64_t* boff;       // [S+1] byte offsets
+    const uint64_t* ooff;       // [S+1] output (boundary) offsets
+    const uint32_t* tile_first; // [n_tiles+1]
+    int32_t* scores;
+    uint8_t* labels;
+    uint32_t* status;
+    uint32_t* slow_list;        // tiles deferred to the global-scratch path
+    uint32_t* slow_count;
+    unsigned char* scratch;     // slabs for score_slow_kernel
+    uint64_t scratch_stride;    // bytes per workgroup slab
+    uint32_t scratch_cap;       // flat positions per slab
+};
+
+size_t score_tiles_lds_bytes();
+hipError_t launch_assign_tiles(const uint64_t* ooff, uint64_t n_sent, int pad, uint32_t n_tiles, uint32_t* tile_first,
+                               hipStream_t stream);
+hipError_t launch_score_tiles(const ScoreParams& P, int chunks, uint32_t n_tiles, hipStream_t stream);
+hipError_t launch_score_slow(const ScoreParams& P, int chunks, uint32_t n_blocks, hipStream_t stream);
+
+}  // namespace vpt

@@ -1,0 +1,75 @@
+// Table layout shared by the host-side builder (tables.cpp) and the HIP kernels (kernels.hip).
+//
+// What Predictor::new builds in the reference -- a double-array Aho-Corasick automaton over all char n-grams
+// and dictionary words with suffix-merged weight vectors (char_scorer/boundary_scorer.rs:56-89,
+// char_scorer.rs:50-78) -- is replaced by position-parallel lookup tables.  Integer addition is associative
+// and commutative, so "for every start position, add the weights of EVERY pattern that starts there" gives
+// bit-identical scores to the reference's "longest match + pre-merged suffix weights".
+//
+// Pattern table (one for characters; one for character types when the window table cannot be used):
+//
+//   level n = 1..3   strings of <= 3 symbols, key = s1 | s2 << 21 | s3 << 42 (absent symbols = 0; a symbol is
+//                    never 0: sentence.rs:174-179 bans U+0000 and type ids are 1..6).
+//                    Entry = [key_lo, key_hi, slot_0 .. slot_{SC-1}] as dwords, stride padded to 16 bytes,
+//                    open addressing + linear probing, key 0 = empty.
+//                    slot_j of a level-n entry = total weight this string adds to boundary (start + lo[n] + j):
+//                      lo[n]  = min(n-1-W, -1)      hi[n] = max(W-1, n-1)      len[n] = hi[n]-lo[n]+1
+//                    (n-gram w[k] lands on boundary start+n-1-W+k, char_scorer/boundary_scorer.rs:63 with
+//                     predictor.rs:178-179; dict-word w[k] on boundary start-1+k, boundary_scorer.rs:67-74;
+//                     when the same string is both, the two vectors are summed like CharWeightMerger::add).
+//                    Level-3 entries keep one extra slot (index ext_slot): id of the trie node that continues
+//                    this 3-symbol prefix, or 0.
+//   unigram rows     symbols < uni_n index `uni` directly (row = the slots of the level-1 entry, no key).
+//   long trie        strings of > 3 symbols: edge table keyed (parent_node << 32 | symbol) ->
+//                    {child node, woff}; the row of a node at depth n has len[n] (same formula) entries at
+//                    wdata[woff ..]; woff = kNoRow when the node is only a prefix.
+#pragma once
+#include <cstdint>
+#if defined(__HIPCC__)
+#include <hip/hip_runtime.h>
+#endif
+
+namespace vpt {
+
+constexpr int kMaxWindow = 8;                 // windows above this are rejected (model contract)
+constexpr uint32_t kUniDirectChars = 0x10000; // BMP code points index the unigram rows directly
+constexpr uint32_t kUniDirectTypes = 256;     // type ids are bytes
+constexpr uint32_t kNoRow = 0xFFFFFFFFu;
+constexpr uint64_t kHashMul = 0x9E3779B97F4A7C15ull;
+
+#if defined(__HIPCC__)
+#define VPT_HD __host__ __device__ __forceinline__
+#else
+#define VPT_HD inline
+#endif
+
+VPT_HD uint64_t short_key(uint32_t s1, uint32_t s2, uint32_t s3) {
+    return uint64_t(s1) | (uint64_t(s2) << 21) | (uint64_t(s3) << 42);
+}
+VPT_HD uint64_t edge_key(uint32_t parent, uint32_t sym) { return (uint64_t(parent) << 32) | sym; }
+VPT_HD uint32_t hash_slot(uint64_t key, uint32_t shift) { return uint32_t((key * kHashMul) >> shift); }
+
+// geometry of the row of a pattern of n symbols under window W (see the header comment)
+VPT_HD int row_lo(int n, int W) { return (n - 1 - W) < -1 ? (n - 1 - W) : -1; }
+VPT_HD int row_hi(int n, int W) { return (W - 1) > (n - 1) ? (W - 1) : (n - 1); }
+VPT_HD int row_len(int n, int W) { return row_hi(n, W) - row_lo(n, W) + 1; }
+
+// Device view of one pattern table; passed to kernels by value.
+struct PatternTableView {
+    const uint32_t* short_tab;
+    const uint32_t* uni;
+    const uint32_t* edges;   // 4 dwords per edge slot: key_lo, key_hi, child, woff
+    const int32_t* wdata;
+    uint32_t short_shift, short_mask;
+    uint32_t edge_shift, edge_mask;
+    uint32_t stride_dw;      // dwords per short entry (2 + slots, rounded up to a multiple of 4)
+    uint32_t uni_dw;         // dwords per unigram row (rounded up to a multiple of 4)
+    uint32_t uni_n;          // symbols below this use `uni`
+    uint32_t ext_slot;       // slot of a level-3 entry that holds the continuation node
+    int32_t window;
+    int32_t lo[3], len[3];
+    uint32_t has_long;       // any pattern longer than 3 symbols
+    uint32_t present;        // 0 = this scorer is None (char_scorer.rs:98-100 / type_scorer.rs:109-111)
+};
+
+}  // namespace vpt

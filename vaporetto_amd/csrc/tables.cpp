@@ -1,0 +1,308 @@
+// Table compiler.  Reference behaviour mirrored here:
+//   CharScorer::new / CharScorerBoundary::new     char_scorer.rs:92-124, char_scorer/boundary_scorer.rs:56-89
+//   TypeScorer::new (variant choice)              type_scorer.rs:104-144
+//   TypeScorerBoundaryCache::new                  type_scorer/boundary_scorer_cache.rs:22-57
+//   TypeScorerBoundary::new                       type_scorer/boundary_scorer.rs:45-62
+// See layout.h for why all-matches tables give the same sums as the reference's merged automaton.
+#include "tables.hpp"
+
+#include <algorithm>
+#include <string>
+#include <unordered_map>
+
+namespace vpt {
+namespace {
+
+inline int32_t wadd(int32_t a, int32_t b) { return int32_t(uint32_t(a) + uint32_t(b)); }  // release builds wrap
+
+struct Pat {
+    SymString s;
+    std::vector<int32_t> row;  // row_len(n, W) totals, first entry = boundary (start + row_lo(n, W))
+};
+
+bool has_zero(const SymString& s) {
+    for (Sym c : s)
+        if (c == 0) return true;
+    return false;
+}
+
+// n-gram weights: w[k] -> boundary start + n-1-W + k   (offset -W from the END position, boundary_scorer.rs:63)
+void add_ngram(std::vector<Pat>& out, const SymString& g, const std::vector<int32_t>& w, int W, bool is_char) {
+    const int n = int(g.size());
+    if (n == 0) throw ModelError("InvalidModelError: failed to build the automaton");  // daachorse rejects ""
+    const int cap = std::max(0, 2 * W - n + 1);
+    if (int(w.size()) > cap)
+        throw ModelError(std::string("InvalidModelError: ") + (is_char ? "character" : "character type") +
+                         " n-gram weight vector is longer than 2*window_size-n+1");
+    if (w.empty() || has_zero(g)) return;  // contributes nothing / can never match a sentence
+    Pat p;
+    p.s = g;
+    p.row.assign(size_t(row_len(n, W)), 0);
+    const int base = (n - 1 - W) - row_lo(n, W);
+    for (size_t k = 0; k < w.size(); ++k) p.row[size_t(base) + k] = w[k];
+    out.push_back(std::move(p));
+}
+
+// dictionary word weights: w[k] -> boundary start - 1 + k   (offset -len from the END position, rs:67-74)
+void add_word(std::vector<Pat>& out, const SymString& g, const std::vector<int32_t>& w, int W) {
+    const size_t n = g.size();
+    if (n == 0) throw ModelError("InvalidModelError: failed to build the automaton");
+    if (n > 32767)
+        throw ModelError("InvalidModelError: words must be shorter than or equal to 32767 characters");
+    if (w.size() > n + 1)
+        throw ModelError("InvalidModelError: dictionary weight vector is longer than the word length + 1");
+    if (w.empty() || has_zero(g)) return;
+    Pat p;
+    p.s = g;
+    p.row.assign(size_t(row_len(int(n), W)), 0);
+    const int base = -1 - row_lo(int(n), W);
+    for (size_t k = 0; k < w.size(); ++k) p.row[size_t(base) + k] = w[k];
+    out.push_back(std::move(p));
+}
+
+uint32_t bits_for(size_t count) {  // capacity 2^bits >= 2*count, at least 16
+    uint32_t bits = 4;
+    while ((size_t(1) << bits) < count * 2) ++bits;
+    return bits;
+}
+
+HostPatternTable build_table(std::vector<Pat>& pats, int W, uint32_t uni_n) {
+    HostPatternTable t;
+    t.present = true;
+    t.window = W;
+    t.uni_n = uni_n;
+    for (int n = 1; n <= 3; ++n) {
+        t.lo[n - 1] = row_lo(n, W);
+        t.len[n - 1] = row_len(n, W);
+    }
+    // identical strings are summed (CharWeightMerger::add, char_scorer.rs:37-47)
+    std::sort(pats.begin(), pats.end(), [](const Pat& a, const Pat& b) { return a.s < b.s; });
+    size_t o = 0;
+    for (size_t i = 0; i < pats.size(); ++i) {
+        if (o > 0 && pats[o - 1].s == pats[i].s) {
+            for (size_t k = 0; k < pats[i].row.size(); ++k) pats[o - 1].row[k] = wadd(pats[o - 1].row[k], pats[i].row[k]);
+        } else {
+            if (o != i) pats[o] = std::move(pats[i]);
+            ++o;
+        }
+    }
+    pats.resize(o);
+
+    // ---- long trie (strings of more than 3 symbols)
+    struct Root { uint32_t node; };
+    std::unordered_map<uint64_t, uint32_t> root3;   // short_key(3-prefix) -> node id
+    std::unordered_map<uint64_t, uint32_t> edge;    // edge_key(parent, sym) -> child
+    std::vector<uint32_t> node_woff(1, kNoRow);     // node 0 is unused (0 = "no continuation")
+    for (const Pat& p : pats) {
+        const size_t n = p.s.size();
+        t.max_pattern = std::max<uint32_t>(t.max_pattern, uint32_t(n));
+        if (n <= 3) continue;
+        t.has_long = true;
+        uint64_t k3 = short_key(p.s[0], p.s[1], p.s[2]);
+        auto it = root3.find(k3);
+        uint32_t node;
+        if (it == root3.end()) {
+            node = uint32_t(node_woff.size());
+            node_woff.push_back(kNoRow);
+            root3.emplace(k3, node);
+        } else node = it->second;
+        for (size_t i = 3; i < n; ++i) {
+            uint64_t ek = edge_key(node, p.s[i]);
+            auto e = edge.find(ek);
+            if (e == edge.end()) {
+                uint32_t child = uint32_t(node_woff.size());
+                node_woff.push_back(kNoRow);
+                edge.emplace(ek, child);
+                node = child;
+            } else node = e->second;
+        }
+        node_woff[node] = uint32_t(t.wdata.size());
+        t.wdata.insert(t.wdata.end(), p.row.begin(), p.row.end());
+    }
+    t.n_long_nodes = uint32_t(node_woff.size() - 1);
+    if (t.wdata.empty()) t.wdata.push_back(0);
+
+    // ---- short entries (<= 3 symbols) and their slot count
+    t.slots = uint32_t(std::max(std::max(t.len[0], t.len[1]), t.len[2] + 1));
+    t.ext_slot = t.slots - 1;
+    t.stride_dw = (2 + t.slots + 3) & ~3u;
+    t.uni_dw = (t.slots + 3) & ~3u;
+    t.uni.assign(size_t(uni_n) * t.uni_dw, 0);
+
+    struct ShortEnt { uint64_t key; const std::vector<int32_t>* row; uint32_t ext; };
+    std::vector<ShortEnt> ents;
+    std::unordered_map<uint64_t, size_t> ent_of;  // only for 3-symbol keys that need a continuation
+    for (const Pat& p : pats) {
+        const size_t n = p.s.size();
+        if (n > 3) continue;
+        if (n == 1 && p.s[0] < uni_n) {
+            for (size_t k = 0; k < p.row.size(); ++k) t.uni[size_t(p.s[0]) * t.uni_dw + k] = uint32_t(p.row[k]);
+            ++t.n_short;
+            continue;
+        }
+        uint64_t key = short_key(p.s[0], n > 1 ? p.s[1] : 0, n > 2 ? p.s[2] : 0);
+        if (n == 3) ent_of.emplace(key, ents.size());
+        ents.push_back({key, &p.row, 0});
+    }
+    for (const auto& r : root3) {  // prefix closure at level 3 only
+        auto it = ent_of.find(r.first);
+        if (it == ent_of.end()) ents.push_back({r.first, nullptr, r.second});
+        else ents[it->second].ext = r.second;
+    }
+    t.n_short += uint32_t(ents.size());
+    t.short_bits = bits_for(ents.size());
+    const uint32_t smask = (1u << t.short_bits) - 1;
+    t.short_tab.assign((size_t(1) << t.short_bits) * t.stride_dw, 0);
+    for (const ShortEnt& e : ents) {
+        uint32_t idx = hash_slot(e.key, 64 - t.short_bits), probes = 1;
+        while (t.short_tab[size_t(idx) * t.stride_dw] | t.short_tab[size_t(idx) * t.stride_dw + 1]) {
+            idx = (idx + 1) & smask;
+            ++probes;
+        }
+        t.max_probe_short = std::max(t.max_probe_short, probes);
+        uint32_t* d = &t.short_tab[size_t(idx) * t.stride_dw];
+        d[0] = uint32_t(e.key);
+        d[1] = uint32_t(e.key >> 32);
+        if (e.row)
+            for (size_t k = 0; k < e.row->size(); ++k) d[2 + k] = uint32_t((*e.row)[k]);
+        if (e.ext) d[2 + t.ext_slot] = e.ext;
+    }
+
+    // ---- edge table
+    t.edge_bits = bits_for(edge.size());
+    const uint32_t emask = (1u << t.edge_bits) - 1;
+    t.edges.assign((size_t(1) << t.edge_bits) * 4, 0);
+    for (const auto& e : edge) {
+        uint32_t idx = hash_slot(e.first, 64 - t.edge_bits), probes = 1;
+        while (t.edges[size_t(idx) * 4] | t.edges[size_t(idx) * 4 + 1]) {
+            idx = (idx + 1) & emask;
+            ++probes;
+        }
+        t.max_probe_edge = std::max(t.max_probe_edge, probes);
+        uint32_t* d = &t.edges[size_t(idx) * 4];
+        d[0] = uint32_t(e.first);
+        d[1] = uint32_t(e.first >> 32);
+        d[2] = e.second;
+        d[3] = node_woff[e.second];
+    }
+    return t;
+}
+
+// TypeScorerBoundaryCache::new (boundary_scorer_cache.rs:22-57): scores[seq] for every window of 2W type codes
+// (3 bits each, leftmost = most significant, 0 = outside the sentence, 7 = invalid -> score 0) is the sum over
+// every pattern occurrence inside the window of w[2W - end] when that index exists.
+std::vector<int32_t> build_type_window_table(const std::vector<NgramRecord>& ngrams, int W) {
+    const int L = 2 * W;
+    std::unordered_map<uint64_t, const std::vector<int32_t>*> by_key;  // (n << 32 | packed codes) -> weights
+    for (const NgramRecord& d : ngrams) {
+        // the reference feeds the UNMERGED list to the automaton builder: empty or duplicate patterns fail
+        if (d.ngram.empty()) throw ModelError("InvalidModelError: invalid character type n-grams");
+        bool usable = int(d.ngram.size()) <= L;
+        uint64_t packed = 0;
+        for (Sym s : d.ngram) {
+            if (s > 6) usable = false;  // windows only hold codes 0..6
+            packed = (packed << 3) | (s & 7);
+        }
+        if (!usable) continue;
+        uint64_t key = (uint64_t(d.ngram.size()) << 32) | packed;
+        if (!by_key.emplace(key, &d.weights).second)
+            throw ModelError("InvalidModelError: invalid character type n-grams");
+    }
+    {  // duplicate check for the patterns skipped above (longer than the window or with codes > 6)
+        std::vector<const SymString*> all;
+        for (const NgramRecord& d : ngrams) all.push_back(&d.ngram);
+        std::sort(all.begin(), all.end(), [](const SymString* a, const SymString* b) { return *a < *b; });
+        for (size_t i = 1; i < all.size(); ++i)
+            if (*all[i] == *all[i - 1]) throw ModelError("InvalidModelError: invalid character type n-grams");
+    }
+    std::vector<int32_t> table(size_t(1) << (3 * L), 0);
+    std::vector<uint32_t> codes(size_t(L), 0);
+    const size_t total = table.size();
+    for (size_t seq = 0; seq < total; ++seq) {
+        bool valid = true;
+        for (int i = 0; i < L; ++i) {
+            uint32_t c = uint32_t(seq >> (3 * (L - 1 - i))) & 7;
+            if (c == 7) { valid = false; break; }
+            codes[size_t(i)] = c;
+        }
+        if (!valid) continue;
+        int32_t y = 0;
+        for (int end = 1; end <= L; ++end) {
+            uint64_t packed = 0;
+            for (int n = 1; n <= end; ++n) {  // pattern = codes[end-n .. end)
+                packed |= uint64_t(codes[size_t(end - n)]) << (3 * (n - 1));
+                auto it = by_key.find((uint64_t(n) << 32) | packed);
+                if (it == by_key.end()) continue;
+                size_t k = size_t(L - end);
+                if (k < it->second->size()) y = wadd(y, (*it->second)[k]);
+            }
+        }
+        table[seq] = y;
+    }
+    return table;
+}
+
+}  // namespace
+
+CompiledModel compile_model(const ModelData& m, bool predict_tags) {
+    CompiledModel c;
+    c.bias = m.bias;
+    c.predict_tags = predict_tags;
+    c.n_char_ngrams = uint32_t(m.char_ngrams.size());
+    c.n_type_ngrams = uint32_t(m.type_ngrams.size());
+    c.n_dict_words = uint32_t(m.dict.size());
+    c.n_tag_models = uint32_t(m.tag_models.size());
+    const bool tags_on = predict_tags && !m.tag_models.empty();  // predictor.rs:463-479
+    if (tags_on) {
+        // With tag models the reference adds every tag n-gram to the automata (boundary_tag_scorer.rs:87-104):
+        // an empty one fails the build, a rel_position beyond the window indexes out of bounds (panic).
+        for (const auto& t : m.tag_models) {
+            for (const auto& d : t.char_ngrams) {
+                if (d.ngram.empty() && m.char_window != 0 && !(m.char_ngrams.empty() && m.dict.empty()))
+                    throw ModelError("InvalidModelError: failed to build the automaton");
+                for (const auto& w : d.weights)
+                    if (w.rel_position > m.char_window)
+                        throw ModelError("InvalidModelError: tag n-gram rel_position exceeds char_window_size");
+            }
+            for (const auto& d : t.type_ngrams) {
+                if (d.ngram.empty() && m.type_window != 0 && !m.type_ngrams.empty())
+                    throw ModelError("InvalidModelError: failed to build the automaton");
+                for (const auto& w : d.weights)
+                    if (w.rel_position > m.type_window)
+                        throw ModelError("InvalidModelError: tag n-gram rel_position exceeds type_window_size");
+            }
+        }
+    }
+
+    // CharScorer::new: None when there is nothing to match or the window is 0 (char_scorer.rs:98-100)
+    const int wc = m.char_window;
+    if (!((m.char_ngrams.empty() && m.dict.empty()) || wc == 0)) {
+        if (wc > kMaxWindow) throw ModelError("InvalidModelError: char_window_size above 8 is not supported");
+        std::vector<Pat> pats;
+        pats.reserve(m.char_ngrams.size() + m.dict.size());
+        for (const auto& d : m.char_ngrams) add_ngram(pats, d.ngram, d.weights, wc, true);
+        for (const auto& d : m.dict) add_word(pats, d.word, d.weights, wc);
+        c.chars = build_table(pats, wc, kUniDirectChars);
+    }
+
+    // TypeScorer::new: None without n-grams or window (type_scorer.rs:109-111); the window table when
+    // window <= 3 and no tag models take part, pattern matching otherwise (type_scorer.rs:113-131)
+    const int wt = m.type_window;
+    if (!(m.type_ngrams.empty() || wt == 0)) {
+        c.type_window = wt;
+        if (!tags_on && wt <= 3) {
+            c.type_kind = kTypeWindowTable;
+            c.type_table = build_type_window_table(m.type_ngrams, wt);
+        } else {
+            if (wt > kMaxWindow) throw ModelError("InvalidModelError: type_window_size above 8 is not supported");
+            c.type_kind = kTypePatternTable;
+            std::vector<Pat> pats;
+            for (const auto& d : m.type_ngrams) add_ngram(pats, d.ngram, d.weights, wt, false);
+            c.types = build_table(pats, wt, kUniDirectTypes);
+        }
+    }
+    c.pad = std::max(1, std::max(c.chars.present ? wc : 0, c.type_kind != kTypeNone ? wt : 0));
+    return c;
+}
+
+}  // namespace vpt

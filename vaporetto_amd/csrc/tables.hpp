@@ -1,0 +1,48 @@
+// Host-side table compiler: what Predictor::new does in the reference (predictor.rs:450-508), producing the
+// position-parallel tables of layout.h instead of automata.
+#pragma once
+#include <cstdint>
+#include <vector>
+
+#include "layout.h"
+#include "model.hpp"
+
+namespace vpt {
+
+struct HostPatternTable {
+    bool present = false;
+    int window = 0;
+    int lo[3] = {0, 0, 0}, len[3] = {0, 0, 0};
+    uint32_t slots = 0;       // weight slots per short entry (incl. the level-3 extension slot)
+    uint32_t stride_dw = 4, uni_dw = 4, uni_n = 0, ext_slot = 0;
+    uint32_t short_bits = 4, edge_bits = 4;
+    bool has_long = false;
+    std::vector<uint32_t> short_tab, uni, edges;
+    std::vector<int32_t> wdata;
+    // statistics
+    uint32_t n_short = 0, n_long_nodes = 0, max_pattern = 0, max_probe_short = 0, max_probe_edge = 0;
+
+    uint64_t bytes() const {
+        return 4ull * (short_tab.size() + uni.size() + edges.size() + wdata.size());
+    }
+};
+
+enum TypeKind : int { kTypeNone = 0, kTypeWindowTable = 1, kTypePatternTable = 2 };
+
+struct CompiledModel {
+    int32_t bias = 0;
+    int pad = 1;                       // zero symbols placed between sentences inside a tile
+    HostPatternTable chars;            // char n-grams + dictionary words
+    int type_kind = kTypeNone;
+    int type_window = 0;
+    std::vector<int32_t> type_table;   // 8^(2W) scores indexed by the 3-bit packed type window (cache variant)
+    HostPatternTable types;            // used when type_kind == kTypePatternTable
+    // counts for vpt_model_info
+    uint32_t n_char_ngrams = 0, n_type_ngrams = 0, n_dict_words = 0, n_tag_models = 0;
+    bool predict_tags = false;
+};
+
+// Throws ModelError with the reference's message where it defines one.
+CompiledModel compile_model(const ModelData& m, bool predict_tags);
+
+}  // namespace vpt

@@ -1,0 +1,70 @@
+"""Synthetic models and sentences in the real Vaporetto formats (bench / test tooling).
+
+Not on the product path.  `build_synth()` compiles libvpt_synth.so with g++ in-tree."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libvpt_synth.so")
+_SOURCES = [os.path.join(HERE, "synth.cpp"), os.path.join(HERE, "..", "csrc", "model.cpp")]
+
+M1_BCCWJ_LIKE, M2_KYTEA_LIKE, M3_TAGS = 1, 2, 3
+SEED_BASE = 0x5EED0000  # + config number
+
+
+def build_synth(force: bool = False) -> str:
+    if force or not os.path.exists(LIB_PATH) or any(os.path.getmtime(s) > os.path.getmtime(LIB_PATH) for s in _SOURCES):
+        subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-o", LIB_PATH] + _SOURCES)
+    return LIB_PATH
+
+
+_lib = None
+
+
+def _load():
+    global _lib
+    if _lib is None:
+        build_synth()
+        L = C.CDLL(LIB_PATH)
+        L.vpt_synth_model.argtypes = [C.c_int, C.c_uint64, C.c_double, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]
+        L.vpt_synth_sentences.argtypes = [C.c_char_p, C.c_size_t, C.c_uint64, C.c_size_t, C.c_uint32, C.c_uint32,
+                                          C.POINTER(C.c_void_p), C.POINTER(C.c_size_t), C.POINTER(C.c_void_p)]
+        L.vpt_synth_free.argtypes = [C.c_void_p]
+        _lib = L
+    return _lib
+
+
+def synth_model(kind: int = M1_BCCWJ_LIKE, seed: int = SEED_BASE + 2, scale: float = 1.0) -> bytes:
+    """Model file bytes ("VaporettoTokenizer 0.5.0\\n" + bincode) of the documented shape."""
+    L = _load()
+    out, n = C.c_void_p(), C.c_size_t()
+    st = L.vpt_synth_model(kind, seed, scale, C.byref(out), C.byref(n))
+    if st != 0:
+        raise RuntimeError("vpt_synth_model failed: %d" % st)
+    try:
+        return C.string_at(out, n.value)
+    finally:
+        L.vpt_synth_free(out)
+
+
+def synth_sentences(model_bytes: bytes, n_sentences: int, min_len: int = 64, max_len: int = 64,
+                    seed: int = SEED_BASE + 2):
+    """(utf8 uint8[bytes], byte_offsets uint64[S+1]) -- 70 % model patterns (Zipf), 30 % alphabet-A characters."""
+    L = _load()
+    text, nbytes, boff = C.c_void_p(), C.c_size_t(), C.c_void_p()
+    st = L.vpt_synth_sentences(model_bytes, len(model_bytes), seed, n_sentences, min_len, max_len,
+                               C.byref(text), C.byref(nbytes), C.byref(boff))
+    if st != 0:
+        raise RuntimeError("vpt_synth_sentences failed: %d" % st)
+    try:
+        utf8 = np.frombuffer(C.string_at(text, nbytes.value), dtype=np.uint8).copy()
+        offs = np.frombuffer(C.string_at(boff, 8 * (n_sentences + 1)), dtype=np.uint64).copy()
+    finally:
+        L.vpt_synth_free(text)
+        L.vpt_synth_free(boff)
+    return utf8, offs

@@ -1,0 +1,290 @@
+// Synthetic models and sentences (bench / test tooling; NOT on the product path).
+//
+// The real bccwj-suw+unidic and jp-0.4.7-5 model files are not available offline, so the benchmark follows
+// models of the documented shape (W = 3, n <= 3, KyTea-style dictionary) written in
+// the real Vaporetto model format, and sentences whose pattern hit rates resemble real text.  Deterministic:
+// splitmix64 streams keyed by the seed.
+#include <algorithm>
+#include <cmath>
+#include <cstdint>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <unordered_set>
+#include <vector>
+
+#include "../csrc/model.hpp"
+
+namespace {
+
+struct Rng {
+    uint64_t s;
+    explicit Rng(uint64_t seed) : s(seed) {}
+    uint64_t next() {
+        uint64_t z = (s += 0x9E3779B97F4A7C15ull);
+        z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+        z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+        return z ^ (z >> 31);
+    }
+    double uniform() { return double(next() >> 11) * (1.0 / 9007199254740992.0); }
+    uint32_t below(uint32_t n) { return uint32_t(uniform() * n); }
+    // Zipf(s = 1) rank in [0, n): continuous inverse-CDF approximation r = (n+1)^u
+    uint32_t zipf(uint32_t n) {
+        uint32_t r = uint32_t(std::exp(uniform() * std::log(double(n) + 1.0))) - 1;
+        return r < n ? r : n - 1;
+    }
+    int32_t weight(double p_nonzero) {
+        if (uniform() >= p_nonzero) return 0;
+        return int32_t(below(65535)) - 32767;
+    }
+};
+
+struct Writer {  // bincode-2 standard encoding
+    std::vector<uint8_t> b;
+    void u8(uint8_t v) { b.push_back(v); }
+    void uvar(uint64_t v) {
+        if (v < 251) b.push_back(uint8_t(v));
+        else if (v < (1u << 16)) { b.push_back(251); for (int i = 0; i < 2; ++i) b.push_back(uint8_t(v >> (8 * i))); }
+        else if (v < (1ull << 32)) { b.push_back(252); for (int i = 0; i < 4; ++i) b.push_back(uint8_t(v >> (8 * i))); }
+        else { b.push_back(253); for (int i = 0; i < 8; ++i) b.push_back(uint8_t(v >> (8 * i))); }
+    }
+    void i32(int32_t v) { uvar((uint32_t(v) << 1) ^ uint32_t(v >> 31)); }
+    void utf8(const std::vector<uint32_t>& s) {
+        std::string o;
+        for (uint32_t c : s) {
+            if (c < 0x80) o.push_back(char(c));
+            else if (c < 0x800) { o.push_back(char(0xC0 | (c >> 6))); o.push_back(char(0x80 | (c & 0x3F))); }
+            else if (c < 0x10000) { o.push_back(char(0xE0 | (c >> 12))); o.push_back(char(0x80 | ((c >> 6) & 0x3F))); o.push_back(char(0x80 | (c & 0x3F))); }
+            else { o.push_back(char(0xF0 | (c >> 18))); o.push_back(char(0x80 | ((c >> 12) & 0x3F))); o.push_back(char(0x80 | ((c >> 6) & 0x3F))); o.push_back(char(0x80 | (c & 0x3F))); }
+        }
+        uvar(o.size());
+        b.insert(b.end(), o.begin(), o.end());
+    }
+    void str(const std::string& s) { uvar(s.size()); b.insert(b.end(), s.begin(), s.end()); }
+    void bytes(const std::vector<uint8_t>& s) { uvar(s.size()); b.insert(b.end(), s.begin(), s.end()); }
+    void weights(const std::vector<int32_t>& w) { uvar(w.size()); for (int32_t x : w) i32(x); }
+};
+
+// 4000-character vocabulary, most frequent first: kana, punctuation, full-width digits/roman, kanji
+std::vector<uint32_t> make_vocab(uint32_t size) {
+    std::vector<uint32_t> v;
+    for (uint32_t c = 0x3041; c <= 0x3093; ++c) v.push_back(c);  // hiragana
+    for (uint32_t c : {0x3001u, 0x3002u, 0x300Cu, 0x300Du, 0x30FBu, 0x30FCu}) v.push_back(c);
+    for (uint32_t c = 0x30A1; c <= 0x30F6; ++c) v.push_back(c);  // katakana
+    for (uint32_t c = 0xFF10; c <= 0xFF19; ++c) v.push_back(c);
+    for (uint32_t c = 0xFF21; c <= 0xFF3A; ++c) v.push_back(c);
+    for (uint32_t c = 0xFF41; c <= 0xFF5A; ++c) v.push_back(c);
+    for (uint32_t c = 0x4E00; v.size() < size; ++c) v.push_back(c);
+    v.resize(size);
+    return v;
+}
+
+std::vector<int32_t> rand_weights(Rng& r, size_t n, double p) {
+    std::vector<int32_t> w(n);
+    for (auto& x : w) x = r.weight(p);
+    return w;
+}
+
+uint32_t dict_len(Rng& r, int kind) {
+    double u = r.uniform();
+    if (kind == 2) {  // jp-0.4.7-5-like: longer words, mean ~3.5, max 16
+        static const double cdf[16] = {0.02, 0.24, 0.50, 0.72, 0.84, 0.90, 0.935, 0.955, 0.97, 0.98, 0.986, 0.991, 0.994, 0.996, 0.998, 1.0};
+        for (uint32_t i = 0; i < 16; ++i) if (u < cdf[i]) return i + 1;
+        return 16;
+    }
+    // bccwj-suw+unidic-like: {1:3, 2:35, 3:27, 4:20, 5:8, 6:4, 7-12:3} %
+    if (u < 0.03) return 1;
+    if (u < 0.38) return 2;
+    if (u < 0.65) return 3;
+    if (u < 0.85) return 4;
+    if (u < 0.93) return 5;
+    if (u < 0.97) return 6;
+    return 7 + r.below(6);
+}
+
+}  // namespace
+
+extern "C" {
+
+void vpt_synth_free(void* p) { std::free(p); }
+
+// kind: 1 = M1 (bccwj-suw+unidic-like), 2 = M2 (jp-0.4.7-5-like), 3 = M3 (M1 + tag models).  scale multiplies
+// every count (1.0 = full size).  Returns 0 and a malloc'ed model file.
+int vpt_synth_model(int kind, uint64_t seed, double scale, uint8_t** out, size_t* out_len) {
+    if (kind < 1 || kind > 3 || !(scale > 0) || !out || !out_len) return 2;
+    Rng r(seed);
+    const uint32_t V = std::max<uint32_t>(300, uint32_t(4000 * std::min(1.0, std::sqrt(scale))));
+    const std::vector<uint32_t> vocab = make_vocab(V);
+    const size_t n_bi = size_t(400000 * scale), n_tri = size_t(600000 * scale);
+    const size_t n_dict = size_t((kind == 2 ? 1000000 : 700000) * scale);
+    const size_t n_tag = kind == 3 ? size_t(50000 * scale) : 0;
+    const double p_nz = 0.35;
+    const int W = 3;
+
+    Writer w;
+    const char magic[] = "VaporettoTokenizer 0.5.0\n";
+    w.b.insert(w.b.end(), magic, magic + sizeof(magic) - 1);
+
+    // ---- char n-grams: all unigrams, Zipf-composed bigrams and trigrams
+    std::unordered_set<uint64_t> seen;
+    std::vector<std::vector<uint32_t>> grams;
+    for (uint32_t i = 0; i < V; ++i) grams.push_back({vocab[i]});
+    auto draw = [&](size_t count, int n) {
+        size_t made = 0, tries = 0;
+        while (made < count && tries < count * 50) {
+            ++tries;
+            uint64_t key = uint64_t(n);
+            std::vector<uint32_t> g(static_cast<size_t>(n));
+            for (int k = 0; k < n; ++k) { uint32_t id = r.zipf(V); g[size_t(k)] = vocab[id]; key = key * 4099 + id; }
+            if (!seen.insert(key).second) continue;
+            grams.push_back(std::move(g));
+            ++made;
+        }
+    };
+    draw(n_bi, 2);
+    draw(n_tri, 3);
+    w.uvar(grams.size());
+    for (const auto& g : grams) {
+        w.utf8(g);
+        w.weights(rand_weights(r, size_t(2 * W - int(g.size()) + 1), p_nz));
+    }
+    // ---- all 258 type n-grams
+    std::vector<std::vector<uint8_t>> tgrams;
+    for (uint8_t a = 1; a <= 6; ++a) {
+        tgrams.push_back({a});
+        for (uint8_t b = 1; b <= 6; ++b) {
+            tgrams.push_back({a, b});
+            for (uint8_t c = 1; c <= 6; ++c) tgrams.push_back({a, b, c});
+        }
+    }
+    w.uvar(tgrams.size());
+    for (const auto& g : tgrams) {
+        w.bytes(g);
+        w.weights(rand_weights(r, size_t(2 * W - int(g.size()) + 1), 0.8));
+    }
+    // ---- dictionary
+    seen.clear();
+    std::vector<std::vector<uint32_t>> words;
+    {
+        size_t tries = 0;
+        while (words.size() < n_dict && tries < n_dict * 50) {
+            ++tries;
+            uint32_t L = dict_len(r, kind);
+            std::vector<uint32_t> g(L);
+            uint64_t key = L;
+            for (uint32_t k = 0; k < L; ++k) { uint32_t id = r.zipf(V); g[k] = vocab[id]; key = key * 0x100000001B3ull + id + 1; }
+            if (!seen.insert(key).second) continue;
+            words.push_back(std::move(g));
+        }
+    }
+    w.uvar(words.size());
+    for (const auto& g : words) {
+        w.utf8(g);
+        w.weights(rand_weights(r, g.size() + 1, 0.6));
+        w.str("");
+    }
+    w.i32(int32_t(r.below(20001)) - 10000);  // bias
+    w.u8(uint8_t(W));
+    w.u8(uint8_t(W));
+    // ---- tag models (M3): tokens are dictionary words; 2 slots (<=10 POS, <=6 pron candidates)
+    const size_t nt = std::min(n_tag, words.size());
+    w.uvar(nt);
+    for (size_t t = 0; t < nt; ++t) {
+        const auto& tok = words[t * (words.size() / std::max<size_t>(nt, 1))];
+        w.utf8(tok);
+        uint32_t k1 = 1 + r.below(10), k2 = 1 + r.below(6);
+        w.uvar(2);
+        w.uvar(k1); for (uint32_t i = 0; i < k1; ++i) w.str("P" + std::to_string(i));
+        w.uvar(k2); for (uint32_t i = 0; i < k2; ++i) w.str("R" + std::to_string(i));
+        const size_t zlen = (k1 >= 2 ? k1 : 0) + (k2 >= 2 ? k2 : 0);
+        const uint32_t nc = 8 + r.below(9);
+        w.uvar(nc);
+        for (uint32_t i = 0; i < nc; ++i) {  // left context + token + rel extra chars
+            uint32_t left = r.below(3), rel = r.below(4);
+            std::vector<uint32_t> g;
+            for (uint32_t k = 0; k < left; ++k) g.push_back(vocab[r.zipf(V)]);
+            g.insert(g.end(), tok.begin(), tok.end());
+            for (uint32_t k = 0; k < rel; ++k) g.push_back(vocab[r.zipf(V)]);
+            w.utf8(g);
+            w.uvar(1); w.u8(uint8_t(rel)); w.weights(rand_weights(r, zlen, 0.7));
+        }
+        const uint32_t ntp = 4 + r.below(5);
+        w.uvar(ntp);
+        for (uint32_t i = 0; i < ntp; ++i) {
+            uint32_t n = 1 + r.below(4), rel = r.below(4);
+            std::vector<uint8_t> g(n);
+            for (auto& x : g) x = uint8_t(1 + r.below(6));
+            w.bytes(g);
+            w.uvar(1); w.u8(uint8_t(rel)); w.weights(rand_weights(r, zlen, 0.7));
+        }
+        w.weights(rand_weights(r, zlen, 0.9));
+    }
+    *out_len = w.b.size();
+    *out = static_cast<uint8_t*>(std::malloc(w.b.size() ? w.b.size() : 1));
+    if (!*out) return 3;
+    std::memcpy(*out, w.b.data(), w.b.size());
+    return 0;
+}
+
+// Sentences: items drawn 70 % from the model's own pattern list (Zipf over code-point order, which is the
+// BTreeMap order of the reference's merger) and 30 % single characters from alphabet A, cut to a length drawn
+// log-uniformly in [min_len, max_len].  Every character is 3-byte UTF-8.
+int vpt_synth_sentences(const uint8_t* model, size_t model_len, uint64_t seed, size_t n_sent, uint32_t min_len,
+                        uint32_t max_len, uint8_t** utf8_out, size_t* nbytes_out, uint64_t** boff_out) {
+    if (!model || !utf8_out || !nbytes_out || !boff_out || min_len < 1 || max_len < min_len) return 2;
+    vpt::ModelData m;
+    try { m = vpt::parse_model(model, model_len, nullptr); } catch (const vpt::ModelError&) { return 1; }
+    std::vector<const vpt::SymString*> pats;
+    for (const auto& d : m.char_ngrams) pats.push_back(&d.ngram);
+    for (const auto& d : m.dict) pats.push_back(&d.word);
+    std::sort(pats.begin(), pats.end(), [](const vpt::SymString* a, const vpt::SymString* b) { return *a < *b; });
+    pats.erase(std::unique(pats.begin(), pats.end(), [](const vpt::SymString* a, const vpt::SymString* b) { return *a == *b; }), pats.end());
+    Rng r(seed);
+    auto alphabet_a = [&]() -> uint32_t {
+        double u = r.uniform();
+        if (u < 0.50) return 0x3041 + r.below(0x3093 - 0x3041 + 1);
+        if (u < 0.65) return 0x30A1 + r.below(0x30F6 - 0x30A1 + 1);
+        if (u < 0.90) return 0x4E00 + r.below(0x9FA5 - 0x4E00 + 1);
+        if (u < 0.94) return 0xFF10 + r.below(10);
+        if (u < 0.98) return (r.below(2) ? 0xFF21 : 0xFF41) + r.below(26);
+        static const uint32_t punct[6] = {0x3001, 0x3002, 0x300C, 0x300D, 0x30FB, 0x30FC};
+        return punct[r.below(6)];
+    };
+    std::vector<uint8_t> text;
+    text.reserve(n_sent * size_t(max_len + min_len) / 2 * 3 + 64);
+    uint64_t* boff = static_cast<uint64_t*>(std::malloc(sizeof(uint64_t) * (n_sent + 1)));
+    if (!boff) return 3;
+    std::vector<uint32_t> sent;
+    for (size_t i = 0; i < n_sent; ++i) {
+        boff[i] = text.size();
+        uint32_t L = min_len;
+        if (max_len > min_len) {
+            L = uint32_t(std::exp(std::log(double(min_len)) + r.uniform() * (std::log(double(max_len) + 1.0) - std::log(double(min_len)))));
+            L = std::min(std::max(L, min_len), max_len);
+        }
+        sent.clear();
+        while (sent.size() < L) {
+            if (!pats.empty() && r.uniform() < 0.7) {
+                const vpt::SymString& p = *pats[r.zipf(uint32_t(pats.size()))];
+                sent.insert(sent.end(), p.begin(), p.end());
+            } else sent.push_back(alphabet_a());
+        }
+        sent.resize(L);
+        for (uint32_t c : sent) {
+            if (c < 0x80) text.push_back(uint8_t(c));
+            else if (c < 0x800) { text.push_back(uint8_t(0xC0 | (c >> 6))); text.push_back(uint8_t(0x80 | (c & 0x3F))); }
+            else if (c < 0x10000) { text.push_back(uint8_t(0xE0 | (c >> 12))); text.push_back(uint8_t(0x80 | ((c >> 6) & 0x3F))); text.push_back(uint8_t(0x80 | (c & 0x3F))); }
+            else { text.push_back(uint8_t(0xF0 | (c >> 18))); text.push_back(uint8_t(0x80 | ((c >> 12) & 0x3F))); text.push_back(uint8_t(0x80 | ((c >> 6) & 0x3F))); text.push_back(uint8_t(0x80 | (c & 0x3F))); }
+        }
+    }
+    boff[n_sent] = text.size();
+    *utf8_out = static_cast<uint8_t*>(std::malloc(text.size() + 64));
+    if (!*utf8_out) { std::free(boff); return 3; }
+    std::memcpy(*utf8_out, text.data(), text.size());
+    std::memset(*utf8_out + text.size(), 0, 64);
+    *nbytes_out = text.size();
+    *boff_out = boff;
+    return 0;
+}
+
+}  // extern "C"
