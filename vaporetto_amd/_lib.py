@@ -49,10 +49,23 @@ SIGNATURES = {
 _lib = None
 
 
+def _init_torch_hip_first():
+    """PyTorch wheels bundle their own libamdhip64/libhsa-runtime64 (different soname from /opt/rocm's, which
+    this library links).  Two HIP runtimes can share a process only if torch's initialises first, so when torch
+    is importable and sees a GPU, let it.  Torch is never used for compute here."""
+    try:
+        import torch
+        if torch.cuda.is_available():
+            torch.cuda.init()
+    except ImportError:
+        pass
+
+
 def load():
     """Loads the shared library; raises if it is missing (no fallback)."""
     global _lib
     if _lib is None:
+        _init_torch_hip_first()
         if not os.path.exists(LIB_PATH):
             raise OSError("%s is missing: build it with `python -m vaporetto_amd.build` "
                           "(there is no CPU or Python fallback)" % LIB_PATH)
