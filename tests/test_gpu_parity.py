@@ -233,3 +233,20 @@ def test_concurrent_host_threads_share_a_predictor():
     [t.start() for t in th]
     [t.join() for t in th]
     assert not errors, errors[0]
+
+
+# ------------------------------------------------------------------------------------------------ both kernels
+@pytest.mark.parametrize("force_generic", [False, True])
+def test_fast_and_general_kernels_agree_with_oracle(force_generic, monkeypatch):
+    """W = 3 models run on the specialised kernel; VPT_FORCE_GENERIC routes the same model through the general
+    kernel.  Both must match the oracle on the same ragged batch (long words, many tiny sentences, long ones)."""
+    if force_generic:
+        monkeypatch.setenv("VPT_FORCE_GENERIC", "1")
+    m = randmodel.rand_model(4242, alphabet="kana", wc=3, wt=3, max_word=14, n_char=200, n_dict=300, n_type=60)
+    pred, orc = make_predictor(m)
+    rng = np.random.RandomState(11)
+    texts = randmodel.rand_sentences(5, m, 1500, alphabet="kana", max_len=90)
+    texts += randmodel.rand_sentences(6, m, 40, alphabet="kana", min_len=400, max_len=1600)
+    texts += randmodel.rand_sentences(7, m, 800, alphabet="kana", max_len=2)
+    order = rng.permutation(len(texts))
+    check_batch(pred, orc, [texts[i] for i in order])

@@ -5,6 +5,7 @@
 #include <hip/hip_runtime_api.h>
 
 #include <algorithm>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <new>
@@ -60,8 +61,8 @@ vpt::PatternTableView make_view(const vpt::HostPatternTable& h, const DeviceTabl
     v.present = h.present ? 1u : 0u;
     if (!h.present) return v;
     v.short_tab = d.short_tab; v.uni = d.uni; v.edges = d.edges; v.wdata = d.wdata;
-    v.short_shift = 64 - h.short_bits; v.short_mask = (1u << h.short_bits) - 1;
-    v.edge_shift = 64 - h.edge_bits; v.edge_mask = (1u << h.edge_bits) - 1;
+    v.short_shift = 32 - h.short_bits; v.short_mask = (1u << h.short_bits) - 1;
+    v.edge_shift = 32 - h.edge_bits; v.edge_mask = (1u << h.edge_bits) - 1;
     v.stride_dw = h.stride_dw; v.uni_dw = h.uni_dw; v.uni_n = h.uni_n; v.ext_slot = h.ext_slot;
     v.window = h.window;
     for (int i = 0; i < 3; ++i) { v.lo[i] = h.lo[i]; v.len[i] = h.len[i]; }
@@ -316,8 +317,17 @@ vpt_status vpt_predict_batch_device(const vpt_predictor* p, vpt_batch* b, const 
     if (n_sentences >= 0xFFFFFFFFull) return fail(VPT_INVALID_ARGUMENT, "InvalidArgumentError: n_sentences: at most 2^32-2 per call");
     hipStream_t stream = static_cast<hipStream_t>(hip_stream);
     VPT_HIP(hipSetDevice(p->device));
+    vpt::ScoreParams P{};
+    P.ct = p->ct; P.tt = p->tt; P.type_table = p->d_type_table;
+    P.type_window = p->type_window; P.type_kind = p->type_kind; P.bias = p->bias; P.pad = p->pad;
+    // Tiles are cut every `tile_flat` flat positions (chars + separators) and end with the sentence that crosses
+    // the cut, so a tile holds < tile_flat + longest sentence: pick tile_flat to fill the kernel's LDS capacity.
+    const bool fast = vpt::fast_path_supported(P) && !std::getenv("VPT_FORCE_GENERIC");
+    const uint64_t cap = fast ? vpt::kFastCap : vpt::kCap;
+    uint64_t tile_flat = cap / 2;
+    if (max_sentence_bytes + 2 * uint64_t(p->pad) + cap / 2 <= cap) tile_flat = cap - 2 * uint64_t(p->pad) - max_sentence_bytes;
     const uint64_t total_flat = total_boundaries + uint64_t(n_sentences) * uint64_t(1 + p->pad);
-    const uint64_t n_tiles64 = (total_flat + vpt::kTileFlat - 1) / vpt::kTileFlat;
+    const uint64_t n_tiles64 = (total_flat + tile_flat - 1) / tile_flat;
     if (n_tiles64 >= 0x7FFFFFFFull) return fail(VPT_INVALID_ARGUMENT, "InvalidArgumentError: batch too large for one call");
     const uint32_t n_tiles = uint32_t(n_tiles64);
     if (size_t(n_tiles) + 1 > b->tile_cap || !b->d_tile_first) {
@@ -329,7 +339,7 @@ vpt_status vpt_predict_batch_device(const vpt_predictor* p, vpt_batch* b, const 
         VPT_HIP(hipMalloc(reinterpret_cast<void**>(&b->d_slow_list), cap * sizeof(uint32_t) + 64));
     }
     // long-sentence scratch (only when a sentence might not fit the LDS tile)
-    const bool need_slow = max_sentence_bytes + 2 * uint64_t(p->pad) > uint64_t(vpt::kCap - vpt::kTileFlat);
+    const bool need_slow = max_sentence_bytes + 2 * uint64_t(p->pad) + tile_flat > cap;
     uint32_t slow_blocks = 0, scratch_cap = 0;
     uint64_t slab = 0;
     if (need_slow) {
@@ -345,18 +355,17 @@ vpt_status vpt_predict_batch_device(const vpt_predictor* p, vpt_batch* b, const 
             b->scratch_bytes = need;
         }
     }
-    vpt::ScoreParams P{};
-    P.ct = p->ct; P.tt = p->tt; P.type_table = p->d_type_table;
-    P.type_window = p->type_window; P.type_kind = p->type_kind; P.bias = p->bias; P.pad = p->pad;
     P.text = d_utf8; P.boff = d_byte_offsets; P.ooff = d_out_offsets; P.tile_first = b->d_tile_first;
     P.scores = d_scores; P.labels = d_labels; P.status = b->d_ctrl; P.slow_list = b->d_slow_list; P.slow_count = b->d_ctrl + 1;
     P.scratch = b->d_scratch; P.scratch_stride = slab; P.scratch_cap = scratch_cap;
+    if (const char* dbg = std::getenv("VPT_DEBUG_ABLATE")) { P.debug = uint32_t(std::atoi(dbg)); P.ct.debug = P.debug; P.tt.debug = P.debug; }
 
     VPT_HIP(hipMemsetAsync(b->d_ctrl, 0, 8, stream));
-    VPT_HIP(vpt::launch_assign_tiles(d_out_offsets, n_sentences, p->pad, n_tiles, b->d_tile_first, stream));
+    VPT_HIP(vpt::launch_assign_tiles(d_out_offsets, n_sentences, p->pad, uint32_t(tile_flat), n_tiles, b->d_tile_first, stream));
     const size_t slot = b->ev_calls % kTimingRing;
     if (b->timing) VPT_HIP(hipEventRecord(b->ev[2 * slot], stream));
-    VPT_HIP(vpt::launch_score_tiles(P, p->chunks, n_tiles, stream));
+    if (fast) VPT_HIP(vpt::launch_score_tiles_fast(P, n_tiles, stream));
+    else VPT_HIP(vpt::launch_score_tiles(P, p->chunks, n_tiles, stream));
     if (b->timing) { VPT_HIP(hipEventRecord(b->ev[2 * slot + 1], stream)); ++b->ev_calls; }
     if (need_slow) VPT_HIP(vpt::launch_score_slow(P, p->chunks, slow_blocks, stream));
     b->last_tiles = n_tiles; b->last_stream = stream; b->pending = true;

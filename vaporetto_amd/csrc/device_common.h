@@ -1,0 +1,40 @@
+// Device helpers shared by the general (kernels.hip) and specialised (kernels_fast.hip) tile kernels.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+
+namespace vpt {
+
+// CharacterType::get_type (sentence.rs:50-67): 1 Digit, 2 Roman, 3 Hiragana, 4 Katakana, 5 Kanji, 6 Other
+__device__ __forceinline__ uint32_t char_type(uint32_t c) {
+    if ((c - 0x30u) <= 9u || (c - 0xFF10u) <= 9u) return 1;
+    if ((c - 0x41u) <= 25u || (c - 0x61u) <= 25u || (c - 0xFF21u) <= 25u || (c - 0xFF41u) <= 25u) return 2;
+    if ((c - 0x3040u) <= (0x3096u - 0x3040u)) return 3;
+    if ((c - 0x30A0u) <= (0x30FAu - 0x30A0u) || (c - 0x30FCu) <= 3u || (c - 0xFF66u) <= (0xFF9Fu - 0xFF66u))
+        return 4;
+    if ((c - 0x3400u) <= (0x4DBFu - 0x3400u) || (c - 0x4E00u) <= (0x9FFFu - 0x4E00u) ||
+        (c - 0xF900u) <= (0xFAFFu - 0xF900u) || (c - 0x20000u) <= (0x2A6DFu - 0x20000u) ||
+        (c - 0x2A700u) <= (0x2B73Fu - 0x2A700u) || (c - 0x2B740u) <= (0x2B81Fu - 0x2B740u) ||
+        (c - 0x2B820u) <= (0x2CEAFu - 0x2B820u) || (c - 0x2F800u) <= (0x2FA1Fu - 0x2F800u))
+        return 5;
+    return 6;
+}
+
+// 4-bit mask of the bytes of x that are NOT UTF-8 continuation bytes (10xxxxxx)
+__device__ __forceinline__ uint32_t lead_nibble(uint32_t x) {
+    uint32_t cont = x & ~(x << 1) & 0x80808080u;  // bit7 set and bit6 clear
+    uint32_t lead = (~cont & 0x80808080u) >> 7;   // 0/1 at bits 0, 8, 16, 24
+    return ((lead * 0x00204081u) >> 21) & 0xFu;
+}
+
+// scalar value of the UTF-8 sequence whose four bytes (lead first) are packed little-endian in b4
+__device__ __forceinline__ uint32_t utf8_scalar(uint32_t b4) {
+    const uint32_t b0 = b4 & 0xFF, b1 = (b4 >> 8) & 0x3F, b2 = (b4 >> 16) & 0x3F, b3 = (b4 >> 24) & 0x3F;
+    if (b0 < 0x80) return b0;
+    if (b0 < 0xE0) return ((b0 & 0x1F) << 6) | b1;
+    if (b0 < 0xF0) return ((b0 & 0x0F) << 12) | (b1 << 6) | b2;
+    return ((b0 & 0x07) << 18) | (b1 << 12) | (b2 << 6) | b3;
+}
+
+}  // namespace vpt

@@ -14,6 +14,7 @@
 // (L2 / Infinity Cache / HBM), which is what bounds the kernel.
 #include <hip/hip_runtime.h>
 
+#include "device_common.h"
 #include "kernels.hpp"
 
 namespace vpt {
@@ -26,28 +27,6 @@ constexpr int kWaves = kThreads / 64;
 // device error word bits (read back by vpt_batch_sync)
 // ------------------------------------------------------------------------------------------------------------
 __device__ __forceinline__ void raise(uint32_t* status, uint32_t bit) { atomicOr(status, bit); }
-
-// CharacterType::get_type (sentence.rs:50-67)
-__device__ __forceinline__ uint32_t char_type(uint32_t c) {
-    if ((c - 0x30u) <= 9u || (c - 0xFF10u) <= 9u) return 1;                                             // Digit
-    if ((c - 0x41u) <= 25u || (c - 0x61u) <= 25u || (c - 0xFF21u) <= 25u || (c - 0xFF41u) <= 25u) return 2;  // Roman
-    if ((c - 0x3040u) <= (0x3096u - 0x3040u)) return 3;                                                 // Hiragana
-    if ((c - 0x30A0u) <= (0x30FAu - 0x30A0u) || (c - 0x30FCu) <= 3u || (c - 0xFF66u) <= (0xFF9Fu - 0xFF66u))
-        return 4;                                                                                       // Katakana
-    if ((c - 0x3400u) <= (0x4DBFu - 0x3400u) || (c - 0x4E00u) <= (0x9FFFu - 0x4E00u) ||
-        (c - 0xF900u) <= (0xFAFFu - 0xF900u) || (c - 0x20000u) <= (0x2A6DFu - 0x20000u) ||
-        (c - 0x2A700u) <= (0x2B73Fu - 0x2A700u) || (c - 0x2B740u) <= (0x2B81Fu - 0x2B740u) ||
-        (c - 0x2B820u) <= (0x2CEAFu - 0x2B820u) || (c - 0x2F800u) <= (0x2FA1Fu - 0x2F800u))
-        return 5;                                                                                       // Kanji
-    return 6;                                                                                           // Other
-}
-
-// bit7 of every byte that is NOT a UTF-8 continuation byte (10xxxxxx), gathered into a 4-bit nibble
-__device__ __forceinline__ uint32_t lead_nibble(uint32_t x) {
-    uint32_t cont = x & ~(x << 1) & 0x80808080u;       // bit7 set and bit6 clear
-    uint32_t lead = (~cont & 0x80808080u) >> 7;        // 0/1 at bits 0, 8, 16, 24
-    return ((lead * 0x00204081u) >> 21) & 0xFu;
-}
 
 // tile memory: LDS on the fast path, a global scratch slab for sentences that do not fit in LDS
 template <bool kLds>
@@ -83,7 +62,7 @@ __device__ __forceinline__ bool probe_short(const PatternTableView& T, uint64_t 
             uint4 v = p[q];
             e[4 * q] = v.x; e[4 * q + 1] = v.y; e[4 * q + 2] = v.z; e[4 * q + 3] = v.w;
         }
-        if (e[0] == klo && e[1] == khi) return true;
+        if (e[0] == klo && (e[1] & ~kDisplacedBit) == khi) return true;
         if ((e[0] | e[1]) == 0) return false;
         idx = (idx + 1) & T.short_mask;
     }
@@ -93,8 +72,10 @@ template <bool kLds, int kChunks, typename SymT>
 __device__ __forceinline__ void score_start(const PatternTableView& T, const SymT* sym, int32_t* score, int s) {
     const uint32_t c1 = sym[s];
     if (c1 == 0) return;
-    const uint32_t c2 = sym[s + 1];
-    const uint32_t c3 = c2 ? uint32_t(sym[s + 2]) : 0u;
+    uint32_t c2 = sym[s + 1];
+    uint32_t c3 = c2 ? uint32_t(sym[s + 2]) : 0u;
+    if (T.debug & 2) c2 = 0;        // ablation: unigram rows only
+    else if (T.debug & 4) c3 = 0;   // ablation: no trigram probes
     uint32_t e[4 * kChunks];
 
     // level 1
@@ -140,11 +121,11 @@ __device__ __forceinline__ void score_start(const PatternTableView& T, const Sym
         uint4 ed;
         for (;;) {
             ed = reinterpret_cast<const uint4*>(T.edges)[idx];
-            if (ed.x == uint32_t(key) && ed.y == uint32_t(key >> 32)) break;
+            if (ed.x == uint32_t(key) && (ed.y & ~kDisplacedBit) == uint32_t(key >> 32)) break;
             if ((ed.x | ed.y) == 0) { ed.z = 0; ed.w = kNoRow; break; }
             idx = (idx + 1) & T.edge_mask;
         }
-        node = ed.z;
+        node = ed.z & ~kHasKidsBit;
         ++n;
         if (ed.w != kNoRow) {
             const int lo = row_lo(n, T.window), len = row_len(n, T.window);
@@ -251,12 +232,7 @@ __device__ __forceinline__ void process_tile(const ScoreParams& P, const TileMem
             const uint32_t q = k >> 2, r = (k & 3) * 8;
             const uint64_t two = (uint64_t(w[q + 1]) << 32) | w[q];
             const uint32_t b4 = uint32_t(two >> r);
-            const uint32_t b0 = b4 & 0xFF, b1 = (b4 >> 8) & 0x3F, b2 = (b4 >> 16) & 0x3F, b3 = (b4 >> 24) & 0x3F;
-            uint32_t cp;
-            if (b0 < 0x80) cp = b0;
-            else if (b0 < 0xE0) cp = ((b0 & 0x1F) << 6) | b1;
-            else if (b0 < 0xF0) cp = ((b0 & 0x0F) << 12) | (b1 << 6) | b2;
-            else cp = ((b0 & 0x07) << 18) | (b1 << 12) | (b2 << 6) | b3;
+            const uint32_t cp = utf8_scalar(b4);
             if (cp == 0) raise(P.status, kErrNulChar);           // sentence.rs:174-179
             const uint32_t flat = uint32_t(pad) + ci + uint32_t(pad) * si;
             if (flat < flat_len) {
@@ -270,7 +246,7 @@ __device__ __forceinline__ void process_tile(const ScoreParams& P, const TileMem
     __syncthreads();
 
     // ---- B. patterns
-    if (P.ct.present) {
+    if (P.ct.present && !(P.debug & 1)) {
         for (uint32_t s = tid; s < flat_len; s += kThreads) score_start<kLds, kChunks, uint32_t>(P.ct, M.sym, M.score, int(s));
     }
     if (P.type_kind == kTypePatternTable) {
@@ -281,6 +257,7 @@ __device__ __forceinline__ void process_tile(const ScoreParams& P, const TileMem
     // ---- C. boundaries: bias + patterns + type window, sign threshold (predictor.rs:520-541)
     const int wt = P.type_window;
     for (uint32_t p = uint32_t(pad) + tid; p + 1 < flat_len; p += kThreads) {
+        if (P.debug & 8) break;     // ablation: no output phase
         if (M.sym[p] == 0 || M.sym[p + 1] == 0) continue;
         int32_t y = P.bias + score_get<kLds>(M.score + p);
         if (P.type_kind == kTypeWindowTable) {
@@ -301,12 +278,12 @@ __device__ __forceinline__ void process_tile(const ScoreParams& P, const TileMem
 // kernels
 // ------------------------------------------------------------------------------------------------------------
 
-// tile_first[t] = first sentence whose flat start F(i) = ooff[i] + i*(1+pad) is >= t*kTileFlat  (t = 0..n_tiles)
-__global__ void assign_tiles_kernel(const uint64_t* __restrict__ ooff, uint64_t n_sent, int pad, uint32_t n_tiles,
-                                    uint32_t* __restrict__ tile_first) {
+// tile_first[t] = first sentence whose flat start F(i) = ooff[i] + i*(1+pad) is >= t*tile_flat  (t = 0..n_tiles)
+__global__ void assign_tiles_kernel(const uint64_t* __restrict__ ooff, uint64_t n_sent, int pad, uint32_t tile_flat,
+                                    uint32_t n_tiles, uint32_t* __restrict__ tile_first) {
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t > n_tiles) return;
-    const uint64_t target = uint64_t(t) * kTileFlat;
+    const uint64_t target = uint64_t(t) * tile_flat;
     uint64_t lo = 0, hi = n_sent;  // first i in [0, n_sent] with F(i) >= target; F(n_sent) is the total
     while (lo < hi) {
         const uint64_t mid = (lo + hi) >> 1;
@@ -373,10 +350,10 @@ size_t score_tiles_lds_bytes() {
     return size_t(kCap + kMargin) * (4 + 4 + 2 + 1) + size_t(kBitmapWords + 8) * 4;
 }
 
-hipError_t launch_assign_tiles(const uint64_t* ooff, uint64_t n_sent, int pad, uint32_t n_tiles, uint32_t* tile_first,
-                               hipStream_t stream) {
+hipError_t launch_assign_tiles(const uint64_t* ooff, uint64_t n_sent, int pad, uint32_t tile_flat, uint32_t n_tiles,
+                               uint32_t* tile_first, hipStream_t stream) {
     const uint32_t threads = 256, blocks = (n_tiles + 1 + threads - 1) / threads;
-    hipLaunchKernelGGL(assign_tiles_kernel, dim3(blocks), dim3(threads), 0, stream, ooff, n_sent, pad, n_tiles, tile_first);
+    hipLaunchKernelGGL(assign_tiles_kernel, dim3(blocks), dim3(threads), 0, stream, ooff, n_sent, pad, tile_flat, n_tiles, tile_first);
     return hipGetLastError();
 }
 

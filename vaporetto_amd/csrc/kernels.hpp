@@ -15,6 +15,7 @@ constexpr int kCap = 2048;                       // flat positions (chars + sepa
 constexpr int kTileFlat = 1024;                  // flat positions a tile is cut at (a tile ends with the sentence
                                                  // that crosses the cut, so it needs kCap - kTileFlat of slack)
 constexpr int kMargin = 8;                       // zeroed slack past the tile for the s+1, s+2 look-ahead
+constexpr int kFastCap = 1536;                   // flat positions of a tile of the specialised kernel (20 KB of LDS)
 constexpr int kBitmapWords = 4 * kCap / 32 + 4;  // one bit per text byte of a tile (UTF-8: <= 4 bytes per char)
 
 // device status word (OR of bits)
@@ -43,11 +44,15 @@ struct ScoreParams {
     unsigned char* scratch;     // slabs for score_slow_kernel
     uint64_t scratch_stride;    // bytes per workgroup slab
     uint32_t scratch_cap;       // flat positions per slab
+    uint32_t debug;             // profiling ablation bits (VPT_DEBUG_ABLATE env, 0 in production)
 };
 
 size_t score_tiles_lds_bytes();
-hipError_t launch_assign_tiles(const uint64_t* ooff, uint64_t n_sent, int pad, uint32_t n_tiles, uint32_t* tile_first,
-                               hipStream_t stream);
+hipError_t launch_assign_tiles(const uint64_t* ooff, uint64_t n_sent, int pad, uint32_t tile_flat, uint32_t n_tiles,
+                               uint32_t* tile_first, hipStream_t stream);
+// specialised kernel (kernels_fast.hip): char window 3, type window table or none
+bool fast_path_supported(const ScoreParams& P);
+hipError_t launch_score_tiles_fast(const ScoreParams& P, uint32_t n_tiles, hipStream_t stream);
 hipError_t launch_score_tiles(const ScoreParams& P, int chunks, uint32_t n_tiles, hipStream_t stream);
 hipError_t launch_score_slow(const ScoreParams& P, int chunks, uint32_t n_blocks, hipStream_t stream);
 

@@ -11,7 +11,10 @@
 //   level n = 1..3   strings of <= 3 symbols, key = s1 | s2 << 21 | s3 << 42 (absent symbols = 0; a symbol is
 //                    never 0: sentence.rs:174-179 bans U+0000 and type ids are 1..6).
 //                    Entry = [key_lo, key_hi, slot_0 .. slot_{SC-1}] as dwords, stride padded to 16 bytes,
-//                    open addressing + linear probing, key 0 = empty.
+//                    open addressing + linear probing, key 0 = empty.  Keys use 63 bits; bit 63 (kDisplacedBit of
+//                    key_hi) on a slot's occupant says "some key whose home is this slot lives further down the
+//                    probe sequence".  A lookup that finds a different key at the home slot without that mark is
+//                    a definite miss after ONE load (most lookups of absent strings end this way).
 //                    slot_j of a level-n entry = total weight this string adds to boundary (start + lo[n] + j):
 //                      lo[n]  = min(n-1-W, -1)      hi[n] = max(W-1, n-1)      len[n] = hi[n]-lo[n]+1
 //                    (n-gram w[k] lands on boundary start+n-1-W+k, char_scorer/boundary_scorer.rs:63 with
@@ -22,7 +25,8 @@
 //   unigram rows     symbols < uni_n index `uni` directly (row = the slots of the level-1 entry, no key).
 //   long trie        strings of > 3 symbols: edge table keyed (parent_node << 32 | symbol) ->
 //                    {child node, woff}; the row of a node at depth n has len[n] (same formula) entries at
-//                    wdata[woff ..]; woff = kNoRow when the node is only a prefix.
+//                    wdata[woff ..]; woff = kNoRow when the node is only a prefix.  Same kDisplacedBit rule on
+//                    key_hi (parent ids stay below 2^31); kHasKidsBit on the child id = the child has edges.
 #pragma once
 #include <cstdint>
 #if defined(__HIPCC__)
@@ -35,7 +39,9 @@ constexpr int kMaxWindow = 8;                 // windows above this are rejected
 constexpr uint32_t kUniDirectChars = 0x10000; // BMP code points index the unigram rows directly
 constexpr uint32_t kUniDirectTypes = 256;     // type ids are bytes
 constexpr uint32_t kNoRow = 0xFFFFFFFFu;
-constexpr uint64_t kHashMul = 0x9E3779B97F4A7C15ull;
+constexpr uint32_t kDisplacedBit = 0x80000000u;  // in key_hi of a hash slot
+constexpr uint32_t kHasKidsBit = 0x80000000u;    // in the child id of an edge
+constexpr uint32_t kHashMulLo = 0x9E3779B1u, kHashMulHi = 0x85EBCA77u;
 
 #if defined(__HIPCC__)
 #define VPT_HD __host__ __device__ __forceinline__
@@ -47,7 +53,10 @@ VPT_HD uint64_t short_key(uint32_t s1, uint32_t s2, uint32_t s3) {
     return uint64_t(s1) | (uint64_t(s2) << 21) | (uint64_t(s3) << 42);
 }
 VPT_HD uint64_t edge_key(uint32_t parent, uint32_t sym) { return (uint64_t(parent) << 32) | sym; }
-VPT_HD uint32_t hash_slot(uint64_t key, uint32_t shift) { return uint32_t((key * kHashMul) >> shift); }
+// two-word multiplicative hash; `shift` = 32 - log2(capacity)
+VPT_HD uint32_t hash_slot(uint64_t key, uint32_t shift) {
+    return (uint32_t(key) * kHashMulLo + uint32_t(key >> 32) * kHashMulHi) >> shift;
+}
 
 // geometry of the row of a pattern of n symbols under window W (see the header comment)
 VPT_HD int row_lo(int n, int W) { return (n - 1 - W) < -1 ? (n - 1 - W) : -1; }
@@ -69,6 +78,7 @@ struct PatternTableView {
     int32_t window;
     int32_t lo[3], len[3];
     uint32_t has_long;       // any pattern longer than 3 symbols
+    uint32_t debug;          // profiling ablation bits (0 in production)
     uint32_t present;        // 0 = this scorer is None (char_scorer.rs:98-100 / type_scorer.rs:109-111)
 };
 

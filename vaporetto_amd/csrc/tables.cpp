@@ -93,6 +93,7 @@ HostPatternTable build_table(std::vector<Pat>& pats, int W, uint32_t uni_n) {
     std::unordered_map<uint64_t, uint32_t> root3;   // short_key(3-prefix) -> node id
     std::unordered_map<uint64_t, uint32_t> edge;    // edge_key(parent, sym) -> child
     std::vector<uint32_t> node_woff(1, kNoRow);     // node 0 is unused (0 = "no continuation")
+    std::vector<uint32_t> node_kids(1, 0);          // number of outgoing edges per node
     for (const Pat& p : pats) {
         const size_t n = p.s.size();
         t.max_pattern = std::max<uint32_t>(t.max_pattern, uint32_t(n));
@@ -104,6 +105,7 @@ HostPatternTable build_table(std::vector<Pat>& pats, int W, uint32_t uni_n) {
         if (it == root3.end()) {
             node = uint32_t(node_woff.size());
             node_woff.push_back(kNoRow);
+            node_kids.push_back(0);
             root3.emplace(k3, node);
         } else node = it->second;
         for (size_t i = 3; i < n; ++i) {
@@ -112,7 +114,9 @@ HostPatternTable build_table(std::vector<Pat>& pats, int W, uint32_t uni_n) {
             if (e == edge.end()) {
                 uint32_t child = uint32_t(node_woff.size());
                 node_woff.push_back(kNoRow);
+                node_kids.push_back(0);
                 edge.emplace(ek, child);
+                ++node_kids[node];
                 node = child;
             } else node = e->second;
         }
@@ -154,15 +158,19 @@ HostPatternTable build_table(std::vector<Pat>& pats, int W, uint32_t uni_n) {
     const uint32_t smask = (1u << t.short_bits) - 1;
     t.short_tab.assign((size_t(1) << t.short_bits) * t.stride_dw, 0);
     for (const ShortEnt& e : ents) {
-        uint32_t idx = hash_slot(e.key, 64 - t.short_bits), probes = 1;
+        const uint32_t home = hash_slot(e.key, 32 - t.short_bits);
+        uint32_t idx = home, probes = 1;
         while (t.short_tab[size_t(idx) * t.stride_dw] | t.short_tab[size_t(idx) * t.stride_dw + 1]) {
             idx = (idx + 1) & smask;
             ++probes;
         }
         t.max_probe_short = std::max(t.max_probe_short, probes);
+        // a key displaced from its home slot marks the home slot's occupant (kDisplacedBit of key_hi): a
+        // lookup that finds another key there WITHOUT the mark knows the key is absent after one load
+        if (idx != home) { t.short_tab[size_t(home) * t.stride_dw + 1] |= kDisplacedBit; ++t.n_displaced_short; }
         uint32_t* d = &t.short_tab[size_t(idx) * t.stride_dw];
         d[0] = uint32_t(e.key);
-        d[1] = uint32_t(e.key >> 32);
+        d[1] |= uint32_t(e.key >> 32);
         if (e.row)
             for (size_t k = 0; k < e.row->size(); ++k) d[2 + k] = uint32_t((*e.row)[k]);
         if (e.ext) d[2 + t.ext_slot] = e.ext;
@@ -173,16 +181,18 @@ HostPatternTable build_table(std::vector<Pat>& pats, int W, uint32_t uni_n) {
     const uint32_t emask = (1u << t.edge_bits) - 1;
     t.edges.assign((size_t(1) << t.edge_bits) * 4, 0);
     for (const auto& e : edge) {
-        uint32_t idx = hash_slot(e.first, 64 - t.edge_bits), probes = 1;
+        const uint32_t home = hash_slot(e.first, 32 - t.edge_bits);
+        uint32_t idx = home, probes = 1;
         while (t.edges[size_t(idx) * 4] | t.edges[size_t(idx) * 4 + 1]) {
             idx = (idx + 1) & emask;
             ++probes;
         }
         t.max_probe_edge = std::max(t.max_probe_edge, probes);
+        if (idx != home) t.edges[size_t(home) * 4 + 1] |= kDisplacedBit;
         uint32_t* d = &t.edges[size_t(idx) * 4];
         d[0] = uint32_t(e.first);
-        d[1] = uint32_t(e.first >> 32);
-        d[2] = e.second;
+        d[1] |= uint32_t(e.first >> 32);
+        d[2] = e.second | (node_kids[e.second] ? kHasKidsBit : 0u);  // node ids stay below 2^31
         d[3] = node_woff[e.second];
     }
     return t;

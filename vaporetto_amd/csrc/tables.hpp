@@ -21,6 +21,7 @@ struct HostPatternTable {
     std::vector<int32_t> wdata;
     // statistics
     uint32_t n_short = 0, n_long_nodes = 0, max_pattern = 0, max_probe_short = 0, max_probe_edge = 0;
+    uint32_t n_displaced_short = 0;
 
     uint64_t bytes() const {
         return 4ull * (short_tab.size() + uni.size() + edges.size() + wdata.size());
