@@ -61,8 +61,8 @@ vpt::PatternTableView make_view(const vpt::HostPatternTable& h, const DeviceTabl
     v.present = h.present ? 1u : 0u;
     if (!h.present) return v;
     v.short_tab = d.short_tab; v.uni = d.uni; v.edges = d.edges; v.wdata = d.wdata;
-    v.short_shift = 32 - h.short_bits; v.short_mask = (1u << h.short_bits) - 1;
-    v.edge_shift = 32 - h.edge_bits; v.edge_mask = (1u << h.edge_bits) - 1;
+    v.short_shift = 32 - (h.short_bits - 1); v.short_mask = (1u << (h.short_bits - 1)) - 1;
+    v.edge_shift = 32 - (h.edge_bits - 2); v.edge_mask = (1u << (h.edge_bits - 2)) - 1;
     v.stride_dw = h.stride_dw; v.uni_dw = h.uni_dw; v.uni_n = h.uni_n; v.ext_slot = h.ext_slot;
     v.window = h.window;
     for (int i = 0; i < 3; ++i) { v.lo[i] = h.lo[i]; v.len[i] = h.len[i]; }
@@ -113,6 +113,7 @@ struct vpt_predictor {
     int32_t bias = 0; int pad = 1; int type_kind = 0; int type_window = 0; int chunks = 2;
     DeviceTable dc, dt;
     int32_t* d_type_table = nullptr;
+    uint8_t* d_ctype = nullptr;
     vpt::PatternTableView ct{}, tt{};
     mutable std::mutex pool_mu;
     mutable std::vector<vpt_batch*> pool;  // idle workspaces for the host-buffer entry points
@@ -208,6 +209,11 @@ vpt_status vpt_predictor_create(const uint8_t* model_bytes, size_t len, int pred
     up(c.chars, p->dc);
     up(c.types, p->dt);
     if (e == hipSuccess && c.type_kind == vpt::kTypeWindowTable) e = upload(c.type_table, &p->d_type_table);
+    if (e == hipSuccess) {
+        std::vector<uint8_t> ctype(65536);
+        for (uint32_t cp = 0; cp < 65536; ++cp) ctype[cp] = vpt::char_type_host(cp);
+        e = upload(ctype, &p->d_ctype);
+    }
     if (e != hipSuccess) {
         std::string msg = std::string("HIP error while uploading the tables: ") + hipGetErrorString(e);
         vpt_predictor_destroy(p);
@@ -229,6 +235,7 @@ void vpt_predictor_destroy(vpt_predictor* p) {
     for (vpt_batch* b : p->pool) batch_release(b);
     p->dc.release(); p->dt.release();
     (void)hipFree(p->d_type_table);
+    (void)hipFree(p->d_ctype);
     delete p;
 }
 
@@ -318,7 +325,7 @@ vpt_status vpt_predict_batch_device(const vpt_predictor* p, vpt_batch* b, const 
     hipStream_t stream = static_cast<hipStream_t>(hip_stream);
     VPT_HIP(hipSetDevice(p->device));
     vpt::ScoreParams P{};
-    P.ct = p->ct; P.tt = p->tt; P.type_table = p->d_type_table;
+    P.ct = p->ct; P.tt = p->tt; P.type_table = p->d_type_table; P.ctype = p->d_ctype;
     P.type_window = p->type_window; P.type_kind = p->type_kind; P.bias = p->bias; P.pad = p->pad;
     // Tiles are cut every `tile_flat` flat positions (chars + separators) and end with the sentence that crosses
     // the cut, so a tile holds < tile_flat + longest sentence: pick tile_flat to fill the kernel's LDS capacity.

@@ -53,18 +53,26 @@ __device__ __forceinline__ int32_t score_get(const int32_t* p) {
 // ------------------------------------------------------------------------------------------------------------
 template <int kChunks>
 __device__ __forceinline__ bool probe_short(const PatternTableView& T, uint64_t key, uint32_t (&e)[4 * kChunks]) {
-    uint32_t idx = hash_slot(key, T.short_shift);
+    uint32_t b = hash_slot(key, T.short_shift);
     const uint32_t klo = uint32_t(key), khi = uint32_t(key >> 32);
-    for (;;) {
-        const uint4* p = reinterpret_cast<const uint4*>(T.short_tab + size_t(idx) * T.stride_dw);
+    bool home = true;
+    for (;;) {  // buckets of two entries (layout.h)
+        bool free_slot = false, displaced = false;
 #pragma unroll
-        for (int q = 0; q < kChunks; ++q) {
-            uint4 v = p[q];
-            e[4 * q] = v.x; e[4 * q + 1] = v.y; e[4 * q + 2] = v.z; e[4 * q + 3] = v.w;
+        for (uint32_t j = 0; j < kShortBucket; ++j) {
+            const uint4* p = reinterpret_cast<const uint4*>(T.short_tab + (size_t(b) * kShortBucket + j) * T.stride_dw);
+#pragma unroll
+            for (int q = 0; q < kChunks; ++q) {
+                uint4 v = p[q];
+                e[4 * q] = v.x; e[4 * q + 1] = v.y; e[4 * q + 2] = v.z; e[4 * q + 3] = v.w;
+            }
+            if (e[0] == klo && (e[1] & ~kDisplacedBit) == khi) return true;
+            if ((e[0] | e[1]) == 0) free_slot = true;
+            if (j == 0 && (e[1] & kDisplacedBit)) displaced = true;
         }
-        if (e[0] == klo && (e[1] & ~kDisplacedBit) == khi) return true;
-        if ((e[0] | e[1]) == 0) return false;
-        idx = (idx + 1) & T.short_mask;
+        if (free_slot || (home && !displaced)) return false;
+        home = false;
+        b = (b + 1) & T.short_mask;
     }
 }
 
@@ -117,13 +125,20 @@ __device__ __forceinline__ void score_start(const PatternTableView& T, const Sym
         const uint32_t c = sym[s + n];
         if (c == 0) break;  // sentence end (separator) -- also bounds the walk
         const uint64_t key = edge_key(node, c);
-        uint32_t idx = hash_slot(key, T.edge_shift);
-        uint4 ed;
-        for (;;) {
-            ed = reinterpret_cast<const uint4*>(T.edges)[idx];
-            if (ed.x == uint32_t(key) && (ed.y & ~kDisplacedBit) == uint32_t(key >> 32)) break;
-            if ((ed.x | ed.y) == 0) { ed.z = 0; ed.w = kNoRow; break; }
-            idx = (idx + 1) & T.edge_mask;
+        uint32_t b = hash_slot(key, T.edge_shift);
+        uint4 ed = make_uint4(0, 0, 0, kNoRow);
+        bool home = true;
+        for (bool done = false; !done;) {  // buckets of four edges (layout.h)
+            bool free_slot = false, displaced = false;
+            for (uint32_t j = 0; j < kEdgeBucket && !done; ++j) {
+                const uint4 c4 = reinterpret_cast<const uint4*>(T.edges)[size_t(b) * kEdgeBucket + j];
+                if (c4.x == uint32_t(key) && (c4.y & ~kDisplacedBit) == uint32_t(key >> 32)) { ed = c4; done = true; }
+                if ((c4.x | c4.y) == 0) free_slot = true;
+                if (j == 0 && (c4.y & kDisplacedBit)) displaced = true;
+            }
+            if (free_slot || (home && !displaced)) done = true;
+            home = false;
+            b = (b + 1) & T.edge_mask;
         }
         node = ed.z & ~kHasKidsBit;
         ++n;

@@ -28,6 +28,7 @@ struct ScoreParams {
     PatternTableView ct;        // characters: n-grams + dictionary words
     PatternTableView tt;        // character types, when type_kind == kTypePatternTable
     const int32_t* type_table;  // 8^(2W) window scores, when type_kind == kTypeWindowTable
+    const uint8_t* ctype;       // CharacterType of every BMP scalar value (65536 bytes)
     int32_t type_window;
     int32_t type_kind;
     int32_t bias;

@@ -11,10 +11,13 @@
 //   level n = 1..3   strings of <= 3 symbols, key = s1 | s2 << 21 | s3 << 42 (absent symbols = 0; a symbol is
 //                    never 0: sentence.rs:174-179 bans U+0000 and type ids are 1..6).
 //                    Entry = [key_lo, key_hi, slot_0 .. slot_{SC-1}] as dwords, stride padded to 16 bytes,
-//                    open addressing + linear probing, key 0 = empty.  Keys use 63 bits; bit 63 (kDisplacedBit of
-//                    key_hi) on a slot's occupant says "some key whose home is this slot lives further down the
-//                    probe sequence".  A lookup that finds a different key at the home slot without that mark is
-//                    a definite miss after ONE load (most lookups of absent strings end this way).
+//                    key 0 = empty.  Entries sit in BUCKETS of kShortBucket = 2 (64 bytes at the common 32-byte
+//                    entry): hash -> home bucket, a lookup reads the whole bucket; a key is displaced to the
+//                    next bucket with a free slot only when its home bucket is full.  Keys use 63 bits; bit 63
+//                    (kDisplacedBit of key_hi) of a bucket's FIRST entry says "some key whose home is this
+//                    bucket lives further on".  A lookup that finds neither its key nor that mark in the home
+//                    bucket is a definite miss after one 64-byte read (most absent strings end this way); a
+//                    continued lookup stops at the first bucket that has a free slot.
 //                    slot_j of a level-n entry = total weight this string adds to boundary (start + lo[n] + j):
 //                      lo[n]  = min(n-1-W, -1)      hi[n] = max(W-1, n-1)      len[n] = hi[n]-lo[n]+1
 //                    (n-gram w[k] lands on boundary start+n-1-W+k, char_scorer/boundary_scorer.rs:63 with
@@ -25,8 +28,9 @@
 //   unigram rows     symbols < uni_n index `uni` directly (row = the slots of the level-1 entry, no key).
 //   long trie        strings of > 3 symbols: edge table keyed (parent_node << 32 | symbol) ->
 //                    {child node, woff}; the row of a node at depth n has len[n] (same formula) entries at
-//                    wdata[woff ..]; woff = kNoRow when the node is only a prefix.  Same kDisplacedBit rule on
-//                    key_hi (parent ids stay below 2^31); kHasKidsBit on the child id = the child has edges.
+//                    wdata[woff ..]; woff = kNoRow when the node is only a prefix.  Buckets of kEdgeBucket = 4
+//                    (64 bytes), same kDisplacedBit rule (parent ids stay below 2^31); kHasKidsBit on the child
+//                    id = the child has edges of its own.
 #pragma once
 #include <cstdint>
 #if defined(__HIPCC__)
@@ -41,6 +45,8 @@ constexpr uint32_t kUniDirectTypes = 256;     // type ids are bytes
 constexpr uint32_t kNoRow = 0xFFFFFFFFu;
 constexpr uint32_t kDisplacedBit = 0x80000000u;  // in key_hi of a hash slot
 constexpr uint32_t kHasKidsBit = 0x80000000u;    // in the child id of an edge
+constexpr uint32_t kShortBucket = 2;             // entries per bucket of the short table
+constexpr uint32_t kEdgeBucket = 4;              // edges per bucket of the trie edge table
 constexpr uint32_t kHashMulLo = 0x9E3779B1u, kHashMulHi = 0x85EBCA77u;
 
 #if defined(__HIPCC__)
@@ -69,7 +75,7 @@ struct PatternTableView {
     const uint32_t* uni;
     const uint32_t* edges;   // 4 dwords per edge slot: key_lo, key_hi, child, woff
     const int32_t* wdata;
-    uint32_t short_shift, short_mask;
+    uint32_t short_shift, short_mask;   // hash_slot shift and mask in BUCKETS
     uint32_t edge_shift, edge_mask;
     uint32_t stride_dw;      // dwords per short entry (2 + slots, rounded up to a multiple of 4)
     uint32_t uni_dw;         // dwords per unigram row (rounded up to a multiple of 4)

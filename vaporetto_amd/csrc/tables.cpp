@@ -154,21 +154,28 @@ HostPatternTable build_table(std::vector<Pat>& pats, int W, uint32_t uni_n) {
         else ents[it->second].ext = r.second;
     }
     t.n_short += uint32_t(ents.size());
+    // buckets of kShortBucket (2) entries = 64 bytes when the entry is 32 bytes: a lookup reads its whole home
+    // bucket at once; only keys that overflow a bucket are displaced to the following buckets
     t.short_bits = bits_for(ents.size());
-    const uint32_t smask = (1u << t.short_bits) - 1;
+    const uint32_t sb_bits = t.short_bits - 1, sb_mask = (1u << sb_bits) - 1;
     t.short_tab.assign((size_t(1) << t.short_bits) * t.stride_dw, 0);
+    auto slot_used = [&](size_t slot) { return (t.short_tab[slot * t.stride_dw] | t.short_tab[slot * t.stride_dw + 1]) != 0; };
     for (const ShortEnt& e : ents) {
-        const uint32_t home = hash_slot(e.key, 32 - t.short_bits);
-        uint32_t idx = home, probes = 1;
-        while (t.short_tab[size_t(idx) * t.stride_dw] | t.short_tab[size_t(idx) * t.stride_dw + 1]) {
-            idx = (idx + 1) & smask;
+        const uint32_t home = hash_slot(e.key, 32 - sb_bits);
+        uint32_t b = home, probes = 1;
+        size_t slot;
+        for (;;) {
+            slot = size_t(b) * kShortBucket;
+            if (!slot_used(slot)) break;
+            if (!slot_used(slot + 1)) { ++slot; break; }
+            b = (b + 1) & sb_mask;
             ++probes;
         }
         t.max_probe_short = std::max(t.max_probe_short, probes);
-        // a key displaced from its home slot marks the home slot's occupant (kDisplacedBit of key_hi): a
-        // lookup that finds another key there WITHOUT the mark knows the key is absent after one load
-        if (idx != home) { t.short_tab[size_t(home) * t.stride_dw + 1] |= kDisplacedBit; ++t.n_displaced_short; }
-        uint32_t* d = &t.short_tab[size_t(idx) * t.stride_dw];
+        // a key that overflowed its home bucket marks that bucket (kDisplacedBit of the first entry's key_hi):
+        // a lookup that finds neither the key nor the mark in the home bucket knows the key is absent
+        if (b != home) { t.short_tab[size_t(home) * kShortBucket * t.stride_dw + 1] |= kDisplacedBit; ++t.n_displaced_short; }
+        uint32_t* d = &t.short_tab[slot * t.stride_dw];
         d[0] = uint32_t(e.key);
         d[1] |= uint32_t(e.key >> 32);
         if (e.row)
@@ -176,20 +183,24 @@ HostPatternTable build_table(std::vector<Pat>& pats, int W, uint32_t uni_n) {
         if (e.ext) d[2 + t.ext_slot] = e.ext;
     }
 
-    // ---- edge table
-    t.edge_bits = bits_for(edge.size());
-    const uint32_t emask = (1u << t.edge_bits) - 1;
+    // ---- edge table: buckets of kEdgeBucket (4) edges = 64 bytes
+    t.edge_bits = std::max<uint32_t>(bits_for(edge.size()), 4);
+    const uint32_t eb_bits = t.edge_bits - 2, eb_mask = (1u << eb_bits) - 1;
     t.edges.assign((size_t(1) << t.edge_bits) * 4, 0);
     for (const auto& e : edge) {
-        const uint32_t home = hash_slot(e.first, 32 - t.edge_bits);
-        uint32_t idx = home, probes = 1;
-        while (t.edges[size_t(idx) * 4] | t.edges[size_t(idx) * 4 + 1]) {
-            idx = (idx + 1) & emask;
-            ++probes;
+        const uint32_t home = hash_slot(e.first, 32 - eb_bits);
+        uint32_t b = home, probes = 1;
+        size_t slot = 0;
+        for (bool placed = false; !placed;) {
+            for (uint32_t k = 0; k < kEdgeBucket; ++k) {
+                slot = size_t(b) * kEdgeBucket + k;
+                if ((t.edges[slot * 4] | t.edges[slot * 4 + 1]) == 0) { placed = true; break; }
+            }
+            if (!placed) { b = (b + 1) & eb_mask; ++probes; }
         }
         t.max_probe_edge = std::max(t.max_probe_edge, probes);
-        if (idx != home) t.edges[size_t(home) * 4 + 1] |= kDisplacedBit;
-        uint32_t* d = &t.edges[size_t(idx) * 4];
+        if (b != home) t.edges[size_t(home) * kEdgeBucket * 4 + 1] |= kDisplacedBit;
+        uint32_t* d = &t.edges[slot * 4];
         d[0] = uint32_t(e.first);
         d[1] |= uint32_t(e.first >> 32);
         d[2] = e.second | (node_kids[e.second] ? kHasKidsBit : 0u);  // node ids stay below 2^31
@@ -253,6 +264,18 @@ std::vector<int32_t> build_type_window_table(const std::vector<NgramRecord>& ngr
 }
 
 }  // namespace
+
+uint8_t char_type_host(uint32_t c) {
+    auto in = [c](uint32_t lo, uint32_t hi) { return c >= lo && c <= hi; };
+    if (in(0x30, 0x39) || in(0xFF10, 0xFF19)) return 1;
+    if (in(0x41, 0x5A) || in(0x61, 0x7A) || in(0xFF21, 0xFF3A) || in(0xFF41, 0xFF5A)) return 2;
+    if (in(0x3040, 0x3096)) return 3;
+    if (in(0x30A0, 0x30FA) || in(0x30FC, 0x30FF) || in(0xFF66, 0xFF9F)) return 4;
+    if (in(0x3400, 0x4DBF) || in(0x4E00, 0x9FFF) || in(0xF900, 0xFAFF) || in(0x20000, 0x2A6DF) || in(0x2A700, 0x2B73F) ||
+        in(0x2B740, 0x2B81F) || in(0x2B820, 0x2CEAF) || in(0x2F800, 0x2FA1F))
+        return 5;
+    return 6;
+}
 
 CompiledModel compile_model(const ModelData& m, bool predict_tags) {
     CompiledModel c;

@@ -43,6 +43,9 @@ struct CompiledModel {
     bool predict_tags = false;
 };
 
+// CharacterType::get_type (sentence.rs:50-67) on the host; used to build the device's BMP class table.
+uint8_t char_type_host(uint32_t c);
+
 // Throws ModelError with the reference's message where it defines one.
 CompiledModel compile_model(const ModelData& m, bool predict_tags);
 
