@@ -53,6 +53,7 @@ def main():
     ap.add_argument("--model-kind", type=int, default=1, help="1 bccwj-suw+unidic-like, 2 jp-0.4.7-5-like")
     ap.add_argument("--model-scale", type=float, default=1.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--phases", action="store_true", help="diagnostics: per-phase shader cycles of the scoring kernel (slows it)")
     args = ap.parse_args()
 
     import torch
@@ -99,6 +100,8 @@ def main():
     d_ooff = torch.from_numpy(ooff.astype(np.int64)).to(dev)
     d_scores = torch.empty(nb + 1, dtype=torch.int32, device=dev)
     d_labels = torch.empty(nb + 1, dtype=torch.uint8, device=dev)
+    if args.phases:
+        os.environ["VPT_PROFILE_PHASES"] = "1"
     batch = api.DeviceBatch(predictor, timing=True)
     stream = torch.cuda.current_stream().cuda_stream
 
@@ -122,6 +125,7 @@ def main():
     elapsed = time.perf_counter() - t0
     batch.sync()
     kernel_ms, n_tiles = batch.kernel_ms()
+    phases = batch.phase_cycles() if args.phases else None
     el = torch.tensor([elapsed], dtype=torch.float64, device=dev)
     tot = torch.tensor([float(nb)], dtype=torch.float64, device=dev)
     if world > 1:
@@ -139,13 +143,19 @@ def main():
                        % (model_name, S, args.min_len, args.max_len),
                        "model": model_name, "sentences_per_gpu": S, "boundaries_per_gpu": nb, "text_bytes_per_gpu": nbytes,
                        "char_ngrams": info["n_char_ngrams"], "dict_words": info["n_dict_words"],
-                       "table_bytes": info["device_table_bytes"], "tiles": n_tiles, "parallelism": "sentence shards x%d" % world},
+                       "table_bytes": info["device_table_bytes"], "hot_table_bytes": info["hot_table_bytes"],
+                       "packed_tables": bool(info["packed"]), "tiles": n_tiles, "parallelism": "sentence shards x%d" % world},
         }
+        if phases is not None:
+            tot = float(sum(phases[:5])) or 1.0
+            out["phase_share"] = dict(zip(["scan", "decode", "patterns", "barrier", "output"], [round(p / tot, 4) for p in phases[:5]]))
+            out["phase_cycles_per_tile"] = [round(p / max(n_tiles, 1) / (args.steps + args.warmup), 1) for p in phases[:5]]
         # ---- roofline of the dominant kernel (score_tiles_kernel): algorithmic bytes per launch / its duration
         a_stream = nbytes + 5 * nb + 16 * S   # text + i32 score + u8 label per boundary + two u64 offsets per sentence
         a_type = 4 * nb                        # one type-window table word per boundary (the reference's cache form)
         a_char = None
         cpu = None
+        kernel_name = "score_tiles_fast_kernel" if info["packed"] and info["type_kind"] in (0, 1) else "score_tiles_kernel"
         if not args.no_cpu_baseline:
             from oracle import cbind
             orc = cbind.OraclePredictor(model_bytes)
@@ -170,12 +180,12 @@ def main():
             achieved = a / (kernel_ms * 1e-3) / 1e9
             out["roofline"] = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                               "kernel": "score_tiles_kernel", "kernel_ms": kernel_ms,
+                               "kernel": kernel_name, "kernel_ms": kernel_ms,
                                "algorithmic_bytes_per_launch": a, "bytes_per_boundary": a / nb,
                                "a_stream": a_stream, "a_char": a_char, "a_type": a_type}
         else:
             out["roofline"] = {"bound": "hbm", "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None,
-                               "traffic": None, "kernel": "score_tiles_kernel", "kernel_ms": kernel_ms}
+                               "traffic": None, "kernel": kernel_name, "kernel_ms": kernel_ms}
         out["cpu_baseline"] = cpu
         print(json.dumps(out))
     if world > 1:

@@ -120,6 +120,12 @@ vpt_status vpt_batch_sync(vpt_batch *b);
 vpt_status vpt_batch_set_timing(vpt_batch *b, int enabled);
 vpt_status vpt_batch_kernel_ms(vpt_batch *b, float *score_kernel_ms, uint32_t *n_tiles);
 
+/* Diagnostics: when the environment variable VPT_PROFILE_PHASES is set at vpt_batch_create, the specialised
+ * kernel accumulates, per workgroup (wave 0), the shader cycles spent in 0 text scan, 1 per-char decode,
+ * 2 pattern lookups, 3 barrier wait, 4 boundary output.  Reads the sums (after a device sync) and resets them;
+ * all zeros when profiling is off. */
+vpt_status vpt_batch_phase_cycles(vpt_batch *b, uint64_t cycles[8]);
+
 /* ---------------------------------------------------------------------------------------------------------
  * Introspection (host-only; used by tests and the bench's roofline accounting)
  */
@@ -131,7 +137,10 @@ typedef struct vpt_model_info {
     uint32_t n_short_entries;      /* distinct strings of <= 3 chars (plus 3-char prefixes of longer ones) */
     uint32_t n_long_nodes;         /* trie nodes for strings of > 3 chars */
     uint32_t type_kind;            /* 0 none, 1 window table (cache variant), 2 pattern tables */
-    uint64_t device_table_bytes;   /* bytes the tables occupy in HBM */
+    uint64_t device_table_bytes;   /* bytes all tables occupy in HBM */
+    uint64_t hot_table_bytes;      /* bytes of the tables the scoring kernel chosen for this model reads */
+    uint32_t packed;               /* 1: the specialised kernel's 16-byte-entry tables are in use */
+    uint32_t n_displaced;          /* hash-table keys that do not sit in their home slot */
 } vpt_model_info;
 
 /* Parses + validates + compiles the tables on the host only (no device).  Same errors as create. */

@@ -250,3 +250,52 @@ def test_fast_and_general_kernels_agree_with_oracle(force_generic, monkeypatch):
     texts += randmodel.rand_sentences(7, m, 800, alphabet="kana", max_len=2)
     order = rng.permutation(len(texts))
     check_batch(pred, orc, [texts[i] for i in order])
+
+
+# ------------------------------------------------------------------------------------------------ packed tables
+def test_packed_path_is_used_and_handles_wide_rows():
+    """W = 3 BMP models run on the 16-byte packed tables; rows with values outside i16 take the kPkWide escape."""
+    m = ModelData(bias=-7, char_window_size=3, type_window_size=3)
+    m.char_ngram_model.append(NgramData("あ", [0, 0, 40000, -5, 1, 2]))
+    m.char_ngram_model.append(NgramData("あい", [1, 2, 30000, 4, 5]))
+    m.dict_model.append(WordWeightRecord("あい", [7, 30000, -9], ""))
+    m.char_ngram_model.append(NgramData("いうえ", [32767, 32767, 3, 4]))
+    m.dict_model.append(WordWeightRecord("いうえ", [1, 32767, 5, 32767], ""))
+    m.dict_model.append(WordWeightRecord("いうえお", [1, 2, 3, 4, 5], ""))
+    m.dict_model.append(WordWeightRecord("あいうえおか", [100000, -100000, 3, 4, 5, 6, 2000000000], ""))
+    m.dict_model.append(WordWeightRecord("あいうえおかきくけこ", [1, 2, 3, 4, 5, 6, 7, 8, 9, 10, -70000], ""))
+    m.type_ngram_model.append(NgramData(bytes([3, 3]), [5, -6, 7, 8, 9]))
+    pred, orc = make_predictor(m)
+    assert pred.info()["packed"] == 1
+    texts = ["あいうえおかきくけこ", "ああいいうえお", "いうえ", "あ", "んあいうえおかん", "えおかきあいうえおかきくけこあい"] * 50
+    check_batch(pred, orc, texts)
+
+
+def test_packed_text_with_non_bmp_and_noncharacters():
+    m = randmodel.rand_model(5, alphabet="kana", wc=3, wt=2, n_char=200, n_dict=200, max_word=8)
+    pred, orc = make_predictor(m)
+    assert pred.info()["packed"] == 1
+    pats = [d.ngram for d in m.char_ngram_model] + [r.word for r in m.dict_model]
+    texts = []
+    for i, p in enumerate(pats):
+        for filler in ("𠮷", "￿", "🤌", "￾"):
+            texts.append(p[: len(p) // 2] + filler + p + filler + pats[(i + 1) % len(pats)])
+    check_batch(pred, orc, texts)
+
+
+def test_non_bmp_pattern_models_use_the_general_tables():
+    m = randmodel.rand_model(21, alphabet="mixed", wc=3, wt=3, n_char=120, n_dict=120, max_word=6)
+    pred, orc = make_predictor(m)
+    assert pred.info()["packed"] == 0   # the "mixed" alphabet has non-BMP pattern chars
+    check_batch(pred, orc, randmodel.rand_sentences(3, m, 600, alphabet="mixed", max_len=70))
+
+
+@pytest.mark.parametrize("seed", range(4))
+def test_dense_packed_tables_with_displaced_keys(seed):
+    alpha = [chr(c) for c in range(0x3041, 0x3051)]
+    m = randmodel.rand_model(70 + seed, alphabet=alpha, wc=3, wt=3, n_char=3000, n_dict=6000, max_word=12)
+    pred, orc = make_predictor(m)
+    info = pred.info()
+    assert info["packed"] == 1 and info["n_displaced"] > 0
+    texts = randmodel.rand_sentences(seed, m, 3000, alphabet=alpha, max_len=120)
+    check_batch(pred, orc, texts)

@@ -1,0 +1,149 @@
+"""CPU check of the PACKED tables (vaporetto_amd/csrc/tables.cpp, layout.h): a small g++-built walker
+(tests/native/tablecheck.cpp, test infrastructure) follows the specialised kernel's lookup protocol over the tables
+the host-side compiler emits; its char-pattern scores must equal the oracle's for models without type n-grams."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from oracle import cbind
+from tests import randmodel
+from vaporetto_amd.modelfmt import ModelData, NgramData, WordWeightRecord, encode_model
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "..", "vaporetto_amd", "csrc")
+LIB = os.path.join(HERE, "native", "libvpt_tablecheck.so")
+SRCS = [os.path.join(HERE, "native", "tablecheck.cpp"), os.path.join(CSRC, "tables.cpp"), os.path.join(CSRC, "model.cpp")]
+DEPS = SRCS + [os.path.join(CSRC, h) for h in ("layout.h", "tables.hpp", "model.hpp")]
+
+
+@pytest.fixture(scope="module")
+def tc():
+    if not os.path.exists(LIB) or any(os.path.getmtime(s) > os.path.getmtime(LIB) for s in DEPS):
+        subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-o", LIB] + SRCS)
+    L = C.CDLL(LIB)
+    L.tc_create.argtypes = [C.c_char_p, C.c_size_t, C.POINTER(C.c_void_p)]
+    L.tc_destroy.argtypes = [C.c_void_p]
+    L.tc_packed_present.argtypes = [C.c_void_p]
+    L.tc_stats.argtypes = [C.c_void_p, C.POINTER(C.c_uint32 * 8)]
+    L.tc_score_chars.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.POINTER(C.c_uint64 * 3)]
+    return L
+
+
+class Walker:
+    def __init__(self, L, raw):
+        self.L = L
+        self.h = C.c_void_p()
+        assert L.tc_create(raw, len(raw), C.byref(self.h)) == 0
+
+    def __del__(self):
+        self.L.tc_destroy(self.h)
+
+    @property
+    def packed(self):
+        return bool(self.L.tc_packed_present(self.h))
+
+    def stats(self):
+        a = (C.c_uint32 * 8)()
+        self.L.tc_stats(self.h, C.byref(a))
+        return dict(zip(["n_bi", "n_tri", "n_edge", "disp_bi", "disp_tri", "disp_edge", "max_probe", "n_wide"], list(a)))
+
+    def score(self, text, probes=None):
+        cps = np.frombuffer(text.encode("utf-32-le"), dtype=np.uint32).copy()
+        y = np.zeros(max(len(cps) - 1, 1), dtype=np.int32)
+        pr = (C.c_uint64 * 3)()
+        assert self.L.tc_score_chars(self.h, cps.ctypes.data, len(cps), y.ctypes.data, C.byref(pr)) == 0
+        if probes is not None:
+            for i in range(3):
+                probes[i] += pr[i]
+        return y[:len(cps) - 1].tolist()
+
+
+def strip_types(m: ModelData) -> ModelData:
+    m.type_ngram_model = []
+    return m
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_packed_walk_matches_oracle_random_models(tc, seed):
+    alphabet = ["kana", "tiny", [chr(c) for c in range(0x3041, 0x3049)] + list("漢字AZ09")][seed % 3]
+    m = strip_types(randmodel.rand_model(900 + seed, alphabet=alphabet, wc=3, wt=3, n_char=400, n_dict=500, max_word=11))
+    raw = encode_model(m)
+    w = Walker(tc, raw)
+    assert w.packed
+    orc = cbind.OraclePredictor(raw)
+    probes = [0, 0, 0]
+    for t in randmodel.rand_sentences(seed, m, 300, alphabet=alphabet, max_len=60):
+        assert w.score(t, probes) == orc.predict(t)[0], t
+    st = w.stats()
+    assert st["n_bi"] > 0 and st["n_tri"] > 0 and st["n_edge"] > 0
+
+
+def test_packed_walk_dense_tables_exercise_displacement(tc):
+    """Tiny alphabets fill the tables' probe sequences: displaced keys, continued lookups, deep tries."""
+    alpha = [chr(c) for c in range(0x3041, 0x3051)]
+    m = strip_types(randmodel.rand_model(77, alphabet=alpha, wc=3, wt=3, n_char=3000, n_dict=6000, max_word=9))
+    raw = encode_model(m)
+    w = Walker(tc, raw)
+    assert w.packed
+    st = w.stats()
+    assert st["disp_bi"] + st["disp_tri"] + st["disp_edge"] > 0
+    orc = cbind.OraclePredictor(raw)
+    probes = [0, 0, 0]
+    for t in randmodel.rand_sentences(5, m, 400, alphabet=alpha, max_len=80):
+        assert w.score(t, probes) == orc.predict(t)[0], t
+    assert sum(probes) > 0   # the continuation protocol was actually used
+
+
+def test_packed_not_eligible_models_fall_back(tc):
+    base = dict(bias=3, char_window_size=3, type_window_size=3)
+    # a non-BMP symbol in a pattern
+    m = ModelData(**base)
+    m.char_ngram_model.append(NgramData("𠮷", [1, 2, 3, 4, 5, 6]))
+    assert not Walker(tc, encode_model(m)).packed
+    # U+FFFF in a pattern (the packed tables use 0xFFFF as the matches-nothing symbol)
+    m = ModelData(**base)
+    m.dict_model.append(WordWeightRecord("a￿", [1, 2, 3], ""))
+    assert not Walker(tc, encode_model(m)).packed
+    # another char window
+    m = ModelData(bias=3, char_window_size=2, type_window_size=3)
+    m.char_ngram_model.append(NgramData("あ", [1, 2, 3, 4]))
+    assert not Walker(tc, encode_model(m)).packed
+    # and the plain eligible case
+    m = ModelData(**base)
+    m.char_ngram_model.append(NgramData("あ", [1, 2, 3, 4, 5, 6]))
+    assert Walker(tc, encode_model(m)).packed
+
+
+def test_packed_wide_rows(tc):
+    """Values outside i16 (a large weight, or an n-gram and a word with the same string summing past 16 bits)
+    keep the model on the packed path through the kPkWide escape."""
+    m = ModelData(bias=-7, char_window_size=3, type_window_size=3)
+    m.char_ngram_model.append(NgramData("あ", [0, 0, 40000, -5, 1, 2]))
+    m.char_ngram_model.append(NgramData("あい", [1, 2, 30000, 4, 5]))
+    m.dict_model.append(WordWeightRecord("あい", [7, 30000, -9], ""))
+    m.char_ngram_model.append(NgramData("いうえ", [32767, 32767, 3, 4]))
+    m.dict_model.append(WordWeightRecord("いうえ", [1, 32767, 5, 32767], ""))
+    m.dict_model.append(WordWeightRecord("いうえお", [1, 2, 3, 4, 5], ""))
+    m.dict_model.append(WordWeightRecord("あいうえおか", [100000, -100000, 3, 4, 5, 6, 2000000000], ""))
+    m.dict_model.append(WordWeightRecord("あいうえおかきくけこ", [1, 2, 3, 4, 5, 6, 7, 8, 9, 10, -70000], ""))
+    raw = encode_model(m)
+    w = Walker(tc, raw)
+    assert w.packed and w.stats()["n_wide"] == 5
+    orc = cbind.OraclePredictor(raw)
+    for t in ["あいうえおかきくけこ", "ああいいうえお", "いうえ", "あ", "んあいうえおかん", "えおかきあいうえおかきくけこあい"]:
+        assert w.score(t) == orc.predict(t)[0], t
+
+
+def test_packed_text_with_non_bmp_and_ffff_chars(tc):
+    m = strip_types(randmodel.rand_model(5, alphabet="kana", wc=3, wt=3, n_char=200, n_dict=200, max_word=8))
+    raw = encode_model(m)
+    w = Walker(tc, raw)
+    orc = cbind.OraclePredictor(raw)
+    pats = [d.ngram for d in m.char_ngram_model] + [r.word for r in m.dict_model]
+    for i, p in enumerate(pats[:60]):
+        for filler in ("𠮷", "￿", "🤌"):
+            t = p[: len(p) // 2] + filler + p + filler + pats[(i + 1) % len(pats)]
+            assert w.score(t) == orc.predict(t)[0], t

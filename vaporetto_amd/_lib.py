@@ -19,7 +19,8 @@ class ModelInfo(C.Structure):
         ("n_char_ngrams", C.c_uint32), ("n_type_ngrams", C.c_uint32), ("n_dict_words", C.c_uint32),
         ("n_tag_models", C.c_uint32), ("bias", C.c_int32), ("char_window", C.c_uint32), ("type_window", C.c_uint32),
         ("max_pattern_chars", C.c_uint32), ("n_short_entries", C.c_uint32), ("n_long_nodes", C.c_uint32),
-        ("type_kind", C.c_uint32), ("device_table_bytes", C.c_uint64),
+        ("type_kind", C.c_uint32), ("device_table_bytes", C.c_uint64), ("hot_table_bytes", C.c_uint64),
+        ("packed", C.c_uint32), ("n_displaced", C.c_uint32),
     ]
 
     def as_dict(self):
@@ -42,6 +43,7 @@ SIGNATURES = {
     "vpt_batch_sync": (C.c_int, [_P]),
     "vpt_batch_set_timing": (C.c_int, [_P, C.c_int]),
     "vpt_batch_kernel_ms": (C.c_int, [_P, C.POINTER(C.c_float), C.POINTER(C.c_uint32)]),
+    "vpt_batch_phase_cycles": (C.c_int, [_P, C.POINTER(C.c_uint64 * 8)]),
     "vpt_model_inspect": (C.c_int, [_P, C.c_size_t, C.c_int, C.POINTER(ModelInfo)]),
     "vpt_predictor_info": (C.c_int, [_P, C.POINTER(ModelInfo)]),
 }

@@ -302,6 +302,15 @@ class DeviceBatch:
         return ms.value, nt.value
 
 
+    def phase_cycles(self):
+        """Per-phase shader cycles of the specialised kernel (needs VPT_PROFILE_PHASES set before creation)."""
+        arr = (C.c_uint64 * 8)()
+        st = _lib.load().vpt_batch_phase_cycles(self._h, C.byref(arr))
+        if st != _lib.VPT_OK:
+            _raise(st)
+        return list(arr)
+
+
 def pack_texts(raws: Sequence[bytes]) -> Tuple[np.ndarray, np.ndarray]:
     boff = np.zeros(len(raws) + 1, dtype=np.uint64)
     boff[1:] = np.cumsum([len(r) for r in raws], dtype=np.uint64)

@@ -32,6 +32,14 @@ vpt_status fail(vpt_status st, const std::string& msg) {
             return fail(VPT_RUNTIME_ERROR, std::string("HIP error: ") + hipGetErrorString(e_) + " at " #expr); \
     } while (0)
 
+struct DevicePacked {
+    uint32_t *uni = nullptr, *bi = nullptr, *tri = nullptr, *edge = nullptr, *wrows = nullptr;
+    void release() {
+        (void)hipFree(uni); (void)hipFree(bi); (void)hipFree(tri); (void)hipFree(edge); (void)hipFree(wrows);
+        uni = bi = tri = edge = wrows = nullptr;
+    }
+};
+
 struct DeviceTable {
     uint32_t *short_tab = nullptr, *uni = nullptr, *edges = nullptr;
     int32_t* wdata = nullptr;
@@ -70,6 +78,17 @@ vpt::PatternTableView make_view(const vpt::HostPatternTable& h, const DeviceTabl
     return v;
 }
 
+vpt::PackedView make_packed_view(const vpt::HostPackedTable& h, const DevicePacked& d) {
+    vpt::PackedView v{};
+    v.present = h.present ? 1u : 0u;
+    if (!h.present) return v;
+    v.uni = d.uni; v.bi = d.bi; v.tri = d.tri; v.edge = d.edge; v.wrows = d.wrows;
+    v.bi_shift = 32 - h.bi_bits; v.bi_mask = (1u << h.bi_bits) - 1;
+    v.tri_shift = 32 - h.tri_bits; v.tri_mask = (1u << h.tri_bits) - 1;
+    v.edge_shift = 32 - h.edge_bits; v.edge_mask = (1u << h.edge_bits) - 1;
+    return v;
+}
+
 void fill_info(const vpt::CompiledModel& c, vpt_model_info* info) {
     std::memset(info, 0, sizeof(*info));
     info->n_char_ngrams = c.n_char_ngrams; info->n_type_ngrams = c.n_type_ngrams;
@@ -80,8 +99,12 @@ void fill_info(const vpt::CompiledModel& c, vpt_model_info* info) {
     info->max_pattern_chars = c.chars.max_pattern;
     info->n_short_entries = c.chars.n_short; info->n_long_nodes = c.chars.n_long_nodes;
     info->type_kind = uint32_t(c.type_kind);
+    info->packed = c.packed.present ? 1u : 0u;
+    info->n_displaced = c.packed.present ? c.packed.n_disp_bi + c.packed.n_disp_tri + c.packed.n_disp_edge : c.chars.n_displaced_short;
+    // the specialised kernel reads only the packed tables; the general ones stay resident for oversized sentences
     info->device_table_bytes = (c.chars.present ? c.chars.bytes() : 0) + (c.types.present ? c.types.bytes() : 0) +
-                               4ull * c.type_table.size();
+                               4ull * c.type_table.size() + (c.packed.present ? c.packed.bytes() : 0);
+    info->hot_table_bytes = c.packed.present ? c.packed.bytes() + 4ull * c.type_table.size() : info->device_table_bytes;
 }
 
 }  // namespace
@@ -93,6 +116,7 @@ struct vpt_batch {
     uint32_t* d_tile_first = nullptr; size_t tile_cap = 0;
     uint32_t* d_slow_list = nullptr;
     uint32_t* d_ctrl = nullptr;        // [0] status bits, [1] slow tile count
+    uint64_t* d_prof = nullptr;        // 8 per-phase cycle counters (only with VPT_PROFILE_PHASES set)
     unsigned char* d_scratch = nullptr; size_t scratch_bytes = 0;
     // timing
     bool timing = false;
@@ -112,6 +136,8 @@ struct vpt_predictor {
     vpt_model_info info{};
     int32_t bias = 0; int pad = 1; int type_kind = 0; int type_window = 0; int chunks = 2;
     DeviceTable dc, dt;
+    DevicePacked dp;
+    vpt::PackedView pk{};
     int32_t* d_type_table = nullptr;
     uint8_t* d_ctype = nullptr;
     vpt::PatternTableView ct{}, tt{};
@@ -138,6 +164,7 @@ void batch_release(vpt_batch* b) {
     if (!b) return;
     (void)hipSetDevice(b->device);
     (void)hipFree(b->d_tile_first); (void)hipFree(b->d_slow_list); (void)hipFree(b->d_ctrl); (void)hipFree(b->d_scratch);
+    (void)hipFree(b->d_prof);
     (void)hipFree(b->d_text); (void)hipFree(b->d_boff); (void)hipFree(b->d_ooff); (void)hipFree(b->d_scores); (void)hipFree(b->d_labels);
     for (hipEvent_t e : b->ev) (void)hipEventDestroy(e);
     if (b->own_stream) (void)hipStreamDestroy(b->own_stream);
@@ -208,6 +235,13 @@ vpt_status vpt_predictor_create(const uint8_t* model_bytes, size_t len, int pred
     };
     up(c.chars, p->dc);
     up(c.types, p->dt);
+    if (c.packed.present) {
+        if (e == hipSuccess) e = upload(c.packed.uni, &p->dp.uni);
+        if (e == hipSuccess) e = upload(c.packed.bi, &p->dp.bi);
+        if (e == hipSuccess) e = upload(c.packed.tri, &p->dp.tri);
+        if (e == hipSuccess) e = upload(c.packed.edge, &p->dp.edge);
+        if (e == hipSuccess) e = upload(c.packed.wrows, &p->dp.wrows);
+    }
     if (e == hipSuccess && c.type_kind == vpt::kTypeWindowTable) e = upload(c.type_table, &p->d_type_table);
     if (e == hipSuccess) {
         std::vector<uint8_t> ctype(65536);
@@ -221,6 +255,7 @@ vpt_status vpt_predictor_create(const uint8_t* model_bytes, size_t len, int pred
     }
     p->ct = make_view(c.chars, p->dc);
     p->tt = make_view(c.types, p->dt);
+    p->pk = make_packed_view(c.packed, p->dp);
     uint32_t stride = 4;
     if (c.chars.present) stride = std::max(stride, c.chars.stride_dw);
     if (c.types.present) stride = std::max(stride, c.types.stride_dw);
@@ -233,7 +268,7 @@ void vpt_predictor_destroy(vpt_predictor* p) {
     if (!p) return;
     (void)hipSetDevice(p->device);
     for (vpt_batch* b : p->pool) batch_release(b);
-    p->dc.release(); p->dt.release();
+    p->dc.release(); p->dt.release(); p->dp.release();
     (void)hipFree(p->d_type_table);
     (void)hipFree(p->d_ctype);
     delete p;
@@ -273,6 +308,10 @@ vpt_status vpt_batch_create(const vpt_predictor* p, vpt_batch** out) {
     b->pred = p; b->device = p->device;
     hipError_t e = hipMalloc(reinterpret_cast<void**>(&b->d_ctrl), 64);
     if (e == hipSuccess) e = hipMemset(b->d_ctrl, 0, 64);
+    if (e == hipSuccess && std::getenv("VPT_PROFILE_PHASES")) {
+        e = hipMalloc(reinterpret_cast<void**>(&b->d_prof), 64);
+        if (e == hipSuccess) e = hipMemset(b->d_prof, 0, 64);
+    }
     if (e != hipSuccess) { batch_release(b); return fail(VPT_RUNTIME_ERROR, std::string("HIP error: ") + hipGetErrorString(e)); }
     *out = b;
     return VPT_OK;
@@ -315,6 +354,17 @@ vpt_status vpt_batch_kernel_ms(vpt_batch* b, float* score_kernel_ms, uint32_t* n
     return VPT_OK;
 }
 
+vpt_status vpt_batch_phase_cycles(vpt_batch* b, uint64_t cycles[8]) {
+    if (!b || !cycles) return fail(VPT_INVALID_ARGUMENT, "InvalidArgumentError: NULL argument");
+    std::memset(cycles, 0, 64);
+    if (!b->d_prof) return VPT_OK;
+    VPT_HIP(hipSetDevice(b->device));
+    VPT_HIP(hipDeviceSynchronize());
+    VPT_HIP(hipMemcpy(cycles, b->d_prof, 64, hipMemcpyDeviceToHost));
+    VPT_HIP(hipMemset(b->d_prof, 0, 64));
+    return VPT_OK;
+}
+
 vpt_status vpt_predict_batch_device(const vpt_predictor* p, vpt_batch* b, const uint8_t* d_utf8, const uint64_t* d_byte_offsets,
                                     const uint64_t* d_out_offsets, size_t n_sentences, uint64_t total_boundaries,
                                     uint64_t max_sentence_bytes, int32_t* d_scores, uint8_t* d_labels, void* hip_stream) {
@@ -325,7 +375,7 @@ vpt_status vpt_predict_batch_device(const vpt_predictor* p, vpt_batch* b, const 
     hipStream_t stream = static_cast<hipStream_t>(hip_stream);
     VPT_HIP(hipSetDevice(p->device));
     vpt::ScoreParams P{};
-    P.ct = p->ct; P.tt = p->tt; P.type_table = p->d_type_table; P.ctype = p->d_ctype;
+    P.ct = p->ct; P.tt = p->tt; P.pk = p->pk; P.type_table = p->d_type_table; P.ctype = p->d_ctype;
     P.type_window = p->type_window; P.type_kind = p->type_kind; P.bias = p->bias; P.pad = p->pad;
     // Tiles are cut every `tile_flat` flat positions (chars + separators) and end with the sentence that crosses
     // the cut, so a tile holds < tile_flat + longest sentence: pick tile_flat to fill the kernel's LDS capacity.
@@ -365,6 +415,7 @@ vpt_status vpt_predict_batch_device(const vpt_predictor* p, vpt_batch* b, const 
     P.text = d_utf8; P.boff = d_byte_offsets; P.ooff = d_out_offsets; P.tile_first = b->d_tile_first;
     P.scores = d_scores; P.labels = d_labels; P.status = b->d_ctrl; P.slow_list = b->d_slow_list; P.slow_count = b->d_ctrl + 1;
     P.scratch = b->d_scratch; P.scratch_stride = slab; P.scratch_cap = scratch_cap;
+    P.prof = b->d_prof;
     if (const char* dbg = std::getenv("VPT_DEBUG_ABLATE")) { P.debug = uint32_t(std::atoi(dbg)); P.ct.debug = P.debug; P.tt.debug = P.debug; }
 
     VPT_HIP(hipMemsetAsync(b->d_ctrl, 0, 8, stream));

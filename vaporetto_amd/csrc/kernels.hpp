@@ -27,6 +27,7 @@ constexpr uint32_t kErrScratchTooSmall = 8u;  // max_sentence_bytes was understa
 struct ScoreParams {
     PatternTableView ct;        // characters: n-grams + dictionary words
     PatternTableView tt;        // character types, when type_kind == kTypePatternTable
+    PackedView pk;              // characters again, 16-byte-entry layout of the specialised kernel (if eligible)
     const int32_t* type_table;  // 8^(2W) window scores, when type_kind == kTypeWindowTable
     const uint8_t* ctype;       // CharacterType of every BMP scalar value (65536 bytes)
     int32_t type_window;
@@ -46,12 +47,13 @@ struct ScoreParams {
     uint64_t scratch_stride;    // bytes per workgroup slab
     uint32_t scratch_cap;       // flat positions per slab
     uint32_t debug;             // profiling ablation bits (VPT_DEBUG_ABLATE env, 0 in production)
+    uint64_t* prof;             // per-phase shader-cycle counters (VPT_PROFILE_PHASES env), else nullptr
 };
 
 size_t score_tiles_lds_bytes();
 hipError_t launch_assign_tiles(const uint64_t* ooff, uint64_t n_sent, int pad, uint32_t tile_flat, uint32_t n_tiles,
                                uint32_t* tile_first, hipStream_t stream);
-// specialised kernel (kernels_fast.hip): char window 3, type window table or none
+// specialised kernel (kernels_fast.hip): packed tables (char window 3, BMP, i16), type window table or none
 bool fast_path_supported(const ScoreParams& P);
 hipError_t launch_score_tiles_fast(const ScoreParams& P, uint32_t n_tiles, hipStream_t stream);
 hipError_t launch_score_tiles(const ScoreParams& P, int chunks, uint32_t n_tiles, hipStream_t stream);

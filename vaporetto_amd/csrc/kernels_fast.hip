@@ -25,7 +25,7 @@ namespace {
 
 constexpr int kQCap = 256;                   // deferred items per wave (both stacks together)
 constexpr uint32_t kQHigh = kQCap - 128;     // replay until one more iteration (<= 64 + 64 pushes) fits
-constexpr uint32_t kCpMask = 0x1FFFFFu;      // sym = scalar value | tile-local sentence index << 21
+constexpr uint32_t kCpMask = 0xFFFFu;        // sym = char (non-BMP -> 0xFFFF) | tile-local sentence index << 16
 constexpr int kPerThread = kFastCap / kThreads;
 constexpr int kWavesF = kThreads / 64;
 
@@ -57,8 +57,8 @@ __device__ __forceinline__ uint32_t utf8_scalar_bf(uint32_t b4) {
 }
 
 // Two stacks in one wave-private buffer: trie steps grow from the bottom, lookup continuations from the top.
-//   trie step      x = s | depth << 11          y = node
-//   continuation   x = s | levels << 11 (bit 0: non-BMP unigram, 1: bigram, 2: trigram lookups still open)
+//   trie step      x = s | depth << 11          y = parent id (layout.h: tri slot, or kPackedEdgeId | edge slot)
+//   continuation   x = s | levels << 11 (bit 1: bigram, bit 2: trigram lookup to be continued past its home slot)
 struct WaveStacks {
     uint2* q;
     uint32_t nw, nr;  // wave-uniform counts
@@ -76,6 +76,9 @@ struct WaveStacks {
     }
 };
 
+__device__ __forceinline__ int32_t lo16(uint32_t x) { return int32_t(x << 16) >> 16; }
+__device__ __forceinline__ int32_t hi16(uint32_t x) { return int32_t(x) >> 16; }
+
 __device__ __forceinline__ void add_row6(int32_t* score, uint32_t s, int32_t a0, int32_t a1, int32_t a2, int32_t a3,
                                          int32_t a4, int32_t a5) {
     int32_t* p = score + s - 3;
@@ -83,8 +86,8 @@ __device__ __forceinline__ void add_row6(int32_t* score, uint32_t s, int32_t a0,
     atomicAdd(p + 3, a3); atomicAdd(p + 4, a4); atomicAdd(p + 5, a5);
 }
 
-// Up to 64 queued trie steps, all lanes busy: the edge (node, sym[s + depth]).
-__device__ __forceinline__ void replay_walk(const PatternTableView& T, FastLds& L, WaveStacks& Q, int lane) {
+// Up to 64 queued trie steps, all lanes busy: the edge (parent, sym[s + depth]).
+__device__ __forceinline__ void replay_walk(const PackedView& K, FastLds& L, WaveStacks& Q, int lane) {
     const uint32_t take = Q.nw < 64u ? Q.nw : 64u;
     Q.nw -= take;
     const bool have = uint32_t(lane) < take;
@@ -95,84 +98,134 @@ __device__ __forceinline__ void replay_walk(const PatternTableView& T, FastLds& 
     bool again = false;
     uint32_t nx = 0, ny = 0;
     if (c != 0) {
-        const uint64_t key = edge_key(it.y, c);
-        const uint32_t klo = uint32_t(key), khi = uint32_t(key >> 32);
-        uint32_t b = hash_slot(key, T.edge_shift);
+        const uint4* tab = reinterpret_cast<const uint4*>(K.edge);
+        uint32_t b = packed_hash2(it.y, c, K.edge_shift);
         bool home = true;
         for (;;) {
-            const uint4* p = reinterpret_cast<const uint4*>(T.edges) + size_t(b) * kEdgeBucket;
-            const uint4 e0 = p[0], e1 = p[1], e2 = p[2], e3 = p[3];
-            const bool m0 = e0.x == klo && (e0.y & ~kDisplacedBit) == khi;
-            const bool m1 = e1.x == klo && e1.y == khi, m2 = e2.x == klo && e2.y == khi, m3 = e3.x == klo && e3.y == khi;
-            if (m0 || m1 || m2 || m3) {
-                const uint32_t child = m0 ? e0.z : m1 ? e1.z : m2 ? e2.z : e3.z;
-                const uint32_t woff = m0 ? e0.w : m1 ? e1.w : m2 ? e2.w : e3.w;
-                const uint32_t m = depth + 1;  // chars matched so far: a pattern of m chars has m + 1 weights
-                if (woff != kNoRow) {           // starting at boundary s - 1
-                    const int32_t* w = T.wdata + woff;
+            const uint4 e = tab[b];
+            if (e.x == it.y && (e.y & 0xFFFFu) == c) {
+                const uint32_t m = depth + 1;  // chars matched so far: a pattern of m chars has m + 1 weights,
+                if (e.y & (kPkHasRow << 16)) {  // the first on boundary s - 1
+                    const uint4* wr = reinterpret_cast<const uint4*>(K.wrows) + e.z;
                     int32_t* dst = L.score + s - 1;
-                    const int32_t w0 = w[0], w1 = w[1], w2 = w[2], w3 = w[3], w4 = w[4];  // m >= 4
-                    atomicAdd(dst, w0); atomicAdd(dst + 1, w1); atomicAdd(dst + 2, w2); atomicAdd(dst + 3, w3); atomicAdd(dst + 4, w4);
-                    for (uint32_t j = 5; j <= m; ++j) atomicAdd(dst + j, w[j]);
+                    if (e.y & (kPkWide << 16)) {  // a value outside i16: the row is stored as i32 (rare)
+                        const int32_t* w32 = reinterpret_cast<const int32_t*>(wr);
+                        for (uint32_t j = 0; j <= m; ++j) atomicAdd(dst + j, w32[j]);
+                        if (e.y & (kPkHasKids << 16)) { again = true; nx = s | (m << 11); ny = kPackedEdgeId | b; }
+                        break;
+                    }
+                    const uint4 r = wr[0];
+                    atomicAdd(dst, lo16(r.x)); atomicAdd(dst + 1, hi16(r.x)); atomicAdd(dst + 2, lo16(r.y));
+                    atomicAdd(dst + 3, hi16(r.y)); atomicAdd(dst + 4, lo16(r.z));  // m >= 4
+                    if (m >= 5) atomicAdd(dst + 5, hi16(r.z));
+                    if (m >= 6) atomicAdd(dst + 6, lo16(r.w));
+                    if (m >= 7) atomicAdd(dst + 7, hi16(r.w));
+                    for (uint32_t j0 = 8; j0 <= m; j0 += 8) {
+                        const uint4 q = wr[j0 >> 3];
+                        const uint32_t w[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+                        for (uint32_t j = 0; j < 8; ++j)
+                            if (j0 + j <= m) atomicAdd(dst + j0 + j, (j & 1) ? hi16(w[j >> 1]) : lo16(w[j >> 1]));
+                    }
                 }
-                if (child & kHasKidsBit) { again = true; nx = s | (m << 11); ny = child & ~kHasKidsBit; }
+                if (e.y & (kPkHasKids << 16)) { again = true; nx = s | (m << 11); ny = kPackedEdgeId | b; }
                 break;
             }
-            const bool free_slot = (e0.x | e0.y) == 0 || (e1.x | e1.y) == 0 || (e2.x | e2.y) == 0 || (e3.x | e3.y) == 0;
-            if (free_slot || (home && !(e0.y & kDisplacedBit))) break;
+            if (e.y == 0 || (home && !(e.y & (kPkDisp << 16)))) break;
             home = false;
-            b = (b + 1) & T.edge_mask;
+            b = (b + 1) & K.edge_mask;
         }
     }
     Q.push_walk(again, nx, ny);
 }
 
-// Up to 64 queued lookup continuations: for the start position s, the flagged levels still have to be looked
-// up past the home bucket (a key displaced by a full bucket), or at all (non-BMP unigram: no direct row).
-__device__ __forceinline__ void replay_retry(const PatternTableView& T, FastLds& L, WaveStacks& Q, int lane) {
+// Row of a <= 3-char string in the GENERAL short table (layout.h; 32-byte entries, buckets of two): used for the
+// rare packed slots marked kPkWide.
+__device__ __forceinline__ bool general_row(const PatternTableView& T, uint64_t key, uint4& r0, uint4& r1) {
+    const uint4* tab = reinterpret_cast<const uint4*>(T.short_tab);
+    const uint32_t klo = uint32_t(key), khi = uint32_t(key >> 32);
+    uint32_t b = hash_slot(key, T.short_shift);
+    bool home = true;
+    for (;;) {
+        const uint4 a0 = tab[size_t(b) * 4], b0 = tab[size_t(b) * 4 + 2];
+        if (a0.x == klo && (a0.y & ~kDisplacedBit) == khi) { r0 = a0; r1 = tab[size_t(b) * 4 + 1]; return true; }
+        if (b0.x == klo && b0.y == khi) { r0 = b0; r1 = tab[size_t(b) * 4 + 3]; return true; }
+        if ((a0.x | a0.y) == 0 || (b0.x | b0.y) == 0 || (home && !(a0.y & kDisplacedBit))) return false;
+        home = false;
+        b = (b + 1) & T.short_mask;
+    }
+}
+
+// Up to 64 queued lookup continuations for start position s.  levels: 2 / 4 = the bigram / trigram lookup goes on
+// past its home slot; 1 / 8 / 16 = the unigram / bigram / trigram row is kPkWide and comes from the general tables.
+__device__ __forceinline__ void replay_retry(const PackedView& K, const PatternTableView& T, FastLds& L, WaveStacks& Q, int lane) {
     const uint32_t take = Q.nr < 64u ? Q.nr : 64u;
     Q.nr -= take;
     const bool have = uint32_t(lane) < take;
     const uint2 it = have ? Q.q[kQCap - 1 - (Q.nr + lane)] : make_uint2(0u, 0u);
     const uint32_t s = it.x & 0x7FFu;
-    uint32_t levels = have ? (it.x >> 11) & 7u : 0u;
+    uint32_t levels = have ? (it.x >> 11) & 31u : 0u;
     bool walk = false;
-    uint32_t node = 0;
+    uint32_t parent = 0;
     const uint32_t c1 = L.sym[s] & kCpMask, c2 = L.sym[s + 1] & kCpMask, c3 = L.sym[s + 2] & kCpMask;
-    while (levels) {
-        const uint32_t level = uint32_t(__ffs(int(levels))) - 1u;  // 0..2 = 1..3 chars
-        levels &= levels - 1;
-        const uint64_t key = short_key(c1, level >= 1 ? c2 : 0u, level >= 2 ? c3 : 0u);
-        const uint32_t klo = uint32_t(key), khi = uint32_t(key >> 32);
-        uint32_t b = hash_slot(key, T.short_shift);
-        if (level != 0) b = (b + 1) & T.short_mask;  // the home bucket was already examined
+    const uint32_t kb = c1 | (c2 << 16);
+    if (levels & 2u) {
+        const uint4* tab = reinterpret_cast<const uint4*>(K.bi);
+        uint32_t b = packed_hash1(kb, K.bi_shift);
         for (;;) {
-            const uint4* p = reinterpret_cast<const uint4*>(T.short_tab) + size_t(b) * 4;
-            const uint4 a0 = p[0], a1 = p[1], b0 = p[2], b1 = p[3];
-            const bool ma = a0.x == klo && (a0.y & ~kDisplacedBit) == khi, mb = b0.x == klo && b0.y == khi;
-            if (ma || mb) {
-                const int32_t r0 = int32_t(ma ? a0.z : b0.z), r1 = int32_t(ma ? a0.w : b0.w), r2 = int32_t(ma ? a1.x : b1.x);
-                const int32_t r3 = int32_t(ma ? a1.y : b1.y), r4 = int32_t(ma ? a1.z : b1.z), r5 = int32_t(ma ? a1.w : b1.w);
-                if (level == 0) add_row6(L.score, s, r0, r1, r2, r3, r4, r5);
-                else if (level == 1) add_row6(L.score, s, 0, r0, r1, r2, r3, r4);
-                else {
-                    add_row6(L.score, s, 0, 0, r0, r1, r2, r3);
-                    if (r5 != 0) { walk = true; node = uint32_t(r5); }
-                }
+            b = (b + 1) & K.bi_mask;
+            const uint4 e = tab[b];
+            if (e.x == kb) {
+                if (e.w & (kPkWide << 16)) levels |= 8u;
+                else add_row6(L.score, s, 0, lo16(e.y), hi16(e.y), lo16(e.z), hi16(e.z), lo16(e.w));
                 break;
             }
-            if ((a0.x | a0.y) == 0 || (b0.x | b0.y) == 0) break;  // a bucket with a free slot ends the chain
-            b = (b + 1) & T.short_mask;
+            if (e.x == 0) break;
         }
     }
-    Q.push_walk(walk, s | (3u << 11), node);
+    if (levels & 4u) {
+        const uint4* tab = reinterpret_cast<const uint4*>(K.tri);
+        uint32_t b = packed_hash2(kb, c3, K.tri_shift);
+        for (;;) {
+            b = (b + 1) & K.tri_mask;
+            const uint4 e = tab[b];
+            if (e.x == kb && (e.y & 0xFFFFu) == c3) {
+                if (e.y & (kPkWide << 16)) levels |= 16u;
+                else add_row6(L.score, s, 0, 0, lo16(e.z), hi16(e.z), lo16(e.w), hi16(e.w));
+                if (e.y & (kPkHasKids << 16)) { walk = true; parent = b; }
+                break;
+            }
+            if (e.x == 0) break;
+        }
+    }
+    if (levels & 25u) {  // wide rows (rare): i32 rows of the general tables
+        uint4 r0, r1;
+        if (levels & 1u) {
+            const uint4* u = reinterpret_cast<const uint4*>(T.uni) + size_t(c1) * 2;
+            r0 = u[0]; r1 = u[1];
+            add_row6(L.score, s, int32_t(r0.x), int32_t(r0.y), int32_t(r0.z), int32_t(r0.w), int32_t(r1.x), int32_t(r1.y));
+        }
+        if ((levels & 8u) && general_row(T, short_key(c1, c2, 0), r0, r1))
+            add_row6(L.score, s, 0, int32_t(r0.z), int32_t(r0.w), int32_t(r1.x), int32_t(r1.y), int32_t(r1.z));
+        if ((levels & 16u) && general_row(T, short_key(c1, c2, c3), r0, r1))
+            add_row6(L.score, s, 0, 0, int32_t(r0.z), int32_t(r0.w), int32_t(r1.x), int32_t(r1.y));
+    }
+    Q.push_walk(walk, s | (3u << 11), parent);
 }
 
-__device__ __forceinline__ void make_room(const PatternTableView& T, FastLds& L, WaveStacks& Q, int lane) {
+__device__ __forceinline__ void make_room(const PackedView& K, const PatternTableView& T, FastLds& L, WaveStacks& Q, int lane) {
     while (Q.nw + Q.nr > kQHigh) {
-        if (Q.nw >= Q.nr) replay_walk(T, L, Q, lane);
-        else replay_retry(T, L, Q, lane);
+        if (Q.nw >= Q.nr) replay_walk(K, L, Q, lane);
+        else replay_retry(K, T, L, Q, lane);
     }
+}
+
+// optional phase timing (VPT_PROFILE_PHASES): wave 0 of every workgroup adds the shader cycles it spent per phase
+__device__ __forceinline__ uint64_t phase_mark(uint64_t* prof, int slot, uint64_t t_prev) {
+    if (!prof) return 0;
+    const uint64_t now = __builtin_amdgcn_s_memtime();
+    if (threadIdx.x == 0) atomicAdd(reinterpret_cast<unsigned long long*>(prof + slot), (unsigned long long)(now - t_prev));
+    return now;
 }
 
 template <int WT>
@@ -201,6 +254,8 @@ __global__ __launch_bounds__(kThreads) void score_tiles_fast_kernel(const ScoreP
     const uint32_t expect_chars = uint32_t((O1 + i1) - (O0 + i0));
     const uint32_t nchunks = (nbytes_al + 15) >> 4;
     uint32_t err = 0;
+    uint64_t* const prof = P.prof;
+    uint64_t tmark = prof ? __builtin_amdgcn_s_memtime() : 0;
 
     // ---------------------------------------------------------------- A. decode
     uint32_t* bitmap = reinterpret_cast<uint32_t*>(&L.queue[0][0]);
@@ -262,6 +317,7 @@ __global__ __launch_bounds__(kThreads) void score_tiles_fast_kernel(const ScoreP
     }
     const uint32_t nchars = base_leads;
     if (nchars != expect_chars) err |= kErrBadOffsets;
+    tmark = phase_mark(prof, 0, tmark);
     if (tid == 0) raw[nchunks * 4] = 0;  // the dword after the staged text is read (as padding) by the last char
     __syncthreads();
 
@@ -298,7 +354,7 @@ __global__ __launch_bounds__(kThreads) void score_tiles_fast_kernel(const ScoreP
         if (meta[k] == 0xFFFFFFFFu) continue;
         const uint32_t flat = meta[k] & 0xFFFu, cp = cps[k];
         const uint32_t ty = cp < 0x10000u ? uint32_t(P.ctype[cp]) : char_type(cp);
-        L.sym[flat] = cp | ((meta[k] >> 16) << 21);
+        L.sym[flat] = (cp < kPackedNoMatchSym ? cp : kPackedNoMatchSym) | (meta[k] & 0xFFFF0000u);
         L.typ[flat] = uint8_t(ty);
         if (meta[k] & 0x8000u) {
 #pragma unroll
@@ -307,15 +363,14 @@ __global__ __launch_bounds__(kThreads) void score_tiles_fast_kernel(const ScoreP
     }
     __syncthreads();
 
+    tmark = phase_mark(prof, 1, tmark);
     // ---------------------------------------------------------------- B. patterns
-    const PatternTableView& T = P.ct;
+    const PackedView& K = P.pk;
     WaveStacks Q{&L.queue[wave][0], 0u, 0u};
-    const uint4* uni4 = reinterpret_cast<const uint4*>(T.uni);
-    const uint4* tab4 = reinterpret_cast<const uint4*>(T.short_tab);
+    const uint4* uni4 = reinterpret_cast<const uint4*>(K.uni);
+    const uint4* bi4 = reinterpret_cast<const uint4*>(K.bi);
+    const uint4* tri4 = reinterpret_cast<const uint4*>(K.tri);
     for (int k = 0; k < kPerThread; ++k) {
-#ifdef VPT_ABLATE_NO_PATTERNS
-        break;
-#endif
         const uint32_t s = uint32_t(tid) + uint32_t(k) * kThreads;
         if (s - uint32_t(lane) >= flat_len) break;  // wave-uniform: this wave's 64 positions are past the tile
         const uint32_t c1 = s < flat_len ? (L.sym[s] & kCpMask) : 0u;
@@ -323,41 +378,37 @@ __global__ __launch_bounds__(kThreads) void score_tiles_fast_kernel(const ScoreP
         const bool live = c1 != 0;
         const bool has2 = live && c2 != 0;
         const bool has3 = has2 && c3 != 0;
-        const bool big1 = c1 >= kUniDirectChars;
-        const uint64_t k2 = short_key(c1, c2, 0), k3 = short_key(c1, c2, c3);
-        const uint32_t h2 = hash_slot(k2, T.short_shift), h3 = hash_slot(k3, T.short_shift);
-        // every load first (row 0 of `uni` and whatever bucket a dead lane hashes to are harmless to read)
-        const uint32_t urow = big1 ? 0u : c1;
-        const uint4 u0 = uni4[size_t(urow) * 2], u1 = uni4[size_t(urow) * 2 + 1];
-        const uint4* pb = tab4 + size_t(h2) * 4;
-        const uint4* pt = tab4 + size_t(h3) * 4;
-        const uint4 ba0 = pb[0], ba1 = pb[1], bb0 = pb[2], bb1 = pb[3];
-        const uint4 ta0 = pt[0], ta1 = pt[1], tb0 = pt[2], tb1 = pt[3];
-
-        const uint32_t k2lo = uint32_t(k2), k2hi = uint32_t(k2 >> 32), k3lo = uint32_t(k3), k3hi = uint32_t(k3 >> 32);
-        const bool m2a = has2 && ba0.x == k2lo && (ba0.y & ~kDisplacedBit) == k2hi;
-        const bool m2b = has2 && bb0.x == k2lo && bb0.y == k2hi;
-        const bool m3a = has3 && ta0.x == k3lo && (ta0.y & ~kDisplacedBit) == k3hi;
-        const bool m3b = has3 && tb0.x == k3lo && tb0.y == k3hi;
-        const bool more2 = has2 && !m2a && !m2b && (ba0.y & kDisplacedBit);
-        const bool more3 = has3 && !m3a && !m3b && (ta0.y & kDisplacedBit);
-        int32_t a0 = int32_t(u0.x), a1 = int32_t(u0.y), a2 = int32_t(u0.z), a3 = int32_t(u0.w), a4 = int32_t(u1.x), a5 = int32_t(u1.y);
-        a1 += int32_t(m2a ? ba0.z : m2b ? bb0.z : 0u);
-        a2 += int32_t(m2a ? ba0.w : m2b ? bb0.w : 0u) + int32_t(m3a ? ta0.z : m3b ? tb0.z : 0u);
-        a3 += int32_t(m2a ? ba1.x : m2b ? bb1.x : 0u) + int32_t(m3a ? ta0.w : m3b ? tb0.w : 0u);
-        a4 += int32_t(m2a ? ba1.y : m2b ? bb1.y : 0u) + int32_t(m3a ? ta1.x : m3b ? tb1.x : 0u);
-        a5 += int32_t(m2a ? ba1.z : m2b ? bb1.z : 0u) + int32_t(m3a ? ta1.y : m3b ? tb1.y : 0u);
+        const uint32_t kb = c1 | (c2 << 16);
+        const uint32_t hb = packed_hash1(kb, K.bi_shift), ht = packed_hash2(kb, c3, K.tri_shift);
+        // the three loads first (row 0 of `uni` and whatever slot a dead lane hashes to are harmless to read)
+        const uint4 u = uni4[c1];
+        const uint4 eb = bi4[hb];
+        const uint4 et = tri4[ht];
+        const bool mb = has2 && eb.x == kb;
+        const bool mt = has3 && et.x == kb && (et.y & 0xFFFFu) == c3;
+        const bool moreb = has2 && !mb && (eb.w & (kPkDisp << 16));
+        const bool moret = has3 && !mt && (et.y & (kPkDisp << 16));
+        const uint32_t b1 = mb ? eb.y : 0u, b2 = mb ? eb.z : 0u, b3 = mb ? eb.w : 0u;
+        const uint32_t t2 = mt ? et.z : 0u, t3 = mt ? et.w : 0u;
+        const int32_t a0 = lo16(u.x);
+        const int32_t a1 = hi16(u.x) + lo16(b1);
+        const int32_t a2 = lo16(u.y) + hi16(b1) + lo16(t2);
+        const int32_t a3 = hi16(u.y) + lo16(b2) + hi16(t2);
+        const int32_t a4 = lo16(u.z) + hi16(b2) + lo16(t3);
+        const int32_t a5 = hi16(u.z) + lo16(b3) + hi16(t3);
         if (live) add_row6(L.score, s, a0, a1, a2, a3, a4, a5);
-        const uint32_t node = m3a ? ta1.w : m3b ? tb1.w : 0u;
 
-        make_room(T, L, Q, lane);
-        Q.push_walk(node != 0, s | (3u << 11), node);
-        const uint32_t levels = (live && big1 ? 1u : 0u) | (more2 ? 2u : 0u) | (more3 ? 4u : 0u);
+        make_room(K, P.ct, L, Q, lane);
+        Q.push_walk(mt && (et.y & (kPkHasKids << 16)), s | (3u << 11), ht);
+        const uint32_t levels = ((live && u.w != 0) ? 1u : 0u) | (moreb ? 2u : 0u) | (moret ? 4u : 0u) |
+                                ((mb && (eb.w & (kPkWide << 16))) ? 8u : 0u) | ((mt && (et.y & (kPkWide << 16))) ? 16u : 0u);
         Q.push_retry(levels != 0, s | (levels << 11), 0u);
     }
-    while (Q.nr > 0) replay_retry(T, L, Q, lane);
-    while (Q.nw > 0) replay_walk(T, L, Q, lane);
+    while (Q.nr > 0) replay_retry(K, P.ct, L, Q, lane);
+    while (Q.nw > 0) replay_walk(K, L, Q, lane);
+    tmark = phase_mark(prof, 2, tmark);
     __syncthreads();
+    tmark = phase_mark(prof, 3, tmark);
 
     // ---------------------------------------------------------------- C. boundaries
     for (uint32_t p = pad + uint32_t(tid); p + 1 < flat_len; p += kThreads) {
@@ -370,20 +421,20 @@ __global__ __launch_bounds__(kThreads) void score_tiles_fast_kernel(const ScoreP
             for (int i = 1 - WT; i <= WT; ++i) id = (id << 3) | L.typ[int(p) + i];
             y += P.type_table[id];
         }
-        const uint32_t si = x >> 21;
+        const uint32_t si = x >> 16;
         const uint64_t o = O0 + (p - pad) - uint64_t(pad + 1) * si;
         if (P.scores) P.scores[o] = y;
         if (P.labels) P.labels[o] = y > 0 ? 1 : 0;
     }
     if (err) atomicOr(P.status, err);
+    phase_mark(prof, 4, tmark);
 }
 
 }  // namespace
 
 bool fast_path_supported(const ScoreParams& P) {
-    const PatternTableView& T = P.ct;
-    if (!T.present || T.window != 3 || T.stride_dw != 8 || T.uni_dw != 8 || T.uni_n != kUniDirectChars || T.ext_slot != 5) return false;
-    if (P.pad != 3 || !P.ctype) return false;
+    if (!P.pk.present || P.pad != 3 || !P.ctype) return false;
+    if (!P.ct.present || P.ct.stride_dw != 8 || P.ct.uni_dw != 8 || P.ct.uni_n != kUniDirectChars) return false;  // kPkWide rows
     if (P.type_kind == kTypeNone) return true;
     return P.type_kind == kTypeWindowTable && P.type_window >= 1 && P.type_window <= 3;
 }

@@ -31,6 +31,31 @@
 //                    wdata[woff ..]; woff = kNoRow when the node is only a prefix.  Buckets of kEdgeBucket = 4
 //                    (64 bytes), same kDisplacedBit rule (parent ids stay below 2^31); kHasKidsBit on the child
 //                    id = the child has edges of its own.
+//
+// PACKED TABLES (specialised kernel, kernels_fast.hip).  Every model a Vaporetto / KyTea trainer produces has
+// char window 3, weights quantised to 16 bits (trainer.rs:18,383-397; kytea_model.rs:72-79) and BMP-only patterns.
+// For such models -- W = 3, every pattern symbol in [1, 0xFFFE], every merged row value within i16 -- the same
+// all-matches tables are also emitted with 16-BYTE entries, so that one lookup is ONE dwordx4 load per lane
+// (the kernel is bound by the number of divergent vector-memory lane requests, not by bytes):
+//
+//   uni    65536 rows, indexed by the char:   {w[0..5] i16 (boundaries s-3 .. s+2), 0}
+//   bi     open addressing, key = c1 | c2<<16 {key, w[0..4] i16 (boundaries s-2 .. s+2), flags u16}
+//   tri    key = (c1 | c2<<16, c3)            {c1|c2<<16, c3 | flags<<16, w[0..3] i16 (boundaries s-1 .. s+2)}
+//          holds every 3-char pattern and the 3-char prefix of every longer one (zero weights).
+//   edge   trie of the patterns longer than 3 chars, key = (parent id, sym):
+//                                             {parent, sym | flags<<16, row offset (16-byte units), 0}
+//          parent id = slot index of the 3-char prefix in `tri`, or kPackedEdgeId | slot index in `edge`.
+//   wrows  i16 weight rows of those patterns (a pattern of m chars has m+1 weights, boundaries s-1 .. s+m-1),
+//          each row padded to a multiple of 16 bytes.
+//
+// A key lives in its home slot hash(key) or, if that was taken, in the next free slot (linear probing).  The
+// flags of a SLOT carry kPkDisp when some key whose home is this slot lives further on: a lookup that finds
+// neither its key nor kPkDisp in the home slot is done after one load; otherwise it is continued (replayed)
+// until the key or an empty slot is met.  Empty slot: bi/tri dword 0 == 0, edge dword 1 == 0.
+// kPkWide marks a row with a value outside i16 (an n-gram and a dictionary word with the same string can sum past
+// 16 bits): a uni/bi/tri slot then keeps zero weights and the row is taken from the general tables above
+// (`uni` row flag: dword 3 == kPkWide); an edge's row in `wrows` is then stored as i32.
+// A text char >= 0x10000 is mapped to 0xFFFF before lookups: no pattern contains either, so it matches nothing.
 #pragma once
 #include <cstdint>
 #if defined(__HIPCC__)
@@ -49,6 +74,10 @@ constexpr uint32_t kShortBucket = 2;             // entries per bucket of the sh
 constexpr uint32_t kEdgeBucket = 4;              // edges per bucket of the trie edge table
 constexpr uint32_t kHashMulLo = 0x9E3779B1u, kHashMulHi = 0x85EBCA77u;
 
+constexpr uint32_t kPkDisp = 1u, kPkHasKids = 2u, kPkHasRow = 4u, kPkWide = 8u;  // flags of a packed slot
+constexpr uint32_t kPackedEdgeId = 0x80000000u;                    // parent ids that name an `edge` slot
+constexpr uint32_t kPackedNoMatchSym = 0xFFFFu;
+
 #if defined(__HIPCC__)
 #define VPT_HD __host__ __device__ __forceinline__
 #else
@@ -63,6 +92,10 @@ VPT_HD uint64_t edge_key(uint32_t parent, uint32_t sym) { return (uint64_t(paren
 VPT_HD uint32_t hash_slot(uint64_t key, uint32_t shift) {
     return (uint32_t(key) * kHashMulLo + uint32_t(key >> 32) * kHashMulHi) >> shift;
 }
+
+// packed-table hashes; `shift` = 32 - log2(capacity)
+VPT_HD uint32_t packed_hash1(uint32_t k, uint32_t shift) { return (k * kHashMulLo) >> shift; }
+VPT_HD uint32_t packed_hash2(uint32_t a, uint32_t b, uint32_t shift) { return (a * kHashMulLo + b * kHashMulHi) >> shift; }
 
 // geometry of the row of a pattern of n symbols under window W (see the header comment)
 VPT_HD int row_lo(int n, int W) { return (n - 1 - W) < -1 ? (n - 1 - W) : -1; }
@@ -86,6 +119,13 @@ struct PatternTableView {
     uint32_t has_long;       // any pattern longer than 3 symbols
     uint32_t debug;          // profiling ablation bits (0 in production)
     uint32_t present;        // 0 = this scorer is None (char_scorer.rs:98-100 / type_scorer.rs:109-111)
+};
+
+// Device view of the packed tables; passed to the specialised kernel by value.
+struct PackedView {
+    const uint32_t *uni, *bi, *tri, *edge, *wrows;   // 16-byte entries (uint4)
+    uint32_t bi_shift, bi_mask, tri_shift, tri_mask, edge_shift, edge_mask;
+    uint32_t present;
 };
 
 }  // namespace vpt

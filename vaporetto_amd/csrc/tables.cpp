@@ -209,6 +209,158 @@ HostPatternTable build_table(std::vector<Pat>& pats, int W, uint32_t uni_n) {
     return t;
 }
 
+// ---- packed tables (layout.h, "PACKED TABLES").  `pats` must already be sorted and merged (build_table did it).
+// Not eligible (present = false) when a pattern symbol is outside [1, 0xFFFE]: the general tables/kernel handle
+// such a model.  A merged row with a value outside i16 (the same string as n-gram AND dictionary word can sum past
+// 16 bits) keeps its slot with zero weights and kPkWide: the kernel then takes the row from the general tables
+// (patterns of <= 3 chars) or reads the row as i32 (longer patterns).
+inline bool fits_i16(int32_t v) { return v >= -32768 && v <= 32767; }
+inline uint32_t pack16(int32_t lo, int32_t hi) { return (uint32_t(lo) & 0xFFFFu) | (uint32_t(hi) << 16); }
+
+struct PackedInserter {
+    std::vector<uint32_t>& tab;
+    uint32_t bits, mask;
+    int empty_dw;   // the dword whose value 0 marks an empty slot
+    int flag_dw;    // flags live in the HIGH half of this dword
+    uint32_t n_disp = 0, max_probe = 0;
+    PackedInserter(std::vector<uint32_t>& t, size_t count, int empty_dw_, int flag_dw_) : tab(t), empty_dw(empty_dw_), flag_dw(flag_dw_) {
+        bits = bits_for(count);
+        mask = (1u << bits) - 1;
+        tab.assign((size_t(1) << bits) * 4, 0);
+    }
+    // places {d0..d3} at home or the next free slot; returns the slot
+    uint32_t insert(uint32_t home, uint32_t d0, uint32_t d1, uint32_t d2, uint32_t d3) {
+        uint32_t s = home, probes = 1;
+        while (tab[size_t(s) * 4 + empty_dw] != 0) { s = (s + 1) & mask; ++probes; }
+        max_probe = std::max(max_probe, probes);
+        uint32_t* d = &tab[size_t(s) * 4];
+        d[0] = d0; d[1] = d1; d[2] = d2; d[3] = d3;
+        if (s != home) { tab[size_t(home) * 4 + flag_dw] |= kPkDisp << 16; ++n_disp; }
+        return s;
+    }
+};
+
+HostPackedTable build_packed(const std::vector<Pat>& pats) {
+    HostPackedTable t;
+    for (const Pat& p : pats) {
+        for (Sym c : p.s)
+            if (c == 0 || c >= kPackedNoMatchSym) return t;
+    }
+    auto wide = [](const Pat& p) {
+        for (int32_t v : p.row)
+            if (!fits_i16(v)) return true;
+        return false;
+    };
+    t.uni.assign(size_t(65536) * 4, 0);
+    struct Node { uint32_t parent; Sym sym; uint32_t depth; const Pat* pat; uint32_t kids; uint32_t id; };
+    // trigram-level keys: patterns of 3 chars and 3-char prefixes of longer ones
+    struct Tri { const Pat* pat; uint32_t kids; uint32_t slot; };
+    std::unordered_map<uint64_t, uint32_t> tri_of;   // short_key -> index in tris
+    std::vector<Tri> tris;
+    std::vector<uint64_t> tri_keys;
+    std::vector<Node> nodes;                          // trie nodes of depth >= 4
+    std::unordered_map<uint64_t, uint32_t> child_of;  // (parent ref << 21 | sym) -> index in nodes; parent ref: tri index or 2^31 | node index
+    auto tri_index = [&](const SymString& s) {
+        const uint64_t k = short_key(s[0], s[1], s[2]);
+        auto it = tri_of.find(k);
+        if (it != tri_of.end()) return it->second;
+        const uint32_t i = uint32_t(tris.size());
+        tris.push_back({nullptr, 0, 0});
+        tri_keys.push_back(k);
+        tri_of.emplace(k, i);
+        return i;
+    };
+    size_t n_bi = 0;
+    for (const Pat& p : pats) {
+        const size_t n = p.s.size();
+        if (n == 1) {
+            uint32_t* d = &t.uni[size_t(p.s[0]) * 4];
+            if (wide(p)) { d[3] = kPkWide; ++t.n_wide; }
+            else { d[0] = pack16(p.row[0], p.row[1]); d[1] = pack16(p.row[2], p.row[3]); d[2] = pack16(p.row[4], p.row[5]); }
+        } else if (n == 2) ++n_bi;
+        else if (n == 3) tris[tri_index(p.s)].pat = &p;
+        else {
+            uint32_t ti = tri_index(p.s);
+            uint64_t ref = ti;           // parent reference
+            uint32_t* kids = nullptr;
+            for (size_t i = 3; i < n; ++i) {
+                const uint64_t ck = (ref << 21) | p.s[i];
+                auto it = child_of.find(ck);
+                uint32_t ni;
+                if (it == child_of.end()) {
+                    ni = uint32_t(nodes.size());
+                    nodes.push_back({uint32_t(ref), p.s[i], uint32_t(i + 1), nullptr, 0, 0});
+                    child_of.emplace(ck, ni);
+                    if (ref & kPackedEdgeId) ++nodes[ref & ~kPackedEdgeId].kids; else ++tris[ref].kids;
+                } else ni = it->second;
+                ref = uint64_t(kPackedEdgeId) | ni;
+            }
+            (void)kids;
+            nodes[ref & ~kPackedEdgeId].pat = &p;
+        }
+    }
+    // bigrams
+    {
+        PackedInserter ins(t.bi, n_bi, 0, 3);
+        for (const Pat& p : pats) {
+            if (p.s.size() != 2) continue;
+            const uint32_t key = p.s[0] | (p.s[1] << 16);
+            // flags share dword 3 with w[4]: insert() only ORs into the high half
+            if (wide(p)) { ins.insert(packed_hash1(key, 32 - ins.bits), key, 0, 0, kPkWide << 16); ++t.n_wide; }
+            else ins.insert(packed_hash1(key, 32 - ins.bits), key, pack16(p.row[0], p.row[1]), pack16(p.row[2], p.row[3]), pack16(p.row[4], 0));
+        }
+        t.bi_bits = ins.bits; t.n_bi = uint32_t(n_bi); t.n_disp_bi = ins.n_disp; t.max_probe = std::max(t.max_probe, ins.max_probe);
+    }
+    // trigram level
+    {
+        PackedInserter ins(t.tri, tris.size(), 0, 1);
+        for (size_t i = 0; i < tris.size(); ++i) {
+            const uint64_t k = tri_keys[i];
+            const uint32_t c1 = uint32_t(k & 0x1FFFFF), c2 = uint32_t((k >> 21) & 0x1FFFFF), c3 = uint32_t(k >> 42);
+            const uint32_t klo = c1 | (c2 << 16);
+            const Pat* p = tris[i].pat;
+            uint32_t fl = tris[i].kids ? kPkHasKids : 0u;
+            if (p && wide(*p)) { fl |= kPkWide; p = nullptr; ++t.n_wide; }
+            tris[i].slot = ins.insert(packed_hash2(klo, c3, 32 - ins.bits), klo, c3 | (fl << 16),
+                                      p ? pack16(p->row[0], p->row[1]) : 0u, p ? pack16(p->row[2], p->row[3]) : 0u);
+        }
+        t.tri_bits = ins.bits; t.n_tri = uint32_t(tris.size()); t.n_disp_tri = ins.n_disp; t.max_probe = std::max(t.max_probe, ins.max_probe);
+    }
+    // deeper levels, one depth at a time (a child's key needs its parent's slot)
+    {
+        PackedInserter ins(t.edge, nodes.size(), 1, 1);
+        std::vector<std::vector<uint32_t>> by_depth;
+        for (uint32_t i = 0; i < nodes.size(); ++i) {
+            if (nodes[i].depth >= by_depth.size()) by_depth.resize(nodes[i].depth + 1);
+            by_depth[nodes[i].depth].push_back(i);
+        }
+        for (const auto& level : by_depth) {
+            for (uint32_t i : level) {
+                Node& nd = nodes[i];
+                const uint32_t parent = (nd.parent & kPackedEdgeId) ? (kPackedEdgeId | nodes[nd.parent & ~kPackedEdgeId].id) : tris[nd.parent].slot;
+                uint32_t fl = nd.kids ? kPkHasKids : 0u, woff = 0;
+                if (nd.pat) {
+                    fl |= kPkHasRow;
+                    woff = uint32_t(t.wrows.size() / 4);
+                    const std::vector<int32_t>& r = nd.pat->row;   // depth + 1 values, first = boundary s - 1
+                    if (wide(*nd.pat)) {
+                        fl |= kPkWide;
+                        ++t.n_wide;
+                        for (int32_t v : r) t.wrows.push_back(uint32_t(v));
+                    } else
+                        for (size_t j = 0; j < r.size(); j += 2) t.wrows.push_back(pack16(r[j], j + 1 < r.size() ? r[j + 1] : 0));
+                    while (t.wrows.size() % 4) t.wrows.push_back(0);
+                }
+                nd.id = ins.insert(packed_hash2(parent, nd.sym, 32 - ins.bits), parent, nd.sym | (fl << 16), woff, 0);
+            }
+        }
+        t.edge_bits = ins.bits; t.n_edge = uint32_t(nodes.size()); t.n_disp_edge = ins.n_disp; t.max_probe = std::max(t.max_probe, ins.max_probe);
+    }
+    if (t.wrows.empty()) t.wrows.assign(4, 0);
+    t.present = true;
+    return t;
+}
+
 // TypeScorerBoundaryCache::new (boundary_scorer_cache.rs:22-57): scores[seq] for every window of 2W type codes
 // (3 bits each, leftmost = most significant, 0 = outside the sentence, 7 = invalid -> score 0) is the sum over
 // every pattern occurrence inside the window of w[2W - end] when that index exists.
@@ -316,6 +468,7 @@ CompiledModel compile_model(const ModelData& m, bool predict_tags) {
         for (const auto& d : m.char_ngrams) add_ngram(pats, d.ngram, d.weights, wc, true);
         for (const auto& d : m.dict) add_word(pats, d.word, d.weights, wc);
         c.chars = build_table(pats, wc, kUniDirectChars);
+        if (wc == 3) c.packed = build_packed(pats);
     }
 
     // TypeScorer::new: None without n-grams or window (type_scorer.rs:109-111); the window table when

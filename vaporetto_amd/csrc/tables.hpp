@@ -28,12 +28,26 @@ struct HostPatternTable {
     }
 };
 
+// Packed tables of the specialised kernel (layout.h, "packed tables"): 16-byte entries, i16 weights.
+struct HostPackedTable {
+    bool present = false;          // false: the model is not eligible (see build notes in tables.cpp)
+    std::vector<uint32_t> uni;     // 65536 rows x 4 dwords
+    std::vector<uint32_t> bi, tri, edge;  // 4 dwords per slot
+    std::vector<uint32_t> wrows;   // i16 rows of patterns longer than 3 chars, each padded to 16 bytes
+    uint32_t bi_bits = 4, tri_bits = 4, edge_bits = 4;
+    // statistics
+    uint32_t n_bi = 0, n_tri = 0, n_edge = 0, n_disp_bi = 0, n_disp_tri = 0, n_disp_edge = 0;
+    uint32_t max_probe = 0, n_wide = 0;
+    uint64_t bytes() const { return 4ull * (uni.size() + bi.size() + tri.size() + edge.size() + wrows.size()); }
+};
+
 enum TypeKind : int { kTypeNone = 0, kTypeWindowTable = 1, kTypePatternTable = 2 };
 
 struct CompiledModel {
     int32_t bias = 0;
     int pad = 1;                       // zero symbols placed between sentences inside a tile
     HostPatternTable chars;            // char n-grams + dictionary words
+    HostPackedTable packed;            // the same patterns in the specialised kernel's layout, when eligible
     int type_kind = kTypeNone;
     int type_window = 0;
     std::vector<int32_t> type_table;   // 8^(2W) scores indexed by the 3-bit packed type window (cache variant)
