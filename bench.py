@@ -42,6 +42,19 @@ def load_model_bytes(kind: int, scale: float):
     return synth.synth_model(kind, synth.SEED_BASE + 2, scale), "synthetic-" + {1: "M1", 2: "M2", 3: "M3"}[kind]
 
 
+def measured_traffic(kernel: str, model: str, sentences: int):
+    """HBM bytes per launch from the committed rocprofv3 PMC summary (profiles/traffic.json), or None."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "traffic.json")) as fh:
+            entries = json.load(fh)["entries"]
+    except (OSError, ValueError, KeyError):
+        return None
+    for e in reversed(entries):
+        if e["kernel"] == kernel and e["model"] == model and e["sentences_per_gpu"] == sentences:
+            return int(1024 * (e["fetch_size_kib"] * e["fetch_correction"] + e["write_size_kib"]))
+    return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -71,20 +84,10 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
-    # ---- model: rank 0 loads/synthesises, everyone receives the bytes over RCCL (xGMI)
-    model_name = ""
-    if rank == 0:
-        model_bytes, model_name = load_model_bytes(args.model_kind, args.model_scale)
-        n = torch.tensor([len(model_bytes)], dtype=torch.int64, device=dev)
-    else:
-        model_bytes, n = None, torch.zeros(1, dtype=torch.int64, device=dev)
-    if world > 1:
-        dist.broadcast(n, 0)
-        blob = torch.empty(int(n.item()), dtype=torch.uint8, device=dev)
-        if rank == 0:
-            blob.copy_(torch.frombuffer(bytearray(model_bytes), dtype=torch.uint8))
-        dist.broadcast(blob, 0)
-        model_bytes = blob.cpu().numpy().tobytes()
+    # ---- model: rank 0 loads/synthesises, everyone receives the bytes over RCCL (xGMI) -- vaporetto_amd/dist.py
+    from vaporetto_amd import dist as vdist
+    model_bytes, model_name = (load_model_bytes(args.model_kind, args.model_scale) if rank == 0 else (None, ""))
+    model_bytes = vdist.broadcast_model_bytes(model_bytes, src=0, device=dev)
     predictor = api.Predictor(api.Model.read_slice(model_bytes)[0], False, device=local_rank)
     info = predictor.info()
 
@@ -126,13 +129,7 @@ def main():
     batch.sync()
     kernel_ms, n_tiles = batch.kernel_ms()
     phases = batch.phase_cycles() if args.phases else None
-    el = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-    tot = torch.tensor([float(nb)], dtype=torch.float64, device=dev)
-    if world > 1:
-        dist.all_reduce(el, op=dist.ReduceOp.MAX)
-        dist.all_reduce(tot, op=dist.ReduceOp.SUM)
-    elapsed = float(el.item())
-    total_boundaries = float(tot.item())
+    elapsed, total_boundaries = vdist.reduce_throughput(elapsed, float(nb), device=dev)
 
     if rank == 0:
         out = {
@@ -179,7 +176,8 @@ def main():
             a = a_stream + a_char + a_type
             achieved = a / (kernel_ms * 1e-3) / 1e9
             out["roofline"] = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                               "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                               "frac": achieved / HBM_PEAK_GBS,
+                               "traffic": measured_traffic(kernel_name, model_name, S) if args.min_len == 64 and args.max_len == 64 else None,
                                "kernel": kernel_name, "kernel_ms": kernel_ms,
                                "algorithmic_bytes_per_launch": a, "bytes_per_boundary": a / nb,
                                "a_stream": a_stream, "a_char": a_char, "a_type": a_type}

@@ -17,6 +17,8 @@
 //   * 22 KB of LDS per workgroup and <= 64 VGPRs: 7 workgroups = 28 waves per CU.
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
+
 #include "device_common.h"
 #include "kernels.hpp"
 
@@ -379,9 +381,13 @@ __global__ __launch_bounds__(kThreads) void score_tiles_fast_kernel(const ScoreP
         const bool has2 = live && c2 != 0;
         const bool has3 = has2 && c3 != 0;
         const uint32_t kb = c1 | (c2 << 16);
-        const uint32_t hb = packed_hash1(kb, K.bi_shift), ht = packed_hash2(kb, c3, K.tri_shift);
+        uint32_t hb = packed_hash1(kb, K.bi_shift), ht = packed_hash2(kb, c3, K.tri_shift);
+        if (P.debug) {  // timing ablations (VPT_DEBUG_ABLATE; results are wrong): pin a lookup to slot 0
+            if (P.debug & 1u) hb = 0;
+            if (P.debug & 2u) ht = 0;
+        }
         // the three loads first (row 0 of `uni` and whatever slot a dead lane hashes to are harmless to read)
-        const uint4 u = uni4[c1];
+        const uint4 u = uni4[(P.debug & 4u) ? 0u : c1];
         const uint4 eb = bi4[hb];
         const uint4 et = tri4[ht];
         const bool mb = has2 && eb.x == kb;
@@ -399,7 +405,7 @@ __global__ __launch_bounds__(kThreads) void score_tiles_fast_kernel(const ScoreP
         if (live) add_row6(L.score, s, a0, a1, a2, a3, a4, a5);
 
         make_room(K, P.ct, L, Q, lane);
-        Q.push_walk(mt && (et.y & (kPkHasKids << 16)), s | (3u << 11), ht);
+        Q.push_walk(mt && (et.y & (kPkHasKids << 16)) && !(P.debug & 8u), s | (3u << 11), ht);
         const uint32_t levels = ((live && u.w != 0) ? 1u : 0u) | (moreb ? 2u : 0u) | (moret ? 4u : 0u) |
                                 ((mb && (eb.w & (kPkWide << 16))) ? 8u : 0u) | ((mt && (et.y & (kPkWide << 16))) ? 16u : 0u);
         Q.push_retry(levels != 0, s | (levels << 11), 0u);
@@ -440,7 +446,8 @@ bool fast_path_supported(const ScoreParams& P) {
 }
 
 hipError_t launch_score_tiles_fast(const ScoreParams& P, uint32_t n_tiles, hipStream_t stream) {
-    const size_t lds = sizeof(FastLds);
+    size_t lds = sizeof(FastLds);
+    if (const char* padv = std::getenv("VPT_DEBUG_LDS_PAD")) lds += size_t(std::atoi(padv));  // occupancy experiments
     const int wt = P.type_kind == kTypeWindowTable ? P.type_window : 0;
     switch (wt) {
         case 0: hipLaunchKernelGGL(score_tiles_fast_kernel<0>, dim3(n_tiles), dim3(kThreads), lds, stream, P); break;
