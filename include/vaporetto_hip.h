@@ -139,8 +139,10 @@ typedef struct vpt_model_info {
     uint32_t type_kind;            /* 0 none, 1 window table (cache variant), 2 pattern tables */
     uint64_t device_table_bytes;   /* bytes all tables occupy in HBM */
     uint64_t hot_table_bytes;      /* bytes of the tables the scoring kernel chosen for this model reads */
-    uint32_t packed;               /* 1: the specialised kernel's 16-byte-entry tables are in use */
+    uint32_t packed;               /* 1: the specialised kernel's packed tables (128-byte prefix records) are in use */
     uint32_t n_displaced;          /* hash-table keys that do not sit in their home slot */
+    uint32_t type_rows;            /* 1: type scores come from the 512 LDS type rows (else: window table / patterns) */
+    uint32_t n_overflow_children;  /* trigram-level children kept outside their prefix record (more than six) */
 } vpt_model_info;
 
 /* Parses + validates + compiles the tables on the host only (no device).  Same errors as create. */

@@ -58,105 +58,115 @@ int tc_create(const uint8_t* bytes, size_t len, tc_model** out) {
 }
 void tc_destroy(tc_model* t) { delete t; }
 int tc_packed_present(const tc_model* t) { return t->c.packed.present ? 1 : 0; }
+int tc_trow_present(const tc_model* t) { return t->c.packed.present && !t->c.packed.trow.empty() ? 1 : 0; }
 void tc_stats(const tc_model* t, uint32_t out[8]) {
     const HostPackedTable& k = t->c.packed;
-    out[0] = k.n_bi; out[1] = k.n_tri; out[2] = k.n_edge; out[3] = k.n_disp_bi; out[4] = k.n_disp_tri; out[5] = k.n_disp_edge;
-    out[6] = k.max_probe; out[7] = k.n_wide;
+    out[0] = k.n_rec; out[1] = k.n_children; out[2] = k.n_overflow; out[3] = k.n_deep; out[4] = k.n_disp;
+    out[5] = k.max_probe; out[6] = k.n_wide; out[7] = uint32_t(k.bytes() >> 10);
 }
 
-// char-pattern part of the boundary scores of one sentence (n code points) + bias; y has n-1 entries.
-// probes[0..2] count continued bigram / trigram / edge lookups (diagnostics).
-int tc_score_chars(const tc_model* t, const uint32_t* cps, size_t n, int32_t* y_out, uint64_t probes[3]) {
+namespace {
+// mini-table probe (layout.h): returns the entry or nullptr
+const uint32_t* mini_find(const std::vector<uint32_t>& arena, uint32_t dw, uint32_t ref, uint32_t sym, uint64_t* steps) {
+    const uint32_t size = 1u << (ref & 31u), base = ref >> 5;
+    uint32_t i = packed_mini_slot(sym, ref);
+    for (uint32_t n = 0; n < size; ++n) {
+        const uint32_t* e = &arena[(size_t(base) + i) * dw];
+        ++*steps;
+        if ((e[0] & 0xFFFFu) == sym) return e;
+        if (e[0] == 0) return nullptr;
+        i = (i + 1) & (size - 1);
+    }
+    return nullptr;
+}
+}  // namespace
+
+// Boundary scores of one sentence (n code points) from the packed tables: bias + char patterns (+ type rows when
+// the model has them in the packed form; returns 2 then, 1 when types are NOT included, < 0 on error).
+// probes[0..3] count continued record lookups / overflow mini-table probes / deep probes / filter rejections.
+int tc_score(const tc_model* t, const uint32_t* cps, size_t n, int32_t* y_out, uint64_t probes[4]) {
     const HostPackedTable& K = t->c.packed;
+    const HostPatternTable& G = t->c.chars;
     if (!K.present) return -1;
     std::vector<int32_t> y(n > 0 ? n - 1 : 0, t->c.bias);
-    std::vector<uint32_t> sym(n + 3, 0);
-    for (size_t i = 0; i < n; ++i) sym[i] = cps[i] < kPackedNoMatchSym ? cps[i] : kPackedNoMatchSym;
-    const uint32_t bi_mask = (1u << K.bi_bits) - 1, tri_mask = (1u << K.tri_bits) - 1, edge_mask = (1u << K.edge_bits) - 1;
+    std::vector<uint32_t> sym(n + 3, 0), typ(n + 3, 0);
+    for (size_t i = 0; i < n; ++i) {
+        sym[i] = cps[i] < kPackedNoMatchSym ? cps[i] : kPackedNoMatchSym;
+        typ[i] = char_type_host(cps[i]);
+    }
+    const uint32_t rmask = (1u << K.rec_bits) - 1;
     for (size_t s = 0; s < n; ++s) {
         const uint32_t c1 = sym[s], c2 = sym[s + 1], c3 = sym[s + 2];
         const long S = long(s);
+        if (!K.trow.empty()) {
+            const uint32_t* r = &K.trow[size_t(typ[s] | (typ[s + 1] << 3) | (typ[s + 2] << 6)) * 4];
+            for (int j = 0; j < 6; ++j) add(y, S - 3 + j, trow_field(r[0], r[1], r[2], r[3], j));
+        }
         const uint32_t* u = &K.uni[size_t(c1) * 4];
         add(y, S - 3, lo16(u[0])); add(y, S - 2, hi16(u[0])); add(y, S - 1, lo16(u[1]));
         add(y, S, hi16(u[1])); add(y, S + 1, lo16(u[2])); add(y, S + 2, hi16(u[2]));
-        const HostPatternTable& G = t->c.chars;
         if (u[3] == kPkWide) {
             const uint32_t* g = &G.uni[size_t(c1) * G.uni_dw];
             for (int j = 0; j < 6; ++j) add(y, S - 3 + j, int32_t(g[j]));
         }
         if (c2 == 0) continue;
         const uint32_t kb = c1 | (c2 << 16);
-        {
-            uint32_t b = packed_hash1(kb, 32 - K.bi_bits);
-            const uint32_t* e = &K.bi[size_t(b) * 4];
-            bool hit = e[0] == kb;
-            if (!hit && (e[3] & (kPkDisp << 16))) {
-                ++probes[0];
-                for (;;) {
-                    b = (b + 1) & bi_mask;
-                    e = &K.bi[size_t(b) * 4];
-                    if (e[0] == kb) { hit = true; break; }
-                    if (e[0] == 0) break;
-                }
+        uint32_t b = packed_hash1(kb, 32 - K.rec_bits);
+        const uint32_t* r = &K.rec[size_t(b) * 32];
+        if (r[0] != kb) {
+            if (!(r[3] & (kPkDisp << 16))) continue;
+            ++probes[0];
+            for (;;) {
+                b = (b + 1) & rmask;
+                r = &K.rec[size_t(b) * 32];
+                if (r[0] == kb || r[0] == 0) break;
             }
-            if (hit && (e[3] & (kPkWide << 16))) {
-                const uint32_t* g = general_find(G, short_key(c1, c2, 0));
-                if (!g) return -2;
-                for (int j = 0; j < 5; ++j) add(y, S - 2 + j, int32_t(g[2 + j]));
-            } else if (hit) {
-                add(y, S - 2, lo16(e[1])); add(y, S - 1, hi16(e[1])); add(y, S, lo16(e[2]));
-                add(y, S + 1, hi16(e[2])); add(y, S + 2, lo16(e[3]));
-            }
+            if (r[0] != kb) continue;
+        }
+        if (r[16] != kb) return -3;   // both halves carry the key
+        if (r[3] & (kPkWide << 16)) {
+            const uint32_t* g = general_find(G, short_key(c1, c2, 0));
+            if (!g) return -2;
+            for (int j = 0; j < 5; ++j) add(y, S - 2 + j, int32_t(g[2 + j]));
+        } else {
+            add(y, S - 2, lo16(r[1])); add(y, S - 1, hi16(r[1])); add(y, S, lo16(r[2]));
+            add(y, S + 1, hi16(r[2])); add(y, S + 2, lo16(r[3]));
         }
         if (c3 == 0) continue;
-        uint32_t b = packed_hash2(kb, c3, 32 - K.tri_bits);
-        const uint32_t* e = &K.tri[size_t(b) * 4];
-        bool hit = e[0] == kb && (e[1] & 0xFFFFu) == c3;
-        if (!hit && (e[1] & (kPkDisp << 16))) {
-            ++probes[1];
-            for (;;) {
-                b = (b + 1) & tri_mask;
-                e = &K.tri[size_t(b) * 4];
-                if (e[0] == kb && (e[1] & 0xFFFFu) == c3) { hit = true; break; }
-                if (e[0] == 0) break;
-            }
+        const uint32_t* ch = nullptr;
+        for (int j = 0; j < 6 && !ch; ++j) {
+            const uint32_t* e = r + (j < 3 ? 4 + 4 * j : 20 + 4 * (j - 3));
+            if ((e[0] & 0xFFFFu) == c3) ch = e;
         }
-        if (!hit) continue;
-        if (e[1] & (kPkWide << 16)) {
+        if (!ch && (r[3] & (kPkOv << 16))) {
+            const uint64_t mask = uint64_t(r[18]) | (uint64_t(r[19]) << 32);
+            if ((mask >> packed_filter_bit(c3)) & 1) ch = mini_find(K.kids3, 4, r[17], c3, &probes[1]);
+            else ++probes[3];
+        }
+        if (!ch) continue;
+        if (ch[0] & (kPkWide << 16)) {
             const uint32_t* g = general_find(G, short_key(c1, c2, c3));
             if (!g) return -2;
             for (int j = 0; j < 4; ++j) add(y, S - 1 + j, int32_t(g[2 + j]));
-        } else { add(y, S - 1, lo16(e[2])); add(y, S, hi16(e[2])); add(y, S + 1, lo16(e[3])); add(y, S + 2, hi16(e[3])); }
-        if (!(e[1] & (kPkHasKids << 16))) continue;
-        uint32_t parent = b, depth = 3;
-        for (;;) {
+        } else { add(y, S - 1, lo16(ch[1])); add(y, S, hi16(ch[1])); add(y, S + 1, lo16(ch[2])); add(y, S + 2, hi16(ch[2])); }
+        uint32_t ref = ch[3], depth = 3;
+        while (ref != 0) {
             const uint32_t c = sym[s + depth < n ? s + depth : n];
             if (c == 0) break;
-            uint32_t eb = packed_hash2(parent, c, 32 - K.edge_bits);
-            const uint32_t* ed = nullptr;
-            bool home = true, found = false;
-            for (;;) {
-                ed = &K.edge[size_t(eb) * 4];
-                if (ed[0] == parent && (ed[1] & 0xFFFFu) == c) { found = true; break; }
-                if (ed[1] == 0 || (home && !(ed[1] & (kPkDisp << 16)))) break;
-                if (home) ++probes[2];
-                home = false;
-                eb = (eb + 1) & edge_mask;
-            }
-            if (!found) break;
+            const uint32_t* e = mini_find(K.deep, 8, ref, c, &probes[2]);
+            if (!e) break;
             const uint32_t m = depth + 1;
-            if (ed[1] & (kPkHasRow << 16)) {
-                const uint32_t* w = &K.wrows[size_t(ed[2]) * 4];
-                for (uint32_t j = 0; j <= m; ++j)
-                    add(y, S - 1 + long(j), (ed[1] & (kPkWide << 16)) ? int32_t(w[j]) : (j & 1) ? hi16(w[j >> 1]) : lo16(w[j >> 1]));
+            if (e[0] & (kPkHasRow << 16)) {
+                for (uint32_t j = 0; j <= m; ++j) add(y, S - 1 + long(j), (j & 1) ? hi16(e[2 + (j >> 1)]) : lo16(e[2 + (j >> 1)]));
+            } else if (e[0] & (kPkExtRow << 16)) {
+                for (uint32_t j = 0; j <= m; ++j) add(y, S - 1 + long(j), K.xrows[size_t(e[2]) + j]);
             }
-            if (!(ed[1] & (kPkHasKids << 16))) break;
-            parent = kPackedEdgeId | eb;
+            ref = e[1];
             depth = m;
         }
     }
     std::memcpy(y_out, y.data(), y.size() * sizeof(int32_t));
-    return 0;
+    return K.trow.empty() ? 1 : 2;
 }
 
 }  // extern "C"

@@ -296,6 +296,31 @@ def test_dense_packed_tables_with_displaced_keys(seed):
     m = randmodel.rand_model(70 + seed, alphabet=alpha, wc=3, wt=3, n_char=3000, n_dict=6000, max_word=12)
     pred, orc = make_predictor(m)
     info = pred.info()
-    assert info["packed"] == 1 and info["n_displaced"] > 0
+    assert info["packed"] == 1 and info["n_displaced"] > 0 and info["n_overflow_children"] > 0
     texts = randmodel.rand_sentences(seed, m, 3000, alphabet=alpha, max_len=120)
     check_batch(pred, orc, texts)
+
+
+@pytest.mark.parametrize("wt,force_window", [(3, False), (3, True), (2, False), (1, False), (2, True)])
+def test_type_rows_and_window_table_agree_with_oracle(wt, force_window, monkeypatch):
+    """Type n-grams of <= 3 symbols are scored from 512 LDS type rows; VPT_FORCE_WINDOW_TABLE routes the same model
+    through the 8^(2W) window table (the reference's cache variant).  Both must match the oracle."""
+    if force_window:
+        monkeypatch.setenv("VPT_FORCE_WINDOW_TABLE", "1")
+    m = randmodel.rand_model(500 + wt, alphabet="kana", wc=3, wt=wt, n_char=150, n_dict=150, n_type=120, max_word=8)
+    pred, orc = make_predictor(m)
+    info = pred.info()
+    assert info["packed"] == 1 and info["type_rows"] == 1
+    mixed = randmodel.ALPHABETS["mixed"] + randmodel.ALPHABETS["kana"][:8]
+    texts = randmodel.rand_sentences(8, m, 2500, alphabet=mixed, max_len=80)
+    check_batch(pred, orc, texts)
+
+
+def test_long_type_ngrams_use_the_window_table():
+    m = randmodel.rand_model(77, alphabet="kana", wc=3, wt=3, n_char=80, n_dict=80, n_type=40, max_word=6)
+    m.type_ngram_model.append(NgramData(bytes([3, 3, 3, 3]), [5, -6, 7]))
+    m.type_ngram_model.append(NgramData(bytes([3, 5, 3, 3, 6]), [11, -12]))
+    pred, orc = make_predictor(m)
+    assert pred.info()["type_rows"] == 0 and pred.info()["packed"] == 1
+    mixed = randmodel.ALPHABETS["mixed"] + randmodel.ALPHABETS["kana"][:8]
+    check_batch(pred, orc, randmodel.rand_sentences(2, m, 1500, alphabet=mixed, max_len=60))

@@ -28,7 +28,8 @@ def tc():
     L.tc_destroy.argtypes = [C.c_void_p]
     L.tc_packed_present.argtypes = [C.c_void_p]
     L.tc_stats.argtypes = [C.c_void_p, C.POINTER(C.c_uint32 * 8)]
-    L.tc_score_chars.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.POINTER(C.c_uint64 * 3)]
+    L.tc_trow_present.argtypes = [C.c_void_p]
+    L.tc_score.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.POINTER(C.c_uint64 * 4)]
     return L
 
 
@@ -48,15 +49,23 @@ class Walker:
     def stats(self):
         a = (C.c_uint32 * 8)()
         self.L.tc_stats(self.h, C.byref(a))
-        return dict(zip(["n_bi", "n_tri", "n_edge", "disp_bi", "disp_tri", "disp_edge", "max_probe", "n_wide"], list(a)))
+        return dict(zip(["n_rec", "n_children", "n_overflow", "n_deep", "n_disp", "max_probe", "n_wide", "kib"], list(a)))
 
-    def score(self, text, probes=None):
+    @property
+    def trow(self):
+        return bool(self.L.tc_trow_present(self.h))
+
+    def score(self, text, probes=None, want=None):
+        """Scores from the packed tables; `want` = 1 (types not included) or 2 (type rows included)."""
         cps = np.frombuffer(text.encode("utf-32-le"), dtype=np.uint32).copy()
         y = np.zeros(max(len(cps) - 1, 1), dtype=np.int32)
-        pr = (C.c_uint64 * 3)()
-        assert self.L.tc_score_chars(self.h, cps.ctypes.data, len(cps), y.ctypes.data, C.byref(pr)) == 0
+        pr = (C.c_uint64 * 4)()
+        rc = self.L.tc_score(self.h, cps.ctypes.data, len(cps), y.ctypes.data, C.byref(pr))
+        assert rc in (1, 2), rc
+        if want is not None:
+            assert rc == want
         if probes is not None:
-            for i in range(3):
+            for i in range(4):
                 probes[i] += pr[i]
         return y[:len(cps) - 1].tolist()
 
@@ -74,11 +83,11 @@ def test_packed_walk_matches_oracle_random_models(tc, seed):
     w = Walker(tc, raw)
     assert w.packed
     orc = cbind.OraclePredictor(raw)
-    probes = [0, 0, 0]
+    probes = [0, 0, 0, 0]
     for t in randmodel.rand_sentences(seed, m, 300, alphabet=alphabet, max_len=60):
-        assert w.score(t, probes) == orc.predict(t)[0], t
+        assert w.score(t, probes, want=1) == orc.predict(t)[0], t
     st = w.stats()
-    assert st["n_bi"] > 0 and st["n_tri"] > 0 and st["n_edge"] > 0
+    assert st["n_rec"] > 0 and st["n_children"] > 0 and st["n_deep"] > 0
 
 
 def test_packed_walk_dense_tables_exercise_displacement(tc):
@@ -89,12 +98,12 @@ def test_packed_walk_dense_tables_exercise_displacement(tc):
     w = Walker(tc, raw)
     assert w.packed
     st = w.stats()
-    assert st["disp_bi"] + st["disp_tri"] + st["disp_edge"] > 0
+    assert st["n_disp"] > 0 and st["n_overflow"] > 0
     orc = cbind.OraclePredictor(raw)
-    probes = [0, 0, 0]
+    probes = [0, 0, 0, 0]
     for t in randmodel.rand_sentences(5, m, 400, alphabet=alpha, max_len=80):
         assert w.score(t, probes) == orc.predict(t)[0], t
-    assert sum(probes) > 0   # the continuation protocol was actually used
+    assert probes[0] > 0 and probes[1] > 0 and probes[2] > 0   # continued records, overflow and deep mini-tables
 
 
 def test_packed_not_eligible_models_fall_back(tc):
@@ -147,3 +156,36 @@ def test_packed_text_with_non_bmp_and_ffff_chars(tc):
         for filler in ("𠮷", "￿", "🤌"):
             t = p[: len(p) // 2] + filler + p + filler + pats[(i + 1) % len(pats)]
             assert w.score(t) == orc.predict(t)[0], t
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_type_rows_match_oracle(tc, seed):
+    """Models whose type n-grams have <= 3 symbols get LDS type rows; the walker then reproduces the FULL score."""
+    wt = [3, 2, 1, 3][seed % 4]
+    m = randmodel.rand_model(300 + seed, alphabet="mixed" if seed % 2 else "kana", wc=3, wt=wt, n_char=60, n_dict=60, n_type=80, max_word=7)
+    # patterns must be BMP for the packed tables: drop the others
+    m.char_ngram_model = [d for d in m.char_ngram_model if all(ord(c) < 0xFFFF for c in d.ngram)]
+    m.dict_model = [d for d in m.dict_model if all(ord(c) < 0xFFFF for c in d.word)]
+    raw = encode_model(m)
+    w = Walker(tc, raw)
+    assert w.packed and w.trow
+    orc = cbind.OraclePredictor(raw)
+    for t in randmodel.rand_sentences(seed, m, 300, alphabet="mixed", max_len=50):
+        assert w.score(t, want=2) == orc.predict(t)[0], t
+
+
+def test_type_rows_absent_for_long_or_large_type_ngrams(tc):
+    base = dict(bias=1, char_window_size=3, type_window_size=3)
+    m = ModelData(**base)
+    m.char_ngram_model.append(NgramData("あ", [1, 2, 3, 4, 5, 6]))
+    m.type_ngram_model.append(NgramData(bytes([3, 3, 5, 3]), [1, 2, 3]))          # 4 symbols
+    assert not Walker(tc, encode_model(m)).trow
+    m = ModelData(**base)
+    m.char_ngram_model.append(NgramData("あ", [1, 2, 3, 4, 5, 6]))
+    m.type_ngram_model.append(NgramData(bytes([3]), [0, 0, 100000]))
+    m.type_ngram_model.append(NgramData(bytes([3, 3]), [0, 100000]))               # merged 200000 > 18 bits
+    assert not Walker(tc, encode_model(m)).trow
+    m = ModelData(**base)
+    m.char_ngram_model.append(NgramData("あ", [1, 2, 3, 4, 5, 6]))
+    m.type_ngram_model.append(NgramData(bytes([3, 5]), [1, 2, 3, 4, 5]))
+    assert Walker(tc, encode_model(m)).trow

@@ -1,0 +1,75 @@
+// Microbenchmark (diagnostics, not product code): rate of random gathers on MI355X by access shape.
+//   hipcc --offload-arch=gfx950 -O3 -o gather_bench tools/gather_bench.hip && ./gather_bench
+// Every thread issues ITER independent random accesses (address = hash(thread, i)); modes:
+//   0: 16 B from a random 16-B slot                1: 64 B (4 x 16) from a random 64-B record
+//   2: 128 B (8 x 16) from a random 128-B record   3: lane PAIRS share a random 128-B record, 64 B each
+//   4: 32 B (2 x 16) from a random 32-B record     5: as 1 with non-temporal loads
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
+#define CHECK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %s\n", hipGetErrorString(e_), #x); exit(1); } } while (0)
+
+__device__ __forceinline__ uint32_t mix(uint32_t x) {
+    x ^= x >> 16; x *= 0x7FEB352Du; x ^= x >> 15; x *= 0x846CA68Bu; x ^= x >> 16;
+    return x;
+}
+
+template <int MODE>
+__global__ __launch_bounds__(256) void gather(const uint4* __restrict__ tab, uint32_t mask16, int iters, uint32_t* out) {
+    const uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x;
+    uint32_t acc = 0;
+    for (int i = 0; i < iters; ++i) {
+        uint32_t who = (MODE == 3) ? (tid >> 1) : tid;
+        uint32_t h = mix(who * 0x9E3779B1u + uint32_t(i) * 0x85EBCA77u) & mask16;   // index in 16-B units
+        if (MODE == 0) { uint4 v = tab[h]; acc ^= v.x ^ v.w; }
+        else if (MODE == 4) { h &= ~1u; uint4 a = tab[h], b = tab[h + 1]; acc ^= a.x ^ b.w; }
+        else if (MODE == 1) { h &= ~3u; uint4 a = tab[h], b = tab[h + 1], c = tab[h + 2], d = tab[h + 3]; acc ^= a.x ^ b.y ^ c.z ^ d.w; }
+        else if (MODE == 5) {
+            h &= ~3u;
+            const uint32_t* p = reinterpret_cast<const uint32_t*>(tab + h);
+            uint32_t a = __builtin_nontemporal_load(p), b = __builtin_nontemporal_load(p + 5), c = __builtin_nontemporal_load(p + 10), d = __builtin_nontemporal_load(p + 15);
+            acc ^= a ^ b ^ c ^ d;
+        }
+        else if (MODE == 2) {
+            h &= ~7u;
+            uint4 a = tab[h], b = tab[h + 1], c = tab[h + 2], d = tab[h + 3], e = tab[h + 4], f = tab[h + 5], g = tab[h + 6], k = tab[h + 7];
+            acc ^= a.x ^ b.y ^ c.z ^ d.w ^ e.x ^ f.y ^ g.z ^ k.w;
+        } else if (MODE == 3) {
+            h = (h & ~7u) + ((tid & 1u) << 2);
+            uint4 a = tab[h], b = tab[h + 1], c = tab[h + 2], d = tab[h + 3]; acc ^= a.x ^ b.y ^ c.z ^ d.w;
+        }
+    }
+    if (acc == 0x12345678u) out[0] = acc;  // keep the loads alive
+}
+
+template <int MODE>
+double run(const uint4* tab, uint32_t mask16, int blocks, int iters, uint32_t* out) {
+    hipEvent_t a, b; CHECK(hipEventCreate(&a)); CHECK(hipEventCreate(&b));
+    hipLaunchKernelGGL(gather<MODE>, dim3(blocks), dim3(256), 0, 0, tab, mask16, iters, out);
+    CHECK(hipDeviceSynchronize());
+    CHECK(hipEventRecord(a));
+    for (int r = 0; r < 5; ++r) hipLaunchKernelGGL(gather<MODE>, dim3(blocks), dim3(256), 0, 0, tab, mask16, iters, out);
+    CHECK(hipEventRecord(b)); CHECK(hipEventSynchronize(b));
+    float ms = 0; CHECK(hipEventElapsedTime(&ms, a, b));
+    return ms / 5.0;
+}
+
+int main() {
+    const int blocks = 256 * 8, iters = 64;
+    uint32_t* out; CHECK(hipMalloc(&out, 64));
+    const double positions = double(blocks) * 256 * iters;
+    printf("positions per launch: %.1f M (mode 3: half as many records)\n", positions / 1e6);
+    for (int logmb : {1, 2, 5, 7, 9}) {   // 2 MB, 4 MB, 32 MB, 128 MB, 512 MB
+        const size_t bytes = size_t(1) << (20 + logmb);
+        uint4* tab; CHECK(hipMalloc(&tab, bytes + 256)); CHECK(hipMemset(tab, 1, bytes + 256));
+        const uint32_t mask16 = uint32_t(bytes / 16 - 1);
+        double t0 = run<0>(tab, mask16, blocks, iters, out), t4 = run<4>(tab, mask16, blocks, iters, out), t1 = run<1>(tab, mask16, blocks, iters, out);
+        double t5 = run<5>(tab, mask16, blocks, iters, out), t2 = run<2>(tab, mask16, blocks, iters, out), t3 = run<3>(tab, mask16, blocks, iters, out);
+        printf("table %4zu MB | G accesses/s: 16B %.1f | 32B %.1f | 64B %.1f | 64B-nt %.1f | 128B %.1f | pair128B %.1f (records/s %.1f)\n", bytes >> 20,
+               positions / t0 / 1e6, positions / t4 / 1e6, positions / t1 / 1e6, positions / t5 / 1e6, positions / t2 / 1e6, positions / t3 / 1e6, positions / 2 / t3 / 1e6);
+        CHECK(hipFree(tab));
+    }
+    return 0;
+}

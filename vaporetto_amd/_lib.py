@@ -20,7 +20,7 @@ class ModelInfo(C.Structure):
         ("n_tag_models", C.c_uint32), ("bias", C.c_int32), ("char_window", C.c_uint32), ("type_window", C.c_uint32),
         ("max_pattern_chars", C.c_uint32), ("n_short_entries", C.c_uint32), ("n_long_nodes", C.c_uint32),
         ("type_kind", C.c_uint32), ("device_table_bytes", C.c_uint64), ("hot_table_bytes", C.c_uint64),
-        ("packed", C.c_uint32), ("n_displaced", C.c_uint32),
+        ("packed", C.c_uint32), ("n_displaced", C.c_uint32), ("type_rows", C.c_uint32), ("n_overflow_children", C.c_uint32),
     ]
 
     def as_dict(self):

@@ -33,10 +33,11 @@ vpt_status fail(vpt_status st, const std::string& msg) {
     } while (0)
 
 struct DevicePacked {
-    uint32_t *uni = nullptr, *bi = nullptr, *tri = nullptr, *edge = nullptr, *wrows = nullptr;
+    uint32_t *uni = nullptr, *rec = nullptr, *kids3 = nullptr, *deep = nullptr, *trow = nullptr;
+    int32_t* xrows = nullptr;
     void release() {
-        (void)hipFree(uni); (void)hipFree(bi); (void)hipFree(tri); (void)hipFree(edge); (void)hipFree(wrows);
-        uni = bi = tri = edge = wrows = nullptr;
+        (void)hipFree(uni); (void)hipFree(rec); (void)hipFree(kids3); (void)hipFree(deep); (void)hipFree(trow); (void)hipFree(xrows);
+        uni = rec = kids3 = deep = trow = nullptr; xrows = nullptr;
     }
 };
 
@@ -82,10 +83,9 @@ vpt::PackedView make_packed_view(const vpt::HostPackedTable& h, const DevicePack
     vpt::PackedView v{};
     v.present = h.present ? 1u : 0u;
     if (!h.present) return v;
-    v.uni = d.uni; v.bi = d.bi; v.tri = d.tri; v.edge = d.edge; v.wrows = d.wrows;
-    v.bi_shift = 32 - h.bi_bits; v.bi_mask = (1u << h.bi_bits) - 1;
-    v.tri_shift = 32 - h.tri_bits; v.tri_mask = (1u << h.tri_bits) - 1;
-    v.edge_shift = 32 - h.edge_bits; v.edge_mask = (1u << h.edge_bits) - 1;
+    v.uni = d.uni; v.rec = d.rec; v.kids3 = d.kids3; v.deep = d.deep; v.trow = d.trow; v.xrows = d.xrows;
+    v.rec_shift = 32 - h.rec_bits; v.rec_mask = (1u << h.rec_bits) - 1;
+    v.has_trow = h.trow.empty() ? 0u : 1u;
     return v;
 }
 
@@ -100,11 +100,13 @@ void fill_info(const vpt::CompiledModel& c, vpt_model_info* info) {
     info->n_short_entries = c.chars.n_short; info->n_long_nodes = c.chars.n_long_nodes;
     info->type_kind = uint32_t(c.type_kind);
     info->packed = c.packed.present ? 1u : 0u;
-    info->n_displaced = c.packed.present ? c.packed.n_disp_bi + c.packed.n_disp_tri + c.packed.n_disp_edge : c.chars.n_displaced_short;
+    info->n_displaced = c.packed.present ? c.packed.n_disp : c.chars.n_displaced_short;
+    info->type_rows = c.packed.present && !c.packed.trow.empty() ? 1u : 0u;
+    info->n_overflow_children = c.packed.present ? c.packed.n_overflow : 0u;
     // the specialised kernel reads only the packed tables; the general ones stay resident for oversized sentences
     info->device_table_bytes = (c.chars.present ? c.chars.bytes() : 0) + (c.types.present ? c.types.bytes() : 0) +
                                4ull * c.type_table.size() + (c.packed.present ? c.packed.bytes() : 0);
-    info->hot_table_bytes = c.packed.present ? c.packed.bytes() + 4ull * c.type_table.size() : info->device_table_bytes;
+    info->hot_table_bytes = c.packed.present ? c.packed.bytes() + (c.packed.trow.empty() ? 4ull * c.type_table.size() : 0) : info->device_table_bytes;
 }
 
 }  // namespace
@@ -237,10 +239,11 @@ vpt_status vpt_predictor_create(const uint8_t* model_bytes, size_t len, int pred
     up(c.types, p->dt);
     if (c.packed.present) {
         if (e == hipSuccess) e = upload(c.packed.uni, &p->dp.uni);
-        if (e == hipSuccess) e = upload(c.packed.bi, &p->dp.bi);
-        if (e == hipSuccess) e = upload(c.packed.tri, &p->dp.tri);
-        if (e == hipSuccess) e = upload(c.packed.edge, &p->dp.edge);
-        if (e == hipSuccess) e = upload(c.packed.wrows, &p->dp.wrows);
+        if (e == hipSuccess) e = upload(c.packed.rec, &p->dp.rec);
+        if (e == hipSuccess) e = upload(c.packed.kids3, &p->dp.kids3);
+        if (e == hipSuccess) e = upload(c.packed.deep, &p->dp.deep);
+        if (e == hipSuccess) e = upload(c.packed.xrows, &p->dp.xrows);
+        if (e == hipSuccess && !c.packed.trow.empty()) e = upload(c.packed.trow, &p->dp.trow);
     }
     if (e == hipSuccess && c.type_kind == vpt::kTypeWindowTable) e = upload(c.type_table, &p->d_type_table);
     if (e == hipSuccess) {

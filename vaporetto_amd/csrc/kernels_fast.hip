@@ -1,22 +1,27 @@
-// Specialised tile kernel for the model geometry every distributed Vaporetto / KyTea model has:
-// char window 3, char n-grams of at most 3 chars (+ dictionary words of any length), type scores from the
-// 8^(2W) window table (W <= 3) or none.  Same algorithm and tables as kernels.hip (which stays the general
-// path); what changes is how the work is scheduled on a CDNA4 wave:
+// Specialised tile kernel for the model geometry every distributed Vaporetto / KyTea model has: char window 3,
+// BMP patterns (layout.h, "PACKED TABLES"), type scores from type rows in LDS, the 8^(2W) window table (W <= 3) or
+// none.  Same all-matches algorithm as kernels.hip (which stays the general path); what changes is how the work is
+// laid out for a CDNA4 CU, whose limiter on this workload is the number of random memory lines in flight
+// (profiles/r01_c_*: the vector L1's miss queue), not bytes, lanes or VALU:
 //
-//   * geometry is compile-time: level rows are 6/5/4 slots at boundary offsets -3/-2/-1, one bucket = 64 bytes
-//     = four dwordx4 loads, so the per-start-position code is branch-free: the unigram row, the bigram bucket
-//     and the trigram bucket are all requested before anything is compared, the three rows are summed in
-//     registers and land in the LDS score array with six ds_add_u32;
-//   * everything data-dependent -- a lookup that must continue past its home bucket (kDisplacedBit), a non-BMP
-//     unigram, a dictionary word longer than 3 chars walking the trie -- is NOT done in place (64 lanes would
-//     wait for the unluckiest one): it is pushed, ballot/mbcnt-compacted, onto a wave-private LDS stack and
-//     replayed 64 items at a time with every lane busy; a trie step that matches re-queues its continuation.
-//     Trie steps and lookup continuations use separate stacks, so a replay has no per-lane kind divergence;
-//   * UTF-8 decode is two-step: a chunk scan finds (byte position, sentence) of every char, then one thread
-//     per CHAR decodes from the LDS-staged text (branch-free) and classifies it with a 64 KB table;
-//   * 22 KB of LDS per workgroup and <= 64 VGPRs: 7 workgroups = 28 waves per CU.
+//   * one 128-byte RECORD per (c1,c2) prefix holds the bigram row and up to six trigram-level children, so a start
+//     position costs ONE random line; a lane PAIR fetches the two 64-byte halves of a record in the same
+//     instruction (lane 2j and 2j+1 serve position 2j, then position 2j+1), each half validates the key itself,
+//     and the lane that finds the matching child adds its row;
+//   * the unigram row (16 bytes, cache-hot) and the type row (LDS) of the position are summed in registers with
+//     the bigram and child rows and land in the LDS score array with six ds_add_u32 (integer => order-free =>
+//     bit-exact);
+//   * everything data-dependent -- a record displaced from its home slot, a prefix with more than six children
+//     (per-prefix overflow mini-table behind a 64-bit filter), a row with a value outside i16, a dictionary word
+//     longer than 3 chars walking the trie -- is NOT done in place (64 lanes would wait for the unluckiest one): it
+//     is pushed, ballot/mbcnt-compacted, onto a wave-private LDS stack and replayed 64 items at a time with every
+//     lane busy; a trie step that matches re-queues its continuation;
+//   * UTF-8 decode is two-step: a chunk scan finds (byte position, sentence) of every char, then one thread per
+//     CHAR decodes from the LDS-staged text (branch-free) and classifies it with a 64 KB table;
+//   * 23-31 KB of LDS per workgroup, <= 64 VGPRs: 5-7 workgroups per CU (the time is flat from 5 up).
 #include <hip/hip_runtime.h>
 
+#include <cstddef>
 #include <cstdlib>
 
 #include "device_common.h"
@@ -26,10 +31,11 @@ namespace vpt {
 namespace {
 
 constexpr int kQCap = 256;                   // deferred items per wave (both stacks together)
-constexpr uint32_t kQHigh = kQCap - 128;     // replay until one more iteration (<= 64 + 64 pushes) fits
-constexpr uint32_t kCpMask = 0xFFFFu;        // sym = char (non-BMP -> 0xFFFF) | tile-local sentence index << 16
+constexpr uint32_t kQHigh = kQCap - 128;     // replay until one more round of pushes (<= 64 + 64) fits
+constexpr uint32_t kCpMask = 0xFFFFu;        // sym = char (>= 0xFFFF -> 0xFFFF) | type << 16 | tile-local sentence << 19
 constexpr int kPerThread = kFastCap / kThreads;
 constexpr int kWavesF = kThreads / 64;
+constexpr int kTypeRows = 4;                 // TM value: type rows in LDS (1..3 = window table of that W, 0 = none)
 
 struct FastLds {
     uint32_t sym[kFastCap + kMargin];        // decode step 1 keeps (byte pos | sentence << 16) per char here
@@ -37,12 +43,16 @@ struct FastLds {
     uint2 queue[kWavesF][kQCap];             // sentence-start bitmap during decode
     uint8_t typ[kFastCap + kMargin];
     uint32_t wtot[8];
+    uint4 trow[512];                         // type rows (only allocated for TM == kTypeRows)
 };
-static_assert(sizeof(FastLds) <= 23400, "7 workgroups per CU need <= 22.8 KB each");
-static_assert((kFastCap + kMargin) * 4 % 16 == 0, "carve offsets stay 16-byte aligned");
+static_assert(offsetof(FastLds, trow) <= 23400, "7 workgroups per CU need <= 22.8 KB each (window-table modes)");
+static_assert(offsetof(FastLds, trow) % 16 == 0 && (kFastCap + kMargin) * 4 % 16 == 0, "carve offsets stay 16-byte aligned");
 
 __device__ __forceinline__ uint32_t lane_rank(uint64_t mask) {  // set bits of `mask` below this lane
     return __builtin_amdgcn_mbcnt_hi(uint32_t(mask >> 32), __builtin_amdgcn_mbcnt_lo(uint32_t(mask), 0u));
+}
+__device__ __forceinline__ uint32_t pair_swap(uint32_t x) {  // value of lane ^ 1 (DPP quad_perm [1,0,3,2])
+    return uint32_t(__builtin_amdgcn_update_dpp(0, int(x), 0xB1, 0xF, 0xF, false));
 }
 
 // branch-free UTF-8 -> scalar value; b4 = the lead byte and the three bytes after it, little-endian
@@ -59,8 +69,9 @@ __device__ __forceinline__ uint32_t utf8_scalar_bf(uint32_t b4) {
 }
 
 // Two stacks in one wave-private buffer: trie steps grow from the bottom, lookup continuations from the top.
-//   trie step      x = s | depth << 11          y = parent id (layout.h: tri slot, or kPackedEdgeId | edge slot)
-//   continuation   x = s | levels << 11 (bit 1: bigram, bit 2: trigram lookup to be continued past its home slot)
+//   trie step      x = s | depth << 11     y = mini-table ref (in `deep`) of the children to search
+//   continuation   x = s | kinds << 11     y = overflow mini-table ref (kind kOvProbe)
+constexpr uint32_t kRecMore = 1u, kOvProbe = 2u, kWideUni = 4u, kWideBi = 8u, kWideTri = 16u;
 struct WaveStacks {
     uint2* q;
     uint32_t nw, nr;  // wave-uniform counts
@@ -87,8 +98,13 @@ __device__ __forceinline__ void add_row6(int32_t* score, uint32_t s, int32_t a0,
     atomicAdd(p, a0); atomicAdd(p + 1, a1); atomicAdd(p + 2, a2);
     atomicAdd(p + 3, a3); atomicAdd(p + 4, a4); atomicAdd(p + 5, a5);
 }
+// a trigram-level child row: boundaries s-1 .. s+2
+__device__ __forceinline__ void add_child(int32_t* score, uint32_t s, uint32_t w01, uint32_t w23) {
+    int32_t* p = score + s - 1;
+    atomicAdd(p, lo16(w01)); atomicAdd(p + 1, hi16(w01)); atomicAdd(p + 2, lo16(w23)); atomicAdd(p + 3, hi16(w23));
+}
 
-// Up to 64 queued trie steps, all lanes busy: the edge (parent, sym[s + depth]).
+// Up to 64 queued trie steps, all lanes busy: the child sym[s + depth] in the mini-table `ref` of `deep`.
 __device__ __forceinline__ void replay_walk(const PackedView& K, FastLds& L, WaveStacks& Q, int lane) {
     const uint32_t take = Q.nw < 64u ? Q.nw : 64u;
     Q.nw -= take;
@@ -100,42 +116,31 @@ __device__ __forceinline__ void replay_walk(const PackedView& K, FastLds& L, Wav
     bool again = false;
     uint32_t nx = 0, ny = 0;
     if (c != 0) {
-        const uint4* tab = reinterpret_cast<const uint4*>(K.edge);
-        uint32_t b = packed_hash2(it.y, c, K.edge_shift);
-        bool home = true;
-        for (;;) {
-            const uint4 e = tab[b];
-            if (e.x == it.y && (e.y & 0xFFFFu) == c) {
+        const uint4* tab = reinterpret_cast<const uint4*>(K.deep) + size_t(it.y >> 5) * 2;
+        const uint32_t last = (1u << (it.y & 31u)) - 1u;
+        uint32_t i = packed_mini_slot(c, it.y);
+        for (uint32_t n = 0; n <= last; ++n) {
+            const uint4 e = tab[size_t(i) * 2];
+            if ((e.x & 0xFFFFu) == c) {
                 const uint32_t m = depth + 1;  // chars matched so far: a pattern of m chars has m + 1 weights,
-                if (e.y & (kPkHasRow << 16)) {  // the first on boundary s - 1
-                    const uint4* wr = reinterpret_cast<const uint4*>(K.wrows) + e.z;
-                    int32_t* dst = L.score + s - 1;
-                    if (e.y & (kPkWide << 16)) {  // a value outside i16: the row is stored as i32 (rare)
-                        const int32_t* w32 = reinterpret_cast<const int32_t*>(wr);
-                        for (uint32_t j = 0; j <= m; ++j) atomicAdd(dst + j, w32[j]);
-                        if (e.y & (kPkHasKids << 16)) { again = true; nx = s | (m << 11); ny = kPackedEdgeId | b; }
-                        break;
-                    }
-                    const uint4 r = wr[0];
-                    atomicAdd(dst, lo16(r.x)); atomicAdd(dst + 1, hi16(r.x)); atomicAdd(dst + 2, lo16(r.y));
-                    atomicAdd(dst + 3, hi16(r.y)); atomicAdd(dst + 4, lo16(r.z));  // m >= 4
-                    if (m >= 5) atomicAdd(dst + 5, hi16(r.z));
-                    if (m >= 6) atomicAdd(dst + 6, lo16(r.w));
-                    if (m >= 7) atomicAdd(dst + 7, hi16(r.w));
-                    for (uint32_t j0 = 8; j0 <= m; j0 += 8) {
-                        const uint4 q = wr[j0 >> 3];
-                        const uint32_t w[4] = {q.x, q.y, q.z, q.w};
+                int32_t* dst = L.score + s - 1;  // the first on boundary s - 1
+                if (e.x & (kPkHasRow << 16)) {
+                    const uint4 f = tab[size_t(i) * 2 + 1];
+                    atomicAdd(dst, lo16(e.z)); atomicAdd(dst + 1, hi16(e.z)); atomicAdd(dst + 2, lo16(e.w));
+                    atomicAdd(dst + 3, hi16(e.w)); atomicAdd(dst + 4, lo16(f.x));  // m >= 4
+                    const uint32_t w[4] = {f.x, f.y, f.z, f.w};
 #pragma unroll
-                        for (uint32_t j = 0; j < 8; ++j)
-                            if (j0 + j <= m) atomicAdd(dst + j0 + j, (j & 1) ? hi16(w[j >> 1]) : lo16(w[j >> 1]));
-                    }
+                    for (uint32_t j = 5; j < kPackedInlineRow; ++j)
+                        if (j <= m) atomicAdd(dst + j, (j & 1) ? hi16(w[(j - 4) >> 1]) : lo16(w[(j - 4) >> 1]));
+                } else if (e.x & (kPkExtRow << 16)) {  // longer than 11 chars or a value outside i16: i32 row
+                    const int32_t* w32 = K.xrows + e.z;
+                    for (uint32_t j = 0; j <= m; ++j) atomicAdd(dst + j, w32[j]);
                 }
-                if (e.y & (kPkHasKids << 16)) { again = true; nx = s | (m << 11); ny = kPackedEdgeId | b; }
+                if (e.y != 0) { again = true; nx = s | (m << 11); ny = e.y; }
                 break;
             }
-            if (e.y == 0 || (home && !(e.y & (kPkDisp << 16)))) break;
-            home = false;
-            b = (b + 1) & K.edge_mask;
+            if (e.x == 0) break;
+            i = (i + 1) & last;
         }
     }
     Q.push_walk(again, nx, ny);
@@ -158,61 +163,79 @@ __device__ __forceinline__ bool general_row(const PatternTableView& T, uint64_t 
     }
 }
 
-// Up to 64 queued lookup continuations for start position s.  levels: 2 / 4 = the bigram / trigram lookup goes on
-// past its home slot; 1 / 8 / 16 = the unigram / bigram / trigram row is kPkWide and comes from the general tables.
+// Up to 64 queued lookup continuations for start position s (kinds: see WaveStacks).
 __device__ __forceinline__ void replay_retry(const PackedView& K, const PatternTableView& T, FastLds& L, WaveStacks& Q, int lane) {
     const uint32_t take = Q.nr < 64u ? Q.nr : 64u;
     Q.nr -= take;
     const bool have = uint32_t(lane) < take;
     const uint2 it = have ? Q.q[kQCap - 1 - (Q.nr + lane)] : make_uint2(0u, 0u);
     const uint32_t s = it.x & 0x7FFu;
-    uint32_t levels = have ? (it.x >> 11) & 31u : 0u;
+    uint32_t kinds = have ? (it.x >> 11) & 31u : 0u;
+    uint32_t ov_ref = it.y;
     bool walk = false;
-    uint32_t parent = 0;
+    uint32_t kids = 0;
     const uint32_t c1 = L.sym[s] & kCpMask, c2 = L.sym[s + 1] & kCpMask, c3 = L.sym[s + 2] & kCpMask;
     const uint32_t kb = c1 | (c2 << 16);
-    if (levels & 2u) {
-        const uint4* tab = reinterpret_cast<const uint4*>(K.bi);
-        uint32_t b = packed_hash1(kb, K.bi_shift);
+    if (kinds & kRecMore) {  // the record is not in its home slot: look in the following ones
+        const uint4* rec4 = reinterpret_cast<const uint4*>(K.rec);
+        uint32_t b = packed_hash1(kb, K.rec_shift);
         for (;;) {
-            b = (b + 1) & K.bi_mask;
-            const uint4 e = tab[b];
-            if (e.x == kb) {
-                if (e.w & (kPkWide << 16)) levels |= 8u;
-                else add_row6(L.score, s, 0, lo16(e.y), hi16(e.y), lo16(e.z), hi16(e.z), lo16(e.w));
+            b = (b + 1) & K.rec_mask;
+            const uint4* r = rec4 + size_t(b) * 8;
+            const uint4 h0 = r[0];
+            if (h0.x == kb) {
+                if (h0.w & (kPkWide << 16)) kinds |= kWideBi;
+                else add_row6(L.score, s, 0, lo16(h0.y), hi16(h0.y), lo16(h0.z), hi16(h0.z), lo16(h0.w));
+                if (c3 != 0) {
+                    bool hit = false;
+#pragma unroll
+                    for (int j = 0; j < 6; ++j) {
+                        const uint4 ch = r[j < 3 ? 1 + j : 2 + j];
+                        if (!hit && (ch.x & 0xFFFFu) == c3) {
+                            hit = true;
+                            if (ch.x & (kPkWide << 16)) kinds |= kWideTri; else add_child(L.score, s, ch.y, ch.z);
+                            if (ch.w != 0) { walk = true; kids = ch.w; }
+                        }
+                    }
+                    if (!hit && (h0.w & (kPkOv << 16))) {
+                        const uint4 h1 = r[4];
+                        const uint32_t bit = packed_filter_bit(c3);
+                        if (((bit < 32 ? h1.z >> bit : h1.w >> (bit - 32)) & 1u) != 0) { kinds |= kOvProbe; ov_ref = h1.y; }
+                    }
+                }
                 break;
             }
-            if (e.x == 0) break;
+            if (h0.x == 0) break;
         }
     }
-    if (levels & 4u) {
-        const uint4* tab = reinterpret_cast<const uint4*>(K.tri);
-        uint32_t b = packed_hash2(kb, c3, K.tri_shift);
-        for (;;) {
-            b = (b + 1) & K.tri_mask;
-            const uint4 e = tab[b];
-            if (e.x == kb && (e.y & 0xFFFFu) == c3) {
-                if (e.y & (kPkWide << 16)) levels |= 16u;
-                else add_row6(L.score, s, 0, 0, lo16(e.z), hi16(e.z), lo16(e.w), hi16(e.w));
-                if (e.y & (kPkHasKids << 16)) { walk = true; parent = b; }
+    if (kinds & kOvProbe) {  // a prefix with more than six children: its overflow mini-table
+        const uint4* tab = reinterpret_cast<const uint4*>(K.kids3) + (ov_ref >> 5);
+        const uint32_t last = (1u << (ov_ref & 31u)) - 1u;
+        uint32_t i = packed_mini_slot(c3, ov_ref);
+        for (uint32_t n = 0; n <= last; ++n) {
+            const uint4 ch = tab[i];
+            if ((ch.x & 0xFFFFu) == c3) {
+                if (ch.x & (kPkWide << 16)) kinds |= kWideTri; else add_child(L.score, s, ch.y, ch.z);
+                if (ch.w != 0) { walk = true; kids = ch.w; }
                 break;
             }
-            if (e.x == 0) break;
+            if (ch.x == 0) break;
+            i = (i + 1) & last;
         }
     }
-    if (levels & 25u) {  // wide rows (rare): i32 rows of the general tables
+    if (kinds & (kWideUni | kWideBi | kWideTri)) {  // rows with a value outside i16 (rare): general tables, i32
         uint4 r0, r1;
-        if (levels & 1u) {
+        if (kinds & kWideUni) {
             const uint4* u = reinterpret_cast<const uint4*>(T.uni) + size_t(c1) * 2;
             r0 = u[0]; r1 = u[1];
             add_row6(L.score, s, int32_t(r0.x), int32_t(r0.y), int32_t(r0.z), int32_t(r0.w), int32_t(r1.x), int32_t(r1.y));
         }
-        if ((levels & 8u) && general_row(T, short_key(c1, c2, 0), r0, r1))
+        if ((kinds & kWideBi) && general_row(T, short_key(c1, c2, 0), r0, r1))
             add_row6(L.score, s, 0, int32_t(r0.z), int32_t(r0.w), int32_t(r1.x), int32_t(r1.y), int32_t(r1.z));
-        if ((levels & 16u) && general_row(T, short_key(c1, c2, c3), r0, r1))
+        if ((kinds & kWideTri) && general_row(T, short_key(c1, c2, c3), r0, r1))
             add_row6(L.score, s, 0, 0, int32_t(r0.z), int32_t(r0.w), int32_t(r1.x), int32_t(r1.y));
     }
-    Q.push_walk(walk, s | (3u << 11), parent);
+    Q.push_walk(walk, s | (3u << 11), kids);
 }
 
 __device__ __forceinline__ void make_room(const PackedView& K, const PatternTableView& T, FastLds& L, WaveStacks& Q, int lane) {
@@ -230,7 +253,25 @@ __device__ __forceinline__ uint64_t phase_mark(uint64_t* prof, int slot, uint64_
     return now;
 }
 
-template <int WT>
+// One half (64 bytes: q0 = H0 or H1, q1..q3 = children) of the record of the position (o_s, o_kb, o_c3) this lane
+// serves in the current sub-round: as OWNER (its own position, half 0) or as HELPER (its pair partner's, half 1).
+struct HalfResult {
+    bool hit;        // a child matched in this half
+    uint32_t w01, w23, kids, cflags;
+};
+__device__ __forceinline__ HalfResult match_children(bool keyok_has3, uint32_t c3, const uint4& q1, const uint4& q2, const uint4& q3) {
+    const bool m1 = keyok_has3 && (q1.x & 0xFFFFu) == c3, m2 = keyok_has3 && (q2.x & 0xFFFFu) == c3;
+    const bool m3 = keyok_has3 && (q3.x & 0xFFFFu) == c3;
+    HalfResult r;
+    r.hit = m1 || m2 || m3;
+    r.w01 = m1 ? q1.y : m2 ? q2.y : m3 ? q3.y : 0u;
+    r.w23 = m1 ? q1.z : m2 ? q2.z : m3 ? q3.z : 0u;
+    r.kids = m1 ? q1.w : m2 ? q2.w : m3 ? q3.w : 0u;
+    r.cflags = (m1 ? q1.x : m2 ? q2.x : m3 ? q3.x : 0u) >> 16;
+    return r;
+}
+
+template <int TM>
 __global__ __launch_bounds__(kThreads) void score_tiles_fast_kernel(const ScoreParams P) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     FastLds& L = *reinterpret_cast<FastLds*>(smem);
@@ -256,6 +297,9 @@ __global__ __launch_bounds__(kThreads) void score_tiles_fast_kernel(const ScoreP
     const uint32_t expect_chars = uint32_t((O1 + i1) - (O0 + i0));
     const uint32_t nchunks = (nbytes_al + 15) >> 4;
     uint32_t err = 0;
+    if (TM == kTypeRows) {  // 512 type rows -> LDS (not aliased by the decode scratch; barriers follow before use)
+        for (uint32_t i = tid; i < 512u; i += kThreads) L.trow[i] = reinterpret_cast<const uint4*>(P.pk.trow)[i];
+    }
     uint64_t* const prof = P.prof;
     uint64_t tmark = prof ? __builtin_amdgcn_s_memtime() : 0;
 
@@ -356,7 +400,7 @@ __global__ __launch_bounds__(kThreads) void score_tiles_fast_kernel(const ScoreP
         if (meta[k] == 0xFFFFFFFFu) continue;
         const uint32_t flat = meta[k] & 0xFFFu, cp = cps[k];
         const uint32_t ty = cp < 0x10000u ? uint32_t(P.ctype[cp]) : char_type(cp);
-        L.sym[flat] = (cp < kPackedNoMatchSym ? cp : kPackedNoMatchSym) | (meta[k] & 0xFFFF0000u);
+        L.sym[flat] = (cp < kPackedNoMatchSym ? cp : kPackedNoMatchSym) | (ty << 16) | ((meta[k] >> 16) << 19);
         L.typ[flat] = uint8_t(ty);
         if (meta[k] & 0x8000u) {
 #pragma unroll
@@ -370,45 +414,84 @@ __global__ __launch_bounds__(kThreads) void score_tiles_fast_kernel(const ScoreP
     const PackedView& K = P.pk;
     WaveStacks Q{&L.queue[wave][0], 0u, 0u};
     const uint4* uni4 = reinterpret_cast<const uint4*>(K.uni);
-    const uint4* bi4 = reinterpret_cast<const uint4*>(K.bi);
-    const uint4* tri4 = reinterpret_cast<const uint4*>(K.tri);
+    const uint4* rec4 = reinterpret_cast<const uint4*>(K.rec);
+    const uint32_t odd = uint32_t(lane) & 1u;
     for (int k = 0; k < kPerThread; ++k) {
         const uint32_t s = uint32_t(tid) + uint32_t(k) * kThreads;
         if (s - uint32_t(lane) >= flat_len) break;  // wave-uniform: this wave's 64 positions are past the tile
-        const uint32_t c1 = s < flat_len ? (L.sym[s] & kCpMask) : 0u;
-        const uint32_t c2 = L.sym[s + 1] & kCpMask, c3 = L.sym[s + 2] & kCpMask;
+        const uint32_t x1 = s < flat_len ? L.sym[s] : 0u, x2 = L.sym[s + 1], x3 = L.sym[s + 2];
+        const uint32_t c1 = x1 & kCpMask, c2 = x2 & kCpMask, c3 = x3 & kCpMask;
         const bool live = c1 != 0;
         const bool has2 = live && c2 != 0;
         const bool has3 = has2 && c3 != 0;
         const uint32_t kb = c1 | (c2 << 16);
-        uint32_t hb = packed_hash1(kb, K.bi_shift), ht = packed_hash2(kb, c3, K.tri_shift);
-        if (P.debug) {  // timing ablations (VPT_DEBUG_ABLATE; results are wrong): pin a lookup to slot 0
-            if (P.debug & 1u) hb = 0;
-            if (P.debug & 2u) ht = 0;
-        }
-        // the three loads first (row 0 of `uni` and whatever slot a dead lane hashes to are harmless to read)
+        uint32_t hrec = packed_hash1(kb, K.rec_shift);
+        if (P.debug & 1u) hrec = 0;  // timing ablation (VPT_DEBUG_ABLATE; results are wrong): pin the record
+        const uint32_t c3f = c3 | (has2 ? 0x10000u : 0u) | (has3 ? 0x20000u : 0u);
+        // the pair partner's position (s ^ 1): sub-round 0 serves the even lane's position, sub-round 1 the odd one's
+        const uint32_t p_kb = pair_swap(kb), p_c3f = pair_swap(c3f), p_hrec = pair_swap(hrec);
+        const uint32_t kbA = odd ? p_kb : kb, c3fA = odd ? p_c3f : c3f, hA = odd ? p_hrec : hrec;  // sub-round 0
+        const uint32_t kbB = odd ? kb : p_kb, c3fB = odd ? c3f : p_c3f, hB = odd ? hrec : p_hrec;  // sub-round 1
+        // every load first: the unigram row, then per sub-round this lane's 64-byte half (owner: half 0)
         const uint4 u = uni4[(P.debug & 4u) ? 0u : c1];
-        const uint4 eb = bi4[hb];
-        const uint4 et = tri4[ht];
-        const bool mb = has2 && eb.x == kb;
-        const bool mt = has3 && et.x == kb && (et.y & 0xFFFFu) == c3;
-        const bool moreb = has2 && !mb && (eb.w & (kPkDisp << 16));
-        const bool moret = has3 && !mt && (et.y & (kPkDisp << 16));
-        const uint32_t b1 = mb ? eb.y : 0u, b2 = mb ? eb.z : 0u, b3 = mb ? eb.w : 0u;
-        const uint32_t t2 = mt ? et.z : 0u, t3 = mt ? et.w : 0u;
-        const int32_t a0 = lo16(u.x);
-        const int32_t a1 = hi16(u.x) + lo16(b1);
-        const int32_t a2 = lo16(u.y) + hi16(b1) + lo16(t2);
-        const int32_t a3 = hi16(u.y) + lo16(b2) + hi16(t2);
-        const int32_t a4 = lo16(u.z) + hi16(b2) + lo16(t3);
-        const int32_t a5 = hi16(u.z) + lo16(b3) + hi16(t3);
-        if (live) add_row6(L.score, s, a0, a1, a2, a3, a4, a5);
-
+        const uint4* pa = rec4 + size_t(hA) * 8 + odd * 4;
+        const uint4* pb = rec4 + size_t(hB) * 8 + (odd ^ 1u) * 4;
+        const uint4 a0 = pa[0], a1 = pa[1], a2 = pa[2], a3 = pa[3];
+        const uint4 b0 = pb[0], b1 = pb[1], b2 = pb[2], b3 = pb[3];
+        // own row so far: unigram (+ type row)
+        int32_t r0 = lo16(u.x), r1 = hi16(u.x), r2 = lo16(u.y), r3 = hi16(u.y), r4 = lo16(u.z), r5 = hi16(u.z);
+        if (TM == kTypeRows) {
+            const uint4 tr = L.trow[((x1 >> 16) & 7u) | (((x2 >> 16) & 7u) << 3) | (((x3 >> 16) & 7u) << 6)];
+            // six 18-bit signed fields at bits 0, 18, 36, 54, 72, 90 (layout.h, trow_field)
+            r0 += int32_t(tr.x << 14) >> 14;
+            r1 += int32_t(__builtin_amdgcn_alignbit(tr.y, tr.x, 18) << 14) >> 14;
+            r2 += int32_t(tr.y << 10) >> 14;
+            r3 += int32_t(__builtin_amdgcn_alignbit(tr.z, tr.y, 22) << 14) >> 14;
+            r4 += int32_t(tr.z << 6) >> 14;
+            r5 += int32_t(__builtin_amdgcn_alignbit(tr.w, tr.z, 26) << 14) >> 14;
+        }
+        uint32_t kinds = (live && u.w != 0) ? kWideUni : 0u;   // continuation kinds of the OWN position
+        uint32_t h_kinds = 0, h_ref = 0;                        // ... of the partner's position, found as helper
+        bool walk_own = false, walk_help = false;
+        uint32_t kids_own = 0, kids_help = 0;
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            const uint4& q0 = r == 0 ? a0 : b0;
+            const uint4& q1 = r == 0 ? a1 : b1;
+            const uint4& q2 = r == 0 ? a2 : b2;
+            const uint4& q3 = r == 0 ? a3 : b3;
+            const uint32_t o_kb = r == 0 ? kbA : kbB, o_c3f = r == 0 ? c3fA : c3fB;
+            const bool owner = (odd != 0) == (r != 0);
+            const bool keyok = (o_c3f & 0x10000u) && q0.x == o_kb;
+            const HalfResult ch = match_children(keyok && (o_c3f & 0x20000u), o_c3f & 0xFFFFu, q1, q2, q3);
+            const bool partner_hit = pair_swap(ch.hit ? 1u : 0u) != 0;
+            if (owner) {
+                const uint32_t y = keyok ? q0.y : 0u, z = keyok ? q0.z : 0u, w = keyok ? q0.w : 0u;
+                r1 += lo16(y); r2 += hi16(y) + lo16(ch.w01); r3 += lo16(z) + hi16(ch.w01);
+                r4 += hi16(z) + lo16(ch.w23); r5 += lo16(w) + hi16(ch.w23);
+                if ((o_c3f & 0x10000u) && !keyok && (q0.w & (kPkDisp << 16))) kinds |= kRecMore;
+                if (w & (kPkWide << 16)) kinds |= kWideBi;
+                if (ch.cflags & kPkWide) kinds |= kWideTri;
+                walk_own = ch.kids != 0; kids_own = ch.kids;
+            } else {
+                if (ch.hit && !(ch.cflags & kPkWide)) add_child(L.score, s ^ 1u, ch.w01, ch.w23);
+                if (ch.cflags & kPkWide) h_kinds |= kWideTri;
+                walk_help = ch.kids != 0; kids_help = ch.kids;
+                // H1 = {kb, overflow ref, filter lo, filter hi}: children beyond the six inline ones
+                if (keyok && (o_c3f & 0x20000u) && !ch.hit && !partner_hit && q0.y != 0 && !(P.debug & 2u)) {
+                    const uint32_t bit = packed_filter_bit(o_c3f & 0xFFFFu);
+                    if (((bit < 32 ? q0.z >> bit : q0.w >> (bit - 32)) & 1u) != 0) { h_kinds |= kOvProbe; h_ref = q0.y; }
+                }
+            }
+        }
+        if (live) add_row6(L.score, s, r0, r1, r2, r3, r4, r5);
+        const bool nowalk = (P.debug & 8u) != 0;
         make_room(K, P.ct, L, Q, lane);
-        Q.push_walk(mt && (et.y & (kPkHasKids << 16)) && !(P.debug & 8u), s | (3u << 11), ht);
-        const uint32_t levels = ((live && u.w != 0) ? 1u : 0u) | (moreb ? 2u : 0u) | (moret ? 4u : 0u) |
-                                ((mb && (eb.w & (kPkWide << 16))) ? 8u : 0u) | ((mt && (et.y & (kPkWide << 16))) ? 16u : 0u);
-        Q.push_retry(levels != 0, s | (levels << 11), 0u);
+        Q.push_walk(walk_own && !nowalk, s | (3u << 11), kids_own);
+        Q.push_retry(kinds != 0, s | (kinds << 11), 0u);
+        make_room(K, P.ct, L, Q, lane);
+        Q.push_walk(walk_help && !nowalk, (s ^ 1u) | (3u << 11), kids_help);
+        Q.push_retry(h_kinds != 0, (s ^ 1u) | (h_kinds << 11), h_ref);
     }
     while (Q.nr > 0) replay_retry(K, P.ct, L, Q, lane);
     while (Q.nw > 0) replay_walk(K, L, Q, lane);
@@ -421,13 +504,13 @@ __global__ __launch_bounds__(kThreads) void score_tiles_fast_kernel(const ScoreP
         const uint32_t x = L.sym[p];
         if ((x & kCpMask) == 0 || (L.sym[p + 1] & kCpMask) == 0) continue;
         int32_t y = P.bias + L.score[p];
-        if (WT > 0) {
+        if (TM >= 1 && TM <= 3) {
             uint32_t id = 0;  // window t[b-W+1 .. b+W], 3 bits each (boundary_scorer_cache.rs:59-81)
 #pragma unroll
-            for (int i = 1 - WT; i <= WT; ++i) id = (id << 3) | L.typ[int(p) + i];
+            for (int i = 1 - TM; i <= TM; ++i) id = (id << 3) | L.typ[int(p) + i];
             y += P.type_table[id];
         }
-        const uint32_t si = x >> 16;
+        const uint32_t si = x >> 19;
         const uint64_t o = O0 + (p - pad) - uint64_t(pad + 1) * si;
         if (P.scores) P.scores[o] = y;
         if (P.labels) P.labels[o] = y > 0 ? 1 : 0;
@@ -446,14 +529,16 @@ bool fast_path_supported(const ScoreParams& P) {
 }
 
 hipError_t launch_score_tiles_fast(const ScoreParams& P, uint32_t n_tiles, hipStream_t stream) {
-    size_t lds = sizeof(FastLds);
+    const bool rows = P.type_kind == kTypeWindowTable && P.pk.has_trow && !std::getenv("VPT_FORCE_WINDOW_TABLE");
+    size_t lds = rows ? sizeof(FastLds) : offsetof(FastLds, trow);
     if (const char* padv = std::getenv("VPT_DEBUG_LDS_PAD")) lds += size_t(std::atoi(padv));  // occupancy experiments
-    const int wt = P.type_kind == kTypeWindowTable ? P.type_window : 0;
-    switch (wt) {
+    const int tm = rows ? kTypeRows : P.type_kind == kTypeWindowTable ? P.type_window : 0;
+    switch (tm) {
         case 0: hipLaunchKernelGGL(score_tiles_fast_kernel<0>, dim3(n_tiles), dim3(kThreads), lds, stream, P); break;
         case 1: hipLaunchKernelGGL(score_tiles_fast_kernel<1>, dim3(n_tiles), dim3(kThreads), lds, stream, P); break;
         case 2: hipLaunchKernelGGL(score_tiles_fast_kernel<2>, dim3(n_tiles), dim3(kThreads), lds, stream, P); break;
         case 3: hipLaunchKernelGGL(score_tiles_fast_kernel<3>, dim3(n_tiles), dim3(kThreads), lds, stream, P); break;
+        case 4: hipLaunchKernelGGL(score_tiles_fast_kernel<4>, dim3(n_tiles), dim3(kThreads), lds, stream, P); break;
         default: return hipErrorInvalidValue;
     }
     return hipGetLastError();

@@ -34,28 +34,47 @@
 //
 // PACKED TABLES (specialised kernel, kernels_fast.hip).  Every model a Vaporetto / KyTea trainer produces has
 // char window 3, weights quantised to 16 bits (trainer.rs:18,383-397; kytea_model.rs:72-79) and BMP-only patterns.
-// For such models -- W = 3, every pattern symbol in [1, 0xFFFE], every merged row value within i16 -- the same
-// all-matches tables are also emitted with 16-BYTE entries, so that one lookup is ONE dwordx4 load per lane
-// (the kernel is bound by the number of divergent vector-memory lane requests, not by bytes):
+// For such models -- W = 3, every pattern symbol in [1, 0xFFFE] -- the same all-matches information is also emitted
+// in a layout shaped by what bounds the kernel on MI355X: the number of random memory LINES touched per start
+// position (tools/gather_bench.hip: a random 128-byte line read by a lane PAIR costs the same as a random 16-byte
+// read, ~57 G/s chip-wide out of L2), not bytes and not lane requests.  So everything the patterns starting with
+// (c1, c2) need at depth 2 and 3 lives in ONE 128-byte record:
 //
-//   uni    65536 rows, indexed by the char:   {w[0..5] i16 (boundaries s-3 .. s+2), 0}
-//   bi     open addressing, key = c1 | c2<<16 {key, w[0..4] i16 (boundaries s-2 .. s+2), flags u16}
-//   tri    key = (c1 | c2<<16, c3)            {c1|c2<<16, c3 | flags<<16, w[0..3] i16 (boundaries s-1 .. s+2)}
-//          holds every 3-char pattern and the 3-char prefix of every longer one (zero weights).
-//   edge   trie of the patterns longer than 3 chars, key = (parent id, sym):
-//                                             {parent, sym | flags<<16, row offset (16-byte units), 0}
-//          parent id = slot index of the 3-char prefix in `tri`, or kPackedEdgeId | slot index in `edge`.
-//   wrows  i16 weight rows of those patterns (a pattern of m chars has m+1 weights, boundaries s-1 .. s+m-1),
-//          each row padded to a multiple of 16 bytes.
+//   uni    65536 rows of 16 bytes, indexed by c1: {w[0..5] i16 (boundaries s-3 .. s+2), flags}      (L1/L2-hot)
+//   rec    open addressing over 128-byte records keyed by kb = c1 | c2 << 16, two self-validating 64-byte halves:
+//            half 0: H0 = {kb, w0|w1<<16, w2|w3<<16, w4 | flags<<16}   bigram row (boundaries s-2 .. s+2), zero
+//                         when (c1,c2) is only a prefix; flags: kPkDisp, kPkWide, kPkOv
+//                    C1..C3 = children, each {c3 | cflags<<16, w0|w1<<16, w2|w3<<16, kids}   (boundaries s-1 .. s+2)
+//            half 1: H1 = {kb, overflow ref, mask lo, mask hi}
+//                    C4..C6
+//          A child = a 3-char pattern and/or the 3-char prefix of longer ones; `kids` = mini-table ref of its
+//          depth-4 children in `deep` (0: none); cflags: kPkWide.  Unused child slots are zero (c3 = 0 never
+//          matches).  A prefix with more than 6 children keeps 6 inline and the rest in a mini-table of `kids3`
+//          (kPkOv, H1.y); H1.z/w is a 64-bit filter over hash6(c3) of those overflow children.
+//   kids3  16-byte entries, same format as an inline child.
+//   deep   32-byte entries for trie nodes at depth m >= 4:
+//            {sym | dflags<<16, kids, w0|w1<<16, w2|w3<<16} {w4|w5<<16 ... w10|w11<<16}
+//          the row of a pattern of m chars has m+1 weights (boundaries s-1 .. s+m-1) and sits inline when m <= 11
+//          and every value fits i16 (kPkHasRow); otherwise kPkExtRow and dword 2 = offset of an i32 row in `xrows`.
+//   mini-table ref = base << 5 | log2(size): `size` consecutive entries of one arena holding the children of ONE
+//          node (so a hot node's children are contiguous and cache-hot together); entry index
+//          (sym * kHashMulLo >> 15) & (size-1), linear probing inside the mini-table, at most `size` probes,
+//          an entry with dword 0 == 0 ends the search.  Entry 0 of each arena is unused so that ref 0 = none.
 //
-// A key lives in its home slot hash(key) or, if that was taken, in the next free slot (linear probing).  The
-// flags of a SLOT carry kPkDisp when some key whose home is this slot lives further on: a lookup that finds
-// neither its key nor kPkDisp in the home slot is done after one load; otherwise it is continued (replayed)
-// until the key or an empty slot is met.  Empty slot: bi/tri dword 0 == 0, edge dword 1 == 0.
-// kPkWide marks a row with a value outside i16 (an n-gram and a dictionary word with the same string can sum past
-// 16 bits): a uni/bi/tri slot then keeps zero weights and the row is taken from the general tables above
-// (`uni` row flag: dword 3 == kPkWide); an edge's row in `wrows` is then stored as i32.
-// A text char >= 0x10000 is mapped to 0xFFFF before lookups: no pattern contains either, so it matches nothing.
+// A record key lives at hash(kb) or, if that was taken, in the next free record (linear probing); H0 carries
+// kPkDisp when some key homed there lives further on, so a lookup that finds neither its key nor kPkDisp is over
+// after one line.  kPkWide marks a row with a value outside i16 (an n-gram and a dictionary word with the same
+// string can sum past 16 bits): the slot keeps zero weights and the row comes from the general tables above
+// (`uni` row flag: dword 3 == kPkWide).  A text char >= 0xFFFF is mapped to 0xFFFF before lookups: no pattern
+// contains it, so it matches nothing.
+//
+// TYPE ROWS.  When every type n-gram has at most 3 symbols and W_t <= 3 (the trainer's defaults), the type scores
+// are folded into the same start-position form: trow[t1 | t2<<3 | t3<<6] = the six totals (boundaries
+// s-3 .. s+2; 18-bit signed fields, three i16 weights always fit) of the type unigram t1, bigram (t1,t2) and
+// trigram (t1,t2,t3) -- 512 rows of 16 bytes that the
+// kernel keeps in LDS, which removes the per-boundary gather from the 8^(2W) window table.  Code 0 (outside the
+// sentence) only ever appears as t2/t3 and selects the shorter n-grams, exactly what the window table encodes
+// (boundary_scorer_cache.rs:30-57).  Models outside this shape use the window table (W_t <= 3) as before.
 #pragma once
 #include <cstdint>
 #if defined(__HIPCC__)
@@ -74,9 +93,10 @@ constexpr uint32_t kShortBucket = 2;             // entries per bucket of the sh
 constexpr uint32_t kEdgeBucket = 4;              // edges per bucket of the trie edge table
 constexpr uint32_t kHashMulLo = 0x9E3779B1u, kHashMulHi = 0x85EBCA77u;
 
-constexpr uint32_t kPkDisp = 1u, kPkHasKids = 2u, kPkHasRow = 4u, kPkWide = 8u;  // flags of a packed slot
-constexpr uint32_t kPackedEdgeId = 0x80000000u;                    // parent ids that name an `edge` slot
+constexpr uint32_t kPkDisp = 1u, kPkExtRow = 2u, kPkHasRow = 4u, kPkWide = 8u, kPkOv = 16u;  // packed flags
 constexpr uint32_t kPackedNoMatchSym = 0xFFFFu;
+constexpr uint32_t kPackedInlineKids = 6;      // children held by a record itself
+constexpr uint32_t kPackedInlineRow = 12;      // weights a `deep` entry holds inline
 
 #if defined(__HIPCC__)
 #define VPT_HD __host__ __device__ __forceinline__
@@ -93,9 +113,19 @@ VPT_HD uint32_t hash_slot(uint64_t key, uint32_t shift) {
     return (uint32_t(key) * kHashMulLo + uint32_t(key >> 32) * kHashMulHi) >> shift;
 }
 
-// packed-table hashes; `shift` = 32 - log2(capacity)
+// packed-table hashes; `shift` = 32 - log2(capacity in records)
 VPT_HD uint32_t packed_hash1(uint32_t k, uint32_t shift) { return (k * kHashMulLo) >> shift; }
-VPT_HD uint32_t packed_hash2(uint32_t a, uint32_t b, uint32_t shift) { return (a * kHashMulLo + b * kHashMulHi) >> shift; }
+VPT_HD uint32_t packed_mini_slot(uint32_t sym, uint32_t ref) { return ((sym * kHashMulLo) >> 15) & ((1u << (ref & 31u)) - 1u); }
+VPT_HD uint32_t packed_filter_bit(uint32_t sym) { return (sym * kHashMulHi) >> 26; }   // 0..63
+
+// type row: six 18-bit signed fields packed little-endian into dwords 0..3 (bits 0..107)
+VPT_HD int32_t trow_field(uint32_t x, uint32_t y, uint32_t z, uint32_t w, int j) {
+    const uint64_t lo = uint64_t(x) | (uint64_t(y) << 32), hi = uint64_t(z) | (uint64_t(w) << 32);
+    const int bit = 18 * j;
+    uint64_t v = bit < 64 ? (lo >> bit) : (hi >> (bit - 64));
+    if (bit < 64 && bit + 18 > 64) v |= hi << (64 - bit);
+    return int32_t(uint32_t(v) << 14) >> 14;
+}
 
 // geometry of the row of a pattern of n symbols under window W (see the header comment)
 VPT_HD int row_lo(int n, int W) { return (n - 1 - W) < -1 ? (n - 1 - W) : -1; }
@@ -123,9 +153,11 @@ struct PatternTableView {
 
 // Device view of the packed tables; passed to the specialised kernel by value.
 struct PackedView {
-    const uint32_t *uni, *bi, *tri, *edge, *wrows;   // 16-byte entries (uint4)
-    uint32_t bi_shift, bi_mask, tri_shift, tri_mask, edge_shift, edge_mask;
+    const uint32_t *uni, *rec, *kids3, *deep, *trow;   // 16-byte units (uint4)
+    const int32_t* xrows;
+    uint32_t rec_shift, rec_mask;   // hash shift and mask in RECORDS
     uint32_t present;
+    uint32_t has_trow;              // type rows available (else: window table / none)
 };
 
 }  // namespace vpt

@@ -211,154 +211,202 @@ HostPatternTable build_table(std::vector<Pat>& pats, int W, uint32_t uni_n) {
 
 // ---- packed tables (layout.h, "PACKED TABLES").  `pats` must already be sorted and merged (build_table did it).
 // Not eligible (present = false) when a pattern symbol is outside [1, 0xFFFE]: the general tables/kernel handle
-// such a model.  A merged row with a value outside i16 (the same string as n-gram AND dictionary word can sum past
-// 16 bits) keeps its slot with zero weights and kPkWide: the kernel then takes the row from the general tables
-// (patterns of <= 3 chars) or reads the row as i32 (longer patterns).
+// such a model.  A merged row with a value outside i16 keeps its slot with zero weights and kPkWide (patterns of
+// <= 3 chars: the kernel takes the row from the general tables) or goes to `xrows` as i32 (longer patterns).
 inline bool fits_i16(int32_t v) { return v >= -32768 && v <= 32767; }
 inline uint32_t pack16(int32_t lo, int32_t hi) { return (uint32_t(lo) & 0xFFFFu) | (uint32_t(hi) << 16); }
 
-struct PackedInserter {
-    std::vector<uint32_t>& tab;
-    uint32_t bits, mask;
-    int empty_dw;   // the dword whose value 0 marks an empty slot
-    int flag_dw;    // flags live in the HIGH half of this dword
-    uint32_t n_disp = 0, max_probe = 0;
-    PackedInserter(std::vector<uint32_t>& t, size_t count, int empty_dw_, int flag_dw_) : tab(t), empty_dw(empty_dw_), flag_dw(flag_dw_) {
-        bits = bits_for(count);
-        mask = (1u << bits) - 1;
-        tab.assign((size_t(1) << bits) * 4, 0);
-    }
-    // places {d0..d3} at home or the next free slot; returns the slot
-    uint32_t insert(uint32_t home, uint32_t d0, uint32_t d1, uint32_t d2, uint32_t d3) {
-        uint32_t s = home, probes = 1;
-        while (tab[size_t(s) * 4 + empty_dw] != 0) { s = (s + 1) & mask; ++probes; }
-        max_probe = std::max(max_probe, probes);
-        uint32_t* d = &tab[size_t(s) * 4];
-        d[0] = d0; d[1] = d1; d[2] = d2; d[3] = d3;
-        if (s != home) { tab[size_t(home) * 4 + flag_dw] |= kPkDisp << 16; ++n_disp; }
-        return s;
-    }
-};
+// mini-table (layout.h): `size` consecutive entries of `dw` dwords each; returns the ref, entries zeroed
+uint32_t mini_alloc(std::vector<uint32_t>& arena, uint32_t dw, size_t count) {
+    uint32_t lg = 0;
+    const size_t want = count <= 2 ? count : count + count / 3 + 1;
+    while ((size_t(1) << lg) < want) ++lg;
+    const size_t base = arena.size() / dw;
+    if (base >= (size_t(1) << 27)) throw ModelError("InvalidModelError: too many patterns for the packed tables");
+    arena.resize(arena.size() + (size_t(dw) << lg), 0);
+    return uint32_t(base << 5) | lg;
+}
+uint32_t* mini_insert(std::vector<uint32_t>& arena, uint32_t dw, uint32_t ref, uint32_t sym) {
+    const uint32_t size = 1u << (ref & 31u), base = ref >> 5;
+    uint32_t i = packed_mini_slot(sym, ref);
+    while (arena[(size_t(base) + i) * dw] != 0) i = (i + 1) & (size - 1);   // count <= size: a free entry exists
+    return &arena[(size_t(base) + i) * dw];
+}
 
 HostPackedTable build_packed(const std::vector<Pat>& pats) {
     HostPackedTable t;
-    for (const Pat& p : pats) {
+    for (const Pat& p : pats)
         for (Sym c : p.s)
             if (c == 0 || c >= kPackedNoMatchSym) return t;
-    }
     auto wide = [](const Pat& p) {
         for (int32_t v : p.row)
             if (!fits_i16(v)) return true;
         return false;
     };
     t.uni.assign(size_t(65536) * 4, 0);
-    struct Node { uint32_t parent; Sym sym; uint32_t depth; const Pat* pat; uint32_t kids; uint32_t id; };
-    // trigram-level keys: patterns of 3 chars and 3-char prefixes of longer ones
-    struct Tri { const Pat* pat; uint32_t kids; uint32_t slot; };
-    std::unordered_map<uint64_t, uint32_t> tri_of;   // short_key -> index in tris
-    std::vector<Tri> tris;
-    std::vector<uint64_t> tri_keys;
-    std::vector<Node> nodes;                          // trie nodes of depth >= 4
-    std::unordered_map<uint64_t, uint32_t> child_of;  // (parent ref << 21 | sym) -> index in nodes; parent ref: tri index or 2^31 | node index
-    auto tri_index = [&](const SymString& s) {
-        const uint64_t k = short_key(s[0], s[1], s[2]);
-        auto it = tri_of.find(k);
-        if (it != tri_of.end()) return it->second;
-        const uint32_t i = uint32_t(tris.size());
-        tris.push_back({nullptr, 0, 0});
-        tri_keys.push_back(k);
-        tri_of.emplace(k, i);
-        return i;
-    };
-    size_t n_bi = 0;
+
+    // ---- trie over the patterns of >= 2 chars: prefixes (depth 2) own nodes (depth >= 3)
+    struct Node { Sym sym; uint32_t depth; const Pat* pat; std::vector<uint32_t> kids; uint32_t ref; };
+    struct Prefix { uint32_t key; const Pat* pat; std::vector<uint32_t> kids; };
+    std::vector<Node> nodes;
+    std::vector<Prefix> prefixes;
+    std::unordered_map<uint32_t, uint32_t> prefix_of;
+    std::unordered_map<uint64_t, uint32_t> pchild, nchild;   // (prefix | node index) << 21 | sym -> node index
+    uint32_t max_depth = 0;
     for (const Pat& p : pats) {
         const size_t n = p.s.size();
         if (n == 1) {
             uint32_t* d = &t.uni[size_t(p.s[0]) * 4];
             if (wide(p)) { d[3] = kPkWide; ++t.n_wide; }
             else { d[0] = pack16(p.row[0], p.row[1]); d[1] = pack16(p.row[2], p.row[3]); d[2] = pack16(p.row[4], p.row[5]); }
-        } else if (n == 2) ++n_bi;
-        else if (n == 3) tris[tri_index(p.s)].pat = &p;
-        else {
-            uint32_t ti = tri_index(p.s);
-            uint64_t ref = ti;           // parent reference
-            uint32_t* kids = nullptr;
-            for (size_t i = 3; i < n; ++i) {
-                const uint64_t ck = (ref << 21) | p.s[i];
-                auto it = child_of.find(ck);
-                uint32_t ni;
-                if (it == child_of.end()) {
-                    ni = uint32_t(nodes.size());
-                    nodes.push_back({uint32_t(ref), p.s[i], uint32_t(i + 1), nullptr, 0, 0});
-                    child_of.emplace(ck, ni);
-                    if (ref & kPackedEdgeId) ++nodes[ref & ~kPackedEdgeId].kids; else ++tris[ref].kids;
-                } else ni = it->second;
-                ref = uint64_t(kPackedEdgeId) | ni;
-            }
-            (void)kids;
-            nodes[ref & ~kPackedEdgeId].pat = &p;
+            continue;
         }
+        const uint32_t key = p.s[0] | (p.s[1] << 16);
+        auto it = prefix_of.find(key);
+        uint32_t pi;
+        if (it == prefix_of.end()) {
+            pi = uint32_t(prefixes.size());
+            prefixes.push_back({key, nullptr, {}});
+            prefix_of.emplace(key, pi);
+        } else pi = it->second;
+        if (n == 2) { prefixes[pi].pat = &p; continue; }
+        uint32_t cur = 0;
+        for (size_t i = 2; i < n; ++i) {
+            auto& map = (i == 2) ? pchild : nchild;
+            const uint64_t ck = (uint64_t(i == 2 ? pi : cur) << 21) | p.s[i];
+            auto f = map.find(ck);
+            if (f == map.end()) {
+                const uint32_t ni = uint32_t(nodes.size());
+                nodes.push_back({p.s[i], uint32_t(i + 1), nullptr, {}, 0});
+                map.emplace(ck, ni);
+                if (i == 2) prefixes[pi].kids.push_back(ni); else nodes[cur].kids.push_back(ni);
+                cur = ni;
+            } else cur = f->second;
+        }
+        nodes[cur].pat = &p;
+        max_depth = std::max<uint32_t>(max_depth, uint32_t(n));
     }
-    // bigrams
-    {
-        PackedInserter ins(t.bi, n_bi, 0, 3);
-        for (const Pat& p : pats) {
-            if (p.s.size() != 2) continue;
-            const uint32_t key = p.s[0] | (p.s[1] << 16);
-            // flags share dword 3 with w[4]: insert() only ORs into the high half
-            if (wide(p)) { ins.insert(packed_hash1(key, 32 - ins.bits), key, 0, 0, kPkWide << 16); ++t.n_wide; }
-            else ins.insert(packed_hash1(key, 32 - ins.bits), key, pack16(p.row[0], p.row[1]), pack16(p.row[2], p.row[3]), pack16(p.row[4], 0));
-        }
-        t.bi_bits = ins.bits; t.n_bi = uint32_t(n_bi); t.n_disp_bi = ins.n_disp; t.max_probe = std::max(t.max_probe, ins.max_probe);
-    }
-    // trigram level
-    {
-        PackedInserter ins(t.tri, tris.size(), 0, 1);
-        for (size_t i = 0; i < tris.size(); ++i) {
-            const uint64_t k = tri_keys[i];
-            const uint32_t c1 = uint32_t(k & 0x1FFFFF), c2 = uint32_t((k >> 21) & 0x1FFFFF), c3 = uint32_t(k >> 42);
-            const uint32_t klo = c1 | (c2 << 16);
-            const Pat* p = tris[i].pat;
-            uint32_t fl = tris[i].kids ? kPkHasKids : 0u;
-            if (p && wide(*p)) { fl |= kPkWide; p = nullptr; ++t.n_wide; }
-            tris[i].slot = ins.insert(packed_hash2(klo, c3, 32 - ins.bits), klo, c3 | (fl << 16),
-                                      p ? pack16(p->row[0], p->row[1]) : 0u, p ? pack16(p->row[2], p->row[3]) : 0u);
-        }
-        t.tri_bits = ins.bits; t.n_tri = uint32_t(tris.size()); t.n_disp_tri = ins.n_disp; t.max_probe = std::max(t.max_probe, ins.max_probe);
-    }
-    // deeper levels, one depth at a time (a child's key needs its parent's slot)
-    {
-        PackedInserter ins(t.edge, nodes.size(), 1, 1);
-        std::vector<std::vector<uint32_t>> by_depth;
-        for (uint32_t i = 0; i < nodes.size(); ++i) {
-            if (nodes[i].depth >= by_depth.size()) by_depth.resize(nodes[i].depth + 1);
-            by_depth[nodes[i].depth].push_back(i);
-        }
-        for (const auto& level : by_depth) {
-            for (uint32_t i : level) {
-                Node& nd = nodes[i];
-                const uint32_t parent = (nd.parent & kPackedEdgeId) ? (kPackedEdgeId | nodes[nd.parent & ~kPackedEdgeId].id) : tris[nd.parent].slot;
-                uint32_t fl = nd.kids ? kPkHasKids : 0u, woff = 0;
-                if (nd.pat) {
-                    fl |= kPkHasRow;
-                    woff = uint32_t(t.wrows.size() / 4);
-                    const std::vector<int32_t>& r = nd.pat->row;   // depth + 1 values, first = boundary s - 1
-                    if (wide(*nd.pat)) {
-                        fl |= kPkWide;
-                        ++t.n_wide;
-                        for (int32_t v : r) t.wrows.push_back(uint32_t(v));
-                    } else
-                        for (size_t j = 0; j < r.size(); j += 2) t.wrows.push_back(pack16(r[j], j + 1 < r.size() ? r[j + 1] : 0));
-                    while (t.wrows.size() % 4) t.wrows.push_back(0);
+    t.n_deep = 0;
+
+    // ---- deep arena: the children mini-table of every node, deepest nodes first (an entry names its own kids' table)
+    t.deep.assign(8, 0);    // entry 0 unused: ref 0 = none
+    t.kids3.assign(4, 0);
+    std::vector<std::vector<uint32_t>> by_depth(max_depth + 1);
+    for (uint32_t i = 0; i < nodes.size(); ++i) by_depth[nodes[i].depth].push_back(i);
+    for (uint32_t d = max_depth; d >= 3 && d <= max_depth; --d) {
+        for (uint32_t ni : by_depth[d]) {
+            Node& nd = nodes[ni];
+            if (nd.kids.empty()) continue;
+            nd.ref = mini_alloc(t.deep, 8, nd.kids.size());
+            for (uint32_t ki : nd.kids) {
+                const Node& k = nodes[ki];
+                uint32_t* e = mini_insert(t.deep, 8, nd.ref, k.sym);
+                uint32_t fl = 0;
+                if (k.pat) {
+                    const std::vector<int32_t>& r = k.pat->row;   // depth + 1 values, first = boundary s - 1
+                    if (r.size() <= kPackedInlineRow && !wide(*k.pat)) {
+                        fl |= kPkHasRow;
+                        for (size_t j = 0; j < r.size(); j += 2) e[2 + j / 2] = pack16(r[j], j + 1 < r.size() ? r[j + 1] : 0);
+                    } else {
+                        fl |= kPkExtRow;
+                        if (wide(*k.pat)) ++t.n_wide;
+                        e[2] = uint32_t(t.xrows.size());
+                        t.xrows.insert(t.xrows.end(), r.begin(), r.end());
+                    }
                 }
-                nd.id = ins.insert(packed_hash2(parent, nd.sym, 32 - ins.bits), parent, nd.sym | (fl << 16), woff, 0);
+                e[0] = k.sym | (fl << 16);
+                e[1] = k.ref;
+                ++t.n_deep;
             }
         }
-        t.edge_bits = ins.bits; t.n_edge = uint32_t(nodes.size()); t.n_disp_edge = ins.n_disp; t.max_probe = std::max(t.max_probe, ins.max_probe);
     }
-    if (t.wrows.empty()) t.wrows.assign(4, 0);
+    if (t.xrows.empty()) t.xrows.push_back(0);
+
+    // ---- records
+    auto child_entry = [&](uint32_t* e, const Node& k) {
+        uint32_t fl = 0;
+        if (k.pat && wide(*k.pat)) { fl |= kPkWide; ++t.n_wide; }
+        else if (k.pat) { e[1] = pack16(k.pat->row[0], k.pat->row[1]); e[2] = pack16(k.pat->row[2], k.pat->row[3]); }
+        e[0] = k.sym | (fl << 16);
+        e[3] = k.ref;
+    };
+    t.rec_bits = bits_for(prefixes.size());
+    const uint32_t rmask = (1u << t.rec_bits) - 1;
+    t.rec.assign((size_t(1) << t.rec_bits) * 32, 0);
+    for (const Prefix& pf : prefixes) {
+        const uint32_t home = packed_hash1(pf.key, 32 - t.rec_bits);
+        uint32_t b = home, probes = 1;
+        while (t.rec[size_t(b) * 32] != 0) { b = (b + 1) & rmask; ++probes; }
+        t.max_probe = std::max(t.max_probe, probes);
+        if (b != home) { t.rec[size_t(home) * 32 + 3] |= kPkDisp << 16; ++t.n_disp; }
+        uint32_t* r = &t.rec[size_t(b) * 32];
+        uint32_t fl = 0;
+        r[0] = pf.key; r[16] = pf.key;
+        if (pf.pat && wide(*pf.pat)) { fl |= kPkWide; ++t.n_wide; }
+        else if (pf.pat) {
+            r[1] = pack16(pf.pat->row[0], pf.pat->row[1]); r[2] = pack16(pf.pat->row[2], pf.pat->row[3]);
+            r[3] = pack16(pf.pat->row[4], 0);
+        }
+        const size_t nk = pf.kids.size(), n_in = std::min<size_t>(nk, kPackedInlineKids);
+        for (size_t j = 0; j < n_in; ++j) child_entry(r + (j < 3 ? 4 + 4 * j : 20 + 4 * (j - 3)), nodes[pf.kids[j]]);
+        if (nk > n_in) {
+            fl |= kPkOv;
+            const uint32_t ref = mini_alloc(t.kids3, 4, nk - n_in);
+            uint64_t mask = 0;
+            for (size_t j = n_in; j < nk; ++j) {
+                const Node& k = nodes[pf.kids[j]];
+                child_entry(mini_insert(t.kids3, 4, ref, k.sym), k);
+                mask |= uint64_t(1) << packed_filter_bit(k.sym);
+            }
+            r[17] = ref; r[18] = uint32_t(mask); r[19] = uint32_t(mask >> 32);
+            t.n_overflow += uint32_t(nk - n_in);
+        }
+        r[3] |= fl << 16;
+        t.n_children += uint32_t(nk);
+    }
+    t.n_rec = uint32_t(prefixes.size());
     t.present = true;
     return t;
+}
+
+// Type rows (layout.h, "TYPE ROWS"); empty when the n-grams do not fit the form.  `ngrams` already passed the
+// window-table builder's validity checks.
+std::vector<uint32_t> build_type_rows(const std::vector<NgramRecord>& ngrams, int W) {
+    std::vector<int32_t> uni(8 * 6, 0), bi(64 * 6, 0), tri(512 * 6, 0);
+    for (const NgramRecord& d : ngrams) {
+        const int n = int(d.ngram.size());
+        bool usable = true;
+        for (Sym s : d.ngram)
+            if (s == 0 || s > 6) usable = false;   // can never match a character type
+        if (!usable || d.weights.empty()) continue;
+        if (n > 3) return {};
+        uint32_t idx = 0;
+        for (int i = 0; i < n; ++i) idx |= d.ngram[size_t(i)] << (3 * i);
+        int32_t* row = n == 1 ? &uni[idx * 6] : n == 2 ? &bi[idx * 6] : &tri[idx * 6];
+        for (size_t k = 0; k < d.weights.size(); ++k) {
+            const int slot = (n - 1 - W + int(k)) + 3;   // boundary start + n-1-W+k  (type_scorer/boundary_scorer.rs:48)
+            if (slot < 0 || slot > 5) return {};
+            row[slot] = wadd(row[slot], d.weights[k]);
+        }
+    }
+    std::vector<uint32_t> out(size_t(512) * 4, 0);
+    for (uint32_t idx = 0; idx < 512; ++idx) {
+        const uint32_t t1 = idx & 7, t2 = (idx >> 3) & 7, t3 = idx >> 6;
+        if (t1 == 0 || t1 == 7) continue;
+        int64_t r[6];
+        for (int j = 0; j < 6; ++j) {
+            r[j] = uni[t1 * 6 + j];
+            if (t2 >= 1 && t2 <= 6) {
+                r[j] += bi[(t1 | t2 << 3) * 6 + j];
+                if (t3 >= 1 && t3 <= 6) r[j] += tri[idx * 6 + j];
+            }
+            if (r[j] < -131072 || r[j] > 131071) return {};   // 18-bit fields
+        }
+        unsigned __int128 bits = 0;
+        for (int j = 0; j < 6; ++j) bits |= (unsigned __int128)(uint64_t(r[j]) & 0x3FFFFu) << (18 * j);
+        for (int q = 0; q < 4; ++q) out[idx * 4 + q] = uint32_t(bits >> (32 * q));
+    }
+    return out;
 }
 
 // TypeScorerBoundaryCache::new (boundary_scorer_cache.rs:22-57): scores[seq] for every window of 2W type codes
@@ -479,6 +527,7 @@ CompiledModel compile_model(const ModelData& m, bool predict_tags) {
         if (!tags_on && wt <= 3) {
             c.type_kind = kTypeWindowTable;
             c.type_table = build_type_window_table(m.type_ngrams, wt);
+            if (c.packed.present) c.packed.trow = build_type_rows(m.type_ngrams, wt);
         } else {
             if (wt > kMaxWindow) throw ModelError("InvalidModelError: type_window_size above 8 is not supported");
             c.type_kind = kTypePatternTable;

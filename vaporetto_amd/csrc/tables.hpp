@@ -28,17 +28,19 @@ struct HostPatternTable {
     }
 };
 
-// Packed tables of the specialised kernel (layout.h, "packed tables"): 16-byte entries, i16 weights.
+// Packed tables of the specialised kernel (layout.h, "PACKED TABLES").
 struct HostPackedTable {
     bool present = false;          // false: the model is not eligible (see build notes in tables.cpp)
     std::vector<uint32_t> uni;     // 65536 rows x 4 dwords
-    std::vector<uint32_t> bi, tri, edge;  // 4 dwords per slot
-    std::vector<uint32_t> wrows;   // i16 rows of patterns longer than 3 chars, each padded to 16 bytes
-    uint32_t bi_bits = 4, tri_bits = 4, edge_bits = 4;
+    std::vector<uint32_t> rec;     // 32 dwords per record
+    std::vector<uint32_t> kids3;   // 4 dwords per entry
+    std::vector<uint32_t> deep;    // 8 dwords per entry
+    std::vector<int32_t> xrows;    // external i32 rows
+    std::vector<uint32_t> trow;    // 512 type rows x 4 dwords, empty when the type n-grams do not fit the form
+    uint32_t rec_bits = 4;
     // statistics
-    uint32_t n_bi = 0, n_tri = 0, n_edge = 0, n_disp_bi = 0, n_disp_tri = 0, n_disp_edge = 0;
-    uint32_t max_probe = 0, n_wide = 0;
-    uint64_t bytes() const { return 4ull * (uni.size() + bi.size() + tri.size() + edge.size() + wrows.size()); }
+    uint32_t n_rec = 0, n_children = 0, n_overflow = 0, n_deep = 0, n_disp = 0, max_probe = 0, n_wide = 0;
+    uint64_t bytes() const { return 4ull * (uni.size() + rec.size() + kids3.size() + deep.size() + xrows.size() + trow.size()); }
 };
 
 enum TypeKind : int { kTypeNone = 0, kTypeWindowTable = 1, kTypePatternTable = 2 };
