@@ -62,7 +62,7 @@ int tc_trow_present(const tc_model* t) { return t->c.packed.present && !t->c.pac
 void tc_stats(const tc_model* t, uint32_t out[8]) {
     const HostPackedTable& k = t->c.packed;
     out[0] = k.n_rec; out[1] = k.n_children; out[2] = k.n_overflow; out[3] = k.n_deep; out[4] = k.n_disp;
-    out[5] = k.max_probe; out[6] = k.n_wide; out[7] = uint32_t(k.bytes() >> 10);
+    out[5] = k.max_probe; out[6] = k.n_wide; out[7] = k.n_left;
 }
 
 namespace {
@@ -132,10 +132,44 @@ int tc_score(const tc_model* t, const uint32_t* cps, size_t n, int32_t* y_out, u
             add(y, S - 2, lo16(r[1])); add(y, S - 1, hi16(r[1])); add(y, S, lo16(r[2]));
             add(y, S + 1, hi16(r[2])); add(y, S + 2, lo16(r[3]));
         }
+        // a trigram-level child (row + deeper walk) of the string that starts at position `st`
+        auto apply_child = [&](long st, uint32_t k1, uint32_t k2, uint32_t k3, const uint32_t* ch) -> int {
+            if (ch[0] & (kPkWide << 16)) {
+                const uint32_t* g = general_find(G, short_key(k1, k2, k3));
+                if (!g) return -2;
+                for (int j = 0; j < 4; ++j) add(y, st - 1 + j, int32_t(g[2 + j]));
+            } else { add(y, st - 1, lo16(ch[1])); add(y, st, hi16(ch[1])); add(y, st + 1, lo16(ch[2])); add(y, st + 2, hi16(ch[2])); }
+            uint32_t ref = ch[3], depth = 3;
+            while (ref != 0) {
+                const size_t at = size_t(st) + depth;
+                const uint32_t c = sym[at < n ? at : n];
+                if (c == 0) break;
+                const uint32_t* e = mini_find(K.deep, 8, ref, c, &probes[2]);
+                if (!e) break;
+                const uint32_t m = depth + 1;
+                if (e[0] & (kPkHasRow << 16)) {
+                    for (uint32_t j = 0; j <= m; ++j) add(y, st - 1 + long(j), (j & 1) ? hi16(e[2 + (j >> 1)]) : lo16(e[2 + (j >> 1)]));
+                } else if (e[0] & (kPkExtRow << 16)) {
+                    for (uint32_t j = 0; j <= m; ++j) add(y, st - 1 + long(j), K.xrows[size_t(e[2]) + j]);
+                }
+                ref = e[1];
+                depth = m;
+            }
+            return 0;
+        };
+        // LEFT children: the string (c0,c1,c2) that started one position earlier
+        const uint32_t c0 = s > 0 ? sym[s - 1] : 0u;
+        if (c0 != 0) {
+            for (int j = 0; j < 3; ++j) {
+                const uint32_t* e = r + 20 + 4 * j;
+                if ((e[0] & 0xFFFFu) == c0) { if (apply_child(S - 1, c0, c1, c2, e) != 0) return -2; break; }
+            }
+        }
         if (c3 == 0) continue;
+        // RIGHT children, then the overflow mini-table behind its filter
         const uint32_t* ch = nullptr;
-        for (int j = 0; j < 6 && !ch; ++j) {
-            const uint32_t* e = r + (j < 3 ? 4 + 4 * j : 20 + 4 * (j - 3));
+        for (int j = 0; j < 3 && !ch; ++j) {
+            const uint32_t* e = r + 4 + 4 * j;
             if ((e[0] & 0xFFFFu) == c3) ch = e;
         }
         if (!ch && (r[3] & (kPkOv << 16))) {
@@ -143,27 +177,7 @@ int tc_score(const tc_model* t, const uint32_t* cps, size_t n, int32_t* y_out, u
             if ((mask >> packed_filter_bit(c3)) & 1) ch = mini_find(K.kids3, 4, r[17], c3, &probes[1]);
             else ++probes[3];
         }
-        if (!ch) continue;
-        if (ch[0] & (kPkWide << 16)) {
-            const uint32_t* g = general_find(G, short_key(c1, c2, c3));
-            if (!g) return -2;
-            for (int j = 0; j < 4; ++j) add(y, S - 1 + j, int32_t(g[2 + j]));
-        } else { add(y, S - 1, lo16(ch[1])); add(y, S, hi16(ch[1])); add(y, S + 1, lo16(ch[2])); add(y, S + 2, hi16(ch[2])); }
-        uint32_t ref = ch[3], depth = 3;
-        while (ref != 0) {
-            const uint32_t c = sym[s + depth < n ? s + depth : n];
-            if (c == 0) break;
-            const uint32_t* e = mini_find(K.deep, 8, ref, c, &probes[2]);
-            if (!e) break;
-            const uint32_t m = depth + 1;
-            if (e[0] & (kPkHasRow << 16)) {
-                for (uint32_t j = 0; j <= m; ++j) add(y, S - 1 + long(j), (j & 1) ? hi16(e[2 + (j >> 1)]) : lo16(e[2 + (j >> 1)]));
-            } else if (e[0] & (kPkExtRow << 16)) {
-                for (uint32_t j = 0; j <= m; ++j) add(y, S - 1 + long(j), K.xrows[size_t(e[2]) + j]);
-            }
-            ref = e[1];
-            depth = m;
-        }
+        if (ch && apply_child(S, c1, c2, c3, ch) != 0) return -2;
     }
     std::memcpy(y_out, y.data(), y.size() * sizeof(int32_t));
     return K.trow.empty() ? 1 : 2;

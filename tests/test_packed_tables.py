@@ -49,7 +49,7 @@ class Walker:
     def stats(self):
         a = (C.c_uint32 * 8)()
         self.L.tc_stats(self.h, C.byref(a))
-        return dict(zip(["n_rec", "n_children", "n_overflow", "n_deep", "n_disp", "max_probe", "n_wide", "kib"], list(a)))
+        return dict(zip(["n_rec", "n_children", "n_overflow", "n_deep", "n_disp", "max_probe", "n_wide", "n_left"], list(a)))
 
     @property
     def trow(self):
@@ -98,7 +98,7 @@ def test_packed_walk_dense_tables_exercise_displacement(tc):
     w = Walker(tc, raw)
     assert w.packed
     st = w.stats()
-    assert st["n_disp"] > 0 and st["n_overflow"] > 0
+    assert st["n_disp"] > 0 and st["n_overflow"] > 0 and st["n_left"] > 0
     orc = cbind.OraclePredictor(raw)
     probes = [0, 0, 0, 0]
     for t in randmodel.rand_sentences(5, m, 400, alphabet=alpha, max_len=80):

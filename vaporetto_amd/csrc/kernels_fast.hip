@@ -1,24 +1,23 @@
 // Specialised tile kernel for the model geometry every distributed Vaporetto / KyTea model has: char window 3,
 // BMP patterns (layout.h, "PACKED TABLES"), type scores from type rows in LDS, the 8^(2W) window table (W <= 3) or
 // none.  Same all-matches algorithm as kernels.hip (which stays the general path); what changes is how the work is
-// laid out for a CDNA4 CU, whose limiter on this workload is the number of random memory lines in flight
-// (profiles/r01_c_*: the vector L1's miss queue), not bytes, lanes or VALU:
+// laid out for a CDNA4 CU, whose limiters on this workload are the number of random memory lines in flight
+// (profiles/r01_c_*: the vector L1's miss queue) and, once those are few, instruction issue (profiles/r01_d_*):
 //
-//   * one 128-byte RECORD per (c1,c2) prefix holds the bigram row and up to six trigram-level children, so a start
-//     position costs ONE random line; a lane PAIR fetches the two 64-byte halves of a record in the same
-//     instruction (lane 2j and 2j+1 serve position 2j, then position 2j+1), each half validates the key itself,
-//     and the lane that finds the matching child adds its row;
-//   * the unigram row (16 bytes, cache-hot) and the type row (LDS) of the position are summed in registers with
-//     the bigram and child rows and land in the LDS score array with six ds_add_u32 (integer => order-free =>
-//     bit-exact);
-//   * everything data-dependent -- a record displaced from its home slot, a prefix with more than six children
-//     (per-prefix overflow mini-table behind a 64-bit filter), a row with a value outside i16, a dictionary word
-//     longer than 3 chars walking the trie -- is NOT done in place (64 lanes would wait for the unluckiest one): it
-//     is pushed, ballot/mbcnt-compacted, onto a wave-private LDS stack and replayed 64 items at a time with every
-//     lane busy; a trie step that matches re-queues its continuation;
+//   * one 128-byte RECORD per (c1,c2) prefix holds the bigram row, three right children (c1,c2,c3) and three left
+//     children (c0,c1,c2), so a start position costs ONE random line; the lane reads the whole record (8 x 16 B)
+//     right after its unigram row, before anything is compared;
+//   * the unigram row (16 bytes, cache-hot), the type row (LDS), the bigram row and the matching right child are
+//     summed in registers and land in the LDS score array with six ds_add_u32 (integer => order-free => bit-exact);
+//     a matching left child adds its four values one position earlier;
+//   * everything data-dependent is NOT done in place (64 lanes would wait for the unluckiest one): it is pushed,
+//     ballot/mbcnt-compacted, onto wave-private LDS stacks -- one per kind, so that a replay runs one short code
+//     path with every lane busy: W trie steps of dictionary words longer than 3 chars (a step that matches
+//     re-queues its continuation), O overflow-child probes (prefixes whose children fit neither side), M the rare
+//     rest (a record displaced from its home slot, rows with a value outside i16);
 //   * UTF-8 decode is two-step: a chunk scan finds (byte position, sentence) of every char, then one thread per
 //     CHAR decodes from the LDS-staged text (branch-free) and classifies it with a 64 KB table;
-//   * 23-31 KB of LDS per workgroup, <= 64 VGPRs: 5-7 workgroups per CU (the time is flat from 5 up).
+//   * 26-32 KB of LDS per workgroup: 5-6 workgroups per CU (the time is flat from 5 up).
 #include <hip/hip_runtime.h>
 
 #include <cstddef>
@@ -30,29 +29,31 @@
 namespace vpt {
 namespace {
 
-constexpr int kQCap = 256;                   // deferred items per wave (both stacks together)
+constexpr int kQCap = 256;                   // W + O items per wave (W grows from the bottom, O from the top)
 constexpr uint32_t kQHigh = kQCap - 128;     // replay until one more round of pushes (<= 64 + 64) fits
+constexpr int kMCap = 128;                   // M items per wave
 constexpr uint32_t kCpMask = 0xFFFFu;        // sym = char (>= 0xFFFF -> 0xFFFF) | type << 16 | tile-local sentence << 19
 constexpr int kPerThread = kFastCap / kThreads;
 constexpr int kWavesF = kThreads / 64;
 constexpr int kTypeRows = 4;                 // TM value: type rows in LDS (1..3 = window table of that W, 0 = none)
+constexpr int kTrowCount = 448;              // rows t1 | t2 << 3 | t3 << 6 with t3 <= 6
 
 struct FastLds {
     uint32_t sym[kFastCap + kMargin];        // decode step 1 keeps (byte pos | sentence << 16) per char here
     int32_t score[kFastCap + kMargin];       // staged text bytes during decode
     uint2 queue[kWavesF][kQCap];             // sentence-start bitmap during decode
-    uint8_t typ[kFastCap + kMargin];
+    uint2 mqueue[kWavesF][kMCap];
     uint32_t wtot[8];
-    uint4 trow[512];                         // type rows (only allocated for TM == kTypeRows)
+    union {                                  // never needed together; the launch allocates the one in use
+        uint8_t typ[kFastCap + kMargin];     // window-table modes
+        uint4 trow[kTrowCount];              // TM == kTypeRows
+    };
 };
-static_assert(offsetof(FastLds, trow) <= 23400, "7 workgroups per CU need <= 22.8 KB each (window-table modes)");
-static_assert(offsetof(FastLds, trow) % 16 == 0 && (kFastCap + kMargin) * 4 % 16 == 0, "carve offsets stay 16-byte aligned");
+static_assert(offsetof(FastLds, typ) % 16 == 0 && (kFastCap + kMargin) * 4 % 16 == 0, "carve offsets stay 16-byte aligned");
+static_assert(offsetof(FastLds, typ) + sizeof(uint4) * kTrowCount <= 32768, "5 workgroups per CU need <= 32 KB each");
 
 __device__ __forceinline__ uint32_t lane_rank(uint64_t mask) {  // set bits of `mask` below this lane
     return __builtin_amdgcn_mbcnt_hi(uint32_t(mask >> 32), __builtin_amdgcn_mbcnt_lo(uint32_t(mask), 0u));
-}
-__device__ __forceinline__ uint32_t pair_swap(uint32_t x) {  // value of lane ^ 1 (DPP quad_perm [1,0,3,2])
-    return uint32_t(__builtin_amdgcn_update_dpp(0, int(x), 0xB1, 0xF, 0xF, false));
 }
 
 // branch-free UTF-8 -> scalar value; b4 = the lead byte and the three bytes after it, little-endian
@@ -68,24 +69,32 @@ __device__ __forceinline__ uint32_t utf8_scalar_bf(uint32_t b4) {
     return cp;
 }
 
-// Two stacks in one wave-private buffer: trie steps grow from the bottom, lookup continuations from the top.
-//   trie step      x = s | depth << 11     y = mini-table ref (in `deep`) of the children to search
-//   continuation   x = s | kinds << 11     y = overflow mini-table ref (kind kOvProbe)
-constexpr uint32_t kRecMore = 1u, kOvProbe = 2u, kWideUni = 4u, kWideBi = 8u, kWideTri = 16u;
+// Wave-private stacks of deferred work (wave-uniform counts):
+//   W  x = s | depth << 11   y = mini-table ref (in `deep`) of the children to search      trie step
+//   O  x = s                 y = overflow mini-table ref (in `kids3`)                       overflow-child probe
+//   M  x = s | kinds << 11                                                                  the rare rest
+constexpr uint32_t kRecMore = 1u, kWideUni = 4u, kWideBi = 8u, kWideTri = 16u, kWideLeft = 32u;
 struct WaveStacks {
     uint2* q;
-    uint32_t nw, nr;  // wave-uniform counts
-    __device__ __forceinline__ void push_walk(bool pred, uint32_t x, uint32_t y) {
+    uint2* mq;
+    uint32_t nw, no, nm;
+    __device__ __forceinline__ void push_w(bool pred, uint32_t x, uint32_t y) {
         const uint64_t m = __ballot(pred);
         if (m == 0) return;
         if (pred) q[nw + lane_rank(m)] = make_uint2(x, y);
         nw += uint32_t(__popcll(m));
     }
-    __device__ __forceinline__ void push_retry(bool pred, uint32_t x, uint32_t y) {
+    __device__ __forceinline__ void push_o(bool pred, uint32_t x, uint32_t y) {
         const uint64_t m = __ballot(pred);
         if (m == 0) return;
-        if (pred) q[kQCap - 1 - (nr + lane_rank(m))] = make_uint2(x, y);
-        nr += uint32_t(__popcll(m));
+        if (pred) q[kQCap - 1 - (no + lane_rank(m))] = make_uint2(x, y);
+        no += uint32_t(__popcll(m));
+    }
+    __device__ __forceinline__ void push_m(bool pred, uint32_t x) {
+        const uint64_t m = __ballot(pred);
+        if (m == 0) return;
+        if (pred) mq[nm + lane_rank(m)] = make_uint2(x, 0u);
+        nm += uint32_t(__popcll(m));
     }
 };
 
@@ -98,14 +107,14 @@ __device__ __forceinline__ void add_row6(int32_t* score, uint32_t s, int32_t a0,
     atomicAdd(p, a0); atomicAdd(p + 1, a1); atomicAdd(p + 2, a2);
     atomicAdd(p + 3, a3); atomicAdd(p + 4, a4); atomicAdd(p + 5, a5);
 }
-// a trigram-level child row: boundaries s-1 .. s+2
-__device__ __forceinline__ void add_child(int32_t* score, uint32_t s, uint32_t w01, uint32_t w23) {
-    int32_t* p = score + s - 1;
+// the row of a 3-char string starting at `st`: boundaries st-1 .. st+2
+__device__ __forceinline__ void add_child(int32_t* score, uint32_t st, uint32_t w01, uint32_t w23) {
+    int32_t* p = score + st - 1;
     atomicAdd(p, lo16(w01)); atomicAdd(p + 1, hi16(w01)); atomicAdd(p + 2, lo16(w23)); atomicAdd(p + 3, hi16(w23));
 }
 
-// Up to 64 queued trie steps, all lanes busy: the child sym[s + depth] in the mini-table `ref` of `deep`.
-__device__ __forceinline__ void replay_walk(const PackedView& K, FastLds& L, WaveStacks& Q, int lane) {
+// W: up to 64 queued trie steps, all lanes busy: the child sym[s + depth] in the mini-table `ref` of `deep`.
+__device__ __forceinline__ void replay_w(const PackedView& K, FastLds& L, WaveStacks& Q, int lane) {
     const uint32_t take = Q.nw < 64u ? Q.nw : 64u;
     Q.nw -= take;
     const bool have = uint32_t(lane) < take;
@@ -113,37 +122,45 @@ __device__ __forceinline__ void replay_walk(const PackedView& K, FastLds& L, Wav
     const uint32_t s = it.x & 0x7FFu, depth = it.x >> 11;
     const uint32_t at = s + depth;
     const uint32_t c = (have && at < uint32_t(kFastCap + kMargin)) ? (L.sym[at] & kCpMask) : 0u;  // 0: sentence over
-    bool again = false;
-    uint32_t nx = 0, ny = 0;
-    if (c != 0) {
-        const uint4* tab = reinterpret_cast<const uint4*>(K.deep) + size_t(it.y >> 5) * 2;
-        const uint32_t last = (1u << (it.y & 31u)) - 1u;
-        uint32_t i = packed_mini_slot(c, it.y);
-        for (uint32_t n = 0; n <= last; ++n) {
-            const uint4 e = tab[size_t(i) * 2];
-            if ((e.x & 0xFFFFu) == c) {
-                const uint32_t m = depth + 1;  // chars matched so far: a pattern of m chars has m + 1 weights,
-                int32_t* dst = L.score + s - 1;  // the first on boundary s - 1
-                if (e.x & (kPkHasRow << 16)) {
-                    const uint4 f = tab[size_t(i) * 2 + 1];
-                    atomicAdd(dst, lo16(e.z)); atomicAdd(dst + 1, hi16(e.z)); atomicAdd(dst + 2, lo16(e.w));
-                    atomicAdd(dst + 3, hi16(e.w)); atomicAdd(dst + 4, lo16(f.x));  // m >= 4
-                    const uint32_t w[4] = {f.x, f.y, f.z, f.w};
-#pragma unroll
-                    for (uint32_t j = 5; j < kPackedInlineRow; ++j)
-                        if (j <= m) atomicAdd(dst + j, (j & 1) ? hi16(w[(j - 4) >> 1]) : lo16(w[(j - 4) >> 1]));
-                } else if (e.x & (kPkExtRow << 16)) {  // longer than 11 chars or a value outside i16: i32 row
-                    const int32_t* w32 = K.xrows + e.z;
-                    for (uint32_t j = 0; j <= m; ++j) atomicAdd(dst + j, w32[j]);
-                }
-                if (e.y != 0) { again = true; nx = s | (m << 11); ny = e.y; }
-                break;
-            }
-            if (e.x == 0) break;
+    const uint4* tab = reinterpret_cast<const uint4*>(K.deep) + size_t(it.y >> 5) * 2;
+    const uint32_t last = (1u << (it.y & 31u)) - 1u;
+    uint32_t i = packed_mini_slot(c, it.y);
+    bool found = false, open = c != 0;
+    uint4 e = make_uint4(0, 0, 0, 0);
+    uint32_t n = 0;
+    while (__ballot(open) != 0) {  // nearly always one round: most nodes have a single child
+        if (open) {
+            e = tab[size_t(i) * 2];
+            found = (e.x & 0xFFFFu) == c;
+            open = !found && e.x != 0 && n < last;
             i = (i + 1) & last;
+            ++n;
         }
     }
-    Q.push_walk(again, nx, ny);
+    const uint32_t m = depth + 1;  // chars matched so far: a pattern of m chars has m + 1 weights, the first on
+    int32_t* dst = L.score + s - 1;  // boundary s - 1
+    const bool row = found && (e.x & (kPkHasRow << 16));
+    if (row) {
+        const uint4 f = tab[size_t((i - 1) & last) * 2 + 1];
+        atomicAdd(dst, lo16(e.z)); atomicAdd(dst + 1, hi16(e.z)); atomicAdd(dst + 2, lo16(e.w));
+        atomicAdd(dst + 3, hi16(e.w)); atomicAdd(dst + 4, lo16(f.x));  // m >= 4
+        if (m >= 5) atomicAdd(dst + 5, hi16(f.x));
+        if (__ballot(row && m >= 6) != 0) {  // wave-uniform skips: most dictionary words have 4-5 chars
+            if (m >= 6) atomicAdd(dst + 6, lo16(f.y));
+            if (m >= 7) atomicAdd(dst + 7, hi16(f.y));
+            if (__ballot(row && m >= 8) != 0) {
+                if (m >= 8) atomicAdd(dst + 8, lo16(f.z));
+                if (m >= 9) atomicAdd(dst + 9, hi16(f.z));
+                if (m >= 10) atomicAdd(dst + 10, lo16(f.w));
+                if (m >= 11) atomicAdd(dst + 11, hi16(f.w));
+            }
+        }
+    }
+    if (found && (e.x & (kPkExtRow << 16))) {  // longer than 11 chars or a value outside i16: i32 row (rare)
+        const int32_t* w32 = K.xrows + e.z;
+        for (uint32_t j = 0; j <= m; ++j) atomicAdd(dst + j, w32[j]);
+    }
+    Q.push_w(found && e.y != 0, s | (m << 11), e.y);
 }
 
 // Row of a <= 3-char string in the GENERAL short table (layout.h; 32-byte entries, buckets of two): used for the
@@ -163,20 +180,55 @@ __device__ __forceinline__ bool general_row(const PatternTableView& T, uint64_t 
     }
 }
 
-// Up to 64 queued lookup continuations for start position s (kinds: see WaveStacks).
-__device__ __forceinline__ void replay_retry(const PackedView& K, const PatternTableView& T, FastLds& L, WaveStacks& Q, int lane) {
-    const uint32_t take = Q.nr < 64u ? Q.nr : 64u;
-    Q.nr -= take;
+// O: up to 64 queued overflow-child probes: c3 = sym[s + 2] in the mini-table `ref` of `kids3`.
+__device__ __forceinline__ void replay_o(const PackedView& K, const PatternTableView& T, FastLds& L, WaveStacks& Q, int lane) {
+    const uint32_t take = Q.no < 64u ? Q.no : 64u;
+    Q.no -= take;
     const bool have = uint32_t(lane) < take;
-    const uint2 it = have ? Q.q[kQCap - 1 - (Q.nr + lane)] : make_uint2(0u, 0u);
+    const uint2 it = have ? Q.q[kQCap - 1 - (Q.no + lane)] : make_uint2(0u, 0u);
+    const uint32_t s = it.x;
+    const uint32_t c3 = have ? (L.sym[s + 2] & kCpMask) : 0u;
+    const uint4* tab = reinterpret_cast<const uint4*>(K.kids3) + (it.y >> 5);
+    const uint32_t last = (1u << (it.y & 31u)) - 1u;
+    uint32_t i = packed_mini_slot(c3, it.y);
+    bool found = false, open = have;
+    uint4 ch = make_uint4(0, 0, 0, 0);
+    uint32_t n = 0;
+    while (__ballot(open) != 0) {
+        if (open) {
+            ch = tab[i];
+            found = (ch.x & 0xFFFFu) == c3;
+            open = !found && ch.x != 0 && n < last;
+            i = (i + 1) & last;
+            ++n;
+        }
+    }
+    const bool wide = found && (ch.x & (kPkWide << 16));
+    if (found && !wide) add_child(L.score, s, ch.y, ch.z);
+    if (__ballot(wide) != 0) {  // a value outside i16 (rare): the row comes from the general tables
+        uint4 r0, r1;
+        if (wide && general_row(T, short_key(L.sym[s] & kCpMask, L.sym[s + 1] & kCpMask, c3), r0, r1))
+            add_row6(L.score, s, 0, 0, int32_t(r0.z), int32_t(r0.w), int32_t(r1.x), int32_t(r1.y));
+    }
+    Q.push_w(found && ch.w != 0, s | (3u << 11), ch.w);
+}
+
+// M: the rare rest, one lane per item, written for brevity rather than speed.
+//   kRecMore: the record of (c1,c2) is not in its home slot -- find it further on and do what the main loop does.
+//   kWide*:   a row with a value outside i16 -- take it from the general tables (i32).
+__device__ __forceinline__ void replay_m(const PackedView& K, const PatternTableView& T, FastLds& L, WaveStacks& Q, int lane) {
+    const uint32_t take = Q.nm < 64u ? Q.nm : 64u;
+    Q.nm -= take;
+    const bool have = uint32_t(lane) < take;
+    const uint2 it = have ? Q.mq[Q.nm + lane] : make_uint2(0u, 0u);
     const uint32_t s = it.x & 0x7FFu;
-    uint32_t kinds = have ? (it.x >> 11) & 31u : 0u;
-    uint32_t ov_ref = it.y;
-    bool walk = false;
-    uint32_t kids = 0;
+    uint32_t kinds = have ? (it.x >> 11) : 0u;
+    const uint32_t c0 = have ? (L.sym[s - 1] & kCpMask) : 0u;
     const uint32_t c1 = L.sym[s] & kCpMask, c2 = L.sym[s + 1] & kCpMask, c3 = L.sym[s + 2] & kCpMask;
     const uint32_t kb = c1 | (c2 << 16);
-    if (kinds & kRecMore) {  // the record is not in its home slot: look in the following ones
+    bool walk_r = false, walk_l = false, ovp = false;
+    uint32_t kids_r = 0, kids_l = 0, ov_ref = 0;
+    if (kinds & kRecMore) {
         const uint4* rec4 = reinterpret_cast<const uint4*>(K.rec);
         uint32_t b = packed_hash1(kb, K.rec_shift);
         for (;;) {
@@ -186,44 +238,33 @@ __device__ __forceinline__ void replay_retry(const PackedView& K, const PatternT
             if (h0.x == kb) {
                 if (h0.w & (kPkWide << 16)) kinds |= kWideBi;
                 else add_row6(L.score, s, 0, lo16(h0.y), hi16(h0.y), lo16(h0.z), hi16(h0.z), lo16(h0.w));
-                if (c3 != 0) {
-                    bool hit = false;
-#pragma unroll
-                    for (int j = 0; j < 6; ++j) {
-                        const uint4 ch = r[j < 3 ? 1 + j : 2 + j];
-                        if (!hit && (ch.x & 0xFFFFu) == c3) {
-                            hit = true;
-                            if (ch.x & (kPkWide << 16)) kinds |= kWideTri; else add_child(L.score, s, ch.y, ch.z);
-                            if (ch.w != 0) { walk = true; kids = ch.w; }
-                        }
+                bool hit = false;
+                for (int j = 1; j <= 3; ++j) {
+                    const uint4 ch = r[j];
+                    if (c3 != 0 && (ch.x & 0xFFFFu) == c3) {
+                        hit = true;
+                        if (ch.x & (kPkWide << 16)) kinds |= kWideTri; else add_child(L.score, s, ch.y, ch.z);
+                        walk_r = ch.w != 0; kids_r = ch.w;
                     }
-                    if (!hit && (h0.w & (kPkOv << 16))) {
-                        const uint4 h1 = r[4];
-                        const uint32_t bit = packed_filter_bit(c3);
-                        if (((bit < 32 ? h1.z >> bit : h1.w >> (bit - 32)) & 1u) != 0) { kinds |= kOvProbe; ov_ref = h1.y; }
+                }
+                for (int j = 5; j <= 7; ++j) {
+                    const uint4 ch = r[j];
+                    if (c0 != 0 && (ch.x & 0xFFFFu) == c0) {
+                        if (ch.x & (kPkWide << 16)) kinds |= kWideLeft; else add_child(L.score, s - 1, ch.y, ch.z);
+                        walk_l = ch.w != 0; kids_l = ch.w;
                     }
+                }
+                if (c3 != 0 && !hit && (h0.w & (kPkOv << 16))) {
+                    const uint4 h1 = r[4];
+                    const uint32_t bit = packed_filter_bit(c3);
+                    if (((bit < 32 ? h1.z >> bit : h1.w >> (bit - 32)) & 1u) != 0) { ovp = true; ov_ref = h1.y; }
                 }
                 break;
             }
             if (h0.x == 0) break;
         }
     }
-    if (kinds & kOvProbe) {  // a prefix with more than six children: its overflow mini-table
-        const uint4* tab = reinterpret_cast<const uint4*>(K.kids3) + (ov_ref >> 5);
-        const uint32_t last = (1u << (ov_ref & 31u)) - 1u;
-        uint32_t i = packed_mini_slot(c3, ov_ref);
-        for (uint32_t n = 0; n <= last; ++n) {
-            const uint4 ch = tab[i];
-            if ((ch.x & 0xFFFFu) == c3) {
-                if (ch.x & (kPkWide << 16)) kinds |= kWideTri; else add_child(L.score, s, ch.y, ch.z);
-                if (ch.w != 0) { walk = true; kids = ch.w; }
-                break;
-            }
-            if (ch.x == 0) break;
-            i = (i + 1) & last;
-        }
-    }
-    if (kinds & (kWideUni | kWideBi | kWideTri)) {  // rows with a value outside i16 (rare): general tables, i32
+    if (kinds & (kWideUni | kWideBi | kWideTri | kWideLeft)) {
         uint4 r0, r1;
         if (kinds & kWideUni) {
             const uint4* u = reinterpret_cast<const uint4*>(T.uni) + size_t(c1) * 2;
@@ -234,15 +275,30 @@ __device__ __forceinline__ void replay_retry(const PackedView& K, const PatternT
             add_row6(L.score, s, 0, int32_t(r0.z), int32_t(r0.w), int32_t(r1.x), int32_t(r1.y), int32_t(r1.z));
         if ((kinds & kWideTri) && general_row(T, short_key(c1, c2, c3), r0, r1))
             add_row6(L.score, s, 0, 0, int32_t(r0.z), int32_t(r0.w), int32_t(r1.x), int32_t(r1.y));
+        if ((kinds & kWideLeft) && general_row(T, short_key(c0, c1, c2), r0, r1))
+            add_row6(L.score, s - 1, 0, 0, int32_t(r0.z), int32_t(r0.w), int32_t(r1.x), int32_t(r1.y));
     }
-    Q.push_walk(walk, s | (3u << 11), kids);
+    Q.push_w(walk_r, s | (3u << 11), kids_r);
+    Q.push_w(walk_l, (s - 1) | (3u << 11), kids_l);
+    Q.push_o(ovp, s, ov_ref);
 }
 
-__device__ __forceinline__ void make_room(const PackedView& K, const PatternTableView& T, FastLds& L, WaveStacks& Q, int lane) {
-    while (Q.nw + Q.nr > kQHigh) {
-        if (Q.nw >= Q.nr) replay_walk(K, L, Q, lane);
-        else replay_retry(K, T, L, Q, lane);
+// W/O replays until at most `mark` items are left.  A replay never grows W + O (an O item becomes at most one W
+// item, a W item at most one W item), so the loop ends.
+__device__ __forceinline__ void drain_wo(const PackedView& K, const PatternTableView& T, FastLds& L, WaveStacks& Q, int lane, uint32_t mark) {
+    while (Q.nw + Q.no > mark) {
+        if (Q.nw >= Q.no) replay_w(K, L, Q, lane);
+        else replay_o(K, T, L, Q, lane);
     }
+}
+// Room for one more round of pushes (W <= 64, O <= 64, M <= 64).  An M replay adds at most 128 W and 64 O items,
+// so W + O go down to 32 before it.
+__device__ __forceinline__ void make_room(const PackedView& K, const PatternTableView& T, FastLds& L, WaveStacks& Q, int lane) {
+    if (Q.nm > uint32_t(kMCap - 64)) {
+        drain_wo(K, T, L, Q, lane, 32u);
+        replay_m(K, T, L, Q, lane);
+    }
+    drain_wo(K, T, L, Q, lane, kQHigh);
 }
 
 // optional phase timing (VPT_PROFILE_PHASES): wave 0 of every workgroup adds the shader cycles it spent per phase
@@ -251,24 +307,6 @@ __device__ __forceinline__ uint64_t phase_mark(uint64_t* prof, int slot, uint64_
     const uint64_t now = __builtin_amdgcn_s_memtime();
     if (threadIdx.x == 0) atomicAdd(reinterpret_cast<unsigned long long*>(prof + slot), (unsigned long long)(now - t_prev));
     return now;
-}
-
-// One half (64 bytes: q0 = H0 or H1, q1..q3 = children) of the record of the position (o_s, o_kb, o_c3) this lane
-// serves in the current sub-round: as OWNER (its own position, half 0) or as HELPER (its pair partner's, half 1).
-struct HalfResult {
-    bool hit;        // a child matched in this half
-    uint32_t w01, w23, kids, cflags;
-};
-__device__ __forceinline__ HalfResult match_children(bool keyok_has3, uint32_t c3, const uint4& q1, const uint4& q2, const uint4& q3) {
-    const bool m1 = keyok_has3 && (q1.x & 0xFFFFu) == c3, m2 = keyok_has3 && (q2.x & 0xFFFFu) == c3;
-    const bool m3 = keyok_has3 && (q3.x & 0xFFFFu) == c3;
-    HalfResult r;
-    r.hit = m1 || m2 || m3;
-    r.w01 = m1 ? q1.y : m2 ? q2.y : m3 ? q3.y : 0u;
-    r.w23 = m1 ? q1.z : m2 ? q2.z : m3 ? q3.z : 0u;
-    r.kids = m1 ? q1.w : m2 ? q2.w : m3 ? q3.w : 0u;
-    r.cflags = (m1 ? q1.x : m2 ? q2.x : m3 ? q3.x : 0u) >> 16;
-    return r;
 }
 
 template <int TM>
@@ -298,7 +336,7 @@ __global__ __launch_bounds__(kThreads) void score_tiles_fast_kernel(const ScoreP
     const uint32_t nchunks = (nbytes_al + 15) >> 4;
     uint32_t err = 0;
     if (TM == kTypeRows) {  // 512 type rows -> LDS (not aliased by the decode scratch; barriers follow before use)
-        for (uint32_t i = tid; i < 512u; i += kThreads) L.trow[i] = reinterpret_cast<const uint4*>(P.pk.trow)[i];
+        for (uint32_t i = tid; i < uint32_t(kTrowCount); i += kThreads) L.trow[i] = reinterpret_cast<const uint4*>(P.pk.trow)[i];
     }
     uint64_t* const prof = P.prof;
     uint64_t tmark = prof ? __builtin_amdgcn_s_memtime() : 0;
@@ -390,10 +428,10 @@ __global__ __launch_bounds__(kThreads) void score_tiles_fast_kernel(const ScoreP
     __syncthreads();  // every (pos, sentence) record has been read; sym and score can be reused
     for (uint32_t i = tid; i < (uint32_t(kFastCap + kMargin) * 4) / 16; i += kThreads)
         reinterpret_cast<uint4*>(L.score)[i] = make_uint4(0, 0, 0, 0);
-    if (tid < int(pad)) { L.sym[tid] = 0; L.typ[tid] = 0; }
+    if (tid < int(pad)) { L.sym[tid] = 0; if (TM != kTypeRows) L.typ[tid] = 0; }
     if (tid >= 64 && tid < 64 + kMargin) {  // slack past the tile for the s+1, s+2 look-ahead
         const uint32_t p = flat_len + uint32_t(tid - 64);
-        if (p < uint32_t(kFastCap + kMargin)) { L.sym[p] = 0; L.typ[p] = 0; }
+        if (p < uint32_t(kFastCap + kMargin)) { L.sym[p] = 0; if (TM != kTypeRows) L.typ[p] = 0; }
     }
 #pragma unroll
     for (int k = 0; k < kPerThread; ++k) {
@@ -401,10 +439,10 @@ __global__ __launch_bounds__(kThreads) void score_tiles_fast_kernel(const ScoreP
         const uint32_t flat = meta[k] & 0xFFFu, cp = cps[k];
         const uint32_t ty = cp < 0x10000u ? uint32_t(P.ctype[cp]) : char_type(cp);
         L.sym[flat] = (cp < kPackedNoMatchSym ? cp : kPackedNoMatchSym) | (ty << 16) | ((meta[k] >> 16) << 19);
-        L.typ[flat] = uint8_t(ty);
+        if (TM != kTypeRows) L.typ[flat] = uint8_t(ty);
         if (meta[k] & 0x8000u) {
 #pragma unroll
-            for (uint32_t z = 1; z <= pad; ++z) { L.sym[flat + z] = 0; L.typ[flat + z] = 0; }
+            for (uint32_t z = 1; z <= pad; ++z) { L.sym[flat + z] = 0; if (TM != kTypeRows) L.typ[flat + z] = 0; }
         }
     }
     __syncthreads();
@@ -412,89 +450,87 @@ __global__ __launch_bounds__(kThreads) void score_tiles_fast_kernel(const ScoreP
     tmark = phase_mark(prof, 1, tmark);
     // ---------------------------------------------------------------- B. patterns
     const PackedView& K = P.pk;
-    WaveStacks Q{&L.queue[wave][0], 0u, 0u};
+    WaveStacks Q{&L.queue[wave][0], &L.mqueue[wave][0], 0u, 0u, 0u};
     const uint4* uni4 = reinterpret_cast<const uint4*>(K.uni);
     const uint4* rec4 = reinterpret_cast<const uint4*>(K.rec);
-    const uint32_t odd = uint32_t(lane) & 1u;
     for (int k = 0; k < kPerThread; ++k) {
+        if (P.debug & 16u) break;  // timing ablation: no pattern phase at all
         const uint32_t s = uint32_t(tid) + uint32_t(k) * kThreads;
         if (s - uint32_t(lane) >= flat_len) break;  // wave-uniform: this wave's 64 positions are past the tile
-        const uint32_t x1 = s < flat_len ? L.sym[s] : 0u, x2 = L.sym[s + 1], x3 = L.sym[s + 2];
-        const uint32_t c1 = x1 & kCpMask, c2 = x2 & kCpMask, c3 = x3 & kCpMask;
+        const uint32_t x1 = s < flat_len ? L.sym[s] : 0u;
+        const uint32_t c1 = x1 & kCpMask;
         const bool live = c1 != 0;
+        const uint32_t c0 = live ? (L.sym[s - 1] & kCpMask) : 0u;   // s >= pad whenever c1 != 0
+        const uint32_t x2 = L.sym[s + 1], x3 = L.sym[s + 2];
+        const uint32_t c2 = x2 & kCpMask, c3 = x3 & kCpMask;
         const bool has2 = live && c2 != 0;
-        const bool has3 = has2 && c3 != 0;
         const uint32_t kb = c1 | (c2 << 16);
         uint32_t hrec = packed_hash1(kb, K.rec_shift);
         if (P.debug & 1u) hrec = 0;  // timing ablation (VPT_DEBUG_ABLATE; results are wrong): pin the record
-        const uint32_t c3f = c3 | (has2 ? 0x10000u : 0u) | (has3 ? 0x20000u : 0u);
-        // the pair partner's position (s ^ 1): sub-round 0 serves the even lane's position, sub-round 1 the odd one's
-        const uint32_t p_kb = pair_swap(kb), p_c3f = pair_swap(c3f), p_hrec = pair_swap(hrec);
-        const uint32_t kbA = odd ? p_kb : kb, c3fA = odd ? p_c3f : c3f, hA = odd ? p_hrec : hrec;  // sub-round 0
-        const uint32_t kbB = odd ? kb : p_kb, c3fB = odd ? c3f : p_c3f, hB = odd ? hrec : p_hrec;  // sub-round 1
-        // every load first: the unigram row, then per sub-round this lane's 64-byte half (owner: half 0)
+        // every load first: the unigram row and the whole record of (c1,c2)
         const uint4 u = uni4[(P.debug & 4u) ? 0u : c1];
-        const uint4* pa = rec4 + size_t(hA) * 8 + odd * 4;
-        const uint4* pb = rec4 + size_t(hB) * 8 + (odd ^ 1u) * 4;
-        const uint4 a0 = pa[0], a1 = pa[1], a2 = pa[2], a3 = pa[3];
-        const uint4 b0 = pb[0], b1 = pb[1], b2 = pb[2], b3 = pb[3];
+        const uint4* r = reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(rec4) + (hrec << 7));
+        const uint4 h0 = r[0], r1 = r[1], r2 = r[2], r3 = r[3], h1 = r[4], l1 = r[5], l2 = r[6], l3 = r[7];
         // own row so far: unigram (+ type row)
-        int32_t r0 = lo16(u.x), r1 = hi16(u.x), r2 = lo16(u.y), r3 = hi16(u.y), r4 = lo16(u.z), r5 = hi16(u.z);
+        int32_t a0 = lo16(u.x), a1 = hi16(u.x), a2 = lo16(u.y), a3 = hi16(u.y), a4 = lo16(u.z), a5 = hi16(u.z);
         if (TM == kTypeRows) {
             const uint4 tr = L.trow[((x1 >> 16) & 7u) | (((x2 >> 16) & 7u) << 3) | (((x3 >> 16) & 7u) << 6)];
             // six 18-bit signed fields at bits 0, 18, 36, 54, 72, 90 (layout.h, trow_field)
-            r0 += int32_t(tr.x << 14) >> 14;
-            r1 += int32_t(__builtin_amdgcn_alignbit(tr.y, tr.x, 18) << 14) >> 14;
-            r2 += int32_t(tr.y << 10) >> 14;
-            r3 += int32_t(__builtin_amdgcn_alignbit(tr.z, tr.y, 22) << 14) >> 14;
-            r4 += int32_t(tr.z << 6) >> 14;
-            r5 += int32_t(__builtin_amdgcn_alignbit(tr.w, tr.z, 26) << 14) >> 14;
+            a0 += int32_t(tr.x << 14) >> 14;
+            a1 += int32_t(__builtin_amdgcn_alignbit(tr.y, tr.x, 18) << 14) >> 14;
+            a2 += int32_t(tr.y << 10) >> 14;
+            a3 += int32_t(__builtin_amdgcn_alignbit(tr.z, tr.y, 22) << 14) >> 14;
+            a4 += int32_t(tr.z << 6) >> 14;
+            a5 += int32_t(__builtin_amdgcn_alignbit(tr.w, tr.z, 26) << 14) >> 14;
         }
-        uint32_t kinds = (live && u.w != 0) ? kWideUni : 0u;   // continuation kinds of the OWN position
-        uint32_t h_kinds = 0, h_ref = 0;                        // ... of the partner's position, found as helper
-        bool walk_own = false, walk_help = false;
-        uint32_t kids_own = 0, kids_help = 0;
-#pragma unroll
-        for (int r = 0; r < 2; ++r) {
-            const uint4& q0 = r == 0 ? a0 : b0;
-            const uint4& q1 = r == 0 ? a1 : b1;
-            const uint4& q2 = r == 0 ? a2 : b2;
-            const uint4& q3 = r == 0 ? a3 : b3;
-            const uint32_t o_kb = r == 0 ? kbA : kbB, o_c3f = r == 0 ? c3fA : c3fB;
-            const bool owner = (odd != 0) == (r != 0);
-            const bool keyok = (o_c3f & 0x10000u) && q0.x == o_kb;
-            const HalfResult ch = match_children(keyok && (o_c3f & 0x20000u), o_c3f & 0xFFFFu, q1, q2, q3);
-            const bool partner_hit = pair_swap(ch.hit ? 1u : 0u) != 0;
-            if (owner) {
-                const uint32_t y = keyok ? q0.y : 0u, z = keyok ? q0.z : 0u, w = keyok ? q0.w : 0u;
-                r1 += lo16(y); r2 += hi16(y) + lo16(ch.w01); r3 += lo16(z) + hi16(ch.w01);
-                r4 += hi16(z) + lo16(ch.w23); r5 += lo16(w) + hi16(ch.w23);
-                if ((o_c3f & 0x10000u) && !keyok && (q0.w & (kPkDisp << 16))) kinds |= kRecMore;
-                if (w & (kPkWide << 16)) kinds |= kWideBi;
-                if (ch.cflags & kPkWide) kinds |= kWideTri;
-                walk_own = ch.kids != 0; kids_own = ch.kids;
-            } else {
-                if (ch.hit && !(ch.cflags & kPkWide)) add_child(L.score, s ^ 1u, ch.w01, ch.w23);
-                if (ch.cflags & kPkWide) h_kinds |= kWideTri;
-                walk_help = ch.kids != 0; kids_help = ch.kids;
-                // H1 = {kb, overflow ref, filter lo, filter hi}: children beyond the six inline ones
-                if (keyok && (o_c3f & 0x20000u) && !ch.hit && !partner_hit && q0.y != 0 && !(P.debug & 2u)) {
-                    const uint32_t bit = packed_filter_bit(o_c3f & 0xFFFFu);
-                    if (((bit < 32 ? q0.z >> bit : q0.w >> (bit - 32)) & 1u) != 0) { h_kinds |= kOvProbe; h_ref = q0.y; }
-                }
-            }
+        const bool keyok = has2 && h0.x == kb;
+        // right children: (c1,c2,c3) starts here
+        const bool kr = keyok && c3 != 0;
+        const bool mr1 = kr && (r1.x & 0xFFFFu) == c3, mr2 = kr && (r2.x & 0xFFFFu) == c3, mr3 = kr && (r3.x & 0xFFFFu) == c3;
+        const bool hit_r = mr1 || mr2 || mr3;
+        const uint32_t rx = mr1 ? r1.x : mr2 ? r2.x : mr3 ? r3.x : 0u;
+        const uint32_t ry = mr1 ? r1.y : mr2 ? r2.y : mr3 ? r3.y : 0u;
+        const uint32_t rz = mr1 ? r1.z : mr2 ? r2.z : mr3 ? r3.z : 0u;
+        const uint32_t rk = mr1 ? r1.w : mr2 ? r2.w : mr3 ? r3.w : 0u;
+        // left children: (c0,c1,c2) started one position earlier
+        const bool kl = keyok && c0 != 0;
+        const bool ml1 = kl && (l1.x & 0xFFFFu) == c0, ml2 = kl && (l2.x & 0xFFFFu) == c0, ml3 = kl && (l3.x & 0xFFFFu) == c0;
+        const bool hit_l = ml1 || ml2 || ml3;
+        const uint32_t lx = ml1 ? l1.x : ml2 ? l2.x : ml3 ? l3.x : 0u;
+        const uint32_t ly = ml1 ? l1.y : ml2 ? l2.y : l3.y;
+        const uint32_t lz = ml1 ? l1.z : ml2 ? l2.z : l3.z;
+        const uint32_t lk = ml1 ? l1.w : ml2 ? l2.w : ml3 ? l3.w : 0u;
+        // bigram row + right child (a kPkWide slot holds zero weights)
+        const uint32_t by = keyok ? h0.y : 0u, bz = keyok ? h0.z : 0u, bw = keyok ? h0.w : 0u;
+        a1 += lo16(by); a2 += hi16(by) + lo16(ry); a3 += lo16(bz) + hi16(ry);
+        a4 += hi16(bz) + lo16(rz); a5 += lo16(bw) + hi16(rz);
+        if (live) add_row6(L.score, s, a0, a1, a2, a3, a4, a5);
+        if (hit_l) add_child(L.score, s - 1, ly, lz);
+        // deferred work
+        bool ovp = false;
+        if (kr && !hit_r && (bw & (kPkOv << 16)) && !(P.debug & 2u)) {
+            const uint32_t bit = packed_filter_bit(c3);
+            ovp = ((bit < 32 ? h1.z >> bit : h1.w >> (bit - 32)) & 1u) != 0;
         }
-        if (live) add_row6(L.score, s, r0, r1, r2, r3, r4, r5);
+        const uint32_t kinds = ((live && u.w != 0) ? kWideUni : 0u) | ((has2 && !keyok && (h0.w & (kPkDisp << 16))) ? kRecMore : 0u) |
+                               ((bw & (kPkWide << 16)) ? kWideBi : 0u) | ((rx & (kPkWide << 16)) ? kWideTri : 0u) |
+                               ((lx & (kPkWide << 16)) ? kWideLeft : 0u);
         const bool nowalk = (P.debug & 8u) != 0;
         make_room(K, P.ct, L, Q, lane);
-        Q.push_walk(walk_own && !nowalk, s | (3u << 11), kids_own);
-        Q.push_retry(kinds != 0, s | (kinds << 11), 0u);
-        make_room(K, P.ct, L, Q, lane);
-        Q.push_walk(walk_help && !nowalk, (s ^ 1u) | (3u << 11), kids_help);
-        Q.push_retry(h_kinds != 0, (s ^ 1u) | (h_kinds << 11), h_ref);
+        Q.push_w(rk != 0 && !nowalk, s | (3u << 11), rk);
+        Q.push_o(ovp, s, h1.y);
+        Q.push_m(kinds != 0, s | (kinds << 11));
+        if (__ballot(lk != 0) != 0) {
+            make_room(K, P.ct, L, Q, lane);
+            Q.push_w(lk != 0 && !nowalk, (s - 1) | (3u << 11), lk);
+        }
     }
-    while (Q.nr > 0) replay_retry(K, P.ct, L, Q, lane);
-    while (Q.nw > 0) replay_walk(K, L, Q, lane);
+    while (Q.nm > 0) {
+        drain_wo(K, P.ct, L, Q, lane, 32u);
+        replay_m(K, P.ct, L, Q, lane);
+    }
+    while (Q.no > 0) replay_o(K, P.ct, L, Q, lane);
+    while (Q.nw > 0) replay_w(K, L, Q, lane);
     tmark = phase_mark(prof, 2, tmark);
     __syncthreads();
     tmark = phase_mark(prof, 3, tmark);
@@ -530,7 +566,7 @@ bool fast_path_supported(const ScoreParams& P) {
 
 hipError_t launch_score_tiles_fast(const ScoreParams& P, uint32_t n_tiles, hipStream_t stream) {
     const bool rows = P.type_kind == kTypeWindowTable && P.pk.has_trow && !std::getenv("VPT_FORCE_WINDOW_TABLE");
-    size_t lds = rows ? sizeof(FastLds) : offsetof(FastLds, trow);
+    size_t lds = offsetof(FastLds, typ) + (rows ? sizeof(uint4) * kTrowCount : size_t(kFastCap + kMargin));
     if (const char* padv = std::getenv("VPT_DEBUG_LDS_PAD")) lds += size_t(std::atoi(padv));  // occupancy experiments
     const int tm = rows ? kTypeRows : P.type_kind == kTypeWindowTable ? P.type_window : 0;
     switch (tm) {

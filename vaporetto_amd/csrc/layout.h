@@ -41,16 +41,21 @@
 // (c1, c2) need at depth 2 and 3 lives in ONE 128-byte record:
 //
 //   uni    65536 rows of 16 bytes, indexed by c1: {w[0..5] i16 (boundaries s-3 .. s+2), flags}      (L1/L2-hot)
-//   rec    open addressing over 128-byte records keyed by kb = c1 | c2 << 16, two self-validating 64-byte halves:
-//            half 0: H0 = {kb, w0|w1<<16, w2|w3<<16, w4 | flags<<16}   bigram row (boundaries s-2 .. s+2), zero
-//                         when (c1,c2) is only a prefix; flags: kPkDisp, kPkWide, kPkOv
-//                    C1..C3 = children, each {c3 | cflags<<16, w0|w1<<16, w2|w3<<16, kids}   (boundaries s-1 .. s+2)
-//            half 1: H1 = {kb, overflow ref, mask lo, mask hi}
-//                    C4..C6
+//   rec    open addressing over 128-byte records keyed by kb = c1 | c2 << 16 (eight 16-byte units):
+//            H0      = {kb, w0|w1<<16, w2|w3<<16, w4 | flags<<16}   bigram row (boundaries s-2 .. s+2), zero when
+//                      (c1,c2) is only a prefix; flags: kPkDisp, kPkWide, kPkOv
+//            R1..R3  = RIGHT children {c3 | cflags<<16, w0|w1<<16, w2|w3<<16, kids}: the 3-char string (c1,c2,c3)
+//                      starting at s (boundaries s-1 .. s+2)
+//            H1      = {kb, overflow ref, filter lo, filter hi}
+//            L1..L3  = LEFT children {c0 | cflags<<16, ...}: the 3-char string (c0,c1,c2) starting at s-1 (boundaries
+//                      s-2 .. s+1), found by the position AFTER its start -- which fetches record (c1,c2) anyway
 //          A child = a 3-char pattern and/or the 3-char prefix of longer ones; `kids` = mini-table ref of its
-//          depth-4 children in `deep` (0: none); cflags: kPkWide.  Unused child slots are zero (c3 = 0 never
-//          matches).  A prefix with more than 6 children keeps 6 inline and the rest in a mini-table of `kids3`
-//          (kPkOv, H1.y); H1.z/w is a 64-bit filter over hash6(c3) of those overflow children.
+//          depth-4 children in `deep` (0: none); cflags: kPkWide.  Unused child slots are zero (sym 0 never
+//          matches).  Each such string is stored exactly once: in a right slot of its (c1,c2) record, or in a left
+//          slot of its (c2,c3) record (created if needed), or -- when both are full -- in the overflow mini-table
+//          of (c1,c2) in `kids3` (kPkOv, H1.y), guarded by a 64-bit filter over hash6(c3) (H1.z/w).  Prefixes with
+//          many children are the frequent ones; spreading their children over the records of the FOLLOWING prefix
+//          keeps most lookups to the one line per position.
 //   kids3  16-byte entries, same format as an inline child.
 //   deep   32-byte entries for trie nodes at depth m >= 4:
 //            {sym | dflags<<16, kids, w0|w1<<16, w2|w3<<16} {w4|w5<<16 ... w10|w11<<16}

@@ -322,18 +322,56 @@ HostPackedTable build_packed(const std::vector<Pat>& pats) {
     }
     if (t.xrows.empty()) t.xrows.push_back(0);
 
+    // ---- placement of the trigram-level children (layout.h): a child (a,b,c) sits in a RIGHT slot of record (a,b)
+    // or in a LEFT slot of record (b,c) -- the record the NEXT start position fetches anyway -- else in the overflow
+    // mini-table of (a,b).  Prefixes with <= 3 children keep them all on the right; the children of bigger prefixes
+    // go left first (targets with the fewest takers first), then into the 3 right slots, then overflow.
+    struct Placed { uint32_t node; Sym lead; };                  // a left child: trie node + its first char
+    std::vector<std::vector<Placed>> lefts(prefixes.size());
+    std::vector<std::vector<uint32_t>> rights(prefixes.size()), overflow(prefixes.size());
+    {
+        struct Cand { uint32_t parent, node, target_key; };
+        std::vector<Cand> cands;
+        std::unordered_map<uint32_t, uint32_t> ldeg;
+        for (uint32_t pi = 0; pi < prefixes.size(); ++pi) {
+            const Prefix& pf = prefixes[pi];
+            if (pf.kids.size() <= 3) { rights[pi] = pf.kids; continue; }
+            for (uint32_t ni : pf.kids) {
+                const uint32_t tk = (pf.key >> 16) | (nodes[ni].sym << 16);
+                cands.push_back({pi, ni, tk});
+                ++ldeg[tk];
+            }
+        }
+        std::stable_sort(cands.begin(), cands.end(), [&](const Cand& x, const Cand& y) { return ldeg[x.target_key] < ldeg[y.target_key]; });
+        for (const Cand& c : cands) {
+            auto it = prefix_of.find(c.target_key);
+            uint32_t ti;
+            if (it == prefix_of.end()) {   // the target record exists only to carry left children
+                ti = uint32_t(prefixes.size());
+                prefixes.push_back({c.target_key, nullptr, {}});
+                prefix_of.emplace(c.target_key, ti);
+                lefts.emplace_back(); rights.emplace_back(); overflow.emplace_back();
+            } else ti = it->second;
+            if (lefts[ti].size() < 3) lefts[ti].push_back({c.node, Sym(prefixes[c.parent].key & 0xFFFFu)});
+            else if (rights[c.parent].size() < 3) rights[c.parent].push_back(c.node);
+            else overflow[c.parent].push_back(c.node);
+        }
+    }
+
     // ---- records
-    auto child_entry = [&](uint32_t* e, const Node& k) {
+    auto child_entry = [&](uint32_t* e, const Node& k, Sym sym) {
         uint32_t fl = 0;
         if (k.pat && wide(*k.pat)) { fl |= kPkWide; ++t.n_wide; }
         else if (k.pat) { e[1] = pack16(k.pat->row[0], k.pat->row[1]); e[2] = pack16(k.pat->row[2], k.pat->row[3]); }
-        e[0] = k.sym | (fl << 16);
+        e[0] = sym | (fl << 16);
         e[3] = k.ref;
     };
     t.rec_bits = bits_for(prefixes.size());
+    if (t.rec_bits > 24) return t;   // byte offsets of records stay below 4 GB
     const uint32_t rmask = (1u << t.rec_bits) - 1;
     t.rec.assign((size_t(1) << t.rec_bits) * 32, 0);
-    for (const Prefix& pf : prefixes) {
+    for (uint32_t pi = 0; pi < prefixes.size(); ++pi) {
+        const Prefix& pf = prefixes[pi];
         const uint32_t home = packed_hash1(pf.key, 32 - t.rec_bits);
         uint32_t b = home, probes = 1;
         while (t.rec[size_t(b) * 32] != 0) { b = (b + 1) & rmask; ++probes; }
@@ -347,22 +385,23 @@ HostPackedTable build_packed(const std::vector<Pat>& pats) {
             r[1] = pack16(pf.pat->row[0], pf.pat->row[1]); r[2] = pack16(pf.pat->row[2], pf.pat->row[3]);
             r[3] = pack16(pf.pat->row[4], 0);
         }
-        const size_t nk = pf.kids.size(), n_in = std::min<size_t>(nk, kPackedInlineKids);
-        for (size_t j = 0; j < n_in; ++j) child_entry(r + (j < 3 ? 4 + 4 * j : 20 + 4 * (j - 3)), nodes[pf.kids[j]]);
-        if (nk > n_in) {
+        for (size_t j = 0; j < rights[pi].size(); ++j) child_entry(r + 4 + 4 * j, nodes[rights[pi][j]], nodes[rights[pi][j]].sym);
+        for (size_t j = 0; j < lefts[pi].size(); ++j) child_entry(r + 20 + 4 * j, nodes[lefts[pi][j].node], lefts[pi][j].lead);
+        if (!overflow[pi].empty()) {
             fl |= kPkOv;
-            const uint32_t ref = mini_alloc(t.kids3, 4, nk - n_in);
+            const uint32_t ref = mini_alloc(t.kids3, 4, overflow[pi].size());
             uint64_t mask = 0;
-            for (size_t j = n_in; j < nk; ++j) {
-                const Node& k = nodes[pf.kids[j]];
-                child_entry(mini_insert(t.kids3, 4, ref, k.sym), k);
+            for (uint32_t ni : overflow[pi]) {
+                const Node& k = nodes[ni];
+                child_entry(mini_insert(t.kids3, 4, ref, k.sym), k, k.sym);
                 mask |= uint64_t(1) << packed_filter_bit(k.sym);
             }
             r[17] = ref; r[18] = uint32_t(mask); r[19] = uint32_t(mask >> 32);
-            t.n_overflow += uint32_t(nk - n_in);
+            t.n_overflow += uint32_t(overflow[pi].size());
         }
         r[3] |= fl << 16;
-        t.n_children += uint32_t(nk);
+        t.n_children += uint32_t(pf.kids.size());
+        t.n_left += uint32_t(lefts[pi].size());
     }
     t.n_rec = uint32_t(prefixes.size());
     t.present = true;
