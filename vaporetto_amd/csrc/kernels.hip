@@ -282,6 +282,7 @@ __device__ __forceinline__ void process_tile(const ScoreParams& P, const TileMem
         }
         const uint32_t si = kLds ? uint32_t(M.sidx[p]) : 0u;
         const uint64_t o = O0 + (p - uint32_t(pad)) - uint64_t(pad + 1) * si;
+        if (o >= P.ooff[i1]) { raise(P.status, kErrBadOffsets); continue; }  // only with offsets that do not match the text
         if (P.scores) P.scores[o] = y;
         if (P.labels) P.labels[o] = y > 0 ? 1 : 0;
     }

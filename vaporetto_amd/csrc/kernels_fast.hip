@@ -56,6 +56,20 @@ __device__ __forceinline__ uint32_t lane_rank(uint64_t mask) {  // set bits of `
     return __builtin_amdgcn_mbcnt_hi(uint32_t(mask >> 32), __builtin_amdgcn_mbcnt_lo(uint32_t(mask), 0u));
 }
 
+__device__ __forceinline__ uint32_t pair_swap(uint32_t x) {  // value of lane ^ 1 (DPP quad_perm [1,0,3,2])
+    return uint32_t(__builtin_amdgcn_update_dpp(0, int(x), 0xB1, 0xF, 0xF, false));
+}
+// A 64-byte half-record as loaded by one lane of a pair, and the exchange that leaves every lane with its OWN record:
+// in sub-round A the pair (2j, 2j+1) reads halves (0, 1) of lane 2j's record, in sub-round B of lane 2j+1's -- the
+// two halves of a 128-byte line are requested by adjacent lanes of ONE instruction, which is what the memory
+// pipeline rewards (tools/gather_bench.hip: 57 G records/s against 42 G/s when one lane reads all eight units).
+__device__ __forceinline__ uint4 pick(bool mine, const uint4& own, const uint4& partners) {
+    uint4 r;
+    r.x = mine ? own.x : pair_swap(partners.x); r.y = mine ? own.y : pair_swap(partners.y);
+    r.z = mine ? own.z : pair_swap(partners.z); r.w = mine ? own.w : pair_swap(partners.w);
+    return r;
+}
+
 // branch-free UTF-8 -> scalar value; b4 = the lead byte and the three bytes after it, little-endian
 __device__ __forceinline__ uint32_t utf8_scalar_bf(uint32_t b4) {
     const uint32_t b0 = b4 & 0xFF, b1 = (b4 >> 8) & 0x3F, b2 = (b4 >> 16) & 0x3F, b3 = (b4 >> 24) & 0x3F;
@@ -426,8 +440,15 @@ __global__ __launch_bounds__(kThreads) void score_tiles_fast_kernel(const ScoreP
         meta[k] = (ok && fits) ? (flat | ((nsi != si ? 1u : 0u) << 15) | (si << 16)) : 0xFFFFFFFFu;
     }
     __syncthreads();  // every (pos, sentence) record has been read; sym and score can be reused
-    for (uint32_t i = tid; i < (uint32_t(kFastCap + kMargin) * 4) / 16; i += kThreads)
+    // sym too: with offsets that do not match the text some flat positions would otherwise keep stale LDS contents
+    for (uint32_t i = tid; i < (uint32_t(kFastCap + kMargin) * 4) / 16; i += kThreads) {
         reinterpret_cast<uint4*>(L.score)[i] = make_uint4(0, 0, 0, 0);
+        reinterpret_cast<uint4*>(L.sym)[i] = make_uint4(0, 0, 0, 0);
+    }
+    if (TM != kTypeRows) {
+        for (uint32_t i = tid; i < uint32_t(kFastCap + kMargin) / 4; i += kThreads) reinterpret_cast<uint32_t*>(L.typ)[i] = 0;
+    }
+    __syncthreads();
     if (tid < int(pad)) { L.sym[tid] = 0; if (TM != kTypeRows) L.typ[tid] = 0; }
     if (tid >= 64 && tid < 64 + kMargin) {  // slack past the tile for the s+1, s+2 look-ahead
         const uint32_t p = flat_len + uint32_t(tid - 64);
@@ -469,8 +490,23 @@ __global__ __launch_bounds__(kThreads) void score_tiles_fast_kernel(const ScoreP
         if (P.debug & 1u) hrec = 0;  // timing ablation (VPT_DEBUG_ABLATE; results are wrong): pin the record
         // every load first: the unigram row and the whole record of (c1,c2)
         const uint4 u = uni4[(P.debug & 4u) ? 0u : c1];
-        const uint4* r = reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(rec4) + (hrec << 7));
-        const uint4 h0 = r[0], r1 = r[1], r2 = r[2], r3 = r[3], h1 = r[4], l1 = r[5], l2 = r[6], l3 = r[7];
+        const uint32_t p_hrec = pair_swap(hrec);
+        const bool odd = (lane & 1) != 0;
+        const uint4* ra = reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(rec4) + (((odd ? p_hrec : hrec) << 7) | (odd ? 64u : 0u)));
+        const uint4* rb = reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(rec4) + (((odd ? hrec : p_hrec) << 7) | (odd ? 0u : 64u)));
+        const uint4 qa0 = ra[0], qa1 = ra[1], qa2 = ra[2], qa3 = ra[3];   // even lane: own half 0; odd lane: partner's half 1
+        const uint4 qb0 = rb[0], qb1 = rb[1], qb2 = rb[2], qb3 = rb[3];   // even lane: partner's half 1; odd lane: own half 0
+        // own half 0 = even ? qa : qb (already here); own half 1 = the partner's qb (even lanes) / qa (odd lanes)
+        const uint4 h0 = odd ? qb0 : qa0, r1 = odd ? qb1 : qa1, r2 = odd ? qb2 : qa2, r3 = odd ? qb3 : qa3;
+        uint4 h1, l1, l2, l3;
+        {
+            // what this lane holds of the PARTNER's record, handed over through DPP
+            const uint4 g0 = odd ? qa0 : qb0, g1 = odd ? qa1 : qb1, g2 = odd ? qa2 : qb2, g3 = odd ? qa3 : qb3;
+            h1 = make_uint4(pair_swap(g0.x), pair_swap(g0.y), pair_swap(g0.z), pair_swap(g0.w));
+            l1 = make_uint4(pair_swap(g1.x), pair_swap(g1.y), pair_swap(g1.z), pair_swap(g1.w));
+            l2 = make_uint4(pair_swap(g2.x), pair_swap(g2.y), pair_swap(g2.z), pair_swap(g2.w));
+            l3 = make_uint4(pair_swap(g3.x), pair_swap(g3.y), pair_swap(g3.z), pair_swap(g3.w));
+        }
         // own row so far: unigram (+ type row)
         int32_t a0 = lo16(u.x), a1 = hi16(u.x), a2 = lo16(u.y), a3 = hi16(u.y), a4 = lo16(u.z), a5 = hi16(u.z);
         if (TM == kTypeRows) {
@@ -543,11 +579,12 @@ __global__ __launch_bounds__(kThreads) void score_tiles_fast_kernel(const ScoreP
         if (TM >= 1 && TM <= 3) {
             uint32_t id = 0;  // window t[b-W+1 .. b+W], 3 bits each (boundary_scorer_cache.rs:59-81)
 #pragma unroll
-            for (int i = 1 - TM; i <= TM; ++i) id = (id << 3) | L.typ[int(p) + i];
+            for (int i = 1 - TM; i <= TM; ++i) id = (id << 3) | (L.typ[int(p) + i] & 7u);
             y += P.type_table[id];
         }
         const uint32_t si = x >> 19;
         const uint64_t o = O0 + (p - pad) - uint64_t(pad + 1) * si;
+        if (o >= O1) { err |= kErrBadOffsets; continue; }  // only with offsets that do not match the text
         if (P.scores) P.scores[o] = y;
         if (P.labels) P.labels[o] = y > 0 ? 1 : 0;
     }
