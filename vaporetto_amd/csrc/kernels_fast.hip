@@ -128,6 +128,8 @@ __device__ __forceinline__ void add_child(int32_t* score, uint32_t st, uint32_t 
 }
 
 // W: up to 64 queued trie steps, all lanes busy: the child sym[s + depth] in the mini-table `ref` of `deep`.
+// The home entry and the next one are read together (a mini-table keeps a quarter of its entries free, so nearly
+// every search ends within two); the rare longer search loops.
 __device__ __forceinline__ void replay_w(const PackedView& K, FastLds& L, WaveStacks& Q, int lane) {
     const uint32_t take = Q.nw < 64u ? Q.nw : 64u;
     Q.nw -= take;
@@ -138,41 +140,50 @@ __device__ __forceinline__ void replay_w(const PackedView& K, FastLds& L, WaveSt
     const uint32_t c = (have && at < uint32_t(kFastCap + kMargin)) ? (L.sym[at] & kCpMask) : 0u;  // 0: sentence over
     const uint4* tab = reinterpret_cast<const uint4*>(K.deep) + size_t(it.y >> 5) * 2;
     const uint32_t last = (1u << (it.y & 31u)) - 1u;
-    uint32_t i = packed_mini_slot(c, it.y);
-    bool found = false, open = c != 0;
-    uint4 e = make_uint4(0, 0, 0, 0);
-    uint32_t n = 0;
-    while (__ballot(open) != 0) {  // nearly always one round: most nodes have a single child
-        if (open) {
-            e = tab[size_t(i) * 2];
-            found = (e.x & 0xFFFFu) == c;
-            open = !found && e.x != 0 && n < last;
-            i = (i + 1) & last;
-            ++n;
-        }
-    }
-    const uint32_t m = depth + 1;  // chars matched so far: a pattern of m chars has m + 1 weights, the first on
-    int32_t* dst = L.score + s - 1;  // boundary s - 1
-    const bool row = found && (e.x & (kPkHasRow << 16));
-    if (row) {
-        const uint4 f = tab[size_t((i - 1) & last) * 2 + 1];
-        atomicAdd(dst, lo16(e.z)); atomicAdd(dst + 1, hi16(e.z)); atomicAdd(dst + 2, lo16(e.w));
-        atomicAdd(dst + 3, hi16(e.w)); atomicAdd(dst + 4, lo16(f.x));  // m >= 4
-        if (m >= 5) atomicAdd(dst + 5, hi16(f.x));
-        if (__ballot(row && m >= 6) != 0) {  // wave-uniform skips: most dictionary words have 4-5 chars
-            if (m >= 6) atomicAdd(dst + 6, lo16(f.y));
-            if (m >= 7) atomicAdd(dst + 7, hi16(f.y));
-            if (__ballot(row && m >= 8) != 0) {
-                if (m >= 8) atomicAdd(dst + 8, lo16(f.z));
-                if (m >= 9) atomicAdd(dst + 9, hi16(f.z));
-                if (m >= 10) atomicAdd(dst + 10, lo16(f.w));
-                if (m >= 11) atomicAdd(dst + 11, hi16(f.w));
+    const uint32_t i0 = packed_mini_slot(c, it.y), i1 = (i0 + 1) & last;
+    const uint4 ea = tab[size_t(i0) * 2], fa = tab[size_t(i0) * 2 + 1], eb = tab[size_t(i1) * 2];
+    const bool ma = c != 0 && (ea.x & 0xFFFFu) == c;
+    const bool mb = c != 0 && !ma && ea.x != 0 && (eb.x & 0xFFFFu) == c;   // last == 0: eb is ea again, no match
+    bool found = ma || mb;
+    uint4 e = ma ? ea : eb;
+    uint32_t idx = ma ? i0 : i1;
+    bool open = c != 0 && !found && ea.x != 0 && eb.x != 0 && last > 1u;
+    if (__ballot(open) != 0) {  // rare
+        uint32_t i = (i1 + 1) & last, n = 2;
+        while (__ballot(open) != 0) {
+            if (open) {
+                e = tab[size_t(i) * 2];
+                found = (e.x & 0xFFFFu) == c;
+                idx = i;
+                open = !found && e.x != 0 && n < last;
+                i = (i + 1) & last;
+                ++n;
             }
         }
     }
-    if (found && (e.x & (kPkExtRow << 16))) {  // longer than 11 chars or a value outside i16: i32 row (rare)
-        const int32_t* w32 = K.xrows + e.z;
-        for (uint32_t j = 0; j <= m; ++j) atomicAdd(dst + j, w32[j]);
+    const uint32_t m = depth + 1;  // chars matched so far: a pattern of m chars has m + 1 weights, the first on
+    int32_t* dst = L.score + s - 1;  // boundary s - 1; unused row slots hold zero, adding them is harmless
+    const bool row = found && (e.x & (kPkHasRow << 16));
+    if (__ballot(row && !ma) != 0) {  // the row half of an entry that was not the home one (rare)
+        uint4 f2 = fa;
+        if (row && !ma) f2 = tab[size_t(idx) * 2 + 1];
+        if (row) {
+            atomicAdd(dst, lo16(e.z)); atomicAdd(dst + 1, hi16(e.z)); atomicAdd(dst + 2, lo16(e.w)); atomicAdd(dst + 3, hi16(e.w));
+            atomicAdd(dst + 4, lo16(f2.x)); atomicAdd(dst + 5, hi16(f2.x)); atomicAdd(dst + 6, lo16(f2.y)); atomicAdd(dst + 7, hi16(f2.y));
+            if (m >= 8) { atomicAdd(dst + 8, lo16(f2.z)); atomicAdd(dst + 9, hi16(f2.z)); atomicAdd(dst + 10, lo16(f2.w)); atomicAdd(dst + 11, hi16(f2.w)); }
+        }
+    } else if (row) {
+        atomicAdd(dst, lo16(e.z)); atomicAdd(dst + 1, hi16(e.z)); atomicAdd(dst + 2, lo16(e.w)); atomicAdd(dst + 3, hi16(e.w));
+        atomicAdd(dst + 4, lo16(fa.x)); atomicAdd(dst + 5, hi16(fa.x)); atomicAdd(dst + 6, lo16(fa.y)); atomicAdd(dst + 7, hi16(fa.y));
+        if (__ballot(m >= 8) != 0) {
+            if (m >= 8) { atomicAdd(dst + 8, lo16(fa.z)); atomicAdd(dst + 9, hi16(fa.z)); atomicAdd(dst + 10, lo16(fa.w)); atomicAdd(dst + 11, hi16(fa.w)); }
+        }
+    }
+    if (__ballot(found && (e.x & (kPkExtRow << 16))) != 0) {  // longer than 11 chars or a value outside i16 (rare)
+        if (found && (e.x & (kPkExtRow << 16))) {
+            const int32_t* w32 = K.xrows + e.z;
+            for (uint32_t j = 0; j <= m; ++j) atomicAdd(dst + j, w32[j]);
+        }
     }
     Q.push_w(found && e.y != 0, s | (m << 11), e.y);
 }
@@ -194,7 +205,8 @@ __device__ __forceinline__ bool general_row(const PatternTableView& T, uint64_t 
     }
 }
 
-// O: up to 64 queued overflow-child probes: c3 = sym[s + 2] in the mini-table `ref` of `kids3`.
+// O: up to 64 queued overflow-child probes: c3 = sym[s + 2] in the mini-table `ref` of `kids3` (two entries at once,
+// as in replay_w).
 __device__ __forceinline__ void replay_o(const PackedView& K, const PatternTableView& T, FastLds& L, WaveStacks& Q, int lane) {
     const uint32_t take = Q.no < 64u ? Q.no : 64u;
     Q.no -= take;
@@ -204,17 +216,23 @@ __device__ __forceinline__ void replay_o(const PackedView& K, const PatternTable
     const uint32_t c3 = have ? (L.sym[s + 2] & kCpMask) : 0u;
     const uint4* tab = reinterpret_cast<const uint4*>(K.kids3) + (it.y >> 5);
     const uint32_t last = (1u << (it.y & 31u)) - 1u;
-    uint32_t i = packed_mini_slot(c3, it.y);
-    bool found = false, open = have;
-    uint4 ch = make_uint4(0, 0, 0, 0);
-    uint32_t n = 0;
-    while (__ballot(open) != 0) {
-        if (open) {
-            ch = tab[i];
-            found = (ch.x & 0xFFFFu) == c3;
-            open = !found && ch.x != 0 && n < last;
-            i = (i + 1) & last;
-            ++n;
+    const uint32_t i0 = packed_mini_slot(c3, it.y), i1 = (i0 + 1) & last;
+    const uint4 ea = tab[i0], eb = tab[i1];
+    const bool ma = have && (ea.x & 0xFFFFu) == c3;
+    const bool mb = have && !ma && ea.x != 0 && (eb.x & 0xFFFFu) == c3;
+    bool found = ma || mb;
+    uint4 ch = ma ? ea : eb;
+    bool open = have && !found && ea.x != 0 && eb.x != 0 && last > 1u;
+    if (__ballot(open) != 0) {  // rare
+        uint32_t i = (i1 + 1) & last, n = 2;
+        while (__ballot(open) != 0) {
+            if (open) {
+                ch = tab[i];
+                found = (ch.x & 0xFFFFu) == c3;
+                open = !found && ch.x != 0 && n < last;
+                i = (i + 1) & last;
+                ++n;
+            }
         }
     }
     const bool wide = found && (ch.x & (kPkWide << 16));
