@@ -144,13 +144,21 @@ int tc_score(const tc_model* t, const uint32_t* cps, size_t n, int32_t* y_out, u
                 const size_t at = size_t(st) + depth;
                 const uint32_t c = sym[at < n ? at : n];
                 if (c == 0) break;
-                const uint32_t* e = mini_find(K.deep, 8, ref, c, &probes[2]);
+                const uint32_t* e = mini_find(K.deep, 16, ref, c, &probes[2]);
                 if (!e) break;
-                const uint32_t m = depth + 1;
+                const uint32_t nskip = (e[0] >> 24) & 15u;
+                bool ok = true;
+                for (uint32_t j = 0; j < nskip; ++j) {
+                    const size_t q = at + 1 + j;
+                    const uint32_t want = (e[2 + j / 2] >> (16 * (j & 1))) & 0xFFFFu;
+                    if ((q < n ? sym[q] : 0u) != want) ok = false;
+                }
+                if (!ok) break;
+                const uint32_t m = depth + 1 + nskip;
                 if (e[0] & (kPkHasRow << 16)) {
-                    for (uint32_t j = 0; j <= m; ++j) add(y, st - 1 + long(j), (j & 1) ? hi16(e[2 + (j >> 1)]) : lo16(e[2 + (j >> 1)]));
+                    for (uint32_t j = 0; j <= m; ++j) add(y, st - 1 + long(j), (j & 1) ? hi16(e[8 + (j >> 1)]) : lo16(e[8 + (j >> 1)]));
                 } else if (e[0] & (kPkExtRow << 16)) {
-                    for (uint32_t j = 0; j <= m; ++j) add(y, st - 1 + long(j), K.xrows[size_t(e[2]) + j]);
+                    for (uint32_t j = 0; j <= m; ++j) add(y, st - 1 + long(j), K.xrows[size_t(e[8]) + j]);
                 }
                 ref = e[1];
                 depth = m;

@@ -324,3 +324,26 @@ def test_long_type_ngrams_use_the_window_table():
     assert pred.info()["type_rows"] == 0 and pred.info()["packed"] == 1
     mixed = randmodel.ALPHABETS["mixed"] + randmodel.ALPHABETS["kana"][:8]
     check_batch(pred, orc, randmodel.rand_sentences(2, m, 1500, alphabet=mixed, max_len=60))
+
+
+def test_very_long_words_and_compressed_chains():
+    import random
+    rng = random.Random(5)
+    alpha = [chr(c) for c in range(0x3041, 0x3049)]
+    m = ModelData(bias=11, char_window_size=3, type_window_size=3)
+    words = set()
+    base = "".join(rng.choice(alpha) for _ in range(40))
+    for n in (4, 5, 9, 12, 13, 14, 15, 21, 22, 30, 40):
+        words.add(base[:n])
+    for n in (6, 13, 17, 25):
+        words.add(base[:n - 1] + "ん")
+    for _ in range(60):
+        words.add("".join(rng.choice(alpha) for _ in range(rng.randint(4, 28))))
+    for w in sorted(words):
+        m.dict_model.append(WordWeightRecord(w, [rng.randint(-3000, 3000) for _ in range(len(w) + 1)], ""))
+    m.type_ngram_model.append(NgramData(bytes([3, 3]), [5, -6, 7, 8, 9]))
+    pred, orc = make_predictor(m)
+    assert pred.info()["packed"] == 1
+    texts = [base, base[:29] + "ん" + base, "あ" + base[:13] + base[:24] + "ん", base[3:] + base]
+    texts += ["".join(rng.choice(sorted(words)) for _ in range(3)) for _ in range(400)]
+    check_batch(pred, orc, texts)

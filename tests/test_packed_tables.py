@@ -189,3 +189,30 @@ def test_type_rows_absent_for_long_or_large_type_ngrams(tc):
     m.char_ngram_model.append(NgramData("あ", [1, 2, 3, 4, 5, 6]))
     m.type_ngram_model.append(NgramData(bytes([3, 5]), [1, 2, 3, 4, 5]))
     assert Walker(tc, encode_model(m)).trow
+
+
+def test_long_words_compressed_chains(tc):
+    """Dictionary words far longer than one compressed chain (3 + 1 + 8 chars) and than an inline row (14 weights),
+    nested prefixes that own rows in the middle of a chain, and branches inside long words."""
+    import random
+    rng = random.Random(5)
+    alpha = [chr(c) for c in range(0x3041, 0x3049)]
+    m = ModelData(bias=11, char_window_size=3, type_window_size=3)
+    words = set()
+    base = "".join(rng.choice(alpha) for _ in range(40))
+    for n in (4, 5, 9, 12, 13, 14, 15, 21, 22, 30, 40):
+        words.add(base[:n])                      # nested prefixes of one long string
+    for n in (6, 13, 17, 25):
+        words.add(base[:n - 1] + "ん")            # branches off the long string
+    for _ in range(60):
+        words.add("".join(rng.choice(alpha) for _ in range(rng.randint(4, 28))))
+    for w in sorted(words):
+        m.dict_model.append(WordWeightRecord(w, [rng.randint(-3000, 3000) for _ in range(len(w) + 1)], ""))
+    raw = encode_model(m)
+    w = Walker(tc, raw)
+    assert w.packed
+    orc = cbind.OraclePredictor(raw)
+    texts = [base, base[:29] + "ん" + base, "あ" + base[:13] + base[:24] + "ん", base[3:] + base]
+    texts += ["".join(rng.choice(sorted(words)) for _ in range(3)) for _ in range(80)]
+    for t in texts:
+        assert w.score(t) == orc.predict(t)[0], t

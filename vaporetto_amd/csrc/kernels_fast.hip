@@ -127,7 +127,8 @@ __device__ __forceinline__ void add_child(int32_t* score, uint32_t st, uint32_t 
     atomicAdd(p, lo16(w01)); atomicAdd(p + 1, hi16(w01)); atomicAdd(p + 2, lo16(w23)); atomicAdd(p + 3, hi16(w23));
 }
 
-// W: up to 64 queued trie steps, all lanes busy: the child sym[s + depth] in the mini-table `ref` of `deep`.
+// W: up to 64 queued trie steps, all lanes busy: the child sym[s + depth] in the mini-table `ref` of `deep`, whose
+// 64-byte entries also name the up-to-8 symbols that must follow (compressed single-child chains; layout.h).
 // The home entry and the next one are read together (a mini-table keeps a quarter of its entries free, so nearly
 // every search ends within two); the rare longer search loops.
 __device__ __forceinline__ void replay_w(const PackedView& K, FastLds& L, WaveStacks& Q, int lane) {
@@ -138,10 +139,10 @@ __device__ __forceinline__ void replay_w(const PackedView& K, FastLds& L, WaveSt
     const uint32_t s = it.x & 0x7FFu, depth = it.x >> 11;
     const uint32_t at = s + depth;
     const uint32_t c = (have && at < uint32_t(kFastCap + kMargin)) ? (L.sym[at] & kCpMask) : 0u;  // 0: sentence over
-    const uint4* tab = reinterpret_cast<const uint4*>(K.deep) + size_t(it.y >> 5) * 2;
+    const uint4* tab = reinterpret_cast<const uint4*>(K.deep) + size_t(it.y >> 5) * 4;
     const uint32_t last = (1u << (it.y & 31u)) - 1u;
     const uint32_t i0 = packed_mini_slot(c, it.y), i1 = (i0 + 1) & last;
-    const uint4 ea = tab[size_t(i0) * 2], fa = tab[size_t(i0) * 2 + 1], eb = tab[size_t(i1) * 2];
+    const uint4 ea = tab[size_t(i0) * 4], eb = tab[size_t(i1) * 4];
     const bool ma = c != 0 && (ea.x & 0xFFFFu) == c;
     const bool mb = c != 0 && !ma && ea.x != 0 && (eb.x & 0xFFFFu) == c;   // last == 0: eb is ea again, no match
     bool found = ma || mb;
@@ -152,7 +153,7 @@ __device__ __forceinline__ void replay_w(const PackedView& K, FastLds& L, WaveSt
         uint32_t i = (i1 + 1) & last, n = 2;
         while (__ballot(open) != 0) {
             if (open) {
-                e = tab[size_t(i) * 2];
+                e = tab[size_t(i) * 4];
                 found = (e.x & 0xFFFFu) == c;
                 idx = i;
                 open = !found && e.x != 0 && n < last;
@@ -161,27 +162,43 @@ __device__ __forceinline__ void replay_w(const PackedView& K, FastLds& L, WaveSt
             }
         }
     }
-    const uint32_t m = depth + 1;  // chars matched so far: a pattern of m chars has m + 1 weights, the first on
-    int32_t* dst = L.score + s - 1;  // boundary s - 1; unused row slots hold zero, adding them is harmless
-    const bool row = found && (e.x & (kPkHasRow << 16));
-    if (__ballot(row && !ma) != 0) {  // the row half of an entry that was not the home one (rare)
-        uint4 f2 = fa;
-        if (row && !ma) f2 = tab[size_t(idx) * 2 + 1];
-        if (row) {
-            atomicAdd(dst, lo16(e.z)); atomicAdd(dst + 1, hi16(e.z)); atomicAdd(dst + 2, lo16(e.w)); atomicAdd(dst + 3, hi16(e.w));
-            atomicAdd(dst + 4, lo16(f2.x)); atomicAdd(dst + 5, hi16(f2.x)); atomicAdd(dst + 6, lo16(f2.y)); atomicAdd(dst + 7, hi16(f2.y));
-            if (m >= 8) { atomicAdd(dst + 8, lo16(f2.z)); atomicAdd(dst + 9, hi16(f2.z)); atomicAdd(dst + 10, lo16(f2.w)); atomicAdd(dst + 11, hi16(f2.w)); }
-        }
-    } else if (row) {
-        atomicAdd(dst, lo16(e.z)); atomicAdd(dst + 1, hi16(e.z)); atomicAdd(dst + 2, lo16(e.w)); atomicAdd(dst + 3, hi16(e.w));
-        atomicAdd(dst + 4, lo16(fa.x)); atomicAdd(dst + 5, hi16(fa.x)); atomicAdd(dst + 6, lo16(fa.y)); atomicAdd(dst + 7, hi16(fa.y));
-        if (__ballot(m >= 8) != 0) {
-            if (m >= 8) { atomicAdd(dst + 8, lo16(fa.z)); atomicAdd(dst + 9, hi16(fa.z)); atomicAdd(dst + 10, lo16(fa.w)); atomicAdd(dst + 11, hi16(fa.w)); }
+    const uint4* ent = tab + size_t(idx) * 4;
+    // the symbols that must follow (none for most entries of a dense trie, several for a long rare word)
+    const uint32_t nskip = found ? (e.x >> 24) & 15u : 0u;
+    if (__ballot(nskip != 0) != 0) {
+        uint4 e1 = make_uint4(0, 0, 0, 0);
+        if (__ballot(nskip > 2) != 0) { if (nskip > 2) e1 = ent[1]; }
+        const uint32_t sk[4] = {e.z, e.w, e1.x, e1.y};
+#pragma unroll
+        for (uint32_t j = 0; j < kPackedMaxSkip; ++j) {
+            if (__ballot(j < nskip) == 0) break;
+            const uint32_t q = at + 1 + j;
+            const uint32_t have_c = (j < nskip && q < uint32_t(kFastCap + kMargin)) ? (L.sym[q] & kCpMask) : 0u;
+            const uint32_t want = (sk[j >> 1] >> (16 * (j & 1))) & 0xFFFFu;
+            if (j < nskip && have_c != want) found = false;
         }
     }
-    if (__ballot(found && (e.x & (kPkExtRow << 16))) != 0) {  // longer than 11 chars or a value outside i16 (rare)
+    const uint32_t m = depth + 1 + nskip;  // chars matched so far: a pattern of m chars has m + 1 weights, the first
+    int32_t* dst = L.score + s - 1;        // on boundary s - 1; unused row slots hold zero, adding them is harmless
+    const bool row = found && (e.x & (kPkHasRow << 16));
+    if (__ballot(row) != 0) {
+        uint4 f0 = make_uint4(0, 0, 0, 0), f1 = make_uint4(0, 0, 0, 0);
+        if (row) f0 = ent[2];
+        if (__ballot(row && m >= 8) != 0) { if (row && m >= 8) f1 = ent[3]; }
+        if (row) {
+            atomicAdd(dst, lo16(f0.x)); atomicAdd(dst + 1, hi16(f0.x)); atomicAdd(dst + 2, lo16(f0.y)); atomicAdd(dst + 3, hi16(f0.y));
+            atomicAdd(dst + 4, lo16(f0.z)); atomicAdd(dst + 5, hi16(f0.z)); atomicAdd(dst + 6, lo16(f0.w)); atomicAdd(dst + 7, hi16(f0.w));
+        }
+        if (__ballot(row && m >= 8) != 0) {
+            if (row && m >= 8) {
+                atomicAdd(dst + 8, lo16(f1.x)); atomicAdd(dst + 9, hi16(f1.x)); atomicAdd(dst + 10, lo16(f1.y));
+                atomicAdd(dst + 11, hi16(f1.y)); atomicAdd(dst + 12, lo16(f1.z)); atomicAdd(dst + 13, hi16(f1.z));
+            }
+        }
+    }
+    if (__ballot(found && (e.x & (kPkExtRow << 16))) != 0) {  // more than 14 weights or a value outside i16 (rare)
         if (found && (e.x & (kPkExtRow << 16))) {
-            const int32_t* w32 = K.xrows + e.z;
+            const int32_t* w32 = K.xrows + ent[2].x;
             for (uint32_t j = 0; j <= m; ++j) atomicAdd(dst + j, w32[j]);
         }
     }
@@ -573,7 +590,7 @@ __global__ __launch_bounds__(kThreads) void score_tiles_fast_kernel(const ScoreP
         make_room(K, P.ct, L, Q, lane);
         Q.push_w(rk != 0 && !nowalk, s | (3u << 11), rk);
         Q.push_o(ovp, s, h1.y);
-        Q.push_m(kinds != 0, s | (kinds << 11));
+        Q.push_m(kinds != 0 && !(P.debug & 32u), s | (kinds << 11));
         if (__ballot(lk != 0) != 0) {
             make_room(K, P.ct, L, Q, lane);
             Q.push_w(lk != 0 && !nowalk, (s - 1) | (3u << 11), lk);

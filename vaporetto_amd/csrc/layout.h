@@ -57,10 +57,14 @@
 //          many children are the frequent ones; spreading their children over the records of the FOLLOWING prefix
 //          keeps most lookups to the one line per position.
 //   kids3  16-byte entries, same format as an inline child.
-//   deep   32-byte entries for trie nodes at depth m >= 4:
-//            {sym | dflags<<16, kids, w0|w1<<16, w2|w3<<16} {w4|w5<<16 ... w10|w11<<16}
-//          the row of a pattern of m chars has m+1 weights (boundaries s-1 .. s+m-1) and sits inline when m <= 11
-//          and every value fits i16 (kPkHasRow); otherwise kPkExtRow and dword 2 = offset of an i32 row in `xrows`.
+//   deep   64-byte entries for the trie below depth 3.  An entry stands for a child symbol PLUS the chain of up to 8
+//          further symbols that must follow it (nodes with a single child and no row of their own are compressed
+//          away), and ends at a node of depth m:
+//            dword 0      sym | dflags<<16 | nskip<<24          dword 1   kids (mini-table of the end node's children)
+//            dwords 2..5  the nskip further symbols, 16 bits each
+//            dwords 8..14 the row of the end node's pattern: m+1 weights i16 (boundaries s-1 .. s+m-1), inline when
+//                         m+1 <= 14 and every value fits i16 (kPkHasRow); otherwise kPkExtRow and dword 8 = offset of
+//                         an i32 row in `xrows`.
 //   mini-table ref = base << 5 | log2(size): `size` consecutive entries of one arena holding the children of ONE
 //          node (so a hot node's children are contiguous and cache-hot together); entry index
 //          (sym * kHashMulLo >> 15) & (size-1), linear probing inside the mini-table, at most `size` probes,
@@ -101,7 +105,8 @@ constexpr uint32_t kHashMulLo = 0x9E3779B1u, kHashMulHi = 0x85EBCA77u;
 constexpr uint32_t kPkDisp = 1u, kPkExtRow = 2u, kPkHasRow = 4u, kPkWide = 8u, kPkOv = 16u;  // packed flags
 constexpr uint32_t kPackedNoMatchSym = 0xFFFFu;
 constexpr uint32_t kPackedInlineKids = 6;      // children held by a record itself
-constexpr uint32_t kPackedInlineRow = 12;      // weights a `deep` entry holds inline
+constexpr uint32_t kPackedInlineRow = 14;      // weights a `deep` entry holds inline
+constexpr uint32_t kPackedMaxSkip = 8;         // further symbols a `deep` entry can require (path compression)
 
 #if defined(__HIPCC__)
 #define VPT_HD __host__ __device__ __forceinline__

@@ -288,36 +288,61 @@ HostPackedTable build_packed(const std::vector<Pat>& pats) {
     }
     t.n_deep = 0;
 
-    // ---- deep arena: the children mini-table of every node, deepest nodes first (an entry names its own kids' table)
-    t.deep.assign(8, 0);    // entry 0 unused: ref 0 = none
+    // ---- deep arena: the children mini-table of every node that owns one, deepest owners first (an entry names
+    // the table of the node it ends at).  Chains of nodes that carry no row and have a single child are COMPRESSED
+    // into the entry of their first node (up to kPackedMaxSkip further symbols), so that a dictionary word of any
+    // ordinary length costs one trie step past its third char.
+    t.deep.assign(16, 0);   // entry 0 unused: ref 0 = none
     t.kids3.assign(4, 0);
-    std::vector<std::vector<uint32_t>> by_depth(max_depth + 1);
-    for (uint32_t i = 0; i < nodes.size(); ++i) by_depth[nodes[i].depth].push_back(i);
-    for (uint32_t d = max_depth; d >= 3 && d <= max_depth; --d) {
-        for (uint32_t ni : by_depth[d]) {
-            Node& nd = nodes[ni];
-            if (nd.kids.empty()) continue;
-            nd.ref = mini_alloc(t.deep, 8, nd.kids.size());
-            for (uint32_t ki : nd.kids) {
-                const Node& k = nodes[ki];
-                uint32_t* e = mini_insert(t.deep, 8, nd.ref, k.sym);
-                uint32_t fl = 0;
-                if (k.pat) {
-                    const std::vector<int32_t>& r = k.pat->row;   // depth + 1 values, first = boundary s - 1
-                    if (r.size() <= kPackedInlineRow && !wide(*k.pat)) {
-                        fl |= kPkHasRow;
-                        for (size_t j = 0; j < r.size(); j += 2) e[2 + j / 2] = pack16(r[j], j + 1 < r.size() ? r[j + 1] : 0);
-                    } else {
-                        fl |= kPkExtRow;
-                        if (wide(*k.pat)) ++t.n_wide;
-                        e[2] = uint32_t(t.xrows.size());
-                        t.xrows.insert(t.xrows.end(), r.begin(), r.end());
-                    }
-                }
-                e[0] = k.sym | (fl << 16);
-                e[1] = k.ref;
-                ++t.n_deep;
+    auto chain_end = [&](uint32_t ki, std::vector<Sym>* skipped) {
+        uint32_t cur = ki, steps = 0;
+        while (nodes[cur].pat == nullptr && nodes[cur].kids.size() == 1 && steps < kPackedMaxSkip) {
+            cur = nodes[cur].kids[0];
+            if (skipped) skipped->push_back(nodes[cur].sym);
+            ++steps;
+        }
+        return cur;
+    };
+    std::vector<uint32_t> owners;           // nodes that own a mini-table: depth-3 nodes and chain ends, with children
+    {
+        std::vector<uint32_t> work;
+        for (uint32_t i = 0; i < nodes.size(); ++i)
+            if (nodes[i].depth == 3 && !nodes[i].kids.empty()) work.push_back(i);
+        while (!work.empty()) {
+            const uint32_t ni = work.back();
+            work.pop_back();
+            owners.push_back(ni);
+            for (uint32_t ki : nodes[ni].kids) {
+                const uint32_t e = chain_end(ki, nullptr);
+                if (!nodes[e].kids.empty()) work.push_back(e);
             }
+        }
+    }
+    std::sort(owners.begin(), owners.end(), [&](uint32_t x, uint32_t y) { return nodes[x].depth > nodes[y].depth; });
+    for (uint32_t ni : owners) {
+        Node& nd = nodes[ni];
+        nd.ref = mini_alloc(t.deep, 16, nd.kids.size());
+        for (uint32_t ki : nd.kids) {
+            std::vector<Sym> skipped;
+            const Node& k = nodes[chain_end(ki, &skipped)];      // the node this entry ends at
+            uint32_t* e = mini_insert(t.deep, 16, nd.ref, nodes[ki].sym);
+            uint32_t fl = 0;
+            if (k.pat) {
+                const std::vector<int32_t>& r = k.pat->row;   // depth + 1 values, first = boundary s - 1
+                if (r.size() <= kPackedInlineRow && !wide(*k.pat)) {
+                    fl |= kPkHasRow;
+                    for (size_t j = 0; j < r.size(); j += 2) e[8 + j / 2] = pack16(r[j], j + 1 < r.size() ? r[j + 1] : 0);
+                } else {
+                    fl |= kPkExtRow;
+                    if (wide(*k.pat)) ++t.n_wide;
+                    e[8] = uint32_t(t.xrows.size());
+                    t.xrows.insert(t.xrows.end(), r.begin(), r.end());
+                }
+            }
+            e[0] = nodes[ki].sym | (fl << 16) | (uint32_t(skipped.size()) << 24);
+            e[1] = k.ref;
+            for (size_t j = 0; j < skipped.size(); ++j) e[2 + j / 2] |= skipped[j] << (16 * (j & 1));
+            ++t.n_deep;
         }
     }
     if (t.xrows.empty()) t.xrows.push_back(0);
