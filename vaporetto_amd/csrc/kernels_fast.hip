@@ -86,7 +86,7 @@ __device__ __forceinline__ uint32_t utf8_scalar_bf(uint32_t b4) {
 // Wave-private stacks of deferred work (wave-uniform counts):
 //   W  x = s | depth << 11   y = mini-table ref (in `deep`) of the children to search      trie step
 //   O  x = s                 y = overflow mini-table ref (in `kids3`)                       overflow-child probe
-//   M  x = s | kinds << 11                                                                  the rare rest
+//   M  x = s | kinds << 11   y = record slot to look at next (kRecMore)                     the rare rest
 constexpr uint32_t kRecMore = 1u, kWideUni = 4u, kWideBi = 8u, kWideTri = 16u, kWideLeft = 32u;
 struct WaveStacks {
     uint2* q;
@@ -104,10 +104,10 @@ struct WaveStacks {
         if (pred) q[kQCap - 1 - (no + lane_rank(m))] = make_uint2(x, y);
         no += uint32_t(__popcll(m));
     }
-    __device__ __forceinline__ void push_m(bool pred, uint32_t x) {
+    __device__ __forceinline__ void push_m(bool pred, uint32_t x, uint32_t y) {
         const uint64_t m = __ballot(pred);
         if (m == 0) return;
-        if (pred) mq[nm + lane_rank(m)] = make_uint2(x, 0u);
+        if (pred) mq[nm + lane_rank(m)] = make_uint2(x, y);
         nm += uint32_t(__popcll(m));
     }
 };
@@ -262,10 +262,75 @@ __device__ __forceinline__ void replay_o(const PackedView& K, const PatternTable
     Q.push_w(found && ch.w != 0, s | (3u << 11), ch.w);
 }
 
-// M: the rare rest, one lane per item, written for brevity rather than speed.
-//   kRecMore: the record of (c1,c2) is not in its home slot -- find it further on and do what the main loop does.
-//   kWide*:   a row with a value outside i16 -- take it from the general tables (i32).
+// What a record contributes to the start position that fetched it (the main loop and the M replay share this).
+struct RecMatch {
+    int32_t b1, b2, b3, b4, b5;   // bigram row + matching right child, boundaries s-2 .. s+2
+    bool hit_l;                   // a left child matched: its row (ly, lz) belongs to the string starting at s-1
+    uint32_t ly, lz;
+    uint32_t rk, lk;              // trie continuations (mini-table refs in `deep`) of the right / left child, or 0
+    bool ovp;                     // the overflow mini-table `ov_ref` may hold (c1,c2,c3)
+    uint32_t ov_ref;
+    uint32_t wide;                // kWideBi | kWideTri | kWideLeft
+};
+__device__ __forceinline__ RecMatch match_record(bool keyok, uint32_t c0, uint32_t c3, const uint4& h0, const uint4& r1, const uint4& r2,
+                                                 const uint4& r3, const uint4& h1, const uint4& l1, const uint4& l2, const uint4& l3) {
+    RecMatch o;
+    // right children: (c1,c2,c3) starts here
+    const bool kr = keyok && c3 != 0;
+    const bool mr1 = kr && (r1.x & 0xFFFFu) == c3, mr2 = kr && (r2.x & 0xFFFFu) == c3, mr3 = kr && (r3.x & 0xFFFFu) == c3;
+    const bool hit_r = mr1 || mr2 || mr3;
+    const uint32_t rx = mr1 ? r1.x : mr2 ? r2.x : mr3 ? r3.x : 0u;
+    const uint32_t ry = mr1 ? r1.y : mr2 ? r2.y : mr3 ? r3.y : 0u;
+    const uint32_t rz = mr1 ? r1.z : mr2 ? r2.z : mr3 ? r3.z : 0u;
+    o.rk = mr1 ? r1.w : mr2 ? r2.w : mr3 ? r3.w : 0u;
+    // left children: (c0,c1,c2) started one position earlier
+    const bool kl = keyok && c0 != 0;
+    const bool ml1 = kl && (l1.x & 0xFFFFu) == c0, ml2 = kl && (l2.x & 0xFFFFu) == c0, ml3 = kl && (l3.x & 0xFFFFu) == c0;
+    const uint32_t lx = ml1 ? l1.x : ml2 ? l2.x : ml3 ? l3.x : 0u;
+    o.hit_l = (ml1 || ml2 || ml3) && !(lx & (kPkWide << 16));
+    o.ly = ml1 ? l1.y : ml2 ? l2.y : l3.y;
+    o.lz = ml1 ? l1.z : ml2 ? l2.z : l3.z;
+    o.lk = ml1 ? l1.w : ml2 ? l2.w : ml3 ? l3.w : 0u;
+    // bigram row + right child (a kPkWide slot holds zero weights)
+    const uint32_t by = keyok ? h0.y : 0u, bz = keyok ? h0.z : 0u, bw = keyok ? h0.w : 0u;
+    o.b1 = lo16(by); o.b2 = hi16(by) + lo16(ry); o.b3 = lo16(bz) + hi16(ry);
+    o.b4 = hi16(bz) + lo16(rz); o.b5 = lo16(bw) + hi16(rz);
+    o.ovp = false;
+    if (kr && !hit_r && (bw & (kPkOv << 16))) {
+        const uint32_t bit = packed_filter_bit(c3);
+        o.ovp = ((bit < 32 ? h1.z >> bit : h1.w >> (bit - 32)) & 1u) != 0;
+    }
+    o.ov_ref = h1.y;
+    o.wide = ((bw & (kPkWide << 16)) ? kWideBi : 0u) | ((rx & (kPkWide << 16)) ? kWideTri : 0u) | ((lx & (kPkWide << 16)) ? kWideLeft : 0u);
+    return o;
+}
+
+// rows with a value outside i16 (rare): the general tables hold them as i32
+__device__ __forceinline__ void add_wide_rows(const PatternTableView& T, FastLds& L, uint32_t kinds, uint32_t s, uint32_t c0, uint32_t c1,
+                                              uint32_t c2, uint32_t c3) {
+    uint4 r0, r1;
+    if (kinds & kWideUni) {
+        const uint4* u = reinterpret_cast<const uint4*>(T.uni) + size_t(c1) * 2;
+        r0 = u[0]; r1 = u[1];
+        add_row6(L.score, s, int32_t(r0.x), int32_t(r0.y), int32_t(r0.z), int32_t(r0.w), int32_t(r1.x), int32_t(r1.y));
+    }
+    if ((kinds & kWideBi) && general_row(T, short_key(c1, c2, 0), r0, r1))
+        add_row6(L.score, s, 0, int32_t(r0.z), int32_t(r0.w), int32_t(r1.x), int32_t(r1.y), int32_t(r1.z));
+    if ((kinds & kWideTri) && general_row(T, short_key(c1, c2, c3), r0, r1))
+        add_row6(L.score, s, 0, 0, int32_t(r0.z), int32_t(r0.w), int32_t(r1.x), int32_t(r1.y));
+    if ((kinds & kWideLeft) && general_row(T, short_key(c0, c1, c2), r0, r1))
+        add_row6(L.score, s - 1, 0, 0, int32_t(r0.z), int32_t(r0.w), int32_t(r1.x), int32_t(r1.y));
+}
+
+__device__ __forceinline__ void drain_wo(const PackedView& K, const PatternTableView& T, FastLds& L, WaveStacks& Q, int lane, uint32_t mark);
+
+// M: up to 64 queued items of the rare kinds.
+//   kRecMore: the record of (c1,c2) was not in its home slot -- y names the next slot to look at; the record found
+//             there is scored like in the main loop, a different key re-queues the item for the following slot,
+//             an empty slot ends the search.
+//   kWide*:   a row with a value outside i16 -- taken from the general tables (i32).
 __device__ __forceinline__ void replay_m(const PackedView& K, const PatternTableView& T, FastLds& L, WaveStacks& Q, int lane) {
+    drain_wo(K, T, L, Q, lane, kQHigh);  // room for this call's pushes
     const uint32_t take = Q.nm < 64u ? Q.nm : 64u;
     Q.nm -= take;
     const bool have = uint32_t(lane) < take;
@@ -275,61 +340,25 @@ __device__ __forceinline__ void replay_m(const PackedView& K, const PatternTable
     const uint32_t c0 = have ? (L.sym[s - 1] & kCpMask) : 0u;
     const uint32_t c1 = L.sym[s] & kCpMask, c2 = L.sym[s + 1] & kCpMask, c3 = L.sym[s + 2] & kCpMask;
     const uint32_t kb = c1 | (c2 << 16);
-    bool walk_r = false, walk_l = false, ovp = false;
-    uint32_t kids_r = 0, kids_l = 0, ov_ref = 0;
-    if (kinds & kRecMore) {
-        const uint4* rec4 = reinterpret_cast<const uint4*>(K.rec);
-        uint32_t b = packed_hash1(kb, K.rec_shift);
-        for (;;) {
-            b = (b + 1) & K.rec_mask;
-            const uint4* r = rec4 + size_t(b) * 8;
-            const uint4 h0 = r[0];
-            if (h0.x == kb) {
-                if (h0.w & (kPkWide << 16)) kinds |= kWideBi;
-                else add_row6(L.score, s, 0, lo16(h0.y), hi16(h0.y), lo16(h0.z), hi16(h0.z), lo16(h0.w));
-                bool hit = false;
-                for (int j = 1; j <= 3; ++j) {
-                    const uint4 ch = r[j];
-                    if (c3 != 0 && (ch.x & 0xFFFFu) == c3) {
-                        hit = true;
-                        if (ch.x & (kPkWide << 16)) kinds |= kWideTri; else add_child(L.score, s, ch.y, ch.z);
-                        walk_r = ch.w != 0; kids_r = ch.w;
-                    }
-                }
-                for (int j = 5; j <= 7; ++j) {
-                    const uint4 ch = r[j];
-                    if (c0 != 0 && (ch.x & 0xFFFFu) == c0) {
-                        if (ch.x & (kPkWide << 16)) kinds |= kWideLeft; else add_child(L.score, s - 1, ch.y, ch.z);
-                        walk_l = ch.w != 0; kids_l = ch.w;
-                    }
-                }
-                if (c3 != 0 && !hit && (h0.w & (kPkOv << 16))) {
-                    const uint4 h1 = r[4];
-                    const uint32_t bit = packed_filter_bit(c3);
-                    if (((bit < 32 ? h1.z >> bit : h1.w >> (bit - 32)) & 1u) != 0) { ovp = true; ov_ref = h1.y; }
-                }
-                break;
-            }
-            if (h0.x == 0) break;
-        }
+    const bool more = (kinds & kRecMore) != 0;
+    const uint4* r = reinterpret_cast<const uint4*>(K.rec) + size_t(more ? it.y : 0u) * 8;
+    const uint4 h0 = r[0], r1 = r[1], r2 = r[2], r3 = r[3], h1 = r[4], l1 = r[5], l2 = r[6], l3 = r[7];
+    const bool keyok = more && h0.x == kb;
+    const bool again = more && !keyok && h0.x != 0;
+    const RecMatch mt = match_record(keyok, c0, c3, h0, r1, r2, r3, h1, l1, l2, l3);
+    if (keyok) add_row6(L.score, s, 0, mt.b1, mt.b2, mt.b3, mt.b4, mt.b5);
+    if (mt.hit_l) add_child(L.score, s - 1, mt.ly, mt.lz);
+    kinds = (kinds & (kWideUni | kWideBi | kWideTri | kWideLeft)) | mt.wide;
+    if (__ballot(kinds != 0) != 0) {
+        if (kinds != 0) add_wide_rows(T, L, kinds, s, c0, c1, c2, c3);
     }
-    if (kinds & (kWideUni | kWideBi | kWideTri | kWideLeft)) {
-        uint4 r0, r1;
-        if (kinds & kWideUni) {
-            const uint4* u = reinterpret_cast<const uint4*>(T.uni) + size_t(c1) * 2;
-            r0 = u[0]; r1 = u[1];
-            add_row6(L.score, s, int32_t(r0.x), int32_t(r0.y), int32_t(r0.z), int32_t(r0.w), int32_t(r1.x), int32_t(r1.y));
-        }
-        if ((kinds & kWideBi) && general_row(T, short_key(c1, c2, 0), r0, r1))
-            add_row6(L.score, s, 0, int32_t(r0.z), int32_t(r0.w), int32_t(r1.x), int32_t(r1.y), int32_t(r1.z));
-        if ((kinds & kWideTri) && general_row(T, short_key(c1, c2, c3), r0, r1))
-            add_row6(L.score, s, 0, 0, int32_t(r0.z), int32_t(r0.w), int32_t(r1.x), int32_t(r1.y));
-        if ((kinds & kWideLeft) && general_row(T, short_key(c0, c1, c2), r0, r1))
-            add_row6(L.score, s - 1, 0, 0, int32_t(r0.z), int32_t(r0.w), int32_t(r1.x), int32_t(r1.y));
+    Q.push_w(mt.rk != 0, s | (3u << 11), mt.rk);
+    Q.push_o(mt.ovp, s, mt.ov_ref);
+    Q.push_m(again, s | (kRecMore << 11), (it.y + 1) & K.rec_mask);
+    if (__ballot(mt.lk != 0) != 0) {
+        drain_wo(K, T, L, Q, lane, kQHigh);
+        Q.push_w(mt.lk != 0, (s - 1) | (3u << 11), mt.lk);
     }
-    Q.push_w(walk_r, s | (3u << 11), kids_r);
-    Q.push_w(walk_l, (s - 1) | (3u << 11), kids_l);
-    Q.push_o(ovp, s, ov_ref);
 }
 
 // W/O replays until at most `mark` items are left.  A replay never grows W + O (an O item becomes at most one W
@@ -340,13 +369,9 @@ __device__ __forceinline__ void drain_wo(const PackedView& K, const PatternTable
         else replay_o(K, T, L, Q, lane);
     }
 }
-// Room for one more round of pushes (W <= 64, O <= 64, M <= 64).  An M replay adds at most 128 W and 64 O items,
-// so W + O go down to 32 before it.
+// Room for one more round of pushes (W <= 64, O <= 64, M <= 64).
 __device__ __forceinline__ void make_room(const PackedView& K, const PatternTableView& T, FastLds& L, WaveStacks& Q, int lane) {
-    if (Q.nm > uint32_t(kMCap - 64)) {
-        drain_wo(K, T, L, Q, lane, 32u);
-        replay_m(K, T, L, Q, lane);
-    }
+    while (Q.nm > uint32_t(kMCap - 64)) replay_m(K, T, L, Q, lane);   // every pass moves its items one slot on
     drain_wo(K, T, L, Q, lane, kQHigh);
 }
 
@@ -555,51 +580,25 @@ __global__ __launch_bounds__(kThreads) void score_tiles_fast_kernel(const ScoreP
             a5 += int32_t(__builtin_amdgcn_alignbit(tr.w, tr.z, 26) << 14) >> 14;
         }
         const bool keyok = has2 && h0.x == kb;
-        // right children: (c1,c2,c3) starts here
-        const bool kr = keyok && c3 != 0;
-        const bool mr1 = kr && (r1.x & 0xFFFFu) == c3, mr2 = kr && (r2.x & 0xFFFFu) == c3, mr3 = kr && (r3.x & 0xFFFFu) == c3;
-        const bool hit_r = mr1 || mr2 || mr3;
-        const uint32_t rx = mr1 ? r1.x : mr2 ? r2.x : mr3 ? r3.x : 0u;
-        const uint32_t ry = mr1 ? r1.y : mr2 ? r2.y : mr3 ? r3.y : 0u;
-        const uint32_t rz = mr1 ? r1.z : mr2 ? r2.z : mr3 ? r3.z : 0u;
-        const uint32_t rk = mr1 ? r1.w : mr2 ? r2.w : mr3 ? r3.w : 0u;
-        // left children: (c0,c1,c2) started one position earlier
-        const bool kl = keyok && c0 != 0;
-        const bool ml1 = kl && (l1.x & 0xFFFFu) == c0, ml2 = kl && (l2.x & 0xFFFFu) == c0, ml3 = kl && (l3.x & 0xFFFFu) == c0;
-        const bool hit_l = ml1 || ml2 || ml3;
-        const uint32_t lx = ml1 ? l1.x : ml2 ? l2.x : ml3 ? l3.x : 0u;
-        const uint32_t ly = ml1 ? l1.y : ml2 ? l2.y : l3.y;
-        const uint32_t lz = ml1 ? l1.z : ml2 ? l2.z : l3.z;
-        const uint32_t lk = ml1 ? l1.w : ml2 ? l2.w : ml3 ? l3.w : 0u;
-        // bigram row + right child (a kPkWide slot holds zero weights)
-        const uint32_t by = keyok ? h0.y : 0u, bz = keyok ? h0.z : 0u, bw = keyok ? h0.w : 0u;
-        a1 += lo16(by); a2 += hi16(by) + lo16(ry); a3 += lo16(bz) + hi16(ry);
-        a4 += hi16(bz) + lo16(rz); a5 += lo16(bw) + hi16(rz);
+        const RecMatch mt = match_record(keyok, c0, c3, h0, r1, r2, r3, h1, l1, l2, l3);
+        a1 += mt.b1; a2 += mt.b2; a3 += mt.b3; a4 += mt.b4; a5 += mt.b5;
         if (live) add_row6(L.score, s, a0, a1, a2, a3, a4, a5);
-        if (hit_l) add_child(L.score, s - 1, ly, lz);
+        if (mt.hit_l) add_child(L.score, s - 1, mt.ly, mt.lz);
         // deferred work
-        bool ovp = false;
-        if (kr && !hit_r && (bw & (kPkOv << 16)) && !(P.debug & 2u)) {
-            const uint32_t bit = packed_filter_bit(c3);
-            ovp = ((bit < 32 ? h1.z >> bit : h1.w >> (bit - 32)) & 1u) != 0;
-        }
-        const uint32_t kinds = ((live && u.w != 0) ? kWideUni : 0u) | ((has2 && !keyok && (h0.w & (kPkDisp << 16))) ? kRecMore : 0u) |
-                               ((bw & (kPkWide << 16)) ? kWideBi : 0u) | ((rx & (kPkWide << 16)) ? kWideTri : 0u) |
-                               ((lx & (kPkWide << 16)) ? kWideLeft : 0u);
+        const bool ovp = mt.ovp && !(P.debug & 2u);
+        const uint32_t rk = mt.rk, lk = mt.lk;
+        const uint32_t kinds = ((live && u.w != 0) ? kWideUni : 0u) | ((has2 && !keyok && (h0.w & (kPkDisp << 16))) ? kRecMore : 0u) | mt.wide;
         const bool nowalk = (P.debug & 8u) != 0;
         make_room(K, P.ct, L, Q, lane);
         Q.push_w(rk != 0 && !nowalk, s | (3u << 11), rk);
-        Q.push_o(ovp, s, h1.y);
-        Q.push_m(kinds != 0 && !(P.debug & 32u), s | (kinds << 11));
+        Q.push_o(ovp, s, mt.ov_ref);
+        Q.push_m(kinds != 0 && !(P.debug & 32u), s | (kinds << 11), (hrec + 1) & K.rec_mask);
         if (__ballot(lk != 0) != 0) {
             make_room(K, P.ct, L, Q, lane);
             Q.push_w(lk != 0 && !nowalk, (s - 1) | (3u << 11), lk);
         }
     }
-    while (Q.nm > 0) {
-        drain_wo(K, P.ct, L, Q, lane, 32u);
-        replay_m(K, P.ct, L, Q, lane);
-    }
+    while (Q.nm > 0) replay_m(K, P.ct, L, Q, lane);
     while (Q.no > 0) replay_o(K, P.ct, L, Q, lane);
     while (Q.nw > 0) replay_w(K, L, Q, lane);
     tmark = phase_mark(prof, 2, tmark);
