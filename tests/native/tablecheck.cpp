@@ -114,14 +114,26 @@ int tc_score(const tc_model* t, const uint32_t* cps, size_t n, int32_t* y_out, u
         uint32_t b = packed_hash1(kb, 32 - K.rec_bits);
         const uint32_t* r = &K.rec[size_t(b) * 32];
         if (r[0] != kb) {
-            if (!(r[3] & (kPkDisp << 16))) continue;
-            ++probes[0];
-            for (;;) {
-                b = (b + 1) & rmask;
-                r = &K.rec[size_t(b) * 32];
-                if (r[0] == kb || r[0] == 0) break;
+            const uint32_t fl = r[3] >> 16;
+            const uint32_t* found = nullptr;
+            if (fl & kPkFar) {              // some key homed here lives more than 8 records on: walk to the first hole
+                ++probes[0];
+                for (;;) {
+                    b = (b + 1) & rmask;
+                    const uint32_t* q = &K.rec[size_t(b) * 32];
+                    if (q[0] == kb) { found = q; break; }
+                    if (q[0] == 0) break;
+                }
+            } else {
+                for (uint32_t hop = fl >> kPkHopShift; hop != 0 && !found; hop &= hop - 1) {
+                    const uint32_t d = uint32_t(__builtin_ctz(hop)) + 1;
+                    const uint32_t* q = &K.rec[size_t((b + d) & rmask) * 32];
+                    ++probes[0];
+                    if (q[0] == kb) found = q;
+                }
             }
-            if (r[0] != kb) continue;
+            if (!found) continue;
+            r = found;
         }
         if (r[16] != kb) return -3;   // both halves carry the key
         if (r[3] & (kPkWide << 16)) {

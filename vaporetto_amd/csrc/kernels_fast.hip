@@ -86,8 +86,8 @@ __device__ __forceinline__ uint32_t utf8_scalar_bf(uint32_t b4) {
 // Wave-private stacks of deferred work (wave-uniform counts):
 //   W  x = s | depth << 11   y = mini-table ref (in `deep`) of the children to search      trie step
 //   O  x = s                 y = overflow mini-table ref (in `kids3`)                       overflow-child probe
-//   M  x = s | kinds << 11   y = record slot to look at next (kRecMore)                     the rare rest
-constexpr uint32_t kRecMore = 1u, kWideUni = 4u, kWideBi = 8u, kWideTri = 16u, kWideLeft = 32u;
+//   M  x = s | kinds << 11   y = home slot | remaining hop bits << 24 (kRecMore), next slot (kRecFar)   the rare rest
+constexpr uint32_t kRecMore = 1u, kRecFar = 2u, kWideUni = 4u, kWideBi = 8u, kWideTri = 16u, kWideLeft = 32u;
 struct WaveStacks {
     uint2* q;
     uint2* mq;
@@ -325,9 +325,9 @@ __device__ __forceinline__ void add_wide_rows(const PatternTableView& T, FastLds
 __device__ __forceinline__ void drain_wo(const PackedView& K, const PatternTableView& T, FastLds& L, WaveStacks& Q, int lane, uint32_t mark);
 
 // M: up to 64 queued items of the rare kinds.
-//   kRecMore: the record of (c1,c2) was not in its home slot -- y names the next slot to look at; the record found
-//             there is scored like in the main loop, a different key re-queues the item for the following slot,
-//             an empty slot ends the search.
+//   kRecMore: the record of (c1,c2) was not in its home slot, whose hop bitmap names the records to look at
+//             (layout.h); the one visited in this pass is scored like in the main loop if it has the key, else the
+//             item is re-queued with the remaining bits.  kRecFar: walk on to the first empty record instead.
 //   kWide*:   a row with a value outside i16 -- taken from the general tables (i32).
 __device__ __forceinline__ void replay_m(const PackedView& K, const PatternTableView& T, FastLds& L, WaveStacks& Q, int lane) {
     drain_wo(K, T, L, Q, lane, kQHigh);  // room for this call's pushes
@@ -340,11 +340,14 @@ __device__ __forceinline__ void replay_m(const PackedView& K, const PatternTable
     const uint32_t c0 = have ? (L.sym[s - 1] & kCpMask) : 0u;
     const uint32_t c1 = L.sym[s] & kCpMask, c2 = L.sym[s + 1] & kCpMask, c3 = L.sym[s + 2] & kCpMask;
     const uint32_t kb = c1 | (c2 << 16);
-    const bool more = (kinds & kRecMore) != 0;
-    const uint4* r = reinterpret_cast<const uint4*>(K.rec) + size_t(more ? it.y : 0u) * 8;
+    const bool far = (kinds & kRecFar) != 0, more = (kinds & (kRecMore | kRecFar)) != 0;
+    const uint32_t hop = far ? 0u : it.y >> 24;                       // records still to visit, as distances from home
+    const uint32_t hop_next = hop & (hop - 1u);
+    const uint32_t slot = far ? it.y : ((it.y & 0xFFFFFFu) + (hop ? uint32_t(__ffs(int(hop))) : 0u)) & K.rec_mask;
+    const uint4* r = reinterpret_cast<const uint4*>(K.rec) + size_t(more ? slot : 0u) * 8;
     const uint4 h0 = r[0], r1 = r[1], r2 = r[2], r3 = r[3], h1 = r[4], l1 = r[5], l2 = r[6], l3 = r[7];
     const bool keyok = more && h0.x == kb;
-    const bool again = more && !keyok && h0.x != 0;
+    const bool again = more && !keyok && (far ? h0.x != 0 : hop_next != 0);
     const RecMatch mt = match_record(keyok, c0, c3, h0, r1, r2, r3, h1, l1, l2, l3);
     if (keyok) add_row6(L.score, s, 0, mt.b1, mt.b2, mt.b3, mt.b4, mt.b5);
     if (mt.hit_l) add_child(L.score, s - 1, mt.ly, mt.lz);
@@ -354,7 +357,7 @@ __device__ __forceinline__ void replay_m(const PackedView& K, const PatternTable
     }
     Q.push_w(mt.rk != 0, s | (3u << 11), mt.rk);
     Q.push_o(mt.ovp, s, mt.ov_ref);
-    Q.push_m(again, s | (kRecMore << 11), (it.y + 1) & K.rec_mask);
+    Q.push_m(again, s | ((far ? kRecFar : kRecMore) << 11), far ? (slot + 1) & K.rec_mask : (it.y & 0xFFFFFFu) | (hop_next << 24));
     if (__ballot(mt.lk != 0) != 0) {
         drain_wo(K, T, L, Q, lane, kQHigh);
         Q.push_w(mt.lk != 0, (s - 1) | (3u << 11), mt.lk);
@@ -587,12 +590,13 @@ __global__ __launch_bounds__(kThreads) void score_tiles_fast_kernel(const ScoreP
         // deferred work
         const bool ovp = mt.ovp && !(P.debug & 2u);
         const uint32_t rk = mt.rk, lk = mt.lk;
-        const uint32_t kinds = ((live && u.w != 0) ? kWideUni : 0u) | ((has2 && !keyok && (h0.w & (kPkDisp << 16))) ? kRecMore : 0u) | mt.wide;
+        const uint32_t dfl = (has2 && !keyok) ? h0.w >> 16 : 0u;   // where keys homed in this record were displaced to
+        const uint32_t kinds = ((live && u.w != 0) ? kWideUni : 0u) | ((dfl & kPkFar) ? kRecFar : (dfl >> kPkHopShift) ? kRecMore : 0u) | mt.wide;
         const bool nowalk = (P.debug & 8u) != 0;
         make_room(K, P.ct, L, Q, lane);
         Q.push_w(rk != 0 && !nowalk, s | (3u << 11), rk);
         Q.push_o(ovp, s, mt.ov_ref);
-        Q.push_m(kinds != 0 && !(P.debug & 32u), s | (kinds << 11), (hrec + 1) & K.rec_mask);
+        Q.push_m(kinds != 0 && !(P.debug & 32u), s | (kinds << 11), (dfl & kPkFar) ? (hrec + 1) & K.rec_mask : hrec | ((dfl >> kPkHopShift) << 24));
         if (__ballot(lk != 0) != 0) {
             make_room(K, P.ct, L, Q, lane);
             Q.push_w(lk != 0 && !nowalk, (s - 1) | (3u << 11), lk);

@@ -70,9 +70,11 @@
 //          (sym * kHashMulLo >> 15) & (size-1), linear probing inside the mini-table, at most `size` probes,
 //          an entry with dword 0 == 0 ends the search.  Entry 0 of each arena is unused so that ref 0 = none.
 //
-// A record key lives at hash(kb) or, if that was taken, in the next free record (linear probing); H0 carries
-// kPkDisp when some key homed there lives further on, so a lookup that finds neither its key nor kPkDisp is over
-// after one line.  kPkWide marks a row with a value outside i16 (an n-gram and a dictionary word with the same
+// A record key lives at hash(kb) or, if that was taken, in the next free record (linear probing).  The flags of the
+// HOME record say where: bit d-1 of the hop bitmap = "a key homed here lives d records further on" (d = 1..8),
+// kPkFar = "... more than 8 further on" (then the search walks on to the first empty record).  A lookup that finds
+// neither its key nor any of these in the home record is over after one line; otherwise it visits exactly the
+// records the bitmap names -- an absent key costs popcount(bitmap) extra lines, not a walk to the next hole.  kPkWide marks a row with a value outside i16 (an n-gram and a dictionary word with the same
 // string can sum past 16 bits): the slot keeps zero weights and the row comes from the general tables above
 // (`uni` row flag: dword 3 == kPkWide).  A text char >= 0xFFFF is mapped to 0xFFFF before lookups: no pattern
 // contains it, so it matches nothing.
@@ -102,7 +104,8 @@ constexpr uint32_t kShortBucket = 2;             // entries per bucket of the sh
 constexpr uint32_t kEdgeBucket = 4;              // edges per bucket of the trie edge table
 constexpr uint32_t kHashMulLo = 0x9E3779B1u, kHashMulHi = 0x85EBCA77u;
 
-constexpr uint32_t kPkDisp = 1u, kPkExtRow = 2u, kPkHasRow = 4u, kPkWide = 8u, kPkOv = 16u;  // packed flags
+constexpr uint32_t kPkDisp = 1u, kPkExtRow = 2u, kPkHasRow = 4u, kPkWide = 8u, kPkOv = 16u, kPkFar = 32u;  // packed flags
+constexpr uint32_t kPkHopShift = 8;            // record flags bits 8..15: hop bitmap (bit d-1: a key homed here lives d slots on)
 constexpr uint32_t kPackedNoMatchSym = 0xFFFFu;
 constexpr uint32_t kPackedInlineKids = 6;      // children held by a record itself
 constexpr uint32_t kPackedInlineRow = 14;      // weights a `deep` entry holds inline

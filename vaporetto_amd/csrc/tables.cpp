@@ -401,7 +401,11 @@ HostPackedTable build_packed(const std::vector<Pat>& pats) {
         uint32_t b = home, probes = 1;
         while (t.rec[size_t(b) * 32] != 0) { b = (b + 1) & rmask; ++probes; }
         t.max_probe = std::max(t.max_probe, probes);
-        if (b != home) { t.rec[size_t(home) * 32 + 3] |= kPkDisp << 16; ++t.n_disp; }
+        if (b != home) {
+            const uint32_t d = (b - home) & rmask;
+            t.rec[size_t(home) * 32 + 3] |= (kPkDisp | (d <= 8 ? 1u << (kPkHopShift + d - 1) : kPkFar)) << 16;
+            ++t.n_disp;
+        }
         uint32_t* r = &t.rec[size_t(b) * 32];
         uint32_t fl = 0;
         r[0] = pf.key; r[16] = pf.key;
