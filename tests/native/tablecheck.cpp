@@ -111,7 +111,7 @@ int tc_score(const tc_model* t, const uint32_t* cps, size_t n, int32_t* y_out, u
         }
         if (c2 == 0) continue;
         const uint32_t kb = c1 | (c2 << 16);
-        uint32_t b = packed_hash1(kb, 32 - K.rec_bits);
+        uint32_t b = packed_ph_slot(kb, K.seed[packed_ph_bucket(kb, 32 - K.seed_bits)], 32 - K.rec_bits);
         const uint32_t* r = &K.rec[size_t(b) * 32];
         if (r[0] != kb) {
             const uint32_t fl = r[3] >> 16;

@@ -290,13 +290,18 @@ def test_non_bmp_pattern_models_use_the_general_tables():
     check_batch(pred, orc, randmodel.rand_sentences(3, m, 600, alphabet="mixed", max_len=70))
 
 
-@pytest.mark.parametrize("seed", range(4))
-def test_dense_packed_tables_with_displaced_keys(seed):
+@pytest.mark.parametrize("seed,ph_seeds", [(0, None), (1, None), (2, "1"), (3, "0")])
+def test_dense_packed_tables(seed, ph_seeds, monkeypatch):
+    """Crowded records, overflow mini-tables, left children; with VPT_DEBUG_PH_SEEDS the perfect-hash seed search is
+    starved so that displaced records (hop bitmap / kPkFar fallback) occur."""
+    if ph_seeds is not None:
+        monkeypatch.setenv("VPT_DEBUG_PH_SEEDS", ph_seeds)
     alpha = [chr(c) for c in range(0x3041, 0x3051)]
     m = randmodel.rand_model(70 + seed, alphabet=alpha, wc=3, wt=3, n_char=3000, n_dict=6000, max_word=12)
     pred, orc = make_predictor(m)
     info = pred.info()
-    assert info["packed"] == 1 and info["n_displaced"] > 0 and info["n_overflow_children"] > 0
+    assert info["packed"] == 1 and info["n_overflow_children"] > 0
+    assert (info["n_displaced"] == 0) == (ph_seeds is None)
     texts = randmodel.rand_sentences(seed, m, 3000, alphabet=alpha, max_len=120)
     check_batch(pred, orc, texts)
 

@@ -90,20 +90,27 @@ def test_packed_walk_matches_oracle_random_models(tc, seed):
     assert st["n_rec"] > 0 and st["n_children"] > 0 and st["n_deep"] > 0
 
 
-def test_packed_walk_dense_tables_exercise_displacement(tc):
-    """Tiny alphabets fill the tables' probe sequences: displaced keys, continued lookups, deep tries."""
+@pytest.mark.parametrize("ph_seeds", [None, "1", "0"])
+def test_packed_walk_dense_tables(tc, ph_seeds, monkeypatch):
+    """Tiny alphabets make crowded records, overflow mini-tables, left children and deep tries.  With the normal
+    perfect hash no record is displaced; VPT_DEBUG_PH_SEEDS starves the seed search so that the linear-probing
+    fallback (hop bitmap / kPkFar) is exercised too."""
+    if ph_seeds is not None:
+        monkeypatch.setenv("VPT_DEBUG_PH_SEEDS", ph_seeds)
     alpha = [chr(c) for c in range(0x3041, 0x3051)]
     m = strip_types(randmodel.rand_model(77, alphabet=alpha, wc=3, wt=3, n_char=3000, n_dict=6000, max_word=9))
     raw = encode_model(m)
     w = Walker(tc, raw)
     assert w.packed
     st = w.stats()
-    assert st["n_disp"] > 0 and st["n_overflow"] > 0 and st["n_left"] > 0
+    assert st["n_overflow"] > 0 and st["n_left"] > 0
+    assert (st["n_disp"] == 0) == (ph_seeds is None)
     orc = cbind.OraclePredictor(raw)
     probes = [0, 0, 0, 0]
     for t in randmodel.rand_sentences(5, m, 400, alphabet=alpha, max_len=80):
         assert w.score(t, probes) == orc.predict(t)[0], t
-    assert probes[0] > 0 and probes[1] > 0 and probes[2] > 0   # continued records, overflow and deep mini-tables
+    assert probes[1] > 0 and probes[2] > 0          # overflow and deep mini-tables were used
+    assert (probes[0] > 0) == (ph_seeds is not None)   # displaced records only in the starved builds
 
 
 def test_packed_not_eligible_models_fall_back(tc):

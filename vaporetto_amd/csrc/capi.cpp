@@ -35,7 +35,9 @@ vpt_status fail(vpt_status st, const std::string& msg) {
 struct DevicePacked {
     uint32_t *uni = nullptr, *rec = nullptr, *kids3 = nullptr, *deep = nullptr, *trow = nullptr;
     int32_t* xrows = nullptr;
+    uint8_t* seed = nullptr;
     void release() {
+        (void)hipFree(seed); seed = nullptr;
         (void)hipFree(uni); (void)hipFree(rec); (void)hipFree(kids3); (void)hipFree(deep); (void)hipFree(trow); (void)hipFree(xrows);
         uni = rec = kids3 = deep = trow = nullptr; xrows = nullptr;
     }
@@ -84,6 +86,7 @@ vpt::PackedView make_packed_view(const vpt::HostPackedTable& h, const DevicePack
     v.present = h.present ? 1u : 0u;
     if (!h.present) return v;
     v.uni = d.uni; v.rec = d.rec; v.kids3 = d.kids3; v.deep = d.deep; v.trow = d.trow; v.xrows = d.xrows;
+    v.seed = d.seed; v.seed_shift = 32 - h.seed_bits;
     v.rec_shift = 32 - h.rec_bits; v.rec_mask = (1u << h.rec_bits) - 1;
     v.has_trow = h.trow.empty() ? 0u : 1u;
     return v;
@@ -243,6 +246,7 @@ vpt_status vpt_predictor_create(const uint8_t* model_bytes, size_t len, int pred
         if (e == hipSuccess) e = upload(c.packed.kids3, &p->dp.kids3);
         if (e == hipSuccess) e = upload(c.packed.deep, &p->dp.deep);
         if (e == hipSuccess) e = upload(c.packed.xrows, &p->dp.xrows);
+        if (e == hipSuccess) e = upload(c.packed.seed, &p->dp.seed);
         if (e == hipSuccess && !c.packed.trow.empty()) e = upload(c.packed.trow, &p->dp.trow);
     }
     if (e == hipSuccess && c.type_kind == vpt::kTypeWindowTable) e = upload(c.type_table, &p->d_type_table);

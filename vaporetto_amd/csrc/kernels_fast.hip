@@ -549,7 +549,7 @@ __global__ __launch_bounds__(kThreads) void score_tiles_fast_kernel(const ScoreP
         const uint32_t c2 = x2 & kCpMask, c3 = x3 & kCpMask;
         const bool has2 = live && c2 != 0;
         const uint32_t kb = c1 | (c2 << 16);
-        uint32_t hrec = packed_hash1(kb, K.rec_shift);
+        uint32_t hrec = packed_ph_slot(kb, uint32_t(K.seed[packed_ph_bucket(kb, K.seed_shift)]), K.rec_shift);
         if (P.debug & 1u) hrec = 0;  // timing ablation (VPT_DEBUG_ABLATE; results are wrong): pin the record
         // every load first: the unigram row and the whole record of (c1,c2)
         const uint4 u = uni4[(P.debug & 4u) ? 0u : c1];

@@ -70,11 +70,15 @@
 //          (sym * kHashMulLo >> 15) & (size-1), linear probing inside the mini-table, at most `size` probes,
 //          an entry with dword 0 == 0 ends the search.  Entry 0 of each arena is unused so that ref 0 = none.
 //
-// A record key lives at hash(kb) or, if that was taken, in the next free record (linear probing).  The flags of the
-// HOME record say where: bit d-1 of the hop bitmap = "a key homed here lives d records further on" (d = 1..8),
+// Record slots come from a PERFECT HASH built at load time (the key set is static): `seed` holds one byte per
+// bucket(kb) (a few keys each), slot = packed_ph_slot(kb, seed): bucket by bucket, largest first, the builder picks
+// the seed that sends all the bucket's keys to free records.  Every present key is therefore found by ONE record
+// read (plus the cache-hot seed byte), an absent key lands on a record with another key or none.  Only a bucket for
+// which no seed below 255 works (not observed) falls back to seed 255 + linear probing, described by flags of the
+// HOME record: bit d-1 of the hop bitmap = "a key homed here lives d records further on" (d = 1..8),
 // kPkFar = "... more than 8 further on" (then the search walks on to the first empty record).  A lookup that finds
 // neither its key nor any of these in the home record is over after one line; otherwise it visits exactly the
-// records the bitmap names -- an absent key costs popcount(bitmap) extra lines, not a walk to the next hole.  kPkWide marks a row with a value outside i16 (an n-gram and a dictionary word with the same
+// records the bitmap names.  kPkWide marks a row with a value outside i16 (an n-gram and a dictionary word with the same
 // string can sum past 16 bits): the slot keeps zero weights and the row comes from the general tables above
 // (`uni` row flag: dword 3 == kPkWide).  A text char >= 0xFFFF is mapped to 0xFFFF before lookups: no pattern
 // contains it, so it matches nothing.
@@ -128,6 +132,8 @@ VPT_HD uint32_t hash_slot(uint64_t key, uint32_t shift) {
 
 // packed-table hashes; `shift` = 32 - log2(capacity in records)
 VPT_HD uint32_t packed_hash1(uint32_t k, uint32_t shift) { return (k * kHashMulLo) >> shift; }
+VPT_HD uint32_t packed_ph_bucket(uint32_t k, uint32_t shift) { return (k * kHashMulHi) >> shift; }
+VPT_HD uint32_t packed_ph_slot(uint32_t k, uint32_t seed, uint32_t shift) { return ((k ^ (seed * 0x7FEB352Du)) * kHashMulLo) >> shift; }
 VPT_HD uint32_t packed_mini_slot(uint32_t sym, uint32_t ref) { return ((sym * kHashMulLo) >> 15) & ((1u << (ref & 31u)) - 1u); }
 VPT_HD uint32_t packed_filter_bit(uint32_t sym) { return (sym * kHashMulHi) >> 26; }   // 0..63
 
@@ -168,7 +174,9 @@ struct PatternTableView {
 struct PackedView {
     const uint32_t *uni, *rec, *kids3, *deep, *trow;   // 16-byte units (uint4)
     const int32_t* xrows;
+    const uint8_t* seed;            // perfect-hash seed per bucket
     uint32_t rec_shift, rec_mask;   // hash shift and mask in RECORDS
+    uint32_t seed_shift;            // 32 - log2(buckets)
     uint32_t present;
     uint32_t has_trow;              // type rows available (else: window table / none)
 };

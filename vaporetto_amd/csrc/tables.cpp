@@ -7,6 +7,7 @@
 #include "tables.hpp"
 
 #include <algorithm>
+#include <cstdlib>
 #include <string>
 #include <unordered_map>
 
@@ -393,26 +394,70 @@ HostPackedTable build_packed(const std::vector<Pat>& pats) {
     };
     t.rec_bits = bits_for(prefixes.size());
     if (t.rec_bits > 24) return t;   // byte offsets of records stay below 4 GB
-    const uint32_t rmask = (1u << t.rec_bits) - 1;
+    const uint32_t rmask = (1u << t.rec_bits) - 1, rshift = 32 - t.rec_bits;
     t.rec.assign((size_t(1) << t.rec_bits) * 32, 0);
+    // perfect hash (layout.h): one seed byte per bucket, buckets placed largest first
+    std::vector<uint32_t> slot_of(prefixes.size(), 0);
+    {
+        t.seed_bits = 4;
+        while ((size_t(3) << t.seed_bits) < prefixes.size()) ++t.seed_bits;   // about 3 keys per bucket
+        const uint32_t bshift = 32 - t.seed_bits;
+        t.seed.assign(size_t(1) << t.seed_bits, 0);
+        std::vector<std::vector<uint32_t>> buckets(size_t(1) << t.seed_bits);
+        for (uint32_t pi = 0; pi < prefixes.size(); ++pi) buckets[packed_ph_bucket(prefixes[pi].key, bshift)].push_back(pi);
+        std::vector<uint32_t> order(buckets.size());
+        for (uint32_t i = 0; i < order.size(); ++i) order[i] = i;
+        std::stable_sort(order.begin(), order.end(), [&](uint32_t x, uint32_t y) { return buckets[x].size() > buckets[y].size(); });
+        std::vector<uint8_t> used(size_t(1) << t.rec_bits, 0);
+        // test hook: fewer seeds to try, so that the linear-probing fallback gets exercised
+        const char* dbg = std::getenv("VPT_DEBUG_PH_SEEDS");
+        const uint32_t max_seed = dbg ? std::min<uint32_t>(255u, uint32_t(std::atoi(dbg))) : 255u;
+        std::vector<uint32_t> trial;
+        for (uint32_t bi : order) {
+            const std::vector<uint32_t>& keys = buckets[bi];
+            if (keys.empty()) break;
+            uint32_t seed = 0;
+            for (; seed < max_seed; ++seed) {
+                trial.clear();
+                bool ok = true;
+                for (uint32_t pi : keys) {
+                    const uint32_t sl = packed_ph_slot(prefixes[pi].key, seed, rshift);
+                    if (used[sl] || std::find(trial.begin(), trial.end(), sl) != trial.end()) { ok = false; break; }
+                    trial.push_back(sl);
+                }
+                if (ok) break;
+            }
+            if (seed >= max_seed) seed = 255;
+            t.seed[bi] = uint8_t(seed);
+            if (seed < 255) {
+                for (size_t j = 0; j < keys.size(); ++j) { slot_of[keys[j]] = trial[j]; used[trial[j]] = 1; }
+                continue;
+            }
+            for (uint32_t pi : keys) {   // fallback: linear probing from the seed-255 slot, the home record says where to
+                const uint32_t home = packed_ph_slot(prefixes[pi].key, 255, rshift);
+                uint32_t b = home, probes = 1;
+                while (used[b]) { b = (b + 1) & rmask; ++probes; }
+                used[b] = 1;
+                slot_of[pi] = b;
+                t.max_probe = std::max(t.max_probe, probes);
+                if (b != home) {
+                    const uint32_t d = (b - home) & rmask;
+                    t.rec[size_t(home) * 32 + 3] |= (kPkDisp | (d <= 8 ? 1u << (kPkHopShift + d - 1) : kPkFar)) << 16;
+                    ++t.n_disp;
+                }
+            }
+        }
+    }
     for (uint32_t pi = 0; pi < prefixes.size(); ++pi) {
         const Prefix& pf = prefixes[pi];
-        const uint32_t home = packed_hash1(pf.key, 32 - t.rec_bits);
-        uint32_t b = home, probes = 1;
-        while (t.rec[size_t(b) * 32] != 0) { b = (b + 1) & rmask; ++probes; }
-        t.max_probe = std::max(t.max_probe, probes);
-        if (b != home) {
-            const uint32_t d = (b - home) & rmask;
-            t.rec[size_t(home) * 32 + 3] |= (kPkDisp | (d <= 8 ? 1u << (kPkHopShift + d - 1) : kPkFar)) << 16;
-            ++t.n_disp;
-        }
+        const uint32_t b = slot_of[pi];
         uint32_t* r = &t.rec[size_t(b) * 32];
         uint32_t fl = 0;
         r[0] = pf.key; r[16] = pf.key;
         if (pf.pat && wide(*pf.pat)) { fl |= kPkWide; ++t.n_wide; }
         else if (pf.pat) {
             r[1] = pack16(pf.pat->row[0], pf.pat->row[1]); r[2] = pack16(pf.pat->row[2], pf.pat->row[3]);
-            r[3] = pack16(pf.pat->row[4], 0);
+            r[3] |= pack16(pf.pat->row[4], 0);   // the flags half may already name displaced keys
         }
         for (size_t j = 0; j < rights[pi].size(); ++j) child_entry(r + 4 + 4 * j, nodes[rights[pi][j]], nodes[rights[pi][j]].sym);
         for (size_t j = 0; j < lefts[pi].size(); ++j) child_entry(r + 20 + 4 * j, nodes[lefts[pi][j].node], lefts[pi][j].lead);

@@ -37,10 +37,11 @@ struct HostPackedTable {
     std::vector<uint32_t> deep;    // 8 dwords per entry
     std::vector<int32_t> xrows;    // external i32 rows
     std::vector<uint32_t> trow;    // 512 type rows x 4 dwords, empty when the type n-grams do not fit the form
-    uint32_t rec_bits = 4;
+    std::vector<uint8_t> seed;     // perfect-hash seed per bucket of record keys
+    uint32_t rec_bits = 4, seed_bits = 0;
     // statistics
     uint32_t n_rec = 0, n_children = 0, n_left = 0, n_overflow = 0, n_deep = 0, n_disp = 0, max_probe = 0, n_wide = 0;
-    uint64_t bytes() const { return 4ull * (uni.size() + rec.size() + kids3.size() + deep.size() + xrows.size() + trow.size()); }
+    uint64_t bytes() const { return 4ull * (uni.size() + rec.size() + kids3.size() + deep.size() + xrows.size() + trow.size()) + seed.size(); }
 };
 
 enum TypeKind : int { kTypeNone = 0, kTypeWindowTable = 1, kTypePatternTable = 2 };
