@@ -5,8 +5,10 @@
 // (profiles/r01_c_*: the vector L1's miss queue) and, once those are few, instruction issue (profiles/r01_d_*):
 //
 //   * one 128-byte RECORD per (c1,c2) prefix holds the bigram row, three right children (c1,c2,c3) and three left
-//     children (c0,c1,c2), so a start position costs ONE random line; the lane reads the whole record (8 x 16 B)
-//     right after its unigram row, before anything is compared;
+//     children (c0,c1,c2), and its slot comes from a perfect hash (one cache-hot seed byte), so a start position
+//     costs ONE random line.  A lane PAIR fetches the two 64-byte halves of a record in the same instruction (first
+//     the even lane's record, then the odd lane's), which the memory pipeline rewards (tools/gather_bench.hip), and
+//     hands the partner's half over through DPP, so that every lane ends up with its own whole record;
 //   * the unigram row (16 bytes, cache-hot), the type row (LDS), the bigram row and the matching right child are
 //     summed in registers and land in the LDS score array with six ds_add_u32 (integer => order-free => bit-exact);
 //     a matching left child adds its four values one position earlier;
@@ -59,17 +61,6 @@ __device__ __forceinline__ uint32_t lane_rank(uint64_t mask) {  // set bits of `
 __device__ __forceinline__ uint32_t pair_swap(uint32_t x) {  // value of lane ^ 1 (DPP quad_perm [1,0,3,2])
     return uint32_t(__builtin_amdgcn_update_dpp(0, int(x), 0xB1, 0xF, 0xF, false));
 }
-// A 64-byte half-record as loaded by one lane of a pair, and the exchange that leaves every lane with its OWN record:
-// in sub-round A the pair (2j, 2j+1) reads halves (0, 1) of lane 2j's record, in sub-round B of lane 2j+1's -- the
-// two halves of a 128-byte line are requested by adjacent lanes of ONE instruction, which is what the memory
-// pipeline rewards (tools/gather_bench.hip: 57 G records/s against 42 G/s when one lane reads all eight units).
-__device__ __forceinline__ uint4 pick(bool mine, const uint4& own, const uint4& partners) {
-    uint4 r;
-    r.x = mine ? own.x : pair_swap(partners.x); r.y = mine ? own.y : pair_swap(partners.y);
-    r.z = mine ? own.z : pair_swap(partners.z); r.w = mine ? own.w : pair_swap(partners.w);
-    return r;
-}
-
 // branch-free UTF-8 -> scalar value; b4 = the lead byte and the three bytes after it, little-endian
 __device__ __forceinline__ uint32_t utf8_scalar_bf(uint32_t b4) {
     const uint32_t b0 = b4 & 0xFF, b1 = (b4 >> 8) & 0x3F, b2 = (b4 >> 16) & 0x3F, b3 = (b4 >> 24) & 0x3F;
@@ -537,19 +528,28 @@ __global__ __launch_bounds__(kThreads) void score_tiles_fast_kernel(const ScoreP
     WaveStacks Q{&L.queue[wave][0], &L.mqueue[wave][0], 0u, 0u, 0u};
     const uint4* uni4 = reinterpret_cast<const uint4*>(K.uni);
     const uint4* rec4 = reinterpret_cast<const uint4*>(K.rec);
+    // The slot of a record needs the seed byte of its key's bucket: a dependent, cache-hot load.  It is issued one
+    // iteration ahead (together with the LDS reads of that iteration's symbols), so the record loads never wait for it.
+    uint32_t nx0, nx1, nx2, nx3, nseed;
+    auto stage = [&](uint32_t sn) {
+        nx1 = sn < flat_len ? L.sym[sn] : 0u;
+        nx0 = (nx1 & kCpMask) != 0 ? L.sym[sn - 1] : 0u;   // sn >= pad whenever the position holds a char
+        nx2 = L.sym[sn + 1]; nx3 = L.sym[sn + 2];          // past the tile: zeroed slack, then unrelated LDS (dead lanes)
+        nseed = uint32_t(K.seed[packed_ph_bucket((nx1 & kCpMask) | ((nx2 & kCpMask) << 16), K.seed_shift)]);
+    };
+    stage(uint32_t(tid));
     for (int k = 0; k < kPerThread; ++k) {
         if (P.debug & 16u) break;  // timing ablation: no pattern phase at all
         const uint32_t s = uint32_t(tid) + uint32_t(k) * kThreads;
         if (s - uint32_t(lane) >= flat_len) break;  // wave-uniform: this wave's 64 positions are past the tile
-        const uint32_t x1 = s < flat_len ? L.sym[s] : 0u;
+        const uint32_t x1 = nx1, x2 = nx2, x3 = nx3;
         const uint32_t c1 = x1 & kCpMask;
         const bool live = c1 != 0;
-        const uint32_t c0 = live ? (L.sym[s - 1] & kCpMask) : 0u;   // s >= pad whenever c1 != 0
-        const uint32_t x2 = L.sym[s + 1], x3 = L.sym[s + 2];
+        const uint32_t c0 = nx0 & kCpMask;
         const uint32_t c2 = x2 & kCpMask, c3 = x3 & kCpMask;
         const bool has2 = live && c2 != 0;
         const uint32_t kb = c1 | (c2 << 16);
-        uint32_t hrec = packed_ph_slot(kb, uint32_t(K.seed[packed_ph_bucket(kb, K.seed_shift)]), K.rec_shift);
+        uint32_t hrec = packed_ph_slot(kb, nseed, K.rec_shift);
         if (P.debug & 1u) hrec = 0;  // timing ablation (VPT_DEBUG_ABLATE; results are wrong): pin the record
         // every load first: the unigram row and the whole record of (c1,c2)
         const uint4 u = uni4[(P.debug & 4u) ? 0u : c1];
@@ -559,6 +559,7 @@ __global__ __launch_bounds__(kThreads) void score_tiles_fast_kernel(const ScoreP
         const uint4* rb = reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(rec4) + (((odd ? hrec : p_hrec) << 7) | (odd ? 0u : 64u)));
         const uint4 qa0 = ra[0], qa1 = ra[1], qa2 = ra[2], qa3 = ra[3];   // even lane: own half 0; odd lane: partner's half 1
         const uint4 qb0 = rb[0], qb1 = rb[1], qb2 = rb[2], qb3 = rb[3];   // even lane: partner's half 1; odd lane: own half 0
+        if (k + 1 < kPerThread) stage(s + uint32_t(kThreads));          // next iteration's symbols and seed
         // own half 0 = even ? qa : qb (already here); own half 1 = the partner's qb (even lanes) / qa (odd lanes)
         const uint4 h0 = odd ? qb0 : qa0, r1 = odd ? qb1 : qa1, r2 = odd ? qb2 : qa2, r3 = odd ? qb3 : qa3;
         uint4 h1, l1, l2, l3;
@@ -596,7 +597,8 @@ __global__ __launch_bounds__(kThreads) void score_tiles_fast_kernel(const ScoreP
         make_room(K, P.ct, L, Q, lane);
         Q.push_w(rk != 0 && !nowalk, s | (3u << 11), rk);
         Q.push_o(ovp, s, mt.ov_ref);
-        Q.push_m(kinds != 0 && !(P.debug & 32u), s | (kinds << 11), (dfl & kPkFar) ? (hrec + 1) & K.rec_mask : hrec | ((dfl >> kPkHopShift) << 24));
+        if (__ballot(kinds != 0) != 0)   // rare: rows outside i16, or a record placed by the fallback of the perfect hash
+            Q.push_m(kinds != 0 && !(P.debug & 32u), s | (kinds << 11), (dfl & kPkFar) ? (hrec + 1) & K.rec_mask : hrec | ((dfl >> kPkHopShift) << 24));
         if (__ballot(lk != 0) != 0) {
             make_room(K, P.ct, L, Q, lane);
             Q.push_w(lk != 0 && !nowalk, (s - 1) | (3u << 11), lk);
