@@ -352,3 +352,54 @@ def test_very_long_words_and_compressed_chains():
     texts = [base, base[:29] + "ん" + base, "あ" + base[:13] + base[:24] + "ん", base[3:] + base]
     texts += ["".join(rng.choice(sorted(words)) for _ in range(3)) for _ in range(400)]
     check_batch(pred, orc, texts)
+
+
+# ------------------------------------------------------------------------------------------------ BASELINE configs
+@pytest.mark.parametrize("kind,scale,min_len,max_len,n", [
+    (1, 0.05, 64, 64, 20000),     # configs[1] shape (bccwj-suw+unidic-like), scaled model
+    (2, 0.05, 64, 64, 20000),     # configs[3] shape (jp-0.4.7-5-like: dictionary-heavy)
+    (1, 0.05, 8, 512, 6000),      # configs[4] text shape: mixed 8..512-char sentences
+    (2, 0.02, 1, 40, 30000),      # many short sentences
+])
+def test_synthetic_configs_match_oracle(kind, scale, min_len, max_len, n):
+    from vaporetto_amd import synth
+    raw = synth.synth_model(kind, synth.SEED_BASE + kind, scale)
+    utf8, boff = synth.synth_sentences(raw, n, min_len, max_len, seed=synth.SEED_BASE + 7 * kind)
+    pred = api.Predictor(api.Model.read_slice(raw)[0], False)
+    assert pred.info()["packed"] == 1
+    scores, labels, ooff = pred.predict_packed(utf8, boff)
+    o_scores, o_labels, o_ooff, _ = cbind.OraclePredictor(raw).predict_batch(utf8, boff, nthreads=8)
+    assert np.array_equal(ooff, o_ooff) and np.array_equal(scores, o_scores) and np.array_equal(labels, o_labels)
+
+
+def test_batch_properties_at_full_config_size():
+    """Size-independent properties on a configs[1]-sized batch (100 K x 64 chars): sentences are independent, so a
+    permuted batch gives the permuted scores, a batch scored in two halves gives the same scores, and every label is
+    the sign of its score."""
+    from vaporetto_amd import synth
+    raw = synth.synth_model(1, synth.SEED_BASE + 2, 0.1)
+    n = 100000
+    utf8, boff = synth.synth_sentences(raw, n, 64, 64, seed=synth.SEED_BASE + 2)
+    pred = api.Predictor(api.Model.read_slice(raw)[0], False)
+    scores, labels, ooff = pred.predict_packed(utf8, boff)
+    assert len(scores) == 63 * n and np.array_equal(labels, (scores > 0).astype(np.uint8))
+    # two halves
+    h = n // 2
+    cut = int(boff[h])
+    s1, l1, _ = pred.predict_packed(utf8[:cut], boff[:h + 1])
+    s2, l2, _ = pred.predict_packed(utf8[cut:], boff[h:] - boff[h])
+    assert np.array_equal(np.concatenate([s1, s2]), scores) and np.array_equal(np.concatenate([l1, l2]), labels)
+    # a permutation of the sentences
+    perm = np.random.RandomState(3).permutation(n)
+    b = boff.astype(np.int64)
+    text = utf8.reshape(n, 192)            # every synthetic char is 3 bytes, 64 chars per sentence
+    assert np.all(np.diff(b) == 192)
+    sp, lp, _ = pred.predict_packed(np.ascontiguousarray(text[perm]).reshape(-1), boff)
+    assert np.array_equal(sp.reshape(n, 63), scores.reshape(n, 63)[perm])
+    # checksum of checksums against the oracle on a 5 % sample of sentences
+    idx = np.sort(perm[: n // 20])
+    sub = np.ascontiguousarray(text[idx]).reshape(-1)
+    sub_boff = (np.arange(len(idx) + 1, dtype=np.uint64) * 192)
+    o_scores, _, _, _ = cbind.OraclePredictor(raw).predict_batch(sub, sub_boff, nthreads=8)
+    assert int(o_scores.astype(np.int64).sum()) == int(scores.reshape(n, 63)[idx].astype(np.int64).sum())
+    assert np.array_equal(o_scores.reshape(-1, 63), scores.reshape(n, 63)[idx])

@@ -425,8 +425,7 @@ vpt_status vpt_predict_batch_device(const vpt_predictor* p, vpt_batch* b, const 
     P.prof = b->d_prof;
     if (const char* dbg = std::getenv("VPT_DEBUG_ABLATE")) { P.debug = uint32_t(std::atoi(dbg)); P.ct.debug = P.debug; P.tt.debug = P.debug; }
 
-    VPT_HIP(hipMemsetAsync(b->d_ctrl, 0, 8, stream));
-    VPT_HIP(vpt::launch_assign_tiles(d_out_offsets, n_sentences, p->pad, uint32_t(tile_flat), n_tiles, b->d_tile_first, stream));
+    VPT_HIP(vpt::launch_assign_tiles(d_out_offsets, n_sentences, p->pad, uint32_t(tile_flat), n_tiles, b->d_tile_first, b->d_ctrl, stream));
     const size_t slot = b->ev_calls % kTimingRing;
     if (b->timing) VPT_HIP(hipEventRecord(b->ev[2 * slot], stream));
     if (fast) VPT_HIP(vpt::launch_score_tiles_fast(P, n_tiles, stream));

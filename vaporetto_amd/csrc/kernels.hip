@@ -295,9 +295,12 @@ __device__ __forceinline__ void process_tile(const ScoreParams& P, const TileMem
 // ------------------------------------------------------------------------------------------------------------
 
 // tile_first[t] = first sentence whose flat start F(i) = ooff[i] + i*(1+pad) is >= t*tile_flat  (t = 0..n_tiles)
+// Also clears the batch's control words (status bits, deferred-tile count) for the scoring kernels that follow on
+// the same stream -- one launch less than a separate memset.
 __global__ void assign_tiles_kernel(const uint64_t* __restrict__ ooff, uint64_t n_sent, int pad, uint32_t tile_flat,
-                                    uint32_t n_tiles, uint32_t* __restrict__ tile_first) {
+                                    uint32_t n_tiles, uint32_t* __restrict__ tile_first, uint32_t* __restrict__ ctrl) {
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < 2) ctrl[t] = 0;
     if (t > n_tiles) return;
     const uint64_t target = uint64_t(t) * tile_flat;
     uint64_t lo = 0, hi = n_sent;  // first i in [0, n_sent] with F(i) >= target; F(n_sent) is the total
@@ -367,9 +370,9 @@ size_t score_tiles_lds_bytes() {
 }
 
 hipError_t launch_assign_tiles(const uint64_t* ooff, uint64_t n_sent, int pad, uint32_t tile_flat, uint32_t n_tiles,
-                               uint32_t* tile_first, hipStream_t stream) {
+                               uint32_t* tile_first, uint32_t* ctrl, hipStream_t stream) {
     const uint32_t threads = 256, blocks = (n_tiles + 1 + threads - 1) / threads;
-    hipLaunchKernelGGL(assign_tiles_kernel, dim3(blocks), dim3(threads), 0, stream, ooff, n_sent, pad, tile_flat, n_tiles, tile_first);
+    hipLaunchKernelGGL(assign_tiles_kernel, dim3(blocks), dim3(threads), 0, stream, ooff, n_sent, pad, tile_flat, n_tiles, tile_first, ctrl);
     return hipGetLastError();
 }
 

@@ -52,7 +52,7 @@ struct ScoreParams {
 
 size_t score_tiles_lds_bytes();
 hipError_t launch_assign_tiles(const uint64_t* ooff, uint64_t n_sent, int pad, uint32_t tile_flat, uint32_t n_tiles,
-                               uint32_t* tile_first, hipStream_t stream);
+                               uint32_t* tile_first, uint32_t* ctrl, hipStream_t stream);
 // specialised kernel (kernels_fast.hip): packed tables (char window 3, BMP, i16), type window table or none
 bool fast_path_supported(const ScoreParams& P);
 hipError_t launch_score_tiles_fast(const ScoreParams& P, uint32_t n_tiles, hipStream_t stream);
