@@ -106,6 +106,7 @@ def main():
     if args.phases:
         os.environ["VPT_PROFILE_PHASES"] = "1"
     batch = api.DeviceBatch(predictor, timing=True)
+    batch.set_max_sentence_chars(int(np.max(np.diff(ooff.astype(np.int64)))) + 1)
     stream = torch.cuda.current_stream().cuda_stream
 
     def step():

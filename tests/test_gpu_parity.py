@@ -403,3 +403,41 @@ def test_batch_properties_at_full_config_size():
     o_scores, _, _, _ = cbind.OraclePredictor(raw).predict_batch(sub, sub_boff, nthreads=8)
     assert int(o_scores.astype(np.int64).sum()) == int(scores.reshape(n, 63)[idx].astype(np.int64).sum())
     assert np.array_equal(o_scores.reshape(-1, 63), scores.reshape(n, 63)[idx])
+
+
+def test_understated_length_bounds_are_reported():
+    """Device entry point: a sentence longer than the caller's max_sentence_bytes / max_sentence_chars is an error
+    at sync (never a silent gap in the outputs)."""
+    import torch
+    raw, _ = kat.load_fixture("model.bin")
+    pred, orc = make_predictor(raw)
+    texts = ["まぁ良いだろう" * 300, "まぁ社長は火星猫だ"] * 3      # 2100-char sentences need the long-sentence path
+    utf8, boff = api.pack_texts([t.encode("utf-8") for t in texts])
+    ooff = api.count_boundaries(utf8, boff)
+    nb = int(ooff[-1])
+    d_text = torch.from_numpy(np.concatenate([utf8, np.zeros(16, np.uint8)])).cuda()
+    d_boff = torch.from_numpy(boff.astype(np.int64)).cuda()
+    d_ooff = torch.from_numpy(ooff.astype(np.int64)).cuda()
+    d_scores = torch.zeros(nb + 1, dtype=torch.int32, device="cuda")
+    d_labels = torch.zeros(nb + 1, dtype=torch.uint8, device="cuda")
+    stream = torch.cuda.current_stream().cuda_stream
+
+    def run(batch, max_bytes):
+        batch.predict(d_text.data_ptr(), d_boff.data_ptr(), d_ooff.data_ptr(), len(texts), nb, max_bytes,
+                      d_scores.data_ptr(), d_labels.data_ptr(), stream)
+        batch.sync()
+        return d_scores[:nb].cpu().numpy()
+
+    want = orc.predict_batch(utf8, boff)[0]
+    true_bytes = int(np.max(np.diff(boff.astype(np.int64))))
+    batch = api.DeviceBatch(pred)
+    assert np.array_equal(run(batch, true_bytes), want)
+    batch.set_max_sentence_chars(2100)
+    assert np.array_equal(run(batch, true_bytes), want)
+    batch.set_max_sentence_chars(100)          # understated: the 2100-char sentences do not fit the tiles cut for 100
+    with pytest.raises(api.VaporettoError, match="smaller than the longest sentence"):
+        run(batch, true_bytes)
+    batch.set_max_sentence_chars(0)
+    with pytest.raises(api.VaporettoError, match="smaller than the longest sentence"):
+        run(batch, 64)                         # understated bytes
+    assert np.array_equal(run(batch, true_bytes), want)

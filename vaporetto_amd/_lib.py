@@ -41,6 +41,7 @@ SIGNATURES = {
     "vpt_batch_destroy": (None, [_P]),
     "vpt_predict_batch_device": (C.c_int, [_P, _P, _P, _P, _P, C.c_size_t, C.c_uint64, C.c_uint64, _P, _P, _P]),
     "vpt_batch_sync": (C.c_int, [_P]),
+    "vpt_batch_set_max_sentence_chars": (C.c_int, [_P, C.c_uint64]),
     "vpt_batch_set_timing": (C.c_int, [_P, C.c_int]),
     "vpt_batch_kernel_ms": (C.c_int, [_P, C.POINTER(C.c_float), C.POINTER(C.c_uint32)]),
     "vpt_batch_phase_cycles": (C.c_int, [_P, C.POINTER(C.c_uint64 * 8)]),

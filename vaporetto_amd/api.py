@@ -289,6 +289,12 @@ class DeviceBatch:
         if st != _lib.VPT_OK:
             _raise(st)
 
+    def set_max_sentence_chars(self, max_chars: int) -> None:
+        """Optional tighter bound than max_sentence_bytes (fuller tiles); 0 = unknown."""
+        st = _lib.load().vpt_batch_set_max_sentence_chars(self._h, int(max_chars))
+        if st != _lib.VPT_OK:
+            _raise(st)
+
     def sync(self) -> None:
         st = _lib.load().vpt_batch_sync(self._h)
         if st != _lib.VPT_OK:

@@ -123,6 +123,7 @@ struct vpt_batch {
     uint32_t* d_ctrl = nullptr;        // [0] status bits, [1] slow tile count
     uint64_t* d_prof = nullptr;        // 8 per-phase cycle counters (only with VPT_PROFILE_PHASES set)
     unsigned char* d_scratch = nullptr; size_t scratch_bytes = 0;
+    uint64_t max_chars = 0;            // caller's bound on chars per sentence (0 = unknown)
     // timing
     bool timing = false;
     std::vector<hipEvent_t> ev;        // ring of (start, stop) pairs around the scoring kernel
@@ -195,7 +196,7 @@ vpt_status status_from_bits(uint32_t bits) {
     if (bits & vpt::kErrNulChar) return fail(VPT_INVALID_ARGUMENT, "InvalidArgumentError: text: must not contain NULL");
     if (bits & vpt::kErrBadOffsets)
         return fail(VPT_INVALID_ARGUMENT, "InvalidArgumentError: out_offsets: do not match the text (or the text is not valid UTF-8)");
-    return fail(VPT_INVALID_ARGUMENT, "InvalidArgumentError: max_sentence_bytes: smaller than the longest sentence");
+    return fail(VPT_INVALID_ARGUMENT, "InvalidArgumentError: max_sentence_bytes / max_sentence_chars: smaller than the longest sentence");
 }
 
 }  // namespace
@@ -361,6 +362,12 @@ vpt_status vpt_batch_kernel_ms(vpt_batch* b, float* score_kernel_ms, uint32_t* n
     return VPT_OK;
 }
 
+vpt_status vpt_batch_set_max_sentence_chars(vpt_batch* b, uint64_t max_sentence_chars) {
+    if (!b) return fail(VPT_INVALID_ARGUMENT, "InvalidArgumentError: NULL argument");
+    b->max_chars = max_sentence_chars;
+    return VPT_OK;
+}
+
 vpt_status vpt_batch_phase_cycles(vpt_batch* b, uint64_t cycles[8]) {
     if (!b || !cycles) return fail(VPT_INVALID_ARGUMENT, "InvalidArgumentError: NULL argument");
     std::memset(cycles, 0, 64);
@@ -389,7 +396,9 @@ vpt_status vpt_predict_batch_device(const vpt_predictor* p, vpt_batch* b, const 
     const bool fast = vpt::fast_path_supported(P) && !std::getenv("VPT_FORCE_GENERIC");
     const uint64_t cap = fast ? vpt::kFastCap : vpt::kCap;
     uint64_t tile_flat = cap / 2;
-    if (max_sentence_bytes + 2 * uint64_t(p->pad) + cap / 2 <= cap) tile_flat = cap - 2 * uint64_t(p->pad) - max_sentence_bytes;
+    // flat positions of the longest sentence: its chars, bounded by the caller's hint or else by its bytes
+    const uint64_t max_chars = (b->max_chars && b->max_chars < max_sentence_bytes) ? b->max_chars : max_sentence_bytes;
+    if (max_chars + 2 * uint64_t(p->pad) + cap / 2 <= cap) tile_flat = cap - 2 * uint64_t(p->pad) - max_chars;
     const uint64_t total_flat = total_boundaries + uint64_t(n_sentences) * uint64_t(1 + p->pad);
     const uint64_t n_tiles64 = (total_flat + tile_flat - 1) / tile_flat;
     if (n_tiles64 >= 0x7FFFFFFFull) return fail(VPT_INVALID_ARGUMENT, "InvalidArgumentError: batch too large for one call");
@@ -403,11 +412,11 @@ vpt_status vpt_predict_batch_device(const vpt_predictor* p, vpt_batch* b, const 
         VPT_HIP(hipMalloc(reinterpret_cast<void**>(&b->d_slow_list), cap * sizeof(uint32_t) + 64));
     }
     // long-sentence scratch (only when a sentence might not fit the LDS tile)
-    const bool need_slow = max_sentence_bytes + 2 * uint64_t(p->pad) + tile_flat > cap;
+    const bool need_slow = max_chars + 2 * uint64_t(p->pad) + tile_flat > cap;
     uint32_t slow_blocks = 0, scratch_cap = 0;
     uint64_t slab = 0;
     if (need_slow) {
-        const uint64_t cap64 = max_sentence_bytes + 2 * uint64_t(p->pad) + vpt::kMargin + 8;
+        const uint64_t cap64 = max_chars + 2 * uint64_t(p->pad) + vpt::kMargin + 8;
         if (cap64 >= 0x7FFFFFF0ull) return fail(VPT_INVALID_ARGUMENT, "InvalidArgumentError: max_sentence_bytes: too large");
         scratch_cap = uint32_t((cap64 + 15) & ~15ull);
         slab = (uint64_t(scratch_cap) * 9 + 255) & ~255ull;
@@ -475,12 +484,14 @@ vpt_status vpt_predict_batch(const vpt_predictor* p, const uint8_t* utf8, const 
     if (t1 < t0) return give_back(fail(VPT_INVALID_ARGUMENT, "InvalidArgumentError: byte_offsets: must be non-decreasing"));
     const size_t nbytes = size_t(t1 - t0);
     const uint64_t total_b = out_offsets[n_sentences] - out_offsets[0];
-    uint64_t max_bytes = 0;
+    uint64_t max_bytes = 0, max_chars = 0;
     for (size_t i = 0; i < n_sentences; ++i) {
         if (byte_offsets[i + 1] <= byte_offsets[i])
             return give_back(fail(VPT_INVALID_ARGUMENT, "InvalidArgumentError: text: must contain at least one character"));
         max_bytes = std::max<uint64_t>(max_bytes, byte_offsets[i + 1] - byte_offsets[i]);
+        max_chars = std::max<uint64_t>(max_chars, out_offsets[i + 1] - out_offsets[i] + 1);
     }
+    b->max_chars = max_chars;
     vpt_status st;
     if ((st = grow(&b->d_text, &b->text_cap, nbytes + 32)) != VPT_OK) return give_back(st);
     {

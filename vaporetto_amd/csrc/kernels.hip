@@ -329,7 +329,10 @@ __global__ __launch_bounds__(kThreads) void score_tiles_kernel(const ScoreParams
     const uint64_t flat_len = uint64_t(P.pad) + (F1 - F0);
     const uint64_t nbytes = P.boff[i1] - P.boff[i0];
     if (flat_len > kCap || nbytes + 16 > uint64_t(kBitmapWords - 2) * 32) {  // does not fit in LDS: defer
-        if (threadIdx.x == 0) P.slow_list[atomicAdd(P.slow_count, 1u)] = t;
+        if (threadIdx.x == 0) {
+            if (P.scratch_cap == 0) atomicOr(P.status, kErrScratchTooSmall);   // the caller's length bounds were understated
+            else P.slow_list[atomicAdd(P.slow_count, 1u)] = t;
+        }
         return;
     }
     process_tile<true, kChunks>(P, M, bitmap, wtot, i0, i1, uint32_t(flat_len));

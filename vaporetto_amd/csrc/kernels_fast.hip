@@ -395,7 +395,10 @@ __global__ __launch_bounds__(kThreads) void score_tiles_fast_kernel(const ScoreP
     const uint32_t head = uint32_t(reinterpret_cast<uintptr_t>(tbase) - a0);
     const uint64_t nbytes_al64 = head + (B1 - B0);
     if (flat_len64 > kFastCap || nbytes_al64 > uint64_t(kFastCap) * 4 + 15) {  // does not fit in LDS: defer
-        if (tid == 0) P.slow_list[atomicAdd(P.slow_count, 1u)] = t;
+        if (tid == 0) {
+            if (P.scratch_cap == 0) atomicOr(P.status, kErrScratchTooSmall);   // the caller's length bounds were understated
+            else P.slow_list[atomicAdd(P.slow_count, 1u)] = t;
+        }
         return;
     }
     const uint32_t flat_len = uint32_t(flat_len64), nbytes_al = uint32_t(nbytes_al64);
