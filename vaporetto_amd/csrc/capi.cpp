@@ -33,14 +33,9 @@ vpt_status fail(vpt_status st, const std::string& msg) {
     } while (0)
 
 struct DevicePacked {
-    uint32_t *uni = nullptr, *rec = nullptr, *kids3 = nullptr, *deep = nullptr, *trow = nullptr;
-    int32_t* xrows = nullptr;
-    uint8_t* seed = nullptr;
-    void release() {
-        (void)hipFree(seed); seed = nullptr;
-        (void)hipFree(uni); (void)hipFree(rec); (void)hipFree(kids3); (void)hipFree(deep); (void)hipFree(trow); (void)hipFree(xrows);
-        uni = rec = kids3 = deep = trow = nullptr; xrows = nullptr;
-    }
+    unsigned char* base = nullptr;
+    uint32_t off[7] = {0, 0, 0, 0, 0, 0, 0};   // uni, rec, kids3, deep, xrows, seed, trow
+    void release() { (void)hipFree(base); base = nullptr; }
 };
 
 struct DeviceTable {
@@ -85,11 +80,33 @@ vpt::PackedView make_packed_view(const vpt::HostPackedTable& h, const DevicePack
     vpt::PackedView v{};
     v.present = h.present ? 1u : 0u;
     if (!h.present) return v;
-    v.uni = d.uni; v.rec = d.rec; v.kids3 = d.kids3; v.deep = d.deep; v.trow = d.trow; v.xrows = d.xrows;
-    v.seed = d.seed; v.seed_shift = 32 - h.seed_bits;
+    v.base = d.base;
+    v.off_uni = d.off[0]; v.off_rec = d.off[1]; v.off_kids3 = d.off[2]; v.off_deep = d.off[3];
+    v.off_xrows = d.off[4]; v.off_seed = d.off[5]; v.off_trow = d.off[6];
+    v.seed_shift = 32 - h.seed_bits;
     v.rec_shift = 32 - h.rec_bits; v.rec_mask = (1u << h.rec_bits) - 1;
     v.has_trow = h.trow.empty() ? 0u : 1u;
     return v;
+}
+
+// all packed arrays in one allocation (PackedView); false if they do not fit 32-bit offsets
+hipError_t upload_packed(const vpt::HostPackedTable& h, DevicePacked* d, bool* fits) {
+    const void* src[7] = {h.uni.data(), h.rec.data(), h.kids3.data(), h.deep.data(), h.xrows.data(), h.seed.data(), h.trow.data()};
+    const size_t bytes[7] = {4 * h.uni.size(), 4 * h.rec.size(), 4 * h.kids3.size(), 4 * h.deep.size(), 4 * h.xrows.size(),
+                             h.seed.size(), 4 * h.trow.size()};
+    size_t total = 0;
+    size_t off[7];
+    for (int i = 0; i < 7; ++i) { off[i] = total; total += (bytes[i] + kTablePadBytes + 255) & ~size_t(255); }
+    *fits = total < (size_t(1) << 32);
+    if (!*fits) return hipSuccess;
+    hipError_t e = hipMalloc(reinterpret_cast<void**>(&d->base), total);
+    if (e != hipSuccess) return e;
+    e = hipMemset(d->base, 0, total);
+    for (int i = 0; i < 7 && e == hipSuccess; ++i) {
+        d->off[i] = uint32_t(off[i]);
+        if (bytes[i]) e = hipMemcpy(d->base + off[i], src[i], bytes[i], hipMemcpyHostToDevice);
+    }
+    return e;
 }
 
 void fill_info(const vpt::CompiledModel& c, vpt_model_info* info) {
@@ -141,6 +158,7 @@ struct vpt_predictor {
     int device = 0;
     vpt_model_info info{};
     int32_t bias = 0; int pad = 1; int type_kind = 0; int type_window = 0; int chunks = 2;
+    uint32_t tile_slots = 0;           // workgroups of the scoring kernel the device runs at a time (0 = unknown)
     DeviceTable dc, dt;
     DevicePacked dp;
     vpt::PackedView pk{};
@@ -241,15 +259,8 @@ vpt_status vpt_predictor_create(const uint8_t* model_bytes, size_t len, int pred
     };
     up(c.chars, p->dc);
     up(c.types, p->dt);
-    if (c.packed.present) {
-        if (e == hipSuccess) e = upload(c.packed.uni, &p->dp.uni);
-        if (e == hipSuccess) e = upload(c.packed.rec, &p->dp.rec);
-        if (e == hipSuccess) e = upload(c.packed.kids3, &p->dp.kids3);
-        if (e == hipSuccess) e = upload(c.packed.deep, &p->dp.deep);
-        if (e == hipSuccess) e = upload(c.packed.xrows, &p->dp.xrows);
-        if (e == hipSuccess) e = upload(c.packed.seed, &p->dp.seed);
-        if (e == hipSuccess && !c.packed.trow.empty()) e = upload(c.packed.trow, &p->dp.trow);
-    }
+    bool packed_ok = c.packed.present;
+    if (c.packed.present && e == hipSuccess) e = upload_packed(c.packed, &p->dp, &packed_ok);
     if (e == hipSuccess && c.type_kind == vpt::kTypeWindowTable) e = upload(c.type_table, &p->d_type_table);
     if (e == hipSuccess) {
         std::vector<uint8_t> ctype(65536);
@@ -264,10 +275,22 @@ vpt_status vpt_predictor_create(const uint8_t* model_bytes, size_t len, int pred
     p->ct = make_view(c.chars, p->dc);
     p->tt = make_view(c.types, p->dt);
     p->pk = make_packed_view(c.packed, p->dp);
+    if (!packed_ok) { p->pk.present = 0; p->info.packed = 0; p->info.type_rows = 0; }
     uint32_t stride = 4;
     if (c.chars.present) stride = std::max(stride, c.chars.stride_dw);
     if (c.types.present) stride = std::max(stride, c.types.stride_dw);
     p->chunks = int(std::max<uint32_t>(2, stride / 4));
+    {
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, device_id) == hipSuccess && prop.multiProcessorCount > 0) {
+            vpt::ScoreParams probe{};
+            probe.ct = p->ct; probe.pk = p->pk; probe.pad = p->pad; probe.ctype = p->d_ctype; probe.type_kind = p->type_kind;
+            probe.type_window = p->type_window;
+            const size_t lds = vpt::fast_path_supported(probe) ? vpt::score_tiles_fast_lds_bytes(probe) : vpt::score_tiles_lds_bytes();
+            const uint32_t per_cu = uint32_t(std::min<size_t>(8, std::max<size_t>(1, (160u << 10) / std::max<size_t>(lds, 1))));
+            p->tile_slots = uint32_t(prop.multiProcessorCount) * per_cu;
+        }
+    }
     *out = p;
     return VPT_OK;
 }
@@ -400,6 +423,14 @@ vpt_status vpt_predict_batch_device(const vpt_predictor* p, vpt_batch* b, const 
     const uint64_t max_chars = (b->max_chars && b->max_chars < max_sentence_bytes) ? b->max_chars : max_sentence_bytes;
     if (max_chars + 2 * uint64_t(p->pad) + cap / 2 <= cap) tile_flat = cap - 2 * uint64_t(p->pad) - max_chars;
     const uint64_t total_flat = total_boundaries + uint64_t(n_sentences) * uint64_t(1 + p->pad);
+    // Whole rounds: the chip runs `slots` tiles at a time; cutting the batch into a multiple of that many tiles (by
+    // shrinking the tiles a little) avoids a last round that leaves most CUs idle.
+    if (p->tile_slots > 0) {
+        const uint64_t n_min = (total_flat + tile_flat - 1) / tile_flat;
+        const uint64_t rounds = (n_min + p->tile_slots - 1) / p->tile_slots;
+        const uint64_t even = (total_flat + rounds * p->tile_slots - 1) / (rounds * p->tile_slots);
+        if (even < tile_flat) tile_flat = std::max<uint64_t>(even, 256);
+    }
     const uint64_t n_tiles64 = (total_flat + tile_flat - 1) / tile_flat;
     if (n_tiles64 >= 0x7FFFFFFFull) return fail(VPT_INVALID_ARGUMENT, "InvalidArgumentError: batch too large for one call");
     const uint32_t n_tiles = uint32_t(n_tiles64);

@@ -55,6 +55,7 @@ hipError_t launch_assign_tiles(const uint64_t* ooff, uint64_t n_sent, int pad, u
                                uint32_t* tile_first, uint32_t* ctrl, hipStream_t stream);
 // specialised kernel (kernels_fast.hip): packed tables (char window 3, BMP, i16), type window table or none
 bool fast_path_supported(const ScoreParams& P);
+size_t score_tiles_fast_lds_bytes(const ScoreParams& P);
 hipError_t launch_score_tiles_fast(const ScoreParams& P, uint32_t n_tiles, hipStream_t stream);
 hipError_t launch_score_tiles(const ScoreParams& P, int chunks, uint32_t n_tiles, hipStream_t stream);
 hipError_t launch_score_slow(const ScoreParams& P, int chunks, uint32_t n_blocks, hipStream_t stream);

@@ -59,7 +59,11 @@ __device__ __forceinline__ uint32_t lane_rank(uint64_t mask) {  // set bits of `
 }
 
 __device__ __forceinline__ uint32_t pair_swap(uint32_t x) {  // value of lane ^ 1 (DPP quad_perm [1,0,3,2])
-    return uint32_t(__builtin_amdgcn_update_dpp(0, int(x), 0xB1, 0xF, 0xF, false));
+    return uint32_t(__builtin_amdgcn_mov_dpp(int(x), 0xB1, 0xF, 0xF, true));   // every lane is written: no `old`
+}
+// 16 bytes at base + byte offset (32-bit): one scalar base for all packed arrays
+__device__ __forceinline__ uint4 ld16(const unsigned char* base, uint32_t byte_off) {
+    return *reinterpret_cast<const uint4*>(base + byte_off);
 }
 // branch-free UTF-8 -> scalar value; b4 = the lead byte and the three bytes after it, little-endian
 __device__ __forceinline__ uint32_t utf8_scalar_bf(uint32_t b4) {
@@ -130,10 +134,10 @@ __device__ __forceinline__ void replay_w(const PackedView& K, FastLds& L, WaveSt
     const uint32_t s = it.x & 0x7FFu, depth = it.x >> 11;
     const uint32_t at = s + depth;
     const uint32_t c = (have && at < uint32_t(kFastCap + kMargin)) ? (L.sym[at] & kCpMask) : 0u;  // 0: sentence over
-    const uint4* tab = reinterpret_cast<const uint4*>(K.deep) + size_t(it.y >> 5) * 4;
+    const uint32_t tab = K.off_deep + ((it.y >> 5) << 6);   // byte offset of the mini-table (64-byte entries)
     const uint32_t last = (1u << (it.y & 31u)) - 1u;
     const uint32_t i0 = packed_mini_slot(c, it.y), i1 = (i0 + 1) & last;
-    const uint4 ea = tab[size_t(i0) * 4], eb = tab[size_t(i1) * 4];
+    const uint4 ea = ld16(K.base, tab + (i0 << 6)), eb = ld16(K.base, tab + (i1 << 6));
     const bool ma = c != 0 && (ea.x & 0xFFFFu) == c;
     const bool mb = c != 0 && !ma && ea.x != 0 && (eb.x & 0xFFFFu) == c;   // last == 0: eb is ea again, no match
     bool found = ma || mb;
@@ -144,7 +148,7 @@ __device__ __forceinline__ void replay_w(const PackedView& K, FastLds& L, WaveSt
         uint32_t i = (i1 + 1) & last, n = 2;
         while (__ballot(open) != 0) {
             if (open) {
-                e = tab[size_t(i) * 4];
+                e = ld16(K.base, tab + (i << 6));
                 found = (e.x & 0xFFFFu) == c;
                 idx = i;
                 open = !found && e.x != 0 && n < last;
@@ -153,12 +157,12 @@ __device__ __forceinline__ void replay_w(const PackedView& K, FastLds& L, WaveSt
             }
         }
     }
-    const uint4* ent = tab + size_t(idx) * 4;
+    const uint32_t ent = tab + (idx << 6);
     // the symbols that must follow (none for most entries of a dense trie, several for a long rare word)
     const uint32_t nskip = found ? (e.x >> 24) & 15u : 0u;
     if (__ballot(nskip != 0) != 0) {
         uint4 e1 = make_uint4(0, 0, 0, 0);
-        if (__ballot(nskip > 2) != 0) { if (nskip > 2) e1 = ent[1]; }
+        if (__ballot(nskip > 2) != 0) { if (nskip > 2) e1 = ld16(K.base, ent + 16); }
         const uint32_t sk[4] = {e.z, e.w, e1.x, e1.y};
 #pragma unroll
         for (uint32_t j = 0; j < kPackedMaxSkip; ++j) {
@@ -174,8 +178,8 @@ __device__ __forceinline__ void replay_w(const PackedView& K, FastLds& L, WaveSt
     const bool row = found && (e.x & (kPkHasRow << 16));
     if (__ballot(row) != 0) {
         uint4 f0 = make_uint4(0, 0, 0, 0), f1 = make_uint4(0, 0, 0, 0);
-        if (row) f0 = ent[2];
-        if (__ballot(row && m >= 8) != 0) { if (row && m >= 8) f1 = ent[3]; }
+        if (row) f0 = ld16(K.base, ent + 32);
+        if (__ballot(row && m >= 8) != 0) { if (row && m >= 8) f1 = ld16(K.base, ent + 48); }
         if (row) {
             atomicAdd(dst, lo16(f0.x)); atomicAdd(dst + 1, hi16(f0.x)); atomicAdd(dst + 2, lo16(f0.y)); atomicAdd(dst + 3, hi16(f0.y));
             atomicAdd(dst + 4, lo16(f0.z)); atomicAdd(dst + 5, hi16(f0.z)); atomicAdd(dst + 6, lo16(f0.w)); atomicAdd(dst + 7, hi16(f0.w));
@@ -189,7 +193,7 @@ __device__ __forceinline__ void replay_w(const PackedView& K, FastLds& L, WaveSt
     }
     if (__ballot(found && (e.x & (kPkExtRow << 16))) != 0) {  // more than 14 weights or a value outside i16 (rare)
         if (found && (e.x & (kPkExtRow << 16))) {
-            const int32_t* w32 = K.xrows + ent[2].x;
+            const int32_t* w32 = reinterpret_cast<const int32_t*>(K.base + K.off_xrows) + ld16(K.base, ent + 32).x;
             for (uint32_t j = 0; j <= m; ++j) atomicAdd(dst + j, w32[j]);
         }
     }
@@ -222,10 +226,10 @@ __device__ __forceinline__ void replay_o(const PackedView& K, const PatternTable
     const uint2 it = have ? Q.q[kQCap - 1 - (Q.no + lane)] : make_uint2(0u, 0u);
     const uint32_t s = it.x;
     const uint32_t c3 = have ? (L.sym[s + 2] & kCpMask) : 0u;
-    const uint4* tab = reinterpret_cast<const uint4*>(K.kids3) + (it.y >> 5);
+    const uint32_t tab = K.off_kids3 + ((it.y >> 5) << 4);   // byte offset of the mini-table (16-byte entries)
     const uint32_t last = (1u << (it.y & 31u)) - 1u;
     const uint32_t i0 = packed_mini_slot(c3, it.y), i1 = (i0 + 1) & last;
-    const uint4 ea = tab[i0], eb = tab[i1];
+    const uint4 ea = ld16(K.base, tab + (i0 << 4)), eb = ld16(K.base, tab + (i1 << 4));
     const bool ma = have && (ea.x & 0xFFFFu) == c3;
     const bool mb = have && !ma && ea.x != 0 && (eb.x & 0xFFFFu) == c3;
     bool found = ma || mb;
@@ -235,7 +239,7 @@ __device__ __forceinline__ void replay_o(const PackedView& K, const PatternTable
         uint32_t i = (i1 + 1) & last, n = 2;
         while (__ballot(open) != 0) {
             if (open) {
-                ch = tab[i];
+                ch = ld16(K.base, tab + (i << 4));
                 found = (ch.x & 0xFFFFu) == c3;
                 open = !found && ch.x != 0 && n < last;
                 i = (i + 1) & last;
@@ -335,8 +339,9 @@ __device__ __forceinline__ void replay_m(const PackedView& K, const PatternTable
     const uint32_t hop = far ? 0u : it.y >> 24;                       // records still to visit, as distances from home
     const uint32_t hop_next = hop & (hop - 1u);
     const uint32_t slot = far ? it.y : ((it.y & 0xFFFFFFu) + (hop ? uint32_t(__ffs(int(hop))) : 0u)) & K.rec_mask;
-    const uint4* r = reinterpret_cast<const uint4*>(K.rec) + size_t(more ? slot : 0u) * 8;
-    const uint4 h0 = r[0], r1 = r[1], r2 = r[2], r3 = r[3], h1 = r[4], l1 = r[5], l2 = r[6], l3 = r[7];
+    const uint32_t r = K.off_rec + ((more ? slot : 0u) << 7);
+    const uint4 h0 = ld16(K.base, r), r1 = ld16(K.base, r + 16), r2 = ld16(K.base, r + 32), r3 = ld16(K.base, r + 48);
+    const uint4 h1 = ld16(K.base, r + 64), l1 = ld16(K.base, r + 80), l2 = ld16(K.base, r + 96), l3 = ld16(K.base, r + 112);
     const bool keyok = more && h0.x == kb;
     const bool again = more && !keyok && (far ? h0.x != 0 : hop_next != 0);
     const RecMatch mt = match_record(keyok, c0, c3, h0, r1, r2, r3, h1, l1, l2, l3);
@@ -378,7 +383,7 @@ __device__ __forceinline__ uint64_t phase_mark(uint64_t* prof, int slot, uint64_
 }
 
 template <int TM>
-__global__ __launch_bounds__(kThreads) void score_tiles_fast_kernel(const ScoreParams P) {
+__global__ __launch_bounds__(kThreads, 5) void score_tiles_fast_kernel(const ScoreParams P) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     FastLds& L = *reinterpret_cast<FastLds*>(smem);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -407,7 +412,7 @@ __global__ __launch_bounds__(kThreads) void score_tiles_fast_kernel(const ScoreP
     const uint32_t nchunks = (nbytes_al + 15) >> 4;
     uint32_t err = 0;
     if (TM == kTypeRows) {  // 512 type rows -> LDS (not aliased by the decode scratch; barriers follow before use)
-        for (uint32_t i = tid; i < uint32_t(kTrowCount); i += kThreads) L.trow[i] = reinterpret_cast<const uint4*>(P.pk.trow)[i];
+        for (uint32_t i = tid; i < uint32_t(kTrowCount); i += kThreads) L.trow[i] = ld16(P.pk.base, P.pk.off_trow + (i << 4));
     }
     uint64_t* const prof = P.prof;
     uint64_t tmark = prof ? __builtin_amdgcn_s_memtime() : 0;
@@ -529,8 +534,6 @@ __global__ __launch_bounds__(kThreads) void score_tiles_fast_kernel(const ScoreP
     // ---------------------------------------------------------------- B. patterns
     const PackedView& K = P.pk;
     WaveStacks Q{&L.queue[wave][0], &L.mqueue[wave][0], 0u, 0u, 0u};
-    const uint4* uni4 = reinterpret_cast<const uint4*>(K.uni);
-    const uint4* rec4 = reinterpret_cast<const uint4*>(K.rec);
     // The slot of a record needs the seed byte of its key's bucket: a dependent, cache-hot load.  It is issued one
     // iteration ahead (together with the LDS reads of that iteration's symbols), so the record loads never wait for it.
     uint32_t nx0, nx1, nx2, nx3, nseed;
@@ -538,7 +541,7 @@ __global__ __launch_bounds__(kThreads) void score_tiles_fast_kernel(const ScoreP
         nx1 = sn < flat_len ? L.sym[sn] : 0u;
         nx0 = (nx1 & kCpMask) != 0 ? L.sym[sn - 1] : 0u;   // sn >= pad whenever the position holds a char
         nx2 = L.sym[sn + 1]; nx3 = L.sym[sn + 2];          // past the tile: zeroed slack, then unrelated LDS (dead lanes)
-        nseed = uint32_t(K.seed[packed_ph_bucket((nx1 & kCpMask) | ((nx2 & kCpMask) << 16), K.seed_shift)]);
+        nseed = uint32_t(K.base[K.off_seed + packed_ph_bucket((nx1 & kCpMask) | ((nx2 & kCpMask) << 16), K.seed_shift)]);
     };
     stage(uint32_t(tid));
     for (int k = 0; k < kPerThread; ++k) {
@@ -555,13 +558,13 @@ __global__ __launch_bounds__(kThreads) void score_tiles_fast_kernel(const ScoreP
         uint32_t hrec = packed_ph_slot(kb, nseed, K.rec_shift);
         if (P.debug & 1u) hrec = 0;  // timing ablation (VPT_DEBUG_ABLATE; results are wrong): pin the record
         // every load first: the unigram row and the whole record of (c1,c2)
-        const uint4 u = uni4[(P.debug & 4u) ? 0u : c1];
+        const uint4 u = ld16(K.base, K.off_uni + (((P.debug & 4u) ? 0u : c1) << 4));
         const uint32_t p_hrec = pair_swap(hrec);
         const bool odd = (lane & 1) != 0;
-        const uint4* ra = reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(rec4) + (((odd ? p_hrec : hrec) << 7) | (odd ? 64u : 0u)));
-        const uint4* rb = reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(rec4) + (((odd ? hrec : p_hrec) << 7) | (odd ? 0u : 64u)));
-        const uint4 qa0 = ra[0], qa1 = ra[1], qa2 = ra[2], qa3 = ra[3];   // even lane: own half 0; odd lane: partner's half 1
-        const uint4 qb0 = rb[0], qb1 = rb[1], qb2 = rb[2], qb3 = rb[3];   // even lane: partner's half 1; odd lane: own half 0
+        const uint32_t ra = K.off_rec + (((odd ? p_hrec : hrec) << 7) | (odd ? 64u : 0u));
+        const uint32_t rb = K.off_rec + (((odd ? hrec : p_hrec) << 7) | (odd ? 0u : 64u));
+        const uint4 qa0 = ld16(K.base, ra), qa1 = ld16(K.base, ra + 16), qa2 = ld16(K.base, ra + 32), qa3 = ld16(K.base, ra + 48);   // even lane: own half 0; odd lane: partner's half 1
+        const uint4 qb0 = ld16(K.base, rb), qb1 = ld16(K.base, rb + 16), qb2 = ld16(K.base, rb + 32), qb3 = ld16(K.base, rb + 48);   // even lane: partner's half 1; odd lane: own half 0
         if (k + 1 < kPerThread) stage(s + uint32_t(kThreads));          // next iteration's symbols and seed
         // own half 0 = even ? qa : qb (already here); own half 1 = the partner's qb (even lanes) / qa (odd lanes)
         const uint4 h0 = odd ? qb0 : qa0, r1 = odd ? qb1 : qa1, r2 = odd ? qb2 : qa2, r3 = odd ? qb3 : qa3;
@@ -644,9 +647,16 @@ bool fast_path_supported(const ScoreParams& P) {
     return P.type_kind == kTypeWindowTable && P.type_window >= 1 && P.type_window <= 3;
 }
 
+static bool use_type_rows(const ScoreParams& P) {
+    return P.type_kind == kTypeWindowTable && P.pk.has_trow && !std::getenv("VPT_FORCE_WINDOW_TABLE");
+}
+size_t score_tiles_fast_lds_bytes(const ScoreParams& P) {
+    return offsetof(FastLds, typ) + (use_type_rows(P) ? sizeof(uint4) * kTrowCount : size_t(kFastCap + kMargin));
+}
+
 hipError_t launch_score_tiles_fast(const ScoreParams& P, uint32_t n_tiles, hipStream_t stream) {
-    const bool rows = P.type_kind == kTypeWindowTable && P.pk.has_trow && !std::getenv("VPT_FORCE_WINDOW_TABLE");
-    size_t lds = offsetof(FastLds, typ) + (rows ? sizeof(uint4) * kTrowCount : size_t(kFastCap + kMargin));
+    const bool rows = use_type_rows(P);
+    size_t lds = score_tiles_fast_lds_bytes(P);
     if (const char* padv = std::getenv("VPT_DEBUG_LDS_PAD")) lds += size_t(std::atoi(padv));  // occupancy experiments
     const int tm = rows ? kTypeRows : P.type_kind == kTypeWindowTable ? P.type_window : 0;
     switch (tm) {

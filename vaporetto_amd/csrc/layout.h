@@ -170,11 +170,11 @@ struct PatternTableView {
     uint32_t present;        // 0 = this scorer is None (char_scorer.rs:98-100 / type_scorer.rs:109-111)
 };
 
-// Device view of the packed tables; passed to the specialised kernel by value.
+// Device view of the packed tables; passed to the specialised kernel by value.  All arrays live in ONE device
+// allocation (below 4 GB), addressed as base + 32-bit byte offset: one scalar base pointer instead of seven.
 struct PackedView {
-    const uint32_t *uni, *rec, *kids3, *deep, *trow;   // 16-byte units (uint4)
-    const int32_t* xrows;
-    const uint8_t* seed;            // perfect-hash seed per bucket
+    const unsigned char* base;
+    uint32_t off_uni, off_rec, off_kids3, off_deep, off_xrows, off_seed, off_trow;   // byte offsets, 256-byte aligned
     uint32_t rec_shift, rec_mask;   // hash shift and mask in RECORDS
     uint32_t seed_shift;            // 32 - log2(buckets)
     uint32_t present;
