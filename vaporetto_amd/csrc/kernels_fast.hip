@@ -61,6 +61,16 @@ __device__ __forceinline__ uint32_t lane_rank(uint64_t mask) {  // set bits of `
 __device__ __forceinline__ uint32_t pair_swap(uint32_t x) {  // value of lane ^ 1 (DPP quad_perm [1,0,3,2])
     return uint32_t(__builtin_amdgcn_mov_dpp(int(x), 0xB1, 0xF, 0xF, true));   // every lane is written: no `old`
 }
+// inclusive prefix sum over the 64 lanes of a wave: DPP row shifts, then the two row broadcasts (no LDS round trips)
+__device__ __forceinline__ uint32_t wave_inclusive_scan(uint32_t x) {
+    x += uint32_t(__builtin_amdgcn_update_dpp(0, int(x), 0x111, 0xF, 0xF, false));  // row_shr:1
+    x += uint32_t(__builtin_amdgcn_update_dpp(0, int(x), 0x112, 0xF, 0xF, false));  // row_shr:2
+    x += uint32_t(__builtin_amdgcn_update_dpp(0, int(x), 0x114, 0xF, 0xF, false));  // row_shr:4
+    x += uint32_t(__builtin_amdgcn_update_dpp(0, int(x), 0x118, 0xF, 0xF, false));  // row_shr:8
+    x += uint32_t(__builtin_amdgcn_update_dpp(0, int(x), 0x142, 0xA, 0xF, false));  // row_bcast:15 -> rows 1, 3
+    x += uint32_t(__builtin_amdgcn_update_dpp(0, int(x), 0x143, 0xC, 0xF, false));  // row_bcast:31 -> rows 2, 3
+    return x;
+}
 // 16 bytes at base + byte offset (32-bit): one scalar base for all packed arrays
 __device__ __forceinline__ uint4 ld16(const unsigned char* base, uint32_t byte_off) {
     return *reinterpret_cast<const uint4*>(base + byte_off);
@@ -429,28 +439,27 @@ __global__ __launch_bounds__(kThreads, 5) void score_tiles_fast_kernel(const Sco
         atomicOr(&bitmap[pos >> 5], 1u << (pos & 31));
     }
     __syncthreads();
-    uint32_t base_leads = 0, base_starts = 0;
-    for (uint32_t c0 = 0; c0 < nchunks; c0 += kThreads) {
-        const uint32_t c = c0 + tid;
+    // one pass: thread t owns bytes [32 t, 32 t + 32) of the (16-byte aligned) tile text -- 8 KB, more than a tile holds
+    uint32_t base_leads = 0;
+    {
+        const uint32_t pos0 = uint32_t(tid) * 32u;
         uint32_t lm = 0, sm = 0;
-        const uint32_t pos0 = c * 16;
-        if (c < nchunks) {
-            const uint4 v = reinterpret_cast<const uint4*>(a0)[c];
-            reinterpret_cast<uint4*>(raw)[c] = v;  // stage the text for the per-char decode
-            const uint32_t lo = pos0 < head ? head - pos0 : 0u;
+        if (pos0 < nbytes_al) {
+            const uint4* src = reinterpret_cast<const uint4*>(a0) + size_t(tid) * 2;
+            const uint4 v0 = src[0];
+            const bool two = pos0 + 16 < nbytes_al;
+            const uint4 v1 = two ? src[1] : make_uint4(0, 0, 0, 0);
+            reinterpret_cast<uint4*>(raw)[tid * 2] = v0;  // stage the text for the per-char decode
+            reinterpret_cast<uint4*>(raw)[tid * 2 + 1] = v1;
+            const uint32_t lo = pos0 < head ? head - pos0 : 0u;   // head < 16
             const uint32_t rem = nbytes_al - pos0;
-            const uint32_t hi = rem < 16 ? rem : 16u;
-            const uint32_t vm = ((1u << hi) - 1u) & ~((1u << lo) - 1u);
-            lm = (lead_nibble(v.x) | (lead_nibble(v.y) << 4) | (lead_nibble(v.z) << 8) | (lead_nibble(v.w) << 12)) & vm;
-            sm = (bitmap[pos0 >> 5] >> (pos0 & 31)) & 0xFFFFu;
+            const uint32_t vm = (rem < 32 ? (1u << rem) - 1u : 0xFFFFFFFFu) & ~((1u << lo) - 1u);
+            lm = (lead_nibble(v0.x) | (lead_nibble(v0.y) << 4) | (lead_nibble(v0.z) << 8) | (lead_nibble(v0.w) << 12) |
+                  (lead_nibble(v1.x) << 16) | (lead_nibble(v1.y) << 20) | (lead_nibble(v1.z) << 24) | (lead_nibble(v1.w) << 28)) & vm;
+            sm = bitmap[tid];
         }
         const uint32_t mine = __popc(lm) | (__popc(sm) << 16);
-        uint32_t incl = mine;
-#pragma unroll
-        for (int d = 1; d < 64; d <<= 1) {
-            const uint32_t u = __shfl_up(incl, d);
-            if (lane >= d) incl += u;
-        }
+        const uint32_t incl = wave_inclusive_scan(mine);
         if (lane == 63) L.wtot[wave] = incl;
         __syncthreads();
         uint32_t woff = 0, total = 0;
@@ -461,16 +470,15 @@ __global__ __launch_bounds__(kThreads, 5) void score_tiles_fast_kernel(const Sco
             total += u;
         }
         const uint32_t excl = woff + incl - mine;
-        uint32_t ci = base_leads + (excl & 0xFFFFu);
-        const uint32_t si0 = base_starts + (excl >> 16);
-        base_leads += total & 0xFFFFu;
-        base_starts += total >> 16;
-        __syncthreads();
+        uint32_t ci = excl & 0xFFFFu;
+        const uint32_t si0 = excl >> 16;
+        base_leads = total & 0xFFFFu;
+        __syncthreads();   // every thread has read its bitmap word: the queue area is free again
         uint32_t m = lm;
         while (m) {
             const uint32_t k = uint32_t(__ffs(int(m))) - 1u;
             m &= m - 1;
-            const uint32_t si = si0 + uint32_t(__popc(sm & ((2u << k) - 1u))) - 1u;
+            const uint32_t si = si0 + uint32_t(__popc(sm & (0xFFFFFFFFu >> (31u - k)))) - 1u;
             if (ci < uint32_t(kFastCap)) L.sym[ci] = (pos0 + k) | (si << 16);
             ++ci;
         }
@@ -479,6 +487,7 @@ __global__ __launch_bounds__(kThreads, 5) void score_tiles_fast_kernel(const Sco
     if (nchars != expect_chars) err |= kErrBadOffsets;
     tmark = phase_mark(prof, 0, tmark);
     if (tid == 0) raw[nchunks * 4] = 0;  // the dword after the staged text is read (as padding) by the last char
+    (void)nchunks;
     __syncthreads();
 
     // one thread per char: decode from the staged text
