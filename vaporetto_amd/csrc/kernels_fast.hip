@@ -439,24 +439,20 @@ __global__ __launch_bounds__(kThreads, 5) void score_tiles_fast_kernel(const Sco
         atomicOr(&bitmap[pos >> 5], 1u << (pos & 31));
     }
     __syncthreads();
-    // one pass: thread t owns bytes [32 t, 32 t + 32) of the (16-byte aligned) tile text -- 8 KB, more than a tile holds
-    uint32_t base_leads = 0;
-    {
-        const uint32_t pos0 = uint32_t(tid) * 32u;
+    uint32_t base_leads = 0, base_starts = 0;
+    for (uint32_t c0 = 0; c0 < nchunks; c0 += kThreads) {   // one pass for up to 4 KB of tile text, else two
+        const uint32_t c = c0 + tid;
         uint32_t lm = 0, sm = 0;
-        if (pos0 < nbytes_al) {
-            const uint4* src = reinterpret_cast<const uint4*>(a0) + size_t(tid) * 2;
-            const uint4 v0 = src[0];
-            const bool two = pos0 + 16 < nbytes_al;
-            const uint4 v1 = two ? src[1] : make_uint4(0, 0, 0, 0);
-            reinterpret_cast<uint4*>(raw)[tid * 2] = v0;  // stage the text for the per-char decode
-            reinterpret_cast<uint4*>(raw)[tid * 2 + 1] = v1;
-            const uint32_t lo = pos0 < head ? head - pos0 : 0u;   // head < 16
+        const uint32_t pos0 = c * 16;
+        if (c < nchunks) {
+            const uint4 v = reinterpret_cast<const uint4*>(a0)[c];
+            reinterpret_cast<uint4*>(raw)[c] = v;  // stage the text for the per-char decode
+            const uint32_t lo = pos0 < head ? head - pos0 : 0u;
             const uint32_t rem = nbytes_al - pos0;
-            const uint32_t vm = (rem < 32 ? (1u << rem) - 1u : 0xFFFFFFFFu) & ~((1u << lo) - 1u);
-            lm = (lead_nibble(v0.x) | (lead_nibble(v0.y) << 4) | (lead_nibble(v0.z) << 8) | (lead_nibble(v0.w) << 12) |
-                  (lead_nibble(v1.x) << 16) | (lead_nibble(v1.y) << 20) | (lead_nibble(v1.z) << 24) | (lead_nibble(v1.w) << 28)) & vm;
-            sm = bitmap[tid];
+            const uint32_t hi = rem < 16 ? rem : 16u;
+            const uint32_t vm = ((1u << hi) - 1u) & ~((1u << lo) - 1u);
+            lm = (lead_nibble(v.x) | (lead_nibble(v.y) << 4) | (lead_nibble(v.z) << 8) | (lead_nibble(v.w) << 12)) & vm;
+            sm = (bitmap[pos0 >> 5] >> (pos0 & 31)) & 0xFFFFu;
         }
         const uint32_t mine = __popc(lm) | (__popc(sm) << 16);
         const uint32_t incl = wave_inclusive_scan(mine);
@@ -470,15 +466,16 @@ __global__ __launch_bounds__(kThreads, 5) void score_tiles_fast_kernel(const Sco
             total += u;
         }
         const uint32_t excl = woff + incl - mine;
-        uint32_t ci = excl & 0xFFFFu;
-        const uint32_t si0 = excl >> 16;
-        base_leads = total & 0xFFFFu;
-        __syncthreads();   // every thread has read its bitmap word: the queue area is free again
+        uint32_t ci = base_leads + (excl & 0xFFFFu);
+        const uint32_t si0 = base_starts + (excl >> 16);
+        base_leads += total & 0xFFFFu;
+        base_starts += total >> 16;
+        __syncthreads();
         uint32_t m = lm;
         while (m) {
             const uint32_t k = uint32_t(__ffs(int(m))) - 1u;
             m &= m - 1;
-            const uint32_t si = si0 + uint32_t(__popc(sm & (0xFFFFFFFFu >> (31u - k)))) - 1u;
+            const uint32_t si = si0 + uint32_t(__popc(sm & ((2u << k) - 1u))) - 1u;
             if (ci < uint32_t(kFastCap)) L.sym[ci] = (pos0 + k) | (si << 16);
             ++ci;
         }
@@ -487,7 +484,6 @@ __global__ __launch_bounds__(kThreads, 5) void score_tiles_fast_kernel(const Sco
     if (nchars != expect_chars) err |= kErrBadOffsets;
     tmark = phase_mark(prof, 0, tmark);
     if (tid == 0) raw[nchunks * 4] = 0;  // the dword after the staged text is read (as padding) by the last char
-    (void)nchunks;
     __syncthreads();
 
     // one thread per char: decode from the staged text
@@ -544,7 +540,8 @@ __global__ __launch_bounds__(kThreads, 5) void score_tiles_fast_kernel(const Sco
     const PackedView& K = P.pk;
     WaveStacks Q{&L.queue[wave][0], &L.mqueue[wave][0], 0u, 0u, 0u};
     // The slot of a record needs the seed byte of its key's bucket: a dependent, cache-hot load.  It is issued one
-    // iteration ahead (together with the LDS reads of that iteration's symbols), so the record loads never wait for it.
+    // iteration ahead (together with the LDS reads of that iteration's symbols), right after the current records have
+    // arrived, so that neither the record loads wait for it nor it for them.
     uint32_t nx0, nx1, nx2, nx3, nseed;
     auto stage = [&](uint32_t sn) {
         nx1 = sn < flat_len ? L.sym[sn] : 0u;
@@ -574,7 +571,6 @@ __global__ __launch_bounds__(kThreads, 5) void score_tiles_fast_kernel(const Sco
         const uint32_t rb = K.off_rec + (((odd ? hrec : p_hrec) << 7) | (odd ? 0u : 64u));
         const uint4 qa0 = ld16(K.base, ra), qa1 = ld16(K.base, ra + 16), qa2 = ld16(K.base, ra + 32), qa3 = ld16(K.base, ra + 48);   // even lane: own half 0; odd lane: partner's half 1
         const uint4 qb0 = ld16(K.base, rb), qb1 = ld16(K.base, rb + 16), qb2 = ld16(K.base, rb + 32), qb3 = ld16(K.base, rb + 48);   // even lane: partner's half 1; odd lane: own half 0
-        if (k + 1 < kPerThread) stage(s + uint32_t(kThreads));          // next iteration's symbols and seed
         // own half 0 = even ? qa : qb (already here); own half 1 = the partner's qb (even lanes) / qa (odd lanes)
         const uint4 h0 = odd ? qb0 : qa0, r1 = odd ? qb1 : qa1, r2 = odd ? qb2 : qa2, r3 = odd ? qb3 : qa3;
         uint4 h1, l1, l2, l3;
@@ -599,6 +595,8 @@ __global__ __launch_bounds__(kThreads, 5) void score_tiles_fast_kernel(const Sco
             a5 += int32_t(__builtin_amdgcn_alignbit(tr.w, tr.z, 26) << 14) >> 14;
         }
         const bool keyok = has2 && h0.x == kb;
+        // the record has arrived: request the next iteration's seed byte now, it has this iteration's arithmetic to land
+        if (k + 1 < kPerThread) stage(s + uint32_t(kThreads));
         const RecMatch mt = match_record(keyok, c0, c3, h0, r1, r2, r3, h1, l1, l2, l3);
         a1 += mt.b1; a2 += mt.b2; a3 += mt.b3; a4 += mt.b4; a5 += mt.b5;
         if (live) add_row6(L.score, s, a0, a1, a2, a3, a4, a5);
