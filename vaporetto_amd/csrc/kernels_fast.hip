@@ -540,8 +540,7 @@ __global__ __launch_bounds__(kThreads, 5) void score_tiles_fast_kernel(const Sco
     const PackedView& K = P.pk;
     WaveStacks Q{&L.queue[wave][0], &L.mqueue[wave][0], 0u, 0u, 0u};
     // The slot of a record needs the seed byte of its key's bucket: a dependent, cache-hot load.  It is issued one
-    // iteration ahead (together with the LDS reads of that iteration's symbols), right after the current records have
-    // arrived, so that neither the record loads wait for it nor it for them.
+    // iteration ahead (together with the LDS reads of that iteration's symbols), behind the current record loads.
     uint32_t nx0, nx1, nx2, nx3, nseed;
     auto stage = [&](uint32_t sn) {
         nx1 = sn < flat_len ? L.sym[sn] : 0u;
@@ -573,6 +572,7 @@ __global__ __launch_bounds__(kThreads, 5) void score_tiles_fast_kernel(const Sco
         const uint4 qb0 = ld16(K.base, rb), qb1 = ld16(K.base, rb + 16), qb2 = ld16(K.base, rb + 32), qb3 = ld16(K.base, rb + 48);   // even lane: partner's half 1; odd lane: own half 0
         // own half 0 = even ? qa : qb (already here); own half 1 = the partner's qb (even lanes) / qa (odd lanes)
         const uint4 h0 = odd ? qb0 : qa0, r1 = odd ? qb1 : qa1, r2 = odd ? qb2 : qa2, r3 = odd ? qb3 : qa3;
+        if (k + 1 < kPerThread) stage(s + uint32_t(kThreads));          // next iteration's symbols and seed
         uint4 h1, l1, l2, l3;
         {
             // what this lane holds of the PARTNER's record, handed over through DPP
@@ -595,8 +595,6 @@ __global__ __launch_bounds__(kThreads, 5) void score_tiles_fast_kernel(const Sco
             a5 += int32_t(__builtin_amdgcn_alignbit(tr.w, tr.z, 26) << 14) >> 14;
         }
         const bool keyok = has2 && h0.x == kb;
-        // the record has arrived: request the next iteration's seed byte now, it has this iteration's arithmetic to land
-        if (k + 1 < kPerThread) stage(s + uint32_t(kThreads));
         const RecMatch mt = match_record(keyok, c0, c3, h0, r1, r2, r3, h1, l1, l2, l3);
         a1 += mt.b1; a2 += mt.b2; a3 += mt.b3; a4 += mt.b4; a5 += mt.b5;
         if (live) add_row6(L.score, s, a0, a1, a2, a3, a4, a5);
