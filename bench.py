@@ -63,8 +63,9 @@ def main():
     ap.add_argument("--sentences", type=int, default=100000, help="sentences per GPU per step")
     ap.add_argument("--min-len", type=int, default=64)
     ap.add_argument("--max-len", type=int, default=64)
-    ap.add_argument("--model-kind", type=int, default=1, help="1 bccwj-suw+unidic-like, 2 jp-0.4.7-5-like")
+    ap.add_argument("--model-kind", type=int, default=1, help="1 bccwj-suw+unidic-like, 2 jp-0.4.7-5-like, 3 = 1 + tag models")
     ap.add_argument("--model-scale", type=float, default=1.0)
+    ap.add_argument("--predict-tags", action="store_true", help="Predictor::new(model, true): the reference's BoundaryTag scorers (boundary scores only)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--phases", action="store_true", help="diagnostics: per-phase shader cycles of the scoring kernel (slows it)")
     args = ap.parse_args()
@@ -88,7 +89,7 @@ def main():
     from vaporetto_amd import dist as vdist
     model_bytes, model_name = (load_model_bytes(args.model_kind, args.model_scale) if rank == 0 else (None, ""))
     model_bytes = vdist.broadcast_model_bytes(model_bytes, src=0, device=dev)
-    predictor = api.Predictor(api.Model.read_slice(model_bytes)[0], False, device=local_rank)
+    predictor = api.Predictor(api.Model.read_slice(model_bytes)[0], args.predict_tags, device=local_rank)
     info = predictor.info()
 
     # ---- this rank's batch, resident in HBM
@@ -156,7 +157,7 @@ def main():
         kernel_name = "score_tiles_fast_kernel" if info["packed"] and info["type_kind"] in (0, 1) else "score_tiles_kernel"
         if not args.no_cpu_baseline:
             from oracle import cbind
-            orc = cbind.OraclePredictor(model_bytes)
+            orc = cbind.OraclePredictor(model_bytes, args.predict_tags)
             ncores = os.cpu_count() or 1
             t = time.perf_counter()
             o_scores, o_labels, _, a_char = orc.predict_batch(utf8, boff, nthreads=1)

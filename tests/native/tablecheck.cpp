@@ -56,6 +56,17 @@ int tc_create(const uint8_t* bytes, size_t len, tc_model** out) {
         return 1;
     }
 }
+int tc_create_tags(const uint8_t* bytes, size_t len, int predict_tags, tc_model** out) {
+    try {
+        ModelData m = parse_model(bytes, len, nullptr);
+        tc_model* t = new tc_model();
+        t->c = compile_model(m, predict_tags != 0);
+        *out = t;
+        return 0;
+    } catch (const ModelError&) {
+        return 1;
+    }
+}
 void tc_destroy(tc_model* t) { delete t; }
 int tc_packed_present(const tc_model* t) { return t->c.packed.present ? 1 : 0; }
 int tc_trow_present(const tc_model* t) { return t->c.packed.present && !t->c.packed.trow.empty() ? 1 : 0; }

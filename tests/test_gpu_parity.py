@@ -441,3 +441,14 @@ def test_understated_length_bounds_are_reported():
     with pytest.raises(api.VaporettoError, match="smaller than the longest sentence"):
         run(batch, 64)                         # understated bytes
     assert np.array_equal(run(batch, true_bytes), want)
+
+
+def test_tag_enabled_model_with_duplicate_type_ngrams_runs_on_the_packed_path():
+    m = randmodel.rand_model(41, alphabet="kana", wc=3, wt=3, n_char=80, n_dict=80, n_type=50, max_word=6, n_tag_models=4)
+    m.type_ngram_model.append(NgramData(bytes([3, 3]), [100, -200, 300, 400, -500]))
+    m.type_ngram_model.append(NgramData(bytes([3, 3]), [7, 8, 9]))
+    pred, orc = make_predictor(m, predict_tags=True)
+    info = pred.info()
+    assert info["packed"] == 1 and info["type_kind"] == 1
+    mixed = randmodel.ALPHABETS["kana"][:10] + list("漢字AZ09、")
+    check_batch(pred, orc, randmodel.rand_sentences(4, m, 1500, alphabet=mixed, max_len=60))

@@ -25,6 +25,7 @@ def tc():
         subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-o", LIB] + SRCS)
     L = C.CDLL(LIB)
     L.tc_create.argtypes = [C.c_char_p, C.c_size_t, C.POINTER(C.c_void_p)]
+    L.tc_create_tags.argtypes = [C.c_char_p, C.c_size_t, C.c_int, C.POINTER(C.c_void_p)]
     L.tc_destroy.argtypes = [C.c_void_p]
     L.tc_packed_present.argtypes = [C.c_void_p]
     L.tc_stats.argtypes = [C.c_void_p, C.POINTER(C.c_uint32 * 8)]
@@ -34,10 +35,10 @@ def tc():
 
 
 class Walker:
-    def __init__(self, L, raw):
+    def __init__(self, L, raw, predict_tags=False):
         self.L = L
         self.h = C.c_void_p()
-        assert L.tc_create(raw, len(raw), C.byref(self.h)) == 0
+        assert L.tc_create_tags(raw, len(raw), int(predict_tags), C.byref(self.h)) == 0
 
     def __del__(self):
         self.L.tc_destroy(self.h)
@@ -223,3 +224,21 @@ def test_long_words_compressed_chains(tc):
     texts += ["".join(rng.choice(sorted(words)) for _ in range(3)) for _ in range(80)]
     for t in texts:
         assert w.score(t) == orc.predict(t)[0], t
+
+
+def test_tag_enabled_models_merge_duplicate_type_ngrams(tc):
+    """predict_tags = true with tag models: the reference merges identical type n-grams (TypeWeightMerger) instead of
+    rejecting them; the type rows are built from the merged list and must match the oracle in that mode."""
+    from vaporetto_amd.modelfmt import TagModel
+    m = randmodel.rand_model(41, alphabet="kana", wc=3, wt=3, n_char=80, n_dict=80, n_type=50, max_word=6, n_tag_models=4)
+    m.type_ngram_model.append(NgramData(bytes([3, 3]), [100, -200, 300, 400, -500]))
+    m.type_ngram_model.append(NgramData(bytes([3, 3]), [7, 8, 9]))                      # duplicate, shorter vector
+    m.type_ngram_model.append(NgramData(bytes([3]), [1, 2, 3, 4, 5, 6]))
+    m.type_ngram_model.append(NgramData(bytes([3]), [-1, -2, -3, -4, -5, -6]))
+    raw = encode_model(m)
+    w = Walker(tc, raw, predict_tags=True)
+    assert w.packed and w.trow
+    orc = cbind.OraclePredictor(raw, True)
+    mixed = randmodel.ALPHABETS["kana"][:10] + list("漢字AZ09、")
+    for t in randmodel.rand_sentences(4, m, 300, alphabet=mixed, max_len=40):
+        assert w.score(t, want=2) == orc.predict(t)[0], t

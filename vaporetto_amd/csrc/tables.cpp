@@ -641,6 +641,28 @@ CompiledModel compile_model(const ModelData& m, bool predict_tags) {
             c.type_kind = kTypeWindowTable;
             c.type_table = build_type_window_table(m.type_ngrams, wt);
             if (c.packed.present) c.packed.trow = build_type_rows(m.type_ngrams, wt);
+        } else if (wt <= 3) {
+            // With tag models the reference scores types through TypeScorerBoundaryTag (type_scorer.rs:113-131): an
+            // automaton over the MERGED n-grams (identical n-grams sum, TypeWeightMerger::add, type_scorer.rs:46-56).
+            // The sums per boundary are the same function of the 2W-type window, so the same table / type rows serve.
+            std::vector<NgramRecord> merged;
+            std::vector<size_t> order(m.type_ngrams.size());
+            for (size_t i = 0; i < order.size(); ++i) order[i] = i;
+            std::stable_sort(order.begin(), order.end(), [&](size_t x, size_t y) { return m.type_ngrams[x].ngram < m.type_ngrams[y].ngram; });
+            for (size_t i : order) {
+                const NgramRecord& d = m.type_ngrams[i];
+                if (d.ngram.empty()) throw ModelError("InvalidModelError: failed to build the automaton");
+                if (int(d.weights.size()) > std::max(0, 2 * wt - int(d.ngram.size()) + 1))
+                    throw ModelError("InvalidModelError: character type n-gram weight vector is longer than 2*window_size-n+1");
+                if (!merged.empty() && merged.back().ngram == d.ngram) {
+                    std::vector<int32_t>& w = merged.back().weights;
+                    if (w.size() < d.weights.size()) w.resize(d.weights.size(), 0);
+                    for (size_t k = 0; k < d.weights.size(); ++k) w[k] = wadd(w[k], d.weights[k]);
+                } else merged.push_back(d);
+            }
+            c.type_kind = kTypeWindowTable;
+            c.type_table = build_type_window_table(merged, wt);
+            if (c.packed.present) c.packed.trow = build_type_rows(merged, wt);
         } else {
             if (wt > kMaxWindow) throw ModelError("InvalidModelError: type_window_size above 8 is not supported");
             c.type_kind = kTypePatternTable;
