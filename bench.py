@@ -138,8 +138,9 @@ def main():
             "metric": "boundary scores/sec", "value": total_boundaries * args.steps / elapsed, "unit": "boundaries/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "int32", "data": "synthetic",
-            "config": {"workload": "configs[1]: %s model, %d sentences x %d..%d chars per GPU per step, inputs resident in HBM"
-                       % (model_name, S, args.min_len, args.max_len),
+            "config": {"workload": "%s: %s model, %d sentences x %d..%d chars per GPU per step, inputs resident in HBM"
+                       % (("configs[1]" if (args.model_kind, args.sentences, args.min_len, args.max_len) == (1, 100000, 64, 64)
+                           else "configs[%d]-shaped" % {1: 1, 2: 3, 3: 4}[args.model_kind]), model_name, S, args.min_len, args.max_len),
                        "model": model_name, "sentences_per_gpu": S, "boundaries_per_gpu": nb, "text_bytes_per_gpu": nbytes,
                        "char_ngrams": info["n_char_ngrams"], "dict_words": info["n_dict_words"],
                        "table_bytes": info["device_table_bytes"], "hot_table_bytes": info["hot_table_bytes"],
