@@ -55,7 +55,8 @@ const char *vpt_version(void);
  * Errors      : VPT_INVALID_MODEL  "model version mismatch" | decode error | "failed to build the automaton"
  *               (empty pattern) | "invalid character type n-grams" (empty/duplicate type n-gram, cache
  *               variant, boundary_scorer_cache.rs:23-24) | "words must be shorter than or equal to 32767
- *               characters" | weight vector longer than its pattern allows (model contract);
+ *               characters" | weight vector longer than its pattern allows | a tag n-gram whose rel_position exceeds
+ *               the window (model contract);
  *               VPT_RUNTIME_ERROR when the device cannot be used.
  */
 vpt_status vpt_predictor_create(const uint8_t *model_bytes, size_t len, int predict_tags, int device_id,
@@ -125,6 +126,24 @@ vpt_status vpt_batch_sync(vpt_batch *b);
  * workgroups (tiles) of the last call. */
 vpt_status vpt_batch_set_timing(vpt_batch *b, int enabled);
 vpt_status vpt_batch_kernel_ms(vpt_batch *b, float *score_kernel_ms, uint32_t *n_tiles);
+
+/* ---------------------------------------------------------------------------------------------------------
+ * Sentence::fill_tags -> Predictor::predict_tags over a batch     (sentence.rs:1144-1148, predictor.rs:546-637)
+ *
+ * The predictor must have been created with predict_tags != 0 (the reference panics otherwise, predictor.rs:548-551:
+ * here VPT_INVALID_ARGUMENT "this predictor is created with predict_tags = false").
+ * n_tags  = the largest number of tag slots of any tag model (predictor.rs:466); 0 when the model has no tag models.
+ * labels  : CharacterBoundary per boundary, laid out like labels_out of vpt_predict_batch -- normally its output,
+ *           possibly edited by the caller's post-filters (as predict/src/main.rs:130-134 does between predict and
+ *           fill_tags); VPT_BOUNDARY_UNKNOWN is honoured (tokens touching it get no tags).
+ * tags_out: int32 [(total boundaries + n_sentences) * n_tags]: for char c (0-based) of sentence i, slot j:
+ *           tags_out[(out_offsets[i] + i + c) * n_tags + j] = index of the chosen candidate in the matching tag
+ *           model's j-th candidate list (model.rs:41-47), or -1 (None).  Only the LAST char of a token carries tags
+ *           (predictor.rs:595-598), like Sentence::tags(). */
+vpt_status vpt_predictor_n_tags(const vpt_predictor *p, uint32_t *n_tags);
+vpt_status vpt_fill_tags_batch(const vpt_predictor *p, const uint8_t *utf8, const uint64_t *byte_offsets,
+                               size_t n_sentences, const uint64_t *out_offsets, const uint8_t *labels,
+                               int32_t *tags_out);
 
 /* Diagnostics: when the environment variable VPT_PROFILE_PHASES is set at vpt_batch_create, the specialised
  * kernel accumulates, per workgroup (wave 0), the shader cycles spent in 0 text scan, 1 per-char decode,

@@ -452,3 +452,78 @@ def test_tag_enabled_model_with_duplicate_type_ngrams_runs_on_the_packed_path():
     assert info["packed"] == 1 and info["type_kind"] == 1
     mixed = randmodel.ALPHABETS["kana"][:10] + list("漢字AZ09、")
     check_batch(pred, orc, randmodel.rand_sentences(4, m, 1500, alphabet=mixed, max_len=60))
+
+
+# ------------------------------------------------------------------------------------------------ tags
+def _tag_strings(m, text, labels, tags, nt):
+    """tags[(char, slot)] candidate indices -> the reference's flat Option<str> list (Sentence::tags())."""
+    flat, start = [None] * (len(text) * nt), 0
+    for i, b in enumerate(list(labels) + [1]):
+        if b == 1:
+            tms = [t for t in m.tag_models if t.token == text[start:i + 1]]
+            if tms:
+                for j in range(min(nt, len(tms[-1].tags))):
+                    if tags[i, j] >= 0:
+                        flat[i * nt + j] = tms[-1].tags[j][tags[i, j]]
+            start = i + 1
+    return flat
+
+
+def test_predict_tags_like_reference():
+    """predictor.rs:861-903 through the C ABI: same scores, labels and the 16-slot tag array."""
+    m = kat.predictor_test_model()
+    text = "この人は地球人だ"
+    model, _ = api.Model.read_slice(encode_model(m))
+    pred = api.Predictor(model, True)
+    s = api.Sentence.from_raw(text)
+    pred.predict(s)
+    assert s.boundary_scores().tolist() == [-22, 54, 58, 43, -54, 68, 48]
+    s.fill_tags()
+    assert s.n_tags() == 2 and s.tags() == kat.PREDICT_TAGS_EXPECTED
+
+
+def test_fill_tags_requires_predict_tags_gpu():
+    model, _ = api.Model.read_slice(encode_model(kat.predictor_test_model()))
+    pred = api.Predictor(model, False)
+    s = api.Sentence.from_raw("この人は地球人だ")
+    pred.predict(s)
+    with pytest.raises(api.VaporettoError, match="predict_tags = false"):   # predictor.rs:974-983 (#[should_panic])
+        s.fill_tags()
+
+
+@pytest.mark.parametrize("fixture,text,expected", kat.FIXTURE_TAGGED)
+def test_fixture_tags_gpu(fixture, text, expected):
+    raw, m = kat.load_fixture(fixture)
+    pred = api.Predictor(api.Model.read_slice(raw)[0], True)
+    s = api.Sentence.from_raw(text)
+    pred.predict(s)
+    s.fill_tags()
+    assert s.write_tokenized_text() == expected   # lib.rs:25-41 / resources/docs.tok
+
+
+@pytest.mark.parametrize("seed", range(10))
+def test_random_tag_models_match_oracle(seed):
+    """Tag candidate indices for predicted AND caller-edited boundaries (incl. Unknown) equal the oracle's."""
+    m = randmodel.rand_model(800 + seed, alphabet="tiny" if seed % 2 else "kana", n_tag_models=25, max_word=4, n_char=40, n_dict=30)
+    raw = encode_model(m)
+    pred = api.Predictor(api.Model.read_slice(raw)[0], True)
+    orc = cbind.OraclePredictor(raw, True)
+    nt = pred.n_tags()
+    rng = np.random.RandomState(seed)
+    texts = randmodel.rand_sentences(seed, m, 150, alphabet="tiny" if seed % 2 else "kana", max_len=40)
+    texts += [t.token * 3 for t in m.tag_models[:10]] + [t.token for t in m.tag_models]
+    utf8, boff = api.pack_texts([t.encode("utf-8") for t in texts])
+    scores, labels, ooff = pred.predict_packed(utf8, boff)
+    for edit in (False, True):
+        lab = labels.copy()
+        if edit and len(lab):
+            k = rng.randint(0, len(lab), size=max(1, len(lab) // 7))
+            lab[k] = rng.randint(0, 3, size=len(k))          # NotWordBoundary / WordBoundary / Unknown
+        got = pred.fill_tags_packed(utf8, boff, ooff, lab)
+        assert got.shape == (int(ooff[-1]) + len(texts), nt)
+        for i, t in enumerate(texts):
+            a, b = int(ooff[i]), int(ooff[i + 1])
+            want, ont = orc.predict_tags(t, labels=lab[a:b])
+            assert ont == nt
+            g0 = a + i
+            assert np.array_equal(got[g0:g0 + len(t)], want), (t, lab[a:b].tolist())

@@ -37,6 +37,8 @@ SIGNATURES = {
     "vpt_count_boundaries": (C.c_int, [_P, _P, C.c_size_t, _P]),
     "vpt_predict_batch": (C.c_int, [_P, _P, _P, C.c_size_t, _P, _P, _P]),
     "vpt_predict_one": (C.c_int, [_P, _P, C.c_size_t, _P, _P, C.POINTER(C.c_size_t)]),
+    "vpt_predictor_n_tags": (C.c_int, [_P, C.POINTER(C.c_uint32)]),
+    "vpt_fill_tags_batch": (C.c_int, [_P, _P, _P, C.c_size_t, _P, _P, _P]),
     "vpt_batch_create": (C.c_int, [_P, C.POINTER(_P)]),
     "vpt_batch_destroy": (None, [_P]),
     "vpt_predict_batch_device": (C.c_int, [_P, _P, _P, _P, _P, C.c_size_t, C.c_uint64, C.c_uint64, _P, _P, _P]),

@@ -117,6 +117,9 @@ class Sentence:
         self._boundaries = np.zeros(0, dtype=np.uint8)
         self._scores = np.zeros(0, dtype=np.int32)
         self._has_scores = False
+        self._predictor = None
+        self._tags = []
+        self._n_tags = 0
 
     @staticmethod
     def default() -> "Sentence":
@@ -134,6 +137,9 @@ class Sentence:
         self._boundaries = np.full(len(cps) - 1, CharacterBoundary.Unknown, dtype=np.uint8)
         self._scores = np.zeros(0, dtype=np.int32)
         self._has_scores = False
+        self._predictor = None
+        self._tags = []
+        self._n_tags = 0
 
     @staticmethod
     def from_raw(text: str) -> "Sentence":  # sentence.rs:217-245
@@ -173,18 +179,50 @@ class Sentence:
             out.append(pos)
         return out
 
-    def iter_tokens(self) -> Iterable[str]:  # sentence.rs:819 (surfaces only)
-        start = 0
-        for i, b in enumerate(self._boundaries):
-            if b == CharacterBoundary.WordBoundary:
-                yield self._text[start:i + 1]
-                start = i + 1
-        yield self._text[start:]
+    def n_tags(self) -> int:  # sentence.rs:1161
+        return self._n_tags
 
-    def write_tokenized_text(self) -> str:  # sentence.rs:850-886, without tags
+    def tags(self) -> List[Optional[str]]:  # sentence.rs:1068: len() * n_tags entries, set on a token's LAST char
+        return self._tags
+
+    def fill_tags(self) -> None:
+        """sentence.rs:1144-1148: tags for the current boundaries, with the predictor that last predicted this
+        sentence (which must have been created with predict_tags = True, predictor.rs:548-551)."""
+        if self._predictor is None:
+            raise VaporettoError("InvalidArgument", "InvalidArgumentError: sentence: predict() has not been called")
+        self._predictor.fill_tags_batch([self])
+
+    def _token_ranges(self):
+        """(start, end) char ranges of the tokens; tokens adjacent to an Unknown boundary are skipped
+        (TokenIterator, sentence.rs:1265-1309)."""
+        n = len(self)
+        start, valid = 0, True
+        for e in range(n):
+            b = CharacterBoundary.WordBoundary if e == n - 1 else int(self._boundaries[e])
+            if b == CharacterBoundary.Unknown:
+                valid = False
+            elif b == CharacterBoundary.WordBoundary:
+                if valid:
+                    yield start, e
+                start, valid = e + 1, True
+
+    def iter_tokens(self) -> Iterable[str]:  # sentence.rs:819 (surfaces only)
+        for a, e in self._token_ranges():
+            yield self._text[a:e + 1]
+
+    def write_tokenized_text(self) -> str:  # sentence.rs:850-886
         def esc(tok):
             return "".join("\\" + c if c in " \\/" else c for c in tok)
-        return " ".join(esc(t) for t in self.iter_tokens())
+        out = []
+        for a, e in self._token_ranges():
+            parts = [esc(self._text[a:e + 1])]
+            if self._n_tags:
+                row = list(self._tags[e * self._n_tags:(e + 1) * self._n_tags])
+                while row and row[-1] is None:   # up to the last Some (sentence.rs:868)
+                    row.pop()
+                parts += [esc(t) if t is not None else "" for t in row]
+            out.append("/".join(parts))
+        return " ".join(out)
 
 
 class Predictor:
@@ -192,6 +230,9 @@ class Predictor:
 
     def __init__(self, model: Model, predict_tags: bool = False, device: int = 0):  # Predictor::new, predictor.rs:450
         raw = model.to_vec()
+        self._model = model
+        self._predict_tags = bool(predict_tags)
+        self._tag_models = None
         self._h = C.c_void_p()
         st = _lib.load().vpt_predictor_create(raw, len(raw), int(predict_tags), device, C.byref(self._h))
         if st != _lib.VPT_OK:
@@ -227,6 +268,7 @@ class Predictor:
         sentence._scores = scores[:nb.value]
         sentence._boundaries = labels[:nb.value]
         sentence._has_scores = True
+        sentence._predictor = self   # predictor.rs:542: enables a later fill_tags
 
     def predict_batch(self, sentences: Sequence[Sentence]) -> None:
         """Predictor::predict for many sentences in one launch."""
@@ -239,6 +281,70 @@ class Predictor:
             s._scores = scores[a:b]
             s._boundaries = labels[a:b]
             s._has_scores = True
+            s._predictor = self
+
+    def n_tags(self) -> int:
+        v = C.c_uint32()
+        st = _lib.load().vpt_predictor_n_tags(self._h, C.byref(v))
+        if st != _lib.VPT_OK:
+            _raise(st)
+        return v.value
+
+    def fill_tags_packed(self, utf8: np.ndarray, byte_offsets: np.ndarray, out_offsets: np.ndarray, labels: np.ndarray) -> np.ndarray:
+        """Predictor::predict_tags over a packed batch (predictor.rs:546-637).  labels: uint8 per boundary (0/1/2).
+        Returns int32 [total chars, n_tags]: candidate index per slot, -1 = None."""
+        L = _lib.load()
+        utf8 = np.ascontiguousarray(utf8, dtype=np.uint8)
+        byte_offsets = np.ascontiguousarray(byte_offsets, dtype=np.uint64)
+        out_offsets = np.ascontiguousarray(out_offsets, dtype=np.uint64)
+        labels = np.ascontiguousarray(labels, dtype=np.uint8)
+        S = len(byte_offsets) - 1
+        nt = self.n_tags() if self._predict_tags else 0
+        total_c = int(out_offsets[S]) + S
+        tags = np.full((total_c, max(nt, 1)), -1, dtype=np.int32)
+        lab = labels if len(labels) else np.zeros(1, dtype=np.uint8)
+        st = L.vpt_fill_tags_batch(self._h, utf8.ctypes.data, byte_offsets.ctypes.data, S, out_offsets.ctypes.data,
+                                   lab.ctypes.data, tags.ctypes.data)
+        if st != _lib.VPT_OK:
+            _raise(st)
+        return tags[:, :nt]
+
+    def fill_tags_batch(self, sentences: Sequence["Sentence"]) -> None:
+        """Sentence::fill_tags for many sentences in one launch; candidate indices are mapped to the tag strings of
+        the tag model whose token equals the token's surface (the LAST one of a repeated token, predictor.rs:466-478)."""
+        if not sentences:
+            return
+        utf8, boff = pack_texts([s._utf8 for s in sentences])
+        ooff = np.zeros(len(sentences) + 1, dtype=np.uint64)
+        ooff[1:] = np.cumsum([len(s) - 1 for s in sentences])
+        labels = np.concatenate([np.asarray(s._boundaries, dtype=np.uint8) for s in sentences]) if int(ooff[-1]) else np.zeros(0, np.uint8)
+        tags = self.fill_tags_packed(utf8, boff, ooff, labels)
+        nt = tags.shape[1]
+        if self._tag_models is None:
+            self._tag_models = {tm.token: tm for tm in self._model.tag_models()}
+        for i, s in enumerate(sentences):
+            g0 = int(ooff[i]) + i
+            n = len(s)
+            s._n_tags = nt
+            s._tags = [None] * (n * nt)
+            if nt == 0:
+                continue
+            start, valid = 0, True
+            for e in range(n):
+                b = CharacterBoundary.WordBoundary if e == n - 1 else int(s._boundaries[e])
+                if b == CharacterBoundary.Unknown:
+                    valid = False
+                    continue
+                if b != CharacterBoundary.WordBoundary:
+                    continue
+                if valid:
+                    tm = self._tag_models.get(s._text[start:e + 1])
+                    if tm is not None:
+                        for j in range(min(nt, len(tm.tags))):
+                            idx = int(tags[g0 + e, j])
+                            if idx >= 0:
+                                s._tags[e * nt + j] = tm.tags[j][idx]
+                start, valid = e + 1, True
 
     def predict_packed(self, utf8: np.ndarray, byte_offsets: np.ndarray):
         """utf8: uint8[total bytes]; byte_offsets: uint64[S+1].  Returns (scores, labels, out_offsets)."""

@@ -154,8 +154,22 @@ struct vpt_batch {
     int32_t* d_scores = nullptr; uint8_t* d_labels = nullptr; size_t out_cap = 0;
 };
 
+struct DeviceTags {
+    uint32_t *tok_tab = nullptr, *models = nullptr, *ngrams = nullptr, *syms = nullptr, *slots = nullptr;
+    int32_t* weights = nullptr;
+    void release() {
+        (void)hipFree(tok_tab); (void)hipFree(models); (void)hipFree(ngrams); (void)hipFree(syms); (void)hipFree(slots); (void)hipFree(weights);
+        tok_tab = models = ngrams = syms = slots = nullptr; weights = nullptr;
+    }
+};
+
 struct vpt_predictor {
     int device = 0;
+    bool predict_tags = false;
+    bool has_tags = false;
+    uint32_t n_tags = 0, tok_bits = 0;
+    bool tag_use_char = false, tag_use_type = false;
+    DeviceTags dtag;
     vpt_model_info info{};
     int32_t bias = 0; int pad = 1; int type_kind = 0; int type_window = 0; int chunks = 2;
     uint32_t tile_slots = 0;           // workgroups of the scoring kernel the device runs at a time (0 = unknown)
@@ -259,6 +273,17 @@ vpt_status vpt_predictor_create(const uint8_t* model_bytes, size_t len, int pred
     };
     up(c.chars, p->dc);
     up(c.types, p->dt);
+    p->predict_tags = predict_tags != 0;
+    if (c.tags.present) {
+        p->has_tags = true; p->n_tags = c.tags.n_tags; p->tok_bits = c.tags.tok_bits;
+        p->tag_use_char = c.tags.use_char; p->tag_use_type = c.tags.use_type;
+        if (e == hipSuccess) e = upload(c.tags.tok_tab, &p->dtag.tok_tab);
+        if (e == hipSuccess) e = upload(c.tags.models, &p->dtag.models);
+        if (e == hipSuccess) e = upload(c.tags.ngrams, &p->dtag.ngrams);
+        if (e == hipSuccess) e = upload(c.tags.syms, &p->dtag.syms);
+        if (e == hipSuccess) e = upload(c.tags.slots, &p->dtag.slots);
+        if (e == hipSuccess) e = upload(c.tags.weights, &p->dtag.weights);
+    }
     bool packed_ok = c.packed.present;
     if (c.packed.present && e == hipSuccess) e = upload_packed(c.packed, &p->dp, &packed_ok);
     if (e == hipSuccess && c.type_kind == vpt::kTypeWindowTable) e = upload(c.type_table, &p->d_type_table);
@@ -299,7 +324,7 @@ void vpt_predictor_destroy(vpt_predictor* p) {
     if (!p) return;
     (void)hipSetDevice(p->device);
     for (vpt_batch* b : p->pool) batch_release(b);
-    p->dc.release(); p->dt.release(); p->dp.release();
+    p->dc.release(); p->dt.release(); p->dp.release(); p->dtag.release();
     (void)hipFree(p->d_type_table);
     (void)hipFree(p->d_ctype);
     delete p;
@@ -557,6 +582,61 @@ vpt_status vpt_predict_batch(const vpt_predictor* p, const uint8_t* utf8, const 
         (e = hipMemcpyAsync(labels_out + out_offsets[0], b->d_labels, total_b, hipMemcpyDeviceToHost, s)) != hipSuccess) return hip_fail(e);
     st = vpt_batch_sync(b);
     return give_back(st);
+}
+
+vpt_status vpt_predictor_n_tags(const vpt_predictor* p, uint32_t* n_tags) {
+    if (!p || !n_tags) return fail(VPT_INVALID_ARGUMENT, "InvalidArgumentError: NULL argument");
+    *n_tags = p->n_tags;
+    return VPT_OK;
+}
+
+vpt_status vpt_fill_tags_batch(const vpt_predictor* p, const uint8_t* utf8, const uint64_t* byte_offsets, size_t n_sentences,
+                               const uint64_t* out_offsets, const uint8_t* labels, int32_t* tags_out) {
+    if (!p) return fail(VPT_INVALID_ARGUMENT, "InvalidArgumentError: predictor: must not be NULL");
+    if (!p->predict_tags) return fail(VPT_INVALID_ARGUMENT, "InvalidArgumentError: this predictor is created with predict_tags = false");
+    if (n_sentences == 0 || p->n_tags == 0) return VPT_OK;   // predictor.rs:553-555
+    if (!utf8 || !byte_offsets || !out_offsets || !tags_out) return fail(VPT_INVALID_ARGUMENT, "InvalidArgumentError: NULL argument");
+    const uint64_t t0 = byte_offsets[0], t1 = byte_offsets[n_sentences];
+    const uint64_t total_b = out_offsets[n_sentences] - out_offsets[0];
+    if (total_b && !labels) return fail(VPT_INVALID_ARGUMENT, "InvalidArgumentError: labels: must not be NULL");
+    const uint64_t total_c = total_b + n_sentences;
+    for (size_t i = 0; i < n_sentences; ++i)
+        if (byte_offsets[i + 1] <= byte_offsets[i])
+            return fail(VPT_INVALID_ARGUMENT, "InvalidArgumentError: text: must contain at least one character");
+    VPT_HIP(hipSetDevice(p->device));
+    struct Bufs {
+        uint8_t *text = nullptr, *labels = nullptr; uint64_t *boff = nullptr, *ooff = nullptr; uint32_t* cps = nullptr; int32_t* tags = nullptr;
+        hipStream_t s = nullptr;
+        ~Bufs() {
+            (void)hipFree(text); (void)hipFree(labels); (void)hipFree(boff); (void)hipFree(ooff); (void)hipFree(cps); (void)hipFree(tags);
+            if (s) (void)hipStreamDestroy(s);
+        }
+    } B;
+    std::vector<uint64_t> boff(n_sentences + 1), ooff(n_sentences + 1);
+    for (size_t i = 0; i <= n_sentences; ++i) { boff[i] = byte_offsets[i] - t0; ooff[i] = out_offsets[i] - out_offsets[0]; }
+    const size_t tag_bytes = size_t(total_c) * p->n_tags * sizeof(int32_t);
+    VPT_HIP(hipStreamCreateWithFlags(&B.s, hipStreamNonBlocking));
+    VPT_HIP(hipMalloc(reinterpret_cast<void**>(&B.text), size_t(t1 - t0) + 64));
+    VPT_HIP(hipMalloc(reinterpret_cast<void**>(&B.labels), size_t(total_b) + 64));
+    VPT_HIP(hipMalloc(reinterpret_cast<void**>(&B.boff), 8 * (n_sentences + 1)));
+    VPT_HIP(hipMalloc(reinterpret_cast<void**>(&B.ooff), 8 * (n_sentences + 1)));
+    VPT_HIP(hipMalloc(reinterpret_cast<void**>(&B.cps), 4 * size_t(total_c) + 64));
+    VPT_HIP(hipMalloc(reinterpret_cast<void**>(&B.tags), tag_bytes + 64));
+    VPT_HIP(hipMemcpyAsync(B.text, utf8 + t0, size_t(t1 - t0), hipMemcpyHostToDevice, B.s));
+    if (total_b) VPT_HIP(hipMemcpyAsync(B.labels, labels + out_offsets[0], size_t(total_b), hipMemcpyHostToDevice, B.s));
+    VPT_HIP(hipMemcpyAsync(B.boff, boff.data(), 8 * (n_sentences + 1), hipMemcpyHostToDevice, B.s));
+    VPT_HIP(hipMemcpyAsync(B.ooff, ooff.data(), 8 * (n_sentences + 1), hipMemcpyHostToDevice, B.s));
+    VPT_HIP(hipMemsetAsync(B.tags, 0xFF, tag_bytes, B.s));   // -1 = None
+    VPT_HIP(vpt::launch_decode_chars(B.text, B.boff, B.ooff, n_sentences, B.cps, B.s));
+    vpt::TagParams T{};
+    T.tok_tab = p->dtag.tok_tab; T.models = p->dtag.models; T.ngrams = p->dtag.ngrams; T.syms = p->dtag.syms; T.slots = p->dtag.slots;
+    T.weights = p->dtag.weights; T.ctype = p->d_ctype; T.tok_bits = p->tok_bits; T.n_tags = p->n_tags;
+    T.use_char = p->tag_use_char ? 1u : 0u; T.use_type = p->tag_use_type ? 1u : 0u;
+    T.cps = B.cps; T.ooff = B.ooff; T.labels = B.labels; T.n_sent = n_sentences; T.tags = B.tags;
+    VPT_HIP(vpt::launch_tag_tokens(T, B.s));
+    VPT_HIP(hipMemcpyAsync(tags_out + size_t(out_offsets[0] + 0) * p->n_tags, B.tags, tag_bytes, hipMemcpyDeviceToHost, B.s));
+    VPT_HIP(hipStreamSynchronize(B.s));
+    return VPT_OK;
 }
 
 vpt_status vpt_predict_one(const vpt_predictor* p, const uint8_t* utf8, size_t len, int32_t* scores, uint8_t* labels, size_t* n_boundaries) {

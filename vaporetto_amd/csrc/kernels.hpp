@@ -50,6 +50,22 @@ struct ScoreParams {
     uint64_t* prof;             // per-phase shader-cycle counters (VPT_PROFILE_PHASES env), else nullptr
 };
 
+// tag prediction (kernels_tags.hip); table layouts: HostTagTables in tables.hpp
+struct TagParams {
+    const uint32_t *tok_tab, *models, *ngrams, *syms, *slots;
+    const int32_t* weights;
+    const uint8_t* ctype;
+    uint32_t tok_bits, n_tags, use_char, use_type;
+    const uint32_t* cps;        // flat scalar values of the batch (decode_chars_kernel)
+    const uint64_t* ooff;       // [S+1]
+    const uint8_t* labels;      // [total boundaries] CharacterBoundary values (0, 1, 2 = Unknown)
+    uint64_t n_sent;
+    int32_t* tags;              // [(total boundaries + S) * n_tags] candidate index per slot, -1 = None
+};
+hipError_t launch_decode_chars(const uint8_t* text, const uint64_t* boff, const uint64_t* ooff, uint64_t n_sent, uint32_t* cps,
+                               hipStream_t stream);
+hipError_t launch_tag_tokens(const TagParams& P, hipStream_t stream);
+
 size_t score_tiles_lds_bytes();
 hipError_t launch_assign_tiles(const uint64_t* ooff, uint64_t n_sent, int pad, uint32_t tile_flat, uint32_t n_tiles,
                                uint32_t* tile_first, uint32_t* ctrl, hipStream_t stream);

@@ -1,0 +1,186 @@
+// Tag prediction on the device: Sentence::fill_tags -> Predictor::predict_tags (sentence.rs:1144-1148,
+// predictor.rs:546-637), all-matches form ("Tag scoring"):
+//
+//   for every token (maximal run between WordBoundary labels; tokens touching an Unknown label are skipped) whose
+//   surface is the token of a tag model M:   z = M.bias
+//     + w of every char tag n-gram (g, rel, w) of M with  text[p + rel + 1 - |g| .. p + rel + 1) == g   (p = last char)
+//     + w of every type tag n-gram likewise on the character types
+//   slot j with >= 2 candidates: argmax of its run of z, first maximum wins; 1 candidate: that one; 0: none.
+//
+// The reference reaches the same sums through the per-position longest-match pattern ids it records during predict
+// (char_scorer/boundary_tag_scorer.rs:62-174, type_scorer/boundary_tag_scorer.rs:51-143) with suffix-merged tag
+// weights; integer adds are order-free, so the sums are bit-identical.
+//
+// Two kernels, one wave per sentence each (a first, simple mapping: the tag path is not the measured hot path):
+//   decode_chars_kernel  UTF-8 -> scalar values, flat per batch (char g of sentence i at out_offsets[i] + i + g)
+//   tag_tokens_kernel    token walk over the labels, token lookup, z accumulation in LDS, argmax per slot
+#include <hip/hip_runtime.h>
+
+#include "device_common.h"
+#include "kernels.hpp"
+
+namespace vpt {
+namespace {
+
+constexpr int kTagThreads = 256;
+constexpr int kTagWaves = kTagThreads / 64;
+
+__device__ __forceinline__ uint32_t lanes_below(uint64_t mask, int lane) {
+    return uint32_t(__popcll(mask & ((uint64_t(1) << lane) - 1)));
+}
+
+__global__ __launch_bounds__(kTagThreads) void decode_chars_kernel(const uint8_t* __restrict__ text, const uint64_t* __restrict__ boff,
+                                                                   const uint64_t* __restrict__ ooff, uint64_t n_sent,
+                                                                   uint32_t* __restrict__ cps) {
+    const int lane = threadIdx.x & 63;
+    const uint64_t wave = uint64_t(blockIdx.x) * kTagWaves + (threadIdx.x >> 6);
+    const uint64_t n_waves = uint64_t(gridDim.x) * kTagWaves;
+    for (uint64_t i = wave; i < n_sent; i += n_waves) {
+        const uint64_t b0 = boff[i], b1 = boff[i + 1];
+        uint64_t g = ooff[i] + i;  // first char of the sentence in the flat char array
+        for (uint64_t pos = b0; pos < b1; pos += 64) {
+            const uint64_t at = pos + uint64_t(lane);
+            const bool in = at < b1;
+            const uint32_t byte0 = in ? text[at] : 0x80u;
+            const bool lead = in && (byte0 & 0xC0u) != 0x80u;
+            const uint64_t m = __ballot(lead);
+            if (lead) {
+                uint32_t b4 = byte0;
+                if (byte0 >= 0xC0u && at + 1 < b1) b4 |= uint32_t(text[at + 1]) << 8;
+                if (byte0 >= 0xE0u && at + 2 < b1) b4 |= uint32_t(text[at + 2]) << 16;
+                if (byte0 >= 0xF0u && at + 3 < b1) b4 |= uint32_t(text[at + 3]) << 24;
+                cps[g + lanes_below(m, lane)] = utf8_scalar(b4);
+            }
+            g += uint64_t(__popcll(m));
+        }
+    }
+}
+
+struct TagLds {
+    int32_t z[kTagWaves][1024];   // kTagMaxZ scores per token, one buffer per wave
+};
+
+__device__ __forceinline__ uint32_t type_of(const uint8_t* ctype, uint32_t cp) {
+    return cp < 0x10000u ? uint32_t(ctype[cp]) : char_type(cp);
+}
+
+__global__ __launch_bounds__(kTagThreads) void tag_tokens_kernel(const TagParams P) {
+    __shared__ TagLds L;
+    const int lane = threadIdx.x & 63;
+    volatile int32_t* z = L.z[threadIdx.x >> 6];
+    const uint64_t wave = uint64_t(blockIdx.x) * kTagWaves + (threadIdx.x >> 6);
+    const uint64_t n_waves = uint64_t(gridDim.x) * kTagWaves;
+    const uint32_t tok_mask = (1u << P.tok_bits) - 1u;
+    for (uint64_t si = wave; si < P.n_sent; si += n_waves) {
+        const uint64_t g0 = P.ooff[si] + si;                     // flat index of the sentence's first char
+        const int64_t n = int64_t(P.ooff[si + 1] - P.ooff[si]) + 1;  // chars
+        const uint32_t* cps = P.cps + g0;
+        const uint8_t* lab = P.labels + P.ooff[si];              // n - 1 labels
+        int64_t start = 0;
+        bool have_start = true;
+        for (int64_t base = 0; base < n; base += 64) {
+            const int64_t p = base + lane;
+            const uint32_t b = p < n ? (p == n - 1 ? 1u : uint32_t(lab[p])) : 0u;
+            uint64_t ends = __ballot(b == 1u), unk = __ballot(b == 2u);
+            uint64_t events = ends | unk;
+            while (events) {   // wave-uniform walk over the boundaries of this chunk, in order
+                const int k = __ffsll((long long)events) - 1;
+                events &= events - 1;
+                const int64_t e = base + k;
+                if ((unk >> k) & 1) { have_start = false; continue; }   // predictor.rs:566-567
+                const bool take = have_start;
+                const int64_t s0 = start;
+                start = e + 1;
+                have_start = true;
+                if (!take) continue;
+                // ---- token [s0, e]: look its surface up
+                const int64_t len = e - s0 + 1;
+                uint32_t h = 0x811C9DC5u;
+                for (int64_t j = 0; j < len; ++j) h = (h ^ cps[s0 + j]) * 0x01000193u;   // uniform: every lane the same
+                h ^= h >> 15;
+                h *= kHashMulLo;
+                uint32_t slot = h >> (32 - P.tok_bits);
+                uint32_t model = 0;   // index + 1
+                for (;;) {
+                    const uint32_t cur = P.tok_tab[slot];
+                    if (cur == 0) break;
+                    const uint32_t* mr = P.models + size_t(cur - 1) * 12;
+                    if (int64_t(mr[1]) == len) {
+                        bool same = true;
+                        for (int64_t j0 = 0; j0 < len; j0 += 64) {
+                            const int64_t j = j0 + lane;
+                            const bool ne = j < len && P.syms[mr[0] + j] != cps[s0 + j];
+                            if (__ballot(ne) != 0) { same = false; break; }
+                        }
+                        if (same) { model = cur; break; }
+                    }
+                    slot = (slot + 1) & tok_mask;
+                }
+                if (model == 0) continue;
+                const uint32_t* mr = P.models + size_t(model - 1) * 12;
+                const uint32_t zlen = mr[7];
+                for (uint32_t i = lane; i < zlen; i += 64) z[i] = P.weights[mr[6] + i];
+                // ---- tag n-grams that end rel chars past the token end (rel <= window was checked at load time)
+                for (int kind = 0; kind < 2; ++kind) {
+                    if (kind == 0 ? !P.use_char : !P.use_type) continue;
+                    const uint32_t first = mr[kind == 0 ? 2 : 4], count = mr[kind == 0 ? 3 : 5];
+                    for (uint32_t q = 0; q < count; ++q) {
+                        const uint32_t* nr = P.ngrams + size_t(first + q) * 4;
+                        const int64_t glen = int64_t(nr[1] & 0xFFFFFFu), rel = int64_t(nr[1] >> 24);
+                        const int64_t endp = e + rel + 1, beg = endp - glen;
+                        if (beg < 0 || endp > n) continue;
+                        bool same = true;
+                        for (int64_t j0 = 0; j0 < glen; j0 += 64) {
+                            const int64_t j = j0 + lane;
+                            bool ne = false;
+                            if (j < glen) {
+                                const uint32_t c = cps[beg + j];
+                                ne = P.syms[nr[0] + j] != (kind == 0 ? c : type_of(P.ctype, c));
+                            }
+                            if (__ballot(ne) != 0) { same = false; break; }
+                        }
+                        if (!same) continue;
+                        const uint32_t wl = nr[3] < zlen ? nr[3] : zlen;   // zip: the shorter of the two (predictor.rs:82-89)
+                        for (uint32_t i = lane; i < wl; i += 64) z[i] = int32_t(uint32_t(z[i]) + uint32_t(P.weights[nr[2] + i]));
+                    }
+                }
+                __builtin_amdgcn_wave_barrier();
+                // ---- argmax per slot (TagPredictor::predict, predictor.rs:286-304)
+                const uint32_t n_slots = mr[9] < P.n_tags ? mr[9] : P.n_tags;
+                for (uint32_t j = lane; j < n_slots; j += 64) {
+                    const uint32_t cnt = P.slots[size_t(mr[8] + j) * 2], off = P.slots[size_t(mr[8] + j) * 2 + 1];
+                    int32_t tag = cnt == 1 ? 0 : -1;
+                    if (cnt >= 2) {
+                        int32_t best = INT32_MIN;
+                        tag = 0;
+                        for (uint32_t c = 0; c < cnt && off + c < zlen; ++c) {
+                            const int32_t v = z[off + c];
+                            if (v > best) { best = v; tag = int32_t(c); }
+                        }
+                    }
+                    P.tags[(g0 + uint64_t(e)) * P.n_tags + j] = tag;
+                }
+                __builtin_amdgcn_wave_barrier();
+            }
+        }
+    }
+}
+
+}  // namespace
+
+hipError_t launch_decode_chars(const uint8_t* text, const uint64_t* boff, const uint64_t* ooff, uint64_t n_sent, uint32_t* cps,
+                               hipStream_t stream) {
+    const uint64_t want = (n_sent + kTagWaves - 1) / kTagWaves;
+    const uint32_t blocks = uint32_t(want < 1 ? 1 : want > 65536 ? 65536 : want);
+    hipLaunchKernelGGL(decode_chars_kernel, dim3(blocks), dim3(kTagThreads), 0, stream, text, boff, ooff, n_sent, cps);
+    return hipGetLastError();
+}
+
+hipError_t launch_tag_tokens(const TagParams& P, hipStream_t stream) {
+    const uint64_t want = (P.n_sent + kTagWaves - 1) / kTagWaves;
+    const uint32_t blocks = uint32_t(want < 1 ? 1 : want > 65536 ? 65536 : want);
+    hipLaunchKernelGGL(tag_tokens_kernel, dim3(blocks), dim3(kTagThreads), 0, stream, P);
+    return hipGetLastError();
+}
+
+}  // namespace vpt

@@ -578,6 +578,76 @@ std::vector<int32_t> build_type_window_table(const std::vector<NgramRecord>& ngr
 
 }  // namespace
 
+uint32_t tag_token_hash(const uint32_t* cps, size_t n) {
+    uint32_t h = 0x811C9DC5u;
+    for (size_t i = 0; i < n; ++i) h = (h ^ cps[i]) * 0x01000193u;
+    h ^= h >> 15;
+    return h * kHashMulLo;
+}
+
+namespace {
+HostTagTables build_tag_tables(const ModelData& m, bool use_char, bool use_type) {
+    HostTagTables t;
+    t.present = true;
+    t.use_char = use_char; t.use_type = use_type;
+    t.n_models = uint32_t(m.tag_models.size());
+    t.tok_bits = bits_for(m.tag_models.size());
+    t.tok_tab.assign(size_t(1) << t.tok_bits, 0);
+    const uint32_t mask = (1u << t.tok_bits) - 1;
+    for (uint32_t mi = 0; mi < m.tag_models.size(); ++mi) {
+        const TagModelRecord& tm = m.tag_models[mi];
+        t.n_tags = std::max<uint32_t>(t.n_tags, uint32_t(tm.tags.size()));   // predictor.rs:466
+        uint32_t rec[12] = {0};
+        rec[0] = uint32_t(t.syms.size()); rec[1] = uint32_t(tm.token.size());
+        t.syms.insert(t.syms.end(), tm.token.begin(), tm.token.end());
+        auto add_ngrams = [&](const std::vector<TagNgramRecord>& list, uint32_t* first, uint32_t* count) {
+            *first = uint32_t(t.ngrams.size() / 4);
+            for (const TagNgramRecord& d : list) {
+                const uint32_t so = uint32_t(t.syms.size());
+                t.syms.insert(t.syms.end(), d.ngram.begin(), d.ngram.end());
+                for (const TagWeightRecord& w : d.weights) {
+                    if (d.ngram.size() >= (size_t(1) << 24)) throw ModelError("InvalidModelError: tag n-gram too long");
+                    t.ngrams.push_back(so);
+                    t.ngrams.push_back(uint32_t(d.ngram.size()) | (uint32_t(w.rel_position) << 24));
+                    t.ngrams.push_back(uint32_t(t.weights.size()));
+                    t.ngrams.push_back(uint32_t(w.weights.size()));
+                    t.weights.insert(t.weights.end(), w.weights.begin(), w.weights.end());
+                }
+            }
+            *count = uint32_t(t.ngrams.size() / 4) - *first;
+        };
+        add_ngrams(tm.char_ngrams, &rec[2], &rec[3]);
+        add_ngrams(tm.type_ngrams, &rec[4], &rec[5]);
+        rec[6] = uint32_t(t.weights.size()); rec[7] = uint32_t(tm.bias.size());
+        t.weights.insert(t.weights.end(), tm.bias.begin(), tm.bias.end());
+        if (tm.bias.size() > kTagMaxZ) throw ModelError("InvalidModelError: more than 1024 tag scores per token are not supported");
+        t.max_zlen = std::max<uint32_t>(t.max_zlen, uint32_t(tm.bias.size()));
+        rec[8] = uint32_t(t.slots.size() / 2); rec[9] = uint32_t(tm.tags.size());
+        uint32_t off = 0;
+        for (const auto& cands : tm.tags) {   // TagPredictor::predict, predictor.rs:286-304
+            t.slots.push_back(uint32_t(cands.size()));
+            t.slots.push_back(off);
+            if (cands.size() >= 2) off += uint32_t(cands.size());
+        }
+        t.models.insert(t.models.end(), rec, rec + 12);
+        // token table: a repeated token keeps its slot and takes the later model
+        uint32_t b = tag_token_hash(tm.token.data(), tm.token.size()) >> (32 - t.tok_bits);
+        for (;;) {
+            const uint32_t cur = t.tok_tab[b];
+            if (cur == 0) { t.tok_tab[b] = mi + 1; break; }
+            const uint32_t* cr = &t.models[size_t(cur - 1) * 12];
+            if (cr[1] == tm.token.size() && std::equal(tm.token.begin(), tm.token.end(), t.syms.begin() + cr[0])) { t.tok_tab[b] = mi + 1; break; }
+            b = (b + 1) & mask;
+        }
+    }
+    if (t.syms.empty()) t.syms.push_back(0);
+    if (t.weights.empty()) t.weights.push_back(0);
+    if (t.ngrams.empty()) t.ngrams.assign(4, 0);
+    if (t.slots.empty()) t.slots.assign(2, 0);
+    return t;
+}
+}  // namespace
+
 uint8_t char_type_host(uint32_t c) {
     auto in = [c](uint32_t lo, uint32_t hi) { return c >= lo && c <= hi; };
     if (in(0x30, 0x39) || in(0xFF10, 0xFF19)) return 1;
@@ -672,6 +742,7 @@ CompiledModel compile_model(const ModelData& m, bool predict_tags) {
         }
     }
     c.pad = std::max(1, std::max(c.chars.present ? wc : 0, c.type_kind != kTypeNone ? wt : 0));
+    if (tags_on) c.tags = build_tag_tables(m, c.chars.present, c.type_kind != kTypeNone);
     return c;
 }
 

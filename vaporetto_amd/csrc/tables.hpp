@@ -44,6 +44,22 @@ struct HostPackedTable {
     uint64_t bytes() const { return 4ull * (uni.size() + rec.size() + kids3.size() + deep.size() + xrows.size() + trow.size()) + seed.size(); }
 };
 
+// Tag prediction tables (Predictor::predict_tags, predictor.rs:546-637), see kernels_tags.hip.
+//   tok_tab   open addressing over token surfaces: slot = model index + 1 (0 = empty); the LAST model of a repeated
+//             token wins, like HashMap::insert in predictor.rs:466-478
+//   models    12 dwords per tag model: sym_off, sym_len, char-ngram first/count, type-ngram first/count, bias_off, zlen,
+//             slot first/count, 0, 0
+//   ngrams    4 dwords per (tag n-gram, rel_position): sym_off, len | rel << 24, w_off, wlen
+//   slots     2 dwords per tag slot: candidate count, offset of its scores in z (slots with >= 2 candidates)
+struct HostTagTables {
+    bool present = false;
+    uint32_t n_tags = 0, n_models = 0, tok_bits = 4, max_zlen = 0;
+    bool use_char = false, use_type = false;   // the scorers exist (char_scorer.rs:98-100, type_scorer.rs:109-111)
+    std::vector<uint32_t> tok_tab, models, ngrams, syms, slots;
+    std::vector<int32_t> weights;
+};
+constexpr uint32_t kTagMaxZ = 1024;   // tag scores per token the kernel keeps in LDS
+
 enum TypeKind : int { kTypeNone = 0, kTypeWindowTable = 1, kTypePatternTable = 2 };
 
 struct CompiledModel {
@@ -58,7 +74,11 @@ struct CompiledModel {
     // counts for vpt_model_info
     uint32_t n_char_ngrams = 0, n_type_ngrams = 0, n_dict_words = 0, n_tag_models = 0;
     bool predict_tags = false;
+    HostTagTables tags;                // only with predict_tags and tag models
 };
+
+// hash of a token surface (code points) for HostTagTables::tok_tab; the kernel computes the same
+uint32_t tag_token_hash(const uint32_t* cps, size_t n);
 
 // CharacterType::get_type (sentence.rs:50-67) on the host; used to build the device's BMP class table.
 uint8_t char_type_host(uint32_t c);
