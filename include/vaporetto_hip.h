@@ -50,7 +50,7 @@ const char *vpt_version(void);
  * model_bytes : an un-compressed model file: "VaporettoTokenizer 0.5.0\n" + bincode (zstd is outside the
  *               API in the reference too, README.md:50-63).  The bytes are copied; the caller may free them.
  * predict_tags: as Predictor::new's flag.  Tag models are parsed and validated; boundary scores are
- *               identical either way (tag scoring itself is vpt_fill_tags_*, see DESIGN.md "next").
+ *               identical either way; tag scoring itself is vpt_fill_tags_batch below.
  * device_id   : HIP device ordinal.
  * Errors      : VPT_INVALID_MODEL  "model version mismatch" | decode error | "failed to build the automaton"
  *               (empty pattern) | "invalid character type n-grams" (empty/duplicate type n-gram, cache
