@@ -491,6 +491,7 @@ __global__ __launch_bounds__(kThreads, 5) void score_tiles_fast_kernel(const Sco
 #pragma unroll
     for (int k = 0; k < kPerThread; ++k) {
         const uint32_t ci = uint32_t(tid) + uint32_t(k) * kThreads;
+        if (ci - uint32_t(lane) >= nchars) { cps[k] = 0; meta[k] = 0xFFFFFFFFu; continue; }  // wave-uniform: no chars left for this wave
         const bool ok = ci < nchars && ci < uint32_t(kFastCap);
         const uint32_t info = L.sym[ok ? ci : 0u];
         const uint32_t ninfo = L.sym[ok ? ci + 1 : 0u];
