@@ -39,6 +39,11 @@ def load_model_bytes(kind: int, scale: float):
             env = dict(os.environ, LD_LIBRARY_PATH="/opt/conda/lib:" + os.environ.get("LD_LIBRARY_PATH", ""))
             raw = subprocess.check_output(["/opt/conda/bin/zstd", "-d", "-c", path], env=env)
             return raw, name
+        path = os.path.join(d, name + ".mod")   # a KyTea model (jp-0.4.7-5.mod): converted like convert_kytea_model does
+        if os.path.exists(path):
+            from vaporetto_amd import kytea
+            with open(path, "rb") as fh:
+                return kytea.convert(fh.read()), name
     return synth.synth_model(kind, synth.SEED_BASE + 2, scale), "synthetic-" + {1: "M1", 2: "M2", 3: "M3"}[kind]
 
 

@@ -1,5 +1,7 @@
 """GPU parity tests (run with -m gpu on an MI355X): the HIP path, called through the C ABI, must reproduce
 bit-exactly (i32 scores, u8 labels) the reference's known-answer vectors and the CPU oracle."""
+import os
+
 import numpy as np
 import pytest
 
@@ -527,3 +529,14 @@ def test_random_tag_models_match_oracle(seed):
             assert ont == nt
             g0 = a + i
             assert np.array_equal(got[g0:g0 + len(t)], want), (t, lab[a:b].tolist())
+
+
+def test_converted_kytea_fixture_on_gpu():
+    """resources/kytea-model.bin converted by vaporetto_amd/kytea.py (kytea_model.rs:401-422): same tokens on the GPU."""
+    from vaporetto_amd import kytea
+    raw = kytea.convert(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "kytea-model.bin"), "rb").read())
+    pred, orc = make_predictor(raw)
+    s = api.Sentence.from_raw("まぁ社長は火星猫だ")
+    pred.predict(s)
+    assert s.write_tokenized_text() == "まぁ 社長 は 火星 猫 だ"
+    check_batch(pred, orc, ["まぁ社長は火星猫だ", "まぁ良いだろう", "火星猫"] * 20)
