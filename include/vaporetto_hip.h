@@ -35,6 +35,13 @@ typedef enum vpt_status {
 /* CharacterBoundary discriminants written to `labels` (sentence.rs:70-82) */
 enum { VPT_NOT_WORD_BOUNDARY = 0, VPT_WORD_BOUNDARY = 1, VPT_BOUNDARY_UNKNOWN = 2 };
 
+/* Flags of the *_flags entry points and of vpt_batch_set_flags.
+ * VPT_FLAG_KYTEA_FULLWIDTH: score the text as KyteaFullwidthFilter would rewrite it
+ *   (vaporetto_rules/src/string_filters/kytea_fullwidth.rs:13-117: a 1:1 char map, so boundaries keep their places);
+ *   this is what the reference's CLI does before update_raw unless --no-norm is given (predict/src/main.rs:126-129),
+ *   folded into the kernel's char classification table at no extra cost. */
+enum { VPT_FLAG_KYTEA_FULLWIDTH = 1 };
+
 typedef struct vpt_predictor vpt_predictor;
 typedef struct vpt_batch vpt_batch;
 
@@ -86,6 +93,11 @@ vpt_status vpt_predict_batch(const vpt_predictor *p, const uint8_t *utf8, const 
                              size_t n_sentences, int32_t *scores_out, uint8_t *labels_out,
                              const uint64_t *out_offsets);
 
+/* The same with VPT_FLAG_* (0 = exactly vpt_predict_batch). */
+vpt_status vpt_predict_batch_flags(const vpt_predictor *p, const uint8_t *utf8, const uint64_t *byte_offsets,
+                                   size_t n_sentences, int32_t *scores_out, uint8_t *labels_out,
+                                   const uint64_t *out_offsets, unsigned flags);
+
 /* Sentence::from_raw + Predictor::predict for one sentence (same path, batch of one).
  * scores/labels need room for chars-1 entries (<= len-1). */
 vpt_status vpt_predict_one(const vpt_predictor *p, const uint8_t *utf8, size_t len, int32_t *scores,
@@ -117,6 +129,9 @@ vpt_status vpt_predict_batch_device(const vpt_predictor *p, vpt_batch *b, const 
  * understated max_sentence_bytes. */
 vpt_status vpt_batch_set_max_sentence_chars(vpt_batch *b, uint64_t max_sentence_chars);
 
+/* VPT_FLAG_* for the following vpt_predict_batch_device calls on this workspace (default 0). */
+vpt_status vpt_batch_set_flags(vpt_batch *b, unsigned flags);
+
 /* Waits for the batch's last enqueued work and returns its device-side verdict. */
 vpt_status vpt_batch_sync(vpt_batch *b);
 
@@ -144,6 +159,11 @@ vpt_status vpt_predictor_n_tags(const vpt_predictor *p, uint32_t *n_tags);
 vpt_status vpt_fill_tags_batch(const vpt_predictor *p, const uint8_t *utf8, const uint64_t *byte_offsets,
                                size_t n_sentences, const uint64_t *out_offsets, const uint8_t *labels,
                                int32_t *tags_out);
+/* The same with VPT_FLAG_*: with VPT_FLAG_KYTEA_FULLWIDTH tokens and tag n-grams are matched on the normalised text,
+ * as the CLI fills tags on the normalised sentence (predict/src/main.rs:156-170). */
+vpt_status vpt_fill_tags_batch_flags(const vpt_predictor *p, const uint8_t *utf8, const uint64_t *byte_offsets,
+                                     size_t n_sentences, const uint64_t *out_offsets, const uint8_t *labels,
+                                     int32_t *tags_out, unsigned flags);
 
 /* Diagnostics: when the environment variable VPT_PROFILE_PHASES is set at vpt_batch_create, the specialised
  * kernel accumulates, per workgroup (wave 0), the shader cycles spent in 0 text scan, 1 per-char decode,

@@ -68,6 +68,7 @@ int tc_create_tags(const uint8_t* bytes, size_t len, int predict_tags, tc_model*
     }
 }
 void tc_destroy(tc_model* t) { delete t; }
+uint32_t tc_fullwidth(uint32_t c) { return kytea_fullwidth_host(c); }
 int tc_packed_present(const tc_model* t) { return t->c.packed.present ? 1 : 0; }
 int tc_trow_present(const tc_model* t) { return t->c.packed.present && !t->c.packed.trow.empty() ? 1 : 0; }
 void tc_stats(const tc_model* t, uint32_t out[8]) {

@@ -540,3 +540,35 @@ def test_converted_kytea_fixture_on_gpu():
     pred.predict(s)
     assert s.write_tokenized_text() == "まぁ 社長 は 火星 猫 だ"
     check_batch(pred, orc, ["まぁ社長は火星猫だ", "まぁ良いだろう", "火星猫"] * 20)
+
+
+def test_fullwidth_filter_on_device():
+    """VPT_FLAG_KYTEA_FULLWIDTH scores the text as KyteaFullwidthFilter rewrites it.  Pinned by the tantivy adapter's
+    test (vaporetto_tantivy/src/lib.rs:298-364): "123456円" + emoji with the filter splits into single chars; and
+    checked against the oracle on the host-filtered text for both kernels, boundary scores and tags."""
+    raw, _ = kat.load_fixture("tantivy_model.bin")
+    pred, orc = make_predictor(raw)
+    utf8, boff = api.pack_texts(["123456円🤌🏿".encode("utf-8")])
+    scores, labels, _ = pred.predict_packed(utf8, boff, fullwidth=True)
+    assert scores.tolist() == [36480, 36480, 40155, 40155, 40155, 40155, 36442, 36442] and labels.tolist() == [1] * 8
+    f = api.KyteaFullwidthFilter()
+    for model_seed, alphabet in ((3, "mixed"), (4, "kana")):
+        extra = list("abcXYZ019-.,!?()[]/_+:&*@=%<>{}\"'") + ["｢", "｣", "～", "－", "､", "―", "･", "─", "–", "｡"]
+        alpha = (randmodel.ALPHABETS[alphabet] if alphabet == "mixed" else randmodel.ALPHABETS["kana"][:12]) + extra + [f.filter(c) for c in extra]
+        m = randmodel.rand_model(600 + model_seed, alphabet=alpha, wc=3, wt=3, n_char=300, n_dict=300, n_type=60, max_word=6, n_tag_models=12)
+        rawm = encode_model(m)
+        texts = randmodel.rand_sentences(model_seed, m, 800, alphabet=alpha, max_len=50)
+        utf8, boff = api.pack_texts([t.encode("utf-8") for t in texts])
+        n_utf8, n_boff = api.pack_texts([f.filter(t).encode("utf-8") for t in texts])
+        for predict_tags in (False, True):
+            p = api.Predictor(api.Model.read_slice(rawm)[0], predict_tags)
+            o = cbind.OraclePredictor(rawm, predict_tags)
+            scores, labels, ooff = p.predict_packed(utf8, boff, fullwidth=True)
+            o_scores, o_labels, o_ooff, _ = o.predict_batch(n_utf8, n_boff)
+            assert np.array_equal(ooff, o_ooff) and np.array_equal(scores, o_scores) and np.array_equal(labels, o_labels)
+            if predict_tags:
+                got = p.fill_tags_packed(utf8, boff, ooff, labels, fullwidth=True)
+                for i, t in enumerate(texts[:200]):
+                    a, b = int(ooff[i]), int(ooff[i + 1])
+                    want, _ = o.predict_tags(f.filter(t), labels=labels[a:b])
+                    assert np.array_equal(got[a + i:a + i + len(t)], want), t

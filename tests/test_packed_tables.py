@@ -242,3 +242,13 @@ def test_tag_enabled_models_merge_duplicate_type_ngrams(tc):
     mixed = randmodel.ALPHABETS["kana"][:10] + list("漢字AZ09、")
     for t in randmodel.rand_sentences(4, m, 300, alphabet=mixed, max_len=40):
         assert w.score(t, want=2) == orc.predict(t)[0], t
+
+
+def test_cpp_fullwidth_map_equals_reference_pairs(tc):
+    import ctypes as C
+    tc.tc_fullwidth.argtypes = [C.c_uint32]
+    tc.tc_fullwidth.restype = C.c_uint32
+    golden = {int(a, 16): int(b, 16) for a, b in
+              (line.split() for line in open(os.path.join(HERE, "golden", "kytea_fullwidth_pairs.txt"), encoding="utf-8"))}
+    for cp in range(0x10000):
+        assert tc.tc_fullwidth(cp) == golden.get(cp, cp), hex(cp)

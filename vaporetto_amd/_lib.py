@@ -12,6 +12,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "lib", "libvaporetto_hip.so")
 
 VPT_OK, VPT_INVALID_MODEL, VPT_INVALID_ARGUMENT, VPT_RUNTIME_ERROR = 0, 1, 2, 3
+VPT_FLAG_KYTEA_FULLWIDTH = 1
 
 
 class ModelInfo(C.Structure):
@@ -36,9 +37,12 @@ SIGNATURES = {
     "vpt_predictor_destroy": (None, [_P]),
     "vpt_count_boundaries": (C.c_int, [_P, _P, C.c_size_t, _P]),
     "vpt_predict_batch": (C.c_int, [_P, _P, _P, C.c_size_t, _P, _P, _P]),
+    "vpt_predict_batch_flags": (C.c_int, [_P, _P, _P, C.c_size_t, _P, _P, _P, C.c_uint]),
     "vpt_predict_one": (C.c_int, [_P, _P, C.c_size_t, _P, _P, C.POINTER(C.c_size_t)]),
     "vpt_predictor_n_tags": (C.c_int, [_P, C.POINTER(C.c_uint32)]),
     "vpt_fill_tags_batch": (C.c_int, [_P, _P, _P, C.c_size_t, _P, _P, _P]),
+    "vpt_fill_tags_batch_flags": (C.c_int, [_P, _P, _P, C.c_size_t, _P, _P, _P, C.c_uint]),
+    "vpt_batch_set_flags": (C.c_int, [_P, C.c_uint]),
     "vpt_batch_create": (C.c_int, [_P, C.POINTER(_P)]),
     "vpt_batch_destroy": (None, [_P]),
     "vpt_predict_batch_device": (C.c_int, [_P, _P, _P, _P, _P, C.c_size_t, C.c_uint64, C.c_uint64, _P, _P, _P]),

@@ -65,6 +65,34 @@ def _types_of(cps: np.ndarray) -> np.ndarray:
     return out
 
 
+class KyteaFullwidthFilter:
+    """vaporetto_rules/src/string_filters/kytea_fullwidth.rs:13-117 (host-side statement of the map the kernels apply
+    when `fullwidth=True` is passed; useful to build the normalised text that tokens are NOT taken from)."""
+
+    _PAIRS = None
+
+    @classmethod
+    def table(cls) -> dict:
+        if cls._PAIRS is None:
+            t = {}
+            for i in range(26):
+                t[ord("a") + i] = 0xFF41 + i
+                t[ord("A") + i] = 0xFF21 + i
+            for i in range(10):
+                t[ord("0") + i] = 0xFF10 + i
+            t.update({ord("("): 0xFF08, ord(")"): 0xFF09, ord("{"): 0xFF5B, ord("}"): 0xFF5D, ord("<"): 0xFF1C, ord(">"): 0xFF1E,
+                      0xFF62: 0x300C, 0xFF63: 0x300D, ord("["): 0xFF3B, ord("]"): 0xFF3D, ord("-"): 0x2212, 0xFF5E: 0x301C,
+                      ord("."): 0x3002, 0xFF0D: 0x30FC, ord("/"): 0xFF0F, ord("_"): 0xFF3F, ord(","): 0xFF0C, ord("%"): 0xFF05,
+                      ord("?"): 0xFF1F, 0xFF64: 0x3001, 0x2015: 0x30FC, ord('"'): 0x201D, ord("'"): 0x2019, 0xFF65: 0x30FB,
+                      0x2500: 0x30FC, ord("+"): 0xFF0B, ord(":"): 0xFF1A, 0x2013: 0x30FC, ord("!"): 0xFF01, 0xFF61: 0x3002,
+                      ord("&"): 0xFF06, ord("*"): 0xFF0A, ord("@"): 0xFF20, ord("="): 0xFF1D})
+            cls._PAIRS = t
+        return cls._PAIRS
+
+    def filter(self, string: str) -> str:
+        return string.translate(self.table())
+
+
 class Model:
     """model.rs:55-169."""
 
@@ -270,12 +298,12 @@ class Predictor:
         sentence._has_scores = True
         sentence._predictor = self   # predictor.rs:542: enables a later fill_tags
 
-    def predict_batch(self, sentences: Sequence[Sentence]) -> None:
+    def predict_batch(self, sentences: Sequence[Sentence], fullwidth: bool = False) -> None:
         """Predictor::predict for many sentences in one launch."""
         if not sentences:
             return
         utf8, boff = pack_texts([s._utf8 for s in sentences])
-        scores, labels, ooff = self.predict_packed(utf8, boff)
+        scores, labels, ooff = self.predict_packed(utf8, boff, fullwidth=fullwidth)
         for i, s in enumerate(sentences):
             a, b = int(ooff[i]), int(ooff[i + 1])
             s._scores = scores[a:b]
@@ -290,7 +318,8 @@ class Predictor:
             _raise(st)
         return v.value
 
-    def fill_tags_packed(self, utf8: np.ndarray, byte_offsets: np.ndarray, out_offsets: np.ndarray, labels: np.ndarray) -> np.ndarray:
+    def fill_tags_packed(self, utf8: np.ndarray, byte_offsets: np.ndarray, out_offsets: np.ndarray, labels: np.ndarray,
+                         fullwidth: bool = False) -> np.ndarray:
         """Predictor::predict_tags over a packed batch (predictor.rs:546-637).  labels: uint8 per boundary (0/1/2).
         Returns int32 [total chars, n_tags]: candidate index per slot, -1 = None."""
         L = _lib.load()
@@ -303,8 +332,8 @@ class Predictor:
         total_c = int(out_offsets[S]) + S
         tags = np.full((total_c, max(nt, 1)), -1, dtype=np.int32)
         lab = labels if len(labels) else np.zeros(1, dtype=np.uint8)
-        st = L.vpt_fill_tags_batch(self._h, utf8.ctypes.data, byte_offsets.ctypes.data, S, out_offsets.ctypes.data,
-                                   lab.ctypes.data, tags.ctypes.data)
+        st = L.vpt_fill_tags_batch_flags(self._h, utf8.ctypes.data, byte_offsets.ctypes.data, S, out_offsets.ctypes.data,
+                                         lab.ctypes.data, tags.ctypes.data, _lib.VPT_FLAG_KYTEA_FULLWIDTH if fullwidth else 0)
         if st != _lib.VPT_OK:
             _raise(st)
         return tags[:, :nt]
@@ -346,8 +375,9 @@ class Predictor:
                                 s._tags[e * nt + j] = tm.tags[j][idx]
                 start, valid = e + 1, True
 
-    def predict_packed(self, utf8: np.ndarray, byte_offsets: np.ndarray):
-        """utf8: uint8[total bytes]; byte_offsets: uint64[S+1].  Returns (scores, labels, out_offsets)."""
+    def predict_packed(self, utf8: np.ndarray, byte_offsets: np.ndarray, fullwidth: bool = False):
+        """utf8: uint8[total bytes]; byte_offsets: uint64[S+1].  Returns (scores, labels, out_offsets).
+        fullwidth: score the text as KyteaFullwidthFilter would rewrite it (the CLI's default normalisation)."""
         L = _lib.load()
         utf8 = np.ascontiguousarray(utf8, dtype=np.uint8)
         byte_offsets = np.ascontiguousarray(byte_offsets, dtype=np.uint64)
@@ -359,8 +389,8 @@ class Predictor:
         nb = int(ooff[S])
         scores = np.zeros(max(nb, 1), dtype=np.int32)
         labels = np.zeros(max(nb, 1), dtype=np.uint8)
-        st = L.vpt_predict_batch(self._h, utf8.ctypes.data, byte_offsets.ctypes.data, S, scores.ctypes.data,
-                                 labels.ctypes.data, ooff.ctypes.data)
+        st = L.vpt_predict_batch_flags(self._h, utf8.ctypes.data, byte_offsets.ctypes.data, S, scores.ctypes.data,
+                                       labels.ctypes.data, ooff.ctypes.data, _lib.VPT_FLAG_KYTEA_FULLWIDTH if fullwidth else 0)
         if st != _lib.VPT_OK:
             _raise(st)
         return scores[:nb], labels[:nb], ooff
@@ -392,6 +422,12 @@ class DeviceBatch:
         """All pointers are raw device addresses (e.g. torch.Tensor.data_ptr()); enqueues and returns."""
         st = _lib.load().vpt_predict_batch_device(self._p.handle, self._h, d_utf8, d_boff, d_ooff, n_sentences,
                                                   total_boundaries, max_sentence_bytes, d_scores, d_labels, stream)
+        if st != _lib.VPT_OK:
+            _raise(st)
+
+    def set_fullwidth(self, enabled: bool) -> None:
+        """Score the text as KyteaFullwidthFilter would rewrite it (vpt_batch_set_flags)."""
+        st = _lib.load().vpt_batch_set_flags(self._h, _lib.VPT_FLAG_KYTEA_FULLWIDTH if enabled else 0)
         if st != _lib.VPT_OK:
             _raise(st)
 

@@ -141,6 +141,7 @@ struct vpt_batch {
     uint64_t* d_prof = nullptr;        // 8 per-phase cycle counters (only with VPT_PROFILE_PHASES set)
     unsigned char* d_scratch = nullptr; size_t scratch_bytes = 0;
     uint64_t max_chars = 0;            // caller's bound on chars per sentence (0 = unknown)
+    unsigned flags = 0;                // VPT_FLAG_*
     // timing
     bool timing = false;
     std::vector<hipEvent_t> ev;        // ring of (start, stop) pairs around the scoring kernel
@@ -177,7 +178,7 @@ struct vpt_predictor {
     DevicePacked dp;
     vpt::PackedView pk{};
     int32_t* d_type_table = nullptr;
-    uint8_t* d_ctype = nullptr;
+    uint32_t* d_cinfo = nullptr;       // [0, 65536): plain; [65536, 131072): through KyteaFullwidthFilter
     vpt::PatternTableView ct{}, tt{};
     mutable std::mutex pool_mu;
     mutable std::vector<vpt_batch*> pool;  // idle workspaces for the host-buffer entry points
@@ -288,9 +289,13 @@ vpt_status vpt_predictor_create(const uint8_t* model_bytes, size_t len, int pred
     if (c.packed.present && e == hipSuccess) e = upload_packed(c.packed, &p->dp, &packed_ok);
     if (e == hipSuccess && c.type_kind == vpt::kTypeWindowTable) e = upload(c.type_table, &p->d_type_table);
     if (e == hipSuccess) {
-        std::vector<uint8_t> ctype(65536);
-        for (uint32_t cp = 0; cp < 65536; ++cp) ctype[cp] = vpt::char_type_host(cp);
-        e = upload(ctype, &p->d_ctype);
+        std::vector<uint32_t> cinfo(2 * 65536);   // the char a BMP char is scored as | its CharacterType << 16
+        for (uint32_t cp = 0; cp < 65536; ++cp) {
+            cinfo[cp] = cp | (uint32_t(vpt::char_type_host(cp)) << 16);
+            const uint32_t fw = vpt::kytea_fullwidth_host(cp);
+            cinfo[65536 + cp] = fw | (uint32_t(vpt::char_type_host(fw)) << 16);
+        }
+        e = upload(cinfo, &p->d_cinfo);
     }
     if (e != hipSuccess) {
         std::string msg = std::string("HIP error while uploading the tables: ") + hipGetErrorString(e);
@@ -309,7 +314,7 @@ vpt_status vpt_predictor_create(const uint8_t* model_bytes, size_t len, int pred
         hipDeviceProp_t prop;
         if (hipGetDeviceProperties(&prop, device_id) == hipSuccess && prop.multiProcessorCount > 0) {
             vpt::ScoreParams probe{};
-            probe.ct = p->ct; probe.pk = p->pk; probe.pad = p->pad; probe.ctype = p->d_ctype; probe.type_kind = p->type_kind;
+            probe.ct = p->ct; probe.pk = p->pk; probe.pad = p->pad; probe.cinfo = p->d_cinfo; probe.type_kind = p->type_kind;
             probe.type_window = p->type_window;
             const size_t lds = vpt::fast_path_supported(probe) ? vpt::score_tiles_fast_lds_bytes(probe) : vpt::score_tiles_lds_bytes();
             const uint32_t per_cu = uint32_t(std::min<size_t>(8, std::max<size_t>(1, (160u << 10) / std::max<size_t>(lds, 1))));
@@ -326,7 +331,7 @@ void vpt_predictor_destroy(vpt_predictor* p) {
     for (vpt_batch* b : p->pool) batch_release(b);
     p->dc.release(); p->dt.release(); p->dp.release(); p->dtag.release();
     (void)hipFree(p->d_type_table);
-    (void)hipFree(p->d_ctype);
+    (void)hipFree(p->d_cinfo);
     delete p;
 }
 
@@ -416,6 +421,13 @@ vpt_status vpt_batch_set_max_sentence_chars(vpt_batch* b, uint64_t max_sentence_
     return VPT_OK;
 }
 
+vpt_status vpt_batch_set_flags(vpt_batch* b, unsigned flags) {
+    if (!b) return fail(VPT_INVALID_ARGUMENT, "InvalidArgumentError: NULL argument");
+    if (flags & ~unsigned(VPT_FLAG_KYTEA_FULLWIDTH)) return fail(VPT_INVALID_ARGUMENT, "InvalidArgumentError: flags: unknown bit");
+    b->flags = flags;
+    return VPT_OK;
+}
+
 vpt_status vpt_batch_phase_cycles(vpt_batch* b, uint64_t cycles[8]) {
     if (!b || !cycles) return fail(VPT_INVALID_ARGUMENT, "InvalidArgumentError: NULL argument");
     std::memset(cycles, 0, 64);
@@ -437,7 +449,8 @@ vpt_status vpt_predict_batch_device(const vpt_predictor* p, vpt_batch* b, const 
     hipStream_t stream = static_cast<hipStream_t>(hip_stream);
     VPT_HIP(hipSetDevice(p->device));
     vpt::ScoreParams P{};
-    P.ct = p->ct; P.tt = p->tt; P.pk = p->pk; P.type_table = p->d_type_table; P.ctype = p->d_ctype;
+    P.ct = p->ct; P.tt = p->tt; P.pk = p->pk; P.type_table = p->d_type_table;
+    P.cinfo = p->d_cinfo + ((b->flags & VPT_FLAG_KYTEA_FULLWIDTH) ? 65536 : 0);
     P.type_window = p->type_window; P.type_kind = p->type_kind; P.bias = p->bias; P.pad = p->pad;
     // Tiles are cut every `tile_flat` flat positions (chars + separators) and end with the sentence that crosses
     // the cut, so a tile holds < tile_flat + longest sentence: pick tile_flat to fill the kernel's LDS capacity.
@@ -514,6 +527,12 @@ vpt_status vpt_batch_sync(vpt_batch* b) {
 
 vpt_status vpt_predict_batch(const vpt_predictor* p, const uint8_t* utf8, const uint64_t* byte_offsets, size_t n_sentences,
                              int32_t* scores_out, uint8_t* labels_out, const uint64_t* out_offsets) {
+    return vpt_predict_batch_flags(p, utf8, byte_offsets, n_sentences, scores_out, labels_out, out_offsets, 0u);
+}
+
+vpt_status vpt_predict_batch_flags(const vpt_predictor* p, const uint8_t* utf8, const uint64_t* byte_offsets, size_t n_sentences,
+                                   int32_t* scores_out, uint8_t* labels_out, const uint64_t* out_offsets, unsigned flags) {
+    if (flags & ~unsigned(VPT_FLAG_KYTEA_FULLWIDTH)) return fail(VPT_INVALID_ARGUMENT, "InvalidArgumentError: flags: unknown bit");
     if (!p) return fail(VPT_INVALID_ARGUMENT, "InvalidArgumentError: predictor: must not be NULL");
     if (n_sentences == 0) return VPT_OK;
     if (!utf8 || !byte_offsets || !out_offsets) return fail(VPT_INVALID_ARGUMENT, "InvalidArgumentError: NULL argument");
@@ -548,6 +567,7 @@ vpt_status vpt_predict_batch(const vpt_predictor* p, const uint8_t* utf8, const 
         max_chars = std::max<uint64_t>(max_chars, out_offsets[i + 1] - out_offsets[i] + 1);
     }
     b->max_chars = max_chars;
+    b->flags = flags;
     vpt_status st;
     if ((st = grow(&b->d_text, &b->text_cap, nbytes + 32)) != VPT_OK) return give_back(st);
     {
@@ -592,6 +612,12 @@ vpt_status vpt_predictor_n_tags(const vpt_predictor* p, uint32_t* n_tags) {
 
 vpt_status vpt_fill_tags_batch(const vpt_predictor* p, const uint8_t* utf8, const uint64_t* byte_offsets, size_t n_sentences,
                                const uint64_t* out_offsets, const uint8_t* labels, int32_t* tags_out) {
+    return vpt_fill_tags_batch_flags(p, utf8, byte_offsets, n_sentences, out_offsets, labels, tags_out, 0u);
+}
+
+vpt_status vpt_fill_tags_batch_flags(const vpt_predictor* p, const uint8_t* utf8, const uint64_t* byte_offsets, size_t n_sentences,
+                                     const uint64_t* out_offsets, const uint8_t* labels, int32_t* tags_out, unsigned flags) {
+    if (flags & ~unsigned(VPT_FLAG_KYTEA_FULLWIDTH)) return fail(VPT_INVALID_ARGUMENT, "InvalidArgumentError: flags: unknown bit");
     if (!p) return fail(VPT_INVALID_ARGUMENT, "InvalidArgumentError: predictor: must not be NULL");
     if (!p->predict_tags) return fail(VPT_INVALID_ARGUMENT, "InvalidArgumentError: this predictor is created with predict_tags = false");
     if (n_sentences == 0 || p->n_tags == 0) return VPT_OK;   // predictor.rs:553-555
@@ -627,10 +653,11 @@ vpt_status vpt_fill_tags_batch(const vpt_predictor* p, const uint8_t* utf8, cons
     VPT_HIP(hipMemcpyAsync(B.boff, boff.data(), 8 * (n_sentences + 1), hipMemcpyHostToDevice, B.s));
     VPT_HIP(hipMemcpyAsync(B.ooff, ooff.data(), 8 * (n_sentences + 1), hipMemcpyHostToDevice, B.s));
     VPT_HIP(hipMemsetAsync(B.tags, 0xFF, tag_bytes, B.s));   // -1 = None
-    VPT_HIP(vpt::launch_decode_chars(B.text, B.boff, B.ooff, n_sentences, B.cps, B.s));
+    const uint32_t* cinfo = p->d_cinfo + ((flags & VPT_FLAG_KYTEA_FULLWIDTH) ? 65536 : 0);
+    VPT_HIP(vpt::launch_decode_chars(B.text, B.boff, B.ooff, n_sentences, cinfo, B.cps, B.s));
     vpt::TagParams T{};
     T.tok_tab = p->dtag.tok_tab; T.models = p->dtag.models; T.ngrams = p->dtag.ngrams; T.syms = p->dtag.syms; T.slots = p->dtag.slots;
-    T.weights = p->dtag.weights; T.ctype = p->d_ctype; T.tok_bits = p->tok_bits; T.n_tags = p->n_tags;
+    T.weights = p->dtag.weights; T.cinfo = cinfo; T.tok_bits = p->tok_bits; T.n_tags = p->n_tags;
     T.use_char = p->tag_use_char ? 1u : 0u; T.use_type = p->tag_use_type ? 1u : 0u;
     T.cps = B.cps; T.ooff = B.ooff; T.labels = B.labels; T.n_sent = n_sentences; T.tags = B.tags;
     VPT_HIP(vpt::launch_tag_tokens(T, B.s));

@@ -29,7 +29,8 @@ struct ScoreParams {
     PatternTableView tt;        // character types, when type_kind == kTypePatternTable
     PackedView pk;              // characters again, 16-byte-entry layout of the specialised kernel (if eligible)
     const int32_t* type_table;  // 8^(2W) window scores, when type_kind == kTypeWindowTable
-    const uint8_t* ctype;       // CharacterType of every BMP scalar value (65536 bytes)
+    const uint32_t* cinfo;      // per BMP scalar value: the char it is scored as (identity, or KyteaFullwidthFilter's
+                                // image) | CharacterType of that char << 16
     int32_t type_window;
     int32_t type_kind;
     int32_t bias;
@@ -54,7 +55,7 @@ struct ScoreParams {
 struct TagParams {
     const uint32_t *tok_tab, *models, *ngrams, *syms, *slots;
     const int32_t* weights;
-    const uint8_t* ctype;
+    const uint32_t* cinfo;      // as in ScoreParams
     uint32_t tok_bits, n_tags, use_char, use_type;
     const uint32_t* cps;        // flat scalar values of the batch (decode_chars_kernel)
     const uint64_t* ooff;       // [S+1]
@@ -62,8 +63,8 @@ struct TagParams {
     uint64_t n_sent;
     int32_t* tags;              // [(total boundaries + S) * n_tags] candidate index per slot, -1 = None
 };
-hipError_t launch_decode_chars(const uint8_t* text, const uint64_t* boff, const uint64_t* ooff, uint64_t n_sent, uint32_t* cps,
-                               hipStream_t stream);
+hipError_t launch_decode_chars(const uint8_t* text, const uint64_t* boff, const uint64_t* ooff, uint64_t n_sent, const uint32_t* cinfo,
+                               uint32_t* cps, hipStream_t stream);
 hipError_t launch_tag_tokens(const TagParams& P, hipStream_t stream);
 
 size_t score_tiles_lds_bytes();

@@ -31,7 +31,7 @@ __device__ __forceinline__ uint32_t lanes_below(uint64_t mask, int lane) {
 
 __global__ __launch_bounds__(kTagThreads) void decode_chars_kernel(const uint8_t* __restrict__ text, const uint64_t* __restrict__ boff,
                                                                    const uint64_t* __restrict__ ooff, uint64_t n_sent,
-                                                                   uint32_t* __restrict__ cps) {
+                                                                   const uint32_t* __restrict__ cinfo, uint32_t* __restrict__ cps) {
     const int lane = threadIdx.x & 63;
     const uint64_t wave = uint64_t(blockIdx.x) * kTagWaves + (threadIdx.x >> 6);
     const uint64_t n_waves = uint64_t(gridDim.x) * kTagWaves;
@@ -49,7 +49,8 @@ __global__ __launch_bounds__(kTagThreads) void decode_chars_kernel(const uint8_t
                 if (byte0 >= 0xC0u && at + 1 < b1) b4 |= uint32_t(text[at + 1]) << 8;
                 if (byte0 >= 0xE0u && at + 2 < b1) b4 |= uint32_t(text[at + 2]) << 16;
                 if (byte0 >= 0xF0u && at + 3 < b1) b4 |= uint32_t(text[at + 3]) << 24;
-                cps[g + lanes_below(m, lane)] = utf8_scalar(b4);
+                const uint32_t cp = utf8_scalar(b4);
+                cps[g + lanes_below(m, lane)] = cp < 0x10000u ? cinfo[cp] & 0xFFFFu : cp;   // the scored char
             }
             g += uint64_t(__popcll(m));
         }
@@ -60,8 +61,8 @@ struct TagLds {
     int32_t z[kTagWaves][1024];   // kTagMaxZ scores per token, one buffer per wave
 };
 
-__device__ __forceinline__ uint32_t type_of(const uint8_t* ctype, uint32_t cp) {
-    return cp < 0x10000u ? uint32_t(ctype[cp]) : char_type(cp);
+__device__ __forceinline__ uint32_t type_of(const uint32_t* cinfo, uint32_t cp) {
+    return cp < 0x10000u ? cinfo[cp] >> 16 : char_type(cp);   // cp is already the scored char: its image is itself
 }
 
 __global__ __launch_bounds__(kTagThreads) void tag_tokens_kernel(const TagParams P) {
@@ -135,7 +136,7 @@ __global__ __launch_bounds__(kTagThreads) void tag_tokens_kernel(const TagParams
                             bool ne = false;
                             if (j < glen) {
                                 const uint32_t c = cps[beg + j];
-                                ne = P.syms[nr[0] + j] != (kind == 0 ? c : type_of(P.ctype, c));
+                                ne = P.syms[nr[0] + j] != (kind == 0 ? c : type_of(P.cinfo, c));
                             }
                             if (__ballot(ne) != 0) { same = false; break; }
                         }
@@ -168,11 +169,11 @@ __global__ __launch_bounds__(kTagThreads) void tag_tokens_kernel(const TagParams
 
 }  // namespace
 
-hipError_t launch_decode_chars(const uint8_t* text, const uint64_t* boff, const uint64_t* ooff, uint64_t n_sent, uint32_t* cps,
-                               hipStream_t stream) {
+hipError_t launch_decode_chars(const uint8_t* text, const uint64_t* boff, const uint64_t* ooff, uint64_t n_sent, const uint32_t* cinfo,
+                               uint32_t* cps, hipStream_t stream) {
     const uint64_t want = (n_sent + kTagWaves - 1) / kTagWaves;
     const uint32_t blocks = uint32_t(want < 1 ? 1 : want > 65536 ? 65536 : want);
-    hipLaunchKernelGGL(decode_chars_kernel, dim3(blocks), dim3(kTagThreads), 0, stream, text, boff, ooff, n_sent, cps);
+    hipLaunchKernelGGL(decode_chars_kernel, dim3(blocks), dim3(kTagThreads), 0, stream, text, boff, ooff, n_sent, cinfo, cps);
     return hipGetLastError();
 }
 

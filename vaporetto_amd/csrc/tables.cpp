@@ -648,6 +648,24 @@ HostTagTables build_tag_tables(const ModelData& m, bool use_char, bool use_type)
 }
 }  // namespace
 
+uint32_t kytea_fullwidth_host(uint32_t c) {
+    if (c >= 'a' && c <= 'z') return 0xFF41 + (c - 'a');   // kytea_fullwidth.rs:17-42
+    if (c >= 'A' && c <= 'Z') return 0xFF21 + (c - 'A');   // :43-68
+    if (c >= '0' && c <= '9') return 0xFF10 + (c - '0');   // :69-78
+    switch (c) {                                           // :79-113
+        case '(': return 0xFF08; case ')': return 0xFF09; case '{': return 0xFF5B; case '}': return 0xFF5D;
+        case '<': return 0xFF1C; case '>': return 0xFF1E; case 0xFF62: return 0x300C; case 0xFF63: return 0x300D;
+        case '[': return 0xFF3B; case ']': return 0xFF3D; case '-': return 0x2212; case 0xFF5E: return 0x301C;
+        case '.': return 0x3002; case 0xFF0D: return 0x30FC; case '/': return 0xFF0F; case '_': return 0xFF3F;
+        case ',': return 0xFF0C; case '%': return 0xFF05; case '?': return 0xFF1F; case 0xFF64: return 0x3001;
+        case 0x2015: return 0x30FC; case '"': return 0x201D; case '\'': return 0x2019; case 0xFF65: return 0x30FB;
+        case 0x2500: return 0x30FC; case '+': return 0xFF0B; case ':': return 0xFF1A; case 0x2013: return 0x30FC;
+        case '!': return 0xFF01; case 0xFF61: return 0x3002; case '&': return 0xFF06; case '*': return 0xFF0A;
+        case '@': return 0xFF20; case '=': return 0xFF1D;
+        default: return c;
+    }
+}
+
 uint8_t char_type_host(uint32_t c) {
     auto in = [c](uint32_t lo, uint32_t hi) { return c >= lo && c <= hi; };
     if (in(0x30, 0x39) || in(0xFF10, 0xFF19)) return 1;

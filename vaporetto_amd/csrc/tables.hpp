@@ -80,6 +80,9 @@ struct CompiledModel {
 // hash of a token surface (code points) for HostTagTables::tok_tab; the kernel computes the same
 uint32_t tag_token_hash(const uint32_t* cps, size_t n);
 
+// KyteaFullwidthFilter (vaporetto_rules/src/string_filters/kytea_fullwidth.rs:13-117): the char a BMP char maps to
+uint32_t kytea_fullwidth_host(uint32_t c);
+
 // CharacterType::get_type (sentence.rs:50-67) on the host; used to build the device's BMP class table.
 uint8_t char_type_host(uint32_t c);
 
