@@ -178,6 +178,7 @@ struct vpt_predictor {
     DevicePacked dp;
     vpt::PackedView pk{};
     int32_t* d_type_table = nullptr;
+    uint8_t* d_ctype = nullptr;
     uint32_t* d_cinfo = nullptr;       // [0, 65536): plain; [65536, 131072): through KyteaFullwidthFilter
     vpt::PatternTableView ct{}, tt{};
     mutable std::mutex pool_mu;
@@ -296,6 +297,9 @@ vpt_status vpt_predictor_create(const uint8_t* model_bytes, size_t len, int pred
             cinfo[65536 + cp] = fw | (uint32_t(vpt::char_type_host(fw)) << 16);
         }
         e = upload(cinfo, &p->d_cinfo);
+        std::vector<uint8_t> ctype(65536);
+        for (uint32_t cp = 0; cp < 65536; ++cp) ctype[cp] = vpt::char_type_host(cp);
+        if (e == hipSuccess) e = upload(ctype, &p->d_ctype);
     }
     if (e != hipSuccess) {
         std::string msg = std::string("HIP error while uploading the tables: ") + hipGetErrorString(e);
@@ -314,7 +318,7 @@ vpt_status vpt_predictor_create(const uint8_t* model_bytes, size_t len, int pred
         hipDeviceProp_t prop;
         if (hipGetDeviceProperties(&prop, device_id) == hipSuccess && prop.multiProcessorCount > 0) {
             vpt::ScoreParams probe{};
-            probe.ct = p->ct; probe.pk = p->pk; probe.pad = p->pad; probe.cinfo = p->d_cinfo; probe.type_kind = p->type_kind;
+            probe.ct = p->ct; probe.pk = p->pk; probe.pad = p->pad; probe.ctype = p->d_ctype; probe.type_kind = p->type_kind;
             probe.type_window = p->type_window;
             const size_t lds = vpt::fast_path_supported(probe) ? vpt::score_tiles_fast_lds_bytes(probe) : vpt::score_tiles_lds_bytes();
             const uint32_t per_cu = uint32_t(std::min<size_t>(8, std::max<size_t>(1, (160u << 10) / std::max<size_t>(lds, 1))));
@@ -331,7 +335,7 @@ void vpt_predictor_destroy(vpt_predictor* p) {
     for (vpt_batch* b : p->pool) batch_release(b);
     p->dc.release(); p->dt.release(); p->dp.release(); p->dtag.release();
     (void)hipFree(p->d_type_table);
-    (void)hipFree(p->d_cinfo);
+    (void)hipFree(p->d_cinfo); (void)hipFree(p->d_ctype);
     delete p;
 }
 
@@ -450,7 +454,8 @@ vpt_status vpt_predict_batch_device(const vpt_predictor* p, vpt_batch* b, const 
     VPT_HIP(hipSetDevice(p->device));
     vpt::ScoreParams P{};
     P.ct = p->ct; P.tt = p->tt; P.pk = p->pk; P.type_table = p->d_type_table;
-    P.cinfo = p->d_cinfo + ((b->flags & VPT_FLAG_KYTEA_FULLWIDTH) ? 65536 : 0);
+    P.ctype = p->d_ctype;
+    P.cinfo = (b->flags & VPT_FLAG_KYTEA_FULLWIDTH) ? p->d_cinfo + 65536 : nullptr;
     P.type_window = p->type_window; P.type_kind = p->type_kind; P.bias = p->bias; P.pad = p->pad;
     // Tiles are cut every `tile_flat` flat positions (chars + separators) and end with the sentence that crosses
     // the cut, so a tile holds < tile_flat + longest sentence: pick tile_flat to fill the kernel's LDS capacity.

@@ -249,7 +249,7 @@ __device__ __forceinline__ void process_tile(const ScoreParams& P, const TileMem
             const uint32_t b4 = uint32_t(two >> r);
             uint32_t cp = utf8_scalar(b4);
             if (cp == 0) raise(P.status, kErrNulChar);           // sentence.rs:174-179
-            if (cp < 0x10000u) cp = P.cinfo[cp] & 0xFFFFu;       // identity, or KyteaFullwidthFilter's image
+            if (P.cinfo && cp < 0x10000u) cp = P.cinfo[cp] & 0xFFFFu;   // KyteaFullwidthFilter's image
             const uint32_t flat = uint32_t(pad) + ci + uint32_t(pad) * si;
             if (flat < flat_len) {
                 M.sym[flat] = cp;

@@ -29,8 +29,9 @@ struct ScoreParams {
     PatternTableView tt;        // character types, when type_kind == kTypePatternTable
     PackedView pk;              // characters again, 16-byte-entry layout of the specialised kernel (if eligible)
     const int32_t* type_table;  // 8^(2W) window scores, when type_kind == kTypeWindowTable
-    const uint32_t* cinfo;      // per BMP scalar value: the char it is scored as (identity, or KyteaFullwidthFilter's
-                                // image) | CharacterType of that char << 16
+    const uint8_t* ctype;       // CharacterType of every BMP scalar value (65536 bytes)
+    const uint32_t* cinfo;      // only with VPT_FLAG_KYTEA_FULLWIDTH, else nullptr: per BMP scalar value the char it is
+                                // scored as (KyteaFullwidthFilter's image) | CharacterType of that char << 16
     int32_t type_window;
     int32_t type_kind;
     int32_t bias;

@@ -526,8 +526,14 @@ __global__ __launch_bounds__(kThreads, 5) void score_tiles_fast_kernel(const Sco
     for (int k = 0; k < kPerThread; ++k) {
         if (meta[k] == 0xFFFFFFFFu) continue;
         const uint32_t flat = meta[k] & 0xFFFu, cp = cps[k];
-        const uint32_t info = cp < 0x10000u ? P.cinfo[cp] : (kPackedNoMatchSym | (char_type(cp) << 16));   // (scored char, its type)
-        const uint32_t ty = info >> 16, cs = info & 0xFFFFu;
+        uint32_t ty, cs;   // CharacterType and the char the position is scored as
+        if (P.cinfo) {     // wave-uniform: KyteaFullwidthFilter folded into the classification table
+            const uint32_t info = cp < 0x10000u ? P.cinfo[cp] : (kPackedNoMatchSym | (char_type(cp) << 16));
+            ty = info >> 16; cs = info & 0xFFFFu;
+        } else {
+            ty = cp < 0x10000u ? uint32_t(P.ctype[cp]) : char_type(cp);
+            cs = cp;
+        }
         L.sym[flat] = (cs < kPackedNoMatchSym ? cs : kPackedNoMatchSym) | (ty << 16) | ((meta[k] >> 16) << 19);
         if (TM != kTypeRows) L.typ[flat] = uint8_t(ty);
         if (meta[k] & 0x8000u) {
@@ -648,7 +654,7 @@ __global__ __launch_bounds__(kThreads, 5) void score_tiles_fast_kernel(const Sco
 }  // namespace
 
 bool fast_path_supported(const ScoreParams& P) {
-    if (!P.pk.present || P.pad != 3 || !P.cinfo) return false;
+    if (!P.pk.present || P.pad != 3 || !P.ctype) return false;
     if (!P.ct.present || P.ct.stride_dw != 8 || P.ct.uni_dw != 8 || P.ct.uni_n != kUniDirectChars) return false;  // kPkWide rows
     if (P.type_kind == kTypeNone) return true;
     return P.type_kind == kTypeWindowTable && P.type_window >= 1 && P.type_window <= 3;
