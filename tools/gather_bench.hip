@@ -4,6 +4,7 @@
 //   0: 16 B from a random 16-B slot                1: 64 B (4 x 16) from a random 64-B record
 //   2: 128 B (8 x 16) from a random 128-B record   3: lane PAIRS share a random 128-B record, 64 B each
 //   4: 32 B (2 x 16) from a random 32-B record     5: as 1 with non-temporal loads
+//   6: lanes L and L+32 share a random 128-B record, 64 B each (the pairing v_permlane32_swap_b32 can undo)
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
@@ -21,7 +22,7 @@ __global__ __launch_bounds__(256) void gather(const uint4* __restrict__ tab, uin
     const uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x;
     uint32_t acc = 0;
     for (int i = 0; i < iters; ++i) {
-        uint32_t who = (MODE == 3) ? (tid >> 1) : tid;
+        uint32_t who = (MODE == 3) ? (tid >> 1) : (MODE == 6) ? ((tid >> 6) * 32 + (tid & 31)) : tid;
         uint32_t h = mix(who * 0x9E3779B1u + uint32_t(i) * 0x85EBCA77u) & mask16;   // index in 16-B units
         if (MODE == 0) { uint4 v = tab[h]; acc ^= v.x ^ v.w; }
         else if (MODE == 4) { h &= ~1u; uint4 a = tab[h], b = tab[h + 1]; acc ^= a.x ^ b.w; }
@@ -36,6 +37,9 @@ __global__ __launch_bounds__(256) void gather(const uint4* __restrict__ tab, uin
             h &= ~7u;
             uint4 a = tab[h], b = tab[h + 1], c = tab[h + 2], d = tab[h + 3], e = tab[h + 4], f = tab[h + 5], g = tab[h + 6], k = tab[h + 7];
             acc ^= a.x ^ b.y ^ c.z ^ d.w ^ e.x ^ f.y ^ g.z ^ k.w;
+        } else if (MODE == 6) {
+            h = (h & ~7u) + (((tid >> 5) & 1u) << 2);
+            uint4 a = tab[h], b = tab[h + 1], c = tab[h + 2], d = tab[h + 3]; acc ^= a.x ^ b.y ^ c.z ^ d.w;
         } else if (MODE == 3) {
             h = (h & ~7u) + ((tid & 1u) << 2);
             uint4 a = tab[h], b = tab[h + 1], c = tab[h + 2], d = tab[h + 3]; acc ^= a.x ^ b.y ^ c.z ^ d.w;
@@ -67,8 +71,9 @@ int main() {
         const uint32_t mask16 = uint32_t(bytes / 16 - 1);
         double t0 = run<0>(tab, mask16, blocks, iters, out), t4 = run<4>(tab, mask16, blocks, iters, out), t1 = run<1>(tab, mask16, blocks, iters, out);
         double t5 = run<5>(tab, mask16, blocks, iters, out), t2 = run<2>(tab, mask16, blocks, iters, out), t3 = run<3>(tab, mask16, blocks, iters, out);
-        printf("table %4zu MB | G accesses/s: 16B %.1f | 32B %.1f | 64B %.1f | 64B-nt %.1f | 128B %.1f | pair128B %.1f (records/s %.1f)\n", bytes >> 20,
-               positions / t0 / 1e6, positions / t4 / 1e6, positions / t1 / 1e6, positions / t5 / 1e6, positions / t2 / 1e6, positions / t3 / 1e6, positions / 2 / t3 / 1e6);
+        double t6 = run<6>(tab, mask16, blocks, iters, out);
+        printf("table %4zu MB | G accesses/s: 16B %.1f | 32B %.1f | 64B %.1f | 64B-nt %.1f | 128B %.1f | pair128B %.1f (records/s %.1f) | half-wave pair records/s %.1f\n", bytes >> 20,
+               positions / t0 / 1e6, positions / t4 / 1e6, positions / t1 / 1e6, positions / t5 / 1e6, positions / t2 / 1e6, positions / t3 / 1e6, positions / 2 / t3 / 1e6, positions / 2 / t6 / 1e6);
         CHECK(hipFree(tab));
     }
     return 0;
