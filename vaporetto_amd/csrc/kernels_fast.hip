@@ -6,9 +6,9 @@
 //
 //   * one 128-byte RECORD per (c1,c2) prefix holds the bigram row, three right children (c1,c2,c3) and three left
 //     children (c0,c1,c2), and its slot comes from a perfect hash (one cache-hot seed byte), so a start position
-//     costs ONE random line.  A lane PAIR (L, L+32) fetches the two 64-byte halves of a record in the same
-//     instruction (first the lower lane's record, then the upper lane's), which the memory pipeline rewards
-//     (tools/gather_bench.hip), and sixteen v_permlane32_swap_b32 leave every lane with its own whole record;
+//     costs ONE random line.  A lane PAIR fetches the two 64-byte halves of a record in the same instruction (first
+//     the even lane's record, then the odd lane's), which the memory pipeline rewards (tools/gather_bench.hip), and
+//     hands the partner's half over through DPP, so that every lane ends up with its own whole record;
 //   * the unigram row (16 bytes, cache-hot), the type row (LDS), the bigram row and the matching right child are
 //     summed in registers and land in the LDS score array with six ds_add_u32 (integer => order-free => bit-exact);
 //     a matching left child adds its four values one position earlier;
@@ -58,6 +58,9 @@ __device__ __forceinline__ uint32_t lane_rank(uint64_t mask) {  // set bits of `
     return __builtin_amdgcn_mbcnt_hi(uint32_t(mask >> 32), __builtin_amdgcn_mbcnt_lo(uint32_t(mask), 0u));
 }
 
+__device__ __forceinline__ uint32_t pair_swap(uint32_t x) {  // value of lane ^ 1 (DPP quad_perm [1,0,3,2])
+    return uint32_t(__builtin_amdgcn_mov_dpp(int(x), 0xB1, 0xF, 0xF, true));   // every lane is written: no `old`
+}
 // inclusive prefix sum over the 64 lanes of a wave: DPP row shifts, then the two row broadcasts (no LDS round trips)
 __device__ __forceinline__ uint32_t wave_inclusive_scan(uint32_t x) {
     x += uint32_t(__builtin_amdgcn_update_dpp(0, int(x), 0x111, 0xF, 0xF, false));  // row_shr:1
@@ -67,11 +70,6 @@ __device__ __forceinline__ uint32_t wave_inclusive_scan(uint32_t x) {
     x += uint32_t(__builtin_amdgcn_update_dpp(0, int(x), 0x142, 0xA, 0xF, false));  // row_bcast:15 -> rows 1, 3
     x += uint32_t(__builtin_amdgcn_update_dpp(0, int(x), 0x143, 0xC, 0xF, false));  // row_bcast:31 -> rows 2, 3
     return x;
-}
-// v_permlane32_swap_b32: x[32..63] <-> y[0..31]
-__device__ __forceinline__ void half_swap(uint32_t& x, uint32_t& y) {
-    const auto r = __builtin_amdgcn_permlane32_swap(x, y, false, false);
-    x = r[0]; y = r[1];
 }
 // 16 bytes at base + byte offset (32-bit): one scalar base for all packed arrays
 __device__ __forceinline__ uint4 ld16(const unsigned char* base, uint32_t byte_off) {
@@ -572,29 +570,26 @@ __global__ __launch_bounds__(kThreads, 5) void score_tiles_fast_kernel(const Sco
         const uint32_t kb = c1 | (c2 << 16);
         uint32_t hrec = packed_ph_slot(kb, nseed, K.rec_shift);
         if (P.debug & 1u) hrec = 0;  // timing ablation (VPT_DEBUG_ABLATE; results are wrong): pin the record
-        const bool upper = lane >= 32;
         // every load first: the unigram row and the whole record of (c1,c2)
         const uint4 u = ld16(K.base, K.off_uni + (((P.debug & 4u) ? 0u : c1) << 4));
-        // Lanes L and L+32 form a pair: first (X) they read the two 64-byte halves of the LOWER lane's record, then (Y)
-        // of the UPPER lane's -- both halves of a 128-byte line requested by one instruction, which the memory pipeline
-        // merges (tools/gather_bench.hip).  v_permlane32_swap_b32 then exchanges X[32..63] with Y[0..31], which leaves
-        // every lane with its own half 0 in X and its own half 1 in Y.
-        uint32_t p_hrec;
-        {
-            uint32_t t0 = hrec, t1 = hrec;
-            half_swap(t0, t1);                 // t0 = [hrec[0..31], hrec[0..31]], t1 = [hrec[32..63], hrec[32..63]]
-            p_hrec = upper ? t0 : t1;
-        }
-        const uint32_t half = upper ? 64u : 0u;
-        const uint32_t ra = K.off_rec + (((upper ? p_hrec : hrec) << 7) | half);   // lower: own half 0, upper: partner's half 1
-        const uint32_t rb = K.off_rec + (((upper ? hrec : p_hrec) << 7) | half);   // lower: partner's half 0, upper: own half 1
-        uint4 h0 = ld16(K.base, ra), r1 = ld16(K.base, ra + 16), r2 = ld16(K.base, ra + 32), r3 = ld16(K.base, ra + 48);
-        uint4 h1 = ld16(K.base, rb), l1 = ld16(K.base, rb + 16), l2 = ld16(K.base, rb + 32), l3 = ld16(K.base, rb + 48);
+        const uint32_t p_hrec = pair_swap(hrec);
+        const bool odd = (lane & 1) != 0;
+        const uint32_t ra = K.off_rec + (((odd ? p_hrec : hrec) << 7) | (odd ? 64u : 0u));
+        const uint32_t rb = K.off_rec + (((odd ? hrec : p_hrec) << 7) | (odd ? 0u : 64u));
+        const uint4 qa0 = ld16(K.base, ra), qa1 = ld16(K.base, ra + 16), qa2 = ld16(K.base, ra + 32), qa3 = ld16(K.base, ra + 48);   // even lane: own half 0; odd lane: partner's half 1
+        const uint4 qb0 = ld16(K.base, rb), qb1 = ld16(K.base, rb + 16), qb2 = ld16(K.base, rb + 32), qb3 = ld16(K.base, rb + 48);   // even lane: partner's half 1; odd lane: own half 0
+        // own half 0 = even ? qa : qb (already here); own half 1 = the partner's qb (even lanes) / qa (odd lanes)
+        const uint4 h0 = odd ? qb0 : qa0, r1 = odd ? qb1 : qa1, r2 = odd ? qb2 : qa2, r3 = odd ? qb3 : qa3;
         if (k + 1 < kPerThread) stage(s + uint32_t(kThreads));          // next iteration's symbols and seed
-        half_swap(h0.x, h1.x); half_swap(h0.y, h1.y); half_swap(h0.z, h1.z); half_swap(h0.w, h1.w);
-        half_swap(r1.x, l1.x); half_swap(r1.y, l1.y); half_swap(r1.z, l1.z); half_swap(r1.w, l1.w);
-        half_swap(r2.x, l2.x); half_swap(r2.y, l2.y); half_swap(r2.z, l2.z); half_swap(r2.w, l2.w);
-        half_swap(r3.x, l3.x); half_swap(r3.y, l3.y); half_swap(r3.z, l3.z); half_swap(r3.w, l3.w);
+        uint4 h1, l1, l2, l3;
+        {
+            // what this lane holds of the PARTNER's record, handed over through DPP
+            const uint4 g0 = odd ? qa0 : qb0, g1 = odd ? qa1 : qb1, g2 = odd ? qa2 : qb2, g3 = odd ? qa3 : qb3;
+            h1 = make_uint4(pair_swap(g0.x), pair_swap(g0.y), pair_swap(g0.z), pair_swap(g0.w));
+            l1 = make_uint4(pair_swap(g1.x), pair_swap(g1.y), pair_swap(g1.z), pair_swap(g1.w));
+            l2 = make_uint4(pair_swap(g2.x), pair_swap(g2.y), pair_swap(g2.z), pair_swap(g2.w));
+            l3 = make_uint4(pair_swap(g3.x), pair_swap(g3.y), pair_swap(g3.z), pair_swap(g3.w));
+        }
         // own row so far: unigram (+ type row)
         int32_t a0 = lo16(u.x), a1 = hi16(u.x), a2 = lo16(u.y), a3 = hi16(u.y), a4 = lo16(u.z), a5 = hi16(u.z);
         if (TM == kTypeRows) {
