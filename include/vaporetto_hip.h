@@ -41,6 +41,14 @@ enum { VPT_NOT_WORD_BOUNDARY = 0, VPT_WORD_BOUNDARY = 1, VPT_BOUNDARY_UNKNOWN = 
  *   this is what the reference's CLI does before update_raw unless --no-norm is given (predict/src/main.rs:126-129),
  *   folded into the kernel's char classification table at no extra cost. */
 enum { VPT_FLAG_KYTEA_FULLWIDTH = 1 };
+/* Post-filters on the LABELS (scores are never touched), applied in this order after the sign threshold:
+ * VPT_FLAG_WSCONST(t), t = CharacterType 1..6: KyteaWsConstFilter::new(t) -- a boundary between two chars of type t
+ *   becomes NotWordBoundary (vaporetto_rules/src/sentence_filters/kytea_wsconst.rs:26-43; the CLI's --wsconst);
+ * VPT_FLAG_SPLIT_LINEBREAKS: SplitLinebreaksFilter -- a boundary next to '\r' or '\n' becomes WordBoundary
+ *   (vaporetto_rules/src/sentence_filters/split_linebreaks.rs:9-36).
+ * Types are those of the scored text (after VPT_FLAG_KYTEA_FULLWIDTH, as in the CLI). */
+#define VPT_FLAG_WSCONST(char_type) (1u << (char_type))
+enum { VPT_FLAG_SPLIT_LINEBREAKS = 1 << 7, VPT_FLAG_ALL = 0xFF };
 
 typedef struct vpt_predictor vpt_predictor;
 typedef struct vpt_batch vpt_batch;

@@ -572,3 +572,39 @@ def test_fullwidth_filter_on_device():
                     a, b = int(ooff[i]), int(ooff[i + 1])
                     want, _ = o.predict_tags(f.filter(t), labels=labels[a:b])
                     assert np.array_equal(got[a + i:a + i + len(t)], want), t
+
+
+@pytest.mark.parametrize("alphabet_name", ["kana", "mixed"])
+def test_label_post_filters_on_device(alphabet_name):
+    """KyteaWsConstFilter (kytea_wsconst.rs:26-43) and SplitLinebreaksFilter (split_linebreaks.rs:9-36) as label masks:
+    scores stay those of the oracle, labels equal the oracle's labels with the filters applied on the host; pinned
+    by the tantivy adapter's expectation for wsconst "D" (vaporetto_tantivy/src/lib.rs:366-420: "123456円" keeps the
+    digit run together)."""
+    raw, _ = kat.load_fixture("tantivy_model.bin")
+    pred, _ = make_predictor(raw)
+    utf8, boff = api.pack_texts(["123456円🤌🏿".encode("utf-8")])
+    _, labels, _ = pred.predict_packed(utf8, boff, fullwidth=True, wsconst=[api.CharacterType.Digit])
+    assert labels.tolist() == [0, 0, 0, 0, 0, 1, 1, 1]      # １２３４５６ | 円 | 🤌 | 🏿
+
+    extra = list("0123456789abcXYZ\\n\\r ")
+    base = randmodel.ALPHABETS["mixed"] if alphabet_name == "mixed" else randmodel.ALPHABETS["kana"][:12]
+    alpha = base + extra
+    m = randmodel.rand_model(640, alphabet=alpha, wc=3, wt=3, n_char=300, n_dict=300, n_type=60, max_word=6)
+    pred, orc = make_predictor(m)
+    texts = randmodel.rand_sentences(9, m, 1200, alphabet=alpha, max_len=60)
+    utf8, boff = api.pack_texts([t.encode("utf-8") for t in texts])
+    o_scores, o_labels, o_ooff, _ = orc.predict_batch(utf8, boff)
+    ws = [api.CharacterType.Digit, api.CharacterType.Roman, api.CharacterType.Kanji]
+    scores, labels, ooff = pred.predict_packed(utf8, boff, wsconst=ws, split_linebreaks=True)
+    assert np.array_equal(scores, o_scores)
+    want = o_labels.copy()
+    for i, t in enumerate(texts):
+        a = int(o_ooff[i])
+        types = api._types_of(np.frombuffer(t.encode("utf-32-le"), dtype=np.uint32))
+        for k in range(len(t) - 1):
+            if types[k] == types[k + 1] and int(types[k]) in [int(x) for x in ws]:
+                want[a + k] = 0
+        for k in range(len(t) - 1):
+            if t[k] in "\\r\\n" or t[k + 1] in "\\r\\n":
+                want[a + k] = 1
+    assert np.array_equal(labels, want)

@@ -13,6 +13,11 @@ LIB_PATH = os.path.join(HERE, "lib", "libvaporetto_hip.so")
 
 VPT_OK, VPT_INVALID_MODEL, VPT_INVALID_ARGUMENT, VPT_RUNTIME_ERROR = 0, 1, 2, 3
 VPT_FLAG_KYTEA_FULLWIDTH = 1
+VPT_FLAG_SPLIT_LINEBREAKS = 1 << 7
+
+
+def VPT_FLAG_WSCONST(char_type: int) -> int:
+    return 1 << int(char_type)
 
 
 class ModelInfo(C.Structure):

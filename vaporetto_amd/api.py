@@ -375,9 +375,16 @@ class Predictor:
                                 s._tags[e * nt + j] = tm.tags[j][idx]
                 start, valid = e + 1, True
 
-    def predict_packed(self, utf8: np.ndarray, byte_offsets: np.ndarray, fullwidth: bool = False):
+    def predict_packed(self, utf8: np.ndarray, byte_offsets: np.ndarray, fullwidth: bool = False,
+                       wsconst: Sequence[int] = (), split_linebreaks: bool = False):
         """utf8: uint8[total bytes]; byte_offsets: uint64[S+1].  Returns (scores, labels, out_offsets).
-        fullwidth: score the text as KyteaFullwidthFilter would rewrite it (the CLI's default normalisation)."""
+        fullwidth: score the text as KyteaFullwidthFilter would rewrite it (the CLI's default normalisation).
+        wsconst: CharacterTypes for KyteaWsConstFilter; split_linebreaks: SplitLinebreaksFilter (labels only)."""
+        flags = _lib.VPT_FLAG_KYTEA_FULLWIDTH if fullwidth else 0
+        for t in wsconst:
+            flags |= _lib.VPT_FLAG_WSCONST(int(t))
+        if split_linebreaks:
+            flags |= _lib.VPT_FLAG_SPLIT_LINEBREAKS
         L = _lib.load()
         utf8 = np.ascontiguousarray(utf8, dtype=np.uint8)
         byte_offsets = np.ascontiguousarray(byte_offsets, dtype=np.uint64)
@@ -390,7 +397,7 @@ class Predictor:
         scores = np.zeros(max(nb, 1), dtype=np.int32)
         labels = np.zeros(max(nb, 1), dtype=np.uint8)
         st = L.vpt_predict_batch_flags(self._h, utf8.ctypes.data, byte_offsets.ctypes.data, S, scores.ctypes.data,
-                                       labels.ctypes.data, ooff.ctypes.data, _lib.VPT_FLAG_KYTEA_FULLWIDTH if fullwidth else 0)
+                                       labels.ctypes.data, ooff.ctypes.data, flags)
         if st != _lib.VPT_OK:
             _raise(st)
         return scores[:nb], labels[:nb], ooff

@@ -285,7 +285,15 @@ __device__ __forceinline__ void process_tile(const ScoreParams& P, const TileMem
         const uint64_t o = O0 + (p - uint32_t(pad)) - uint64_t(pad + 1) * si;
         if (o >= P.ooff[i1]) { raise(P.status, kErrBadOffsets); continue; }  // only with offsets that do not match the text
         if (P.scores) P.scores[o] = y;
-        if (P.labels) P.labels[o] = y > 0 ? 1 : 0;
+        if (P.labels) {
+            uint32_t label = y > 0 ? 1u : 0u;
+            if (P.post) {   // KyteaWsConstFilter / SplitLinebreaksFilter on the label
+                const uint32_t t1 = M.typ[p], t2 = M.typ[p + 1], ca = M.sym[p], cb = M.sym[p + 1];
+                if (t1 == t2 && ((P.post >> t1) & 1u) && t1 >= 1 && t1 <= 6) label = 0;
+                if ((P.post & 0x80u) && (ca == 0x0Au || ca == 0x0Du || cb == 0x0Au || cb == 0x0Du)) label = 1;
+            }
+            P.labels[o] = uint8_t(label);
+        }
     }
 }
 

@@ -48,6 +48,7 @@ struct ScoreParams {
     unsigned char* scratch;     // slabs for score_slow_kernel
     uint64_t scratch_stride;    // bytes per workgroup slab
     uint32_t scratch_cap;       // flat positions per slab
+    uint32_t post;              // label post-filters: bits 1..6 KyteaWsConstFilter per CharacterType, bit 7 SplitLinebreaksFilter
     uint32_t debug;             // profiling ablation bits (VPT_DEBUG_ABLATE env, 0 in production)
     uint64_t* prof;             // per-phase shader-cycle counters (VPT_PROFILE_PHASES env), else nullptr
 };

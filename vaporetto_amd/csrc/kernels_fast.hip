@@ -645,7 +645,16 @@ __global__ __launch_bounds__(kThreads, 5) void score_tiles_fast_kernel(const Sco
         const uint64_t o = O0 + (p - pad) - uint64_t(pad + 1) * si;
         if (o >= O1) { err |= kErrBadOffsets; continue; }  // only with offsets that do not match the text
         if (P.scores) P.scores[o] = y;
-        if (P.labels) P.labels[o] = y > 0 ? 1 : 0;
+        if (P.labels) {
+            uint32_t label = y > 0 ? 1u : 0u;
+            if (P.post) {   // wave-uniform: KyteaWsConstFilter / SplitLinebreaksFilter on the label
+                const uint32_t x2 = L.sym[p + 1];
+                const uint32_t t1 = (x >> 16) & 7u, t2 = (x2 >> 16) & 7u, ca = x & kCpMask, cb = x2 & kCpMask;
+                if (t1 == t2 && ((P.post >> t1) & 1u) && t1 != 0 && t1 != 7) label = 0;
+                if ((P.post & 0x80u) && (ca == 0x0Au || ca == 0x0Du || cb == 0x0Au || cb == 0x0Du)) label = 1;
+            }
+            P.labels[o] = uint8_t(label);
+        }
     }
     if (err) atomicOr(P.status, err);
     phase_mark(prof, 4, tmark);
