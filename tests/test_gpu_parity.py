@@ -586,7 +586,7 @@ def test_label_post_filters_on_device(alphabet_name):
     _, labels, _ = pred.predict_packed(utf8, boff, fullwidth=True, wsconst=[api.CharacterType.Digit])
     assert labels.tolist() == [0, 0, 0, 0, 0, 1, 1, 1]      # １２３４５６ | 円 | 🤌 | 🏿
 
-    extra = list("0123456789abcXYZ\\n\\r ")
+    extra = list("0123456789abcXYZ ") + [chr(10), chr(13)]
     base = randmodel.ALPHABETS["mixed"] if alphabet_name == "mixed" else randmodel.ALPHABETS["kana"][:12]
     alpha = base + extra
     m = randmodel.rand_model(640, alphabet=alpha, wc=3, wt=3, n_char=300, n_dict=300, n_type=60, max_word=6)
@@ -605,6 +605,6 @@ def test_label_post_filters_on_device(alphabet_name):
             if types[k] == types[k + 1] and int(types[k]) in [int(x) for x in ws]:
                 want[a + k] = 0
         for k in range(len(t) - 1):
-            if t[k] in "\\r\\n" or t[k + 1] in "\\r\\n":
+            if t[k] in (chr(10), chr(13)) or t[k + 1] in (chr(10), chr(13)):
                 want[a + k] = 1
     assert np.array_equal(labels, want)
