@@ -173,6 +173,15 @@ vpt_status vpt_fill_tags_batch_flags(const vpt_predictor *p, const uint8_t *utf8
                                      size_t n_sentences, const uint64_t *out_offsets, const uint8_t *labels,
                                      int32_t *tags_out, unsigned flags);
 
+/* Device-resident variant of vpt_fill_tags_batch: all pointers are device pointers, asynchronous on `hip_stream`
+ * (NULL = default stream).  d_labels as written by vpt_predict_batch_device (possibly edited by the caller's own
+ * kernels); d_tags_out must hold (total_boundaries + n_sentences) * n_tags int32.  The workspace keeps the decoded
+ * scalar values (4 bytes per char) between the two kernels; flags as set by vpt_batch_set_flags (fullwidth only). */
+vpt_status vpt_fill_tags_batch_device(const vpt_predictor *p, vpt_batch *b, const uint8_t *d_utf8,
+                                      const uint64_t *d_byte_offsets, const uint64_t *d_out_offsets,
+                                      size_t n_sentences, uint64_t total_boundaries, const uint8_t *d_labels,
+                                      int32_t *d_tags_out, void *hip_stream);
+
 /* Diagnostics: when the environment variable VPT_PROFILE_PHASES is set at vpt_batch_create, the specialised
  * kernel accumulates, per workgroup (wave 0), the shader cycles spent in 0 text scan, 1 per-char decode,
  * 2 pattern lookups, 3 barrier wait, 4 boundary output.  Reads the sums (after a device sync) and resets them;

@@ -608,3 +608,32 @@ def test_label_post_filters_on_device(alphabet_name):
             if t[k] in (chr(10), chr(13)) or t[k + 1] in (chr(10), chr(13)):
                 want[a + k] = 1
     assert np.array_equal(labels, want)
+
+
+def test_device_resident_predict_then_fill_tags():
+    """The whole config-5 pipeline without leaving HBM: vpt_predict_batch_device -> vpt_fill_tags_batch_device on the
+    labels it wrote, one stream; equals the host-buffer path."""
+    import torch
+    m = randmodel.rand_model(830, alphabet="kana", wc=3, wt=3, n_tag_models=30, max_word=4, n_char=60, n_dict=60)
+    raw = encode_model(m)
+    pred = api.Predictor(api.Model.read_slice(raw)[0], True)
+    nt = pred.n_tags()
+    texts = randmodel.rand_sentences(2, m, 3000, alphabet="kana", max_len=45) + [t.token * 2 for t in m.tag_models]
+    utf8, boff = api.pack_texts([t.encode("utf-8") for t in texts])
+    scores, labels, ooff = pred.predict_packed(utf8, boff)
+    want = pred.fill_tags_packed(utf8, boff, ooff, labels)
+    nb, S = int(ooff[-1]), len(texts)
+    d_text = torch.from_numpy(np.concatenate([utf8, np.zeros(16, np.uint8)])).cuda()
+    d_boff = torch.from_numpy(boff.astype(np.int64)).cuda()
+    d_ooff = torch.from_numpy(ooff.astype(np.int64)).cuda()
+    d_scores = torch.zeros(nb + 1, dtype=torch.int32, device="cuda")
+    d_labels = torch.zeros(nb + 1, dtype=torch.uint8, device="cuda")
+    d_tags = torch.zeros((nb + S) * nt + 1, dtype=torch.int32, device="cuda")
+    batch = api.DeviceBatch(pred)
+    stream = torch.cuda.current_stream().cuda_stream
+    batch.predict(d_text.data_ptr(), d_boff.data_ptr(), d_ooff.data_ptr(), S, nb, int(np.max(np.diff(boff.astype(np.int64)))),
+                  d_scores.data_ptr(), d_labels.data_ptr(), stream)
+    batch.fill_tags(d_text.data_ptr(), d_boff.data_ptr(), d_ooff.data_ptr(), S, nb, d_labels.data_ptr(), d_tags.data_ptr(), stream)
+    batch.sync()
+    assert np.array_equal(d_scores[:nb].cpu().numpy(), scores) and np.array_equal(d_labels[:nb].cpu().numpy(), labels)
+    assert np.array_equal(d_tags[:(nb + S) * nt].cpu().numpy().reshape(nb + S, nt), want)

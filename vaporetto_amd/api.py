@@ -432,6 +432,14 @@ class DeviceBatch:
         if st != _lib.VPT_OK:
             _raise(st)
 
+    def fill_tags(self, d_utf8: int, d_boff: int, d_ooff: int, n_sentences: int, total_boundaries: int, d_labels: int,
+                  d_tags: int, stream: int = 0) -> None:
+        """Device-resident Sentence::fill_tags for the batch (vpt_fill_tags_batch_device); enqueues and returns."""
+        st = _lib.load().vpt_fill_tags_batch_device(self._p.handle, self._h, d_utf8, d_boff, d_ooff, n_sentences,
+                                                    total_boundaries, d_labels, d_tags, stream)
+        if st != _lib.VPT_OK:
+            _raise(st)
+
     def set_fullwidth(self, enabled: bool) -> None:
         """Score the text as KyteaFullwidthFilter would rewrite it (vpt_batch_set_flags)."""
         st = _lib.load().vpt_batch_set_flags(self._h, _lib.VPT_FLAG_KYTEA_FULLWIDTH if enabled else 0)

@@ -140,6 +140,7 @@ struct vpt_batch {
     uint32_t* d_ctrl = nullptr;        // [0] status bits, [1] slow tile count
     uint64_t* d_prof = nullptr;        // 8 per-phase cycle counters (only with VPT_PROFILE_PHASES set)
     unsigned char* d_scratch = nullptr; size_t scratch_bytes = 0;
+    uint32_t* d_cps = nullptr; size_t cps_cap = 0;   // decoded scalar values for vpt_fill_tags_batch_device
     uint64_t max_chars = 0;            // caller's bound on chars per sentence (0 = unknown)
     unsigned flags = 0;                // VPT_FLAG_*
     // timing
@@ -204,7 +205,7 @@ void batch_release(vpt_batch* b) {
     if (!b) return;
     (void)hipSetDevice(b->device);
     (void)hipFree(b->d_tile_first); (void)hipFree(b->d_slow_list); (void)hipFree(b->d_ctrl); (void)hipFree(b->d_scratch);
-    (void)hipFree(b->d_prof);
+    (void)hipFree(b->d_prof); (void)hipFree(b->d_cps);
     (void)hipFree(b->d_text); (void)hipFree(b->d_boff); (void)hipFree(b->d_ooff); (void)hipFree(b->d_scores); (void)hipFree(b->d_labels);
     for (hipEvent_t e : b->ev) (void)hipEventDestroy(e);
     if (b->own_stream) (void)hipStreamDestroy(b->own_stream);
@@ -669,6 +670,32 @@ vpt_status vpt_fill_tags_batch_flags(const vpt_predictor* p, const uint8_t* utf8
     VPT_HIP(vpt::launch_tag_tokens(T, B.s));
     VPT_HIP(hipMemcpyAsync(tags_out + size_t(out_offsets[0] + 0) * p->n_tags, B.tags, tag_bytes, hipMemcpyDeviceToHost, B.s));
     VPT_HIP(hipStreamSynchronize(B.s));
+    return VPT_OK;
+}
+
+vpt_status vpt_fill_tags_batch_device(const vpt_predictor* p, vpt_batch* b, const uint8_t* d_utf8, const uint64_t* d_byte_offsets,
+                                      const uint64_t* d_out_offsets, size_t n_sentences, uint64_t total_boundaries,
+                                      const uint8_t* d_labels, int32_t* d_tags_out, void* hip_stream) {
+    if (!p || !b || b->pred != p) return fail(VPT_INVALID_ARGUMENT, "InvalidArgumentError: batch: does not belong to this predictor");
+    if (!p->predict_tags) return fail(VPT_INVALID_ARGUMENT, "InvalidArgumentError: this predictor is created with predict_tags = false");
+    if (n_sentences == 0 || p->n_tags == 0) return VPT_OK;
+    if (!d_utf8 || !d_byte_offsets || !d_out_offsets || !d_tags_out || (total_boundaries && !d_labels))
+        return fail(VPT_INVALID_ARGUMENT, "InvalidArgumentError: NULL device pointer");
+    hipStream_t stream = static_cast<hipStream_t>(hip_stream);
+    VPT_HIP(hipSetDevice(p->device));
+    const uint64_t total_c = total_boundaries + n_sentences;
+    vpt_status st = grow(&b->d_cps, &b->cps_cap, size_t(total_c) + 16);
+    if (st != VPT_OK) return st;
+    const uint32_t* cinfo = p->d_cinfo + ((b->flags & VPT_FLAG_KYTEA_FULLWIDTH) ? 65536 : 0);
+    VPT_HIP(hipMemsetAsync(d_tags_out, 0xFF, size_t(total_c) * p->n_tags * sizeof(int32_t), stream));   // -1 = None
+    VPT_HIP(vpt::launch_decode_chars(d_utf8, d_byte_offsets, d_out_offsets, n_sentences, cinfo, b->d_cps, stream));
+    vpt::TagParams T{};
+    T.tok_tab = p->dtag.tok_tab; T.models = p->dtag.models; T.ngrams = p->dtag.ngrams; T.syms = p->dtag.syms; T.slots = p->dtag.slots;
+    T.weights = p->dtag.weights; T.cinfo = cinfo; T.tok_bits = p->tok_bits; T.n_tags = p->n_tags;
+    T.use_char = p->tag_use_char ? 1u : 0u; T.use_type = p->tag_use_type ? 1u : 0u;
+    T.cps = b->d_cps; T.ooff = d_out_offsets; T.labels = d_labels; T.n_sent = n_sentences; T.tags = d_tags_out;
+    VPT_HIP(vpt::launch_tag_tokens(T, stream));
+    b->last_stream = stream; b->pending = true;
     return VPT_OK;
 }
 
