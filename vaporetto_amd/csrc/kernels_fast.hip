@@ -269,9 +269,8 @@ __device__ __forceinline__ void replay_o(const PackedView& K, const PatternTable
 
 // What a record contributes to the start position that fetched it (the main loop and the M replay share this).
 struct RecMatch {
-    int32_t b1, b2, b3, b4, b5;   // bigram row + matching right child, boundaries s-2 .. s+2
-    bool hit_l;                   // a left child matched: its row (ly, lz) belongs to the string starting at s-1
-    uint32_t ly, lz;
+    int32_t b1, b2, b3, b4, b5;   // bigram row + matching right child + matching left child, boundaries s-2 .. s+2
+    uint32_t ly, lz;              // row of the matching left child (the string starting at s-1: boundaries s-2 .. s+1), or 0
     uint32_t rk, lk;              // trie continuations (mini-table refs in `deep`) of the right / left child, or 0
     bool ovp;                     // the overflow mini-table `ov_ref` may hold (c1,c2,c3)
     uint32_t ov_ref;
@@ -292,14 +291,13 @@ __device__ __forceinline__ RecMatch match_record(bool keyok, uint32_t c0, uint32
     const bool kl = keyok && c0 != 0;
     const bool ml1 = kl && (l1.x & 0xFFFFu) == c0, ml2 = kl && (l2.x & 0xFFFFu) == c0, ml3 = kl && (l3.x & 0xFFFFu) == c0;
     const uint32_t lx = ml1 ? l1.x : ml2 ? l2.x : ml3 ? l3.x : 0u;
-    o.hit_l = (ml1 || ml2 || ml3) && !(lx & (kPkWide << 16));
-    o.ly = ml1 ? l1.y : ml2 ? l2.y : l3.y;
-    o.lz = ml1 ? l1.z : ml2 ? l2.z : l3.z;
+    o.ly = ml1 ? l1.y : ml2 ? l2.y : ml3 ? l3.y : 0u;   // zero without a hit (and in a kPkWide slot)
+    o.lz = ml1 ? l1.z : ml2 ? l2.z : ml3 ? l3.z : 0u;
     o.lk = ml1 ? l1.w : ml2 ? l2.w : ml3 ? l3.w : 0u;
     // bigram row + right child (a kPkWide slot holds zero weights)
     const uint32_t by = keyok ? h0.y : 0u, bz = keyok ? h0.z : 0u, bw = keyok ? h0.w : 0u;
-    o.b1 = lo16(by); o.b2 = hi16(by) + lo16(ry); o.b3 = lo16(bz) + hi16(ry);
-    o.b4 = hi16(bz) + lo16(rz); o.b5 = lo16(bw) + hi16(rz);
+    o.b1 = lo16(by) + lo16(o.ly); o.b2 = hi16(by) + lo16(ry) + hi16(o.ly); o.b3 = lo16(bz) + hi16(ry) + lo16(o.lz);
+    o.b4 = hi16(bz) + lo16(rz) + hi16(o.lz); o.b5 = lo16(bw) + hi16(rz);
     o.ovp = false;
     if (kr && !hit_r && (bw & (kPkOv << 16))) {
         const uint32_t bit = packed_filter_bit(c3);
@@ -356,7 +354,6 @@ __device__ __forceinline__ void replay_m(const PackedView& K, const PatternTable
     const bool again = more && !keyok && (far ? h0.x != 0 : hop_next != 0);
     const RecMatch mt = match_record(keyok, c0, c3, h0, r1, r2, r3, h1, l1, l2, l3);
     if (keyok) add_row6(L.score, s, 0, mt.b1, mt.b2, mt.b3, mt.b4, mt.b5);
-    if (mt.hit_l) add_child(L.score, s - 1, mt.ly, mt.lz);
     kinds = (kinds & (kWideUni | kWideBi | kWideTri | kWideLeft)) | mt.wide;
     if (__ballot(kinds != 0) != 0) {
         if (kinds != 0) add_wide_rows(T, L, kinds, s, c0, c1, c2, c3);
@@ -392,8 +389,12 @@ __device__ __forceinline__ uint64_t phase_mark(uint64_t* prof, int slot, uint64_
     return now;
 }
 
-template <int TM>
-__global__ __launch_bounds__(kThreads, 5) void score_tiles_fast_kernel(const ScoreParams P) {
+// DBG: the diagnostics build (VPT_DEBUG_ABLATE timing ablations, VPT_PROFILE_PHASES) -- compiled out of the kernel
+// production launches use.
+template <int TM, bool DBG>
+__global__ __launch_bounds__(kThreads, 5) void score_tiles_fast_kernel(const ScoreParams P_in) {
+    ScoreParams P = P_in;
+    if (!DBG) { P.debug = 0; P.prof = nullptr; }
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     FastLds& L = *reinterpret_cast<FastLds*>(smem);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -606,7 +607,6 @@ __global__ __launch_bounds__(kThreads, 5) void score_tiles_fast_kernel(const Sco
         const RecMatch mt = match_record(keyok, c0, c3, h0, r1, r2, r3, h1, l1, l2, l3);
         a1 += mt.b1; a2 += mt.b2; a3 += mt.b3; a4 += mt.b4; a5 += mt.b5;
         if (live) add_row6(L.score, s, a0, a1, a2, a3, a4, a5);
-        if (mt.hit_l) add_child(L.score, s - 1, mt.ly, mt.lz);
         // deferred work
         const bool ovp = mt.ovp && !(P.debug & 2u);
         const uint32_t rk = mt.rk, lk = mt.lk;
@@ -681,14 +681,20 @@ hipError_t launch_score_tiles_fast(const ScoreParams& P, uint32_t n_tiles, hipSt
     size_t lds = score_tiles_fast_lds_bytes(P);
     if (const char* padv = std::getenv("VPT_DEBUG_LDS_PAD")) lds += size_t(std::atoi(padv));  // occupancy experiments
     const int tm = rows ? kTypeRows : P.type_kind == kTypeWindowTable ? P.type_window : 0;
+    const bool dbg = P.debug != 0 || P.prof != nullptr;
+#define VPT_LAUNCH_FAST(TM_)                                                                                                   \
+    if (dbg) hipLaunchKernelGGL((score_tiles_fast_kernel<TM_, true>), dim3(n_tiles), dim3(kThreads), lds, stream, P);          \
+    else hipLaunchKernelGGL((score_tiles_fast_kernel<TM_, false>), dim3(n_tiles), dim3(kThreads), lds, stream, P);             \
+    break;
     switch (tm) {
-        case 0: hipLaunchKernelGGL(score_tiles_fast_kernel<0>, dim3(n_tiles), dim3(kThreads), lds, stream, P); break;
-        case 1: hipLaunchKernelGGL(score_tiles_fast_kernel<1>, dim3(n_tiles), dim3(kThreads), lds, stream, P); break;
-        case 2: hipLaunchKernelGGL(score_tiles_fast_kernel<2>, dim3(n_tiles), dim3(kThreads), lds, stream, P); break;
-        case 3: hipLaunchKernelGGL(score_tiles_fast_kernel<3>, dim3(n_tiles), dim3(kThreads), lds, stream, P); break;
-        case 4: hipLaunchKernelGGL(score_tiles_fast_kernel<4>, dim3(n_tiles), dim3(kThreads), lds, stream, P); break;
+        case 0: VPT_LAUNCH_FAST(0)
+        case 1: VPT_LAUNCH_FAST(1)
+        case 2: VPT_LAUNCH_FAST(2)
+        case 3: VPT_LAUNCH_FAST(3)
+        case 4: VPT_LAUNCH_FAST(4)
         default: return hipErrorInvalidValue;
     }
+#undef VPT_LAUNCH_FAST
     return hipGetLastError();
 }
 
