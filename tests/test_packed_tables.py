@@ -252,3 +252,21 @@ def test_cpp_fullwidth_map_equals_reference_pairs(tc):
               (line.split() for line in open(os.path.join(HERE, "golden", "kytea_fullwidth_pairs.txt"), encoding="utf-8"))}
     for cp in range(0x10000):
         assert tc.tc_fullwidth(cp) == golden.get(cp, cp), hex(cp)
+
+
+@pytest.mark.parametrize("kind", [1, 2])
+def test_packed_walk_on_scaled_synthetic_models(tc, kind):
+    """The bench models at 1/20 scale (tens of thousands of patterns: a perfect hash over ~40 K prefixes, overflow
+    mini-tables, compressed chains): the table walk reproduces the oracle's FULL scores (type rows included)."""
+    from vaporetto_amd import synth
+    raw = synth.synth_model(kind, synth.SEED_BASE + kind, 0.05)
+    w = Walker(tc, raw)
+    assert w.packed and w.trow
+    st = w.stats()
+    assert st["n_disp"] == 0 and st["n_left"] > 0 and st["n_deep"] > 0
+    utf8, boff = synth.synth_sentences(raw, 400, 8, 96, seed=synth.SEED_BASE + 11 * kind)
+    orc = cbind.OraclePredictor(raw)
+    text = bytes(utf8)
+    for i in range(400):
+        t = text[int(boff[i]):int(boff[i + 1])].decode("utf-8")
+        assert w.score(t, want=2) == orc.predict(t)[0], t
