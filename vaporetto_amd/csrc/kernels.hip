@@ -312,10 +312,40 @@ __global__ void assign_tiles_kernel(const uint64_t* __restrict__ ooff, uint64_t 
     if (t < 2) ctrl[t] = 0;
     if (t > n_tiles) return;
     const uint64_t target = uint64_t(t) * tile_flat;
-    uint64_t lo = 0, hi = n_sent;  // first i in [0, n_sent] with F(i) >= target; F(n_sent) is the total
+    const uint64_t step = uint64_t(1 + pad);
+    auto F = [&](uint64_t i) { return ooff[i] + i * step; };   // non-decreasing; F(n_sent) is the total
+    // first i in [0, n_sent] with F(i) >= target.  Sentences of similar length make F nearly linear, so start from the
+    // interpolated position and gallop outwards (two or three dependent loads instead of log2(n_sent)), then bisect.
+    const uint64_t total = F(n_sent);
+    uint64_t g = total ? uint64_t((unsigned __int128)(target) * n_sent / total) : 0;
+    if (g > n_sent) g = n_sent;
+    uint64_t lo, hi;
+    if (F(g) >= target) {          // answer <= g: gallop down to an i with F(i) < target (or 0)
+        hi = g;
+        uint64_t w = 1;
+        lo = 0;
+        while (hi - lo > 0) {
+            const uint64_t p = g >= w ? g - w : 0;
+            if (F(p) < target) { lo = p + 1; break; }
+            hi = p;
+            if (p == 0) { lo = 0; break; }
+            w <<= 2;
+        }
+    } else {                       // answer > g: gallop up to an i with F(i) >= target (n_sent at the latest)
+        lo = g + 1;
+        uint64_t w = 1;
+        hi = n_sent;
+        for (;;) {
+            const uint64_t p = g + w < n_sent ? g + w : n_sent;
+            if (F(p) >= target) { hi = p; break; }
+            lo = p + 1;
+            if (p == n_sent) { hi = n_sent; break; }
+            w <<= 2;
+        }
+    }
     while (lo < hi) {
         const uint64_t mid = (lo + hi) >> 1;
-        if (ooff[mid] + mid * uint64_t(1 + pad) >= target) hi = mid; else lo = mid + 1;
+        if (F(mid) >= target) hi = mid; else lo = mid + 1;
     }
     tile_first[t] = t == n_tiles ? uint32_t(n_sent) : uint32_t(lo);
 }
