@@ -72,6 +72,7 @@ def main():
     ap.add_argument("--model-scale", type=float, default=1.0)
     ap.add_argument("--predict-tags", action="store_true", help="Predictor::new(model, true): the reference's BoundaryTag scorers (boundary scores only)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--time-tags", action="store_true", help="with --predict-tags: also time vpt_fill_tags_batch_device (extra JSON field `tags`)")
     ap.add_argument("--phases", action="store_true", help="diagnostics: per-phase shader cycles of the scoring kernel (slows it)")
     args = ap.parse_args()
 
@@ -138,6 +139,39 @@ def main():
     phases = batch.phase_cycles() if args.phases else None
     elapsed, total_boundaries = vdist.reduce_throughput(elapsed, float(nb), device=dev)
 
+    tags_info = None
+    if args.time_tags and args.predict_tags and predictor.n_tags() > 0:
+        nt = predictor.n_tags()
+        d_tags = torch.empty((nb + S) * nt + 1, dtype=torch.int32, device=dev)
+
+        def tag_step():
+            batch.fill_tags(d_text.data_ptr(), d_boff.data_ptr(), d_ooff.data_ptr(), S, nb, d_labels.data_ptr(), d_tags.data_ptr(), stream)
+
+        for _ in range(max(1, args.warmup)):
+            tag_step()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            tag_step()
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / args.steps
+        lab = d_labels[:nb].cpu().numpy()
+        n_tokens = int((lab == 1).sum()) + S
+        tags_info = {"ms_per_step": 1e3 * dt, "tokens_per_s": n_tokens / dt, "chars_per_s": (nb + S) / dt, "n_tags": nt,
+                     "note": "decode_chars_kernel + tag_tokens_kernel on the predicted labels (first, untuned mapping)"}
+        if not args.no_cpu_baseline and rank == 0:
+            from oracle import cbind as _cb
+            o = _cb.OraclePredictor(model_bytes, True)
+            got = d_tags[:(nb + S) * nt].cpu().numpy().reshape(nb + S, nt)
+            text = bytes(utf8)
+            ok = True
+            for i in range(0, S, max(1, S // 200)):    # a 200-sentence sample against the oracle
+                t = text[int(boff[i]):int(boff[i + 1])].decode("utf-8")
+                a = int(ooff[i])
+                want, _ = o.predict_tags(t, labels=lab[a:a + len(t) - 1])
+                ok = ok and bool(np.array_equal(got[a + i:a + i + len(t)], want))
+            tags_info["parity_sample"] = ok
+
     if rank == 0:
         out = {
             "metric": "boundary scores/sec", "value": total_boundaries * args.steps / elapsed, "unit": "boundaries/s",
@@ -193,6 +227,8 @@ def main():
             out["roofline"] = {"bound": "hbm", "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None,
                                "traffic": None, "kernel": kernel_name, "kernel_ms": kernel_ms}
         out["cpu_baseline"] = cpu
+        if tags_info is not None:
+            out["tags"] = tags_info
         print(json.dumps(out))
     if world > 1:
         dist.barrier()
