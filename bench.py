@@ -180,10 +180,10 @@ def main():
             "config": {"workload": "%s: %s model, %d sentences x %d..%d chars per GPU per step, inputs resident in HBM"
                        % (("configs[1]" if (args.model_kind, args.sentences, args.min_len, args.max_len) == (1, 100000, 64, 64)
                            else "configs[%d]-shaped" % {1: 1, 2: 3, 3: 4}[args.model_kind]), model_name, S, args.min_len, args.max_len),
-                       "model": model_name, "sentences_per_gpu": S, "boundaries_per_gpu": nb, "text_bytes_per_gpu": nbytes,
+                       "tokenizer_model": model_name, "sentences_per_gpu": S, "boundaries_per_gpu": nb, "text_bytes_per_gpu": nbytes,
                        "char_ngrams": info["n_char_ngrams"], "dict_words": info["n_dict_words"],
                        "table_bytes": info["device_table_bytes"], "hot_table_bytes": info["hot_table_bytes"],
-                       "packed_tables": bool(info["packed"]), "tiles": n_tiles, "parallelism": "sentence shards x%d" % world},
+                       "packed_tables": bool(info["packed"]), "tiles": n_tiles, "sharding": "sentences x%d ranks, no data-path collective" % world},
         }
         if phases is not None:
             tot = float(sum(phases[:5])) or 1.0
