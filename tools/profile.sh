@@ -1,6 +1,6 @@
 #!/bin/bash
 # Runs on the GPU box (via gpurun): rocprofv3 kernel trace + PMC passes of the bench command.
-# Usage: tools_profile.sh <tag> [bench args...]     (extra counter groups: env VPT_PMC_GROUPS="A B|C D")
+# Usage: tools/profile.sh <tag> [bench args...]     (extra counter groups: env VPT_PMC_GROUPS="A B|C D")
 set -u
 TAG=$1; shift
 REPO=$(pwd)
