@@ -1,0 +1,53 @@
+"""Randomised GPU-vs-oracle sweep (run on the GPU box from the repo root: `python tools/fuzz_gpu.py [seconds]`).
+Random models (alphabet size, pattern counts, windows, word lengths, wide weights, tag models) and random ragged
+batches with the label post-filters / fullwidth flag toggled; stops at the first mismatch."""
+import os
+import random
+import sys
+import time
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from oracle import cbind  # noqa: E402
+from tests import randmodel  # noqa: E402
+from vaporetto_amd import api  # noqa: E402
+from vaporetto_amd.modelfmt import encode_model  # noqa: E402
+
+budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
+t_end = time.time() + budget
+seed = n_models = n_sent = 0
+f = api.KyteaFullwidthFilter()
+while time.time() < t_end:
+    seed += 1
+    rng = random.Random(seed)
+    alpha = [chr(c) for c in range(0x3041, 0x3041 + rng.choice([3, 6, 12, 30]))] + rng.sample(list("漢字AZ09az-.、。ｱ￾𠮷"), rng.randint(0, 6))
+    m = randmodel.rand_model(9000 + seed, alphabet=alpha, wc=rng.choice([3, 3, 3, 2, 4]), wt=rng.choice([1, 2, 3, 4]),
+                             n_char=rng.choice([20, 200, 1500]), n_dict=rng.choice([0, 30, 400, 3000]), n_type=rng.choice([0, 10, 80]),
+                             max_word=rng.choice([2, 5, 9, 15]), big=(seed % 7 == 0), n_tag_models=rng.choice([0, 0, 10]))
+    raw = encode_model(m)
+    tags = bool(m.tag_models) and seed % 2 == 0
+    pred = api.Predictor(api.Model.read_slice(raw)[0], tags)
+    orc = cbind.OraclePredictor(raw, tags)
+    texts = randmodel.rand_sentences(seed, m, rng.choice([50, 800]), alphabet=alpha, max_len=rng.choice([5, 60, 400]))
+    if seed % 5 == 0:
+        texts.append("".join(rng.choice(alpha) for _ in range(rng.choice([1700, 5000]))))   # longer than a tile
+    fw = seed % 3 == 0
+    utf8, boff = api.pack_texts([t.encode("utf-8") for t in texts])
+    scores, labels, ooff = pred.predict_packed(utf8, boff, fullwidth=fw)
+    n_utf8, n_boff = api.pack_texts([(f.filter(t) if fw else t).encode("utf-8") for t in texts])
+    o_scores, o_labels, o_ooff, _ = orc.predict_batch(n_utf8, n_boff)
+    if not (np.array_equal(scores, o_scores) and np.array_equal(labels, o_labels) and np.array_equal(ooff, o_ooff)):
+        print("MISMATCH boundary scores: seed", seed, "info", pred.info())
+        sys.exit(1)
+    if tags:
+        got = pred.fill_tags_packed(utf8, boff, ooff, labels, fullwidth=fw)
+        for i, t in enumerate(texts[:40]):
+            a, b = int(ooff[i]), int(ooff[i + 1])
+            want, _ = orc.predict_tags(f.filter(t) if fw else t, labels=labels[a:b])
+            if not np.array_equal(got[a + i:a + i + len(t)], want):
+                print("MISMATCH tags: seed", seed, repr(t[:60]))
+                sys.exit(1)
+    n_models += 1
+    n_sent += len(texts)
+print("fuzz ok: %d models, %d sentences, no mismatch" % (n_models, n_sent))
