@@ -1,0 +1,146 @@
+// TEST INFRASTRUCTURE ONLY -- never part of the product, never loaded by vaporetto_amd.
+//
+// A minimal stand-in for <hip/hip_runtime.h> that lets g++ compile the kernel SOURCES of vaporetto_amd/csrc
+// (kernels*.hip) and the host side of the C ABI for the CPU, so that the `-m "not gpu"` tests can run the very
+// code the GPU runs -- the LDS tile layout, the wave stacks, the DPP exchanges -- against the oracle without a GPU
+// (tests/test_kernel_emu.py).  It is an interpreter of the execution MODEL, not a second implementation:
+//
+//   * a workgroup is `blockDim.x` fibers (hipemu.cpp) on one OS thread; a fiber runs until it reaches a
+//     cross-lane operation (__ballot, DPP, __shfl_up, wave barrier, __syncthreads), where it waits for the other
+//     lanes of its wave / workgroup.  Nothing else orders the lanes: code that silently relies on lock-step
+//     execution between two such points fails here (a stricter model than the hardware's);
+//   * "device memory" is host memory with red zones (checked on hipFree) filled with a poison pattern, and the
+//     dynamic LDS of every workgroup starts out as garbage;
+//   * workgroups run one after the other; streams are synchronous; events measure nothing.
+//
+// Only what vaporetto_amd/csrc uses is provided; anything else fails to compile or aborts with a message.
+#pragma once
+#include <cstddef>
+#include <cstdint>
+#include <cstdlib>
+#include <cstring>
+#include <functional>
+
+#define VPT_HIPEMU 1
+
+#define __global__
+#define __device__
+#define __host__
+#define __forceinline__ inline __attribute__((always_inline))
+#define __launch_bounds__(...)
+#define __shared__ static   /* static LDS: one workgroup runs at a time */
+// dynamic LDS: kernels declare it through VPT_DYNAMIC_LDS (device_common.h)
+#define VPT_DYNAMIC_LDS(name) unsigned char* const name = ::hipemu::dynamic_lds()
+// lock-step marker of the kernels (device_common.h): the lanes of the wave meet here
+#define VPT_WAVE_LOCKSTEP() ::hipemu::wave_sync()
+
+struct uint2 { uint32_t x, y; };
+struct uint4 { uint32_t x, y, z, w; } __attribute__((aligned(16)));
+static inline uint2 make_uint2(uint32_t x, uint32_t y) { return uint2{x, y}; }
+static inline uint4 make_uint4(uint32_t x, uint32_t y, uint32_t z, uint32_t w) { return uint4{x, y, z, w}; }
+struct dim3 {
+    unsigned x, y, z;
+    dim3(unsigned x_ = 1, unsigned y_ = 1, unsigned z_ = 1) : x(x_), y(y_), z(z_) {}
+};
+
+// ---------------------------------------------------------------------------------------------- runtime API
+typedef int hipError_t;
+enum { hipSuccess = 0, hipErrorInvalidValue = 1, hipErrorOutOfMemory = 2 };
+enum hipMemcpyKind { hipMemcpyHostToHost, hipMemcpyHostToDevice, hipMemcpyDeviceToHost, hipMemcpyDeviceToDevice };
+enum { hipStreamNonBlocking = 1 };
+struct hipemu_stream;
+struct hipemu_event;
+typedef hipemu_stream* hipStream_t;
+typedef hipemu_event* hipEvent_t;
+struct hipDeviceProp_t { int multiProcessorCount; };
+
+hipError_t hipGetDeviceCount(int* n);
+hipError_t hipSetDevice(int dev);
+hipError_t hipGetDeviceProperties(hipDeviceProp_t* prop, int dev);
+hipError_t hipMalloc(void** p, size_t bytes);
+hipError_t hipFree(void* p);
+hipError_t hipMemcpy(void* dst, const void* src, size_t bytes, hipMemcpyKind kind);
+hipError_t hipMemcpyAsync(void* dst, const void* src, size_t bytes, hipMemcpyKind kind, hipStream_t s);
+hipError_t hipMemset(void* dst, int value, size_t bytes);
+hipError_t hipMemsetAsync(void* dst, int value, size_t bytes, hipStream_t s);
+hipError_t hipStreamCreateWithFlags(hipStream_t* s, unsigned flags);
+hipError_t hipStreamDestroy(hipStream_t s);
+hipError_t hipStreamSynchronize(hipStream_t s);
+hipError_t hipDeviceSynchronize();
+hipError_t hipEventCreate(hipEvent_t* e);
+hipError_t hipEventDestroy(hipEvent_t e);
+hipError_t hipEventRecord(hipEvent_t e, hipStream_t s);
+hipError_t hipEventElapsedTime(float* ms, hipEvent_t a, hipEvent_t b);
+hipError_t hipGetLastError();
+const char* hipGetErrorString(hipError_t e);
+
+// ---------------------------------------------------------------------------------------------- execution model
+namespace hipemu {
+struct Idx { unsigned x, y, z; };
+extern Idx g_threadIdx, g_blockIdx, g_blockDim, g_gridDim;
+unsigned char* dynamic_lds();
+unsigned lane();                       // threadIdx.x & 63
+void run_grid(dim3 grid, dim3 block, size_t lds_bytes, const std::function<void()>& body);
+// collectives: every live lane of the wave (workgroup) must call them in the same order
+uint64_t ballot(bool pred);
+uint32_t dpp(uint32_t old, uint32_t src, unsigned ctrl, unsigned row_mask, unsigned bank_mask, bool bound_ctrl);
+uint32_t shfl_up(uint32_t v, unsigned delta);
+void wave_sync();
+void block_sync();
+uint64_t clock();
+}  // namespace hipemu
+
+#define threadIdx (::hipemu::g_threadIdx)
+#define blockIdx (::hipemu::g_blockIdx)
+#define blockDim (::hipemu::g_blockDim)
+#define gridDim (::hipemu::g_gridDim)
+
+#define hipLaunchKernelGGL(kernel, grid, block, lds, stream, ...) \
+    ::hipemu::run_grid((grid), (block), (lds), [=]() { kernel(__VA_ARGS__); })
+
+static inline void __syncthreads() { ::hipemu::block_sync(); }
+static inline uint64_t __ballot(int pred) { return ::hipemu::ballot(pred != 0); }
+static inline int __shfl_up(int v, unsigned d) { return int(::hipemu::shfl_up(uint32_t(v), d)); }
+static inline unsigned __shfl_up(unsigned v, unsigned d) { return ::hipemu::shfl_up(v, d); }
+static inline int __popc(uint32_t x) { return __builtin_popcount(x); }
+static inline int __popcll(uint64_t x) { return __builtin_popcountll(x); }
+static inline int __ffs(int x) { return __builtin_ffs(x); }
+static inline int __ffsll(long long x) { return __builtin_ffsll(x); }
+
+// atomics: one fiber runs at a time, so plain read-modify-write is atomic
+static inline int atomicAdd(int* p, int v) { int o = *p; *p = int(uint32_t(o) + uint32_t(v)); return o; }
+static inline unsigned atomicAdd(unsigned* p, unsigned v) { unsigned o = *p; *p = o + v; return o; }
+static inline unsigned long long atomicAdd(unsigned long long* p, unsigned long long v) { unsigned long long o = *p; *p = o + v; return o; }
+static inline unsigned atomicOr(unsigned* p, unsigned v) { unsigned o = *p; *p = o | v; return o; }
+#define __HIP_MEMORY_SCOPE_AGENT 0
+template <typename T, typename V> static inline T __hip_atomic_fetch_add(T* p, V v, int, int) {
+    T o = *p;
+    *p = T(uint32_t(o) + uint32_t(v));
+    return o;
+}
+template <typename T> static inline T __hip_atomic_load(const T* p, int, int) { return *p; }
+template <typename T, typename V> static inline void __hip_atomic_store(T* p, V v, int, int) { *p = T(v); }
+
+// the gfx950 builtins the kernels use
+#define __builtin_amdgcn_mov_dpp(src, ctrl, rm, bm, bc) int(::hipemu::dpp(0xDEADBEEFu, uint32_t(src), (ctrl), (rm), (bm), (bc)))
+#define __builtin_amdgcn_update_dpp(old, src, ctrl, rm, bm, bc) int(::hipemu::dpp(uint32_t(old), uint32_t(src), (ctrl), (rm), (bm), (bc)))
+#define __builtin_amdgcn_wave_barrier() ::hipemu::wave_sync()
+#define __builtin_amdgcn_s_memtime() ::hipemu::clock()
+static inline uint32_t hipemu_mbcnt_lo(uint32_t mask, uint32_t base) {
+    const unsigned l = ::hipemu::lane();
+    return base + uint32_t(__builtin_popcount(l >= 32 ? mask : mask & ((1u << l) - 1u)));
+}
+static inline uint32_t hipemu_mbcnt_hi(uint32_t mask, uint32_t base) {
+    const unsigned l = ::hipemu::lane();
+    return base + uint32_t(l <= 32 ? 0 : __builtin_popcount(mask & ((1u << (l - 32)) - 1u)));
+}
+#define __builtin_amdgcn_mbcnt_lo(mask, base) hipemu_mbcnt_lo((mask), (base))
+#define __builtin_amdgcn_mbcnt_hi(mask, base) hipemu_mbcnt_hi((mask), (base))
+static inline uint32_t hipemu_alignbyte(uint32_t hi, uint32_t lo, uint32_t sh) {
+    return uint32_t(((uint64_t(hi) << 32) | lo) >> (8 * (sh & 3u)));
+}
+static inline uint32_t hipemu_alignbit(uint32_t hi, uint32_t lo, uint32_t sh) {
+    return uint32_t(((uint64_t(hi) << 32) | lo) >> (sh & 31u));
+}
+#define __builtin_amdgcn_alignbyte(hi, lo, sh) hipemu_alignbyte((hi), (lo), (sh))
+#define __builtin_amdgcn_alignbit(hi, lo, sh) hipemu_alignbit((hi), (lo), (sh))

@@ -6,7 +6,7 @@ import numpy as np
 import pytest
 
 from oracle import cbind, spec
-from tests import kat, randmodel
+from tests import devmem, kat, randmodel
 from vaporetto_amd import api
 from vaporetto_amd.modelfmt import ModelData, NgramData, WordWeightRecord, encode_model
 
@@ -185,7 +185,6 @@ def test_batch_errors():
 def test_device_side_error_flags():
     """Device-resident entry point: the caller's offsets are trusted, so NUL / empty sentences / inconsistent
     offsets are detected by the kernel and reported at sync."""
-    import torch
     raw, _ = kat.load_fixture("model.bin")
     pred, _ = make_predictor(raw)
     batch = api.DeviceBatch(pred)
@@ -194,17 +193,16 @@ def test_device_side_error_flags():
         utf8, boff = api.pack_texts(raws)
         if ooff is None:
             ooff = np.cumsum([0] + [max(len(r.decode()) - 1, 0) for r in raws]).astype(np.uint64)
-        d_text = torch.from_numpy(np.concatenate([utf8, np.zeros(16, np.uint8)])).cuda()
-        d_boff = torch.from_numpy(boff.astype(np.int64)).cuda()
-        d_ooff = torch.from_numpy(np.asarray(ooff).astype(np.int64)).cuda()
+        d_text = devmem.put(np.concatenate([utf8, np.zeros(16, np.uint8)]))
+        d_boff = devmem.put(boff.astype(np.uint64))
+        d_ooff = devmem.put(np.asarray(ooff).astype(np.uint64))
         nb = int(ooff[-1])
-        d_scores = torch.zeros(nb + 1, dtype=torch.int32, device="cuda")
-        d_labels = torch.zeros(nb + 1, dtype=torch.uint8, device="cuda")
-        batch.predict(d_text.data_ptr(), d_boff.data_ptr(), d_ooff.data_ptr(), len(raws), nb,
-                      max(len(r) for r in raws), d_scores.data_ptr(), d_labels.data_ptr(),
-                      torch.cuda.current_stream().cuda_stream)
+        d_scores = devmem.zeros(nb + 1, np.int32)
+        d_labels = devmem.zeros(nb + 1, np.uint8)
+        batch.predict(d_text.ptr, d_boff.ptr, d_ooff.ptr, len(raws), nb, max(len(r) for r in raws), d_scores.ptr,
+                      d_labels.ptr, devmem.stream())
         batch.sync()
-        return d_scores[:nb].cpu().numpy()
+        return d_scores.get(nb)
 
     assert run(["まぁ良いだろう".encode()]).tolist() == kat.APPENDIX_SCORES[1][2]
     with pytest.raises(api.VaporettoError, match="must not contain NULL"):
@@ -410,25 +408,22 @@ def test_batch_properties_at_full_config_size():
 def test_understated_length_bounds_are_reported():
     """Device entry point: a sentence longer than the caller's max_sentence_bytes / max_sentence_chars is an error
     at sync (never a silent gap in the outputs)."""
-    import torch
     raw, _ = kat.load_fixture("model.bin")
     pred, orc = make_predictor(raw)
     texts = ["まぁ良いだろう" * 300, "まぁ社長は火星猫だ"] * 3      # 2100-char sentences need the long-sentence path
     utf8, boff = api.pack_texts([t.encode("utf-8") for t in texts])
     ooff = api.count_boundaries(utf8, boff)
     nb = int(ooff[-1])
-    d_text = torch.from_numpy(np.concatenate([utf8, np.zeros(16, np.uint8)])).cuda()
-    d_boff = torch.from_numpy(boff.astype(np.int64)).cuda()
-    d_ooff = torch.from_numpy(ooff.astype(np.int64)).cuda()
-    d_scores = torch.zeros(nb + 1, dtype=torch.int32, device="cuda")
-    d_labels = torch.zeros(nb + 1, dtype=torch.uint8, device="cuda")
-    stream = torch.cuda.current_stream().cuda_stream
+    d_text = devmem.put(np.concatenate([utf8, np.zeros(16, np.uint8)]))
+    d_boff = devmem.put(boff.astype(np.uint64))
+    d_ooff = devmem.put(ooff.astype(np.uint64))
+    d_scores = devmem.zeros(nb + 1, np.int32)
+    d_labels = devmem.zeros(nb + 1, np.uint8)
 
     def run(batch, max_bytes):
-        batch.predict(d_text.data_ptr(), d_boff.data_ptr(), d_ooff.data_ptr(), len(texts), nb, max_bytes,
-                      d_scores.data_ptr(), d_labels.data_ptr(), stream)
+        batch.predict(d_text.ptr, d_boff.ptr, d_ooff.ptr, len(texts), nb, max_bytes, d_scores.ptr, d_labels.ptr, devmem.stream())
         batch.sync()
-        return d_scores[:nb].cpu().numpy()
+        return d_scores.get(nb)
 
     want = orc.predict_batch(utf8, boff)[0]
     true_bytes = int(np.max(np.diff(boff.astype(np.int64))))
@@ -613,7 +608,6 @@ def test_label_post_filters_on_device(alphabet_name):
 def test_device_resident_predict_then_fill_tags():
     """The whole config-5 pipeline without leaving HBM: vpt_predict_batch_device -> vpt_fill_tags_batch_device on the
     labels it wrote, one stream; equals the host-buffer path."""
-    import torch
     m = randmodel.rand_model(830, alphabet="kana", wc=3, wt=3, n_tag_models=30, max_word=4, n_char=60, n_dict=60)
     raw = encode_model(m)
     pred = api.Predictor(api.Model.read_slice(raw)[0], True)
@@ -623,17 +617,16 @@ def test_device_resident_predict_then_fill_tags():
     scores, labels, ooff = pred.predict_packed(utf8, boff)
     want = pred.fill_tags_packed(utf8, boff, ooff, labels)
     nb, S = int(ooff[-1]), len(texts)
-    d_text = torch.from_numpy(np.concatenate([utf8, np.zeros(16, np.uint8)])).cuda()
-    d_boff = torch.from_numpy(boff.astype(np.int64)).cuda()
-    d_ooff = torch.from_numpy(ooff.astype(np.int64)).cuda()
-    d_scores = torch.zeros(nb + 1, dtype=torch.int32, device="cuda")
-    d_labels = torch.zeros(nb + 1, dtype=torch.uint8, device="cuda")
-    d_tags = torch.zeros((nb + S) * nt + 1, dtype=torch.int32, device="cuda")
+    d_text = devmem.put(np.concatenate([utf8, np.zeros(16, np.uint8)]))
+    d_boff = devmem.put(boff.astype(np.uint64))
+    d_ooff = devmem.put(ooff.astype(np.uint64))
+    d_scores = devmem.zeros(nb + 1, np.int32)
+    d_labels = devmem.zeros(nb + 1, np.uint8)
+    d_tags = devmem.zeros((nb + S) * nt + 1, np.int32)
     batch = api.DeviceBatch(pred)
-    stream = torch.cuda.current_stream().cuda_stream
-    batch.predict(d_text.data_ptr(), d_boff.data_ptr(), d_ooff.data_ptr(), S, nb, int(np.max(np.diff(boff.astype(np.int64)))),
-                  d_scores.data_ptr(), d_labels.data_ptr(), stream)
-    batch.fill_tags(d_text.data_ptr(), d_boff.data_ptr(), d_ooff.data_ptr(), S, nb, d_labels.data_ptr(), d_tags.data_ptr(), stream)
+    batch.predict(d_text.ptr, d_boff.ptr, d_ooff.ptr, S, nb, int(np.max(np.diff(boff.astype(np.int64)))), d_scores.ptr,
+                  d_labels.ptr, devmem.stream())
+    batch.fill_tags(d_text.ptr, d_boff.ptr, d_ooff.ptr, S, nb, d_labels.ptr, d_tags.ptr, devmem.stream())
     batch.sync()
-    assert np.array_equal(d_scores[:nb].cpu().numpy(), scores) and np.array_equal(d_labels[:nb].cpu().numpy(), labels)
-    assert np.array_equal(d_tags[:(nb + S) * nt].cpu().numpy().reshape(nb + S, nt), want)
+    assert np.array_equal(d_scores.get(nb), scores) and np.array_equal(d_labels.get(nb), labels)
+    assert np.array_equal(d_tags.get((nb + S) * nt).reshape(nb + S, nt), want)

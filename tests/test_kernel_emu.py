@@ -1,0 +1,87 @@
+"""The kernel SOURCES, run on the CPU: `tests/emu.py` compiles vaporetto_amd/csrc (the HIP kernels and the host side
+of the C ABI, unchanged) with g++ against `tests/native/hipemu`, an emulator of the HIP execution model (fibers for
+lanes; ballots, DPP, barriers, LDS, device allocations with red zones), and the GPU parity tests are then run against
+that library.  What this pins without a GPU: the tile layout, the decode, the wave stacks and replays, the packed /
+general / long-sentence paths, the tag kernels and the device-side error flags -- against the oracle, bit for bit.
+What it cannot pin: anything about gfx950 itself (code generation, memory model, timing); `-m gpu` does that.
+
+TEST INFRASTRUCTURE: the emulated library is loaded here and nowhere else; the product (`vaporetto_amd`) has no CPU
+path and `tests/test_host_cabi.py::test_no_gpu_fails_loudly` keeps checking that."""
+import numpy as np
+import pytest
+
+from tests import devmem, emu
+from tests import test_gpu_parity as G
+from vaporetto_amd import _lib, api
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _kernels_on_the_emulator():
+    lib = emu.load()
+    saved = _lib._lib
+    _lib._lib = lib
+    devmem.EMULATED = True
+    yield
+    devmem.EMULATED = False
+    _lib._lib = saved
+
+
+def test_the_emulated_library_is_the_one_in_use():
+    assert b"gfx950" in _lib.load().vpt_version()       # same sources, same version string
+    assert _lib.load()._name.endswith("libvaporetto_emu.so")
+
+
+# every GPU parity test that finishes in seconds on the emulator, as is
+_AS_IS = [
+    "test_boundary_kats", "test_predict_boundaries_like_reference", "test_fixture_splits", "test_appendix_scores",
+    "test_sentence_reuse_and_overwrite", "test_random_models_vs_oracle", "test_window_sizes",
+    "test_predict_tags_variant_same_scores", "test_ragged_and_edge_lengths", "test_ascii_and_four_byte_text",
+    "test_packed_text_with_non_bmp_and_noncharacters", "test_batch_errors", "test_device_side_error_flags",
+    "test_many_batches_through_one_predictor", "test_fast_and_general_kernels_agree_with_oracle",
+    "test_packed_path_is_used_and_handles_wide_rows", "test_dense_packed_tables",
+    "test_long_dictionary_words_cross_tile_sized_sentences", "test_very_long_words_and_compressed_chains",
+    "test_non_bmp_pattern_models_use_the_general_tables", "test_long_type_ngrams_use_the_window_table",
+    "test_type_rows_and_window_table_agree_with_oracle", "test_understated_length_bounds_are_reported",
+    "test_tag_enabled_model_with_duplicate_type_ngrams_runs_on_the_packed_path", "test_predict_tags_like_reference",
+    "test_fill_tags_requires_predict_tags_gpu", "test_fixture_tags_gpu", "test_random_tag_models_match_oracle",
+    "test_converted_kytea_fixture_on_gpu", "test_fullwidth_filter_on_device", "test_label_post_filters_on_device",
+    "test_device_resident_predict_then_fill_tags",
+]
+for _name in _AS_IS:
+    globals()[_name] = getattr(G, _name)
+del _name
+
+
+def test_every_gpu_parity_test_is_accounted_for():
+    """A new GPU parity test must be added to _AS_IS or to the sized-down list below."""
+    sized_down = {"test_synthetic_configs_match_oracle", "test_batch_properties_at_full_config_size",
+                  "test_concurrent_host_threads_share_a_predictor"}
+    have = {n for n in dir(G) if n.startswith("test_") and callable(getattr(G, n))}
+    assert have == set(_AS_IS) | sized_down, have ^ (set(_AS_IS) | sized_down)
+
+
+@pytest.mark.parametrize("kind,scale,min_len,max_len,n", [(1, 0.02, 64, 64, 1500), (2, 0.02, 8, 512, 400), (2, 0.02, 1, 40, 2000)])
+def test_synthetic_configs_sized_down(kind, scale, min_len, max_len, n):
+    G.test_synthetic_configs_match_oracle(kind, scale, min_len, max_len, n)
+
+
+def test_halves_and_permutation_sized_down():
+    """test_batch_properties_at_full_config_size on 3 000 sentences."""
+    from vaporetto_amd import synth
+    raw = synth.synth_model(1, synth.SEED_BASE + 2, 0.02)
+    n = 3000
+    utf8, boff = synth.synth_sentences(raw, n, 64, 64, seed=synth.SEED_BASE + 2)
+    pred = api.Predictor(api.Model.read_slice(raw)[0], False)
+    scores, labels, _ = pred.predict_packed(utf8, boff)
+    assert len(scores) == 63 * n and np.array_equal(labels, (scores > 0).astype(np.uint8))
+    h = n // 2
+    cut = int(boff[h])
+    s1, _, _ = pred.predict_packed(utf8[:cut], boff[:h + 1])
+    s2, _, _ = pred.predict_packed(utf8[cut:], boff[h:] - boff[h])
+    assert np.array_equal(np.concatenate([s1, s2]), scores)
+    perm = np.random.default_rng(5).permutation(n)
+    parts = [utf8[int(boff[i]):int(boff[i + 1])] for i in perm]
+    p_utf8 = np.concatenate(parts)
+    p_boff = np.concatenate([[0], np.cumsum([len(p) for p in parts])]).astype(np.uint64)
+    ps, _, _ = pred.predict_packed(p_utf8, p_boff)
+    assert np.array_equal(ps.reshape(n, 63), scores.reshape(n, 63)[perm])

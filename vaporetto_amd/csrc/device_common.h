@@ -4,6 +4,19 @@
 
 #include <cstdint>
 
+// the workgroup's dynamic LDS as a byte array (the CPU emulator of tests/native/hipemu supplies its own definition)
+#ifndef VPT_DYNAMIC_LDS
+#define VPT_DYNAMIC_LDS(name) extern __shared__ __attribute__((aligned(16))) unsigned char name[]
+#endif
+
+// The lanes of a wave execute in lock step, so an LDS write by one lane is visible to the next instruction of
+// every other lane of that wave.  Where the kernels rely on that WITHOUT a cross-lane operation in between, they say
+// so with this marker: nothing on the GPU, a wave rendezvous in the emulator (whose lanes are only ordered by
+// cross-lane operations).
+#ifndef VPT_WAVE_LOCKSTEP
+#define VPT_WAVE_LOCKSTEP() ((void)0)
+#endif
+
 namespace vpt {
 
 // CharacterType::get_type (sentence.rs:50-67): 1 Digit, 2 Roman, 3 Hiragana, 4 Katakana, 5 Kanji, 6 Other

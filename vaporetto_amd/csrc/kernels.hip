@@ -352,7 +352,7 @@ __global__ void assign_tiles_kernel(const uint64_t* __restrict__ ooff, uint64_t 
 
 template <int kChunks>
 __global__ __launch_bounds__(kThreads) void score_tiles_kernel(const ScoreParams P) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    VPT_DYNAMIC_LDS(smem);
     TileMem<true> M;
     M.sym = reinterpret_cast<uint32_t*>(smem);
     M.score = reinterpret_cast<int32_t*>(M.sym + (kCap + kMargin));

@@ -137,6 +137,7 @@ __device__ __forceinline__ void add_child(int32_t* score, uint32_t st, uint32_t 
 // The home entry and the next one are read together (a mini-table keeps a quarter of its entries free, so nearly
 // every search ends within two); the rare longer search loops.
 __device__ __forceinline__ void replay_w(const PackedView& K, FastLds& L, WaveStacks& Q, int lane) {
+    VPT_WAVE_LOCKSTEP();   // the queue entries were written by other lanes
     const uint32_t take = Q.nw < 64u ? Q.nw : 64u;
     Q.nw -= take;
     const bool have = uint32_t(lane) < take;
@@ -230,6 +231,7 @@ __device__ __forceinline__ bool general_row(const PatternTableView& T, uint64_t 
 // O: up to 64 queued overflow-child probes: c3 = sym[s + 2] in the mini-table `ref` of `kids3` (two entries at once,
 // as in replay_w).
 __device__ __forceinline__ void replay_o(const PackedView& K, const PatternTableView& T, FastLds& L, WaveStacks& Q, int lane) {
+    VPT_WAVE_LOCKSTEP();   // the queue entries were written by other lanes
     const uint32_t take = Q.no < 64u ? Q.no : 64u;
     Q.no -= take;
     const bool have = uint32_t(lane) < take;
@@ -334,6 +336,7 @@ __device__ __forceinline__ void drain_wo(const PackedView& K, const PatternTable
 //   kWide*:   a row with a value outside i16 -- taken from the general tables (i32).
 __device__ __forceinline__ void replay_m(const PackedView& K, const PatternTableView& T, FastLds& L, WaveStacks& Q, int lane) {
     drain_wo(K, T, L, Q, lane, kQHigh);  // room for this call's pushes
+    VPT_WAVE_LOCKSTEP();   // the queue entries were written by other lanes
     const uint32_t take = Q.nm < 64u ? Q.nm : 64u;
     Q.nm -= take;
     const bool have = uint32_t(lane) < take;
@@ -395,7 +398,7 @@ template <int TM, bool DBG>
 __global__ __launch_bounds__(kThreads, 5) void score_tiles_fast_kernel(const ScoreParams P_in) {
     ScoreParams P = P_in;
     if (!DBG) { P.debug = 0; P.prof = nullptr; }
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    VPT_DYNAMIC_LDS(smem);
     FastLds& L = *reinterpret_cast<FastLds*>(smem);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     constexpr uint32_t pad = 3;
