@@ -21,6 +21,7 @@ def build_emulated() -> str:
     if os.path.exists(LIB) and all(os.path.getmtime(d) <= os.path.getmtime(LIB) for d in deps):
         return LIB
     cmd = ["g++", "-O1", "-g", "-std=c++17", "-fPIC", "-shared", "-Wall", "-Wno-unused-function", "-Wno-unknown-pragmas",
+           "-Wl,-Bsymbolic",   # its hip* definitions bind locally even if a real HIP runtime is loaded in the process
            "-I" + EMU, "-o", LIB]
     cmd += [s for s in srcs if s.endswith(".cpp")] + ["-x", "c++"] + [s for s in srcs if s.endswith(".hip")]
     cmd += ["-x", "none", _EMU_FILES[0]]

@@ -630,3 +630,37 @@ def test_device_resident_predict_then_fill_tags():
     batch.sync()
     assert np.array_equal(d_scores.get(nb), scores) and np.array_equal(d_labels.get(nb), labels)
     assert np.array_equal(d_tags.get((nb + S) * nt).reshape(nb + S, nt), want)
+
+
+def test_fill_tags_with_offsets_that_do_not_match_the_text():
+    """The tag entry points trust the caller's out_offsets as little as predict does: offsets that promise fewer (or
+    more) chars than the text holds are an error, never a write outside the batch's arrays."""
+    m = randmodel.rand_model(831, alphabet="kana", wc=3, wt=3, n_tag_models=10, max_word=4, n_char=40, n_dict=40)
+    pred = api.Predictor(api.Model.read_slice(encode_model(m))[0], True)
+    texts = randmodel.rand_sentences(3, m, 40, alphabet="kana", max_len=30)
+    utf8, boff = api.pack_texts([t.encode("utf-8") for t in texts])
+    _, labels, ooff = pred.predict_packed(utf8, boff)
+    want = pred.fill_tags_packed(utf8, boff, ooff, labels)
+    S, nb, nt = len(texts), int(ooff[-1]), pred.n_tags()
+    short = ooff.copy(); short[5:] -= 3              # sentence 4 is promised 3 chars fewer than it has
+    long_ = ooff.copy(); long_[7:] += 2              # sentence 6 two more
+    back = ooff.copy(); back[9] = back[8] - 1        # decreasing
+    for bad in (short, long_, back):
+        nlab = max(int(bad[-1]), nb)
+        lab = np.zeros(nlab + 1, np.uint8); lab[:nb] = labels
+        with pytest.raises(api.VaporettoError, match="do not match the text"):
+            pred.fill_tags_packed(utf8, boff, bad, lab)
+    # device-resident entry point: reported at sync, once; the workspace stays usable
+    d_text = devmem.put(np.concatenate([utf8, np.zeros(16, np.uint8)]))
+    d_boff = devmem.put(boff.astype(np.uint64))
+    d_labels = devmem.put(np.concatenate([labels, np.zeros(16, np.uint8)]))
+    d_tags = devmem.zeros((nb + S) * nt + 1, np.int32)
+    batch = api.DeviceBatch(pred)
+    d_bad = devmem.put(short.astype(np.uint64))
+    batch.fill_tags(d_text.ptr, d_boff.ptr, d_bad.ptr, S, int(short[-1]), d_labels.ptr, d_tags.ptr, devmem.stream())
+    with pytest.raises(api.VaporettoError, match="do not match the text"):
+        batch.sync()
+    d_ooff = devmem.put(ooff.astype(np.uint64))
+    batch.fill_tags(d_text.ptr, d_boff.ptr, d_ooff.ptr, S, nb, d_labels.ptr, d_tags.ptr, devmem.stream())
+    batch.sync()
+    assert np.array_equal(d_tags.get((nb + S) * nt).reshape(nb + S, nt), want)

@@ -448,7 +448,7 @@ vpt_status vpt_predict_batch_device(const vpt_predictor* p, vpt_batch* b, const 
                                     const uint64_t* d_out_offsets, size_t n_sentences, uint64_t total_boundaries,
                                     uint64_t max_sentence_bytes, int32_t* d_scores, uint8_t* d_labels, void* hip_stream) {
     if (!p || !b || b->pred != p) return fail(VPT_INVALID_ARGUMENT, "InvalidArgumentError: batch: does not belong to this predictor");
-    if (n_sentences == 0) { b->pending = false; b->last_tiles = 0; return VPT_OK; }
+    if (n_sentences == 0) { b->last_tiles = 0; return VPT_OK; }   // nothing enqueued; earlier work stays pending
     if (!d_utf8 || !d_byte_offsets || !d_out_offsets) return fail(VPT_INVALID_ARGUMENT, "InvalidArgumentError: NULL device pointer");
     if (n_sentences >= 0xFFFFFFFFull) return fail(VPT_INVALID_ARGUMENT, "InvalidArgumentError: n_sentences: at most 2^32-2 per call");
     hipStream_t stream = static_cast<hipStream_t>(hip_stream);
@@ -529,6 +529,7 @@ vpt_status vpt_batch_sync(vpt_batch* b) {
     VPT_HIP(hipMemcpyAsync(ctrl, b->d_ctrl, sizeof(ctrl), hipMemcpyDeviceToHost, b->last_stream));
     VPT_HIP(hipStreamSynchronize(b->last_stream));
     b->pending = false;
+    if (ctrl[0]) VPT_HIP(hipMemset(b->d_ctrl, 0, sizeof(uint32_t)));   // reported once (a predict call clears it too)
     return status_from_bits(ctrl[0]);
 }
 
@@ -638,10 +639,12 @@ vpt_status vpt_fill_tags_batch_flags(const vpt_predictor* p, const uint8_t* utf8
             return fail(VPT_INVALID_ARGUMENT, "InvalidArgumentError: text: must contain at least one character");
     VPT_HIP(hipSetDevice(p->device));
     struct Bufs {
-        uint8_t *text = nullptr, *labels = nullptr; uint64_t *boff = nullptr, *ooff = nullptr; uint32_t* cps = nullptr; int32_t* tags = nullptr;
+        uint8_t *text = nullptr, *labels = nullptr; uint64_t *boff = nullptr, *ooff = nullptr; uint32_t *cps = nullptr, *status = nullptr;
+        int32_t* tags = nullptr;
         hipStream_t s = nullptr;
         ~Bufs() {
             (void)hipFree(text); (void)hipFree(labels); (void)hipFree(boff); (void)hipFree(ooff); (void)hipFree(cps); (void)hipFree(tags);
+            (void)hipFree(status);
             if (s) (void)hipStreamDestroy(s);
         }
     } B;
@@ -655,21 +658,26 @@ vpt_status vpt_fill_tags_batch_flags(const vpt_predictor* p, const uint8_t* utf8
     VPT_HIP(hipMalloc(reinterpret_cast<void**>(&B.ooff), 8 * (n_sentences + 1)));
     VPT_HIP(hipMalloc(reinterpret_cast<void**>(&B.cps), 4 * size_t(total_c) + 64));
     VPT_HIP(hipMalloc(reinterpret_cast<void**>(&B.tags), tag_bytes + 64));
+    VPT_HIP(hipMalloc(reinterpret_cast<void**>(&B.status), 64));
+    VPT_HIP(hipMemsetAsync(B.status, 0, 64, B.s));
     VPT_HIP(hipMemcpyAsync(B.text, utf8 + t0, size_t(t1 - t0), hipMemcpyHostToDevice, B.s));
     if (total_b) VPT_HIP(hipMemcpyAsync(B.labels, labels + out_offsets[0], size_t(total_b), hipMemcpyHostToDevice, B.s));
     VPT_HIP(hipMemcpyAsync(B.boff, boff.data(), 8 * (n_sentences + 1), hipMemcpyHostToDevice, B.s));
     VPT_HIP(hipMemcpyAsync(B.ooff, ooff.data(), 8 * (n_sentences + 1), hipMemcpyHostToDevice, B.s));
     VPT_HIP(hipMemsetAsync(B.tags, 0xFF, tag_bytes, B.s));   // -1 = None
     const uint32_t* cinfo = p->d_cinfo + ((flags & VPT_FLAG_KYTEA_FULLWIDTH) ? 65536 : 0);
-    VPT_HIP(vpt::launch_decode_chars(B.text, B.boff, B.ooff, n_sentences, cinfo, B.cps, B.s));
+    VPT_HIP(vpt::launch_decode_chars(B.text, B.boff, B.ooff, n_sentences, total_c, cinfo, B.cps, B.status, B.s));
     vpt::TagParams T{};
     T.tok_tab = p->dtag.tok_tab; T.models = p->dtag.models; T.ngrams = p->dtag.ngrams; T.syms = p->dtag.syms; T.slots = p->dtag.slots;
     T.weights = p->dtag.weights; T.cinfo = cinfo; T.tok_bits = p->tok_bits; T.n_tags = p->n_tags;
     T.use_char = p->tag_use_char ? 1u : 0u; T.use_type = p->tag_use_type ? 1u : 0u;
-    T.cps = B.cps; T.ooff = B.ooff; T.labels = B.labels; T.n_sent = n_sentences; T.tags = B.tags;
+    T.cps = B.cps; T.ooff = B.ooff; T.labels = B.labels; T.n_sent = n_sentences; T.total_chars = total_c; T.tags = B.tags;
     VPT_HIP(vpt::launch_tag_tokens(T, B.s));
-    VPT_HIP(hipMemcpyAsync(tags_out + size_t(out_offsets[0] + 0) * p->n_tags, B.tags, tag_bytes, hipMemcpyDeviceToHost, B.s));
+    uint32_t bits = 0;
+    VPT_HIP(hipMemcpyAsync(&bits, B.status, sizeof(bits), hipMemcpyDeviceToHost, B.s));
     VPT_HIP(hipStreamSynchronize(B.s));
+    if (bits) return status_from_bits(bits);
+    VPT_HIP(hipMemcpy(tags_out + size_t(out_offsets[0]) * p->n_tags, B.tags, tag_bytes, hipMemcpyDeviceToHost));
     return VPT_OK;
 }
 
@@ -688,12 +696,12 @@ vpt_status vpt_fill_tags_batch_device(const vpt_predictor* p, vpt_batch* b, cons
     if (st != VPT_OK) return st;
     const uint32_t* cinfo = p->d_cinfo + ((b->flags & VPT_FLAG_KYTEA_FULLWIDTH) ? 65536 : 0);
     VPT_HIP(hipMemsetAsync(d_tags_out, 0xFF, size_t(total_c) * p->n_tags * sizeof(int32_t), stream));   // -1 = None
-    VPT_HIP(vpt::launch_decode_chars(d_utf8, d_byte_offsets, d_out_offsets, n_sentences, cinfo, b->d_cps, stream));
+    VPT_HIP(vpt::launch_decode_chars(d_utf8, d_byte_offsets, d_out_offsets, n_sentences, total_c, cinfo, b->d_cps, b->d_ctrl, stream));
     vpt::TagParams T{};
     T.tok_tab = p->dtag.tok_tab; T.models = p->dtag.models; T.ngrams = p->dtag.ngrams; T.syms = p->dtag.syms; T.slots = p->dtag.slots;
     T.weights = p->dtag.weights; T.cinfo = cinfo; T.tok_bits = p->tok_bits; T.n_tags = p->n_tags;
     T.use_char = p->tag_use_char ? 1u : 0u; T.use_type = p->tag_use_type ? 1u : 0u;
-    T.cps = b->d_cps; T.ooff = d_out_offsets; T.labels = d_labels; T.n_sent = n_sentences; T.tags = d_tags_out;
+    T.cps = b->d_cps; T.ooff = d_out_offsets; T.labels = d_labels; T.n_sent = n_sentences; T.total_chars = total_c; T.tags = d_tags_out;
     VPT_HIP(vpt::launch_tag_tokens(T, stream));
     b->last_stream = stream; b->pending = true;
     return VPT_OK;

@@ -63,10 +63,11 @@ struct TagParams {
     const uint64_t* ooff;       // [S+1]
     const uint8_t* labels;      // [total boundaries] CharacterBoundary values (0, 1, 2 = Unknown)
     uint64_t n_sent;
+    uint64_t total_chars;       // total boundaries + S: what `cps` and `tags / n_tags` hold
     int32_t* tags;              // [(total boundaries + S) * n_tags] candidate index per slot, -1 = None
 };
-hipError_t launch_decode_chars(const uint8_t* text, const uint64_t* boff, const uint64_t* ooff, uint64_t n_sent, const uint32_t* cinfo,
-                               uint32_t* cps, hipStream_t stream);
+hipError_t launch_decode_chars(const uint8_t* text, const uint64_t* boff, const uint64_t* ooff, uint64_t n_sent, uint64_t total_chars,
+                               const uint32_t* cinfo, uint32_t* cps, uint32_t* status, hipStream_t stream);
 hipError_t launch_tag_tokens(const TagParams& P, hipStream_t stream);
 
 size_t score_tiles_lds_bytes();

@@ -29,31 +29,40 @@ __device__ __forceinline__ uint32_t lanes_below(uint64_t mask, int lane) {
     return uint32_t(__popcll(mask & ((uint64_t(1) << lane) - 1)));
 }
 
+// `total_chars` = chars the caller's offsets promise for the whole batch (the size of `cps`): offsets that do not match
+// the text raise kErrBadOffsets instead of writing outside it
 __global__ __launch_bounds__(kTagThreads) void decode_chars_kernel(const uint8_t* __restrict__ text, const uint64_t* __restrict__ boff,
-                                                                   const uint64_t* __restrict__ ooff, uint64_t n_sent,
-                                                                   const uint32_t* __restrict__ cinfo, uint32_t* __restrict__ cps) {
+                                                                   const uint64_t* __restrict__ ooff, uint64_t n_sent, uint64_t total_chars,
+                                                                   const uint32_t* __restrict__ cinfo, uint32_t* __restrict__ cps,
+                                                                   uint32_t* __restrict__ status) {
     const int lane = threadIdx.x & 63;
     const uint64_t wave = uint64_t(blockIdx.x) * kTagWaves + (threadIdx.x >> 6);
     const uint64_t n_waves = uint64_t(gridDim.x) * kTagWaves;
     for (uint64_t i = wave; i < n_sent; i += n_waves) {
         const uint64_t b0 = boff[i], b1 = boff[i + 1];
-        uint64_t g = ooff[i] + i;  // first char of the sentence in the flat char array
-        for (uint64_t pos = b0; pos < b1; pos += 64) {
+        const uint64_t o0 = ooff[i], o1 = ooff[i + 1];
+        const uint64_t g = o0 + i;  // first char of the sentence in the flat char array
+        const bool sane = o1 >= o0 && b1 >= b0 && o1 + i + 1 <= total_chars;
+        const uint64_t want = sane ? o1 - o0 + 1 : 0;   // chars of this sentence
+        uint64_t seen = 0;
+        for (uint64_t pos = b0; sane && pos < b1; pos += 64) {
             const uint64_t at = pos + uint64_t(lane);
             const bool in = at < b1;
             const uint32_t byte0 = in ? text[at] : 0x80u;
             const bool lead = in && (byte0 & 0xC0u) != 0x80u;
             const uint64_t m = __ballot(lead);
-            if (lead) {
+            const uint64_t idx = seen + lanes_below(m, lane);
+            if (lead && idx < want) {
                 uint32_t b4 = byte0;
                 if (byte0 >= 0xC0u && at + 1 < b1) b4 |= uint32_t(text[at + 1]) << 8;
                 if (byte0 >= 0xE0u && at + 2 < b1) b4 |= uint32_t(text[at + 2]) << 16;
                 if (byte0 >= 0xF0u && at + 3 < b1) b4 |= uint32_t(text[at + 3]) << 24;
                 const uint32_t cp = utf8_scalar(b4);
-                cps[g + lanes_below(m, lane)] = cp < 0x10000u ? cinfo[cp] & 0xFFFFu : cp;   // the scored char
+                cps[g + idx] = cp < 0x10000u ? cinfo[cp] & 0xFFFFu : cp;   // the scored char
             }
-            g += uint64_t(__popcll(m));
+            seen += uint64_t(__popcll(m));
         }
+        if (lane == 0 && (!sane || seen != want)) atomicOr(status, kErrBadOffsets);   // an empty sentence too (want >= 1)
     }
 }
 
@@ -74,6 +83,7 @@ __global__ __launch_bounds__(kTagThreads) void tag_tokens_kernel(const TagParams
     const uint32_t tok_mask = (1u << P.tok_bits) - 1u;
     for (uint64_t si = wave; si < P.n_sent; si += n_waves) {
         const uint64_t g0 = P.ooff[si] + si;                     // flat index of the sentence's first char
+        if (P.ooff[si + 1] < P.ooff[si] || P.ooff[si + 1] + si + 1 > P.total_chars) continue;   // reported by decode_chars_kernel
         const int64_t n = int64_t(P.ooff[si + 1] - P.ooff[si]) + 1;  // chars
         const uint32_t* cps = P.cps + g0;
         const uint8_t* lab = P.labels + P.ooff[si];              // n - 1 labels
@@ -169,11 +179,12 @@ __global__ __launch_bounds__(kTagThreads) void tag_tokens_kernel(const TagParams
 
 }  // namespace
 
-hipError_t launch_decode_chars(const uint8_t* text, const uint64_t* boff, const uint64_t* ooff, uint64_t n_sent, const uint32_t* cinfo,
-                               uint32_t* cps, hipStream_t stream) {
+hipError_t launch_decode_chars(const uint8_t* text, const uint64_t* boff, const uint64_t* ooff, uint64_t n_sent, uint64_t total_chars,
+                               const uint32_t* cinfo, uint32_t* cps, uint32_t* status, hipStream_t stream) {
     const uint64_t want = (n_sent + kTagWaves - 1) / kTagWaves;
     const uint32_t blocks = uint32_t(want < 1 ? 1 : want > 65536 ? 65536 : want);
-    hipLaunchKernelGGL(decode_chars_kernel, dim3(blocks), dim3(kTagThreads), 0, stream, text, boff, ooff, n_sent, cinfo, cps);
+    hipLaunchKernelGGL(decode_chars_kernel, dim3(blocks), dim3(kTagThreads), 0, stream, text, boff, ooff, n_sent, total_chars, cinfo, cps,
+                       status);
     return hipGetLastError();
 }
 
