@@ -85,6 +85,7 @@ void run_grid(dim3 grid, dim3 block, size_t lds_bytes, const std::function<void(
 uint64_t ballot(bool pred);
 uint32_t dpp(uint32_t old, uint32_t src, unsigned ctrl, unsigned row_mask, unsigned bank_mask, bool bound_ctrl);
 uint32_t shfl_up(uint32_t v, unsigned delta);
+uint32_t readfirstlane(uint32_t v);
 void wave_sync();
 void block_sync();
 uint64_t clock();
@@ -106,6 +107,7 @@ static inline int __popc(uint32_t x) { return __builtin_popcount(x); }
 static inline int __popcll(uint64_t x) { return __builtin_popcountll(x); }
 static inline int __ffs(int x) { return __builtin_ffs(x); }
 static inline int __ffsll(long long x) { return __builtin_ffsll(x); }
+static inline unsigned __umul24(unsigned a, unsigned b) { return (a & 0xFFFFFFu) * (b & 0xFFFFFFu); }
 
 // atomics: one fiber runs at a time, so plain read-modify-write is atomic
 static inline int atomicAdd(int* p, int v) { int o = *p; *p = int(uint32_t(o) + uint32_t(v)); return o; }
@@ -124,6 +126,7 @@ template <typename T, typename V> static inline void __hip_atomic_store(T* p, V 
 // the gfx950 builtins the kernels use
 #define __builtin_amdgcn_mov_dpp(src, ctrl, rm, bm, bc) int(::hipemu::dpp(0xDEADBEEFu, uint32_t(src), (ctrl), (rm), (bm), (bc)))
 #define __builtin_amdgcn_update_dpp(old, src, ctrl, rm, bm, bc) int(::hipemu::dpp(uint32_t(old), uint32_t(src), (ctrl), (rm), (bm), (bc)))
+#define __builtin_amdgcn_readfirstlane(x) int(::hipemu::readfirstlane(uint32_t(x)))
 #define __builtin_amdgcn_wave_barrier() ::hipemu::wave_sync()
 #define __builtin_amdgcn_s_memtime() ::hipemu::clock()
 static inline uint32_t hipemu_mbcnt_lo(uint32_t mask, uint32_t base) {

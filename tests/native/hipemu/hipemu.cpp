@@ -125,6 +125,14 @@ uint32_t shfl_up(uint32_t v, unsigned delta) {
     return (l >= delta && ((*who >> (l - delta)) & 1u)) ? b[l - delta] : v;
 }
 
+uint32_t readfirstlane(uint32_t v) {   // the value of the lowest lane that takes part
+    Wave& w = my_wave();
+    const uint64_t* who;
+    const uint32_t* b = w.deposit(lane(), v, &who);
+    arrive_and_wait(w);
+    return b[__builtin_ctzll(*who)];
+}
+
 // DPP controls as in the CDNA ISA manual ("DPP_CTRL"); a lane whose source is invalid or whose row/bank is masked
 // keeps `old` (or reads 0 with bound_ctrl when only the source is invalid)
 uint32_t dpp(uint32_t old, uint32_t src, unsigned ctrl, unsigned row_mask, unsigned bank_mask, bool bound_ctrl) {

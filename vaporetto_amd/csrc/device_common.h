@@ -19,6 +19,11 @@
 
 namespace vpt {
 
+// A value that every lane of the wave holds alike, moved to a scalar register.  The hardware gains nothing; the
+// COMPILER learns that branches and loop exits depending on it are wave-uniform, so it keeps counters in SGPRs and
+// emits scalar branches instead of exec-mask loops (thread ids and LDS loads are divergent as far as it can tell).
+__device__ __forceinline__ uint32_t wave_uniform(uint32_t x) { return uint32_t(__builtin_amdgcn_readfirstlane(int(x))); }
+
 // CharacterType::get_type (sentence.rs:50-67): 1 Digit, 2 Roman, 3 Hiragana, 4 Katakana, 5 Kanji, 6 Other
 __device__ __forceinline__ uint32_t char_type(uint32_t c) {
     if ((c - 0x30u) <= 9u || (c - 0xFF10u) <= 9u) return 1;

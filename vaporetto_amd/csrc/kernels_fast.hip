@@ -101,13 +101,13 @@ struct WaveStacks {
         const uint64_t m = __ballot(pred);
         if (m == 0) return;
         if (pred) q[nw + lane_rank(m)] = make_uint2(x, y);
-        nw += uint32_t(__popcll(m));
+        nw = wave_uniform(nw + uint32_t(__popcll(m)));
     }
     __device__ __forceinline__ void push_o(bool pred, uint32_t x, uint32_t y) {
         const uint64_t m = __ballot(pred);
         if (m == 0) return;
         if (pred) q[kQCap - 1 - (no + lane_rank(m))] = make_uint2(x, y);
-        no += uint32_t(__popcll(m));
+        no = wave_uniform(no + uint32_t(__popcll(m)));
     }
     __device__ __forceinline__ void push_m(bool pred, uint32_t x, uint32_t y) {
         const uint64_t m = __ballot(pred);
@@ -138,8 +138,8 @@ __device__ __forceinline__ void add_child(int32_t* score, uint32_t st, uint32_t 
 // every search ends within two); the rare longer search loops.
 __device__ __forceinline__ void replay_w(const PackedView& K, FastLds& L, WaveStacks& Q, int lane) {
     VPT_WAVE_LOCKSTEP();   // the queue entries were written by other lanes
-    const uint32_t take = Q.nw < 64u ? Q.nw : 64u;
-    Q.nw -= take;
+    const uint32_t take = wave_uniform(Q.nw < 64u ? Q.nw : 64u);   // opaque: nw - min(nw, 64) would become a VALU-only saturating subtract
+    Q.nw = wave_uniform(Q.nw - take);
     const bool have = uint32_t(lane) < take;
     const uint2 it = have ? Q.q[Q.nw + lane] : make_uint2(0u, 0u);
     const uint32_t s = it.x & 0x7FFu, depth = it.x >> 11;
@@ -232,8 +232,8 @@ __device__ __forceinline__ bool general_row(const PatternTableView& T, uint64_t 
 // as in replay_w).
 __device__ __forceinline__ void replay_o(const PackedView& K, const PatternTableView& T, FastLds& L, WaveStacks& Q, int lane) {
     VPT_WAVE_LOCKSTEP();   // the queue entries were written by other lanes
-    const uint32_t take = Q.no < 64u ? Q.no : 64u;
-    Q.no -= take;
+    const uint32_t take = wave_uniform(Q.no < 64u ? Q.no : 64u);
+    Q.no = wave_uniform(Q.no - take);
     const bool have = uint32_t(lane) < take;
     const uint2 it = have ? Q.q[kQCap - 1 - (Q.no + lane)] : make_uint2(0u, 0u);
     const uint32_t s = it.x;
@@ -337,7 +337,7 @@ __device__ __forceinline__ void drain_wo(const PackedView& K, const PatternTable
 __device__ __forceinline__ void replay_m(const PackedView& K, const PatternTableView& T, FastLds& L, WaveStacks& Q, int lane) {
     drain_wo(K, T, L, Q, lane, kQHigh);  // room for this call's pushes
     VPT_WAVE_LOCKSTEP();   // the queue entries were written by other lanes
-    const uint32_t take = Q.nm < 64u ? Q.nm : 64u;
+    const uint32_t take = wave_uniform(Q.nm < 64u ? Q.nm : 64u);
     Q.nm -= take;
     const bool have = uint32_t(lane) < take;
     const uint2 it = have ? Q.mq[Q.nm + lane] : make_uint2(0u, 0u);
@@ -400,7 +400,8 @@ __global__ __launch_bounds__(kThreads, 5) void score_tiles_fast_kernel(const Sco
     if (!DBG) { P.debug = 0; P.prof = nullptr; }
     VPT_DYNAMIC_LDS(smem);
     FastLds& L = *reinterpret_cast<FastLds*>(smem);
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = int(wave_uniform(uint32_t(tid) >> 6));
+    const uint32_t wbase = uint32_t(wave) << 6;   // this wave's first thread, as a scalar
     constexpr uint32_t pad = 3;
 
     const uint32_t t = blockIdx.x;
@@ -432,9 +433,19 @@ __global__ __launch_bounds__(kThreads, 5) void score_tiles_fast_kernel(const Sco
     uint64_t tmark = prof ? __builtin_amdgcn_s_memtime() : 0;
 
     // ---------------------------------------------------------------- A. decode
-    uint32_t* bitmap = reinterpret_cast<uint32_t*>(&L.queue[0][0]);
+    // Flat layout: char g of the tile's sentence j sits at pad + g + pad * j, everything else is zero (separators,
+    // the slack past the tile).  The text is staged in LDS (the score array is free until phase B), a chunk scan
+    // numbers the chars and the sentences, and the thread that scanned a chunk decodes its chars straight into
+    // their flat positions; a second pass classifies them (one cache-hot table read each, all in flight together).
+    uint32_t* bitmap = reinterpret_cast<uint32_t*>(&L.queue[0][0]);   // one bit per text byte: a sentence starts here
     uint32_t* raw = reinterpret_cast<uint32_t*>(&L.score[0]);
     for (uint32_t i = tid; i < ((nbytes_al + 31) >> 5) + 1; i += kThreads) bitmap[i] = 0;
+    for (uint32_t i = tid; i < (uint32_t(kFastCap + kMargin) * 4) / 16; i += kThreads) reinterpret_cast<uint4*>(L.sym)[i] = make_uint4(0, 0, 0, 0);
+    if (TM != kTypeRows) {
+        for (uint32_t i = tid; i < uint32_t(kFastCap + kMargin) / 4; i += kThreads) reinterpret_cast<uint32_t*>(L.typ)[i] = 0;
+    }
+    for (uint32_t c = tid; c < nchunks; c += kThreads) reinterpret_cast<uint4*>(raw)[c] = reinterpret_cast<const uint4*>(a0)[c];
+    if (tid == 0) raw[nchunks * 4] = 0;  // the dword after the staged text is read (as padding) by the last char
     __syncthreads();
     for (uint32_t j = tid; j < nsent; j += kThreads) {
         const uint64_t b = P.boff[i0 + j], bn = P.boff[i0 + j + 1];
@@ -444,13 +455,13 @@ __global__ __launch_bounds__(kThreads, 5) void score_tiles_fast_kernel(const Sco
     }
     __syncthreads();
     uint32_t base_leads = 0, base_starts = 0;
+    uint32_t min_cp = 0xFFFFFFFFu, max_si = 0, max_flat = 0;   // over this thread's chars: NUL / a char outside the tile
     for (uint32_t c0 = 0; c0 < nchunks; c0 += kThreads) {   // one pass for up to 4 KB of tile text, else two
         const uint32_t c = c0 + tid;
         uint32_t lm = 0, sm = 0;
         const uint32_t pos0 = c * 16;
         if (c < nchunks) {
-            const uint4 v = reinterpret_cast<const uint4*>(a0)[c];
-            reinterpret_cast<uint4*>(raw)[c] = v;  // stage the text for the per-char decode
+            const uint4 v = reinterpret_cast<const uint4*>(raw)[c];
             const uint32_t lo = pos0 < head ? head - pos0 : 0u;
             const uint32_t rem = nbytes_al - pos0;
             const uint32_t hi = rem < 16 ? rem : 16u;
@@ -465,84 +476,60 @@ __global__ __launch_bounds__(kThreads, 5) void score_tiles_fast_kernel(const Sco
         uint32_t woff = 0, total = 0;
 #pragma unroll
         for (int k = 0; k < kWavesF; ++k) {
-            const uint32_t u = L.wtot[k];
+            const uint32_t u = wave_uniform(L.wtot[k]);
             if (k < wave) woff += u;
             total += u;
         }
         const uint32_t excl = woff + incl - mine;
-        uint32_t ci = base_leads + (excl & 0xFFFFu);
+        const uint32_t ci = base_leads + (excl & 0xFFFFu);
         const uint32_t si0 = base_starts + (excl >> 16);
         base_leads += total & 0xFFFFu;
         base_starts += total >> 16;
-        __syncthreads();
+        __syncthreads();   // wtot is rewritten by the next pass
         uint32_t m = lm;
+        const uint32_t sib = si0 - 1u;                        // sentence of a char = sib + starts up to it in this chunk
+        uint32_t fb = pad + ci + sib + (sib << 1);            // flat = pad + char index + pad * si (mod 2^32: sib may be -1)
         while (m) {
             const uint32_t k = uint32_t(__ffs(int(m))) - 1u;
             m &= m - 1;
-            const uint32_t si = si0 + uint32_t(__popc(sm & ((2u << k) - 1u))) - 1u;
-            if (ci < uint32_t(kFastCap)) L.sym[ci] = (pos0 + k) | (si << 16);
-            ++ci;
+            const uint32_t r = uint32_t(__popc(sm & ((2u << k) - 1u)));
+            const uint32_t si = sib + r;                      // 0xFFFFFFFF before the first start
+            const uint32_t pos = pos0 + k;
+            const uint32_t cp = utf8_scalar_bf(__builtin_amdgcn_alignbyte(raw[(pos >> 2) + 1], raw[pos >> 2], pos & 3u));
+            const uint32_t flat = fb + __umul24(r, pad);
+            ++fb;
+            static_assert(pad == 3, "fb adds 3 * sib");
+            min_cp = cp < min_cp ? cp : min_cp;
+            max_si = si > max_si ? si : max_si;
+            max_flat = flat > max_flat ? flat : max_flat;
+            if (si < 1024u && flat + pad < uint32_t(kFastCap + kMargin)) L.sym[flat] = cp | (si << 21);   // 21 + 10 bits; classified below
         }
     }
     const uint32_t nchars = base_leads;
     if (nchars != expect_chars) err |= kErrBadOffsets;
+    if (min_cp == 0) err |= kErrNulChar;
+    if (max_si >= 1024u || max_flat + pad >= uint32_t(kFastCap + kMargin)) err |= kErrBadOffsets;   // a char that did not fit
     tmark = phase_mark(prof, 0, tmark);
-    if (tid == 0) raw[nchunks * 4] = 0;  // the dword after the staged text is read (as padding) by the last char
-    __syncthreads();
-
-    // one thread per char: decode from the staged text
-    uint32_t cps[kPerThread], meta[kPerThread];  // meta = flat | last-of-sentence << 15 | sentence << 16
+    __syncthreads();  // the staged text has been read: the score array can be zeroed; every char is in place
+    for (uint32_t i = tid; i < (uint32_t(kFastCap + kMargin) * 4) / 16; i += kThreads) reinterpret_cast<uint4*>(L.score)[i] = make_uint4(0, 0, 0, 0);
+    {   // classify: table reads first (all in flight together), then the final symbols
+        uint32_t xs[kPerThread], info[kPerThread];
 #pragma unroll
-    for (int k = 0; k < kPerThread; ++k) {
-        const uint32_t ci = uint32_t(tid) + uint32_t(k) * kThreads;
-        if (ci - uint32_t(lane) >= nchars) { cps[k] = 0; meta[k] = 0xFFFFFFFFu; continue; }  // wave-uniform: no chars left for this wave
-        const bool ok = ci < nchars && ci < uint32_t(kFastCap);
-        const uint32_t info = L.sym[ok ? ci : 0u];
-        const uint32_t ninfo = L.sym[ok ? ci + 1 : 0u];
-        const uint32_t pos = info & 0xFFFFu, si = info >> 16;
-        const uint32_t nsi = (ci + 1 < nchars) ? (ninfo >> 16) : 0xFFFFu;
-        const uint32_t pw = (pos >> 2) < uint32_t(kFastCap + kMargin - 1) ? (pos >> 2) : 0u;
-        const uint32_t w0 = raw[pw], w1 = raw[pw + 1];
-        const uint32_t cp = utf8_scalar_bf(__builtin_amdgcn_alignbyte(w1, w0, pos & 3u));
-        const uint32_t flat = pad + ci + pad * si;
-        const bool fits = flat + pad < uint32_t(kFastCap + kMargin) && si < 1024u;
-        if (ok && cp == 0) err |= kErrNulChar;
-        if (ok && !fits) err |= kErrBadOffsets;
-        cps[k] = cp;
-        meta[k] = (ok && fits) ? (flat | ((nsi != si ? 1u : 0u) << 15) | (si << 16)) : 0xFFFFFFFFu;
-    }
-    __syncthreads();  // every (pos, sentence) record has been read; sym and score can be reused
-    // sym too: with offsets that do not match the text some flat positions would otherwise keep stale LDS contents
-    for (uint32_t i = tid; i < (uint32_t(kFastCap + kMargin) * 4) / 16; i += kThreads) {
-        reinterpret_cast<uint4*>(L.score)[i] = make_uint4(0, 0, 0, 0);
-        reinterpret_cast<uint4*>(L.sym)[i] = make_uint4(0, 0, 0, 0);
-    }
-    if (TM != kTypeRows) {
-        for (uint32_t i = tid; i < uint32_t(kFastCap + kMargin) / 4; i += kThreads) reinterpret_cast<uint32_t*>(L.typ)[i] = 0;
-    }
-    __syncthreads();
-    if (tid < int(pad)) { L.sym[tid] = 0; if (TM != kTypeRows) L.typ[tid] = 0; }
-    if (tid >= 64 && tid < 64 + kMargin) {  // slack past the tile for the s+1, s+2 look-ahead
-        const uint32_t p = flat_len + uint32_t(tid - 64);
-        if (p < uint32_t(kFastCap + kMargin)) { L.sym[p] = 0; if (TM != kTypeRows) L.typ[p] = 0; }
-    }
-#pragma unroll
-    for (int k = 0; k < kPerThread; ++k) {
-        if (meta[k] == 0xFFFFFFFFu) continue;
-        const uint32_t flat = meta[k] & 0xFFFu, cp = cps[k];
-        uint32_t ty, cs;   // CharacterType and the char the position is scored as
-        if (P.cinfo) {     // wave-uniform: KyteaFullwidthFilter folded into the classification table
-            const uint32_t info = cp < 0x10000u ? P.cinfo[cp] : (kPackedNoMatchSym | (char_type(cp) << 16));
-            ty = info >> 16; cs = info & 0xFFFFu;
-        } else {
-            ty = cp < 0x10000u ? uint32_t(P.ctype[cp]) : char_type(cp);
-            cs = cp;
+        for (int k = 0; k < kPerThread; ++k) {
+            xs[k] = L.sym[uint32_t(tid) + uint32_t(k) * kThreads];   // zero past the tile
+            const uint32_t cp = xs[k] & 0x1FFFFFu;
+            info[k] = P.ctab[cp < 0x10000u ? cp : 0u];               // the char it is scored as | CharacterType << 16
         }
-        L.sym[flat] = (cs < kPackedNoMatchSym ? cs : kPackedNoMatchSym) | (ty << 16) | ((meta[k] >> 16) << 19);
-        if (TM != kTypeRows) L.typ[flat] = uint8_t(ty);
-        if (meta[k] & 0x8000u) {
 #pragma unroll
-            for (uint32_t z = 1; z <= pad; ++z) { L.sym[flat + z] = 0; if (TM != kTypeRows) L.typ[flat + z] = 0; }
+        for (int k = 0; k < kPerThread; ++k) {
+            const uint32_t cp = xs[k] & 0x1FFFFFu;
+            uint32_t v = info[k] | ((xs[k] >> 21) << 19);
+            if (__ballot(cp >= 0x10000u) != 0) {   // rare: outside the BMP nothing is tabulated (and nothing can match)
+                if (cp >= 0x10000u) v = kPackedNoMatchSym | (char_type(cp) << 16) | ((xs[k] >> 21) << 19);
+            }
+            v = cp != 0 ? v : 0u;                  // a separator (or NUL, which has raised kErrNulChar)
+            L.sym[uint32_t(tid) + uint32_t(k) * kThreads] = v;
+            if (TM != kTypeRows) L.typ[uint32_t(tid) + uint32_t(k) * kThreads] = uint8_t((v >> 16) & 7u);
         }
     }
     __syncthreads();
@@ -555,16 +542,16 @@ __global__ __launch_bounds__(kThreads, 5) void score_tiles_fast_kernel(const Sco
     // iteration ahead (together with the LDS reads of that iteration's symbols), behind the current record loads.
     uint32_t nx0, nx1, nx2, nx3, nseed;
     auto stage = [&](uint32_t sn) {
-        nx1 = sn < flat_len ? L.sym[sn] : 0u;
-        nx0 = (nx1 & kCpMask) != 0 ? L.sym[sn - 1] : 0u;   // sn >= pad whenever the position holds a char
-        nx2 = L.sym[sn + 1]; nx3 = L.sym[sn + 2];          // past the tile: zeroed slack, then unrelated LDS (dead lanes)
+        nx1 = L.sym[sn];                                   // the whole array is zero except for the tile's chars
+        nx0 = L.sym[(sn > 1u ? sn : 1u) - 1u];             // position 0 is a separator: its left neighbour is never used
+        nx2 = L.sym[sn + 1]; nx3 = L.sym[sn + 2];          // sn + 2 < kFastCap + kMargin
         nseed = uint32_t(K.base[K.off_seed + packed_ph_bucket((nx1 & kCpMask) | ((nx2 & kCpMask) << 16), K.seed_shift)]);
     };
     stage(uint32_t(tid));
     for (int k = 0; k < kPerThread; ++k) {
         if (P.debug & 16u) break;  // timing ablation: no pattern phase at all
         const uint32_t s = uint32_t(tid) + uint32_t(k) * kThreads;
-        if (s - uint32_t(lane) >= flat_len) break;  // wave-uniform: this wave's 64 positions are past the tile
+        if (wbase + uint32_t(k) * kThreads >= flat_len) break;  // wave-uniform: this wave's 64 positions are past the tile
         const uint32_t x1 = nx1, x2 = nx2, x3 = nx3;
         const uint32_t c1 = x1 & kCpMask;
         const bool live = c1 != 0;
@@ -666,7 +653,7 @@ __global__ __launch_bounds__(kThreads, 5) void score_tiles_fast_kernel(const Sco
 }  // namespace
 
 bool fast_path_supported(const ScoreParams& P) {
-    if (!P.pk.present || P.pad != 3 || !P.ctype) return false;
+    if (!P.pk.present || P.pad != 3 || !P.ctab) return false;
     if (!P.ct.present || P.ct.stride_dw != 8 || P.ct.uni_dw != 8 || P.ct.uni_n != kUniDirectChars) return false;  // kPkWide rows
     if (P.type_kind == kTypeNone) return true;
     return P.type_kind == kTypeWindowTable && P.type_window >= 1 && P.type_window <= 3;
