@@ -33,6 +33,7 @@
 #define VPT_DYNAMIC_LDS(name) unsigned char* const name = ::hipemu::dynamic_lds()
 // lock-step marker of the kernels (device_common.h): the lanes of the wave meet here
 #define VPT_WAVE_LOCKSTEP() ::hipemu::wave_sync()
+#define VPT_PIN(x) ((void)0)   /* a code-generation hint on the GPU */
 
 struct uint2 { uint32_t x, y; };
 struct uint4 { uint32_t x, y, z, w; } __attribute__((aligned(16)));

@@ -115,9 +115,8 @@ int tc_score(const tc_model* t, const uint32_t* cps, size_t n, int32_t* y_out, u
             for (int j = 0; j < 6; ++j) add(y, S - 3 + j, trow_field(r[0], r[1], r[2], r[3], j));
         }
         const uint32_t* u = &K.uni[size_t(c1) * 4];
-        add(y, S - 3, lo16(u[0])); add(y, S - 2, hi16(u[0])); add(y, S - 1, lo16(u[1]));
-        add(y, S, hi16(u[1])); add(y, S + 1, lo16(u[2])); add(y, S + 2, hi16(u[2]));
-        if (u[3] == kPkWide) {
+        for (int j = 0; j < 6; ++j) add(y, S - 3 + j, row_field(u[0], u[1], u[2], u[3] & ~kUniWideBit, j, kUniFieldBits));
+        if (u[3] & kUniWideBit) {
             const uint32_t* g = &G.uni[size_t(c1) * G.uni_dw];
             for (int j = 0; j < 6; ++j) add(y, S - 3 + j, int32_t(g[j]));
         }
@@ -125,7 +124,7 @@ int tc_score(const tc_model* t, const uint32_t* cps, size_t n, int32_t* y_out, u
         const uint32_t kb = c1 | (c2 << 16);
         uint32_t b = packed_ph_slot(kb, K.seed[packed_ph_bucket(kb, 32 - K.seed_bits)], 32 - K.rec_bits);
         const uint32_t* r = &K.rec[size_t(b) * 32];
-        if (r[0] != kb) {
+        if (r[16] != kb) {
             const uint32_t fl = r[3] >> 16;
             const uint32_t* found = nullptr;
             if (fl & kPkFar) {              // some key homed here lives more than 8 records on: walk to the first hole
@@ -133,28 +132,26 @@ int tc_score(const tc_model* t, const uint32_t* cps, size_t n, int32_t* y_out, u
                 for (;;) {
                     b = (b + 1) & rmask;
                     const uint32_t* q = &K.rec[size_t(b) * 32];
-                    if (q[0] == kb) { found = q; break; }
-                    if (q[0] == 0) break;
+                    if (q[16] == kb) { found = q; break; }
+                    if (q[16] == 0) break;
                 }
             } else {
                 for (uint32_t hop = fl >> kPkHopShift; hop != 0 && !found; hop &= hop - 1) {
                     const uint32_t d = uint32_t(__builtin_ctz(hop)) + 1;
                     const uint32_t* q = &K.rec[size_t((b + d) & rmask) * 32];
                     ++probes[0];
-                    if (q[0] == kb) found = q;
+                    if (q[16] == kb) found = q;
                 }
             }
             if (!found) continue;
             r = found;
         }
-        if (r[16] != kb) return -3;   // both halves carry the key
         if (r[3] & (kPkWide << 16)) {
             const uint32_t* g = general_find(G, short_key(c1, c2, 0));
             if (!g) return -2;
             for (int j = 0; j < 5; ++j) add(y, S - 2 + j, int32_t(g[2 + j]));
         } else {
-            add(y, S - 2, lo16(r[1])); add(y, S - 1, hi16(r[1])); add(y, S, lo16(r[2]));
-            add(y, S + 1, hi16(r[2])); add(y, S + 2, lo16(r[3]));
+            for (int j = 0; j < 5; ++j) add(y, S - 2 + j, row_field(r[0], r[1], r[2], r[3] & 0xFFFFu, j, kBiFieldBits));
         }
         // a trigram-level child (row + deeper walk) of the string that starts at position `st`
         auto apply_child = [&](long st, uint32_t k1, uint32_t k2, uint32_t k3, const uint32_t* ch) -> int {

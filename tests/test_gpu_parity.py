@@ -254,7 +254,7 @@ def test_fast_and_general_kernels_agree_with_oracle(force_generic, monkeypatch):
 
 # ------------------------------------------------------------------------------------------------ packed tables
 def test_packed_path_is_used_and_handles_wide_rows():
-    """W = 3 BMP models run on the 16-byte packed tables; rows with values outside i16 take the kPkWide escape."""
+    """W = 3 BMP models run on the packed tables; rows with values outside their fields take the kPkWide escape."""
     m = ModelData(bias=-7, char_window_size=3, type_window_size=3)
     m.char_ngram_model.append(NgramData("あ", [0, 0, 40000, -5, 1, 2]))
     m.char_ngram_model.append(NgramData("あい", [1, 2, 30000, 4, 5]))
@@ -262,6 +262,10 @@ def test_packed_path_is_used_and_handles_wide_rows():
     m.char_ngram_model.append(NgramData("いうえ", [32767, 32767, 3, 4]))
     m.dict_model.append(WordWeightRecord("いうえ", [1, 32767, 5, 32767], ""))
     m.dict_model.append(WordWeightRecord("いうえお", [1, 2, 3, 4, 5], ""))
+    m.char_ngram_model.append(NgramData("う", [-1048577, 0, 1048576, -5, 1, 2]))          # just outside 21 bits
+    m.char_ngram_model.append(NgramData("え", [-1048576, 1048575, 0, -5, 1, 2]))          # just inside
+    m.char_ngram_model.append(NgramData("いう", [5, 2097152, -2097153, 1, 2]))            # just outside 22 bits
+    m.char_ngram_model.append(NgramData("うえ", [2097151, -2097152, 2097151, -1, -2097152]))  # just inside
     m.dict_model.append(WordWeightRecord("あいうえおか", [100000, -100000, 3, 4, 5, 6, 2000000000], ""))
     m.dict_model.append(WordWeightRecord("あいうえおかきくけこ", [1, 2, 3, 4, 5, 6, 7, 8, 9, 10, -70000], ""))
     m.type_ngram_model.append(NgramData(bytes([3, 3]), [5, -6, 7, 8, 9]))

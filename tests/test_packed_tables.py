@@ -135,8 +135,9 @@ def test_packed_not_eligible_models_fall_back(tc):
 
 
 def test_packed_wide_rows(tc):
-    """Values outside i16 (a large weight, or an n-gram and a word with the same string summing past 16 bits)
-    keep the model on the packed path through the kPkWide escape."""
+    """Values outside a row's fields (21 bits in a unigram row, 22 in a bigram row, i16 below: a large weight, or an
+    n-gram and a word with the same string summing past the field) keep the model on the packed path through the
+    kPkWide escape; values that only the wider unigram / bigram fields hold are scored in place."""
     m = ModelData(bias=-7, char_window_size=3, type_window_size=3)
     m.char_ngram_model.append(NgramData("あ", [0, 0, 40000, -5, 1, 2]))
     m.char_ngram_model.append(NgramData("あい", [1, 2, 30000, 4, 5]))
@@ -144,6 +145,10 @@ def test_packed_wide_rows(tc):
     m.char_ngram_model.append(NgramData("いうえ", [32767, 32767, 3, 4]))
     m.dict_model.append(WordWeightRecord("いうえ", [1, 32767, 5, 32767], ""))
     m.dict_model.append(WordWeightRecord("いうえお", [1, 2, 3, 4, 5], ""))
+    m.char_ngram_model.append(NgramData("う", [-1048577, 0, 1048576, -5, 1, 2]))          # just outside 21 bits
+    m.char_ngram_model.append(NgramData("え", [-1048576, 1048575, 0, -5, 1, 2]))          # just inside
+    m.char_ngram_model.append(NgramData("いう", [5, 2097152, -2097153, 1, 2]))            # just outside 22 bits
+    m.char_ngram_model.append(NgramData("うえ", [2097151, -2097152, 2097151, -1, -2097152]))  # just inside
     m.dict_model.append(WordWeightRecord("あいうえおか", [100000, -100000, 3, 4, 5, 6, 2000000000], ""))
     m.dict_model.append(WordWeightRecord("あいうえおかきくけこ", [1, 2, 3, 4, 5, 6, 7, 8, 9, 10, -70000], ""))
     raw = encode_model(m)

@@ -17,6 +17,12 @@
 #define VPT_WAVE_LOCKSTEP() ((void)0)
 #endif
 
+// Have a value computed HERE: the compiler otherwise sinks a chain of selects to its first use and keeps every input
+// register and every compare mask alive until then (VGPR and SGPR pressure in the main loop of the specialised kernel).
+#ifndef VPT_PIN
+#define VPT_PIN(x) __asm__ volatile("" : "+v"(x))
+#endif
+
 namespace vpt {
 
 // A value that every lane of the wave holds alike, moved to a scalar register.  The hardware gains nothing; the

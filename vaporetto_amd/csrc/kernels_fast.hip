@@ -9,8 +9,8 @@
 //     costs ONE random line.  A lane PAIR fetches the two 64-byte halves of a record in the same instruction (first
 //     the even lane's record, then the odd lane's), which the memory pipeline rewards (tools/gather_bench.hip), and
 //     hands the partner's half over through DPP, so that every lane ends up with its own whole record;
-//   * the unigram row (16 bytes, cache-hot), the type row (LDS), the bigram row and the matching right child are
-//     summed in registers and land in the LDS score array with six ds_add_u32 (integer => order-free => bit-exact);
+//   * the unigram row (16 bytes, cache-hot; 21-bit fields), the type row (LDS; 18-bit fields), the bigram row (22-bit
+//     fields) and the matching right child are summed in registers and land in the LDS score array with six ds_add_u32 (integer => order-free => bit-exact);
 //     a matching left child adds its four values one position earlier;
 //   * everything data-dependent is NOT done in place (64 lanes would wait for the unluckiest one): it is pushed,
 //     ballot/mbcnt-compacted, onto wave-private LDS stacks -- one per kind, so that a replay runs one short code
@@ -38,6 +38,7 @@ constexpr uint32_t kCpMask = 0xFFFFu;        // sym = char (>= 0xFFFF -> 0xFFFF)
 constexpr int kPerThread = kFastCap / kThreads;
 constexpr int kWavesF = kThreads / 64;
 constexpr int kTypeRows = 4;                 // TM value: type rows in LDS (1..3 = window table of that W, 0 = none)
+static_assert(kMargin >= int(kPackedMaxSkip), "replay_w reads up to kPackedMaxSkip symbols past a char");
 constexpr int kTrowCount = 448;              // rows t1 | t2 << 3 | t3 << 6 with t3 <= 6
 
 struct FastLds {
@@ -117,6 +118,7 @@ struct WaveStacks {
     }
 };
 
+__device__ __forceinline__ int32_t sext(uint32_t x, int bits) { return int32_t(x << (32 - bits)) >> (32 - bits); }   // low `bits` bits, signed
 __device__ __forceinline__ int32_t lo16(uint32_t x) { return int32_t(x << 16) >> 16; }
 __device__ __forceinline__ int32_t hi16(uint32_t x) { return int32_t(x) >> 16; }
 
@@ -144,7 +146,8 @@ __device__ __forceinline__ void replay_w(const PackedView& K, FastLds& L, WaveSt
     const uint2 it = have ? Q.q[Q.nw + lane] : make_uint2(0u, 0u);
     const uint32_t s = it.x & 0x7FFu, depth = it.x >> 11;
     const uint32_t at = s + depth;
-    const uint32_t c = (have && at < uint32_t(kFastCap + kMargin)) ? (L.sym[at] & kCpMask) : 0u;  // 0: sentence over
+    // at <= flat_len: the steps before this one matched chars, and the array is zero from the end of the tile on
+    const uint32_t c = have ? (L.sym[at] & kCpMask) : 0u;  // 0: sentence over
     const uint32_t tab = K.off_deep + ((it.y >> 5) << 6);   // byte offset of the mini-table (64-byte entries)
     const uint32_t last = (1u << (it.y & 31u)) - 1u;
     const uint32_t i0 = packed_mini_slot(c, it.y), i1 = (i0 + 1) & last;
@@ -178,8 +181,8 @@ __device__ __forceinline__ void replay_w(const PackedView& K, FastLds& L, WaveSt
 #pragma unroll
         for (uint32_t j = 0; j < kPackedMaxSkip; ++j) {
             if (__ballot(j < nskip) == 0) break;
-            const uint32_t q = at + 1 + j;
-            const uint32_t have_c = (j < nskip && q < uint32_t(kFastCap + kMargin)) ? (L.sym[q] & kCpMask) : 0u;
+            const uint32_t q = at + 1 + j;   // < flat_len + kPackedMaxSkip <= kFastCap + kMargin (found: sym[at] is a char)
+            const uint32_t have_c = j < nskip ? (L.sym[q] & kCpMask) : 0u;
             const uint32_t want = (sk[j >> 1] >> (16 * (j & 1))) & 0xFFFFu;
             if (j < nskip && have_c != want) found = false;
         }
@@ -296,10 +299,14 @@ __device__ __forceinline__ RecMatch match_record(bool keyok, uint32_t c0, uint32
     o.ly = ml1 ? l1.y : ml2 ? l2.y : ml3 ? l3.y : 0u;   // zero without a hit (and in a kPkWide slot)
     o.lz = ml1 ? l1.z : ml2 ? l2.z : ml3 ? l3.z : 0u;
     o.lk = ml1 ? l1.w : ml2 ? l2.w : ml3 ? l3.w : 0u;
-    // bigram row + right child (a kPkWide slot holds zero weights)
-    const uint32_t by = keyok ? h0.y : 0u, bz = keyok ? h0.z : 0u, bw = keyok ? h0.w : 0u;
-    o.b1 = lo16(by) + lo16(o.ly); o.b2 = hi16(by) + lo16(ry) + hi16(o.ly); o.b3 = lo16(bz) + hi16(ry) + lo16(o.lz);
-    o.b4 = hi16(bz) + lo16(rz) + hi16(o.lz); o.b5 = lo16(bw) + hi16(rz);
+    // bigram row (five 22-bit fields at bits 0, 22, 44, 66, 88 of H0; layout.h) + right child + left child; a kPkWide
+    // slot holds zero weights
+    const uint32_t bx = keyok ? h0.x : 0u, by = keyok ? h0.y : 0u, bz = keyok ? h0.z : 0u, bw = keyok ? h0.w : 0u;
+    o.b1 = sext(bx, kBiFieldBits) + lo16(o.ly);
+    o.b2 = sext(__builtin_amdgcn_alignbit(by, bx, 22), kBiFieldBits) + lo16(ry) + hi16(o.ly);
+    o.b3 = sext(__builtin_amdgcn_alignbit(bz, by, 12), kBiFieldBits) + hi16(ry) + lo16(o.lz);
+    o.b4 = sext(bz >> 2, kBiFieldBits) + lo16(rz) + hi16(o.lz);
+    o.b5 = sext(__builtin_amdgcn_alignbit(bw, bz, 24), kBiFieldBits) + hi16(rz);
     o.ovp = false;
     if (kr && !hit_r && (bw & (kPkOv << 16))) {
         const uint32_t bit = packed_filter_bit(c3);
@@ -335,7 +342,6 @@ __device__ __forceinline__ void drain_wo(const PackedView& K, const PatternTable
 //             item is re-queued with the remaining bits.  kRecFar: walk on to the first empty record instead.
 //   kWide*:   a row with a value outside i16 -- taken from the general tables (i32).
 __device__ __forceinline__ void replay_m(const PackedView& K, const PatternTableView& T, FastLds& L, WaveStacks& Q, int lane) {
-    drain_wo(K, T, L, Q, lane, kQHigh);  // room for this call's pushes
     VPT_WAVE_LOCKSTEP();   // the queue entries were written by other lanes
     const uint32_t take = wave_uniform(Q.nm < 64u ? Q.nm : 64u);
     Q.nm -= take;
@@ -345,28 +351,33 @@ __device__ __forceinline__ void replay_m(const PackedView& K, const PatternTable
     uint32_t kinds = have ? (it.x >> 11) : 0u;
     const uint32_t c0 = have ? (L.sym[s - 1] & kCpMask) : 0u;
     const uint32_t c1 = L.sym[s] & kCpMask, c2 = L.sym[s + 1] & kCpMask, c3 = L.sym[s + 2] & kCpMask;
-    const uint32_t kb = c1 | (c2 << 16);
-    const bool far = (kinds & kRecFar) != 0, more = (kinds & (kRecMore | kRecFar)) != 0;
-    const uint32_t hop = far ? 0u : it.y >> 24;                       // records still to visit, as distances from home
-    const uint32_t hop_next = hop & (hop - 1u);
-    const uint32_t slot = far ? it.y : ((it.y & 0xFFFFFFu) + (hop ? uint32_t(__ffs(int(hop))) : 0u)) & K.rec_mask;
-    const uint32_t r = K.off_rec + ((more ? slot : 0u) << 7);
-    const uint4 h0 = ld16(K.base, r), r1 = ld16(K.base, r + 16), r2 = ld16(K.base, r + 32), r3 = ld16(K.base, r + 48);
-    const uint4 h1 = ld16(K.base, r + 64), l1 = ld16(K.base, r + 80), l2 = ld16(K.base, r + 96), l3 = ld16(K.base, r + 112);
-    const bool keyok = more && h0.x == kb;
-    const bool again = more && !keyok && (far ? h0.x != 0 : hop_next != 0);
-    const RecMatch mt = match_record(keyok, c0, c3, h0, r1, r2, r3, h1, l1, l2, l3);
-    if (keyok) add_row6(L.score, s, 0, mt.b1, mt.b2, mt.b3, mt.b4, mt.b5);
-    kinds = (kinds & (kWideUni | kWideBi | kWideTri | kWideLeft)) | mt.wide;
+    const bool more = (kinds & (kRecMore | kRecFar)) != 0;
+    if (__ballot(more) != 0) {   // only after the perfect hash fell back to probing: another record to look at
+        drain_wo(K, T, L, Q, lane, kQHigh);  // room for the pushes below
+        const uint32_t kb = c1 | (c2 << 16);
+        const bool far = (kinds & kRecFar) != 0;
+        const uint32_t hop = far ? 0u : it.y >> 24;                       // records still to visit, as distances from home
+        const uint32_t hop_next = hop & (hop - 1u);
+        const uint32_t slot = far ? it.y : ((it.y & 0xFFFFFFu) + (hop ? uint32_t(__ffs(int(hop))) : 0u)) & K.rec_mask;
+        const uint32_t r = K.off_rec + ((more ? slot : 0u) << 7);
+        const uint4 h0 = ld16(K.base, r), r1 = ld16(K.base, r + 16), r2 = ld16(K.base, r + 32), r3 = ld16(K.base, r + 48);
+        const uint4 h1 = ld16(K.base, r + 64), l1 = ld16(K.base, r + 80), l2 = ld16(K.base, r + 96), l3 = ld16(K.base, r + 112);
+        const bool keyok = more && h1.x == kb;
+        const bool again = more && !keyok && (far ? h1.x != 0 : hop_next != 0);
+        const RecMatch mt = match_record(keyok, c0, c3, h0, r1, r2, r3, h1, l1, l2, l3);
+        if (keyok) add_row6(L.score, s, 0, mt.b1, mt.b2, mt.b3, mt.b4, mt.b5);
+        kinds |= mt.wide;
+        Q.push_w(mt.rk != 0, s | (3u << 11), mt.rk);
+        Q.push_o(mt.ovp, s, mt.ov_ref);
+        Q.push_m(again, s | ((far ? kRecFar : kRecMore) << 11), far ? (slot + 1) & K.rec_mask : (it.y & 0xFFFFFFu) | (hop_next << 24));
+        if (__ballot(mt.lk != 0) != 0) {
+            drain_wo(K, T, L, Q, lane, kQHigh);
+            Q.push_w(mt.lk != 0, (s - 1) | (3u << 11), mt.lk);
+        }
+    }
+    kinds &= kWideUni | kWideBi | kWideTri | kWideLeft;
     if (__ballot(kinds != 0) != 0) {
         if (kinds != 0) add_wide_rows(T, L, kinds, s, c0, c1, c2, c3);
-    }
-    Q.push_w(mt.rk != 0, s | (3u << 11), mt.rk);
-    Q.push_o(mt.ovp, s, mt.ov_ref);
-    Q.push_m(again, s | ((far ? kRecFar : kRecMore) << 11), far ? (slot + 1) & K.rec_mask : (it.y & 0xFFFFFFu) | (hop_next << 24));
-    if (__ballot(mt.lk != 0) != 0) {
-        drain_wo(K, T, L, Q, lane, kQHigh);
-        Q.push_w(mt.lk != 0, (s - 1) | (3u << 11), mt.lk);
     }
 }
 
@@ -582,7 +593,10 @@ __global__ __launch_bounds__(kThreads, 5) void score_tiles_fast_kernel(const Sco
             l3 = make_uint4(pair_swap(g3.x), pair_swap(g3.y), pair_swap(g3.z), pair_swap(g3.w));
         }
         // own row so far: unigram (+ type row)
-        int32_t a0 = lo16(u.x), a1 = hi16(u.x), a2 = lo16(u.y), a3 = hi16(u.y), a4 = lo16(u.z), a5 = hi16(u.z);
+        // six 21-bit fields at bits 0, 21, 42, 63, 84, 105 (layout.h); bit 127 = the row is wide (M stack)
+        int32_t a0 = sext(u.x, kUniFieldBits), a1 = sext(__builtin_amdgcn_alignbit(u.y, u.x, 21), kUniFieldBits);
+        int32_t a2 = sext(u.y >> 10, kUniFieldBits), a3 = sext(__builtin_amdgcn_alignbit(u.z, u.y, 31), kUniFieldBits);
+        int32_t a4 = sext(__builtin_amdgcn_alignbit(u.w, u.z, 20), kUniFieldBits), a5 = sext(u.w >> 9, kUniFieldBits);
         if (TM == kTypeRows) {
             const uint4 tr = L.trow[((x1 >> 16) & 7u) | (((x2 >> 16) & 7u) << 3) | (((x3 >> 16) & 7u) << 6)];
             // six 18-bit signed fields at bits 0, 18, 36, 54, 72, 90 (layout.h, trow_field)
@@ -593,19 +607,20 @@ __global__ __launch_bounds__(kThreads, 5) void score_tiles_fast_kernel(const Sco
             a4 += int32_t(tr.z << 6) >> 14;
             a5 += int32_t(__builtin_amdgcn_alignbit(tr.w, tr.z, 26) << 14) >> 14;
         }
-        const bool keyok = has2 && h0.x == kb;
+        const bool keyok = has2 && h1.x == kb;
         const RecMatch mt = match_record(keyok, c0, c3, h0, r1, r2, r3, h1, l1, l2, l3);
         a1 += mt.b1; a2 += mt.b2; a3 += mt.b3; a4 += mt.b4; a5 += mt.b5;
         if (live) add_row6(L.score, s, a0, a1, a2, a3, a4, a5);
         // deferred work
         const bool ovp = mt.ovp && !(P.debug & 2u);
-        const uint32_t rk = mt.rk, lk = mt.lk;
-        const uint32_t dfl = (has2 && !keyok) ? h0.w >> 16 : 0u;   // where keys homed in this record were displaced to
-        const uint32_t kinds = ((live && u.w != 0) ? kWideUni : 0u) | ((dfl & kPkFar) ? kRecFar : (dfl >> kPkHopShift) ? kRecMore : 0u) | mt.wide;
+        uint32_t rk = mt.rk, lk = mt.lk, ov_ref = mt.ov_ref;
+        uint32_t dfl = (has2 && !keyok) ? h0.w >> 16 : 0u;   // where keys homed in this record were displaced to
+        uint32_t kinds = ((live && (u.w & kUniWideBit)) ? kWideUni : 0u) | ((dfl & kPkFar) ? kRecFar : (dfl >> kPkHopShift) ? kRecMore : 0u) | mt.wide;
+        VPT_PIN(rk); VPT_PIN(lk); VPT_PIN(ov_ref); VPT_PIN(kinds); VPT_PIN(dfl);   // the record's registers and the match masks end here
         const bool nowalk = (P.debug & 8u) != 0;
         make_room(K, P.ct, L, Q, lane);
         Q.push_w(rk != 0 && !nowalk, s | (3u << 11), rk);
-        Q.push_o(ovp, s, mt.ov_ref);
+        Q.push_o(ovp, s, ov_ref);
         if (__ballot(kinds != 0) != 0)   // rare: rows outside i16, or a record placed by the fallback of the perfect hash
             Q.push_m(kinds != 0 && !(P.debug & 32u), s | (kinds << 11), (dfl & kPkFar) ? (hrec + 1) & K.rec_mask : hrec | ((dfl >> kPkHopShift) << 24));
         if (__ballot(lk != 0) != 0) {

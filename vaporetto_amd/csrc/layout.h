@@ -40,13 +40,16 @@
 // read, ~57 G/s chip-wide out of L2), not bytes and not lane requests.  So everything the patterns starting with
 // (c1, c2) need at depth 2 and 3 lives in ONE 128-byte record:
 //
-//   uni    65536 rows of 16 bytes, indexed by c1: {w[0..5] i16 (boundaries s-3 .. s+2), flags}      (L1/L2-hot)
+//   uni    65536 rows of 16 bytes, indexed by c1: six signed 21-bit fields (boundaries s-3 .. s+2) at bits
+//          0, 21, .., 105; bit 127 = kUniWideBit                                                    (L1/L2-hot)
 //   rec    open addressing over 128-byte records keyed by kb = c1 | c2 << 16 (eight 16-byte units):
-//            H0      = {kb, w0|w1<<16, w2|w3<<16, w4 | flags<<16}   bigram row (boundaries s-2 .. s+2), zero when
-//                      (c1,c2) is only a prefix; flags: kPkDisp, kPkWide, kPkOv
+//            H0      = the bigram row: five signed 22-bit fields (boundaries s-2 .. s+2) at bits 0, 22, .., 88, zero
+//                      when (c1,c2) is only a prefix; bits 112..127 = flags: kPkDisp, kPkWide, kPkOv, kPkFar, hops
+//                      (unigram and bigram rows are the hot ones and sum the most patterns -- an n-gram plus a
+//                      dictionary word of the same string -- so they get more than the 16 bits of a single weight)
 //            R1..R3  = RIGHT children {c3 | cflags<<16, w0|w1<<16, w2|w3<<16, kids}: the 3-char string (c1,c2,c3)
 //                      starting at s (boundaries s-1 .. s+2)
-//            H1      = {kb, overflow ref, filter lo, filter hi}
+//            H1      = {kb, overflow ref, filter lo, filter hi}           (the key of the record lives here)
 //            L1..L3  = LEFT children {c0 | cflags<<16, ...}: the 3-char string (c0,c1,c2) starting at s-1 (boundaries
 //                      s-2 .. s+1), found by the position AFTER its start -- which fetches record (c1,c2) anyway
 //          A child = a 3-char pattern and/or the 3-char prefix of longer ones; `kids` = mini-table ref of its
@@ -78,9 +81,9 @@
 // HOME record: bit d-1 of the hop bitmap = "a key homed here lives d records further on" (d = 1..8),
 // kPkFar = "... more than 8 further on" (then the search walks on to the first empty record).  A lookup that finds
 // neither its key nor any of these in the home record is over after one line; otherwise it visits exactly the
-// records the bitmap names.  kPkWide marks a row with a value outside i16 (an n-gram and a dictionary word with the same
-// string can sum past 16 bits): the slot keeps zero weights and the row comes from the general tables above
-// (`uni` row flag: dword 3 == kPkWide).  A text char >= 0xFFFF is mapped to 0xFFFF before lookups: no pattern
+// records the bitmap names.  kPkWide marks a row with a value outside its fields (i16 in a child or `deep` entry,
+// 22 bits in a bigram row; `uni`: kUniWideBit, 21 bits): the slot keeps zero weights and the row comes from the
+// general tables above.  A text char >= 0xFFFF is mapped to 0xFFFF before lookups: no pattern
 // contains it, so it matches nothing.
 //
 // TYPE ROWS.  When every type n-gram has at most 3 symbols and W_t <= 3 (the trainer's defaults), the type scores
@@ -114,6 +117,9 @@ constexpr uint32_t kPackedNoMatchSym = 0xFFFFu;
 constexpr uint32_t kPackedInlineKids = 6;      // children held by a record itself
 constexpr uint32_t kPackedInlineRow = 14;      // weights a `deep` entry holds inline
 constexpr uint32_t kPackedMaxSkip = 8;         // further symbols a `deep` entry can require (path compression)
+constexpr int kUniFieldBits = 21;              // unigram row: six fields
+constexpr int kBiFieldBits = 22;               // bigram row (record unit H0): five fields
+constexpr uint32_t kUniWideBit = 0x80000000u;  // dword 3 of a unigram row: the row is in the general tables (i32)
 
 #if defined(__HIPCC__)
 #define VPT_HD __host__ __device__ __forceinline__
@@ -136,6 +142,15 @@ VPT_HD uint32_t packed_ph_bucket(uint32_t k, uint32_t shift) { return (k * kHash
 VPT_HD uint32_t packed_ph_slot(uint32_t k, uint32_t seed, uint32_t shift) { return ((k ^ (seed * 0x7FEB352Du)) * kHashMulLo) >> shift; }
 VPT_HD uint32_t packed_mini_slot(uint32_t sym, uint32_t ref) { return ((sym * kHashMulLo) >> 15) & ((1u << (ref & 31u)) - 1u); }
 VPT_HD uint32_t packed_filter_bit(uint32_t sym) { return (sym * kHashMulHi) >> 26; }   // 0..63
+
+// signed `bits`-wide field number j of a 128-bit little-endian row (unigram rows, bigram rows)
+VPT_HD int32_t row_field(uint32_t x, uint32_t y, uint32_t z, uint32_t w, int j, int bits) {
+    const uint32_t d[5] = {x, y, z, w, 0u};
+    const int bit = bits * j, q = bit >> 5, r = bit & 31;
+    const uint64_t v = (uint64_t(d[q]) | (uint64_t(d[q + 1]) << 32)) >> r;
+    return int32_t(uint32_t(v) << (32 - bits)) >> (32 - bits);
+}
+VPT_HD bool fits_field(int32_t v, int bits) { return v >= -(1 << (bits - 1)) && v < (1 << (bits - 1)); }
 
 // type row: six 18-bit signed fields packed little-endian into dwords 0..3 (bits 0..107)
 VPT_HD int32_t trow_field(uint32_t x, uint32_t y, uint32_t z, uint32_t w, int j) {

@@ -216,6 +216,20 @@ HostPatternTable build_table(std::vector<Pat>& pats, int W, uint32_t uni_n) {
 // <= 3 chars: the kernel takes the row from the general tables) or goes to `xrows` as i32 (longer patterns).
 inline bool fits_i16(int32_t v) { return v >= -32768 && v <= 32767; }
 inline uint32_t pack16(int32_t lo, int32_t hi) { return (uint32_t(lo) & 0xFFFFu) | (uint32_t(hi) << 16); }
+// n signed `bits`-wide fields, little-endian from bit 0 of d[0..3] (OR-ed in: the flag bits are left alone)
+inline void pack_fields(uint32_t* d, const int32_t* v, int n, int bits) {
+    for (int j = 0; j < n; ++j) {
+        const uint64_t f = uint64_t(uint32_t(v[j])) & ((uint64_t(1) << bits) - 1);
+        const int bit = bits * j, q = bit >> 5, r = bit & 31;
+        d[q] |= uint32_t(f << r);
+        if (r + bits > 32) d[q + 1] |= uint32_t(f >> (32 - r));
+    }
+}
+inline bool row_fits(const std::vector<int32_t>& row, int bits) {
+    for (int32_t v : row)
+        if (!fits_field(v, bits)) return false;
+    return true;
+}
 
 // mini-table (layout.h): `size` consecutive entries of `dw` dwords each; returns the ref, entries zeroed
 uint32_t mini_alloc(std::vector<uint32_t>& arena, uint32_t dw, size_t count) {
@@ -258,8 +272,8 @@ HostPackedTable build_packed(const std::vector<Pat>& pats) {
         const size_t n = p.s.size();
         if (n == 1) {
             uint32_t* d = &t.uni[size_t(p.s[0]) * 4];
-            if (wide(p)) { d[3] = kPkWide; ++t.n_wide; }
-            else { d[0] = pack16(p.row[0], p.row[1]); d[1] = pack16(p.row[2], p.row[3]); d[2] = pack16(p.row[4], p.row[5]); }
+            if (!row_fits(p.row, kUniFieldBits)) { d[3] = kUniWideBit; ++t.n_wide; }
+            else pack_fields(d, p.row.data(), 6, kUniFieldBits);
             continue;
         }
         const uint32_t key = p.s[0] | (p.s[1] << 16);
@@ -453,12 +467,9 @@ HostPackedTable build_packed(const std::vector<Pat>& pats) {
         const uint32_t b = slot_of[pi];
         uint32_t* r = &t.rec[size_t(b) * 32];
         uint32_t fl = 0;
-        r[0] = pf.key; r[16] = pf.key;
-        if (pf.pat && wide(*pf.pat)) { fl |= kPkWide; ++t.n_wide; }
-        else if (pf.pat) {
-            r[1] = pack16(pf.pat->row[0], pf.pat->row[1]); r[2] = pack16(pf.pat->row[2], pf.pat->row[3]);
-            r[3] |= pack16(pf.pat->row[4], 0);   // the flags half may already name displaced keys
-        }
+        r[16] = pf.key;
+        if (pf.pat && !row_fits(pf.pat->row, kBiFieldBits)) { fl |= kPkWide; ++t.n_wide; }
+        else if (pf.pat) pack_fields(r, pf.pat->row.data(), 5, kBiFieldBits);   // bits 0..109; the flags half of dword 3 may already name displaced keys
         for (size_t j = 0; j < rights[pi].size(); ++j) child_entry(r + 4 + 4 * j, nodes[rights[pi][j]], nodes[rights[pi][j]].sym);
         for (size_t j = 0; j < lefts[pi].size(); ++j) child_entry(r + 20 + 4 * j, nodes[lefts[pi][j].node], lefts[pi][j].lead);
         if (!overflow[pi].empty()) {
