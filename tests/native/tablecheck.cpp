@@ -111,7 +111,7 @@ int tc_score(const tc_model* t, const uint32_t* cps, size_t n, int32_t* y_out, u
         const uint32_t c1 = sym[s], c2 = sym[s + 1], c3 = sym[s + 2];
         const long S = long(s);
         if (!K.trow.empty()) {
-            const uint32_t* r = &K.trow[size_t(typ[s] | (typ[s + 1] << 3) | (typ[s + 2] << 6)) * 4];
+            const uint32_t* r = &K.trow[size_t(type_row_index(typ[s], typ[s + 1], typ[s + 2])) * 4];
             for (int j = 0; j < 6; ++j) add(y, S - 3 + j, trow_field(r[0], r[1], r[2], r[3], j));
         }
         const uint32_t* u = &K.uni[size_t(c1) * 4];

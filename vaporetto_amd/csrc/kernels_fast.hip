@@ -19,7 +19,7 @@
 //     rest (a record displaced from its home slot, rows with a value outside i16);
 //   * UTF-8 decode is two-step: a chunk scan finds (byte position, sentence) of every char, then one thread per
 //     CHAR decodes from the LDS-staged text (branch-free) and classifies it with a 64 KB table;
-//   * 26-32 KB of LDS per workgroup: 5-6 workgroups per CU (the time is flat from 5 up).
+//   * 26 KB of LDS and at most 80 VGPRs per workgroup: 6 workgroups per CU.
 #include <hip/hip_runtime.h>
 
 #include <cstddef>
@@ -31,15 +31,15 @@
 namespace vpt {
 namespace {
 
-constexpr int kQCap = 256;                   // W + O items per wave (W grows from the bottom, O from the top)
+constexpr int kQCap = 224;                   // W + O items per wave (W grows from the bottom, O from the top)
 constexpr uint32_t kQHigh = kQCap - 128;     // replay until one more round of pushes (<= 64 + 64) fits
-constexpr int kMCap = 128;                   // M items per wave
+constexpr int kMCap = 64;                    // M items per wave (a handful per tile: only rows outside their fields)
 constexpr uint32_t kCpMask = 0xFFFFu;        // sym = char (>= 0xFFFF -> 0xFFFF) | type << 16 | tile-local sentence << 19
 constexpr int kPerThread = kFastCap / kThreads;
 constexpr int kWavesF = kThreads / 64;
 constexpr int kTypeRows = 4;                 // TM value: type rows in LDS (1..3 = window table of that W, 0 = none)
 static_assert(kMargin >= int(kPackedMaxSkip), "replay_w reads up to kPackedMaxSkip symbols past a char");
-constexpr int kTrowCount = 448;              // rows t1 | t2 << 3 | t3 << 6 with t3 <= 6
+constexpr int kTrowCount = int(kTypeRowCount);   // layout.h, type_row_index
 
 struct FastLds {
     uint32_t sym[kFastCap + kMargin];        // decode step 1 keeps (byte pos | sentence << 16) per char here
@@ -53,7 +53,8 @@ struct FastLds {
     };
 };
 static_assert(offsetof(FastLds, typ) % 16 == 0 && (kFastCap + kMargin) * 4 % 16 == 0, "carve offsets stay 16-byte aligned");
-static_assert(offsetof(FastLds, typ) + sizeof(uint4) * kTrowCount <= 32768, "5 workgroups per CU need <= 32 KB each");
+// gfx950 hands out LDS in granules of 1280 bytes: six workgroups per CU get 21 of the 128 each
+static_assert(offsetof(FastLds, typ) + sizeof(uint4) * kTrowCount <= 21 * 1280, "6 workgroups per CU");
 
 __device__ __forceinline__ uint32_t lane_rank(uint64_t mask) {  // set bits of `mask` below this lane
     return __builtin_amdgcn_mbcnt_hi(uint32_t(mask >> 32), __builtin_amdgcn_mbcnt_lo(uint32_t(mask), 0u));
@@ -389,9 +390,8 @@ __device__ __forceinline__ void drain_wo(const PackedView& K, const PatternTable
         else replay_o(K, T, L, Q, lane);
     }
 }
-// Room for one more round of pushes (W <= 64, O <= 64, M <= 64).
+// Room for one more round of pushes (W <= 64, O <= 64); the M stack is checked where an M item turns up.
 __device__ __forceinline__ void make_room(const PackedView& K, const PatternTableView& T, FastLds& L, WaveStacks& Q, int lane) {
-    while (Q.nm > uint32_t(kMCap - 64)) replay_m(K, T, L, Q, lane);   // every pass moves its items one slot on
     drain_wo(K, T, L, Q, lane, kQHigh);
 }
 
@@ -406,7 +406,7 @@ __device__ __forceinline__ uint64_t phase_mark(uint64_t* prof, int slot, uint64_
 // DBG: the diagnostics build (VPT_DEBUG_ABLATE timing ablations, VPT_PROFILE_PHASES) -- compiled out of the kernel
 // production launches use.
 template <int TM, bool DBG>
-__global__ __launch_bounds__(kThreads, 5) void score_tiles_fast_kernel(const ScoreParams P_in) {
+__global__ __launch_bounds__(kThreads, 6) void score_tiles_fast_kernel(const ScoreParams P_in) {
     ScoreParams P = P_in;
     if (!DBG) { P.debug = 0; P.prof = nullptr; }
     VPT_DYNAMIC_LDS(smem);
@@ -598,7 +598,8 @@ __global__ __launch_bounds__(kThreads, 5) void score_tiles_fast_kernel(const Sco
         int32_t a2 = sext(u.y >> 10, kUniFieldBits), a3 = sext(__builtin_amdgcn_alignbit(u.z, u.y, 31), kUniFieldBits);
         int32_t a4 = sext(__builtin_amdgcn_alignbit(u.w, u.z, 20), kUniFieldBits), a5 = sext(u.w >> 9, kUniFieldBits);
         if (TM == kTypeRows) {
-            const uint4 tr = L.trow[((x1 >> 16) & 7u) | (((x2 >> 16) & 7u) << 3) | (((x3 >> 16) & 7u) << 6)];
+            // a dead lane (t1 = 0) reads the 16 bytes in front of the rows; nothing is added for it
+            const uint4 tr = L.trow[int32_t(type_row_index((x1 >> 16) & 7u, (x2 >> 16) & 7u, (x3 >> 16) & 7u))];
             // six 18-bit signed fields at bits 0, 18, 36, 54, 72, 90 (layout.h, trow_field)
             a0 += int32_t(tr.x << 14) >> 14;
             a1 += int32_t(__builtin_amdgcn_alignbit(tr.y, tr.x, 18) << 14) >> 14;
@@ -621,8 +622,11 @@ __global__ __launch_bounds__(kThreads, 5) void score_tiles_fast_kernel(const Sco
         make_room(K, P.ct, L, Q, lane);
         Q.push_w(rk != 0 && !nowalk, s | (3u << 11), rk);
         Q.push_o(ovp, s, ov_ref);
-        if (__ballot(kinds != 0) != 0)   // rare: rows outside i16, or a record placed by the fallback of the perfect hash
+        const uint64_t mm = __ballot(kinds != 0 && !(P.debug & 32u));
+        if (mm != 0) {   // rare: rows outside their fields, or a record placed by the fallback of the perfect hash
+            while (Q.nm + uint32_t(__popcll(mm)) > uint32_t(kMCap)) replay_m(K, P.ct, L, Q, lane);   // every pass moves its items one slot on
             Q.push_m(kinds != 0 && !(P.debug & 32u), s | (kinds << 11), (dfl & kPkFar) ? (hrec + 1) & K.rec_mask : hrec | ((dfl >> kPkHopShift) << 24));
+        }
         if (__ballot(lk != 0) != 0) {
             make_room(K, P.ct, L, Q, lane);
             Q.push_w(lk != 0 && !nowalk, (s - 1) | (3u << 11), lk);

@@ -87,9 +87,9 @@
 // contains it, so it matches nothing.
 //
 // TYPE ROWS.  When every type n-gram has at most 3 symbols and W_t <= 3 (the trainer's defaults), the type scores
-// are folded into the same start-position form: trow[t1 | t2<<3 | t3<<6] = the six totals (boundaries
+// are folded into the same start-position form: trow[type_row_index(t1, t2, t3)] = the six totals (boundaries
 // s-3 .. s+2; 18-bit signed fields, three i16 weights always fit) of the type unigram t1, bigram (t1,t2) and
-// trigram (t1,t2,t3) -- 512 rows of 16 bytes that the
+// trigram (t1,t2,t3) -- 6 * 7 * 7 = 294 rows of 16 bytes (t1 = 1..6, t2 and t3 = 0..6) that the
 // kernel keeps in LDS, which removes the per-boundary gather from the 8^(2W) window table.  Code 0 (outside the
 // sentence) only ever appears as t2/t3 and selects the shorter n-grams, exactly what the window table encodes
 // (boundary_scorer_cache.rs:30-57).  Models outside this shape use the window table (W_t <= 3) as before.
@@ -151,6 +151,9 @@ VPT_HD int32_t row_field(uint32_t x, uint32_t y, uint32_t z, uint32_t w, int j, 
     return int32_t(uint32_t(v) << (32 - bits)) >> (32 - bits);
 }
 VPT_HD bool fits_field(int32_t v, int bits) { return v >= -(1 << (bits - 1)) && v < (1 << (bits - 1)); }
+
+constexpr uint32_t kTypeRowCount = 6 * 7 * 7;
+VPT_HD uint32_t type_row_index(uint32_t t1, uint32_t t2, uint32_t t3) { return (t1 - 1u) + 6u * t2 + 42u * t3; }   // t1 in 1..6
 
 // type row: six 18-bit signed fields packed little-endian into dwords 0..3 (bits 0..107)
 VPT_HD int32_t trow_field(uint32_t x, uint32_t y, uint32_t z, uint32_t w, int j) {

@@ -513,10 +513,11 @@ std::vector<uint32_t> build_type_rows(const std::vector<NgramRecord>& ngrams, in
             row[slot] = wadd(row[slot], d.weights[k]);
         }
     }
-    std::vector<uint32_t> out(size_t(512) * 4, 0);
+    std::vector<uint32_t> out(size_t(kTypeRowCount) * 4, 0);
     for (uint32_t idx = 0; idx < 512; ++idx) {
         const uint32_t t1 = idx & 7, t2 = (idx >> 3) & 7, t3 = idx >> 6;
-        if (t1 == 0 || t1 == 7) continue;
+        if (t1 == 0 || t1 == 7 || t2 == 7 || t3 == 7) continue;
+        const uint32_t row = type_row_index(t1, t2, t3);
         int64_t r[6];
         for (int j = 0; j < 6; ++j) {
             r[j] = uni[t1 * 6 + j];
@@ -528,7 +529,7 @@ std::vector<uint32_t> build_type_rows(const std::vector<NgramRecord>& ngrams, in
         }
         unsigned __int128 bits = 0;
         for (int j = 0; j < 6; ++j) bits |= (unsigned __int128)(uint64_t(r[j]) & 0x3FFFFu) << (18 * j);
-        for (int q = 0; q < 4; ++q) out[idx * 4 + q] = uint32_t(bits >> (32 * q));
+        for (int q = 0; q < 4; ++q) out[row * 4 + q] = uint32_t(bits >> (32 * q));
     }
     return out;
 }

@@ -36,7 +36,7 @@ struct HostPackedTable {
     std::vector<uint32_t> kids3;   // 4 dwords per entry
     std::vector<uint32_t> deep;    // 8 dwords per entry
     std::vector<int32_t> xrows;    // external i32 rows
-    std::vector<uint32_t> trow;    // 512 type rows x 4 dwords, empty when the type n-grams do not fit the form
+    std::vector<uint32_t> trow;    // kTypeRowCount type rows x 4 dwords, empty when the type n-grams do not fit the form
     std::vector<uint8_t> seed;     // perfect-hash seed per bucket of record keys
     uint32_t rec_bits = 4, seed_bits = 0;
     // statistics
