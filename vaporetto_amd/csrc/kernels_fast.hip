@@ -559,6 +559,7 @@ __global__ __launch_bounds__(kThreads, 6) void score_tiles_fast_kernel(const Sco
         nseed = uint32_t(K.base[K.off_seed + packed_ph_bucket((nx1 & kCpMask) | ((nx2 & kCpMask) << 16), K.seed_shift)]);
     };
     stage(uint32_t(tid));
+    const uint32_t off_rec = K.off_rec & ~255u;   // it IS 256-byte aligned (capi.cpp); now the compiler knows
     for (int k = 0; k < kPerThread; ++k) {
         if (P.debug & 16u) break;  // timing ablation: no pattern phase at all
         const uint32_t s = uint32_t(tid) + uint32_t(k) * kThreads;
@@ -576,10 +577,12 @@ __global__ __launch_bounds__(kThreads, 6) void score_tiles_fast_kernel(const Sco
         const uint4 u = ld16(K.base, K.off_uni + (((P.debug & 4u) ? 0u : c1) << 4));
         const uint32_t p_hrec = pair_swap(hrec);
         const bool odd = (lane & 1) != 0;
-        const uint32_t ra = K.off_rec + (((odd ? p_hrec : hrec) << 7) | (odd ? 64u : 0u));
-        const uint32_t rb = K.off_rec + (((odd ? hrec : p_hrec) << 7) | (odd ? 0u : 64u));
-        const uint4 qa0 = ld16(K.base, ra), qa1 = ld16(K.base, ra + 16), qa2 = ld16(K.base, ra + 32), qa3 = ld16(K.base, ra + 48);   // even lane: own half 0; odd lane: partner's half 1
-        const uint4 qb0 = ld16(K.base, rb), qb1 = ld16(K.base, rb + 16), qb2 = ld16(K.base, rb + 32), qb3 = ld16(K.base, rb + 48);   // even lane: partner's half 1; odd lane: own half 0
+        // a half record = 64 aligned bytes: the three further units are the same address with 16, 32, 48 OR-ed in,
+        // which the compiler folds into the loads' immediate offsets
+        const uint32_t ra = off_rec + (((odd ? p_hrec : hrec) << 7) | (odd ? 64u : 0u));
+        const uint32_t rb = off_rec + (((odd ? hrec : p_hrec) << 7) | (odd ? 0u : 64u));
+        const uint4 qa0 = ld16(K.base, ra), qa1 = ld16(K.base, ra | 16u), qa2 = ld16(K.base, ra | 32u), qa3 = ld16(K.base, ra | 48u);   // even lane: own half 0; odd lane: partner's half 1
+        const uint4 qb0 = ld16(K.base, rb), qb1 = ld16(K.base, rb | 16u), qb2 = ld16(K.base, rb | 32u), qb3 = ld16(K.base, rb | 48u);   // even lane: partner's half 1; odd lane: own half 0
         // own half 0 = even ? qa : qb (already here); own half 1 = the partner's qb (even lanes) / qa (odd lanes)
         const uint4 h0 = odd ? qb0 : qa0, r1 = odd ? qb1 : qa1, r2 = odd ? qb2 : qa2, r3 = odd ? qb3 : qa3;
         if (k + 1 < kPerThread) stage(s + uint32_t(kThreads));          // next iteration's symbols and seed
@@ -640,29 +643,35 @@ __global__ __launch_bounds__(kThreads, 6) void score_tiles_fast_kernel(const Sco
     tmark = phase_mark(prof, 3, tmark);
 
     // ---------------------------------------------------------------- C. boundaries
-    for (uint32_t p = pad + uint32_t(tid); p + 1 < flat_len; p += kThreads) {
-        const uint32_t x = L.sym[p];
-        if ((x & kCpMask) == 0 || (L.sym[p + 1] & kCpMask) == 0) continue;
+    // boundary p lies between flat positions p and p + 1, both chars of one sentence; its output index is the
+    // tile's first boundary + (p - pad) - (pad + 1) * (sentence in tile): 32-bit offsets from scalar bases
+    const uint32_t nb = uint32_t(O1 - O0);
+    int32_t* const sc = P.scores ? P.scores + O0 : nullptr;
+    uint8_t* const lb = P.labels ? P.labels + O0 : nullptr;
+#pragma unroll
+    for (int k = 0; k < kPerThread; ++k) {
+        if (wbase + uint32_t(k) * kThreads + pad + 1 >= flat_len) break;   // wave-uniform
+        const uint32_t p = pad + uint32_t(tid) + uint32_t(k) * kThreads;   // p + 1 < kFastCap + kMargin; zero past the tile
+        const uint32_t x = L.sym[p], x2 = L.sym[p + 1];
         int32_t y = P.bias + L.score[p];
+        if ((x & kCpMask) == 0 || (x2 & kCpMask) == 0) continue;
         if (TM >= 1 && TM <= 3) {
             uint32_t id = 0;  // window t[b-W+1 .. b+W], 3 bits each (boundary_scorer_cache.rs:59-81)
 #pragma unroll
             for (int i = 1 - TM; i <= TM; ++i) id = (id << 3) | (L.typ[int(p) + i] & 7u);
             y += P.type_table[id];
         }
-        const uint32_t si = x >> 19;
-        const uint64_t o = O0 + (p - pad) - uint64_t(pad + 1) * si;
-        if (o >= O1) { err |= kErrBadOffsets; continue; }  // only with offsets that do not match the text
-        if (P.scores) P.scores[o] = y;
-        if (P.labels) {
+        const uint32_t o = (p - pad) - (pad + 1) * (x >> 19);
+        if (o >= nb) { err |= kErrBadOffsets; continue; }  // only with offsets that do not match the text
+        if (sc) sc[o] = y;
+        if (lb) {
             uint32_t label = y > 0 ? 1u : 0u;
             if (P.post) {   // wave-uniform: KyteaWsConstFilter / SplitLinebreaksFilter on the label
-                const uint32_t x2 = L.sym[p + 1];
                 const uint32_t t1 = (x >> 16) & 7u, t2 = (x2 >> 16) & 7u, ca = x & kCpMask, cb = x2 & kCpMask;
                 if (t1 == t2 && ((P.post >> t1) & 1u) && t1 != 0 && t1 != 7) label = 0;
                 if ((P.post & 0x80u) && (ca == 0x0Au || ca == 0x0Du || cb == 0x0Au || cb == 0x0Du)) label = 1;
             }
-            P.labels[o] = uint8_t(label);
+            lb[o] = uint8_t(label);
         }
     }
     if (err) atomicOr(P.status, err);
