@@ -1,4 +1,5 @@
-"""Randomised GPU-vs-oracle sweep (run on the GPU box from the repo root: `python tools/fuzz_gpu.py [seconds]`).
+"""Randomised GPU-vs-oracle sweep (run on the GPU box from the repo root: `python tools/fuzz_gpu.py [seconds]`;
+with VPT_FUZZ_EMULATED=1 the kernels run on the CPU emulator of tests/native/hipemu instead -- slower, no GPU needed).
 Random models (alphabet size, pattern counts, windows, word lengths, wide weights, tag models) and random ragged
 batches with the label post-filters / fullwidth flag toggled; stops at the first mismatch."""
 import os
@@ -15,6 +16,10 @@ from vaporetto_amd import api  # noqa: E402
 from vaporetto_amd.modelfmt import encode_model  # noqa: E402
 
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
+if os.environ.get("VPT_FUZZ_EMULATED"):   # the same sweep over the kernel sources on the CPU emulator (tests/emu.py)
+    from tests import emu  # noqa: E402
+    from vaporetto_amd import _lib  # noqa: E402
+    _lib._lib = emu.load()
 t_end = time.time() + budget
 seed = n_models = n_sent = 0
 f = api.KyteaFullwidthFilter()

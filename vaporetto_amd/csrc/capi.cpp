@@ -322,7 +322,8 @@ vpt_status vpt_predictor_create(const uint8_t* model_bytes, size_t len, int pred
             probe.ct = p->ct; probe.pk = p->pk; probe.pad = p->pad; probe.ctype = p->d_ctype; probe.ctab = p->d_cinfo; probe.type_kind = p->type_kind;
             probe.type_window = p->type_window;
             const bool fast = vpt::fast_path_supported(probe);
-            const size_t lds = fast ? vpt::score_tiles_fast_lds_bytes(probe) : vpt::score_tiles_lds_bytes();
+            size_t lds = fast ? vpt::score_tiles_fast_lds_bytes(probe) : vpt::score_tiles_lds_bytes();
+            if (const char* padv = std::getenv("VPT_DEBUG_LDS_PAD")) lds += size_t(std::atoi(padv));   // occupancy experiments (kernels_fast.hip)
             const size_t granules = (lds + 1279) / 1280;   // gfx950 hands out its 160 KB of LDS in 1280-byte granules
             // the specialised kernel is built for 6 workgroups of 4 waves per CU (<= 80 VGPRs), the general one for 8
             const uint32_t per_cu = uint32_t(std::min<size_t>(fast ? 6 : 8, std::max<size_t>(1, 128 / std::max<size_t>(granules, 1))));
