@@ -9,16 +9,16 @@
 //     costs ONE random line.  A lane PAIR fetches the two 64-byte halves of a record in the same instruction (first
 //     the even lane's record, then the odd lane's), which the memory pipeline rewards (tools/gather_bench.hip), and
 //     hands the partner's half over through DPP, so that every lane ends up with its own whole record;
-//   * the unigram row (16 bytes, cache-hot; 21-bit fields), the type row (LDS; 18-bit fields), the bigram row (22-bit
-//     fields) and the matching right child are summed in registers and land in the LDS score array with six ds_add_u32 (integer => order-free => bit-exact);
-//     a matching left child adds its four values one position earlier;
+//   * the unigram row (16 bytes, cache-hot; 21-bit fields), the type row (LDS; 18-bit fields), the bigram row
+//     (22-bit fields) and the matching right and left children are summed in registers and land in the LDS score
+//     array with six ds_add_u32 (integer => order-free => bit-exact);
 //   * everything data-dependent is NOT done in place (64 lanes would wait for the unluckiest one): it is pushed,
 //     ballot/mbcnt-compacted, onto wave-private LDS stacks -- one per kind, so that a replay runs one short code
 //     path with every lane busy: W trie steps of dictionary words longer than 3 chars (a step that matches
 //     re-queues its continuation), O overflow-child probes (prefixes whose children fit neither side), M the rare
-//     rest (a record displaced from its home slot, rows with a value outside i16);
-//   * UTF-8 decode is two-step: a chunk scan finds (byte position, sentence) of every char, then one thread per
-//     CHAR decodes from the LDS-staged text (branch-free) and classifies it with a 64 KB table;
+//     rest (a record displaced from its home slot, rows with a value outside their fields);
+//   * UTF-8 decode: the text is staged in LDS, a chunk scan numbers chars and sentences, the thread that scanned a
+//     chunk decodes its chars (branch-free) straight into their flat positions, a second pass classifies them;
 //   * 26 KB of LDS and at most 80 VGPRs per workgroup: 6 workgroups per CU.
 #include <hip/hip_runtime.h>
 
@@ -42,7 +42,7 @@ static_assert(kMargin >= int(kPackedMaxSkip), "replay_w reads up to kPackedMaxSk
 constexpr int kTrowCount = int(kTypeRowCount);   // layout.h, type_row_index
 
 struct FastLds {
-    uint32_t sym[kFastCap + kMargin];        // decode step 1 keeps (byte pos | sentence << 16) per char here
+    uint32_t sym[kFastCap + kMargin];        // zero except for the tile's chars (scalar value | sentence << 21 until classified)
     int32_t score[kFastCap + kMargin];       // staged text bytes during decode
     uint2 queue[kWavesF][kQCap];             // sentence-start bitmap during decode
     uint2 mqueue[kWavesF][kMCap];
