@@ -319,7 +319,7 @@ vpt_status vpt_predictor_create(const uint8_t* model_bytes, size_t len, int pred
         hipDeviceProp_t prop;
         if (hipGetDeviceProperties(&prop, device_id) == hipSuccess && prop.multiProcessorCount > 0) {
             vpt::ScoreParams probe{};
-            probe.ct = p->ct; probe.pk = p->pk; probe.pad = p->pad; probe.ctype = p->d_ctype; probe.ctab = p->d_cinfo; probe.type_kind = p->type_kind;
+            probe.ct = p->ct; probe.pk = p->pk; probe.pad = p->pad; probe.ctype = p->d_ctype; probe.type_kind = p->type_kind;
             probe.type_window = p->type_window;
             const bool fast = vpt::fast_path_supported(probe);
             size_t lds = fast ? vpt::score_tiles_fast_lds_bytes(probe) : vpt::score_tiles_lds_bytes();
@@ -461,7 +461,6 @@ vpt_status vpt_predict_batch_device(const vpt_predictor* p, vpt_batch* b, const 
     P.ct = p->ct; P.tt = p->tt; P.pk = p->pk; P.type_table = p->d_type_table;
     P.ctype = p->d_ctype;
     P.cinfo = (b->flags & VPT_FLAG_KYTEA_FULLWIDTH) ? p->d_cinfo + 65536 : nullptr;
-    P.ctab = p->d_cinfo + ((b->flags & VPT_FLAG_KYTEA_FULLWIDTH) ? 65536 : 0);
     P.post = b->flags & 0xFEu;
     P.type_window = p->type_window; P.type_kind = p->type_kind; P.bias = p->bias; P.pad = p->pad;
     // Tiles are cut every `tile_flat` flat positions (chars + separators) and end with the sentence that crosses

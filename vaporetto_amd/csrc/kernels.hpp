@@ -32,8 +32,6 @@ struct ScoreParams {
     const uint8_t* ctype;       // CharacterType of every BMP scalar value (65536 bytes)
     const uint32_t* cinfo;      // only with VPT_FLAG_KYTEA_FULLWIDTH, else nullptr: per BMP scalar value the char it is
                                 // scored as (KyteaFullwidthFilter's image) | CharacterType of that char << 16
-    const uint32_t* ctab;       // the same table, always set: the plain half or (VPT_FLAG_KYTEA_FULLWIDTH) the filtered half;
-                                // U+FFFF is scored as kPackedNoMatchSym there (specialised kernel)
     int32_t type_window;
     int32_t type_kind;
     int32_t bias;

@@ -528,8 +528,10 @@ __global__ __launch_bounds__(kThreads, 6) void score_tiles_fast_kernel(const Sco
 #pragma unroll
         for (int k = 0; k < kPerThread; ++k) {
             xs[k] = L.sym[uint32_t(tid) + uint32_t(k) * kThreads];   // zero past the tile
-            const uint32_t cp = xs[k] & 0x1FFFFFu;
-            info[k] = P.ctab[cp < 0x10000u ? cp : 0u];               // the char it is scored as | CharacterType << 16
+            const uint32_t cp = xs[k] & 0x1FFFFFu, idx = cp < 0x10000u ? cp : 0u;
+            // the char it is scored as | CharacterType << 16: itself and a byte of the 64 KB type table, or -- wave-uniform,
+            // with VPT_FLAG_KYTEA_FULLWIDTH -- a word of the table that also holds KyteaFullwidthFilter's image
+            info[k] = P.cinfo ? P.cinfo[idx] : (idx | (uint32_t(P.ctype[idx]) << 16));
         }
 #pragma unroll
         for (int k = 0; k < kPerThread; ++k) {
@@ -681,7 +683,7 @@ __global__ __launch_bounds__(kThreads, 6) void score_tiles_fast_kernel(const Sco
 }  // namespace
 
 bool fast_path_supported(const ScoreParams& P) {
-    if (!P.pk.present || P.pad != 3 || !P.ctab) return false;
+    if (!P.pk.present || P.pad != 3 || !P.ctype) return false;
     if (!P.ct.present || P.ct.stride_dw != 8 || P.ct.uni_dw != 8 || P.ct.uni_n != kUniDirectChars) return false;  // kPkWide rows
     if (P.type_kind == kTypeNone) return true;
     return P.type_kind == kTypeWindowTable && P.type_window >= 1 && P.type_window <= 3;
