@@ -182,6 +182,28 @@ vpt_status vpt_fill_tags_batch_device(const vpt_predictor *p, vpt_batch *b, cons
                                       size_t n_sentences, uint64_t total_boundaries, const uint8_t *d_labels,
                                       int32_t *d_tags_out, void *hip_stream);
 
+/* ---------------------------------------------------------------------------------------------------------
+ * Sentence::write_tokenized_text over a batch, boundary part                            (sentence.rs:850-886)
+ *
+ * Every sentence's tokens (the runs between WordBoundary labels, sentence.rs:1270-1300) joined by ' ', with a '\\' in
+ * front of every ' ', '\\' and '/' of a surface -- what `vaporetto` prints for a model without tag models.  ("/tag"
+ * suffixes are host-side strings: append them from vpt_fill_tags_batch's indices, as vaporetto_amd/api.py does.)
+ * labels          : 0 / 1 per boundary, laid out like labels_out of vpt_predict_batch; VPT_BOUNDARY_UNKNOWN (only
+ *                   partially annotated corpora have it, never predict) is VPT_INVALID_ARGUMENT.
+ * text_out        : the tokenized sentences back to back, text_capacity bytes; 2 * (text bytes) + (chars) always
+ *                   suffices.  Too small a capacity is VPT_INVALID_ARGUMENT, nothing useful is written.
+ * text_offsets_out: [n_sentences + 1] byte range of every sentence's tokenized text in text_out. */
+vpt_status vpt_write_tokenized_batch(const vpt_predictor *p, const uint8_t *utf8, const uint64_t *byte_offsets,
+                                     size_t n_sentences, const uint64_t *out_offsets, const uint8_t *labels,
+                                     uint8_t *text_out, uint64_t text_capacity, uint64_t *text_offsets_out);
+/* Device-resident variant: all pointers are device pointers, asynchronous on `hip_stream`; errors at vpt_batch_sync.
+ * Three small kernels: count, prefix sum over the sentences, write (kernels_emit.hip). */
+vpt_status vpt_write_tokenized_batch_device(const vpt_predictor *p, vpt_batch *b, const uint8_t *d_utf8,
+                                            const uint64_t *d_byte_offsets, const uint64_t *d_out_offsets,
+                                            size_t n_sentences, uint64_t total_boundaries, const uint8_t *d_labels,
+                                            uint8_t *d_text_out, uint64_t text_capacity,
+                                            uint64_t *d_text_offsets_out, void *hip_stream);
+
 /* Diagnostics: when the environment variable VPT_PROFILE_PHASES is set at vpt_batch_create, the specialised
  * kernel accumulates, per workgroup (wave 0), the shader cycles spent in 0 text scan, 1 per-char decode,
  * 2 pattern lookups, 3 barrier wait, 4 boundary output.  Reads the sums (after a device sync) and resets them;

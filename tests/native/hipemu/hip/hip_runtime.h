@@ -86,6 +86,7 @@ void run_grid(dim3 grid, dim3 block, size_t lds_bytes, const std::function<void(
 uint64_t ballot(bool pred);
 uint32_t dpp(uint32_t old, uint32_t src, unsigned ctrl, unsigned row_mask, unsigned bank_mask, bool bound_ctrl);
 uint32_t shfl_up(uint32_t v, unsigned delta);
+uint32_t shfl_xor(uint32_t v, unsigned mask);
 uint32_t readfirstlane(uint32_t v);
 void wave_sync();
 void block_sync();
@@ -104,6 +105,7 @@ static inline void __syncthreads() { ::hipemu::block_sync(); }
 static inline uint64_t __ballot(int pred) { return ::hipemu::ballot(pred != 0); }
 static inline int __shfl_up(int v, unsigned d) { return int(::hipemu::shfl_up(uint32_t(v), d)); }
 static inline unsigned __shfl_up(unsigned v, unsigned d) { return ::hipemu::shfl_up(v, d); }
+static inline int __shfl_xor(int v, int m) { return int(::hipemu::shfl_xor(uint32_t(v), unsigned(m))); }
 static inline int __popc(uint32_t x) { return __builtin_popcount(x); }
 static inline int __popcll(uint64_t x) { return __builtin_popcountll(x); }
 static inline int __ffs(int x) { return __builtin_ffs(x); }

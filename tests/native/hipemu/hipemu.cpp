@@ -125,6 +125,15 @@ uint32_t shfl_up(uint32_t v, unsigned delta) {
     return (l >= delta && ((*who >> (l - delta)) & 1u)) ? b[l - delta] : v;
 }
 
+uint32_t shfl_xor(uint32_t v, unsigned mask) {
+    Wave& w = my_wave();
+    const unsigned l = lane(), from = (l ^ mask) & 63u;
+    const uint64_t* who;
+    const uint32_t* b = w.deposit(l, v, &who);
+    arrive_and_wait(w);
+    return ((*who >> from) & 1u) ? b[from] : v;
+}
+
 uint32_t readfirstlane(uint32_t v) {   // the value of the lowest lane that takes part
     Wave& w = my_wave();
     const uint64_t* who;

@@ -668,3 +668,68 @@ def test_fill_tags_with_offsets_that_do_not_match_the_text():
     batch.fill_tags(d_text.ptr, d_boff.ptr, d_ooff.ptr, S, nb, d_labels.ptr, d_tags.ptr, devmem.stream())
     batch.sync()
     assert np.array_equal(d_tags.get((nb + S) * nt).reshape(nb + S, nt), want)
+
+
+# ------------------------------------------------------------------------------------------------ token emission
+def _tokenized_reference(text, labels):
+    """sentence.rs:850-886 restated: runs between WordBoundary labels, ' ' between them, '\\' before ' ', '\\', '/'."""
+    out, tok = [], []
+    for i, c in enumerate(text):
+        tok.append("\\" + c if c in " \\/" else c)
+        if i == len(text) - 1 or labels[i] == 1:
+            out.append("".join(tok))
+            tok = []
+    return " ".join(out)
+
+
+def test_write_tokenized_text_on_device():
+    """vpt_write_tokenized_batch = Sentence::write_tokenized_text (boundary part) for every sentence of a batch."""
+    raw, _ = kat.load_fixture("model.bin")
+    pred = api.Predictor(api.Model.read_slice(raw)[0], False)
+    for text, expected, _cite in [(t, e, c) for _f, t, e, c in kat.FIXTURE_SPLITS if _f == "model.bin"]:
+        s = api.Sentence.from_raw(text)
+        pred.predict(s)
+        assert pred.write_tokenized_batch([s]) == [" ".join(expected)] == [s.write_tokenized_text()]
+    rng = np.random.default_rng(11)
+    alphabet = list("あいう漢字ab /\\\\/ .🤌é") + ["\n"]
+    texts = ["".join(rng.choice(alphabet, size=int(n))) for n in list(rng.integers(1, 40, 300)) + [1, 1, 63, 64, 65, 127, 128, 129, 700]]
+    utf8, boff = api.pack_texts([t.encode("utf-8") for t in texts])
+    ooff = api.count_boundaries(utf8, boff)
+    labels = (rng.random(int(ooff[-1])) < 0.4).astype(np.uint8)
+    text, toff = pred.write_tokenized_packed(utf8, boff, ooff, labels)
+    got = bytes(text)
+    for i, t in enumerate(texts):
+        want = _tokenized_reference(t, labels[int(ooff[i]):int(ooff[i + 1])])
+        assert got[int(toff[i]):int(toff[i + 1])].decode("utf-8") == want, (i, t)
+    # the mirror's own writer agrees (it is the oracle of the reference's doc tests, tests/test_host_cabi.py)
+    sents = []
+    for i, t in enumerate(texts[:50]):
+        s = api.Sentence.from_raw(t)
+        s._boundaries = labels[int(ooff[i]):int(ooff[i + 1])].copy()
+        sents.append(s)
+    assert pred.write_tokenized_batch(sents) == [s.write_tokenized_text() for s in sents]
+    # errors: an Unknown label, offsets that do not match the text, too small a buffer
+    bad = labels.copy(); bad[3] = 2
+    with pytest.raises(api.VaporettoError, match="can be written as tokenized text"):
+        pred.write_tokenized_packed(utf8, boff, ooff, bad)
+    short = ooff.copy(); short[5:] -= 1
+    with pytest.raises(api.VaporettoError, match="do not match the text"):
+        pred.write_tokenized_packed(utf8, boff, short, labels)
+    L = api._lib.load()
+    tiny = np.zeros(8, np.uint8); toff2 = np.zeros(len(texts) + 1, np.uint64)
+    st = L.vpt_write_tokenized_batch(pred.handle, utf8.ctypes.data, boff.ctypes.data, len(texts), ooff.ctypes.data, labels.ctypes.data,
+                                     tiny.ctypes.data, 8, toff2.ctypes.data)
+    assert st == api._lib.VPT_INVALID_ARGUMENT and "text_capacity" in api._lib.last_error()
+    # device-resident: predict -> write on one stream
+    d_text = devmem.put(np.concatenate([utf8, np.zeros(16, np.uint8)])); d_boff = devmem.put(boff.astype(np.uint64)); d_ooff = devmem.put(ooff.astype(np.uint64))
+    nb, S = int(ooff[-1]), len(texts)
+    d_scores = devmem.zeros(nb + 1, np.int32); d_labels = devmem.zeros(nb + 1, np.uint8)
+    cap = 2 * len(utf8) + nb + S
+    d_out = devmem.zeros(cap + 1, np.uint8); d_toff = devmem.zeros(S + 1, np.uint64)
+    batch = api.DeviceBatch(pred)
+    batch.predict(d_text.ptr, d_boff.ptr, d_ooff.ptr, S, nb, int(np.max(np.diff(boff.astype(np.int64)))), d_scores.ptr, d_labels.ptr, devmem.stream())
+    batch.write_tokenized(d_text.ptr, d_boff.ptr, d_ooff.ptr, S, nb, d_labels.ptr, d_out.ptr, cap, d_toff.ptr, devmem.stream())
+    batch.sync()
+    _, lab, _ = pred.predict_packed(utf8, boff)
+    want_text, want_off = pred.write_tokenized_packed(utf8, boff, ooff, lab)
+    assert np.array_equal(d_toff.get(S + 1), want_off) and np.array_equal(d_out.get(int(want_off[-1])), want_text)

@@ -46,6 +46,7 @@ _AS_IS = [
     "test_fill_tags_requires_predict_tags_gpu", "test_fixture_tags_gpu", "test_random_tag_models_match_oracle",
     "test_converted_kytea_fixture_on_gpu", "test_fullwidth_filter_on_device", "test_label_post_filters_on_device",
     "test_device_resident_predict_then_fill_tags", "test_fill_tags_with_offsets_that_do_not_match_the_text",
+    "test_write_tokenized_text_on_device",
 ]
 for _name in _AS_IS:
     globals()[_name] = getattr(G, _name)

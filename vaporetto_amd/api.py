@@ -338,6 +338,45 @@ class Predictor:
             _raise(st)
         return tags[:, :nt]
 
+    def write_tokenized_packed(self, utf8: np.ndarray, byte_offsets: np.ndarray, out_offsets: np.ndarray,
+                               labels: np.ndarray):
+        """Sentence::write_tokenized_text (sentence.rs:850-886), boundary part, over a packed batch on the device.
+        Returns (uint8 text, uint64 [S+1] offsets): sentence i is text[offsets[i]:offsets[i+1]]."""
+        L = _lib.load()
+        utf8 = np.ascontiguousarray(utf8, dtype=np.uint8)
+        byte_offsets = np.ascontiguousarray(byte_offsets, dtype=np.uint64)
+        out_offsets = np.ascontiguousarray(out_offsets, dtype=np.uint64)
+        labels = np.ascontiguousarray(labels, dtype=np.uint8)
+        S = len(byte_offsets) - 1
+        nbytes = int(byte_offsets[S] - byte_offsets[0]) if S else 0
+        cap = 2 * nbytes + (int(out_offsets[S] - out_offsets[0]) + S if S else 0)
+        text = np.zeros(max(cap, 1), dtype=np.uint8)
+        toff = np.zeros(S + 1, dtype=np.uint64)
+        lab = labels if len(labels) else np.zeros(1, dtype=np.uint8)
+        st = L.vpt_write_tokenized_batch(self._h, utf8.ctypes.data, byte_offsets.ctypes.data, S, out_offsets.ctypes.data,
+                                         lab.ctypes.data, text.ctypes.data, cap, toff.ctypes.data)
+        if st != _lib.VPT_OK:
+            _raise(st)
+        return text[:int(toff[S])], toff
+
+    def write_tokenized_batch(self, sentences: Sequence["Sentence"]) -> List[str]:
+        """write_tokenized_text for many sentences in one launch; tag suffixes (host-side strings) are appended here."""
+        if not sentences:
+            return []
+        utf8, boff = pack_texts([s._utf8 for s in sentences])
+        ooff = np.zeros(len(sentences) + 1, dtype=np.uint64)
+        ooff[1:] = np.cumsum([len(s) - 1 for s in sentences])
+        labels = np.concatenate([np.asarray(s._boundaries, dtype=np.uint8) for s in sentences]) if int(ooff[-1]) else np.zeros(0, np.uint8)
+        text, toff = self.write_tokenized_packed(utf8, boff, ooff, labels)
+        raw = bytes(text)
+        out = []
+        for i, s in enumerate(sentences):
+            t = raw[int(toff[i]):int(toff[i + 1])].decode("utf-8")
+            if s._n_tags:   # "/tag" suffixes: splice them in token by token (rare path, host strings)
+                t = s.write_tokenized_text()
+            out.append(t)
+        return out
+
     def fill_tags_batch(self, sentences: Sequence["Sentence"]) -> None:
         """Sentence::fill_tags for many sentences in one launch; candidate indices are mapped to the tag strings of
         the tag model whose token equals the token's surface (the LAST one of a repeated token, predictor.rs:466-478)."""
@@ -437,6 +476,14 @@ class DeviceBatch:
         """Device-resident Sentence::fill_tags for the batch (vpt_fill_tags_batch_device); enqueues and returns."""
         st = _lib.load().vpt_fill_tags_batch_device(self._p.handle, self._h, d_utf8, d_boff, d_ooff, n_sentences,
                                                     total_boundaries, d_labels, d_tags, stream)
+        if st != _lib.VPT_OK:
+            _raise(st)
+
+    def write_tokenized(self, d_utf8: int, d_boff: int, d_ooff: int, n_sentences: int, total_boundaries: int, d_labels: int,
+                        d_text_out: int, text_capacity: int, d_text_offsets: int, stream: int = 0) -> None:
+        """Device-resident write_tokenized_text for the batch (vpt_write_tokenized_batch_device); enqueues and returns."""
+        st = _lib.load().vpt_write_tokenized_batch_device(self._p.handle, self._h, d_utf8, d_boff, d_ooff, n_sentences,
+                                                          total_boundaries, d_labels, d_text_out, text_capacity, d_text_offsets, stream)
         if st != _lib.VPT_OK:
             _raise(st)
 

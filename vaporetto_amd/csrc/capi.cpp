@@ -231,6 +231,10 @@ vpt_status status_from_bits(uint32_t bits) {
     if (bits & vpt::kErrNulChar) return fail(VPT_INVALID_ARGUMENT, "InvalidArgumentError: text: must not contain NULL");
     if (bits & vpt::kErrBadOffsets)
         return fail(VPT_INVALID_ARGUMENT, "InvalidArgumentError: out_offsets: do not match the text (or the text is not valid UTF-8)");
+    if (bits & vpt::kErrUnknownLabel)
+        return fail(VPT_INVALID_ARGUMENT, "InvalidArgumentError: labels: only NotWordBoundary (0) and WordBoundary (1) can be written as tokenized text");
+    if (bits & vpt::kErrOutputTooSmall)
+        return fail(VPT_INVALID_ARGUMENT, "InvalidArgumentError: text_capacity: smaller than the tokenized text");
     return fail(VPT_INVALID_ARGUMENT, "InvalidArgumentError: max_sentence_bytes / max_sentence_chars: smaller than the longest sentence");
 }
 
@@ -708,6 +712,78 @@ vpt_status vpt_fill_tags_batch_device(const vpt_predictor* p, vpt_batch* b, cons
     T.cps = b->d_cps; T.ooff = d_out_offsets; T.labels = d_labels; T.n_sent = n_sentences; T.total_chars = total_c; T.tags = d_tags_out;
     VPT_HIP(vpt::launch_tag_tokens(T, stream));
     b->last_stream = stream; b->pending = true;
+    return VPT_OK;
+}
+
+vpt_status vpt_write_tokenized_batch_device(const vpt_predictor* p, vpt_batch* b, const uint8_t* d_utf8, const uint64_t* d_byte_offsets,
+                                            const uint64_t* d_out_offsets, size_t n_sentences, uint64_t total_boundaries,
+                                            const uint8_t* d_labels, uint8_t* d_text_out, uint64_t text_capacity,
+                                            uint64_t* d_text_offsets_out, void* hip_stream) {
+    if (!p || !b || b->pred != p) return fail(VPT_INVALID_ARGUMENT, "InvalidArgumentError: batch: does not belong to this predictor");
+    if (!d_text_offsets_out) return fail(VPT_INVALID_ARGUMENT, "InvalidArgumentError: NULL device pointer");
+    hipStream_t stream = static_cast<hipStream_t>(hip_stream);
+    VPT_HIP(hipSetDevice(p->device));
+    if (n_sentences == 0) {
+        VPT_HIP(hipMemsetAsync(d_text_offsets_out, 0, sizeof(uint64_t), stream));
+        b->last_stream = stream; b->pending = true;
+        return VPT_OK;
+    }
+    if (!d_utf8 || !d_byte_offsets || !d_out_offsets || (total_boundaries && !d_labels) || (text_capacity && !d_text_out))
+        return fail(VPT_INVALID_ARGUMENT, "InvalidArgumentError: NULL device pointer");
+    vpt::EmitParams E{};
+    E.text = d_utf8; E.boff = d_byte_offsets; E.ooff = d_out_offsets; E.labels = d_labels; E.n_sent = n_sentences;
+    E.total_boundaries = total_boundaries; E.out_text = d_text_out; E.out_offsets = d_text_offsets_out; E.capacity = text_capacity;
+    E.status = b->d_ctrl;
+    VPT_HIP(vpt::launch_emit_tokenized(E, stream));
+    b->last_stream = stream; b->pending = true;
+    return VPT_OK;
+}
+
+vpt_status vpt_write_tokenized_batch(const vpt_predictor* p, const uint8_t* utf8, const uint64_t* byte_offsets, size_t n_sentences,
+                                     const uint64_t* out_offsets, const uint8_t* labels, uint8_t* text_out, uint64_t text_capacity,
+                                     uint64_t* text_offsets_out) {
+    if (!p) return fail(VPT_INVALID_ARGUMENT, "InvalidArgumentError: predictor: must not be NULL");
+    if (!text_offsets_out) return fail(VPT_INVALID_ARGUMENT, "InvalidArgumentError: NULL argument");
+    text_offsets_out[0] = 0;
+    if (n_sentences == 0) return VPT_OK;
+    if (!utf8 || !byte_offsets || !out_offsets || (text_capacity && !text_out)) return fail(VPT_INVALID_ARGUMENT, "InvalidArgumentError: NULL argument");
+    const uint64_t t0 = byte_offsets[0], t1 = byte_offsets[n_sentences];
+    if (t1 < t0) return fail(VPT_INVALID_ARGUMENT, "InvalidArgumentError: byte_offsets: must be non-decreasing");
+    const uint64_t total_b = out_offsets[n_sentences] - out_offsets[0];
+    if (total_b && !labels) return fail(VPT_INVALID_ARGUMENT, "InvalidArgumentError: labels: must not be NULL");
+    VPT_HIP(hipSetDevice(p->device));
+    vpt_batch* b = nullptr;
+    vpt_status st = vpt_batch_create(p, &b);
+    if (st != VPT_OK) return st;
+    struct Bufs {
+        vpt_batch* b; uint8_t *text = nullptr, *labels = nullptr, *out = nullptr; uint64_t *boff = nullptr, *ooff = nullptr, *toff = nullptr;
+        hipStream_t s = nullptr;
+        ~Bufs() {
+            (void)hipFree(text); (void)hipFree(labels); (void)hipFree(out); (void)hipFree(boff); (void)hipFree(ooff); (void)hipFree(toff);
+            if (s) (void)hipStreamDestroy(s);
+            batch_release(b);
+        }
+    } B{b};
+    std::vector<uint64_t> boff(n_sentences + 1), ooff(n_sentences + 1);
+    for (size_t i = 0; i <= n_sentences; ++i) { boff[i] = byte_offsets[i] - t0; ooff[i] = out_offsets[i] - out_offsets[0]; }
+    VPT_HIP(hipStreamCreateWithFlags(&B.s, hipStreamNonBlocking));
+    VPT_HIP(hipMalloc(reinterpret_cast<void**>(&B.text), size_t(t1 - t0) + 64));
+    VPT_HIP(hipMalloc(reinterpret_cast<void**>(&B.labels), size_t(total_b) + 64));
+    VPT_HIP(hipMalloc(reinterpret_cast<void**>(&B.out), size_t(text_capacity) + 64));
+    VPT_HIP(hipMalloc(reinterpret_cast<void**>(&B.boff), 8 * (n_sentences + 1)));
+    VPT_HIP(hipMalloc(reinterpret_cast<void**>(&B.ooff), 8 * (n_sentences + 1)));
+    VPT_HIP(hipMalloc(reinterpret_cast<void**>(&B.toff), 8 * (n_sentences + 1)));
+    VPT_HIP(hipMemcpyAsync(B.text, utf8 + t0, size_t(t1 - t0), hipMemcpyHostToDevice, B.s));
+    if (total_b) VPT_HIP(hipMemcpyAsync(B.labels, labels + out_offsets[0], size_t(total_b), hipMemcpyHostToDevice, B.s));
+    VPT_HIP(hipMemcpyAsync(B.boff, boff.data(), 8 * (n_sentences + 1), hipMemcpyHostToDevice, B.s));
+    VPT_HIP(hipMemcpyAsync(B.ooff, ooff.data(), 8 * (n_sentences + 1), hipMemcpyHostToDevice, B.s));
+    st = vpt_write_tokenized_batch_device(p, b, B.text, B.boff, B.ooff, n_sentences, total_b, B.labels, B.out, text_capacity, B.toff, B.s);
+    if (st != VPT_OK) return st;
+    st = vpt_batch_sync(b);
+    if (st != VPT_OK) return st;
+    VPT_HIP(hipMemcpy(text_offsets_out, B.toff, 8 * (n_sentences + 1), hipMemcpyDeviceToHost));
+    const uint64_t total = text_offsets_out[n_sentences];
+    if (total) VPT_HIP(hipMemcpy(text_out, B.out, size_t(total), hipMemcpyDeviceToHost));
     return VPT_OK;
 }
 

@@ -23,6 +23,8 @@ constexpr uint32_t kErrEmptySentence = 1u;    // "text: must contain at least on
 constexpr uint32_t kErrNulChar = 2u;          // "text: must not contain NULL"               (sentence.rs:174-179)
 constexpr uint32_t kErrBadOffsets = 4u;       // out_offsets do not match the text (or invalid UTF-8)
 constexpr uint32_t kErrScratchTooSmall = 8u;  // max_sentence_bytes was understated
+constexpr uint32_t kErrUnknownLabel = 16u;    // token emission: a label that is neither 0 nor 1
+constexpr uint32_t kErrOutputTooSmall = 32u;  // token emission: text_capacity is smaller than the tokenized text
 
 struct ScoreParams {
     PatternTableView ct;        // characters: n-grams + dictionary words
@@ -69,6 +71,20 @@ struct TagParams {
 hipError_t launch_decode_chars(const uint8_t* text, const uint64_t* boff, const uint64_t* ooff, uint64_t n_sent, uint64_t total_chars,
                                const uint32_t* cinfo, uint32_t* cps, uint32_t* status, hipStream_t stream);
 hipError_t launch_tag_tokens(const TagParams& P, hipStream_t stream);
+
+// token emission (kernels_emit.hip): Sentence::write_tokenized_text, boundary part
+struct EmitParams {
+    const uint8_t* text;
+    const uint64_t* boff;       // [S+1]
+    const uint64_t* ooff;       // [S+1]
+    const uint8_t* labels;      // [total boundaries] 0 / 1
+    uint64_t n_sent, total_boundaries;
+    uint8_t* out_text;          // [capacity]
+    uint64_t* out_offsets;      // [S+1] byte range of every sentence's tokenized text in out_text
+    uint64_t capacity;
+    uint32_t* status;
+};
+hipError_t launch_emit_tokenized(const EmitParams& P, hipStream_t stream);
 
 size_t score_tiles_lds_bytes();
 hipError_t launch_assign_tiles(const uint64_t* ooff, uint64_t n_sent, int pad, uint32_t tile_flat, uint32_t n_tiles,
