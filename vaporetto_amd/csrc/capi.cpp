@@ -154,6 +154,10 @@ struct vpt_batch {
     uint8_t* d_text = nullptr; size_t text_cap = 0;
     uint64_t *d_boff = nullptr, *d_ooff = nullptr; size_t off_cap = 0;
     int32_t* d_scores = nullptr; uint8_t* d_labels = nullptr; size_t out_cap = 0;
+    int32_t* d_tags = nullptr; size_t tags_cap = 0;                 // vpt_fill_tags_batch
+    uint8_t* d_tok = nullptr; size_t tok_cap = 0;                   // vpt_write_tokenized_batch
+    uint64_t* d_toff = nullptr; size_t toff_cap = 0;
+    std::vector<uint64_t> h_boff, h_ooff;                           // rebased offsets of the call in flight (copied asynchronously)
 };
 
 struct DeviceTags {
@@ -207,6 +211,7 @@ void batch_release(vpt_batch* b) {
     (void)hipFree(b->d_tile_first); (void)hipFree(b->d_slow_list); (void)hipFree(b->d_ctrl); (void)hipFree(b->d_scratch);
     (void)hipFree(b->d_prof); (void)hipFree(b->d_cps);
     (void)hipFree(b->d_text); (void)hipFree(b->d_boff); (void)hipFree(b->d_ooff); (void)hipFree(b->d_scores); (void)hipFree(b->d_labels);
+    (void)hipFree(b->d_tags); (void)hipFree(b->d_tok); (void)hipFree(b->d_toff);
     for (hipEvent_t e : b->ev) (void)hipEventDestroy(e);
     if (b->own_stream) (void)hipStreamDestroy(b->own_stream);
     delete b;
@@ -236,6 +241,81 @@ vpt_status status_from_bits(uint32_t bits) {
     if (bits & vpt::kErrOutputTooSmall)
         return fail(VPT_INVALID_ARGUMENT, "InvalidArgumentError: text_capacity: smaller than the tokenized text");
     return fail(VPT_INVALID_ARGUMENT, "InvalidArgumentError: max_sentence_bytes / max_sentence_chars: smaller than the longest sentence");
+}
+
+// An idle workspace of the predictor's pool for one host-buffer call (created, with a stream of its own, when the
+// pool is empty); goes back to the pool when the guard dies.
+struct Workspace {
+    const vpt_predictor* p = nullptr;
+    vpt_batch* b = nullptr;
+    ~Workspace() {
+        if (!b) return;
+        (void)hipStreamSynchronize(b->own_stream);   // an error return may leave copies from the caller's buffers in flight
+        std::lock_guard<std::mutex> g(p->pool_mu);
+        p->pool.push_back(b);
+    }
+};
+vpt_status acquire(const vpt_predictor* p, Workspace* w) {
+    w->p = p;
+    {
+        std::lock_guard<std::mutex> g(p->pool_mu);
+        if (!p->pool.empty()) { w->b = p->pool.back(); p->pool.pop_back(); }
+    }
+    if (w->b) return VPT_OK;
+    vpt_batch* b = nullptr;
+    vpt_status st = vpt_batch_create(p, &b);
+    if (st != VPT_OK) return st;
+    if (hipStreamCreateWithFlags(&b->own_stream, hipStreamNonBlocking) != hipSuccess) {
+        batch_release(b);
+        return fail(VPT_RUNTIME_ERROR, "HIP error: cannot create a stream");
+    }
+    w->b = b;
+    return VPT_OK;
+}
+
+// The caller's batch -> the workspace's staging buffers, on its stream: text, offsets rebased so that the device sees
+// text and outputs starting at 0, and (when given) the labels.  `max_bytes` / `max_chars`: the longest sentence.
+vpt_status stage(vpt_batch* b, const uint8_t* utf8, const uint64_t* byte_offsets, const uint64_t* out_offsets, size_t n_sentences,
+                 const uint8_t* labels, uint64_t* total_b_out, uint64_t* max_bytes_out, uint64_t* max_chars_out) {
+    const uint64_t t0 = byte_offsets[0], t1 = byte_offsets[n_sentences];
+    if (t1 < t0) return fail(VPT_INVALID_ARGUMENT, "InvalidArgumentError: byte_offsets: must be non-decreasing");
+    const size_t nbytes = size_t(t1 - t0);
+    const uint64_t total_b = out_offsets[n_sentences] - out_offsets[0];
+    uint64_t max_bytes = 0, max_chars = 0;
+    for (size_t i = 0; i < n_sentences; ++i) {
+        if (byte_offsets[i + 1] <= byte_offsets[i])
+            return fail(VPT_INVALID_ARGUMENT, "InvalidArgumentError: text: must contain at least one character");
+        max_bytes = std::max<uint64_t>(max_bytes, byte_offsets[i + 1] - byte_offsets[i]);
+        max_chars = std::max<uint64_t>(max_chars, out_offsets[i + 1] - out_offsets[i] + 1);
+    }
+    vpt_status st;
+    if ((st = grow(&b->d_text, &b->text_cap, nbytes + 32)) != VPT_OK) return st;
+    {
+        size_t cap = b->off_cap;
+        if ((st = grow(&b->d_boff, &cap, n_sentences + 1)) != VPT_OK) return st;
+        size_t cap2 = b->off_cap;
+        if ((st = grow(&b->d_ooff, &cap2, n_sentences + 1)) != VPT_OK) return st;
+        b->off_cap = std::min(cap, cap2);
+    }
+    {
+        size_t cap = b->out_cap;
+        if ((st = grow(&b->d_scores, &cap, size_t(total_b) + 1)) != VPT_OK) return st;
+        size_t cap2 = b->out_cap;
+        if ((st = grow(&b->d_labels, &cap2, size_t(total_b) + 1)) != VPT_OK) return st;
+        b->out_cap = std::min(cap, cap2);
+    }
+    std::vector<uint64_t>&boff = b->h_boff, &ooff = b->h_ooff;   // they outlive the asynchronous copies: the call ends with a sync
+    boff.resize(n_sentences + 1); ooff.resize(n_sentences + 1);
+    for (size_t i = 0; i <= n_sentences; ++i) { boff[i] = byte_offsets[i] - t0; ooff[i] = out_offsets[i] - out_offsets[0]; }
+    hipStream_t s = b->own_stream;
+    VPT_HIP(hipMemcpyAsync(b->d_text, utf8 + t0, nbytes, hipMemcpyHostToDevice, s));
+    VPT_HIP(hipMemcpyAsync(b->d_boff, boff.data(), 8 * (n_sentences + 1), hipMemcpyHostToDevice, s));
+    VPT_HIP(hipMemcpyAsync(b->d_ooff, ooff.data(), 8 * (n_sentences + 1), hipMemcpyHostToDevice, s));
+    if (labels && total_b) VPT_HIP(hipMemcpyAsync(b->d_labels, labels + out_offsets[0], size_t(total_b), hipMemcpyHostToDevice, s));
+    *total_b_out = total_b;
+    if (max_bytes_out) *max_bytes_out = max_bytes;
+    if (max_chars_out) *max_chars_out = max_chars;
+    return VPT_OK;
 }
 
 }  // namespace
@@ -553,71 +633,21 @@ vpt_status vpt_predict_batch_flags(const vpt_predictor* p, const uint8_t* utf8, 
     if (n_sentences == 0) return VPT_OK;
     if (!utf8 || !byte_offsets || !out_offsets) return fail(VPT_INVALID_ARGUMENT, "InvalidArgumentError: NULL argument");
     VPT_HIP(hipSetDevice(p->device));
-    vpt_batch* b = nullptr;
-    {
-        std::lock_guard<std::mutex> g(p->pool_mu);
-        if (!p->pool.empty()) { b = p->pool.back(); p->pool.pop_back(); }
-    }
-    if (!b) {
-        vpt_status st = vpt_batch_create(p, &b);
-        if (st != VPT_OK) return st;
-        if (hipStreamCreateWithFlags(&b->own_stream, hipStreamNonBlocking) != hipSuccess) {
-            batch_release(b);
-            return fail(VPT_RUNTIME_ERROR, "HIP error: cannot create a stream");
-        }
-    }
-    auto give_back = [&](vpt_status st) {
-        std::lock_guard<std::mutex> g(p->pool_mu);
-        p->pool.push_back(b);
-        return st;
-    };
-    const uint64_t t0 = byte_offsets[0], t1 = byte_offsets[n_sentences];
-    if (t1 < t0) return give_back(fail(VPT_INVALID_ARGUMENT, "InvalidArgumentError: byte_offsets: must be non-decreasing"));
-    const size_t nbytes = size_t(t1 - t0);
-    const uint64_t total_b = out_offsets[n_sentences] - out_offsets[0];
-    uint64_t max_bytes = 0, max_chars = 0;
-    for (size_t i = 0; i < n_sentences; ++i) {
-        if (byte_offsets[i + 1] <= byte_offsets[i])
-            return give_back(fail(VPT_INVALID_ARGUMENT, "InvalidArgumentError: text: must contain at least one character"));
-        max_bytes = std::max<uint64_t>(max_bytes, byte_offsets[i + 1] - byte_offsets[i]);
-        max_chars = std::max<uint64_t>(max_chars, out_offsets[i + 1] - out_offsets[i] + 1);
-    }
+    Workspace w;
+    vpt_status st = acquire(p, &w);
+    if (st != VPT_OK) return st;
+    vpt_batch* b = w.b;
+    uint64_t total_b = 0, max_bytes = 0, max_chars = 0;
+    if ((st = stage(b, utf8, byte_offsets, out_offsets, n_sentences, nullptr, &total_b, &max_bytes, &max_chars)) != VPT_OK) return st;
     b->max_chars = max_chars;
     b->flags = flags;
-    vpt_status st;
-    if ((st = grow(&b->d_text, &b->text_cap, nbytes + 32)) != VPT_OK) return give_back(st);
-    {
-        size_t cap = b->off_cap;
-        if ((st = grow(&b->d_boff, &cap, n_sentences + 1)) != VPT_OK) return give_back(st);
-        size_t cap2 = b->off_cap;
-        if ((st = grow(&b->d_ooff, &cap2, n_sentences + 1)) != VPT_OK) return give_back(st);
-        b->off_cap = std::min(cap, cap2);
-    }
-    {
-        size_t cap = b->out_cap;
-        if ((st = grow(&b->d_scores, &cap, size_t(total_b) + 1)) != VPT_OK) return give_back(st);
-        size_t cap2 = b->out_cap;
-        if ((st = grow(&b->d_labels, &cap2, size_t(total_b) + 1)) != VPT_OK) return give_back(st);
-        b->out_cap = std::min(cap, cap2);
-    }
-    // offsets are rebased so that the device sees text starting at 0 and outputs starting at 0
-    std::vector<uint64_t> boff(n_sentences + 1), ooff(n_sentences + 1);
-    for (size_t i = 0; i <= n_sentences; ++i) { boff[i] = byte_offsets[i] - t0; ooff[i] = out_offsets[i] - out_offsets[0]; }
     hipStream_t s = b->own_stream;
-    auto hip_fail = [&](hipError_t e) { return give_back(fail(VPT_RUNTIME_ERROR, std::string("HIP error: ") + hipGetErrorString(e))); };
-    hipError_t e;
-    if ((e = hipMemcpyAsync(b->d_text, utf8 + t0, nbytes, hipMemcpyHostToDevice, s)) != hipSuccess) return hip_fail(e);
-    if ((e = hipMemcpyAsync(b->d_boff, boff.data(), 8 * (n_sentences + 1), hipMemcpyHostToDevice, s)) != hipSuccess) return hip_fail(e);
-    if ((e = hipMemcpyAsync(b->d_ooff, ooff.data(), 8 * (n_sentences + 1), hipMemcpyHostToDevice, s)) != hipSuccess) return hip_fail(e);
     st = vpt_predict_batch_device(p, b, b->d_text, b->d_boff, b->d_ooff, n_sentences, total_b, max_bytes,
                                   scores_out ? b->d_scores : nullptr, labels_out ? b->d_labels : nullptr, s);
-    if (st != VPT_OK) return give_back(st);
-    if (scores_out && total_b &&
-        (e = hipMemcpyAsync(scores_out + out_offsets[0], b->d_scores, 4 * total_b, hipMemcpyDeviceToHost, s)) != hipSuccess) return hip_fail(e);
-    if (labels_out && total_b &&
-        (e = hipMemcpyAsync(labels_out + out_offsets[0], b->d_labels, total_b, hipMemcpyDeviceToHost, s)) != hipSuccess) return hip_fail(e);
-    st = vpt_batch_sync(b);
-    return give_back(st);
+    if (st != VPT_OK) return st;
+    if (scores_out && total_b) VPT_HIP(hipMemcpyAsync(scores_out + out_offsets[0], b->d_scores, 4 * total_b, hipMemcpyDeviceToHost, s));
+    if (labels_out && total_b) VPT_HIP(hipMemcpyAsync(labels_out + out_offsets[0], b->d_labels, total_b, hipMemcpyDeviceToHost, s));
+    return vpt_batch_sync(b);
 }
 
 vpt_status vpt_predictor_n_tags(const vpt_predictor* p, uint32_t* n_tags) {
@@ -638,54 +668,21 @@ vpt_status vpt_fill_tags_batch_flags(const vpt_predictor* p, const uint8_t* utf8
     if (!p->predict_tags) return fail(VPT_INVALID_ARGUMENT, "InvalidArgumentError: this predictor is created with predict_tags = false");
     if (n_sentences == 0 || p->n_tags == 0) return VPT_OK;   // predictor.rs:553-555
     if (!utf8 || !byte_offsets || !out_offsets || !tags_out) return fail(VPT_INVALID_ARGUMENT, "InvalidArgumentError: NULL argument");
-    const uint64_t t0 = byte_offsets[0], t1 = byte_offsets[n_sentences];
-    const uint64_t total_b = out_offsets[n_sentences] - out_offsets[0];
-    if (total_b && !labels) return fail(VPT_INVALID_ARGUMENT, "InvalidArgumentError: labels: must not be NULL");
-    const uint64_t total_c = total_b + n_sentences;
-    for (size_t i = 0; i < n_sentences; ++i)
-        if (byte_offsets[i + 1] <= byte_offsets[i])
-            return fail(VPT_INVALID_ARGUMENT, "InvalidArgumentError: text: must contain at least one character");
+    if (out_offsets[n_sentences] != out_offsets[0] && !labels) return fail(VPT_INVALID_ARGUMENT, "InvalidArgumentError: labels: must not be NULL");
     VPT_HIP(hipSetDevice(p->device));
-    struct Bufs {
-        uint8_t *text = nullptr, *labels = nullptr; uint64_t *boff = nullptr, *ooff = nullptr; uint32_t *cps = nullptr, *status = nullptr;
-        int32_t* tags = nullptr;
-        hipStream_t s = nullptr;
-        ~Bufs() {
-            (void)hipFree(text); (void)hipFree(labels); (void)hipFree(boff); (void)hipFree(ooff); (void)hipFree(cps); (void)hipFree(tags);
-            (void)hipFree(status);
-            if (s) (void)hipStreamDestroy(s);
-        }
-    } B;
-    std::vector<uint64_t> boff(n_sentences + 1), ooff(n_sentences + 1);
-    for (size_t i = 0; i <= n_sentences; ++i) { boff[i] = byte_offsets[i] - t0; ooff[i] = out_offsets[i] - out_offsets[0]; }
-    const size_t tag_bytes = size_t(total_c) * p->n_tags * sizeof(int32_t);
-    VPT_HIP(hipStreamCreateWithFlags(&B.s, hipStreamNonBlocking));
-    VPT_HIP(hipMalloc(reinterpret_cast<void**>(&B.text), size_t(t1 - t0) + 64));
-    VPT_HIP(hipMalloc(reinterpret_cast<void**>(&B.labels), size_t(total_b) + 64));
-    VPT_HIP(hipMalloc(reinterpret_cast<void**>(&B.boff), 8 * (n_sentences + 1)));
-    VPT_HIP(hipMalloc(reinterpret_cast<void**>(&B.ooff), 8 * (n_sentences + 1)));
-    VPT_HIP(hipMalloc(reinterpret_cast<void**>(&B.cps), 4 * size_t(total_c) + 64));
-    VPT_HIP(hipMalloc(reinterpret_cast<void**>(&B.tags), tag_bytes + 64));
-    VPT_HIP(hipMalloc(reinterpret_cast<void**>(&B.status), 64));
-    VPT_HIP(hipMemsetAsync(B.status, 0, 64, B.s));
-    VPT_HIP(hipMemcpyAsync(B.text, utf8 + t0, size_t(t1 - t0), hipMemcpyHostToDevice, B.s));
-    if (total_b) VPT_HIP(hipMemcpyAsync(B.labels, labels + out_offsets[0], size_t(total_b), hipMemcpyHostToDevice, B.s));
-    VPT_HIP(hipMemcpyAsync(B.boff, boff.data(), 8 * (n_sentences + 1), hipMemcpyHostToDevice, B.s));
-    VPT_HIP(hipMemcpyAsync(B.ooff, ooff.data(), 8 * (n_sentences + 1), hipMemcpyHostToDevice, B.s));
-    VPT_HIP(hipMemsetAsync(B.tags, 0xFF, tag_bytes, B.s));   // -1 = None
-    const uint32_t* cinfo = p->d_cinfo + ((flags & VPT_FLAG_KYTEA_FULLWIDTH) ? 65536 : 0);
-    VPT_HIP(vpt::launch_decode_chars(B.text, B.boff, B.ooff, n_sentences, total_c, cinfo, B.cps, B.status, B.s));
-    vpt::TagParams T{};
-    T.tok_tab = p->dtag.tok_tab; T.models = p->dtag.models; T.ngrams = p->dtag.ngrams; T.syms = p->dtag.syms; T.slots = p->dtag.slots;
-    T.weights = p->dtag.weights; T.cinfo = cinfo; T.tok_bits = p->tok_bits; T.n_tags = p->n_tags;
-    T.use_char = p->tag_use_char ? 1u : 0u; T.use_type = p->tag_use_type ? 1u : 0u;
-    T.cps = B.cps; T.ooff = B.ooff; T.labels = B.labels; T.n_sent = n_sentences; T.total_chars = total_c; T.tags = B.tags;
-    VPT_HIP(vpt::launch_tag_tokens(T, B.s));
-    uint32_t bits = 0;
-    VPT_HIP(hipMemcpyAsync(&bits, B.status, sizeof(bits), hipMemcpyDeviceToHost, B.s));
-    VPT_HIP(hipStreamSynchronize(B.s));
-    if (bits) return status_from_bits(bits);
-    VPT_HIP(hipMemcpy(tags_out + size_t(out_offsets[0]) * p->n_tags, B.tags, tag_bytes, hipMemcpyDeviceToHost));
+    Workspace w;
+    vpt_status st = acquire(p, &w);
+    if (st != VPT_OK) return st;
+    vpt_batch* b = w.b;
+    uint64_t total_b = 0;
+    if ((st = stage(b, utf8, byte_offsets, out_offsets, n_sentences, labels, &total_b, nullptr, nullptr)) != VPT_OK) return st;
+    const size_t n_tag_words = size_t(total_b + n_sentences) * p->n_tags;
+    if ((st = grow(&b->d_tags, &b->tags_cap, n_tag_words + 16)) != VPT_OK) return st;
+    b->flags = flags;
+    st = vpt_fill_tags_batch_device(p, b, b->d_text, b->d_boff, b->d_ooff, n_sentences, total_b, b->d_labels, b->d_tags, b->own_stream);
+    if (st != VPT_OK) return st;
+    if ((st = vpt_batch_sync(b)) != VPT_OK) return st;
+    VPT_HIP(hipMemcpy(tags_out + size_t(out_offsets[0]) * p->n_tags, b->d_tags, n_tag_words * sizeof(int32_t), hipMemcpyDeviceToHost));
     return VPT_OK;
 }
 
@@ -747,43 +744,23 @@ vpt_status vpt_write_tokenized_batch(const vpt_predictor* p, const uint8_t* utf8
     text_offsets_out[0] = 0;
     if (n_sentences == 0) return VPT_OK;
     if (!utf8 || !byte_offsets || !out_offsets || (text_capacity && !text_out)) return fail(VPT_INVALID_ARGUMENT, "InvalidArgumentError: NULL argument");
-    const uint64_t t0 = byte_offsets[0], t1 = byte_offsets[n_sentences];
-    if (t1 < t0) return fail(VPT_INVALID_ARGUMENT, "InvalidArgumentError: byte_offsets: must be non-decreasing");
-    const uint64_t total_b = out_offsets[n_sentences] - out_offsets[0];
-    if (total_b && !labels) return fail(VPT_INVALID_ARGUMENT, "InvalidArgumentError: labels: must not be NULL");
+    if (out_offsets[n_sentences] != out_offsets[0] && !labels) return fail(VPT_INVALID_ARGUMENT, "InvalidArgumentError: labels: must not be NULL");
     VPT_HIP(hipSetDevice(p->device));
-    vpt_batch* b = nullptr;
-    vpt_status st = vpt_batch_create(p, &b);
+    Workspace w;
+    vpt_status st = acquire(p, &w);
     if (st != VPT_OK) return st;
-    struct Bufs {
-        vpt_batch* b; uint8_t *text = nullptr, *labels = nullptr, *out = nullptr; uint64_t *boff = nullptr, *ooff = nullptr, *toff = nullptr;
-        hipStream_t s = nullptr;
-        ~Bufs() {
-            (void)hipFree(text); (void)hipFree(labels); (void)hipFree(out); (void)hipFree(boff); (void)hipFree(ooff); (void)hipFree(toff);
-            if (s) (void)hipStreamDestroy(s);
-            batch_release(b);
-        }
-    } B{b};
-    std::vector<uint64_t> boff(n_sentences + 1), ooff(n_sentences + 1);
-    for (size_t i = 0; i <= n_sentences; ++i) { boff[i] = byte_offsets[i] - t0; ooff[i] = out_offsets[i] - out_offsets[0]; }
-    VPT_HIP(hipStreamCreateWithFlags(&B.s, hipStreamNonBlocking));
-    VPT_HIP(hipMalloc(reinterpret_cast<void**>(&B.text), size_t(t1 - t0) + 64));
-    VPT_HIP(hipMalloc(reinterpret_cast<void**>(&B.labels), size_t(total_b) + 64));
-    VPT_HIP(hipMalloc(reinterpret_cast<void**>(&B.out), size_t(text_capacity) + 64));
-    VPT_HIP(hipMalloc(reinterpret_cast<void**>(&B.boff), 8 * (n_sentences + 1)));
-    VPT_HIP(hipMalloc(reinterpret_cast<void**>(&B.ooff), 8 * (n_sentences + 1)));
-    VPT_HIP(hipMalloc(reinterpret_cast<void**>(&B.toff), 8 * (n_sentences + 1)));
-    VPT_HIP(hipMemcpyAsync(B.text, utf8 + t0, size_t(t1 - t0), hipMemcpyHostToDevice, B.s));
-    if (total_b) VPT_HIP(hipMemcpyAsync(B.labels, labels + out_offsets[0], size_t(total_b), hipMemcpyHostToDevice, B.s));
-    VPT_HIP(hipMemcpyAsync(B.boff, boff.data(), 8 * (n_sentences + 1), hipMemcpyHostToDevice, B.s));
-    VPT_HIP(hipMemcpyAsync(B.ooff, ooff.data(), 8 * (n_sentences + 1), hipMemcpyHostToDevice, B.s));
-    st = vpt_write_tokenized_batch_device(p, b, B.text, B.boff, B.ooff, n_sentences, total_b, B.labels, B.out, text_capacity, B.toff, B.s);
+    vpt_batch* b = w.b;
+    uint64_t total_b = 0;
+    if ((st = stage(b, utf8, byte_offsets, out_offsets, n_sentences, labels, &total_b, nullptr, nullptr)) != VPT_OK) return st;
+    if ((st = grow(&b->d_tok, &b->tok_cap, size_t(text_capacity) + 16)) != VPT_OK) return st;
+    if ((st = grow(&b->d_toff, &b->toff_cap, n_sentences + 1)) != VPT_OK) return st;
+    st = vpt_write_tokenized_batch_device(p, b, b->d_text, b->d_boff, b->d_ooff, n_sentences, total_b, b->d_labels, b->d_tok, text_capacity,
+                                          b->d_toff, b->own_stream);
     if (st != VPT_OK) return st;
-    st = vpt_batch_sync(b);
-    if (st != VPT_OK) return st;
-    VPT_HIP(hipMemcpy(text_offsets_out, B.toff, 8 * (n_sentences + 1), hipMemcpyDeviceToHost));
+    if ((st = vpt_batch_sync(b)) != VPT_OK) return st;
+    VPT_HIP(hipMemcpy(text_offsets_out, b->d_toff, 8 * (n_sentences + 1), hipMemcpyDeviceToHost));
     const uint64_t total = text_offsets_out[n_sentences];
-    if (total) VPT_HIP(hipMemcpy(text_out, B.out, size_t(total), hipMemcpyDeviceToHost));
+    if (total) VPT_HIP(hipMemcpy(text_out, b->d_tok, size_t(total), hipMemcpyDeviceToHost));
     return VPT_OK;
 }
 
