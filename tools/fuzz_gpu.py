@@ -26,7 +26,7 @@ f = api.KyteaFullwidthFilter()
 while time.time() < t_end:
     seed += 1
     rng = random.Random(seed)
-    alpha = [chr(c) for c in range(0x3041, 0x3041 + rng.choice([3, 6, 12, 30]))] + rng.sample(list("漢字AZ09az-.、。ｱ￾𠮷"), rng.randint(0, 6))
+    alpha = [chr(c) for c in range(0x3041, 0x3041 + rng.choice([3, 6, 12, 30]))] + rng.sample(list("漢字AZ09az-.、。ｱ￾𠮷 /\\"), rng.randint(0, 6))
     m = randmodel.rand_model(9000 + seed, alphabet=alpha, wc=rng.choice([3, 3, 3, 2, 4]), wt=rng.choice([1, 2, 3, 4]),
                              n_char=rng.choice([20, 200, 1500]), n_dict=rng.choice([0, 30, 400, 3000]), n_type=rng.choice([0, 10, 80]),
                              max_word=rng.choice([2, 5, 9, 15]), big=(seed % 7 == 0), n_tag_models=rng.choice([0, 0, 10]))
@@ -45,6 +45,19 @@ while time.time() < t_end:
     if not (np.array_equal(scores, o_scores) and np.array_equal(labels, o_labels) and np.array_equal(ooff, o_ooff)):
         print("MISMATCH boundary scores: seed", seed, "info", pred.info())
         sys.exit(1)
+    if seed % 4 == 0:   # token emission (vpt_write_tokenized_batch) against the restated writer
+        ttext, toff = pred.write_tokenized_packed(utf8, boff, ooff, labels)
+        tb = bytes(ttext)
+        for i, t in enumerate(texts[:60]):
+            lab = labels[int(ooff[i]):int(ooff[i + 1])]
+            out, tok = [], []
+            for k, c in enumerate(t):
+                tok.append("\\" + c if c in " \\/" else c)
+                if k == len(t) - 1 or lab[k] == 1:
+                    out.append("".join(tok)); tok = []
+            if tb[int(toff[i]):int(toff[i + 1])].decode("utf-8") != " ".join(out):
+                print("MISMATCH tokenized text: seed", seed, repr(t[:60]))
+                sys.exit(1)
     if tags:
         got = pred.fill_tags_packed(utf8, boff, ooff, labels, fullwidth=fw)
         for i, t in enumerate(texts[:40]):
