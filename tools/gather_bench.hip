@@ -5,6 +5,11 @@
 //   2: 128 B (8 x 16) from a random 128-B record   3: lane PAIRS share a random 128-B record, 64 B each
 //   4: 32 B (2 x 16) from a random 32-B record     5: as 1 with non-temporal loads
 //   6: lanes L and L+32 share a random 128-B record, 64 B each (the pairing v_permlane32_swap_b32 can undo)
+// Second table (the kernel's access MIX, 256 MB of records, 77 % of the accesses to a 2 MB hot set = its L2 hit rate),
+// every lane needs its own record, rates in records/s:
+//   7: lane pairs fetch both halves of the even lane's record, then of the odd lane's (what score_tiles_fast_kernel does)
+//   8: every lane fetches the first 64 B of its record, 43 % of the lanes also the second 64 B ("light" records)
+//   9: as 8 with the second half requested by the partner lane in the same instruction (pair issue, masked)
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
@@ -48,6 +53,52 @@ __global__ __launch_bounds__(256) void gather(const uint4* __restrict__ tab, uin
     if (acc == 0x12345678u) out[0] = acc;  // keep the loads alive
 }
 
+// record index for the skewed mix: 77 % from the first `hot` records, the rest uniform over the table
+__device__ __forceinline__ uint32_t skewed(uint32_t who, uint32_t i, uint32_t nrec_mask, uint32_t hot_mask) {
+    const uint32_t r = mix(who * 0x9E3779B1u + i * 0x85EBCA77u);
+    const uint32_t pick = mix(r ^ 0x5bd1e995u);
+    return ((pick & 1023u) < 788u) ? (r & hot_mask) : (r & nrec_mask);
+}
+
+template <int MODE>
+__global__ __launch_bounds__(256) void gather_mix(const uint4* __restrict__ tab, uint32_t nrec_mask, uint32_t hot_mask, int iters, uint32_t* out) {
+    const uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x;
+    const bool odd = tid & 1u;
+    uint32_t acc = 0;
+    for (int i = 0; i < iters; ++i) {
+        const uint32_t mine = skewed(tid, uint32_t(i), nrec_mask, hot_mask);
+        const uint32_t partner = skewed(tid ^ 1u, uint32_t(i), nrec_mask, hot_mask);
+        const bool heavy = (mix(mine + 77u) & 127u) < 55u, partner_heavy = (mix(partner + 77u) & 127u) < 55u;   // 43 %
+        if (MODE == 7) {
+            const uint32_t ra = ((odd ? partner : mine) << 3) + (odd ? 4u : 0u), rb = ((odd ? mine : partner) << 3) + (odd ? 0u : 4u);
+            uint4 a = tab[ra], b = tab[ra + 1], c = tab[ra + 2], d = tab[ra + 3], e = tab[rb], f = tab[rb + 1], g = tab[rb + 2], k = tab[rb + 3];
+            acc ^= a.x ^ b.y ^ c.z ^ d.w ^ e.x ^ f.y ^ g.z ^ k.w;
+        } else if (MODE == 8) {
+            const uint32_t r = mine << 3;
+            uint4 a = tab[r], b = tab[r + 1], c = tab[r + 2], d = tab[r + 3];
+            acc ^= a.x ^ b.y ^ c.z ^ d.w;
+            if (heavy) { uint4 e = tab[r + 4], f = tab[r + 5], g = tab[r + 6], k = tab[r + 7]; acc ^= e.x ^ f.y ^ g.z ^ k.w; }
+        } else {   // 9: first the even lane's record (even lane: half 0, odd lane: half 1 if that record is heavy), then the odd lane's
+            const uint32_t ra = ((odd ? partner : mine) << 3) + (odd ? 4u : 0u), rb = ((odd ? mine : partner) << 3) + (odd ? 0u : 4u);
+            if (!odd || partner_heavy) { uint4 a = tab[ra], b = tab[ra + 1], c = tab[ra + 2], d = tab[ra + 3]; acc ^= a.x ^ b.y ^ c.z ^ d.w; }
+            if (odd || partner_heavy) { uint4 e = tab[rb], f = tab[rb + 1], g = tab[rb + 2], k = tab[rb + 3]; acc ^= e.x ^ f.y ^ g.z ^ k.w; }
+        }
+    }
+    if (acc == 0x12345678u) out[0] = acc;
+}
+
+template <int MODE>
+double run_mix(const uint4* tab, uint32_t nrec_mask, uint32_t hot_mask, int blocks, int iters, uint32_t* out) {
+    hipEvent_t a, b; CHECK(hipEventCreate(&a)); CHECK(hipEventCreate(&b));
+    hipLaunchKernelGGL(gather_mix<MODE>, dim3(blocks), dim3(256), 0, 0, tab, nrec_mask, hot_mask, iters, out);
+    CHECK(hipDeviceSynchronize());
+    CHECK(hipEventRecord(a));
+    for (int r = 0; r < 5; ++r) hipLaunchKernelGGL(gather_mix<MODE>, dim3(blocks), dim3(256), 0, 0, tab, nrec_mask, hot_mask, iters, out);
+    CHECK(hipEventRecord(b)); CHECK(hipEventSynchronize(b));
+    float ms = 0; CHECK(hipEventElapsedTime(&ms, a, b));
+    return ms / 5.0;
+}
+
 template <int MODE>
 double run(const uint4* tab, uint32_t mask16, int blocks, int iters, uint32_t* out) {
     hipEvent_t a, b; CHECK(hipEventCreate(&a)); CHECK(hipEventCreate(&b));
@@ -74,6 +125,16 @@ int main() {
         double t6 = run<6>(tab, mask16, blocks, iters, out);
         printf("table %4zu MB | G accesses/s: 16B %.1f | 32B %.1f | 64B %.1f | 64B-nt %.1f | 128B %.1f | pair128B %.1f (records/s %.1f) | half-wave pair records/s %.1f\n", bytes >> 20,
                positions / t0 / 1e6, positions / t4 / 1e6, positions / t1 / 1e6, positions / t5 / 1e6, positions / t2 / 1e6, positions / t3 / 1e6, positions / 2 / t3 / 1e6, positions / 2 / t6 / 1e6);
+        CHECK(hipFree(tab));
+    }
+    {   // the kernel's mix: 2 M records of 128 B, hot set 16 K records
+        const size_t bytes = size_t(256) << 20;
+        uint4* tab; CHECK(hipMalloc(&tab, bytes + 256)); CHECK(hipMemset(tab, 1, bytes + 256));
+        const uint32_t nrec_mask = uint32_t(bytes / 128 - 1), hot_mask = (1u << 14) - 1;
+        const double t7 = run_mix<7>(tab, nrec_mask, hot_mask, blocks, iters, out), t8 = run_mix<8>(tab, nrec_mask, hot_mask, blocks, iters, out);
+        const double t9 = run_mix<9>(tab, nrec_mask, hot_mask, blocks, iters, out);
+        printf("skewed mix, one record per lane | G records/s: pair-issued 128 B %.1f | 64 B + 43%% second half, own lane %.1f | same, pair-issued %.1f\n",
+               positions / t7 / 1e6, positions / t8 / 1e6, positions / t9 / 1e6);
         CHECK(hipFree(tab));
     }
     return 0;
