@@ -196,13 +196,30 @@ vpt_status vpt_fill_tags_batch_device(const vpt_predictor *p, vpt_batch *b, cons
 vpt_status vpt_write_tokenized_batch(const vpt_predictor *p, const uint8_t *utf8, const uint64_t *byte_offsets,
                                      size_t n_sentences, const uint64_t *out_offsets, const uint8_t *labels,
                                      uint8_t *text_out, uint64_t text_capacity, uint64_t *text_offsets_out);
-/* Device-resident variant: all pointers are device pointers, asynchronous on `hip_stream`; errors at vpt_batch_sync.
- * Three small kernels: count, prefix sum over the sentences, write (kernels_emit.hip). */
+/* The whole of write_tokenized_text for a predictor with tag models: Sentence::fill_tags on the given labels, then
+ * every token followed by "/tag" for its slots up to the last Some -- an empty string for a None in between -- with
+ * the same escaping (sentence.rs:866-881); what `vaporetto --predict-tags` prints.  flags: VPT_FLAG_KYTEA_FULLWIDTH
+ * as for vpt_fill_tags_batch_flags (the tokens printed are the caller's text either way).  text_capacity: the bound
+ * above + vpt_predictor_max_tag_suffix bytes per char.  A predictor without tag models writes what
+ * vpt_write_tokenized_batch writes; one created with predict_tags == 0 is VPT_INVALID_ARGUMENT. */
+vpt_status vpt_predictor_max_tag_suffix(const vpt_predictor *p, uint32_t *n_bytes);
+vpt_status vpt_write_tagged_batch(const vpt_predictor *p, const uint8_t *utf8, const uint64_t *byte_offsets,
+                                  size_t n_sentences, const uint64_t *out_offsets, const uint8_t *labels, unsigned flags,
+                                  uint8_t *text_out, uint64_t text_capacity, uint64_t *text_offsets_out);
+/* Device-resident variants: all pointers are device pointers, asynchronous on `hip_stream`; errors at vpt_batch_sync.
+ * Three small kernels: count, prefix sum over the sentences, write (kernels_emit.hip).  The tagged one takes the
+ * d_tags_out of a vpt_fill_tags_batch_device call made on the SAME workspace for the same batch (the workspace keeps
+ * the tag model that call found for every token). */
 vpt_status vpt_write_tokenized_batch_device(const vpt_predictor *p, vpt_batch *b, const uint8_t *d_utf8,
                                             const uint64_t *d_byte_offsets, const uint64_t *d_out_offsets,
                                             size_t n_sentences, uint64_t total_boundaries, const uint8_t *d_labels,
                                             uint8_t *d_text_out, uint64_t text_capacity,
                                             uint64_t *d_text_offsets_out, void *hip_stream);
+vpt_status vpt_write_tagged_batch_device(const vpt_predictor *p, vpt_batch *b, const uint8_t *d_utf8,
+                                         const uint64_t *d_byte_offsets, const uint64_t *d_out_offsets,
+                                         size_t n_sentences, uint64_t total_boundaries, const uint8_t *d_labels,
+                                         const int32_t *d_tags, uint8_t *d_text_out, uint64_t text_capacity,
+                                         uint64_t *d_text_offsets_out, void *hip_stream);
 
 /* Diagnostics: when the environment variable VPT_PROFILE_PHASES is set at vpt_batch_create, the specialised
  * kernel accumulates, per workgroup (wave 0), the shader cycles spent in 0 text scan, 1 per-char decode,

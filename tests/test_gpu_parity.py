@@ -733,3 +733,49 @@ def test_write_tokenized_text_on_device():
     _, lab, _ = pred.predict_packed(utf8, boff)
     want_text, want_off = pred.write_tokenized_packed(utf8, boff, ooff, lab)
     assert np.array_equal(d_toff.get(S + 1), want_off) and np.array_equal(d_out.get(int(want_off[-1])), want_text)
+
+
+def test_write_tagged_text_on_device():
+    """vpt_write_tagged_batch = fill_tags + write_tokenized_text with "/tag" suffixes (sentence.rs:850-886) on the device."""
+    # the reference's own tagged outputs (resources/docs.tok lines, kat.FIXTURE_TAGGED)
+    for fixture, text, expected in kat.FIXTURE_TAGGED:
+        raw, _ = kat.load_fixture(fixture)
+        pred = api.Predictor(api.Model.read_slice(raw)[0], True)
+        s = api.Sentence.from_raw(text)
+        pred.predict(s)
+        assert pred.write_tokenized_batch([s], tagged=True) == [expected]
+    # random tag models (tags with ' ', '/', '\\' in them, None slots in the middle) against the host writer
+    m = randmodel.rand_model(840, alphabet="kana", wc=3, wt=3, n_tag_models=40, max_word=4, n_char=60, n_dict=60)
+    for k, tm in enumerate(m.tag_models):
+        tm.tags = [[t + (" /\\"[k % 3]) * (k % 2) for t in cands] for cands in tm.tags]
+    pred = api.Predictor(api.Model.read_slice(encode_model(m))[0], True)
+    texts = randmodel.rand_sentences(4, m, 400, alphabet="kana", max_len=40) + [t.token * 3 for t in m.tag_models] + ["あ", "い/う え\\"]
+    sents = [api.Sentence.from_raw(t) for t in texts]
+    pred.predict_batch(sents)
+    got = pred.write_tokenized_batch(sents, tagged=True)
+    pred.fill_tags_batch(sents)
+    want = [s.write_tokenized_text() for s in sents]
+    assert got == want
+    assert any("/" in w.replace("\\/", "") for w in want)   # some token did get a tag
+    # a predictor without predict_tags refuses
+    plain = api.Predictor(api.Model.read_slice(encode_model(m))[0], False)
+    with pytest.raises(api.VaporettoError, match="predict_tags = false"):
+        plain.write_tokenized_batch(sents[:3], tagged=True)
+    # device-resident: predict -> fill_tags -> write_tagged on one stream
+    utf8, boff = api.pack_texts([t.encode("utf-8") for t in texts])
+    ooff = api.count_boundaries(utf8, boff)
+    nb, S, nt = int(ooff[-1]), len(texts), pred.n_tags()
+    d_text = devmem.put(np.concatenate([utf8, np.zeros(16, np.uint8)])); d_boff = devmem.put(boff.astype(np.uint64)); d_ooff = devmem.put(ooff.astype(np.uint64))
+    d_scores = devmem.zeros(nb + 1, np.int32); d_labels = devmem.zeros(nb + 1, np.uint8); d_tags = devmem.zeros((nb + S) * nt + 1, np.int32)
+    cap = 2 * len(utf8) + (nb + S) * 64
+    d_out = devmem.zeros(cap + 1, np.uint8); d_toff = devmem.zeros(S + 1, np.uint64)
+    batch = api.DeviceBatch(pred)
+    with pytest.raises(api.VaporettoError, match="vpt_fill_tags_batch_device on this workspace"):
+        batch.write_tagged(d_text.ptr, d_boff.ptr, d_ooff.ptr, S, nb, d_labels.ptr, d_tags.ptr, d_out.ptr, cap, d_toff.ptr, devmem.stream())
+    batch.predict(d_text.ptr, d_boff.ptr, d_ooff.ptr, S, nb, int(np.max(np.diff(boff.astype(np.int64)))), d_scores.ptr, d_labels.ptr, devmem.stream())
+    batch.fill_tags(d_text.ptr, d_boff.ptr, d_ooff.ptr, S, nb, d_labels.ptr, d_tags.ptr, devmem.stream())
+    batch.write_tagged(d_text.ptr, d_boff.ptr, d_ooff.ptr, S, nb, d_labels.ptr, d_tags.ptr, d_out.ptr, cap, d_toff.ptr, devmem.stream())
+    batch.sync()
+    toff = d_toff.get(S + 1)
+    out = bytes(d_out.get(int(toff[-1])))
+    assert [out[int(toff[i]):int(toff[i + 1])].decode("utf-8") for i in range(S)] == want

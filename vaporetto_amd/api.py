@@ -339,8 +339,9 @@ class Predictor:
         return tags[:, :nt]
 
     def write_tokenized_packed(self, utf8: np.ndarray, byte_offsets: np.ndarray, out_offsets: np.ndarray,
-                               labels: np.ndarray):
-        """Sentence::write_tokenized_text (sentence.rs:850-886), boundary part, over a packed batch on the device.
+                               labels: np.ndarray, tagged: bool = False, fullwidth: bool = False):
+        """Sentence::write_tokenized_text (sentence.rs:850-886) over a packed batch on the device; with `tagged`
+        (predictors created with predict_tags) fill_tags runs first and every token gets its "/tag" suffixes.
         Returns (uint8 text, uint64 [S+1] offsets): sentence i is text[offsets[i]:offsets[i+1]]."""
         L = _lib.load()
         utf8 = np.ascontiguousarray(utf8, dtype=np.uint8)
@@ -349,20 +350,39 @@ class Predictor:
         labels = np.ascontiguousarray(labels, dtype=np.uint8)
         S = len(byte_offsets) - 1
         nbytes = int(byte_offsets[S] - byte_offsets[0]) if S else 0
-        cap = 2 * nbytes + (int(out_offsets[S] - out_offsets[0]) + S if S else 0)
+        nchars = int(out_offsets[S] - out_offsets[0]) + S if S else 0
+        cap = 2 * nbytes + nchars
+        if tagged:
+            sfx = C.c_uint32(0)
+            if L.vpt_predictor_max_tag_suffix(self._h, C.byref(sfx)) != _lib.VPT_OK:
+                _raise(_lib.VPT_INVALID_ARGUMENT)
+            cap += nchars * int(sfx.value)
         text = np.zeros(max(cap, 1), dtype=np.uint8)
         toff = np.zeros(S + 1, dtype=np.uint64)
         lab = labels if len(labels) else np.zeros(1, dtype=np.uint8)
-        st = L.vpt_write_tokenized_batch(self._h, utf8.ctypes.data, byte_offsets.ctypes.data, S, out_offsets.ctypes.data,
-                                         lab.ctypes.data, text.ctypes.data, cap, toff.ctypes.data)
+        if tagged:
+            st = L.vpt_write_tagged_batch(self._h, utf8.ctypes.data, byte_offsets.ctypes.data, S, out_offsets.ctypes.data, lab.ctypes.data,
+                                          _lib.VPT_FLAG_KYTEA_FULLWIDTH if fullwidth else 0, text.ctypes.data, cap, toff.ctypes.data)
+        else:
+            st = L.vpt_write_tokenized_batch(self._h, utf8.ctypes.data, byte_offsets.ctypes.data, S, out_offsets.ctypes.data,
+                                             lab.ctypes.data, text.ctypes.data, cap, toff.ctypes.data)
         if st != _lib.VPT_OK:
             _raise(st)
         return text[:int(toff[S])], toff
 
-    def write_tokenized_batch(self, sentences: Sequence["Sentence"]) -> List[str]:
-        """write_tokenized_text for many sentences in one launch; tag suffixes (host-side strings) are appended here."""
+    def write_tokenized_batch(self, sentences: Sequence["Sentence"], tagged: bool = False) -> List[str]:
+        """write_tokenized_text for many sentences in one launch.  tagged: fill_tags + "/tag" suffixes on the device
+        (the sentences' own tags are not touched); otherwise sentences that carry tags take the host writer."""
         if not sentences:
             return []
+        if tagged:
+            utf8, boff = pack_texts([s._utf8 for s in sentences])
+            ooff = np.zeros(len(sentences) + 1, dtype=np.uint64)
+            ooff[1:] = np.cumsum([len(s) - 1 for s in sentences])
+            labels = np.concatenate([np.asarray(s._boundaries, dtype=np.uint8) for s in sentences]) if int(ooff[-1]) else np.zeros(0, np.uint8)
+            text, toff = self.write_tokenized_packed(utf8, boff, ooff, labels, tagged=True)
+            raw = bytes(text)
+            return [raw[int(toff[i]):int(toff[i + 1])].decode("utf-8") for i in range(len(sentences))]
         utf8, boff = pack_texts([s._utf8 for s in sentences])
         ooff = np.zeros(len(sentences) + 1, dtype=np.uint64)
         ooff[1:] = np.cumsum([len(s) - 1 for s in sentences])
@@ -484,6 +504,15 @@ class DeviceBatch:
         """Device-resident write_tokenized_text for the batch (vpt_write_tokenized_batch_device); enqueues and returns."""
         st = _lib.load().vpt_write_tokenized_batch_device(self._p.handle, self._h, d_utf8, d_boff, d_ooff, n_sentences,
                                                           total_boundaries, d_labels, d_text_out, text_capacity, d_text_offsets, stream)
+        if st != _lib.VPT_OK:
+            _raise(st)
+
+    def write_tagged(self, d_utf8: int, d_boff: int, d_ooff: int, n_sentences: int, total_boundaries: int, d_labels: int,
+                     d_tags: int, d_text_out: int, text_capacity: int, d_text_offsets: int, stream: int = 0) -> None:
+        """write_tokenized_text with "/tag" suffixes from the d_tags of a fill_tags call on this workspace
+        (vpt_write_tagged_batch_device); enqueues and returns."""
+        st = _lib.load().vpt_write_tagged_batch_device(self._p.handle, self._h, d_utf8, d_boff, d_ooff, n_sentences, total_boundaries,
+                                                       d_labels, d_tags, d_text_out, text_capacity, d_text_offsets, stream)
         if st != _lib.VPT_OK:
             _raise(st)
 

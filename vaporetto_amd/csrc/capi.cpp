@@ -157,15 +157,20 @@ struct vpt_batch {
     int32_t* d_tags = nullptr; size_t tags_cap = 0;                 // vpt_fill_tags_batch
     uint8_t* d_tok = nullptr; size_t tok_cap = 0;                   // vpt_write_tokenized_batch
     uint64_t* d_toff = nullptr; size_t toff_cap = 0;
+    int32_t* d_tok_model = nullptr; size_t tok_model_cap = 0;      // tag model of every token, from the last fill_tags on this workspace
+    uint64_t tok_model_chars = 0;                                   // ... which covered this many chars
     std::vector<uint64_t> h_boff, h_ooff;                           // rebased offsets of the call in flight (copied asynchronously)
 };
 
 struct DeviceTags {
-    uint32_t *tok_tab = nullptr, *models = nullptr, *ngrams = nullptr, *syms = nullptr, *slots = nullptr;
+    uint32_t *tok_tab = nullptr, *models = nullptr, *ngrams = nullptr, *syms = nullptr, *slots = nullptr, *slot_str = nullptr, *str_off = nullptr;
+    uint8_t* str_bytes = nullptr;
     int32_t* weights = nullptr;
+    uint32_t n_models = 0, n_strings = 0;
     void release() {
         (void)hipFree(tok_tab); (void)hipFree(models); (void)hipFree(ngrams); (void)hipFree(syms); (void)hipFree(slots); (void)hipFree(weights);
-        tok_tab = models = ngrams = syms = slots = nullptr; weights = nullptr;
+        (void)hipFree(slot_str); (void)hipFree(str_off); (void)hipFree(str_bytes);
+        tok_tab = models = ngrams = syms = slots = slot_str = str_off = nullptr; weights = nullptr; str_bytes = nullptr;
     }
 };
 
@@ -173,7 +178,7 @@ struct vpt_predictor {
     int device = 0;
     bool predict_tags = false;
     bool has_tags = false;
-    uint32_t n_tags = 0, tok_bits = 0;
+    uint32_t n_tags = 0, tok_bits = 0, max_tag_suffix = 0;
     bool tag_use_char = false, tag_use_type = false;
     DeviceTags dtag;
     vpt_model_info info{};
@@ -211,7 +216,7 @@ void batch_release(vpt_batch* b) {
     (void)hipFree(b->d_tile_first); (void)hipFree(b->d_slow_list); (void)hipFree(b->d_ctrl); (void)hipFree(b->d_scratch);
     (void)hipFree(b->d_prof); (void)hipFree(b->d_cps);
     (void)hipFree(b->d_text); (void)hipFree(b->d_boff); (void)hipFree(b->d_ooff); (void)hipFree(b->d_scores); (void)hipFree(b->d_labels);
-    (void)hipFree(b->d_tags); (void)hipFree(b->d_tok); (void)hipFree(b->d_toff);
+    (void)hipFree(b->d_tags); (void)hipFree(b->d_tok); (void)hipFree(b->d_toff); (void)hipFree(b->d_tok_model);
     for (hipEvent_t e : b->ev) (void)hipEventDestroy(e);
     if (b->own_stream) (void)hipStreamDestroy(b->own_stream);
     delete b;
@@ -370,6 +375,21 @@ vpt_status vpt_predictor_create(const uint8_t* model_bytes, size_t len, int pred
         if (e == hipSuccess) e = upload(c.tags.syms, &p->dtag.syms);
         if (e == hipSuccess) e = upload(c.tags.slots, &p->dtag.slots);
         if (e == hipSuccess) e = upload(c.tags.weights, &p->dtag.weights);
+        if (e == hipSuccess) e = upload(c.tags.slot_str, &p->dtag.slot_str);
+        if (e == hipSuccess) e = upload(c.tags.str_off, &p->dtag.str_off);
+        if (e == hipSuccess) e = upload(c.tags.str_bytes, &p->dtag.str_bytes);
+        p->dtag.n_models = c.tags.n_models; p->dtag.n_strings = uint32_t(c.tags.str_off.size() - 1);
+        for (uint32_t mi = 0; mi < c.tags.n_models; ++mi) {   // the longest "/tag/tag.." a token can get
+            const uint32_t* mr = &c.tags.models[size_t(mi) * 12];
+            uint32_t worst = 0;
+            for (uint32_t j = 0; j < mr[9]; ++j) {
+                const uint32_t first = c.tags.slot_str[mr[8] + j], cnt = c.tags.slots[size_t(mr[8] + j) * 2];
+                uint32_t longest = 0;
+                for (uint32_t k = 0; k < cnt; ++k) longest = std::max(longest, c.tags.str_off[first + k + 1] - c.tags.str_off[first + k]);
+                worst += 1 + longest;
+            }
+            p->max_tag_suffix = std::max(p->max_tag_suffix, worst);
+        }
     }
     bool packed_ok = c.packed.present;
     if (c.packed.present && e == hipSuccess) e = upload_packed(c.packed, &p->dp, &packed_ok);
@@ -656,6 +676,12 @@ vpt_status vpt_predictor_n_tags(const vpt_predictor* p, uint32_t* n_tags) {
     return VPT_OK;
 }
 
+vpt_status vpt_predictor_max_tag_suffix(const vpt_predictor* p, uint32_t* n_bytes) {
+    if (!p || !n_bytes) return fail(VPT_INVALID_ARGUMENT, "InvalidArgumentError: NULL argument");
+    *n_bytes = p->max_tag_suffix;
+    return VPT_OK;
+}
+
 vpt_status vpt_fill_tags_batch(const vpt_predictor* p, const uint8_t* utf8, const uint64_t* byte_offsets, size_t n_sentences,
                                const uint64_t* out_offsets, const uint8_t* labels, int32_t* tags_out) {
     return vpt_fill_tags_batch_flags(p, utf8, byte_offsets, n_sentences, out_offsets, labels, tags_out, 0u);
@@ -699,26 +725,29 @@ vpt_status vpt_fill_tags_batch_device(const vpt_predictor* p, vpt_batch* b, cons
     const uint64_t total_c = total_boundaries + n_sentences;
     vpt_status st = grow(&b->d_cps, &b->cps_cap, size_t(total_c) + 16);
     if (st != VPT_OK) return st;
+    if ((st = grow(&b->d_tok_model, &b->tok_model_cap, size_t(total_c) + 16)) != VPT_OK) return st;
+    b->tok_model_chars = total_c;
     const uint32_t* cinfo = p->d_cinfo + ((b->flags & VPT_FLAG_KYTEA_FULLWIDTH) ? 65536 : 0);
     VPT_HIP(hipMemsetAsync(d_tags_out, 0xFF, size_t(total_c) * p->n_tags * sizeof(int32_t), stream));   // -1 = None
+    VPT_HIP(hipMemsetAsync(b->d_tok_model, 0, size_t(total_c) * sizeof(int32_t), stream));
     VPT_HIP(vpt::launch_decode_chars(d_utf8, d_byte_offsets, d_out_offsets, n_sentences, total_c, cinfo, b->d_cps, b->d_ctrl, stream));
     vpt::TagParams T{};
     T.tok_tab = p->dtag.tok_tab; T.models = p->dtag.models; T.ngrams = p->dtag.ngrams; T.syms = p->dtag.syms; T.slots = p->dtag.slots;
     T.weights = p->dtag.weights; T.cinfo = cinfo; T.tok_bits = p->tok_bits; T.n_tags = p->n_tags;
     T.use_char = p->tag_use_char ? 1u : 0u; T.use_type = p->tag_use_type ? 1u : 0u;
     T.cps = b->d_cps; T.ooff = d_out_offsets; T.labels = d_labels; T.n_sent = n_sentences; T.total_chars = total_c; T.tags = d_tags_out;
+    T.tok_model = b->d_tok_model;
     VPT_HIP(vpt::launch_tag_tokens(T, stream));
     b->last_stream = stream; b->pending = true;
     return VPT_OK;
 }
 
-vpt_status vpt_write_tokenized_batch_device(const vpt_predictor* p, vpt_batch* b, const uint8_t* d_utf8, const uint64_t* d_byte_offsets,
-                                            const uint64_t* d_out_offsets, size_t n_sentences, uint64_t total_boundaries,
-                                            const uint8_t* d_labels, uint8_t* d_text_out, uint64_t text_capacity,
-                                            uint64_t* d_text_offsets_out, void* hip_stream) {
+static vpt_status emit_device(const vpt_predictor* p, vpt_batch* b, const uint8_t* d_utf8, const uint64_t* d_byte_offsets,
+                              const uint64_t* d_out_offsets, size_t n_sentences, uint64_t total_boundaries, const uint8_t* d_labels,
+                              const int32_t* d_tags, uint8_t* d_text_out, uint64_t text_capacity, uint64_t* d_text_offsets_out,
+                              hipStream_t stream) {
     if (!p || !b || b->pred != p) return fail(VPT_INVALID_ARGUMENT, "InvalidArgumentError: batch: does not belong to this predictor");
     if (!d_text_offsets_out) return fail(VPT_INVALID_ARGUMENT, "InvalidArgumentError: NULL device pointer");
-    hipStream_t stream = static_cast<hipStream_t>(hip_stream);
     VPT_HIP(hipSetDevice(p->device));
     if (n_sentences == 0) {
         VPT_HIP(hipMemsetAsync(d_text_offsets_out, 0, sizeof(uint64_t), stream));
@@ -731,16 +760,42 @@ vpt_status vpt_write_tokenized_batch_device(const vpt_predictor* p, vpt_batch* b
     E.text = d_utf8; E.boff = d_byte_offsets; E.ooff = d_out_offsets; E.labels = d_labels; E.n_sent = n_sentences;
     E.total_boundaries = total_boundaries; E.out_text = d_text_out; E.out_offsets = d_text_offsets_out; E.capacity = text_capacity;
     E.status = b->d_ctrl;
+    if (d_tags && p->n_tags > 0) {   // "/tag" suffixes: the indices of fill_tags + the tag model it found for every token
+        if (!p->predict_tags) return fail(VPT_INVALID_ARGUMENT, "InvalidArgumentError: this predictor is created with predict_tags = false");
+        if (b->tok_model_chars != total_boundaries + n_sentences || !b->d_tok_model)
+            return fail(VPT_INVALID_ARGUMENT, "InvalidArgumentError: batch: call vpt_fill_tags_batch_device on this workspace for this batch first");
+        E.tags = d_tags; E.tok_model = b->d_tok_model; E.n_tags = p->n_tags; E.n_models = p->dtag.n_models; E.n_strings = p->dtag.n_strings;
+        E.models = p->dtag.models; E.slot_str = p->dtag.slot_str; E.str_off = p->dtag.str_off; E.str_bytes = p->dtag.str_bytes;
+    }
     VPT_HIP(vpt::launch_emit_tokenized(E, stream));
     b->last_stream = stream; b->pending = true;
     return VPT_OK;
 }
 
-vpt_status vpt_write_tokenized_batch(const vpt_predictor* p, const uint8_t* utf8, const uint64_t* byte_offsets, size_t n_sentences,
-                                     const uint64_t* out_offsets, const uint8_t* labels, uint8_t* text_out, uint64_t text_capacity,
-                                     uint64_t* text_offsets_out) {
+vpt_status vpt_write_tokenized_batch_device(const vpt_predictor* p, vpt_batch* b, const uint8_t* d_utf8, const uint64_t* d_byte_offsets,
+                                            const uint64_t* d_out_offsets, size_t n_sentences, uint64_t total_boundaries,
+                                            const uint8_t* d_labels, uint8_t* d_text_out, uint64_t text_capacity,
+                                            uint64_t* d_text_offsets_out, void* hip_stream) {
+    return emit_device(p, b, d_utf8, d_byte_offsets, d_out_offsets, n_sentences, total_boundaries, d_labels, nullptr, d_text_out, text_capacity,
+                       d_text_offsets_out, static_cast<hipStream_t>(hip_stream));
+}
+
+vpt_status vpt_write_tagged_batch_device(const vpt_predictor* p, vpt_batch* b, const uint8_t* d_utf8, const uint64_t* d_byte_offsets,
+                                         const uint64_t* d_out_offsets, size_t n_sentences, uint64_t total_boundaries,
+                                         const uint8_t* d_labels, const int32_t* d_tags, uint8_t* d_text_out, uint64_t text_capacity,
+                                         uint64_t* d_text_offsets_out, void* hip_stream) {
+    if (p && p->n_tags > 0 && !d_tags) return fail(VPT_INVALID_ARGUMENT, "InvalidArgumentError: NULL device pointer");
+    return emit_device(p, b, d_utf8, d_byte_offsets, d_out_offsets, n_sentences, total_boundaries, d_labels, d_tags, d_text_out, text_capacity,
+                       d_text_offsets_out, static_cast<hipStream_t>(hip_stream));
+}
+
+static vpt_status emit_host(const vpt_predictor* p, const uint8_t* utf8, const uint64_t* byte_offsets, size_t n_sentences,
+                            const uint64_t* out_offsets, const uint8_t* labels, bool tagged, unsigned flags, uint8_t* text_out,
+                            uint64_t text_capacity, uint64_t* text_offsets_out) {
     if (!p) return fail(VPT_INVALID_ARGUMENT, "InvalidArgumentError: predictor: must not be NULL");
     if (!text_offsets_out) return fail(VPT_INVALID_ARGUMENT, "InvalidArgumentError: NULL argument");
+    if (flags & ~unsigned(VPT_FLAG_KYTEA_FULLWIDTH)) return fail(VPT_INVALID_ARGUMENT, "InvalidArgumentError: flags: unknown bit");
+    if (tagged && !p->predict_tags) return fail(VPT_INVALID_ARGUMENT, "InvalidArgumentError: this predictor is created with predict_tags = false");
     text_offsets_out[0] = 0;
     if (n_sentences == 0) return VPT_OK;
     if (!utf8 || !byte_offsets || !out_offsets || (text_capacity && !text_out)) return fail(VPT_INVALID_ARGUMENT, "InvalidArgumentError: NULL argument");
@@ -754,14 +809,33 @@ vpt_status vpt_write_tokenized_batch(const vpt_predictor* p, const uint8_t* utf8
     if ((st = stage(b, utf8, byte_offsets, out_offsets, n_sentences, labels, &total_b, nullptr, nullptr)) != VPT_OK) return st;
     if ((st = grow(&b->d_tok, &b->tok_cap, size_t(text_capacity) + 16)) != VPT_OK) return st;
     if ((st = grow(&b->d_toff, &b->toff_cap, n_sentences + 1)) != VPT_OK) return st;
-    st = vpt_write_tokenized_batch_device(p, b, b->d_text, b->d_boff, b->d_ooff, n_sentences, total_b, b->d_labels, b->d_tok, text_capacity,
-                                          b->d_toff, b->own_stream);
+    const bool with_tags = tagged && p->n_tags > 0;
+    if (with_tags) {   // Sentence::fill_tags, then the writer, as the CLI does (predict/src/main.rs:156-176)
+        if ((st = grow(&b->d_tags, &b->tags_cap, size_t(total_b + n_sentences) * p->n_tags + 16)) != VPT_OK) return st;
+        b->flags = flags;
+        st = vpt_fill_tags_batch_device(p, b, b->d_text, b->d_boff, b->d_ooff, n_sentences, total_b, b->d_labels, b->d_tags, b->own_stream);
+        if (st != VPT_OK) return st;
+    }
+    st = emit_device(p, b, b->d_text, b->d_boff, b->d_ooff, n_sentences, total_b, b->d_labels, with_tags ? b->d_tags : nullptr, b->d_tok,
+                     text_capacity, b->d_toff, b->own_stream);
     if (st != VPT_OK) return st;
     if ((st = vpt_batch_sync(b)) != VPT_OK) return st;
     VPT_HIP(hipMemcpy(text_offsets_out, b->d_toff, 8 * (n_sentences + 1), hipMemcpyDeviceToHost));
     const uint64_t total = text_offsets_out[n_sentences];
     if (total) VPT_HIP(hipMemcpy(text_out, b->d_tok, size_t(total), hipMemcpyDeviceToHost));
     return VPT_OK;
+}
+
+vpt_status vpt_write_tokenized_batch(const vpt_predictor* p, const uint8_t* utf8, const uint64_t* byte_offsets, size_t n_sentences,
+                                     const uint64_t* out_offsets, const uint8_t* labels, uint8_t* text_out, uint64_t text_capacity,
+                                     uint64_t* text_offsets_out) {
+    return emit_host(p, utf8, byte_offsets, n_sentences, out_offsets, labels, false, 0u, text_out, text_capacity, text_offsets_out);
+}
+
+vpt_status vpt_write_tagged_batch(const vpt_predictor* p, const uint8_t* utf8, const uint64_t* byte_offsets, size_t n_sentences,
+                                  const uint64_t* out_offsets, const uint8_t* labels, unsigned flags, uint8_t* text_out,
+                                  uint64_t text_capacity, uint64_t* text_offsets_out) {
+    return emit_host(p, utf8, byte_offsets, n_sentences, out_offsets, labels, true, flags, text_out, text_capacity, text_offsets_out);
 }
 
 vpt_status vpt_predict_one(const vpt_predictor* p, const uint8_t* utf8, size_t len, int32_t* scores, uint8_t* labels, size_t* n_boundaries) {

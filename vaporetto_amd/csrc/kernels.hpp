@@ -66,6 +66,7 @@ struct TagParams {
     const uint8_t* labels;      // [total boundaries] CharacterBoundary values (0, 1, 2 = Unknown)
     uint64_t n_sent;
     uint64_t total_chars;       // total boundaries + S: what `cps` and `tags / n_tags` hold
+    int32_t* tok_model;         // [total chars] or nullptr: tag model index + 1 of the token ending at the char (token emission)
     int32_t* tags;              // [(total boundaries + S) * n_tags] candidate index per slot, -1 = None
 };
 hipError_t launch_decode_chars(const uint8_t* text, const uint64_t* boff, const uint64_t* ooff, uint64_t n_sent, uint64_t total_chars,
@@ -83,6 +84,12 @@ struct EmitParams {
     uint64_t* out_offsets;      // [S+1] byte range of every sentence's tokenized text in out_text
     uint64_t capacity;
     uint32_t* status;
+    // "/tag" suffixes (sentence.rs:866-881); tags == nullptr: none
+    const int32_t* tags;        // [(total boundaries + S) * n_tags] as vpt_fill_tags_batch wrote them
+    const int32_t* tok_model;   // [total boundaries + S] from the same fill_tags call (TagParams::tok_model)
+    uint32_t n_tags, n_models, n_strings;
+    const uint32_t *models, *slot_str, *str_off;
+    const uint8_t* str_bytes;
 };
 hipError_t launch_emit_tokenized(const EmitParams& P, hipStream_t stream);
 

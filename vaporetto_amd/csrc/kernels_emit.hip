@@ -1,8 +1,9 @@
 // Token emission on the device: Sentence::write_tokenized_text for a batch (sentence.rs:850-886), boundary part:
 // the tokens of a sentence are the runs between WordBoundary labels (sentence.rs:1270-1300), written in order with
-// one ' ' between them and a '\' in front of every ' ', '\' and '/' byte of a surface.  (Tags are "/tag" suffixes of
-// host-side strings; the Python mirror appends them.  Unknown boundaries only come from partially annotated
-// corpora, never from predict: they are rejected here, kErrUnknownLabel.)
+// one ' ' between them and a '\' in front of every ' ', '\' and '/' byte of a surface; with tags (the indices
+// vpt_fill_tags_batch wrote and the tag model it found for every token) each token is followed by "/tag" for its tag
+// slots up to the last Some, an empty string for a None in between (sentence.rs:866-881).  (Unknown boundaries only
+// come from partially annotated corpora, never from predict: they are rejected here, kErrUnknownLabel.)
 //
 // Output size is data dependent, so three launches on one stream:
 //   emit_count_kernel   one wave per sentence: bytes this sentence will take -> offsets[i + 1]
@@ -56,6 +57,31 @@ __device__ __forceinline__ ByteOut classify_byte(const uint8_t* __restrict__ tex
     return o;
 }
 
+// "/tag/tag.." of the token whose last char is char `c` (batch-flat index): bytes it takes; written to `dst` when given
+__device__ __forceinline__ uint32_t tag_suffix(const EmitParams& P, uint64_t c, uint8_t* dst) {
+    if (!P.tags) return 0;
+    const int32_t model = P.tok_model[c];
+    if (model <= 0 || uint32_t(model) > P.n_models) return 0;   // no tag model for this surface (or not our array)
+    const uint32_t* mr = P.models + size_t(model - 1) * 12;
+    const int32_t* tg = P.tags + c * P.n_tags;
+    const uint32_t n_slots = mr[9] < P.n_tags ? mr[9] : P.n_tags;
+    uint32_t last = 0;   // slots to write: up to the last Some
+    for (uint32_t j = 0; j < n_slots; ++j)
+        if (tg[j] >= 0) last = j + 1;
+    uint32_t n = 0;
+    for (uint32_t j = 0; j < last; ++j) {
+        if (dst) dst[n] = 0x2Fu;
+        ++n;
+        if (tg[j] < 0) continue;
+        const uint32_t k = P.slot_str[mr[8] + j] + uint32_t(tg[j]);
+        if (k >= P.n_strings) continue;                            // an index fill_tags cannot have written
+        const uint32_t a = P.str_off[k], b = P.str_off[k + 1];
+        if (dst) for (uint32_t q = a; q < b; ++q) dst[n + (q - a)] = P.str_bytes[q];
+        n += b - a;
+    }
+    return n;
+}
+
 __device__ __forceinline__ uint32_t wave_sum(uint32_t x) {   // total over the 64 lanes, in every lane
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) x += uint32_t(__shfl_xor(int(x), d));
@@ -84,11 +110,14 @@ __global__ __launch_bounds__(kEmitThreads) void emit_count_kernel(const EmitPara
         for (uint64_t pos = b0; sane && pos < b1; pos += 64) {
             uint64_t leads;
             const ByteOut o = classify_byte(P.text, pos + uint64_t(lane), b1, P.labels + o0, n_labels, chars, lane, leads, err);
-            bytes_out += wave_sum(o.n);
+            // a token's tag suffix goes in front of the space that starts the next token: char index of its last char
+            const uint32_t sfx = o.space ? tag_suffix(P, o0 + i + chars + below(leads, lane) - 1, nullptr) : 0u;
+            bytes_out += wave_sum(o.n + sfx);
             chars += uint64_t(__popcll(leads));
         }
         if (!sane) err |= b1 > b0 ? kErrBadOffsets : kErrEmptySentence;
         else if (chars != n_labels + 1) err |= kErrBadOffsets;
+        else bytes_out += tag_suffix(P, o1 + i, nullptr);   // the last token's (every lane computes the same)
         if (lane == 0) P.out_offsets[i + 1] = bytes_out;
     }
     if (err) atomicOr(P.status, err);
@@ -138,14 +167,21 @@ __global__ __launch_bounds__(kEmitThreads) void emit_write_kernel(const EmitPara
             uint64_t leads;
             const uint64_t at = pos + uint64_t(lane);
             const ByteOut o = classify_byte(P.text, at, b1, P.labels + o0, n_labels, chars, lane, leads, err);
-            uint64_t w = at_out + wave_exclusive(o.n, lane);
-            if (o.n != 0 && w + o.n <= end) {                              // `end` only binds when the inputs changed under us
+            const uint64_t prev = o0 + i + chars + below(leads, lane) - 1;   // last char of the token in front of a space
+            const uint32_t sfx = o.space ? tag_suffix(P, prev, nullptr) : 0u;
+            uint64_t w = at_out + wave_exclusive(o.n + sfx, lane);
+            if (o.n != 0 && w + o.n + sfx <= end) {                        // `end` only binds when the inputs changed under us
+                if (sfx) w += tag_suffix(P, prev, P.out_text + w);
                 if (o.space) P.out_text[w++] = 0x20u;
                 if (o.esc) P.out_text[w++] = 0x5Cu;
                 P.out_text[w] = P.text[at];
             }
-            at_out += wave_sum(o.n);
+            at_out += wave_sum(o.n + sfx);
             chars += uint64_t(__popcll(leads));
+        }
+        if (lane == 0 && chars == n_labels + 1) {                          // the last token's tags
+            const uint32_t sfx = tag_suffix(P, o1 + i, nullptr);
+            if (sfx && at_out + sfx <= end) tag_suffix(P, o1 + i, P.out_text + at_out);
         }
     }
 }

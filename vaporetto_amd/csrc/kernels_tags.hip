@@ -127,6 +127,7 @@ __global__ __launch_bounds__(kTagThreads) void tag_tokens_kernel(const TagParams
                     }
                     slot = (slot + 1) & tok_mask;
                 }
+                if (P.tok_model && lane == 0) P.tok_model[g0 + uint64_t(e)] = int32_t(model);   // 0: no tag model for this surface
                 if (model == 0) continue;
                 const uint32_t* mr = P.models + size_t(model - 1) * 12;
                 const uint32_t zlen = mr[7];

@@ -640,6 +640,14 @@ HostTagTables build_tag_tables(const ModelData& m, bool use_char, bool use_type)
             t.slots.push_back(uint32_t(cands.size()));
             t.slots.push_back(off);
             if (cands.size() >= 2) off += uint32_t(cands.size());
+            t.slot_str.push_back(uint32_t(t.str_off.size()));
+            for (const std::string& tag : cands) {
+                t.str_off.push_back(uint32_t(t.str_bytes.size()));
+                for (unsigned char ch : tag) {
+                    if (ch == ' ' || ch == '\\' || ch == '/') t.str_bytes.push_back('\\');
+                    t.str_bytes.push_back(ch);
+                }
+            }
         }
         t.models.insert(t.models.end(), rec, rec + 12);
         // token table: a repeated token keeps its slot and takes the later model
@@ -656,6 +664,9 @@ HostTagTables build_tag_tables(const ModelData& m, bool use_char, bool use_type)
     if (t.weights.empty()) t.weights.push_back(0);
     if (t.ngrams.empty()) t.ngrams.assign(4, 0);
     if (t.slots.empty()) t.slots.assign(2, 0);
+    if (t.slot_str.empty()) t.slot_str.push_back(0);
+    t.str_off.push_back(uint32_t(t.str_bytes.size()));   // the end of the last string
+    if (t.str_bytes.empty()) t.str_bytes.push_back(0);
     return t;
 }
 }  // namespace

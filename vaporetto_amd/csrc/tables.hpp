@@ -51,11 +51,14 @@ struct HostPackedTable {
 //             slot first/count, 0, 0
 //   ngrams    4 dwords per (tag n-gram, rel_position): sym_off, len | rel << 24, w_off, wlen
 //   slots     2 dwords per tag slot: candidate count, offset of its scores in z (slots with >= 2 candidates)
+//   slot_str  per tag slot: index of its first candidate in str_off; str_off[k] .. str_off[k+1] = the bytes of candidate
+//             string k in str_bytes, ALREADY escaped the way Sentence::write_tokenized_text writes a tag (sentence.rs:871-880)
 struct HostTagTables {
     bool present = false;
     uint32_t n_tags = 0, n_models = 0, tok_bits = 4, max_zlen = 0;
     bool use_char = false, use_type = false;   // the scorers exist (char_scorer.rs:98-100, type_scorer.rs:109-111)
-    std::vector<uint32_t> tok_tab, models, ngrams, syms, slots;
+    std::vector<uint32_t> tok_tab, models, ngrams, syms, slots, slot_str, str_off;
+    std::vector<uint8_t> str_bytes;
     std::vector<int32_t> weights;
 };
 constexpr uint32_t kTagMaxZ = 1024;   // tag scores per token the kernel keeps in LDS
