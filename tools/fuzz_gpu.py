@@ -66,6 +66,14 @@ while time.time() < t_end:
             if not np.array_equal(got[a + i:a + i + len(t)], want):
                 print("MISMATCH tags: seed", seed, repr(t[:60]))
                 sys.exit(1)
+    if tags and not fw and seed % 4 == 2:   # the whole tagged writer against the mirror's (fill_tags + write_tokenized_text)
+        sents = [api.Sentence.from_raw(t) for t in texts[:40]]
+        pred.predict_batch(sents)
+        got_t = pred.write_tokenized_batch(sents, tagged=True)
+        pred.fill_tags_batch(sents)
+        if got_t != [s.write_tokenized_text() for s in sents]:
+            print("MISMATCH tagged text: seed", seed)
+            sys.exit(1)
     n_models += 1
     n_sent += len(texts)
 print("fuzz ok: %d models, %d sentences, no mismatch" % (n_models, n_sent))
