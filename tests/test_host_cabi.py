@@ -118,3 +118,15 @@ def test_no_gpu_fails_loudly():
     with pytest.raises(api.VaporettoError) as e:
         api.Predictor(api.Model.read_slice(raw)[0])
     assert e.value.kind == "Runtime" and "no CPU fallback" in str(e.value)
+
+
+def test_entry_points_reject_null_handles_without_a_device():
+    """Argument errors are host-side: they are reported before any HIP call (so also on a box without a GPU)."""
+    L = _lib.load()
+    toff = np.zeros(2, np.uint64)
+    for call in (lambda: L.vpt_write_tokenized_batch(None, None, None, 1, None, None, None, 0, toff.ctypes.data),
+                 lambda: L.vpt_write_tagged_batch(None, None, None, 1, None, None, 0, None, 0, toff.ctypes.data),
+                 lambda: L.vpt_fill_tags_batch(None, None, None, 1, None, None, None),
+                 lambda: L.vpt_predict_batch(None, None, None, 1, None, None, None),
+                 lambda: L.vpt_predictor_max_tag_suffix(None, None)):
+        assert call() == _lib.VPT_INVALID_ARGUMENT and "InvalidArgumentError" in _lib.last_error()
