@@ -221,6 +221,21 @@ vpt_status vpt_write_tagged_batch_device(const vpt_predictor *p, vpt_batch *b, c
                                          const int32_t *d_tags, uint8_t *d_text_out, uint64_t text_capacity,
                                          uint64_t *d_text_offsets_out, void *hip_stream);
 
+/* vpt_count_boundaries on the device (one wave per sentence + a prefix sum): d_out_offsets[n_sentences + 1]; the same
+ * validation, reported at vpt_batch_sync. */
+vpt_status vpt_count_boundaries_device(const vpt_predictor *p, vpt_batch *b, const uint8_t *d_utf8,
+                                       const uint64_t *d_byte_offsets, size_t n_sentences, uint64_t *d_out_offsets,
+                                       void *hip_stream);
+
+/* Lines in, tokenized lines out -- the loop of predict/src/main.rs:122-176 for a whole batch: Sentence::from_raw,
+ * [KyteaFullwidthFilter], Predictor::predict, [KyteaWsConstFilter / SplitLinebreaksFilter], [fill_tags],
+ * write_tokenized_text.  Only the text crosses PCIe: char counting, scoring, tagging and the writer run on the
+ * device.  flags: any VPT_FLAG_*; tagged != 0 needs a predictor created with predict_tags.  text_capacity:
+ * 3 * (text bytes), plus (text bytes) * vpt_predictor_max_tag_suffix when tagged, always suffices. */
+vpt_status vpt_tokenize_batch(const vpt_predictor *p, const uint8_t *utf8, const uint64_t *byte_offsets,
+                              size_t n_sentences, unsigned flags, int tagged, uint8_t *text_out,
+                              uint64_t text_capacity, uint64_t *text_offsets_out);
+
 /* Diagnostics: when the environment variable VPT_PROFILE_PHASES is set at vpt_batch_create, the specialised
  * kernel accumulates, per workgroup (wave 0), the shader cycles spent in 0 text scan, 1 per-char decode,
  * 2 pattern lookups, 3 barrier wait, 4 boundary output.  Reads the sums (after a device sync) and resets them;

@@ -117,6 +117,7 @@ static inline int atomicAdd(int* p, int v) { int o = *p; *p = int(uint32_t(o) + 
 static inline unsigned atomicAdd(unsigned* p, unsigned v) { unsigned o = *p; *p = o + v; return o; }
 static inline unsigned long long atomicAdd(unsigned long long* p, unsigned long long v) { unsigned long long o = *p; *p = o + v; return o; }
 static inline unsigned atomicOr(unsigned* p, unsigned v) { unsigned o = *p; *p = o | v; return o; }
+static inline unsigned atomicMax(unsigned* p, unsigned v) { unsigned o = *p; *p = o > v ? o : v; return o; }
 #define __HIP_MEMORY_SCOPE_AGENT 0
 template <typename T, typename V> static inline T __hip_atomic_fetch_add(T* p, V v, int, int) {
     T o = *p;

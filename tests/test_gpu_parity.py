@@ -779,3 +779,47 @@ def test_write_tagged_text_on_device():
     toff = d_toff.get(S + 1)
     out = bytes(d_out.get(int(toff[-1])))
     assert [out[int(toff[i]):int(toff[i + 1])].decode("utf-8") for i in range(S)] == want
+
+
+def test_tokenize_batch_is_the_whole_pipeline():
+    """vpt_tokenize_batch (lines in, tokenized lines out) = from_raw + predict (+ filters) (+ fill_tags) + write_tokenized_text,
+    and vpt_count_boundaries_device = vpt_count_boundaries."""
+    m = randmodel.rand_model(850, alphabet="mixed", wc=3, wt=3, n_tag_models=25, max_word=5, n_char=120, n_dict=120)
+    raw = encode_model(m)
+    texts = randmodel.rand_sentences(6, m, 500, alphabet="mixed", max_len=50) + ["a", "あ", "12 ab/c\\d", "x" * 300, "\n改行\r\n", "🤌🏿"]
+    for tagged in (False, True):
+        pred = api.Predictor(api.Model.read_slice(raw)[0], tagged)
+        for kw in ({}, {"fullwidth": True}, {"wsconst": [1, 2], "split_linebreaks": True}):
+            sents = [api.Sentence.from_raw(t) for t in texts]
+            pred.predict_batch(sents, fullwidth=kw.get("fullwidth", False))
+            if "wsconst" in kw:   # the label flags of predict_packed, applied through the packed entry point
+                utf8, boff = api.pack_texts([t.encode("utf-8") for t in texts])
+                _, labels, ooff = pred.predict_packed(utf8, boff, wsconst=kw["wsconst"], split_linebreaks=True)
+                for i, s in enumerate(sents):
+                    s._boundaries = labels[int(ooff[i]):int(ooff[i + 1])].copy()
+            if tagged:
+                want = pred.write_tokenized_batch(sents, tagged=True) if not kw.get("fullwidth") else None
+            else:
+                want = pred.write_tokenized_batch(sents)
+            got = pred.tokenize(texts, tagged=tagged, **kw)
+            if want is not None:
+                assert got == want, kw
+            else:   # tags on the normalised text: the same tokens, checked against the packed tagged writer with the flag
+                utf8, boff = api.pack_texts([t.encode("utf-8") for t in texts])
+                ooff = api.count_boundaries(utf8, boff)
+                labels = np.concatenate([np.asarray(s._boundaries, np.uint8) for s in sents])
+                t2, o2 = pred.write_tokenized_packed(utf8, boff, ooff, labels, tagged=True, fullwidth=True)
+                assert got == [bytes(t2[int(o2[i]):int(o2[i + 1])]).decode("utf-8") for i in range(len(texts))]
+    # errors of Sentence::from_raw, found on the device
+    pred = api.Predictor(api.Model.read_slice(raw)[0], False)
+    with pytest.raises(api.VaporettoError, match="must not contain NULL"):
+        pred.tokenize(["ab", "c\0d"])
+    # device-resident counting
+    utf8, boff = api.pack_texts([t.encode("utf-8") for t in texts])
+    d_text = devmem.put(np.concatenate([utf8, np.zeros(16, np.uint8)])); d_boff = devmem.put(boff.astype(np.uint64))
+    d_ooff = devmem.zeros(len(texts) + 1, np.uint64)
+    batch = api.DeviceBatch(pred)
+    st = api._lib.load().vpt_count_boundaries_device(pred.handle, batch._h, d_text.ptr, d_boff.ptr, len(texts), d_ooff.ptr, devmem.stream())
+    assert st == api._lib.VPT_OK
+    batch.sync()
+    assert np.array_equal(d_ooff.get(len(texts) + 1), api.count_boundaries(utf8, boff))

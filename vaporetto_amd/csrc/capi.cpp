@@ -838,6 +838,96 @@ vpt_status vpt_write_tagged_batch(const vpt_predictor* p, const uint8_t* utf8, c
     return emit_host(p, utf8, byte_offsets, n_sentences, out_offsets, labels, true, flags, text_out, text_capacity, text_offsets_out);
 }
 
+vpt_status vpt_count_boundaries_device(const vpt_predictor* p, vpt_batch* b, const uint8_t* d_utf8, const uint64_t* d_byte_offsets,
+                                       size_t n_sentences, uint64_t* d_out_offsets, void* hip_stream) {
+    if (!p || !b || b->pred != p) return fail(VPT_INVALID_ARGUMENT, "InvalidArgumentError: batch: does not belong to this predictor");
+    if (!d_out_offsets || (n_sentences && (!d_utf8 || !d_byte_offsets))) return fail(VPT_INVALID_ARGUMENT, "InvalidArgumentError: NULL device pointer");
+    hipStream_t stream = static_cast<hipStream_t>(hip_stream);
+    VPT_HIP(hipSetDevice(p->device));
+    VPT_HIP(hipMemsetAsync(b->d_ctrl + 2, 0, sizeof(uint32_t), stream));   // [2]: the longest sentence in chars
+    if (n_sentences == 0) VPT_HIP(hipMemsetAsync(d_out_offsets, 0, sizeof(uint64_t), stream));
+    else VPT_HIP(vpt::launch_count_boundaries(d_utf8, d_byte_offsets, n_sentences, d_out_offsets, b->d_ctrl, b->d_ctrl + 2, stream));
+    b->last_stream = stream; b->pending = true;
+    return VPT_OK;
+}
+
+// Lines in, tokenized lines out: Sentence::from_raw -> [KyteaFullwidthFilter] -> Predictor::predict -> [post-filters]
+// -> [fill_tags] -> write_tokenized_text for a whole batch (the loop of predict/src/main.rs:122-176), with only the
+// text crossing PCIe: char counting, scoring, tagging and the writer all run on the device.
+vpt_status vpt_tokenize_batch(const vpt_predictor* p, const uint8_t* utf8, const uint64_t* byte_offsets, size_t n_sentences, unsigned flags,
+                              int tagged, uint8_t* text_out, uint64_t text_capacity, uint64_t* text_offsets_out) {
+    if (!p) return fail(VPT_INVALID_ARGUMENT, "InvalidArgumentError: predictor: must not be NULL");
+    if (!text_offsets_out) return fail(VPT_INVALID_ARGUMENT, "InvalidArgumentError: NULL argument");
+    if (flags & ~unsigned(VPT_FLAG_ALL)) return fail(VPT_INVALID_ARGUMENT, "InvalidArgumentError: flags: unknown bit");
+    if (tagged && !p->predict_tags) return fail(VPT_INVALID_ARGUMENT, "InvalidArgumentError: this predictor is created with predict_tags = false");
+    text_offsets_out[0] = 0;
+    if (n_sentences == 0) return VPT_OK;
+    if (!utf8 || !byte_offsets || (text_capacity && !text_out)) return fail(VPT_INVALID_ARGUMENT, "InvalidArgumentError: NULL argument");
+    const uint64_t t0 = byte_offsets[0], t1 = byte_offsets[n_sentences];
+    if (t1 < t0) return fail(VPT_INVALID_ARGUMENT, "InvalidArgumentError: byte_offsets: must be non-decreasing");
+    uint64_t max_bytes = 0;
+    for (size_t i = 0; i < n_sentences; ++i) {
+        if (byte_offsets[i + 1] <= byte_offsets[i])
+            return fail(VPT_INVALID_ARGUMENT, "InvalidArgumentError: text: must contain at least one character");
+        max_bytes = std::max<uint64_t>(max_bytes, byte_offsets[i + 1] - byte_offsets[i]);
+    }
+    VPT_HIP(hipSetDevice(p->device));
+    Workspace w;
+    vpt_status st = acquire(p, &w);
+    if (st != VPT_OK) return st;
+    vpt_batch* b = w.b;
+    hipStream_t s = b->own_stream;
+    const size_t nbytes = size_t(t1 - t0);
+    if ((st = grow(&b->d_text, &b->text_cap, nbytes + 32)) != VPT_OK) return st;
+    {
+        size_t cap = b->off_cap;
+        if ((st = grow(&b->d_boff, &cap, n_sentences + 1)) != VPT_OK) return st;
+        size_t cap2 = b->off_cap;
+        if ((st = grow(&b->d_ooff, &cap2, n_sentences + 1)) != VPT_OK) return st;
+        b->off_cap = std::min(cap, cap2);
+    }
+    std::vector<uint64_t>& boff = b->h_boff;
+    boff.resize(n_sentences + 1);
+    for (size_t i = 0; i <= n_sentences; ++i) boff[i] = byte_offsets[i] - t0;
+    VPT_HIP(hipMemcpyAsync(b->d_text, utf8 + t0, nbytes, hipMemcpyHostToDevice, s));
+    VPT_HIP(hipMemcpyAsync(b->d_boff, boff.data(), 8 * (n_sentences + 1), hipMemcpyHostToDevice, s));
+    // chars per sentence on the device; the totals come back to size the outputs (the one mid-pipeline sync)
+    if ((st = vpt_count_boundaries_device(p, b, b->d_text, b->d_boff, n_sentences, b->d_ooff, s)) != VPT_OK) return st;
+    uint64_t total_b = 0;
+    uint32_t max_chars = 0;
+    VPT_HIP(hipMemcpyAsync(&total_b, b->d_ooff + n_sentences, sizeof(total_b), hipMemcpyDeviceToHost, s));
+    VPT_HIP(hipMemcpyAsync(&max_chars, b->d_ctrl + 2, sizeof(max_chars), hipMemcpyDeviceToHost, s));
+    if ((st = vpt_batch_sync(b)) != VPT_OK) return st;   // NUL / empty sentences are reported here
+    {
+        size_t cap = b->out_cap;
+        if ((st = grow(&b->d_scores, &cap, size_t(total_b) + 1)) != VPT_OK) return st;
+        size_t cap2 = b->out_cap;
+        if ((st = grow(&b->d_labels, &cap2, size_t(total_b) + 1)) != VPT_OK) return st;
+        b->out_cap = std::min(cap, cap2);
+    }
+    if ((st = grow(&b->d_tok, &b->tok_cap, size_t(text_capacity) + 16)) != VPT_OK) return st;
+    if ((st = grow(&b->d_toff, &b->toff_cap, n_sentences + 1)) != VPT_OK) return st;
+    b->max_chars = max_chars;
+    b->flags = flags;
+    st = vpt_predict_batch_device(p, b, b->d_text, b->d_boff, b->d_ooff, n_sentences, total_b, max_bytes, nullptr, b->d_labels, s);
+    if (st != VPT_OK) return st;
+    const bool with_tags = tagged && p->n_tags > 0;
+    if (with_tags) {
+        if ((st = grow(&b->d_tags, &b->tags_cap, size_t(total_b + n_sentences) * p->n_tags + 16)) != VPT_OK) return st;
+        b->flags = flags & VPT_FLAG_KYTEA_FULLWIDTH;
+        st = vpt_fill_tags_batch_device(p, b, b->d_text, b->d_boff, b->d_ooff, n_sentences, total_b, b->d_labels, b->d_tags, s);
+        if (st != VPT_OK) return st;
+    }
+    st = emit_device(p, b, b->d_text, b->d_boff, b->d_ooff, n_sentences, total_b, b->d_labels, with_tags ? b->d_tags : nullptr, b->d_tok,
+                     text_capacity, b->d_toff, s);
+    if (st != VPT_OK) return st;
+    if ((st = vpt_batch_sync(b)) != VPT_OK) return st;
+    VPT_HIP(hipMemcpy(text_offsets_out, b->d_toff, 8 * (n_sentences + 1), hipMemcpyDeviceToHost));
+    const uint64_t total = text_offsets_out[n_sentences];
+    if (total) VPT_HIP(hipMemcpy(text_out, b->d_tok, size_t(total), hipMemcpyDeviceToHost));
+    return VPT_OK;
+}
+
 vpt_status vpt_predict_one(const vpt_predictor* p, const uint8_t* utf8, size_t len, int32_t* scores, uint8_t* labels, size_t* n_boundaries) {
     uint64_t boff[2] = {0, uint64_t(len)}, ooff[2] = {0, 0};
     if (len == 0) return fail(VPT_INVALID_ARGUMENT, "InvalidArgumentError: text: must contain at least one character");

@@ -92,6 +92,9 @@ struct EmitParams {
     const uint8_t* str_bytes;
 };
 hipError_t launch_emit_tokenized(const EmitParams& P, hipStream_t stream);
+// vpt_count_boundaries on the device: ooff_out[S+1]; *max_chars (atomicMax) = the longest sentence in chars
+hipError_t launch_count_boundaries(const uint8_t* text, const uint64_t* boff, uint64_t n_sent, uint64_t* ooff_out, uint32_t* status,
+                                   uint32_t* max_chars, hipStream_t stream);
 
 size_t score_tiles_lds_bytes();
 hipError_t launch_assign_tiles(const uint64_t* ooff, uint64_t n_sent, int pad, uint32_t tile_flat, uint32_t n_tiles,

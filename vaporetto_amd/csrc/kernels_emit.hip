@@ -186,7 +186,46 @@ __global__ __launch_bounds__(kEmitThreads) void emit_write_kernel(const EmitPara
     }
 }
 
+// vpt_count_boundaries on the device: chars - 1 of every sentence -> offsets[i + 1] (the scan follows), the same
+// validation as Sentence::from_raw (sentence.rs:160-196), the longest sentence (in chars) -> *max_chars
+__global__ __launch_bounds__(kEmitThreads) void count_chars_kernel(const uint8_t* __restrict__ text, const uint64_t* __restrict__ boff,
+                                                                   uint64_t n_sent, uint64_t* __restrict__ offsets, uint32_t* __restrict__ status,
+                                                                   uint32_t* __restrict__ max_chars) {
+    const int lane = threadIdx.x & 63;
+    const uint64_t wave = uint64_t(blockIdx.x) * kEmitWaves + (threadIdx.x >> 6);
+    const uint64_t n_waves = uint64_t(gridDim.x) * kEmitWaves;
+    uint32_t err = 0, longest = 0;
+    for (uint64_t i = wave; i < n_sent; i += n_waves) {
+        const uint64_t b0 = boff[i], b1 = boff[i + 1];
+        uint64_t chars = 0;
+        bool nul = false;
+        for (uint64_t pos = b0; pos < b1; pos += 64) {
+            const uint64_t at = pos + uint64_t(lane);
+            const bool in = at < b1;
+            const uint32_t byte = in ? text[at] : 0x80u;
+            nul = nul || (in && byte == 0);
+            chars += uint64_t(__popcll(__ballot(in && (byte & 0xC0u) != 0x80u)));
+        }
+        if (__ballot(nul) != 0) err |= kErrNulChar;
+        if (b1 <= b0 || chars == 0) err |= kErrEmptySentence;
+        if (chars > 0xFFFFFFFFull) err |= kErrBadOffsets;
+        longest = chars > longest ? uint32_t(chars) : longest;
+        if (lane == 0) offsets[i + 1] = chars > 0 ? chars - 1 : 0;
+    }
+    if (err) atomicOr(status, err);
+    if (lane == 0 && longest) atomicMax(max_chars, longest);
+}
+
 }  // namespace
+
+hipError_t launch_count_boundaries(const uint8_t* text, const uint64_t* boff, uint64_t n_sent, uint64_t* ooff_out, uint32_t* status,
+                                   uint32_t* max_chars, hipStream_t stream) {
+    const uint64_t want = (n_sent + kEmitWaves - 1) / kEmitWaves;
+    const uint32_t blocks = uint32_t(want < 1 ? 1 : want > 65536 ? 65536 : want);
+    hipLaunchKernelGGL(count_chars_kernel, dim3(blocks), dim3(kEmitThreads), 0, stream, text, boff, n_sent, ooff_out, status, max_chars);
+    hipLaunchKernelGGL(emit_scan_kernel, dim3(1), dim3(kScanThreads), 0, stream, ooff_out, n_sent, ~uint64_t(0), status);
+    return hipGetLastError();
+}
 
 hipError_t launch_emit_tokenized(const EmitParams& P, hipStream_t stream) {
     const uint64_t want = (P.n_sent + kEmitWaves - 1) / kEmitWaves;
