@@ -74,6 +74,13 @@ while time.time() < t_end:
         if got_t != [s.write_tokenized_text() for s in sents]:
             print("MISMATCH tagged text: seed", seed)
             sys.exit(1)
+    if seed % 4 == 1:   # the one-call pipeline (vpt_tokenize_batch) against predict_batch + the packed writer
+        sub = texts[:60]
+        sents = [api.Sentence.from_raw(t) for t in sub]
+        pred.predict_batch(sents, fullwidth=fw)
+        if pred.tokenize(sub, fullwidth=fw) != pred.write_tokenized_batch(sents):
+            print("MISMATCH tokenize: seed", seed)
+            sys.exit(1)
     n_models += 1
     n_sent += len(texts)
 print("fuzz ok: %d models, %d sentences, no mismatch" % (n_models, n_sent))
