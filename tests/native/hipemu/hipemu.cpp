@@ -3,6 +3,7 @@
 #include <ucontext.h>
 
 #include <cstdio>
+#include <cstdlib>
 #include <memory>
 #include <mutex>
 #include <vector>
@@ -12,6 +13,7 @@
 namespace hipemu {
 
 Idx g_threadIdx, g_blockIdx, g_blockDim, g_gridDim;
+bool g_reverse = std::getenv("HIPEMU_REVERSE") != nullptr;   // lane order of the scheduler; also hipemu_set_lane_order()
 
 namespace {
 
@@ -55,6 +57,7 @@ alignas(16) unsigned char g_lds[kMaxLds];
 uint64_t g_progress = 0;          // bumps whenever a group is released or a fiber ends
 uint64_t g_clock = 0;
 uint32_t g_garbage = 0x9E3779B9u;
+
 
 [[noreturn]] void die(const char* msg) {
     std::fprintf(stderr, "hipemu: %s (block %u, thread %u)\n", msg, g_blockIdx.x, g_threadIdx.x);
@@ -208,7 +211,8 @@ void run_grid(dim3 grid, dim3 block, size_t lds_bytes, const std::function<void(
         while (left > 0) {
             const uint64_t before = g_progress;
             left = 0;
-            for (unsigned t = 0; t < n; ++t) {
+            for (unsigned k = 0; k < n; ++k) {
+                const unsigned t = g_reverse ? n - 1 - k : k;   // HIPEMU_REVERSE=1: the other lane order must give the same results
                 Fiber& f = g_fibers[t];
                 if (f.done) continue;
                 g_cur = &f;
@@ -224,6 +228,9 @@ void run_grid(dim3 grid, dim3 block, size_t lds_bytes, const std::function<void(
 }
 
 }  // namespace hipemu
+
+// The order in which the scheduler visits the lanes must not matter (0: ascending, 1: descending).
+extern "C" void hipemu_set_lane_order(int descending) { hipemu::g_reverse = descending != 0; }
 
 // ------------------------------------------------------------------------------------------------ fake runtime
 namespace {

@@ -54,6 +54,22 @@ for _name in _AS_IS:
 del _name
 
 
+def test_lane_order_does_not_matter():
+    """The scheduler visits the lanes of a workgroup in ascending order; in descending order (every cross-lane
+    rendezvous is then reached by the HIGHEST lane first) a kernel that only orders its lanes through cross-lane
+    operations must give the same results.  (The whole module also passes with HIPEMU_REVERSE=1.)"""
+    lib = _lib.load()
+    lib.hipemu_set_lane_order(1)
+    try:
+        for seed in (0, 7, 14):
+            G.test_random_models_vs_oracle(seed)
+        G.test_predict_tags_like_reference()
+        G.test_tokenize_batch_is_the_whole_pipeline()
+        G.test_device_side_error_flags()
+    finally:
+        lib.hipemu_set_lane_order(0)
+
+
 def test_every_gpu_parity_test_is_accounted_for():
     """A new GPU parity test must be added to _AS_IS or to the sized-down list below."""
     sized_down = {"test_synthetic_configs_match_oracle", "test_batch_properties_at_full_config_size"}
