@@ -105,6 +105,8 @@ static inline void __syncthreads() { ::hipemu::block_sync(); }
 static inline uint64_t __ballot(int pred) { return ::hipemu::ballot(pred != 0); }
 static inline int __shfl_up(int v, unsigned d) { return int(::hipemu::shfl_up(uint32_t(v), d)); }
 static inline unsigned __shfl_up(unsigned v, unsigned d) { return ::hipemu::shfl_up(v, d); }
+static inline int __shfl(int v, int src) { return int(::hipemu::shfl_xor(uint32_t(v), unsigned(src) ^ ::hipemu::lane())); }
+static inline int __clzll(long long x) { return x ? __builtin_clzll((unsigned long long)x) : 64; }
 static inline int __shfl_xor(int v, int m) { return int(::hipemu::shfl_xor(uint32_t(v), unsigned(m))); }
 static inline int __popc(uint32_t x) { return __builtin_popcount(x); }
 static inline int __popcll(uint64_t x) { return __builtin_popcountll(x); }
