@@ -34,6 +34,8 @@
 // lock-step marker of the kernels (device_common.h): the lanes of the wave meet here
 #define VPT_WAVE_LOCKSTEP() ::hipemu::wave_sync()
 #define VPT_PIN(x) ((void)0)   /* a code-generation hint on the GPU */
+#define VPT_STREAM_LOAD16(ptr) (*reinterpret_cast<const uint4*>(ptr))   /* cache hints on the GPU */
+#define VPT_STREAM_STORE(val, ptr) (*(ptr) = (val))
 
 struct uint2 { uint32_t x, y; };
 struct uint4 { uint32_t x, y, z, w; } __attribute__((aligned(16)));
