@@ -325,6 +325,42 @@ def test_type_rows_and_window_table_agree_with_oracle(wt, force_window, monkeypa
     check_batch(pred, orc, texts)
 
 
+@pytest.mark.parametrize("wt", [1, 2, 3])
+@pytest.mark.parametrize("predict_tags", [False, True])
+def test_type_weights_no_window_reads_and_padding_ngrams(wt, predict_tags, monkeypatch):
+    """boundary_scorer_cache.rs:41-46 only ever reads w[2W - end]: a type n-gram weight with an index above 2W - n is in
+    no window and must add nothing -- on the type rows as on the window table (the rows used to add it).  A
+    type n-gram holding code 0 matches the padding in the window table (it is a pattern like any other there), which a
+    start-position row cannot express: such a model must be scored from the window table.  With tag models the
+    reference matches types with an automaton over char_types (1..6), where a 0 never matches."""
+    from vaporetto_amd.modelfmt import TagModel
+    for case in ("overlong", "padding"):
+        m = randmodel.rand_model(900 + wt, alphabet="kana", wc=3, wt=wt, n_char=60, n_dict=60, n_type=0, max_word=6,
+                                 n_tag_models=3 if predict_tags else 0)
+        m.type_ngram_model = []
+        if case == "overlong" and not predict_tags:   # (with tag models an over-long vector is InvalidModel: DESIGN.md, model contract)
+            m.type_ngram_model.append(NgramData(bytes([3]), [1, 10, 100, 1000, 10000, 100000][:min(6, 2 * wt + 3)]))
+            m.type_ngram_model.append(NgramData(bytes([3, 5]), [7, 70, 700, 7000, 70000][:min(5, 2 * wt + 2)]))
+        elif case == "overlong":
+            m.type_ngram_model.append(NgramData(bytes([3]), [1, 10, 100, 1000, 10000, 100000][:2 * wt]))
+        else:
+            m.type_ngram_model.append(NgramData(bytes([0, 3]), [5, -50, 500, -5000, 50000][:2 * wt - 1]))
+            m.type_ngram_model.append(NgramData(bytes([3, 0]), [3, -30, 300, -3000, 30000][:2 * wt - 1]))
+            m.type_ngram_model.append(NgramData(bytes([5]), [2, -20, 200, -2000, 20000, -200000][:2 * wt]))
+        pred, orc = make_predictor(m, predict_tags)
+        info = pred.info()
+        assert info["packed"] == 1
+        if case == "padding" and not predict_tags:
+            assert info["type_rows"] == 0   # the window table, which knows about the padding
+        mixed = randmodel.ALPHABETS["kana"][:6] + list("漢字カA9、")
+        texts = randmodel.rand_sentences(3, m, 800, alphabet=mixed, max_len=30) + ["あ", "あ漢", "漢あ", "あああ", "カあ"]
+        check_batch(pred, orc, texts)
+        if case == "overlong" and not predict_tags:
+            monkeypatch.setenv("VPT_FORCE_WINDOW_TABLE", "1")
+            check_batch(make_predictor(m, predict_tags)[0], orc, texts)
+            monkeypatch.delenv("VPT_FORCE_WINDOW_TABLE")
+
+
 def test_long_type_ngrams_use_the_window_table():
     m = randmodel.rand_model(77, alphabet="kana", wc=3, wt=3, n_char=80, n_dict=80, n_type=40, max_word=6)
     m.type_ngram_model.append(NgramData(bytes([3, 3, 3, 3]), [5, -6, 7]))

@@ -41,7 +41,7 @@ _AS_IS = [
     "test_packed_path_is_used_and_handles_wide_rows", "test_dense_packed_tables",
     "test_long_dictionary_words_cross_tile_sized_sentences", "test_very_long_words_and_compressed_chains",
     "test_non_bmp_pattern_models_use_the_general_tables", "test_long_type_ngrams_use_the_window_table",
-    "test_type_rows_and_window_table_agree_with_oracle", "test_understated_length_bounds_are_reported",
+    "test_type_rows_and_window_table_agree_with_oracle", "test_type_weights_no_window_reads_and_padding_ngrams", "test_understated_length_bounds_are_reported",
     "test_tag_enabled_model_with_duplicate_type_ngrams_runs_on_the_packed_path", "test_predict_tags_like_reference",
     "test_fill_tags_requires_predict_tags_gpu", "test_fixture_tags_gpu", "test_random_tag_models_match_oracle",
     "test_converted_kytea_fixture_on_gpu", "test_fullwidth_filter_on_device", "test_label_post_filters_on_device",

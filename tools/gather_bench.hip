@@ -54,10 +54,11 @@ __global__ __launch_bounds__(256) void gather(const uint4* __restrict__ tab, uin
 }
 
 // record index for the skewed mix: 77 % from the first `hot` records, the rest uniform over the table
+__device__ uint32_t g_hot_per_1024 = 788u;   // share of the accesses that go to the hot set
 __device__ __forceinline__ uint32_t skewed(uint32_t who, uint32_t i, uint32_t nrec_mask, uint32_t hot_mask) {
     const uint32_t r = mix(who * 0x9E3779B1u + i * 0x85EBCA77u);
     const uint32_t pick = mix(r ^ 0x5bd1e995u);
-    return ((pick & 1023u) < 788u) ? (r & hot_mask) : (r & nrec_mask);
+    return ((pick & 1023u) < g_hot_per_1024) ? (r & hot_mask) : (r & nrec_mask);
 }
 
 template <int MODE>
@@ -135,6 +136,13 @@ int main() {
         const double t9 = run_mix<9>(tab, nrec_mask, hot_mask, blocks, iters, out);
         printf("skewed mix, one record per lane | G records/s: pair-issued 128 B %.1f | 64 B + 43%% second half, own lane %.1f | same, pair-issued %.1f\n",
                positions / t7 / 1e6, positions / t8 / 1e6, positions / t9 / 1e6);
+        // the same pair-issued record gather with a hotter mix: what filtering the absent keys (14 % of the positions,
+        // all of them cold) before the fetch would leave -- 788/1024 hot of 100 % -> 788/(1024 - 0.8 * 143) = 88 % hot
+        for (uint32_t hot : {788u, 900u, 1024u}) {
+            CHECK(hipMemcpyToSymbol(HIP_SYMBOL(g_hot_per_1024), &hot, sizeof(hot)));
+            const double t = run_mix<7>(tab, nrec_mask, hot_mask, blocks, iters, out);
+            printf("pair-issued 128 B, hot share %u/1024: %.1f G records/s\n", hot, positions / t / 1e6);
+        }
         CHECK(hipFree(tab));
     }
     return 0;

@@ -290,7 +290,12 @@ vpt_status stage(vpt_batch* b, const uint8_t* utf8, const uint64_t* byte_offsets
     for (size_t i = 0; i < n_sentences; ++i) {
         if (byte_offsets[i + 1] <= byte_offsets[i])
             return fail(VPT_INVALID_ARGUMENT, "InvalidArgumentError: text: must contain at least one character");
-        max_bytes = std::max<uint64_t>(max_bytes, byte_offsets[i + 1] - byte_offsets[i]);
+        const uint64_t nb = byte_offsets[i + 1] - byte_offsets[i];
+        // n chars take between n and 4n bytes: anything else cannot have come from vpt_count_boundaries (checked
+        // before any buffer is sized from these numbers)
+        if (out_offsets[i + 1] < out_offsets[i] || out_offsets[i + 1] - out_offsets[i] + 1 > nb)
+            return fail(VPT_INVALID_ARGUMENT, "InvalidArgumentError: out_offsets: do not match the text (or the text is not valid UTF-8)");
+        max_bytes = std::max<uint64_t>(max_bytes, nb);
         max_chars = std::max<uint64_t>(max_chars, out_offsets[i + 1] - out_offsets[i] + 1);
     }
     vpt_status st;
@@ -618,7 +623,10 @@ vpt_status vpt_predict_batch_device(const vpt_predictor* p, vpt_batch* b, const 
     P.prof = b->d_prof;
     if (const char* dbg = std::getenv("VPT_DEBUG_ABLATE")) { P.debug = uint32_t(std::atoi(dbg)); P.ct.debug = P.debug; P.tt.debug = P.debug; }
 
-    VPT_HIP(vpt::launch_assign_tiles(d_out_offsets, n_sentences, p->pad, uint32_t(tile_flat), n_tiles, b->d_tile_first, b->d_ctrl, stream));
+    P.n_sent = n_sentences; P.tile_flat = uint32_t(tile_flat); P.n_tiles = n_tiles;
+    const bool inline_assign = fast && !need_slow && !std::getenv("VPT_SEPARATE_ASSIGN");   // the status word is cleared by vpt_batch_sync
+    if (inline_assign) P.tile_first = nullptr;
+    else VPT_HIP(vpt::launch_assign_tiles(d_out_offsets, n_sentences, p->pad, uint32_t(tile_flat), n_tiles, b->d_tile_first, b->d_ctrl, stream));
     const size_t slot = b->ev_calls % kTimingRing;
     if (b->timing) VPT_HIP(hipEventRecord(b->ev[2 * slot], stream));
     if (fast) VPT_HIP(vpt::launch_score_tiles_fast(P, n_tiles, stream));
@@ -637,7 +645,7 @@ vpt_status vpt_batch_sync(vpt_batch* b) {
     VPT_HIP(hipMemcpyAsync(ctrl, b->d_ctrl, sizeof(ctrl), hipMemcpyDeviceToHost, b->last_stream));
     VPT_HIP(hipStreamSynchronize(b->last_stream));
     b->pending = false;
-    if (ctrl[0]) VPT_HIP(hipMemset(b->d_ctrl, 0, sizeof(uint32_t)));   // reported once (a predict call clears it too)
+    if (ctrl[0]) VPT_HIP(hipMemset(b->d_ctrl, 0, sizeof(uint32_t)));   // reported once; accumulates over every call enqueued since the last sync
     return status_from_bits(ctrl[0]);
 }
 

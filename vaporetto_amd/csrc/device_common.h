@@ -23,12 +23,63 @@
 #define VPT_PIN(x) __asm__ volatile("" : "+v"(x))
 #endif
 
+// Streaming accesses (text read once, outputs written once): non-temporal, so that they do not push the hot table
+// lines out of the 32 KB vector L1.  Plain accesses in the emulator.
+#if !defined(VPT_STREAM_LOAD16) && defined(VPT_NO_STREAM_HINTS)   // A/B builds (tools/ab_bench.py): plain accesses
+#define VPT_STREAM_LOAD16(ptr) (*reinterpret_cast<const uint4*>(ptr))
+#define VPT_STREAM_STORE(val, ptr) (*(ptr) = (val))
+#endif
+#ifndef VPT_STREAM_LOAD16
+typedef unsigned int vpt_u32x4 __attribute__((ext_vector_type(4)));
+#define VPT_STREAM_LOAD16(ptr) ({ const vpt_u32x4 v_ = __builtin_nontemporal_load(reinterpret_cast<const vpt_u32x4*>(ptr)); make_uint4(v_.x, v_.y, v_.z, v_.w); })
+#define VPT_STREAM_STORE(val, ptr) __builtin_nontemporal_store((val), (ptr))
+#endif
+
 namespace vpt {
 
 // A value that every lane of the wave holds alike, moved to a scalar register.  The hardware gains nothing; the
 // COMPILER learns that branches and loop exits depending on it are wave-uniform, so it keeps counters in SGPRs and
 // emits scalar branches instead of exec-mask loops (thread ids and LDS loads are divergent as far as it can tell).
 __device__ __forceinline__ uint32_t wave_uniform(uint32_t x) { return uint32_t(__builtin_amdgcn_readfirstlane(int(x))); }
+
+// First sentence i in [0, n_sent] whose flat start F(i) = ooff[i] + i * (1 + pad) is >= target (F is non-decreasing and
+// F(n_sent) is the total).  Sentences of similar length make F nearly linear: start from the interpolated position
+// and gallop outwards (two or three dependent loads instead of log2(n_sent)), then bisect.
+__device__ __forceinline__ uint64_t first_sentence_at(const uint64_t* __restrict__ ooff, uint64_t n_sent, uint64_t step, uint64_t target) {
+    auto F = [&](uint64_t i) { return ooff[i] + i * step; };
+    const uint64_t total = F(n_sent);
+    uint64_t g = total ? uint64_t((unsigned __int128)(target) * n_sent / total) : 0;
+    if (g > n_sent) g = n_sent;
+    uint64_t lo, hi;
+    if (F(g) >= target) {          // answer <= g: gallop down to an i with F(i) < target (or 0)
+        hi = g;
+        uint64_t w = 1;
+        lo = 0;
+        while (hi - lo > 0) {
+            const uint64_t p = g >= w ? g - w : 0;
+            if (F(p) < target) { lo = p + 1; break; }
+            hi = p;
+            if (p == 0) { lo = 0; break; }
+            w <<= 2;
+        }
+    } else {                       // answer > g: gallop up to an i with F(i) >= target (n_sent at the latest)
+        lo = g + 1;
+        uint64_t w = 1;
+        hi = n_sent;
+        for (;;) {
+            const uint64_t p = g + w < n_sent ? g + w : n_sent;
+            if (F(p) >= target) { hi = p; break; }
+            lo = p + 1;
+            if (p == n_sent) { hi = n_sent; break; }
+            w <<= 2;
+        }
+    }
+    while (lo < hi) {
+        const uint64_t mid = (lo + hi) >> 1;
+        if (F(mid) >= target) hi = mid; else lo = mid + 1;
+    }
+    return lo;
+}
 
 // CharacterType::get_type (sentence.rs:50-67): 1 Digit, 2 Roman, 3 Hiragana, 4 Katakana, 5 Kanji, 6 Other
 __device__ __forceinline__ uint32_t char_type(uint32_t c) {

@@ -304,49 +304,15 @@ __device__ __forceinline__ void process_tile(const ScoreParams& P, const TileMem
 // ------------------------------------------------------------------------------------------------------------
 
 // tile_first[t] = first sentence whose flat start F(i) = ooff[i] + i*(1+pad) is >= t*tile_flat  (t = 0..n_tiles)
-// Also clears the batch's control words (status bits, deferred-tile count) for the scoring kernels that follow on
-// the same stream -- one launch less than a separate memset.
+// Also clears the batch's deferred-tile count for the scoring kernels that follow on the same stream -- one launch
+// less than a separate memset.  The status word (ctrl[0]) is NOT cleared here: it accumulates over every call
+// enqueued on the workspace until vpt_batch_sync reads and clears it, so an error of any of them is reported.
 __global__ void assign_tiles_kernel(const uint64_t* __restrict__ ooff, uint64_t n_sent, int pad, uint32_t tile_flat,
                                     uint32_t n_tiles, uint32_t* __restrict__ tile_first, uint32_t* __restrict__ ctrl) {
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t < 2) ctrl[t] = 0;
+    if (t == 1) ctrl[1] = 0;
     if (t > n_tiles) return;
-    const uint64_t target = uint64_t(t) * tile_flat;
-    const uint64_t step = uint64_t(1 + pad);
-    auto F = [&](uint64_t i) { return ooff[i] + i * step; };   // non-decreasing; F(n_sent) is the total
-    // first i in [0, n_sent] with F(i) >= target.  Sentences of similar length make F nearly linear, so start from the
-    // interpolated position and gallop outwards (two or three dependent loads instead of log2(n_sent)), then bisect.
-    const uint64_t total = F(n_sent);
-    uint64_t g = total ? uint64_t((unsigned __int128)(target) * n_sent / total) : 0;
-    if (g > n_sent) g = n_sent;
-    uint64_t lo, hi;
-    if (F(g) >= target) {          // answer <= g: gallop down to an i with F(i) < target (or 0)
-        hi = g;
-        uint64_t w = 1;
-        lo = 0;
-        while (hi - lo > 0) {
-            const uint64_t p = g >= w ? g - w : 0;
-            if (F(p) < target) { lo = p + 1; break; }
-            hi = p;
-            if (p == 0) { lo = 0; break; }
-            w <<= 2;
-        }
-    } else {                       // answer > g: gallop up to an i with F(i) >= target (n_sent at the latest)
-        lo = g + 1;
-        uint64_t w = 1;
-        hi = n_sent;
-        for (;;) {
-            const uint64_t p = g + w < n_sent ? g + w : n_sent;
-            if (F(p) >= target) { hi = p; break; }
-            lo = p + 1;
-            if (p == n_sent) { hi = n_sent; break; }
-            w <<= 2;
-        }
-    }
-    while (lo < hi) {
-        const uint64_t mid = (lo + hi) >> 1;
-        if (F(mid) >= target) hi = mid; else lo = mid + 1;
-    }
+    const uint64_t lo = first_sentence_at(ooff, n_sent, uint64_t(1 + pad), uint64_t(t) * tile_flat);
     tile_first[t] = t == n_tiles ? uint32_t(n_sent) : uint32_t(lo);
 }
 

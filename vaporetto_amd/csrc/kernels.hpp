@@ -41,7 +41,9 @@ struct ScoreParams {
     const uint8_t* text;
     const uint64_t* boff;       // [S+1] byte offsets
     const uint64_t* ooff;       // [S+1] output (boundary) offsets
-    const uint32_t* tile_first; // [n_tiles+1]
+    const uint32_t* tile_first; // [n_tiles+1]; nullptr: the specialised kernel finds its tile itself (n_sent, tile_flat, n_tiles)
+    uint64_t n_sent;
+    uint32_t tile_flat, n_tiles;
     int32_t* scores;
     uint8_t* labels;
     uint32_t* status;

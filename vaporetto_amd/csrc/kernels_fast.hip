@@ -416,7 +416,21 @@ __global__ __launch_bounds__(kThreads, 6) void score_tiles_fast_kernel(const Sco
     constexpr uint32_t pad = 3;
 
     const uint32_t t = blockIdx.x;
-    const uint64_t i0 = P.tile_first[t], i1 = P.tile_first[t + 1];
+    uint64_t i0, i1;
+    if (P.tile_first) {
+        i0 = P.tile_first[t]; i1 = P.tile_first[t + 1];
+    } else {   // no assign_tiles_kernel in front: lanes 0 and 1 find the tile's two ends (a few dependent, L2-hot loads)
+        uint64_t mine = 0;
+        if (tid < 2) {
+            const uint32_t tt = t + uint32_t(tid);
+            mine = tt >= P.n_tiles ? P.n_sent : first_sentence_at(P.ooff, P.n_sent, uint64_t(1 + pad), uint64_t(tt) * P.tile_flat);
+        }
+        if (tid < 2) L.wtot[tid * 2] = uint32_t(mine), L.wtot[tid * 2 + 1] = uint32_t(mine >> 32);
+        __syncthreads();
+        i0 = uint64_t(wave_uniform(L.wtot[0])) | (uint64_t(wave_uniform(L.wtot[1])) << 32);
+        i1 = uint64_t(wave_uniform(L.wtot[2])) | (uint64_t(wave_uniform(L.wtot[3])) << 32);
+        __syncthreads();   // wtot is reused by the scan
+    }
     if (i0 >= i1) return;
     const uint64_t O0 = P.ooff[i0], O1 = P.ooff[i1];
     const uint64_t flat_len64 = uint64_t(pad) + (O1 + i1 * 4) - (O0 + i0 * 4);
@@ -455,7 +469,7 @@ __global__ __launch_bounds__(kThreads, 6) void score_tiles_fast_kernel(const Sco
     if (TM != kTypeRows) {
         for (uint32_t i = tid; i < uint32_t(kFastCap + kMargin) / 4; i += kThreads) reinterpret_cast<uint32_t*>(L.typ)[i] = 0;
     }
-    for (uint32_t c = tid; c < nchunks; c += kThreads) reinterpret_cast<uint4*>(raw)[c] = reinterpret_cast<const uint4*>(a0)[c];
+    for (uint32_t c = tid; c < nchunks; c += kThreads) reinterpret_cast<uint4*>(raw)[c] = VPT_STREAM_LOAD16(tbase - head + (size_t(c) << 4));   // = a0 + 16 c, still a global pointer
     if (tid == 0) raw[nchunks * 4] = 0;  // the dword after the staged text is read (as padding) by the last char
     __syncthreads();
     for (uint32_t j = tid; j < nsent; j += kThreads) {
@@ -558,7 +572,8 @@ __global__ __launch_bounds__(kThreads, 6) void score_tiles_fast_kernel(const Sco
         nx1 = L.sym[sn];                                   // the whole array is zero except for the tile's chars
         nx0 = L.sym[(sn > 1u ? sn : 1u) - 1u];             // position 0 is a separator: its left neighbour is never used
         nx2 = L.sym[sn + 1]; nx3 = L.sym[sn + 2];          // sn + 2 < kFastCap + kMargin
-        nseed = uint32_t(K.base[K.off_seed + packed_ph_bucket((nx1 & kCpMask) | ((nx2 & kCpMask) << 16), K.seed_shift)]);
+        const uint32_t bkt = packed_ph_bucket((nx1 & kCpMask) | ((nx2 & kCpMask) << 16), K.seed_shift);
+        nseed = uint32_t(K.base[K.off_seed + ((P.debug & 64u) ? 0u : bkt)]);   // 64: timing ablation, the seed load pinned (results wrong); 256: none (the DBG build as is)
     };
     stage(uint32_t(tid));
     const uint32_t off_rec = K.off_rec & ~255u;   // it IS 256-byte aligned (capi.cpp); now the compiler knows
@@ -665,7 +680,7 @@ __global__ __launch_bounds__(kThreads, 6) void score_tiles_fast_kernel(const Sco
         }
         const uint32_t o = (p - pad) - (pad + 1) * (x >> 19);
         if (o >= nb) { err |= kErrBadOffsets; continue; }  // only with offsets that do not match the text
-        if (sc) sc[o] = y;
+        if (sc) VPT_STREAM_STORE(y, sc + o);
         if (lb) {
             uint32_t label = y > 0 ? 1u : 0u;
             if (P.post) {   // wave-uniform: KyteaWsConstFilter / SplitLinebreaksFilter on the label
@@ -673,7 +688,7 @@ __global__ __launch_bounds__(kThreads, 6) void score_tiles_fast_kernel(const Sco
                 if (t1 == t2 && ((P.post >> t1) & 1u) && t1 != 0 && t1 != 7) label = 0;
                 if ((P.post & 0x80u) && (ca == 0x0Au || ca == 0x0Du || cb == 0x0Au || cb == 0x0Du)) label = 1;
             }
-            lb[o] = uint8_t(label);
+            VPT_STREAM_STORE(uint8_t(label), lb + o);
         }
     }
     if (err) atomicOr(P.status, err);

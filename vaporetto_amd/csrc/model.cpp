@@ -120,6 +120,10 @@ bool decode_utf8(const uint8_t* s, size_t n, SymString& out) {
             if ((s[i + j] & 0xC0) != 0x80) return false;
             cp = (cp << 6) | (s[i + j] & 0x3F);
         }
+        // a Rust String holds well-formed UTF-8 only (bincode's String decode fails otherwise): no overlong forms,
+        // no surrogates, nothing above U+10FFFF -- the same verdicts as vaporetto_amd/modelfmt.py
+        static const uint32_t kMinCp[4] = {0u, 0x80u, 0x800u, 0x10000u};
+        if (cp < kMinCp[extra] || cp > 0x10FFFFu || (cp >= 0xD800u && cp <= 0xDFFFu)) return false;
         out.push_back(cp);
         i += extra + 1;
     }

@@ -499,15 +499,21 @@ std::vector<uint32_t> build_type_rows(const std::vector<NgramRecord>& ngrams, in
     std::vector<int32_t> uni(8 * 6, 0), bi(64 * 6, 0), tri(512 * 6, 0);
     for (const NgramRecord& d : ngrams) {
         const int n = int(d.ngram.size());
-        bool usable = true;
-        for (Sym s : d.ngram)
-            if (s == 0 || s > 6) usable = false;   // can never match a character type
-        if (!usable || d.weights.empty()) continue;
+        bool usable = true, pads = false;
+        for (Sym s : d.ngram) {
+            if (s > 6) usable = false;   // can never match: windows only hold codes 0..6
+            if (s == 0) pads = true;     // code 0 = outside the sentence: the window table matches it against the padding
+        }
+        if (!usable || d.weights.empty() || n > 2 * W) continue;
+        if (pads) return {};             // a start-position row cannot say "outside": the window table scores this model
         if (n > 3) return {};
         uint32_t idx = 0;
         for (int i = 0; i < n; ++i) idx |= d.ngram[size_t(i)] << (3 * i);
         int32_t* row = n == 1 ? &uni[idx * 6] : n == 2 ? &bi[idx * 6] : &tri[idx * 6];
-        for (size_t k = 0; k < d.weights.size(); ++k) {
+        // the window table only ever reads w[2W - end], end = n .. 2W (boundary_scorer_cache.rs:41-46): a weight with an
+        // index above 2W - n exists in no window and is ignored there, so it is ignored here
+        const size_t used = std::min(d.weights.size(), size_t(2 * W - n + 1));
+        for (size_t k = 0; k < used; ++k) {
             const int slot = (n - 1 - W + int(k)) + 3;   // boundary start + n-1-W+k  (type_scorer/boundary_scorer.rs:48)
             if (slot < 0 || slot > 5) return {};
             row[slot] = wadd(row[slot], d.weights[k]);
@@ -765,6 +771,9 @@ CompiledModel compile_model(const ModelData& m, bool predict_tags) {
                 if (d.ngram.empty()) throw ModelError("InvalidModelError: failed to build the automaton");
                 if (int(d.weights.size()) > std::max(0, 2 * wt - int(d.ngram.size()) + 1))
                     throw ModelError("InvalidModelError: character type n-gram weight vector is longer than 2*window_size-n+1");
+                // TypeScorerBoundaryTag matches the n-grams against char_types, whose bytes are 1..6 (sentence.rs:50-67): an
+                // n-gram with a 0 in it matches nothing there, while the window table below would match it against the padding
+                if (has_zero(d.ngram)) continue;
                 if (!merged.empty() && merged.back().ngram == d.ngram) {
                     std::vector<int32_t>& w = merged.back().weights;
                     if (w.size() < d.weights.size()) w.resize(d.weights.size(), 0);
