@@ -1,7 +1,8 @@
 // Test infrastructure (NOT part of the product library): walks the PACKED tables the host-side table compiler
 // emits (vaporetto_amd/csrc/tables.cpp, layout.h "PACKED TABLES") on the CPU with exactly the lookup protocol the
-// specialised HIP kernel uses (home slot, kPkDisp continuation, empty-slot stop, trie parent ids), so that the
-// table compiler can be checked against the oracle without a GPU.  Built by tests/test_packed_tables.py with g++.
+// specialised HIP kernel uses (ids, unigram base + id -> bigram node with its key, filter, bigram base + id -> trigram
+// node with its parent, mini-tables below), so that the table compiler can be checked against the oracle without a GPU.
+// Built by tests/test_packed_tables.py with g++.
 #include <cstdint>
 #include <cstring>
 #include <vector>
@@ -73,8 +74,8 @@ int tc_packed_present(const tc_model* t) { return t->c.packed.present ? 1 : 0; }
 int tc_trow_present(const tc_model* t) { return t->c.packed.present && !t->c.packed.trow.empty() ? 1 : 0; }
 void tc_stats(const tc_model* t, uint32_t out[8]) {
     const HostPackedTable& k = t->c.packed;
-    out[0] = k.n_rec; out[1] = k.n_children; out[2] = k.n_overflow; out[3] = k.n_deep; out[4] = k.n_disp;
-    out[5] = k.max_probe; out[6] = k.n_wide; out[7] = k.n_left;
+    out[0] = k.n_bi; out[1] = k.n_tri; out[2] = uint32_t(k.bi.size() / 8); out[3] = k.n_deep; out[4] = uint32_t(k.tri.size() / 4);
+    out[5] = k.bi_shift; out[6] = k.n_wide; out[7] = k.n_alpha;
 }
 
 namespace {
@@ -95,7 +96,7 @@ const uint32_t* mini_find(const std::vector<uint32_t>& arena, uint32_t dw, uint3
 
 // Boundary scores of one sentence (n code points) from the packed tables: bias + char patterns (+ type rows when
 // the model has them in the packed form; returns 2 then, 1 when types are NOT included, < 0 on error).
-// probes[0..3] count continued record lookups / overflow mini-table probes / deep probes / filter rejections.
+// probes[0..3] count bigram nodes read / trigram nodes read / deep probes / filter rejections.
 int tc_score(const tc_model* t, const uint32_t* cps, size_t n, int32_t* y_out, uint64_t probes[4]) {
     const HostPackedTable& K = t->c.packed;
     const HostPatternTable& G = t->c.chars;
@@ -103,10 +104,11 @@ int tc_score(const tc_model* t, const uint32_t* cps, size_t n, int32_t* y_out, u
     std::vector<int32_t> y(n > 0 ? n - 1 : 0, t->c.bias);
     std::vector<uint32_t> sym(n + 3, 0), typ(n + 3, 0);
     for (size_t i = 0; i < n; ++i) {
-        sym[i] = cps[i] < kPackedNoMatchSym ? cps[i] : kPackedNoMatchSym;
+        sym[i] = cps[i] < 0x10000u ? K.id_of[cps[i]] : kNoId;
         typ[i] = char_type_host(cps[i]);
     }
-    const uint32_t rmask = (1u << K.rec_bits) - 1;
+    const uint32_t uni_last = uint32_t(K.uni.size() / 4) - 1, n_tri = uint32_t(K.tri.size() / 4);
+    auto cp_of = [&](uint32_t id) { return K.cpid[id < uni_last ? id : uni_last]; };
     for (size_t s = 0; s < n; ++s) {
         const uint32_t c1 = sym[s], c2 = sym[s + 1], c3 = sym[s + 2];
         const long S = long(s);
@@ -114,99 +116,62 @@ int tc_score(const tc_model* t, const uint32_t* cps, size_t n, int32_t* y_out, u
             const uint32_t* r = &K.trow[size_t(type_row_index(typ[s], typ[s + 1], typ[s + 2])) * 4];
             for (int j = 0; j < 6; ++j) add(y, S - 3 + j, trow_field(r[0], r[1], r[2], r[3], j));
         }
-        const uint32_t* u = &K.uni[size_t(c1) * 4];
-        for (int j = 0; j < 6; ++j) add(y, S - 3 + j, row_field(u[0], u[1], u[2], u[3] & ~kUniWideBit, j, kUniFieldBits));
+        const uint32_t* u = &K.uni[size_t(c1 < uni_last ? c1 : uni_last) * 4];
+        for (int j = 0; j < 6; ++j) add(y, S - 3 + j, row_field(u[0], u[1], u[2], u[3], j, kUniFieldBits));
         if (u[3] & kUniWideBit) {
-            const uint32_t* g = &G.uni[size_t(c1) * G.uni_dw];
+            const uint32_t* g = &G.uni[size_t(cp_of(c1)) * G.uni_dw];
             for (int j = 0; j < 6; ++j) add(y, S - 3 + j, int32_t(g[j]));
         }
         if (c2 == 0) continue;
-        const uint32_t kb = c1 | (c2 << 16);
-        uint32_t b = packed_ph_slot(kb, K.seed[packed_ph_bucket(kb, 32 - K.seed_bits)], 32 - K.rec_bits);
-        const uint32_t* r = &K.rec[size_t(b) * 32];
-        if (r[16] != kb) {
-            const uint32_t fl = r[3] >> 16;
-            const uint32_t* found = nullptr;
-            if (fl & kPkFar) {              // some key homed here lives more than 8 records on: walk to the first hole
-                ++probes[0];
-                for (;;) {
-                    b = (b + 1) & rmask;
-                    const uint32_t* q = &K.rec[size_t(b) * 32];
-                    if (q[16] == kb) { found = q; break; }
-                    if (q[16] == 0) break;
-                }
-            } else {
-                for (uint32_t hop = fl >> kPkHopShift; hop != 0 && !found; hop &= hop - 1) {
-                    const uint32_t d = uint32_t(__builtin_ctz(hop)) + 1;
-                    const uint32_t* q = &K.rec[size_t((b + d) & rmask) * 32];
-                    ++probes[0];
-                    if (q[16] == kb) found = q;
-                }
-            }
-            if (!found) continue;
-            r = found;
-        }
-        if (r[3] & (kPkWide << 16)) {
-            const uint32_t* g = general_find(G, short_key(c1, c2, 0));
+        const uint32_t slot = (((u[3] >> kUniBaseShift) & kUniBaseMask) << K.bi_shift) + c2;
+        if (size_t(slot) * 8 + 8 > K.bi.size()) return -3;   // the table must cover any id behind any base
+        const uint32_t* r = &K.bi[size_t(slot) * 8];
+        ++probes[0];
+        if (r[0] != (c1 | (c2 << 16))) continue;
+        if (r[3] & kBiWideBit) {
+            const uint32_t* g = general_find(G, short_key(cp_of(c1), cp_of(c2), 0));
             if (!g) return -2;
             for (int j = 0; j < 5; ++j) add(y, S - 2 + j, int32_t(g[2 + j]));
         } else {
-            for (int j = 0; j < 5; ++j) add(y, S - 2 + j, row_field(r[0], r[1], r[2], r[3] & 0xFFFFu, j, kBiFieldBits));
-        }
-        // a trigram-level child (row + deeper walk) of the string that starts at position `st`
-        auto apply_child = [&](long st, uint32_t k1, uint32_t k2, uint32_t k3, const uint32_t* ch) -> int {
-            if (ch[0] & (kPkWide << 16)) {
-                const uint32_t* g = general_find(G, short_key(k1, k2, k3));
-                if (!g) return -2;
-                for (int j = 0; j < 4; ++j) add(y, st - 1 + j, int32_t(g[2 + j]));
-            } else { add(y, st - 1, lo16(ch[1])); add(y, st, hi16(ch[1])); add(y, st + 1, lo16(ch[2])); add(y, st + 2, hi16(ch[2])); }
-            uint32_t ref = ch[3], depth = 3;
-            while (ref != 0) {
-                const size_t at = size_t(st) + depth;
-                const uint32_t c = sym[at < n ? at : n];
-                if (c == 0) break;
-                const uint32_t* e = mini_find(K.deep, 16, ref, c, &probes[2]);
-                if (!e) break;
-                const uint32_t nskip = (e[0] >> 24) & 15u;
-                bool ok = true;
-                for (uint32_t j = 0; j < nskip; ++j) {
-                    const size_t q = at + 1 + j;
-                    const uint32_t want = (e[2 + j / 2] >> (16 * (j & 1))) & 0xFFFFu;
-                    if ((q < n ? sym[q] : 0u) != want) ok = false;
-                }
-                if (!ok) break;
-                const uint32_t m = depth + 1 + nskip;
-                if (e[0] & (kPkHasRow << 16)) {
-                    for (uint32_t j = 0; j <= m; ++j) add(y, st - 1 + long(j), (j & 1) ? hi16(e[8 + (j >> 1)]) : lo16(e[8 + (j >> 1)]));
-                } else if (e[0] & (kPkExtRow << 16)) {
-                    for (uint32_t j = 0; j <= m; ++j) add(y, st - 1 + long(j), K.xrows[size_t(e[8]) + j]);
-                }
-                ref = e[1];
-                depth = m;
-            }
-            return 0;
-        };
-        // LEFT children: the string (c0,c1,c2) that started one position earlier
-        const uint32_t c0 = s > 0 ? sym[s - 1] : 0u;
-        if (c0 != 0) {
-            for (int j = 0; j < 3; ++j) {
-                const uint32_t* e = r + 20 + 4 * j;
-                if ((e[0] & 0xFFFFu) == c0) { if (apply_child(S - 1, c0, c1, c2, e) != 0) return -2; break; }
-            }
+            for (int j = 0; j < 5; ++j) add(y, S - 2 + j, row_field(r[1], r[2], r[3] & ~kBiWideBit, 0, j, kBiFieldBits));
         }
         if (c3 == 0) continue;
-        // RIGHT children, then the overflow mini-table behind its filter
-        const uint32_t* ch = nullptr;
-        for (int j = 0; j < 3 && !ch; ++j) {
-            const uint32_t* e = r + 4 + 4 * j;
-            if ((e[0] & 0xFFFFu) == c3) ch = e;
+        const uint64_t mask = uint64_t(r[5]) | (uint64_t(r[6]) << 32);
+        if (!((mask >> packed_filter_bit(c3)) & 1)) { ++probes[3]; continue; }
+        const uint32_t ts = r[4] + c3;   // modulo 2^32
+        if (ts >= n_tri) continue;
+        const uint32_t* ch = &K.tri[size_t(ts) * 4];
+        ++probes[1];
+        if ((ch[0] & kTriParentMask) != slot + 1) continue;
+        if (ch[0] & (kPkWide << 24)) {
+            const uint32_t* g = general_find(G, short_key(cp_of(c1), cp_of(c2), cp_of(c3)));
+            if (!g) return -2;
+            for (int j = 0; j < 4; ++j) add(y, S - 1 + j, int32_t(g[2 + j]));
+        } else { add(y, S - 1, lo16(ch[1])); add(y, S, hi16(ch[1])); add(y, S + 1, lo16(ch[2])); add(y, S + 2, hi16(ch[2])); }
+        uint32_t ref = ch[3], depth = 3;
+        while (ref != 0) {
+            const size_t at = s + depth;
+            const uint32_t c = sym[at < n ? at : n];
+            if (c == 0) break;
+            const uint32_t* e = mini_find(K.deep, 16, ref, c, &probes[2]);
+            if (!e) break;
+            const uint32_t nskip = (e[0] >> 24) & 15u;
+            bool ok = true;
+            for (uint32_t j = 0; j < nskip; ++j) {
+                const size_t q = at + 1 + j;
+                const uint32_t want = (e[2 + j / 2] >> (16 * (j & 1))) & 0xFFFFu;
+                if ((q < n ? sym[q] : 0u) != want) ok = false;
+            }
+            if (!ok) break;
+            const uint32_t m = depth + 1 + nskip;
+            if (e[0] & (kPkHasRow << 16)) {
+                for (uint32_t j = 0; j <= m; ++j) add(y, S - 1 + long(j), (j & 1) ? hi16(e[8 + (j >> 1)]) : lo16(e[8 + (j >> 1)]));
+            } else if (e[0] & (kPkExtRow << 16)) {
+                for (uint32_t j = 0; j <= m; ++j) add(y, S - 1 + long(j), K.xrows[size_t(e[8]) + j]);
+            }
+            ref = e[1];
+            depth = m;
         }
-        if (!ch && (r[3] & (kPkOv << 16))) {
-            const uint64_t mask = uint64_t(r[18]) | (uint64_t(r[19]) << 32);
-            if ((mask >> packed_filter_bit(c3)) & 1) ch = mini_find(K.kids3, 4, r[17], c3, &probes[1]);
-            else ++probes[3];
-        }
-        if (ch && apply_child(S, c1, c2, c3, ch) != 0) return -2;
     }
     std::memcpy(y_out, y.data(), y.size() * sizeof(int32_t));
     return K.trow.empty() ? 1 : 2;

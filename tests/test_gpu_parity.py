@@ -294,19 +294,31 @@ def test_non_bmp_pattern_models_use_the_general_tables():
     check_batch(pred, orc, randmodel.rand_sentences(3, m, 600, alphabet="mixed", max_len=70))
 
 
-@pytest.mark.parametrize("seed,ph_seeds", [(0, None), (1, None), (2, "1"), (3, "0")])
-def test_dense_packed_tables(seed, ph_seeds, monkeypatch):
-    """Crowded records, overflow mini-tables, left children; with VPT_DEBUG_PH_SEEDS the perfect-hash seed search is
-    starved so that displaced records (hop bitmap / kPkFar fallback) occur."""
-    if ph_seeds is not None:
-        monkeypatch.setenv("VPT_DEBUG_PH_SEEDS", ph_seeds)
+@pytest.mark.parametrize("seed", [0, 1, 2, 3])
+def test_dense_packed_tables(seed):
+    """A 16-char alphabet with 9 000 patterns: every char continues every char (dense double-array rows, saturated
+    child filters), deep tries behind most trigrams, and -- seeds 2, 3 -- text with chars outside the alphabet, whose
+    lookups land on other parents' nodes."""
     alpha = [chr(c) for c in range(0x3041, 0x3051)]
     m = randmodel.rand_model(70 + seed, alphabet=alpha, wc=3, wt=3, n_char=3000, n_dict=6000, max_word=12)
     pred, orc = make_predictor(m)
     info = pred.info()
-    assert info["packed"] == 1 and info["n_overflow_children"] > 0
-    assert (info["n_displaced"] == 0) == (ph_seeds is None)
-    texts = randmodel.rand_sentences(seed, m, 3000, alphabet=alpha, max_len=120)
+    assert info["packed"] == 1 and info["n_displaced"] == 0
+    text_alpha = alpha if seed < 2 else alpha + list("漢字カA9、んー")
+    texts = randmodel.rand_sentences(seed, m, 3000, alphabet=text_alpha, max_len=120)
+    check_batch(pred, orc, texts)
+
+
+def test_sparse_double_array_rows_interleave():
+    """600 kanji with few patterns each: the rows of different parents share the double arrays slot by slot, so absent
+    bigrams and trigrams land on FOREIGN nodes; the key / parent checks must reject every one of them."""
+    alpha = [chr(c) for c in range(0x4E00, 0x4E00 + 600)]
+    m = randmodel.rand_model(79, alphabet=alpha, wc=3, wt=3, n_char=2500, n_dict=2500, max_word=6)
+    pred, orc = make_predictor(m)
+    assert pred.info()["packed"] == 1
+    pats = [d.ngram for d in m.char_ngram_model] + [r.word for r in m.dict_model]
+    texts = randmodel.rand_sentences(9, m, 2500, alphabet=alpha, max_len=90)
+    texts += [p[:2] + q[2:] for p, q in zip(pats[:800], pats[800:1600]) if len(p) >= 2 and len(q) >= 3]
     check_batch(pred, orc, texts)
 
 

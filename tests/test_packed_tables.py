@@ -16,13 +16,13 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "..", "vaporetto_amd", "csrc")
 LIB = os.path.join(HERE, "native", "libvpt_tablecheck.so")
 SRCS = [os.path.join(HERE, "native", "tablecheck.cpp"), os.path.join(CSRC, "tables.cpp"), os.path.join(CSRC, "model.cpp")]
-DEPS = SRCS + [os.path.join(CSRC, h) for h in ("layout.h", "tables.hpp", "model.hpp")]
+DEPS = SRCS + [os.path.join(CSRC, h) for h in ("layout.h", "tables.hpp", "model.hpp", "patset.hpp")]
 
 
 @pytest.fixture(scope="module")
 def tc():
     if not os.path.exists(LIB) or any(os.path.getmtime(s) > os.path.getmtime(LIB) for s in DEPS):
-        subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-o", LIB] + SRCS)
+        subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-pthread", "-o", LIB] + SRCS)
     L = C.CDLL(LIB)
     L.tc_create.argtypes = [C.c_char_p, C.c_size_t, C.POINTER(C.c_void_p)]
     L.tc_create_tags.argtypes = [C.c_char_p, C.c_size_t, C.c_int, C.POINTER(C.c_void_p)]
@@ -50,7 +50,7 @@ class Walker:
     def stats(self):
         a = (C.c_uint32 * 8)()
         self.L.tc_stats(self.h, C.byref(a))
-        return dict(zip(["n_rec", "n_children", "n_overflow", "n_deep", "n_disp", "max_probe", "n_wide", "n_left"], list(a)))
+        return dict(zip(["n_bi", "n_tri", "bi_slots", "n_deep", "tri_slots", "bi_shift", "n_wide", "n_alpha"], list(a)))
 
     @property
     def trow(self):
@@ -88,30 +88,45 @@ def test_packed_walk_matches_oracle_random_models(tc, seed):
     for t in randmodel.rand_sentences(seed, m, 300, alphabet=alphabet, max_len=60):
         assert w.score(t, probes, want=1) == orc.predict(t)[0], t
     st = w.stats()
-    assert st["n_rec"] > 0 and st["n_children"] > 0 and st["n_deep"] > 0
+    assert st["n_bi"] > 0 and st["n_tri"] > 0 and st["n_deep"] > 0
 
 
-@pytest.mark.parametrize("ph_seeds", [None, "1", "0"])
-def test_packed_walk_dense_tables(tc, ph_seeds, monkeypatch):
-    """Tiny alphabets make crowded records, overflow mini-tables, left children and deep tries.  With the normal
-    perfect hash no record is displaced; VPT_DEBUG_PH_SEEDS starves the seed search so that the linear-probing
-    fallback (hop bitmap / kPkFar) is exercised too."""
-    if ph_seeds is not None:
-        monkeypatch.setenv("VPT_DEBUG_PH_SEEDS", ph_seeds)
+def test_packed_walk_dense_tables(tc):
+    """Tiny alphabets make dense double-array rows (every char continues every char), saturated child filters and deep
+    tries: every present key must be found by one node read per level, every absent one must be recognised."""
     alpha = [chr(c) for c in range(0x3041, 0x3051)]
     m = strip_types(randmodel.rand_model(77, alphabet=alpha, wc=3, wt=3, n_char=3000, n_dict=6000, max_word=9))
     raw = encode_model(m)
     w = Walker(tc, raw)
     assert w.packed
     st = w.stats()
-    assert st["n_overflow"] > 0 and st["n_left"] > 0
-    assert (st["n_disp"] == 0) == (ph_seeds is None)
+    assert st["n_alpha"] == 16 and st["n_bi"] == 256 and st["n_tri"] > 2000 and st["tri_slots"] < 2 * st["n_tri"]
     orc = cbind.OraclePredictor(raw)
     probes = [0, 0, 0, 0]
-    for t in randmodel.rand_sentences(5, m, 400, alphabet=alpha, max_len=80):
+    mixed = alpha + list("漢字カA9、")   # chars outside the alphabet too: kNoId lookups
+    for t in randmodel.rand_sentences(5, m, 400, alphabet=mixed, max_len=80):
         assert w.score(t, probes) == orc.predict(t)[0], t
-    assert probes[1] > 0 and probes[2] > 0          # overflow and deep mini-tables were used
-    assert (probes[0] > 0) == (ph_seeds is not None)   # displaced records only in the starved builds
+    assert probes[0] > 0 and probes[1] > 0 and probes[2] > 0   # bigram, trigram and deep levels were all walked
+
+
+def test_packed_walk_sparse_rows_and_filters(tc):
+    """A wide alphabet with few patterns: sparse rows interleave in the double arrays (absent keys land on other
+    parents' nodes, which the key / parent checks must reject) and the child filters reject most third chars."""
+    alpha = [chr(c) for c in range(0x4E00, 0x4E00 + 600)]
+    m = strip_types(randmodel.rand_model(78, alphabet=alpha, wc=3, wt=3, n_char=2500, n_dict=2500, max_word=6))
+    raw = encode_model(m)
+    w = Walker(tc, raw)
+    assert w.packed
+    st = w.stats()
+    assert st["bi_slots"] < 80000 + 65536   # far fewer than one 600-slot span per first char: the rows interleave
+    orc = cbind.OraclePredictor(raw)
+    probes = [0, 0, 0, 0]
+    pats = [d.ngram for d in m.char_ngram_model] + [r.word for r in m.dict_model]
+    texts = randmodel.rand_sentences(6, m, 500, alphabet=alpha, max_len=60)
+    texts += [p[:2] + q[2:] for p, q in zip(pats[:300], pats[300:600]) if len(p) >= 2 and len(q) >= 3]   # right prefix, foreign third char
+    for t in texts:
+        assert w.score(t, probes) == orc.predict(t)[0], t
+    assert probes[3] > 0 and probes[1] > 0          # the filters rejected lookups, and admitted some
 
 
 def test_packed_not_eligible_models_fall_back(tc):
@@ -135,9 +150,9 @@ def test_packed_not_eligible_models_fall_back(tc):
 
 
 def test_packed_wide_rows(tc):
-    """Values outside a row's fields (21 bits in a unigram row, 22 in a bigram row, i16 below: a large weight, or an
+    """Values outside a row's fields (18 bits in a unigram node, 19 in a bigram node, i16 below: a large weight, or an
     n-gram and a word with the same string summing past the field) keep the model on the packed path through the
-    kPkWide escape; values that only the wider unigram / bigram fields hold are scored in place."""
+    wide-row escape; values that only the wider unigram / bigram fields hold are scored in place."""
     m = ModelData(bias=-7, char_window_size=3, type_window_size=3)
     m.char_ngram_model.append(NgramData("あ", [0, 0, 40000, -5, 1, 2]))
     m.char_ngram_model.append(NgramData("あい", [1, 2, 30000, 4, 5]))
@@ -145,10 +160,10 @@ def test_packed_wide_rows(tc):
     m.char_ngram_model.append(NgramData("いうえ", [32767, 32767, 3, 4]))
     m.dict_model.append(WordWeightRecord("いうえ", [1, 32767, 5, 32767], ""))
     m.dict_model.append(WordWeightRecord("いうえお", [1, 2, 3, 4, 5], ""))
-    m.char_ngram_model.append(NgramData("う", [-1048577, 0, 1048576, -5, 1, 2]))          # just outside 21 bits
-    m.char_ngram_model.append(NgramData("え", [-1048576, 1048575, 0, -5, 1, 2]))          # just inside
-    m.char_ngram_model.append(NgramData("いう", [5, 2097152, -2097153, 1, 2]))            # just outside 22 bits
-    m.char_ngram_model.append(NgramData("うえ", [2097151, -2097152, 2097151, -1, -2097152]))  # just inside
+    m.char_ngram_model.append(NgramData("う", [-131073, 0, 131072, -5, 1, 2]))            # just outside 18 bits
+    m.char_ngram_model.append(NgramData("え", [-131072, 131071, 0, -5, 1, 2]))            # just inside
+    m.char_ngram_model.append(NgramData("いう", [5, 262144, -262145, 1, 2]))              # just outside 19 bits
+    m.char_ngram_model.append(NgramData("うえ", [262143, -262144, 262143, -1, -262144]))  # just inside
     m.dict_model.append(WordWeightRecord("あいうえおか", [100000, -100000, 3, 4, 5, 6, 2000000000], ""))
     m.dict_model.append(WordWeightRecord("あいうえおかきくけこ", [1, 2, 3, 4, 5, 6, 7, 8, 9, 10, -70000], ""))
     raw = encode_model(m)
@@ -268,7 +283,7 @@ def test_packed_walk_on_scaled_synthetic_models(tc, kind):
     w = Walker(tc, raw)
     assert w.packed and w.trow
     st = w.stats()
-    assert st["n_disp"] == 0 and st["n_left"] > 0 and st["n_deep"] > 0
+    assert st["n_bi"] > 0 and st["n_tri"] > 0 and st["n_deep"] > 0
     utf8, boff = synth.synth_sentences(raw, 400, 8, 96, seed=synth.SEED_BASE + 11 * kind)
     orc = cbind.OraclePredictor(raw)
     text = bytes(utf8)

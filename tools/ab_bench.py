@@ -19,7 +19,7 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
-KNOBS = ("VPT_DEBUG_LDS_PAD", "VPT_DEBUG_ABLATE", "VPT_SEPARATE_ASSIGN", "VPT_FORCE_WINDOW_TABLE", "VPT_FORCE_GENERIC")
+KNOBS = ("VPT_DEBUG_LDS_PAD", "VPT_DEBUG_ABLATE", "VPT_SEPARATE_ASSIGN", "VPT_INLINE_ASSIGN", "VPT_FORCE_WINDOW_TABLE", "VPT_FORCE_GENERIC")
 
 
 def lib_path(name):
@@ -30,7 +30,7 @@ def lib_path(name):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--variants", default="new,new:VPT_SEPARATE_ASSIGN=1")
+    ap.add_argument("--variants", default="new,new:VPT_INLINE_ASSIGN=1")
     ap.add_argument("--ablate", default="")
     ap.add_argument("--model-kind", type=int, default=1)
     ap.add_argument("--model-scale", type=float, default=1.0)

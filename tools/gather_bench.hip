@@ -88,6 +88,45 @@ __global__ __launch_bounds__(256) void gather_mix(const uint4* __restrict__ tab,
     if (acc == 0x12345678u) out[0] = acc;
 }
 
+
+// ---- whole-position access mixes (round 2): what ONE start position asks of the memory system, all lanes busy, no ALU work.
+//   v1: today's kernel -- a seed byte (512 KB array, random), a 16-byte unigram row (1 MB table, 4 K rows in use, 256 B apart),
+//       the pair-issued 128-byte record (256 MB, 77 % of the accesses to a 2 MB hot set)
+//   v2: a double-array trie walk -- a 16-byte unigram node (64 KB, dense), a 32-byte bigram node (64 MB of nodes, hot set 16 K nodes),
+//       a 16-byte trigram node for `tri_per_1024` of the lanes (32 MB of nodes, hot set 32 K nodes)
+__device__ __forceinline__ uint32_t zipfish(uint32_t r, uint32_t n_mask, uint32_t hot_mask) {
+    const uint32_t pick = mix(r ^ 0x5bd1e995u);
+    return ((pick & 1023u) < 788u) ? (r & hot_mask) : (r & n_mask);
+}
+__global__ __launch_bounds__(256) void mix_v1(const uint4* __restrict__ rec, const uint4* __restrict__ uni, const uint8_t* __restrict__ seed, int iters, uint32_t* out) {
+    const uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x;
+    const bool odd = tid & 1u;
+    uint32_t acc = 0;
+    for (int i = 0; i < iters; ++i) {
+        const uint32_t r = mix(tid * 0x9E3779B1u + uint32_t(i) * 0x85EBCA77u), rp = mix((tid ^ 1u) * 0x9E3779B1u + uint32_t(i) * 0x85EBCA77u);
+        const uint32_t mine = zipfish(r, (1u << 21) - 1, (1u << 14) - 1), partner = zipfish(rp, (1u << 21) - 1, (1u << 14) - 1);
+        const uint32_t sd = seed[mix(r + 1) & ((1u << 19) - 1)];
+        const uint4 u = uni[zipfish(mix(r + 2), 4095u, 255u) << 4];
+        const uint32_t ra = ((odd ? partner : mine) << 3) + (odd ? 4u : 0u), rb = ((odd ? mine : partner) << 3) + (odd ? 0u : 4u);
+        const uint4 a = rec[ra], b = rec[ra + 1], c = rec[ra + 2], d = rec[ra + 3], e = rec[rb], f = rec[rb + 1], g = rec[rb + 2], k = rec[rb + 3];
+        acc ^= a.x ^ b.y ^ c.z ^ d.w ^ e.x ^ f.y ^ g.z ^ k.w ^ u.x ^ sd;
+    }
+    if (acc == 0x12345678u) out[0] = acc;
+}
+__global__ __launch_bounds__(256) void mix_v2(const uint4* __restrict__ bi, const uint4* __restrict__ tri, const uint4* __restrict__ uni, uint32_t tri_per_1024, int iters, uint32_t* out) {
+    const uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x;
+    uint32_t acc = 0;
+    for (int i = 0; i < iters; ++i) {
+        const uint32_t r = mix(tid * 0x9E3779B1u + uint32_t(i) * 0x85EBCA77u);
+        const uint4 u = uni[zipfish(mix(r + 2), 4095u, 255u)];
+        const uint32_t nb = zipfish(r, (1u << 21) - 1, (1u << 14) - 1) << 1;
+        const uint4 b0 = bi[nb], b1 = bi[nb + 1];
+        acc ^= u.x ^ b0.y ^ b1.z;
+        if ((mix(r + 3) & 1023u) < tri_per_1024) { const uint4 t = tri[zipfish(mix(r + 4), (1u << 21) - 1, (1u << 15) - 1)]; acc ^= t.w; }
+    }
+    if (acc == 0x12345678u) out[0] = acc;
+}
+
 template <int MODE>
 double run_mix(const uint4* tab, uint32_t nrec_mask, uint32_t hot_mask, int blocks, int iters, uint32_t* out) {
     hipEvent_t a, b; CHECK(hipEventCreate(&a)); CHECK(hipEventCreate(&b));
@@ -144,6 +183,25 @@ int main() {
             printf("pair-issued 128 B, hot share %u/1024: %.1f G records/s\n", hot, positions / t / 1e6);
         }
         CHECK(hipFree(tab));
+    }
+    {   // whole-position mixes
+        uint4 *rec, *uni, *bi, *tri; uint8_t* seed;
+        CHECK(hipMalloc(&rec, (size_t(256) << 20) + 256)); CHECK(hipMemset(rec, 1, (size_t(256) << 20) + 256));
+        CHECK(hipMalloc(&uni, (size_t(1) << 20) + 256)); CHECK(hipMemset(uni, 1, (size_t(1) << 20) + 256));
+        CHECK(hipMalloc(&seed, (size_t(1) << 19) + 256)); CHECK(hipMemset(seed, 1, (size_t(1) << 19) + 256));
+        CHECK(hipMalloc(&bi, (size_t(64) << 20) + 256)); CHECK(hipMemset(bi, 1, (size_t(64) << 20) + 256));
+        CHECK(hipMalloc(&tri, (size_t(32) << 20) + 256)); CHECK(hipMemset(tri, 1, (size_t(32) << 20) + 256));
+        auto time5 = [&](auto launch) {
+            hipEvent_t a, b; CHECK(hipEventCreate(&a)); CHECK(hipEventCreate(&b));
+            launch(); CHECK(hipDeviceSynchronize());
+            CHECK(hipEventRecord(a)); for (int r = 0; r < 5; ++r) launch(); CHECK(hipEventRecord(b)); CHECK(hipEventSynchronize(b));
+            float ms = 0; CHECK(hipEventElapsedTime(&ms, a, b)); return double(ms) / 5.0; };
+        const double t1 = time5([&] { hipLaunchKernelGGL(mix_v1, dim3(blocks), dim3(256), 0, 0, rec, uni, seed, iters, out); });
+        printf("position mix v1 (seed + unigram row + pair-issued 128-B record): %.1f G positions/s\n", positions / t1 / 1e6);
+        for (uint32_t tp : {0u, 300u, 560u, 1024u}) {
+            const double t2 = time5([&] { hipLaunchKernelGGL(mix_v2, dim3(blocks), dim3(256), 0, 0, bi, tri, uni, tp, iters, out); });
+            printf("position mix v2 (16-B unigram node + 32-B bigram node + 16-B trigram node for %u/1024 of the lanes): %.1f G positions/s\n", tp, positions / t2 / 1e6);
+        }
     }
     return 0;
 }

@@ -34,7 +34,7 @@ vpt_status fail(vpt_status st, const std::string& msg) {
 
 struct DevicePacked {
     unsigned char* base = nullptr;
-    uint32_t off[7] = {0, 0, 0, 0, 0, 0, 0};   // uni, rec, kids3, deep, xrows, seed, trow
+    uint32_t off[7] = {0, 0, 0, 0, 0, 0, 0};   // uni, bi, tri, deep, xrows, trow, cpid
     void release() { (void)hipFree(base); base = nullptr; }
 };
 
@@ -81,19 +81,18 @@ vpt::PackedView make_packed_view(const vpt::HostPackedTable& h, const DevicePack
     v.present = h.present ? 1u : 0u;
     if (!h.present) return v;
     v.base = d.base;
-    v.off_uni = d.off[0]; v.off_rec = d.off[1]; v.off_kids3 = d.off[2]; v.off_deep = d.off[3];
-    v.off_xrows = d.off[4]; v.off_seed = d.off[5]; v.off_trow = d.off[6];
-    v.seed_shift = 32 - h.seed_bits;
-    v.rec_shift = 32 - h.rec_bits; v.rec_mask = (1u << h.rec_bits) - 1;
+    v.off_uni = d.off[0]; v.off_bi = d.off[1]; v.off_tri = d.off[2]; v.off_deep = d.off[3];
+    v.off_xrows = d.off[4]; v.off_trow = d.off[5]; v.off_cpid = d.off[6];
+    v.n_uni = uint32_t(h.uni.size() / 4); v.n_tri = uint32_t(h.tri.size() / 4); v.bi_shift = h.bi_shift;
     v.has_trow = h.trow.empty() ? 0u : 1u;
     return v;
 }
 
 // all packed arrays in one allocation (PackedView); false if they do not fit 32-bit offsets
 hipError_t upload_packed(const vpt::HostPackedTable& h, DevicePacked* d, bool* fits) {
-    const void* src[7] = {h.uni.data(), h.rec.data(), h.kids3.data(), h.deep.data(), h.xrows.data(), h.seed.data(), h.trow.data()};
-    const size_t bytes[7] = {4 * h.uni.size(), 4 * h.rec.size(), 4 * h.kids3.size(), 4 * h.deep.size(), 4 * h.xrows.size(),
-                             h.seed.size(), 4 * h.trow.size()};
+    const void* src[7] = {h.uni.data(), h.bi.data(), h.tri.data(), h.deep.data(), h.xrows.data(), h.trow.data(), h.cpid.data()};
+    const size_t bytes[7] = {4 * h.uni.size(), 4 * h.bi.size(), 4 * h.tri.size(), 4 * h.deep.size(), 4 * h.xrows.size(),
+                             4 * h.trow.size(), 4 * h.cpid.size()};
     size_t total = 0;
     size_t off[7];
     for (int i = 0; i < 7; ++i) { off[i] = total; total += (bytes[i] + kTablePadBytes + 255) & ~size_t(255); }
@@ -120,9 +119,9 @@ void fill_info(const vpt::CompiledModel& c, vpt_model_info* info) {
     info->n_short_entries = c.chars.n_short; info->n_long_nodes = c.chars.n_long_nodes;
     info->type_kind = uint32_t(c.type_kind);
     info->packed = c.packed.present ? 1u : 0u;
-    info->n_displaced = c.packed.present ? c.packed.n_disp : c.chars.n_displaced_short;
+    info->n_displaced = c.packed.present ? 0u : c.chars.n_displaced_short;
     info->type_rows = c.packed.present && !c.packed.trow.empty() ? 1u : 0u;
-    info->n_overflow_children = c.packed.present ? c.packed.n_overflow : 0u;
+    info->n_overflow_children = 0u;
     // the specialised kernel reads only the packed tables; the general ones stay resident for oversized sentences
     info->device_table_bytes = (c.chars.present ? c.chars.bytes() : 0) + (c.types.present ? c.types.bytes() : 0) +
                                4ull * c.type_table.size() + (c.packed.present ? c.packed.bytes() : 0);
@@ -190,6 +189,7 @@ struct vpt_predictor {
     int32_t* d_type_table = nullptr;
     uint8_t* d_ctype = nullptr;
     uint32_t* d_cinfo = nullptr;       // [0, 65536): plain; [65536, 131072): through KyteaFullwidthFilter
+    uint32_t* d_cid = nullptr;         // the same two tables for the specialised kernel: id | type << 16 | linebreak << 19
     vpt::PatternTableView ct{}, tt{};
     mutable std::mutex pool_mu;
     mutable std::vector<vpt_batch*> pool;  // idle workspaces for the host-buffer entry points
@@ -407,6 +407,16 @@ vpt_status vpt_predictor_create(const uint8_t* model_bytes, size_t len, int pred
             cinfo[65536 + cp] = fw | (uint32_t(vpt::char_type_host(fw)) << 16);
         }
         e = upload(cinfo, &p->d_cinfo);
+        if (e == hipSuccess && c.packed.present) {
+            std::vector<uint32_t> cid(2 * 65536);
+            for (uint32_t cp = 0; cp < 65536; ++cp)
+                for (int mode = 0; mode < 2; ++mode) {
+                    const uint32_t scored = mode ? vpt::kytea_fullwidth_host(cp) : cp;   // 1:1 on the BMP
+                    cid[size_t(mode) * 65536 + cp] = uint32_t(c.packed.id_of[scored]) | (uint32_t(vpt::char_type_host(scored)) << 16) |
+                                                     ((scored == 0x0Au || scored == 0x0Du) ? vpt::kCinfoLinebreak : 0u);
+                }
+            e = upload(cid, &p->d_cid);
+        }
         std::vector<uint8_t> ctype(65536);
         for (uint32_t cp = 0; cp < 65536; ++cp) ctype[cp] = vpt::char_type_host(cp);
         if (e == hipSuccess) e = upload(ctype, &p->d_ctype);
@@ -428,7 +438,7 @@ vpt_status vpt_predictor_create(const uint8_t* model_bytes, size_t len, int pred
         hipDeviceProp_t prop;
         if (hipGetDeviceProperties(&prop, device_id) == hipSuccess && prop.multiProcessorCount > 0) {
             vpt::ScoreParams probe{};
-            probe.ct = p->ct; probe.pk = p->pk; probe.pad = p->pad; probe.ctype = p->d_ctype; probe.type_kind = p->type_kind;
+            probe.ct = p->ct; probe.pk = p->pk; probe.pad = p->pad; probe.ctype = p->d_ctype; probe.cid = p->d_cid; probe.type_kind = p->type_kind;
             probe.type_window = p->type_window;
             const bool fast = vpt::fast_path_supported(probe);
             size_t lds = fast ? vpt::score_tiles_fast_lds_bytes(probe) : vpt::score_tiles_lds_bytes();
@@ -449,7 +459,7 @@ void vpt_predictor_destroy(vpt_predictor* p) {
     for (vpt_batch* b : p->pool) batch_release(b);
     p->dc.release(); p->dt.release(); p->dp.release(); p->dtag.release();
     (void)hipFree(p->d_type_table);
-    (void)hipFree(p->d_cinfo); (void)hipFree(p->d_ctype);
+    (void)hipFree(p->d_cinfo); (void)hipFree(p->d_ctype); (void)hipFree(p->d_cid);
     delete p;
 }
 
@@ -570,6 +580,7 @@ vpt_status vpt_predict_batch_device(const vpt_predictor* p, vpt_batch* b, const 
     P.ct = p->ct; P.tt = p->tt; P.pk = p->pk; P.type_table = p->d_type_table;
     P.ctype = p->d_ctype;
     P.cinfo = (b->flags & VPT_FLAG_KYTEA_FULLWIDTH) ? p->d_cinfo + 65536 : nullptr;
+    P.cid = p->d_cid ? p->d_cid + ((b->flags & VPT_FLAG_KYTEA_FULLWIDTH) ? 65536 : 0) : nullptr;
     P.post = b->flags & 0xFEu;
     P.type_window = p->type_window; P.type_kind = p->type_kind; P.bias = p->bias; P.pad = p->pad;
     // Tiles are cut every `tile_flat` flat positions (chars + separators) and end with the sentence that crosses
@@ -624,7 +635,10 @@ vpt_status vpt_predict_batch_device(const vpt_predictor* p, vpt_batch* b, const 
     if (const char* dbg = std::getenv("VPT_DEBUG_ABLATE")) { P.debug = uint32_t(std::atoi(dbg)); P.ct.debug = P.debug; P.tt.debug = P.debug; }
 
     P.n_sent = n_sentences; P.tile_flat = uint32_t(tile_flat); P.n_tiles = n_tiles;
-    const bool inline_assign = fast && !need_slow && !std::getenv("VPT_SEPARATE_ASSIGN");   // the status word is cleared by vpt_batch_sync
+    // The specialised kernel can find its tiles itself (one launch per step).  Measured on MI355X (profiles/r02_c1_ab.jsonl):
+    // the search at the head of every workgroup costs the scoring kernel more (+4 us) than the separate 5 us kernel and its
+    // launch gap cost the step, so the separate kernel stays the default.
+    const bool inline_assign = fast && !need_slow && std::getenv("VPT_INLINE_ASSIGN");
     if (inline_assign) P.tile_first = nullptr;
     else VPT_HIP(vpt::launch_assign_tiles(d_out_offsets, n_sentences, p->pad, uint32_t(tile_flat), n_tiles, b->d_tile_first, b->d_ctrl, stream));
     const size_t slot = b->ev_calls % kTimingRing;

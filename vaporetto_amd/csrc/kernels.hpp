@@ -29,11 +29,13 @@ constexpr uint32_t kErrOutputTooSmall = 32u;  // token emission: text_capacity i
 struct ScoreParams {
     PatternTableView ct;        // characters: n-grams + dictionary words
     PatternTableView tt;        // character types, when type_kind == kTypePatternTable
-    PackedView pk;              // characters again, 16-byte-entry layout of the specialised kernel (if eligible)
+    PackedView pk;              // characters again, as the double-array trie of the specialised kernel (if eligible)
     const int32_t* type_table;  // 8^(2W) window scores, when type_kind == kTypeWindowTable
     const uint8_t* ctype;       // CharacterType of every BMP scalar value (65536 bytes)
     const uint32_t* cinfo;      // only with VPT_FLAG_KYTEA_FULLWIDTH, else nullptr: per BMP scalar value the char it is
                                 // scored as (KyteaFullwidthFilter's image) | CharacterType of that char << 16
+    const uint32_t* cid;        // specialised kernel: per BMP scalar value id | CharacterType << 16 | linebreak << 19 of the char it is
+                                // scored as (layout.h, "ids"; the plain table or the one through KyteaFullwidthFilter)
     int32_t type_window;
     int32_t type_kind;
     int32_t bias;

@@ -1,25 +1,25 @@
 // Specialised tile kernel for the model geometry every distributed Vaporetto / KyTea model has: char window 3,
 // BMP patterns (layout.h, "PACKED TABLES"), type scores from type rows in LDS, the 8^(2W) window table (W <= 3) or
 // none.  Same all-matches algorithm as kernels.hip (which stays the general path); what changes is how the work is
-// laid out for a CDNA4 CU, whose limiters on this workload are the number of random memory lines in flight
-// (profiles/r01_c_*: the vector L1's miss queue) and, once those are few, instruction issue (profiles/r01_d_*):
+// laid out for a CDNA4 CU, whose limiter on this workload is the vector L1's address pipeline: every 16-byte load of
+// a lane costs a slot of it and every distinct line it touches two more (profiles/r02_*), while VALU work is two
+// orders of magnitude cheaper per lane.  So a start position issues as few loads as the data structure allows:
 //
-//   * one 128-byte RECORD per (c1,c2) prefix holds the bigram row, three right children (c1,c2,c3) and three left
-//     children (c0,c1,c2), and its slot comes from a perfect hash (one cache-hot seed byte), so a start position
-//     costs ONE random line.  A lane PAIR fetches the two 64-byte halves of a record in the same instruction (first
-//     the even lane's record, then the odd lane's), which the memory pipeline rewards (tools/gather_bench.hip), and
-//     hands the partner's half over through DPP, so that every lane ends up with its own whole record;
-//   * the unigram row (16 bytes, cache-hot; 21-bit fields), the type row (LDS; 18-bit fields), the bigram row
-//     (22-bit fields) and the matching right and left children are summed in registers and land in the LDS score
-//     array with six ds_add_u32 (integer => order-free => bit-exact);
-//   * everything data-dependent is NOT done in place (64 lanes would wait for the unluckiest one): it is pushed,
-//     ballot/mbcnt-compacted, onto wave-private LDS stacks -- one per kind, so that a replay runs one short code
-//     path with every lane busy: W trie steps of dictionary words longer than 3 chars (a step that matches
-//     re-queues its continuation), O overflow-child probes (prefixes whose children fit neither side), M the rare
-//     rest (a record displaced from its home slot, rows with a value outside their fields);
+//   * the patterns form a DOUBLE-ARRAY trie over their first three symbols: one 16-byte unigram node (indexed by the
+//     char's id), one 32-byte bigram node at (unigram base + id of the next char), and -- only when the bigram's 64-bit
+//     filter admits the third char -- one 16-byte trigram node at (bigram base + its id): 4 loads to 3 lines, no hash,
+//     no seed table, no probing; a node names its parent, so a lookup that lands on a foreign node knows it;
+//   * the three loads depend on each other, so they are software-pipelined: a trip of the main loop loads the
+//     unigram nodes of the positions two trips ahead, the bigram nodes of the next trip's positions and the trigram
+//     nodes of its own -- all independent of each other -- and waits once;
+//   * rows are added to the LDS score array where they arrive (ds_add_u32: integer => order-free => bit-exact);
+//   * what is data-dependent beyond depth 3 is NOT done in place (64 lanes would wait for the unluckiest one): it is
+//     pushed, ballot/mbcnt-compacted, onto wave-private LDS stacks, so that a replay runs one short code path with
+//     every lane busy: W trie steps of dictionary words longer than 3 chars (a step that matches re-queues its
+//     continuation), M the rare rows with a value outside their fields (taken from the general tables);
 //   * UTF-8 decode: the text is staged in LDS, a chunk scan numbers chars and sentences, the thread that scanned a
-//     chunk decodes its chars (branch-free) straight into their flat positions, a second pass classifies them;
-//   * 26 KB of LDS and at most 80 VGPRs per workgroup: 6 workgroups per CU.
+//     chunk decodes its chars (branch-free) straight into their flat positions, a second pass maps them to ids;
+//   * 24 KB of LDS and at most 80 VGPRs per workgroup: 6 workgroups per CU.
 #include <hip/hip_runtime.h>
 
 #include <cstddef>
@@ -31,10 +31,11 @@
 namespace vpt {
 namespace {
 
-constexpr int kQCap = 224;                   // W + O items per wave (W grows from the bottom, O from the top)
-constexpr uint32_t kQHigh = kQCap - 128;     // replay until one more round of pushes (<= 64 + 64) fits
+constexpr int kQCap = 160;                   // W items per wave
+constexpr uint32_t kQHigh = kQCap - 64;      // replay until one more round of pushes (<= 64) fits
 constexpr int kMCap = 64;                    // M items per wave (a handful per tile: only rows outside their fields)
-constexpr uint32_t kCpMask = 0xFFFFu;        // sym = char (>= 0xFFFF -> 0xFFFF) | type << 16 | tile-local sentence << 19
+constexpr uint32_t kCpMask = 0xFFFFu;        // sym = id (kNoId: in no pattern) | type << 16 | tile-local sentence << 19 | linebreak << 29
+constexpr uint32_t kSymLinebreak = 1u << 29;
 constexpr int kPerThread = kFastCap / kThreads;
 constexpr int kWavesF = kThreads / 64;
 constexpr int kTypeRows = 4;                 // TM value: type rows in LDS (1..3 = window table of that W, 0 = none)
@@ -53,6 +54,7 @@ struct FastLds {
     };
 };
 static_assert(offsetof(FastLds, typ) % 16 == 0 && (kFastCap + kMargin) * 4 % 16 == 0, "carve offsets stay 16-byte aligned");
+static_assert(sizeof(uint2) * kWavesF * kQCap >= size_t(kFastCap) * 4 / 8 + 16, "the sentence-start bitmap of the decode phase lives in the W queues");
 // gfx950 hands out LDS in granules of 1280 bytes: six workgroups per CU get 21 of the 128 each
 static_assert(offsetof(FastLds, typ) + sizeof(uint4) * kTrowCount <= 21 * 1280, "6 workgroups per CU");
 
@@ -60,9 +62,6 @@ __device__ __forceinline__ uint32_t lane_rank(uint64_t mask) {  // set bits of `
     return __builtin_amdgcn_mbcnt_hi(uint32_t(mask >> 32), __builtin_amdgcn_mbcnt_lo(uint32_t(mask), 0u));
 }
 
-__device__ __forceinline__ uint32_t pair_swap(uint32_t x) {  // value of lane ^ 1 (DPP quad_perm [1,0,3,2])
-    return uint32_t(__builtin_amdgcn_mov_dpp(int(x), 0xB1, 0xF, 0xF, true));   // every lane is written: no `old`
-}
 // inclusive prefix sum over the 64 lanes of a wave: DPP row shifts, then the two row broadcasts (no LDS round trips)
 __device__ __forceinline__ uint32_t wave_inclusive_scan(uint32_t x) {
     x += uint32_t(__builtin_amdgcn_update_dpp(0, int(x), 0x111, 0xF, 0xF, false));  // row_shr:1
@@ -92,24 +91,17 @@ __device__ __forceinline__ uint32_t utf8_scalar_bf(uint32_t b4) {
 
 // Wave-private stacks of deferred work (wave-uniform counts):
 //   W  x = s | depth << 11   y = mini-table ref (in `deep`) of the children to search      trie step
-//   O  x = s                 y = overflow mini-table ref (in `kids3`)                       overflow-child probe
-//   M  x = s | kinds << 11   y = home slot | remaining hop bits << 24 (kRecMore), next slot (kRecFar)   the rare rest
-constexpr uint32_t kRecMore = 1u, kRecFar = 2u, kWideUni = 4u, kWideBi = 8u, kWideTri = 16u, kWideLeft = 32u;
+//   M  x = s | kinds << 11                                                                 a row outside its fields
+constexpr uint32_t kWideUni = 4u, kWideBi = 8u, kWideTri = 16u;
 struct WaveStacks {
     uint2* q;
     uint2* mq;
-    uint32_t nw, no, nm;
+    uint32_t nw, nm;
     __device__ __forceinline__ void push_w(bool pred, uint32_t x, uint32_t y) {
         const uint64_t m = __ballot(pred);
         if (m == 0) return;
         if (pred) q[nw + lane_rank(m)] = make_uint2(x, y);
         nw = wave_uniform(nw + uint32_t(__popcll(m)));
-    }
-    __device__ __forceinline__ void push_o(bool pred, uint32_t x, uint32_t y) {
-        const uint64_t m = __ballot(pred);
-        if (m == 0) return;
-        if (pred) q[kQCap - 1 - (no + lane_rank(m))] = make_uint2(x, y);
-        no = wave_uniform(no + uint32_t(__popcll(m)));
     }
     __device__ __forceinline__ void push_m(bool pred, uint32_t x, uint32_t y) {
         const uint64_t m = __ballot(pred);
@@ -232,95 +224,13 @@ __device__ __forceinline__ bool general_row(const PatternTableView& T, uint64_t 
     }
 }
 
-// O: up to 64 queued overflow-child probes: c3 = sym[s + 2] in the mini-table `ref` of `kids3` (two entries at once,
-// as in replay_w).
-__device__ __forceinline__ void replay_o(const PackedView& K, const PatternTableView& T, FastLds& L, WaveStacks& Q, int lane) {
-    VPT_WAVE_LOCKSTEP();   // the queue entries were written by other lanes
-    const uint32_t take = wave_uniform(Q.no < 64u ? Q.no : 64u);
-    Q.no = wave_uniform(Q.no - take);
-    const bool have = uint32_t(lane) < take;
-    const uint2 it = have ? Q.q[kQCap - 1 - (Q.no + lane)] : make_uint2(0u, 0u);
-    const uint32_t s = it.x;
-    const uint32_t c3 = have ? (L.sym[s + 2] & kCpMask) : 0u;
-    const uint32_t tab = K.off_kids3 + ((it.y >> 5) << 4);   // byte offset of the mini-table (16-byte entries)
-    const uint32_t last = (1u << (it.y & 31u)) - 1u;
-    const uint32_t i0 = packed_mini_slot(c3, it.y), i1 = (i0 + 1) & last;
-    const uint4 ea = ld16(K.base, tab + (i0 << 4)), eb = ld16(K.base, tab + (i1 << 4));
-    const bool ma = have && (ea.x & 0xFFFFu) == c3;
-    const bool mb = have && !ma && ea.x != 0 && (eb.x & 0xFFFFu) == c3;
-    bool found = ma || mb;
-    uint4 ch = ma ? ea : eb;
-    bool open = have && !found && ea.x != 0 && eb.x != 0 && last > 1u;
-    if (__ballot(open) != 0) {  // rare
-        uint32_t i = (i1 + 1) & last, n = 2;
-        while (__ballot(open) != 0) {
-            if (open) {
-                ch = ld16(K.base, tab + (i << 4));
-                found = (ch.x & 0xFFFFu) == c3;
-                open = !found && ch.x != 0 && n < last;
-                i = (i + 1) & last;
-                ++n;
-            }
-        }
-    }
-    const bool wide = found && (ch.x & (kPkWide << 16));
-    if (found && !wide) add_child(L.score, s, ch.y, ch.z);
-    if (__ballot(wide) != 0) {  // a value outside i16 (rare): the row comes from the general tables
-        uint4 r0, r1;
-        if (wide && general_row(T, short_key(L.sym[s] & kCpMask, L.sym[s + 1] & kCpMask, c3), r0, r1))
-            add_row6(L.score, s, 0, 0, int32_t(r0.z), int32_t(r0.w), int32_t(r1.x), int32_t(r1.y));
-    }
-    Q.push_w(found && ch.w != 0, s | (3u << 11), ch.w);
-}
-
-// What a record contributes to the start position that fetched it (the main loop and the M replay share this).
-struct RecMatch {
-    int32_t b1, b2, b3, b4, b5;   // bigram row + matching right child + matching left child, boundaries s-2 .. s+2
-    uint32_t ly, lz;              // row of the matching left child (the string starting at s-1: boundaries s-2 .. s+1), or 0
-    uint32_t rk, lk;              // trie continuations (mini-table refs in `deep`) of the right / left child, or 0
-    bool ovp;                     // the overflow mini-table `ov_ref` may hold (c1,c2,c3)
-    uint32_t ov_ref;
-    uint32_t wide;                // kWideBi | kWideTri | kWideLeft
-};
-__device__ __forceinline__ RecMatch match_record(bool keyok, uint32_t c0, uint32_t c3, const uint4& h0, const uint4& r1, const uint4& r2,
-                                                 const uint4& r3, const uint4& h1, const uint4& l1, const uint4& l2, const uint4& l3) {
-    RecMatch o;
-    // right children: (c1,c2,c3) starts here
-    const bool kr = keyok && c3 != 0;
-    const bool mr1 = kr && (r1.x & 0xFFFFu) == c3, mr2 = kr && (r2.x & 0xFFFFu) == c3, mr3 = kr && (r3.x & 0xFFFFu) == c3;
-    const bool hit_r = mr1 || mr2 || mr3;
-    const uint32_t rx = mr1 ? r1.x : mr2 ? r2.x : mr3 ? r3.x : 0u;
-    const uint32_t ry = mr1 ? r1.y : mr2 ? r2.y : mr3 ? r3.y : 0u;
-    const uint32_t rz = mr1 ? r1.z : mr2 ? r2.z : mr3 ? r3.z : 0u;
-    o.rk = mr1 ? r1.w : mr2 ? r2.w : mr3 ? r3.w : 0u;
-    // left children: (c0,c1,c2) started one position earlier
-    const bool kl = keyok && c0 != 0;
-    const bool ml1 = kl && (l1.x & 0xFFFFu) == c0, ml2 = kl && (l2.x & 0xFFFFu) == c0, ml3 = kl && (l3.x & 0xFFFFu) == c0;
-    const uint32_t lx = ml1 ? l1.x : ml2 ? l2.x : ml3 ? l3.x : 0u;
-    o.ly = ml1 ? l1.y : ml2 ? l2.y : ml3 ? l3.y : 0u;   // zero without a hit (and in a kPkWide slot)
-    o.lz = ml1 ? l1.z : ml2 ? l2.z : ml3 ? l3.z : 0u;
-    o.lk = ml1 ? l1.w : ml2 ? l2.w : ml3 ? l3.w : 0u;
-    // bigram row (five 22-bit fields at bits 0, 22, 44, 66, 88 of H0; layout.h) + right child + left child; a kPkWide
-    // slot holds zero weights
-    const uint32_t bx = keyok ? h0.x : 0u, by = keyok ? h0.y : 0u, bz = keyok ? h0.z : 0u, bw = keyok ? h0.w : 0u;
-    o.b1 = sext(bx, kBiFieldBits) + lo16(o.ly);
-    o.b2 = sext(__builtin_amdgcn_alignbit(by, bx, 22), kBiFieldBits) + lo16(ry) + hi16(o.ly);
-    o.b3 = sext(__builtin_amdgcn_alignbit(bz, by, 12), kBiFieldBits) + hi16(ry) + lo16(o.lz);
-    o.b4 = sext(bz >> 2, kBiFieldBits) + lo16(rz) + hi16(o.lz);
-    o.b5 = sext(__builtin_amdgcn_alignbit(bw, bz, 24), kBiFieldBits) + hi16(rz);
-    o.ovp = false;
-    if (kr && !hit_r && (bw & (kPkOv << 16))) {
-        const uint32_t bit = packed_filter_bit(c3);
-        o.ovp = ((bit < 32 ? h1.z >> bit : h1.w >> (bit - 32)) & 1u) != 0;
-    }
-    o.ov_ref = h1.y;
-    o.wide = ((bw & (kPkWide << 16)) ? kWideBi : 0u) | ((rx & (kPkWide << 16)) ? kWideTri : 0u) | ((lx & (kPkWide << 16)) ? kWideLeft : 0u);
-    return o;
-}
-
-// rows with a value outside i16 (rare): the general tables hold them as i32
-__device__ __forceinline__ void add_wide_rows(const PatternTableView& T, FastLds& L, uint32_t kinds, uint32_t s, uint32_t c0, uint32_t c1,
-                                              uint32_t c2, uint32_t c3) {
+// rows with a value outside their fields (rare): the general tables hold them as i32, keyed by code points
+__device__ __forceinline__ void add_wide_rows(const PackedView& K, const PatternTableView& T, FastLds& L, uint32_t kinds, uint32_t s) {
+    const uint32_t* cpid = reinterpret_cast<const uint32_t*>(K.base + K.off_cpid);
+    // a wide row belongs to a pattern that matched here: its chars are in the alphabet (ids below n_uni)
+    const uint32_t last = K.n_uni - 1u;
+    const uint32_t i1 = L.sym[s] & kCpMask, i2 = L.sym[s + 1] & kCpMask, i3 = L.sym[s + 2] & kCpMask;
+    const uint32_t c1 = cpid[i1 < last ? i1 : last], c2 = cpid[i2 < last ? i2 : last], c3 = cpid[i3 < last ? i3 : last];
     uint4 r0, r1;
     if (kinds & kWideUni) {
         const uint4* u = reinterpret_cast<const uint4*>(T.uni) + size_t(c1) * 2;
@@ -331,68 +241,22 @@ __device__ __forceinline__ void add_wide_rows(const PatternTableView& T, FastLds
         add_row6(L.score, s, 0, int32_t(r0.z), int32_t(r0.w), int32_t(r1.x), int32_t(r1.y), int32_t(r1.z));
     if ((kinds & kWideTri) && general_row(T, short_key(c1, c2, c3), r0, r1))
         add_row6(L.score, s, 0, 0, int32_t(r0.z), int32_t(r0.w), int32_t(r1.x), int32_t(r1.y));
-    if ((kinds & kWideLeft) && general_row(T, short_key(c0, c1, c2), r0, r1))
-        add_row6(L.score, s - 1, 0, 0, int32_t(r0.z), int32_t(r0.w), int32_t(r1.x), int32_t(r1.y));
 }
 
-__device__ __forceinline__ void drain_wo(const PackedView& K, const PatternTableView& T, FastLds& L, WaveStacks& Q, int lane, uint32_t mark);
-
-// M: up to 64 queued items of the rare kinds.
-//   kRecMore: the record of (c1,c2) was not in its home slot, whose hop bitmap names the records to look at
-//             (layout.h); the one visited in this pass is scored like in the main loop if it has the key, else the
-//             item is re-queued with the remaining bits.  kRecFar: walk on to the first empty record instead.
-//   kWide*:   a row with a value outside i16 -- taken from the general tables (i32).
+// M: up to 64 queued rows with a value outside their fields -- taken from the general tables (i32).
 __device__ __forceinline__ void replay_m(const PackedView& K, const PatternTableView& T, FastLds& L, WaveStacks& Q, int lane) {
     VPT_WAVE_LOCKSTEP();   // the queue entries were written by other lanes
     const uint32_t take = wave_uniform(Q.nm < 64u ? Q.nm : 64u);
     Q.nm -= take;
-    const bool have = uint32_t(lane) < take;
-    const uint2 it = have ? Q.mq[Q.nm + lane] : make_uint2(0u, 0u);
-    const uint32_t s = it.x & 0x7FFu;
-    uint32_t kinds = have ? (it.x >> 11) : 0u;
-    const uint32_t c0 = have ? (L.sym[s - 1] & kCpMask) : 0u;
-    const uint32_t c1 = L.sym[s] & kCpMask, c2 = L.sym[s + 1] & kCpMask, c3 = L.sym[s + 2] & kCpMask;
-    const bool more = (kinds & (kRecMore | kRecFar)) != 0;
-    if (__ballot(more) != 0) {   // only after the perfect hash fell back to probing: another record to look at
-        drain_wo(K, T, L, Q, lane, kQHigh);  // room for the pushes below
-        const uint32_t kb = c1 | (c2 << 16);
-        const bool far = (kinds & kRecFar) != 0;
-        const uint32_t hop = far ? 0u : it.y >> 24;                       // records still to visit, as distances from home
-        const uint32_t hop_next = hop & (hop - 1u);
-        const uint32_t slot = far ? it.y : ((it.y & 0xFFFFFFu) + (hop ? uint32_t(__ffs(int(hop))) : 0u)) & K.rec_mask;
-        const uint32_t r = K.off_rec + ((more ? slot : 0u) << 7);
-        const uint4 h0 = ld16(K.base, r), r1 = ld16(K.base, r + 16), r2 = ld16(K.base, r + 32), r3 = ld16(K.base, r + 48);
-        const uint4 h1 = ld16(K.base, r + 64), l1 = ld16(K.base, r + 80), l2 = ld16(K.base, r + 96), l3 = ld16(K.base, r + 112);
-        const bool keyok = more && h1.x == kb;
-        const bool again = more && !keyok && (far ? h1.x != 0 : hop_next != 0);
-        const RecMatch mt = match_record(keyok, c0, c3, h0, r1, r2, r3, h1, l1, l2, l3);
-        if (keyok) add_row6(L.score, s, 0, mt.b1, mt.b2, mt.b3, mt.b4, mt.b5);
-        kinds |= mt.wide;
-        Q.push_w(mt.rk != 0, s | (3u << 11), mt.rk);
-        Q.push_o(mt.ovp, s, mt.ov_ref);
-        Q.push_m(again, s | ((far ? kRecFar : kRecMore) << 11), far ? (slot + 1) & K.rec_mask : (it.y & 0xFFFFFFu) | (hop_next << 24));
-        if (__ballot(mt.lk != 0) != 0) {
-            drain_wo(K, T, L, Q, lane, kQHigh);
-            Q.push_w(mt.lk != 0, (s - 1) | (3u << 11), mt.lk);
-        }
-    }
-    kinds &= kWideUni | kWideBi | kWideTri | kWideLeft;
-    if (__ballot(kinds != 0) != 0) {
-        if (kinds != 0) add_wide_rows(T, L, kinds, s, c0, c1, c2, c3);
+    if (uint32_t(lane) < take) {
+        const uint2 it = Q.mq[Q.nm + lane];
+        add_wide_rows(K, T, L, it.x >> 11, it.x & 0x7FFu);
     }
 }
 
-// W/O replays until at most `mark` items are left.  A replay never grows W + O (an O item becomes at most one W
-// item, a W item at most one W item), so the loop ends.
-__device__ __forceinline__ void drain_wo(const PackedView& K, const PatternTableView& T, FastLds& L, WaveStacks& Q, int lane, uint32_t mark) {
-    while (Q.nw + Q.no > mark) {
-        if (Q.nw >= Q.no) replay_w(K, L, Q, lane);
-        else replay_o(K, T, L, Q, lane);
-    }
-}
-// Room for one more round of pushes (W <= 64, O <= 64); the M stack is checked where an M item turns up.
-__device__ __forceinline__ void make_room(const PackedView& K, const PatternTableView& T, FastLds& L, WaveStacks& Q, int lane) {
-    drain_wo(K, T, L, Q, lane, kQHigh);
+// W replays until at most `mark` items are left (a W item becomes at most one W item, so the loop ends).
+__device__ __forceinline__ void drain_w(const PackedView& K, FastLds& L, WaveStacks& Q, int lane, uint32_t mark) {
+    while (Q.nw > mark) replay_w(K, L, Q, lane);
 }
 
 // optional phase timing (VPT_PROFILE_PHASES): wave 0 of every workgroup adds the shader cycles it spent per phase
@@ -543,16 +407,16 @@ __global__ __launch_bounds__(kThreads, 6) void score_tiles_fast_kernel(const Sco
         for (int k = 0; k < kPerThread; ++k) {
             xs[k] = L.sym[uint32_t(tid) + uint32_t(k) * kThreads];   // zero past the tile
             const uint32_t cp = xs[k] & 0x1FFFFFu, idx = cp < 0x10000u ? cp : 0u;
-            // the char it is scored as | CharacterType << 16: itself and a byte of the 64 KB type table, or -- wave-uniform,
-            // with VPT_FLAG_KYTEA_FULLWIDTH -- a word of the table that also holds KyteaFullwidthFilter's image
-            info[k] = P.cinfo ? P.cinfo[idx] : (idx | (uint32_t(P.ctype[idx]) << 16));
+            // id of the char it is scored as | CharacterType << 16 | linebreak << 19: one word of a 256 KB table (plain, or --
+            // with VPT_FLAG_KYTEA_FULLWIDTH -- the one that looks through KyteaFullwidthFilter)
+            info[k] = P.cid[idx];
         }
 #pragma unroll
         for (int k = 0; k < kPerThread; ++k) {
             const uint32_t cp = xs[k] & 0x1FFFFFu;
-            uint32_t v = info[k] | ((xs[k] >> 21) << 19);
+            uint32_t v = (info[k] & 0x7FFFFu) | ((xs[k] >> 21) << 19) | ((info[k] & kCinfoLinebreak) ? kSymLinebreak : 0u);
             if (__ballot(cp >= 0x10000u) != 0) {   // rare: outside the BMP nothing is tabulated (and nothing can match)
-                if (cp >= 0x10000u) v = kPackedNoMatchSym | (char_type(cp) << 16) | ((xs[k] >> 21) << 19);
+                if (cp >= 0x10000u) v = kNoId | (char_type(cp) << 16) | ((xs[k] >> 21) << 19);
             }
             v = cp != 0 ? v : 0u;                  // a separator (or NUL, which has raised kErrNulChar)
             L.sym[uint32_t(tid) + uint32_t(k) * kThreads] = v;
@@ -563,97 +427,108 @@ __global__ __launch_bounds__(kThreads, 6) void score_tiles_fast_kernel(const Sco
 
     tmark = phase_mark(prof, 1, tmark);
     // ---------------------------------------------------------------- B. patterns
+    // One lane per start position, three trips in flight: trip j loads the TRIGRAM nodes of its own positions
+    // (tid + 256 j), the BIGRAM nodes of the next trip's and the UNIGRAM nodes of the positions two trips ahead -- loads
+    // that do not depend on each other -- waits once, adds the rows that arrived to the LDS score array and computes the
+    // addresses the next trip needs (child slot = base in the parent + id of the next char; layout.h).
     const PackedView& K = P.pk;
-    WaveStacks Q{&L.queue[wave][0], &L.mqueue[wave][0], 0u, 0u, 0u};
-    // The slot of a record needs the seed byte of its key's bucket: a dependent, cache-hot load.  It is issued one
-    // iteration ahead (together with the LDS reads of that iteration's symbols), behind the current record loads.
-    uint32_t nx0, nx1, nx2, nx3, nseed;
-    auto stage = [&](uint32_t sn) {
-        nx1 = L.sym[sn];                                   // the whole array is zero except for the tile's chars
-        nx0 = L.sym[(sn > 1u ? sn : 1u) - 1u];             // position 0 is a separator: its left neighbour is never used
-        nx2 = L.sym[sn + 1]; nx3 = L.sym[sn + 2];          // sn + 2 < kFastCap + kMargin
-        const uint32_t bkt = packed_ph_bucket((nx1 & kCpMask) | ((nx2 & kCpMask) << 16), K.seed_shift);
-        nseed = uint32_t(K.base[K.off_seed + ((P.debug & 64u) ? 0u : bkt)]);   // 64: timing ablation, the seed load pinned (results wrong); 256: none (the DBG build as is)
-    };
-    stage(uint32_t(tid));
-    const uint32_t off_rec = K.off_rec & ~255u;   // it IS 256-byte aligned (capi.cpp); now the compiler knows
-    for (int k = 0; k < kPerThread; ++k) {
+    WaveStacks Q{&L.queue[wave][0], &L.mqueue[wave][0], 0u, 0u};
+    const uint32_t uni_last = K.n_uni - 1u;
+    const uint32_t off_bi = K.off_bi & ~255u, off_tri = K.off_tri & ~255u;   // they ARE 256-byte aligned (capi.cpp); now the compiler knows
+    uint32_t b_slot = 0, b_key = 0, b_id3 = 0;   // next trip's bigram stage: node slot, its key (0: no bigram starts there), id of the third char
+    uint32_t t_slot = ~0u, t_par = 0;            // this trip's trigram stage: node slot (~0: none) and parent slot + 1
+    for (int j = -2; j < kPerThread; ++j) {
         if (P.debug & 16u) break;  // timing ablation: no pattern phase at all
-        const uint32_t s = uint32_t(tid) + uint32_t(k) * kThreads;
-        if (wbase + uint32_t(k) * kThreads >= flat_len) break;  // wave-uniform: this wave's 64 positions are past the tile
-        const uint32_t x1 = nx1, x2 = nx2, x3 = nx3;
-        const uint32_t c1 = x1 & kCpMask;
-        const bool live = c1 != 0;
-        const uint32_t c0 = nx0 & kCpMask;
-        const uint32_t c2 = x2 & kCpMask, c3 = x3 & kCpMask;
-        const bool has2 = live && c2 != 0;
-        const uint32_t kb = c1 | (c2 << 16);
-        uint32_t hrec = packed_ph_slot(kb, nseed, K.rec_shift);
-        if (P.debug & 1u) hrec = 0;  // timing ablation (VPT_DEBUG_ABLATE; results are wrong): pin the record
-        // every load first: the unigram row and the whole record of (c1,c2)
-        const uint4 u = ld16(K.base, K.off_uni + (((P.debug & 4u) ? 0u : c1) << 4));
-        const uint32_t p_hrec = pair_swap(hrec);
-        const bool odd = (lane & 1) != 0;
-        // a half record = 64 aligned bytes: the three further units are the same address with 16, 32, 48 OR-ed in,
-        // which the compiler folds into the loads' immediate offsets
-        const uint32_t ra = off_rec + (((odd ? p_hrec : hrec) << 7) | (odd ? 64u : 0u));
-        const uint32_t rb = off_rec + (((odd ? hrec : p_hrec) << 7) | (odd ? 0u : 64u));
-        const uint4 qa0 = ld16(K.base, ra), qa1 = ld16(K.base, ra | 16u), qa2 = ld16(K.base, ra | 32u), qa3 = ld16(K.base, ra | 48u);   // even lane: own half 0; odd lane: partner's half 1
-        const uint4 qb0 = ld16(K.base, rb), qb1 = ld16(K.base, rb | 16u), qb2 = ld16(K.base, rb | 32u), qb3 = ld16(K.base, rb | 48u);   // even lane: partner's half 1; odd lane: own half 0
-        // own half 0 = even ? qa : qb (already here); own half 1 = the partner's qb (even lanes) / qa (odd lanes)
-        const uint4 h0 = odd ? qb0 : qa0, r1 = odd ? qb1 : qa1, r2 = odd ? qb2 : qa2, r3 = odd ? qb3 : qa3;
-        if (k + 1 < kPerThread) stage(s + uint32_t(kThreads));          // next iteration's symbols and seed
-        uint4 h1, l1, l2, l3;
-        {
-            // what this lane holds of the PARTNER's record, handed over through DPP
-            const uint4 g0 = odd ? qa0 : qb0, g1 = odd ? qa1 : qb1, g2 = odd ? qa2 : qb2, g3 = odd ? qa3 : qb3;
-            h1 = make_uint4(pair_swap(g0.x), pair_swap(g0.y), pair_swap(g0.z), pair_swap(g0.w));
-            l1 = make_uint4(pair_swap(g1.x), pair_swap(g1.y), pair_swap(g1.z), pair_swap(g1.w));
-            l2 = make_uint4(pair_swap(g2.x), pair_swap(g2.y), pair_swap(g2.z), pair_swap(g2.w));
-            l3 = make_uint4(pair_swap(g3.x), pair_swap(g3.y), pair_swap(g3.z), pair_swap(g3.w));
+        // wave-uniform: which stages have positions of this wave inside the tile
+        const bool do_t = j >= 0 && wbase + uint32_t(j) * kThreads < flat_len;
+        const bool do_b = j + 1 >= 0 && j + 1 < kPerThread && wbase + uint32_t(j + 1) * kThreads < flat_len;
+        const bool do_u = j + 2 < kPerThread && wbase + uint32_t(j + 2) * kThreads < flat_len;
+        if (!do_t && !do_b && !do_u) break;
+        const uint32_t s_t = uint32_t(tid) + uint32_t(j) * kThreads, s_b = s_t + kThreads, s_u = s_b + kThreads;
+        // ---- every load first
+        uint4 tn = make_uint4(0, 0, 0, 0), n0 = make_uint4(0, 0, 0, 0), n1 = make_uint4(0, 0, 0, 0), u = make_uint4(0, 0, 0, 0);
+        uint32_t x1 = 0, x2 = 0, x3 = 0;
+        if (do_t) { if (t_slot != ~0u) tn = ld16(K.base, off_tri + (((P.debug & 1u) ? 0u : t_slot) << 4)); }
+        if (do_b) {
+            const uint32_t a = off_bi + (((P.debug & 1u) ? 0u : b_slot) << 5);
+            n0 = ld16(K.base, a); n1 = ld16(K.base, a | 16u);
         }
-        // own row so far: unigram (+ type row)
-        // six 21-bit fields at bits 0, 21, 42, 63, 84, 105 (layout.h); bit 127 = the row is wide (M stack)
-        int32_t a0 = sext(u.x, kUniFieldBits), a1 = sext(__builtin_amdgcn_alignbit(u.y, u.x, 21), kUniFieldBits);
-        int32_t a2 = sext(u.y >> 10, kUniFieldBits), a3 = sext(__builtin_amdgcn_alignbit(u.z, u.y, 31), kUniFieldBits);
-        int32_t a4 = sext(__builtin_amdgcn_alignbit(u.w, u.z, 20), kUniFieldBits), a5 = sext(u.w >> 9, kUniFieldBits);
-        if (TM == kTypeRows) {
-            // a dead lane (t1 = 0) reads the 16 bytes in front of the rows; nothing is added for it
-            const uint4 tr = L.trow[int32_t(type_row_index((x1 >> 16) & 7u, (x2 >> 16) & 7u, (x3 >> 16) & 7u))];
-            // six 18-bit signed fields at bits 0, 18, 36, 54, 72, 90 (layout.h, trow_field)
-            a0 += int32_t(tr.x << 14) >> 14;
-            a1 += int32_t(__builtin_amdgcn_alignbit(tr.y, tr.x, 18) << 14) >> 14;
-            a2 += int32_t(tr.y << 10) >> 14;
-            a3 += int32_t(__builtin_amdgcn_alignbit(tr.z, tr.y, 22) << 14) >> 14;
-            a4 += int32_t(tr.z << 6) >> 14;
-            a5 += int32_t(__builtin_amdgcn_alignbit(tr.w, tr.z, 26) << 14) >> 14;
+        if (do_u) {
+            x1 = L.sym[s_u]; x2 = L.sym[s_u + 1]; x3 = L.sym[s_u + 2];   // the array is zero past the tile; s_u + 2 < kFastCap + kMargin
+            const uint32_t id1 = x1 & kCpMask;
+            u = ld16(K.base, K.off_uni + (((P.debug & 4u) ? 0u : (id1 < uni_last ? id1 : uni_last)) << 4));
         }
-        const bool keyok = has2 && h1.x == kb;
-        const RecMatch mt = match_record(keyok, c0, c3, h0, r1, r2, r3, h1, l1, l2, l3);
-        a1 += mt.b1; a2 += mt.b2; a3 += mt.b3; a4 += mt.b4; a5 += mt.b5;
-        if (live) add_row6(L.score, s, a0, a1, a2, a3, a4, a5);
-        // deferred work
-        const bool ovp = mt.ovp && !(P.debug & 2u);
-        uint32_t rk = mt.rk, lk = mt.lk, ov_ref = mt.ov_ref;
-        uint32_t dfl = (has2 && !keyok) ? h0.w >> 16 : 0u;   // where keys homed in this record were displaced to
-        uint32_t kinds = ((live && (u.w & kUniWideBit)) ? kWideUni : 0u) | ((dfl & kPkFar) ? kRecFar : (dfl >> kPkHopShift) ? kRecMore : 0u) | mt.wide;
-        VPT_PIN(rk); VPT_PIN(lk); VPT_PIN(ov_ref); VPT_PIN(kinds); VPT_PIN(dfl);   // the record's registers and the match masks end here
-        const bool nowalk = (P.debug & 8u) != 0;
-        make_room(K, P.ct, L, Q, lane);
-        Q.push_w(rk != 0 && !nowalk, s | (3u << 11), rk);
-        Q.push_o(ovp, s, ov_ref);
-        const uint64_t mm = __ballot(kinds != 0 && !(P.debug & 32u));
-        if (mm != 0) {   // rare: rows outside their fields, or a record placed by the fallback of the perfect hash
-            while (Q.nm + uint32_t(__popcll(mm)) > uint32_t(kMCap)) replay_m(K, P.ct, L, Q, lane);   // every pass moves its items one slot on
-            Q.push_m(kinds != 0 && !(P.debug & 32u), s | (kinds << 11), (dfl & kPkFar) ? (hrec + 1) & K.rec_mask : hrec | ((dfl >> kPkHopShift) << 24));
+        // ---- trigram stage of positions s_t: the node is ours if it names our bigram node as its parent
+        if (do_t) {
+            const bool hit = t_slot != ~0u && (tn.x & kTriParentMask) == t_par;
+            if (hit) add_child(L.score, s_t, tn.y, tn.z);   // a kPkWide node holds zero weights
+            const bool wide = hit && (tn.x & (kPkWide << 24));
+            uint32_t kids = hit ? tn.w : 0u;
+            VPT_PIN(kids);
+            drain_w(K, L, Q, lane, kQHigh);                 // room for one more round of pushes
+            Q.push_w(kids != 0 && !(P.debug & 8u), s_t | (3u << 11), kids);
+            const uint64_t mm = __ballot(wide);
+            if (mm != 0) {
+                while (Q.nm + uint32_t(__popcll(mm)) > uint32_t(kMCap)) replay_m(K, P.ct, L, Q, lane);
+                Q.push_m(wide, s_t | (kWideTri << 11), 0u);
+            }
         }
-        if (__ballot(lk != 0) != 0) {
-            make_room(K, P.ct, L, Q, lane);
-            Q.push_w(lk != 0 && !nowalk, (s - 1) | (3u << 11), lk);
+        // ---- bigram stage of positions s_b: key check, the row, and the address of the trigram node
+        t_slot = ~0u;
+        if (do_b) {
+            const bool keyok = b_key != 0 && n0.x == b_key;
+            if (keyok) {
+                // five 19-bit fields at bits 0, 19, 38, 57, 76 of dwords 1..3 (layout.h); bit 95 = the row is wide (M stack)
+                int32_t* p = L.score + s_b - 2;
+                atomicAdd(p, sext(n0.y, kBiFieldBits));
+                atomicAdd(p + 1, sext(__builtin_amdgcn_alignbit(n0.z, n0.y, 19), kBiFieldBits));
+                atomicAdd(p + 2, sext(n0.z >> 6, kBiFieldBits));
+                atomicAdd(p + 3, sext(__builtin_amdgcn_alignbit(n0.w, n0.z, 25), kBiFieldBits));
+                atomicAdd(p + 4, sext(n0.w >> 12, kBiFieldBits));
+            }
+            const uint32_t bit = packed_filter_bit(b_id3);
+            const bool cont = keyok && b_id3 != 0 && (((bit < 32 ? n1.y >> bit : n1.z >> (bit - 32)) & 1u) != 0);
+            const uint32_t ts = n1.x + b_id3;               // modulo 2^32 (layout.h); a false positive of the filter may point anywhere
+            t_slot = (cont && ts < K.n_tri && !(P.debug & 2u)) ? ts : ~0u;
+            t_par = b_slot + 1u;
+            const uint64_t mm = __ballot(keyok && (n0.w & kBiWideBit));
+            if (mm != 0) {
+                while (Q.nm + uint32_t(__popcll(mm)) > uint32_t(kMCap)) replay_m(K, P.ct, L, Q, lane);
+                Q.push_m(keyok && (n0.w & kBiWideBit), s_b | (kWideBi << 11), 0u);
+            }
+        }
+        // ---- unigram stage of positions s_u: the row (+ the type row), and the address of the bigram node
+        b_key = 0;
+        if (do_u) {
+            const uint32_t id1 = x1 & kCpMask, id2 = x2 & kCpMask;
+            const bool live = id1 != 0;
+            // six 18-bit fields at bits 0, 18, 36, 54, 72, 90 (layout.h); bits 108..126 = the base of the bigram nodes; bit 127 = wide
+            int32_t a0 = sext(u.x, kUniFieldBits), a1 = sext(__builtin_amdgcn_alignbit(u.y, u.x, 18), kUniFieldBits);
+            int32_t a2 = sext(u.y >> 4, kUniFieldBits), a3 = sext(__builtin_amdgcn_alignbit(u.z, u.y, 22), kUniFieldBits);
+            int32_t a4 = sext(u.z >> 8, kUniFieldBits), a5 = sext(__builtin_amdgcn_alignbit(u.w, u.z, 26), kUniFieldBits);
+            if (TM == kTypeRows) {
+                // a dead lane (t1 = 0) reads the 16 bytes in front of the rows; nothing is added for it
+                const uint4 tr = L.trow[int32_t(type_row_index((x1 >> 16) & 7u, (x2 >> 16) & 7u, (x3 >> 16) & 7u))];
+                // six 18-bit signed fields at bits 0, 18, 36, 54, 72, 90 (layout.h, trow_field)
+                a0 += int32_t(tr.x << 14) >> 14;
+                a1 += int32_t(__builtin_amdgcn_alignbit(tr.y, tr.x, 18) << 14) >> 14;
+                a2 += int32_t(tr.y << 10) >> 14;
+                a3 += int32_t(__builtin_amdgcn_alignbit(tr.z, tr.y, 22) << 14) >> 14;
+                a4 += int32_t(tr.z << 6) >> 14;
+                a5 += int32_t(__builtin_amdgcn_alignbit(tr.w, tr.z, 26) << 14) >> 14;
+            }
+            if (live) add_row6(L.score, s_u, a0, a1, a2, a3, a4, a5);
+            b_slot = (((u.w >> kUniBaseShift) & kUniBaseMask) << K.bi_shift) + id2;
+            b_key = (live && id2 != 0) ? (id1 | (id2 << 16)) : 0u;
+            b_id3 = x3 & kCpMask;
+            const uint64_t mm = __ballot(live && (u.w & kUniWideBit) && !(P.debug & 32u));
+            if (mm != 0) {
+                while (Q.nm + uint32_t(__popcll(mm)) > uint32_t(kMCap)) replay_m(K, P.ct, L, Q, lane);
+                Q.push_m(live && (u.w & kUniWideBit), s_u | (kWideUni << 11), 0u);
+            }
         }
     }
     while (Q.nm > 0) replay_m(K, P.ct, L, Q, lane);
-    while (Q.no > 0) replay_o(K, P.ct, L, Q, lane);
     while (Q.nw > 0) replay_w(K, L, Q, lane);
     tmark = phase_mark(prof, 2, tmark);
     __syncthreads();
@@ -678,15 +553,15 @@ __global__ __launch_bounds__(kThreads, 6) void score_tiles_fast_kernel(const Sco
             for (int i = 1 - TM; i <= TM; ++i) id = (id << 3) | (L.typ[int(p) + i] & 7u);
             y += P.type_table[id];
         }
-        const uint32_t o = (p - pad) - (pad + 1) * (x >> 19);
+        const uint32_t o = (p - pad) - (pad + 1) * ((x >> 19) & 1023u);
         if (o >= nb) { err |= kErrBadOffsets; continue; }  // only with offsets that do not match the text
         if (sc) VPT_STREAM_STORE(y, sc + o);
         if (lb) {
             uint32_t label = y > 0 ? 1u : 0u;
             if (P.post) {   // wave-uniform: KyteaWsConstFilter / SplitLinebreaksFilter on the label
-                const uint32_t t1 = (x >> 16) & 7u, t2 = (x2 >> 16) & 7u, ca = x & kCpMask, cb = x2 & kCpMask;
+                const uint32_t t1 = (x >> 16) & 7u, t2 = (x2 >> 16) & 7u;
                 if (t1 == t2 && ((P.post >> t1) & 1u) && t1 != 0 && t1 != 7) label = 0;
-                if ((P.post & 0x80u) && (ca == 0x0Au || ca == 0x0Du || cb == 0x0Au || cb == 0x0Du)) label = 1;
+                if ((P.post & 0x80u) && ((x | x2) & kSymLinebreak)) label = 1;
             }
             VPT_STREAM_STORE(uint8_t(label), lb + o);
         }
@@ -698,7 +573,7 @@ __global__ __launch_bounds__(kThreads, 6) void score_tiles_fast_kernel(const Sco
 }  // namespace
 
 bool fast_path_supported(const ScoreParams& P) {
-    if (!P.pk.present || P.pad != 3 || !P.ctype) return false;
+    if (!P.pk.present || P.pad != 3 || !P.cid) return false;
     if (!P.ct.present || P.ct.stride_dw != 8 || P.ct.uni_dw != 8 || P.ct.uni_n != kUniDirectChars) return false;  // kPkWide rows
     if (P.type_kind == kTypeNone) return true;
     return P.type_kind == kTypeWindowTable && P.type_window >= 1 && P.type_window <= 3;

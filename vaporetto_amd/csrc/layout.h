@@ -34,57 +34,54 @@
 //
 // PACKED TABLES (specialised kernel, kernels_fast.hip).  Every model a Vaporetto / KyTea trainer produces has
 // char window 3, weights quantised to 16 bits (trainer.rs:18,383-397; kytea_model.rs:72-79) and BMP-only patterns.
-// For such models -- W = 3, every pattern symbol in [1, 0xFFFE] -- the same all-matches information is also emitted
-// in a layout shaped by what bounds the kernel on MI355X: the number of random memory LINES touched per start
-// position (tools/gather_bench.hip: a random 128-byte line read by a lane PAIR costs the same as a random 16-byte
-// read, ~57 G/s chip-wide out of L2), not bytes and not lane requests.  So everything the patterns starting with
-// (c1, c2) need at depth 2 and 3 lives in ONE 128-byte record:
+// For such models -- W = 3, every pattern symbol in [1, 0xFFFE] -- the same all-matches information is also emitted as a
+// DOUBLE-ARRAY TRIE over the first three symbols of the patterns, walked from every start position.  What shapes it is
+// what bounds the kernel on MI355X (profiles/r02_*): the vector L1's address pipeline -- a lane's 16-byte load costs
+// about 1.4 ns / 256 CUs of it and every distinct line it touches another 2.7 -- so a position should issue few
+// loads to few lines, and nothing it does not need.  One position = one 16-byte unigram node, one 32-byte bigram node and,
+// when the bigram's filter says the third char may continue it, one 16-byte trigram node: 4 loads to 3 lines, each
+// address computed from the node before it (Tarjan-Yao row displacement: child slot = parent's base + child symbol, so
+// there is no hash, no seed table and no probing; a node names its parent so that a lookup which lands on somebody
+// else's node knows it).  The three dependent loads of a position are software-pipelined over three iterations of the
+// kernel's main loop, so every iteration still waits once.
 //
-//   uni    65536 rows of 16 bytes, indexed by c1: six signed 21-bit fields (boundaries s-3 .. s+2) at bits
-//          0, 21, .., 105; bit 127 = kUniWideBit                                                    (L1/L2-hot)
-//   rec    open addressing over 128-byte records keyed by kb = c1 | c2 << 16 (eight 16-byte units):
-//            H0      = the bigram row: five signed 22-bit fields (boundaries s-2 .. s+2) at bits 0, 22, .., 88, zero
-//                      when (c1,c2) is only a prefix; bits 112..127 = flags: kPkDisp, kPkWide, kPkOv, kPkFar, hops
-//                      (unigram and bigram rows are the hot ones and sum the most patterns -- an n-gram plus a
-//                      dictionary word of the same string -- so they get more than the 16 bits of a single weight)
-//            R1..R3  = RIGHT children {c3 | cflags<<16, w0|w1<<16, w2|w3<<16, kids}: the 3-char string (c1,c2,c3)
-//                      starting at s (boundaries s-1 .. s+2)
-//            H1      = {kb, overflow ref, filter lo, filter hi}           (the key of the record lives here)
-//            L1..L3  = LEFT children {c0 | cflags<<16, ...}: the 3-char string (c0,c1,c2) starting at s-1 (boundaries
-//                      s-2 .. s+1), found by the position AFTER its start -- which fetches record (c1,c2) anyway
-//          A child = a 3-char pattern and/or the 3-char prefix of longer ones; `kids` = mini-table ref of its
-//          depth-4 children in `deep` (0: none); cflags: kPkWide.  Unused child slots are zero (sym 0 never
-//          matches).  Each such string is stored exactly once: in a right slot of its (c1,c2) record, or in a left
-//          slot of its (c2,c3) record (created if needed), or -- when both are full -- in the overflow mini-table
-//          of (c1,c2) in `kids3` (kPkOv, H1.y), guarded by a 64-bit filter over hash6(c3) (H1.z/w).  Prefixes with
-//          many children are the frequent ones; spreading their children over the records of the FOLLOWING prefix
-//          keeps most lookups to the one line per position.
-//   kids3  16-byte entries, same format as an inline child.
+//   ids    pattern symbols are renumbered 1 .. n_alpha in code-point order (the alphabet of the model: every char of
+//          every n-gram and dictionary word); the kernel's char classification table (cinfo, below) maps a text char
+//          to its id, 0xFFFF (kNoId) when no pattern contains it.  0 stays "outside the sentence".
+//   cinfo  65536 words per mode (plain / through KyteaFullwidthFilter): id | CharacterType << 16 | linebreak << 19
+//   uni    n_alpha + 2 rows of 16 bytes indexed by id (row 0 and the last row are zero: separators, chars outside the
+//          alphabet): six signed 18-bit fields (boundaries s-3 .. s+2) at bits 0, 18, .., 90; bits 108..126 = B1, the
+//          base of this char's bigram nodes in units of (1 << bi_shift) nodes; bit 127 = kUniWideBit
+//   bi     32-byte bigram nodes, node (id1, id2) at slot (B1[id1] << bi_shift) + id2:
+//            dword 0      key = id1 | id2 << 16 (0 = free)
+//            dwords 1..3  the bigram row: five signed 19-bit fields (boundaries s-2 .. s+2) at bits 0, 19, .., 76 of the
+//                         96; bit 95 = kBiWideBit (the row has a value outside its fields: it comes from the general tables)
+//            dword 4      B2 = base of this prefix's trigram nodes: node (id1, id2, id3) at slot B2 + id3 (mod 2^32)
+//            dwords 5, 6  64-bit filter over packed_filter_bit(id3) of the children (0: none)
+//            dword 7      number of children (statistics)
+//   tri    16-byte trigram nodes: dword 0 = (slot of the parent bigram node + 1) | cflags << 24 (0 = free; cflags: kPkWide),
+//          dwords 1, 2 = w0|w1<<16, w2|w3<<16 (boundaries s-1 .. s+2), dword 3 = `kids`: mini-table ref of its depth-4
+//          children in `deep` (0: none).  A node = a 3-char pattern and/or the 3-char prefix of longer ones.
 //   deep   64-byte entries for the trie below depth 3.  An entry stands for a child symbol PLUS the chain of up to 8
 //          further symbols that must follow it (nodes with a single child and no row of their own are compressed
 //          away), and ends at a node of depth m:
-//            dword 0      sym | dflags<<16 | nskip<<24          dword 1   kids (mini-table of the end node's children)
-//            dwords 2..5  the nskip further symbols, 16 bits each
+//            dword 0      id | dflags<<16 | nskip<<24              dword 1   kids (mini-table of the end node's children)
+//            dwords 2..5  the nskip further ids, 16 bits each
 //            dwords 8..14 the row of the end node's pattern: m+1 weights i16 (boundaries s-1 .. s+m-1), inline when
 //                         m+1 <= 14 and every value fits i16 (kPkHasRow); otherwise kPkExtRow and dword 8 = offset of
 //                         an i32 row in `xrows`.
-//   mini-table ref = base << 5 | log2(size): `size` consecutive entries of one arena holding the children of ONE
+//   mini-table ref = base << 5 | log2(size): `size` consecutive entries of `deep` holding the children of ONE
 //          node (so a hot node's children are contiguous and cache-hot together); entry index
-//          (sym * kHashMulLo >> 15) & (size-1), linear probing inside the mini-table, at most `size` probes,
-//          an entry with dword 0 == 0 ends the search.  Entry 0 of each arena is unused so that ref 0 = none.
+//          (id * kHashMulLo >> 15) & (size-1), linear probing inside the mini-table, at most `size` probes,
+//          an entry with dword 0 == 0 ends the search.  Entry 0 of the arena is unused so that ref 0 = none.
+//   cpid   n_alpha + 2 words: the code point of an id (only the rare kPkWide replay needs it: the general tables are
+//          keyed by code points).
 //
-// Record slots come from a PERFECT HASH built at load time (the key set is static): `seed` holds one byte per
-// bucket(kb) (a few keys each), slot = packed_ph_slot(kb, seed): bucket by bucket, largest first, the builder picks
-// the seed that sends all the bucket's keys to free records.  Every present key is therefore found by ONE record
-// read (plus the cache-hot seed byte), an absent key lands on a record with another key or none.  Only a bucket for
-// which no seed below 255 works (not observed) falls back to seed 255 + linear probing, described by flags of the
-// HOME record: bit d-1 of the hop bitmap = "a key homed here lives d records further on" (d = 1..8),
-// kPkFar = "... more than 8 further on" (then the search walks on to the first empty record).  A lookup that finds
-// neither its key nor any of these in the home record is over after one line; otherwise it visits exactly the
-// records the bitmap names.  kPkWide marks a row with a value outside its fields (i16 in a child or `deep` entry,
-// 22 bits in a bigram row; `uni`: kUniWideBit, 21 bits): the slot keeps zero weights and the row comes from the
-// general tables above.  A text char >= 0xFFFF is mapped to 0xFFFF before lookups: no pattern
-// contains it, so it matches nothing.
+// Bases come from first-fit placement at load time (rows with the most children first; a row = the set of child ids of
+// one parent): every present key is found by exactly one node read, an absent key lands on a free node or on another
+// parent's.  kPkWide / kBiWideBit / kUniWideBit mark a row with a value outside its fields (i16 in a trigram node or
+// `deep` entry, 19 bits in a bigram row, 18 in a unigram row -- a single weight has 16, a merged row sums an n-gram and
+// the dictionary word of the same string): the node keeps zero weights and the row comes from the general tables above.
 //
 // TYPE ROWS.  When every type n-gram has at most 3 symbols and W_t <= 3 (the trainer's defaults), the type scores
 // are folded into the same start-position form: trow[type_row_index(t1, t2, t3)] = the six totals (boundaries
@@ -111,15 +108,17 @@ constexpr uint32_t kShortBucket = 2;             // entries per bucket of the sh
 constexpr uint32_t kEdgeBucket = 4;              // edges per bucket of the trie edge table
 constexpr uint32_t kHashMulLo = 0x9E3779B1u, kHashMulHi = 0x85EBCA77u;
 
-constexpr uint32_t kPkDisp = 1u, kPkExtRow = 2u, kPkHasRow = 4u, kPkWide = 8u, kPkOv = 16u, kPkFar = 32u;  // packed flags
-constexpr uint32_t kPkHopShift = 8;            // record flags bits 8..15: hop bitmap (bit d-1: a key homed here lives d slots on)
-constexpr uint32_t kPackedNoMatchSym = 0xFFFFu;
-constexpr uint32_t kPackedInlineKids = 6;      // children held by a record itself
+constexpr uint32_t kPkExtRow = 2u, kPkHasRow = 4u, kPkWide = 8u;  // packed flags (deep entries: dflags; trigram nodes: cflags)
+constexpr uint32_t kNoId = 0xFFFFu;            // id of a text char that no pattern contains
 constexpr uint32_t kPackedInlineRow = 14;      // weights a `deep` entry holds inline
 constexpr uint32_t kPackedMaxSkip = 8;         // further symbols a `deep` entry can require (path compression)
-constexpr int kUniFieldBits = 21;              // unigram row: six fields
-constexpr int kBiFieldBits = 22;               // bigram row (record unit H0): five fields
-constexpr uint32_t kUniWideBit = 0x80000000u;  // dword 3 of a unigram row: the row is in the general tables (i32)
+constexpr int kUniFieldBits = 18;              // unigram node: six fields
+constexpr int kBiFieldBits = 19;               // bigram node (dwords 1..3): five fields
+constexpr uint32_t kUniBaseShift = 12, kUniBaseMask = 0x7FFFFu;   // dword 3 of a unigram node: B1 at bits 12..30
+constexpr uint32_t kUniWideBit = 0x80000000u;  // dword 3 of a unigram node: the row is in the general tables (i32)
+constexpr uint32_t kBiWideBit = 0x80000000u;   // dword 3 of a bigram node: likewise
+constexpr uint32_t kTriParentMask = 0xFFFFFFu; // dword 0 of a trigram node: parent slot + 1; cflags above
+constexpr uint32_t kCinfoLinebreak = 1u << 19; // cinfo word: the (scored) char is '\n' or '\r'
 
 #if defined(__HIPCC__)
 #define VPT_HD __host__ __device__ __forceinline__
@@ -136,10 +135,7 @@ VPT_HD uint32_t hash_slot(uint64_t key, uint32_t shift) {
     return (uint32_t(key) * kHashMulLo + uint32_t(key >> 32) * kHashMulHi) >> shift;
 }
 
-// packed-table hashes; `shift` = 32 - log2(capacity in records)
-VPT_HD uint32_t packed_hash1(uint32_t k, uint32_t shift) { return (k * kHashMulLo) >> shift; }
-VPT_HD uint32_t packed_ph_bucket(uint32_t k, uint32_t shift) { return (k * kHashMulHi) >> shift; }
-VPT_HD uint32_t packed_ph_slot(uint32_t k, uint32_t seed, uint32_t shift) { return ((k ^ (seed * 0x7FEB352Du)) * kHashMulLo) >> shift; }
+// packed-table hashes
 VPT_HD uint32_t packed_mini_slot(uint32_t sym, uint32_t ref) { return ((sym * kHashMulLo) >> 15) & ((1u << (ref & 31u)) - 1u); }
 VPT_HD uint32_t packed_filter_bit(uint32_t sym) { return (sym * kHashMulHi) >> 26; }   // 0..63
 
@@ -192,9 +188,10 @@ struct PatternTableView {
 // allocation (below 4 GB), addressed as base + 32-bit byte offset: one scalar base pointer instead of seven.
 struct PackedView {
     const unsigned char* base;
-    uint32_t off_uni, off_rec, off_kids3, off_deep, off_xrows, off_seed, off_trow;   // byte offsets, 256-byte aligned
-    uint32_t rec_shift, rec_mask;   // hash shift and mask in RECORDS
-    uint32_t seed_shift;            // 32 - log2(buckets)
+    uint32_t off_uni, off_bi, off_tri, off_deep, off_xrows, off_trow, off_cpid;   // byte offsets, 256-byte aligned
+    uint32_t n_uni;                 // unigram nodes (ids above n_uni - 1 read the last, all-zero one)
+    uint32_t n_tri;                 // trigram nodes (a filter false positive may point past them)
+    uint32_t bi_shift;              // bigram slot = (B1 << bi_shift) + id2
     uint32_t present;
     uint32_t has_trow;              // type rows available (else: window table / none)
 };

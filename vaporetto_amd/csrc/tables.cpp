@@ -5,21 +5,33 @@
 //   TypeScorerBoundary::new                       type_scorer/boundary_scorer.rs:45-62
 // See layout.h for why all-matches tables give the same sums as the reference's merged automaton.
 #include "tables.hpp"
+#include "patset.hpp"
 
 #include <algorithm>
+#include <chrono>
+#include <cstdio>
 #include <cstdlib>
+#include <exception>
 #include <string>
+#include <thread>
 #include <unordered_map>
 
 namespace vpt {
 namespace {
 
-inline int32_t wadd(int32_t a, int32_t b) { return int32_t(uint32_t(a) + uint32_t(b)); }  // release builds wrap
-
-struct Pat {
-    SymString s;
-    std::vector<int32_t> row;  // row_len(n, W) totals, first entry = boundary (start + row_lo(n, W))
+// VPT_DEBUG_TIMING=1: stage times of the table compiler on stderr
+struct StageTimer {
+    const bool on = std::getenv("VPT_DEBUG_TIMING") != nullptr;
+    std::chrono::steady_clock::time_point t = std::chrono::steady_clock::now();
+    void mark(const char* what) {
+        if (!on) return;
+        const auto now = std::chrono::steady_clock::now();
+        std::fprintf(stderr, "[vpt compile] %-28s %.3f s\n", what, std::chrono::duration<double>(now - t).count());
+        t = now;
+    }
 };
+
+inline int32_t wadd(int32_t a, int32_t b) { return int32_t(uint32_t(a) + uint32_t(b)); }  // release builds wrap
 
 bool has_zero(const SymString& s) {
     for (Sym c : s)
@@ -28,7 +40,7 @@ bool has_zero(const SymString& s) {
 }
 
 // n-gram weights: w[k] -> boundary start + n-1-W + k   (offset -W from the END position, boundary_scorer.rs:63)
-void add_ngram(std::vector<Pat>& out, const SymString& g, const std::vector<int32_t>& w, int W, bool is_char) {
+void add_ngram(PatSet& out, const SymString& g, const std::vector<int32_t>& w, int W, bool is_char) {
     const int n = int(g.size());
     if (n == 0) throw ModelError("InvalidModelError: failed to build the automaton");  // daachorse rejects ""
     const int cap = std::max(0, 2 * W - n + 1);
@@ -36,16 +48,13 @@ void add_ngram(std::vector<Pat>& out, const SymString& g, const std::vector<int3
         throw ModelError(std::string("InvalidModelError: ") + (is_char ? "character" : "character type") +
                          " n-gram weight vector is longer than 2*window_size-n+1");
     if (w.empty() || has_zero(g)) return;  // contributes nothing / can never match a sentence
-    Pat p;
-    p.s = g;
-    p.row.assign(size_t(row_len(n, W)), 0);
+    int32_t* row = out.add(g, size_t(row_len(n, W)));
     const int base = (n - 1 - W) - row_lo(n, W);
-    for (size_t k = 0; k < w.size(); ++k) p.row[size_t(base) + k] = w[k];
-    out.push_back(std::move(p));
+    for (size_t k = 0; k < w.size(); ++k) row[size_t(base) + k] = w[k];
 }
 
 // dictionary word weights: w[k] -> boundary start - 1 + k   (offset -len from the END position, rs:67-74)
-void add_word(std::vector<Pat>& out, const SymString& g, const std::vector<int32_t>& w, int W) {
+void add_word(PatSet& out, const SymString& g, const std::vector<int32_t>& w, int W) {
     const size_t n = g.size();
     if (n == 0) throw ModelError("InvalidModelError: failed to build the automaton");
     if (n > 32767)
@@ -53,12 +62,9 @@ void add_word(std::vector<Pat>& out, const SymString& g, const std::vector<int32
     if (w.size() > n + 1)
         throw ModelError("InvalidModelError: dictionary weight vector is longer than the word length + 1");
     if (w.empty() || has_zero(g)) return;
-    Pat p;
-    p.s = g;
-    p.row.assign(size_t(row_len(int(n), W)), 0);
+    int32_t* row = out.add(g, size_t(row_len(int(n), W)));
     const int base = -1 - row_lo(int(n), W);
-    for (size_t k = 0; k < w.size(); ++k) p.row[size_t(base) + k] = w[k];
-    out.push_back(std::move(p));
+    for (size_t k = 0; k < w.size(); ++k) row[size_t(base) + k] = w[k];
 }
 
 uint32_t bits_for(size_t count) {  // capacity 2^bits >= 2*count, at least 16
@@ -67,7 +73,10 @@ uint32_t bits_for(size_t count) {  // capacity 2^bits >= 2*count, at least 16
     return bits;
 }
 
-HostPatternTable build_table(std::vector<Pat>& pats, int W, uint32_t uni_n) {
+// General tables (layout.h, top) from the sorted, merged pattern set.  Sorted order puts the patterns that share a
+// prefix next to each other, so the long trie is built by one scan with the current path on a stack.
+HostPatternTable build_table(const PatSet& S, int W, uint32_t uni_n) {
+    StageTimer tm;
     HostPatternTable t;
     t.present = true;
     t.window = W;
@@ -76,56 +85,44 @@ HostPatternTable build_table(std::vector<Pat>& pats, int W, uint32_t uni_n) {
         t.lo[n - 1] = row_lo(n, W);
         t.len[n - 1] = row_len(n, W);
     }
-    // identical strings are summed (CharWeightMerger::add, char_scorer.rs:37-47)
-    std::sort(pats.begin(), pats.end(), [](const Pat& a, const Pat& b) { return a.s < b.s; });
-    size_t o = 0;
-    for (size_t i = 0; i < pats.size(); ++i) {
-        if (o > 0 && pats[o - 1].s == pats[i].s) {
-            for (size_t k = 0; k < pats[i].row.size(); ++k) pats[o - 1].row[k] = wadd(pats[o - 1].row[k], pats[i].row[k]);
-        } else {
-            if (o != i) pats[o] = std::move(pats[i]);
-            ++o;
-        }
-    }
-    pats.resize(o);
 
     // ---- long trie (strings of more than 3 symbols)
-    struct Root { uint32_t node; };
-    std::unordered_map<uint64_t, uint32_t> root3;   // short_key(3-prefix) -> node id
-    std::unordered_map<uint64_t, uint32_t> edge;    // edge_key(parent, sym) -> child
+    struct Edge { uint32_t parent; Sym sym; uint32_t child; };
+    struct Root { uint64_t key3; uint32_t node; };
+    std::vector<Edge> edges;
+    std::vector<Root> roots;                        // one per 3-symbol prefix of a long pattern, in key order
     std::vector<uint32_t> node_woff(1, kNoRow);     // node 0 is unused (0 = "no continuation")
     std::vector<uint32_t> node_kids(1, 0);          // number of outgoing edges per node
-    for (const Pat& p : pats) {
-        const size_t n = p.s.size();
-        t.max_pattern = std::max<uint32_t>(t.max_pattern, uint32_t(n));
-        if (n <= 3) continue;
-        t.has_long = true;
-        uint64_t k3 = short_key(p.s[0], p.s[1], p.s[2]);
-        auto it = root3.find(k3);
-        uint32_t node;
-        if (it == root3.end()) {
-            node = uint32_t(node_woff.size());
-            node_woff.push_back(kNoRow);
-            node_kids.push_back(0);
-            root3.emplace(k3, node);
-        } else node = it->second;
-        for (size_t i = 3; i < n; ++i) {
-            uint64_t ek = edge_key(node, p.s[i]);
-            auto e = edge.find(ek);
-            if (e == edge.end()) {
-                uint32_t child = uint32_t(node_woff.size());
-                node_woff.push_back(kNoRow);
-                node_kids.push_back(0);
-                edge.emplace(ek, child);
-                ++node_kids[node];
-                node = child;
-            } else node = e->second;
+    {
+        std::vector<uint32_t> path;                 // path[i] = node of depth 3 + i of the previous long pattern
+        const PatRef* prev = nullptr;
+        auto new_node = [&]() { node_woff.push_back(kNoRow); node_kids.push_back(0); return uint32_t(node_woff.size() - 1); };
+        for (const PatRef& p : S.p) {
+            t.max_pattern = std::max<uint32_t>(t.max_pattern, p.n);
+            if (p.n <= 3) continue;
+            t.has_long = true;
+            uint32_t keep = (prev && prev->key3 == p.key3) ? S.lcp(*prev, p) : 0;   // symbols already on the path (>= 3 then)
+            if (keep < 3) {
+                path.clear();
+                path.push_back(new_node());
+                roots.push_back({p.key3, path.back()});
+                keep = 3;
+            } else path.resize(keep - 2);
+            const Sym* s = S.s(p);
+            for (uint32_t i = keep; i < p.n; ++i) {
+                const uint32_t child = new_node();
+                edges.push_back({path.back(), s[i], child});
+                ++node_kids[path.back()];
+                path.push_back(child);
+            }
+            node_woff[path.back()] = uint32_t(t.wdata.size());
+            t.wdata.insert(t.wdata.end(), S.row(p), S.row(p) + p.rlen);
+            prev = &p;
         }
-        node_woff[node] = uint32_t(t.wdata.size());
-        t.wdata.insert(t.wdata.end(), p.row.begin(), p.row.end());
     }
     t.n_long_nodes = uint32_t(node_woff.size() - 1);
     if (t.wdata.empty()) t.wdata.push_back(0);
+    tm.mark("general: long trie");
 
     // ---- short entries (<= 3 symbols) and their slot count
     t.slots = uint32_t(std::max(std::max(t.len[0], t.len[1]), t.len[2] + 1));
@@ -134,25 +131,25 @@ HostPatternTable build_table(std::vector<Pat>& pats, int W, uint32_t uni_n) {
     t.uni_dw = (t.slots + 3) & ~3u;
     t.uni.assign(size_t(uni_n) * t.uni_dw, 0);
 
-    struct ShortEnt { uint64_t key; const std::vector<int32_t>* row; uint32_t ext; };
+    struct ShortEnt { uint64_t key; const PatRef* pat; uint32_t ext; };
     std::vector<ShortEnt> ents;
-    std::unordered_map<uint64_t, size_t> ent_of;  // only for 3-symbol keys that need a continuation
-    for (const Pat& p : pats) {
-        const size_t n = p.s.size();
-        if (n > 3) continue;
-        if (n == 1 && p.s[0] < uni_n) {
-            for (size_t k = 0; k < p.row.size(); ++k) t.uni[size_t(p.s[0]) * t.uni_dw + k] = uint32_t(p.row[k]);
-            ++t.n_short;
-            continue;
+    {
+        auto key_of = [](uint64_t key3) { return short_key(uint32_t(key3 >> 42), uint32_t(key3 >> 21) & 0x1FFFFFu, uint32_t(key3) & 0x1FFFFFu); };
+        size_t ri = 0;   // the 3-symbol prefixes of long patterns (prefix closure at level 3 only) merge in by key order
+        for (const PatRef& p : S.p) {
+            if (p.n > 3) continue;
+            while (ri < roots.size() && roots[ri].key3 < p.key3) { ents.push_back({key_of(roots[ri].key3), nullptr, roots[ri].node}); ++ri; }
+            const Sym* s = S.s(p);
+            if (p.n == 1 && s[0] < uni_n) {
+                for (uint32_t k = 0; k < p.rlen; ++k) t.uni[size_t(s[0]) * t.uni_dw + k] = uint32_t(S.row(p)[k]);
+                ++t.n_short;
+                continue;
+            }
+            uint32_t ext = 0;
+            if (ri < roots.size() && roots[ri].key3 == p.key3) ext = roots[ri++].node;   // only a 3-symbol pattern can tie
+            ents.push_back({key_of(p.key3), &p, ext});
         }
-        uint64_t key = short_key(p.s[0], n > 1 ? p.s[1] : 0, n > 2 ? p.s[2] : 0);
-        if (n == 3) ent_of.emplace(key, ents.size());
-        ents.push_back({key, &p.row, 0});
-    }
-    for (const auto& r : root3) {  // prefix closure at level 3 only
-        auto it = ent_of.find(r.first);
-        if (it == ent_of.end()) ents.push_back({r.first, nullptr, r.second});
-        else ents[it->second].ext = r.second;
+        for (; ri < roots.size(); ++ri) ents.push_back({key_of(roots[ri].key3), nullptr, roots[ri].node});
     }
     t.n_short += uint32_t(ents.size());
     // buckets of kShortBucket (2) entries = 64 bytes when the entry is 32 bytes: a lookup reads its whole home
@@ -179,17 +176,19 @@ HostPatternTable build_table(std::vector<Pat>& pats, int W, uint32_t uni_n) {
         uint32_t* d = &t.short_tab[slot * t.stride_dw];
         d[0] = uint32_t(e.key);
         d[1] |= uint32_t(e.key >> 32);
-        if (e.row)
-            for (size_t k = 0; k < e.row->size(); ++k) d[2 + k] = uint32_t((*e.row)[k]);
+        if (e.pat)
+            for (uint32_t k = 0; k < e.pat->rlen; ++k) d[2 + k] = uint32_t(S.row(*e.pat)[k]);
         if (e.ext) d[2 + t.ext_slot] = e.ext;
     }
+    tm.mark("general: short table");
 
     // ---- edge table: buckets of kEdgeBucket (4) edges = 64 bytes
-    t.edge_bits = std::max<uint32_t>(bits_for(edge.size()), 4);
+    t.edge_bits = std::max<uint32_t>(bits_for(edges.size()), 4);
     const uint32_t eb_bits = t.edge_bits - 2, eb_mask = (1u << eb_bits) - 1;
     t.edges.assign((size_t(1) << t.edge_bits) * 4, 0);
-    for (const auto& e : edge) {
-        const uint32_t home = hash_slot(e.first, 32 - eb_bits);
+    for (const Edge& e : edges) {
+        const uint64_t ek = edge_key(e.parent, e.sym);
+        const uint32_t home = hash_slot(ek, 32 - eb_bits);
         uint32_t b = home, probes = 1;
         size_t slot = 0;
         for (bool placed = false; !placed;) {
@@ -202,21 +201,22 @@ HostPatternTable build_table(std::vector<Pat>& pats, int W, uint32_t uni_n) {
         t.max_probe_edge = std::max(t.max_probe_edge, probes);
         if (b != home) t.edges[size_t(home) * kEdgeBucket * 4 + 1] |= kDisplacedBit;
         uint32_t* d = &t.edges[slot * 4];
-        d[0] = uint32_t(e.first);
-        d[1] |= uint32_t(e.first >> 32);
-        d[2] = e.second | (node_kids[e.second] ? kHasKidsBit : 0u);  // node ids stay below 2^31
-        d[3] = node_woff[e.second];
+        d[0] = uint32_t(ek);
+        d[1] |= uint32_t(ek >> 32);
+        d[2] = e.child | (node_kids[e.child] ? kHasKidsBit : 0u);  // node ids stay below 2^31
+        d[3] = node_woff[e.child];
     }
+    tm.mark("general: edge table");
     return t;
 }
 
-// ---- packed tables (layout.h, "PACKED TABLES").  `pats` must already be sorted and merged (build_table did it).
+// ---- packed tables (layout.h, "PACKED TABLES").  `S` must be sorted and merged.
 // Not eligible (present = false) when a pattern symbol is outside [1, 0xFFFE]: the general tables/kernel handle
-// such a model.  A merged row with a value outside i16 keeps its slot with zero weights and kPkWide (patterns of
-// <= 3 chars: the kernel takes the row from the general tables) or goes to `xrows` as i32 (longer patterns).
+// such a model.  A merged row with a value outside its fields keeps its node with zero weights and a wide flag (patterns
+// of <= 3 chars: the kernel takes the row from the general tables) or goes to `xrows` as i32 (longer patterns).
 inline bool fits_i16(int32_t v) { return v >= -32768 && v <= 32767; }
 inline uint32_t pack16(int32_t lo, int32_t hi) { return (uint32_t(lo) & 0xFFFFu) | (uint32_t(hi) << 16); }
-// n signed `bits`-wide fields, little-endian from bit 0 of d[0..3] (OR-ed in: the flag bits are left alone)
+// n signed `bits`-wide fields, little-endian from bit 0 of d[0..] (OR-ed in: other bits are left alone)
 inline void pack_fields(uint32_t* d, const int32_t* v, int n, int bits) {
     for (int j = 0; j < n; ++j) {
         const uint64_t f = uint64_t(uint32_t(v[j])) & ((uint64_t(1) << bits) - 1);
@@ -225,9 +225,9 @@ inline void pack_fields(uint32_t* d, const int32_t* v, int n, int bits) {
         if (r + bits > 32) d[q + 1] |= uint32_t(f >> (32 - r));
     }
 }
-inline bool row_fits(const std::vector<int32_t>& row, int bits) {
-    for (int32_t v : row)
-        if (!fits_field(v, bits)) return false;
+inline bool row_fits(const int32_t* row, uint32_t n, int bits) {
+    for (uint32_t k = 0; k < n; ++k)
+        if (!fits_field(row[k], bits)) return false;
     return true;
 }
 
@@ -248,247 +248,317 @@ uint32_t* mini_insert(std::vector<uint32_t>& arena, uint32_t dw, uint32_t ref, u
     return &arena[(size_t(base) + i) * dw];
 }
 
-HostPackedTable build_packed(const std::vector<Pat>& pats) {
+// First-fit placement of child rows into a double array (Tarjan-Yao row displacement): `cols` = the sorted child symbols
+// of one parent; returns the smallest base d >= from, a multiple of `align`, with every slot d + cols[i] free, and takes
+// the slots.  A failed try jumps past the run of taken slots that blocked it instead of stepping by one.
+struct Occupancy {
+    std::vector<uint64_t> w;
+    bool test(size_t i) const { return (i >> 6) < w.size() && ((w[i >> 6] >> (i & 63)) & 1u); }
+    void set(size_t i) {
+        if ((i >> 6) >= w.size()) w.resize(std::max((i >> 6) + 1, w.size() * 2), 0);
+        w[i >> 6] |= uint64_t(1) << (i & 63);
+    }
+    size_t next_zero(size_t i) const {
+        size_t q = i >> 6;
+        if (q >= w.size()) return i;
+        uint64_t v = ~w[q] & (~uint64_t(0) << (i & 63));
+        while (v == 0) {
+            if (++q >= w.size()) return q << 6;
+            v = ~w[q];
+        }
+        return (q << 6) + size_t(__builtin_ctzll(v));
+    }
+    // `first` = the slot the row's first child takes; the base is first - cols[0], which may be negative when `align` is 1
+    // (the kernel adds modulo 2^32); otherwise the base is >= 0 and a multiple of `align`
+    size_t place(const uint32_t* cols, size_t n, size_t align, size_t from_first) {
+        const size_t c0 = cols[0];
+        auto legal = [&](size_t first) {   // the first legal position at or after `first`
+            if (align == 1) return first;
+            if (first < c0) first = c0;
+            return c0 + (first - c0 + align - 1) / align * align;
+        };
+        size_t first = legal(from_first);
+        for (;;) {
+            size_t i = 0;
+            for (; i < n; ++i)
+                if (test(first + (cols[i] - c0))) break;
+            if (i == n) break;
+            const size_t free_at = next_zero(first + (cols[i] - c0));   // the first slot this child could take
+            first = legal(free_at - (cols[i] - c0));                    // > first
+        }
+        for (size_t i = 0; i < n; ++i) set(first + (cols[i] - c0));
+        return first;
+    }
+};
+// Rows arrive largest first.  A row starts its search at the lowest free slot, except that a row of two or more children
+// does not go back further than a look-back window behind where the last row of its size class went: what did not take
+// that row will hardly take this one, and the holes left behind are filled by the one-child rows, which come last and
+// fit anywhere.  Keeps the whole placement linear in the table size.
+struct Placer {
+    Occupancy occ;
+    size_t low = 0, lookback, lookback_small;
+    size_t hint[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    Placer(size_t lb, size_t lb_small) : lookback(lb), lookback_small(lb_small) {}
+    // returns the slot of the row's first child (the row's base = that - cols[0])
+    size_t put(const uint32_t* cols, size_t n, size_t align) {
+        low = occ.next_zero(low);
+        size_t from = low;
+        const size_t cls = n < 8 ? n : 8;
+        const size_t lb = n < 8 ? lookback_small : lookback;
+        if (n > 1 && hint[cls] > lb) from = std::max(from, hint[cls] - lb);
+        const size_t first = occ.place(cols, n, align, from);
+        hint[cls] = first;
+        return first;
+    }
+};
+
+HostPackedTable build_packed(const PatSet& S) {
+    StageTimer tm;
     HostPackedTable t;
-    for (const Pat& p : pats)
-        for (Sym c : p.s)
-            if (c == 0 || c >= kPackedNoMatchSym) return t;
-    auto wide = [](const Pat& p) {
-        for (int32_t v : p.row)
-            if (!fits_i16(v)) return true;
+    // ---- the alphabet: ids in code-point order
+    {
+        std::vector<uint8_t> seen(65536, 0);
+        for (const PatRef& p : S.p)
+            for (uint32_t i = 0; i < p.n; ++i) {
+                const Sym c = S.s(p)[i];
+                if (c == 0 || c >= kNoId) return t;
+                seen[c] = 1;
+            }
+        t.id_of.assign(65536, uint16_t(kNoId));
+        t.cpid.push_back(0);
+        for (uint32_t cp = 1; cp < kNoId; ++cp)
+            if (seen[cp]) { t.id_of[cp] = uint16_t(t.cpid.size()); t.cpid.push_back(cp); }
+        t.n_alpha = uint32_t(t.cpid.size() - 1);
+        t.cpid.push_back(0);   // the id every char outside the alphabet reads its (zero) unigram node at
+    }
+    auto id = [&](Sym c) { return uint32_t(t.id_of[c]); };
+    auto wide16 = [&](const PatRef& p) {
+        for (uint32_t k = 0; k < p.rlen; ++k)
+            if (!fits_i16(S.row(p)[k])) return true;
         return false;
     };
-    t.uni.assign(size_t(65536) * 4, 0);
+    t.uni.assign(size_t(t.n_alpha + 2) * 4, 0);
 
-    // ---- trie over the patterns of >= 2 chars: prefixes (depth 2) own nodes (depth >= 3)
-    struct Node { Sym sym; uint32_t depth; const Pat* pat; std::vector<uint32_t> kids; uint32_t ref; };
-    struct Prefix { uint32_t key; const Pat* pat; std::vector<uint32_t> kids; };
+    // ---- trie over the patterns of >= 2 chars by one scan: prefixes (depth 2) own nodes (depth >= 3)
+    struct Node { uint32_t sym, depth; const PatRef* pat; uint32_t parent; uint32_t ref; };   // parent: prefix index at depth 3, node index below
+    struct Prefix { uint32_t key; const PatRef* pat; uint32_t slot; };
     std::vector<Node> nodes;
     std::vector<Prefix> prefixes;
-    std::unordered_map<uint32_t, uint32_t> prefix_of;
-    std::unordered_map<uint64_t, uint32_t> pchild, nchild;   // (prefix | node index) << 21 | sym -> node index
-    uint32_t max_depth = 0;
-    for (const Pat& p : pats) {
-        const size_t n = p.s.size();
-        if (n == 1) {
-            uint32_t* d = &t.uni[size_t(p.s[0]) * 4];
-            if (!row_fits(p.row, kUniFieldBits)) { d[3] = kUniWideBit; ++t.n_wide; }
-            else pack_fields(d, p.row.data(), 6, kUniFieldBits);
-            continue;
-        }
-        const uint32_t key = p.s[0] | (p.s[1] << 16);
-        auto it = prefix_of.find(key);
-        uint32_t pi;
-        if (it == prefix_of.end()) {
-            pi = uint32_t(prefixes.size());
-            prefixes.push_back({key, nullptr, {}});
-            prefix_of.emplace(key, pi);
-        } else pi = it->second;
-        if (n == 2) { prefixes[pi].pat = &p; continue; }
-        uint32_t cur = 0;
-        for (size_t i = 2; i < n; ++i) {
-            auto& map = (i == 2) ? pchild : nchild;
-            const uint64_t ck = (uint64_t(i == 2 ? pi : cur) << 21) | p.s[i];
-            auto f = map.find(ck);
-            if (f == map.end()) {
+    std::vector<const PatRef*> uni_pat(size_t(t.n_alpha) + 2, nullptr);
+    {
+        std::vector<uint32_t> path;   // path[i] = node of depth 3 + i of the previous pattern
+        const PatRef* prev = nullptr;
+        for (const PatRef& p : S.p) {
+            const Sym* s = S.s(p);
+            if (p.n == 1) { uni_pat[id(s[0])] = &p; continue; }
+            const bool same_prefix = prev && (prev->key3 >> 21) == (p.key3 >> 21);
+            if (!same_prefix) {
+                prefixes.push_back({id(s[0]) | (id(s[1]) << 16), nullptr, 0});
+                path.clear();
+            }
+            if (p.n == 2) { prefixes.back().pat = &p; prev = &p; continue; }   // the first pattern of its prefix
+            const uint32_t keep = same_prefix ? S.lcp(*prev, p) : 2;              // >= 2, < p.n, <= prev->n
+            path.resize(keep - 2);
+            for (uint32_t i = keep; i < p.n; ++i) {
                 const uint32_t ni = uint32_t(nodes.size());
-                nodes.push_back({p.s[i], uint32_t(i + 1), nullptr, {}, 0});
-                map.emplace(ck, ni);
-                if (i == 2) prefixes[pi].kids.push_back(ni); else nodes[cur].kids.push_back(ni);
-                cur = ni;
-            } else cur = f->second;
+                nodes.push_back({id(s[i]), i + 1, nullptr, i == 2 ? uint32_t(prefixes.size() - 1) : path.back(), 0});
+                path.push_back(ni);
+            }
+            nodes[path.back()].pat = &p;
+            prev = &p;
         }
-        nodes[cur].pat = &p;
-        max_depth = std::max<uint32_t>(max_depth, uint32_t(n));
     }
-    t.n_deep = 0;
+    // children lists (CSR, in symbol order: a parent's children are created in that order)
+    std::vector<uint32_t> nkid_off(nodes.size() + 1, 0), pkid_off(prefixes.size() + 1, 0), nkid(0), pkid(0);
+    for (const Node& nd : nodes) ++(nd.depth == 3 ? pkid_off : nkid_off)[nd.parent + 1];
+    for (size_t i = 0; i < nodes.size(); ++i) nkid_off[i + 1] += nkid_off[i];
+    for (size_t i = 0; i < prefixes.size(); ++i) pkid_off[i + 1] += pkid_off[i];
+    nkid.resize(nkid_off.back()); pkid.resize(pkid_off.back());
+    {
+        std::vector<uint32_t> nfill(nkid_off.begin(), nkid_off.end() - 1), pfill(pkid_off.begin(), pkid_off.end() - 1);
+        for (uint32_t i = 0; i < nodes.size(); ++i) {
+            const Node& nd = nodes[i];
+            if (nd.depth == 3) pkid[pfill[nd.parent]++] = i; else nkid[nfill[nd.parent]++] = i;
+        }
+    }
+    auto n_kids = [&](uint32_t ni) { return nkid_off[ni + 1] - nkid_off[ni]; };
+    auto kid = [&](uint32_t ni, uint32_t j) { return nkid[nkid_off[ni] + j]; };
+    tm.mark("packed: trie");
 
+    // (on a thread of its own: the placements below do not depend on it; joined before the nodes are written)
     // ---- deep arena: the children mini-table of every node that owns one, deepest owners first (an entry names
     // the table of the node it ends at).  Chains of nodes that carry no row and have a single child are COMPRESSED
     // into the entry of their first node (up to kPackedMaxSkip further symbols), so that a dictionary word of any
     // ordinary length costs one trie step past its third char.
+    std::exception_ptr deep_err;
+    std::thread deep_thread([&] { try {
     t.deep.assign(16, 0);   // entry 0 unused: ref 0 = none
-    t.kids3.assign(4, 0);
-    auto chain_end = [&](uint32_t ki, std::vector<Sym>* skipped) {
+    auto chain_end = [&](uint32_t ki, uint32_t* skipped, uint32_t* n_skipped) {
         uint32_t cur = ki, steps = 0;
-        while (nodes[cur].pat == nullptr && nodes[cur].kids.size() == 1 && steps < kPackedMaxSkip) {
-            cur = nodes[cur].kids[0];
-            if (skipped) skipped->push_back(nodes[cur].sym);
+        while (nodes[cur].pat == nullptr && n_kids(cur) == 1 && steps < kPackedMaxSkip) {
+            cur = kid(cur, 0);
+            if (skipped) skipped[steps] = nodes[cur].sym;
             ++steps;
         }
+        if (n_skipped) *n_skipped = steps;
         return cur;
     };
     std::vector<uint32_t> owners;           // nodes that own a mini-table: depth-3 nodes and chain ends, with children
     {
         std::vector<uint32_t> work;
         for (uint32_t i = 0; i < nodes.size(); ++i)
-            if (nodes[i].depth == 3 && !nodes[i].kids.empty()) work.push_back(i);
+            if (nodes[i].depth == 3 && n_kids(i) != 0) work.push_back(i);
         while (!work.empty()) {
             const uint32_t ni = work.back();
             work.pop_back();
             owners.push_back(ni);
-            for (uint32_t ki : nodes[ni].kids) {
-                const uint32_t e = chain_end(ki, nullptr);
-                if (!nodes[e].kids.empty()) work.push_back(e);
+            for (uint32_t j = 0; j < n_kids(ni); ++j) {
+                const uint32_t e = chain_end(kid(ni, j), nullptr, nullptr);
+                if (n_kids(e) != 0) work.push_back(e);
             }
         }
     }
-    std::sort(owners.begin(), owners.end(), [&](uint32_t x, uint32_t y) { return nodes[x].depth > nodes[y].depth; });
+    std::stable_sort(owners.begin(), owners.end(), [&](uint32_t x, uint32_t y) { return nodes[x].depth > nodes[y].depth; });
     for (uint32_t ni : owners) {
-        Node& nd = nodes[ni];
-        nd.ref = mini_alloc(t.deep, 16, nd.kids.size());
-        for (uint32_t ki : nd.kids) {
-            std::vector<Sym> skipped;
-            const Node& k = nodes[chain_end(ki, &skipped)];      // the node this entry ends at
-            uint32_t* e = mini_insert(t.deep, 16, nd.ref, nodes[ki].sym);
+        nodes[ni].ref = mini_alloc(t.deep, 16, n_kids(ni));
+        for (uint32_t j = 0; j < n_kids(ni); ++j) {
+            const uint32_t ki = kid(ni, j);
+            uint32_t skipped[kPackedMaxSkip], n_skipped = 0;
+            const Node& k = nodes[chain_end(ki, skipped, &n_skipped)];      // the node this entry ends at
+            uint32_t* e = mini_insert(t.deep, 16, nodes[ni].ref, nodes[ki].sym);
             uint32_t fl = 0;
             if (k.pat) {
-                const std::vector<int32_t>& r = k.pat->row;   // depth + 1 values, first = boundary s - 1
-                if (r.size() <= kPackedInlineRow && !wide(*k.pat)) {
+                const int32_t* r = S.row(*k.pat);   // depth + 1 values, first = boundary s - 1
+                const uint32_t rl = k.pat->rlen;
+                if (rl <= kPackedInlineRow && !wide16(*k.pat)) {
                     fl |= kPkHasRow;
-                    for (size_t j = 0; j < r.size(); j += 2) e[8 + j / 2] = pack16(r[j], j + 1 < r.size() ? r[j + 1] : 0);
+                    for (uint32_t q = 0; q < rl; q += 2) e[8 + q / 2] = pack16(r[q], q + 1 < rl ? r[q + 1] : 0);
                 } else {
                     fl |= kPkExtRow;
-                    if (wide(*k.pat)) ++t.n_wide;
+                    if (wide16(*k.pat)) ++t.n_wide;
                     e[8] = uint32_t(t.xrows.size());
-                    t.xrows.insert(t.xrows.end(), r.begin(), r.end());
+                    t.xrows.insert(t.xrows.end(), r, r + rl);
                 }
             }
-            e[0] = nodes[ki].sym | (fl << 16) | (uint32_t(skipped.size()) << 24);
+            e[0] = nodes[ki].sym | (fl << 16) | (n_skipped << 24);
             e[1] = k.ref;
-            for (size_t j = 0; j < skipped.size(); ++j) e[2 + j / 2] |= skipped[j] << (16 * (j & 1));
+            for (uint32_t q = 0; q < n_skipped; ++q) e[2 + q / 2] |= skipped[q] << (16 * (q & 1));
             ++t.n_deep;
         }
     }
     if (t.xrows.empty()) t.xrows.push_back(0);
+    } catch (...) { deep_err = std::current_exception(); } });
+    struct Joiner { std::thread& th; ~Joiner() { if (th.joinable()) th.join(); } } deep_join{deep_thread};
 
-    // ---- placement of the trigram-level children (layout.h): a child (a,b,c) sits in a RIGHT slot of record (a,b)
-    // or in a LEFT slot of record (b,c) -- the record the NEXT start position fetches anyway -- else in the overflow
-    // mini-table of (a,b).  Prefixes with <= 3 children keep them all on the right; the children of bigger prefixes
-    // go left first (targets with the fewest takers first), then into the 3 right slots, then overflow.
-    struct Placed { uint32_t node; Sym lead; };                  // a left child: trie node + its first char
-    std::vector<std::vector<Placed>> lefts(prefixes.size());
-    std::vector<std::vector<uint32_t>> rights(prefixes.size()), overflow(prefixes.size());
+    // ---- bigram level: the bigram nodes of a first char id1 sit at (B1[id1] << bi_shift) + id2.  Rows with the most
+    // children are placed first; the base must fit the 19 bits a unigram node has for it.
+    std::vector<uint32_t> b1(size_t(t.n_alpha) + 2, 0);
+    size_t bi_slots = 0;
     {
-        struct Cand { uint32_t parent, node, target_key; };
-        std::vector<Cand> cands;
-        std::unordered_map<uint32_t, uint32_t> ldeg;
-        for (uint32_t pi = 0; pi < prefixes.size(); ++pi) {
-            const Prefix& pf = prefixes[pi];
-            if (pf.kids.size() <= 3) { rights[pi] = pf.kids; continue; }
-            for (uint32_t ni : pf.kids) {
-                const uint32_t tk = (pf.key >> 16) | (nodes[ni].sym << 16);
-                cands.push_back({pi, ni, tk});
-                ++ldeg[tk];
-            }
+        struct Row { uint32_t id1, first, count; };
+        std::vector<Row> rows;
+        for (uint32_t pi = 0; pi < prefixes.size();) {
+            uint32_t e = pi;
+            while (e < prefixes.size() && (prefixes[e].key & 0xFFFFu) == (prefixes[pi].key & 0xFFFFu)) ++e;
+            rows.push_back({prefixes[pi].key & 0xFFFFu, pi, e - pi});
+            pi = e;
         }
-        std::stable_sort(cands.begin(), cands.end(), [&](const Cand& x, const Cand& y) { return ldeg[x.target_key] < ldeg[y.target_key]; });
-        for (const Cand& c : cands) {
-            auto it = prefix_of.find(c.target_key);
-            uint32_t ti;
-            if (it == prefix_of.end()) {   // the target record exists only to carry left children
-                ti = uint32_t(prefixes.size());
-                prefixes.push_back({c.target_key, nullptr, {}});
-                prefix_of.emplace(c.target_key, ti);
-                lefts.emplace_back(); rights.emplace_back(); overflow.emplace_back();
-            } else ti = it->second;
-            if (lefts[ti].size() < 3) lefts[ti].push_back({c.node, Sym(prefixes[c.parent].key & 0xFFFFu)});
-            else if (rights[c.parent].size() < 3) rights[c.parent].push_back(c.node);
-            else overflow[c.parent].push_back(c.node);
+        std::stable_sort(rows.begin(), rows.end(), [](const Row& x, const Row& y) { return x.count > y.count; });
+        std::vector<uint32_t> cols;
+        // a first guess at the alignment the 19-bit base needs (no interleaving at all would take one span per row; half of
+        // that is typical), raised if the placement does not fit
+        size_t spans = 0;
+        for (const Row& r : rows) spans += (prefixes[r.first + r.count - 1].key >> 16) - (prefixes[r.first].key >> 16) + 1;
+        t.bi_shift = 2;
+        while (t.bi_shift < 8 && (size_t(kUniBaseMask) << t.bi_shift) < spans / 2) ++t.bi_shift;
+        for (;; ++t.bi_shift) {
+            if (t.bi_shift > 8) return t;   // not placeable within the format: the general tables serve the model
+            Placer pl(8192, 8192);
+            bool ok = true;
+            size_t top = 0;
+            for (const Row& r : rows) {
+                cols.clear();
+                for (uint32_t j = 0; j < r.count; ++j) cols.push_back(prefixes[r.first + j].key >> 16);   // ascending
+                const size_t d = pl.put(cols.data(), cols.size(), size_t(1) << t.bi_shift) - cols[0];
+                if ((d >> t.bi_shift) > kUniBaseMask) { ok = false; break; }
+                b1[r.id1] = uint32_t(d >> t.bi_shift);
+                for (uint32_t j = 0; j < r.count; ++j) prefixes[r.first + j].slot = uint32_t(d + cols[j]);
+                top = std::max(top, d + cols.back() + 1);
+            }
+            if (ok) { bi_slots = top; break; }
         }
     }
-
-    // ---- records
-    auto child_entry = [&](uint32_t* e, const Node& k, Sym sym) {
-        uint32_t fl = 0;
-        if (k.pat && wide(*k.pat)) { fl |= kPkWide; ++t.n_wide; }
-        else if (k.pat) { e[1] = pack16(k.pat->row[0], k.pat->row[1]); e[2] = pack16(k.pat->row[2], k.pat->row[3]); }
-        e[0] = sym | (fl << 16);
-        e[3] = k.ref;
-    };
-    t.rec_bits = bits_for(prefixes.size());
-    if (t.rec_bits > 24) return t;   // byte offsets of records stay below 4 GB
-    const uint32_t rmask = (1u << t.rec_bits) - 1, rshift = 32 - t.rec_bits;
-    t.rec.assign((size_t(1) << t.rec_bits) * 32, 0);
-    // perfect hash (layout.h): one seed byte per bucket, buckets placed largest first
-    std::vector<uint32_t> slot_of(prefixes.size(), 0);
+    // any id2 may be asked of any base: keep 65536 nodes of slack behind the highest base
     {
-        t.seed_bits = 4;
-        while ((size_t(3) << t.seed_bits) < prefixes.size()) ++t.seed_bits;   // about 3 keys per bucket
-        const uint32_t bshift = 32 - t.seed_bits;
-        t.seed.assign(size_t(1) << t.seed_bits, 0);
-        std::vector<std::vector<uint32_t>> buckets(size_t(1) << t.seed_bits);
-        for (uint32_t pi = 0; pi < prefixes.size(); ++pi) buckets[packed_ph_bucket(prefixes[pi].key, bshift)].push_back(pi);
-        std::vector<uint32_t> order(buckets.size());
-        for (uint32_t i = 0; i < order.size(); ++i) order[i] = i;
-        std::stable_sort(order.begin(), order.end(), [&](uint32_t x, uint32_t y) { return buckets[x].size() > buckets[y].size(); });
-        std::vector<uint8_t> used(size_t(1) << t.rec_bits, 0);
-        // test hook: fewer seeds to try, so that the linear-probing fallback gets exercised
-        const char* dbg = std::getenv("VPT_DEBUG_PH_SEEDS");
-        const uint32_t max_seed = dbg ? std::min<uint32_t>(255u, uint32_t(std::atoi(dbg))) : 255u;
-        std::vector<uint32_t> trial;
-        for (uint32_t bi : order) {
-            const std::vector<uint32_t>& keys = buckets[bi];
-            if (keys.empty()) break;
-            uint32_t seed = 0;
-            for (; seed < max_seed; ++seed) {
-                trial.clear();
-                bool ok = true;
-                for (uint32_t pi : keys) {
-                    const uint32_t sl = packed_ph_slot(prefixes[pi].key, seed, rshift);
-                    if (used[sl] || std::find(trial.begin(), trial.end(), sl) != trial.end()) { ok = false; break; }
-                    trial.push_back(sl);
-                }
-                if (ok) break;
-            }
-            if (seed >= max_seed) seed = 255;
-            t.seed[bi] = uint8_t(seed);
-            if (seed < 255) {
-                for (size_t j = 0; j < keys.size(); ++j) { slot_of[keys[j]] = trial[j]; used[trial[j]] = 1; }
-                continue;
-            }
-            for (uint32_t pi : keys) {   // fallback: linear probing from the seed-255 slot, the home record says where to
-                const uint32_t home = packed_ph_slot(prefixes[pi].key, 255, rshift);
-                uint32_t b = home, probes = 1;
-                while (used[b]) { b = (b + 1) & rmask; ++probes; }
-                used[b] = 1;
-                slot_of[pi] = b;
-                t.max_probe = std::max(t.max_probe, probes);
-                if (b != home) {
-                    const uint32_t d = (b - home) & rmask;
-                    t.rec[size_t(home) * 32 + 3] |= (kPkDisp | (d <= 8 ? 1u << (kPkHopShift + d - 1) : kPkFar)) << 16;
-                    ++t.n_disp;
-                }
-            }
+        size_t max_base = 0;
+        for (uint32_t v : b1) max_base = std::max<size_t>(max_base, size_t(v) << t.bi_shift);
+        bi_slots = std::max(bi_slots, max_base + 65536);
+    }
+    if (bi_slots >= kTriParentMask) return t;
+    tm.mark("packed: bigram placement");
+
+    // ---- trigram level: the children of bigram node p sit at B2[p] + id3
+    std::vector<uint32_t> b2(prefixes.size(), 0);
+    std::vector<uint32_t> tri_slot(nodes.size(), 0);   // depth-3 nodes only
+    size_t tri_slots = 1;
+    {
+        std::vector<uint32_t> order;
+        for (uint32_t pi = 0; pi < prefixes.size(); ++pi)
+            if (pkid_off[pi + 1] != pkid_off[pi]) order.push_back(pi);
+        std::stable_sort(order.begin(), order.end(), [&](uint32_t x, uint32_t y) { return pkid_off[x + 1] - pkid_off[x] > pkid_off[y + 1] - pkid_off[y]; });
+        Placer pl(4096, 256);
+        pl.occ.set(0);   // slot 0 stays free: the base of a node without children is 0
+        std::vector<uint32_t> cols;
+        for (uint32_t pi : order) {
+            cols.clear();
+            for (uint32_t j = pkid_off[pi]; j < pkid_off[pi + 1]; ++j) cols.push_back(nodes[pkid[j]].sym);   // ascending
+            const size_t first = pl.put(cols.data(), cols.size(), 1);
+            b2[pi] = uint32_t(first) - cols[0];   // modulo 2^32: a row of high ids may start below slot cols[0]
+            for (uint32_t j = pkid_off[pi]; j < pkid_off[pi + 1]; ++j) tri_slot[pkid[j]] = uint32_t(first + (nodes[pkid[j]].sym - cols[0]));
+            tri_slots = std::max(tri_slots, first + (cols.back() - cols[0]) + 1);
         }
     }
+    if (tri_slots >= (size_t(1) << 28)) return t;
+    tm.mark("packed: trigram placement");
+
+    // ---- emit
+    deep_thread.join();
+    if (deep_err) std::rethrow_exception(deep_err);
+    tm.mark("packed: deep arena (joined)");
+    for (uint32_t i = 1; i <= t.n_alpha; ++i) {
+        uint32_t* d = &t.uni[size_t(i) * 4];
+        if (const PatRef* p = uni_pat[i]) {
+            if (!row_fits(S.row(*p), 6, kUniFieldBits)) { d[3] |= kUniWideBit; ++t.n_wide; }
+            else pack_fields(d, S.row(*p), 6, kUniFieldBits);
+        }
+        d[3] |= b1[i] << kUniBaseShift;
+    }
+    t.bi.assign(bi_slots * 8, 0);
+    t.tri.assign(tri_slots * 4, 0);
     for (uint32_t pi = 0; pi < prefixes.size(); ++pi) {
         const Prefix& pf = prefixes[pi];
-        const uint32_t b = slot_of[pi];
-        uint32_t* r = &t.rec[size_t(b) * 32];
-        uint32_t fl = 0;
-        r[16] = pf.key;
-        if (pf.pat && !row_fits(pf.pat->row, kBiFieldBits)) { fl |= kPkWide; ++t.n_wide; }
-        else if (pf.pat) pack_fields(r, pf.pat->row.data(), 5, kBiFieldBits);   // bits 0..109; the flags half of dword 3 may already name displaced keys
-        for (size_t j = 0; j < rights[pi].size(); ++j) child_entry(r + 4 + 4 * j, nodes[rights[pi][j]], nodes[rights[pi][j]].sym);
-        for (size_t j = 0; j < lefts[pi].size(); ++j) child_entry(r + 20 + 4 * j, nodes[lefts[pi][j].node], lefts[pi][j].lead);
-        if (!overflow[pi].empty()) {
-            fl |= kPkOv;
-            const uint32_t ref = mini_alloc(t.kids3, 4, overflow[pi].size());
-            uint64_t mask = 0;
-            for (uint32_t ni : overflow[pi]) {
-                const Node& k = nodes[ni];
-                child_entry(mini_insert(t.kids3, 4, ref, k.sym), k, k.sym);
-                mask |= uint64_t(1) << packed_filter_bit(k.sym);
-            }
-            r[17] = ref; r[18] = uint32_t(mask); r[19] = uint32_t(mask >> 32);
-            t.n_overflow += uint32_t(overflow[pi].size());
+        uint32_t* r = &t.bi[size_t(pf.slot) * 8];
+        r[0] = pf.key;
+        if (pf.pat && !row_fits(S.row(*pf.pat), 5, kBiFieldBits)) { r[3] |= kBiWideBit; ++t.n_wide; }
+        else if (pf.pat) pack_fields(r + 1, S.row(*pf.pat), 5, kBiFieldBits);
+        uint64_t mask = 0;
+        for (uint32_t j = pkid_off[pi]; j < pkid_off[pi + 1]; ++j) {
+            const Node& k = nodes[pkid[j]];
+            mask |= uint64_t(1) << packed_filter_bit(k.sym);
+            uint32_t* e = &t.tri[size_t(tri_slot[pkid[j]]) * 4];
+            uint32_t fl = 0;
+            if (k.pat && wide16(*k.pat)) { fl |= kPkWide; ++t.n_wide; }
+            else if (k.pat) { const int32_t* w = S.row(*k.pat); e[1] = pack16(w[0], w[1]); e[2] = pack16(w[2], w[3]); }
+            e[0] = (pf.slot + 1) | (fl << 24);
+            e[3] = k.ref;
+            ++t.n_tri;
         }
-        r[3] |= fl << 16;
-        t.n_children += uint32_t(pf.kids.size());
-        t.n_left += uint32_t(lefts[pi].size());
+        r[4] = b2[pi]; r[5] = uint32_t(mask); r[6] = uint32_t(mask >> 32); r[7] = pkid_off[pi + 1] - pkid_off[pi];
     }
-    t.n_rec = uint32_t(prefixes.size());
+    t.n_bi = uint32_t(prefixes.size());
+    tm.mark("packed: nodes");
+    if (tm.on) std::fprintf(stderr, "[vpt compile] alphabet %u, bigram nodes %u in %zu slots (shift %u), trigram nodes %u in %zu slots, deep entries %u, wide rows %u\n",
+                            t.n_alpha, t.n_bi, bi_slots, t.bi_shift, t.n_tri, tri_slots, t.n_deep, t.n_wide);
     t.present = true;
     return t;
 }
@@ -741,12 +811,27 @@ CompiledModel compile_model(const ModelData& m, bool predict_tags) {
     const int wc = m.char_window;
     if (!((m.char_ngrams.empty() && m.dict.empty()) || wc == 0)) {
         if (wc > kMaxWindow) throw ModelError("InvalidModelError: char_window_size above 8 is not supported");
-        std::vector<Pat> pats;
-        pats.reserve(m.char_ngrams.size() + m.dict.size());
+        StageTimer tm;
+        PatSet pats;
+        {
+            size_t n_syms = 0, n_rows = 0;
+            for (const auto& d : m.char_ngrams) { n_syms += d.ngram.size(); n_rows += size_t(row_len(int(d.ngram.size()), wc)); }
+            for (const auto& d : m.dict) { n_syms += d.word.size(); n_rows += size_t(row_len(int(d.word.size()), wc)); }
+            pats.reserve(m.char_ngrams.size() + m.dict.size(), n_syms, n_rows);
+        }
         for (const auto& d : m.char_ngrams) add_ngram(pats, d.ngram, d.weights, wc, true);
         for (const auto& d : m.dict) add_word(pats, d.word, d.weights, wc);
-        c.chars = build_table(pats, wc, kUniDirectChars);
-        if (wc == 3) c.packed = build_packed(pats);
+        tm.mark("pattern rows");
+        pats.finish();
+        tm.mark("sort + merge");
+        // the general and the packed tables are independent of each other: two threads
+        std::exception_ptr packed_err;
+        std::thread packed_thread([&] {
+            try { if (wc == 3) c.packed = build_packed(pats); } catch (...) { packed_err = std::current_exception(); }
+        });
+        try { c.chars = build_table(pats, wc, kUniDirectChars); } catch (...) { packed_thread.join(); throw; }
+        packed_thread.join();
+        if (packed_err) std::rethrow_exception(packed_err);
     }
 
     // TypeScorer::new: None without n-grams or window (type_scorer.rs:109-111); the window table when
@@ -786,8 +871,9 @@ CompiledModel compile_model(const ModelData& m, bool predict_tags) {
         } else {
             if (wt > kMaxWindow) throw ModelError("InvalidModelError: type_window_size above 8 is not supported");
             c.type_kind = kTypePatternTable;
-            std::vector<Pat> pats;
+            PatSet pats;
             for (const auto& d : m.type_ngrams) add_ngram(pats, d.ngram, d.weights, wt, false);
+            pats.finish();
             c.types = build_table(pats, wt, kUniDirectTypes);
         }
     }

@@ -28,20 +28,21 @@ struct HostPatternTable {
     }
 };
 
-// Packed tables of the specialised kernel (layout.h, "PACKED TABLES").
+// Packed tables of the specialised kernel (layout.h, "PACKED TABLES": a double-array trie over the first three symbols).
 struct HostPackedTable {
     bool present = false;          // false: the model is not eligible (see build notes in tables.cpp)
-    std::vector<uint32_t> uni;     // 65536 rows x 4 dwords
-    std::vector<uint32_t> rec;     // 32 dwords per record
-    std::vector<uint32_t> kids3;   // 4 dwords per entry
-    std::vector<uint32_t> deep;    // 8 dwords per entry
+    std::vector<uint32_t> uni;     // (n_alpha + 2) unigram nodes x 4 dwords, indexed by id
+    std::vector<uint32_t> bi;      // 8 dwords per bigram node
+    std::vector<uint32_t> tri;     // 4 dwords per trigram node
+    std::vector<uint32_t> deep;    // 16 dwords per entry
     std::vector<int32_t> xrows;    // external i32 rows
     std::vector<uint32_t> trow;    // kTypeRowCount type rows x 4 dwords, empty when the type n-grams do not fit the form
-    std::vector<uint8_t> seed;     // perfect-hash seed per bucket of record keys
-    uint32_t rec_bits = 4, seed_bits = 0;
+    std::vector<uint32_t> cpid;    // n_alpha + 2: id -> code point
+    std::vector<uint16_t> id_of;   // 65536: BMP code point -> id (kNoId: no pattern contains it)
+    uint32_t n_alpha = 0, bi_shift = 2;
     // statistics
-    uint32_t n_rec = 0, n_children = 0, n_left = 0, n_overflow = 0, n_deep = 0, n_disp = 0, max_probe = 0, n_wide = 0;
-    uint64_t bytes() const { return 4ull * (uni.size() + rec.size() + kids3.size() + deep.size() + xrows.size() + trow.size()) + seed.size(); }
+    uint32_t n_bi = 0, n_tri = 0, n_deep = 0, n_wide = 0;
+    uint64_t bytes() const { return 4ull * (uni.size() + bi.size() + tri.size() + deep.size() + xrows.size() + trow.size() + cpid.size()); }
 };
 
 // Tag prediction tables (Predictor::predict_tags, predictor.rs:546-637), see kernels_tags.hip.
