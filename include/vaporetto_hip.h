@@ -79,6 +79,23 @@ vpt_status vpt_predictor_create(const uint8_t *model_bytes, size_t len, int pred
 void vpt_predictor_destroy(vpt_predictor *p);
 
 /* ---------------------------------------------------------------------------------------------------------
+ * The compiled predictor: Predictor::serialize_to_vec / deserialize_from_slice_unchecked   (predictor.rs:640-664)
+ *
+ * Compiling a bccwj-suw+unidic-sized model takes seconds; the result -- every device table plus a fixed-size
+ * description -- can be saved and loaded back without the model (a format of this library: not the reference's
+ * daachorse-internal one, and only valid for the library version that wrote it; like the reference's *_unchecked
+ * loader it trusts the bytes beyond a version check and a checksum), and copied from one GPU to another device to
+ * device (xGMI between the GPUs of a node), which is how the ranks of a multi-GPU job get their predictor.
+ *
+ * vpt_predictor_save : *needed = the size of the compiled form; with out == NULL only that; else capacity must cover it.
+ * vpt_predictor_load : VPT_INVALID_MODEL "not a compiled predictor" | "... version mismatch" | "... truncated" |
+ *                      "... corrupt (checksum)".
+ * vpt_predictor_clone_to_device: a predictor on device_id with the same tables (hipMemcpyPeer; same device: a copy). */
+vpt_status vpt_predictor_save(const vpt_predictor *p, uint8_t *out, size_t capacity, size_t *needed);
+vpt_status vpt_predictor_load(const uint8_t *blob, size_t len, int device_id, vpt_predictor **out);
+vpt_status vpt_predictor_clone_to_device(const vpt_predictor *src, int device_id, vpt_predictor **out);
+
+/* ---------------------------------------------------------------------------------------------------------
  * Sentence::from_raw's bookkeeping for a batch     (sentence.rs:160-196)
  *
  * Sentence i is utf8[byte_offsets[i] .. byte_offsets[i+1]) (valid UTF-8, as a Rust &str always is).
@@ -255,11 +272,17 @@ typedef struct vpt_model_info {
     uint32_t type_kind;            /* 0 none, 1 window table (cache variant), 2 pattern tables */
     uint64_t device_table_bytes;   /* bytes all tables occupy in HBM */
     uint64_t hot_table_bytes;      /* bytes of the tables the scoring kernel chosen for this model reads */
-    uint32_t packed;               /* 1: the specialised kernel's packed tables (128-byte prefix records) are in use */
+    uint32_t packed;               /* 1: the specialised kernel's packed tables (double-array trie, layout.h) are in use */
     uint32_t n_displaced;          /* hash-table keys that do not sit in their home slot */
-    uint32_t type_rows;            /* 1: type scores come from the 512 LDS type rows (else: window table / patterns) */
-    uint32_t n_overflow_children;  /* trigram-level children kept outside their prefix record (more than six) */
+    uint32_t type_rows;            /* 1: type scores come from the 294 LDS type rows (else: window table / patterns) */
+    uint32_t n_overflow_children;  /* 0 (kept for layout compatibility: the double-array tables have no overflow) */
+    uint32_t predict_tags;         /* the predict_tags flag the predictor was created with (0 from vpt_model_inspect without it) */
 } vpt_model_info;
+
+/* Model::read_slice's decoding (model.rs:127-135) without keeping the model: validates the bytes ("VaporettoTokenizer 0.5.0\n"
+ * + bincode) and reports how many of them the model takes -- read_slice returns the rest to the caller.  Host only.
+ * Errors: VPT_INVALID_MODEL "model version mismatch" | a decode error. */
+vpt_status vpt_model_read_len(const uint8_t *model_bytes, size_t len, size_t *consumed);
 
 /* Parses + validates + compiles the tables on the host only (no device).  Same errors as create. */
 vpt_status vpt_model_inspect(const uint8_t *model_bytes, size_t len, int predict_tags, vpt_model_info *info);

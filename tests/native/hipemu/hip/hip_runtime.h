@@ -34,8 +34,6 @@
 // lock-step marker of the kernels (device_common.h): the lanes of the wave meet here
 #define VPT_WAVE_LOCKSTEP() ::hipemu::wave_sync()
 #define VPT_PIN(x) ((void)0)   /* a code-generation hint on the GPU */
-#define VPT_STREAM_LOAD16(ptr) (*reinterpret_cast<const uint4*>(ptr))   /* cache hints on the GPU */
-#define VPT_STREAM_STORE(val, ptr) (*(ptr) = (val))
 
 struct uint2 { uint32_t x, y; };
 struct uint4 { uint32_t x, y, z, w; } __attribute__((aligned(16)));
@@ -50,7 +48,7 @@ struct dim3 {
 typedef int hipError_t;
 enum { hipSuccess = 0, hipErrorInvalidValue = 1, hipErrorOutOfMemory = 2 };
 enum hipMemcpyKind { hipMemcpyHostToHost, hipMemcpyHostToDevice, hipMemcpyDeviceToHost, hipMemcpyDeviceToDevice };
-enum { hipStreamNonBlocking = 1 };
+enum { hipStreamNonBlocking = 1, hipHostMallocDefault = 0, hipEventDisableTiming = 2 };
 struct hipemu_stream;
 struct hipemu_event;
 typedef hipemu_stream* hipStream_t;
@@ -64,6 +62,12 @@ hipError_t hipMalloc(void** p, size_t bytes);
 hipError_t hipFree(void* p);
 hipError_t hipMemcpy(void* dst, const void* src, size_t bytes, hipMemcpyKind kind);
 hipError_t hipMemcpyAsync(void* dst, const void* src, size_t bytes, hipMemcpyKind kind, hipStream_t s);
+hipError_t hipMemcpyPeer(void* dst, int dst_device, const void* src, int src_device, size_t bytes);
+hipError_t hipHostMalloc(void** p, size_t bytes, unsigned flags);
+hipError_t hipHostFree(void* p);
+hipError_t hipStreamWaitEvent(hipStream_t s, hipEvent_t e, unsigned flags);
+hipError_t hipEventSynchronize(hipEvent_t e);
+hipError_t hipEventCreateWithFlags(hipEvent_t* e, unsigned flags);
 hipError_t hipMemset(void* dst, int value, size_t bytes);
 hipError_t hipMemsetAsync(void* dst, int value, size_t bytes, hipStream_t s);
 hipError_t hipStreamCreateWithFlags(hipStream_t* s, unsigned flags);

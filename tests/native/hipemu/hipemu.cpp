@@ -243,8 +243,9 @@ using hipemu::kRedZone;
 struct hipemu_stream { int unused; };
 struct hipemu_event { int unused; };
 
-hipError_t hipGetDeviceCount(int* n) { *n = 1; return hipSuccess; }
-hipError_t hipSetDevice(int dev) { return dev == 0 ? hipSuccess : hipErrorInvalidValue; }
+// two pretend devices (one address space), so that the multi-device entry points run on the emulator too
+hipError_t hipGetDeviceCount(int* n) { *n = 2; return hipSuccess; }
+hipError_t hipSetDevice(int dev) { return (dev == 0 || dev == 1) ? hipSuccess : hipErrorInvalidValue; }
 hipError_t hipGetDeviceProperties(hipDeviceProp_t* prop, int) { prop->multiProcessorCount = 2; return hipSuccess; }
 
 hipError_t hipMalloc(void** p, size_t bytes) {
@@ -272,6 +273,12 @@ hipError_t hipFree(void* p) {
 }
 hipError_t hipMemcpy(void* dst, const void* src, size_t bytes, hipMemcpyKind) { std::memcpy(dst, src, bytes); return hipSuccess; }
 hipError_t hipMemcpyAsync(void* dst, const void* src, size_t bytes, hipMemcpyKind, hipStream_t) { std::memcpy(dst, src, bytes); return hipSuccess; }
+hipError_t hipMemcpyPeer(void* dst, int, const void* src, int, size_t bytes) { std::memcpy(dst, src, bytes); return hipSuccess; }
+hipError_t hipHostMalloc(void** p, size_t bytes, unsigned) { *p = std::malloc(bytes ? bytes : 1); return *p ? hipSuccess : hipErrorOutOfMemory; }
+hipError_t hipHostFree(void* p) { std::free(p); return hipSuccess; }
+hipError_t hipStreamWaitEvent(hipStream_t, hipEvent_t, unsigned) { return hipSuccess; }
+hipError_t hipEventSynchronize(hipEvent_t) { return hipSuccess; }
+hipError_t hipEventCreateWithFlags(hipEvent_t* e, unsigned) { *e = new hipemu_event(); return hipSuccess; }
 hipError_t hipMemset(void* dst, int value, size_t bytes) { std::memset(dst, value, bytes); return hipSuccess; }
 hipError_t hipMemsetAsync(void* dst, int value, size_t bytes, hipStream_t) { std::memset(dst, value, bytes); return hipSuccess; }
 hipError_t hipStreamCreateWithFlags(hipStream_t* s, unsigned) { *s = new hipemu_stream(); return hipSuccess; }

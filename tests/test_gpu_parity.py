@@ -871,3 +871,58 @@ def test_tokenize_batch_is_the_whole_pipeline():
     assert st == api._lib.VPT_OK
     batch.sync()
     assert np.array_equal(d_ooff.get(len(texts) + 1), api.count_boundaries(utf8, boff))
+
+
+# ------------------------------------------------------------------------------------------------ compiled form, clones
+def test_compiled_predictor_round_trip_and_clone():
+    """vpt_predictor_save -> vpt_predictor_load and vpt_predictor_clone_to_device give predictors that score and tag
+    exactly like the one compiled from the model (packed path, with tag models; and a model on the general path)."""
+    m = randmodel.rand_model(611, alphabet="kana", wc=3, wt=3, n_char=300, n_dict=300, max_word=9, n_tag_models=6)
+    raw = encode_model(m)
+    model = api.Model.read_slice(raw)[0]
+    pred = api.Predictor(model, True)
+    orc = cbind.OraclePredictor(raw, True)
+    assert pred.info()["packed"] == 1 and pred.info()["predict_tags"] == 1
+    blob = pred.save_compiled()
+    loaded = api.Predictor.load_compiled(blob, model=model)
+    clone = pred.clone_to_device(0)
+    assert loaded.info() == pred.info() == clone.info()
+    mixed = randmodel.ALPHABETS["kana"][:12] + list("漢字A9、")
+    texts = randmodel.rand_sentences(4, m, 1200, alphabet=mixed, max_len=70)
+    base = check_batch(pred, orc, texts)
+    for other in (loaded, clone):
+        got = check_batch(other, orc, texts)
+        assert all(np.array_equal(a, b) for a, b in zip(base, got))
+        utf8, boff = api.pack_texts([t.encode("utf-8") for t in texts])
+        t_a = pred.fill_tags_packed(utf8, boff, base[2], base[1])
+        t_b = other.fill_tags_packed(utf8, boff, base[2], base[1])
+        assert np.array_equal(t_a, t_b)
+    del pred   # the copies own their tables
+    check_batch(loaded, orc, texts[:100])
+    check_batch(clone, orc, texts[:100])
+    # the general path (non-BMP pattern symbols): no packed tables in the compiled form
+    m2 = randmodel.rand_model(612, alphabet="mixed", wc=4, wt=4, n_char=100, n_dict=100, max_word=6)
+    raw2 = encode_model(m2)
+    p2 = api.Predictor(api.Model.read_slice(raw2)[0], False)
+    l2 = api.Predictor.load_compiled(p2.save_compiled())
+    assert l2.info()["packed"] == 0
+    check_batch(l2, cbind.OraclePredictor(raw2), randmodel.rand_sentences(5, m2, 400, alphabet="mixed", max_len=50))
+
+
+def test_compiled_predictor_rejects_damaged_blobs():
+    m = randmodel.rand_model(613, alphabet="kana", wc=3, wt=3, n_char=50, n_dict=50, max_word=5)
+    blob = bytearray(api.Predictor(api.Model.read_slice(encode_model(m))[0], False).save_compiled())
+
+    def refuse(b, what):
+        with pytest.raises(api.VaporettoError) as e:
+            api.Predictor.load_compiled(bytes(b))
+        assert e.value.kind == "InvalidModel" and what in str(e.value), str(e.value)
+
+    refuse(blob[:100], "too short")
+    refuse(b"VaporettoTokenizer 0.5.0\n" + bytes(blob[25:]), "not a compiled predictor")
+    refuse(blob[:-256], "truncated")
+    bad = bytearray(blob); bad[len(bad) // 2] ^= 0x40
+    refuse(bad, "checksum")
+    bad = bytearray(blob); bad[16] ^= 0x01            # the version word
+    refuse(bad, "version mismatch")
+    assert api.Predictor.load_compiled(bytes(blob)).info()["n_char_ngrams"] == len(m.char_ngram_model)

@@ -48,6 +48,7 @@ _AS_IS = [
     "test_device_resident_predict_then_fill_tags", "test_fill_tags_with_offsets_that_do_not_match_the_text",
     "test_write_tokenized_text_on_device", "test_concurrent_host_threads_share_a_predictor",
     "test_write_tagged_text_on_device", "test_tokenize_batch_is_the_whole_pipeline",
+    "test_compiled_predictor_round_trip_and_clone", "test_compiled_predictor_rejects_damaged_blobs",
 ]
 for _name in _AS_IS:
     globals()[_name] = getattr(G, _name)

@@ -27,6 +27,7 @@ class ModelInfo(C.Structure):
         ("max_pattern_chars", C.c_uint32), ("n_short_entries", C.c_uint32), ("n_long_nodes", C.c_uint32),
         ("type_kind", C.c_uint32), ("device_table_bytes", C.c_uint64), ("hot_table_bytes", C.c_uint64),
         ("packed", C.c_uint32), ("n_displaced", C.c_uint32), ("type_rows", C.c_uint32), ("n_overflow_children", C.c_uint32),
+        ("predict_tags", C.c_uint32),
     ]
 
     def as_dict(self):
@@ -40,6 +41,9 @@ SIGNATURES = {
     "vpt_version": (C.c_char_p, []),
     "vpt_predictor_create": (C.c_int, [_P, C.c_size_t, C.c_int, C.c_int, C.POINTER(_P)]),
     "vpt_predictor_destroy": (None, [_P]),
+    "vpt_predictor_save": (C.c_int, [_P, _P, C.c_size_t, C.POINTER(C.c_size_t)]),
+    "vpt_predictor_load": (C.c_int, [_P, C.c_size_t, C.c_int, C.POINTER(_P)]),
+    "vpt_predictor_clone_to_device": (C.c_int, [_P, C.c_int, C.POINTER(_P)]),
     "vpt_count_boundaries": (C.c_int, [_P, _P, C.c_size_t, _P]),
     "vpt_predict_batch": (C.c_int, [_P, _P, _P, C.c_size_t, _P, _P, _P]),
     "vpt_predict_batch_flags": (C.c_int, [_P, _P, _P, C.c_size_t, _P, _P, _P, C.c_uint]),
@@ -65,6 +69,7 @@ SIGNATURES = {
     "vpt_batch_kernel_ms": (C.c_int, [_P, C.POINTER(C.c_float), C.POINTER(C.c_uint32)]),
     "vpt_batch_phase_cycles": (C.c_int, [_P, C.POINTER(C.c_uint64 * 8)]),
     "vpt_model_inspect": (C.c_int, [_P, C.c_size_t, C.c_int, C.POINTER(ModelInfo)]),
+    "vpt_model_read_len": (C.c_int, [_P, C.c_size_t, C.POINTER(C.c_size_t)]),
     "vpt_predictor_info": (C.c_int, [_P, C.POINTER(ModelInfo)]),
 }
 

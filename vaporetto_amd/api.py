@@ -96,9 +96,16 @@ class KyteaFullwidthFilter:
 class Model:
     """model.rs:55-169."""
 
-    def __init__(self, data: modelfmt.ModelData, raw: Optional[bytes] = None):
-        self._data = data
+    def __init__(self, data: Optional[modelfmt.ModelData], raw: Optional[bytes] = None):
+        self._data_ = data      # decoded records; None until somebody asks for them (a 34 MB model takes Python 20 s)
         self._raw = raw
+        assert data is not None or raw is not None
+
+    @property
+    def _data(self) -> modelfmt.ModelData:
+        if self._data_ is None:
+            self._data_ = modelfmt.decode_model(self._raw)[0]
+        return self._data_
 
     @staticmethod
     def read(rdr) -> "Model":  # model.rs:138-153
@@ -106,11 +113,15 @@ class Model:
 
     @staticmethod
     def read_slice(buf: bytes) -> Tuple["Model", bytes]:  # model.rs:127-135
-        try:
-            data, used = modelfmt.decode_model(buf)
-        except modelfmt.ModelFormatError as e:
-            raise VaporettoError("InvalidModel", "InvalidModelError: %s" % e) from e
-        return Model(data, bytes(buf[:used])), bytes(buf[used:])
+        """The bytes are validated by the library's decoder (the same one vpt_predictor_create uses); the Python records
+        behind dictionary() / tag_models() are decoded on first use."""
+        buf = bytes(buf)
+        L = _lib.load()
+        used = C.c_size_t(0)
+        st = L.vpt_model_read_len(buf, len(buf), C.byref(used))
+        if st != _lib.VPT_OK:
+            raise VaporettoError("InvalidModel" if st == _lib.VPT_INVALID_MODEL else "Runtime", L.vpt_last_error().decode("utf-8"))
+        return Model(None, buf[:used.value]), buf[used.value:]
 
     def to_vec(self) -> bytes:  # model.rs:99-104
         if self._raw is None:
@@ -276,6 +287,49 @@ class Predictor:
     @property
     def handle(self):
         return self._h
+
+    @classmethod
+    def _adopt(cls, handle, model: Optional[Model], device: int) -> "Predictor":
+        self = cls.__new__(cls)
+        self._h = handle
+        self._model = model
+        self._tag_models = None
+        self.device = device
+        self._predict_tags = bool(self.info()["predict_tags"])
+        return self
+
+    def save_compiled(self) -> bytes:
+        """Predictor::serialize_to_vec (predictor.rs:640-651), in this library's own format: the device tables + a header."""
+        L = _lib.load()
+        need = C.c_size_t(0)
+        st = L.vpt_predictor_save(self._h, None, 0, C.byref(need))
+        if st != _lib.VPT_OK:
+            _raise(st)
+        buf = np.empty(need.value, dtype=np.uint8)
+        st = L.vpt_predictor_save(self._h, buf.ctypes.data, buf.nbytes, C.byref(need))
+        if st != _lib.VPT_OK:
+            _raise(st)
+        return buf.tobytes()
+
+    @classmethod
+    def load_compiled(cls, blob, device: int = 0, model: Optional[Model] = None) -> "Predictor":
+        """Predictor::deserialize_from_slice_unchecked (predictor.rs:653-664).  `model` is only needed to turn tag indices
+        into tag strings (Sentence.tags); scoring does not use it."""
+        arr = np.frombuffer(blob, dtype=np.uint8)
+        h = C.c_void_p()
+        st = _lib.load().vpt_predictor_load(arr.ctypes.data, arr.nbytes, device, C.byref(h))
+        if st != _lib.VPT_OK:
+            _raise(st)
+        return cls._adopt(h, model, device)
+
+    def clone_to_device(self, device: int) -> "Predictor":
+        """The same predictor on another GPU of the node: the compiled tables go device to device (xGMI), nothing is
+        compiled again."""
+        h = C.c_void_p()
+        st = _lib.load().vpt_predictor_clone_to_device(self._h, device, C.byref(h))
+        if st != _lib.VPT_OK:
+            _raise(st)
+        return Predictor._adopt(h, self._model, device)
 
     def info(self) -> dict:
         mi = _lib.ModelInfo()

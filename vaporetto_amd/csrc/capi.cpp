@@ -32,80 +32,58 @@ vpt_status fail(vpt_status st, const std::string& msg) {
             return fail(VPT_RUNTIME_ERROR, std::string("HIP error: ") + hipGetErrorString(e_) + " at " #expr); \
     } while (0)
 
-struct DevicePacked {
-    unsigned char* base = nullptr;
-    uint32_t off[7] = {0, 0, 0, 0, 0, 0, 0};   // uni, bi, tri, deep, xrows, trow, cpid
-    void release() { (void)hipFree(base); base = nullptr; }
-};
-
-struct DeviceTable {
-    uint32_t *short_tab = nullptr, *uni = nullptr, *edges = nullptr;
-    int32_t* wdata = nullptr;
-    void release() {
-        (void)hipFree(short_tab); (void)hipFree(uni); (void)hipFree(edges); (void)hipFree(wdata);
-        short_tab = uni = edges = nullptr; wdata = nullptr;
-    }
-};
-
 constexpr size_t kTimingRing = 256;     // timed launches remembered per vpt_batch
-constexpr size_t kTablePadBytes = 256;  // probes read whole 16-byte chunks; keep the tail readable
+constexpr size_t kTablePadBytes = 256;  // probes read whole 16-byte chunks; keep the tail of every table readable
 
-template <typename T>
-hipError_t upload(const std::vector<T>& v, T** out) {
-    *out = nullptr;
-    size_t bytes = v.size() * sizeof(T);
-    hipError_t e = hipMalloc(reinterpret_cast<void**>(out), bytes + kTablePadBytes);
-    if (e != hipSuccess) return e;
-    e = hipMemset(*out, 0, bytes + kTablePadBytes);
-    if (e != hipSuccess) return e;
-    if (bytes) e = hipMemcpy(*out, v.data(), bytes, hipMemcpyHostToDevice);
-    return e;
-}
+// Every table of a predictor lives in ONE device allocation (the arena), each in a section of its own, 256-byte aligned
+// and followed by kTablePadBytes of zeros.  With the fixed-size description below (PredictorMeta) the arena IS the compiled
+// predictor: it can be written out and read back (vpt_predictor_save / _load: the analogue of Predictor::serialize_to_vec /
+// deserialize_from_slice_unchecked, predictor.rs:640-664, in a format of our own) and copied to another GPU device to
+// device (vpt_predictor_clone_to_device) without compiling the model again.
+enum Section : int {
+    kSecCShort, kSecCUni, kSecCEdges, kSecCWdata,              // general char tables
+    kSecTShort, kSecTUni, kSecTEdges, kSecTWdata,              // general type tables (type_kind == pattern tables)
+    kSecPUni, kSecPBi, kSecPTri, kSecPDeep, kSecPXrows, kSecPTrow, kSecPCpid,   // packed tables: contiguous, addressed from kSecPUni
+    kSecTypeTable, kSecCtype, kSecCinfo, kSecCid,
+    kSecTagTokTab, kSecTagModels, kSecTagNgrams, kSecTagSyms, kSecTagSlots, kSecTagWeights, kSecTagSlotStr, kSecTagStrOff, kSecTagStrBytes,
+    kSectionCount
+};
+struct TableGeom {
+    uint32_t present, short_bits, edge_bits, stride_dw, uni_dw, uni_n, ext_slot, has_long;
+    int32_t window, lo[3], len[3];
+};
+constexpr char kCompiledMagic[16] = "VaporettoHIP-C\x01";   // 15 chars + NUL
+constexpr uint32_t kCompiledVersion = 2;                    // bump whenever layout.h or a kernel's reading of it changes
+struct PredictorMeta {                                      // plain data: written and read as is (little-endian hosts)
+    char magic[16];
+    uint32_t version, meta_bytes;
+    uint64_t arena_bytes, checksum;
+    uint64_t sec_off[kSectionCount], sec_bytes[kSectionCount];
+    int32_t bias, pad, type_kind, type_window, chunks;
+    uint32_t predict_tags, has_tags, n_tags, tok_bits, max_tag_suffix, tag_use_char, tag_use_type, n_tag_models, n_tag_strings;
+    TableGeom geom[2];                                      // chars, types
+    uint32_t pk_present, pk_n_uni, pk_n_tri, pk_bi_shift, pk_has_trow;
+    vpt_model_info info;
+};
 
-vpt::PatternTableView make_view(const vpt::HostPatternTable& h, const DeviceTable& d) {
-    vpt::PatternTableView v{};
-    v.present = h.present ? 1u : 0u;
-    if (!h.present) return v;
-    v.short_tab = d.short_tab; v.uni = d.uni; v.edges = d.edges; v.wdata = d.wdata;
-    v.short_shift = 32 - (h.short_bits - 1); v.short_mask = (1u << (h.short_bits - 1)) - 1;
-    v.edge_shift = 32 - (h.edge_bits - 2); v.edge_mask = (1u << (h.edge_bits - 2)) - 1;
-    v.stride_dw = h.stride_dw; v.uni_dw = h.uni_dw; v.uni_n = h.uni_n; v.ext_slot = h.ext_slot;
-    v.window = h.window;
-    for (int i = 0; i < 3; ++i) { v.lo[i] = h.lo[i]; v.len[i] = h.len[i]; }
-    v.has_long = h.has_long ? 1u : 0u;
-    return v;
-}
-
-vpt::PackedView make_packed_view(const vpt::HostPackedTable& h, const DevicePacked& d) {
-    vpt::PackedView v{};
-    v.present = h.present ? 1u : 0u;
-    if (!h.present) return v;
-    v.base = d.base;
-    v.off_uni = d.off[0]; v.off_bi = d.off[1]; v.off_tri = d.off[2]; v.off_deep = d.off[3];
-    v.off_xrows = d.off[4]; v.off_trow = d.off[5]; v.off_cpid = d.off[6];
-    v.n_uni = uint32_t(h.uni.size() / 4); v.n_tri = uint32_t(h.tri.size() / 4); v.bi_shift = h.bi_shift;
-    v.has_trow = h.trow.empty() ? 0u : 1u;
-    return v;
-}
-
-// all packed arrays in one allocation (PackedView); false if they do not fit 32-bit offsets
-hipError_t upload_packed(const vpt::HostPackedTable& h, DevicePacked* d, bool* fits) {
-    const void* src[7] = {h.uni.data(), h.bi.data(), h.tri.data(), h.deep.data(), h.xrows.data(), h.trow.data(), h.cpid.data()};
-    const size_t bytes[7] = {4 * h.uni.size(), 4 * h.bi.size(), 4 * h.tri.size(), 4 * h.deep.size(), 4 * h.xrows.size(),
-                             4 * h.trow.size(), 4 * h.cpid.size()};
-    size_t total = 0;
-    size_t off[7];
-    for (int i = 0; i < 7; ++i) { off[i] = total; total += (bytes[i] + kTablePadBytes + 255) & ~size_t(255); }
-    *fits = total < (size_t(1) << 32);
-    if (!*fits) return hipSuccess;
-    hipError_t e = hipMalloc(reinterpret_cast<void**>(&d->base), total);
-    if (e != hipSuccess) return e;
-    e = hipMemset(d->base, 0, total);
-    for (int i = 0; i < 7 && e == hipSuccess; ++i) {
-        d->off[i] = uint32_t(off[i]);
-        if (bytes[i]) e = hipMemcpy(d->base + off[i], src[i], bytes[i], hipMemcpyHostToDevice);
+uint64_t arena_checksum(const unsigned char* p, size_t n) {   // n is a multiple of 256
+    const uint64_t* w = reinterpret_cast<const uint64_t*>(p);
+    uint64_t a = 0x9E3779B97F4A7C15ull, b = 0xC2B2AE3D27D4EB4Full, c = 0x165667B19E3779F9ull, d = 0x27D4EB2F165667C5ull;
+    for (size_t i = 0; i + 4 <= n / 8; i += 4) {   // four independent lanes: memory-bound, not multiply-bound
+        a = (a ^ w[i]) * 0x100000001B3ull; b = (b ^ w[i + 1]) * 0x100000001B3ull;
+        c = (c ^ w[i + 2]) * 0x100000001B3ull; d = (d ^ w[i + 3]) * 0x100000001B3ull;
     }
-    return e;
+    return a ^ (b << 1 | b >> 63) ^ (c << 2 | c >> 62) ^ (d << 3 | d >> 61) ^ uint64_t(n);
+}
+
+TableGeom geom_of(const vpt::HostPatternTable& h) {
+    TableGeom g{};
+    g.present = h.present ? 1u : 0u;
+    if (!h.present) return g;
+    g.short_bits = h.short_bits; g.edge_bits = h.edge_bits; g.stride_dw = h.stride_dw; g.uni_dw = h.uni_dw; g.uni_n = h.uni_n;
+    g.ext_slot = h.ext_slot; g.has_long = h.has_long ? 1u : 0u; g.window = h.window;
+    for (int i = 0; i < 3; ++i) { g.lo[i] = h.lo[i]; g.len[i] = h.len[i]; }
+    return g;
 }
 
 void fill_info(const vpt::CompiledModel& c, vpt_model_info* info) {
@@ -161,20 +139,18 @@ struct vpt_batch {
     std::vector<uint64_t> h_boff, h_ooff;                           // rebased offsets of the call in flight (copied asynchronously)
 };
 
-struct DeviceTags {
-    uint32_t *tok_tab = nullptr, *models = nullptr, *ngrams = nullptr, *syms = nullptr, *slots = nullptr, *slot_str = nullptr, *str_off = nullptr;
-    uint8_t* str_bytes = nullptr;
-    int32_t* weights = nullptr;
+struct DeviceTags {   // views into the arena
+    const uint32_t *tok_tab = nullptr, *models = nullptr, *ngrams = nullptr, *syms = nullptr, *slots = nullptr, *slot_str = nullptr, *str_off = nullptr;
+    const uint8_t* str_bytes = nullptr;
+    const int32_t* weights = nullptr;
     uint32_t n_models = 0, n_strings = 0;
-    void release() {
-        (void)hipFree(tok_tab); (void)hipFree(models); (void)hipFree(ngrams); (void)hipFree(syms); (void)hipFree(slots); (void)hipFree(weights);
-        (void)hipFree(slot_str); (void)hipFree(str_off); (void)hipFree(str_bytes);
-        tok_tab = models = ngrams = syms = slots = slot_str = str_off = nullptr; weights = nullptr; str_bytes = nullptr;
-    }
 };
 
 struct vpt_predictor {
     int device = 0;
+    unsigned char* arena = nullptr;    // the one device allocation that holds every table
+    PredictorMeta meta{};
+    // what the launches use, bound from meta + arena (bind_predictor)
     bool predict_tags = false;
     bool has_tags = false;
     uint32_t n_tags = 0, tok_bits = 0, max_tag_suffix = 0;
@@ -183,13 +159,11 @@ struct vpt_predictor {
     vpt_model_info info{};
     int32_t bias = 0; int pad = 1; int type_kind = 0; int type_window = 0; int chunks = 2;
     uint32_t tile_slots = 0;           // workgroups of the scoring kernel the device runs at a time (0 = unknown)
-    DeviceTable dc, dt;
-    DevicePacked dp;
     vpt::PackedView pk{};
-    int32_t* d_type_table = nullptr;
-    uint8_t* d_ctype = nullptr;
-    uint32_t* d_cinfo = nullptr;       // [0, 65536): plain; [65536, 131072): through KyteaFullwidthFilter
-    uint32_t* d_cid = nullptr;         // the same two tables for the specialised kernel: id | type << 16 | linebreak << 19
+    const int32_t* d_type_table = nullptr;
+    const uint8_t* d_ctype = nullptr;
+    const uint32_t* d_cinfo = nullptr; // [0, 65536): plain; [65536, 131072): through KyteaFullwidthFilter
+    const uint32_t* d_cid = nullptr;   // the same two tables for the specialised kernel: id | type << 16 | linebreak << 19
     vpt::PatternTableView ct{}, tt{};
     mutable std::mutex pool_mu;
     mutable std::vector<vpt_batch*> pool;  // idle workspaces for the host-buffer entry points
@@ -335,6 +309,18 @@ extern "C" {
 const char* vpt_last_error(void) { return g_last_error.c_str(); }
 const char* vpt_version(void) { return "vaporetto_hip 0.1.0 (gfx950)"; }
 
+vpt_status vpt_model_read_len(const uint8_t* model_bytes, size_t len, size_t* consumed) {
+    if (!model_bytes || !consumed) return fail(VPT_INVALID_ARGUMENT, "InvalidArgumentError: NULL argument");
+    try {
+        (void)vpt::parse_model(model_bytes, len, consumed);
+    } catch (const vpt::ModelError& e) {
+        return fail(VPT_INVALID_MODEL, e.what());
+    } catch (const std::bad_alloc&) {
+        return fail(VPT_RUNTIME_ERROR, "out of host memory while decoding the model");
+    }
+    return VPT_OK;
+}
+
 vpt_status vpt_model_inspect(const uint8_t* model_bytes, size_t len, int predict_tags, vpt_model_info* info) {
     if (!info) return fail(VPT_INVALID_ARGUMENT, "InvalidArgumentError: info: must not be NULL");
     vpt::CompiledModel c;
@@ -344,46 +330,165 @@ vpt_status vpt_model_inspect(const uint8_t* model_bytes, size_t len, int predict
     return VPT_OK;
 }
 
+namespace {
+
+struct SectionSrc { const void* ptr; size_t bytes; };
+
+// Views and scalars of a predictor from its meta block and arena; the occupancy figure comes from the device.
+void bind_predictor(vpt_predictor* p) {
+    const PredictorMeta& m = p->meta;
+    auto at = [&](int sec) { return p->arena + m.sec_off[sec]; };
+    auto view = [&](const TableGeom& g, int first) {
+        vpt::PatternTableView v{};
+        v.present = g.present;
+        if (!g.present) return v;
+        v.short_tab = reinterpret_cast<const uint32_t*>(at(first)); v.uni = reinterpret_cast<const uint32_t*>(at(first + 1));
+        v.edges = reinterpret_cast<const uint32_t*>(at(first + 2)); v.wdata = reinterpret_cast<const int32_t*>(at(first + 3));
+        v.short_shift = 32 - (g.short_bits - 1); v.short_mask = (1u << (g.short_bits - 1)) - 1;
+        v.edge_shift = 32 - (g.edge_bits - 2); v.edge_mask = (1u << (g.edge_bits - 2)) - 1;
+        v.stride_dw = g.stride_dw; v.uni_dw = g.uni_dw; v.uni_n = g.uni_n; v.ext_slot = g.ext_slot;
+        v.window = g.window;
+        for (int i = 0; i < 3; ++i) { v.lo[i] = g.lo[i]; v.len[i] = g.len[i]; }
+        v.has_long = g.has_long;
+        return v;
+    };
+    p->ct = view(m.geom[0], kSecCShort);
+    p->tt = view(m.geom[1], kSecTShort);
+    p->pk = vpt::PackedView{};
+    p->pk.present = m.pk_present;
+    if (m.pk_present) {
+        p->pk.base = at(kSecPUni);
+        auto rel = [&](int sec) { return uint32_t(m.sec_off[sec] - m.sec_off[kSecPUni]); };
+        p->pk.off_uni = 0; p->pk.off_bi = rel(kSecPBi); p->pk.off_tri = rel(kSecPTri); p->pk.off_deep = rel(kSecPDeep);
+        p->pk.off_xrows = rel(kSecPXrows); p->pk.off_trow = rel(kSecPTrow); p->pk.off_cpid = rel(kSecPCpid);
+        p->pk.n_uni = m.pk_n_uni; p->pk.n_tri = m.pk_n_tri; p->pk.bi_shift = m.pk_bi_shift; p->pk.has_trow = m.pk_has_trow;
+    }
+    p->d_type_table = m.sec_bytes[kSecTypeTable] ? reinterpret_cast<const int32_t*>(at(kSecTypeTable)) : nullptr;
+    p->d_ctype = at(kSecCtype);
+    p->d_cinfo = reinterpret_cast<const uint32_t*>(at(kSecCinfo));
+    p->d_cid = m.sec_bytes[kSecCid] ? reinterpret_cast<const uint32_t*>(at(kSecCid)) : nullptr;
+    p->predict_tags = m.predict_tags != 0; p->has_tags = m.has_tags != 0;
+    p->n_tags = m.n_tags; p->tok_bits = m.tok_bits; p->max_tag_suffix = m.max_tag_suffix;
+    p->tag_use_char = m.tag_use_char != 0; p->tag_use_type = m.tag_use_type != 0;
+    if (m.has_tags) {
+        p->dtag.tok_tab = reinterpret_cast<const uint32_t*>(at(kSecTagTokTab)); p->dtag.models = reinterpret_cast<const uint32_t*>(at(kSecTagModels));
+        p->dtag.ngrams = reinterpret_cast<const uint32_t*>(at(kSecTagNgrams)); p->dtag.syms = reinterpret_cast<const uint32_t*>(at(kSecTagSyms));
+        p->dtag.slots = reinterpret_cast<const uint32_t*>(at(kSecTagSlots)); p->dtag.weights = reinterpret_cast<const int32_t*>(at(kSecTagWeights));
+        p->dtag.slot_str = reinterpret_cast<const uint32_t*>(at(kSecTagSlotStr)); p->dtag.str_off = reinterpret_cast<const uint32_t*>(at(kSecTagStrOff));
+        p->dtag.str_bytes = at(kSecTagStrBytes);
+        p->dtag.n_models = m.n_tag_models; p->dtag.n_strings = m.n_tag_strings;
+    }
+    p->info = m.info;
+    p->bias = m.bias; p->pad = m.pad; p->type_kind = m.type_kind; p->type_window = m.type_window; p->chunks = m.chunks;
+    p->tile_slots = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, p->device) == hipSuccess && prop.multiProcessorCount > 0) {
+        vpt::ScoreParams probe{};
+        probe.ct = p->ct; probe.pk = p->pk; probe.pad = p->pad; probe.ctype = p->d_ctype; probe.cid = p->d_cid; probe.type_kind = p->type_kind;
+        probe.type_window = p->type_window;
+        const bool fast = vpt::fast_path_supported(probe);
+        size_t lds = fast ? vpt::score_tiles_fast_lds_bytes(probe) : vpt::score_tiles_lds_bytes();
+        if (const char* padv = std::getenv("VPT_DEBUG_LDS_PAD")) lds += size_t(std::atoi(padv));   // occupancy experiments (kernels_fast.hip)
+        const size_t granules = (lds + 1279) / 1280;   // gfx950 hands out its 160 KB of LDS in 1280-byte granules
+        // the specialised kernel is built for 6 workgroups of 4 waves per CU, the general one for 8
+        const uint32_t per_cu = uint32_t(std::min<size_t>(fast ? 6 : 8, std::max<size_t>(1, 128 / std::max<size_t>(granules, 1))));
+        p->tile_slots = uint32_t(prop.multiProcessorCount) * per_cu;
+    }
+}
+
+vpt_status check_device(int device_id) {
+    int n_dev = 0;
+    if (hipGetDeviceCount(&n_dev) != hipSuccess || n_dev <= 0)
+        return fail(VPT_RUNTIME_ERROR, "no HIP device available (this library has no CPU fallback)");
+    if (device_id < 0 || device_id >= n_dev) return fail(VPT_INVALID_ARGUMENT, "InvalidArgumentError: device_id: no such HIP device");
+    return VPT_OK;
+}
+
+// the section layout of an arena: 256-byte aligned starts, kTablePadBytes of zeros behind every table
+uint64_t layout_sections(const size_t bytes[kSectionCount], uint64_t off[kSectionCount]) {
+    uint64_t total = 0;
+    for (int i = 0; i < kSectionCount; ++i) { off[i] = total; total += (uint64_t(bytes[i]) + kTablePadBytes + 255) & ~uint64_t(255); }
+    return total;
+}
+
+}  // namespace
+
 vpt_status vpt_predictor_create(const uint8_t* model_bytes, size_t len, int predict_tags, int device_id, vpt_predictor** out) {
     if (!out) return fail(VPT_INVALID_ARGUMENT, "InvalidArgumentError: out: must not be NULL");
     *out = nullptr;
     vpt::CompiledModel c;
     vpt_status st = compile(model_bytes, len, predict_tags, &c);
     if (st != VPT_OK) return st;
-    int n_dev = 0;
-    if (hipGetDeviceCount(&n_dev) != hipSuccess || n_dev <= 0)
-        return fail(VPT_RUNTIME_ERROR, "no HIP device available (this library has no CPU fallback)");
-    if (device_id < 0 || device_id >= n_dev) return fail(VPT_INVALID_ARGUMENT, "InvalidArgumentError: device_id: no such HIP device");
+    if ((st = check_device(device_id)) != VPT_OK) return st;
     VPT_HIP(hipSetDevice(device_id));
+
+    // ---- the small tables made here: CharacterType / KyteaFullwidthFilter images of the BMP, ids for the packed tables
+    std::vector<uint32_t> cinfo(2 * 65536);   // the char a BMP char is scored as | its CharacterType << 16
+    std::vector<uint8_t> ctype(65536);
+    for (uint32_t cp = 0; cp < 65536; ++cp) {
+        cinfo[cp] = cp | (uint32_t(vpt::char_type_host(cp)) << 16);
+        const uint32_t fw = vpt::kytea_fullwidth_host(cp);
+        cinfo[65536 + cp] = fw | (uint32_t(vpt::char_type_host(fw)) << 16);
+        ctype[cp] = vpt::char_type_host(cp);
+    }
+    std::vector<uint32_t> cid;
+    if (c.packed.present) {
+        cid.resize(2 * 65536);
+        for (uint32_t cp = 0; cp < 65536; ++cp)
+            for (int mode = 0; mode < 2; ++mode) {
+                const uint32_t scored = mode ? vpt::kytea_fullwidth_host(cp) : cp;   // 1:1 on the BMP
+                cid[size_t(mode) * 65536 + cp] = uint32_t(c.packed.id_of[scored]) | (uint32_t(vpt::char_type_host(scored)) << 16) |
+                                                 ((scored == 0x0Au || scored == 0x0Du) ? vpt::kCinfoLinebreak : 0u);
+            }
+    }
+
+    // ---- sections
+    SectionSrc src[kSectionCount] = {};
+    auto put = [&](int sec, const auto& v) { src[sec] = {v.data(), v.size() * sizeof(v[0])}; };
+    if (c.chars.present) { put(kSecCShort, c.chars.short_tab); put(kSecCUni, c.chars.uni); put(kSecCEdges, c.chars.edges); put(kSecCWdata, c.chars.wdata); }
+    if (c.types.present) { put(kSecTShort, c.types.short_tab); put(kSecTUni, c.types.uni); put(kSecTEdges, c.types.edges); put(kSecTWdata, c.types.wdata); }
+    bool packed_ok = c.packed.present;
+    if (packed_ok) {
+        put(kSecPUni, c.packed.uni); put(kSecPBi, c.packed.bi); put(kSecPTri, c.packed.tri); put(kSecPDeep, c.packed.deep);
+        put(kSecPXrows, c.packed.xrows); put(kSecPTrow, c.packed.trow); put(kSecPCpid, c.packed.cpid);
+        size_t packed_total = 0;
+        for (int i = kSecPUni; i <= kSecPCpid; ++i) packed_total += (src[i].bytes + kTablePadBytes + 255) & ~size_t(255);
+        if (packed_total >= (size_t(1) << 32)) {   // the specialised kernel addresses them with 32-bit offsets: the general tables serve
+            packed_ok = false;
+            for (int i = kSecPUni; i <= kSecPCpid; ++i) src[i] = {nullptr, 0};
+        }
+    }
+    if (c.type_kind == vpt::kTypeWindowTable) put(kSecTypeTable, c.type_table);
+    put(kSecCtype, ctype); put(kSecCinfo, cinfo);
+    if (packed_ok) put(kSecCid, cid);
+    if (c.tags.present) {
+        put(kSecTagTokTab, c.tags.tok_tab); put(kSecTagModels, c.tags.models); put(kSecTagNgrams, c.tags.ngrams); put(kSecTagSyms, c.tags.syms);
+        put(kSecTagSlots, c.tags.slots); put(kSecTagWeights, c.tags.weights); put(kSecTagSlotStr, c.tags.slot_str);
+        put(kSecTagStrOff, c.tags.str_off); put(kSecTagStrBytes, c.tags.str_bytes);
+    }
+
     vpt_predictor* p = new (std::nothrow) vpt_predictor();
     if (!p) return fail(VPT_RUNTIME_ERROR, "out of host memory");
     p->device = device_id;
-    fill_info(c, &p->info);
-    p->bias = c.bias; p->pad = c.pad; p->type_kind = c.type_kind; p->type_window = c.type_window;
-    hipError_t e = hipSuccess;
-    auto up = [&](const vpt::HostPatternTable& h, DeviceTable& d) {
-        if (!h.present) return;
-        if (e == hipSuccess) e = upload(h.short_tab, &d.short_tab);
-        if (e == hipSuccess) e = upload(h.uni, &d.uni);
-        if (e == hipSuccess) e = upload(h.edges, &d.edges);
-        if (e == hipSuccess) e = upload(h.wdata, &d.wdata);
-    };
-    up(c.chars, p->dc);
-    up(c.types, p->dt);
-    p->predict_tags = predict_tags != 0;
+    PredictorMeta& m = p->meta;
+    std::memset(&m, 0, sizeof(m));
+    std::memcpy(m.magic, kCompiledMagic, sizeof(m.magic));
+    m.version = kCompiledVersion; m.meta_bytes = uint32_t(sizeof(PredictorMeta));
+    size_t bytes[kSectionCount];
+    for (int i = 0; i < kSectionCount; ++i) { bytes[i] = src[i].bytes; m.sec_bytes[i] = src[i].bytes; }
+    m.arena_bytes = layout_sections(bytes, m.sec_off);
+    m.bias = c.bias; m.pad = c.pad; m.type_kind = c.type_kind; m.type_window = c.type_window;
+    {
+        uint32_t stride = 4;
+        if (c.chars.present) stride = std::max(stride, c.chars.stride_dw);
+        if (c.types.present) stride = std::max(stride, c.types.stride_dw);
+        m.chunks = int32_t(std::max<uint32_t>(2, stride / 4));
+    }
+    m.predict_tags = predict_tags != 0;
     if (c.tags.present) {
-        p->has_tags = true; p->n_tags = c.tags.n_tags; p->tok_bits = c.tags.tok_bits;
-        p->tag_use_char = c.tags.use_char; p->tag_use_type = c.tags.use_type;
-        if (e == hipSuccess) e = upload(c.tags.tok_tab, &p->dtag.tok_tab);
-        if (e == hipSuccess) e = upload(c.tags.models, &p->dtag.models);
-        if (e == hipSuccess) e = upload(c.tags.ngrams, &p->dtag.ngrams);
-        if (e == hipSuccess) e = upload(c.tags.syms, &p->dtag.syms);
-        if (e == hipSuccess) e = upload(c.tags.slots, &p->dtag.slots);
-        if (e == hipSuccess) e = upload(c.tags.weights, &p->dtag.weights);
-        if (e == hipSuccess) e = upload(c.tags.slot_str, &p->dtag.slot_str);
-        if (e == hipSuccess) e = upload(c.tags.str_off, &p->dtag.str_off);
-        if (e == hipSuccess) e = upload(c.tags.str_bytes, &p->dtag.str_bytes);
-        p->dtag.n_models = c.tags.n_models; p->dtag.n_strings = uint32_t(c.tags.str_off.size() - 1);
+        m.has_tags = 1; m.n_tags = c.tags.n_tags; m.tok_bits = c.tags.tok_bits;
+        m.tag_use_char = c.tags.use_char; m.tag_use_type = c.tags.use_type;
+        m.n_tag_models = c.tags.n_models; m.n_tag_strings = uint32_t(c.tags.str_off.size() - 1);
         for (uint32_t mi = 0; mi < c.tags.n_models; ++mi) {   // the longest "/tag/tag.." a token can get
             const uint32_t* mr = &c.tags.models[size_t(mi) * 12];
             uint32_t worst = 0;
@@ -393,62 +498,29 @@ vpt_status vpt_predictor_create(const uint8_t* model_bytes, size_t len, int pred
                 for (uint32_t k = 0; k < cnt; ++k) longest = std::max(longest, c.tags.str_off[first + k + 1] - c.tags.str_off[first + k]);
                 worst += 1 + longest;
             }
-            p->max_tag_suffix = std::max(p->max_tag_suffix, worst);
+            m.max_tag_suffix = std::max(m.max_tag_suffix, worst);
         }
     }
-    bool packed_ok = c.packed.present;
-    if (c.packed.present && e == hipSuccess) e = upload_packed(c.packed, &p->dp, &packed_ok);
-    if (e == hipSuccess && c.type_kind == vpt::kTypeWindowTable) e = upload(c.type_table, &p->d_type_table);
-    if (e == hipSuccess) {
-        std::vector<uint32_t> cinfo(2 * 65536);   // the char a BMP char is scored as | its CharacterType << 16
-        for (uint32_t cp = 0; cp < 65536; ++cp) {
-            cinfo[cp] = cp | (uint32_t(vpt::char_type_host(cp)) << 16);
-            const uint32_t fw = vpt::kytea_fullwidth_host(cp);
-            cinfo[65536 + cp] = fw | (uint32_t(vpt::char_type_host(fw)) << 16);
-        }
-        e = upload(cinfo, &p->d_cinfo);
-        if (e == hipSuccess && c.packed.present) {
-            std::vector<uint32_t> cid(2 * 65536);
-            for (uint32_t cp = 0; cp < 65536; ++cp)
-                for (int mode = 0; mode < 2; ++mode) {
-                    const uint32_t scored = mode ? vpt::kytea_fullwidth_host(cp) : cp;   // 1:1 on the BMP
-                    cid[size_t(mode) * 65536 + cp] = uint32_t(c.packed.id_of[scored]) | (uint32_t(vpt::char_type_host(scored)) << 16) |
-                                                     ((scored == 0x0Au || scored == 0x0Du) ? vpt::kCinfoLinebreak : 0u);
-                }
-            e = upload(cid, &p->d_cid);
-        }
-        std::vector<uint8_t> ctype(65536);
-        for (uint32_t cp = 0; cp < 65536; ++cp) ctype[cp] = vpt::char_type_host(cp);
-        if (e == hipSuccess) e = upload(ctype, &p->d_ctype);
+    m.geom[0] = geom_of(c.chars); m.geom[1] = geom_of(c.types);
+    m.pk_present = packed_ok ? 1u : 0u;
+    if (packed_ok) {
+        m.pk_n_uni = uint32_t(c.packed.uni.size() / 4); m.pk_n_tri = uint32_t(c.packed.tri.size() / 4);
+        m.pk_bi_shift = c.packed.bi_shift; m.pk_has_trow = c.packed.trow.empty() ? 0u : 1u;
     }
+    fill_info(c, &m.info);
+    m.info.predict_tags = predict_tags != 0;
+    if (!packed_ok) { m.info.packed = 0; m.info.type_rows = 0; }
+
+    hipError_t e = hipMalloc(reinterpret_cast<void**>(&p->arena), m.arena_bytes);
+    if (e == hipSuccess) e = hipMemset(p->arena, 0, m.arena_bytes);
+    for (int i = 0; i < kSectionCount && e == hipSuccess; ++i)
+        if (src[i].bytes) e = hipMemcpy(p->arena + m.sec_off[i], src[i].ptr, src[i].bytes, hipMemcpyHostToDevice);
     if (e != hipSuccess) {
         std::string msg = std::string("HIP error while uploading the tables: ") + hipGetErrorString(e);
         vpt_predictor_destroy(p);
         return fail(VPT_RUNTIME_ERROR, msg);
     }
-    p->ct = make_view(c.chars, p->dc);
-    p->tt = make_view(c.types, p->dt);
-    p->pk = make_packed_view(c.packed, p->dp);
-    if (!packed_ok) { p->pk.present = 0; p->info.packed = 0; p->info.type_rows = 0; }
-    uint32_t stride = 4;
-    if (c.chars.present) stride = std::max(stride, c.chars.stride_dw);
-    if (c.types.present) stride = std::max(stride, c.types.stride_dw);
-    p->chunks = int(std::max<uint32_t>(2, stride / 4));
-    {
-        hipDeviceProp_t prop;
-        if (hipGetDeviceProperties(&prop, device_id) == hipSuccess && prop.multiProcessorCount > 0) {
-            vpt::ScoreParams probe{};
-            probe.ct = p->ct; probe.pk = p->pk; probe.pad = p->pad; probe.ctype = p->d_ctype; probe.cid = p->d_cid; probe.type_kind = p->type_kind;
-            probe.type_window = p->type_window;
-            const bool fast = vpt::fast_path_supported(probe);
-            size_t lds = fast ? vpt::score_tiles_fast_lds_bytes(probe) : vpt::score_tiles_lds_bytes();
-            if (const char* padv = std::getenv("VPT_DEBUG_LDS_PAD")) lds += size_t(std::atoi(padv));   // occupancy experiments (kernels_fast.hip)
-            const size_t granules = (lds + 1279) / 1280;   // gfx950 hands out its 160 KB of LDS in 1280-byte granules
-            // the specialised kernel is built for 6 workgroups of 4 waves per CU (<= 80 VGPRs), the general one for 8
-            const uint32_t per_cu = uint32_t(std::min<size_t>(fast ? 6 : 8, std::max<size_t>(1, 128 / std::max<size_t>(granules, 1))));
-            p->tile_slots = uint32_t(prop.multiProcessorCount) * per_cu;
-        }
-    }
+    bind_predictor(p);
     *out = p;
     return VPT_OK;
 }
@@ -457,10 +529,87 @@ void vpt_predictor_destroy(vpt_predictor* p) {
     if (!p) return;
     (void)hipSetDevice(p->device);
     for (vpt_batch* b : p->pool) batch_release(b);
-    p->dc.release(); p->dt.release(); p->dp.release(); p->dtag.release();
-    (void)hipFree(p->d_type_table);
-    (void)hipFree(p->d_cinfo); (void)hipFree(p->d_ctype); (void)hipFree(p->d_cid);
+    (void)hipFree(p->arena);
     delete p;
+}
+
+// ---- the compiled form: PredictorMeta + the arena's bytes
+vpt_status vpt_predictor_save(const vpt_predictor* p, uint8_t* out, size_t capacity, size_t* needed) {
+    if (!p || !needed) return fail(VPT_INVALID_ARGUMENT, "InvalidArgumentError: NULL argument");
+    const size_t total = sizeof(PredictorMeta) + size_t(p->meta.arena_bytes);
+    *needed = total;
+    if (!out || capacity < total) return out ? fail(VPT_INVALID_ARGUMENT, "InvalidArgumentError: capacity: smaller than the compiled predictor") : VPT_OK;
+    VPT_HIP(hipSetDevice(p->device));
+    VPT_HIP(hipMemcpy(out + sizeof(PredictorMeta), p->arena, size_t(p->meta.arena_bytes), hipMemcpyDeviceToHost));
+    PredictorMeta m = p->meta;
+    m.checksum = arena_checksum(out + sizeof(PredictorMeta), size_t(m.arena_bytes));
+    std::memcpy(out, &m, sizeof(m));
+    return VPT_OK;
+}
+
+vpt_status vpt_predictor_load(const uint8_t* blob, size_t len, int device_id, vpt_predictor** out) {
+    if (!out) return fail(VPT_INVALID_ARGUMENT, "InvalidArgumentError: out: must not be NULL");
+    *out = nullptr;
+    if (!blob) return fail(VPT_INVALID_ARGUMENT, "InvalidArgumentError: blob: must not be NULL");
+    PredictorMeta m;
+    if (len < sizeof(m)) return fail(VPT_INVALID_MODEL, "InvalidModelError: not a compiled predictor (too short)");
+    std::memcpy(&m, blob, sizeof(m));
+    if (std::memcmp(m.magic, kCompiledMagic, sizeof(m.magic)) != 0) return fail(VPT_INVALID_MODEL, "InvalidModelError: not a compiled predictor");
+    if (m.version != kCompiledVersion || m.meta_bytes != sizeof(PredictorMeta))
+        return fail(VPT_INVALID_MODEL, "InvalidModelError: compiled predictor version mismatch (compile the model again with this library)");
+    if (m.arena_bytes % 256 != 0 || len != sizeof(m) + m.arena_bytes) return fail(VPT_INVALID_MODEL, "InvalidModelError: compiled predictor is truncated");
+    {   // the sections must be the layout this library would make of their sizes
+        size_t bytes[kSectionCount];
+        uint64_t off[kSectionCount];
+        for (int i = 0; i < kSectionCount; ++i) bytes[i] = size_t(m.sec_bytes[i]);
+        if (layout_sections(bytes, off) != m.arena_bytes || std::memcmp(off, m.sec_off, sizeof(off)) != 0)
+            return fail(VPT_INVALID_MODEL, "InvalidModelError: compiled predictor has an inconsistent section table");
+    }
+    if (arena_checksum(blob + sizeof(m), size_t(m.arena_bytes)) != m.checksum) return fail(VPT_INVALID_MODEL, "InvalidModelError: compiled predictor is corrupt (checksum)");
+    vpt_status st = check_device(device_id);
+    if (st != VPT_OK) return st;
+    VPT_HIP(hipSetDevice(device_id));
+    vpt_predictor* p = new (std::nothrow) vpt_predictor();
+    if (!p) return fail(VPT_RUNTIME_ERROR, "out of host memory");
+    p->device = device_id;
+    p->meta = m;
+    hipError_t e = hipMalloc(reinterpret_cast<void**>(&p->arena), m.arena_bytes);
+    if (e == hipSuccess) e = hipMemcpy(p->arena, blob + sizeof(m), size_t(m.arena_bytes), hipMemcpyHostToDevice);
+    if (e != hipSuccess) {
+        std::string msg = std::string("HIP error while uploading the tables: ") + hipGetErrorString(e);
+        vpt_predictor_destroy(p);
+        return fail(VPT_RUNTIME_ERROR, msg);
+    }
+    bind_predictor(p);
+    *out = p;
+    return VPT_OK;
+}
+
+vpt_status vpt_predictor_clone_to_device(const vpt_predictor* src, int device_id, vpt_predictor** out) {
+    if (!out) return fail(VPT_INVALID_ARGUMENT, "InvalidArgumentError: out: must not be NULL");
+    *out = nullptr;
+    if (!src) return fail(VPT_INVALID_ARGUMENT, "InvalidArgumentError: predictor: must not be NULL");
+    vpt_status st = check_device(device_id);
+    if (st != VPT_OK) return st;
+    VPT_HIP(hipSetDevice(device_id));
+    vpt_predictor* p = new (std::nothrow) vpt_predictor();
+    if (!p) return fail(VPT_RUNTIME_ERROR, "out of host memory");
+    p->device = device_id;
+    p->meta = src->meta;
+    hipError_t e = hipMalloc(reinterpret_cast<void**>(&p->arena), src->meta.arena_bytes);
+    // device to device: over xGMI between two GPUs of a node (hipMemcpyPeer falls back to staging through the host when
+    // peer access is not possible), a plain copy on the same device
+    if (e == hipSuccess)
+        e = device_id == src->device ? hipMemcpy(p->arena, src->arena, size_t(src->meta.arena_bytes), hipMemcpyDeviceToDevice)
+                                     : hipMemcpyPeer(p->arena, device_id, src->arena, src->device, size_t(src->meta.arena_bytes));
+    if (e != hipSuccess) {
+        std::string msg = std::string("HIP error while copying the tables: ") + hipGetErrorString(e);
+        vpt_predictor_destroy(p);
+        return fail(VPT_RUNTIME_ERROR, msg);
+    }
+    bind_predictor(p);
+    *out = p;
+    return VPT_OK;
 }
 
 vpt_status vpt_predictor_info(const vpt_predictor* p, vpt_model_info* info) {

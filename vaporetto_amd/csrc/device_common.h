@@ -23,18 +23,6 @@
 #define VPT_PIN(x) __asm__ volatile("" : "+v"(x))
 #endif
 
-// Streaming accesses (text read once, outputs written once): non-temporal, so that they do not push the hot table
-// lines out of the 32 KB vector L1.  Plain accesses in the emulator.
-#if !defined(VPT_STREAM_LOAD16) && defined(VPT_NO_STREAM_HINTS)   // A/B builds (tools/ab_bench.py): plain accesses
-#define VPT_STREAM_LOAD16(ptr) (*reinterpret_cast<const uint4*>(ptr))
-#define VPT_STREAM_STORE(val, ptr) (*(ptr) = (val))
-#endif
-#ifndef VPT_STREAM_LOAD16
-typedef unsigned int vpt_u32x4 __attribute__((ext_vector_type(4)));
-#define VPT_STREAM_LOAD16(ptr) ({ const vpt_u32x4 v_ = __builtin_nontemporal_load(reinterpret_cast<const vpt_u32x4*>(ptr)); make_uint4(v_.x, v_.y, v_.z, v_.w); })
-#define VPT_STREAM_STORE(val, ptr) __builtin_nontemporal_store((val), (ptr))
-#endif
-
 namespace vpt {
 
 // A value that every lane of the wave holds alike, moved to a scalar register.  The hardware gains nothing; the

@@ -333,7 +333,7 @@ __global__ __launch_bounds__(kThreads, 6) void score_tiles_fast_kernel(const Sco
     if (TM != kTypeRows) {
         for (uint32_t i = tid; i < uint32_t(kFastCap + kMargin) / 4; i += kThreads) reinterpret_cast<uint32_t*>(L.typ)[i] = 0;
     }
-    for (uint32_t c = tid; c < nchunks; c += kThreads) reinterpret_cast<uint4*>(raw)[c] = VPT_STREAM_LOAD16(tbase - head + (size_t(c) << 4));   // = a0 + 16 c, still a global pointer
+    for (uint32_t c = tid; c < nchunks; c += kThreads) reinterpret_cast<uint4*>(raw)[c] = reinterpret_cast<const uint4*>(a0)[c];   // (non-temporal loads / stores here measured 1-2 % slower: profiles/r02_c1_ab.jsonl, r02_c3_ab.jsonl)
     if (tid == 0) raw[nchunks * 4] = 0;  // the dword after the staged text is read (as padding) by the last char
     __syncthreads();
     for (uint32_t j = tid; j < nsent; j += kThreads) {
@@ -555,7 +555,7 @@ __global__ __launch_bounds__(kThreads, 6) void score_tiles_fast_kernel(const Sco
         }
         const uint32_t o = (p - pad) - (pad + 1) * ((x >> 19) & 1023u);
         if (o >= nb) { err |= kErrBadOffsets; continue; }  // only with offsets that do not match the text
-        if (sc) VPT_STREAM_STORE(y, sc + o);
+        if (sc) sc[o] = y;
         if (lb) {
             uint32_t label = y > 0 ? 1u : 0u;
             if (P.post) {   // wave-uniform: KyteaWsConstFilter / SplitLinebreaksFilter on the label
@@ -563,7 +563,7 @@ __global__ __launch_bounds__(kThreads, 6) void score_tiles_fast_kernel(const Sco
                 if (t1 == t2 && ((P.post >> t1) & 1u) && t1 != 0 && t1 != 7) label = 0;
                 if ((P.post & 0x80u) && ((x | x2) & kSymLinebreak)) label = 1;
             }
-            VPT_STREAM_STORE(uint8_t(label), lb + o);
+            lb[o] = uint8_t(label);
         }
     }
     if (err) atomicOr(P.status, err);
