@@ -123,6 +123,36 @@ vpt_status vpt_predict_batch_flags(const vpt_predictor *p, const uint8_t *utf8, 
                                    size_t n_sentences, int32_t *scores_out, uint8_t *labels_out,
                                    const uint64_t *out_offsets, unsigned flags);
 
+/* Host buffers and the PCIe link.  vpt_predict_batch cuts a large batch into chunks of about a million chars and runs the copy
+ * in of one chunk, the kernels of the one before and the copy out of the one before that at the same time (three streams,
+ * two sets of device buffers).  With PINNED caller buffers -- vpt_host_alloc, or memory the caller registered with HIP
+ * itself -- the copies are DMA transfers in both directions at once; with pageable buffers they go through the runtime's
+ * staging.  vpt_host_alloc / vpt_host_free = hipHostMalloc / hipHostFree, exported so that callers need no HIP headers. */
+vpt_status vpt_host_alloc(size_t bytes, void **out);
+void vpt_host_free(void *ptr);
+
+/* Predictor::predict over ONE batch on SEVERAL GPUs of a node: the batch is cut into n_preds contiguous sentence ranges of
+ * about equal CHARACTER count (vpt_shard_bounds), range r is scored by preds[r] (normally vpt_predictor_clone_to_device
+ * copies of one predictor) on a host thread of its own and written straight into its slice of scores_out / labels_out.
+ * Sentences are independent (predictor.rs:518-543 keeps no state between calls), so there is no exchange step.
+ * Arguments as for vpt_predict_batch_flags.  Mirrors how vaporetto_tantivy shares one Arc<Predictor> between indexing
+ * threads (vaporetto_tantivy/src/lib.rs:62-67), with one device per thread. */
+vpt_status vpt_predict_batch_sharded(const vpt_predictor *const *preds, size_t n_preds, const uint8_t *utf8,
+                                     const uint64_t *byte_offsets, size_t n_sentences, int32_t *scores_out,
+                                     uint8_t *labels_out, const uint64_t *out_offsets, unsigned flags);
+/* bounds[0 .. n_shards]: shard r = sentences bounds[r] .. bounds[r+1], balanced by chars (host only). */
+vpt_status vpt_shard_bounds(const uint64_t *out_offsets, size_t n_sentences, size_t n_shards, uint64_t *bounds);
+
+/* Sentence::char_types for a batch (sentence.rs:1016; CharacterType::get_type, sentence.rs:50-67), computed on the device:
+ * types_out[out_offsets[i] + i + c] = CharacterType (1..6) of char c of sentence i; flags: VPT_FLAG_KYTEA_FULLWIDTH gives the
+ * types of the normalised text.  The *_device variant: device pointers, asynchronous, flags from vpt_batch_set_flags. */
+vpt_status vpt_char_types_batch(const vpt_predictor *p, const uint8_t *utf8, const uint64_t *byte_offsets,
+                                size_t n_sentences, const uint64_t *out_offsets, unsigned flags, uint8_t *types_out);
+vpt_status vpt_char_types_batch_device(const vpt_predictor *p, vpt_batch *b, const uint8_t *d_utf8,
+                                       const uint64_t *d_byte_offsets, const uint64_t *d_out_offsets,
+                                       size_t n_sentences, uint64_t total_boundaries, uint8_t *d_types_out,
+                                       void *hip_stream);
+
 /* Sentence::from_raw + Predictor::predict for one sentence (same path, batch of one).
  * scores/labels need room for chars-1 entries (<= len-1). */
 vpt_status vpt_predict_one(const vpt_predictor *p, const uint8_t *utf8, size_t len, int32_t *scores,

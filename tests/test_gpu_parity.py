@@ -926,3 +926,79 @@ def test_compiled_predictor_rejects_damaged_blobs():
     bad = bytearray(blob); bad[16] ^= 0x01            # the version word
     refuse(bad, "version mismatch")
     assert api.Predictor.load_compiled(bytes(blob)).info()["n_char_ngrams"] == len(m.char_ngram_model)
+
+
+# ------------------------------------------------------------------------------------------------ host-buffer pipeline, shards
+@pytest.mark.parametrize("chunk_chars,pinned", [("700", False), ("2500", True)])
+def test_pipelined_host_path_matches_oracle(chunk_chars, pinned, monkeypatch):
+    """vpt_predict_batch cuts a large batch into chunks and overlaps copy in / kernels / copy out on three streams; with
+    VPT_CHUNK_CHARS tiny, a 1 000-sentence batch goes through dozens of chunks, ragged sizes, both buffer sets, pinned and
+    pageable caller buffers -- scores identical to the oracle's, device-side errors still reported."""
+    monkeypatch.setenv("VPT_CHUNK_CHARS", chunk_chars)
+    m = randmodel.rand_model(777, alphabet="kana", wc=3, wt=3, n_char=200, n_dict=200, max_word=8)
+    raw = encode_model(m)
+    pred, orc = make_predictor(raw)
+    mixed = randmodel.ALPHABETS["kana"][:12] + list("漢字A9、")
+    texts = randmodel.rand_sentences(3, m, 1000, alphabet=mixed, max_len=90)
+    utf8, boff = api.pack_texts([t.encode("utf-8") for t in texts])
+    o_scores, o_labels, o_ooff, _ = orc.predict_batch(utf8, boff, nthreads=4)
+    if pinned:
+        keep = [api.PinnedArray(utf8.shape, np.uint8), api.PinnedArray(o_scores.shape, np.int32), api.PinnedArray(o_labels.shape, np.uint8)]
+        keep[0].array[:] = utf8
+        keep[1].array[:] = 0
+        keep[2].array[:] = 9
+        scores, labels, ooff = api.predict_packed_sharded([pred], keep[0].array, boff, scores=keep[1].array, labels=keep[2].array)
+    else:
+        scores, labels, ooff = pred.predict_packed(utf8, boff)
+    assert np.array_equal(ooff, o_ooff) and np.array_equal(scores, o_scores) and np.array_equal(labels, o_labels)
+    # a NUL char in the middle of the batch: reported by the chunk that holds it
+    texts2 = list(texts)
+    texts2[500] = "a\x00b"
+    u2, b2 = api.pack_texts([t.encode("utf-8") for t in texts2])
+    with pytest.raises(api.VaporettoError) as e:
+        api.predict_packed_sharded([pred], u2, b2, out_offsets=np.concatenate([[0], np.cumsum([len(t) - 1 for t in texts2])]).astype(np.uint64))
+    assert "NULL" in str(e.value)
+
+
+def test_sharded_predict_over_clones_equals_unsharded(monkeypatch):
+    """take shards -> score each on its own predictor (clones of one, as the ranks of a multi-GPU job hold) -> the
+    concatenation is the unsharded result; shard bounds balance CHARACTERS, not sentences or bytes."""
+    m = randmodel.rand_model(778, alphabet="kana", wc=3, wt=3, n_char=200, n_dict=200, max_word=8)
+    raw = encode_model(m)
+    pred, orc = make_predictor(raw)
+    import random
+    rng = random.Random(11)
+    # mixed ASCII / JA text: bytes per char vary 1..3, lengths vary 1..200
+    texts = []
+    for i in range(600):
+        alpha = list("abcdefgh 0123") if i % 3 == 0 else randmodel.ALPHABETS["kana"][:20] + list("漢字")
+        texts.append("".join(rng.choice(alpha) for _ in range(rng.randint(1, 200 if i % 7 == 0 else 30))))
+    utf8, boff = api.pack_texts([t.encode("utf-8") for t in texts])
+    o_scores, o_labels, o_ooff, _ = orc.predict_batch(utf8, boff, nthreads=4)
+    for n in (1, 2, 3, 5):
+        bounds = api.shard_bounds(o_ooff, n)
+        assert bounds[0] == 0 and bounds[n] == len(texts) and all(bounds[r] <= bounds[r + 1] for r in range(n))
+        chars = [sum(len(t) for t in texts[int(bounds[r]):int(bounds[r + 1])]) for r in range(n)]
+        assert max(chars) - min(chars) <= 2 * 200            # every cut is within one (longest) sentence of its target
+        clones = [pred] + [pred.clone_to_device(0) for _ in range(n - 1)]
+        scores, labels, ooff = api.predict_packed_sharded(clones, utf8, boff)
+        assert np.array_equal(scores, o_scores) and np.array_equal(labels, o_labels) and np.array_equal(ooff, o_ooff)
+    monkeypatch.setenv("VPT_CHUNK_CHARS", "300")            # shards that are themselves pipelined
+    clones = [pred, pred.clone_to_device(0)]
+    scores, labels, _ = api.predict_packed_sharded(clones, utf8, boff)
+    assert np.array_equal(scores, o_scores) and np.array_equal(labels, o_labels)
+
+
+def test_char_types_from_the_device():
+    """vpt_char_types_batch = Sentence::char_types (sentence.rs:1016) for a batch, plain and through KyteaFullwidthFilter."""
+    pred, _ = make_predictor(kat.predictor_test_model())
+    texts = ["Ab1あア漢、𠮷", "x", "ｱＡ１", "0９a"] + randmodel.rand_sentences(2, kat.predictor_test_model(), 200, alphabet="mixed", max_len=40)
+    utf8, boff = api.pack_texts([t.encode("utf-8") for t in texts])
+    ooff = api.count_boundaries(utf8, boff)
+    got = pred.char_types_packed(utf8, boff, ooff)
+    want = np.concatenate([api.Sentence.from_raw(t).char_types() for t in texts])
+    assert np.array_equal(got, want)
+    got_fw = pred.char_types_packed(utf8, boff, ooff, fullwidth=True)
+    fw = api.KyteaFullwidthFilter()
+    want_fw = np.concatenate([api.Sentence.from_raw(fw.filter(t)).char_types() for t in texts])
+    assert np.array_equal(got_fw, want_fw)

@@ -48,6 +48,12 @@ SIGNATURES = {
     "vpt_predict_batch": (C.c_int, [_P, _P, _P, C.c_size_t, _P, _P, _P]),
     "vpt_predict_batch_flags": (C.c_int, [_P, _P, _P, C.c_size_t, _P, _P, _P, C.c_uint]),
     "vpt_predict_one": (C.c_int, [_P, _P, C.c_size_t, _P, _P, C.POINTER(C.c_size_t)]),
+    "vpt_host_alloc": (C.c_int, [C.c_size_t, C.POINTER(_P)]),
+    "vpt_host_free": (None, [_P]),
+    "vpt_predict_batch_sharded": (C.c_int, [_P, C.c_size_t, _P, _P, C.c_size_t, _P, _P, _P, C.c_uint]),
+    "vpt_shard_bounds": (C.c_int, [_P, C.c_size_t, C.c_size_t, _P]),
+    "vpt_char_types_batch": (C.c_int, [_P, _P, _P, C.c_size_t, _P, C.c_uint, _P]),
+    "vpt_char_types_batch_device": (C.c_int, [_P, _P, _P, _P, _P, C.c_size_t, C.c_uint64, _P, _P]),
     "vpt_predictor_n_tags": (C.c_int, [_P, C.POINTER(C.c_uint32)]),
     "vpt_fill_tags_batch": (C.c_int, [_P, _P, _P, C.c_size_t, _P, _P, _P]),
     "vpt_fill_tags_batch_flags": (C.c_int, [_P, _P, _P, C.c_size_t, _P, _P, _P, C.c_uint]),

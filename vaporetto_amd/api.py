@@ -544,6 +544,76 @@ class Predictor:
         return scores[:nb], labels[:nb], ooff
 
 
+    def char_types_packed(self, utf8: np.ndarray, byte_offsets: np.ndarray, out_offsets: np.ndarray, fullwidth: bool = False) -> np.ndarray:
+        """Sentence::char_types for a packed batch, from the device: uint8 per char (char c of sentence i at out_offsets[i] + i + c)."""
+        utf8 = np.ascontiguousarray(utf8, dtype=np.uint8)
+        byte_offsets = np.ascontiguousarray(byte_offsets, dtype=np.uint64)
+        out_offsets = np.ascontiguousarray(out_offsets, dtype=np.uint64)
+        S = len(byte_offsets) - 1
+        types = np.zeros(int(out_offsets[S]) + S + 1, dtype=np.uint8)
+        st = _lib.load().vpt_char_types_batch(self._h, utf8.ctypes.data, byte_offsets.ctypes.data, S, out_offsets.ctypes.data,
+                                              _lib.VPT_FLAG_KYTEA_FULLWIDTH if fullwidth else 0, types.ctypes.data)
+        if st != _lib.VPT_OK:
+            _raise(st)
+        return types[:int(out_offsets[S]) + S]
+
+
+def predict_packed_sharded(predictors: Sequence[Predictor], utf8: np.ndarray, byte_offsets: np.ndarray, out_offsets: Optional[np.ndarray] = None,
+                           scores: Optional[np.ndarray] = None, labels: Optional[np.ndarray] = None, flags: int = 0):
+    """vpt_predict_batch_sharded: one batch over several predictors (one per GPU), contiguous shards balanced by chars.
+    `scores` / `labels` may be preallocated (pinned) arrays.  Returns (scores, labels, out_offsets)."""
+    L = _lib.load()
+    utf8 = np.ascontiguousarray(utf8, dtype=np.uint8)
+    byte_offsets = np.ascontiguousarray(byte_offsets, dtype=np.uint64)
+    S = len(byte_offsets) - 1
+    if out_offsets is None:
+        out_offsets = count_boundaries(utf8, byte_offsets)
+    out_offsets = np.ascontiguousarray(out_offsets, dtype=np.uint64)
+    nb = int(out_offsets[S])
+    if scores is None:
+        scores = np.zeros(max(nb, 1), dtype=np.int32)
+    if labels is None:
+        labels = np.zeros(max(nb, 1), dtype=np.uint8)
+    handles = (C.c_void_p * len(predictors))(*[p.handle for p in predictors])
+    st = L.vpt_predict_batch_sharded(handles, len(predictors), utf8.ctypes.data, byte_offsets.ctypes.data, S, scores.ctypes.data,
+                                     labels.ctypes.data, out_offsets.ctypes.data, flags)
+    if st != _lib.VPT_OK:
+        _raise(st)
+    return scores[:nb], labels[:nb], out_offsets
+
+
+def shard_bounds(out_offsets: np.ndarray, n_shards: int) -> np.ndarray:
+    """vpt_shard_bounds: contiguous sentence ranges balanced by characters."""
+    out_offsets = np.ascontiguousarray(out_offsets, dtype=np.uint64)
+    bounds = np.zeros(n_shards + 1, dtype=np.uint64)
+    st = _lib.load().vpt_shard_bounds(out_offsets.ctypes.data, len(out_offsets) - 1, n_shards, bounds.ctypes.data)
+    if st != _lib.VPT_OK:
+        _raise(st)
+    return bounds
+
+
+class PinnedArray:
+    """A numpy array over page-locked host memory from vpt_host_alloc (hipHostMalloc): copies to and from the device are
+    DMA transfers at the PCIe rate.  Keep the object alive as long as `.array` is in use."""
+
+    def __init__(self, shape, dtype):
+        self.array = None
+        n = int(np.prod(shape)) * np.dtype(dtype).itemsize
+        self._ptr = C.c_void_p()
+        st = _lib.load().vpt_host_alloc(max(n, 1), C.byref(self._ptr))
+        if st != _lib.VPT_OK:
+            self._ptr = None
+            _raise(st)
+        buf = (C.c_uint8 * max(n, 1)).from_address(self._ptr.value)
+        self.array = np.frombuffer(buf, dtype=dtype, count=int(np.prod(shape))).reshape(shape)
+
+    def __del__(self):
+        if getattr(self, "_ptr", None):
+            self.array = None
+            _lib.load().vpt_host_free(self._ptr)
+            self._ptr = None
+
+
 class DeviceBatch:
     """Per-caller workspace for the device-resident entry point (vpt_batch)."""
 

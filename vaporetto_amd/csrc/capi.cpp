@@ -10,6 +10,7 @@
 #include <mutex>
 #include <new>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "kernels.hpp"
@@ -137,6 +138,16 @@ struct vpt_batch {
     int32_t* d_tok_model = nullptr; size_t tok_model_cap = 0;      // tag model of every token, from the last fill_tags on this workspace
     uint64_t tok_model_chars = 0;                                   // ... which covered this many chars
     std::vector<uint64_t> h_boff, h_ooff;                           // rebased offsets of the call in flight (copied asynchronously)
+    uint8_t* d_types = nullptr; size_t types_cap = 0;               // vpt_char_types_batch
+    // the pipelined host-buffer path (predict_pipelined): two sets of device buffers, copy streams, pinned offset staging
+    struct PipeSet {
+        uint8_t* text = nullptr; size_t text_cap = 0;
+        uint64_t *boff = nullptr, *ooff = nullptr; size_t boff_cap = 0, ooff_cap = 0;
+        int32_t* scores = nullptr; uint8_t* labels = nullptr; size_t scores_cap = 0, labels_cap = 0;
+        hipEvent_t ev_in = nullptr, ev_k = nullptr, ev_out = nullptr;   // chunk copied in / scored / copied out
+    } pipe[2];
+    hipStream_t s_in = nullptr, s_out = nullptr;
+    uint64_t* h_off = nullptr; size_t h_off_cap = 0;                // pinned: the rebased offsets of every chunk of the call in flight
 };
 
 struct DeviceTags {   // views into the arena
@@ -191,6 +202,16 @@ void batch_release(vpt_batch* b) {
     (void)hipFree(b->d_prof); (void)hipFree(b->d_cps);
     (void)hipFree(b->d_text); (void)hipFree(b->d_boff); (void)hipFree(b->d_ooff); (void)hipFree(b->d_scores); (void)hipFree(b->d_labels);
     (void)hipFree(b->d_tags); (void)hipFree(b->d_tok); (void)hipFree(b->d_toff); (void)hipFree(b->d_tok_model);
+    (void)hipFree(b->d_types);
+    for (auto& ps : b->pipe) {
+        (void)hipFree(ps.text); (void)hipFree(ps.boff); (void)hipFree(ps.ooff); (void)hipFree(ps.scores); (void)hipFree(ps.labels);
+        if (ps.ev_in) (void)hipEventDestroy(ps.ev_in);
+        if (ps.ev_k) (void)hipEventDestroy(ps.ev_k);
+        if (ps.ev_out) (void)hipEventDestroy(ps.ev_out);
+    }
+    if (b->h_off) (void)hipHostFree(b->h_off);
+    if (b->s_in) (void)hipStreamDestroy(b->s_in);
+    if (b->s_out) (void)hipStreamDestroy(b->s_out);
     for (hipEvent_t e : b->ev) (void)hipEventDestroy(e);
     if (b->own_stream) (void)hipStreamDestroy(b->own_stream);
     delete b;
@@ -230,6 +251,8 @@ struct Workspace {
     ~Workspace() {
         if (!b) return;
         (void)hipStreamSynchronize(b->own_stream);   // an error return may leave copies from the caller's buffers in flight
+        if (b->s_in) (void)hipStreamSynchronize(b->s_in);
+        if (b->s_out) (void)hipStreamSynchronize(b->s_out);
         std::lock_guard<std::mutex> g(p->pool_mu);
         p->pool.push_back(b);
     }
@@ -812,6 +835,80 @@ vpt_status vpt_batch_sync(vpt_batch* b) {
     return status_from_bits(ctrl[0]);
 }
 
+namespace {
+
+// Chars per chunk of the pipelined host-buffer path: large enough for a launch to cover the chip's workgroup slots a few
+// times over, small enough that a 100 K-sentence batch is seven chunks in flight (VPT_CHUNK_CHARS overrides; tests use it).
+uint64_t pipeline_chunk_chars() {
+    if (const char* v = std::getenv("VPT_CHUNK_CHARS")) { const long long n = std::atoll(v); if (n > 0) return uint64_t(n); }
+    return uint64_t(1) << 20;
+}
+
+// vpt_predict_batch for a batch of several chunks: the copy in of chunk k + 1, the kernels of chunk k and the copy out
+// of chunk k - 1 run at the same time on three streams over two sets of device buffers, so that a caller with PINNED
+// buffers (vpt_host_alloc) gets both directions of the PCIe link busy at once instead of a copy-launch-copy sequence;
+// pageable buffers go through the runtime's staging and still overlap with the kernels.  `cuts` = the first sentence of
+// every chunk, then n_sentences.
+vpt_status predict_pipelined(const vpt_predictor* p, vpt_batch* b, const uint8_t* utf8, const uint64_t* byte_offsets, size_t n_sentences,
+                             int32_t* scores_out, uint8_t* labels_out, const uint64_t* out_offsets, const std::vector<size_t>& cuts,
+                             uint64_t max_bytes, uint64_t max_chars) {
+    const size_t n_chunks = cuts.size() - 1;
+    if (!b->s_in) {
+        VPT_HIP(hipStreamCreateWithFlags(&b->s_in, hipStreamNonBlocking));
+        VPT_HIP(hipStreamCreateWithFlags(&b->s_out, hipStreamNonBlocking));
+        for (auto& ps : b->pipe) {
+            VPT_HIP(hipEventCreateWithFlags(&ps.ev_in, hipEventDisableTiming));
+            VPT_HIP(hipEventCreateWithFlags(&ps.ev_k, hipEventDisableTiming));
+            VPT_HIP(hipEventCreateWithFlags(&ps.ev_out, hipEventDisableTiming));
+        }
+    }
+    const size_t need_off = 2 * (n_sentences + n_chunks);   // every chunk has one entry more than sentences, twice (bytes, boundaries)
+    if (need_off > b->h_off_cap) {
+        if (b->h_off) (void)hipHostFree(b->h_off);
+        b->h_off = nullptr; b->h_off_cap = 0;
+        VPT_HIP(hipHostMalloc(reinterpret_cast<void**>(&b->h_off), (need_off + need_off / 2) * sizeof(uint64_t), hipHostMallocDefault));
+        b->h_off_cap = need_off + need_off / 2;
+    }
+    uint64_t* h_boff = b->h_off;
+    uint64_t* h_ooff = b->h_off + (n_sentences + n_chunks);
+    b->max_chars = max_chars;
+    vpt_status st;
+    for (size_t k = 0; k < n_chunks; ++k) {
+        vpt_batch::PipeSet& ps = b->pipe[k & 1];
+        const size_t a = cuts[k], e = cuts[k + 1], n = e - a;
+        const uint64_t t0 = byte_offsets[a], nbytes = byte_offsets[e] - t0;
+        const uint64_t o0 = out_offsets[a], nb = out_offsets[e] - o0;
+        uint64_t* hb = h_boff + a + k;
+        uint64_t* ho = h_ooff + a + k;
+        for (size_t j = 0; j <= n; ++j) { hb[j] = byte_offsets[a + j] - t0; ho[j] = out_offsets[a + j] - o0; }
+        // this set's buffers are free once chunk k - 2 has been scored (inputs) and copied out (outputs)
+        if (k >= 2) { VPT_HIP(hipEventSynchronize(ps.ev_out)); }   // also bounds how far the host runs ahead; growing a buffer below is then safe
+        if ((st = grow(&ps.text, &ps.text_cap, size_t(nbytes) + 32)) != VPT_OK) return st;
+        if ((st = grow(&ps.boff, &ps.boff_cap, n + 1)) != VPT_OK) return st;
+        if ((st = grow(&ps.ooff, &ps.ooff_cap, n + 1)) != VPT_OK) return st;
+        if (scores_out && (st = grow(&ps.scores, &ps.scores_cap, size_t(nb) + 1)) != VPT_OK) return st;
+        if (labels_out && (st = grow(&ps.labels, &ps.labels_cap, size_t(nb) + 1)) != VPT_OK) return st;
+        VPT_HIP(hipMemcpyAsync(ps.text, utf8 + t0, size_t(nbytes), hipMemcpyHostToDevice, b->s_in));
+        VPT_HIP(hipMemcpyAsync(ps.boff, hb, 8 * (n + 1), hipMemcpyHostToDevice, b->s_in));
+        VPT_HIP(hipMemcpyAsync(ps.ooff, ho, 8 * (n + 1), hipMemcpyHostToDevice, b->s_in));
+        VPT_HIP(hipEventRecord(ps.ev_in, b->s_in));
+        VPT_HIP(hipStreamWaitEvent(b->own_stream, ps.ev_in, 0));
+        st = vpt_predict_batch_device(p, b, ps.text, ps.boff, ps.ooff, n, nb, max_bytes, scores_out ? ps.scores : nullptr,
+                                      labels_out ? ps.labels : nullptr, b->own_stream);
+        if (st != VPT_OK) return st;
+        VPT_HIP(hipEventRecord(ps.ev_k, b->own_stream));
+        VPT_HIP(hipStreamWaitEvent(b->s_out, ps.ev_k, 0));
+        if (scores_out && nb) VPT_HIP(hipMemcpyAsync(scores_out + o0, ps.scores, 4 * size_t(nb), hipMemcpyDeviceToHost, b->s_out));
+        if (labels_out && nb) VPT_HIP(hipMemcpyAsync(labels_out + o0, ps.labels, size_t(nb), hipMemcpyDeviceToHost, b->s_out));
+        VPT_HIP(hipEventRecord(ps.ev_out, b->s_out));
+    }
+    VPT_HIP(hipStreamSynchronize(b->s_in));
+    VPT_HIP(hipStreamSynchronize(b->s_out));
+    return vpt_batch_sync(b);   // the device's verdict over every chunk (the status word accumulates)
+}
+
+}  // namespace
+
 vpt_status vpt_predict_batch(const vpt_predictor* p, const uint8_t* utf8, const uint64_t* byte_offsets, size_t n_sentences,
                              int32_t* scores_out, uint8_t* labels_out, const uint64_t* out_offsets) {
     return vpt_predict_batch_flags(p, utf8, byte_offsets, n_sentences, scores_out, labels_out, out_offsets, 0u);
@@ -828,10 +925,31 @@ vpt_status vpt_predict_batch_flags(const vpt_predictor* p, const uint8_t* utf8, 
     vpt_status st = acquire(p, &w);
     if (st != VPT_OK) return st;
     vpt_batch* b = w.b;
+    b->flags = flags;
+    {   // a batch of several chunks goes through the copy/compute pipeline
+        const uint64_t chunk = pipeline_chunk_chars();
+        const uint64_t total_chars = out_offsets[n_sentences] - out_offsets[0] + n_sentences;
+        if (byte_offsets[n_sentences] >= byte_offsets[0] && out_offsets[n_sentences] >= out_offsets[0] && total_chars > chunk + chunk / 2) {
+            std::vector<size_t> cuts(1, 0);
+            uint64_t max_bytes = 0, max_chars = 0, in_chunk = 0;
+            for (size_t i = 0; i < n_sentences; ++i) {
+                if (byte_offsets[i + 1] <= byte_offsets[i])
+                    return fail(VPT_INVALID_ARGUMENT, "InvalidArgumentError: text: must contain at least one character");
+                const uint64_t nby = byte_offsets[i + 1] - byte_offsets[i];
+                if (out_offsets[i + 1] < out_offsets[i] || out_offsets[i + 1] - out_offsets[i] + 1 > nby)
+                    return fail(VPT_INVALID_ARGUMENT, "InvalidArgumentError: out_offsets: do not match the text (or the text is not valid UTF-8)");
+                const uint64_t nch = out_offsets[i + 1] - out_offsets[i] + 1;
+                max_bytes = std::max(max_bytes, nby); max_chars = std::max(max_chars, nch);
+                if (in_chunk >= chunk) { cuts.push_back(i); in_chunk = 0; }
+                in_chunk += nch;
+            }
+            cuts.push_back(n_sentences);
+            if (cuts.size() > 2) return predict_pipelined(p, b, utf8, byte_offsets, n_sentences, scores_out, labels_out, out_offsets, cuts, max_bytes, max_chars);
+        }
+    }
     uint64_t total_b = 0, max_bytes = 0, max_chars = 0;
     if ((st = stage(b, utf8, byte_offsets, out_offsets, n_sentences, nullptr, &total_b, &max_bytes, &max_chars)) != VPT_OK) return st;
     b->max_chars = max_chars;
-    b->flags = flags;
     hipStream_t s = b->own_stream;
     st = vpt_predict_batch_device(p, b, b->d_text, b->d_boff, b->d_ooff, n_sentences, total_b, max_bytes,
                                   scores_out ? b->d_scores : nullptr, labels_out ? b->d_labels : nullptr, s);
@@ -901,7 +1019,7 @@ vpt_status vpt_fill_tags_batch_device(const vpt_predictor* p, vpt_batch* b, cons
     const uint32_t* cinfo = p->d_cinfo + ((b->flags & VPT_FLAG_KYTEA_FULLWIDTH) ? 65536 : 0);
     VPT_HIP(hipMemsetAsync(d_tags_out, 0xFF, size_t(total_c) * p->n_tags * sizeof(int32_t), stream));   // -1 = None
     VPT_HIP(hipMemsetAsync(b->d_tok_model, 0, size_t(total_c) * sizeof(int32_t), stream));
-    VPT_HIP(vpt::launch_decode_chars(d_utf8, d_byte_offsets, d_out_offsets, n_sentences, total_c, cinfo, b->d_cps, b->d_ctrl, stream));
+    VPT_HIP(vpt::launch_decode_chars(d_utf8, d_byte_offsets, d_out_offsets, n_sentences, total_c, cinfo, b->d_cps, nullptr, b->d_ctrl, stream));
     vpt::TagParams T{};
     T.tok_tab = p->dtag.tok_tab; T.models = p->dtag.models; T.ngrams = p->dtag.ngrams; T.syms = p->dtag.syms; T.slots = p->dtag.slots;
     T.weights = p->dtag.weights; T.cinfo = cinfo; T.tok_bits = p->tok_bits; T.n_tags = p->n_tags;
@@ -1096,6 +1214,110 @@ vpt_status vpt_tokenize_batch(const vpt_predictor* p, const uint8_t* utf8, const
     VPT_HIP(hipMemcpy(text_offsets_out, b->d_toff, 8 * (n_sentences + 1), hipMemcpyDeviceToHost));
     const uint64_t total = text_offsets_out[n_sentences];
     if (total) VPT_HIP(hipMemcpy(text_out, b->d_tok, size_t(total), hipMemcpyDeviceToHost));
+    return VPT_OK;
+}
+
+// ---- pinned host memory for callers that want the PCIe link at full rate
+vpt_status vpt_host_alloc(size_t bytes, void** out) {
+    if (!out) return fail(VPT_INVALID_ARGUMENT, "InvalidArgumentError: out: must not be NULL");
+    *out = nullptr;
+    int n_dev = 0;
+    if (hipGetDeviceCount(&n_dev) != hipSuccess || n_dev <= 0)
+        return fail(VPT_RUNTIME_ERROR, "no HIP device available (this library has no CPU fallback)");
+    VPT_HIP(hipHostMalloc(out, bytes ? bytes : 1, hipHostMallocDefault));
+    return VPT_OK;
+}
+void vpt_host_free(void* ptr) { if (ptr) (void)hipHostFree(ptr); }
+
+// Contiguous sentence ranges with about the same number of CHARACTERS each (what the scoring costs; a sentence of n chars
+// has out_offsets[i+1] - out_offsets[i] + 1 of them): bounds[r] .. bounds[r+1] is shard r.
+vpt_status vpt_shard_bounds(const uint64_t* out_offsets, size_t n_sentences, size_t n_shards, uint64_t* bounds) {
+    if (!out_offsets || !bounds || n_shards == 0) return fail(VPT_INVALID_ARGUMENT, "InvalidArgumentError: NULL argument or n_shards = 0");
+    const uint64_t base = out_offsets[0];
+    auto chars_before = [&](size_t i) { return out_offsets[i] - base + i; };
+    const uint64_t total = chars_before(n_sentences);
+    bounds[0] = 0;
+    for (size_t r = 1; r < n_shards; ++r) {
+        const uint64_t target = (unsigned __int128)(total) * r / n_shards;
+        size_t lo = size_t(bounds[r - 1]), hi = n_sentences;      // first sentence with chars_before >= target
+        while (lo < hi) {
+            const size_t mid = lo + (hi - lo) / 2;
+            if (chars_before(mid) >= target) hi = mid; else lo = mid + 1;
+        }
+        bounds[r] = lo;
+    }
+    bounds[n_shards] = n_sentences;
+    return VPT_OK;
+}
+
+// Predictor::predict over one batch on SEVERAL GPUs: shard r (vpt_shard_bounds) is scored by preds[r] -- normally
+// vpt_predictor_clone_to_device copies of one predictor, one per GPU of the node -- on a host thread of its own through the
+// pipelined host-buffer path, straight into its slice of the caller's outputs.  No exchange between the devices.
+vpt_status vpt_predict_batch_sharded(const vpt_predictor* const* preds, size_t n_preds, const uint8_t* utf8, const uint64_t* byte_offsets,
+                                     size_t n_sentences, int32_t* scores_out, uint8_t* labels_out, const uint64_t* out_offsets, unsigned flags) {
+    if (!preds || n_preds == 0) return fail(VPT_INVALID_ARGUMENT, "InvalidArgumentError: preds: must name at least one predictor");
+    for (size_t r = 0; r < n_preds; ++r)
+        if (!preds[r]) return fail(VPT_INVALID_ARGUMENT, "InvalidArgumentError: predictor: must not be NULL");
+    if (n_sentences == 0) return VPT_OK;
+    if (!utf8 || !byte_offsets || !out_offsets) return fail(VPT_INVALID_ARGUMENT, "InvalidArgumentError: NULL argument");
+    if (n_preds == 1) return vpt_predict_batch_flags(preds[0], utf8, byte_offsets, n_sentences, scores_out, labels_out, out_offsets, flags);
+    std::vector<uint64_t> bounds(n_preds + 1);
+    vpt_status st = vpt_shard_bounds(out_offsets, n_sentences, n_preds, bounds.data());
+    if (st != VPT_OK) return st;
+    std::vector<vpt_status> rc(n_preds, VPT_OK);
+    std::vector<std::string> msg(n_preds);
+    std::vector<std::thread> th;
+    for (size_t r = 0; r < n_preds; ++r)
+        th.emplace_back([&, r] {
+            const size_t a = size_t(bounds[r]), n = size_t(bounds[r + 1] - bounds[r]);
+            if (n == 0) return;
+            // the offsets stay absolute: shard r reads utf8[byte_offsets[a] ..) and writes scores_out[out_offsets[a] ..)
+            rc[r] = vpt_predict_batch_flags(preds[r], utf8, byte_offsets + a, n, scores_out, labels_out, out_offsets + a, flags);
+            if (rc[r] != VPT_OK) msg[r] = g_last_error;   // thread-local: carried back to the caller's thread
+        });
+    for (std::thread& t : th) t.join();
+    for (size_t r = 0; r < n_preds; ++r)
+        if (rc[r] != VPT_OK) return fail(rc[r], msg[r]);
+    return VPT_OK;
+}
+
+// Sentence::char_types for a batch (sentence.rs:1016; CharacterType::get_type, sentence.rs:50-67): one u8 per char,
+// char c of sentence i at types_out[out_offsets[i] + i + c]; with VPT_FLAG_KYTEA_FULLWIDTH the types of the normalised text
+// (what the CLI's Sentence holds, predict/src/main.rs:126-129).
+vpt_status vpt_char_types_batch_device(const vpt_predictor* p, vpt_batch* b, const uint8_t* d_utf8, const uint64_t* d_byte_offsets,
+                                       const uint64_t* d_out_offsets, size_t n_sentences, uint64_t total_boundaries, uint8_t* d_types_out,
+                                       void* hip_stream) {
+    if (!p || !b || b->pred != p) return fail(VPT_INVALID_ARGUMENT, "InvalidArgumentError: batch: does not belong to this predictor");
+    if (n_sentences == 0) return VPT_OK;
+    if (!d_utf8 || !d_byte_offsets || !d_out_offsets || !d_types_out) return fail(VPT_INVALID_ARGUMENT, "InvalidArgumentError: NULL device pointer");
+    hipStream_t stream = static_cast<hipStream_t>(hip_stream);
+    VPT_HIP(hipSetDevice(p->device));
+    const uint32_t* cinfo = p->d_cinfo + ((b->flags & VPT_FLAG_KYTEA_FULLWIDTH) ? 65536 : 0);
+    VPT_HIP(vpt::launch_decode_chars(d_utf8, d_byte_offsets, d_out_offsets, n_sentences, total_boundaries + n_sentences, cinfo, nullptr, d_types_out,
+                                     b->d_ctrl, stream));
+    b->last_stream = stream; b->pending = true;
+    return VPT_OK;
+}
+
+vpt_status vpt_char_types_batch(const vpt_predictor* p, const uint8_t* utf8, const uint64_t* byte_offsets, size_t n_sentences,
+                                const uint64_t* out_offsets, unsigned flags, uint8_t* types_out) {
+    if (flags & ~unsigned(VPT_FLAG_KYTEA_FULLWIDTH)) return fail(VPT_INVALID_ARGUMENT, "InvalidArgumentError: flags: unknown bit");
+    if (!p) return fail(VPT_INVALID_ARGUMENT, "InvalidArgumentError: predictor: must not be NULL");
+    if (n_sentences == 0) return VPT_OK;
+    if (!utf8 || !byte_offsets || !out_offsets || !types_out) return fail(VPT_INVALID_ARGUMENT, "InvalidArgumentError: NULL argument");
+    VPT_HIP(hipSetDevice(p->device));
+    Workspace w;
+    vpt_status st = acquire(p, &w);
+    if (st != VPT_OK) return st;
+    vpt_batch* b = w.b;
+    uint64_t total_b = 0;
+    if ((st = stage(b, utf8, byte_offsets, out_offsets, n_sentences, nullptr, &total_b, nullptr, nullptr)) != VPT_OK) return st;
+    const size_t total_c = size_t(total_b) + n_sentences;
+    if ((st = grow(&b->d_types, &b->types_cap, total_c + 16)) != VPT_OK) return st;
+    b->flags = flags;
+    if ((st = vpt_char_types_batch_device(p, b, b->d_text, b->d_boff, b->d_ooff, n_sentences, total_b, b->d_types, b->own_stream)) != VPT_OK) return st;
+    if ((st = vpt_batch_sync(b)) != VPT_OK) return st;
+    VPT_HIP(hipMemcpy(types_out + size_t(out_offsets[0]) + 0, b->d_types, total_c, hipMemcpyDeviceToHost));
     return VPT_OK;
 }
 

@@ -74,7 +74,7 @@ struct TagParams {
     int32_t* tags;              // [(total boundaries + S) * n_tags] candidate index per slot, -1 = None
 };
 hipError_t launch_decode_chars(const uint8_t* text, const uint64_t* boff, const uint64_t* ooff, uint64_t n_sent, uint64_t total_chars,
-                               const uint32_t* cinfo, uint32_t* cps, uint32_t* status, hipStream_t stream);
+                               const uint32_t* cinfo, uint32_t* cps, uint8_t* types, uint32_t* status, hipStream_t stream);
 hipError_t launch_tag_tokens(const TagParams& P, hipStream_t stream);
 
 // token emission (kernels_emit.hip): Sentence::write_tokenized_text, boundary part

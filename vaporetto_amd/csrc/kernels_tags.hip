@@ -34,7 +34,7 @@ __device__ __forceinline__ uint32_t lanes_below(uint64_t mask, int lane) {
 __global__ __launch_bounds__(kTagThreads) void decode_chars_kernel(const uint8_t* __restrict__ text, const uint64_t* __restrict__ boff,
                                                                    const uint64_t* __restrict__ ooff, uint64_t n_sent, uint64_t total_chars,
                                                                    const uint32_t* __restrict__ cinfo, uint32_t* __restrict__ cps,
-                                                                   uint32_t* __restrict__ status) {
+                                                                   uint8_t* __restrict__ types, uint32_t* __restrict__ status) {
     const int lane = threadIdx.x & 63;
     const uint64_t wave = uint64_t(blockIdx.x) * kTagWaves + (threadIdx.x >> 6);
     const uint64_t n_waves = uint64_t(gridDim.x) * kTagWaves;
@@ -58,7 +58,9 @@ __global__ __launch_bounds__(kTagThreads) void decode_chars_kernel(const uint8_t
                 if (byte0 >= 0xE0u && at + 2 < b1) b4 |= uint32_t(text[at + 2]) << 16;
                 if (byte0 >= 0xF0u && at + 3 < b1) b4 |= uint32_t(text[at + 3]) << 24;
                 const uint32_t cp = utf8_scalar(b4);
-                cps[g + idx] = cp < 0x10000u ? cinfo[cp] & 0xFFFFu : cp;   // the scored char
+                const uint32_t info = cp < 0x10000u ? cinfo[cp] : 0u;   // the scored char | its CharacterType << 16 (BMP only)
+                if (cps) cps[g + idx] = cp < 0x10000u ? info & 0xFFFFu : cp;
+                if (types) types[g + idx] = uint8_t(cp < 0x10000u ? info >> 16 : char_type(cp));   // Sentence::char_types (sentence.rs:1016)
             }
             seen += uint64_t(__popcll(m));
         }
@@ -181,11 +183,11 @@ __global__ __launch_bounds__(kTagThreads) void tag_tokens_kernel(const TagParams
 }  // namespace
 
 hipError_t launch_decode_chars(const uint8_t* text, const uint64_t* boff, const uint64_t* ooff, uint64_t n_sent, uint64_t total_chars,
-                               const uint32_t* cinfo, uint32_t* cps, uint32_t* status, hipStream_t stream) {
+                               const uint32_t* cinfo, uint32_t* cps, uint8_t* types, uint32_t* status, hipStream_t stream) {
     const uint64_t want = (n_sent + kTagWaves - 1) / kTagWaves;
     const uint32_t blocks = uint32_t(want < 1 ? 1 : want > 65536 ? 65536 : want);
     hipLaunchKernelGGL(decode_chars_kernel, dim3(blocks), dim3(kTagThreads), 0, stream, text, boff, ooff, n_sent, total_chars, cinfo, cps,
-                       status);
+                       types, status);
     return hipGetLastError();
 }
 
