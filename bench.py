@@ -1,10 +1,17 @@
 #!/usr/bin/env python
 """bench.py -- boundary scores/sec of the MI355X hot path (BASELINE.json metric).
 
-One "step" = one pass of Predictor::predict over one batch of synthetic sentences that is already resident in
-HBM (configs[1]: bccwj-suw+unidic-shaped model, 100 K sentences x 64 chars per GPU).  With N GPUs every rank
-scores its own batch (sentences shard trivially; no data-path collective) after the model file has been
-broadcast from rank 0 over RCCL -- weak scaling.
+One "step" = one pass of Predictor::predict over one batch of synthetic sentences that is already resident in HBM.
+The workloads are BASELINE.json's configs:
+
+  configs[1]  bccwj-suw+unidic-shaped model (synthetic M1), 100 K sentences x 64 chars            -- the line's `value` at N = 1
+  configs[2]  the same model, 10 M sentences x 64 chars cut into character-balanced shards over the N ranks (strong
+              scaling; the predictor is compiled on rank 0 and its tables are broadcast over RCCL) -- the `value` at N > 1
+  configs[3]  jp-0.4.7-5-shaped model (synthetic M2, dictionary heavy), 100 K x 64
+  configs[4]  M1 + tag models (synthetic M3), predict_tags on, 1 M sentences of 8..512 chars / N, step = predict + fill_tags
+
+With no --config, N = 1 reports configs[1] and folds configs[3], [4] and [2] (its N = 1 point) into `workloads`, each with
+its own parity, kernel time and roofline; N > 1 reports configs[2].  (--quick: the primary workload only.)
 
     python bench.py --gpus 1 --steps 20 --warmup 3
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
@@ -13,6 +20,7 @@ broadcast from rank 0 over RCCL -- weak scaling.
 from __future__ import annotations
 
 import argparse
+import hashlib
 import json
 import os
 import subprocess
@@ -25,7 +33,16 @@ if ROOT not in sys.path:
 
 import numpy as np  # noqa: E402
 
-HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+PCIE_GBS = 63.0         # MI355X_MICROARCH.md: PCIe Gen5 x16, per direction
+
+CONFIGS = {
+    1: dict(name="configs[1]", kind=1, sentences=100_000, min_len=64, max_len=64, tags=False, blocks=False),
+    2: dict(name="configs[2]", kind=1, sentences=10_000_000, min_len=64, max_len=64, tags=False, blocks=True),
+    3: dict(name="configs[3]", kind=2, sentences=100_000, min_len=64, max_len=64, tags=False, blocks=False),
+    4: dict(name="configs[4]", kind=3, sentences=1_000_000, min_len=8, max_len=512, tags=True, blocks=True),
+}
+BLOCK = 100_000
 
 
 def load_model_bytes(kind: int, scale: float):
@@ -47,17 +64,296 @@ def load_model_bytes(kind: int, scale: float):
     return synth.synth_model(kind, synth.SEED_BASE + 2, scale), "synthetic-" + {1: "M1", 2: "M2", 3: "M3"}[kind]
 
 
-def measured_traffic(kernel: str, model: str, sentences: int):
-    """HBM bytes per launch from the committed rocprofv3 PMC summary (profiles/traffic.json), or None."""
+def kernel_source_hash() -> str:
+    """What the rocprofv3 traffic numbers of profiles/traffic.json are valid for: the kernel and table sources."""
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "vaporetto_amd", "csrc")
+    for f in sorted(os.listdir(d)):
+        if f.endswith((".hip", ".cpp", ".h", ".hpp")):
+            with open(os.path.join(d, f), "rb") as fh:
+                h.update(f.encode() + b"\0" + fh.read())
+    return h.hexdigest()[:16]
+
+
+def measured_traffic(kernel: str, model: str, workload: str):
+    """HBM-side bytes per launch of `kernel` from the rocprofv3 PMC passes tools/profile.sh ran on THESE sources
+    (profiles/traffic.json: reads = 128 B x TCC_EA0_RDREQ_128B + 64 B x .._64B + 32 B x .._32B, writes = WRITE_SIZE; both
+    checked against known byte counts, profiles/r02_c2_read_request_sizes.txt), or None when the sources have changed since."""
     try:
         with open(os.path.join(ROOT, "profiles", "traffic.json")) as fh:
             entries = json.load(fh)["entries"]
     except (OSError, ValueError, KeyError):
         return None
+    sha = kernel_source_hash()
     for e in reversed(entries):
-        if e["kernel"] == kernel and e["model"] == model and e["sentences_per_gpu"] == sentences:
-            return int(1024 * (e["fetch_size_kib"] * e["fetch_correction"] + e["write_size_kib"]))
+        if e.get("kernel") == kernel and e.get("model") == model and e.get("workload") == workload and e.get("source_hash") == sha:
+            return int(e["read_bytes"] + e["write_bytes"])
     return None
+
+
+def cpu_model_name() -> str:
+    try:
+        with open("/proc/cpuinfo") as fh:
+            for line in fh:
+                if line.startswith("model name"):
+                    return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+class Runner:
+    def __init__(self, args):
+        import torch
+        import torch.distributed as dist
+        self.args, self.torch, self.dist = args, torch, dist
+        self.rank = int(os.environ.get("RANK", "0"))
+        self.world = int(os.environ.get("WORLD_SIZE", "1"))
+        self.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+        if self.world != args.gpus and self.world > 1:
+            raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, self.world))
+        # (test hook for a 1-GPU box: VPT_BENCH_ONE_DEVICE=1 VPT_BENCH_BACKEND=gloo runs the N-rank code path with every rank on device 0)
+        if os.environ.get("VPT_BENCH_ONE_DEVICE"):
+            self.local_rank = 0
+        backend = os.environ.get("VPT_BENCH_BACKEND", "nccl")
+        torch.cuda.set_device(self.local_rank)
+        self.dev = torch.device("cuda", self.local_rank)
+        if self.world > 1:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            if backend == "nccl":
+                dist.init_process_group("nccl", rank=self.rank, world_size=self.world, device_id=self.dev)   # RCCL
+            else:
+                dist.init_process_group(backend, rank=self.rank, world_size=self.world)
+        self.backend = backend if self.world > 1 else None
+        self.ncores = max(1, (os.cpu_count() or 1) // self.world)
+
+    # ---- the predictor: compiled on rank 0, its tables broadcast device to device
+    def make_predictor(self, kind: int, tags: bool):
+        from vaporetto_amd import api, dist as vdist
+        raw, name = (load_model_bytes(kind, self.args.model_scale) if self.rank == 0 else (None, ""))
+        raw = vdist.broadcast_model_bytes(raw, src=0, device=self.dev)   # every rank draws its text from the model's patterns
+        t = time.perf_counter()
+        p0 = api.Predictor(api.Model.read_slice(raw)[0], tags, device=self.local_rank) if self.rank == 0 else None
+        create_s = time.perf_counter() - t
+        t = time.perf_counter()
+        pred = vdist.broadcast_predictor(p0, src=0, device=self.dev)
+        if self.world > 1:
+            self.torch.cuda.synchronize()
+        bcast_s = time.perf_counter() - t
+        if self.world > 1:
+            names = [None]
+            if self.rank == 0:
+                names = [name]
+            self.dist.broadcast_object_list(names, src=0)
+            name = names[0]
+        return pred, raw, name, create_s, bcast_s
+
+    # ---- this rank's shard of the batch
+    def make_shard(self, cfg, raw):
+        from vaporetto_amd import api, synth, dist as vdist
+        S, lo_len, hi_len = cfg["sentences"], cfg["min_len"], cfg["max_len"]
+        if self.args.sentences:
+            S = self.args.sentences
+        if not cfg["blocks"]:
+            utf8, boff = synth.synth_sentences(raw, S, lo_len, hi_len, seed=synth.SEED_BASE + 2)
+            ooff = api.count_boundaries(utf8, boff)
+            if self.world == 1:
+                return utf8, boff, ooff, 0, S
+            u, b, o, first = vdist.take_shard(utf8, boff, ooff, self.rank, self.world)
+            return u, b, o, first, S
+        n_blocks = (S + BLOCK - 1) // BLOCK
+        S = n_blocks * BLOCK
+        seed = synth.SEED_BASE + (3 if cfg["name"] == "configs[2]" else 5)
+        if lo_len == hi_len:
+            # equal lengths: the global offsets are arithmetic, so a rank generates only the blocks its shard touches
+            g_ooff = np.arange(S + 1, dtype=np.uint64) * np.uint64(lo_len - 1)
+            bounds = vdist.shard_bounds(g_ooff, self.world)
+            a, e = int(bounds[self.rank]), int(bounds[self.rank + 1])
+            b0, b1 = a // BLOCK, (e + BLOCK - 1) // BLOCK
+            utf8, boff = synth.synth_blocks(raw, b0, max(b1 - b0, 1), BLOCK, lo_len, hi_len, seed=seed, nthreads=min(32, self.ncores))
+            i0, i1 = a - b0 * BLOCK, e - b0 * BLOCK
+            t0, t1 = int(boff[i0]), int(boff[i1])
+            utf8, boff = np.ascontiguousarray(utf8[t0:t1]), (boff[i0:i1 + 1] - boff[i0]).astype(np.uint64)
+            ooff = (g_ooff[a:e + 1] - g_ooff[a]).astype(np.uint64)
+            return utf8, boff, ooff, a, S
+        # ragged lengths: every rank generates the batch and takes its character-balanced shard
+        utf8, boff = synth.synth_blocks(raw, 0, n_blocks, BLOCK, lo_len, hi_len, seed=seed, nthreads=min(32, self.ncores))
+        ooff = api.count_boundaries(utf8, boff)
+        if self.world == 1:
+            return utf8, boff, ooff, 0, S
+        u, b, o, first = vdist.take_shard(utf8, boff, ooff, self.rank, self.world)
+        return u, b, o, first, S
+
+    def all_true(self, flag: bool) -> bool:
+        if self.world == 1:
+            return flag
+        t = self.torch.tensor([1 if flag else 0], dtype=self.torch.int32, device=self.dev)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MIN)
+        return bool(t.item())
+
+    def run(self, cfg_id: int, primary: bool):
+        torch, dist = self.torch, self.dist
+        from vaporetto_amd import api, dist as vdist
+        args = self.args
+        cfg = CONFIGS[cfg_id]
+        pred, raw, model_name, create_s, bcast_s = self.make_predictor(cfg["kind"], cfg["tags"])
+        info = pred.info()
+        t = time.perf_counter()
+        utf8, boff, ooff, first, S_total = self.make_shard(cfg, raw)
+        synth_s = time.perf_counter() - t
+        S, nb, nbytes = len(boff) - 1, int(ooff[-1]), int(boff[-1])
+        max_bytes = int(np.max(np.diff(boff.astype(np.int64)))) if S else 1
+        max_chars = (int(np.max(np.diff(ooff.astype(np.int64)))) + 1) if S else 1
+        dev = self.dev
+        d_text = torch.from_numpy(np.concatenate([utf8, np.zeros(64, np.uint8)])).to(dev)
+        d_boff = torch.from_numpy(boff.astype(np.int64)).to(dev)
+        d_ooff = torch.from_numpy(ooff.astype(np.int64)).to(dev)
+        d_scores = torch.empty(nb + 1, dtype=torch.int32, device=dev)
+        d_labels = torch.empty(nb + 1, dtype=torch.uint8, device=dev)
+        if args.phases:
+            os.environ["VPT_PROFILE_PHASES"] = "1"
+        batch = api.DeviceBatch(pred, timing=True)
+        batch.set_max_sentence_chars(max_chars)
+        stream = torch.cuda.current_stream().cuda_stream
+        nt = pred.n_tags() if cfg["tags"] else 0
+        d_tags = torch.empty((nb + S) * nt + 1, dtype=torch.int32, device=dev) if nt else None
+
+        def step():
+            batch.predict(d_text.data_ptr(), d_boff.data_ptr(), d_ooff.data_ptr(), S, nb, max_bytes,
+                          d_scores.data_ptr(), d_labels.data_ptr(), stream)
+            if nt:   # Sentence::fill_tags on the labels just predicted: configs[4]'s step is the whole tagging job
+                batch.fill_tags(d_text.data_ptr(), d_boff.data_ptr(), d_ooff.data_ptr(), S, nb, d_labels.data_ptr(), d_tags.data_ptr(), stream)
+
+        steps = args.steps if primary else max(10, min(args.steps, 20))
+        for _ in range(args.warmup):
+            step()
+        batch.sync()
+        batch.kernel_ms()  # reset the event ring
+        if self.world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step()
+        torch.cuda.synchronize()
+        if self.world > 1:
+            dist.barrier()
+        elapsed = time.perf_counter() - t0
+        batch.sync()
+        ktimes = batch.kernel_times()
+        kernel_ms_mean, n_tiles = batch.kernel_ms()
+        kernel_ms = float(np.median(ktimes)) if len(ktimes) else kernel_ms_mean
+        phases = batch.phase_cycles() if args.phases else None
+        elapsed, total_boundaries = vdist.reduce_throughput(elapsed, float(nb), device=dev)
+
+        # ---- tag kernels on their own (event-free wall clock over the same steps)
+        tags_info = None
+        if nt:
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                batch.fill_tags(d_text.data_ptr(), d_boff.data_ptr(), d_ooff.data_ptr(), S, nb, d_labels.data_ptr(), d_tags.data_ptr(), stream)
+            torch.cuda.synchronize()
+            dt = (time.perf_counter() - t0) / steps
+            lab = d_labels[:nb].cpu().numpy()
+            n_tokens = int((lab == 1).sum()) + S
+            tags_info = {"ms_per_step": 1e3 * dt, "tokens_per_s": n_tokens / dt, "chars_per_s": (nb + S) / dt, "n_tags": nt,
+                         "kernels": "decode_chars_kernel + tag_tokens_kernel on the predicted labels"}
+
+        # ---- parity against the oracle (this rank's whole shard, bit for bit) and the algorithmic bytes it counts
+        a_char, parity, cpu = None, None, None
+        if not args.no_cpu_baseline:
+            from oracle import cbind
+            orc = cbind.OraclePredictor(raw, cfg["tags"])
+            t = time.perf_counter()
+            if primary and self.world == 1 and cfg_id == 1:
+                o_scores, o_labels, _, a_char = orc.predict_batch(utf8, boff, nthreads=1)
+                t1 = time.perf_counter() - t
+                reps = max(1, min(20, int(10.0 / max(t1 / self.ncores * 1.5, 1e-3))))
+                t = time.perf_counter()
+                for _ in range(reps):
+                    orc.predict_batch(utf8, boff, nthreads=self.ncores)
+                tn = (time.perf_counter() - t) / reps
+                cpu = {"value": nb / tn, "unit": "boundaries/s", "cores": self.ncores, "kind": "port",
+                       "single_thread_value": nb / t1, "cpu": cpu_model_name(),
+                       "sample": "the same %d-sentence batch: 1 pass on 1 thread, %d passes on %d threads (C restatement of the "
+                                 "reference algorithm with a hash-table automaton, not the Rust binary: a lower bound for it)" % (S, reps, self.ncores)}
+            else:
+                o_scores, o_labels, _, a_char = orc.predict_batch(utf8, boff, nthreads=self.ncores)
+            g_scores = d_scores[:nb].cpu().numpy()
+            g_labels = d_labels[:nb].cpu().numpy()
+            ok = bool(np.array_equal(g_scores, o_scores) and np.array_equal(g_labels, o_labels))
+            if nt:
+                got = d_tags[:(nb + S) * nt].cpu().numpy().reshape(nb + S, nt)
+                text = bytes(utf8)
+                tag_ok = True
+                for i in range(0, S, max(1, S // 300)):    # a 300-sentence sample of the tags against the oracle
+                    tx = text[int(boff[i]):int(boff[i + 1])].decode("utf-8")
+                    a = int(ooff[i])
+                    want, _ = orc.predict_tags(tx, labels=g_labels[a:a + len(tx) - 1])
+                    tag_ok = tag_ok and bool(np.array_equal(got[a + i:a + i + len(tx)], want))
+                tags_info["parity_sample"] = tag_ok
+                ok = ok and tag_ok
+            parity = self.all_true(ok)
+        del d_tags
+
+        # ---- end to end over PCIe: pinned caller buffers through the pipelined host path (N = 1, primary only)
+        e2e = None
+        if primary and self.world == 1 and not args.no_e2e:
+            keep = [api.PinnedArray((nbytes,), np.uint8), api.PinnedArray((max(nb, 1),), np.int32), api.PinnedArray((max(nb, 1),), np.uint8)]
+            keep[0].array[:] = utf8
+            for _ in range(2):
+                api.predict_packed_sharded([pred], keep[0].array, boff, out_offsets=ooff, scores=keep[1].array, labels=keep[2].array)
+            k = max(5, min(steps, 20))
+            t0 = time.perf_counter()
+            for _ in range(k):
+                api.predict_packed_sharded([pred], keep[0].array, boff, out_offsets=ooff, scores=keep[1].array, labels=keep[2].array)
+            dt = (time.perf_counter() - t0) / k
+            bytes_in, bytes_out = nbytes + 16 * (S + 1), 5 * nb
+            e2e = {"boundaries_per_s": nb / dt, "ms_per_batch": 1e3 * dt, "h2d_GBps": bytes_in / dt / 1e9, "d2h_GBps": bytes_out / dt / 1e9,
+                   "pcie_peak_GBps_per_direction": PCIE_GBS, "frac_of_pcie": max(bytes_in, bytes_out) / dt / 1e9 / PCIE_GBS,
+                   "parity": bool(parity is None or (np.array_equal(keep[1].array[:nb], o_scores) and np.array_equal(keep[2].array[:nb], o_labels))),
+                   "path": "vpt_predict_batch: pinned host buffers (vpt_host_alloc), ~1 M-char chunks, copy in / kernels / copy out on three streams"}
+            del keep
+
+        if self.rank != 0:
+            return None
+        out = {
+            "workload": "%s: %s model, %d sentences x %d..%d chars%s, inputs resident in HBM"
+                        % (cfg["name"], model_name, S_total, cfg["min_len"], cfg["max_len"],
+                           " in character-balanced shards over %d ranks" % self.world if self.world > 1 else ""),
+            "value": total_boundaries * steps / elapsed, "ms_per_step": 1e3 * elapsed / steps, "steps": steps,
+            "tokenizer_model": model_name, "sentences_per_gpu": S, "boundaries_per_gpu": nb, "text_bytes_per_gpu": nbytes,
+            "char_ngrams": info["n_char_ngrams"], "dict_words": info["n_dict_words"], "tag_models": info["n_tag_models"],
+            "table_bytes": info["device_table_bytes"], "hot_table_bytes": info["hot_table_bytes"],
+            "packed_tables": bool(info["packed"]), "tiles": n_tiles,
+            "create_s": round(create_s, 2), "tables_broadcast_s": round(bcast_s, 3) if self.world > 1 else None, "synth_s": round(synth_s, 2),
+        }
+        if phases is not None:
+            tot = float(sum(phases[:5])) or 1.0
+            out["phase_share"] = dict(zip(["scan", "decode", "patterns", "barrier", "output"], [round(p / tot, 4) for p in phases[:5]]))
+        # roofline of the dominant kernel: algorithmic bytes per launch (SURVEY.md 8d) / its duration
+        a_stream = nbytes + 5 * nb + 16 * S   # text + i32 score + u8 label per boundary + two u64 offsets per sentence
+        a_type = 4 * nb                        # one type-window table word per boundary (the reference's cache form)
+        kernel_name = "score_tiles_fast_kernel" if info["packed"] and info["type_kind"] in (0, 1) else "score_tiles_kernel"
+        roof = {"bound": "hbm", "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None, "traffic": None, "kernel": kernel_name,
+                "kernel_ms": kernel_ms, "kernel_ms_mean": kernel_ms_mean, "kernel_ms_min": float(np.min(ktimes)) if len(ktimes) else None,
+                "timed_launches": int(len(ktimes)), "timing": "HIP events on the launch stream around the kernel; median of the timed launches"}
+        if a_char is not None and kernel_ms > 0:
+            a = a_stream + a_char + a_type
+            roof.update({"achieved": a / (kernel_ms * 1e-3) / 1e9, "frac": a / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                         "traffic": measured_traffic(kernel_name, model_name, cfg["name"]) if self.world == 1 and not self.args.sentences else None,
+                         "algorithmic_bytes_per_launch": a, "bytes_per_boundary": a / max(nb, 1),
+                         "a_stream": a_stream, "a_char": a_char, "a_type": a_type})
+        out["roofline"] = roof
+        out["parity"] = parity
+        if tags_info is not None:
+            out["tags"] = tags_info
+        if e2e is not None:
+            out["e2e"] = e2e
+        if cpu is not None:
+            out["cpu_baseline"] = cpu
+        return out
 
 
 def main():
@@ -65,174 +361,45 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--sentences", type=int, default=100000, help="sentences per GPU per step")
-    ap.add_argument("--min-len", type=int, default=64)
-    ap.add_argument("--max-len", type=int, default=64)
-    ap.add_argument("--model-kind", type=int, default=1, help="1 bccwj-suw+unidic-like, 2 jp-0.4.7-5-like, 3 = 1 + tag models")
+    ap.add_argument("--config", type=int, default=0, choices=[0, 1, 2, 3, 4], help="BASELINE.json configs index (0: 1 at N = 1, 2 at N > 1, plus the others as `workloads`)")
+    ap.add_argument("--quick", action="store_true", help="the primary workload only")
+    ap.add_argument("--sentences", type=int, default=0, help="override the config's sentence count (diagnostics; traffic is then not reported)")
     ap.add_argument("--model-scale", type=float, default=1.0)
-    ap.add_argument("--predict-tags", action="store_true", help="Predictor::new(model, true): the reference's BoundaryTag scorers (boundary scores only)")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--time-tags", action="store_true", help="with --predict-tags: also time vpt_fill_tags_batch_device (extra JSON field `tags`)")
+    ap.add_argument("--no-cpu-baseline", action="store_true", help="skip the oracle: no parity, no roofline, no cpu_baseline (profiling runs)")
+    ap.add_argument("--no-e2e", action="store_true")
     ap.add_argument("--phases", action="store_true", help="diagnostics: per-phase shader cycles of the scoring kernel (slows it)")
     args = ap.parse_args()
 
-    import torch
-    import torch.distributed as dist
-    from vaporetto_amd import api
-
-    rank = int(os.environ.get("RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus and world > 1:
-        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
-
-    # ---- model: rank 0 loads/synthesises, everyone receives the bytes over RCCL (xGMI) -- vaporetto_amd/dist.py
-    from vaporetto_amd import dist as vdist
-    model_bytes, model_name = (load_model_bytes(args.model_kind, args.model_scale) if rank == 0 else (None, ""))
-    model_bytes = vdist.broadcast_model_bytes(model_bytes, src=0, device=dev)
-    predictor = api.Predictor(api.Model.read_slice(model_bytes)[0], args.predict_tags, device=local_rank)
-    info = predictor.info()
-
-    # ---- this rank's batch, resident in HBM
-    from vaporetto_amd import synth
-    utf8, boff = synth.synth_sentences(model_bytes, args.sentences, args.min_len, args.max_len,
-                                       seed=synth.SEED_BASE + 2 + 1000 * rank)
-    ooff = api.count_boundaries(utf8, boff)
-    S, nb, nbytes = args.sentences, int(ooff[-1]), int(boff[-1])
-    max_bytes = int(np.max(np.diff(boff.astype(np.int64))))
-    d_text = torch.from_numpy(np.concatenate([utf8, np.zeros(64, np.uint8)])).to(dev)
-    d_boff = torch.from_numpy(boff.astype(np.int64)).to(dev)
-    d_ooff = torch.from_numpy(ooff.astype(np.int64)).to(dev)
-    d_scores = torch.empty(nb + 1, dtype=torch.int32, device=dev)
-    d_labels = torch.empty(nb + 1, dtype=torch.uint8, device=dev)
-    if args.phases:
-        os.environ["VPT_PROFILE_PHASES"] = "1"
-    batch = api.DeviceBatch(predictor, timing=True)
-    batch.set_max_sentence_chars(int(np.max(np.diff(ooff.astype(np.int64)))) + 1)
-    stream = torch.cuda.current_stream().cuda_stream
-
-    def step():
-        batch.predict(d_text.data_ptr(), d_boff.data_ptr(), d_ooff.data_ptr(), S, nb, max_bytes,
-                      d_scores.data_ptr(), d_labels.data_ptr(), stream)
-
-    for _ in range(args.warmup):
-        step()
-    batch.sync()
-    batch.kernel_ms()  # reset the event ring
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    elapsed = time.perf_counter() - t0
-    batch.sync()
-    kernel_ms, n_tiles = batch.kernel_ms()
-    phases = batch.phase_cycles() if args.phases else None
-    elapsed, total_boundaries = vdist.reduce_throughput(elapsed, float(nb), device=dev)
-
-    tags_info = None
-    if args.time_tags and args.predict_tags and predictor.n_tags() > 0:
-        nt = predictor.n_tags()
-        d_tags = torch.empty((nb + S) * nt + 1, dtype=torch.int32, device=dev)
-
-        def tag_step():
-            batch.fill_tags(d_text.data_ptr(), d_boff.data_ptr(), d_ooff.data_ptr(), S, nb, d_labels.data_ptr(), d_tags.data_ptr(), stream)
-
-        for _ in range(max(1, args.warmup)):
-            tag_step()
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(args.steps):
-            tag_step()
-        torch.cuda.synchronize()
-        dt = (time.perf_counter() - t0) / args.steps
-        lab = d_labels[:nb].cpu().numpy()
-        n_tokens = int((lab == 1).sum()) + S
-        tags_info = {"ms_per_step": 1e3 * dt, "tokens_per_s": n_tokens / dt, "chars_per_s": (nb + S) / dt, "n_tags": nt,
-                     "note": "decode_chars_kernel + tag_tokens_kernel on the predicted labels (first, untuned mapping)"}
-        if not args.no_cpu_baseline and rank == 0:
-            from oracle import cbind as _cb
-            o = _cb.OraclePredictor(model_bytes, True)
-            got = d_tags[:(nb + S) * nt].cpu().numpy().reshape(nb + S, nt)
-            text = bytes(utf8)
-            ok = True
-            for i in range(0, S, max(1, S // 200)):    # a 200-sentence sample against the oracle
-                t = text[int(boff[i]):int(boff[i + 1])].decode("utf-8")
-                a = int(ooff[i])
-                want, _ = o.predict_tags(t, labels=lab[a:a + len(t) - 1])
-                ok = ok and bool(np.array_equal(got[a + i:a + i + len(t)], want))
-            tags_info["parity_sample"] = ok
-
-    if rank == 0:
-        out = {
-            "metric": "boundary scores/sec", "value": total_boundaries * args.steps / elapsed, "unit": "boundaries/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "int32", "data": "synthetic",
-            "config": {"workload": "%s: %s model, %d sentences x %d..%d chars per GPU per step, inputs resident in HBM"
-                       % (("configs[1]" if (args.model_kind, args.sentences, args.min_len, args.max_len) == (1, 100000, 64, 64)
-                           else "configs[%d]-shaped" % {1: 1, 2: 3, 3: 4}[args.model_kind]), model_name, S, args.min_len, args.max_len),
-                       "tokenizer_model": model_name, "sentences_per_gpu": S, "boundaries_per_gpu": nb, "text_bytes_per_gpu": nbytes,
-                       "char_ngrams": info["n_char_ngrams"], "dict_words": info["n_dict_words"],
-                       "table_bytes": info["device_table_bytes"], "hot_table_bytes": info["hot_table_bytes"],
-                       "packed_tables": bool(info["packed"]), "tiles": n_tiles, "sharding": "sentences x%d ranks, no data-path collective" % world},
+    R = Runner(args)
+    primary_id = args.config or (1 if R.world == 1 else 2)
+    prim = R.run(primary_id, primary=True)
+    extra = []
+    if not args.config and not args.quick and R.world == 1:
+        for cid in (3, 4, 2):
+            extra.append(R.run(cid, primary=False))
+    if R.rank == 0:
+        line = {
+            "metric": "boundary scores/sec", "value": prim["value"], "unit": "boundaries/s", "n_gpus": R.world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": prim["ms_per_step"], "higher_is_better": True,
+            "scaling": "strong" if primary_id == 2 else "weak", "vs_baseline": None, "dtype": "int32", "data": "synthetic",
+            "config": {k: prim[k] for k in ("workload", "tokenizer_model", "sentences_per_gpu", "boundaries_per_gpu", "text_bytes_per_gpu", "char_ngrams",
+                                            "dict_words", "tag_models", "table_bytes", "hot_table_bytes", "packed_tables", "tiles", "create_s",
+                                            "tables_broadcast_s", "synth_s")},
+            "parity": prim["parity"], "roofline": prim["roofline"], "cpu_baseline": prim.get("cpu_baseline"),
         }
-        if phases is not None:
-            tot = float(sum(phases[:5])) or 1.0
-            out["phase_share"] = dict(zip(["scan", "decode", "patterns", "barrier", "output"], [round(p / tot, 4) for p in phases[:5]]))
-            out["phase_cycles_per_tile"] = [round(p / max(n_tiles, 1) / (args.steps + args.warmup), 1) for p in phases[:5]]
-        # ---- roofline of the dominant kernel (score_tiles_kernel): algorithmic bytes per launch / its duration
-        a_stream = nbytes + 5 * nb + 16 * S   # text + i32 score + u8 label per boundary + two u64 offsets per sentence
-        a_type = 4 * nb                        # one type-window table word per boundary (the reference's cache form)
-        a_char = None
-        cpu = None
-        kernel_name = "score_tiles_fast_kernel" if info["packed"] and info["type_kind"] in (0, 1) else "score_tiles_kernel"
-        if not args.no_cpu_baseline:
-            from oracle import cbind
-            orc = cbind.OraclePredictor(model_bytes, args.predict_tags)
-            ncores = os.cpu_count() or 1
-            t = time.perf_counter()
-            o_scores, o_labels, _, a_char = orc.predict_batch(utf8, boff, nthreads=1)
-            t1 = time.perf_counter() - t
-            reps = max(1, min(20, int(10.0 / max(t1 / ncores * 1.5, 1e-3))))
-            t = time.perf_counter()
-            for _ in range(reps):
-                orc.predict_batch(utf8, boff, nthreads=ncores)
-            tn = (time.perf_counter() - t) / reps
-            cpu = {"value": nb / tn, "unit": "boundaries/s", "cores": ncores, "kind": "port",
-                   "single_thread_value": nb / t1,
-                   "sample": "the same %d-sentence batch: 1 pass on 1 thread, %d passes on %d threads (C restatement of the "
-                             "reference algorithm, not the Rust binary)" % (S, reps, ncores)}
-            g_scores = d_scores[:nb].cpu().numpy()
-            g_labels = d_labels[:nb].cpu().numpy()
-            out["parity"] = bool(np.array_equal(g_scores, o_scores) and np.array_equal(g_labels, o_labels))
-        if a_char is not None and kernel_ms > 0:
-            a = a_stream + a_char + a_type
-            achieved = a / (kernel_ms * 1e-3) / 1e9
-            out["roofline"] = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                               "frac": achieved / HBM_PEAK_GBS,
-                               "traffic": measured_traffic(kernel_name, model_name, S) if args.min_len == 64 and args.max_len == 64 else None,
-                               "kernel": kernel_name, "kernel_ms": kernel_ms,
-                               "algorithmic_bytes_per_launch": a, "bytes_per_boundary": a / nb,
-                               "a_stream": a_stream, "a_char": a_char, "a_type": a_type}
-        else:
-            out["roofline"] = {"bound": "hbm", "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None,
-                               "traffic": None, "kernel": kernel_name, "kernel_ms": kernel_ms}
-        out["cpu_baseline"] = cpu
-        if tags_info is not None:
-            out["tags"] = tags_info
-        print(json.dumps(out))
-    if world > 1:
-        dist.barrier()
-        dist.destroy_process_group()
+        line["config"]["sharding"] = "contiguous sentence ranges balanced by chars over %d rank(s), no data-path collective" % R.world
+        line["config"]["hip_devices_visible"] = R.torch.cuda.device_count()
+        line["config"]["world_size"] = R.world
+        line["config"]["collective_backend"] = ("RCCL (torch.distributed nccl)" if R.backend == "nccl" else R.backend) if R.world > 1 else None
+        for k in ("e2e", "tags", "phase_share"):
+            if k in prim:
+                line[k] = prim[k]
+        if extra:
+            line["workloads"] = extra
+        print(json.dumps(line))
+    if R.world > 1:
+        R.dist.barrier()
+        R.dist.destroy_process_group()
 
 
 if __name__ == "__main__":

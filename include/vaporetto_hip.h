@@ -94,6 +94,14 @@ void vpt_predictor_destroy(vpt_predictor *p);
 vpt_status vpt_predictor_save(const vpt_predictor *p, uint8_t *out, size_t capacity, size_t *needed);
 vpt_status vpt_predictor_load(const uint8_t *blob, size_t len, int device_id, vpt_predictor **out);
 vpt_status vpt_predictor_clone_to_device(const vpt_predictor *src, int device_id, vpt_predictor **out);
+/* For one process per GPU: vpt_predictor_describe gives the fixed-size description (meta_out may be NULL to ask for its size)
+ * and the device address and size of the table arena; the caller moves those bytes to the other ranks' GPUs itself -- one
+ * RCCL broadcast over xGMI -- and every rank turns what it received into a predictor with vpt_predictor_adopt_device
+ * (device-to-device copy into an allocation the predictor owns; d_arena stays the caller's). */
+vpt_status vpt_predictor_describe(const vpt_predictor *p, uint8_t *meta_out, size_t capacity, size_t *meta_bytes,
+                                  const void **d_arena, size_t *arena_bytes);
+vpt_status vpt_predictor_adopt_device(const uint8_t *meta, size_t meta_len, const void *d_arena, size_t arena_bytes,
+                                      int device_id, vpt_predictor **out);
 
 /* ---------------------------------------------------------------------------------------------------------
  * Sentence::from_raw's bookkeeping for a batch     (sentence.rs:160-196)
@@ -196,6 +204,9 @@ vpt_status vpt_batch_sync(vpt_batch *b);
  * workgroups (tiles) of the last call. */
 vpt_status vpt_batch_set_timing(vpt_batch *b, int enabled);
 vpt_status vpt_batch_kernel_ms(vpt_batch *b, float *score_kernel_ms, uint32_t *n_tiles);
+/* The individual durations (ms, oldest first) of the timed calls since the previous vpt_batch_kernel_ms, at most `capacity`
+ * of the 256 most recent; *n_out = how many were written (with ms_out == NULL: how many there are).  Does not reset. */
+vpt_status vpt_batch_kernel_times(vpt_batch *b, float *ms_out, size_t capacity, size_t *n_out);
 
 /* ---------------------------------------------------------------------------------------------------------
  * Sentence::fill_tags -> Predictor::predict_tags over a batch     (sentence.rs:1144-1148, predictor.rs:546-637)

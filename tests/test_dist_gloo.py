@@ -1,6 +1,8 @@
-"""world_size-2 `gloo` test of the multi-GPU host logic (vaporetto_amd/dist.py): model broadcast from rank 0, byte-
-balanced contiguous shards, whole-job reductions.  Scoring on each rank is done by the CPU oracle here (the GPU
-path is covered by the -m gpu tests); the sharded results must concatenate to the unsharded ones."""
+"""world_size-2 `gloo` test of the multi-GPU path (vaporetto_amd/dist.py) with the PRODUCT's code on every rank: the
+kernel and C-ABI sources built against the CPU emulator of the HIP execution model (tests/emu.py; test infrastructure).
+Rank 0 compiles the model; the compiled tables are broadcast (vpt_predictor_describe -> dist.broadcast ->
+vpt_predictor_adopt_device: what RCCL over xGMI does between GPUs, gloo between processes here); every rank takes its
+character-balanced shard, scores it through vpt_predict_batch and the results must tile the unsharded oracle scores."""
 import os
 import socket
 import subprocess
@@ -20,22 +22,30 @@ import os, sys, hashlib
 import numpy as np
 sys.path.insert(0, {root!r})
 import torch, torch.distributed as dist
-from vaporetto_amd import dist as vdist, api
-from oracle import cbind
-from tests import randmodel
+from tests import emu, devmem, randmodel
+from vaporetto_amd import _lib, dist as vdist, api
 from vaporetto_amd.modelfmt import encode_model
+_lib._lib = emu.load()            # the product's sources on the emulator: this process has no GPU
+devmem.EMULATED = True
 
 rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
 dist.init_process_group("gloo", rank=rank, world_size=world)
 m = randmodel.rand_model(31, alphabet="kana", wc=3, wt=3, n_char=150, n_dict=150, max_word=9)
 raw0 = encode_model(m) if rank == 0 else None
-raw = vdist.broadcast_model_bytes(raw0, src=0)
-texts = randmodel.rand_sentences(9, m, 900, alphabet="kana", max_len=150)   # every rank builds the same batch
+raw = vdist.broadcast_model_bytes(raw0, src=0)                      # the model file (kept: checked below)
+pred0 = api.Predictor(api.Model.read_slice(raw)[0], False) if rank == 0 else None
+pred = vdist.broadcast_predictor(pred0, src=0, device=torch.device("cpu"))   # the COMPILED tables; rank 1 compiles nothing
+texts = randmodel.rand_sentences(9, m, 900, alphabet="kana", max_len=150)    # every rank builds the same batch
+texts = [t if i % 3 else "abc de" * (1 + i % 20) for i, t in enumerate(texts)]   # mixed 1- and 3-byte chars
 utf8, boff = api.pack_texts([t.encode("utf-8") for t in texts])
-s_utf8, s_boff, first = vdist.take_shard(utf8, boff, rank, world)
-scores, labels, ooff, _ = cbind.OraclePredictor(raw).predict_batch(s_utf8, s_boff)
+ooff = api.count_boundaries(utf8, boff)
+s_utf8, s_boff, s_ooff, first = vdist.take_shard(utf8, boff, ooff, rank, world)
+os.environ["VPT_CHUNK_CHARS"] = "4000"                              # the pipelined host path, several chunks per shard
+scores, labels, got_ooff = pred.predict_packed(s_utf8, s_boff)
+assert np.array_equal(got_ooff, s_ooff)
 el, tot = vdist.reduce_throughput(1.0 + rank, float(len(scores)))
 np.savez(os.path.join({out!r}, "rank%d.npz" % rank), scores=scores, labels=labels, first=first, n=len(s_boff) - 1,
+         chars=int(s_ooff[-1]) + len(s_boff) - 1, info=np.array(sorted(pred.info().items()), dtype=object),
          sha=np.frombuffer(hashlib.sha256(raw).digest(), dtype=np.uint8), el=el, tot=tot)
 dist.barrier()
 dist.destroy_process_group()
@@ -50,19 +60,24 @@ def _free_port():
 
 def test_shard_bounds_balance_and_cover():
     rng = np.random.RandomState(0)
-    lens = rng.randint(1, 600, size=5000)
-    boff = np.concatenate([[0], np.cumsum(lens)]).astype(np.uint64)
+    lens = rng.randint(1, 600, size=5000)                       # chars per sentence
+    ooff = np.concatenate([[0], np.cumsum(lens - 1)]).astype(np.uint64)
     for world in (1, 2, 3, 4, 8):
-        b = vdist.shard_bounds(boff, world)
+        b = vdist.shard_bounds(ooff, world)
         assert b[0] == 0 and b[-1] == 5000 and np.all(np.diff(b) >= 0)
-        sizes = [int(boff[b[r + 1]] - boff[b[r]]) for r in range(world)]
+        sizes = [int(lens[b[r]:b[r + 1]].sum()) for r in range(world)]
         assert max(sizes) - min(sizes) <= 2 * 600
+    # balanced by CHARS, not bytes: one half ASCII, one half 3-byte text of the same char count -> equal sentence counts
+    ooff = (np.arange(1001, dtype=np.uint64) * 9)
+    assert vdist.shard_bounds(ooff, 2).tolist() == [0, 500, 1000]
     # degenerate: fewer sentences than ranks
-    b = vdist.shard_bounds(np.array([0, 5, 9], dtype=np.uint64), 4)
+    b = vdist.shard_bounds(np.array([0, 4, 7], dtype=np.uint64), 4)
     assert b[0] == 0 and b[-1] == 2 and np.all(np.diff(b) >= 0)
 
 
 def test_two_rank_gloo_broadcast_shard_and_reduce(tmp_path):
+    from tests import emu
+    emu.build_emulated()        # once, before the ranks race for it
     port = _free_port()
     script = tmp_path / "worker.py"
     script.write_text(WORKER.format(root=ROOT, out=str(tmp_path)))
@@ -71,19 +86,22 @@ def test_two_rank_gloo_broadcast_shard_and_reduce(tmp_path):
         env = dict(os.environ, RANK=str(rank), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
                    LOCAL_RANK=str(rank))
         procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
-    outs = [p.communicate(timeout=300)[0].decode() for p in procs]
+    outs = [p.communicate(timeout=600)[0].decode() for p in procs]
     assert all(p.returncode == 0 for p in procs), "\n".join(outs)
 
     m = randmodel.rand_model(31, alphabet="kana", wc=3, wt=3, n_char=150, n_dict=150, max_word=9)
     raw = encode_model(m)
     texts = randmodel.rand_sentences(9, m, 900, alphabet="kana", max_len=150)
+    texts = [t if i % 3 else "abc de" * (1 + i % 20) for i, t in enumerate(texts)]
     utf8, boff = api.pack_texts([t.encode("utf-8") for t in texts])
     full_scores, full_labels, _, _ = cbind.OraclePredictor(raw).predict_batch(utf8, boff)
-    r = [np.load(tmp_path / ("rank%d.npz" % k)) for k in range(2)]
+    r = [np.load(tmp_path / ("rank%d.npz" % k), allow_pickle=True) for k in range(2)]
     import hashlib
     want = np.frombuffer(hashlib.sha256(raw).digest(), dtype=np.uint8)
     assert np.array_equal(r[0]["sha"], want) and np.array_equal(r[1]["sha"], want)      # broadcast delivered the model
+    assert r[0]["info"].tolist() == r[1]["info"].tolist()                                # ... and the compiled predictor
     assert int(r[0]["first"]) == 0 and int(r[1]["first"]) == int(r[0]["n"]) and int(r[0]["n"]) + int(r[1]["n"]) == 900
+    assert abs(int(r[0]["chars"]) - int(r[1]["chars"])) <= 2 * 150                       # balanced by characters
     assert np.array_equal(np.concatenate([r[0]["scores"], r[1]["scores"]]), full_scores)   # shards tile the batch
     assert np.array_equal(np.concatenate([r[0]["labels"], r[1]["labels"]]), full_labels)
     for k in range(2):

@@ -44,6 +44,8 @@ SIGNATURES = {
     "vpt_predictor_save": (C.c_int, [_P, _P, C.c_size_t, C.POINTER(C.c_size_t)]),
     "vpt_predictor_load": (C.c_int, [_P, C.c_size_t, C.c_int, C.POINTER(_P)]),
     "vpt_predictor_clone_to_device": (C.c_int, [_P, C.c_int, C.POINTER(_P)]),
+    "vpt_predictor_describe": (C.c_int, [_P, _P, C.c_size_t, C.POINTER(C.c_size_t), C.POINTER(_P), C.POINTER(C.c_size_t)]),
+    "vpt_predictor_adopt_device": (C.c_int, [_P, C.c_size_t, _P, C.c_size_t, C.c_int, C.POINTER(_P)]),
     "vpt_count_boundaries": (C.c_int, [_P, _P, C.c_size_t, _P]),
     "vpt_predict_batch": (C.c_int, [_P, _P, _P, C.c_size_t, _P, _P, _P]),
     "vpt_predict_batch_flags": (C.c_int, [_P, _P, _P, C.c_size_t, _P, _P, _P, C.c_uint]),
@@ -73,6 +75,7 @@ SIGNATURES = {
     "vpt_batch_set_max_sentence_chars": (C.c_int, [_P, C.c_uint64]),
     "vpt_batch_set_timing": (C.c_int, [_P, C.c_int]),
     "vpt_batch_kernel_ms": (C.c_int, [_P, C.POINTER(C.c_float), C.POINTER(C.c_uint32)]),
+    "vpt_batch_kernel_times": (C.c_int, [_P, _P, C.c_size_t, C.POINTER(C.c_size_t)]),
     "vpt_batch_phase_cycles": (C.c_int, [_P, C.POINTER(C.c_uint64 * 8)]),
     "vpt_model_inspect": (C.c_int, [_P, C.c_size_t, C.c_int, C.POINTER(ModelInfo)]),
     "vpt_model_read_len": (C.c_int, [_P, C.c_size_t, C.POINTER(C.c_size_t)]),

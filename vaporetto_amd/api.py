@@ -693,6 +693,15 @@ class DeviceBatch:
         return ms.value, nt.value
 
 
+    def kernel_times(self) -> np.ndarray:
+        """Durations (ms) of the timed scoring-kernel launches since the last kernel_ms(), oldest first (at most 256)."""
+        out = np.zeros(256, dtype=np.float32)
+        n = C.c_size_t(0)
+        st = _lib.load().vpt_batch_kernel_times(self._h, out.ctypes.data, len(out), C.byref(n))
+        if st != _lib.VPT_OK:
+            _raise(st)
+        return out[:n.value].copy()
+
     def phase_cycles(self):
         """Per-phase shader cycles of the specialised kernel (needs VPT_PROFILE_PHASES set before creation)."""
         arr = (C.c_uint64 * 8)()

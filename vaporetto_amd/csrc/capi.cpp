@@ -608,6 +608,60 @@ vpt_status vpt_predictor_load(const uint8_t* blob, size_t len, int device_id, vp
     return VPT_OK;
 }
 
+// The two halves of the compiled form for callers that move the tables themselves (one process per GPU: the arena goes from
+// rank 0 to the others with one RCCL broadcast over xGMI, device to device, and every rank adopts the bytes it received).
+vpt_status vpt_predictor_describe(const vpt_predictor* p, uint8_t* meta_out, size_t capacity, size_t* meta_bytes, const void** d_arena,
+                                  size_t* arena_bytes) {
+    if (!p || !meta_bytes) return fail(VPT_INVALID_ARGUMENT, "InvalidArgumentError: NULL argument");
+    *meta_bytes = sizeof(PredictorMeta);
+    if (d_arena) *d_arena = p->arena;
+    if (arena_bytes) *arena_bytes = size_t(p->meta.arena_bytes);
+    if (meta_out) {
+        if (capacity < sizeof(PredictorMeta)) return fail(VPT_INVALID_ARGUMENT, "InvalidArgumentError: capacity: smaller than the description");
+        PredictorMeta m = p->meta;
+        m.checksum = 0;   // the device bytes are not read back for it; a transport that can corrupt them has its own checks
+        std::memcpy(meta_out, &m, sizeof(m));
+    }
+    return VPT_OK;
+}
+
+vpt_status vpt_predictor_adopt_device(const uint8_t* meta, size_t meta_len, const void* d_arena, size_t arena_bytes, int device_id,
+                                      vpt_predictor** out) {
+    if (!out) return fail(VPT_INVALID_ARGUMENT, "InvalidArgumentError: out: must not be NULL");
+    *out = nullptr;
+    if (!meta || !d_arena) return fail(VPT_INVALID_ARGUMENT, "InvalidArgumentError: NULL argument");
+    PredictorMeta m;
+    if (meta_len != sizeof(m)) return fail(VPT_INVALID_MODEL, "InvalidModelError: not a compiled predictor description");
+    std::memcpy(&m, meta, sizeof(m));
+    if (std::memcmp(m.magic, kCompiledMagic, sizeof(m.magic)) != 0 || m.version != kCompiledVersion || m.meta_bytes != sizeof(PredictorMeta))
+        return fail(VPT_INVALID_MODEL, "InvalidModelError: compiled predictor version mismatch (compile the model again with this library)");
+    if (m.arena_bytes != arena_bytes) return fail(VPT_INVALID_MODEL, "InvalidModelError: compiled predictor is truncated");
+    {
+        size_t bytes[kSectionCount];
+        uint64_t off[kSectionCount];
+        for (int i = 0; i < kSectionCount; ++i) bytes[i] = size_t(m.sec_bytes[i]);
+        if (layout_sections(bytes, off) != m.arena_bytes || std::memcmp(off, m.sec_off, sizeof(off)) != 0)
+            return fail(VPT_INVALID_MODEL, "InvalidModelError: compiled predictor has an inconsistent section table");
+    }
+    vpt_status st = check_device(device_id);
+    if (st != VPT_OK) return st;
+    VPT_HIP(hipSetDevice(device_id));
+    vpt_predictor* p = new (std::nothrow) vpt_predictor();
+    if (!p) return fail(VPT_RUNTIME_ERROR, "out of host memory");
+    p->device = device_id;
+    p->meta = m;
+    hipError_t e = hipMalloc(reinterpret_cast<void**>(&p->arena), m.arena_bytes);
+    if (e == hipSuccess) e = hipMemcpy(p->arena, d_arena, size_t(m.arena_bytes), hipMemcpyDeviceToDevice);
+    if (e != hipSuccess) {
+        std::string msg = std::string("HIP error while copying the tables: ") + hipGetErrorString(e);
+        vpt_predictor_destroy(p);
+        return fail(VPT_RUNTIME_ERROR, msg);
+    }
+    bind_predictor(p);
+    *out = p;
+    return VPT_OK;
+}
+
 vpt_status vpt_predictor_clone_to_device(const vpt_predictor* src, int device_id, vpt_predictor** out) {
     if (!out) return fail(VPT_INVALID_ARGUMENT, "InvalidArgumentError: out: must not be NULL");
     *out = nullptr;
@@ -712,6 +766,18 @@ vpt_status vpt_batch_kernel_ms(vpt_batch* b, float* score_kernel_ms, uint32_t* n
         if (n) *score_kernel_ms = float(sum / double(n));
         b->ev_calls = 0;
     }
+    return VPT_OK;
+}
+
+vpt_status vpt_batch_kernel_times(vpt_batch* b, float* ms_out, size_t capacity, size_t* n_out) {
+    if (!b || !n_out) return fail(VPT_INVALID_ARGUMENT, "InvalidArgumentError: NULL argument");
+    if (b->pending) return fail(VPT_INVALID_ARGUMENT, "InvalidArgumentError: batch: call vpt_batch_sync first");
+    const size_t n = std::min(std::min(b->ev_calls, kTimingRing), ms_out ? capacity : size_t(0));
+    for (size_t k = 0; k < n; ++k) {   // oldest first
+        const size_t slot = (b->ev_calls - n + k) % kTimingRing;
+        VPT_HIP(hipEventElapsedTime(&ms_out[k], b->ev[2 * slot], b->ev[2 * slot + 1]));
+    }
+    *n_out = ms_out ? n : std::min(b->ev_calls, kTimingRing);
     return VPT_OK;
 }
 

@@ -1,10 +1,12 @@
 """Multi-GPU host logic: one process per GPU, `torch.distributed` (backend "nccl" = RCCL on ROCm, "gloo" in the
 CPU tests).  Sentences are independent (predictor.rs:518-543 carries no state between calls), so the only
-collective on the path is the one-time broadcast of the model file from rank 0; every rank then scores its own
-contiguous shard of the batch and there is no data-path exchange.
+collective on the path is the one-time broadcast of the predictor from rank 0 -- the model file bytes, or better the
+COMPILED tables, device to device over xGMI, so that only one rank compiles -- and every rank then scores its own
+contiguous shard of the batch, balanced by character count; there is no data-path exchange.
 """
 from __future__ import annotations
 
+import ctypes as C
 from typing import Optional, Tuple
 
 import numpy as np
@@ -29,25 +31,82 @@ def broadcast_model_bytes(model_bytes: Optional[bytes], src: int = 0, device=Non
     return blob.cpu().numpy().tobytes()
 
 
-def shard_bounds(byte_offsets: np.ndarray, world: int) -> np.ndarray:
-    """Contiguous sentence ranges balanced by BYTE count (a proxy for chars that needs no decode; it matters
-    for ragged batches such as configs[4]).  Returns int64[world + 1]: rank r owns sentences [b[r], b[r+1])."""
-    boff = np.asarray(byte_offsets, dtype=np.uint64)
-    S = len(boff) - 1
-    total = int(boff[S] - boff[0])
-    targets = int(boff[0]) + (np.arange(1, world, dtype=np.float64) * total / world)
-    cuts = np.searchsorted(boff.astype(np.float64), targets, side="left").astype(np.int64)
-    bounds = np.concatenate([[0], np.clip(cuts, 0, S), [S]]).astype(np.int64)
-    return np.maximum.accumulate(bounds)
+class _DeviceBytes:
+    """A device address range as an object torch can view without copying (CUDA array interface, which ROCm builds honour)."""
+
+    def __init__(self, ptr: int, nbytes: int):
+        self.__cuda_array_interface__ = {"shape": (nbytes,), "typestr": "|u1", "data": (ptr, False), "version": 2}
 
 
-def take_shard(utf8: np.ndarray, byte_offsets: np.ndarray, rank: int, world: int) -> Tuple[np.ndarray, np.ndarray, int]:
-    """This rank's slice of a packed batch: (utf8 slice, rebased byte offsets, index of its first sentence)."""
-    b = shard_bounds(byte_offsets, world)
+def broadcast_predictor(predictor, src: int = 0, device=None, model=None):
+    """Rank `src` passes its compiled Predictor, the others None; every rank returns a predictor on ITS device holding the
+    same tables.  The table arena is broadcast straight out of rank src's device memory (one `dist.broadcast` of a few
+    hundred MB: RCCL over xGMI) and adopted with a device-to-device copy (vpt_predictor_describe /
+    vpt_predictor_adopt_device); nobody but rank src compiles the model.  `device`: this rank's torch device ("cpu" with the
+    gloo backend and the emulated library of the tests, whose device memory is host memory)."""
+    import torch
+    import torch.distributed as dist
+    from . import _lib, api
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        assert predictor is not None
+        return predictor
+    L = _lib.load()
+    dev = device if device is not None else torch.device("cpu")
+    rank = dist.get_rank()
+    meta_len, d_arena, arena_len = C.c_size_t(0), C.c_void_p(), C.c_size_t(0)
+    meta = np.zeros(1, dtype=np.uint8)
+    if rank == src:
+        st = L.vpt_predictor_describe(predictor.handle, None, 0, C.byref(meta_len), C.byref(d_arena), C.byref(arena_len))
+        if st != _lib.VPT_OK:
+            api._raise(st)
+        meta = np.zeros(meta_len.value, dtype=np.uint8)
+        st = L.vpt_predictor_describe(predictor.handle, meta.ctypes.data, meta.nbytes, C.byref(meta_len), C.byref(d_arena), C.byref(arena_len))
+        if st != _lib.VPT_OK:
+            api._raise(st)
+    sizes = torch.tensor([meta_len.value, arena_len.value], dtype=torch.int64, device=dev)
+    dist.broadcast(sizes, src)
+    n_meta, n_arena = int(sizes[0].item()), int(sizes[1].item())
+    t_meta = torch.empty(n_meta, dtype=torch.uint8, device=dev)
+    if rank == src:
+        t_meta.copy_(torch.from_numpy(meta))
+    dist.broadcast(t_meta, src)
+    if rank == src:
+        if dev.type == "cuda":
+            arena = torch.as_tensor(_DeviceBytes(d_arena.value, n_arena), device=dev)     # a view of the predictor's own tables
+        else:
+            arena = torch.from_numpy(np.ctypeslib.as_array(C.cast(d_arena, C.POINTER(C.c_uint8)), shape=(n_arena,)))
+        dist.broadcast(arena, src)
+        return predictor
+    arena = torch.empty(n_arena, dtype=torch.uint8, device=dev)
+    dist.broadcast(arena, src)
+    if dev.type == "cuda":
+        torch.cuda.synchronize(dev)
+    meta_b = t_meta.cpu().numpy()
+    h = C.c_void_p()
+    dev_index = dev.index if (dev.type == "cuda" and dev.index is not None) else 0
+    st = L.vpt_predictor_adopt_device(meta_b.ctypes.data, meta_b.nbytes, arena.data_ptr(), n_arena, dev_index, C.byref(h))
+    if st != _lib.VPT_OK:
+        api._raise(st)
+    return api.Predictor._adopt(h, model, dev_index)
+
+
+def shard_bounds(out_offsets: np.ndarray, world: int) -> np.ndarray:
+    """Contiguous sentence ranges balanced by CHARACTER count (what scoring costs; bytes per char vary 1..4 in mixed
+    text, so byte balance can be off by 3x).  `out_offsets` = vpt_count_boundaries' output (boundaries before sentence i);
+    chars before sentence i = out_offsets[i] + i.  Returns int64[world + 1]: rank r owns sentences [b[r], b[r+1])."""
+    from . import api
+    return api.shard_bounds(out_offsets, world).astype(np.int64)
+
+
+def take_shard(utf8: np.ndarray, byte_offsets: np.ndarray, out_offsets: np.ndarray, rank: int, world: int):
+    """This rank's slice of a packed batch: (utf8 slice, rebased byte offsets, rebased out offsets, index of its first sentence)."""
+    b = shard_bounds(out_offsets, world)
     lo, hi = int(b[rank]), int(b[rank + 1])
     boff = np.asarray(byte_offsets, dtype=np.uint64)
+    ooff = np.asarray(out_offsets, dtype=np.uint64)
     t0, t1 = int(boff[lo]), int(boff[hi])
-    return np.ascontiguousarray(utf8[t0:t1]), (boff[lo:hi + 1] - boff[lo]).astype(np.uint64), lo
+    return (np.ascontiguousarray(utf8[t0:t1]), (boff[lo:hi + 1] - boff[lo]).astype(np.uint64),
+            (ooff[lo:hi + 1] - ooff[lo]).astype(np.uint64), lo)
 
 
 def reduce_throughput(elapsed_s: float, units: float, device=None) -> Tuple[float, float]:

@@ -19,7 +19,7 @@ SEED_BASE = 0x5EED0000  # + config number
 
 def build_synth(force: bool = False) -> str:
     if force or not os.path.exists(LIB_PATH) or any(os.path.getmtime(s) > os.path.getmtime(LIB_PATH) for s in _SOURCES):
-        subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-o", LIB_PATH] + _SOURCES)
+        subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-pthread", "-o", LIB_PATH] + _SOURCES)
     return LIB_PATH
 
 
@@ -34,6 +34,8 @@ def _load():
         L.vpt_synth_model.argtypes = [C.c_int, C.c_uint64, C.c_double, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]
         L.vpt_synth_sentences.argtypes = [C.c_char_p, C.c_size_t, C.c_uint64, C.c_size_t, C.c_uint32, C.c_uint32,
                                           C.POINTER(C.c_void_p), C.POINTER(C.c_size_t), C.POINTER(C.c_void_p)]
+        L.vpt_synth_blocks.argtypes = [C.c_char_p, C.c_size_t, C.c_uint64, C.c_size_t, C.c_size_t, C.c_size_t, C.c_uint32, C.c_uint32, C.c_uint32,
+                                       C.POINTER(C.c_void_p), C.POINTER(C.c_size_t), C.POINTER(C.c_void_p)]
         L.vpt_synth_free.argtypes = [C.c_void_p]
         _lib = L
     return _lib
@@ -64,6 +66,25 @@ def synth_sentences(model_bytes: bytes, n_sentences: int, min_len: int = 64, max
     try:
         utf8 = np.frombuffer(C.string_at(text, nbytes.value), dtype=np.uint8).copy()
         offs = np.frombuffer(C.string_at(boff, 8 * (n_sentences + 1)), dtype=np.uint64).copy()
+    finally:
+        L.vpt_synth_free(text)
+        L.vpt_synth_free(boff)
+    return utf8, offs
+
+
+def synth_blocks(model_bytes: bytes, first_block: int, n_blocks: int, block_sentences: int = 100000, min_len: int = 64, max_len: int = 64,
+                 seed: int = SEED_BASE + 3, nthreads: int = 0):
+    """A run of blocks of a big batch (block j = `block_sentences` sentences from the stream seeded seed + 7919 j), generated in
+    parallel: (utf8, byte_offsets) of blocks first_block .. first_block + n_blocks - 1, offsets starting at 0."""
+    L = _load()
+    text, nbytes, boff = C.c_void_p(), C.c_size_t(), C.c_void_p()
+    st = L.vpt_synth_blocks(model_bytes, len(model_bytes), seed, first_block, n_blocks, block_sentences, min_len, max_len,
+                            nthreads or min(32, os.cpu_count() or 1), C.byref(text), C.byref(nbytes), C.byref(boff))
+    if st != 0:
+        raise RuntimeError("vpt_synth_blocks failed: %d" % st)
+    try:
+        utf8 = np.ctypeslib.as_array(C.cast(text, C.POINTER(C.c_uint8)), shape=(nbytes.value,)).copy()
+        offs = np.ctypeslib.as_array(C.cast(boff, C.POINTER(C.c_uint64)), shape=(n_blocks * block_sentences + 1,)).copy()
     finally:
         L.vpt_synth_free(text)
         L.vpt_synth_free(boff)

@@ -5,11 +5,13 @@
 // the real Vaporetto model format, and sentences whose pattern hit rates resemble real text.  Deterministic:
 // splitmix64 streams keyed by the seed.
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstdint>
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <thread>
 #include <unordered_set>
 #include <vector>
 
@@ -226,19 +228,28 @@ int vpt_synth_model(int kind, uint64_t seed, double scale, uint8_t** out, size_t
     return 0;
 }
 
+}  // extern "C"
+
 // Sentences: items drawn 70 % from the model's own pattern list (Zipf over code-point order, which is the
 // BTreeMap order of the reference's merger) and 30 % single characters from alphabet A, cut to a length drawn
 // log-uniformly in [min_len, max_len].  Every character is 3-byte UTF-8.
-int vpt_synth_sentences(const uint8_t* model, size_t model_len, uint64_t seed, size_t n_sent, uint32_t min_len,
-                        uint32_t max_len, uint8_t** utf8_out, size_t* nbytes_out, uint64_t** boff_out) {
-    if (!model || !utf8_out || !nbytes_out || !boff_out || min_len < 1 || max_len < min_len) return 2;
+namespace {
+struct PatternList {
     vpt::ModelData m;
-    try { m = vpt::parse_model(model, model_len, nullptr); } catch (const vpt::ModelError&) { return 1; }
     std::vector<const vpt::SymString*> pats;
-    for (const auto& d : m.char_ngrams) pats.push_back(&d.ngram);
-    for (const auto& d : m.dict) pats.push_back(&d.word);
-    std::sort(pats.begin(), pats.end(), [](const vpt::SymString* a, const vpt::SymString* b) { return *a < *b; });
-    pats.erase(std::unique(pats.begin(), pats.end(), [](const vpt::SymString* a, const vpt::SymString* b) { return *a == *b; }), pats.end());
+    bool load(const uint8_t* model, size_t model_len) {
+        try { m = vpt::parse_model(model, model_len, nullptr); } catch (const vpt::ModelError&) { return false; }
+        for (const auto& d : m.char_ngrams) pats.push_back(&d.ngram);
+        for (const auto& d : m.dict) pats.push_back(&d.word);
+        std::sort(pats.begin(), pats.end(), [](const vpt::SymString* a, const vpt::SymString* b) { return *a < *b; });
+        pats.erase(std::unique(pats.begin(), pats.end(), [](const vpt::SymString* a, const vpt::SymString* b) { return *a == *b; }), pats.end());
+        return true;
+    }
+};
+// one block of sentences from its own splitmix64 stream: text bytes appended to `text`, byte length of every sentence to `lens`
+void gen_block(const PatternList& P, uint64_t seed, size_t n_sent, uint32_t min_len, uint32_t max_len, std::vector<uint8_t>& text,
+               std::vector<uint32_t>& lens) {
+    const std::vector<const vpt::SymString*>& pats = P.pats;
     Rng r(seed);
     auto alphabet_a = [&]() -> uint32_t {
         double u = r.uniform();
@@ -250,13 +261,10 @@ int vpt_synth_sentences(const uint8_t* model, size_t model_len, uint64_t seed, s
         static const uint32_t punct[6] = {0x3001, 0x3002, 0x300C, 0x300D, 0x30FB, 0x30FC};
         return punct[r.below(6)];
     };
-    std::vector<uint8_t> text;
-    text.reserve(n_sent * size_t(max_len + min_len) / 2 * 3 + 64);
-    uint64_t* boff = static_cast<uint64_t*>(std::malloc(sizeof(uint64_t) * (n_sent + 1)));
-    if (!boff) return 3;
+    text.reserve(text.size() + n_sent * size_t(max_len + min_len) / 2 * 3 + 64);
     std::vector<uint32_t> sent;
     for (size_t i = 0; i < n_sent; ++i) {
-        boff[i] = text.size();
+        const size_t before = text.size();
         uint32_t L = min_len;
         if (max_len > min_len) {
             L = uint32_t(std::exp(std::log(double(min_len)) + r.uniform() * (std::log(double(max_len) + 1.0) - std::log(double(min_len)))));
@@ -276,15 +284,62 @@ int vpt_synth_sentences(const uint8_t* model, size_t model_len, uint64_t seed, s
             else if (c < 0x10000) { text.push_back(uint8_t(0xE0 | (c >> 12))); text.push_back(uint8_t(0x80 | ((c >> 6) & 0x3F))); text.push_back(uint8_t(0x80 | (c & 0x3F))); }
             else { text.push_back(uint8_t(0xF0 | (c >> 18))); text.push_back(uint8_t(0x80 | ((c >> 12) & 0x3F))); text.push_back(uint8_t(0x80 | ((c >> 6) & 0x3F))); text.push_back(uint8_t(0x80 | (c & 0x3F))); }
         }
+        lens.push_back(uint32_t(text.size() - before));
     }
-    boff[n_sent] = text.size();
-    *utf8_out = static_cast<uint8_t*>(std::malloc(text.size() + 64));
-    if (!*utf8_out) { std::free(boff); return 3; }
-    std::memcpy(*utf8_out, text.data(), text.size());
-    std::memset(*utf8_out + text.size(), 0, 64);
-    *nbytes_out = text.size();
-    *boff_out = boff;
+}
+int emit(const std::vector<std::vector<uint8_t>>& texts, const std::vector<std::vector<uint32_t>>& lens, uint8_t** utf8_out, size_t* nbytes_out,
+         uint64_t** boff_out) {
+    size_t total = 0, n_sent = 0;
+    for (size_t b = 0; b < texts.size(); ++b) { total += texts[b].size(); n_sent += lens[b].size(); }
+    uint64_t* boff = static_cast<uint64_t*>(std::malloc(sizeof(uint64_t) * (n_sent + 1)));
+    uint8_t* out = static_cast<uint8_t*>(std::malloc(total + 64));
+    if (!boff || !out) { std::free(boff); std::free(out); return 3; }
+    size_t at = 0, si = 0;
+    for (size_t b = 0; b < texts.size(); ++b) {
+        std::memcpy(out + at, texts[b].data(), texts[b].size());
+        size_t o = at;
+        for (uint32_t l : lens[b]) { boff[si++] = o; o += l; }
+        at += texts[b].size();
+    }
+    boff[n_sent] = total;
+    std::memset(out + total, 0, 64);
+    *utf8_out = out; *nbytes_out = total; *boff_out = boff;
     return 0;
+}
+}  // namespace
+
+extern "C" {
+
+int vpt_synth_sentences(const uint8_t* model, size_t model_len, uint64_t seed, size_t n_sent, uint32_t min_len,
+                        uint32_t max_len, uint8_t** utf8_out, size_t* nbytes_out, uint64_t** boff_out) {
+    if (!model || !utf8_out || !nbytes_out || !boff_out || min_len < 1 || max_len < min_len) return 2;
+    PatternList P;
+    if (!P.load(model, model_len)) return 1;
+    std::vector<std::vector<uint8_t>> texts(1);
+    std::vector<std::vector<uint32_t>> lens(1);
+    gen_block(P, seed, n_sent, min_len, max_len, texts[0], lens[0]);
+    return emit(texts, lens, utf8_out, nbytes_out, boff_out);
+}
+
+// A big batch as BLOCKS of `block_sentences` sentences, block j from the stream seeded seed0 + 7919 j: any contiguous run of
+// blocks can be generated on its own (a rank's shard of the 10 M-sentence batch), on `nthreads` threads.
+int vpt_synth_blocks(const uint8_t* model, size_t model_len, uint64_t seed0, size_t first_block, size_t n_blocks, size_t block_sentences,
+                     uint32_t min_len, uint32_t max_len, uint32_t nthreads, uint8_t** utf8_out, size_t* nbytes_out, uint64_t** boff_out) {
+    if (!model || !utf8_out || !nbytes_out || !boff_out || min_len < 1 || max_len < min_len) return 2;
+    PatternList P;
+    if (!P.load(model, model_len)) return 1;
+    std::vector<std::vector<uint8_t>> texts(n_blocks);
+    std::vector<std::vector<uint32_t>> lens(n_blocks);
+    std::atomic<size_t> next{0};
+    auto work = [&] {
+        for (size_t b; (b = next.fetch_add(1)) < n_blocks;)
+            gen_block(P, seed0 + 7919ull * (first_block + b), block_sentences, min_len, max_len, texts[b], lens[b]);
+    };
+    std::vector<std::thread> th;
+    for (uint32_t t = 1; t < std::max<uint32_t>(1, nthreads); ++t) th.emplace_back(work);
+    work();
+    for (std::thread& t : th) t.join();
+    return emit(texts, lens, utf8_out, nbytes_out, boff_out);
 }
 
 }  // extern "C"
