@@ -313,7 +313,7 @@ class Runner:
             e2e = {"boundaries_per_s": nb / dt, "ms_per_batch": 1e3 * dt, "h2d_GBps": bytes_in / dt / 1e9, "d2h_GBps": bytes_out / dt / 1e9,
                    "pcie_peak_GBps_per_direction": PCIE_GBS, "frac_of_pcie": max(bytes_in, bytes_out) / dt / 1e9 / PCIE_GBS,
                    "parity": bool(parity is None or (np.array_equal(keep[1].array[:nb], o_scores) and np.array_equal(keep[2].array[:nb], o_labels))),
-                   "path": "vpt_predict_batch: pinned host buffers (vpt_host_alloc), ~1 M-char chunks, copy in / kernels / copy out on three streams"}
+                   "path": "vpt_predict_batch: pinned host buffers (vpt_host_alloc), ~2 M-char chunks, copy in / kernels / copy out on three streams"}
             del keep
 
         if self.rank != 0:

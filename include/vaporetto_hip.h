@@ -131,7 +131,7 @@ vpt_status vpt_predict_batch_flags(const vpt_predictor *p, const uint8_t *utf8, 
                                    size_t n_sentences, int32_t *scores_out, uint8_t *labels_out,
                                    const uint64_t *out_offsets, unsigned flags);
 
-/* Host buffers and the PCIe link.  vpt_predict_batch cuts a large batch into chunks of about a million chars and runs the copy
+/* Host buffers and the PCIe link.  vpt_predict_batch cuts a large batch into chunks of about two million chars and runs the copy
  * in of one chunk, the kernels of the one before and the copy out of the one before that at the same time (three streams,
  * two sets of device buffers).  With PINNED caller buffers -- vpt_host_alloc, or memory the caller registered with HIP
  * itself -- the copies are DMA transfers in both directions at once; with pageable buffers they go through the runtime's

@@ -19,7 +19,7 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
-KNOBS = ("VPT_DEBUG_LDS_PAD", "VPT_DEBUG_ABLATE", "VPT_SEPARATE_ASSIGN", "VPT_INLINE_ASSIGN", "VPT_FORCE_WINDOW_TABLE", "VPT_FORCE_GENERIC")
+KNOBS = ("VPT_DEBUG_LDS_PAD", "VPT_DEBUG_ABLATE", "VPT_SEPARATE_ASSIGN", "VPT_INLINE_ASSIGN", "VPT_FAST_CAP", "VPT_FORCE_WINDOW_TABLE", "VPT_FORCE_GENERIC")
 
 
 def lib_path(name):

@@ -142,10 +142,12 @@ struct vpt_batch {
     // the pipelined host-buffer path (predict_pipelined): two sets of device buffers, copy streams, pinned offset staging
     struct PipeSet {
         uint8_t* text = nullptr; size_t text_cap = 0;
-        uint64_t *boff = nullptr, *ooff = nullptr; size_t boff_cap = 0, ooff_cap = 0;
+        uint64_t* off = nullptr; size_t off_cap = 0;      // byte offsets, then boundary offsets: one copy
         int32_t* scores = nullptr; uint8_t* labels = nullptr; size_t scores_cap = 0, labels_cap = 0;
         hipEvent_t ev_in = nullptr, ev_k = nullptr, ev_out = nullptr;   // chunk copied in / scored / copied out
-    } pipe[2];
+    } pipe[2];   // (four sets, i.e. the host running further ahead, measured no faster at 2 M-char chunks and slower at 1 M: profiles/r02_c7_e2e.txt)
+    // ONE copy stream per direction: a single hipMemcpyAsync stream moves 56 GB/s each way and 84 GB/s both ways at once on
+    // this link; two streams per direction were slower (profiles/r02_c6_pcie_microbench.txt)
     hipStream_t s_in = nullptr, s_out = nullptr;
     uint64_t* h_off = nullptr; size_t h_off_cap = 0;                // pinned: the rebased offsets of every chunk of the call in flight
 };
@@ -170,6 +172,7 @@ struct vpt_predictor {
     vpt_model_info info{};
     int32_t bias = 0; int pad = 1; int type_kind = 0; int type_window = 0; int chunks = 2;
     uint32_t tile_slots = 0;           // workgroups of the scoring kernel the device runs at a time (0 = unknown)
+    uint32_t tile_slots_small = 0;     // ... of the specialised kernel's small-tile geometry
     vpt::PackedView pk{};
     const int32_t* d_type_table = nullptr;
     const uint8_t* d_ctype = nullptr;
@@ -204,7 +207,7 @@ void batch_release(vpt_batch* b) {
     (void)hipFree(b->d_tags); (void)hipFree(b->d_tok); (void)hipFree(b->d_toff); (void)hipFree(b->d_tok_model);
     (void)hipFree(b->d_types);
     for (auto& ps : b->pipe) {
-        (void)hipFree(ps.text); (void)hipFree(ps.boff); (void)hipFree(ps.ooff); (void)hipFree(ps.scores); (void)hipFree(ps.labels);
+        (void)hipFree(ps.text); (void)hipFree(ps.off); (void)hipFree(ps.scores); (void)hipFree(ps.labels);
         if (ps.ev_in) (void)hipEventDestroy(ps.ev_in);
         if (ps.ev_k) (void)hipEventDestroy(ps.ev_k);
         if (ps.ev_out) (void)hipEventDestroy(ps.ev_out);
@@ -403,19 +406,24 @@ void bind_predictor(vpt_predictor* p) {
     }
     p->info = m.info;
     p->bias = m.bias; p->pad = m.pad; p->type_kind = m.type_kind; p->type_window = m.type_window; p->chunks = m.chunks;
-    p->tile_slots = 0;
+    p->tile_slots = 0; p->tile_slots_small = 0;
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, p->device) == hipSuccess && prop.multiProcessorCount > 0) {
         vpt::ScoreParams probe{};
         probe.ct = p->ct; probe.pk = p->pk; probe.pad = p->pad; probe.ctype = p->d_ctype; probe.cid = p->d_cid; probe.type_kind = p->type_kind;
         probe.type_window = p->type_window;
         const bool fast = vpt::fast_path_supported(probe);
-        size_t lds = fast ? vpt::score_tiles_fast_lds_bytes(probe) : vpt::score_tiles_lds_bytes();
-        if (const char* padv = std::getenv("VPT_DEBUG_LDS_PAD")) lds += size_t(std::atoi(padv));   // occupancy experiments (kernels_fast.hip)
-        const size_t granules = (lds + 1279) / 1280;   // gfx950 hands out its 160 KB of LDS in 1280-byte granules
-        // the specialised kernel is built for 6 workgroups of 4 waves per CU, the general one for 8
-        const uint32_t per_cu = uint32_t(std::min<size_t>(fast ? 6 : 8, std::max<size_t>(1, 128 / std::max<size_t>(granules, 1))));
-        p->tile_slots = uint32_t(prop.multiProcessorCount) * per_cu;
+        auto slots_for = [&](size_t lds, size_t built_for) {
+            if (const char* padv = std::getenv("VPT_DEBUG_LDS_PAD")) lds += size_t(std::atoi(padv));   // occupancy experiments (kernels_fast.hip)
+            const size_t granules = (lds + 1279) / 1280;   // gfx950 hands out its 160 KB of LDS in 1280-byte granules
+            return uint32_t(prop.multiProcessorCount) * uint32_t(std::min<size_t>(built_for, std::max<size_t>(1, 128 / std::max<size_t>(granules, 1))));
+        };
+        if (fast) {
+            p->tile_slots_small = slots_for(vpt::score_tiles_fast_lds_bytes(probe, vpt::kFastCapSmall), vpt::kFastWgSmall);
+            p->tile_slots = slots_for(vpt::score_tiles_fast_lds_bytes(probe, vpt::kFastCapLarge), vpt::kFastWgLarge);
+        } else {
+            p->tile_slots = slots_for(vpt::score_tiles_lds_bytes(), 8);   // the general kernel is built for 8 workgroups per CU
+        }
     }
 }
 
@@ -824,18 +832,22 @@ vpt_status vpt_predict_batch_device(const vpt_predictor* p, vpt_batch* b, const 
     // Tiles are cut every `tile_flat` flat positions (chars + separators) and end with the sentence that crosses
     // the cut, so a tile holds < tile_flat + longest sentence: pick tile_flat to fill the kernel's LDS capacity.
     const bool fast = vpt::fast_path_supported(P) && !std::getenv("VPT_FORCE_GENERIC");
-    const uint64_t cap = fast ? vpt::kFastCap : vpt::kCap;
-    uint64_t tile_flat = cap / 2;
     // flat positions of the longest sentence: its chars, bounded by the caller's hint or else by its bytes
     const uint64_t max_chars = (b->max_chars && b->max_chars < max_sentence_bytes) ? b->max_chars : max_sentence_bytes;
+    // the specialised kernel's tile geometry (kernels.hpp): small tiles, 8 workgroups per CU, unless a sentence is long
+    int fast_cap = max_chars > uint64_t(vpt::kFastLongSentence) ? vpt::kFastCapLarge : vpt::kFastCapSmall;
+    if (const char* g = std::getenv("VPT_FAST_CAP")) fast_cap = std::atoi(g) == vpt::kFastCapSmall ? vpt::kFastCapSmall : vpt::kFastCapLarge;   // A/B runs
+    const uint32_t tile_slots = fast && fast_cap == vpt::kFastCapSmall ? p->tile_slots_small : p->tile_slots;
+    const uint64_t cap = fast ? uint64_t(fast_cap) : vpt::kCap;
+    uint64_t tile_flat = cap / 2;
     if (max_chars + 2 * uint64_t(p->pad) + cap / 2 <= cap) tile_flat = cap - 2 * uint64_t(p->pad) - max_chars;
     const uint64_t total_flat = total_boundaries + uint64_t(n_sentences) * uint64_t(1 + p->pad);
     // Whole rounds: the chip runs `slots` tiles at a time; cutting the batch into a multiple of that many tiles (by
     // shrinking the tiles a little) avoids a last round that leaves most CUs idle.
-    if (p->tile_slots > 0) {
+    if (tile_slots > 0) {
         const uint64_t n_min = (total_flat + tile_flat - 1) / tile_flat;
-        const uint64_t rounds = (n_min + p->tile_slots - 1) / p->tile_slots;
-        const uint64_t even = (total_flat + rounds * p->tile_slots - 1) / (rounds * p->tile_slots);
+        const uint64_t rounds = (n_min + tile_slots - 1) / tile_slots;
+        const uint64_t even = (total_flat + rounds * tile_slots - 1) / (rounds * tile_slots);
         if (even < tile_flat) tile_flat = std::max<uint64_t>(even, 256);
     }
     const uint64_t n_tiles64 = (total_flat + tile_flat - 1) / tile_flat;
@@ -881,7 +893,7 @@ vpt_status vpt_predict_batch_device(const vpt_predictor* p, vpt_batch* b, const 
     else VPT_HIP(vpt::launch_assign_tiles(d_out_offsets, n_sentences, p->pad, uint32_t(tile_flat), n_tiles, b->d_tile_first, b->d_ctrl, stream));
     const size_t slot = b->ev_calls % kTimingRing;
     if (b->timing) VPT_HIP(hipEventRecord(b->ev[2 * slot], stream));
-    if (fast) VPT_HIP(vpt::launch_score_tiles_fast(P, n_tiles, stream));
+    if (fast) VPT_HIP(vpt::launch_score_tiles_fast(P, fast_cap, n_tiles, stream));
     else VPT_HIP(vpt::launch_score_tiles(P, p->chunks, n_tiles, stream));
     if (b->timing) { VPT_HIP(hipEventRecord(b->ev[2 * slot + 1], stream)); ++b->ev_calls; }
     if (need_slow) VPT_HIP(vpt::launch_score_slow(P, p->chunks, slow_blocks, stream));
@@ -903,22 +915,21 @@ vpt_status vpt_batch_sync(vpt_batch* b) {
 
 namespace {
 
-// Chars per chunk of the pipelined host-buffer path: large enough for a launch to cover the chip's workgroup slots a few
-// times over, small enough that a 100 K-sentence batch is seven chunks in flight (VPT_CHUNK_CHARS overrides; tests use it).
+// Chars per chunk of the pipelined host-buffer path (VPT_CHUNK_CHARS overrides; tests use it): see predict_pipelined.
 uint64_t pipeline_chunk_chars() {
     if (const char* v = std::getenv("VPT_CHUNK_CHARS")) { const long long n = std::atoll(v); if (n > 0) return uint64_t(n); }
-    return uint64_t(1) << 20;
+    return uint64_t(2) << 20;
 }
 
 // vpt_predict_batch for a batch of several chunks: the copy in of chunk k + 1, the kernels of chunk k and the copy out
 // of chunk k - 1 run at the same time on three streams over two sets of device buffers, so that a caller with PINNED
 // buffers (vpt_host_alloc) gets both directions of the PCIe link busy at once instead of a copy-launch-copy sequence;
-// pageable buffers go through the runtime's staging and still overlap with the kernels.  `cuts` = the first sentence of
-// every chunk, then n_sentences.
+// pageable buffers go through the runtime's staging and still overlap with the kernels.  The host walks the sentences
+// ONCE, chunk by chunk -- validating them, rebasing their offsets into pinned staging, finding the cut -- while the
+// chunks before are in flight; a chunk costs eleven runtime calls (two copies in, two launches, two copies out, events),
+// which is why chunks are about two million chars: at a few microseconds per call smaller ones leave the link idle.
 vpt_status predict_pipelined(const vpt_predictor* p, vpt_batch* b, const uint8_t* utf8, const uint64_t* byte_offsets, size_t n_sentences,
-                             int32_t* scores_out, uint8_t* labels_out, const uint64_t* out_offsets, const std::vector<size_t>& cuts,
-                             uint64_t max_bytes, uint64_t max_chars) {
-    const size_t n_chunks = cuts.size() - 1;
+                             int32_t* scores_out, uint8_t* labels_out, const uint64_t* out_offsets, uint64_t chunk_chars) {
     if (!b->s_in) {
         VPT_HIP(hipStreamCreateWithFlags(&b->s_in, hipStreamNonBlocking));
         VPT_HIP(hipStreamCreateWithFlags(&b->s_out, hipStreamNonBlocking));
@@ -928,38 +939,51 @@ vpt_status predict_pipelined(const vpt_predictor* p, vpt_batch* b, const uint8_t
             VPT_HIP(hipEventCreateWithFlags(&ps.ev_out, hipEventDisableTiming));
         }
     }
-    const size_t need_off = 2 * (n_sentences + n_chunks);   // every chunk has one entry more than sentences, twice (bytes, boundaries)
+    const uint64_t total_chars = out_offsets[n_sentences] - out_offsets[0] + n_sentences;
+    const size_t max_chunks = size_t(total_chars / chunk_chars) + 2;
+    const size_t need_off = 2 * (n_sentences + max_chunks);   // a chunk of n sentences stages 2 (n + 1) offsets
     if (need_off > b->h_off_cap) {
         if (b->h_off) (void)hipHostFree(b->h_off);
         b->h_off = nullptr; b->h_off_cap = 0;
         VPT_HIP(hipHostMalloc(reinterpret_cast<void**>(&b->h_off), (need_off + need_off / 2) * sizeof(uint64_t), hipHostMallocDefault));
         b->h_off_cap = need_off + need_off / 2;
     }
-    uint64_t* h_boff = b->h_off;
-    uint64_t* h_ooff = b->h_off + (n_sentences + n_chunks);
-    b->max_chars = max_chars;
     vpt_status st;
-    for (size_t k = 0; k < n_chunks; ++k) {
+    size_t i = 0, staged = 0;
+    for (size_t k = 0; i < n_sentences; ++k) {
         vpt_batch::PipeSet& ps = b->pipe[k & 1];
-        const size_t a = cuts[k], e = cuts[k + 1], n = e - a;
-        const uint64_t t0 = byte_offsets[a], nbytes = byte_offsets[e] - t0;
-        const uint64_t o0 = out_offsets[a], nb = out_offsets[e] - o0;
-        uint64_t* hb = h_boff + a + k;
-        uint64_t* ho = h_ooff + a + k;
+        // ---- walk the chunk's sentences: validate, rebase, cut
+        const size_t a = i;
+        const uint64_t t0 = byte_offsets[a], o0 = out_offsets[a];
+        uint64_t* hb = b->h_off + staged;             // n + 1 byte offsets, then n + 1 boundary offsets, filled below
+        uint64_t chars = 0, max_bytes = 0, max_chars = 0;
+        while (i < n_sentences && chars < chunk_chars) {
+            if (byte_offsets[i + 1] <= byte_offsets[i]) return fail(VPT_INVALID_ARGUMENT, "InvalidArgumentError: text: must contain at least one character");
+            const uint64_t nby = byte_offsets[i + 1] - byte_offsets[i];
+            if (out_offsets[i + 1] < out_offsets[i] || out_offsets[i + 1] - out_offsets[i] + 1 > nby)
+                return fail(VPT_INVALID_ARGUMENT, "InvalidArgumentError: out_offsets: do not match the text (or the text is not valid UTF-8)");
+            const uint64_t nch = out_offsets[i + 1] - out_offsets[i] + 1;
+            max_bytes = std::max(max_bytes, nby); max_chars = std::max(max_chars, nch);
+            chars += nch;
+            ++i;
+        }
+        const size_t n = i - a;
+        uint64_t* ho = hb + (n + 1);
         for (size_t j = 0; j <= n; ++j) { hb[j] = byte_offsets[a + j] - t0; ho[j] = out_offsets[a + j] - o0; }
-        // this set's buffers are free once chunk k - 2 has been scored (inputs) and copied out (outputs)
+        staged += 2 * (n + 1);
+        const uint64_t nbytes = byte_offsets[i] - t0, nb = out_offsets[i] - o0;
+        // ---- this set's buffers are free once chunk k - 2 has been scored (inputs) and copied out (outputs)
         if (k >= 2) { VPT_HIP(hipEventSynchronize(ps.ev_out)); }   // also bounds how far the host runs ahead; growing a buffer below is then safe
         if ((st = grow(&ps.text, &ps.text_cap, size_t(nbytes) + 32)) != VPT_OK) return st;
-        if ((st = grow(&ps.boff, &ps.boff_cap, n + 1)) != VPT_OK) return st;
-        if ((st = grow(&ps.ooff, &ps.ooff_cap, n + 1)) != VPT_OK) return st;
+        if ((st = grow(&ps.off, &ps.off_cap, 2 * (n + 1))) != VPT_OK) return st;
         if (scores_out && (st = grow(&ps.scores, &ps.scores_cap, size_t(nb) + 1)) != VPT_OK) return st;
         if (labels_out && (st = grow(&ps.labels, &ps.labels_cap, size_t(nb) + 1)) != VPT_OK) return st;
         VPT_HIP(hipMemcpyAsync(ps.text, utf8 + t0, size_t(nbytes), hipMemcpyHostToDevice, b->s_in));
-        VPT_HIP(hipMemcpyAsync(ps.boff, hb, 8 * (n + 1), hipMemcpyHostToDevice, b->s_in));
-        VPT_HIP(hipMemcpyAsync(ps.ooff, ho, 8 * (n + 1), hipMemcpyHostToDevice, b->s_in));
+        VPT_HIP(hipMemcpyAsync(ps.off, hb, 16 * (n + 1), hipMemcpyHostToDevice, b->s_in));
         VPT_HIP(hipEventRecord(ps.ev_in, b->s_in));
         VPT_HIP(hipStreamWaitEvent(b->own_stream, ps.ev_in, 0));
-        st = vpt_predict_batch_device(p, b, ps.text, ps.boff, ps.ooff, n, nb, max_bytes, scores_out ? ps.scores : nullptr,
+        b->max_chars = max_chars;
+        st = vpt_predict_batch_device(p, b, ps.text, ps.off, ps.off + (n + 1), n, nb, max_bytes, scores_out ? ps.scores : nullptr,
                                       labels_out ? ps.labels : nullptr, b->own_stream);
         if (st != VPT_OK) return st;
         VPT_HIP(hipEventRecord(ps.ev_k, b->own_stream));
@@ -994,24 +1018,9 @@ vpt_status vpt_predict_batch_flags(const vpt_predictor* p, const uint8_t* utf8, 
     b->flags = flags;
     {   // a batch of several chunks goes through the copy/compute pipeline
         const uint64_t chunk = pipeline_chunk_chars();
-        const uint64_t total_chars = out_offsets[n_sentences] - out_offsets[0] + n_sentences;
-        if (byte_offsets[n_sentences] >= byte_offsets[0] && out_offsets[n_sentences] >= out_offsets[0] && total_chars > chunk + chunk / 2) {
-            std::vector<size_t> cuts(1, 0);
-            uint64_t max_bytes = 0, max_chars = 0, in_chunk = 0;
-            for (size_t i = 0; i < n_sentences; ++i) {
-                if (byte_offsets[i + 1] <= byte_offsets[i])
-                    return fail(VPT_INVALID_ARGUMENT, "InvalidArgumentError: text: must contain at least one character");
-                const uint64_t nby = byte_offsets[i + 1] - byte_offsets[i];
-                if (out_offsets[i + 1] < out_offsets[i] || out_offsets[i + 1] - out_offsets[i] + 1 > nby)
-                    return fail(VPT_INVALID_ARGUMENT, "InvalidArgumentError: out_offsets: do not match the text (or the text is not valid UTF-8)");
-                const uint64_t nch = out_offsets[i + 1] - out_offsets[i] + 1;
-                max_bytes = std::max(max_bytes, nby); max_chars = std::max(max_chars, nch);
-                if (in_chunk >= chunk) { cuts.push_back(i); in_chunk = 0; }
-                in_chunk += nch;
-            }
-            cuts.push_back(n_sentences);
-            if (cuts.size() > 2) return predict_pipelined(p, b, utf8, byte_offsets, n_sentences, scores_out, labels_out, out_offsets, cuts, max_bytes, max_chars);
-        }
+        if (byte_offsets[n_sentences] >= byte_offsets[0] && out_offsets[n_sentences] >= out_offsets[0] &&
+            out_offsets[n_sentences] - out_offsets[0] + n_sentences > chunk + chunk / 2)
+            return predict_pipelined(p, b, utf8, byte_offsets, n_sentences, scores_out, labels_out, out_offsets, chunk);
     }
     uint64_t total_b = 0, max_bytes = 0, max_chars = 0;
     if ((st = stage(b, utf8, byte_offsets, out_offsets, n_sentences, nullptr, &total_b, &max_bytes, &max_chars)) != VPT_OK) return st;

@@ -15,7 +15,12 @@ constexpr int kCap = 2048;                       // flat positions (chars + sepa
 constexpr int kTileFlat = 1024;                  // flat positions a tile is cut at (a tile ends with the sentence
                                                  // that crosses the cut, so it needs kCap - kTileFlat of slack)
 constexpr int kMargin = 8;                       // zeroed slack past the tile for the s+1, s+2 look-ahead
-constexpr int kFastCap = 1536;                   // flat positions of a tile of the specialised kernel (20 KB of LDS)
+// The specialised kernel ships in two tile geometries (measured on MI355X, profiles/r02_c5_ab*.jsonl): tiles of 1280 flat
+// positions leave room for 8 workgroups per CU -- the best for ordinary sentences --, tiles of 1536 (7 per CU) waste less on
+// long ones (a tile ends with the sentence that crosses its cut).  vpt_predict_batch_device picks by the longest sentence.
+constexpr int kFastCapSmall = 1280, kFastWgSmall = 8;
+constexpr int kFastCapLarge = 1536, kFastWgLarge = 7;
+constexpr int kFastLongSentence = 160;           // chars: batches with a longer sentence use the large geometry
 constexpr int kBitmapWords = 4 * kCap / 32 + 4;  // one bit per text byte of a tile (UTF-8: <= 4 bytes per char)
 
 // device status word (OR of bits)
@@ -105,8 +110,8 @@ hipError_t launch_assign_tiles(const uint64_t* ooff, uint64_t n_sent, int pad, u
                                uint32_t* tile_first, uint32_t* ctrl, hipStream_t stream);
 // specialised kernel (kernels_fast.hip): packed tables (char window 3, BMP, i16), type window table or none
 bool fast_path_supported(const ScoreParams& P);
-size_t score_tiles_fast_lds_bytes(const ScoreParams& P);
-hipError_t launch_score_tiles_fast(const ScoreParams& P, uint32_t n_tiles, hipStream_t stream);
+size_t score_tiles_fast_lds_bytes(const ScoreParams& P, int cap);   // cap: kFastCapSmall or kFastCapLarge
+hipError_t launch_score_tiles_fast(const ScoreParams& P, int cap, uint32_t n_tiles, hipStream_t stream);
 hipError_t launch_score_tiles(const ScoreParams& P, int chunks, uint32_t n_tiles, hipStream_t stream);
 hipError_t launch_score_slow(const ScoreParams& P, int chunks, uint32_t n_blocks, hipStream_t stream);
 

@@ -31,32 +31,41 @@
 namespace vpt {
 namespace {
 
-constexpr int kQCap = 160;                   // W items per wave
+constexpr int kQCap = 128;                   // W items per wave
 constexpr uint32_t kQHigh = kQCap - 64;      // replay until one more round of pushes (<= 64) fits
-constexpr int kMCap = 64;                    // M items per wave (a handful per tile: only rows outside their fields)
+constexpr int kMCap = 64;                    // M items per wave: one round of pushes (<= 64) always fits an empty stack
 constexpr uint32_t kCpMask = 0xFFFFu;        // sym = id (kNoId: in no pattern) | type << 16 | tile-local sentence << 19 | linebreak << 29
 constexpr uint32_t kSymLinebreak = 1u << 29;
-constexpr int kPerThread = kFastCap / kThreads;
 constexpr int kWavesF = kThreads / 64;
 constexpr int kTypeRows = 4;                 // TM value: type rows in LDS (1..3 = window table of that W, 0 = none)
 static_assert(kMargin >= int(kPackedMaxSkip), "replay_w reads up to kPackedMaxSkip symbols past a char");
 constexpr int kTrowCount = int(kTypeRowCount);   // layout.h, type_row_index
 
-struct FastLds {
-    uint32_t sym[kFastCap + kMargin];        // zero except for the tile's chars (scalar value | sentence << 21 until classified)
-    int32_t score[kFastCap + kMargin];       // staged text bytes during decode
+template <int CAP>
+struct FastLdsT {
+    uint32_t sym[CAP + kMargin];             // zero except for the tile's chars (scalar value | sentence << 21 until classified)
+    int32_t score[CAP + kMargin];            // staged text bytes during decode
     uint2 queue[kWavesF][kQCap];             // sentence-start bitmap during decode
-    uint2 mqueue[kWavesF][kMCap];
+    uint32_t mqueue[kWavesF][kMCap];
     uint32_t wtot[8];
     union {                                  // never needed together; the launch allocates the one in use
-        uint8_t typ[kFastCap + kMargin];     // window-table modes
+        uint8_t typ[CAP + kMargin];          // window-table modes
         uint4 trow[kTrowCount];              // TM == kTypeRows
     };
 };
-static_assert(offsetof(FastLds, typ) % 16 == 0 && (kFastCap + kMargin) * 4 % 16 == 0, "carve offsets stay 16-byte aligned");
-static_assert(sizeof(uint2) * kWavesF * kQCap >= size_t(kFastCap) * 4 / 8 + 16, "the sentence-start bitmap of the decode phase lives in the W queues");
-// gfx950 hands out LDS in granules of 1280 bytes: six workgroups per CU get 21 of the 128 each
-static_assert(offsetof(FastLds, typ) + sizeof(uint4) * kTrowCount <= 21 * 1280, "6 workgroups per CU");
+// the replay routines only index the arrays: they see the layout through the largest geometry's type (sym and score start
+// every geometry; the queues are passed as pointers)
+struct FastLds {
+    uint32_t* sym;
+    int32_t* score;
+};
+template <int CAP>
+constexpr bool fast_lds_ok(int wg_per_cu) {
+    return offsetof(FastLdsT<CAP>, typ) % 16 == 0 && (CAP + kMargin) * 4 % 16 == 0 &&                    // carve offsets stay 16-byte aligned
+           sizeof(uint2) * kWavesF * kQCap >= size_t(CAP) * 4 / 8 + 16 &&                                 // the decode phase's sentence-start bitmap lives in the W queues
+           offsetof(FastLdsT<CAP>, typ) + sizeof(uint4) * kTrowCount <= size_t(128 / wg_per_cu) * 1280;   // gfx950 hands out LDS in 1280-byte granules, 128 per CU
+}
+static_assert(fast_lds_ok<kFastCapSmall>(kFastWgSmall) && fast_lds_ok<kFastCapLarge>(kFastWgLarge), "LDS budget of the two tile geometries");
 
 __device__ __forceinline__ uint32_t lane_rank(uint64_t mask) {  // set bits of `mask` below this lane
     return __builtin_amdgcn_mbcnt_hi(uint32_t(mask >> 32), __builtin_amdgcn_mbcnt_lo(uint32_t(mask), 0u));
@@ -91,11 +100,11 @@ __device__ __forceinline__ uint32_t utf8_scalar_bf(uint32_t b4) {
 
 // Wave-private stacks of deferred work (wave-uniform counts):
 //   W  x = s | depth << 11   y = mini-table ref (in `deep`) of the children to search      trie step
-//   M  x = s | kinds << 11                                                                 a row outside its fields
+//   M  s | kinds << 11                                                                     a row outside its fields
 constexpr uint32_t kWideUni = 4u, kWideBi = 8u, kWideTri = 16u;
 struct WaveStacks {
     uint2* q;
-    uint2* mq;
+    uint32_t* mq;
     uint32_t nw, nm;
     __device__ __forceinline__ void push_w(bool pred, uint32_t x, uint32_t y) {
         const uint64_t m = __ballot(pred);
@@ -103,10 +112,10 @@ struct WaveStacks {
         if (pred) q[nw + lane_rank(m)] = make_uint2(x, y);
         nw = wave_uniform(nw + uint32_t(__popcll(m)));
     }
-    __device__ __forceinline__ void push_m(bool pred, uint32_t x, uint32_t y) {
+    __device__ __forceinline__ void push_m(bool pred, uint32_t x) {
         const uint64_t m = __ballot(pred);
         if (m == 0) return;
-        if (pred) mq[nm + lane_rank(m)] = make_uint2(x, y);
+        if (pred) mq[nm + lane_rank(m)] = x;
         nm += uint32_t(__popcll(m));
     }
 };
@@ -185,7 +194,7 @@ __device__ __forceinline__ void replay_w(const PackedView& K, FastLds& L, WaveSt
     const bool row = found && (e.x & (kPkHasRow << 16));
     if (__ballot(row) != 0) {
         uint4 f0 = make_uint4(0, 0, 0, 0), f1 = make_uint4(0, 0, 0, 0);
-        if (row) f0 = ld16(K.base, ent + 32);
+        if (row) f0 = ld16(K.base, ent + 32);   // (loading the home entry's row speculatively with the entry: no faster, profiles/r02_c5_ab*.jsonl)
         if (__ballot(row && m >= 8) != 0) { if (row && m >= 8) f1 = ld16(K.base, ent + 48); }
         if (row) {
             atomicAdd(dst, lo16(f0.x)); atomicAdd(dst + 1, hi16(f0.x)); atomicAdd(dst + 2, lo16(f0.y)); atomicAdd(dst + 3, hi16(f0.y));
@@ -249,8 +258,8 @@ __device__ __forceinline__ void replay_m(const PackedView& K, const PatternTable
     const uint32_t take = wave_uniform(Q.nm < 64u ? Q.nm : 64u);
     Q.nm -= take;
     if (uint32_t(lane) < take) {
-        const uint2 it = Q.mq[Q.nm + lane];
-        add_wide_rows(K, T, L, it.x >> 11, it.x & 0x7FFu);
+        const uint32_t it = Q.mq[Q.nm + lane];
+        add_wide_rows(K, T, L, it >> 11, it & 0x7FFu);
     }
 }
 
@@ -269,12 +278,14 @@ __device__ __forceinline__ uint64_t phase_mark(uint64_t* prof, int slot, uint64_
 
 // DBG: the diagnostics build (VPT_DEBUG_ABLATE timing ablations, VPT_PROFILE_PHASES) -- compiled out of the kernel
 // production launches use.
-template <int TM, bool DBG>
-__global__ __launch_bounds__(kThreads, 6) void score_tiles_fast_kernel(const ScoreParams P_in) {
+template <int TM, bool DBG, int CAP, int WG>
+__global__ __launch_bounds__(kThreads, WG) void score_tiles_fast_kernel(const ScoreParams P_in) {
     ScoreParams P = P_in;
     if (!DBG) { P.debug = 0; P.prof = nullptr; }
     VPT_DYNAMIC_LDS(smem);
-    FastLds& L = *reinterpret_cast<FastLds*>(smem);
+    FastLdsT<CAP>& M = *reinterpret_cast<FastLdsT<CAP>*>(smem);
+    FastLds L{M.sym, M.score};
+    constexpr int kFastCap = CAP, kPerThread = CAP / kThreads;
     const int tid = threadIdx.x, lane = tid & 63, wave = int(wave_uniform(uint32_t(tid) >> 6));
     const uint32_t wbase = uint32_t(wave) << 6;   // this wave's first thread, as a scalar
     constexpr uint32_t pad = 3;
@@ -289,10 +300,10 @@ __global__ __launch_bounds__(kThreads, 6) void score_tiles_fast_kernel(const Sco
             const uint32_t tt = t + uint32_t(tid);
             mine = tt >= P.n_tiles ? P.n_sent : first_sentence_at(P.ooff, P.n_sent, uint64_t(1 + pad), uint64_t(tt) * P.tile_flat);
         }
-        if (tid < 2) L.wtot[tid * 2] = uint32_t(mine), L.wtot[tid * 2 + 1] = uint32_t(mine >> 32);
+        if (tid < 2) M.wtot[tid * 2] = uint32_t(mine), M.wtot[tid * 2 + 1] = uint32_t(mine >> 32);
         __syncthreads();
-        i0 = uint64_t(wave_uniform(L.wtot[0])) | (uint64_t(wave_uniform(L.wtot[1])) << 32);
-        i1 = uint64_t(wave_uniform(L.wtot[2])) | (uint64_t(wave_uniform(L.wtot[3])) << 32);
+        i0 = uint64_t(wave_uniform(M.wtot[0])) | (uint64_t(wave_uniform(M.wtot[1])) << 32);
+        i1 = uint64_t(wave_uniform(M.wtot[2])) | (uint64_t(wave_uniform(M.wtot[3])) << 32);
         __syncthreads();   // wtot is reused by the scan
     }
     if (i0 >= i1) return;
@@ -316,7 +327,7 @@ __global__ __launch_bounds__(kThreads, 6) void score_tiles_fast_kernel(const Sco
     const uint32_t nchunks = (nbytes_al + 15) >> 4;
     uint32_t err = 0;
     if (TM == kTypeRows) {  // 512 type rows -> LDS (not aliased by the decode scratch; barriers follow before use)
-        for (uint32_t i = tid; i < uint32_t(kTrowCount); i += kThreads) L.trow[i] = ld16(P.pk.base, P.pk.off_trow + (i << 4));
+        for (uint32_t i = tid; i < uint32_t(kTrowCount); i += kThreads) M.trow[i] = ld16(P.pk.base, P.pk.off_trow + (i << 4));
     }
     uint64_t* const prof = P.prof;
     uint64_t tmark = prof ? __builtin_amdgcn_s_memtime() : 0;
@@ -326,12 +337,12 @@ __global__ __launch_bounds__(kThreads, 6) void score_tiles_fast_kernel(const Sco
     // the slack past the tile).  The text is staged in LDS (the score array is free until phase B), a chunk scan
     // numbers the chars and the sentences, and the thread that scanned a chunk decodes its chars straight into
     // their flat positions; a second pass classifies them (one cache-hot table read each, all in flight together).
-    uint32_t* bitmap = reinterpret_cast<uint32_t*>(&L.queue[0][0]);   // one bit per text byte: a sentence starts here
+    uint32_t* bitmap = reinterpret_cast<uint32_t*>(&M.queue[0][0]);   // one bit per text byte: a sentence starts here
     uint32_t* raw = reinterpret_cast<uint32_t*>(&L.score[0]);
     for (uint32_t i = tid; i < ((nbytes_al + 31) >> 5) + 1; i += kThreads) bitmap[i] = 0;
     for (uint32_t i = tid; i < (uint32_t(kFastCap + kMargin) * 4) / 16; i += kThreads) reinterpret_cast<uint4*>(L.sym)[i] = make_uint4(0, 0, 0, 0);
     if (TM != kTypeRows) {
-        for (uint32_t i = tid; i < uint32_t(kFastCap + kMargin) / 4; i += kThreads) reinterpret_cast<uint32_t*>(L.typ)[i] = 0;
+        for (uint32_t i = tid; i < uint32_t(kFastCap + kMargin) / 4; i += kThreads) reinterpret_cast<uint32_t*>(M.typ)[i] = 0;
     }
     for (uint32_t c = tid; c < nchunks; c += kThreads) reinterpret_cast<uint4*>(raw)[c] = reinterpret_cast<const uint4*>(a0)[c];   // (non-temporal loads / stores here measured 1-2 % slower: profiles/r02_c1_ab.jsonl, r02_c3_ab.jsonl)
     if (tid == 0) raw[nchunks * 4] = 0;  // the dword after the staged text is read (as padding) by the last char
@@ -360,12 +371,12 @@ __global__ __launch_bounds__(kThreads, 6) void score_tiles_fast_kernel(const Sco
         }
         const uint32_t mine = __popc(lm) | (__popc(sm) << 16);
         const uint32_t incl = wave_inclusive_scan(mine);
-        if (lane == 63) L.wtot[wave] = incl;
+        if (lane == 63) M.wtot[wave] = incl;
         __syncthreads();
         uint32_t woff = 0, total = 0;
 #pragma unroll
         for (int k = 0; k < kWavesF; ++k) {
-            const uint32_t u = wave_uniform(L.wtot[k]);
+            const uint32_t u = wave_uniform(M.wtot[k]);
             if (k < wave) woff += u;
             total += u;
         }
@@ -420,7 +431,7 @@ __global__ __launch_bounds__(kThreads, 6) void score_tiles_fast_kernel(const Sco
             }
             v = cp != 0 ? v : 0u;                  // a separator (or NUL, which has raised kErrNulChar)
             L.sym[uint32_t(tid) + uint32_t(k) * kThreads] = v;
-            if (TM != kTypeRows) L.typ[uint32_t(tid) + uint32_t(k) * kThreads] = uint8_t((v >> 16) & 7u);
+            if (TM != kTypeRows) M.typ[uint32_t(tid) + uint32_t(k) * kThreads] = uint8_t((v >> 16) & 7u);
         }
     }
     __syncthreads();
@@ -432,7 +443,7 @@ __global__ __launch_bounds__(kThreads, 6) void score_tiles_fast_kernel(const Sco
     // that do not depend on each other -- waits once, adds the rows that arrived to the LDS score array and computes the
     // addresses the next trip needs (child slot = base in the parent + id of the next char; layout.h).
     const PackedView& K = P.pk;
-    WaveStacks Q{&L.queue[wave][0], &L.mqueue[wave][0], 0u, 0u};
+    WaveStacks Q{&M.queue[wave][0], &M.mqueue[wave][0], 0u, 0u};
     const uint32_t uni_last = K.n_uni - 1u;
     const uint32_t off_bi = K.off_bi & ~255u, off_tri = K.off_tri & ~255u;   // they ARE 256-byte aligned (capi.cpp); now the compiler knows
     uint32_t b_slot = 0, b_key = 0, b_id3 = 0;   // next trip's bigram stage: node slot, its key (0: no bigram starts there), id of the third char
@@ -470,7 +481,7 @@ __global__ __launch_bounds__(kThreads, 6) void score_tiles_fast_kernel(const Sco
             const uint64_t mm = __ballot(wide);
             if (mm != 0) {
                 while (Q.nm + uint32_t(__popcll(mm)) > uint32_t(kMCap)) replay_m(K, P.ct, L, Q, lane);
-                Q.push_m(wide, s_t | (kWideTri << 11), 0u);
+                Q.push_m(wide, s_t | (kWideTri << 11));
             }
         }
         // ---- bigram stage of positions s_b: key check, the row, and the address of the trigram node
@@ -494,7 +505,7 @@ __global__ __launch_bounds__(kThreads, 6) void score_tiles_fast_kernel(const Sco
             const uint64_t mm = __ballot(keyok && (n0.w & kBiWideBit));
             if (mm != 0) {
                 while (Q.nm + uint32_t(__popcll(mm)) > uint32_t(kMCap)) replay_m(K, P.ct, L, Q, lane);
-                Q.push_m(keyok && (n0.w & kBiWideBit), s_b | (kWideBi << 11), 0u);
+                Q.push_m(keyok && (n0.w & kBiWideBit), s_b | (kWideBi << 11));
             }
         }
         // ---- unigram stage of positions s_u: the row (+ the type row), and the address of the bigram node
@@ -508,7 +519,7 @@ __global__ __launch_bounds__(kThreads, 6) void score_tiles_fast_kernel(const Sco
             int32_t a4 = sext(u.z >> 8, kUniFieldBits), a5 = sext(__builtin_amdgcn_alignbit(u.w, u.z, 26), kUniFieldBits);
             if (TM == kTypeRows) {
                 // a dead lane (t1 = 0) reads the 16 bytes in front of the rows; nothing is added for it
-                const uint4 tr = L.trow[int32_t(type_row_index((x1 >> 16) & 7u, (x2 >> 16) & 7u, (x3 >> 16) & 7u))];
+                const uint4 tr = M.trow[int32_t(type_row_index((x1 >> 16) & 7u, (x2 >> 16) & 7u, (x3 >> 16) & 7u))];
                 // six 18-bit signed fields at bits 0, 18, 36, 54, 72, 90 (layout.h, trow_field)
                 a0 += int32_t(tr.x << 14) >> 14;
                 a1 += int32_t(__builtin_amdgcn_alignbit(tr.y, tr.x, 18) << 14) >> 14;
@@ -524,7 +535,7 @@ __global__ __launch_bounds__(kThreads, 6) void score_tiles_fast_kernel(const Sco
             const uint64_t mm = __ballot(live && (u.w & kUniWideBit) && !(P.debug & 32u));
             if (mm != 0) {
                 while (Q.nm + uint32_t(__popcll(mm)) > uint32_t(kMCap)) replay_m(K, P.ct, L, Q, lane);
-                Q.push_m(live && (u.w & kUniWideBit), s_u | (kWideUni << 11), 0u);
+                Q.push_m(live && (u.w & kUniWideBit), s_u | (kWideUni << 11));
             }
         }
     }
@@ -550,7 +561,7 @@ __global__ __launch_bounds__(kThreads, 6) void score_tiles_fast_kernel(const Sco
         if (TM >= 1 && TM <= 3) {
             uint32_t id = 0;  // window t[b-W+1 .. b+W], 3 bits each (boundary_scorer_cache.rs:59-81)
 #pragma unroll
-            for (int i = 1 - TM; i <= TM; ++i) id = (id << 3) | (L.typ[int(p) + i] & 7u);
+            for (int i = 1 - TM; i <= TM; ++i) id = (id << 3) | (M.typ[int(p) + i] & 7u);
             y += P.type_table[id];
         }
         const uint32_t o = (p - pad) - (pad + 1) * ((x >> 19) & 1023u);
@@ -582,19 +593,23 @@ bool fast_path_supported(const ScoreParams& P) {
 static bool use_type_rows(const ScoreParams& P) {
     return P.type_kind == kTypeWindowTable && P.pk.has_trow && !std::getenv("VPT_FORCE_WINDOW_TABLE");
 }
-size_t score_tiles_fast_lds_bytes(const ScoreParams& P) {
-    return offsetof(FastLds, typ) + (use_type_rows(P) ? sizeof(uint4) * kTrowCount : size_t(kFastCap + kMargin));
+size_t score_tiles_fast_lds_bytes(const ScoreParams& P, int cap) {
+    const size_t head = cap == kFastCapSmall ? offsetof(FastLdsT<kFastCapSmall>, typ) : offsetof(FastLdsT<kFastCapLarge>, typ);
+    return head + (use_type_rows(P) ? sizeof(uint4) * kTrowCount : size_t(cap + kMargin));
 }
 
-hipError_t launch_score_tiles_fast(const ScoreParams& P, uint32_t n_tiles, hipStream_t stream) {
+hipError_t launch_score_tiles_fast(const ScoreParams& P, int cap, uint32_t n_tiles, hipStream_t stream) {
     const bool rows = use_type_rows(P);
-    size_t lds = score_tiles_fast_lds_bytes(P);
+    size_t lds = score_tiles_fast_lds_bytes(P, cap);
     if (const char* padv = std::getenv("VPT_DEBUG_LDS_PAD")) lds += size_t(std::atoi(padv));  // occupancy experiments
     const int tm = rows ? kTypeRows : P.type_kind == kTypeWindowTable ? P.type_window : 0;
     const bool dbg = P.debug != 0 || P.prof != nullptr;
-#define VPT_LAUNCH_FAST(TM_)                                                                                                   \
-    if (dbg) hipLaunchKernelGGL((score_tiles_fast_kernel<TM_, true>), dim3(n_tiles), dim3(kThreads), lds, stream, P);          \
-    else hipLaunchKernelGGL((score_tiles_fast_kernel<TM_, false>), dim3(n_tiles), dim3(kThreads), lds, stream, P);             \
+    if (cap != kFastCapSmall && cap != kFastCapLarge) return hipErrorInvalidValue;
+#define VPT_LAUNCH_FAST2(TM_, DBG_)                                                                                                          \
+    if (cap == kFastCapSmall) hipLaunchKernelGGL((score_tiles_fast_kernel<TM_, DBG_, kFastCapSmall, kFastWgSmall>), dim3(n_tiles), dim3(kThreads), lds, stream, P); \
+    else hipLaunchKernelGGL((score_tiles_fast_kernel<TM_, DBG_, kFastCapLarge, kFastWgLarge>), dim3(n_tiles), dim3(kThreads), lds, stream, P);
+#define VPT_LAUNCH_FAST(TM_)                                  \
+    if (dbg) { VPT_LAUNCH_FAST2(TM_, true) } else { VPT_LAUNCH_FAST2(TM_, false) } \
     break;
     switch (tm) {
         case 0: VPT_LAUNCH_FAST(0)
@@ -605,6 +620,7 @@ hipError_t launch_score_tiles_fast(const ScoreParams& P, uint32_t n_tiles, hipSt
         default: return hipErrorInvalidValue;
     }
 #undef VPT_LAUNCH_FAST
+#undef VPT_LAUNCH_FAST2
     return hipGetLastError();
 }
 
