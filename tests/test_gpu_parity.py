@@ -578,6 +578,61 @@ def test_random_tag_models_match_oracle(seed):
             assert np.array_equal(got[g0:g0 + len(t)], want), (t, lab[a:b].tolist())
 
 
+def test_tag_models_inside_and_outside_the_record_form():
+    """The tag kernel's fast path checks whole n-grams from 32-byte records (<= 12 BMP symbols, <= 16 scores per model);
+    models outside that form -- an n-gram of 14 chars, a non-BMP n-gram, 24 scores -- take the whole-wave routine.  Both kinds
+    mixed in the same sentences, many tokens with models per 64-char step, long sentences (several steps, tokens that
+    cross a step), predicted and edited labels."""
+    from vaporetto_amd.modelfmt import TagModel, TagNgramData, TagWeight
+    import random
+    rng = random.Random(7)
+    alpha = randmodel.ALPHABETS["kana"][:6]
+    m = randmodel.rand_model(950, alphabet=alpha, wc=3, wt=3, n_char=60, n_dict=40, max_word=3, n_tag_models=0)
+    toks = sorted({"".join(rng.choice(alpha) for _ in range(rng.randint(1, 2))) for _ in range(30)})
+
+    def w(n):
+        return [rng.randint(-3000, 3000) for _ in range(n)]
+    for i, tok in enumerate(toks):
+        kind = i % 5
+        slots = [["a", "b", "c"], ["x", "y"]] if kind != 3 else [["t%d" % k for k in range(8)] for _ in range(3)]   # 5 or 24 scores
+        zlen = sum(len(s_) for s_ in slots if len(s_) >= 2)
+        tm = TagModel(tok, slots, bias=w(zlen))
+        for _ in range(rng.randint(2, 8)):
+            left = "".join(rng.choice(alpha) for _ in range(rng.randint(0, 2)))
+            right = "".join(rng.choice(alpha) for _ in range(rng.randint(0, 2)))
+            tm.char_ngram_model.append(TagNgramData(left + tok + right, [TagWeight(r, w(zlen)) for r in sorted({rng.randint(0, 3), len(right)})]))
+        for _ in range(rng.randint(0, 4)):
+            tm.type_ngram_model.append(TagNgramData(bytes(rng.choice([3, 3, 5, 4]) for _ in range(rng.randint(1, 4))),
+                                                    [TagWeight(rng.randint(0, 3), w(zlen))]))
+        if kind == 1:   # 14 chars: more than a record holds
+            tm.char_ngram_model.append(TagNgramData("".join(rng.choice(alpha) for _ in range(13 - len(tok))) + tok + alpha[0], [TagWeight(1, w(zlen))]))
+        if kind == 2:   # a non-BMP symbol
+            tm.char_ngram_model.append(TagNgramData(tok + "𠮷", [TagWeight(1, w(zlen))]))
+        m.tag_models.append(tm)
+    raw = encode_model(m)
+    pred = api.Predictor(api.Model.read_slice(raw)[0], True)
+    orc = cbind.OraclePredictor(raw, True)
+    nt = pred.n_tags()
+    assert nt == 3
+    texts = ["".join(rng.choice(alpha + ["𠮷"] if rng.random() < 0.05 else alpha) for _ in range(rng.choice([3, 20, 64, 65, 130, 300]))) for _ in range(120)]
+    texts += ["".join(rng.choice(toks) for _ in range(40)) for _ in range(20)]          # dense in tokens with models
+    utf8, boff = api.pack_texts([t.encode("utf-8") for t in texts])
+    scores, labels, ooff = pred.predict_packed(utf8, boff)
+    nrng = np.random.RandomState(3)
+    for edit in (0, 1, 2):
+        lab = labels.copy()
+        if edit == 1:
+            lab[:] = 1                                   # every char a token: 64 tokens per step
+        if edit == 2:
+            k = nrng.randint(0, len(lab), size=len(lab) // 5)
+            lab[k] = nrng.randint(0, 3, size=len(k))
+        got = pred.fill_tags_packed(utf8, boff, ooff, lab)
+        for i, t in enumerate(texts):
+            a, b = int(ooff[i]), int(ooff[i + 1])
+            want, _ = orc.predict_tags(t, labels=lab[a:b])
+            assert np.array_equal(got[a + i:a + i + len(t)], want), (edit, i, t[:30])
+
+
 def test_converted_kytea_fixture_on_gpu():
     """resources/kytea-model.bin converted by vaporetto_amd/kytea.py (kytea_model.rs:401-422): same tokens on the GPU."""
     from vaporetto_amd import kytea

@@ -46,7 +46,7 @@ enum Section : int {
     kSecTShort, kSecTUni, kSecTEdges, kSecTWdata,              // general type tables (type_kind == pattern tables)
     kSecPUni, kSecPBi, kSecPTri, kSecPDeep, kSecPXrows, kSecPTrow, kSecPCpid,   // packed tables: contiguous, addressed from kSecPUni
     kSecTypeTable, kSecCtype, kSecCinfo, kSecCid,
-    kSecTagTokTab, kSecTagModels, kSecTagNgrams, kSecTagSyms, kSecTagSlots, kSecTagWeights, kSecTagSlotStr, kSecTagStrOff, kSecTagStrBytes,
+    kSecTagTokTab, kSecTagModels, kSecTagNgrams, kSecTagNrec, kSecTagSyms, kSecTagSlots, kSecTagWeights, kSecTagSlotStr, kSecTagStrOff, kSecTagStrBytes,
     kSectionCount
 };
 struct TableGeom {
@@ -54,7 +54,7 @@ struct TableGeom {
     int32_t window, lo[3], len[3];
 };
 constexpr char kCompiledMagic[16] = "VaporettoHIP-C\x01";   // 15 chars + NUL
-constexpr uint32_t kCompiledVersion = 2;                    // bump whenever layout.h or a kernel's reading of it changes
+constexpr uint32_t kCompiledVersion = 4;                    // bump whenever layout.h or a kernel's reading of it changes
 struct PredictorMeta {                                      // plain data: written and read as is (little-endian hosts)
     char magic[16];
     uint32_t version, meta_bytes;
@@ -153,7 +153,7 @@ struct vpt_batch {
 };
 
 struct DeviceTags {   // views into the arena
-    const uint32_t *tok_tab = nullptr, *models = nullptr, *ngrams = nullptr, *syms = nullptr, *slots = nullptr, *slot_str = nullptr, *str_off = nullptr;
+    const uint32_t *tok_tab = nullptr, *models = nullptr, *ngrams = nullptr, *nrec = nullptr, *syms = nullptr, *slots = nullptr, *slot_str = nullptr, *str_off = nullptr;
     const uint8_t* str_bytes = nullptr;
     const int32_t* weights = nullptr;
     uint32_t n_models = 0, n_strings = 0;
@@ -398,7 +398,8 @@ void bind_predictor(vpt_predictor* p) {
     p->tag_use_char = m.tag_use_char != 0; p->tag_use_type = m.tag_use_type != 0;
     if (m.has_tags) {
         p->dtag.tok_tab = reinterpret_cast<const uint32_t*>(at(kSecTagTokTab)); p->dtag.models = reinterpret_cast<const uint32_t*>(at(kSecTagModels));
-        p->dtag.ngrams = reinterpret_cast<const uint32_t*>(at(kSecTagNgrams)); p->dtag.syms = reinterpret_cast<const uint32_t*>(at(kSecTagSyms));
+        p->dtag.ngrams = reinterpret_cast<const uint32_t*>(at(kSecTagNgrams)); p->dtag.nrec = reinterpret_cast<const uint32_t*>(at(kSecTagNrec));
+        p->dtag.syms = reinterpret_cast<const uint32_t*>(at(kSecTagSyms));
         p->dtag.slots = reinterpret_cast<const uint32_t*>(at(kSecTagSlots)); p->dtag.weights = reinterpret_cast<const int32_t*>(at(kSecTagWeights));
         p->dtag.slot_str = reinterpret_cast<const uint32_t*>(at(kSecTagSlotStr)); p->dtag.str_off = reinterpret_cast<const uint32_t*>(at(kSecTagStrOff));
         p->dtag.str_bytes = at(kSecTagStrBytes);
@@ -493,7 +494,7 @@ vpt_status vpt_predictor_create(const uint8_t* model_bytes, size_t len, int pred
     put(kSecCtype, ctype); put(kSecCinfo, cinfo);
     if (packed_ok) put(kSecCid, cid);
     if (c.tags.present) {
-        put(kSecTagTokTab, c.tags.tok_tab); put(kSecTagModels, c.tags.models); put(kSecTagNgrams, c.tags.ngrams); put(kSecTagSyms, c.tags.syms);
+        put(kSecTagTokTab, c.tags.tok_tab); put(kSecTagModels, c.tags.models); put(kSecTagNgrams, c.tags.ngrams); put(kSecTagNrec, c.tags.nrec); put(kSecTagSyms, c.tags.syms);
         put(kSecTagSlots, c.tags.slots); put(kSecTagWeights, c.tags.weights); put(kSecTagSlotStr, c.tags.slot_str);
         put(kSecTagStrOff, c.tags.str_off); put(kSecTagStrBytes, c.tags.str_bytes);
     }
@@ -1096,7 +1097,7 @@ vpt_status vpt_fill_tags_batch_device(const vpt_predictor* p, vpt_batch* b, cons
     VPT_HIP(hipMemsetAsync(b->d_tok_model, 0, size_t(total_c) * sizeof(int32_t), stream));
     VPT_HIP(vpt::launch_decode_chars(d_utf8, d_byte_offsets, d_out_offsets, n_sentences, total_c, cinfo, b->d_cps, nullptr, b->d_ctrl, stream));
     vpt::TagParams T{};
-    T.tok_tab = p->dtag.tok_tab; T.models = p->dtag.models; T.ngrams = p->dtag.ngrams; T.syms = p->dtag.syms; T.slots = p->dtag.slots;
+    T.tok_tab = p->dtag.tok_tab; T.models = p->dtag.models; T.ngrams = p->dtag.ngrams; T.nrec = p->dtag.nrec; T.syms = p->dtag.syms; T.slots = p->dtag.slots;
     T.weights = p->dtag.weights; T.cinfo = cinfo; T.tok_bits = p->tok_bits; T.n_tags = p->n_tags;
     T.use_char = p->tag_use_char ? 1u : 0u; T.use_type = p->tag_use_type ? 1u : 0u;
     T.cps = b->d_cps; T.ooff = d_out_offsets; T.labels = d_labels; T.n_sent = n_sentences; T.total_chars = total_c; T.tags = d_tags_out;

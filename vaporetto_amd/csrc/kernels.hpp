@@ -66,11 +66,11 @@ struct ScoreParams {
 
 // tag prediction (kernels_tags.hip); table layouts: HostTagTables in tables.hpp
 struct TagParams {
-    const uint32_t *tok_tab, *models, *ngrams, *syms, *slots;
+    const uint32_t *tok_tab, *models, *ngrams, *nrec, *syms, *slots;
     const int32_t* weights;
     const uint32_t* cinfo;      // as in ScoreParams
     uint32_t tok_bits, n_tags, use_char, use_type;
-    const uint32_t* cps;        // flat scalar values of the batch (decode_chars_kernel)
+    const uint32_t* cps;        // the batch's chars, flat (decode_chars_kernel): scored scalar value | CharacterType << 24
     const uint64_t* ooff;       // [S+1]
     const uint8_t* labels;      // [total boundaries] CharacterBoundary values (0, 1, 2 = Unknown)
     uint64_t n_sent;

@@ -11,9 +11,18 @@
 // (char_scorer/boundary_tag_scorer.rs:62-174, type_scorer/boundary_tag_scorer.rs:51-143) with suffix-merged tag
 // weights; integer adds are order-free, so the sums are bit-identical.
 //
-// Two kernels, one wave per sentence each (a first, simple mapping: the tag path is not the measured hot path):
-//   decode_chars_kernel  UTF-8 -> scalar values, flat per batch (char g of sentence i at out_offsets[i] + i + g)
-//   tag_tokens_kernel    token walk over the labels, token lookup, z accumulation in LDS, argmax per slot
+// Two kernels, one wave per sentence each:
+//   decode_chars_kernel  UTF-8 -> flat per batch (char g of sentence i at out_offsets[i] + i + g): the scored scalar value
+//                        | CharacterType << 24; optionally Sentence::char_types on their own
+//   tag_tokens_kernel    64 chars per step.  (1) Every lane whose char ends a token owns it: start from the step's boundary
+//                        masks, surface lookup in the hashed token table.  (2) The tokens that found a tag model are
+//                        compacted, and the wave's lanes then enumerate (token, tag n-gram) PAIRS, 64 per round: a lane
+//                        checks one whole n-gram from one 32-byte record against the text window in LDS and, on a match, adds
+//                        its weights to the token's scores in LDS -- the n-grams of ALL the step's tokens are checked in
+//                        a few rounds of independent loads instead of token after token, n-gram after n-gram, symbol after
+//                        symbol.  (3) Lanes over (token, slot) pairs take the argmax.  Models that do not fit the record
+//                        form (an n-gram over 12 symbols or outside the BMP, more than 16 scores) go through a whole-wave
+//                        routine, one token at a time.
 #include <hip/hip_runtime.h>
 
 #include "device_common.h"
@@ -30,7 +39,8 @@ __device__ __forceinline__ uint32_t lanes_below(uint64_t mask, int lane) {
 }
 
 // `total_chars` = chars the caller's offsets promise for the whole batch (the size of `cps`): offsets that do not match
-// the text raise kErrBadOffsets instead of writing outside it
+// the text raise kErrBadOffsets instead of writing outside it.  A lane takes FOUR text bytes per step (one dword, and the
+// next one for the tail of a char that starts in its own), counts its lead bytes, and a wave prefix sum places its chars.
 __global__ __launch_bounds__(kTagThreads) void decode_chars_kernel(const uint8_t* __restrict__ text, const uint64_t* __restrict__ boff,
                                                                    const uint64_t* __restrict__ ooff, uint64_t n_sent, uint64_t total_chars,
                                                                    const uint32_t* __restrict__ cinfo, uint32_t* __restrict__ cps,
@@ -45,102 +55,97 @@ __global__ __launch_bounds__(kTagThreads) void decode_chars_kernel(const uint8_t
         const bool sane = o1 >= o0 && b1 >= b0 && o1 + i + 1 <= total_chars;
         const uint64_t want = sane ? o1 - o0 + 1 : 0;   // chars of this sentence
         uint64_t seen = 0;
-        for (uint64_t pos = b0; sane && pos < b1; pos += 64) {
-            const uint64_t at = pos + uint64_t(lane);
-            const bool in = at < b1;
-            const uint32_t byte0 = in ? text[at] : 0x80u;
-            const bool lead = in && (byte0 & 0xC0u) != 0x80u;
-            const uint64_t m = __ballot(lead);
-            const uint64_t idx = seen + lanes_below(m, lane);
-            if (lead && idx < want) {
-                uint32_t b4 = byte0;
-                if (byte0 >= 0xC0u && at + 1 < b1) b4 |= uint32_t(text[at + 1]) << 8;
-                if (byte0 >= 0xE0u && at + 2 < b1) b4 |= uint32_t(text[at + 2]) << 16;
-                if (byte0 >= 0xF0u && at + 3 < b1) b4 |= uint32_t(text[at + 3]) << 24;
-                const uint32_t cp = utf8_scalar(b4);
-                const uint32_t info = cp < 0x10000u ? cinfo[cp] : 0u;   // the scored char | its CharacterType << 16 (BMP only)
-                if (cps) cps[g + idx] = cp < 0x10000u ? info & 0xFFFFu : cp;
-                if (types) types[g + idx] = uint8_t(cp < 0x10000u ? info >> 16 : char_type(cp));   // Sentence::char_types (sentence.rs:1016)
+        for (uint64_t pos = b0; sane && pos < b1; pos += 256) {
+            const uint64_t at = pos + 4 * uint64_t(lane);
+            // eight bytes from `at`, never reading at or past b1 (the text may end where its allocation does)
+            uint64_t x = 0;
+            if (at + 8 <= b1) {
+                uint32_t lo, hi;
+                __builtin_memcpy(&lo, text + at, 4);
+                __builtin_memcpy(&hi, text + at + 4, 4);
+                x = uint64_t(lo) | (uint64_t(hi) << 32);
+            } else {
+                for (uint64_t k = 0; k < 8 && at + k < b1; ++k) x |= uint64_t(text[at + k]) << (8 * k);
             }
-            seen += uint64_t(__popcll(m));
+            const uint32_t mine = at < b1 ? uint32_t(b1 - at < 4 ? b1 - at : 4) : 0u;          // bytes of this lane's own dword inside the sentence
+            const uint32_t lm = lead_nibble(uint32_t(x)) & ((1u << mine) - 1u);              // which of them start a char
+            uint32_t incl = uint32_t(__popc(lm));
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) {
+                const uint32_t up = uint32_t(__shfl_up(int(incl), d));
+                if (lane >= d) incl += up;
+            }
+            const uint32_t total = uint32_t(__shfl(int(incl), 63));
+            uint64_t idx = seen + incl - uint32_t(__popc(lm));
+#pragma unroll
+            for (uint32_t k = 0; k < 4; ++k) {
+                if ((lm >> k) & 1u) {
+                    if (idx < want) {
+                        const uint32_t cp = utf8_scalar(uint32_t(x >> (8 * k)));
+                        const uint32_t info = cp < 0x10000u ? cinfo[cp] : 0u;   // the scored char | its CharacterType << 16 (BMP only)
+                        const uint32_t ty = cp < 0x10000u ? info >> 16 : char_type(cp);
+                        if (cps) cps[g + idx] = (cp < 0x10000u ? info & 0xFFFFu : cp) | (ty << 24);
+                        if (types) types[g + idx] = uint8_t(ty);   // Sentence::char_types (sentence.rs:1016)
+                    }
+                    ++idx;
+                }
+            }
+            seen += total;
         }
         if (lane == 0 && (!sane || seen != want)) atomicOr(status, kErrBadOffsets);   // an empty sentence too (want >= 1)
     }
 }
 
-struct TagLds {
-    int32_t z[kTagWaves][1024];   // kTagMaxZ scores per token, one buffer per wave
+constexpr uint32_t kCharMask = 0x1FFFFFu;   // a cps word: scored scalar value | CharacterType << 24
+constexpr int kWin = 128, kWinBack = 32;     // the text window of a step in LDS: positions base - 32 .. base + 95
+constexpr int kTagPass = 32;                 // tokens with a model the fast path takes per pass (a step has at most 64)
+
+struct TagWaveLds {
+    union {
+        int32_t z[kTagMaxZ];                 // the whole-wave routine: one token's scores
+        struct {
+            int32_t zt[kTagPass][kTagFastZ + 1];   // the fast path: what the n-grams add to every token of the pass (rows padded against bank conflicts)
+            uint32_t tok[kTagPass][4];             // per token: first record, position in the step | zlen << 8 | n_slots << 16, bias offset, packed slots
+            uint32_t pref[kTagPass + 1];           // records before token t (exclusive prefix of the counts)
+        } f;
+    };
+    uint32_t txt[kWin];                      // cps words of the window, 0 outside the sentence
 };
+struct TagLds { TagWaveLds w[kTagWaves]; };
+static_assert(sizeof(TagLds) <= 20 * 1024, "8 workgroups per CU");
 
-__device__ __forceinline__ uint32_t type_of(const uint32_t* cinfo, uint32_t cp) {
-    return cp < 0x10000u ? cinfo[cp] >> 16 : char_type(cp);   // cp is already the scored char: its image is itself
-}
-
-constexpr uint32_t kLaneZ = 16;   // tag scores a token may have to be handled by ONE lane (z interleaved in the wave's LDS buffer)
-
-// the tag model (index + 1) whose token is cps[s0 .. e], or 0: one lane on its own
-__device__ __forceinline__ uint32_t find_tag_model(const TagParams& P, const uint32_t* cps, int64_t s0, int64_t e) {
-    const int64_t len = e - s0 + 1;
+// the tag model (index + 1) whose token is the chars [s0, e] of the sentence, or 0: one lane on its own.  The chars come
+// from the step's LDS window when the token starts inside it (nearly always), a token of up to 4 BMP chars is verified
+// from its table slot alone.
+__device__ __forceinline__ uint32_t find_tag_model(const TagParams& P, const uint32_t* cps, const uint32_t* txt, int base, int s0, int e) {
+    const int len = e - s0 + 1;
+    const bool in_win = s0 >= base - kWinBack;
+    auto ch = [&](int q) { return (in_win ? txt[q - base + kWinBack] : cps[q]) & kCharMask; };
     uint32_t h = 0x811C9DC5u;
-    for (int64_t j = 0; j < len; ++j) h = (h ^ cps[s0 + j]) * 0x01000193u;
+    for (int j = 0; j < len; ++j) h = (h ^ ch(s0 + j)) * 0x01000193u;
     h ^= h >> 15;
     h *= kHashMulLo;
     const uint32_t tok_mask = (1u << P.tok_bits) - 1u;
     uint32_t slot = h >> (32 - P.tok_bits);
     for (;;) {
-        const uint32_t cur = P.tok_tab[slot];
-        if (cur == 0) return 0;
-        const uint32_t* mr = P.models + size_t(cur - 1) * 12;
-        if (int64_t(mr[1]) == len) {
+        const uint4 t = reinterpret_cast<const uint4*>(P.tok_tab)[slot];
+        if (t.x == 0) return 0;
+        if (int(t.y & 0x7FFFFFFFu) == len) {
             bool same = true;
-            for (int64_t j = 0; j < len && same; ++j) same = P.syms[mr[0] + j] == cps[s0 + j];
-            if (same) return cur;
+            if (t.y & 0x80000000u) {
+                const uint32_t sy[2] = {t.z, t.w};
+                for (int j = 0; j < len && same; ++j) same = ((sy[j >> 1] >> (16 * (j & 1))) & 0xFFFFu) == ch(s0 + j);
+            } else {
+                const uint32_t* mr = P.models + size_t(t.x - 1) * 12;
+                for (int j = 0; j < len && same; ++j) same = P.syms[mr[0] + j] == ch(s0 + j);
+            }
+            if (same) return t.x;
         }
         slot = (slot + 1) & tok_mask;
     }
 }
 
-// One token handled by one lane: z lives at zl[i * 64] (i < kLaneZ), so that the lanes of a wave never share a bank.
-__device__ __forceinline__ void tag_token_by_lane(const TagParams& P, const uint32_t* cps, int64_t n, int64_t e, uint64_t g0, uint32_t model,
-                                                  volatile int32_t* zl) {
-    const uint32_t* mr = P.models + size_t(model - 1) * 12;
-    const uint32_t zlen = mr[7];
-    for (uint32_t i = 0; i < zlen; ++i) zl[i * 64] = P.weights[mr[6] + i];
-    for (int kind = 0; kind < 2; ++kind) {
-        if (kind == 0 ? !P.use_char : !P.use_type) continue;
-        const uint32_t first = mr[kind == 0 ? 2 : 4], count = mr[kind == 0 ? 3 : 5];
-        for (uint32_t q = 0; q < count; ++q) {
-            const uint32_t* nr = P.ngrams + size_t(first + q) * 4;
-            const int64_t glen = int64_t(nr[1] & 0xFFFFFFu), rel = int64_t(nr[1] >> 24);
-            const int64_t endp = e + rel + 1, beg = endp - glen;
-            if (beg < 0 || endp > n) continue;
-            bool same = true;
-            for (int64_t j = 0; j < glen && same; ++j) {
-                const uint32_t c = cps[beg + j];
-                same = P.syms[nr[0] + j] == (kind == 0 ? c : type_of(P.cinfo, c));
-            }
-            if (!same) continue;
-            const uint32_t wl = nr[3] < zlen ? nr[3] : zlen;   // zip: the shorter of the two (predictor.rs:82-89)
-            for (uint32_t i = 0; i < wl; ++i) zl[i * 64] = int32_t(uint32_t(zl[i * 64]) + uint32_t(P.weights[nr[2] + i]));
-        }
-    }
-    const uint32_t n_slots = mr[9] < P.n_tags ? mr[9] : P.n_tags;
-    for (uint32_t j = 0; j < n_slots; ++j) {   // argmax per slot (TagPredictor::predict, predictor.rs:286-304)
-        const uint32_t cnt = P.slots[size_t(mr[8] + j) * 2], off = P.slots[size_t(mr[8] + j) * 2 + 1];
-        int32_t tag = cnt == 1 ? 0 : -1;
-        if (cnt >= 2) {
-            int32_t best = INT32_MIN;
-            tag = 0;
-            for (uint32_t c = 0; c < cnt && off + c < zlen; ++c) {
-                const int32_t v = zl[(off + c) * 64];
-                if (v > best) { best = v; tag = int32_t(c); }
-            }
-        }
-        P.tags[(g0 + uint64_t(e)) * P.n_tags + j] = tag;
-    }
-}
-
-// One token handled by the whole wave (tokens with more than kLaneZ tag scores): lanes over z entries, n-gram chars, slots.
+// One token handled by the whole wave (models outside the record form): lanes over z entries, n-gram chars, slots.
 __device__ __forceinline__ void tag_token_by_wave(const TagParams& P, const uint32_t* cps, int64_t n, int64_t e, uint64_t g0, uint32_t model,
                                                   volatile int32_t* z, int lane) {
     const uint32_t* mr = P.models + size_t(model - 1) * 12;
@@ -160,7 +165,7 @@ __device__ __forceinline__ void tag_token_by_wave(const TagParams& P, const uint
                 bool ne = false;
                 if (j < glen) {
                     const uint32_t c = cps[beg + j];
-                    ne = P.syms[nr[0] + j] != (kind == 0 ? c : type_of(P.cinfo, c));
+                    ne = P.syms[nr[0] + j] != (kind == 0 ? (c & kCharMask) : (c >> 24));
                 }
                 if (__ballot(ne) != 0) { same = false; break; }
             }
@@ -187,42 +192,176 @@ __device__ __forceinline__ void tag_token_by_wave(const TagParams& P, const uint
     __builtin_amdgcn_wave_barrier();
 }
 
-// One wave per sentence, 64 chars per step.  Every lane whose char ends a token (its label is WordBoundary, or it is the
-// last char) owns that token: it finds the token's start from the boundary masks of the step, looks the surface up and,
-// when the tag model has at most kLaneZ scores (the usual case: a few candidates per slot), scores and tags the token
-// on its own -- up to 64 tokens in flight per wave instead of one.  The rare bigger models go through the whole-wave
-// routine afterwards, one token at a time.
-__global__ __launch_bounds__(kTagThreads) void tag_tokens_kernel(const TagParams P) {
-    __shared__ TagLds L;
+__global__ __launch_bounds__(kTagThreads, 6) void tag_tokens_kernel(const TagParams P) {
+    __shared__ TagLds LDS;
     const int lane = threadIdx.x & 63;
-    volatile int32_t* z = L.z[threadIdx.x >> 6];
+    TagWaveLds& L = LDS.w[threadIdx.x >> 6];
+    volatile int32_t* z = L.z;
     const uint64_t wave = uint64_t(blockIdx.x) * kTagWaves + (threadIdx.x >> 6);
     const uint64_t n_waves = uint64_t(gridDim.x) * kTagWaves;
+    const uint32_t nt = P.n_tags;
     for (uint64_t si = wave; si < P.n_sent; si += n_waves) {
         const uint64_t g0 = P.ooff[si] + si;                     // flat index of the sentence's first char
         if (P.ooff[si + 1] < P.ooff[si] || P.ooff[si + 1] + si + 1 > P.total_chars) continue;   // reported by decode_chars_kernel
-        const int64_t n = int64_t(P.ooff[si + 1] - P.ooff[si]) + 1;  // chars
+        if (P.ooff[si + 1] - P.ooff[si] >= 0x7FFFFF00ull) continue;   // (a sentence of 2^31 chars: not in this kernel's index width)
+        const int n = int(P.ooff[si + 1] - P.ooff[si]) + 1;  // chars
         const uint32_t* cps = P.cps + g0;
         const uint8_t* lab = P.labels + P.ooff[si];              // n - 1 labels
-        int64_t start = 0;          // where the token that is open at the beginning of this step started
+        int start = 0;              // where the token that is open at the beginning of this step started
         bool have_start = true;     // ... and no Unknown boundary has been seen inside it (predictor.rs:566-567)
-        for (int64_t base = 0; base < n; base += 64) {
-            const int64_t p = base + lane;
+        for (int base = 0; base < n; base += 64) {
+            const int p = base + lane;
             const uint32_t b = p < n ? (p == n - 1 ? 1u : uint32_t(lab[p])) : 0u;
+            // the text window of this step
+            for (int w = lane; w < kWin; w += 64) {
+                const int q = base - kWinBack + w;
+                L.txt[w] = (q >= 0 && q < n) ? cps[q] : 0u;
+            }
             const uint64_t ends = __ballot(b == 1u), unk = __ballot(b == 2u);
-            // this lane's token, if its char ends one: [s0, p], valid when no Unknown lies inside
+            __builtin_amdgcn_wave_barrier();
+            // ---- (1) this lane's token, if its char ends one: [s0, p], valid when no Unknown lies inside
             const uint64_t below_me = (uint64_t(1) << lane) - 1;
             const uint64_t prev_ends = ends & below_me;
             const int prev = prev_ends ? 63 - __clzll((long long)prev_ends) : -1;
-            const int64_t s0 = prev >= 0 ? base + prev + 1 : start;
+            const int s0 = prev >= 0 ? base + prev + 1 : start;
             const uint64_t after_prev = prev >= 0 ? ~((uint64_t(2) << prev) - 1) : ~uint64_t(0);
             const bool valid = b == 1u && (unk & below_me & after_prev) == 0 && (prev >= 0 || have_start);
-            uint32_t model = valid ? find_tag_model(P, cps, s0, p) : 0u;
+            const uint32_t model = valid ? find_tag_model(P, cps, L.txt, base, s0, p) : 0u;
             if (valid && P.tok_model) P.tok_model[g0 + uint64_t(p)] = int32_t(model);   // 0: no tag model for this surface
-            const bool big = model != 0 && (P.models + size_t(model - 1) * 12)[7] > kLaneZ;
-            if (model != 0 && !big) tag_token_by_lane(P, cps, n, p, g0, model, z + lane);
-            uint64_t todo = __ballot(big);
-            __builtin_amdgcn_wave_barrier();
+            // the model record: first record, counts, bias offset, zlen, slots (one trip: three 16-byte loads)
+            uint32_t m_first = 0, m_count = 0, m_zlen = 0, m_bias = 0, m_pslots = 0, m_nslots = 0;
+            bool fast = false;
+            if (model != 0) {
+                const uint4* mr = reinterpret_cast<const uint4*>(P.models + size_t(model - 1) * 12);
+                const uint4 r0 = mr[0], r1 = mr[1], r2 = mr[2];   // dwords 0..3, 4..7, 8..11
+                fast = (r2.z & 1u) != 0;
+                m_first = r0.z; m_count = r0.w + r1.y; m_bias = r1.z; m_zlen = r1.w; m_pslots = r2.w;
+                m_nslots = r2.y < nt ? r2.y : nt;
+            }
+            const uint64_t fmask = __ballot(fast);
+            const uint32_t n_fast = uint32_t(__popcll(fmask));
+            const uint32_t rank = uint32_t(__popcll(fmask & below_me));
+            // ---- (2) the tokens whose model fits the record form, kTagPass at a time
+            for (uint32_t t0 = 0; t0 < n_fast; t0 += kTagPass) {
+                const bool mine = fast && rank >= t0 && rank < t0 + kTagPass;
+                const uint32_t t_me = rank - t0;
+                const uint32_t n_pass = n_fast - t0 < uint32_t(kTagPass) ? n_fast - t0 : uint32_t(kTagPass);
+                // exclusive prefix of the record counts over the pass's tokens (wave scan; the other lanes add 0)
+                uint32_t incl = mine ? m_count : 0u;
+#pragma unroll
+                for (int d = 1; d < 64; d <<= 1) {
+                    const uint32_t up = uint32_t(__shfl_up(int(incl), d));
+                    if (lane >= d) incl += up;
+                }
+                const uint32_t total = uint32_t(__shfl(int(incl), 63));
+                if (mine) {
+                    L.f.tok[t_me][0] = m_first; L.f.tok[t_me][1] = uint32_t(p - base) | (m_zlen << 8) | (m_nslots << 16);
+                    L.f.tok[t_me][2] = m_bias; L.f.tok[t_me][3] = m_pslots;
+                    L.f.pref[t_me] = incl - m_count;
+                }
+                if (lane == 0) L.f.pref[n_pass] = total;
+                for (int q = lane; q < kTagPass * (int(kTagFastZ) + 1); q += 64) (&L.f.zt[0][0])[q] = 0;
+                __builtin_amdgcn_wave_barrier();
+                // rounds of 128 (token, record) pairs, two per lane: every record load of a round is in flight together
+                for (uint32_t r0 = 0; r0 < total; r0 += 128) {
+                    uint32_t tk[2], hdr[2], woff[2];
+                    bool same[2];
+                    uint4 ra[2], rb[2];
+#pragma unroll
+                    for (int u = 0; u < 2; ++u) {
+                        const uint32_t pi = r0 + uint32_t(u) * 64u + uint32_t(lane);
+                        const bool have = pi < total;
+                        uint32_t t = 0;
+                        if (have) {   // the token of this pair: the last t with pref[t] <= pi
+                            uint32_t lo = 0, hi = n_pass;   // pref[lo] <= pi < pref[hi]
+                            while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (L.f.pref[mid] <= pi) lo = mid; else hi = mid; }
+                            t = lo;
+                        }
+                        tk[u] = t;
+                        same[u] = have;
+                        const uint32_t ri = have ? L.f.tok[t][0] + (pi - L.f.pref[t]) : 0u;
+                        ra[u] = have ? reinterpret_cast<const uint4*>(P.nrec)[size_t(ri) * 2] : make_uint4(0, 0, 0, 0);
+                        rb[u] = have ? reinterpret_cast<const uint4*>(P.nrec)[size_t(ri) * 2 + 1] : make_uint4(0, 0, 0, 0);
+                    }
+                    // the longest n-gram of this round bounds the compare loops (wave-uniform: no lane runs 12 steps for 3-char n-grams)
+                    uint32_t gmax = (ra[0].x & 0xFFu) > (ra[1].x & 0xFFu) ? (ra[0].x & 0xFFu) : (ra[1].x & 0xFFu);
+#pragma unroll
+                    for (int d = 32; d >= 1; d >>= 1) { const uint32_t o = uint32_t(__shfl_xor(int(gmax), d)); gmax = o > gmax ? o : gmax; }
+                    gmax = wave_uniform(gmax < kTagFastSyms ? gmax : kTagFastSyms);
+#pragma unroll
+                    for (int u = 0; u < 2; ++u) {
+                        const uint32_t glen = ra[u].x & 0xFFu, rel = (ra[u].x >> 8) & 0xFFu, kind = (ra[u].x >> 16) & 1u;
+                        const int e = base + int(same[u] ? L.f.tok[tk[u]][1] & 0xFFu : 0u);
+                        const int endp = e + int(rel) + 1, beg = endp - int(glen);
+                        bool ok = same[u] && glen != 0 && beg >= 0 && endp <= n && (kind == 0 ? P.use_char != 0 : P.use_type != 0);
+                        // beg >= base - 11 and endp <= base + 72 (glen <= 12, rel <= the window <= 8): inside the LDS window
+                        // the record's symbols as a 192-bit shift register: the next one is always the low 16 bits
+                        uint32_t s0w = ra[u].z, s1w = ra[u].w, s2w = rb[u].x, s3w = rb[u].y, s4w = rb[u].z, s5w = rb[u].w;
+                        const int wbeg = beg - base + kWinBack;
+                        for (uint32_t j = 0; j < gmax; ++j) {
+                            if (j < glen && ok) {
+                                const uint32_t c = L.txt[(wbeg + int(j)) & (kWin - 1)];
+                                ok = (s0w & 0xFFFFu) == (kind == 0 ? (c & kCharMask) : (c >> 24));
+                            }
+                            s0w = (s0w >> 16) | (s1w << 16); s1w = (s1w >> 16) | (s2w << 16); s2w = (s2w >> 16) | (s3w << 16);
+                            s3w = (s3w >> 16) | (s4w << 16); s4w = (s4w >> 16) | (s5w << 16); s5w >>= 16;
+                        }
+                        same[u] = ok;
+                        hdr[u] = ra[u].x; woff[u] = ra[u].y;
+                    }
+                    if (__ballot(same[0] || same[1]) != 0) {   // the weights of the matches: independent loads again, then LDS adds
+#pragma unroll
+                        for (int u = 0; u < 2; ++u) {
+                            if (same[u]) {
+                                const uint32_t zlen = (L.f.tok[tk[u]][1] >> 8) & 0xFFu;
+                                const uint32_t wl = (hdr[u] >> 24) < zlen ? (hdr[u] >> 24) : zlen;   // zip: the shorter of the two (predictor.rs:82-89)
+                                for (uint32_t i0 = 0; i0 < wl; i0 += 4) {   // four independent loads at a time (matches are few; registers are not)
+                                    int32_t w[4];
+#pragma unroll
+                                    for (uint32_t i = 0; i < 4; ++i) w[i] = i0 + i < wl ? P.weights[woff[u] + i0 + i] : 0;
+#pragma unroll
+                                    for (uint32_t i = 0; i < 4; ++i)
+                                        if (i0 + i < wl) atomicAdd(&L.f.zt[tk[u]][i0 + i], w[i]);   // several n-grams of one token may match in one round
+                                }
+                            }
+                        }
+                    }
+                }
+                __builtin_amdgcn_wave_barrier();
+                // ---- (3) argmax per (token, slot) over bias + what the n-grams added (TagPredictor::predict, predictor.rs:286-304)
+                for (uint32_t a0 = 0; a0 < n_pass * nt; a0 += 64) {
+                    const uint32_t a = a0 + uint32_t(lane);
+                    if (a < n_pass * nt) {
+                        const uint32_t t = a / nt, j = a - t * nt;
+                        const uint32_t info = L.f.tok[t][1], zlen = (info >> 8) & 0xFFu, n_slots = info >> 16;
+                        if (j < n_slots) {
+                            const uint32_t ps = L.f.tok[t][3] >> (9 * j), cnt = ps & 31u, off = (ps >> 5) & 15u;
+                            int32_t tag = cnt == 1 ? 0 : -1;
+                            if (cnt >= 2) {
+                                int32_t best = INT32_MIN;
+                                tag = 0;
+                                const uint32_t lim = off + cnt < zlen ? cnt : zlen - off;   // candidates that have a score (off < zlen for a slot of >= 2)
+                                for (uint32_t c0 = 0; c0 < lim; c0 += 4) {
+                                    int32_t bias[4];
+#pragma unroll
+                                    for (uint32_t c = 0; c < 4; ++c) bias[c] = c0 + c < lim ? P.weights[L.f.tok[t][2] + off + c0 + c] : 0;
+#pragma unroll
+                                    for (uint32_t c = 0; c < 4; ++c) {
+                                        if (c0 + c < lim) {
+                                            const int32_t v = int32_t(uint32_t(bias[c]) + uint32_t(L.f.zt[t][off + c0 + c]));
+                                            if (v > best) { best = v; tag = int32_t(c0 + c); }
+                                        }
+                                    }
+                                }
+                            }
+                            P.tags[(g0 + uint64_t(uint32_t(base) + (info & 0xFFu))) * nt + j] = tag;
+                        }
+                    }
+                }
+                __builtin_amdgcn_wave_barrier();
+            }
+            // ---- the models outside the record form: the whole wave, one token at a time
+            uint64_t todo = __ballot(model != 0 && !fast);
             while (todo) {   // wave-uniform
                 const int k = __ffsll((long long)todo) - 1;
                 todo &= todo - 1;
@@ -237,6 +376,7 @@ __global__ __launch_bounds__(kTagThreads) void tag_tokens_kernel(const TagParams
             } else if (unk) {
                 have_start = false;
             }
+            __builtin_amdgcn_wave_barrier();   // the window is rewritten by the next step
         }
     }
 }

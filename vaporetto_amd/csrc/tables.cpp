@@ -680,7 +680,7 @@ HostTagTables build_tag_tables(const ModelData& m, bool use_char, bool use_type)
     t.use_char = use_char; t.use_type = use_type;
     t.n_models = uint32_t(m.tag_models.size());
     t.tok_bits = bits_for(m.tag_models.size());
-    t.tok_tab.assign(size_t(1) << t.tok_bits, 0);
+    t.tok_tab.assign(size_t(4) << t.tok_bits, 0);
     const uint32_t mask = (1u << t.tok_bits) - 1;
     for (uint32_t mi = 0; mi < m.tag_models.size(); ++mi) {
         const TagModelRecord& tm = m.tag_models[mi];
@@ -688,24 +688,37 @@ HostTagTables build_tag_tables(const ModelData& m, bool use_char, bool use_type)
         uint32_t rec[12] = {0};
         rec[0] = uint32_t(t.syms.size()); rec[1] = uint32_t(tm.token.size());
         t.syms.insert(t.syms.end(), tm.token.begin(), tm.token.end());
-        auto add_ngrams = [&](const std::vector<TagNgramRecord>& list, uint32_t* first, uint32_t* count) {
+        bool all_compact = true;
+        auto add_ngrams = [&](const std::vector<TagNgramRecord>& list, uint32_t kind, uint32_t* first, uint32_t* count) {
             *first = uint32_t(t.ngrams.size() / 4);
             for (const TagNgramRecord& d : list) {
                 const uint32_t so = uint32_t(t.syms.size());
                 t.syms.insert(t.syms.end(), d.ngram.begin(), d.ngram.end());
+                bool compact = d.ngram.size() <= kTagFastSyms;
+                for (Sym c : d.ngram) compact = compact && c < 0xFFFFu;
                 for (const TagWeightRecord& w : d.weights) {
                     if (d.ngram.size() >= (size_t(1) << 24)) throw ModelError("InvalidModelError: tag n-gram too long");
                     t.ngrams.push_back(so);
                     t.ngrams.push_back(uint32_t(d.ngram.size()) | (uint32_t(w.rel_position) << 24));
                     t.ngrams.push_back(uint32_t(t.weights.size()));
                     t.ngrams.push_back(uint32_t(w.weights.size()));
+                    uint32_t r[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+                    r[0] = (compact ? uint32_t(d.ngram.size()) : 0u) | (uint32_t(w.rel_position) << 8) | (kind << 16) | (compact ? 1u << 17 : 0u) |
+                           (uint32_t(std::min<size_t>(w.weights.size(), 255)) << 24);
+                    r[1] = uint32_t(t.weights.size());
+                    if (compact)
+                        for (size_t j = 0; j < d.ngram.size(); ++j) r[2 + j / 2] |= d.ngram[j] << (16 * (j & 1));
+                    t.nrec.insert(t.nrec.end(), r, r + 8);
+                    all_compact = all_compact && compact;
                     t.weights.insert(t.weights.end(), w.weights.begin(), w.weights.end());
                 }
             }
             *count = uint32_t(t.ngrams.size() / 4) - *first;
         };
-        add_ngrams(tm.char_ngrams, &rec[2], &rec[3]);
-        add_ngrams(tm.type_ngrams, &rec[4], &rec[5]);
+        add_ngrams(tm.char_ngrams, 0u, &rec[2], &rec[3]);
+        add_ngrams(tm.type_ngrams, 1u, &rec[4], &rec[5]);
+        // the fast path walks char and type entries as one run of records
+        const bool fast_model = all_compact && rec[4] == rec[2] + rec[3] && tm.bias.size() <= kTagFastZ && tm.tags.size() <= 3;
         rec[6] = uint32_t(t.weights.size()); rec[7] = uint32_t(tm.bias.size());
         t.weights.insert(t.weights.end(), tm.bias.begin(), tm.bias.end());
         if (tm.bias.size() > kTagMaxZ) throw ModelError("InvalidModelError: more than 1024 tag scores per token are not supported");
@@ -725,20 +738,34 @@ HostTagTables build_tag_tables(const ModelData& m, bool use_char, bool use_type)
                 }
             }
         }
+        if (fast_model) {
+            rec[10] = 1u;
+            for (size_t j = 0; j < tm.tags.size(); ++j)
+                rec[11] |= (t.slots[size_t(rec[8] + j) * 2] | (t.slots[size_t(rec[8] + j) * 2 + 1] << 5)) << (9 * j);   // <= 16 candidates, offset <= 15
+        }
         t.models.insert(t.models.end(), rec, rec + 12);
         // token table: a repeated token keeps its slot and takes the later model
         uint32_t b = tag_token_hash(tm.token.data(), tm.token.size()) >> (32 - t.tok_bits);
         for (;;) {
-            const uint32_t cur = t.tok_tab[b];
-            if (cur == 0) { t.tok_tab[b] = mi + 1; break; }
-            const uint32_t* cr = &t.models[size_t(cur - 1) * 12];
-            if (cr[1] == tm.token.size() && std::equal(tm.token.begin(), tm.token.end(), t.syms.begin() + cr[0])) { t.tok_tab[b] = mi + 1; break; }
-            b = (b + 1) & mask;
+            uint32_t* e = &t.tok_tab[size_t(b) * 4];
+            if (e[0] != 0) {
+                const uint32_t* cr = &t.models[size_t(e[0] - 1) * 12];
+                if (!(cr[1] == tm.token.size() && std::equal(tm.token.begin(), tm.token.end(), t.syms.begin() + cr[0]))) { b = (b + 1) & mask; continue; }
+            }
+            e[0] = mi + 1;
+            bool inl = tm.token.size() <= 4;
+            for (Sym c : tm.token) inl = inl && c < 0xFFFFu;
+            e[1] = uint32_t(tm.token.size()) | (inl ? 0x80000000u : 0u);
+            e[2] = e[3] = 0;
+            if (inl)
+                for (size_t j = 0; j < tm.token.size(); ++j) e[2 + j / 2] |= tm.token[j] << (16 * (j & 1));
+            break;
         }
     }
     if (t.syms.empty()) t.syms.push_back(0);
     if (t.weights.empty()) t.weights.push_back(0);
     if (t.ngrams.empty()) t.ngrams.assign(4, 0);
+    if (t.nrec.empty()) t.nrec.assign(8, 0);
     if (t.slots.empty()) t.slots.assign(2, 0);
     if (t.slot_str.empty()) t.slot_str.push_back(0);
     t.str_off.push_back(uint32_t(t.str_bytes.size()));   // the end of the last string

@@ -46,11 +46,19 @@ struct HostPackedTable {
 };
 
 // Tag prediction tables (Predictor::predict_tags, predictor.rs:546-637), see kernels_tags.hip.
-//   tok_tab   open addressing over token surfaces: slot = model index + 1 (0 = empty); the LAST model of a repeated
+//   tok_tab   open addressing over token surfaces, 4 dwords per slot: model index + 1 (0 = empty), len | inline << 31,
+//             sym0 | sym1 << 16, sym2 | sym3 << 16 -- a token of at most 4 symbols below 0xFFFF is verified from the slot
+//             itself (inline), a longer one against `syms` through its model record; the LAST model of a repeated
 //             token wins, like HashMap::insert in predictor.rs:466-478
 //   models    12 dwords per tag model: sym_off, sym_len, char-ngram first/count, type-ngram first/count, bias_off, zlen,
 //             slot first/count, 0, 0
 //   ngrams    4 dwords per (tag n-gram, rel_position): sym_off, len | rel << 24, w_off, wlen
+//   nrec      the same entries again as self-contained 32-byte records for the kernel's fast path (a lane checks a whole
+//             n-gram from ONE record and the text window in LDS): dword 0 = len | rel << 8 | kind << 16 (0 char, 1 type) |
+//             compact << 17 | min(wlen, 255) << 24, dword 1 = w_off, dwords 2..7 = up to 12 symbols, 16 bits each; compact =
+//             the n-gram has at most 12 symbols, all below 0xFFFF.  models[10] bit 0 = every entry of the model is compact,
+//             its char and type entries are adjacent, it has at most 16 scores and at most 3 slots: the fast path may take its
+//             tokens; models[11] then packs the slots: (candidates | score offset << 5) << (9 * slot).
 //   slots     2 dwords per tag slot: candidate count, offset of its scores in z (slots with >= 2 candidates)
 //   slot_str  per tag slot: index of its first candidate in str_off; str_off[k] .. str_off[k+1] = the bytes of candidate
 //             string k in str_bytes, ALREADY escaped the way Sentence::write_tokenized_text writes a tag (sentence.rs:871-880)
@@ -58,11 +66,13 @@ struct HostTagTables {
     bool present = false;
     uint32_t n_tags = 0, n_models = 0, tok_bits = 4, max_zlen = 0;
     bool use_char = false, use_type = false;   // the scorers exist (char_scorer.rs:98-100, type_scorer.rs:109-111)
-    std::vector<uint32_t> tok_tab, models, ngrams, syms, slots, slot_str, str_off;
+    std::vector<uint32_t> tok_tab, models, ngrams, nrec, syms, slots, slot_str, str_off;
     std::vector<uint8_t> str_bytes;
     std::vector<int32_t> weights;
 };
 constexpr uint32_t kTagMaxZ = 1024;   // tag scores per token the kernel keeps in LDS
+constexpr uint32_t kTagFastZ = 16;    // ... per token on the fast path
+constexpr uint32_t kTagFastSyms = 12; // symbols of an n-gram a 32-byte record holds
 
 enum TypeKind : int { kTypeNone = 0, kTypeWindowTable = 1, kTypePatternTable = 2 };
 
