@@ -234,7 +234,10 @@ vpt_status vpt_fill_tags_batch_flags(const vpt_predictor *p, const uint8_t *utf8
 /* Device-resident variant of vpt_fill_tags_batch: all pointers are device pointers, asynchronous on `hip_stream`
  * (NULL = default stream).  d_labels as written by vpt_predict_batch_device (possibly edited by the caller's own
  * kernels); d_tags_out must hold (total_boundaries + n_sentences) * n_tags int32.  The workspace keeps the decoded
- * scalar values (4 bytes per char) between the two kernels; flags as set by vpt_batch_set_flags (fullwidth only). */
+ * scalar values (4 bytes per char) between the two kernels; flags as set by vpt_batch_set_flags (fullwidth only).
+ * When the previous call on this workspace was vpt_predict_batch_device for the SAME buffers, sizes, flags and stream (as
+ * Sentence::fill_tags follows Predictor::predict on the same sentence, predictor.rs:542), the chars that call decoded are
+ * reused and the decode kernel is skipped: do not rewrite d_utf8 in place between the two calls. */
 vpt_status vpt_fill_tags_batch_device(const vpt_predictor *p, vpt_batch *b, const uint8_t *d_utf8,
                                       const uint64_t *d_byte_offsets, const uint64_t *d_out_offsets,
                                       size_t n_sentences, uint64_t total_boundaries, const uint8_t *d_labels,

@@ -137,6 +137,7 @@ template <typename T, typename V> static inline void __hip_atomic_store(T* p, V 
 
 // the gfx950 builtins the kernels use
 #define __builtin_amdgcn_mov_dpp(src, ctrl, rm, bm, bc) int(::hipemu::dpp(0xDEADBEEFu, uint32_t(src), (ctrl), (rm), (bm), (bc)))
+#define __builtin_amdgcn_readlane(v, l) int(::hipemu::shfl_xor(uint32_t(v), unsigned(l) ^ ::hipemu::lane()))
 #define __builtin_amdgcn_update_dpp(old, src, ctrl, rm, bm, bc) int(::hipemu::dpp(uint32_t(old), uint32_t(src), (ctrl), (rm), (bm), (bc)))
 #define __builtin_amdgcn_readfirstlane(x) int(::hipemu::readfirstlane(uint32_t(x)))
 #define __builtin_amdgcn_wave_barrier() ::hipemu::wave_sync()

@@ -737,6 +737,27 @@ def test_device_resident_predict_then_fill_tags():
     batch.sync()
     assert np.array_equal(d_scores.get(nb), scores) and np.array_equal(d_labels.get(nb), labels)
     assert np.array_equal(d_tags.get((nb + S) * nt).reshape(nb + S, nt), want)
+    # fill_tags after predict on the same workspace reuses the chars predict decoded; a fill_tags on its own (another
+    # workspace: it decodes itself), through KyteaFullwidthFilter too, with mixed-width text, must give the same tags
+    mixed = ["ab1" + t + "Ｚ９" for t in texts[:500]] + texts[500:1500]
+    utf8, boff = api.pack_texts([t.encode("utf-8") for t in mixed])
+    for fw in (False, True):
+        _, labels, ooff = pred.predict_packed(utf8, boff, fullwidth=fw)
+        want = pred.fill_tags_packed(utf8, boff, ooff, labels, fullwidth=fw)
+        nb, S = int(ooff[-1]), len(mixed)
+        d_text = devmem.put(np.concatenate([utf8, np.zeros(16, np.uint8)]))
+        d_boff, d_ooff = devmem.put(boff.astype(np.uint64)), devmem.put(ooff.astype(np.uint64))
+        d_scores, d_labels = devmem.zeros(nb + 1, np.int32), devmem.zeros(nb + 1, np.uint8)
+        got = []
+        for reuse in (True, False):
+            d_tags = devmem.zeros((nb + S) * nt + 1, np.int32)
+            b1, b2 = api.DeviceBatch(pred), api.DeviceBatch(pred)
+            b1.set_fullwidth(fw); b2.set_fullwidth(fw)
+            b1.predict(d_text.ptr, d_boff.ptr, d_ooff.ptr, S, nb, int(np.max(np.diff(boff.astype(np.int64)))), d_scores.ptr, d_labels.ptr, devmem.stream())
+            (b1 if reuse else b2).fill_tags(d_text.ptr, d_boff.ptr, d_ooff.ptr, S, nb, d_labels.ptr, d_tags.ptr, devmem.stream())
+            b1.sync(); b2.sync()
+            got.append(d_tags.get((nb + S) * nt).reshape(nb + S, nt))
+        assert np.array_equal(got[0], want) and np.array_equal(got[1], want), fw
 
 
 def test_fill_tags_with_offsets_that_do_not_match_the_text():

@@ -46,7 +46,7 @@ enum Section : int {
     kSecTShort, kSecTUni, kSecTEdges, kSecTWdata,              // general type tables (type_kind == pattern tables)
     kSecPUni, kSecPBi, kSecPTri, kSecPDeep, kSecPXrows, kSecPTrow, kSecPCpid,   // packed tables: contiguous, addressed from kSecPUni
     kSecTypeTable, kSecCtype, kSecCinfo, kSecCid,
-    kSecTagTokTab, kSecTagModels, kSecTagNgrams, kSecTagNrec, kSecTagSyms, kSecTagSlots, kSecTagWeights, kSecTagSlotStr, kSecTagStrOff, kSecTagStrBytes,
+    kSecTagTokTab, kSecTagModels, kSecTagMfilt, kSecTagNgrams, kSecTagNrec, kSecTagSyms, kSecTagSlots, kSecTagWeights, kSecTagSlotStr, kSecTagStrOff, kSecTagStrBytes,
     kSectionCount
 };
 struct TableGeom {
@@ -54,7 +54,7 @@ struct TableGeom {
     int32_t window, lo[3], len[3];
 };
 constexpr char kCompiledMagic[16] = "VaporettoHIP-C\x01";   // 15 chars + NUL
-constexpr uint32_t kCompiledVersion = 4;                    // bump whenever layout.h or a kernel's reading of it changes
+constexpr uint32_t kCompiledVersion = 5;                    // bump whenever layout.h or a kernel's reading of it changes
 struct PredictorMeta {                                      // plain data: written and read as is (little-endian hosts)
     char magic[16];
     uint32_t version, meta_bytes;
@@ -119,6 +119,8 @@ struct vpt_batch {
     uint64_t* d_prof = nullptr;        // 8 per-phase cycle counters (only with VPT_PROFILE_PHASES set)
     unsigned char* d_scratch = nullptr; size_t scratch_bytes = 0;
     uint32_t* d_cps = nullptr; size_t cps_cap = 0;   // decoded scalar values for vpt_fill_tags_batch_device
+    // the batch whose chars d_cps holds because the scoring kernel of a predict call on this workspace wrote them (all 0: none)
+    const void* cps_text = nullptr; const void* cps_ooff = nullptr; size_t cps_sentences = 0; uint64_t cps_boundaries = 0; unsigned cps_flags = 0;
     uint64_t max_chars = 0;            // caller's bound on chars per sentence (0 = unknown)
     unsigned flags = 0;                // VPT_FLAG_*
     // timing
@@ -153,7 +155,7 @@ struct vpt_batch {
 };
 
 struct DeviceTags {   // views into the arena
-    const uint32_t *tok_tab = nullptr, *models = nullptr, *ngrams = nullptr, *nrec = nullptr, *syms = nullptr, *slots = nullptr, *slot_str = nullptr, *str_off = nullptr;
+    const uint32_t *tok_tab = nullptr, *models = nullptr, *mfilt = nullptr, *ngrams = nullptr, *nrec = nullptr, *syms = nullptr, *slots = nullptr, *slot_str = nullptr, *str_off = nullptr;
     const uint8_t* str_bytes = nullptr;
     const int32_t* weights = nullptr;
     uint32_t n_models = 0, n_strings = 0;
@@ -398,6 +400,7 @@ void bind_predictor(vpt_predictor* p) {
     p->tag_use_char = m.tag_use_char != 0; p->tag_use_type = m.tag_use_type != 0;
     if (m.has_tags) {
         p->dtag.tok_tab = reinterpret_cast<const uint32_t*>(at(kSecTagTokTab)); p->dtag.models = reinterpret_cast<const uint32_t*>(at(kSecTagModels));
+        p->dtag.mfilt = reinterpret_cast<const uint32_t*>(at(kSecTagMfilt));
         p->dtag.ngrams = reinterpret_cast<const uint32_t*>(at(kSecTagNgrams)); p->dtag.nrec = reinterpret_cast<const uint32_t*>(at(kSecTagNrec));
         p->dtag.syms = reinterpret_cast<const uint32_t*>(at(kSecTagSyms));
         p->dtag.slots = reinterpret_cast<const uint32_t*>(at(kSecTagSlots)); p->dtag.weights = reinterpret_cast<const int32_t*>(at(kSecTagWeights));
@@ -494,7 +497,7 @@ vpt_status vpt_predictor_create(const uint8_t* model_bytes, size_t len, int pred
     put(kSecCtype, ctype); put(kSecCinfo, cinfo);
     if (packed_ok) put(kSecCid, cid);
     if (c.tags.present) {
-        put(kSecTagTokTab, c.tags.tok_tab); put(kSecTagModels, c.tags.models); put(kSecTagNgrams, c.tags.ngrams); put(kSecTagNrec, c.tags.nrec); put(kSecTagSyms, c.tags.syms);
+        put(kSecTagTokTab, c.tags.tok_tab); put(kSecTagModels, c.tags.models); put(kSecTagMfilt, c.tags.mfilt); put(kSecTagNgrams, c.tags.ngrams); put(kSecTagNrec, c.tags.nrec); put(kSecTagSyms, c.tags.syms);
         put(kSecTagSlots, c.tags.slots); put(kSecTagWeights, c.tags.weights); put(kSecTagSlotStr, c.tags.slot_str);
         put(kSecTagStrOff, c.tags.str_off); put(kSecTagStrBytes, c.tags.str_bytes);
     }
@@ -883,6 +886,17 @@ vpt_status vpt_predict_batch_device(const vpt_predictor* p, vpt_batch* b, const 
     P.scores = d_scores; P.labels = d_labels; P.status = b->d_ctrl; P.slow_list = b->d_slow_list; P.slow_count = b->d_ctrl + 1;
     P.scratch = b->d_scratch; P.scratch_stride = slab; P.scratch_cap = scratch_cap;
     P.prof = b->d_prof;
+    // A predictor with tag models: the specialised kernel also leaves the decoded chars behind, and a vpt_fill_tags_batch_device
+    // call for the same buffers on this workspace (Sentence::fill_tags follows Predictor::predict on the same sentence,
+    // predictor.rs:542) skips its own decode pass.
+    b->cps_text = nullptr;
+    if (p->has_tags && p->predict_tags && fast && !need_slow && !std::getenv("VPT_NO_CPS_FROM_PREDICT")) {
+        vpt_status st2 = grow(&b->d_cps, &b->cps_cap, size_t(total_boundaries + n_sentences) + 16);
+        if (st2 != VPT_OK) return st2;
+        P.cps_out = b->d_cps;
+        b->cps_text = d_utf8; b->cps_ooff = d_out_offsets; b->cps_sentences = n_sentences; b->cps_boundaries = total_boundaries;
+        b->cps_flags = b->flags & VPT_FLAG_KYTEA_FULLWIDTH;
+    }
     if (const char* dbg = std::getenv("VPT_DEBUG_ABLATE")) { P.debug = uint32_t(std::atoi(dbg)); P.ct.debug = P.debug; P.tt.debug = P.debug; }
 
     P.n_sent = n_sentences; P.tile_flat = uint32_t(tile_flat); P.n_tiles = n_tiles;
@@ -1095,9 +1109,14 @@ vpt_status vpt_fill_tags_batch_device(const vpt_predictor* p, vpt_batch* b, cons
     const uint32_t* cinfo = p->d_cinfo + ((b->flags & VPT_FLAG_KYTEA_FULLWIDTH) ? 65536 : 0);
     VPT_HIP(hipMemsetAsync(d_tags_out, 0xFF, size_t(total_c) * p->n_tags * sizeof(int32_t), stream));   // -1 = None
     VPT_HIP(hipMemsetAsync(b->d_tok_model, 0, size_t(total_c) * sizeof(int32_t), stream));
-    VPT_HIP(vpt::launch_decode_chars(d_utf8, d_byte_offsets, d_out_offsets, n_sentences, total_c, cinfo, b->d_cps, nullptr, b->d_ctrl, stream));
+    const bool have_cps = b->cps_text == d_utf8 && b->cps_ooff == d_out_offsets && b->cps_sentences == n_sentences &&
+                          b->cps_boundaries == total_boundaries && b->cps_flags == (b->flags & VPT_FLAG_KYTEA_FULLWIDTH) && b->last_stream == stream;
+    if (!have_cps) {
+        b->cps_text = nullptr;
+        VPT_HIP(vpt::launch_decode_chars(d_utf8, d_byte_offsets, d_out_offsets, n_sentences, total_c, cinfo, b->d_cps, nullptr, b->d_ctrl, stream));
+    }
     vpt::TagParams T{};
-    T.tok_tab = p->dtag.tok_tab; T.models = p->dtag.models; T.ngrams = p->dtag.ngrams; T.nrec = p->dtag.nrec; T.syms = p->dtag.syms; T.slots = p->dtag.slots;
+    T.tok_tab = p->dtag.tok_tab; T.models = p->dtag.models; T.mfilt = p->dtag.mfilt; T.ngrams = p->dtag.ngrams; T.nrec = p->dtag.nrec; T.syms = p->dtag.syms; T.slots = p->dtag.slots;
     T.weights = p->dtag.weights; T.cinfo = cinfo; T.tok_bits = p->tok_bits; T.n_tags = p->n_tags;
     T.use_char = p->tag_use_char ? 1u : 0u; T.use_type = p->tag_use_type ? 1u : 0u;
     T.cps = b->d_cps; T.ooff = d_out_offsets; T.labels = d_labels; T.n_sent = n_sentences; T.total_chars = total_c; T.tags = d_tags_out;

@@ -69,6 +69,29 @@ __device__ __forceinline__ uint64_t first_sentence_at(const uint64_t* __restrict
     return lo;
 }
 
+// inclusive prefix sum over the 64 lanes of a wave: DPP row shifts, then the two row broadcasts (no LDS round trips)
+__device__ __forceinline__ uint32_t wave_inclusive_scan(uint32_t x) {
+    x += uint32_t(__builtin_amdgcn_update_dpp(0, int(x), 0x111, 0xF, 0xF, false));  // row_shr:1
+    x += uint32_t(__builtin_amdgcn_update_dpp(0, int(x), 0x112, 0xF, 0xF, false));  // row_shr:2
+    x += uint32_t(__builtin_amdgcn_update_dpp(0, int(x), 0x114, 0xF, 0xF, false));  // row_shr:4
+    x += uint32_t(__builtin_amdgcn_update_dpp(0, int(x), 0x118, 0xF, 0xF, false));  // row_shr:8
+    x += uint32_t(__builtin_amdgcn_update_dpp(0, int(x), 0x142, 0xA, 0xF, false));  // row_bcast:15 -> rows 1, 3
+    x += uint32_t(__builtin_amdgcn_update_dpp(0, int(x), 0x143, 0xC, 0xF, false));  // row_bcast:31 -> rows 2, 3
+    return x;
+}
+// maximum over the 64 lanes of a wave, in every lane: the same DPP steps (row_bcast feeds the rows above; the last lane holds the
+// total, which readlane 63 hands to everybody)
+__device__ __forceinline__ uint32_t wave_max(uint32_t x) {
+    auto mx = [](uint32_t a, uint32_t b) { return a > b ? a : b; };
+    x = mx(x, uint32_t(__builtin_amdgcn_update_dpp(0, int(x), 0x111, 0xF, 0xF, false)));  // row_shr:1
+    x = mx(x, uint32_t(__builtin_amdgcn_update_dpp(0, int(x), 0x112, 0xF, 0xF, false)));  // row_shr:2
+    x = mx(x, uint32_t(__builtin_amdgcn_update_dpp(0, int(x), 0x114, 0xF, 0xF, false)));  // row_shr:4
+    x = mx(x, uint32_t(__builtin_amdgcn_update_dpp(0, int(x), 0x118, 0xF, 0xF, false)));  // row_shr:8
+    x = mx(x, uint32_t(__builtin_amdgcn_update_dpp(0, int(x), 0x142, 0xA, 0xF, false)));  // row_bcast:15 -> rows 1, 3
+    x = mx(x, uint32_t(__builtin_amdgcn_update_dpp(0, int(x), 0x143, 0xC, 0xF, false)));  // row_bcast:31 -> rows 2, 3
+    return uint32_t(__builtin_amdgcn_readlane(int(x), 63));
+}
+
 // CharacterType::get_type (sentence.rs:50-67): 1 Digit, 2 Roman, 3 Hiragana, 4 Katakana, 5 Kanji, 6 Other
 __device__ __forceinline__ uint32_t char_type(uint32_t c) {
     if ((c - 0x30u) <= 9u || (c - 0xFF10u) <= 9u) return 1;

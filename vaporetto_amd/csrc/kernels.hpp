@@ -59,6 +59,8 @@ struct ScoreParams {
     unsigned char* scratch;     // slabs for score_slow_kernel
     uint64_t scratch_stride;    // bytes per workgroup slab
     uint32_t scratch_cap;       // flat positions per slab
+    uint32_t* cps_out;          // specialised kernel, optional: the batch's chars flat (char g of sentence i at ooff[i] + i + g) as scored
+                                // scalar value | CharacterType << 24 -- what decode_chars_kernel makes for the tag kernel
     uint32_t post;              // label post-filters: bits 1..6 KyteaWsConstFilter per CharacterType, bit 7 SplitLinebreaksFilter
     uint32_t debug;             // profiling ablation bits (VPT_DEBUG_ABLATE env, 0 in production)
     uint64_t* prof;             // per-phase shader-cycle counters (VPT_PROFILE_PHASES env), else nullptr
@@ -66,7 +68,7 @@ struct ScoreParams {
 
 // tag prediction (kernels_tags.hip); table layouts: HostTagTables in tables.hpp
 struct TagParams {
-    const uint32_t *tok_tab, *models, *ngrams, *nrec, *syms, *slots;
+    const uint32_t *tok_tab, *models, *mfilt, *ngrams, *nrec, *syms, *slots;
     const int32_t* weights;
     const uint32_t* cinfo;      // as in ScoreParams
     uint32_t tok_bits, n_tags, use_char, use_type;

@@ -71,16 +71,6 @@ __device__ __forceinline__ uint32_t lane_rank(uint64_t mask) {  // set bits of `
     return __builtin_amdgcn_mbcnt_hi(uint32_t(mask >> 32), __builtin_amdgcn_mbcnt_lo(uint32_t(mask), 0u));
 }
 
-// inclusive prefix sum over the 64 lanes of a wave: DPP row shifts, then the two row broadcasts (no LDS round trips)
-__device__ __forceinline__ uint32_t wave_inclusive_scan(uint32_t x) {
-    x += uint32_t(__builtin_amdgcn_update_dpp(0, int(x), 0x111, 0xF, 0xF, false));  // row_shr:1
-    x += uint32_t(__builtin_amdgcn_update_dpp(0, int(x), 0x112, 0xF, 0xF, false));  // row_shr:2
-    x += uint32_t(__builtin_amdgcn_update_dpp(0, int(x), 0x114, 0xF, 0xF, false));  // row_shr:4
-    x += uint32_t(__builtin_amdgcn_update_dpp(0, int(x), 0x118, 0xF, 0xF, false));  // row_shr:8
-    x += uint32_t(__builtin_amdgcn_update_dpp(0, int(x), 0x142, 0xA, 0xF, false));  // row_bcast:15 -> rows 1, 3
-    x += uint32_t(__builtin_amdgcn_update_dpp(0, int(x), 0x143, 0xC, 0xF, false));  // row_bcast:31 -> rows 2, 3
-    return x;
-}
 // 16 bytes at base + byte offset (32-bit): one scalar base for all packed arrays
 __device__ __forceinline__ uint4 ld16(const unsigned char* base, uint32_t byte_off) {
     return *reinterpret_cast<const uint4*>(base + byte_off);
@@ -431,6 +421,12 @@ __global__ __launch_bounds__(kThreads, WG) void score_tiles_fast_kernel(const Sc
             }
             v = cp != 0 ? v : 0u;                  // a separator (or NUL, which has raised kErrNulChar)
             L.sym[uint32_t(tid) + uint32_t(k) * kThreads] = v;
+            if (P.cps_out) {   // wave-uniform: a fill_tags call on this batch follows and wants the chars decoded (it then skips its own pass)
+                const uint32_t flat = uint32_t(tid) + uint32_t(k) * kThreads, si = xs[k] >> 21;
+                const uint32_t scored = (P.cinfo && cp < 0x10000u) ? (P.cinfo[cp] & 0xFFFFu) : cp;   // through KyteaFullwidthFilter when that flag is on
+                if (cp != 0 && flat >= pad * (si + 1u) && flat - pad * (si + 1u) < expect_chars)
+                    P.cps_out[(O0 + i0) + (flat - pad * (si + 1u))] = scored | (((v >> 16) & 7u) << 24);
+            }
             if (TM != kTypeRows) M.typ[uint32_t(tid) + uint32_t(k) * kThreads] = uint8_t((v >> 16) & 7u);
         }
     }

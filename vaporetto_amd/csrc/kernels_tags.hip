@@ -15,14 +15,19 @@
 //   decode_chars_kernel  UTF-8 -> flat per batch (char g of sentence i at out_offsets[i] + i + g): the scored scalar value
 //                        | CharacterType << 24; optionally Sentence::char_types on their own
 //   tag_tokens_kernel    64 chars per step.  (1) Every lane whose char ends a token owns it: start from the step's boundary
-//                        masks, surface lookup in the hashed token table.  (2) The tokens that found a tag model are
-//                        compacted, and the wave's lanes then enumerate (token, tag n-gram) PAIRS, 64 per round: a lane
-//                        checks one whole n-gram from one 32-byte record against the text window in LDS and, on a match, adds
-//                        its weights to the token's scores in LDS -- the n-grams of ALL the step's tokens are checked in
-//                        a few rounds of independent loads instead of token after token, n-gram after n-gram, symbol after
-//                        symbol.  (3) Lanes over (token, slot) pairs take the argmax.  Models that do not fit the record
-//                        form (an n-gram over 12 symbols or outside the BMP, more than 16 scores) go through a whole-wave
-//                        routine, one token at a time.
+//                        masks, surface hashed from the step's text window in LDS, looked up in the token table (tokens of up
+//                        to 4 chars are verified from the 16-byte slot itself).  (2) The tokens that found a tag model are
+//                        compacted; a model's char n-grams come in groups by rel_position with a 64-bit filter over the chars
+//                        they END with, so a token only enumerates the groups the text can match; the wave's lanes then take
+//                        (token, tag n-gram) PAIRS, 64 per round: a lane checks one whole n-gram from one 32-byte record
+//                        against the text window in LDS; the matches are compacted and lanes over (match, score) pairs add
+//                        their weights to the token's scores in LDS (which start as the model's bias).  The n-grams of ALL the
+//                        step's tokens are checked in a few rounds of independent loads instead of token after token, n-gram
+//                        after n-gram, symbol after symbol.  (3) Lanes over (token, slot) pairs take the argmax.  Models that
+//                        do not fit the record form (an n-gram over 12 symbols or outside the BMP, more than 16 scores or 3
+//                        slots, rel_position above 3) go through a whole-wave routine, one token at a time.
+//   With predict_tags the scoring kernel of the preceding vpt_predict_batch_device call leaves the decoded chars behind and
+//   decode_chars_kernel is skipped (capi.cpp).
 #include <hip/hip_runtime.h>
 
 #include "device_common.h"
@@ -69,13 +74,8 @@ __global__ __launch_bounds__(kTagThreads) void decode_chars_kernel(const uint8_t
             }
             const uint32_t mine = at < b1 ? uint32_t(b1 - at < 4 ? b1 - at : 4) : 0u;          // bytes of this lane's own dword inside the sentence
             const uint32_t lm = lead_nibble(uint32_t(x)) & ((1u << mine) - 1u);              // which of them start a char
-            uint32_t incl = uint32_t(__popc(lm));
-#pragma unroll
-            for (int d = 1; d < 64; d <<= 1) {
-                const uint32_t up = uint32_t(__shfl_up(int(incl), d));
-                if (lane >= d) incl += up;
-            }
-            const uint32_t total = uint32_t(__shfl(int(incl), 63));
+            const uint32_t incl = wave_inclusive_scan(uint32_t(__popc(lm)));
+            const uint32_t total = uint32_t(__builtin_amdgcn_readlane(int(incl), 63));
             uint64_t idx = seen + incl - uint32_t(__popc(lm));
 #pragma unroll
             for (uint32_t k = 0; k < 4; ++k) {
@@ -98,6 +98,7 @@ __global__ __launch_bounds__(kTagThreads) void decode_chars_kernel(const uint8_t
 
 constexpr uint32_t kCharMask = 0x1FFFFFu;   // a cps word: scored scalar value | CharacterType << 24
 constexpr int kWin = 128, kWinBack = 32;     // the text window of a step in LDS: positions base - 32 .. base + 95
+constexpr int kPairs = 1;                    // (token, record) pairs a lane takes per round: two need 78 VGPRs (6 waves per SIMD), one 64 (8)
 constexpr int kTagPass = 32;                 // tokens with a model the fast path takes per pass (a step has at most 64)
 
 struct TagWaveLds {
@@ -105,8 +106,10 @@ struct TagWaveLds {
         int32_t z[kTagMaxZ];                 // the whole-wave routine: one token's scores
         struct {
             int32_t zt[kTagPass][kTagFastZ + 1];   // the fast path: what the n-grams add to every token of the pass (rows padded against bank conflicts)
-            uint32_t tok[kTagPass][4];             // per token: first record, position in the step | zlen << 8 | n_slots << 16, bias offset, packed slots
+            uint32_t tok[kTagPass][6];             // per token: first record, position in the step | zlen << 8 | n_slots << 16, bias offset, packed slots,
+                                                   // the four char group sizes, type entries | active groups << 8
             uint32_t pref[kTagPass + 1];           // records before token t (exclusive prefix of the counts)
+            uint32_t mlist[128][2];                // the matches of a round: weight offset, token | scores to add << 8
         } f;
     };
     uint32_t txt[kWin];                      // cps words of the window, 0 outside the sentence
@@ -192,7 +195,7 @@ __device__ __forceinline__ void tag_token_by_wave(const TagParams& P, const uint
     __builtin_amdgcn_wave_barrier();
 }
 
-__global__ __launch_bounds__(kTagThreads, 6) void tag_tokens_kernel(const TagParams P) {
+__global__ __launch_bounds__(kTagThreads, 8) void tag_tokens_kernel(const TagParams P) {
     __shared__ TagLds LDS;
     const int lane = threadIdx.x & 63;
     TagWaveLds& L = LDS.w[threadIdx.x >> 6];
@@ -229,14 +232,33 @@ __global__ __launch_bounds__(kTagThreads, 6) void tag_tokens_kernel(const TagPar
             const uint32_t model = valid ? find_tag_model(P, cps, L.txt, base, s0, p) : 0u;
             if (valid && P.tok_model) P.tok_model[g0 + uint64_t(p)] = int32_t(model);   // 0: no tag model for this surface
             // the model record: first record, counts, bias offset, zlen, slots (one trip: three 16-byte loads)
-            uint32_t m_first = 0, m_count = 0, m_zlen = 0, m_bias = 0, m_pslots = 0, m_nslots = 0;
+            uint32_t m_first = 0, m_count = 0, m_zlen = 0, m_bias = 0, m_pslots = 0, m_nslots = 0, m_groups = 0, m_tc = 0, m_act = 0;
             bool fast = false;
             if (model != 0) {
                 const uint4* mr = reinterpret_cast<const uint4*>(P.models + size_t(model - 1) * 12);
                 const uint4 r0 = mr[0], r1 = mr[1], r2 = mr[2];   // dwords 0..3, 4..7, 8..11
                 fast = (r2.z & 1u) != 0;
-                m_first = r0.z; m_count = r0.w + r1.y; m_bias = r1.z; m_zlen = r1.w; m_pslots = r2.w;
+                m_first = r0.z; m_bias = r1.z; m_zlen = r1.w; m_pslots = r2.w;
                 m_nslots = r2.y < nt ? r2.y : nt;
+                if (fast) {
+                    // the char entries come in groups by rel_position r: the n-grams of group r END at char p + r, and the group's
+                    // filter says which chars they end with -- a group the text cannot match is not enumerated at all
+                    const uint4* fr = reinterpret_cast<const uint4*>(P.mfilt + size_t(model - 1) * 12);
+                    const uint4 f0 = fr[0], f1 = fr[1], f2 = fr[2];
+                    const uint32_t flo[4] = {f0.x, f0.z, f1.x, f1.z}, fhi[4] = {f0.y, f0.w, f1.y, f1.w};
+                    m_groups = f2.x;
+                    uint32_t act = 0;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const uint32_t c = p + r < n ? (L.txt[p + r - base + kWinBack] & kCharMask) : 0u;
+                        const uint32_t bit = packed_filter_bit(c);
+                        const bool on = P.use_char != 0 && c != 0 && c < 0xFFFFu && (((bit < 32 ? flo[r] >> bit : fhi[r] >> (bit - 32)) & 1u) != 0);
+                        if (on) { act |= 1u << r; m_count += (m_groups >> (8 * r)) & 0xFFu; }
+                    }
+                    m_tc = P.use_type != 0 ? r1.y : 0u;
+                    m_count += m_tc;
+                    m_act = act;
+                }
             }
             const uint64_t fmask = __ballot(fast);
             const uint32_t n_fast = uint32_t(__popcll(fmask));
@@ -247,28 +269,36 @@ __global__ __launch_bounds__(kTagThreads, 6) void tag_tokens_kernel(const TagPar
                 const uint32_t t_me = rank - t0;
                 const uint32_t n_pass = n_fast - t0 < uint32_t(kTagPass) ? n_fast - t0 : uint32_t(kTagPass);
                 // exclusive prefix of the record counts over the pass's tokens (wave scan; the other lanes add 0)
-                uint32_t incl = mine ? m_count : 0u;
-#pragma unroll
-                for (int d = 1; d < 64; d <<= 1) {
-                    const uint32_t up = uint32_t(__shfl_up(int(incl), d));
-                    if (lane >= d) incl += up;
-                }
-                const uint32_t total = uint32_t(__shfl(int(incl), 63));
+                const uint32_t incl = wave_inclusive_scan(mine ? m_count : 0u);
+                const uint32_t total = uint32_t(__builtin_amdgcn_readlane(int(incl), 63));
                 if (mine) {
                     L.f.tok[t_me][0] = m_first; L.f.tok[t_me][1] = uint32_t(p - base) | (m_zlen << 8) | (m_nslots << 16);
-                    L.f.tok[t_me][2] = m_bias; L.f.tok[t_me][3] = m_pslots;
+                    L.f.tok[t_me][2] = m_bias; L.f.tok[t_me][3] = m_pslots; L.f.tok[t_me][4] = m_groups; L.f.tok[t_me][5] = m_tc | (m_act << 8);
                     L.f.pref[t_me] = incl - m_count;
                 }
                 if (lane == 0) L.f.pref[n_pass] = total;
-                for (int q = lane; q < kTagPass * (int(kTagFastZ) + 1); q += 64) (&L.f.zt[0][0])[q] = 0;
                 __builtin_amdgcn_wave_barrier();
-                // rounds of 128 (token, record) pairs, two per lane: every record load of a round is in flight together
-                for (uint32_t r0 = 0; r0 < total; r0 += 128) {
-                    uint32_t tk[2], hdr[2], woff[2];
-                    bool same[2];
-                    uint4 ra[2], rb[2];
+                {   // the scores start as the models' bias: lanes over (token, score) pairs, every load of the pass in flight together
+                    int32_t bias[kTagPass * kTagFastZ / 64];
 #pragma unroll
-                    for (int u = 0; u < 2; ++u) {
+                    for (int q0 = 0; q0 < kTagPass * int(kTagFastZ) / 64; ++q0) {
+                        const uint32_t q = uint32_t(q0) * 64u + uint32_t(lane), t = q / kTagFastZ, i = q % kTagFastZ;
+                        bias[q0] = (t < n_pass && i < ((L.f.tok[t][1] >> 8) & 0xFFu)) ? P.weights[L.f.tok[t][2] + i] : 0;
+                    }
+#pragma unroll
+                    for (int q0 = 0; q0 < kTagPass * int(kTagFastZ) / 64; ++q0) {
+                        const uint32_t q = uint32_t(q0) * 64u + uint32_t(lane);
+                        L.f.zt[q / kTagFastZ][q % kTagFastZ] = bias[q0];
+                    }
+                }
+                __builtin_amdgcn_wave_barrier();
+                // rounds of 64 * kPairs (token, record) pairs: every record load of a round is in flight together
+                for (uint32_t r0 = 0; r0 < total; r0 += 64 * kPairs) {
+                    uint32_t tk[kPairs], hdr[kPairs], woff[kPairs];
+                    bool same[kPairs];
+                    uint4 ra[kPairs], rb[kPairs];
+#pragma unroll
+                    for (int u = 0; u < kPairs; ++u) {
                         const uint32_t pi = r0 + uint32_t(u) * 64u + uint32_t(lane);
                         const bool have = pi < total;
                         uint32_t t = 0;
@@ -279,17 +309,27 @@ __global__ __launch_bounds__(kTagThreads, 6) void tag_tokens_kernel(const TagPar
                         }
                         tk[u] = t;
                         same[u] = have;
-                        const uint32_t ri = have ? L.f.tok[t][0] + (pi - L.f.pref[t]) : 0u;
+                        uint32_t ri = 0;
+                        if (have) {   // the k-th entry of the token's ACTIVE groups (then its type entries) -> record index
+                            uint32_t k = pi - L.f.pref[t], off = L.f.tok[t][0];
+                            const uint32_t groups = L.f.tok[t][4], act = L.f.tok[t][5] >> 8;
+                            bool placed = false;
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) {
+                                const uint32_t c = (groups >> (8 * r)) & 0xFFu;
+                                if (!placed && ((act >> r) & 1u)) { if (k < c) { ri = off + k; placed = true; } else k -= c; }
+                                off += c;
+                            }
+                            if (!placed) ri = off + k;   // a type entry
+                        }
                         ra[u] = have ? reinterpret_cast<const uint4*>(P.nrec)[size_t(ri) * 2] : make_uint4(0, 0, 0, 0);
                         rb[u] = have ? reinterpret_cast<const uint4*>(P.nrec)[size_t(ri) * 2 + 1] : make_uint4(0, 0, 0, 0);
                     }
                     // the longest n-gram of this round bounds the compare loops (wave-uniform: no lane runs 12 steps for 3-char n-grams)
-                    uint32_t gmax = (ra[0].x & 0xFFu) > (ra[1].x & 0xFFu) ? (ra[0].x & 0xFFu) : (ra[1].x & 0xFFu);
+                    uint32_t gmax = wave_max(kPairs == 2 ? ((ra[0].x & 0xFFu) > (ra[kPairs - 1].x & 0xFFu) ? (ra[0].x & 0xFFu) : (ra[kPairs - 1].x & 0xFFu)) : (ra[0].x & 0xFFu));
+                    gmax = gmax < kTagFastSyms ? gmax : kTagFastSyms;
 #pragma unroll
-                    for (int d = 32; d >= 1; d >>= 1) { const uint32_t o = uint32_t(__shfl_xor(int(gmax), d)); gmax = o > gmax ? o : gmax; }
-                    gmax = wave_uniform(gmax < kTagFastSyms ? gmax : kTagFastSyms);
-#pragma unroll
-                    for (int u = 0; u < 2; ++u) {
+                    for (int u = 0; u < kPairs; ++u) {
                         const uint32_t glen = ra[u].x & 0xFFu, rel = (ra[u].x >> 8) & 0xFFu, kind = (ra[u].x >> 16) & 1u;
                         const int e = base + int(same[u] ? L.f.tok[tk[u]][1] & 0xFFu : 0u);
                         const int endp = e + int(rel) + 1, beg = endp - int(glen);
@@ -309,26 +349,41 @@ __global__ __launch_bounds__(kTagThreads, 6) void tag_tokens_kernel(const TagPar
                         same[u] = ok;
                         hdr[u] = ra[u].x; woff[u] = ra[u].y;
                     }
-                    if (__ballot(same[0] || same[1]) != 0) {   // the weights of the matches: independent loads again, then LDS adds
+                    // the matches of the round, compacted; then lanes over (match, score) pairs add the weights: four matches per
+                    // 64 lanes, the loads of up to sixteen matches in flight together
+                    const uint64_t m0 = __ballot(same[0]), m1 = kPairs == 2 ? __ballot(same[kPairs - 1]) : 0;
+                    const uint32_t n0m = uint32_t(__popcll(m0)), n_match = n0m + uint32_t(__popcll(m1));
+                    if (n_match != 0) {
 #pragma unroll
-                        for (int u = 0; u < 2; ++u) {
+                        for (int u = 0; u < kPairs; ++u) {
                             if (same[u]) {
+                                const uint32_t k = (u ? n0m : 0u) + uint32_t(__popcll((u ? m1 : m0) & below_me));
                                 const uint32_t zlen = (L.f.tok[tk[u]][1] >> 8) & 0xFFu;
                                 const uint32_t wl = (hdr[u] >> 24) < zlen ? (hdr[u] >> 24) : zlen;   // zip: the shorter of the two (predictor.rs:82-89)
-                                for (uint32_t i0 = 0; i0 < wl; i0 += 4) {   // four independent loads at a time (matches are few; registers are not)
-                                    int32_t w[4];
-#pragma unroll
-                                    for (uint32_t i = 0; i < 4; ++i) w[i] = i0 + i < wl ? P.weights[woff[u] + i0 + i] : 0;
-#pragma unroll
-                                    for (uint32_t i = 0; i < 4; ++i)
-                                        if (i0 + i < wl) atomicAdd(&L.f.zt[tk[u]][i0 + i], w[i]);   // several n-grams of one token may match in one round
-                                }
+                                L.f.mlist[k][0] = woff[u]; L.f.mlist[k][1] = tk[u] | (wl << 8);
                             }
                         }
+                        __builtin_amdgcn_wave_barrier();
+                        for (uint32_t k0 = 0; k0 < n_match; k0 += 16) {
+                            int32_t w[4];
+                            uint32_t info[4];
+#pragma unroll
+                            for (uint32_t q = 0; q < 4; ++q) {
+                                const uint32_t k = k0 + q * 4u + (uint32_t(lane) >> 4), i = uint32_t(lane) & 15u;
+                                info[q] = k < n_match ? L.f.mlist[k][1] : 0u;
+                                w[q] = (k < n_match && i < (info[q] >> 8)) ? P.weights[L.f.mlist[k][0] + i] : 0;
+                            }
+#pragma unroll
+                            for (uint32_t q = 0; q < 4; ++q) {
+                                const uint32_t i = uint32_t(lane) & 15u;
+                                if (i < (info[q] >> 8)) atomicAdd(&L.f.zt[info[q] & 0xFFu][i], w[q]);   // several n-grams of one token may match
+                            }
+                        }
+                        __builtin_amdgcn_wave_barrier();
                     }
                 }
                 __builtin_amdgcn_wave_barrier();
-                // ---- (3) argmax per (token, slot) over bias + what the n-grams added (TagPredictor::predict, predictor.rs:286-304)
+                // ---- (3) argmax per (token, slot) (TagPredictor::predict, predictor.rs:286-304)
                 for (uint32_t a0 = 0; a0 < n_pass * nt; a0 += 64) {
                     const uint32_t a = a0 + uint32_t(lane);
                     if (a < n_pass * nt) {
@@ -340,18 +395,9 @@ __global__ __launch_bounds__(kTagThreads, 6) void tag_tokens_kernel(const TagPar
                             if (cnt >= 2) {
                                 int32_t best = INT32_MIN;
                                 tag = 0;
-                                const uint32_t lim = off + cnt < zlen ? cnt : zlen - off;   // candidates that have a score (off < zlen for a slot of >= 2)
-                                for (uint32_t c0 = 0; c0 < lim; c0 += 4) {
-                                    int32_t bias[4];
-#pragma unroll
-                                    for (uint32_t c = 0; c < 4; ++c) bias[c] = c0 + c < lim ? P.weights[L.f.tok[t][2] + off + c0 + c] : 0;
-#pragma unroll
-                                    for (uint32_t c = 0; c < 4; ++c) {
-                                        if (c0 + c < lim) {
-                                            const int32_t v = int32_t(uint32_t(bias[c]) + uint32_t(L.f.zt[t][off + c0 + c]));
-                                            if (v > best) { best = v; tag = int32_t(c0 + c); }
-                                        }
-                                    }
+                                for (uint32_t c = 0; c < cnt && off + c < zlen; ++c) {
+                                    const int32_t v = L.f.zt[t][off + c];
+                                    if (v > best) { best = v; tag = int32_t(c); }
                                 }
                             }
                             P.tags[(g0 + uint64_t(uint32_t(base) + (info & 0xFFu))) * nt + j] = tag;

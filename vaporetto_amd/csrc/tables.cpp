@@ -679,7 +679,7 @@ HostTagTables build_tag_tables(const ModelData& m, bool use_char, bool use_type)
     t.present = true;
     t.use_char = use_char; t.use_type = use_type;
     t.n_models = uint32_t(m.tag_models.size());
-    t.tok_bits = bits_for(m.tag_models.size());
+    t.tok_bits = bits_for(m.tag_models.size()) + 1;   // a quarter full: a lane's probe sequence is the wave's when it is the longest
     t.tok_tab.assign(size_t(4) << t.tok_bits, 0);
     const uint32_t mask = (1u << t.tok_bits) - 1;
     for (uint32_t mi = 0; mi < m.tag_models.size(); ++mi) {
@@ -688,37 +688,59 @@ HostTagTables build_tag_tables(const ModelData& m, bool use_char, bool use_type)
         uint32_t rec[12] = {0};
         rec[0] = uint32_t(t.syms.size()); rec[1] = uint32_t(tm.token.size());
         t.syms.insert(t.syms.end(), tm.token.begin(), tm.token.end());
+        // The entries of a model: (n-gram, rel_position) pairs, char ones first -- ordered by rel_position, so that the kernel
+        // can skip a whole group whose filter does not hold the text char the n-grams of the group must END with -- then type ones.
         bool all_compact = true;
+        uint32_t rel_count[4] = {0, 0, 0, 0};
+        uint64_t rel_filter[4] = {0, 0, 0, 0};
+        bool rel_ok = true;
         auto add_ngrams = [&](const std::vector<TagNgramRecord>& list, uint32_t kind, uint32_t* first, uint32_t* count) {
             *first = uint32_t(t.ngrams.size() / 4);
+            struct Ent { uint32_t rel; const TagNgramRecord* d; const TagWeightRecord* w; uint32_t so; };
+            std::vector<Ent> ents;
             for (const TagNgramRecord& d : list) {
                 const uint32_t so = uint32_t(t.syms.size());
                 t.syms.insert(t.syms.end(), d.ngram.begin(), d.ngram.end());
+                if (d.ngram.size() >= (size_t(1) << 24)) throw ModelError("InvalidModelError: tag n-gram too long");
+                for (const TagWeightRecord& w : d.weights) ents.push_back({w.rel_position, &d, &w, so});
+            }
+            if (kind == 0) std::stable_sort(ents.begin(), ents.end(), [](const Ent& a, const Ent& b) { return a.rel < b.rel; });
+            for (const Ent& e : ents) {
+                const TagNgramRecord& d = *e.d;
+                const TagWeightRecord& w = *e.w;
                 bool compact = d.ngram.size() <= kTagFastSyms;
                 for (Sym c : d.ngram) compact = compact && c < 0xFFFFu;
-                for (const TagWeightRecord& w : d.weights) {
-                    if (d.ngram.size() >= (size_t(1) << 24)) throw ModelError("InvalidModelError: tag n-gram too long");
-                    t.ngrams.push_back(so);
-                    t.ngrams.push_back(uint32_t(d.ngram.size()) | (uint32_t(w.rel_position) << 24));
-                    t.ngrams.push_back(uint32_t(t.weights.size()));
-                    t.ngrams.push_back(uint32_t(w.weights.size()));
-                    uint32_t r[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-                    r[0] = (compact ? uint32_t(d.ngram.size()) : 0u) | (uint32_t(w.rel_position) << 8) | (kind << 16) | (compact ? 1u << 17 : 0u) |
-                           (uint32_t(std::min<size_t>(w.weights.size(), 255)) << 24);
-                    r[1] = uint32_t(t.weights.size());
-                    if (compact)
-                        for (size_t j = 0; j < d.ngram.size(); ++j) r[2 + j / 2] |= d.ngram[j] << (16 * (j & 1));
-                    t.nrec.insert(t.nrec.end(), r, r + 8);
-                    all_compact = all_compact && compact;
-                    t.weights.insert(t.weights.end(), w.weights.begin(), w.weights.end());
+                t.ngrams.push_back(e.so);
+                t.ngrams.push_back(uint32_t(d.ngram.size()) | (uint32_t(w.rel_position) << 24));
+                t.ngrams.push_back(uint32_t(t.weights.size()));
+                t.ngrams.push_back(uint32_t(w.weights.size()));
+                uint32_t r[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+                r[0] = (compact ? uint32_t(d.ngram.size()) : 0u) | (uint32_t(w.rel_position) << 8) | (kind << 16) | (compact ? 1u << 17 : 0u) |
+                       (uint32_t(std::min<size_t>(w.weights.size(), 255)) << 24);
+                r[1] = uint32_t(t.weights.size());
+                if (compact)
+                    for (size_t j = 0; j < d.ngram.size(); ++j) r[2 + j / 2] |= d.ngram[j] << (16 * (j & 1));
+                t.nrec.insert(t.nrec.end(), r, r + 8);
+                all_compact = all_compact && compact;
+                if (kind == 0) {
+                    if (w.rel_position > 3 || d.ngram.empty()) rel_ok = false;
+                    else { ++rel_count[w.rel_position]; rel_filter[w.rel_position] |= uint64_t(1) << packed_filter_bit(d.ngram.back()); }
                 }
+                t.weights.insert(t.weights.end(), w.weights.begin(), w.weights.end());
             }
             *count = uint32_t(t.ngrams.size() / 4) - *first;
         };
         add_ngrams(tm.char_ngrams, 0u, &rec[2], &rec[3]);
         add_ngrams(tm.type_ngrams, 1u, &rec[4], &rec[5]);
         // the fast path walks char and type entries as one run of records
-        const bool fast_model = all_compact && rec[4] == rec[2] + rec[3] && tm.bias.size() <= kTagFastZ && tm.tags.size() <= 3;
+        const bool fast_model = all_compact && rel_ok && rec[4] == rec[2] + rec[3] && tm.bias.size() <= kTagFastZ && tm.tags.size() <= 3 &&
+                                rel_count[0] < 256 && rel_count[1] < 256 && rel_count[2] < 256 && rel_count[3] < 256 && rec[5] < 256;
+        {   // mfilt: per rel_position 0..3 the filter over the last chars of the group's n-grams, then the group sizes
+            uint32_t f[12] = {0};
+            for (int r = 0; r < 4; ++r) { f[2 * r] = uint32_t(rel_filter[r]); f[2 * r + 1] = uint32_t(rel_filter[r] >> 32); }
+            f[8] = rel_count[0] | (rel_count[1] << 8) | (rel_count[2] << 16) | (rel_count[3] << 24);
+            t.mfilt.insert(t.mfilt.end(), f, f + 12);
+        }
         rec[6] = uint32_t(t.weights.size()); rec[7] = uint32_t(tm.bias.size());
         t.weights.insert(t.weights.end(), tm.bias.begin(), tm.bias.end());
         if (tm.bias.size() > kTagMaxZ) throw ModelError("InvalidModelError: more than 1024 tag scores per token are not supported");
@@ -766,6 +788,7 @@ HostTagTables build_tag_tables(const ModelData& m, bool use_char, bool use_type)
     if (t.weights.empty()) t.weights.push_back(0);
     if (t.ngrams.empty()) t.ngrams.assign(4, 0);
     if (t.nrec.empty()) t.nrec.assign(8, 0);
+    if (t.mfilt.empty()) t.mfilt.assign(12, 0);
     if (t.slots.empty()) t.slots.assign(2, 0);
     if (t.slot_str.empty()) t.slot_str.push_back(0);
     t.str_off.push_back(uint32_t(t.str_bytes.size()));   // the end of the last string

@@ -59,6 +59,9 @@ struct HostPackedTable {
 //             the n-gram has at most 12 symbols, all below 0xFFFF.  models[10] bit 0 = every entry of the model is compact,
 //             its char and type entries are adjacent, it has at most 16 scores and at most 3 slots: the fast path may take its
 //             tokens; models[11] then packs the slots: (candidates | score offset << 5) << (9 * slot).
+//   mfilt     12 dwords per tag model: the char entries of a model are ordered by rel_position; dwords 2r, 2r+1 = a 64-bit filter
+//             over packed_filter_bit(last symbol) of the n-grams with rel_position r (0..3), dword 8 = the four group sizes, 8 bits
+//             each -- a token whose text has no candidate last char at offset r skips the whole group.
 //   slots     2 dwords per tag slot: candidate count, offset of its scores in z (slots with >= 2 candidates)
 //   slot_str  per tag slot: index of its first candidate in str_off; str_off[k] .. str_off[k+1] = the bytes of candidate
 //             string k in str_bytes, ALREADY escaped the way Sentence::write_tokenized_text writes a tag (sentence.rs:871-880)
@@ -66,7 +69,7 @@ struct HostTagTables {
     bool present = false;
     uint32_t n_tags = 0, n_models = 0, tok_bits = 4, max_zlen = 0;
     bool use_char = false, use_type = false;   // the scorers exist (char_scorer.rs:98-100, type_scorer.rs:109-111)
-    std::vector<uint32_t> tok_tab, models, ngrams, nrec, syms, slots, slot_str, str_off;
+    std::vector<uint32_t> tok_tab, models, mfilt, ngrams, nrec, syms, slots, slot_str, str_off;
     std::vector<uint8_t> str_bytes;
     std::vector<int32_t> weights;
 };
