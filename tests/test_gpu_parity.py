@@ -633,6 +633,65 @@ def test_tag_models_inside_and_outside_the_record_form():
             assert np.array_equal(got[a + i:a + i + len(t)], want), (edit, i, t[:30])
 
 
+def test_tag_token_table_keys_and_queue():
+    """The token table is keyed by the length and the low 16 bits of the first four chars: surfaces that share both
+    (same 4-char prefix and length; a non-BMP char whose low 16 bits are another model's BMP char) must be told apart, a
+    token that began more than a ring (64 chars) before its last char is read from the batch's chars, and tokens with
+    models are queued across steps AND sentences (16 per pass): short sentences with one token each, sentences with
+    more than 16 per step."""
+    from vaporetto_amd.modelfmt import TagModel, TagNgramData, TagWeight
+    import random
+    rng = random.Random(11)
+    alpha = randmodel.ALPHABETS["kana"][:5]
+    m = randmodel.rand_model(951, alphabet=alpha, wc=3, wt=2, n_char=40, n_dict=20, max_word=3, n_tag_models=0)
+    a = alpha
+    long_tok = "".join(rng.choice(a) for _ in range(75))
+    toks = [a[0] + a[1] + a[2] + a[3] + a[4], a[0] + a[1] + a[2] + a[3] + a[0], a[0] + a[1] + a[2] + a[3], a[0] + a[1] + a[2] + a[3] + a[4] + a[0],
+            "\u0bb7", "𠮷", "\u0bb7" + a[0], a[0], a[1], a[2] + a[3], long_tok, long_tok[:74] + ("x" if long_tok[74] != "x" else "y")]
+
+    def w(n):
+        return [rng.randint(-3000, 3000) for _ in range(n)]
+    for i, tok in enumerate(toks):
+        slots = [["a%d" % i, "b", "c"], ["x", "y%d" % i]]
+        tm = TagModel(tok, slots, bias=w(5))
+        for _ in range(3):
+            left = "".join(rng.choice(a) for _ in range(rng.randint(0, 2)))
+            right = "".join(rng.choice(a) for _ in range(rng.randint(0, 2)))
+            tm.char_ngram_model.append(TagNgramData((left + tok + right)[-12:] if len(left + tok + right) > 12 and not right else (tok[-3:] + right),
+                                                    [TagWeight(len(right), w(5))]))
+        tm.type_ngram_model.append(TagNgramData(bytes([3]), [TagWeight(0, w(5))]))
+        m.tag_models.append(tm)
+    raw = encode_model(m)
+    pred = api.Predictor(api.Model.read_slice(raw)[0], True)
+    orc = cbind.OraclePredictor(raw, True)
+    nt = pred.n_tags()
+    texts, labs = [], []
+
+    def add(tokens):
+        t = "".join(tokens)
+        lab = []
+        for tk in tokens:
+            lab += [0] * (len(tk) - 1) + [1]
+        texts.append(t); labs.append(lab[:-1])
+    for _ in range(60):
+        add([rng.choice(toks + ["𠮷" + a[0], "\u0bb7" + a[1], a[4] * 3]) for _ in range(rng.randint(1, 12))])
+    for tk in toks:
+        add([tk])                                         # one token per sentence: the queue fills across sentences
+    for _ in range(10):
+        add([rng.choice([a[0], a[1], a[2] + a[3]]) for _ in range(200)])   # > 16 tokens with models per step
+    add([a[1]] * 30 + [long_tok] + [a[0]] + [toks[-1]] + [a[1]])
+    utf8, boff = api.pack_texts([t.encode("utf-8") for t in texts])
+    ooff = api.count_boundaries(utf8, boff)
+    lab = np.array([x for l in labs for x in l], dtype=np.uint8)
+    assert len(lab) == int(ooff[-1])
+    got = pred.fill_tags_packed(utf8, boff, ooff, lab)
+    for i, t in enumerate(texts):
+        s, e = int(ooff[i]), int(ooff[i + 1])
+        want, _ = orc.predict_tags(t, labels=lab[s:e])
+        assert np.array_equal(got[s + i:s + i + len(t)], want), (i, t[:30])
+    assert (got >= 0).any()
+
+
 def test_converted_kytea_fixture_on_gpu():
     """resources/kytea-model.bin converted by vaporetto_amd/kytea.py (kytea_model.rs:401-422): same tokens on the GPU."""
     from vaporetto_amd import kytea

@@ -54,7 +54,7 @@ struct TableGeom {
     int32_t window, lo[3], len[3];
 };
 constexpr char kCompiledMagic[16] = "VaporettoHIP-C\x01";   // 15 chars + NUL
-constexpr uint32_t kCompiledVersion = 5;                    // bump whenever layout.h or a kernel's reading of it changes
+constexpr uint32_t kCompiledVersion = 6;                    // bump whenever layout.h or a kernel's reading of it changes
 struct PredictorMeta {                                      // plain data: written and read as is (little-endian hosts)
     char magic[16];
     uint32_t version, meta_bytes;
@@ -175,6 +175,7 @@ struct vpt_predictor {
     int32_t bias = 0; int pad = 1; int type_kind = 0; int type_window = 0; int chunks = 2;
     uint32_t tile_slots = 0;           // workgroups of the scoring kernel the device runs at a time (0 = unknown)
     uint32_t tile_slots_small = 0;     // ... of the specialised kernel's small-tile geometry
+    uint32_t n_cus = 0;                // compute units of the device (0 = unknown)
     vpt::PackedView pk{};
     const int32_t* d_type_table = nullptr;
     const uint8_t* d_ctype = nullptr;
@@ -413,6 +414,7 @@ void bind_predictor(vpt_predictor* p) {
     p->tile_slots = 0; p->tile_slots_small = 0;
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, p->device) == hipSuccess && prop.multiProcessorCount > 0) {
+        p->n_cus = uint32_t(prop.multiProcessorCount);
         vpt::ScoreParams probe{};
         probe.ct = p->ct; probe.pk = p->pk; probe.pad = p->pad; probe.ctype = p->d_ctype; probe.cid = p->d_cid; probe.type_kind = p->type_kind;
         probe.type_window = p->type_window;
@@ -1107,8 +1109,6 @@ vpt_status vpt_fill_tags_batch_device(const vpt_predictor* p, vpt_batch* b, cons
     if ((st = grow(&b->d_tok_model, &b->tok_model_cap, size_t(total_c) + 16)) != VPT_OK) return st;
     b->tok_model_chars = total_c;
     const uint32_t* cinfo = p->d_cinfo + ((b->flags & VPT_FLAG_KYTEA_FULLWIDTH) ? 65536 : 0);
-    VPT_HIP(hipMemsetAsync(d_tags_out, 0xFF, size_t(total_c) * p->n_tags * sizeof(int32_t), stream));   // -1 = None
-    VPT_HIP(hipMemsetAsync(b->d_tok_model, 0, size_t(total_c) * sizeof(int32_t), stream));
     const bool have_cps = b->cps_text == d_utf8 && b->cps_ooff == d_out_offsets && b->cps_sentences == n_sentences &&
                           b->cps_boundaries == total_boundaries && b->cps_flags == (b->flags & VPT_FLAG_KYTEA_FULLWIDTH) && b->last_stream == stream;
     if (!have_cps) {
@@ -1121,6 +1121,11 @@ vpt_status vpt_fill_tags_batch_device(const vpt_predictor* p, vpt_batch* b, cons
     T.use_char = p->tag_use_char ? 1u : 0u; T.use_type = p->tag_use_type ? 1u : 0u;
     T.cps = b->d_cps; T.ooff = d_out_offsets; T.labels = d_labels; T.n_sent = n_sentences; T.total_chars = total_c; T.tags = d_tags_out;
     T.tok_model = b->d_tok_model;
+    // tag_tokens_kernel runs 8 workgroups per CU at a time; four generations of them stride over the batch, so that the
+    // sentences' lengths (8..512 chars in BASELINE's configs[4]) even out without one workgroup per four sentences
+    // (measured on configs[4], 300 K sentences: 65536 workgroups 1.09 ms, 8 per CU 0.67, 32 per CU 0.64)
+    static const int tag_wgs = [] { const char* e = std::getenv("VPT_TAG_WGS_PER_CU"); return e ? std::atoi(e) : 32; }();
+    T.max_blocks = p->n_cus * uint32_t(tag_wgs);
     VPT_HIP(vpt::launch_tag_tokens(T, stream));
     b->last_stream = stream; b->pending = true;
     return VPT_OK;

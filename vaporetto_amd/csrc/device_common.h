@@ -29,6 +29,7 @@ namespace vpt {
 // COMPILER learns that branches and loop exits depending on it are wave-uniform, so it keeps counters in SGPRs and
 // emits scalar branches instead of exec-mask loops (thread ids and LDS loads are divergent as far as it can tell).
 __device__ __forceinline__ uint32_t wave_uniform(uint32_t x) { return uint32_t(__builtin_amdgcn_readfirstlane(int(x))); }
+__device__ __forceinline__ uint64_t wave_uniform64(uint64_t x) { return uint64_t(wave_uniform(uint32_t(x))) | (uint64_t(wave_uniform(uint32_t(x >> 32))) << 32); }
 
 // First sentence i in [0, n_sent] whose flat start F(i) = ooff[i] + i * (1 + pad) is >= target (F is non-decreasing and
 // F(n_sent) is the total).  Sentences of similar length make F nearly linear: start from the interpolated position

@@ -79,6 +79,7 @@ struct TagParams {
     uint64_t total_chars;       // total boundaries + S: what `cps` and `tags / n_tags` hold
     int32_t* tok_model;         // [total chars] or nullptr: tag model index + 1 of the token ending at the char (token emission)
     int32_t* tags;              // [(total boundaries + S) * n_tags] candidate index per slot, -1 = None
+    uint32_t max_blocks;        // workgroups the device runs at a time (0: one wave per sentence up to 65536 workgroups)
 };
 hipError_t launch_decode_chars(const uint8_t* text, const uint64_t* boff, const uint64_t* ooff, uint64_t n_sent, uint64_t total_chars,
                                const uint32_t* cinfo, uint32_t* cps, uint8_t* types, uint32_t* status, hipStream_t stream);

@@ -14,24 +14,30 @@
 // Two kernels, one wave per sentence each:
 //   decode_chars_kernel  UTF-8 -> flat per batch (char g of sentence i at out_offsets[i] + i + g): the scored scalar value
 //                        | CharacterType << 24; optionally Sentence::char_types on their own
-//   tag_tokens_kernel    64 chars per step.  (1) Every lane whose char ends a token owns it: start from the step's boundary
-//                        masks, surface hashed from the step's text window in LDS, looked up in the token table (tokens of up
-//                        to 4 chars are verified from the 16-byte slot itself).  (2) The tokens that found a tag model are
-//                        compacted; a model's char n-grams come in groups by rel_position with a 64-bit filter over the chars
-//                        they END with, so a token only enumerates the groups the text can match; the wave's lanes then take
-//                        (token, tag n-gram) PAIRS, 64 per round: a lane checks one whole n-gram from one 32-byte record
-//                        against the text window in LDS; the matches are compacted and lanes over (match, score) pairs add
-//                        their weights to the token's scores in LDS (which start as the model's bias).  The n-grams of ALL the
-//                        step's tokens are checked in a few rounds of independent loads instead of token after token, n-gram
-//                        after n-gram, symbol after symbol.  (3) Lanes over (token, slot) pairs take the argmax.  Models that
-//                        do not fit the record form (an n-gram over 12 symbols or outside the BMP, more than 16 scores or 3
-//                        slots, rel_position above 3) go through a whole-wave routine, one token at a time.
+//   tag_tokens_kernel    The waves stay and stride over the sentences, 64 chars per step, chars and labels fetched one step
+//                        ahead.  (1) Every lane whose char ends a token owns it: start from the step's boundary masks, surface
+//                        looked up in the token table -- keyed by the length and the first four chars, which the lane reads
+//                        from the sentence's ring in LDS, so there is no loop over the token; a token of up to 4 chars is
+//                        verified from its 16-byte slot alone.  Every char gets its entries here (no tag model: None).
+//                        (2) The tokens that found a tag model join a QUEUE in LDS that outlives the step and the sentence; 16
+//                        of them are a pass: their context chars (p - 11 .. p + 4), model records and bias arrive in one trip;
+//                        a model's char n-grams come in groups by rel_position with a 64-bit filter over the chars they END
+//                        with, so a token only enumerates the groups its text can match; the wave's lanes then take (token,
+//                        tag n-gram) PAIRS, 64 per round: a lane checks one whole n-gram from one 32-byte record against the
+//                        token's context in LDS; the matches are collected and lanes over (match, score) pairs add their
+//                        weights to the token's scores in LDS (which start as the model's bias); lanes over (token, slot)
+//                        pairs take the argmax.  With one token in thirty carrying a model (BASELINE's configs[4]) a step
+//                        would fill a round to a quarter and pay the pass's four dependent trips for one or two tokens;
+//                        the queue fills every round and pays them once per sixteen.  Models that do not fit the record form
+//                        (an n-gram over 12 symbols or outside the BMP, more than 16 scores or 3 slots, rel_position above
+//                        3) go through a whole-wave routine, one token at a time.
 //   With predict_tags the scoring kernel of the preceding vpt_predict_batch_device call leaves the decoded chars behind and
 //   decode_chars_kernel is skipped (capi.cpp).
 #include <hip/hip_runtime.h>
 
 #include "device_common.h"
 #include "kernels.hpp"
+#include <cstdlib>
 
 namespace vpt {
 namespace {
@@ -97,52 +103,57 @@ __global__ __launch_bounds__(kTagThreads) void decode_chars_kernel(const uint8_t
 }
 
 constexpr uint32_t kCharMask = 0x1FFFFFu;   // a cps word: scored scalar value | CharacterType << 24
-constexpr int kWin = 128, kWinBack = 32;     // the text window of a step in LDS: positions base - 32 .. base + 95
-constexpr int kPairs = 1;                    // (token, record) pairs a lane takes per round: two need 78 VGPRs (6 waves per SIMD), one 64 (8)
-constexpr int kTagPass = 32;                 // tokens with a model the fast path takes per pass (a step has at most 64)
+constexpr int kRing = 128;                   // the sentence's cps words in LDS: char q at txt[q & 127]; a step holds [base - 64, base + 64)
+constexpr int kTagPass = 16;                 // queued tokens a pass takes
+constexpr int kCtx = 16, kCtxBack = 11;      // the text a queued token's n-grams can touch: chars p - 11 .. p + 4 around its last char p
+constexpr int kMatchCap = 128;               // matched (token, n-gram) pairs collected before their weights are added
 
 struct TagWaveLds {
     union {
         int32_t z[kTagMaxZ];                 // the whole-wave routine: one token's scores
         struct {
-            int32_t zt[kTagPass][kTagFastZ + 1];   // the fast path: what the n-grams add to every token of the pass (rows padded against bank conflicts)
-            uint32_t tok[kTagPass][6];             // per token: first record, position in the step | zlen << 8 | n_slots << 16, bias offset, packed slots,
-                                                   // the four char group sizes, type entries | active groups << 8
+            uint32_t tok[kTagPass][8];             // the queue: tag model + 1, flat char index (2), chars before | after << 8 inside the sentence (clipped
+                                                   // to the context); a pass adds: first record, scores | slots << 8 | type entries << 16 | active
+                                                   // groups << 24, packed slots, the four char group sizes
+            uint32_t ctx[kTagPass][kCtx];          // cps words p - 11 .. p + 4 of every token, 0 outside its sentence
+            int32_t zt[kTagPass][kTagFastZ + 1];   // the scores (rows padded against bank conflicts)
             uint32_t pref[kTagPass + 1];           // records before token t (exclusive prefix of the counts)
-            uint32_t mlist[128][2];                // the matches of a round: weight offset, token | scores to add << 8
+            uint32_t mlist[kMatchCap][2];          // matches: weight offset, token | scores to add << 8
         } f;
     };
-    uint32_t txt[kWin];                      // cps words of the window, 0 outside the sentence
+    uint32_t txt[kRing];
 };
 struct TagLds { TagWaveLds w[kTagWaves]; };
 static_assert(sizeof(TagLds) <= 20 * 1024, "8 workgroups per CU");
 
-// the tag model (index + 1) whose token is the chars [s0, e] of the sentence, or 0: one lane on its own.  The chars come
-// from the step's LDS window when the token starts inside it (nearly always), a token of up to 4 BMP chars is verified
-// from its table slot alone.
-__device__ __forceinline__ uint32_t find_tag_model(const TagParams& P, const uint32_t* cps, const uint32_t* txt, int base, int s0, int e) {
+// The tag model (index + 1) whose token is the chars [s0, e] of the sentence, or 0: one lane on its own, no loop over the
+// token -- the table is keyed by the length and the first four chars (layout.h, tag_token_hash_key); a surface of up to four
+// BMP chars is verified by the slot itself, a longer candidate against `syms`.
+__device__ __forceinline__ uint32_t find_tag_model(const TagParams& P, const uint32_t* cps, const uint32_t* txt, int base, int s0, int e, bool* fast) {
     const int len = e - s0 + 1;
-    const bool in_win = s0 >= base - kWinBack;
-    auto ch = [&](int q) { return (in_win ? txt[q - base + kWinBack] : cps[q]) & kCharMask; };
-    uint32_t h = 0x811C9DC5u;
-    for (int j = 0; j < len; ++j) h = (h ^ ch(s0 + j)) * 0x01000193u;
-    h ^= h >> 15;
-    h *= kHashMulLo;
+    const bool in_ring = s0 >= base - (kRing - 64);
+    uint32_t c[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) c[j] = j < len ? txt[(s0 + j) & (kRing - 1)] & kCharMask : 0u;   // always an LDS read ...
+    if (!in_ring) {   // ... and for a token that began before the ring (rare) the chars themselves
+#pragma unroll
+        for (int j = 0; j < 4; ++j) c[j] = j < len ? cps[s0 + j] & kCharMask : 0u;
+    }
+    const uint32_t lo = (c[0] & 0xFFFFu) | (c[1] << 16), hi = (c[2] & 0xFFFFu) | (c[3] << 16);
+    const bool bmp = ((c[0] | c[1] | c[2] | c[3]) >> 16) == 0;
     const uint32_t tok_mask = (1u << P.tok_bits) - 1u;
-    uint32_t slot = h >> (32 - P.tok_bits);
+    uint32_t slot = tag_token_hash_key(lo, hi, uint32_t(len)) >> (32 - P.tok_bits);
     for (;;) {
         const uint4 t = reinterpret_cast<const uint4*>(P.tok_tab)[slot];
         if (t.x == 0) return 0;
-        if (int(t.y & 0x7FFFFFFFu) == len) {
-            bool same = true;
-            if (t.y & 0x80000000u) {
-                const uint32_t sy[2] = {t.z, t.w};
-                for (int j = 0; j < len && same; ++j) same = ((sy[j >> 1] >> (16 * (j & 1))) & 0xFFFFu) == ch(s0 + j);
-            } else {
-                const uint32_t* mr = P.models + size_t(t.x - 1) * 12;
-                for (int j = 0; j < len && same; ++j) same = P.syms[mr[0] + j] == ch(s0 + j);
+        if (int(t.y & kTagTokLenMask) == len && t.z == lo && t.w == hi) {
+            bool same = bmp;
+            if (!(t.y & kTagTokInline)) {
+                const uint32_t so = P.models[size_t(t.x - 1) * 12];
+                same = true;
+                for (int j = 0; j < len && same; ++j) same = P.syms[so + j] == (cps[s0 + j] & kCharMask);
             }
-            if (same) return t.x;
+            if (same) { *fast = (t.y & kTagTokFast) != 0; return t.x; }
         }
         slot = (slot + 1) & tok_mask;
     }
@@ -179,8 +190,8 @@ __device__ __forceinline__ void tag_token_by_wave(const TagParams& P, const uint
     }
     __builtin_amdgcn_wave_barrier();
     const uint32_t n_slots = mr[9] < P.n_tags ? mr[9] : P.n_tags;
-    for (uint32_t j = lane; j < n_slots; j += 64) {
-        const uint32_t cnt = P.slots[size_t(mr[8] + j) * 2], off = P.slots[size_t(mr[8] + j) * 2 + 1];
+    for (uint32_t j = lane; j < P.n_tags; j += 64) {   // the slots past the model's own are None
+        const uint32_t cnt = j < n_slots ? P.slots[size_t(mr[8] + j) * 2] : 0u, off = j < n_slots ? P.slots[size_t(mr[8] + j) * 2 + 1] : 0u;
         int32_t tag = cnt == 1 ? 0 : -1;
         if (cnt >= 2) {
             int32_t best = INT32_MIN;
@@ -195,224 +206,245 @@ __device__ __forceinline__ void tag_token_by_wave(const TagParams& P, const uint
     __builtin_amdgcn_wave_barrier();
 }
 
-__global__ __launch_bounds__(kTagThreads, 8) void tag_tokens_kernel(const TagParams P) {
+// add the weights of the collected matches: lanes over (match, score) pairs, four matches per 64 lanes, the loads of sixteen
+// matches in flight together
+__device__ __forceinline__ void tag_add_matches(const TagParams& P, TagWaveLds& L, uint32_t n_match, int lane) {
+    __builtin_amdgcn_wave_barrier();
+    for (uint32_t k0 = 0; k0 < n_match; k0 += 16) {
+        int32_t w[4];
+        uint32_t info[4];
+#pragma unroll
+        for (uint32_t q = 0; q < 4; ++q) {
+            const uint32_t k = k0 + q * 4u + (uint32_t(lane) >> 4), i = uint32_t(lane) & 15u;
+            info[q] = k < n_match ? L.f.mlist[k][1] : 0u;
+            w[q] = (k < n_match && i < (info[q] >> 8)) ? P.weights[L.f.mlist[k][0] + i] : 0;
+        }
+#pragma unroll
+        for (uint32_t q = 0; q < 4; ++q) {
+            const uint32_t i = uint32_t(lane) & 15u;
+            if (i < (info[q] >> 8)) atomicAdd(&L.f.zt[info[q] & 0xFFu][i], w[q]);   // several n-grams of one token may match
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+}
+
+// A pass over the `nq` queued tokens (they come from any of the wave's sentences): their context chars, model records and
+// bias are fetched in ONE trip -- lanes over (token, char), tokens, (token, score) -- then the n-grams of ALL of them are
+// checked in rounds of 64 (token, n-gram) pairs, the weights of the matches added, the argmax taken.
+__device__ __forceinline__ void tag_pass(const TagParams& P, TagWaveLds& L, uint32_t nq, int lane, uint32_t dbg) {
+    const uint32_t nt = P.n_tags;
+    const uint64_t below_me = (uint64_t(1) << lane) - 1;
+    __builtin_amdgcn_wave_barrier();
+    uint32_t cw[kTagPass * kCtx / 64];
+    int32_t bias[kTagPass * kTagFastZ / 64];
+    static_assert(kCtx == 16 && kTagFastZ == 16, "lanes over (token, 16 entries)");
+#pragma unroll
+    for (int q0 = 0; q0 < kTagPass * kCtx / 64; ++q0) {
+        const uint32_t t = uint32_t(q0) * 4u + (uint32_t(lane) >> 4);
+        const int k = (lane & 15) - kCtxBack;
+        const uint32_t clip = L.f.tok[t][3];
+        const bool have = t < nq && k >= -int(clip & 0xFFu) && k <= int(clip >> 8);
+        const uint64_t gp = uint64_t(L.f.tok[t][1]) | (uint64_t(L.f.tok[t][2]) << 32);
+        cw[q0] = have ? P.cps[gp + uint64_t(int64_t(k))] : 0u;
+        bias[q0] = (t < nq && !(dbg & 32u)) ? int32_t(P.mfilt[size_t(L.f.tok[t][0] - 1) * kTagFiltStride + 12u + (uint32_t(lane) & 15u)]) : 0;
+    }
+    uint4 f0 = make_uint4(0, 0, 0, 0), f1 = f0, f2 = f0;
+    if (uint32_t(lane) < nq) {
+        const uint4* fr = reinterpret_cast<const uint4*>(P.mfilt + size_t(L.f.tok[lane][0] - 1) * kTagFiltStride);
+        f0 = fr[0]; f1 = fr[1]; f2 = fr[2];
+    }
+#pragma unroll
+    for (int q0 = 0; q0 < kTagPass * kCtx / 64; ++q0) {
+        const uint32_t t = uint32_t(q0) * 4u + (uint32_t(lane) >> 4);
+        L.f.ctx[t][lane & 15] = cw[q0];
+        L.f.zt[t][lane & 15] = bias[q0];
+    }
+    __builtin_amdgcn_wave_barrier();
+    // the char entries of a model come in groups by rel_position r: the n-grams of group r END at char p + r, and the group's
+    // filter says which chars they end with -- a group the text cannot match is not enumerated at all
+    uint32_t m_count = 0;
+    if (uint32_t(lane) < nq) {
+        const uint32_t flo[4] = {f0.x, f0.z, f1.x, f1.z}, fhi[4] = {f0.y, f0.w, f1.y, f1.w};
+        uint32_t act = 0;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const uint32_t c = L.f.ctx[lane][kCtxBack + r] & kCharMask;   // 0 past the sentence's end
+            const uint32_t bit = packed_filter_bit(c);
+            const bool on = P.use_char != 0 && c != 0 && c < 0xFFFFu && (((bit < 32 ? flo[r] >> bit : fhi[r] >> (bit - 32)) & 1u) != 0);
+            if (on) { act |= 1u << r; m_count += (f2.x >> (8 * r)) & 0xFFu; }
+        }
+        const uint32_t tc = P.use_type != 0 ? (f2.z & 0xFFu) : 0u;
+        m_count += tc;
+        const uint32_t n_slots = ((f2.z >> 16) & 0xFFu) < nt ? ((f2.z >> 16) & 0xFFu) : nt;
+        L.f.tok[lane][4] = f2.y; L.f.tok[lane][5] = ((f2.z >> 8) & 0xFFu) | (n_slots << 8) | (tc << 16) | (act << 24);
+        L.f.tok[lane][6] = f2.w; L.f.tok[lane][7] = f2.x;
+    }
+    const uint32_t incl = wave_inclusive_scan(m_count);
+    const uint32_t total = (dbg & 4u) ? 0u : uint32_t(__builtin_amdgcn_readlane(int(incl), 63));
+    if (uint32_t(lane) < nq) L.f.pref[lane] = incl - m_count;
+    if (uint32_t(lane) == nq) L.f.pref[nq] = total;
+    __builtin_amdgcn_wave_barrier();
+    uint32_t n_acc = 0;   // matches waiting in mlist
+    for (uint32_t r0 = 0; r0 < total; r0 += 64) {
+        const uint32_t pi = r0 + uint32_t(lane);
+        const bool have = pi < total;
+        uint32_t t = 0, ri = 0;
+        if (have) {   // the token of this pair: the last t with pref[t] <= pi
+            uint32_t lo = 0, hi = nq;   // pref[lo] <= pi < pref[hi]
+            while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (L.f.pref[mid] <= pi) lo = mid; else hi = mid; }
+            t = lo;
+            // the k-th entry of the token's ACTIVE groups (then its type entries) -> record index
+            uint32_t k = pi - L.f.pref[t], off = L.f.tok[t][4];
+            const uint32_t groups = L.f.tok[t][7], act = L.f.tok[t][5] >> 24;
+            bool placed = false;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const uint32_t c = (groups >> (8 * r)) & 0xFFu;
+                if (!placed && ((act >> r) & 1u)) { if (k < c) { ri = off + k; placed = true; } else k -= c; }
+                off += c;
+            }
+            if (!placed) ri = off + k;   // a type entry
+        }
+        const uint4 ra = have ? reinterpret_cast<const uint4*>(P.nrec)[size_t(ri) * 2] : make_uint4(0, 0, 0, 0);
+        const uint4 rb = have ? reinterpret_cast<const uint4*>(P.nrec)[size_t(ri) * 2 + 1] : make_uint4(0, 0, 0, 0);
+        // the longest n-gram of this round bounds the compare loop (wave-uniform: no lane runs 12 steps for 3-char n-grams)
+        uint32_t gmax = wave_max(ra.x & 0xFFu);
+        gmax = gmax < kTagFastSyms ? gmax : kTagFastSyms;
+        const uint32_t glen = ra.x & 0xFFu, rel = (ra.x >> 8) & 0xFFu, kind = (ra.x >> 16) & 1u;
+        const uint32_t clip = have ? L.f.tok[t][3] : 0u;
+        // chars [p + rel + 1 - glen, p + rel + 1) of the sentence: inside it, and inside the context (glen <= 12, rel <= 3)
+        bool ok = have && glen != 0 && glen <= rel + 1u + (clip & 0xFFu) && rel <= (clip >> 8) && (kind == 0 ? P.use_char != 0 : P.use_type != 0);
+        // the record's symbols as a 192-bit shift register: the next one is always the low 16 bits
+        uint32_t s0w = ra.z, s1w = ra.w, s2w = rb.x, s3w = rb.y, s4w = rb.z, s5w = rb.w;
+        const uint32_t wbeg = (uint32_t(kCtxBack) + 1u + rel - glen) & uint32_t(kCtx - 1);
+        for (uint32_t j = 0; j < gmax; ++j) {
+            if (j < glen && ok) {
+                const uint32_t c = L.f.ctx[t][(wbeg + j) & uint32_t(kCtx - 1)];
+                ok = (s0w & 0xFFFFu) == (kind == 0 ? (c & kCharMask) : (c >> 24));
+            }
+            s0w = (s0w >> 16) | (s1w << 16); s1w = (s1w >> 16) | (s2w << 16); s2w = (s2w >> 16) | (s3w << 16);
+            s3w = (s3w >> 16) | (s4w << 16); s4w = (s4w >> 16) | (s5w << 16); s5w >>= 16;
+        }
+        const uint64_t m0 = __ballot(ok);
+        if (ok) {
+            const uint32_t k = n_acc + uint32_t(__popcll(m0 & below_me));
+            const uint32_t zlen = L.f.tok[t][5] & 0xFFu;
+            const uint32_t wl = (ra.x >> 24) < zlen ? (ra.x >> 24) : zlen;   // zip: the shorter of the two (predictor.rs:82-89)
+            L.f.mlist[k][0] = ra.y; L.f.mlist[k][1] = t | (wl << 8);
+        }
+        n_acc += uint32_t(__popcll(m0));
+        if (n_acc > uint32_t(kMatchCap - 64)) {   // the next round may not fit
+            if (!(dbg & 8u)) tag_add_matches(P, L, n_acc, lane);
+            n_acc = 0;
+        }
+    }
+    if (n_acc != 0 && !(dbg & 8u)) tag_add_matches(P, L, n_acc, lane);
+    __builtin_amdgcn_wave_barrier();
+    // argmax per (token, slot) (TagPredictor::predict, predictor.rs:286-304)
+    for (uint32_t a0 = 0; a0 < ((dbg & 16u) ? 0u : nq * nt); a0 += 64) {
+        const uint32_t a = a0 + uint32_t(lane);
+        if (a < nq * nt) {
+            const uint32_t t = a / nt, j = a - t * nt;
+            const uint32_t info = L.f.tok[t][5], zlen = info & 0xFFu, n_slots = (info >> 8) & 0xFFu;
+            const uint32_t ps = j < n_slots ? L.f.tok[t][6] >> (9 * j) : 0u, cnt = ps & 31u, off = (ps >> 5) & 15u;
+            int32_t tag = cnt == 1 ? 0 : -1;   // None: no candidates, or a slot this model does not have
+            if (cnt >= 2) {
+                int32_t best = INT32_MIN;
+                tag = 0;
+                for (uint32_t c = 0; c < cnt && off + c < zlen; ++c) {
+                    const int32_t v = L.f.zt[t][off + c];
+                    if (v > best) { best = v; tag = int32_t(c); }
+                }
+            }
+            const uint64_t gp = uint64_t(L.f.tok[t][1]) | (uint64_t(L.f.tok[t][2]) << 32);
+            P.tags[gp * nt + j] = tag;
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+}
+
+template <bool DBG>
+__global__ __launch_bounds__(kTagThreads, 8) void tag_tokens_kernel(const TagParams P, const uint32_t dbg_in) {
+    const uint32_t dbg = DBG ? dbg_in : 0u;   // timing ablations (VPT_DEBUG_TAGS; results are wrong with any bit set)
     __shared__ TagLds LDS;
     const int lane = threadIdx.x & 63;
-    TagWaveLds& L = LDS.w[threadIdx.x >> 6];
-    volatile int32_t* z = L.z;
-    const uint64_t wave = uint64_t(blockIdx.x) * kTagWaves + (threadIdx.x >> 6);
+    const uint32_t wid = wave_uniform(threadIdx.x >> 6);     // a scalar, and everything derived from it below
+    TagWaveLds& L = LDS.w[wid];
+    const uint64_t wave = uint64_t(blockIdx.x) * kTagWaves + wid;
     const uint64_t n_waves = uint64_t(gridDim.x) * kTagWaves;
     const uint32_t nt = P.n_tags;
+    const uint64_t below_me = (uint64_t(1) << lane) - 1;
+    uint32_t nq = 0;   // queued tokens (wave-uniform)
     for (uint64_t si = wave; si < P.n_sent; si += n_waves) {
-        const uint64_t g0 = P.ooff[si] + si;                     // flat index of the sentence's first char
-        if (P.ooff[si + 1] < P.ooff[si] || P.ooff[si + 1] + si + 1 > P.total_chars) continue;   // reported by decode_chars_kernel
-        if (P.ooff[si + 1] - P.ooff[si] >= 0x7FFFFF00ull) continue;   // (a sentence of 2^31 chars: not in this kernel's index width)
-        const int n = int(P.ooff[si + 1] - P.ooff[si]) + 1;  // chars
+        const uint64_t o0 = wave_uniform64(P.ooff[si]), o1 = wave_uniform64(P.ooff[si + 1]);
+        const uint64_t g0 = o0 + si;                            // flat index of the sentence's first char
+        // offsets that do not fit the batch are reported by decode_chars_kernel / the scoring kernel; such a sentence (and one of
+        // 2^31 chars: not in this kernel's index width) is taken as empty here
+        const bool sane = o1 >= o0 && o1 + si + 1 <= P.total_chars && o1 - o0 < 0x7FFFFF00ull;
+        const int n = sane ? int(o1 - o0) + 1 : 0;  // chars
+        const bool last_sentence = si + n_waves >= P.n_sent;    // of this wave: its last step empties the queue
         const uint32_t* cps = P.cps + g0;
-        const uint8_t* lab = P.labels + P.ooff[si];              // n - 1 labels
+        const uint8_t* lab = P.labels + o0;                      // n - 1 labels
         int start = 0;              // where the token that is open at the beginning of this step started
         bool have_start = true;     // ... and no Unknown boundary has been seen inside it (predictor.rs:566-567)
-        for (int base = 0; base < n; base += 64) {
+        // the step's chars and labels are fetched one step ahead
+        uint32_t c_next = lane < n ? cps[lane] : 0u;
+        uint32_t b_next = lane < n - 1 ? uint32_t(lab[lane]) : (lane == n - 1 ? 1u : 0u);
+        for (int base = 0; base == 0 || base < n; base += 64) {
             const int p = base + lane;
-            const uint32_t b = p < n ? (p == n - 1 ? 1u : uint32_t(lab[p])) : 0u;
-            // the text window of this step
-            for (int w = lane; w < kWin; w += 64) {
-                const int q = base - kWinBack + w;
-                L.txt[w] = (q >= 0 && q < n) ? cps[q] : 0u;
+            const uint32_t c = c_next, b = b_next;
+            {
+                const int pn = p + 64;
+                c_next = pn < n ? cps[pn] : 0u;
+                b_next = pn < n - 1 ? uint32_t(lab[pn]) : (pn == n - 1 ? 1u : 0u);
             }
+            L.txt[p & (kRing - 1)] = c;
             const uint64_t ends = __ballot(b == 1u), unk = __ballot(b == 2u);
             __builtin_amdgcn_wave_barrier();
             // ---- (1) this lane's token, if its char ends one: [s0, p], valid when no Unknown lies inside
-            const uint64_t below_me = (uint64_t(1) << lane) - 1;
             const uint64_t prev_ends = ends & below_me;
             const int prev = prev_ends ? 63 - __clzll((long long)prev_ends) : -1;
             const int s0 = prev >= 0 ? base + prev + 1 : start;
             const uint64_t after_prev = prev >= 0 ? ~((uint64_t(2) << prev) - 1) : ~uint64_t(0);
             const bool valid = b == 1u && (unk & below_me & after_prev) == 0 && (prev >= 0 || have_start);
-            const uint32_t model = valid ? find_tag_model(P, cps, L.txt, base, s0, p) : 0u;
-            if (valid && P.tok_model) P.tok_model[g0 + uint64_t(p)] = int32_t(model);   // 0: no tag model for this surface
-            // the model record: first record, counts, bias offset, zlen, slots (one trip: three 16-byte loads)
-            uint32_t m_first = 0, m_count = 0, m_zlen = 0, m_bias = 0, m_pslots = 0, m_nslots = 0, m_groups = 0, m_tc = 0, m_act = 0;
             bool fast = false;
-            if (model != 0) {
-                const uint4* mr = reinterpret_cast<const uint4*>(P.models + size_t(model - 1) * 12);
-                const uint4 r0 = mr[0], r1 = mr[1], r2 = mr[2];   // dwords 0..3, 4..7, 8..11
-                fast = (r2.z & 1u) != 0;
-                m_first = r0.z; m_bias = r1.z; m_zlen = r1.w; m_pslots = r2.w;
-                m_nslots = r2.y < nt ? r2.y : nt;
-                if (fast) {
-                    // the char entries come in groups by rel_position r: the n-grams of group r END at char p + r, and the group's
-                    // filter says which chars they end with -- a group the text cannot match is not enumerated at all
-                    const uint4* fr = reinterpret_cast<const uint4*>(P.mfilt + size_t(model - 1) * 12);
-                    const uint4 f0 = fr[0], f1 = fr[1], f2 = fr[2];
-                    const uint32_t flo[4] = {f0.x, f0.z, f1.x, f1.z}, fhi[4] = {f0.y, f0.w, f1.y, f1.w};
-                    m_groups = f2.x;
-                    uint32_t act = 0;
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const uint32_t c = p + r < n ? (L.txt[p + r - base + kWinBack] & kCharMask) : 0u;
-                        const uint32_t bit = packed_filter_bit(c);
-                        const bool on = P.use_char != 0 && c != 0 && c < 0xFFFFu && (((bit < 32 ? flo[r] >> bit : fhi[r] >> (bit - 32)) & 1u) != 0);
-                        if (on) { act |= 1u << r; m_count += (m_groups >> (8 * r)) & 0xFFu; }
+            uint32_t model = (valid && !(dbg & 1u)) ? find_tag_model(P, cps, L.txt, base, s0, p, &fast) : 0u;
+            if (dbg & 2u) model = 0;
+            // every char of the sentence gets its entries here or below (nothing is cleared beforehand): 0 / None where no token with a
+            // tag model ends, the rest from the argmax of the token's scores
+            if (p < n) {
+                if (P.tok_model) P.tok_model[g0 + uint64_t(p)] = int32_t(model);   // 0: no tag model for this surface
+                if (model == 0) for (uint32_t j = 0; j < nt; ++j) P.tags[(g0 + uint64_t(p)) * nt + j] = -1;
+            }
+            if (dbg & 64u) model = 0;
+            // ---- (2) the tokens whose model fits the record form join the queue; a full queue is a pass
+            const uint64_t qmask = __ballot(model != 0 && fast);
+            uint64_t todo = __ballot(model != 0 && !fast);   // the models outside the record form: their routine's scores take the queue's place
+            const bool drain = todo != 0 || (last_sentence && base + 64 >= n);
+            if (qmask != 0 || (drain && nq != 0)) {
+                const uint32_t rank = uint32_t(__popcll(qmask & below_me));
+                uint32_t remaining = uint32_t(__popcll(qmask)), done = 0;
+                for (;;) {
+                    const uint32_t room = uint32_t(kTagPass) - nq, take = remaining < room ? remaining : room;
+                    if (model != 0 && fast && rank >= done && rank < done + take) {
+                        const uint32_t row = nq + rank - done;
+                        const uint64_t gp = g0 + uint64_t(p);
+                        const uint32_t back = p < kCtxBack ? uint32_t(p) : uint32_t(kCtxBack);
+                        const uint32_t fwd = n - 1 - p < kCtx - 1 - kCtxBack ? uint32_t(n - 1 - p) : uint32_t(kCtx - 1 - kCtxBack);
+                        L.f.tok[row][0] = model; L.f.tok[row][1] = uint32_t(gp); L.f.tok[row][2] = uint32_t(gp >> 32); L.f.tok[row][3] = back | (fwd << 8);
                     }
-                    m_tc = P.use_type != 0 ? r1.y : 0u;
-                    m_count += m_tc;
-                    m_act = act;
+                    nq += take; done += take; remaining -= take;
+                    if (!(nq == uint32_t(kTagPass) || (nq != 0 && remaining == 0 && drain))) break;
+                    tag_pass(P, L, nq, lane, dbg);
+                    nq = 0;
+                    if (!remaining) break;
                 }
             }
-            const uint64_t fmask = __ballot(fast);
-            const uint32_t n_fast = uint32_t(__popcll(fmask));
-            const uint32_t rank = uint32_t(__popcll(fmask & below_me));
-            // ---- (2) the tokens whose model fits the record form, kTagPass at a time
-            for (uint32_t t0 = 0; t0 < n_fast; t0 += kTagPass) {
-                const bool mine = fast && rank >= t0 && rank < t0 + kTagPass;
-                const uint32_t t_me = rank - t0;
-                const uint32_t n_pass = n_fast - t0 < uint32_t(kTagPass) ? n_fast - t0 : uint32_t(kTagPass);
-                // exclusive prefix of the record counts over the pass's tokens (wave scan; the other lanes add 0)
-                const uint32_t incl = wave_inclusive_scan(mine ? m_count : 0u);
-                const uint32_t total = uint32_t(__builtin_amdgcn_readlane(int(incl), 63));
-                if (mine) {
-                    L.f.tok[t_me][0] = m_first; L.f.tok[t_me][1] = uint32_t(p - base) | (m_zlen << 8) | (m_nslots << 16);
-                    L.f.tok[t_me][2] = m_bias; L.f.tok[t_me][3] = m_pslots; L.f.tok[t_me][4] = m_groups; L.f.tok[t_me][5] = m_tc | (m_act << 8);
-                    L.f.pref[t_me] = incl - m_count;
-                }
-                if (lane == 0) L.f.pref[n_pass] = total;
-                __builtin_amdgcn_wave_barrier();
-                {   // the scores start as the models' bias: lanes over (token, score) pairs, every load of the pass in flight together
-                    int32_t bias[kTagPass * kTagFastZ / 64];
-#pragma unroll
-                    for (int q0 = 0; q0 < kTagPass * int(kTagFastZ) / 64; ++q0) {
-                        const uint32_t q = uint32_t(q0) * 64u + uint32_t(lane), t = q / kTagFastZ, i = q % kTagFastZ;
-                        bias[q0] = (t < n_pass && i < ((L.f.tok[t][1] >> 8) & 0xFFu)) ? P.weights[L.f.tok[t][2] + i] : 0;
-                    }
-#pragma unroll
-                    for (int q0 = 0; q0 < kTagPass * int(kTagFastZ) / 64; ++q0) {
-                        const uint32_t q = uint32_t(q0) * 64u + uint32_t(lane);
-                        L.f.zt[q / kTagFastZ][q % kTagFastZ] = bias[q0];
-                    }
-                }
-                __builtin_amdgcn_wave_barrier();
-                // rounds of 64 * kPairs (token, record) pairs: every record load of a round is in flight together
-                for (uint32_t r0 = 0; r0 < total; r0 += 64 * kPairs) {
-                    uint32_t tk[kPairs], hdr[kPairs], woff[kPairs];
-                    bool same[kPairs];
-                    uint4 ra[kPairs], rb[kPairs];
-#pragma unroll
-                    for (int u = 0; u < kPairs; ++u) {
-                        const uint32_t pi = r0 + uint32_t(u) * 64u + uint32_t(lane);
-                        const bool have = pi < total;
-                        uint32_t t = 0;
-                        if (have) {   // the token of this pair: the last t with pref[t] <= pi
-                            uint32_t lo = 0, hi = n_pass;   // pref[lo] <= pi < pref[hi]
-                            while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (L.f.pref[mid] <= pi) lo = mid; else hi = mid; }
-                            t = lo;
-                        }
-                        tk[u] = t;
-                        same[u] = have;
-                        uint32_t ri = 0;
-                        if (have) {   // the k-th entry of the token's ACTIVE groups (then its type entries) -> record index
-                            uint32_t k = pi - L.f.pref[t], off = L.f.tok[t][0];
-                            const uint32_t groups = L.f.tok[t][4], act = L.f.tok[t][5] >> 8;
-                            bool placed = false;
-#pragma unroll
-                            for (int r = 0; r < 4; ++r) {
-                                const uint32_t c = (groups >> (8 * r)) & 0xFFu;
-                                if (!placed && ((act >> r) & 1u)) { if (k < c) { ri = off + k; placed = true; } else k -= c; }
-                                off += c;
-                            }
-                            if (!placed) ri = off + k;   // a type entry
-                        }
-                        ra[u] = have ? reinterpret_cast<const uint4*>(P.nrec)[size_t(ri) * 2] : make_uint4(0, 0, 0, 0);
-                        rb[u] = have ? reinterpret_cast<const uint4*>(P.nrec)[size_t(ri) * 2 + 1] : make_uint4(0, 0, 0, 0);
-                    }
-                    // the longest n-gram of this round bounds the compare loops (wave-uniform: no lane runs 12 steps for 3-char n-grams)
-                    uint32_t gmax = wave_max(kPairs == 2 ? ((ra[0].x & 0xFFu) > (ra[kPairs - 1].x & 0xFFu) ? (ra[0].x & 0xFFu) : (ra[kPairs - 1].x & 0xFFu)) : (ra[0].x & 0xFFu));
-                    gmax = gmax < kTagFastSyms ? gmax : kTagFastSyms;
-#pragma unroll
-                    for (int u = 0; u < kPairs; ++u) {
-                        const uint32_t glen = ra[u].x & 0xFFu, rel = (ra[u].x >> 8) & 0xFFu, kind = (ra[u].x >> 16) & 1u;
-                        const int e = base + int(same[u] ? L.f.tok[tk[u]][1] & 0xFFu : 0u);
-                        const int endp = e + int(rel) + 1, beg = endp - int(glen);
-                        bool ok = same[u] && glen != 0 && beg >= 0 && endp <= n && (kind == 0 ? P.use_char != 0 : P.use_type != 0);
-                        // beg >= base - 11 and endp <= base + 72 (glen <= 12, rel <= the window <= 8): inside the LDS window
-                        // the record's symbols as a 192-bit shift register: the next one is always the low 16 bits
-                        uint32_t s0w = ra[u].z, s1w = ra[u].w, s2w = rb[u].x, s3w = rb[u].y, s4w = rb[u].z, s5w = rb[u].w;
-                        const int wbeg = beg - base + kWinBack;
-                        for (uint32_t j = 0; j < gmax; ++j) {
-                            if (j < glen && ok) {
-                                const uint32_t c = L.txt[(wbeg + int(j)) & (kWin - 1)];
-                                ok = (s0w & 0xFFFFu) == (kind == 0 ? (c & kCharMask) : (c >> 24));
-                            }
-                            s0w = (s0w >> 16) | (s1w << 16); s1w = (s1w >> 16) | (s2w << 16); s2w = (s2w >> 16) | (s3w << 16);
-                            s3w = (s3w >> 16) | (s4w << 16); s4w = (s4w >> 16) | (s5w << 16); s5w >>= 16;
-                        }
-                        same[u] = ok;
-                        hdr[u] = ra[u].x; woff[u] = ra[u].y;
-                    }
-                    // the matches of the round, compacted; then lanes over (match, score) pairs add the weights: four matches per
-                    // 64 lanes, the loads of up to sixteen matches in flight together
-                    const uint64_t m0 = __ballot(same[0]), m1 = kPairs == 2 ? __ballot(same[kPairs - 1]) : 0;
-                    const uint32_t n0m = uint32_t(__popcll(m0)), n_match = n0m + uint32_t(__popcll(m1));
-                    if (n_match != 0) {
-#pragma unroll
-                        for (int u = 0; u < kPairs; ++u) {
-                            if (same[u]) {
-                                const uint32_t k = (u ? n0m : 0u) + uint32_t(__popcll((u ? m1 : m0) & below_me));
-                                const uint32_t zlen = (L.f.tok[tk[u]][1] >> 8) & 0xFFu;
-                                const uint32_t wl = (hdr[u] >> 24) < zlen ? (hdr[u] >> 24) : zlen;   // zip: the shorter of the two (predictor.rs:82-89)
-                                L.f.mlist[k][0] = woff[u]; L.f.mlist[k][1] = tk[u] | (wl << 8);
-                            }
-                        }
-                        __builtin_amdgcn_wave_barrier();
-                        for (uint32_t k0 = 0; k0 < n_match; k0 += 16) {
-                            int32_t w[4];
-                            uint32_t info[4];
-#pragma unroll
-                            for (uint32_t q = 0; q < 4; ++q) {
-                                const uint32_t k = k0 + q * 4u + (uint32_t(lane) >> 4), i = uint32_t(lane) & 15u;
-                                info[q] = k < n_match ? L.f.mlist[k][1] : 0u;
-                                w[q] = (k < n_match && i < (info[q] >> 8)) ? P.weights[L.f.mlist[k][0] + i] : 0;
-                            }
-#pragma unroll
-                            for (uint32_t q = 0; q < 4; ++q) {
-                                const uint32_t i = uint32_t(lane) & 15u;
-                                if (i < (info[q] >> 8)) atomicAdd(&L.f.zt[info[q] & 0xFFu][i], w[q]);   // several n-grams of one token may match
-                            }
-                        }
-                        __builtin_amdgcn_wave_barrier();
-                    }
-                }
-                __builtin_amdgcn_wave_barrier();
-                // ---- (3) argmax per (token, slot) (TagPredictor::predict, predictor.rs:286-304)
-                for (uint32_t a0 = 0; a0 < n_pass * nt; a0 += 64) {
-                    const uint32_t a = a0 + uint32_t(lane);
-                    if (a < n_pass * nt) {
-                        const uint32_t t = a / nt, j = a - t * nt;
-                        const uint32_t info = L.f.tok[t][1], zlen = (info >> 8) & 0xFFu, n_slots = info >> 16;
-                        if (j < n_slots) {
-                            const uint32_t ps = L.f.tok[t][3] >> (9 * j), cnt = ps & 31u, off = (ps >> 5) & 15u;
-                            int32_t tag = cnt == 1 ? 0 : -1;
-                            if (cnt >= 2) {
-                                int32_t best = INT32_MIN;
-                                tag = 0;
-                                for (uint32_t c = 0; c < cnt && off + c < zlen; ++c) {
-                                    const int32_t v = L.f.zt[t][off + c];
-                                    if (v > best) { best = v; tag = int32_t(c); }
-                                }
-                            }
-                            P.tags[(g0 + uint64_t(uint32_t(base) + (info & 0xFFu))) * nt + j] = tag;
-                        }
-                    }
-                }
-                __builtin_amdgcn_wave_barrier();
-            }
-            // ---- the models outside the record form: the whole wave, one token at a time
-            uint64_t todo = __ballot(model != 0 && !fast);
-            while (todo) {   // wave-uniform
+            while (todo) {   // wave-uniform: the whole wave, one token at a time
                 const int k = __ffsll((long long)todo) - 1;
                 todo &= todo - 1;
                 const uint32_t mk = uint32_t(__shfl(int(model), k));
-                tag_token_by_wave(P, cps, n, base + k, g0, mk, z, lane);
+                tag_token_by_wave(P, cps, n, base + k, g0, mk, L.z, lane);
             }
             // the token that stays open into the next step
             if (ends) {
@@ -422,7 +454,7 @@ __global__ __launch_bounds__(kTagThreads, 8) void tag_tokens_kernel(const TagPar
             } else if (unk) {
                 have_start = false;
             }
-            __builtin_amdgcn_wave_barrier();   // the window is rewritten by the next step
+            __builtin_amdgcn_wave_barrier();   // the ring is written by the next step
         }
     }
 }
@@ -439,9 +471,13 @@ hipError_t launch_decode_chars(const uint8_t* text, const uint64_t* boff, const 
 }
 
 hipError_t launch_tag_tokens(const TagParams& P, hipStream_t stream) {
-    const uint64_t want = (P.n_sent + kTagWaves - 1) / kTagWaves;
-    const uint32_t blocks = uint32_t(want < 1 ? 1 : want > 65536 ? 65536 : want);
-    hipLaunchKernelGGL(tag_tokens_kernel, dim3(blocks), dim3(kTagThreads), 0, stream, P);
+    // sentences differ in length (8..512 chars in BASELINE's configs[4]): a grid of one wave per sentence leaves the waves of a
+    // workgroup waiting for its longest one, so the waves stay (P.max_blocks = what the device runs at a time) and stride over the batch
+    const uint64_t want = (P.n_sent + kTagWaves - 1) / kTagWaves, cap = P.max_blocks ? P.max_blocks : 65536;
+    const uint32_t blocks = uint32_t(want < 1 ? 1 : want > cap ? cap : want);
+    static const uint32_t dbg = [] { const char* e = std::getenv("VPT_DEBUG_TAGS"); return e ? uint32_t(std::atoi(e)) : 0u; }();
+    if (dbg) hipLaunchKernelGGL(tag_tokens_kernel<true>, dim3(blocks), dim3(kTagThreads), 0, stream, P, dbg);
+    else hipLaunchKernelGGL(tag_tokens_kernel<false>, dim3(blocks), dim3(kTagThreads), 0, stream, P, 0u);
     return hipGetLastError();
 }
 

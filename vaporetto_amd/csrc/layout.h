@@ -139,6 +139,17 @@ VPT_HD uint32_t hash_slot(uint64_t key, uint32_t shift) {
 VPT_HD uint32_t packed_mini_slot(uint32_t sym, uint32_t ref) { return ((sym * kHashMulLo) >> 15) & ((1u << (ref & 31u)) - 1u); }
 VPT_HD uint32_t packed_filter_bit(uint32_t sym) { return (sym * kHashMulHi) >> 26; }   // 0..63
 
+// Tag token table (HostTagTables::tok_tab): a surface is hashed from its length and the low 16 bits of its first four chars
+// (lo = c0 | c1 << 16, hi = c2 | c3 << 16, zero past the end) -- a lane builds the key with four reads and no loop over the
+// token; surfaces that agree in both share a probe sequence and are told apart by the slot.  The top bits are the slot.
+VPT_HD uint32_t tag_token_hash_key(uint32_t lo, uint32_t hi, uint32_t len) {
+    uint32_t h = lo * kHashMulLo + hi * kHashMulHi + len * 0x7FEB352Du;
+    h ^= h >> 15;
+    return h * kHashMulLo;
+}
+constexpr uint32_t kTagTokInline = 1u << 31, kTagTokFast = 1u << 30, kTagTokLenMask = (1u << 30) - 1u;
+constexpr uint32_t kTagFiltStride = 28;   // dwords per model in HostTagTables::mfilt
+
 // signed `bits`-wide field number j of a 128-bit little-endian row (unigram rows, bigram rows)
 VPT_HD int32_t row_field(uint32_t x, uint32_t y, uint32_t z, uint32_t w, int j, int bits) {
     const uint32_t d[5] = {x, y, z, w, 0u};

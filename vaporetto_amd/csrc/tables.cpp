@@ -667,10 +667,9 @@ std::vector<int32_t> build_type_window_table(const std::vector<NgramRecord>& ngr
 }  // namespace
 
 uint32_t tag_token_hash(const uint32_t* cps, size_t n) {
-    uint32_t h = 0x811C9DC5u;
-    for (size_t i = 0; i < n; ++i) h = (h ^ cps[i]) * 0x01000193u;
-    h ^= h >> 15;
-    return h * kHashMulLo;
+    uint32_t k[4] = {0, 0, 0, 0};
+    for (size_t i = 0; i < n && i < 4; ++i) k[i] = cps[i] & 0xFFFFu;
+    return tag_token_hash_key(k[0] | (k[1] << 16), k[2] | (k[3] << 16), uint32_t(n));
 }
 
 namespace {
@@ -735,12 +734,6 @@ HostTagTables build_tag_tables(const ModelData& m, bool use_char, bool use_type)
         // the fast path walks char and type entries as one run of records
         const bool fast_model = all_compact && rel_ok && rec[4] == rec[2] + rec[3] && tm.bias.size() <= kTagFastZ && tm.tags.size() <= 3 &&
                                 rel_count[0] < 256 && rel_count[1] < 256 && rel_count[2] < 256 && rel_count[3] < 256 && rec[5] < 256;
-        {   // mfilt: per rel_position 0..3 the filter over the last chars of the group's n-grams, then the group sizes
-            uint32_t f[12] = {0};
-            for (int r = 0; r < 4; ++r) { f[2 * r] = uint32_t(rel_filter[r]); f[2 * r + 1] = uint32_t(rel_filter[r] >> 32); }
-            f[8] = rel_count[0] | (rel_count[1] << 8) | (rel_count[2] << 16) | (rel_count[3] << 24);
-            t.mfilt.insert(t.mfilt.end(), f, f + 12);
-        }
         rec[6] = uint32_t(t.weights.size()); rec[7] = uint32_t(tm.bias.size());
         t.weights.insert(t.weights.end(), tm.bias.begin(), tm.bias.end());
         if (tm.bias.size() > kTagMaxZ) throw ModelError("InvalidModelError: more than 1024 tag scores per token are not supported");
@@ -766,6 +759,18 @@ HostTagTables build_tag_tables(const ModelData& m, bool use_char, bool use_type)
                 rec[11] |= (t.slots[size_t(rec[8] + j) * 2] | (t.slots[size_t(rec[8] + j) * 2 + 1] << 5)) << (9 * j);   // <= 16 candidates, offset <= 15
         }
         t.models.insert(t.models.end(), rec, rec + 12);
+        {   // mfilt: everything the fast path needs of a model in one record
+            uint32_t f[kTagFiltStride] = {0};
+            for (int r = 0; r < 4; ++r) { f[2 * r] = uint32_t(rel_filter[r]); f[2 * r + 1] = uint32_t(rel_filter[r] >> 32); }
+            f[8] = rel_count[0] | (rel_count[1] << 8) | (rel_count[2] << 16) | (rel_count[3] << 24);
+            if (fast_model) {
+                f[9] = rec[2];
+                f[10] = rec[5] | (uint32_t(tm.bias.size()) << 8) | (uint32_t(tm.tags.size()) << 16);
+                f[11] = rec[11];
+                for (size_t i = 0; i < tm.bias.size(); ++i) f[12 + i] = uint32_t(tm.bias[i]);
+            }
+            t.mfilt.insert(t.mfilt.end(), f, f + kTagFiltStride);
+        }
         // token table: a repeated token keeps its slot and takes the later model
         uint32_t b = tag_token_hash(tm.token.data(), tm.token.size()) >> (32 - t.tok_bits);
         for (;;) {
@@ -777,10 +782,10 @@ HostTagTables build_tag_tables(const ModelData& m, bool use_char, bool use_type)
             e[0] = mi + 1;
             bool inl = tm.token.size() <= 4;
             for (Sym c : tm.token) inl = inl && c < 0xFFFFu;
-            e[1] = uint32_t(tm.token.size()) | (inl ? 0x80000000u : 0u);
-            e[2] = e[3] = 0;
-            if (inl)
-                for (size_t j = 0; j < tm.token.size(); ++j) e[2 + j / 2] |= tm.token[j] << (16 * (j & 1));
+            if (tm.token.size() > kTagTokLenMask) throw ModelError("InvalidModelError: tag token too long");
+            e[1] = uint32_t(tm.token.size()) | (inl ? kTagTokInline : 0u) | (fast_model ? kTagTokFast : 0u);
+            e[2] = e[3] = 0;   // the hashed key: low 16 bits of the first four chars (the whole surface when inline)
+            for (size_t j = 0; j < tm.token.size() && j < 4; ++j) e[2 + j / 2] |= (tm.token[j] & 0xFFFFu) << (16 * (j & 1));
             break;
         }
     }
@@ -788,7 +793,7 @@ HostTagTables build_tag_tables(const ModelData& m, bool use_char, bool use_type)
     if (t.weights.empty()) t.weights.push_back(0);
     if (t.ngrams.empty()) t.ngrams.assign(4, 0);
     if (t.nrec.empty()) t.nrec.assign(8, 0);
-    if (t.mfilt.empty()) t.mfilt.assign(12, 0);
+    if (t.mfilt.empty()) t.mfilt.assign(kTagFiltStride, 0);
     if (t.slots.empty()) t.slots.assign(2, 0);
     if (t.slot_str.empty()) t.slot_str.push_back(0);
     t.str_off.push_back(uint32_t(t.str_bytes.size()));   // the end of the last string

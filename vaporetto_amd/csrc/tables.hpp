@@ -46,10 +46,11 @@ struct HostPackedTable {
 };
 
 // Tag prediction tables (Predictor::predict_tags, predictor.rs:546-637), see kernels_tags.hip.
-//   tok_tab   open addressing over token surfaces, 4 dwords per slot: model index + 1 (0 = empty), len | inline << 31,
-//             sym0 | sym1 << 16, sym2 | sym3 << 16 -- a token of at most 4 symbols below 0xFFFF is verified from the slot
-//             itself (inline), a longer one against `syms` through its model record; the LAST model of a repeated
-//             token wins, like HashMap::insert in predictor.rs:466-478
+//   tok_tab   open addressing over token surfaces, 4 dwords per slot: model index + 1 (0 = empty), len | fast << 30 | inline << 31,
+//             then the hashed key (layout.h, tag_token_hash_key): the low 16 bits of the first four chars.  inline = at most 4
+//             symbols, all below 0xFFFF: the key IS the surface; any other candidate is verified against `syms` through its
+//             model record.  fast = the model fits the record form below.  The LAST model of a repeated token wins, like
+//             HashMap::insert in predictor.rs:466-478
 //   models    12 dwords per tag model: sym_off, sym_len, char-ngram first/count, type-ngram first/count, bias_off, zlen,
 //             slot first/count, 0, 0
 //   ngrams    4 dwords per (tag n-gram, rel_position): sym_off, len | rel << 24, w_off, wlen
@@ -59,9 +60,11 @@ struct HostPackedTable {
 //             the n-gram has at most 12 symbols, all below 0xFFFF.  models[10] bit 0 = every entry of the model is compact,
 //             its char and type entries are adjacent, it has at most 16 scores and at most 3 slots: the fast path may take its
 //             tokens; models[11] then packs the slots: (candidates | score offset << 5) << (9 * slot).
-//   mfilt     12 dwords per tag model: the char entries of a model are ordered by rel_position; dwords 2r, 2r+1 = a 64-bit filter
-//             over packed_filter_bit(last symbol) of the n-grams with rel_position r (0..3), dword 8 = the four group sizes, 8 bits
-//             each -- a token whose text has no candidate last char at offset r skips the whole group.
+//   mfilt     28 dwords per tag model, all the fast path reads of a model: the char entries of a model are ordered by rel_position;
+//             dwords 2r, 2r+1 = a 64-bit filter over packed_filter_bit(last symbol) of the n-grams with rel_position r (0..3), dword 8 =
+//             the four group sizes, 8 bits each -- a token whose text has no candidate last char at offset r skips the whole group;
+//             for a model in the record form also dword 9 = its first record, 10 = type entries | scores << 8 | slots << 16,
+//             11 = models[11], 12..27 = the bias, zero padded.
 //   slots     2 dwords per tag slot: candidate count, offset of its scores in z (slots with >= 2 candidates)
 //   slot_str  per tag slot: index of its first candidate in str_off; str_off[k] .. str_off[k+1] = the bytes of candidate
 //             string k in str_bytes, ALREADY escaped the way Sentence::write_tokenized_text writes a tag (sentence.rs:871-880)
