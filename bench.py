@@ -313,7 +313,34 @@ class Runner:
             e2e = {"boundaries_per_s": nb / dt, "ms_per_batch": 1e3 * dt, "h2d_GBps": bytes_in / dt / 1e9, "d2h_GBps": bytes_out / dt / 1e9,
                    "pcie_peak_GBps_per_direction": PCIE_GBS, "frac_of_pcie": max(bytes_in, bytes_out) / dt / 1e9 / PCIE_GBS,
                    "parity": bool(parity is None or (np.array_equal(keep[1].array[:nb], o_scores) and np.array_equal(keep[2].array[:nb], o_labels))),
-                   "path": "vpt_predict_batch: pinned host buffers (vpt_host_alloc), ~2 M-char chunks, copy in / kernels / copy out on three streams"}
+                   "path": "vpt_predict_batch: pinned host buffers (vpt_host_alloc); batches up to 16 M chars in 512 K-char chunks over 4 "
+                           "in-order lanes, larger ones in 4 M-char chunks on three streams with events"}
+            # the same batch when only the labels come back (what a tokenizer needs: 1 of the 5 bytes per boundary)
+            keep[2].array[:] = 9
+            t0 = time.perf_counter()
+            for _ in range(k):
+                api.predict_packed_sharded([pred], keep[0].array, boff, out_offsets=ooff, labels=keep[2].array, want_scores=False)
+            dt = (time.perf_counter() - t0) / k
+            e2e["labels_only"] = {"boundaries_per_s": nb / dt, "ms_per_batch": 1e3 * dt, "h2d_GBps": bytes_in / dt / 1e9,
+                                  "frac_of_pcie": bytes_in / dt / 1e9 / PCIE_GBS,
+                                  "parity": bool(parity is None or np.array_equal(keep[2].array[:nb], o_labels))}
+            # ten of these batches as one call: what the pipeline does once its start-up no longer counts
+            rep = 10
+            big = [api.PinnedArray((nbytes * rep,), np.uint8), api.PinnedArray((nb * rep,), np.int32), api.PinnedArray((nb * rep,), np.uint8)]
+            big[0].array[:] = np.tile(utf8, rep)
+            boff_big = np.concatenate([boff[:-1] + np.uint64(r * nbytes) for r in range(rep)] + [np.array([rep * nbytes], dtype=np.uint64)])
+            ooff_big = np.concatenate([ooff[:-1] + np.uint64(r * nb) for r in range(rep)] + [np.array([rep * nb], dtype=np.uint64)])
+            for _ in range(2):
+                api.predict_packed_sharded([pred], big[0].array, boff_big, out_offsets=ooff_big, scores=big[1].array, labels=big[2].array)
+            kb = 5
+            t0 = time.perf_counter()
+            for _ in range(kb):
+                api.predict_packed_sharded([pred], big[0].array, boff_big, out_offsets=ooff_big, scores=big[1].array, labels=big[2].array)
+            dt = (time.perf_counter() - t0) / kb
+            e2e["large_batch"] = {"sentences": S * rep, "boundaries_per_s": nb * rep / dt, "ms_per_batch": 1e3 * dt, "d2h_GBps": bytes_out * rep / dt / 1e9,
+                                  "h2d_GBps": bytes_in * rep / dt / 1e9, "frac_of_pcie": bytes_out * rep / dt / 1e9 / PCIE_GBS,
+                                  "parity": bool(parity is None or (np.array_equal(big[1].array[(rep - 1) * nb:], o_scores) and np.array_equal(big[2].array[:nb], o_labels)))}
+            del big
             del keep
 
         if self.rank != 0:

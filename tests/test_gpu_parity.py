@@ -1064,12 +1064,14 @@ def test_compiled_predictor_rejects_damaged_blobs():
 
 
 # ------------------------------------------------------------------------------------------------ host-buffer pipeline, shards
-@pytest.mark.parametrize("chunk_chars,pinned", [("700", False), ("2500", True)])
-def test_pipelined_host_path_matches_oracle(chunk_chars, pinned, monkeypatch):
-    """vpt_predict_batch cuts a large batch into chunks and overlaps copy in / kernels / copy out on three streams; with
-    VPT_CHUNK_CHARS tiny, a 1 000-sentence batch goes through dozens of chunks, ragged sizes, both buffer sets, pinned and
-    pageable caller buffers -- scores identical to the oracle's, device-side errors still reported."""
+@pytest.mark.parametrize("chunk_chars,pinned,lanes", [("700", False, "0"), ("2500", True, "0"), ("700", True, "4"), ("2500", False, "3"), ("1500", True, "8")])
+def test_pipelined_host_path_matches_oracle(chunk_chars, pinned, lanes, monkeypatch):
+    """vpt_predict_batch cuts a large batch into chunks and overlaps copy in / kernels / copy out -- on three streams with events
+    (VPT_PIPE_LANES=0: what batches over 16 M chars take) or chunk by chunk over several independent lanes (what smaller ones
+    take); with VPT_CHUNK_CHARS tiny, a 1 000-sentence batch goes through dozens of chunks, ragged sizes, every buffer set, pinned
+    and pageable caller buffers -- scores identical to the oracle's, device-side errors still reported."""
     monkeypatch.setenv("VPT_CHUNK_CHARS", chunk_chars)
+    monkeypatch.setenv("VPT_PIPE_LANES", lanes)
     m = randmodel.rand_model(777, alphabet="kana", wc=3, wt=3, n_char=200, n_dict=200, max_word=8)
     raw = encode_model(m)
     pred, orc = make_predictor(raw)

@@ -1,14 +1,13 @@
 #!/bin/bash
 set -u
-O=gpurun_out/c25; mkdir -p $O
+O=gpurun_out/c33; mkdir -p $O
 export TMPDIR=/tmp
-run() { # name env...
-  n=$1; shift
-  env "$@" timeout 300 python bench.py --config 4 --quick --steps 8 --warmup 2 --no-cpu-baseline --no-e2e --sentences 300000 > $O/b_$n.json 2> $O/b_$n.err
-  python -c "
-import json;d=json.loads(open('$O/b_$n.json').read().strip().splitlines()[-1]);print('$n','tags_ms',round(d['tags']['ms_per_step'],4),'kernel_ms',round(d['roofline']['kernel_ms'],4))"
-}
-timeout 300 python -m pytest tests -m gpu -x -q -k "tag or emit or token" > $O/pytest.log 2>&1; tail -2 $O/pytest.log
-run base X=1
-run wgs32 VPT_TAG_WGS_PER_CU=32
-for d in 1 2; do run dbg$d VPT_DEBUG_TAGS=$d; done
+timeout 900 python -m pytest tests -m gpu -x -q > $O/pytest.log 2>&1; echo "pytest rc=$?"; tail -3 $O/pytest.log
+timeout 900 python bench.py --steps 20 --warmup 5 > $O/bench.json 2> $O/bench.err; echo "bench rc=$?"; tail -2 $O/bench.err
+python - <<'PY'
+import json
+d=json.loads(open("gpurun_out/c33/bench.json").read().strip().splitlines()[-1])
+print("value",d["value"],"kernel_ms",d["roofline"]["kernel_ms"],"frac",d["roofline"]["frac"],"parity",d["parity"])
+print("e2e",json.dumps(d.get("e2e")))
+for w in d.get("workloads",[]): print(w["workload"][:50], w["value"], w["roofline"]["kernel_ms"], w["roofline"]["frac"], w.get("parity"), w.get("tags"))
+PY

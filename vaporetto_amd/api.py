@@ -559,9 +559,11 @@ class Predictor:
 
 
 def predict_packed_sharded(predictors: Sequence[Predictor], utf8: np.ndarray, byte_offsets: np.ndarray, out_offsets: Optional[np.ndarray] = None,
-                           scores: Optional[np.ndarray] = None, labels: Optional[np.ndarray] = None, flags: int = 0):
+                           scores: Optional[np.ndarray] = None, labels: Optional[np.ndarray] = None, flags: int = 0, want_scores: bool = True):
     """vpt_predict_batch_sharded: one batch over several predictors (one per GPU), contiguous shards balanced by chars.
-    `scores` / `labels` may be preallocated (pinned) arrays.  Returns (scores, labels, out_offsets)."""
+    `scores` / `labels` may be preallocated (pinned) arrays.  Returns (scores, labels, out_offsets); with want_scores=False the
+    scores stay on the device (NULL scores_out: a tokenizer only needs the labels, and 4 of the 5 bytes per boundary that
+    would cross the link back are scores) and None is returned for them."""
     L = _lib.load()
     utf8 = np.ascontiguousarray(utf8, dtype=np.uint8)
     byte_offsets = np.ascontiguousarray(byte_offsets, dtype=np.uint64)
@@ -570,16 +572,16 @@ def predict_packed_sharded(predictors: Sequence[Predictor], utf8: np.ndarray, by
         out_offsets = count_boundaries(utf8, byte_offsets)
     out_offsets = np.ascontiguousarray(out_offsets, dtype=np.uint64)
     nb = int(out_offsets[S])
-    if scores is None:
+    if scores is None and want_scores:
         scores = np.zeros(max(nb, 1), dtype=np.int32)
     if labels is None:
         labels = np.zeros(max(nb, 1), dtype=np.uint8)
     handles = (C.c_void_p * len(predictors))(*[p.handle for p in predictors])
-    st = L.vpt_predict_batch_sharded(handles, len(predictors), utf8.ctypes.data, byte_offsets.ctypes.data, S, scores.ctypes.data,
-                                     labels.ctypes.data, out_offsets.ctypes.data, flags)
+    st = L.vpt_predict_batch_sharded(handles, len(predictors), utf8.ctypes.data, byte_offsets.ctypes.data, S,
+                                     scores.ctypes.data if want_scores else None, labels.ctypes.data, out_offsets.ctypes.data, flags)
     if st != _lib.VPT_OK:
         _raise(st)
-    return scores[:nb], labels[:nb], out_offsets
+    return (scores[:nb] if want_scores else None), labels[:nb], out_offsets
 
 
 def shard_bounds(out_offsets: np.ndarray, n_shards: int) -> np.ndarray:

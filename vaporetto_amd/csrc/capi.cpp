@@ -932,10 +932,20 @@ vpt_status vpt_batch_sync(vpt_batch* b) {
 
 namespace {
 
-// Chars per chunk of the pipelined host-buffer path (VPT_CHUNK_CHARS overrides; tests use it): see predict_pipelined.
-uint64_t pipeline_chunk_chars() {
-    if (const char* v = std::getenv("VPT_CHUNK_CHARS")) { const long long n = std::atoll(v); if (n > 0) return uint64_t(n); }
-    return uint64_t(2) << 20;
+// How vpt_predict_batch takes a host batch of `total_chars` (measured on MI355X behind PCIe 5 x16, profiles/r02_g_e2e.txt):
+//   up to 1.5 M chars            one copy in, the kernels, one copy out
+//   up to 16 M chars             predict_lanes: 4 lanes, 512 K-char chunks -- the batch is over in about a millisecond, so what counts
+//                                is how soon the first copy out starts (0.85 ms per 6.4 M chars against 0.98 through the events)
+//   more                         predict_pipelined: three streams and events, 4 M-char chunks -- steadier over hundreds of chunks
+//                                (6.9 ms per 64 M chars; the lanes' copies contend there: 7.4 .. 10 ms)
+// VPT_CHUNK_CHARS / VPT_PIPE_LANES (0 = the event pipeline) override; the tests use them to cut small batches into many chunks.
+struct PipePlan { int lanes; uint64_t chunk; bool pipelined; };
+PipePlan pipeline_plan(uint64_t total_chars) {
+    PipePlan plan = total_chars <= (uint64_t(16) << 20) ? PipePlan{4, uint64_t(512) << 10, false} : PipePlan{0, uint64_t(4) << 20, false};
+    if (const char* v = std::getenv("VPT_PIPE_LANES")) plan.lanes = std::atoi(v);
+    if (const char* v = std::getenv("VPT_CHUNK_CHARS")) { const long long n = std::atoll(v); if (n > 0) plan.chunk = uint64_t(n); }
+    plan.pipelined = total_chars > (plan.lanes > 0 ? 3 * plan.chunk : plan.chunk + plan.chunk / 2);
+    return plan;
 }
 
 // vpt_predict_batch for a batch of several chunks: the copy in of chunk k + 1, the kernels of chunk k and the copy out
@@ -957,7 +967,7 @@ vpt_status predict_pipelined(const vpt_predictor* p, vpt_batch* b, const uint8_t
         }
     }
     const uint64_t total_chars = out_offsets[n_sentences] - out_offsets[0] + n_sentences;
-    const size_t max_chunks = size_t(total_chars / chunk_chars) + 2;
+    const size_t max_chunks = std::min<size_t>(n_sentences, size_t(total_chars / chunk_chars) + 2);   // every chunk holds a sentence
     const size_t need_off = 2 * (n_sentences + max_chunks);   // a chunk of n sentences stages 2 (n + 1) offsets
     if (need_off > b->h_off_cap) {
         if (b->h_off) (void)hipHostFree(b->h_off);
@@ -1014,6 +1024,90 @@ vpt_status predict_pipelined(const vpt_predictor* p, vpt_batch* b, const uint8_t
     return vpt_batch_sync(b);   // the device's verdict over every chunk (the status word accumulates)
 }
 
+// The same batch as predict_pipelined, the other way round: every chunk's copy in, kernels and copy out are enqueued IN ORDER on
+// one stream, and the chunks alternate over `n_lanes` streams (each with a workspace and one set of device buffers of its own).
+// The overlap is between the lanes -- one copies out while the next copies in and scores -- and nothing crosses streams: no
+// events, no host synchronisation before the end (a set's reuse is ordered by its own stream).
+vpt_status predict_lanes(const vpt_predictor* p, vpt_batch* b, const uint8_t* utf8, const uint64_t* byte_offsets, size_t n_sentences,
+                         int32_t* scores_out, uint8_t* labels_out, const uint64_t* out_offsets, uint64_t chunk_chars, int n_lanes) {
+    constexpr int kMaxLanes = 8;
+    n_lanes = std::max(1, std::min(n_lanes, kMaxLanes));
+    Workspace extra[kMaxLanes - 1];
+    vpt_batch* lane[kMaxLanes] = {b};
+    vpt_status st;
+    for (int l = 1; l < n_lanes; ++l) {
+        if ((st = acquire(p, &extra[l - 1])) != VPT_OK) return st;
+        lane[l] = extra[l - 1].b;
+        lane[l]->flags = b->flags;
+    }
+    const uint64_t total_chars = out_offsets[n_sentences] - out_offsets[0] + n_sentences;
+    const size_t max_chunks = std::min<size_t>(n_sentences, size_t(total_chars / chunk_chars) + 2);
+    const size_t need_off = 2 * (n_sentences + max_chunks);   // a chunk of n sentences stages 2 (n + 1) offsets
+    if (need_off > b->h_off_cap) {
+        if (b->h_off) (void)hipHostFree(b->h_off);
+        b->h_off = nullptr; b->h_off_cap = 0;
+        VPT_HIP(hipHostMalloc(reinterpret_cast<void**>(&b->h_off), (need_off + need_off / 2) * sizeof(uint64_t), hipHostMallocDefault));
+        b->h_off_cap = need_off + need_off / 2;
+    }
+    size_t i = 0, staged = 0;
+    for (size_t k = 0; i < n_sentences; ++k) {
+        vpt_batch* bb = lane[k % size_t(n_lanes)];
+        vpt_batch::PipeSet& ps = bb->pipe[0];
+        hipStream_t s = bb->own_stream;
+        const size_t a = i;
+        const uint64_t t0 = byte_offsets[a], o0 = out_offsets[a];
+        uint64_t* hb = b->h_off + staged;
+        uint64_t chars = 0, max_bytes = 0, max_chars = 0;
+        while (i < n_sentences && chars < chunk_chars) {
+            if (byte_offsets[i + 1] <= byte_offsets[i]) return fail(VPT_INVALID_ARGUMENT, "InvalidArgumentError: text: must contain at least one character");
+            const uint64_t nby = byte_offsets[i + 1] - byte_offsets[i];
+            if (out_offsets[i + 1] < out_offsets[i] || out_offsets[i + 1] - out_offsets[i] + 1 > nby)
+                return fail(VPT_INVALID_ARGUMENT, "InvalidArgumentError: out_offsets: do not match the text (or the text is not valid UTF-8)");
+            const uint64_t nch = out_offsets[i + 1] - out_offsets[i] + 1;
+            max_bytes = std::max(max_bytes, nby); max_chars = std::max(max_chars, nch);
+            chars += nch;
+            ++i;
+        }
+        const size_t n = i - a;
+        uint64_t* ho = hb + (n + 1);
+        for (size_t j = 0; j <= n; ++j) { hb[j] = byte_offsets[a + j] - t0; ho[j] = out_offsets[a + j] - o0; }
+        staged += 2 * (n + 1);
+        const uint64_t nbytes = byte_offsets[i] - t0, nb = out_offsets[i] - o0;
+        // a buffer that has to grow may still be read or written by the lane's earlier chunk
+        if (size_t(nbytes) + 32 > ps.text_cap || 2 * (n + 1) > ps.off_cap || (scores_out && size_t(nb) + 1 > ps.scores_cap) ||
+            (labels_out && size_t(nb) + 1 > ps.labels_cap))
+            VPT_HIP(hipStreamSynchronize(s));
+        if ((st = grow(&ps.text, &ps.text_cap, size_t(nbytes) + 32)) != VPT_OK) return st;
+        if ((st = grow(&ps.off, &ps.off_cap, 2 * (n + 1))) != VPT_OK) return st;
+        if (scores_out && (st = grow(&ps.scores, &ps.scores_cap, size_t(nb) + 1)) != VPT_OK) return st;
+        if (labels_out && (st = grow(&ps.labels, &ps.labels_cap, size_t(nb) + 1)) != VPT_OK) return st;
+        VPT_HIP(hipMemcpyAsync(ps.text, utf8 + t0, size_t(nbytes), hipMemcpyHostToDevice, s));
+        VPT_HIP(hipMemcpyAsync(ps.off, hb, 16 * (n + 1), hipMemcpyHostToDevice, s));
+        bb->max_chars = max_chars;
+        st = vpt_predict_batch_device(p, bb, ps.text, ps.off, ps.off + (n + 1), n, nb, max_bytes, scores_out ? ps.scores : nullptr,
+                                      labels_out ? ps.labels : nullptr, s);
+        if (st != VPT_OK) return st;
+        if (scores_out && nb) VPT_HIP(hipMemcpyAsync(scores_out + o0, ps.scores, 4 * size_t(nb), hipMemcpyDeviceToHost, s));
+        if (labels_out && nb) VPT_HIP(hipMemcpyAsync(labels_out + o0, ps.labels, size_t(nb), hipMemcpyDeviceToHost, s));
+    }
+    // the device's verdict over every chunk (a lane's status word accumulates): the lanes' words are fetched together, one
+    // round trip for all of them instead of one each
+    uint32_t ctrl[kMaxLanes][2] = {};
+    for (int l = 0; l < n_lanes; ++l)
+        if (lane[l]->pending) VPT_HIP(hipMemcpyAsync(ctrl[l], lane[l]->d_ctrl, sizeof(ctrl[l]), hipMemcpyDeviceToHost, lane[l]->last_stream));
+    st = VPT_OK;
+    for (int l = 0; l < n_lanes; ++l) {
+        if (!lane[l]->pending) continue;
+        VPT_HIP(hipStreamSynchronize(lane[l]->last_stream));
+        lane[l]->pending = false;
+        if (ctrl[l][0]) {
+            VPT_HIP(hipMemset(lane[l]->d_ctrl, 0, sizeof(uint32_t)));
+            if (st == VPT_OK) st = status_from_bits(ctrl[l][0]);
+        }
+    }
+    return st;
+}
+
 }  // namespace
 
 vpt_status vpt_predict_batch(const vpt_predictor* p, const uint8_t* utf8, const uint64_t* byte_offsets, size_t n_sentences,
@@ -1033,11 +1127,10 @@ vpt_status vpt_predict_batch_flags(const vpt_predictor* p, const uint8_t* utf8, 
     if (st != VPT_OK) return st;
     vpt_batch* b = w.b;
     b->flags = flags;
-    {   // a batch of several chunks goes through the copy/compute pipeline
-        const uint64_t chunk = pipeline_chunk_chars();
-        if (byte_offsets[n_sentences] >= byte_offsets[0] && out_offsets[n_sentences] >= out_offsets[0] &&
-            out_offsets[n_sentences] - out_offsets[0] + n_sentences > chunk + chunk / 2)
-            return predict_pipelined(p, b, utf8, byte_offsets, n_sentences, scores_out, labels_out, out_offsets, chunk);
+    if (byte_offsets[n_sentences] >= byte_offsets[0] && out_offsets[n_sentences] >= out_offsets[0]) {   // a batch of several chunks goes through a copy/compute pipeline
+        const PipePlan plan = pipeline_plan(out_offsets[n_sentences] - out_offsets[0] + n_sentences);
+        if (plan.pipelined && plan.lanes > 0) return predict_lanes(p, b, utf8, byte_offsets, n_sentences, scores_out, labels_out, out_offsets, plan.chunk, plan.lanes);
+        if (plan.pipelined) return predict_pipelined(p, b, utf8, byte_offsets, n_sentences, scores_out, labels_out, out_offsets, plan.chunk);
     }
     uint64_t total_b = 0, max_bytes = 0, max_chars = 0;
     if ((st = stage(b, utf8, byte_offsets, out_offsets, n_sentences, nullptr, &total_b, &max_bytes, &max_chars)) != VPT_OK) return st;
