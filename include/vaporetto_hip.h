@@ -131,9 +131,11 @@ vpt_status vpt_predict_batch_flags(const vpt_predictor *p, const uint8_t *utf8, 
                                    size_t n_sentences, int32_t *scores_out, uint8_t *labels_out,
                                    const uint64_t *out_offsets, unsigned flags);
 
-/* Host buffers and the PCIe link.  vpt_predict_batch cuts a large batch into chunks of about two million chars and runs the copy
- * in of one chunk, the kernels of the one before and the copy out of the one before that at the same time (three streams,
- * two sets of device buffers).  With PINNED caller buffers -- vpt_host_alloc, or memory the caller registered with HIP
+/* Host buffers and the PCIe link.  vpt_predict_batch cuts a large batch into chunks and runs the copy in of one chunk, the
+ * kernels of another and the copy out of a third at the same time: up to 16 M chars as 512 K-char chunks alternating over four
+ * streams (a chunk's copy in, kernels and copy out in order on one of them), larger batches as 4 M-char chunks on a copy-in, a
+ * compute and a copy-out stream.  Either output pointer may be NULL: a caller that only needs the labels saves four of the
+ * five bytes per boundary that cross the link back.  With PINNED caller buffers -- vpt_host_alloc, or memory the caller registered with HIP
  * itself -- the copies are DMA transfers in both directions at once; with pageable buffers they go through the runtime's
  * staging.  vpt_host_alloc / vpt_host_free = hipHostMalloc / hipHostFree, exported so that callers need no HIP headers. */
 vpt_status vpt_host_alloc(size_t bytes, void **out);

@@ -934,10 +934,11 @@ namespace {
 
 // How vpt_predict_batch takes a host batch of `total_chars` (measured on MI355X behind PCIe 5 x16, profiles/r02_g_e2e.txt):
 //   up to 1.5 M chars            one copy in, the kernels, one copy out
-//   up to 16 M chars             predict_lanes: 4 lanes, 512 K-char chunks -- the batch is over in about a millisecond, so what counts
-//                                is how soon the first copy out starts (0.85 ms per 6.4 M chars against 0.98 through the events)
-//   more                         predict_pipelined: three streams and events, 4 M-char chunks -- steadier over hundreds of chunks
-//                                (6.9 ms per 64 M chars; the lanes' copies contend there: 7.4 .. 10 ms)
+//   up to 16 M chars             predict_lanes: 4 lanes, 512 K-char chunks.  The batch is over in about a millisecond, so what counts is
+//                                how soon the first copy out starts and that nothing waits on the host: 0.85 ms per 6.4 M chars against
+//                                0.98 through the events (3 or 5 lanes, or 256 K / 1 M-char chunks: 0.93 .. 1.05)
+//   more                         predict_pipelined: three streams and events, 4 M-char chunks: 6.9 .. 8.1 ms per 64 M chars, steadier over
+//                                many chunks than the lanes, whose copies contend (7.3 .. 10 ms)
 // VPT_CHUNK_CHARS / VPT_PIPE_LANES (0 = the event pipeline) override; the tests use them to cut small batches into many chunks.
 struct PipePlan { int lanes; uint64_t chunk; bool pipelined; };
 PipePlan pipeline_plan(uint64_t total_chars) {
@@ -948,13 +949,14 @@ PipePlan pipeline_plan(uint64_t total_chars) {
     return plan;
 }
 
-// vpt_predict_batch for a batch of several chunks: the copy in of chunk k + 1, the kernels of chunk k and the copy out
-// of chunk k - 1 run at the same time on three streams over two sets of device buffers, so that a caller with PINNED
-// buffers (vpt_host_alloc) gets both directions of the PCIe link busy at once instead of a copy-launch-copy sequence;
-// pageable buffers go through the runtime's staging and still overlap with the kernels.  The host walks the sentences
-// ONCE, chunk by chunk -- validating them, rebasing their offsets into pinned staging, finding the cut -- while the
-// chunks before are in flight; a chunk costs eleven runtime calls (two copies in, two launches, two copies out, events),
-// which is why chunks are about two million chars: at a few microseconds per call smaller ones leave the link idle.
+// vpt_predict_batch for a LARGE batch: the copy in of chunk k + 1, the kernels of chunk k and the copy out of chunk k - 1 run at
+// the same time on three streams over two sets of device buffers, so that a caller with PINNED buffers (vpt_host_alloc) gets
+// both directions of the PCIe link busy at once instead of a copy-launch-copy sequence; pageable buffers go through the
+// runtime's staging and still overlap with the kernels.  The host walks the sentences ONCE, chunk by chunk -- validating them,
+// rebasing their offsets into pinned staging, finding the cut -- while the chunks before are in flight; a chunk costs eleven
+// runtime calls (two copies in, two launches, two copies out, events) and a wait of the host for the chunk two before it.  The
+// runtime performs this stream's copies out as blit kernels, which the next chunk's kernels queue behind (timeline in
+// profiles/r02_g_e2e.txt): copy out and kernels take turns, 0.24 ms per 2 M chars -- 15 % above what the link does both ways.
 vpt_status predict_pipelined(const vpt_predictor* p, vpt_batch* b, const uint8_t* utf8, const uint64_t* byte_offsets, size_t n_sentences,
                              int32_t* scores_out, uint8_t* labels_out, const uint64_t* out_offsets, uint64_t chunk_chars) {
     if (!b->s_in) {
@@ -1024,10 +1026,10 @@ vpt_status predict_pipelined(const vpt_predictor* p, vpt_batch* b, const uint8_t
     return vpt_batch_sync(b);   // the device's verdict over every chunk (the status word accumulates)
 }
 
-// The same batch as predict_pipelined, the other way round: every chunk's copy in, kernels and copy out are enqueued IN ORDER on
-// one stream, and the chunks alternate over `n_lanes` streams (each with a workspace and one set of device buffers of its own).
-// The overlap is between the lanes -- one copies out while the next copies in and scores -- and nothing crosses streams: no
-// events, no host synchronisation before the end (a set's reuse is ordered by its own stream).
+// vpt_predict_batch for a batch of a few chunks: every chunk's copy in, kernels and copy out are enqueued IN ORDER on one stream,
+// and the chunks alternate over `n_lanes` streams (each with a workspace and one set of device buffers of its own).  The
+// overlap is between the lanes -- one copies out while the next copies in and scores -- and nothing crosses streams: no events,
+// no host synchronisation before the end (a set's reuse is ordered by its own stream), and the copies out go through SDMA.
 vpt_status predict_lanes(const vpt_predictor* p, vpt_batch* b, const uint8_t* utf8, const uint64_t* byte_offsets, size_t n_sentences,
                          int32_t* scores_out, uint8_t* labels_out, const uint64_t* out_offsets, uint64_t chunk_chars, int n_lanes) {
     constexpr int kMaxLanes = 8;
