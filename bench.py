@@ -260,6 +260,53 @@ class Runner:
             tags_info = {"ms_per_step": 1e3 * dt, "tokens_per_s": n_tokens / dt, "chars_per_s": (nb + S) / dt, "n_tags": nt,
                          "kernels": "decode_chars_kernel + tag_tokens_kernel on the predicted labels"}
 
+        # ---- token emission on the labels just predicted (Sentence::write_tokenized_text, with "/tag" suffixes for tag models)
+        emit_info = None
+        if not args.no_emit:
+            cap = 3 * nbytes + 64 + ((nbytes * pred.max_tag_suffix()) if nt else 0)
+            d_out = torch.empty(cap + 1, dtype=torch.uint8, device=dev)
+            d_toff = torch.empty(S + 1, dtype=torch.int64, device=dev)
+
+            def emit():
+                if nt:
+                    batch.write_tagged(d_text.data_ptr(), d_boff.data_ptr(), d_ooff.data_ptr(), S, nb, d_labels.data_ptr(), d_tags.data_ptr(),
+                                       d_out.data_ptr(), cap, d_toff.data_ptr(), stream)
+                else:
+                    batch.write_tokenized(d_text.data_ptr(), d_boff.data_ptr(), d_ooff.data_ptr(), S, nb, d_labels.data_ptr(),
+                                          d_out.data_ptr(), cap, d_toff.data_ptr(), stream)
+            for _ in range(2):
+                emit()
+            batch.sync()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                emit()
+            torch.cuda.synchronize()
+            dt = (time.perf_counter() - t0) / steps
+            batch.sync()
+            toff = d_toff.cpu().numpy().astype(np.uint64)
+            out_bytes = int(toff[-1])
+            moved = nbytes + nb + out_bytes + 16 * S + (4 * (nb + S) * (nt + 1) if nt else 0)   # text + labels (+ tags, token models) in, text + offsets out
+            emit_info = {"ms_per_step": 1e3 * dt, "out_bytes": out_bytes, "algorithmic_GBps": moved / dt / 1e9, "frac_of_hbm": moved / dt / 1e9 / HBM_PEAK_GBS,
+                         "kernels": "count + prefix sum + write (kernels_emit.hip), %s" % ("tagged" if nt else "boundaries only")}
+            # a sample against the writer restated on the host (sentence.rs:850-886; boundaries only)
+            if not nt:
+                lab_h = d_labels[:nb].cpu().numpy()
+                out_h = d_out[:out_bytes].cpu().numpy().tobytes()
+                text_b = utf8.tobytes()
+                ok_e = True
+                for i in range(0, S, max(1, S // 200)):
+                    tx = text_b[int(boff[i]):int(boff[i + 1])].decode("utf-8")
+                    lab = lab_h[int(ooff[i]):int(ooff[i + 1])]
+                    toks, cur = [], []
+                    for k_, ch in enumerate(tx):
+                        cur.append("\\" + ch if ch in " \\/" else ch)
+                        if k_ == len(tx) - 1 or lab[k_] == 1:
+                            toks.append("".join(cur)); cur = []
+                    ok_e = ok_e and out_h[int(toff[i]):int(toff[i + 1])].decode("utf-8") == " ".join(toks)
+                emit_info["parity_sample"] = bool(ok_e)
+            del d_out, d_toff
+
         # ---- parity against the oracle (this rank's whole shard, bit for bit) and the algorithmic bytes it counts
         a_char, parity, cpu = None, None, None
         if not args.no_cpu_baseline:
@@ -378,6 +425,8 @@ class Runner:
             out["tags"] = tags_info
         if e2e is not None:
             out["e2e"] = e2e
+        if emit_info is not None:
+            out["emit"] = emit_info
         if cpu is not None:
             out["cpu_baseline"] = cpu
         return out
@@ -394,6 +443,7 @@ def main():
     ap.add_argument("--model-scale", type=float, default=1.0)
     ap.add_argument("--no-cpu-baseline", action="store_true", help="skip the oracle: no parity, no roofline, no cpu_baseline (profiling runs)")
     ap.add_argument("--no-e2e", action="store_true")
+    ap.add_argument("--no-emit", action="store_true")
     ap.add_argument("--phases", action="store_true", help="diagnostics: per-phase shader cycles of the scoring kernel (slows it)")
     args = ap.parse_args()
 
@@ -418,7 +468,7 @@ def main():
         line["config"]["hip_devices_visible"] = R.torch.cuda.device_count()
         line["config"]["world_size"] = R.world
         line["config"]["collective_backend"] = ("RCCL (torch.distributed nccl)" if R.backend == "nccl" else R.backend) if R.world > 1 else None
-        for k in ("e2e", "tags", "phase_share"):
+        for k in ("e2e", "tags", "emit", "phase_share"):
             if k in prim:
                 line[k] = prim[k]
         if extra:

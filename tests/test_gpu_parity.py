@@ -964,6 +964,47 @@ def test_write_tagged_text_on_device():
     assert [out[int(toff[i]):int(toff[i + 1])].decode("utf-8") for i in range(S)] == want
 
 
+def test_writer_long_tags_many_sentences_and_long_sentences():
+    """The writer assembles a step's output (256 text bytes and what is inserted) in LDS; tag strings of hundreds of bytes
+    do not fit there and go out byte by byte; the sentences' positions come from a three-kernel prefix sum whose
+    workgroups take 4 096 sentences each: more sentences than that, sentences of thousands of bytes, every alignment."""
+    m = randmodel.rand_model(841, alphabet="kana", wc=3, wt=3, n_tag_models=30, max_word=3, n_char=60, n_dict=60)
+    for k, tm in enumerate(m.tag_models):
+        tm.tags = [[(t + "/x " * 3) * (40 + 25 * (k % 5)) if k % 2 else t for t in cands] for cands in tm.tags]   # up to ~1.7 KB per tag
+    pred = api.Predictor(api.Model.read_slice(encode_model(m))[0], True)
+    texts = randmodel.rand_sentences(5, m, 300, alphabet="kana", max_len=30) + [t.token * 5 for t in m.tag_models]
+    sents = [api.Sentence.from_raw(t) for t in texts]
+    pred.predict_batch(sents)
+    got = pred.write_tokenized_batch(sents, tagged=True)
+    pred.fill_tags_batch(sents)
+    assert got == [s.write_tokenized_text() for s in sents]
+    assert max(len(g) for g in got) > 2000
+    # 9 000 short sentences (three scan workgroups) and a few of 2 000 .. 6 000 chars, ASCII with escapes among them
+    import random
+    rng = random.Random(5)
+    alpha = randmodel.ALPHABETS["kana"][:20] + list("ab /\\9")
+    texts = ["".join(rng.choice(alpha) for _ in range(rng.randint(1, 9))) for _ in range(9000)]
+    for at, n in ((17, 2000), (4095, 6000), (4096, 3001), (8999, 2500)):
+        texts[at] = "".join(rng.choice(alpha) for _ in range(n))
+    plain = api.Predictor(api.Model.read_slice(encode_model(m))[0], False)
+    utf8, boff = api.pack_texts([t.encode("utf-8") for t in texts])
+    scores, labels, ooff = plain.predict_packed(utf8, boff)
+    ttext, toff = plain.write_tokenized_packed(utf8, boff, ooff, labels)
+    tb = bytes(ttext)
+    for i, t in enumerate(texts):
+        lab = labels[int(ooff[i]):int(ooff[i + 1])]
+        out, tok = [], []
+        for k, c in enumerate(t):
+            tok.append("\\" + c if c in " \\/" else c)
+            if k == len(t) - 1 or lab[k] == 1:
+                out.append("".join(tok)); tok = []
+        assert tb[int(toff[i]):int(toff[i + 1])].decode("utf-8") == " ".join(out), i
+    assert np.array_equal(api.count_boundaries(utf8, boff), ooff)
+    # the whole pipeline on the device (vpt_count_boundaries_device's prefix sum over the same 9 000 sentences)
+    lines = plain.tokenize(texts)
+    assert lines == [tb[int(toff[i]):int(toff[i + 1])].decode("utf-8") for i in range(len(texts))]
+
+
 def test_tokenize_batch_is_the_whole_pipeline():
     """vpt_tokenize_batch (lines in, tokenized lines out) = from_raw + predict (+ filters) (+ fill_tags) + write_tokenized_text,
     and vpt_count_boundaries_device = vpt_count_boundaries."""

@@ -338,7 +338,18 @@ class Predictor:
             _raise(st)
         return mi.as_dict()
 
+    def max_tag_suffix(self) -> int:
+        """vpt_predictor_max_tag_suffix: the most bytes "/tag/tag.." can add per char (sizes write_tagged's output)."""
+        sfx = C.c_uint32(0)
+        st = _lib.load().vpt_predictor_max_tag_suffix(self._h, C.byref(sfx))
+        if st != _lib.VPT_OK:
+            _raise(st)
+        return int(sfx.value)
+
     def predict(self, sentence: Sentence) -> None:  # predictor.rs:518-543
+        """One sentence through vpt_predict_one: two kernel launches and a synchronisation, tens of microseconds for work the
+        reference does in one -- it exists for API parity and tests.  Anything with more than a handful of sentences belongs in
+        predict_batch / predict_packed (one launch for all of them); a loop over this method is the slowest way to use the library."""
         n = len(sentence)
         scores = np.zeros(max(n - 1, 1), dtype=np.int32)
         labels = np.zeros(max(n - 1, 1), dtype=np.uint8)

@@ -141,6 +141,7 @@ struct vpt_batch {
     uint64_t tok_model_chars = 0;                                   // ... which covered this many chars
     std::vector<uint64_t> h_boff, h_ooff;                           // rebased offsets of the call in flight (copied asynchronously)
     uint8_t* d_types = nullptr; size_t types_cap = 0;               // vpt_char_types_batch
+    uint64_t* d_scan_part = nullptr; size_t scan_part_cap = 0;      // per-workgroup partials of the prefix sums (kernels_emit.hip)
     // the pipelined host-buffer path (predict_pipelined): two sets of device buffers, copy streams, pinned offset staging
     struct PipeSet {
         uint8_t* text = nullptr; size_t text_cap = 0;
@@ -204,6 +205,7 @@ vpt_status compile(const uint8_t* bytes, size_t len, int predict_tags, vpt::Comp
 void batch_release(vpt_batch* b) {
     if (!b) return;
     (void)hipSetDevice(b->device);
+    (void)hipFree(b->d_scan_part);
     (void)hipFree(b->d_tile_first); (void)hipFree(b->d_slow_list); (void)hipFree(b->d_ctrl); (void)hipFree(b->d_scratch);
     (void)hipFree(b->d_prof); (void)hipFree(b->d_cps);
     (void)hipFree(b->d_text); (void)hipFree(b->d_boff); (void)hipFree(b->d_ooff); (void)hipFree(b->d_scores); (void)hipFree(b->d_labels);
@@ -1251,7 +1253,11 @@ static vpt_status emit_device(const vpt_predictor* p, vpt_batch* b, const uint8_
         E.tags = d_tags; E.tok_model = b->d_tok_model; E.n_tags = p->n_tags; E.n_models = p->dtag.n_models; E.n_strings = p->dtag.n_strings;
         E.models = p->dtag.models; E.slot_str = p->dtag.slot_str; E.str_off = p->dtag.str_off; E.str_bytes = p->dtag.str_bytes;
     }
-    VPT_HIP(vpt::launch_emit_tokenized(E, stream));
+    {
+        const vpt_status st = grow(&b->d_scan_part, &b->scan_part_cap, vpt::scan_part_entries(n_sentences));
+        if (st != VPT_OK) return st;
+    }
+    VPT_HIP(vpt::launch_emit_tokenized(E, b->d_scan_part, p->n_cus * 32u, stream));
     b->last_stream = stream; b->pending = true;
     return VPT_OK;
 }
@@ -1330,7 +1336,11 @@ vpt_status vpt_count_boundaries_device(const vpt_predictor* p, vpt_batch* b, con
     VPT_HIP(hipSetDevice(p->device));
     VPT_HIP(hipMemsetAsync(b->d_ctrl + 2, 0, sizeof(uint32_t), stream));   // [2]: the longest sentence in chars
     if (n_sentences == 0) VPT_HIP(hipMemsetAsync(d_out_offsets, 0, sizeof(uint64_t), stream));
-    else VPT_HIP(vpt::launch_count_boundaries(d_utf8, d_byte_offsets, n_sentences, d_out_offsets, b->d_ctrl, b->d_ctrl + 2, stream));
+    else {
+        const vpt_status st = grow(&b->d_scan_part, &b->scan_part_cap, vpt::scan_part_entries(n_sentences));
+        if (st != VPT_OK) return st;
+        VPT_HIP(vpt::launch_count_boundaries(d_utf8, d_byte_offsets, n_sentences, d_out_offsets, b->d_scan_part, b->d_ctrl, b->d_ctrl + 2, p->n_cus * 32u, stream));
+    }
     b->last_stream = stream; b->pending = true;
     return VPT_OK;
 }

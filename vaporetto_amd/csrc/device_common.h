@@ -108,6 +108,21 @@ __device__ __forceinline__ uint32_t char_type(uint32_t c) {
     return 6;
 }
 
+// bytes [at, at + 4) of p as a little-endian dword, zero at and past `end`: the one or two ALIGNED dwords that hold the wanted
+// bytes, both loads issued together -- no byte loop at a sentence's end (the whole wave would wait three trips for its
+// last lane), and nothing is read outside the aligned words the wanted bytes live in
+__device__ __forceinline__ uint32_t load4(const uint8_t* __restrict__ p, uint64_t at, uint64_t end) {
+    if (at >= end) return 0;
+    const uint32_t nv = end - at < 4 ? uint32_t(end - at) : 4u;
+    const uintptr_t addr = reinterpret_cast<uintptr_t>(p + at);
+    const uint32_t sh = uint32_t(addr & 3u);
+    const uint32_t* a0 = reinterpret_cast<const uint32_t*>(addr - sh);
+    const uint32_t d0 = a0[0];
+    const uint32_t d1 = sh + nv > 4u ? a0[1] : 0u;
+    const uint32_t x = __builtin_amdgcn_alignbyte(d1, d0, sh);
+    return nv == 4u ? x : x & ((1u << (8u * nv)) - 1u);
+}
+
 // 4-bit mask of the bytes of x that are NOT UTF-8 continuation bytes (10xxxxxx)
 __device__ __forceinline__ uint32_t lead_nibble(uint32_t x) {
     uint32_t cont = x & ~(x << 1) & 0x80808080u;  // bit7 set and bit6 clear

@@ -103,10 +103,12 @@ struct EmitParams {
     const uint32_t *models, *slot_str, *str_off;
     const uint8_t* str_bytes;
 };
-hipError_t launch_emit_tokenized(const EmitParams& P, hipStream_t stream);
+// scan_part: workspace of scan_part_entries(n_sent) uint64 (the prefix sum's per-workgroup partials)
+size_t scan_part_entries(uint64_t n);
+hipError_t launch_emit_tokenized(const EmitParams& P, uint64_t* scan_part, uint32_t max_blocks, hipStream_t stream);
 // vpt_count_boundaries on the device: ooff_out[S+1]; *max_chars (atomicMax) = the longest sentence in chars
-hipError_t launch_count_boundaries(const uint8_t* text, const uint64_t* boff, uint64_t n_sent, uint64_t* ooff_out, uint32_t* status,
-                                   uint32_t* max_chars, hipStream_t stream);
+hipError_t launch_count_boundaries(const uint8_t* text, const uint64_t* boff, uint64_t n_sent, uint64_t* ooff_out, uint64_t* scan_part, uint32_t* status,
+                                   uint32_t* max_chars, uint32_t max_blocks, hipStream_t stream);
 
 size_t score_tiles_lds_bytes();
 hipError_t launch_assign_tiles(const uint64_t* ooff, uint64_t n_sent, int pad, uint32_t tile_flat, uint32_t n_tiles,

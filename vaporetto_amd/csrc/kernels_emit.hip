@@ -5,10 +5,16 @@
 // slots up to the last Some, an empty string for a None in between (sentence.rs:866-881).  (Unknown boundaries only
 // come from partially annotated corpora, never from predict: they are rejected here, kErrUnknownLabel.)
 //
-// Output size is data dependent, so three launches on one stream:
-//   emit_count_kernel   one wave per sentence: bytes this sentence will take -> offsets[i + 1]
-//   emit_scan_kernel    one workgroup: exclusive prefix sum over the sentences, in place (offsets[0] = 0)
-//   emit_write_kernel   one wave per sentence: 64 text bytes per step, a wave prefix sum places every byte
+// Output size is data dependent, so:
+//   emit_count_kernel   one wave per sentence: bytes this sentence will take -> offsets[i + 1].  The count needs no
+//                       byte <-> char correspondence: text bytes + escaped bytes (a pass over the text, four bytes per lane)
+//                       + WordBoundary labels (a pass over the labels, four per lane) + the tag suffixes of the tokens,
+//                       which hang on label positions
+//   scan_*_kernel       inclusive prefix sum over the sentences, in place (offsets[0] = 0): per-workgroup partial sums,
+//                       one workgroup over the partials, per-workgroup apply -- three small launches, all parallel
+//   emit_write_kernel   one wave per sentence, 256 text bytes per step (a dword per lane): lead and escape bits from the
+//                       dword, the labels of the lane's chars in one unaligned load, a DPP prefix sum places every lane's
+//                       output, which is assembled in LDS and leaves as aligned dword stores
 // A sentence's bytes are independent of the other sentences', its position is not: that is the scan.
 #include <hip/hip_runtime.h>
 
@@ -20,47 +26,22 @@ namespace {
 
 constexpr int kEmitThreads = 256;
 constexpr int kEmitWaves = kEmitThreads / 64;
-constexpr int kScanThreads = 1024;
+constexpr int kScanThreads = 256, kScanPer = 16;
+constexpr uint64_t kScanBlock = uint64_t(kScanThreads) * kScanPer;   // offsets one workgroup of the scan takes
+constexpr int kTopThreads = 1024;
+constexpr uint32_t kStageBytes = 1024;   // a wave's output of one step in LDS: <= 3 + 3 * 256 bytes without tag suffixes
 
-__device__ __forceinline__ uint32_t below(uint64_t mask, int lane) { return uint32_t(__popcll(mask & ((uint64_t(1) << lane) - 1))); }
-
-// what one text byte turns into: [' '] ['\'] byte
-struct ByteOut {
-    uint32_t n;        // 1..3 bytes (0 outside the sentence)
-    bool space, esc;
-};
-
-// The per-chunk state machine shared by the counting and the writing kernel.  `chars_before` = chars of the sentence
-// in front of this chunk; returns what this lane's byte becomes and, through `leads`, the chunk's lead-byte mask.
-__device__ __forceinline__ ByteOut classify_byte(const uint8_t* __restrict__ text, uint64_t at, uint64_t b1, const uint8_t* __restrict__ lab,
-                                                 uint64_t n_labels, uint64_t chars_before, int lane, uint64_t& leads, uint32_t& err) {
-    const bool in = at < b1;
-    const uint32_t byte = in ? text[at] : 0x80u;
-    const bool lead = in && (byte & 0xC0u) != 0x80u;
-    leads = __ballot(lead);
-    ByteOut o;
-    o.esc = in && (byte == 0x20u || byte == 0x5Cu || byte == 0x2Fu);
-    o.space = false;
-    if (lead) {
-        const uint64_t ci = chars_before + below(leads, lane);   // index of this char in the sentence
-        if (ci >= 1) {
-            if (ci - 1 < n_labels) {
-                const uint32_t l = lab[ci - 1];
-                o.space = l == 1u;
-                if (l > 1u) err |= kErrUnknownLabel;
-            } else {
-                err |= kErrBadOffsets;   // more chars than out_offsets promise
-            }
-        }
-    }
-    o.n = in ? 1u + (o.esc ? 1u : 0u) + (o.space ? 1u : 0u) : 0u;
-    return o;
+// 0x80 in every byte of v that is zero (exact: no carries between the bytes)
+__device__ __forceinline__ uint32_t zero_bytes(uint32_t v) { return ~(((v & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | v | 0x7F7F7F7Fu); }
+// bits 7, 15, 23, 31 -> bits 0..3
+__device__ __forceinline__ uint32_t byte_flags_to_nibble(uint32_t m) { return (((m >> 7) * 0x00204081u) >> 21) & 0xFu; }
+// 4-bit mask of the bytes of x that write_tokenized_text escapes: ' ', '\', '/'
+__device__ __forceinline__ uint32_t esc_nibble(uint32_t x) {
+    return byte_flags_to_nibble(zero_bytes(x ^ 0x20202020u) | zero_bytes(x ^ 0x5C5C5C5Cu) | zero_bytes(x ^ 0x2F2F2F2Fu));
 }
-
-// "/tag/tag.." of the token whose last char is char `c` (batch-flat index): bytes it takes; written to `dst` when given
-__device__ __forceinline__ uint32_t tag_suffix(const EmitParams& P, uint64_t c, uint8_t* dst) {
-    if (!P.tags) return 0;
-    const int32_t model = P.tok_model[c];
+// "/tag/tag.." of the token whose last char is char `c` (batch-flat index) and whose tag model (index + 1, from the
+// fill_tags call) is `model`: bytes it takes; written to `dst` when given
+__device__ __forceinline__ uint32_t tag_suffix_of(const EmitParams& P, uint64_t c, int32_t model, uint8_t* dst) {
     if (model <= 0 || uint32_t(model) > P.n_models) return 0;   // no tag model for this surface (or not our array)
     const uint32_t* mr = P.models + size_t(model - 1) * 12;
     const int32_t* tg = P.tags + c * P.n_tags;
@@ -81,41 +62,66 @@ __device__ __forceinline__ uint32_t tag_suffix(const EmitParams& P, uint64_t c, 
     }
     return n;
 }
-
-__device__ __forceinline__ uint32_t wave_sum(uint32_t x) {   // total over the 64 lanes, in every lane
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) x += uint32_t(__shfl_xor(int(x), d));
-    return x;
+__device__ __forceinline__ uint32_t tag_suffix(const EmitParams& P, uint64_t c, uint8_t* dst) {
+    return P.tags ? tag_suffix_of(P, c, P.tok_model[c], dst) : 0u;
 }
-__device__ __forceinline__ uint32_t wave_exclusive(uint32_t x, int lane) {   // sum of the lanes below this one
-    uint32_t incl = x;
+// the tag models of the four chars from `c` on in one load (the array is padded past the batch's chars: capi.cpp)
+struct Models4 { int32_t m[4]; };
+__device__ __forceinline__ Models4 load_models4(const EmitParams& P, uint64_t c) {
+    Models4 r;
+    __builtin_memcpy(&r, P.tok_model + c, sizeof(r));
+    return r;
+}
+
+__device__ __forceinline__ uint64_t wave_sum64(uint64_t x) {   // total over the 64 lanes, in every lane
 #pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        const uint32_t t = uint32_t(__shfl_up(int(incl), unsigned(d)));
-        if (lane >= d) incl += t;
+    for (int d = 32; d >= 1; d >>= 1) {
+        const uint32_t lo = uint32_t(__shfl_xor(int(uint32_t(x)), d)), hi = uint32_t(__shfl_xor(int(uint32_t(x >> 32)), d));
+        x += uint64_t(lo) | (uint64_t(hi) << 32);
     }
-    return incl - x;
+    return x;
 }
 
 __global__ __launch_bounds__(kEmitThreads) void emit_count_kernel(const EmitParams P) {
     const int lane = threadIdx.x & 63;
-    const uint64_t wave = uint64_t(blockIdx.x) * kEmitWaves + (threadIdx.x >> 6);
+    const uint64_t wave = uint64_t(blockIdx.x) * kEmitWaves + wave_uniform(threadIdx.x >> 6);
     const uint64_t n_waves = uint64_t(gridDim.x) * kEmitWaves;
     uint32_t err = 0;
     for (uint64_t i = wave; i < P.n_sent; i += n_waves) {
-        const uint64_t b0 = P.boff[i], b1 = P.boff[i + 1], o0 = P.ooff[i], o1 = P.ooff[i + 1];
+        const uint64_t b0 = wave_uniform64(P.boff[i]), b1 = wave_uniform64(P.boff[i + 1]);
+        const uint64_t o0 = wave_uniform64(P.ooff[i]), o1 = wave_uniform64(P.ooff[i + 1]);
         const bool sane = b1 > b0 && o1 >= o0 && o1 <= P.total_boundaries;
         const uint64_t n_labels = sane ? o1 - o0 : 0;
-        uint64_t chars = 0, bytes_out = 0;
-        for (uint64_t pos = b0; sane && pos < b1; pos += 64) {
-            uint64_t leads;
-            const ByteOut o = classify_byte(P.text, pos + uint64_t(lane), b1, P.labels + o0, n_labels, chars, lane, leads, err);
-            // a token's tag suffix goes in front of the space that starts the next token: char index of its last char
-            const uint32_t sfx = o.space ? tag_suffix(P, o0 + i + chars + below(leads, lane) - 1, nullptr) : 0u;
-            bytes_out += wave_sum(o.n + sfx);
-            chars += uint64_t(__popcll(leads));
+        uint64_t mine = 0, leads = 0;   // this lane's share of the added bytes / of the chars
+        if (sane) {
+            for (uint64_t pos = b0; pos < b1; pos += 256) {
+                const uint64_t at = pos + 4 * uint64_t(lane);
+                const uint32_t x = load4(P.text, at, b1);
+                const uint32_t nv = at < b1 ? uint32_t(b1 - at < 4 ? b1 - at : 4) : 0u, vm = (1u << nv) - 1u;
+                leads += uint32_t(__popc(lead_nibble(x) & vm));
+                mine += uint32_t(__popc(esc_nibble(x) & vm));
+            }
+            const uint8_t* lab = P.labels + o0;
+            for (uint64_t k0 = 0; k0 < n_labels; k0 += 256) {
+                const uint64_t k = k0 + 4 * uint64_t(lane);
+                const uint32_t y = load4(lab, k, n_labels);
+                if (y & 0xFEFEFEFEu) err |= kErrUnknownLabel;
+                uint32_t om = byte_flags_to_nibble(zero_bytes(y ^ 0x01010101u));   // (a byte past n_labels reads 0: not a boundary)
+                mine += uint32_t(__popc(om));
+                if (P.tags && om) {   // a token's tag suffix hangs on the label that ends it: char k + q is its last char
+                    const Models4 tm = load_models4(P, o0 + i + k);
+                    uint32_t todo = om & ((tm.m[0] > 0 ? 1u : 0u) | (tm.m[1] > 0 ? 2u : 0u) | (tm.m[2] > 0 ? 4u : 0u) | (tm.m[3] > 0 ? 8u : 0u));
+                    while (todo) {   // the few tokens with a tag model (one call site: the routine is long)
+                        const uint32_t q = uint32_t(__ffs(int(todo))) - 1u;
+                        todo &= todo - 1u;
+                        mine += tag_suffix(P, o0 + i + k + q, nullptr);
+                    }
+                }
+            }
         }
-        if (!sane) err |= b1 > b0 ? kErrBadOffsets : kErrEmptySentence;
+        const uint64_t chars = wave_sum64(leads);
+        uint64_t bytes_out = (b1 - b0) + wave_sum64(mine);
+        if (!sane) { err |= b1 > b0 ? kErrBadOffsets : kErrEmptySentence; bytes_out = 0; }
         else if (chars != n_labels + 1) err |= kErrBadOffsets;
         else bytes_out += tag_suffix(P, o1 + i, nullptr);   // the last token's (every lane computes the same)
         if (lane == 0) P.out_offsets[i + 1] = bytes_out;
@@ -123,65 +129,199 @@ __global__ __launch_bounds__(kEmitThreads) void emit_count_kernel(const EmitPara
     if (err) atomicOr(P.status, err);
 }
 
-// exclusive scan over offsets[1 .. n] in place (offsets[k] = sum of the lengths of sentences 0 .. k-1), one workgroup
-__global__ __launch_bounds__(kScanThreads) void emit_scan_kernel(uint64_t* __restrict__ offsets, uint64_t n, uint64_t capacity,
-                                                                 uint32_t* __restrict__ status) {
-    __shared__ uint64_t part[kScanThreads];
-    const uint32_t tid = threadIdx.x;
-    const uint64_t per = (n + kScanThreads - 1) / kScanThreads;     // consecutive sentences per thread
-    const uint64_t lo = uint64_t(tid) * per, hi = lo + per < n ? lo + per : n;
-    uint64_t sum = 0;
-    for (uint64_t k = lo; k < hi; ++k) sum += offsets[k + 1];
-    part[tid] = sum;
+// ---- inclusive prefix sum over offsets[1 .. n] in place (offsets[k] = sum of the lengths of sentences 0 .. k-1)
+__device__ __forceinline__ uint64_t block_exclusive_scan(uint64_t* lds, uint64_t v, uint32_t tid, uint32_t n_threads, uint64_t* total) {
+    lds[tid] = v;
     __syncthreads();
-    for (uint32_t d = 1; d < uint32_t(kScanThreads); d <<= 1) {        // Hillis-Steele over the per-thread totals
-        const uint64_t v = tid >= d ? part[tid - d] : 0;
+    for (uint32_t d = 1; d < n_threads; d <<= 1) {        // Hillis-Steele
+        const uint64_t t = tid >= d ? lds[tid - d] : 0;
         __syncthreads();
-        part[tid] += v;
+        lds[tid] += t;
         __syncthreads();
     }
-    uint64_t run = tid == 0 ? 0 : part[tid - 1];
-    for (uint64_t k = lo; k < hi; ++k) {                               // lengths -> end offsets, in place
-        run += offsets[k + 1];
-        offsets[k + 1] = run;
+    const uint64_t incl = lds[tid];
+    *total = lds[n_threads - 1];
+    __syncthreads();
+    return incl - v;
+}
+
+__global__ __launch_bounds__(kScanThreads) void scan_partials_kernel(const uint64_t* __restrict__ offsets, uint64_t n, uint64_t* __restrict__ part) {
+    __shared__ uint64_t lds[kScanThreads];
+    const uint32_t tid = threadIdx.x;
+    const uint64_t base = uint64_t(blockIdx.x) * kScanBlock;
+    uint64_t sum = 0;
+#pragma unroll
+    for (int j = 0; j < kScanPer; ++j) {   // coalesced
+        const uint64_t k = base + uint64_t(j) * kScanThreads + tid;
+        sum += k < n ? offsets[k + 1] : 0;
+    }
+    uint64_t total;
+    (void)block_exclusive_scan(lds, sum, tid, kScanThreads, &total);
+    if (tid == 0) part[blockIdx.x] = total;
+}
+
+__global__ __launch_bounds__(kTopThreads) void scan_top_kernel(uint64_t* __restrict__ part, uint64_t n_part, uint64_t* __restrict__ offsets, uint64_t capacity,
+                                                               uint32_t* __restrict__ status) {
+    __shared__ uint64_t lds[kTopThreads];
+    const uint32_t tid = threadIdx.x;
+    const uint64_t per = (n_part + kTopThreads - 1) / kTopThreads;     // consecutive partials per thread
+    const uint64_t lo = uint64_t(tid) * per, hi = lo + per < n_part ? lo + per : n_part;
+    uint64_t sum = 0;
+    for (uint64_t k = lo; k < hi; ++k) sum += part[k];
+    uint64_t total;
+    uint64_t run = block_exclusive_scan(lds, sum, tid, kTopThreads, &total);
+    for (uint64_t k = lo; k < hi; ++k) {                               // sums -> exclusive prefixes, in place
+        const uint64_t v = part[k];
+        part[k] = run;
+        run += v;
     }
     if (tid == 0) {
         offsets[0] = 0;
-        if (part[kScanThreads - 1] > capacity) atomicOr(status, kErrOutputTooSmall);
+        if (total > capacity) atomicOr(status, kErrOutputTooSmall);
     }
 }
 
+__global__ __launch_bounds__(kScanThreads) void scan_apply_kernel(uint64_t* __restrict__ offsets, uint64_t n, const uint64_t* __restrict__ part) {
+    __shared__ uint64_t lds[kScanThreads];
+    const uint32_t tid = threadIdx.x;
+    const uint64_t first = uint64_t(blockIdx.x) * kScanBlock + uint64_t(tid) * kScanPer;   // this thread's consecutive entries
+    uint64_t v[kScanPer];
+    uint64_t sum = 0;
+#pragma unroll
+    for (int j = 0; j < kScanPer; ++j) {
+        v[j] = first + j < n ? offsets[first + j + 1] : 0;
+        sum += v[j];
+    }
+    uint64_t total;
+    uint64_t run = part[blockIdx.x] + block_exclusive_scan(lds, sum, tid, kScanThreads, &total);
+#pragma unroll
+    for (int j = 0; j < kScanPer; ++j) {
+        run += v[j];
+        if (first + j < n) offsets[first + j + 1] = run;
+    }
+}
+
+hipError_t launch_scan(uint64_t* offsets, uint64_t n, uint64_t* part, uint64_t capacity, uint32_t* status, hipStream_t stream) {
+    const uint64_t n_part = (n + kScanBlock - 1) / kScanBlock;
+    hipLaunchKernelGGL(scan_partials_kernel, dim3(uint32_t(n_part)), dim3(kScanThreads), 0, stream, offsets, n, part);
+    hipLaunchKernelGGL(scan_top_kernel, dim3(1), dim3(kTopThreads), 0, stream, part, n_part, offsets, capacity, status);
+    hipLaunchKernelGGL(scan_apply_kernel, dim3(uint32_t(n_part)), dim3(kScanThreads), 0, stream, offsets, n, part);
+    return hipGetLastError();
+}
+
+struct EmitLds { uint32_t stage[kEmitWaves][kStageBytes / 4]; };
+
 __global__ __launch_bounds__(kEmitThreads) void emit_write_kernel(const EmitParams P) {
+    __shared__ EmitLds LDS;
     const int lane = threadIdx.x & 63;
-    const uint64_t wave = uint64_t(blockIdx.x) * kEmitWaves + (threadIdx.x >> 6);
+    const uint32_t wid = wave_uniform(threadIdx.x >> 6);
+    uint32_t* const stage = LDS.stage[wid];
+    uint8_t* const sb = reinterpret_cast<uint8_t*>(stage);
+    const uint64_t wave = uint64_t(blockIdx.x) * kEmitWaves + wid;
     const uint64_t n_waves = uint64_t(gridDim.x) * kEmitWaves;
     for (uint64_t i = wave; i < P.n_sent; i += n_waves) {
-        const uint64_t b0 = P.boff[i], b1 = P.boff[i + 1], o0 = P.ooff[i], o1 = P.ooff[i + 1];
+        const uint64_t b0 = wave_uniform64(P.boff[i]), b1 = wave_uniform64(P.boff[i + 1]);
+        const uint64_t o0 = wave_uniform64(P.ooff[i]), o1 = wave_uniform64(P.ooff[i + 1]);
         if (!(b1 > b0 && o1 >= o0 && o1 <= P.total_boundaries)) continue;   // reported by emit_count_kernel
         const uint64_t n_labels = o1 - o0;
-        const uint64_t end = P.out_offsets[i + 1];
-        uint64_t at_out = P.out_offsets[i], chars = 0;
-        if (end > P.capacity) continue;                                    // kErrOutputTooSmall
-        uint32_t err = 0;
-        for (uint64_t pos = b0; pos < b1; pos += 64) {
-            uint64_t leads;
-            const uint64_t at = pos + uint64_t(lane);
-            const ByteOut o = classify_byte(P.text, at, b1, P.labels + o0, n_labels, chars, lane, leads, err);
-            const uint64_t prev = o0 + i + chars + below(leads, lane) - 1;   // last char of the token in front of a space
-            const uint32_t sfx = o.space ? tag_suffix(P, prev, nullptr) : 0u;
-            uint64_t w = at_out + wave_exclusive(o.n + sfx, lane);
-            if (o.n != 0 && w + o.n + sfx <= end) {                        // `end` only binds when the inputs changed under us
-                if (sfx) w += tag_suffix(P, prev, P.out_text + w);
-                if (o.space) P.out_text[w++] = 0x20u;
-                if (o.esc) P.out_text[w++] = 0x5Cu;
-                P.out_text[w] = P.text[at];
+        const uint8_t* lab = P.labels + o0;
+        const uint64_t end = wave_uniform64(P.out_offsets[i + 1]);
+        uint64_t at_out = wave_uniform64(P.out_offsets[i]), chars = 0;
+        if (end > P.capacity || end < at_out) continue;                    // kErrOutputTooSmall
+        bool fits = true;                                                  // `end` only binds when the inputs changed under us
+        for (uint64_t pos = b0; pos < b1 && fits; pos += 256) {
+            const uint64_t at = pos + 4 * uint64_t(lane);
+            const uint32_t x = load4(P.text, at, b1);
+            const uint32_t nv = at < b1 ? uint32_t(b1 - at < 4 ? b1 - at : 4) : 0u, vm = (1u << nv) - 1u;
+            const uint32_t lm = lead_nibble(x) & vm, em = esc_nibble(x) & vm;
+            const uint32_t nl = uint32_t(__popc(lm));
+            const uint32_t incl_l = wave_inclusive_scan(nl);
+            const uint64_t ci0 = chars + (incl_l - nl);                    // index in the sentence of this lane's first char
+            // the labels in front of this lane's chars: label[ci0 - 1 + q] for its q-th char (none in front of char 0)
+            uint32_t y = nl ? load4(lab, ci0 ? ci0 - 1 : 0, n_labels) : 0u;
+            if (ci0 == 0) y <<= 8;
+            // which of the lane's chars have a space in front (bit q: its q-th char), moved onto the chars' lead bytes (bit k: byte k)
+            const uint32_t spq = byte_flags_to_nibble(zero_bytes(y ^ 0x01010101u)) & ((1u << nl) - 1u);
+            uint32_t spm = 0;
+            {
+                uint32_t rem = lm;
+#pragma unroll
+                for (uint32_t q = 0; q < 4; ++q) {
+                    const uint32_t low = rem & (0u - rem);
+                    if ((spq >> q) & 1u) spm |= low;
+                    rem &= rem - 1u;
+                }
             }
-            at_out += wave_sum(o.n + sfx);
-            chars += uint64_t(__popcll(leads));
+            // the token in front of a space ends at the char before it and its tags go in front of the space: the tag models of
+            // chars ci0 - 1 .. ci0 + 2 in one load, the suffix lengths of the few that have one (one call site: the routine is long)
+            uint32_t sfx[4] = {0, 0, 0, 0};
+            if (P.tags && spq) {
+                Models4 tm = load_models4(P, o0 + i + (ci0 ? ci0 - 1 : 0));
+                if (ci0 == 0) { tm.m[3] = tm.m[2]; tm.m[2] = tm.m[1]; tm.m[1] = tm.m[0]; tm.m[0] = 0; }
+                uint32_t todo = spq & ((tm.m[0] > 0 ? 1u : 0u) | (tm.m[1] > 0 ? 2u : 0u) | (tm.m[2] > 0 ? 4u : 0u) | (tm.m[3] > 0 ? 8u : 0u));
+                while (todo) {
+                    const uint32_t q = uint32_t(__ffs(int(todo))) - 1u;
+                    todo &= todo - 1u;
+                    const uint32_t len = tag_suffix(P, o0 + i + ci0 + q - 1, nullptr);
+                    // char q's lead byte: the q-th set bit of lm
+                    uint32_t rem = lm;
+                    for (uint32_t r = 0; r < q; ++r) rem &= rem - 1u;
+                    const uint32_t k = uint32_t(__ffs(int(rem))) - 1u;
+                    sfx[0] += k == 0 ? len : 0u; sfx[1] += k == 1 ? len : 0u; sfx[2] += k == 2 ? len : 0u; sfx[3] += k == 3 ? len : 0u;
+                }
+            }
+            const uint32_t t = nv + uint32_t(__popc(spm)) + uint32_t(__popc(em)) + sfx[0] + sfx[1] + sfx[2] + sfx[3];
+            const uint32_t incl_t = wave_inclusive_scan(t);
+            const uint32_t total = uint32_t(__builtin_amdgcn_readlane(int(incl_t), 63));
+            const uint32_t w = incl_t - t;                                 // where this lane's output starts in the step's
+            if (at_out + total > end) { fits = false; break; }
+            uint8_t* const dst = P.out_text + at_out;
+            const uint32_t head = uint32_t(reinterpret_cast<uintptr_t>(dst) & 3u);
+            const bool staged = head + total <= kStageBytes;               // (wave-uniform) else: byte stores straight to the output
+            auto put = [&](uint8_t* const o) {   // byte k of the lane goes to w + k + what is inserted up to it: [tags] [' '] ['\\'] byte
+                uint32_t ins = w;
+#pragma unroll
+                for (uint32_t k = 0; k < 4; ++k) {
+                    const uint32_t sp = (spm >> k) & 1u, es = (em >> k) & 1u;
+                    ins += sfx[k] + sp + es;
+                    if (k < nv) {
+                        o[ins + k] = uint8_t(x >> (8 * k));
+                        if (es) o[ins + k - 1u] = 0x5Cu;
+                        if (sp) o[ins + k - 1u - es] = 0x20u;
+                    }
+                }
+                uint32_t todo = (sfx[0] ? 1u : 0u) | (sfx[1] ? 2u : 0u) | (sfx[2] ? 4u : 0u) | (sfx[3] ? 8u : 0u);
+                while (todo) {   // rare: the tags themselves, in front of the space of lead byte k
+                    const uint32_t k = uint32_t(__ffs(int(todo))) - 1u;
+                    todo &= todo - 1u;
+                    uint32_t at_k = w + k, q = 0;   // bytes of the lane in front of byte k's own insertions; k is the lane's q-th char
+                    for (uint32_t j = 0; j < k; ++j) { at_k += sfx[j] + ((spm >> j) & 1u) + ((em >> j) & 1u); q += (lm >> j) & 1u; }
+                    (void)tag_suffix(P, o0 + i + ci0 + q - 1, o + at_k);
+                }
+            };
+            if (staged) put(sb + head);   // (two calls: one writes LDS, one global memory -- not one through a generic pointer)
+            else put(dst);
+            if (staged) {   // LDS byte j is output byte j - head: whole dwords leave aligned, the two edges byte by byte
+                __builtin_amdgcn_wave_barrier();
+                uint8_t* const abase = dst - head;
+                const uint32_t nd = (head + total + 3u) >> 2;
+                for (uint32_t d = uint32_t(lane); d < nd; d += 64) {
+                    const uint32_t lo = d * 4u, hi = lo + 4u;
+                    if (lo >= head && hi <= head + total) {
+                        *reinterpret_cast<uint32_t*>(abase + lo) = stage[d];
+                    } else {
+                        const uint32_t a = lo > head ? lo : head, b = hi < head + total ? hi : head + total;
+                        for (uint32_t j = a; j < b; ++j) abase[j] = sb[j];
+                    }
+                }
+                __builtin_amdgcn_wave_barrier();
+            }
+            at_out += total;
+            chars += uint32_t(__builtin_amdgcn_readlane(int(incl_l), 63));
         }
-        if (lane == 0 && chars == n_labels + 1) {                          // the last token's tags
-            const uint32_t sfx = tag_suffix(P, o1 + i, nullptr);
-            if (sfx && at_out + sfx <= end) tag_suffix(P, o1 + i, P.out_text + at_out);
+        if (fits && lane == 0 && chars == n_labels + 1) {                  // the last token's tags
+            const uint32_t s = tag_suffix(P, o1 + i, nullptr);
+            if (s && at_out + s <= end) tag_suffix(P, o1 + i, P.out_text + at_out);
         }
     }
 }
@@ -192,20 +332,21 @@ __global__ __launch_bounds__(kEmitThreads) void count_chars_kernel(const uint8_t
                                                                    uint64_t n_sent, uint64_t* __restrict__ offsets, uint32_t* __restrict__ status,
                                                                    uint32_t* __restrict__ max_chars) {
     const int lane = threadIdx.x & 63;
-    const uint64_t wave = uint64_t(blockIdx.x) * kEmitWaves + (threadIdx.x >> 6);
+    const uint64_t wave = uint64_t(blockIdx.x) * kEmitWaves + wave_uniform(threadIdx.x >> 6);
     const uint64_t n_waves = uint64_t(gridDim.x) * kEmitWaves;
     uint32_t err = 0, longest = 0;
     for (uint64_t i = wave; i < n_sent; i += n_waves) {
-        const uint64_t b0 = boff[i], b1 = boff[i + 1];
-        uint64_t chars = 0;
+        const uint64_t b0 = wave_uniform64(boff[i]), b1 = wave_uniform64(boff[i + 1]);
+        uint64_t mine = 0;
         bool nul = false;
-        for (uint64_t pos = b0; pos < b1; pos += 64) {
-            const uint64_t at = pos + uint64_t(lane);
-            const bool in = at < b1;
-            const uint32_t byte = in ? text[at] : 0x80u;
-            nul = nul || (in && byte == 0);
-            chars += uint64_t(__popcll(__ballot(in && (byte & 0xC0u) != 0x80u)));
+        for (uint64_t pos = b0; pos < b1; pos += 256) {
+            const uint64_t at = pos + 4 * uint64_t(lane);
+            const uint32_t x = load4(text, at, b1);
+            const uint32_t nv = at < b1 ? uint32_t(b1 - at < 4 ? b1 - at : 4) : 0u, vm = (1u << nv) - 1u;
+            nul = nul || (byte_flags_to_nibble(zero_bytes(x)) & vm) != 0;
+            mine += uint32_t(__popc(lead_nibble(x) & vm));
         }
+        const uint64_t chars = wave_sum64(mine);
         if (__ballot(nul) != 0) err |= kErrNulChar;
         if (b1 <= b0 || chars == 0) err |= kErrEmptySentence;
         if (chars > 0xFFFFFFFFull) err |= kErrBadOffsets;
@@ -218,20 +359,27 @@ __global__ __launch_bounds__(kEmitThreads) void count_chars_kernel(const uint8_t
 
 }  // namespace
 
-hipError_t launch_count_boundaries(const uint8_t* text, const uint64_t* boff, uint64_t n_sent, uint64_t* ooff_out, uint32_t* status,
-                                   uint32_t* max_chars, hipStream_t stream) {
-    const uint64_t want = (n_sent + kEmitWaves - 1) / kEmitWaves;
-    const uint32_t blocks = uint32_t(want < 1 ? 1 : want > 65536 ? 65536 : want);
-    hipLaunchKernelGGL(count_chars_kernel, dim3(blocks), dim3(kEmitThreads), 0, stream, text, boff, n_sent, ooff_out, status, max_chars);
-    hipLaunchKernelGGL(emit_scan_kernel, dim3(1), dim3(kScanThreads), 0, stream, ooff_out, n_sent, ~uint64_t(0), status);
-    return hipGetLastError();
+size_t scan_part_entries(uint64_t n) { return size_t((n + kScanBlock - 1) / kScanBlock) + 1; }
+
+// one wave per sentence, but no more workgroups than `max_blocks` (a few generations of what the device runs at a time; 0: 65536):
+// the waves then stride over the batch and the sentences' lengths even out (see launch_tag_tokens)
+static uint32_t emit_blocks(uint64_t n_sent, uint32_t max_blocks) {
+    const uint64_t want = (n_sent + kEmitWaves - 1) / kEmitWaves, cap = max_blocks ? max_blocks : 65536;
+    return uint32_t(want < 1 ? 1 : want > cap ? cap : want);
 }
 
-hipError_t launch_emit_tokenized(const EmitParams& P, hipStream_t stream) {
-    const uint64_t want = (P.n_sent + kEmitWaves - 1) / kEmitWaves;
-    const uint32_t blocks = uint32_t(want < 1 ? 1 : want > 65536 ? 65536 : want);
+hipError_t launch_count_boundaries(const uint8_t* text, const uint64_t* boff, uint64_t n_sent, uint64_t* ooff_out, uint64_t* scan_part, uint32_t* status,
+                                   uint32_t* max_chars, uint32_t max_blocks, hipStream_t stream) {
+    const uint32_t blocks = emit_blocks(n_sent, max_blocks);
+    hipLaunchKernelGGL(count_chars_kernel, dim3(blocks), dim3(kEmitThreads), 0, stream, text, boff, n_sent, ooff_out, status, max_chars);
+    return launch_scan(ooff_out, n_sent, scan_part, ~uint64_t(0), status, stream);
+}
+
+hipError_t launch_emit_tokenized(const EmitParams& P, uint64_t* scan_part, uint32_t max_blocks, hipStream_t stream) {
+    const uint32_t blocks = emit_blocks(P.n_sent, max_blocks);
     hipLaunchKernelGGL(emit_count_kernel, dim3(blocks), dim3(kEmitThreads), 0, stream, P);
-    hipLaunchKernelGGL(emit_scan_kernel, dim3(1), dim3(kScanThreads), 0, stream, P.out_offsets, P.n_sent, P.capacity, P.status);
+    const hipError_t e = launch_scan(P.out_offsets, P.n_sent, scan_part, P.capacity, P.status, stream);
+    if (e != hipSuccess) return e;
     hipLaunchKernelGGL(emit_write_kernel, dim3(blocks), dim3(kEmitThreads), 0, stream, P);
     return hipGetLastError();
 }

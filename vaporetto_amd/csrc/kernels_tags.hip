@@ -68,16 +68,9 @@ __global__ __launch_bounds__(kTagThreads) void decode_chars_kernel(const uint8_t
         uint64_t seen = 0;
         for (uint64_t pos = b0; sane && pos < b1; pos += 256) {
             const uint64_t at = pos + 4 * uint64_t(lane);
-            // eight bytes from `at`, never reading at or past b1 (the text may end where its allocation does)
-            uint64_t x = 0;
-            if (at + 8 <= b1) {
-                uint32_t lo, hi;
-                __builtin_memcpy(&lo, text + at, 4);
-                __builtin_memcpy(&hi, text + at + 4, 4);
-                x = uint64_t(lo) | (uint64_t(hi) << 32);
-            } else {
-                for (uint64_t k = 0; k < 8 && at + k < b1; ++k) x |= uint64_t(text[at + k]) << (8 * k);
-            }
+            // eight bytes from `at` (the lane's own four and the rest of a char that starts in them), never reading past the aligned
+            // word that holds the sentence's last byte (the text may end where its allocation does)
+            const uint64_t x = uint64_t(load4(text, at, b1)) | (uint64_t(load4(text, at + 4, b1)) << 32);
             const uint32_t mine = at < b1 ? uint32_t(b1 - at < 4 ? b1 - at : 4) : 0u;          // bytes of this lane's own dword inside the sentence
             const uint32_t lm = lead_nibble(uint32_t(x)) & ((1u << mine) - 1u);              // which of them start a char
             const uint32_t incl = wave_inclusive_scan(uint32_t(__popc(lm)));
