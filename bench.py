@@ -352,10 +352,15 @@ class Runner:
             for _ in range(2):
                 api.predict_packed_sharded([pred], keep[0].array, boff, out_offsets=ooff, scores=keep[1].array, labels=keep[2].array)
             k = max(5, min(steps, 20))
-            t0 = time.perf_counter()
-            for _ in range(k):
-                api.predict_packed_sharded([pred], keep[0].array, boff, out_offsets=ooff, scores=keep[1].array, labels=keep[2].array)
-            dt = (time.perf_counter() - t0) / k
+
+            def median_time(fn, n):   # per-call wall clock, median: the host's other threads (the CPU baseline just ran on all of them) show up as outliers
+                ts = []
+                for _ in range(n):
+                    t0 = time.perf_counter()
+                    fn()
+                    ts.append(time.perf_counter() - t0)
+                return float(np.median(ts))
+            dt = median_time(lambda: api.predict_packed_sharded([pred], keep[0].array, boff, out_offsets=ooff, scores=keep[1].array, labels=keep[2].array), k)
             bytes_in, bytes_out = nbytes + 16 * (S + 1), 5 * nb
             e2e = {"boundaries_per_s": nb / dt, "ms_per_batch": 1e3 * dt, "h2d_GBps": bytes_in / dt / 1e9, "d2h_GBps": bytes_out / dt / 1e9,
                    "pcie_peak_GBps_per_direction": PCIE_GBS, "frac_of_pcie": max(bytes_in, bytes_out) / dt / 1e9 / PCIE_GBS,
@@ -364,13 +369,20 @@ class Runner:
                            "in-order lanes, larger ones in 4 M-char chunks on three streams with events"}
             # the same batch when only the labels come back (what a tokenizer needs: 1 of the 5 bytes per boundary)
             keep[2].array[:] = 9
-            t0 = time.perf_counter()
-            for _ in range(k):
-                api.predict_packed_sharded([pred], keep[0].array, boff, out_offsets=ooff, labels=keep[2].array, want_scores=False)
-            dt = (time.perf_counter() - t0) / k
+            dt = median_time(lambda: api.predict_packed_sharded([pred], keep[0].array, boff, out_offsets=ooff, labels=keep[2].array, want_scores=False), k)
             e2e["labels_only"] = {"boundaries_per_s": nb / dt, "ms_per_batch": 1e3 * dt, "h2d_GBps": bytes_in / dt / 1e9,
                                   "frac_of_pcie": bytes_in / dt / 1e9 / PCIE_GBS,
                                   "parity": bool(parity is None or np.array_equal(keep[2].array[:nb], o_labels))}
+            # lines in, tokenized lines out (vpt_tokenize_batch: what the reference's CLI loop does, predict/src/main.rs:122-176):
+            # only text crosses the link, in one piece each way
+            tk = [api.PinnedArray((3 * nbytes + 64,), np.uint8), api.PinnedArray((S + 1,), np.uint64)]
+            for _ in range(2):
+                tok_text, tok_off = pred.tokenize_packed(keep[0].array, boff, text_out=tk[0].array, offsets_out=tk[1].array)
+            dt = median_time(lambda: pred.tokenize_packed(keep[0].array, boff, text_out=tk[0].array, offsets_out=tk[1].array), k)
+            e2e["tokenize"] = {"ms_per_batch": 1e3 * dt, "chars_per_s": (nb + S) / dt, "h2d_GBps": (nbytes + 8 * (S + 1)) / dt / 1e9,
+                               "d2h_GBps": (len(tok_text) + 8 * (S + 1)) / dt / 1e9, "out_bytes": int(len(tok_text)),
+                               "path": "vpt_tokenize_batch: copy in, count chars, score, write tokens, copy out on one stream (not chunked)"}
+            del tk
             # ten of these batches as one call: what the pipeline does once its start-up no longer counts
             rep = 10
             big = [api.PinnedArray((nbytes * rep,), np.uint8), api.PinnedArray((nb * rep,), np.int32), api.PinnedArray((nb * rep,), np.uint8)]
@@ -379,11 +391,7 @@ class Runner:
             ooff_big = np.concatenate([ooff[:-1] + np.uint64(r * nb) for r in range(rep)] + [np.array([rep * nb], dtype=np.uint64)])
             for _ in range(2):
                 api.predict_packed_sharded([pred], big[0].array, boff_big, out_offsets=ooff_big, scores=big[1].array, labels=big[2].array)
-            kb = 5
-            t0 = time.perf_counter()
-            for _ in range(kb):
-                api.predict_packed_sharded([pred], big[0].array, boff_big, out_offsets=ooff_big, scores=big[1].array, labels=big[2].array)
-            dt = (time.perf_counter() - t0) / kb
+            dt = median_time(lambda: api.predict_packed_sharded([pred], big[0].array, boff_big, out_offsets=ooff_big, scores=big[1].array, labels=big[2].array), 7)
             e2e["large_batch"] = {"sentences": S * rep, "boundaries_per_s": nb * rep / dt, "ms_per_batch": 1e3 * dt, "d2h_GBps": bytes_out * rep / dt / 1e9,
                                   "h2d_GBps": bytes_in * rep / dt / 1e9, "frac_of_pcie": bytes_out * rep / dt / 1e9 / PCIE_GBS,
                                   "parity": bool(parity is None or (np.array_equal(big[1].array[(rep - 1) * nb:], o_scores) and np.array_equal(big[2].array[:nb], o_labels)))}

@@ -1,11 +1,12 @@
 #!/bin/bash
 set -u
-O=gpurun_out/c38; mkdir -p $O
-export TMPDIR=/tmp
-timeout 600 python -m pytest tests -m gpu -x -q > $O/pytest.log 2>&1; echo "pytest rc=$?"; tail -2 $O/pytest.log
-for c in 1 4; do
-timeout 600 python bench.py --config $c --quick --steps 10 --warmup 2 --no-e2e > $O/b$c.json 2> $O/b$c.err; echo "rc=$?"; tail -2 $O/b$c.err | cut -c1-300
-python -c "
-import json;d=json.loads(open('$O/b$c.json').read().strip().splitlines()[-1]);print('emit',d.get('emit'));print('tags',d.get('tags'));print('kernel_ms',d['roofline']['kernel_ms'],'parity',d['parity'])"
-done
-timeout 120 python tools/fuzz_gpu.py 60 > $O/fuzz.log 2>&1; tail -1 $O/fuzz.log
+O=gpurun_out/c41; mkdir -p $O
+for i in 1 2 3; do timeout 200 python tools/e2e_bench.py > $O/e_$i.json 2>/dev/null; cut -c1-150 $O/e_$i.json; done
+timeout 600 python bench.py --config 1 --quick --steps 20 --warmup 5 --no-emit > $O/b_noemit.json 2>/dev/null
+timeout 600 python bench.py --config 1 --quick --steps 20 --warmup 5 > $O/b_emit.json 2>/dev/null
+python - <<'PY'
+import json
+for n in ("b_noemit","b_emit"):
+    d=json.loads(open("gpurun_out/c41/%s.json"%n).read().strip().splitlines()[-1])
+    e=d["e2e"]; print(n, round(e["ms_per_batch"],4), round(e["labels_only"]["ms_per_batch"],4), round(e["tokenize"]["ms_per_batch"],4), round(e["large_batch"]["ms_per_batch"],3))
+PY

@@ -403,13 +403,31 @@ class Predictor:
             _raise(st)
         return tags[:, :nt]
 
+    def tokenize_packed(self, utf8: np.ndarray, byte_offsets: np.ndarray, tagged: bool = False, flags: int = 0,
+                        text_out: Optional[np.ndarray] = None, offsets_out: Optional[np.ndarray] = None):
+        """vpt_tokenize_batch over a packed batch: (uint8 tokenized text, uint64 [S+1] offsets).  `text_out` / `offsets_out` may be
+        preallocated (pinned) arrays; text_out needs 3 x the text bytes (+ text bytes x max_tag_suffix() when tagged)."""
+        L = _lib.load()
+        utf8 = np.ascontiguousarray(utf8, dtype=np.uint8)
+        byte_offsets = np.ascontiguousarray(byte_offsets, dtype=np.uint64)
+        S = len(byte_offsets) - 1
+        cap = 3 * len(utf8) + (len(utf8) * self.max_tag_suffix() if tagged else 0)
+        if text_out is None:
+            text_out = np.zeros(max(cap, 1), dtype=np.uint8)
+        if offsets_out is None:
+            offsets_out = np.zeros(S + 1, dtype=np.uint64)
+        st = L.vpt_tokenize_batch(self._h, utf8.ctypes.data, byte_offsets.ctypes.data, S, flags, int(tagged), text_out.ctypes.data,
+                                  min(cap, text_out.nbytes), offsets_out.ctypes.data)
+        if st != _lib.VPT_OK:
+            _raise(st)
+        return text_out[:int(offsets_out[S])], offsets_out
+
     def tokenize(self, texts: Sequence[str], tagged: bool = False, fullwidth: bool = False, wsconst: Sequence[int] = (),
                  split_linebreaks: bool = False) -> List[str]:
         """Lines in, tokenized lines out (vpt_tokenize_batch): the CLI's loop (predict/src/main.rs:122-176) for a batch,
         with char counting, scoring, post-filters, tagging and the writer on the device."""
         if not texts:
             return []
-        L = _lib.load()
         utf8, boff = pack_texts([t.encode("utf-8") for t in texts])
         S = len(texts)
         flags = _lib.VPT_FLAG_KYTEA_FULLWIDTH if fullwidth else 0
@@ -417,18 +435,8 @@ class Predictor:
             flags |= _lib.VPT_FLAG_WSCONST(int(t))
         if split_linebreaks:
             flags |= _lib.VPT_FLAG_SPLIT_LINEBREAKS
-        cap = 3 * len(utf8)
-        if tagged:
-            sfx = C.c_uint32(0)
-            if L.vpt_predictor_max_tag_suffix(self._h, C.byref(sfx)) != _lib.VPT_OK:
-                _raise(_lib.VPT_INVALID_ARGUMENT)
-            cap += len(utf8) * int(sfx.value)
-        text = np.zeros(max(cap, 1), dtype=np.uint8)
-        toff = np.zeros(S + 1, dtype=np.uint64)
-        st = L.vpt_tokenize_batch(self._h, utf8.ctypes.data, boff.ctypes.data, S, flags, int(tagged), text.ctypes.data, cap, toff.ctypes.data)
-        if st != _lib.VPT_OK:
-            _raise(st)
-        raw = bytes(text[:int(toff[S])])
+        text, toff = self.tokenize_packed(utf8, boff, tagged=tagged, flags=flags)
+        raw = bytes(text)
         return [raw[int(toff[i]):int(toff[i + 1])].decode("utf-8") for i in range(S)]
 
     def write_tokenized_packed(self, utf8: np.ndarray, byte_offsets: np.ndarray, out_offsets: np.ndarray,
