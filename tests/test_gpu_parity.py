@@ -692,6 +692,23 @@ def test_tag_token_table_keys_and_queue():
     assert (got >= 0).any()
 
 
+@pytest.mark.parametrize("chunk_bytes", ["700"])
+def test_tokenize_batch_in_chunks(chunk_bytes, monkeypatch):
+    """vpt_tokenize_batch runs chunk by chunk over several lanes with every slice of its device buffers placed by an upper
+    bound and no number read back on the way; with VPT_TOKENIZE_CHUNK_BYTES tiny the same batches go through dozens of chunks
+    (tagged and plain, filters on, a sentence longer than a chunk, errors still reported)."""
+    monkeypatch.setenv("VPT_TOKENIZE_CHUNK_BYTES", chunk_bytes)
+    test_tokenize_batch_is_the_whole_pipeline()
+    m = randmodel.rand_model(852, alphabet="kana", wc=3, wt=3, n_char=60, n_dict=60)
+    pred = api.Predictor(api.Model.read_slice(encode_model(m))[0], False)
+    texts = randmodel.rand_sentences(8, m, 300, alphabet="kana", max_len=40)
+    texts[150] = "a\x00b"
+    with pytest.raises(api.VaporettoError) as e:
+        pred.tokenize(texts)
+    assert "NULL" in str(e.value)
+    assert pred.tokenize(texts[:150]) == pred.tokenize(texts[:100]) + pred.tokenize(texts[100:150])   # and the workspaces are clean again
+
+
 def test_converted_kytea_fixture_on_gpu():
     """resources/kytea-model.bin converted by vaporetto_amd/kytea.py (kytea_model.rs:401-422): same tokens on the GPU."""
     from vaporetto_amd import kytea

@@ -1,12 +1,12 @@
 #!/bin/bash
 set -u
-O=gpurun_out/c41; mkdir -p $O
-for i in 1 2 3; do timeout 200 python tools/e2e_bench.py > $O/e_$i.json 2>/dev/null; cut -c1-150 $O/e_$i.json; done
-timeout 600 python bench.py --config 1 --quick --steps 20 --warmup 5 --no-emit > $O/b_noemit.json 2>/dev/null
-timeout 600 python bench.py --config 1 --quick --steps 20 --warmup 5 > $O/b_emit.json 2>/dev/null
-python - <<'PY'
-import json
-for n in ("b_noemit","b_emit"):
-    d=json.loads(open("gpurun_out/c41/%s.json"%n).read().strip().splitlines()[-1])
-    e=d["e2e"]; print(n, round(e["ms_per_batch"],4), round(e["labels_only"]["ms_per_batch"],4), round(e["tokenize"]["ms_per_batch"],4), round(e["large_batch"]["ms_per_batch"],3))
-PY
+O=gpurun_out/c43; mkdir -p $O
+run() { n=$1; shift; env "$@" timeout 300 python tools/tokenize_bench.py $EXTRA > $O/t_$n.json 2> $O/t_$n.err; echo "$n $(cut -c1-200 $O/t_$n.json)"; }
+EXTRA="--repeat 10 --iters 6"
+run big_one VPT_TOKENIZE_CHUNK_BYTES=9999999999
+run big_c12m VPT_TOKENIZE_CHUNK_BYTES=12582912
+run big_c24m VPT_TOKENIZE_CHUNK_BYTES=25165824
+run big_c48m VPT_TOKENIZE_CHUNK_BYTES=50331648
+EXTRA="--config 4 --repeat 4 --iters 6"
+run tagbig_one VPT_TOKENIZE_CHUNK_BYTES=9999999999
+run tagbig_c24m VPT_TOKENIZE_CHUNK_BYTES=25165824

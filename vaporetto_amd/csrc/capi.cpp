@@ -136,6 +136,7 @@ struct vpt_batch {
     int32_t* d_scores = nullptr; uint8_t* d_labels = nullptr; size_t out_cap = 0;
     int32_t* d_tags = nullptr; size_t tags_cap = 0;                 // vpt_fill_tags_batch
     uint8_t* d_tok = nullptr; size_t tok_cap = 0;                   // vpt_write_tokenized_batch
+    uint8_t* d_tlab = nullptr; size_t tlab_cap = 0;                 // vpt_tokenize_batch: the labels of the whole batch (no scores are kept)
     uint64_t* d_toff = nullptr; size_t toff_cap = 0;
     int32_t* d_tok_model = nullptr; size_t tok_model_cap = 0;      // tag model of every token, from the last fill_tags on this workspace
     uint64_t tok_model_chars = 0;                                   // ... which covered this many chars
@@ -153,6 +154,7 @@ struct vpt_batch {
     // this link; two streams per direction were slower (profiles/r02_c6_pcie_microbench.txt)
     hipStream_t s_in = nullptr, s_out = nullptr;
     uint64_t* h_off = nullptr; size_t h_off_cap = 0;                // pinned: the rebased offsets of every chunk of the call in flight
+    std::vector<hipEvent_t> chunk_ev;                               // vpt_tokenize_batch: one per chunk in flight
 };
 
 struct DeviceTags {   // views into the arena
@@ -209,7 +211,7 @@ void batch_release(vpt_batch* b) {
     (void)hipFree(b->d_tile_first); (void)hipFree(b->d_slow_list); (void)hipFree(b->d_ctrl); (void)hipFree(b->d_scratch);
     (void)hipFree(b->d_prof); (void)hipFree(b->d_cps);
     (void)hipFree(b->d_text); (void)hipFree(b->d_boff); (void)hipFree(b->d_ooff); (void)hipFree(b->d_scores); (void)hipFree(b->d_labels);
-    (void)hipFree(b->d_tags); (void)hipFree(b->d_tok); (void)hipFree(b->d_toff); (void)hipFree(b->d_tok_model);
+    (void)hipFree(b->d_tags); (void)hipFree(b->d_tok); (void)hipFree(b->d_tlab); (void)hipFree(b->d_toff); (void)hipFree(b->d_tok_model);
     (void)hipFree(b->d_types);
     for (auto& ps : b->pipe) {
         (void)hipFree(ps.text); (void)hipFree(ps.off); (void)hipFree(ps.scores); (void)hipFree(ps.labels);
@@ -218,6 +220,7 @@ void batch_release(vpt_batch* b) {
         if (ps.ev_out) (void)hipEventDestroy(ps.ev_out);
     }
     if (b->h_off) (void)hipHostFree(b->h_off);
+    for (hipEvent_t e : b->chunk_ev) (void)hipEventDestroy(e);
     if (b->s_in) (void)hipStreamDestroy(b->s_in);
     if (b->s_out) (void)hipStreamDestroy(b->s_out);
     for (hipEvent_t e : b->ev) (void)hipEventDestroy(e);
@@ -1231,7 +1234,7 @@ vpt_status vpt_fill_tags_batch_device(const vpt_predictor* p, vpt_batch* b, cons
 static vpt_status emit_device(const vpt_predictor* p, vpt_batch* b, const uint8_t* d_utf8, const uint64_t* d_byte_offsets,
                               const uint64_t* d_out_offsets, size_t n_sentences, uint64_t total_boundaries, const uint8_t* d_labels,
                               const int32_t* d_tags, uint8_t* d_text_out, uint64_t text_capacity, uint64_t* d_text_offsets_out,
-                              hipStream_t stream) {
+                              hipStream_t stream, uint64_t* total_out = nullptr) {
     if (!p || !b || b->pred != p) return fail(VPT_INVALID_ARGUMENT, "InvalidArgumentError: batch: does not belong to this predictor");
     if (!d_text_offsets_out) return fail(VPT_INVALID_ARGUMENT, "InvalidArgumentError: NULL device pointer");
     VPT_HIP(hipSetDevice(p->device));
@@ -1257,7 +1260,7 @@ static vpt_status emit_device(const vpt_predictor* p, vpt_batch* b, const uint8_
         const vpt_status st = grow(&b->d_scan_part, &b->scan_part_cap, vpt::scan_part_entries(n_sentences));
         if (st != VPT_OK) return st;
     }
-    VPT_HIP(vpt::launch_emit_tokenized(E, b->d_scan_part, p->n_cus * 32u, stream));
+    VPT_HIP(vpt::launch_emit_tokenized(E, b->d_scan_part, p->n_cus * 32u, total_out, stream));
     b->last_stream = stream; b->pending = true;
     return VPT_OK;
 }
@@ -1370,55 +1373,128 @@ vpt_status vpt_tokenize_batch(const vpt_predictor* p, const uint8_t* utf8, const
     vpt_status st = acquire(p, &w);
     if (st != VPT_OK) return st;
     vpt_batch* b = w.b;
-    hipStream_t s = b->own_stream;
     const size_t nbytes = size_t(t1 - t0);
+    const bool with_tags = tagged && p->n_tags > 0;
+    // NOTHING on the way needs a number from the device: the device buffers hold the whole batch and a slice of an output starts
+    // where an upper bound puts it (a char is at least one byte: boundaries and chars in front of a slice <= text bytes in front
+    // of it; tokenized text <= 3 bytes per text byte + the longest tag suffix per char), so copy in, char count, scoring, tagging
+    // and writer are enqueued back to back; the host then waits for the event behind them, reads the size of the text from pinned
+    // memory (the prefix sum's last kernel wrote it there) and copies text and offsets to where they belong.  The code can cut the
+    // batch into chunks that alternate over a few lanes (streams with a workspace each, as in predict_lanes) and collect them in
+    // order -- but a chunk is fifteen runtime calls, and measured on MI355X (profiles/r02_j_tokenize.txt) that enqueueing costs
+    // more than the overlap returns: 100 K sentences 1.55 ms as one chunk, 1.73 .. 2.4 in 7 .. 25; a million 11.0 ms as one, 10.6 ..
+    // 22.7 in 4 .. 125.  So a chunk is 256 MB of text -- one, unless the batch is larger than that (VPT_TOKENIZE_CHUNK_BYTES
+    // overrides; the tests use it).
+    constexpr int kMaxLanes = 4;
+    const uint64_t chunk_bytes = [] { const char* v = std::getenv("VPT_TOKENIZE_CHUNK_BYTES"); return v && std::atoll(v) > 0 ? uint64_t(std::atoll(v)) : (uint64_t(256) << 20); }();
+    const uint64_t per_byte = 3 + (with_tags ? uint64_t(p->max_tag_suffix) : 0);   // tokenized bytes per text byte, at most
+    const size_t max_chunks = std::min<size_t>(n_sentences, size_t(nbytes / chunk_bytes) + 2);
+    const int n_lanes = int(std::min<size_t>(kMaxLanes, max_chunks));
+    Workspace extra[kMaxLanes - 1];
+    vpt_batch* lane[kMaxLanes] = {b};
+    for (int l = 1; l < n_lanes; ++l) {
+        if ((st = acquire(p, &extra[l - 1])) != VPT_OK) return st;
+        lane[l] = extra[l - 1].b;
+    }
+    if (!b->s_out) VPT_HIP(hipStreamCreateWithFlags(&b->s_out, hipStreamNonBlocking));
+    while (b->chunk_ev.size() < max_chunks) {
+        hipEvent_t e;
+        VPT_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        b->chunk_ev.push_back(e);
+    }
+    // whole-batch device buffers (lane 0's workspace owns them); the other lanes only lend their scratch
     if ((st = grow(&b->d_text, &b->text_cap, nbytes + 32)) != VPT_OK) return st;
     {
         size_t cap = b->off_cap;
-        if ((st = grow(&b->d_boff, &cap, n_sentences + 1)) != VPT_OK) return st;
+        if ((st = grow(&b->d_boff, &cap, n_sentences + max_chunks + 1)) != VPT_OK) return st;
         size_t cap2 = b->off_cap;
-        if ((st = grow(&b->d_ooff, &cap2, n_sentences + 1)) != VPT_OK) return st;
+        if ((st = grow(&b->d_ooff, &cap2, n_sentences + max_chunks + 1)) != VPT_OK) return st;
         b->off_cap = std::min(cap, cap2);
     }
-    std::vector<uint64_t>& boff = b->h_boff;
-    boff.resize(n_sentences + 1);
-    for (size_t i = 0; i <= n_sentences; ++i) boff[i] = byte_offsets[i] - t0;
-    VPT_HIP(hipMemcpyAsync(b->d_text, utf8 + t0, nbytes, hipMemcpyHostToDevice, s));
-    VPT_HIP(hipMemcpyAsync(b->d_boff, boff.data(), 8 * (n_sentences + 1), hipMemcpyHostToDevice, s));
-    // chars per sentence on the device; the totals come back to size the outputs (the one mid-pipeline sync)
-    if ((st = vpt_count_boundaries_device(p, b, b->d_text, b->d_boff, n_sentences, b->d_ooff, s)) != VPT_OK) return st;
-    uint64_t total_b = 0;
-    uint32_t max_chars = 0;
-    VPT_HIP(hipMemcpyAsync(&total_b, b->d_ooff + n_sentences, sizeof(total_b), hipMemcpyDeviceToHost, s));
-    VPT_HIP(hipMemcpyAsync(&max_chars, b->d_ctrl + 2, sizeof(max_chars), hipMemcpyDeviceToHost, s));
-    if ((st = vpt_batch_sync(b)) != VPT_OK) return st;   // NUL / empty sentences are reported here
-    {
-        size_t cap = b->out_cap;
-        if ((st = grow(&b->d_scores, &cap, size_t(total_b) + 1)) != VPT_OK) return st;
-        size_t cap2 = b->out_cap;
-        if ((st = grow(&b->d_labels, &cap2, size_t(total_b) + 1)) != VPT_OK) return st;
-        b->out_cap = std::min(cap, cap2);
+    if ((st = grow(&b->d_tlab, &b->tlab_cap, nbytes + 1)) != VPT_OK) return st;
+    if (with_tags && (st = grow(&b->d_tags, &b->tags_cap, nbytes * p->n_tags + 16)) != VPT_OK) return st;
+    if ((st = grow(&b->d_tok, &b->tok_cap, size_t(nbytes * per_byte) + 16)) != VPT_OK) return st;
+    if ((st = grow(&b->d_toff, &b->toff_cap, n_sentences + max_chunks + 1)) != VPT_OK) return st;
+    const size_t need_off = n_sentences + 1 + max_chunks;   // pinned: the offsets relative to the batch's text, then one total per chunk
+    if (need_off > b->h_off_cap) {
+        if (b->h_off) (void)hipHostFree(b->h_off);
+        b->h_off = nullptr; b->h_off_cap = 0;
+        VPT_HIP(hipHostMalloc(reinterpret_cast<void**>(&b->h_off), (need_off + need_off / 2) * sizeof(uint64_t), hipHostMallocDefault));
+        b->h_off_cap = need_off + need_off / 2;
     }
-    if ((st = grow(&b->d_tok, &b->tok_cap, size_t(text_capacity) + 16)) != VPT_OK) return st;
-    if ((st = grow(&b->d_toff, &b->toff_cap, n_sentences + 1)) != VPT_OK) return st;
-    b->max_chars = max_chars;
-    b->flags = flags;
-    st = vpt_predict_batch_device(p, b, b->d_text, b->d_boff, b->d_ooff, n_sentences, total_b, max_bytes, nullptr, b->d_labels, s);
-    if (st != VPT_OK) return st;
-    const bool with_tags = tagged && p->n_tags > 0;
-    if (with_tags) {
-        if ((st = grow(&b->d_tags, &b->tags_cap, size_t(total_b + n_sentences) * p->n_tags + 16)) != VPT_OK) return st;
-        b->flags = flags & VPT_FLAG_KYTEA_FULLWIDTH;
-        st = vpt_fill_tags_batch_device(p, b, b->d_text, b->d_boff, b->d_ooff, n_sentences, total_b, b->d_labels, b->d_tags, s);
+    uint64_t* const h_boff = b->h_off;
+    uint64_t* const h_total = b->h_off + n_sentences + 1;
+    for (size_t i = 0; i <= n_sentences; ++i) h_boff[i] = byte_offsets[i] - t0;
+    struct Chunk { size_t a, n; uint64_t tb; };   // first sentence, sentences, first text byte (relative to the batch's)
+    std::vector<Chunk> chunks;
+    for (size_t i = 0; i < n_sentences;) {
+        const size_t a = i;
+        uint64_t mb = 0;
+        while (i < n_sentences && h_boff[i] - h_boff[a] < chunk_bytes) { mb = std::max<uint64_t>(mb, h_boff[i + 1] - h_boff[i]); ++i; }
+        const size_t k = chunks.size(), n = i - a;
+        const uint64_t tb = h_boff[a], nby = h_boff[i] - tb;
+        vpt_batch* bb = lane[k % size_t(n_lanes)];
+        hipStream_t s = bb->own_stream;
+        bb->flags = flags;
+        bb->max_chars = 0;   // unknown on the host (no round trip for it): the scoring kernel takes the geometry that fits any sentence
+        uint64_t* d_boff_k = b->d_boff + a + k;                   // n + 1 entries per chunk; offsets into the WHOLE text: no rebasing
+        uint64_t* d_ooff_k = b->d_ooff + a + k;                   // n + 1 entries per chunk, chunk-relative
+        uint8_t* d_labels_k = b->d_tlab + tb;
+        VPT_HIP(hipMemcpyAsync(b->d_text + tb, utf8 + t0 + tb, size_t(nby), hipMemcpyHostToDevice, s));
+        VPT_HIP(hipMemcpyAsync(d_boff_k, h_boff + a, 8 * (n + 1), hipMemcpyHostToDevice, s));
+        if ((st = vpt_count_boundaries_device(p, bb, b->d_text, d_boff_k, n, d_ooff_k, s)) != VPT_OK) return st;
+        const uint64_t tb_bound = nby - n;                        // boundaries of the chunk, at most
+        st = vpt_predict_batch_device(p, bb, b->d_text, d_boff_k, d_ooff_k, n, tb_bound, mb, nullptr, d_labels_k, s);
         if (st != VPT_OK) return st;
+        int32_t* d_tags_k = with_tags ? b->d_tags + tb * p->n_tags : nullptr;
+        if (with_tags) {
+            bb->flags = flags & VPT_FLAG_KYTEA_FULLWIDTH;
+            st = vpt_fill_tags_batch_device(p, bb, b->d_text, d_boff_k, d_ooff_k, n, tb_bound, d_labels_k, d_tags_k, s);
+            if (st != VPT_OK) return st;
+        }
+        h_total[k] = 0;
+        st = emit_device(p, bb, b->d_text, d_boff_k, d_ooff_k, n, tb_bound, d_labels_k, d_tags_k, b->d_tok + tb * per_byte, nby * per_byte,
+                         b->d_toff + a + k, s, h_total + k);
+        if (st != VPT_OK) return st;
+        VPT_HIP(hipEventRecord(b->chunk_ev[k], s));
+        chunks.push_back({a, n, tb});
     }
-    st = emit_device(p, b, b->d_text, b->d_boff, b->d_ooff, n_sentences, total_b, b->d_labels, with_tags ? b->d_tags : nullptr, b->d_tok,
-                     text_capacity, b->d_toff, s);
+    // ---- collect: chunk by chunk, in order
+    uint64_t at = 0;   // tokenized bytes in front of the chunk
+    std::vector<uint64_t> base(chunks.size());
+    bool incomplete = false;
+    st = VPT_OK;
+    for (size_t k = 0; k < chunks.size() && st == VPT_OK; ++k) {
+        const Chunk& c = chunks[k];
+        VPT_HIP(hipEventSynchronize(b->chunk_ev[k]));
+        const uint64_t total = h_total[k];
+        if (total > (h_boff[c.a + c.n] - c.tb) * per_byte) { incomplete = true; break; }   // the device found the inputs inconsistent and says so below
+        if (total > text_capacity || at > text_capacity - total) { st = fail(VPT_INVALID_ARGUMENT, "InvalidArgumentError: text_capacity: smaller than the tokenized text"); break; }
+        base[k] = at;
+        if (total) VPT_HIP(hipMemcpyAsync(text_out + at, b->d_tok + c.tb * per_byte, size_t(total), hipMemcpyDeviceToHost, b->s_out));
+        VPT_HIP(hipMemcpyAsync(text_offsets_out + c.a + 1, b->d_toff + c.a + k + 1, 8 * c.n, hipMemcpyDeviceToHost, b->s_out));
+        at += total;
+    }
+    VPT_HIP(hipStreamSynchronize(b->s_out));
+    // the device's verdict over every chunk (a lane's status word accumulates), fetched together
+    uint32_t ctrl[kMaxLanes][2] = {};
+    for (int l = 0; l < n_lanes; ++l)
+        if (lane[l]->pending) VPT_HIP(hipMemcpyAsync(ctrl[l], lane[l]->d_ctrl, sizeof(ctrl[l]), hipMemcpyDeviceToHost, lane[l]->last_stream));
+    for (int l = 0; l < n_lanes; ++l) {
+        if (!lane[l]->pending) continue;
+        VPT_HIP(hipStreamSynchronize(lane[l]->last_stream));
+        lane[l]->pending = false;
+        if (ctrl[l][0]) {
+            VPT_HIP(hipMemset(lane[l]->d_ctrl, 0, sizeof(uint32_t)));
+            if (st == VPT_OK) st = status_from_bits(ctrl[l][0]);
+        }
+    }
     if (st != VPT_OK) return st;
-    if ((st = vpt_batch_sync(b)) != VPT_OK) return st;
-    VPT_HIP(hipMemcpy(text_offsets_out, b->d_toff, 8 * (n_sentences + 1), hipMemcpyDeviceToHost));
-    const uint64_t total = text_offsets_out[n_sentences];
-    if (total) VPT_HIP(hipMemcpy(text_out, b->d_tok, size_t(total), hipMemcpyDeviceToHost));
+    if (incomplete) return fail(VPT_RUNTIME_ERROR, "vpt_tokenize_batch: a chunk's output size is out of range");
+    // the offsets came back relative to their chunk's text
+    text_offsets_out[0] = 0;
+    for (size_t k = 1; k < chunks.size(); ++k)
+        for (size_t j = 1; j <= chunks[k].n; ++j) text_offsets_out[chunks[k].a + j] += base[k];
     return VPT_OK;
 }
 

@@ -67,7 +67,7 @@ __device__ __forceinline__ uint64_t first_sentence_at(const uint64_t* __restrict
         const uint64_t mid = (lo + hi) >> 1;
         if (F(mid) >= target) hi = mid; else lo = mid + 1;
     }
-    return lo;
+    return lo < n_sent ? lo : n_sent;   // a target past the total (a caller that only knows an upper bound of it): no sentence starts there
 }
 
 // inclusive prefix sum over the 64 lanes of a wave: DPP row shifts, then the two row broadcasts (no LDS round trips)

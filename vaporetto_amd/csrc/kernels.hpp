@@ -105,7 +105,8 @@ struct EmitParams {
 };
 // scan_part: workspace of scan_part_entries(n_sent) uint64 (the prefix sum's per-workgroup partials)
 size_t scan_part_entries(uint64_t n);
-hipError_t launch_emit_tokenized(const EmitParams& P, uint64_t* scan_part, uint32_t max_blocks, hipStream_t stream);
+// total_out: optional device-writable HOST address that receives the output's total size (see scan_top_kernel)
+hipError_t launch_emit_tokenized(const EmitParams& P, uint64_t* scan_part, uint32_t max_blocks, uint64_t* total_out, hipStream_t stream);
 // vpt_count_boundaries on the device: ooff_out[S+1]; *max_chars (atomicMax) = the longest sentence in chars
 hipError_t launch_count_boundaries(const uint8_t* text, const uint64_t* boff, uint64_t n_sent, uint64_t* ooff_out, uint64_t* scan_part, uint32_t* status,
                                    uint32_t* max_chars, uint32_t max_blocks, hipStream_t stream);

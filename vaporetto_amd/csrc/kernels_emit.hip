@@ -160,8 +160,10 @@ __global__ __launch_bounds__(kScanThreads) void scan_partials_kernel(const uint6
     if (tid == 0) part[blockIdx.x] = total;
 }
 
+// total_out (optional): where the grand total is left as well -- host memory the device can write (hipHostMalloc), so that a
+// caller waiting on an event of the stream reads the size of the output without a copy of its own
 __global__ __launch_bounds__(kTopThreads) void scan_top_kernel(uint64_t* __restrict__ part, uint64_t n_part, uint64_t* __restrict__ offsets, uint64_t capacity,
-                                                               uint32_t* __restrict__ status) {
+                                                               uint32_t* __restrict__ status, uint64_t* __restrict__ total_out) {
     __shared__ uint64_t lds[kTopThreads];
     const uint32_t tid = threadIdx.x;
     const uint64_t per = (n_part + kTopThreads - 1) / kTopThreads;     // consecutive partials per thread
@@ -178,6 +180,7 @@ __global__ __launch_bounds__(kTopThreads) void scan_top_kernel(uint64_t* __restr
     if (tid == 0) {
         offsets[0] = 0;
         if (total > capacity) atomicOr(status, kErrOutputTooSmall);
+        if (total_out) *total_out = total;
     }
 }
 
@@ -201,10 +204,10 @@ __global__ __launch_bounds__(kScanThreads) void scan_apply_kernel(uint64_t* __re
     }
 }
 
-hipError_t launch_scan(uint64_t* offsets, uint64_t n, uint64_t* part, uint64_t capacity, uint32_t* status, hipStream_t stream) {
+hipError_t launch_scan(uint64_t* offsets, uint64_t n, uint64_t* part, uint64_t capacity, uint32_t* status, uint64_t* total_out, hipStream_t stream) {
     const uint64_t n_part = (n + kScanBlock - 1) / kScanBlock;
     hipLaunchKernelGGL(scan_partials_kernel, dim3(uint32_t(n_part)), dim3(kScanThreads), 0, stream, offsets, n, part);
-    hipLaunchKernelGGL(scan_top_kernel, dim3(1), dim3(kTopThreads), 0, stream, part, n_part, offsets, capacity, status);
+    hipLaunchKernelGGL(scan_top_kernel, dim3(1), dim3(kTopThreads), 0, stream, part, n_part, offsets, capacity, status, total_out);
     hipLaunchKernelGGL(scan_apply_kernel, dim3(uint32_t(n_part)), dim3(kScanThreads), 0, stream, offsets, n, part);
     return hipGetLastError();
 }
@@ -372,13 +375,13 @@ hipError_t launch_count_boundaries(const uint8_t* text, const uint64_t* boff, ui
                                    uint32_t* max_chars, uint32_t max_blocks, hipStream_t stream) {
     const uint32_t blocks = emit_blocks(n_sent, max_blocks);
     hipLaunchKernelGGL(count_chars_kernel, dim3(blocks), dim3(kEmitThreads), 0, stream, text, boff, n_sent, ooff_out, status, max_chars);
-    return launch_scan(ooff_out, n_sent, scan_part, ~uint64_t(0), status, stream);
+    return launch_scan(ooff_out, n_sent, scan_part, ~uint64_t(0), status, nullptr, stream);
 }
 
-hipError_t launch_emit_tokenized(const EmitParams& P, uint64_t* scan_part, uint32_t max_blocks, hipStream_t stream) {
+hipError_t launch_emit_tokenized(const EmitParams& P, uint64_t* scan_part, uint32_t max_blocks, uint64_t* total_out, hipStream_t stream) {
     const uint32_t blocks = emit_blocks(P.n_sent, max_blocks);
     hipLaunchKernelGGL(emit_count_kernel, dim3(blocks), dim3(kEmitThreads), 0, stream, P);
-    const hipError_t e = launch_scan(P.out_offsets, P.n_sent, scan_part, P.capacity, P.status, stream);
+    const hipError_t e = launch_scan(P.out_offsets, P.n_sent, scan_part, P.capacity, P.status, total_out, stream);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(emit_write_kernel, dim3(blocks), dim3(kEmitThreads), 0, stream, P);
     return hipGetLastError();
