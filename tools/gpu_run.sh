@@ -1,8 +1,11 @@
 #!/bin/bash
 set -u
-O=gpurun_out/c44; mkdir -p $O
-export TMPDIR=/tmp
-timeout 600 python -m pytest tests -m gpu -x -q > $O/pytest.log 2>&1; echo "pytest rc=$?"; tail -2 $O/pytest.log
-bash tools/profile.sh r02_k 2>&1 | tail -1
-bash tools/profile.sh r02_k_m2 --config 3 2>&1 | tail -1
-timeout 120 python tools/fuzz_gpu.py 45 > $O/fuzz.log 2>&1; tail -1 $O/fuzz.log
+O=gpurun_out/c45; mkdir -p $O
+timeout 500 python tools/ab_bench.py --variants new,new:VPT_TILE_ROUNDS_MULT=2,new:VPT_TILE_ROUNDS_MULT=3,new:VPT_TILE_ROUNDS_MULT=4 --rounds 3 > $O/ab.jsonl 2> $O/ab.err; echo "ab rc=$?"; tail -2 $O/ab.err
+python - <<'PY'
+import json
+for l in open("gpurun_out/c45/ab.jsonl"):
+    try: d=json.loads(l)
+    except Exception: continue
+    print({k:d[k] for k in d if k in ("variant","kernel_ms","parity","tiles")})
+PY
