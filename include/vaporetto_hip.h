@@ -179,7 +179,9 @@ vpt_status vpt_batch_create(const vpt_predictor *p, vpt_batch **out);
 void vpt_batch_destroy(vpt_batch *b);
 
 /* d_utf8, d_byte_offsets[S+1], d_out_offsets[S+1], d_scores, d_labels are device pointers (d_scores or
- * d_labels may be NULL).  total_boundaries = out_offsets[S] (the caller sized the outputs with it).
+ * d_labels may be NULL).  total_boundaries = out_offsets[S] (the caller sized the outputs with it), or any upper bound of it
+ * when the offsets were made on the device and the caller will not wait for them (text bytes - S always is one; the same bound
+ * must then be passed to the fill_tags / write calls that follow on this batch).
  * max_sentence_bytes: an upper bound on the byte length of any sentence (sizes the long-sentence scratch).
  * hip_stream: a hipStream_t (NULL = default stream).  Returns after enqueueing; errors found on the device
  * (empty sentence, NUL char, offsets inconsistent with the text) are reported by vpt_batch_sync. */

@@ -1022,6 +1022,36 @@ def test_writer_long_tags_many_sentences_and_long_sentences():
     assert lines == [tb[int(toff[i]):int(toff[i + 1])].decode("utf-8") for i in range(len(texts))]
 
 
+def test_device_calls_accept_an_upper_bound_of_the_boundaries():
+    """A caller that counted the chars on the device and does not wait for the total passes an upper bound of it (text bytes - S)
+    to predict / fill_tags / write_tagged: same scores, tags and text (tiles that start past the real total are empty)."""
+    m = randmodel.rand_model(843, alphabet="kana", wc=3, wt=3, n_tag_models=30, max_word=4, n_char=80, n_dict=80)
+    pred = api.Predictor(api.Model.read_slice(encode_model(m))[0], True)
+    texts = randmodel.rand_sentences(7, m, 300, alphabet="kana", max_len=60) + ["abc de", "x" * 2000, "あ"]
+    utf8, boff = api.pack_texts([t.encode("utf-8") for t in texts])
+    ooff = api.count_boundaries(utf8, boff)
+    nb, S, nt = int(ooff[-1]), len(texts), pred.n_tags()
+    max_bytes = int(np.max(np.diff(boff.astype(np.int64))))
+    outs = []
+    for bound in (nb, len(utf8) - S):
+        assert bound >= nb
+        d_text = devmem.put(np.concatenate([utf8, np.zeros(16, np.uint8)])); d_boff = devmem.put(boff.astype(np.uint64)); d_ooff = devmem.put(ooff.astype(np.uint64))
+        d_scores = devmem.zeros(bound + 1, np.int32); d_labels = devmem.zeros(bound + 1, np.uint8); d_tags = devmem.zeros((bound + S) * nt + 1, np.int32)
+        cap = 3 * len(utf8) + len(utf8) * pred.max_tag_suffix()
+        d_out = devmem.zeros(cap + 1, np.uint8); d_toff = devmem.zeros(S + 1, np.uint64)
+        batch = api.DeviceBatch(pred)
+        batch.predict(d_text.ptr, d_boff.ptr, d_ooff.ptr, S, bound, max_bytes, d_scores.ptr, d_labels.ptr, devmem.stream())
+        batch.fill_tags(d_text.ptr, d_boff.ptr, d_ooff.ptr, S, bound, d_labels.ptr, d_tags.ptr, devmem.stream())
+        batch.write_tagged(d_text.ptr, d_boff.ptr, d_ooff.ptr, S, bound, d_labels.ptr, d_tags.ptr, d_out.ptr, cap, d_toff.ptr, devmem.stream())
+        batch.sync()
+        toff = d_toff.get(S + 1)
+        outs.append((d_scores.get(nb).copy(), d_labels.get(nb).copy(), d_tags.get((nb + S) * nt).copy(), bytes(d_out.get(int(toff[-1]))), toff.copy()))
+    for a, b in zip(outs[0], outs[1]):
+        assert np.array_equal(a, b) if isinstance(a, np.ndarray) else a == b
+    o_scores, o_labels, _, _ = cbind.OraclePredictor(encode_model(m), True).predict_batch(utf8, boff)
+    assert np.array_equal(outs[1][0], o_scores) and np.array_equal(outs[1][1], o_labels)
+
+
 def test_tokenize_batch_is_the_whole_pipeline():
     """vpt_tokenize_batch (lines in, tokenized lines out) = from_raw + predict (+ filters) (+ fill_tags) + write_tokenized_text,
     and vpt_count_boundaries_device = vpt_count_boundaries."""

@@ -49,7 +49,7 @@ _AS_IS = [
     "test_device_resident_predict_then_fill_tags", "test_fill_tags_with_offsets_that_do_not_match_the_text",
     "test_write_tokenized_text_on_device", "test_concurrent_host_threads_share_a_predictor",
     "test_write_tagged_text_on_device", "test_writer_long_tags_many_sentences_and_long_sentences", "test_tokenize_batch_is_the_whole_pipeline",
-    "test_tokenize_batch_in_chunks",
+    "test_tokenize_batch_in_chunks", "test_device_calls_accept_an_upper_bound_of_the_boundaries",
     "test_compiled_predictor_round_trip_and_clone", "test_compiled_predictor_rejects_damaged_blobs",
     "test_pipelined_host_path_matches_oracle", "test_sharded_predict_over_clones_equals_unsharded", "test_char_types_from_the_device",
 ]
