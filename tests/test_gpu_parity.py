@@ -981,6 +981,9 @@ def test_write_tagged_text_on_device():
     assert [out[int(toff[i]):int(toff[i + 1])].decode("utf-8") for i in range(S)] == want
 
 
+WRITER_TEST_SENTENCES = 9000   # (tests/test_kernel_emu.py runs the same test on fewer)
+
+
 def test_writer_long_tags_many_sentences_and_long_sentences():
     """The writer assembles a step's output (256 text bytes and what is inserted) in LDS; tag strings of hundreds of bytes
     do not fit there and go out byte by byte; the sentences' positions come from a three-kernel prefix sum whose
@@ -1000,8 +1003,8 @@ def test_writer_long_tags_many_sentences_and_long_sentences():
     import random
     rng = random.Random(5)
     alpha = randmodel.ALPHABETS["kana"][:20] + list("ab /\\9")
-    texts = ["".join(rng.choice(alpha) for _ in range(rng.randint(1, 9))) for _ in range(9000)]
-    for at, n in ((17, 2000), (4095, 6000), (4096, 3001), (8999, 2500)):
+    texts = ["".join(rng.choice(alpha) for _ in range(rng.randint(1, 9))) for _ in range(WRITER_TEST_SENTENCES)]
+    for at, n in ((17, 2000), (4095, 6000), (4096, 3001), (WRITER_TEST_SENTENCES - 1, 2500)):
         texts[at] = "".join(rng.choice(alpha) for _ in range(n))
     plain = api.Predictor(api.Model.read_slice(encode_model(m))[0], False)
     utf8, boff = api.pack_texts([t.encode("utf-8") for t in texts])

@@ -48,7 +48,7 @@ _AS_IS = [
     "test_converted_kytea_fixture_on_gpu", "test_fullwidth_filter_on_device", "test_label_post_filters_on_device",
     "test_device_resident_predict_then_fill_tags", "test_fill_tags_with_offsets_that_do_not_match_the_text",
     "test_write_tokenized_text_on_device", "test_concurrent_host_threads_share_a_predictor",
-    "test_write_tagged_text_on_device", "test_writer_long_tags_many_sentences_and_long_sentences", "test_tokenize_batch_is_the_whole_pipeline",
+    "test_write_tagged_text_on_device", "test_tokenize_batch_is_the_whole_pipeline",
     "test_tokenize_batch_in_chunks", "test_device_calls_accept_an_upper_bound_of_the_boundaries",
     "test_compiled_predictor_round_trip_and_clone", "test_compiled_predictor_rejects_damaged_blobs",
     "test_pipelined_host_path_matches_oracle", "test_sharded_predict_over_clones_equals_unsharded", "test_char_types_from_the_device",
@@ -74,9 +74,16 @@ def test_lane_order_does_not_matter():
         lib.hipemu_set_lane_order(0)
 
 
+def test_writer_long_tags_many_sentences_sized_down(monkeypatch):
+    """test_writer_long_tags_many_sentences_and_long_sentences on 4 200 sentences (still more than one workgroup of the prefix sum)."""
+    monkeypatch.setattr(G, "WRITER_TEST_SENTENCES", 4200)
+    G.test_writer_long_tags_many_sentences_and_long_sentences()
+
+
 def test_every_gpu_parity_test_is_accounted_for():
     """A new GPU parity test must be added to _AS_IS or to the sized-down list below."""
-    sized_down = {"test_synthetic_configs_match_oracle", "test_batch_properties_at_full_config_size"}
+    sized_down = {"test_synthetic_configs_match_oracle", "test_batch_properties_at_full_config_size",
+                  "test_writer_long_tags_many_sentences_and_long_sentences"}
     have = {n for n in dir(G) if n.startswith("test_") and callable(getattr(G, n))}
     assert have == set(_AS_IS) | sized_down, have ^ (set(_AS_IS) | sized_down)
 
