@@ -53,8 +53,13 @@ def load_model_bytes(kind: int, scale: float):
     if d:
         path = os.path.join(d, name + ".model.zst")
         if os.path.exists(path):
-            env = dict(os.environ, LD_LIBRARY_PATH="/opt/conda/lib:" + os.environ.get("LD_LIBRARY_PATH", ""))
-            raw = subprocess.check_output(["/opt/conda/bin/zstd", "-d", "-c", path], env=env)
+            try:    # zstd is outside the reference's API too (README.md:50-63): whatever decoder this image has
+                import pyarrow as pa
+                with open(path, "rb") as fh:
+                    raw = pa.CompressedInputStream(pa.BufferReader(fh.read()), "zstd").read()
+            except Exception:
+                env = dict(os.environ, LD_LIBRARY_PATH="/opt/conda/lib:" + os.environ.get("LD_LIBRARY_PATH", ""))
+                raw = subprocess.check_output(["/opt/conda/bin/zstd", "-d", "-c", path], env=env)
             return raw, name
         path = os.path.join(d, name + ".mod")   # a KyTea model (jp-0.4.7-5.mod): converted like convert_kytea_model does
         if os.path.exists(path):
