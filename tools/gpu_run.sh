@@ -1,14 +1,5 @@
 #!/bin/bash
 set -u
-O=gpurun_out/c48; mkdir -p $O
-export TMPDIR=/tmp
-timeout 900 python bench.py --steps 20 --warmup 5 > $O/bench.json 2> $O/bench.err; echo "bench rc=$?"; tail -2 $O/bench.err | cut -c1-300
-python - <<'PY'
-import json
-d=json.loads(open("gpurun_out/c48/bench.json").read().strip().splitlines()[-1])
-print("value",d["value"],"kernel_ms",d["roofline"]["kernel_ms"],"frac",d["roofline"]["frac"],"traffic",d["roofline"]["traffic"],"parity",d["parity"])
-e=d["e2e"]; print("e2e",round(e["ms_per_batch"],4),round(e["frac_of_pcie"],3),"labels",round(e["labels_only"]["ms_per_batch"],4),"tok",round(e["tokenize"]["ms_per_batch"],4),"big",round(e["large_batch"]["ms_per_batch"],3), e["parity"])
-print("emit",d.get("emit"))
-for w in d.get("workloads",[]): print(w["workload"][:30], round(w["value"]/1e9,2), round(w["roofline"]["kernel_ms"],4), round(w["roofline"]["frac"],3), w["roofline"]["traffic"], w.get("parity"), w.get("tags",{}) and round(w["tags"]["ms_per_step"],3), w.get("emit") and round(w["emit"]["ms_per_step"],3))
-PY
-timeout 330 python tools/fuzz_gpu.py 300 > $O/fuzz.log 2>&1; tail -1 $O/fuzz.log
+O=gpurun_out/c49; mkdir -p $O
+timeout 600 python -m pytest tests -m gpu -x -q > $O/pytest.log 2>&1; echo "pytest rc=$?"; tail -2 $O/pytest.log
+python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -1
