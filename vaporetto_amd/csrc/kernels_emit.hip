@@ -45,16 +45,16 @@ __device__ __forceinline__ uint32_t tag_suffix_of(const EmitParams& P, uint64_t 
     if (model <= 0 || uint32_t(model) > P.n_models) return 0;   // no tag model for this surface (or not our array)
     const uint32_t* mr = P.models + size_t(model - 1) * 12;
     const int32_t* tg = P.tags + c * P.n_tags;
-    const uint32_t n_slots = mr[9] < P.n_tags ? mr[9] : P.n_tags;
-    uint32_t last = 0;   // slots to write: up to the last Some
-    for (uint32_t j = 0; j < n_slots; ++j)
-        if (tg[j] >= 0) last = j + 1;
+    const uint32_t slot0 = mr[8], n_slots = mr[9] < P.n_tags ? mr[9] : P.n_tags;
+    uint32_t last = 0;   // slots to write: up to the last Some (the tags are fetched with the model record, not after it)
+    for (uint32_t j = 0; j < P.n_tags; ++j)
+        if (tg[j] >= 0 && j < n_slots) last = j + 1;
     uint32_t n = 0;
     for (uint32_t j = 0; j < last; ++j) {
         if (dst) dst[n] = 0x2Fu;
         ++n;
         if (tg[j] < 0) continue;
-        const uint32_t k = P.slot_str[mr[8] + j] + uint32_t(tg[j]);
+        const uint32_t k = P.slot_str[slot0 + j] + uint32_t(tg[j]);
         if (k >= P.n_strings) continue;                            // an index fill_tags cannot have written
         const uint32_t a = P.str_off[k], b = P.str_off[k + 1];
         if (dst) for (uint32_t q = a; q < b; ++q) dst[n + (q - a)] = P.str_bytes[q];
@@ -114,7 +114,7 @@ __global__ __launch_bounds__(kEmitThreads) void emit_count_kernel(const EmitPara
                     while (todo) {   // the few tokens with a tag model (one call site: the routine is long)
                         const uint32_t q = uint32_t(__ffs(int(todo))) - 1u;
                         todo &= todo - 1u;
-                        mine += tag_suffix(P, o0 + i + k + q, nullptr);
+                        mine += tag_suffix_of(P, o0 + i + k + q, q == 0 ? tm.m[0] : q == 1 ? tm.m[1] : q == 2 ? tm.m[2] : tm.m[3], nullptr);
                     }
                 }
             }
@@ -258,14 +258,15 @@ __global__ __launch_bounds__(kEmitThreads) void emit_write_kernel(const EmitPara
             // the token in front of a space ends at the char before it and its tags go in front of the space: the tag models of
             // chars ci0 - 1 .. ci0 + 2 in one load, the suffix lengths of the few that have one (one call site: the routine is long)
             uint32_t sfx[4] = {0, 0, 0, 0};
+            Models4 tm = {{0, 0, 0, 0}};
             if (P.tags && spq) {
-                Models4 tm = load_models4(P, o0 + i + (ci0 ? ci0 - 1 : 0));
+                tm = load_models4(P, o0 + i + (ci0 ? ci0 - 1 : 0));
                 if (ci0 == 0) { tm.m[3] = tm.m[2]; tm.m[2] = tm.m[1]; tm.m[1] = tm.m[0]; tm.m[0] = 0; }
                 uint32_t todo = spq & ((tm.m[0] > 0 ? 1u : 0u) | (tm.m[1] > 0 ? 2u : 0u) | (tm.m[2] > 0 ? 4u : 0u) | (tm.m[3] > 0 ? 8u : 0u));
                 while (todo) {
                     const uint32_t q = uint32_t(__ffs(int(todo))) - 1u;
                     todo &= todo - 1u;
-                    const uint32_t len = tag_suffix(P, o0 + i + ci0 + q - 1, nullptr);
+                    const uint32_t len = tag_suffix_of(P, o0 + i + ci0 + q - 1, q == 0 ? tm.m[0] : q == 1 ? tm.m[1] : q == 2 ? tm.m[2] : tm.m[3], nullptr);
                     // char q's lead byte: the q-th set bit of lm
                     uint32_t rem = lm;
                     for (uint32_t r = 0; r < q; ++r) rem &= rem - 1u;
@@ -299,7 +300,7 @@ __global__ __launch_bounds__(kEmitThreads) void emit_write_kernel(const EmitPara
                     todo &= todo - 1u;
                     uint32_t at_k = w + k, q = 0;   // bytes of the lane in front of byte k's own insertions; k is the lane's q-th char
                     for (uint32_t j = 0; j < k; ++j) { at_k += sfx[j] + ((spm >> j) & 1u) + ((em >> j) & 1u); q += (lm >> j) & 1u; }
-                    (void)tag_suffix(P, o0 + i + ci0 + q - 1, o + at_k);
+                    (void)tag_suffix_of(P, o0 + i + ci0 + q - 1, q == 0 ? tm.m[0] : q == 1 ? tm.m[1] : q == 2 ? tm.m[2] : tm.m[3], o + at_k);
                 }
             };
             if (staged) put(sb + head);   // (two calls: one writes LDS, one global memory -- not one through a generic pointer)
