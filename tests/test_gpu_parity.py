@@ -1188,6 +1188,28 @@ def test_pipelined_host_path_matches_oracle(chunk_chars, pinned, lanes, monkeypa
     assert "NULL" in str(e.value)
 
 
+def test_labels_only_and_packed_tokenize_through_the_host_path(monkeypatch):
+    """scores_out = NULL (a tokenizer only needs the labels; 4 of the 5 bytes per boundary stay on the device) gives the same
+    labels one-shot, through the lanes and through the event pipeline; tokenize_packed returns what tokenize returns."""
+    m = randmodel.rand_model(779, alphabet="kana", wc=3, wt=3, n_char=150, n_dict=150, max_word=6)
+    raw = encode_model(m)
+    pred, orc = make_predictor(raw)
+    texts = randmodel.rand_sentences(12, m, 700, alphabet="kana", max_len=70)
+    utf8, boff = api.pack_texts([t.encode("utf-8") for t in texts])
+    o_scores, o_labels, o_ooff, _ = orc.predict_batch(utf8, boff, nthreads=4)
+    for chunk, lanes in ((None, None), ("900", "4"), ("900", "0")):
+        if chunk:
+            monkeypatch.setenv("VPT_CHUNK_CHARS", chunk)
+            monkeypatch.setenv("VPT_PIPE_LANES", lanes)
+        scores, labels, ooff = api.predict_packed_sharded([pred], utf8, boff, want_scores=False)
+        assert scores is None and np.array_equal(labels, o_labels) and np.array_equal(ooff, o_ooff)
+    text, toff = pred.tokenize_packed(utf8, boff)
+    lines = pred.tokenize(texts)
+    tb = bytes(text)
+    assert [tb[int(toff[i]):int(toff[i + 1])].decode("utf-8") for i in range(len(texts))] == lines
+    assert "".join(lines[5].split(" ")) == texts[5] or any(c in texts[5] for c in " /\\")
+
+
 def test_sharded_predict_over_clones_equals_unsharded(monkeypatch):
     """take shards -> score each on its own predictor (clones of one, as the ranks of a multi-GPU job hold) -> the
     concatenation is the unsharded result; shard bounds balance CHARACTERS, not sentences or bytes."""

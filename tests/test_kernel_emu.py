@@ -51,7 +51,8 @@ _AS_IS = [
     "test_write_tagged_text_on_device", "test_tokenize_batch_is_the_whole_pipeline",
     "test_tokenize_batch_in_chunks", "test_device_calls_accept_an_upper_bound_of_the_boundaries",
     "test_compiled_predictor_round_trip_and_clone", "test_compiled_predictor_rejects_damaged_blobs",
-    "test_pipelined_host_path_matches_oracle", "test_sharded_predict_over_clones_equals_unsharded", "test_char_types_from_the_device",
+    "test_pipelined_host_path_matches_oracle", "test_labels_only_and_packed_tokenize_through_the_host_path",
+    "test_sharded_predict_over_clones_equals_unsharded", "test_char_types_from_the_device",
 ]
 for _name in _AS_IS:
     globals()[_name] = getattr(G, _name)

@@ -1,4 +1,2 @@
 #!/bin/bash
-set -u
-O=gpurun_out/c53; mkdir -p $O
-timeout 260 python tools/fuzz_gpu.py 230 > $O/fuzz.log 2>&1; tail -1 $O/fuzz.log
+timeout 300 python -m pytest tests -m gpu -x -q -k "labels_only or upper_bound or tokenize_batch_in_chunks" 2>&1 | tail -2
