@@ -27,6 +27,9 @@ def test_header_symbols_exported():
     for name in declared:
         assert getattr(L, name) is not None
     assert b"gfx950" in L.vpt_version()
+    # ... and the Rust binding a maintainer would add names every one of them
+    doc = open(os.path.join(ROOT, "INTEGRATION.md"), encoding="utf-8").read()
+    assert not [n for n in declared if n not in doc]
 
 
 def test_model_codec_roundtrip_fixtures():
