@@ -1,0 +1,62 @@
+// Driver for include/vaporetto_hip.hpp (the C++ mirror of the crate's Predictor / Sentence on this path), built by
+// tests/test_cpp_mirror.py against libvaporetto_hip.so (GPU) or the emulated build of the same sources (CPU tests).
+//   cpp_mirror_test model.bin tags|plain < lines      prints, per line: tokens, scores, labels, tokenized text, char types
+#include <fstream>
+#include <iostream>
+#include <iterator>
+#include <string>
+#include <vector>
+
+#include "vaporetto_hip.hpp"
+
+using namespace vaporetto_hip;
+
+int main(int argc, char** argv) {
+    if (argc < 3) return 2;
+    std::ifstream f(argv[1], std::ios::binary);
+    std::vector<uint8_t> bytes((std::istreambuf_iterator<char>(f)), std::istreambuf_iterator<char>());
+    const bool tags = std::string(argv[2]) == "tags";
+    try {
+        bytes.push_back('x');   // read_slice returns what it did not consume
+        auto mr = Model::read_slice(bytes.data(), bytes.size());
+        std::cout << "consumed " << mr.second << " of " << bytes.size() << "\n";
+        Predictor predictor(mr.first, tags);
+        std::vector<std::string> lines;
+        for (std::string l; std::getline(std::cin, l);) lines.push_back(l);
+        std::vector<Sentence> batch;
+        for (const std::string& l : lines) {
+            Sentence s = Sentence::from_raw(l);
+            predictor.predict(s);
+            std::cout << "tokens";
+            for (const std::string& t : s.iter_tokens()) std::cout << " [" << t << "]";
+            std::cout << "\nscores";
+            for (int32_t v : s.boundary_scores()) std::cout << " " << v;
+            std::cout << "\nlabels";
+            for (uint8_t v : s.boundaries()) std::cout << " " << int(v);
+            std::cout << "\ntypes";
+            for (uint8_t v : s.char_types()) std::cout << " " << int(v);
+            if (tags) s.fill_tags();
+            std::cout << "\ntext " << s.write_tokenized_text() << "\n";
+            batch.push_back(Sentence::from_raw(l));
+        }
+        predictor.predict_batch(batch);   // one launch: the same scores
+        for (size_t i = 0; i < batch.size(); ++i) {
+            Sentence one = Sentence::from_raw(lines[i]);
+            predictor.predict(one);
+            if (one.boundary_scores() != batch[i].boundary_scores() || one.boundaries() != batch[i].boundaries()) { std::cout << "BATCH MISMATCH " << i << "\n"; return 1; }
+        }
+        const auto toks = predictor.tokenize(lines, tags);
+        for (const std::string& t : toks) std::cout << "tokenize " << t << "\n";
+        // errors: the reference's messages, and update_raw leaves " " behind (sentence.rs:264-283)
+        Sentence s = Sentence::from_raw("abc");
+        try { s.update_raw(""); } catch (const VaporettoError& e) { std::cout << "error " << e.kind() << " " << e.what() << " -> [" << s.as_raw_text() << "]\n"; }
+        try { s.update_raw(std::string("a\0b", 3)); } catch (const VaporettoError& e) { std::cout << "error " << e.kind() << " " << e.what() << "\n"; }
+        try { Sentence::from_raw("x").fill_tags(); } catch (const VaporettoError& e) { std::cout << "error " << e.kind() << " " << e.what() << "\n"; }
+        std::vector<uint8_t> junk(bytes.begin(), bytes.begin() + 30);
+        try { Model::read_slice(junk.data(), junk.size()); } catch (const VaporettoError& e) { std::cout << "error " << e.kind() << " model\n"; }
+    } catch (const VaporettoError& e) {
+        std::cout << "FAILED " << e.kind() << " " << e.what() << "\n";
+        return 1;
+    }
+    return 0;
+}
