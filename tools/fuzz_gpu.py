@@ -21,7 +21,8 @@ if os.environ.get("VPT_FUZZ_EMULATED"):   # the same sweep over the kernel sourc
     from vaporetto_amd import _lib  # noqa: E402
     _lib._lib = emu.load()
 t_end = time.time() + budget
-seed = n_models = n_sent = 0
+seed = int(os.environ.get("VPT_FUZZ_SEED0", "0"))   # first seed - 1: a later run continues where an earlier one stopped
+n_models = n_sent = 0
 f = api.KyteaFullwidthFilter()
 while time.time() < t_end:
     seed += 1
@@ -83,4 +84,4 @@ while time.time() < t_end:
             sys.exit(1)
     n_models += 1
     n_sent += len(texts)
-print("fuzz ok: %d models, %d sentences, no mismatch" % (n_models, n_sent))
+print("fuzz ok: %d models (seeds up to %d), %d sentences, no mismatch" % (n_models, seed, n_sent))
