@@ -1,2 +1,3 @@
 #!/bin/bash
-timeout 300 python -m pytest tests/test_cpp_mirror.py -m gpu -x -q 2>&1 | tail -3
+O=gpurun_out/c54; mkdir -p $O
+VPT_FUZZ_SEED0=20000 timeout 110 python tools/fuzz_gpu.py 95 > $O/fuzz.log 2>&1; tail -1 $O/fuzz.log
