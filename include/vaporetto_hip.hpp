@@ -19,6 +19,7 @@
 #define VAPORETTO_HIP_HPP
 
 #include <cstdint>
+#include <memory>
 #include <stdexcept>
 #include <string>
 #include <utility>
@@ -141,7 +142,7 @@ private:
         char_types_.assign(1, uint8_t(CharacterType::Other));
         char_pos_ = {0, 1};
         boundaries_.clear(); scores_.clear(); tags_.clear();
-        n_tags_ = 0; predictor_ = nullptr;
+        n_tags_ = 0; predictor_.reset();
     }
     void parse_raw(const std::string& text) {                       // sentence.rs:160-196
         if (text.find('\0') != std::string::npos) throw VaporettoError(VaporettoError::InvalidArgument, "InvalidArgumentError: text: must not contain NULL");
@@ -164,7 +165,7 @@ private:
         char_pos_ = std::move(pos);
         boundaries_.assign(char_types_.size() - 1, uint8_t(VPT_BOUNDARY_UNKNOWN));
         scores_.clear(); tags_.clear();
-        n_tags_ = 0; predictor_ = nullptr;
+        n_tags_ = 0; predictor_.reset();
     }
 
     std::string text_;
@@ -174,22 +175,29 @@ private:
     std::vector<int32_t> scores_;
     std::vector<int32_t> tags_;
     uint32_t n_tags_ = 0;
-    const Predictor* predictor_ = nullptr;   // predictor.rs:542: the predictor that last predicted this sentence
+    // predictor.rs:542: the predictor that last predicted this sentence.  The reference ties the two with a lifetime
+    // (`Sentence<'_, 'a>` borrows `&'a Predictor`); here the sentence SHARES the library handle, so fill_tags() and
+    // write_tokenized_text() stay valid when the Predictor object has been moved from or destroyed in the meantime.
+    std::shared_ptr<vpt_predictor> predictor_;
 };
 
 // predictor.rs:433-665.  Immutable after construction; `predict` takes `&self`, any number of threads may share one.
 class Predictor {
 public:
     Predictor(const Model& model, bool predict_tags, int device_id = 0) : predict_tags_(predict_tags) {   // Predictor::new, predictor.rs:450-508
-        detail::check(vpt_predictor_create(model.to_vec().data(), model.to_vec().size(), predict_tags ? 1 : 0, device_id, &raw_));
+        vpt_predictor* h = nullptr;
+        detail::check(vpt_predictor_create(model.to_vec().data(), model.to_vec().size(), predict_tags ? 1 : 0, device_id, &h));
+        raw_ = std::shared_ptr<vpt_predictor>(h, [](vpt_predictor* q) { vpt_predictor_destroy(q); });
     }
-    ~Predictor() { if (raw_) vpt_predictor_destroy(raw_); }
+    // the handle is reference-counted (sentences that were predicted hold it too): moving is cheap, copying is not offered
+    // -- the reference's Predictor is not Clone either
     Predictor(const Predictor&) = delete;
     Predictor& operator=(const Predictor&) = delete;
-    Predictor(Predictor&& o) noexcept : raw_(o.raw_), predict_tags_(o.predict_tags_) { o.raw_ = nullptr; }
+    Predictor(Predictor&&) noexcept = default;
+    Predictor& operator=(Predictor&&) noexcept = default;
 
-    const vpt_predictor* raw() const { return raw_; }
-    uint32_t n_tags() const { uint32_t n = 0; detail::check(vpt_predictor_n_tags(raw_, &n)); return n; }
+    const vpt_predictor* raw() const { return raw_.get(); }
+    uint32_t n_tags() const { uint32_t n = 0; detail::check(vpt_predictor_n_tags(raw_.get(), &n)); return n; }
 
     // Predictor::predict (predictor.rs:518-543): scores and labels of one sentence.
     void predict(Sentence& s) const {
@@ -197,10 +205,10 @@ public:
         std::vector<int32_t> scores(n > 1 ? n - 1 : 1);
         std::vector<uint8_t> labels(n > 1 ? n - 1 : 1);
         size_t nb = 0;
-        detail::check(vpt_predict_one(raw_, reinterpret_cast<const uint8_t*>(s.text_.data()), s.text_.size(), scores.data(), labels.data(), &nb));
+        detail::check(vpt_predict_one(raw_.get(), reinterpret_cast<const uint8_t*>(s.text_.data()), s.text_.size(), scores.data(), labels.data(), &nb));
         scores.resize(nb); labels.resize(nb);
         s.scores_ = std::move(scores); s.boundaries_ = std::move(labels);
-        s.tags_.clear(); s.n_tags_ = 0; s.predictor_ = this;
+        s.tags_.clear(); s.n_tags_ = 0; s.predictor_ = raw_;
     }
 
     // The same for many sentences with one launch (flags: VPT_FLAG_*).
@@ -215,13 +223,13 @@ public:
         }
         std::vector<int32_t> scores(size_t(ooff.back()) + 1);
         std::vector<uint8_t> labels(size_t(ooff.back()) + 1);
-        detail::check(vpt_predict_batch_flags(raw_, reinterpret_cast<const uint8_t*>(text.data()), boff.data(), sentences.size(), scores.data(),
+        detail::check(vpt_predict_batch_flags(raw_.get(), reinterpret_cast<const uint8_t*>(text.data()), boff.data(), sentences.size(), scores.data(),
                                               labels.data(), ooff.data(), flags));
         for (size_t i = 0; i < sentences.size(); ++i) {
             Sentence& s = sentences[i];
             s.scores_.assign(scores.begin() + ooff[i], scores.begin() + ooff[i + 1]);
             s.boundaries_.assign(labels.begin() + ooff[i], labels.begin() + ooff[i + 1]);
-            s.tags_.clear(); s.n_tags_ = 0; s.predictor_ = this;
+            s.tags_.clear(); s.n_tags_ = 0; s.predictor_ = raw_;
         }
     }
 
@@ -233,10 +241,10 @@ public:
         std::vector<uint64_t> boff(1, 0);
         for (const std::string& l : lines) { text += l; boff.push_back(text.size()); }
         uint32_t sfx = 0;
-        if (tagged) detail::check(vpt_predictor_max_tag_suffix(raw_, &sfx));
+        if (tagged) detail::check(vpt_predictor_max_tag_suffix(raw_.get(), &sfx));
         std::vector<uint8_t> buf(3 * text.size() + text.size() * sfx + 16);
         std::vector<uint64_t> toff(lines.size() + 1);
-        detail::check(vpt_tokenize_batch(raw_, reinterpret_cast<const uint8_t*>(text.data()), boff.data(), lines.size(), flags, tagged ? 1 : 0, buf.data(),
+        detail::check(vpt_tokenize_batch(raw_.get(), reinterpret_cast<const uint8_t*>(text.data()), boff.data(), lines.size(), flags, tagged ? 1 : 0, buf.data(),
                                          buf.size(), toff.data()));
         for (size_t i = 0; i < lines.size(); ++i) out.emplace_back(buf.begin() + toff[i], buf.begin() + toff[i + 1]);
         return out;
@@ -244,16 +252,17 @@ public:
 
 private:
     friend class Sentence;
-    vpt_predictor* raw_ = nullptr;
+    std::shared_ptr<vpt_predictor> raw_;
     bool predict_tags_;
 };
 
 inline void Sentence::fill_tags() {
     if (!predictor_) throw VaporettoError(VaporettoError::InvalidArgument, "InvalidArgumentError: sentence: predict() has not been called");
     const uint64_t boff[2] = {0, text_.size()}, ooff[2] = {0, len() - 1};
-    const uint32_t nt = predictor_->n_tags();
+    uint32_t nt = 0;
+    detail::check(vpt_predictor_n_tags(predictor_.get(), &nt));
     std::vector<int32_t> tags(len() * size_t(nt) + 1);
-    detail::check(vpt_fill_tags_batch(predictor_->raw(), reinterpret_cast<const uint8_t*>(text_.data()), boff, 1, ooff, boundaries_.data(), tags.data()));
+    detail::check(vpt_fill_tags_batch(predictor_.get(), reinterpret_cast<const uint8_t*>(text_.data()), boff, 1, ooff, boundaries_.data(), tags.data()));
     tags.resize(len() * size_t(nt));
     tags_ = std::move(tags);
     n_tags_ = nt;
@@ -266,14 +275,14 @@ inline std::string Sentence::write_tokenized_text() const {
     uint64_t toff[2] = {0, 0};
     const bool tagged = n_tags_ != 0 && predictor_ != nullptr;
     uint32_t sfx = 0;
-    if (tagged) detail::check(vpt_predictor_max_tag_suffix(predictor_->raw(), &sfx));
+    if (tagged) detail::check(vpt_predictor_max_tag_suffix(predictor_.get(), &sfx));
     std::vector<uint8_t> buf(3 * text_.size() + text_.size() * sfx + 16);
     if (tagged) {
-        detail::check(vpt_write_tagged_batch(predictor_->raw(), reinterpret_cast<const uint8_t*>(text_.data()), boff, 1, ooff, boundaries_.data(), 0u,
+        detail::check(vpt_write_tagged_batch(predictor_.get(), reinterpret_cast<const uint8_t*>(text_.data()), boff, 1, ooff, boundaries_.data(), 0u,
                                              buf.data(), buf.size(), toff));
     } else {
         if (!predictor_) throw VaporettoError(VaporettoError::InvalidArgument, "InvalidArgumentError: sentence: predict() has not been called");
-        detail::check(vpt_write_tokenized_batch(predictor_->raw(), reinterpret_cast<const uint8_t*>(text_.data()), boff, 1, ooff, boundaries_.data(),
+        detail::check(vpt_write_tokenized_batch(predictor_.get(), reinterpret_cast<const uint8_t*>(text_.data()), boff, 1, ooff, boundaries_.data(),
                                                 buf.data(), buf.size(), toff));
     }
     return std::string(buf.begin(), buf.begin() + toff[1]);

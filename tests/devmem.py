@@ -19,6 +19,17 @@ class Buf:
             self._dtype = arr.dtype
             self.ptr = self._t.data_ptr()
 
+    def set(self, arr: np.ndarray) -> None:
+        """Overwrites the buffer in place (same address: what a caller reusing its device buffers does)."""
+        arr = np.ascontiguousarray(arr)
+        if EMULATED:
+            self._a[:len(arr)] = arr
+        else:
+            import torch
+            signed = {np.dtype(np.uint64): np.int64, np.dtype(np.uint32): np.int32}.get(arr.dtype)
+            self._t[:len(arr)].copy_(torch.from_numpy(arr.view(signed) if signed else arr))
+            torch.cuda.synchronize()
+
     def get(self, n=None) -> np.ndarray:
         if EMULATED:
             return self._a[:n].copy()

@@ -52,6 +52,22 @@ int main(int argc, char** argv) {
         try { s.update_raw(""); } catch (const VaporettoError& e) { std::cout << "error " << e.kind() << " " << e.what() << " -> [" << s.as_raw_text() << "]\n"; }
         try { s.update_raw(std::string("a\0b", 3)); } catch (const VaporettoError& e) { std::cout << "error " << e.kind() << " " << e.what() << "\n"; }
         try { Sentence::from_raw("x").fill_tags(); } catch (const VaporettoError& e) { std::cout << "error " << e.kind() << " " << e.what() << "\n"; }
+        {   // a predicted sentence shares the library handle (the reference: a borrow with the predictor's lifetime, predictor.rs:542):
+            // it stays usable after the Predictor object was moved from and after the last Predictor object is gone
+            Sentence kept = Sentence::from_raw(lines.empty() ? std::string("abc") : lines[0]);
+            std::string before;
+            {
+                Predictor p2(mr.first, tags);
+                p2.predict(kept);
+                if (tags) kept.fill_tags();
+                before = kept.write_tokenized_text();
+                Predictor p3(std::move(p2));
+                if (kept.write_tokenized_text() != before) { std::cout << "LIFETIME MISMATCH (moved)\n"; return 1; }
+            }
+            if (tags) kept.fill_tags();
+            if (kept.write_tokenized_text() != before) { std::cout << "LIFETIME MISMATCH (destroyed)\n"; return 1; }
+            std::cout << "lifetime ok\n";
+        }
         std::vector<uint8_t> junk(bytes.begin(), bytes.begin() + 30);
         try { Model::read_slice(junk.data(), junk.size()); } catch (const VaporettoError& e) { std::cout << "error " << e.kind() << " model\n"; }
     } catch (const VaporettoError& e) {

@@ -41,6 +41,7 @@ def _expected(tags: bool) -> str:
     out.append("error 1 InvalidArgumentError: text: must contain at least one character -> [ ]")
     out.append("error 1 InvalidArgumentError: text: must not contain NULL")
     out.append("error 1 InvalidArgumentError: sentence: predict() has not been called")
+    out.append("lifetime ok")
     out.append("error 0 model")
     return "\n".join(out) + "\n"
 

@@ -836,6 +836,43 @@ def test_device_resident_predict_then_fill_tags():
         assert np.array_equal(got[0], want) and np.array_equal(got[1], want), fw
 
 
+def test_chars_left_by_predict_are_never_another_batchs():
+    """the chars a predict call leaves decoded for the fill_tags call that follows it (predictor.rs:542) were
+    remembered by buffer address and shape, and the host entry points reuse their staging buffers: predict(A) followed by
+    fill_tags(B) with as many sentences and chars tagged B with A's chars.  The chars are now good for the NEXT fill_tags call
+    only, and forgotten whenever a workspace is taken from the pool or staged into."""
+    m = randmodel.rand_model(831, alphabet="kana", wc=3, wt=3, n_tag_models=40, max_word=3, n_char=60, n_dict=60)
+    raw = encode_model(m)
+    fresh = api.Predictor(api.Model.read_slice(raw)[0], True)
+    pred = api.Predictor(api.Model.read_slice(raw)[0], True)
+    toks = [t.token for t in m.tag_models]
+    a_texts = [(toks[i % len(toks)] + toks[(i + 3) % len(toks)]) * 3 for i in range(200)]
+    b_texts = [(toks[(i + 7) % len(toks)] + toks[(i + 11) % len(toks)]) * 3 for i in range(200)]
+    b_texts = [b[:len(a)].ljust(len(a), "あ") for a, b in zip(a_texts, b_texts)]      # the same shape, char for char
+    ua, ba = api.pack_texts([t.encode("utf-8") for t in a_texts])
+    ub, bb = api.pack_texts([t.encode("utf-8") for t in b_texts])
+    assert len(ua) == len(ub) and np.array_equal(ba, bb)
+    _, lab_b, ooff = fresh.predict_packed(ub, bb)
+    want = fresh.fill_tags_packed(ub, bb, ooff, lab_b)
+    pred.predict_packed(ua, ba)                                   # leaves A's chars in the pooled workspace
+    assert np.array_equal(pred.fill_tags_packed(ub, bb, ooff, lab_b), want)
+    # the device entry points: the chars are taken once, by the call that follows; a later fill_tags on rewritten text decodes
+    nb, S, nt = int(ooff[-1]), len(a_texts), pred.n_tags()
+    d_text = devmem.put(np.concatenate([ua, np.zeros(16, np.uint8)]))
+    d_boff, d_ooff = devmem.put(ba.astype(np.uint64)), devmem.put(ooff.astype(np.uint64))
+    d_scores, d_labels, d_tags = devmem.zeros(nb + 1, np.int32), devmem.zeros(nb + 1, np.uint8), devmem.zeros((nb + S) * nt + 1, np.int32)
+    batch = api.DeviceBatch(pred)
+    mb = int(np.max(np.diff(ba.astype(np.int64))))
+    batch.predict(d_text.ptr, d_boff.ptr, d_ooff.ptr, S, nb, mb, d_scores.ptr, d_labels.ptr, devmem.stream())
+    batch.fill_tags(d_text.ptr, d_boff.ptr, d_ooff.ptr, S, nb, d_labels.ptr, d_tags.ptr, devmem.stream())
+    batch.sync()
+    d_text.set(np.concatenate([ub, np.zeros(16, np.uint8)]))
+    d_labels.set(np.concatenate([lab_b, np.zeros(1, np.uint8)]))
+    batch.fill_tags(d_text.ptr, d_boff.ptr, d_ooff.ptr, S, nb, d_labels.ptr, d_tags.ptr, devmem.stream())
+    batch.sync()
+    assert np.array_equal(d_tags.get((nb + S) * nt).reshape(nb + S, nt), want)
+
+
 def test_fill_tags_with_offsets_that_do_not_match_the_text():
     """The tag entry points trust the caller's out_offsets as little as predict does: offsets that promise fewer (or
     more) chars than the text holds are an error, never a write outside the batch's arrays."""
@@ -1151,6 +1188,12 @@ def test_compiled_predictor_rejects_damaged_blobs():
     refuse(bad, "checksum")
     bad = bytearray(blob); bad[16] ^= 0x01            # the version word
     refuse(bad, "version mismatch")
+    # the description is covered too (a flipped bit in bias / geometry / section sizes passed the arena's checksum)
+    import struct
+    meta_bytes = struct.unpack_from("<I", blob, 20)[0]
+    for at in (48, meta_bytes - 200, meta_bytes - 100):
+        bad = bytearray(blob); bad[at] ^= 0x04
+        refuse(bad, "checksum")
     assert api.Predictor.load_compiled(bytes(blob)).info()["n_char_ngrams"] == len(m.char_ngram_model)
 
 
@@ -1201,6 +1244,7 @@ def test_labels_only_and_packed_tokenize_through_the_host_path(monkeypatch):
         if chunk:
             monkeypatch.setenv("VPT_CHUNK_CHARS", chunk)
             monkeypatch.setenv("VPT_PIPE_LANES", lanes)
+            pred, _ = make_predictor(raw)      # the library reads its knobs when a predictor is made, never on the launch path
         scores, labels, ooff = api.predict_packed_sharded([pred], utf8, boff, want_scores=False)
         assert scores is None and np.array_equal(labels, o_labels) and np.array_equal(ooff, o_ooff)
     text, toff = pred.tokenize_packed(utf8, boff)
@@ -1233,8 +1277,8 @@ def test_sharded_predict_over_clones_equals_unsharded(monkeypatch):
         clones = [pred] + [pred.clone_to_device(0) for _ in range(n - 1)]
         scores, labels, ooff = api.predict_packed_sharded(clones, utf8, boff)
         assert np.array_equal(scores, o_scores) and np.array_equal(labels, o_labels) and np.array_equal(ooff, o_ooff)
-    monkeypatch.setenv("VPT_CHUNK_CHARS", "300")            # shards that are themselves pipelined
-    clones = [pred, pred.clone_to_device(0)]
+    monkeypatch.setenv("VPT_CHUNK_CHARS", "300")            # shards that are themselves pipelined (knobs are read when a predictor is made)
+    clones = [pred.clone_to_device(0), pred.clone_to_device(0)]
     scores, labels, _ = api.predict_packed_sharded(clones, utf8, boff)
     assert np.array_equal(scores, o_scores) and np.array_equal(labels, o_labels)
 

@@ -46,7 +46,7 @@ _AS_IS = [
     "test_fill_tags_requires_predict_tags_gpu", "test_fixture_tags_gpu", "test_random_tag_models_match_oracle",
     "test_tag_models_inside_and_outside_the_record_form", "test_tag_token_table_keys_and_queue",
     "test_converted_kytea_fixture_on_gpu", "test_fullwidth_filter_on_device", "test_label_post_filters_on_device",
-    "test_device_resident_predict_then_fill_tags", "test_fill_tags_with_offsets_that_do_not_match_the_text",
+    "test_device_resident_predict_then_fill_tags", "test_chars_left_by_predict_are_never_another_batchs", "test_fill_tags_with_offsets_that_do_not_match_the_text",
     "test_write_tokenized_text_on_device", "test_concurrent_host_threads_share_a_predictor",
     "test_write_tagged_text_on_device", "test_tokenize_batch_is_the_whole_pipeline",
     "test_tokenize_batch_in_chunks", "test_device_calls_accept_an_upper_bound_of_the_boundaries",

@@ -90,7 +90,8 @@ def main():
                     os.environ.pop(k, None)
                 os.environ.update(env)
                 # occupancy knobs are read when the predictor / workspace is made
-                pred = api.Predictor(api.Model.read_slice(raw)[0], False, device=0) if "VPT_DEBUG_LDS_PAD" in env else predictor
+                # the library reads its knobs once: table-level ones when a predictor is made, launch-level ones when a workspace is
+                pred = api.Predictor(api.Model.read_slice(raw)[0], False, device=0) if ("VPT_DEBUG_LDS_PAD" in env or "VPT_FORCE_WINDOW_TABLE" in env) else predictor
                 batch = api.DeviceBatch(pred, timing=True)
                 batch.set_max_sentence_chars(int(np.max(np.diff(ooff.astype(np.int64)))) + 1)
 

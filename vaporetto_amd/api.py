@@ -104,7 +104,10 @@ class Model:
     @property
     def _data(self) -> modelfmt.ModelData:
         if self._data_ is None:
-            self._data_ = modelfmt.decode_model(self._raw)[0]
+            try:
+                self._data_ = modelfmt.decode_model(self._raw)[0]
+            except modelfmt.ModelFormatError as e:   # cannot happen after read_slice's validation; still the crate's error type
+                raise VaporettoError("InvalidModel", "InvalidModelError: %s" % e)
         return self._data_
 
     @staticmethod
@@ -116,7 +119,17 @@ class Model:
         """The bytes are validated by the library's decoder (the same one vpt_predictor_create uses); the Python records
         behind dictionary() / tag_models() are decoded on first use."""
         buf = bytes(buf)
-        L = _lib.load()
+        try:
+            L = _lib.load()
+        except OSError:
+            # Reading, inspecting or converting a model needs no GPU and no built library (model tooling on a host without
+            # ROCm): the Python codec decodes -- and so validates -- the records right away instead.  COMPUTE never takes this
+            # route: Predictor() loads the library and fails loudly without it.
+            try:
+                data, n_used = modelfmt.decode_model(buf)
+            except modelfmt.ModelFormatError as e:
+                raise VaporettoError("InvalidModel", "InvalidModelError: %s" % e)
+            return Model(data, buf[:n_used]), buf[n_used:]
         used = C.c_size_t(0)
         st = L.vpt_model_read_len(buf, len(buf), C.byref(used))
         if st != _lib.VPT_OK:

@@ -33,6 +33,46 @@ vpt_status fail(vpt_status st, const std::string& msg) {
             return fail(VPT_RUNTIME_ERROR, std::string("HIP error: ") + hipGetErrorString(e_) + " at " #expr); \
     } while (0)
 
+// Experiment / test knobs from the environment (tools/README.md).  Read ONCE -- the table-level ones when a predictor is made
+// (bind_predictor), the launch-level ones when a workspace is made (vpt_batch_create) -- never on the launch path: getenv is
+// not thread-safe against setenv, and a drop-in library must not change behaviour under a running host.
+struct PredictorKnobs {
+    bool force_window_table = false;    // VPT_FORCE_WINDOW_TABLE: the 8^(2W) type table instead of the type rows
+    uint32_t lds_pad = 0;               // VPT_DEBUG_LDS_PAD: occupancy experiments
+    int pipe_lanes = -1;                // VPT_PIPE_LANES (-1: the size rule)
+    uint64_t chunk_chars = 0;           // VPT_CHUNK_CHARS (0: the size rule)
+    uint64_t tokenize_chunk_bytes = uint64_t(256) << 20;   // VPT_TOKENIZE_CHUNK_BYTES
+    int tag_wgs_per_cu = 32;            // VPT_TAG_WGS_PER_CU
+};
+struct BatchKnobs {
+    bool force_generic = false;         // VPT_FORCE_GENERIC
+    int fast_cap = 0;                   // VPT_FAST_CAP (0: by the longest sentence)
+    bool no_cps_from_predict = false;   // VPT_NO_CPS_FROM_PREDICT
+    bool inline_assign = false;         // VPT_INLINE_ASSIGN
+    uint32_t debug_ablate = 0;          // VPT_DEBUG_ABLATE
+    bool profile_phases = false;        // VPT_PROFILE_PHASES
+};
+PredictorKnobs read_predictor_knobs() {
+    PredictorKnobs k;
+    k.force_window_table = std::getenv("VPT_FORCE_WINDOW_TABLE") != nullptr;
+    if (const char* v = std::getenv("VPT_DEBUG_LDS_PAD")) k.lds_pad = uint32_t(std::max(0, std::atoi(v)));
+    if (const char* v = std::getenv("VPT_PIPE_LANES")) k.pipe_lanes = std::max(0, std::atoi(v));
+    if (const char* v = std::getenv("VPT_CHUNK_CHARS")) { const long long n = std::atoll(v); if (n > 0) k.chunk_chars = uint64_t(n); }
+    if (const char* v = std::getenv("VPT_TOKENIZE_CHUNK_BYTES")) { const long long n = std::atoll(v); if (n > 0) k.tokenize_chunk_bytes = uint64_t(n); }
+    if (const char* v = std::getenv("VPT_TAG_WGS_PER_CU")) k.tag_wgs_per_cu = std::atoi(v);
+    return k;
+}
+BatchKnobs read_batch_knobs() {
+    BatchKnobs k;
+    k.force_generic = std::getenv("VPT_FORCE_GENERIC") != nullptr;
+    if (const char* v = std::getenv("VPT_FAST_CAP")) k.fast_cap = std::atoi(v);
+    k.no_cps_from_predict = std::getenv("VPT_NO_CPS_FROM_PREDICT") != nullptr;
+    k.inline_assign = std::getenv("VPT_INLINE_ASSIGN") != nullptr;
+    if (const char* v = std::getenv("VPT_DEBUG_ABLATE")) k.debug_ablate = uint32_t(std::atoi(v));
+    k.profile_phases = std::getenv("VPT_PROFILE_PHASES") != nullptr;
+    return k;
+}
+
 constexpr size_t kTimingRing = 256;     // timed launches remembered per vpt_batch
 constexpr size_t kTablePadBytes = 256;  // probes read whole 16-byte chunks; keep the tail of every table readable
 
@@ -54,11 +94,12 @@ struct TableGeom {
     int32_t window, lo[3], len[3];
 };
 constexpr char kCompiledMagic[16] = "VaporettoHIP-C\x01";   // 15 chars + NUL
-constexpr uint32_t kCompiledVersion = 6;                    // bump whenever layout.h or a kernel's reading of it changes
+constexpr uint32_t kCompiledVersion = 7;                    // bump whenever layout.h or a kernel's reading of it changes
 struct PredictorMeta {                                      // plain data: written and read as is (little-endian hosts)
     char magic[16];
     uint32_t version, meta_bytes;
-    uint64_t arena_bytes, checksum;
+    uint64_t arena_bytes, checksum;                         // checksum: of the arena's bytes (0 in a description: vpt_predictor_describe)
+    uint64_t meta_checksum;                                 // of this block with both checksum fields zero
     uint64_t sec_off[kSectionCount], sec_bytes[kSectionCount];
     int32_t bias, pad, type_kind, type_window, chunks;
     uint32_t predict_tags, has_tags, n_tags, tok_bits, max_tag_suffix, tag_use_char, tag_use_type, n_tag_models, n_tag_strings;
@@ -75,6 +116,51 @@ uint64_t arena_checksum(const unsigned char* p, size_t n) {   // n is a multiple
         c = (c ^ w[i + 2]) * 0x100000001B3ull; d = (d ^ w[i + 3]) * 0x100000001B3ull;
     }
     return a ^ (b << 1 | b >> 63) ^ (c << 2 | c >> 62) ^ (d << 3 | d >> 61) ^ uint64_t(n);
+}
+
+uint64_t meta_checksum_of(PredictorMeta m) {   // by value: the two checksum fields are hashed as zero
+    m.checksum = 0; m.meta_checksum = 0;
+    const unsigned char* p = reinterpret_cast<const unsigned char*>(&m);
+    uint64_t h = 0xCBF29CE484222325ull;
+    for (size_t i = 0; i < sizeof(m); ++i) h = (h ^ p[i]) * 0x100000001B3ull;
+    return h ^ 0x5A17EDull;
+}
+
+// What the kernels assume of the scalars and section sizes of a compiled predictor that did not come from compile_model in
+// this process (vpt_predictor_load, vpt_predictor_adopt_device): a flipped bit in the description must not become an
+// out-of-bounds device read or a silently different score.  The arena's CONTENT is covered by its own checksum.
+const char* validate_meta(const PredictorMeta& m) {
+    auto sz = [&](int sec) { return m.sec_bytes[sec]; };
+    if (m.pad < 1 || m.pad > vpt::kMaxWindow || m.chunks < 1 || m.chunks > 16) return "pad / chunks";
+    if (m.type_kind < 0 || m.type_kind > 2 || m.type_window < 0 || m.type_window > vpt::kMaxWindow) return "type scorer";
+    if (sz(kSecCtype) != 65536 || sz(kSecCinfo) != 2ull * 65536 * 4) return "char class tables";
+    if (sz(kSecCid) != (m.pk_present ? 2ull * 65536 * 4 : 0ull)) return "char id table";
+    if (m.type_kind == vpt::kTypeWindowTable && (m.type_window > 3 || sz(kSecTypeTable) < (4ull << (6 * m.type_window)))) return "type window table";
+    for (int t = 0; t < 2; ++t) {
+        const TableGeom& g = m.geom[t];
+        if (!g.present) continue;
+        const int first = t == 0 ? kSecCShort : kSecTShort;
+        if (g.short_bits < 2 || g.short_bits > 30 || g.edge_bits < 3 || g.edge_bits > 30) return "table geometry (bits)";
+        if (g.stride_dw < 4 || g.stride_dw > 64 || g.stride_dw % 4 || g.uni_dw < 4 || g.uni_dw > 64 || g.uni_dw % 4) return "table geometry (strides)";
+        if (g.window < 0 || g.window > vpt::kMaxWindow || g.ext_slot + 2 > g.stride_dw) return "table geometry (window)";
+        if (g.uni_n > (t == 0 ? vpt::kUniDirectChars : vpt::kUniDirectTypes)) return "table geometry (direct rows)";
+        for (int i = 0; i < 3; ++i)
+            if (g.len[i] < 0 || g.len[i] > 2 * vpt::kMaxWindow + 2 || g.lo[i] > 0 || g.lo[i] < -vpt::kMaxWindow - 1 || uint32_t(g.len[i]) + 2 > g.stride_dw || uint32_t(g.len[i]) > g.uni_dw + (i ? 64u : 0u)) return "table geometry (rows)";
+        if (sz(first) < (4ull << g.short_bits) * g.stride_dw || sz(first + 1) < 4ull * g.uni_n * g.uni_dw || sz(first + 2) < (16ull << g.edge_bits)) return "table geometry (sections)";
+    }
+    if (m.type_kind == vpt::kTypePatternTable && !m.geom[1].present) return "type pattern tables";
+    if (m.pk_present) {
+        if (m.pk_n_uni < 2 || sz(kSecPUni) < 16ull * m.pk_n_uni || sz(kSecPCpid) < 4ull * m.pk_n_uni || sz(kSecPTri) < 16ull * m.pk_n_tri) return "packed tables";
+        if (m.pk_bi_shift > 16 || sz(kSecPBi) < 32 || sz(kSecPDeep) < 64) return "packed tables (bigram level)";
+        if (m.pk_has_trow ? sz(kSecPTrow) < 16ull * vpt::kTypeRowCount : false) return "type rows";
+        if (m.sec_off[kSecPCpid] + sz(kSecPCpid) - m.sec_off[kSecPUni] >= (1ull << 32)) return "packed tables (32-bit offsets)";
+    }
+    if (m.has_tags) {
+        if (m.n_tags == 0 || m.n_tags > 4096 || m.tok_bits < 2 || m.tok_bits > 30) return "tag tables";
+        if (sz(kSecTagTokTab) < (16ull << m.tok_bits) || sz(kSecTagModels) < 48ull * m.n_tag_models || sz(kSecTagMfilt) < 4ull * vpt::kTagFiltStride * m.n_tag_models) return "tag tables (sections)";
+        if (sz(kSecTagStrOff) < 4ull * (uint64_t(m.n_tag_strings) + 1)) return "tag strings";
+    } else if (m.predict_tags > 1) return "predict_tags";
+    return nullptr;
 }
 
 TableGeom geom_of(const vpt::HostPatternTable& h) {
@@ -112,6 +198,7 @@ void fill_info(const vpt::CompiledModel& c, vpt_model_info* info) {
 struct vpt_batch {
     const vpt_predictor* pred = nullptr;
     int device = 0;
+    BatchKnobs knobs;                  // read once, when the workspace was made
     // per-call device tables
     uint32_t* d_tile_first = nullptr; size_t tile_cap = 0;
     uint32_t* d_slow_list = nullptr;
@@ -166,6 +253,7 @@ struct DeviceTags {   // views into the arena
 
 struct vpt_predictor {
     int device = 0;
+    PredictorKnobs knobs;              // read once, when the predictor was made (bind_predictor)
     unsigned char* arena = nullptr;    // the one device allocation that holds every table
     PredictorMeta meta{};
     // what the launches use, bound from meta + arena (bind_predictor)
@@ -274,7 +362,7 @@ vpt_status acquire(const vpt_predictor* p, Workspace* w) {
         std::lock_guard<std::mutex> g(p->pool_mu);
         if (!p->pool.empty()) { w->b = p->pool.back(); p->pool.pop_back(); }
     }
-    if (w->b) return VPT_OK;
+    if (w->b) { w->b->cps_text = nullptr; return VPT_OK; }   // a pooled workspace remembers nothing of the call before
     vpt_batch* b = nullptr;
     vpt_status st = vpt_batch_create(p, &b);
     if (st != VPT_OK) return st;
@@ -290,6 +378,7 @@ vpt_status acquire(const vpt_predictor* p, Workspace* w) {
 // text and outputs starting at 0, and (when given) the labels.  `max_bytes` / `max_chars`: the longest sentence.
 vpt_status stage(vpt_batch* b, const uint8_t* utf8, const uint64_t* byte_offsets, const uint64_t* out_offsets, size_t n_sentences,
                  const uint8_t* labels, uint64_t* total_b_out, uint64_t* max_bytes_out, uint64_t* max_chars_out) {
+    b->cps_text = nullptr;   // d_text is about to be rewritten: whatever chars a predict call left decoded are another batch's
     const uint64_t t0 = byte_offsets[0], t1 = byte_offsets[n_sentences];
     if (t1 < t0) return fail(VPT_INVALID_ARGUMENT, "InvalidArgumentError: byte_offsets: must be non-decreasing");
     const size_t nbytes = size_t(t1 - t0);
@@ -371,6 +460,7 @@ struct SectionSrc { const void* ptr; size_t bytes; };
 // Views and scalars of a predictor from its meta block and arena; the occupancy figure comes from the device.
 void bind_predictor(vpt_predictor* p) {
     const PredictorMeta& m = p->meta;
+    p->knobs = read_predictor_knobs();
     auto at = [&](int sec) { return p->arena + m.sec_off[sec]; };
     auto view = [&](const TableGeom& g, int first) {
         vpt::PatternTableView v{};
@@ -422,10 +512,10 @@ void bind_predictor(vpt_predictor* p) {
         p->n_cus = uint32_t(prop.multiProcessorCount);
         vpt::ScoreParams probe{};
         probe.ct = p->ct; probe.pk = p->pk; probe.pad = p->pad; probe.ctype = p->d_ctype; probe.cid = p->d_cid; probe.type_kind = p->type_kind;
-        probe.type_window = p->type_window;
+        probe.type_window = p->type_window; probe.force_window_table = p->knobs.force_window_table ? 1u : 0u;
         const bool fast = vpt::fast_path_supported(probe);
         auto slots_for = [&](size_t lds, size_t built_for) {
-            if (const char* padv = std::getenv("VPT_DEBUG_LDS_PAD")) lds += size_t(std::atoi(padv));   // occupancy experiments (kernels_fast.hip)
+            lds += p->knobs.lds_pad;   // occupancy experiments (kernels_fast.hip)
             const size_t granules = (lds + 1279) / 1280;   // gfx950 hands out its 160 KB of LDS in 1280-byte granules
             return uint32_t(prop.multiProcessorCount) * uint32_t(std::min<size_t>(built_for, std::max<size_t>(1, 128 / std::max<size_t>(granules, 1))));
         };
@@ -585,6 +675,7 @@ vpt_status vpt_predictor_save(const vpt_predictor* p, uint8_t* out, size_t capac
     VPT_HIP(hipMemcpy(out + sizeof(PredictorMeta), p->arena, size_t(p->meta.arena_bytes), hipMemcpyDeviceToHost));
     PredictorMeta m = p->meta;
     m.checksum = arena_checksum(out + sizeof(PredictorMeta), size_t(m.arena_bytes));
+    m.meta_checksum = meta_checksum_of(m);
     std::memcpy(out, &m, sizeof(m));
     return VPT_OK;
 }
@@ -599,6 +690,7 @@ vpt_status vpt_predictor_load(const uint8_t* blob, size_t len, int device_id, vp
     if (std::memcmp(m.magic, kCompiledMagic, sizeof(m.magic)) != 0) return fail(VPT_INVALID_MODEL, "InvalidModelError: not a compiled predictor");
     if (m.version != kCompiledVersion || m.meta_bytes != sizeof(PredictorMeta))
         return fail(VPT_INVALID_MODEL, "InvalidModelError: compiled predictor version mismatch (compile the model again with this library)");
+    if (meta_checksum_of(m) != m.meta_checksum) return fail(VPT_INVALID_MODEL, "InvalidModelError: compiled predictor is corrupt (checksum of the description)");
     if (m.arena_bytes % 256 != 0 || len != sizeof(m) + m.arena_bytes) return fail(VPT_INVALID_MODEL, "InvalidModelError: compiled predictor is truncated");
     {   // the sections must be the layout this library would make of their sizes
         size_t bytes[kSectionCount];
@@ -607,7 +699,9 @@ vpt_status vpt_predictor_load(const uint8_t* blob, size_t len, int device_id, vp
         if (layout_sections(bytes, off) != m.arena_bytes || std::memcmp(off, m.sec_off, sizeof(off)) != 0)
             return fail(VPT_INVALID_MODEL, "InvalidModelError: compiled predictor has an inconsistent section table");
     }
-    if (arena_checksum(blob + sizeof(m), size_t(m.arena_bytes)) != m.checksum) return fail(VPT_INVALID_MODEL, "InvalidModelError: compiled predictor is corrupt (checksum)");
+    if (arena_checksum(blob + sizeof(m), size_t(m.arena_bytes)) != m.checksum)
+        return fail(VPT_INVALID_MODEL, "InvalidModelError: compiled predictor is corrupt (checksum)");
+    if (const char* what = validate_meta(m)) return fail(VPT_INVALID_MODEL, std::string("InvalidModelError: compiled predictor has an inconsistent description (") + what + ")");
     vpt_status st = check_device(device_id);
     if (st != VPT_OK) return st;
     VPT_HIP(hipSetDevice(device_id));
@@ -639,6 +733,7 @@ vpt_status vpt_predictor_describe(const vpt_predictor* p, uint8_t* meta_out, siz
         if (capacity < sizeof(PredictorMeta)) return fail(VPT_INVALID_ARGUMENT, "InvalidArgumentError: capacity: smaller than the description");
         PredictorMeta m = p->meta;
         m.checksum = 0;   // the device bytes are not read back for it; a transport that can corrupt them has its own checks
+        m.meta_checksum = meta_checksum_of(m);
         std::memcpy(meta_out, &m, sizeof(m));
     }
     return VPT_OK;
@@ -654,7 +749,9 @@ vpt_status vpt_predictor_adopt_device(const uint8_t* meta, size_t meta_len, cons
     std::memcpy(&m, meta, sizeof(m));
     if (std::memcmp(m.magic, kCompiledMagic, sizeof(m.magic)) != 0 || m.version != kCompiledVersion || m.meta_bytes != sizeof(PredictorMeta))
         return fail(VPT_INVALID_MODEL, "InvalidModelError: compiled predictor version mismatch (compile the model again with this library)");
+    if (meta_checksum_of(m) != m.meta_checksum) return fail(VPT_INVALID_MODEL, "InvalidModelError: compiled predictor is corrupt (checksum of the description)");
     if (m.arena_bytes != arena_bytes) return fail(VPT_INVALID_MODEL, "InvalidModelError: compiled predictor is truncated");
+    if (const char* what = validate_meta(m)) return fail(VPT_INVALID_MODEL, std::string("InvalidModelError: compiled predictor has an inconsistent description (") + what + ")");
     {
         size_t bytes[kSectionCount];
         uint64_t off[kSectionCount];
@@ -740,9 +837,10 @@ vpt_status vpt_batch_create(const vpt_predictor* p, vpt_batch** out) {
     vpt_batch* b = new (std::nothrow) vpt_batch();
     if (!b) return fail(VPT_RUNTIME_ERROR, "out of host memory");
     b->pred = p; b->device = p->device;
+    b->knobs = read_batch_knobs();
     hipError_t e = hipMalloc(reinterpret_cast<void**>(&b->d_ctrl), 64);
     if (e == hipSuccess) e = hipMemset(b->d_ctrl, 0, 64);
-    if (e == hipSuccess && std::getenv("VPT_PROFILE_PHASES")) {
+    if (e == hipSuccess && b->knobs.profile_phases) {
         e = hipMalloc(reinterpret_cast<void**>(&b->d_prof), 64);
         if (e == hipSuccess) e = hipMemset(b->d_prof, 0, 64);
     }
@@ -842,12 +940,13 @@ vpt_status vpt_predict_batch_device(const vpt_predictor* p, vpt_batch* b, const 
     P.type_window = p->type_window; P.type_kind = p->type_kind; P.bias = p->bias; P.pad = p->pad;
     // Tiles are cut every `tile_flat` flat positions (chars + separators) and end with the sentence that crosses
     // the cut, so a tile holds < tile_flat + longest sentence: pick tile_flat to fill the kernel's LDS capacity.
-    const bool fast = vpt::fast_path_supported(P) && !std::getenv("VPT_FORCE_GENERIC");
+    P.force_window_table = p->knobs.force_window_table ? 1u : 0u; P.lds_pad = p->knobs.lds_pad;
+    const bool fast = vpt::fast_path_supported(P) && !b->knobs.force_generic;
     // flat positions of the longest sentence: its chars, bounded by the caller's hint or else by its bytes
     const uint64_t max_chars = (b->max_chars && b->max_chars < max_sentence_bytes) ? b->max_chars : max_sentence_bytes;
     // the specialised kernel's tile geometry (kernels.hpp): small tiles, 8 workgroups per CU, unless a sentence is long
     int fast_cap = max_chars > uint64_t(vpt::kFastLongSentence) ? vpt::kFastCapLarge : vpt::kFastCapSmall;
-    if (const char* g = std::getenv("VPT_FAST_CAP")) fast_cap = std::atoi(g) == vpt::kFastCapSmall ? vpt::kFastCapSmall : vpt::kFastCapLarge;   // A/B runs
+    if (b->knobs.fast_cap) fast_cap = b->knobs.fast_cap == vpt::kFastCapSmall ? vpt::kFastCapSmall : vpt::kFastCapLarge;   // A/B runs
     const uint32_t tile_slots = fast && fast_cap == vpt::kFastCapSmall ? p->tile_slots_small : p->tile_slots;
     const uint64_t cap = fast ? uint64_t(fast_cap) : vpt::kCap;
     uint64_t tile_flat = cap / 2;
@@ -897,20 +996,20 @@ vpt_status vpt_predict_batch_device(const vpt_predictor* p, vpt_batch* b, const 
     // call for the same buffers on this workspace (Sentence::fill_tags follows Predictor::predict on the same sentence,
     // predictor.rs:542) skips its own decode pass.
     b->cps_text = nullptr;
-    if (p->has_tags && p->predict_tags && fast && !need_slow && !std::getenv("VPT_NO_CPS_FROM_PREDICT")) {
+    if (p->has_tags && p->predict_tags && fast && !need_slow && !b->knobs.no_cps_from_predict) {
         vpt_status st2 = grow(&b->d_cps, &b->cps_cap, size_t(total_boundaries + n_sentences) + 16);
         if (st2 != VPT_OK) return st2;
-        P.cps_out = b->d_cps;
+        P.cps_out = b->d_cps; P.total_chars = total_boundaries + n_sentences;
         b->cps_text = d_utf8; b->cps_ooff = d_out_offsets; b->cps_sentences = n_sentences; b->cps_boundaries = total_boundaries;
         b->cps_flags = b->flags & VPT_FLAG_KYTEA_FULLWIDTH;
     }
-    if (const char* dbg = std::getenv("VPT_DEBUG_ABLATE")) { P.debug = uint32_t(std::atoi(dbg)); P.ct.debug = P.debug; P.tt.debug = P.debug; }
+    if (b->knobs.debug_ablate) { P.debug = b->knobs.debug_ablate; P.ct.debug = P.debug; P.tt.debug = P.debug; }
 
     P.n_sent = n_sentences; P.tile_flat = uint32_t(tile_flat); P.n_tiles = n_tiles;
     // The specialised kernel can find its tiles itself (one launch per step).  Measured on MI355X (profiles/r02_c1_ab.jsonl):
     // the search at the head of every workgroup costs the scoring kernel more (+4 us) than the separate 5 us kernel and its
     // launch gap cost the step, so the separate kernel stays the default.
-    const bool inline_assign = fast && !need_slow && std::getenv("VPT_INLINE_ASSIGN");
+    const bool inline_assign = fast && !need_slow && b->knobs.inline_assign;
     if (inline_assign) P.tile_first = nullptr;
     else VPT_HIP(vpt::launch_assign_tiles(d_out_offsets, n_sentences, p->pad, uint32_t(tile_flat), n_tiles, b->d_tile_first, b->d_ctrl, stream));
     const size_t slot = b->ev_calls % kTimingRing;
@@ -946,10 +1045,10 @@ namespace {
 //                                many chunks than the lanes, whose copies contend (7.3 .. 10 ms)
 // VPT_CHUNK_CHARS / VPT_PIPE_LANES (0 = the event pipeline) override; the tests use them to cut small batches into many chunks.
 struct PipePlan { int lanes; uint64_t chunk; bool pipelined; };
-PipePlan pipeline_plan(uint64_t total_chars) {
+PipePlan pipeline_plan(const PredictorKnobs& knobs, uint64_t total_chars) {
     PipePlan plan = total_chars <= (uint64_t(16) << 20) ? PipePlan{4, uint64_t(512) << 10, false} : PipePlan{0, uint64_t(4) << 20, false};
-    if (const char* v = std::getenv("VPT_PIPE_LANES")) plan.lanes = std::atoi(v);
-    if (const char* v = std::getenv("VPT_CHUNK_CHARS")) { const long long n = std::atoll(v); if (n > 0) plan.chunk = uint64_t(n); }
+    if (knobs.pipe_lanes >= 0) plan.lanes = knobs.pipe_lanes;
+    if (knobs.chunk_chars) plan.chunk = knobs.chunk_chars;
     plan.pipelined = total_chars > (plan.lanes > 0 ? 3 * plan.chunk : plan.chunk + plan.chunk / 2);
     return plan;
 }
@@ -1135,7 +1234,7 @@ vpt_status vpt_predict_batch_flags(const vpt_predictor* p, const uint8_t* utf8, 
     vpt_batch* b = w.b;
     b->flags = flags;
     if (byte_offsets[n_sentences] >= byte_offsets[0] && out_offsets[n_sentences] >= out_offsets[0]) {   // a batch of several chunks goes through a copy/compute pipeline
-        const PipePlan plan = pipeline_plan(out_offsets[n_sentences] - out_offsets[0] + n_sentences);
+        const PipePlan plan = pipeline_plan(p->knobs, out_offsets[n_sentences] - out_offsets[0] + n_sentences);
         if (plan.pipelined && plan.lanes > 0) return predict_lanes(p, b, utf8, byte_offsets, n_sentences, scores_out, labels_out, out_offsets, plan.chunk, plan.lanes);
         if (plan.pipelined) return predict_pipelined(p, b, utf8, byte_offsets, n_sentences, scores_out, labels_out, out_offsets, plan.chunk);
     }
@@ -1211,8 +1310,8 @@ vpt_status vpt_fill_tags_batch_device(const vpt_predictor* p, vpt_batch* b, cons
     const uint32_t* cinfo = p->d_cinfo + ((b->flags & VPT_FLAG_KYTEA_FULLWIDTH) ? 65536 : 0);
     const bool have_cps = b->cps_text == d_utf8 && b->cps_ooff == d_out_offsets && b->cps_sentences == n_sentences &&
                           b->cps_boundaries == total_boundaries && b->cps_flags == (b->flags & VPT_FLAG_KYTEA_FULLWIDTH) && b->last_stream == stream;
+    b->cps_text = nullptr;   // one shot: only the fill_tags call that FOLLOWS the predict call takes its chars (predictor.rs:542)
     if (!have_cps) {
-        b->cps_text = nullptr;
         VPT_HIP(vpt::launch_decode_chars(d_utf8, d_byte_offsets, d_out_offsets, n_sentences, total_c, cinfo, b->d_cps, nullptr, b->d_ctrl, stream));
     }
     vpt::TagParams T{};
@@ -1224,8 +1323,7 @@ vpt_status vpt_fill_tags_batch_device(const vpt_predictor* p, vpt_batch* b, cons
     // tag_tokens_kernel runs 8 workgroups per CU at a time; four generations of them stride over the batch, so that the
     // sentences' lengths (8..512 chars in BASELINE's configs[4]) even out without one workgroup per four sentences
     // (measured on configs[4], 300 K sentences: 65536 workgroups 1.09 ms, 8 per CU 0.67, 32 per CU 0.64)
-    static const int tag_wgs = [] { const char* e = std::getenv("VPT_TAG_WGS_PER_CU"); return e ? std::atoi(e) : 32; }();
-    T.max_blocks = p->n_cus * uint32_t(tag_wgs);
+    T.max_blocks = p->n_cus * uint32_t(std::max(0, p->knobs.tag_wgs_per_cu));
     VPT_HIP(vpt::launch_tag_tokens(T, stream));
     b->last_stream = stream; b->pending = true;
     return VPT_OK;
@@ -1240,7 +1338,7 @@ static vpt_status emit_device(const vpt_predictor* p, vpt_batch* b, const uint8_
     VPT_HIP(hipSetDevice(p->device));
     if (n_sentences == 0) {
         VPT_HIP(hipMemsetAsync(d_text_offsets_out, 0, sizeof(uint64_t), stream));
-        b->last_stream = stream; b->pending = true;
+        b->last_stream = stream; b->pending = true; b->cps_text = nullptr;
         return VPT_OK;
     }
     if (!d_utf8 || !d_byte_offsets || !d_out_offsets || (total_boundaries && !d_labels) || (text_capacity && !d_text_out))
@@ -1261,7 +1359,7 @@ static vpt_status emit_device(const vpt_predictor* p, vpt_batch* b, const uint8_
         if (st != VPT_OK) return st;
     }
     VPT_HIP(vpt::launch_emit_tokenized(E, b->d_scan_part, p->n_cus * 32u, total_out, stream));
-    b->last_stream = stream; b->pending = true;
+    b->last_stream = stream; b->pending = true; b->cps_text = nullptr;
     return VPT_OK;
 }
 
@@ -1344,7 +1442,7 @@ vpt_status vpt_count_boundaries_device(const vpt_predictor* p, vpt_batch* b, con
         if (st != VPT_OK) return st;
         VPT_HIP(vpt::launch_count_boundaries(d_utf8, d_byte_offsets, n_sentences, d_out_offsets, b->d_scan_part, b->d_ctrl, b->d_ctrl + 2, p->n_cus * 32u, stream));
     }
-    b->last_stream = stream; b->pending = true;
+    b->last_stream = stream; b->pending = true; b->cps_text = nullptr;
     return VPT_OK;
 }
 
@@ -1386,7 +1484,7 @@ vpt_status vpt_tokenize_batch(const vpt_predictor* p, const uint8_t* utf8, const
     // 22.7 in 4 .. 125.  So a chunk is 256 MB of text -- one, unless the batch is larger than that (VPT_TOKENIZE_CHUNK_BYTES
     // overrides; the tests use it).
     constexpr int kMaxLanes = 4;
-    const uint64_t chunk_bytes = [] { const char* v = std::getenv("VPT_TOKENIZE_CHUNK_BYTES"); return v && std::atoll(v) > 0 ? uint64_t(std::atoll(v)) : (uint64_t(256) << 20); }();
+    const uint64_t chunk_bytes = p->knobs.tokenize_chunk_bytes;
     const uint64_t per_byte = 3 + (with_tags ? uint64_t(p->max_tag_suffix) : 0);   // tokenized bytes per text byte, at most
     const size_t max_chunks = std::min<size_t>(n_sentences, size_t(nbytes / chunk_bytes) + 2);
     const int n_lanes = int(std::min<size_t>(kMaxLanes, max_chunks));
@@ -1576,7 +1674,7 @@ vpt_status vpt_char_types_batch_device(const vpt_predictor* p, vpt_batch* b, con
     const uint32_t* cinfo = p->d_cinfo + ((b->flags & VPT_FLAG_KYTEA_FULLWIDTH) ? 65536 : 0);
     VPT_HIP(vpt::launch_decode_chars(d_utf8, d_byte_offsets, d_out_offsets, n_sentences, total_boundaries + n_sentences, cinfo, nullptr, d_types_out,
                                      b->d_ctrl, stream));
-    b->last_stream = stream; b->pending = true;
+    b->last_stream = stream; b->pending = true; b->cps_text = nullptr;
     return VPT_OK;
 }
 

@@ -23,7 +23,6 @@
 #include <hip/hip_runtime.h>
 
 #include <cstddef>
-#include <cstdlib>
 
 #include "device_common.h"
 #include "kernels.hpp"
@@ -424,8 +423,11 @@ __global__ __launch_bounds__(kThreads, WG) void score_tiles_fast_kernel(const Sc
             if (P.cps_out) {   // wave-uniform: a fill_tags call on this batch follows and wants the chars decoded (it then skips its own pass)
                 const uint32_t flat = uint32_t(tid) + uint32_t(k) * kThreads, si = xs[k] >> 21;
                 const uint32_t scored = (P.cinfo && cp < 0x10000u) ? (P.cinfo[cp] & 0xFFFFu) : cp;   // through KyteaFullwidthFilter when that flag is on
-                if (cp != 0 && flat >= pad * (si + 1u) && flat - pad * (si + 1u) < expect_chars)
-                    P.cps_out[(O0 + i0) + (flat - pad * (si + 1u))] = scored | (((v >> 16) & 7u) << 24);
+                if (cp != 0 && flat >= pad * (si + 1u) && flat - pad * (si + 1u) < expect_chars) {
+                    const uint64_t at = (O0 + i0) + (flat - pad * (si + 1u));
+                    if (at < P.total_chars) P.cps_out[at] = scored | (((v >> 16) & 7u) << 24);
+                    else err |= kErrBadOffsets;   // out_offsets that run past the total the caller stated
+                }
             }
             if (TM != kTypeRows) M.typ[uint32_t(tid) + uint32_t(k) * kThreads] = uint8_t((v >> 16) & 7u);
         }
@@ -587,7 +589,7 @@ bool fast_path_supported(const ScoreParams& P) {
 }
 
 static bool use_type_rows(const ScoreParams& P) {
-    return P.type_kind == kTypeWindowTable && P.pk.has_trow && !std::getenv("VPT_FORCE_WINDOW_TABLE");
+    return P.type_kind == kTypeWindowTable && P.pk.has_trow && !P.force_window_table;
 }
 size_t score_tiles_fast_lds_bytes(const ScoreParams& P, int cap) {
     const size_t head = cap == kFastCapSmall ? offsetof(FastLdsT<kFastCapSmall>, typ) : offsetof(FastLdsT<kFastCapLarge>, typ);
@@ -597,7 +599,7 @@ size_t score_tiles_fast_lds_bytes(const ScoreParams& P, int cap) {
 hipError_t launch_score_tiles_fast(const ScoreParams& P, int cap, uint32_t n_tiles, hipStream_t stream) {
     const bool rows = use_type_rows(P);
     size_t lds = score_tiles_fast_lds_bytes(P, cap);
-    if (const char* padv = std::getenv("VPT_DEBUG_LDS_PAD")) lds += size_t(std::atoi(padv));  // occupancy experiments
+    lds += P.lds_pad;  // occupancy experiments
     const int tm = rows ? kTypeRows : P.type_kind == kTypeWindowTable ? P.type_window : 0;
     const bool dbg = P.debug != 0 || P.prof != nullptr;
     if (cap != kFastCapSmall && cap != kFastCapLarge) return hipErrorInvalidValue;
