@@ -4,18 +4,27 @@
 One "step" = one pass of Predictor::predict over one batch of synthetic sentences that is already resident in HBM.
 The workloads are BASELINE.json's configs:
 
-  configs[1]  bccwj-suw+unidic-shaped model (synthetic M1), 100 K sentences x 64 chars            -- the line's `value` at N = 1
+  configs[1]  bccwj-suw+unidic-shaped model (synthetic M1), 100 K sentences x 64 chars
   configs[2]  the same model, 10 M sentences x 64 chars cut into character-balanced shards over the N ranks (strong
-              scaling; the predictor is compiled on rank 0 and its tables are broadcast over RCCL) -- the `value` at N > 1
+              scaling; the predictor is compiled on rank 0 and its tables are broadcast over RCCL)
+                                                                   -- the line's `value` at EVERY N, N = 1 included
   configs[3]  jp-0.4.7-5-shaped model (synthetic M2, dictionary heavy), 100 K x 64
   configs[4]  M1 + tag models (synthetic M3), predict_tags on, 1 M sentences of 8..512 chars / N, step = predict + fill_tags
 
-With no --config, N = 1 reports configs[1] and folds configs[3], [4] and [2] (its N = 1 point) into `workloads`, each with
-its own parity, kernel time and roofline; N > 1 reports configs[2].  (--quick: the primary workload only.)
+ONE workload over the whole 1 -> 8 curve: with no --config the `value` is configs[2] at every N (the north-star's "10 M-sentence
+synthetic batch"; it fits one GPU), so that a scaling curve built from the per-N values compares like with like.  N = 1 also
+folds configs[1], [3] and [4] into `workloads`, each with its own parity, kernel time and roofline (configs[1] carries the
+PCIe end-to-end figures).  (--quick: the primary workload only.)
 
-    python bench.py --gpus 1 --steps 20 --warmup 3
+    python bench.py --gpus N --steps 20 --warmup 3        # N > 1 without WORLD_SIZE: launches its N ranks itself (below)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
+
+`python bench.py --gpus N` (N > 1) outside torch.distributed.run re-executes itself under it, one rank per GPU over RCCL; when that
+job fails (e.g. RCCL cannot initialise) it falls back to ONE process that clones the predictor to the N devices
+(vpt_predictor_clone_to_device: hipMemcpyPeer) and drives one host thread + stream per device -- a measured curve either
+way, and the line says which (`config.launch`).  Fewer than N visible HIP devices is an error (exit code 2), never a
+silent 1-GPU run.  (Test hook for a 1-GPU box: VPT_BENCH_ONE_DEVICE=1 puts every rank on device 0, VPT_BENCH_BACKEND=gloo.)
 """
 from __future__ import annotations
 
@@ -107,6 +116,49 @@ def cpu_model_name() -> str:
     return "unknown"
 
 
+def make_shard(cfg, raw, rank: int, world: int, ncores: int, sentences_override: int = 0):
+    """This rank's shard of the workload's batch: (utf8, byte offsets, boundary offsets, index of its first sentence, sentences of the whole batch)."""
+    from vaporetto_amd import api, synth, dist as vdist
+    S, lo_len, hi_len = cfg["sentences"], cfg["min_len"], cfg["max_len"]
+    if sentences_override:
+        S = sentences_override
+    if not cfg["blocks"]:
+        utf8, boff = synth.synth_sentences(raw, S, lo_len, hi_len, seed=synth.SEED_BASE + 2)
+        ooff = api.count_boundaries(utf8, boff)
+        if world == 1:
+            return utf8, boff, ooff, 0, S
+        u, b, o, first = vdist.take_shard(utf8, boff, ooff, rank, world)
+        return u, b, o, first, S
+    n_blocks = (S + BLOCK - 1) // BLOCK
+    S = n_blocks * BLOCK
+    seed = synth.SEED_BASE + (3 if cfg["name"] == "configs[2]" else 5)
+    if lo_len == hi_len:
+        # equal lengths: the global offsets are arithmetic, so a rank generates only the blocks its shard touches
+        g_ooff = np.arange(S + 1, dtype=np.uint64) * np.uint64(lo_len - 1)
+        bounds = vdist.shard_bounds(g_ooff, world)
+        a, e = int(bounds[rank]), int(bounds[rank + 1])
+        b0, b1 = a // BLOCK, (e + BLOCK - 1) // BLOCK
+        utf8, boff = synth.synth_blocks(raw, b0, max(b1 - b0, 1), BLOCK, lo_len, hi_len, seed=seed, nthreads=min(32, ncores))
+        i0, i1 = a - b0 * BLOCK, e - b0 * BLOCK
+        t0, t1 = int(boff[i0]), int(boff[i1])
+        utf8, boff = np.ascontiguousarray(utf8[t0:t1]), (boff[i0:i1 + 1] - boff[i0]).astype(np.uint64)
+        ooff = (g_ooff[a:e + 1] - g_ooff[a]).astype(np.uint64)
+        return utf8, boff, ooff, a, S
+    # ragged lengths: every rank generates the batch and takes its character-balanced shard
+    utf8, boff = synth.synth_blocks(raw, 0, n_blocks, BLOCK, lo_len, hi_len, seed=seed, nthreads=min(32, ncores))
+    ooff = api.count_boundaries(utf8, boff)
+    if world == 1:
+        return utf8, boff, ooff, 0, S
+    u, b, o, first = vdist.take_shard(utf8, boff, ooff, rank, world)
+    return u, b, o, first, S
+
+
+def die(msg: str, code: int = 2):
+    sys.stderr.write("bench.py: error: %s\n" % msg)
+    sys.stderr.flush()
+    raise SystemExit(code)
+
+
 class Runner:
     def __init__(self, args):
         import torch
@@ -115,11 +167,16 @@ class Runner:
         self.rank = int(os.environ.get("RANK", "0"))
         self.world = int(os.environ.get("WORLD_SIZE", "1"))
         self.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-        if self.world != args.gpus and self.world > 1:
-            raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, self.world))
+        if self.world != args.gpus:   # never a line whose n_gpus is not what was asked for
+            die("--gpus %d but WORLD_SIZE=%d: launch %d ranks (python -m torch.distributed.run --nproc-per-node %d ... bench.py --gpus %d), "
+                "or plain `python bench.py --gpus %d`, which launches them itself" % (args.gpus, self.world, args.gpus, args.gpus, args.gpus, args.gpus))
+        visible = torch.cuda.device_count()
         # (test hook for a 1-GPU box: VPT_BENCH_ONE_DEVICE=1 VPT_BENCH_BACKEND=gloo runs the N-rank code path with every rank on device 0)
         if os.environ.get("VPT_BENCH_ONE_DEVICE"):
             self.local_rank = 0
+        if visible <= self.local_rank:
+            die("rank %d of %d wants HIP device %d but %d device(s) are visible: --gpus %d needs %d GPUs on this node"
+                % (self.rank, self.world, self.local_rank, visible, args.gpus, args.gpus))
         backend = os.environ.get("VPT_BENCH_BACKEND", "nccl")
         torch.cuda.set_device(self.local_rank)
         self.dev = torch.device("cuda", self.local_rank)
@@ -155,39 +212,7 @@ class Runner:
 
     # ---- this rank's shard of the batch
     def make_shard(self, cfg, raw):
-        from vaporetto_amd import api, synth, dist as vdist
-        S, lo_len, hi_len = cfg["sentences"], cfg["min_len"], cfg["max_len"]
-        if self.args.sentences:
-            S = self.args.sentences
-        if not cfg["blocks"]:
-            utf8, boff = synth.synth_sentences(raw, S, lo_len, hi_len, seed=synth.SEED_BASE + 2)
-            ooff = api.count_boundaries(utf8, boff)
-            if self.world == 1:
-                return utf8, boff, ooff, 0, S
-            u, b, o, first = vdist.take_shard(utf8, boff, ooff, self.rank, self.world)
-            return u, b, o, first, S
-        n_blocks = (S + BLOCK - 1) // BLOCK
-        S = n_blocks * BLOCK
-        seed = synth.SEED_BASE + (3 if cfg["name"] == "configs[2]" else 5)
-        if lo_len == hi_len:
-            # equal lengths: the global offsets are arithmetic, so a rank generates only the blocks its shard touches
-            g_ooff = np.arange(S + 1, dtype=np.uint64) * np.uint64(lo_len - 1)
-            bounds = vdist.shard_bounds(g_ooff, self.world)
-            a, e = int(bounds[self.rank]), int(bounds[self.rank + 1])
-            b0, b1 = a // BLOCK, (e + BLOCK - 1) // BLOCK
-            utf8, boff = synth.synth_blocks(raw, b0, max(b1 - b0, 1), BLOCK, lo_len, hi_len, seed=seed, nthreads=min(32, self.ncores))
-            i0, i1 = a - b0 * BLOCK, e - b0 * BLOCK
-            t0, t1 = int(boff[i0]), int(boff[i1])
-            utf8, boff = np.ascontiguousarray(utf8[t0:t1]), (boff[i0:i1 + 1] - boff[i0]).astype(np.uint64)
-            ooff = (g_ooff[a:e + 1] - g_ooff[a]).astype(np.uint64)
-            return utf8, boff, ooff, a, S
-        # ragged lengths: every rank generates the batch and takes its character-balanced shard
-        utf8, boff = synth.synth_blocks(raw, 0, n_blocks, BLOCK, lo_len, hi_len, seed=seed, nthreads=min(32, self.ncores))
-        ooff = api.count_boundaries(utf8, boff)
-        if self.world == 1:
-            return utf8, boff, ooff, 0, S
-        u, b, o, first = vdist.take_shard(utf8, boff, ooff, self.rank, self.world)
-        return u, b, o, first, S
+        return make_shard(cfg, raw, self.rank, self.world, self.ncores, self.args.sentences)
 
     def all_true(self, flag: bool) -> bool:
         if self.world == 1:
@@ -196,7 +221,7 @@ class Runner:
         self.dist.all_reduce(t, op=self.dist.ReduceOp.MIN)
         return bool(t.item())
 
-    def run(self, cfg_id: int, primary: bool):
+    def run(self, cfg_id: int, primary: bool, e2e_leg: bool = False):
         torch, dist = self.torch, self.dist
         from vaporetto_amd import api, dist as vdist
         args = self.args
@@ -318,18 +343,29 @@ class Runner:
             from oracle import cbind
             orc = cbind.OraclePredictor(raw, cfg["tags"])
             t = time.perf_counter()
-            if primary and self.world == 1 and cfg_id == 1:
-                o_scores, o_labels, _, a_char = orc.predict_batch(utf8, boff, nthreads=1)
-                t1 = time.perf_counter() - t
-                reps = max(1, min(20, int(10.0 / max(t1 / self.ncores * 1.5, 1e-3))))
+            if primary or cfg_id == 1:
+                # the CPU baseline, on this rank's host cores: a bounded sample of the same workload -- one pass over (at most) the
+                # first 100 K sentences on ONE thread (the reference is single-threaded), then the whole shard on this rank's share
+                # of the host threads (that pass is also the parity check's reference); repeated while it stays within ~10 s
+                n1 = min(S, 100_000)
                 t = time.perf_counter()
-                for _ in range(reps):
+                orc.predict_batch(utf8[:int(boff[n1])], boff[:n1 + 1], nthreads=1)
+                t1 = time.perf_counter() - t
+                nb1 = int(ooff[n1])
+                t = time.perf_counter()
+                o_scores, o_labels, _, a_char = orc.predict_batch(utf8, boff, nthreads=self.ncores)
+                tn = time.perf_counter() - t
+                reps = 1
+                while tn * (reps + 1) < 10.0 and reps < 20:
+                    t = time.perf_counter()
                     orc.predict_batch(utf8, boff, nthreads=self.ncores)
-                tn = (time.perf_counter() - t) / reps
+                    tn = min(tn, time.perf_counter() - t)
+                    reps += 1
                 cpu = {"value": nb / tn, "unit": "boundaries/s", "cores": self.ncores, "kind": "port",
-                       "single_thread_value": nb / t1, "cpu": cpu_model_name(),
-                       "sample": "the same %d-sentence batch: 1 pass on 1 thread, %d passes on %d threads (C restatement of the "
-                                 "reference algorithm with a hash-table automaton, not the Rust binary: a lower bound for it)" % (S, reps, self.ncores)}
+                       "single_thread_value": nb1 / t1, "cpu": cpu_model_name(),
+                       "sample": "rank 0's shard of this workload (%d sentences): best of %d pass(es) on %d threads; its first %d sentences once on 1 "
+                                 "thread (C restatement of the reference algorithm with a hash-table automaton, not the Rust binary: a lower "
+                                 "bound for it)" % (S, reps, self.ncores, n1)}
             else:
                 o_scores, o_labels, _, a_char = orc.predict_batch(utf8, boff, nthreads=self.ncores)
             g_scores = d_scores[:nb].cpu().numpy()
@@ -351,7 +387,7 @@ class Runner:
 
         # ---- end to end over PCIe: pinned caller buffers through the pipelined host path (N = 1, primary only)
         e2e = None
-        if primary and self.world == 1 and not args.no_e2e:
+        if e2e_leg and self.world == 1 and not args.no_e2e:
             keep = [api.PinnedArray((nbytes,), np.uint8), api.PinnedArray((max(nb, 1),), np.int32), api.PinnedArray((max(nb, 1),), np.uint8)]
             keep[0].array[:] = utf8
             for _ in range(2):
@@ -406,9 +442,7 @@ class Runner:
         if self.rank != 0:
             return None
         out = {
-            "workload": "%s: %s model, %d sentences x %d..%d chars%s, inputs resident in HBM"
-                        % (cfg["name"], model_name, S_total, cfg["min_len"], cfg["max_len"],
-                           " in character-balanced shards over %d ranks" % self.world if self.world > 1 else ""),
+            "workload": "%s: %s model, %d sentences x %d..%d chars, inputs resident in HBM" % (cfg["name"], model_name, S_total, cfg["min_len"], cfg["max_len"]),
             "value": total_boundaries * steps / elapsed, "ms_per_step": 1e3 * elapsed / steps, "steps": steps,
             "tokenizer_model": model_name, "sentences_per_gpu": S, "boundaries_per_gpu": nb, "text_bytes_per_gpu": nbytes,
             "char_ngrams": info["n_char_ngrams"], "dict_words": info["n_dict_words"], "tag_models": info["n_tag_models"],
@@ -445,12 +479,13 @@ class Runner:
         return out
 
 
-def main():
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--config", type=int, default=0, choices=[0, 1, 2, 3, 4], help="BASELINE.json configs index (0: 1 at N = 1, 2 at N > 1, plus the others as `workloads`)")
+    ap.add_argument("--config", type=int, default=0, choices=[0, 1, 2, 3, 4],
+                    help="BASELINE.json configs index (0: configs[2] as the value at every N, plus -- at N = 1 -- the others as `workloads`)")
     ap.add_argument("--quick", action="store_true", help="the primary workload only")
     ap.add_argument("--sentences", type=int, default=0, help="override the config's sentence count (diagnostics; traffic is then not reported)")
     ap.add_argument("--model-scale", type=float, default=1.0)
@@ -458,15 +493,195 @@ def main():
     ap.add_argument("--no-e2e", action="store_true")
     ap.add_argument("--no-emit", action="store_true")
     ap.add_argument("--phases", action="store_true", help="diagnostics: per-phase shader cycles of the scoring kernel (slows it)")
-    args = ap.parse_args()
+    ap.add_argument("--in-process", action="store_true", help="N > 1: skip torch.distributed, drive the N devices from this process (the fallback path)")
+    args = ap.parse_args(argv)
+    if args.gpus < 1:
+        die("--gpus must be at least 1")
+    return args
 
+
+def visible_devices() -> int:
+    import torch
+    return torch.cuda.device_count()
+
+
+def self_launch(args) -> int:
+    """`python bench.py --gpus N` (N > 1) outside torch.distributed.run: check the devices, run the N-rank job, fall back to the
+    in-process clones when it fails.  Returns the exit code."""
+    import socket
+    n_vis = visible_devices()
+    one_dev = bool(os.environ.get("VPT_BENCH_ONE_DEVICE"))
+    if n_vis < (1 if one_dev else args.gpus):
+        die("--gpus %d but only %d HIP device(s) are visible on this node (hipGetDeviceCount): refusing to print a line for fewer GPUs than "
+            "asked for (test hook for a 1-GPU box: VPT_BENCH_ONE_DEVICE=1 VPT_BENCH_BACKEND=gloo)" % (args.gpus, n_vis))
+    reason = "--in-process"
+    if not args.in_process:
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        env = dict(os.environ, VPT_BENCH_LAUNCH="bench.py launched its %d ranks itself (torch.distributed.run)" % args.gpus)
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC: RCCL between processes needs it on this host driver
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
+               "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        sys.stderr.write("bench.py: launching %d ranks: %s\n" % (args.gpus, " ".join(cmd)))
+        sys.stderr.flush()
+        job = subprocess.run(cmd, env=env, stdout=subprocess.PIPE)
+        out = job.stdout.decode("utf-8", "replace")
+        lines = [l for l in out.splitlines() if l.startswith("{") and '"metric"' in l]
+        if job.returncode == 0 and lines:
+            sys.stdout.write(out)
+            sys.stdout.flush()
+            return 0
+        sys.stderr.write(out)
+        reason = "the %d-rank torch.distributed job exited with code %d%s" % (args.gpus, job.returncode, "" if lines else " and printed no result line")
+        sys.stderr.write("bench.py: %s; falling back to one process driving %d devices\n" % (reason, args.gpus))
+        sys.stderr.flush()
+    return run_in_process(args, reason)
+
+
+def run_in_process(args, reason: str) -> int:
+    """The fallback curve: ONE process, N devices.  The predictor is compiled on device 0 and cloned device to device
+    (vpt_predictor_clone_to_device: hipMemcpyPeer over xGMI); every device holds its character-balanced shard of the workload in its own
+    HBM and is driven by a host thread + stream of its own.  Timed like the N-rank job: all threads start together, each runs K steps
+    and waits for its device; the job's time is first start to last finish."""
+    import threading
+    import torch
+    from vaporetto_amd import api
+    N = args.gpus
+    one_dev = bool(os.environ.get("VPT_BENCH_ONE_DEVICE"))
+    n_vis = visible_devices()
+    if n_vis < (1 if one_dev else N):
+        die("--gpus %d but only %d HIP device(s) are visible on this node" % (N, n_vis))
+    devs = [0] * N if one_dev else list(range(N))
+    cfg_id = args.config or 2
+    cfg = CONFIGS[cfg_id]
+    if cfg["tags"]:
+        die("the in-process fallback runs the boundary workloads (configs 1-3)")
+    ncores = max(1, os.cpu_count() or 1)
+    raw, model_name = load_model_bytes(cfg["kind"], args.model_scale)
+    t = time.perf_counter()
+    p0 = api.Predictor(api.Model.read_slice(raw)[0], False, device=devs[0])
+    create_s = time.perf_counter() - t
+    t = time.perf_counter()
+    preds = [p0] + [p0.clone_to_device(d) for d in devs[1:]]
+    clone_s = time.perf_counter() - t
+    info = p0.info()
+    shards, S_total, synth_s = [], 0, 0.0
+    for r in range(N):
+        t = time.perf_counter()
+        utf8, boff, ooff, first, S_total = make_shard(cfg, raw, r, N, ncores, args.sentences)
+        synth_s += time.perf_counter() - t
+        torch.cuda.set_device(devs[r])
+        dev = torch.device("cuda", devs[r])
+        S, nb = len(boff) - 1, int(ooff[-1])
+        sh = dict(utf8=utf8, boff=boff, ooff=ooff, S=S, nb=nb, nbytes=int(boff[-1]), dev=dev,
+                  max_bytes=int(np.max(np.diff(boff.astype(np.int64)))) if S else 1,
+                  d_text=torch.from_numpy(np.concatenate([utf8, np.zeros(64, np.uint8)])).to(dev),
+                  d_boff=torch.from_numpy(boff.astype(np.int64)).to(dev), d_ooff=torch.from_numpy(ooff.astype(np.int64)).to(dev),
+                  d_scores=torch.empty(nb + 1, dtype=torch.int32, device=dev), d_labels=torch.empty(nb + 1, dtype=torch.uint8, device=dev),
+                  stream=torch.cuda.Stream(device=dev), batch=api.DeviceBatch(preds[r], timing=True))
+        sh["batch"].set_max_sentence_chars((int(np.max(np.diff(ooff.astype(np.int64)))) + 1) if S else 1)
+        shards.append(sh)
+    start = threading.Barrier(N)
+    t_start, t_end, errors = [0.0] * N, [0.0] * N, []
+
+    def work(r):
+        try:
+            sh = shards[r]
+            torch.cuda.set_device(sh["dev"])
+            st = sh["stream"].cuda_stream
+
+            def step():
+                sh["batch"].predict(sh["d_text"].data_ptr(), sh["d_boff"].data_ptr(), sh["d_ooff"].data_ptr(), sh["S"], sh["nb"], sh["max_bytes"],
+                                    sh["d_scores"].data_ptr(), sh["d_labels"].data_ptr(), st)
+            for _ in range(args.warmup):
+                step()
+            sh["batch"].sync()
+            sh["batch"].kernel_ms()
+            sh["stream"].synchronize()
+            start.wait()
+            t_start[r] = time.perf_counter()
+            for _ in range(args.steps):
+                step()
+            sh["stream"].synchronize()
+            t_end[r] = time.perf_counter()
+            sh["batch"].sync()
+        except BaseException as e:   # noqa: a failed thread must not leave the others at the barrier
+            errors.append(e)
+            start.abort()
+    threads = [threading.Thread(target=work, args=(r,)) for r in range(N)]
+    [th.start() for th in threads]
+    [th.join() for th in threads]
+    if errors:
+        die("in-process run failed: %r" % (errors[0],), 1)
+    elapsed = max(t_end) - min(t_start)
+    total_nb = sum(sh["nb"] for sh in shards)
+    ktimes = shards[0]["batch"].kernel_times()
+    kernel_ms_mean, n_tiles = shards[0]["batch"].kernel_ms()
+    kernel_ms = float(np.median(ktimes)) if len(ktimes) else kernel_ms_mean
+    parity, cpu, a_char = None, None, None
+    if not args.no_cpu_baseline:
+        from oracle import cbind
+        orc = cbind.OraclePredictor(raw, False)
+        parity = True
+        for r, sh in enumerate(shards):
+            t = time.perf_counter()
+            o_scores, o_labels, _, ac = orc.predict_batch(sh["utf8"], sh["boff"], nthreads=ncores)
+            tn = time.perf_counter() - t
+            torch.cuda.set_device(sh["dev"])
+            ok = bool(np.array_equal(sh["d_scores"][:sh["nb"]].cpu().numpy(), o_scores) and np.array_equal(sh["d_labels"][:sh["nb"]].cpu().numpy(), o_labels))
+            parity = parity and ok
+            if r == 0:
+                a_char = ac
+                n1 = min(sh["S"], 100_000)
+                t = time.perf_counter()
+                orc.predict_batch(sh["utf8"][:int(sh["boff"][n1])], sh["boff"][:n1 + 1], nthreads=1)
+                t1 = time.perf_counter() - t
+                cpu = {"value": sh["nb"] / tn, "unit": "boundaries/s", "cores": ncores, "kind": "port", "single_thread_value": int(sh["ooff"][n1]) / t1,
+                       "cpu": cpu_model_name(),
+                       "sample": "device 0's shard of this workload (%d sentences): 1 pass on %d threads; its first %d sentences once on 1 thread (C "
+                                 "restatement of the reference algorithm with a hash-table automaton, not the Rust binary: a lower bound for it)" % (sh["S"], ncores, n1)}
+    sh0 = shards[0]
+    a_stream, a_type = sh0["nbytes"] + 5 * sh0["nb"] + 16 * sh0["S"], 4 * sh0["nb"]
+    kernel_name = "score_tiles_fast_kernel" if info["packed"] and info["type_kind"] in (0, 1) else "score_tiles_kernel"
+    roof = {"bound": "hbm", "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None, "traffic": None, "kernel": kernel_name,
+            "kernel_ms": kernel_ms, "kernel_ms_mean": kernel_ms_mean, "kernel_ms_min": float(np.min(ktimes)) if len(ktimes) else None,
+            "timed_launches": int(len(ktimes)), "timing": "HIP events on device 0's launch stream around the kernel; median of the timed launches (device 0's shard)"}
+    if a_char is not None and kernel_ms > 0:
+        a = a_stream + a_char + a_type
+        roof.update({"achieved": a / (kernel_ms * 1e-3) / 1e9, "frac": a / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "algorithmic_bytes_per_launch": a,
+                     "bytes_per_boundary": a / max(sh0["nb"], 1), "a_stream": a_stream, "a_char": a_char, "a_type": a_type})
+    line = {
+        "metric": "boundary scores/sec", "value": total_nb * args.steps / elapsed, "unit": "boundaries/s", "n_gpus": N, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True,
+        "scaling": "strong" if cfg_id == 2 else "weak", "vs_baseline": None, "dtype": "int32", "data": "synthetic",
+        "config": {"workload": "%s: %s model, %d sentences x %d..%d chars, inputs resident in HBM" % (cfg["name"], model_name, S_total, cfg["min_len"], cfg["max_len"]),
+                   "tokenizer_model": model_name, "sentences_per_gpu": sh0["S"], "boundaries_per_gpu": sh0["nb"], "text_bytes_per_gpu": sh0["nbytes"],
+                   "char_ngrams": info["n_char_ngrams"], "dict_words": info["n_dict_words"], "tag_models": info["n_tag_models"],
+                   "table_bytes": info["device_table_bytes"], "hot_table_bytes": info["hot_table_bytes"], "packed_tables": bool(info["packed"]),
+                   "tiles": n_tiles, "create_s": round(create_s, 2), "tables_broadcast_s": round(clone_s, 3), "synth_s": round(synth_s, 2),
+                   "sharding": "contiguous sentence ranges balanced by chars over %d device(s), no data-path collective" % N,
+                   "hip_devices_visible": n_vis, "world_size": N, "collective_backend": None,
+                   "launch": "in-process fallback: one process, vpt_predictor_clone_to_device (hipMemcpyPeer) to %d device(s), one host thread + stream "
+                             "per device (%s)%s" % (N, reason, "; VPT_BENCH_ONE_DEVICE: every shard on device 0" if one_dev else "")},
+        "parity": parity, "roofline": roof, "cpu_baseline": cpu,
+    }
+    print(json.dumps(line))
+    sys.stdout.flush()
+    return 0
+
+
+def main():
+    args = parse_args()
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        raise SystemExit(self_launch(args))
     R = Runner(args)
-    primary_id = args.config or (1 if R.world == 1 else 2)
-    prim = R.run(primary_id, primary=True)
+    primary_id = args.config or 2          # ONE workload over the whole 1 -> 8 curve (module docstring)
+    prim = R.run(primary_id, primary=True, e2e_leg=(primary_id == 1))
     extra = []
     if not args.config and not args.quick and R.world == 1:
-        for cid in (3, 4, 2):
-            extra.append(R.run(cid, primary=False))
+        for cid in (1, 3, 4):
+            extra.append(R.run(cid, primary=False, e2e_leg=(cid == 1)))
     if R.rank == 0:
         line = {
             "metric": "boundary scores/sec", "value": prim["value"], "unit": "boundaries/s", "n_gpus": R.world, "steps": args.steps,
@@ -481,12 +696,16 @@ def main():
         line["config"]["hip_devices_visible"] = R.torch.cuda.device_count()
         line["config"]["world_size"] = R.world
         line["config"]["collective_backend"] = ("RCCL (torch.distributed nccl)" if R.backend == "nccl" else R.backend) if R.world > 1 else None
+        line["config"]["launch"] = os.environ.get("VPT_BENCH_LAUNCH") or ("one process, one GPU" if R.world == 1 else "torch.distributed.run started by the caller")
+        if os.environ.get("VPT_BENCH_ONE_DEVICE") and R.world > 1:
+            line["config"]["launch"] += "; VPT_BENCH_ONE_DEVICE: every rank on device 0"
         for k in ("e2e", "tags", "emit", "phase_share"):
             if k in prim:
                 line[k] = prim[k]
         if extra:
             line["workloads"] = extra
         print(json.dumps(line))
+        sys.stdout.flush()
     if R.world > 1:
         R.dist.barrier()
         R.dist.destroy_process_group()

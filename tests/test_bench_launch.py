@@ -1,0 +1,61 @@
+"""bench.py's launch contract: `python bench.py --gpus N` must never print a line for fewer GPUs than it
+was asked for.  Runs wherever fewer than two HIP devices are visible (this container: none; a 1-GPU box: one)."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _visible() -> int:
+    import torch
+    return torch.cuda.device_count()
+
+
+def _run(args, env=None):
+    e = dict(os.environ)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "VPT_BENCH_ONE_DEVICE", "VPT_BENCH_BACKEND"):
+        e.pop(k, None)
+    e.update(env or {})
+    return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, env=e, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+
+
+def test_more_gpus_than_visible_is_a_loud_error():
+    if _visible() >= 2:
+        pytest.skip("needs a machine with fewer than 2 HIP devices")
+    r = _run(["--gpus", "2", "--quick"])
+    assert r.returncode == 2 and b"HIP device(s) are visible" in r.stderr
+    assert b'"metric"' not in r.stdout                       # no result line at all, in particular none with n_gpus = 1
+
+
+def test_world_size_must_match_gpus():
+    r = _run(["--gpus", "2", "--quick"], {"WORLD_SIZE": "1", "RANK": "0", "LOCAL_RANK": "0"})
+    assert r.returncode == 2 and b"WORLD_SIZE=1" in r.stderr and b'"metric"' not in r.stdout
+    r = _run(["--gpus", "1", "--quick"], {"WORLD_SIZE": "2", "RANK": "0", "LOCAL_RANK": "0"})
+    assert r.returncode == 2 and b"WORLD_SIZE=2" in r.stderr and b'"metric"' not in r.stdout
+
+
+@pytest.mark.gpu
+def test_two_ranks_on_one_device_through_the_self_launch():
+    """The N-rank code path on a 1-GPU box (both ranks on device 0, gloo): bench.py launches its ranks itself, the line says
+    n_gpus = 2 and names the same workload as the 1-rank line; the in-process fallback gives the same shape of line."""
+    env = {"VPT_BENCH_ONE_DEVICE": "1", "VPT_BENCH_BACKEND": "gloo"}
+    common = ["--config", "2", "--sentences", "200000", "--model-scale", "0.05", "--steps", "3", "--warmup", "1", "--no-emit", "--no-e2e"]
+    one = _run(["--gpus", "1"] + common)
+    assert one.returncode == 0, one.stderr[-2000:]
+    l1 = json.loads([l for l in one.stdout.decode().splitlines() if l.startswith("{")][-1])
+    two = _run(["--gpus", "2"] + common, env)
+    assert two.returncode == 0, two.stderr[-2000:]
+    l2 = json.loads([l for l in two.stdout.decode().splitlines() if l.startswith("{")][-1])
+    assert l1["n_gpus"] == 1 and l2["n_gpus"] == 2 and l2["config"]["world_size"] == 2
+    assert l1["config"]["workload"] == l2["config"]["workload"] and l1["scaling"] == l2["scaling"] == "strong"
+    assert l1["parity"] is True and l2["parity"] is True and l2["cpu_baseline"] is not None
+    assert "launched its 2 ranks itself" in l2["config"]["launch"]
+    fb = _run(["--gpus", "2", "--in-process"] + common, env)
+    assert fb.returncode == 0, fb.stderr[-2000:]
+    l3 = json.loads([l for l in fb.stdout.decode().splitlines() if l.startswith("{")][-1])
+    assert l3["n_gpus"] == 2 and l3["parity"] is True and l3["config"]["workload"] == l1["config"]["workload"]
+    assert "in-process fallback" in l3["config"]["launch"]

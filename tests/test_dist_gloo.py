@@ -29,6 +29,7 @@ _lib._lib = emu.load()            # the product's sources on the emulator: this 
 devmem.EMULATED = True
 
 rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+os.environ["VPT_CHUNK_CHARS"] = "4000"                              # the pipelined host path, several chunks per shard (read when a predictor is made)
 dist.init_process_group("gloo", rank=rank, world_size=world)
 m = randmodel.rand_model(31, alphabet="kana", wc=3, wt=3, n_char=150, n_dict=150, max_word=9)
 raw0 = encode_model(m) if rank == 0 else None
@@ -40,7 +41,6 @@ texts = [t if i % 3 else "abc de" * (1 + i % 20) for i, t in enumerate(texts)]  
 utf8, boff = api.pack_texts([t.encode("utf-8") for t in texts])
 ooff = api.count_boundaries(utf8, boff)
 s_utf8, s_boff, s_ooff, first = vdist.take_shard(utf8, boff, ooff, rank, world)
-os.environ["VPT_CHUNK_CHARS"] = "4000"                              # the pipelined host path, several chunks per shard
 scores, labels, got_ooff = pred.predict_packed(s_utf8, s_boff)
 assert np.array_equal(got_ooff, s_ooff)
 el, tot = vdist.reduce_throughput(1.0 + rank, float(len(scores)))
