@@ -239,13 +239,38 @@ vpt_status vpt_fill_tags_batch_flags(const vpt_predictor *p, const uint8_t *utf8
  * (NULL = default stream).  d_labels as written by vpt_predict_batch_device (possibly edited by the caller's own
  * kernels); d_tags_out must hold (total_boundaries + n_sentences) * n_tags int32.  The workspace keeps the decoded
  * scalar values (4 bytes per char) between the two kernels; flags as set by vpt_batch_set_flags (fullwidth only).
- * When the previous call on this workspace was vpt_predict_batch_device for the SAME buffers, sizes, flags and stream (as
- * Sentence::fill_tags follows Predictor::predict on the same sentence, predictor.rs:542), the chars that call decoded are
- * reused and the decode kernel is skipped: do not rewrite d_utf8 in place between the two calls. */
+ * When the call BEFORE this one on this workspace was vpt_predict_batch_device for the SAME buffers, sizes, flags and stream
+ * (as Sentence::fill_tags follows Predictor::predict on the same sentence, predictor.rs:542), the chars that call decoded are
+ * taken over and the decode kernel is skipped: do not rewrite d_utf8 in place between those two calls.  The chars are good
+ * for that one call only: any later fill_tags call decodes the text it is given. */
 vpt_status vpt_fill_tags_batch_device(const vpt_predictor *p, vpt_batch *b, const uint8_t *d_utf8,
                                       const uint64_t *d_byte_offsets, const uint64_t *d_out_offsets,
                                       size_t n_sentences, uint64_t total_boundaries, const uint8_t *d_labels,
                                       int32_t *d_tags_out, void *hip_stream);
+
+/* ---------------------------------------------------------------------------------------------------------
+ * Predictor::store_tag_scores(true) + Token::tag_candidates       (predictor.rs:510-514,599-601,632-634; sentence.rs:1218-1250)
+ *
+ * vpt_fill_tags_batch_flags, and besides the chosen candidates the i32 tag SCORES of every token that has a tag model --
+ * the vector the reference keeps in sentence.tag_scores[i] when store_tag_scores is on: bias + the weights of the tag
+ * n-grams that match around the token, laid out slot after slot over the slots with >= 2 candidates (a slot with one
+ * candidate takes no entries; Token::tag_candidates reports score 0 for it).
+ * vpt_predictor_tag_score_stride: the longest such vector over the predictor's tag models (0: none has scores).
+ * tag_scores_out: int32 [(total boundaries + n_sentences) * stride] or NULL; row of char c of sentence i = out_offsets[i] + i + c;
+ *                 the row of a token's LAST char holds its scores in entries [0, bias.len()); other rows read 0 (host variant)
+ *                 or are left untouched (device variant).
+ * tag_models_out: int32 [total boundaries + n_sentences] or NULL: index, in Model::tag_models order, of the tag model whose
+ *                 token the token ending at that char is (the LAST one of a repeated token, predictor.rs:466-478); -1 where
+ *                 no such token ends.  It says which rows of tag_scores_out are meaningful and whose candidate lists they score. */
+vpt_status vpt_predictor_tag_score_stride(const vpt_predictor *p, uint32_t *stride);
+vpt_status vpt_fill_tags_scores_batch(const vpt_predictor *p, const uint8_t *utf8, const uint64_t *byte_offsets,
+                                      size_t n_sentences, const uint64_t *out_offsets, const uint8_t *labels, unsigned flags,
+                                      int32_t *tags_out, int32_t *tag_scores_out, int32_t *tag_models_out);
+vpt_status vpt_fill_tags_scores_batch_device(const vpt_predictor *p, vpt_batch *b, const uint8_t *d_utf8,
+                                             const uint64_t *d_byte_offsets, const uint64_t *d_out_offsets,
+                                             size_t n_sentences, uint64_t total_boundaries, const uint8_t *d_labels,
+                                             int32_t *d_tags_out, int32_t *d_tag_scores_out, int32_t *d_tag_models_out,
+                                             void *hip_stream);
 
 /* ---------------------------------------------------------------------------------------------------------
  * Sentence::write_tokenized_text over a batch, boundary part                            (sentence.rs:850-886)

@@ -48,6 +48,12 @@ inline void check(vpt_status st) {
                                                  : st == VPT_INVALID_ARGUMENT ? VaporettoError::InvalidArgument : VaporettoError::Device,
                          msg);
 }
+// What a Predictor and the sentences it predicted share: the library handle and the store_tag_scores flag (predictor.rs:436).
+struct Shared {
+    vpt_predictor* raw = nullptr;
+    bool store_tag_scores = false;
+    ~Shared() { if (raw) vpt_predictor_destroy(raw); }
+};
 }  // namespace detail
 
 // sentence.rs:70-82
@@ -114,6 +120,14 @@ public:
     // Candidate indices per (char, slot), -1 = None; an entry is set on a token's LAST char (sentence.rs:1068 holds the strings:
     // the C ABI hands out indices, write_tokenized_text the strings).
     const std::vector<int32_t>& tag_indices() const { return tags_; }
+    // Token::tag_candidates' numbers (sentence.rs:1218-1250) for the token that ENDS at char `c`: the tag model it matched (index
+    // in Model::tag_models order, -1: none) and its score vector, slot after slot over the slots with >= 2 candidates.  Like the
+    // reference this needs Predictor::store_tag_scores(true) before fill_tags (it throws otherwise, where the reference panics).
+    int32_t tag_model(size_t c) const { need_scores(); return tag_models_.at(c); }
+    std::vector<int32_t> tag_scores(size_t c) const {
+        need_scores();
+        return std::vector<int32_t>(tag_scores_.begin() + c * score_stride_, tag_scores_.begin() + (c + 1) * score_stride_);
+    }
     inline void fill_tags();                                                         // sentence.rs:1144-1148
     inline std::string write_tokenized_text() const;                                 // sentence.rs:850-886
 
@@ -137,11 +151,14 @@ public:
 
 private:
     friend class Predictor;
+    void need_scores() const {
+        if (tag_models_.empty()) throw VaporettoError(VaporettoError::InvalidArgument, "Predictor::store_tag_scores() must be set to true to use this function.");
+    }
     void set_default() {                                            // sentence.rs:140-158
         text_ = " ";
         char_types_.assign(1, uint8_t(CharacterType::Other));
         char_pos_ = {0, 1};
-        boundaries_.clear(); scores_.clear(); tags_.clear();
+        boundaries_.clear(); scores_.clear(); tags_.clear(); tag_scores_.clear(); tag_models_.clear();
         n_tags_ = 0; predictor_.reset();
     }
     void parse_raw(const std::string& text) {                       // sentence.rs:160-196
@@ -164,7 +181,7 @@ private:
         char_types_ = std::move(types);
         char_pos_ = std::move(pos);
         boundaries_.assign(char_types_.size() - 1, uint8_t(VPT_BOUNDARY_UNKNOWN));
-        scores_.clear(); tags_.clear();
+        scores_.clear(); tags_.clear(); tag_scores_.clear(); tag_models_.clear();
         n_tags_ = 0; predictor_.reset();
     }
 
@@ -174,20 +191,20 @@ private:
     std::vector<uint8_t> boundaries_;
     std::vector<int32_t> scores_;
     std::vector<int32_t> tags_;
-    uint32_t n_tags_ = 0;
+    std::vector<int32_t> tag_scores_, tag_models_;   // only with store_tag_scores (sentence.rs:96)
+    uint32_t n_tags_ = 0, score_stride_ = 0;
     // predictor.rs:542: the predictor that last predicted this sentence.  The reference ties the two with a lifetime
     // (`Sentence<'_, 'a>` borrows `&'a Predictor`); here the sentence SHARES the library handle, so fill_tags() and
     // write_tokenized_text() stay valid when the Predictor object has been moved from or destroyed in the meantime.
-    std::shared_ptr<vpt_predictor> predictor_;
+    std::shared_ptr<detail::Shared> predictor_;
 };
 
 // predictor.rs:433-665.  Immutable after construction; `predict` takes `&self`, any number of threads may share one.
 class Predictor {
 public:
     Predictor(const Model& model, bool predict_tags, int device_id = 0) : predict_tags_(predict_tags) {   // Predictor::new, predictor.rs:450-508
-        vpt_predictor* h = nullptr;
-        detail::check(vpt_predictor_create(model.to_vec().data(), model.to_vec().size(), predict_tags ? 1 : 0, device_id, &h));
-        raw_ = std::shared_ptr<vpt_predictor>(h, [](vpt_predictor* q) { vpt_predictor_destroy(q); });
+        raw_ = std::make_shared<detail::Shared>();
+        detail::check(vpt_predictor_create(model.to_vec().data(), model.to_vec().size(), predict_tags ? 1 : 0, device_id, &raw_->raw));
     }
     // the handle is reference-counted (sentences that were predicted hold it too): moving is cheap, copying is not offered
     // -- the reference's Predictor is not Clone either
@@ -196,8 +213,9 @@ public:
     Predictor(Predictor&&) noexcept = default;
     Predictor& operator=(Predictor&&) noexcept = default;
 
-    const vpt_predictor* raw() const { return raw_.get(); }
-    uint32_t n_tags() const { uint32_t n = 0; detail::check(vpt_predictor_n_tags(raw_.get(), &n)); return n; }
+    const vpt_predictor* raw() const { return raw_->raw; }
+    uint32_t n_tags() const { uint32_t n = 0; detail::check(vpt_predictor_n_tags(raw_->raw, &n)); return n; }
+    void store_tag_scores(bool flag) { raw_->store_tag_scores = flag; }   // predictor.rs:510-514
 
     // Predictor::predict (predictor.rs:518-543): scores and labels of one sentence.
     void predict(Sentence& s) const {
@@ -205,7 +223,7 @@ public:
         std::vector<int32_t> scores(n > 1 ? n - 1 : 1);
         std::vector<uint8_t> labels(n > 1 ? n - 1 : 1);
         size_t nb = 0;
-        detail::check(vpt_predict_one(raw_.get(), reinterpret_cast<const uint8_t*>(s.text_.data()), s.text_.size(), scores.data(), labels.data(), &nb));
+        detail::check(vpt_predict_one(raw_->raw, reinterpret_cast<const uint8_t*>(s.text_.data()), s.text_.size(), scores.data(), labels.data(), &nb));
         scores.resize(nb); labels.resize(nb);
         s.scores_ = std::move(scores); s.boundaries_ = std::move(labels);
         s.tags_.clear(); s.n_tags_ = 0; s.predictor_ = raw_;
@@ -223,7 +241,7 @@ public:
         }
         std::vector<int32_t> scores(size_t(ooff.back()) + 1);
         std::vector<uint8_t> labels(size_t(ooff.back()) + 1);
-        detail::check(vpt_predict_batch_flags(raw_.get(), reinterpret_cast<const uint8_t*>(text.data()), boff.data(), sentences.size(), scores.data(),
+        detail::check(vpt_predict_batch_flags(raw_->raw, reinterpret_cast<const uint8_t*>(text.data()), boff.data(), sentences.size(), scores.data(),
                                               labels.data(), ooff.data(), flags));
         for (size_t i = 0; i < sentences.size(); ++i) {
             Sentence& s = sentences[i];
@@ -241,10 +259,10 @@ public:
         std::vector<uint64_t> boff(1, 0);
         for (const std::string& l : lines) { text += l; boff.push_back(text.size()); }
         uint32_t sfx = 0;
-        if (tagged) detail::check(vpt_predictor_max_tag_suffix(raw_.get(), &sfx));
+        if (tagged) detail::check(vpt_predictor_max_tag_suffix(raw_->raw, &sfx));
         std::vector<uint8_t> buf(3 * text.size() + text.size() * sfx + 16);
         std::vector<uint64_t> toff(lines.size() + 1);
-        detail::check(vpt_tokenize_batch(raw_.get(), reinterpret_cast<const uint8_t*>(text.data()), boff.data(), lines.size(), flags, tagged ? 1 : 0, buf.data(),
+        detail::check(vpt_tokenize_batch(raw_->raw, reinterpret_cast<const uint8_t*>(text.data()), boff.data(), lines.size(), flags, tagged ? 1 : 0, buf.data(),
                                          buf.size(), toff.data()));
         for (size_t i = 0; i < lines.size(); ++i) out.emplace_back(buf.begin() + toff[i], buf.begin() + toff[i + 1]);
         return out;
@@ -252,17 +270,27 @@ public:
 
 private:
     friend class Sentence;
-    std::shared_ptr<vpt_predictor> raw_;
+    std::shared_ptr<detail::Shared> raw_;
     bool predict_tags_;
 };
 
 inline void Sentence::fill_tags() {
     if (!predictor_) throw VaporettoError(VaporettoError::InvalidArgument, "InvalidArgumentError: sentence: predict() has not been called");
     const uint64_t boff[2] = {0, text_.size()}, ooff[2] = {0, len() - 1};
-    uint32_t nt = 0;
-    detail::check(vpt_predictor_n_tags(predictor_.get(), &nt));
+    uint32_t nt = 0, stride = 0;
+    detail::check(vpt_predictor_n_tags(predictor_->raw, &nt));
     std::vector<int32_t> tags(len() * size_t(nt) + 1);
-    detail::check(vpt_fill_tags_batch(predictor_.get(), reinterpret_cast<const uint8_t*>(text_.data()), boff, 1, ooff, boundaries_.data(), tags.data()));
+    tag_scores_.clear(); tag_models_.clear();
+    if (predictor_->store_tag_scores && nt != 0) {   // predictor.rs:563-566
+        detail::check(vpt_predictor_tag_score_stride(predictor_->raw, &stride));
+        std::vector<int32_t> sc(len() * size_t(stride) + 1), md(len(), -1);
+        detail::check(vpt_fill_tags_scores_batch(predictor_->raw, reinterpret_cast<const uint8_t*>(text_.data()), boff, 1, ooff, boundaries_.data(), 0u,
+                                                 tags.data(), sc.data(), md.data()));
+        sc.resize(len() * size_t(stride));
+        tag_scores_ = std::move(sc); tag_models_ = std::move(md); score_stride_ = stride;
+    } else {
+        detail::check(vpt_fill_tags_batch(predictor_->raw, reinterpret_cast<const uint8_t*>(text_.data()), boff, 1, ooff, boundaries_.data(), tags.data()));
+    }
     tags.resize(len() * size_t(nt));
     tags_ = std::move(tags);
     n_tags_ = nt;
@@ -275,14 +303,14 @@ inline std::string Sentence::write_tokenized_text() const {
     uint64_t toff[2] = {0, 0};
     const bool tagged = n_tags_ != 0 && predictor_ != nullptr;
     uint32_t sfx = 0;
-    if (tagged) detail::check(vpt_predictor_max_tag_suffix(predictor_.get(), &sfx));
+    if (tagged) detail::check(vpt_predictor_max_tag_suffix(predictor_->raw, &sfx));
     std::vector<uint8_t> buf(3 * text_.size() + text_.size() * sfx + 16);
     if (tagged) {
-        detail::check(vpt_write_tagged_batch(predictor_.get(), reinterpret_cast<const uint8_t*>(text_.data()), boff, 1, ooff, boundaries_.data(), 0u,
+        detail::check(vpt_write_tagged_batch(predictor_->raw, reinterpret_cast<const uint8_t*>(text_.data()), boff, 1, ooff, boundaries_.data(), 0u,
                                              buf.data(), buf.size(), toff));
     } else {
         if (!predictor_) throw VaporettoError(VaporettoError::InvalidArgument, "InvalidArgumentError: sentence: predict() has not been called");
-        detail::check(vpt_write_tokenized_batch(predictor_.get(), reinterpret_cast<const uint8_t*>(text_.data()), boff, 1, ooff, boundaries_.data(),
+        detail::check(vpt_write_tokenized_batch(predictor_->raw, reinterpret_cast<const uint8_t*>(text_.data()), boff, 1, ooff, boundaries_.data(),
                                                 buf.data(), buf.size(), toff));
     }
     return std::string(buf.begin(), buf.begin() + toff[1]);

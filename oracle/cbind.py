@@ -37,6 +37,14 @@ def lib():
         L.vo_predict_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p,
                                        C.c_void_p, C.c_int, C.POINTER(C.c_uint64)]
         L.vo_predict_tags.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t, C.c_void_p, C.c_void_p, C.POINTER(C.c_uint32)]
+        L.vo_n_tags.argtypes = [C.c_void_p]
+        L.vo_n_tags.restype = C.c_uint32
+        L.vo_tag_score_stride.argtypes = [C.c_void_p]
+        L.vo_tag_score_stride.restype = C.c_uint32
+        L.vo_fill_tags_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                         C.c_uint32, C.c_void_p, C.c_int]
+        L.vo_write_tokenized_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                               C.c_void_p, C.c_uint64, C.c_void_p, C.c_int]
         L.vo_tag_scores_probe.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t, C.c_int, C.c_uint32, C.c_uint32,
                                           C.c_void_p, C.c_uint32]
         L.vo_char_pattern_count.argtypes = [C.c_void_p]
@@ -113,6 +121,60 @@ class OraclePredictor:
         if st != 0:
             raise OracleError(st, "predict_tags failed")
         return out[:n * nt.value].reshape(n, nt.value) if nt.value else out[:0].reshape(n, 0), nt.value
+
+    def n_tags(self) -> int:
+        return int(lib().vo_n_tags(self._h))
+
+    def tag_score_stride(self) -> int:
+        return int(lib().vo_tag_score_stride(self._h))
+
+    def fill_tags_batch(self, utf8: np.ndarray, byte_offsets: np.ndarray, out_offsets: np.ndarray, labels: np.ndarray, nthreads: int = 1,
+                        want_scores: bool = True):
+        """Sentence::fill_tags over a packed batch on the caller's labels (uint8 per boundary, 0/1/2).  Returns (tags [chars, n_tags],
+        scores [chars, stride] or None, models [chars]): what Predictor::store_tag_scores(true) keeps per token (predictor.rs:599-601)."""
+        S = len(byte_offsets) - 1
+        utf8 = np.ascontiguousarray(utf8, dtype=np.uint8)
+        byte_offsets = np.ascontiguousarray(byte_offsets, dtype=np.uint64)
+        out_offsets = np.ascontiguousarray(out_offsets, dtype=np.uint64)
+        labels = np.ascontiguousarray(labels, dtype=np.uint8)
+        nt, stride = self.n_tags(), self.tag_score_stride()
+        rows = int(out_offsets[S]) + S
+        tags = np.full((rows, max(nt, 1)), -1, dtype=np.int32)
+        scores = np.zeros((rows, max(stride, 1)), dtype=np.int32) if want_scores else None
+        models = np.full(rows, -1, dtype=np.int32)
+        lab = labels if len(labels) else np.zeros(1, dtype=np.uint8)
+        st = lib().vo_fill_tags_batch(self._h, utf8.ctypes.data, byte_offsets.ctypes.data, S, out_offsets.ctypes.data, lab.ctypes.data,
+                                      tags.ctypes.data, scores.ctypes.data if want_scores else None, stride, models.ctypes.data, nthreads)
+        if st != 0:
+            raise OracleError(st, "fill_tags_batch failed")
+        return tags[:, :nt], (scores[:, :stride] if want_scores else None), models
+
+    def write_tokenized_batch(self, utf8: np.ndarray, byte_offsets: np.ndarray, out_offsets: np.ndarray, labels: np.ndarray,
+                              tags: np.ndarray = None, models: np.ndarray = None, nthreads: int = 1):
+        """Sentence::write_tokenized_text (sentence.rs:850-886) for every sentence of a packed batch; with `tags` / `models` (as
+        fill_tags_batch returned them) the "/tag" suffixes too.  Returns (text uint8, text offsets uint64[S+1])."""
+        S = len(byte_offsets) - 1
+        utf8 = np.ascontiguousarray(utf8, dtype=np.uint8)
+        byte_offsets = np.ascontiguousarray(byte_offsets, dtype=np.uint64)
+        out_offsets = np.ascontiguousarray(out_offsets, dtype=np.uint64)
+        labels = np.ascontiguousarray(labels, dtype=np.uint8)
+        lab = labels if len(labels) else np.zeros(1, dtype=np.uint8)
+        toff = np.zeros(S + 1, dtype=np.uint64)
+        if tags is not None:
+            tags = np.ascontiguousarray(tags, dtype=np.int32)
+            models = np.ascontiguousarray(models, dtype=np.int32)
+            assert tags.shape[1] == self.n_tags()
+        # the size first (a capacity of 0 fails after the offsets are complete), then the text
+        lib().vo_write_tokenized_batch(self._h, utf8.ctypes.data, byte_offsets.ctypes.data, S, out_offsets.ctypes.data, lab.ctypes.data,
+                                       tags.ctypes.data if tags is not None else None, models.ctypes.data if tags is not None else None,
+                                       None, 0, toff.ctypes.data, nthreads)
+        out = np.zeros(int(toff[S]) + 1, dtype=np.uint8)
+        st = lib().vo_write_tokenized_batch(self._h, utf8.ctypes.data, byte_offsets.ctypes.data, S, out_offsets.ctypes.data, lab.ctypes.data,
+                                            tags.ctypes.data if tags is not None else None, models.ctypes.data if tags is not None else None,
+                                            out.ctypes.data, int(toff[S]), toff.ctypes.data, nthreads)
+        if st != 0:
+            raise OracleError(st, "write_tokenized_batch failed")
+        return out[:int(toff[S])], toff
 
     def tag_scores_probe(self, text: str, which: int, token_id: int, pos: int, init):
         raw = text.encode("utf-8")

@@ -16,7 +16,9 @@
  *   type cache table      type_scorer/boundary_scorer_cache.rs:22-110
  *   type automaton        type_scorer/boundary_scorer.rs:45-80, boundary_tag_scorer.rs:51-116
  *   predict               predictor.rs:518-543
- *   tag prediction        predictor.rs:264-305,546-637; boundary_tag_scorer.rs add_tag_scores
+ *   tag prediction        predictor.rs:264-305,546-637; boundary_tag_scorer.rs add_tag_scores; the stored scores of
+ *                         Predictor::store_tag_scores (predictor.rs:510-514,599-601) / Token::tag_candidates (sentence.rs:1218-1250)
+ *   tokenized text        Sentence::write_tokenized_text, sentence.rs:850-886 (tokens, escaping, "/tag" up to the last Some)
  *   char classes          sentence.rs:50-67; sentence checks sentence.rs:160-196
  *
  * The pattern matcher `daachorse 1.0.0` (Cargo.toml:17) is a third-party crate that is not in
@@ -145,6 +147,15 @@ static symstr rd_bytes_sym(rd_t *r) { /* Vec<u8> -> symbols */
     return v;
 }
 static void rd_skip_string(rd_t *r) { size_t n = rd_len(r); r->pos += n; }
+static uint8_t *rd_string_raw(rd_t *r, uint32_t *len_out) { /* String -> its UTF-8 bytes (copied) */
+    size_t n = rd_len(r);
+    if (r->bad) { *len_out = 0; return NULL; }
+    uint8_t *q = (uint8_t *)xmalloc(n + 1);
+    memcpy(q, r->p + r->pos, n);
+    r->pos += n;
+    *len_out = (uint32_t)n;
+    return q;
+}
 
 /* ------------------------------------------------------------------------------------------ */
 /* decoded model (model.rs:58-70)                                                             */
@@ -154,6 +165,8 @@ typedef struct { symstr g; uint32_t nw; uint8_t *rel; wvec *w; } tag_ngram_rec;
 typedef struct {
     symstr token;
     uint32_t n_slots; uint32_t *n_cands; /* only the candidate counts matter for scoring */
+    uint32_t *cand_first;                /* per slot: index of its first candidate in cand_str / cand_len (the writer needs the strings) */
+    uint8_t **cand_str; uint32_t *cand_len; uint32_t n_cand_total;
     uint32_t n_char; tag_ngram_rec *chr;
     uint32_t n_type; tag_ngram_rec *typ;
     wvec bias;
@@ -205,9 +218,16 @@ static int model_decode(const uint8_t *buf, size_t len, model_t *m) {
         t->token = rd_string_cp(&r);
         t->n_slots = (uint32_t)rd_len(&r);
         t->n_cands = (uint32_t *)xcalloc(t->n_slots, sizeof(uint32_t));
+        t->cand_first = (uint32_t *)xcalloc(t->n_slots + 1, sizeof(uint32_t));
         for (uint32_t j = 0; j < t->n_slots && !r.bad; j++) {
             t->n_cands[j] = (uint32_t)rd_len(&r);
-            for (uint32_t k = 0; k < t->n_cands[j] && !r.bad; k++) rd_skip_string(&r);
+            t->cand_first[j] = t->n_cand_total;
+            t->cand_str = (uint8_t **)xrealloc(t->cand_str, sizeof(uint8_t *) * (t->n_cand_total + t->n_cands[j] + 1));
+            t->cand_len = (uint32_t *)xrealloc(t->cand_len, sizeof(uint32_t) * (t->n_cand_total + t->n_cands[j] + 1));
+            for (uint32_t k = 0; k < t->n_cands[j] && !r.bad; k++) {
+                t->cand_str[t->n_cand_total] = rd_string_raw(&r, &t->cand_len[t->n_cand_total]);
+                t->n_cand_total++;
+            }
         }
         t->chr = rd_tag_ngrams(&r, &t->n_char, 1);
         t->typ = rd_tag_ngrams(&r, &t->n_type, 0);
@@ -638,6 +658,9 @@ typedef struct vo_predictor {
     scorer_t typ; tcache_t tcache;
     int32_t bias;
     int predict_tags; uint32_t n_tags;
+    /* tag_predictor: HashMap<String, (token id, TagPredictor)> (predictor.rs:466-478): open addressing over the token's
+     * code points; an insert of an equal token replaces the model index, so the LAST model of a repeated token wins */
+    uint32_t *tokmap; uint32_t tokmask; uint32_t max_zlen;
 } vo_predictor;
 
 static uint8_t get_type(uint32_t c) { /* sentence.rs:50-67 */
@@ -652,6 +675,22 @@ static uint8_t get_type(uint32_t c) { /* sentence.rs:50-67 */
 }
 
 void vo_predictor_destroy(vo_predictor *p);
+
+static uint32_t tok_hash(const uint32_t *s, uint32_t n) {
+    uint32_t h = 2166136261u;
+    for (uint32_t i = 0; i < n; i++) { h ^= s[i]; h *= 16777619u; h ^= h >> 15; }
+    return h;
+}
+/* tag_predictor.get(token): index of the tag model whose token is s[0..n), or -1 */
+static long tok_find(const vo_predictor *p, const uint32_t *s, long n) {
+    if (!p->tokmap) return -1;
+    for (uint32_t h = tok_hash(s, (uint32_t)n) & p->tokmask;; h = (h + 1) & p->tokmask) {
+        uint32_t e = p->tokmap[h];
+        if (e == 0) return -1;
+        const symstr *tk = &p->model.tag[e - 1].token;
+        if ((long)tk->len == n && memcmp(tk->s, s, sizeof(uint32_t) * tk->len) == 0) return (long)e - 1;
+    }
+}
 
 int vo_predictor_create(const uint8_t *bytes, size_t len, int predict_tags, vo_predictor **out, char *err, size_t errlen) {
     vo_predictor *p = (vo_predictor *)xcalloc(1, sizeof(vo_predictor));
@@ -713,6 +752,21 @@ int vo_predictor_create(const uint8_t *bytes, size_t len, int predict_tags, vo_p
             p->type_kind = 2;
         }
     }
+    if (n_tagm) {
+        uint32_t cap = 16;
+        while (cap < 2 * n_tagm) cap <<= 1;
+        p->tokmap = (uint32_t *)xcalloc(cap, sizeof(uint32_t));
+        p->tokmask = cap - 1;
+        for (uint32_t t = 0; t < n_tagm; t++) {
+            const symstr *tk = &m->tag[t].token;
+            if (m->tag[t].bias.len > p->max_zlen) p->max_zlen = m->tag[t].bias.len;
+            uint32_t h = tok_hash(tk->s, tk->len) & p->tokmask;
+            for (;; h = (h + 1) & p->tokmask) {
+                uint32_t e = p->tokmap[h];
+                if (e == 0 || (m->tag[e - 1].token.len == tk->len && memcmp(m->tag[e - 1].token.s, tk->s, sizeof(uint32_t) * tk->len) == 0)) { p->tokmap[h] = t + 1; break; }
+            }
+        }
+    }
     *out = p;
     return VO_OK;
 }
@@ -730,7 +784,9 @@ void vo_predictor_destroy(vo_predictor *p) {
     for (uint32_t i = 0; i < m->n_dict; i++) { free_symstr(&m->dict[i].g); free(m->dict[i].w.w); }
     free(m->chr); free(m->typ); free(m->dict);
     for (uint32_t i = 0; i < m->n_tag; i++) {
-        free_symstr(&m->tag[i].token); free(m->tag[i].n_cands);
+        free_symstr(&m->tag[i].token); free(m->tag[i].n_cands); free(m->tag[i].cand_first);
+        for (uint32_t k = 0; k < m->tag[i].n_cand_total; k++) free(m->tag[i].cand_str[k]);
+        free(m->tag[i].cand_str); free(m->tag[i].cand_len);
         free_tag_ngrams(m->tag[i].chr, m->tag[i].n_char); free_tag_ngrams(m->tag[i].typ, m->tag[i].n_type);
         free(m->tag[i].bias.w);
     }
@@ -738,6 +794,7 @@ void vo_predictor_destroy(vo_predictor *p) {
     if (p->has_char) scorer_free(&p->chr);
     if (p->type_kind == 2) scorer_free(&p->typ);
     free(p->tcache.scores);
+    free(p->tokmap);
     free(p);
 }
 
@@ -884,43 +941,33 @@ static void add_tag_scores(const scorer_t *sc, uint32_t token_id, long pos, cons
     }
 }
 
-/* Scores boundaries, then fills tags for the given boundary labels (0/1/2 = Unknown) exactly like
- * `predict` + (caller edits boundaries) + `fill_tags`.  `labels_in` may be NULL: the predicted ones are used.
- * tags_out: n * n_tags int32 entries, candidate index per slot or -1 (None).
- * tag_scores_out (optional): for token_id/pos probes used by the scorer-level KATs. */
-int vo_predict_tags(const vo_predictor *p, const uint8_t *utf8, size_t len, const uint8_t *labels_in,
-                    int32_t *tags_out, uint32_t *n_tags_out) {
-    if (!p->predict_tags) return VO_INVALID_ARGUMENT; /* "this predictor is created with predict_tags = false" */
-    scratch_t s; memset(&s, 0, sizeof(s));
-    scratch_reserve(&s, (long)len + 1);
-    uint8_t *lab = (uint8_t *)xmalloc(len + 1);
-    long n = predict_one(p, utf8, len, &s, NULL, lab, NULL);
-    if (n < 0) { free(lab); scratch_free(&s); return (int)-n; }
-    if (labels_in) memcpy(lab, labels_in, (size_t)(n - 1));
+/* Predictor::predict_tags (predictor.rs:546-637) on a sentence whose pattern states `s` holds (predict_one ran): tags for
+ * the boundary labels `lab` (n - 1 of them; 0/1/2 = Unknown).  tags_out: n * nt candidate indices or -1 (None).  With
+ * store_tag_scores (predictor.rs:510-514): scores_out (n * stride, optional) receives at the LAST char of every token that
+ * has a tag model the score vector the reference keeps in sentence.tag_scores[i] (predictor.rs:599-601,632-634), entries
+ * [0, bias.len()); models_out (n, optional) the index of that tag model in Model::tag_models order, -1 elsewhere. */
+static void fill_tags_one(const vo_predictor *p, const scratch_t *s, long n, const uint8_t *lab, int32_t *tags_out,
+                          int32_t *scores_out, uint32_t stride, int32_t *models_out, int32_t **zbuf, uint32_t *zcap) {
     const model_t *m = &p->model;
-    uint32_t nt = p->n_tags;
-    if (n_tags_out) *n_tags_out = nt;
+    const uint32_t nt = p->n_tags;
     for (long i = 0; i < n * (long)nt; i++) tags_out[i] = -1;
-    if (nt == 0) { free(lab); scratch_free(&s); return VO_OK; }
+    if (models_out) for (long i = 0; i < n; i++) models_out[i] = -1;
+    if (nt == 0) return;
     long start = 0; int have_start = 1;
     for (long i = 0; i < n; i++) {
         int b = i < n - 1 ? lab[i] : 1;
         if (b == 2) { have_start = 0; continue; }
         if (b != 1) continue;
         if (have_start) {
-            /* tag_predictor.get(token): HashMap insert keeps the LAST model of a repeated token */
-            long tm = -1;
-            for (uint32_t t = 0; t < m->n_tag; t++) {
-                const symstr *tk = &m->tag[t].token;
-                if ((long)tk->len == i + 1 - start && memcmp(tk->s, s.cps + start, sizeof(uint32_t) * tk->len) == 0) tm = t;
-            }
+            long tm = tok_find(p, s->cps + start, i + 1 - start);   /* tag_predictor.get(token) */
             if (tm >= 0) {
                 const tag_model_rec *t = &m->tag[tm];
                 uint32_t zlen = t->bias.len;
-                int32_t *z = (int32_t *)xcalloc(zlen + 1, sizeof(int32_t));
+                if (zlen + 1 > *zcap) { *zcap = 2 * (zlen + 1); *zbuf = (int32_t *)xrealloc(*zbuf, sizeof(int32_t) * *zcap); }
+                int32_t *z = *zbuf;
                 memcpy(z, t->bias.w, sizeof(int32_t) * zlen);
-                if (p->has_char) add_tag_scores(&p->chr, (uint32_t)tm, i, s.cstates, n, z, zlen);
-                if (p->type_kind == 2) add_tag_scores(&p->typ, (uint32_t)tm, i, s.tstates, n, z, zlen);
+                if (p->has_char) add_tag_scores(&p->chr, (uint32_t)tm, i, s->cstates, n, z, zlen);
+                if (p->type_kind == 2) add_tag_scores(&p->typ, (uint32_t)tm, i, s->tstates, n, z, zlen);
                 uint32_t off = 0; /* TagPredictor::predict, predictor.rs:286-304 */
                 for (uint32_t j = 0; j < t->n_slots && j < nt; j++) {
                     uint32_t nc = t->n_cands[j];
@@ -930,12 +977,181 @@ int vo_predict_tags(const vo_predictor *p, const uint8_t *utf8, size_t len, cons
                         tags_out[i * nt + j] = (int32_t)idx; off += nc;
                     } else tags_out[i * nt + j] = nc == 1 ? 0 : -1;
                 }
-                free(z);
+                if (scores_out) for (uint32_t k = 0; k < zlen && k < stride; k++) scores_out[i * (long)stride + k] = z[k];
+                if (models_out) models_out[i] = (int32_t)tm;
             }
         }
         start = i + 1; have_start = 1;
     }
-    free(lab); scratch_free(&s);
+}
+
+/* Scores boundaries, then fills tags for the given boundary labels (0/1/2 = Unknown) exactly like
+ * `predict` + (caller edits boundaries) + `fill_tags`.  `labels_in` may be NULL: the predicted ones are used.
+ * tags_out: n * n_tags int32 entries, candidate index per slot or -1 (None). */
+int vo_predict_tags(const vo_predictor *p, const uint8_t *utf8, size_t len, const uint8_t *labels_in,
+                    int32_t *tags_out, uint32_t *n_tags_out) {
+    if (!p->predict_tags) return VO_INVALID_ARGUMENT; /* "this predictor is created with predict_tags = false" */
+    scratch_t s; memset(&s, 0, sizeof(s));
+    scratch_reserve(&s, (long)len + 1);
+    uint8_t *lab = (uint8_t *)xmalloc(len + 1);
+    long n = predict_one(p, utf8, len, &s, NULL, lab, NULL);
+    if (n < 0) { free(lab); scratch_free(&s); return (int)-n; }
+    if (labels_in) memcpy(lab, labels_in, (size_t)(n - 1));
+    if (n_tags_out) *n_tags_out = p->n_tags;
+    int32_t *z = NULL; uint32_t zcap = 0;
+    fill_tags_one(p, &s, n, lab, tags_out, NULL, 0, NULL, &z, &zcap);
+    free(z); free(lab); scratch_free(&s);
+    return VO_OK;
+}
+
+uint32_t vo_n_tags(const vo_predictor *p) { return p->n_tags; }
+uint32_t vo_tag_score_stride(const vo_predictor *p) { return p->max_zlen; }   /* the longest TagPredictor bias */
+
+/* Sentence::fill_tags over a batch (the labels are the caller's: `predict`, possibly post-filtered, then `fill_tags`,
+ * predict/src/main.rs:130-170), on `nthreads` host threads over contiguous sentence shards.  Layouts as the product's:
+ * char c of sentence i is row out_offsets[i] + i + c of tags_out [rows * n_tags], scores_out [rows * stride] (optional),
+ * models_out [rows] (optional). */
+typedef struct {
+    const vo_predictor *p; const uint8_t *utf8; const uint64_t *boff, *ooff; const uint8_t *labels;
+    size_t lo, hi; int32_t *tags, *scores, *models; uint32_t stride; int status;
+} tjob_t;
+static void *tjob_run(void *arg) {
+    tjob_t *j = (tjob_t *)arg;
+    scratch_t s; memset(&s, 0, sizeof(s));
+    int32_t *z = NULL; uint32_t zcap = 0;
+    const uint32_t nt = j->p->n_tags;
+    for (size_t i = j->lo; i < j->hi; i++) {
+        long n = predict_one(j->p, j->utf8 + j->boff[i], (size_t)(j->boff[i + 1] - j->boff[i]), &s, NULL, NULL, NULL);
+        if (n < 0) { j->status = (int)-n; break; }
+        if ((uint64_t)(n - 1) != j->ooff[i + 1] - j->ooff[i]) { j->status = VO_INVALID_ARGUMENT; break; }
+        const uint64_t row = j->ooff[i] + i;
+        fill_tags_one(j->p, &s, n, j->labels + j->ooff[i], j->tags + row * nt, j->scores ? j->scores + row * j->stride : NULL, j->stride,
+                      j->models ? j->models + row : NULL, &z, &zcap);
+    }
+    free(z); scratch_free(&s);
+    return NULL;
+}
+int vo_fill_tags_batch(const vo_predictor *p, const uint8_t *utf8, const uint64_t *byte_offsets, size_t S, const uint64_t *out_offsets,
+                       const uint8_t *labels, int32_t *tags_out, int32_t *scores_out, uint32_t stride, int32_t *models_out, int nthreads) {
+    if (!p->predict_tags) return VO_INVALID_ARGUMENT;
+    if (nthreads < 1) nthreads = 1;
+    if ((size_t)nthreads > S) nthreads = S ? (int)S : 1;
+    tjob_t *jobs = (tjob_t *)xcalloc((size_t)nthreads, sizeof(tjob_t));
+    pthread_t *th = (pthread_t *)xcalloc((size_t)nthreads, sizeof(pthread_t));
+    uint64_t total = S ? byte_offsets[S] - byte_offsets[0] : 0;
+    size_t lo = 0;
+    for (int t = 0; t < nthreads; t++) {
+        size_t hi = lo;
+        uint64_t target = byte_offsets[0] + total * (uint64_t)(t + 1) / (uint64_t)nthreads;
+        if (t == nthreads - 1) hi = S; else while (hi < S && byte_offsets[hi + 1] <= target) hi++;
+        tjob_t *j = &jobs[t];
+        j->p = p; j->utf8 = utf8; j->boff = byte_offsets; j->ooff = out_offsets; j->labels = labels; j->lo = lo; j->hi = hi;
+        j->tags = tags_out; j->scores = scores_out; j->models = models_out; j->stride = stride;
+        lo = hi;
+    }
+    if (nthreads == 1) tjob_run(&jobs[0]);
+    else {
+        for (int t = 0; t < nthreads; t++) pthread_create(&th[t], NULL, tjob_run, &jobs[t]);
+        for (int t = 0; t < nthreads; t++) pthread_join(th[t], NULL);
+    }
+    int status = VO_OK;
+    for (int t = 0; t < nthreads; t++) if (jobs[t].status && !status) status = jobs[t].status;
+    free(jobs); free(th);
+    return status;
+}
+
+/* Sentence::write_tokenized_text (sentence.rs:850-886) for sentence i of a batch: tokens = the runs between WordBoundary
+ * labels, those adjacent to an Unknown label skipped (TokenIterator, sentence.rs:1265-1309); ' ' between tokens; '\\' in
+ * front of ' ', '\\', '/' in surfaces and tags; "/tag" for the token's slots up to the last Some, empty for a None in
+ * between.  tags (may be NULL) / models: rows as vo_fill_tags_batch wrote them.  dst NULL: only the size. */
+static uint64_t put_escaped(uint8_t *dst, uint64_t at, const uint8_t *src, size_t n) {
+    for (size_t k = 0; k < n; k++) {
+        uint8_t b = src[k];
+        if (b == ' ' || b == '\\' || b == '/') { if (dst) dst[at] = '\\'; at++; }
+        if (dst) dst[at] = b;
+        at++;
+    }
+    return at;
+}
+static uint64_t write_one(const vo_predictor *p, const uint8_t *text, size_t len, long n, const uint8_t *lab, const int32_t *tags,
+                          const int32_t *models, uint8_t *dst) {
+    const uint32_t nt = tags ? p->n_tags : 0;
+    uint64_t at = 0;
+    size_t tok_byte = 0, pos = 0;          /* byte where the open token starts; byte of char c */
+    int have_start = 1, first = 1;
+    for (long c = 0; c < n; c++) {
+        size_t nxt = pos + 1;               /* byte after char c */
+        while (nxt < len && (text[nxt] & 0xC0) == 0x80) nxt++;
+        int b = c < n - 1 ? lab[c] : 1;
+        if (b == 2) have_start = 0;
+        else if (b == 1) {
+            if (have_start) {
+                if (!first) { if (dst) dst[at] = ' '; at++; }
+                first = 0;
+                at = put_escaped(dst, at, text + tok_byte, nxt - tok_byte);
+                if (nt && models && models[c] >= 0) {
+                    const tag_model_rec *t = &p->model.tag[models[c]];
+                    long last = -1;
+                    for (uint32_t j = 0; j < nt; j++) if (tags[c * (long)nt + j] >= 0) last = j;
+                    for (long j = 0; j <= last; j++) {
+                        if (dst) dst[at] = '/';
+                        at++;
+                        int32_t idx = tags[c * (long)nt + j];
+                        if (idx >= 0 && (uint32_t)j < t->n_slots && (uint32_t)idx < t->n_cands[j]) {
+                            uint32_t k = t->cand_first[j] + (uint32_t)idx;
+                            at = put_escaped(dst, at, t->cand_str[k], t->cand_len[k]);
+                        }
+                    }
+                }
+            }
+            tok_byte = nxt; have_start = 1;
+        }
+        pos = nxt;
+    }
+    return at;
+}
+typedef struct {
+    const vo_predictor *p; const uint8_t *utf8; const uint64_t *boff, *ooff; const uint8_t *labels; const int32_t *tags, *models;
+    size_t lo, hi; uint8_t *out; uint64_t *toff; int pass;
+} wjob_t;
+static void *wjob_run(void *arg) {
+    wjob_t *j = (wjob_t *)arg;
+    const uint32_t nt = j->p->n_tags;
+    for (size_t i = j->lo; i < j->hi; i++) {
+        const uint64_t row = j->ooff[i] + i;
+        const long n = (long)(j->ooff[i + 1] - j->ooff[i]) + 1;
+        const uint64_t sz = write_one(j->p, j->utf8 + j->boff[i], (size_t)(j->boff[i + 1] - j->boff[i]), n, j->labels + j->ooff[i],
+                                      j->tags ? j->tags + row * nt : NULL, j->models ? j->models + row : NULL, j->pass ? j->out + j->toff[i] : NULL);
+        if (!j->pass) j->toff[i + 1] = sz;
+    }
+    return NULL;
+}
+/* text_offsets_out [S + 1]; returns VO_INVALID_ARGUMENT when `cap` is too small (text_offsets_out is complete even then) */
+int vo_write_tokenized_batch(const vo_predictor *p, const uint8_t *utf8, const uint64_t *byte_offsets, size_t S, const uint64_t *out_offsets,
+                             const uint8_t *labels, const int32_t *tags, const int32_t *models, uint8_t *out, uint64_t cap,
+                             uint64_t *text_offsets_out, int nthreads) {
+    if (nthreads < 1) nthreads = 1;
+    if ((size_t)nthreads > S) nthreads = S ? (int)S : 1;
+    wjob_t *jobs = (wjob_t *)xcalloc((size_t)nthreads, sizeof(wjob_t));
+    pthread_t *th = (pthread_t *)xcalloc((size_t)nthreads, sizeof(pthread_t));
+    text_offsets_out[0] = 0;
+    for (int pass = 0; pass < 2; pass++) {
+        for (int t = 0; t < nthreads; t++) {
+            wjob_t *j = &jobs[t];
+            j->p = p; j->utf8 = utf8; j->boff = byte_offsets; j->ooff = out_offsets; j->labels = labels; j->tags = tags; j->models = models;
+            j->lo = S * (size_t)t / (size_t)nthreads; j->hi = S * (size_t)(t + 1) / (size_t)nthreads; j->out = out; j->toff = text_offsets_out; j->pass = pass;
+        }
+        if (nthreads == 1) wjob_run(&jobs[0]);
+        else {
+            for (int t = 0; t < nthreads; t++) pthread_create(&th[t], NULL, wjob_run, &jobs[t]);
+            for (int t = 0; t < nthreads; t++) pthread_join(th[t], NULL);
+        }
+        if (pass == 0) {
+            for (size_t i = 0; i < S; i++) text_offsets_out[i + 1] += text_offsets_out[i];
+            if (text_offsets_out[S] > cap) { free(jobs); free(th); return VO_INVALID_ARGUMENT; }
+        }
+    }
+    free(jobs); free(th);
     return VO_OK;
 }
 

@@ -137,6 +137,21 @@ TYPE_TAG_TEXT = "この人は火星人だ"
 TYPE_TAG_BOUNDARY_SCORES = [8, 10, 12, 9, 15, 7, 8]
 TYPE_TAG_SCORES = [(0, 2, [27, 29, 31]), (0, 6, [39, 41, 43]), (2, 3, [55, 57])]
 
+def tag_score_kat_through_the_public_path(model: ModelData):
+    """The scorer-level vectors above call add_tag_scores(token_id, pos) directly; through the public path (predict, the caller's
+    labels, fill_tags with store_tag_scores) a token with that tag model must END at char `pos`.  The tag models are renamed to
+    surfaces of the KAT text -- t0 -> "人" (chars 2 and 6), t2 -> "は" (char 3), t1 -> "だ" -- and the labels cut exactly those tokens;
+    scores start from the bias [1, ..], the `[1; 8]` the reference's test starts from, so the stored vectors are the KAT values.
+    Returns (model, labels, {pos: (model index, scores)})."""
+    import copy
+    m = copy.deepcopy(model)
+    for tm, tok in zip(m.tag_models, ["人", "だ", "は"]):
+        tm.token = tok
+    #        こ の 人 は 火 星 人 だ      boundaries after chars 0..6
+    labels = [0, 1, 1, 1, 0, 1, 1]
+    return m, labels
+
+
 # predictor.rs:861-903: tags of "この人は地球人だ" with create_test_model(), n_tags = 2
 PREDICT_TAGS_EXPECTED = [None, None, None, None, "名詞", "ヒト", None, None, None, None,
                          "名詞", "チキュー", "接尾辞", "ジン", None, None]

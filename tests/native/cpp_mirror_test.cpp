@@ -35,7 +35,17 @@ int main(int argc, char** argv) {
             for (uint8_t v : s.boundaries()) std::cout << " " << int(v);
             std::cout << "\ntypes";
             for (uint8_t v : s.char_types()) std::cout << " " << int(v);
-            if (tags) s.fill_tags();
+            if (tags) {
+                predictor.store_tag_scores(true);       // predictor.rs:510-514: fill_tags keeps every token's score vector
+                s.fill_tags();
+                std::cout << "\nstored";
+                for (size_t c = 0; c < s.len(); ++c) {
+                    if (s.tag_model(c) < 0) continue;
+                    std::cout << " " << c << ":" << s.tag_model(c) << ":";
+                    for (int32_t v : s.tag_scores(c)) std::cout << v << ",";
+                }
+                predictor.store_tag_scores(false);
+            }
             std::cout << "\ntext " << s.write_tokenized_text() << "\n";
             batch.push_back(Sentence::from_raw(l));
         }

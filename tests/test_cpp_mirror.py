@@ -35,6 +35,9 @@ def _expected(tags: bool) -> str:
         out.append("labels" + "".join(" %d" % v for v in s.boundaries()))
         out.append("types" + "".join(" %d" % v for v in s.char_types()))
         if tags:
+            utf8, boff = api.pack_texts([l.encode("utf-8")])
+            _, sc, md = pred.fill_tags_scores_packed(utf8, boff, api.count_boundaries(utf8, boff), s.boundaries())
+            out.append("stored" + "".join(" %d:%d:%s" % (c, md[c], "".join("%d," % v for v in sc[c])) for c in range(len(md)) if md[c] >= 0))
             s.fill_tags()
         out.append("text " + s.write_tokenized_text())
     out += ["tokenize " + t for t in pred.tokenize(LINES, tagged=tags)]

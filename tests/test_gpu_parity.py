@@ -578,6 +578,99 @@ def test_random_tag_models_match_oracle(seed):
             assert np.array_equal(got[g0:g0 + len(t)], want), (t, lab[a:b].tolist())
 
 
+@pytest.mark.parametrize("model_fn,text,expected", [(kat.char_tag_test_model, kat.CHAR_TAG_TEXT, kat.CHAR_TAG_SCORES),
+                                                   (kat.type_tag_test_model, kat.TYPE_TAG_TEXT, kat.TYPE_TAG_SCORES)], ids=["char_scorer.rs:508-524", "type_scorer.rs:456-472"])
+def test_stored_tag_scores_reproduce_the_scorer_kats(model_fn, text, expected):
+    """Predictor::store_tag_scores(true) (predictor.rs:510-514) on the HIP path: the reference's scorer-level tag vectors
+    ([37,39,41], [28,29,30], [59,61] / [27,29,31], [39,41,43], [55,57]) are the STORED scores of tokens ending at those chars,
+    and Token::tag_candidates (sentence.rs:1218-1250) pairs them with the candidates."""
+    m, labels = kat.tag_score_kat_through_the_public_path(model_fn())
+    model, _ = api.Model.read_slice(encode_model(m))
+    pred = api.Predictor(model, True)
+    assert pred.tag_score_stride() == 3
+    utf8, boff = api.pack_texts([text.encode("utf-8")])
+    ooff = api.count_boundaries(utf8, boff)
+    tags, scores, models = pred.fill_tags_scores_packed(utf8, boff, ooff, np.array(labels, dtype=np.uint8))
+    for token_id, pos, want in expected:
+        assert models[pos] == token_id and scores[pos, :len(want)].tolist() == want, (token_id, pos)
+    assert models.tolist() == [-1, -1, 0, 2, -1, -1, 0, 1]
+    assert not scores[[0, 1, 4, 5, 7]].any() and tags[7].tolist() == [0]
+    # the crate's surface: store_tag_scores -> predict -> (edit boundaries) -> fill_tags -> Token::tag_candidates
+    pred.store_tag_scores(True)
+    s = api.Sentence.from_raw(text)
+    pred.predict(s)
+    s.boundaries_mut()[:] = labels
+    s.fill_tags()
+    by_end = {t.end() - 1: t for t in s.tokens()}
+    for token_id, pos, want in expected:
+        cands = m.tag_models[token_id].tags[0]
+        assert by_end[pos].tag_candidates() == [list(zip(cands, want))], pos
+        assert by_end[pos].tags() == [cands[int(np.argmax(want))]]
+    assert by_end[7].tag_candidates() == [[("a", 0)]] and by_end[7].surface() == "だ"      # one candidate: score 0 (sentence.rs:1233-1235)
+    assert by_end[1].tag_candidates() == [] and by_end[1].tags() == [None]
+    pred.store_tag_scores(False)
+    s.fill_tags()
+    with pytest.raises(AssertionError, match="store_tag_scores"):
+        s.tokens()[0].tag_candidates()
+
+
+@pytest.mark.parametrize("seed", [0, 1, 2])
+def test_stored_tag_scores_match_oracle_on_random_models(seed):
+    """Tags, the stored score vectors and the tag model of every token against the oracle's batch fill_tags -- predicted and edited
+    labels (Unknown included), models inside and outside the kernel's record form (more than 16 scores), device-resident too."""
+    from vaporetto_amd.modelfmt import TagModel
+    import random
+    m = randmodel.rand_model(870 + seed, alphabet="tiny" if seed % 2 else "kana", n_tag_models=30, max_word=4, n_char=50, n_dict=40)
+    rng = random.Random(seed)
+    big = m.tag_models[3]
+    big.tags = [["t%d" % k for k in range(11)], ["u%d" % k for k in range(9)], ["solo"]]      # 20 scores: the whole-wave routine
+    big.bias = [rng.randint(-500, 500) for _ in range(20)]
+    for ng in big.char_ngram_model + big.type_ngram_model:
+        for tw in ng.weights:
+            tw.weights = [rng.randint(-900, 900) for _ in range(20)]
+    m.tag_models.append(TagModel(m.tag_models[5].token, [["late", "later"]], bias=[7, -7]))   # a repeated token: the last model wins
+    raw = encode_model(m)
+    pred, orc = api.Predictor(api.Model.read_slice(raw)[0], True), cbind.OraclePredictor(raw, True)
+    assert pred.tag_score_stride() == orc.tag_score_stride() == 20
+    texts = randmodel.rand_sentences(seed, m, 250, alphabet="tiny" if seed % 2 else "kana", max_len=60)
+    texts += [t.token * 3 for t in m.tag_models] + [big.token + m.tag_models[5].token + big.token] + [t.token for t in m.tag_models]
+    utf8, boff = api.pack_texts([t.encode("utf-8") for t in texts])
+    _, labels, ooff = pred.predict_packed(utf8, boff)
+    nrng = np.random.RandomState(seed)
+    for edit in (0, 1, 2):
+        lab = labels.copy()
+        if edit == 1:
+            k = nrng.randint(0, len(lab), size=len(lab) // 9)
+            lab[k] = nrng.randint(0, 3, size=len(k))
+        elif edit == 2:
+            lab[:] = 0        # every sentence one token: the sentences that ARE a model's token get that model
+        tags, scores, models = pred.fill_tags_scores_packed(utf8, boff, ooff, lab)
+        o_tags, o_scores, o_models = orc.fill_tags_batch(utf8, boff, ooff, lab, nthreads=2)
+        assert np.array_equal(models, o_models) and np.array_equal(tags, o_tags)
+        bad = np.nonzero((scores != o_scores).any(axis=1))[0]
+        assert len(bad) == 0, (int(bad[0]), int(models[bad[0]]), scores[bad[0]].tolist(), o_scores[bad[0]].tolist())
+        assert not (models == 5).any()
+        if edit == 2:
+            assert (models == 3).any() and (models == len(m.tag_models) - 1).any()
+    # device-resident: predict -> fill_tags with scores on one stream; rows without a model are left untouched
+    nb, S, nt, stride = int(ooff[-1]), len(texts), pred.n_tags(), pred.tag_score_stride()
+    d_text = devmem.put(np.concatenate([utf8, np.zeros(16, np.uint8)])); d_boff = devmem.put(boff.astype(np.uint64)); d_ooff = devmem.put(ooff.astype(np.uint64))
+    d_scores, d_labels, d_tags = devmem.zeros(nb + 1, np.int32), devmem.zeros(nb + 1, np.uint8), devmem.zeros((nb + S) * nt + 1, np.int32)
+    d_ts, d_tm = devmem.put(np.full((nb + S) * stride + 1, 12345, np.int32)), devmem.zeros(nb + S + 1, np.int32)
+    batch = api.DeviceBatch(pred)
+    batch.predict(d_text.ptr, d_boff.ptr, d_ooff.ptr, S, nb, int(np.max(np.diff(boff.astype(np.int64)))), d_scores.ptr, d_labels.ptr, devmem.stream())
+    batch.fill_tags_scores(d_text.ptr, d_boff.ptr, d_ooff.ptr, S, nb, d_labels.ptr, d_tags.ptr, d_ts.ptr, d_tm.ptr, devmem.stream())
+    batch.sync()
+    o_tags, o_scores, o_models = orc.fill_tags_batch(utf8, boff, ooff, labels)
+    got_m, got_s = d_tm.get(nb + S), d_ts.get((nb + S) * stride).reshape(nb + S, stride)
+    assert np.array_equal(got_m, o_models) and np.array_equal(d_tags.get((nb + S) * nt).reshape(nb + S, nt), o_tags)
+    lens = np.array([len(t.bias) for t in m.tag_models])
+    for r in np.nonzero(o_models >= 0)[0]:
+        n = lens[o_models[r]]
+        assert got_s[r, :n].tolist() == o_scores[r, :n].tolist() and (got_s[r, n:] == 12345).all()
+    assert (got_s[o_models < 0] == 12345).all()
+
+
 def test_tag_models_inside_and_outside_the_record_form():
     """The tag kernel's fast path checks whole n-grams from 32-byte records (<= 12 BMP symbols, <= 16 scores per model);
     models outside that form -- an n-gram of 14 chars, a non-BMP n-gram, 24 scores -- take the whole-wave routine.  Both kinds

@@ -118,6 +118,81 @@ def test_fixture_tags(fixture, text, expected):
     assert " ".join(out) == expected
 
 
+@pytest.mark.parametrize("which,model_fn,text,expected", [(0, kat.char_tag_test_model, kat.CHAR_TAG_TEXT, kat.CHAR_TAG_SCORES),
+                                                         (1, kat.type_tag_test_model, kat.TYPE_TAG_TEXT, kat.TYPE_TAG_SCORES)])
+def test_stored_tag_scores_reproduce_the_scorer_kats(which, model_fn, text, expected):
+    """Predictor::store_tag_scores (predictor.rs:510-514,599-601) through the batch entry point: the vectors of
+    char_scorer.rs:508-524 / type_scorer.rs:456-472 as the STORED scores of tokens that end at those chars."""
+    m, labels = kat.tag_score_kat_through_the_public_path(model_fn())
+    p = cbind.OraclePredictor(encode_model(m), predict_tags=True)
+    utf8, boff = np.frombuffer(text.encode("utf-8"), dtype=np.uint8), np.array([0, len(text.encode("utf-8"))], dtype=np.uint64)
+    ooff = np.array([0, len(text) - 1], dtype=np.uint64)
+    tags, scores, models = p.fill_tags_batch(utf8, boff, ooff, np.array(labels, dtype=np.uint8))
+    assert p.tag_score_stride() == 3
+    for token_id, pos, want in expected:
+        assert models[pos] == token_id and scores[pos, :len(want)].tolist() == want, (token_id, pos)
+    assert models.tolist() == [-1, -1, 0, 2, -1, -1, 0, 1]      # "だ" carries t1: one candidate, no scores
+    assert tags[7].tolist() == [0] and scores[7].tolist() == [0, 0, 0]
+
+
+def test_fill_tags_batch_equals_sentence_by_sentence():
+    from tests import randmodel
+    m = randmodel.rand_model(4, alphabet="kana", wc=3, wt=3, n_tag_models=40, max_word=3, n_char=80, n_dict=80)
+    raw = encode_model(m)
+    p = cbind.OraclePredictor(raw, predict_tags=True)
+    texts = randmodel.rand_sentences(5, m, 300, alphabet="kana", max_len=40) + [t.token * 3 for t in m.tag_models]
+    utf8 = np.frombuffer("".join(texts).encode("utf-8"), dtype=np.uint8)
+    boff = np.concatenate([[0], np.cumsum([len(t.encode("utf-8")) for t in texts])]).astype(np.uint64)
+    _, labels, ooff, _ = p.predict_batch(utf8, boff)
+    tags, scores, models = p.fill_tags_batch(utf8, boff, ooff, labels, nthreads=3)
+    assert (models >= 0).sum() > 50
+    for i, t in enumerate(texts):
+        a = int(ooff[i])
+        want, nt = p.predict_tags(t, labels=labels[a:a + len(t) - 1])
+        assert np.array_equal(tags[a + i:a + i + len(t)], want)
+    # the models named are the LAST of a repeated token, and rows without a model hold no scores
+    toks = [tm.token for tm in m.tag_models]
+    for r in np.nonzero(models >= 0)[0][:200]:
+        assert toks.index(toks[models[r]], models[r]) == len(toks) - 1 - toks[::-1].index(toks[models[r]])
+    assert not scores[models < 0].any()
+
+
+@pytest.mark.parametrize("fixture,text,expected", kat.FIXTURE_TAGGED)
+def test_tokenized_text_writer_on_the_fixtures(fixture, text, expected):
+    """Sentence::write_tokenized_text (sentence.rs:850-886) restated: lib.rs:25-41 / resources/docs.tok."""
+    raw, _ = kat.load_fixture(fixture)
+    p = cbind.OraclePredictor(raw, predict_tags=True)
+    utf8, boff = np.frombuffer(text.encode("utf-8"), dtype=np.uint8), np.array([0, len(text.encode("utf-8"))], dtype=np.uint64)
+    _, labels, ooff, _ = p.predict_batch(utf8, boff)
+    tags, _, models = p.fill_tags_batch(utf8, boff, ooff, labels)
+    out, toff = p.write_tokenized_batch(utf8, boff, ooff, labels, tags, models)
+    assert bytes(out).decode("utf-8") == expected and toff.tolist() == [0, len(expected.encode("utf-8"))]
+    plain, _ = p.write_tokenized_batch(utf8, boff, ooff, labels)
+    assert bytes(plain).decode("utf-8") == " ".join(tok.split("/")[0] for tok in expected.split(" "))
+
+
+def test_tokenized_text_writer_escapes_and_skips_like_the_reference():
+    """sentence.rs:828-848 (doc-test): tokens adjacent to an Unknown boundary are skipped; ' ', '\\' and '/' get a '\\' in surfaces and tags;
+    a None between two Some tags is an empty field, trailing Nones are dropped (sentence.rs:866-881)."""
+    from vaporetto_amd.modelfmt import ModelData, TagModel
+    m = ModelData(bias=5, char_window_size=3, type_window_size=3)
+    m.char_ngram_model.append(kat._n("あ", [0, 0, 0, 1, 0, 0]))
+    m.tag_models = [TagModel("a/b", [["x y", "q"], [], ["z\\w"]], bias=[3, 1]), TagModel("c", [[], ["only"]], bias=[]), TagModel("d e", [[]], bias=[])]
+    p = cbind.OraclePredictor(encode_model(m), predict_tags=True)
+    text = "a/bcd ef"
+    utf8, boff = np.frombuffer(text.encode("utf-8"), dtype=np.uint8), np.array([0, len(text)], dtype=np.uint64)
+    ooff = np.array([0, len(text) - 1], dtype=np.uint64)
+    #         a / b | c | d ' ' e | f
+    labels = np.array([0, 0, 1, 1, 0, 0, 1], dtype=np.uint8)
+    tags, _, models = p.fill_tags_batch(utf8, boff, ooff, labels)
+    out, _ = p.write_tokenized_batch(utf8, boff, ooff, labels, tags, models)
+    assert bytes(out).decode("utf-8") == "a\\/b/x\\ y//z\\\\w c//only d\\ e f"
+    labels[3] = 2     # Unknown between "c" and "d e": both tokens are skipped
+    tags, _, models = p.fill_tags_batch(utf8, boff, ooff, labels)
+    out, _ = p.write_tokenized_batch(utf8, boff, ooff, labels, tags, models)
+    assert bytes(out).decode("utf-8") == "a\\/b/x\\ y//z\\\\w f"
+
+
 @pytest.mark.parametrize("fixture,text,expected", kat.APPENDIX_SCORES)
 def test_appendix_scores(fixture, text, expected):
     raw, _ = kat.load_fixture(fixture)

@@ -58,6 +58,9 @@ SIGNATURES = {
     "vpt_char_types_batch_device": (C.c_int, [_P, _P, _P, _P, _P, C.c_size_t, C.c_uint64, _P, _P]),
     "vpt_predictor_n_tags": (C.c_int, [_P, C.POINTER(C.c_uint32)]),
     "vpt_fill_tags_batch": (C.c_int, [_P, _P, _P, C.c_size_t, _P, _P, _P]),
+    "vpt_predictor_tag_score_stride": (C.c_int, [_P, C.POINTER(C.c_uint32)]),
+    "vpt_fill_tags_scores_batch": (C.c_int, [_P, _P, _P, C.c_size_t, _P, _P, C.c_uint, _P, _P, _P]),
+    "vpt_fill_tags_scores_batch_device": (C.c_int, [_P, _P, _P, _P, _P, C.c_size_t, C.c_uint64, _P, _P, _P, _P, _P]),
     "vpt_fill_tags_batch_flags": (C.c_int, [_P, _P, _P, C.c_size_t, _P, _P, _P, C.c_uint]),
     "vpt_batch_set_flags": (C.c_int, [_P, C.c_uint]),
     "vpt_write_tokenized_batch": (C.c_int, [_P, _P, _P, C.c_size_t, _P, _P, _P, C.c_uint64, _P]),

@@ -155,6 +155,44 @@ class Model:
         return self._data.tag_models
 
 
+class Token:
+    """sentence.rs:1195-1263: a token of a Sentence, chars [start, end)."""
+
+    def __init__(self, sentence: "Sentence", start: int, end: int):
+        self._s, self._start, self._end = sentence, start, end
+
+    def surface(self) -> str:
+        return self._s._text[self._start:self._end]
+
+    def tags(self) -> List[Optional[str]]:  # sentence.rs:1210-1214
+        nt = self._s._n_tags
+        return list(self._s._tags[(self._end - 1) * nt:self._end * nt])
+
+    def tag_candidates(self) -> List[List[Tuple[str, int]]]:  # sentence.rs:1216-1250
+        """Per tag slot the candidates with their scores (score 0 for the only candidate of a slot).  Like the reference this
+        requires Predictor.store_tag_scores(True) before fill_tags."""
+        if not self._s._tag_scores:
+            raise AssertionError("Predictor::store_tag_scores() must be set to true to use this function.")
+        entry = self._s._tag_scores[self._end - 1]
+        results = []
+        if entry is not None:
+            tags, scores = entry
+            i = 0
+            for cands in tags:
+                if len(cands) == 1:
+                    results.append([(cands[0], 0)])
+                else:
+                    results.append([(c, scores[i + k]) for k, c in enumerate(cands)])
+                    i += len(cands)
+        return results
+
+    def start(self) -> int:
+        return self._start
+
+    def end(self) -> int:
+        return self._end
+
+
 class Sentence:
     """sentence.rs:85-101 (raw-text path).  Holds the text, its character types, and after `predict`
     the boundary scores and labels."""
@@ -172,6 +210,7 @@ class Sentence:
         self._predictor = None
         self._tags = []
         self._n_tags = 0
+        self._tag_scores = []
 
     @staticmethod
     def default() -> "Sentence":
@@ -192,6 +231,7 @@ class Sentence:
         self._predictor = None
         self._tags = []
         self._n_tags = 0
+        self._tag_scores = []
 
     @staticmethod
     def from_raw(text: str) -> "Sentence":  # sentence.rs:217-245
@@ -262,6 +302,9 @@ class Sentence:
         for a, e in self._token_ranges():
             yield self._text[a:e + 1]
 
+    def tokens(self) -> List["Token"]:  # sentence.rs:819: the Token objects of iter_tokens (surface, tags, tag_candidates, start, end)
+        return [Token(self, a, e + 1) for a, e in self._token_ranges()]
+
     def write_tokenized_text(self) -> str:  # sentence.rs:850-886
         def esc(tok):
             return "".join("\\" + c if c in " \\/" else c for c in tok)
@@ -285,6 +328,7 @@ class Predictor:
         self._model = model
         self._predict_tags = bool(predict_tags)
         self._tag_models = None
+        self._store_tag_scores = False
         self._h = C.c_void_p()
         st = _lib.load().vpt_predictor_create(raw, len(raw), int(predict_tags), device, C.byref(self._h))
         if st != _lib.VPT_OK:
@@ -307,9 +351,46 @@ class Predictor:
         self._h = handle
         self._model = model
         self._tag_models = None
+        self._store_tag_scores = False
         self.device = device
         self._predict_tags = bool(self.info()["predict_tags"])
         return self
+
+    def store_tag_scores(self, flag: bool) -> None:  # predictor.rs:510-514
+        """Stores tag scores if `flag` is true: fill_tags then keeps every token's score vector for Token.tag_candidates."""
+        self._store_tag_scores = bool(flag)
+
+    def tag_score_stride(self) -> int:
+        """vpt_predictor_tag_score_stride: the longest score vector (TagPredictor bias) over the tag models."""
+        v = C.c_uint32()
+        st = _lib.load().vpt_predictor_tag_score_stride(self._h, C.byref(v))
+        if st != _lib.VPT_OK:
+            _raise(st)
+        return v.value
+
+    def fill_tags_scores_packed(self, utf8: np.ndarray, byte_offsets: np.ndarray, out_offsets: np.ndarray, labels: np.ndarray,
+                                fullwidth: bool = False):
+        """fill_tags_packed plus what Predictor::store_tag_scores(true) keeps (predictor.rs:599-601): returns (tags, scores, models)
+        -- tags int32 [chars, n_tags]; scores int32 [chars, stride]: at a token's last char its score vector in entries
+        [0, bias.len()), zeros elsewhere; models int32 [chars]: index into Model.tag_models() of the token's tag model or -1."""
+        L = _lib.load()
+        utf8 = np.ascontiguousarray(utf8, dtype=np.uint8)
+        byte_offsets = np.ascontiguousarray(byte_offsets, dtype=np.uint64)
+        out_offsets = np.ascontiguousarray(out_offsets, dtype=np.uint64)
+        labels = np.ascontiguousarray(labels, dtype=np.uint8)
+        S = len(byte_offsets) - 1
+        nt = self.n_tags() if self._predict_tags else 0
+        stride = self.tag_score_stride() if self._predict_tags else 0
+        total_c = int(out_offsets[S]) + S
+        tags = np.full((total_c, max(nt, 1)), -1, dtype=np.int32)
+        scores = np.zeros((total_c, max(stride, 1)), dtype=np.int32)
+        models = np.full(total_c, -1, dtype=np.int32)
+        lab = labels if len(labels) else np.zeros(1, dtype=np.uint8)
+        st = L.vpt_fill_tags_scores_batch(self._h, utf8.ctypes.data, byte_offsets.ctypes.data, S, out_offsets.ctypes.data, lab.ctypes.data,
+                                          _lib.VPT_FLAG_KYTEA_FULLWIDTH if fullwidth else 0, tags.ctypes.data, scores.ctypes.data, models.ctypes.data)
+        if st != _lib.VPT_OK:
+            _raise(st)
+        return tags[:, :nt], scores[:, :stride], models
 
     def save_compiled(self) -> bytes:
         """Predictor::serialize_to_vec (predictor.rs:640-651), in this library's own format: the device tables + a header."""
@@ -520,8 +601,13 @@ class Predictor:
         ooff = np.zeros(len(sentences) + 1, dtype=np.uint64)
         ooff[1:] = np.cumsum([len(s) - 1 for s in sentences])
         labels = np.concatenate([np.asarray(s._boundaries, dtype=np.uint8) for s in sentences]) if int(ooff[-1]) else np.zeros(0, np.uint8)
-        tags = self.fill_tags_packed(utf8, boff, ooff, labels)
+        scores = models = None
+        if self._store_tag_scores:
+            tags, scores, models = self.fill_tags_scores_packed(utf8, boff, ooff, labels)
+        else:
+            tags = self.fill_tags_packed(utf8, boff, ooff, labels)
         nt = tags.shape[1]
+        tag_model_list = self._model.tag_models() if scores is not None else None
         if self._tag_models is None:
             self._tag_models = {tm.token: tm for tm in self._model.tag_models()}
         for i, s in enumerate(sentences):
@@ -529,6 +615,14 @@ class Predictor:
             n = len(s)
             s._n_tags = nt
             s._tags = [None] * (n * nt)
+            s._tag_scores = []   # sentence.rs:96: Vec<Option<(&[Vec<String>], Vec<i32>)>>, empty unless store_tag_scores
+            if scores is not None and nt:
+                s._tag_scores = [None] * n
+                for e in range(n):
+                    mi = int(models[g0 + e])
+                    if mi >= 0:
+                        tm_ = tag_model_list[mi]
+                        s._tag_scores[e] = (tm_.tags, scores[g0 + e, :len(tm_.bias)].tolist())
             if nt == 0:
                 continue
             start, valid = 0, True
@@ -682,6 +776,15 @@ class DeviceBatch:
         """Device-resident Sentence::fill_tags for the batch (vpt_fill_tags_batch_device); enqueues and returns."""
         st = _lib.load().vpt_fill_tags_batch_device(self._p.handle, self._h, d_utf8, d_boff, d_ooff, n_sentences,
                                                     total_boundaries, d_labels, d_tags, stream)
+        if st != _lib.VPT_OK:
+            _raise(st)
+
+    def fill_tags_scores(self, d_utf8: int, d_boff: int, d_ooff: int, n_sentences: int, total_boundaries: int, d_labels: int,
+                         d_tags: int, d_tag_scores: int, d_tag_models: int, stream: int = 0) -> None:
+        """fill_tags plus Predictor::store_tag_scores' score vectors and every token's tag model (vpt_fill_tags_scores_batch_device);
+        d_tag_scores / d_tag_models may be 0 (NULL)."""
+        st = _lib.load().vpt_fill_tags_scores_batch_device(self._p.handle, self._h, d_utf8, d_boff, d_ooff, n_sentences, total_boundaries,
+                                                           d_labels, d_tags, d_tag_scores or None, d_tag_models or None, stream)
         if st != _lib.VPT_OK:
             _raise(st)
 

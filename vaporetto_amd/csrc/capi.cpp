@@ -102,7 +102,7 @@ struct PredictorMeta {                                      // plain data: writt
     uint64_t meta_checksum;                                 // of this block with both checksum fields zero
     uint64_t sec_off[kSectionCount], sec_bytes[kSectionCount];
     int32_t bias, pad, type_kind, type_window, chunks;
-    uint32_t predict_tags, has_tags, n_tags, tok_bits, max_tag_suffix, tag_use_char, tag_use_type, n_tag_models, n_tag_strings;
+    uint32_t predict_tags, has_tags, n_tags, tok_bits, max_tag_suffix, tag_use_char, tag_use_type, n_tag_models, n_tag_strings, max_tag_scores;
     TableGeom geom[2];                                      // chars, types
     uint32_t pk_present, pk_n_uni, pk_n_tri, pk_bi_shift, pk_has_trow;
     vpt_model_info info;
@@ -156,7 +156,7 @@ const char* validate_meta(const PredictorMeta& m) {
         if (m.sec_off[kSecPCpid] + sz(kSecPCpid) - m.sec_off[kSecPUni] >= (1ull << 32)) return "packed tables (32-bit offsets)";
     }
     if (m.has_tags) {
-        if (m.n_tags == 0 || m.n_tags > 4096 || m.tok_bits < 2 || m.tok_bits > 30) return "tag tables";
+        if (m.n_tags == 0 || m.n_tags > 4096 || m.tok_bits < 2 || m.tok_bits > 30 || m.max_tag_scores > vpt::kTagMaxZ) return "tag tables";
         if (sz(kSecTagTokTab) < (16ull << m.tok_bits) || sz(kSecTagModels) < 48ull * m.n_tag_models || sz(kSecTagMfilt) < 4ull * vpt::kTagFiltStride * m.n_tag_models) return "tag tables (sections)";
         if (sz(kSecTagStrOff) < 4ull * (uint64_t(m.n_tag_strings) + 1)) return "tag strings";
     } else if (m.predict_tags > 1) return "predict_tags";
@@ -222,6 +222,8 @@ struct vpt_batch {
     uint64_t *d_boff = nullptr, *d_ooff = nullptr; size_t off_cap = 0;
     int32_t* d_scores = nullptr; uint8_t* d_labels = nullptr; size_t out_cap = 0;
     int32_t* d_tags = nullptr; size_t tags_cap = 0;                 // vpt_fill_tags_batch
+    int32_t* d_tag_scores = nullptr; size_t tag_scores_cap = 0;     // vpt_fill_tags_scores_batch
+    int32_t* d_tag_models = nullptr; size_t tag_models_cap = 0;
     uint8_t* d_tok = nullptr; size_t tok_cap = 0;                   // vpt_write_tokenized_batch
     uint8_t* d_tlab = nullptr; size_t tlab_cap = 0;                 // vpt_tokenize_batch: the labels of the whole batch (no scores are kept)
     uint64_t* d_toff = nullptr; size_t toff_cap = 0;
@@ -259,7 +261,7 @@ struct vpt_predictor {
     // what the launches use, bound from meta + arena (bind_predictor)
     bool predict_tags = false;
     bool has_tags = false;
-    uint32_t n_tags = 0, tok_bits = 0, max_tag_suffix = 0;
+    uint32_t n_tags = 0, tok_bits = 0, max_tag_suffix = 0, max_tag_scores = 0;
     bool tag_use_char = false, tag_use_type = false;
     DeviceTags dtag;
     vpt_model_info info{};
@@ -299,7 +301,7 @@ void batch_release(vpt_batch* b) {
     (void)hipFree(b->d_tile_first); (void)hipFree(b->d_slow_list); (void)hipFree(b->d_ctrl); (void)hipFree(b->d_scratch);
     (void)hipFree(b->d_prof); (void)hipFree(b->d_cps);
     (void)hipFree(b->d_text); (void)hipFree(b->d_boff); (void)hipFree(b->d_ooff); (void)hipFree(b->d_scores); (void)hipFree(b->d_labels);
-    (void)hipFree(b->d_tags); (void)hipFree(b->d_tok); (void)hipFree(b->d_tlab); (void)hipFree(b->d_toff); (void)hipFree(b->d_tok_model);
+    (void)hipFree(b->d_tags); (void)hipFree(b->d_tag_scores); (void)hipFree(b->d_tag_models); (void)hipFree(b->d_tok); (void)hipFree(b->d_tlab); (void)hipFree(b->d_toff); (void)hipFree(b->d_tok_model);
     (void)hipFree(b->d_types);
     for (auto& ps : b->pipe) {
         (void)hipFree(ps.text); (void)hipFree(ps.off); (void)hipFree(ps.scores); (void)hipFree(ps.labels);
@@ -492,7 +494,7 @@ void bind_predictor(vpt_predictor* p) {
     p->d_cinfo = reinterpret_cast<const uint32_t*>(at(kSecCinfo));
     p->d_cid = m.sec_bytes[kSecCid] ? reinterpret_cast<const uint32_t*>(at(kSecCid)) : nullptr;
     p->predict_tags = m.predict_tags != 0; p->has_tags = m.has_tags != 0;
-    p->n_tags = m.n_tags; p->tok_bits = m.tok_bits; p->max_tag_suffix = m.max_tag_suffix;
+    p->n_tags = m.n_tags; p->tok_bits = m.tok_bits; p->max_tag_suffix = m.max_tag_suffix; p->max_tag_scores = m.max_tag_scores;
     p->tag_use_char = m.tag_use_char != 0; p->tag_use_type = m.tag_use_type != 0;
     if (m.has_tags) {
         p->dtag.tok_tab = reinterpret_cast<const uint32_t*>(at(kSecTagTokTab)); p->dtag.models = reinterpret_cast<const uint32_t*>(at(kSecTagModels));
@@ -620,7 +622,7 @@ vpt_status vpt_predictor_create(const uint8_t* model_bytes, size_t len, int pred
     if (c.tags.present) {
         m.has_tags = 1; m.n_tags = c.tags.n_tags; m.tok_bits = c.tags.tok_bits;
         m.tag_use_char = c.tags.use_char; m.tag_use_type = c.tags.use_type;
-        m.n_tag_models = c.tags.n_models; m.n_tag_strings = uint32_t(c.tags.str_off.size() - 1);
+        m.n_tag_models = c.tags.n_models; m.n_tag_strings = uint32_t(c.tags.str_off.size() - 1); m.max_tag_scores = c.tags.max_zlen;
         for (uint32_t mi = 0; mi < c.tags.n_models; ++mi) {   // the longest "/tag/tag.." a token can get
             const uint32_t* mr = &c.tags.models[size_t(mi) * 12];
             uint32_t worst = 0;
@@ -1262,6 +1264,12 @@ vpt_status vpt_predictor_max_tag_suffix(const vpt_predictor* p, uint32_t* n_byte
     return VPT_OK;
 }
 
+vpt_status vpt_predictor_tag_score_stride(const vpt_predictor* p, uint32_t* stride) {
+    if (!p || !stride) return fail(VPT_INVALID_ARGUMENT, "InvalidArgumentError: NULL argument");
+    *stride = p->max_tag_scores;
+    return VPT_OK;
+}
+
 vpt_status vpt_fill_tags_batch(const vpt_predictor* p, const uint8_t* utf8, const uint64_t* byte_offsets, size_t n_sentences,
                                const uint64_t* out_offsets, const uint8_t* labels, int32_t* tags_out) {
     return vpt_fill_tags_batch_flags(p, utf8, byte_offsets, n_sentences, out_offsets, labels, tags_out, 0u);
@@ -1269,6 +1277,12 @@ vpt_status vpt_fill_tags_batch(const vpt_predictor* p, const uint8_t* utf8, cons
 
 vpt_status vpt_fill_tags_batch_flags(const vpt_predictor* p, const uint8_t* utf8, const uint64_t* byte_offsets, size_t n_sentences,
                                      const uint64_t* out_offsets, const uint8_t* labels, int32_t* tags_out, unsigned flags) {
+    return vpt_fill_tags_scores_batch(p, utf8, byte_offsets, n_sentences, out_offsets, labels, flags, tags_out, nullptr, nullptr);
+}
+
+vpt_status vpt_fill_tags_scores_batch(const vpt_predictor* p, const uint8_t* utf8, const uint64_t* byte_offsets, size_t n_sentences,
+                                      const uint64_t* out_offsets, const uint8_t* labels, unsigned flags, int32_t* tags_out,
+                                      int32_t* tag_scores_out, int32_t* tag_models_out) {
     if (flags & ~unsigned(VPT_FLAG_KYTEA_FULLWIDTH)) return fail(VPT_INVALID_ARGUMENT, "InvalidArgumentError: flags: unknown bit");
     if (!p) return fail(VPT_INVALID_ARGUMENT, "InvalidArgumentError: predictor: must not be NULL");
     if (!p->predict_tags) return fail(VPT_INVALID_ARGUMENT, "InvalidArgumentError: this predictor is created with predict_tags = false");
@@ -1282,19 +1296,35 @@ vpt_status vpt_fill_tags_batch_flags(const vpt_predictor* p, const uint8_t* utf8
     vpt_batch* b = w.b;
     uint64_t total_b = 0;
     if ((st = stage(b, utf8, byte_offsets, out_offsets, n_sentences, labels, &total_b, nullptr, nullptr)) != VPT_OK) return st;
-    const size_t n_tag_words = size_t(total_b + n_sentences) * p->n_tags;
+    const size_t n_rows = size_t(total_b + n_sentences), n_tag_words = n_rows * p->n_tags, n_score_words = n_rows * p->max_tag_scores;
     if ((st = grow(&b->d_tags, &b->tags_cap, n_tag_words + 16)) != VPT_OK) return st;
+    if (tag_scores_out && (st = grow(&b->d_tag_scores, &b->tag_scores_cap, n_score_words + 16)) != VPT_OK) return st;
+    if (tag_models_out && (st = grow(&b->d_tag_models, &b->tag_models_cap, n_rows + 16)) != VPT_OK) return st;
+    // rows that end no token with a tag model are not written by the kernel: they read 0 (the reference holds None there)
+    if (tag_scores_out && n_score_words) VPT_HIP(hipMemsetAsync(b->d_tag_scores, 0, n_score_words * sizeof(int32_t), b->own_stream));
     b->flags = flags;
-    st = vpt_fill_tags_batch_device(p, b, b->d_text, b->d_boff, b->d_ooff, n_sentences, total_b, b->d_labels, b->d_tags, b->own_stream);
+    st = vpt_fill_tags_scores_batch_device(p, b, b->d_text, b->d_boff, b->d_ooff, n_sentences, total_b, b->d_labels, b->d_tags,
+                                           tag_scores_out ? b->d_tag_scores : nullptr, tag_models_out ? b->d_tag_models : nullptr, b->own_stream);
     if (st != VPT_OK) return st;
     if ((st = vpt_batch_sync(b)) != VPT_OK) return st;
-    VPT_HIP(hipMemcpy(tags_out + size_t(out_offsets[0]) * p->n_tags, b->d_tags, n_tag_words * sizeof(int32_t), hipMemcpyDeviceToHost));
+    const size_t row0 = size_t(out_offsets[0]);   // (the caller's rows start at out_offsets[0] + 0)
+    VPT_HIP(hipMemcpy(tags_out + row0 * p->n_tags, b->d_tags, n_tag_words * sizeof(int32_t), hipMemcpyDeviceToHost));
+    if (tag_scores_out && n_score_words) VPT_HIP(hipMemcpy(tag_scores_out + row0 * p->max_tag_scores, b->d_tag_scores, n_score_words * sizeof(int32_t), hipMemcpyDeviceToHost));
+    if (tag_models_out) VPT_HIP(hipMemcpy(tag_models_out + row0, b->d_tag_models, n_rows * sizeof(int32_t), hipMemcpyDeviceToHost));
     return VPT_OK;
 }
 
 vpt_status vpt_fill_tags_batch_device(const vpt_predictor* p, vpt_batch* b, const uint8_t* d_utf8, const uint64_t* d_byte_offsets,
                                       const uint64_t* d_out_offsets, size_t n_sentences, uint64_t total_boundaries,
                                       const uint8_t* d_labels, int32_t* d_tags_out, void* hip_stream) {
+    return vpt_fill_tags_scores_batch_device(p, b, d_utf8, d_byte_offsets, d_out_offsets, n_sentences, total_boundaries, d_labels, d_tags_out,
+                                             nullptr, nullptr, hip_stream);
+}
+
+vpt_status vpt_fill_tags_scores_batch_device(const vpt_predictor* p, vpt_batch* b, const uint8_t* d_utf8, const uint64_t* d_byte_offsets,
+                                             const uint64_t* d_out_offsets, size_t n_sentences, uint64_t total_boundaries,
+                                             const uint8_t* d_labels, int32_t* d_tags_out, int32_t* d_tag_scores_out,
+                                             int32_t* d_tag_models_out, void* hip_stream) {
     if (!p || !b || b->pred != p) return fail(VPT_INVALID_ARGUMENT, "InvalidArgumentError: batch: does not belong to this predictor");
     if (!p->predict_tags) return fail(VPT_INVALID_ARGUMENT, "InvalidArgumentError: this predictor is created with predict_tags = false");
     if (n_sentences == 0 || p->n_tags == 0) return VPT_OK;
@@ -1320,6 +1350,7 @@ vpt_status vpt_fill_tags_batch_device(const vpt_predictor* p, vpt_batch* b, cons
     T.use_char = p->tag_use_char ? 1u : 0u; T.use_type = p->tag_use_type ? 1u : 0u;
     T.cps = b->d_cps; T.ooff = d_out_offsets; T.labels = d_labels; T.n_sent = n_sentences; T.total_chars = total_c; T.tags = d_tags_out;
     T.tok_model = b->d_tok_model;
+    T.scores_out = p->max_tag_scores ? d_tag_scores_out : nullptr; T.model_out = d_tag_models_out; T.score_stride = p->max_tag_scores;
     // tag_tokens_kernel runs 8 workgroups per CU at a time; four generations of them stride over the batch, so that the
     // sentences' lengths (8..512 chars in BASELINE's configs[4]) even out without one workgroup per four sentences
     // (measured on configs[4], 300 K sentences: 65536 workgroups 1.09 ms, 8 per CU 0.67, 32 per CU 0.64)

@@ -82,6 +82,11 @@ struct TagParams {
     uint64_t total_chars;       // total boundaries + S: what `cps` and `tags / n_tags` hold
     int32_t* tok_model;         // [total chars] or nullptr: tag model index + 1 of the token ending at the char (token emission)
     int32_t* tags;              // [(total boundaries + S) * n_tags] candidate index per slot, -1 = None
+    // Predictor::store_tag_scores (predictor.rs:510-514): optional outputs, both indexed by char like `tags`
+    int32_t* scores_out;        // [(total boundaries + S) * score_stride] or nullptr: at the last char of a token with a tag model, entries
+                                // [0, bias.len()) = the scores the reference keeps in sentence.tag_scores[i] (predictor.rs:599-601)
+    int32_t* model_out;         // [total boundaries + S] or nullptr: index of that tag model (Model::tag_models order), -1 elsewhere
+    uint32_t score_stride;
     uint32_t max_blocks;        // workgroups the device runs at a time (0: one wave per sentence up to 65536 workgroups)
 };
 hipError_t launch_decode_chars(const uint8_t* text, const uint64_t* boff, const uint64_t* ooff, uint64_t n_sent, uint64_t total_chars,

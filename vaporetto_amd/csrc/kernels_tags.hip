@@ -182,6 +182,9 @@ __device__ __forceinline__ void tag_token_by_wave(const TagParams& P, const uint
         }
     }
     __builtin_amdgcn_wave_barrier();
+    if (P.scores_out) {   // Predictor::store_tag_scores: the token's whole score vector (predictor.rs:599-601)
+        for (uint32_t i = lane; i < zlen && i < P.score_stride; i += 64) P.scores_out[(g0 + uint64_t(e)) * P.score_stride + i] = z[i];
+    }
     const uint32_t n_slots = mr[9] < P.n_tags ? mr[9] : P.n_tags;
     for (uint32_t j = lane; j < P.n_tags; j += 64) {   // the slots past the model's own are None
         const uint32_t cnt = j < n_slots ? P.slots[size_t(mr[8] + j) * 2] : 0u, off = j < n_slots ? P.slots[size_t(mr[8] + j) * 2 + 1] : 0u;
@@ -333,6 +336,16 @@ __device__ __forceinline__ void tag_pass(const TagParams& P, TagWaveLds& L, uint
     }
     if (n_acc != 0 && !(dbg & 8u)) tag_add_matches(P, L, n_acc, lane);
     __builtin_amdgcn_wave_barrier();
+    if (P.scores_out) {   // wave-uniform.  Predictor::store_tag_scores: lanes over (token, score), 4 tokens per 64 lanes
+#pragma unroll
+        for (int q0 = 0; q0 < kTagPass * kTagFastZ / 64; ++q0) {
+            const uint32_t t = uint32_t(q0) * 4u + (uint32_t(lane) >> 4), i = uint32_t(lane) & 15u;
+            if (t < nq && i < (L.f.tok[t][5] & 0xFFu) && i < P.score_stride) {
+                const uint64_t gp = uint64_t(L.f.tok[t][1]) | (uint64_t(L.f.tok[t][2]) << 32);
+                P.scores_out[gp * P.score_stride + i] = L.f.zt[t][i];
+            }
+        }
+    }
     // argmax per (token, slot) (TagPredictor::predict, predictor.rs:286-304)
     for (uint32_t a0 = 0; a0 < ((dbg & 16u) ? 0u : nq * nt); a0 += 64) {
         const uint32_t a = a0 + uint32_t(lane);
@@ -407,6 +420,7 @@ __global__ __launch_bounds__(kTagThreads, 8) void tag_tokens_kernel(const TagPar
             // tag model ends, the rest from the argmax of the token's scores
             if (p < n) {
                 if (P.tok_model) P.tok_model[g0 + uint64_t(p)] = int32_t(model);   // 0: no tag model for this surface
+                if (P.model_out) P.model_out[g0 + uint64_t(p)] = int32_t(model) - 1;
                 if (model == 0) for (uint32_t j = 0; j < nt; ++j) P.tags[(g0 + uint64_t(p)) * nt + j] = -1;
             }
             if (dbg & 64u) model = 0;
