@@ -291,7 +291,7 @@ class Runner:
                          "kernels": "decode_chars_kernel + tag_tokens_kernel on the predicted labels"}
 
         # ---- token emission on the labels just predicted (Sentence::write_tokenized_text, with "/tag" suffixes for tag models)
-        emit_info = None
+        emit_info, emit_out = None, None
         if not args.no_emit:
             cap = 3 * nbytes + 64 + ((nbytes * pred.max_tag_suffix()) if nt else 0)
             d_out = torch.empty(cap + 1, dtype=torch.uint8, device=dev)
@@ -319,26 +319,12 @@ class Runner:
             moved = nbytes + nb + out_bytes + 16 * S + (4 * (nb + S) * (nt + 1) if nt else 0)   # text + labels (+ tags, token models) in, text + offsets out
             emit_info = {"ms_per_step": 1e3 * dt, "out_bytes": out_bytes, "algorithmic_GBps": moved / dt / 1e9, "frac_of_hbm": moved / dt / 1e9 / HBM_PEAK_GBS,
                          "kernels": "count + prefix sum + write (kernels_emit.hip), %s" % ("tagged" if nt else "boundaries only")}
-            # a sample against the writer restated on the host (sentence.rs:850-886; boundaries only)
-            if not nt:
-                lab_h = d_labels[:nb].cpu().numpy()
-                out_h = d_out[:out_bytes].cpu().numpy().tobytes()
-                text_b = utf8.tobytes()
-                ok_e = True
-                for i in range(0, S, max(1, S // 200)):
-                    tx = text_b[int(boff[i]):int(boff[i + 1])].decode("utf-8")
-                    lab = lab_h[int(ooff[i]):int(ooff[i + 1])]
-                    toks, cur = [], []
-                    for k_, ch in enumerate(tx):
-                        cur.append("\\" + ch if ch in " \\/" else ch)
-                        if k_ == len(tx) - 1 or lab[k_] == 1:
-                            toks.append("".join(cur)); cur = []
-                    ok_e = ok_e and out_h[int(toff[i]):int(toff[i + 1])].decode("utf-8") == " ".join(toks)
-                emit_info["parity_sample"] = bool(ok_e)
+            # the whole output is compared with the oracle's writer below (sentence.rs:850-886 restated in oracle/vaporetto_oracle.c)
+            emit_out = (d_out[:out_bytes].cpu().numpy(), toff) if not args.no_cpu_baseline else None
             del d_out, d_toff
 
         # ---- parity against the oracle (this rank's whole shard, bit for bit) and the algorithmic bytes it counts
-        a_char, parity, cpu = None, None, None
+        a_char, parity, cpu, mismatch = None, None, None, None
         if not args.no_cpu_baseline:
             from oracle import cbind
             orc = cbind.OraclePredictor(raw, cfg["tags"])
@@ -370,19 +356,52 @@ class Runner:
                 o_scores, o_labels, _, a_char = orc.predict_batch(utf8, boff, nthreads=self.ncores)
             g_scores = d_scores[:nb].cpu().numpy()
             g_labels = d_labels[:nb].cpu().numpy()
+            mismatch = None     # where the first difference is, not only that there is one
+
+            def first_diff(kind, got, want, rows_are_chars=False):
+                bad = np.flatnonzero(got != want)
+                if not len(bad):
+                    return None
+                k = int(bad[0])
+                if rows_are_chars:   # row of char c of sentence i = ooff[i] + i + c
+                    i = int(np.searchsorted(ooff + np.arange(S + 1, dtype=np.uint64), k, side="right") - 1)
+                else:
+                    i = int(np.searchsorted(ooff, k, side="right") - 1)
+                tx = bytes(utf8[int(boff[i]):int(boff[i + 1])]).decode("utf-8", "replace")
+                return {"what": kind, "index": k, "sentence": first + i, "text": tx[:80], "gpu": int(got[k]), "oracle": int(want[k]), "differing": int(len(bad))}
             ok = bool(np.array_equal(g_scores, o_scores) and np.array_equal(g_labels, o_labels))
-            if nt:
+            if not ok:
+                mismatch = first_diff("boundary score", g_scores, o_scores) or first_diff("label", g_labels, o_labels)
+            o_tags = o_models = None
+            if nt:   # EVERY token of the shard: Sentence::fill_tags on the labels the GPU predicted (they are the oracle's: checked above)
                 got = d_tags[:(nb + S) * nt].cpu().numpy().reshape(nb + S, nt)
-                text = bytes(utf8)
-                tag_ok = True
-                for i in range(0, S, max(1, S // 300)):    # a 300-sentence sample of the tags against the oracle
-                    tx = text[int(boff[i]):int(boff[i + 1])].decode("utf-8")
-                    a = int(ooff[i])
-                    want, _ = orc.predict_tags(tx, labels=g_labels[a:a + len(tx) - 1])
-                    tag_ok = tag_ok and bool(np.array_equal(got[a + i:a + i + len(tx)], want))
-                tags_info["parity_sample"] = tag_ok
+                o_tags, _, o_models = orc.fill_tags_batch(utf8, boff, ooff, g_labels, nthreads=self.ncores, want_scores=False)
+                tag_ok = bool(np.array_equal(got, o_tags))
+                if not tag_ok and mismatch is None:
+                    mismatch = first_diff("tags of the token ending at this char (1 = some slot differs)", (got != o_tags).any(axis=1).astype(np.int8),
+                                          np.zeros(nb + S, np.int8), rows_are_chars=True)
+                tags_info["parity"] = tag_ok
+                tags_info["tokens_checked"] = int((g_labels == 1).sum()) + S
+                tags_info["tokens_with_a_tag_model"] = int((o_models >= 0).sum())
                 ok = ok and tag_ok
+                del got
+            if emit_out is not None:   # the writer's whole output, byte for byte
+                o_text, o_toff = orc.write_tokenized_batch(utf8, boff, ooff, g_labels, o_tags, o_models, nthreads=self.ncores)
+                e_ok = bool(np.array_equal(emit_out[1], o_toff) and np.array_equal(emit_out[0], o_text))
+                if not e_ok and mismatch is None:
+                    bad = np.flatnonzero(emit_out[1] != o_toff)
+                    i = max(int(bad[0]) - 1, 0) if len(bad) else int(np.searchsorted(o_toff, np.flatnonzero(emit_out[0] != o_text)[0], side="right") - 1)
+                    mismatch = {"what": "tokenized text", "sentence": first + i,
+                                "gpu": bytes(emit_out[0][int(emit_out[1][i]):int(emit_out[1][min(i + 1, S)])]).decode("utf-8", "replace")[:120],
+                                "oracle": bytes(o_text[int(o_toff[i]):int(o_toff[i + 1])]).decode("utf-8", "replace")[:120]}
+                emit_info["parity"] = e_ok
+                emit_info["bytes_checked"] = int(len(o_text))
+                ok = ok and e_ok
+                emit_out = None
+            del o_tags, o_models
             parity = self.all_true(ok)
+            if mismatch is not None:
+                sys.stderr.write("bench.py: PARITY MISMATCH on rank %d: %s\n" % (self.rank, json.dumps(mismatch, ensure_ascii=False)))
         del d_tags
 
         # ---- end to end over PCIe: pinned caller buffers through the pipelined host path (N = 1, primary only)
@@ -468,6 +487,10 @@ class Runner:
                          "a_stream": a_stream, "a_char": a_char, "a_type": a_type})
         out["roofline"] = roof
         out["parity"] = parity
+        if not args.no_cpu_baseline:
+            out["parity_covers"] = "every i32 score and label of the shard%s%s" % (", every token's tags" if nt else "", ", the writer's whole output" if emit_info is not None else "")
+            if mismatch is not None:
+                out["first_mismatch"] = mismatch
         if tags_info is not None:
             out["tags"] = tags_info
         if e2e is not None:

@@ -409,7 +409,8 @@ __global__ __launch_bounds__(kThreads, WG) void score_tiles_fast_kernel(const Sc
             const uint32_t cp = xs[k] & 0x1FFFFFu, idx = cp < 0x10000u ? cp : 0u;
             // id of the char it is scored as | CharacterType << 16 | linebreak << 19: one word of a 256 KB table (plain, or --
             // with VPT_FLAG_KYTEA_FULLWIDTH -- the one that looks through KyteaFullwidthFilter)
-            info[k] = P.cid[idx];
+            if (DBG && (P.debug & 64u)) info[k] = (cp & 7u) == 0 ? P.cid[idx] : ((cp * 2654435761u) >> 20) | (3u << 16);   // timing ablation: one gather in eight
+            else info[k] = P.cid[idx];
         }
 #pragma unroll
         for (int k = 0; k < kPerThread; ++k) {
@@ -465,7 +466,8 @@ __global__ __launch_bounds__(kThreads, WG) void score_tiles_fast_kernel(const Sc
         if (do_u) {
             x1 = L.sym[s_u]; x2 = L.sym[s_u + 1]; x3 = L.sym[s_u + 2];   // the array is zero past the tile; s_u + 2 < kFastCap + kMargin
             const uint32_t id1 = x1 & kCpMask;
-            u = ld16(K.base, K.off_uni + (((P.debug & 4u) ? 0u : (id1 < uni_last ? id1 : uni_last)) << 4));
+            if (DBG && (P.debug & 128u)) { if ((id1 & 3u) == 0) u = ld16(K.base, K.off_uni + ((id1 < uni_last ? id1 : uni_last) << 4)); }   // timing ablation: one unigram node in four
+            else u = ld16(K.base, K.off_uni + (((P.debug & 4u) ? 0u : (id1 < uni_last ? id1 : uni_last)) << 4));
         }
         // ---- trigram stage of positions s_t: the node is ours if it names our bigram node as its parent
         if (do_t) {
