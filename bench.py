@@ -10,10 +10,11 @@ The workloads are BASELINE.json's configs:
                                                                    -- the line's `value` at EVERY N, N = 1 included
   configs[3]  jp-0.4.7-5-shaped model (synthetic M2, dictionary heavy), 100 K x 64
   configs[4]  M1 + tag models (synthetic M3), predict_tags on, 1 M sentences of 8..512 chars / N, step = predict + fill_tags
+  documents   (not a BASELINE config) M1, 10 K sentences of 2 000..20 000 chars: every sentence is cut across many tiles
 
 ONE workload over the whole 1 -> 8 curve: with no --config the `value` is configs[2] at every N (the north-star's "10 M-sentence
 synthetic batch"; it fits one GPU), so that a scaling curve built from the per-N values compares like with like.  N = 1 also
-folds configs[1], [3] and [4] into `workloads`, each with its own parity, kernel time and roofline (configs[1] carries the
+folds configs[1], [3], [4] and the documents workload into `workloads`, each with its own parity, kernel time and roofline (configs[1] carries the
 PCIe end-to-end figures).  (--quick: the primary workload only.)
 
     python bench.py --gpus N --steps 20 --warmup 3        # N > 1 without WORLD_SIZE: launches its N ranks itself (below)
@@ -50,6 +51,9 @@ CONFIGS = {
     2: dict(name="configs[2]", kind=1, sentences=10_000_000, min_len=64, max_len=64, tags=False, blocks=True),
     3: dict(name="configs[3]", kind=2, sentences=100_000, min_len=64, max_len=64, tags=False, blocks=False),
     4: dict(name="configs[4]", kind=3, sentences=1_000_000, min_len=8, max_len=512, tags=True, blocks=True),
+    # not a BASELINE config: whole documents as ONE sentence each, what the reference's tantivy adapter feeds Predictor::predict
+    # (vaporetto_tantivy/src/lib.rs:171-176) -- every sentence spans many tiles
+    5: dict(name="documents", kind=1, sentences=10_000, min_len=2_000, max_len=20_000, tags=False, blocks=False),
 }
 BLOCK = 100_000
 
@@ -272,6 +276,7 @@ class Runner:
         batch.sync()
         ktimes = batch.kernel_times()
         kernel_ms_mean, n_tiles = batch.kernel_ms()
+        plan = batch.last_plan()
         kernel_ms = float(np.median(ktimes)) if len(ktimes) else kernel_ms_mean
         phases = batch.phase_cycles() if args.phases else None
         elapsed, total_boundaries = vdist.reduce_throughput(elapsed, float(nb), device=dev)
@@ -466,12 +471,12 @@ class Runner:
             "tokenizer_model": model_name, "sentences_per_gpu": S, "boundaries_per_gpu": nb, "text_bytes_per_gpu": nbytes,
             "char_ngrams": info["n_char_ngrams"], "dict_words": info["n_dict_words"], "tag_models": info["n_tag_models"],
             "table_bytes": info["device_table_bytes"], "hot_table_bytes": info["hot_table_bytes"],
-            "packed_tables": bool(info["packed"]), "tiles": n_tiles,
+            "packed_tables": bool(info["packed"]), "tiles": n_tiles, "tile_plan": "%s of %d flat positions" % (plan["kind"], plan["tile_flat"]),
             "create_s": round(create_s, 2), "tables_broadcast_s": round(bcast_s, 3) if self.world > 1 else None, "synth_s": round(synth_s, 2),
         }
         if phases is not None:
-            tot = float(sum(phases[:5])) or 1.0
-            out["phase_share"] = dict(zip(["scan", "decode", "patterns", "barrier", "output"], [round(p / tot, 4) for p in phases[:5]]))
+            tot = float(sum(phases[:7])) or 1.0
+            out["phase_share"] = dict(zip(["stage", "sentence_starts", "scan_decode", "classify", "patterns", "barrier", "output"], [round(p / tot, 4) for p in phases[:7]]))
         # roofline of the dominant kernel: algorithmic bytes per launch / its duration
         a_stream = nbytes + 5 * nb + 16 * S   # text + i32 score + u8 label per boundary + two u64 offsets per sentence
         a_type = 4 * nb                        # one type-window table word per boundary (the reference's cache form)
@@ -507,7 +512,7 @@ def parse_args(argv=None):
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--config", type=int, default=0, choices=[0, 1, 2, 3, 4],
+    ap.add_argument("--config", type=int, default=0, choices=[0, 1, 2, 3, 4, 5],
                     help="BASELINE.json configs index (0: configs[2] as the value at every N, plus -- at N = 1 -- the others as `workloads`)")
     ap.add_argument("--quick", action="store_true", help="the primary workload only")
     ap.add_argument("--sentences", type=int, default=0, help="override the config's sentence count (diagnostics; traffic is then not reported)")
@@ -703,7 +708,7 @@ def main():
     prim = R.run(primary_id, primary=True, e2e_leg=(primary_id == 1))
     extra = []
     if not args.config and not args.quick and R.world == 1:
-        for cid in (1, 3, 4):
+        for cid in (1, 3, 4, 5):
             extra.append(R.run(cid, primary=False, e2e_leg=(cid == 1)))
     if R.rank == 0:
         line = {
@@ -711,7 +716,7 @@ def main():
             "warmup": args.warmup, "ms_per_step": prim["ms_per_step"], "higher_is_better": True,
             "scaling": "strong" if primary_id == 2 else "weak", "vs_baseline": None, "dtype": "int32", "data": "synthetic",
             "config": {k: prim[k] for k in ("workload", "tokenizer_model", "sentences_per_gpu", "boundaries_per_gpu", "text_bytes_per_gpu", "char_ngrams",
-                                            "dict_words", "tag_models", "table_bytes", "hot_table_bytes", "packed_tables", "tiles", "create_s",
+                                            "dict_words", "tag_models", "table_bytes", "hot_table_bytes", "packed_tables", "tiles", "tile_plan", "create_s",
                                             "tables_broadcast_s", "synth_s")},
             "parity": prim["parity"], "roofline": prim["roofline"], "cpu_baseline": prim.get("cpu_baseline"),
         }

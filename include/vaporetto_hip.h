@@ -206,6 +206,10 @@ vpt_status vpt_batch_sync(vpt_batch *b);
  * on the launch stream; after vpt_batch_sync, vpt_batch_kernel_ms returns that kernel's AVERAGE duration (ms)
  * over the calls made since the previous vpt_batch_kernel_ms (at most the 256 most recent) and the number of
  * workgroups (tiles) of the last call. */
+/* How the last vpt_predict_batch_device call on this workspace cut its batch (diagnostics): the number of tiles, the flat
+ * positions (chars + separators) a tile covers, and the kind -- 1 whole-sentence tiles, 2 tiles cut at any position with a halo
+ * (batches with sentences too long for a tile), 0 the general kernels (models outside the packed shape). */
+vpt_status vpt_batch_last_plan(const vpt_batch *b, uint32_t *n_tiles, uint32_t *tile_flat, uint32_t *kind);
 vpt_status vpt_batch_set_timing(vpt_batch *b, int enabled);
 vpt_status vpt_batch_kernel_ms(vpt_batch *b, float *score_kernel_ms, uint32_t *n_tiles);
 /* The individual durations (ms, oldest first) of the timed calls since the previous vpt_batch_kernel_ms, at most `capacity`

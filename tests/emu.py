@@ -11,7 +11,9 @@ from vaporetto_amd import _lib, build
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 EMU = os.path.join(HERE, "native", "hipemu")
-LIB = os.path.join(HERE, "native", "libvaporetto_emu.so")
+# VPT_EMU_DEFINES="-DVPT_FAST_STAGED=1 ..." builds (and loads) another geometry of the kernels into a library of its own
+_DEFINES = os.environ.get("VPT_EMU_DEFINES", "").split()
+LIB = os.path.join(HERE, "native", "libvaporetto_emu%s.so" % ("_" + "".join(c for c in "".join(_DEFINES) if c.isalnum()) if _DEFINES else ""))
 _EMU_FILES = [os.path.join(EMU, "hipemu.cpp"), os.path.join(EMU, "hip", "hip_runtime.h")]
 
 
@@ -22,7 +24,7 @@ def build_emulated() -> str:
         return LIB
     cmd = ["g++", "-O1", "-g", "-std=c++17", "-fPIC", "-shared", "-Wall", "-Wno-unused-function", "-Wno-unknown-pragmas",
            "-Wl,-Bsymbolic",   # its hip* definitions bind locally even if a real HIP runtime is loaded in the process
-           "-I" + EMU, "-o", LIB]
+           "-I" + EMU, "-o", LIB] + _DEFINES
     cmd += [s for s in srcs if s.endswith(".cpp")] + ["-x", "c++"] + [s for s in srcs if s.endswith(".hip")]
     cmd += ["-x", "none", _EMU_FILES[0]]
     subprocess.check_call(cmd)

@@ -122,8 +122,8 @@ int tc_score(const tc_model* t, const uint32_t* cps, size_t n, int32_t* y_out, u
             const uint32_t* g = &G.uni[size_t(cp_of(c1)) * G.uni_dw];
             for (int j = 0; j < 6; ++j) add(y, S - 3 + j, int32_t(g[j]));
         }
-        if (c2 == 0) continue;
-        const uint32_t slot = (((u[3] >> kUniBaseShift) & kUniBaseMask) << K.bi_shift) + c2;
+        if (c2 == 0 || c1 == kNoId || c2 == kNoId) continue;   // (the kernel issues no load for a char outside the alphabet)
+        const uint32_t slot = c2 < kBiDenseCols ? c1 * kBiDenseCols + c2 : (((u[3] >> kUniBaseShift) & kUniBaseMask) << K.bi_shift) + c2;
         if (size_t(slot) * 8 + 8 > K.bi.size()) return -3;   // the table must cover any id behind any base
         const uint32_t* r = &K.bi[size_t(slot) * 8];
         ++probes[0];

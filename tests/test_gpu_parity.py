@@ -157,6 +157,109 @@ def test_long_dictionary_words_cross_tile_sized_sentences():
     check_batch(pred, orc, texts)
 
 
+# ------------------------------------------------------------------------------------------------ cut tiles
+def _documents(seed, m, n_docs, lo, hi, alphabet):
+    """Sentences of lo..hi chars whose bytes per char vary 1..4 (so tiles are cut at every kind of byte position), with the
+    model's words sprinkled in so that dictionary words and n-grams straddle the cuts."""
+    import random
+    rng = random.Random(seed)
+    words = [w.word for w in m.dict_model] + [g.ngram for g in m.char_ngram_model]
+    filler = list(alphabet) + list("ab 1/") + ["🤌", "𠮷"]
+    out = []
+    for _ in range(n_docs):
+        n, parts, have = rng.randint(lo, hi), [], 0
+        while have < n:
+            w = rng.choice(words) if rng.random() < 0.6 else rng.choice(filler)
+            parts.append(w); have += len(w)
+        out.append("".join(parts)[:n])
+    return out
+
+
+@pytest.mark.parametrize("force_cut,tile_flat", [(False, None), (True, None), (False, "256"), (True, "61")])
+def test_sentences_of_any_length_are_cut_across_tiles(force_cut, tile_flat, monkeypatch):
+    """the reference scores a sentence of any length in one loop (char_scorer/boundary_scorer.rs:93-113; its
+    tantivy adapter passes a whole document as ONE Sentence, vaporetto_tantivy/src/lib.rs:171-176).  The specialised kernel cuts
+    such a batch at fixed flat positions: a tile scores a range of positions and reads a halo of the longest pattern on either
+    side -- dictionary words, n-grams and type windows that straddle a cut, cuts inside multi-byte chars' neighbourhood, sentence
+    breaks at and next to a cut, 1-char sentences.  VPT_FORCE_CUT_TILES=1 sends batches of SHORT sentences the same way."""
+    if force_cut:
+        monkeypatch.setenv("VPT_FORCE_CUT_TILES", "1")
+    if tile_flat:
+        monkeypatch.setenv("VPT_TILE_FLAT", tile_flat)     # small tiles: cuts at many more places (a full GPU cuts small batches finely too)
+    alpha = randmodel.ALPHABETS["kana"][:14]
+    m = randmodel.rand_model(9100, alphabet=alpha, wc=3, wt=3, max_word=14, n_char=300, n_dict=300, n_type=80)
+    pred, orc = make_predictor(m)
+    assert pred.info()["packed"] == 1
+    docs = _documents(1, m, 12, 2000, 9000, alpha) + _documents(2, m, 3, 20000, 30000, alpha)
+    shorts = randmodel.rand_sentences(3, m, 900, alphabet=alpha, max_len=70) + ["あ"] * 40 + _documents(4, m, 200, 1, 12, alpha)
+    rng = np.random.RandomState(5)
+    for texts in ([docs[i] for i in rng.permutation(len(docs))],
+                  [(docs + shorts)[i] for i in rng.permutation(len(docs) + len(shorts))],
+                  shorts):
+        check_batch(pred, orc, texts)
+    # every tile boundary in turn next to a sentence break: sentences whose lengths walk over the tile size
+    check_batch(pred, orc, [docs[0][:n] for n in range(700, 760)] + [docs[1][:n] for n in range(1690, 1720)])
+
+
+def test_cut_tiles_with_tags_filters_unaligned_text_and_errors(monkeypatch):
+    """Cut tiles carry everything whole-sentence tiles do: the chars left for fill_tags, KyteaFullwidthFilter, the label
+    post-filters, a text pointer that is not 16-byte aligned, and the device-side error flags."""
+    monkeypatch.setenv("VPT_FORCE_CUT_TILES", "1")
+    alpha = randmodel.ALPHABETS["kana"][:10] + list("Ａ１ア")
+    m = randmodel.rand_model(9200, alphabet=alpha, wc=3, wt=3, max_word=6, n_char=200, n_dict=150, n_type=60, n_tag_models=30)
+    raw = encode_model(m)
+    pred, orc = api.Predictor(api.Model.read_slice(raw)[0], True), cbind.OraclePredictor(raw, True)
+    texts = _documents(7, m, 6, 1500, 5000, alpha) + randmodel.rand_sentences(8, m, 300, alphabet=alpha, max_len=50) + [t.token * 2 for t in m.tag_models]
+    utf8, boff = api.pack_texts([t.encode("utf-8") for t in texts])
+    scores, labels, ooff = pred.predict_packed(utf8, boff)
+    o_scores, o_labels, _, _ = orc.predict_batch(utf8, boff, nthreads=4)
+    assert np.array_equal(scores, o_scores) and np.array_equal(labels, o_labels)
+    # device-resident, the text 5 bytes into its allocation: predict -> fill_tags (takes the chars predict left)
+    nb, S, nt = int(ooff[-1]), len(texts), pred.n_tags()
+    d_text = devmem.put(np.concatenate([np.full(5, 0x41, np.uint8), utf8, np.zeros(32, np.uint8)]))
+    d_boff, d_ooff = devmem.put(boff.astype(np.uint64)), devmem.put(ooff.astype(np.uint64))
+    d_scores, d_labels, d_tags = devmem.zeros(nb + 1, np.int32), devmem.zeros(nb + 1, np.uint8), devmem.zeros((nb + S) * nt + 1, np.int32)
+    batch = api.DeviceBatch(pred)
+    mb = int(np.max(np.diff(boff.astype(np.int64))))
+    batch.predict(d_text.ptr + 5, d_boff.ptr, d_ooff.ptr, S, nb, mb, d_scores.ptr, d_labels.ptr, devmem.stream())
+    assert batch.last_plan()["kind"] == "cut tiles"
+    batch.fill_tags(d_text.ptr + 5, d_boff.ptr, d_ooff.ptr, S, nb, d_labels.ptr, d_tags.ptr, devmem.stream())
+    batch.sync()
+    assert np.array_equal(d_scores.get(nb), o_scores)
+    o_tags, _, _ = orc.fill_tags_batch(utf8, boff, ooff, o_labels, nthreads=2, want_scores=False)
+    assert np.array_equal(d_tags.get((nb + S) * nt).reshape(nb + S, nt), o_tags)
+    # the filters: fullwidth on the way in, wsconst / linebreaks on the labels
+    plain = api.Predictor(api.Model.read_slice(raw)[0], False)
+    fw = api.KyteaFullwidthFilter()
+    half = [t.replace("Ａ", "A").replace("１", "1") + "\n" + "ｱ1A" for t in texts[:40]]
+    u2, b2 = api.pack_texts([t.encode("utf-8") for t in half])
+    got, glab, _ = plain.predict_packed(u2, b2, fullwidth=True, wsconst=[api.CharacterType.Hiragana], split_linebreaks=True)
+    u3, b3 = api.pack_texts([fw.filter(t).encode("utf-8") for t in half])
+    want, wlab, wooff, _ = cbind.OraclePredictor(raw, False).predict_batch(u3, b3, nthreads=2)
+    assert np.array_equal(got, want)
+    for i, t in enumerate(half):
+        f = fw.filter(t)
+        types = api.Sentence.from_raw(f).char_types()
+        for k in range(len(f) - 1):
+            lab = wlab[int(wooff[i]) + k]
+            if types[k] == types[k + 1] == api.CharacterType.Hiragana:
+                lab = 0
+            if f[k] in "\n\r" or f[k + 1] in "\n\r":
+                lab = 1
+            assert glab[int(wooff[i]) + k] == lab, (i, k)
+    # errors: offsets that promise a different number of chars, a NUL deep inside a long sentence
+    bad = ooff.copy(); bad[3:] += 1
+    d_bad = devmem.put(bad.astype(np.uint64))
+    d_s2, d_l2 = devmem.zeros(int(bad[-1]) + 1, np.int32), devmem.zeros(int(bad[-1]) + 1, np.uint8)
+    batch.predict(d_text.ptr + 5, d_boff.ptr, d_bad.ptr, S, int(bad[-1]), mb, d_s2.ptr, d_l2.ptr, devmem.stream())
+    with pytest.raises(api.VaporettoError, match="do not match the text"):
+        batch.sync()
+    nul = list(texts); nul[2] = nul[2][:1234] + "\0" + nul[2][1235:]
+    with pytest.raises(api.VaporettoError, match="must not contain NULL"):
+        plain.predict_packed(*api.pack_texts([t.encode("utf-8") for t in nul]))
+    assert np.array_equal(plain.predict_packed(utf8, boff)[0], o_scores)      # and the workspace is clean again
+
+
 def test_many_batches_through_one_predictor():
     raw, _ = kat.load_fixture("tantivy_model.bin")
     pred, orc = make_predictor(raw)

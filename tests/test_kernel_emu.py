@@ -37,7 +37,7 @@ _AS_IS = [
     "test_sentence_reuse_and_overwrite", "test_random_models_vs_oracle", "test_window_sizes",
     "test_predict_tags_variant_same_scores", "test_ragged_and_edge_lengths", "test_ascii_and_four_byte_text",
     "test_packed_text_with_non_bmp_and_noncharacters", "test_batch_errors", "test_device_side_error_flags",
-    "test_many_batches_through_one_predictor", "test_fast_and_general_kernels_agree_with_oracle",
+    "test_many_batches_through_one_predictor", "test_sentences_of_any_length_are_cut_across_tiles", "test_cut_tiles_with_tags_filters_unaligned_text_and_errors", "test_fast_and_general_kernels_agree_with_oracle",
     "test_packed_path_is_used_and_handles_wide_rows", "test_dense_packed_tables", "test_sparse_double_array_rows_interleave",
     "test_long_dictionary_words_cross_tile_sized_sentences", "test_very_long_words_and_compressed_chains",
     "test_non_bmp_pattern_models_use_the_general_tables", "test_long_type_ngrams_use_the_window_table",

@@ -19,7 +19,7 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
-KNOBS = ("VPT_DEBUG_LDS_PAD", "VPT_DEBUG_ABLATE", "VPT_SEPARATE_ASSIGN", "VPT_INLINE_ASSIGN", "VPT_FAST_CAP", "VPT_FORCE_WINDOW_TABLE", "VPT_FORCE_GENERIC")
+KNOBS = ("VPT_DEBUG_LDS_PAD", "VPT_DEBUG_ABLATE", "VPT_FORCE_CUT_TILES", "VPT_TILE_FLAT", "VPT_FORCE_WINDOW_TABLE", "VPT_FORCE_GENERIC")
 
 
 def lib_path(name):
@@ -40,6 +40,7 @@ def main():
     ap.add_argument("--steps", type=int, default=30)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--rounds", type=int, default=2)
+    ap.add_argument("--phases", action="store_true", help="VPT_PROFILE_PHASES: wave 0's shader cycles per phase and tile (slows the kernel)")
     args = ap.parse_args()
     import torch
     from oracle import cbind
@@ -79,6 +80,8 @@ def main():
         _lib._lib = L
         for k in KNOBS:
             os.environ.pop(k, None)
+        if args.phases:
+            os.environ["VPT_PROFILE_PHASES"] = "1"
         t = time.perf_counter()
         predictor = api.Predictor(api.Model.read_slice(raw)[0], False, device=0)
         t_create = time.perf_counter() - t
@@ -110,6 +113,9 @@ def main():
                 ms = 1e3 * (time.perf_counter() - t) / args.steps
                 batch.sync()
                 kernel_ms, tiles = batch.kernel_ms()
+                if args.phases:
+                    ph = batch.phase_cycles()
+                    results.setdefault(v + "#phases", {"variant": v, "phase_cycles_per_tile": [round(c / max(tiles, 1) / max(args.steps + args.warmup, 1)) for c in ph]})
                 ok = bool(np.array_equal(d_scores[:nb].cpu().numpy(), o_scores) and np.array_equal(d_labels[:nb].cpu().numpy(), o_labels))
                 r = results.setdefault(v, {"variant": v, "model": name, "ms_per_step": [], "kernel_ms": [], "tiles": tiles, "parity": ok,
                                            "create_s": round(t_create, 1), "sentences": S, "len": [args.min_len, args.max_len]})
@@ -121,7 +127,12 @@ def main():
             r = results[v]
             r["G_boundaries_per_s"] = round(nb / min(r["ms_per_step"]) / 1e6, 2)
             print(json.dumps(r), flush=True)
-        del predictor
+            if v + "#phases" in results:
+                print(json.dumps(results[v + "#phases"]), flush=True)
+        # every handle of this library is destroyed BY this library (the next one's structs may differ)
+        pred = predictor = batch = None
+        import gc
+        gc.collect()
 
 
 if __name__ == "__main__":

@@ -58,6 +58,7 @@ SIGNATURES = {
     "vpt_char_types_batch_device": (C.c_int, [_P, _P, _P, _P, _P, C.c_size_t, C.c_uint64, _P, _P]),
     "vpt_predictor_n_tags": (C.c_int, [_P, C.POINTER(C.c_uint32)]),
     "vpt_fill_tags_batch": (C.c_int, [_P, _P, _P, C.c_size_t, _P, _P, _P]),
+    "vpt_batch_last_plan": (C.c_int, [_P, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
     "vpt_predictor_tag_score_stride": (C.c_int, [_P, C.POINTER(C.c_uint32)]),
     "vpt_fill_tags_scores_batch": (C.c_int, [_P, _P, _P, C.c_size_t, _P, _P, C.c_uint, _P, _P, _P]),
     "vpt_fill_tags_scores_batch_device": (C.c_int, [_P, _P, _P, _P, _P, C.c_size_t, C.c_uint64, _P, _P, _P, _P, _P]),

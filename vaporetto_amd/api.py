@@ -830,6 +830,14 @@ class DeviceBatch:
         return ms.value, nt.value
 
 
+    def last_plan(self) -> dict:
+        """How the last predict call cut its batch (vpt_batch_last_plan)."""
+        n, tf, kind = C.c_uint32(), C.c_uint32(), C.c_uint32()
+        st = _lib.load().vpt_batch_last_plan(self._h, C.byref(n), C.byref(tf), C.byref(kind))
+        if st != _lib.VPT_OK:
+            _raise(st)
+        return {"tiles": n.value, "tile_flat": tf.value, "kind": ("general kernels", "whole-sentence tiles", "cut tiles")[min(kind.value, 2)]}
+
     def kernel_times(self) -> np.ndarray:
         """Durations (ms) of the timed scoring-kernel launches since the last kernel_ms(), oldest first (at most 256)."""
         out = np.zeros(256, dtype=np.float32)

@@ -46,9 +46,9 @@ struct PredictorKnobs {
 };
 struct BatchKnobs {
     bool force_generic = false;         // VPT_FORCE_GENERIC
-    int fast_cap = 0;                   // VPT_FAST_CAP (0: by the longest sentence)
+    int force_cut = 0;                  // VPT_FORCE_CUT_TILES: 1 = cut tiles for every batch, -1 = whole-sentence tiles whenever they fit (tests, A/B)
+    uint32_t tile_flat = 0;             // VPT_TILE_FLAT: flat positions per tile (tests: cuts at many places; never above what fits)
     bool no_cps_from_predict = false;   // VPT_NO_CPS_FROM_PREDICT
-    bool inline_assign = false;         // VPT_INLINE_ASSIGN
     uint32_t debug_ablate = 0;          // VPT_DEBUG_ABLATE
     bool profile_phases = false;        // VPT_PROFILE_PHASES
 };
@@ -65,9 +65,9 @@ PredictorKnobs read_predictor_knobs() {
 BatchKnobs read_batch_knobs() {
     BatchKnobs k;
     k.force_generic = std::getenv("VPT_FORCE_GENERIC") != nullptr;
-    if (const char* v = std::getenv("VPT_FAST_CAP")) k.fast_cap = std::atoi(v);
+    if (const char* v = std::getenv("VPT_FORCE_CUT_TILES")) k.force_cut = std::atoi(v);
+    if (const char* v = std::getenv("VPT_TILE_FLAT")) k.tile_flat = uint32_t(std::max(0, std::atoi(v)));
     k.no_cps_from_predict = std::getenv("VPT_NO_CPS_FROM_PREDICT") != nullptr;
-    k.inline_assign = std::getenv("VPT_INLINE_ASSIGN") != nullptr;
     if (const char* v = std::getenv("VPT_DEBUG_ABLATE")) k.debug_ablate = uint32_t(std::atoi(v));
     k.profile_phases = std::getenv("VPT_PROFILE_PHASES") != nullptr;
     return k;
@@ -84,7 +84,7 @@ constexpr size_t kTablePadBytes = 256;  // probes read whole 16-byte chunks; kee
 enum Section : int {
     kSecCShort, kSecCUni, kSecCEdges, kSecCWdata,              // general char tables
     kSecTShort, kSecTUni, kSecTEdges, kSecTWdata,              // general type tables (type_kind == pattern tables)
-    kSecPUni, kSecPBi, kSecPTri, kSecPDeep, kSecPXrows, kSecPTrow, kSecPCpid,   // packed tables: contiguous, addressed from kSecPUni
+    kSecPUni, kSecPBi, kSecPTri, kSecPDeep, kSecPXrows, kSecPTrow, kSecPCpid, kSecPCc, kSecPUtag, kSecPUrow,   // packed tables: contiguous, addressed from kSecPUni
     kSecTypeTable, kSecCtype, kSecCinfo, kSecCid,
     kSecTagTokTab, kSecTagModels, kSecTagMfilt, kSecTagNgrams, kSecTagNrec, kSecTagSyms, kSecTagSlots, kSecTagWeights, kSecTagSlotStr, kSecTagStrOff, kSecTagStrBytes,
     kSectionCount
@@ -94,7 +94,7 @@ struct TableGeom {
     int32_t window, lo[3], len[3];
 };
 constexpr char kCompiledMagic[16] = "VaporettoHIP-C\x01";   // 15 chars + NUL
-constexpr uint32_t kCompiledVersion = 7;                    // bump whenever layout.h or a kernel's reading of it changes
+constexpr uint32_t kCompiledVersion = 8;                    // bump whenever layout.h or a kernel's reading of it changes
 struct PredictorMeta {                                      // plain data: written and read as is (little-endian hosts)
     char magic[16];
     uint32_t version, meta_bytes;
@@ -153,7 +153,8 @@ const char* validate_meta(const PredictorMeta& m) {
         if (m.pk_n_uni < 2 || sz(kSecPUni) < 16ull * m.pk_n_uni || sz(kSecPCpid) < 4ull * m.pk_n_uni || sz(kSecPTri) < 16ull * m.pk_n_tri) return "packed tables";
         if (m.pk_bi_shift > 16 || sz(kSecPBi) < 32 || sz(kSecPDeep) < 64) return "packed tables (bigram level)";
         if (m.pk_has_trow ? sz(kSecPTrow) < 16ull * vpt::kTypeRowCount : false) return "type rows";
-        if (m.sec_off[kSecPCpid] + sz(kSecPCpid) - m.sec_off[kSecPUni] >= (1ull << 32)) return "packed tables (32-bit offsets)";
+        if (m.sec_off[kSecPUrow] + sz(kSecPUrow) - m.sec_off[kSecPUni] >= (1ull << 32)) return "packed tables (32-bit offsets)";
+        if (sz(kSecPCc) < 8ull * std::max(vpt::kFastCharCache, 4) || sz(kSecPUtag) < 2ull * std::max(vpt::kFastUniCache, 8) || sz(kSecPUrow) < 16ull * std::max(vpt::kFastUniCache, 1)) return "packed tables (caches)";
     }
     if (m.has_tags) {
         if (m.n_tags == 0 || m.n_tags > 4096 || m.tok_bits < 2 || m.tok_bits > 30 || m.max_tag_scores > vpt::kTagMaxZ) return "tag tables";
@@ -201,6 +202,9 @@ struct vpt_batch {
     BatchKnobs knobs;                  // read once, when the workspace was made
     // per-call device tables
     uint32_t* d_tile_first = nullptr; size_t tile_cap = 0;
+    vpt::TileDesc* d_tiles = nullptr; size_t tiles_cap = 0;          // the specialised kernel's tiles
+    uint32_t* d_cut_local = nullptr; size_t cut_local_cap = 0;       // ... and, for cut tiles, the lead-byte index of the text
+    uint64_t* d_cut_super = nullptr; size_t cut_super_cap = 0;
     uint32_t* d_slow_list = nullptr;
     uint32_t* d_ctrl = nullptr;        // [0] status bits, [1] slow tile count
     uint64_t* d_prof = nullptr;        // 8 per-phase cycle counters (only with VPT_PROFILE_PHASES set)
@@ -214,7 +218,7 @@ struct vpt_batch {
     bool timing = false;
     std::vector<hipEvent_t> ev;        // ring of (start, stop) pairs around the scoring kernel
     size_t ev_calls = 0;               // timed calls since the last vpt_batch_kernel_ms
-    uint32_t last_tiles = 0;
+    uint32_t last_tiles = 0, last_tile_flat = 0, last_plan = 0;   // last_plan: 0 general kernels, 1 whole-sentence tiles, 2 cut tiles
     hipStream_t last_stream = nullptr; bool pending = false;
     // staging for the host-buffer entry points
     hipStream_t own_stream = nullptr;
@@ -267,7 +271,6 @@ struct vpt_predictor {
     vpt_model_info info{};
     int32_t bias = 0; int pad = 1; int type_kind = 0; int type_window = 0; int chunks = 2;
     uint32_t tile_slots = 0;           // workgroups of the scoring kernel the device runs at a time (0 = unknown)
-    uint32_t tile_slots_small = 0;     // ... of the specialised kernel's small-tile geometry
     uint32_t n_cus = 0;                // compute units of the device (0 = unknown)
     vpt::PackedView pk{};
     const int32_t* d_type_table = nullptr;
@@ -298,6 +301,7 @@ void batch_release(vpt_batch* b) {
     if (!b) return;
     (void)hipSetDevice(b->device);
     (void)hipFree(b->d_scan_part);
+    (void)hipFree(b->d_tiles); (void)hipFree(b->d_cut_local); (void)hipFree(b->d_cut_super);
     (void)hipFree(b->d_tile_first); (void)hipFree(b->d_slow_list); (void)hipFree(b->d_ctrl); (void)hipFree(b->d_scratch);
     (void)hipFree(b->d_prof); (void)hipFree(b->d_cps);
     (void)hipFree(b->d_text); (void)hipFree(b->d_boff); (void)hipFree(b->d_ooff); (void)hipFree(b->d_scores); (void)hipFree(b->d_labels);
@@ -487,6 +491,7 @@ void bind_predictor(vpt_predictor* p) {
         auto rel = [&](int sec) { return uint32_t(m.sec_off[sec] - m.sec_off[kSecPUni]); };
         p->pk.off_uni = 0; p->pk.off_bi = rel(kSecPBi); p->pk.off_tri = rel(kSecPTri); p->pk.off_deep = rel(kSecPDeep);
         p->pk.off_xrows = rel(kSecPXrows); p->pk.off_trow = rel(kSecPTrow); p->pk.off_cpid = rel(kSecPCpid);
+        p->pk.off_cc = rel(kSecPCc); p->pk.off_utag = rel(kSecPUtag); p->pk.off_urow = rel(kSecPUrow);
         p->pk.n_uni = m.pk_n_uni; p->pk.n_tri = m.pk_n_tri; p->pk.bi_shift = m.pk_bi_shift; p->pk.has_trow = m.pk_has_trow;
     }
     p->d_type_table = m.sec_bytes[kSecTypeTable] ? reinterpret_cast<const int32_t*>(at(kSecTypeTable)) : nullptr;
@@ -508,7 +513,7 @@ void bind_predictor(vpt_predictor* p) {
     }
     p->info = m.info;
     p->bias = m.bias; p->pad = m.pad; p->type_kind = m.type_kind; p->type_window = m.type_window; p->chunks = m.chunks;
-    p->tile_slots = 0; p->tile_slots_small = 0;
+    p->tile_slots = 0;
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, p->device) == hipSuccess && prop.multiProcessorCount > 0) {
         p->n_cus = uint32_t(prop.multiProcessorCount);
@@ -522,8 +527,7 @@ void bind_predictor(vpt_predictor* p) {
             return uint32_t(prop.multiProcessorCount) * uint32_t(std::min<size_t>(built_for, std::max<size_t>(1, 128 / std::max<size_t>(granules, 1))));
         };
         if (fast) {
-            p->tile_slots_small = slots_for(vpt::score_tiles_fast_lds_bytes(probe, vpt::kFastCapSmall), vpt::kFastWgSmall);
-            p->tile_slots = slots_for(vpt::score_tiles_fast_lds_bytes(probe, vpt::kFastCapLarge), vpt::kFastWgLarge);
+            p->tile_slots = slots_for(vpt::score_tiles_fast_lds_bytes(probe), vpt::kFastWg);
         } else {
             p->tile_slots = slots_for(vpt::score_tiles_lds_bytes(), 8);   // the general kernel is built for 8 workgroups per CU
         }
@@ -566,6 +570,9 @@ vpt_status vpt_predictor_create(const uint8_t* model_bytes, size_t len, int pred
         ctype[cp] = vpt::char_type_host(cp);
     }
     std::vector<uint32_t> cid;
+    // the contents of the kernel's LDS caches (layout.h): per slot the entry that the most patterns contain
+    std::vector<uint32_t> cc(2 * std::max(vpt::kFastCharCache, 4), 0), urow(4 * std::max(vpt::kFastUniCache, 1), 0);
+    std::vector<uint16_t> utag(std::max(vpt::kFastUniCache, 8), 0);
     if (c.packed.present) {
         cid.resize(2 * 65536);
         for (uint32_t cp = 0; cp < 65536; ++cp)
@@ -574,6 +581,31 @@ vpt_status vpt_predictor_create(const uint8_t* model_bytes, size_t len, int pred
                 cid[size_t(mode) * 65536 + cp] = uint32_t(c.packed.id_of[scored]) | (uint32_t(vpt::char_type_host(scored)) << 16) |
                                                  ((scored == 0x0Au || scored == 0x0Du) ? vpt::kCinfoLinebreak : 0u);
             }
+        if (vpt::kFastCharCache) {
+            const uint32_t mask = uint32_t(vpt::kFastCharCache) - 1;
+            for (int mode = 0; mode < 2; ++mode) {
+                std::vector<uint32_t> best(vpt::kFastCharCache, 0);
+                for (uint32_t cp = 1; cp < 65536; ++cp) {
+                    const uint32_t w = cid[size_t(mode) * 65536 + cp], id = w & 0xFFFFu;
+                    const uint32_t scored = mode ? vpt::kytea_fullwidth_host(cp) : cp;
+                    const uint32_t heat = c.packed.hot[scored];
+                    if (id >= 0x1FFFu || (w & vpt::kCinfoLinebreak) || heat == 0) continue;   // ids of 13 bits, no line breaks, chars of the alphabet
+                    uint32_t& e = cc[size_t(mode) * vpt::kFastCharCache + (cp & mask)];
+                    if (e == 0 || heat > best[cp & mask]) { e = (cp << 16) | (((w >> 16) & 7u) << 13) | id; best[cp & mask] = heat; }
+                }
+            }
+        }
+        if (vpt::kFastUniCache) {
+            const uint32_t mask = uint32_t(vpt::kFastUniCache) - 1;
+            std::vector<uint32_t> best(vpt::kFastUniCache, 0);
+            for (uint32_t id = 1; id <= c.packed.n_alpha; ++id) {
+                const uint32_t heat = c.packed.hot[c.packed.cpid[id]];
+                if (utag[id & mask] == 0 || heat > best[id & mask]) {
+                    utag[id & mask] = uint16_t(id); best[id & mask] = heat;
+                    for (int q = 0; q < 4; ++q) urow[size_t(id & mask) * 4 + q] = c.packed.uni[size_t(id) * 4 + q];
+                }
+            }
+        }
     }
 
     // ---- sections
@@ -585,11 +617,12 @@ vpt_status vpt_predictor_create(const uint8_t* model_bytes, size_t len, int pred
     if (packed_ok) {
         put(kSecPUni, c.packed.uni); put(kSecPBi, c.packed.bi); put(kSecPTri, c.packed.tri); put(kSecPDeep, c.packed.deep);
         put(kSecPXrows, c.packed.xrows); put(kSecPTrow, c.packed.trow); put(kSecPCpid, c.packed.cpid);
+        put(kSecPCc, cc); put(kSecPUtag, utag); put(kSecPUrow, urow);
         size_t packed_total = 0;
-        for (int i = kSecPUni; i <= kSecPCpid; ++i) packed_total += (src[i].bytes + kTablePadBytes + 255) & ~size_t(255);
+        for (int i = kSecPUni; i <= kSecPUrow; ++i) packed_total += (src[i].bytes + kTablePadBytes + 255) & ~size_t(255);
         if (packed_total >= (size_t(1) << 32)) {   // the specialised kernel addresses them with 32-bit offsets: the general tables serve
             packed_ok = false;
-            for (int i = kSecPUni; i <= kSecPCpid; ++i) src[i] = {nullptr, 0};
+            for (int i = kSecPUni; i <= kSecPUrow; ++i) src[i] = {nullptr, 0};
         }
     }
     if (c.type_kind == vpt::kTypeWindowTable) put(kSecTypeTable, c.type_table);
@@ -940,87 +973,125 @@ vpt_status vpt_predict_batch_device(const vpt_predictor* p, vpt_batch* b, const 
     P.cid = p->d_cid ? p->d_cid + ((b->flags & VPT_FLAG_KYTEA_FULLWIDTH) ? 65536 : 0) : nullptr;
     P.post = b->flags & 0xFEu;
     P.type_window = p->type_window; P.type_kind = p->type_kind; P.bias = p->bias; P.pad = p->pad;
-    // Tiles are cut every `tile_flat` flat positions (chars + separators) and end with the sentence that crosses
-    // the cut, so a tile holds < tile_flat + longest sentence: pick tile_flat to fill the kernel's LDS capacity.
     P.force_window_table = p->knobs.force_window_table ? 1u : 0u; P.lds_pad = p->knobs.lds_pad;
-    const bool fast = vpt::fast_path_supported(P) && !b->knobs.force_generic;
+    if (b->flags & VPT_FLAG_KYTEA_FULLWIDTH) P.pk.off_cc += 4u * uint32_t(std::max(vpt::kFastCharCache, 4));   // the char cache of that char table
     // flat positions of the longest sentence: its chars, bounded by the caller's hint or else by its bytes
     const uint64_t max_chars = (b->max_chars && b->max_chars < max_sentence_bytes) ? b->max_chars : max_sentence_bytes;
-    // the specialised kernel's tile geometry (kernels.hpp): small tiles, 8 workgroups per CU, unless a sentence is long
-    int fast_cap = max_chars > uint64_t(vpt::kFastLongSentence) ? vpt::kFastCapLarge : vpt::kFastCapSmall;
-    if (b->knobs.fast_cap) fast_cap = b->knobs.fast_cap == vpt::kFastCapSmall ? vpt::kFastCapSmall : vpt::kFastCapLarge;   // A/B runs
-    const uint32_t tile_slots = fast && fast_cap == vpt::kFastCapSmall ? p->tile_slots_small : p->tile_slots;
-    const uint64_t cap = fast ? uint64_t(fast_cap) : vpt::kCap;
-    uint64_t tile_flat = cap / 2;
-    if (max_chars + 2 * uint64_t(p->pad) + cap / 2 <= cap) tile_flat = cap - 2 * uint64_t(p->pad) - max_chars;
     const uint64_t total_flat = total_boundaries + uint64_t(n_sentences) * uint64_t(1 + p->pad);
+    const uint64_t total_chars = total_boundaries + n_sentences;
+    // The specialised kernel takes whole-sentence tiles while every sentence is short, and tiles cut at any flat position (with a
+    // halo of the longest pattern on either side) otherwise -- a sentence of any length is scored there.  Only a model whose longest
+    // pattern leaves no room for a tile between its halos sends long sentences to the general kernels.
+    bool fast = vpt::fast_path_supported(P) && !b->knobs.force_generic;
+    vpt::CutGeometry cut{};
+    bool cut_tiles = false;
+    if (fast) {
+        const uint32_t lmax = std::max<uint32_t>(p->info.max_pattern_chars, 3);
+        cut.halo_left = std::max<uint32_t>(lmax - 1, 3); cut.halo_right = std::max<uint32_t>(lmax + 2, 6);
+        cut.cap_eff = uint32_t(vpt::kFastCap - vpt::kFastStageSlack);
+        const int64_t room = int64_t(cut.cap_eff) - int64_t(p->pad) - int64_t(cut.halo_left) - int64_t(cut.halo_right);
+        const bool can_cut = room >= 256;
+        cut.tile_flat = can_cut ? uint32_t(room) : 0u;
+        cut.mis = uint32_t(reinterpret_cast<uintptr_t>(d_utf8) & 15u);
+        const bool fits_whole = max_chars <= uint64_t(vpt::kFastWholeMaxChars);
+        cut_tiles = can_cut && (b->knobs.force_cut > 0 || (!fits_whole && !(b->knobs.force_cut < 0 && max_chars + 2 * uint64_t(p->pad) + vpt::kFastCap / 2 <= uint64_t(vpt::kFastCap))));
+        if (!cut_tiles && max_chars + 2 * uint64_t(p->pad) + vpt::kFastCap / 2 > uint64_t(vpt::kFastCap)) fast = false;   // neither kind of tile holds the batch
+    }
+    const uint64_t cap = fast ? uint64_t(vpt::kFastCap) : vpt::kCap;
+    // Whole-sentence tiles are cut every `tile_flat` flat positions (chars + separators) and end with the sentence that crosses
+    // the cut, so a tile holds < tile_flat + longest sentence: pick tile_flat to fill the kernel's LDS capacity.
+    uint64_t tile_flat = cap / 2;
+    if (cut_tiles) tile_flat = cut.tile_flat;
+    else if (max_chars + 2 * uint64_t(p->pad) + cap / 2 <= cap) tile_flat = cap - 2 * uint64_t(p->pad) - max_chars;
     // Whole rounds: the chip runs `slots` tiles at a time; cutting the batch into a multiple of that many tiles (by
     // shrinking the tiles a little) avoids a last round that leaves most CUs idle.
-    if (tile_slots > 0) {
+    if (p->tile_slots > 0) {
         const uint64_t n_min = (total_flat + tile_flat - 1) / tile_flat;
-        const uint64_t rounds = (n_min + tile_slots - 1) / tile_slots;
-        const uint64_t even = (total_flat + rounds * tile_slots - 1) / (rounds * tile_slots);
+        const uint64_t rounds = (n_min + p->tile_slots - 1) / p->tile_slots;
+        const uint64_t even = (total_flat + rounds * p->tile_slots - 1) / (rounds * p->tile_slots);
         if (even < tile_flat) tile_flat = std::max<uint64_t>(even, 256);
+    }
+    if (b->knobs.tile_flat && b->knobs.tile_flat < tile_flat) tile_flat = std::max<uint64_t>(b->knobs.tile_flat, 16);
+    if (cut_tiles) {   // the window a cut tile decodes and walks: its own positions and the two halos
+        cut.tile_flat = uint32_t(tile_flat);
+        cut.cap_eff = uint32_t(p->pad) + cut.halo_left + cut.tile_flat + cut.halo_right;
     }
     const uint64_t n_tiles64 = (total_flat + tile_flat - 1) / tile_flat;
     if (n_tiles64 >= 0x7FFFFFFFull) return fail(VPT_INVALID_ARGUMENT, "InvalidArgumentError: batch too large for one call");
     const uint32_t n_tiles = uint32_t(n_tiles64);
-    if (size_t(n_tiles) + 1 > b->tile_cap || !b->d_tile_first) {
-        (void)hipFree(b->d_slow_list); b->d_slow_list = nullptr;
-        size_t cap = b->tile_cap;
-        vpt_status st = grow(&b->d_tile_first, &cap, size_t(n_tiles) + 1);
-        if (st != VPT_OK) return st;
-        b->tile_cap = cap;
-        VPT_HIP(hipMalloc(reinterpret_cast<void**>(&b->d_slow_list), cap * sizeof(uint32_t) + 64));
-    }
-    // long-sentence scratch (only when a sentence might not fit the LDS tile)
-    const bool need_slow = max_chars + 2 * uint64_t(p->pad) + tile_flat > cap;
+    vpt_status st;
+    bool need_slow = false;
     uint32_t slow_blocks = 0, scratch_cap = 0;
     uint64_t slab = 0;
-    if (need_slow) {
-        const uint64_t cap64 = max_chars + 2 * uint64_t(p->pad) + vpt::kMargin + 8;
-        if (cap64 >= 0x7FFFFFF0ull) return fail(VPT_INVALID_ARGUMENT, "InvalidArgumentError: max_sentence_bytes: too large");
-        scratch_cap = uint32_t((cap64 + 15) & ~15ull);
-        slab = (uint64_t(scratch_cap) * 9 + 255) & ~255ull;
-        slow_blocks = uint32_t(std::max<uint64_t>(1, std::min<uint64_t>(64, (8ull << 30) / slab)));
-        const size_t need = size_t(slab) * slow_blocks;
-        if (need > b->scratch_bytes) {
-            (void)hipFree(b->d_scratch); b->d_scratch = nullptr; b->scratch_bytes = 0;
-            VPT_HIP(hipMalloc(reinterpret_cast<void**>(&b->d_scratch), need));
-            b->scratch_bytes = need;
+    if (fast && cut_tiles) {
+        if ((st = grow(&b->d_tiles, &b->tiles_cap, size_t(n_tiles) + 1)) != VPT_OK) return st;
+        size_t n_local = 0, n_super = 0;
+        vpt::cut_index_entries(total_chars, &n_local, &n_super);
+        if ((st = grow(&b->d_cut_local, &b->cut_local_cap, n_local + 16)) != VPT_OK) return st;
+        if ((st = grow(&b->d_cut_super, &b->cut_super_cap, n_super + 16)) != VPT_OK) return st;
+    } else {
+        if (size_t(n_tiles) + 1 > b->tile_cap || !b->d_tile_first) {
+            (void)hipFree(b->d_slow_list); b->d_slow_list = nullptr;
+            size_t tcap = b->tile_cap;
+            if ((st = grow(&b->d_tile_first, &tcap, size_t(n_tiles) + 1)) != VPT_OK) return st;
+            b->tile_cap = tcap;
+            VPT_HIP(hipMalloc(reinterpret_cast<void**>(&b->d_slow_list), tcap * sizeof(uint32_t) + 64));
+        }
+        // long-sentence scratch of the general kernels (only when a sentence might not fit the LDS tile)
+        need_slow = !fast && max_chars + 2 * uint64_t(p->pad) + tile_flat > cap;
+        if (need_slow) {
+            const uint64_t cap64 = max_chars + 2 * uint64_t(p->pad) + vpt::kMargin + 8;
+            if (cap64 >= 0x7FFFFFF0ull) return fail(VPT_INVALID_ARGUMENT, "InvalidArgumentError: max_sentence_bytes: too large");
+            scratch_cap = uint32_t((cap64 + 15) & ~15ull);
+            slab = (uint64_t(scratch_cap) * 9 + 255) & ~255ull;
+            slow_blocks = uint32_t(std::max<uint64_t>(1, std::min<uint64_t>(64, (8ull << 30) / slab)));
+            const size_t need = size_t(slab) * slow_blocks;
+            if (need > b->scratch_bytes) {
+                (void)hipFree(b->d_scratch); b->d_scratch = nullptr; b->scratch_bytes = 0;
+                VPT_HIP(hipMalloc(reinterpret_cast<void**>(&b->d_scratch), need));
+                b->scratch_bytes = need;
+            }
         }
     }
-    P.text = d_utf8; P.boff = d_byte_offsets; P.ooff = d_out_offsets; P.tile_first = b->d_tile_first;
+    P.text = d_utf8; P.boff = d_byte_offsets; P.ooff = d_out_offsets; P.tile_first = b->d_tile_first; P.tiles = (fast && cut_tiles) ? b->d_tiles : nullptr;
     P.scores = d_scores; P.labels = d_labels; P.status = b->d_ctrl; P.slow_list = b->d_slow_list; P.slow_count = b->d_ctrl + 1;
     P.scratch = b->d_scratch; P.scratch_stride = slab; P.scratch_cap = scratch_cap;
     P.prof = b->d_prof;
+    P.total_chars = total_chars;
     // A predictor with tag models: the specialised kernel also leaves the decoded chars behind, and a vpt_fill_tags_batch_device
     // call for the same buffers on this workspace (Sentence::fill_tags follows Predictor::predict on the same sentence,
     // predictor.rs:542) skips its own decode pass.
     b->cps_text = nullptr;
-    if (p->has_tags && p->predict_tags && fast && !need_slow && !b->knobs.no_cps_from_predict) {
-        vpt_status st2 = grow(&b->d_cps, &b->cps_cap, size_t(total_boundaries + n_sentences) + 16);
+    if (p->has_tags && p->predict_tags && fast && !b->knobs.no_cps_from_predict) {
+        vpt_status st2 = grow(&b->d_cps, &b->cps_cap, size_t(total_chars) + 16);
         if (st2 != VPT_OK) return st2;
-        P.cps_out = b->d_cps; P.total_chars = total_boundaries + n_sentences;
+        P.cps_out = b->d_cps;
         b->cps_text = d_utf8; b->cps_ooff = d_out_offsets; b->cps_sentences = n_sentences; b->cps_boundaries = total_boundaries;
         b->cps_flags = b->flags & VPT_FLAG_KYTEA_FULLWIDTH;
     }
     if (b->knobs.debug_ablate) { P.debug = b->knobs.debug_ablate; P.ct.debug = P.debug; P.tt.debug = P.debug; }
 
     P.n_sent = n_sentences; P.tile_flat = uint32_t(tile_flat); P.n_tiles = n_tiles;
-    // The specialised kernel can find its tiles itself (one launch per step).  Measured on MI355X (profiles/r02_c1_ab.jsonl):
-    // the search at the head of every workgroup costs the scoring kernel more (+4 us) than the separate 5 us kernel and its
-    // launch gap cost the step, so the separate kernel stays the default.
-    const bool inline_assign = fast && !need_slow && b->knobs.inline_assign;
-    if (inline_assign) P.tile_first = nullptr;
+    // the tiles (a kernel of its own: finding them at the head of every workgroup measured slower, profiles/r02_c1_ab.jsonl); for
+    // cut tiles preceded by the lead-byte index of the text
+    if (fast && cut_tiles) VPT_HIP(vpt::launch_assign_tiles_cut(P, cut, n_tiles, total_chars, b->d_cut_local, b->d_cut_super, b->d_tiles, b->d_ctrl, stream));
     else VPT_HIP(vpt::launch_assign_tiles(d_out_offsets, n_sentences, p->pad, uint32_t(tile_flat), n_tiles, b->d_tile_first, b->d_ctrl, stream));
     const size_t slot = b->ev_calls % kTimingRing;
     if (b->timing) VPT_HIP(hipEventRecord(b->ev[2 * slot], stream));
-    if (fast) VPT_HIP(vpt::launch_score_tiles_fast(P, fast_cap, n_tiles, stream));
+    if (fast) VPT_HIP(vpt::launch_score_tiles_fast(P, n_tiles, stream));
     else VPT_HIP(vpt::launch_score_tiles(P, p->chunks, n_tiles, stream));
+    if (need_slow) VPT_HIP(vpt::launch_score_slow(P, p->chunks, slow_blocks, stream));   // inside the timed events: it is part of the scoring
     if (b->timing) { VPT_HIP(hipEventRecord(b->ev[2 * slot + 1], stream)); ++b->ev_calls; }
-    if (need_slow) VPT_HIP(vpt::launch_score_slow(P, p->chunks, slow_blocks, stream));
     b->last_tiles = n_tiles; b->last_stream = stream; b->pending = true;
+    b->last_tile_flat = uint32_t(tile_flat); b->last_plan = !fast ? 0u : cut_tiles ? 2u : 1u;
+    return VPT_OK;
+}
+
+vpt_status vpt_batch_last_plan(const vpt_batch* b, uint32_t* n_tiles, uint32_t* tile_flat, uint32_t* kind) {
+    if (!b) return fail(VPT_INVALID_ARGUMENT, "InvalidArgumentError: NULL argument");
+    if (n_tiles) *n_tiles = b->last_tiles;
+    if (tile_flat) *tile_flat = b->last_tile_flat;
+    if (kind) *kind = b->last_plan;
     return VPT_OK;
 }
 

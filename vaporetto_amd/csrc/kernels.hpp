@@ -15,12 +15,40 @@ constexpr int kCap = 2048;                       // flat positions (chars + sepa
 constexpr int kTileFlat = 1024;                  // flat positions a tile is cut at (a tile ends with the sentence
                                                  // that crosses the cut, so it needs kCap - kTileFlat of slack)
 constexpr int kMargin = 8;                       // zeroed slack past the tile for the s+1, s+2 look-ahead
-// The specialised kernel ships in two tile geometries (measured on MI355X, profiles/r02_c5_ab*.jsonl): tiles of 1280 flat
-// positions leave room for 8 workgroups per CU -- the best for ordinary sentences --, tiles of 1536 (7 per CU) waste less on
-// long ones (a tile ends with the sentence that crosses its cut).  vpt_predict_batch_device picks by the longest sentence.
-constexpr int kFastCapSmall = 1280, kFastWgSmall = 8;
-constexpr int kFastCapLarge = 1536, kFastWgLarge = 7;
-constexpr int kFastLongSentence = 160;           // chars: batches with a longer sentence use the large geometry
+// The specialised kernel's tile: kFastCap flat positions, kFastWg workgroups per CU (1280 / 8: the best of the geometries measured
+// on MI355X, profiles/r02_c5_ab*.jsonl, r03_d_ab_geometries.jsonl), and -- compiled out by default -- two LDS-resident caches in front
+// of the two small tables every position reads, the char -> (id, CharacterType) table and the unigram nodes.  Measured (r03_d): a
+// 512-entry char cache hits 83 % of the chars of the benchmark text and buys 2 % (those gathers hit the vector L1 anyway; what the
+// kernel waits for are the bigram / trigram nodes that miss the L2), less than the smaller tile that makes room for it costs.
+// (-D overrides: A/B builds of tools/build_variants.sh.)
+#ifndef VPT_FAST_CAP
+#define VPT_FAST_CAP 1280
+#endif
+#ifndef VPT_FAST_WG
+#define VPT_FAST_WG 8
+#endif
+#ifndef VPT_FAST_CC
+#define VPT_FAST_CC 0
+#endif
+#ifndef VPT_FAST_UC
+#define VPT_FAST_UC 0
+#endif
+#ifndef VPT_FAST_STAGED
+#define VPT_FAST_STAGED 0
+#endif
+constexpr int kFastCap = VPT_FAST_CAP, kFastWg = VPT_FAST_WG;
+constexpr int kFastCharCache = VPT_FAST_CC;      // entries (a power of two); 0: none
+constexpr int kFastUniCache = VPT_FAST_UC;       // unigram nodes (a power of two); 0: none
+// Two ways of cutting a batch into tiles ("Tiles"):
+//   whole sentences   a tile = the sentences whose flat start lies in its range; needs every sentence to fit beside tile_flat
+//   cut anywhere      a tile = a range of flat positions plus a halo of max(pattern length) chars on either side, so a sentence
+//                     of ANY length is scored by as many tiles as it spans (the reference scores any length in one loop,
+//                     char_scorer/boundary_scorer.rs:93-113; its tantivy adapter passes whole documents as one Sentence)
+constexpr int kFastWholeMaxChars = kFastCap / 2 - 6;   // batches whose longest sentence has more chars are cut anywhere (a whole-sentence
+                                                 // tile holds tile_flat >= cap / 2 positions plus the sentence that crosses its end)
+constexpr int kCutBlockShift = 8;                // cut tiles find their text through lead-byte counts per 256-byte block
+constexpr int kFastStageSlack = 136;             // flat positions a cut tile leaves unused so that its text always fits the staging area
+                                                 // (a tile of n chars stages at most 4 n + 2 * 256 bytes; the area holds 4 * cap + 32)
 constexpr int kBitmapWords = 4 * kCap / 32 + 4;  // one bit per text byte of a tile (UTF-8: <= 4 bytes per char)
 
 // device status word (OR of bits)
@@ -48,7 +76,8 @@ struct ScoreParams {
     const uint8_t* text;
     const uint64_t* boff;       // [S+1] byte offsets
     const uint64_t* ooff;       // [S+1] output (boundary) offsets
-    const uint32_t* tile_first; // [n_tiles+1]; nullptr: the specialised kernel finds its tile itself (n_sent, tile_flat, n_tiles)
+    const uint32_t* tile_first; // [n_tiles+1] (general kernel)
+    const struct TileDesc* tiles; // [n_tiles] (specialised kernel, cut tiles; nullptr: whole-sentence tiles from tile_first)
     uint64_t n_sent;
     uint32_t tile_flat, n_tiles;
     int32_t* scores;
@@ -68,6 +97,24 @@ struct ScoreParams {
     uint32_t debug;             // profiling ablation bits (VPT_DEBUG_ABLATE env, 0 in production)
     uint64_t* prof;             // per-phase shader-cycle counters (VPT_PROFILE_PHASES env), else nullptr
 };
+
+// What a workgroup of the specialised kernel needs to know of its tile, made by the assign kernels (kernels_fast.hip).  The tile's
+// text is bytes [byte0, byte0 + nbytes); lead number ci of it (0-based) in tile-local sentence si sits at LDS position
+// c_off + ci + pad * si, si = sib0 + (sentence starts at or before its byte); positions outside [pad, flat_len) are not kept.
+struct TileDesc {
+    uint32_t i0, nsent;         // sentences [i0, i0 + nsent): every sentence with a byte in the staged text
+    uint32_t byte0_lo, byte0_hi;
+    uint32_t nbytes;
+    int32_t c_off;
+    int32_t sib0;               // -1: byte0 starts sentence i0; 0: it lies inside sentence i0
+    uint32_t own_lo, own_hi;    // the boundaries (and chars) at LDS positions [own_lo, own_hi) are this tile's to write
+    uint32_t flat_len;
+    uint32_t g0_lo, g0_hi;      // global char number (out_offsets[i] + i + char index) of the first staged lead
+    uint32_t expect_chars;      // leads the staged text must hold (whole-sentence tiles), 0xFFFFFFFF: not checked
+    uint32_t strict_end;        // a lead at or past flat_len is an error (the text ends with the tile)
+    uint32_t rsv0, rsv1;
+};
+static_assert(sizeof(TileDesc) == 64, "four 16-byte scalar loads");
 
 // tag prediction (kernels_tags.hip); table layouts: HostTagTables in tables.hpp
 struct TagParams {
@@ -124,8 +171,14 @@ hipError_t launch_assign_tiles(const uint64_t* ooff, uint64_t n_sent, int pad, u
                                uint32_t* tile_first, uint32_t* ctrl, hipStream_t stream);
 // specialised kernel (kernels_fast.hip): packed tables (char window 3, BMP, i16), type window table or none
 bool fast_path_supported(const ScoreParams& P);
-size_t score_tiles_fast_lds_bytes(const ScoreParams& P, int cap);   // cap: kFastCapSmall or kFastCapLarge
-hipError_t launch_score_tiles_fast(const ScoreParams& P, int cap, uint32_t n_tiles, hipStream_t stream);
+size_t score_tiles_fast_lds_bytes(const ScoreParams& P);
+hipError_t launch_score_tiles_fast(const ScoreParams& P, uint32_t n_tiles, hipStream_t stream);
+// its tiles: whole sentences (launch_assign_tiles, as for the general kernel; ScoreParams::tiles stays nullptr) or cut anywhere: lead-byte counts per 256-byte block of the text (cut_local: exclusive inside a superblock of 256 blocks,
+// cut_super: exclusive over the superblocks; sized from cut_index_entries), then the tiles
+struct CutGeometry { uint32_t tile_flat, halo_left, halo_right, cap_eff, mis /* text pointer & 15 */; };
+void cut_index_entries(uint64_t total_chars_bound, size_t* n_local, size_t* n_super);
+hipError_t launch_assign_tiles_cut(const ScoreParams& P, const CutGeometry& G, uint32_t n_tiles, uint64_t total_chars_bound, uint32_t* cut_local,
+                                   uint64_t* cut_super, TileDesc* tiles, uint32_t* ctrl, hipStream_t stream);
 hipError_t launch_score_tiles(const ScoreParams& P, int chunks, uint32_t n_tiles, hipStream_t stream);
 hipError_t launch_score_slow(const ScoreParams& P, int chunks, uint32_t n_blocks, hipStream_t stream);
 

@@ -2,7 +2,7 @@
 // BMP patterns (layout.h, "PACKED TABLES"), type scores from type rows in LDS, the 8^(2W) window table (W <= 3) or
 // none.  Same all-matches algorithm as kernels.hip (which stays the general path); what changes is how the work is
 // laid out for a CDNA4 CU, whose limiter on this workload is the vector L1's address pipeline: every 16-byte load of
-// a lane costs a slot of it and every distinct line it touches two more (profiles/r02_*), while VALU work is two
+// a lane costs a slot of it and every distinct line it touches two more (profiles/r02_*, r03_b_*), while VALU work is two
 // orders of magnitude cheaper per lane.  So a start position issues as few loads as the data structure allows:
 //
 //   * the patterns form a DOUBLE-ARRAY trie over their first three symbols: one 16-byte unigram node (indexed by the
@@ -12,14 +12,20 @@
 //   * the three loads depend on each other, so they are software-pipelined: a trip of the main loop loads the
 //     unigram nodes of the positions two trips ahead, the bigram nodes of the next trip's positions and the trigram
 //     nodes of its own -- all independent of each other -- and waits once;
+//   * only lanes that can match load at all: separators, chars no pattern contains and positions past the tile issue nothing;
+//   * the two SMALL tables every char reads -- char -> (id, CharacterType) and the unigram nodes -- sit behind LDS-resident
+//     caches of their hottest entries (direct mapped, filled from the predictor's arena at the start of every tile): the tables
+//     are L2-resident, but a gather costs the L1's address pipeline the same whether it hits or not;
 //   * rows are added to the LDS score array where they arrive (ds_add_u32: integer => order-free => bit-exact);
 //   * what is data-dependent beyond depth 3 is NOT done in place (64 lanes would wait for the unluckiest one): it is
 //     pushed, ballot/mbcnt-compacted, onto wave-private LDS stacks, so that a replay runs one short code path with
 //     every lane busy: W trie steps of dictionary words longer than 3 chars (a step that matches re-queues its
 //     continuation), M the rare rows with a value outside their fields (taken from the general tables);
 //   * UTF-8 decode: the text is staged in LDS, a chunk scan numbers chars and sentences, the thread that scanned a
-//     chunk decodes its chars (branch-free) straight into their flat positions, a second pass maps them to ids;
-//   * 24 KB of LDS and at most 80 VGPRs per workgroup: 6 workgroups per CU.
+//     chunk decodes its chars straight into their flat positions (a 3-byte-only round when the wave's chars allow it),
+//     a second pass maps them to ids;
+//   * a tile is EITHER a run of whole sentences OR a range of flat positions with a halo of max(pattern length) chars on
+//     either side (kernels.hpp, TileDesc): sentences of any length are scored here, by as many tiles as they span.
 #include <hip/hip_runtime.h>
 
 #include <cstddef>
@@ -35,36 +41,42 @@ constexpr uint32_t kQHigh = kQCap - 64;      // replay until one more round of p
 constexpr int kMCap = 64;                    // M items per wave: one round of pushes (<= 64) always fits an empty stack
 constexpr uint32_t kCpMask = 0xFFFFu;        // sym = id (kNoId: in no pattern) | type << 16 | tile-local sentence << 19 | linebreak << 29
 constexpr uint32_t kSymLinebreak = 1u << 29;
+static_assert(kSymLinebreak == kCinfoLinebreak, "the char table's words are symbol words");
 constexpr int kWavesF = kThreads / 64;
 constexpr int kTypeRows = 4;                 // TM value: type rows in LDS (1..3 = window table of that W, 0 = none)
 static_assert(kMargin >= int(kPackedMaxSkip), "replay_w reads up to kPackedMaxSkip symbols past a char");
 constexpr int kTrowCount = int(kTypeRowCount);   // layout.h, type_row_index
+constexpr uint32_t kPad = 3;                 // separator slots between sentences (= the char window)
+constexpr int kSymSlots = kFastCap + kMargin + 4;   // the last one is the DUMP slot: where a char outside the tile's window is written
+constexpr uint32_t kDump = kFastCap + kMargin;
+static_assert(kFastCap % kThreads == 0 && (kFastCharCache & (kFastCharCache - 1)) == 0 && (kFastUniCache & (kFastUniCache - 1)) == 0, "geometry");
 
-template <int CAP>
 struct FastLdsT {
-    uint32_t sym[CAP + kMargin];             // zero except for the tile's chars (scalar value | sentence << 21 until classified)
-    int32_t score[CAP + kMargin];            // staged text bytes during decode
+    uint32_t sym[kSymSlots];                 // zero except for the tile's chars (scalar value | sentence << 21 until classified)
+    int32_t score[kSymSlots];                // staged text bytes during decode
     uint2 queue[kWavesF][kQCap];             // sentence-start bitmap during decode
     uint32_t mqueue[kWavesF][kMCap];
     uint32_t wtot[8];
+    uint32_t cc[kFastCharCache ? kFastCharCache : 4];   // char cache (layout.h)
+    uint4 urow[kFastUniCache ? kFastUniCache : 1];      // unigram cache
+    uint16_t utag[kFastUniCache ? kFastUniCache : 8];
     union {                                  // never needed together; the launch allocates the one in use
-        uint8_t typ[CAP + kMargin];          // window-table modes
+        uint8_t typ[kSymSlots];              // window-table modes
         uint4 trow[kTrowCount];              // TM == kTypeRows
     };
 };
-// the replay routines only index the arrays: they see the layout through the largest geometry's type (sym and score start
-// every geometry; the queues are passed as pointers)
+// the replay routines only index the arrays (the queues are passed as pointers)
 struct FastLds {
     uint32_t* sym;
     int32_t* score;
 };
-template <int CAP>
-constexpr bool fast_lds_ok(int wg_per_cu) {
-    return offsetof(FastLdsT<CAP>, typ) % 16 == 0 && (CAP + kMargin) * 4 % 16 == 0 &&                    // carve offsets stay 16-byte aligned
-           sizeof(uint2) * kWavesF * kQCap >= size_t(CAP) * 4 / 8 + 16 &&                                 // the decode phase's sentence-start bitmap lives in the W queues
-           offsetof(FastLdsT<CAP>, typ) + sizeof(uint4) * kTrowCount <= size_t(128 / wg_per_cu) * 1280;   // gfx950 hands out LDS in 1280-byte granules, 128 per CU
+constexpr bool fast_lds_ok() {
+    return offsetof(FastLdsT, typ) % 16 == 0 && offsetof(FastLdsT, score) % 16 == 0 && offsetof(FastLdsT, cc) % 16 == 0 && offsetof(FastLdsT, urow) % 16 == 0 &&
+           sizeof(uint2) * kWavesF * kQCap >= size_t(kFastCap) * 4 / 8 + 80 &&                              // the decode phase's sentence-start bitmap lives in the W queues
+           sizeof(int32_t) * kSymSlots >= size_t(kFastCap) * 4 + 36 &&                                       // ... and the staged text in the score array
+           offsetof(FastLdsT, typ) + sizeof(uint4) * kTrowCount <= size_t(128 / kFastWg) * 1280;             // gfx950 hands out LDS in 1280-byte granules, 128 per CU
 }
-static_assert(fast_lds_ok<kFastCapSmall>(kFastWgSmall) && fast_lds_ok<kFastCapLarge>(kFastWgLarge), "LDS budget of the two tile geometries");
+static_assert(fast_lds_ok(), "LDS budget of the tile geometry");
 
 __device__ __forceinline__ uint32_t lane_rank(uint64_t mask) {  // set bits of `mask` below this lane
     return __builtin_amdgcn_mbcnt_hi(uint32_t(mask >> 32), __builtin_amdgcn_mbcnt_lo(uint32_t(mask), 0u));
@@ -267,88 +279,108 @@ __device__ __forceinline__ uint64_t phase_mark(uint64_t* prof, int slot, uint64_
 
 // DBG: the diagnostics build (VPT_DEBUG_ABLATE timing ablations, VPT_PROFILE_PHASES) -- compiled out of the kernel
 // production launches use.
-template <int TM, bool DBG, int CAP, int WG>
-__global__ __launch_bounds__(kThreads, WG) void score_tiles_fast_kernel(const ScoreParams P_in) {
+template <int TM, bool DBG>
+__global__ __launch_bounds__(kThreads, kFastWg) void score_tiles_fast_kernel(const ScoreParams P_in) {
     ScoreParams P = P_in;
     if (!DBG) { P.debug = 0; P.prof = nullptr; }
     VPT_DYNAMIC_LDS(smem);
-    FastLdsT<CAP>& M = *reinterpret_cast<FastLdsT<CAP>*>(smem);
+    FastLdsT& M = *reinterpret_cast<FastLdsT*>(smem);
     FastLds L{M.sym, M.score};
-    constexpr int kFastCap = CAP, kPerThread = CAP / kThreads;
+    constexpr int kPerThread = kFastCap / kThreads;
     const int tid = threadIdx.x, lane = tid & 63, wave = int(wave_uniform(uint32_t(tid) >> 6));
     const uint32_t wbase = uint32_t(wave) << 6;   // this wave's first thread, as a scalar
-    constexpr uint32_t pad = 3;
 
-    const uint32_t t = blockIdx.x;
-    uint64_t i0, i1;
-    if (P.tile_first) {
-        i0 = P.tile_first[t]; i1 = P.tile_first[t + 1];
-    } else {   // no assign_tiles_kernel in front: lanes 0 and 1 find the tile's two ends (a few dependent, L2-hot loads)
-        uint64_t mine = 0;
-        if (tid < 2) {
-            const uint32_t tt = t + uint32_t(tid);
-            mine = tt >= P.n_tiles ? P.n_sent : first_sentence_at(P.ooff, P.n_sent, uint64_t(1 + pad), uint64_t(tt) * P.tile_flat);
+    // ---------------------------------------------------------------- the tile
+    // Cut tiles come with a description (kernels.hpp, TileDesc: four scalar loads).  A whole-sentence tile is described by its
+    // first sentence and its neighbour's (the general kernel's assign_tiles_kernel: the cheapest thing in front of this launch); the
+    // rest follows from the offsets of the two -- a second trip of scalar loads that other tiles' work hides.
+    uint64_t i0, byte0, g0;
+    uint32_t nbytes, nsent, flat_len, own_lo, own_hi, expect_chars, strict_end;
+    int32_t c_off, sib0;
+    if (P.tiles) {
+        const TileDesc* const dp = P.tiles + blockIdx.x;
+        nbytes = dp->nbytes;
+        if (nbytes == 0) return;   // an empty tile (past the batch's end; reported as not fitting)
+        i0 = dp->i0; nsent = dp->nsent; flat_len = dp->flat_len; own_lo = dp->own_lo; own_hi = dp->own_hi;
+        c_off = dp->c_off; sib0 = dp->sib0;
+        byte0 = uint64_t(dp->byte0_lo) | (uint64_t(dp->byte0_hi) << 32); g0 = uint64_t(dp->g0_lo) | (uint64_t(dp->g0_hi) << 32);
+        expect_chars = dp->expect_chars; strict_end = dp->strict_end;
+    } else {
+        i0 = P.tile_first[blockIdx.x];
+        const uint64_t i1 = P.tile_first[blockIdx.x + 1];
+        if (i0 >= i1) return;      // no sentence starts in this tile's range
+        const uint64_t O0 = P.ooff[i0], O1 = P.ooff[i1], B0 = P.boff[i0], B1 = P.boff[i1];
+        const uint64_t fl = uint64_t(kPad) + (O1 + i1 * 4) - (O0 + i0 * 4);
+        if (O1 < O0 || B1 <= B0 || fl > uint64_t(kFastCap) || B1 - B0 > uint64_t(kFastCap) * 4 + 15 || i1 - i0 > 1023) {
+            if (tid == 0) atomicOr(P.status, kErrScratchTooSmall);   // a sentence longer than the caller's bound (or offsets that are no offsets)
+            return;
         }
-        if (tid < 2) M.wtot[tid * 2] = uint32_t(mine), M.wtot[tid * 2 + 1] = uint32_t(mine >> 32);
-        __syncthreads();
-        i0 = uint64_t(wave_uniform(M.wtot[0])) | (uint64_t(wave_uniform(M.wtot[1])) << 32);
-        i1 = uint64_t(wave_uniform(M.wtot[2])) | (uint64_t(wave_uniform(M.wtot[3])) << 32);
-        __syncthreads();   // wtot is reused by the scan
+        nsent = uint32_t(i1 - i0); byte0 = B0; nbytes = uint32_t(B1 - B0); c_off = int32_t(kPad); sib0 = -1;
+        flat_len = uint32_t(fl); own_lo = kPad; own_hi = flat_len; g0 = O0 + i0;
+        expect_chars = uint32_t((O1 + i1) - (O0 + i0)); strict_end = 1;
     }
-    if (i0 >= i1) return;
-    const uint64_t O0 = P.ooff[i0], O1 = P.ooff[i1];
-    const uint64_t flat_len64 = uint64_t(pad) + (O1 + i1 * 4) - (O0 + i0 * 4);
-    const uint64_t B0 = P.boff[i0], B1 = P.boff[i1];
-    const uint8_t* tbase = P.text + B0;
+    const uint8_t* tbase = P.text + byte0;
     const uintptr_t a0 = reinterpret_cast<uintptr_t>(tbase) & ~uintptr_t(15);
     const uint32_t head = uint32_t(reinterpret_cast<uintptr_t>(tbase) - a0);
-    const uint64_t nbytes_al64 = head + (B1 - B0);
-    if (flat_len64 > kFastCap || nbytes_al64 > uint64_t(kFastCap) * 4 + 15) {  // does not fit in LDS: defer
-        if (tid == 0) {
-            if (P.scratch_cap == 0) atomicOr(P.status, kErrScratchTooSmall);   // the caller's length bounds were understated
-            else P.slow_list[atomicAdd(P.slow_count, 1u)] = t;
-        }
-        return;
-    }
-    const uint32_t flat_len = uint32_t(flat_len64), nbytes_al = uint32_t(nbytes_al64);
-    const uint32_t nsent = uint32_t(i1 - i0);
-    const uint32_t expect_chars = uint32_t((O1 + i1) - (O0 + i0));
+    const uint32_t nbytes_al = head + nbytes;   // <= 4 * kFastCap + 15 + 16: the assign kernels see to it
     const uint32_t nchunks = (nbytes_al + 15) >> 4;
+    // LDS positions in use, rounded up to whole waves of start positions plus the look-ahead margin: what is zeroed and walked
+    const uint32_t span = ((flat_len + 63u) & ~63u) + uint32_t(kMargin) + 4u < uint32_t(kSymSlots) ? ((flat_len + 63u) & ~63u) + uint32_t(kMargin) + 4u : uint32_t(kSymSlots);
     uint32_t err = 0;
-    if (TM == kTypeRows) {  // 512 type rows -> LDS (not aliased by the decode scratch; barriers follow before use)
-        for (uint32_t i = tid; i < uint32_t(kTrowCount); i += kThreads) M.trow[i] = ld16(P.pk.base, P.pk.off_trow + (i << 4));
-    }
     uint64_t* const prof = P.prof;
     uint64_t tmark = prof ? __builtin_amdgcn_s_memtime() : 0;
 
     // ---------------------------------------------------------------- A. decode
-    // Flat layout: char g of the tile's sentence j sits at pad + g + pad * j, everything else is zero (separators,
-    // the slack past the tile).  The text is staged in LDS (the score array is free until phase B), a chunk scan
-    // numbers the chars and the sentences, and the thread that scanned a chunk decodes its chars straight into
-    // their flat positions; a second pass classifies them (one cache-hot table read each, all in flight together).
+    // Flat layout: lead number ci of the staged text, in the tile's sentence si, sits at c_off + ci + kPad * si; everything else is
+    // zero (separators, the slack past the tile).  The text is staged in LDS (the score array is free until phase B), a chunk
+    // scan numbers the chars and the sentences, and the thread that scanned a chunk decodes its chars straight into their flat
+    // positions; a second pass classifies them.  Chars outside [kPad, flat_len) (a cut tile stages whole 256-byte blocks) go to
+    // the dump slot.
     uint32_t* bitmap = reinterpret_cast<uint32_t*>(&M.queue[0][0]);   // one bit per text byte: a sentence starts here
     uint32_t* raw = reinterpret_cast<uint32_t*>(&L.score[0]);
+    // this thread's sentence (the first 256 of the tile: a tile of more, i.e. of sentences of a char or two, loops below): its
+    // offsets are asked for NOW, together with the text and the tables -- one trip to memory instead of three on the tile's
+    // critical path -- and used after the barriers
+    uint64_t my_b = 0, my_bn = 1, my_oa = 0, my_ob = 0;
+    if (uint32_t(tid) < nsent) { my_b = P.boff[i0 + tid]; my_bn = P.boff[i0 + tid + 1]; my_oa = P.ooff[i0 + tid]; my_ob = P.ooff[i0 + tid + 1]; }
     for (uint32_t i = tid; i < ((nbytes_al + 31) >> 5) + 1; i += kThreads) bitmap[i] = 0;
-    for (uint32_t i = tid; i < (uint32_t(kFastCap + kMargin) * 4) / 16; i += kThreads) reinterpret_cast<uint4*>(L.sym)[i] = make_uint4(0, 0, 0, 0);
+    for (uint32_t i = tid; i < (span + 3) / 4; i += kThreads) reinterpret_cast<uint4*>(L.sym)[i] = make_uint4(0, 0, 0, 0);
     if (TM != kTypeRows) {
-        for (uint32_t i = tid; i < uint32_t(kFastCap + kMargin) / 4; i += kThreads) reinterpret_cast<uint32_t*>(M.typ)[i] = 0;
+        for (uint32_t i = tid; i < (span + 3) / 4; i += kThreads) reinterpret_cast<uint32_t*>(M.typ)[i] = 0;
     }
     for (uint32_t c = tid; c < nchunks; c += kThreads) reinterpret_cast<uint4*>(raw)[c] = reinterpret_cast<const uint4*>(a0)[c];   // (non-temporal loads / stores here measured 1-2 % slower: profiles/r02_c1_ab.jsonl, r02_c3_ab.jsonl)
     if (tid == 0) raw[nchunks * 4] = 0;  // the dword after the staged text is read (as padding) by the last char
-    __syncthreads();
-    for (uint32_t j = tid; j < nsent; j += kThreads) {
-        const uint64_t b = P.boff[i0 + j], bn = P.boff[i0 + j + 1];
-        if (bn <= b) err |= kErrEmptySentence;
-        const uint32_t pos = head + uint32_t(b - B0);
-        atomicOr(&bitmap[pos >> 5], 1u << (pos & 31));
+    // the LDS-resident tables: type rows, char cache, unigram cache (coalesced 16-byte loads from the predictor's arena)
+    if (TM == kTypeRows) {
+        for (uint32_t i = tid; i < uint32_t(kTrowCount); i += kThreads) M.trow[i] = ld16(P.pk.base, P.pk.off_trow + (i << 4));
+    }
+    if (kFastCharCache) {
+        for (uint32_t i = tid; i < uint32_t(kFastCharCache) / 4; i += kThreads) reinterpret_cast<uint4*>(M.cc)[i] = ld16(P.pk.base, P.pk.off_cc + (i << 4));
+    }
+    if (kFastUniCache) {
+        for (uint32_t i = tid; i < uint32_t(kFastUniCache); i += kThreads) M.urow[i] = ld16(P.pk.base, P.pk.off_urow + (i << 4));
+        for (uint32_t i = tid; i < uint32_t(kFastUniCache) / 8; i += kThreads) reinterpret_cast<uint4*>(M.utag)[i] = ld16(P.pk.base, P.pk.off_utag + (i << 4));
     }
     __syncthreads();
+    tmark = phase_mark(prof, 0, tmark);   // zeroing, staging, table loads
+    for (uint32_t j = tid; j < nsent; j += kThreads) {
+        const uint64_t b = j == uint32_t(tid) ? my_b : P.boff[i0 + j], bn = j == uint32_t(tid) ? my_bn : P.boff[i0 + j + 1];
+        if (bn <= b) err |= kErrEmptySentence;
+        if (b >= byte0 && b - byte0 < nbytes) {   // (sentence i0 of a cut tile may have started before the staged text)
+            const uint32_t pos = head + uint32_t(b - byte0);
+            atomicOr(&bitmap[pos >> 5], 1u << (pos & 31));
+        }
+    }
+    __syncthreads();
+    tmark = phase_mark(prof, 1, tmark);   // sentence starts
     uint32_t base_leads = 0, base_starts = 0;
-    uint32_t min_cp = 0xFFFFFFFFu, max_si = 0, max_flat = 0;   // over this thread's chars: NUL / a char outside the tile
+    uint32_t min_lead = 0xFFu;     // over this thread's chars: the smallest lead byte (a NUL char is the byte 0; a cut tile's last staged
+                                   // char may miss its continuation bytes, so the decoded value is not what is looked at)
+    int32_t max_p = -1;            // ... and the last flat position (a char past the tile)
     for (uint32_t c0 = 0; c0 < nchunks; c0 += kThreads) {   // one pass for up to 4 KB of tile text, else two
         const uint32_t c = c0 + tid;
         uint32_t lm = 0, sm = 0;
-        const uint32_t pos0 = c * 16;
+        const uint32_t pos0 = c < nchunks ? c * 16 : 0u;   // (a thread without a chunk still runs the rounds below, at position 0)
         if (c < nchunks) {
             const uint4 v = reinterpret_cast<const uint4*>(raw)[c];
             const uint32_t lo = pos0 < head ? head - pos0 : 0u;
@@ -371,71 +403,110 @@ __global__ __launch_bounds__(kThreads, WG) void score_tiles_fast_kernel(const Sc
         }
         const uint32_t excl = woff + incl - mine;
         const uint32_t ci = base_leads + (excl & 0xFFFFu);
-        const uint32_t si0 = base_starts + (excl >> 16);
+        const int32_t sib = sib0 + int32_t(base_starts + (excl >> 16));   // sentence of a char = sib + starts up to it in this chunk
         base_leads += total & 0xFFFFu;
         base_starts += total >> 16;
         __syncthreads();   // wtot is rewritten by the next pass
         uint32_t m = lm;
-        const uint32_t sib = si0 - 1u;                        // sentence of a char = sib + starts up to it in this chunk
-        uint32_t fb = pad + ci + sib + (sib << 1);            // flat = pad + char index + pad * si (mod 2^32: sib may be -1)
-        while (m) {
-            const uint32_t k = uint32_t(__ffs(int(m))) - 1u;
+        int32_t fb = c_off + int32_t(ci) + 3 * sib;               // flat = c_off + char index + kPad * sentence
+        static_assert(kPad == 3, "fb adds 3 * sib");
+        // Every round takes one char per lane; a three-byte sequence (Japanese text mostly is) decodes with five instructions.
+        while (m != 0) {   // (a loop every lane stays in until the wave's last char, with the idle lanes writing the dump slot, measured
+            const bool has = true;   //  0.5 % slower: profiles/r03_j_ab_m1.jsonl)
+            const uint32_t k = uint32_t(__builtin_ctz(m | 0x10000u));
             m &= m - 1;
             const uint32_t r = uint32_t(__popc(sm & ((2u << k) - 1u)));
-            const uint32_t si = sib + r;                      // 0xFFFFFFFF before the first start
             const uint32_t pos = pos0 + k;
-            const uint32_t cp = utf8_scalar_bf(__builtin_amdgcn_alignbyte(raw[(pos >> 2) + 1], raw[pos >> 2], pos & 3u));
-            const uint32_t flat = fb + __umul24(r, pad);
-            ++fb;
-            static_assert(pad == 3, "fb adds 3 * sib");
-            min_cp = cp < min_cp ? cp : min_cp;
-            max_si = si > max_si ? si : max_si;
-            max_flat = flat > max_flat ? flat : max_flat;
-            if (si < 1024u && flat + pad < uint32_t(kFastCap + kMargin)) L.sym[flat] = cp | (si << 21);   // 21 + 10 bits; classified below
+            const uint32_t w = __builtin_amdgcn_alignbyte(raw[(pos >> 2) + 1], raw[pos >> 2], pos & 3u);
+            uint32_t cp;
+            if ((w & 0xF0u) == 0xE0u) {   // a three-byte sequence (the side of the branch nobody takes is skipped)
+                cp = ((w & 0xFu) << 12) | ((w >> 2) & 0xFC0u) | ((w >> 16) & 0x3Fu);
+            } else {
+                cp = utf8_scalar_bf(w);
+            }
+            const int32_t p = fb + 3 * int32_t(r);
+            if (has) {
+                ++fb;
+                min_lead = (w & 0xFFu) < min_lead ? (w & 0xFFu) : min_lead;
+                max_p = p > max_p ? p : max_p;
+            }
+            const bool inside = has && uint32_t(p - int32_t(kPad)) < flat_len - kPad;   // (p < kPad wraps to a large number)
+            L.sym[inside ? uint32_t(p) : kDump] = cp | (uint32_t(sib + int32_t(r)) << 21);   // 21 + 10 bits; classified below
         }
     }
-    const uint32_t nchars = base_leads;
-    if (nchars != expect_chars) err |= kErrBadOffsets;
-    if (min_cp == 0) err |= kErrNulChar;
-    if (max_si >= 1024u || max_flat + pad >= uint32_t(kFastCap + kMargin)) err |= kErrBadOffsets;   // a char that did not fit
-    tmark = phase_mark(prof, 0, tmark);
+    if (expect_chars != 0xFFFFFFFFu && base_leads != expect_chars) err |= kErrBadOffsets;
+    if (min_lead == 0) err |= kErrNulChar;
+    if (strict_end && max_p >= int32_t(flat_len)) err |= kErrBadOffsets;   // more chars than the offsets promise
+    tmark = phase_mark(prof, 2, tmark);   // chunk scan + decode rounds
     __syncthreads();  // the staged text has been read: the score array can be zeroed; every char is in place
-    for (uint32_t i = tid; i < (uint32_t(kFastCap + kMargin) * 4) / 16; i += kThreads) reinterpret_cast<uint4*>(L.score)[i] = make_uint4(0, 0, 0, 0);
-    {   // classify: table reads first (all in flight together), then the final symbols
+    for (uint32_t i = tid; i < (span + 3) / 4; i += kThreads) reinterpret_cast<uint4*>(L.score)[i] = make_uint4(0, 0, 0, 0);
+    {   // classify: cache probes first, then the table reads of every miss (all in flight together), then the final symbols
         uint32_t xs[kPerThread], info[kPerThread];
+        bool miss[kPerThread];
+        bool any_miss = false;
 #pragma unroll
         for (int k = 0; k < kPerThread; ++k) {
-            xs[k] = L.sym[uint32_t(tid) + uint32_t(k) * kThreads];   // zero past the tile
-            const uint32_t cp = xs[k] & 0x1FFFFFu, idx = cp < 0x10000u ? cp : 0u;
-            // id of the char it is scored as | CharacterType << 16 | linebreak << 19: one word of a 256 KB table (plain, or --
-            // with VPT_FLAG_KYTEA_FULLWIDTH -- the one that looks through KyteaFullwidthFilter)
-            if (DBG && (P.debug & 64u)) info[k] = (cp & 7u) == 0 ? P.cid[idx] : ((cp * 2654435761u) >> 20) | (3u << 16);   // timing ablation: one gather in eight
-            else info[k] = P.cid[idx];
+            xs[k] = 0; info[k] = 0; miss[k] = false;
+            if (wbase + uint32_t(k) * kThreads >= flat_len) continue;   // wave-uniform
+            xs[k] = L.sym[uint32_t(tid) + uint32_t(k) * kThreads];
+            const uint32_t cp = xs[k] & 0x1FFFFFu;
+            // id of the char it is scored as | CharacterType << 16 | linebreak << 29: from the char cache, else one word of a 256 KB
+            // table (plain, or -- with VPT_FLAG_KYTEA_FULLWIDTH -- the one that looks through KyteaFullwidthFilter)
+            bool hit = cp == 0;   // a separator: no lookup at all
+            if (kFastCharCache) {
+                const uint32_t e = M.cc[cp & uint32_t(kFastCharCache - 1)];
+                if ((e >> 16) == cp && cp != 0 && !(DBG && (P.debug & 256u))) { hit = true; info[k] = (e & 0x1FFFu) | ((e << 3) & 0x70000u); }
+            }
+            if (DBG && (P.debug & 64u) && !hit && (cp & 7u) != 0) { hit = true; info[k] = P.cid[0x3042]; }   // timing ablation: one gather in eight (the others: one line)
+            miss[k] = !hit;
+            any_miss = any_miss || !hit;
+        }
+        if (__ballot(any_miss) != 0) {
+#pragma unroll
+            for (int k = 0; k < kPerThread; ++k) {
+                const uint32_t cp = xs[k] & 0x1FFFFFu;
+                if (miss[k]) info[k] = P.cid[cp < 0x10000u ? cp : 0u];
+            }
         }
 #pragma unroll
         for (int k = 0; k < kPerThread; ++k) {
-            const uint32_t cp = xs[k] & 0x1FFFFFu;
-            uint32_t v = (info[k] & 0x7FFFFu) | ((xs[k] >> 21) << 19) | ((info[k] & kCinfoLinebreak) ? kSymLinebreak : 0u);
+            if (wbase + uint32_t(k) * kThreads >= flat_len) continue;   // wave-uniform
+            const uint32_t pos = uint32_t(tid) + uint32_t(k) * kThreads;
+            const uint32_t cp = xs[k] & 0x1FFFFFu, si = xs[k] >> 21;
+            uint32_t v = info[k] | (si << 19);
             if (__ballot(cp >= 0x10000u) != 0) {   // rare: outside the BMP nothing is tabulated (and nothing can match)
-                if (cp >= 0x10000u) v = kNoId | (char_type(cp) << 16) | ((xs[k] >> 21) << 19);
+                if (cp >= 0x10000u) v = kNoId | (char_type(cp) << 16) | (si << 19);
             }
             v = cp != 0 ? v : 0u;                  // a separator (or NUL, which has raised kErrNulChar)
-            L.sym[uint32_t(tid) + uint32_t(k) * kThreads] = v;
+            L.sym[pos] = v;
             if (P.cps_out) {   // wave-uniform: a fill_tags call on this batch follows and wants the chars decoded (it then skips its own pass)
-                const uint32_t flat = uint32_t(tid) + uint32_t(k) * kThreads, si = xs[k] >> 21;
                 const uint32_t scored = (P.cinfo && cp < 0x10000u) ? (P.cinfo[cp] & 0xFFFFu) : cp;   // through KyteaFullwidthFilter when that flag is on
-                if (cp != 0 && flat >= pad * (si + 1u) && flat - pad * (si + 1u) < expect_chars) {
-                    const uint64_t at = (O0 + i0) + (flat - pad * (si + 1u));
+                if (cp != 0 && pos >= own_lo && pos < own_hi) {
+                    const uint64_t at = g0 + uint64_t(int64_t(int32_t(pos) - c_off - 3 * int32_t(si)));
                     if (at < P.total_chars) P.cps_out[at] = scored | (((v >> 16) & 7u) << 24);
                     else err |= kErrBadOffsets;   // out_offsets that run past the total the caller stated
                 }
             }
-            if (TM != kTypeRows) M.typ[uint32_t(tid) + uint32_t(k) * kThreads] = uint8_t((v >> 16) & 7u);
+            if (TM != kTypeRows) M.typ[pos] = uint8_t((v >> 16) & 7u);
         }
     }
     __syncthreads();
+    // the sentences' places, as out_offsets state them, against where the text put them: sentence j of the tile starts at
+    // e = c_off + (its first char's global number - g0) + kPad * j and is followed by a separator -- checked wherever e or its end
+    // falls into the tile's window.  (A sentence longer or shorter than stated moves everything behind it.)
+    for (uint32_t j = tid; j < nsent; j += kThreads) {
+        const uint64_t oa = j == uint32_t(tid) ? my_oa : P.ooff[i0 + j], ob = j == uint32_t(tid) ? my_ob : P.ooff[i0 + j + 1];
+        const int64_t e = int64_t(c_off) + int64_t(oa + i0 + j - g0) + 3 * int64_t(j);
+        const int64_t end = e + int64_t(ob - oa) + 1;
+        if (ob < oa) err |= kErrBadOffsets;
+        if (e >= int64_t(kPad) && e < int64_t(flat_len)) {
+            const uint32_t x = L.sym[e], xm = L.sym[e - 1];
+            if ((x & kCpMask) == 0 || ((x >> 19) & 1023u) != (j & 1023u) || (xm & kCpMask) != 0) err |= kErrBadOffsets;
+        }
+        if (end >= int64_t(kPad) && end < int64_t(flat_len) && (L.sym[end] & kCpMask) != 0) err |= kErrBadOffsets;
+    }
 
-    tmark = phase_mark(prof, 1, tmark);
+    tmark = phase_mark(prof, 3, tmark);   // classify + sentence checks
     // ---------------------------------------------------------------- B. patterns
     // One lane per start position, three trips in flight: trip j loads the TRIGRAM nodes of its own positions
     // (tid + 256 j), the BIGRAM nodes of the next trip's and the UNIGRAM nodes of the positions two trips ahead -- loads
@@ -443,8 +514,125 @@ __global__ __launch_bounds__(kThreads, WG) void score_tiles_fast_kernel(const Sc
     // addresses the next trip needs (child slot = base in the parent + id of the next char; layout.h).
     const PackedView& K = P.pk;
     WaveStacks Q{&M.queue[wave][0], &M.mqueue[wave][0], 0u, 0u};
-    const uint32_t uni_last = K.n_uni - 1u;
     const uint32_t off_bi = K.off_bi & ~255u, off_tri = K.off_tri & ~255u;   // they ARE 256-byte aligned (capi.cpp); now the compiler knows
+#if VPT_FAST_STAGED
+    // STAGE-MAJOR: all of a lane's kPerThread positions go through a level together -- every unigram node in one trip to memory,
+    // then every bigram node, then every trigram node: three waits per tile instead of kPerThread + 2, at the price of the
+    // registers that hold a level's nodes (occupancy kFastWg below 8).
+    if (!(P.debug & 16u)) {   // (timing ablation: no pattern phase at all)
+        uint32_t b_slot[kPerThread], b_key[kPerThread], b_id3[kPerThread];
+        {   // ---- unigram level
+            uint4 u[kPerThread];
+#pragma unroll
+            for (int k = 0; k < kPerThread; ++k) {
+                u[k] = make_uint4(0, 0, 0, 0);
+                if (wbase + uint32_t(k) * kThreads >= flat_len) continue;   // wave-uniform
+                const uint32_t id1 = L.sym[uint32_t(tid) + uint32_t(k) * kThreads] & kCpMask;
+                bool want = id1 != 0 && id1 != kNoId;   // a char no pattern contains has no unigram node (its row is zero, its base unused)
+                if (kFastUniCache) {
+                    const uint32_t slot = id1 & uint32_t(kFastUniCache - 1);
+                    if (want && uint32_t(M.utag[slot]) == id1) { u[k] = M.urow[slot]; want = false; }
+                }
+                if (want) u[k] = ld16(K.base, K.off_uni + (id1 << 4));
+            }
+#pragma unroll
+            for (int k = 0; k < kPerThread; ++k) {
+                b_key[k] = 0; b_slot[k] = 0; b_id3[k] = 0;
+                if (wbase + uint32_t(k) * kThreads >= flat_len) continue;   // wave-uniform
+                const uint32_t s_u = uint32_t(tid) + uint32_t(k) * kThreads;
+                const uint32_t x1 = L.sym[s_u], x2 = L.sym[s_u + 1], x3 = L.sym[s_u + 2];   // the array is zero past the tile
+                const uint32_t id1 = x1 & kCpMask, id2 = x2 & kCpMask;
+                const bool live = id1 != 0;
+                // six 18-bit fields at bits 0, 18, 36, 54, 72, 90 (layout.h); bits 108..126 = the base of the bigram nodes; bit 127 = wide
+                int32_t a0 = sext(u[k].x, kUniFieldBits), a1 = sext(__builtin_amdgcn_alignbit(u[k].y, u[k].x, 18), kUniFieldBits);
+                int32_t a2 = sext(u[k].y >> 4, kUniFieldBits), a3 = sext(__builtin_amdgcn_alignbit(u[k].z, u[k].y, 22), kUniFieldBits);
+                int32_t a4 = sext(u[k].z >> 8, kUniFieldBits), a5 = sext(__builtin_amdgcn_alignbit(u[k].w, u[k].z, 26), kUniFieldBits);
+                if (TM == kTypeRows) {
+                    // a dead lane (t1 = 0) reads the 16 bytes in front of the rows; nothing is added for it
+                    const uint4 tr = M.trow[int32_t(type_row_index((x1 >> 16) & 7u, (x2 >> 16) & 7u, (x3 >> 16) & 7u))];
+                    a0 += int32_t(tr.x << 14) >> 14;
+                    a1 += int32_t(__builtin_amdgcn_alignbit(tr.y, tr.x, 18) << 14) >> 14;
+                    a2 += int32_t(tr.y << 10) >> 14;
+                    a3 += int32_t(__builtin_amdgcn_alignbit(tr.z, tr.y, 22) << 14) >> 14;
+                    a4 += int32_t(tr.z << 6) >> 14;
+                    a5 += int32_t(__builtin_amdgcn_alignbit(tr.w, tr.z, 26) << 14) >> 14;
+                }
+                if (live) add_row6(L.score, s_u, a0, a1, a2, a3, a4, a5);
+                b_slot[k] = id2 < kBiDenseCols ? id1 * kBiDenseCols + id2 : (((u[k].w >> kUniBaseShift) & kUniBaseMask) << K.bi_shift) + id2;
+                b_key[k] = (live && id1 != kNoId && id2 != 0 && id2 != kNoId) ? (id1 | (id2 << 16)) : 0u;
+                b_id3[k] = x3 & kCpMask;
+                const uint64_t mm = __ballot(live && (u[k].w & kUniWideBit));
+                if (mm != 0) {
+                    while (Q.nm + uint32_t(__popcll(mm)) > uint32_t(kMCap)) replay_m(K, P.ct, L, Q, lane);
+                    Q.push_m(live && (u[k].w & kUniWideBit), s_u | (kWideUni << 11));
+                }
+            }
+        }
+        uint32_t t_slot[kPerThread];
+        {   // ---- bigram level: key check, the row, and the address of the trigram node
+            uint4 n0[kPerThread], n1[kPerThread];
+#pragma unroll
+            for (int k = 0; k < kPerThread; ++k) {
+                n0[k] = make_uint4(0, 0, 0, 0); n1[k] = n0[k];
+                if (wbase + uint32_t(k) * kThreads >= flat_len) continue;   // wave-uniform
+                if (b_key[k] != 0) {
+                    const uint32_t a = off_bi + (b_slot[k] << 5);
+                    n0[k] = ld16(K.base, a); n1[k] = ld16(K.base, a | 16u);
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < kPerThread; ++k) {
+                t_slot[k] = ~0u;
+                if (wbase + uint32_t(k) * kThreads >= flat_len) continue;   // wave-uniform
+                const uint32_t s_b = uint32_t(tid) + uint32_t(k) * kThreads;
+                const bool keyok = b_key[k] != 0 && n0[k].x == b_key[k];
+                if (keyok) {
+                    // five 19-bit fields at bits 0, 19, 38, 57, 76 of dwords 1..3 (layout.h); bit 95 = the row is wide (M stack)
+                    int32_t* p = L.score + s_b - 2;
+                    atomicAdd(p, sext(n0[k].y, kBiFieldBits));
+                    atomicAdd(p + 1, sext(__builtin_amdgcn_alignbit(n0[k].z, n0[k].y, 19), kBiFieldBits));
+                    atomicAdd(p + 2, sext(n0[k].z >> 6, kBiFieldBits));
+                    atomicAdd(p + 3, sext(__builtin_amdgcn_alignbit(n0[k].w, n0[k].z, 25), kBiFieldBits));
+                    atomicAdd(p + 4, sext(n0[k].w >> 12, kBiFieldBits));
+                }
+                const uint32_t bit = packed_filter_bit(b_id3[k]);
+                const bool cont = keyok && b_id3[k] != 0 && b_id3[k] != kNoId && (((bit < 32 ? n1[k].y >> bit : n1[k].z >> (bit - 32)) & 1u) != 0);
+                const uint32_t ts = n1[k].x + b_id3[k];         // modulo 2^32 (layout.h); a false positive of the filter may point anywhere
+                t_slot[k] = (cont && ts < K.n_tri) ? ts : ~0u;
+                const uint64_t mm = __ballot(keyok && (n0[k].w & kBiWideBit));
+                if (mm != 0) {
+                    while (Q.nm + uint32_t(__popcll(mm)) > uint32_t(kMCap)) replay_m(K, P.ct, L, Q, lane);
+                    Q.push_m(keyok && (n0[k].w & kBiWideBit), s_b | (kWideBi << 11));
+                }
+            }
+        }
+        {   // ---- trigram level: the node is ours if it names our bigram node as its parent
+            uint4 tn[kPerThread];
+#pragma unroll
+            for (int k = 0; k < kPerThread; ++k) {
+                tn[k] = make_uint4(0, 0, 0, 0);
+                if (wbase + uint32_t(k) * kThreads >= flat_len) continue;   // wave-uniform
+                if (t_slot[k] != ~0u) tn[k] = ld16(K.base, off_tri + (t_slot[k] << 4));
+            }
+#pragma unroll
+            for (int k = 0; k < kPerThread; ++k) {
+                if (wbase + uint32_t(k) * kThreads >= flat_len) continue;   // wave-uniform
+                const uint32_t s_t = uint32_t(tid) + uint32_t(k) * kThreads;
+                const bool hit = t_slot[k] != ~0u && (tn[k].x & kTriParentMask) == b_slot[k] + 1u;
+                if (hit) add_child(L.score, s_t, tn[k].y, tn[k].z);   // a kPkWide node holds zero weights
+                const bool wide = hit && (tn[k].x & (kPkWide << 24));
+                uint32_t kids = hit ? tn[k].w : 0u;
+                drain_w(K, L, Q, lane, kQHigh);                 // room for one more round of pushes
+                Q.push_w(kids != 0, s_t | (3u << 11), kids);
+                const uint64_t mm = __ballot(wide);
+                if (mm != 0) {
+                    while (Q.nm + uint32_t(__popcll(mm)) > uint32_t(kMCap)) replay_m(K, P.ct, L, Q, lane);
+                    Q.push_m(wide, s_t | (kWideTri << 11));
+                }
+            }
+        }
+    }
+#else
     uint32_t b_slot = 0, b_key = 0, b_id3 = 0;   // next trip's bigram stage: node slot, its key (0: no bigram starts there), id of the third char
     uint32_t t_slot = ~0u, t_par = 0;            // this trip's trigram stage: node slot (~0: none) and parent slot + 1
     for (int j = -2; j < kPerThread; ++j) {
@@ -455,19 +643,30 @@ __global__ __launch_bounds__(kThreads, WG) void score_tiles_fast_kernel(const Sc
         const bool do_u = j + 2 < kPerThread && wbase + uint32_t(j + 2) * kThreads < flat_len;
         if (!do_t && !do_b && !do_u) break;
         const uint32_t s_t = uint32_t(tid) + uint32_t(j) * kThreads, s_b = s_t + kThreads, s_u = s_b + kThreads;
-        // ---- every load first
+        // ---- every load first; only lanes that can match issue one
         uint4 tn = make_uint4(0, 0, 0, 0), n0 = make_uint4(0, 0, 0, 0), n1 = make_uint4(0, 0, 0, 0), u = make_uint4(0, 0, 0, 0);
         uint32_t x1 = 0, x2 = 0, x3 = 0;
         if (do_t) { if (t_slot != ~0u) tn = ld16(K.base, off_tri + (((P.debug & 1u) ? 0u : t_slot) << 4)); }
         if (do_b) {
-            const uint32_t a = off_bi + (((P.debug & 1u) ? 0u : b_slot) << 5);
-            n0 = ld16(K.base, a); n1 = ld16(K.base, a | 16u);
+            if (b_key != 0) {
+                const uint32_t a = off_bi + (((P.debug & 1u) ? 0u : b_slot) << 5);
+                n0 = ld16(K.base, a); n1 = ld16(K.base, a | 16u);
+            }
         }
+        bool live = false;
         if (do_u) {
-            x1 = L.sym[s_u]; x2 = L.sym[s_u + 1]; x3 = L.sym[s_u + 2];   // the array is zero past the tile; s_u + 2 < kFastCap + kMargin
+            x1 = L.sym[s_u]; x2 = L.sym[s_u + 1]; x3 = L.sym[s_u + 2];   // the array is zero past the tile; s_u + 2 < kSymSlots
             const uint32_t id1 = x1 & kCpMask;
-            if (DBG && (P.debug & 128u)) { if ((id1 & 3u) == 0) u = ld16(K.base, K.off_uni + ((id1 < uni_last ? id1 : uni_last) << 4)); }   // timing ablation: one unigram node in four
-            else u = ld16(K.base, K.off_uni + (((P.debug & 4u) ? 0u : (id1 < uni_last ? id1 : uni_last)) << 4));
+            live = id1 != 0;
+            bool want = live && id1 != kNoId;   // a char no pattern contains has no unigram node (its row is zero, its base unused)
+            if (kFastUniCache) {
+                const uint32_t slot = id1 & uint32_t(kFastUniCache - 1);
+                if (want && uint32_t(M.utag[slot]) == id1 && !(DBG && (P.debug & 512u))) { u = M.urow[slot]; want = false; }
+            }
+            if (DBG && (P.debug & 128u)) want = want && (id1 & 3u) == 0;   // timing ablation: one unigram node in four
+            if (__ballot(want) != 0) {
+                if (want) u = ld16(K.base, K.off_uni + (((P.debug & 4u) ? 0u : id1) << 4));
+            }
         }
         // ---- trigram stage of positions s_t: the node is ours if it names our bigram node as its parent
         if (do_t) {
@@ -498,7 +697,7 @@ __global__ __launch_bounds__(kThreads, WG) void score_tiles_fast_kernel(const Sc
                 atomicAdd(p + 4, sext(n0.w >> 12, kBiFieldBits));
             }
             const uint32_t bit = packed_filter_bit(b_id3);
-            const bool cont = keyok && b_id3 != 0 && (((bit < 32 ? n1.y >> bit : n1.z >> (bit - 32)) & 1u) != 0);
+            const bool cont = keyok && b_id3 != 0 && b_id3 != kNoId && (((bit < 32 ? n1.y >> bit : n1.z >> (bit - 32)) & 1u) != 0);
             const uint32_t ts = n1.x + b_id3;               // modulo 2^32 (layout.h); a false positive of the filter may point anywhere
             t_slot = (cont && ts < K.n_tri && !(P.debug & 2u)) ? ts : ~0u;
             t_par = b_slot + 1u;
@@ -512,7 +711,6 @@ __global__ __launch_bounds__(kThreads, WG) void score_tiles_fast_kernel(const Sc
         b_key = 0;
         if (do_u) {
             const uint32_t id1 = x1 & kCpMask, id2 = x2 & kCpMask;
-            const bool live = id1 != 0;
             // six 18-bit fields at bits 0, 18, 36, 54, 72, 90 (layout.h); bits 108..126 = the base of the bigram nodes; bit 127 = wide
             int32_t a0 = sext(u.x, kUniFieldBits), a1 = sext(__builtin_amdgcn_alignbit(u.y, u.x, 18), kUniFieldBits);
             int32_t a2 = sext(u.y >> 4, kUniFieldBits), a3 = sext(__builtin_amdgcn_alignbit(u.z, u.y, 22), kUniFieldBits);
@@ -529,8 +727,9 @@ __global__ __launch_bounds__(kThreads, WG) void score_tiles_fast_kernel(const Sc
                 a5 += int32_t(__builtin_amdgcn_alignbit(tr.w, tr.z, 26) << 14) >> 14;
             }
             if (live) add_row6(L.score, s_u, a0, a1, a2, a3, a4, a5);
-            b_slot = (((u.w >> kUniBaseShift) & kUniBaseMask) << K.bi_shift) + id2;
-            b_key = (live && id2 != 0) ? (id1 | (id2 << 16)) : 0u;
+            // the node of a frequent second char sits in the dense matrix, any other in the first char's displaced row (layout.h)
+            b_slot = id2 < kBiDenseCols ? id1 * kBiDenseCols + id2 : (((u.w >> kUniBaseShift) & kUniBaseMask) << K.bi_shift) + id2;
+            b_key = (live && id1 != kNoId && id2 != 0 && id2 != kNoId) ? (id1 | (id2 << 16)) : 0u;
             b_id3 = x3 & kCpMask;
             const uint64_t mm = __ballot(live && (u.w & kUniWideBit) && !(P.debug & 32u));
             if (mm != 0) {
@@ -539,33 +738,36 @@ __global__ __launch_bounds__(kThreads, WG) void score_tiles_fast_kernel(const Sc
             }
         }
     }
+#endif
     while (Q.nm > 0) replay_m(K, P.ct, L, Q, lane);
     while (Q.nw > 0) replay_w(K, L, Q, lane);
-    tmark = phase_mark(prof, 2, tmark);
+    tmark = phase_mark(prof, 4, tmark);   // patterns
     __syncthreads();
-    tmark = phase_mark(prof, 3, tmark);
+    tmark = phase_mark(prof, 5, tmark);   // waiting for the other waves
 
     // ---------------------------------------------------------------- C. boundaries
-    // boundary p lies between flat positions p and p + 1, both chars of one sentence; its output index is the
-    // tile's first boundary + (p - pad) - (pad + 1) * (sentence in tile): 32-bit offsets from scalar bases
-    const uint32_t nb = uint32_t(O1 - O0);
-    int32_t* const sc = P.scores ? P.scores + O0 : nullptr;
-    uint8_t* const lb = P.labels ? P.labels + O0 : nullptr;
+    // boundary p lies between flat positions p and p + 1, both chars of one sentence; the tile writes those in [own_lo, own_hi).
+    // Its output index is (g0 - i0) + (p - c_off) - (kPad + 1) * (sentence in tile): a 32-bit offset from a scalar base.
+    const uint64_t obase = g0 - i0;                            // >= 0: every sentence in front of the tile has a char
+    const uint64_t total_b = P.total_chars - P.n_sent;         // boundaries of the call (or the caller's upper bound of them)
+    const uint32_t o_lim = obase >= total_b ? 0u : (total_b - obase > 0xFFFFFFFFull ? 0xFFFFFFFFu : uint32_t(total_b - obase));
+    int32_t* const sc = P.scores ? P.scores + obase : nullptr;
+    uint8_t* const lb = P.labels ? P.labels + obase : nullptr;
 #pragma unroll
     for (int k = 0; k < kPerThread; ++k) {
-        if (wbase + uint32_t(k) * kThreads + pad + 1 >= flat_len) break;   // wave-uniform
-        const uint32_t p = pad + uint32_t(tid) + uint32_t(k) * kThreads;   // p + 1 < kFastCap + kMargin; zero past the tile
+        if (wbase + uint32_t(k) * kThreads + kPad + 1 >= flat_len) break;   // wave-uniform
+        const uint32_t p = kPad + uint32_t(tid) + uint32_t(k) * kThreads;   // p + 1 < kSymSlots; zero past the tile
         const uint32_t x = L.sym[p], x2 = L.sym[p + 1];
         int32_t y = P.bias + L.score[p];
-        if ((x & kCpMask) == 0 || (x2 & kCpMask) == 0) continue;
+        if ((x & kCpMask) == 0 || (x2 & kCpMask) == 0 || p < own_lo || p >= own_hi) continue;
         if (TM >= 1 && TM <= 3) {
             uint32_t id = 0;  // window t[b-W+1 .. b+W], 3 bits each (boundary_scorer_cache.rs:59-81)
 #pragma unroll
             for (int i = 1 - TM; i <= TM; ++i) id = (id << 3) | (M.typ[int(p) + i] & 7u);
             y += P.type_table[id];
         }
-        const uint32_t o = (p - pad) - (pad + 1) * ((x >> 19) & 1023u);
-        if (o >= nb) { err |= kErrBadOffsets; continue; }  // only with offsets that do not match the text
+        const uint32_t o = uint32_t(int32_t(p) - c_off) - (kPad + 1) * ((x >> 19) & 1023u);
+        if (o >= o_lim) { err |= kErrBadOffsets; continue; }  // only with offsets that do not match the text
         if (sc) sc[o] = y;
         if (lb) {
             uint32_t label = y > 0 ? 1u : 0u;
@@ -578,13 +780,187 @@ __global__ __launch_bounds__(kThreads, WG) void score_tiles_fast_kernel(const Sc
         }
     }
     if (err) atomicOr(P.status, err);
-    phase_mark(prof, 4, tmark);
+    phase_mark(prof, 6, tmark);           // boundaries out
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// The tiles.  F(i) = ooff[i] + i * (1 + kPad) is the flat position of sentence i's first separator; its chars follow at F(i) + kPad.
+// ------------------------------------------------------------------------------------------------------------
+constexpr uint32_t kStageBytes = uint32_t(kFastCap) * 4 + 15;   // what a tile may stage besides its alignment head
+
+__device__ __forceinline__ void put_desc(TileDesc* out, const TileDesc& d) {
+    const uint4* s = reinterpret_cast<const uint4*>(&d);
+    uint4* o = reinterpret_cast<uint4*>(out);
+    o[0] = s[0]; o[1] = s[1]; o[2] = s[2]; o[3] = s[3];
+}
+
+// ---- CUT anywhere.  Index of the text: lead bytes per 256-byte block, so that a tile can start in the middle of a sentence of any
+// length.  Blocks are absolute (block b = bytes [256 b, 256 b + 256) of `text`); a superblock is 256 blocks (64 KB).
+// cut_local[b - first block] = leads in the superblock's earlier blocks, cut_super[s] = leads in the earlier superblocks.
+// (Block positions are relative to `text` rounded DOWN to 16 bytes -- `mis` = what was rounded off -- so that every load is aligned.)
+__global__ __launch_bounds__(256) void cut_count_kernel(const uint8_t* __restrict__ text, uint32_t mis, const uint64_t* __restrict__ boff, uint64_t n_sent,
+                                                        uint32_t* __restrict__ cut_local, uint64_t* __restrict__ cut_super) {
+    __shared__ uint32_t cnt[256];
+    __shared__ uint32_t wsum[4];
+    text -= mis;
+    const uint64_t T0 = boff[0] + mis, T1 = boff[n_sent] + mis;
+    const uint64_t sb0 = T0 >> 16, sb = sb0 + blockIdx.x;
+    if ((sb << 16) >= T1) return;
+    const int tid = threadIdx.x, lane = tid & 63;
+    for (int it = 0; it < 16; ++it) {   // 4 KB per trip: a lane takes 16 bytes, a row of 16 lanes one block
+        const uint64_t at = (sb << 16) + uint64_t(it) * 4096 + uint64_t(tid) * 16;
+        uint32_t n = 0;
+        if (at + 16 > T0 && at < T1) {
+            const uint4 v = *reinterpret_cast<const uint4*>(text + at);   // 16-byte aligned when `text` is; bytes outside the batch are masked
+            const uint32_t lo = at < T0 ? uint32_t(T0 - at) : 0u, hi = T1 - at < 16 ? uint32_t(T1 - at) : 16u;
+            const uint32_t vm = ((1u << hi) - 1u) & ~((1u << lo) - 1u);
+            n = uint32_t(__popc((lead_nibble(v.x) | (lead_nibble(v.y) << 4) | (lead_nibble(v.z) << 8) | (lead_nibble(v.w) << 12)) & vm));
+        }
+        n += uint32_t(__builtin_amdgcn_update_dpp(0, int(n), 0x111, 0xF, 0xF, false));  // row_shr:1 .. 8: lane 15 of a row holds the row's sum
+        n += uint32_t(__builtin_amdgcn_update_dpp(0, int(n), 0x112, 0xF, 0xF, false));
+        n += uint32_t(__builtin_amdgcn_update_dpp(0, int(n), 0x114, 0xF, 0xF, false));
+        n += uint32_t(__builtin_amdgcn_update_dpp(0, int(n), 0x118, 0xF, 0xF, false));
+        if ((lane & 15) == 15) cnt[it * 16 + (tid >> 4)] = n;
+    }
+    __syncthreads();
+    const uint32_t mine = cnt[tid];
+    const uint32_t incl = wave_inclusive_scan(mine);
+    if (lane == 63) wsum[tid >> 6] = incl;
+    __syncthreads();
+    uint32_t before = 0, total = 0;
+    for (int k = 0; k < 4; ++k) { if (k < (tid >> 6)) before += wsum[k]; total += wsum[k]; }
+    cut_local[uint64_t(blockIdx.x) * 256 + uint32_t(tid)] = before + incl - mine;
+    if (tid == 0) cut_super[blockIdx.x + 1] = total;   // scanned in place by the next kernel
+}
+// cut_super[s] -> leads in the superblocks before s (exclusive), one workgroup; n_super_max bounds the array
+__global__ __launch_bounds__(256) void cut_scan_kernel(uint32_t mis, const uint64_t* __restrict__ boff, uint64_t n_sent, uint64_t* __restrict__ cut_super, uint64_t n_super_max) {
+    __shared__ uint32_t wsum[4];
+    __shared__ uint64_t carry_s;
+    const uint64_t T0 = boff[0] + mis, T1 = boff[n_sent] + mis;
+    uint64_t n_super = T1 > T0 ? ((T1 - 1) >> 16) - (T0 >> 16) + 1 : 0;
+    if (n_super > n_super_max) n_super = n_super_max;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    if (tid == 0) { carry_s = 0; cut_super[0] = 0; }
+    __syncthreads();
+    for (uint64_t base = 1; base <= n_super; base += 256) {
+        const uint64_t i = base + uint64_t(tid);
+        const uint32_t v = i <= n_super ? uint32_t(cut_super[i]) : 0u;   // a superblock holds at most 65536 leads
+        const uint32_t incl = wave_inclusive_scan(v);
+        if (lane == 63) wsum[w] = incl;
+        __syncthreads();
+        uint64_t before = carry_s;
+        for (int k = 0; k < w; ++k) before += wsum[k];
+        if (i <= n_super) cut_super[i] = before + incl;   // inclusive over the counts = exclusive for superblock i
+        __syncthreads();
+        if (tid == 255) carry_s = before + incl;
+        __syncthreads();
+    }
+}
+
+struct CutIndex {
+    const uint32_t* local;
+    const uint64_t* super;
+    uint64_t blk0;      // first block of the first superblock
+    uint64_t n_blocks;  // blocks the index covers
+    __device__ __forceinline__ uint64_t leads_before(uint64_t b) const {   // leads in front of block b (b - blk0 <= n_blocks)
+        const uint64_t r = b - blk0;
+        if (r >= n_blocks) return super[n_blocks >> 8];                      // the batch's total (n_blocks is a multiple of 256)
+        return super[r >> 8] + local[r];
+    }
+};
+// the last block b in [lo, hi] with leads_before(b) <= G, or lo - 1 when there is none
+__device__ __forceinline__ uint64_t last_block_le(const CutIndex& X, uint64_t lo, uint64_t hi, uint64_t G) {
+    if (lo > hi || X.leads_before(lo) > G) return lo - 1;
+    uint64_t a = lo, b = hi;   // leads_before(a) <= G
+    // chars are spread almost evenly over a sentence's bytes: start where the straight line says and gallop
+    const uint64_t ga = X.leads_before(lo), gb = X.leads_before(hi);
+    if (gb <= G) return hi;
+    uint64_t g = gb > ga ? lo + uint64_t((unsigned __int128)(G - ga) * (hi - lo) / (gb - ga)) : lo;
+    if (g > hi) g = hi;
+    if (X.leads_before(g) <= G) {
+        a = g;
+        for (uint64_t w = 1;; w <<= 2) { const uint64_t q = a + w < hi ? a + w : hi; if (X.leads_before(q) > G) { b = q; break; } a = q; if (q == hi) return hi; }
+    } else {
+        b = g;
+        for (uint64_t w = 1;; w <<= 2) { const uint64_t q = b > lo + w ? b - w : lo; if (X.leads_before(q) <= G) { a = q; break; } b = q; }
+    }
+    while (b - a > 1) { const uint64_t mid = a + (b - a) / 2; if (X.leads_before(mid) <= G) a = mid; else b = mid; }
+    return a;
+}
+
+// One thread per tile.  Tile t writes the boundaries at flat positions [t * TF, (t + 1) * TF); its window starts halo_left + kPad in front
+// (LDS position 0) and is cap_eff long.
+__global__ __launch_bounds__(256) void assign_tiles_cut_kernel(const uint64_t* __restrict__ boff, const uint64_t* __restrict__ ooff, uint64_t n_sent,
+                                                               CutGeometry Gm, uint32_t n_tiles, const uint32_t* __restrict__ cut_local,
+                                                               const uint64_t* __restrict__ cut_super, uint64_t n_super_max, TileDesc* __restrict__ tiles,
+                                                               uint32_t* __restrict__ ctrl) {
+    const uint32_t t = blockIdx.x * 256u + threadIdx.x;
+    if (t == 1) ctrl[1] = 0;
+    if (t >= n_tiles) return;
+    TileDesc d{};
+    const uint64_t step = 1 + kPad;
+    auto F = [&](uint64_t i) { return ooff[i] + i * step; };
+    const uint64_t total_flat = F(n_sent);
+    const uint64_t own0 = uint64_t(t) * Gm.tile_flat;
+    if (own0 >= total_flat || n_sent == 0) { put_desc(tiles + t, d); return; }
+    const int64_t base = int64_t(own0) - int64_t(Gm.halo_left) - int64_t(kPad);   // global flat position of LDS position 0
+    const uint64_t mis = Gm.mis;   // block positions are relative to `text` rounded down to 16 bytes
+    const uint64_t T0 = boff[0] + mis, T1 = boff[n_sent] + mis;
+    CutIndex X{cut_local, cut_super, (T0 >> 16) << 8, 0};
+    {
+        uint64_t n_super = T1 > T0 ? ((T1 - 1) >> 16) - (T0 >> 16) + 1 : 0;
+        if (n_super > n_super_max) n_super = n_super_max;
+        X.n_blocks = n_super << 8;
+    }
+    // ---- where the staged text starts: the sentence that holds the first flat position the window keeps
+    const uint64_t f_need = base + int64_t(kPad) > 0 ? uint64_t(base + int64_t(kPad)) : 0;
+    const uint64_t i_lo = first_sentence_at(ooff, n_sent, step, f_need + 1) - 1;          // the last sentence with F <= f_need (F(0) = 0)
+    const uint64_t F_lo = F(i_lo), G_lo = ooff[i_lo] + i_lo, B_lo = boff[i_lo], B_lo1 = boff[i_lo + 1];
+    const uint64_t k_need = f_need > F_lo + kPad ? f_need - (F_lo + kPad) : 0;          // chars of it in front of the window
+    uint64_t byte0 = B_lo, g0 = G_lo;
+    if (k_need > 32 && B_lo1 > B_lo) {   // deep inside a long sentence: the last block boundary at or before the first char wanted
+        const uint64_t b_first = (B_lo + mis + 255) >> kCutBlockShift, b_last = (B_lo1 + mis - 1) >> kCutBlockShift;
+        const uint64_t b = last_block_le(X, b_first, b_last, G_lo + k_need);
+        if (b + 1 != b_first && (b << kCutBlockShift) > B_lo + mis) { byte0 = (b << kCutBlockShift) - mis; g0 = X.leads_before(b); }
+    }
+    // ---- where it ends: the window's last position, or the batch's
+    const uint64_t f_end = uint64_t(base + int64_t(Gm.cap_eff));                         // exclusive
+    const bool last = f_end >= total_flat;
+    const uint64_t i_hi = last ? n_sent : first_sentence_at(ooff, n_sent, step, f_end);  // sentences below i_hi start inside the window
+    uint64_t byte1 = boff[i_hi];
+    if (!last && i_hi > 0) {
+        const uint64_t ie = i_hi - 1, Fe = F(ie), Be = boff[ie], Be1 = boff[ie + 1];
+        const uint64_t k_end = f_end > Fe + kPad ? f_end - (Fe + kPad) : 0;              // chars of the last sentence the window holds
+        if (k_end < ooff[ie + 1] - ooff[ie] + 1 && Be1 > Be) {
+            const uint64_t b_first = (Be + mis + 255) >> kCutBlockShift, b_last = (Be1 + mis - 1) >> kCutBlockShift;
+            const uint64_t b = last_block_le(X, b_first, b_last, ooff[ie] + ie + k_end);
+            // block b holds (or precedes) the first char past the window: the text up to the end of block b covers the window
+            const uint64_t cut = (b + 1 == b_first ? (b_first << kCutBlockShift) : ((b + 1) << kCutBlockShift)) - mis;
+            if (cut < byte1) byte1 = cut;
+        }
+    }
+    const uint64_t flat_len = last ? total_flat - uint64_t(base) : uint64_t(Gm.cap_eff);   // (base < total_flat: own0 < total_flat)
+    if (byte1 <= byte0 || byte1 - byte0 > uint64_t(kStageBytes) || flat_len > uint64_t(kFastCap) || i_hi - i_lo > 1023 || B_lo1 < B_lo) {
+        atomicOr(ctrl, kErrBadOffsets);   // only with offsets that do not match the text (4 bytes per char at most)
+        put_desc(tiles + t, d);
+        return;
+    }
+    d.i0 = uint32_t(i_lo); d.nsent = uint32_t(i_hi - i_lo);
+    d.byte0_lo = uint32_t(byte0); d.byte0_hi = uint32_t(byte0 >> 32); d.nbytes = uint32_t(byte1 - byte0);
+    d.c_off = int32_t(int64_t(g0 + kPad * (i_lo + 1)) - base);   // char G of sentence i sits at global flat G + kPad * (i + 1)
+    d.sib0 = byte0 > B_lo ? 0 : -1;
+    d.own_lo = Gm.halo_left + kPad;
+    d.own_hi = d.own_lo + Gm.tile_flat < uint32_t(flat_len) ? d.own_lo + Gm.tile_flat : uint32_t(flat_len);
+    d.flat_len = uint32_t(flat_len);
+    d.g0_lo = uint32_t(g0); d.g0_hi = uint32_t(g0 >> 32);
+    d.expect_chars = 0xFFFFFFFFu; d.strict_end = last ? 1u : 0u;
+    put_desc(tiles + t, d);
 }
 
 }  // namespace
 
 bool fast_path_supported(const ScoreParams& P) {
-    if (!P.pk.present || P.pad != 3 || !P.cid) return false;
+    if (!P.pk.present || P.pad != int(kPad) || !P.cid) return false;
     if (!P.ct.present || P.ct.stride_dw != 8 || P.ct.uni_dw != 8 || P.ct.uni_n != kUniDirectChars) return false;  // kPkWide rows
     if (P.type_kind == kTypeNone) return true;
     return P.type_kind == kTypeWindowTable && P.type_window >= 1 && P.type_window <= 3;
@@ -593,23 +969,18 @@ bool fast_path_supported(const ScoreParams& P) {
 static bool use_type_rows(const ScoreParams& P) {
     return P.type_kind == kTypeWindowTable && P.pk.has_trow && !P.force_window_table;
 }
-size_t score_tiles_fast_lds_bytes(const ScoreParams& P, int cap) {
-    const size_t head = cap == kFastCapSmall ? offsetof(FastLdsT<kFastCapSmall>, typ) : offsetof(FastLdsT<kFastCapLarge>, typ);
-    return head + (use_type_rows(P) ? sizeof(uint4) * kTrowCount : size_t(cap + kMargin));
+size_t score_tiles_fast_lds_bytes(const ScoreParams& P) {
+    return offsetof(FastLdsT, typ) + (use_type_rows(P) ? sizeof(uint4) * kTrowCount : size_t(kSymSlots));
 }
 
-hipError_t launch_score_tiles_fast(const ScoreParams& P, int cap, uint32_t n_tiles, hipStream_t stream) {
+hipError_t launch_score_tiles_fast(const ScoreParams& P, uint32_t n_tiles, hipStream_t stream) {
     const bool rows = use_type_rows(P);
-    size_t lds = score_tiles_fast_lds_bytes(P, cap);
-    lds += P.lds_pad;  // occupancy experiments
+    const size_t lds = score_tiles_fast_lds_bytes(P) + P.lds_pad;  // (the pad: occupancy experiments)
     const int tm = rows ? kTypeRows : P.type_kind == kTypeWindowTable ? P.type_window : 0;
     const bool dbg = P.debug != 0 || P.prof != nullptr;
-    if (cap != kFastCapSmall && cap != kFastCapLarge) return hipErrorInvalidValue;
-#define VPT_LAUNCH_FAST2(TM_, DBG_)                                                                                                          \
-    if (cap == kFastCapSmall) hipLaunchKernelGGL((score_tiles_fast_kernel<TM_, DBG_, kFastCapSmall, kFastWgSmall>), dim3(n_tiles), dim3(kThreads), lds, stream, P); \
-    else hipLaunchKernelGGL((score_tiles_fast_kernel<TM_, DBG_, kFastCapLarge, kFastWgLarge>), dim3(n_tiles), dim3(kThreads), lds, stream, P);
-#define VPT_LAUNCH_FAST(TM_)                                  \
-    if (dbg) { VPT_LAUNCH_FAST2(TM_, true) } else { VPT_LAUNCH_FAST2(TM_, false) } \
+#define VPT_LAUNCH_FAST(TM_)                                                                                                                  \
+    if (dbg) hipLaunchKernelGGL((score_tiles_fast_kernel<TM_, true>), dim3(n_tiles), dim3(kThreads), lds, stream, P);                      \
+    else hipLaunchKernelGGL((score_tiles_fast_kernel<TM_, false>), dim3(n_tiles), dim3(kThreads), lds, stream, P);                        \
     break;
     switch (tm) {
         case 0: VPT_LAUNCH_FAST(0)
@@ -620,7 +991,25 @@ hipError_t launch_score_tiles_fast(const ScoreParams& P, int cap, uint32_t n_til
         default: return hipErrorInvalidValue;
     }
 #undef VPT_LAUNCH_FAST
-#undef VPT_LAUNCH_FAST2
+    return hipGetLastError();
+}
+
+void cut_index_entries(uint64_t total_chars_bound, size_t* n_local, size_t* n_super) {
+    // a char takes at most 4 bytes; the batch's text may start and end inside a superblock
+    const uint64_t supers = ((total_chars_bound * 4) >> 16) + 2;
+    *n_super = size_t(supers + 1);
+    *n_local = size_t(supers << 8);
+}
+
+hipError_t launch_assign_tiles_cut(const ScoreParams& P, const CutGeometry& G, uint32_t n_tiles, uint64_t total_chars_bound, uint32_t* cut_local,
+                                   uint64_t* cut_super, TileDesc* tiles, uint32_t* ctrl, hipStream_t stream) {
+    size_t n_local = 0, n_super = 0;
+    cut_index_entries(total_chars_bound, &n_local, &n_super);
+    const uint64_t supers = uint64_t(n_super - 1);
+    hipLaunchKernelGGL(cut_count_kernel, dim3(uint32_t(supers)), dim3(256), 0, stream, P.text, G.mis, P.boff, P.n_sent, cut_local, cut_super);
+    hipLaunchKernelGGL(cut_scan_kernel, dim3(1), dim3(256), 0, stream, G.mis, P.boff, P.n_sent, cut_super, supers);
+    hipLaunchKernelGGL(assign_tiles_cut_kernel, dim3((n_tiles + 255) / 256), dim3(256), 0, stream, P.boff, P.ooff, P.n_sent, G, n_tiles, cut_local, cut_super,
+                       supers, tiles, ctrl);
     return hipGetLastError();
 }
 

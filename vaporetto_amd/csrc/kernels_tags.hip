@@ -338,7 +338,7 @@ __device__ __forceinline__ void tag_pass(const TagParams& P, TagWaveLds& L, uint
     __builtin_amdgcn_wave_barrier();
     if (P.scores_out) {   // wave-uniform.  Predictor::store_tag_scores: lanes over (token, score), 4 tokens per 64 lanes
 #pragma unroll
-        for (int q0 = 0; q0 < kTagPass * kTagFastZ / 64; ++q0) {
+        for (int q0 = 0; q0 < kTagPass * int(kTagFastZ) / 64; ++q0) {
             const uint32_t t = uint32_t(q0) * 4u + (uint32_t(lane) >> 4), i = uint32_t(lane) & 15u;
             if (t < nq && i < (L.f.tok[t][5] & 0xFFu) && i < P.score_stride) {
                 const uint64_t gp = uint64_t(L.f.tok[t][1]) | (uint64_t(L.f.tok[t][2]) << 32);

@@ -45,14 +45,18 @@
 // else's node knows it).  The three dependent loads of a position are software-pipelined over three iterations of the
 // kernel's main loop, so every iteration still waits once.
 //
-//   ids    pattern symbols are renumbered 1 .. n_alpha in code-point order (the alphabet of the model: every char of
-//          every n-gram and dictionary word); the kernel's char classification table (cinfo, below) maps a text char
-//          to its id, 0xFFFF (kNoId) when no pattern contains it.  0 stays "outside the sentence".
+//   ids    pattern symbols are renumbered 1 .. n_alpha (the alphabet of the model: every char of every n-gram and dictionary
+//          word), the char that the most pattern symbols are first: a small id is a frequent char.  The kernel's char
+//          classification table (cid, below) maps a text char to its id, 0xFFFF (kNoId) when no pattern contains it.  0 stays
+//          "outside the sentence".
 //   cinfo  65536 words per mode (plain / through KyteaFullwidthFilter): id | CharacterType << 16 | linebreak << 19
 //   uni    n_alpha + 2 rows of 16 bytes indexed by id (row 0 and the last row are zero: separators, chars outside the
 //          alphabet): six signed 18-bit fields (boundaries s-3 .. s+2) at bits 0, 18, .., 90; bits 108..126 = B1, the
 //          base of this char's bigram nodes in units of (1 << bi_shift) nodes; bit 127 = kUniWideBit
-//   bi     32-byte bigram nodes, node (id1, id2) at slot (B1[id1] << bi_shift) + id2:
+//   bi     32-byte bigram nodes, node (id1, id2) at slot (B1[id1] << bi_shift) + id2 of its first char's displaced row.  (Build option
+//          kBiDenseCols > 0: the nodes of the kBiDenseCols most frequent second chars sit in a dense matrix at the head of the array
+//          instead, slot id1 * kBiDenseCols + id2, a row's nodes four to a cache line -- an experiment in L2 locality that measured
+//          no gain, off by default.)
 //            dword 0      key = id1 | id2 << 16 (0 = free)
 //            dwords 1..3  the bigram row: five signed 19-bit fields (boundaries s-2 .. s+2) at bits 0, 19, .., 76 of the
 //                         96; bit 95 = kBiWideBit (the row has a value outside its fields: it comes from the general tables)
@@ -118,7 +122,15 @@ constexpr uint32_t kUniBaseShift = 12, kUniBaseMask = 0x7FFFFu;   // dword 3 of 
 constexpr uint32_t kUniWideBit = 0x80000000u;  // dword 3 of a unigram node: the row is in the general tables (i32)
 constexpr uint32_t kBiWideBit = 0x80000000u;   // dword 3 of a bigram node: likewise
 constexpr uint32_t kTriParentMask = 0xFFFFFFu; // dword 0 of a trigram node: parent slot + 1; cflags above
-constexpr uint32_t kCinfoLinebreak = 1u << 19; // cinfo word: the (scored) char is '\n' or '\r'
+constexpr uint32_t kCinfoLinebreak = 1u << 29; // cid word: the (scored) char is '\n' or '\r' (where the kernel's symbol word keeps it)
+constexpr uint32_t kCharCacheNoEntry = 0u;     // char cache (layout below): an empty slot
+#ifndef VPT_BI_DENSE
+#define VPT_BI_DENSE 0    // measured on MI355X (profiles/r03_f_ab_*.jsonl, r03_j_ab_m1.jsonl): 16 / 64 columns 1 % slower than none on M1, 256 columns
+#endif                    // 1-2 % faster on M1 and M2 for 32 MB of matrix -- within the noise of either; the displaced rows alone serve
+constexpr uint32_t kBiDenseCols = VPT_BI_DENSE;   // second chars (ids below this) whose bigram nodes live in the dense matrix (A/B builds: -D)
+// CHAR CACHE (LDS): slot cp & (entries - 1) holds  cp << 16 | CharacterType << 13 | id  of ONE char with that slot index -- the one
+// that the most patterns contain -- or 0; only chars of the alphabet with ids below 0x1FFF that are no line breaks are cached.
+// UNIGRAM CACHE (LDS): slot id & (nodes - 1) holds the unigram node of one id with that slot index (utag = the id, 0: empty).
 
 #if defined(__HIPCC__)
 #define VPT_HD __host__ __device__ __forceinline__
@@ -200,6 +212,7 @@ struct PatternTableView {
 struct PackedView {
     const unsigned char* base;
     uint32_t off_uni, off_bi, off_tri, off_deep, off_xrows, off_trow, off_cpid;   // byte offsets, 256-byte aligned
+    uint32_t off_cc, off_utag, off_urow;   // the LDS-resident caches' contents (off_cc: for the batch's char table mode)
     uint32_t n_uni;                 // unigram nodes (ids above n_uni - 1 read the last, all-zero one)
     uint32_t n_tri;                 // trigram nodes (a filter false positive may point past them)
     uint32_t bi_shift;              // bigram slot = (B1 << bi_shift) + id2

@@ -315,19 +315,24 @@ struct Placer {
 HostPackedTable build_packed(const PatSet& S) {
     StageTimer tm;
     HostPackedTable t;
-    // ---- the alphabet: ids in code-point order
+    // ---- the alphabet: ids by how many pattern symbols the char is (most first; ties in code-point order)
     {
         std::vector<uint8_t> seen(65536, 0);
+        t.hot.assign(65536, 0);
         for (const PatRef& p : S.p)
             for (uint32_t i = 0; i < p.n; ++i) {
                 const Sym c = S.s(p)[i];
                 if (c == 0 || c >= kNoId) return t;
                 seen[c] = 1;
+                ++t.hot[c];
             }
         t.id_of.assign(65536, uint16_t(kNoId));
         t.cpid.push_back(0);
+        std::vector<uint32_t> order;
         for (uint32_t cp = 1; cp < kNoId; ++cp)
-            if (seen[cp]) { t.id_of[cp] = uint16_t(t.cpid.size()); t.cpid.push_back(cp); }
+            if (seen[cp]) order.push_back(cp);
+        std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return t.hot[a] > t.hot[b]; });
+        for (uint32_t cp : order) { t.id_of[cp] = uint16_t(t.cpid.size()); t.cpid.push_back(cp); }
         t.n_alpha = uint32_t(t.cpid.size() - 1);
         t.cpid.push_back(0);   // the id every char outside the alphabet reads its (zero) unigram node at
     }
@@ -368,7 +373,7 @@ HostPackedTable build_packed(const PatSet& S) {
             prev = &p;
         }
     }
-    // children lists (CSR, in symbol order: a parent's children are created in that order)
+    // children lists (CSR, in code-point order: a parent's children are created in that order; the placements sort them by id)
     std::vector<uint32_t> nkid_off(nodes.size() + 1, 0), pkid_off(prefixes.size() + 1, 0), nkid(0), pkid(0);
     for (const Node& nd : nodes) ++(nd.depth == 3 ? pkid_off : nkid_off)[nd.parent + 1];
     for (size_t i = 0; i < nodes.size(); ++i) nkid_off[i + 1] += nkid_off[i];
@@ -463,26 +468,44 @@ HostPackedTable build_packed(const PatSet& S) {
             rows.push_back({prefixes[pi].key & 0xFFFFu, pi, e - pi});
             pi = e;
         }
-        std::stable_sort(rows.begin(), rows.end(), [](const Row& x, const Row& y) { return x.count > y.count; });
+        // the dense matrix at the head of the array takes the nodes whose second char is frequent (layout.h); the displaced rows
+        // hold the rest and start behind it
+        const size_t dense_slots = size_t(t.n_alpha + 2) * kBiDenseCols;
+        struct Col { uint32_t id2, pi; };
+        std::vector<std::vector<Col>> rest(rows.size());
+        for (size_t ri = 0; ri < rows.size(); ++ri) {
+            const Row& r = rows[ri];
+            for (uint32_t j = 0; j < r.count; ++j) {
+                const uint32_t id2 = prefixes[r.first + j].key >> 16;
+                if (id2 < kBiDenseCols) prefixes[r.first + j].slot = r.id1 * kBiDenseCols + id2;
+                else rest[ri].push_back({id2, r.first + j});
+            }
+            std::sort(rest[ri].begin(), rest[ri].end(), [](const Col& a, const Col& b) { return a.id2 < b.id2; });   // ids are not in code-point order
+        }
+        std::vector<uint32_t> by_size(rows.size());
+        for (uint32_t i = 0; i < rows.size(); ++i) by_size[i] = i;
+        std::stable_sort(by_size.begin(), by_size.end(), [&](uint32_t x, uint32_t y) { return rest[x].size() > rest[y].size(); });
         std::vector<uint32_t> cols;
         // a first guess at the alignment the 19-bit base needs (no interleaving at all would take one span per row; half of
         // that is typical), raised if the placement does not fit
-        size_t spans = 0;
-        for (const Row& r : rows) spans += (prefixes[r.first + r.count - 1].key >> 16) - (prefixes[r.first].key >> 16) + 1;
+        size_t spans = dense_slots;
+        for (const auto& r : rest) if (!r.empty()) spans += r.back().id2 - r.front().id2 + 1;
         t.bi_shift = 2;
         while (t.bi_shift < 8 && (size_t(kUniBaseMask) << t.bi_shift) < spans / 2) ++t.bi_shift;
         for (;; ++t.bi_shift) {
             if (t.bi_shift > 8) return t;   // not placeable within the format: the general tables serve the model
             Placer pl(8192, 8192);
+            for (size_t i = 0; i < dense_slots; ++i) pl.occ.set(i);
             bool ok = true;
-            size_t top = 0;
-            for (const Row& r : rows) {
+            size_t top = dense_slots;
+            for (uint32_t ri : by_size) {
+                if (rest[ri].empty()) continue;
                 cols.clear();
-                for (uint32_t j = 0; j < r.count; ++j) cols.push_back(prefixes[r.first + j].key >> 16);   // ascending
+                for (const Col& c : rest[ri]) cols.push_back(c.id2);   // ascending
                 const size_t d = pl.put(cols.data(), cols.size(), size_t(1) << t.bi_shift) - cols[0];
                 if ((d >> t.bi_shift) > kUniBaseMask) { ok = false; break; }
-                b1[r.id1] = uint32_t(d >> t.bi_shift);
-                for (uint32_t j = 0; j < r.count; ++j) prefixes[r.first + j].slot = uint32_t(d + cols[j]);
+                b1[rows[ri].id1] = uint32_t(d >> t.bi_shift);
+                for (const Col& c : rest[ri]) prefixes[c.pi].slot = uint32_t(d + c.id2);
                 top = std::max(top, d + cols.back() + 1);
             }
             if (ok) { bi_slots = top; break; }
@@ -511,7 +534,8 @@ HostPackedTable build_packed(const PatSet& S) {
         std::vector<uint32_t> cols;
         for (uint32_t pi : order) {
             cols.clear();
-            for (uint32_t j = pkid_off[pi]; j < pkid_off[pi + 1]; ++j) cols.push_back(nodes[pkid[j]].sym);   // ascending
+            for (uint32_t j = pkid_off[pi]; j < pkid_off[pi + 1]; ++j) cols.push_back(nodes[pkid[j]].sym);
+            std::sort(cols.begin(), cols.end());   // ascending (ids are not in code-point order)
             const size_t first = pl.put(cols.data(), cols.size(), 1);
             b2[pi] = uint32_t(first) - cols[0];   // modulo 2^32: a row of high ids may start below slot cols[0]
             for (uint32_t j = pkid_off[pi]; j < pkid_off[pi + 1]; ++j) tri_slot[pkid[j]] = uint32_t(first + (nodes[pkid[j]].sym - cols[0]));

@@ -39,6 +39,7 @@ struct HostPackedTable {
     std::vector<uint32_t> trow;    // kTypeRowCount type rows x 4 dwords, empty when the type n-grams do not fit the form
     std::vector<uint32_t> cpid;    // n_alpha + 2: id -> code point
     std::vector<uint16_t> id_of;   // 65536: BMP code point -> id (kNoId: no pattern contains it)
+    std::vector<uint32_t> hot;     // 65536: how many pattern symbols are this code point (what the LDS caches of the kernel are filled by)
     uint32_t n_alpha = 0, bi_shift = 2;
     // statistics
     uint32_t n_bi = 0, n_tri = 0, n_deep = 0, n_wide = 0;
