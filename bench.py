@@ -11,6 +11,7 @@ The workloads are BASELINE.json's configs:
   configs[3]  jp-0.4.7-5-shaped model (synthetic M2, dictionary heavy), 100 K x 64
   configs[4]  M1 + tag models (synthetic M3), predict_tags on, 1 M sentences of 8..512 chars / N, step = predict + fill_tags
   documents   (not a BASELINE config) M1, 10 K sentences of 2 000..20 000 chars: every sentence is cut across many tiles
+  charw2 / charw4  (not BASELINE configs) M1 trained with --charw 2 --typew 2 / --charw 4 --typew 4, 100 K x 64
 
 ONE workload over the whole 1 -> 8 curve: with no --config the `value` is configs[2] at every N (the north-star's "10 M-sentence
 synthetic batch"; it fits one GPU), so that a scaling curve built from the per-N values compares like with like.  N = 1 also
@@ -54,6 +55,10 @@ CONFIGS = {
     # not a BASELINE config: whole documents as ONE sentence each, what the reference's tantivy adapter feeds Predictor::predict
     # (vaporetto_tantivy/src/lib.rs:171-176) -- every sentence spans many tiles
     5: dict(name="documents", kind=1, sentences=10_000, min_len=2_000, max_len=20_000, tags=False, blocks=False),
+    # the windows are free parameters of the trainer (train/src/main.rs:33-51): M1 trained with --charw 2 --typew 2 (laid out in the rows
+    # of window 3: the specialised kernel) and with --charw 4 --typew 4 (the general tables and kernel)
+    6: dict(name="charw2", kind=4, sentences=100_000, min_len=64, max_len=64, tags=False, blocks=False),
+    7: dict(name="charw4", kind=5, sentences=100_000, min_len=64, max_len=64, tags=False, blocks=False),
 }
 BLOCK = 100_000
 
@@ -61,7 +66,7 @@ BLOCK = 100_000
 def load_model_bytes(kind: int, scale: float):
     """A real model when $VAPORETTO_MODEL_DIR holds one (zstd, as distributed), else the synthetic stand-in."""
     from vaporetto_amd import synth
-    name = {1: "bccwj-suw+unidic", 2: "jp-0.4.7-5", 3: "bccwj-suw+unidic_pos+pron"}[kind]
+    name = {1: "bccwj-suw+unidic", 2: "jp-0.4.7-5", 3: "bccwj-suw+unidic_pos+pron", 4: "bccwj-suw+unidic-charw2", 5: "bccwj-suw+unidic-charw4"}[kind]
     d = os.environ.get("VAPORETTO_MODEL_DIR")
     if d:
         path = os.path.join(d, name + ".model.zst")
@@ -79,7 +84,7 @@ def load_model_bytes(kind: int, scale: float):
             from vaporetto_amd import kytea
             with open(path, "rb") as fh:
                 return kytea.convert(fh.read()), name
-    return synth.synth_model(kind, synth.SEED_BASE + 2, scale), "synthetic-" + {1: "M1", 2: "M2", 3: "M3"}[kind]
+    return synth.synth_model(kind, synth.SEED_BASE + 2, scale), "synthetic-" + {1: "M1", 2: "M2", 3: "M3", 4: "M1-charw2-typew2", 5: "M1-charw4-typew4"}[kind]
 
 
 def kernel_source_hash() -> str:
@@ -512,7 +517,7 @@ def parse_args(argv=None):
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--config", type=int, default=0, choices=[0, 1, 2, 3, 4, 5],
+    ap.add_argument("--config", type=int, default=0, choices=[0, 1, 2, 3, 4, 5, 6, 7],
                     help="BASELINE.json configs index (0: configs[2] as the value at every N, plus -- at N = 1 -- the others as `workloads`)")
     ap.add_argument("--quick", action="store_true", help="the primary workload only")
     ap.add_argument("--sentences", type=int, default=0, help="override the config's sentence count (diagnostics; traffic is then not reported)")
@@ -708,7 +713,7 @@ def main():
     prim = R.run(primary_id, primary=True, e2e_leg=(primary_id == 1))
     extra = []
     if not args.config and not args.quick and R.world == 1:
-        for cid in (1, 3, 4, 5):
+        for cid in (1, 3, 4, 5, 6, 7):
             extra.append(R.run(cid, primary=False, e2e_leg=(cid == 1)))
     if R.rank == 0:
         line = {

@@ -109,8 +109,22 @@ def test_random_models_vs_oracle(seed):
 def test_window_sizes(wc, wt):
     m = randmodel.rand_model(100 + wc * 10 + wt, alphabet="tiny", wc=wc, wt=wt, max_n=4, n_char=40, n_type=30)
     pred, orc = make_predictor(m)
+    info = pred.info()
+    assert info["char_window"] == wc
+    # char windows 1 and 2 are laid out in the rows of window 3 (train/src/main.rs:33-51 lets --charw be anything) and run on the
+    # packed tables / the specialised kernel like the distributed models; wider ones take the general tables
+    assert info["packed"] == (1 if 1 <= wc <= 3 else 0)
     texts = randmodel.rand_sentences(wc * 10 + wt, m, 200, alphabet="tiny", max_len=30)
+    texts += randmodel.rand_sentences(wc * 10 + wt + 1, m, 6, alphabet="tiny", min_len=1500, max_len=4000)
     check_batch(pred, orc, texts)
+    if 1 <= wc <= 3 and wt <= 3:
+        batch = api.DeviceBatch(pred)
+        utf8, boff = api.pack_texts([t.encode("utf-8") for t in texts[:50]])
+        ooff = api.count_boundaries(utf8, boff)
+        d = [devmem.put(np.concatenate([utf8, np.zeros(32, np.uint8)])), devmem.put(boff), devmem.put(ooff), devmem.zeros(int(ooff[-1]) + 1, np.int32), devmem.zeros(int(ooff[-1]) + 1, np.uint8)]
+        batch.predict(d[0].ptr, d[1].ptr, d[2].ptr, 50, int(ooff[-1]), int(np.max(np.diff(boff.astype(np.int64)))), d[3].ptr, d[4].ptr, devmem.stream())
+        batch.sync()
+        assert batch.last_plan()["kind"] == "whole-sentence tiles"      # i.e. the specialised kernel
 
 
 @pytest.mark.parametrize("seed", range(6))

@@ -139,10 +139,20 @@ def test_packed_not_eligible_models_fall_back(tc):
     m = ModelData(**base)
     m.dict_model.append(WordWeightRecord("a￿", [1, 2, 3], ""))
     assert not Walker(tc, encode_model(m)).packed
-    # another char window
-    m = ModelData(bias=3, char_window_size=2, type_window_size=3)
-    m.char_ngram_model.append(NgramData("あ", [1, 2, 3, 4]))
+    # a char window above 3 (windows 1 and 2 are laid out in the rows of window 3 and ARE eligible)
+    m = ModelData(bias=3, char_window_size=4, type_window_size=3)
+    m.char_ngram_model.append(NgramData("あ", [1, 2, 3, 4, 5, 6, 7, 8]))
     assert not Walker(tc, encode_model(m)).packed
+    for wc, w in ((2, [1, 2, 3, 4]), (1, [5, 6])):
+        m = ModelData(bias=3, char_window_size=wc, type_window_size=3)
+        m.char_ngram_model.append(NgramData("あ", w))
+        m.char_ngram_model.append(NgramData("あい", w[:2 * wc - 1]))
+        m.dict_model.append(WordWeightRecord("あいう", [9, 8, 7, 6], ""))
+        wk = Walker(tc, encode_model(m))
+        assert wk.packed
+        orc = cbind.OraclePredictor(encode_model(m))
+        for t in ("あ", "あい", "ああいういあ", "いあいうあ"):
+            assert wk.score(t, [0, 0, 0, 0]) == orc.predict(t)[0], (wc, t)
     # and the plain eligible case
     m = ModelData(**base)
     m.char_ngram_model.append(NgramData("あ", [1, 2, 3, 4, 5, 6]))

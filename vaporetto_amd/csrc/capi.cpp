@@ -179,7 +179,7 @@ void fill_info(const vpt::CompiledModel& c, vpt_model_info* info) {
     info->n_char_ngrams = c.n_char_ngrams; info->n_type_ngrams = c.n_type_ngrams;
     info->n_dict_words = c.n_dict_words; info->n_tag_models = c.n_tag_models;
     info->bias = c.bias;
-    info->char_window = c.chars.present ? uint32_t(c.chars.window) : 0;
+    info->char_window = c.chars.present ? uint32_t(c.char_window) : 0;
     info->type_window = uint32_t(c.type_window);
     info->max_pattern_chars = c.chars.max_pattern;
     info->n_short_entries = c.chars.n_short; info->n_long_nodes = c.chars.n_long_nodes;

@@ -39,8 +39,12 @@ bool has_zero(const SymString& s) {
     return false;
 }
 
-// n-gram weights: w[k] -> boundary start + n-1-W + k   (offset -W from the END position, boundary_scorer.rs:63)
-void add_ngram(PatSet& out, const SymString& g, const std::vector<int32_t>& w, int W, bool is_char) {
+// n-gram weights: w[k] -> boundary start + n-1-W + k   (offset -W from the END position, boundary_scorer.rs:63).
+// WL >= W is the window the ROW is laid out for (row_lo / row_len): a model trained with a char window of 1 or 2 is stored in
+// the rows of window 3 -- its weights at the boundaries they belong to, zeros around them -- and so runs on the tables and the
+// kernel of the window every distributed model has (train/src/main.rs:33-51 lets --charw be anything).
+void add_ngram(PatSet& out, const SymString& g, const std::vector<int32_t>& w, int W, bool is_char, int WL = 0) {
+    if (WL < W) WL = W;
     const int n = int(g.size());
     if (n == 0) throw ModelError("InvalidModelError: failed to build the automaton");  // daachorse rejects ""
     const int cap = std::max(0, 2 * W - n + 1);
@@ -48,8 +52,8 @@ void add_ngram(PatSet& out, const SymString& g, const std::vector<int32_t>& w, i
         throw ModelError(std::string("InvalidModelError: ") + (is_char ? "character" : "character type") +
                          " n-gram weight vector is longer than 2*window_size-n+1");
     if (w.empty() || has_zero(g)) return;  // contributes nothing / can never match a sentence
-    int32_t* row = out.add(g, size_t(row_len(n, W)));
-    const int base = (n - 1 - W) - row_lo(n, W);
+    int32_t* row = out.add(g, size_t(row_len(n, WL)));
+    const int base = (n - 1 - W) - row_lo(n, WL);   // >= 0: row_lo(n, WL) <= n - 1 - WL <= n - 1 - W
     for (size_t k = 0; k < w.size(); ++k) row[size_t(base) + k] = w[k];
 }
 
@@ -898,17 +902,20 @@ CompiledModel compile_model(const ModelData& m, bool predict_tags) {
             for (const auto& d : m.dict) { n_syms += d.word.size(); n_rows += size_t(row_len(int(d.word.size()), wc)); }
             pats.reserve(m.char_ngrams.size() + m.dict.size(), n_syms, n_rows);
         }
-        for (const auto& d : m.char_ngrams) add_ngram(pats, d.ngram, d.weights, wc, true);
-        for (const auto& d : m.dict) add_word(pats, d.word, d.weights, wc);
+        // windows 1 and 2 are laid out as window 3 (add_ngram): the packed tables and the specialised kernel take them
+        const int wl = wc < 3 ? 3 : wc;
+        c.char_window = wc;
+        for (const auto& d : m.char_ngrams) add_ngram(pats, d.ngram, d.weights, wc, true, wl);
+        for (const auto& d : m.dict) add_word(pats, d.word, d.weights, wl);
         tm.mark("pattern rows");
         pats.finish();
         tm.mark("sort + merge");
         // the general and the packed tables are independent of each other: two threads
         std::exception_ptr packed_err;
         std::thread packed_thread([&] {
-            try { if (wc == 3) c.packed = build_packed(pats); } catch (...) { packed_err = std::current_exception(); }
+            try { if (wl == 3) c.packed = build_packed(pats); } catch (...) { packed_err = std::current_exception(); }
         });
-        try { c.chars = build_table(pats, wc, kUniDirectChars); } catch (...) { packed_thread.join(); throw; }
+        try { c.chars = build_table(pats, wl, kUniDirectChars); } catch (...) { packed_thread.join(); throw; }
         packed_thread.join();
         if (packed_err) std::rethrow_exception(packed_err);
     }
@@ -956,7 +963,7 @@ CompiledModel compile_model(const ModelData& m, bool predict_tags) {
             c.types = build_table(pats, wt, kUniDirectTypes);
         }
     }
-    c.pad = std::max(1, std::max(c.chars.present ? wc : 0, c.type_kind != kTypeNone ? wt : 0));
+    c.pad = std::max(1, std::max(c.chars.present ? c.chars.window : 0, c.type_kind != kTypeNone ? wt : 0));   // (the window the rows are laid out for)
     if (tags_on) c.tags = build_tag_tables(m, c.chars.present, c.type_kind != kTypeNone);
     return c;
 }

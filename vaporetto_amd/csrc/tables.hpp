@@ -90,6 +90,7 @@ struct CompiledModel {
     HostPackedTable packed;            // the same patterns in the specialised kernel's layout, when eligible
     int type_kind = kTypeNone;
     int type_window = 0;
+    int char_window = 0;               // the model's own char window (chars.window is the one its rows are laid out for: >= 3)
     std::vector<int32_t> type_table;   // 8^(2W) scores indexed by the 3-bit packed type window (cache variant)
     HostPatternTable types;            // used when type_kind == kTypePatternTable
     // counts for vpt_model_info

@@ -110,10 +110,11 @@ extern "C" {
 
 void vpt_synth_free(void* p) { std::free(p); }
 
-// kind: 1 = M1 (bccwj-suw+unidic-like), 2 = M2 (jp-0.4.7-5-like), 3 = M3 (M1 + tag models).  scale multiplies
+// kind: 1 = M1 (bccwj-suw+unidic-like), 2 = M2 (jp-0.4.7-5-like), 3 = M3 (M1 + tag models), 4 / 5 = M1 trained with
+// --charw 2 --typew 2 / --charw 4 --typew 4 (train/src/main.rs:33-51: the windows are free parameters).  scale multiplies
 // every count (1.0 = full size).  Returns 0 and a malloc'ed model file.
 int vpt_synth_model(int kind, uint64_t seed, double scale, uint8_t** out, size_t* out_len) {
-    if (kind < 1 || kind > 3 || !(scale > 0) || !out || !out_len) return 2;
+    if (kind < 1 || kind > 5 || !(scale > 0) || !out || !out_len) return 2;
     Rng r(seed);
     const uint32_t V = std::max<uint32_t>(300, uint32_t(4000 * std::min(1.0, std::sqrt(scale))));
     const std::vector<uint32_t> vocab = make_vocab(V);
@@ -121,7 +122,7 @@ int vpt_synth_model(int kind, uint64_t seed, double scale, uint8_t** out, size_t
     const size_t n_dict = size_t((kind == 2 ? 1000000 : 700000) * scale);
     const size_t n_tag = kind == 3 ? size_t(50000 * scale) : 0;
     const double p_nz = 0.35;
-    const int W = 3;
+    const int W = kind == 4 ? 2 : kind == 5 ? 4 : 3;
 
     Writer w;
     const char magic[] = "VaporettoTokenizer 0.5.0\n";
