@@ -10,8 +10,8 @@
 //                       byte <-> char correspondence: text bytes + escaped bytes (a pass over the text, four bytes per lane)
 //                       + WordBoundary labels (a pass over the labels, four per lane) + the tag suffixes of the tokens,
 //                       which hang on label positions
-//   scan_*_kernel       inclusive prefix sum over the sentences, in place (offsets[0] = 0): per-workgroup partial sums,
-//                       one workgroup over the partials, per-workgroup apply -- three small launches, all parallel
+//   scan_chained_kernel inclusive prefix sum over the sentences, in place (offsets[0] = 0): one launch, every workgroup looks back
+//                       over its predecessors' published sums (three launches before: profiles/r02_j_emit_kernels.txt)
 //   emit_write_kernel   one wave per sentence, 256 text bytes per step (a dword per lane): lead and escape bits from the
 //                       dword, the labels of the lane's chars in one unaligned load, a DPP prefix sum places every lane's
 //                       output, which is assembled in LDS and leaves as aligned dword stores
@@ -28,7 +28,6 @@ constexpr int kEmitThreads = 256;
 constexpr int kEmitWaves = kEmitThreads / 64;
 constexpr int kScanThreads = 256, kScanPer = 16;
 constexpr uint64_t kScanBlock = uint64_t(kScanThreads) * kScanPer;   // offsets one workgroup of the scan takes
-constexpr int kTopThreads = 1024;
 constexpr uint32_t kStageBytes = 1024;   // a wave's output of one step in LDS: <= 3 + 3 * 256 bytes without tag suffixes
 
 // 0x80 in every byte of v that is zero (exact: no carries between the bytes)
@@ -82,29 +81,51 @@ __device__ __forceinline__ uint64_t wave_sum64(uint64_t x) {   // total over the
     return x;
 }
 
-__global__ __launch_bounds__(kEmitThreads) void emit_count_kernel(const EmitParams P) {
+// the scan's state, zeroed by the kernel in front of it: workgroup b of that kernel clears word b (its grid is at least as large)
+__device__ __forceinline__ void clear_scan_state(uint64_t* state, uint64_t n) {
+    const uint64_t n_part = (n + kScanBlock - 1) / kScanBlock;
+    if (threadIdx.x == 0) {
+        for (uint64_t k = blockIdx.x; k <= n_part; k += gridDim.x) state[k] = 0;
+    }
+}
+
+// the four offsets of sentence i (the same in every lane), loaded one sentence ahead of their use: a wave's sentences are n_waves
+// apart, so every one of them starts with a trip to memory that nothing else of the sentence can overlap with
+struct SentOff { uint64_t b0, b1, o0, o1; };
+__device__ __forceinline__ SentOff load_sent_off(const EmitParams& P, uint64_t i) {
+    SentOff r{0, 0, 0, 0};
+    if (i < P.n_sent) { r.b0 = P.boff[i]; r.b1 = P.boff[i + 1]; r.o0 = P.ooff[i]; r.o1 = P.ooff[i + 1]; }
+    return r;
+}
+
+__global__ __launch_bounds__(kEmitThreads) void emit_count_kernel(const EmitParams P, uint64_t* scan_state) {
+    clear_scan_state(scan_state, P.n_sent);
     const int lane = threadIdx.x & 63;
     const uint64_t wave = uint64_t(blockIdx.x) * kEmitWaves + wave_uniform(threadIdx.x >> 6);
     const uint64_t n_waves = uint64_t(gridDim.x) * kEmitWaves;
     uint32_t err = 0;
+    SentOff nxt = load_sent_off(P, wave);
     for (uint64_t i = wave; i < P.n_sent; i += n_waves) {
-        const uint64_t b0 = wave_uniform64(P.boff[i]), b1 = wave_uniform64(P.boff[i + 1]);
-        const uint64_t o0 = wave_uniform64(P.ooff[i]), o1 = wave_uniform64(P.ooff[i + 1]);
+        const uint64_t b0 = wave_uniform64(nxt.b0), b1 = wave_uniform64(nxt.b1), o0 = wave_uniform64(nxt.o0), o1 = wave_uniform64(nxt.o1);
+        nxt = load_sent_off(P, i + n_waves);
         const bool sane = b1 > b0 && o1 >= o0 && o1 <= P.total_boundaries;
         const uint64_t n_labels = sane ? o1 - o0 : 0;
         uint64_t mine = 0, leads = 0;   // this lane's share of the added bytes / of the chars
         if (sane) {
+            const uint8_t* lab = P.labels + o0;
+            // the first 256 text bytes and the first 256 labels -- all there is of an ordinary sentence -- are asked for together
+            const uint32_t x0 = load4(P.text, b0 + 4 * uint64_t(lane), b1);
+            uint32_t y0 = load4(lab, 4 * uint64_t(lane), n_labels);
             for (uint64_t pos = b0; pos < b1; pos += 256) {
                 const uint64_t at = pos + 4 * uint64_t(lane);
-                const uint32_t x = load4(P.text, at, b1);
+                const uint32_t x = pos == b0 ? x0 : load4(P.text, at, b1);
                 const uint32_t nv = at < b1 ? uint32_t(b1 - at < 4 ? b1 - at : 4) : 0u, vm = (1u << nv) - 1u;
                 leads += uint32_t(__popc(lead_nibble(x) & vm));
                 mine += uint32_t(__popc(esc_nibble(x) & vm));
             }
-            const uint8_t* lab = P.labels + o0;
             for (uint64_t k0 = 0; k0 < n_labels; k0 += 256) {
                 const uint64_t k = k0 + 4 * uint64_t(lane);
-                const uint32_t y = load4(lab, k, n_labels);
+                const uint32_t y = k0 == 0 ? y0 : load4(lab, k, n_labels);
                 if (y & 0xFEFEFEFEu) err |= kErrUnknownLabel;
                 uint32_t om = byte_flags_to_nibble(zero_bytes(y ^ 0x01010101u));   // (a byte past n_labels reads 0: not a boundary)
                 mine += uint32_t(__popc(om));
@@ -119,8 +140,13 @@ __global__ __launch_bounds__(kEmitThreads) void emit_count_kernel(const EmitPara
                 }
             }
         }
-        const uint64_t chars = wave_sum64(leads);
-        uint64_t bytes_out = (b1 - b0) + wave_sum64(mine);
+        // one reduction for both sums: chars in the high half (a sentence of 2^31 chars is not in this kernel's index width anyway)
+        uint64_t chars, added;
+        if (b1 - b0 < (uint64_t(1) << 30)) {   // one reduction for both sums (wave-uniform; neither can reach 2^32 then)
+            const uint64_t both = wave_sum64(mine | (leads << 32));
+            chars = both >> 32; added = both & 0xFFFFFFFFull;
+        } else { chars = wave_sum64(leads); added = wave_sum64(mine); }
+        uint64_t bytes_out = (b1 - b0) + added;
         if (!sane) { err |= b1 > b0 ? kErrBadOffsets : kErrEmptySentence; bytes_out = 0; }
         else if (chars != n_labels + 1) err |= kErrBadOffsets;
         else bytes_out += tag_suffix(P, o1 + i, nullptr);   // the last token's (every lane computes the same)
@@ -145,49 +171,23 @@ __device__ __forceinline__ uint64_t block_exclusive_scan(uint64_t* lds, uint64_t
     return incl - v;
 }
 
-__global__ __launch_bounds__(kScanThreads) void scan_partials_kernel(const uint64_t* __restrict__ offsets, uint64_t n, uint64_t* __restrict__ part) {
-    __shared__ uint64_t lds[kScanThreads];
-    const uint32_t tid = threadIdx.x;
-    const uint64_t base = uint64_t(blockIdx.x) * kScanBlock;
-    uint64_t sum = 0;
-#pragma unroll
-    for (int j = 0; j < kScanPer; ++j) {   // coalesced
-        const uint64_t k = base + uint64_t(j) * kScanThreads + tid;
-        sum += k < n ? offsets[k + 1] : 0;
-    }
-    uint64_t total;
-    (void)block_exclusive_scan(lds, sum, tid, kScanThreads, &total);
-    if (tid == 0) part[blockIdx.x] = total;
-}
-
+// ONE launch: a chained scan.  A workgroup takes a ticket (so that every workgroup with a smaller number is already running: the
+// look-back below cannot wait for one that has not started), sums its kScanBlock entries, publishes the sum, walks back over its
+// predecessors' words until one holds an inclusive prefix, publishes its own inclusive prefix and writes its entries.  A word =
+// flag << 62 | value (1: the block's sum, 2: the prefix up to and including the block; 0: nothing yet), written and read as one
+// 64-bit access, so value and flag can never be seen apart.  `state` (n_part words + the ticket) is zeroed by the kernel that
+// produced the lengths (the launch in front of this one on the stream).
 // total_out (optional): where the grand total is left as well -- host memory the device can write (hipHostMalloc), so that a
 // caller waiting on an event of the stream reads the size of the output without a copy of its own
-__global__ __launch_bounds__(kTopThreads) void scan_top_kernel(uint64_t* __restrict__ part, uint64_t n_part, uint64_t* __restrict__ offsets, uint64_t capacity,
-                                                               uint32_t* __restrict__ status, uint64_t* __restrict__ total_out) {
-    __shared__ uint64_t lds[kTopThreads];
-    const uint32_t tid = threadIdx.x;
-    const uint64_t per = (n_part + kTopThreads - 1) / kTopThreads;     // consecutive partials per thread
-    const uint64_t lo = uint64_t(tid) * per, hi = lo + per < n_part ? lo + per : n_part;
-    uint64_t sum = 0;
-    for (uint64_t k = lo; k < hi; ++k) sum += part[k];
-    uint64_t total;
-    uint64_t run = block_exclusive_scan(lds, sum, tid, kTopThreads, &total);
-    for (uint64_t k = lo; k < hi; ++k) {                               // sums -> exclusive prefixes, in place
-        const uint64_t v = part[k];
-        part[k] = run;
-        run += v;
-    }
-    if (tid == 0) {
-        offsets[0] = 0;
-        if (total > capacity) atomicOr(status, kErrOutputTooSmall);
-        if (total_out) *total_out = total;
-    }
-}
-
-__global__ __launch_bounds__(kScanThreads) void scan_apply_kernel(uint64_t* __restrict__ offsets, uint64_t n, const uint64_t* __restrict__ part) {
+__global__ __launch_bounds__(kScanThreads) void scan_chained_kernel(uint64_t* __restrict__ offsets, uint64_t n, uint64_t* __restrict__ state, uint64_t n_part,
+                                                                    uint64_t capacity, uint32_t* __restrict__ status, uint64_t* __restrict__ total_out) {
     __shared__ uint64_t lds[kScanThreads];
+    __shared__ uint64_t bcast[2];
     const uint32_t tid = threadIdx.x;
-    const uint64_t first = uint64_t(blockIdx.x) * kScanBlock + uint64_t(tid) * kScanPer;   // this thread's consecutive entries
+    if (tid == 0) bcast[0] = atomicAdd(reinterpret_cast<unsigned long long*>(state + n_part), 1ull);
+    __syncthreads();
+    const uint64_t blk = bcast[0];
+    const uint64_t first = blk * kScanBlock + uint64_t(tid) * kScanPer;   // this thread's consecutive entries
     uint64_t v[kScanPer];
     uint64_t sum = 0;
 #pragma unroll
@@ -196,7 +196,29 @@ __global__ __launch_bounds__(kScanThreads) void scan_apply_kernel(uint64_t* __re
         sum += v[j];
     }
     uint64_t total;
-    uint64_t run = part[blockIdx.x] + block_exclusive_scan(lds, sum, tid, kScanThreads, &total);
+    uint64_t run = block_exclusive_scan(lds, sum, tid, kScanThreads, &total);
+    if (tid == 0) {
+        constexpr uint64_t kVal = (uint64_t(1) << 62) - 1;
+        uint64_t base = 0;
+        if (blk != 0) {
+            __hip_atomic_store(state + blk, (uint64_t(1) << 62) | total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            for (uint64_t p = blk; p-- > 0;) {
+                uint64_t w;
+                do { w = __hip_atomic_load(state + p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); } while ((w >> 62) == 0);
+                base += w & kVal;
+                if ((w >> 62) == 2) break;
+            }
+        }
+        __hip_atomic_store(state + blk, (uint64_t(2) << 62) | ((base + total) & kVal), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        bcast[1] = base;
+        if (blk == 0) offsets[0] = 0;
+        if (blk == n_part - 1) {
+            if (base + total > capacity) atomicOr(status, kErrOutputTooSmall);
+            if (total_out) *total_out = base + total;
+        }
+    }
+    __syncthreads();
+    run += bcast[1];
 #pragma unroll
     for (int j = 0; j < kScanPer; ++j) {
         run += v[j];
@@ -206,13 +228,13 @@ __global__ __launch_bounds__(kScanThreads) void scan_apply_kernel(uint64_t* __re
 
 hipError_t launch_scan(uint64_t* offsets, uint64_t n, uint64_t* part, uint64_t capacity, uint32_t* status, uint64_t* total_out, hipStream_t stream) {
     const uint64_t n_part = (n + kScanBlock - 1) / kScanBlock;
-    hipLaunchKernelGGL(scan_partials_kernel, dim3(uint32_t(n_part)), dim3(kScanThreads), 0, stream, offsets, n, part);
-    hipLaunchKernelGGL(scan_top_kernel, dim3(1), dim3(kTopThreads), 0, stream, part, n_part, offsets, capacity, status, total_out);
-    hipLaunchKernelGGL(scan_apply_kernel, dim3(uint32_t(n_part)), dim3(kScanThreads), 0, stream, offsets, n, part);
+    hipLaunchKernelGGL(scan_chained_kernel, dim3(uint32_t(n_part)), dim3(kScanThreads), 0, stream, offsets, n, part, n_part, capacity, status, total_out);
     return hipGetLastError();
 }
-
-struct EmitLds { uint32_t stage[kEmitWaves][kStageBytes / 4]; };
+struct EmitLds {
+    uint32_t stage[kEmitWaves][kStageBytes / 4];
+    uint32_t labs[kEmitWaves][68];   // the labels a step's chars can ask for: 256 + 3 bytes, fetched with the step's text
+};
 
 __global__ __launch_bounds__(kEmitThreads) void emit_write_kernel(const EmitParams P) {
     __shared__ EmitLds LDS;
@@ -220,28 +242,40 @@ __global__ __launch_bounds__(kEmitThreads) void emit_write_kernel(const EmitPara
     const uint32_t wid = wave_uniform(threadIdx.x >> 6);
     uint32_t* const stage = LDS.stage[wid];
     uint8_t* const sb = reinterpret_cast<uint8_t*>(stage);
+    uint32_t* const labs = LDS.labs[wid];
     const uint64_t wave = uint64_t(blockIdx.x) * kEmitWaves + wid;
     const uint64_t n_waves = uint64_t(gridDim.x) * kEmitWaves;
+    // a sentence's offsets are loaded one sentence ahead (see emit_count_kernel)
+    SentOff nxt = load_sent_off(P, wave);
+    uint64_t nxt_a = wave < P.n_sent ? P.out_offsets[wave] : 0, nxt_e = wave < P.n_sent ? P.out_offsets[wave + 1] : 0;
     for (uint64_t i = wave; i < P.n_sent; i += n_waves) {
-        const uint64_t b0 = wave_uniform64(P.boff[i]), b1 = wave_uniform64(P.boff[i + 1]);
-        const uint64_t o0 = wave_uniform64(P.ooff[i]), o1 = wave_uniform64(P.ooff[i + 1]);
+        const uint64_t b0 = wave_uniform64(nxt.b0), b1 = wave_uniform64(nxt.b1), o0 = wave_uniform64(nxt.o0), o1 = wave_uniform64(nxt.o1);
+        const uint64_t end = wave_uniform64(nxt_e);
+        uint64_t at_out = wave_uniform64(nxt_a), chars = 0;
+        nxt = load_sent_off(P, i + n_waves);
+        if (i + n_waves < P.n_sent) { nxt_a = P.out_offsets[i + n_waves]; nxt_e = P.out_offsets[i + n_waves + 1]; }
         if (!(b1 > b0 && o1 >= o0 && o1 <= P.total_boundaries)) continue;   // reported by emit_count_kernel
         const uint64_t n_labels = o1 - o0;
         const uint8_t* lab = P.labels + o0;
-        const uint64_t end = wave_uniform64(P.out_offsets[i + 1]);
-        uint64_t at_out = wave_uniform64(P.out_offsets[i]), chars = 0;
         if (end > P.capacity || end < at_out) continue;                    // kErrOutputTooSmall
         bool fits = true;                                                  // `end` only binds when the inputs changed under us
         for (uint64_t pos = b0; pos < b1 && fits; pos += 256) {
             const uint64_t at = pos + 4 * uint64_t(lane);
+            // the step's text and the labels its chars can ask for (label[chars - 1] onwards: at most 256 chars start in 256 bytes) leave
+            // in ONE trip to memory; a lane then finds the labels of its own chars in LDS (which ones it learns from the text)
+            const uint64_t lbase = chars ? chars - 1 : 0;
             const uint32_t x = load4(P.text, at, b1);
+            labs[lane] = load4(lab, lbase + 4 * uint64_t(lane), n_labels);
+            if (lane < 4) labs[64 + lane] = lane == 0 ? load4(lab, lbase + 256, n_labels) : 0u;
             const uint32_t nv = at < b1 ? uint32_t(b1 - at < 4 ? b1 - at : 4) : 0u, vm = (1u << nv) - 1u;
             const uint32_t lm = lead_nibble(x) & vm, em = esc_nibble(x) & vm;
             const uint32_t nl = uint32_t(__popc(lm));
             const uint32_t incl_l = wave_inclusive_scan(nl);
             const uint64_t ci0 = chars + (incl_l - nl);                    // index in the sentence of this lane's first char
+            __builtin_amdgcn_wave_barrier();
             // the labels in front of this lane's chars: label[ci0 - 1 + q] for its q-th char (none in front of char 0)
-            uint32_t y = nl ? load4(lab, ci0 ? ci0 - 1 : 0, n_labels) : 0u;
+            const uint32_t loff = uint32_t((ci0 ? ci0 - 1 : 0) - lbase);   // <= 256
+            uint32_t y = nl ? __builtin_amdgcn_alignbyte(labs[(loff >> 2) + 1], labs[loff >> 2], loff & 3u) : 0u;
             if (ci0 == 0) y <<= 8;
             // which of the lane's chars have a space in front (bit q: its q-th char), moved onto the chars' lead bytes (bit k: byte k)
             const uint32_t spq = byte_flags_to_nibble(zero_bytes(y ^ 0x01010101u)) & ((1u << nl) - 1u);
@@ -334,7 +368,8 @@ __global__ __launch_bounds__(kEmitThreads) void emit_write_kernel(const EmitPara
 // validation as Sentence::from_raw (sentence.rs:160-196), the longest sentence (in chars) -> *max_chars
 __global__ __launch_bounds__(kEmitThreads) void count_chars_kernel(const uint8_t* __restrict__ text, const uint64_t* __restrict__ boff,
                                                                    uint64_t n_sent, uint64_t* __restrict__ offsets, uint32_t* __restrict__ status,
-                                                                   uint32_t* __restrict__ max_chars) {
+                                                                   uint32_t* __restrict__ max_chars, uint64_t* scan_state) {
+    clear_scan_state(scan_state, n_sent);
     const int lane = threadIdx.x & 63;
     const uint64_t wave = uint64_t(blockIdx.x) * kEmitWaves + wave_uniform(threadIdx.x >> 6);
     const uint64_t n_waves = uint64_t(gridDim.x) * kEmitWaves;
@@ -363,7 +398,7 @@ __global__ __launch_bounds__(kEmitThreads) void count_chars_kernel(const uint8_t
 
 }  // namespace
 
-size_t scan_part_entries(uint64_t n) { return size_t((n + kScanBlock - 1) / kScanBlock) + 1; }
+size_t scan_part_entries(uint64_t n) { return size_t((n + kScanBlock - 1) / kScanBlock) + 2; }   // the blocks' words + the ticket
 
 // one wave per sentence, but no more workgroups than `max_blocks` (a few generations of what the device runs at a time; 0: 65536):
 // the waves then stride over the batch and the sentences' lengths even out (see launch_tag_tokens)
@@ -375,13 +410,13 @@ static uint32_t emit_blocks(uint64_t n_sent, uint32_t max_blocks) {
 hipError_t launch_count_boundaries(const uint8_t* text, const uint64_t* boff, uint64_t n_sent, uint64_t* ooff_out, uint64_t* scan_part, uint32_t* status,
                                    uint32_t* max_chars, uint32_t max_blocks, hipStream_t stream) {
     const uint32_t blocks = emit_blocks(n_sent, max_blocks);
-    hipLaunchKernelGGL(count_chars_kernel, dim3(blocks), dim3(kEmitThreads), 0, stream, text, boff, n_sent, ooff_out, status, max_chars);
+    hipLaunchKernelGGL(count_chars_kernel, dim3(blocks), dim3(kEmitThreads), 0, stream, text, boff, n_sent, ooff_out, status, max_chars, scan_part);
     return launch_scan(ooff_out, n_sent, scan_part, ~uint64_t(0), status, nullptr, stream);
 }
 
 hipError_t launch_emit_tokenized(const EmitParams& P, uint64_t* scan_part, uint32_t max_blocks, uint64_t* total_out, hipStream_t stream) {
     const uint32_t blocks = emit_blocks(P.n_sent, max_blocks);
-    hipLaunchKernelGGL(emit_count_kernel, dim3(blocks), dim3(kEmitThreads), 0, stream, P);
+    hipLaunchKernelGGL(emit_count_kernel, dim3(blocks), dim3(kEmitThreads), 0, stream, P, scan_part);
     const hipError_t e = launch_scan(P.out_offsets, P.n_sent, scan_part, P.capacity, P.status, total_out, stream);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(emit_write_kernel, dim3(blocks), dim3(kEmitThreads), 0, stream, P);
