@@ -27,6 +27,7 @@
 #define __device__
 #define __host__
 #define __forceinline__ inline __attribute__((always_inline))
+#define __noinline__ __attribute__((noinline))
 #define __launch_bounds__(...)
 #define __shared__ static   /* static LDS: one workgroup runs at a time */
 // dynamic LDS: kernels declare it through VPT_DYNAMIC_LDS (device_common.h)
@@ -142,6 +143,7 @@ template <typename T, typename V> static inline void __hip_atomic_store(T* p, V 
 #define __builtin_amdgcn_readfirstlane(x) int(::hipemu::readfirstlane(uint32_t(x)))
 #define __builtin_amdgcn_wave_barrier() ::hipemu::wave_sync()
 #define __builtin_amdgcn_s_memtime() ::hipemu::clock()
+#define __builtin_amdgcn_s_sleep(n) ((void)0)
 static inline uint32_t hipemu_mbcnt_lo(uint32_t mask, uint32_t base) {
     const unsigned l = ::hipemu::lane();
     return base + uint32_t(__builtin_popcount(l >= 32 ? mask : mask & ((1u << l) - 1u)));

@@ -143,7 +143,7 @@ int tc_score(const tc_model* t, const uint32_t* cps, size_t n, int32_t* y_out, u
         const uint32_t* ch = &K.tri[size_t(ts) * 4];
         ++probes[1];
         if ((ch[0] & kTriParentMask) != slot + 1) continue;
-        if (ch[0] & (kPkWide << 24)) {
+        if (ch[0] & (kPkWide << kTriFlagShift)) {
             const uint32_t* g = general_find(G, short_key(cp_of(c1), cp_of(c2), cp_of(c3)));
             if (!g) return -2;
             for (int j = 0; j < 4; ++j) add(y, S - 1 + j, int32_t(g[2 + j]));

@@ -1228,6 +1228,39 @@ def test_write_tagged_text_on_device():
     assert [out[int(toff[i]):int(toff[i + 1])].decode("utf-8") for i in range(S)] == want
 
 
+@pytest.mark.parametrize("per_block", [1, 3, 64])
+def test_writer_blocks_of_any_size(per_block, monkeypatch):
+    """The writer's waves take blocks of consecutive sentences (kernels_emit.hip); the block size comes from the mean sentence
+    length -- here it is forced (VPT_EMIT_PER_BLOCK, read when a workspace is made): one sentence per wave, a few, 64; sentences
+    of 1 .. 900 chars with escapes, 1- to 4-byte chars, every alignment of text, labels and output."""
+    monkeypatch.setenv("VPT_EMIT_PER_BLOCK", str(per_block))
+    m = randmodel.rand_model(843, alphabet="kana", wc=3, wt=3, n_tag_models=30, max_word=3, n_char=60, n_dict=60)
+    for k, tm in enumerate(m.tag_models):
+        tm.tags = [[t + (" /\\"[k % 3]) * (k % 2) for t in cands] for cands in tm.tags]
+    raw = encode_model(m)
+    rng = np.random.default_rng(13 + per_block)
+    alphabet = list("あいう漢字ab /\\/ .🤌é") + ["\n"]
+    lens = list(rng.integers(1, 40, 500)) + [1, 1, 63, 64, 65, 127, 128, 129, 341, 342, 343, 700, 900]
+    texts = ["".join(rng.choice(alphabet, size=int(n))) for n in lens]
+    utf8, boff = api.pack_texts([t.encode("utf-8") for t in texts])
+    ooff = api.count_boundaries(utf8, boff)
+    for trial in range(3):   # the same workspace again: its state words alternate between two arrays
+        pred = api.Predictor(api.Model.read_slice(raw)[0], False) if trial == 0 else pred
+        labels = (rng.random(int(ooff[-1])) < (0.1, 0.5, 1.0)[trial]).astype(np.uint8)
+        text, toff = pred.write_tokenized_packed(utf8, boff, ooff, labels)
+        got = bytes(text)
+        for i, t in enumerate(texts):
+            assert got[int(toff[i]):int(toff[i + 1])].decode("utf-8") == _tokenized_reference(t, labels[int(ooff[i]):int(ooff[i + 1])]), (trial, i, t)
+    # with tags: against the mirror's writer
+    tagged = api.Predictor(api.Model.read_slice(raw)[0], True)
+    ttexts = randmodel.rand_sentences(6, m, 300, alphabet="kana", max_len=40) + [t.token * 3 for t in m.tag_models] + ["あ", "い/う え\\"]
+    sents = [api.Sentence.from_raw(t) for t in ttexts]
+    tagged.predict_batch(sents)
+    got = tagged.write_tokenized_batch(sents, tagged=True)
+    tagged.fill_tags_batch(sents)
+    assert got == [s.write_tokenized_text() for s in sents]
+
+
 WRITER_TEST_SENTENCES = 9000   # (tests/test_kernel_emu.py runs the same test on fewer)
 
 

@@ -1,16 +1,18 @@
 #!/bin/bash
-O=gpurun_out/r03_k; mkdir -p $O
+O=gpurun_out/r03_n; mkdir -p $O
 export TMPDIR=/tmp
-( timeout 900 python -m pytest tests -m gpu -x -q 2>&1 | tail -8 ) > $O/gpu_tests.log; tail -3 $O/gpu_tests.log
-for C in 1 4 6 7; do
-( timeout 600 python bench.py --config $C --steps 20 --warmup 5 2>> $O/bench.err | tail -1 ) > $O/bench_c$C.json
-python - <<PY
-import json
-w=json.load(open("$O/bench_c$C.json"))
-print(w["config"]["workload"], "| value %.4g"%w["value"], "ms %.4f"%w["ms_per_step"], "kernel_ms %.4f"%w["roofline"]["kernel_ms"], "frac %.3f"%w["roofline"]["frac"], "parity", w["parity"], w["config"]["tile_plan"])
-for k in ("tags","emit"):
-    if k in w: print("    ", k, {a:b for a,b in w[k].items() if a in ("ms_per_step","parity","frac_of_hbm","tokens_checked","bytes_checked")})
-if "e2e" in w: print("     e2e", w["e2e"]["frac_of_pcie"], "tokenize ms", w["e2e"]["tokenize"]["ms_per_batch"], w["e2e"]["tokenize"]["chars_per_s"])
+timeout 900 python -m pytest tests -m gpu -x -q 2>&1 | tail -5 | tee $O/gpu_tests.log
+emit() { python - "$1" <<'PY'
+import json, sys
+d=json.load(open(sys.argv[1]))
+e=d.get('emit') or {}
+print(sys.argv[1], 'emit ms', e.get('ms_per_step'), 'parity', e.get('parity'), 'step ms', d['ms_per_step'])
 PY
+}
+for k in 0 4 8 12 24 32 64; do
+  VPT_EMIT_PER_BLOCK=$k timeout 600 python bench.py --config 1 --steps 20 --warmup 5 --no-e2e --quick > $O/bench_c1_k$k.json 2> $O/bench_c1_k$k.err; emit $O/bench_c1_k$k.json
 done
-tail -3 $O/bench.err
+for k in 0 2 4 16 32; do
+  VPT_EMIT_PER_BLOCK=$k timeout 900 python bench.py --config 4 --steps 10 --warmup 3 --no-e2e --quick > $O/bench_c4_k$k.json 2> $O/bench_c4_k$k.err; emit $O/bench_c4_k$k.json
+done
+VPT_FUZZ_SEED0=0 timeout 200 python tools/fuzz_gpu.py 100 2>&1 | tail -3 | tee $O/fuzz.log

@@ -51,6 +51,7 @@ struct BatchKnobs {
     bool no_cps_from_predict = false;   // VPT_NO_CPS_FROM_PREDICT
     uint32_t debug_ablate = 0;          // VPT_DEBUG_ABLATE
     bool profile_phases = false;        // VPT_PROFILE_PHASES
+    uint32_t emit_per_block = 0;        // VPT_EMIT_PER_BLOCK: sentences a wave of the writer takes (1..64; 0: from the mean sentence length)
 };
 PredictorKnobs read_predictor_knobs() {
     PredictorKnobs k;
@@ -67,6 +68,7 @@ BatchKnobs read_batch_knobs() {
     k.force_generic = std::getenv("VPT_FORCE_GENERIC") != nullptr;
     if (const char* v = std::getenv("VPT_FORCE_CUT_TILES")) k.force_cut = std::atoi(v);
     if (const char* v = std::getenv("VPT_TILE_FLAT")) k.tile_flat = uint32_t(std::max(0, std::atoi(v)));
+    if (const char* v = std::getenv("VPT_EMIT_PER_BLOCK")) k.emit_per_block = uint32_t(std::min(64, std::max(0, std::atoi(v))));
     k.no_cps_from_predict = std::getenv("VPT_NO_CPS_FROM_PREDICT") != nullptr;
     if (const char* v = std::getenv("VPT_DEBUG_ABLATE")) k.debug_ablate = uint32_t(std::atoi(v));
     k.profile_phases = std::getenv("VPT_PROFILE_PHASES") != nullptr;
@@ -94,7 +96,7 @@ struct TableGeom {
     int32_t window, lo[3], len[3];
 };
 constexpr char kCompiledMagic[16] = "VaporettoHIP-C\x01";   // 15 chars + NUL
-constexpr uint32_t kCompiledVersion = 8;                    // bump whenever layout.h or a kernel's reading of it changes
+constexpr uint32_t kCompiledVersion = 9;                    // bump whenever layout.h or a kernel's reading of it changes
 struct PredictorMeta {                                      // plain data: written and read as is (little-endian hosts)
     char magic[16];
     uint32_t version, meta_bytes;
@@ -236,6 +238,9 @@ struct vpt_batch {
     std::vector<uint64_t> h_boff, h_ooff;                           // rebased offsets of the call in flight (copied asynchronously)
     uint8_t* d_types = nullptr; size_t types_cap = 0;               // vpt_char_types_batch
     uint64_t* d_scan_part = nullptr; size_t scan_part_cap = 0;      // per-workgroup partials of the prefix sums (kernels_emit.hip)
+    // the writer's state words (EmitFuse): two arrays of emit_state_cap words, used in turn; a call zeroes what the call before it
+    // left in the other one (emit_dirty = how many words that is)
+    uint64_t* d_emit_state = nullptr; size_t emit_state_cap = 0; size_t emit_dirty[2] = {0, 0}; int emit_flip = 0;
     // the pipelined host-buffer path (predict_pipelined): two sets of device buffers, copy streams, pinned offset staging
     struct PipeSet {
         uint8_t* text = nullptr; size_t text_cap = 0;
@@ -301,6 +306,7 @@ void batch_release(vpt_batch* b) {
     if (!b) return;
     (void)hipSetDevice(b->device);
     (void)hipFree(b->d_scan_part);
+    (void)hipFree(b->d_emit_state);
     (void)hipFree(b->d_tiles); (void)hipFree(b->d_cut_local); (void)hipFree(b->d_cut_super);
     (void)hipFree(b->d_tile_first); (void)hipFree(b->d_slow_list); (void)hipFree(b->d_ctrl); (void)hipFree(b->d_scratch);
     (void)hipFree(b->d_prof); (void)hipFree(b->d_cps);
@@ -1456,11 +1462,31 @@ static vpt_status emit_device(const vpt_predictor* p, vpt_batch* b, const uint8_
         E.tags = d_tags; E.tok_model = b->d_tok_model; E.n_tags = p->n_tags; E.n_models = p->dtag.n_models; E.n_strings = p->dtag.n_strings;
         E.models = p->dtag.models; E.slot_str = p->dtag.slot_str; E.str_off = p->dtag.str_off; E.str_bytes = p->dtag.str_bytes;
     }
+    // a wave per block of sentences: about a thousand chars of them (three steps of CJK text), at most 64
+    vpt::EmitFuse F{};
     {
-        const vpt_status st = grow(&b->d_scan_part, &b->scan_part_cap, vpt::scan_part_entries(n_sentences));
-        if (st != VPT_OK) return st;
+        const uint64_t chars = total_boundaries + n_sentences;
+        const uint64_t per = (uint64_t(1024) * n_sentences + chars / 2) / chars;   // round(1024 / mean chars per sentence)
+        F.per_block = uint32_t(std::min<uint64_t>(std::max<uint64_t>(per, 1), vpt::kEmitFuseMaxBlock));
+        if (b->knobs.emit_per_block) F.per_block = b->knobs.emit_per_block;
+        F.n_blocks = (n_sentences + F.per_block - 1) / F.per_block;
     }
-    VPT_HIP(vpt::launch_emit_tokenized(E, b->d_scan_part, p->n_cus * 32u, total_out, stream));
+    const size_t words = size_t(F.n_blocks) + 1;
+    if (words > b->emit_state_cap) {
+        const size_t cap = std::max(words + words / 2, size_t(4096));
+        (void)hipFree(b->d_emit_state);   // (waits for the device)
+        b->d_emit_state = nullptr; b->emit_state_cap = 0;
+        VPT_HIP(hipMalloc(reinterpret_cast<void**>(&b->d_emit_state), 2 * cap * sizeof(uint64_t)));
+        VPT_HIP(hipMemsetAsync(b->d_emit_state, 0, 2 * cap * sizeof(uint64_t), stream));   // (in front of the kernel on ITS stream: a plain hipMemset is not ordered with a non-blocking stream)
+        b->emit_state_cap = cap; b->emit_dirty[0] = b->emit_dirty[1] = 0; b->emit_flip = 0;
+    }
+    F.state = b->d_emit_state + size_t(b->emit_flip) * b->emit_state_cap;
+    F.clear = b->d_emit_state + size_t(b->emit_flip ^ 1) * b->emit_state_cap;
+    F.clear_n = b->emit_dirty[b->emit_flip ^ 1];
+    F.total_out = total_out;
+    b->emit_dirty[b->emit_flip ^ 1] = 0; b->emit_dirty[b->emit_flip] = words;
+    b->emit_flip ^= 1;
+    VPT_HIP(vpt::launch_emit_tokenized(E, F, stream));
     b->last_stream = stream; b->pending = true; b->cps_text = nullptr;
     return VPT_OK;
 }

@@ -160,8 +160,16 @@ struct EmitParams {
 };
 // scan_part: workspace of scan_part_entries(n_sent) uint64 (the prefix sum's per-workgroup partials)
 size_t scan_part_entries(uint64_t n);
-// total_out: optional device-writable HOST address that receives the output's total size (see scan_top_kernel)
-hipError_t launch_emit_tokenized(const EmitParams& P, uint64_t* scan_part, uint32_t max_blocks, uint64_t* total_out, hipStream_t stream);
+// The writer's launch (emit_fused_kernel): a wave per block of `per_block` consecutive sentences (1 .. kEmitFuseMaxBlock).
+constexpr uint32_t kEmitFuseMaxBlock = 64;
+struct EmitFuse {
+    uint64_t* state;        // n_blocks + 1 words, ZERO when the kernel starts: the blocks' sizes / positions and the ticket
+    uint64_t* clear;        // the state words of the NEXT call (the other of two arrays), zeroed by this one: [0, clear_n)
+    uint64_t clear_n, n_blocks;
+    uint32_t per_block;
+    uint64_t* total_out;    // optional device-writable HOST address that receives the output's total size
+};
+hipError_t launch_emit_tokenized(const EmitParams& P, const EmitFuse& F, hipStream_t stream);
 // vpt_count_boundaries on the device: ooff_out[S+1]; *max_chars (atomicMax) = the longest sentence in chars
 hipError_t launch_count_boundaries(const uint8_t* text, const uint64_t* boff, uint64_t n_sent, uint64_t* ooff_out, uint64_t* scan_part, uint32_t* status,
                                    uint32_t* max_chars, uint32_t max_blocks, hipStream_t stream);

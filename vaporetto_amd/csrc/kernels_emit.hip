@@ -5,17 +5,9 @@
 // slots up to the last Some, an empty string for a None in between (sentence.rs:866-881).  (Unknown boundaries only
 // come from partially annotated corpora, never from predict: they are rejected here, kErrUnknownLabel.)
 //
-// Output size is data dependent, so:
-//   emit_count_kernel   one wave per sentence: bytes this sentence will take -> offsets[i + 1].  The count needs no
-//                       byte <-> char correspondence: text bytes + escaped bytes (a pass over the text, four bytes per lane)
-//                       + WordBoundary labels (a pass over the labels, four per lane) + the tag suffixes of the tokens,
-//                       which hang on label positions
-//   scan_chained_kernel inclusive prefix sum over the sentences, in place (offsets[0] = 0): one launch, every workgroup looks back
-//                       over its predecessors' published sums (three launches before: profiles/r02_j_emit_kernels.txt)
-//   emit_write_kernel   one wave per sentence, 256 text bytes per step (a dword per lane): lead and escape bits from the
-//                       dword, the labels of the lane's chars in one unaligned load, a DPP prefix sum places every lane's
-//                       output, which is assembled in LDS and leaves as aligned dword stores
-// A sentence's bytes are independent of the other sentences', its position is not: that is the scan.
+// Output size is data dependent: emit_fused_kernel (below) sizes, places and writes the batch in one launch (three launches --
+// count, prefix sum, write, a wave per sentence -- until round 3: profiles/r02_j_emit_kernels.txt, r03_l_emit_kernel_stats.csv).
+// count_chars_kernel + scan_chained_kernel are vpt_count_boundaries on the device.
 #include <hip/hip_runtime.h>
 
 #include "device_common.h"
@@ -28,7 +20,6 @@ constexpr int kEmitThreads = 256;
 constexpr int kEmitWaves = kEmitThreads / 64;
 constexpr int kScanThreads = 256, kScanPer = 16;
 constexpr uint64_t kScanBlock = uint64_t(kScanThreads) * kScanPer;   // offsets one workgroup of the scan takes
-constexpr uint32_t kStageBytes = 1024;   // a wave's output of one step in LDS: <= 3 + 3 * 256 bytes without tag suffixes
 
 // 0x80 in every byte of v that is zero (exact: no carries between the bytes)
 __device__ __forceinline__ uint32_t zero_bytes(uint32_t v) { return ~(((v & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | v | 0x7F7F7F7Fu); }
@@ -40,7 +31,7 @@ __device__ __forceinline__ uint32_t esc_nibble(uint32_t x) {
 }
 // "/tag/tag.." of the token whose last char is char `c` (batch-flat index) and whose tag model (index + 1, from the
 // fill_tags call) is `model`: bytes it takes; written to `dst` when given
-__device__ __forceinline__ uint32_t tag_suffix_of(const EmitParams& P, uint64_t c, int32_t model, uint8_t* dst) {
+__device__ __noinline__ uint32_t tag_suffix_of(const EmitParams& P, uint64_t c, int32_t model, uint8_t* dst) {
     if (model <= 0 || uint32_t(model) > P.n_models) return 0;   // no tag model for this surface (or not our array)
     const uint32_t* mr = P.models + size_t(model - 1) * 12;
     const int32_t* tg = P.tags + c * P.n_tags;
@@ -64,14 +55,6 @@ __device__ __forceinline__ uint32_t tag_suffix_of(const EmitParams& P, uint64_t 
 __device__ __forceinline__ uint32_t tag_suffix(const EmitParams& P, uint64_t c, uint8_t* dst) {
     return P.tags ? tag_suffix_of(P, c, P.tok_model[c], dst) : 0u;
 }
-// the tag models of the four chars from `c` on in one load (the array is padded past the batch's chars: capi.cpp)
-struct Models4 { int32_t m[4]; };
-__device__ __forceinline__ Models4 load_models4(const EmitParams& P, uint64_t c) {
-    Models4 r;
-    __builtin_memcpy(&r, P.tok_model + c, sizeof(r));
-    return r;
-}
-
 __device__ __forceinline__ uint64_t wave_sum64(uint64_t x) {   // total over the 64 lanes, in every lane
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) {
@@ -87,72 +70,6 @@ __device__ __forceinline__ void clear_scan_state(uint64_t* state, uint64_t n) {
     if (threadIdx.x == 0) {
         for (uint64_t k = blockIdx.x; k <= n_part; k += gridDim.x) state[k] = 0;
     }
-}
-
-// the four offsets of sentence i (the same in every lane), loaded one sentence ahead of their use: a wave's sentences are n_waves
-// apart, so every one of them starts with a trip to memory that nothing else of the sentence can overlap with
-struct SentOff { uint64_t b0, b1, o0, o1; };
-__device__ __forceinline__ SentOff load_sent_off(const EmitParams& P, uint64_t i) {
-    SentOff r{0, 0, 0, 0};
-    if (i < P.n_sent) { r.b0 = P.boff[i]; r.b1 = P.boff[i + 1]; r.o0 = P.ooff[i]; r.o1 = P.ooff[i + 1]; }
-    return r;
-}
-
-__global__ __launch_bounds__(kEmitThreads) void emit_count_kernel(const EmitParams P, uint64_t* scan_state) {
-    clear_scan_state(scan_state, P.n_sent);
-    const int lane = threadIdx.x & 63;
-    const uint64_t wave = uint64_t(blockIdx.x) * kEmitWaves + wave_uniform(threadIdx.x >> 6);
-    const uint64_t n_waves = uint64_t(gridDim.x) * kEmitWaves;
-    uint32_t err = 0;
-    SentOff nxt = load_sent_off(P, wave);
-    for (uint64_t i = wave; i < P.n_sent; i += n_waves) {
-        const uint64_t b0 = wave_uniform64(nxt.b0), b1 = wave_uniform64(nxt.b1), o0 = wave_uniform64(nxt.o0), o1 = wave_uniform64(nxt.o1);
-        nxt = load_sent_off(P, i + n_waves);
-        const bool sane = b1 > b0 && o1 >= o0 && o1 <= P.total_boundaries;
-        const uint64_t n_labels = sane ? o1 - o0 : 0;
-        uint64_t mine = 0, leads = 0;   // this lane's share of the added bytes / of the chars
-        if (sane) {
-            const uint8_t* lab = P.labels + o0;
-            // the first 256 text bytes and the first 256 labels -- all there is of an ordinary sentence -- are asked for together
-            const uint32_t x0 = load4(P.text, b0 + 4 * uint64_t(lane), b1);
-            uint32_t y0 = load4(lab, 4 * uint64_t(lane), n_labels);
-            for (uint64_t pos = b0; pos < b1; pos += 256) {
-                const uint64_t at = pos + 4 * uint64_t(lane);
-                const uint32_t x = pos == b0 ? x0 : load4(P.text, at, b1);
-                const uint32_t nv = at < b1 ? uint32_t(b1 - at < 4 ? b1 - at : 4) : 0u, vm = (1u << nv) - 1u;
-                leads += uint32_t(__popc(lead_nibble(x) & vm));
-                mine += uint32_t(__popc(esc_nibble(x) & vm));
-            }
-            for (uint64_t k0 = 0; k0 < n_labels; k0 += 256) {
-                const uint64_t k = k0 + 4 * uint64_t(lane);
-                const uint32_t y = k0 == 0 ? y0 : load4(lab, k, n_labels);
-                if (y & 0xFEFEFEFEu) err |= kErrUnknownLabel;
-                uint32_t om = byte_flags_to_nibble(zero_bytes(y ^ 0x01010101u));   // (a byte past n_labels reads 0: not a boundary)
-                mine += uint32_t(__popc(om));
-                if (P.tags && om) {   // a token's tag suffix hangs on the label that ends it: char k + q is its last char
-                    const Models4 tm = load_models4(P, o0 + i + k);
-                    uint32_t todo = om & ((tm.m[0] > 0 ? 1u : 0u) | (tm.m[1] > 0 ? 2u : 0u) | (tm.m[2] > 0 ? 4u : 0u) | (tm.m[3] > 0 ? 8u : 0u));
-                    while (todo) {   // the few tokens with a tag model (one call site: the routine is long)
-                        const uint32_t q = uint32_t(__ffs(int(todo))) - 1u;
-                        todo &= todo - 1u;
-                        mine += tag_suffix_of(P, o0 + i + k + q, q == 0 ? tm.m[0] : q == 1 ? tm.m[1] : q == 2 ? tm.m[2] : tm.m[3], nullptr);
-                    }
-                }
-            }
-        }
-        // one reduction for both sums: chars in the high half (a sentence of 2^31 chars is not in this kernel's index width anyway)
-        uint64_t chars, added;
-        if (b1 - b0 < (uint64_t(1) << 30)) {   // one reduction for both sums (wave-uniform; neither can reach 2^32 then)
-            const uint64_t both = wave_sum64(mine | (leads << 32));
-            chars = both >> 32; added = both & 0xFFFFFFFFull;
-        } else { chars = wave_sum64(leads); added = wave_sum64(mine); }
-        uint64_t bytes_out = (b1 - b0) + added;
-        if (!sane) { err |= b1 > b0 ? kErrBadOffsets : kErrEmptySentence; bytes_out = 0; }
-        else if (chars != n_labels + 1) err |= kErrBadOffsets;
-        else bytes_out += tag_suffix(P, o1 + i, nullptr);   // the last token's (every lane computes the same)
-        if (lane == 0) P.out_offsets[i + 1] = bytes_out;
-    }
-    if (err) atomicOr(P.status, err);
 }
 
 // ---- inclusive prefix sum over offsets[1 .. n] in place (offsets[k] = sum of the lengths of sentences 0 .. k-1)
@@ -231,137 +148,321 @@ hipError_t launch_scan(uint64_t* offsets, uint64_t n, uint64_t* part, uint64_t c
     hipLaunchKernelGGL(scan_chained_kernel, dim3(uint32_t(n_part)), dim3(kScanThreads), 0, stream, offsets, n, part, n_part, capacity, status, total_out);
     return hipGetLastError();
 }
-struct EmitLds {
-    uint32_t stage[kEmitWaves][kStageBytes / 4];
-    uint32_t labs[kEmitWaves][68];   // the labels a step's chars can ask for: 256 + 3 bytes, fetched with the step's text
+// ------------------------------------------------------------------------------------------------------------
+// emit_fused_kernel: the whole writer in ONE launch.
+//
+// The batch is FLAT for the writer: the output is the text with insertions (a ' ' in front of a char whose label in front is a
+// boundary, a '\' in front of an escaped byte, "/tag.." in front of the ' ' -- or of the sentence's end -- that ends a token with
+// tags), and the sentences' positions are the output positions of their first bytes.  A WAVE takes a block of consecutive
+// sentences (`per_block` of them, at most 64: about a KB or three of text) and walks its bytes in steps of 1 KB, SIXTEEN bytes per
+// lane, every lane busy whatever the sentences' lengths are:
+//   pass A  what the block will write: its bytes + the escaped bytes + the boundary labels of its label range (plain reductions
+//           over 16-byte loads; with tags: a dry run of pass B) -> published; a decoupled look-back over the earlier blocks'
+//           words (64 of them per trip) gives the block's position in the output
+//   pass B  per step: lead / escape / sentence-start masks of the lane's 16 bytes (the starts come from the block's byte offsets
+//           through an LDS bitmap), ONE DPP prefix sum numbers the lane's chars and sentences, which names the labels of its chars
+//           in the window of labels staged in LDS with the step; a second prefix sum places the lane's output, which is assembled
+//           in LDS and leaves as aligned 16-byte stores.  The lane that holds a sentence's first byte writes its offset and checks
+//           that the sentence starts at the char its boundary offset promises.
+// Blocks take a TICKET, so that every block with a smaller number is running or done (the look-back cannot wait for one that
+// has not started).  The state words of a call (one per block + the ticket) were zeroed by the call before it, which used the
+// other of two arrays: no launch in front of this one.  A word = flag << 62 | value (1: the block's size, 2: the output position
+// behind the block), one 64-bit access.
+// ------------------------------------------------------------------------------------------------------------
+constexpr uint32_t kFuseStepBytes = 1024;                    // text bytes of a wave's step
+constexpr uint32_t kFuseStageBytes = 3 * kFuseStepBytes + 32; // a step's output without tag suffixes (every byte escaped, a space per char) + the alignment head
+constexpr uint32_t kFuseLabDwords = (kFuseStepBytes + 48) / 4;
+struct alignas(16) FuseWaveLds {
+    uint32_t stage[kFuseStageBytes / 4];
+    uint32_t labs[kFuseLabDwords];            // the labels a step's chars can ask for, from a 16-byte aligned address
+    uint32_t starts[kFuseStepBytes / 32];     // one bit per byte of the step: a sentence starts here
+    uint32_t so[kEmitFuseMaxBlock + 1];       // the block's boundary offsets, relative to its first
+    uint32_t dump[64];                        // where a lane's stores of bytes that are not there go
+};
+struct FuseLds {
+    FuseWaveLds w[kEmitWaves];
+    uint64_t ticket;
 };
 
-__global__ __launch_bounds__(kEmitThreads) void emit_write_kernel(const EmitParams P) {
-    __shared__ EmitLds LDS;
-    const int lane = threadIdx.x & 63;
-    const uint32_t wid = wave_uniform(threadIdx.x >> 6);
-    uint32_t* const stage = LDS.stage[wid];
-    uint8_t* const sb = reinterpret_cast<uint8_t*>(stage);
-    uint32_t* const labs = LDS.labs[wid];
-    const uint64_t wave = uint64_t(blockIdx.x) * kEmitWaves + wid;
-    const uint64_t n_waves = uint64_t(gridDim.x) * kEmitWaves;
-    // a sentence's offsets are loaded one sentence ahead (see emit_count_kernel)
-    SentOff nxt = load_sent_off(P, wave);
-    uint64_t nxt_a = wave < P.n_sent ? P.out_offsets[wave] : 0, nxt_e = wave < P.n_sent ? P.out_offsets[wave + 1] : 0;
-    for (uint64_t i = wave; i < P.n_sent; i += n_waves) {
-        const uint64_t b0 = wave_uniform64(nxt.b0), b1 = wave_uniform64(nxt.b1), o0 = wave_uniform64(nxt.o0), o1 = wave_uniform64(nxt.o1);
-        const uint64_t end = wave_uniform64(nxt_e);
-        uint64_t at_out = wave_uniform64(nxt_a), chars = 0;
-        nxt = load_sent_off(P, i + n_waves);
-        if (i + n_waves < P.n_sent) { nxt_a = P.out_offsets[i + n_waves]; nxt_e = P.out_offsets[i + n_waves + 1]; }
-        if (!(b1 > b0 && o1 >= o0 && o1 <= P.total_boundaries)) continue;   // reported by emit_count_kernel
-        const uint64_t n_labels = o1 - o0;
-        const uint8_t* lab = P.labels + o0;
-        if (end > P.capacity || end < at_out) continue;                    // kErrOutputTooSmall
-        bool fits = true;                                                  // `end` only binds when the inputs changed under us
-        for (uint64_t pos = b0; pos < b1 && fits; pos += 256) {
-            const uint64_t at = pos + 4 * uint64_t(lane);
-            // the step's text and the labels its chars can ask for (label[chars - 1] onwards: at most 256 chars start in 256 bytes) leave
-            // in ONE trip to memory; a lane then finds the labels of its own chars in LDS (which ones it learns from the text)
-            const uint64_t lbase = chars ? chars - 1 : 0;
-            const uint32_t x = load4(P.text, at, b1);
-            labs[lane] = load4(lab, lbase + 4 * uint64_t(lane), n_labels);
-            if (lane < 4) labs[64 + lane] = lane == 0 ? load4(lab, lbase + 256, n_labels) : 0u;
-            const uint32_t nv = at < b1 ? uint32_t(b1 - at < 4 ? b1 - at : 4) : 0u, vm = (1u << nv) - 1u;
-            const uint32_t lm = lead_nibble(x) & vm, em = esc_nibble(x) & vm;
-            const uint32_t nl = uint32_t(__popc(lm));
-            const uint32_t incl_l = wave_inclusive_scan(nl);
-            const uint64_t ci0 = chars + (incl_l - nl);                    // index in the sentence of this lane's first char
-            __builtin_amdgcn_wave_barrier();
-            // the labels in front of this lane's chars: label[ci0 - 1 + q] for its q-th char (none in front of char 0)
-            const uint32_t loff = uint32_t((ci0 ? ci0 - 1 : 0) - lbase);   // <= 256
-            uint32_t y = nl ? __builtin_amdgcn_alignbyte(labs[(loff >> 2) + 1], labs[loff >> 2], loff & 3u) : 0u;
-            if (ci0 == 0) y <<= 8;
-            // which of the lane's chars have a space in front (bit q: its q-th char), moved onto the chars' lead bytes (bit k: byte k)
-            const uint32_t spq = byte_flags_to_nibble(zero_bytes(y ^ 0x01010101u)) & ((1u << nl) - 1u);
-            uint32_t spm = 0;
-            {
-                uint32_t rem = lm;
-#pragma unroll
-                for (uint32_t q = 0; q < 4; ++q) {
-                    const uint32_t low = rem & (0u - rem);
-                    if ((spq >> q) & 1u) spm |= low;
-                    rem &= rem - 1u;
-                }
+__device__ __forceinline__ uint32_t lead16(const uint4& x) { return lead_nibble(x.x) | (lead_nibble(x.y) << 4) | (lead_nibble(x.z) << 8) | (lead_nibble(x.w) << 12); }
+__device__ __forceinline__ uint32_t esc16(const uint4& x) { return esc_nibble(x.x) | (esc_nibble(x.y) << 4) | (esc_nibble(x.z) << 8) | (esc_nibble(x.w) << 12); }
+__device__ __forceinline__ uint32_t one_nibble(uint32_t y) { return byte_flags_to_nibble(zero_bytes(y ^ 0x01010101u)); }   // bytes equal to 1
+__device__ __forceinline__ uint32_t one16(const uint4& y) { return one_nibble(y.x) | (one_nibble(y.y) << 4) | (one_nibble(y.z) << 8) | (one_nibble(y.w) << 12); }
+__device__ __forceinline__ uint32_t unk_nibble(uint32_t y) { return byte_flags_to_nibble(~zero_bytes(y & 0xFEFEFEFEu) & 0x80808080u); }   // bytes above 1
+__device__ __forceinline__ uint32_t unk16(const uint4& y) { return unk_nibble(y.x) | (unk_nibble(y.y) << 4) | (unk_nibble(y.z) << 8) | (unk_nibble(y.w) << 12); }
+// which of the 16 bytes at `addr` lie in [lo, hi)
+__device__ __forceinline__ uint32_t in_range16(uintptr_t addr, uintptr_t lo, uintptr_t hi) {
+    const uint32_t a = lo > addr ? (lo - addr < 16 ? uint32_t(lo - addr) : 16u) : 0u;
+    const uint32_t b = hi > addr ? (hi - addr < 16 ? uint32_t(hi - addr) : 16u) : 0u;
+    return b > a ? ((1u << b) - 1u) & ~((1u << a) - 1u) : 0u;
+}
+__device__ __forceinline__ uint32_t byte_of(const uint4& x, uint32_t k) {
+    const uint32_t d = k < 4 ? x.x : k < 8 ? x.y : k < 12 ? x.z : x.w;
+    return (d >> (8 * (k & 3u))) & 0xFFu;
+}
+__device__ __forceinline__ uint32_t byte_of_rt(const uint4& x, uint32_t k) {   // k not known at compile time
+    const uint32_t q = k >> 2;
+    const uint32_t d = q == 0 ? x.x : q == 1 ? x.y : q == 2 ? x.z : x.w;
+    return (d >> (8 * (k & 3u))) & 0xFFu;
+}
+__device__ __forceinline__ uint64_t lane_value64(uint64_t v, int src) {
+    return uint64_t(uint32_t(__builtin_amdgcn_readlane(int(uint32_t(v)), src))) | (uint64_t(uint32_t(__builtin_amdgcn_readlane(int(uint32_t(v >> 32)), src))) << 32);
+}
+
+struct FuseBlock {            // a wave's block (the same in every lane)
+    uint64_t i0, B0, B1, O0, O1;
+    uint32_t ns;
+};
+
+// Pass B over a block (kStore) or its dry run (the size only; with tags).  `my_b`: boff[i0 + lane] for the block's sentences.
+// Returns the bytes the block takes.  `at_out`: where they go; nothing is stored past `end` (the size pass A published) and nothing
+// at all unless `store_ok` (the output fits the caller's buffer).  kTags: the kernel's variant with "/tag" suffixes.
+template <bool kStore, bool kTags>
+__device__ __forceinline__ uint64_t fuse_walk(const EmitParams& P, const FuseBlock& K, uint64_t my_b, int lane, FuseWaveLds& L, uint64_t at_out, uint64_t end,
+                                              bool store_ok, uint32_t& err) {
+    uint8_t* const sbytes = reinterpret_cast<uint8_t*>(L.stage);
+    const uintptr_t t_lo = reinterpret_cast<uintptr_t>(P.text) + K.B0, t_hi = reinterpret_cast<uintptr_t>(P.text) + K.B1;
+    const uintptr_t l_lo = reinterpret_cast<uintptr_t>(P.labels), l_hi = l_lo + P.total_boundaries;
+    const uintptr_t my_start = reinterpret_cast<uintptr_t>(P.text) + my_b;
+    const uint64_t out0 = at_out;
+    uint64_t cb = 0, sb = 0;   // chars / sentence starts of the block in front of the step
+    bool fits = true;
+    for (uintptr_t step = t_lo & ~uintptr_t(15); step < t_hi && fits; step += kFuseStepBytes) {
+        const uintptr_t addr = step + 16u * uint32_t(lane);
+        const uint32_t vm = in_range16(addr, t_lo, t_hi);
+        const uint4 x = vm ? *reinterpret_cast<const uint4*>(addr) : make_uint4(0, 0, 0, 0);
+        // the labels the step's chars can ask for: label (O0 + cb - sb) onwards (every char but a sentence's first has one in front)
+        const uint64_t lw = K.O0 + cb - sb;
+        const uintptr_t lab_at = l_lo + lw, lab_al = lab_at & ~uintptr_t(15);
+        {
+            const uintptr_t a = lab_al + 16u * uint32_t(lane);
+            reinterpret_cast<uint4*>(L.labs)[lane] = (a + 16 > l_lo && a < l_hi) ? *reinterpret_cast<const uint4*>(a) : make_uint4(0, 0, 0, 0);
+            if (lane < 3) {
+                const uintptr_t a2 = lab_al + 16u * uint32_t(64 + lane);
+                reinterpret_cast<uint4*>(L.labs)[64 + lane] = (a2 + 16 > l_lo && a2 < l_hi) ? *reinterpret_cast<const uint4*>(a2) : make_uint4(0, 0, 0, 0);
             }
-            // the token in front of a space ends at the char before it and its tags go in front of the space: the tag models of
-            // chars ci0 - 1 .. ci0 + 2 in one load, the suffix lengths of the few that have one (one call site: the routine is long)
-            uint32_t sfx[4] = {0, 0, 0, 0};
-            Models4 tm = {{0, 0, 0, 0}};
-            if (P.tags && spq) {
-                tm = load_models4(P, o0 + i + (ci0 ? ci0 - 1 : 0));
-                if (ci0 == 0) { tm.m[3] = tm.m[2]; tm.m[2] = tm.m[1]; tm.m[1] = tm.m[0]; tm.m[0] = 0; }
-                uint32_t todo = spq & ((tm.m[0] > 0 ? 1u : 0u) | (tm.m[1] > 0 ? 2u : 0u) | (tm.m[2] > 0 ? 4u : 0u) | (tm.m[3] > 0 ? 8u : 0u));
-                while (todo) {
-                    const uint32_t q = uint32_t(__ffs(int(todo))) - 1u;
-                    todo &= todo - 1u;
-                    const uint32_t len = tag_suffix_of(P, o0 + i + ci0 + q - 1, q == 0 ? tm.m[0] : q == 1 ? tm.m[1] : q == 2 ? tm.m[2] : tm.m[3], nullptr);
-                    // char q's lead byte: the q-th set bit of lm
-                    uint32_t rem = lm;
-                    for (uint32_t r = 0; r < q; ++r) rem &= rem - 1u;
-                    const uint32_t k = uint32_t(__ffs(int(rem))) - 1u;
-                    sfx[0] += k == 0 ? len : 0u; sfx[1] += k == 1 ? len : 0u; sfx[2] += k == 2 ? len : 0u; sfx[3] += k == 3 ? len : 0u;
-                }
+        }
+        if (uint32_t(lane) < K.ns && my_start >= step && my_start - step < kFuseStepBytes) {
+            const uint32_t r = uint32_t(my_start - step);
+            atomicOr(&L.starts[r >> 5], 1u << (r & 31u));
+        }
+        __builtin_amdgcn_wave_barrier();
+        uint32_t sm = (L.starts[lane >> 1] >> (16 * (lane & 1))) & 0xFFFFu;
+        __builtin_amdgcn_wave_barrier();
+        if (lane < int(kFuseStepBytes / 32)) L.starts[lane] = 0;
+        const uint32_t lm = lead16(x) & vm, em = esc16(x) & vm;
+        if (sm & ~lm) err |= kErrBadOffsets;   // a sentence that starts inside a char (or outside the block)
+        sm &= lm;
+        const uint32_t nl = uint32_t(__popc(lm)), nst = uint32_t(__popc(sm));
+        const uint32_t incl = wave_inclusive_scan(nl | (nst << 16));
+        const uint32_t tot = uint32_t(__builtin_amdgcn_readlane(int(incl), 63));
+        const uint32_t c_in = (incl & 0xFFFFu) - nl, s_in = (incl >> 16) - nst;   // chars / starts of the step in front of this lane
+        // the lane's chars that have a label in front take consecutive labels from (c_in - s_in) of the window on
+        const uint32_t nm = lm & ~sm;
+        const uint32_t loff = uint32_t(lab_at - lab_al) + (c_in - s_in);           // byte offset in labs: <= 15 + 1024
+        uint32_t spm = 0;
+        {
+            const uint32_t d = loff >> 2, r = loff & 3u;
+            uint4 y;
+            y.x = __builtin_amdgcn_alignbyte(L.labs[d + 1], L.labs[d], r); y.y = __builtin_amdgcn_alignbyte(L.labs[d + 2], L.labs[d + 1], r);
+            y.z = __builtin_amdgcn_alignbyte(L.labs[d + 3], L.labs[d + 2], r); y.w = __builtin_amdgcn_alignbyte(L.labs[d + 4], L.labs[d + 3], r);
+            uint32_t bits = one16(y), rem = nm;
+            while (rem) {   // label q of the lane onto its q-th labelled char
+                const uint32_t low = rem & (0u - rem);
+                if (bits & 1u) spm |= low;
+                bits >>= 1;
+                rem &= rem - 1u;
             }
-            const uint32_t t = nv + uint32_t(__popc(spm)) + uint32_t(__popc(em)) + sfx[0] + sfx[1] + sfx[2] + sfx[3];
-            const uint32_t incl_t = wave_inclusive_scan(t);
-            const uint32_t total = uint32_t(__builtin_amdgcn_readlane(int(incl_t), 63));
-            const uint32_t w = incl_t - t;                                 // where this lane's output starts in the step's
+        }
+        // tag suffixes go in front of a space and in front of a sentence's first byte (the last token of the sentence before it),
+        // except the block's first (the block before this one wrote that one behind its last byte)
+        uint32_t tmask = 0, sfx_total = 0;
+        const uint64_t g_first = K.O0 + K.i0 + cb + c_in;     // batch-flat index of the lane's first char
+        if (kTags) {
+            tmask = spm | sm;
+            if (sb + s_in == 0 && sm) tmask &= ~(sm & (0u - sm));
+            uint32_t todo = tmask;
+            while (todo) {
+                const uint32_t low = todo & (0u - todo);
+                todo &= todo - 1u;
+                sfx_total += tag_suffix(P, g_first + uint32_t(__popc(lm & (low - 1u))) - 1u, nullptr);
+            }
+        }
+        const uint32_t t = uint32_t(__popc(vm)) + uint32_t(__popc(spm)) + uint32_t(__popc(em)) + sfx_total;
+        const uint32_t incl_t = wave_inclusive_scan(t);
+        const uint32_t total = uint32_t(__builtin_amdgcn_readlane(int(incl_t), 63));
+        if (kStore) {
             if (at_out + total > end) { fits = false; break; }
             uint8_t* const dst = P.out_text + at_out;
-            const uint32_t head = uint32_t(reinterpret_cast<uintptr_t>(dst) & 3u);
-            const bool staged = head + total <= kStageBytes;               // (wave-uniform) else: byte stores straight to the output
-            auto put = [&](uint8_t* const o) {   // byte k of the lane goes to w + k + what is inserted up to it: [tags] [' '] ['\\'] byte
-                uint32_t ins = w;
+            const uint32_t head = uint32_t(reinterpret_cast<uintptr_t>(dst) & 15u);
+            const bool staged = !kTags || head + total <= kFuseStageBytes;   // (wave-uniform) else: byte stores straight to the output
+            const uint32_t w = incl_t - t;
+            if (!kTags) {
+                // the lane's bytes in order: [' '] ['\\'] byte.  No branches: what is not there goes to a slot of the lane's own
+                if (store_ok) {
+                    uint8_t* const o = sbytes + head;
+                    uint8_t* const dump = reinterpret_cast<uint8_t*>(L.dump + lane);
+                    uint32_t pos = w;
 #pragma unroll
-                for (uint32_t k = 0; k < 4; ++k) {
-                    const uint32_t sp = (spm >> k) & 1u, es = (em >> k) & 1u;
-                    ins += sfx[k] + sp + es;
-                    if (k < nv) {
-                        o[ins + k] = uint8_t(x >> (8 * k));
-                        if (es) o[ins + k - 1u] = 0x5Cu;
-                        if (sp) o[ins + k - 1u - es] = 0x20u;
+                    for (uint32_t k = 0; k < 16; ++k) {
+                        const uint32_t v = (vm >> k) & 1u, sp = (spm >> k) & 1u, es = (em >> k) & 1u;
+                        *(sp ? o + pos : dump) = 0x20u; pos += sp;
+                        *(es ? o + pos : dump) = 0x5Cu; pos += es;
+                        *(v ? o + pos : dump) = uint8_t(byte_of(x, k)); pos += v;
                     }
                 }
-                uint32_t todo = (sfx[0] ? 1u : 0u) | (sfx[1] ? 2u : 0u) | (sfx[2] ? 4u : 0u) | (sfx[3] ? 8u : 0u);
-                while (todo) {   // rare: the tags themselves, in front of the space of lead byte k
-                    const uint32_t k = uint32_t(__ffs(int(todo))) - 1u;
-                    todo &= todo - 1u;
-                    uint32_t at_k = w + k, q = 0;   // bytes of the lane in front of byte k's own insertions; k is the lane's q-th char
-                    for (uint32_t j = 0; j < k; ++j) { at_k += sfx[j] + ((spm >> j) & 1u) + ((em >> j) & 1u); q += (lm >> j) & 1u; }
-                    (void)tag_suffix_of(P, o0 + i + ci0 + q - 1, q == 0 ? tm.m[0] : q == 1 ? tm.m[1] : q == 2 ? tm.m[2] : tm.m[3], o + at_k);
+                uint32_t rem = sm;   // the sentences that start in the lane's bytes (few lanes, one as a rule)
+                while (rem) {
+                    const uint32_t k = uint32_t(__ffs(int(rem))) - 1u, below = (1u << k) - 1u;
+                    rem &= rem - 1u;
+                    const uint64_t s = sb + s_in + uint32_t(__popc(sm & below));
+                    if (s < K.ns) {
+                        P.out_offsets[K.i0 + s] = at_out + w + uint32_t(__popc(vm & below)) + uint32_t(__popc(spm & below)) + uint32_t(__popc(em & below));
+                        if (cb + c_in + uint32_t(__popc(lm & below)) != uint64_t(L.so[s]) + s) err |= kErrBadOffsets;   // not the char its offset names
+                    } else err |= kErrBadOffsets;
                 }
-            };
-            if (staged) put(sb + head);   // (two calls: one writes LDS, one global memory -- not one through a generic pointer)
-            else put(dst);
-            if (staged) {   // LDS byte j is output byte j - head: whole dwords leave aligned, the two edges byte by byte
+            } else {
+                // [tags] [' '] | sentence offset | ['\\'] byte, one loop for every case (o: LDS or the output itself)
+                uint8_t* const o = !store_ok ? nullptr : staged ? sbytes + head : dst;
+                uint32_t pos = w, ci = 0;
+#pragma unroll 1
+                for (uint32_t k = 0; k < 16; ++k) {
+                    if (!((vm >> k) & 1u)) continue;
+                    if ((tmask >> k) & 1u) pos += tag_suffix(P, g_first + ci - 1u, o ? o + pos : nullptr);
+                    if ((spm >> k) & 1u) { if (o) o[pos] = 0x20u; ++pos; }
+                    if ((sm >> k) & 1u) {
+                        const uint64_t s = sb + s_in + uint32_t(__popc(sm & ((1u << k) - 1u)));
+                        if (s < K.ns) {
+                            P.out_offsets[K.i0 + s] = at_out + pos;
+                            if (cb + c_in + ci != uint64_t(L.so[s]) + s) err |= kErrBadOffsets;
+                        } else err |= kErrBadOffsets;
+                    }
+                    if ((em >> k) & 1u) { if (o) o[pos] = 0x5Cu; ++pos; }
+                    if (o) o[pos] = uint8_t(byte_of_rt(x, k));
+                    ++pos;
+                    ci += (lm >> k) & 1u;
+                }
+            }
+            if (store_ok && staged) {   // LDS byte j is output byte j - head: whole 16-byte chunks leave aligned, the two edges byte by byte
                 __builtin_amdgcn_wave_barrier();
                 uint8_t* const abase = dst - head;
-                const uint32_t nd = (head + total + 3u) >> 2;
+                const uint32_t nd = (head + total + 15u) >> 4;
                 for (uint32_t d = uint32_t(lane); d < nd; d += 64) {
-                    const uint32_t lo = d * 4u, hi = lo + 4u;
+                    const uint32_t lo = d * 16u, hi = lo + 16u;
                     if (lo >= head && hi <= head + total) {
-                        *reinterpret_cast<uint32_t*>(abase + lo) = stage[d];
+                        *reinterpret_cast<uint4*>(abase + lo) = reinterpret_cast<const uint4*>(L.stage)[d];
                     } else {
                         const uint32_t a = lo > head ? lo : head, b = hi < head + total ? hi : head + total;
-                        for (uint32_t j = a; j < b; ++j) abase[j] = sb[j];
+                        for (uint32_t j = a; j < b; ++j) abase[j] = sbytes[j];
                     }
                 }
                 __builtin_amdgcn_wave_barrier();
             }
-            at_out += total;
-            chars += uint32_t(__builtin_amdgcn_readlane(int(incl_l), 63));
         }
-        if (fits && lane == 0 && chars == n_labels + 1) {                  // the last token's tags
-            const uint32_t s = tag_suffix(P, o1 + i, nullptr);
-            if (s && at_out + s <= end) tag_suffix(P, o1 + i, P.out_text + at_out);
-        }
+        at_out += total;
+        cb += tot & 0xFFFFu;
+        sb += tot >> 16;
     }
+    if (kTags && fits) {   // the tags of the block's last token
+        const uint64_t g_last = K.O1 + K.i0 + K.ns - 1;
+        const uint32_t s = tag_suffix(P, g_last, nullptr);   // (every lane computes the same)
+        if (kStore && s && store_ok && at_out + s <= end && lane == 0) tag_suffix(P, g_last, P.out_text + at_out);
+        at_out += s;
+    }
+    if (kStore && fits && (cb != (K.O1 - K.O0) + K.ns || sb != K.ns)) err |= kErrBadOffsets;
+    return at_out - out0;
+}
+
+template <bool kTags>
+__global__ __launch_bounds__(kEmitThreads) void emit_fused_kernel(const EmitParams P, const EmitFuse F) {
+    __shared__ FuseLds LDS;
+    // the other array of state words, for the call after this one
+    for (uint64_t k = uint64_t(blockIdx.x) * kEmitThreads + threadIdx.x; k < F.clear_n; k += uint64_t(gridDim.x) * kEmitThreads) F.clear[k] = 0;
+    const int lane = threadIdx.x & 63;
+    const uint32_t wid = wave_uniform(threadIdx.x >> 6);
+    FuseWaveLds& L = LDS.w[wid];
+    // a workgroup's waves take consecutive tickets with one atomic
+    if (threadIdx.x == 0) LDS.ticket = atomicAdd(reinterpret_cast<unsigned long long*>(F.state + F.n_blocks), (unsigned long long)kEmitWaves);
+    __syncthreads();
+    const uint64_t blk = wave_uniform64(LDS.ticket) + wid;
+    if (blk >= F.n_blocks) return;   // (the grid is whole workgroups)
+    FuseBlock K;
+    K.i0 = blk * F.per_block;
+    K.ns = uint32_t(P.n_sent - K.i0 < F.per_block ? P.n_sent - K.i0 : F.per_block);
+    // the block's offsets: lane j holds sentence i0 + j's; what follows the block's last in every lane
+    uint64_t my_b = ~uint64_t(0), my_o = 0;
+    if (uint32_t(lane) < K.ns) { my_b = P.boff[K.i0 + lane]; my_o = P.ooff[K.i0 + lane]; }
+    K.B1 = wave_uniform64(P.boff[K.i0 + K.ns]); K.O1 = wave_uniform64(P.ooff[K.i0 + K.ns]);
+    K.B0 = lane_value64(my_b, 0); K.O0 = lane_value64(my_o, 0);
+    uint32_t err = 0;
+    bool sane;
+    {
+        const int up = (lane + 1) & 63;
+        const uint64_t nb = uint64_t(uint32_t(__shfl(int(uint32_t(my_b)), up))) | (uint64_t(uint32_t(__shfl(int(uint32_t(my_b >> 32)), up))) << 32);
+        const uint64_t no = uint64_t(uint32_t(__shfl(int(uint32_t(my_o)), up))) | (uint64_t(uint32_t(__shfl(int(uint32_t(my_o >> 32)), up))) << 32);
+        const bool last = uint32_t(lane) + 1 == K.ns;
+        const uint64_t b_next = last ? K.B1 : nb, o_next = last ? K.O1 : no;
+        const bool mine = uint32_t(lane) < K.ns;
+        const bool empty = mine && b_next <= my_b, bad = mine && (o_next < my_o || o_next > P.total_boundaries);
+        if (empty) err |= kErrEmptySentence;
+        if (bad) err |= kErrBadOffsets;
+        sane = __ballot(empty || bad) == 0 && K.O1 - K.O0 < 0xFFFF0000ull && K.B1 - K.B0 < 0xFFFF0000ull;
+        if (!sane) err |= kErrBadOffsets;
+    }
+    if (uint32_t(lane) < K.ns) L.so[lane] = uint32_t(my_o - K.O0);
+    if (lane == 0) L.so[K.ns] = uint32_t(K.O1 - K.O0);
+    if (lane < int(kFuseStepBytes / 32)) L.starts[lane] = 0;
+    __builtin_amdgcn_wave_barrier();
+
+    // ---- pass A: the block's size
+    uint64_t size = 0;
+    if (sane) {
+        uint32_t added = 0;
+        const uintptr_t l_lo = reinterpret_cast<uintptr_t>(P.labels) + K.O0, l_hi = reinterpret_cast<uintptr_t>(P.labels) + K.O1;
+        if (!kTags) {
+            const uintptr_t t_lo = reinterpret_cast<uintptr_t>(P.text) + K.B0, t_hi = reinterpret_cast<uintptr_t>(P.text) + K.B1;
+            for (uintptr_t a = (t_lo & ~uintptr_t(15)) + 16u * uint32_t(lane); a < t_hi; a += kFuseStepBytes)
+                added += uint32_t(__popc(esc16(*reinterpret_cast<const uint4*>(a)) & in_range16(a, t_lo, t_hi)));
+        }
+        for (uintptr_t a = (l_lo & ~uintptr_t(15)) + 16u * uint32_t(lane); a < l_hi; a += kFuseStepBytes) {
+            const uint4 y = *reinterpret_cast<const uint4*>(a);
+            const uint32_t m = in_range16(a, l_lo, l_hi);
+            added += uint32_t(__popc(one16(y) & m));
+            if (unk16(y) & m) err |= kErrUnknownLabel;
+        }
+        if (kTags) size = fuse_walk<false, true>(P, K, my_b, lane, L, 0, ~uint64_t(0), false, err);   // (the labels above: only their check)
+        else size = (K.B1 - K.B0) + wave_sum64(added);
+    }
+
+    // ---- the block's position: the earlier blocks' words, 64 per trip
+    constexpr uint64_t kVal = (uint64_t(1) << 62) - 1;
+    if (lane == 0) __hip_atomic_store(F.state + blk, (uint64_t(1) << 62) | size, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    uint64_t base = 0;
+    for (uint64_t p = blk; p > 0;) {
+        const bool have = uint64_t(lane) < p;
+        uint64_t w = uint64_t(2) << 62;   // in front of block 0: position 0
+        if (have) w = __hip_atomic_load(F.state + (p - 1 - uint64_t(lane)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const uint64_t pending = __ballot((w >> 62) == 0), prefixed = __ballot((w >> 62) == 2);
+        const int first = prefixed ? __ffsll((long long)prefixed) - 1 : 64;   // the nearest block whose position is known
+        const uint64_t need = first < 63 ? (uint64_t(2) << first) - 1 : ~uint64_t(0);
+        if (pending & need) { __builtin_amdgcn_s_sleep(2); continue; }         // not all published yet: look again
+        base += wave_sum64(lane <= first ? (w & kVal) : 0);
+        if (first < 64) break;
+        p -= 64;
+    }
+    if (lane == 0) __hip_atomic_store(F.state + blk, (uint64_t(2) << 62) | ((base + size) & kVal), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const uint64_t end = base + size;
+    const bool store_ok = end <= P.capacity;
+    if (blk == F.n_blocks - 1 && lane == 0) {
+        P.out_offsets[P.n_sent] = end;
+        if (end > P.capacity) err |= kErrOutputTooSmall;
+        if (F.total_out) *F.total_out = end;
+    }
+
+    // ---- pass B
+    if (sane) (void)fuse_walk<true, kTags>(P, K, my_b, lane, L, base, end, store_ok, err);
+    else if (uint32_t(lane) < K.ns) P.out_offsets[K.i0 + lane] = base;
+    if (err) atomicOr(P.status, err);
 }
 
 // vpt_count_boundaries on the device: chars - 1 of every sentence -> offsets[i + 1] (the scan follows), the same
@@ -414,12 +515,10 @@ hipError_t launch_count_boundaries(const uint8_t* text, const uint64_t* boff, ui
     return launch_scan(ooff_out, n_sent, scan_part, ~uint64_t(0), status, nullptr, stream);
 }
 
-hipError_t launch_emit_tokenized(const EmitParams& P, uint64_t* scan_part, uint32_t max_blocks, uint64_t* total_out, hipStream_t stream) {
-    const uint32_t blocks = emit_blocks(P.n_sent, max_blocks);
-    hipLaunchKernelGGL(emit_count_kernel, dim3(blocks), dim3(kEmitThreads), 0, stream, P, scan_part);
-    const hipError_t e = launch_scan(P.out_offsets, P.n_sent, scan_part, P.capacity, P.status, total_out, stream);
-    if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(emit_write_kernel, dim3(blocks), dim3(kEmitThreads), 0, stream, P);
+hipError_t launch_emit_tokenized(const EmitParams& P, const EmitFuse& F, hipStream_t stream) {
+    const dim3 grid(uint32_t((F.n_blocks + kEmitWaves - 1) / kEmitWaves));
+    if (P.tags) hipLaunchKernelGGL(emit_fused_kernel<true>, grid, dim3(kEmitThreads), 0, stream, P, F);
+    else hipLaunchKernelGGL(emit_fused_kernel<false>, grid, dim3(kEmitThreads), 0, stream, P, F);
     return hipGetLastError();
 }
 

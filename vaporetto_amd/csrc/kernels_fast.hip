@@ -620,7 +620,7 @@ __global__ __launch_bounds__(kThreads, kFastWg) void score_tiles_fast_kernel(con
                 const uint32_t s_t = uint32_t(tid) + uint32_t(k) * kThreads;
                 const bool hit = t_slot[k] != ~0u && (tn[k].x & kTriParentMask) == b_slot[k] + 1u;
                 if (hit) add_child(L.score, s_t, tn[k].y, tn[k].z);   // a kPkWide node holds zero weights
-                const bool wide = hit && (tn[k].x & (kPkWide << 24));
+                const bool wide = hit && (tn[k].x & (kPkWide << kTriFlagShift));
                 uint32_t kids = hit ? tn[k].w : 0u;
                 drain_w(K, L, Q, lane, kQHigh);                 // room for one more round of pushes
                 Q.push_w(kids != 0, s_t | (3u << 11), kids);
@@ -672,7 +672,7 @@ __global__ __launch_bounds__(kThreads, kFastWg) void score_tiles_fast_kernel(con
         if (do_t) {
             const bool hit = t_slot != ~0u && (tn.x & kTriParentMask) == t_par;
             if (hit) add_child(L.score, s_t, tn.y, tn.z);   // a kPkWide node holds zero weights
-            const bool wide = hit && (tn.x & (kPkWide << 24));
+            const bool wide = hit && (tn.x & (kPkWide << kTriFlagShift));
             uint32_t kids = hit ? tn.w : 0u;
             VPT_PIN(kids);
             drain_w(K, L, Q, lane, kQHigh);                 // room for one more round of pushes

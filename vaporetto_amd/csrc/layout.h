@@ -121,7 +121,7 @@ constexpr int kBiFieldBits = 19;               // bigram node (dwords 1..3): fiv
 constexpr uint32_t kUniBaseShift = 12, kUniBaseMask = 0x7FFFFu;   // dword 3 of a unigram node: B1 at bits 12..30
 constexpr uint32_t kUniWideBit = 0x80000000u;  // dword 3 of a unigram node: the row is in the general tables (i32)
 constexpr uint32_t kBiWideBit = 0x80000000u;   // dword 3 of a bigram node: likewise
-constexpr uint32_t kTriParentMask = 0xFFFFFFu; // dword 0 of a trigram node: parent slot + 1; cflags above
+constexpr uint32_t kTriParentMask = 0x0FFFFFFFu, kTriFlagShift = 28;   // dword 0 of a trigram node: parent slot + 1; cflags above
 constexpr uint32_t kCinfoLinebreak = 1u << 29; // cid word: the (scored) char is '\n' or '\r' (where the kernel's symbol word keeps it)
 constexpr uint32_t kCharCacheNoEntry = 0u;     // char cache (layout below): an empty slot
 #ifndef VPT_BI_DENSE

@@ -495,9 +495,12 @@ HostPackedTable build_packed(const PatSet& S) {
         size_t spans = dense_slots;
         for (const auto& r : rest) if (!r.empty()) spans += r.back().id2 - r.front().id2 + 1;
         t.bi_shift = 2;
-        while (t.bi_shift < 8 && (size_t(kUniBaseMask) << t.bi_shift) < spans / 2) ++t.bi_shift;
+        while (t.bi_shift < 8 && (size_t(kUniBaseMask) << t.bi_shift) < spans / 16) ++t.bi_shift;
         for (;; ++t.bi_shift) {
-            if (t.bi_shift > 8) return t;   // not placeable within the format: the general tables serve the model
+            if (t.bi_shift > 8) {   // not placeable within the format: the general tables serve the model
+                if (tm.on) std::fprintf(stderr, "[vpt compile] packed tables refused: bigram bases do not fit %u bits\n", 19u);
+                return t;
+            }
             Placer pl(8192, 8192);
             for (size_t i = 0; i < dense_slots; ++i) pl.occ.set(i);
             bool ok = true;
@@ -521,7 +524,10 @@ HostPackedTable build_packed(const PatSet& S) {
         for (uint32_t v : b1) max_base = std::max<size_t>(max_base, size_t(v) << t.bi_shift);
         bi_slots = std::max(bi_slots, max_base + 65536);
     }
-    if (bi_slots >= kTriParentMask) return t;
+    if (bi_slots >= kTriParentMask) {
+        if (tm.on) std::fprintf(stderr, "[vpt compile] packed tables refused: %zu bigram slots (shift %u) for %zu nodes\n", bi_slots, t.bi_shift, prefixes.size());
+        return t;
+    }
     tm.mark("packed: bigram placement");
 
     // ---- trigram level: the children of bigram node p sit at B2[p] + id3
@@ -577,7 +583,7 @@ HostPackedTable build_packed(const PatSet& S) {
             uint32_t fl = 0;
             if (k.pat && wide16(*k.pat)) { fl |= kPkWide; ++t.n_wide; }
             else if (k.pat) { const int32_t* w = S.row(*k.pat); e[1] = pack16(w[0], w[1]); e[2] = pack16(w[2], w[3]); }
-            e[0] = (pf.slot + 1) | (fl << 24);
+            e[0] = (pf.slot + 1) | (fl << kTriFlagShift);
             e[3] = k.ref;
             ++t.n_tri;
         }

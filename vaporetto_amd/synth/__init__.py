@@ -32,6 +32,7 @@ def _load():
         build_synth()
         L = C.CDLL(LIB_PATH)
         L.vpt_synth_model.argtypes = [C.c_int, C.c_uint64, C.c_double, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]
+        L.vpt_synth_model_ex.argtypes = [C.c_int, C.c_uint64, C.c_double, C.c_uint32, C.c_double, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]
         L.vpt_synth_sentences.argtypes = [C.c_char_p, C.c_size_t, C.c_uint64, C.c_size_t, C.c_uint32, C.c_uint32,
                                           C.POINTER(C.c_void_p), C.POINTER(C.c_size_t), C.POINTER(C.c_void_p)]
         L.vpt_synth_blocks.argtypes = [C.c_char_p, C.c_size_t, C.c_uint64, C.c_size_t, C.c_size_t, C.c_size_t, C.c_uint32, C.c_uint32, C.c_uint32,
@@ -41,11 +42,12 @@ def _load():
     return _lib
 
 
-def synth_model(kind: int = M1_BCCWJ_LIKE, seed: int = SEED_BASE + 2, scale: float = 1.0) -> bytes:
-    """Model file bytes ("VaporettoTokenizer 0.5.0\\n" + bincode) of the documented shape."""
+def synth_model(kind: int = M1_BCCWJ_LIKE, seed: int = SEED_BASE + 2, scale: float = 1.0, vocab: int = 0, dup_share: float = 0.0) -> bytes:
+    """Model file bytes ("VaporettoTokenizer 0.5.0\\n" + bincode) of the documented shape.  vocab / dup_share: the model-shape sweep's
+    knobs (alphabet size; share of dictionary words that repeat a char n-gram, i.e. of rows outside the packed fields)."""
     L = _load()
     out, n = C.c_void_p(), C.c_size_t()
-    st = L.vpt_synth_model(kind, seed, scale, C.byref(out), C.byref(n))
+    st = L.vpt_synth_model_ex(kind, seed, scale, vocab, dup_share, C.byref(out), C.byref(n))
     if st != 0:
         raise RuntimeError("vpt_synth_model failed: %d" % st)
     try:

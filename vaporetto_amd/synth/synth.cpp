@@ -113,10 +113,17 @@ void vpt_synth_free(void* p) { std::free(p); }
 // kind: 1 = M1 (bccwj-suw+unidic-like), 2 = M2 (jp-0.4.7-5-like), 3 = M3 (M1 + tag models), 4 / 5 = M1 trained with
 // --charw 2 --typew 2 / --charw 4 --typew 4 (train/src/main.rs:33-51: the windows are free parameters).  scale multiplies
 // every count (1.0 = full size).  Returns 0 and a malloc'ed model file.
+int vpt_synth_model_ex(int kind, uint64_t seed, double scale, uint32_t vocab, double dup_share, uint8_t** out, size_t* out_len);
 int vpt_synth_model(int kind, uint64_t seed, double scale, uint8_t** out, size_t* out_len) {
-    if (kind < 1 || kind > 5 || !(scale > 0) || !out || !out_len) return 2;
+    return vpt_synth_model_ex(kind, seed, scale, 0, 0.0, out, out_len);
+}
+// vocab (0: 4000 at full scale): size of the alphabet -- a unidic-sized model has about twice M1's; dup_share: that share of the
+// dictionary words are copies of the model's own 2- and 3-char n-grams, whose merged rows then overflow the packed tables' 16-bit
+// fields (the kernel's wide-row path); the model-shape sweep of tools/model_sweep.py
+int vpt_synth_model_ex(int kind, uint64_t seed, double scale, uint32_t vocab_size, double dup_share, uint8_t** out, size_t* out_len) {
+    if (kind < 1 || kind > 5 || !(scale > 0) || !out || !out_len || vocab_size > 20000 || dup_share < 0 || dup_share > 1) return 2;
     Rng r(seed);
-    const uint32_t V = std::max<uint32_t>(300, uint32_t(4000 * std::min(1.0, std::sqrt(scale))));
+    const uint32_t V = vocab_size ? std::max<uint32_t>(300, vocab_size) : std::max<uint32_t>(300, uint32_t(4000 * std::min(1.0, std::sqrt(scale))));
     const std::vector<uint32_t> vocab = make_vocab(V);
     const size_t n_bi = size_t(400000 * scale), n_tri = size_t(600000 * scale);
     const size_t n_dict = size_t((kind == 2 ? 1000000 : 700000) * scale);
@@ -172,6 +179,14 @@ int vpt_synth_model(int kind, uint64_t seed, double scale, uint8_t** out, size_t
         size_t tries = 0;
         while (words.size() < n_dict && tries < n_dict * 50) {
             ++tries;
+            if (dup_share > 0 && r.uniform() < dup_share && grams.size() > V) {   // a copy of one of the 2- / 3-char n-grams
+                const std::vector<uint32_t>& src = grams[V + r.below(uint32_t(grams.size() - V))];
+                uint64_t key = 0x9E3779B97F4A7C15ull + src.size();
+                for (uint32_t c : src) key = key * 0x100000001B3ull + c;
+                if (!seen.insert(key).second) continue;
+                words.push_back(src);
+                continue;
+            }
             uint32_t L = dict_len(r, kind);
             std::vector<uint32_t> g(L);
             uint64_t key = L;
