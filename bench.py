@@ -328,7 +328,7 @@ class Runner:
             out_bytes = int(toff[-1])
             moved = nbytes + nb + out_bytes + 16 * S + (4 * (nb + S) * (nt + 1) if nt else 0)   # text + labels (+ tags, token models) in, text + offsets out
             emit_info = {"ms_per_step": 1e3 * dt, "out_bytes": out_bytes, "algorithmic_GBps": moved / dt / 1e9, "frac_of_hbm": moved / dt / 1e9 / HBM_PEAK_GBS,
-                         "kernels": "count + prefix sum + write (kernels_emit.hip), %s" % ("tagged" if nt else "boundaries only")}
+                         "kernels": "emit_fused_kernel: one launch (kernels_emit.hip), %s" % ("tagged" if nt else "boundaries only")}
             # the whole output is compared with the oracle's writer below (sentence.rs:850-886 restated in oracle/vaporetto_oracle.c)
             emit_out = (d_out[:out_bytes].cpu().numpy(), toff) if not args.no_cpu_baseline else None
             del d_out, d_toff

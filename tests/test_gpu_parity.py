@@ -1259,6 +1259,17 @@ def test_writer_blocks_of_any_size(per_block, monkeypatch):
     got = tagged.write_tokenized_batch(sents, tagged=True)
     tagged.fill_tags_batch(sents)
     assert got == [s.write_tokenized_text() for s in sents]
+    # one-byte chars whose one- and two-char tokens nearly all have tags: many suffixes in front of a lane's sixteen bytes
+    m2 = randmodel.rand_model(844, alphabet=list("abc"), wc=3, wt=3, n_tag_models=12, max_word=2, n_char=20, n_dict=10)
+    dense = api.Predictor(api.Model.read_slice(encode_model(m2))[0], True)
+    sents = [api.Sentence.from_raw("".join(rng.choice(list("abc"), size=int(n)))) for n in list(rng.integers(1, 90, 120)) + [400]]
+    dense.predict_batch(sents)
+    for s in sents:
+        s._boundaries = (rng.random(len(s._boundaries)) < 0.7).astype(np.uint8)
+    got = dense.write_tokenized_batch(sents, tagged=True)
+    dense.fill_tags_batch(sents)
+    assert got == [s.write_tokenized_text() for s in sents]
+    assert sum(g.count("/") for g in got) > 1000
 
 
 WRITER_TEST_SENTENCES = 9000   # (tests/test_kernel_emu.py runs the same test on fewer)

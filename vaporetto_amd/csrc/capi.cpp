@@ -51,6 +51,7 @@ struct BatchKnobs {
     bool no_cps_from_predict = false;   // VPT_NO_CPS_FROM_PREDICT
     uint32_t debug_ablate = 0;          // VPT_DEBUG_ABLATE
     bool profile_phases = false;        // VPT_PROFILE_PHASES
+    uint32_t debug_emit = 0;            // VPT_DEBUG_EMIT
     uint32_t emit_per_block = 0;        // VPT_EMIT_PER_BLOCK: sentences a wave of the writer takes (1..64; 0: from the mean sentence length)
 };
 PredictorKnobs read_predictor_knobs() {
@@ -68,6 +69,7 @@ BatchKnobs read_batch_knobs() {
     k.force_generic = std::getenv("VPT_FORCE_GENERIC") != nullptr;
     if (const char* v = std::getenv("VPT_FORCE_CUT_TILES")) k.force_cut = std::atoi(v);
     if (const char* v = std::getenv("VPT_TILE_FLAT")) k.tile_flat = uint32_t(std::max(0, std::atoi(v)));
+    if (const char* v = std::getenv("VPT_DEBUG_EMIT")) k.debug_emit = uint32_t(std::max(0, std::atoi(v)));
     if (const char* v = std::getenv("VPT_EMIT_PER_BLOCK")) k.emit_per_block = uint32_t(std::min(64, std::max(0, std::atoi(v))));
     k.no_cps_from_predict = std::getenv("VPT_NO_CPS_FROM_PREDICT") != nullptr;
     if (const char* v = std::getenv("VPT_DEBUG_ABLATE")) k.debug_ablate = uint32_t(std::atoi(v));
@@ -1412,7 +1414,7 @@ vpt_status vpt_fill_tags_scores_batch_device(const vpt_predictor* p, vpt_batch* 
     const uint64_t total_c = total_boundaries + n_sentences;
     vpt_status st = grow(&b->d_cps, &b->cps_cap, size_t(total_c) + 16);
     if (st != VPT_OK) return st;
-    if ((st = grow(&b->d_tok_model, &b->tok_model_cap, size_t(total_c) + 16)) != VPT_OK) return st;
+    if ((st = grow(&b->d_tok_model, &b->tok_model_cap, size_t(total_c) + 16 + 4)) != VPT_OK) return st;   // (+ 4 in front: the writer reads the entry before a char's)
     b->tok_model_chars = total_c;
     const uint32_t* cinfo = p->d_cinfo + ((b->flags & VPT_FLAG_KYTEA_FULLWIDTH) ? 65536 : 0);
     const bool have_cps = b->cps_text == d_utf8 && b->cps_ooff == d_out_offsets && b->cps_sentences == n_sentences &&
@@ -1426,7 +1428,7 @@ vpt_status vpt_fill_tags_scores_batch_device(const vpt_predictor* p, vpt_batch* 
     T.weights = p->dtag.weights; T.cinfo = cinfo; T.tok_bits = p->tok_bits; T.n_tags = p->n_tags;
     T.use_char = p->tag_use_char ? 1u : 0u; T.use_type = p->tag_use_type ? 1u : 0u;
     T.cps = b->d_cps; T.ooff = d_out_offsets; T.labels = d_labels; T.n_sent = n_sentences; T.total_chars = total_c; T.tags = d_tags_out;
-    T.tok_model = b->d_tok_model;
+    T.tok_model = b->d_tok_model + 4;
     T.scores_out = p->max_tag_scores ? d_tag_scores_out : nullptr; T.model_out = d_tag_models_out; T.score_stride = p->max_tag_scores;
     // tag_tokens_kernel runs 8 workgroups per CU at a time; four generations of them stride over the batch, so that the
     // sentences' lengths (8..512 chars in BASELINE's configs[4]) even out without one workgroup per four sentences
@@ -1459,14 +1461,15 @@ static vpt_status emit_device(const vpt_predictor* p, vpt_batch* b, const uint8_
         if (!p->predict_tags) return fail(VPT_INVALID_ARGUMENT, "InvalidArgumentError: this predictor is created with predict_tags = false");
         if (b->tok_model_chars != total_boundaries + n_sentences || !b->d_tok_model)
             return fail(VPT_INVALID_ARGUMENT, "InvalidArgumentError: batch: call vpt_fill_tags_batch_device on this workspace for this batch first");
-        E.tags = d_tags; E.tok_model = b->d_tok_model; E.n_tags = p->n_tags; E.n_models = p->dtag.n_models; E.n_strings = p->dtag.n_strings;
+        E.tags = d_tags; E.tok_model = b->d_tok_model + 4; E.n_tags = p->n_tags; E.n_models = p->dtag.n_models; E.n_strings = p->dtag.n_strings;
         E.models = p->dtag.models; E.slot_str = p->dtag.slot_str; E.str_off = p->dtag.str_off; E.str_bytes = p->dtag.str_bytes;
     }
-    // a wave per block of sentences: about a thousand chars of them (three steps of CJK text), at most 64
+    // a wave per block of sentences: about two thousand chars of them (six steps of CJK text), at most 64 (measured on MI355X,
+    // configs[1]: 4 sentences of 64 chars per wave 0.122 ms, 8 0.093, 16 0.070, 32 0.063, 64 0.066: profiles/r03_n_emit_block_sizes.txt)
     vpt::EmitFuse F{};
     {
         const uint64_t chars = total_boundaries + n_sentences;
-        const uint64_t per = (uint64_t(1024) * n_sentences + chars / 2) / chars;   // round(1024 / mean chars per sentence)
+        const uint64_t per = (uint64_t(2048) * n_sentences + chars / 2) / chars;   // round(2048 / mean chars per sentence)
         F.per_block = uint32_t(std::min<uint64_t>(std::max<uint64_t>(per, 1), vpt::kEmitFuseMaxBlock));
         if (b->knobs.emit_per_block) F.per_block = b->knobs.emit_per_block;
         F.n_blocks = (n_sentences + F.per_block - 1) / F.per_block;
@@ -1484,6 +1487,7 @@ static vpt_status emit_device(const vpt_predictor* p, vpt_batch* b, const uint8_
     F.clear = b->d_emit_state + size_t(b->emit_flip ^ 1) * b->emit_state_cap;
     F.clear_n = b->emit_dirty[b->emit_flip ^ 1];
     F.total_out = total_out;
+    F.dbg = b->knobs.debug_emit;
     b->emit_dirty[b->emit_flip ^ 1] = 0; b->emit_dirty[b->emit_flip] = words;
     b->emit_flip ^= 1;
     VPT_HIP(vpt::launch_emit_tokenized(E, F, stream));

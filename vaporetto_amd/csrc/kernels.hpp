@@ -167,6 +167,7 @@ struct EmitFuse {
     uint64_t* clear;        // the state words of the NEXT call (the other of two arrays), zeroed by this one: [0, clear_n)
     uint64_t clear_n, n_blocks;
     uint32_t per_block;
+    uint32_t dbg;           // VPT_DEBUG_EMIT timing ablations (a diagnostics build of the kernel; results are wrong by design)
     uint64_t* total_out;    // optional device-writable HOST address that receives the output's total size
 };
 hipError_t launch_emit_tokenized(const EmitParams& P, const EmitFuse& F, hipStream_t stream);

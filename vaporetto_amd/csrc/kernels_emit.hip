@@ -214,34 +214,42 @@ struct FuseBlock {            // a wave's block (the same in every lane)
     uint32_t ns;
 };
 
-// Pass B over a block (kStore) or its dry run (the size only; with tags).  `my_b`: boff[i0 + lane] for the block's sentences.
-// Returns the bytes the block takes.  `at_out`: where they go; nothing is stored past `end` (the size pass A published) and nothing
-// at all unless `store_ok` (the output fits the caller's buffer).  kTags: the kernel's variant with "/tag" suffixes.
-template <bool kStore, bool kTags>
-__device__ __forceinline__ uint64_t fuse_walk(const EmitParams& P, const FuseBlock& K, uint64_t my_b, int lane, FuseWaveLds& L, uint64_t at_out, uint64_t end,
-                                              bool store_ok, uint32_t& err) {
+// a step's loads: the lane's 16 text bytes and its 16 (lanes 0..2: 32) bytes of the label window, which starts at label `lw`
+struct FuseLoads { uint4 x, la, lb; uint32_t vm, lab_head; };
+__device__ __forceinline__ FuseLoads fuse_load(uintptr_t step, uintptr_t t_lo, uintptr_t t_hi, uintptr_t l_lo, uintptr_t l_hi, uint64_t lw, int lane) {
+    FuseLoads r;
+    const uintptr_t addr = step + 16u * uint32_t(lane);
+    r.vm = in_range16(addr, t_lo, t_hi);
+    r.x = r.vm ? *reinterpret_cast<const uint4*>(addr) : make_uint4(0, 0, 0, 0);
+    const uintptr_t lab_at = l_lo + lw, lab_al = lab_at & ~uintptr_t(15);
+    r.lab_head = uint32_t(lab_at - lab_al);
+    const uintptr_t a = lab_al + 16u * uint32_t(lane), a2 = lab_al + 16u * uint32_t(64 + lane);
+    r.la = (step < t_hi && a + 16 > l_lo && a < l_hi) ? *reinterpret_cast<const uint4*>(a) : make_uint4(0, 0, 0, 0);
+    r.lb = (step < t_hi && lane < 3 && a2 + 16 > l_lo && a2 < l_hi) ? *reinterpret_cast<const uint4*>(a2) : make_uint4(0, 0, 0, 0);
+    return r;
+}
+
+// Pass B over a block: every byte of its sentences to its place.  `my_b`: boff[i0 + lane] for the block's sentences; `at_out`: where
+// the block goes; nothing is stored past `end` (the size pass A published) and nothing at all unless `store_ok` (the output fits
+// the caller's buffer) -- the sentences' offsets are written either way.  kTags: the kernel's variant with "/tag" suffixes.
+template <bool kTags, bool kDbg>
+__device__ __forceinline__ void fuse_walk(const EmitParams& P, const FuseBlock& K, uint64_t my_b, int lane, FuseWaveLds& L, uint64_t at_out, uint64_t end,
+                                          bool store_ok, uint32_t& err, uint32_t dbg) {
     uint8_t* const sbytes = reinterpret_cast<uint8_t*>(L.stage);
     const uintptr_t t_lo = reinterpret_cast<uintptr_t>(P.text) + K.B0, t_hi = reinterpret_cast<uintptr_t>(P.text) + K.B1;
     const uintptr_t l_lo = reinterpret_cast<uintptr_t>(P.labels), l_hi = l_lo + P.total_boundaries;
     const uintptr_t my_start = reinterpret_cast<uintptr_t>(P.text) + my_b;
-    const uint64_t out0 = at_out;
     uint64_t cb = 0, sb = 0;   // chars / sentence starts of the block in front of the step
     bool fits = true;
-    for (uintptr_t step = t_lo & ~uintptr_t(15); step < t_hi && fits; step += kFuseStepBytes) {
-        const uintptr_t addr = step + 16u * uint32_t(lane);
-        const uint32_t vm = in_range16(addr, t_lo, t_hi);
-        const uint4 x = vm ? *reinterpret_cast<const uint4*>(addr) : make_uint4(0, 0, 0, 0);
-        // the labels the step's chars can ask for: label (O0 + cb - sb) onwards (every char but a sentence's first has one in front)
-        const uint64_t lw = K.O0 + cb - sb;
-        const uintptr_t lab_at = l_lo + lw, lab_al = lab_at & ~uintptr_t(15);
-        {
-            const uintptr_t a = lab_al + 16u * uint32_t(lane);
-            reinterpret_cast<uint4*>(L.labs)[lane] = (a + 16 > l_lo && a < l_hi) ? *reinterpret_cast<const uint4*>(a) : make_uint4(0, 0, 0, 0);
-            if (lane < 3) {
-                const uintptr_t a2 = lab_al + 16u * uint32_t(64 + lane);
-                reinterpret_cast<uint4*>(L.labs)[64 + lane] = (a2 + 16 > l_lo && a2 < l_hi) ? *reinterpret_cast<const uint4*>(a2) : make_uint4(0, 0, 0, 0);
-            }
-        }
+    uintptr_t step = t_lo & ~uintptr_t(15);
+    // the labels the step's chars can ask for: label (O0 + cb - sb) onwards (every char but a sentence's first has one in front)
+    FuseLoads nxt = fuse_load(step, t_lo, t_hi, l_lo, l_hi, K.O0, lane);
+    for (; step < t_hi && fits; step += kFuseStepBytes) {
+        const FuseLoads cur = nxt;
+        const uint4 x = cur.x;
+        const uint32_t vm = cur.vm;
+        reinterpret_cast<uint4*>(L.labs)[lane] = cur.la;
+        if (lane < 3) reinterpret_cast<uint4*>(L.labs)[64 + lane] = cur.lb;
         if (uint32_t(lane) < K.ns && my_start >= step && my_start - step < kFuseStepBytes) {
             const uint32_t r = uint32_t(my_start - step);
             atomicOr(&L.starts[r >> 5], 1u << (r & 31u));
@@ -257,11 +265,13 @@ __device__ __forceinline__ uint64_t fuse_walk(const EmitParams& P, const FuseBlo
         const uint32_t incl = wave_inclusive_scan(nl | (nst << 16));
         const uint32_t tot = uint32_t(__builtin_amdgcn_readlane(int(incl), 63));
         const uint32_t c_in = (incl & 0xFFFFu) - nl, s_in = (incl >> 16) - nst;   // chars / starts of the step in front of this lane
+        // the next step's text and labels are on their way while this one is placed
+        nxt = fuse_load(step + kFuseStepBytes, t_lo, t_hi, l_lo, l_hi, K.O0 + (cb + (tot & 0xFFFFu)) - (sb + (tot >> 16)), lane);
         // the lane's chars that have a label in front take consecutive labels from (c_in - s_in) of the window on
         const uint32_t nm = lm & ~sm;
-        const uint32_t loff = uint32_t(lab_at - lab_al) + (c_in - s_in);           // byte offset in labs: <= 15 + 1024
+        const uint32_t loff = cur.lab_head + (c_in - s_in);           // byte offset in labs: <= 15 + 1024
         uint32_t spm = 0;
-        {
+        if (!(kDbg && (dbg & 16u))) {
             const uint32_t d = loff >> 2, r = loff & 3u;
             uint4 y;
             y.x = __builtin_amdgcn_alignbyte(L.labs[d + 1], L.labs[d], r); y.y = __builtin_amdgcn_alignbyte(L.labs[d + 2], L.labs[d + 1], r);
@@ -274,13 +284,48 @@ __device__ __forceinline__ uint64_t fuse_walk(const EmitParams& P, const FuseBlo
                 rem &= rem - 1u;
             }
         }
-        // tag suffixes go in front of a space and in front of a sentence's first byte (the last token of the sentence before it),
-        // except the block's first (the block before this one wrote that one behind its last byte)
-        uint32_t tmask = 0, sfx_total = 0;
+        // Tag suffixes go in front of a space and in front of a sentence's first byte (the last token of the sentence before it),
+        // except the block's first (the block before this one wrote that one behind its last byte).  The lane that holds the byte
+        // in FRONT of which a suffix goes owns it; at most two per lane are carried in registers (tk: the byte, tl: the length,
+        // tc: the token's last char), a third sends the lane through its chars one by one.
+        uint32_t tmask = 0, tk1 = 16, tl1 = 0, tk2 = 16, tl2 = 0, tc1 = 0, tc2 = 0;
+        int32_t tm1 = 0, tm2 = 0;
+        bool many = false;
         const uint64_t g_first = K.O0 + K.i0 + cb + c_in;     // batch-flat index of the lane's first char
         if (kTags) {
             tmask = spm | sm;
             if (sb + s_in == 0 && sm) tmask &= ~(sm & (0u - sm));
+            if (tmask) {
+                // the tag models of the chars in front of the lane's chars: tok_model[g_first - 1 + j] for its j-th char (the array has
+                // zeros in front of the batch's first char and behind its last: capi.cpp); which of them are there at all
+                const int32_t* tmod = P.tok_model + g_first - 1;
+                uint32_t pm = 0;
+                for (uint32_t j0 = 0; j0 < nl; j0 += 4) {
+                    int32_t m4[4];
+                    __builtin_memcpy(m4, tmod + j0, sizeof(m4));
+                    pm |= ((m4[0] > 0 ? 1u : 0u) | (m4[1] > 0 ? 2u : 0u) | (m4[2] > 0 ? 4u : 0u) | (m4[3] > 0 ? 8u : 0u)) << j0;
+                }
+                pm &= (1u << nl) - 1u;
+                while (pm) {   // few
+                    const uint32_t j = uint32_t(__ffs(int(pm))) - 1u;
+                    pm &= pm - 1u;
+                    uint32_t rem = lm;
+                    for (uint32_t q = 0; q < j; ++q) rem &= rem - 1u;
+                    const uint32_t k = uint32_t(__ffs(int(rem))) - 1u;          // the byte of the lane's j-th char
+                    if (!((tmask >> k) & 1u)) continue;                          // no token ends in front of it
+                    const int32_t mdl = tmod[j];
+                    const uint32_t len = tag_suffix_of(P, g_first + j - 1u, mdl, nullptr);
+                    if (!len) continue;
+                    if (tk1 == 16) { tk1 = k; tl1 = len; tc1 = j; tm1 = mdl; }
+                    else if (tk2 == 16) { tk2 = k; tl2 = len; tc2 = j; tm2 = mdl; }
+                    else many = true;
+                }
+            }
+        }
+        const bool slow = kTags && __ballot(many) != 0;        // (wave-uniform)
+        uint32_t sfx_total = tl1 + tl2;
+        if (slow) {
+            sfx_total = 0;
             uint32_t todo = tmask;
             while (todo) {
                 const uint32_t low = todo & (0u - todo);
@@ -291,73 +336,78 @@ __device__ __forceinline__ uint64_t fuse_walk(const EmitParams& P, const FuseBlo
         const uint32_t t = uint32_t(__popc(vm)) + uint32_t(__popc(spm)) + uint32_t(__popc(em)) + sfx_total;
         const uint32_t incl_t = wave_inclusive_scan(t);
         const uint32_t total = uint32_t(__builtin_amdgcn_readlane(int(incl_t), 63));
-        if (kStore) {
-            if (at_out + total > end) { fits = false; break; }
-            uint8_t* const dst = P.out_text + at_out;
-            const uint32_t head = uint32_t(reinterpret_cast<uintptr_t>(dst) & 15u);
-            const bool staged = !kTags || head + total <= kFuseStageBytes;   // (wave-uniform) else: byte stores straight to the output
-            const uint32_t w = incl_t - t;
-            if (!kTags) {
-                // the lane's bytes in order: [' '] ['\\'] byte.  No branches: what is not there goes to a slot of the lane's own
-                if (store_ok) {
-                    uint8_t* const o = sbytes + head;
-                    uint8_t* const dump = reinterpret_cast<uint8_t*>(L.dump + lane);
-                    uint32_t pos = w;
+        if (at_out + total > end) { fits = false; break; }
+        uint8_t* const dst = P.out_text + at_out;
+        const uint32_t head = uint32_t(reinterpret_cast<uintptr_t>(dst) & 15u);
+        const bool staged = !kTags || head + total <= kFuseStageBytes;   // (wave-uniform) else: byte stores straight to the output
+        const uint32_t w = incl_t - t;
+        if (!slow) {
+            // the lane's bytes in order: [tags] [' '] ['\\'] byte.  No branches: what is not there goes to a slot of the lane's own
+            if (store_ok && !(kDbg && (dbg & 1u))) {
+                uint8_t* const o = !kTags || staged ? sbytes + head : dst;   // (with tags: a generic pointer)
+                uint8_t* const dump = reinterpret_cast<uint8_t*>(L.dump + lane);
+                uint32_t pos = w;
 #pragma unroll
-                    for (uint32_t k = 0; k < 16; ++k) {
-                        const uint32_t v = (vm >> k) & 1u, sp = (spm >> k) & 1u, es = (em >> k) & 1u;
-                        *(sp ? o + pos : dump) = 0x20u; pos += sp;
-                        *(es ? o + pos : dump) = 0x5Cu; pos += es;
-                        *(v ? o + pos : dump) = uint8_t(byte_of(x, k)); pos += v;
-                    }
+                for (uint32_t k = 0; k < 16; ++k) {
+                    const uint32_t v = (vm >> k) & 1u, sp = (spm >> k) & 1u, es = (em >> k) & 1u;
+                    if (kTags) pos += (k == tk1 ? tl1 : 0u) + (k == tk2 ? tl2 : 0u);
+                    *(sp ? o + pos : dump) = 0x20u; pos += sp;
+                    *(es ? o + pos : dump) = 0x5Cu; pos += es;
+                    *(v ? o + pos : dump) = uint8_t(byte_of(x, k)); pos += v;
                 }
-                uint32_t rem = sm;   // the sentences that start in the lane's bytes (few lanes, one as a rule)
-                while (rem) {
-                    const uint32_t k = uint32_t(__ffs(int(rem))) - 1u, below = (1u << k) - 1u;
-                    rem &= rem - 1u;
-                    const uint64_t s = sb + s_in + uint32_t(__popc(sm & below));
+                if (kTags && tl1) {   // the tags themselves (few lanes)
+                    const uint32_t b1 = (1u << tk1) - 1u, b2 = (1u << tk2) - 1u;
+                    (void)tag_suffix_of(P, g_first + tc1 - 1u, tm1, o + w + uint32_t(__popc(vm & b1)) + uint32_t(__popc(spm & b1)) + uint32_t(__popc(em & b1)));
+                    if (tl2) (void)tag_suffix_of(P, g_first + tc2 - 1u, tm2, o + w + tl1 + uint32_t(__popc(vm & b2)) + uint32_t(__popc(spm & b2)) + uint32_t(__popc(em & b2)));
+                }
+            }
+            uint32_t rem = sm;   // the sentences that start in the lane's bytes (few lanes, one as a rule)
+            while (rem) {
+                const uint32_t k = uint32_t(__ffs(int(rem))) - 1u, below = (1u << k) - 1u;
+                rem &= rem - 1u;
+                const uint64_t s = sb + s_in + uint32_t(__popc(sm & below));
+                if (s < K.ns) {
+                    P.out_offsets[K.i0 + s] = at_out + w + uint32_t(__popc(vm & below)) + uint32_t(__popc(spm & below)) + uint32_t(__popc(em & below)) +
+                                              (kTags ? (tk1 <= k ? tl1 : 0u) + (tk2 <= k ? tl2 : 0u) : 0u);
+                    if (cb + c_in + uint32_t(__popc(lm & below)) != uint64_t(L.so[s]) + s) err |= kErrBadOffsets;   // not the char its offset names
+                } else err |= kErrBadOffsets;
+            }
+        } else {
+            // [tags] [' '] | sentence offset | ['\\'] byte, char by char (o: LDS or the output itself)
+            uint8_t* const o = !store_ok ? nullptr : staged ? sbytes + head : dst;
+            uint32_t pos = w, ci = 0;
+#pragma unroll 1
+            for (uint32_t k = 0; k < 16; ++k) {
+                if (!((vm >> k) & 1u)) continue;
+                if ((tmask >> k) & 1u) pos += tag_suffix(P, g_first + ci - 1u, o ? o + pos : nullptr);
+                if ((spm >> k) & 1u) { if (o) o[pos] = 0x20u; ++pos; }
+                if ((sm >> k) & 1u) {
+                    const uint64_t s = sb + s_in + uint32_t(__popc(sm & ((1u << k) - 1u)));
                     if (s < K.ns) {
-                        P.out_offsets[K.i0 + s] = at_out + w + uint32_t(__popc(vm & below)) + uint32_t(__popc(spm & below)) + uint32_t(__popc(em & below));
-                        if (cb + c_in + uint32_t(__popc(lm & below)) != uint64_t(L.so[s]) + s) err |= kErrBadOffsets;   // not the char its offset names
+                        P.out_offsets[K.i0 + s] = at_out + pos;
+                        if (cb + c_in + ci != uint64_t(L.so[s]) + s) err |= kErrBadOffsets;
                     } else err |= kErrBadOffsets;
                 }
-            } else {
-                // [tags] [' '] | sentence offset | ['\\'] byte, one loop for every case (o: LDS or the output itself)
-                uint8_t* const o = !store_ok ? nullptr : staged ? sbytes + head : dst;
-                uint32_t pos = w, ci = 0;
-#pragma unroll 1
-                for (uint32_t k = 0; k < 16; ++k) {
-                    if (!((vm >> k) & 1u)) continue;
-                    if ((tmask >> k) & 1u) pos += tag_suffix(P, g_first + ci - 1u, o ? o + pos : nullptr);
-                    if ((spm >> k) & 1u) { if (o) o[pos] = 0x20u; ++pos; }
-                    if ((sm >> k) & 1u) {
-                        const uint64_t s = sb + s_in + uint32_t(__popc(sm & ((1u << k) - 1u)));
-                        if (s < K.ns) {
-                            P.out_offsets[K.i0 + s] = at_out + pos;
-                            if (cb + c_in + ci != uint64_t(L.so[s]) + s) err |= kErrBadOffsets;
-                        } else err |= kErrBadOffsets;
-                    }
-                    if ((em >> k) & 1u) { if (o) o[pos] = 0x5Cu; ++pos; }
-                    if (o) o[pos] = uint8_t(byte_of_rt(x, k));
-                    ++pos;
-                    ci += (lm >> k) & 1u;
+                if ((em >> k) & 1u) { if (o) o[pos] = 0x5Cu; ++pos; }
+                if (o) o[pos] = uint8_t(byte_of_rt(x, k));
+                ++pos;
+                ci += (lm >> k) & 1u;
+            }
+        }
+        if (store_ok && staged && !(kDbg && (dbg & 2u))) {   // LDS byte j is output byte j - head: whole 16-byte chunks leave aligned, the two edges byte by byte
+            __builtin_amdgcn_wave_barrier();
+            uint8_t* const abase = dst - head;
+            const uint32_t nd = (head + total + 15u) >> 4;
+            for (uint32_t d = uint32_t(lane); d < nd; d += 64) {
+                const uint32_t lo = d * 16u, hi = lo + 16u;
+                if (lo >= head && hi <= head + total) {
+                    *reinterpret_cast<uint4*>(abase + lo) = reinterpret_cast<const uint4*>(L.stage)[d];
+                } else {
+                    const uint32_t a = lo > head ? lo : head, b = hi < head + total ? hi : head + total;
+                    for (uint32_t j = a; j < b; ++j) abase[j] = sbytes[j];
                 }
             }
-            if (store_ok && staged) {   // LDS byte j is output byte j - head: whole 16-byte chunks leave aligned, the two edges byte by byte
-                __builtin_amdgcn_wave_barrier();
-                uint8_t* const abase = dst - head;
-                const uint32_t nd = (head + total + 15u) >> 4;
-                for (uint32_t d = uint32_t(lane); d < nd; d += 64) {
-                    const uint32_t lo = d * 16u, hi = lo + 16u;
-                    if (lo >= head && hi <= head + total) {
-                        *reinterpret_cast<uint4*>(abase + lo) = reinterpret_cast<const uint4*>(L.stage)[d];
-                    } else {
-                        const uint32_t a = lo > head ? lo : head, b = hi < head + total ? hi : head + total;
-                        for (uint32_t j = a; j < b; ++j) abase[j] = sbytes[j];
-                    }
-                }
-                __builtin_amdgcn_wave_barrier();
-            }
+            __builtin_amdgcn_wave_barrier();
         }
         at_out += total;
         cb += tot & 0xFFFFu;
@@ -366,15 +416,39 @@ __device__ __forceinline__ uint64_t fuse_walk(const EmitParams& P, const FuseBlo
     if (kTags && fits) {   // the tags of the block's last token
         const uint64_t g_last = K.O1 + K.i0 + K.ns - 1;
         const uint32_t s = tag_suffix(P, g_last, nullptr);   // (every lane computes the same)
-        if (kStore && s && store_ok && at_out + s <= end && lane == 0) tag_suffix(P, g_last, P.out_text + at_out);
+        if (s && store_ok && at_out + s <= end && lane == 0) tag_suffix(P, g_last, P.out_text + at_out);
         at_out += s;
     }
-    if (kStore && fits && (cb != (K.O1 - K.O0) + K.ns || sb != K.ns)) err |= kErrBadOffsets;
-    return at_out - out0;
+    if (fits && (cb != (K.O1 - K.O0) + K.ns || sb != K.ns)) err |= kErrBadOffsets;
 }
 
-template <bool kTags>
+// Pass A with tags: the bytes of the block's tag suffixes.  The tag models of the block's chars are read flat, four per lane; a char
+// with one (one in thirty) ends a token -- and has its suffix written -- if the label behind it is a boundary or it is its sentence's
+// last: its sentence is found in the block's offsets (LDS).
+__device__ __forceinline__ uint32_t fuse_tag_bytes(const EmitParams& P, const FuseBlock& K, int lane, const FuseWaveLds& L) {
+    const uint64_t g0 = K.O0 + K.i0, n_chars = (K.O1 - K.O0) + K.ns;
+    uint32_t bytes = 0;
+    for (uint64_t c0 = 4 * uint64_t(lane); c0 < n_chars; c0 += 256) {
+        int32_t m4[4];
+        __builtin_memcpy(m4, P.tok_model + g0 + c0, sizeof(m4));   // (zeros behind the batch's last char)
+        for (uint32_t q = 0; q < 4; ++q) {
+            const uint64_t c = c0 + q;                  // char of the block
+            if (m4[q] <= 0 || c >= n_chars) continue;
+            uint32_t lo = 0, hi = K.ns;                 // the sentence s with so[s] + s <= c: the last such
+            while (hi - lo > 1) {
+                const uint32_t mid = (lo + hi) >> 1;
+                if (uint64_t(L.so[mid]) + mid <= c) lo = mid; else hi = mid;
+            }
+            const uint64_t p = c - (uint64_t(L.so[lo]) + lo), n_s = uint64_t(L.so[lo + 1]) - L.so[lo] + 1;   // char p of n_s
+            if (p + 1 == n_s || (p + 1 < n_s && P.labels[K.O0 + L.so[lo] + p] == 1u)) bytes += tag_suffix_of(P, g0 + c, m4[q], nullptr);
+        }
+    }
+    return bytes;
+}
+
+template <bool kTags, bool kDbg>
 __global__ __launch_bounds__(kEmitThreads) void emit_fused_kernel(const EmitParams P, const EmitFuse F) {
+    const uint32_t dbg = kDbg ? F.dbg : 0u;   // timing ablations (VPT_DEBUG_EMIT; results are wrong with any bit set)
     __shared__ FuseLds LDS;
     // the other array of state words, for the call after this one
     for (uint64_t k = uint64_t(blockIdx.x) * kEmitThreads + threadIdx.x; k < F.clear_n; k += uint64_t(gridDim.x) * kEmitThreads) F.clear[k] = 0;
@@ -414,31 +488,31 @@ __global__ __launch_bounds__(kEmitThreads) void emit_fused_kernel(const EmitPara
     if (lane < int(kFuseStepBytes / 32)) L.starts[lane] = 0;
     __builtin_amdgcn_wave_barrier();
 
-    // ---- pass A: the block's size
+    // ---- pass A: the block's size = its bytes + the escaped bytes + the boundary labels of its label range (+ the tag suffixes)
     uint64_t size = 0;
-    if (sane) {
+    if (kDbg && (dbg & 8u)) size = 3 * (K.B1 - K.B0);
+    else if (sane) {
         uint32_t added = 0;
         const uintptr_t l_lo = reinterpret_cast<uintptr_t>(P.labels) + K.O0, l_hi = reinterpret_cast<uintptr_t>(P.labels) + K.O1;
-        if (!kTags) {
-            const uintptr_t t_lo = reinterpret_cast<uintptr_t>(P.text) + K.B0, t_hi = reinterpret_cast<uintptr_t>(P.text) + K.B1;
-            for (uintptr_t a = (t_lo & ~uintptr_t(15)) + 16u * uint32_t(lane); a < t_hi; a += kFuseStepBytes)
-                added += uint32_t(__popc(esc16(*reinterpret_cast<const uint4*>(a)) & in_range16(a, t_lo, t_hi)));
-        }
+        const uintptr_t t_lo = reinterpret_cast<uintptr_t>(P.text) + K.B0, t_hi = reinterpret_cast<uintptr_t>(P.text) + K.B1;
+        for (uintptr_t a = (t_lo & ~uintptr_t(15)) + 16u * uint32_t(lane); a < t_hi; a += kFuseStepBytes)
+            added += uint32_t(__popc(esc16(*reinterpret_cast<const uint4*>(a)) & in_range16(a, t_lo, t_hi)));
         for (uintptr_t a = (l_lo & ~uintptr_t(15)) + 16u * uint32_t(lane); a < l_hi; a += kFuseStepBytes) {
             const uint4 y = *reinterpret_cast<const uint4*>(a);
             const uint32_t m = in_range16(a, l_lo, l_hi);
             added += uint32_t(__popc(one16(y) & m));
             if (unk16(y) & m) err |= kErrUnknownLabel;
         }
-        if (kTags) size = fuse_walk<false, true>(P, K, my_b, lane, L, 0, ~uint64_t(0), false, err);   // (the labels above: only their check)
-        else size = (K.B1 - K.B0) + wave_sum64(added);
+        if (kTags) added += fuse_tag_bytes(P, K, lane, L);
+        size = (K.B1 - K.B0) + wave_sum64(added);
     }
 
     // ---- the block's position: the earlier blocks' words, 64 per trip
     constexpr uint64_t kVal = (uint64_t(1) << 62) - 1;
     if (lane == 0) __hip_atomic_store(F.state + blk, (uint64_t(1) << 62) | size, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     uint64_t base = 0;
-    for (uint64_t p = blk; p > 0;) {
+    if (kDbg && (dbg & 4u)) base = blk * 3 * (K.B1 - K.B0);
+    else for (uint64_t p = blk; p > 0;) {
         const bool have = uint64_t(lane) < p;
         uint64_t w = uint64_t(2) << 62;   // in front of block 0: position 0
         if (have) w = __hip_atomic_load(F.state + (p - 1 - uint64_t(lane)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -460,7 +534,8 @@ __global__ __launch_bounds__(kEmitThreads) void emit_fused_kernel(const EmitPara
     }
 
     // ---- pass B
-    if (sane) (void)fuse_walk<true, kTags>(P, K, my_b, lane, L, base, end, store_ok, err);
+    if (kDbg && (dbg & 32u)) return;
+    if (sane) fuse_walk<kTags, kDbg>(P, K, my_b, lane, L, base, end, store_ok, err, dbg);
     else if (uint32_t(lane) < K.ns) P.out_offsets[K.i0 + lane] = base;
     if (err) atomicOr(P.status, err);
 }
@@ -517,8 +592,11 @@ hipError_t launch_count_boundaries(const uint8_t* text, const uint64_t* boff, ui
 
 hipError_t launch_emit_tokenized(const EmitParams& P, const EmitFuse& F, hipStream_t stream) {
     const dim3 grid(uint32_t((F.n_blocks + kEmitWaves - 1) / kEmitWaves));
-    if (P.tags) hipLaunchKernelGGL(emit_fused_kernel<true>, grid, dim3(kEmitThreads), 0, stream, P, F);
-    else hipLaunchKernelGGL(emit_fused_kernel<false>, grid, dim3(kEmitThreads), 0, stream, P, F);
+    if (F.dbg) {
+        if (P.tags) hipLaunchKernelGGL((emit_fused_kernel<true, true>), grid, dim3(kEmitThreads), 0, stream, P, F);
+        else hipLaunchKernelGGL((emit_fused_kernel<false, true>), grid, dim3(kEmitThreads), 0, stream, P, F);
+    } else if (P.tags) hipLaunchKernelGGL((emit_fused_kernel<true, false>), grid, dim3(kEmitThreads), 0, stream, P, F);
+    else hipLaunchKernelGGL((emit_fused_kernel<false, false>), grid, dim3(kEmitThreads), 0, stream, P, F);
     return hipGetLastError();
 }
 

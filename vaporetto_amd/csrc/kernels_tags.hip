@@ -15,10 +15,15 @@
 //   decode_chars_kernel  UTF-8 -> flat per batch (char g of sentence i at out_offsets[i] + i + g): the scored scalar value
 //                        | CharacterType << 24; optionally Sentence::char_types on their own
 //   tag_tokens_kernel    The waves stay and stride over the sentences, 64 chars per step, chars and labels fetched one step
-//                        ahead.  (1) Every lane whose char ends a token owns it: start from the step's boundary masks, surface
-//                        looked up in the token table -- keyed by the length and the first four chars, which the lane reads
-//                        from the sentence's ring in LDS, so there is no loop over the token; a token of up to 4 chars is
-//                        verified from its 16-byte slot alone.  Every char gets its entries here (no tag model: None).
+//                        ahead.  (1) Every lane whose char ends a token owns it: start from the step's boundary masks; the token
+//                        table's FILTER -- keyed like the table by the length and the first four chars, which the lane reads
+//                        from the sentence's ring in LDS, so there is no loop over the token -- says with one 4-byte read whether
+//                        the surface can be a tag model's at all.  One token in thirty has a model (BASELINE's configs[4]), not
+//                        one in a hundred of the others passes: every char that does not get its entries (None) at once.  The
+//                        CANDIDATES wait in LDS, across steps and sentences, until there are 64: then every lane probes the table
+//                        for one (round 2: each step probed for its own token ends, 28 of 64 lanes busy, the step's critical path
+//                        as long as its longest probe sequence: profiles/r02_g_tag_steps.txt); a token of up to 4 chars is
+//                        verified from its 16-byte slot alone.
 //                        (2) The tokens that found a tag model join a QUEUE in LDS that outlives the step and the sentence; 16
 //                        of them are a pass: their context chars (p - 11 .. p + 4), model records and bias arrive in one trip;
 //                        a model's char n-grams come in groups by rel_position with a 64-bit filter over the chars they END
@@ -99,6 +104,7 @@ constexpr uint32_t kCharMask = 0x1FFFFFu;   // a cps word: scored scalar value |
 constexpr int kRing = 128;                   // the sentence's cps words in LDS: char q at txt[q & 127]; a step holds [base - 64, base + 64)
 constexpr int kTagPass = 16;                 // queued tokens a pass takes
 constexpr int kCtx = 16, kCtxBack = 11;      // the text a queued token's n-grams can touch: chars p - 11 .. p + 4 around its last char p
+constexpr int kTagCand = 64;                 // tokens that wait for the token table together
 constexpr int kMatchCap = 128;               // matched (token, n-gram) pairs collected before their weights are added
 
 struct TagWaveLds {
@@ -115,14 +121,16 @@ struct TagWaveLds {
         } f;
     };
     uint32_t txt[kRing];
+    uint32_t cand[kTagCand][4];              // tokens the filter let through, waiting for the token table: flat index of the last char (2),
+                                             // chars, chars before | after << 8 inside the sentence (clipped to the context)
 };
 struct TagLds { TagWaveLds w[kTagWaves]; };
-static_assert(sizeof(TagLds) <= 20 * 1024, "8 workgroups per CU");
+static_assert(sizeof(TagLds) <= 160 * 1024 / 7, "7 workgroups per CU");
 
-// The tag model (index + 1) whose token is the chars [s0, e] of the sentence, or 0: one lane on its own, no loop over the
-// token -- the table is keyed by the length and the first four chars (layout.h, tag_token_hash_key); a surface of up to four
-// BMP chars is verified by the slot itself, a longer candidate against `syms`.
-__device__ __forceinline__ uint32_t find_tag_model(const TagParams& P, const uint32_t* cps, const uint32_t* txt, int base, int s0, int e, bool* fast) {
+// Can the chars [s0, e] of the sentence be the token of a tag model?  One lane on its own, no loop over the token: the table's
+// filter is keyed like the table -- by the length and the first four chars (layout.h, tag_token_hash_key), which the lane reads from
+// the sentence's ring in LDS -- and answers with one 4-byte read (no for all but a percent of the tokens without a model).
+__device__ __forceinline__ bool tag_filter_hit(const TagParams& P, const uint32_t* cps, const uint32_t* txt, int base, int s0, int e) {
     const int len = e - s0 + 1;
     const bool in_ring = s0 >= base - (kRing - 64);
     uint32_t c[4];
@@ -133,18 +141,29 @@ __device__ __forceinline__ uint32_t find_tag_model(const TagParams& P, const uin
         for (int j = 0; j < 4; ++j) c[j] = j < len ? cps[s0 + j] & kCharMask : 0u;
     }
     const uint32_t lo = (c[0] & 0xFFFFu) | (c[1] << 16), hi = (c[2] & 0xFFFFu) | (c[3] << 16);
+    const uint32_t fbit = tag_token_hash_key(lo, hi, uint32_t(len)) >> (32 - P.tok_bits - kTagFilterLog2);
+    return ((P.tok_tab[(size_t(4) << P.tok_bits) + (fbit >> 5)] >> (fbit & 31u)) & 1u) != 0;
+}
+
+// The tag model (index + 1) whose token is the `len` chars at `tc` (flat cps words), or 0: the table is keyed by the length and the
+// first four chars; a surface of up to four BMP chars is verified by the slot itself, a longer candidate against `syms`.
+__device__ __forceinline__ uint32_t find_tag_model(const TagParams& P, const uint32_t* tc, uint32_t len, bool* fast) {
+    uint32_t c[4];
+#pragma unroll
+    for (uint32_t j = 0; j < 4; ++j) c[j] = j < len ? tc[j] & kCharMask : 0u;
+    const uint32_t lo = (c[0] & 0xFFFFu) | (c[1] << 16), hi = (c[2] & 0xFFFFu) | (c[3] << 16);
     const bool bmp = ((c[0] | c[1] | c[2] | c[3]) >> 16) == 0;
     const uint32_t tok_mask = (1u << P.tok_bits) - 1u;
-    uint32_t slot = tag_token_hash_key(lo, hi, uint32_t(len)) >> (32 - P.tok_bits);
+    uint32_t slot = tag_token_hash_key(lo, hi, len) >> (32 - P.tok_bits);
     for (;;) {
         const uint4 t = reinterpret_cast<const uint4*>(P.tok_tab)[slot];
         if (t.x == 0) return 0;
-        if (int(t.y & kTagTokLenMask) == len && t.z == lo && t.w == hi) {
+        if ((t.y & kTagTokLenMask) == len && t.z == lo && t.w == hi) {
             bool same = bmp;
             if (!(t.y & kTagTokInline)) {
                 const uint32_t so = P.models[size_t(t.x - 1) * 12];
                 same = true;
-                for (int j = 0; j < len && same; ++j) same = P.syms[so + j] == (cps[s0 + j] & kCharMask);
+                for (uint32_t j = 0; j < len && same; ++j) same = P.syms[so + j] == (tc[j] & kCharMask);
             }
             if (same) { *fast = (t.y & kTagTokFast) != 0; return t.x; }
         }
@@ -369,8 +388,63 @@ __device__ __forceinline__ void tag_pass(const TagParams& P, TagWaveLds& L, uint
     __builtin_amdgcn_wave_barrier();
 }
 
+// The `nc` tokens that wait in L.cand, one per lane: the token table says which tag model each has (most have one: the filter let
+// them through); every one of them gets its entries (no tag model: None); those whose model fits the record form join the QUEUE of
+// tag_pass -- a full queue is a pass --, the others go through the whole-wave routine, one token at a time.  drain: nothing may
+// stay in the queue (the wave's last call).
+__device__ __forceinline__ void tag_resolve(const TagParams& P, TagWaveLds& L, uint32_t nc, uint32_t& nq, bool drain, int lane, uint32_t dbg) {
+    const uint32_t nt = P.n_tags;
+    const uint64_t below_me = (uint64_t(1) << lane) - 1;
+    __builtin_amdgcn_wave_barrier();
+    const bool have = uint32_t(lane) < nc;
+    const uint64_t gp = have ? uint64_t(L.cand[lane][0]) | (uint64_t(L.cand[lane][1]) << 32) : 0;
+    const uint32_t len = have ? L.cand[lane][2] : 0u, clip = have ? L.cand[lane][3] : 0u;
+    bool fast = false;
+    uint32_t model = have ? find_tag_model(P, P.cps + (gp + 1 - len), len, &fast) : 0u;
+    if (dbg & 2u) model = 0;
+    if (have) {
+        if (P.tok_model) P.tok_model[gp] = int32_t(model);   // 0: no tag model for this surface
+        if (P.model_out) P.model_out[gp] = int32_t(model) - 1;
+        if (model == 0) for (uint32_t j = 0; j < nt; ++j) P.tags[gp * nt + j] = -1;
+    }
+    if (dbg & 64u) model = 0;
+    const uint64_t qmask = __ballot(model != 0 && fast);
+    uint64_t todo = __ballot(model != 0 && !fast);   // the models outside the record form: their routine's scores take the queue's place
+    const bool flush = drain || todo != 0;
+    if (qmask != 0 || (flush && nq != 0)) {
+        const uint32_t rank = uint32_t(__popcll(qmask & below_me));
+        uint32_t remaining = uint32_t(__popcll(qmask)), done = 0;
+        for (;;) {
+            const uint32_t room = uint32_t(kTagPass) - nq, take = remaining < room ? remaining : room;
+            if (model != 0 && fast && rank >= done && rank < done + take) {
+                const uint32_t row = nq + rank - done;
+                L.f.tok[row][0] = model; L.f.tok[row][1] = uint32_t(gp); L.f.tok[row][2] = uint32_t(gp >> 32); L.f.tok[row][3] = clip;
+            }
+            nq += take; done += take; remaining -= take;
+            if (!(nq == uint32_t(kTagPass) || (nq != 0 && remaining == 0 && flush))) break;
+            tag_pass(P, L, nq, lane, dbg);
+            nq = 0;
+            if (!remaining) break;
+        }
+    }
+    while (todo) {   // wave-uniform: the whole wave, one token at a time; its sentence is looked up in the offsets (rare models)
+        const int k = __ffsll((long long)todo) - 1;
+        todo &= todo - 1;
+        const uint32_t mk = uint32_t(__shfl(int(model), k));
+        const uint64_t gk = uint64_t(uint32_t(__shfl(int(uint32_t(gp)), k))) | (uint64_t(uint32_t(__shfl(int(uint32_t(gp >> 32)), k))) << 32);
+        uint64_t lo = 0, hi = P.n_sent;   // the last sentence i with ooff[i] + i <= gk
+        while (hi - lo > 1) {
+            const uint64_t mid = (lo + hi) >> 1;
+            if (P.ooff[mid] + mid <= gk) lo = mid; else hi = mid;
+        }
+        const uint64_t g0 = P.ooff[lo] + lo;
+        tag_token_by_wave(P, P.cps + g0, int64_t(P.ooff[lo + 1] - P.ooff[lo]) + 1, int64_t(gk - g0), g0, mk, L.z, lane);
+    }
+    __builtin_amdgcn_wave_barrier();
+}
+
 template <bool DBG>
-__global__ __launch_bounds__(kTagThreads, 8) void tag_tokens_kernel(const TagParams P, const uint32_t dbg_in) {
+__global__ __launch_bounds__(kTagThreads, 7) void tag_tokens_kernel(const TagParams P, const uint32_t dbg_in) {
     const uint32_t dbg = DBG ? dbg_in : 0u;   // timing ablations (VPT_DEBUG_TAGS; results are wrong with any bit set)
     __shared__ TagLds LDS;
     const int lane = threadIdx.x & 63;
@@ -380,7 +454,7 @@ __global__ __launch_bounds__(kTagThreads, 8) void tag_tokens_kernel(const TagPar
     const uint64_t n_waves = uint64_t(gridDim.x) * kTagWaves;
     const uint32_t nt = P.n_tags;
     const uint64_t below_me = (uint64_t(1) << lane) - 1;
-    uint32_t nq = 0;   // queued tokens (wave-uniform)
+    uint32_t nq = 0, nc = 0;   // queued tokens, waiting candidates (wave-uniform)
     for (uint64_t si = wave; si < P.n_sent; si += n_waves) {
         const uint64_t o0 = wave_uniform64(P.ooff[si]), o1 = wave_uniform64(P.ooff[si + 1]);
         const uint64_t g0 = o0 + si;                            // flat index of the sentence's first char
@@ -388,7 +462,6 @@ __global__ __launch_bounds__(kTagThreads, 8) void tag_tokens_kernel(const TagPar
         // 2^31 chars: not in this kernel's index width) is taken as empty here
         const bool sane = o1 >= o0 && o1 + si + 1 <= P.total_chars && o1 - o0 < 0x7FFFFF00ull;
         const int n = sane ? int(o1 - o0) + 1 : 0;  // chars
-        const bool last_sentence = si + n_waves >= P.n_sent;    // of this wave: its last step empties the queue
         const uint32_t* cps = P.cps + g0;
         const uint8_t* lab = P.labels + o0;                      // n - 1 labels
         int start = 0;              // where the token that is open at the beginning of this step started
@@ -407,51 +480,40 @@ __global__ __launch_bounds__(kTagThreads, 8) void tag_tokens_kernel(const TagPar
             L.txt[p & (kRing - 1)] = c;
             const uint64_t ends = __ballot(b == 1u), unk = __ballot(b == 2u);
             __builtin_amdgcn_wave_barrier();
-            // ---- (1) this lane's token, if its char ends one: [s0, p], valid when no Unknown lies inside
+            // ---- (1) this lane's token, if its char ends one: [s0, p], valid when no Unknown lies inside.  Could it have a tag model?
             const uint64_t prev_ends = ends & below_me;
             const int prev = prev_ends ? 63 - __clzll((long long)prev_ends) : -1;
             const int s0 = prev >= 0 ? base + prev + 1 : start;
             const uint64_t after_prev = prev >= 0 ? ~((uint64_t(2) << prev) - 1) : ~uint64_t(0);
             const bool valid = b == 1u && (unk & below_me & after_prev) == 0 && (prev >= 0 || have_start);
-            bool fast = false;
-            uint32_t model = (valid && !(dbg & 1u)) ? find_tag_model(P, cps, L.txt, base, s0, p, &fast) : 0u;
-            if (dbg & 2u) model = 0;
-            // every char of the sentence gets its entries here or below (nothing is cleared beforehand): 0 / None where no token with a
-            // tag model ends, the rest from the argmax of the token's scores
-            if (p < n) {
-                if (P.tok_model) P.tok_model[g0 + uint64_t(p)] = int32_t(model);   // 0: no tag model for this surface
-                if (P.model_out) P.model_out[g0 + uint64_t(p)] = int32_t(model) - 1;
-                if (model == 0) for (uint32_t j = 0; j < nt; ++j) P.tags[(g0 + uint64_t(p)) * nt + j] = -1;
+            const bool cand = valid && !(dbg & 1u) && tag_filter_hit(P, cps, L.txt, base, s0, p);
+            // every char of the sentence gets its entries here or when its token has been looked up (nothing is cleared beforehand):
+            // 0 / None where no token with a tag model ends
+            if (p < n && !cand) {
+                if (P.tok_model) P.tok_model[g0 + uint64_t(p)] = 0;
+                if (P.model_out) P.model_out[g0 + uint64_t(p)] = -1;
+                for (uint32_t j = 0; j < nt; ++j) P.tags[(g0 + uint64_t(p)) * nt + j] = -1;
             }
-            if (dbg & 64u) model = 0;
-            // ---- (2) the tokens whose model fits the record form join the queue; a full queue is a pass
-            const uint64_t qmask = __ballot(model != 0 && fast);
-            uint64_t todo = __ballot(model != 0 && !fast);   // the models outside the record form: their routine's scores take the queue's place
-            const bool drain = todo != 0 || (last_sentence && base + 64 >= n);
-            if (qmask != 0 || (drain && nq != 0)) {
-                const uint32_t rank = uint32_t(__popcll(qmask & below_me));
-                uint32_t remaining = uint32_t(__popcll(qmask)), done = 0;
+            // ---- (2) the candidates wait for the token table together: 64 of them are a lookup with every lane busy
+            const uint64_t cmask = __ballot(cand);
+            if (cmask != 0) {
+                const uint32_t rank = uint32_t(__popcll(cmask & below_me));
+                uint32_t remaining = uint32_t(__popcll(cmask)), done = 0;
                 for (;;) {
-                    const uint32_t room = uint32_t(kTagPass) - nq, take = remaining < room ? remaining : room;
-                    if (model != 0 && fast && rank >= done && rank < done + take) {
-                        const uint32_t row = nq + rank - done;
+                    const uint32_t room = uint32_t(kTagCand) - nc, take = remaining < room ? remaining : room;
+                    if (cand && rank >= done && rank < done + take) {
+                        const uint32_t row = nc + rank - done;
                         const uint64_t gp = g0 + uint64_t(p);
                         const uint32_t back = p < kCtxBack ? uint32_t(p) : uint32_t(kCtxBack);
                         const uint32_t fwd = n - 1 - p < kCtx - 1 - kCtxBack ? uint32_t(n - 1 - p) : uint32_t(kCtx - 1 - kCtxBack);
-                        L.f.tok[row][0] = model; L.f.tok[row][1] = uint32_t(gp); L.f.tok[row][2] = uint32_t(gp >> 32); L.f.tok[row][3] = back | (fwd << 8);
+                        L.cand[row][0] = uint32_t(gp); L.cand[row][1] = uint32_t(gp >> 32); L.cand[row][2] = uint32_t(p - s0 + 1); L.cand[row][3] = back | (fwd << 8);
                     }
-                    nq += take; done += take; remaining -= take;
-                    if (!(nq == uint32_t(kTagPass) || (nq != 0 && remaining == 0 && drain))) break;
-                    tag_pass(P, L, nq, lane, dbg);
-                    nq = 0;
+                    nc += take; done += take; remaining -= take;
+                    if (nc != uint32_t(kTagCand)) break;
+                    tag_resolve(P, L, nc, nq, false, lane, dbg);
+                    nc = 0;
                     if (!remaining) break;
                 }
-            }
-            while (todo) {   // wave-uniform: the whole wave, one token at a time
-                const int k = __ffsll((long long)todo) - 1;
-                todo &= todo - 1;
-                const uint32_t mk = uint32_t(__shfl(int(model), k));
-                tag_token_by_wave(P, cps, n, base + k, g0, mk, L.z, lane);
             }
             // the token that stays open into the next step
             if (ends) {
@@ -464,6 +526,8 @@ __global__ __launch_bounds__(kTagThreads, 8) void tag_tokens_kernel(const TagPar
             __builtin_amdgcn_wave_barrier();   // the ring is written by the next step
         }
     }
+    // what still waits: the candidates, then the queue
+    if (nc != 0 || nq != 0) tag_resolve(P, L, nc, nq, true, lane, dbg);
 }
 
 }  // namespace

@@ -159,6 +159,7 @@ VPT_HD uint32_t tag_token_hash_key(uint32_t lo, uint32_t hi, uint32_t len) {
     h ^= h >> 15;
     return h * kHashMulLo;
 }
+constexpr uint32_t kTagFilterLog2 = 5;    // filter bits per slot of the token table, as a power of two (the filter follows the slots)
 constexpr uint32_t kTagTokInline = 1u << 31, kTagTokFast = 1u << 30, kTagTokLenMask = (1u << 30) - 1u;
 constexpr uint32_t kTagFiltStride = 28;   // dwords per model in HostTagTables::mfilt
 

@@ -713,7 +713,9 @@ HostTagTables build_tag_tables(const ModelData& m, bool use_char, bool use_type)
     t.use_char = use_char; t.use_type = use_type;
     t.n_models = uint32_t(m.tag_models.size());
     t.tok_bits = bits_for(m.tag_models.size()) + 1;   // a quarter full: a lane's probe sequence is the wave's when it is the longest
-    t.tok_tab.assign(size_t(4) << t.tok_bits, 0);
+    // ... followed by the FILTER: 32 bits per slot, bit (hash >> (32 - tok_bits - 5)) set for every token of the table -- one
+    // token in thirty has a tag model (BASELINE's configs[4]); the others learn it from one 4-byte read (layout.h, kTagFilterLog2)
+    t.tok_tab.assign((size_t(4) << t.tok_bits) + (size_t(1) << t.tok_bits), 0);
     const uint32_t mask = (1u << t.tok_bits) - 1;
     for (uint32_t mi = 0; mi < m.tag_models.size(); ++mi) {
         const TagModelRecord& tm = m.tag_models[mi];
@@ -806,7 +808,12 @@ HostTagTables build_tag_tables(const ModelData& m, bool use_char, bool use_type)
             t.mfilt.insert(t.mfilt.end(), f, f + kTagFiltStride);
         }
         // token table: a repeated token keeps its slot and takes the later model
-        uint32_t b = tag_token_hash(tm.token.data(), tm.token.size()) >> (32 - t.tok_bits);
+        const uint32_t th = tag_token_hash(tm.token.data(), tm.token.size());
+        {
+            const uint32_t fbit = th >> (32 - t.tok_bits - kTagFilterLog2);
+            t.tok_tab[(size_t(4) << t.tok_bits) + (fbit >> 5)] |= 1u << (fbit & 31u);
+        }
+        uint32_t b = th >> (32 - t.tok_bits);
         for (;;) {
             uint32_t* e = &t.tok_tab[size_t(b) * 4];
             if (e[0] != 0) {
