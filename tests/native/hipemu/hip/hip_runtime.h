@@ -144,6 +144,7 @@ template <typename T, typename V> static inline void __hip_atomic_store(T* p, V 
 #define __builtin_amdgcn_wave_barrier() ::hipemu::wave_sync()
 #define __builtin_amdgcn_s_memtime() ::hipemu::clock()
 #define __builtin_amdgcn_s_sleep(n) ((void)0)
+#define __builtin_amdgcn_s_setprio(n) ((void)0)
 static inline uint32_t hipemu_mbcnt_lo(uint32_t mask, uint32_t base) {
     const unsigned l = ::hipemu::lane();
     return base + uint32_t(__builtin_popcount(l >= 32 ? mask : mask & ((1u << l) - 1u)));

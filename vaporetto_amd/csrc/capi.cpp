@@ -1429,6 +1429,7 @@ vpt_status vpt_fill_tags_scores_batch_device(const vpt_predictor* p, vpt_batch* 
     T.use_char = p->tag_use_char ? 1u : 0u; T.use_type = p->tag_use_type ? 1u : 0u;
     T.cps = b->d_cps; T.ooff = d_out_offsets; T.labels = d_labels; T.n_sent = n_sentences; T.total_chars = total_c; T.tags = d_tags_out;
     T.tok_model = b->d_tok_model + 4;
+    T.slot_str = p->dtag.slot_str; T.str_off = p->dtag.str_off; T.n_strings = p->dtag.n_strings;
     T.scores_out = p->max_tag_scores ? d_tag_scores_out : nullptr; T.model_out = d_tag_models_out; T.score_stride = p->max_tag_scores;
     // tag_tokens_kernel runs 8 workgroups per CU at a time; four generations of them stride over the batch, so that the
     // sentences' lengths (8..512 chars in BASELINE's configs[4]) even out without one workgroup per four sentences

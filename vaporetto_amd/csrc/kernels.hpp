@@ -127,7 +127,9 @@ struct TagParams {
     const uint8_t* labels;      // [total boundaries] CharacterBoundary values (0, 1, 2 = Unknown)
     uint64_t n_sent;
     uint64_t total_chars;       // total boundaries + S: what `cps` and `tags / n_tags` hold
-    int32_t* tok_model;         // [total chars] or nullptr: tag model index + 1 of the token ending at the char (token emission)
+    int32_t* tok_model;         // [total chars] or nullptr: the token ending at the char for the writer (layout.h, tok_model words)
+    const uint32_t *slot_str, *str_off;   // the tag strings' lengths (HostTagTables): what a token's tags take in the tokenized text
+    uint32_t n_strings;
     int32_t* tags;              // [(total boundaries + S) * n_tags] candidate index per slot, -1 = None
     // Predictor::store_tag_scores (predictor.rs:510-514): optional outputs, both indexed by char like `tags`
     int32_t* scores_out;        // [(total boundaries + S) * score_stride] or nullptr: at the last char of a token with a tag model, entries

@@ -53,7 +53,12 @@ __device__ __noinline__ uint32_t tag_suffix_of(const EmitParams& P, uint64_t c, 
     return n;
 }
 __device__ __forceinline__ uint32_t tag_suffix(const EmitParams& P, uint64_t c, uint8_t* dst) {
-    return P.tags ? tag_suffix_of(P, c, P.tok_model[c], dst) : 0u;
+    return P.tags ? tag_suffix_of(P, c, int32_t(uint32_t(P.tok_model[c]) & kTokModelMask), dst) : 0u;
+}
+// the bytes of the suffix of the token whose tok_model word is w (layout.h): carried from fill_tags unless it is a long one
+__device__ __forceinline__ uint32_t tag_suffix_bytes(const EmitParams& P, uint64_t c, uint32_t w) {
+    const uint32_t code = w >> kTokSuffixShift;
+    return (w & kTokModelMask) == 0 ? 0u : code != kTokSuffixLong ? code : tag_suffix_of(P, c, int32_t(w & kTokModelMask), nullptr);
 }
 __device__ __forceinline__ uint64_t wave_sum64(uint64_t x) {   // total over the 64 lanes, in every lane
 #pragma unroll
@@ -295,6 +300,7 @@ __device__ __forceinline__ void fuse_walk(const EmitParams& P, const FuseBlock& 
         if (kTags) {
             tmask = spm | sm;
             if (sb + s_in == 0 && sm) tmask &= ~(sm & (0u - sm));
+            if (kDbg && (dbg & 64u)) tmask = 0;
             if (tmask) {
                 // the tag models of the chars in front of the lane's chars: tok_model[g_first - 1 + j] for its j-th char (the array has
                 // zeros in front of the batch's first char and behind its last: capi.cpp); which of them are there at all
@@ -303,7 +309,8 @@ __device__ __forceinline__ void fuse_walk(const EmitParams& P, const FuseBlock& 
                 for (uint32_t j0 = 0; j0 < nl; j0 += 4) {
                     int32_t m4[4];
                     __builtin_memcpy(m4, tmod + j0, sizeof(m4));
-                    pm |= ((m4[0] > 0 ? 1u : 0u) | (m4[1] > 0 ? 2u : 0u) | (m4[2] > 0 ? 4u : 0u) | (m4[3] > 0 ? 8u : 0u)) << j0;
+                    pm |= (((uint32_t(m4[0]) & kTokModelMask) ? 1u : 0u) | ((uint32_t(m4[1]) & kTokModelMask) ? 2u : 0u) | ((uint32_t(m4[2]) & kTokModelMask) ? 4u : 0u) |
+                           ((uint32_t(m4[3]) & kTokModelMask) ? 8u : 0u)) << j0;
                 }
                 pm &= (1u << nl) - 1u;
                 while (pm) {   // few
@@ -313,8 +320,9 @@ __device__ __forceinline__ void fuse_walk(const EmitParams& P, const FuseBlock& 
                     for (uint32_t q = 0; q < j; ++q) rem &= rem - 1u;
                     const uint32_t k = uint32_t(__ffs(int(rem))) - 1u;          // the byte of the lane's j-th char
                     if (!((tmask >> k) & 1u)) continue;                          // no token ends in front of it
-                    const int32_t mdl = tmod[j];
-                    const uint32_t len = tag_suffix_of(P, g_first + j - 1u, mdl, nullptr);
+                    const uint32_t word = uint32_t(tmod[j]);
+                    const int32_t mdl = int32_t(word & kTokModelMask);
+                    const uint32_t len = tag_suffix_bytes(P, g_first + j - 1u, word);   // (carried from fill_tags)
                     if (!len) continue;
                     if (tk1 == 16) { tk1 = k; tl1 = len; tc1 = j; tm1 = mdl; }
                     else if (tk2 == 16) { tk2 = k; tl2 = len; tc2 = j; tm2 = mdl; }
@@ -419,29 +427,30 @@ __device__ __forceinline__ void fuse_walk(const EmitParams& P, const FuseBlock& 
         if (s && store_ok && at_out + s <= end && lane == 0) tag_suffix(P, g_last, P.out_text + at_out);
         at_out += s;
     }
-    if (fits && (cb != (K.O1 - K.O0) + K.ns || sb != K.ns)) err |= kErrBadOffsets;
+    // (what was written is what pass A said: anything else means chars, labels, offsets -- or the tags' token words and the labels,
+    // which must be the ones fill_tags saw -- do not belong together)
+    if (!fits || at_out != end || cb != (K.O1 - K.O0) + K.ns || sb != K.ns) err |= kErrBadOffsets;
 }
 
-// Pass A with tags: the bytes of the block's tag suffixes.  The tag models of the block's chars are read flat, four per lane; a char
-// with one (one in thirty) ends a token -- and has its suffix written -- if the label behind it is a boundary or it is its sentence's
-// last: its sentence is found in the block's offsets (LDS).
-__device__ __forceinline__ uint32_t fuse_tag_bytes(const EmitParams& P, const FuseBlock& K, int lane, const FuseWaveLds& L) {
+// Pass A with tags: the bytes of the block's tag suffixes -- a reduction over the token words of its chars (fill_tags left the bytes
+// of a token's tags in the word of its last char: layout.h), sixteen chars per lane in flight.
+__device__ __forceinline__ uint32_t fuse_tag_bytes(const EmitParams& P, const FuseBlock& K, int lane) {
     const uint64_t g0 = K.O0 + K.i0, n_chars = (K.O1 - K.O0) + K.ns;
     uint32_t bytes = 0;
-    for (uint64_t c0 = 4 * uint64_t(lane); c0 < n_chars; c0 += 256) {
-        int32_t m4[4];
-        __builtin_memcpy(m4, P.tok_model + g0 + c0, sizeof(m4));   // (zeros behind the batch's last char)
-        for (uint32_t q = 0; q < 4; ++q) {
-            const uint64_t c = c0 + q;                  // char of the block
-            if (m4[q] <= 0 || c >= n_chars) continue;
-            uint32_t lo = 0, hi = K.ns;                 // the sentence s with so[s] + s <= c: the last such
-            while (hi - lo > 1) {
-                const uint32_t mid = (lo + hi) >> 1;
-                if (uint64_t(L.so[mid]) + mid <= c) lo = mid; else hi = mid;
-            }
-            const uint64_t p = c - (uint64_t(L.so[lo]) + lo), n_s = uint64_t(L.so[lo + 1]) - L.so[lo] + 1;   // char p of n_s
-            if (p + 1 == n_s || (p + 1 < n_s && P.labels[K.O0 + L.so[lo] + p] == 1u)) bytes += tag_suffix_of(P, g0 + c, m4[q], nullptr);
+    for (uint64_t c0 = 4 * uint64_t(lane); c0 < n_chars; c0 += 1024) {
+        int32_t m[4][4];
+#pragma unroll
+        for (uint32_t r = 0; r < 4; ++r) {
+            if (c0 + 256 * r < n_chars) __builtin_memcpy(m[r], P.tok_model + g0 + c0 + 256 * r, sizeof(m[r]));   // (the array goes on behind the batch's last char)
+            else m[r][0] = m[r][1] = m[r][2] = m[r][3] = 0;
         }
+#pragma unroll
+        for (uint32_t r = 0; r < 4; ++r)
+#pragma unroll
+            for (uint32_t q = 0; q < 4; ++q) {
+                const uint64_t c = c0 + 256 * r + q;
+                if (c < n_chars) bytes += tag_suffix_bytes(P, g0 + c, uint32_t(m[r][q]));
+            }
     }
     return bytes;
 }
@@ -488,6 +497,8 @@ __global__ __launch_bounds__(kEmitThreads) void emit_fused_kernel(const EmitPara
     if (lane < int(kFuseStepBytes / 32)) L.starts[lane] = 0;
     __builtin_amdgcn_wave_barrier();
 
+    // (a wave that has not published its size yet holds up every block behind it: it goes first on its SIMD)
+    __builtin_amdgcn_s_setprio(3);
     // ---- pass A: the block's size = its bytes + the escaped bytes + the boundary labels of its label range (+ the tag suffixes)
     uint64_t size = 0;
     if (kDbg && (dbg & 8u)) size = 3 * (K.B1 - K.B0);
@@ -495,15 +506,20 @@ __global__ __launch_bounds__(kEmitThreads) void emit_fused_kernel(const EmitPara
         uint32_t added = 0;
         const uintptr_t l_lo = reinterpret_cast<uintptr_t>(P.labels) + K.O0, l_hi = reinterpret_cast<uintptr_t>(P.labels) + K.O1;
         const uintptr_t t_lo = reinterpret_cast<uintptr_t>(P.text) + K.B0, t_hi = reinterpret_cast<uintptr_t>(P.text) + K.B1;
-        for (uintptr_t a = (t_lo & ~uintptr_t(15)) + 16u * uint32_t(lane); a < t_hi; a += kFuseStepBytes)
-            added += uint32_t(__popc(esc16(*reinterpret_cast<const uint4*>(a)) & in_range16(a, t_lo, t_hi)));
+        for (uintptr_t a = (t_lo & ~uintptr_t(15)) + 16u * uint32_t(lane); a < t_hi; a += 4 * kFuseStepBytes) {   // four loads in flight
+            uint4 x[4];
+#pragma unroll
+            for (uint32_t q = 0; q < 4; ++q) x[q] = a + q * kFuseStepBytes < t_hi ? *reinterpret_cast<const uint4*>(a + q * kFuseStepBytes) : make_uint4(0, 0, 0, 0);
+#pragma unroll
+            for (uint32_t q = 0; q < 4; ++q) added += uint32_t(__popc(esc16(x[q]) & in_range16(a + q * kFuseStepBytes, t_lo, t_hi)));
+        }
         for (uintptr_t a = (l_lo & ~uintptr_t(15)) + 16u * uint32_t(lane); a < l_hi; a += kFuseStepBytes) {
             const uint4 y = *reinterpret_cast<const uint4*>(a);
             const uint32_t m = in_range16(a, l_lo, l_hi);
             added += uint32_t(__popc(one16(y) & m));
             if (unk16(y) & m) err |= kErrUnknownLabel;
         }
-        if (kTags) added += fuse_tag_bytes(P, K, lane, L);
+        if (kTags && !(kDbg && (dbg & 128u))) added += fuse_tag_bytes(P, K, lane);
         size = (K.B1 - K.B0) + wave_sum64(added);
     }
 
@@ -525,6 +541,7 @@ __global__ __launch_bounds__(kEmitThreads) void emit_fused_kernel(const EmitPara
         p -= 64;
     }
     if (lane == 0) __hip_atomic_store(F.state + blk, (uint64_t(2) << 62) | ((base + size) & kVal), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __builtin_amdgcn_s_setprio(0);
     const uint64_t end = base + size;
     const bool store_ok = end <= P.capacity;
     if (blk == F.n_blocks - 1 && lane == 0) {

@@ -50,6 +50,14 @@ namespace {
 constexpr int kTagThreads = 256;
 constexpr int kTagWaves = kTagThreads / 64;
 
+__device__ __forceinline__ uint64_t wave_sum64(uint64_t x) {   // total over the 64 lanes, in every lane
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+        const uint32_t lo = uint32_t(__shfl_xor(int(uint32_t(x)), d)), hi = uint32_t(__shfl_xor(int(uint32_t(x >> 32)), d));
+        x += uint64_t(lo) | (uint64_t(hi) << 32);
+    }
+    return x;
+}
 __device__ __forceinline__ uint32_t lanes_below(uint64_t mask, int lane) {
     return uint32_t(__popcll(mask & ((uint64_t(1) << lane) - 1)));
 }
@@ -111,9 +119,9 @@ struct TagWaveLds {
     union {
         int32_t z[kTagMaxZ];                 // the whole-wave routine: one token's scores
         struct {
-            uint32_t tok[kTagPass][8];             // the queue: tag model + 1, flat char index (2), chars before | after << 8 inside the sentence (clipped
+            uint32_t tok[kTagPass][12];             // the queue: tag model + 1, flat char index (2), chars before | after << 8 inside the sentence (clipped
                                                    // to the context); a pass adds: first record, scores | slots << 8 | type entries << 16 | active
-                                                   // groups << 24, packed slots, the four char group sizes
+                                                   // groups << 24, packed slots, the four char group sizes, slot_str of its slots (3)
             uint32_t ctx[kTagPass][kCtx];          // cps words p - 11 .. p + 4 of every token, 0 outside its sentence
             int32_t zt[kTagPass][kTagFastZ + 1];   // the scores (rows padded against bank conflicts)
             uint32_t pref[kTagPass + 1];           // records before token t (exclusive prefix of the counts)
@@ -205,6 +213,7 @@ __device__ __forceinline__ void tag_token_by_wave(const TagParams& P, const uint
         for (uint32_t i = lane; i < zlen && i < P.score_stride; i += 64) P.scores_out[(g0 + uint64_t(e)) * P.score_stride + i] = z[i];
     }
     const uint32_t n_slots = mr[9] < P.n_tags ? mr[9] : P.n_tags;
+    uint32_t str_bytes = 0, last_some = 0;   // what the token's tags take in the tokenized text (layout.h, tok_model words)
     for (uint32_t j = lane; j < P.n_tags; j += 64) {   // the slots past the model's own are None
         const uint32_t cnt = j < n_slots ? P.slots[size_t(mr[8] + j) * 2] : 0u, off = j < n_slots ? P.slots[size_t(mr[8] + j) * 2 + 1] : 0u;
         int32_t tag = cnt == 1 ? 0 : -1;
@@ -217,6 +226,16 @@ __device__ __forceinline__ void tag_token_by_wave(const TagParams& P, const uint
             }
         }
         P.tags[(g0 + uint64_t(e)) * P.n_tags + j] = tag;
+        if (tag >= 0) {
+            const uint32_t k = P.slot_str[mr[8] + j] + uint32_t(tag);
+            const uint32_t sl = k < P.n_strings ? P.str_off[k + 1] - P.str_off[k] : 0u;
+            str_bytes += sl < 0x10000u ? sl : 0x10000u;
+            last_some = j + 1;
+        }
+    }
+    if (P.tok_model) {
+        const uint32_t bytes = uint32_t(wave_sum64(str_bytes < 0x10000u ? str_bytes : 0x10000u)) + wave_max(last_some);
+        if (lane == 0) P.tok_model[g0 + uint64_t(e)] = int32_t(model | ((bytes < kTokSuffixLong ? bytes : kTokSuffixLong) << kTokSuffixShift));
     }
     __builtin_amdgcn_wave_barrier();
 }
@@ -267,6 +286,8 @@ __device__ __forceinline__ void tag_pass(const TagParams& P, TagWaveLds& L, uint
     if (uint32_t(lane) < nq) {
         const uint4* fr = reinterpret_cast<const uint4*>(P.mfilt + size_t(L.f.tok[lane][0] - 1) * kTagFiltStride);
         f0 = fr[0]; f1 = fr[1]; f2 = fr[2];
+        const uint4 f7 = fr[7];   // slot_str of the model's (up to three) slots: where the strings of their candidates start
+        L.f.tok[lane][8] = f7.x; L.f.tok[lane][9] = f7.y; L.f.tok[lane][10] = f7.z;
     }
 #pragma unroll
     for (int q0 = 0; q0 < kTagPass * kCtx / 64; ++q0) {
@@ -365,7 +386,10 @@ __device__ __forceinline__ void tag_pass(const TagParams& P, TagWaveLds& L, uint
             }
         }
     }
-    // argmax per (token, slot) (TagPredictor::predict, predictor.rs:286-304)
+    // argmax per (token, slot) (TagPredictor::predict, predictor.rs:286-304); the bytes the token's tags take in the tokenized text
+    // ("/tag" per slot up to the last Some, sentence.rs:866-881) are summed on the way for the writer (layout.h, tok_model words)
+    if (uint32_t(lane) < nq) { L.f.pref[lane] = 0; L.f.zt[lane][kTagFastZ] = 0; }   // bytes of the Some slots' strings / last Some + 1
+    __builtin_amdgcn_wave_barrier();
     for (uint32_t a0 = 0; a0 < ((dbg & 16u) ? 0u : nq * nt); a0 += 64) {
         const uint32_t a = a0 + uint32_t(lane);
         if (a < nq * nt) {
@@ -383,7 +407,19 @@ __device__ __forceinline__ void tag_pass(const TagParams& P, TagWaveLds& L, uint
             }
             const uint64_t gp = uint64_t(L.f.tok[t][1]) | (uint64_t(L.f.tok[t][2]) << 32);
             P.tags[gp * nt + j] = tag;
+            if (P.tok_model && tag >= 0) {
+                const uint32_t k = L.f.tok[t][8 + j] + uint32_t(tag);   // (j < 3: the record form)
+                const uint32_t sl = k < P.n_strings ? P.str_off[k + 1] - P.str_off[k] : 0u;
+                atomicAdd(&L.f.pref[t], sl < 0x10000u ? sl : 0x10000u);
+                atomicMax(reinterpret_cast<uint32_t*>(&L.f.zt[t][kTagFastZ]), j + 1u);
+            }
         }
+    }
+    __builtin_amdgcn_wave_barrier();
+    if (P.tok_model && uint32_t(lane) < nq && !(dbg & 16u)) {
+        const uint64_t gp = uint64_t(L.f.tok[lane][1]) | (uint64_t(L.f.tok[lane][2]) << 32);
+        const uint32_t bytes = L.f.pref[lane] + uint32_t(L.f.zt[lane][kTagFastZ]);
+        P.tok_model[gp] = int32_t(L.f.tok[lane][0] | ((bytes < kTokSuffixLong ? bytes : kTokSuffixLong) << kTokSuffixShift));
     }
     __builtin_amdgcn_wave_barrier();
 }
@@ -403,7 +439,7 @@ __device__ __forceinline__ void tag_resolve(const TagParams& P, TagWaveLds& L, u
     uint32_t model = have ? find_tag_model(P, P.cps + (gp + 1 - len), len, &fast) : 0u;
     if (dbg & 2u) model = 0;
     if (have) {
-        if (P.tok_model) P.tok_model[gp] = int32_t(model);   // 0: no tag model for this surface
+        if (P.tok_model && (model == 0 || (dbg & 80u))) P.tok_model[gp] = int32_t(model);   // 0: no tag model for this surface (else: written with its tags' bytes by tag_pass / tag_token_by_wave)
         if (P.model_out) P.model_out[gp] = int32_t(model) - 1;
         if (model == 0) for (uint32_t j = 0; j < nt; ++j) P.tags[gp * nt + j] = -1;
     }

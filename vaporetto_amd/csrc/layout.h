@@ -159,9 +159,13 @@ VPT_HD uint32_t tag_token_hash_key(uint32_t lo, uint32_t hi, uint32_t len) {
     h ^= h >> 15;
     return h * kHashMulLo;
 }
+// tok_model words (fill_tags -> the writer, a workspace array): tag model index + 1 of the token that ENDS at the char (0: none) in the
+// low 24 bits, above them the bytes of its "/tag/tag.." suffix (Sentence::write_tokenized_text, sentence.rs:866-881) -- 255: longer
+// than 254, the writer walks the tags itself
+constexpr uint32_t kTokModelMask = 0xFFFFFFu, kTokSuffixShift = 24, kTokSuffixLong = 255;
 constexpr uint32_t kTagFilterLog2 = 5;    // filter bits per slot of the token table, as a power of two (the filter follows the slots)
 constexpr uint32_t kTagTokInline = 1u << 31, kTagTokFast = 1u << 30, kTagTokLenMask = (1u << 30) - 1u;
-constexpr uint32_t kTagFiltStride = 28;   // dwords per model in HostTagTables::mfilt
+constexpr uint32_t kTagFiltStride = 32;   // dwords per model in HostTagTables::mfilt
 
 // signed `bits`-wide field number j of a 128-bit little-endian row (unigram rows, bigram rows)
 VPT_HD int32_t row_field(uint32_t x, uint32_t y, uint32_t z, uint32_t w, int j, int bits) {

@@ -711,6 +711,7 @@ HostTagTables build_tag_tables(const ModelData& m, bool use_char, bool use_type)
     HostTagTables t;
     t.present = true;
     t.use_char = use_char; t.use_type = use_type;
+    if (m.tag_models.size() >= kTokModelMask) throw ModelError("InvalidModelError: too many tag models");
     t.n_models = uint32_t(m.tag_models.size());
     t.tok_bits = bits_for(m.tag_models.size()) + 1;   // a quarter full: a lane's probe sequence is the wave's when it is the longest
     // ... followed by the FILTER: 32 bits per slot, bit (hash >> (32 - tok_bits - 5)) set for every token of the table -- one
@@ -804,6 +805,7 @@ HostTagTables build_tag_tables(const ModelData& m, bool use_char, bool use_type)
                 f[10] = rec[5] | (uint32_t(tm.bias.size()) << 8) | (uint32_t(tm.tags.size()) << 16);
                 f[11] = rec[11];
                 for (size_t i = 0; i < tm.bias.size(); ++i) f[12 + i] = uint32_t(tm.bias[i]);
+                for (size_t j = 0; j < tm.tags.size(); ++j) f[28 + j] = t.slot_str[size_t(rec[8]) + j];   // (<= 3 slots)
             }
             t.mfilt.insert(t.mfilt.end(), f, f + kTagFiltStride);
         }

@@ -61,11 +61,11 @@ struct HostPackedTable {
 //             the n-gram has at most 12 symbols, all below 0xFFFF.  models[10] bit 0 = every entry of the model is compact,
 //             its char and type entries are adjacent, it has at most 16 scores and at most 3 slots: the fast path may take its
 //             tokens; models[11] then packs the slots: (candidates | score offset << 5) << (9 * slot).
-//   mfilt     28 dwords per tag model, all the fast path reads of a model: the char entries of a model are ordered by rel_position;
+//   mfilt     32 dwords per tag model, all the fast path reads of a model: the char entries of a model are ordered by rel_position;
 //             dwords 2r, 2r+1 = a 64-bit filter over packed_filter_bit(last symbol) of the n-grams with rel_position r (0..3), dword 8 =
 //             the four group sizes, 8 bits each -- a token whose text has no candidate last char at offset r skips the whole group;
 //             for a model in the record form also dword 9 = its first record, 10 = type entries | scores << 8 | slots << 16,
-//             11 = models[11], 12..27 = the bias, zero padded.
+//             11 = models[11], 12..27 = the bias, zero padded, 28..30 = slot_str of its slots (the first candidate string of each).
 //   slots     2 dwords per tag slot: candidate count, offset of its scores in z (slots with >= 2 candidates)
 //   slot_str  per tag slot: index of its first candidate in str_off; str_off[k] .. str_off[k+1] = the bytes of candidate
 //             string k in str_bytes, ALREADY escaped the way Sentence::write_tokenized_text writes a tag (sentence.rs:871-880)
