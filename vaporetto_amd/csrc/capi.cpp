@@ -1002,7 +1002,13 @@ vpt_status vpt_predict_batch_device(const vpt_predictor* p, vpt_batch* b, const 
         cut.tile_flat = can_cut ? uint32_t(room) : 0u;
         cut.mis = uint32_t(reinterpret_cast<uintptr_t>(d_utf8) & 15u);
         const bool fits_whole = max_chars <= uint64_t(vpt::kFastWholeMaxChars);
-        cut_tiles = can_cut && (b->knobs.force_cut > 0 || (!fits_whole && !(b->knobs.force_cut < 0 && max_chars + 2 * uint64_t(p->pad) + vpt::kFastCap / 2 <= uint64_t(vpt::kFastCap))));
+        const bool whole_possible = max_chars + 2 * uint64_t(p->pad) + vpt::kFastCap / 2 <= uint64_t(vpt::kFastCap);
+        // Whole-sentence tiles are cut every (capacity - longest sentence) positions: the longer the longest sentence, the emptier
+        // they run, while a tile cut anywhere is always full -- at the price of the index of the text (a pass over it).  Measured on
+        // configs[4] (8 .. 512 chars, profiles/r03_u_cut_vs_whole.txt): kernel 2.14 -> 1.99 ms, step 3.80 -> 3.76; on configs[1] (64
+        // chars) the kernel is the same and the index costs 19 us of 117.  So: cut above a quarter of the capacity.
+        const bool prefer_cut = max_chars > uint64_t(vpt::kFastCap / 4);
+        cut_tiles = can_cut && (b->knobs.force_cut > 0 || (b->knobs.force_cut == 0 ? (prefer_cut || !fits_whole) : !whole_possible));
         if (!cut_tiles && max_chars + 2 * uint64_t(p->pad) + vpt::kFastCap / 2 > uint64_t(vpt::kFastCap)) fast = false;   // neither kind of tile holds the batch
     }
     const uint64_t cap = fast ? uint64_t(vpt::kFastCap) : vpt::kCap;

@@ -16,7 +16,7 @@ constexpr int kTileFlat = 1024;                  // flat positions a tile is cut
                                                  // that crosses the cut, so it needs kCap - kTileFlat of slack)
 constexpr int kMargin = 8;                       // zeroed slack past the tile for the s+1, s+2 look-ahead
 // The specialised kernel's tile: kFastCap flat positions, kFastWg workgroups per CU (1280 / 8: the best of the geometries measured
-// on MI355X, profiles/r02_c5_ab*.jsonl, r03_d_ab_geometries.jsonl), and -- compiled out by default -- two LDS-resident caches in front
+// on MI355X, profiles/r02_c5_ab*.jsonl, r03_d_ab_m1.jsonl), and -- compiled out by default -- two LDS-resident caches in front
 // of the two small tables every position reads, the char -> (id, CharacterType) table and the unigram nodes.  Measured (r03_d): a
 // 512-entry char cache hits 83 % of the chars of the benchmark text and buys 2 % (those gathers hit the vector L1 anyway; what the
 // kernel waits for are the bigram / trigram nodes that miss the L2), less than the smaller tile that makes room for it costs.

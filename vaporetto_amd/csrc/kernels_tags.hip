@@ -133,7 +133,10 @@ struct TagWaveLds {
                                              // chars, chars before | after << 8 inside the sentence (clipped to the context)
 };
 struct TagLds { TagWaveLds w[kTagWaves]; };
-static_assert(sizeof(TagLds) <= 160 * 1024 / 7, "7 workgroups per CU");
+#ifndef VPT_TAG_OCC
+#define VPT_TAG_OCC 6     // workgroups per CU the kernel is compiled for (A/B builds: -D)
+#endif
+static_assert(sizeof(TagLds) <= 160 * 1024 / VPT_TAG_OCC, "workgroups per CU");
 
 // Can the chars [s0, e] of the sentence be the token of a tag model?  One lane on its own, no loop over the token: the table's
 // filter is keyed like the table -- by the length and the first four chars (layout.h, tag_token_hash_key), which the lane reads from
@@ -480,7 +483,7 @@ __device__ __forceinline__ void tag_resolve(const TagParams& P, TagWaveLds& L, u
 }
 
 template <bool DBG>
-__global__ __launch_bounds__(kTagThreads, 7) void tag_tokens_kernel(const TagParams P, const uint32_t dbg_in) {
+__global__ __launch_bounds__(kTagThreads, VPT_TAG_OCC) void tag_tokens_kernel(const TagParams P, const uint32_t dbg_in) {
     const uint32_t dbg = DBG ? dbg_in : 0u;   // timing ablations (VPT_DEBUG_TAGS; results are wrong with any bit set)
     __shared__ TagLds LDS;
     const int lane = threadIdx.x & 63;
