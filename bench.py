@@ -88,11 +88,12 @@ def load_model_bytes(kind: int, scale: float):
 
 
 def kernel_source_hash() -> str:
-    """What the rocprofv3 traffic numbers of profiles/traffic.json are valid for: the kernel and table sources."""
+    """What the rocprofv3 traffic numbers of profiles/traffic.json are valid for: the sources of the scoring kernels, of the tables
+    they read and of the host code that plans their tiles (the tag kernel and the writer are measured by other means)."""
     h = hashlib.sha256()
     d = os.path.join(ROOT, "vaporetto_amd", "csrc")
     for f in sorted(os.listdir(d)):
-        if f.endswith((".hip", ".cpp", ".h", ".hpp")):
+        if f.endswith((".hip", ".cpp", ".h", ".hpp")) and f not in ("kernels_tags.hip", "kernels_emit.hip"):
             with open(os.path.join(d, f), "rb") as fh:
                 h.update(f.encode() + b"\0" + fh.read())
     return h.hexdigest()[:16]

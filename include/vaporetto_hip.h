@@ -301,9 +301,11 @@ vpt_status vpt_write_tagged_batch(const vpt_predictor *p, const uint8_t *utf8, c
                                   size_t n_sentences, const uint64_t *out_offsets, const uint8_t *labels, unsigned flags,
                                   uint8_t *text_out, uint64_t text_capacity, uint64_t *text_offsets_out);
 /* Device-resident variants: all pointers are device pointers, asynchronous on `hip_stream`; errors at vpt_batch_sync.
- * Three small kernels: count, prefix sum over the sentences, write (kernels_emit.hip).  The tagged one takes the
- * d_tags_out of a vpt_fill_tags_batch_device call made on the SAME workspace for the same batch (the workspace keeps
- * the tag model that call found for every token). */
+ * One kernel (kernels_emit.hip: a wave per block of sentences sizes, places and writes it).  The tagged one takes the
+ * d_tags_out of a vpt_fill_tags_batch_device call made on the SAME workspace for the same batch AND THE SAME LABELS (the
+ * workspace keeps, for every token that call found a tag model for, the model and the bytes its tags take; tags or labels
+ * changed in between are reported as offsets that do not match -- Sentence::fill_tags and write_tokenized_text see the
+ * same boundaries too, sentence.rs:1144-1148, 850-886). */
 vpt_status vpt_write_tokenized_batch_device(const vpt_predictor *p, vpt_batch *b, const uint8_t *d_utf8,
                                             const uint64_t *d_byte_offsets, const uint64_t *d_out_offsets,
                                             size_t n_sentences, uint64_t total_boundaries, const uint8_t *d_labels,

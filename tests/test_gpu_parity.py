@@ -1227,6 +1227,11 @@ def test_write_tagged_text_on_device():
     toff = d_toff.get(S + 1)
     out = bytes(d_out.get(int(toff[-1])))
     assert [out[int(toff[i]):int(toff[i + 1])].decode("utf-8") for i in range(S)] == want
+    # tags changed after fill_tags (the workspace still holds the bytes the OLD ones take): reported, nothing written out of place
+    d_none = devmem.put(np.full((nb + S) * nt + 1, -1, np.int32))
+    batch.write_tagged(d_text.ptr, d_boff.ptr, d_ooff.ptr, S, nb, d_labels.ptr, d_none.ptr, d_out.ptr, cap, d_toff.ptr, devmem.stream())
+    with pytest.raises(api.VaporettoError, match="do not match the text"):
+        batch.sync()
 
 
 @pytest.mark.parametrize("per_block", [1, 3, 64])

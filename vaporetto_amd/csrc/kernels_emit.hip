@@ -30,8 +30,9 @@ __device__ __forceinline__ uint32_t esc_nibble(uint32_t x) {
     return byte_flags_to_nibble(zero_bytes(x ^ 0x20202020u) | zero_bytes(x ^ 0x5C5C5C5Cu) | zero_bytes(x ^ 0x2F2F2F2Fu));
 }
 // "/tag/tag.." of the token whose last char is char `c` (batch-flat index) and whose tag model (index + 1, from the
-// fill_tags call) is `model`: bytes it takes; written to `dst` when given
-__device__ __noinline__ uint32_t tag_suffix_of(const EmitParams& P, uint64_t c, int32_t model, uint8_t* dst) {
+// fill_tags call) is `model`: bytes it takes; written to `dst` when given -- never more than `limit` of them (what was reserved
+// for it: a caller that changed the tags after fill_tags gets the offsets error, not a write outside the suffix's place)
+__device__ __noinline__ uint32_t tag_suffix_of(const EmitParams& P, uint64_t c, int32_t model, uint8_t* dst, uint32_t limit = 0xFFFFFFFFu) {
     if (model <= 0 || uint32_t(model) > P.n_models) return 0;   // no tag model for this surface (or not our array)
     const uint32_t* mr = P.models + size_t(model - 1) * 12;
     const int32_t* tg = P.tags + c * P.n_tags;
@@ -41,13 +42,13 @@ __device__ __noinline__ uint32_t tag_suffix_of(const EmitParams& P, uint64_t c, 
         if (tg[j] >= 0 && j < n_slots) last = j + 1;
     uint32_t n = 0;
     for (uint32_t j = 0; j < last; ++j) {
-        if (dst) dst[n] = 0x2Fu;
+        if (dst && n < limit) dst[n] = 0x2Fu;
         ++n;
         if (tg[j] < 0) continue;
         const uint32_t k = P.slot_str[slot0 + j] + uint32_t(tg[j]);
         if (k >= P.n_strings) continue;                            // an index fill_tags cannot have written
         const uint32_t a = P.str_off[k], b = P.str_off[k + 1];
-        if (dst) for (uint32_t q = a; q < b; ++q) dst[n + (q - a)] = P.str_bytes[q];
+        if (dst) for (uint32_t q = a; q < b && n + (q - a) < limit; ++q) dst[n + (q - a)] = P.str_bytes[q];
         n += b - a;
     }
     return n;
@@ -365,8 +366,8 @@ __device__ __forceinline__ void fuse_walk(const EmitParams& P, const FuseBlock& 
                 }
                 if (kTags && tl1) {   // the tags themselves (few lanes)
                     const uint32_t b1 = (1u << tk1) - 1u, b2 = (1u << tk2) - 1u;
-                    (void)tag_suffix_of(P, g_first + tc1 - 1u, tm1, o + w + uint32_t(__popc(vm & b1)) + uint32_t(__popc(spm & b1)) + uint32_t(__popc(em & b1)));
-                    if (tl2) (void)tag_suffix_of(P, g_first + tc2 - 1u, tm2, o + w + tl1 + uint32_t(__popc(vm & b2)) + uint32_t(__popc(spm & b2)) + uint32_t(__popc(em & b2)));
+                    if (tag_suffix_of(P, g_first + tc1 - 1u, tm1, o + w + uint32_t(__popc(vm & b1)) + uint32_t(__popc(spm & b1)) + uint32_t(__popc(em & b1)), tl1) != tl1) err |= kErrBadOffsets;
+                    if (tl2 && tag_suffix_of(P, g_first + tc2 - 1u, tm2, o + w + tl1 + uint32_t(__popc(vm & b2)) + uint32_t(__popc(spm & b2)) + uint32_t(__popc(em & b2)), tl2) != tl2) err |= kErrBadOffsets;
                 }
             }
             uint32_t rem = sm;   // the sentences that start in the lane's bytes (few lanes, one as a rule)
