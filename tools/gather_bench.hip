@@ -127,6 +127,27 @@ __global__ __launch_bounds__(256) void mix_v2(const uint4* __restrict__ bi, cons
     if (acc == 0x12345678u) out[0] = acc;
 }
 
+//   v3: the trigram children of a bigram node in the node's own 128-byte line (a 32-byte node + six 16-byte child slots): the child is
+//       asked for together with the node (its slot follows from the third char alone), one L2 request for both levels; `over_per_1024`
+//       of the trigram lanes find their child in the separate table all the same (bigrams with more children than fit)
+__global__ __launch_bounds__(256) void mix_v3(const uint4* __restrict__ bi, const uint4* __restrict__ tri, const uint4* __restrict__ uni, uint32_t tri_per_1024,
+                                              uint32_t over_per_1024, int iters, uint32_t* out) {
+    const uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x;
+    uint32_t acc = 0;
+    for (int i = 0; i < iters; ++i) {
+        const uint32_t r = mix(tid * 0x9E3779B1u + uint32_t(i) * 0x85EBCA77u);
+        const uint4 u = uni[zipfish(mix(r + 2), 4095u, 255u)];
+        const uint32_t nb = zipfish(r, (1u << 21) - 1, (1u << 14) - 1) << 3;   // 128-byte records
+        const bool want_tri = (mix(r + 3) & 1023u) < tri_per_1024, over = (mix(r + 5) & 1023u) < over_per_1024;
+        const uint4 b0 = bi[nb], b1 = bi[nb + 1];
+        uint4 t = make_uint4(0, 0, 0, 0);
+        if (want_tri && !over) t = bi[nb + 2 + (mix(r + 4) % 6u)];
+        acc ^= u.x ^ b0.y ^ b1.z ^ t.w;
+        if (want_tri && over) { const uint4 t2 = tri[zipfish(mix(r + 4), (1u << 21) - 1, (1u << 15) - 1)]; acc ^= t2.w; }
+    }
+    if (acc == 0x12345678u) out[0] = acc;
+}
+
 template <int MODE>
 double run_mix(const uint4* tab, uint32_t nrec_mask, uint32_t hot_mask, int blocks, int iters, uint32_t* out) {
     hipEvent_t a, b; CHECK(hipEventCreate(&a)); CHECK(hipEventCreate(&b));
@@ -201,6 +222,12 @@ int main() {
         for (uint32_t tp : {0u, 300u, 560u, 1024u}) {
             const double t2 = time5([&] { hipLaunchKernelGGL(mix_v2, dim3(blocks), dim3(256), 0, 0, bi, tri, uni, tp, iters, out); });
             printf("position mix v2 (16-B unigram node + 32-B bigram node + 16-B trigram node for %u/1024 of the lanes): %.1f G positions/s\n", tp, positions / t2 / 1e6);
+        }
+        uint4* bi3;   // the same 2 M bigram nodes as 128-byte records
+        CHECK(hipMalloc(&bi3, (size_t(256) << 20) + 256)); CHECK(hipMemset(bi3, 1, (size_t(256) << 20) + 256));
+        for (uint32_t ov : {0u, 300u, 600u}) {
+            const double t3 = time5([&] { hipLaunchKernelGGL(mix_v3, dim3(blocks), dim3(256), 0, 0, bi3, tri, uni, 560u, ov, iters, out); });
+            printf("position mix v3 (trigram child in its bigram node's 128-B line, 560/1024 of the lanes want one, %u/1024 of those from the separate table): %.1f G positions/s\n", ov, positions / t3 / 1e6);
         }
     }
     return 0;
