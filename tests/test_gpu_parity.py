@@ -1282,9 +1282,9 @@ WRITER_TEST_SENTENCES = 9000   # (tests/test_kernel_emu.py runs the same test on
 
 
 def test_writer_long_tags_many_sentences_and_long_sentences():
-    """The writer assembles a step's output (256 text bytes and what is inserted) in LDS; tag strings of hundreds of bytes
-    do not fit there and go out byte by byte; the sentences' positions come from a three-kernel prefix sum whose
-    workgroups take 4 096 sentences each: more sentences than that, sentences of thousands of bytes, every alignment."""
+    """The writer assembles a step's output (1 KB of text and what is inserted) in LDS; tag strings of hundreds of bytes do not
+    fit there and go out byte by byte; a block's position comes from the look-back over the earlier blocks' sizes, 64 per trip:
+    thousands of blocks, sentences of thousands of bytes (a block of its own, many steps), every alignment."""
     m = randmodel.rand_model(841, alphabet="kana", wc=3, wt=3, n_tag_models=30, max_word=3, n_char=60, n_dict=60)
     for k, tm in enumerate(m.tag_models):
         tm.tags = [[(t + "/x " * 3) * (40 + 25 * (k % 5)) if k % 2 else t for t in cands] for cands in tm.tags]   # up to ~1.7 KB per tag

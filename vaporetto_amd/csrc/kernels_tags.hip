@@ -112,7 +112,11 @@ constexpr uint32_t kCharMask = 0x1FFFFFu;   // a cps word: scored scalar value |
 constexpr int kRing = 128;                   // the sentence's cps words in LDS: char q at txt[q & 127]; a step holds [base - 64, base + 64)
 constexpr int kTagPass = 16;                 // queued tokens a pass takes
 constexpr int kCtx = 16, kCtxBack = 11;      // the text a queued token's n-grams can touch: chars p - 11 .. p + 4 around its last char p
+#ifdef VPT_TAG_NO_PASS
+constexpr int kTagCand = 32;                 // (the experiment runs 8 workgroups per CU)
+#else
 constexpr int kTagCand = 64;                 // tokens that wait for the token table together
+#endif
 constexpr int kMatchCap = 128;               // matched (token, n-gram) pairs collected before their weights are added
 
 struct TagWaveLds {
@@ -461,7 +465,9 @@ __device__ __forceinline__ void tag_resolve(const TagParams& P, TagWaveLds& L, u
             }
             nq += take; done += take; remaining -= take;
             if (!(nq == uint32_t(kTagPass) || (nq != 0 && remaining == 0 && flush))) break;
+#ifndef VPT_TAG_NO_PASS   // (experiment: the step loop and the lookups alone -- what a pass of its own launch would leave behind)
             tag_pass(P, L, nq, lane, dbg);
+#endif
             nq = 0;
             if (!remaining) break;
         }
@@ -477,7 +483,9 @@ __device__ __forceinline__ void tag_resolve(const TagParams& P, TagWaveLds& L, u
             if (P.ooff[mid] + mid <= gk) lo = mid; else hi = mid;
         }
         const uint64_t g0 = P.ooff[lo] + lo;
+#ifndef VPT_TAG_NO_PASS
         tag_token_by_wave(P, P.cps + g0, int64_t(P.ooff[lo + 1] - P.ooff[lo]) + 1, int64_t(gk - g0), g0, mk, L.z, lane);
+#endif
     }
     __builtin_amdgcn_wave_barrier();
 }
