@@ -789,6 +789,24 @@ def test_stored_tag_scores_match_oracle_on_random_models(seed):
     assert (got_s[o_models < 0] == 12345).all()
 
 
+@pytest.mark.parametrize("queue", [None, "8"])
+def test_fill_tags_as_two_launches(queue, monkeypatch):
+    """Batches of 256 K chars and more take fill_tags as two launches: the step loop leaves the tokens that have a tag model in a queue
+    in HBM, a launch of passes runs over it (VPT_TAG_SPLIT=1 forces that for any batch; read when a workspace is made).  A queue
+    of 8 entries (VPT_TAG_QUEUE) overflows at once: the one-launch kernel does the batch again.  Same tags, same score vectors,
+    same tagged text as through one launch -- on models inside and outside the record form."""
+    monkeypatch.setenv("VPT_TAG_SPLIT", "1")
+    if queue:
+        monkeypatch.setenv("VPT_TAG_QUEUE", queue)
+    test_predict_tags_like_reference()
+    test_tag_models_inside_and_outside_the_record_form()
+    for seed in (0, 3, 7):
+        test_random_tag_models_match_oracle(seed)
+    test_stored_tag_scores_match_oracle_on_random_models(1)
+    test_device_resident_predict_then_fill_tags()
+    test_write_tagged_text_on_device()
+
+
 def test_tag_models_inside_and_outside_the_record_form():
     """The tag kernel's fast path checks whole n-grams from 32-byte records (<= 12 BMP symbols, <= 16 scores per model);
     models outside that form -- an n-gram of 14 chars, a non-BMP n-gram, 24 scores -- take the whole-wave routine.  Both kinds

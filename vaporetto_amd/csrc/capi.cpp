@@ -51,6 +51,8 @@ struct BatchKnobs {
     bool no_cps_from_predict = false;   // VPT_NO_CPS_FROM_PREDICT
     uint32_t debug_ablate = 0;          // VPT_DEBUG_ABLATE
     bool profile_phases = false;        // VPT_PROFILE_PHASES
+    int tag_split = 0;                  // VPT_TAG_SPLIT: 1 = fill_tags always as two launches (step loop -> queue in HBM -> passes), -1 = never (default: batches of 256 K chars and more)
+    uint32_t tag_queue = 0;             // VPT_TAG_QUEUE: entries of that queue (tests: overflow; default: an eighth of the batch's chars + 64 K)
     uint32_t debug_emit = 0;            // VPT_DEBUG_EMIT
     uint32_t emit_per_block = 0;        // VPT_EMIT_PER_BLOCK: sentences a wave of the writer takes (1..64; 0: from the mean sentence length)
 };
@@ -69,6 +71,8 @@ BatchKnobs read_batch_knobs() {
     k.force_generic = std::getenv("VPT_FORCE_GENERIC") != nullptr;
     if (const char* v = std::getenv("VPT_FORCE_CUT_TILES")) k.force_cut = std::atoi(v);
     if (const char* v = std::getenv("VPT_TILE_FLAT")) k.tile_flat = uint32_t(std::max(0, std::atoi(v)));
+    if (const char* v = std::getenv("VPT_TAG_SPLIT")) k.tag_split = std::atoi(v);
+    if (const char* v = std::getenv("VPT_TAG_QUEUE")) k.tag_queue = uint32_t(std::max(0, std::atoi(v)));
     if (const char* v = std::getenv("VPT_DEBUG_EMIT")) k.debug_emit = uint32_t(std::max(0, std::atoi(v)));
     if (const char* v = std::getenv("VPT_EMIT_PER_BLOCK")) k.emit_per_block = uint32_t(std::min(64, std::max(0, std::atoi(v))));
     k.no_cps_from_predict = std::getenv("VPT_NO_CPS_FROM_PREDICT") != nullptr;
@@ -242,6 +246,7 @@ struct vpt_batch {
     uint64_t* d_scan_part = nullptr; size_t scan_part_cap = 0;      // per-workgroup partials of the prefix sums (kernels_emit.hip)
     // the writer's state words (EmitFuse): two arrays of emit_state_cap words, used in turn; a call zeroes what the call before it
     // left in the other one (emit_dirty = how many words that is)
+    uint4* d_tag_queue = nullptr; size_t tag_queue_cap = 0;        // fill_tags as two launches: the tokens that have a tag model (TagParams::queue), + 4 dwords of counters
     uint64_t* d_emit_state = nullptr; size_t emit_state_cap = 0; size_t emit_dirty[2] = {0, 0}; int emit_flip = 0;
     // the pipelined host-buffer path (predict_pipelined): two sets of device buffers, copy streams, pinned offset staging
     struct PipeSet {
@@ -309,6 +314,7 @@ void batch_release(vpt_batch* b) {
     (void)hipSetDevice(b->device);
     (void)hipFree(b->d_scan_part);
     (void)hipFree(b->d_emit_state);
+    (void)hipFree(b->d_tag_queue);
     (void)hipFree(b->d_tiles); (void)hipFree(b->d_cut_local); (void)hipFree(b->d_cut_super);
     (void)hipFree(b->d_tile_first); (void)hipFree(b->d_slow_list); (void)hipFree(b->d_ctrl); (void)hipFree(b->d_scratch);
     (void)hipFree(b->d_prof); (void)hipFree(b->d_cps);
@@ -1441,6 +1447,18 @@ vpt_status vpt_fill_tags_scores_batch_device(const vpt_predictor* p, vpt_batch* 
     // sentences' lengths (8..512 chars in BASELINE's configs[4]) even out without one workgroup per four sentences
     // (measured on configs[4], 300 K sentences: 65536 workgroups 1.09 ms, 8 per CU 0.67, 32 per CU 0.64)
     T.max_blocks = p->n_cus * uint32_t(std::max(0, p->knobs.tag_wgs_per_cu));
+    // Two launches for a batch worth them: the step loop (every token end: filter, lookup, the entries of the tokens without a model)
+    // leaves the tokens that have one in a queue in HBM, the passes run over that queue -- each launch with the registers it needs
+    // and no more (one launch: the pass's peak on top of the loop's own values, 80 VGPRs at 6 workgroups per CU; measured on
+    // configs[4], profiles/r03_zb_tag_split.txt).  The queue holds an eighth of the batch's chars (one token in thirty has a model in
+    // BASELINE's configs[4]); a batch that overflows it is done again by the one-launch kernel, which otherwise returns at once.
+    if (b->knobs.tag_split > 0 || (b->knobs.tag_split == 0 && total_c >= (uint64_t(1) << 18))) {
+        const uint64_t want = b->knobs.tag_queue ? uint64_t(b->knobs.tag_queue) : total_c / 8 + 65536;
+        const uint32_t entries = uint32_t(std::min<uint64_t>(want, 0x7FFFFF00ull));
+        if ((st = grow(&b->d_tag_queue, &b->tag_queue_cap, size_t(entries) + 1)) != VPT_OK) return st;
+        T.queue = b->d_tag_queue + 1; T.qctl = reinterpret_cast<uint32_t*>(b->d_tag_queue);
+        T.queue_slow = std::max<uint32_t>(entries / 8, 1u); T.queue_fast = entries - T.queue_slow;
+    }
     VPT_HIP(vpt::launch_tag_tokens(T, stream));
     b->last_stream = stream; b->pending = true;
     return VPT_OK;

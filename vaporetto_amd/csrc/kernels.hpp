@@ -137,6 +137,13 @@ struct TagParams {
     int32_t* model_out;         // [total boundaries + S] or nullptr: index of that tag model (Model::tag_models order), -1 elsewhere
     uint32_t score_stride;
     uint32_t max_blocks;        // workgroups the device runs at a time (0: one wave per sentence up to 65536 workgroups)
+    // Two launches instead of one (nullptr: one): the step loop appends the tokens that have a tag model to a queue in HBM -- those whose
+    // model fits the record form at [0, queue_fast), the others at [queue_fast, queue_fast + queue_slow) -- and a launch of passes
+    // takes them from there.  qctl = {fast tokens, slow tokens, overflow}: zeroed in front of the launches; on overflow the one-launch
+    // kernel does the batch again.
+    uint4* queue;
+    uint32_t* qctl;
+    uint32_t queue_fast, queue_slow;
 };
 hipError_t launch_decode_chars(const uint8_t* text, const uint64_t* boff, const uint64_t* ooff, uint64_t n_sent, uint64_t total_chars,
                                const uint32_t* cinfo, uint32_t* cps, uint8_t* types, uint32_t* status, hipStream_t stream);

@@ -11,7 +11,7 @@
 // (char_scorer/boundary_tag_scorer.rs:62-174, type_scorer/boundary_tag_scorer.rs:51-143) with suffix-merged tag
 // weights; integer adds are order-free, so the sums are bit-identical.
 //
-// Two kernels, one wave per sentence each:
+// Kernels (a wave takes sentences in turn):
 //   decode_chars_kernel  UTF-8 -> flat per batch (char g of sentence i at out_offsets[i] + i + g): the scored scalar value
 //                        | CharacterType << 24; optionally Sentence::char_types on their own
 //   tag_tokens_kernel    The waves stay and stride over the sentences, 64 chars per step, chars and labels fetched one step
@@ -36,6 +36,16 @@
 //                        the queue fills every round and pays them once per sixteen.  Models that do not fit the record form
 //                        (an n-gram over 12 symbols or outside the BMP, more than 16 scores or 3 slots, rel_position above
 //                        3) go through a whole-wave routine, one token at a time.
+//   tag_tokens_kernel<.., kSplit> + tag_pass_kernel
+//                        For batches of 256 K chars and more the work above is TWO launches: the step loop ("front end": every token
+//                        end's filter word, the candidates' lookups, the entries of every char without a model) appends the tokens that
+//                        have a model to a queue in HBM, a wave's share with one atomic, and the passes are a launch of their own over
+//                        that queue.  In one launch the pass's peak register use sits on top of the loop's own values (80 VGPRs at 6
+//                        workgroups per CU, the loop's loads cannot be issued further ahead without spilling:
+//                        profiles/r03_w_tag_variants.txt); apart, the loop has 69 VGPRs at 7 per CU with steps of two 64-char
+//                        half-steps and the next sentence's offsets and first chars in flight a sentence ahead, the passes 57 at 8
+//                        per CU.  A queue that overflows (an eighth of the batch's chars) sets a flag: the one-launch kernel, always
+//                        launched behind the pair, then does the batch again -- otherwise it returns at once.
 //   With predict_tags the scoring kernel of the preceding vpt_predict_batch_device call leaves the decoded chars behind and
 //   decode_chars_kernel is skipped (capi.cpp).
 #include <hip/hip_runtime.h>
@@ -109,7 +119,7 @@ __global__ __launch_bounds__(kTagThreads) void decode_chars_kernel(const uint8_t
 }
 
 constexpr uint32_t kCharMask = 0x1FFFFFu;   // a cps word: scored scalar value | CharacterType << 24
-constexpr int kRing = 128;                   // the sentence's cps words in LDS: char q at txt[q & 127]; a step holds [base - 64, base + 64)
+constexpr int kRing = 256;                   // the sentence's cps words in LDS: char q at txt[q & 255]: the last 192 (one launch) / 128 (front-end launch: steps of two half-steps) chars in front of a step and the step itself
 constexpr int kTagPass = 16;                 // queued tokens a pass takes
 constexpr int kCtx = 16, kCtxBack = 11;      // the text a queued token's n-grams can touch: chars p - 11 .. p + 4 around its last char p
 #ifdef VPT_TAG_NO_PASS
@@ -132,15 +142,31 @@ struct TagWaveLds {
             uint32_t mlist[kMatchCap][2];          // matches: weight offset, token | scores to add << 8
         } f;
     };
+};
+struct TagFrontLds {                         // what the step loop keeps per wave
     uint32_t txt[kRing];
     uint32_t cand[kTagCand][4];              // tokens the filter let through, waiting for the token table: flat index of the last char (2),
                                              // chars, chars before | after << 8 inside the sentence (clipped to the context)
 };
-struct TagLds { TagWaveLds w[kTagWaves]; };
+// one launch: both; the front-end launch of the pair: the step loop's alone
+template <bool kSplit> struct TagKernelLds {
+    TagWaveLds w[kTagWaves];
+    TagFrontLds fr[kTagWaves];
+    __device__ __forceinline__ TagWaveLds* pass(uint32_t wid) { return &w[wid]; }
+};
+template <> struct TagKernelLds<true> {
+    TagFrontLds fr[kTagWaves];
+    __device__ __forceinline__ TagWaveLds* pass(uint32_t) { return nullptr; }
+};
 #ifndef VPT_TAG_OCC
-#define VPT_TAG_OCC 6     // workgroups per CU the kernel is compiled for (A/B builds: -D)
+#define VPT_TAG_OCC 6     // workgroups per CU the one-launch kernel is compiled for (A/B builds: -D)
 #endif
-static_assert(sizeof(TagLds) <= 160 * 1024 / VPT_TAG_OCC, "workgroups per CU");
+#ifndef VPT_TAG_FRONT_OCC
+#define VPT_TAG_FRONT_OCC 7
+#endif
+constexpr int kTagPairOcc = 8, kTagFrontOcc = VPT_TAG_FRONT_OCC;   // ... and the kernels of the pair (the passes: 57 VGPRs; the step loop: 64 at 8 per CU with 4 spilled, 72 at 7)
+static_assert(sizeof(TagKernelLds<false>) <= 160 * 1024 / VPT_TAG_OCC && sizeof(TagKernelLds<true>) <= 160 * 1024 / kTagPairOcc &&
+              sizeof(TagWaveLds) * kTagWaves <= 160 * 1024 / kTagPairOcc, "workgroups per CU");
 
 // Can the chars [s0, e] of the sentence be the token of a tag model?  One lane on its own, no loop over the token: the table's
 // filter is keyed like the table -- by the length and the first four chars (layout.h, tag_token_hash_key), which the lane reads from
@@ -158,6 +184,23 @@ __device__ __forceinline__ bool tag_filter_hit(const TagParams& P, const uint32_
     const uint32_t lo = (c[0] & 0xFFFFu) | (c[1] << 16), hi = (c[2] & 0xFFFFu) | (c[3] << 16);
     const uint32_t fbit = tag_token_hash_key(lo, hi, uint32_t(len)) >> (32 - P.tok_bits - kTagFilterLog2);
     return ((P.tok_tab[(size_t(4) << P.tok_bits) + (fbit >> 5)] >> (fbit & 31u)) & 1u) != 0;
+}
+
+// The same for the front-end launch's wide steps.  One lane on its own, no loop over the token: the table's
+// filter is keyed like the table -- by the length and the first four chars (layout.h, tag_token_hash_key), which the lane reads from
+// the sentence's ring in LDS (chars from `ring_lo` on) -- and answers with one 4-byte read (no for all but a percent of the tokens
+// without a model).  This is the number of the filter's bit; the caller reads the word (two half-steps' reads go out together).
+__device__ __forceinline__ uint32_t tag_filter_bit(const TagParams& P, const uint32_t* cps, const uint32_t* txt, int ring_lo, int s0, int e) {
+    const int len = e - s0 + 1;
+    uint32_t c[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) c[j] = j < len ? txt[(s0 + j) & (kRing - 1)] & kCharMask : 0u;   // always an LDS read ...
+    if (s0 < ring_lo) {   // ... and for a token that began before the ring (rare) the chars themselves
+#pragma unroll
+        for (int j = 0; j < 4; ++j) c[j] = j < len ? cps[s0 + j] & kCharMask : 0u;
+    }
+    const uint32_t lo = (c[0] & 0xFFFFu) | (c[1] << 16), hi = (c[2] & 0xFFFFu) | (c[3] << 16);
+    return tag_token_hash_key(lo, hi, uint32_t(len)) >> (32 - P.tok_bits - kTagFilterLog2);
 }
 
 // The tag model (index + 1) whose token is the `len` chars at `tc` (flat cps words), or 0: the table is keyed by the length and the
@@ -435,24 +478,44 @@ __device__ __forceinline__ void tag_pass(const TagParams& P, TagWaveLds& L, uint
 // them through); every one of them gets its entries (no tag model: None); those whose model fits the record form join the QUEUE of
 // tag_pass -- a full queue is a pass --, the others go through the whole-wave routine, one token at a time.  drain: nothing may
 // stay in the queue (the wave's last call).
-__device__ __forceinline__ void tag_resolve(const TagParams& P, TagWaveLds& L, uint32_t nc, uint32_t& nq, bool drain, int lane, uint32_t dbg) {
+// kSplit: the front-end launch -- the tokens that have a model are appended to the queue in HBM instead (TagParams::queue), a wave's
+// share with one atomic.
+template <bool kSplit>
+__device__ __forceinline__ void tag_resolve(const TagParams& P, TagFrontLds& F, TagWaveLds* Lp, uint32_t nc, uint32_t& nq, bool drain, int lane, uint32_t dbg) {
     const uint32_t nt = P.n_tags;
     const uint64_t below_me = (uint64_t(1) << lane) - 1;
     __builtin_amdgcn_wave_barrier();
     const bool have = uint32_t(lane) < nc;
-    const uint64_t gp = have ? uint64_t(L.cand[lane][0]) | (uint64_t(L.cand[lane][1]) << 32) : 0;
-    const uint32_t len = have ? L.cand[lane][2] : 0u, clip = have ? L.cand[lane][3] : 0u;
+    const uint64_t gp = have ? uint64_t(F.cand[lane][0]) | (uint64_t(F.cand[lane][1]) << 32) : 0;
+    const uint32_t len = have ? F.cand[lane][2] : 0u, clip = have ? F.cand[lane][3] : 0u;
     bool fast = false;
     uint32_t model = have ? find_tag_model(P, P.cps + (gp + 1 - len), len, &fast) : 0u;
     if (dbg & 2u) model = 0;
     if (have) {
-        if (P.tok_model && (model == 0 || (dbg & 80u))) P.tok_model[gp] = int32_t(model);   // 0: no tag model for this surface (else: written with its tags' bytes by tag_pass / tag_token_by_wave)
+        if (P.tok_model && (model == 0 || (!kSplit && (dbg & 80u)))) P.tok_model[gp] = int32_t(model);   // 0: no tag model for this surface (else: written with its tags' bytes by tag_pass / tag_token_by_wave)
         if (P.model_out) P.model_out[gp] = int32_t(model) - 1;
         if (model == 0) for (uint32_t j = 0; j < nt; ++j) P.tags[gp * nt + j] = -1;
     }
     if (dbg & 64u) model = 0;
     const uint64_t qmask = __ballot(model != 0 && fast);
     uint64_t todo = __ballot(model != 0 && !fast);   // the models outside the record form: their routine's scores take the queue's place
+    if (kSplit) {
+#pragma unroll
+        for (int kind = 0; kind < 2; ++kind) {
+            const uint64_t m = kind == 0 ? qmask : todo;
+            if (m == 0) continue;   // wave-uniform
+            const uint32_t n = uint32_t(__popcll(m)), cap = kind == 0 ? P.queue_fast : P.queue_slow;
+            uint32_t base = 0;
+            if (lane == 0) base = atomicAdd(&P.qctl[kind], n);
+            base = wave_uniform(base);
+            if (base + n > cap || base + n < base) { if (lane == 0) P.qctl[2] = 1u; continue; }   // the one-launch kernel does the batch again
+            if ((m >> lane) & 1u)
+                P.queue[(kind == 0 ? 0u : P.queue_fast) + base + uint32_t(__popcll(m & below_me))] = make_uint4(uint32_t(gp), uint32_t(gp >> 32), model, clip);
+        }
+        __builtin_amdgcn_wave_barrier();
+        return;
+    }
+    TagWaveLds& L = *Lp;   // (one launch: the passes' share of the LDS)
     const bool flush = drain || todo != 0;
     if (qmask != 0 || (flush && nq != 0)) {
         const uint32_t rank = uint32_t(__popcll(qmask & below_me));
@@ -490,18 +553,173 @@ __device__ __forceinline__ void tag_resolve(const TagParams& P, TagWaveLds& L, u
     __builtin_amdgcn_wave_barrier();
 }
 
-template <bool DBG>
-__global__ __launch_bounds__(kTagThreads, VPT_TAG_OCC) void tag_tokens_kernel(const TagParams P, const uint32_t dbg_in) {
+// The passes as a launch of their own: the waves stride over the queue the front-end launch left in HBM, 16 tokens a pass; then over
+// the tokens of the models outside the record form, one per wave at a time.
+__global__ __launch_bounds__(kTagThreads, kTagPairOcc) void tag_pass_kernel(const TagParams P) {
+    __shared__ TagWaveLds LDS[kTagWaves];
+    const int lane = threadIdx.x & 63;
+    const uint32_t wid = wave_uniform(threadIdx.x >> 6);
+    TagWaveLds& L = LDS[wid];
+    const uint64_t wave = uint64_t(blockIdx.x) * kTagWaves + wid, n_waves = uint64_t(gridDim.x) * kTagWaves;
+    if (wave_uniform(P.qctl[2]) != 0) return;   // overflow: the one-launch kernel behind this one does the batch
+    const uint64_t n_fast = wave_uniform(P.qctl[0]), n_slow = wave_uniform(P.qctl[1]);
+    for (uint64_t q0 = wave * kTagPass; q0 < n_fast; q0 += n_waves * kTagPass) {
+        const uint32_t nq = uint32_t(n_fast - q0 < uint64_t(kTagPass) ? n_fast - q0 : uint64_t(kTagPass));
+        if (uint32_t(lane) < nq) {
+            const uint4 e = P.queue[q0 + lane];
+            L.f.tok[lane][0] = e.z; L.f.tok[lane][1] = e.x; L.f.tok[lane][2] = e.y; L.f.tok[lane][3] = e.w;
+        }
+        tag_pass(P, L, nq, lane, 0u);
+    }
+    for (uint64_t k = wave; k < n_slow; k += n_waves) {
+        const uint4 e = P.queue[P.queue_fast + k];
+        const uint64_t gk = uint64_t(wave_uniform(e.x)) | (uint64_t(wave_uniform(e.y)) << 32);
+        uint64_t lo = 0, hi = P.n_sent;   // the last sentence i with ooff[i] + i <= gk
+        while (hi - lo > 1) {
+            const uint64_t mid = (lo + hi) >> 1;
+            if (P.ooff[mid] + mid <= gk) lo = mid; else hi = mid;
+        }
+        const uint64_t g0 = P.ooff[lo] + lo;
+        tag_token_by_wave(P, P.cps + g0, int64_t(P.ooff[lo + 1] - P.ooff[lo]) + 1, int64_t(gk - g0), g0, wave_uniform(e.z), L.z, lane);
+    }
+}
+
+// kSplit: the front-end launch of the pair (the step loop and the lookups; tag_pass_kernel follows).  Without it: everything in one
+// launch -- small batches, and any batch whose queue overflowed (then the pair has left `overflow` set and this kernel, launched
+// behind it, runs; otherwise it returns at once).
+template <bool DBG, bool kSplit>
+__global__ __launch_bounds__(kTagThreads, kSplit ? kTagFrontOcc : VPT_TAG_OCC) void tag_tokens_kernel(const TagParams P, const uint32_t dbg_in) {
     const uint32_t dbg = DBG ? dbg_in : 0u;   // timing ablations (VPT_DEBUG_TAGS; results are wrong with any bit set)
-    __shared__ TagLds LDS;
+    if (!kSplit && P.qctl && wave_uniform(P.qctl[2]) == 0) return;   // the pair did the batch
+    __shared__ TagKernelLds<kSplit> LDS;
     const int lane = threadIdx.x & 63;
     const uint32_t wid = wave_uniform(threadIdx.x >> 6);     // a scalar, and everything derived from it below
-    TagWaveLds& L = LDS.w[wid];
+    TagFrontLds& L = LDS.fr[wid];
+    TagWaveLds* const Lp = LDS.pass(wid);
     const uint64_t wave = uint64_t(blockIdx.x) * kTagWaves + wid;
     const uint64_t n_waves = uint64_t(gridDim.x) * kTagWaves;
     const uint32_t nt = P.n_tags;
     const uint64_t below_me = (uint64_t(1) << lane) - 1;
     uint32_t nq = 0, nc = 0;   // queued tokens, waiting candidates (wave-uniform)
+    if constexpr (kSplit) {
+    // ---- the front-end launch: with 49 VGPRs there is room to hide its trips to memory (in the one-launch kernel the same loop spills
+    // 35 VGPRs and loses: profiles/r03_w_tag_variants.txt)
+    // A sentence starts with two dependent trips to memory (its offsets, then its first chars and labels) that nothing of the sentence
+    // can overlap with -- a wave takes 140 sentences of configs[4] in turn: the offsets are loaded TWO sentences ahead, the first
+    // step's chars and labels one sentence ahead.
+    auto sent_offsets = [&](uint64_t i, uint64_t* o0, uint64_t* o1) {
+        *o0 = 0; *o1 = 0;
+        if (i < P.n_sent) { *o0 = wave_uniform64(P.ooff[i]); *o1 = wave_uniform64(P.ooff[i + 1]); }
+    };
+    // chars of a sentence, or 0 when its offsets do not fit the batch (reported by decode_chars_kernel / the scoring kernel; such a
+    // sentence -- and one of 2^31 chars: not in this kernel's index width -- is taken as empty here)
+    auto sent_chars = [&](uint64_t i, uint64_t o0, uint64_t o1) {
+        const bool sane = i < P.n_sent && o1 >= o0 && o1 + i + 1 <= P.total_chars && o1 - o0 < 0x7FFFFF00ull;
+        return sane ? int(o1 - o0) + 1 : 0;
+    };
+    auto first_step = [&](uint64_t i, uint64_t o0, int n, uint32_t* c, uint32_t* b) {   // (two half-steps of 64 chars)
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int q = 64 * h + lane;
+            c[h] = q < n ? P.cps[o0 + i + uint64_t(q)] : 0u;
+            b[h] = q < n - 1 ? uint32_t(P.labels[o0 + uint64_t(q)]) : (q == n - 1 ? 1u : 0u);
+        }
+    };
+    uint64_t o0_a, o1_a, o0_b, o1_b;
+    sent_offsets(wave, &o0_a, &o1_a);
+    sent_offsets(wave + n_waves, &o0_b, &o1_b);
+    uint32_t c_first[2], b_first[2];
+    first_step(wave, o0_a, sent_chars(wave, o0_a, o1_a), c_first, b_first);
+    for (uint64_t si = wave; si < P.n_sent; si += n_waves) {
+        const uint64_t o0 = o0_a, o1 = o1_a;
+        const uint64_t g0 = o0 + si;                            // flat index of the sentence's first char
+        const int n = sent_chars(si, o0, o1);  // chars
+        const uint32_t* cps = P.cps + g0;
+        const uint8_t* lab = P.labels + o0;                      // n - 1 labels
+        int start = 0;              // where the token that is open at the beginning of this step started
+        bool have_start = true;     // ... and no Unknown boundary has been seen inside it (predictor.rs:566-567)
+        // the step's chars and labels are fetched one step ahead
+        uint32_t c_next[2] = {c_first[0], c_first[1]}, b_next[2] = {b_first[0], b_first[1]};
+        o0_a = o0_b; o1_a = o1_b;
+        first_step(si + n_waves, o0_a, sent_chars(si + n_waves, o0_a, o1_a), c_first, b_first);
+        sent_offsets(si + 2 * n_waves, &o0_b, &o1_b);
+        // A step = two half-steps of 64 chars: their chars, labels and filter words travel together, so a wave waits once per 128
+        // chars for each (round 2 asked for exactly this: "tokens of two 64-char steps per lookup").
+        for (int base = 0; base == 0 || base < n; base += 128) {
+            uint32_t c[2], b[2];
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                c[h] = c_next[h]; b[h] = b_next[h];
+                const int pn = base + 128 + 64 * h + lane;
+                c_next[h] = pn < n ? cps[pn] : 0u;
+                b_next[h] = pn < n - 1 ? uint32_t(lab[pn]) : (pn == n - 1 ? 1u : 0u);
+                L.txt[(base + 64 * h + lane) & (kRing - 1)] = c[h];
+            }
+            uint64_t ends[2], unk[2];
+#pragma unroll
+            for (int h = 0; h < 2; ++h) { ends[h] = __ballot(b[h] == 1u); unk[h] = __ballot(b[h] == 2u); }
+            __builtin_amdgcn_wave_barrier();
+            // ---- (1) this lane's tokens, if its chars end one: [s0, p], valid when no Unknown lies inside.  Could they have a tag model?
+            int s0[2];
+            bool valid[2];
+            uint32_t fbit[2], fword[2];
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int hb = base + 64 * h;
+                const uint64_t prev_ends = ends[h] & below_me;
+                const int prev = prev_ends ? 63 - __clzll((long long)prev_ends) : -1;
+                s0[h] = prev >= 0 ? hb + prev + 1 : start;
+                const uint64_t after_prev = prev >= 0 ? ~((uint64_t(2) << prev) - 1) : ~uint64_t(0);
+                valid[h] = b[h] == 1u && (unk[h] & below_me & after_prev) == 0 && (prev >= 0 || have_start) && !(dbg & 1u);
+                fbit[h] = valid[h] ? tag_filter_bit(P, cps, L.txt, base - 128, s0[h], hb + lane) : 0u;
+                // the token that stays open into the next half-step
+                if (ends[h]) {
+                    const int last = 63 - __clzll((long long)ends[h]);
+                    start = hb + last + 1;
+                    have_start = last == 63 || (unk[h] >> (last + 1)) == 0;
+                } else if (unk[h]) {
+                    have_start = false;
+                }
+            }
+#pragma unroll
+            for (int h = 0; h < 2; ++h) fword[h] = valid[h] ? P.tok_tab[(size_t(4) << P.tok_bits) + (fbit[h] >> 5)] : 0u;
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int p = base + 64 * h + lane;
+                const bool cand = valid[h] && ((fword[h] >> (fbit[h] & 31u)) & 1u) != 0;
+                // every char of the sentence gets its entries here or when its token has been looked up (nothing is cleared beforehand):
+                // 0 / None where no token with a tag model ends
+                if (p < n && !cand) {
+                    if (P.tok_model) P.tok_model[g0 + uint64_t(p)] = 0;
+                    if (P.model_out) P.model_out[g0 + uint64_t(p)] = -1;
+                    for (uint32_t j = 0; j < nt; ++j) P.tags[(g0 + uint64_t(p)) * nt + j] = -1;
+                }
+                // ---- (2) the candidates wait for the token table together: 64 of them are a lookup with every lane busy
+                const uint64_t cmask = __ballot(cand);
+                if (cmask != 0) {
+                    const uint32_t rank = uint32_t(__popcll(cmask & below_me));
+                    uint32_t remaining = uint32_t(__popcll(cmask)), done = 0;
+                    for (;;) {
+                        const uint32_t room = uint32_t(kTagCand) - nc, take = remaining < room ? remaining : room;
+                        if (cand && rank >= done && rank < done + take) {
+                            const uint32_t row = nc + rank - done;
+                            const uint64_t gp = g0 + uint64_t(p);
+                            const uint32_t back = p < kCtxBack ? uint32_t(p) : uint32_t(kCtxBack);
+                            const uint32_t fwd = n - 1 - p < kCtx - 1 - kCtxBack ? uint32_t(n - 1 - p) : uint32_t(kCtx - 1 - kCtxBack);
+                            L.cand[row][0] = uint32_t(gp); L.cand[row][1] = uint32_t(gp >> 32); L.cand[row][2] = uint32_t(p - s0[h] + 1); L.cand[row][3] = back | (fwd << 8);
+                        }
+                        nc += take; done += take; remaining -= take;
+                        if (nc != uint32_t(kTagCand)) break;
+                        tag_resolve<kSplit>(P, L, Lp, nc, nq, false, lane, dbg);
+                        nc = 0;
+                        if (!remaining) break;
+                    }
+                }
+            }
+            __builtin_amdgcn_wave_barrier();   // the ring is written by the next step
+        }
+    }
+    } else {
     for (uint64_t si = wave; si < P.n_sent; si += n_waves) {
         const uint64_t o0 = wave_uniform64(P.ooff[si]), o1 = wave_uniform64(P.ooff[si + 1]);
         const uint64_t g0 = o0 + si;                            // flat index of the sentence's first char
@@ -557,7 +775,7 @@ __global__ __launch_bounds__(kTagThreads, VPT_TAG_OCC) void tag_tokens_kernel(co
                     }
                     nc += take; done += take; remaining -= take;
                     if (nc != uint32_t(kTagCand)) break;
-                    tag_resolve(P, L, nc, nq, false, lane, dbg);
+                    tag_resolve<kSplit>(P, L, Lp, nc, nq, false, lane, dbg);
                     nc = 0;
                     if (!remaining) break;
                 }
@@ -573,8 +791,9 @@ __global__ __launch_bounds__(kTagThreads, VPT_TAG_OCC) void tag_tokens_kernel(co
             __builtin_amdgcn_wave_barrier();   // the ring is written by the next step
         }
     }
+    }
     // what still waits: the candidates, then the queue
-    if (nc != 0 || nq != 0) tag_resolve(P, L, nc, nq, true, lane, dbg);
+    if (nc != 0 || nq != 0) tag_resolve<kSplit>(P, L, Lp, nc, nq, true, lane, dbg);
 }
 
 }  // namespace
@@ -594,8 +813,18 @@ hipError_t launch_tag_tokens(const TagParams& P, hipStream_t stream) {
     const uint64_t want = (P.n_sent + kTagWaves - 1) / kTagWaves, cap = P.max_blocks ? P.max_blocks : 65536;
     const uint32_t blocks = uint32_t(want < 1 ? 1 : want > cap ? cap : want);
     static const uint32_t dbg = [] { const char* e = std::getenv("VPT_DEBUG_TAGS"); return e ? uint32_t(std::atoi(e)) : 0u; }();
-    if (dbg) hipLaunchKernelGGL(tag_tokens_kernel<true>, dim3(blocks), dim3(kTagThreads), 0, stream, P, dbg);
-    else hipLaunchKernelGGL(tag_tokens_kernel<false>, dim3(blocks), dim3(kTagThreads), 0, stream, P, 0u);
+    if (P.queue && !dbg) {   // the pair, then the one-launch kernel for the case that the queue overflowed (it returns at once otherwise)
+        const hipError_t e = hipMemsetAsync(P.qctl, 0, 3 * sizeof(uint32_t), stream);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL((tag_tokens_kernel<false, true>), dim3(blocks), dim3(kTagThreads), 0, stream, P, 0u);
+        hipLaunchKernelGGL(tag_pass_kernel, dim3(blocks), dim3(kTagThreads), 0, stream, P);
+        hipLaunchKernelGGL((tag_tokens_kernel<false, false>), dim3(blocks), dim3(kTagThreads), 0, stream, P, 0u);
+        return hipGetLastError();
+    }
+    TagParams Q = P;
+    Q.queue = nullptr; Q.qctl = nullptr;
+    if (dbg) hipLaunchKernelGGL((tag_tokens_kernel<true, false>), dim3(blocks), dim3(kTagThreads), 0, stream, Q, dbg);
+    else hipLaunchKernelGGL((tag_tokens_kernel<false, false>), dim3(blocks), dim3(kTagThreads), 0, stream, Q, 0u);
     return hipGetLastError();
 }
 
