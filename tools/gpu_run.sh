@@ -1,17 +1,8 @@
 #!/bin/bash
-O=gpurun_out/r03_zc; mkdir -p $O
+# HBM-side traffic of the scoring kernel on the final sources (read-request size classes + WRITE_SIZE, separate passes) -> profiles/traffic.json
+O=gpurun_out/r03_zt; mkdir -p $O
 export TMPDIR=/tmp
-( timeout 300 python -m pytest tests -m gpu -x -q -k "tag or write or tokenize" 2>&1 | tail -3 ) | tee $O/gpu_tests_tags.log
-emit() { python - "$1" <<'PY'
-import json, sys
-d=json.load(open(sys.argv[1]))
-t=d.get('tags') or {}
-print(sys.argv[1], 'step ms', d['ms_per_step'], 'kernel', d['roofline']['kernel_ms'], 'tags ms', t.get('ms_per_step'), 'parity', d.get('parity'), t.get('parity'))
-PY
-}
-timeout 900 python bench.py --config 4 --steps 10 --warmup 3 --no-e2e --quick --no-emit > $O/bench_c4_split.json 2> $O/bench_c4_split.err; emit $O/bench_c4_split.json
-cp vaporetto_amd/lib/libvaporetto_hip.so /tmp/lib_keep.so
-cp tools/prebuilt/libvaporetto_f8.so vaporetto_amd/lib/libvaporetto_hip.so
-timeout 900 python bench.py --config 4 --steps 10 --warmup 3 --no-e2e --quick --no-emit --no-cpu-baseline > $O/bench_c4_f8.json 2> $O/bench_c4_f8.err; emit $O/bench_c4_f8.json
-cp /tmp/lib_keep.so vaporetto_amd/lib/libvaporetto_hip.so
-VPT_TAG_SPLIT=1 VPT_FUZZ_SEED0=41000 timeout 100 python tools/fuzz_gpu.py 45 2>&1 | tail -2 | tee $O/fuzz_split.log
+G="TCC_EA0_RDREQ_128B_sum TCC_EA0_RDREQ_64B_sum TCC_EA0_RDREQ_32B_sum|WRITE_SIZE"
+VPT_PMC_GROUPS="$G" ./tools/profile.sh r03_zt_c1 --config 1 > $O/profile_c1.log 2>&1; grep "traffic entry" $O/profile_c1.log | cut -c1-330
+VPT_PMC_GROUPS="$G" ./tools/profile.sh r03_zt_c2 > $O/profile_c2.log 2>&1; grep "traffic entry" $O/profile_c2.log | cut -c1-330
+VPT_PMC_GROUPS="$G" ./tools/profile.sh r03_zt_c3 --config 3 > $O/profile_c3.log 2>&1; grep "traffic entry" $O/profile_c3.log | cut -c1-330
