@@ -1,6 +1,6 @@
 #!/bin/bash
-# scratch: the script of the latest gpurun call -- here a long fuzz over two fresh seed ranges on the round's final sources
-O=gpurun_out/r03_zy; mkdir -p $O
+# scratch: the script of the latest gpurun call -- rocprofv3 kernel trace of configs[4] (scoring, tags, tagged writer) on the final sources
+O=gpurun_out/r03_zx; mkdir -p $O
 export TMPDIR=/tmp
-VPT_FUZZ_SEED0=60000 timeout 230 python tools/fuzz_gpu.py 200 2>&1 | tail -2 | tee $O/fuzz.log
-VPT_TAG_SPLIT=1 VPT_TAG_QUEUE=8 VPT_FUZZ_SEED0=70000 timeout 100 python tools/fuzz_gpu.py 70 2>&1 | tail -2 | tee $O/fuzz_split_overflow.log
+cd /tmp && timeout 150 rocprofv3 --kernel-trace --stats --output-format csv -d $OLDPWD/$O/trace -- python $OLDPWD/bench.py --config 4 --steps 5 --warmup 2 --no-cpu-baseline --no-e2e --quick > $OLDPWD/$O/trace.log 2>&1; cd $OLDPWD
+cat $O/trace/*/*kernel_stats.csv | cut -c1-200 | head -16
