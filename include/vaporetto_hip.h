@@ -353,7 +353,8 @@ typedef struct vpt_model_info {
     uint64_t hot_table_bytes;      /* bytes of the tables the scoring kernel chosen for this model reads */
     uint32_t packed;               /* 1: the specialised kernel's packed tables (double-array trie, layout.h) are in use */
     uint32_t n_displaced;          /* hash-table keys that do not sit in their home slot */
-    uint32_t type_rows;            /* 1: type scores come from the 294 LDS type rows (else: window table / patterns) */
+    uint32_t type_rows;            /* type scores as rows added with a position's unigram row: 1 = the 294 rows in LDS (type n-grams of <= 3
+                                      symbols), 2 = rows in global memory (up to 6 symbols); 0: window table / pattern tables */
     uint32_t n_overflow_children;  /* 0 (kept for layout compatibility: the double-array tables have no overflow) */
     uint32_t predict_tags;         /* the predict_tags flag the predictor was created with (0 from vpt_model_inspect without it) */
 } vpt_model_info;

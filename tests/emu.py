@@ -18,16 +18,20 @@ _EMU_FILES = [os.path.join(EMU, "hipemu.cpp"), os.path.join(EMU, "hip", "hip_run
 
 
 def build_emulated() -> str:
+    import fcntl
     srcs = [os.path.join(build.CSRC, f) for f in build.SOURCES]
     deps = srcs + [os.path.join(build.CSRC, h) for h in build.HEADERS] + _EMU_FILES
-    if os.path.exists(LIB) and all(os.path.getmtime(d) <= os.path.getmtime(LIB) for d in deps):
-        return LIB
-    cmd = ["g++", "-O1", "-g", "-std=c++17", "-fPIC", "-shared", "-Wall", "-Wno-unused-function", "-Wno-unknown-pragmas",
-           "-Wl,-Bsymbolic",   # its hip* definitions bind locally even if a real HIP runtime is loaded in the process
-           "-I" + EMU, "-o", LIB] + _DEFINES
-    cmd += [s for s in srcs if s.endswith(".cpp")] + ["-x", "c++"] + [s for s in srcs if s.endswith(".hip")]
-    cmd += ["-x", "none", _EMU_FILES[0]]
-    subprocess.check_call(cmd)
+    with open(LIB + ".lock", "w") as lock:   # pytest-xdist workers: one of them builds, the others wait for it
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        if os.path.exists(LIB) and all(os.path.getmtime(d) <= os.path.getmtime(LIB) for d in deps):
+            return LIB
+        cmd = ["g++", "-O1", "-g", "-std=c++17", "-fPIC", "-shared", "-Wall", "-Wno-unused-function", "-Wno-unknown-pragmas",
+               "-Wl,-Bsymbolic",   # its hip* definitions bind locally even if a real HIP runtime is loaded in the process
+               "-I" + EMU, "-o", LIB + ".tmp"] + _DEFINES
+        cmd += [s for s in srcs if s.endswith(".cpp")] + ["-x", "c++"] + [s for s in srcs if s.endswith(".hip")]
+        cmd += ["-x", "none", _EMU_FILES[0]]
+        subprocess.check_call(cmd)
+        os.replace(LIB + ".tmp", LIB)
     return LIB
 
 

@@ -71,10 +71,11 @@ int tc_create_tags(const uint8_t* bytes, size_t len, int predict_tags, tc_model*
 void tc_destroy(tc_model* t) { delete t; }
 uint32_t tc_fullwidth(uint32_t c) { return kytea_fullwidth_host(c); }
 int tc_packed_present(const tc_model* t) { return t->c.packed.present ? 1 : 0; }
-int tc_trow_present(const tc_model* t) { return t->c.packed.present && !t->c.packed.trow.empty() ? 1 : 0; }
+int tc_trow_present(const tc_model* t) { return t->c.packed.present ? int(t->c.packed.trow_mode) : 0; }
+int tc_row_window(const tc_model* t) { return t->c.packed.present ? t->c.packed.wl : 0; }
 void tc_stats(const tc_model* t, uint32_t out[8]) {
     const HostPackedTable& k = t->c.packed;
-    out[0] = k.n_bi; out[1] = k.n_tri; out[2] = uint32_t(k.bi.size() / 8); out[3] = k.n_deep; out[4] = uint32_t(k.tri.size() / 4);
+    out[0] = k.n_bi; out[1] = k.n_tri; out[2] = uint32_t(k.bi.size() / size_t(pk_bi_dw(k.wl))); out[3] = k.n_deep; out[4] = uint32_t(k.tri.size() / size_t(pk_tri_dw(k.wl)));
     out[5] = k.bi_shift; out[6] = k.n_wide; out[7] = k.n_alpha;
 }
 
@@ -101,54 +102,67 @@ int tc_score(const tc_model* t, const uint32_t* cps, size_t n, int32_t* y_out, u
     const HostPackedTable& K = t->c.packed;
     const HostPatternTable& G = t->c.chars;
     if (!K.present) return -1;
+    const int wl = K.wl;
+    const size_t udw = size_t(pk_uni_dw(wl)), bdw = size_t(pk_bi_dw(wl)), tdw = size_t(pk_tri_dw(wl));
+    const int nu = pk_uni_fields(wl), nb = pk_bi_fields(wl), nt = pk_tri_fields(wl);
     std::vector<int32_t> y(n > 0 ? n - 1 : 0, t->c.bias);
-    std::vector<uint32_t> sym(n + 3, 0), typ(n + 3, 0);
+    std::vector<uint32_t> sym(n + 8, 0), typ(n + 8, 0);
     for (size_t i = 0; i < n; ++i) {
         sym[i] = cps[i] < 0x10000u ? K.id_of[cps[i]] : kNoId;
         typ[i] = char_type_host(cps[i]);
     }
-    const uint32_t uni_last = uint32_t(K.uni.size() / 4) - 1, n_tri = uint32_t(K.tri.size() / 4);
+    const uint32_t uni_last = uint32_t(K.uni.size() / udw) - 1, n_tri = uint32_t(K.tri.size() / tdw);
     auto cp_of = [&](uint32_t id) { return K.cpid[id < uni_last ? id : uni_last]; };
     for (size_t s = 0; s < n; ++s) {
         const uint32_t c1 = sym[s], c2 = sym[s + 1], c3 = sym[s + 2];
         const long S = long(s);
-        if (!K.trow.empty()) {
-            const uint32_t* r = &K.trow[size_t(type_row_index(typ[s], typ[s + 1], typ[s + 2])) * 4];
-            for (int j = 0; j < 6; ++j) add(y, S - 3 + j, trow_field(r[0], r[1], r[2], r[3], j));
+        if (K.trow_mode == kTypeRowsLds) {
+            const uint32_t* r = &K.trow[size_t(type_row_index(typ[s], typ[s + 1], typ[s + 2])) * size_t(pk_trow_dw(wl))];
+            for (int j = 0; j < nu; ++j) add(y, S - wl + j, bits_signed(r, kUniFieldBits * j, kUniFieldBits));
+        } else if (K.trow_mode == kTypeRowsGlobal) {
+            uint32_t idx = 0;
+            for (int i = int(K.trow_levels) - 1; i >= 1; --i) idx = idx * 7u + typ[s + size_t(i)];
+            idx = idx * 6u + (typ[s] - 1u);
+            const uint32_t* r = &K.trow[size_t(idx) * size_t(pk_trow_global_dw(wl))];
+            for (int j = 0; j < nu; ++j) add(y, S - wl + j, int32_t(r[j]));
         }
-        const uint32_t* u = &K.uni[size_t(c1 < uni_last ? c1 : uni_last) * 4];
-        for (int j = 0; j < 6; ++j) add(y, S - 3 + j, row_field(u[0], u[1], u[2], u[3], j, kUniFieldBits));
-        if (u[3] & kUniWideBit) {
+        const uint32_t* u = &K.uni[size_t(c1 < uni_last ? c1 : uni_last) * udw];
+        for (int j = 0; j < nu; ++j) add(y, S - wl + j, bits_signed(u, kUniFieldBits * j, kUniFieldBits));
+        if (bits_unsigned(u, pk_uni_base_bit(wl) + kUniBaseBits, 1)) {
             const uint32_t* g = &G.uni[size_t(cp_of(c1)) * G.uni_dw];
-            for (int j = 0; j < 6; ++j) add(y, S - 3 + j, int32_t(g[j]));
+            for (int j = 0; j < G.len[0]; ++j) add(y, S + G.lo[0] + j, int32_t(g[j]));
         }
         if (c2 == 0 || c1 == kNoId || c2 == kNoId) continue;   // (the kernel issues no load for a char outside the alphabet)
-        const uint32_t slot = c2 < kBiDenseCols ? c1 * kBiDenseCols + c2 : (((u[3] >> kUniBaseShift) & kUniBaseMask) << K.bi_shift) + c2;
-        if (size_t(slot) * 8 + 8 > K.bi.size()) return -3;   // the table must cover any id behind any base
-        const uint32_t* r = &K.bi[size_t(slot) * 8];
+        const uint32_t slot = (bits_unsigned(u, pk_uni_base_bit(wl), kUniBaseBits) << K.bi_shift) + c2;
+        if (size_t(slot) * bdw + bdw > K.bi.size()) return -3;   // the table must cover any id behind any base
+        const uint32_t* r = &K.bi[size_t(slot) * bdw];
         ++probes[0];
-        if (r[0] != (c1 | (c2 << 16))) continue;
-        if (r[3] & kBiWideBit) {
+        if (r[pk_bi_key_dw(wl)] != (c1 | (c2 << 16))) continue;
+        const uint32_t* rrow = r + pk_bi_row_dw(wl);
+        if (bits_unsigned(rrow, pk_bi_wide_bit(wl), 1)) {
             const uint32_t* g = general_find(G, short_key(cp_of(c1), cp_of(c2), 0));
             if (!g) return -2;
-            for (int j = 0; j < 5; ++j) add(y, S - 2 + j, int32_t(g[2 + j]));
+            for (int j = 0; j < G.len[1]; ++j) add(y, S + G.lo[1] + j, int32_t(g[2 + j]));
         } else {
-            for (int j = 0; j < 5; ++j) add(y, S - 2 + j, row_field(r[1], r[2], r[3] & ~kBiWideBit, 0, j, kBiFieldBits));
+            for (int j = 0; j < nb; ++j) add(y, S - wl + 1 + j, bits_signed(rrow, kBiFieldBits * j, kBiFieldBits));
         }
         if (c3 == 0) continue;
-        const uint64_t mask = uint64_t(r[5]) | (uint64_t(r[6]) << 32);
+        const uint64_t mask = uint64_t(r[pk_bi_filter_dw(wl)]) | (uint64_t(r[pk_bi_filter_dw(wl) + 1]) << 32);
         if (!((mask >> packed_filter_bit(c3)) & 1)) { ++probes[3]; continue; }
-        const uint32_t ts = r[4] + c3;   // modulo 2^32
+        const uint32_t ts = r[pk_bi_base_dw(wl)] + c3;   // modulo 2^32
         if (ts >= n_tri) continue;
-        const uint32_t* ch = &K.tri[size_t(ts) * 4];
+        const uint32_t* ch = &K.tri[size_t(ts) * tdw];
         ++probes[1];
         if ((ch[0] & kTriParentMask) != slot + 1) continue;
         if (ch[0] & (kPkWide << kTriFlagShift)) {
             const uint32_t* g = general_find(G, short_key(cp_of(c1), cp_of(c2), cp_of(c3)));
             if (!g) return -2;
-            for (int j = 0; j < 4; ++j) add(y, S - 1 + j, int32_t(g[2 + j]));
-        } else { add(y, S - 1, lo16(ch[1])); add(y, S, hi16(ch[1])); add(y, S + 1, lo16(ch[2])); add(y, S + 2, hi16(ch[2])); }
-        uint32_t ref = ch[3], depth = 3;
+            for (int j = 0; j < G.len[2]; ++j) add(y, S + G.lo[2] + j, int32_t(g[2 + j]));
+        } else {
+            const uint32_t* w = ch + pk_tri_w_dw(wl);
+            for (int j = 0; j < nt; ++j) add(y, S - wl + 2 + j, (j & 1) ? hi16(w[j >> 1]) : lo16(w[j >> 1]));
+        }
+        uint32_t ref = ch[pk_tri_kids_dw(wl)], depth = 3;
         while (ref != 0) {
             const size_t at = s + depth;
             const uint32_t c = sym[at < n ? at : n];
@@ -164,17 +178,19 @@ int tc_score(const tc_model* t, const uint32_t* cps, size_t n, int32_t* y_out, u
             }
             if (!ok) break;
             const uint32_t m = depth + 1 + nskip;
+            const long lo = row_lo(int(m), wl);
+            const uint32_t rlen = uint32_t(row_len(int(m), wl));
             if (e[0] & (kPkHasRow << 16)) {
-                for (uint32_t j = 0; j <= m; ++j) add(y, S - 1 + long(j), (j & 1) ? hi16(e[8 + (j >> 1)]) : lo16(e[8 + (j >> 1)]));
+                for (uint32_t j = 0; j < rlen; ++j) add(y, S + lo + long(j), (j & 1) ? hi16(e[8 + (j >> 1)]) : lo16(e[8 + (j >> 1)]));
             } else if (e[0] & (kPkExtRow << 16)) {
-                for (uint32_t j = 0; j <= m; ++j) add(y, S - 1 + long(j), K.xrows[size_t(e[8]) + j]);
+                for (uint32_t j = 0; j < rlen; ++j) add(y, S + lo + long(j), K.xrows[size_t(e[8]) + j]);
             }
             ref = e[1];
             depth = m;
         }
     }
     std::memcpy(y_out, y.data(), y.size() * sizeof(int32_t));
-    return K.trow.empty() ? 1 : 2;
+    return K.trow_mode == kTypeRowsNone ? 1 : 2;
 }
 
 }  // extern "C"

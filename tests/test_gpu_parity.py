@@ -105,26 +105,30 @@ def test_random_models_vs_oracle(seed):
     check_batch(pred, orc, texts)
 
 
-@pytest.mark.parametrize("wc,wt", [(1, 1), (2, 2), (3, 3), (4, 4), (1, 4), (4, 1), (5, 2), (8, 8), (3, 0), (0, 3)])
+@pytest.mark.parametrize("wc,wt", [(1, 1), (2, 2), (3, 3), (4, 4), (1, 4), (4, 1), (5, 2), (8, 8), (3, 0), (0, 3), (6, 3), (7, 7), (3, 5), (5, 5), (8, 1), (2, 8)])
 def test_window_sizes(wc, wt):
     m = randmodel.rand_model(100 + wc * 10 + wt, alphabet="tiny", wc=wc, wt=wt, max_n=4, n_char=40, n_type=30)
     pred, orc = make_predictor(m)
     info = pred.info()
     assert info["char_window"] == wc
-    # char windows 1 and 2 are laid out in the rows of window 3 (train/src/main.rs:33-51 lets --charw be anything) and run on the
-    # packed tables / the specialised kernel like the distributed models; wider ones take the general tables
-    assert info["packed"] == (1 if 1 <= wc <= 3 else 0)
+    # every window up to 8 (train/src/main.rs:33-51 lets --charw / --typew be anything) runs on the packed tables and the specialised
+    # kernel: windows 1 .. 3 in the rows of window 3, like the distributed models, wider ones in rows of their own; the type n-grams
+    # (up to 4 symbols here) as type rows -- in LDS when none is longer than 3, in global memory otherwise
+    assert info["packed"] == (1 if wc >= 1 else 0)
+    if wc >= 1 and wt >= 1 and m.type_ngram_model:
+        assert info["type_rows"] == (1 if max(len(d.ngram) for d in m.type_ngram_model) <= 3 else 2)
     texts = randmodel.rand_sentences(wc * 10 + wt, m, 200, alphabet="tiny", max_len=30)
     texts += randmodel.rand_sentences(wc * 10 + wt + 1, m, 6, alphabet="tiny", min_len=1500, max_len=4000)
     check_batch(pred, orc, texts)
-    if 1 <= wc <= 3 and wt <= 3:
-        batch = api.DeviceBatch(pred)
-        utf8, boff = api.pack_texts([t.encode("utf-8") for t in texts[:50]])
-        ooff = api.count_boundaries(utf8, boff)
-        d = [devmem.put(np.concatenate([utf8, np.zeros(32, np.uint8)])), devmem.put(boff), devmem.put(ooff), devmem.zeros(int(ooff[-1]) + 1, np.int32), devmem.zeros(int(ooff[-1]) + 1, np.uint8)]
-        batch.predict(d[0].ptr, d[1].ptr, d[2].ptr, 50, int(ooff[-1]), int(np.max(np.diff(boff.astype(np.int64)))), d[3].ptr, d[4].ptr, devmem.stream())
-        batch.sync()
-        assert batch.last_plan()["kind"] == "whole-sentence tiles"      # i.e. the specialised kernel
+    if wc >= 1:
+        for n_first, want in ((50, "whole-sentence tiles"), (len(texts), "cut tiles")):   # i.e. the specialised kernel, both kinds of tile
+            batch = api.DeviceBatch(pred)
+            utf8, boff = api.pack_texts([t.encode("utf-8") for t in texts[:n_first]])
+            ooff = api.count_boundaries(utf8, boff)
+            d = [devmem.put(np.concatenate([utf8, np.zeros(32, np.uint8)])), devmem.put(boff), devmem.put(ooff), devmem.zeros(int(ooff[-1]) + 1, np.int32), devmem.zeros(int(ooff[-1]) + 1, np.uint8)]
+            batch.predict(d[0].ptr, d[1].ptr, d[2].ptr, n_first, int(ooff[-1]), int(np.max(np.diff(boff.astype(np.int64)))), d[3].ptr, d[4].ptr, devmem.stream())
+            batch.sync()
+            assert batch.last_plan()["kind"] == want
 
 
 @pytest.mark.parametrize("seed", range(6))
@@ -491,14 +495,20 @@ def test_type_weights_no_window_reads_and_padding_ngrams(wt, predict_tags, monke
             monkeypatch.delenv("VPT_FORCE_WINDOW_TABLE")
 
 
-def test_long_type_ngrams_use_the_window_table():
+def test_long_type_ngrams_use_global_type_rows(monkeypatch):
+    """Type n-grams of 4 .. 6 symbols: type rows in global memory (layout.h, "TYPE ROWS"); with the window table forced, that table."""
     m = randmodel.rand_model(77, alphabet="kana", wc=3, wt=3, n_char=80, n_dict=80, n_type=40, max_word=6)
     m.type_ngram_model.append(NgramData(bytes([3, 3, 3, 3]), [5, -6, 7]))
     m.type_ngram_model.append(NgramData(bytes([3, 5, 3, 3, 6]), [11, -12]))
-    pred, orc = make_predictor(m)
-    assert pred.info()["type_rows"] == 0 and pred.info()["packed"] == 1
+    m.type_ngram_model.append(NgramData(bytes([3, 3, 5, 3, 3, 6]), [-70000]))
     mixed = randmodel.ALPHABETS["mixed"] + randmodel.ALPHABETS["kana"][:8]
-    check_batch(pred, orc, randmodel.rand_sentences(2, m, 1500, alphabet=mixed, max_len=60))
+    texts = randmodel.rand_sentences(2, m, 1500, alphabet=mixed, max_len=60)
+    pred, orc = make_predictor(m)
+    assert pred.info()["type_rows"] == 2 and pred.info()["packed"] == 1
+    check_batch(pred, orc, texts)
+    monkeypatch.setenv("VPT_FORCE_WINDOW_TABLE", "1")
+    pred, orc = make_predictor(m)
+    check_batch(pred, orc, texts)
 
 
 def test_very_long_words_and_compressed_chains():

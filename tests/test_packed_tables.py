@@ -21,8 +21,12 @@ DEPS = SRCS + [os.path.join(CSRC, h) for h in ("layout.h", "tables.hpp", "model.
 
 @pytest.fixture(scope="module")
 def tc():
-    if not os.path.exists(LIB) or any(os.path.getmtime(s) > os.path.getmtime(LIB) for s in DEPS):
-        subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-pthread", "-o", LIB] + SRCS)
+    import fcntl
+    with open(LIB + ".lock", "w") as lock:   # pytest-xdist workers build it once, not at the same time
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        if not os.path.exists(LIB) or any(os.path.getmtime(s) > os.path.getmtime(LIB) for s in DEPS):
+            subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-pthread", "-o", LIB + ".tmp"] + SRCS)
+            os.replace(LIB + ".tmp", LIB)
     L = C.CDLL(LIB)
     L.tc_create.argtypes = [C.c_char_p, C.c_size_t, C.POINTER(C.c_void_p)]
     L.tc_create_tags.argtypes = [C.c_char_p, C.c_size_t, C.c_int, C.POINTER(C.c_void_p)]
@@ -30,6 +34,7 @@ def tc():
     L.tc_packed_present.argtypes = [C.c_void_p]
     L.tc_stats.argtypes = [C.c_void_p, C.POINTER(C.c_uint32 * 8)]
     L.tc_trow_present.argtypes = [C.c_void_p]
+    L.tc_row_window.argtypes = [C.c_void_p]
     L.tc_score.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.POINTER(C.c_uint64 * 4)]
     return L
 
@@ -54,7 +59,12 @@ class Walker:
 
     @property
     def trow(self):
-        return bool(self.L.tc_trow_present(self.h))
+        """0 = no type rows, 1 = LDS rows (n-grams of <= 3 symbols, 18-bit totals), 2 = global rows (up to 6 symbols, i32)"""
+        return int(self.L.tc_trow_present(self.h))
+
+    @property
+    def row_window(self):
+        return int(self.L.tc_row_window(self.h))
 
     def score(self, text, probes=None, want=None):
         """Scores from the packed tables; `want` = 1 (types not included) or 2 (type rows included)."""
@@ -139,10 +149,11 @@ def test_packed_not_eligible_models_fall_back(tc):
     m = ModelData(**base)
     m.dict_model.append(WordWeightRecord("a￿", [1, 2, 3], ""))
     assert not Walker(tc, encode_model(m)).packed
-    # a char window above 3 (windows 1 and 2 are laid out in the rows of window 3 and ARE eligible)
+    # every char window up to 8 is eligible: 1 and 2 are laid out in the rows of window 3, wider ones have rows of their own
     m = ModelData(bias=3, char_window_size=4, type_window_size=3)
     m.char_ngram_model.append(NgramData("あ", [1, 2, 3, 4, 5, 6, 7, 8]))
-    assert not Walker(tc, encode_model(m)).packed
+    wk = Walker(tc, encode_model(m))
+    assert wk.packed and wk.row_window == 4
     for wc, w in ((2, [1, 2, 3, 4]), (1, [5, 6])):
         m = ModelData(bias=3, char_window_size=wc, type_window_size=3)
         m.char_ngram_model.append(NgramData("あ", w))
@@ -206,27 +217,88 @@ def test_type_rows_match_oracle(tc, seed):
     m.dict_model = [d for d in m.dict_model if all(ord(c) < 0xFFFF for c in d.word)]
     raw = encode_model(m)
     w = Walker(tc, raw)
-    assert w.packed and w.trow
+    assert w.packed and w.trow == 1
     orc = cbind.OraclePredictor(raw)
     for t in randmodel.rand_sentences(seed, m, 300, alphabet="mixed", max_len=50):
         assert w.score(t, want=2) == orc.predict(t)[0], t
 
 
-def test_type_rows_absent_for_long_or_large_type_ngrams(tc):
+def test_type_rows_homes_for_long_or_large_type_ngrams(tc):
     base = dict(bias=1, char_window_size=3, type_window_size=3)
+    texts = ["あ", "ああカあ", "あああカあああ漢あ", "カあああ", "AあああカZ"]
+
+    def check(m, want_mode):
+        raw = encode_model(m)
+        w = Walker(tc, raw)
+        assert w.trow == want_mode
+        if want_mode:
+            orc = cbind.OraclePredictor(raw)
+            for t in texts:
+                assert w.score(t, want=2) == orc.predict(t)[0], t
     m = ModelData(**base)
     m.char_ngram_model.append(NgramData("あ", [1, 2, 3, 4, 5, 6]))
-    m.type_ngram_model.append(NgramData(bytes([3, 3, 5, 3]), [1, 2, 3]))          # 4 symbols
-    assert not Walker(tc, encode_model(m)).trow
+    m.type_ngram_model.append(NgramData(bytes([3, 3, 4, 3]), [1, 2, 3]))          # 4 symbols: global rows
+    check(m, 2)
     m = ModelData(**base)
     m.char_ngram_model.append(NgramData("あ", [1, 2, 3, 4, 5, 6]))
     m.type_ngram_model.append(NgramData(bytes([3]), [0, 0, 100000]))
-    m.type_ngram_model.append(NgramData(bytes([3, 3]), [0, 100000]))               # merged 200000 > 18 bits
-    assert not Walker(tc, encode_model(m)).trow
+    m.type_ngram_model.append(NgramData(bytes([3, 3]), [0, 100000]))               # merged 200000 > 18 bits: global rows (i32)
+    check(m, 2)
     m = ModelData(**base)
     m.char_ngram_model.append(NgramData("あ", [1, 2, 3, 4, 5, 6]))
-    m.type_ngram_model.append(NgramData(bytes([3, 5]), [1, 2, 3, 4, 5]))
-    assert Walker(tc, encode_model(m)).trow
+    m.type_ngram_model.append(NgramData(bytes([3, 4]), [1, 2, 3, 4, 5]))
+    check(m, 1)
+    m = ModelData(**base)
+    m.char_ngram_model.append(NgramData("あ", [1, 2, 3, 4, 5, 6]))
+    m.type_ngram_model.append(NgramData(bytes([3, 3, 4, 3, 3, 3]), [7]))           # 6 symbols = 2 W: still rows
+    m.type_ngram_model.append(NgramData(bytes([3, 3, 4]), [1, 2, 3, 4]))
+    check(m, 2)
+    m = ModelData(**base)
+    m.char_ngram_model.append(NgramData("あ", [1, 2, 3, 4, 5, 6]))
+    m.type_ngram_model.append(NgramData(bytes([3, 0]), [1, 2, 3, 4, 5]))           # code 0: only the window table can say "outside"
+    check(m, 0)
+    m = ModelData(bias=1, char_window_size=3, type_window_size=4)
+    m.char_ngram_model.append(NgramData("あ", [1, 2, 3, 4, 5, 6]))
+    m.type_ngram_model.append(NgramData(bytes([3, 3, 4, 3, 3, 3, 3]), [7, 8]))     # 7 symbols: no rows, the general tables score it
+    check(m, 0)
+
+
+@pytest.mark.parametrize("wc,wt", [(4, 4), (5, 3), (3, 5), (6, 6), (7, 2), (8, 8), (2, 7), (4, 1), (1, 4)])
+def test_packed_walk_other_windows(tc, wc, wt):
+    """Row windows 4 .. 8 (layout.h, "ROW WINDOW"): wider nodes, the same protocol; type n-grams of up to 4 symbols; the walker
+    reproduces the FULL score."""
+    for seed in range(3):
+        alphabet = ["kana", "tiny", [chr(c) for c in range(0x3041, 0x3049)] + list("漢字AZ09")][seed % 3]
+        m = randmodel.rand_model(7000 + 100 * wc + 10 * wt + seed, alphabet=alphabet, wc=wc, wt=wt, max_n=4, n_char=300, n_dict=300, n_type=60, max_word=16)
+        raw = encode_model(m)
+        w = Walker(tc, raw)
+        assert w.packed and w.row_window == max(3, wc, wt) and w.trow in (1, 2)
+        orc = cbind.OraclePredictor(raw)
+        probes = [0, 0, 0, 0]
+        for t in randmodel.rand_sentences(seed, m, 200, alphabet="mixed" if seed == 2 else alphabet, max_len=60):
+            assert w.score(t, probes, want=2) == orc.predict(t)[0], t
+        assert probes[0] > 0 and probes[1] > 0 and probes[2] > 0
+
+
+def test_packed_wide_rows_other_windows(tc):
+    """Values outside the fields of the wider nodes, and rows past the 14 inline weights of a deep entry."""
+    for wc in (4, 6, 8):
+        m = ModelData(bias=-7, char_window_size=wc, type_window_size=2)
+        m.char_ngram_model.append(NgramData("あ", [0, 0, 40000, -5, 1, 2] + [9] * (2 * wc - 6)))
+        m.char_ngram_model.append(NgramData("う", [-131073, 0, 131072, -5, 1, 2] + [-3] * (2 * wc - 6)))          # outside 18 bits
+        m.char_ngram_model.append(NgramData("いう", [5, 262144, -262145, 1, 2] + [4] * (2 * wc - 6)))            # outside 19 bits
+        m.char_ngram_model.append(NgramData("いうえ", [32767, 32767, 3, 4] + [-32768] * (2 * wc - 6)))
+        m.dict_model.append(WordWeightRecord("いうえ", [1, 32767, 5, 32767], ""))                               # sums past i16
+        m.char_ngram_model.append(NgramData("いうえお", [11] * (2 * wc - 3)))
+        m.dict_model.append(WordWeightRecord("あいうえおか", [100000, -100000, 3, 4, 5, 6, 2000000000], ""))
+        m.dict_model.append(WordWeightRecord("あいうえおかきくけこさしすせ", list(range(1, 16)), ""))               # 15 weights: external row
+        m.type_ngram_model.append(NgramData(bytes([3, 3]), [1, 2, 3]))
+        raw = encode_model(m)
+        w = Walker(tc, raw)
+        assert w.packed and w.row_window == wc and w.stats()["n_wide"] >= 3
+        orc = cbind.OraclePredictor(raw)
+        for t in ["あいうえおかきくけこさしすせそ", "ああいいうえお", "いうえ", "あ", "んあいうえおかん", "えおかきあいうえおかきくけこあい", "いうえおいうえお"]:
+            assert w.score(t, want=2) == orc.predict(t)[0], (wc, t)
 
 
 def test_long_words_compressed_chains(tc):
@@ -267,7 +339,7 @@ def test_tag_enabled_models_merge_duplicate_type_ngrams(tc):
     m.type_ngram_model.append(NgramData(bytes([3]), [-1, -2, -3, -4, -5, -6]))
     raw = encode_model(m)
     w = Walker(tc, raw, predict_tags=True)
-    assert w.packed and w.trow
+    assert w.packed and w.trow == 1
     orc = cbind.OraclePredictor(raw, True)
     mixed = randmodel.ALPHABETS["kana"][:10] + list("漢字AZ09、")
     for t in randmodel.rand_sentences(4, m, 300, alphabet=mixed, max_len=40):
@@ -291,7 +363,7 @@ def test_packed_walk_on_scaled_synthetic_models(tc, kind):
     from vaporetto_amd import synth
     raw = synth.synth_model(kind, synth.SEED_BASE + kind, 0.05)
     w = Walker(tc, raw)
-    assert w.packed and w.trow
+    assert w.packed and w.trow == 1
     st = w.stats()
     assert st["n_bi"] > 0 and st["n_tri"] > 0 and st["n_deep"] > 0
     utf8, boff = synth.synth_sentences(raw, 400, 8, 96, seed=synth.SEED_BASE + 11 * kind)

@@ -1,6 +1,7 @@
 #!/bin/bash
-# scratch: the script of the latest gpurun call -- rocprofv3 kernel trace of configs[4] (scoring, tags, tagged writer) on the final sources
-O=gpurun_out/r03_zx; mkdir -p $O
+# Runs one recipe of tools/recipes/ on the GPU box:  gpurun --timeout N -- './tools/gpu_run.sh <recipe> [args]'
+# A recipe is a committed, named script (one per measurement, never rewritten): what produced a file under profiles/ can be read there.
+set -u
+R=${1:?usage: tools/gpu_run.sh <recipe> [args]}; shift
 export TMPDIR=/tmp
-cd /tmp && timeout 150 rocprofv3 --kernel-trace --stats --output-format csv -d $OLDPWD/$O/trace -- python $OLDPWD/bench.py --config 4 --steps 5 --warmup 2 --no-cpu-baseline --no-e2e --quick > $OLDPWD/$O/trace.log 2>&1; cd $OLDPWD
-cat $O/trace/*/*kernel_stats.csv | cut -c1-200 | head -16
+exec bash "$(dirname "$0")/recipes/$R.sh" "$@"

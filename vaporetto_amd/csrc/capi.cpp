@@ -92,7 +92,7 @@ constexpr size_t kTablePadBytes = 256;  // probes read whole 16-byte chunks; kee
 enum Section : int {
     kSecCShort, kSecCUni, kSecCEdges, kSecCWdata,              // general char tables
     kSecTShort, kSecTUni, kSecTEdges, kSecTWdata,              // general type tables (type_kind == pattern tables)
-    kSecPUni, kSecPBi, kSecPTri, kSecPDeep, kSecPXrows, kSecPTrow, kSecPCpid, kSecPCc, kSecPUtag, kSecPUrow,   // packed tables: contiguous, addressed from kSecPUni
+    kSecPUni, kSecPBi, kSecPTri, kSecPDeep, kSecPXrows, kSecPTrow, kSecPCpid,   // packed tables: contiguous, addressed from kSecPUni
     kSecTypeTable, kSecCtype, kSecCinfo, kSecCid,
     kSecTagTokTab, kSecTagModels, kSecTagMfilt, kSecTagNgrams, kSecTagNrec, kSecTagSyms, kSecTagSlots, kSecTagWeights, kSecTagSlotStr, kSecTagStrOff, kSecTagStrBytes,
     kSectionCount
@@ -102,7 +102,7 @@ struct TableGeom {
     int32_t window, lo[3], len[3];
 };
 constexpr char kCompiledMagic[16] = "VaporettoHIP-C\x01";   // 15 chars + NUL
-constexpr uint32_t kCompiledVersion = 9;                    // bump whenever layout.h or a kernel's reading of it changes
+constexpr uint32_t kCompiledVersion = 10;                    // bump whenever layout.h or a kernel's reading of it changes
 struct PredictorMeta {                                      // plain data: written and read as is (little-endian hosts)
     char magic[16];
     uint32_t version, meta_bytes;
@@ -112,7 +112,7 @@ struct PredictorMeta {                                      // plain data: writt
     int32_t bias, pad, type_kind, type_window, chunks;
     uint32_t predict_tags, has_tags, n_tags, tok_bits, max_tag_suffix, tag_use_char, tag_use_type, n_tag_models, n_tag_strings, max_tag_scores;
     TableGeom geom[2];                                      // chars, types
-    uint32_t pk_present, pk_n_uni, pk_n_tri, pk_bi_shift, pk_has_trow;
+    uint32_t pk_present, pk_n_uni, pk_n_tri, pk_bi_shift, pk_wl, pk_trow_mode, pk_trow_levels;
     vpt_model_info info;
 };
 
@@ -158,11 +158,15 @@ const char* validate_meta(const PredictorMeta& m) {
     }
     if (m.type_kind == vpt::kTypePatternTable && !m.geom[1].present) return "type pattern tables";
     if (m.pk_present) {
-        if (m.pk_n_uni < 2 || sz(kSecPUni) < 16ull * m.pk_n_uni || sz(kSecPCpid) < 4ull * m.pk_n_uni || sz(kSecPTri) < 16ull * m.pk_n_tri) return "packed tables";
-        if (m.pk_bi_shift > 16 || sz(kSecPBi) < 32 || sz(kSecPDeep) < 64) return "packed tables (bigram level)";
-        if (m.pk_has_trow ? sz(kSecPTrow) < 16ull * vpt::kTypeRowCount : false) return "type rows";
-        if (m.sec_off[kSecPUrow] + sz(kSecPUrow) - m.sec_off[kSecPUni] >= (1ull << 32)) return "packed tables (32-bit offsets)";
-        if (sz(kSecPCc) < 8ull * std::max(vpt::kFastCharCache, 4) || sz(kSecPUtag) < 2ull * std::max(vpt::kFastUniCache, 8) || sz(kSecPUrow) < 16ull * std::max(vpt::kFastUniCache, 1)) return "packed tables (caches)";
+        if (m.pk_wl < 3 || m.pk_wl > uint32_t(vpt::kMaxWindow)) return "packed tables (row window)";
+        const int wl = int(m.pk_wl);
+        if (m.pk_n_uni < 2 || sz(kSecPUni) < 4ull * vpt::pk_uni_dw(wl) * m.pk_n_uni || sz(kSecPCpid) < 4ull * m.pk_n_uni || sz(kSecPTri) < 4ull * vpt::pk_tri_dw(wl) * m.pk_n_tri) return "packed tables";
+        if (m.pk_bi_shift > 16 || sz(kSecPBi) < 4ull * vpt::pk_bi_dw(wl) || sz(kSecPDeep) < 64) return "packed tables (bigram level)";
+        if (m.pk_trow_mode > vpt::kTypeRowsGlobal) return "type rows";
+        if (m.pk_trow_mode == vpt::kTypeRowsLds && (m.pk_trow_levels != 3 || sz(kSecPTrow) < 4ull * vpt::pk_trow_dw(wl) * vpt::kTypeRowCount)) return "type rows";
+        if (m.pk_trow_mode == vpt::kTypeRowsGlobal && (m.pk_trow_levels < 3 || m.pk_trow_levels > uint32_t(vpt::kMaxTypeRowLevels) ||
+                                                      sz(kSecPTrow) < 4ull * vpt::pk_trow_global_dw(wl) * vpt::type_row_count(int(m.pk_trow_levels)))) return "type rows";
+        if (m.sec_off[kSecPCpid] + sz(kSecPCpid) - m.sec_off[kSecPUni] >= (1ull << 32)) return "packed tables (32-bit offsets)";
     }
     if (m.has_tags) {
         if (m.n_tags == 0 || m.n_tags > 4096 || m.tok_bits < 2 || m.tok_bits > 30 || m.max_tag_scores > vpt::kTagMaxZ) return "tag tables";
@@ -194,12 +198,12 @@ void fill_info(const vpt::CompiledModel& c, vpt_model_info* info) {
     info->type_kind = uint32_t(c.type_kind);
     info->packed = c.packed.present ? 1u : 0u;
     info->n_displaced = c.packed.present ? 0u : c.chars.n_displaced_short;
-    info->type_rows = c.packed.present && !c.packed.trow.empty() ? 1u : 0u;
+    info->type_rows = c.packed.present ? c.packed.trow_mode : 0u;
     info->n_overflow_children = 0u;
     // the specialised kernel reads only the packed tables; the general ones stay resident for oversized sentences
     info->device_table_bytes = (c.chars.present ? c.chars.bytes() : 0) + (c.types.present ? c.types.bytes() : 0) +
                                4ull * c.type_table.size() + (c.packed.present ? c.packed.bytes() : 0);
-    info->hot_table_bytes = c.packed.present ? c.packed.bytes() + (c.packed.trow.empty() ? 4ull * c.type_table.size() : 0) : info->device_table_bytes;
+    info->hot_table_bytes = c.packed.present ? c.packed.bytes() + (c.packed.trow_mode == vpt::kTypeRowsNone ? 4ull * c.type_table.size() : 0) : info->device_table_bytes;
 }
 
 }  // namespace
@@ -505,8 +509,8 @@ void bind_predictor(vpt_predictor* p) {
         auto rel = [&](int sec) { return uint32_t(m.sec_off[sec] - m.sec_off[kSecPUni]); };
         p->pk.off_uni = 0; p->pk.off_bi = rel(kSecPBi); p->pk.off_tri = rel(kSecPTri); p->pk.off_deep = rel(kSecPDeep);
         p->pk.off_xrows = rel(kSecPXrows); p->pk.off_trow = rel(kSecPTrow); p->pk.off_cpid = rel(kSecPCpid);
-        p->pk.off_cc = rel(kSecPCc); p->pk.off_utag = rel(kSecPUtag); p->pk.off_urow = rel(kSecPUrow);
-        p->pk.n_uni = m.pk_n_uni; p->pk.n_tri = m.pk_n_tri; p->pk.bi_shift = m.pk_bi_shift; p->pk.has_trow = m.pk_has_trow;
+        p->pk.n_uni = m.pk_n_uni; p->pk.n_tri = m.pk_n_tri; p->pk.bi_shift = m.pk_bi_shift;
+        p->pk.wl = m.pk_wl; p->pk.trow_mode = m.pk_trow_mode; p->pk.trow_levels = m.pk_trow_levels;
     }
     p->d_type_table = m.sec_bytes[kSecTypeTable] ? reinterpret_cast<const int32_t*>(at(kSecTypeTable)) : nullptr;
     p->d_ctype = at(kSecCtype);
@@ -541,7 +545,7 @@ void bind_predictor(vpt_predictor* p) {
             return uint32_t(prop.multiProcessorCount) * uint32_t(std::min<size_t>(built_for, std::max<size_t>(1, 128 / std::max<size_t>(granules, 1))));
         };
         if (fast) {
-            p->tile_slots = slots_for(vpt::score_tiles_fast_lds_bytes(probe), vpt::kFastWg);
+            p->tile_slots = slots_for(vpt::score_tiles_fast_lds_bytes(probe), size_t(vpt::fast_path_wg(probe)));
         } else {
             p->tile_slots = slots_for(vpt::score_tiles_lds_bytes(), 8);   // the general kernel is built for 8 workgroups per CU
         }
@@ -584,9 +588,6 @@ vpt_status vpt_predictor_create(const uint8_t* model_bytes, size_t len, int pred
         ctype[cp] = vpt::char_type_host(cp);
     }
     std::vector<uint32_t> cid;
-    // the contents of the kernel's LDS caches (layout.h): per slot the entry that the most patterns contain
-    std::vector<uint32_t> cc(2 * std::max(vpt::kFastCharCache, 4), 0), urow(4 * std::max(vpt::kFastUniCache, 1), 0);
-    std::vector<uint16_t> utag(std::max(vpt::kFastUniCache, 8), 0);
     if (c.packed.present) {
         cid.resize(2 * 65536);
         for (uint32_t cp = 0; cp < 65536; ++cp)
@@ -595,31 +596,6 @@ vpt_status vpt_predictor_create(const uint8_t* model_bytes, size_t len, int pred
                 cid[size_t(mode) * 65536 + cp] = uint32_t(c.packed.id_of[scored]) | (uint32_t(vpt::char_type_host(scored)) << 16) |
                                                  ((scored == 0x0Au || scored == 0x0Du) ? vpt::kCinfoLinebreak : 0u);
             }
-        if (vpt::kFastCharCache) {
-            const uint32_t mask = uint32_t(vpt::kFastCharCache) - 1;
-            for (int mode = 0; mode < 2; ++mode) {
-                std::vector<uint32_t> best(vpt::kFastCharCache, 0);
-                for (uint32_t cp = 1; cp < 65536; ++cp) {
-                    const uint32_t w = cid[size_t(mode) * 65536 + cp], id = w & 0xFFFFu;
-                    const uint32_t scored = mode ? vpt::kytea_fullwidth_host(cp) : cp;
-                    const uint32_t heat = c.packed.hot[scored];
-                    if (id >= 0x1FFFu || (w & vpt::kCinfoLinebreak) || heat == 0) continue;   // ids of 13 bits, no line breaks, chars of the alphabet
-                    uint32_t& e = cc[size_t(mode) * vpt::kFastCharCache + (cp & mask)];
-                    if (e == 0 || heat > best[cp & mask]) { e = (cp << 16) | (((w >> 16) & 7u) << 13) | id; best[cp & mask] = heat; }
-                }
-            }
-        }
-        if (vpt::kFastUniCache) {
-            const uint32_t mask = uint32_t(vpt::kFastUniCache) - 1;
-            std::vector<uint32_t> best(vpt::kFastUniCache, 0);
-            for (uint32_t id = 1; id <= c.packed.n_alpha; ++id) {
-                const uint32_t heat = c.packed.hot[c.packed.cpid[id]];
-                if (utag[id & mask] == 0 || heat > best[id & mask]) {
-                    utag[id & mask] = uint16_t(id); best[id & mask] = heat;
-                    for (int q = 0; q < 4; ++q) urow[size_t(id & mask) * 4 + q] = c.packed.uni[size_t(id) * 4 + q];
-                }
-            }
-        }
     }
 
     // ---- sections
@@ -631,12 +607,11 @@ vpt_status vpt_predictor_create(const uint8_t* model_bytes, size_t len, int pred
     if (packed_ok) {
         put(kSecPUni, c.packed.uni); put(kSecPBi, c.packed.bi); put(kSecPTri, c.packed.tri); put(kSecPDeep, c.packed.deep);
         put(kSecPXrows, c.packed.xrows); put(kSecPTrow, c.packed.trow); put(kSecPCpid, c.packed.cpid);
-        put(kSecPCc, cc); put(kSecPUtag, utag); put(kSecPUrow, urow);
         size_t packed_total = 0;
-        for (int i = kSecPUni; i <= kSecPUrow; ++i) packed_total += (src[i].bytes + kTablePadBytes + 255) & ~size_t(255);
+        for (int i = kSecPUni; i <= kSecPCpid; ++i) packed_total += (src[i].bytes + kTablePadBytes + 255) & ~size_t(255);
         if (packed_total >= (size_t(1) << 32)) {   // the specialised kernel addresses them with 32-bit offsets: the general tables serve
             packed_ok = false;
-            for (int i = kSecPUni; i <= kSecPUrow; ++i) src[i] = {nullptr, 0};
+            for (int i = kSecPUni; i <= kSecPCpid; ++i) src[i] = {nullptr, 0};
         }
     }
     if (c.type_kind == vpt::kTypeWindowTable) put(kSecTypeTable, c.type_table);
@@ -685,8 +660,9 @@ vpt_status vpt_predictor_create(const uint8_t* model_bytes, size_t len, int pred
     m.geom[0] = geom_of(c.chars); m.geom[1] = geom_of(c.types);
     m.pk_present = packed_ok ? 1u : 0u;
     if (packed_ok) {
-        m.pk_n_uni = uint32_t(c.packed.uni.size() / 4); m.pk_n_tri = uint32_t(c.packed.tri.size() / 4);
-        m.pk_bi_shift = c.packed.bi_shift; m.pk_has_trow = c.packed.trow.empty() ? 0u : 1u;
+        m.pk_wl = uint32_t(c.packed.wl);
+        m.pk_n_uni = uint32_t(c.packed.uni.size() / size_t(vpt::pk_uni_dw(c.packed.wl))); m.pk_n_tri = uint32_t(c.packed.tri.size() / size_t(vpt::pk_tri_dw(c.packed.wl)));
+        m.pk_bi_shift = c.packed.bi_shift; m.pk_trow_mode = c.packed.trow_mode; m.pk_trow_levels = c.packed.trow_levels;
     }
     fill_info(c, &m.info);
     m.info.predict_tags = predict_tags != 0;
@@ -988,7 +964,6 @@ vpt_status vpt_predict_batch_device(const vpt_predictor* p, vpt_batch* b, const 
     P.post = b->flags & 0xFEu;
     P.type_window = p->type_window; P.type_kind = p->type_kind; P.bias = p->bias; P.pad = p->pad;
     P.force_window_table = p->knobs.force_window_table ? 1u : 0u; P.lds_pad = p->knobs.lds_pad;
-    if (b->flags & VPT_FLAG_KYTEA_FULLWIDTH) P.pk.off_cc += 4u * uint32_t(std::max(vpt::kFastCharCache, 4));   // the char cache of that char table
     // flat positions of the longest sentence: its chars, bounded by the caller's hint or else by its bytes
     const uint64_t max_chars = (b->max_chars && b->max_chars < max_sentence_bytes) ? b->max_chars : max_sentence_bytes;
     const uint64_t total_flat = total_boundaries + uint64_t(n_sentences) * uint64_t(1 + p->pad);
@@ -997,27 +972,34 @@ vpt_status vpt_predict_batch_device(const vpt_predictor* p, vpt_batch* b, const 
     // halo of the longest pattern on either side) otherwise -- a sentence of any length is scored there.  Only a model whose longest
     // pattern leaves no room for a tile between its halos sends long sentences to the general kernels.
     bool fast = vpt::fast_path_supported(P) && !b->knobs.force_generic;
+    const uint64_t fast_cap = fast ? uint64_t(vpt::fast_path_cap(P)) : 0;   // flat positions per tile of the instance that scores this predictor
     vpt::CutGeometry cut{};
     bool cut_tiles = false;
     if (fast) {
         const uint32_t lmax = std::max<uint32_t>(p->info.max_pattern_chars, 3);
-        cut.halo_left = std::max<uint32_t>(lmax - 1, 3); cut.halo_right = std::max<uint32_t>(lmax + 2, 6);
-        cut.cap_eff = uint32_t(vpt::kFastCap - vpt::kFastStageSlack);
+        // A pattern of m chars that starts at s touches the boundaries s - wl .. s + max(wl, m) - 1 (layout.h, row_lo / row_hi): a
+        // boundary needs the start positions within max(lmax, wl) - 1 to its left and within wl to its right, and those need their
+        // chars -- lmax - 1 further on -- and the types their row is indexed by.
+        const uint32_t wl = p->pk.wl;
+        const uint32_t levels = p->pk.trow_mode == vpt::kTypeRowsGlobal ? p->pk.trow_levels : 3u;
+        cut.halo_left = std::max<uint32_t>(lmax - 1, wl); cut.halo_right = wl + std::max<uint32_t>(std::max<uint32_t>(lmax - 1, wl), levels);
+        cut.pad = uint32_t(p->pad); cut.cap = uint32_t(fast_cap);
+        cut.cap_eff = uint32_t(fast_cap - vpt::kFastStageSlack);
         const int64_t room = int64_t(cut.cap_eff) - int64_t(p->pad) - int64_t(cut.halo_left) - int64_t(cut.halo_right);
         const bool can_cut = room >= 256;
         cut.tile_flat = can_cut ? uint32_t(room) : 0u;
         cut.mis = uint32_t(reinterpret_cast<uintptr_t>(d_utf8) & 15u);
-        const bool fits_whole = max_chars <= uint64_t(vpt::kFastWholeMaxChars);
-        const bool whole_possible = max_chars + 2 * uint64_t(p->pad) + vpt::kFastCap / 2 <= uint64_t(vpt::kFastCap);
+        const bool fits_whole = max_chars + 2 * uint64_t(p->pad) <= fast_cap / 2;
+        const bool whole_possible = max_chars + 2 * uint64_t(p->pad) + fast_cap / 2 <= fast_cap;
         // Whole-sentence tiles are cut every (capacity - longest sentence) positions: the longer the longest sentence, the emptier
         // they run, while a tile cut anywhere is always full -- at the price of the index of the text (a pass over it).  Measured on
         // configs[4] (8 .. 512 chars, profiles/r03_u_cut_vs_whole.txt): kernel 2.14 -> 1.99 ms, step 3.80 -> 3.76; on configs[1] (64
         // chars) the kernel is the same and the index costs 19 us of 117.  So: cut above a quarter of the capacity.
-        const bool prefer_cut = max_chars > uint64_t(vpt::kFastCap / 4);
+        const bool prefer_cut = max_chars > fast_cap / 4;
         cut_tiles = can_cut && (b->knobs.force_cut > 0 || (b->knobs.force_cut == 0 ? (prefer_cut || !fits_whole) : !whole_possible));
-        if (!cut_tiles && max_chars + 2 * uint64_t(p->pad) + vpt::kFastCap / 2 > uint64_t(vpt::kFastCap)) fast = false;   // neither kind of tile holds the batch
+        if (!cut_tiles && max_chars + 2 * uint64_t(p->pad) + fast_cap / 2 > fast_cap) fast = false;   // neither kind of tile holds the batch
     }
-    const uint64_t cap = fast ? uint64_t(vpt::kFastCap) : vpt::kCap;
+    const uint64_t cap = fast ? fast_cap : vpt::kCap;
     // Whole-sentence tiles are cut every `tile_flat` flat positions (chars + separators) and end with the sentence that crosses
     // the cut, so a tile holds < tile_flat + longest sentence: pick tile_flat to fill the kernel's LDS capacity.
     uint64_t tile_flat = cap / 2;
@@ -1035,6 +1017,10 @@ vpt_status vpt_predict_batch_device(const vpt_predictor* p, vpt_batch* b, const 
     if (cut_tiles) {   // the window a cut tile decodes and walks: its own positions and the two halos
         cut.tile_flat = uint32_t(tile_flat);
         cut.cap_eff = uint32_t(p->pad) + cut.halo_left + cut.tile_flat + cut.halo_right;
+        // what the tile planner promises the scoring kernel (kernels_fast.hip: a tile of n positions stages at most 4 n + 2 * 256 bytes,
+        // the staging area holds 4 * cap + 15): an internal inconsistency, not the caller's offsets
+        if (uint64_t(cut.cap_eff) * 4 + 2 * 256 > cap * 4 + 15 || cut.cap_eff > cap)
+            return fail(VPT_RUNTIME_ERROR, "internal error: the tile planner produced a cut tile that does not fit the kernel's staging area");
     }
     const uint64_t n_tiles64 = (total_flat + tile_flat - 1) / tile_flat;
     if (n_tiles64 >= 0x7FFFFFFFull) return fail(VPT_INVALID_ARGUMENT, "InvalidArgumentError: batch too large for one call");

@@ -15,11 +15,11 @@ constexpr int kCap = 2048;                       // flat positions (chars + sepa
 constexpr int kTileFlat = 1024;                  // flat positions a tile is cut at (a tile ends with the sentence
                                                  // that crosses the cut, so it needs kCap - kTileFlat of slack)
 constexpr int kMargin = 8;                       // zeroed slack past the tile for the s+1, s+2 look-ahead
-// The specialised kernel's tile: kFastCap flat positions, kFastWg workgroups per CU (1280 / 8: the best of the geometries measured
-// on MI355X, profiles/r02_c5_ab*.jsonl, r03_d_ab_m1.jsonl), and -- compiled out by default -- two LDS-resident caches in front
-// of the two small tables every position reads, the char -> (id, CharacterType) table and the unigram nodes.  Measured (r03_d): a
-// 512-entry char cache hits 83 % of the chars of the benchmark text and buys 2 % (those gathers hit the vector L1 anyway; what the
-// kernel waits for are the bigram / trigram nodes that miss the L2), less than the smaller tile that makes room for it costs.
+// The specialised kernel's tile per ROW WINDOW wl (layout.h): fast_cap(wl) flat positions, fast_wg(wl) workgroups per CU.  Window 3
+// (every distributed model): 1280 / 8, the best of the geometries measured on MI355X (profiles/r02_c5_ab*.jsonl, r03_d_ab_m1.jsonl;
+// LDS-resident caches in front of the char table and the unigram nodes, a dense matrix for the bigram nodes of frequent second
+// chars and a stage-major walk were measured in round 3 and are gone: profiles/r03_d/f/h_ab_*.jsonl).  Wider windows have wider
+// nodes in flight and wider type rows in LDS: 1024 positions at 6 (5 for window 8) workgroups per CU.
 // (-D overrides: A/B builds of tools/build_variants.sh.)
 #ifndef VPT_FAST_CAP
 #define VPT_FAST_CAP 1280
@@ -27,25 +27,19 @@ constexpr int kMargin = 8;                       // zeroed slack past the tile f
 #ifndef VPT_FAST_WG
 #define VPT_FAST_WG 8
 #endif
-#ifndef VPT_FAST_CC
-#define VPT_FAST_CC 0
+#ifndef VPT_FAST_CAP_WIDE
+#define VPT_FAST_CAP_WIDE 1024
 #endif
-#ifndef VPT_FAST_UC
-#define VPT_FAST_UC 0
-#endif
-#ifndef VPT_FAST_STAGED
-#define VPT_FAST_STAGED 0
-#endif
-constexpr int kFastCap = VPT_FAST_CAP, kFastWg = VPT_FAST_WG;
-constexpr int kFastCharCache = VPT_FAST_CC;      // entries (a power of two); 0: none
-constexpr int kFastUniCache = VPT_FAST_UC;       // unigram nodes (a power of two); 0: none
+constexpr int fast_cap(int wl) { return wl <= 3 ? VPT_FAST_CAP : VPT_FAST_CAP_WIDE; }
+constexpr int fast_wg(int wl) { return wl <= 3 ? VPT_FAST_WG : wl <= 7 ? 6 : 5; }
+constexpr int kFastCapMax = VPT_FAST_CAP > VPT_FAST_CAP_WIDE ? VPT_FAST_CAP : VPT_FAST_CAP_WIDE;
 // Two ways of cutting a batch into tiles ("Tiles"):
 //   whole sentences   a tile = the sentences whose flat start lies in its range; needs every sentence to fit beside tile_flat
 //   cut anywhere      a tile = a range of flat positions plus a halo of max(pattern length) chars on either side, so a sentence
 //                     of ANY length is scored by as many tiles as it spans (the reference scores any length in one loop,
 //                     char_scorer/boundary_scorer.rs:93-113; its tantivy adapter passes whole documents as one Sentence)
-constexpr int kFastWholeMaxChars = kFastCap / 2 - 6;   // batches whose longest sentence has more chars are cut anywhere (a whole-sentence
-                                                 // tile holds tile_flat >= cap / 2 positions plus the sentence that crosses its end)
+constexpr int fast_whole_max_chars(int wl) { return fast_cap(wl) / 2 - 2 * pk_pad(wl); }   // batches whose longest sentence has more chars are cut
+                                                 // anywhere (a whole-sentence tile holds tile_flat >= cap / 2 positions plus the sentence that crosses its end)
 constexpr int kCutBlockShift = 8;                // cut tiles find their text through lead-byte counts per 256-byte block
 constexpr int kFastStageSlack = 136;             // flat positions a cut tile leaves unused so that its text always fits the staging area
                                                  // (a tile of n chars stages at most 4 n + 2 * 256 bytes; the area holds 4 * cap + 32)
@@ -187,13 +181,15 @@ hipError_t launch_count_boundaries(const uint8_t* text, const uint64_t* boff, ui
 size_t score_tiles_lds_bytes();
 hipError_t launch_assign_tiles(const uint64_t* ooff, uint64_t n_sent, int pad, uint32_t tile_flat, uint32_t n_tiles,
                                uint32_t* tile_first, uint32_t* ctrl, hipStream_t stream);
-// specialised kernel (kernels_fast.hip): packed tables (char window 3, BMP, i16), type window table or none
+// specialised kernel (kernels_fast.hip): packed tables (windows up to 8, BMP, i16), type rows, the type window table (row window 3) or none
 bool fast_path_supported(const ScoreParams& P);
+int fast_path_cap(const ScoreParams& P);   // flat positions per tile / workgroups per CU of the instance that scores P
+int fast_path_wg(const ScoreParams& P);
 size_t score_tiles_fast_lds_bytes(const ScoreParams& P);
 hipError_t launch_score_tiles_fast(const ScoreParams& P, uint32_t n_tiles, hipStream_t stream);
 // its tiles: whole sentences (launch_assign_tiles, as for the general kernel; ScoreParams::tiles stays nullptr) or cut anywhere: lead-byte counts per 256-byte block of the text (cut_local: exclusive inside a superblock of 256 blocks,
 // cut_super: exclusive over the superblocks; sized from cut_index_entries), then the tiles
-struct CutGeometry { uint32_t tile_flat, halo_left, halo_right, cap_eff, mis /* text pointer & 15 */; };
+struct CutGeometry { uint32_t tile_flat, halo_left, halo_right, cap_eff, mis /* text pointer & 15 */, pad /* separator slots */, cap /* the kernel's tile */; };
 void cut_index_entries(uint64_t total_chars_bound, size_t* n_local, size_t* n_super);
 hipError_t launch_assign_tiles_cut(const ScoreParams& P, const CutGeometry& G, uint32_t n_tiles, uint64_t total_chars_bound, uint32_t* cut_local,
                                    uint64_t* cut_super, TileDesc* tiles, uint32_t* ctrl, hipStream_t stream);

@@ -1,22 +1,21 @@
-// Specialised tile kernel for the model geometry every distributed Vaporetto / KyTea model has: char window 3,
-// BMP patterns (layout.h, "PACKED TABLES"), type scores from type rows in LDS, the 8^(2W) window table (W <= 3) or
-// none.  Same all-matches algorithm as kernels.hip (which stays the general path); what changes is how the work is
-// laid out for a CDNA4 CU, whose limiter on this workload is the vector L1's address pipeline: every 16-byte load of
-// a lane costs a slot of it and every distinct line it touches two more (profiles/r02_*, r03_b_*), while VALU work is two
-// orders of magnitude cheaper per lane.  So a start position issues as few loads as the data structure allows:
+// Specialised tile kernel for the models a Vaporetto / KyTea trainer produces: BMP patterns, 16-bit weights, char and type
+// windows up to 8 (layout.h, "PACKED TABLES"; one instance per ROW WINDOW wl = max(3, W_c, W_t) -- every distributed model has 3),
+// type scores from type rows (in LDS, or in global memory for long type n-grams), the 8^(2W) window table (wl = 3) or none.  Same
+// all-matches algorithm as kernels.hip (which stays the general path); what changes is how the work is laid out for a CDNA4 CU,
+// whose limiter on this workload is the vector L1's address pipeline: every 16-byte load of a lane costs a slot of it and every
+// distinct line it touches two more (profiles/r02_*, r03_b_*), while VALU work is two orders of magnitude cheaper per lane.  So a
+// start position issues as few loads as the data structure allows:
 //
-//   * the patterns form a DOUBLE-ARRAY trie over their first three symbols: one 16-byte unigram node (indexed by the
-//     char's id), one 32-byte bigram node at (unigram base + id of the next char), and -- only when the bigram's 64-bit
-//     filter admits the third char -- one 16-byte trigram node at (bigram base + its id): 4 loads to 3 lines, no hash,
-//     no seed table, no probing; a node names its parent, so a lookup that lands on a foreign node knows it;
+//   * the patterns form a DOUBLE-ARRAY trie over their first three symbols: one unigram node (indexed by the char's id), one
+//     bigram node at (unigram base + id of the next char), and -- only when the bigram's 64-bit filter admits the third char --
+//     one trigram node at (bigram base + its id): for wl = 3 that is 4 loads of 16 bytes to 3 lines; no hash, no seed table, no
+//     probing; a node names its parent, so a lookup that lands on a foreign node knows it;
 //   * the three loads depend on each other, so they are software-pipelined: a trip of the main loop loads the
 //     unigram nodes of the positions two trips ahead, the bigram nodes of the next trip's positions and the trigram
 //     nodes of its own -- all independent of each other -- and waits once;
 //   * only lanes that can match load at all: separators, chars no pattern contains and positions past the tile issue nothing;
-//   * the two SMALL tables every char reads -- char -> (id, CharacterType) and the unigram nodes -- sit behind LDS-resident
-//     caches of their hottest entries (direct mapped, filled from the predictor's arena at the start of every tile): the tables
-//     are L2-resident, but a gather costs the L1's address pipeline the same whether it hits or not;
-//   * rows are added to the LDS score array where they arrive (ds_add_u32: integer => order-free => bit-exact);
+//   * rows are added to the LDS score array where they arrive (ds_add_u32: integer => order-free => bit-exact); the type row of a
+//     position is added to its unigram row in registers first;
 //   * what is data-dependent beyond depth 3 is NOT done in place (64 lanes would wait for the unluckiest one): it is
 //     pushed, ballot/mbcnt-compacted, onto wave-private LDS stacks, so that a replay runs one short code path with
 //     every lane busy: W trie steps of dictionary words longer than 3 chars (a step that matches re-queues its
@@ -43,26 +42,36 @@ constexpr uint32_t kCpMask = 0xFFFFu;        // sym = id (kNoId: in no pattern) 
 constexpr uint32_t kSymLinebreak = 1u << 29;
 static_assert(kSymLinebreak == kCinfoLinebreak, "the char table's words are symbol words");
 constexpr int kWavesF = kThreads / 64;
-constexpr int kTypeRows = 4;                 // TM value: type rows in LDS (1..3 = window table of that W, 0 = none)
-static_assert(kMargin >= int(kPackedMaxSkip), "replay_w reads up to kPackedMaxSkip symbols past a char");
+constexpr int kTypeRows = 4;                 // TM value: type rows (1..3 = window table of that W, 0 = none)
+static_assert(kMargin >= int(kPackedMaxSkip) && kMargin >= kMaxWindow, "replay_w reads up to kPackedMaxSkip symbols past a char; rows reach wl - 1 boundaries past one");
 constexpr int kTrowCount = int(kTypeRowCount);   // layout.h, type_row_index
-constexpr uint32_t kPad = 3;                 // separator slots between sentences (= the char window)
-constexpr int kSymSlots = kFastCap + kMargin + 4;   // the last one is the DUMP slot: where a char outside the tile's window is written
-constexpr uint32_t kDump = kFastCap + kMargin;
-static_assert(kFastCap % kThreads == 0 && (kFastCharCache & (kFastCharCache - 1)) == 0 && (kFastUniCache & (kFastUniCache - 1)) == 0, "geometry");
 
+// geometry of the instance for row window WL (layout.h, kernels.hpp)
+template <int WL>
+struct FastGeom {
+    static constexpr int kCapG = fast_cap(WL);
+    static constexpr uint32_t kPadG = uint32_t(pk_pad(WL));         // separator slots between sentences
+    static constexpr int kSymSlots = kCapG + kMargin + 4;           // the last one is the DUMP slot: where a char outside the tile's window is written
+    static constexpr uint32_t kDump = uint32_t(kCapG + kMargin);
+    static constexpr int kPerThread = kCapG / kThreads;
+    static constexpr int kTrowQ = pk_trow_dw(WL) / 4;               // 16-byte words per LDS type row
+    static constexpr int kUniQ = ((kUniFieldBits * 2 * WL + kUniBaseBits + 1 + 31) / 32 + 3) / 4;   // 16-byte loads of a unigram node
+    static constexpr int kBiQ = (pk_bi_used_dw(WL) + 3) / 4;
+    static constexpr int kTriQ = (pk_tri_used_dw(WL) + 3) / 4;
+    static_assert(kCapG % kThreads == 0 && kCapG <= 2047, "geometry (a W item keeps its position in 11 bits)");
+};
+
+template <int WL>
 struct FastLdsT {
-    uint32_t sym[kSymSlots];                 // zero except for the tile's chars (scalar value | sentence << 21 until classified)
-    int32_t score[kSymSlots];                // staged text bytes during decode
+    using G = FastGeom<WL>;
+    uint32_t sym[G::kSymSlots];              // zero except for the tile's chars (scalar value | sentence << 21 until classified)
+    int32_t score[G::kSymSlots];             // staged text bytes during decode
     uint2 queue[kWavesF][kQCap];             // sentence-start bitmap during decode
     uint32_t mqueue[kWavesF][kMCap];
     uint32_t wtot[8];
-    uint32_t cc[kFastCharCache ? kFastCharCache : 4];   // char cache (layout.h)
-    uint4 urow[kFastUniCache ? kFastUniCache : 1];      // unigram cache
-    uint16_t utag[kFastUniCache ? kFastUniCache : 8];
     union {                                  // never needed together; the launch allocates the one in use
-        uint8_t typ[kSymSlots];              // window-table modes
-        uint4 trow[kTrowCount];              // TM == kTypeRows
+        uint8_t typ[G::kSymSlots];           // window-table modes
+        uint4 trow[kTrowCount * G::kTrowQ];  // TM == kTypeRows, rows in LDS
     };
 };
 // the replay routines only index the arrays (the queues are passed as pointers)
@@ -70,13 +79,16 @@ struct FastLds {
     uint32_t* sym;
     int32_t* score;
 };
+template <int WL>
 constexpr bool fast_lds_ok() {
-    return offsetof(FastLdsT, typ) % 16 == 0 && offsetof(FastLdsT, score) % 16 == 0 && offsetof(FastLdsT, cc) % 16 == 0 && offsetof(FastLdsT, urow) % 16 == 0 &&
-           sizeof(uint2) * kWavesF * kQCap >= size_t(kFastCap) * 4 / 8 + 80 &&                              // the decode phase's sentence-start bitmap lives in the W queues
-           sizeof(int32_t) * kSymSlots >= size_t(kFastCap) * 4 + 36 &&                                       // ... and the staged text in the score array
-           offsetof(FastLdsT, typ) + sizeof(uint4) * kTrowCount <= size_t(128 / kFastWg) * 1280;             // gfx950 hands out LDS in 1280-byte granules, 128 per CU
+    using T = FastLdsT<WL>;
+    using G = FastGeom<WL>;
+    return offsetof(T, typ) % 16 == 0 && offsetof(T, score) % 16 == 0 &&
+           sizeof(uint2) * kWavesF * kQCap >= size_t(G::kCapG) * 4 / 8 + 80 &&                              // the decode phase's sentence-start bitmap lives in the W queues
+           sizeof(int32_t) * G::kSymSlots >= size_t(G::kCapG) * 4 + 36 &&                                    // ... and the staged text in the score array
+           offsetof(T, typ) + sizeof(uint4) * kTrowCount * G::kTrowQ <= size_t(128 / fast_wg(WL)) * 1280;    // gfx950 hands out LDS in 1280-byte granules, 128 per CU
 }
-static_assert(fast_lds_ok(), "LDS budget of the tile geometry");
+static_assert(fast_lds_ok<3>() && fast_lds_ok<4>() && fast_lds_ok<5>() && fast_lds_ok<6>() && fast_lds_ok<7>() && fast_lds_ok<8>(), "LDS budget of the tile geometries");
 
 __device__ __forceinline__ uint32_t lane_rank(uint64_t mask) {  // set bits of `mask` below this lane
     return __builtin_amdgcn_mbcnt_hi(uint32_t(mask >> 32), __builtin_amdgcn_mbcnt_lo(uint32_t(mask), 0u));
@@ -121,26 +133,42 @@ struct WaveStacks {
     }
 };
 
-__device__ __forceinline__ int32_t sext(uint32_t x, int bits) { return int32_t(x << (32 - bits)) >> (32 - bits); }   // low `bits` bits, signed
 __device__ __forceinline__ int32_t lo16(uint32_t x) { return int32_t(x << 16) >> 16; }
 __device__ __forceinline__ int32_t hi16(uint32_t x) { return int32_t(x) >> 16; }
 
-__device__ __forceinline__ void add_row6(int32_t* score, uint32_t s, int32_t a0, int32_t a1, int32_t a2, int32_t a3,
-                                         int32_t a4, int32_t a5) {
-    int32_t* p = score + s - 3;
-    atomicAdd(p, a0); atomicAdd(p + 1, a1); atomicAdd(p + 2, a2);
-    atomicAdd(p + 3, a3); atomicAdd(p + 4, a4); atomicAdd(p + 5, a5);
+// signed NB-bit field at bit BIT of a node held in registers (d[] is indexed by constants only)
+template <int BIT, int NB>
+__device__ __forceinline__ int32_t sfield(const uint32_t* d) {
+    constexpr int q = BIT >> 5, r = BIT & 31;
+    if constexpr (r + NB <= 32) return int32_t(d[q] << (32 - r - NB)) >> (32 - NB);
+    else return int32_t(__builtin_amdgcn_alignbit(d[q + 1], d[q], r) << (32 - NB)) >> (32 - NB);
 }
-// the row of a 3-char string starting at `st`: boundaries st-1 .. st+2
-__device__ __forceinline__ void add_child(int32_t* score, uint32_t st, uint32_t w01, uint32_t w23) {
-    int32_t* p = score + st - 1;
-    atomicAdd(p, lo16(w01)); atomicAdd(p + 1, hi16(w01)); atomicAdd(p + 2, lo16(w23)); atomicAdd(p + 3, hi16(w23));
+template <int BIT, int NB>
+__device__ __forceinline__ uint32_t ufield(const uint32_t* d) {
+    constexpr int q = BIT >> 5, r = BIT & 31;
+    if constexpr (r + NB <= 32) return (d[q] >> r) & ((1u << NB) - 1u);
+    else return __builtin_amdgcn_alignbit(d[q + 1], d[q], r) & ((1u << NB) - 1u);
+}
+// f(j, value of field j) for the N fields of NB bits from bit 0 of d[], unrolled at compile time
+template <int J, int N, int NB, typename F>
+__device__ __forceinline__ void each_field(const uint32_t* d, F&& f) {
+    if constexpr (J < N) {
+        f(J, sfield<NB * J, NB>(d));
+        each_field<J + 1, N, NB>(d, f);
+    }
+}
+template <int Q>
+__device__ __forceinline__ void unpack4(const uint4 (&v)[Q], uint32_t (&d)[4 * Q + 1]) {
+#pragma unroll
+    for (int i = 0; i < Q; ++i) { d[4 * i] = v[i].x; d[4 * i + 1] = v[i].y; d[4 * i + 2] = v[i].z; d[4 * i + 3] = v[i].w; }
+    d[4 * Q] = 0;
 }
 
 // W: up to 64 queued trie steps, all lanes busy: the child sym[s + depth] in the mini-table `ref` of `deep`, whose
 // 64-byte entries also name the up-to-8 symbols that must follow (compressed single-child chains; layout.h).
 // The home entry and the next one are read together (a mini-table keeps a quarter of its entries free, so nearly
 // every search ends within two); the rare longer search loops.
+template <int WL>
 __device__ __forceinline__ void replay_w(const PackedView& K, FastLds& L, WaveStacks& Q, int lane) {
     VPT_WAVE_LOCKSTEP();   // the queue entries were written by other lanes
     const uint32_t take = wave_uniform(Q.nw < 64u ? Q.nw : 64u);   // opaque: nw - min(nw, 64) would become a VALU-only saturating subtract
@@ -190,19 +218,22 @@ __device__ __forceinline__ void replay_w(const PackedView& K, FastLds& L, WaveSt
             if (j < nskip && have_c != want) found = false;
         }
     }
-    const uint32_t m = depth + 1 + nskip;  // chars matched so far: a pattern of m chars has m + 1 weights, the first
-    int32_t* dst = L.score + s - 1;        // on boundary s - 1; unused row slots hold zero, adding them is harmless
+    const uint32_t m = depth + 1 + nskip;  // chars matched so far (>= 4): the row of a pattern of m chars has row_len(m, WL) weights, the
+    // first on boundary s + row_lo(m, WL) (wl = 3: m + 1 weights from s - 1); unused row slots hold zero, adding them is harmless
+    const int32_t lo = WL == 3 ? -1 : (int32_t(m) - 1 - WL < -1 ? int32_t(m) - 1 - WL : -1);
+    const uint32_t rlen = WL == 3 ? m + 1 : uint32_t(int32_t(m - 1 > uint32_t(WL - 1) ? m - 1 : uint32_t(WL - 1)) - lo + 1);
+    int32_t* dst = L.score + int32_t(s) + lo;   // s >= WL (the separators in front of the tile's first char)
     const bool row = found && (e.x & (kPkHasRow << 16));
     if (__ballot(row) != 0) {
         uint4 f0 = make_uint4(0, 0, 0, 0), f1 = make_uint4(0, 0, 0, 0);
         if (row) f0 = ld16(K.base, ent + 32);   // (loading the home entry's row speculatively with the entry: no faster, profiles/r02_c5_ab*.jsonl)
-        if (__ballot(row && m >= 8) != 0) { if (row && m >= 8) f1 = ld16(K.base, ent + 48); }
+        if (__ballot(row && rlen > 8) != 0) { if (row && rlen > 8) f1 = ld16(K.base, ent + 48); }
         if (row) {
             atomicAdd(dst, lo16(f0.x)); atomicAdd(dst + 1, hi16(f0.x)); atomicAdd(dst + 2, lo16(f0.y)); atomicAdd(dst + 3, hi16(f0.y));
             atomicAdd(dst + 4, lo16(f0.z)); atomicAdd(dst + 5, hi16(f0.z)); atomicAdd(dst + 6, lo16(f0.w)); atomicAdd(dst + 7, hi16(f0.w));
         }
-        if (__ballot(row && m >= 8) != 0) {
-            if (row && m >= 8) {
+        if (__ballot(row && rlen > 8) != 0) {
+            if (row && rlen > 8) {
                 atomicAdd(dst + 8, lo16(f1.x)); atomicAdd(dst + 9, hi16(f1.x)); atomicAdd(dst + 10, lo16(f1.y));
                 atomicAdd(dst + 11, hi16(f1.y)); atomicAdd(dst + 12, lo16(f1.z)); atomicAdd(dst + 13, hi16(f1.z));
             }
@@ -211,46 +242,50 @@ __device__ __forceinline__ void replay_w(const PackedView& K, FastLds& L, WaveSt
     if (__ballot(found && (e.x & (kPkExtRow << 16))) != 0) {  // more than 14 weights or a value outside i16 (rare)
         if (found && (e.x & (kPkExtRow << 16))) {
             const int32_t* w32 = reinterpret_cast<const int32_t*>(K.base + K.off_xrows) + ld16(K.base, ent + 32).x;
-            for (uint32_t j = 0; j <= m; ++j) atomicAdd(dst + j, w32[j]);
+            for (uint32_t j = 0; j < rlen; ++j) atomicAdd(dst + j, w32[j]);
         }
     }
     Q.push_w(found && e.y != 0, s | (m << 11), e.y);
 }
 
-// Row of a <= 3-char string in the GENERAL short table (layout.h; 32-byte entries, buckets of two): used for the
-// rare packed slots marked kPkWide.
-__device__ __forceinline__ bool general_row(const PatternTableView& T, uint64_t key, uint4& r0, uint4& r1) {
-    const uint4* tab = reinterpret_cast<const uint4*>(T.short_tab);
+// Entry of a <= 3-char string in the GENERAL short table (layout.h; buckets of two entries of stride_dw dwords): used for the
+// rare packed nodes whose row is marked wide.  Returns the entry's first dword or nullptr.
+__device__ __forceinline__ const uint32_t* general_row(const PatternTableView& T, uint64_t key) {
     const uint32_t klo = uint32_t(key), khi = uint32_t(key >> 32);
     uint32_t b = hash_slot(key, T.short_shift);
     bool home = true;
     for (;;) {
-        const uint4 a0 = tab[size_t(b) * 4], b0 = tab[size_t(b) * 4 + 2];
-        if (a0.x == klo && (a0.y & ~kDisplacedBit) == khi) { r0 = a0; r1 = tab[size_t(b) * 4 + 1]; return true; }
-        if (b0.x == klo && b0.y == khi) { r0 = b0; r1 = tab[size_t(b) * 4 + 3]; return true; }
-        if ((a0.x | a0.y) == 0 || (b0.x | b0.y) == 0 || (home && !(a0.y & kDisplacedBit))) return false;
+        const uint32_t* e0 = T.short_tab + size_t(b) * 2 * T.stride_dw;
+        const uint32_t* e1 = e0 + T.stride_dw;
+        const uint32_t a0 = e0[0], a1 = e0[1], b0 = e1[0], b1 = e1[1];
+        if (a0 == klo && (a1 & ~kDisplacedBit) == khi) return e0;
+        if (b0 == klo && b1 == khi) return e1;
+        if ((a0 | a1) == 0 || (b0 | b1) == 0 || (home && !(a1 & kDisplacedBit))) return nullptr;
         home = false;
         b = (b + 1) & T.short_mask;
     }
 }
 
-// rows with a value outside their fields (rare): the general tables hold them as i32, keyed by code points
+// rows with a value outside their fields (rare): the general tables hold them as i32, keyed by code points; the row of a string of
+// n chars covers the boundaries s + lo[n] .. (layout.h, general tables -- laid out for the same row window)
 __device__ __forceinline__ void add_wide_rows(const PackedView& K, const PatternTableView& T, FastLds& L, uint32_t kinds, uint32_t s) {
     const uint32_t* cpid = reinterpret_cast<const uint32_t*>(K.base + K.off_cpid);
     // a wide row belongs to a pattern that matched here: its chars are in the alphabet (ids below n_uni)
     const uint32_t last = K.n_uni - 1u;
     const uint32_t i1 = L.sym[s] & kCpMask, i2 = L.sym[s + 1] & kCpMask, i3 = L.sym[s + 2] & kCpMask;
     const uint32_t c1 = cpid[i1 < last ? i1 : last], c2 = cpid[i2 < last ? i2 : last], c3 = cpid[i3 < last ? i3 : last];
-    uint4 r0, r1;
     if (kinds & kWideUni) {
-        const uint4* u = reinterpret_cast<const uint4*>(T.uni) + size_t(c1) * 2;
-        r0 = u[0]; r1 = u[1];
-        add_row6(L.score, s, int32_t(r0.x), int32_t(r0.y), int32_t(r0.z), int32_t(r0.w), int32_t(r1.x), int32_t(r1.y));
+        const uint32_t* u = T.uni + size_t(c1) * T.uni_dw;
+        for (int32_t j = 0; j < T.len[0]; ++j) atomicAdd(L.score + int32_t(s) + T.lo[0] + j, int32_t(u[j]));
     }
-    if ((kinds & kWideBi) && general_row(T, short_key(c1, c2, 0), r0, r1))
-        add_row6(L.score, s, 0, int32_t(r0.z), int32_t(r0.w), int32_t(r1.x), int32_t(r1.y), int32_t(r1.z));
-    if ((kinds & kWideTri) && general_row(T, short_key(c1, c2, c3), r0, r1))
-        add_row6(L.score, s, 0, 0, int32_t(r0.z), int32_t(r0.w), int32_t(r1.x), int32_t(r1.y));
+    if (kinds & kWideBi) {
+        if (const uint32_t* e = general_row(T, short_key(c1, c2, 0)))
+            for (int32_t j = 0; j < T.len[1]; ++j) atomicAdd(L.score + int32_t(s) + T.lo[1] + j, int32_t(e[2 + j]));
+    }
+    if (kinds & kWideTri) {
+        if (const uint32_t* e = general_row(T, short_key(c1, c2, c3)))
+            for (int32_t j = 0; j < T.len[2]; ++j) atomicAdd(L.score + int32_t(s) + T.lo[2] + j, int32_t(e[2 + j]));
+    }
 }
 
 // M: up to 64 queued rows with a value outside their fields -- taken from the general tables (i32).
@@ -265,8 +300,9 @@ __device__ __forceinline__ void replay_m(const PackedView& K, const PatternTable
 }
 
 // W replays until at most `mark` items are left (a W item becomes at most one W item, so the loop ends).
+template <int WL>
 __device__ __forceinline__ void drain_w(const PackedView& K, FastLds& L, WaveStacks& Q, int lane, uint32_t mark) {
-    while (Q.nw > mark) replay_w(K, L, Q, lane);
+    while (Q.nw > mark) replay_w<WL>(K, L, Q, lane);
 }
 
 // optional phase timing (VPT_PROFILE_PHASES): wave 0 of every workgroup adds the shader cycles it spent per phase
@@ -278,15 +314,18 @@ __device__ __forceinline__ uint64_t phase_mark(uint64_t* prof, int slot, uint64_
 }
 
 // DBG: the diagnostics build (VPT_DEBUG_ABLATE timing ablations, VPT_PROFILE_PHASES) -- compiled out of the kernel
-// production launches use.
-template <int TM, bool DBG>
-__global__ __launch_bounds__(kThreads, kFastWg) void score_tiles_fast_kernel(const ScoreParams P_in) {
+// production launches use.  WL: the row window of the packed tables (layout.h); TM: where the type scores come from.
+template <int WL, int TM, bool DBG>
+__global__ __launch_bounds__(kThreads, fast_wg(WL)) void score_tiles_fast_kernel(const ScoreParams P_in) {
+    using G = FastGeom<WL>;
+    constexpr uint32_t kPad = G::kPadG, kDump = G::kDump;
+    constexpr int kFastCap = G::kCapG, kSymSlots = G::kSymSlots, kPerThread = G::kPerThread;
+    constexpr int kNU = pk_uni_fields(WL), kNB = pk_bi_fields(WL), kNT = pk_tri_fields(WL);
     ScoreParams P = P_in;
     if (!DBG) { P.debug = 0; P.prof = nullptr; }
     VPT_DYNAMIC_LDS(smem);
-    FastLdsT& M = *reinterpret_cast<FastLdsT*>(smem);
+    FastLdsT<WL>& M = *reinterpret_cast<FastLdsT<WL>*>(smem);
     FastLds L{M.sym, M.score};
-    constexpr int kPerThread = kFastCap / kThreads;
     const int tid = threadIdx.x, lane = tid & 63, wave = int(wave_uniform(uint32_t(tid) >> 6));
     const uint32_t wbase = uint32_t(wave) << 6;   // this wave's first thread, as a scalar
 
@@ -310,7 +349,7 @@ __global__ __launch_bounds__(kThreads, kFastWg) void score_tiles_fast_kernel(con
         const uint64_t i1 = P.tile_first[blockIdx.x + 1];
         if (i0 >= i1) return;      // no sentence starts in this tile's range
         const uint64_t O0 = P.ooff[i0], O1 = P.ooff[i1], B0 = P.boff[i0], B1 = P.boff[i1];
-        const uint64_t fl = uint64_t(kPad) + (O1 + i1 * 4) - (O0 + i0 * 4);
+        const uint64_t fl = uint64_t(kPad) + (O1 + i1 * (kPad + 1)) - (O0 + i0 * (kPad + 1));
         if (O1 < O0 || B1 <= B0 || fl > uint64_t(kFastCap) || B1 - B0 > uint64_t(kFastCap) * 4 + 15 || i1 - i0 > 1023) {
             if (tid == 0) atomicOr(P.status, kErrScratchTooSmall);   // a sentence longer than the caller's bound (or offsets that are no offsets)
             return;
@@ -329,6 +368,7 @@ __global__ __launch_bounds__(kThreads, kFastWg) void score_tiles_fast_kernel(con
     uint32_t err = 0;
     uint64_t* const prof = P.prof;
     uint64_t tmark = prof ? __builtin_amdgcn_s_memtime() : 0;
+    const bool trow_lds = TM == kTypeRows && P.pk.trow_mode == kTypeRowsLds;   // wave-uniform (a kernel argument)
 
     // ---------------------------------------------------------------- A. decode
     // Flat layout: lead number ci of the staged text, in the tile's sentence si, sits at c_off + ci + kPad * si; everything else is
@@ -350,16 +390,9 @@ __global__ __launch_bounds__(kThreads, kFastWg) void score_tiles_fast_kernel(con
     }
     for (uint32_t c = tid; c < nchunks; c += kThreads) reinterpret_cast<uint4*>(raw)[c] = reinterpret_cast<const uint4*>(a0)[c];   // (non-temporal loads / stores here measured 1-2 % slower: profiles/r02_c1_ab.jsonl, r02_c3_ab.jsonl)
     if (tid == 0) raw[nchunks * 4] = 0;  // the dword after the staged text is read (as padding) by the last char
-    // the LDS-resident tables: type rows, char cache, unigram cache (coalesced 16-byte loads from the predictor's arena)
-    if (TM == kTypeRows) {
-        for (uint32_t i = tid; i < uint32_t(kTrowCount); i += kThreads) M.trow[i] = ld16(P.pk.base, P.pk.off_trow + (i << 4));
-    }
-    if (kFastCharCache) {
-        for (uint32_t i = tid; i < uint32_t(kFastCharCache) / 4; i += kThreads) reinterpret_cast<uint4*>(M.cc)[i] = ld16(P.pk.base, P.pk.off_cc + (i << 4));
-    }
-    if (kFastUniCache) {
-        for (uint32_t i = tid; i < uint32_t(kFastUniCache); i += kThreads) M.urow[i] = ld16(P.pk.base, P.pk.off_urow + (i << 4));
-        for (uint32_t i = tid; i < uint32_t(kFastUniCache) / 8; i += kThreads) reinterpret_cast<uint4*>(M.utag)[i] = ld16(P.pk.base, P.pk.off_utag + (i << 4));
+    // the LDS-resident type rows (coalesced 16-byte loads from the predictor's arena)
+    if (trow_lds) {
+        for (uint32_t i = tid; i < uint32_t(kTrowCount * G::kTrowQ); i += kThreads) M.trow[i] = ld16(P.pk.base, P.pk.off_trow + (i << 4));
     }
     __syncthreads();
     tmark = phase_mark(prof, 0, tmark);   // zeroing, staging, table loads
@@ -408,8 +441,7 @@ __global__ __launch_bounds__(kThreads, kFastWg) void score_tiles_fast_kernel(con
         base_starts += total >> 16;
         __syncthreads();   // wtot is rewritten by the next pass
         uint32_t m = lm;
-        int32_t fb = c_off + int32_t(ci) + 3 * sib;               // flat = c_off + char index + kPad * sentence
-        static_assert(kPad == 3, "fb adds 3 * sib");
+        int32_t fb = c_off + int32_t(ci) + int32_t(kPad) * sib;   // flat = c_off + char index + kPad * sentence
         // Every round takes one char per lane; a three-byte sequence (Japanese text mostly is) decodes with five instructions.
         while (m != 0) {   // (a loop every lane stays in until the wave's last char, with the idle lanes writing the dump slot, measured
             const bool has = true;   //  0.5 % slower: profiles/r03_j_ab_m1.jsonl)
@@ -424,7 +456,7 @@ __global__ __launch_bounds__(kThreads, kFastWg) void score_tiles_fast_kernel(con
             } else {
                 cp = utf8_scalar_bf(w);
             }
-            const int32_t p = fb + 3 * int32_t(r);
+            const int32_t p = fb + int32_t(kPad) * int32_t(r);
             if (has) {
                 ++fb;
                 min_lead = (w & 0xFFu) < min_lead ? (w & 0xFFu) : min_lead;
@@ -440,33 +472,17 @@ __global__ __launch_bounds__(kThreads, kFastWg) void score_tiles_fast_kernel(con
     tmark = phase_mark(prof, 2, tmark);   // chunk scan + decode rounds
     __syncthreads();  // the staged text has been read: the score array can be zeroed; every char is in place
     for (uint32_t i = tid; i < (span + 3) / 4; i += kThreads) reinterpret_cast<uint4*>(L.score)[i] = make_uint4(0, 0, 0, 0);
-    {   // classify: cache probes first, then the table reads of every miss (all in flight together), then the final symbols
+    {   // classify: one word of the char table per char (all of a thread's reads in flight together), then the final symbols
         uint32_t xs[kPerThread], info[kPerThread];
-        bool miss[kPerThread];
-        bool any_miss = false;
 #pragma unroll
         for (int k = 0; k < kPerThread; ++k) {
-            xs[k] = 0; info[k] = 0; miss[k] = false;
+            xs[k] = 0; info[k] = 0;
             if (wbase + uint32_t(k) * kThreads >= flat_len) continue;   // wave-uniform
             xs[k] = L.sym[uint32_t(tid) + uint32_t(k) * kThreads];
             const uint32_t cp = xs[k] & 0x1FFFFFu;
-            // id of the char it is scored as | CharacterType << 16 | linebreak << 29: from the char cache, else one word of a 256 KB
-            // table (plain, or -- with VPT_FLAG_KYTEA_FULLWIDTH -- the one that looks through KyteaFullwidthFilter)
-            bool hit = cp == 0;   // a separator: no lookup at all
-            if (kFastCharCache) {
-                const uint32_t e = M.cc[cp & uint32_t(kFastCharCache - 1)];
-                if ((e >> 16) == cp && cp != 0 && !(DBG && (P.debug & 256u))) { hit = true; info[k] = (e & 0x1FFFu) | ((e << 3) & 0x70000u); }
-            }
-            if (DBG && (P.debug & 64u) && !hit && (cp & 7u) != 0) { hit = true; info[k] = P.cid[0x3042]; }   // timing ablation: one gather in eight (the others: one line)
-            miss[k] = !hit;
-            any_miss = any_miss || !hit;
-        }
-        if (__ballot(any_miss) != 0) {
-#pragma unroll
-            for (int k = 0; k < kPerThread; ++k) {
-                const uint32_t cp = xs[k] & 0x1FFFFFu;
-                if (miss[k]) info[k] = P.cid[cp < 0x10000u ? cp : 0u];
-            }
+            // id of the char it is scored as | CharacterType << 16 | linebreak << 29: one word of a 256 KB table (plain, or -- with
+            // VPT_FLAG_KYTEA_FULLWIDTH -- the one that looks through KyteaFullwidthFilter); a separator asks for nothing
+            if (cp != 0) info[k] = P.cid[cp < 0x10000u ? cp : 0u];
         }
 #pragma unroll
         for (int k = 0; k < kPerThread; ++k) {
@@ -482,7 +498,7 @@ __global__ __launch_bounds__(kThreads, kFastWg) void score_tiles_fast_kernel(con
             if (P.cps_out) {   // wave-uniform: a fill_tags call on this batch follows and wants the chars decoded (it then skips its own pass)
                 const uint32_t scored = (P.cinfo && cp < 0x10000u) ? (P.cinfo[cp] & 0xFFFFu) : cp;   // through KyteaFullwidthFilter when that flag is on
                 if (cp != 0 && pos >= own_lo && pos < own_hi) {
-                    const uint64_t at = g0 + uint64_t(int64_t(int32_t(pos) - c_off - 3 * int32_t(si)));
+                    const uint64_t at = g0 + uint64_t(int64_t(int32_t(pos) - c_off - int32_t(kPad) * int32_t(si)));
                     if (at < P.total_chars) P.cps_out[at] = scored | (((v >> 16) & 7u) << 24);
                     else err |= kErrBadOffsets;   // out_offsets that run past the total the caller stated
                 }
@@ -496,7 +512,7 @@ __global__ __launch_bounds__(kThreads, kFastWg) void score_tiles_fast_kernel(con
     // falls into the tile's window.  (A sentence longer or shorter than stated moves everything behind it.)
     for (uint32_t j = tid; j < nsent; j += kThreads) {
         const uint64_t oa = j == uint32_t(tid) ? my_oa : P.ooff[i0 + j], ob = j == uint32_t(tid) ? my_ob : P.ooff[i0 + j + 1];
-        const int64_t e = int64_t(c_off) + int64_t(oa + i0 + j - g0) + 3 * int64_t(j);
+        const int64_t e = int64_t(c_off) + int64_t(oa + i0 + j - g0) + int64_t(kPad) * int64_t(j);
         const int64_t end = e + int64_t(ob - oa) + 1;
         if (ob < oa) err |= kErrBadOffsets;
         if (e >= int64_t(kPad) && e < int64_t(flat_len)) {
@@ -515,124 +531,6 @@ __global__ __launch_bounds__(kThreads, kFastWg) void score_tiles_fast_kernel(con
     const PackedView& K = P.pk;
     WaveStacks Q{&M.queue[wave][0], &M.mqueue[wave][0], 0u, 0u};
     const uint32_t off_bi = K.off_bi & ~255u, off_tri = K.off_tri & ~255u;   // they ARE 256-byte aligned (capi.cpp); now the compiler knows
-#if VPT_FAST_STAGED
-    // STAGE-MAJOR: all of a lane's kPerThread positions go through a level together -- every unigram node in one trip to memory,
-    // then every bigram node, then every trigram node: three waits per tile instead of kPerThread + 2, at the price of the
-    // registers that hold a level's nodes (occupancy kFastWg below 8).
-    if (!(P.debug & 16u)) {   // (timing ablation: no pattern phase at all)
-        uint32_t b_slot[kPerThread], b_key[kPerThread], b_id3[kPerThread];
-        {   // ---- unigram level
-            uint4 u[kPerThread];
-#pragma unroll
-            for (int k = 0; k < kPerThread; ++k) {
-                u[k] = make_uint4(0, 0, 0, 0);
-                if (wbase + uint32_t(k) * kThreads >= flat_len) continue;   // wave-uniform
-                const uint32_t id1 = L.sym[uint32_t(tid) + uint32_t(k) * kThreads] & kCpMask;
-                bool want = id1 != 0 && id1 != kNoId;   // a char no pattern contains has no unigram node (its row is zero, its base unused)
-                if (kFastUniCache) {
-                    const uint32_t slot = id1 & uint32_t(kFastUniCache - 1);
-                    if (want && uint32_t(M.utag[slot]) == id1) { u[k] = M.urow[slot]; want = false; }
-                }
-                if (want) u[k] = ld16(K.base, K.off_uni + (id1 << 4));
-            }
-#pragma unroll
-            for (int k = 0; k < kPerThread; ++k) {
-                b_key[k] = 0; b_slot[k] = 0; b_id3[k] = 0;
-                if (wbase + uint32_t(k) * kThreads >= flat_len) continue;   // wave-uniform
-                const uint32_t s_u = uint32_t(tid) + uint32_t(k) * kThreads;
-                const uint32_t x1 = L.sym[s_u], x2 = L.sym[s_u + 1], x3 = L.sym[s_u + 2];   // the array is zero past the tile
-                const uint32_t id1 = x1 & kCpMask, id2 = x2 & kCpMask;
-                const bool live = id1 != 0;
-                // six 18-bit fields at bits 0, 18, 36, 54, 72, 90 (layout.h); bits 108..126 = the base of the bigram nodes; bit 127 = wide
-                int32_t a0 = sext(u[k].x, kUniFieldBits), a1 = sext(__builtin_amdgcn_alignbit(u[k].y, u[k].x, 18), kUniFieldBits);
-                int32_t a2 = sext(u[k].y >> 4, kUniFieldBits), a3 = sext(__builtin_amdgcn_alignbit(u[k].z, u[k].y, 22), kUniFieldBits);
-                int32_t a4 = sext(u[k].z >> 8, kUniFieldBits), a5 = sext(__builtin_amdgcn_alignbit(u[k].w, u[k].z, 26), kUniFieldBits);
-                if (TM == kTypeRows) {
-                    // a dead lane (t1 = 0) reads the 16 bytes in front of the rows; nothing is added for it
-                    const uint4 tr = M.trow[int32_t(type_row_index((x1 >> 16) & 7u, (x2 >> 16) & 7u, (x3 >> 16) & 7u))];
-                    a0 += int32_t(tr.x << 14) >> 14;
-                    a1 += int32_t(__builtin_amdgcn_alignbit(tr.y, tr.x, 18) << 14) >> 14;
-                    a2 += int32_t(tr.y << 10) >> 14;
-                    a3 += int32_t(__builtin_amdgcn_alignbit(tr.z, tr.y, 22) << 14) >> 14;
-                    a4 += int32_t(tr.z << 6) >> 14;
-                    a5 += int32_t(__builtin_amdgcn_alignbit(tr.w, tr.z, 26) << 14) >> 14;
-                }
-                if (live) add_row6(L.score, s_u, a0, a1, a2, a3, a4, a5);
-                b_slot[k] = id2 < kBiDenseCols ? id1 * kBiDenseCols + id2 : (((u[k].w >> kUniBaseShift) & kUniBaseMask) << K.bi_shift) + id2;
-                b_key[k] = (live && id1 != kNoId && id2 != 0 && id2 != kNoId) ? (id1 | (id2 << 16)) : 0u;
-                b_id3[k] = x3 & kCpMask;
-                const uint64_t mm = __ballot(live && (u[k].w & kUniWideBit));
-                if (mm != 0) {
-                    while (Q.nm + uint32_t(__popcll(mm)) > uint32_t(kMCap)) replay_m(K, P.ct, L, Q, lane);
-                    Q.push_m(live && (u[k].w & kUniWideBit), s_u | (kWideUni << 11));
-                }
-            }
-        }
-        uint32_t t_slot[kPerThread];
-        {   // ---- bigram level: key check, the row, and the address of the trigram node
-            uint4 n0[kPerThread], n1[kPerThread];
-#pragma unroll
-            for (int k = 0; k < kPerThread; ++k) {
-                n0[k] = make_uint4(0, 0, 0, 0); n1[k] = n0[k];
-                if (wbase + uint32_t(k) * kThreads >= flat_len) continue;   // wave-uniform
-                if (b_key[k] != 0) {
-                    const uint32_t a = off_bi + (b_slot[k] << 5);
-                    n0[k] = ld16(K.base, a); n1[k] = ld16(K.base, a | 16u);
-                }
-            }
-#pragma unroll
-            for (int k = 0; k < kPerThread; ++k) {
-                t_slot[k] = ~0u;
-                if (wbase + uint32_t(k) * kThreads >= flat_len) continue;   // wave-uniform
-                const uint32_t s_b = uint32_t(tid) + uint32_t(k) * kThreads;
-                const bool keyok = b_key[k] != 0 && n0[k].x == b_key[k];
-                if (keyok) {
-                    // five 19-bit fields at bits 0, 19, 38, 57, 76 of dwords 1..3 (layout.h); bit 95 = the row is wide (M stack)
-                    int32_t* p = L.score + s_b - 2;
-                    atomicAdd(p, sext(n0[k].y, kBiFieldBits));
-                    atomicAdd(p + 1, sext(__builtin_amdgcn_alignbit(n0[k].z, n0[k].y, 19), kBiFieldBits));
-                    atomicAdd(p + 2, sext(n0[k].z >> 6, kBiFieldBits));
-                    atomicAdd(p + 3, sext(__builtin_amdgcn_alignbit(n0[k].w, n0[k].z, 25), kBiFieldBits));
-                    atomicAdd(p + 4, sext(n0[k].w >> 12, kBiFieldBits));
-                }
-                const uint32_t bit = packed_filter_bit(b_id3[k]);
-                const bool cont = keyok && b_id3[k] != 0 && b_id3[k] != kNoId && (((bit < 32 ? n1[k].y >> bit : n1[k].z >> (bit - 32)) & 1u) != 0);
-                const uint32_t ts = n1[k].x + b_id3[k];         // modulo 2^32 (layout.h); a false positive of the filter may point anywhere
-                t_slot[k] = (cont && ts < K.n_tri) ? ts : ~0u;
-                const uint64_t mm = __ballot(keyok && (n0[k].w & kBiWideBit));
-                if (mm != 0) {
-                    while (Q.nm + uint32_t(__popcll(mm)) > uint32_t(kMCap)) replay_m(K, P.ct, L, Q, lane);
-                    Q.push_m(keyok && (n0[k].w & kBiWideBit), s_b | (kWideBi << 11));
-                }
-            }
-        }
-        {   // ---- trigram level: the node is ours if it names our bigram node as its parent
-            uint4 tn[kPerThread];
-#pragma unroll
-            for (int k = 0; k < kPerThread; ++k) {
-                tn[k] = make_uint4(0, 0, 0, 0);
-                if (wbase + uint32_t(k) * kThreads >= flat_len) continue;   // wave-uniform
-                if (t_slot[k] != ~0u) tn[k] = ld16(K.base, off_tri + (t_slot[k] << 4));
-            }
-#pragma unroll
-            for (int k = 0; k < kPerThread; ++k) {
-                if (wbase + uint32_t(k) * kThreads >= flat_len) continue;   // wave-uniform
-                const uint32_t s_t = uint32_t(tid) + uint32_t(k) * kThreads;
-                const bool hit = t_slot[k] != ~0u && (tn[k].x & kTriParentMask) == b_slot[k] + 1u;
-                if (hit) add_child(L.score, s_t, tn[k].y, tn[k].z);   // a kPkWide node holds zero weights
-                const bool wide = hit && (tn[k].x & (kPkWide << kTriFlagShift));
-                uint32_t kids = hit ? tn[k].w : 0u;
-                drain_w(K, L, Q, lane, kQHigh);                 // room for one more round of pushes
-                Q.push_w(kids != 0, s_t | (3u << 11), kids);
-                const uint64_t mm = __ballot(wide);
-                if (mm != 0) {
-                    while (Q.nm + uint32_t(__popcll(mm)) > uint32_t(kMCap)) replay_m(K, P.ct, L, Q, lane);
-                    Q.push_m(wide, s_t | (kWideTri << 11));
-                }
-            }
-        }
-    }
-#else
     uint32_t b_slot = 0, b_key = 0, b_id3 = 0;   // next trip's bigram stage: node slot, its key (0: no bigram starts there), id of the third char
     uint32_t t_slot = ~0u, t_par = 0;            // this trip's trigram stage: node slot (~0: none) and parent slot + 1
     for (int j = -2; j < kPerThread; ++j) {
@@ -644,13 +542,26 @@ __global__ __launch_bounds__(kThreads, kFastWg) void score_tiles_fast_kernel(con
         if (!do_t && !do_b && !do_u) break;
         const uint32_t s_t = uint32_t(tid) + uint32_t(j) * kThreads, s_b = s_t + kThreads, s_u = s_b + kThreads;
         // ---- every load first; only lanes that can match issue one
-        uint4 tn = make_uint4(0, 0, 0, 0), n0 = make_uint4(0, 0, 0, 0), n1 = make_uint4(0, 0, 0, 0), u = make_uint4(0, 0, 0, 0);
+        uint4 tn[G::kTriQ], nn[G::kBiQ], un[G::kUniQ];
+#pragma unroll
+        for (int q = 0; q < G::kTriQ; ++q) tn[q] = make_uint4(0, 0, 0, 0);
+#pragma unroll
+        for (int q = 0; q < G::kBiQ; ++q) nn[q] = make_uint4(0, 0, 0, 0);
+#pragma unroll
+        for (int q = 0; q < G::kUniQ; ++q) un[q] = make_uint4(0, 0, 0, 0);
         uint32_t x1 = 0, x2 = 0, x3 = 0;
-        if (do_t) { if (t_slot != ~0u) tn = ld16(K.base, off_tri + (((P.debug & 1u) ? 0u : t_slot) << 4)); }
+        if (do_t) {
+            if (t_slot != ~0u) {
+                const uint32_t a = off_tri + (((P.debug & 1u) ? 0u : t_slot) * uint32_t(4 * pk_tri_dw(WL)));
+#pragma unroll
+                for (int q = 0; q < G::kTriQ; ++q) tn[q] = ld16(K.base, a + 16u * uint32_t(q));
+            }
+        }
         if (do_b) {
             if (b_key != 0) {
-                const uint32_t a = off_bi + (((P.debug & 1u) ? 0u : b_slot) << 5);
-                n0 = ld16(K.base, a); n1 = ld16(K.base, a | 16u);
+                const uint32_t a = off_bi + (((P.debug & 1u) ? 0u : b_slot) * uint32_t(4 * pk_bi_dw(WL)));
+#pragma unroll
+                for (int q = 0; q < G::kBiQ; ++q) nn[q] = ld16(K.base, a | (16u * uint32_t(q)));
             }
         }
         bool live = false;
@@ -658,24 +569,32 @@ __global__ __launch_bounds__(kThreads, kFastWg) void score_tiles_fast_kernel(con
             x1 = L.sym[s_u]; x2 = L.sym[s_u + 1]; x3 = L.sym[s_u + 2];   // the array is zero past the tile; s_u + 2 < kSymSlots
             const uint32_t id1 = x1 & kCpMask;
             live = id1 != 0;
-            bool want = live && id1 != kNoId;   // a char no pattern contains has no unigram node (its row is zero, its base unused)
-            if (kFastUniCache) {
-                const uint32_t slot = id1 & uint32_t(kFastUniCache - 1);
-                if (want && uint32_t(M.utag[slot]) == id1 && !(DBG && (P.debug & 512u))) { u = M.urow[slot]; want = false; }
-            }
-            if (DBG && (P.debug & 128u)) want = want && (id1 & 3u) == 0;   // timing ablation: one unigram node in four
+            const bool want = live && id1 != kNoId;   // a char no pattern contains has no unigram node (its row is zero, its base unused)
             if (__ballot(want) != 0) {
-                if (want) u = ld16(K.base, K.off_uni + (((P.debug & 4u) ? 0u : id1) << 4));
+                if (want) {
+                    const uint32_t a = K.off_uni + (((P.debug & 4u) ? 0u : id1) * uint32_t(4 * pk_uni_dw(WL)));
+#pragma unroll
+                    for (int q = 0; q < G::kUniQ; ++q) un[q] = ld16(K.base, a + 16u * uint32_t(q));
+                }
             }
         }
         // ---- trigram stage of positions s_t: the node is ours if it names our bigram node as its parent
         if (do_t) {
-            const bool hit = t_slot != ~0u && (tn.x & kTriParentMask) == t_par;
-            if (hit) add_child(L.score, s_t, tn.y, tn.z);   // a kPkWide node holds zero weights
-            const bool wide = hit && (tn.x & (kPkWide << kTriFlagShift));
-            uint32_t kids = hit ? tn.w : 0u;
+            uint32_t td[4 * G::kTriQ + 1];
+            unpack4(tn, td);
+            const bool hit = t_slot != ~0u && (td[0] & kTriParentMask) == t_par;
+            if (hit) {   // 2 WL - 2 weights of 16 bits from boundary s - WL + 2 (a kPkWide node holds zero weights)
+                int32_t* p = L.score + s_t - uint32_t(WL - 2);
+#pragma unroll
+                for (int q = 0; q < kNT; q += 2) {
+                    const uint32_t w = td[pk_tri_w_dw(WL) + q / 2];
+                    atomicAdd(p + q, lo16(w)); atomicAdd(p + q + 1, hi16(w));
+                }
+            }
+            const bool wide = hit && (td[0] & (kPkWide << kTriFlagShift));
+            uint32_t kids = hit ? td[pk_tri_kids_dw(WL)] : 0u;
             VPT_PIN(kids);
-            drain_w(K, L, Q, lane, kQHigh);                 // room for one more round of pushes
+            drain_w<WL>(K, L, Q, lane, kQHigh);                 // room for one more round of pushes
             Q.push_w(kids != 0 && !(P.debug & 8u), s_t | (3u << 11), kids);
             const uint64_t mm = __ballot(wide);
             if (mm != 0) {
@@ -686,61 +605,83 @@ __global__ __launch_bounds__(kThreads, kFastWg) void score_tiles_fast_kernel(con
         // ---- bigram stage of positions s_b: key check, the row, and the address of the trigram node
         t_slot = ~0u;
         if (do_b) {
-            const bool keyok = b_key != 0 && n0.x == b_key;
-            if (keyok) {
-                // five 19-bit fields at bits 0, 19, 38, 57, 76 of dwords 1..3 (layout.h); bit 95 = the row is wide (M stack)
-                int32_t* p = L.score + s_b - 2;
-                atomicAdd(p, sext(n0.y, kBiFieldBits));
-                atomicAdd(p + 1, sext(__builtin_amdgcn_alignbit(n0.z, n0.y, 19), kBiFieldBits));
-                atomicAdd(p + 2, sext(n0.z >> 6, kBiFieldBits));
-                atomicAdd(p + 3, sext(__builtin_amdgcn_alignbit(n0.w, n0.z, 25), kBiFieldBits));
-                atomicAdd(p + 4, sext(n0.w >> 12, kBiFieldBits));
+            uint32_t nd[4 * G::kBiQ + 1];
+            unpack4(nn, nd);
+            const bool keyok = b_key != 0 && nd[pk_bi_key_dw(WL)] == b_key;
+            const uint32_t* const rowd = nd + pk_bi_row_dw(WL);
+            if (keyok) {   // 2 WL - 1 fields of 19 bits from boundary s - WL + 1; behind them the wide flag (the row then holds zeros: M stack)
+                int32_t* p = L.score + s_b - uint32_t(WL - 1);
+                each_field<0, kNB, kBiFieldBits>(rowd, [&](int f, int32_t v) { atomicAdd(p + f, v); });
             }
             const uint32_t bit = packed_filter_bit(b_id3);
-            const bool cont = keyok && b_id3 != 0 && b_id3 != kNoId && (((bit < 32 ? n1.y >> bit : n1.z >> (bit - 32)) & 1u) != 0);
-            const uint32_t ts = n1.x + b_id3;               // modulo 2^32 (layout.h); a false positive of the filter may point anywhere
+            const uint32_t flo = nd[pk_bi_filter_dw(WL)], fhi = nd[pk_bi_filter_dw(WL) + 1];
+            const bool cont = keyok && b_id3 != 0 && b_id3 != kNoId && (((bit < 32 ? flo >> bit : fhi >> (bit - 32)) & 1u) != 0);
+            const uint32_t ts = nd[pk_bi_base_dw(WL)] + b_id3;   // modulo 2^32 (layout.h); a false positive of the filter may point anywhere
             t_slot = (cont && ts < K.n_tri && !(P.debug & 2u)) ? ts : ~0u;
             t_par = b_slot + 1u;
-            const uint64_t mm = __ballot(keyok && (n0.w & kBiWideBit));
+            const bool bwide = keyok && ufield<pk_bi_wide_bit(WL), 1>(rowd) != 0;
+            const uint64_t mm = __ballot(bwide);
             if (mm != 0) {
                 while (Q.nm + uint32_t(__popcll(mm)) > uint32_t(kMCap)) replay_m(K, P.ct, L, Q, lane);
-                Q.push_m(keyok && (n0.w & kBiWideBit), s_b | (kWideBi << 11));
+                Q.push_m(bwide, s_b | (kWideBi << 11));
             }
         }
         // ---- unigram stage of positions s_u: the row (+ the type row), and the address of the bigram node
         b_key = 0;
         if (do_u) {
+            uint32_t ud[4 * G::kUniQ + 1];
+            unpack4(un, ud);
             const uint32_t id1 = x1 & kCpMask, id2 = x2 & kCpMask;
-            // six 18-bit fields at bits 0, 18, 36, 54, 72, 90 (layout.h); bits 108..126 = the base of the bigram nodes; bit 127 = wide
-            int32_t a0 = sext(u.x, kUniFieldBits), a1 = sext(__builtin_amdgcn_alignbit(u.y, u.x, 18), kUniFieldBits);
-            int32_t a2 = sext(u.y >> 4, kUniFieldBits), a3 = sext(__builtin_amdgcn_alignbit(u.z, u.y, 22), kUniFieldBits);
-            int32_t a4 = sext(u.z >> 8, kUniFieldBits), a5 = sext(__builtin_amdgcn_alignbit(u.w, u.z, 26), kUniFieldBits);
+            // 2 WL fields of 18 bits from boundary s - WL; behind them the base of the bigram nodes (19 bits) and the wide flag
+            int32_t a[kNU];
+            each_field<0, kNU, kUniFieldBits>(ud, [&](int f, int32_t v) { a[f] = v; });
             if (TM == kTypeRows) {
-                // a dead lane (t1 = 0) reads the 16 bytes in front of the rows; nothing is added for it
-                const uint4 tr = M.trow[int32_t(type_row_index((x1 >> 16) & 7u, (x2 >> 16) & 7u, (x3 >> 16) & 7u))];
-                // six 18-bit signed fields at bits 0, 18, 36, 54, 72, 90 (layout.h, trow_field)
-                a0 += int32_t(tr.x << 14) >> 14;
-                a1 += int32_t(__builtin_amdgcn_alignbit(tr.y, tr.x, 18) << 14) >> 14;
-                a2 += int32_t(tr.y << 10) >> 14;
-                a3 += int32_t(__builtin_amdgcn_alignbit(tr.z, tr.y, 22) << 14) >> 14;
-                a4 += int32_t(tr.z << 6) >> 14;
-                a5 += int32_t(__builtin_amdgcn_alignbit(tr.w, tr.z, 26) << 14) >> 14;
+                if (trow_lds) {   // (wave-uniform)
+                    // a dead lane (t1 = 0) reads in front of the rows; nothing is added for it
+                    const int32_t ri = int32_t(type_row_index((x1 >> 16) & 7u, (x2 >> 16) & 7u, (x3 >> 16) & 7u)) * G::kTrowQ;
+                    uint4 tr[G::kTrowQ];
+#pragma unroll
+                    for (int q = 0; q < G::kTrowQ; ++q) tr[q] = M.trow[ri + q];
+                    uint32_t rd[4 * G::kTrowQ + 1];
+                    unpack4(tr, rd);
+                    each_field<0, kNU, kUniFieldBits>(rd, [&](int f, int32_t v) { a[f] += v; });
+                } else {
+                    // rows of i32 in global memory, indexed by the types of s .. s + levels - 1 (layout.h, "TYPE ROWS"; the array is zero past the
+                    // tile: code 0 ends the prefix)
+                    uint32_t idx = 0;
+                    for (int32_t i = int32_t(K.trow_levels) - 1; i >= 3; --i) idx = idx * 7u + ((L.sym[s_u + uint32_t(i)] >> 16) & 7u);
+                    idx = (idx * 7u + ((x3 >> 16) & 7u)) * 7u + ((x2 >> 16) & 7u);
+                    idx = idx * 6u + (((x1 >> 16) & 7u) - 1u);
+                    if (live) {
+                        const uint32_t ra = K.off_trow + idx * uint32_t(4 * pk_trow_global_dw(WL));
+                        uint4 tr[pk_trow_global_dw(WL) / 4];
+#pragma unroll
+                        for (int q = 0; q < pk_trow_global_dw(WL) / 4; ++q) tr[q] = ld16(K.base, ra + 16u * uint32_t(q));
+                        uint32_t rd[pk_trow_global_dw(WL) + 1];
+                        unpack4(tr, rd);
+#pragma unroll
+                        for (int f = 0; f < kNU; ++f) a[f] += int32_t(rd[f]);
+                    }
+                }
             }
-            if (live) add_row6(L.score, s_u, a0, a1, a2, a3, a4, a5);
-            // the node of a frequent second char sits in the dense matrix, any other in the first char's displaced row (layout.h)
-            b_slot = id2 < kBiDenseCols ? id1 * kBiDenseCols + id2 : (((u.w >> kUniBaseShift) & kUniBaseMask) << K.bi_shift) + id2;
+            if (live) {
+                int32_t* p = L.score + s_u - uint32_t(WL);
+#pragma unroll
+                for (int f = 0; f < kNU; ++f) atomicAdd(p + f, a[f]);
+            }
+            b_slot = (ufield<pk_uni_base_bit(WL), kUniBaseBits>(ud) << K.bi_shift) + id2;
             b_key = (live && id1 != kNoId && id2 != 0 && id2 != kNoId) ? (id1 | (id2 << 16)) : 0u;
             b_id3 = x3 & kCpMask;
-            const uint64_t mm = __ballot(live && (u.w & kUniWideBit) && !(P.debug & 32u));
+            const bool uwide = live && ufield<pk_uni_base_bit(WL) + kUniBaseBits, 1>(ud) != 0 && !(P.debug & 32u);
+            const uint64_t mm = __ballot(uwide);
             if (mm != 0) {
                 while (Q.nm + uint32_t(__popcll(mm)) > uint32_t(kMCap)) replay_m(K, P.ct, L, Q, lane);
-                Q.push_m(live && (u.w & kUniWideBit), s_u | (kWideUni << 11));
+                Q.push_m(uwide, s_u | (kWideUni << 11));
             }
         }
     }
-#endif
     while (Q.nm > 0) replay_m(K, P.ct, L, Q, lane);
-    while (Q.nw > 0) replay_w(K, L, Q, lane);
+    while (Q.nw > 0) replay_w<WL>(K, L, Q, lane);
     tmark = phase_mark(prof, 4, tmark);   // patterns
     __syncthreads();
     tmark = phase_mark(prof, 5, tmark);   // waiting for the other waves
@@ -784,9 +725,10 @@ __global__ __launch_bounds__(kThreads, kFastWg) void score_tiles_fast_kernel(con
 }
 
 // ------------------------------------------------------------------------------------------------------------
-// The tiles.  F(i) = ooff[i] + i * (1 + kPad) is the flat position of sentence i's first separator; its chars follow at F(i) + kPad.
+// The tiles.  F(i) = ooff[i] + i * (1 + pad) is the flat position of sentence i's first separator; its chars follow at F(i) + pad
+// (pad = the separator slots of the kernel instance, pk_pad(wl)).
 // ------------------------------------------------------------------------------------------------------------
-constexpr uint32_t kStageBytes = uint32_t(kFastCap) * 4 + 15;   // what a tile may stage besides its alignment head
+__host__ __device__ constexpr uint32_t stage_bytes(uint32_t cap) { return cap * 4 + 15; }   // what a tile may stage besides its alignment head
 
 __device__ __forceinline__ void put_desc(TileDesc* out, const TileDesc& d) {
     const uint4* s = reinterpret_cast<const uint4*>(&d);
@@ -888,7 +830,7 @@ __device__ __forceinline__ uint64_t last_block_le(const CutIndex& X, uint64_t lo
     return a;
 }
 
-// One thread per tile.  Tile t writes the boundaries at flat positions [t * TF, (t + 1) * TF); its window starts halo_left + kPad in front
+// One thread per tile.  Tile t writes the boundaries at flat positions [t * TF, (t + 1) * TF); its window starts halo_left + pad in front
 // (LDS position 0) and is cap_eff long.
 __global__ __launch_bounds__(256) void assign_tiles_cut_kernel(const uint64_t* __restrict__ boff, const uint64_t* __restrict__ ooff, uint64_t n_sent,
                                                                CutGeometry Gm, uint32_t n_tiles, const uint32_t* __restrict__ cut_local,
@@ -898,6 +840,7 @@ __global__ __launch_bounds__(256) void assign_tiles_cut_kernel(const uint64_t* _
     if (t == 1) ctrl[1] = 0;
     if (t >= n_tiles) return;
     TileDesc d{};
+    const uint64_t kPad = Gm.pad;
     const uint64_t step = 1 + kPad;
     auto F = [&](uint64_t i) { return ooff[i] + i * step; };
     const uint64_t total_flat = F(n_sent);
@@ -940,7 +883,7 @@ __global__ __launch_bounds__(256) void assign_tiles_cut_kernel(const uint64_t* _
         }
     }
     const uint64_t flat_len = last ? total_flat - uint64_t(base) : uint64_t(Gm.cap_eff);   // (base < total_flat: own0 < total_flat)
-    if (byte1 <= byte0 || byte1 - byte0 > uint64_t(kStageBytes) || flat_len > uint64_t(kFastCap) || i_hi - i_lo > 1023 || B_lo1 < B_lo) {
+    if (byte1 <= byte0 || byte1 - byte0 > uint64_t(stage_bytes(Gm.cap)) || flat_len > uint64_t(Gm.cap) || i_hi - i_lo > 1023 || B_lo1 < B_lo) {
         atomicOr(ctrl, kErrBadOffsets);   // only with offsets that do not match the text (4 bytes per char at most)
         put_desc(tiles + t, d);
         return;
@@ -949,7 +892,7 @@ __global__ __launch_bounds__(256) void assign_tiles_cut_kernel(const uint64_t* _
     d.byte0_lo = uint32_t(byte0); d.byte0_hi = uint32_t(byte0 >> 32); d.nbytes = uint32_t(byte1 - byte0);
     d.c_off = int32_t(int64_t(g0 + kPad * (i_lo + 1)) - base);   // char G of sentence i sits at global flat G + kPad * (i + 1)
     d.sib0 = byte0 > B_lo ? 0 : -1;
-    d.own_lo = Gm.halo_left + kPad;
+    d.own_lo = Gm.halo_left + uint32_t(kPad);
     d.own_hi = d.own_lo + Gm.tile_flat < uint32_t(flat_len) ? d.own_lo + Gm.tile_flat : uint32_t(flat_len);
     d.flat_len = uint32_t(flat_len);
     d.g0_lo = uint32_t(g0); d.g0_hi = uint32_t(g0 >> 32);
@@ -959,28 +902,71 @@ __global__ __launch_bounds__(256) void assign_tiles_cut_kernel(const uint64_t* _
 
 }  // namespace
 
-bool fast_path_supported(const ScoreParams& P) {
-    if (!P.pk.present || P.pad != int(kPad) || !P.cid) return false;
-    if (!P.ct.present || P.ct.stride_dw != 8 || P.ct.uni_dw != 8 || P.ct.uni_n != kUniDirectChars) return false;  // kPkWide rows
-    if (P.type_kind == kTypeNone) return true;
-    return P.type_kind == kTypeWindowTable && P.type_window >= 1 && P.type_window <= 3;
+// The instance that scores a predictor: its row window and where its type scores come from, or nothing (the general kernels).
+static bool fast_instance(const ScoreParams& P, int* wl_out, int* tm_out) {
+    if (!P.pk.present || !P.cid || P.pk.wl < 3 || P.pk.wl > uint32_t(kMaxWindow) || P.pad != pk_pad(int(P.pk.wl))) return false;
+    if (!P.ct.present || P.ct.uni_n != kUniDirectChars || P.ct.window != int32_t(P.pk.wl)) return false;   // the rows marked wide come from the general tables
+    const int wl = int(P.pk.wl);
+    int tm;
+    if (P.type_kind == kTypeNone) tm = 0;
+    else if (P.pk.trow_mode != kTypeRowsNone && !(P.force_window_table && P.type_kind == kTypeWindowTable && wl == 3)) tm = kTypeRows;
+    else if (P.type_kind == kTypeWindowTable && wl == 3 && P.type_window >= 1 && P.type_window <= 3) tm = P.type_window;
+    else return false;   // type n-grams outside the row forms with a window above 3 (or a row window above 3): the general kernels
+    if (tm == kTypeRows) {
+        if (P.pk.trow_mode == kTypeRowsLds ? P.pk.trow_levels != 3 : (P.pk.trow_levels < 3 || P.pk.trow_levels > uint32_t(kMaxTypeRowLevels))) return false;
+    }
+    if (wl_out) *wl_out = wl;
+    if (tm_out) *tm_out = tm;
+    return true;
 }
+bool fast_path_supported(const ScoreParams& P) { return fast_instance(P, nullptr, nullptr); }
+int fast_path_cap(const ScoreParams& P) { return fast_cap(int(P.pk.wl)); }
+int fast_path_wg(const ScoreParams& P) { return fast_wg(int(P.pk.wl)); }
 
-static bool use_type_rows(const ScoreParams& P) {
-    return P.type_kind == kTypeWindowTable && P.pk.has_trow && !P.force_window_table;
+template <int WL>
+static size_t lds_bytes_for(int tm, uint32_t trow_mode) {
+    using T = FastLdsT<WL>;
+    if (tm == kTypeRows) return offsetof(T, typ) + (trow_mode == kTypeRowsLds ? sizeof(uint4) * kTrowCount * FastGeom<WL>::kTrowQ : size_t(16));
+    return offsetof(T, typ) + (tm == 0 ? size_t(16) : size_t(FastGeom<WL>::kSymSlots));
 }
 size_t score_tiles_fast_lds_bytes(const ScoreParams& P) {
-    return offsetof(FastLdsT, typ) + (use_type_rows(P) ? sizeof(uint4) * kTrowCount : size_t(kSymSlots));
+    int wl = 3, tm = 0;
+    if (!fast_instance(P, &wl, &tm)) return 0;
+    switch (wl) {
+        case 3: return lds_bytes_for<3>(tm, P.pk.trow_mode);
+        case 4: return lds_bytes_for<4>(tm, P.pk.trow_mode);
+        case 5: return lds_bytes_for<5>(tm, P.pk.trow_mode);
+        case 6: return lds_bytes_for<6>(tm, P.pk.trow_mode);
+        case 7: return lds_bytes_for<7>(tm, P.pk.trow_mode);
+        default: return lds_bytes_for<8>(tm, P.pk.trow_mode);
+    }
+}
+
+// The instances: row window 3 with every type source and the diagnostics build; the wider windows with type rows or none.
+template <int WL>
+static hipError_t launch_wide(const ScoreParams& P, int tm, uint32_t n_tiles, size_t lds, hipStream_t stream) {
+    if (tm == kTypeRows) hipLaunchKernelGGL((score_tiles_fast_kernel<WL, kTypeRows, false>), dim3(n_tiles), dim3(kThreads), lds, stream, P);
+    else if (tm == 0) hipLaunchKernelGGL((score_tiles_fast_kernel<WL, 0, false>), dim3(n_tiles), dim3(kThreads), lds, stream, P);
+    else return hipErrorInvalidValue;
+    return hipGetLastError();
 }
 
 hipError_t launch_score_tiles_fast(const ScoreParams& P, uint32_t n_tiles, hipStream_t stream) {
-    const bool rows = use_type_rows(P);
+    int wl = 3, tm = 0;
+    if (!fast_instance(P, &wl, &tm)) return hipErrorInvalidValue;
     const size_t lds = score_tiles_fast_lds_bytes(P) + P.lds_pad;  // (the pad: occupancy experiments)
-    const int tm = rows ? kTypeRows : P.type_kind == kTypeWindowTable ? P.type_window : 0;
     const bool dbg = P.debug != 0 || P.prof != nullptr;
+    switch (wl) {
+        case 4: return launch_wide<4>(P, tm, n_tiles, lds, stream);
+        case 5: return launch_wide<5>(P, tm, n_tiles, lds, stream);
+        case 6: return launch_wide<6>(P, tm, n_tiles, lds, stream);
+        case 7: return launch_wide<7>(P, tm, n_tiles, lds, stream);
+        case 8: return launch_wide<8>(P, tm, n_tiles, lds, stream);
+        default: break;
+    }
 #define VPT_LAUNCH_FAST(TM_)                                                                                                                  \
-    if (dbg) hipLaunchKernelGGL((score_tiles_fast_kernel<TM_, true>), dim3(n_tiles), dim3(kThreads), lds, stream, P);                      \
-    else hipLaunchKernelGGL((score_tiles_fast_kernel<TM_, false>), dim3(n_tiles), dim3(kThreads), lds, stream, P);                        \
+    if (dbg) hipLaunchKernelGGL((score_tiles_fast_kernel<3, TM_, true>), dim3(n_tiles), dim3(kThreads), lds, stream, P);                   \
+    else hipLaunchKernelGGL((score_tiles_fast_kernel<3, TM_, false>), dim3(n_tiles), dim3(kThreads), lds, stream, P);                     \
     break;
     switch (tm) {
         case 0: VPT_LAUNCH_FAST(0)

@@ -32,48 +32,50 @@
 //                    (64 bytes), same kDisplacedBit rule (parent ids stay below 2^31); kHasKidsBit on the child
 //                    id = the child has edges of its own.
 //
-// PACKED TABLES (specialised kernel, kernels_fast.hip).  Every model a Vaporetto / KyTea trainer produces has
-// char window 3, weights quantised to 16 bits (trainer.rs:18,383-397; kytea_model.rs:72-79) and BMP-only patterns.
-// For such models -- W = 3, every pattern symbol in [1, 0xFFFE] -- the same all-matches information is also emitted as a
-// DOUBLE-ARRAY TRIE over the first three symbols of the patterns, walked from every start position.  What shapes it is
-// what bounds the kernel on MI355X (profiles/r02_*): the vector L1's address pipeline -- a lane's 16-byte load costs
-// about 1.4 ns / 256 CUs of it and every distinct line it touches another 2.7 -- so a position should issue few
-// loads to few lines, and nothing it does not need.  One position = one 16-byte unigram node, one 32-byte bigram node and,
-// when the bigram's filter says the third char may continue it, one 16-byte trigram node: 4 loads to 3 lines, each
-// address computed from the node before it (Tarjan-Yao row displacement: child slot = parent's base + child symbol, so
-// there is no hash, no seed table and no probing; a node names its parent so that a lookup which lands on somebody
-// else's node knows it).  The three dependent loads of a position are software-pipelined over three iterations of the
-// kernel's main loop, so every iteration still waits once.
+// PACKED TABLES (specialised kernel, kernels_fast.hip).  Every model a Vaporetto / KyTea trainer produces has weights quantised
+// to 16 bits (trainer.rs:18,383-397; kytea_model.rs:72-79) and BMP-only patterns; the distributed ones have char window 3, and
+// train/src/main.rs:33-51 lets --charw / --typew be anything.  For such models -- every pattern symbol in [1, 0xFFFE], windows up to
+// 8 -- the same all-matches information is also emitted as a DOUBLE-ARRAY TRIE over the first three symbols of the patterns,
+// walked from every start position.  What shapes it is what bounds the kernel on MI355X (profiles/r02_*): the vector L1's address
+// pipeline -- a lane's 16-byte load costs about 1.4 ns / 256 CUs of it and every distinct line it touches another 2.7 -- so a
+// position should issue few loads to few lines, and nothing it does not need.  One position = one unigram node, one bigram node
+// and, when the bigram's filter says the third char may continue it, one trigram node, each address computed from the node before
+// it (Tarjan-Yao row displacement: child slot = parent's base + child symbol, so there is no hash, no seed table and no probing; a
+// node names its parent so that a lookup which lands on somebody else's node knows it).  The three dependent loads of a position
+// are software-pipelined over three iterations of the kernel's main loop, so every iteration still waits once.
 //
+//   ROW WINDOW  wl = max(3, W_c, W_t): the window the rows of the packed tables are laid out for.  A pattern of n symbols that
+//          starts at s touches the boundaries s + row_lo(n, wl) .. s + row_hi(n, wl); a model with narrower windows has its
+//          weights at the boundaries they belong to and zeros around them, so windows 1..3 share the nodes (and the kernel
+//          instance) of window 3 -- 16-byte unigram, 32-byte bigram, 16-byte trigram nodes: 4 loads to 3 lines per position --
+//          and every wider window has node sizes of its own (pk_*_dw below), with the same protocol.
 //   ids    pattern symbols are renumbered 1 .. n_alpha (the alphabet of the model: every char of every n-gram and dictionary
 //          word), the char that the most pattern symbols are first: a small id is a frequent char.  The kernel's char
 //          classification table (cid, below) maps a text char to its id, 0xFFFF (kNoId) when no pattern contains it.  0 stays
 //          "outside the sentence".
-//   cinfo  65536 words per mode (plain / through KyteaFullwidthFilter): id | CharacterType << 16 | linebreak << 19
-//   uni    n_alpha + 2 rows of 16 bytes indexed by id (row 0 and the last row are zero: separators, chars outside the
-//          alphabet): six signed 18-bit fields (boundaries s-3 .. s+2) at bits 0, 18, .., 90; bits 108..126 = B1, the
-//          base of this char's bigram nodes in units of (1 << bi_shift) nodes; bit 127 = kUniWideBit
-//   bi     32-byte bigram nodes, node (id1, id2) at slot (B1[id1] << bi_shift) + id2 of its first char's displaced row.  (Build option
-//          kBiDenseCols > 0: the nodes of the kBiDenseCols most frequent second chars sit in a dense matrix at the head of the array
-//          instead, slot id1 * kBiDenseCols + id2, a row's nodes four to a cache line -- an experiment in L2 locality that measured
-//          no gain, off by default.)
-//            dword 0      key = id1 | id2 << 16 (0 = free)
-//            dwords 1..3  the bigram row: five signed 19-bit fields (boundaries s-2 .. s+2) at bits 0, 19, .., 76 of the
-//                         96; bit 95 = kBiWideBit (the row has a value outside its fields: it comes from the general tables)
-//            dword 4      B2 = base of this prefix's trigram nodes: node (id1, id2, id3) at slot B2 + id3 (mod 2^32)
-//            dwords 5, 6  64-bit filter over packed_filter_bit(id3) of the children (0: none)
-//            dword 7      number of children (statistics)
-//   tri    16-byte trigram nodes: dword 0 = (slot of the parent bigram node + 1) | cflags << 24 (0 = free; cflags: kPkWide),
-//          dwords 1, 2 = w0|w1<<16, w2|w3<<16 (boundaries s-1 .. s+2), dword 3 = `kids`: mini-table ref of its depth-4
-//          children in `deep` (0: none).  A node = a 3-char pattern and/or the 3-char prefix of longer ones.
+//   cinfo  65536 words per mode (plain / through KyteaFullwidthFilter): id | CharacterType << 16 | linebreak << 29
+//   uni    n_alpha + 2 nodes of pk_uni_dw(wl) dwords indexed by id (node 0 and the last one are zero: separators, chars outside
+//          the alphabet): 2 wl signed 18-bit fields (boundaries s-wl .. s+wl-1) from bit 0; behind them (bit 36 wl) B1 in 19 bits,
+//          the base of this char's bigram nodes in units of (1 << bi_shift) nodes, and the wide flag (kUniWideBit when wl = 3)
+//   bi     bigram nodes of pk_bi_dw(wl) dwords, node (id1, id2) at slot (B1[id1] << bi_shift) + id2 of its first char's displaced row:
+//            key = id1 | id2 << 16 (0 = free); the bigram row: 2 wl - 1 signed 19-bit fields (boundaries s-wl+1 .. s+wl-1) and,
+//            behind them, the wide flag (the row has a value outside its fields: it comes from the general tables);
+//            B2 = base of this prefix's trigram nodes: node (id1, id2, id3) at slot B2 + id3 (mod 2^32); a 64-bit filter over
+//            packed_filter_bit(id3) of the children (0: none).
+//            wl = 3: dword 0 key, 1..3 row, 4 B2, 5..6 filter, 7 number of children (statistics)
+//            wl > 3: dword 0 key, 1 B2, 2..3 filter, 4.. row  (the first 16 bytes decide, the rest is the row)
+//   tri    trigram nodes of pk_tri_dw(wl) dwords: (slot of the parent bigram node + 1) | cflags << 28 (0 = free; cflags: kPkWide),
+//          2 wl - 2 weights of 16 bits (boundaries s-wl+2 .. s+wl-1), `kids`: mini-table ref of its depth-4 children in `deep`
+//          (0: none).  A node = a 3-char pattern and/or the 3-char prefix of longer ones.
+//            wl = 3: dword 0 parent, 1..2 weights, 3 kids          wl > 3: dword 0 parent, 1 kids, 2.. weights
 //   deep   64-byte entries for the trie below depth 3.  An entry stands for a child symbol PLUS the chain of up to 8
 //          further symbols that must follow it (nodes with a single child and no row of their own are compressed
 //          away), and ends at a node of depth m:
 //            dword 0      id | dflags<<16 | nskip<<24              dword 1   kids (mini-table of the end node's children)
 //            dwords 2..5  the nskip further ids, 16 bits each
-//            dwords 8..14 the row of the end node's pattern: m+1 weights i16 (boundaries s-1 .. s+m-1), inline when
-//                         m+1 <= 14 and every value fits i16 (kPkHasRow); otherwise kPkExtRow and dword 8 = offset of
-//                         an i32 row in `xrows`.
+//            dwords 8..14 the row of the end node's pattern: row_len(m, wl) weights i16 from boundary s + row_lo(m, wl) (wl = 3:
+//                         m + 1 weights from s - 1), inline when there are at most 14 and every value fits i16 (kPkHasRow);
+//                         otherwise kPkExtRow and dword 8 = offset of an i32 row in `xrows`.
 //   mini-table ref = base << 5 | log2(size): `size` consecutive entries of `deep` holding the children of ONE
 //          node (so a hot node's children are contiguous and cache-hot together); entry index
 //          (id * kHashMulLo >> 15) & (size-1), linear probing inside the mini-table, at most `size` probes,
@@ -83,17 +85,20 @@
 //
 // Bases come from first-fit placement at load time (rows with the most children first; a row = the set of child ids of
 // one parent): every present key is found by exactly one node read, an absent key lands on a free node or on another
-// parent's.  kPkWide / kBiWideBit / kUniWideBit mark a row with a value outside its fields (i16 in a trigram node or
-// `deep` entry, 19 bits in a bigram row, 18 in a unigram row -- a single weight has 16, a merged row sums an n-gram and
-// the dictionary word of the same string): the node keeps zero weights and the row comes from the general tables above.
+// parent's.  The wide flags mark a row with a value outside its fields (i16 in a trigram node or `deep` entry, 19 bits in a
+// bigram row, 18 in a unigram row -- a single weight has 16, a merged row sums an n-gram and the dictionary word of the same
+// string): the node keeps zero weights and the row comes from the general tables above.
 //
-// TYPE ROWS.  When every type n-gram has at most 3 symbols and W_t <= 3 (the trainer's defaults), the type scores
-// are folded into the same start-position form: trow[type_row_index(t1, t2, t3)] = the six totals (boundaries
-// s-3 .. s+2; 18-bit signed fields, three i16 weights always fit) of the type unigram t1, bigram (t1,t2) and
-// trigram (t1,t2,t3) -- 6 * 7 * 7 = 294 rows of 16 bytes (t1 = 1..6, t2 and t3 = 0..6) that the
-// kernel keeps in LDS, which removes the per-boundary gather from the 8^(2W) window table.  Code 0 (outside the
-// sentence) only ever appears as t2/t3 and selects the shorter n-grams, exactly what the window table encodes
-// (boundary_scorer_cache.rs:30-57).  Models outside this shape use the window table (W_t <= 3) as before.
+// TYPE ROWS.  The type scores are folded into the same start-position form: the row of (t1, .., tN) holds, for the 2 wl boundaries
+// s-wl .. s+wl-1, the totals of the type n-grams t1, (t1,t2), .. that start at s -- code 0 (outside the sentence) ends the prefix,
+// exactly what the 8^(2W) window table encodes (boundary_scorer_cache.rs:30-57) -- so a position reads ONE row, added together with
+// its unigram row.  Two homes:
+//   LDS rows     every type n-gram has at most 3 symbols (the trainer's default) and every total fits 18 bits: 6 * 7 * 7 = 294 rows
+//                (type_row_index) of pk_trow_dw(wl) dwords, 2 wl signed 18-bit fields from bit 0; the kernel keeps them in LDS.
+//   global rows  n-grams of up to 6 symbols (or totals outside 18 bits): 6 * 7^(N-1) rows of i32, (2 wl + 3) & ~3 dwords each,
+//                indexed by type_row_index_n over s .. s+N-1; an L2-resident gather per position.
+// Models outside both (an n-gram that contains code 0, or longer than 6) use the window table (W_t <= 3, wl = 3) or the general
+// kernels.
 #pragma once
 #include <cstdint>
 #if defined(__HIPCC__)
@@ -116,21 +121,12 @@ constexpr uint32_t kPkExtRow = 2u, kPkHasRow = 4u, kPkWide = 8u;  // packed flag
 constexpr uint32_t kNoId = 0xFFFFu;            // id of a text char that no pattern contains
 constexpr uint32_t kPackedInlineRow = 14;      // weights a `deep` entry holds inline
 constexpr uint32_t kPackedMaxSkip = 8;         // further symbols a `deep` entry can require (path compression)
-constexpr int kUniFieldBits = 18;              // unigram node: six fields
-constexpr int kBiFieldBits = 19;               // bigram node (dwords 1..3): five fields
-constexpr uint32_t kUniBaseShift = 12, kUniBaseMask = 0x7FFFFu;   // dword 3 of a unigram node: B1 at bits 12..30
-constexpr uint32_t kUniWideBit = 0x80000000u;  // dword 3 of a unigram node: the row is in the general tables (i32)
-constexpr uint32_t kBiWideBit = 0x80000000u;   // dword 3 of a bigram node: likewise
+constexpr int kUniFieldBits = 18;              // unigram node / type row: 2 wl fields
+constexpr int kBiFieldBits = 19;               // bigram node: 2 wl - 1 fields
+constexpr int kUniBaseBits = 19;
+constexpr uint32_t kUniBaseMask = 0x7FFFFu;    // B1 of a unigram node: 19 bits behind its fields, the wide flag behind that
 constexpr uint32_t kTriParentMask = 0x0FFFFFFFu, kTriFlagShift = 28;   // dword 0 of a trigram node: parent slot + 1; cflags above
 constexpr uint32_t kCinfoLinebreak = 1u << 29; // cid word: the (scored) char is '\n' or '\r' (where the kernel's symbol word keeps it)
-constexpr uint32_t kCharCacheNoEntry = 0u;     // char cache (layout below): an empty slot
-#ifndef VPT_BI_DENSE
-#define VPT_BI_DENSE 0    // measured on MI355X (profiles/r03_f_ab_*.jsonl, r03_j_ab_m1.jsonl): 16 / 64 columns 1 % slower than none on M1, 256 columns
-#endif                    // 1-2 % faster on M1 and M2 for 32 MB of matrix -- within the noise of either; the displaced rows alone serve
-constexpr uint32_t kBiDenseCols = VPT_BI_DENSE;   // second chars (ids below this) whose bigram nodes live in the dense matrix (A/B builds: -D)
-// CHAR CACHE (LDS): slot cp & (entries - 1) holds  cp << 16 | CharacterType << 13 | id  of ONE char with that slot index -- the one
-// that the most patterns contain -- or 0; only chars of the alphabet with ids below 0x1FFF that are no line breaks are cached.
-// UNIGRAM CACHE (LDS): slot id & (nodes - 1) holds the unigram node of one id with that slot index (utag = the id, 0: empty).
 
 #if defined(__HIPCC__)
 #define VPT_HD __host__ __device__ __forceinline__
@@ -167,31 +163,60 @@ constexpr uint32_t kTagFilterLog2 = 5;    // filter bits per slot of the token t
 constexpr uint32_t kTagTokInline = 1u << 31, kTagTokFast = 1u << 30, kTagTokLenMask = (1u << 30) - 1u;
 constexpr uint32_t kTagFiltStride = 32;   // dwords per model in HostTagTables::mfilt
 
-// signed `bits`-wide field number j of a 128-bit little-endian row (unigram rows, bigram rows)
-VPT_HD int32_t row_field(uint32_t x, uint32_t y, uint32_t z, uint32_t w, int j, int bits) {
-    const uint32_t d[5] = {x, y, z, w, 0u};
-    const int bit = bits * j, q = bit >> 5, r = bit & 31;
-    const uint64_t v = (uint64_t(d[q]) | (uint64_t(d[q + 1]) << 32)) >> r;
-    return int32_t(uint32_t(v) << (32 - bits)) >> (32 - bits);
-}
 VPT_HD bool fits_field(int32_t v, int bits) { return v >= -(1 << (bits - 1)) && v < (1 << (bits - 1)); }
 
 constexpr uint32_t kTypeRowCount = 6 * 7 * 7;
 VPT_HD uint32_t type_row_index(uint32_t t1, uint32_t t2, uint32_t t3) { return (t1 - 1u) + 6u * t2 + 42u * t3; }   // t1 in 1..6
-
-// type row: six 18-bit signed fields packed little-endian into dwords 0..3 (bits 0..107)
-VPT_HD int32_t trow_field(uint32_t x, uint32_t y, uint32_t z, uint32_t w, int j) {
-    const uint64_t lo = uint64_t(x) | (uint64_t(y) << 32), hi = uint64_t(z) | (uint64_t(w) << 32);
-    const int bit = 18 * j;
-    uint64_t v = bit < 64 ? (lo >> bit) : (hi >> (bit - 64));
-    if (bit < 64 && bit + 18 > 64) v |= hi << (64 - bit);
-    return int32_t(uint32_t(v) << 14) >> 14;
-}
+// N levels: (t1 - 1) + 6 (t2 + 7 (t3 + 7 (..))); 6 * 7^(N-1) rows
+VPT_HD uint32_t type_row_count(int levels) { uint32_t n = 6; for (int i = 1; i < levels; ++i) n *= 7u; return n; }
 
 // geometry of the row of a pattern of n symbols under window W (see the header comment)
 VPT_HD int row_lo(int n, int W) { return (n - 1 - W) < -1 ? (n - 1 - W) : -1; }
 VPT_HD int row_hi(int n, int W) { return (W - 1) > (n - 1) ? (W - 1) : (n - 1); }
 VPT_HD int row_len(int n, int W) { return row_hi(n, W) - row_lo(n, W) + 1; }
+
+// ---- packed node geometry by row window wl = 3 .. 8 (header comment, "ROW WINDOW")
+#if defined(__HIPCC__)
+#define VPT_HDC __host__ __device__ constexpr
+#else
+#define VPT_HDC constexpr
+#endif
+VPT_HDC int pk_uni_fields(int wl) { return 2 * wl; }         // boundaries s - wl     .. s + wl - 1
+VPT_HDC int pk_bi_fields(int wl) { return 2 * wl - 1; }      //            s - wl + 1 .. s + wl - 1
+VPT_HDC int pk_tri_fields(int wl) { return 2 * wl - 2; }     //            s - wl + 2 .. s + wl - 1
+VPT_HDC int pk_uni_dw(int wl) { return wl <= 3 ? 4 : wl <= 6 ? 8 : 16; }     // 36 wl + 20 bits
+VPT_HDC int pk_bi_dw(int wl) { return wl <= 3 ? 8 : 16; }
+VPT_HDC int pk_tri_dw(int wl) { return wl <= 3 ? 4 : wl <= 7 ? 8 : 16; }
+VPT_HDC int pk_trow_dw(int wl) { return wl <= 3 ? 4 : wl <= 7 ? 8 : 12; }    // LDS type rows: 36 wl bits
+VPT_HDC int pk_trow_global_dw(int wl) { return (2 * wl + 3) & ~3; }          // global type rows: i32 fields
+VPT_HDC int pk_uni_base_bit(int wl) { return kUniFieldBits * 2 * wl; }       // B1 (19 bits), then the wide flag
+VPT_HDC int pk_bi_key_dw(int) { return 0; }
+VPT_HDC int pk_bi_row_dw(int wl) { return wl <= 3 ? 1 : 4; }                 // first dword of the row's bit string
+VPT_HDC int pk_bi_base_dw(int wl) { return wl <= 3 ? 4 : 1; }
+VPT_HDC int pk_bi_filter_dw(int wl) { return wl <= 3 ? 5 : 2; }
+VPT_HDC int pk_bi_wide_bit(int wl) { return kBiFieldBits * (2 * wl - 1); }   // bit of the row's bit string
+VPT_HDC int pk_bi_used_dw(int wl) { return wl <= 3 ? 8 : 4 + (kBiFieldBits * (2 * wl - 1) + 1 + 31) / 32; }   // dwords a lookup reads
+VPT_HDC int pk_tri_w_dw(int wl) { return wl <= 3 ? 1 : 2; }                  // first dword of the 16-bit weights
+VPT_HDC int pk_tri_kids_dw(int wl) { return wl <= 3 ? 3 : 1; }
+VPT_HDC int pk_tri_used_dw(int wl) { return wl <= 3 ? 4 : 2 + (wl - 1); }
+VPT_HDC int pk_row_window(int wc, int wt) { return wc > wt ? (wc > 3 ? wc : 3) : (wt > 3 ? wt : 3); }
+// the specialised kernel's geometry per row window: separator slots between sentences (>= wl - 1 so that no row reaches the
+// next sentence, = wl so that s - wl never leaves the tile), flat positions per tile, workgroups per CU it is built for
+VPT_HDC int pk_pad(int wl) { return wl; }
+constexpr int kMaxTypeRowLevels = 6;
+constexpr uint32_t kTypeRowsNone = 0, kTypeRowsLds = 1, kTypeRowsGlobal = 2;   // PackedView::trow_mode
+
+// `n` bits from bit `bit` of a little-endian dword string, signed (fields) / unsigned (bases)
+VPT_HD int32_t bits_signed(const uint32_t* d, int bit, int n) {
+    const int q = bit >> 5, r = bit & 31;
+    const uint64_t v = (uint64_t(d[q]) | (r + n > 32 ? uint64_t(d[q + 1]) << 32 : 0ull)) >> r;
+    return int32_t(uint32_t(v) << (32 - n)) >> (32 - n);
+}
+VPT_HD uint32_t bits_unsigned(const uint32_t* d, int bit, int n) {
+    const int q = bit >> 5, r = bit & 31;
+    const uint64_t v = (uint64_t(d[q]) | (r + n > 32 ? uint64_t(d[q + 1]) << 32 : 0ull)) >> r;
+    return uint32_t(v) & ((n >= 32) ? 0xFFFFFFFFu : ((1u << n) - 1u));
+}
 
 // Device view of one pattern table; passed to kernels by value.
 struct PatternTableView {
@@ -217,12 +242,13 @@ struct PatternTableView {
 struct PackedView {
     const unsigned char* base;
     uint32_t off_uni, off_bi, off_tri, off_deep, off_xrows, off_trow, off_cpid;   // byte offsets, 256-byte aligned
-    uint32_t off_cc, off_utag, off_urow;   // the LDS-resident caches' contents (off_cc: for the batch's char table mode)
     uint32_t n_uni;                 // unigram nodes (ids above n_uni - 1 read the last, all-zero one)
     uint32_t n_tri;                 // trigram nodes (a filter false positive may point past them)
     uint32_t bi_shift;              // bigram slot = (B1 << bi_shift) + id2
     uint32_t present;
-    uint32_t has_trow;              // type rows available (else: window table / none)
+    uint32_t wl;                    // the row window the nodes are laid out for (3 .. 8)
+    uint32_t trow_mode;             // kTypeRowsNone / kTypeRowsLds / kTypeRowsGlobal
+    uint32_t trow_levels;           // type symbols a row is indexed by (3 for LDS rows, 3 .. 6 for global ones)
 };
 
 }  // namespace vpt

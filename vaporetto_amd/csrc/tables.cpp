@@ -316,9 +316,11 @@ struct Placer {
     }
 };
 
-HostPackedTable build_packed(const PatSet& S) {
+HostPackedTable build_packed(const PatSet& S, int wl) {
     StageTimer tm;
     HostPackedTable t;
+    t.wl = wl;
+    const size_t udw = size_t(pk_uni_dw(wl)), bdw = size_t(pk_bi_dw(wl)), tdw = size_t(pk_tri_dw(wl));
     // ---- the alphabet: ids by how many pattern symbols the char is (most first; ties in code-point order)
     {
         std::vector<uint8_t> seen(65536, 0);
@@ -346,7 +348,7 @@ HostPackedTable build_packed(const PatSet& S) {
             if (!fits_i16(S.row(p)[k])) return true;
         return false;
     };
-    t.uni.assign(size_t(t.n_alpha + 2) * 4, 0);
+    t.uni.assign(size_t(t.n_alpha + 2) * udw, 0);
 
     // ---- trie over the patterns of >= 2 chars by one scan: prefixes (depth 2) own nodes (depth >= 3)
     struct Node { uint32_t sym, depth; const PatRef* pat; uint32_t parent; uint32_t ref; };   // parent: prefix index at depth 3, node index below
@@ -437,7 +439,7 @@ HostPackedTable build_packed(const PatSet& S) {
             uint32_t* e = mini_insert(t.deep, 16, nodes[ni].ref, nodes[ki].sym);
             uint32_t fl = 0;
             if (k.pat) {
-                const int32_t* r = S.row(*k.pat);   // depth + 1 values, first = boundary s - 1
+                const int32_t* r = S.row(*k.pat);   // row_len(depth, wl) values from boundary s + row_lo(depth, wl) (wl = 3: depth + 1 from s - 1)
                 const uint32_t rl = k.pat->rlen;
                 if (rl <= kPackedInlineRow && !wide16(*k.pat)) {
                     fl |= kPkHasRow;
@@ -472,18 +474,11 @@ HostPackedTable build_packed(const PatSet& S) {
             rows.push_back({prefixes[pi].key & 0xFFFFu, pi, e - pi});
             pi = e;
         }
-        // the dense matrix at the head of the array takes the nodes whose second char is frequent (layout.h); the displaced rows
-        // hold the rest and start behind it
-        const size_t dense_slots = size_t(t.n_alpha + 2) * kBiDenseCols;
         struct Col { uint32_t id2, pi; };
         std::vector<std::vector<Col>> rest(rows.size());
         for (size_t ri = 0; ri < rows.size(); ++ri) {
             const Row& r = rows[ri];
-            for (uint32_t j = 0; j < r.count; ++j) {
-                const uint32_t id2 = prefixes[r.first + j].key >> 16;
-                if (id2 < kBiDenseCols) prefixes[r.first + j].slot = r.id1 * kBiDenseCols + id2;
-                else rest[ri].push_back({id2, r.first + j});
-            }
+            for (uint32_t j = 0; j < r.count; ++j) rest[ri].push_back({prefixes[r.first + j].key >> 16, r.first + j});
             std::sort(rest[ri].begin(), rest[ri].end(), [](const Col& a, const Col& b) { return a.id2 < b.id2; });   // ids are not in code-point order
         }
         std::vector<uint32_t> by_size(rows.size());
@@ -492,7 +487,7 @@ HostPackedTable build_packed(const PatSet& S) {
         std::vector<uint32_t> cols;
         // a first guess at the alignment the 19-bit base needs (no interleaving at all would take one span per row; half of
         // that is typical), raised if the placement does not fit
-        size_t spans = dense_slots;
+        size_t spans = 0;
         for (const auto& r : rest) if (!r.empty()) spans += r.back().id2 - r.front().id2 + 1;
         t.bi_shift = 2;
         while (t.bi_shift < 8 && (size_t(kUniBaseMask) << t.bi_shift) < spans / 16) ++t.bi_shift;
@@ -502,9 +497,8 @@ HostPackedTable build_packed(const PatSet& S) {
                 return t;
             }
             Placer pl(8192, 8192);
-            for (size_t i = 0; i < dense_slots; ++i) pl.occ.set(i);
             bool ok = true;
-            size_t top = dense_slots;
+            size_t top = 0;
             for (uint32_t ri : by_size) {
                 if (rest[ri].empty()) continue;
                 cols.clear();
@@ -559,35 +553,47 @@ HostPackedTable build_packed(const PatSet& S) {
     deep_thread.join();
     if (deep_err) std::rethrow_exception(deep_err);
     tm.mark("packed: deep arena (joined)");
+    const int nu = pk_uni_fields(wl), nb = pk_bi_fields(wl), nt = pk_tri_fields(wl);
+    auto set_bits = [](uint32_t* d, int bit, int n, uint32_t v) {   // n <= 32 bits of v at bit `bit` of the dword string (OR-ed in)
+        const uint64_t f = uint64_t(v) & ((uint64_t(1) << n) - 1);
+        const int q = bit >> 5, r = bit & 31;
+        d[q] |= uint32_t(f << r);
+        if (r + n > 32) d[q + 1] |= uint32_t(f >> (32 - r));
+    };
     for (uint32_t i = 1; i <= t.n_alpha; ++i) {
-        uint32_t* d = &t.uni[size_t(i) * 4];
-        if (const PatRef* p = uni_pat[i]) {
-            if (!row_fits(S.row(*p), 6, kUniFieldBits)) { d[3] |= kUniWideBit; ++t.n_wide; }
-            else pack_fields(d, S.row(*p), 6, kUniFieldBits);
+        uint32_t* d = &t.uni[size_t(i) * udw];
+        if (const PatRef* p = uni_pat[i]) {   // row_len(1, wl) = 2 wl values from boundary s - wl
+            if (!row_fits(S.row(*p), uint32_t(nu), kUniFieldBits)) { set_bits(d, pk_uni_base_bit(wl) + kUniBaseBits, 1, 1u); ++t.n_wide; }
+            else pack_fields(d, S.row(*p), nu, kUniFieldBits);
         }
-        d[3] |= b1[i] << kUniBaseShift;
+        set_bits(d, pk_uni_base_bit(wl), kUniBaseBits, b1[i]);
     }
-    t.bi.assign(bi_slots * 8, 0);
-    t.tri.assign(tri_slots * 4, 0);
+    t.bi.assign(bi_slots * bdw, 0);
+    t.tri.assign(tri_slots * tdw, 0);
     for (uint32_t pi = 0; pi < prefixes.size(); ++pi) {
         const Prefix& pf = prefixes[pi];
-        uint32_t* r = &t.bi[size_t(pf.slot) * 8];
-        r[0] = pf.key;
-        if (pf.pat && !row_fits(S.row(*pf.pat), 5, kBiFieldBits)) { r[3] |= kBiWideBit; ++t.n_wide; }
-        else if (pf.pat) pack_fields(r + 1, S.row(*pf.pat), 5, kBiFieldBits);
+        uint32_t* r = &t.bi[size_t(pf.slot) * bdw];
+        r[pk_bi_key_dw(wl)] = pf.key;
+        uint32_t* rrow = r + pk_bi_row_dw(wl);   // row_len(2, wl) = 2 wl - 1 values from boundary s - wl + 1
+        if (pf.pat && !row_fits(S.row(*pf.pat), uint32_t(nb), kBiFieldBits)) { set_bits(rrow, pk_bi_wide_bit(wl), 1, 1u); ++t.n_wide; }
+        else if (pf.pat) pack_fields(rrow, S.row(*pf.pat), nb, kBiFieldBits);
         uint64_t mask = 0;
         for (uint32_t j = pkid_off[pi]; j < pkid_off[pi + 1]; ++j) {
             const Node& k = nodes[pkid[j]];
             mask |= uint64_t(1) << packed_filter_bit(k.sym);
-            uint32_t* e = &t.tri[size_t(tri_slot[pkid[j]]) * 4];
+            uint32_t* e = &t.tri[size_t(tri_slot[pkid[j]]) * tdw];
             uint32_t fl = 0;
             if (k.pat && wide16(*k.pat)) { fl |= kPkWide; ++t.n_wide; }
-            else if (k.pat) { const int32_t* w = S.row(*k.pat); e[1] = pack16(w[0], w[1]); e[2] = pack16(w[2], w[3]); }
+            else if (k.pat) {   // row_len(3, wl) = 2 wl - 2 values from boundary s - wl + 2
+                const int32_t* w = S.row(*k.pat);
+                for (int q = 0; q < nt; q += 2) e[pk_tri_w_dw(wl) + q / 2] = pack16(w[q], w[q + 1]);
+            }
             e[0] = (pf.slot + 1) | (fl << kTriFlagShift);
-            e[3] = k.ref;
+            e[pk_tri_kids_dw(wl)] = k.ref;
             ++t.n_tri;
         }
-        r[4] = b2[pi]; r[5] = uint32_t(mask); r[6] = uint32_t(mask >> 32); r[7] = pkid_off[pi + 1] - pkid_off[pi];
+        r[pk_bi_base_dw(wl)] = b2[pi]; r[pk_bi_filter_dw(wl)] = uint32_t(mask); r[pk_bi_filter_dw(wl) + 1] = uint32_t(mask >> 32);
+        if (wl <= 3) r[7] = pkid_off[pi + 1] - pkid_off[pi];
     }
     t.n_bi = uint32_t(prefixes.size());
     tm.mark("packed: nodes");
@@ -597,49 +603,75 @@ HostPackedTable build_packed(const PatSet& S) {
     return t;
 }
 
-// Type rows (layout.h, "TYPE ROWS"); empty when the n-grams do not fit the form.  `ngrams` already passed the
-// window-table builder's validity checks.
-std::vector<uint32_t> build_type_rows(const std::vector<NgramRecord>& ngrams, int W) {
-    std::vector<int32_t> uni(8 * 6, 0), bi(64 * 6, 0), tri(512 * 6, 0);
+// Type rows (layout.h, "TYPE ROWS") for the row window `wl` (>= W); mode kTypeRowsNone when the n-grams fit neither form.
+// `cache_semantics`: the n-grams are scored by the reference's window table (boundary_scorer_cache.rs:30-57), which matches code 0
+// against the padding -- a start-position row cannot say "outside", so such a model has no rows; otherwise (the automaton variants,
+// type_scorer/boundary_scorer.rs:45-62) an n-gram with a 0 in it matches nothing (char_types holds 1..6) and is dropped.
+// `ngrams` already passed the validity checks of the table builders.
+struct TypeRows { std::vector<uint32_t> data; uint32_t mode = kTypeRowsNone, levels = 0; };
+TypeRows build_type_rows(const std::vector<NgramRecord>& ngrams, int W, int wl, bool cache_semantics) {
+    TypeRows out;
+    const int nf = 2 * wl;
+    std::unordered_map<uint64_t, std::vector<int64_t>> rows;   // (n << 32 | codes, 3 bits each, first = lowest) -> the n-gram's row
+    int levels = 3;
     for (const NgramRecord& d : ngrams) {
         const int n = int(d.ngram.size());
         bool usable = true, pads = false;
         for (Sym s : d.ngram) {
-            if (s > 6) usable = false;   // can never match: windows only hold codes 0..6
-            if (s == 0) pads = true;     // code 0 = outside the sentence: the window table matches it against the padding
+            if (s > 6) usable = false;   // can never match: char types are 1..6
+            if (s == 0) pads = true;
         }
-        if (!usable || d.weights.empty() || n > 2 * W) continue;
-        if (pads) return {};             // a start-position row cannot say "outside": the window table scores this model
-        if (n > 3) return {};
-        uint32_t idx = 0;
-        for (int i = 0; i < n; ++i) idx |= d.ngram[size_t(i)] << (3 * i);
-        int32_t* row = n == 1 ? &uni[idx * 6] : n == 2 ? &bi[idx * 6] : &tri[idx * 6];
+        if (!usable || d.weights.empty() || n == 0 || n > 2 * W) continue;
+        if (pads) { if (cache_semantics) return out; continue; }
+        if (n > kMaxTypeRowLevels) return out;
+        levels = std::max(levels, n);
+        uint64_t key = uint64_t(n) << 32;
+        for (int i = 0; i < n; ++i) key |= uint64_t(d.ngram[size_t(i)]) << (3 * i);
+        std::vector<int64_t>& row = rows[key];
+        row.resize(size_t(nf), 0);
         // the window table only ever reads w[2W - end], end = n .. 2W (boundary_scorer_cache.rs:41-46): a weight with an
-        // index above 2W - n exists in no window and is ignored there, so it is ignored here
+        // index above 2W - n exists in no window and is ignored there, so it is ignored here (the automaton variants reject it)
         const size_t used = std::min(d.weights.size(), size_t(2 * W - n + 1));
         for (size_t k = 0; k < used; ++k) {
-            const int slot = (n - 1 - W + int(k)) + 3;   // boundary start + n-1-W+k  (type_scorer/boundary_scorer.rs:48)
-            if (slot < 0 || slot > 5) return {};
-            row[slot] = wadd(row[slot], d.weights[k]);
+            const int slot = (n - 1 - W + int(k)) + wl;   // boundary start + n-1-W+k  (type_scorer/boundary_scorer.rs:48); row slot 0 = start - wl
+            row[size_t(slot)] += d.weights[k];             // in [0, 2 wl): W <= wl
         }
     }
-    std::vector<uint32_t> out(size_t(kTypeRowCount) * 4, 0);
-    for (uint32_t idx = 0; idx < 512; ++idx) {
-        const uint32_t t1 = idx & 7, t2 = (idx >> 3) & 7, t3 = idx >> 6;
-        if (t1 == 0 || t1 == 7 || t2 == 7 || t3 == 7) continue;
-        const uint32_t row = type_row_index(t1, t2, t3);
-        int64_t r[6];
-        for (int j = 0; j < 6; ++j) {
-            r[j] = uni[t1 * 6 + j];
-            if (t2 >= 1 && t2 <= 6) {
-                r[j] += bi[(t1 | t2 << 3) * 6 + j];
-                if (t3 >= 1 && t3 <= 6) r[j] += tri[idx * 6 + j];
-            }
-            if (r[j] < -131072 || r[j] > 131071) return {};   // 18-bit fields
+    const uint32_t count = type_row_count(levels);
+    std::vector<int64_t> all(size_t(count) * size_t(nf), 0);
+    bool fits18 = true;
+    for (uint32_t idx = 0; idx < count; ++idx) {
+        uint32_t t[kMaxTypeRowLevels];
+        uint32_t q = idx;
+        t[0] = q % 6u + 1u; q /= 6u;
+        for (int i = 1; i < levels; ++i) { t[i] = q % 7u; q /= 7u; }
+        int64_t* r = &all[size_t(idx) * size_t(nf)];
+        uint64_t key = 0;
+        for (int n = 1; n <= levels; ++n) {
+            if (t[n - 1] == 0) break;   // outside the sentence: only the shorter n-grams start here
+            key |= uint64_t(t[n - 1]) << (3 * (n - 1));
+            auto it = rows.find((uint64_t(n) << 32) | key);
+            if (it == rows.end()) continue;
+            for (int j = 0; j < nf; ++j) r[j] += it->second[size_t(j)];
         }
-        unsigned __int128 bits = 0;
-        for (int j = 0; j < 6; ++j) bits |= (unsigned __int128)(uint64_t(r[j]) & 0x3FFFFu) << (18 * j);
-        for (int q = 0; q < 4; ++q) out[row * 4 + q] = uint32_t(bits >> (32 * q));
+        for (int j = 0; j < nf; ++j) fits18 = fits18 && r[j] >= -131072 && r[j] <= 131071;
+    }
+    out.levels = uint32_t(levels);
+    if (levels == 3 && fits18) {
+        out.mode = kTypeRowsLds;
+        const size_t dw = size_t(pk_trow_dw(wl));
+        out.data.assign(size_t(count) * dw, 0);
+        for (uint32_t idx = 0; idx < count; ++idx) {
+            int32_t v[2 * kMaxWindow];
+            for (int j = 0; j < nf; ++j) v[j] = int32_t(all[size_t(idx) * size_t(nf) + size_t(j)]);
+            pack_fields(&out.data[size_t(idx) * dw], v, nf, kUniFieldBits);
+        }
+    } else {
+        out.mode = kTypeRowsGlobal;
+        const size_t dw = size_t(pk_trow_global_dw(wl));
+        out.data.assign(size_t(count) * dw, 0);
+        for (uint32_t idx = 0; idx < count; ++idx)
+            for (int j = 0; j < nf; ++j) out.data[size_t(idx) * dw + size_t(j)] = uint32_t(uint64_t(all[size_t(idx) * size_t(nf) + size_t(j)]));   // wraps like the reference's i32 sums
     }
     return out;
 }
@@ -907,7 +939,17 @@ CompiledModel compile_model(const ModelData& m, bool predict_tags) {
 
     // CharScorer::new: None when there is nothing to match or the window is 0 (char_scorer.rs:98-100)
     const int wc = m.char_window;
-    if (!((m.char_ngrams.empty() && m.dict.empty()) || wc == 0)) {
+    const int wt = m.type_window;
+    const bool chars_on = !((m.char_ngrams.empty() && m.dict.empty()) || wc == 0);
+    const bool types_on = !(m.type_ngrams.empty() || wt == 0);
+    // The row window of the packed tables (layout.h, "ROW WINDOW") covers the type window too when the type scores can take the
+    // start-position form (type rows, added together with a position's unigram row); whether they can is found out first -- this
+    // pass checks nothing and throws nothing, the builders below do, in the reference's order.
+    TypeRows type_rows;
+    if (chars_on && types_on && wc <= kMaxWindow && wt <= kMaxWindow)
+        type_rows = build_type_rows(m.type_ngrams, wt, pk_row_window(wc, wt), !tags_on && wt <= 3);
+    const int wl = type_rows.mode != kTypeRowsNone ? pk_row_window(wc, wt) : pk_row_window(wc, 0);
+    if (chars_on) {
         if (wc > kMaxWindow) throw ModelError("InvalidModelError: char_window_size above 8 is not supported");
         StageTimer tm;
         PatSet pats;
@@ -917,8 +959,7 @@ CompiledModel compile_model(const ModelData& m, bool predict_tags) {
             for (const auto& d : m.dict) { n_syms += d.word.size(); n_rows += size_t(row_len(int(d.word.size()), wc)); }
             pats.reserve(m.char_ngrams.size() + m.dict.size(), n_syms, n_rows);
         }
-        // windows 1 and 2 are laid out as window 3 (add_ngram): the packed tables and the specialised kernel take them
-        const int wl = wc < 3 ? 3 : wc;
+        // narrower windows are laid out in the rows of `wl` (add_ngram): one set of tables, one kernel instance per row window
         c.char_window = wc;
         for (const auto& d : m.char_ngrams) add_ngram(pats, d.ngram, d.weights, wc, true, wl);
         for (const auto& d : m.dict) add_word(pats, d.word, d.weights, wl);
@@ -928,7 +969,7 @@ CompiledModel compile_model(const ModelData& m, bool predict_tags) {
         // the general and the packed tables are independent of each other: two threads
         std::exception_ptr packed_err;
         std::thread packed_thread([&] {
-            try { if (wl == 3) c.packed = build_packed(pats); } catch (...) { packed_err = std::current_exception(); }
+            try { c.packed = build_packed(pats, wl); } catch (...) { packed_err = std::current_exception(); }
         });
         try { c.chars = build_table(pats, wl, kUniDirectChars); } catch (...) { packed_thread.join(); throw; }
         packed_thread.join();
@@ -937,13 +978,11 @@ CompiledModel compile_model(const ModelData& m, bool predict_tags) {
 
     // TypeScorer::new: None without n-grams or window (type_scorer.rs:109-111); the window table when
     // window <= 3 and no tag models take part, pattern matching otherwise (type_scorer.rs:113-131)
-    const int wt = m.type_window;
-    if (!(m.type_ngrams.empty() || wt == 0)) {
+    if (types_on) {
         c.type_window = wt;
         if (!tags_on && wt <= 3) {
             c.type_kind = kTypeWindowTable;
             c.type_table = build_type_window_table(m.type_ngrams, wt);
-            if (c.packed.present) c.packed.trow = build_type_rows(m.type_ngrams, wt);
         } else if (wt <= 3) {
             // With tag models the reference scores types through TypeScorerBoundaryTag (type_scorer.rs:113-131): an
             // automaton over the MERGED n-grams (identical n-grams sum, TypeWeightMerger::add, type_scorer.rs:46-56).
@@ -968,7 +1007,6 @@ CompiledModel compile_model(const ModelData& m, bool predict_tags) {
             }
             c.type_kind = kTypeWindowTable;
             c.type_table = build_type_window_table(merged, wt);
-            if (c.packed.present) c.packed.trow = build_type_rows(merged, wt);
         } else {
             if (wt > kMaxWindow) throw ModelError("InvalidModelError: type_window_size above 8 is not supported");
             c.type_kind = kTypePatternTable;
@@ -976,6 +1014,9 @@ CompiledModel compile_model(const ModelData& m, bool predict_tags) {
             for (const auto& d : m.type_ngrams) add_ngram(pats, d.ngram, d.weights, wt, false);
             pats.finish();
             c.types = build_table(pats, wt, kUniDirectTypes);
+        }
+        if (c.packed.present && type_rows.mode != kTypeRowsNone) {
+            c.packed.trow = std::move(type_rows.data); c.packed.trow_mode = type_rows.mode; c.packed.trow_levels = type_rows.levels;
         }
     }
     c.pad = std::max(1, std::max(c.chars.present ? c.chars.window : 0, c.type_kind != kTypeNone ? wt : 0));   // (the window the rows are laid out for)

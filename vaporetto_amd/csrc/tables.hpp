@@ -31,12 +31,14 @@ struct HostPatternTable {
 // Packed tables of the specialised kernel (layout.h, "PACKED TABLES": a double-array trie over the first three symbols).
 struct HostPackedTable {
     bool present = false;          // false: the model is not eligible (see build notes in tables.cpp)
-    std::vector<uint32_t> uni;     // (n_alpha + 2) unigram nodes x 4 dwords, indexed by id
-    std::vector<uint32_t> bi;      // 8 dwords per bigram node
-    std::vector<uint32_t> tri;     // 4 dwords per trigram node
+    int wl = 3;                    // the row window the nodes are laid out for (layout.h, "ROW WINDOW"): max(3, W_c, W_t)
+    std::vector<uint32_t> uni;     // (n_alpha + 2) unigram nodes x pk_uni_dw(wl) dwords, indexed by id
+    std::vector<uint32_t> bi;      // pk_bi_dw(wl) dwords per bigram node
+    std::vector<uint32_t> tri;     // pk_tri_dw(wl) dwords per trigram node
     std::vector<uint32_t> deep;    // 16 dwords per entry
     std::vector<int32_t> xrows;    // external i32 rows
-    std::vector<uint32_t> trow;    // kTypeRowCount type rows x 4 dwords, empty when the type n-grams do not fit the form
+    std::vector<uint32_t> trow;    // type rows (layout.h, "TYPE ROWS"), empty when the type n-grams do not fit either form
+    uint32_t trow_mode = kTypeRowsNone, trow_levels = 0;
     std::vector<uint32_t> cpid;    // n_alpha + 2: id -> code point
     std::vector<uint16_t> id_of;   // 65536: BMP code point -> id (kNoId: no pattern contains it)
     std::vector<uint32_t> hot;     // 65536: how many pattern symbols are this code point (what the LDS caches of the kernel are filled by)
