@@ -56,7 +56,7 @@ CONFIGS = {
     # (vaporetto_tantivy/src/lib.rs:171-176) -- every sentence spans many tiles
     5: dict(name="documents", kind=1, sentences=10_000, min_len=2_000, max_len=20_000, tags=False, blocks=False),
     # the windows are free parameters of the trainer (train/src/main.rs:33-51): M1 trained with --charw 2 --typew 2 (laid out in the rows
-    # of window 3: the specialised kernel) and with --charw 4 --typew 4 (the general tables and kernel)
+    # of window 3) and with --charw 4 --typew 4 (rows of window 4): the specialised kernel, one instance per row window
     6: dict(name="charw2", kind=4, sentences=100_000, min_len=64, max_len=64, tags=False, blocks=False),
     7: dict(name="charw4", kind=5, sentences=100_000, min_len=64, max_len=64, tags=False, blocks=False),
 }
@@ -285,7 +285,30 @@ class Runner:
         plan = batch.last_plan()
         kernel_ms = float(np.median(ktimes)) if len(ktimes) else kernel_ms_mean
         phases = batch.phase_cycles() if args.phases else None
+        # With every rank on ONE device (the dry run of the scaling job on a 1-GPU box) the ranks' kernels share the device and an event
+        # pair also times the others' work: the ranks then take turns for a few launches each, and that is the kernel time the line
+        # reports per rank (`kernel_ms_solo`): N ranks' solo kernels should add up to the N = 1 kernel.
+        kernel_ms_solo = None
+        if self.world > 1 and os.environ.get("VPT_BENCH_ONE_DEVICE"):
+            for r in range(self.world):
+                dist.barrier()
+                if r == self.rank:
+                    for _ in range(5):
+                        step()
+                    batch.sync()
+                    kt = batch.kernel_times()
+                    kernel_ms_solo = float(np.median(kt[-5:])) if len(kt) else None
+            dist.barrier()
+        elapsed_local = elapsed
         elapsed, total_boundaries = vdist.reduce_throughput(elapsed, float(nb), device=dev)
+        per_rank = None
+        if self.world > 1:   # what every rank measured, so that a bad curve can be read from the line alone
+            mine = {"rank": self.rank, "device": self.local_rank, "sentences": S, "boundaries": nb, "kernel_ms": round(kernel_ms, 4),
+                    "kernel_ms_solo": None if kernel_ms_solo is None else round(kernel_ms_solo, 4), "ms_per_step": round(1e3 * elapsed_local / steps, 4),
+                    "tiles": n_tiles, "create_s": round(create_s, 2), "tables_broadcast_s": round(bcast_s, 3), "synth_s": round(synth_s, 2)}
+            gathered = [None] * self.world
+            dist.all_gather_object(gathered, mine)
+            per_rank = gathered
 
         # ---- tag kernels on their own (event-free wall clock over the same steps)
         tags_info = None
@@ -340,8 +363,9 @@ class Runner:
             from oracle import cbind
             orc = cbind.OraclePredictor(raw, cfg["tags"])
             t = time.perf_counter()
-            if primary or cfg_id == 1:
-                # the CPU baseline, on this rank's host cores: a bounded sample of the same workload -- one pass over (at most) the
+            if (primary or cfg_id == 1) and self.rank == 0:
+                # the CPU baseline, on RANK 0's host cores only (the other ranks run the parity pass alone, so that at N = 8 nobody
+                # waits on seven redundant baselines): a bounded sample of the same workload -- one pass over (at most) the
                 # first 100 K sentences on ONE thread (the reference is single-threaded), then the whole shard on this rank's share
                 # of the host threads (that pass is also the parity check's reference); repeated while it stays within ~10 s
                 n1 = min(S, 100_000)
@@ -349,20 +373,34 @@ class Runner:
                 orc.predict_batch(utf8[:int(boff[n1])], boff[:n1 + 1], nthreads=1)
                 t1 = time.perf_counter() - t
                 nb1 = int(ooff[n1])
-                t = time.perf_counter()
-                o_scores, o_labels, _, a_char = orc.predict_batch(utf8, boff, nthreads=self.ncores)
-                tn = time.perf_counter() - t
-                reps = 1
-                while tn * (reps + 1) < 10.0 and reps < 20:
+                # the first pass over the shard is the parity check's reference; its outputs are fresh arrays, so it also pays their
+                # page faults (3 GB for configs[2], first touched from every thread) -- it is NOT timed.  The timed passes write the same
+                # arrays again with the workers pinned: what they measure is the algorithm at memory-resident size.
+                o_scores, o_labels, o_ooff, a_char = orc.predict_batch(utf8, boff, nthreads=self.ncores)
+                tn, reps, spent = None, 0, 0.0
+                while reps < 20 and (reps == 0 or spent + (spent / reps) < 10.0):
                     t = time.perf_counter()
-                    orc.predict_batch(utf8, boff, nthreads=self.ncores)
-                    tn = min(tn, time.perf_counter() - t)
+                    orc.predict_batch(utf8, boff, nthreads=self.ncores, out=(o_scores, o_labels, o_ooff), pin=True)
+                    dt = time.perf_counter() - t
+                    tn = dt if tn is None else min(tn, dt)
+                    spent += dt
                     reps += 1
+                # ... and at cache-resident size: the first 100 K sentences (what configs[1] is), best of a few passes on every thread
+                sub = (utf8[:int(boff[n1])], boff[:n1 + 1])
+                c_out = orc.predict_batch(*sub, nthreads=self.ncores)[:3]
+                tc = None
+                for _ in range(10):
+                    t = time.perf_counter()
+                    orc.predict_batch(*sub, nthreads=self.ncores, out=c_out, pin=True)
+                    dt = time.perf_counter() - t
+                    tc = dt if tc is None else min(tc, dt)
+                del c_out
                 cpu = {"value": nb / tn, "unit": "boundaries/s", "cores": self.ncores, "kind": "port",
-                       "single_thread_value": nb1 / t1, "cpu": cpu_model_name(),
-                       "sample": "rank 0's shard of this workload (%d sentences): best of %d pass(es) on %d threads; its first %d sentences once on 1 "
-                                 "thread (C restatement of the reference algorithm with a hash-table automaton, not the Rust binary: a lower "
-                                 "bound for it)" % (S, reps, self.ncores, n1)}
+                       "single_thread_value": nb1 / t1, "cache_resident_value": nb1 / tc, "cpu": cpu_model_name(),
+                       "sample": "rank 0's shard of this workload (%d sentences): best of %d pass(es) on %d pinned threads into pre-faulted outputs; "
+                                 "`cache_resident_value`: its first %d sentences, best of 10 such passes; `single_thread_value`: those once on 1 thread "
+                                 "(C restatement of the reference algorithm with a hash-table automaton, not the Rust binary: a lower bound for it)"
+                                 % (S, reps, self.ncores, n1, )}
             else:
                 o_scores, o_labels, _, a_char = orc.predict_batch(utf8, boff, nthreads=self.ncores)
             g_scores = d_scores[:nb].cpu().numpy()
@@ -480,13 +518,15 @@ class Runner:
             "packed_tables": bool(info["packed"]), "tiles": n_tiles, "tile_plan": "%s of %d flat positions" % (plan["kind"], plan["tile_flat"]),
             "create_s": round(create_s, 2), "tables_broadcast_s": round(bcast_s, 3) if self.world > 1 else None, "synth_s": round(synth_s, 2),
         }
+        if per_rank is not None:
+            out["per_rank"] = per_rank
         if phases is not None:
             tot = float(sum(phases[:7])) or 1.0
             out["phase_share"] = dict(zip(["stage", "sentence_starts", "scan_decode", "classify", "patterns", "barrier", "output"], [round(p / tot, 4) for p in phases[:7]]))
         # roofline of the dominant kernel: algorithmic bytes per launch / its duration
         a_stream = nbytes + 5 * nb + 16 * S   # text + i32 score + u8 label per boundary + two u64 offsets per sentence
         a_type = 4 * nb                        # one type-window table word per boundary (the reference's cache form)
-        kernel_name = "score_tiles_fast_kernel" if info["packed"] and info["type_kind"] in (0, 1) else "score_tiles_kernel"
+        kernel_name = "score_tiles_kernel" if plan["kind"] == "general kernels" else "score_tiles_fast_kernel"   # which launch the events bracketed
         roof = {"bound": "hbm", "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None, "traffic": None, "kernel": kernel_name,
                 "kernel_ms": kernel_ms, "kernel_ms_mean": kernel_ms_mean, "kernel_ms_min": float(np.min(ktimes)) if len(ktimes) else None,
                 "timed_launches": int(len(ktimes)), "timing": "HIP events on the launch stream around the kernel; median of the timed launches"}
@@ -528,6 +568,10 @@ def parse_args(argv=None):
     ap.add_argument("--no-emit", action="store_true")
     ap.add_argument("--phases", action="store_true", help="diagnostics: per-phase shader cycles of the scoring kernel (slows it)")
     ap.add_argument("--in-process", action="store_true", help="N > 1: skip torch.distributed, drive the N devices from this process (the fallback path)")
+    ap.add_argument("--scale-sweep", default="", help="e.g. 1,2,4,8: run the primary workload at every N of the list (one line each, as --gpus N "
+                    "would print it, plus `scaling_efficiency` against the N = 1 value of the same invocation)")
+    ap.add_argument("--dry-scale", action="store_true", help="pre-flight of the scaling job: --scale-sweep 1,2,4,8 on whatever this box has -- N ranks on "
+                    "N devices over RCCL when it has them, else every rank on device 0 over gloo -- and a check of every line (exit code 1 when one fails)")
     args = ap.parse_args(argv)
     if args.gpus < 1:
         die("--gpus must be at least 1")
@@ -677,7 +721,7 @@ def run_in_process(args, reason: str) -> int:
                                  "restatement of the reference algorithm with a hash-table automaton, not the Rust binary: a lower bound for it)" % (sh["S"], ncores, n1)}
     sh0 = shards[0]
     a_stream, a_type = sh0["nbytes"] + 5 * sh0["nb"] + 16 * sh0["S"], 4 * sh0["nb"]
-    kernel_name = "score_tiles_fast_kernel" if info["packed"] and info["type_kind"] in (0, 1) else "score_tiles_kernel"
+    kernel_name = "score_tiles_kernel" if shards[0]["batch"].last_plan()["kind"] == "general kernels" else "score_tiles_fast_kernel"
     roof = {"bound": "hbm", "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None, "traffic": None, "kernel": kernel_name,
             "kernel_ms": kernel_ms, "kernel_ms_mean": kernel_ms_mean, "kernel_ms_min": float(np.min(ktimes)) if len(ktimes) else None,
             "timed_launches": int(len(ktimes)), "timing": "HIP events on device 0's launch stream around the kernel; median of the timed launches (device 0's shard)"}
@@ -705,8 +749,79 @@ def run_in_process(args, reason: str) -> int:
     return 0
 
 
+def scale_sweep(args) -> int:
+    """--scale-sweep / --dry-scale: the primary workload at every N of the list, each as a job of its own (`python bench.py --gpus N ...`, i.e.
+    exactly what the driver runs), the lines relayed with `scaling_efficiency` = value(N) / (N x value(1)).  --dry-scale also checks them."""
+    ns = [1, 2, 4, 8] if args.dry_scale and not args.scale_sweep else [int(x) for x in args.scale_sweep.split(",") if x.strip()]
+    if not ns or any(n < 1 for n in ns):
+        die("--scale-sweep wants a list of GPU counts, e.g. 1,2,4,8")
+    n_vis = visible_devices()
+    passthrough, skip = [], False
+    for a in sys.argv[1:]:
+        if skip:
+            skip = False
+            continue
+        if a in ("--scale-sweep", "--gpus"):
+            skip = True
+            continue
+        if a == "--dry-scale" or a.startswith("--scale-sweep=") or a.startswith("--gpus="):
+            continue
+        passthrough.append(a)
+    lines, failures = [], []
+    for n in ns:
+        env = dict(os.environ)
+        for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+            env.pop(k, None)
+        if n > n_vis:
+            if not args.dry_scale:
+                die("--scale-sweep: %d GPUs asked for, %d visible (--dry-scale puts the ranks on device 0)" % (n, n_vis))
+            env["VPT_BENCH_ONE_DEVICE"] = "1"      # every rank on device 0: RCCL refuses two ranks on one device, so gloo
+            env["VPT_BENCH_BACKEND"] = "gloo"
+        cmd = [sys.executable, os.path.abspath(__file__), "--gpus", str(n)] + passthrough
+        sys.stderr.write("bench.py: sweep N = %d: %s\n" % (n, " ".join(cmd)))
+        sys.stderr.flush()
+        t0 = time.perf_counter()
+        job = subprocess.run(cmd, env=env, stdout=subprocess.PIPE)
+        wall = time.perf_counter() - t0
+        got = [l for l in job.stdout.decode("utf-8", "replace").splitlines() if l.startswith("{") and '"metric"' in l]
+        if job.returncode != 0 or len(got) != 1:
+            failures.append("N = %d: exit code %d, %d result line(s)" % (n, job.returncode, len(got)))
+            continue
+        line = json.loads(got[0])
+        line["sweep_wall_s"] = round(wall, 1)
+        lines.append(line)
+    base = next((l for l in lines if l["n_gpus"] == 1), None)
+    for l in lines:
+        l["scaling_efficiency"] = (l["value"] / (l["n_gpus"] * base["value"])) if base else None
+        if args.dry_scale:
+            n = l["n_gpus"]
+            one_dev = "VPT_BENCH_ONE_DEVICE" in l["config"]["launch"]
+            checks = {"n_gpus is what was asked for": n in ns and l["config"]["world_size"] == n,
+                      "parity": l["parity"] is True,
+                      "the same workload as N = 1": base is None or l["config"]["workload"] == base["config"]["workload"],
+                      "strong scaling of one workload": l["scaling"] == "strong" or bool(args.config and args.config != 2),
+                      "per-rank figures": n == 1 or (len(l.get("per_rank") or []) == n and sum(r["sentences"] for r in l["per_rank"]) > 0)}
+            if base is not None and n > 1 and l.get("per_rank"):
+                k1 = base["roofline"]["kernel_ms"]
+                ks = [(r["kernel_ms_solo"] if one_dev else r["kernel_ms"]) for r in l["per_rank"]]
+                if all(k is not None for k in ks):
+                    # N shards of one batch: the ranks' kernels add up to the N = 1 kernel (10 %, plus a tile round per rank on small batches)
+                    l["kernel_ms_sum_over_ranks"] = round(sum(ks), 4)
+                    checks["the ranks' kernels add up to the N = 1 kernel within 10 %"] = abs(sum(ks) - k1) <= 0.10 * k1 + 0.02 * n
+            l["dry_scale_checks"] = checks
+            failures += ["N = %d: %s" % (n, k) for k, ok in checks.items() if not ok]
+        print(json.dumps(l))
+    sys.stdout.flush()
+    if args.dry_scale:
+        sys.stderr.write("bench.py: dry scale: %d line(s), %s\n" % (len(lines), "all checks passed" if not failures else "FAILED: " + "; ".join(failures)))
+        return 1 if failures else 0
+    return 1 if failures else 0
+
+
 def main():
     args = parse_args()
+    if args.scale_sweep or args.dry_scale:
+        raise SystemExit(scale_sweep(args))
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         raise SystemExit(self_launch(args))
     R = Runner(args)
@@ -733,7 +848,7 @@ def main():
         line["config"]["launch"] = os.environ.get("VPT_BENCH_LAUNCH") or ("one process, one GPU" if R.world == 1 else "torch.distributed.run started by the caller")
         if os.environ.get("VPT_BENCH_ONE_DEVICE") and R.world > 1:
             line["config"]["launch"] += "; VPT_BENCH_ONE_DEVICE: every rank on device 0"
-        for k in ("e2e", "tags", "emit", "phase_share"):
+        for k in ("e2e", "tags", "emit", "phase_share", "per_rank"):
             if k in prim:
                 line[k] = prim[k]
         if extra:

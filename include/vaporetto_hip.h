@@ -337,6 +337,10 @@ vpt_status vpt_tokenize_batch(const vpt_predictor *p, const uint8_t *utf8, const
  * 2 pattern lookups, 3 barrier wait, 4 boundary output.  Reads the sums (after a device sync) and resets them;
  * all zeros when profiling is off. */
 vpt_status vpt_batch_phase_cycles(vpt_batch *b, uint64_t cycles[8]);
+/* Diagnostics, same switch: the node reads the specialised kernel's lanes ISSUED since the last call, per level -- [0] unigram, [1] bigram,
+ * [2] trigram nodes, [3] deep-trie entries, [4] deep-trie rows, [5] type rows in global memory (layout.h) -- i.e. the useful bytes of its
+ * gathers (reads x node size) to set beside the 128-byte lines the L2 fetches for them; zeros without VPT_PROFILE_PHASES. */
+vpt_status vpt_batch_node_reads(vpt_batch *b, uint64_t reads[8]);
 
 /* ---------------------------------------------------------------------------------------------------------
  * Introspection (host-only; used by tests and the bench's roofline accounting)

@@ -29,7 +29,9 @@
  *
  * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load this library.
  */
+#define _GNU_SOURCE   /* pthread_setaffinity_np, sched_getaffinity (the timed baseline pins its workers) */
 #include <pthread.h>
+#include <sched.h>
 #include <stdint.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -869,9 +871,11 @@ int vo_count_boundaries(const uint8_t *utf8, const uint64_t *byte_offsets, size_
 typedef struct {
     const vo_predictor *p; const uint8_t *utf8; const uint64_t *boff, *ooff;
     size_t lo, hi; int32_t *scores; uint8_t *labels; uint64_t abytes; int status;
+    int cpu;   /* >= 0: the worker pins itself to this CPU (timing runs: no migration, first-touch locality) */
 } job_t;
 static void *job_run(void *arg) {
     job_t *j = (job_t *)arg;
+    if (j->cpu >= 0) { cpu_set_t set; CPU_ZERO(&set); CPU_SET(j->cpu, &set); (void)pthread_setaffinity_np(pthread_self(), sizeof(set), &set); }
     scratch_t s; memset(&s, 0, sizeof(s));
     for (size_t i = j->lo; i < j->hi; i++) {
         long n = predict_one(j->p, j->utf8 + j->boff[i], (size_t)(j->boff[i + 1] - j->boff[i]), &s,
@@ -887,12 +891,21 @@ static void *job_run(void *arg) {
  * optionally on `nthreads` host threads over contiguous sentence shards (the reference itself is serial).
  * `char_bytes_out` (may be NULL) receives A_char of BASELINE.md section 4: the sum over every un-merged
  * char n-gram / dict word occurrence of 4*len(w). */
-int vo_predict_batch(const vo_predictor *p, const uint8_t *utf8, const uint64_t *byte_offsets, size_t S,
-                     int32_t *scores, uint8_t *labels, const uint64_t *out_offsets, int nthreads, uint64_t *char_bytes_out) {
+/* flags: bit 0 = pin worker t to the t-th CPU this process may run on (timed baseline runs) */
+int vo_predict_batch_ex(const vo_predictor *p, const uint8_t *utf8, const uint64_t *byte_offsets, size_t S,
+                        int32_t *scores, uint8_t *labels, const uint64_t *out_offsets, int nthreads, uint64_t *char_bytes_out, int flags) {
     if (nthreads < 1) nthreads = 1;
     if ((size_t)nthreads > S) nthreads = S ? (int)S : 1;
     job_t *jobs = (job_t *)xcalloc((size_t)nthreads, sizeof(job_t));
     pthread_t *th = (pthread_t *)xcalloc((size_t)nthreads, sizeof(pthread_t));
+    int *cpus = NULL; int ncpus = 0;
+    if ((flags & 1) && nthreads > 1) {
+        cpu_set_t allowed; CPU_ZERO(&allowed);
+        if (sched_getaffinity(0, sizeof(allowed), &allowed) == 0) {
+            cpus = (int *)xcalloc(CPU_SETSIZE, sizeof(int));
+            for (int c = 0; c < CPU_SETSIZE; c++) if (CPU_ISSET(c, &allowed)) cpus[ncpus++] = c;
+        }
+    }
     /* shards balanced by byte count */
     uint64_t total = S ? byte_offsets[S] - byte_offsets[0] : 0;
     size_t lo = 0;
@@ -902,6 +915,7 @@ int vo_predict_batch(const vo_predictor *p, const uint8_t *utf8, const uint64_t 
         if (t == nthreads - 1) hi = S; else while (hi < S && byte_offsets[hi + 1] <= target) hi++;
         jobs[t].p = p; jobs[t].utf8 = utf8; jobs[t].boff = byte_offsets; jobs[t].ooff = out_offsets;
         jobs[t].lo = lo; jobs[t].hi = hi; jobs[t].scores = scores; jobs[t].labels = labels;
+        jobs[t].cpu = (ncpus >= nthreads) ? cpus[t] : -1;
         lo = hi;
     }
     if (nthreads == 1) job_run(&jobs[0]);
@@ -912,8 +926,12 @@ int vo_predict_batch(const vo_predictor *p, const uint8_t *utf8, const uint64_t 
     int status = VO_OK; uint64_t ab = 0;
     for (int t = 0; t < nthreads; t++) { if (jobs[t].status && !status) status = jobs[t].status; ab += jobs[t].abytes; }
     if (char_bytes_out) *char_bytes_out = ab;
-    free(jobs); free(th);
+    free(jobs); free(th); free(cpus);
     return status;
+}
+int vo_predict_batch(const vo_predictor *p, const uint8_t *utf8, const uint64_t *byte_offsets, size_t S,
+                     int32_t *scores, uint8_t *labels, const uint64_t *out_offsets, int nthreads, uint64_t *char_bytes_out) {
+    return vo_predict_batch_ex(p, utf8, byte_offsets, S, scores, labels, out_offsets, nthreads, char_bytes_out, 0);
 }
 
 /* ------------------------------------------------------------------------------------------ */

@@ -59,3 +59,21 @@ def test_two_ranks_on_one_device_through_the_self_launch():
     l3 = json.loads([l for l in fb.stdout.decode().splitlines() if l.startswith("{")][-1])
     assert l3["n_gpus"] == 2 and l3["parity"] is True and l3["config"]["workload"] == l1["config"]["workload"]
     assert "in-process fallback" in l3["config"]["launch"]
+
+
+@pytest.mark.gpu
+def test_dry_scale_sweep_up_to_four_ranks():
+    """`bench.py --dry-scale`: the scaling job's pre-flight -- N = 1, 2, 4 as jobs of their own (on a 1-GPU box every rank on
+    device 0 over gloo), one line per N with the same workload, parity, per-rank figures, and the ranks' solo kernels adding up to the N = 1 kernel."""
+    r = _run(["--dry-scale", "--scale-sweep", "1,2,4", "--config", "2", "--sentences", "400000", "--model-scale", "0.05", "--steps", "3", "--warmup", "1",
+              "--no-emit", "--no-e2e"])
+    lines = [json.loads(l) for l in r.stdout.decode().splitlines() if l.startswith("{")]
+    assert r.returncode == 0, (r.stderr[-3000:], [l.get("dry_scale_checks") for l in lines])
+    assert [l["n_gpus"] for l in lines] == [1, 2, 4]
+    assert len({l["config"]["workload"] for l in lines}) == 1
+    for l in lines:
+        assert l["parity"] is True and all(l["dry_scale_checks"].values()), l["dry_scale_checks"]
+        assert l["scaling_efficiency"] is not None
+        if l["n_gpus"] > 1:
+            assert len(l["per_rank"]) == l["n_gpus"] and all(pr["tables_broadcast_s"] is not None for pr in l["per_rank"])
+            assert sum(pr["sentences"] for pr in l["per_rank"]) == 400000

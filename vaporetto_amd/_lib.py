@@ -81,6 +81,7 @@ SIGNATURES = {
     "vpt_batch_kernel_ms": (C.c_int, [_P, C.POINTER(C.c_float), C.POINTER(C.c_uint32)]),
     "vpt_batch_kernel_times": (C.c_int, [_P, _P, C.c_size_t, C.POINTER(C.c_size_t)]),
     "vpt_batch_phase_cycles": (C.c_int, [_P, C.POINTER(C.c_uint64 * 8)]),
+    "vpt_batch_node_reads": (C.c_int, [_P, C.POINTER(C.c_uint64 * 8)]),
     "vpt_model_inspect": (C.c_int, [_P, C.c_size_t, C.c_int, C.POINTER(ModelInfo)]),
     "vpt_model_read_len": (C.c_int, [_P, C.c_size_t, C.POINTER(C.c_size_t)]),
     "vpt_predictor_info": (C.c_int, [_P, C.POINTER(ModelInfo)]),

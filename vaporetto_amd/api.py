@@ -855,6 +855,14 @@ class DeviceBatch:
             _raise(st)
         return list(arr)
 
+    def node_reads(self):
+        """Node reads the specialised kernel issued since the last call (vpt_batch_node_reads; needs VPT_PROFILE_PHASES)."""
+        arr = (C.c_uint64 * 8)()
+        st = _lib.load().vpt_batch_node_reads(self._h, C.byref(arr))
+        if st != _lib.VPT_OK:
+            _raise(st)
+        return dict(zip(["unigram_nodes", "bigram_nodes", "trigram_nodes", "deep_entries", "deep_rows", "global_type_rows"], [int(x) for x in arr][:6]))
+
 
 def pack_texts(raws: Sequence[bytes]) -> Tuple[np.ndarray, np.ndarray]:
     boff = np.zeros(len(raws) + 1, dtype=np.uint64)

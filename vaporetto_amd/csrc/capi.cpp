@@ -219,7 +219,7 @@ struct vpt_batch {
     uint64_t* d_cut_super = nullptr; size_t cut_super_cap = 0;
     uint32_t* d_slow_list = nullptr;
     uint32_t* d_ctrl = nullptr;        // [0] status bits, [1] slow tile count
-    uint64_t* d_prof = nullptr;        // 8 per-phase cycle counters (only with VPT_PROFILE_PHASES set)
+    uint64_t* d_prof = nullptr;        // 8 per-phase cycle counters + 8 node-read counters (only with VPT_PROFILE_PHASES set)
     unsigned char* d_scratch = nullptr; size_t scratch_bytes = 0;
     uint32_t* d_cps = nullptr; size_t cps_cap = 0;   // decoded scalar values for vpt_fill_tags_batch_device
     // the batch whose chars d_cps holds because the scoring kernel of a predict call on this workspace wrote them (all 0: none)
@@ -866,8 +866,8 @@ vpt_status vpt_batch_create(const vpt_predictor* p, vpt_batch** out) {
     hipError_t e = hipMalloc(reinterpret_cast<void**>(&b->d_ctrl), 64);
     if (e == hipSuccess) e = hipMemset(b->d_ctrl, 0, 64);
     if (e == hipSuccess && b->knobs.profile_phases) {
-        e = hipMalloc(reinterpret_cast<void**>(&b->d_prof), 64);
-        if (e == hipSuccess) e = hipMemset(b->d_prof, 0, 64);
+        e = hipMalloc(reinterpret_cast<void**>(&b->d_prof), 128);
+        if (e == hipSuccess) e = hipMemset(b->d_prof, 0, 128);
     }
     if (e != hipSuccess) { batch_release(b); return fail(VPT_RUNTIME_ERROR, std::string("HIP error: ") + hipGetErrorString(e)); }
     *out = b;
@@ -944,6 +944,17 @@ vpt_status vpt_batch_phase_cycles(vpt_batch* b, uint64_t cycles[8]) {
     VPT_HIP(hipDeviceSynchronize());
     VPT_HIP(hipMemcpy(cycles, b->d_prof, 64, hipMemcpyDeviceToHost));
     VPT_HIP(hipMemset(b->d_prof, 0, 64));
+    return VPT_OK;
+}
+
+vpt_status vpt_batch_node_reads(vpt_batch* b, uint64_t reads[8]) {
+    if (!b || !reads) return fail(VPT_INVALID_ARGUMENT, "InvalidArgumentError: NULL argument");
+    std::memset(reads, 0, 64);
+    if (!b->d_prof) return VPT_OK;
+    VPT_HIP(hipSetDevice(b->device));
+    VPT_HIP(hipDeviceSynchronize());
+    VPT_HIP(hipMemcpy(reads, b->d_prof + 8, 64, hipMemcpyDeviceToHost));
+    VPT_HIP(hipMemset(b->d_prof + 8, 0, 64));
     return VPT_OK;
 }
 

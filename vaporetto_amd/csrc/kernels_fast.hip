@@ -94,6 +94,14 @@ __device__ __forceinline__ uint32_t lane_rank(uint64_t mask) {  // set bits of `
     return __builtin_amdgcn_mbcnt_hi(uint32_t(mask >> 32), __builtin_amdgcn_mbcnt_lo(uint32_t(mask), 0u));
 }
 
+// Diagnostics (VPT_PROFILE_PHASES): counts the node reads the lanes ISSUE per level (slots 8 ..: unigram, bigram, trigram nodes, deep entries, deep rows, global type
+// rows): the "useful bytes" of the gathers = reads x node size, to set beside the 128-byte lines the L2 fetches for them
+__device__ __forceinline__ void count_reads(uint64_t* prof, int slot, bool pred, uint32_t per_lane = 1) {
+    if (!prof) return;
+    const uint64_t m = __ballot(pred);
+    if (m != 0 && int(threadIdx.x & 63) == __builtin_ctzll(m)) atomicAdd(reinterpret_cast<unsigned long long*>(prof + 8 + slot), (unsigned long long)(__popcll(m)) * per_lane);
+}
+
 // 16 bytes at base + byte offset (32-bit): one scalar base for all packed arrays
 __device__ __forceinline__ uint4 ld16(const unsigned char* base, uint32_t byte_off) {
     return *reinterpret_cast<const uint4*>(base + byte_off);
@@ -169,7 +177,7 @@ __device__ __forceinline__ void unpack4(const uint4 (&v)[Q], uint32_t (&d)[4 * Q
 // The home entry and the next one are read together (a mini-table keeps a quarter of its entries free, so nearly
 // every search ends within two); the rare longer search loops.
 template <int WL>
-__device__ __forceinline__ void replay_w(const PackedView& K, FastLds& L, WaveStacks& Q, int lane) {
+__device__ __forceinline__ void replay_w(const PackedView& K, FastLds& L, WaveStacks& Q, int lane, uint64_t* prof = nullptr) {
     VPT_WAVE_LOCKSTEP();   // the queue entries were written by other lanes
     const uint32_t take = wave_uniform(Q.nw < 64u ? Q.nw : 64u);   // opaque: nw - min(nw, 64) would become a VALU-only saturating subtract
     Q.nw = wave_uniform(Q.nw - take);
@@ -183,6 +191,7 @@ __device__ __forceinline__ void replay_w(const PackedView& K, FastLds& L, WaveSt
     const uint32_t last = (1u << (it.y & 31u)) - 1u;
     const uint32_t i0 = packed_mini_slot(c, it.y), i1 = (i0 + 1) & last;
     const uint4 ea = ld16(K.base, tab + (i0 << 6)), eb = ld16(K.base, tab + (i1 << 6));
+    count_reads(prof, 3, have, 2);
     const bool ma = c != 0 && (ea.x & 0xFFFFu) == c;
     const bool mb = c != 0 && !ma && ea.x != 0 && (eb.x & 0xFFFFu) == c;   // last == 0: eb is ea again, no match
     bool found = ma || mb;
@@ -227,6 +236,7 @@ __device__ __forceinline__ void replay_w(const PackedView& K, FastLds& L, WaveSt
     if (__ballot(row) != 0) {
         uint4 f0 = make_uint4(0, 0, 0, 0), f1 = make_uint4(0, 0, 0, 0);
         if (row) f0 = ld16(K.base, ent + 32);   // (loading the home entry's row speculatively with the entry: no faster, profiles/r02_c5_ab*.jsonl)
+        count_reads(prof, 4, row);
         if (__ballot(row && rlen > 8) != 0) { if (row && rlen > 8) f1 = ld16(K.base, ent + 48); }
         if (row) {
             atomicAdd(dst, lo16(f0.x)); atomicAdd(dst + 1, hi16(f0.x)); atomicAdd(dst + 2, lo16(f0.y)); atomicAdd(dst + 3, hi16(f0.y));
@@ -248,15 +258,24 @@ __device__ __forceinline__ void replay_w(const PackedView& K, FastLds& L, WaveSt
     Q.push_w(found && e.y != 0, s | (m << 11), e.y);
 }
 
-// Entry of a <= 3-char string in the GENERAL short table (layout.h; buckets of two entries of stride_dw dwords): used for the
-// rare packed nodes whose row is marked wide.  Returns the entry's first dword or nullptr.
+// The GENERAL tables are laid out for the same row window (tables.cpp: build_table(pats, wl, ..)), so their geometry is a
+// compile-time function of WL too -- the rare wide rows cost the main loop no scalar registers for strides and row bounds.
+template <int WL>
+struct GeneralGeom {
+    static constexpr uint32_t kStride = uint32_t((2 + 2 * WL + 3) & ~3);   // dwords per short entry: key + max(len) slots (+ the continuation slot)
+    static constexpr uint32_t kUniDw = uint32_t((2 * WL + 3) & ~3);        // dwords per direct unigram row
+};
+// Entry of a <= 3-char string in the GENERAL short table (layout.h; buckets of two entries): used for the rare packed nodes whose
+// row is marked wide.  Returns the entry's first dword or nullptr.
+template <int WL>
 __device__ __forceinline__ const uint32_t* general_row(const PatternTableView& T, uint64_t key) {
+    constexpr uint32_t kStride = GeneralGeom<WL>::kStride;
     const uint32_t klo = uint32_t(key), khi = uint32_t(key >> 32);
     uint32_t b = hash_slot(key, T.short_shift);
     bool home = true;
     for (;;) {
-        const uint32_t* e0 = T.short_tab + size_t(b) * 2 * T.stride_dw;
-        const uint32_t* e1 = e0 + T.stride_dw;
+        const uint32_t* e0 = T.short_tab + size_t(b) * (2 * kStride);
+        const uint32_t* e1 = e0 + kStride;
         const uint32_t a0 = e0[0], a1 = e0[1], b0 = e1[0], b1 = e1[1];
         if (a0 == klo && (a1 & ~kDisplacedBit) == khi) return e0;
         if (b0 == klo && b1 == khi) return e1;
@@ -267,7 +286,8 @@ __device__ __forceinline__ const uint32_t* general_row(const PatternTableView& T
 }
 
 // rows with a value outside their fields (rare): the general tables hold them as i32, keyed by code points; the row of a string of
-// n chars covers the boundaries s + lo[n] .. (layout.h, general tables -- laid out for the same row window)
+// n chars covers the boundaries s + row_lo(n, WL) .. (layout.h)
+template <int WL>
 __device__ __forceinline__ void add_wide_rows(const PackedView& K, const PatternTableView& T, FastLds& L, uint32_t kinds, uint32_t s) {
     const uint32_t* cpid = reinterpret_cast<const uint32_t*>(K.base + K.off_cpid);
     // a wide row belongs to a pattern that matched here: its chars are in the alphabet (ids below n_uni)
@@ -275,34 +295,35 @@ __device__ __forceinline__ void add_wide_rows(const PackedView& K, const Pattern
     const uint32_t i1 = L.sym[s] & kCpMask, i2 = L.sym[s + 1] & kCpMask, i3 = L.sym[s + 2] & kCpMask;
     const uint32_t c1 = cpid[i1 < last ? i1 : last], c2 = cpid[i2 < last ? i2 : last], c3 = cpid[i3 < last ? i3 : last];
     if (kinds & kWideUni) {
-        const uint32_t* u = T.uni + size_t(c1) * T.uni_dw;
-        for (int32_t j = 0; j < T.len[0]; ++j) atomicAdd(L.score + int32_t(s) + T.lo[0] + j, int32_t(u[j]));
+        const uint32_t* u = T.uni + size_t(c1) * GeneralGeom<WL>::kUniDw;
+        for (int j = 0; j < row_len(1, WL); ++j) atomicAdd(L.score + int32_t(s) + row_lo(1, WL) + j, int32_t(u[j]));
     }
     if (kinds & kWideBi) {
-        if (const uint32_t* e = general_row(T, short_key(c1, c2, 0)))
-            for (int32_t j = 0; j < T.len[1]; ++j) atomicAdd(L.score + int32_t(s) + T.lo[1] + j, int32_t(e[2 + j]));
+        if (const uint32_t* e = general_row<WL>(T, short_key(c1, c2, 0)))
+            for (int j = 0; j < row_len(2, WL); ++j) atomicAdd(L.score + int32_t(s) + row_lo(2, WL) + j, int32_t(e[2 + j]));
     }
     if (kinds & kWideTri) {
-        if (const uint32_t* e = general_row(T, short_key(c1, c2, c3)))
-            for (int32_t j = 0; j < T.len[2]; ++j) atomicAdd(L.score + int32_t(s) + T.lo[2] + j, int32_t(e[2 + j]));
+        if (const uint32_t* e = general_row<WL>(T, short_key(c1, c2, c3)))
+            for (int j = 0; j < row_len(3, WL); ++j) atomicAdd(L.score + int32_t(s) + row_lo(3, WL) + j, int32_t(e[2 + j]));
     }
 }
 
 // M: up to 64 queued rows with a value outside their fields -- taken from the general tables (i32).
+template <int WL>
 __device__ __forceinline__ void replay_m(const PackedView& K, const PatternTableView& T, FastLds& L, WaveStacks& Q, int lane) {
     VPT_WAVE_LOCKSTEP();   // the queue entries were written by other lanes
     const uint32_t take = wave_uniform(Q.nm < 64u ? Q.nm : 64u);
     Q.nm -= take;
     if (uint32_t(lane) < take) {
         const uint32_t it = Q.mq[Q.nm + lane];
-        add_wide_rows(K, T, L, it >> 11, it & 0x7FFu);
+        add_wide_rows<WL>(K, T, L, it >> 11, it & 0x7FFu);
     }
 }
 
 // W replays until at most `mark` items are left (a W item becomes at most one W item, so the loop ends).
 template <int WL>
-__device__ __forceinline__ void drain_w(const PackedView& K, FastLds& L, WaveStacks& Q, int lane, uint32_t mark) {
-    while (Q.nw > mark) replay_w<WL>(K, L, Q, lane);
+__device__ __forceinline__ void drain_w(const PackedView& K, FastLds& L, WaveStacks& Q, int lane, uint32_t mark, uint64_t* prof = nullptr) {
+    while (Q.nw > mark) replay_w<WL>(K, L, Q, lane, prof);
 }
 
 // optional phase timing (VPT_PROFILE_PHASES): wave 0 of every workgroup adds the shader cycles it spent per phase
@@ -550,6 +571,8 @@ __global__ __launch_bounds__(kThreads, fast_wg(WL)) void score_tiles_fast_kernel
 #pragma unroll
         for (int q = 0; q < G::kUniQ; ++q) un[q] = make_uint4(0, 0, 0, 0);
         uint32_t x1 = 0, x2 = 0, x3 = 0;
+        if (DBG && do_t) count_reads(prof, 2, t_slot != ~0u);
+        if (DBG && do_b) count_reads(prof, 1, b_key != 0);
         if (do_t) {
             if (t_slot != ~0u) {
                 const uint32_t a = off_tri + (((P.debug & 1u) ? 0u : t_slot) * uint32_t(4 * pk_tri_dw(WL)));
@@ -570,6 +593,7 @@ __global__ __launch_bounds__(kThreads, fast_wg(WL)) void score_tiles_fast_kernel
             const uint32_t id1 = x1 & kCpMask;
             live = id1 != 0;
             const bool want = live && id1 != kNoId;   // a char no pattern contains has no unigram node (its row is zero, its base unused)
+            if (DBG) count_reads(prof, 0, want);
             if (__ballot(want) != 0) {
                 if (want) {
                     const uint32_t a = K.off_uni + (((P.debug & 4u) ? 0u : id1) * uint32_t(4 * pk_uni_dw(WL)));
@@ -594,11 +618,11 @@ __global__ __launch_bounds__(kThreads, fast_wg(WL)) void score_tiles_fast_kernel
             const bool wide = hit && (td[0] & (kPkWide << kTriFlagShift));
             uint32_t kids = hit ? td[pk_tri_kids_dw(WL)] : 0u;
             VPT_PIN(kids);
-            drain_w<WL>(K, L, Q, lane, kQHigh);                 // room for one more round of pushes
+            drain_w<WL>(K, L, Q, lane, kQHigh, prof);           // room for one more round of pushes
             Q.push_w(kids != 0 && !(P.debug & 8u), s_t | (3u << 11), kids);
             const uint64_t mm = __ballot(wide);
             if (mm != 0) {
-                while (Q.nm + uint32_t(__popcll(mm)) > uint32_t(kMCap)) replay_m(K, P.ct, L, Q, lane);
+                while (Q.nm + uint32_t(__popcll(mm)) > uint32_t(kMCap)) replay_m<WL>(K, P.ct, L, Q, lane);
                 Q.push_m(wide, s_t | (kWideTri << 11));
             }
         }
@@ -622,7 +646,7 @@ __global__ __launch_bounds__(kThreads, fast_wg(WL)) void score_tiles_fast_kernel
             const bool bwide = keyok && ufield<pk_bi_wide_bit(WL), 1>(rowd) != 0;
             const uint64_t mm = __ballot(bwide);
             if (mm != 0) {
-                while (Q.nm + uint32_t(__popcll(mm)) > uint32_t(kMCap)) replay_m(K, P.ct, L, Q, lane);
+                while (Q.nm + uint32_t(__popcll(mm)) > uint32_t(kMCap)) replay_m<WL>(K, P.ct, L, Q, lane);
                 Q.push_m(bwide, s_b | (kWideBi << 11));
             }
         }
@@ -652,6 +676,7 @@ __global__ __launch_bounds__(kThreads, fast_wg(WL)) void score_tiles_fast_kernel
                     for (int32_t i = int32_t(K.trow_levels) - 1; i >= 3; --i) idx = idx * 7u + ((L.sym[s_u + uint32_t(i)] >> 16) & 7u);
                     idx = (idx * 7u + ((x3 >> 16) & 7u)) * 7u + ((x2 >> 16) & 7u);
                     idx = idx * 6u + (((x1 >> 16) & 7u) - 1u);
+                    if (DBG) count_reads(prof, 5, live);
                     if (live) {
                         const uint32_t ra = K.off_trow + idx * uint32_t(4 * pk_trow_global_dw(WL));
                         uint4 tr[pk_trow_global_dw(WL) / 4];
@@ -675,13 +700,13 @@ __global__ __launch_bounds__(kThreads, fast_wg(WL)) void score_tiles_fast_kernel
             const bool uwide = live && ufield<pk_uni_base_bit(WL) + kUniBaseBits, 1>(ud) != 0 && !(P.debug & 32u);
             const uint64_t mm = __ballot(uwide);
             if (mm != 0) {
-                while (Q.nm + uint32_t(__popcll(mm)) > uint32_t(kMCap)) replay_m(K, P.ct, L, Q, lane);
+                while (Q.nm + uint32_t(__popcll(mm)) > uint32_t(kMCap)) replay_m<WL>(K, P.ct, L, Q, lane);
                 Q.push_m(uwide, s_u | (kWideUni << 11));
             }
         }
     }
-    while (Q.nm > 0) replay_m(K, P.ct, L, Q, lane);
-    while (Q.nw > 0) replay_w<WL>(K, L, Q, lane);
+    while (Q.nm > 0) replay_m<WL>(K, P.ct, L, Q, lane);
+    while (Q.nw > 0) replay_w<WL>(K, L, Q, lane, prof);
     tmark = phase_mark(prof, 4, tmark);   // patterns
     __syncthreads();
     tmark = phase_mark(prof, 5, tmark);   // waiting for the other waves
@@ -905,7 +930,8 @@ __global__ __launch_bounds__(256) void assign_tiles_cut_kernel(const uint64_t* _
 // The instance that scores a predictor: its row window and where its type scores come from, or nothing (the general kernels).
 static bool fast_instance(const ScoreParams& P, int* wl_out, int* tm_out) {
     if (!P.pk.present || !P.cid || P.pk.wl < 3 || P.pk.wl > uint32_t(kMaxWindow) || P.pad != pk_pad(int(P.pk.wl))) return false;
-    if (!P.ct.present || P.ct.uni_n != kUniDirectChars || P.ct.window != int32_t(P.pk.wl)) return false;   // the rows marked wide come from the general tables
+    if (!P.ct.present || P.ct.uni_n != kUniDirectChars || P.ct.window != int32_t(P.pk.wl)) return false;   // the rows marked wide come from the general tables,
+    if (P.ct.stride_dw != uint32_t((2 + 2 * P.pk.wl + 3) & ~3u) || P.ct.uni_dw != uint32_t((2 * P.pk.wl + 3) & ~3u)) return false;   // whose geometry the kernel knows (GeneralGeom)
     const int wl = int(P.pk.wl);
     int tm;
     if (P.type_kind == kTypeNone) tm = 0;

@@ -35,6 +35,8 @@ def _load():
         L.vpt_synth_model_ex.argtypes = [C.c_int, C.c_uint64, C.c_double, C.c_uint32, C.c_double, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]
         L.vpt_synth_sentences.argtypes = [C.c_char_p, C.c_size_t, C.c_uint64, C.c_size_t, C.c_uint32, C.c_uint32,
                                           C.POINTER(C.c_void_p), C.POINTER(C.c_size_t), C.POINTER(C.c_void_p)]
+        L.vpt_synth_sentences_ex.argtypes = [C.c_char_p, C.c_size_t, C.c_uint64, C.c_size_t, C.c_uint32, C.c_uint32, C.c_double,
+                                             C.POINTER(C.c_void_p), C.POINTER(C.c_size_t), C.POINTER(C.c_void_p)]
         L.vpt_synth_blocks.argtypes = [C.c_char_p, C.c_size_t, C.c_uint64, C.c_size_t, C.c_size_t, C.c_size_t, C.c_uint32, C.c_uint32, C.c_uint32,
                                        C.POINTER(C.c_void_p), C.POINTER(C.c_size_t), C.POINTER(C.c_void_p)]
         L.vpt_synth_free.argtypes = [C.c_void_p]
@@ -57,12 +59,13 @@ def synth_model(kind: int = M1_BCCWJ_LIKE, seed: int = SEED_BASE + 2, scale: flo
 
 
 def synth_sentences(model_bytes: bytes, n_sentences: int, min_len: int = 64, max_len: int = 64,
-                    seed: int = SEED_BASE + 2):
-    """(utf8 uint8[bytes], byte_offsets uint64[S+1]) -- 70 % model patterns (Zipf), 30 % alphabet-A characters."""
+                    seed: int = SEED_BASE + 2, hit_share: float = 0.7):
+    """(utf8 uint8[bytes], byte_offsets uint64[S+1]) -- `hit_share` (70 %) of a sentence's items are model patterns
+    (Zipf), the others alphabet-A characters."""
     L = _load()
     text, nbytes, boff = C.c_void_p(), C.c_size_t(), C.c_void_p()
-    st = L.vpt_synth_sentences(model_bytes, len(model_bytes), seed, n_sentences, min_len, max_len,
-                               C.byref(text), C.byref(nbytes), C.byref(boff))
+    st = L.vpt_synth_sentences_ex(model_bytes, len(model_bytes), seed, n_sentences, min_len, max_len, C.c_double(hit_share),
+                                  C.byref(text), C.byref(nbytes), C.byref(boff))
     if st != 0:
         raise RuntimeError("vpt_synth_sentences failed: %d" % st)
     try:

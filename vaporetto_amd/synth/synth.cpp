@@ -264,7 +264,7 @@ struct PatternList {
 };
 // one block of sentences from its own splitmix64 stream: text bytes appended to `text`, byte length of every sentence to `lens`
 void gen_block(const PatternList& P, uint64_t seed, size_t n_sent, uint32_t min_len, uint32_t max_len, std::vector<uint8_t>& text,
-               std::vector<uint32_t>& lens) {
+               std::vector<uint32_t>& lens, double hit_share = 0.7) {
     const std::vector<const vpt::SymString*>& pats = P.pats;
     Rng r(seed);
     auto alphabet_a = [&]() -> uint32_t {
@@ -288,7 +288,7 @@ void gen_block(const PatternList& P, uint64_t seed, size_t n_sent, uint32_t min_
         }
         sent.clear();
         while (sent.size() < L) {
-            if (!pats.empty() && r.uniform() < 0.7) {
+            if (!pats.empty() && r.uniform() < hit_share) {
                 const vpt::SymString& p = *pats[r.zipf(uint32_t(pats.size()))];
                 sent.insert(sent.end(), p.begin(), p.end());
             } else sent.push_back(alphabet_a());
@@ -326,15 +326,21 @@ int emit(const std::vector<std::vector<uint8_t>>& texts, const std::vector<std::
 
 extern "C" {
 
-int vpt_synth_sentences(const uint8_t* model, size_t model_len, uint64_t seed, size_t n_sent, uint32_t min_len,
-                        uint32_t max_len, uint8_t** utf8_out, size_t* nbytes_out, uint64_t** boff_out) {
-    if (!model || !utf8_out || !nbytes_out || !boff_out || min_len < 1 || max_len < min_len) return 2;
+// hit_share: the share of a sentence's ITEMS drawn from the model's pattern list (0.7); the rest are single chars of
+// alphabet A, most of which no pattern continues -- the knob of the text-realism sweep (tools/hit_share_sweep.py)
+int vpt_synth_sentences_ex(const uint8_t* model, size_t model_len, uint64_t seed, size_t n_sent, uint32_t min_len,
+                           uint32_t max_len, double hit_share, uint8_t** utf8_out, size_t* nbytes_out, uint64_t** boff_out) {
+    if (!model || !utf8_out || !nbytes_out || !boff_out || min_len < 1 || max_len < min_len || !(hit_share >= 0 && hit_share <= 1)) return 2;
     PatternList P;
     if (!P.load(model, model_len)) return 1;
     std::vector<std::vector<uint8_t>> texts(1);
     std::vector<std::vector<uint32_t>> lens(1);
-    gen_block(P, seed, n_sent, min_len, max_len, texts[0], lens[0]);
+    gen_block(P, seed, n_sent, min_len, max_len, texts[0], lens[0], hit_share);
     return emit(texts, lens, utf8_out, nbytes_out, boff_out);
+}
+int vpt_synth_sentences(const uint8_t* model, size_t model_len, uint64_t seed, size_t n_sent, uint32_t min_len,
+                        uint32_t max_len, uint8_t** utf8_out, size_t* nbytes_out, uint64_t** boff_out) {
+    return vpt_synth_sentences_ex(model, model_len, seed, n_sent, min_len, max_len, 0.7, utf8_out, nbytes_out, boff_out);
 }
 
 // A big batch as BLOCKS of `block_sentences` sentences, block j from the stream seeded seed0 + 7919 j: any contiguous run of
