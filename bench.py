@@ -355,6 +355,32 @@ class Runner:
                          "kernels": "emit_fused_kernel: one launch (kernels_emit.hip), %s" % ("tagged" if nt else "boundaries only")}
             # the whole output is compared with the oracle's writer below (sentence.rs:850-886 restated in oracle/vaporetto_oracle.c)
             emit_out = (d_out[:out_bytes].cpu().numpy(), toff) if not args.no_cpu_baseline else None
+            # ... and the writer as a phase of the scoring kernel (vpt_predict_write_batch_device): ONE launch leaves scores, labels and the
+            # tokenized text; compared with predict + emit above (kernel time by the same HIP events), its text with the writer's
+            if not nt:
+                d_out2 = torch.empty(cap + 1, dtype=torch.uint8, device=dev)
+
+                def fused():
+                    batch.predict_write(d_text.data_ptr(), d_boff.data_ptr(), d_ooff.data_ptr(), S, nb, max_bytes, d_scores.data_ptr(), d_labels.data_ptr(),
+                                        d_out2.data_ptr(), cap, d_toff.data_ptr(), stream)
+                for _ in range(3):
+                    fused()
+                batch.sync()
+                batch.kernel_ms()
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for _ in range(steps):
+                    fused()
+                torch.cuda.synchronize()
+                dtf = (time.perf_counter() - t0) / steps
+                batch.sync()
+                kt = batch.kernel_times()
+                toff2 = d_toff.cpu().numpy().astype(np.uint64)
+                same = bool(np.array_equal(toff2, toff) and torch.equal(d_out2[:out_bytes], d_out[:out_bytes]))
+                emit_info["fused"] = {"ms_per_step": 1e3 * dtf, "kernel_ms": float(np.median(kt)) if len(kt) else None, "same_text_as_the_writer": same,
+                                      "separate_ms_per_step": 1e3 * elapsed / steps + emit_info["ms_per_step"],
+                                      "kernels": "score_tiles_fast_kernel<.., EMIT>: phases A-C + D (tokenized text from the tile's LDS, look-back over the tiles' sizes)"}
+                del d_out2
             del d_out, d_toff
 
         # ---- parity against the oracle (this rank's whole shard, bit for bit) and the algorithmic bytes it counts

@@ -300,6 +300,17 @@ vpt_status vpt_predictor_max_tag_suffix(const vpt_predictor *p, uint32_t *n_byte
 vpt_status vpt_write_tagged_batch(const vpt_predictor *p, const uint8_t *utf8, const uint64_t *byte_offsets,
                                   size_t n_sentences, const uint64_t *out_offsets, const uint8_t *labels, unsigned flags,
                                   uint8_t *text_out, uint64_t text_capacity, uint64_t *text_offsets_out);
+/* Predictor::predict (predictor.rs:518-543) AND Sentence::write_tokenized_text without tags (sentence.rs:850-886) for a batch in ONE scoring
+ * launch: every tile of the specialised kernel writes the tokenized text of the chars it owns straight from its LDS, placed by a look-back
+ * over the tiles' sizes (no second pass over the text, no writer launch).  d_scores / d_labels may be NULL (a tokenizer needs neither);
+ * d_text_out needs 3 bytes per text byte at most, d_text_offsets_out [n_sentences + 1].  Asynchronous on hip_stream; errors (an output
+ * larger than text_capacity among them) at vpt_batch_sync.  A model outside the specialised kernel's reach runs predict and the writer
+ * one after the other. */
+vpt_status vpt_predict_write_batch_device(const vpt_predictor *p, vpt_batch *b, const uint8_t *d_utf8, const uint64_t *d_byte_offsets,
+                                          const uint64_t *d_out_offsets, size_t n_sentences, uint64_t total_boundaries,
+                                          uint64_t max_sentence_bytes, int32_t *d_scores, uint8_t *d_labels, uint8_t *d_text_out,
+                                          uint64_t text_capacity, uint64_t *d_text_offsets_out, void *hip_stream);
+
 /* Device-resident variants: all pointers are device pointers, asynchronous on `hip_stream`; errors at vpt_batch_sync.
  * One kernel (kernels_emit.hip: a wave per block of sentences sizes, places and writes it).  The tagged one takes the
  * d_tags_out of a vpt_fill_tags_batch_device call made on the SAME workspace for the same batch AND THE SAME LABELS (the

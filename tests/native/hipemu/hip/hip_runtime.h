@@ -66,6 +66,10 @@ hipError_t hipMemcpyAsync(void* dst, const void* src, size_t bytes, hipMemcpyKin
 hipError_t hipMemcpyPeer(void* dst, int dst_device, const void* src, int src_device, size_t bytes);
 hipError_t hipHostMalloc(void** p, size_t bytes, unsigned flags);
 hipError_t hipHostFree(void* p);
+enum hipMemoryType { hipMemoryTypeUnregistered = 0, hipMemoryTypeHost = 1, hipMemoryTypeDevice = 2, hipMemoryTypeManaged = 3 };
+struct hipPointerAttribute_t { hipMemoryType type; int device; void* devicePointer; void* hostPointer; };
+hipError_t hipPointerGetAttributes(hipPointerAttribute_t* attr, const void* ptr);
+hipError_t hipHostGetDevicePointer(void** dptr, void* hptr, unsigned flags);
 hipError_t hipStreamWaitEvent(hipStream_t s, hipEvent_t e, unsigned flags);
 hipError_t hipEventSynchronize(hipEvent_t e);
 hipError_t hipEventCreateWithFlags(hipEvent_t* e, unsigned flags);
@@ -127,6 +131,7 @@ static inline unsigned atomicAdd(unsigned* p, unsigned v) { unsigned o = *p; *p 
 static inline unsigned long long atomicAdd(unsigned long long* p, unsigned long long v) { unsigned long long o = *p; *p = o + v; return o; }
 static inline unsigned atomicOr(unsigned* p, unsigned v) { unsigned o = *p; *p = o | v; return o; }
 static inline unsigned atomicMax(unsigned* p, unsigned v) { unsigned o = *p; *p = o > v ? o : v; return o; }
+static inline unsigned atomicMin(unsigned* p, unsigned v) { unsigned o = *p; *p = o < v ? o : v; return o; }
 #define __HIP_MEMORY_SCOPE_AGENT 0
 template <typename T, typename V> static inline T __hip_atomic_fetch_add(T* p, V v, int, int) {
     T o = *p;

@@ -1,5 +1,7 @@
 // TEST INFRASTRUCTURE ONLY -- the fiber scheduler and the fake runtime behind tests/native/hipemu/hip/hip_runtime.h.
 // Never linked into libvaporetto_hip.so and never loaded by the vaporetto_amd package.
+#include <map>
+#include <mutex>
 #include <ucontext.h>
 
 #include <cstdio>
@@ -274,8 +276,33 @@ hipError_t hipFree(void* p) {
 hipError_t hipMemcpy(void* dst, const void* src, size_t bytes, hipMemcpyKind) { std::memcpy(dst, src, bytes); return hipSuccess; }
 hipError_t hipMemcpyAsync(void* dst, const void* src, size_t bytes, hipMemcpyKind, hipStream_t) { std::memcpy(dst, src, bytes); return hipSuccess; }
 hipError_t hipMemcpyPeer(void* dst, int, const void* src, int, size_t bytes) { std::memcpy(dst, src, bytes); return hipSuccess; }
-hipError_t hipHostMalloc(void** p, size_t bytes, unsigned) { *p = std::malloc(bytes ? bytes : 1); return *p ? hipSuccess : hipErrorOutOfMemory; }
-hipError_t hipHostFree(void* p) { std::free(p); return hipSuccess; }
+// pinned host memory: plain malloc, remembered so that hipPointerGetAttributes can tell it from pageable memory (the product writes
+// tokenized text straight into a pinned output buffer and copies into a pageable one)
+namespace { std::mutex g_pinned_mu; std::map<uintptr_t, size_t> g_pinned; }
+hipError_t hipHostMalloc(void** p, size_t bytes, unsigned) {
+    *p = std::malloc(bytes ? bytes : 1);
+    if (!*p) return hipErrorOutOfMemory;
+    std::lock_guard<std::mutex> g(g_pinned_mu);
+    g_pinned[reinterpret_cast<uintptr_t>(*p)] = bytes ? bytes : 1;
+    return hipSuccess;
+}
+hipError_t hipHostFree(void* p) {
+    { std::lock_guard<std::mutex> g(g_pinned_mu); g_pinned.erase(reinterpret_cast<uintptr_t>(p)); }
+    std::free(p);
+    return hipSuccess;
+}
+hipError_t hipPointerGetAttributes(hipPointerAttribute_t* attr, const void* ptr) {
+    attr->type = hipMemoryTypeUnregistered; attr->device = 0; attr->devicePointer = nullptr; attr->hostPointer = const_cast<void*>(ptr);
+    std::lock_guard<std::mutex> g(g_pinned_mu);
+    const uintptr_t a = reinterpret_cast<uintptr_t>(ptr);
+    auto it = g_pinned.upper_bound(a);
+    if (it != g_pinned.begin()) {
+        --it;
+        if (a >= it->first && a < it->first + it->second) { attr->type = hipMemoryTypeHost; attr->devicePointer = const_cast<void*>(ptr); }
+    }
+    return hipSuccess;
+}
+hipError_t hipHostGetDevicePointer(void** dptr, void* hptr, unsigned) { *dptr = hptr; return hipSuccess; }
 hipError_t hipStreamWaitEvent(hipStream_t, hipEvent_t, unsigned) { return hipSuccess; }
 hipError_t hipEventSynchronize(hipEvent_t) { return hipSuccess; }
 hipError_t hipEventCreateWithFlags(hipEvent_t* e, unsigned) { *e = new hipemu_event(); return hipSuccess; }

@@ -949,6 +949,109 @@ def test_tokenize_batch_in_chunks(chunk_bytes, monkeypatch):
     assert pred.tokenize(texts[:150]) == pred.tokenize(texts[:100]) + pred.tokenize(texts[100:150])   # and the workspaces are clean again
 
 
+def _fused_write(pred, texts, flags=0, want_scores=True, cap=None):
+    """vpt_predict_write_batch_device over `texts`: (scores, labels, tokenized lines, plan)."""
+    utf8, boff = api.pack_texts([t.encode("utf-8") for t in texts])
+    ooff = api.count_boundaries(utf8, boff)
+    S, nb = len(texts), int(ooff[-1])
+    d = [devmem.put(np.concatenate([utf8, np.zeros(32, np.uint8)])), devmem.put(boff), devmem.put(ooff)]
+    d_scores, d_labels = devmem.zeros(nb + 1, np.int32), devmem.zeros(nb + 1, np.uint8)
+    cap = 3 * len(utf8) + 16 if cap is None else cap
+    d_out, d_toff = devmem.zeros(cap + 16, np.uint8), devmem.zeros(S + 1, np.uint64)
+    batch = api.DeviceBatch(pred)
+    batch.set_flags(flags)
+    batch.predict_write(d[0].ptr, d[1].ptr, d[2].ptr, S, nb, int(np.max(np.diff(boff.astype(np.int64)))), d_scores.ptr if want_scores else 0,
+                        d_labels.ptr if want_scores else 0, d_out.ptr, cap, d_toff.ptr, devmem.stream())
+    batch.sync()
+    toff = d_toff.get()
+    raw = bytes(d_out.get()[:int(toff[S])])
+    lines = [raw[int(toff[i]):int(toff[i + 1])].decode("utf-8") for i in range(S)]
+    return d_scores.get()[:nb], d_labels.get()[:nb], lines, batch.last_plan(), (utf8, boff, ooff)
+
+
+@pytest.mark.parametrize("case", ["rows", "window-table", "no-types", "window-5", "window-8", "general"])
+def test_predict_and_write_in_one_launch(case, monkeypatch):
+    """vpt_predict_write_batch_device: the tokenized text comes out of the scoring kernel's tiles (phase D) -- byte for byte what the
+    oracle's Sentence::write_tokenized_text (sentence.rs:850-886) makes of the oracle's labels, for whole-sentence and cut tiles, every
+    UTF-8 length, the escaped bytes, 1-char sentences, sentences longer than a tile, with and without the score / label outputs."""
+    wc, wt = {"window-5": (5, 2), "window-8": (8, 8)}.get(case, (3, 3))
+    if case == "window-table":
+        monkeypatch.setenv("VPT_FORCE_WINDOW_TABLE", "1")
+    m = randmodel.rand_model(4100 + wc, alphabet="mixed", wc=wc, wt=wt, n_char=120, n_dict=120, n_type=0 if case == "no-types" else 60, max_word=9)
+    m.char_ngram_model = [d for d in m.char_ngram_model if all(ord(c) < 0xFFFF for c in d.ngram)]   # BMP patterns: the packed tables
+    m.dict_model = [d for d in m.dict_model if all(ord(c) < 0xFFFF for c in d.word)]
+    if case == "general":
+        m.dict_model.append(WordWeightRecord("𠮷あ", [5, -6, 7], ""))      # a non-BMP pattern: the general kernels, then the writer's own launch
+    pred, orc = make_predictor(m)
+    rng = np.random.default_rng(23)
+    alphabet = randmodel.ALPHABETS["mixed"] + list("/\\  /") + ["\n"]
+    lens = list(rng.integers(1, 60, 400)) + [1, 1, 1, 2, 63, 64, 65] + [1] * 40      # (at most 4 * 65 bytes: whole-sentence tiles)
+    texts = ["".join(rng.choice(alphabet, size=int(n))) for n in lens]
+    texts += randmodel.rand_sentences(5, m, 120, alphabet="mixed", max_len=50)
+    for long_ones in (False, True):
+        batch_texts = texts + (["".join(rng.choice(alphabet, size=int(n))) for n in (300, 319, 320, 321, 1500, 4000, 2, 2600)] if long_ones else [])
+        for want_scores in (True, False):
+            scores, labels, lines, plan, (utf8, boff, ooff) = _fused_write(pred, batch_texts, want_scores=want_scores)
+            o_scores, o_labels, _, _ = orc.predict_batch(utf8, boff)
+            if want_scores:
+                assert np.array_equal(scores, o_scores) and np.array_equal(labels, o_labels)
+            o_text, o_toff = orc.write_tokenized_batch(utf8, boff, ooff, o_labels, None, None)
+            want = [bytes(o_text[int(o_toff[i]):int(o_toff[i + 1])]).decode("utf-8") for i in range(len(batch_texts))]
+            assert lines == want, next((i, batch_texts[i], lines[i], want[i]) for i in range(len(want)) if lines[i] != want[i])
+            if case == "general":
+                assert plan["kind"] == "general kernels"
+            else:
+                assert plan["kind"] == ("cut tiles" if long_ones else "whole-sentence tiles")
+    # the label filters act before the writer; small tiles cut sentences at many places
+    flags = api._lib.VPT_FLAG_SPLIT_LINEBREAKS | (1 << 3)
+    for tile_flat in ("", "61", "256"):
+        if tile_flat:
+            monkeypatch.setenv("VPT_TILE_FLAT", tile_flat)
+            monkeypatch.setenv("VPT_FORCE_CUT_TILES", "1")
+        _, labels, lines, _, (utf8, boff, ooff) = _fused_write(pred, texts, flags=flags)
+        o_text, o_toff = orc.write_tokenized_batch(utf8, boff, ooff, labels, None, None)
+        assert lines == [bytes(o_text[int(o_toff[i]):int(o_toff[i + 1])]).decode("utf-8") for i in range(len(texts))]
+        assert np.array_equal(labels, pred.predict_packed(utf8, boff, wsconst=(3,), split_linebreaks=True)[1])
+    monkeypatch.delenv("VPT_TILE_FLAT", raising=False)
+    monkeypatch.delenv("VPT_FORCE_CUT_TILES", raising=False)
+    # too small a buffer is an error, not a write outside it
+    with pytest.raises(api.VaporettoError, match="text_capacity"):
+        _fused_write(pred, texts, cap=100)
+
+
+@pytest.mark.parametrize("chunk_bytes", ["", "900", "20000"])
+def test_tokenize_batch_into_pinned_buffers(chunk_bytes, monkeypatch):
+    """vpt_tokenize_batch without tags: the scoring kernel's tiles write the tokenized text themselves; into caller buffers in PINNED memory
+    (vpt_host_alloc) they write it over PCIe directly -- no copy out -- chunk after chunk into one contiguous text (the chunks hand the
+    position on through device words); pageable buffers get the same bytes through one copy.  Too small a buffer is an error either way."""
+    if chunk_bytes:
+        monkeypatch.setenv("VPT_TOKENIZE_CHUNK_BYTES", chunk_bytes)
+    m = randmodel.rand_model(853, alphabet="kana", wc=3, wt=3, n_char=80, n_dict=80, max_word=6)
+    pred, orc = make_predictor(m)
+    rng = np.random.default_rng(4)
+    alphabet = randmodel.ALPHABETS["kana"][:12] + list("漢字 /\\aé🤌")
+    texts = ["".join(rng.choice(alphabet, size=int(n))) for n in list(rng.integers(1, 70, 500)) + [1, 1, 900, 2, 3000, 1]]
+    utf8, boff = api.pack_texts([t.encode("utf-8") for t in texts])
+    S = len(texts)
+    o_scores, o_labels, ooff, _ = orc.predict_batch(utf8, boff)
+    o_text, o_toff = orc.write_tokenized_batch(utf8, boff, ooff, o_labels, None, None)
+    cap = 3 * len(utf8)
+    pin_text, pin_off = api.PinnedArray((cap,), np.uint8), api.PinnedArray((S + 1,), np.uint64)
+    pin_text.array[:] = 0xEE
+    for _ in range(2):   # the workspace, its chain words and the ticket are reused
+        text, toff = pred.tokenize_packed(utf8, boff, text_out=pin_text.array, offsets_out=pin_off.array)
+        assert np.array_equal(toff, o_toff) and np.array_equal(text, o_text)
+        assert (pin_text.array[int(o_toff[-1]):] == 0xEE).all()          # nothing behind the text was touched
+    text, toff = pred.tokenize_packed(utf8, boff)                          # pageable buffers
+    assert np.array_equal(toff, o_toff) and np.array_equal(text, o_text)
+    L = api._lib.load()
+    for out in (pin_text.array, np.zeros(cap, np.uint8)):
+        st = L.vpt_tokenize_batch(pred.handle, utf8.ctypes.data, boff.ctypes.data, S, 0, 0, out.ctypes.data, 64, pin_off.array.ctypes.data)
+        assert st == api._lib.VPT_INVALID_ARGUMENT and "text_capacity" in api._lib.last_error()
+    text, toff = pred.tokenize_packed(utf8, boff, text_out=pin_text.array, offsets_out=pin_off.array)   # and the workspace is clean again
+    assert np.array_equal(toff, o_toff) and np.array_equal(text, o_text)
+
+
 def test_converted_kytea_fixture_on_gpu():
     """resources/kytea-model.bin converted by vaporetto_amd/kytea.py (kytea_model.rs:401-422): same tokens on the GPU."""
     from vaporetto_amd import kytea

@@ -46,4 +46,4 @@ ooff = api.count_boundaries(utf8, boff)
 chars = int(ooff[-1]) + S
 print(json.dumps({"config": args.config, "sentences": S, "ms_per_batch": round(1e3 * dt, 4), "ms_min": round(1e3 * min(ts), 4), "G_chars_per_s": round(chars / dt / 1e9, 3),
                   "h2d_GBps": round(len(utf8) / dt / 1e9, 2), "d2h_GBps": round(len(t) / dt / 1e9, 2), "same": bool(np.array_equal(t, ref_text) and np.array_equal(o, ref_off)),
-                  "env": {k: v for k, v in os.environ.items() if k.startswith("VPT_TOKENIZE")}}))
+                  "env": {k: v for k, v in os.environ.items() if k.startswith("VPT_TOKENIZE") and v}}))

@@ -65,6 +65,7 @@ SIGNATURES = {
     "vpt_fill_tags_batch_flags": (C.c_int, [_P, _P, _P, C.c_size_t, _P, _P, _P, C.c_uint]),
     "vpt_batch_set_flags": (C.c_int, [_P, C.c_uint]),
     "vpt_write_tokenized_batch": (C.c_int, [_P, _P, _P, C.c_size_t, _P, _P, _P, C.c_uint64, _P]),
+    "vpt_predict_write_batch_device": (C.c_int, [_P, _P, _P, _P, _P, C.c_size_t, C.c_uint64, C.c_uint64, _P, _P, _P, C.c_uint64, _P, _P]),
     "vpt_write_tokenized_batch_device": (C.c_int, [_P, _P, _P, _P, _P, C.c_size_t, C.c_uint64, _P, _P, C.c_uint64, _P, _P]),
     "vpt_predictor_max_tag_suffix": (C.c_int, [_P, C.POINTER(C.c_uint32)]),
     "vpt_count_boundaries_device": (C.c_int, [_P, _P, _P, _P, C.c_size_t, _P, _P]),

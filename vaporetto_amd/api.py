@@ -796,6 +796,16 @@ class DeviceBatch:
         if st != _lib.VPT_OK:
             _raise(st)
 
+    def predict_write(self, d_utf8: int, d_boff: int, d_ooff: int, n_sentences: int, total_boundaries: int, max_sentence_bytes: int,
+                      d_scores: int, d_labels: int, d_text_out: int, text_capacity: int, d_text_offsets: int, stream: int = 0) -> None:
+        """Predictor::predict and write_tokenized_text (no tags) in ONE scoring launch (vpt_predict_write_batch_device): the tiles of the
+        specialised kernel write their tokenized text themselves.  d_scores / d_labels may be 0; enqueues and returns."""
+        st = _lib.load().vpt_predict_write_batch_device(self._p.handle, self._h, d_utf8, d_boff, d_ooff, n_sentences, total_boundaries,
+                                                        max_sentence_bytes, d_scores or None, d_labels or None, d_text_out, text_capacity,
+                                                        d_text_offsets, stream)
+        if st != _lib.VPT_OK:
+            _raise(st)
+
     def write_tagged(self, d_utf8: int, d_boff: int, d_ooff: int, n_sentences: int, total_boundaries: int, d_labels: int,
                      d_tags: int, d_text_out: int, text_capacity: int, d_text_offsets: int, stream: int = 0) -> None:
         """write_tokenized_text with "/tag" suffixes from the d_tags of a fill_tags call on this workspace
@@ -808,6 +818,13 @@ class DeviceBatch:
     def set_fullwidth(self, enabled: bool) -> None:
         """Score the text as KyteaFullwidthFilter would rewrite it (vpt_batch_set_flags)."""
         st = _lib.load().vpt_batch_set_flags(self._h, _lib.VPT_FLAG_KYTEA_FULLWIDTH if enabled else 0)
+        if st != _lib.VPT_OK:
+            _raise(st)
+
+    def set_flags(self, flags: int) -> None:
+        """VPT_FLAG_* for the calls that follow on this workspace (vpt_batch_set_flags): KyteaFullwidthFilter on the text, KyteaWsConstFilter /
+        SplitLinebreaksFilter on the labels."""
+        st = _lib.load().vpt_batch_set_flags(self._h, int(flags))
         if st != _lib.VPT_OK:
             _raise(st)
 

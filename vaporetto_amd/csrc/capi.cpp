@@ -41,7 +41,9 @@ struct PredictorKnobs {
     uint32_t lds_pad = 0;               // VPT_DEBUG_LDS_PAD: occupancy experiments
     int pipe_lanes = -1;                // VPT_PIPE_LANES (-1: the size rule)
     uint64_t chunk_chars = 0;           // VPT_CHUNK_CHARS (0: the size rule)
-    uint64_t tokenize_chunk_bytes = uint64_t(256) << 20;   // VPT_TOKENIZE_CHUNK_BYTES
+    uint64_t tokenize_chunk_bytes = uint64_t(256) << 20;   // VPT_TOKENIZE_CHUNK_BYTES (the tagged pipeline's default; the fused one: an eighth of the batch, at least 4 MB)
+    bool tokenize_chunk_bytes_set = false;
+    bool tokenize_no_direct = false;    // VPT_TOKENIZE_NO_DIRECT: never write into the caller's pinned buffers from the kernels (A/B of the copy-out path)
     int tag_wgs_per_cu = 32;            // VPT_TAG_WGS_PER_CU
 };
 struct BatchKnobs {
@@ -62,8 +64,9 @@ PredictorKnobs read_predictor_knobs() {
     if (const char* v = std::getenv("VPT_DEBUG_LDS_PAD")) k.lds_pad = uint32_t(std::max(0, std::atoi(v)));
     if (const char* v = std::getenv("VPT_PIPE_LANES")) k.pipe_lanes = std::max(0, std::atoi(v));
     if (const char* v = std::getenv("VPT_CHUNK_CHARS")) { const long long n = std::atoll(v); if (n > 0) k.chunk_chars = uint64_t(n); }
-    if (const char* v = std::getenv("VPT_TOKENIZE_CHUNK_BYTES")) { const long long n = std::atoll(v); if (n > 0) k.tokenize_chunk_bytes = uint64_t(n); }
+    if (const char* v = std::getenv("VPT_TOKENIZE_CHUNK_BYTES")) { const long long n = std::atoll(v); if (n > 0) { k.tokenize_chunk_bytes = uint64_t(n); k.tokenize_chunk_bytes_set = true; } }
     if (const char* v = std::getenv("VPT_TAG_WGS_PER_CU")) k.tag_wgs_per_cu = std::atoi(v);
+    k.tokenize_no_direct = std::getenv("VPT_TOKENIZE_NO_DIRECT") != nullptr;
     return k;
 }
 BatchKnobs read_batch_knobs() {
@@ -243,6 +246,7 @@ struct vpt_batch {
     uint8_t* d_tok = nullptr; size_t tok_cap = 0;                   // vpt_write_tokenized_batch
     uint8_t* d_tlab = nullptr; size_t tlab_cap = 0;                 // vpt_tokenize_batch: the labels of the whole batch (no scores are kept)
     uint64_t* d_toff = nullptr; size_t toff_cap = 0;
+    uint64_t* d_chain = nullptr; size_t chain_cap = 0;             // vpt_tokenize_batch: where a chunk's tokenized text starts (EmitOut::chain_in / chain_out)
     int32_t* d_tok_model = nullptr; size_t tok_model_cap = 0;      // tag model of every token, from the last fill_tags on this workspace
     uint64_t tok_model_chars = 0;                                   // ... which covered this many chars
     std::vector<uint64_t> h_boff, h_ooff;                           // rebased offsets of the call in flight (copied asynchronously)
@@ -252,6 +256,7 @@ struct vpt_batch {
     // left in the other one (emit_dirty = how many words that is)
     uint4* d_tag_queue = nullptr; size_t tag_queue_cap = 0;        // fill_tags as two launches: the tokens that have a tag model (TagParams::queue), + 4 dwords of counters
     uint64_t* d_emit_state = nullptr; size_t emit_state_cap = 0; size_t emit_dirty[2] = {0, 0}; int emit_flip = 0;
+    uint64_t* d_fuse_state = nullptr; size_t fuse_state_cap = 0;   // the fused writer's words (EmitOut::state): one per tile + the ticket, + the chain word
     // the pipelined host-buffer path (predict_pipelined): two sets of device buffers, copy streams, pinned offset staging
     struct PipeSet {
         uint8_t* text = nullptr; size_t text_cap = 0;
@@ -288,6 +293,8 @@ struct vpt_predictor {
     int32_t bias = 0; int pad = 1; int type_kind = 0; int type_window = 0; int chunks = 2;
     uint32_t tile_slots = 0;           // workgroups of the scoring kernel the device runs at a time (0 = unknown)
     uint32_t n_cus = 0;                // compute units of the device (0 = unknown)
+    bool fused_writer_ok = false;      // the specialised kernel scores ANY batch of this predictor (tiles cut anywhere fit beside its longest pattern):
+                                       // vpt_tokenize_batch can count on the writer fused into it
     vpt::PackedView pk{};
     const int32_t* d_type_table = nullptr;
     const uint8_t* d_ctype = nullptr;
@@ -318,6 +325,7 @@ void batch_release(vpt_batch* b) {
     (void)hipSetDevice(b->device);
     (void)hipFree(b->d_scan_part);
     (void)hipFree(b->d_emit_state);
+    (void)hipFree(b->d_fuse_state); (void)hipFree(b->d_chain);
     (void)hipFree(b->d_tag_queue);
     (void)hipFree(b->d_tiles); (void)hipFree(b->d_cut_local); (void)hipFree(b->d_cut_super);
     (void)hipFree(b->d_tile_first); (void)hipFree(b->d_slow_list); (void)hipFree(b->d_ctrl); (void)hipFree(b->d_scratch);
@@ -539,6 +547,13 @@ void bind_predictor(vpt_predictor* p) {
         probe.ct = p->ct; probe.pk = p->pk; probe.pad = p->pad; probe.ctype = p->d_ctype; probe.cid = p->d_cid; probe.type_kind = p->type_kind;
         probe.type_window = p->type_window; probe.force_window_table = p->knobs.force_window_table ? 1u : 0u;
         const bool fast = vpt::fast_path_supported(probe);
+        if (fast) {   // (the same room as vpt_predict_batch_device's plan: a cut tile between its halos)
+            const uint32_t lmax = std::max<uint32_t>(p->info.max_pattern_chars, 3), wl = p->pk.wl;
+            const uint32_t levels = p->pk.trow_mode == vpt::kTypeRowsGlobal ? p->pk.trow_levels : 3u;
+            const int64_t room = int64_t(vpt::fast_path_cap(probe)) - vpt::kFastStageSlack - int64_t(p->pad) - int64_t(std::max<uint32_t>(lmax - 1, wl)) -
+                                 int64_t(wl + std::max<uint32_t>(std::max<uint32_t>(lmax - 1, wl), levels));
+            p->fused_writer_ok = room >= 256;
+        }
         auto slots_for = [&](size_t lds, size_t built_for) {
             lds += p->knobs.lds_pad;   // occupancy experiments (kernels_fast.hip)
             const size_t granules = (lds + 1279) / 1280;   // gfx950 hands out its 160 KB of LDS in 1280-byte granules
@@ -958,9 +973,19 @@ vpt_status vpt_batch_node_reads(vpt_batch* b, uint64_t reads[8]) {
     return VPT_OK;
 }
 
-vpt_status vpt_predict_batch_device(const vpt_predictor* p, vpt_batch* b, const uint8_t* d_utf8, const uint64_t* d_byte_offsets,
-                                    const uint64_t* d_out_offsets, size_t n_sentences, uint64_t total_boundaries,
-                                    uint64_t max_sentence_bytes, int32_t* d_scores, uint8_t* d_labels, void* hip_stream) {
+namespace {
+// What a fused-writer call asks of predict_device_impl: where the tokenized text goes.  chain: a device word that holds the output
+// position in front of this call's text / receives the position behind it (calls enqueued one after the other on one stream
+// write one contiguous text: vpt_tokenize_batch's chunks); nullptr: the text starts at 0.
+struct FuseRequest { uint8_t* text_out; uint64_t capacity; uint64_t* offsets_out; uint64_t* total_out; const uint64_t* chain_in; uint64_t* chain_out; };
+vpt_status emit_device(const vpt_predictor* p, vpt_batch* b, const uint8_t* d_utf8, const uint64_t* d_byte_offsets,
+                       const uint64_t* d_out_offsets, size_t n_sentences, uint64_t total_boundaries, const uint8_t* d_labels,
+                       const int32_t* d_tags, uint8_t* d_text_out, uint64_t text_capacity, uint64_t* d_text_offsets_out,
+                       hipStream_t stream, uint64_t* total_out = nullptr);
+
+vpt_status predict_device_impl(const vpt_predictor* p, vpt_batch* b, const uint8_t* d_utf8, const uint64_t* d_byte_offsets,
+                               const uint64_t* d_out_offsets, size_t n_sentences, uint64_t total_boundaries,
+                               uint64_t max_sentence_bytes, int32_t* d_scores, uint8_t* d_labels, void* hip_stream, const FuseRequest* fuse) {
     if (!p || !b || b->pred != p) return fail(VPT_INVALID_ARGUMENT, "InvalidArgumentError: batch: does not belong to this predictor");
     if (n_sentences == 0) { b->last_tiles = 0; return VPT_OK; }   // nothing enqueued; earlier work stays pending
     if (!d_utf8 || !d_byte_offsets || !d_out_offsets) return fail(VPT_INVALID_ARGUMENT, "InvalidArgumentError: NULL device pointer");
@@ -1089,10 +1114,28 @@ vpt_status vpt_predict_batch_device(const vpt_predictor* p, vpt_batch* b, const 
     if (b->knobs.debug_ablate) { P.debug = b->knobs.debug_ablate; P.ct.debug = P.debug; P.tt.debug = P.debug; }
 
     P.n_sent = n_sentences; P.tile_flat = uint32_t(tile_flat); P.n_tiles = n_tiles;
+    // The writer fused into the specialised kernel: its words (one per tile + the ticket) are cleared by the assign kernel in front
+    // of it.  The general kernels have no such phase: labels into the workspace, then the writer's own launch.
+    uint64_t* fuse_state = nullptr;
+    uint8_t* labels_for_writer = d_labels;
+    if (fuse) {
+        if (fast) {
+            const size_t words = size_t(n_tiles) + 2;
+            if ((st = grow(&b->d_fuse_state, &b->fuse_state_cap, words)) != VPT_OK) return st;
+            fuse_state = b->d_fuse_state;
+            P.emit.out_text = fuse->text_out; P.emit.capacity = fuse->capacity; P.emit.out_offsets = fuse->offsets_out;
+            P.emit.state = fuse_state; P.emit.total_out = fuse->total_out; P.emit.chain_in = fuse->chain_in; P.emit.chain_out = fuse->chain_out;
+            if (!P.emit.out_text) P.emit.out_text = reinterpret_cast<uint8_t*>(b->d_ctrl);   // capacity 0: nothing is stored, the sizes still are
+        } else if (!labels_for_writer) {
+            if ((st = grow(&b->d_tlab, &b->tlab_cap, size_t(total_boundaries) + 1)) != VPT_OK) return st;
+            labels_for_writer = b->d_tlab;
+            P.labels = labels_for_writer;
+        }
+    }
     // the tiles (a kernel of its own: finding them at the head of every workgroup measured slower, profiles/r02_c1_ab.jsonl); for
     // cut tiles preceded by the lead-byte index of the text
-    if (fast && cut_tiles) VPT_HIP(vpt::launch_assign_tiles_cut(P, cut, n_tiles, total_chars, b->d_cut_local, b->d_cut_super, b->d_tiles, b->d_ctrl, stream));
-    else VPT_HIP(vpt::launch_assign_tiles(d_out_offsets, n_sentences, p->pad, uint32_t(tile_flat), n_tiles, b->d_tile_first, b->d_ctrl, stream));
+    if (fast && cut_tiles) VPT_HIP(vpt::launch_assign_tiles_cut(P, cut, n_tiles, total_chars, b->d_cut_local, b->d_cut_super, b->d_tiles, b->d_ctrl, stream, fuse_state));
+    else VPT_HIP(vpt::launch_assign_tiles(d_out_offsets, n_sentences, p->pad, uint32_t(tile_flat), n_tiles, b->d_tile_first, b->d_ctrl, stream, fuse_state));
     const size_t slot = b->ev_calls % kTimingRing;
     if (b->timing) VPT_HIP(hipEventRecord(b->ev[2 * slot], stream));
     if (fast) VPT_HIP(vpt::launch_score_tiles_fast(P, n_tiles, stream));
@@ -1101,7 +1144,37 @@ vpt_status vpt_predict_batch_device(const vpt_predictor* p, vpt_batch* b, const 
     if (b->timing) { VPT_HIP(hipEventRecord(b->ev[2 * slot + 1], stream)); ++b->ev_calls; }
     b->last_tiles = n_tiles; b->last_stream = stream; b->pending = true;
     b->last_tile_flat = uint32_t(tile_flat); b->last_plan = !fast ? 0u : cut_tiles ? 2u : 1u;
+    if (fuse && !fast) {
+        if (fuse->chain_in || fuse->chain_out) return fail(VPT_RUNTIME_ERROR, "internal error: chained tokenized text needs the specialised kernel");
+        return emit_device(p, b, d_utf8, d_byte_offsets, d_out_offsets, n_sentences, total_boundaries, labels_for_writer, nullptr, fuse->text_out,
+                           fuse->capacity, fuse->offsets_out, stream, fuse->total_out);
+    }
     return VPT_OK;
+}
+}  // namespace
+
+vpt_status vpt_predict_batch_device(const vpt_predictor* p, vpt_batch* b, const uint8_t* d_utf8, const uint64_t* d_byte_offsets,
+                                    const uint64_t* d_out_offsets, size_t n_sentences, uint64_t total_boundaries,
+                                    uint64_t max_sentence_bytes, int32_t* d_scores, uint8_t* d_labels, void* hip_stream) {
+    return predict_device_impl(p, b, d_utf8, d_byte_offsets, d_out_offsets, n_sentences, total_boundaries, max_sentence_bytes, d_scores, d_labels, hip_stream, nullptr);
+}
+
+// Predictor::predict + Sentence::write_tokenized_text (no tags) for a batch in ONE scoring launch: the tiles of the specialised kernel write
+// the tokenized text of their own chars straight from LDS (kernels_fast.hip, phase D); scores and labels are optional outputs.
+vpt_status vpt_predict_write_batch_device(const vpt_predictor* p, vpt_batch* b, const uint8_t* d_utf8, const uint64_t* d_byte_offsets,
+                                          const uint64_t* d_out_offsets, size_t n_sentences, uint64_t total_boundaries,
+                                          uint64_t max_sentence_bytes, int32_t* d_scores, uint8_t* d_labels, uint8_t* d_text_out,
+                                          uint64_t text_capacity, uint64_t* d_text_offsets_out, void* hip_stream) {
+    if (!p || !b || b->pred != p) return fail(VPT_INVALID_ARGUMENT, "InvalidArgumentError: batch: does not belong to this predictor");
+    if (!d_text_offsets_out || (text_capacity && !d_text_out)) return fail(VPT_INVALID_ARGUMENT, "InvalidArgumentError: NULL device pointer");
+    if (n_sentences == 0) {
+        VPT_HIP(hipSetDevice(p->device));
+        VPT_HIP(hipMemsetAsync(d_text_offsets_out, 0, sizeof(uint64_t), static_cast<hipStream_t>(hip_stream)));
+        b->last_stream = static_cast<hipStream_t>(hip_stream); b->pending = true; b->cps_text = nullptr;
+        return VPT_OK;
+    }
+    const FuseRequest fuse{d_text_out, text_capacity, d_text_offsets_out, nullptr, nullptr, nullptr};
+    return predict_device_impl(p, b, d_utf8, d_byte_offsets, d_out_offsets, n_sentences, total_boundaries, max_sentence_bytes, d_scores, d_labels, hip_stream, &fuse);
 }
 
 vpt_status vpt_batch_last_plan(const vpt_batch* b, uint32_t* n_tiles, uint32_t* tile_flat, uint32_t* kind) {
@@ -1461,10 +1534,11 @@ vpt_status vpt_fill_tags_scores_batch_device(const vpt_predictor* p, vpt_batch* 
     return VPT_OK;
 }
 
-static vpt_status emit_device(const vpt_predictor* p, vpt_batch* b, const uint8_t* d_utf8, const uint64_t* d_byte_offsets,
-                              const uint64_t* d_out_offsets, size_t n_sentences, uint64_t total_boundaries, const uint8_t* d_labels,
-                              const int32_t* d_tags, uint8_t* d_text_out, uint64_t text_capacity, uint64_t* d_text_offsets_out,
-                              hipStream_t stream, uint64_t* total_out = nullptr) {
+namespace {
+vpt_status emit_device(const vpt_predictor* p, vpt_batch* b, const uint8_t* d_utf8, const uint64_t* d_byte_offsets,
+                       const uint64_t* d_out_offsets, size_t n_sentences, uint64_t total_boundaries, const uint8_t* d_labels,
+                       const int32_t* d_tags, uint8_t* d_text_out, uint64_t text_capacity, uint64_t* d_text_offsets_out,
+                       hipStream_t stream, uint64_t* total_out) {
     if (!p || !b || b->pred != p) return fail(VPT_INVALID_ARGUMENT, "InvalidArgumentError: batch: does not belong to this predictor");
     if (!d_text_offsets_out) return fail(VPT_INVALID_ARGUMENT, "InvalidArgumentError: NULL device pointer");
     VPT_HIP(hipSetDevice(p->device));
@@ -1516,6 +1590,7 @@ static vpt_status emit_device(const vpt_predictor* p, vpt_batch* b, const uint8_
     b->last_stream = stream; b->pending = true; b->cps_text = nullptr;
     return VPT_OK;
 }
+}  // namespace
 
 vpt_status vpt_write_tokenized_batch_device(const vpt_predictor* p, vpt_batch* b, const uint8_t* d_utf8, const uint64_t* d_byte_offsets,
                                             const uint64_t* d_out_offsets, size_t n_sentences, uint64_t total_boundaries,
@@ -1600,6 +1675,112 @@ vpt_status vpt_count_boundaries_device(const vpt_predictor* p, vpt_batch* b, con
     return VPT_OK;
 }
 
+namespace {
+// memory a kernel can write: pinned host memory (vpt_host_alloc / hipHostMalloc / hipHostRegister) as the device sees it, else nullptr
+void* device_view_of_host(void* host_ptr) {
+    if (!host_ptr) return nullptr;
+    hipPointerAttribute_t attr;
+    if (hipPointerGetAttributes(&attr, host_ptr) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+    if (attr.type != hipMemoryTypeHost) return nullptr;
+    void* d = nullptr;
+    if (hipHostGetDevicePointer(&d, host_ptr, 0) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+    return d;
+}
+
+// vpt_tokenize_batch without tags: the writer is a phase of the scoring kernel (vpt_predict_write_batch_device's path), so a chunk of
+// lines is a copy in (text, offsets), the char count (two launches), the tile search and ONE scoring launch that leaves tokenized
+// text.  Chunks run one after the other on the workspace's stream while the next chunk's copy in runs on another; every chunk's
+// text follows the one before it (the kernels hand the position on through a chain of device words), so the output is one piece:
+//   * caller buffers in PINNED memory (vpt_host_alloc): the kernels write the text and the offsets straight into them over PCIe --
+//     no copy out, no size to wait for, the host enqueues everything and waits once;
+//   * pageable buffers: the text is assembled in device memory and copied out at the end.
+// `text` = the batch's first byte; byte_offsets are the caller's (relative to byte_offsets[0]).
+vpt_status tokenize_fused(const vpt_predictor* p, vpt_batch* b, const uint8_t* text, const uint64_t* byte_offsets, size_t n_sentences, unsigned flags,
+                          uint64_t max_bytes, uint8_t* text_out, uint64_t text_capacity, uint64_t* text_offsets_out) {
+    const uint64_t t0 = byte_offsets[0];
+    const size_t nbytes = size_t(byte_offsets[n_sentences] - t0);
+    uint64_t chunk_bytes = p->knobs.tokenize_chunk_bytes_set ? p->knobs.tokenize_chunk_bytes : std::max<uint64_t>(uint64_t(4) << 20, (uint64_t(nbytes) + 7) / 8);
+    const size_t max_chunks = std::min<size_t>(n_sentences, size_t(nbytes / chunk_bytes) + 2);
+    vpt_status st;
+    if (!b->s_in) VPT_HIP(hipStreamCreateWithFlags(&b->s_in, hipStreamNonBlocking));
+    while (b->chunk_ev.size() < max_chunks) {
+        hipEvent_t e;
+        VPT_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        b->chunk_ev.push_back(e);
+    }
+    if ((st = grow(&b->d_text, &b->text_cap, nbytes + 32)) != VPT_OK) return st;
+    {
+        size_t cap = b->off_cap;
+        if ((st = grow(&b->d_boff, &cap, n_sentences + max_chunks + 1)) != VPT_OK) return st;
+        size_t cap2 = b->off_cap;
+        if ((st = grow(&b->d_ooff, &cap2, n_sentences + max_chunks + 1)) != VPT_OK) return st;
+        b->off_cap = std::min(cap, cap2);
+    }
+    if ((st = grow(&b->d_chain, &b->chain_cap, max_chunks + 2)) != VPT_OK) return st;
+    uint8_t* d_out = static_cast<uint8_t*>(device_view_of_host(text_out));
+    uint64_t* d_off_out = static_cast<uint64_t*>(device_view_of_host(text_offsets_out));
+    const bool direct = (d_out || text_capacity == 0) && d_off_out && !p->knobs.tokenize_no_direct;
+    uint64_t out_cap = text_capacity;
+    if (!direct) {
+        out_cap = uint64_t(nbytes) * 3 + 16;
+        if ((st = grow(&b->d_tok, &b->tok_cap, size_t(out_cap) + 16)) != VPT_OK) return st;
+        if ((st = grow(&b->d_toff, &b->toff_cap, n_sentences + 2)) != VPT_OK) return st;
+        d_out = b->d_tok; d_off_out = b->d_toff;
+    }
+    const size_t need_off = n_sentences + 1 + 1;   // pinned: the offsets relative to the batch's text, then the total
+    if (need_off > b->h_off_cap) {
+        if (b->h_off) (void)hipHostFree(b->h_off);
+        b->h_off = nullptr; b->h_off_cap = 0;
+        VPT_HIP(hipHostMalloc(reinterpret_cast<void**>(&b->h_off), (need_off + need_off / 2) * sizeof(uint64_t), hipHostMallocDefault));
+        b->h_off_cap = need_off + need_off / 2;
+    }
+    uint64_t* const h_boff = b->h_off;
+    uint64_t* const h_total = b->h_off + n_sentences + 1;
+    for (size_t i = 0; i <= n_sentences; ++i) h_boff[i] = byte_offsets[i] - t0;
+    *h_total = ~uint64_t(0);
+    hipStream_t s = b->own_stream, s_in = b->s_in;
+    b->flags = flags;
+    b->max_chars = 0;   // unknown on the host (no round trip for it): the scoring kernel takes the geometry that fits any sentence
+    VPT_HIP(hipMemsetAsync(b->d_chain, 0, sizeof(uint64_t), s));
+    size_t k = 0;
+    for (size_t i = 0; i < n_sentences; ++k) {
+        const size_t a = i;
+        uint64_t mb = 0;
+        while (i < n_sentences && h_boff[i] - h_boff[a] < chunk_bytes) { mb = std::max<uint64_t>(mb, h_boff[i + 1] - h_boff[i]); ++i; }
+        const size_t n = i - a;
+        const uint64_t tb = h_boff[a], nby = h_boff[i] - tb;
+        uint64_t* d_boff_k = b->d_boff + a + k;   // n + 1 entries per chunk; offsets into the WHOLE text: no rebasing
+        uint64_t* d_ooff_k = b->d_ooff + a + k;   // n + 1 entries per chunk, chunk-relative
+        VPT_HIP(hipMemcpyAsync(b->d_text + tb, text + tb, size_t(nby), hipMemcpyHostToDevice, s_in));
+        VPT_HIP(hipMemcpyAsync(d_boff_k, h_boff + a, 8 * (n + 1), hipMemcpyHostToDevice, s_in));
+        VPT_HIP(hipEventRecord(b->chunk_ev[k], s_in));
+        VPT_HIP(hipStreamWaitEvent(s, b->chunk_ev[k], 0));
+        if ((st = vpt_count_boundaries_device(p, b, b->d_text, d_boff_k, n, d_ooff_k, s)) != VPT_OK) return st;
+        const FuseRequest fuse{d_out, out_cap, d_off_out + a, i == n_sentences ? h_total : nullptr, b->d_chain + k, b->d_chain + k + 1};
+        st = predict_device_impl(p, b, b->d_text, d_boff_k, d_ooff_k, n, nby - n /* boundaries of the chunk, at most */, mb, nullptr, nullptr, s, &fuse);
+        if (st != VPT_OK) return st;
+    }
+    // ---- the device's verdict, then (pageable buffers) the text
+    uint32_t ctrl[2] = {0, 0};
+    VPT_HIP(hipMemcpyAsync(ctrl, b->d_ctrl, sizeof(ctrl), hipMemcpyDeviceToHost, s));
+    VPT_HIP(hipStreamSynchronize(s));
+    b->pending = false;
+    if (ctrl[0]) {
+        VPT_HIP(hipMemset(b->d_ctrl, 0, sizeof(uint32_t)));
+        return status_from_bits(ctrl[0]);
+    }
+    const uint64_t total = *h_total;
+    if (total > out_cap) return fail(VPT_RUNTIME_ERROR, "vpt_tokenize_batch: the output size is out of range");
+    if (!direct) {
+        if (total > text_capacity) return fail(VPT_INVALID_ARGUMENT, "InvalidArgumentError: text_capacity: smaller than the tokenized text");
+        if (total) VPT_HIP(hipMemcpyAsync(text_out, d_out, size_t(total), hipMemcpyDeviceToHost, s));
+        VPT_HIP(hipMemcpyAsync(text_offsets_out, d_off_out, 8 * (n_sentences + 1), hipMemcpyDeviceToHost, s));
+        VPT_HIP(hipStreamSynchronize(s));
+    }
+    return VPT_OK;
+}
+}  // namespace
+
 // Lines in, tokenized lines out: Sentence::from_raw -> [KyteaFullwidthFilter] -> Predictor::predict -> [post-filters]
 // -> [fill_tags] -> write_tokenized_text for a whole batch (the loop of predict/src/main.rs:122-176), with only the
 // text crossing PCIe: char counting, scoring, tagging and the writer all run on the device.
@@ -1627,6 +1808,8 @@ vpt_status vpt_tokenize_batch(const vpt_predictor* p, const uint8_t* utf8, const
     vpt_batch* b = w.b;
     const size_t nbytes = size_t(t1 - t0);
     const bool with_tags = tagged && p->n_tags > 0;
+    if (!with_tags && p->fused_writer_ok && !b->knobs.force_generic)
+        return tokenize_fused(p, b, utf8 + t0, byte_offsets, n_sentences, flags, max_bytes, text_out, text_capacity, text_offsets_out);
     // NOTHING on the way needs a number from the device: the device buffers hold the whole batch and a slice of an output starts
     // where an upper bound puts it (a char is at least one byte: boundaries and chars in front of a slice <= text bytes in front
     // of it; tokenized text <= 3 bytes per text byte + the longest tag suffix per char), so copy in, char count, scoring, tagging

@@ -130,6 +130,15 @@ __device__ __forceinline__ uint32_t lead_nibble(uint32_t x) {
     return ((lead * 0x00204081u) >> 21) & 0xFu;
 }
 
+// 0x80 in every byte of v that is zero (exact: no carries between the bytes)
+__device__ __forceinline__ uint32_t zero_bytes(uint32_t v) { return ~(((v & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | v | 0x7F7F7F7Fu); }
+// bits 7, 15, 23, 31 -> bits 0..3
+__device__ __forceinline__ uint32_t byte_flags_to_nibble(uint32_t m) { return (((m >> 7) * 0x00204081u) >> 21) & 0xFu; }
+// 4-bit mask of the bytes of x that Sentence::write_tokenized_text escapes: ' ', '\', '/' (sentence.rs:850-886)
+__device__ __forceinline__ uint32_t esc_nibble(uint32_t x) {
+    return byte_flags_to_nibble(zero_bytes(x ^ 0x20202020u) | zero_bytes(x ^ 0x5C5C5C5Cu) | zero_bytes(x ^ 0x2F2F2F2Fu));
+}
+
 // scalar value of the UTF-8 sequence whose four bytes (lead first) are packed little-endian in b4
 __device__ __forceinline__ uint32_t utf8_scalar(uint32_t b4) {
     const uint32_t b0 = b4 & 0xFF, b1 = (b4 >> 8) & 0x3F, b2 = (b4 >> 16) & 0x3F, b3 = (b4 >> 24) & 0x3F;

@@ -21,14 +21,6 @@ constexpr int kEmitWaves = kEmitThreads / 64;
 constexpr int kScanThreads = 256, kScanPer = 16;
 constexpr uint64_t kScanBlock = uint64_t(kScanThreads) * kScanPer;   // offsets one workgroup of the scan takes
 
-// 0x80 in every byte of v that is zero (exact: no carries between the bytes)
-__device__ __forceinline__ uint32_t zero_bytes(uint32_t v) { return ~(((v & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | v | 0x7F7F7F7Fu); }
-// bits 7, 15, 23, 31 -> bits 0..3
-__device__ __forceinline__ uint32_t byte_flags_to_nibble(uint32_t m) { return (((m >> 7) * 0x00204081u) >> 21) & 0xFu; }
-// 4-bit mask of the bytes of x that write_tokenized_text escapes: ' ', '\', '/'
-__device__ __forceinline__ uint32_t esc_nibble(uint32_t x) {
-    return byte_flags_to_nibble(zero_bytes(x ^ 0x20202020u) | zero_bytes(x ^ 0x5C5C5C5Cu) | zero_bytes(x ^ 0x2F2F2F2Fu));
-}
 // "/tag/tag.." of the token whose last char is char `c` (batch-flat index) and whose tag model (index + 1, from the
 // fill_tags call) is `model`: bytes it takes; written to `dst` when given -- never more than `limit` of them (what was reserved
 // for it: a caller that changed the tags after fill_tags gets the offsets error, not a write outside the suffix's place)
