@@ -246,7 +246,8 @@ vpt_status vpt_fill_tags_batch_flags(const vpt_predictor *p, const uint8_t *utf8
  * When the call BEFORE this one on this workspace was vpt_predict_batch_device for the SAME buffers, sizes, flags and stream
  * (as Sentence::fill_tags follows Predictor::predict on the same sentence, predictor.rs:542), the chars that call decoded are
  * taken over and the decode kernel is skipped: do not rewrite d_utf8 in place between those two calls.  The chars are good
- * for that one call only: any later fill_tags call decodes the text it is given. */
+ * for that one call only, and only while no vpt_batch_sync lies between the two (a caller that waited for the device may have
+ * rewritten its buffers): any other fill_tags call decodes the text it is given. */
 vpt_status vpt_fill_tags_batch_device(const vpt_predictor *p, vpt_batch *b, const uint8_t *d_utf8,
                                       const uint64_t *d_byte_offsets, const uint64_t *d_out_offsets,
                                       size_t n_sentences, uint64_t total_boundaries, const uint8_t *d_labels,

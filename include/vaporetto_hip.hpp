@@ -226,7 +226,7 @@ public:
         detail::check(vpt_predict_one(raw_->raw, reinterpret_cast<const uint8_t*>(s.text_.data()), s.text_.size(), scores.data(), labels.data(), &nb));
         scores.resize(nb); labels.resize(nb);
         s.scores_ = std::move(scores); s.boundaries_ = std::move(labels);
-        s.tags_.clear(); s.n_tags_ = 0; s.predictor_ = raw_;
+        s.tags_.clear(); s.tag_scores_.clear(); s.tag_models_.clear(); s.n_tags_ = 0; s.predictor_ = raw_;   // tags and their scores go together (sentence.rs:96, predictor.rs:599-601)
     }
 
     // The same for many sentences with one launch (flags: VPT_FLAG_*).
@@ -247,7 +247,7 @@ public:
             Sentence& s = sentences[i];
             s.scores_.assign(scores.begin() + ooff[i], scores.begin() + ooff[i + 1]);
             s.boundaries_.assign(labels.begin() + ooff[i], labels.begin() + ooff[i + 1]);
-            s.tags_.clear(); s.n_tags_ = 0; s.predictor_ = raw_;
+            s.tags_.clear(); s.tag_scores_.clear(); s.tag_models_.clear(); s.n_tags_ = 0; s.predictor_ = raw_;   // tags and their scores go together (sentence.rs:96, predictor.rs:599-601)
         }
     }
 

@@ -1214,6 +1214,15 @@ def test_chars_left_by_predict_are_never_another_batchs():
     batch.fill_tags(d_text.ptr, d_boff.ptr, d_ooff.ptr, S, nb, d_labels.ptr, d_tags.ptr, devmem.stream())
     batch.sync()
     assert np.array_equal(d_tags.get((nb + S) * nt).reshape(nb + S, nt), want)
+    # predict(A), a sync, the SAME buffer rewritten with B, fill_tags(B) -- a sync ends the chars' validity
+    d_text.set(np.concatenate([ua, np.zeros(16, np.uint8)]))
+    batch.predict(d_text.ptr, d_boff.ptr, d_ooff.ptr, S, nb, mb, d_scores.ptr, d_labels.ptr, devmem.stream())
+    batch.sync()
+    d_text.set(np.concatenate([ub, np.zeros(16, np.uint8)]))
+    d_labels.set(np.concatenate([lab_b, np.zeros(1, np.uint8)]))
+    batch.fill_tags(d_text.ptr, d_boff.ptr, d_ooff.ptr, S, nb, d_labels.ptr, d_tags.ptr, devmem.stream())
+    batch.sync()
+    assert np.array_equal(d_tags.get((nb + S) * nt).reshape(nb + S, nt), want)
 
 
 def test_fill_tags_with_offsets_that_do_not_match_the_text():

@@ -11,6 +11,7 @@
 #include <new>
 #include <string>
 #include <thread>
+#include <type_traits>
 #include <vector>
 
 #include "kernels.hpp"
@@ -34,8 +35,10 @@ vpt_status fail(vpt_status st, const std::string& msg) {
     } while (0)
 
 // Experiment / test knobs from the environment (tools/README.md).  Read ONCE -- the table-level ones when a predictor is made
-// (bind_predictor), the launch-level ones when a workspace is made (vpt_batch_create) -- never on the launch path: getenv is
-// not thread-safe against setenv, and a drop-in library must not change behaviour under a running host.
+// (bind_predictor), together with the launch-level ones of the workspaces its host entry points make for themselves (a pooled
+// workspace is created lazily, inside predict / fill_tags / tokenize, possibly from several host threads at once: it copies the
+// predictor's snapshot); a workspace the CALLER makes (vpt_batch_create) reads the launch-level ones then -- never on the launch
+// path: getenv is not thread-safe against setenv, and a drop-in library must not change behaviour under a running host.
 struct PredictorKnobs {
     bool force_window_table = false;    // VPT_FORCE_WINDOW_TABLE: the 8^(2W) type table instead of the type rows
     uint32_t lds_pad = 0;               // VPT_DEBUG_LDS_PAD: occupancy experiments
@@ -129,13 +132,39 @@ uint64_t arena_checksum(const unsigned char* p, size_t n) {   // n is a multiple
     return a ^ (b << 1 | b >> 63) ^ (c << 2 | c >> 62) ^ (d << 3 | d >> 61) ^ uint64_t(n);
 }
 
-uint64_t meta_checksum_of(PredictorMeta m) {   // by value: the two checksum fields are hashed as zero
-    m.checksum = 0; m.meta_checksum = 0;
-    const unsigned char* p = reinterpret_cast<const unsigned char*>(&m);
+// Field by field: hashing the struct's raw bytes would take in its padding (vpt_model_info has 4 bytes of it in front of
+// device_table_bytes and 4 at its tail), which only a memcpy of the whole block preserves.  The two checksum fields are left out.
+struct MetaHash {
     uint64_t h = 0xCBF29CE484222325ull;
-    for (size_t i = 0; i < sizeof(m); ++i) h = (h ^ p[i]) * 0x100000001B3ull;
-    return h ^ 0x5A17EDull;
+    template <typename T>
+    void add(const T& v) {
+        static_assert(std::is_arithmetic<T>::value, "scalars only: no padding inside");
+        const unsigned char* p = reinterpret_cast<const unsigned char*>(&v);
+        for (size_t i = 0; i < sizeof(T); ++i) h = (h ^ p[i]) * 0x100000001B3ull;
+    }
+    template <typename T, size_t N>
+    void add(const T (&a)[N]) { for (const T& v : a) add(v); }
+};
+uint64_t meta_checksum_of(const PredictorMeta& m) {
+    MetaHash f;
+    f.add(m.magic); f.add(m.version); f.add(m.meta_bytes); f.add(m.arena_bytes);
+    f.add(m.sec_off); f.add(m.sec_bytes);
+    f.add(m.bias); f.add(m.pad); f.add(m.type_kind); f.add(m.type_window); f.add(m.chunks);
+    f.add(m.predict_tags); f.add(m.has_tags); f.add(m.n_tags); f.add(m.tok_bits); f.add(m.max_tag_suffix); f.add(m.tag_use_char); f.add(m.tag_use_type);
+    f.add(m.n_tag_models); f.add(m.n_tag_strings); f.add(m.max_tag_scores);
+    for (const TableGeom& g : m.geom) {
+        f.add(g.present); f.add(g.short_bits); f.add(g.edge_bits); f.add(g.stride_dw); f.add(g.uni_dw); f.add(g.uni_n); f.add(g.ext_slot); f.add(g.has_long);
+        f.add(g.window); f.add(g.lo); f.add(g.len);
+    }
+    f.add(m.pk_present); f.add(m.pk_n_uni); f.add(m.pk_n_tri); f.add(m.pk_bi_shift); f.add(m.pk_wl); f.add(m.pk_trow_mode); f.add(m.pk_trow_levels);
+    const vpt_model_info& i = m.info;
+    f.add(i.n_char_ngrams); f.add(i.n_type_ngrams); f.add(i.n_dict_words); f.add(i.n_tag_models); f.add(i.bias); f.add(i.char_window); f.add(i.type_window);
+    f.add(i.max_pattern_chars); f.add(i.n_short_entries); f.add(i.n_long_nodes); f.add(i.type_kind); f.add(i.device_table_bytes); f.add(i.hot_table_bytes);
+    f.add(i.packed); f.add(i.n_displaced); f.add(i.type_rows); f.add(i.n_overflow_children); f.add(i.predict_tags);
+    return f.h ^ 0x5A17EDull;
 }
+// (a field added to PredictorMeta / TableGeom / vpt_model_info must be added above: these sizes are the reminder)
+static_assert(sizeof(TableGeom) == 60 && sizeof(vpt_model_info) == 88, "meta_checksum_of lists every field");
 
 // What the kernels assume of the scalars and section sizes of a compiled predictor that did not come from compile_model in
 // this process (vpt_predictor_load, vpt_predictor_adopt_device): a flipped bit in the description must not become an
@@ -281,6 +310,7 @@ struct DeviceTags {   // views into the arena
 struct vpt_predictor {
     int device = 0;
     PredictorKnobs knobs;              // read once, when the predictor was made (bind_predictor)
+    BatchKnobs pool_knobs;             // ... and what the workspaces of its pool are made with
     unsigned char* arena = nullptr;    // the one device allocation that holds every table
     PredictorMeta meta{};
     // what the launches use, bound from meta + arena (bind_predictor)
@@ -388,6 +418,7 @@ struct Workspace {
         p->pool.push_back(b);
     }
 };
+vpt_status batch_create_with(const vpt_predictor* p, const BatchKnobs& knobs, vpt_batch** out);
 vpt_status acquire(const vpt_predictor* p, Workspace* w) {
     w->p = p;
     {
@@ -396,7 +427,7 @@ vpt_status acquire(const vpt_predictor* p, Workspace* w) {
     }
     if (w->b) { w->b->cps_text = nullptr; return VPT_OK; }   // a pooled workspace remembers nothing of the call before
     vpt_batch* b = nullptr;
-    vpt_status st = vpt_batch_create(p, &b);
+    vpt_status st = batch_create_with(p, p->pool_knobs, &b);   // (the knobs the predictor was made under: no getenv from a host thread's first call)
     if (st != VPT_OK) return st;
     if (hipStreamCreateWithFlags(&b->own_stream, hipStreamNonBlocking) != hipSuccess) {
         batch_release(b);
@@ -493,6 +524,7 @@ struct SectionSrc { const void* ptr; size_t bytes; };
 void bind_predictor(vpt_predictor* p) {
     const PredictorMeta& m = p->meta;
     p->knobs = read_predictor_knobs();
+    p->pool_knobs = read_batch_knobs();
     auto at = [&](int sec) { return p->arena + m.sec_off[sec]; };
     auto view = [&](const TableGeom& g, int first) {
         vpt::PatternTableView v{};
@@ -872,12 +904,16 @@ vpt_status vpt_count_boundaries(const uint8_t* utf8, const uint64_t* byte_offset
 
 vpt_status vpt_batch_create(const vpt_predictor* p, vpt_batch** out) {
     if (!p || !out) return fail(VPT_INVALID_ARGUMENT, "InvalidArgumentError: NULL argument");
+    return batch_create_with(p, read_batch_knobs(), out);
+}
+namespace {
+vpt_status batch_create_with(const vpt_predictor* p, const BatchKnobs& knobs, vpt_batch** out) {
     *out = nullptr;
     VPT_HIP(hipSetDevice(p->device));
     vpt_batch* b = new (std::nothrow) vpt_batch();
     if (!b) return fail(VPT_RUNTIME_ERROR, "out of host memory");
     b->pred = p; b->device = p->device;
-    b->knobs = read_batch_knobs();
+    b->knobs = knobs;
     hipError_t e = hipMalloc(reinterpret_cast<void**>(&b->d_ctrl), 64);
     if (e == hipSuccess) e = hipMemset(b->d_ctrl, 0, 64);
     if (e == hipSuccess && b->knobs.profile_phases) {
@@ -888,6 +924,7 @@ vpt_status vpt_batch_create(const vpt_predictor* p, vpt_batch** out) {
     *out = b;
     return VPT_OK;
 }
+}  // namespace
 
 void vpt_batch_destroy(vpt_batch* b) { batch_release(b); }
 
@@ -1187,6 +1224,9 @@ vpt_status vpt_batch_last_plan(const vpt_batch* b, uint32_t* n_tiles, uint32_t* 
 
 vpt_status vpt_batch_sync(vpt_batch* b) {
     if (!b) return fail(VPT_INVALID_ARGUMENT, "InvalidArgumentError: NULL argument");
+    // A caller that waits for the device may rewrite its buffers afterwards: the chars a predict call left decoded for the fill_tags
+    // call behind it (matched by buffer address and shape only) are good for a fill_tags enqueued BEFORE the next sync, no longer.
+    b->cps_text = nullptr;
     if (!b->pending) return VPT_OK;
     VPT_HIP(hipSetDevice(b->device));
     uint32_t ctrl[2] = {0, 0};
