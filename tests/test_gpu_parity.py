@@ -1019,11 +1019,20 @@ def test_predict_and_write_in_one_launch(case, monkeypatch):
         _fused_write(pred, texts, cap=100)
 
 
-@pytest.mark.parametrize("chunk_bytes", ["", "900", "20000"])
+@pytest.mark.parametrize("chunk_bytes", ["", "900", "20000", "20000:no-prefix", "direct", "900:direct", "20000:direct:no-prefix"])
 def test_tokenize_batch_into_pinned_buffers(chunk_bytes, monkeypatch):
-    """vpt_tokenize_batch without tags: the scoring kernel's tiles write the tokenized text themselves; into caller buffers in PINNED memory
-    (vpt_host_alloc) they write it over PCIe directly -- no copy out -- chunk after chunk into one contiguous text (the chunks hand the
-    position on through device words); pageable buffers get the same bytes through one copy.  Too small a buffer is an error either way."""
+    """vpt_tokenize_batch without tags: the scoring kernel's tiles write the tokenized text themselves, chunk after chunk into one contiguous
+    text (the chunks hand the position on through device words), copied out chunk by chunk while the next one is scored; with
+    VPT_TOKENIZE_DIRECT into caller buffers in PINNED memory (vpt_host_alloc) the kernels write it over PCIe themselves -- no copy out.
+    Too small a buffer is an error either way."""
+    if "direct" in chunk_bytes:   # the kernels write into the pinned caller buffers themselves
+        monkeypatch.setenv("VPT_TOKENIZE_DIRECT", "1")
+        chunk_bytes = chunk_bytes.replace(":direct", "").replace("direct", "")
+    if chunk_bytes.endswith(":no-prefix"):   # tiles publish sizes only: every look-back walks back to the launch's start (and, in a chunk behind the
+        chunk_bytes = chunk_bytes.split(":")[0]   # first, adds where that is) -- the path a tile takes when none in front of it has its position yet
+        monkeypatch.setenv("VPT_DEBUG_EMIT_NO_PREFIX", "1")
+        monkeypatch.setenv("VPT_TILE_FLAT", "64")   # many tiles per chunk: tile numbers that are multiples of 64 among them
+        monkeypatch.setenv("VPT_FORCE_CUT_TILES", "1")
     if chunk_bytes:
         monkeypatch.setenv("VPT_TOKENIZE_CHUNK_BYTES", chunk_bytes)
     m = randmodel.rand_model(853, alphabet="kana", wc=3, wt=3, n_char=80, n_dict=80, max_word=6)
@@ -1535,6 +1544,33 @@ def test_tokenize_batch_is_the_whole_pipeline():
     assert st == api._lib.VPT_OK
     batch.sync()
     assert np.array_equal(d_ooff.get(len(texts) + 1), api.count_boundaries(utf8, boff))
+
+
+def test_count_boundaries_on_the_device_flat_kernel():
+    """vpt_count_boundaries_device (round 4: flat over the text, a workgroup per run of sentences, 16 KB pieces): sentences of 1 char and of
+    tens of thousands (several pieces, piece edges inside chars), every UTF-8 length, unaligned text; NUL and empty sentences are reported."""
+    m = randmodel.rand_model(860, alphabet="kana", wc=3, wt=3, n_char=20, n_dict=20)
+    pred = api.Predictor(api.Model.read_slice(encode_model(m))[0], False)
+    rng = np.random.default_rng(9)
+    alphabet = list("あ漢aé🤌 ｱ/") + ["\n"]
+    lens = list(rng.integers(1, 90, 1500)) + [1, 1, 5461, 5462, 16384, 16385, 40000, 1, 2, 70001, 3] + list(rng.integers(1, 5, 700))
+    texts = ["".join(rng.choice(alphabet, size=int(n))) for n in lens]
+    L = api._lib.load()
+    for lead_in in (0, 1, 7):   # the text need not be aligned
+        utf8, boff = api.pack_texts([t.encode("utf-8") for t in texts])
+        buf = devmem.put(np.concatenate([np.zeros(lead_in, np.uint8), utf8, np.zeros(16, np.uint8)]))
+        d_boff = devmem.put((boff + np.uint64(lead_in)).astype(np.uint64)); d_ooff = devmem.zeros(len(texts) + 1, np.uint64)
+        batch = api.DeviceBatch(pred)
+        assert L.vpt_count_boundaries_device(pred.handle, batch._h, buf.ptr, d_boff.ptr, len(texts), d_ooff.ptr, devmem.stream()) == api._lib.VPT_OK
+        batch.sync()
+        assert np.array_equal(d_ooff.get(len(texts) + 1), api.count_boundaries(utf8, boff))
+    for bad, msg in ((["ab", "c\0d", "e"], "must not contain NULL"), (["ab", "", "e"], "at least one character")):
+        utf8, boff = api.pack_texts([t.encode("utf-8") for t in bad])
+        buf = devmem.put(np.concatenate([utf8, np.zeros(16, np.uint8)])); d_boff = devmem.put(boff.astype(np.uint64)); d_ooff = devmem.zeros(4, np.uint64)
+        batch = api.DeviceBatch(pred)
+        assert L.vpt_count_boundaries_device(pred.handle, batch._h, buf.ptr, d_boff.ptr, 3, d_ooff.ptr, devmem.stream()) == api._lib.VPT_OK
+        with pytest.raises(api.VaporettoError, match=msg):
+            batch.sync()
 
 
 # ------------------------------------------------------------------------------------------------ compiled form, clones

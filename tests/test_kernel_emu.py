@@ -48,7 +48,7 @@ _AS_IS = [
     "test_converted_kytea_fixture_on_gpu", "test_fullwidth_filter_on_device", "test_label_post_filters_on_device",
     "test_device_resident_predict_then_fill_tags", "test_chars_left_by_predict_are_never_another_batchs", "test_fill_tags_with_offsets_that_do_not_match_the_text",
     "test_write_tokenized_text_on_device", "test_writer_blocks_of_any_size", "test_concurrent_host_threads_share_a_predictor",
-    "test_write_tagged_text_on_device", "test_predict_and_write_in_one_launch", "test_tokenize_batch_into_pinned_buffers", "test_tokenize_batch_is_the_whole_pipeline",
+    "test_write_tagged_text_on_device", "test_predict_and_write_in_one_launch", "test_count_boundaries_on_the_device_flat_kernel", "test_tokenize_batch_into_pinned_buffers", "test_tokenize_batch_is_the_whole_pipeline",
     "test_tokenize_batch_in_chunks", "test_device_calls_accept_an_upper_bound_of_the_boundaries",
     "test_compiled_predictor_round_trip_and_clone", "test_compiled_predictor_rejects_damaged_blobs",
     "test_pipelined_host_path_matches_oracle", "test_labels_only_and_packed_tokenize_through_the_host_path",

@@ -46,7 +46,8 @@ struct PredictorKnobs {
     uint64_t chunk_chars = 0;           // VPT_CHUNK_CHARS (0: the size rule)
     uint64_t tokenize_chunk_bytes = uint64_t(256) << 20;   // VPT_TOKENIZE_CHUNK_BYTES (the tagged pipeline's default; the fused one: an eighth of the batch, at least 4 MB)
     bool tokenize_chunk_bytes_set = false;
-    bool tokenize_no_direct = false;    // VPT_TOKENIZE_NO_DIRECT: never write into the caller's pinned buffers from the kernels (A/B of the copy-out path)
+    bool tokenize_separate = false;     // VPT_TOKENIZE_SEPARATE: predict and the writer as launches of their own for untagged text too (A/B of the fused path)
+    bool tokenize_direct = false;       // VPT_TOKENIZE_DIRECT: the kernels write the tokenized text straight into a pinned caller buffer (no copies out)
     int tag_wgs_per_cu = 32;            // VPT_TAG_WGS_PER_CU
 };
 struct BatchKnobs {
@@ -56,6 +57,7 @@ struct BatchKnobs {
     bool no_cps_from_predict = false;   // VPT_NO_CPS_FROM_PREDICT
     uint32_t debug_ablate = 0;          // VPT_DEBUG_ABLATE
     bool profile_phases = false;        // VPT_PROFILE_PHASES
+    bool emit_no_prefix = false;        // VPT_DEBUG_EMIT_NO_PREFIX: the fused writer's tiles publish sizes only (tests: every look-back walks to the front)
     int tag_split = 0;                  // VPT_TAG_SPLIT: 1 = fill_tags always as two launches (step loop -> queue in HBM -> passes), -1 = never (default: batches of 256 K chars and more)
     uint32_t tag_queue = 0;             // VPT_TAG_QUEUE: entries of that queue (tests: overflow; default: an eighth of the batch's chars + 64 K)
     uint32_t debug_emit = 0;            // VPT_DEBUG_EMIT
@@ -69,7 +71,8 @@ PredictorKnobs read_predictor_knobs() {
     if (const char* v = std::getenv("VPT_CHUNK_CHARS")) { const long long n = std::atoll(v); if (n > 0) k.chunk_chars = uint64_t(n); }
     if (const char* v = std::getenv("VPT_TOKENIZE_CHUNK_BYTES")) { const long long n = std::atoll(v); if (n > 0) { k.tokenize_chunk_bytes = uint64_t(n); k.tokenize_chunk_bytes_set = true; } }
     if (const char* v = std::getenv("VPT_TAG_WGS_PER_CU")) k.tag_wgs_per_cu = std::atoi(v);
-    k.tokenize_no_direct = std::getenv("VPT_TOKENIZE_NO_DIRECT") != nullptr;
+    k.tokenize_direct = std::getenv("VPT_TOKENIZE_DIRECT") != nullptr;
+    k.tokenize_separate = std::getenv("VPT_TOKENIZE_SEPARATE") != nullptr;
     return k;
 }
 BatchKnobs read_batch_knobs() {
@@ -84,6 +87,7 @@ BatchKnobs read_batch_knobs() {
     k.no_cps_from_predict = std::getenv("VPT_NO_CPS_FROM_PREDICT") != nullptr;
     if (const char* v = std::getenv("VPT_DEBUG_ABLATE")) k.debug_ablate = uint32_t(std::atoi(v));
     k.profile_phases = std::getenv("VPT_PROFILE_PHASES") != nullptr;
+    k.emit_no_prefix = std::getenv("VPT_DEBUG_EMIT_NO_PREFIX") != nullptr;
     return k;
 }
 
@@ -296,6 +300,7 @@ struct vpt_batch {
     // ONE copy stream per direction: a single hipMemcpyAsync stream moves 56 GB/s each way and 84 GB/s both ways at once on
     // this link; two streams per direction were slower (profiles/r02_c6_pcie_microbench.txt)
     hipStream_t s_in = nullptr, s_out = nullptr;
+    hipStream_t s_tok_in = nullptr, s_tok_out = nullptr;            // vpt_tokenize_batch's copy streams (the fused path)
     uint64_t* h_off = nullptr; size_t h_off_cap = 0;                // pinned: the rebased offsets of every chunk of the call in flight
     std::vector<hipEvent_t> chunk_ev;                               // vpt_tokenize_batch: one per chunk in flight
 };
@@ -372,6 +377,8 @@ void batch_release(vpt_batch* b) {
     if (b->h_off) (void)hipHostFree(b->h_off);
     for (hipEvent_t e : b->chunk_ev) (void)hipEventDestroy(e);
     if (b->s_in) (void)hipStreamDestroy(b->s_in);
+    if (b->s_tok_in) (void)hipStreamDestroy(b->s_tok_in);
+    if (b->s_tok_out) (void)hipStreamDestroy(b->s_tok_out);
     if (b->s_out) (void)hipStreamDestroy(b->s_out);
     for (hipEvent_t e : b->ev) (void)hipEventDestroy(e);
     if (b->own_stream) (void)hipStreamDestroy(b->own_stream);
@@ -413,12 +420,31 @@ struct Workspace {
         if (!b) return;
         (void)hipStreamSynchronize(b->own_stream);   // an error return may leave copies from the caller's buffers in flight
         if (b->s_in) (void)hipStreamSynchronize(b->s_in);
+        if (b->s_tok_in) (void)hipStreamSynchronize(b->s_tok_in);
+        if (b->s_tok_out) (void)hipStreamSynchronize(b->s_tok_out);
         if (b->s_out) (void)hipStreamSynchronize(b->s_out);
         std::lock_guard<std::mutex> g(p->pool_mu);
         p->pool.push_back(b);
     }
 };
-vpt_status batch_create_with(const vpt_predictor* p, const BatchKnobs& knobs, vpt_batch** out);
+vpt_status batch_create_with(const vpt_predictor* p, const BatchKnobs& knobs, vpt_batch** out) {
+    *out = nullptr;
+    VPT_HIP(hipSetDevice(p->device));
+    vpt_batch* b = new (std::nothrow) vpt_batch();
+    if (!b) return fail(VPT_RUNTIME_ERROR, "out of host memory");
+    b->pred = p; b->device = p->device;
+    b->knobs = knobs;
+    hipError_t e = hipMalloc(reinterpret_cast<void**>(&b->d_ctrl), 64);
+    if (e == hipSuccess) e = hipMemset(b->d_ctrl, 0, 64);
+    if (e == hipSuccess && b->knobs.profile_phases) {
+        e = hipMalloc(reinterpret_cast<void**>(&b->d_prof), 128);
+        if (e == hipSuccess) e = hipMemset(b->d_prof, 0, 128);
+    }
+    if (e != hipSuccess) { batch_release(b); return fail(VPT_RUNTIME_ERROR, std::string("HIP error: ") + hipGetErrorString(e)); }
+    *out = b;
+    return VPT_OK;
+}
+
 vpt_status acquire(const vpt_predictor* p, Workspace* w) {
     w->p = p;
     {
@@ -906,26 +932,6 @@ vpt_status vpt_batch_create(const vpt_predictor* p, vpt_batch** out) {
     if (!p || !out) return fail(VPT_INVALID_ARGUMENT, "InvalidArgumentError: NULL argument");
     return batch_create_with(p, read_batch_knobs(), out);
 }
-namespace {
-vpt_status batch_create_with(const vpt_predictor* p, const BatchKnobs& knobs, vpt_batch** out) {
-    *out = nullptr;
-    VPT_HIP(hipSetDevice(p->device));
-    vpt_batch* b = new (std::nothrow) vpt_batch();
-    if (!b) return fail(VPT_RUNTIME_ERROR, "out of host memory");
-    b->pred = p; b->device = p->device;
-    b->knobs = knobs;
-    hipError_t e = hipMalloc(reinterpret_cast<void**>(&b->d_ctrl), 64);
-    if (e == hipSuccess) e = hipMemset(b->d_ctrl, 0, 64);
-    if (e == hipSuccess && b->knobs.profile_phases) {
-        e = hipMalloc(reinterpret_cast<void**>(&b->d_prof), 128);
-        if (e == hipSuccess) e = hipMemset(b->d_prof, 0, 128);
-    }
-    if (e != hipSuccess) { batch_release(b); return fail(VPT_RUNTIME_ERROR, std::string("HIP error: ") + hipGetErrorString(e)); }
-    *out = b;
-    return VPT_OK;
-}
-}  // namespace
-
 void vpt_batch_destroy(vpt_batch* b) { batch_release(b); }
 
 vpt_status vpt_batch_set_timing(vpt_batch* b, int enabled) {
@@ -1162,6 +1168,7 @@ vpt_status predict_device_impl(const vpt_predictor* p, vpt_batch* b, const uint8
             fuse_state = b->d_fuse_state;
             P.emit.out_text = fuse->text_out; P.emit.capacity = fuse->capacity; P.emit.out_offsets = fuse->offsets_out;
             P.emit.state = fuse_state; P.emit.total_out = fuse->total_out; P.emit.chain_in = fuse->chain_in; P.emit.chain_out = fuse->chain_out;
+            P.emit.no_prefix = b->knobs.emit_no_prefix ? 1u : 0u;
             if (!P.emit.out_text) P.emit.out_text = reinterpret_cast<uint8_t*>(b->d_ctrl);   // capacity 0: nothing is stored, the sizes still are
         } else if (!labels_for_writer) {
             if ((st = grow(&b->d_tlab, &b->tlab_cap, size_t(total_boundaries) + 1)) != VPT_OK) return st;
@@ -1698,8 +1705,9 @@ vpt_status vpt_write_tagged_batch(const vpt_predictor* p, const uint8_t* utf8, c
     return emit_host(p, utf8, byte_offsets, n_sentences, out_offsets, labels, true, flags, text_out, text_capacity, text_offsets_out);
 }
 
-vpt_status vpt_count_boundaries_device(const vpt_predictor* p, vpt_batch* b, const uint8_t* d_utf8, const uint64_t* d_byte_offsets,
-                                       size_t n_sentences, uint64_t* d_out_offsets, void* hip_stream) {
+namespace {
+vpt_status count_boundaries_impl(const vpt_predictor* p, vpt_batch* b, const uint8_t* d_utf8, const uint64_t* d_byte_offsets,
+                                 size_t n_sentences, uint64_t* d_out_offsets, void* hip_stream, uint64_t text_bytes_hint) {
     if (!p || !b || b->pred != p) return fail(VPT_INVALID_ARGUMENT, "InvalidArgumentError: batch: does not belong to this predictor");
     if (!d_out_offsets || (n_sentences && (!d_utf8 || !d_byte_offsets))) return fail(VPT_INVALID_ARGUMENT, "InvalidArgumentError: NULL device pointer");
     hipStream_t stream = static_cast<hipStream_t>(hip_stream);
@@ -1709,10 +1717,16 @@ vpt_status vpt_count_boundaries_device(const vpt_predictor* p, vpt_batch* b, con
     else {
         const vpt_status st = grow(&b->d_scan_part, &b->scan_part_cap, vpt::scan_part_entries(n_sentences));
         if (st != VPT_OK) return st;
-        VPT_HIP(vpt::launch_count_boundaries(d_utf8, d_byte_offsets, n_sentences, d_out_offsets, b->d_scan_part, b->d_ctrl, b->d_ctrl + 2, p->n_cus * 32u, stream));
+        VPT_HIP(vpt::launch_count_boundaries(d_utf8, d_byte_offsets, n_sentences, d_out_offsets, b->d_scan_part, b->d_ctrl, b->d_ctrl + 2, text_bytes_hint, stream));
     }
     b->last_stream = stream; b->pending = true; b->cps_text = nullptr;
     return VPT_OK;
+}
+}  // namespace
+
+vpt_status vpt_count_boundaries_device(const vpt_predictor* p, vpt_batch* b, const uint8_t* d_utf8, const uint64_t* d_byte_offsets,
+                                       size_t n_sentences, uint64_t* d_out_offsets, void* hip_stream) {
+    return count_boundaries_impl(p, b, d_utf8, d_byte_offsets, n_sentences, d_out_offsets, hip_stream, 0);
 }
 
 namespace {
@@ -1727,23 +1741,26 @@ void* device_view_of_host(void* host_ptr) {
     return d;
 }
 
-// vpt_tokenize_batch without tags: the writer is a phase of the scoring kernel (vpt_predict_write_batch_device's path), so a chunk of
-// lines is a copy in (text, offsets), the char count (two launches), the tile search and ONE scoring launch that leaves tokenized
-// text.  Chunks run one after the other on the workspace's stream while the next chunk's copy in runs on another; every chunk's
-// text follows the one before it (the kernels hand the position on through a chain of device words), so the output is one piece:
-//   * caller buffers in PINNED memory (vpt_host_alloc): the kernels write the text and the offsets straight into them over PCIe --
-//     no copy out, no size to wait for, the host enqueues everything and waits once;
-//   * pageable buffers: the text is assembled in device memory and copied out at the end.
+// vpt_tokenize_batch without tags, on the scoring kernel with the writer fused in (vpt_predict_write_batch_device's path): a chunk of lines
+// is a copy in (text, offsets), the char count (two launches), the tile search and ONE scoring launch that leaves tokenized text.  Every
+// chunk's text follows the one before it -- the kernels hand the output position on through a chain of device words -- so the batch's
+// output is one piece however it is cut.  Three stages overlap: the copy in of chunk k + 1 (its own stream), the kernels of chunk k (the
+// workspace's stream, everything enqueued up front) and the copy out of chunk k - 1, which the host issues as soon as the chunk's event
+// says where its text ends (a pinned word the last tile wrote).  Measured on MI355X (profiles/r04_d_tokenize_timeline.txt,
+// r04_e_tokenize.jsonl): kernels that write the text STRAIGHT into a pinned caller buffer (VPT_TOKENIZE_DIRECT=1) spare the copies
+// out and every wait but the last, but their stores cross PCIe at 27 .. 34 GB/s against the copy engine's 56.
 // `text` = the batch's first byte; byte_offsets are the caller's (relative to byte_offsets[0]).
 vpt_status tokenize_fused(const vpt_predictor* p, vpt_batch* b, const uint8_t* text, const uint64_t* byte_offsets, size_t n_sentences, unsigned flags,
                           uint64_t max_bytes, uint8_t* text_out, uint64_t text_capacity, uint64_t* text_offsets_out) {
+    (void)max_bytes;
     const uint64_t t0 = byte_offsets[0];
     const size_t nbytes = size_t(byte_offsets[n_sentences] - t0);
-    uint64_t chunk_bytes = p->knobs.tokenize_chunk_bytes_set ? p->knobs.tokenize_chunk_bytes : std::max<uint64_t>(uint64_t(4) << 20, (uint64_t(nbytes) + 7) / 8);
+    const uint64_t chunk_bytes = p->knobs.tokenize_chunk_bytes_set ? p->knobs.tokenize_chunk_bytes : std::max<uint64_t>(uint64_t(2) << 20, (uint64_t(nbytes) + 5) / 6);
     const size_t max_chunks = std::min<size_t>(n_sentences, size_t(nbytes / chunk_bytes) + 2);
     vpt_status st;
-    if (!b->s_in) VPT_HIP(hipStreamCreateWithFlags(&b->s_in, hipStreamNonBlocking));
-    while (b->chunk_ev.size() < max_chunks) {
+    if (!b->s_tok_in) VPT_HIP(hipStreamCreateWithFlags(&b->s_tok_in, hipStreamNonBlocking));
+    if (!b->s_tok_out) VPT_HIP(hipStreamCreateWithFlags(&b->s_tok_out, hipStreamNonBlocking));
+    while (b->chunk_ev.size() < 2 * max_chunks) {   // per chunk: copied in, scored
         hipEvent_t e;
         VPT_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
         b->chunk_ev.push_back(e);
@@ -1757,9 +1774,14 @@ vpt_status tokenize_fused(const vpt_predictor* p, vpt_batch* b, const uint8_t* t
         b->off_cap = std::min(cap, cap2);
     }
     if ((st = grow(&b->d_chain, &b->chain_cap, max_chunks + 2)) != VPT_OK) return st;
-    uint8_t* d_out = static_cast<uint8_t*>(device_view_of_host(text_out));
-    uint64_t* d_off_out = static_cast<uint64_t*>(device_view_of_host(text_offsets_out));
-    const bool direct = (d_out || text_capacity == 0) && d_off_out && !p->knobs.tokenize_no_direct;
+    uint8_t* d_out = nullptr;
+    uint64_t* d_off_out = nullptr;
+    bool direct = false;
+    if (p->knobs.tokenize_direct) {
+        d_out = static_cast<uint8_t*>(device_view_of_host(text_out));
+        d_off_out = static_cast<uint64_t*>(device_view_of_host(text_offsets_out));
+        direct = (d_out || text_capacity == 0) && d_off_out;
+    }
     uint64_t out_cap = text_capacity;
     if (!direct) {
         out_cap = uint64_t(nbytes) * 3 + 16;
@@ -1767,7 +1789,7 @@ vpt_status tokenize_fused(const vpt_predictor* p, vpt_batch* b, const uint8_t* t
         if ((st = grow(&b->d_toff, &b->toff_cap, n_sentences + 2)) != VPT_OK) return st;
         d_out = b->d_tok; d_off_out = b->d_toff;
     }
-    const size_t need_off = n_sentences + 1 + 1;   // pinned: the offsets relative to the batch's text, then the total
+    const size_t need_off = n_sentences + 1 + max_chunks + 1;   // pinned: the offsets relative to the batch's text, then where every chunk's text ends
     if (need_off > b->h_off_cap) {
         if (b->h_off) (void)hipHostFree(b->h_off);
         b->h_off = nullptr; b->h_off_cap = 0;
@@ -1775,16 +1797,16 @@ vpt_status tokenize_fused(const vpt_predictor* p, vpt_batch* b, const uint8_t* t
         b->h_off_cap = need_off + need_off / 2;
     }
     uint64_t* const h_boff = b->h_off;
-    uint64_t* const h_total = b->h_off + n_sentences + 1;
+    uint64_t* const h_end = b->h_off + n_sentences + 1;
     for (size_t i = 0; i <= n_sentences; ++i) h_boff[i] = byte_offsets[i] - t0;
-    *h_total = ~uint64_t(0);
-    hipStream_t s = b->own_stream, s_in = b->s_in;
+    hipStream_t s = b->own_stream, s_in = b->s_tok_in, s_out = b->s_tok_out;
     b->flags = flags;
     b->max_chars = 0;   // unknown on the host (no round trip for it): the scoring kernel takes the geometry that fits any sentence
     VPT_HIP(hipMemsetAsync(b->d_chain, 0, sizeof(uint64_t), s));
-    size_t k = 0;
-    for (size_t i = 0; i < n_sentences; ++k) {
-        const size_t a = i;
+    struct Chunk { size_t a, n; };
+    std::vector<Chunk> chunks;
+    for (size_t i = 0; i < n_sentences;) {
+        const size_t a = i, k = chunks.size();
         uint64_t mb = 0;
         while (i < n_sentences && h_boff[i] - h_boff[a] < chunk_bytes) { mb = std::max<uint64_t>(mb, h_boff[i + 1] - h_boff[i]); ++i; }
         const size_t n = i - a;
@@ -1793,30 +1815,40 @@ vpt_status tokenize_fused(const vpt_predictor* p, vpt_batch* b, const uint8_t* t
         uint64_t* d_ooff_k = b->d_ooff + a + k;   // n + 1 entries per chunk, chunk-relative
         VPT_HIP(hipMemcpyAsync(b->d_text + tb, text + tb, size_t(nby), hipMemcpyHostToDevice, s_in));
         VPT_HIP(hipMemcpyAsync(d_boff_k, h_boff + a, 8 * (n + 1), hipMemcpyHostToDevice, s_in));
-        VPT_HIP(hipEventRecord(b->chunk_ev[k], s_in));
-        VPT_HIP(hipStreamWaitEvent(s, b->chunk_ev[k], 0));
-        if ((st = vpt_count_boundaries_device(p, b, b->d_text, d_boff_k, n, d_ooff_k, s)) != VPT_OK) return st;
-        const FuseRequest fuse{d_out, out_cap, d_off_out + a, i == n_sentences ? h_total : nullptr, b->d_chain + k, b->d_chain + k + 1};
+        VPT_HIP(hipEventRecord(b->chunk_ev[2 * k], s_in));
+        VPT_HIP(hipStreamWaitEvent(s, b->chunk_ev[2 * k], 0));
+        if ((st = count_boundaries_impl(p, b, b->d_text, d_boff_k, n, d_ooff_k, s, nby)) != VPT_OK) return st;
+        h_end[k] = ~uint64_t(0);
+        const FuseRequest fuse{d_out, out_cap, d_off_out + a, h_end + k, b->d_chain + k, b->d_chain + k + 1};
         st = predict_device_impl(p, b, b->d_text, d_boff_k, d_ooff_k, n, nby - n /* boundaries of the chunk, at most */, mb, nullptr, nullptr, s, &fuse);
         if (st != VPT_OK) return st;
+        VPT_HIP(hipEventRecord(b->chunk_ev[2 * k + 1], s));
+        chunks.push_back({a, n});
     }
-    // ---- the device's verdict, then (pageable buffers) the text
+    // ---- collect: as a chunk's kernels finish, its text and offsets leave on the copy-out stream (the next chunk's are still running)
+    uint64_t at = 0;
+    bool out_of_range = false, too_small = false;
+    for (size_t k = 0; k < chunks.size() && !direct; ++k) {
+        VPT_HIP(hipEventSynchronize(b->chunk_ev[2 * k + 1]));
+        const uint64_t end = h_end[k];
+        if (end > out_cap || end < at) { out_of_range = true; break; }   // the device found the inputs inconsistent and says so below
+        if (end > text_capacity) { too_small = true; break; }
+        if (end > at) VPT_HIP(hipMemcpyAsync(text_out + at, d_out + at, size_t(end - at), hipMemcpyDeviceToHost, s_out));
+        VPT_HIP(hipMemcpyAsync(text_offsets_out + chunks[k].a, d_off_out + chunks[k].a, 8 * (chunks[k].n + 1), hipMemcpyDeviceToHost, s_out));
+        at = end;
+    }
+    // ---- the device's verdict over every chunk
     uint32_t ctrl[2] = {0, 0};
     VPT_HIP(hipMemcpyAsync(ctrl, b->d_ctrl, sizeof(ctrl), hipMemcpyDeviceToHost, s));
     VPT_HIP(hipStreamSynchronize(s));
+    VPT_HIP(hipStreamSynchronize(s_out));
     b->pending = false;
     if (ctrl[0]) {
         VPT_HIP(hipMemset(b->d_ctrl, 0, sizeof(uint32_t)));
         return status_from_bits(ctrl[0]);
     }
-    const uint64_t total = *h_total;
-    if (total > out_cap) return fail(VPT_RUNTIME_ERROR, "vpt_tokenize_batch: the output size is out of range");
-    if (!direct) {
-        if (total > text_capacity) return fail(VPT_INVALID_ARGUMENT, "InvalidArgumentError: text_capacity: smaller than the tokenized text");
-        if (total) VPT_HIP(hipMemcpyAsync(text_out, d_out, size_t(total), hipMemcpyDeviceToHost, s));
-        VPT_HIP(hipMemcpyAsync(text_offsets_out, d_off_out, 8 * (n_sentences + 1), hipMemcpyDeviceToHost, s));
-        VPT_HIP(hipStreamSynchronize(s));
-    }
+    if (too_small) return fail(VPT_INVALID_ARGUMENT, "InvalidArgumentError: text_capacity: smaller than the tokenized text");
+    if (out_of_range || h_end[chunks.size() - 1] > out_cap) return fail(VPT_RUNTIME_ERROR, "vpt_tokenize_batch: the output size is out of range");
     return VPT_OK;
 }
 }  // namespace
@@ -1848,7 +1880,7 @@ vpt_status vpt_tokenize_batch(const vpt_predictor* p, const uint8_t* utf8, const
     vpt_batch* b = w.b;
     const size_t nbytes = size_t(t1 - t0);
     const bool with_tags = tagged && p->n_tags > 0;
-    if (!with_tags && p->fused_writer_ok && !b->knobs.force_generic)
+    if (!with_tags && p->fused_writer_ok && !b->knobs.force_generic && !p->knobs.tokenize_separate)
         return tokenize_fused(p, b, utf8 + t0, byte_offsets, n_sentences, flags, max_bytes, text_out, text_capacity, text_offsets_out);
     // NOTHING on the way needs a number from the device: the device buffers hold the whole batch and a slice of an output starts
     // where an upper bound puts it (a char is at least one byte: boundaries and chars in front of a slice <= text bytes in front
@@ -1917,7 +1949,7 @@ vpt_status vpt_tokenize_batch(const vpt_predictor* p, const uint8_t* utf8, const
         uint8_t* d_labels_k = b->d_tlab + tb;
         VPT_HIP(hipMemcpyAsync(b->d_text + tb, utf8 + t0 + tb, size_t(nby), hipMemcpyHostToDevice, s));
         VPT_HIP(hipMemcpyAsync(d_boff_k, h_boff + a, 8 * (n + 1), hipMemcpyHostToDevice, s));
-        if ((st = vpt_count_boundaries_device(p, bb, b->d_text, d_boff_k, n, d_ooff_k, s)) != VPT_OK) return st;
+        if ((st = count_boundaries_impl(p, bb, b->d_text, d_boff_k, n, d_ooff_k, s, nby)) != VPT_OK) return st;
         const uint64_t tb_bound = nby - n;                        // boundaries of the chunk, at most
         st = vpt_predict_batch_device(p, bb, b->d_text, d_boff_k, d_ooff_k, n, tb_bound, mb, nullptr, d_labels_k, s);
         if (st != VPT_OK) return st;

@@ -65,6 +65,7 @@ struct EmitOut {
     uint64_t* total_out;        // optional device-writable HOST address that receives the output's total size
     const uint64_t* chain_in;   // optional device word: the output position in front of this launch's text (what the launch before it left
     uint64_t* chain_out;        // in ITS chain_out: one text over several launches on one stream); optional: receives the position behind it
+    uint32_t no_prefix;         // test knob (VPT_DEBUG_EMIT_NO_PREFIX): tiles publish their sizes only, so every look-back walks to the launch's start
 };
 
 struct ScoreParams {
@@ -189,9 +190,10 @@ struct EmitFuse {
     uint64_t* total_out;    // optional device-writable HOST address that receives the output's total size
 };
 hipError_t launch_emit_tokenized(const EmitParams& P, const EmitFuse& F, hipStream_t stream);
-// vpt_count_boundaries on the device: ooff_out[S+1]; *max_chars (atomicMax) = the longest sentence in chars
+// vpt_count_boundaries on the device: ooff_out[S+1]; *max_chars (atomicMax) = the longest sentence in chars; text_bytes_hint: the batch's text
+// bytes when the host knows them (0: not), which sizes the workgroups' shares
 hipError_t launch_count_boundaries(const uint8_t* text, const uint64_t* boff, uint64_t n_sent, uint64_t* ooff_out, uint64_t* scan_part, uint32_t* status,
-                                   uint32_t* max_chars, uint32_t max_blocks, hipStream_t stream);
+                                   uint32_t* max_chars, uint64_t text_bytes_hint, hipStream_t stream);
 
 size_t score_tiles_lds_bytes();
 // `emit_state` (optional): the n_tiles + 1 words of EmitOut::state, cleared here for the scoring kernel behind this launch

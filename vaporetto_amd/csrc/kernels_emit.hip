@@ -10,6 +10,8 @@
 // count_chars_kernel + scan_chained_kernel are vpt_count_boundaries on the device.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
+
 #include "device_common.h"
 #include "kernels.hpp"
 
@@ -551,34 +553,97 @@ __global__ __launch_bounds__(kEmitThreads) void emit_fused_kernel(const EmitPara
 }
 
 // vpt_count_boundaries on the device: chars - 1 of every sentence -> offsets[i + 1] (the scan follows), the same
-// validation as Sentence::from_raw (sentence.rs:160-196), the longest sentence (in chars) -> *max_chars
+// validation as Sentence::from_raw (sentence.rs:160-196), the longest sentence (in chars) -> *max_chars.
+//
+// FLAT over the text (round 4; a wave per sentence took 0.38 ms for configs[1]'s 19 MB -- three dependent trips to memory per sentence
+// -- and was the longest kernel of vpt_tokenize_batch, profiles/r04_d_tokenize_timeline.txt): a workgroup takes `per_block` consecutive
+// sentences and streams their bytes in pieces of 16 KB, 64 contiguous bytes per thread; a block-wide prefix sum over the threads' lead
+// counts and the chunks' lead masks in LDS turn "leads in front of byte x" into two LDS reads, which the thread of every sentence asks
+// for its first byte and for the byte behind its last.
+constexpr uint32_t kCountPiece = kEmitThreads * 64;   // bytes per piece
 __global__ __launch_bounds__(kEmitThreads) void count_chars_kernel(const uint8_t* __restrict__ text, const uint64_t* __restrict__ boff,
                                                                    uint64_t n_sent, uint64_t* __restrict__ offsets, uint32_t* __restrict__ status,
-                                                                   uint32_t* __restrict__ max_chars, uint64_t* scan_state) {
+                                                                   uint32_t* __restrict__ max_chars, uint64_t* scan_state, uint32_t per_block) {
+    __shared__ uint16_t masks[kEmitThreads * 4];   // lead mask of every 16-byte chunk of the piece
+    __shared__ uint32_t pfx[kEmitThreads];         // leads of the piece in front of the thread's 64 bytes
+    __shared__ uint32_t wtot[kEmitWaves];
     clear_scan_state(scan_state, n_sent);
-    const int lane = threadIdx.x & 63;
-    const uint64_t wave = uint64_t(blockIdx.x) * kEmitWaves + wave_uniform(threadIdx.x >> 6);
-    const uint64_t n_waves = uint64_t(gridDim.x) * kEmitWaves;
-    uint32_t err = 0, longest = 0;
-    for (uint64_t i = wave; i < n_sent; i += n_waves) {
-        const uint64_t b0 = wave_uniform64(boff[i]), b1 = wave_uniform64(boff[i + 1]);
-        uint64_t mine = 0;
-        bool nul = false;
-        for (uint64_t pos = b0; pos < b1; pos += 256) {
-            const uint64_t at = pos + 4 * uint64_t(lane);
-            const uint32_t x = load4(text, at, b1);
-            const uint32_t nv = at < b1 ? uint32_t(b1 - at < 4 ? b1 - at : 4) : 0u, vm = (1u << nv) - 1u;
-            nul = nul || (byte_flags_to_nibble(zero_bytes(x)) & vm) != 0;
-            mine += uint32_t(__popc(lead_nibble(x) & vm));
+    const uint32_t tid = threadIdx.x, lane = tid & 63, wave = wave_uniform(tid >> 6);
+    const uint64_t s0 = uint64_t(blockIdx.x) * per_block;
+    if (s0 >= n_sent) return;
+    const uint32_t ns = uint32_t(n_sent - s0 < per_block ? n_sent - s0 : per_block);
+    const uint64_t B0 = boff[s0], B1 = boff[s0 + ns];
+    uint64_t my_b = 0, my_e = 0;
+    if (tid < ns) { my_b = boff[s0 + tid]; my_e = boff[s0 + tid + 1]; }
+    uint32_t err = 0;
+    const bool mine = tid < ns;
+    const bool sane = mine && my_e > my_b && my_b >= B0 && my_e <= B1;   // (offsets that are not non-decreasing: reported, nothing read for them)
+    if (mine && !sane) err |= my_e <= my_b ? kErrEmptySentence : kErrBadOffsets;
+    uint64_t p_start = 0, p_end = 0, carry = 0;
+    bool nul = false;
+    const uintptr_t t_lo = reinterpret_cast<uintptr_t>(text) + B0, t_hi = reinterpret_cast<uintptr_t>(text) + B1;
+    for (uintptr_t piece = t_lo & ~uintptr_t(15); piece < t_hi; piece += kCountPiece) {
+        const uintptr_t mine_at = piece + 64u * tid;
+        uint4 v[4];
+#pragma unroll
+        for (uint32_t q = 0; q < 4; ++q) {
+            const uintptr_t a = mine_at + 16u * q;
+            v[q] = (a + 16 > t_lo && a < t_hi) ? *reinterpret_cast<const uint4*>(a) : make_uint4(0, 0, 0, 0);
         }
-        const uint64_t chars = wave_sum64(mine);
-        if (__ballot(nul) != 0) err |= kErrNulChar;
-        if (b1 <= b0 || chars == 0) err |= kErrEmptySentence;
+        uint32_t cnt = 0;
+#pragma unroll
+        for (uint32_t q = 0; q < 4; ++q) {
+            const uintptr_t a = mine_at + 16u * q;
+            const uint32_t lo = t_lo > a ? (t_lo - a < 16 ? uint32_t(t_lo - a) : 16u) : 0u;
+            const uint32_t hi = t_hi > a ? (t_hi - a < 16 ? uint32_t(t_hi - a) : 16u) : 0u;
+            const uint32_t vm = hi > lo ? ((1u << hi) - 1u) & ~((1u << lo) - 1u) : 0u;
+            const uint32_t lm = (lead_nibble(v[q].x) | (lead_nibble(v[q].y) << 4) | (lead_nibble(v[q].z) << 8) | (lead_nibble(v[q].w) << 12)) & vm;
+            const uint32_t zm = (byte_flags_to_nibble(zero_bytes(v[q].x)) | (byte_flags_to_nibble(zero_bytes(v[q].y)) << 4) |
+                                 (byte_flags_to_nibble(zero_bytes(v[q].z)) << 8) | (byte_flags_to_nibble(zero_bytes(v[q].w)) << 12)) & vm;
+            nul = nul || zm != 0;
+            masks[tid * 4 + q] = uint16_t(lm);
+            cnt += uint32_t(__popc(lm));
+        }
+        const uint32_t incl = wave_inclusive_scan(cnt);
+        if (lane == 63) wtot[wave] = incl;
+        __syncthreads();
+        uint32_t woff = 0, total = 0;
+#pragma unroll
+        for (uint32_t k = 0; k < uint32_t(kEmitWaves); ++k) {
+            const uint32_t u = wtot[k];
+            if (k < wave) woff += u;
+            total += u;
+        }
+        pfx[tid] = woff + incl - cnt;
+        __syncthreads();
+        // leads of the piece in front of byte x (piece <= x <= piece + kCountPiece)
+        auto before = [&](uintptr_t x) -> uint32_t {
+            const uint32_t r = uint32_t(x - piece);
+            if (r >= kCountPiece) return total;
+            const uint32_t t = r >> 6, q = (r >> 4) & 3u, bit = r & 15u;
+            uint32_t c = pfx[t];
+            for (uint32_t qq = 0; qq < q; ++qq) c += uint32_t(__popc(uint32_t(masks[t * 4 + qq])));
+            return c + uint32_t(__popc(uint32_t(masks[t * 4 + q]) & ((1u << bit) - 1u)));
+        };
+        if (sane) {
+            const uintptr_t xs = reinterpret_cast<uintptr_t>(text) + my_b, xe = reinterpret_cast<uintptr_t>(text) + my_e;
+            if (xs >= piece && xs - piece < kCountPiece) p_start = carry + before(xs);
+            if (xe > piece && xe - piece <= kCountPiece) p_end = carry + before(xe);
+        }
+        carry += total;
+        __syncthreads();   // the next piece rewrites masks / pfx / wtot
+    }
+    if (__ballot(nul) != 0) err |= kErrNulChar;
+    uint32_t longest = 0;
+    if (mine) {
+        const uint64_t chars = sane ? p_end - p_start : 0;
+        if (chars == 0) err |= kErrEmptySentence;
         if (chars > 0xFFFFFFFFull) err |= kErrBadOffsets;
-        longest = chars > longest ? uint32_t(chars) : longest;
-        if (lane == 0) offsets[i + 1] = chars > 0 ? chars - 1 : 0;
+        longest = chars > 0xFFFFFFFFull ? 0xFFFFFFFFu : uint32_t(chars);
+        offsets[s0 + tid + 1] = chars > 0 ? chars - 1 : 0;
     }
     if (err) atomicOr(status, err);
+    longest = wave_max(longest);
     if (lane == 0 && longest) atomicMax(max_chars, longest);
 }
 
@@ -594,9 +659,13 @@ static uint32_t emit_blocks(uint64_t n_sent, uint32_t max_blocks) {
 }
 
 hipError_t launch_count_boundaries(const uint8_t* text, const uint64_t* boff, uint64_t n_sent, uint64_t* ooff_out, uint64_t* scan_part, uint32_t* status,
-                                   uint32_t* max_chars, uint32_t max_blocks, hipStream_t stream) {
-    const uint32_t blocks = emit_blocks(n_sent, max_blocks);
-    hipLaunchKernelGGL(count_chars_kernel, dim3(blocks), dim3(kEmitThreads), 0, stream, text, boff, n_sent, ooff_out, status, max_chars, scan_part);
+                                   uint32_t* max_chars, uint64_t text_bytes_hint, hipStream_t stream) {
+    // sentences per workgroup: about 64 KB of text when the caller knows how much text there is (the device entry point does not: then 32 sentences);
+    // at most one per thread
+    uint64_t per = 32;
+    if (text_bytes_hint && n_sent) per = std::min<uint64_t>(std::max<uint64_t>((uint64_t(65536) * n_sent + text_bytes_hint / 2) / std::max<uint64_t>(text_bytes_hint, 1), 1), kEmitThreads);
+    const uint64_t blocks = (n_sent + per - 1) / per;
+    hipLaunchKernelGGL(count_chars_kernel, dim3(uint32_t(blocks)), dim3(kEmitThreads), 0, stream, text, boff, n_sent, ooff_out, status, max_chars, scan_part, uint32_t(per));
     return launch_scan(ooff_out, n_sent, scan_part, ~uint64_t(0), status, nullptr, stream);
 }
 

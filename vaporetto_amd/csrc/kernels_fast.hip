@@ -338,7 +338,7 @@ __device__ __forceinline__ uint64_t phase_mark(uint64_t* prof, int slot, uint64_
 // The fused writer's decoupled look-back (one wave; `state`: EmitOut::state): publishes the tile's size, sums the sizes of the tiles
 // in front of it -- 64 words per trip, stopping at the nearest tile whose position is known -- publishes the position behind the tile
 // and returns the one in front of it (in every lane); `front`: where the launch's text starts.  Every tile with a smaller number is running or done (tickets), so the wait ends.
-__device__ __forceinline__ uint64_t emit_lookback(uint64_t* state, uint32_t tile, uint32_t size, int lane, uint64_t front) {
+__device__ __forceinline__ uint64_t emit_lookback(uint64_t* state, uint32_t tile, uint32_t size, int lane, uint64_t front, bool no_prefix = false) {
     constexpr uint64_t kVal = (uint64_t(1) << 62) - 1;
     if (lane == 0) __hip_atomic_store(state + tile, (uint64_t(1) << 62) | uint64_t(size), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     uint64_t base = tile == 0 ? front : 0;
@@ -359,8 +359,9 @@ __device__ __forceinline__ uint64_t emit_lookback(uint64_t* state, uint32_t tile
         base += part;
         if (first < 64) break;
         pz -= 64;
+        if (pz == 0) base += front;   // 64 sizes and the launch's first tile behind them: what lies in front of it is the launch's start
     }
-    if (lane == 0) __hip_atomic_store(state + tile, (uint64_t(2) << 62) | ((base + size) & kVal), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (lane == 0 && !no_prefix) __hip_atomic_store(state + tile, (uint64_t(2) << 62) | ((base + size) & kVal), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     return base;
 }
 
@@ -398,7 +399,7 @@ __global__ __launch_bounds__(kThreads, fast_wg(WL)) void score_tiles_fast_kernel
         if (tile != P.n_tiles - 1) {
             if (tid == 0) __hip_atomic_store(P.emit.state + tile, uint64_t(1) << 62, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         } else if (wave == 0) {
-            const uint64_t end = emit_lookback(P.emit.state, tile, 0u, lane, P.emit.chain_in ? *P.emit.chain_in : 0ull);
+            const uint64_t end = emit_lookback(P.emit.state, tile, 0u, lane, P.emit.chain_in ? *P.emit.chain_in : 0ull, P.emit.no_prefix != 0);
             if (lane == 0) {
                 P.emit.out_offsets[P.n_sent] = end;
                 if (P.emit.total_out) *P.emit.total_out = end;
@@ -855,13 +856,13 @@ __global__ __launch_bounds__(kThreads, fast_wg(WL)) void score_tiles_fast_kernel
         }
         __syncthreads();
         // ---- pass 1: per chunk the masks of its bytes; where the own chars' bytes begin and end
-        uint32_t e_lm[2], e_sm[2], e_em[2], e_sp[2], e_so[2], e_sib[2], e_vm[2];
+        uint32_t e_sm[2], e_em[2], e_sp[2], e_so[2], e_sib[2], e_vm[2];
         {
             uint32_t bl = 0, bs = 0, lo_pos = 0xFFFFFFFFu, hi_pos = 0xFFFFFFFFu;
 #pragma unroll
             for (int r = 0; r < 2; ++r) {
                 const uint32_t c = uint32_t(tid) + uint32_t(r) * kThreads;
-                e_lm[r] = e_sm[r] = e_em[r] = e_sp[r] = e_so[r] = e_sib[r] = e_vm[r] = 0;
+                e_sm[r] = e_em[r] = e_sp[r] = e_so[r] = e_sib[r] = e_vm[r] = 0;
                 if (uint32_t(r) * kThreads >= nchunks) continue;   // (block-uniform)
                 const uint32_t pos0 = c < nchunks ? c * 16 : 0u;
                 uint32_t lm = 0, sm = 0, em = 0, vm = 0;
@@ -907,7 +908,7 @@ __global__ __launch_bounds__(kThreads, fast_wg(WL)) void score_tiles_fast_kernel
                     if (p >= int32_t(own_lo)) lo_pos = lo_pos < pos0 + k ? lo_pos : pos0 + k;
                     if (p >= int32_t(own_hi)) hi_pos = hi_pos < pos0 + k ? hi_pos : pos0 + k;
                 }
-                e_lm[r] = lm; e_sm[r] = sm; e_em[r] = em; e_sp[r] = spm; e_so[r] = som; e_sib[r] = uint32_t(sib); e_vm[r] = vm;
+                e_sm[r] = sm; e_em[r] = em; e_sp[r] = spm; e_so[r] = som; e_sib[r] = uint32_t(sib); e_vm[r] = vm;
             }
             if (lo_pos != 0xFFFFFFFFu) atomicMin(&ew[0], lo_pos);
             if (hi_pos != 0xFFFFFFFFu) atomicMin(&ew[1], hi_pos);
@@ -945,7 +946,7 @@ __global__ __launch_bounds__(kThreads, fast_wg(WL)) void score_tiles_fast_kernel
         const uint32_t size = run;   // (the same in every thread)
         // ---- the tile's position: wave 0 publishes the size and looks back over the earlier tiles' words, 64 per trip
         if (wave == 0) {
-            const uint64_t base = emit_lookback(P.emit.state, tile, size, lane, P.emit.chain_in ? *P.emit.chain_in : 0ull);
+            const uint64_t base = emit_lookback(P.emit.state, tile, size, lane, P.emit.chain_in ? *P.emit.chain_in : 0ull, P.emit.no_prefix != 0);
             if (lane == 0) { ew[2] = uint32_t(base); ew[3] = uint32_t(base >> 32); }
         }
         // ---- assembly (every wave; needs no position): [' '] ['\\'] byte for the chunk's bytes, in order
