@@ -27,6 +27,9 @@ constexpr int kMargin = 8;                       // zeroed slack past the tile f
 #ifndef VPT_FAST_WG
 #define VPT_FAST_WG 8
 #endif
+#ifndef VPT_FAST_CTAB
+#define VPT_FAST_CTAB 0    // experiment (round 4): char -> symbol words of ASCII, U+3000..30FF and U+FF00..FFEF in LDS (kernels_fast.hip, classify)
+#endif
 #ifndef VPT_FAST_CAP_WIDE
 #define VPT_FAST_CAP_WIDE 1024
 #endif
