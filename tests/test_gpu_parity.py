@@ -1019,12 +1019,15 @@ def test_predict_and_write_in_one_launch(case, monkeypatch):
         _fused_write(pred, texts, cap=100)
 
 
-@pytest.mark.parametrize("chunk_bytes", ["", "900", "20000", "20000:no-prefix", "direct", "900:direct", "20000:direct:no-prefix"])
+@pytest.mark.parametrize("chunk_bytes", ["", "900", "20000", "20000:no-prefix", "direct", "900:direct", "20000:direct:no-prefix", "lanes", "900:lanes", "20000:lanes"])
 def test_tokenize_batch_into_pinned_buffers(chunk_bytes, monkeypatch):
     """vpt_tokenize_batch without tags: the scoring kernel's tiles write the tokenized text themselves, chunk after chunk into one contiguous
     text (the chunks hand the position on through device words), copied out chunk by chunk while the next one is scored; with
     VPT_TOKENIZE_DIRECT into caller buffers in PINNED memory (vpt_host_alloc) the kernels write it over PCIe themselves -- no copy out.
     Too small a buffer is an error either way."""
+    if "lanes" in chunk_bytes:    # the chunks alternate over two streams, copies out behind their kernels
+        monkeypatch.setenv("VPT_TOKENIZE_LANES", "2")
+        chunk_bytes = chunk_bytes.replace(":lanes", "").replace("lanes", "")
     if "direct" in chunk_bytes:   # the kernels write into the pinned caller buffers themselves
         monkeypatch.setenv("VPT_TOKENIZE_DIRECT", "1")
         chunk_bytes = chunk_bytes.replace(":direct", "").replace("direct", "")

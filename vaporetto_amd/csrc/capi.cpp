@@ -47,6 +47,7 @@ struct PredictorKnobs {
     uint64_t tokenize_chunk_bytes = uint64_t(256) << 20;   // VPT_TOKENIZE_CHUNK_BYTES (the tagged pipeline's default; the fused one: an eighth of the batch, at least 4 MB)
     bool tokenize_chunk_bytes_set = false;
     bool tokenize_separate = false;     // VPT_TOKENIZE_SEPARATE: predict and the writer as launches of their own for untagged text too (A/B of the fused path)
+    int tokenize_lanes = 0;             // VPT_TOKENIZE_LANES: 2 = the chunks alternate over two streams, a chunk's copy out BEHIND its kernels on its stream
     bool tokenize_direct = false;       // VPT_TOKENIZE_DIRECT: the kernels write the tokenized text straight into a pinned caller buffer (no copies out)
     int tag_wgs_per_cu = 32;            // VPT_TAG_WGS_PER_CU
 };
@@ -72,6 +73,7 @@ PredictorKnobs read_predictor_knobs() {
     if (const char* v = std::getenv("VPT_TOKENIZE_CHUNK_BYTES")) { const long long n = std::atoll(v); if (n > 0) { k.tokenize_chunk_bytes = uint64_t(n); k.tokenize_chunk_bytes_set = true; } }
     if (const char* v = std::getenv("VPT_TAG_WGS_PER_CU")) k.tag_wgs_per_cu = std::atoi(v);
     k.tokenize_direct = std::getenv("VPT_TOKENIZE_DIRECT") != nullptr;
+    if (const char* v = std::getenv("VPT_TOKENIZE_LANES")) k.tokenize_lanes = std::atoi(v);
     k.tokenize_separate = std::getenv("VPT_TOKENIZE_SEPARATE") != nullptr;
     return k;
 }
@@ -1712,12 +1714,11 @@ vpt_status count_boundaries_impl(const vpt_predictor* p, vpt_batch* b, const uin
     if (!d_out_offsets || (n_sentences && (!d_utf8 || !d_byte_offsets))) return fail(VPT_INVALID_ARGUMENT, "InvalidArgumentError: NULL device pointer");
     hipStream_t stream = static_cast<hipStream_t>(hip_stream);
     VPT_HIP(hipSetDevice(p->device));
-    VPT_HIP(hipMemsetAsync(b->d_ctrl + 2, 0, sizeof(uint32_t), stream));   // [2]: the longest sentence in chars
     if (n_sentences == 0) VPT_HIP(hipMemsetAsync(d_out_offsets, 0, sizeof(uint64_t), stream));
     else {
         const vpt_status st = grow(&b->d_scan_part, &b->scan_part_cap, vpt::scan_part_entries(n_sentences));
         if (st != VPT_OK) return st;
-        VPT_HIP(vpt::launch_count_boundaries(d_utf8, d_byte_offsets, n_sentences, d_out_offsets, b->d_scan_part, b->d_ctrl, b->d_ctrl + 2, text_bytes_hint, stream));
+        VPT_HIP(vpt::launch_count_boundaries(d_utf8, d_byte_offsets, n_sentences, d_out_offsets, b->d_scan_part, b->d_ctrl, nullptr /* nobody reads the longest sentence: no launch to clear it */, text_bytes_hint, stream));
     }
     b->last_stream = stream; b->pending = true; b->cps_text = nullptr;
     return VPT_OK;
@@ -1803,40 +1804,55 @@ vpt_status tokenize_fused(const vpt_predictor* p, vpt_batch* b, const uint8_t* t
     b->flags = flags;
     b->max_chars = 0;   // unknown on the host (no round trip for it): the scoring kernel takes the geometry that fits any sentence
     VPT_HIP(hipMemsetAsync(b->d_chain, 0, sizeof(uint64_t), s));
-    struct Chunk { size_t a, n; };
+    struct Chunk { size_t a, n; uint64_t tb, nby, mb; };
     std::vector<Chunk> chunks;
-    for (size_t i = 0; i < n_sentences;) {
+    for (size_t i = 0; i < n_sentences;) {   // every copy in first: they only depend on the host's buffers
         const size_t a = i, k = chunks.size();
         uint64_t mb = 0;
         while (i < n_sentences && h_boff[i] - h_boff[a] < chunk_bytes) { mb = std::max<uint64_t>(mb, h_boff[i + 1] - h_boff[i]); ++i; }
         const size_t n = i - a;
         const uint64_t tb = h_boff[a], nby = h_boff[i] - tb;
-        uint64_t* d_boff_k = b->d_boff + a + k;   // n + 1 entries per chunk; offsets into the WHOLE text: no rebasing
-        uint64_t* d_ooff_k = b->d_ooff + a + k;   // n + 1 entries per chunk, chunk-relative
         VPT_HIP(hipMemcpyAsync(b->d_text + tb, text + tb, size_t(nby), hipMemcpyHostToDevice, s_in));
-        VPT_HIP(hipMemcpyAsync(d_boff_k, h_boff + a, 8 * (n + 1), hipMemcpyHostToDevice, s_in));
+        VPT_HIP(hipMemcpyAsync(b->d_boff + a + k, h_boff + a, 8 * (n + 1), hipMemcpyHostToDevice, s_in));   // n + 1 entries per chunk; offsets into the WHOLE text: no rebasing
         VPT_HIP(hipEventRecord(b->chunk_ev[2 * k], s_in));
-        VPT_HIP(hipStreamWaitEvent(s, b->chunk_ev[2 * k], 0));
-        if ((st = count_boundaries_impl(p, b, b->d_text, d_boff_k, n, d_ooff_k, s, nby)) != VPT_OK) return st;
-        h_end[k] = ~uint64_t(0);
-        const FuseRequest fuse{d_out, out_cap, d_off_out + a, h_end + k, b->d_chain + k, b->d_chain + k + 1};
-        st = predict_device_impl(p, b, b->d_text, d_boff_k, d_ooff_k, n, nby - n /* boundaries of the chunk, at most */, mb, nullptr, nullptr, s, &fuse);
-        if (st != VPT_OK) return st;
-        VPT_HIP(hipEventRecord(b->chunk_ev[2 * k + 1], s));
-        chunks.push_back({a, n});
+        chunks.push_back({a, n, tb, nby, mb});
     }
-    // ---- collect: as a chunk's kernels finish, its text and offsets leave on the copy-out stream (the next chunk's are still running)
+    // Two schedules.  Default: every chunk's kernels on the workspace's stream, all enqueued up front; the host issues a chunk's copy out
+    // on a third stream when the chunk's event fires.  VPT_TOKENIZE_LANES=2: the chunks alternate over two streams and a chunk's copy out
+    // is enqueued BEHIND its kernels on ITS stream (the runtime then moves it with a copy engine instead of a blit kernel that shares the
+    // CUs with the next chunk's kernels: profiles/r02_g_e2e.txt, r04_e_tokenize_timeline.txt); the host paces: two chunks in flight.
+    const bool lanes = p->knobs.tokenize_lanes >= 2 && !direct;
+    hipStream_t lane_s[2] = {s, lanes ? s_out : s};
     uint64_t at = 0;
     bool out_of_range = false, too_small = false;
-    for (size_t k = 0; k < chunks.size() && !direct; ++k) {
+    auto copy_out = [&](size_t k, hipStream_t on) -> vpt_status {   // after chunk k's event: its text and offsets leave
         VPT_HIP(hipEventSynchronize(b->chunk_ev[2 * k + 1]));
         const uint64_t end = h_end[k];
-        if (end > out_cap || end < at) { out_of_range = true; break; }   // the device found the inputs inconsistent and says so below
-        if (end > text_capacity) { too_small = true; break; }
-        if (end > at) VPT_HIP(hipMemcpyAsync(text_out + at, d_out + at, size_t(end - at), hipMemcpyDeviceToHost, s_out));
-        VPT_HIP(hipMemcpyAsync(text_offsets_out + chunks[k].a, d_off_out + chunks[k].a, 8 * (chunks[k].n + 1), hipMemcpyDeviceToHost, s_out));
+        if (end > out_cap || end < at) { out_of_range = true; return VPT_OK; }   // the device found the inputs inconsistent and says so below
+        if (end > text_capacity) { too_small = true; return VPT_OK; }
+        if (end > at) VPT_HIP(hipMemcpyAsync(text_out + at, d_out + at, size_t(end - at), hipMemcpyDeviceToHost, on));
+        VPT_HIP(hipMemcpyAsync(text_offsets_out + chunks[k].a, d_off_out + chunks[k].a, 8 * (chunks[k].n + 1), hipMemcpyDeviceToHost, on));
         at = end;
+        return VPT_OK;
+    };
+    for (size_t k = 0; k < chunks.size(); ++k) {
+        const Chunk& c = chunks[k];
+        hipStream_t ks = lane_s[k & 1];
+        if (lanes && k >= 2 && !out_of_range && !too_small && (st = copy_out(k - 2, ks)) != VPT_OK) return st;   // in front of this chunk's kernels on its lane
+        uint64_t* d_boff_k = b->d_boff + c.a + k;
+        uint64_t* d_ooff_k = b->d_ooff + c.a + k;   // n + 1 entries per chunk, chunk-relative
+        VPT_HIP(hipStreamWaitEvent(ks, b->chunk_ev[2 * k], 0));
+        if (lanes && k >= 1) VPT_HIP(hipStreamWaitEvent(ks, b->chunk_ev[2 * (k - 1) + 1], 0));   // the chunk before: its text's end, the workspace's scratch
+        if ((st = count_boundaries_impl(p, b, b->d_text, d_boff_k, c.n, d_ooff_k, ks, c.nby)) != VPT_OK) return st;
+        h_end[k] = ~uint64_t(0);
+        const FuseRequest fuse{d_out, out_cap, d_off_out + c.a, h_end + k, b->d_chain + k, b->d_chain + k + 1};
+        st = predict_device_impl(p, b, b->d_text, d_boff_k, d_ooff_k, c.n, c.nby - c.n /* boundaries of the chunk, at most */, c.mb, nullptr, nullptr, ks, &fuse);
+        if (st != VPT_OK) return st;
+        VPT_HIP(hipEventRecord(b->chunk_ev[2 * k + 1], ks));
     }
+    // ---- collect what is still on the device
+    for (size_t k = lanes ? (chunks.size() >= 2 ? chunks.size() - 2 : 0) : 0; k < chunks.size() && !direct && !out_of_range && !too_small; ++k)
+        if ((st = copy_out(k, lanes ? lane_s[k & 1] : s_out)) != VPT_OK) return st;
     // ---- the device's verdict over every chunk
     uint32_t ctrl[2] = {0, 0};
     VPT_HIP(hipMemcpyAsync(ctrl, b->d_ctrl, sizeof(ctrl), hipMemcpyDeviceToHost, s));

@@ -19,16 +19,16 @@ constexpr int kMargin = 8;                       // zeroed slack past the tile f
 // (every distributed model): 1280 / 8, the best of the geometries measured on MI355X (profiles/r02_c5_ab*.jsonl, r03_d_ab_m1.jsonl;
 // LDS-resident caches in front of the char table and the unigram nodes, a dense matrix for the bigram nodes of frequent second
 // chars and a stage-major walk were measured in round 3 and are gone: profiles/r03_d/f/h_ab_*.jsonl).  Wider windows have wider
-// nodes in flight and wider type rows in LDS: 1024 positions at 6 (5 for window 8) workgroups per CU.
+// nodes in flight and wider type rows in LDS: 1024 positions at 6 (5 for window 8) workgroups per CU.  Round 4 measured one more LDS table
+// -- the symbol words of ASCII, U+3000..30FF and U+FF00..FFEF, direct-indexed, in the idle W queues during classify -- 2-3 % SLOWER on
+// every workload (profiles/r04_f_ctab_*.jsonl; the fill and the range tests cost more than the gathers they save) and tiles of 960 /
+// 640 positions (more rounds on a 100 K-sentence batch) 2 % / 13 % slower: out again.
 // (-D overrides: A/B builds of tools/build_variants.sh.)
 #ifndef VPT_FAST_CAP
 #define VPT_FAST_CAP 1280
 #endif
 #ifndef VPT_FAST_WG
 #define VPT_FAST_WG 8
-#endif
-#ifndef VPT_FAST_CTAB
-#define VPT_FAST_CTAB 0    // experiment (round 4): char -> symbol words of ASCII, U+3000..30FF and U+FF00..FFEF in LDS (kernels_fast.hip, classify)
 #endif
 #ifndef VPT_FAST_CAP_WIDE
 #define VPT_FAST_CAP_WIDE 1024

@@ -643,8 +643,10 @@ __global__ __launch_bounds__(kEmitThreads) void count_chars_kernel(const uint8_t
         offsets[s0 + tid + 1] = chars > 0 ? chars - 1 : 0;
     }
     if (err) atomicOr(status, err);
-    longest = wave_max(longest);
-    if (lane == 0 && longest) atomicMax(max_chars, longest);
+    if (max_chars) {   // (optional output; the caller clears it)
+        longest = wave_max(longest);
+        if (lane == 0 && longest) atomicMax(max_chars, longest);
+    }
 }
 
 }  // namespace

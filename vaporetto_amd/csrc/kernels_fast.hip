@@ -469,12 +469,6 @@ __global__ __launch_bounds__(kThreads, fast_wg(WL)) void score_tiles_fast_kernel
     if (trow_lds) {
         for (uint32_t i = tid; i < uint32_t(kTrowCount * G::kTrowQ); i += kThreads) M.trow[i] = ld16(P.pk.base, P.pk.off_trow + (i << 4));
     }
-#if VPT_FAST_CTAB
-    // EXPERIMENT: the symbol words of the chars most text is made of -- ASCII, U+3000..30FF (CJK punctuation, hiragana, katakana), U+FF00..FFEF
-    // (fullwidth forms) -- in LDS behind the bitmap (the W queues are idle until phase B): 624 words, read from the char table with the text
-    uint32_t* const ctab = bitmap + 256;
-    for (uint32_t i = tid; i < 624u; i += kThreads) ctab[i] = P.cid[i < 128u ? i : i < 384u ? 0x3000u + (i - 128u) : 0xFF00u + (i - 384u)];
-#endif
     __syncthreads();
     tmark = phase_mark(prof, 0, tmark);   // zeroing, staging, table loads
     for (uint32_t j = tid; j < nsent; j += kThreads) {
@@ -563,12 +557,7 @@ __global__ __launch_bounds__(kThreads, fast_wg(WL)) void score_tiles_fast_kernel
             const uint32_t cp = xs[k] & 0x1FFFFFu;
             // id of the char it is scored as | CharacterType << 16 | linebreak << 29: one word of a 256 KB table (plain, or -- with
             // VPT_FLAG_KYTEA_FULLWIDTH -- the one that looks through KyteaFullwidthFilter); a separator asks for nothing
-#if VPT_FAST_CTAB
-            const uint32_t ti = cp < 0x80u ? cp : (cp - 0x3000u) < 0x100u ? 128u + (cp - 0x3000u) : (cp - 0xFF00u) < 0xF0u ? 384u + (cp - 0xFF00u) : 0xFFFFFFFFu;
-            if (cp != 0) { if (ti != 0xFFFFFFFFu) info[k] = ctab[ti]; else info[k] = P.cid[cp < 0x10000u ? cp : 0u]; }
-#else
             if (cp != 0) info[k] = P.cid[cp < 0x10000u ? cp : 0u];
-#endif
         }
 #pragma unroll
         for (int k = 0; k < kPerThread; ++k) {
