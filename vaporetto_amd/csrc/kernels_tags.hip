@@ -52,6 +52,7 @@
 
 #include "device_common.h"
 #include "kernels.hpp"
+#include <algorithm>
 #include <cstdlib>
 
 namespace vpt {
@@ -73,49 +74,104 @@ __device__ __forceinline__ uint32_t lanes_below(uint64_t mask, int lane) {
 }
 
 // `total_chars` = chars the caller's offsets promise for the whole batch (the size of `cps`): offsets that do not match
-// the text raise kErrBadOffsets instead of writing outside it.  A lane takes FOUR text bytes per step (one dword, and the
-// next one for the tail of a char that starts in its own), counts its lead bytes, and a wave prefix sum places its chars.
+// the text raise kErrBadOffsets instead of writing outside it.
+//
+// FLAT over the text (round 4; a wave per sentence -- its offsets, then its text, then the char table: three dependent trips per
+// sentence -- took 1.23 ms on configs[4], longer than fill_tags itself): a workgroup takes `per_block` consecutive sentences and
+// streams their bytes in pieces of 4 KB, sixteen bytes per thread; a block-wide prefix sum over the threads' lead counts numbers the
+// chars -- char number c of the run goes to flat position (ooff[s0] + s0) + c, which IS ooff[i] + i + g for char g of sentence i when
+// the offsets match the text, and that is checked per sentence (the same two LDS reads per sentence as count_chars_kernel).
+constexpr uint32_t kDecodePiece = kTagThreads * 16;
 __global__ __launch_bounds__(kTagThreads) void decode_chars_kernel(const uint8_t* __restrict__ text, const uint64_t* __restrict__ boff,
                                                                    const uint64_t* __restrict__ ooff, uint64_t n_sent, uint64_t total_chars,
                                                                    const uint32_t* __restrict__ cinfo, uint32_t* __restrict__ cps,
-                                                                   uint8_t* __restrict__ types, uint32_t* __restrict__ status) {
-    const int lane = threadIdx.x & 63;
-    const uint64_t wave = uint64_t(blockIdx.x) * kTagWaves + (threadIdx.x >> 6);
-    const uint64_t n_waves = uint64_t(gridDim.x) * kTagWaves;
-    for (uint64_t i = wave; i < n_sent; i += n_waves) {
-        const uint64_t b0 = boff[i], b1 = boff[i + 1];
-        const uint64_t o0 = ooff[i], o1 = ooff[i + 1];
-        const uint64_t g = o0 + i;  // first char of the sentence in the flat char array
-        const bool sane = o1 >= o0 && b1 >= b0 && o1 + i + 1 <= total_chars;
-        const uint64_t want = sane ? o1 - o0 + 1 : 0;   // chars of this sentence
-        uint64_t seen = 0;
-        for (uint64_t pos = b0; sane && pos < b1; pos += 256) {
-            const uint64_t at = pos + 4 * uint64_t(lane);
-            // eight bytes from `at` (the lane's own four and the rest of a char that starts in them), never reading past the aligned
-            // word that holds the sentence's last byte (the text may end where its allocation does)
-            const uint64_t x = uint64_t(load4(text, at, b1)) | (uint64_t(load4(text, at + 4, b1)) << 32);
-            const uint32_t mine = at < b1 ? uint32_t(b1 - at < 4 ? b1 - at : 4) : 0u;          // bytes of this lane's own dword inside the sentence
-            const uint32_t lm = lead_nibble(uint32_t(x)) & ((1u << mine) - 1u);              // which of them start a char
-            const uint32_t incl = wave_inclusive_scan(uint32_t(__popc(lm)));
-            const uint32_t total = uint32_t(__builtin_amdgcn_readlane(int(incl), 63));
-            uint64_t idx = seen + incl - uint32_t(__popc(lm));
-#pragma unroll
-            for (uint32_t k = 0; k < 4; ++k) {
-                if ((lm >> k) & 1u) {
-                    if (idx < want) {
-                        const uint32_t cp = utf8_scalar(uint32_t(x >> (8 * k)));
-                        const uint32_t info = cp < 0x10000u ? cinfo[cp] : 0u;   // the scored char | its CharacterType << 16 (BMP only)
-                        const uint32_t ty = cp < 0x10000u ? info >> 16 : char_type(cp);
-                        if (cps) cps[g + idx] = (cp < 0x10000u ? info & 0xFFFFu : cp) | (ty << 24);
-                        if (types) types[g + idx] = uint8_t(ty);   // Sentence::char_types (sentence.rs:1016)
-                    }
-                    ++idx;
-                }
-            }
-            seen += total;
-        }
-        if (lane == 0 && (!sane || seen != want)) atomicOr(status, kErrBadOffsets);   // an empty sentence too (want >= 1)
+                                                                   uint8_t* __restrict__ types, uint32_t* __restrict__ status, uint32_t per_block) {
+    __shared__ uint16_t masks[kTagThreads];   // lead mask of every 16-byte chunk of the piece
+    __shared__ uint32_t pfx[kTagThreads];     // leads of the piece in front of the chunk
+    __shared__ uint32_t wtot[kTagWaves];
+    const uint32_t tid = threadIdx.x, lane = tid & 63, wave = wave_uniform(tid >> 6);
+    const uint64_t s0 = uint64_t(blockIdx.x) * per_block;
+    if (s0 >= n_sent) return;
+    const uint32_t ns = uint32_t(n_sent - s0 < per_block ? n_sent - s0 : per_block);
+    const uint64_t B0 = boff[s0], B1 = boff[s0 + ns];
+    const uint64_t G0 = ooff[s0] + s0;        // flat position of the run's first char
+    uint64_t my_b = 0, my_e = 0, my_want = 0;
+    const bool mine = tid < ns;
+    bool sane = false;
+    if (mine) {
+        my_b = boff[s0 + tid]; my_e = boff[s0 + tid + 1];
+        const uint64_t o0 = ooff[s0 + tid], o1 = ooff[s0 + tid + 1];
+        // the sentence sits where the run's char count puts it, and the whole of it inside the batch's arrays
+        sane = my_e > my_b && my_b >= B0 && my_e <= B1 && o1 >= o0 && o1 + (s0 + tid) + 1 <= total_chars;
+        my_want = sane ? o1 - o0 + 1 : 0;
     }
+    uint32_t err = (mine && !sane) ? kErrBadOffsets : 0u;
+    if (B1 <= B0 || G0 > total_chars) { if (tid == 0) atomicOr(status, kErrBadOffsets); return; }
+    uint64_t p_start = 0, p_end = 0, carry = 0;
+    const uintptr_t t_lo = reinterpret_cast<uintptr_t>(text) + B0, t_hi = reinterpret_cast<uintptr_t>(text) + B1;
+    for (uintptr_t piece = t_lo & ~uintptr_t(15); piece < t_hi; piece += kDecodePiece) {
+        const uintptr_t a = piece + 16u * tid;
+        uint32_t d[5] = {0, 0, 0, 0, 0};
+        if (a + 16 > t_lo && a < t_hi) {
+            const uint4 v = *reinterpret_cast<const uint4*>(a);
+            d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+            if (a + 16 < t_hi) d[4] = *reinterpret_cast<const uint32_t*>(a + 16);   // the tail of a char that starts in the chunk's last bytes
+        }
+        const uint32_t lo = t_lo > a ? (t_lo - a < 16 ? uint32_t(t_lo - a) : 16u) : 0u;
+        const uint32_t hi = t_hi > a ? (t_hi - a < 16 ? uint32_t(t_hi - a) : 16u) : 0u;
+        const uint32_t vm = hi > lo ? ((1u << hi) - 1u) & ~((1u << lo) - 1u) : 0u;
+        const uint32_t lm = (lead_nibble(d[0]) | (lead_nibble(d[1]) << 4) | (lead_nibble(d[2]) << 8) | (lead_nibble(d[3]) << 12)) & vm;
+        const uint32_t cnt = uint32_t(__popc(lm));
+        masks[tid] = uint16_t(lm);
+        const uint32_t incl = wave_inclusive_scan(cnt);
+        if (lane == 63) wtot[wave] = incl;
+        __syncthreads();
+        uint32_t woff = 0, total = 0;
+#pragma unroll
+        for (uint32_t k = 0; k < uint32_t(kTagWaves); ++k) {
+            const uint32_t u = wtot[k];
+            if (k < wave) woff += u;
+            total += u;
+        }
+        const uint32_t excl = woff + incl - cnt;
+        pfx[tid] = excl;
+        __syncthreads();
+        // ---- this chunk's chars: decoded from registers, a dword of the chunk at a time
+        uint64_t dest = G0 + carry + excl;
+#pragma unroll
+        for (uint32_t q = 0; q < 4; ++q) {
+            uint32_t m = (lm >> (4 * q)) & 15u;
+            while (m) {
+                const uint32_t k = uint32_t(__builtin_ctz(m));
+                m &= m - 1u;
+                const uint32_t w = __builtin_amdgcn_alignbyte(d[q + 1], d[q], k);
+                const uint32_t cp = utf8_scalar(w);
+                const uint32_t info = cp < 0x10000u ? cinfo[cp] : 0u;   // the scored char | its CharacterType << 16 (BMP only)
+                const uint32_t ty = cp < 0x10000u ? info >> 16 : char_type(cp);
+                if (dest < total_chars) {
+                    if (cps) cps[dest] = (cp < 0x10000u ? info & 0xFFFFu : cp) | (ty << 24);
+                    if (types) types[dest] = uint8_t(ty);   // Sentence::char_types (sentence.rs:1016)
+                }
+                ++dest;
+            }
+        }
+        // ---- the sentences' char counts against their offsets
+        auto before = [&](uintptr_t x) -> uint32_t {   // leads of the piece in front of byte x (piece <= x <= piece + kDecodePiece)
+            const uint32_t r = uint32_t(x - piece);
+            if (r >= kDecodePiece) return total;
+            return pfx[r >> 4] + uint32_t(__popc(uint32_t(masks[r >> 4]) & ((1u << (r & 15u)) - 1u)));
+        };
+        if (sane) {
+            const uintptr_t xs = reinterpret_cast<uintptr_t>(text) + my_b, xe = reinterpret_cast<uintptr_t>(text) + my_e;
+            if (xs >= piece && xs - piece < kDecodePiece) p_start = carry + before(xs);
+            if (xe > piece && xe - piece <= kDecodePiece) p_end = carry + before(xe);
+        }
+        carry += total;
+        __syncthreads();   // the next piece rewrites masks / pfx / wtot
+    }
+    // a sentence holds the chars its offsets say, and starts at the run's char its offsets say (an empty sentence too: want >= 1)
+    if (sane && (p_end - p_start != my_want || G0 + p_start != ooff[s0 + tid] + (s0 + tid))) err |= kErrBadOffsets;
+    if (err) atomicOr(status, err);
 }
 
 constexpr uint32_t kCharMask = 0x1FFFFFu;   // a cps word: scored scalar value | CharacterType << 24
@@ -800,10 +856,12 @@ __global__ __launch_bounds__(kTagThreads, kSplit ? kTagFrontOcc : VPT_TAG_OCC) v
 
 hipError_t launch_decode_chars(const uint8_t* text, const uint64_t* boff, const uint64_t* ooff, uint64_t n_sent, uint64_t total_chars,
                                const uint32_t* cinfo, uint32_t* cps, uint8_t* types, uint32_t* status, hipStream_t stream) {
-    const uint64_t want = (n_sent + kTagWaves - 1) / kTagWaves;
-    const uint32_t blocks = uint32_t(want < 1 ? 1 : want > 65536 ? 65536 : want);
-    hipLaunchKernelGGL(decode_chars_kernel, dim3(blocks), dim3(kTagThreads), 0, stream, text, boff, ooff, n_sent, total_chars, cinfo, cps,
-                       types, status);
+    // sentences per workgroup: about 16 K chars (4 pieces of CJK text and more; a char is at least a byte, so the chars bound the bytes from
+    // below), at most one per thread
+    const uint64_t per = std::min<uint64_t>(std::max<uint64_t>((uint64_t(16384) * n_sent + total_chars / 2) / std::max<uint64_t>(total_chars, 1), 1), kTagThreads);
+    const uint64_t blocks = (n_sent + per - 1) / per;
+    hipLaunchKernelGGL(decode_chars_kernel, dim3(uint32_t(blocks)), dim3(kTagThreads), 0, stream, text, boff, ooff, n_sent, total_chars, cinfo, cps,
+                       types, status, uint32_t(per));
     return hipGetLastError();
 }
 
