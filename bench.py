@@ -516,7 +516,7 @@ class Runner:
             dt = median_time(lambda: pred.tokenize_packed(keep[0].array, boff, text_out=tk[0].array, offsets_out=tk[1].array), k)
             e2e["tokenize"] = {"ms_per_batch": 1e3 * dt, "chars_per_s": (nb + S) / dt, "h2d_GBps": (nbytes + 8 * (S + 1)) / dt / 1e9,
                                "d2h_GBps": (len(tok_text) + 8 * (S + 1)) / dt / 1e9, "out_bytes": int(len(tok_text)),
-                               "path": "vpt_tokenize_batch: copy in, count chars, score, write tokens, copy out on one stream (not chunked)"}
+                               "path": "vpt_tokenize_batch: chunks of a sixth of the batch; per chunk copy in, char count, tile search, ONE scoring launch that writes the tokenized text (chunks chain into one output), copy out when the chunk's event fires"}
             del tk
             # ten of these batches as one call: what the pipeline does once its start-up no longer counts
             rep = 10
