@@ -818,6 +818,29 @@ def test_fill_tags_as_two_launches(queue, monkeypatch):
     test_write_tagged_text_on_device()
 
 
+@pytest.mark.parametrize("wc,wt", [(3, 6), (5, 5), (8, 8), (4, 2), (2, 7)])
+def test_tag_models_under_wide_windows(wc, wt):
+    """Tag n-grams end up to `window` chars past their token (tag_trainer.rs:79-103).  The fast pass keeps p - 11 .. p + 4 of a token's context:
+    a model with a TYPE tag n-gram further out (type windows above 4) must take the whole-wave routine -- round 4's fuzz over every window found
+    such models tagged from a window that did not hold the n-gram.  Boundaries, tags and tag scores against the oracle."""
+    for seed in range(4):
+        m = randmodel.rand_model(7300 + 10 * wc + wt + 100 * seed, alphabet=["kana", "tiny"][seed % 2], wc=wc, wt=wt, max_n=4, n_char=60, n_dict=60, n_type=40,
+                                 n_tag_models=12, max_word=4)
+        raw = encode_model(m)
+        pred = api.Predictor(api.Model.read_slice(raw)[0], True)
+        orc = cbind.OraclePredictor(raw, True)
+        texts = randmodel.rand_sentences(seed, m, 150, alphabet=["kana", "tiny"][seed % 2], max_len=40)
+        utf8, boff = api.pack_texts([t.encode("utf-8") for t in texts])
+        scores, labels, ooff = pred.predict_packed(utf8, boff)
+        o_scores, o_labels, _, _ = orc.predict_batch(utf8, boff)
+        assert np.array_equal(scores, o_scores) and np.array_equal(labels, o_labels)
+        got = pred.fill_tags_packed(utf8, boff, ooff, labels)
+        for i, t in enumerate(texts):
+            a, b = int(ooff[i]), int(ooff[i + 1])
+            want, _ = orc.predict_tags(t, labels=labels[a:b])
+            assert np.array_equal(got[a + i:a + i + len(t)], want), (seed, t)
+
+
 def test_tag_models_inside_and_outside_the_record_form():
     """The tag kernel's fast path checks whole n-grams from 32-byte records (<= 12 BMP symbols, <= 16 scores per model);
     models outside that form -- an n-gram of 14 chars, a non-BMP n-gram, 24 scores -- take the whole-wave routine.  Both kinds

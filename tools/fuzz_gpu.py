@@ -28,11 +28,16 @@ while time.time() < t_end:
     seed += 1
     rng = random.Random(seed)
     alpha = [chr(c) for c in range(0x3041, 0x3041 + rng.choice([3, 6, 12, 30]))] + rng.sample(list("漢字AZ09az-.、。ｱ￾𠮷 /\\"), rng.randint(0, 6))
-    m = randmodel.rand_model(9000 + seed, alphabet=alpha, wc=rng.choice([3, 3, 3, 2, 4]), wt=rng.choice([1, 2, 3, 4]),
-                             n_char=rng.choice([20, 200, 1500]), n_dict=rng.choice([0, 30, 400, 3000]), n_type=rng.choice([0, 10, 80]),
+    # windows: what the distributed models have (3) half the time, anything up to 8 otherwise (round 4: every window on the packed tables)
+    m = randmodel.rand_model(9000 + seed, alphabet=alpha, wc=rng.choice([3, 3, 3, 3, 2, 1, 4, 5, 6, 7, 8]), wt=rng.choice([1, 2, 3, 3, 3, 4, 5, 6, 8]),
+                             max_n=rng.choice([3, 3, 4, 6]), n_char=rng.choice([20, 200, 1500]), n_dict=rng.choice([0, 30, 400, 3000]), n_type=rng.choice([0, 10, 80]),
                              max_word=rng.choice([2, 5, 9, 15]), big=(seed % 7 == 0), n_tag_models=rng.choice([0, 0, 10]))
     raw = encode_model(m)
     tags = bool(m.tag_models) and seed % 2 == 0
+    if seed % 3 == 1:   # vpt_tokenize_batch in many chunks (the knob is read when the predictor is made)
+        os.environ["VPT_TOKENIZE_CHUNK_BYTES"] = str(rng.choice([300, 2000, 20000]))
+    else:
+        os.environ.pop("VPT_TOKENIZE_CHUNK_BYTES", None)
     pred = api.Predictor(api.Model.read_slice(raw)[0], tags)
     orc = cbind.OraclePredictor(raw, tags)
     texts = randmodel.rand_sentences(seed, m, rng.choice([50, 800]), alphabet=alpha, max_len=rng.choice([5, 60, 400]))
@@ -82,6 +87,27 @@ while time.time() < t_end:
         if pred.tokenize(sub, fullwidth=fw) != pred.write_tokenized_batch(sents):
             print("MISMATCH tokenize: seed", seed)
             sys.exit(1)
+    if not fw and seed % 2 == 1:   # the writer fused into the scoring kernel, the WHOLE batch against the oracle's writer (round 4):
+        o_text, o_toff = orc.write_tokenized_batch(n_utf8, n_boff, o_ooff, o_labels, None, None)
+        t_text, t_toff = pred.tokenize_packed(utf8, boff)       # ... through vpt_tokenize_batch (chunks chained into one text)
+        if not (np.array_equal(t_toff, o_toff) and np.array_equal(t_text, o_text)):
+            print("MISMATCH tokenize (whole batch): seed", seed, "info", pred.info())
+            sys.exit(1)
+        if not os.environ.get("VPT_FUZZ_EMULATED"):               # ... and through the device entry point
+            import torch
+            S, nb = len(texts), int(ooff[-1])
+            d = [torch.from_numpy(np.concatenate([utf8, np.zeros(32, np.uint8)])).cuda(), torch.from_numpy(boff.astype(np.int64)).cuda(), torch.from_numpy(ooff.astype(np.int64)).cuda()]
+            cap = 3 * len(utf8) + 16
+            d_out, d_toff = torch.zeros(cap + 16, dtype=torch.uint8, device="cuda"), torch.zeros(S + 1, dtype=torch.int64, device="cuda")
+            d_sc, d_lb = torch.zeros(nb + 1, dtype=torch.int32, device="cuda"), torch.zeros(nb + 1, dtype=torch.uint8, device="cuda")
+            batch = api.DeviceBatch(pred)
+            batch.predict_write(d[0].data_ptr(), d[1].data_ptr(), d[2].data_ptr(), S, nb, int(np.max(np.diff(boff.astype(np.int64)))), d_sc.data_ptr(), d_lb.data_ptr(),
+                                d_out.data_ptr(), cap, d_toff.data_ptr(), torch.cuda.current_stream().cuda_stream)
+            batch.sync()
+            g_toff = d_toff.cpu().numpy().astype(np.uint64)
+            if not (np.array_equal(g_toff, o_toff) and np.array_equal(d_out[:int(o_toff[-1])].cpu().numpy(), o_text) and np.array_equal(d_sc[:nb].cpu().numpy(), o_scores)):
+                print("MISMATCH predict_write: seed", seed, "info", pred.info())
+                sys.exit(1)
     n_models += 1
     n_sent += len(texts)
 print("fuzz ok: %d models (seeds up to %d), %d sentences, no mismatch" % (n_models, seed, n_sent))

@@ -178,6 +178,7 @@ constexpr uint32_t kCharMask = 0x1FFFFFu;   // a cps word: scored scalar value |
 constexpr int kRing = 256;                   // the sentence's cps words in LDS: char q at txt[q & 255]: the last 192 (one launch) / 128 (front-end launch: steps of two half-steps) chars in front of a step and the step itself
 constexpr int kTagPass = 16;                 // queued tokens a pass takes
 constexpr int kCtx = 16, kCtxBack = 11;      // the text a queued token's n-grams can touch: chars p - 11 .. p + 4 around its last char p
+static_assert(kCtx - 1 - kCtxBack == int(kTagFastMaxRel), "tables.cpp keeps models with a tag n-gram further past the token off the fast path");
 #ifdef VPT_TAG_NO_PASS
 constexpr int kTagCand = 32;                 // (the experiment runs 8 workgroups per CU)
 #else

@@ -793,7 +793,9 @@ HostTagTables build_tag_tables(const ModelData& m, bool use_char, bool use_type)
                 if (kind == 0) {
                     if (w.rel_position > 3 || d.ngram.empty()) rel_ok = false;
                     else { ++rel_count[w.rel_position]; rel_filter[w.rel_position] |= uint64_t(1) << packed_filter_bit(d.ngram.back()); }
-                }
+                } else if (w.rel_position > kTagFastMaxRel) {
+                    rel_ok = false;   // a type tag n-gram that ends further past the token than the pass's context window holds (type windows above 4:
+                }                     // found by the round-4 fuzz over every window) -- the whole-wave routine scores such a model
                 t.weights.insert(t.weights.end(), w.weights.begin(), w.weights.end());
             }
             *count = uint32_t(t.ngrams.size() / 4) - *first;

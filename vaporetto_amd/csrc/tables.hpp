@@ -82,6 +82,7 @@ struct HostTagTables {
 constexpr uint32_t kTagMaxZ = 1024;   // tag scores per token the kernel keeps in LDS
 constexpr uint32_t kTagFastZ = 16;    // ... per token on the fast path
 constexpr uint32_t kTagFastSyms = 12; // symbols of an n-gram a 32-byte record holds
+constexpr uint32_t kTagFastMaxRel = 4; // chars past a token's last one that the fast path's context window holds (kernels_tags.hip: kCtx - 1 - kCtxBack)
 
 enum TypeKind : int { kTypeNone = 0, kTypeWindowTable = 1, kTypePatternTable = 2 };
 
