@@ -10,7 +10,7 @@ REPO=$(pwd)
 OUT=$REPO/gpurun_out/prof_$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
-CMD="python $REPO/bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-e2e --quick $*"
+CMD="python $REPO/bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-e2e --no-emit --quick $*"   # (--no-emit: no writer and no fused-writer instance of the scoring kernel, whose launches would be averaged in)
 cd /tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- $CMD > $OUT/trace.log 2>&1
 DEFAULT_GROUPS="TCC_EA0_RDREQ_128B_sum TCC_EA0_RDREQ_64B_sum TCC_EA0_RDREQ_32B_sum|WRITE_SIZE|TCP_TCC_READ_REQ_sum TCP_TCC_READ_REQ_LATENCY_sum TCP_TOTAL_ACCESSES_sum TCP_PENDING_STALL_CYCLES_sum|TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum|SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_SALU|SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_SMEM SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_LDS GRBM_GUI_ACTIVE"
@@ -31,7 +31,7 @@ def rows(pat):
             yield from csv.DictReader(fh)
 agg=collections.defaultdict(lambda: collections.defaultdict(list))
 for r in rows("pmc_*/**/*counter_collection.csv"):
-    agg[r["Kernel_Name"][:60]][r["Counter_Name"]].append(float(r["Counter_Value"]))
+    agg[r["Kernel_Name"][:96]][r["Counter_Name"]].append(float(r["Counter_Value"]))
 with open(os.path.join(out,"summary.txt"),"w") as w:
     for f in glob.glob(os.path.join(out,"trace","**","*kernel_stats.csv"), recursive=True):
         w.write("== kernel stats (%s)\n" % os.path.basename(f)); w.write(open(f).read()+"\n")
@@ -39,7 +39,7 @@ with open(os.path.join(out,"summary.txt"),"w") as w:
     for k,v in agg.items():
         if not any(x in k for x in ("score", "tag_tokens", "decode_chars", "emit", "count")): continue
         for c,vals in sorted(v.items()):
-            w.write("%-62s %-34s n=%d avg=%.1f\n" % (k,c,len(vals),sum(vals)/len(vals)))
+            w.write("%-98s %-34s n=%d avg=%.1f\n" % (k,c,len(vals),sum(vals)/len(vals)))
     if os.path.exists(os.path.join(out,"failed.txt")):
         w.write("== failed passes\n"+open(os.path.join(out,"failed.txt")).read())
 # traffic entry for the dominant kernel
