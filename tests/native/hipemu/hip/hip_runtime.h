@@ -72,6 +72,7 @@ hipError_t hipPointerGetAttributes(hipPointerAttribute_t* attr, const void* ptr)
 hipError_t hipHostGetDevicePointer(void** dptr, void* hptr, unsigned flags);
 hipError_t hipStreamWaitEvent(hipStream_t s, hipEvent_t e, unsigned flags);
 hipError_t hipEventSynchronize(hipEvent_t e);
+hipError_t hipEventQuery(hipEvent_t e);
 hipError_t hipEventCreateWithFlags(hipEvent_t* e, unsigned flags);
 hipError_t hipMemset(void* dst, int value, size_t bytes);
 hipError_t hipMemsetAsync(void* dst, int value, size_t bytes, hipStream_t s);

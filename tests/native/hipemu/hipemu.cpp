@@ -305,6 +305,7 @@ hipError_t hipPointerGetAttributes(hipPointerAttribute_t* attr, const void* ptr)
 hipError_t hipHostGetDevicePointer(void** dptr, void* hptr, unsigned) { *dptr = hptr; return hipSuccess; }
 hipError_t hipStreamWaitEvent(hipStream_t, hipEvent_t, unsigned) { return hipSuccess; }
 hipError_t hipEventSynchronize(hipEvent_t) { return hipSuccess; }
+hipError_t hipEventQuery(hipEvent_t) { return hipSuccess; }   // (work is done when it is enqueued)
 hipError_t hipEventCreateWithFlags(hipEvent_t* e, unsigned) { *e = new hipemu_event(); return hipSuccess; }
 hipError_t hipMemset(void* dst, int value, size_t bytes) { std::memset(dst, value, bytes); return hipSuccess; }
 hipError_t hipMemsetAsync(void* dst, int value, size_t bytes, hipStream_t) { std::memset(dst, value, bytes); return hipSuccess; }

@@ -1011,8 +1011,12 @@ def test_predict_and_write_in_one_launch(case, monkeypatch):
     lens = list(rng.integers(1, 60, 400)) + [1, 1, 1, 2, 63, 64, 65] + [1] * 40      # (at most 4 * 65 bytes: whole-sentence tiles)
     texts = ["".join(rng.choice(alphabet, size=int(n))) for n in lens]
     texts += randmodel.rand_sentences(5, m, 120, alphabet="mixed", max_len=50)
+    # tiles of more than 4 KB of text (4-byte chars): more 16-byte chunks than the block has threads, the writer numbers the chars again
+    wide = [c for c in alphabet if len(c.encode("utf-8")) == 4] + ["/", "あ"]
+    texts += ["".join(rng.choice(wide, size=60)) for _ in range(60)]
     for long_ones in (False, True):
-        batch_texts = texts + (["".join(rng.choice(alphabet, size=int(n))) for n in (300, 319, 320, 321, 1500, 4000, 2, 2600)] if long_ones else [])
+        batch_texts = texts + (["".join(rng.choice(alphabet, size=int(n))) for n in (300, 319, 320, 321, 1500, 4000, 2, 2600)]
+                               + ["".join(rng.choice(wide, size=3000))] if long_ones else [])
         for want_scores in (True, False):
             scores, labels, lines, plan, (utf8, boff, ooff) = _fused_write(pred, batch_texts, want_scores=want_scores)
             o_scores, o_labels, _, _ = orc.predict_batch(utf8, boff)
@@ -1042,15 +1046,18 @@ def test_predict_and_write_in_one_launch(case, monkeypatch):
         _fused_write(pred, texts, cap=100)
 
 
-@pytest.mark.parametrize("chunk_bytes", ["", "900", "20000", "20000:no-prefix", "direct", "900:direct", "20000:direct:no-prefix", "lanes", "900:lanes", "20000:lanes"])
+@pytest.mark.parametrize("chunk_bytes", ["", "900", "20000", "20000:no-prefix", "direct", "900:direct", "20000:direct:no-prefix", "serial", "900:serial", "20000:serial",
+                                         "prep", "900:prep", "20000:prep", "20000:serial:no-prefix", "900:lanes"])
 def test_tokenize_batch_into_pinned_buffers(chunk_bytes, monkeypatch):
     """vpt_tokenize_batch without tags: the scoring kernel's tiles write the tokenized text themselves, chunk after chunk into one contiguous
-    text (the chunks hand the position on through device words), copied out chunk by chunk while the next one is scored; with
+    text (the chunks hand the position on through device words), copied out chunk by chunk while the next one is scored and the one after
+    it has its chars counted and its tiles found on another stream; with
     VPT_TOKENIZE_DIRECT into caller buffers in PINNED memory (vpt_host_alloc) the kernels write it over PCIe themselves -- no copy out.
     Too small a buffer is an error either way."""
-    if "lanes" in chunk_bytes:    # the chunks alternate over two streams, copies out behind their kernels
-        monkeypatch.setenv("VPT_TOKENIZE_LANES", "2")
-        chunk_bytes = chunk_bytes.replace(":lanes", "").replace("lanes", "")
+    for name, schedule in (("serial", "0"), ("prep", "1"), ("lanes", "2")):   # the chunks' texts chained on the device (default: two independent lanes, placed by the copies out)
+        if name in chunk_bytes:
+            monkeypatch.setenv("VPT_TOKENIZE_SCHEDULE", schedule)
+            chunk_bytes = chunk_bytes.replace(":" + name, "").replace(name, "")
     if "direct" in chunk_bytes:   # the kernels write into the pinned caller buffers themselves
         monkeypatch.setenv("VPT_TOKENIZE_DIRECT", "1")
         chunk_bytes = chunk_bytes.replace(":direct", "").replace("direct", "")

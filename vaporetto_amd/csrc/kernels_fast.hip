@@ -482,6 +482,7 @@ __global__ __launch_bounds__(kThreads, fast_wg(WL)) void score_tiles_fast_kernel
     __syncthreads();
     tmark = phase_mark(prof, 1, tmark);   // sentence starts
     uint32_t base_leads = 0, base_starts = 0;
+    uint32_t keep_masks = 0, keep_idx = 0;   // (fused writer) this thread's first chunk: lead | sentence-start masks, char index | sentence + 1 in front of it
     uint32_t min_lead = 0xFFu;     // over this thread's chars: the smallest lead byte (a NUL char is the byte 0; a cut tile's last staged
                                    // char may miss its continuation bytes, so the decoded value is not what is looked at)
     int32_t max_p = -1;            // ... and the last flat position (a char past the tile)
@@ -514,6 +515,7 @@ __global__ __launch_bounds__(kThreads, fast_wg(WL)) void score_tiles_fast_kernel
         const int32_t sib = sib0 + int32_t(base_starts + (excl >> 16));   // sentence of a char = sib + starts up to it in this chunk
         base_leads += total & 0xFFFFu;
         base_starts += total >> 16;
+        if (EMIT && c0 == 0) { keep_masks = lm | (sm << 16); keep_idx = ci | (uint32_t(sib + 1) << 16); }   // phase D numbers the same chars again
         __syncthreads();   // wtot is rewritten by the next pass
         uint32_t m = lm;
         int32_t fb = c_off + int32_t(ci) + int32_t(kPad) * sib;   // flat = c_off + char index + kPad * sentence
@@ -824,8 +826,8 @@ __global__ __launch_bounds__(kThreads, fast_wg(WL)) void score_tiles_fast_kernel
     // every byte of theirs, a '\' in front of ' ', '\' and '/', and a ' ' behind a char whose boundary is a WordBoundary -- that is,
     // in front of the lead byte of the char at p + 1 for an own boundary p, so that a tile's output depends on nothing another tile
     // computes.  The output of the batch is the tiles' outputs one after the other; a sentence's offset is the output position of its
-    // first byte.  Worked in BYTE space like phase A: the text is staged again (into the symbol array, which is dead), the chunk scan
-    // numbers the chars again, every thread turns its 16 bytes into at most 48 and a block-wide prefix sum places them; the bytes
+    // first byte.  Worked in BYTE space like phase A: every thread holds its 16 bytes of the text again (asked for before phase C) and the
+    // numbers phase A's chunk scan gave them, turns them into at most 48 bytes, and a block-wide prefix sum places them; the bytes
     // are assembled in LDS (the score array and the queues: dead) while wave 0 looks back over the earlier tiles' sizes for the
     // tile's position, and leave as aligned 16-byte stores.
     if (EMIT) {
@@ -839,19 +841,23 @@ __global__ __launch_bounds__(kThreads, fast_wg(WL)) void score_tiles_fast_kernel
         static_assert(offsetof(FastLdsT<WL>, queue) == offsetof(FastLdsT<WL>, score) + sizeof(int32_t) * kSymSlots &&
                       offsetof(FastLdsT<WL>, mqueue) == offsetof(FastLdsT<WL>, queue) + sizeof(uint2) * kWavesF * kQCap, "the assembly area is one piece");
         __syncthreads();   // the symbols and scores have been read, the labels written
+        const bool one_round = nchunks <= uint32_t(kThreads);   // (block-uniform) the usual tile: a chunk per thread at most, its scan kept from phase A
+        if (tid == 0) { ew[0] = 0xFFFFFFFFu; ew[1] = 0xFFFFFFFFu; }
+        if (!one_round) {   // (more than 4 KB of text: 1- and 2-byte chars) the text is staged again, the sentence starts marked again
 #pragma unroll
-        for (int r = 0; r < 2; ++r) {
-            const uint32_t c = uint32_t(tid) + uint32_t(r) * kThreads;
-            if (c < nchunks) reinterpret_cast<uint4*>(raw2)[c] = etx[r];
-        }
-        for (uint32_t i = tid; i < ((nbytes_al + 31) >> 5) + 1; i += kThreads) bm2[i] = 0;
-        if (tid == 0) { raw2[nchunks * 4] = 0; ew[0] = 0xFFFFFFFFu; ew[1] = 0xFFFFFFFFu; }
-        __syncthreads();
-        for (uint32_t j = tid; j < nsent; j += kThreads) {
-            const uint64_t b = P.boff[i0 + j];
-            if (b >= byte0 && b - byte0 < nbytes) {
-                const uint32_t pos = head + uint32_t(b - byte0);
-                atomicOr(&bm2[pos >> 5], 1u << (pos & 31));
+            for (int r = 0; r < 2; ++r) {
+                const uint32_t c = uint32_t(tid) + uint32_t(r) * kThreads;
+                if (c < nchunks) reinterpret_cast<uint4*>(raw2)[c] = etx[r];
+            }
+            for (uint32_t i = tid; i < ((nbytes_al + 31) >> 5) + 1; i += kThreads) bm2[i] = 0;
+            if (tid == 0) raw2[nchunks * 4] = 0;
+            __syncthreads();
+            for (uint32_t j = tid; j < nsent; j += kThreads) {
+                const uint64_t b = P.boff[i0 + j];
+                if (b >= byte0 && b - byte0 < nbytes) {
+                    const uint32_t pos = head + uint32_t(b - byte0);
+                    atomicOr(&bm2[pos >> 5], 1u << (pos & 31));
+                }
             }
         }
         __syncthreads();
@@ -867,32 +873,40 @@ __global__ __launch_bounds__(kThreads, fast_wg(WL)) void score_tiles_fast_kernel
                 const uint32_t pos0 = c < nchunks ? c * 16 : 0u;
                 uint32_t lm = 0, sm = 0, em = 0, vm = 0;
                 if (c < nchunks) {
-                    const uint4 v = reinterpret_cast<const uint4*>(raw2)[c];
+                    const uint4 v = etx[r];
                     const uint32_t lo = pos0 < head ? head - pos0 : 0u;
                     const uint32_t rem = nbytes_al - pos0;
                     const uint32_t hi = rem < 16 ? rem : 16u;
                     vm = ((1u << hi) - 1u) & ~((1u << lo) - 1u);
-                    lm = (lead_nibble(v.x) | (lead_nibble(v.y) << 4) | (lead_nibble(v.z) << 8) | (lead_nibble(v.w) << 12)) & vm;
                     em = (esc_nibble(v.x) | (esc_nibble(v.y) << 4) | (esc_nibble(v.z) << 8) | (esc_nibble(v.w) << 12)) & vm;
-                    sm = (bm2[pos0 >> 5] >> (pos0 & 31)) & 0xFFFFu & lm;
+                    if (one_round) { lm = keep_masks & 0xFFFFu; sm = (keep_masks >> 16) & lm; }
+                    else {
+                        lm = (lead_nibble(v.x) | (lead_nibble(v.y) << 4) | (lead_nibble(v.z) << 8) | (lead_nibble(v.w) << 12)) & vm;
+                        sm = (bm2[pos0 >> 5] >> (pos0 & 31)) & 0xFFFFu & lm;
+                    }
                 }
-                const uint32_t mine = __popc(lm) | (__popc(sm) << 16);
-                const uint32_t incl = wave_inclusive_scan(mine);
-                if (lane == 63) ew[4 + wave] = incl;
-                __syncthreads();
-                uint32_t woff = 0, total = 0;
+                uint32_t ci;
+                int32_t sib;
+                if (one_round) { ci = keep_idx & 0xFFFFu; sib = int32_t(keep_idx >> 16) - 1; }
+                else {
+                    const uint32_t mine = __popc(lm) | (__popc(sm) << 16);
+                    const uint32_t incl = wave_inclusive_scan(mine);
+                    if (lane == 63) ew[4 + wave] = incl;
+                    __syncthreads();
+                    uint32_t woff = 0, total = 0;
 #pragma unroll
-                for (int k = 0; k < kWavesF; ++k) {
-                    const uint32_t u = wave_uniform(ew[4 + k]);
-                    if (k < wave) woff += u;
-                    total += u;
+                    for (int k = 0; k < kWavesF; ++k) {
+                        const uint32_t u = wave_uniform(ew[4 + k]);
+                        if (k < wave) woff += u;
+                        total += u;
+                    }
+                    const uint32_t excl = woff + incl - mine;
+                    ci = bl + (excl & 0xFFFFu);
+                    sib = sib0 + int32_t(bs + (excl >> 16));
+                    bl += total & 0xFFFFu;
+                    bs += total >> 16;
+                    __syncthreads();   // the wave totals are rewritten by the next round
                 }
-                const uint32_t excl = woff + incl - mine;
-                const uint32_t ci = bl + (excl & 0xFFFFu);
-                const int32_t sib = sib0 + int32_t(bs + (excl >> 16));
-                bl += total & 0xFFFFu;
-                bs += total >> 16;
-                __syncthreads();   // the wave totals are rewritten by the next round
                 int32_t fb = c_off + int32_t(ci) + int32_t(kPad) * sib;
                 uint32_t m = lm, spm = 0, som = 0;
                 while (m != 0) {
@@ -955,7 +969,7 @@ __global__ __launch_bounds__(kThreads, fast_wg(WL)) void score_tiles_fast_kernel
             if (uint32_t(r) * kThreads >= nchunks) continue;   // (block-uniform)
             const uint32_t c = uint32_t(tid) + uint32_t(r) * kThreads;
             if (c >= nchunks) continue;
-            const uint4 v = reinterpret_cast<const uint4*>(raw2)[c];
+            const uint4 v = etx[r];
             const uint32_t vm = e_vm[r], spm = e_sp[r], em = e_em[r];
             uint32_t pos = e_w[r];
             if ((vm | spm) == 0) continue;
