@@ -1047,17 +1047,16 @@ def test_predict_and_write_in_one_launch(case, monkeypatch):
 
 
 @pytest.mark.parametrize("chunk_bytes", ["", "900", "20000", "20000:no-prefix", "direct", "900:direct", "20000:direct:no-prefix", "serial", "900:serial", "20000:serial",
-                                         "prep", "900:prep", "20000:prep", "20000:serial:no-prefix", "900:lanes"])
+                                         "20000:serial:no-prefix", "300"])
 def test_tokenize_batch_into_pinned_buffers(chunk_bytes, monkeypatch):
     """vpt_tokenize_batch without tags: the scoring kernel's tiles write the tokenized text themselves, chunk after chunk into one contiguous
     text (the chunks hand the position on through device words), copied out chunk by chunk while the next one is scored and the one after
     it has its chars counted and its tiles found on another stream; with
     VPT_TOKENIZE_DIRECT into caller buffers in PINNED memory (vpt_host_alloc) the kernels write it over PCIe themselves -- no copy out.
     Too small a buffer is an error either way."""
-    for name, schedule in (("serial", "0"), ("prep", "1"), ("lanes", "2")):   # the chunks' texts chained on the device (default: two independent lanes, placed by the copies out)
-        if name in chunk_bytes:
-            monkeypatch.setenv("VPT_TOKENIZE_SCHEDULE", schedule)
-            chunk_bytes = chunk_bytes.replace(":" + name, "").replace(name, "")
+    if "serial" in chunk_bytes:    # every kernel on one stream, one workspace (default: char count and tile search on a stream of their own)
+        monkeypatch.setenv("VPT_TOKENIZE_SERIAL", "1")
+        chunk_bytes = chunk_bytes.replace(":serial", "").replace("serial", "")
     if "direct" in chunk_bytes:   # the kernels write into the pinned caller buffers themselves
         monkeypatch.setenv("VPT_TOKENIZE_DIRECT", "1")
         chunk_bytes = chunk_bytes.replace(":direct", "").replace("direct", "")

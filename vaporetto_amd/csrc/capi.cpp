@@ -47,7 +47,7 @@ struct PredictorKnobs {
     uint64_t tokenize_chunk_bytes = uint64_t(256) << 20;   // VPT_TOKENIZE_CHUNK_BYTES (the tagged pipeline's default; the fused one: an eighth of the batch, at least 4 MB)
     bool tokenize_chunk_bytes_set = false;
     bool tokenize_separate = false;     // VPT_TOKENIZE_SEPARATE: predict and the writer as launches of their own for untagged text too (A/B of the fused path)
-    int tokenize_schedule = 1;          // VPT_TOKENIZE_SCHEDULE: 0 one stream, chunks chained; 1 chained, char count + tile search on a stream of their own; 2 two independent lanes
+    bool tokenize_serial = false;       // VPT_TOKENIZE_SERIAL: every kernel of every chunk on ONE stream with one workspace (A/B of the preparing stream)
     bool tokenize_direct = false;       // VPT_TOKENIZE_DIRECT: the kernels write the tokenized text straight into a pinned caller buffer (no copies out)
     int tag_wgs_per_cu = 32;            // VPT_TAG_WGS_PER_CU
 };
@@ -73,7 +73,7 @@ PredictorKnobs read_predictor_knobs() {
     if (const char* v = std::getenv("VPT_TOKENIZE_CHUNK_BYTES")) { const long long n = std::atoll(v); if (n > 0) { k.tokenize_chunk_bytes = uint64_t(n); k.tokenize_chunk_bytes_set = true; } }
     if (const char* v = std::getenv("VPT_TAG_WGS_PER_CU")) k.tag_wgs_per_cu = std::atoi(v);
     k.tokenize_direct = std::getenv("VPT_TOKENIZE_DIRECT") != nullptr;
-    if (const char* v = std::getenv("VPT_TOKENIZE_SCHEDULE")) k.tokenize_schedule = std::atoi(v);
+    k.tokenize_serial = std::getenv("VPT_TOKENIZE_SERIAL") != nullptr;
     k.tokenize_separate = std::getenv("VPT_TOKENIZE_SEPARATE") != nullptr;
     return k;
 }
@@ -1029,7 +1029,7 @@ struct FuseRequest { uint8_t* text_out; uint64_t capacity; uint64_t* offsets_out
 vpt_status emit_device(const vpt_predictor* p, vpt_batch* b, const uint8_t* d_utf8, const uint64_t* d_byte_offsets,
                        const uint64_t* d_out_offsets, size_t n_sentences, uint64_t total_boundaries, const uint8_t* d_labels,
                        const int32_t* d_tags, uint8_t* d_text_out, uint64_t text_capacity, uint64_t* d_text_offsets_out,
-                       hipStream_t stream, uint64_t* total_out = nullptr, uint64_t chars_hint = 0);
+                       hipStream_t stream, uint64_t* total_out = nullptr);
 
 vpt_status predict_device_impl(const vpt_predictor* p, vpt_batch* b, const uint8_t* d_utf8, const uint64_t* d_byte_offsets,
                                const uint64_t* d_out_offsets, size_t n_sentences, uint64_t total_boundaries,
@@ -1595,7 +1595,7 @@ namespace {
 vpt_status emit_device(const vpt_predictor* p, vpt_batch* b, const uint8_t* d_utf8, const uint64_t* d_byte_offsets,
                        const uint64_t* d_out_offsets, size_t n_sentences, uint64_t total_boundaries, const uint8_t* d_labels,
                        const int32_t* d_tags, uint8_t* d_text_out, uint64_t text_capacity, uint64_t* d_text_offsets_out,
-                       hipStream_t stream, uint64_t* total_out, uint64_t chars_hint) {
+                       hipStream_t stream, uint64_t* total_out) {
     if (!p || !b || b->pred != p) return fail(VPT_INVALID_ARGUMENT, "InvalidArgumentError: batch: does not belong to this predictor");
     if (!d_text_offsets_out) return fail(VPT_INVALID_ARGUMENT, "InvalidArgumentError: NULL device pointer");
     VPT_HIP(hipSetDevice(p->device));
@@ -1621,7 +1621,7 @@ vpt_status emit_device(const vpt_predictor* p, vpt_batch* b, const uint8_t* d_ut
     // configs[1]: 4 sentences of 64 chars per wave 0.122 ms, 8 0.093, 16 0.070, 32 0.063, 64 0.066: profiles/r03_n_emit_block_sizes.txt)
     vpt::EmitFuse F{};
     {
-        const uint64_t chars = chars_hint ? std::max<uint64_t>(chars_hint, n_sentences) : total_boundaries + n_sentences;   // (hint: total_boundaries is only an upper bound)
+        const uint64_t chars = total_boundaries + n_sentences;
         const uint64_t per = (uint64_t(2048) * n_sentences + chars / 2) / chars;   // round(2048 / mean chars per sentence)
         F.per_block = uint32_t(std::min<uint64_t>(std::max<uint64_t>(per, 1), vpt::kEmitFuseMaxBlock));
         if (b->knobs.emit_per_block) F.per_block = b->knobs.emit_per_block;
@@ -1753,45 +1753,41 @@ void* device_view_of_host(void* host_ptr) {
 // vpt_tokenize_batch without tags, on the scoring kernel with the writer fused in (vpt_predict_write_batch_device's path): a chunk of lines
 // is a copy in (text, offsets), the char count, the tile search and ONE scoring launch that leaves tokenized text.  Every chunk's text
 // follows the one before it -- the kernels hand the output position on through a chain of device words -- so the batch's output is one
-// piece however it is cut.  Four stages overlap, everything enqueued up front:
+// piece however it is cut.  Four stages overlap:
 //   copy in of chunk k + 2            its own stream
 //   char count + tile search of k + 1 the PREPARING stream, with the scratch of one of two workspaces (k + 1 & 1)
-//   scoring launch of chunk k         the SCORING stream: the launches follow each other with nothing in between (profiles/
-//                                     r04_e_tokenize_timeline.txt: 33 us of small launches in front of every 88 us scoring launch before)
-//   copy out of chunk k - 1           issued by the host when the chunk's event fires and a pinned word says where its text ends
-// Measured on MI355X (profiles/r04_d_tokenize_timeline.txt, r04_e_tokenize.jsonl): kernels that write the text STRAIGHT into a pinned
-// caller buffer (VPT_TOKENIZE_DIRECT=1) spare the copies out and every wait but the last, but their stores cross PCIe at 27 .. 34 GB/s
-// against the copy engine's 56.  `text` = the batch's first byte; byte_offsets are the caller's (relative to byte_offsets[0]).
+//   scoring launch of chunk k         the SCORING stream: the launches follow each other with an event wait that has long fired in between
+//                                     (profiles/r04_e_tokenize_timeline.txt: 33 us of small launches in front of every scoring launch before)
+//   copy out of chunk k - 1           issued by the host as soon as the chunk's event has fired; a pinned word says where its text ends
+// and the host is a fifth: a chunk is some fifteen runtime calls, and with everything enqueued before the first wait the copies out only
+// started when the LAST chunk was enqueued (r04_i_tokenize_timeline.txt).  So the loop cuts and rebases a chunk's offsets when its copy in
+// is due, keeps the copies in two chunks ahead of the kernels, and after every chunk looks whether an earlier one can leave.
+// Measured and dropped (profiles/r04_{k,m,n}_tokenize*): a small first and last chunk (what is in front of the first scored chunk and behind
+// the last one overlaps with nothing; host timestamps of the equal cut, 100 K lines: first chunk scored at 250 us, one every 100 us after it,
+// 94 us behind the last) -- 0.96 ms against 0.88; two independent lanes, each chunk's text placed by an upper bound and closed up by
+// the copies out -- two scoring launches at a time take twice as long each, 1.07 ms against 0.88; scoring and writer as launches of their
+// own per chunk (28 + 28 us against 88 fused, r04_l_fused_by_batch_size.jsonl) -- the five launches per chunk cost the host more than the
+// device gains, 1.07 ms; kernels storing STRAIGHT into a pinned caller buffer (VPT_TOKENIZE_DIRECT=1, kept): their stores cross PCIe at 27 ..
+// 34 GB/s against the copy engine's 56.  `text` = the batch's first byte; byte_offsets are the caller's (relative to byte_offsets[0]).
 vpt_status tokenize_fused(const vpt_predictor* p, vpt_batch* b, const uint8_t* text, const uint64_t* byte_offsets, size_t n_sentences, unsigned flags,
                           uint64_t max_bytes, uint8_t* text_out, uint64_t text_capacity, uint64_t* text_offsets_out) {
     (void)max_bytes;
     const uint64_t t0 = byte_offsets[0];
     const size_t nbytes = size_t(byte_offsets[n_sentences] - t0);
-    const uint64_t chunk_bytes = p->knobs.tokenize_chunk_bytes_set ? p->knobs.tokenize_chunk_bytes : std::min<uint64_t>(uint64_t(8) << 20, std::max<uint64_t>(uint64_t(2) << 20, (uint64_t(nbytes) + 5) / 6));
-    const size_t max_chunks = std::min<size_t>(n_sentences, size_t(nbytes / chunk_bytes) + 2);
+    // 1/6 of the batch, at least 2 MB (a scoring launch costs 50 us + 1.3 us per 1000 lines) and at most 8 (1 M lines: 5.8 ms in 8 MB chunks, 6.4 in 32)
+    const uint64_t chunk_bytes = p->knobs.tokenize_chunk_bytes_set ? std::max<uint64_t>(p->knobs.tokenize_chunk_bytes, 1)
+                                                                   : std::min<uint64_t>(uint64_t(8) << 20, std::max<uint64_t>(uint64_t(2) << 20, (uint64_t(nbytes) + 5) / 6));
+    const size_t n_cuts = size_t((uint64_t(nbytes) + chunk_bytes - 1) / chunk_bytes);   // chunks, unless sentences longer than one swallow some
+    const size_t max_chunks = std::min<size_t>(n_sentences, n_cuts) + 1;
+    auto cut_end = [&](size_t k) -> uint64_t { return std::min<uint64_t>(uint64_t(nbytes), (k + 1) * chunk_bytes); };   // where chunk k of n_cuts should end
     vpt_status st;
-    uint8_t* d_out = nullptr;
-    uint64_t* d_off_out = nullptr;
-    bool direct = false;
-    if (p->knobs.tokenize_direct) {
-        d_out = static_cast<uint8_t*>(device_view_of_host(text_out));
-        d_off_out = static_cast<uint64_t*>(device_view_of_host(text_offsets_out));
-        direct = (d_out || text_capacity == 0) && d_off_out;
-    }
-    // 0: one stream, one workspace, the chunks' texts chained on the device.  1: chained, but char count and tile search run on a stream
-    // (and workspace) of their own while the chunk before is scored.  2: two lanes (stream + workspace) take the chunks in turn and a chunk
-    // writes its text where an upper bound puts it (3 bytes per byte of text in front of it): no chain, so two chunks' tiles share the
-    // device; the copies out close the gaps and the host adds every chunk's start to its sentences' offsets.
-    // 3: as 1, but scoring (labels only) and the writer as launches of their own, placed like 2's chunks -- the writer's phase costs the scoring
-    // kernel 40 us per round of tiles (profiles/r04_l_fused_by_batch_size.jsonl: 16.7 K sentences 31 us without, 70 with; the writer alone 29).
-    const int schedule = direct ? std::min(p->knobs.tokenize_schedule, 1) : p->knobs.tokenize_schedule;
-    const bool serial = schedule <= 0, lanes = schedule == 2, separate = schedule >= 3, placed = lanes || separate, split = schedule == 1 || separate;
+    const bool serial = p->knobs.tokenize_serial;
     Workspace second;   // the scratch (tiles, partial sums, the writer's words, status) of every other chunk
     if (!serial && (st = acquire(p, &second)) != VPT_OK) return st;
     vpt_batch* const ws[2] = {b, serial ? b : second.b};
     if (!b->s_tok_in) VPT_HIP(hipStreamCreateWithFlags(&b->s_tok_in, hipStreamNonBlocking));
     if (!b->s_tok_out) VPT_HIP(hipStreamCreateWithFlags(&b->s_tok_out, hipStreamNonBlocking));
-    while (b->chunk_ev.size() < 4 * max_chunks) {   // per chunk: copied in, tiles found, scored, copied out
+    while (b->chunk_ev.size() < 3 * max_chunks) {   // per chunk: copied in, tiles found, scored
         hipEvent_t e;
         VPT_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
         b->chunk_ev.push_back(e);
@@ -1805,15 +1801,22 @@ vpt_status tokenize_fused(const vpt_predictor* p, vpt_batch* b, const uint8_t* t
         b->off_cap = std::min(cap, cap2);
     }
     if ((st = grow(&b->d_chain, &b->chain_cap, max_chunks + 2)) != VPT_OK) return st;
+    uint8_t* d_out = nullptr;
+    uint64_t* d_off_out = nullptr;
+    bool direct = false;
+    if (p->knobs.tokenize_direct) {
+        d_out = static_cast<uint8_t*>(device_view_of_host(text_out));
+        d_off_out = static_cast<uint64_t*>(device_view_of_host(text_offsets_out));
+        direct = (d_out || text_capacity == 0) && d_off_out;
+    }
     uint64_t out_cap = text_capacity;
     if (!direct) {
-        out_cap = uint64_t(nbytes) * 3 + 16 * (max_chunks + 1);
+        out_cap = uint64_t(nbytes) * 3 + 16;
         if ((st = grow(&b->d_tok, &b->tok_cap, size_t(out_cap) + 16)) != VPT_OK) return st;
-        if ((st = grow(&b->d_toff, &b->toff_cap, n_sentences + max_chunks + 2)) != VPT_OK) return st;
+        if ((st = grow(&b->d_toff, &b->toff_cap, n_sentences + 2)) != VPT_OK) return st;
         d_out = b->d_tok; d_off_out = b->d_toff;
     }
-    if (separate && (st = grow(&b->d_tlab, &b->tlab_cap, nbytes + 1)) != VPT_OK) return st;
-    const size_t need_off = n_sentences + 1 + max_chunks + 1;   // pinned: the offsets relative to the batch's text, then where every chunk's text ends
+    const size_t need_off = n_sentences + 1 + max_chunks + 1 + 2;   // pinned: the offsets relative to the batch's text, where every chunk's text ends, the workspaces' status words
     if (need_off > b->h_off_cap) {
         if (b->h_off) (void)hipHostFree(b->h_off);
         b->h_off = nullptr; b->h_off_cap = 0;
@@ -1822,125 +1825,92 @@ vpt_status tokenize_fused(const vpt_predictor* p, vpt_batch* b, const uint8_t* t
     }
     uint64_t* const h_boff = b->h_off;
     uint64_t* const h_end = b->h_off + n_sentences + 1;
+    uint64_t* const h_ctrl = h_end + max_chunks + 1;
     hipStream_t s = b->own_stream, s_in = b->s_tok_in, s_out = b->s_tok_out;
-    hipStream_t s_other = serial ? s : second.b->own_stream;
+    hipStream_t s_prep = serial ? s : second.b->own_stream;
     for (vpt_batch* w : ws) {
         w->flags = flags;
         w->max_chars = 0;   // unknown on the host (no round trip for it): the scoring kernel takes the geometry that fits any sentence
     }
-    if (!placed) VPT_HIP(hipMemsetAsync(b->d_chain, 0, sizeof(uint64_t), s));
-    // The host is a stage of its own: a chunk is some fifteen runtime calls, and with everything enqueued before the first wait the copies
-    // out started when the LAST chunk was enqueued (profiles/r04_i_tokenize_timeline.txt: all six behind the kernels).  So the loop below
-    // cuts and rebases a chunk's offsets only when its copy in is due (the first one leaves after 1/6 of that pass), keeps the copies in two
-    // chunks ahead of the kernels, and after every chunk looks whether an earlier one has been scored and sends its text on its way.
-    struct Chunk { size_t a, n; uint64_t tb, nby, mb, out_at; };
+    VPT_HIP(hipMemsetAsync(b->d_chain, 0, sizeof(uint64_t), s));
+    struct Chunk { size_t a, n; uint64_t tb, nby, mb; };
     std::vector<Chunk> chunks;
     chunks.reserve(max_chunks);
-    size_t cut_at = 0;
+    size_t cut_at = 0, cut_k = 0;
     h_boff[0] = 0;
     auto copy_in_next = [&]() -> vpt_status {   // the next chunk of lines: offsets rebased into pinned memory, text and offsets on their way
         if (cut_at >= n_sentences) return VPT_OK;
         const size_t a = cut_at, k = chunks.size();
+        uint64_t want = cut_end(cut_k++);
+        while (want <= h_boff[a] && cut_k < n_cuts) want = cut_end(cut_k++);   // (a sentence longer than a chunk took these)
         size_t i = a;
         uint64_t mb = 0;
-        while (i < n_sentences && h_boff[i] - h_boff[a] < chunk_bytes) {
+        do {
             h_boff[i + 1] = byte_offsets[i + 1] - t0;
             mb = std::max<uint64_t>(mb, h_boff[i + 1] - h_boff[i]);
             ++i;
-        }
+        } while (i < n_sentences && (h_boff[i] < want || chunks.size() + 1 >= max_chunks));
         const size_t n = i - a;
         const uint64_t tb = h_boff[a], nby = h_boff[i] - tb;
         VPT_HIP(hipMemcpyAsync(b->d_text + tb, text + tb, size_t(nby), hipMemcpyHostToDevice, s_in));
         VPT_HIP(hipMemcpyAsync(b->d_boff + a + k, h_boff + a, 8 * (n + 1), hipMemcpyHostToDevice, s_in));   // n + 1 entries per chunk; offsets into the WHOLE text: no rebasing
-        VPT_HIP(hipEventRecord(b->chunk_ev[4 * k], s_in));
-        chunks.push_back({a, n, tb, nby, mb, 0});
+        VPT_HIP(hipEventRecord(b->chunk_ev[3 * k], s_in));
+        chunks.push_back({a, n, tb, nby, mb});
         cut_at = i;
         return VPT_OK;
     };
     uint64_t at = 0;
-    size_t next_out = 0, next_fix = 0;
+    size_t next_out = 0;
     bool out_of_range = false, too_small = false;
     auto copy_out = [&](size_t k) -> vpt_status {   // chunk k has been scored: its text and offsets leave
-        Chunk& c = chunks[k];
-        if (placed) {   // h_end: the size of the chunk's text, which starts at 3 * tb + 16 * k on the device and at `at` for the caller
-            const uint64_t size = h_end[k];
-            if (size > 3 * c.nby + 16) { out_of_range = true; return VPT_OK; }   // the device found the inputs inconsistent and says so below
-            if (at + size > text_capacity) { too_small = true; return VPT_OK; }
-            if (size) VPT_HIP(hipMemcpyAsync(text_out + at, d_out + 3 * c.tb + 16 * k, size_t(size), hipMemcpyDeviceToHost, s_out));
-            VPT_HIP(hipMemcpyAsync(text_offsets_out + c.a, d_off_out + c.a + k, 8 * c.n, hipMemcpyDeviceToHost, s_out));
-            VPT_HIP(hipEventRecord(b->chunk_ev[4 * k + 3], s_out));
-            c.out_at = at;
-            at += size;
-            return VPT_OK;
-        }
         const uint64_t end = h_end[k];
-        if (end > out_cap || end < at) { out_of_range = true; return VPT_OK; }
+        if (end > out_cap || end < at) { out_of_range = true; return VPT_OK; }   // the device found the inputs inconsistent and says so below
         if (end > text_capacity) { too_small = true; return VPT_OK; }
         if (end > at) VPT_HIP(hipMemcpyAsync(text_out + at, d_out + at, size_t(end - at), hipMemcpyDeviceToHost, s_out));
-        VPT_HIP(hipMemcpyAsync(text_offsets_out + c.a, d_off_out + c.a, 8 * (c.n + 1), hipMemcpyDeviceToHost, s_out));
+        VPT_HIP(hipMemcpyAsync(text_offsets_out + chunks[k].a, d_off_out + chunks[k].a, 8 * (chunks[k].n + 1), hipMemcpyDeviceToHost, s_out));
         at = end;
         return VPT_OK;
-    };
-    auto fix_offsets = [&](size_t k) {   // (placed chunks) the chunk's offsets have arrived relative to its own text
-        const Chunk& c = chunks[k];
-        if (c.out_at) for (size_t i = c.a; i < c.a + c.n; ++i) text_offsets_out[i] += c.out_at;
     };
     if ((st = copy_in_next()) != VPT_OK || (st = copy_in_next()) != VPT_OK) return st;
     for (size_t k = 0; k < chunks.size(); ++k) {
         const Chunk c = chunks[k];
         vpt_batch* const w = ws[k & 1];
-        hipStream_t ks = lanes ? ((k & 1) ? s_other : s) : s_other;   // where the char count and the tile search go
         uint64_t* d_boff_k = b->d_boff + c.a + k;
         uint64_t* d_ooff_k = b->d_ooff + c.a + k;   // n + 1 entries per chunk, chunk-relative
-        VPT_HIP(hipStreamWaitEvent(ks, b->chunk_ev[4 * k], 0));
-        if (split && k >= 2) VPT_HIP(hipStreamWaitEvent(ks, b->chunk_ev[4 * (k - 2) + 2], 0));   // this workspace's scratch: the chunk before the last is through with it
-        if ((st = count_boundaries_impl(p, w, b->d_text, d_boff_k, c.n, d_ooff_k, ks, c.nby)) != VPT_OK) return st;
+        VPT_HIP(hipStreamWaitEvent(s_prep, b->chunk_ev[3 * k], 0));
+        if (!serial && k >= 2) VPT_HIP(hipStreamWaitEvent(s_prep, b->chunk_ev[3 * (k - 2) + 2], 0));   // this workspace's scratch: the chunk before the last is through with it
+        if ((st = count_boundaries_impl(p, w, b->d_text, d_boff_k, c.n, d_ooff_k, s_prep, c.nby)) != VPT_OK) return st;
         h_end[k] = ~uint64_t(0);
-        FuseRequest fuse{d_out, out_cap, d_off_out + c.a, h_end + k, b->d_chain + k, b->d_chain + k + 1};
-        if (placed) { fuse.text_out = d_out + 3 * c.tb + 16 * k; fuse.capacity = 3 * c.nby + 16; fuse.offsets_out = d_off_out + c.a + k; fuse.chain_in = nullptr; fuse.chain_out = nullptr; }
-        if (split) { w->split_stream = s; w->split_event = b->chunk_ev[4 * k + 1]; }
-        const uint64_t bounds_max = c.nby - c.n;   // boundaries of the chunk, at most
-        uint8_t* const d_labels_k = separate ? b->d_tlab + c.tb : nullptr;   // (boundaries in front of the chunk <= bytes in front of it)
-        st = predict_device_impl(p, w, b->d_text, d_boff_k, d_ooff_k, c.n, bounds_max, c.mb, nullptr, d_labels_k, ks, separate ? nullptr : &fuse);
+        const FuseRequest fuse{d_out, out_cap, d_off_out + c.a, h_end + k, b->d_chain + k, b->d_chain + k + 1};
+        if (!serial) { w->split_stream = s; w->split_event = b->chunk_ev[3 * k + 1]; }
+        st = predict_device_impl(p, w, b->d_text, d_boff_k, d_ooff_k, c.n, c.nby - c.n /* boundaries of the chunk, at most */, c.mb, nullptr, nullptr, s_prep, &fuse);
         w->split_stream = nullptr; w->split_event = nullptr;
         if (st != VPT_OK) return st;
-        if (separate) {   // the writer's blocks are sized by the chars per sentence: counted over the chunk's first 4 KB
-            const uint64_t sample = std::min<uint64_t>(c.nby, 4096);
-            uint64_t leads = 0;
-            for (uint64_t i = 0; i < sample; ++i) leads += (text[c.tb + i] & 0xC0u) != 0x80u;
-            const uint64_t chars_hint = std::max<uint64_t>(1, leads * c.nby / std::max<uint64_t>(sample, 1));
-            st = emit_device(p, w, b->d_text, d_boff_k, d_ooff_k, c.n, bounds_max, d_labels_k, nullptr, fuse.text_out, fuse.capacity, fuse.offsets_out, s, h_end + k, chars_hint);
-            if (st != VPT_OK) return st;
-        }
-        VPT_HIP(hipEventRecord(b->chunk_ev[4 * k + 2], lanes ? ks : s));
+        VPT_HIP(hipEventRecord(b->chunk_ev[3 * k + 2], s));
         if ((st = copy_in_next()) != VPT_OK) return st;
-        while (!direct && !out_of_range && !too_small && next_out < k && hipEventQuery(b->chunk_ev[4 * next_out + 2]) == hipSuccess)
+        while (!direct && !out_of_range && !too_small && next_out < k && hipEventQuery(b->chunk_ev[3 * next_out + 2]) == hipSuccess)
             if ((st = copy_out(next_out++)) != VPT_OK) return st;
     }
     // ---- collect what is still on the device
     for (; next_out < chunks.size() && !direct && !out_of_range && !too_small; ++next_out) {
-        VPT_HIP(hipEventSynchronize(b->chunk_ev[4 * next_out + 2]));
+        VPT_HIP(hipEventSynchronize(b->chunk_ev[3 * next_out + 2]));
         if ((st = copy_out(next_out)) != VPT_OK) return st;
-        while (placed && !out_of_range && !too_small && next_fix < next_out && hipEventQuery(b->chunk_ev[4 * next_fix + 3]) == hipSuccess) fix_offsets(next_fix++);
     }
-    // ---- the device's verdict over every chunk
-    uint32_t ctrl[2][2] = {{0, 0}, {0, 0}};
-    VPT_HIP(hipStreamSynchronize(s_other));
-    VPT_HIP(hipMemcpyAsync(ctrl[0], b->d_ctrl, sizeof(ctrl[0]), hipMemcpyDeviceToHost, s));
-    if (!serial) VPT_HIP(hipMemcpyAsync(ctrl[1], second.b->d_ctrl, sizeof(ctrl[1]), hipMemcpyDeviceToHost, s));
+    // ---- the device's verdict over every chunk (into pinned words: a copy to the stack is staged and waited for, 25 us each)
+    h_ctrl[0] = h_ctrl[1] = 0;
+    VPT_HIP(hipStreamSynchronize(s_prep));
+    VPT_HIP(hipMemcpyAsync(h_ctrl, b->d_ctrl, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+    if (!serial) VPT_HIP(hipMemcpyAsync(h_ctrl + 1, second.b->d_ctrl, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
     VPT_HIP(hipStreamSynchronize(s));
     VPT_HIP(hipStreamSynchronize(s_out));
     for (vpt_batch* w : ws) w->pending = false;
-    if (placed && !out_of_range && !too_small) {
-        while (next_fix < chunks.size()) fix_offsets(next_fix++);
-        text_offsets_out[n_sentences] = at;
-    }
-    if (ctrl[0][0] | ctrl[1][0]) {
+    const uint32_t bits = uint32_t(h_ctrl[0]) | uint32_t(h_ctrl[1]);
+    if (bits) {
         for (vpt_batch* w : ws) VPT_HIP(hipMemset(w->d_ctrl, 0, sizeof(uint32_t)));
-        return status_from_bits(ctrl[0][0] | ctrl[1][0]);
+        return status_from_bits(bits);
     }
     if (too_small) return fail(VPT_INVALID_ARGUMENT, "InvalidArgumentError: text_capacity: smaller than the tokenized text");
-    if (out_of_range || (!placed && h_end[chunks.size() - 1] > out_cap)) return fail(VPT_RUNTIME_ERROR, "vpt_tokenize_batch: the output size is out of range");
+    if (out_of_range || h_end[chunks.size() - 1] > out_cap) return fail(VPT_RUNTIME_ERROR, "vpt_tokenize_batch: the output size is out of range");
     return VPT_OK;
 }
 }  // namespace
