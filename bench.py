@@ -46,6 +46,8 @@ import numpy as np  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 PCIE_GBS = 63.0         # MI355X_MICROARCH.md: PCIe Gen5 x16, per direction
+PCIE_DUPLEX_GBS = 84.2  # measured on this link with both directions busy at once (one copy each way, 21 MB in + 31 MB out: profiles/r02_c6_pcie_microbench.txt;
+                        # one direction alone: 56 GB/s) -- the two directions share: a batch that needs its input before it can send output is priced against THIS
 
 CONFIGS = {
     1: dict(name="configs[1]", kind=1, sentences=100_000, min_len=64, max_len=64, tags=False, blocks=False),
@@ -508,6 +510,7 @@ class Runner:
             bytes_in, bytes_out = nbytes + 16 * (S + 1), 5 * nb
             e2e = {"boundaries_per_s": nb / dt, "ms_per_batch": 1e3 * dt, "h2d_GBps": bytes_in / dt / 1e9, "d2h_GBps": bytes_out / dt / 1e9,
                    "pcie_peak_GBps_per_direction": PCIE_GBS, "frac_of_pcie": max(bytes_in, bytes_out) / dt / 1e9 / PCIE_GBS,
+                   "pcie_measured_both_ways_GBps": PCIE_DUPLEX_GBS, "frac_of_both_ways": (bytes_in + bytes_out) / dt / 1e9 / PCIE_DUPLEX_GBS,
                    "parity": bool(parity is None or (np.array_equal(keep[1].array[:nb], o_scores) and np.array_equal(keep[2].array[:nb], o_labels))),
                    "path": "vpt_predict_batch: pinned host buffers (vpt_host_alloc); batches up to 16 M chars in 512 K-char chunks over 4 "
                            "in-order lanes, larger ones in 4 M-char chunks on three streams with events"}
@@ -525,7 +528,8 @@ class Runner:
             dt = median_time(lambda: pred.tokenize_packed(keep[0].array, boff, text_out=tk[0].array, offsets_out=tk[1].array), k)
             e2e["tokenize"] = {"ms_per_batch": 1e3 * dt, "chars_per_s": (nb + S) / dt, "h2d_GBps": (nbytes + 8 * (S + 1)) / dt / 1e9,
                                "d2h_GBps": (len(tok_text) + 8 * (S + 1)) / dt / 1e9, "out_bytes": int(len(tok_text)),
-                               "path": "vpt_tokenize_batch: chunks of a sixth of the batch; per chunk copy in, char count, tile search, ONE scoring launch that writes the tokenized text (chunks chain into one output), copy out when the chunk's event fires"}
+                               "frac_of_both_ways": (nbytes + len(tok_text) + 16 * (S + 1)) / dt / 1e9 / PCIE_DUPLEX_GBS,
+                               "path": "vpt_tokenize_batch: chunks of a sixth of the batch (2 .. 8 MB); per chunk copy in, char count + tile search on a stream of their own, ONE scoring launch that writes the tokenized text (chunks chain into one output), copy out as soon as the chunk's event has fired"}
             del tk
             # ten of these batches as one call: what the pipeline does once its start-up no longer counts
             rep = 10
@@ -538,6 +542,7 @@ class Runner:
             dt = median_time(lambda: api.predict_packed_sharded([pred], big[0].array, boff_big, out_offsets=ooff_big, scores=big[1].array, labels=big[2].array), 7)
             e2e["large_batch"] = {"sentences": S * rep, "boundaries_per_s": nb * rep / dt, "ms_per_batch": 1e3 * dt, "d2h_GBps": bytes_out * rep / dt / 1e9,
                                   "h2d_GBps": bytes_in * rep / dt / 1e9, "frac_of_pcie": bytes_out * rep / dt / 1e9 / PCIE_GBS,
+                                  "frac_of_both_ways": (bytes_in + bytes_out) * rep / dt / 1e9 / PCIE_DUPLEX_GBS,
                                   "parity": bool(parity is None or (np.array_equal(big[1].array[(rep - 1) * nb:], o_scores) and np.array_equal(big[2].array[:nb], o_labels)))}
             del big
             del keep
