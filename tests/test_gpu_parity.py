@@ -799,13 +799,17 @@ def test_stored_tag_scores_match_oracle_on_random_models(seed):
     assert (got_s[o_models < 0] == 12345).all()
 
 
-@pytest.mark.parametrize("queue", [None, "8"])
+@pytest.mark.parametrize("queue", [None, "8", "by-sentence"])
 def test_fill_tags_as_two_launches(queue, monkeypatch):
-    """Batches of 256 K chars and more take fill_tags as two launches: the step loop leaves the tokens that have a tag model in a queue
-    in HBM, a launch of passes runs over it (VPT_TAG_SPLIT=1 forces that for any batch; read when a workspace is made).  A queue
-    of 8 entries (VPT_TAG_QUEUE) overflows at once: the one-launch kernel does the batch again.  Same tags, same score vectors,
-    same tagged text as through one launch -- on models inside and outside the record form."""
+    """Batches of 256 K chars and more take fill_tags as two launches: the front end (flat over the batch's chars: a wave takes a run of
+    sentences; VPT_TAG_FRONT_BY_SENTENCE: a sentence at a time) leaves the tokens that have a tag model in a queue in HBM, a launch of passes
+    runs over it (VPT_TAG_SPLIT=1 forces that for any batch; read when a workspace is made).  A queue of 8 entries (VPT_TAG_QUEUE) overflows
+    at once: the one-launch kernel does the batch again.  Same tags, same score vectors, same tagged text as through one launch -- on
+    models inside and outside the record form."""
     monkeypatch.setenv("VPT_TAG_SPLIT", "1")
+    if queue == "by-sentence":
+        monkeypatch.setenv("VPT_TAG_FRONT_BY_SENTENCE", "1")
+        queue = None
     if queue:
         monkeypatch.setenv("VPT_TAG_QUEUE", queue)
     test_predict_tags_like_reference()
@@ -816,6 +820,53 @@ def test_fill_tags_as_two_launches(queue, monkeypatch):
     if not (devmem.EMULATED and queue):
         test_device_resident_predict_then_fill_tags()
     test_write_tagged_text_on_device()
+
+
+@pytest.mark.parametrize("front", ["flat", "by-sentence"])
+def test_tag_front_end_over_runs_of_sentences(front, monkeypatch):
+    """The front-end launch of fill_tags walks RUNS of sentences as consecutive chars, 128 per step: runs of hundreds of one- and two-char
+    sentences (more sentence starts in a step than the 64 offsets the lanes hold), sentences that end exactly at a half-step's or a step's
+    last char, sentences of several steps, tokens that begin steps before they end, Unknown labels anywhere, several runs per wave --
+    tags of every char against the oracle's, for predicted and for edited labels."""
+    monkeypatch.setenv("VPT_TAG_SPLIT", "1")
+    if front == "by-sentence":
+        monkeypatch.setenv("VPT_TAG_FRONT_BY_SENTENCE", "1")
+    m = randmodel.rand_model(9100, alphabet="tiny", n_tag_models=30, max_word=4, n_char=40, n_dict=30)
+    raw = encode_model(m)
+    pred = api.Predictor(api.Model.read_slice(raw)[0], True)
+    orc = cbind.OraclePredictor(raw, True)
+    rng = np.random.RandomState(5)
+    alpha = randmodel.ALPHABETS["tiny"]
+    def text(n):
+        return "".join(alpha[k] for k in rng.randint(0, len(alpha), size=n))
+    toks = [t.token for t in m.tag_models]
+    lens = [1] * 300 + [2] * 150 + [1, 63, 1, 64, 1, 65, 127, 128, 129, 1, 1, 255, 256, 257, 700, 3, 62, 2, 64, 64, 64, 128, 128, 1]
+    lens += list(rng.randint(1, 6, size=400)) + list(rng.randint(1, 300, size=120)) + [1] * 70
+    texts = [text(int(n)) for n in lens]
+    texts += [toks[k % len(toks)] * int(1 + k % 5) for k in range(60)]      # tokens with tag models, back to back
+    texts += ["".join(toks[(k + j) % len(toks)] for j in range(40)) for k in range(6)]
+    order = rng.permutation(len(texts))
+    texts = [texts[k] for k in order]
+    # (a run's 64th sentence starting exactly at the next step's first char: 66 + 62 = 128)
+    texts = [text(66)] + [text(1) for _ in range(62)] + [text(40), text(30)] + [text(1) for _ in range(333)] + texts + [toks[k % len(toks)][:1] for k in range(200)] + [text(2) for _ in range(150)]   # blocks of them, too
+    utf8, boff = api.pack_texts([t.encode("utf-8") for t in texts])
+    scores, labels, ooff = pred.predict_packed(utf8, boff)
+    nt = pred.n_tags()
+    for edit in (0, 1, 2):
+        lab = labels.copy()
+        if edit == 1:
+            k = rng.randint(0, len(lab), size=len(lab) // 5)
+            lab[k] = rng.randint(0, 3, size=len(k))          # NotWordBoundary / WordBoundary / Unknown
+        if edit == 2:
+            lab[:] = 0                                        # whole sentences as tokens: they begin many steps before they end
+            lab[rng.randint(0, len(lab), size=len(lab) // 40)] = 1
+        got = pred.fill_tags_packed(utf8, boff, ooff, lab)
+        assert got.shape == (int(ooff[-1]) + len(texts), nt)
+        for i, t in enumerate(texts):
+            a, b = int(ooff[i]), int(ooff[i + 1])
+            want, _ = orc.predict_tags(t, labels=lab[a:b])
+            g0 = a + i
+            assert np.array_equal(got[g0:g0 + len(t)], want), (edit, i, len(t))
 
 
 @pytest.mark.parametrize("wc,wt", [(3, 6), (5, 5), (8, 8), (4, 2), (2, 7)])

@@ -46,6 +46,11 @@
 //                        half-steps and the next sentence's offsets and first chars in flight a sentence ahead, the passes 57 at 8
 //                        per CU.  A queue that overflows (an eighth of the batch's chars) sets a flag: the one-launch kernel, always
 //                        launched behind the pair, then does the batch again -- otherwise it returns at once.
+//   tag_front_flat_kernel
+//                        Round 4: the front-end launch of the pair, flat over the batch's chars -- a wave takes a run of consecutive sentences
+//                        (about 2 K chars) and walks it in the same 128-char steps with every lane busy; sentence starts and ends come from
+//                        two bitmaps per step built from the run's offsets.  configs[4]: 1.08 -> 1.00 ms (tag_tokens_kernel<.., kSplit> stays
+//                        as the A/B: VPT_TAG_FRONT_BY_SENTENCE).
 //   With predict_tags the scoring kernel of the preceding vpt_predict_batch_device call leaves the decoded chars behind and
 //   decode_chars_kernel is skipped (capi.cpp).
 #include <hip/hip_runtime.h>
@@ -853,6 +858,182 @@ __global__ __launch_bounds__(kTagThreads, kSplit ? kTagFrontOcc : VPT_TAG_OCC) v
     if (nc != 0 || nq != 0) tag_resolve<kSplit>(P, L, Lp, nc, nq, true, lane, dbg);
 }
 
+
+// The front-end launch, FLAT over the batch's chars (round 4).  tag_tokens_kernel<.., kSplit> gives a sentence to a wave: its steps of
+// 128 chars run half empty at a sentence's end (configs[4]'s sentences of 8 .. 512 chars: 2.5 steps where 2.0 would do) and every
+// sentence starts with its own trips for offsets and first chars.  Here a wave takes a RUN of `per` consecutive sentences, which are
+// consecutive chars (char q of sentence i sits at ooff[i] + i + q), and walks them in the same steps of two 64-char half-steps with
+// every lane busy up to the run's last step.  What the per-sentence loop knew from its loop variables comes from two bitmaps per
+// step, built a step ahead from the run's offsets (64 sentences' worth in the lanes at a time): SM, the chars that start a sentence, and EM,
+// the chars that end one -- a sentence's last char ends a token (predictor.rs:563-570), the label of any other char q of sentence i is
+// labels[flat(q) - i], and a candidate's context stops at its sentence's ends.  The token logic (ends, Unknown, filter, candidates,
+// lookups, queue in HBM) is tag_tokens_kernel's, in run-relative positions.
+// 6 workgroups per CU: 78 VGPRs, nothing spilled (7: 72 + 5 spilled, 8: 64 + 12; the same 1.77 / 1.78 / 1.87 ms).
+__global__ __launch_bounds__(kTagThreads, 6) void tag_front_flat_kernel(const TagParams P, const uint32_t per) {
+    __shared__ TagKernelLds<true> LDS;
+    __shared__ uint32_t BITS[kTagWaves][8];   // per wave: SM (4 words), EM (4 words) of the step being prepared
+    const int lane = threadIdx.x & 63;
+    const uint32_t wid = wave_uniform(threadIdx.x >> 6);
+    TagFrontLds& L = LDS.fr[wid];
+    uint32_t* const bits = BITS[wid];
+    const uint64_t wave = uint64_t(blockIdx.x) * kTagWaves + wid, n_waves = uint64_t(gridDim.x) * kTagWaves;
+    const uint32_t nt = P.n_tags;
+    const uint64_t below_me = (uint64_t(1) << lane) - 1, upto_me = below_me | (uint64_t(1) << lane);
+    const uint64_t total_b = P.total_chars - P.n_sent;   // labels of the batch
+    const uint64_t n_runs = (P.n_sent + per - 1) / per;
+    uint32_t nq = 0, nc = 0;   // (queued tokens: unused by the front end), waiting candidates (wave-uniform)
+    for (uint64_t run = wave; run < n_runs; run += n_waves) {
+        const uint64_t i_a = run * per, i_b = i_a + per < P.n_sent ? i_a + per : P.n_sent;
+        const uint64_t run0 = wave_uniform64(P.ooff[i_a]) + i_a, run1 = wave_uniform64(P.ooff[i_b]) + i_b;   // flat chars [run0, run1)
+        // offsets that do not fit the batch are reported by decode_chars_kernel / the scoring kernel; such a run (and one of 2^31 chars:
+        // not in this kernel's index width) is left alone
+        if (run1 < run0 || run1 > P.total_chars || run1 - run0 >= 0x7FFFFF00ull) continue;
+        const int n = int(run1 - run0);
+        const uint32_t* const cps = P.cps + run0;
+        // ---- the run's sentence starts, run-relative, 64 at a time in the lanes: entry k of the window is sentence i_load + k; the entry of
+        // i_b is the run's end (it marks the last char's EM bit); entries past it are "never"
+        constexpr int kNever = 0x7FFFFFFF;
+        uint64_t i_load = i_a;
+        auto load_window = [&]() -> int {
+            const uint64_t i = i_load + uint64_t(lane);
+            if (i > i_b) return kNever;
+            const uint64_t f = P.ooff[i] + i;
+            return (f >= run0 && f <= run1) ? int(f - run0) : kNever;   // (offsets out of order: reported elsewhere; nothing is marked)
+        };
+        int win = load_window();
+        uint64_t sm_n[2], em_n[2];   // the bitmaps of the step that is being prepared
+        auto prepare = [&](int base) {   // SM / EM of the chars [base, base + 128)
+            if (lane < 8) bits[lane] = 0;
+            __builtin_amdgcn_wave_barrier();
+            for (;;) {
+                if (win != kNever) {
+                    const int s = win - base, e = win - 1 - base;
+                    if (s >= 0 && s < 128 && i_load + uint64_t(lane) < i_b) atomicOr(&bits[s >> 5], 1u << (s & 31));
+                    if (e >= 0 && e < 128) atomicOr(&bits[4 + (e >> 5)], 1u << (e & 31));
+                }
+                // the window is used up when its last entry lies in front of the next step (an entry AT the next step's first char has
+                // marked the end in front of it here and marks its start there) -- as long as sentences are left
+                const int last = __builtin_amdgcn_readlane(win, 63);
+                if (last == kNever || last >= base + 128 || i_load + 64 > i_b) break;
+                i_load += 64;
+                win = load_window();
+            }
+            __builtin_amdgcn_wave_barrier();
+            sm_n[0] = uint64_t(wave_uniform(bits[0])) | (uint64_t(wave_uniform(bits[1])) << 32);
+            sm_n[1] = uint64_t(wave_uniform(bits[2])) | (uint64_t(wave_uniform(bits[3])) << 32);
+            em_n[0] = uint64_t(wave_uniform(bits[4])) | (uint64_t(wave_uniform(bits[5])) << 32);
+            em_n[1] = uint64_t(wave_uniform(bits[6])) | (uint64_t(wave_uniform(bits[7])) << 32);
+            __builtin_amdgcn_wave_barrier();
+        };
+        uint32_t cs_n = 0;   // sentence starts of the run in front of the step being prepared
+        uint32_t c_next[2], b_next[2];
+        auto fetch = [&](int base) {   // the prepared step's chars and labels (1 where a sentence ends, 0 past the run)
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int q = base + 64 * h + lane;
+                const bool in_run = q < n;
+                const uint32_t before = cs_n + (h ? uint32_t(__popcll(sm_n[0])) : 0u);
+                const uint64_t i = i_a + before + uint32_t(__popcll(sm_n[h] & upto_me)) - 1u;   // the char's sentence (the run starts with one: >= i_a)
+                uint64_t li = run0 + uint64_t(q) - i;
+                if (total_b != 0 && li >= total_b) li = total_b - 1;
+                const bool last = ((em_n[h] >> lane) & 1u) != 0;
+                c_next[h] = in_run ? cps[q] : 0u;
+                b_next[h] = !in_run ? 0u : (last || total_b == 0) ? 1u : uint32_t(P.labels[li]);
+            }
+        };
+        prepare(0);
+        fetch(0);
+        int start = 0;              // where the token that is open at the beginning of this step started
+        bool have_start = true;     // ... and no Unknown boundary has been seen inside it (predictor.rs:566-567)
+        uint64_t sm_prev = 0;       // SM of the half-step in front of the current one
+        for (int base = 0; base < n; base += 128) {
+            uint32_t c[2], b[2];
+            const uint64_t sm[2] = {sm_n[0], sm_n[1]}, em[2] = {em_n[0], em_n[1]};
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                c[h] = c_next[h]; b[h] = b_next[h];
+                L.txt[(base + 64 * h + lane) & (kRing - 1)] = c[h];
+            }
+            cs_n += uint32_t(__popcll(sm[0])) + uint32_t(__popcll(sm[1]));
+            if (base + 128 < n) { prepare(base + 128); fetch(base + 128); }
+            else { sm_n[0] = 0; }
+            uint64_t ends[2], unk[2];
+#pragma unroll
+            for (int h = 0; h < 2; ++h) { ends[h] = __ballot(b[h] == 1u); unk[h] = __ballot(b[h] == 2u); }
+            __builtin_amdgcn_wave_barrier();
+            // ---- (1) this lane's tokens, if its chars end one: [s0, p], valid when no Unknown lies inside.  Could they have a tag model?
+            int s0[2];
+            bool valid[2];
+            uint32_t fbit[2], fword[2];
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int hb = base + 64 * h;
+                const uint64_t prev_ends = ends[h] & below_me;
+                const int prev = prev_ends ? 63 - __clzll((long long)prev_ends) : -1;
+                s0[h] = prev >= 0 ? hb + prev + 1 : start;
+                const uint64_t after_prev = prev >= 0 ? ~((uint64_t(2) << prev) - 1) : ~uint64_t(0);
+                valid[h] = b[h] == 1u && (unk[h] & below_me & after_prev) == 0 && (prev >= 0 || have_start);
+                fbit[h] = valid[h] ? tag_filter_bit(P, cps, L.txt, base - 128, s0[h], hb + lane) : 0u;
+                // the token that stays open into the next half-step
+                if (ends[h]) {
+                    const int last = 63 - __clzll((long long)ends[h]);
+                    start = hb + last + 1;
+                    have_start = last == 63 || (unk[h] >> (last + 1)) == 0;
+                } else if (unk[h]) {
+                    have_start = false;
+                }
+            }
+#pragma unroll
+            for (int h = 0; h < 2; ++h) fword[h] = valid[h] ? P.tok_tab[(size_t(4) << P.tok_bits) + (fbit[h] >> 5)] : 0u;
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int p = base + 64 * h + lane;
+                const bool cand = valid[h] && ((fword[h] >> (fbit[h] & 31u)) & 1u) != 0;
+                // every char of the run gets its entries here or when its token has been looked up (nothing is cleared beforehand):
+                // 0 / None where no token with a tag model ends
+                if (p < n && !cand) {
+                    const uint64_t g = run0 + uint64_t(p);
+                    if (P.tok_model) P.tok_model[g] = 0;
+                    if (P.model_out) P.model_out[g] = -1;
+                    for (uint32_t j = 0; j < nt; ++j) P.tags[g * nt + j] = -1;
+                }
+                // ---- (2) the candidates wait for the token table together: 64 of them are a lookup with every lane busy
+                const uint64_t cmask = __ballot(cand);
+                if (cmask != 0) {
+                    // chars of the token's sentence in front of / behind its last char, clipped to the context: up to the nearest sentence
+                    // start at or in front of the char, up to the nearest sentence end at or behind it
+                    const uint64_t at_or_before = sm[h] & upto_me, pm = h ? sm[0] : sm_prev;
+                    const uint32_t back_full = at_or_before ? uint32_t(lane - (63 - __clzll((long long)at_or_before)))
+                                                            : pm ? uint32_t(lane + 1 + __clzll((long long)pm)) : 0xFFu;
+                    const uint64_t at_or_after = em[h] & ~below_me, nm = h ? (base + 128 < n ? em_n[0] : 0) : em[1];
+                    const uint32_t fwd_full = at_or_after ? uint32_t(__builtin_ctzll(at_or_after) - lane)
+                                                          : nm ? uint32_t(64 - lane + __builtin_ctzll(nm)) : 0xFFu;
+                    const uint32_t back = back_full < uint32_t(kCtxBack) ? back_full : uint32_t(kCtxBack);
+                    const uint32_t fwd = fwd_full < uint32_t(kCtx - 1 - kCtxBack) ? fwd_full : uint32_t(kCtx - 1 - kCtxBack);
+                    const uint32_t rank = uint32_t(__popcll(cmask & below_me));
+                    uint32_t remaining = uint32_t(__popcll(cmask)), done = 0;
+                    for (;;) {
+                        const uint32_t room = uint32_t(kTagCand) - nc, take = remaining < room ? remaining : room;
+                        if (cand && rank >= done && rank < done + take) {
+                            const uint32_t row = nc + rank - done;
+                            const uint64_t gp = run0 + uint64_t(p);
+                            L.cand[row][0] = uint32_t(gp); L.cand[row][1] = uint32_t(gp >> 32); L.cand[row][2] = uint32_t(p - s0[h] + 1); L.cand[row][3] = back | (fwd << 8);
+                        }
+                        nc += take; done += take; remaining -= take;
+                        if (nc != uint32_t(kTagCand)) break;
+                        tag_resolve<true>(P, L, nullptr, nc, nq, false, lane, 0u);
+                        nc = 0;
+                        if (!remaining) break;
+                    }
+                }
+            }
+            sm_prev = sm[1];
+            __builtin_amdgcn_wave_barrier();   // the ring is written by the next step
+        }
+    }
+    if (nc != 0) tag_resolve<true>(P, L, nullptr, nc, nq, true, lane, 0u);
+}
+
 }  // namespace
 
 hipError_t launch_decode_chars(const uint8_t* text, const uint64_t* boff, const uint64_t* ooff, uint64_t n_sent, uint64_t total_chars,
@@ -875,7 +1056,15 @@ hipError_t launch_tag_tokens(const TagParams& P, hipStream_t stream) {
     if (P.queue && !dbg) {   // the pair, then the one-launch kernel for the case that the queue overflowed (it returns at once otherwise)
         const hipError_t e = hipMemsetAsync(P.qctl, 0, 3 * sizeof(uint32_t), stream);
         if (e != hipSuccess) return e;
-        hipLaunchKernelGGL((tag_tokens_kernel<false, true>), dim3(blocks), dim3(kTagThreads), 0, stream, P, 0u);
+        if (P.front_by_sentence) hipLaunchKernelGGL((tag_tokens_kernel<false, true>), dim3(blocks), dim3(kTagThreads), 0, stream, P, 0u);
+        else {
+            // runs of about 2 K chars (16 steps), at least a sentence: enough runs for every wave of the grid to even out, a window of offsets every
+            // few steps (measured on configs[4], profiles/r04_o_tag_front.jsonl: runs of 2 K / 4 K / 16 K chars 1.761 / 1.781 / 1.970 ms stand-alone)
+            const uint64_t per = std::max<uint64_t>(1, (uint64_t(2048) * P.n_sent + P.total_chars / 2) / std::max<uint64_t>(P.total_chars, 1));
+            const uint64_t runs = (P.n_sent + per - 1) / per, want_f = (runs + kTagWaves - 1) / kTagWaves;
+            const uint32_t blocks_f = uint32_t(want_f < 1 ? 1 : want_f > cap ? cap : want_f);
+            hipLaunchKernelGGL(tag_front_flat_kernel, dim3(blocks_f), dim3(kTagThreads), 0, stream, P, uint32_t(std::min<uint64_t>(per, 0x7FFFFFFFull)));
+        }
         hipLaunchKernelGGL(tag_pass_kernel, dim3(blocks), dim3(kTagThreads), 0, stream, P);
         hipLaunchKernelGGL((tag_tokens_kernel<false, false>), dim3(blocks), dim3(kTagThreads), 0, stream, P, 0u);
         return hipGetLastError();
