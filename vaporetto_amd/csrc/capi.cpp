@@ -59,7 +59,6 @@ struct BatchKnobs {
     uint32_t debug_ablate = 0;          // VPT_DEBUG_ABLATE
     bool profile_phases = false;        // VPT_PROFILE_PHASES
     bool emit_no_prefix = false;        // VPT_DEBUG_EMIT_NO_PREFIX: the fused writer's tiles publish sizes only (tests: every look-back walks to the front)
-    bool tag_front_by_sentence = false; // VPT_TAG_FRONT_BY_SENTENCE: the front-end launch of the pair as a wave per sentence (A/B of the flat walk)
     int tag_split = 0;                  // VPT_TAG_SPLIT: 1 = fill_tags always as two launches (step loop -> queue in HBM -> passes), -1 = never (default: batches of 256 K chars and more)
     uint32_t tag_queue = 0;             // VPT_TAG_QUEUE: entries of that queue (tests: overflow; default: an eighth of the batch's chars + 64 K)
     uint32_t debug_emit = 0;            // VPT_DEBUG_EMIT
@@ -84,7 +83,6 @@ BatchKnobs read_batch_knobs() {
     if (const char* v = std::getenv("VPT_FORCE_CUT_TILES")) k.force_cut = std::atoi(v);
     if (const char* v = std::getenv("VPT_TILE_FLAT")) k.tile_flat = uint32_t(std::max(0, std::atoi(v)));
     if (const char* v = std::getenv("VPT_TAG_SPLIT")) k.tag_split = std::atoi(v);
-    k.tag_front_by_sentence = std::getenv("VPT_TAG_FRONT_BY_SENTENCE") != nullptr;
     if (const char* v = std::getenv("VPT_TAG_QUEUE")) k.tag_queue = uint32_t(std::max(0, std::atoi(v)));
     if (const char* v = std::getenv("VPT_DEBUG_EMIT")) k.debug_emit = uint32_t(std::max(0, std::atoi(v)));
     if (const char* v = std::getenv("VPT_EMIT_PER_BLOCK")) k.emit_per_block = uint32_t(std::min(64, std::max(0, std::atoi(v))));
@@ -1588,7 +1586,6 @@ vpt_status vpt_fill_tags_scores_batch_device(const vpt_predictor* p, vpt_batch* 
         T.queue = b->d_tag_queue + 1; T.qctl = reinterpret_cast<uint32_t*>(b->d_tag_queue);
         T.queue_slow = std::max<uint32_t>(entries / 8, 1u); T.queue_fast = entries - T.queue_slow;
     }
-    T.front_by_sentence = b->knobs.tag_front_by_sentence ? 1u : 0u;
     VPT_HIP(vpt::launch_tag_tokens(T, stream));
     b->last_stream = stream; b->pending = true;
     return VPT_OK;
