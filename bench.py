@@ -333,7 +333,7 @@ class Runner:
             lab = d_labels[:nb].cpu().numpy()
             n_tokens = int((lab == 1).sum()) + S
             tags_info = {"ms_per_step": 1e3 * dt, "tokens_per_s": n_tokens / dt, "chars_per_s": (nb + S) / dt, "n_tags": nt,
-                         "kernels": "decode_chars_kernel + tag_tokens_kernel (step loop) + tag_pass_kernel on the predicted labels"}
+                         "kernels": "decode_chars_kernel + tag_front_flat_kernel (runs of sentences as consecutive chars) + tag_pass_kernel on the predicted labels"}
 
         # ---- token emission on the labels just predicted (Sentence::write_tokenized_text, with "/tag" suffixes for tag models)
         emit_info, emit_out = None, None
