@@ -2,7 +2,9 @@
 // Never linked into libvaporetto_hip.so and never loaded by the vaporetto_amd package.
 #include <map>
 #include <mutex>
+#if !defined(__x86_64__)
 #include <ucontext.h>
+#endif
 
 #include <cstdio>
 #include <cstdlib>
@@ -24,8 +26,24 @@ constexpr size_t kRedZone = 256;          // bytes of poison on either side of e
 constexpr unsigned char kPoison = 0xCB;
 constexpr size_t kMaxLds = 160 << 10;
 
+// A fiber switch is the callee-saved registers and the stack pointer: swapcontext also saves the signal mask -- two system calls per
+// switch, a third of the emulated suite's time -- so on x86-64 the switch is these fourteen instructions (ucontext elsewhere).
+#if defined(__x86_64__)
+struct Context { void* sp = nullptr; };
+__attribute__((naked, noinline)) void switch_context(void** /* save the running stack pointer here: rdi */, void* /* and continue on this one: rsi */) {
+    asm volatile(
+        "pushq %rbp\n\tpushq %rbx\n\tpushq %r12\n\tpushq %r13\n\tpushq %r14\n\tpushq %r15\n\t"
+        "movq %rsp, (%rdi)\n\t"
+        "movq %rsi, %rsp\n\t"
+        "popq %r15\n\tpopq %r14\n\tpopq %r13\n\tpopq %r12\n\tpopq %rbx\n\tpopq %rbp\n\t"
+        "ret\n\t");
+}
+#else
+struct Context { ucontext_t uc; };
+#endif
+
 struct Fiber {
-    ucontext_t ctx;
+    Context ctx;
     unsigned tid = 0;
     bool done = false;
 };
@@ -48,7 +66,7 @@ struct Wave : Group {
 };
 
 std::recursive_mutex g_mu;        // one grid at a time
-ucontext_t g_sched;
+Context g_sched;
 std::vector<Fiber> g_fibers;
 std::unique_ptr<char[]> g_stacks;   // not touched until used
 std::vector<Wave> g_waves;
@@ -66,9 +84,17 @@ uint32_t g_garbage = 0x9E3779B9u;
     std::abort();
 }
 
+void switch_to(Context& from, Context& to) {
+#if defined(__x86_64__)
+    switch_context(&from.sp, to.sp);
+#else
+    swapcontext(&from.uc, &to.uc);
+#endif
+}
+
 void yield() {
     Fiber* me = g_cur;
-    swapcontext(&me->ctx, &g_sched);
+    switch_to(me->ctx, g_sched);
 }
 
 void release_if_complete(Group& g) {
@@ -98,7 +124,28 @@ void fiber_main() {
     release_if_complete(w);       // the hardware barrier counts only the waves (lanes) that are still running
     --g_block.live;
     release_if_complete(g_block);
-    // returning switches to uc_link = the scheduler
+#if defined(__x86_64__)
+    switch_to(me->ctx, g_sched);   // for good: a finished fiber is not resumed
+    std::abort();
+#endif
+    // (ucontext) returning switches to uc_link = the scheduler
+}
+
+void prepare_fiber(Fiber& f, char* stack, size_t bytes) {
+#if defined(__x86_64__)
+    // what switch_context pops on the first switch: six registers, then `ret` into fiber_main with the stack as after a call
+    void** top = reinterpret_cast<void**>((reinterpret_cast<uintptr_t>(stack) + bytes) & ~uintptr_t(15)) - 2;   // 16-byte aligned slot of the entry address
+    top[0] = reinterpret_cast<void*>(&fiber_main);
+    top[1] = nullptr;                                                                                            // fiber_main's return address: never used
+    for (int k = 1; k <= 6; ++k) top[-k] = nullptr;
+    f.ctx.sp = top - 6;
+#else
+    getcontext(&f.ctx.uc);
+    f.ctx.uc.uc_stack.ss_sp = stack;
+    f.ctx.uc.uc_stack.ss_size = bytes;
+    f.ctx.uc.uc_link = &g_sched.uc;
+    makecontext(&f.ctx.uc, fiber_main, 0);
+#endif
 }
 
 }  // namespace
@@ -203,11 +250,7 @@ void run_grid(dim3 grid, dim3 block, size_t lds_bytes, const std::function<void(
             Fiber& f = g_fibers[t];
             f.tid = t;
             f.done = false;
-            getcontext(&f.ctx);
-            f.ctx.uc_stack.ss_sp = g_stacks.get() + size_t(t) * kStackBytes;
-            f.ctx.uc_stack.ss_size = kStackBytes;
-            f.ctx.uc_link = &g_sched;
-            makecontext(&f.ctx, fiber_main, 0);
+            prepare_fiber(f, g_stacks.get() + size_t(t) * kStackBytes, kStackBytes);
         }
         unsigned left = n;
         while (left > 0) {
@@ -219,7 +262,7 @@ void run_grid(dim3 grid, dim3 block, size_t lds_bytes, const std::function<void(
                 if (f.done) continue;
                 g_cur = &f;
                 g_threadIdx = Idx{t, 0, 0};
-                swapcontext(&g_sched, &f.ctx);
+                switch_to(g_sched, f.ctx);
                 if (!f.done) ++left;
             }
             g_cur = nullptr;
