@@ -1718,20 +1718,14 @@ def test_compiled_predictor_rejects_damaged_blobs():
 
 
 # ------------------------------------------------------------------------------------------------ host-buffer pipeline, shards
-@pytest.mark.parametrize("chunk_chars,pinned,lanes", [("700", False, "0"), ("2500", True, "0"), ("700", True, "4"), ("2500", False, "3"), ("1500", True, "8"),
-                                                      ("700", True, "duplex"), ("2500", False, "duplex"), ("40000", True, "duplex")])
+@pytest.mark.parametrize("chunk_chars,pinned,lanes", [("700", False, "0"), ("2500", True, "0"), ("700", True, "4"), ("2500", False, "3"), ("1500", True, "8")])
 def test_pipelined_host_path_matches_oracle(chunk_chars, pinned, lanes, monkeypatch):
     """vpt_predict_batch cuts a large batch into chunks and overlaps copy in / kernels / copy out -- on three streams with events
-    (VPT_PIPE_LANES=0: what batches over 16 M chars take), chunk by chunk over several independent lanes, or with a stream per direction of
-    the link and nothing the host waits for (VPT_PIPE_DUPLEX=1); with VPT_CHUNK_CHARS tiny, a 1 000-sentence batch goes through dozens of
-    chunks, ragged sizes, every buffer set, pinned and pageable caller buffers -- scores identical to the oracle's, device-side errors
-    still reported."""
+    (VPT_PIPE_LANES=0: what batches over 16 M chars take) or chunk by chunk over several independent lanes (what smaller ones
+    take); with VPT_CHUNK_CHARS tiny, a 1 000-sentence batch goes through dozens of chunks, ragged sizes, every buffer set, pinned
+    and pageable caller buffers -- scores identical to the oracle's, device-side errors still reported."""
     monkeypatch.setenv("VPT_CHUNK_CHARS", chunk_chars)
-    if lanes == "duplex":
-        monkeypatch.setenv("VPT_PIPE_DUPLEX", "1")
-    else:
-        monkeypatch.setenv("VPT_PIPE_DUPLEX", "0")
-        monkeypatch.setenv("VPT_PIPE_LANES", lanes)
+    monkeypatch.setenv("VPT_PIPE_LANES", lanes)
     m = randmodel.rand_model(777, alphabet="kana", wc=3, wt=3, n_char=200, n_dict=200, max_word=8)
     raw = encode_model(m)
     pred, orc = make_predictor(raw)
@@ -1766,11 +1760,10 @@ def test_labels_only_and_packed_tokenize_through_the_host_path(monkeypatch):
     texts = randmodel.rand_sentences(12, m, 700, alphabet="kana", max_len=70)
     utf8, boff = api.pack_texts([t.encode("utf-8") for t in texts])
     o_scores, o_labels, o_ooff, _ = orc.predict_batch(utf8, boff, nthreads=4)
-    for chunk, lanes in ((None, None), ("900", "4"), ("900", "0"), ("900", "duplex")):
+    for chunk, lanes in ((None, None), ("900", "4"), ("900", "0")):
         if chunk:
             monkeypatch.setenv("VPT_CHUNK_CHARS", chunk)
-            monkeypatch.setenv("VPT_PIPE_DUPLEX", "1" if lanes == "duplex" else "0")
-            monkeypatch.setenv("VPT_PIPE_LANES", "4" if lanes == "duplex" else lanes)
+            monkeypatch.setenv("VPT_PIPE_LANES", lanes)
             pred, _ = make_predictor(raw)      # the library reads its knobs when a predictor is made, never on the launch path
         scores, labels, ooff = api.predict_packed_sharded([pred], utf8, boff, want_scores=False)
         assert scores is None and np.array_equal(labels, o_labels) and np.array_equal(ooff, o_ooff)

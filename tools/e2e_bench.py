@@ -50,4 +50,4 @@ ok = bool(np.array_equal(keep[2].array[:nb], np.tile(ref_labels, R)) and (args.l
 bytes_in, bytes_out = len(utf8) + 16 * (S + 1), (1 if args.labels_only else 5) * nb
 print(json.dumps({"sentences": S, "labels_only": args.labels_only, "ms_per_batch": round(1e3 * dt, 4), "ms_min": round(1e3 * min(ts), 4),
                   "G_boundaries_per_s": round(nb / dt / 1e9, 3), "h2d_GBps": round(bytes_in / dt / 1e9, 2), "d2h_GBps": round(bytes_out / dt / 1e9, 2),
-                  "parity": ok, "env": {k: v for k, v in os.environ.items() if k.startswith("VPT_CHUNK") or k.startswith("VPT_PIPE")}}))
+                  "parity": ok, "env": {k: v for k, v in os.environ.items() if k.startswith("VPT_CHUNK")}}))

@@ -43,7 +43,6 @@ struct PredictorKnobs {
     bool force_window_table = false;    // VPT_FORCE_WINDOW_TABLE: the 8^(2W) type table instead of the type rows
     uint32_t lds_pad = 0;               // VPT_DEBUG_LDS_PAD: occupancy experiments
     int pipe_lanes = -1;                // VPT_PIPE_LANES (-1: the size rule)
-    int pipe_duplex = -1;               // VPT_PIPE_DUPLEX: 1 = chunks over one stream per DIRECTION of the link and one for the kernels, 0 = never (-1: the size rule)
     uint64_t chunk_chars = 0;           // VPT_CHUNK_CHARS (0: the size rule)
     uint64_t tokenize_chunk_bytes = uint64_t(256) << 20;   // VPT_TOKENIZE_CHUNK_BYTES (the tagged pipeline's default; the fused one: an eighth of the batch, at least 4 MB)
     bool tokenize_chunk_bytes_set = false;
@@ -60,7 +59,6 @@ struct BatchKnobs {
     uint32_t debug_ablate = 0;          // VPT_DEBUG_ABLATE
     bool profile_phases = false;        // VPT_PROFILE_PHASES
     bool emit_no_prefix = false;        // VPT_DEBUG_EMIT_NO_PREFIX: the fused writer's tiles publish sizes only (tests: every look-back walks to the front)
-    bool tag_front_by_sentence = false; // VPT_TAG_FRONT_BY_SENTENCE: the front-end launch of the pair as a wave per sentence (A/B of the flat walk)
     int tag_split = 0;                  // VPT_TAG_SPLIT: 1 = fill_tags always as two launches (step loop -> queue in HBM -> passes), -1 = never (default: batches of 256 K chars and more)
     uint32_t tag_queue = 0;             // VPT_TAG_QUEUE: entries of that queue (tests: overflow; default: an eighth of the batch's chars + 64 K)
     uint32_t debug_emit = 0;            // VPT_DEBUG_EMIT
@@ -71,7 +69,6 @@ PredictorKnobs read_predictor_knobs() {
     k.force_window_table = std::getenv("VPT_FORCE_WINDOW_TABLE") != nullptr;
     if (const char* v = std::getenv("VPT_DEBUG_LDS_PAD")) k.lds_pad = uint32_t(std::max(0, std::atoi(v)));
     if (const char* v = std::getenv("VPT_PIPE_LANES")) k.pipe_lanes = std::max(0, std::atoi(v));
-    if (const char* v = std::getenv("VPT_PIPE_DUPLEX")) k.pipe_duplex = std::atoi(v) != 0 ? 1 : 0;
     if (const char* v = std::getenv("VPT_CHUNK_CHARS")) { const long long n = std::atoll(v); if (n > 0) k.chunk_chars = uint64_t(n); }
     if (const char* v = std::getenv("VPT_TOKENIZE_CHUNK_BYTES")) { const long long n = std::atoll(v); if (n > 0) { k.tokenize_chunk_bytes = uint64_t(n); k.tokenize_chunk_bytes_set = true; } }
     if (const char* v = std::getenv("VPT_TAG_WGS_PER_CU")) k.tag_wgs_per_cu = std::atoi(v);
@@ -86,7 +83,6 @@ BatchKnobs read_batch_knobs() {
     if (const char* v = std::getenv("VPT_FORCE_CUT_TILES")) k.force_cut = std::atoi(v);
     if (const char* v = std::getenv("VPT_TILE_FLAT")) k.tile_flat = uint32_t(std::max(0, std::atoi(v)));
     if (const char* v = std::getenv("VPT_TAG_SPLIT")) k.tag_split = std::atoi(v);
-    k.tag_front_by_sentence = std::getenv("VPT_TAG_FRONT_BY_SENTENCE") != nullptr;
     if (const char* v = std::getenv("VPT_TAG_QUEUE")) k.tag_queue = uint32_t(std::max(0, std::atoi(v)));
     if (const char* v = std::getenv("VPT_DEBUG_EMIT")) k.debug_emit = uint32_t(std::max(0, std::atoi(v)));
     if (const char* v = std::getenv("VPT_EMIT_PER_BLOCK")) k.emit_per_block = uint32_t(std::min(64, std::max(0, std::atoi(v))));
@@ -1268,13 +1264,12 @@ namespace {
 //   more                         predict_pipelined: three streams and events, 4 M-char chunks: 6.9 .. 8.1 ms per 64 M chars, steadier over
 //                                many chunks than the lanes, whose copies contend (7.3 .. 10 ms)
 // VPT_CHUNK_CHARS / VPT_PIPE_LANES (0 = the event pipeline) override; the tests use them to cut small batches into many chunks.
-struct PipePlan { int lanes; uint64_t chunk; bool pipelined; bool duplex; };
+struct PipePlan { int lanes; uint64_t chunk; bool pipelined; };
 PipePlan pipeline_plan(const PredictorKnobs& knobs, uint64_t total_chars) {
-    PipePlan plan = total_chars <= (uint64_t(16) << 20) ? PipePlan{4, uint64_t(512) << 10, false, false} : PipePlan{0, uint64_t(4) << 20, false, false};
+    PipePlan plan = total_chars <= (uint64_t(16) << 20) ? PipePlan{4, uint64_t(512) << 10, false} : PipePlan{0, uint64_t(4) << 20, false};
     if (knobs.pipe_lanes >= 0) plan.lanes = knobs.pipe_lanes;
     if (knobs.chunk_chars) plan.chunk = knobs.chunk_chars;
-    plan.duplex = knobs.pipe_duplex > 0;
-    plan.pipelined = total_chars > (plan.lanes > 0 || plan.duplex ? 3 * plan.chunk : plan.chunk + plan.chunk / 2);
+    plan.pipelined = total_chars > (plan.lanes > 0 ? 3 * plan.chunk : plan.chunk + plan.chunk / 2);
     return plan;
 }
 
@@ -1349,96 +1344,6 @@ vpt_status predict_pipelined(const vpt_predictor* p, vpt_batch* b, const uint8_t
         if (scores_out && nb) VPT_HIP(hipMemcpyAsync(scores_out + o0, ps.scores, 4 * size_t(nb), hipMemcpyDeviceToHost, b->s_out));
         if (labels_out && nb) VPT_HIP(hipMemcpyAsync(labels_out + o0, ps.labels, size_t(nb), hipMemcpyDeviceToHost, b->s_out));
         VPT_HIP(hipEventRecord(ps.ev_out, b->s_out));
-    }
-    VPT_HIP(hipStreamSynchronize(b->s_in));
-    VPT_HIP(hipStreamSynchronize(b->s_out));
-    return vpt_batch_sync(b);   // the device's verdict over every chunk (the status word accumulates)
-}
-
-// vpt_predict_batch with one stream per DIRECTION of the link and one for the kernels, everything enqueued without a wait of the host: the
-// copies in follow each other on their stream, a chunk's kernels wait for its copy in, its copies out -- on THEIR stream -- for its kernels.
-// The batch's device buffers hold all of it (no set is reused: nothing waits for a copy out), the chunks' offsets are rebased into pinned
-// staging as in predict_lanes.  Why: a device-timestamp trace of predict_lanes (round 4) shows a lane's copies in and out going through ONE
-// copy engine in enqueue order and two lanes sharing an engine -- chunk 3's copy in completes behind chunk 1's copy out -- where a stream
-// per direction keeps both directions of the link busy from the second chunk on.
-vpt_status predict_duplex(const vpt_predictor* p, vpt_batch* b, const uint8_t* utf8, const uint64_t* byte_offsets, size_t n_sentences,
-                          int32_t* scores_out, uint8_t* labels_out, const uint64_t* out_offsets, uint64_t chunk_chars) {
-    if (!b->s_in) {
-        VPT_HIP(hipStreamCreateWithFlags(&b->s_in, hipStreamNonBlocking));
-        VPT_HIP(hipStreamCreateWithFlags(&b->s_out, hipStreamNonBlocking));
-        for (auto& ps : b->pipe) {
-            VPT_HIP(hipEventCreateWithFlags(&ps.ev_in, hipEventDisableTiming));
-            VPT_HIP(hipEventCreateWithFlags(&ps.ev_k, hipEventDisableTiming));
-            VPT_HIP(hipEventCreateWithFlags(&ps.ev_out, hipEventDisableTiming));
-        }
-    }
-    const uint64_t t_first = byte_offsets[0], o_first = out_offsets[0];
-    const uint64_t total_chars = out_offsets[n_sentences] - o_first + n_sentences, total_b = out_offsets[n_sentences] - o_first;
-    const size_t nbytes = size_t(byte_offsets[n_sentences] - t_first);
-    const size_t max_chunks = std::min<size_t>(n_sentences, size_t(total_chars / chunk_chars) + 2);   // every chunk holds a sentence
-    const size_t need_off = 2 * (n_sentences + max_chunks);   // a chunk of n sentences stages 2 (n + 1) offsets
-    if (need_off > b->h_off_cap) {
-        if (b->h_off) (void)hipHostFree(b->h_off);
-        b->h_off = nullptr; b->h_off_cap = 0;
-        VPT_HIP(hipHostMalloc(reinterpret_cast<void**>(&b->h_off), (need_off + need_off / 2) * sizeof(uint64_t), hipHostMallocDefault));
-        b->h_off_cap = need_off + need_off / 2;
-    }
-    vpt_status st;
-    while (b->chunk_ev.size() < 2 * max_chunks) {   // per chunk: copied in, scored
-        hipEvent_t e;
-        VPT_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-        b->chunk_ev.push_back(e);
-    }
-    if ((st = grow(&b->d_text, &b->text_cap, nbytes + 32)) != VPT_OK) return st;
-    if ((st = grow(&b->pipe[0].off, &b->pipe[0].off_cap, need_off)) != VPT_OK) return st;
-    if (scores_out || labels_out) {
-        size_t cap = b->out_cap;
-        if ((st = grow(&b->d_scores, &cap, size_t(total_b) + 1)) != VPT_OK) return st;
-        size_t cap2 = b->out_cap;
-        if ((st = grow(&b->d_labels, &cap2, size_t(total_b) + 1)) != VPT_OK) return st;
-        b->out_cap = std::min(cap, cap2);
-    }
-    b->cps_text = nullptr;   // d_text is rewritten
-    uint64_t* const d_off = b->pipe[0].off;
-    hipStream_t s = b->own_stream;
-    size_t i = 0, staged = 0;
-    for (size_t k = 0; i < n_sentences; ++k) {
-        // ---- walk the chunk's sentences: validate, rebase, cut
-        const size_t a = i;
-        const uint64_t t0 = byte_offsets[a], o0 = out_offsets[a];
-        uint64_t* hb = b->h_off + staged;             // n + 1 byte offsets, then n + 1 boundary offsets
-        uint64_t chars = 0, max_bytes = 0, max_chars = 0;
-        while (i < n_sentences && (chars < chunk_chars || k + 1 >= max_chunks)) {
-            if (byte_offsets[i + 1] <= byte_offsets[i]) return fail(VPT_INVALID_ARGUMENT, "InvalidArgumentError: text: must contain at least one character");
-            const uint64_t nby = byte_offsets[i + 1] - byte_offsets[i];
-            if (out_offsets[i + 1] < out_offsets[i] || out_offsets[i + 1] - out_offsets[i] + 1 > nby)
-                return fail(VPT_INVALID_ARGUMENT, "InvalidArgumentError: out_offsets: do not match the text (or the text is not valid UTF-8)");
-            const uint64_t nch = out_offsets[i + 1] - out_offsets[i] + 1;
-            max_bytes = std::max(max_bytes, nby); max_chars = std::max(max_chars, nch);
-            chars += nch;
-            ++i;
-        }
-        const size_t n = i - a;
-        uint64_t* ho = hb + (n + 1);
-        for (size_t j = 0; j <= n; ++j) { hb[j] = byte_offsets[a + j] - t0; ho[j] = out_offsets[a + j] - o0; }
-        const uint64_t cb = byte_offsets[i] - t0, nb = out_offsets[i] - o0;
-        uint8_t* const d_text_k = b->d_text + (t0 - t_first);
-        uint64_t* const d_off_k = d_off + staged;
-        staged += 2 * (n + 1);
-        VPT_HIP(hipMemcpyAsync(d_text_k, utf8 + t0, size_t(cb), hipMemcpyHostToDevice, b->s_in));
-        VPT_HIP(hipMemcpyAsync(d_off_k, hb, 16 * (n + 1), hipMemcpyHostToDevice, b->s_in));
-        VPT_HIP(hipEventRecord(b->chunk_ev[2 * k], b->s_in));
-        VPT_HIP(hipStreamWaitEvent(s, b->chunk_ev[2 * k], 0));
-        b->max_chars = max_chars;
-        int32_t* const d_scores_k = scores_out ? b->d_scores + (o0 - o_first) : nullptr;
-        uint8_t* const d_labels_k = labels_out ? b->d_labels + (o0 - o_first) : nullptr;
-        st = vpt_predict_batch_device(p, b, d_text_k, d_off_k, d_off_k + (n + 1), n, nb, max_bytes, d_scores_k, d_labels_k, s);
-        if (st != VPT_OK) return st;
-        b->cps_text = nullptr;   // (the chars a tag-enabled predictor leaves belong to this chunk only)
-        VPT_HIP(hipEventRecord(b->chunk_ev[2 * k + 1], s));
-        VPT_HIP(hipStreamWaitEvent(b->s_out, b->chunk_ev[2 * k + 1], 0));
-        if (scores_out && nb) VPT_HIP(hipMemcpyAsync(scores_out + o0, d_scores_k, 4 * size_t(nb), hipMemcpyDeviceToHost, b->s_out));
-        if (labels_out && nb) VPT_HIP(hipMemcpyAsync(labels_out + o0, d_labels_k, size_t(nb), hipMemcpyDeviceToHost, b->s_out));
     }
     VPT_HIP(hipStreamSynchronize(b->s_in));
     VPT_HIP(hipStreamSynchronize(b->s_out));
@@ -1550,7 +1455,6 @@ vpt_status vpt_predict_batch_flags(const vpt_predictor* p, const uint8_t* utf8, 
     b->flags = flags;
     if (byte_offsets[n_sentences] >= byte_offsets[0] && out_offsets[n_sentences] >= out_offsets[0]) {   // a batch of several chunks goes through a copy/compute pipeline
         const PipePlan plan = pipeline_plan(p->knobs, out_offsets[n_sentences] - out_offsets[0] + n_sentences);
-        if (plan.pipelined && plan.duplex) return predict_duplex(p, b, utf8, byte_offsets, n_sentences, scores_out, labels_out, out_offsets, plan.chunk);
         if (plan.pipelined && plan.lanes > 0) return predict_lanes(p, b, utf8, byte_offsets, n_sentences, scores_out, labels_out, out_offsets, plan.chunk, plan.lanes);
         if (plan.pipelined) return predict_pipelined(p, b, utf8, byte_offsets, n_sentences, scores_out, labels_out, out_offsets, plan.chunk);
     }
@@ -1682,7 +1586,6 @@ vpt_status vpt_fill_tags_scores_batch_device(const vpt_predictor* p, vpt_batch* 
         T.queue = b->d_tag_queue + 1; T.qctl = reinterpret_cast<uint32_t*>(b->d_tag_queue);
         T.queue_slow = std::max<uint32_t>(entries / 8, 1u); T.queue_fast = entries - T.queue_slow;
     }
-    T.front_by_sentence = b->knobs.tag_front_by_sentence ? 1u : 0u;
     VPT_HIP(vpt::launch_tag_tokens(T, stream));
     b->last_stream = stream; b->pending = true;
     return VPT_OK;
