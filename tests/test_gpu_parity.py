@@ -1751,6 +1751,44 @@ def test_pipelined_host_path_matches_oracle(chunk_chars, pinned, lanes, monkeypa
     assert "NULL" in str(e.value)
 
 
+def test_tokenize_with_the_grapheme_cluster_filter():
+    """`--wsconst G` of the CLI (predict/src/main.rs:101-104): Predictor.tokenize(.., wsconst=("G", ..)) = predict, ConcatGraphemeClustersFilter on
+    the host, [fill_tags,] writer -- line for line what the per-sentence mirror gives, with and without the char-type filter, tags and
+    the fullwidth normalisation beside it; and a ZWJ sequence the model wants to cut stays whole."""
+    m = randmodel.rand_model(9300, alphabet="kana", wc=3, wt=3, n_char=80, n_dict=60, max_word=5, n_tag_models=8)
+    m.bias = 5000                                  # a model that cuts everywhere it can
+    raw = encode_model(m)
+    rng = np.random.default_rng(11)
+    alphabet = randmodel.ALPHABETS["kana"][:10] + list("ab12 ") + ["\u0301", "\u200d", "\U0001f468", "\U0001f469", "\U0001f3fd", "\U0001f44f", "\u3099"]
+    texts = ["".join(rng.choice(alphabet, size=int(n))) for n in rng.integers(1, 50, 200)] + ["\U0001f468\u200d\U0001f469\u200d\U0001f466", "a", "\u200d"]
+    f = api.ConcatGraphemeClustersFilter()
+    for tagged in (False, True):
+        pred = api.Predictor(api.Model.read_slice(raw)[0], tagged)
+        for fullwidth, types in ((False, ()), (True, (int(api.CharacterType.Roman),)), (False, (int(api.CharacterType.Digit), int(api.CharacterType.Kanji)))):
+            got = pred.tokenize(texts, tagged=tagged, fullwidth=fullwidth, wsconst=("G",) + types)
+            plain = pred.tokenize(texts, tagged=tagged, fullwidth=fullwidth, wsconst=types)
+            norm = api.KyteaFullwidthFilter()
+            sents = [api.Sentence.from_raw(norm.filter(t) if fullwidth else t) for t in texts]
+            pred.predict_batch(sents)
+            for s in sents:
+                for ty in types:      # KyteaWsConstFilter (vaporetto_rules/src/sentence_filters/kytea_wsconst.rs): no boundary between two chars of the type
+                    ct = s.char_types()
+                    b = s.boundaries_mut()
+                    b[(ct[:-1] == ty) & (ct[1:] == ty)] = api.CharacterBoundary.NotWordBoundary
+                f.filter(s)
+            if tagged:
+                pred.fill_tags_batch(sents)
+            want = []
+            for t, s in zip(texts, sents):      # the CLI writes the ORIGINAL line with the normalised sentence's boundaries and tags (main.rs:158-163)
+                o = api.Sentence.from_raw(t)
+                o.boundaries_mut()[:] = s.boundaries()
+                o._tags, o._n_tags = s._tags, s._n_tags
+                want.append(o.write_tokenized_text())
+            assert got == want
+            assert any(a != b for a, b in zip(got, plain))      # the filter did something
+        assert " " not in pred.tokenize(["\U0001f468\u200d\U0001f469\u200d\U0001f466"], wsconst=("G",))[0]
+
+
 def test_labels_only_and_packed_tokenize_through_the_host_path(monkeypatch):
     """scores_out = NULL (a tokenizer only needs the labels; 4 of the 5 bytes per boundary stay on the device) gives the same
     labels one-shot, through the lanes and through the event pipeline; tokenize_packed returns what tokenize returns."""

@@ -93,6 +93,47 @@ class KyteaFullwidthFilter:
         return string.translate(self.table())
 
 
+class ConcatGraphemeClustersFilter:
+    """vaporetto_rules/src/sentence_filters/concat_grapheme_clusters.rs:10-36 (the CLI's `--wsconst G`, predict/src/main.rs:101-104): a
+    sentence filter that runs on the HOST between predict and fill_tags -- every boundary inside an extended grapheme cluster (UAX #29)
+    becomes NotWordBoundary, so a ZWJ sequence or a base + modifier is never cut.  The reference segments with the `unicode-segmentation`
+    crate (1.12.0); here the clusters come from the `regex` module's \\X, whichever Unicode version that module carries (the crate's and
+    the module's rules agree on everything the reference's tests hold: concat_grapheme_clusters.rs:43-88).  Like the char-type filters it
+    only clears boundaries and looks at nothing but the text, so its place among the post-filters does not matter."""
+
+    _X = None
+
+    @classmethod
+    def cluster_lengths(cls, text: str) -> List[int]:
+        """Chars of every extended grapheme cluster of `text`, in order."""
+        if cls._X is None:
+            try:
+                import regex
+            except ImportError as e:   # no silent "one char per cluster"
+                raise ImportError("ConcatGraphemeClustersFilter needs the `regex` module (UAX #29 segmentation)") from e
+            cls._X = regex.compile(r"\X")
+        return [len(m.group()) for m in cls._X.finditer(text)]
+
+    def filter(self, sentence: "Sentence") -> None:
+        b = sentence.boundaries_mut()
+        start = 0
+        for n in self.cluster_lengths(sentence.as_raw_text()):
+            b[start:start + n - 1] = CharacterBoundary.NotWordBoundary
+            start += n
+
+    def filter_packed(self, texts: Sequence[str], out_offsets: np.ndarray, labels: np.ndarray) -> None:
+        """The same on a packed batch's labels (sentence i's boundaries are labels[out_offsets[i]:out_offsets[i + 1]]), in place."""
+        for i, t in enumerate(texts):
+            if t.isascii():      # a cluster of several ASCII chars is CR LF only
+                if "\r\n" not in t:
+                    continue
+            start = int(out_offsets[i])
+            for n in self.cluster_lengths(t):
+                if n > 1:
+                    labels[start:start + n - 1] = CharacterBoundary.NotWordBoundary
+                start += n
+
+
 class Model:
     """model.rs:55-169."""
 
@@ -516,20 +557,30 @@ class Predictor:
             _raise(st)
         return text_out[:int(offsets_out[S])], offsets_out
 
-    def tokenize(self, texts: Sequence[str], tagged: bool = False, fullwidth: bool = False, wsconst: Sequence[int] = (),
+    def tokenize(self, texts: Sequence[str], tagged: bool = False, fullwidth: bool = False, wsconst: Sequence = (),
                  split_linebreaks: bool = False) -> List[str]:
         """Lines in, tokenized lines out (vpt_tokenize_batch): the CLI's loop (predict/src/main.rs:122-176) for a batch,
-        with char counting, scoring, post-filters, tagging and the writer on the device."""
+        with char counting, scoring, post-filters, tagging and the writer on the device.  `wsconst`: CharacterType values (the
+        KyteaWsConstFilter of that type, on the device) and / or "G" (ConcatGraphemeClustersFilter, predict/src/main.rs:101-104: on the
+        host -- the batch then takes three calls, predict / the filter on the labels / fill_tags + writer, instead of one)."""
         if not texts:
             return []
         utf8, boff = pack_texts([t.encode("utf-8") for t in texts])
         S = len(texts)
-        flags = _lib.VPT_FLAG_KYTEA_FULLWIDTH if fullwidth else 0
-        for t in wsconst:
-            flags |= _lib.VPT_FLAG_WSCONST(int(t))
-        if split_linebreaks:
-            flags |= _lib.VPT_FLAG_SPLIT_LINEBREAKS
-        text, toff = self.tokenize_packed(utf8, boff, tagged=tagged, flags=flags)
+        graphemes = any(isinstance(t, str) and t == "G" for t in wsconst)
+        types = [int(t) for t in wsconst if not (isinstance(t, str) and t == "G")]
+        if graphemes:
+            _, labels, ooff = self.predict_packed(utf8, boff, fullwidth=fullwidth, wsconst=tuple(types), split_linebreaks=split_linebreaks)
+            norm = KyteaFullwidthFilter()
+            ConcatGraphemeClustersFilter().filter_packed([norm.filter(t) for t in texts] if fullwidth else texts, ooff, labels)
+            text, toff = self.write_tokenized_packed(utf8, boff, ooff, labels, tagged=tagged, fullwidth=fullwidth)
+        else:
+            flags = _lib.VPT_FLAG_KYTEA_FULLWIDTH if fullwidth else 0
+            for t in types:
+                flags |= _lib.VPT_FLAG_WSCONST(t)
+            if split_linebreaks:
+                flags |= _lib.VPT_FLAG_SPLIT_LINEBREAKS
+            text, toff = self.tokenize_packed(utf8, boff, tagged=tagged, flags=flags)
         raw = bytes(text)
         return [raw[int(toff[i]):int(toff[i + 1])].decode("utf-8") for i in range(S)]
 
