@@ -7,6 +7,7 @@
 #include <string>
 #include <vector>
 
+#include "vaporetto_grapheme.hpp"
 #include "vaporetto_hip.hpp"
 
 using namespace vaporetto_hip;
@@ -47,6 +48,12 @@ int main(int argc, char** argv) {
                 predictor.store_tag_scores(false);
             }
             std::cout << "\ntext " << s.write_tokenized_text() << "\n";
+            {   // --wsconst G: the grapheme-cluster filter between predict and the writer (predict/src/main.rs:101-104, 130-134)
+                Sentence g = Sentence::from_raw(l);
+                predictor.predict(g);
+                vaporetto_hip::ConcatGraphemeClustersFilter().filter(g);
+                std::cout << "graphemes " << g.write_tokenized_text() << "\n";
+            }
             batch.push_back(Sentence::from_raw(l));
         }
         predictor.predict_batch(batch);   // one launch: the same scores

@@ -13,7 +13,7 @@ from vaporetto_amd import _lib, api
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SRC = os.path.join(ROOT, "tests", "native", "cpp_mirror_test.cpp")
-LINES = ["まぁ社長は火星猫だ", "まぁ良いだろう", "火星猫", "あ", "12 ab/c\\d", "ＡＢＣ１２３ｱｲｳ漢字𠮷"]
+LINES = ["まぁ社長は火星猫だ", "まぁ良いだろう", "火星猫", "あ", "12 ab/c\\d", "ＡＢＣ１２３ｱｲｳ漢字𠮷", "手\U0001f44f\U0001f3fdです\U0001f468\u200d\U0001f469か\u3099"]
 
 
 def _build(lib_path: str, out: str) -> str:
@@ -40,6 +40,10 @@ def _expected(tags: bool) -> str:
             out.append("stored" + "".join(" %d:%d:%s" % (c, md[c], "".join("%d," % v for v in sc[c])) for c in range(len(md)) if md[c] >= 0))
             s.fill_tags()
         out.append("text " + s.write_tokenized_text())
+        g = api.Sentence.from_raw(l)
+        pred.predict(g)
+        api.ConcatGraphemeClustersFilter().filter(g)
+        out.append("graphemes " + g.write_tokenized_text())
     out += ["tokenize " + t for t in pred.tokenize(LINES, tagged=tags)]
     out.append("error 1 InvalidArgumentError: text: must contain at least one character -> [ ]")
     out.append("error 1 InvalidArgumentError: text: must not contain NULL")

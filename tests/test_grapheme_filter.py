@@ -1,10 +1,15 @@
 """ConcatGraphemeClustersFilter on the host (the CLI's `--wsconst G`): the reference's own tests
 (/root/reference/vaporetto_rules/src/sentence_filters/concat_grapheme_clusters.rs:43-88) restated on the Python mirror, and the
 packed form against the per-sentence one.  No GPU: the filter only edits boundaries."""
+import os
+import subprocess
+
 import numpy as np
 import pytest
 
 from vaporetto_amd import api
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 B = api.CharacterBoundary
 
@@ -61,3 +66,31 @@ def test_packed_form_equals_per_sentence_form():
         assert np.array_equal(s.boundaries(), packed[int(ooff[i]):int(ooff[i + 1])]), repr(t)
     changed = packed != labels
     assert (packed[changed] == B.NotWordBoundary).all()
+
+
+def test_cpp_mirror_segments_like_the_regex_module(tmp_path):
+    """include/vaporetto_grapheme.hpp (UAX #29's rules over generated class tables) against \\X of the `regex` module: the reference's four
+    cases, hand-picked rule cases (Hangul jamo, Indic conjuncts, prepend, flags, ZWJ sequences, CR LF, controls) and 4 000 random strings over
+    code points of every class."""
+    import regex
+    exe = str(tmp_path / "grapheme_test")
+    subprocess.check_call(["g++", "-O1", "-std=c++17", "-Wall", "-I" + os.path.join(ROOT, "include"), "-o", exe,
+                           os.path.join(ROOT, "tests", "native", "grapheme_test.cpp")])
+    rng = np.random.default_rng(29)
+    pool = []
+    props = ["GCB=CR", "GCB=LF", "GCB=Control", "GCB=Extend", "GCB=ZWJ", "GCB=Regional_Indicator", "GCB=Prepend", "GCB=SpacingMark", "GCB=L", "GCB=V",
+             "GCB=T", "GCB=LV", "GCB=LVT", "Extended_Pictographic", "InCB=Consonant", "InCB=Linker", "InCB=Extend"]
+    every = "".join(chr(c) for c in range(0x110000) if not 0xD800 <= c <= 0xDFFF and c != 0)
+    for pr in props:
+        members = [m.group() for m in regex.finditer(r"\p{%s}" % pr, every)]
+        pool += [members[int(k)] for k in rng.integers(0, len(members), 12)] + members[:2] + members[-2:]
+    pool += list("aあ漢 1") + ["\U0001f468", "\U0001f469", "\U0001f466", "\U0001f3fd", "\u200d", "\u0915", "\u094d", "\u0937", "\u0600", "\u1100", "\u1161", "\u11a8", "\uac00", "\uac01"]
+    cases = ["\u200d", "\U0001f468\u200d\U0001f469\u200d\U0001f466", "\U0001f44f\U0001f3fd", "これは手\U0001f44f\U0001f3fdです",
+             "\u0915\u094d\u0937", "\u0915\u094d\u200d\u0937", "\u0915\u0937", "\u0600a", "a\u0600", "\U0001f1ef\U0001f1f5\U0001f1fa\U0001f1f8\U0001f1ef",
+             "\u1100\u1161\u11a8", "\uac00\u11a8\u1100", "\uac01\u11a8", "a\r\nb\n\rc", "\r\u0301", "a\u0301\u0301b", "\U0001f468\u0301\u200d\U0001f469", "\U0001f468\u200d\u200d\U0001f469", "a\u200d\U0001f469"]
+    cases += ["".join(pool[int(k)] for k in rng.integers(0, len(pool), int(n))) for n in rng.integers(1, 24, 4000)]
+    esc = lambda t: t.replace("\\", "\\\\").replace("\r", "\\r").replace("\n", "\\n")
+    out = subprocess.run([exe], input="\n".join(esc(t) for t in cases).encode("utf-8") + b"\n", stdout=subprocess.PIPE, check=True).stdout.decode().split("\n")
+    for t, line in zip(cases, out):
+        want = api.ConcatGraphemeClustersFilter.cluster_lengths(t)
+        assert [int(x) for x in line.split()] == want, [hex(ord(c)) for c in t]
