@@ -114,3 +114,17 @@ def test_halves_and_permutation_sized_down():
     p_boff = np.concatenate([[0], np.cumsum([len(p) for p in parts])]).astype(np.uint64)
     ps, _, _ = pred.predict_packed(p_utf8, p_boff)
     assert np.array_equal(ps.reshape(n, 63), scores.reshape(n, 63)[perm])
+
+
+@pytest.mark.parametrize("env", [{}, {"VPT_TAG_SPLIT": "1", "VPT_TOKENIZE_CHUNK_BYTES": "700"}], ids=["default", "two-launch tags, small tokenize chunks"])
+def test_short_fuzz_of_the_kernel_sources(env):
+    """tools/fuzz_gpu.py for a quarter of a minute on the emulator: random models (every window, tag models, wide weights) x ragged batches x
+    flags against the oracle -- boundaries, tags, writers, vpt_tokenize_batch.  The seeds are fixed: a failure names the one to rerun."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    e = dict(os.environ, VPT_FUZZ_EMULATED="1", VPT_FUZZ_SEED0="400000", **env)
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "fuzz_gpu.py"), "12"], env=e, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600)
+    out = r.stdout.decode("utf-8", "replace")
+    assert r.returncode == 0 and "no mismatch" in out, out[-2000:]
