@@ -450,8 +450,8 @@ __device__ __forceinline__ uint32_t fuse_tag_bytes(const EmitParams& P, const Fu
     return bytes;
 }
 
-template <bool kTags, bool kDbg>
-__global__ __launch_bounds__(kEmitThreads) void emit_fused_kernel(const EmitParams P, const EmitFuse F) {
+template <bool kTags, bool kDbg, int kOcc = 1>
+__global__ __launch_bounds__(kEmitThreads, kOcc) void emit_fused_kernel(const EmitParams P, const EmitFuse F) {
     const uint32_t dbg = kDbg ? F.dbg : 0u;   // timing ablations (VPT_DEBUG_EMIT; results are wrong with any bit set)
     __shared__ FuseLds LDS;
     // the other array of state words, for the call after this one
@@ -676,7 +676,12 @@ hipError_t launch_emit_tokenized(const EmitParams& P, const EmitFuse& F, hipStre
     if (F.dbg) {
         if (P.tags) hipLaunchKernelGGL((emit_fused_kernel<true, true>), grid, dim3(kEmitThreads), 0, stream, P, F);
         else hipLaunchKernelGGL((emit_fused_kernel<false, true>), grid, dim3(kEmitThreads), 0, stream, P, F);
-    } else if (P.tags) hipLaunchKernelGGL((emit_fused_kernel<true, false>), grid, dim3(kEmitThreads), 0, stream, P, F);
+    } else if (P.tags) {
+        // the tagged instance for 4 waves per SIMD: 128 VGPRs + 176 bytes of scratch per lane (the rare suffix routines' call frames) -- left to
+        // itself the compiler takes 135 VGPRs = 3 waves per SIMD.  configs[4], 444 MB of tagged text (profiles/r04_u_tagged_writer.jsonl):
+        // 3 waves 2.72 ms, 4 waves 2.40, 5 waves (96 VGPRs, 304 bytes) 2.57, 6 waves (80, 384) 2.74
+        hipLaunchKernelGGL((emit_fused_kernel<true, false, 4>), grid, dim3(kEmitThreads), 0, stream, P, F);
+    }
     else hipLaunchKernelGGL((emit_fused_kernel<false, false>), grid, dim3(kEmitThreads), 0, stream, P, F);
     return hipGetLastError();
 }
