@@ -51,6 +51,9 @@ fn check(st: c_int) -> Result<()> {
 }
 
 /// `KyteaFullwidthFilter` before scoring, `KyteaWsConstFilter(t)` / `SplitLinebreaksFilter` on the labels (predict/src/main.rs:126-134).
+/// `ConcatGraphemeClustersFilter` (`--wsconst G`, predict/src/main.rs:101-104) has no flag: it segments by UAX #29 and only edits labels, so
+/// it stays on the host -- after `predict_batch` run `vaporetto_rules`' own filter over the sentences (their boundaries are the device's
+/// labels by then), then `fill_tags` / `write_tokenized_text` as the CLI does; `tokenize_lines` cannot take it.
 pub const FLAG_KYTEA_FULLWIDTH: u32 = 1;
 pub const FLAG_SPLIT_LINEBREAKS: u32 = 1 << 7;
 pub const fn flag_wsconst(char_type: u8) -> u32 {
