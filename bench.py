@@ -12,6 +12,7 @@ The workloads are BASELINE.json's configs:
   configs[4]  M1 + tag models (synthetic M3), predict_tags on, 1 M sentences of 8..512 chars / N, step = predict + fill_tags
   documents   (not a BASELINE config) M1, 10 K sentences of 2 000..20 000 chars: every sentence is cut across many tiles
   charw2 / charw4  (not BASELINE configs) M1 trained with --charw 2 --typew 2 / --charw 4 --typew 4, 100 K x 64
+  nonbmp      (not a BASELINE config) M1 + patterns with kanji outside the BMP, 100 K x 64 with about 1 % of the chars outside the BMP
 
 ONE workload over the whole 1 -> 8 curve: with no --config the `value` is configs[2] at every N (the north-star's "10 M-sentence
 synthetic batch"; it fits one GPU), so that a scaling curve built from the per-N values compares like with like.  N = 1 also
@@ -61,6 +62,9 @@ CONFIGS = {
     # of window 3) and with --charw 4 --typew 4 (rows of window 4): the specialised kernel, one instance per row window
     6: dict(name="charw2", kind=4, sentences=100_000, min_len=64, max_len=64, tags=False, blocks=False),
     7: dict(name="charw4", kind=5, sentences=100_000, min_len=64, max_len=64, tags=False, blocks=False),
+    # M1 + 40 unigrams, 100 n-grams and 100 dictionary words with kanji outside the BMP (UniDic has such entries); 2.5 % of the text's items
+    # (about 1 % of its chars) lie outside the BMP, half of them as one of those patterns: configs[1] with the alphabet a real dictionary has
+    8: dict(name="nonbmp", kind=6, sentences=100_000, min_len=64, max_len=64, tags=False, blocks=False, nonbmp_share=0.025),
 }
 BLOCK = 100_000
 
@@ -68,7 +72,7 @@ BLOCK = 100_000
 def load_model_bytes(kind: int, scale: float):
     """A real model when $VAPORETTO_MODEL_DIR holds one (zstd, as distributed), else the synthetic stand-in."""
     from vaporetto_amd import synth
-    name = {1: "bccwj-suw+unidic", 2: "jp-0.4.7-5", 3: "bccwj-suw+unidic_pos+pron", 4: "bccwj-suw+unidic-charw2", 5: "bccwj-suw+unidic-charw4"}[kind]
+    name = {1: "bccwj-suw+unidic", 2: "jp-0.4.7-5", 3: "bccwj-suw+unidic_pos+pron", 4: "bccwj-suw+unidic-charw2", 5: "bccwj-suw+unidic-charw4", 6: "bccwj-suw+unidic-nonbmp"}[kind]
     d = os.environ.get("VAPORETTO_MODEL_DIR")
     if d:
         path = os.path.join(d, name + ".model.zst")
@@ -86,7 +90,7 @@ def load_model_bytes(kind: int, scale: float):
             from vaporetto_amd import kytea
             with open(path, "rb") as fh:
                 return kytea.convert(fh.read()), name
-    return synth.synth_model(kind, synth.SEED_BASE + 2, scale), "synthetic-" + {1: "M1", 2: "M2", 3: "M3", 4: "M1-charw2-typew2", 5: "M1-charw4-typew4"}[kind]
+    return synth.synth_model(kind, synth.SEED_BASE + 2, scale), "synthetic-" + {1: "M1", 2: "M2", 3: "M3", 4: "M1-charw2-typew2", 5: "M1-charw4-typew4", 6: "M1-nonbmp"}[kind]
 
 
 def kernel_source_hash() -> str:
@@ -135,7 +139,7 @@ def make_shard(cfg, raw, rank: int, world: int, ncores: int, sentences_override:
     if sentences_override:
         S = sentences_override
     if not cfg["blocks"]:
-        utf8, boff = synth.synth_sentences(raw, S, lo_len, hi_len, seed=synth.SEED_BASE + 2)
+        utf8, boff = synth.synth_sentences(raw, S, lo_len, hi_len, seed=synth.SEED_BASE + 2, nonbmp_share=cfg.get("nonbmp_share", 0.0))
         ooff = api.count_boundaries(utf8, boff)
         if world == 1:
             return utf8, boff, ooff, 0, S
@@ -558,6 +562,8 @@ class Runner:
             "packed_tables": bool(info["packed"]), "tiles": n_tiles, "tile_plan": "%s of %d flat positions" % (plan["kind"], plan["tile_flat"]),
             "create_s": round(create_s, 2), "tables_broadcast_s": round(bcast_s, 3) if self.world > 1 else None, "synth_s": round(synth_s, 2),
         }
+        if cfg.get("nonbmp_share"):
+            out["chars_outside_the_bmp"] = float(np.count_nonzero(utf8 >= 0xF0)) / max(nb + S, 1)
         if per_rank is not None:
             out["per_rank"] = per_rank
         if phases is not None:
@@ -593,12 +599,48 @@ class Runner:
         return out
 
 
+def compact_row(w):
+    """One workload as a row of the result line."""
+    roof = w.get("roofline") or {}
+    a, tr = roof.get("algorithmic_bytes_per_launch"), roof.get("traffic")
+    r3 = lambda x, n=3: None if x is None else round(float(x), n)   # noqa: E731
+    row = {"name": w["workload"].split(":")[0], "model": w.get("tokenizer_model"), "value_G": r3(w["value"] / 1e9), "ms_per_step": r3(w["ms_per_step"], 4),
+           "kernel": roof.get("kernel"), "kernel_ms": r3(roof.get("kernel_ms"), 4), "frac": r3(roof.get("frac"), 4), "bytes_per_boundary": r3(roof.get("bytes_per_boundary"), 1),
+           "traffic_ratio": r3(tr / a) if (a and tr) else None, "parity": w.get("parity"), "packed": w.get("packed_tables"), "tile_plan": (w.get("tile_plan") or "").split(" of ")[0]}
+    if w.get("tags"):
+        row["tags_ms"], row["tags_parity"] = r3(w["tags"]["ms_per_step"], 4), w["tags"].get("parity")
+    if w.get("emit"):
+        row["emit_ms"], row["emit_frac"], row["emit_parity"] = r3(w["emit"]["ms_per_step"], 4), r3(w["emit"]["frac_of_hbm"], 4), w["emit"].get("parity")
+        if w["emit"].get("fused"):
+            row["fused_ms"] = r3(w["emit"]["fused"]["ms_per_step"], 4)
+    if w.get("e2e"):
+        row["e2e_ms"], row["e2e_frac_both_ways"] = r3(w["e2e"]["ms_per_batch"], 4), r3(w["e2e"]["frac_of_both_ways"])
+        row["tokenize_ms"], row["tokenize_Gchars"] = r3(w["e2e"]["tokenize"]["ms_per_batch"], 4), r3(w["e2e"]["tokenize"]["chars_per_s"] / 1e9)
+    if "chars_outside_the_bmp" in w:
+        row["chars_outside_the_bmp"] = r3(w["chars_outside_the_bmp"], 4)
+    if w.get("first_mismatch"):
+        row["first_mismatch"] = w["first_mismatch"]
+    return row
+
+
+def shorten(x):
+    """The line as printed: floats to 6 significant digits, prose (`kernels`, `path`, `timing`: explanations that live in --detail-out and
+    DESIGN.md) cut to 160 chars."""
+    if isinstance(x, float):
+        return float("%.6g" % x)
+    if isinstance(x, dict):
+        return {k: ((v[:157] + "...") if isinstance(v, str) and len(v) > 160 and k in ("kernels", "path", "timing", "sample", "workloads_columns") else shorten(v)) for k, v in x.items()}
+    if isinstance(x, list):
+        return [shorten(v) for v in x]
+    return x
+
+
 def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--config", type=int, default=0, choices=[0, 1, 2, 3, 4, 5, 6, 7],
+    ap.add_argument("--config", type=int, default=0, choices=[0, 1, 2, 3, 4, 5, 6, 7, 8],
                     help="BASELINE.json configs index (0: configs[2] as the value at every N, plus -- at N = 1 -- the others as `workloads`)")
     ap.add_argument("--quick", action="store_true", help="the primary workload only")
     ap.add_argument("--sentences", type=int, default=0, help="override the config's sentence count (diagnostics; traffic is then not reported)")
@@ -607,6 +649,8 @@ def parse_args(argv=None):
     ap.add_argument("--no-e2e", action="store_true")
     ap.add_argument("--no-emit", action="store_true")
     ap.add_argument("--phases", action="store_true", help="diagnostics: per-phase shader cycles of the scoring kernel (slows it)")
+    ap.add_argument("--detail-out", default=os.path.join(ROOT, "gpurun_out", "bench_detail.json"),
+                    help="where the per-workload detail goes (the line itself carries one compact row per workload and stays below 12 KB)")
     ap.add_argument("--in-process", action="store_true", help="N > 1: skip torch.distributed, drive the N devices from this process (the fallback path)")
     ap.add_argument("--scale-sweep", default="", help="e.g. 1,2,4,8: run the primary workload at every N of the list (one line each, as --gpus N "
                     "would print it, plus `scaling_efficiency` against the N = 1 value of the same invocation)")
@@ -869,7 +913,7 @@ def main():
     prim = R.run(primary_id, primary=True, e2e_leg=(primary_id == 1))
     extra = []
     if not args.config and not args.quick and R.world == 1:
-        for cid in (1, 3, 4, 5, 6, 7):
+        for cid in (1, 3, 4, 5, 6, 7, 8):
             extra.append(R.run(cid, primary=False, e2e_leg=(cid == 1)))
     if R.rank == 0:
         line = {
@@ -891,9 +935,28 @@ def main():
         for k in ("e2e", "tags", "emit", "phase_share", "per_rank"):
             if k in prim:
                 line[k] = prim[k]
+        # ONE row per workload inside the line (the driver keeps a 15 KB tail of stdout: round 4's full detail pushed configs[1] and
+        # configs[3] out of its record); everything else goes to --detail-out
         if extra:
-            line["workloads"] = extra
-        print(json.dumps(line))
+            line["workloads"] = [compact_row(w) for w in [prim] + extra]
+            line["workloads_columns"] = "G boundaries/s; kernel_ms = HIP-event median of the scoring kernel; frac = algorithmic bytes / kernel_ms / 8 TB/s; " \
+                                        "traffic_ratio = PMC bytes / algorithmic bytes (null: no PMC pass on these sources); tags_ms / emit_ms / fused_ms = fill_tags, " \
+                                        "the writer's launch, predict + writer in one launch, wall clock per call"
+        detail = dict(line, workloads=[prim] + extra) if extra else line
+        try:
+            os.makedirs(os.path.dirname(os.path.abspath(args.detail_out)), exist_ok=True)
+            with open(args.detail_out, "w") as fh:
+                json.dump(detail, fh, indent=1)
+            line["config"]["detail_file"] = os.path.relpath(args.detail_out, ROOT)
+        except OSError:
+            pass
+        text = json.dumps(shorten(line))
+        if len(text) >= 12000:   # never past the driver's tail: drop the prose first
+            for k in ("e2e", "emit", "tags", "phase_share"):
+                if len(text) >= 12000 and k in line:
+                    line.pop(k)
+                    text = json.dumps(shorten(line))
+        print(text)
         sys.stdout.flush()
     if R.world > 1:
         R.dist.barrier()

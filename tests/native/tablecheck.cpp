@@ -108,7 +108,7 @@ int tc_score(const tc_model* t, const uint32_t* cps, size_t n, int32_t* y_out, u
     std::vector<int32_t> y(n > 0 ? n - 1 : 0, t->c.bias);
     std::vector<uint32_t> sym(n + 8, 0), typ(n + 8, 0);
     for (size_t i = 0; i < n; ++i) {
-        sym[i] = cps[i] < 0x10000u ? K.id_of[cps[i]] : kNoId;
+        sym[i] = K.id_for(cps[i]);
         typ[i] = char_type_host(cps[i]);
     }
     const uint32_t uni_last = uint32_t(K.uni.size() / udw) - 1, n_tri = uint32_t(K.tri.size() / tdw);
@@ -129,7 +129,9 @@ int tc_score(const tc_model* t, const uint32_t* cps, size_t n, int32_t* y_out, u
         const uint32_t* u = &K.uni[size_t(c1 < uni_last ? c1 : uni_last) * udw];
         for (int j = 0; j < nu; ++j) add(y, S - wl + j, bits_signed(u, kUniFieldBits * j, kUniFieldBits));
         if (bits_unsigned(u, pk_uni_base_bit(wl) + kUniBaseBits, 1)) {
-            const uint32_t* g = &G.uni[size_t(cp_of(c1)) * G.uni_dw];
+            const uint32_t* g = cp_of(c1) < G.uni_n ? &G.uni[size_t(cp_of(c1)) * G.uni_dw] : general_find(G, short_key(cp_of(c1), 0, 0));
+            if (!g) return -2;
+            if (cp_of(c1) >= G.uni_n) g += 2;
             for (int j = 0; j < G.len[0]; ++j) add(y, S + G.lo[0] + j, int32_t(g[j]));
         }
         if (c2 == 0 || c1 == kNoId || c2 == kNoId) continue;   // (the kernel issues no load for a char outside the alphabet)

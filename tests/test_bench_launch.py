@@ -77,3 +77,25 @@ def test_dry_scale_sweep_up_to_four_ranks():
         if l["n_gpus"] > 1:
             assert len(l["per_rank"]) == l["n_gpus"] and all(pr["tables_broadcast_s"] is not None for pr in l["per_rank"])
             assert sum(pr["sentences"] for pr in l["per_rank"]) == 400000
+
+
+def test_the_result_line_stays_below_the_drivers_tail():
+    """the driver keeps a 15 KB tail of stdout and round 4's line (25 KB: every workload's full detail) lost configs[1]
+    and configs[3] to it.  The line now carries ONE compact row per workload; checked here on round 4's own detail (eight workloads)."""
+    sys.path.insert(0, ROOT)
+    import bench
+    with open(os.path.join(ROOT, "profiles", "r04_zz_bench_all_workloads.json")) as fh:
+        old = json.loads([l for l in fh.read().splitlines() if l.startswith("{")][-1])
+    prim = dict(old["config"], value=old["value"], ms_per_step=old["ms_per_step"], roofline=old["roofline"], parity=old["parity"])
+    rows = [bench.compact_row(w) for w in [prim] + old["workloads"] + [old["workloads"][0]]]
+    line = dict(old, workloads=rows, workloads_columns="x" * 400)
+    text = json.dumps(bench.shorten(line))
+    assert len(text) < 12000, len(text)
+    back = json.loads(text)
+    names = [r["name"] for r in back["workloads"]]
+    assert names[:5] == ["configs[2]", "configs[1]", "configs[3]", "configs[4]", "documents"]
+    for r in back["workloads"]:
+        assert r["parity"] is True and r["kernel_ms"] > 0 and 0 < r["frac"] < 1 and r["kernel"].startswith("score_tiles")
+    assert back["workloads"][1]["e2e_ms"] > 0 and back["workloads"][3]["tags_ms"] > 0
+    assert "traffic_ratio" in back["workloads"][0]
+    assert back["roofline"]["frac"] == pytest.approx(old["roofline"]["frac"], rel=1e-5) and back["cpu_baseline"]["value"] > 0

@@ -410,10 +410,49 @@ def test_packed_text_with_non_bmp_and_noncharacters():
 
 
 def test_non_bmp_pattern_models_use_the_general_tables():
+    """(The name is history: until round 5 one pattern char outside the BMP sent a model to the general kernels.)  Any `String` is a
+    pattern to the reference (char_scorer/boundary_scorer.rs:56-89, dict_model.rs:18-50; vaporetto_tantivy/src/lib.rs:298-364 feeds
+    non-BMP text): such chars get ids like every other char of the alphabet, found through the side table `xcid`."""
     m = randmodel.rand_model(21, alphabet="mixed", wc=3, wt=3, n_char=120, n_dict=120, max_word=6)
+    assert any(ord(c) >= 0x10000 for d in m.char_ngram_model for c in d.ngram) and any(ord(c) >= 0x10000 for r in m.dict_model for c in r.word)
     pred, orc = make_predictor(m)
-    assert pred.info()["packed"] == 0   # the "mixed" alphabet has non-BMP pattern chars
+    assert pred.info()["packed"] == 1
     check_batch(pred, orc, randmodel.rand_sentences(3, m, 600, alphabet="mixed", max_len=70))
+
+
+def test_non_bmp_and_ffff_alphabets_on_the_packed_path(monkeypatch):
+    """Patterns made of chars outside the BMP only, U+FFFF / U+FFFE as pattern chars, a wide (outside-its-fields) unigram, bigram and
+    trigram row that start with a non-BMP char (the replay from the general tables, which keep such a unigram with the short strings),
+    long words of them below depth 3, with and without KyteaFullwidthFilter; text with non-BMP chars no pattern holds."""
+    m = ModelData(bias=11, char_window_size=3, type_window_size=3)
+    m.char_ngram_model.append(NgramData("𠮷", [1, -2, 200000, 4, -5, 6]))                 # wide unigram outside the BMP
+    m.char_ngram_model.append(NgramData("𠮷野", [1, 300000, 3, -4, 5]))                   # wide bigram
+    m.char_ngram_model.append(NgramData("𠮷野家", [40000, 2, -3, 4]))                     # wide trigram
+    m.char_ngram_model.append(NgramData("𩸽", [7, 8, 9, 10, 11, 12]))
+    m.char_ngram_model.append(NgramData("𩸽𠮟", [1, 2, 3, 4, 5]))
+    m.char_ngram_model.append(NgramData("a𩸽b", [9, 8, 7, 6]))
+    m.char_ngram_model.append(NgramData("\uffff", [3, 1, 4, 1, 5, 9]))
+    m.char_ngram_model.append(NgramData("\uffff\ufffe", [2, 7, 1, 8, 2]))
+    m.dict_model.append(WordWeightRecord("𠮷野家の𩸽", [1, 2, 3, 4, 5, 6], ""))
+    m.dict_model.append(WordWeightRecord("𠮟る", [-1, -2, -3], ""))
+    m.dict_model.append(WordWeightRecord("🤌🏿🤌🏿🤌🏿🤌", [1, 2, 3, 4, 5, 6, 7, 8], ""))
+    m.dict_model.append(WordWeightRecord("𩸽\uffffＡ１", [5, 4, 3, 2, 1], ""))
+    m.type_ngram_model.append(NgramData(bytes([5, 5]), [5, -6, 7, 8, 9]))
+    m.type_ngram_model.append(NgramData(bytes([6]), [1, 2, 3, 4, 5, 6]))
+    pred, orc = make_predictor(m)
+    assert pred.info()["packed"] == 1
+    texts = ["𠮷野家の𩸽", "𠮷", "𠮷野", "𠮷野家", "あ𠮷野家の𩸽を𠮟る", "a𩸽b𩸽𠮟𩸽", "\uffff\ufffe\uffff", "🤌🏿🤌🏿🤌🏿🤌🏿🤌", "𩸽\uffffA1𩸽\uffffＡ１",
+             "𠀋𠮷𪚲野家", "😀𩸽😀", "𠮟", "る𠮟る𠮟"] * 40
+    check_batch(pred, orc, texts)
+    fw = api.KyteaFullwidthFilter()
+    utf8, boff = api.pack_texts([t.encode("utf-8") for t in texts])
+    n_utf8, n_boff = api.pack_texts([fw.filter(t).encode("utf-8") for t in texts])
+    scores, labels, _ = pred.predict_packed(utf8, boff, fullwidth=True)
+    o_scores, o_labels, _, _ = orc.predict_batch(n_utf8, n_boff)
+    assert np.array_equal(scores, o_scores) and np.array_equal(labels, o_labels)
+    # the general kernels score the same model the same way
+    monkeypatch.setenv("VPT_FORCE_GENERIC", "1")
+    check_batch(api.Predictor(api.Model.read_slice(encode_model(m))[0], False), orc, texts[:60])
 
 
 @pytest.mark.parametrize("seed", [0, 1, 2, 3])
@@ -1052,10 +1091,8 @@ def test_predict_and_write_in_one_launch(case, monkeypatch):
     if case == "window-table":
         monkeypatch.setenv("VPT_FORCE_WINDOW_TABLE", "1")
     m = randmodel.rand_model(4100 + wc, alphabet="mixed", wc=wc, wt=wt, n_char=120, n_dict=120, n_type=0 if case == "no-types" else 60, max_word=9)
-    m.char_ngram_model = [d for d in m.char_ngram_model if all(ord(c) < 0xFFFF for c in d.ngram)]   # BMP patterns: the packed tables
-    m.dict_model = [d for d in m.dict_model if all(ord(c) < 0xFFFF for c in d.word)]
     if case == "general":
-        m.dict_model.append(WordWeightRecord("𠮷あ", [5, -6, 7], ""))      # a non-BMP pattern: the general kernels, then the writer's own launch
+        monkeypatch.setenv("VPT_FORCE_GENERIC", "1")                        # the general kernels, then the writer's own launch
     pred, orc = make_predictor(m)
     rng = np.random.default_rng(23)
     alphabet = randmodel.ALPHABETS["mixed"] + list("/\\  /") + ["\n"]
@@ -1683,8 +1720,10 @@ def test_compiled_predictor_round_trip_and_clone():
     del pred   # the copies own their tables
     check_batch(loaded, orc, texts[:100])
     check_batch(clone, orc, texts[:100])
-    # the general path (non-BMP pattern symbols): no packed tables in the compiled form
+    # the general path (an alphabet of more chars than the packed tables have ids for): no packed tables in the compiled form
     m2 = randmodel.rand_model(612, alphabet="mixed", wc=4, wt=4, n_char=100, n_dict=100, max_word=6)
+    for cp in range(0x20000, 0x20000 + 65600):
+        m2.char_ngram_model.append(NgramData(chr(cp), [cp & 7, 0, -(cp & 3)]))
     raw2 = encode_model(m2)
     p2 = api.Predictor(api.Model.read_slice(raw2)[0], False)
     l2 = api.Predictor.load_compiled(p2.save_compiled())

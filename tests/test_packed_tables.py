@@ -139,16 +139,26 @@ def test_packed_walk_sparse_rows_and_filters(tc):
     assert probes[3] > 0 and probes[1] > 0          # the filters rejected lookups, and admitted some
 
 
-def test_packed_not_eligible_models_fall_back(tc):
+def test_packed_eligibility(tc):
     base = dict(bias=3, char_window_size=3, type_window_size=3)
-    # a non-BMP symbol in a pattern
+    # chars outside the BMP, U+FFFF and U+FFFE are pattern chars like any other (round 5): ids through the side table `xcid`
     m = ModelData(**base)
     m.char_ngram_model.append(NgramData("𠮷", [1, 2, 3, 4, 5, 6]))
-    assert not Walker(tc, encode_model(m)).packed
-    # U+FFFF in a pattern (the packed tables use 0xFFFF as the matches-nothing symbol)
-    m = ModelData(**base)
+    m.char_ngram_model.append(NgramData("𠮷野", [1, 2, 3, 4, 5]))
     m.dict_model.append(WordWeightRecord("a￿", [1, 2, 3], ""))
-    assert not Walker(tc, encode_model(m)).packed
+    m.dict_model.append(WordWeightRecord("𠮷野家の𩸽", [1, 2, 3, 4, 5, 6], ""))
+    wk = Walker(tc, encode_model(m))
+    assert wk.packed
+    orc = cbind.OraclePredictor(encode_model(m))
+    for t in ("𠮷", "𠮷野家の𩸽", "a￿a￿", "あ𠮷野𠮷", "𩸽𠮷野家の𩸽𠀋"):
+        assert wk.score(t, [0, 0, 0, 0]) == orc.predict(t)[0], t
+    # a pattern that holds U+0000 can match no text (sentence.rs:174-179): it is left out, the model stays eligible
+    m = ModelData(**base)
+    m.char_ngram_model.append(NgramData("a\0b", [1, 2, 3, 4]))
+    m.char_ngram_model.append(NgramData("あ", [1, 2, 3, 4, 5, 6]))
+    wk = Walker(tc, encode_model(m))
+    assert wk.packed
+    assert wk.score("あaあ", [0, 0, 0, 0]) == cbind.OraclePredictor(encode_model(m)).predict("あaあ")[0]
     # every char window up to 8 is eligible: 1 and 2 are laid out in the rows of window 3, wider ones have rows of their own
     m = ModelData(bias=3, char_window_size=4, type_window_size=3)
     m.char_ngram_model.append(NgramData("あ", [1, 2, 3, 4, 5, 6, 7, 8]))
@@ -212,9 +222,6 @@ def test_type_rows_match_oracle(tc, seed):
     """Models whose type n-grams have <= 3 symbols get LDS type rows; the walker then reproduces the FULL score."""
     wt = [3, 2, 1, 3][seed % 4]
     m = randmodel.rand_model(300 + seed, alphabet="mixed" if seed % 2 else "kana", wc=3, wt=wt, n_char=60, n_dict=60, n_type=80, max_word=7)
-    # patterns must be BMP for the packed tables: drop the others
-    m.char_ngram_model = [d for d in m.char_ngram_model if all(ord(c) < 0xFFFF for c in d.ngram)]
-    m.dict_model = [d for d in m.dict_model if all(ord(c) < 0xFFFF for c in d.word)]
     raw = encode_model(m)
     w = Walker(tc, raw)
     assert w.packed and w.trow == 1

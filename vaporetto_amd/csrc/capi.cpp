@@ -104,7 +104,7 @@ constexpr size_t kTablePadBytes = 256;  // probes read whole 16-byte chunks; kee
 enum Section : int {
     kSecCShort, kSecCUni, kSecCEdges, kSecCWdata,              // general char tables
     kSecTShort, kSecTUni, kSecTEdges, kSecTWdata,              // general type tables (type_kind == pattern tables)
-    kSecPUni, kSecPBi, kSecPTri, kSecPDeep, kSecPXrows, kSecPTrow, kSecPCpid,   // packed tables: contiguous, addressed from kSecPUni
+    kSecPUni, kSecPBi, kSecPTri, kSecPDeep, kSecPXrows, kSecPTrow, kSecPCpid, kSecPXcid,   // packed tables: contiguous, addressed from kSecPUni
     kSecTypeTable, kSecCtype, kSecCinfo, kSecCid,
     kSecTagTokTab, kSecTagModels, kSecTagMfilt, kSecTagNgrams, kSecTagNrec, kSecTagSyms, kSecTagSlots, kSecTagWeights, kSecTagSlotStr, kSecTagStrOff, kSecTagStrBytes,
     kSectionCount
@@ -114,7 +114,7 @@ struct TableGeom {
     int32_t window, lo[3], len[3];
 };
 constexpr char kCompiledMagic[16] = "VaporettoHIP-C\x01";   // 15 chars + NUL
-constexpr uint32_t kCompiledVersion = 10;                    // bump whenever layout.h or a kernel's reading of it changes
+constexpr uint32_t kCompiledVersion = 11;                    // bump whenever layout.h or a kernel's reading of it changes
 struct PredictorMeta {                                      // plain data: written and read as is (little-endian hosts)
     char magic[16];
     uint32_t version, meta_bytes;
@@ -124,7 +124,7 @@ struct PredictorMeta {                                      // plain data: writt
     int32_t bias, pad, type_kind, type_window, chunks;
     uint32_t predict_tags, has_tags, n_tags, tok_bits, max_tag_suffix, tag_use_char, tag_use_type, n_tag_models, n_tag_strings, max_tag_scores;
     TableGeom geom[2];                                      // chars, types
-    uint32_t pk_present, pk_n_uni, pk_n_tri, pk_bi_shift, pk_wl, pk_trow_mode, pk_trow_levels;
+    uint32_t pk_present, pk_n_uni, pk_n_tri, pk_bi_shift, pk_wl, pk_trow_mode, pk_trow_levels, pk_xcid_bits;
     vpt_model_info info;
 };
 
@@ -162,7 +162,7 @@ uint64_t meta_checksum_of(const PredictorMeta& m) {
         f.add(g.present); f.add(g.short_bits); f.add(g.edge_bits); f.add(g.stride_dw); f.add(g.uni_dw); f.add(g.uni_n); f.add(g.ext_slot); f.add(g.has_long);
         f.add(g.window); f.add(g.lo); f.add(g.len);
     }
-    f.add(m.pk_present); f.add(m.pk_n_uni); f.add(m.pk_n_tri); f.add(m.pk_bi_shift); f.add(m.pk_wl); f.add(m.pk_trow_mode); f.add(m.pk_trow_levels);
+    f.add(m.pk_present); f.add(m.pk_n_uni); f.add(m.pk_n_tri); f.add(m.pk_bi_shift); f.add(m.pk_wl); f.add(m.pk_trow_mode); f.add(m.pk_trow_levels); f.add(m.pk_xcid_bits);
     const vpt_model_info& i = m.info;
     f.add(i.n_char_ngrams); f.add(i.n_type_ngrams); f.add(i.n_dict_words); f.add(i.n_tag_models); f.add(i.bias); f.add(i.char_window); f.add(i.type_window);
     f.add(i.max_pattern_chars); f.add(i.n_short_entries); f.add(i.n_long_nodes); f.add(i.type_kind); f.add(i.device_table_bytes); f.add(i.hot_table_bytes);
@@ -204,7 +204,8 @@ const char* validate_meta(const PredictorMeta& m) {
         if (m.pk_trow_mode == vpt::kTypeRowsLds && (m.pk_trow_levels != 3 || sz(kSecPTrow) < 4ull * vpt::pk_trow_dw(wl) * vpt::kTypeRowCount)) return "type rows";
         if (m.pk_trow_mode == vpt::kTypeRowsGlobal && (m.pk_trow_levels < 3 || m.pk_trow_levels > uint32_t(vpt::kMaxTypeRowLevels) ||
                                                       sz(kSecPTrow) < 4ull * vpt::pk_trow_global_dw(wl) * vpt::type_row_count(int(m.pk_trow_levels)))) return "type rows";
-        if (m.sec_off[kSecPCpid] + sz(kSecPCpid) - m.sec_off[kSecPUni] >= (1ull << 32)) return "packed tables (32-bit offsets)";
+        if (m.pk_xcid_bits > 20 || sz(kSecPXcid) != (m.pk_xcid_bits ? 8ull + (8ull << m.pk_xcid_bits) : 0ull)) return "packed tables (chars outside the BMP)";
+        if (m.sec_off[kSecPXcid] + sz(kSecPXcid) - m.sec_off[kSecPUni] >= (1ull << 32)) return "packed tables (32-bit offsets)";
     }
     if (m.has_tags) {
         if (m.n_tags == 0 || m.n_tags > 4096 || m.tok_bits < 2 || m.tok_bits > 30 || m.max_tag_scores > vpt::kTagMaxZ) return "tag tables";
@@ -580,6 +581,7 @@ void bind_predictor(vpt_predictor* p) {
         auto rel = [&](int sec) { return uint32_t(m.sec_off[sec] - m.sec_off[kSecPUni]); };
         p->pk.off_uni = 0; p->pk.off_bi = rel(kSecPBi); p->pk.off_tri = rel(kSecPTri); p->pk.off_deep = rel(kSecPDeep);
         p->pk.off_xrows = rel(kSecPXrows); p->pk.off_trow = rel(kSecPTrow); p->pk.off_cpid = rel(kSecPCpid);
+        p->pk.off_xcid = m.pk_xcid_bits ? rel(kSecPXcid) : 0u;
         p->pk.n_uni = m.pk_n_uni; p->pk.n_tri = m.pk_n_tri; p->pk.bi_shift = m.pk_bi_shift;
         p->pk.wl = m.pk_wl; p->pk.trow_mode = m.pk_trow_mode; p->pk.trow_levels = m.pk_trow_levels;
     }
@@ -671,7 +673,7 @@ vpt_status vpt_predictor_create(const uint8_t* model_bytes, size_t len, int pred
         for (uint32_t cp = 0; cp < 65536; ++cp)
             for (int mode = 0; mode < 2; ++mode) {
                 const uint32_t scored = mode ? vpt::kytea_fullwidth_host(cp) : cp;   // 1:1 on the BMP
-                cid[size_t(mode) * 65536 + cp] = uint32_t(c.packed.id_of[scored]) | (uint32_t(vpt::char_type_host(scored)) << 16) |
+                cid[size_t(mode) * 65536 + cp] = c.packed.id_for(scored) | (uint32_t(vpt::char_type_host(scored)) << 16) |
                                                  ((scored == 0x0Au || scored == 0x0Du) ? vpt::kCinfoLinebreak : 0u);
             }
     }
@@ -684,12 +686,12 @@ vpt_status vpt_predictor_create(const uint8_t* model_bytes, size_t len, int pred
     bool packed_ok = c.packed.present;
     if (packed_ok) {
         put(kSecPUni, c.packed.uni); put(kSecPBi, c.packed.bi); put(kSecPTri, c.packed.tri); put(kSecPDeep, c.packed.deep);
-        put(kSecPXrows, c.packed.xrows); put(kSecPTrow, c.packed.trow); put(kSecPCpid, c.packed.cpid);
+        put(kSecPXrows, c.packed.xrows); put(kSecPTrow, c.packed.trow); put(kSecPCpid, c.packed.cpid); put(kSecPXcid, c.packed.xcid);
         size_t packed_total = 0;
-        for (int i = kSecPUni; i <= kSecPCpid; ++i) packed_total += (src[i].bytes + kTablePadBytes + 255) & ~size_t(255);
+        for (int i = kSecPUni; i <= kSecPXcid; ++i) packed_total += (src[i].bytes + kTablePadBytes + 255) & ~size_t(255);
         if (packed_total >= (size_t(1) << 32)) {   // the specialised kernel addresses them with 32-bit offsets: the general tables serve
             packed_ok = false;
-            for (int i = kSecPUni; i <= kSecPCpid; ++i) src[i] = {nullptr, 0};
+            for (int i = kSecPUni; i <= kSecPXcid; ++i) src[i] = {nullptr, 0};
         }
     }
     if (c.type_kind == vpt::kTypeWindowTable) put(kSecTypeTable, c.type_table);
@@ -741,6 +743,7 @@ vpt_status vpt_predictor_create(const uint8_t* model_bytes, size_t len, int pred
         m.pk_wl = uint32_t(c.packed.wl);
         m.pk_n_uni = uint32_t(c.packed.uni.size() / size_t(vpt::pk_uni_dw(c.packed.wl))); m.pk_n_tri = uint32_t(c.packed.tri.size() / size_t(vpt::pk_tri_dw(c.packed.wl)));
         m.pk_bi_shift = c.packed.bi_shift; m.pk_trow_mode = c.packed.trow_mode; m.pk_trow_levels = c.packed.trow_levels;
+        m.pk_xcid_bits = c.packed.xcid.empty() ? 0u : c.packed.xcid[0];
     }
     fill_info(c, &m.info);
     m.info.predict_tags = predict_tags != 0;

@@ -1,4 +1,4 @@
-// Specialised tile kernel for the models a Vaporetto / KyTea trainer produces: BMP patterns, 16-bit weights, char and type
+// Specialised tile kernel for the models a Vaporetto / KyTea trainer produces: 16-bit weights, char and type
 // windows up to 8 (layout.h, "PACKED TABLES"; one instance per ROW WINDOW wl = max(3, W_c, W_t) -- every distributed model has 3),
 // type scores from type rows (in LDS, or in global memory for long type n-grams), the 8^(2W) window table (wl = 3) or none.  Same
 // all-matches algorithm as kernels.hip (which stays the general path); what changes is how the work is laid out for a CDNA4 CU,
@@ -295,9 +295,11 @@ __device__ __forceinline__ void add_wide_rows(const PackedView& K, const Pattern
     const uint32_t last = K.n_uni - 1u;
     const uint32_t i1 = L.sym[s] & kCpMask, i2 = L.sym[s + 1] & kCpMask, i3 = L.sym[s + 2] & kCpMask;
     const uint32_t c1 = cpid[i1 < last ? i1 : last], c2 = cpid[i2 < last ? i2 : last], c3 = cpid[i3 < last ? i3 : last];
-    if (kinds & kWideUni) {
-        const uint32_t* u = T.uni + size_t(c1) * GeneralGeom<WL>::kUniDw;
-        for (int j = 0; j < row_len(1, WL); ++j) atomicAdd(L.score + int32_t(s) + row_lo(1, WL) + j, int32_t(u[j]));
+    if (kinds & kWideUni) {   // (the general tables index the chars of the BMP directly and keep the others' rows with the short strings)
+        const uint32_t* u = c1 < kUniDirectChars ? T.uni + size_t(c1) * GeneralGeom<WL>::kUniDw : general_row<WL>(T, short_key(c1, 0, 0));
+        if (u && c1 >= kUniDirectChars) u += 2;
+        if (u)
+            for (int j = 0; j < row_len(1, WL); ++j) atomicAdd(L.score + int32_t(s) + row_lo(1, WL) + j, int32_t(u[j]));
     }
     if (kinds & kWideBi) {
         if (const uint32_t* e = general_row<WL>(T, short_key(c1, c2, 0)))
@@ -567,8 +569,11 @@ __global__ __launch_bounds__(kThreads, fast_wg(WL)) void score_tiles_fast_kernel
             const uint32_t pos = uint32_t(tid) + uint32_t(k) * kThreads;
             const uint32_t cp = xs[k] & 0x1FFFFFu, si = xs[k] >> 21;
             uint32_t v = info[k] | (si << 19);
-            if (__ballot(cp >= 0x10000u) != 0) {   // rare: outside the BMP nothing is tabulated (and nothing can match)
-                if (cp >= 0x10000u) v = kNoId | (char_type(cp) << 16) | (si << 19);
+            if (__ballot(cp >= 0x10000u) != 0) {   // rare: a char outside the BMP has its type computed and its id -- the model's alphabet
+                if (cp >= 0x10000u) {               // may hold a few such chars -- looked up in `xcid` (layout.h); KyteaFullwidthFilter leaves it alone
+                    const uint32_t id = P.pk.off_xcid ? xcid_find(reinterpret_cast<const uint32_t*>(P.pk.base + P.pk.off_xcid), cp) : kNoId;
+                    v = id | (char_type(cp) << 16) | (si << 19);
+                }
             }
             v = cp != 0 ? v : 0u;                  // a separator (or NUL, which has raised kErrNulChar)
             L.sym[pos] = v;

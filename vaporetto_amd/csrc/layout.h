@@ -33,8 +33,8 @@
 //                    id = the child has edges of its own.
 //
 // PACKED TABLES (specialised kernel, kernels_fast.hip).  Every model a Vaporetto / KyTea trainer produces has weights quantised
-// to 16 bits (trainer.rs:18,383-397; kytea_model.rs:72-79) and BMP-only patterns; the distributed ones have char window 3, and
-// train/src/main.rs:33-51 lets --charw / --typew be anything.  For such models -- every pattern symbol in [1, 0xFFFE], windows up to
+// to 16 bits (trainer.rs:18,383-397; kytea_model.rs:72-79); the distributed ones have char window 3, and
+// train/src/main.rs:33-51 lets --charw / --typew be anything.  For such models -- any pattern chars (at most 65 533 distinct ones), windows up to
 // 8 -- the same all-matches information is also emitted as a DOUBLE-ARRAY TRIE over the first three symbols of the patterns,
 // walked from every start position.  What shapes it is what bounds the kernel on MI355X (profiles/r02_*): the vector L1's address
 // pipeline -- a lane's 16-byte load costs about 1.4 ns / 256 CUs of it and every distinct line it touches another 2.7 -- so a
@@ -82,6 +82,11 @@
 //          an entry with dword 0 == 0 ends the search.  Entry 0 of the arena is unused so that ref 0 = none.
 //   cpid   n_alpha + 2 words: the code point of an id (only the rare kPkWide replay needs it: the general tables are
 //          keyed by code points).
+//   xcid   the alphabet's chars OUTSIDE the BMP (UniDic-derived dictionaries have a few: U+20B9F, U+29E3D ..; any `String` is a
+//          pattern to the reference, char_scorer/boundary_scorer.rs:56-89): entry 0 = {log2(entries), 0}, then 2^bits entries
+//          {code point, id} (code point 0 = free; at most half of them taken), home = xcid_slot, linear probing.  The kernel's
+//          classification reads `cid` for a BMP char and probes here for the others -- a branch a wave takes only when one of its
+//          64 chars lies outside the BMP.  No such char in the alphabet: no table (PackedView::off_xcid = 0).
 //
 // Bases come from first-fit placement at load time (rows with the most children first; a row = the set of child ids of
 // one parent): every present key is found by exactly one node read, an absent key lands on a free node or on another
@@ -146,6 +151,18 @@ VPT_HD uint32_t hash_slot(uint64_t key, uint32_t shift) {
 // packed-table hashes
 VPT_HD uint32_t packed_mini_slot(uint32_t sym, uint32_t ref) { return ((sym * kHashMulLo) >> 15) & ((1u << (ref & 31u)) - 1u); }
 VPT_HD uint32_t packed_filter_bit(uint32_t sym) { return (sym * kHashMulHi) >> 26; }   // 0..63
+// the alphabet outside the BMP (header comment, "xcid"): `tab` = the section's first dword
+VPT_HD uint32_t xcid_slot(uint32_t cp, uint32_t bits) { return (cp * kHashMulLo) >> (32u - bits); }   // bits in 1..31
+VPT_HD uint32_t xcid_find(const uint32_t* tab, uint32_t cp) {
+    const uint32_t bits = tab[0], mask = (1u << bits) - 1u;
+    const uint32_t* const e = tab + 2;
+    for (uint32_t i = xcid_slot(cp, bits), n = 0; n <= mask; i = (i + 1u) & mask, ++n) {
+        const uint32_t k = e[2u * i];
+        if (k == cp) return e[2u * i + 1u];
+        if (k == 0u) break;
+    }
+    return 0xFFFFu;   // kNoId
+}
 
 // Tag token table (HostTagTables::tok_tab): a surface is hashed from its length and the low 16 bits of its first four chars
 // (lo = c0 | c1 << 16, hi = c2 | c3 << 16, zero past the end) -- a lane builds the key with four reads and no loop over the
@@ -242,6 +259,7 @@ struct PatternTableView {
 struct PackedView {
     const unsigned char* base;
     uint32_t off_uni, off_bi, off_tri, off_deep, off_xrows, off_trow, off_cpid;   // byte offsets, 256-byte aligned
+    uint32_t off_xcid;              // the alphabet's chars outside the BMP (0: there are none)
     uint32_t n_uni;                 // unigram nodes (ids above n_uni - 1 read the last, all-zero one)
     uint32_t n_tri;                 // trigram nodes (a filter false positive may point past them)
     uint32_t bi_shift;              // bigram slot = (B1 << bi_shift) + id2

@@ -214,9 +214,9 @@ HostPatternTable build_table(const PatSet& S, int W, uint32_t uni_n) {
     return t;
 }
 
-// ---- packed tables (layout.h, "PACKED TABLES").  `S` must be sorted and merged.
-// Not eligible (present = false) when a pattern symbol is outside [1, 0xFFFE]: the general tables/kernel handle
-// such a model.  A merged row with a value outside its fields keeps its node with zero weights and a wide flag (patterns
+// ---- packed tables (layout.h, "PACKED TABLES").  `S_in` must be sorted and merged.
+// Not eligible (present = false) only when the format cannot hold the model (an alphabet of 65 534 chars or more, bigram bases past
+// their 19 bits, more than 2^28 nodes of a level): the general tables/kernel handle such a model.  A merged row with a value outside its fields keeps its node with zero weights and a wide flag (patterns
 // of <= 3 chars: the kernel takes the row from the general tables) or goes to `xrows` as i32 (longer patterns).
 inline bool fits_i16(int32_t v) { return v >= -32768 && v <= 32767; }
 inline uint32_t pack16(int32_t lo, int32_t hi) { return (uint32_t(lo) & 0xFFFFu) | (uint32_t(hi) << 16); }
@@ -316,33 +316,70 @@ struct Placer {
     }
 };
 
-HostPackedTable build_packed(const PatSet& S, int wl) {
+HostPackedTable build_packed(const PatSet& S_in, int wl) {
     StageTimer tm;
     HostPackedTable t;
     t.wl = wl;
     const size_t udw = size_t(pk_uni_dw(wl)), bdw = size_t(pk_bi_dw(wl)), tdw = size_t(pk_tri_dw(wl));
-    // ---- the alphabet: ids by how many pattern symbols the char is (most first; ties in code-point order)
+    // A pattern that holds U+0000 matches no text (a sentence with a NUL is an error, sentence.rs:174-179): it takes no part here (0 is
+    // the tables' "outside the sentence").  `S` = the patterns that can match; the copy is made for such a model only.
+    PatSet filtered;
     {
-        std::vector<uint8_t> seen(65536, 0);
-        t.hot.assign(65536, 0);
+        bool nul = false;
+        for (const PatRef& p : S_in.p)
+            for (uint32_t i = 0; i < p.n && !nul; ++i) nul = S_in.s(p)[i] == 0;
+        if (nul) {
+            filtered.syms = S_in.syms; filtered.rows = S_in.rows;
+            for (const PatRef& p : S_in.p) {
+                bool has = false;
+                for (uint32_t i = 0; i < p.n; ++i) has = has || S_in.s(p)[i] == 0;
+                if (!has) filtered.p.push_back(p);
+            }
+        }
+    }
+    const PatSet& S = filtered.syms.empty() ? S_in : filtered;
+    // ---- the alphabet: ids by how many pattern symbols the char is (most first; ties in code-point order).  A char of the BMP finds
+    // its id in the kernel's 65536-word table, any other in `xcid` (layout.h)
+    {
+        constexpr uint32_t kScalars = 0x110000u;
+        std::vector<uint8_t> seen(kScalars, 0);
+        t.hot.assign(kScalars, 0);
         for (const PatRef& p : S.p)
             for (uint32_t i = 0; i < p.n; ++i) {
                 const Sym c = S.s(p)[i];
-                if (c == 0 || c >= kNoId) return t;
+                if (c >= kScalars) return t;   // no char: nothing a decoded model holds
                 seen[c] = 1;
                 ++t.hot[c];
             }
         t.id_of.assign(65536, uint16_t(kNoId));
         t.cpid.push_back(0);
         std::vector<uint32_t> order;
-        for (uint32_t cp = 1; cp < kNoId; ++cp)
+        for (uint32_t cp = 1; cp < kScalars; ++cp)
             if (seen[cp]) order.push_back(cp);
+        if (order.size() >= size_t(kNoId) - 1) return t;   // ids are 16 bits wide, 0 and kNoId are taken
         std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return t.hot[a] > t.hot[b]; });
-        for (uint32_t cp : order) { t.id_of[cp] = uint16_t(t.cpid.size()); t.cpid.push_back(cp); }
+        std::vector<std::pair<uint32_t, uint32_t>> outside;
+        for (uint32_t cp : order) {
+            const uint32_t id = uint32_t(t.cpid.size());
+            if (cp < 0x10000u) t.id_of[cp] = uint16_t(id); else outside.push_back({cp, id});
+            t.cpid.push_back(cp);
+        }
         t.n_alpha = uint32_t(t.cpid.size() - 1);
         t.cpid.push_back(0);   // the id every char outside the alphabet reads its (zero) unigram node at
+        if (!outside.empty()) {
+            uint32_t bits = 1;
+            while ((size_t(1) << bits) < 2 * outside.size()) ++bits;
+            t.xcid.assign(2 + (size_t(2) << bits), 0);
+            t.xcid[0] = bits;
+            const uint32_t mask = (1u << bits) - 1u;
+            for (const auto& e : outside) {
+                uint32_t i = xcid_slot(e.first, bits);
+                while (t.xcid[2 + 2 * size_t(i)] != 0) i = (i + 1) & mask;
+                t.xcid[2 + 2 * size_t(i)] = e.first; t.xcid[3 + 2 * size_t(i)] = e.second;
+            }
+        }
     }
-    auto id = [&](Sym c) { return uint32_t(t.id_of[c]); };
+    auto id = [&](Sym c) { return t.id_for(c); };
     auto wide16 = [&](const PatRef& p) {
         for (uint32_t k = 0; k < p.rlen; ++k)
             if (!fits_i16(S.row(p)[k])) return true;
@@ -599,6 +636,7 @@ HostPackedTable build_packed(const PatSet& S, int wl) {
     tm.mark("packed: nodes");
     if (tm.on) std::fprintf(stderr, "[vpt compile] alphabet %u, bigram nodes %u in %zu slots (shift %u), trigram nodes %u in %zu slots, deep entries %u, wide rows %u\n",
                             t.n_alpha, t.n_bi, bi_slots, t.bi_shift, t.n_tri, tri_slots, t.n_deep, t.n_wide);
+    t.hot = std::vector<uint32_t>();
     t.present = true;
     return t;
 }

@@ -41,11 +41,13 @@ struct HostPackedTable {
     uint32_t trow_mode = kTypeRowsNone, trow_levels = 0;
     std::vector<uint32_t> cpid;    // n_alpha + 2: id -> code point
     std::vector<uint16_t> id_of;   // 65536: BMP code point -> id (kNoId: no pattern contains it)
-    std::vector<uint32_t> hot;     // 65536: how many pattern symbols are this code point (what the LDS caches of the kernel are filled by)
+    std::vector<uint32_t> xcid;    // the alphabet's chars outside the BMP (layout.h, "xcid"); empty when there are none
+    std::vector<uint32_t> hot;     // 0x110000: how many pattern symbols are this code point (ids go by it)
+    uint32_t id_for(uint32_t cp) const { return cp < 0x10000u ? uint32_t(id_of[cp]) : (xcid.empty() ? kNoId : xcid_find(xcid.data(), cp)); }
     uint32_t n_alpha = 0, bi_shift = 2;
     // statistics
     uint32_t n_bi = 0, n_tri = 0, n_deep = 0, n_wide = 0;
-    uint64_t bytes() const { return 4ull * (uni.size() + bi.size() + tri.size() + deep.size() + xrows.size() + trow.size() + cpid.size()); }
+    uint64_t bytes() const { return 4ull * (uni.size() + bi.size() + tri.size() + deep.size() + xrows.size() + trow.size() + cpid.size() + xcid.size()); }
 };
 
 // Tag prediction tables (Predictor::predict_tags, predictor.rs:546-637), see kernels_tags.hip.

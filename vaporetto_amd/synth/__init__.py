@@ -14,6 +14,7 @@ LIB_PATH = os.path.join(HERE, "libvpt_synth.so")
 _SOURCES = [os.path.join(HERE, "synth.cpp"), os.path.join(HERE, "..", "csrc", "model.cpp")]
 
 M1_BCCWJ_LIKE, M2_KYTEA_LIKE, M3_TAGS = 1, 2, 3
+M1_NONBMP = 6   # M1 + 40 unigrams, 100 n-grams and 100 dictionary words with kanji outside the BMP
 SEED_BASE = 0x5EED0000  # + config number
 
 
@@ -37,6 +38,8 @@ def _load():
                                           C.POINTER(C.c_void_p), C.POINTER(C.c_size_t), C.POINTER(C.c_void_p)]
         L.vpt_synth_sentences_ex.argtypes = [C.c_char_p, C.c_size_t, C.c_uint64, C.c_size_t, C.c_uint32, C.c_uint32, C.c_double,
                                              C.POINTER(C.c_void_p), C.POINTER(C.c_size_t), C.POINTER(C.c_void_p)]
+        L.vpt_synth_sentences_nb.argtypes = [C.c_char_p, C.c_size_t, C.c_uint64, C.c_size_t, C.c_uint32, C.c_uint32, C.c_double, C.c_double,
+                                             C.POINTER(C.c_void_p), C.POINTER(C.c_size_t), C.POINTER(C.c_void_p)]
         L.vpt_synth_blocks.argtypes = [C.c_char_p, C.c_size_t, C.c_uint64, C.c_size_t, C.c_size_t, C.c_size_t, C.c_uint32, C.c_uint32, C.c_uint32,
                                        C.POINTER(C.c_void_p), C.POINTER(C.c_size_t), C.POINTER(C.c_void_p)]
         L.vpt_synth_free.argtypes = [C.c_void_p]
@@ -59,13 +62,18 @@ def synth_model(kind: int = M1_BCCWJ_LIKE, seed: int = SEED_BASE + 2, scale: flo
 
 
 def synth_sentences(model_bytes: bytes, n_sentences: int, min_len: int = 64, max_len: int = 64,
-                    seed: int = SEED_BASE + 2, hit_share: float = 0.7):
+                    seed: int = SEED_BASE + 2, hit_share: float = 0.7, nonbmp_share: float = 0.0):
     """(utf8 uint8[bytes], byte_offsets uint64[S+1]) -- `hit_share` (70 %) of a sentence's items are model patterns
-    (Zipf), the others alphabet-A characters."""
+    (Zipf), the others alphabet-A characters; `nonbmp_share` of the items (in front of that draw) are chars outside the BMP, half of
+    them as one of the model's patterns that hold such a char."""
     L = _load()
     text, nbytes, boff = C.c_void_p(), C.c_size_t(), C.c_void_p()
-    st = L.vpt_synth_sentences_ex(model_bytes, len(model_bytes), seed, n_sentences, min_len, max_len, C.c_double(hit_share),
-                                  C.byref(text), C.byref(nbytes), C.byref(boff))
+    if nonbmp_share:
+        st = L.vpt_synth_sentences_nb(model_bytes, len(model_bytes), seed, n_sentences, min_len, max_len, C.c_double(hit_share), C.c_double(nonbmp_share),
+                                      C.byref(text), C.byref(nbytes), C.byref(boff))
+    else:
+        st = L.vpt_synth_sentences_ex(model_bytes, len(model_bytes), seed, n_sentences, min_len, max_len, C.c_double(hit_share),
+                                      C.byref(text), C.byref(nbytes), C.byref(boff))
     if st != 0:
         raise RuntimeError("vpt_synth_sentences failed: %d" % st)
     try:

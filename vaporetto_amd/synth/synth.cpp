@@ -81,6 +81,13 @@ std::vector<uint32_t> make_vocab(uint32_t size) {
     return v;
 }
 
+// 40 kanji of CJK Extension B (kind 6): the three UniDic is known for, the others spread over the block
+std::vector<uint32_t> nonbmp_chars() {
+    std::vector<uint32_t> v = {0x20B9Fu, 0x20BB7u, 0x29E3Du};
+    for (uint32_t k = 0; v.size() < 40; ++k) v.push_back(0x20000u + 1031u * k + 7u);
+    return v;
+}
+
 std::vector<int32_t> rand_weights(Rng& r, size_t n, double p) {
     std::vector<int32_t> w(n);
     for (auto& x : w) x = r.weight(p);
@@ -111,7 +118,8 @@ extern "C" {
 void vpt_synth_free(void* p) { std::free(p); }
 
 // kind: 1 = M1 (bccwj-suw+unidic-like), 2 = M2 (jp-0.4.7-5-like), 3 = M3 (M1 + tag models), 4 / 5 = M1 trained with
-// --charw 2 --typew 2 / --charw 4 --typew 4 (train/src/main.rs:33-51: the windows are free parameters).  scale multiplies
+// --charw 2 --typew 2 / --charw 4 --typew 4 (train/src/main.rs:33-51: the windows are free parameters), 6 = M1 + 100 char n-grams and
+// 100 dictionary words that hold kanji OUTSIDE the BMP (UniDic has such entries: U+20B9F, U+20BB7, U+29E3D ..).  scale multiplies
 // every count (1.0 = full size).  Returns 0 and a malloc'ed model file.
 int vpt_synth_model_ex(int kind, uint64_t seed, double scale, uint32_t vocab, double dup_share, uint8_t** out, size_t* out_len);
 int vpt_synth_model(int kind, uint64_t seed, double scale, uint8_t** out, size_t* out_len) {
@@ -121,7 +129,7 @@ int vpt_synth_model(int kind, uint64_t seed, double scale, uint8_t** out, size_t
 // dictionary words are copies of the model's own 2- and 3-char n-grams, whose merged rows then overflow the packed tables' 16-bit
 // fields (the kernel's wide-row path); the model-shape sweep of tools/model_sweep.py
 int vpt_synth_model_ex(int kind, uint64_t seed, double scale, uint32_t vocab_size, double dup_share, uint8_t** out, size_t* out_len) {
-    if (kind < 1 || kind > 5 || !(scale > 0) || !out || !out_len || vocab_size > 20000 || dup_share < 0 || dup_share > 1) return 2;
+    if (kind < 1 || kind > 6 || !(scale > 0) || !out || !out_len || vocab_size > 20000 || dup_share < 0 || dup_share > 1) return 2;
     Rng r(seed);
     const uint32_t V = vocab_size ? std::max<uint32_t>(300, vocab_size) : std::max<uint32_t>(300, uint32_t(4000 * std::min(1.0, std::sqrt(scale))));
     const std::vector<uint32_t> vocab = make_vocab(V);
@@ -153,10 +161,31 @@ int vpt_synth_model_ex(int kind, uint64_t seed, double scale, uint32_t vocab_siz
     };
     draw(n_bi, 2);
     draw(n_tri, 3);
+    // (kind 6) the patterns with chars outside the BMP come from a stream of their own: everything else is M1, value for value
+    Rng rx(seed ^ 0x6E6F6E2D424D50ull);
+    const std::vector<uint32_t> outside = nonbmp_chars();
+    auto nonbmp_string = [&](uint32_t n) {
+        std::vector<uint32_t> g(n);
+        for (uint32_t k = 0; k < n; ++k) g[k] = vocab[rx.zipf(V)];
+        g[rx.below(n)] = outside[rx.below(uint32_t(outside.size()))];
+        if (n > 2 && rx.uniform() < 0.3) g[rx.below(n)] = outside[rx.below(uint32_t(outside.size()))];
+        return g;
+    };
+    const size_t n_base_grams = grams.size();
+    if (kind == 6) {
+        for (uint32_t c : outside) grams.push_back({c});
+        std::unordered_set<std::string> have;
+        while (grams.size() < n_base_grams + outside.size() + 100) {
+            std::vector<uint32_t> g = nonbmp_string(2 + rx.below(2));
+            std::string key(reinterpret_cast<const char*>(g.data()), g.size() * 4);
+            if (have.insert(key).second) grams.push_back(std::move(g));
+        }
+    }
     w.uvar(grams.size());
-    for (const auto& g : grams) {
+    for (size_t gi = 0; gi < grams.size(); ++gi) {
+        const auto& g = grams[gi];
         w.utf8(g);
-        w.weights(rand_weights(r, size_t(2 * W - int(g.size()) + 1), p_nz));
+        w.weights(rand_weights(gi < n_base_grams ? r : rx, size_t(2 * W - int(g.size()) + 1), p_nz));
     }
     // ---- all 258 type n-grams
     std::vector<std::vector<uint8_t>> tgrams;
@@ -195,10 +224,20 @@ int vpt_synth_model_ex(int kind, uint64_t seed, double scale, uint32_t vocab_siz
             words.push_back(std::move(g));
         }
     }
+    const size_t n_base_words = words.size();
+    if (kind == 6) {
+        std::unordered_set<std::string> have;
+        while (words.size() < n_base_words + 100) {
+            std::vector<uint32_t> g = nonbmp_string(1 + rx.below(6));
+            std::string key(reinterpret_cast<const char*>(g.data()), g.size() * 4);
+            if (have.insert(key).second) words.push_back(std::move(g));
+        }
+    }
     w.uvar(words.size());
-    for (const auto& g : words) {
+    for (size_t wi = 0; wi < words.size(); ++wi) {
+        const auto& g = words[wi];
         w.utf8(g);
-        w.weights(rand_weights(r, g.size() + 1, 0.6));
+        w.weights(rand_weights(wi < n_base_words ? r : rx, g.size() + 1, 0.6));
         w.str("");
     }
     w.i32(int32_t(r.below(20001)) - 10000);  // bias
@@ -264,9 +303,15 @@ struct PatternList {
 };
 // one block of sentences from its own splitmix64 stream: text bytes appended to `text`, byte length of every sentence to `lens`
 void gen_block(const PatternList& P, uint64_t seed, size_t n_sent, uint32_t min_len, uint32_t max_len, std::vector<uint8_t>& text,
-               std::vector<uint32_t>& lens, double hit_share = 0.7) {
+               std::vector<uint32_t>& lens, double hit_share = 0.7, double nonbmp_share = 0.0) {
     const std::vector<const vpt::SymString*>& pats = P.pats;
     Rng r(seed);
+    // nonbmp_share > 0: that share of a sentence's ITEMS is a char outside the BMP -- half of them one of the model's patterns that hold
+    // such a char (sorted last, a Zipf draw over the list never reaches them), half any kanji of CJK Extension B
+    std::vector<const vpt::SymString*> nb_pats;
+    if (nonbmp_share > 0)
+        for (const vpt::SymString* p : pats)
+            if (std::any_of(p->begin(), p->end(), [](uint32_t c) { return c >= 0x10000u; })) nb_pats.push_back(p);
     auto alphabet_a = [&]() -> uint32_t {
         double u = r.uniform();
         if (u < 0.50) return 0x3041 + r.below(0x3093 - 0x3041 + 1);
@@ -288,6 +333,11 @@ void gen_block(const PatternList& P, uint64_t seed, size_t n_sent, uint32_t min_
         }
         sent.clear();
         while (sent.size() < L) {
+            if (nonbmp_share > 0 && r.uniform() < nonbmp_share) {
+                if (!nb_pats.empty() && r.below(2)) { const vpt::SymString& p = *nb_pats[r.below(uint32_t(nb_pats.size()))]; sent.insert(sent.end(), p.begin(), p.end()); }
+                else sent.push_back(0x20000u + r.below(0xA6E0u));
+                continue;
+            }
             if (!pats.empty() && r.uniform() < hit_share) {
                 const vpt::SymString& p = *pats[r.zipf(uint32_t(pats.size()))];
                 sent.insert(sent.end(), p.begin(), p.end());
@@ -336,6 +386,17 @@ int vpt_synth_sentences_ex(const uint8_t* model, size_t model_len, uint64_t seed
     std::vector<std::vector<uint8_t>> texts(1);
     std::vector<std::vector<uint32_t>> lens(1);
     gen_block(P, seed, n_sent, min_len, max_len, texts[0], lens[0], hit_share);
+    return emit(texts, lens, utf8_out, nbytes_out, boff_out);
+}
+// ... and `nonbmp_share` of the items chars outside the BMP (gen_block)
+int vpt_synth_sentences_nb(const uint8_t* model, size_t model_len, uint64_t seed, size_t n_sent, uint32_t min_len,
+                           uint32_t max_len, double hit_share, double nonbmp_share, uint8_t** utf8_out, size_t* nbytes_out, uint64_t** boff_out) {
+    if (!model || !utf8_out || !nbytes_out || !boff_out || min_len < 1 || max_len < min_len || !(hit_share >= 0 && hit_share <= 1) || !(nonbmp_share >= 0 && nonbmp_share <= 1)) return 2;
+    PatternList P;
+    if (!P.load(model, model_len)) return 1;
+    std::vector<std::vector<uint8_t>> texts(1);
+    std::vector<std::vector<uint32_t>> lens(1);
+    gen_block(P, seed, n_sent, min_len, max_len, texts[0], lens[0], hit_share, nonbmp_share);
     return emit(texts, lens, utf8_out, nbytes_out, boff_out);
 }
 int vpt_synth_sentences(const uint8_t* model, size_t model_len, uint64_t seed, size_t n_sent, uint32_t min_len,
