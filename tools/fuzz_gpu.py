@@ -27,7 +27,7 @@ f = api.KyteaFullwidthFilter()
 while time.time() < t_end:
     seed += 1
     rng = random.Random(seed)
-    alpha = [chr(c) for c in range(0x3041, 0x3041 + rng.choice([3, 6, 12, 30]))] + rng.sample(list("漢字AZ09az-.、。ｱ￾𠮷 /\\"), rng.randint(0, 6))
+    alpha = [chr(c) for c in range(0x3041, 0x3041 + rng.choice([3, 6, 12, 30]))] + rng.sample(list("漢字AZ09az-.、。ｱ￾￿𠮷𩸽🤌 /\\"), rng.randint(0, 6))
     # windows: what the distributed models have (3) half the time, anything up to 8 otherwise (round 4: every window on the packed tables)
     m = randmodel.rand_model(9000 + seed, alphabet=alpha, wc=rng.choice([3, 3, 3, 3, 2, 1, 4, 5, 6, 7, 8]), wt=rng.choice([1, 2, 3, 3, 3, 4, 5, 6, 8]),
                              max_n=rng.choice([3, 3, 4, 6]), n_char=rng.choice([20, 200, 1500]), n_dict=rng.choice([0, 30, 400, 3000]), n_type=rng.choice([0, 10, 80]),
