@@ -35,6 +35,11 @@
 // lock-step marker of the kernels (device_common.h): the lanes of the wave meet here
 #define VPT_WAVE_LOCKSTEP() ::hipemu::wave_sync()
 #define VPT_PIN(x) ((void)0)   /* a code-generation hint on the GPU */
+// the kernel's parameter block through a pointer (device_common.h): here simply the by-value argument
+#define VPT_KARG(T) const T*
+#define VPT_KARG_PTR(T, arg) (&(arg))
+#define VPT_KARG_FENCE(p) ((void)0)
+#define VPT_UNDEF4(v) ((v) = make_uint4(0xDEADBEEFu, 0xDEADBEEFu, 0xDEADBEEFu, 0xDEADBEEFu))   /* poison: a use before the guarded load shows */
 
 struct uint2 { uint32_t x, y; };
 struct uint4 { uint32_t x, y, z, w; } __attribute__((aligned(16)));

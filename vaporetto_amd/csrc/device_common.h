@@ -23,6 +23,19 @@
 #define VPT_PIN(x) __asm__ volatile("" : "+v"(x))
 #endif
 
+// The kernel's parameter block read WHERE IT IS USED.  A by-value kernel argument is loaded from the kernarg segment at the kernel's entry
+// and kept in scalar registers to its last use; the specialised scoring kernel has 70-odd such words and 72 SGPRs at 8 waves per SIMD
+// (800 per SIMD, 16 of every wave's allocation reserved for the trap handler), so the compiler spilled 84 of them to VGPR lanes.  The
+// kernel reads its block through a pointer into the kernarg segment instead (scalar loads out of the constant cache, a phase's fields
+// asked for at the top of the phase) and puts a FENCE between phases, behind which nothing loaded earlier is assumed still at hand.
+// VPT_UNDEF4: a uint4 whose value does not matter until a guarded load has filled it (no zeroing moves).
+#ifndef VPT_KARG
+#define VPT_KARG(T) const __attribute__((address_space(4))) T*
+#define VPT_KARG_PTR(T, arg) ((VPT_KARG(T))__builtin_amdgcn_kernarg_segment_ptr())
+#define VPT_KARG_FENCE(p) __asm__ volatile("" : "+s"(p))
+#define VPT_UNDEF4(v) __asm__ volatile("" : "=v"((v).x), "=v"((v).y), "=v"((v).z), "=v"((v).w))
+#endif
+
 namespace vpt {
 
 // A value that every lane of the wave holds alike, moved to a scalar register.  The hardware gains nothing; the
@@ -123,17 +136,19 @@ __device__ __forceinline__ uint32_t load4(const uint8_t* __restrict__ p, uint64_
     return nv == 4u ? x : x & ((1u << (8u * nv)) - 1u);
 }
 
-// 4-bit mask of the bytes of x that are NOT UTF-8 continuation bytes (10xxxxxx)
-__device__ __forceinline__ uint32_t lead_nibble(uint32_t x) {
-    uint32_t cont = x & ~(x << 1) & 0x80808080u;  // bit7 set and bit6 clear
-    uint32_t lead = (~cont & 0x80808080u) >> 7;   // 0/1 at bits 0, 8, 16, 24
-    return ((lead * 0x00204081u) >> 21) & 0xFu;
+// bits 7, 15, 23, 31 -> bits 0..3.  Bits 7, 15, 23 travel to bits 21, 22, 23 of a 24-bit product (0x4081 = bits 0, 7, 14: the nine
+// partial products fall on nine different bits) -- a full-rate v_mul_u32_u24, where the 32-bit multiply this used to be (v_mul_lo_u32)
+// takes four issue slots and every chunk of text needs eight of them -- and bit 31 is placed by hand.
+__device__ __forceinline__ uint32_t byte_flags_to_nibble(uint32_t m) {
+    return ((((m & 0x00808080u) * 0x4081u) >> 21) & 7u) | ((m >> 31) << 3);
 }
+// 4-bit mask of the bytes of x that are NOT UTF-8 continuation bytes (10xxxxxx): bit 7 clear or bit 6 set
+__device__ __forceinline__ uint32_t lead_nibble(uint32_t x) { return byte_flags_to_nibble((~x | (x << 1)) & 0x80808080u); }
+// 16-bit mask over the 16 bytes of v
+__device__ __forceinline__ uint32_t lead_mask16(const uint4& v) { return lead_nibble(v.x) | (lead_nibble(v.y) << 4) | (lead_nibble(v.z) << 8) | (lead_nibble(v.w) << 12); }
 
 // 0x80 in every byte of v that is zero (exact: no carries between the bytes)
 __device__ __forceinline__ uint32_t zero_bytes(uint32_t v) { return ~(((v & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | v | 0x7F7F7F7Fu); }
-// bits 7, 15, 23, 31 -> bits 0..3
-__device__ __forceinline__ uint32_t byte_flags_to_nibble(uint32_t m) { return (((m >> 7) * 0x00204081u) >> 21) & 0xFu; }
 // 4-bit mask of the bytes of x that Sentence::write_tokenized_text escapes: ' ', '\', '/' (sentence.rs:850-886)
 __device__ __forceinline__ uint32_t esc_nibble(uint32_t x) {
     return byte_flags_to_nibble(zero_bytes(x ^ 0x20202020u) | zero_bytes(x ^ 0x5C5C5C5Cu) | zero_bytes(x ^ 0x2F2F2F2Fu));

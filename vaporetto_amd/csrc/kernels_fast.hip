@@ -70,6 +70,7 @@ struct FastLdsT {
     uint2 queue[kWavesF][kQCap];             // sentence-start bitmap during decode
     uint32_t mqueue[kWavesF][kMCap];
     uint32_t wtot[8];
+    uint32_t geo[8];                         // the tile's geometry for phase C (written in phase A: it does not wait in registers over phase B)
     union {                                  // never needed together; the launch allocates the one in use
         uint8_t typ[G::kSymSlots];           // window-table modes
         uint4 trow[kTrowCount * G::kTrowQ];  // TM == kTypeRows, rows in LDS
@@ -173,12 +174,18 @@ __device__ __forceinline__ void unpack4(const uint4 (&v)[Q], uint32_t (&d)[4 * Q
     d[4 * Q] = 0;
 }
 
+// What the trie replays read of the packed tables: scalars of the launch, kept in registers over the pattern phase.
+struct DeepView {
+    const unsigned char* base;
+    uint32_t off_deep;
+};
+
 // W: up to 64 queued trie steps, all lanes busy: the child sym[s + depth] in the mini-table `ref` of `deep`, whose
 // 64-byte entries also name the up-to-8 symbols that must follow (compressed single-child chains; layout.h).
 // The home entry and the next one are read together (a mini-table keeps a quarter of its entries free, so nearly
-// every search ends within two); the rare longer search loops.
+// every search ends within two); the rare longer search loops.  `P`: the parameter block, for what only the rare rows need.
 template <int WL>
-__device__ __forceinline__ void replay_w(const PackedView& K, FastLds& L, WaveStacks& Q, int lane, uint64_t* prof = nullptr) {
+__device__ __forceinline__ void replay_w(VPT_KARG(ScoreParams) P, const DeepView& K, FastLds& L, WaveStacks& Q, int lane, uint64_t* prof = nullptr) {
     VPT_WAVE_LOCKSTEP();   // the queue entries were written by other lanes
     const uint32_t take = wave_uniform(Q.nw < 64u ? Q.nw : 64u);   // opaque: nw - min(nw, 64) would become a VALU-only saturating subtract
     Q.nw = wave_uniform(Q.nw - take);
@@ -252,7 +259,9 @@ __device__ __forceinline__ void replay_w(const PackedView& K, FastLds& L, WaveSt
     }
     if (__ballot(found && (e.x & (kPkExtRow << 16))) != 0) {  // more than 14 weights or a value outside i16 (rare)
         if (found && (e.x & (kPkExtRow << 16))) {
-            const int32_t* w32 = reinterpret_cast<const int32_t*>(K.base + K.off_xrows) + ld16(K.base, ent + 32).x;
+            VPT_KARG(ScoreParams) R = P;
+            VPT_KARG_FENCE(R);   // (asked for here, not kept over the pattern phase)
+            const int32_t* w32 = reinterpret_cast<const int32_t*>(K.base + R->pk.off_xrows) + ld16(K.base, ent + 32).x;
             for (uint32_t j = 0; j < rlen; ++j) atomicAdd(dst + j, w32[j]);
         }
     }
@@ -269,64 +278,68 @@ struct GeneralGeom {
 // Entry of a <= 3-char string in the GENERAL short table (layout.h; buckets of two entries): used for the rare packed nodes whose
 // row is marked wide.  Returns the entry's first dword or nullptr.
 template <int WL>
-__device__ __forceinline__ const uint32_t* general_row(const PatternTableView& T, uint64_t key) {
+__device__ __forceinline__ const uint32_t* general_row(const uint32_t* short_tab, uint32_t short_shift, uint32_t short_mask, uint64_t key) {
     constexpr uint32_t kStride = GeneralGeom<WL>::kStride;
     const uint32_t klo = uint32_t(key), khi = uint32_t(key >> 32);
-    uint32_t b = hash_slot(key, T.short_shift);
+    uint32_t b = hash_slot(key, short_shift);
     bool home = true;
     for (;;) {
-        const uint32_t* e0 = T.short_tab + size_t(b) * (2 * kStride);
+        const uint32_t* e0 = short_tab + size_t(b) * (2 * kStride);
         const uint32_t* e1 = e0 + kStride;
         const uint32_t a0 = e0[0], a1 = e0[1], b0 = e1[0], b1 = e1[1];
         if (a0 == klo && (a1 & ~kDisplacedBit) == khi) return e0;
         if (b0 == klo && b1 == khi) return e1;
         if ((a0 | a1) == 0 || (b0 | b1) == 0 || (home && !(a1 & kDisplacedBit))) return nullptr;
         home = false;
-        b = (b + 1) & T.short_mask;
+        b = (b + 1) & short_mask;
     }
 }
 
-// rows with a value outside their fields (rare): the general tables hold them as i32, keyed by code points; the row of a string of
-// n chars covers the boundaries s + row_lo(n, WL) .. (layout.h)
+// M: up to 64 queued rows with a value outside their fields (rare) -- taken from the general tables, which hold them as i32 keyed by
+// code points; the row of a string of n chars covers the boundaries s + row_lo(n, WL) .. (layout.h).  An item is what ONE lane of ONE
+// trip of the main loop found wide: su | kinds << 11 with the unigram's start su, the bigram's su - 256, the trigram's su - 512 (the
+// three stages a lane has in flight).  Everything this needs of the parameter block is asked for here.
 template <int WL>
-__device__ __forceinline__ void add_wide_rows(const PackedView& K, const PatternTableView& T, FastLds& L, uint32_t kinds, uint32_t s) {
-    const uint32_t* cpid = reinterpret_cast<const uint32_t*>(K.base + K.off_cpid);
+__device__ __forceinline__ void replay_m(VPT_KARG(ScoreParams) P, FastLds& L, WaveStacks& Q, int lane) {
+    VPT_WAVE_LOCKSTEP();   // the queue entries were written by other lanes
+    VPT_KARG(ScoreParams) R = P;
+    VPT_KARG_FENCE(R);
+    const uint32_t take = wave_uniform(Q.nm < 64u ? Q.nm : 64u);
+    Q.nm -= take;
+    if (uint32_t(lane) >= take) return;
+    const uint32_t it = Q.mq[Q.nm + lane];
+    const uint32_t kinds = it >> 11, su = it & 0x7FFu;
+    const unsigned char* base = R->pk.base;
+    const uint32_t* cpid = reinterpret_cast<const uint32_t*>(base + R->pk.off_cpid);
+    const uint32_t* short_tab = R->ct.short_tab;
+    const uint32_t* uni = R->ct.uni;
+    const uint32_t short_shift = R->ct.short_shift, short_mask = R->ct.short_mask;
     // a wide row belongs to a pattern that matched here: its chars are in the alphabet (ids below n_uni)
-    const uint32_t last = K.n_uni - 1u;
-    const uint32_t i1 = L.sym[s] & kCpMask, i2 = L.sym[s + 1] & kCpMask, i3 = L.sym[s + 2] & kCpMask;
-    const uint32_t c1 = cpid[i1 < last ? i1 : last], c2 = cpid[i2 < last ? i2 : last], c3 = cpid[i3 < last ? i3 : last];
+    const uint32_t last = R->pk.n_uni - 1u;
+    auto cp_at = [&](uint32_t pos) { const uint32_t i = L.sym[pos] & kCpMask; return cpid[i < last ? i : last]; };
     if (kinds & kWideUni) {   // (the general tables index the chars of the BMP directly and keep the others' rows with the short strings)
-        const uint32_t* u = c1 < kUniDirectChars ? T.uni + size_t(c1) * GeneralGeom<WL>::kUniDw : general_row<WL>(T, short_key(c1, 0, 0));
+        const uint32_t s = su, c1 = cp_at(s);
+        const uint32_t* u = c1 < kUniDirectChars ? uni + size_t(c1) * GeneralGeom<WL>::kUniDw : general_row<WL>(short_tab, short_shift, short_mask, short_key(c1, 0, 0));
         if (u && c1 >= kUniDirectChars) u += 2;
         if (u)
             for (int j = 0; j < row_len(1, WL); ++j) atomicAdd(L.score + int32_t(s) + row_lo(1, WL) + j, int32_t(u[j]));
     }
     if (kinds & kWideBi) {
-        if (const uint32_t* e = general_row<WL>(T, short_key(c1, c2, 0)))
+        const uint32_t s = su - uint32_t(kThreads);
+        if (const uint32_t* e = general_row<WL>(short_tab, short_shift, short_mask, short_key(cp_at(s), cp_at(s + 1), 0)))
             for (int j = 0; j < row_len(2, WL); ++j) atomicAdd(L.score + int32_t(s) + row_lo(2, WL) + j, int32_t(e[2 + j]));
     }
     if (kinds & kWideTri) {
-        if (const uint32_t* e = general_row<WL>(T, short_key(c1, c2, c3)))
+        const uint32_t s = su - 2u * uint32_t(kThreads);
+        if (const uint32_t* e = general_row<WL>(short_tab, short_shift, short_mask, short_key(cp_at(s), cp_at(s + 1), cp_at(s + 2))))
             for (int j = 0; j < row_len(3, WL); ++j) atomicAdd(L.score + int32_t(s) + row_lo(3, WL) + j, int32_t(e[2 + j]));
-    }
-}
-
-// M: up to 64 queued rows with a value outside their fields -- taken from the general tables (i32).
-template <int WL>
-__device__ __forceinline__ void replay_m(const PackedView& K, const PatternTableView& T, FastLds& L, WaveStacks& Q, int lane) {
-    VPT_WAVE_LOCKSTEP();   // the queue entries were written by other lanes
-    const uint32_t take = wave_uniform(Q.nm < 64u ? Q.nm : 64u);
-    Q.nm -= take;
-    if (uint32_t(lane) < take) {
-        const uint32_t it = Q.mq[Q.nm + lane];
-        add_wide_rows<WL>(K, T, L, it >> 11, it & 0x7FFu);
     }
 }
 
 // W replays until at most `mark` items are left (a W item becomes at most one W item, so the loop ends).
 template <int WL>
-__device__ __forceinline__ void drain_w(const PackedView& K, FastLds& L, WaveStacks& Q, int lane, uint32_t mark, uint64_t* prof = nullptr) {
-    while (Q.nw > mark) replay_w<WL>(K, L, Q, lane, prof);
+__device__ __forceinline__ void drain_w(VPT_KARG(ScoreParams) P, const DeepView& K, FastLds& L, WaveStacks& Q, int lane, uint32_t mark, uint64_t* prof = nullptr) {
+    while (Q.nw > mark) replay_w<WL>(P, K, L, Q, lane, prof);
 }
 
 // optional phase timing (VPT_PROFILE_PHASES): wave 0 of every workgroup adds the shader cycles it spent per phase
@@ -370,14 +383,17 @@ __device__ __forceinline__ uint64_t emit_lookback(uint64_t* state, uint32_t tile
 // DBG: the diagnostics build (VPT_DEBUG_ABLATE timing ablations, VPT_PROFILE_PHASES) -- compiled out of the kernel
 // production launches use.  WL: the row window of the packed tables (layout.h); TM: where the type scores come from.
 // EMIT: the writer fused in (EmitOut) -- a fourth phase that writes the tokenized text of the tile's own chars.
+// The parameter block is read through a pointer, phase by phase (device_common.h, VPT_KARG); what phase C needs of the tile's geometry
+// waits in LDS (FastLdsT::geo) instead of in registers over the pattern phase.
 template <int WL, int TM, bool DBG, bool EMIT>
 __global__ __launch_bounds__(kThreads, fast_wg(WL)) void score_tiles_fast_kernel(const ScoreParams P_in) {
     using G = FastGeom<WL>;
     constexpr uint32_t kPad = G::kPadG, kDump = G::kDump;
     constexpr int kFastCap = G::kCapG, kSymSlots = G::kSymSlots, kPerThread = G::kPerThread;
     constexpr int kNU = pk_uni_fields(WL), kNB = pk_bi_fields(WL), kNT = pk_tri_fields(WL);
-    ScoreParams P = P_in;
-    if (!DBG) { P.debug = 0; P.prof = nullptr; }
+    VPT_KARG(ScoreParams) P = VPT_KARG_PTR(ScoreParams, P_in);
+    const uint32_t dbg = DBG ? P->debug : 0u;
+    uint64_t* const prof = DBG ? P->prof : nullptr;
     VPT_DYNAMIC_LDS(smem);
     FastLdsT<WL>& M = *reinterpret_cast<FastLdsT<WL>*>(smem);
     FastLds L{M.sym, M.score};
@@ -392,28 +408,30 @@ __global__ __launch_bounds__(kThreads, fast_wg(WL)) void score_tiles_fast_kernel
     // look-back over their sizes (phase D) cannot wait for one that has not started.
     uint32_t tile = blockIdx.x;
     if (EMIT) {
-        if (tid == 0) M.wtot[7] = uint32_t(atomicAdd(reinterpret_cast<unsigned long long*>(P.emit.state + P.n_tiles), 1ull));
+        if (tid == 0) M.wtot[7] = uint32_t(atomicAdd(reinterpret_cast<unsigned long long*>(P->emit.state + P->n_tiles), 1ull));
         __syncthreads();
         tile = wave_uniform(M.wtot[7]);
     }
     auto publish_nothing = [&]() {   // a tile without output still has a word the later tiles look at; the last one leaves the total
         if (!EMIT) return;
-        if (tile != P.n_tiles - 1) {
-            if (tid == 0) __hip_atomic_store(P.emit.state + tile, uint64_t(1) << 62, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (tile != P->n_tiles - 1) {
+            if (tid == 0) __hip_atomic_store(P->emit.state + tile, uint64_t(1) << 62, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         } else if (wave == 0) {
-            const uint64_t end = emit_lookback(P.emit.state, tile, 0u, lane, P.emit.chain_in ? *P.emit.chain_in : 0ull, P.emit.no_prefix != 0);
+            const uint64_t end = emit_lookback(P->emit.state, tile, 0u, lane, P->emit.chain_in ? *P->emit.chain_in : 0ull, P->emit.no_prefix != 0);
             if (lane == 0) {
-                P.emit.out_offsets[P.n_sent] = end;
-                if (P.emit.total_out) *P.emit.total_out = end;
-                if (P.emit.chain_out) *P.emit.chain_out = end;
+                P->emit.out_offsets[P->n_sent] = end;
+                if (P->emit.total_out) *P->emit.total_out = end;
+                if (P->emit.chain_out) *P->emit.chain_out = end;
             }
         }
     };
     uint64_t i0, byte0, g0;
     uint32_t nbytes, nsent, flat_len, own_lo, own_hi, expect_chars, strict_end;
     int32_t c_off, sib0;
-    if (P.tiles) {
-        const TileDesc* const dp = P.tiles + tile;
+    const uint64_t* const p_boff = P->boff;
+    const uint64_t* const p_ooff = P->ooff;
+    if (P->tiles) {
+        const TileDesc* const dp = P->tiles + tile;
         nbytes = dp->nbytes;
         if (nbytes == 0) { publish_nothing(); return; }   // an empty tile (past the batch's end; reported as not fitting)
         i0 = dp->i0; nsent = dp->nsent; flat_len = dp->flat_len; own_lo = dp->own_lo; own_hi = dp->own_hi;
@@ -421,13 +439,13 @@ __global__ __launch_bounds__(kThreads, fast_wg(WL)) void score_tiles_fast_kernel
         byte0 = uint64_t(dp->byte0_lo) | (uint64_t(dp->byte0_hi) << 32); g0 = uint64_t(dp->g0_lo) | (uint64_t(dp->g0_hi) << 32);
         expect_chars = dp->expect_chars; strict_end = dp->strict_end;
     } else {
-        i0 = P.tile_first[tile];
-        const uint64_t i1 = P.tile_first[tile + 1];
+        i0 = P->tile_first[tile];
+        const uint64_t i1 = P->tile_first[tile + 1];
         if (i0 >= i1) { publish_nothing(); return; }      // no sentence starts in this tile's range
-        const uint64_t O0 = P.ooff[i0], O1 = P.ooff[i1], B0 = P.boff[i0], B1 = P.boff[i1];
+        const uint64_t O0 = p_ooff[i0], O1 = p_ooff[i1], B0 = p_boff[i0], B1 = p_boff[i1];
         const uint64_t fl = uint64_t(kPad) + (O1 + i1 * (kPad + 1)) - (O0 + i0 * (kPad + 1));
         if (O1 < O0 || B1 <= B0 || fl > uint64_t(kFastCap) || B1 - B0 > uint64_t(kFastCap) * 4 + 15 || i1 - i0 > 1023) {
-            if (tid == 0) atomicOr(P.status, kErrScratchTooSmall);   // a sentence longer than the caller's bound (or offsets that are no offsets)
+            if (tid == 0) atomicOr(P->status, kErrScratchTooSmall);   // a sentence longer than the caller's bound (or offsets that are no offsets)
             publish_nothing();
             return;
         }
@@ -435,7 +453,7 @@ __global__ __launch_bounds__(kThreads, fast_wg(WL)) void score_tiles_fast_kernel
         flat_len = uint32_t(fl); own_lo = kPad; own_hi = flat_len; g0 = O0 + i0;
         expect_chars = uint32_t((O1 + i1) - (O0 + i0)); strict_end = 1;
     }
-    const uint8_t* tbase = P.text + byte0;
+    const uint8_t* tbase = P->text + byte0;
     const uintptr_t a0 = reinterpret_cast<uintptr_t>(tbase) & ~uintptr_t(15);
     const uint32_t head = uint32_t(reinterpret_cast<uintptr_t>(tbase) - a0);
     const uint32_t nbytes_al = head + nbytes;   // <= 4 * kFastCap + 15 + 16: the assign kernels see to it
@@ -443,9 +461,8 @@ __global__ __launch_bounds__(kThreads, fast_wg(WL)) void score_tiles_fast_kernel
     // LDS positions in use, rounded up to whole waves of start positions plus the look-ahead margin: what is zeroed and walked
     const uint32_t span = ((flat_len + 63u) & ~63u) + uint32_t(kMargin) + 4u < uint32_t(kSymSlots) ? ((flat_len + 63u) & ~63u) + uint32_t(kMargin) + 4u : uint32_t(kSymSlots);
     uint32_t err = 0;
-    uint64_t* const prof = P.prof;
     uint64_t tmark = prof ? __builtin_amdgcn_s_memtime() : 0;
-    const bool trow_lds = TM == kTypeRows && P.pk.trow_mode == kTypeRowsLds;   // wave-uniform (a kernel argument)
+    const bool trow_lds = TM == kTypeRows && P->pk.trow_mode == kTypeRowsLds;   // wave-uniform (a kernel argument)
 
     // ---------------------------------------------------------------- A. decode
     // Flat layout: lead number ci of the staged text, in the tile's sentence si, sits at c_off + ci + kPad * si; everything else is
@@ -459,22 +476,28 @@ __global__ __launch_bounds__(kThreads, fast_wg(WL)) void score_tiles_fast_kernel
     // offsets are asked for NOW, together with the text and the tables -- one trip to memory instead of three on the tile's
     // critical path -- and used after the barriers
     uint64_t my_b = 0, my_bn = 1, my_oa = 0, my_ob = 0;
-    if (uint32_t(tid) < nsent) { my_b = P.boff[i0 + tid]; my_bn = P.boff[i0 + tid + 1]; my_oa = P.ooff[i0 + tid]; my_ob = P.ooff[i0 + tid + 1]; }
+    if (uint32_t(tid) < nsent) { my_b = p_boff[i0 + tid]; my_bn = p_boff[i0 + tid + 1]; my_oa = p_ooff[i0 + tid]; my_ob = p_ooff[i0 + tid + 1]; }
     for (uint32_t i = tid; i < ((nbytes_al + 31) >> 5) + 1; i += kThreads) bitmap[i] = 0;
     for (uint32_t i = tid; i < (span + 3) / 4; i += kThreads) reinterpret_cast<uint4*>(L.sym)[i] = make_uint4(0, 0, 0, 0);
     if (TM != kTypeRows) {
         for (uint32_t i = tid; i < (span + 3) / 4; i += kThreads) reinterpret_cast<uint32_t*>(M.typ)[i] = 0;
     }
     for (uint32_t c = tid; c < nchunks; c += kThreads) reinterpret_cast<uint4*>(raw)[c] = reinterpret_cast<const uint4*>(a0)[c];   // (non-temporal loads / stores here measured 1-2 % slower: profiles/r02_c1_ab.jsonl, r02_c3_ab.jsonl)
-    if (tid == 0) raw[nchunks * 4] = 0;  // the dword after the staged text is read (as padding) by the last char
+    if (tid == 0) {
+        raw[nchunks * 4] = 0;  // the dword after the staged text is read (as padding) by the last char
+        // what phase C needs of the tile: read back there, so that it does not wait in scalar registers over the pattern phase
+        const uint64_t obase = g0 - i0;                        // >= 0: every sentence in front of the tile has a char
+        M.geo[0] = uint32_t(obase); M.geo[1] = uint32_t(obase >> 32); M.geo[2] = uint32_t(c_off); M.geo[3] = own_lo; M.geo[4] = own_hi;
+    }
     // the LDS-resident type rows (coalesced 16-byte loads from the predictor's arena)
     if (trow_lds) {
-        for (uint32_t i = tid; i < uint32_t(kTrowCount * G::kTrowQ); i += kThreads) M.trow[i] = ld16(P.pk.base, P.pk.off_trow + (i << 4));
+        const unsigned char* const tb = P->pk.base + P->pk.off_trow;
+        for (uint32_t i = tid; i < uint32_t(kTrowCount * G::kTrowQ); i += kThreads) M.trow[i] = *reinterpret_cast<const uint4*>(tb + (i << 4));
     }
     __syncthreads();
     tmark = phase_mark(prof, 0, tmark);   // zeroing, staging, table loads
     for (uint32_t j = tid; j < nsent; j += kThreads) {
-        const uint64_t b = j == uint32_t(tid) ? my_b : P.boff[i0 + j], bn = j == uint32_t(tid) ? my_bn : P.boff[i0 + j + 1];
+        const uint64_t b = j == uint32_t(tid) ? my_b : p_boff[i0 + j], bn = j == uint32_t(tid) ? my_bn : p_boff[i0 + j + 1];
         if (bn <= b) err |= kErrEmptySentence;
         if (b >= byte0 && b - byte0 < nbytes) {   // (sentence i0 of a cut tile may have started before the staged text)
             const uint32_t pos = head + uint32_t(b - byte0);
@@ -485,9 +508,10 @@ __global__ __launch_bounds__(kThreads, fast_wg(WL)) void score_tiles_fast_kernel
     tmark = phase_mark(prof, 1, tmark);   // sentence starts
     uint32_t base_leads = 0, base_starts = 0;
     uint32_t keep_masks = 0, keep_idx = 0;   // (fused writer) this thread's first chunk: lead | sentence-start masks, char index | sentence + 1 in front of it
-    uint32_t min_lead = 0xFFu;     // over this thread's chars: the smallest lead byte (a NUL char is the byte 0; a cut tile's last staged
-                                   // char may miss its continuation bytes, so the decoded value is not what is looked at)
+    uint32_t min_lead = 0xFFu;     // over this thread's chars that are not three-byte sequences: the smallest lead byte (a NUL char is the byte 0; a
+                                   // cut tile's last staged char may miss its continuation bytes, so the decoded value is not what is looked at)
     int32_t max_p = -1;            // ... and the last flat position (a char past the tile)
+    const uint8_t* const rawb = reinterpret_cast<const uint8_t*>(raw);
     for (uint32_t c0 = 0; c0 < nchunks; c0 += kThreads) {   // one pass for up to 4 KB of tile text, else two
         const uint32_t c = c0 + tid;
         uint32_t lm = 0, sm = 0;
@@ -498,7 +522,7 @@ __global__ __launch_bounds__(kThreads, fast_wg(WL)) void score_tiles_fast_kernel
             const uint32_t rem = nbytes_al - pos0;
             const uint32_t hi = rem < 16 ? rem : 16u;
             const uint32_t vm = ((1u << hi) - 1u) & ~((1u << lo) - 1u);
-            lm = (lead_nibble(v.x) | (lead_nibble(v.y) << 4) | (lead_nibble(v.z) << 8) | (lead_nibble(v.w) << 12)) & vm;
+            lm = lead_mask16(v) & vm;
             sm = (bitmap[pos0 >> 5] >> (pos0 & 31)) & 0xFFFFu;
         }
         const uint32_t mine = __popc(lm) | (__popc(sm) << 16);
@@ -521,29 +545,29 @@ __global__ __launch_bounds__(kThreads, fast_wg(WL)) void score_tiles_fast_kernel
         __syncthreads();   // wtot is rewritten by the next pass
         uint32_t m = lm;
         int32_t fb = c_off + int32_t(ci) + int32_t(kPad) * sib;   // flat = c_off + char index + kPad * sentence
+        int32_t p = -1;                                          // the chunk's chars go to ascending positions: its last one is its largest
+        const uint8_t* const rb = rawb + pos0;
         // Every round takes one char per lane; a three-byte sequence (Japanese text mostly is) decodes with five instructions.
         while (m != 0) {   // (a loop every lane stays in until the wave's last char, with the idle lanes writing the dump slot, measured
-            const bool has = true;   //  0.5 % slower: profiles/r03_j_ab_m1.jsonl)
-            const uint32_t k = uint32_t(__builtin_ctz(m | 0x10000u));
-            m &= m - 1;
-            const uint32_t r = uint32_t(__popc(sm & ((2u << k) - 1u)));
-            const uint32_t pos = pos0 + k;
-            const uint32_t w = __builtin_amdgcn_alignbyte(raw[(pos >> 2) + 1], raw[pos >> 2], pos & 3u);
+            const uint32_t k = uint32_t(__builtin_ctz(m));   //  0.5 % slower: profiles/r03_j_ab_m1.jsonl)
+            const uint32_t t = m - 1u;
+            const uint32_t r = uint32_t(__popc(sm & (m ^ t)));   // m ^ (m - 1): the bits up to and including bit k
+            m &= t;
+            const uint32_t* const q = reinterpret_cast<const uint32_t*>(reinterpret_cast<uintptr_t>(rb + k) & ~uintptr_t(3));
+            const uint32_t w = __builtin_amdgcn_alignbyte(q[1], q[0], k & 3u);   // (pos0 is a multiple of 16)
             uint32_t cp;
-            if ((w & 0xF0u) == 0xE0u) {   // a three-byte sequence (the side of the branch nobody takes is skipped)
-                cp = ((w & 0xFu) << 12) | ((w >> 2) & 0xFC0u) | ((w >> 16) & 0x3Fu);
+            if ((w & 0xF0u) == 0xE0u) {   // a three-byte sequence (the side of the branch nobody takes is skipped); its lead byte is no NUL
+                cp = (((((w & 0xFu) << 6) | ((w >> 8) & 0x3Fu)) << 6) | ((w >> 16) & 0x3Fu));
             } else {
                 cp = utf8_scalar_bf(w);
-            }
-            const int32_t p = fb + int32_t(kPad) * int32_t(r);
-            if (has) {
-                ++fb;
                 min_lead = (w & 0xFFu) < min_lead ? (w & 0xFFu) : min_lead;
-                max_p = p > max_p ? p : max_p;
             }
-            const bool inside = has && uint32_t(p - int32_t(kPad)) < flat_len - kPad;   // (p < kPad wraps to a large number)
+            p = fb + int32_t(kPad) * int32_t(r);
+            ++fb;
+            const bool inside = uint32_t(p - int32_t(kPad)) < flat_len - kPad;   // (p < kPad wraps to a large number)
             L.sym[inside ? uint32_t(p) : kDump] = cp | (uint32_t(sib + int32_t(r)) << 21);   // 21 + 10 bits; classified below
         }
+        max_p = p > max_p ? p : max_p;
     }
     if (expect_chars != 0xFFFFFFFFu && base_leads != expect_chars) err |= kErrBadOffsets;
     if (min_lead == 0) err |= kErrNulChar;
@@ -551,7 +575,10 @@ __global__ __launch_bounds__(kThreads, fast_wg(WL)) void score_tiles_fast_kernel
     tmark = phase_mark(prof, 2, tmark);   // chunk scan + decode rounds
     __syncthreads();  // the staged text has been read: the score array can be zeroed; every char is in place
     for (uint32_t i = tid; i < (span + 3) / 4; i += kThreads) reinterpret_cast<uint4*>(L.score)[i] = make_uint4(0, 0, 0, 0);
+    VPT_KARG_FENCE(P);
     {   // classify: one word of the char table per char (all of a thread's reads in flight together), then the final symbols
+        const uint32_t* const cid = P->cid;
+        uint32_t* const cps_out = P->cps_out;
         uint32_t xs[kPerThread], info[kPerThread];
 #pragma unroll
         for (int k = 0; k < kPerThread; ++k) {
@@ -561,7 +588,7 @@ __global__ __launch_bounds__(kThreads, fast_wg(WL)) void score_tiles_fast_kernel
             const uint32_t cp = xs[k] & 0x1FFFFFu;
             // id of the char it is scored as | CharacterType << 16 | linebreak << 29: one word of a 256 KB table (plain, or -- with
             // VPT_FLAG_KYTEA_FULLWIDTH -- the one that looks through KyteaFullwidthFilter); a separator asks for nothing
-            if (cp != 0) info[k] = P.cid[cp < 0x10000u ? cp : 0u];
+            if (cp != 0) info[k] = cid[cp < 0x10000u ? cp : 0u];
         }
 #pragma unroll
         for (int k = 0; k < kPerThread; ++k) {
@@ -571,17 +598,21 @@ __global__ __launch_bounds__(kThreads, fast_wg(WL)) void score_tiles_fast_kernel
             uint32_t v = info[k] | (si << 19);
             if (__ballot(cp >= 0x10000u) != 0) {   // rare: a char outside the BMP has its type computed and its id -- the model's alphabet
                 if (cp >= 0x10000u) {               // may hold a few such chars -- looked up in `xcid` (layout.h); KyteaFullwidthFilter leaves it alone
-                    const uint32_t id = P.pk.off_xcid ? xcid_find(reinterpret_cast<const uint32_t*>(P.pk.base + P.pk.off_xcid), cp) : kNoId;
+                    VPT_KARG(ScoreParams) R = P;
+                    VPT_KARG_FENCE(R);
+                    const uint32_t ox = R->pk.off_xcid;
+                    const uint32_t id = ox ? xcid_find(reinterpret_cast<const uint32_t*>(R->pk.base + ox), cp) : kNoId;
                     v = id | (char_type(cp) << 16) | (si << 19);
                 }
             }
             v = cp != 0 ? v : 0u;                  // a separator (or NUL, which has raised kErrNulChar)
             L.sym[pos] = v;
-            if (P.cps_out) {   // wave-uniform: a fill_tags call on this batch follows and wants the chars decoded (it then skips its own pass)
-                const uint32_t scored = (P.cinfo && cp < 0x10000u) ? (P.cinfo[cp] & 0xFFFFu) : cp;   // through KyteaFullwidthFilter when that flag is on
+            if (cps_out) {   // wave-uniform: a fill_tags call on this batch follows and wants the chars decoded (it then skips its own pass)
+                const uint32_t* const cinfo = P->cinfo;
+                const uint32_t scored = (cinfo && cp < 0x10000u) ? (cinfo[cp] & 0xFFFFu) : cp;   // through KyteaFullwidthFilter when that flag is on
                 if (cp != 0 && pos >= own_lo && pos < own_hi) {
                     const uint64_t at = g0 + uint64_t(int64_t(int32_t(pos) - c_off - int32_t(kPad) * int32_t(si)));
-                    if (at < P.total_chars) P.cps_out[at] = scored | (((v >> 16) & 7u) << 24);
+                    if (at < P->total_chars) cps_out[at] = scored | (((v >> 16) & 7u) << 24);
                     else err |= kErrBadOffsets;   // out_offsets that run past the total the caller stated
                 }
             }
@@ -593,7 +624,7 @@ __global__ __launch_bounds__(kThreads, fast_wg(WL)) void score_tiles_fast_kernel
     // e = c_off + (its first char's global number - g0) + kPad * j and is followed by a separator -- checked wherever e or its end
     // falls into the tile's window.  (A sentence longer or shorter than stated moves everything behind it.)
     for (uint32_t j = tid; j < nsent; j += kThreads) {
-        const uint64_t oa = j == uint32_t(tid) ? my_oa : P.ooff[i0 + j], ob = j == uint32_t(tid) ? my_ob : P.ooff[i0 + j + 1];
+        const uint64_t oa = j == uint32_t(tid) ? my_oa : p_ooff[i0 + j], ob = j == uint32_t(tid) ? my_ob : p_ooff[i0 + j + 1];
         const int64_t e = int64_t(c_off) + int64_t(oa + i0 + j - g0) + int64_t(kPad) * int64_t(j);
         const int64_t end = e + int64_t(ob - oa) + 1;
         if (ob < oa) err |= kErrBadOffsets;
@@ -610,42 +641,47 @@ __global__ __launch_bounds__(kThreads, fast_wg(WL)) void score_tiles_fast_kernel
     // (tid + 256 j), the BIGRAM nodes of the next trip's and the UNIGRAM nodes of the positions two trips ahead -- loads
     // that do not depend on each other -- waits once, adds the rows that arrived to the LDS score array and computes the
     // addresses the next trip needs (child slot = base in the parent + id of the next char; layout.h).
-    const PackedView& K = P.pk;
+    VPT_KARG_FENCE(P);
+    const unsigned char* const kbase = P->pk.base;
+    const DeepView K{kbase, P->pk.off_deep};
     WaveStacks Q{&M.queue[wave][0], &M.mqueue[wave][0], 0u, 0u};
-    const uint32_t off_bi = K.off_bi & ~255u, off_tri = K.off_tri & ~255u;   // they ARE 256-byte aligned (capi.cpp); now the compiler knows
+    const uint32_t off_bi = P->pk.off_bi & ~255u, off_tri = P->pk.off_tri & ~255u;   // they ARE 256-byte aligned (capi.cpp); now the compiler knows
+    const uint32_t n_tri = P->pk.n_tri, bi_shift = P->pk.bi_shift;                    // (off_uni is 0: the unigram nodes lead the packed tables)
     uint32_t b_slot = 0, b_key = 0, b_id3 = 0;   // next trip's bigram stage: node slot, its key (0: no bigram starts there), id of the third char
     uint32_t t_slot = ~0u, t_par = 0;            // this trip's trigram stage: node slot (~0: none) and parent slot + 1
     for (int j = -2; j < kPerThread; ++j) {
-        if (P.debug & 16u) break;  // timing ablation: no pattern phase at all
+        if (dbg & 16u) break;  // timing ablation: no pattern phase at all
         // wave-uniform: which stages have positions of this wave inside the tile
         const bool do_t = j >= 0 && wbase + uint32_t(j) * kThreads < flat_len;
         const bool do_b = j + 1 >= 0 && j + 1 < kPerThread && wbase + uint32_t(j + 1) * kThreads < flat_len;
         const bool do_u = j + 2 < kPerThread && wbase + uint32_t(j + 2) * kThreads < flat_len;
         if (!do_t && !do_b && !do_u) break;
+        while (Q.nm > 0) replay_m<WL>(P, L, Q, lane);   // (rare) the rows the trip before found outside their fields: the M stack is empty when a trip pushes
         const uint32_t s_t = uint32_t(tid) + uint32_t(j) * kThreads, s_b = s_t + kThreads, s_u = s_b + kThreads;
-        // ---- every load first; only lanes that can match issue one
+        // ---- every load first; only lanes that can match issue one (a node nobody loaded is never looked at: no zeroing)
         uint4 tn[G::kTriQ], nn[G::kBiQ], un[G::kUniQ];
 #pragma unroll
-        for (int q = 0; q < G::kTriQ; ++q) tn[q] = make_uint4(0, 0, 0, 0);
+        for (int q = 0; q < G::kTriQ; ++q) VPT_UNDEF4(tn[q]);
 #pragma unroll
-        for (int q = 0; q < G::kBiQ; ++q) nn[q] = make_uint4(0, 0, 0, 0);
+        for (int q = 0; q < G::kBiQ; ++q) VPT_UNDEF4(nn[q]);
 #pragma unroll
-        for (int q = 0; q < G::kUniQ; ++q) un[q] = make_uint4(0, 0, 0, 0);
+        for (int q = 0; q < G::kUniQ; ++q) un[q] = make_uint4(0, 0, 0, 0);   // (a char of no pattern has a zero row)
         uint32_t x1 = 0, x2 = 0, x3 = 0;
+        uint32_t wide_kinds = 0;   // what this lane's three stages find outside their fields this trip
         if (DBG && do_t) count_reads(prof, 2, t_slot != ~0u);
         if (DBG && do_b) count_reads(prof, 1, b_key != 0);
         if (do_t) {
             if (t_slot != ~0u) {
-                const uint32_t a = off_tri + (((P.debug & 1u) ? 0u : t_slot) * uint32_t(4 * pk_tri_dw(WL)));
+                const uint32_t a = off_tri + (((dbg & 1u) ? 0u : t_slot) * uint32_t(4 * pk_tri_dw(WL)));
 #pragma unroll
-                for (int q = 0; q < G::kTriQ; ++q) tn[q] = ld16(K.base, a + 16u * uint32_t(q));
+                for (int q = 0; q < G::kTriQ; ++q) tn[q] = ld16(kbase, a + 16u * uint32_t(q));
             }
         }
         if (do_b) {
             if (b_key != 0) {
-                const uint32_t a = off_bi + (((P.debug & 1u) ? 0u : b_slot) * uint32_t(4 * pk_bi_dw(WL)));
+                const uint32_t a = off_bi + (((dbg & 1u) ? 0u : b_slot) * uint32_t(4 * pk_bi_dw(WL)));
 #pragma unroll
-                for (int q = 0; q < G::kBiQ; ++q) nn[q] = ld16(K.base, a | (16u * uint32_t(q)));
+                for (int q = 0; q < G::kBiQ; ++q) nn[q] = ld16(kbase, a | (16u * uint32_t(q)));
             }
         }
         bool live = false;
@@ -653,13 +689,13 @@ __global__ __launch_bounds__(kThreads, fast_wg(WL)) void score_tiles_fast_kernel
             x1 = L.sym[s_u]; x2 = L.sym[s_u + 1]; x3 = L.sym[s_u + 2];   // the array is zero past the tile; s_u + 2 < kSymSlots
             const uint32_t id1 = x1 & kCpMask;
             live = id1 != 0;
-            const bool want = live && id1 != kNoId;   // a char no pattern contains has no unigram node (its row is zero, its base unused)
+            const bool want = uint32_t(id1 - 1u) < kNoId - 1u;   // a separator has no node; a char no pattern contains has none either (its row is zero, its base unused)
             if (DBG) count_reads(prof, 0, want);
             if (__ballot(want) != 0) {
                 if (want) {
-                    const uint32_t a = K.off_uni + (((P.debug & 4u) ? 0u : id1) * uint32_t(4 * pk_uni_dw(WL)));
+                    const uint32_t a = ((dbg & 4u) ? 0u : id1) * uint32_t(4 * pk_uni_dw(WL));
 #pragma unroll
-                    for (int q = 0; q < G::kUniQ; ++q) un[q] = ld16(K.base, a + 16u * uint32_t(q));
+                    for (int q = 0; q < G::kUniQ; ++q) un[q] = ld16(kbase, a + 16u * uint32_t(q));
                 }
             }
         }
@@ -676,16 +712,11 @@ __global__ __launch_bounds__(kThreads, fast_wg(WL)) void score_tiles_fast_kernel
                     atomicAdd(p + q, lo16(w)); atomicAdd(p + q + 1, hi16(w));
                 }
             }
-            const bool wide = hit && (td[0] & (kPkWide << kTriFlagShift));
+            if (hit && (td[0] & (kPkWide << kTriFlagShift))) wide_kinds |= kWideTri;
             uint32_t kids = hit ? td[pk_tri_kids_dw(WL)] : 0u;
             VPT_PIN(kids);
-            drain_w<WL>(K, L, Q, lane, kQHigh, prof);           // room for one more round of pushes
-            Q.push_w(kids != 0 && !(P.debug & 8u), s_t | (3u << 11), kids);
-            const uint64_t mm = __ballot(wide);
-            if (mm != 0) {
-                while (Q.nm + uint32_t(__popcll(mm)) > uint32_t(kMCap)) replay_m<WL>(K, P.ct, L, Q, lane);
-                Q.push_m(wide, s_t | (kWideTri << 11));
-            }
+            drain_w<WL>(P, K, L, Q, lane, kQHigh, prof);           // room for one more round of pushes
+            Q.push_w(kids != 0 && !(dbg & 8u), s_t | (3u << 11), kids);
         }
         // ---- bigram stage of positions s_b: key check, the row, and the address of the trigram node
         t_slot = ~0u;
@@ -698,18 +729,13 @@ __global__ __launch_bounds__(kThreads, fast_wg(WL)) void score_tiles_fast_kernel
                 int32_t* p = L.score + s_b - uint32_t(WL - 1);
                 each_field<0, kNB, kBiFieldBits>(rowd, [&](int f, int32_t v) { atomicAdd(p + f, v); });
             }
-            const uint32_t bit = packed_filter_bit(b_id3);
-            const uint32_t flo = nd[pk_bi_filter_dw(WL)], fhi = nd[pk_bi_filter_dw(WL) + 1];
-            const bool cont = keyok && b_id3 != 0 && b_id3 != kNoId && (((bit < 32 ? flo >> bit : fhi >> (bit - 32)) & 1u) != 0);
+            // the child filter: bit packed_filter_bit(id3) of a 64-bit word (a 64-bit shift: the bit number selects the half)
+            const uint64_t filt = uint64_t(nd[pk_bi_filter_dw(WL)]) | (uint64_t(nd[pk_bi_filter_dw(WL) + 1]) << 32);
+            const bool cont = keyok && uint32_t(b_id3 - 1u) < kNoId - 1u && ((filt >> packed_filter_bit(b_id3)) & 1u) != 0;
             const uint32_t ts = nd[pk_bi_base_dw(WL)] + b_id3;   // modulo 2^32 (layout.h); a false positive of the filter may point anywhere
-            t_slot = (cont && ts < K.n_tri && !(P.debug & 2u)) ? ts : ~0u;
+            t_slot = (cont && ts < n_tri && !(dbg & 2u)) ? ts : ~0u;
             t_par = b_slot + 1u;
-            const bool bwide = keyok && ufield<pk_bi_wide_bit(WL), 1>(rowd) != 0;
-            const uint64_t mm = __ballot(bwide);
-            if (mm != 0) {
-                while (Q.nm + uint32_t(__popcll(mm)) > uint32_t(kMCap)) replay_m<WL>(K, P.ct, L, Q, lane);
-                Q.push_m(bwide, s_b | (kWideBi << 11));
-            }
+            if (keyok && ufield<pk_bi_wide_bit(WL), 1>(rowd) != 0) wide_kinds |= kWideBi;
         }
         // ---- unigram stage of positions s_u: the row (+ the type row), and the address of the bigram node
         b_key = 0;
@@ -734,15 +760,15 @@ __global__ __launch_bounds__(kThreads, fast_wg(WL)) void score_tiles_fast_kernel
                     // rows of i32 in global memory, indexed by the types of s .. s + levels - 1 (layout.h, "TYPE ROWS"; the array is zero past the
                     // tile: code 0 ends the prefix)
                     uint32_t idx = 0;
-                    for (int32_t i = int32_t(K.trow_levels) - 1; i >= 3; --i) idx = idx * 7u + ((L.sym[s_u + uint32_t(i)] >> 16) & 7u);
+                    for (int32_t i = int32_t(P->pk.trow_levels) - 1; i >= 3; --i) idx = idx * 7u + ((L.sym[s_u + uint32_t(i)] >> 16) & 7u);
                     idx = (idx * 7u + ((x3 >> 16) & 7u)) * 7u + ((x2 >> 16) & 7u);
                     idx = idx * 6u + (((x1 >> 16) & 7u) - 1u);
                     if (DBG) count_reads(prof, 5, live);
                     if (live) {
-                        const uint32_t ra = K.off_trow + idx * uint32_t(4 * pk_trow_global_dw(WL));
+                        const uint32_t ra = P->pk.off_trow + idx * uint32_t(4 * pk_trow_global_dw(WL));
                         uint4 tr[pk_trow_global_dw(WL) / 4];
 #pragma unroll
-                        for (int q = 0; q < pk_trow_global_dw(WL) / 4; ++q) tr[q] = ld16(K.base, ra + 16u * uint32_t(q));
+                        for (int q = 0; q < pk_trow_global_dw(WL) / 4; ++q) tr[q] = ld16(kbase, ra + 16u * uint32_t(q));
                         uint32_t rd[pk_trow_global_dw(WL) + 1];
                         unpack4(tr, rd);
 #pragma unroll
@@ -755,19 +781,17 @@ __global__ __launch_bounds__(kThreads, fast_wg(WL)) void score_tiles_fast_kernel
 #pragma unroll
                 for (int f = 0; f < kNU; ++f) atomicAdd(p + f, a[f]);
             }
-            b_slot = (ufield<pk_uni_base_bit(WL), kUniBaseBits>(ud) << K.bi_shift) + id2;
-            b_key = (live && id1 != kNoId && id2 != 0 && id2 != kNoId) ? (id1 | (id2 << 16)) : 0u;
+            b_slot = (ufield<pk_uni_base_bit(WL), kUniBaseBits>(ud) << bi_shift) + id2;
+            // a bigram starts here when both chars are chars of the alphabet (ids in [1, kNoId): 0 is a separator, kNoId a char of no pattern)
+            b_key = (uint32_t(id1 - 1u) < kNoId - 1u && uint32_t(id2 - 1u) < kNoId - 1u) ? (id1 | (id2 << 16)) : 0u;
             b_id3 = x3 & kCpMask;
-            const bool uwide = live && ufield<pk_uni_base_bit(WL) + kUniBaseBits, 1>(ud) != 0 && !(P.debug & 32u);
-            const uint64_t mm = __ballot(uwide);
-            if (mm != 0) {
-                while (Q.nm + uint32_t(__popcll(mm)) > uint32_t(kMCap)) replay_m<WL>(K, P.ct, L, Q, lane);
-                Q.push_m(uwide, s_u | (kWideUni << 11));
-            }
+            if (live && ufield<pk_uni_base_bit(WL) + kUniBaseBits, 1>(ud) != 0 && !(dbg & 32u)) wide_kinds |= kWideUni;
         }
+        // ---- rows outside their fields (rare): ONE item per lane and trip, replayed from the general tables at the top of the next trip
+        Q.push_m(wide_kinds != 0, s_u | (wide_kinds << 11));
     }
-    while (Q.nm > 0) replay_m<WL>(K, P.ct, L, Q, lane);
-    while (Q.nw > 0) replay_w<WL>(K, L, Q, lane, prof);
+    while (Q.nm > 0) replay_m<WL>(P, L, Q, lane);
+    while (Q.nw > 0) replay_w<WL>(P, K, L, Q, lane, prof);
     tmark = phase_mark(prof, 4, tmark);   // patterns
     __syncthreads();
     tmark = phase_mark(prof, 5, tmark);   // waiting for the other waves
@@ -775,11 +799,17 @@ __global__ __launch_bounds__(kThreads, fast_wg(WL)) void score_tiles_fast_kernel
     // ---------------------------------------------------------------- C. boundaries
     // boundary p lies between flat positions p and p + 1, both chars of one sentence; the tile writes those in [own_lo, own_hi).
     // Its output index is (g0 - i0) + (p - c_off) - (kPad + 1) * (sentence in tile): a 32-bit offset from a scalar base.
-    const uint64_t obase = g0 - i0;                            // >= 0: every sentence in front of the tile has a char
-    const uint64_t total_b = P.total_chars - P.n_sent;         // boundaries of the call (or the caller's upper bound of them)
+    // (The tile's geometry comes back from LDS, the outputs' addresses from the parameter block: none of it waited in registers.)
+    VPT_KARG_FENCE(P);
+    const uint64_t obase = EMIT ? g0 - i0 : (uint64_t(wave_uniform(M.geo[0])) | (uint64_t(wave_uniform(M.geo[1])) << 32));
+    const int32_t c_off_c = EMIT ? c_off : int32_t(wave_uniform(M.geo[2]));
+    const uint32_t own_lo_c = EMIT ? own_lo : wave_uniform(M.geo[3]), own_hi_c = EMIT ? own_hi : wave_uniform(M.geo[4]);
+    const uint64_t total_b = P->total_chars - P->n_sent;         // boundaries of the call (or the caller's upper bound of them)
     const uint32_t o_lim = obase >= total_b ? 0u : (total_b - obase > 0xFFFFFFFFull ? 0xFFFFFFFFu : uint32_t(total_b - obase));
-    int32_t* const sc = P.scores ? P.scores + obase : nullptr;
-    uint8_t* const lb = P.labels ? P.labels + obase : nullptr;
+    int32_t* const sc = P->scores ? P->scores + obase : nullptr;
+    uint8_t* const lb = P->labels ? P->labels + obase : nullptr;
+    const int32_t bias = P->bias;
+    const uint32_t post = P->post;
     // the fused writer's scratch behind what phase C still reads of the union (the type codes of the window-table modes; the type rows
     // are dead): a label byte per flat position, the sentence-start bitmap of the tile's text, a few words
     constexpr uint32_t kEmitOff = (TM >= 1 && TM <= 3) ? uint32_t((kSymSlots + 15) & ~15) : 0u;
@@ -802,23 +832,23 @@ __global__ __launch_bounds__(kThreads, fast_wg(WL)) void score_tiles_fast_kernel
             continue;
         }
         const uint32_t x = L.sym[p], x2 = L.sym[p + 1];
-        int32_t y = P.bias + L.score[p];
-        if ((x & kCpMask) == 0 || (x2 & kCpMask) == 0 || p < own_lo || p >= own_hi) { if (EMIT) labb[p] = 0; continue; }
+        int32_t y = bias + L.score[p];
+        if ((x & kCpMask) == 0 || (x2 & kCpMask) == 0 || p < own_lo_c || p >= own_hi_c) { if (EMIT) labb[p] = 0; continue; }
         if (TM >= 1 && TM <= 3) {
             uint32_t id = 0;  // window t[b-W+1 .. b+W], 3 bits each (boundary_scorer_cache.rs:59-81)
 #pragma unroll
             for (int i = 1 - TM; i <= TM; ++i) id = (id << 3) | (M.typ[int(p) + i] & 7u);
-            y += P.type_table[id];
+            y += P->type_table[id];
         }
-        const uint32_t o = uint32_t(int32_t(p) - c_off) - (kPad + 1) * ((x >> 19) & 1023u);
+        const uint32_t o = uint32_t(int32_t(p) - c_off_c) - (kPad + 1) * ((x >> 19) & 1023u);
         if (o >= o_lim) { err |= kErrBadOffsets; if (EMIT) labb[p] = 0; continue; }  // only with offsets that do not match the text
         if (sc) sc[o] = y;
         uint32_t label = y > 0 ? 1u : 0u;
         if (lb || EMIT) {
-            if (P.post) {   // wave-uniform: KyteaWsConstFilter / SplitLinebreaksFilter on the label
+            if (post) {   // wave-uniform: KyteaWsConstFilter / SplitLinebreaksFilter on the label
                 const uint32_t t1 = (x >> 16) & 7u, t2 = (x2 >> 16) & 7u;
-                if (t1 == t2 && ((P.post >> t1) & 1u) && t1 != 0 && t1 != 7) label = 0;
-                if ((P.post & 0x80u) && ((x | x2) & kSymLinebreak)) label = 1;
+                if (t1 == t2 && ((post >> t1) & 1u) && t1 != 0 && t1 != 7) label = 0;
+                if ((post & 0x80u) && ((x | x2) & kSymLinebreak)) label = 1;
             }
             if (lb) lb[o] = uint8_t(label);
             if (EMIT) labb[p] = uint8_t(label);
@@ -858,7 +888,7 @@ __global__ __launch_bounds__(kThreads, fast_wg(WL)) void score_tiles_fast_kernel
             if (tid == 0) raw2[nchunks * 4] = 0;
             __syncthreads();
             for (uint32_t j = tid; j < nsent; j += kThreads) {
-                const uint64_t b = P.boff[i0 + j];
+                const uint64_t b = P->boff[i0 + j];
                 if (b >= byte0 && b - byte0 < nbytes) {
                     const uint32_t pos = head + uint32_t(b - byte0);
                     atomicOr(&bm2[pos >> 5], 1u << (pos & 31));
@@ -886,7 +916,7 @@ __global__ __launch_bounds__(kThreads, fast_wg(WL)) void score_tiles_fast_kernel
                     em = (esc_nibble(v.x) | (esc_nibble(v.y) << 4) | (esc_nibble(v.z) << 8) | (esc_nibble(v.w) << 12)) & vm;
                     if (one_round) { lm = keep_masks & 0xFFFFu; sm = (keep_masks >> 16) & lm; }
                     else {
-                        lm = (lead_nibble(v.x) | (lead_nibble(v.y) << 4) | (lead_nibble(v.z) << 8) | (lead_nibble(v.w) << 12)) & vm;
+                        lm = lead_mask16(v) & vm;
                         sm = (bm2[pos0 >> 5] >> (pos0 & 31)) & 0xFFFFu & lm;
                     }
                 }
@@ -965,7 +995,7 @@ __global__ __launch_bounds__(kThreads, fast_wg(WL)) void score_tiles_fast_kernel
         const uint32_t size = run;   // (the same in every thread)
         // ---- the tile's position: wave 0 publishes the size and looks back over the earlier tiles' words, 64 per trip
         if (wave == 0) {
-            const uint64_t base = emit_lookback(P.emit.state, tile, size, lane, P.emit.chain_in ? *P.emit.chain_in : 0ull, P.emit.no_prefix != 0);
+            const uint64_t base = emit_lookback(P->emit.state, tile, size, lane, P->emit.chain_in ? *P->emit.chain_in : 0ull, P->emit.no_prefix != 0);
             if (lane == 0) { ew[2] = uint32_t(base); ew[3] = uint32_t(base >> 32); }
         }
         // ---- assembly (every wave; needs no position): [' '] ['\\'] byte for the chunk's bytes, in order
@@ -989,12 +1019,12 @@ __global__ __launch_bounds__(kThreads, fast_wg(WL)) void score_tiles_fast_kernel
         __syncthreads();
         const uint64_t base = uint64_t(ew[2]) | (uint64_t(ew[3]) << 32);
         const uint64_t end = base + size;
-        const bool store_ok = end <= P.emit.capacity;
+        const bool store_ok = end <= P->emit.capacity;
         if (!store_ok) err |= kErrOutputTooSmall;
-        if (tile == P.n_tiles - 1 && tid == 0) {
-            P.emit.out_offsets[P.n_sent] = end;
-            if (P.emit.total_out) *P.emit.total_out = end;
-            if (P.emit.chain_out) *P.emit.chain_out = end;
+        if (tile == P->n_tiles - 1 && tid == 0) {
+            P->emit.out_offsets[P->n_sent] = end;
+            if (P->emit.total_out) *P->emit.total_out = end;
+            if (P->emit.chain_out) *P->emit.chain_out = end;
         }
         // ---- the own sentences' offsets: the output position of their first byte (its ' ' never exists, its '\' belongs to it)
 #pragma unroll
@@ -1005,13 +1035,13 @@ __global__ __launch_bounds__(kThreads, fast_wg(WL)) void score_tiles_fast_kernel
                 rem &= rem - 1u;
                 const uint32_t s_in_tile = e_sib[r] + uint32_t(__popc(e_sm[r] & ((2u << k) - 1u)));   // the sentence this lead starts
                 const uint64_t at = base + e_w[r] + uint32_t(__popc(e_vm[r] & below)) + uint32_t(__popc(e_em[r] & below)) + uint32_t(__popc(e_sp[r] & below));
-                if (s_in_tile < nsent) P.emit.out_offsets[i0 + s_in_tile] = at;
+                if (s_in_tile < nsent) P->emit.out_offsets[i0 + s_in_tile] = at;
                 else err |= kErrBadOffsets;
             }
         }
         // ---- out: LDS byte j is output byte base + j; whole 16-byte chunks leave aligned (an LDS funnel shift), the two edges byte by byte
         if (store_ok && size != 0) {
-            uint8_t* const dst = P.emit.out_text + base;
+            uint8_t* const dst = P->emit.out_text + base;
             const uint32_t hd = uint32_t(reinterpret_cast<uintptr_t>(dst) & 15u);   // dst - hd is aligned
             const uint32_t nd = (hd + size + 15u) >> 4;
             const uint32_t* const ow = reinterpret_cast<const uint32_t*>(outb);
@@ -1030,7 +1060,7 @@ __global__ __launch_bounds__(kThreads, fast_wg(WL)) void score_tiles_fast_kernel
             }
         }
     }
-    if (err) atomicOr(P.status, err);
+    if (err) atomicOr(P->status, err);
     phase_mark(prof, 7, tmark);           // (with the fused writer: tokenized text out)
 }
 
@@ -1066,7 +1096,7 @@ __global__ __launch_bounds__(256) void cut_count_kernel(const uint8_t* __restric
             const uint4 v = *reinterpret_cast<const uint4*>(text + at);   // 16-byte aligned when `text` is; bytes outside the batch are masked
             const uint32_t lo = at < T0 ? uint32_t(T0 - at) : 0u, hi = T1 - at < 16 ? uint32_t(T1 - at) : 16u;
             const uint32_t vm = ((1u << hi) - 1u) & ~((1u << lo) - 1u);
-            n = uint32_t(__popc((lead_nibble(v.x) | (lead_nibble(v.y) << 4) | (lead_nibble(v.z) << 8) | (lead_nibble(v.w) << 12)) & vm));
+            n = uint32_t(__popc(lead_mask16(v) & vm));
         }
         n += uint32_t(__builtin_amdgcn_update_dpp(0, int(n), 0x111, 0xF, 0xF, false));  // row_shr:1 .. 8: lane 15 of a row holds the row's sum
         n += uint32_t(__builtin_amdgcn_update_dpp(0, int(n), 0x112, 0xF, 0xF, false));

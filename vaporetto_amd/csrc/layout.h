@@ -78,7 +78,7 @@
 //                         otherwise kPkExtRow and dword 8 = offset of an i32 row in `xrows`.
 //   mini-table ref = base << 5 | log2(size): `size` consecutive entries of `deep` holding the children of ONE
 //          node (so a hot node's children are contiguous and cache-hot together); entry index
-//          (id * kHashMulLo >> 15) & (size-1), linear probing inside the mini-table, at most `size` probes,
+//          packed_mini_slot(id, ref), linear probing inside the mini-table, at most `size` probes,
 //          an entry with dword 0 == 0 ends the search.  Entry 0 of the arena is unused so that ref 0 = none.
 //   cpid   n_alpha + 2 words: the code point of an id (only the rare kPkWide replay needs it: the general tables are
 //          keyed by code points).
@@ -149,8 +149,9 @@ VPT_HD uint32_t hash_slot(uint64_t key, uint32_t shift) {
 }
 
 // packed-table hashes
-VPT_HD uint32_t packed_mini_slot(uint32_t sym, uint32_t ref) { return ((sym * kHashMulLo) >> 15) & ((1u << (ref & 31u)) - 1u); }
-VPT_HD uint32_t packed_filter_bit(uint32_t sym) { return (sym * kHashMulHi) >> 26; }   // 0..63
+// (ids are 16 bits wide: a 16 x 16-bit product is ONE full-rate v_mul_u32_u24 on gfx950, where a 32-bit v_mul_lo_u32 takes four issue slots)
+VPT_HD uint32_t packed_mini_slot(uint32_t sym, uint32_t ref) { return (((sym & 0xFFFFu) * 0x9E37u) >> 7) & ((1u << (ref & 31u)) - 1u); }
+VPT_HD uint32_t packed_filter_bit(uint32_t sym) { return (((sym & 0xFFFFu) * 0x85EBu) >> 10) & 63u; }   // 0..63
 // the alphabet outside the BMP (header comment, "xcid"): `tab` = the section's first dword
 VPT_HD uint32_t xcid_slot(uint32_t cp, uint32_t bits) { return (cp * kHashMulLo) >> (32u - bits); }   // bits in 1..31
 VPT_HD uint32_t xcid_find(const uint32_t* tab, uint32_t cp) {
