@@ -511,7 +511,6 @@ __global__ __launch_bounds__(kThreads, fast_wg(WL)) void score_tiles_fast_kernel
     uint32_t min_lead = 0xFFu;     // over this thread's chars that are not three-byte sequences: the smallest lead byte (a NUL char is the byte 0; a
                                    // cut tile's last staged char may miss its continuation bytes, so the decoded value is not what is looked at)
     int32_t max_p = -1;            // ... and the last flat position (a char past the tile)
-    const uint8_t* const rawb = reinterpret_cast<const uint8_t*>(raw);
     for (uint32_t c0 = 0; c0 < nchunks; c0 += kThreads) {   // one pass for up to 4 KB of tile text, else two
         const uint32_t c = c0 + tid;
         uint32_t lm = 0, sm = 0;
@@ -546,15 +545,14 @@ __global__ __launch_bounds__(kThreads, fast_wg(WL)) void score_tiles_fast_kernel
         uint32_t m = lm;
         int32_t fb = c_off + int32_t(ci) + int32_t(kPad) * sib;   // flat = c_off + char index + kPad * sentence
         int32_t p = -1;                                          // the chunk's chars go to ascending positions: its last one is its largest
-        const uint8_t* const rb = rawb + pos0;
+        const uint32_t* const rp = raw + (pos0 >> 2);            // this chunk's first dword of the staged text
         // Every round takes one char per lane; a three-byte sequence (Japanese text mostly is) decodes with five instructions.
         while (m != 0) {   // (a loop every lane stays in until the wave's last char, with the idle lanes writing the dump slot, measured
             const uint32_t k = uint32_t(__builtin_ctz(m));   //  0.5 % slower: profiles/r03_j_ab_m1.jsonl)
             const uint32_t t = m - 1u;
             const uint32_t r = uint32_t(__popc(sm & (m ^ t)));   // m ^ (m - 1): the bits up to and including bit k
             m &= t;
-            const uint32_t* const q = reinterpret_cast<const uint32_t*>(reinterpret_cast<uintptr_t>(rb + k) & ~uintptr_t(3));
-            const uint32_t w = __builtin_amdgcn_alignbyte(q[1], q[0], k & 3u);   // (pos0 is a multiple of 16)
+            const uint32_t w = __builtin_amdgcn_alignbyte(rp[(k >> 2) + 1], rp[k >> 2], k & 3u);   // the char's four bytes (pos0 is a multiple of 16)
             uint32_t cp;
             if ((w & 0xF0u) == 0xE0u) {   // a three-byte sequence (the side of the branch nobody takes is skipped); its lead byte is no NUL
                 cp = (((((w & 0xFu) << 6) | ((w >> 8) & 0x3Fu)) << 6) | ((w >> 16) & 0x3Fu));
@@ -578,36 +576,11 @@ __global__ __launch_bounds__(kThreads, fast_wg(WL)) void score_tiles_fast_kernel
     VPT_KARG_FENCE(P);
     {   // classify: one word of the char table per char (all of a thread's reads in flight together), then the final symbols
         const uint32_t* const cid = P->cid;
-        uint32_t* const cps_out = P->cps_out;
-        uint32_t xs[kPerThread], info[kPerThread];
-#pragma unroll
-        for (int k = 0; k < kPerThread; ++k) {
-            xs[k] = 0; info[k] = 0;
-            if (wbase + uint32_t(k) * kThreads >= flat_len) continue;   // wave-uniform
-            xs[k] = L.sym[uint32_t(tid) + uint32_t(k) * kThreads];
-            const uint32_t cp = xs[k] & 0x1FFFFFu;
-            // id of the char it is scored as | CharacterType << 16 | linebreak << 29: one word of a 256 KB table (plain, or -- with
-            // VPT_FLAG_KYTEA_FULLWIDTH -- the one that looks through KyteaFullwidthFilter); a separator asks for nothing
-            if (cp != 0) info[k] = cid[cp < 0x10000u ? cp : 0u];
-        }
-#pragma unroll
-        for (int k = 0; k < kPerThread; ++k) {
-            if (wbase + uint32_t(k) * kThreads >= flat_len) continue;   // wave-uniform
-            const uint32_t pos = uint32_t(tid) + uint32_t(k) * kThreads;
-            const uint32_t cp = xs[k] & 0x1FFFFFu, si = xs[k] >> 21;
-            uint32_t v = info[k] | (si << 19);
-            if (__ballot(cp >= 0x10000u) != 0) {   // rare: a char outside the BMP has its type computed and its id -- the model's alphabet
-                if (cp >= 0x10000u) {               // may hold a few such chars -- looked up in `xcid` (layout.h); KyteaFullwidthFilter leaves it alone
-                    VPT_KARG(ScoreParams) R = P;
-                    VPT_KARG_FENCE(R);
-                    const uint32_t ox = R->pk.off_xcid;
-                    const uint32_t id = ox ? xcid_find(reinterpret_cast<const uint32_t*>(R->pk.base + ox), cp) : kNoId;
-                    v = id | (char_type(cp) << 16) | (si << 19);
-                }
-            }
-            v = cp != 0 ? v : 0u;                  // a separator (or NUL, which has raised kErrNulChar)
+        uint32_t* const cps_out = P->cps_out;   // (wave-uniform) a fill_tags call on this batch follows and wants the chars decoded (it then skips its own pass)
+        // a char's final symbol word `v` is in place: the other things that want it
+        auto placed = [&](uint32_t pos, uint32_t cp, uint32_t si, uint32_t v) {
             L.sym[pos] = v;
-            if (cps_out) {   // wave-uniform: a fill_tags call on this batch follows and wants the chars decoded (it then skips its own pass)
+            if (cps_out) {
                 const uint32_t* const cinfo = P->cinfo;
                 const uint32_t scored = (cinfo && cp < 0x10000u) ? (cinfo[cp] & 0xFFFFu) : cp;   // through KyteaFullwidthFilter when that flag is on
                 if (cp != 0 && pos >= own_lo && pos < own_hi) {
@@ -617,6 +590,43 @@ __global__ __launch_bounds__(kThreads, fast_wg(WL)) void score_tiles_fast_kernel
                 }
             }
             if (TM != kTypeRows) M.typ[pos] = uint8_t((v >> 16) & 7u);
+        };
+        uint32_t xs[kPerThread], info[kPerThread];
+#pragma unroll
+        for (int k = 0; k < kPerThread; ++k) {
+            xs[k] = 0;
+            if (wbase + uint32_t(k) * kThreads < flat_len) xs[k] = L.sym[uint32_t(tid) + uint32_t(k) * kThreads];   // (wave-uniform)
+        }
+#pragma unroll
+        for (int k = 0; k < kPerThread; ++k) {
+            info[k] = 0;
+            // id of the char it is scored as | CharacterType << 16 | linebreak << 29: one word of a 256 KB table (plain, or -- with
+            // VPT_FLAG_KYTEA_FULLWIDTH -- the one that looks through KyteaFullwidthFilter); a separator or a char outside the BMP asks for nothing
+            const uint32_t cp = xs[k] & 0x1FFFFFu;
+            if (uint32_t(cp - 1u) < 0xFFFFu) info[k] = cid[cp];
+        }
+        uint32_t outside = 0;   // this lane's chars outside the BMP (bit k), for the pass below
+#pragma unroll
+        for (int k = 0; k < kPerThread; ++k) {
+            if (wbase + uint32_t(k) * kThreads >= flat_len) continue;   // wave-uniform
+            const uint32_t pos = uint32_t(tid) + uint32_t(k) * kThreads;
+            const uint32_t cp = xs[k] & 0x1FFFFFu, si = xs[k] >> 21;
+            if (cp >= 0x10000u) { outside |= 1u << k; continue; }   // its word stays as decoded
+            placed(pos, cp, si, cp != 0 ? (info[k] | (si << 19)) : 0u);   // 0: a separator (or NUL, which has raised kErrNulChar)
+        }
+        if (__ballot(outside != 0) != 0) {   // rare: a char outside the BMP has its type computed and its id -- the model's alphabet may hold a few
+            VPT_KARG(ScoreParams) R = P;     // such chars -- looked up in `xcid` (layout.h); KyteaFullwidthFilter leaves it alone.  One copy of this code.
+            VPT_KARG_FENCE(R);
+            const uint32_t ox = R->pk.off_xcid;
+            const uint32_t* const xt = reinterpret_cast<const uint32_t*>(R->pk.base + ox);
+#pragma nounroll
+            for (int k = 0; k < kPerThread; ++k) {
+                if (!((outside >> k) & 1u)) continue;
+                const uint32_t pos = uint32_t(tid) + uint32_t(k) * kThreads;
+                const uint32_t x = L.sym[pos], cp = x & 0x1FFFFFu, si = x >> 21;
+                const uint32_t id = ox ? xcid_find(xt, cp) : kNoId;
+                placed(pos, cp, si, id | (char_type(cp) << 16) | (si << 19));
+            }
         }
     }
     __syncthreads();

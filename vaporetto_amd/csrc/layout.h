@@ -149,9 +149,18 @@ VPT_HD uint32_t hash_slot(uint64_t key, uint32_t shift) {
 }
 
 // packed-table hashes
-// (ids are 16 bits wide: a 16 x 16-bit product is ONE full-rate v_mul_u32_u24 on gfx950, where a 32-bit v_mul_lo_u32 takes four issue slots)
-VPT_HD uint32_t packed_mini_slot(uint32_t sym, uint32_t ref) { return (((sym & 0xFFFFu) * 0x9E37u) >> 7) & ((1u << (ref & 31u)) - 1u); }
-VPT_HD uint32_t packed_filter_bit(uint32_t sym) { return (((sym & 0xFFFFu) * 0x85EBu) >> 10) & 63u; }   // 0..63
+// (ids are 16 bits wide: a 16 x 16-bit product is ONE full-rate v_mul_u32_u24 on gfx950, where a 32-bit v_mul_lo_u32 takes four issue
+// slots.  The kernels ask for it by name: with a plain `*` the optimiser first drops the `& 0xFFFF` -- the bits looked at do not depend
+// on the operand's high half -- and then no longer knows that the operand fits 24 bits.)
+VPT_HD uint32_t mul_u16(uint32_t a16, uint32_t b16) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __umul24(a16, b16);
+#else
+    return (a16 & 0xFFFFu) * (b16 & 0xFFFFu);
+#endif
+}
+VPT_HD uint32_t packed_mini_slot(uint32_t sym, uint32_t ref) { return (mul_u16(sym & 0xFFFFu, 0x9E37u) >> 7) & ((1u << (ref & 31u)) - 1u); }
+VPT_HD uint32_t packed_filter_bit(uint32_t sym) { return (mul_u16(sym & 0xFFFFu, 0x85EBu) >> 10) & 63u; }   // 0..63
 // the alphabet outside the BMP (header comment, "xcid"): `tab` = the section's first dword
 VPT_HD uint32_t xcid_slot(uint32_t cp, uint32_t bits) { return (cp * kHashMulLo) >> (32u - bits); }   // bits in 1..31
 VPT_HD uint32_t xcid_find(const uint32_t* tab, uint32_t cp) {
