@@ -32,8 +32,16 @@
 #ifndef VPT_KARG
 #define VPT_KARG(T) const __attribute__((address_space(4))) T*
 #define VPT_KARG_PTR(T, arg) ((VPT_KARG(T))__builtin_amdgcn_kernarg_segment_ptr())
+#if defined(VPT_AB_NO_KARG_FENCE)   /* A/B builds (tools/build_variants.sh) */
+#define VPT_KARG_FENCE(p) ((void)0)
+#else
 #define VPT_KARG_FENCE(p) __asm__ volatile("" : "+s"(p))
+#endif
+#if defined(VPT_AB_ZERO_NODES)
+#define VPT_UNDEF4(v) ((v) = make_uint4(0, 0, 0, 0))
+#else
 #define VPT_UNDEF4(v) __asm__ volatile("" : "=v"((v).x), "=v"((v).y), "=v"((v).z), "=v"((v).w))
+#endif
 #endif
 
 namespace vpt {

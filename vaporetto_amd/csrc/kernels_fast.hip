@@ -666,7 +666,6 @@ __global__ __launch_bounds__(kThreads, fast_wg(WL)) void score_tiles_fast_kernel
         const bool do_b = j + 1 >= 0 && j + 1 < kPerThread && wbase + uint32_t(j + 1) * kThreads < flat_len;
         const bool do_u = j + 2 < kPerThread && wbase + uint32_t(j + 2) * kThreads < flat_len;
         if (!do_t && !do_b && !do_u) break;
-        while (Q.nm > 0) replay_m<WL>(P, L, Q, lane);   // (rare) the rows the trip before found outside their fields: the M stack is empty when a trip pushes
         const uint32_t s_t = uint32_t(tid) + uint32_t(j) * kThreads, s_b = s_t + kThreads, s_u = s_b + kThreads;
         // ---- every load first; only lanes that can match issue one (a node nobody loaded is never looked at: no zeroing)
         uint4 tn[G::kTriQ], nn[G::kBiQ], un[G::kUniQ];
@@ -797,8 +796,13 @@ __global__ __launch_bounds__(kThreads, fast_wg(WL)) void score_tiles_fast_kernel
             b_id3 = x3 & kCpMask;
             if (live && ufield<pk_uni_base_bit(WL) + kUniBaseBits, 1>(ud) != 0 && !(dbg & 32u)) wide_kinds |= kWideUni;
         }
-        // ---- rows outside their fields (rare): ONE item per lane and trip, replayed from the general tables at the top of the next trip
-        Q.push_m(wide_kinds != 0, s_u | (wide_kinds << 11));
+        // ---- rows outside their fields (rare): ONE item per lane and trip; they wait on the M stack until a replay finds many of them
+        // (a replay per trip for an item or two cost 22 % more vector-memory instructions than the pattern phase had: profiles/r05_f_*)
+        const uint64_t mm = __ballot(wide_kinds != 0);
+        if (mm != 0) {
+            while (Q.nm + uint32_t(__popcll(mm)) > uint32_t(kMCap)) replay_m<WL>(P, L, Q, lane);
+            Q.push_m(wide_kinds != 0, s_u | (wide_kinds << 11));
+        }
     }
     while (Q.nm > 0) replay_m<WL>(P, L, Q, lane);
     while (Q.nw > 0) replay_w<WL>(P, K, L, Q, lane, prof);

@@ -152,15 +152,26 @@ VPT_HD uint32_t hash_slot(uint64_t key, uint32_t shift) {
 // (ids are 16 bits wide: a 16 x 16-bit product is ONE full-rate v_mul_u32_u24 on gfx950, where a 32-bit v_mul_lo_u32 takes four issue
 // slots.  The kernels ask for it by name: with a plain `*` the optimiser first drops the `& 0xFFFF` -- the bits looked at do not depend
 // on the operand's high half -- and then no longer knows that the operand fits 24 bits.)
-VPT_HD uint32_t mul_u16(uint32_t a16, uint32_t b16) {
+VPT_HD uint32_t mul_u16(uint32_t a16, uint32_t b24) {   // the low 32 bits of a 16-bit x 24-bit product
 #if defined(__HIP_DEVICE_COMPILE__)
-    return __umul24(a16, b16);
+    return __umul24(a16, b24);
 #else
-    return (a16 & 0xFFFFu) * (b16 & 0xFFFFu);
+    return uint32_t(uint64_t(a16 & 0xFFFFu) * uint64_t(b24 & 0xFFFFFFu));
 #endif
 }
+#if defined(VPT_AB_OLD_HASH)   /* A/B builds: the 32-bit multiplies of rounds 2-4 */
+VPT_HD uint32_t packed_mini_slot(uint32_t sym, uint32_t ref) { return ((sym * kHashMulLo) >> 15) & ((1u << (ref & 31u)) - 1u); }
+VPT_HD uint32_t packed_filter_bit(uint32_t sym) { return (sym * kHashMulHi) >> 26; }
+#elif defined(VPT_AB_LOW_HASH) /* A/B builds: 16 x 16-bit products */
 VPT_HD uint32_t packed_mini_slot(uint32_t sym, uint32_t ref) { return (mul_u16(sym & 0xFFFFu, 0x9E37u) >> 7) & ((1u << (ref & 31u)) - 1u); }
 VPT_HD uint32_t packed_filter_bit(uint32_t sym) { return (mul_u16(sym & 0xFFFFu, 0x85EBu) >> 10) & 63u; }   // 0..63
+#else
+// Fibonacci hashing in 24 bits: the multiplier is 2^24 / phi, so that the TOP bits of the product's low 24 spread consecutive ids (ids go by
+// frequency: the chars that matter most are 1, 2, 3 ..) evenly -- taking other bits of the product does not (bits 26 .. 31 of id x 0x85EBCB map
+// eight consecutive small ids to ONE filter bit: 9 % more trigram nodes read, profiles/r05_d_*)
+VPT_HD uint32_t packed_mini_slot(uint32_t sym, uint32_t ref) { return (mul_u16(sym & 0xFFFFu, 0x9E3779u) & 0xFFFFFFu) >> (24u - (ref & 31u)); }   // mini-tables have at most 2^17 entries
+VPT_HD uint32_t packed_filter_bit(uint32_t sym) { return (mul_u16(sym & 0xFFFFu, 0x9E3779u) >> 18) & 63u; }   // 0..63
+#endif
 // the alphabet outside the BMP (header comment, "xcid"): `tab` = the section's first dword
 VPT_HD uint32_t xcid_slot(uint32_t cp, uint32_t bits) { return (cp * kHashMulLo) >> (32u - bits); }   // bits in 1..31
 VPT_HD uint32_t xcid_find(const uint32_t* tab, uint32_t cp) {
