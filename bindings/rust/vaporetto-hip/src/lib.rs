@@ -158,10 +158,19 @@ impl Drop for HipPredictor {
 }
 
 /// One batch over the GPUs of a node: `preds[r]` scores the r-th character-balanced range of the sentences (no data-path collective).
+/// `boff` / `ooff`: the n + 1 byte / boundary offsets of the n sentences (`vpt_count_boundaries` makes the latter); `scores` and `labels` take
+/// `ooff[n]` entries.  The C side trusts these sizes, so they are checked here: a safe function must not let a short slice become a write past it.
 pub fn predict_batch_sharded(preds: &[&HipPredictor], utf8: &[u8], boff: &[u64], ooff: &[u64], scores: &mut [i32], labels: &mut [u8], flags: u32) -> Result<()> {
+    let bad = |what: &str| Err(HipError::InvalidArgument(format!("InvalidArgumentError: {}", what)));
+    if preds.is_empty() { return bad("preds: at least one predictor"); }
+    if boff.is_empty() || ooff.len() != boff.len() { return bad("byte_offsets / out_offsets: n + 1 entries each"); }
+    let n = boff.len() - 1;
+    if boff.windows(2).any(|w| w[1] < w[0]) || ooff.windows(2).any(|w| w[1] < w[0]) { return bad("offsets: must not decrease"); }
+    if (utf8.len() as u64) < boff[n] { return bad("utf8: shorter than byte_offsets[n]"); }
+    if (scores.len() as u64) < ooff[n] || (labels.len() as u64) < ooff[n] { return bad("scores / labels: shorter than out_offsets[n]"); }
     let raws: Vec<*const ffi::vpt_predictor> = preds.iter().map(|p| p.raw as *const _).collect();
     check(unsafe {
-        ffi::vpt_predict_batch_sharded(raws.as_ptr(), raws.len(), utf8.as_ptr(), boff.as_ptr(), boff.len() - 1, scores.as_mut_ptr(), labels.as_mut_ptr(), ooff.as_ptr(), flags)
+        ffi::vpt_predict_batch_sharded(raws.as_ptr(), raws.len(), utf8.as_ptr(), boff.as_ptr(), n, scores.as_mut_ptr(), labels.as_mut_ptr(), ooff.as_ptr(), flags)
     })
 }
 

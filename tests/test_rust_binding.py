@@ -132,3 +132,17 @@ def test_the_safe_layer_only_calls_declared_functions_and_the_crate_is_whole():
         assert os.path.getsize(os.path.join(CRATE, f)) > 0
     assert 'links = "vaporetto_hip"' in open(os.path.join(CRATE, "Cargo.toml")).read()
     assert "rustc-link-lib=dylib=vaporetto_hip" in open(os.path.join(CRATE, "build.rs")).read()
+
+
+def test_safe_wrappers_check_the_sizes_they_hand_to_c():
+    """`predict_batch_sharded` is a safe `pub fn` over caller-sized slices -- it must validate them before the FFI call
+    (an empty `boff` underflowed `len() - 1`; short `scores` / `labels` let the C side write past them).  No rustc here: the checks are
+    pinned as source."""
+    src = open(os.path.join(ROOT, "bindings", "rust", "vaporetto-hip", "src", "lib.rs")).read()
+    body = src[src.index("pub fn predict_batch_sharded"):]
+    body = body[:body.index("\n}\n")]
+    call = body.index("ffi::vpt_predict_batch_sharded")
+    for check in ("boff.is_empty()", "ooff.len() != boff.len()", "(utf8.len() as u64) < boff[n]", "(scores.len() as u64) < ooff[n]", "(labels.len() as u64) < ooff[n]",
+                  "preds.is_empty()"):
+        assert check in body and body.index(check) < call, check
+    assert "boff.len() - 1" not in body[call:]

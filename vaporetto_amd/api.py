@@ -98,8 +98,12 @@ class ConcatGraphemeClustersFilter:
     sentence filter that runs on the HOST between predict and fill_tags -- every boundary inside an extended grapheme cluster (UAX #29)
     becomes NotWordBoundary, so a ZWJ sequence or a base + modifier is never cut.  The reference segments with the `unicode-segmentation`
     crate (1.12.0); here the clusters come from the `regex` module's \\X, whichever Unicode version that module carries (the crate's and
-    the module's rules agree on everything the reference's tests hold: concat_grapheme_clusters.rs:43-88).  Like the char-type filters it
-    only clears boundaries and looks at nothing but the text, so its place among the post-filters does not matter."""
+    the module's rules agree on everything the reference's tests hold: concat_grapheme_clusters.rs:43-88).  It only CLEARS boundaries, so it
+    commutes with KyteaWsConstFilter (which clears too) -- but not with SplitLinebreaksFilter, which SETS the boundary between "\r" and "\n"
+    while CR LF is one cluster: the reference applies its filters in the caller's order (predict/src/main.rs:130-134);
+    `Predictor.tokenize(wsconst=("G", ..), split_linebreaks=True)` has ONE fixed order -- the device's label flags (wsconst types, then
+    split_linebreaks), then "G" on the host -- so "\r\n" stays joined there.  A caller that wants the other order runs this filter itself
+    between `predict_packed(.., wsconst=.., split_linebreaks=False)` and its own SplitLinebreaksFilter pass."""
 
     _X = None
 

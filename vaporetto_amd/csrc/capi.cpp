@@ -59,6 +59,7 @@ struct BatchKnobs {
     uint32_t debug_ablate = 0;          // VPT_DEBUG_ABLATE
     bool profile_phases = false;        // VPT_PROFILE_PHASES
     bool emit_no_prefix = false;        // VPT_DEBUG_EMIT_NO_PREFIX: the fused writer's tiles publish sizes only (tests: every look-back walks to the front)
+    bool tag_front_by_sentence = false; // VPT_TAG_FRONT_BY_SENTENCE: fill_tags' front-end launch as a wave per sentence (A/B of the flat one)
     int tag_split = 0;                  // VPT_TAG_SPLIT: 1 = fill_tags always as two launches (step loop -> queue in HBM -> passes), -1 = never (default: batches of 256 K chars and more)
     uint32_t tag_queue = 0;             // VPT_TAG_QUEUE: entries of that queue (tests: overflow; default: an eighth of the batch's chars + 64 K)
     uint32_t debug_emit = 0;            // VPT_DEBUG_EMIT
@@ -82,6 +83,7 @@ BatchKnobs read_batch_knobs() {
     k.force_generic = std::getenv("VPT_FORCE_GENERIC") != nullptr;
     if (const char* v = std::getenv("VPT_FORCE_CUT_TILES")) k.force_cut = std::atoi(v);
     if (const char* v = std::getenv("VPT_TILE_FLAT")) k.tile_flat = uint32_t(std::max(0, std::atoi(v)));
+    k.tag_front_by_sentence = std::getenv("VPT_TAG_FRONT_BY_SENTENCE") != nullptr;
     if (const char* v = std::getenv("VPT_TAG_SPLIT")) k.tag_split = std::atoi(v);
     if (const char* v = std::getenv("VPT_TAG_QUEUE")) k.tag_queue = uint32_t(std::max(0, std::atoi(v)));
     if (const char* v = std::getenv("VPT_DEBUG_EMIT")) k.debug_emit = uint32_t(std::max(0, std::atoi(v)));
@@ -1589,6 +1591,7 @@ vpt_status vpt_fill_tags_scores_batch_device(const vpt_predictor* p, vpt_batch* 
         T.queue = b->d_tag_queue + 1; T.qctl = reinterpret_cast<uint32_t*>(b->d_tag_queue);
         T.queue_slow = std::max<uint32_t>(entries / 8, 1u); T.queue_fast = entries - T.queue_slow;
     }
+    T.front_by_sentence = b->knobs.tag_front_by_sentence ? 1u : 0u;
     VPT_HIP(vpt::launch_tag_tokens(T, stream));
     b->last_stream = stream; b->pending = true;
     return VPT_OK;
@@ -1787,6 +1790,17 @@ vpt_status tokenize_fused(const vpt_predictor* p, vpt_batch* b, const uint8_t* t
     const bool serial = p->knobs.tokenize_serial;
     Workspace second;   // the scratch (tiles, partial sums, the writer's words, status) of every other chunk
     if (!serial && (st = acquire(p, &second)) != VPT_OK) return st;
+    // Kernels enqueued on THIS workspace's streams look back over the second one's scratch (its writer words, its status): on any return --
+    // an error one in the middle of the chunks included -- those streams are drained BEFORE `second` goes back to the pool (a guard declared
+    // behind it is destroyed in front of it), or another host thread could take and clear what a chunk in flight still reads
+    struct DrainFirst {
+        vpt_batch* b;
+        ~DrainFirst() {
+            (void)hipStreamSynchronize(b->own_stream);
+            if (b->s_tok_in) (void)hipStreamSynchronize(b->s_tok_in);
+            if (b->s_tok_out) (void)hipStreamSynchronize(b->s_tok_out);
+        }
+    } drain_first{b};
     vpt_batch* const ws[2] = {b, serial ? b : second.b};
     if (!b->s_tok_in) VPT_HIP(hipStreamCreateWithFlags(&b->s_tok_in, hipStreamNonBlocking));
     if (!b->s_tok_out) VPT_HIP(hipStreamCreateWithFlags(&b->s_tok_out, hipStreamNonBlocking));

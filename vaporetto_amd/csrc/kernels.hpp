@@ -157,6 +157,7 @@ struct TagParams {
     uint4* queue;
     uint32_t* qctl;
     uint32_t queue_fast, queue_slow;
+    uint32_t front_by_sentence; // A/B knob (read when the workspace was made, like every launch-level knob): the pair's front end as a wave per sentence
 };
 hipError_t launch_decode_chars(const uint8_t* text, const uint64_t* boff, const uint64_t* ooff, uint64_t n_sent, uint64_t total_chars,
                                const uint32_t* cinfo, uint32_t* cps, uint8_t* types, uint32_t* status, hipStream_t stream);

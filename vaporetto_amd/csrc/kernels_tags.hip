@@ -1056,8 +1056,8 @@ hipError_t launch_tag_tokens(const TagParams& P, hipStream_t stream) {
     if (P.queue && !dbg) {   // the pair, then the one-launch kernel for the case that the queue overflowed (it returns at once otherwise)
         const hipError_t e = hipMemsetAsync(P.qctl, 0, 3 * sizeof(uint32_t), stream);
         if (e != hipSuccess) return e;
-        // (A/B, VPT_TAG_FRONT_BY_SENTENCE; read per launch so that a test can switch it) the front end that gives a wave a sentence at a time
-        if (std::getenv("VPT_TAG_FRONT_BY_SENTENCE") != nullptr) hipLaunchKernelGGL((tag_tokens_kernel<false, true>), dim3(blocks), dim3(kTagThreads), 0, stream, P, 0u);
+        // (A/B, VPT_TAG_FRONT_BY_SENTENCE -- read when the workspace was made: nothing on the launch path calls getenv) the front end that gives a wave a sentence at a time
+        if (P.front_by_sentence) hipLaunchKernelGGL((tag_tokens_kernel<false, true>), dim3(blocks), dim3(kTagThreads), 0, stream, P, 0u);
         else {
             // runs of about 2 K chars (16 steps), at least a sentence: enough runs for every wave of the grid to even out, a window of offsets every
             // few steps (measured on configs[4], profiles/r04_o_tag_front.jsonl: runs of 2 K / 4 K / 16 K chars 1.761 / 1.781 / 1.970 ms stand-alone)
