@@ -196,12 +196,25 @@ class Runner:
         backend = os.environ.get("VPT_BENCH_BACKEND", "nccl")
         torch.cuda.set_device(self.local_rank)
         self.dev = torch.device("cuda", self.local_rank)
+        self.dist_failed = None     # why the N-rank job cannot run as one (then rank 0 falls back to driving the N devices itself: main())
         if self.world > 1:
+            import datetime
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-            if backend == "nccl":
-                dist.init_process_group("nccl", rank=self.rank, world_size=self.world, device_id=self.dev)   # RCCL
-            else:
-                dist.init_process_group(backend, rank=self.rank, world_size=self.world)
+            try:
+                if os.environ.get("VPT_BENCH_FAIL_INIT"):   # test hook: as if RCCL could not initialise
+                    raise RuntimeError("VPT_BENCH_FAIL_INIT")
+                if backend == "nccl":
+                    dist.init_process_group("nccl", rank=self.rank, world_size=self.world, device_id=self.dev, timeout=datetime.timedelta(seconds=300))   # RCCL
+                else:
+                    dist.init_process_group(backend, rank=self.rank, world_size=self.world, timeout=datetime.timedelta(seconds=300))
+                # the first collective, here: a fabric that does not work shows before any table is compiled
+                t = torch.ones(1, dtype=torch.int32, device=self.dev if backend == "nccl" else torch.device("cpu"))
+                dist.all_reduce(t)
+                if int(t.item()) != self.world:
+                    raise RuntimeError("all_reduce over %d ranks returned %d" % (self.world, int(t.item())))
+            except Exception as e:   # noqa: BLE001 -- anything: the line must still be printed
+                self.dist_failed = "%s: %s" % (type(e).__name__, str(e).replace("\n", " ")[:300])
+                sys.stderr.write("bench.py: rank %d: torch.distributed (%s) is not usable: %s\n" % (self.rank, backend, self.dist_failed))
         self.backend = backend if self.world > 1 else None
         self.ncores = max(1, (os.cpu_count() or 1) // self.world)
 
@@ -214,7 +227,8 @@ class Runner:
         p0 = api.Predictor(api.Model.read_slice(raw)[0], tags, device=self.local_rank) if self.rank == 0 else None
         create_s = time.perf_counter() - t
         t = time.perf_counter()
-        pred = vdist.broadcast_predictor(p0, src=0, device=self.dev)
+        pred = vdist.broadcast_predictor(p0, src=0, device=self.dev, model_bytes=raw, predict_tags=tags)
+        self.tables_broadcast = getattr(pred, "tables_broadcast", None)   # view / staged / compile: which way the tables took (dist.py)
         if self.world > 1:
             self.torch.cuda.synchronize()
         bcast_s = time.perf_counter() - t
@@ -318,7 +332,8 @@ class Runner:
         elapsed, total_boundaries = vdist.reduce_throughput(elapsed, float(nb), device=dev)
         per_rank = None
         if self.world > 1:   # what every rank measured, so that a bad curve can be read from the line alone
-            mine = {"rank": self.rank, "device": self.local_rank, "sentences": S, "boundaries": nb, "kernel_ms": round(kernel_ms, 4),
+            mine = {"rank": self.rank, "device": self.local_rank, "sentences": S, "boundaries": nb, "chars": nb + S, "kernel_ms": round(kernel_ms, 4),
+                    "tables_broadcast": self.tables_broadcast,
                     "kernel_ms_solo": None if kernel_ms_solo is None else round(kernel_ms_solo, 4), "ms_per_step": round(1e3 * elapsed_local / steps, 4),
                     "tiles": n_tiles, "create_s": round(create_s, 2), "tables_broadcast_s": round(bcast_s, 3), "synth_s": round(synth_s, 2)}
             gathered = [None] * self.world
@@ -642,6 +657,9 @@ def parse_args(argv=None):
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--config", type=int, default=0, choices=[0, 1, 2, 3, 4, 5, 6, 7, 8],
                     help="BASELINE.json configs index (0: configs[2] as the value at every N, plus -- at N = 1 -- the others as `workloads`)")
+    ap.add_argument("--scale-config", type=int, default=0, choices=[0, 1, 2, 3, 4, 5, 6, 7, 8],
+                    help="the workload of a scaling run other than configs[2]: e.g. 4 = BASELINE configs[4] (tags on, 8..512-char sentences), sharded by chars over the "
+                         "N ranks with the per-rank balance in `per_rank` (same as --config K --quick; passes through --scale-sweep / --dry-scale)")
     ap.add_argument("--quick", action="store_true", help="the primary workload only")
     ap.add_argument("--sentences", type=int, default=0, help="override the config's sentence count (diagnostics; traffic is then not reported)")
     ap.add_argument("--model-scale", type=float, default=1.0)
@@ -657,6 +675,8 @@ def parse_args(argv=None):
     ap.add_argument("--dry-scale", action="store_true", help="pre-flight of the scaling job: --scale-sweep 1,2,4,8 on whatever this box has -- N ranks on "
                     "N devices over RCCL when it has them, else every rank on device 0 over gloo -- and a check of every line (exit code 1 when one fails)")
     args = ap.parse_args(argv)
+    if args.scale_config:
+        args.config, args.quick = args.scale_config, True
     if args.gpus < 1:
         die("--gpus must be at least 1")
     return args
@@ -717,12 +737,11 @@ def run_in_process(args, reason: str) -> int:
     devs = [0] * N if one_dev else list(range(N))
     cfg_id = args.config or 2
     cfg = CONFIGS[cfg_id]
-    if cfg["tags"]:
-        die("the in-process fallback runs the boundary workloads (configs 1-3)")
     ncores = max(1, os.cpu_count() or 1)
     raw, model_name = load_model_bytes(cfg["kind"], args.model_scale)
     t = time.perf_counter()
-    p0 = api.Predictor(api.Model.read_slice(raw)[0], False, device=devs[0])
+    p0 = api.Predictor(api.Model.read_slice(raw)[0], bool(cfg["tags"]), device=devs[0])
+    nt = p0.n_tags() if cfg["tags"] else 0
     create_s = time.perf_counter() - t
     t = time.perf_counter()
     preds = [p0] + [p0.clone_to_device(d) for d in devs[1:]]
@@ -741,6 +760,7 @@ def run_in_process(args, reason: str) -> int:
                   d_text=torch.from_numpy(np.concatenate([utf8, np.zeros(64, np.uint8)])).to(dev),
                   d_boff=torch.from_numpy(boff.astype(np.int64)).to(dev), d_ooff=torch.from_numpy(ooff.astype(np.int64)).to(dev),
                   d_scores=torch.empty(nb + 1, dtype=torch.int32, device=dev), d_labels=torch.empty(nb + 1, dtype=torch.uint8, device=dev),
+                  d_tags=torch.empty((nb + S) * nt + 1, dtype=torch.int32, device=dev) if nt else None,
                   stream=torch.cuda.Stream(device=dev), batch=api.DeviceBatch(preds[r], timing=True))
         sh["batch"].set_max_sentence_chars((int(np.max(np.diff(ooff.astype(np.int64)))) + 1) if S else 1)
         shards.append(sh)
@@ -756,6 +776,9 @@ def run_in_process(args, reason: str) -> int:
             def step():
                 sh["batch"].predict(sh["d_text"].data_ptr(), sh["d_boff"].data_ptr(), sh["d_ooff"].data_ptr(), sh["S"], sh["nb"], sh["max_bytes"],
                                     sh["d_scores"].data_ptr(), sh["d_labels"].data_ptr(), st)
+                if nt:   # configs[4]: the step is the whole tagging job
+                    sh["batch"].fill_tags(sh["d_text"].data_ptr(), sh["d_boff"].data_ptr(), sh["d_ooff"].data_ptr(), sh["S"], sh["nb"], sh["d_labels"].data_ptr(),
+                                          sh["d_tags"].data_ptr(), st)
             for _ in range(args.warmup):
                 step()
             sh["batch"].sync()
@@ -784,7 +807,7 @@ def run_in_process(args, reason: str) -> int:
     parity, cpu, a_char = None, None, None
     if not args.no_cpu_baseline:
         from oracle import cbind
-        orc = cbind.OraclePredictor(raw, False)
+        orc = cbind.OraclePredictor(raw, bool(cfg["tags"]))
         parity = True
         for r, sh in enumerate(shards):
             t = time.perf_counter()
@@ -792,6 +815,9 @@ def run_in_process(args, reason: str) -> int:
             tn = time.perf_counter() - t
             torch.cuda.set_device(sh["dev"])
             ok = bool(np.array_equal(sh["d_scores"][:sh["nb"]].cpu().numpy(), o_scores) and np.array_equal(sh["d_labels"][:sh["nb"]].cpu().numpy(), o_labels))
+            if nt:
+                o_tags, _, _ = orc.fill_tags_batch(sh["utf8"], sh["boff"], sh["ooff"], o_labels, nthreads=ncores, want_scores=False)
+                ok = ok and bool(np.array_equal(sh["d_tags"][:(sh["nb"] + sh["S"]) * nt].cpu().numpy().reshape(sh["nb"] + sh["S"], nt), o_tags))
             parity = parity and ok
             if r == 0:
                 a_char = ac
@@ -823,7 +849,8 @@ def run_in_process(args, reason: str) -> int:
                    "table_bytes": info["device_table_bytes"], "hot_table_bytes": info["hot_table_bytes"], "packed_tables": bool(info["packed"]),
                    "tiles": n_tiles, "create_s": round(create_s, 2), "tables_broadcast_s": round(clone_s, 3), "synth_s": round(synth_s, 2),
                    "sharding": "contiguous sentence ranges balanced by chars over %d device(s), no data-path collective" % N,
-                   "hip_devices_visible": n_vis, "world_size": N, "collective_backend": None,
+                   "chars_per_device": [sh["nb"] + sh["S"] for sh in shards],
+                   "hip_devices_visible": n_vis, "world_size": N, "collective_backend": None, "tables_broadcast": "vpt_predictor_clone_to_device (hipMemcpyPeer)",
                    "launch": "in-process fallback: one process, vpt_predictor_clone_to_device (hipMemcpyPeer) to %d device(s), one host thread + stream "
                              "per device (%s)%s" % (N, reason, "; VPT_BENCH_ONE_DEVICE: every shard on device 0" if one_dev else "")},
         "parity": parity, "roofline": roof, "cpu_baseline": cpu,
@@ -909,6 +936,10 @@ def main():
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         raise SystemExit(self_launch(args))
     R = Runner(args)
+    if R.dist_failed:   #  the first time RCCL runs must not cost the curve: rank 0 drives the N devices itself, the others leave
+        if R.rank != 0:
+            raise SystemExit(0)
+        raise SystemExit(run_in_process(args, "torch.distributed could not be used by the %d ranks the caller launched (%s)" % (R.world, R.dist_failed)))
     primary_id = args.config or 2          # ONE workload over the whole 1 -> 8 curve (module docstring)
     prim = R.run(primary_id, primary=True, e2e_leg=(primary_id == 1))
     extra = []
@@ -929,6 +960,7 @@ def main():
         line["config"]["hip_devices_visible"] = R.torch.cuda.device_count()
         line["config"]["world_size"] = R.world
         line["config"]["collective_backend"] = ("RCCL (torch.distributed nccl)" if R.backend == "nccl" else R.backend) if R.world > 1 else None
+        line["config"]["tables_broadcast"] = getattr(R, "tables_broadcast", None) if R.world > 1 else None
         line["config"]["launch"] = os.environ.get("VPT_BENCH_LAUNCH") or ("one process, one GPU" if R.world == 1 else "torch.distributed.run started by the caller")
         if os.environ.get("VPT_BENCH_ONE_DEVICE") and R.world > 1:
             line["config"]["launch"] += "; VPT_BENCH_ONE_DEVICE: every rank on device 0"

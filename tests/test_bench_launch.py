@@ -99,3 +99,35 @@ def test_the_result_line_stays_below_the_drivers_tail():
     assert back["workloads"][1]["e2e_ms"] > 0 and back["workloads"][3]["tags_ms"] > 0
     assert "traffic_ratio" in back["workloads"][0]
     assert back["roofline"]["frac"] == pytest.approx(old["roofline"]["frac"], rel=1e-5) and back["cpu_baseline"]["value"] > 0
+
+
+@pytest.mark.gpu
+def test_table_broadcast_paths_and_a_failed_init_on_one_device():
+    """the 2-rank job (both ranks on device 0 over gloo) with the tables travelling each of the three ways (dist.py), and with
+    an init that fails (VPT_BENCH_FAIL_INIT: as if RCCL could not come up): rank 0 then drives the devices itself and the line says so -- exit code 0."""
+    env = {"VPT_BENCH_ONE_DEVICE": "1", "VPT_BENCH_BACKEND": "gloo"}
+    common = ["--config", "2", "--sentences", "200000", "--model-scale", "0.05", "--steps", "3", "--warmup", "1", "--no-emit", "--no-e2e"]
+    for path in ("view", "staged", "compile"):
+        r = _run(["--gpus", "2"] + common, dict(env, VPT_TABLES_BROADCAST=path))
+        assert r.returncode == 0, r.stderr[-2000:]
+        l = json.loads([x for x in r.stdout.decode().splitlines() if x.startswith("{")][-1])
+        assert l["n_gpus"] == 2 and l["parity"] is True and l["config"]["tables_broadcast"] == path, l["config"]
+        assert [pr["tables_broadcast"] for pr in l["per_rank"]] == [path, path]
+    r = _run(["--gpus", "2"] + common, dict(env, VPT_BENCH_FAIL_INIT="1"))
+    assert r.returncode == 0, r.stderr[-2000:]
+    l = json.loads([x for x in r.stdout.decode().splitlines() if x.startswith("{")][-1])
+    assert l["n_gpus"] == 2 and l["parity"] is True and "in-process fallback" in l["config"]["launch"] and "could not be used" in l["config"]["launch"]
+
+
+@pytest.mark.gpu
+def test_dry_scale_of_the_tagged_ragged_workload_at_four_ranks():
+    """BASELINE configs[4] ("8 x MI355X": tags on, 8..512-char sentences) as a sharded job: `--scale-config 4` through the dry run at N = 1 and 4 --
+    parity of scores, labels and tags on every rank, and the ranks' shares balanced by CHARS (within one longest sentence of each other)."""
+    r = _run(["--dry-scale", "--scale-sweep", "1,4", "--scale-config", "4", "--sentences", "100000", "--model-scale", "0.05", "--steps", "3", "--warmup", "1",
+              "--no-emit", "--no-e2e"])
+    lines = [json.loads(l) for l in r.stdout.decode().splitlines() if l.startswith("{")]
+    assert r.returncode == 0, (r.stderr[-3000:], [l.get("dry_scale_checks") for l in lines])
+    assert [l["n_gpus"] for l in lines] == [1, 4] and all(l["parity"] is True for l in lines)
+    assert all("configs[4]" in l["config"]["workload"] for l in lines) and lines[1]["tags"]["parity"] is True
+    chars = [pr["chars"] for pr in lines[1]["per_rank"]]
+    assert len(chars) == 4 and max(chars) - min(chars) <= 2 * 512, chars

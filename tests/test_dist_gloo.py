@@ -35,7 +35,12 @@ m = randmodel.rand_model(31, alphabet="kana", wc=3, wt=3, n_char=150, n_dict=150
 raw0 = encode_model(m) if rank == 0 else None
 raw = vdist.broadcast_model_bytes(raw0, src=0)                      # the model file (kept: checked below)
 pred0 = api.Predictor(api.Model.read_slice(raw)[0], False) if rank == 0 else None
-pred = vdist.broadcast_predictor(pred0, src=0, device=torch.device("cpu"))   # the COMPILED tables; rank 1 compiles nothing
+if os.environ.get("VPT_TEST_BREAK_VIEW") and rank == 0:                    # as if torch could not view the library's device memory
+    vdist._DeviceBytes = None
+    import numpy.ctypeslib as _ncl
+    _ncl.as_array = lambda *a, **k: (_ for _ in ()).throw(RuntimeError("no view of foreign memory"))
+pred = vdist.broadcast_predictor(pred0, src=0, device=torch.device("cpu"), model_bytes=raw)   # the COMPILED tables; rank 1 compiles nothing (but on the last path)
+open(os.path.join({out!r}, "path%d.txt" % rank), "w").write(str(pred.tables_broadcast))
 texts = randmodel.rand_sentences(9, m, 900, alphabet="kana", max_len=150)    # every rank builds the same batch
 texts = [t if i % 3 else "abc de" * (1 + i % 20) for i, t in enumerate(texts)]   # mixed 1- and 3-byte chars
 utf8, boff = api.pack_texts([t.encode("utf-8") for t in texts])
@@ -75,7 +80,14 @@ def test_shard_bounds_balance_and_cover():
     assert b[0] == 0 and b[-1] == 2 and np.all(np.diff(b) >= 0)
 
 
-def test_two_rank_gloo_broadcast_shard_and_reduce(tmp_path):
+import pytest
+
+
+@pytest.mark.parametrize("path", ["view", "staged", "compile", "view-breaks"])
+def test_two_rank_gloo_broadcast_shard_and_reduce(tmp_path, path):
+    """... over every way the compiled tables can travel (dist.broadcast_predictor; VERDICT r4 item 5: the first 8-GPU run must not trip):
+    the zero-copy view of the library's memory, the compiled form staged through torch-owned memory, every rank compiling for itself --
+    each forced by VPT_TABLES_BROADCAST -- and a view that fails on rank 0, which every rank then answers with the staged path."""
     from tests import emu
     emu.build_emulated()        # once, before the ranks race for it
     port = _free_port()
@@ -85,9 +97,18 @@ def test_two_rank_gloo_broadcast_shard_and_reduce(tmp_path):
     for rank in range(2):
         env = dict(os.environ, RANK=str(rank), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
                    LOCAL_RANK=str(rank))
+        if path == "view-breaks":
+            env["VPT_TEST_BREAK_VIEW"] = "1"
+        else:
+            env["VPT_TABLES_BROADCAST"] = path
         procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
     outs = [p.communicate(timeout=600)[0].decode() for p in procs]
     assert all(p.returncode == 0 for p in procs), "\n".join(outs)
+    paths = [open(tmp_path / ("path%d.txt" % k)).read() for k in range(2)]
+    if path == "view-breaks":
+        assert all(x.startswith("staged (after: view:") for x in paths), paths
+    else:
+        assert paths == [path, path], paths
 
     m = randmodel.rand_model(31, alphabet="kana", wc=3, wt=3, n_char=150, n_dict=150, max_word=9)
     raw = encode_model(m)
