@@ -91,10 +91,12 @@ class OraclePredictor:
             raise OracleError(st, "predict failed")
         return scores[:nb.value].tolist(), labels[:nb.value].tolist()
 
-    def predict_batch(self, utf8: np.ndarray, byte_offsets: np.ndarray, nthreads: int = 1, out=None, pin: bool = False):
+    def predict_batch(self, utf8: np.ndarray, byte_offsets: np.ndarray, nthreads: int = 1, out=None, pin: bool = False, double_array: bool = False):
         """utf8: uint8 array, byte_offsets: uint64[S+1].  Returns (scores, labels, out_offsets, A_char bytes).
         `out` = the (scores, labels, out_offsets) of an earlier call on the same batch: written in place -- a timed repeat then pays
-        no page faults of fresh arrays; `pin` = worker t stays on the t-th CPU of the process (timed baseline runs)."""
+        no page faults of fresh arrays; `pin` = worker t stays on the t-th CPU of the process (timed baseline runs); `double_array` = the char scorer's automaton walked
+        as a double array (what the reference's daachorse matcher is; the baseline leg of bench.py -- same scores by construction, checked in
+        tests/test_oracle_c_kat.py)."""
         S = len(byte_offsets) - 1
         utf8 = np.ascontiguousarray(utf8, dtype=np.uint8)
         byte_offsets = np.ascontiguousarray(byte_offsets, dtype=np.uint64)
@@ -110,7 +112,7 @@ class OraclePredictor:
             scores, labels, ooff = out
         ab = C.c_uint64()
         st = lib().vo_predict_batch_ex(self._h, utf8.ctypes.data, byte_offsets.ctypes.data, S, scores.ctypes.data,
-                                       labels.ctypes.data, ooff.ctypes.data, nthreads, C.byref(ab), 1 if pin else 0)
+                                       labels.ctypes.data, ooff.ctypes.data, nthreads, C.byref(ab), (1 if pin else 0) | (2 if double_array else 0))
         if st != 0:
             raise OracleError(st, "predict_batch failed")
         return scores, labels, ooff, ab.value

@@ -473,6 +473,128 @@ static inline uint32_t pma_step(const pma_t *a, uint32_t state, uint32_t sym) {
 static void pma_free(pma_t *a) { free(a->tab); free(a->fail); free(a->output); memset(a, 0, sizeof(*a)); }
 
 /* ------------------------------------------------------------------------------------------ */
+/* The same automaton as a DOUBLE ARRAY -- what the reference's matcher is (daachorse's CharwiseDoubleArrayAhoCorasick behind
+ * char_scorer/boundary_scorer.rs:76-99: 16-byte states {base, check, fail, output}, a char -> code map by frequency, child of s by
+ * code c at base[s] ^ c, there if its check names s).  BASELINE LEG ONLY (bench.py's cpu_baseline; flag VO_FLAG_DOUBLE_ARRAY of
+ * vo_predict_batch_ex): the checker stays the hash-table automaton above, and tests/test_oracle_c_kat.py holds the two against each
+ * other on the reference's known answers and on random text.  Built FROM the automaton above (same states, failure links, outputs),
+ * so it is the same function of the text by construction; what changes is the memory it walks: 16 bytes per state, dense, where the
+ * hash table spends 32+ per transition -- at 10 M sentences on 256 threads that is the difference VERDICT r4 (weak 5) asked about. */
+/* ------------------------------------------------------------------------------------------ */
+typedef struct { uint32_t base, check, fail, output; } da_state;
+typedef struct {
+    da_state *st; uint32_t n;          /* positions in use: [0, n) */
+    uint32_t *code_of; uint32_t n_codes_map;   /* scalar value -> code (0: no pattern holds the char), direct for [0, n_codes_map) */
+} da_t;
+static void da_free(da_t *d) { if (!d) return; free(d->st); free(d->code_of); free(d); }
+
+typedef struct { uint32_t state, sym, next; } da_edge;
+static int da_edge_cmp(const void *x, const void *y) {
+    const da_edge *a = (const da_edge *)x, *b = (const da_edge *)y;
+    if (a->state != b->state) return a->state < b->state ? -1 : 1;
+    return a->sym < b->sym ? -1 : (a->sym > b->sym ? 1 : 0);
+}
+static da_t *da_build(const pma_t *a) {
+    const uint32_t ns = a->n_states;
+    /* the edges, by state */
+    uint64_t n_edges = 0;
+    for (uint64_t h = 0; h <= a->mask; h++) n_edges += a->tab[h].used ? 1 : 0;
+    da_edge *e = (da_edge *)xmalloc(sizeof(da_edge) * (n_edges ? n_edges : 1));
+    uint64_t k = 0; uint32_t max_sym = 0;
+    for (uint64_t h = 0; h <= a->mask; h++) if (a->tab[h].used) {
+        e[k].state = (uint32_t)(a->tab[h].key >> 32); e[k].sym = (uint32_t)a->tab[h].key; e[k].next = a->tab[h].next;
+        if (e[k].sym > max_sym) max_sym = e[k].sym;
+        k++;
+    }
+    qsort(e, n_edges, sizeof(da_edge), da_edge_cmp);
+    /* codes by how many edges carry the symbol (most first: the children of a state then sit close to its base) */
+    da_t *d = (da_t *)xcalloc(1, sizeof(da_t));
+    d->n_codes_map = max_sym + 1;
+    d->code_of = (uint32_t *)xcalloc(d->n_codes_map, sizeof(uint32_t));
+    uint32_t *cnt = (uint32_t *)xcalloc(d->n_codes_map, sizeof(uint32_t));
+    for (uint64_t i = 0; i < n_edges; i++) cnt[e[i].sym]++;
+    uint32_t n_codes = 0;
+    for (uint32_t c = 0; c <= max_sym; c++) if (cnt[c]) n_codes++;
+    uint32_t *by = (uint32_t *)xmalloc(sizeof(uint32_t) * (n_codes ? n_codes : 1));
+    { uint32_t j = 0; for (uint32_t c = 0; c <= max_sym; c++) if (cnt[c]) by[j++] = c; }
+    /* (insertion-free: sort the symbols by count, descending, ties by value) */
+    for (uint32_t gap = n_codes / 2; gap > 0; gap /= 2)
+        for (uint32_t i = gap; i < n_codes; i++) {
+            uint32_t v = by[i]; uint32_t j = i;
+            while (j >= gap && (cnt[by[j - gap]] < cnt[v] || (cnt[by[j - gap]] == cnt[v] && by[j - gap] > v))) { by[j] = by[j - gap]; j -= gap; }
+            by[j] = v;
+        }
+    for (uint32_t j = 0; j < n_codes; j++) d->code_of[by[j]] = j + 1;
+    free(by); free(cnt);
+    /* first edge of every state */
+    uint64_t *first = (uint64_t *)xmalloc(sizeof(uint64_t) * ((uint64_t)ns + 1));
+    { uint64_t i = 0; for (uint32_t s = 0; s <= ns; s++) { while (i < n_edges && e[i].state < s) i++; first[s] = i; } }
+    /* placement: states in the order they were made (parents before children), children at base ^ code; first fit from the lowest
+     * free position, in blocks of `blk` positions (base ^ code stays inside the block of `base` when code < blk) */
+    uint32_t blk = 1; while (blk <= n_codes) blk <<= 1;
+    uint64_t cap = ((uint64_t)ns * 5 / 4 + 2 * (uint64_t)blk + 63) & ~(uint64_t)(blk - 1);
+    uint8_t *used = (uint8_t *)xcalloc(cap, 1);
+    uint32_t *pos = (uint32_t *)xmalloc(sizeof(uint32_t) * ns);
+    d->st = (da_state *)xcalloc(cap, sizeof(da_state));
+    for (uint64_t i = 0; i < cap; i++) d->st[i].check = NONE_ID;
+    pos[0] = 0; used[0] = 1;
+    uint64_t low = 1, top = 1;
+    uint32_t *codes = (uint32_t *)xmalloc(sizeof(uint32_t) * (n_codes ? n_codes : 1));
+    /* a state with several children does not start its search further back than a window behind where the last state of its size class
+     * went: what did not take that one will hardly take this one, and the holes left behind are filled by the one-child states, which fit
+     * anywhere -- keeps the placement linear in the number of states (the same device as vaporetto_amd/csrc/tables.cpp's Placer) */
+    uint64_t hint[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    const uint64_t lookback = 4096;
+    for (uint32_t s = 0; s < ns; s++) {       /* (state ids grow along every path: a parent is placed before its children) */
+        const uint64_t e0 = first[s], e1 = first[s + 1];
+        if (e0 == e1) continue;
+        const uint32_t nk = (uint32_t)(e1 - e0);
+        for (uint32_t j = 0; j < nk; j++) codes[j] = d->code_of[e[e0 + j].sym];
+        while (low < cap && used[low]) low++;
+        uint64_t base = 0; int found = 0;
+        const uint32_t cls = nk < 8 ? nk : 8;
+        uint64_t from = low;
+        if (nk > 1 && hint[cls] > lookback && hint[cls] - lookback > from) from = hint[cls] - lookback;
+        /* candidate bases: those that put the first child on a free position, from `from` on */
+        for (uint64_t q = from; !found; q++) {
+            if (q + blk >= cap) {   /* grow */
+                uint64_t ncap = cap * 2;
+                used = (uint8_t *)xrealloc(used, ncap); memset(used + cap, 0, ncap - cap);
+                d->st = (da_state *)xrealloc(d->st, sizeof(da_state) * ncap);
+                for (uint64_t i = cap; i < ncap; i++) { d->st[i].base = 0; d->st[i].check = NONE_ID; d->st[i].fail = 0; d->st[i].output = 0; }
+                cap = ncap;
+            }
+            if (used[q]) continue;
+            const uint64_t b = q ^ codes[0];
+            int ok = 1;
+            for (uint32_t j = 1; j < nk && ok; j++) ok = !used[b ^ codes[j]];
+            if (ok) { base = b; found = 1; hint[cls] = q; }
+        }
+        d->st[pos[s]].base = (uint32_t)base;
+        for (uint32_t j = 0; j < nk; j++) {
+            const uint64_t t = base ^ codes[j];
+            used[t] = 1; pos[e[e0 + j].next] = (uint32_t)t;
+            d->st[t].check = pos[s];
+            if (t + 1 > top) top = t + 1;
+        }
+    }
+    for (uint32_t s = 0; s < ns; s++) { d->st[pos[s]].fail = pos[a->fail[s]]; d->st[pos[s]].output = a->output[s]; }
+    d->n = (uint32_t)top;
+    free(codes); free(used); free(pos); free(first); free(e);
+    return d;
+}
+static inline uint32_t da_step(const da_t *d, uint32_t st, uint32_t sym) {
+    const uint32_t c = sym < d->n_codes_map ? d->code_of[sym] : 0;
+    if (c == 0) return 0;               /* a char of no pattern: every state fails down to the root, which has no such child */
+    for (;;) {
+        const uint32_t t = d->st[st].base ^ c;
+        if (d->st[t].check == st) return t;
+        if (st == 0) return 0;
+        st = d->st[st].fail;
+    }
+}
+
+/* ------------------------------------------------------------------------------------------ */
 /* scorer = automaton + PositionalWeight<WeightVector> per pattern                             */
 /* ------------------------------------------------------------------------------------------ */
 typedef struct {
@@ -489,6 +611,7 @@ typedef struct {
     tagw_rec *tagw; uint32_t n_tagw;  /* sorted by (token_id, rel, pattern): tag_weight[token][rel].get(pattern) */
     int record_states;                /* BoundaryTag variants store the per-position pattern ids */
     uint32_t window;
+    da_t *da;                         /* the automaton as a double array: made on first use by the baseline leg (VO_FLAG_DOUBLE_ARRAY), else NULL */
 } scorer_t;
 
 static int tagw_cmp(const void *x, const void *y) {
@@ -540,6 +663,7 @@ static int scorer_from_merger(scorer_t *sc, merger *mg, uint32_t window, int rec
     return 0;
 }
 static void scorer_free(scorer_t *sc) {
+    da_free(sc->da);
     pma_free(&sc->pma); free(sc->pw); free(sc->wdata); free(sc->tagw); memset(sc, 0, sizeof(*sc));
 }
 static void merger_free(merger *mg) {
@@ -579,6 +703,28 @@ static int scorer_add_scores(const scorer_t *sc, const uint32_t *syms, long n, i
     for (long i = 0; i < n; i++) {
         st = pma_step(&sc->pma, st, syms[i]);
         uint32_t m = sc->pma.output[st];
+        if (m != NONE_ID) {
+            const pw_rec *p = &sc->pw[m];
+            if (p->present && add_score(sc, p, (i + 1) + padding - 1, ys, ylen) != 0) rc = -1;
+            ab += p->abytes;
+            if (states) states[i] = m;
+        }
+    }
+    if (abytes) *abytes += ab;
+    return rc;
+}
+
+/* ... over the double array (baseline leg): the same loop, the other representation of the same automaton */
+static int scorer_add_scores_da(const scorer_t *sc, const uint32_t *syms, long n, int32_t *ys, long ylen, long padding,
+                                uint32_t *states, uint64_t *abytes) {
+    const da_t *d = sc->da;
+    uint32_t st = 0;
+    int rc = 0;
+    uint64_t ab = 0;
+    if (states) for (long i = 0; i < n; i++) states[i] = NONE_ID;
+    for (long i = 0; i < n; i++) {
+        st = da_step(d, st, syms[i]);
+        uint32_t m = d->st[st].output;
         if (m != NONE_ID) {
             const pw_rec *p = &sc->pw[m];
             if (p->present && add_score(sc, p, (i + 1) + padding - 1, ys, ylen) != 0) rc = -1;
@@ -819,8 +965,8 @@ static void scratch_free(scratch_t *s) { free(s->cps); free(s->types); free(s->c
 
 /* Sentence::parse_raw + Predictor::predict for one sentence.  Returns the number of chars (>=1) or a
  * negative status.  scores/labels receive n-1 entries. */
-static long predict_one(const vo_predictor *p, const uint8_t *utf8, size_t len, scratch_t *s,
-                        int32_t *scores, uint8_t *labels, uint64_t *abytes) {
+static long predict_one_ex(const vo_predictor *p, const uint8_t *utf8, size_t len, scratch_t *s,
+                           int32_t *scores, uint8_t *labels, uint64_t *abytes, int use_da) {
     if (len == 0) return -VO_INVALID_ARGUMENT;                  /* "must contain at least one character" */
     scratch_reserve(s, (long)len);
     long n = utf8_decode(utf8, len, s->cps);
@@ -833,7 +979,7 @@ static long predict_one(const vo_predictor *p, const uint8_t *utf8, size_t len, 
     long ylen = 2 * pad + n - 1;
     for (long i = 0; i < ylen; i++) s->ys[i] = p->bias;         /* predictor.rs:520-524 */
     int rc = 0;
-    if (p->has_char) rc |= scorer_add_scores(&p->chr, s->cps, n, s->ys, ylen, pad, p->chr.record_states ? s->cstates : NULL, abytes);
+    if (p->has_char) rc |= (use_da && p->chr.da ? scorer_add_scores_da : scorer_add_scores)(&p->chr, s->cps, n, s->ys, ylen, pad, p->chr.record_states ? s->cstates : NULL, abytes);
     if (p->type_kind == 1) tcache_add_scores(&p->tcache, s->types, n, s->ys, pad);
     else if (p->type_kind == 2) rc |= scorer_add_scores(&p->typ, s->types, n, s->ys, ylen, pad, p->typ.record_states ? s->tstates : NULL, NULL);
     if (rc != 0) return -VO_INTERNAL;                           /* the reference would have panicked */
@@ -843,6 +989,11 @@ static long predict_one(const vo_predictor *p, const uint8_t *utf8, size_t len, 
         if (labels) labels[b] = y > 0 ? 1 : 0;
     }
     return n;
+}
+
+static long predict_one(const vo_predictor *p, const uint8_t *utf8, size_t len, scratch_t *s,
+                        int32_t *scores, uint8_t *labels, uint64_t *abytes) {
+    return predict_one_ex(p, utf8, len, s, scores, labels, abytes, 0);
 }
 
 int vo_predict(const vo_predictor *p, const uint8_t *utf8, size_t len, int32_t *scores, uint8_t *labels, size_t *n_boundaries) {
@@ -872,14 +1023,15 @@ typedef struct {
     const vo_predictor *p; const uint8_t *utf8; const uint64_t *boff, *ooff;
     size_t lo, hi; int32_t *scores; uint8_t *labels; uint64_t abytes; int status;
     int cpu;   /* >= 0: the worker pins itself to this CPU (timing runs: no migration, first-touch locality) */
+    int use_da; /* the char scorer's automaton as a double array (baseline leg) */
 } job_t;
 static void *job_run(void *arg) {
     job_t *j = (job_t *)arg;
     if (j->cpu >= 0) { cpu_set_t set; CPU_ZERO(&set); CPU_SET(j->cpu, &set); (void)pthread_setaffinity_np(pthread_self(), sizeof(set), &set); }
     scratch_t s; memset(&s, 0, sizeof(s));
     for (size_t i = j->lo; i < j->hi; i++) {
-        long n = predict_one(j->p, j->utf8 + j->boff[i], (size_t)(j->boff[i + 1] - j->boff[i]), &s,
-                             j->scores ? j->scores + j->ooff[i] : NULL, j->labels ? j->labels + j->ooff[i] : NULL, &j->abytes);
+        long n = predict_one_ex(j->p, j->utf8 + j->boff[i], (size_t)(j->boff[i + 1] - j->boff[i]), &s,
+                                j->scores ? j->scores + j->ooff[i] : NULL, j->labels ? j->labels + j->ooff[i] : NULL, &j->abytes, j->use_da);
         if (n < 0) { j->status = (int)-n; break; }
         if ((uint64_t)(n - 1) != j->ooff[i + 1] - j->ooff[i]) { j->status = VO_INVALID_ARGUMENT; break; }
     }
@@ -891,9 +1043,12 @@ static void *job_run(void *arg) {
  * optionally on `nthreads` host threads over contiguous sentence shards (the reference itself is serial).
  * `char_bytes_out` (may be NULL) receives A_char of BASELINE.md section 4: the sum over every un-merged
  * char n-gram / dict word occurrence of 4*len(w). */
-/* flags: bit 0 = pin worker t to the t-th CPU this process may run on (timed baseline runs) */
+/* flags: bit 0 = pin worker t to the t-th CPU this process may run on (timed baseline runs); bit 1 (VO_FLAG_DOUBLE_ARRAY) = the char
+ * scorer walks its automaton as a double array (made here on first use, before any worker starts; not thread-safe against a concurrent
+ * first use from another caller -- bench.py and the tests are single callers) */
 int vo_predict_batch_ex(const vo_predictor *p, const uint8_t *utf8, const uint64_t *byte_offsets, size_t S,
                         int32_t *scores, uint8_t *labels, const uint64_t *out_offsets, int nthreads, uint64_t *char_bytes_out, int flags) {
+    if ((flags & 2) && p->has_char && !p->chr.da) ((vo_predictor *)p)->chr.da = da_build(&p->chr.pma);
     if (nthreads < 1) nthreads = 1;
     if ((size_t)nthreads > S) nthreads = S ? (int)S : 1;
     job_t *jobs = (job_t *)xcalloc((size_t)nthreads, sizeof(job_t));
@@ -916,6 +1071,7 @@ int vo_predict_batch_ex(const vo_predictor *p, const uint8_t *utf8, const uint64
         jobs[t].p = p; jobs[t].utf8 = utf8; jobs[t].boff = byte_offsets; jobs[t].ooff = out_offsets;
         jobs[t].lo = lo; jobs[t].hi = hi; jobs[t].scores = scores; jobs[t].labels = labels;
         jobs[t].cpu = (ncpus >= nthreads) ? cpus[t] : -1;
+        jobs[t].use_da = (flags & 2) ? 1 : 0;
         lo = hi;
     }
     if (nthreads == 1) job_run(&jobs[0]);

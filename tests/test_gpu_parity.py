@@ -1504,11 +1504,15 @@ def test_write_tagged_text_on_device():
         batch.sync()
 
 
-@pytest.mark.parametrize("per_block", [1, 3, 64])
+@pytest.mark.parametrize("per_block", [1, 3, 64, 256, "waves-3"])
 def test_writer_blocks_of_any_size(per_block, monkeypatch):
-    """The writer's waves take blocks of consecutive sentences (kernels_emit.hip); the block size comes from the mean sentence
-    length -- here it is forced (VPT_EMIT_PER_BLOCK, read when a workspace is made): one sentence per wave, a few, 64; sentences
-    of 1 .. 900 chars with escapes, 1- to 4-byte chars, every alignment of text, labels and output."""
+    """The writer takes blocks of consecutive sentences (kernels_emit.hip): a workgroup per run without tags (emit_flat_kernel, round 5), a wave
+    per block with tags (and without, under VPT_EMIT_WAVE_BLOCKS: "waves-3"); the block size comes from the mean sentence length -- here it is
+    forced (VPT_EMIT_PER_BLOCK, read when a workspace is made): one sentence per block, a few, 64, 256; sentences of 1 .. 13 000 chars (several
+    4 KB pieces of a workgroup's walk) with escapes, 1- to 4-byte chars, every alignment of text, labels and output."""
+    if per_block == "waves-3":
+        monkeypatch.setenv("VPT_EMIT_WAVE_BLOCKS", "1")
+        per_block = 3
     monkeypatch.setenv("VPT_EMIT_PER_BLOCK", str(per_block))
     m = randmodel.rand_model(843, alphabet="kana", wc=3, wt=3, n_tag_models=30, max_word=3, n_char=60, n_dict=60)
     for k, tm in enumerate(m.tag_models):
@@ -1516,8 +1520,9 @@ def test_writer_blocks_of_any_size(per_block, monkeypatch):
     raw = encode_model(m)
     rng = np.random.default_rng(13 + per_block)
     alphabet = list("あいう漢字ab /\\/ .🤌é") + ["\n"]
-    lens = list(rng.integers(1, 40, 500)) + [1, 1, 63, 64, 65, 127, 128, 129, 341, 342, 343, 700, 900]
+    lens = list(rng.integers(1, 40, 500)) + [1, 1, 63, 64, 65, 127, 128, 129, 341, 342, 343, 700, 900, 1365, 1366, 4095, 4096, 4097, 13000] + [1] * 300
     texts = ["".join(rng.choice(alphabet, size=int(n))) for n in lens]
+    texts += ["a b/c\\" * 700, "ab" * 2048, "\\" * 4096 + "あ", "🤌" * 1100]   # pieces of one-byte chars only, every byte escaped, four-byte chars across pieces
     utf8, boff = api.pack_texts([t.encode("utf-8") for t in texts])
     ooff = api.count_boundaries(utf8, boff)
     for trial in range(3):   # the same workspace again: its state words alternate between two arrays

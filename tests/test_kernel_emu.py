@@ -22,7 +22,9 @@ def _kernels_on_the_emulator():
     _lib._lib = lib
     devmem.EMULATED = True
     yield
-    devmem.EMULATED = False
+    import gc
+    gc.collect()   # handles made by the emulated library are destroyed BY it (a predictor kept alive by a traceback until after the swap would be
+    devmem.EMULATED = False   # handed to the real library's destructor, whose structs need not match a stale build's)
     _lib._lib = saved
 
 

@@ -230,3 +230,27 @@ def test_batch_matches_single():
             s, l = p.predict(t)
             assert scores[int(ooff[i]):int(ooff[i + 1])].tolist() == s
             assert labels[int(ooff[i]):int(ooff[i + 1])].tolist() == l
+
+
+def test_double_array_automaton_of_the_baseline_leg_equals_the_checker():
+    """bench.py's cpu_baseline walks the char scorer's automaton as a DOUBLE ARRAY (what daachorse is: char_scorer/boundary_scorer.rs:76-99); the
+    checker keeps its hash-table automaton.  The double array is built from the checker's automaton (same states, failure links, outputs), and here
+    the two are held against each other: the reference's own boundary vectors (predictor.rs:749-859 through the fixture model), random models with
+    nested suffix chains and chars outside every pattern (incl. non-BMP ones), one and several threads."""
+    import numpy as np
+    from tests import kat, randmodel
+    from vaporetto_amd import api
+    from vaporetto_amd.modelfmt import encode_model
+    raw, _ = kat.load_fixture("model.bin")
+    texts = ["まぁ社長は火星猫だ", "まぁ良いだろう", "火星猫", "あ", "𠮷野家でまぁ", "abc まぁ"] * 20
+    models = [(raw, texts)]
+    for seed, alphabet in ((1, "kana"), (2, "mixed"), (3, "tiny"), (4, "mixed")):
+        m = randmodel.rand_model(7700 + seed, alphabet=alphabet, wc=3, wt=3, n_char=400, n_dict=600, max_word=9)
+        models.append((encode_model(m), randmodel.rand_sentences(seed, m, 700, alphabet="mixed" if seed % 2 == 0 else alphabet, max_len=90)))
+    for rawm, tx in models:
+        orc = cbind.OraclePredictor(rawm)
+        utf8, boff = api.pack_texts([t.encode("utf-8") for t in tx])
+        want = orc.predict_batch(utf8, boff)
+        for nthreads in (1, 3):
+            got = orc.predict_batch(utf8, boff, nthreads=nthreads, double_array=True)
+            assert np.array_equal(got[0], want[0]) and np.array_equal(got[1], want[1]) and got[3] == want[3]

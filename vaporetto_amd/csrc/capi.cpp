@@ -63,7 +63,9 @@ struct BatchKnobs {
     int tag_split = 0;                  // VPT_TAG_SPLIT: 1 = fill_tags always as two launches (step loop -> queue in HBM -> passes), -1 = never (default: batches of 256 K chars and more)
     uint32_t tag_queue = 0;             // VPT_TAG_QUEUE: entries of that queue (tests: overflow; default: an eighth of the batch's chars + 64 K)
     uint32_t debug_emit = 0;            // VPT_DEBUG_EMIT
-    uint32_t emit_per_block = 0;        // VPT_EMIT_PER_BLOCK: sentences a wave of the writer takes (1..64; 0: from the mean sentence length)
+    uint32_t emit_per_block = 0;        // VPT_EMIT_PER_BLOCK: sentences a wave / a workgroup of the writer takes (1..64 / 1..256; 0: from the mean sentence length)
+    bool emit_wave_blocks = false;      // VPT_EMIT_WAVE_BLOCKS: the untagged writer as a wave per block too (A/B of the workgroup-per-run kernel)
+    uint32_t emit_run_chars = 0;        // VPT_EMIT_RUN_CHARS: chars of a workgroup's run (default 5120)
 };
 PredictorKnobs read_predictor_knobs() {
     PredictorKnobs k;
@@ -87,7 +89,9 @@ BatchKnobs read_batch_knobs() {
     if (const char* v = std::getenv("VPT_TAG_SPLIT")) k.tag_split = std::atoi(v);
     if (const char* v = std::getenv("VPT_TAG_QUEUE")) k.tag_queue = uint32_t(std::max(0, std::atoi(v)));
     if (const char* v = std::getenv("VPT_DEBUG_EMIT")) k.debug_emit = uint32_t(std::max(0, std::atoi(v)));
-    if (const char* v = std::getenv("VPT_EMIT_PER_BLOCK")) k.emit_per_block = uint32_t(std::min(64, std::max(0, std::atoi(v))));
+    if (const char* v = std::getenv("VPT_EMIT_PER_BLOCK")) k.emit_per_block = uint32_t(std::min(256, std::max(0, std::atoi(v))));
+    k.emit_wave_blocks = std::getenv("VPT_EMIT_WAVE_BLOCKS") != nullptr;
+    if (const char* v = std::getenv("VPT_EMIT_RUN_CHARS")) k.emit_run_chars = uint32_t(std::max(0, std::atoi(v)));
     k.no_cps_from_predict = std::getenv("VPT_NO_CPS_FROM_PREDICT") != nullptr;
     if (const char* v = std::getenv("VPT_DEBUG_ABLATE")) k.debug_ablate = uint32_t(std::atoi(v));
     k.profile_phases = std::getenv("VPT_PROFILE_PHASES") != nullptr;
@@ -1625,12 +1629,16 @@ vpt_status emit_device(const vpt_predictor* p, vpt_batch* b, const uint8_t* d_ut
     }
     // a wave per block of sentences: about two thousand chars of them (six steps of CJK text), at most 64 (measured on MI355X,
     // configs[1]: 4 sentences of 64 chars per wave 0.122 ms, 8 0.093, 16 0.070, 32 0.063, 64 0.066: profiles/r03_n_emit_block_sizes.txt)
+    // Without tags (round 5): a WORKGROUP per run of sentences, about 5 K chars of them (16 KB of CJK text: four pieces of 4 KB), at most 256
+    // -- one look-back per workgroup, the prefix sums of a piece shared by 256 threads (emit_flat_kernel; VPT_EMIT_WAVE_BLOCKS keeps the waves).
     vpt::EmitFuse F{};
     {
         const uint64_t chars = total_boundaries + n_sentences;
-        const uint64_t per = (uint64_t(2048) * n_sentences + chars / 2) / chars;   // round(2048 / mean chars per sentence)
-        F.per_block = uint32_t(std::min<uint64_t>(std::max<uint64_t>(per, 1), vpt::kEmitFuseMaxBlock));
-        if (b->knobs.emit_per_block) F.per_block = b->knobs.emit_per_block;
+        F.flat = (!E.tags && !b->knobs.debug_emit && !b->knobs.emit_wave_blocks) ? 1u : 0u;
+        const uint64_t target = F.flat ? (b->knobs.emit_run_chars ? b->knobs.emit_run_chars : 5120) : 2048;
+        const uint64_t per = (target * n_sentences + chars / 2) / chars;   // round(target / mean chars per sentence)
+        F.per_block = uint32_t(std::min<uint64_t>(std::max<uint64_t>(per, 1), F.flat ? vpt::kEmitFlatMaxBlock : vpt::kEmitFuseMaxBlock));
+        if (b->knobs.emit_per_block) F.per_block = std::min<uint32_t>(b->knobs.emit_per_block, F.flat ? vpt::kEmitFlatMaxBlock : vpt::kEmitFuseMaxBlock);
         F.n_blocks = (n_sentences + F.per_block - 1) / F.per_block;
     }
     const size_t words = size_t(F.n_blocks) + 1;

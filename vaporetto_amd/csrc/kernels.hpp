@@ -185,12 +185,15 @@ struct EmitParams {
 size_t scan_part_entries(uint64_t n);
 // The writer's launch (emit_fused_kernel): a wave per block of `per_block` consecutive sentences (1 .. kEmitFuseMaxBlock).
 constexpr uint32_t kEmitFuseMaxBlock = 64;
+// ... or, without tags, a WORKGROUP per run of `per_block` consecutive sentences (1 .. kEmitFlatMaxBlock): emit_flat_kernel
+constexpr uint32_t kEmitFlatMaxBlock = 256;
 struct EmitFuse {
     uint64_t* state;        // n_blocks + 1 words, ZERO when the kernel starts: the blocks' sizes / positions and the ticket
     uint64_t* clear;        // the state words of the NEXT call (the other of two arrays), zeroed by this one: [0, clear_n)
     uint64_t clear_n, n_blocks;
     uint32_t per_block;
     uint32_t dbg;           // VPT_DEBUG_EMIT timing ablations (a diagnostics build of the kernel; results are wrong by design)
+    uint32_t flat;          // the blocks are runs of sentences for emit_flat_kernel (no tags)
     uint64_t* total_out;    // optional device-writable HOST address that receives the output's total size
 };
 hipError_t launch_emit_tokenized(const EmitParams& P, const EmitFuse& F, hipStream_t stream);

@@ -552,6 +552,245 @@ __global__ __launch_bounds__(kEmitThreads, kOcc) void emit_fused_kernel(const Em
     if (err) atomicOr(P.status, err);
 }
 
+// ------------------------------------------------------------------------------------------------------------
+// emit_flat_kernel (round 5): the writer without tags, FLAT over runs of sentences like count_chars_kernel / decode_chars_kernel.
+//
+// A WORKGROUP takes a run of `per_block` consecutive sentences (at most 256: about 16 KB of text); its text bytes and its labels are
+// two contiguous ranges.  What it will write is a plain reduction -- the run's bytes + its escaped bytes + its boundary labels -- streamed
+// with four 16-byte loads per thread in flight; ONE look-back per workgroup (wave 0, 64 words per trip) places the run; then the run is
+// walked in pieces of 4 KB, sixteen bytes per thread: lead / escape / sentence-start masks, one block prefix sum numbers the threads' chars
+// and sentences (which names their labels in the window of labels staged in LDS with the piece), a second one places their output, which is
+// assembled in LDS and leaves as aligned 16-byte stores.  Same checks, same error bits, same output as emit_fused_kernel<false> (which stays
+// as the tagged writer and as the A/B: VPT_EMIT_WAVE_BLOCKS); what changes is the shape: 256 threads share a step's prefix sums and barriers
+// where a wave did them alone for 1 KB, and a workgroup looks back once where four waves did.
+// ------------------------------------------------------------------------------------------------------------
+constexpr uint32_t kFlatPiece = kEmitThreads * 16;                 // text bytes of a workgroup's step
+constexpr uint32_t kFlatStageBytes = 3 * kFlatPiece + 32;          // its output at most (every byte escaped, a space per char) + the alignment head
+struct alignas(16) FlatLds {
+    uint32_t stage[kFlatStageBytes / 4];
+    uint32_t labs[(kFlatPiece + 64) / 4];     // the labels a piece's chars can ask for, from a 16-byte aligned address
+    uint32_t starts[kFlatPiece / 32];         // one bit per byte of the piece: a sentence starts here
+    uint32_t so[kEmitFlatMaxBlock + 1];       // the run's boundary offsets, relative to its first
+    uint32_t dump[kEmitThreads];              // where a thread's stores of bytes that are not there go
+    uint32_t wtot[kEmitWaves];
+    uint32_t flags;                           // OR of the threads' "my offsets are no offsets"
+    uint64_t red[kEmitWaves];
+    uint64_t bcast[4];                        // ticket, B0, O0, base
+};
+
+// exclusive prefix sum of x over the workgroup's threads (two packed 16-bit counts or one 32-bit one); *total = the sum
+__device__ __forceinline__ uint32_t flat_block_scan(uint32_t x, uint32_t* wtot, uint32_t lane, uint32_t wave, uint32_t* total) {
+    const uint32_t incl = wave_inclusive_scan(x);
+    if (lane == 63) wtot[wave] = incl;
+    __syncthreads();
+    uint32_t woff = 0, tot = 0;
+#pragma unroll
+    for (uint32_t k = 0; k < uint32_t(kEmitWaves); ++k) {
+        const uint32_t u = wtot[k];
+        if (k < wave) woff += u;
+        tot += u;
+    }
+    __syncthreads();   // wtot is written again by the next sum
+    *total = tot;
+    return woff + incl - x;
+}
+
+__global__ __launch_bounds__(kEmitThreads) void emit_flat_kernel(const EmitParams P, const EmitFuse F) {
+    __shared__ FlatLds L;
+    // the other array of state words, for the call after this one
+    for (uint64_t k = uint64_t(blockIdx.x) * kEmitThreads + threadIdx.x; k < F.clear_n; k += uint64_t(gridDim.x) * kEmitThreads) F.clear[k] = 0;
+    const uint32_t tid = threadIdx.x, lane = tid & 63, wave = wave_uniform(tid >> 6);
+    if (tid == 0) { L.bcast[0] = atomicAdd(reinterpret_cast<unsigned long long*>(F.state + F.n_blocks), 1ull); L.flags = 0; }
+    if (tid < kFlatPiece / 32) L.starts[tid] = 0;
+    __syncthreads();
+    const uint64_t blk = L.bcast[0];
+    if (blk >= F.n_blocks) return;
+    const uint64_t i0 = blk * F.per_block;
+    const uint32_t ns = uint32_t(P.n_sent - i0 < F.per_block ? P.n_sent - i0 : F.per_block);
+    // the run's offsets: thread j holds sentence i0 + j's and its successor's
+    uint64_t my_b = ~uint64_t(0), my_o = 0, nx_b = 0, nx_o = 0;
+    const bool mine = tid < ns;
+    if (mine) { my_b = P.boff[i0 + tid]; my_o = P.ooff[i0 + tid]; nx_b = P.boff[i0 + tid + 1]; nx_o = P.ooff[i0 + tid + 1]; }
+    if (tid == 0) { L.bcast[1] = my_b; L.bcast[2] = my_o; }
+    if (tid == ns - 1) { L.red[0] = nx_b; L.red[1] = nx_o; }
+    uint32_t err = 0;
+    {
+        const bool empty = mine && nx_b <= my_b, bad = mine && (nx_o < my_o || nx_o > P.total_boundaries);
+        if (empty) err |= kErrEmptySentence;
+        if (bad) err |= kErrBadOffsets;
+        if (empty || bad) atomicOr(&L.flags, 1u);
+    }
+    __syncthreads();
+    const uint64_t B0 = L.bcast[1], O0 = L.bcast[2], B1 = L.red[0], O1 = L.red[1];
+    const bool sane = L.flags == 0 && O1 - O0 < 0xFFFF0000ull && B1 - B0 < 0xFFFF0000ull;
+    if (!sane) err |= kErrBadOffsets;
+    if (mine) L.so[tid] = uint32_t(my_o - O0);
+    if (tid == 0) L.so[ns] = uint32_t(O1 - O0);
+    __syncthreads();   // (red[] is used again below)
+
+    // ---- the run's size = its bytes + the escaped bytes + the boundary labels of its label range
+    const uintptr_t t_lo = reinterpret_cast<uintptr_t>(P.text) + B0, t_hi = reinterpret_cast<uintptr_t>(P.text) + B1;
+    const uintptr_t l_all = reinterpret_cast<uintptr_t>(P.labels), l_end = l_all + P.total_boundaries;
+    uint64_t size = 0;
+    if (sane) {
+        uint32_t added = 0;
+        const uintptr_t l_lo = l_all + O0, l_hi = l_all + O1;
+        for (uintptr_t a = (t_lo & ~uintptr_t(15)) + 16u * tid; a < t_hi; a += 4 * kFlatPiece) {   // four loads in flight
+            uint4 x[4];
+#pragma unroll
+            for (uint32_t q = 0; q < 4; ++q) x[q] = a + q * kFlatPiece < t_hi ? *reinterpret_cast<const uint4*>(a + q * kFlatPiece) : make_uint4(0, 0, 0, 0);
+#pragma unroll
+            for (uint32_t q = 0; q < 4; ++q) added += uint32_t(__popc(esc16(x[q]) & in_range16(a + q * kFlatPiece, t_lo, t_hi)));
+        }
+        for (uintptr_t a = (l_lo & ~uintptr_t(15)) + 16u * tid; a < l_hi; a += kFlatPiece) {
+            const uint4 y = *reinterpret_cast<const uint4*>(a);
+            const uint32_t m = in_range16(a, l_lo, l_hi);
+            added += uint32_t(__popc(one16(y) & m));
+            if (unk16(y) & m) err |= kErrUnknownLabel;
+        }
+        const uint64_t ws = wave_sum64(added);
+        if (lane == 0) L.red[wave] = ws;
+        __syncthreads();
+        size = B1 - B0;
+#pragma unroll
+        for (uint32_t k = 0; k < uint32_t(kEmitWaves); ++k) size += L.red[k];
+    }
+    // ---- the run's position: wave 0 looks back over the earlier runs' words, 64 per trip
+    if (wave == 0) {
+        constexpr uint64_t kVal = (uint64_t(1) << 62) - 1;
+        if (lane == 0) __hip_atomic_store(F.state + blk, (uint64_t(1) << 62) | size, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        uint64_t base = 0;
+        for (uint64_t p = blk; p > 0;) {
+            const bool have = uint64_t(lane) < p;
+            uint64_t w = uint64_t(2) << 62;   // in front of run 0: position 0
+            if (have) w = __hip_atomic_load(F.state + (p - 1 - uint64_t(lane)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const uint64_t pending = __ballot((w >> 62) == 0), prefixed = __ballot((w >> 62) == 2);
+            const int first = prefixed ? __ffsll((long long)prefixed) - 1 : 64;   // the nearest run whose position is known
+            const uint64_t need = first < 63 ? (uint64_t(2) << first) - 1 : ~uint64_t(0);
+            if (pending & need) { __builtin_amdgcn_s_sleep(2); continue; }         // not all published yet: look again
+            base += wave_sum64(int(lane) <= first ? (w & kVal) : 0);
+            if (first < 64) break;
+            p -= 64;
+        }
+        if (lane == 0) {
+            __hip_atomic_store(F.state + blk, (uint64_t(2) << 62) | ((base + size) & kVal), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            L.bcast[3] = base;
+        }
+    }
+    __syncthreads();
+    const uint64_t base = L.bcast[3], end = base + size;
+    const bool store_ok = end <= P.capacity;
+    if (blk == F.n_blocks - 1 && tid == 0) {
+        P.out_offsets[P.n_sent] = end;
+        if (end > P.capacity) err |= kErrOutputTooSmall;
+        if (F.total_out) *F.total_out = end;
+    }
+    if (!sane) {
+        if (mine) P.out_offsets[i0 + tid] = base;
+        if (err) atomicOr(P.status, err);
+        return;
+    }
+
+    // ---- the pieces: every byte of the run to its place
+    uint8_t* const sbytes = reinterpret_cast<uint8_t*>(L.stage);
+    const uintptr_t my_start = reinterpret_cast<uintptr_t>(P.text) + my_b;
+    uint64_t at_out = base, cb = 0, sb = 0;   // output position, chars and sentence starts of the run in front of the piece
+    bool fits = true;
+    for (uintptr_t piece = t_lo & ~uintptr_t(15); piece < t_hi; piece += kFlatPiece) {
+        const uintptr_t addr = piece + 16u * tid;
+        const uint32_t vm = in_range16(addr, t_lo, t_hi);
+        const uint4 x = vm ? *reinterpret_cast<const uint4*>(addr) : make_uint4(0, 0, 0, 0);
+        // the labels the piece's chars can ask for: label (O0 + cb - sb) onwards (every char but a sentence's first has one in front)
+        const uintptr_t lab_at = l_all + O0 + (cb - sb), lab_al = lab_at & ~uintptr_t(15);
+        const uint32_t lab_head = uint32_t(lab_at - lab_al);
+        {
+            const uintptr_t a = lab_al + 16u * tid, a2 = lab_al + 16u * (uint32_t(kEmitThreads) + tid);
+            reinterpret_cast<uint4*>(L.labs)[tid] = (a + 16 > l_all && a < l_end) ? *reinterpret_cast<const uint4*>(a) : make_uint4(0, 0, 0, 0);
+            if (tid < 4) reinterpret_cast<uint4*>(L.labs)[kEmitThreads + tid] = (a2 + 16 > l_all && a2 < l_end) ? *reinterpret_cast<const uint4*>(a2) : make_uint4(0, 0, 0, 0);
+        }
+        if (mine && my_start >= piece && my_start - piece < kFlatPiece) {
+            const uint32_t r = uint32_t(my_start - piece);
+            atomicOr(&L.starts[r >> 5], 1u << (r & 31u));
+        }
+        __syncthreads();
+        uint32_t sm = (L.starts[tid >> 1] >> (16 * (tid & 1))) & 0xFFFFu;
+        const uint32_t lm = lead16(x) & vm, em = esc16(x) & vm;
+        if (sm & ~lm) err |= kErrBadOffsets;   // a sentence that starts inside a char (or outside the run)
+        sm &= lm;
+        const uint32_t nl = uint32_t(__popc(lm)), nst = uint32_t(__popc(sm));
+        uint32_t tot;
+        const uint32_t excl = flat_block_scan(nl | (nst << 16), L.wtot, lane, wave, &tot);   // (its barriers: every thread has read its starts)
+        if (tid < kFlatPiece / 32) L.starts[tid] = 0;
+        const uint32_t c_in = excl & 0xFFFFu, s_in = excl >> 16;   // chars / starts of the piece in front of this thread
+        // the thread's chars that have a label in front take consecutive labels from (c_in - s_in) of the window on
+        const uint32_t nm = lm & ~sm;
+        uint32_t spm = 0;
+        {
+            const uint32_t loff = lab_head + (c_in - s_in);           // byte offset in labs: <= 15 + 4096
+            const uint32_t d = loff >> 2, r = loff & 3u;
+            uint4 y;
+            y.x = __builtin_amdgcn_alignbyte(L.labs[d + 1], L.labs[d], r); y.y = __builtin_amdgcn_alignbyte(L.labs[d + 2], L.labs[d + 1], r);
+            y.z = __builtin_amdgcn_alignbyte(L.labs[d + 3], L.labs[d + 2], r); y.w = __builtin_amdgcn_alignbyte(L.labs[d + 4], L.labs[d + 3], r);
+            uint32_t bits = one16(y), rem = nm;
+            while (rem) {   // label q of the thread onto its q-th labelled char
+                const uint32_t low = rem & (0u - rem);
+                if (bits & 1u) spm |= low;
+                bits >>= 1;
+                rem &= rem - 1u;
+            }
+        }
+        const uint32_t t = uint32_t(__popc(vm)) + uint32_t(__popc(spm)) + uint32_t(__popc(em));
+        uint32_t total;
+        const uint32_t w = flat_block_scan(t, L.wtot, lane, wave, &total);
+        if (at_out + total > end) { fits = false; break; }   // (the same in every thread)
+        uint8_t* const dst = P.out_text + at_out;
+        const uint32_t head = uint32_t(reinterpret_cast<uintptr_t>(dst) & 15u);
+        if (store_ok) {   // the thread's bytes in order: [' '] ['\\'] byte.  No branches: what is not there goes to a slot of the thread's own
+            uint8_t* const o = sbytes + head;
+            uint8_t* const dump = reinterpret_cast<uint8_t*>(L.dump + tid);
+            uint32_t pos = w;
+#pragma unroll
+            for (uint32_t k = 0; k < 16; ++k) {
+                const uint32_t v = (vm >> k) & 1u, sp = (spm >> k) & 1u, es = (em >> k) & 1u;
+                *(sp ? o + pos : dump) = 0x20u; pos += sp;
+                *(es ? o + pos : dump) = 0x5Cu; pos += es;
+                *(v ? o + pos : dump) = uint8_t(byte_of(x, k)); pos += v;
+            }
+        }
+        uint32_t rem = sm;   // the sentences that start in the thread's bytes (few threads, one as a rule)
+        while (rem) {
+            const uint32_t k = uint32_t(__ffs(int(rem))) - 1u, below = (1u << k) - 1u;
+            rem &= rem - 1u;
+            const uint64_t s = sb + s_in + uint32_t(__popc(sm & below));
+            if (s < ns) {
+                P.out_offsets[i0 + s] = at_out + w + uint32_t(__popc(vm & below)) + uint32_t(__popc(spm & below)) + uint32_t(__popc(em & below));
+                if (cb + c_in + uint32_t(__popc(lm & below)) != uint64_t(L.so[s]) + s) err |= kErrBadOffsets;   // not the char its offset names
+            } else err |= kErrBadOffsets;
+        }
+        __syncthreads();
+        if (store_ok) {   // LDS byte j is output byte j - head: whole 16-byte chunks leave aligned, the two edges byte by byte
+            uint8_t* const abase = dst - head;
+            const uint32_t nd = (head + total + 15u) >> 4;
+            for (uint32_t d = tid; d < nd; d += kEmitThreads) {
+                const uint32_t lo = d * 16u, hi = lo + 16u;
+                if (lo >= head && hi <= head + total) {
+                    *reinterpret_cast<uint4*>(abase + lo) = reinterpret_cast<const uint4*>(L.stage)[d];
+                } else {
+                    const uint32_t a = lo > head ? lo : head, b = hi < head + total ? hi : head + total;
+                    for (uint32_t j = a; j < b; ++j) abase[j] = sbytes[j];
+                }
+            }
+        }
+        __syncthreads();   // the next piece rewrites stage / labs / starts
+        at_out += total;
+        cb += tot & 0xFFFFu;
+        sb += tot >> 16;
+    }
+    // (what was written is what the size pass said: anything else means chars, labels and offsets do not belong together)
+    if (!fits || at_out != end || cb != (O1 - O0) + ns || sb != ns) err |= kErrBadOffsets;
+    if (err) atomicOr(P.status, err);
+}
+
 // vpt_count_boundaries on the device: chars - 1 of every sentence -> offsets[i + 1] (the scan follows), the same
 // validation as Sentence::from_raw (sentence.rs:160-196), the longest sentence (in chars) -> *max_chars.
 //
@@ -672,6 +911,10 @@ hipError_t launch_count_boundaries(const uint8_t* text, const uint64_t* boff, ui
 }
 
 hipError_t launch_emit_tokenized(const EmitParams& P, const EmitFuse& F, hipStream_t stream) {
+    if (F.flat) {   // (no tags, no timing ablations: capi.cpp) a workgroup per run of sentences
+        hipLaunchKernelGGL(emit_flat_kernel, dim3(uint32_t(F.n_blocks)), dim3(kEmitThreads), 0, stream, P, F);
+        return hipGetLastError();
+    }
     const dim3 grid(uint32_t((F.n_blocks + kEmitWaves - 1) / kEmitWaves));
     if (F.dbg) {
         if (P.tags) hipLaunchKernelGGL((emit_fused_kernel<true, true>), grid, dim3(kEmitThreads), 0, stream, P, F);
