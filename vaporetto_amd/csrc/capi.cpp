@@ -64,7 +64,8 @@ struct BatchKnobs {
     uint32_t tag_queue = 0;             // VPT_TAG_QUEUE: entries of that queue (tests: overflow; default: an eighth of the batch's chars + 64 K)
     uint32_t debug_emit = 0;            // VPT_DEBUG_EMIT
     uint32_t emit_per_block = 0;        // VPT_EMIT_PER_BLOCK: sentences a wave / a workgroup of the writer takes (1..64 / 1..256; 0: from the mean sentence length)
-    bool emit_wave_blocks = false;      // VPT_EMIT_WAVE_BLOCKS: the untagged writer as a wave per block too (A/B of the workgroup-per-run kernel)
+    bool emit_wave_blocks = false;      // VPT_EMIT_WAVE_BLOCKS: the writer as a wave per block (A/B of the workgroup-per-run kernel)
+    bool emit_wave_tagged = false;      // VPT_EMIT_WAVE_TAGGED: ... with tags only
     uint32_t emit_run_chars = 0;        // VPT_EMIT_RUN_CHARS: chars of a workgroup's run (default 5120)
 };
 PredictorKnobs read_predictor_knobs() {
@@ -91,6 +92,7 @@ BatchKnobs read_batch_knobs() {
     if (const char* v = std::getenv("VPT_DEBUG_EMIT")) k.debug_emit = uint32_t(std::max(0, std::atoi(v)));
     if (const char* v = std::getenv("VPT_EMIT_PER_BLOCK")) k.emit_per_block = uint32_t(std::min(256, std::max(0, std::atoi(v))));
     k.emit_wave_blocks = std::getenv("VPT_EMIT_WAVE_BLOCKS") != nullptr;
+    k.emit_wave_tagged = std::getenv("VPT_EMIT_WAVE_TAGGED") != nullptr;
     if (const char* v = std::getenv("VPT_EMIT_RUN_CHARS")) k.emit_run_chars = uint32_t(std::max(0, std::atoi(v)));
     k.no_cps_from_predict = std::getenv("VPT_NO_CPS_FROM_PREDICT") != nullptr;
     if (const char* v = std::getenv("VPT_DEBUG_ABLATE")) k.debug_ablate = uint32_t(std::atoi(v));
@@ -1634,8 +1636,12 @@ vpt_status emit_device(const vpt_predictor* p, vpt_batch* b, const uint8_t* d_ut
     vpt::EmitFuse F{};
     {
         const uint64_t chars = total_boundaries + n_sentences;
-        F.flat = (!E.tags && !b->knobs.debug_emit && !b->knobs.emit_wave_blocks) ? 1u : 0u;
-        const uint64_t target = F.flat ? (b->knobs.emit_run_chars ? b->knobs.emit_run_chars : 5120) : 2048;
+        F.flat = (!b->knobs.debug_emit && !b->knobs.emit_wave_blocks && !(E.tags && b->knobs.emit_wave_tagged)) ? 1u : 0u;
+        // a run: 5 K chars when the batch is small (the chip wants a thousand workgroups and more), up to 20 K on a big one -- fewer look-backs and
+        // size passes per byte (measured, profiles/r05_h_*, r05_k_*: configs[1] 5 K 0.057 ms / 10 K 0.060 / 20 K 0.068; configs[2] 2.56 / 2.28 / 2.15;
+        // tagged configs[4] 2.39 / 2.10 / 2.04)
+        const uint64_t auto_run = std::min<uint64_t>(std::max<uint64_t>(chars / (uint64_t(16) * std::max<uint32_t>(p->n_cus, 64)), 5120), 20480);
+        const uint64_t target = F.flat ? (b->knobs.emit_run_chars ? b->knobs.emit_run_chars : auto_run) : 2048;
         const uint64_t per = (target * n_sentences + chars / 2) / chars;   // round(target / mean chars per sentence)
         F.per_block = uint32_t(std::min<uint64_t>(std::max<uint64_t>(per, 1), F.flat ? vpt::kEmitFlatMaxBlock : vpt::kEmitFuseMaxBlock));
         if (b->knobs.emit_per_block) F.per_block = std::min<uint32_t>(b->knobs.emit_per_block, F.flat ? vpt::kEmitFlatMaxBlock : vpt::kEmitFuseMaxBlock);

@@ -595,6 +595,7 @@ __device__ __forceinline__ uint32_t flat_block_scan(uint32_t x, uint32_t* wtot, 
     return woff + incl - x;
 }
 
+template <bool kTags>
 __global__ __launch_bounds__(kEmitThreads) void emit_flat_kernel(const EmitParams P, const EmitFuse F) {
     __shared__ FlatLds L;
     // the other array of state words, for the call after this one
@@ -647,6 +648,16 @@ __global__ __launch_bounds__(kEmitThreads) void emit_flat_kernel(const EmitParam
             const uint32_t m = in_range16(a, l_lo, l_hi);
             added += uint32_t(__popc(one16(y) & m));
             if (unk16(y) & m) err |= kErrUnknownLabel;
+        }
+        if (kTags) {   // the bytes of the run's tag suffixes: fill_tags left them in the token word of every token's last char (layout.h)
+            const uint64_t g0 = O0 + i0, n_chars = (O1 - O0) + ns;
+            for (uint64_t c0 = 4 * uint64_t(tid); c0 < n_chars; c0 += 4 * kEmitThreads) {
+                int32_t m4[4];
+                __builtin_memcpy(m4, P.tok_model + g0 + c0, sizeof(m4));   // (the array goes on behind the batch's last char)
+#pragma unroll
+                for (uint32_t q = 0; q < 4; ++q)
+                    if (c0 + q < n_chars) added += tag_suffix_bytes(P, g0 + c0 + q, uint32_t(m4[q]));
+            }
         }
         const uint64_t ws = wave_sum64(added);
         if (lane == 0) L.red[wave] = ws;
@@ -739,36 +750,118 @@ __global__ __launch_bounds__(kEmitThreads) void emit_flat_kernel(const EmitParam
                 rem &= rem - 1u;
             }
         }
-        const uint32_t t = uint32_t(__popc(vm)) + uint32_t(__popc(spm)) + uint32_t(__popc(em));
+        // Tag suffixes go in front of a space and in front of a sentence's first byte (the last token of the sentence before it), except
+        // the run's first (the run before this one wrote that one behind its last byte).  The thread that holds the byte in FRONT of which
+        // a suffix goes owns it; at most two per thread are carried in registers (tk: the byte, tl: the length, tc: the token's last
+        // char), a third sends the thread's WAVE through its chars one by one (emit_fused_kernel's scheme).
+        uint32_t tmask = 0, tk1 = 16, tl1 = 0, tk2 = 16, tl2 = 0, tc1 = 0, tc2 = 0;
+        int32_t tm1 = 0, tm2 = 0;
+        bool many = false;
+        const uint64_t g_first = O0 + i0 + cb + c_in;     // batch-flat index of the thread's first char
+        if (kTags) {
+            tmask = spm | sm;
+            if (sb + s_in == 0 && sm) tmask &= ~(sm & (0u - sm));
+            if (tmask) {
+                // the tag models of the chars in front of the thread's chars: tok_model[g_first - 1 + j] for its j-th char (the array has
+                // zeros in front of the batch's first char and behind its last: capi.cpp); which of them are there at all
+                const int32_t* tmod = P.tok_model + g_first - 1;
+                uint32_t pm = 0;
+                for (uint32_t j0 = 0; j0 < nl; j0 += 4) {
+                    int32_t m4[4];
+                    __builtin_memcpy(m4, tmod + j0, sizeof(m4));
+                    pm |= (((uint32_t(m4[0]) & kTokModelMask) ? 1u : 0u) | ((uint32_t(m4[1]) & kTokModelMask) ? 2u : 0u) | ((uint32_t(m4[2]) & kTokModelMask) ? 4u : 0u) |
+                           ((uint32_t(m4[3]) & kTokModelMask) ? 8u : 0u)) << j0;
+                }
+                pm &= (1u << nl) - 1u;
+                while (pm) {   // few
+                    const uint32_t j = uint32_t(__ffs(int(pm))) - 1u;
+                    pm &= pm - 1u;
+                    uint32_t remj = lm;
+                    for (uint32_t q = 0; q < j; ++q) remj &= remj - 1u;
+                    const uint32_t k = uint32_t(__ffs(int(remj))) - 1u;          // the byte of the thread's j-th char
+                    if (!((tmask >> k) & 1u)) continue;                          // no token ends in front of it
+                    const uint32_t word = uint32_t(tmod[j]);
+                    const int32_t mdl = int32_t(word & kTokModelMask);
+                    const uint32_t len = tag_suffix_bytes(P, g_first + j - 1u, word);   // (carried from fill_tags)
+                    if (!len) continue;
+                    if (tk1 == 16) { tk1 = k; tl1 = len; tc1 = j; tm1 = mdl; }
+                    else if (tk2 == 16) { tk2 = k; tl2 = len; tc2 = j; tm2 = mdl; }
+                    else many = true;
+                }
+            }
+        }
+        const bool slow = kTags && __ballot(many) != 0;        // (wave-uniform)
+        uint32_t sfx_total = tl1 + tl2;
+        if (slow) {
+            sfx_total = 0;
+            uint32_t todo = tmask;
+            while (todo) {
+                const uint32_t low = todo & (0u - todo);
+                todo &= todo - 1u;
+                sfx_total += tag_suffix(P, g_first + uint32_t(__popc(lm & (low - 1u))) - 1u, nullptr);
+            }
+        }
+        const uint32_t t = uint32_t(__popc(vm)) + uint32_t(__popc(spm)) + uint32_t(__popc(em)) + sfx_total;
         uint32_t total;
         const uint32_t w = flat_block_scan(t, L.wtot, lane, wave, &total);
         if (at_out + total > end) { fits = false; break; }   // (the same in every thread)
         uint8_t* const dst = P.out_text + at_out;
         const uint32_t head = uint32_t(reinterpret_cast<uintptr_t>(dst) & 15u);
-        if (store_ok) {   // the thread's bytes in order: [' '] ['\\'] byte.  No branches: what is not there goes to a slot of the thread's own
-            uint8_t* const o = sbytes + head;
-            uint8_t* const dump = reinterpret_cast<uint8_t*>(L.dump + tid);
-            uint32_t pos = w;
+        const bool staged = !kTags || head + total <= kFlatStageBytes;   // (the same in every thread) else: byte stores straight to the output
+        if (!slow) {
+            if (store_ok) {   // the thread's bytes in order: [tags] [' '] ['\\'] byte.  No branches: what is not there goes to a slot of the thread's own
+                uint8_t* const o = !kTags || staged ? sbytes + head : dst + 0;   // (with tags: a generic pointer)
+                uint8_t* const dump = reinterpret_cast<uint8_t*>(L.dump + tid);
+                uint32_t pos = w;
 #pragma unroll
+                for (uint32_t k = 0; k < 16; ++k) {
+                    const uint32_t v = (vm >> k) & 1u, sp = (spm >> k) & 1u, es = (em >> k) & 1u;
+                    if (kTags) pos += (k == tk1 ? tl1 : 0u) + (k == tk2 ? tl2 : 0u);
+                    *(sp ? o + pos : dump) = 0x20u; pos += sp;
+                    *(es ? o + pos : dump) = 0x5Cu; pos += es;
+                    *(v ? o + pos : dump) = uint8_t(byte_of(x, k)); pos += v;
+                }
+                if (kTags && tl1) {   // the tags themselves (few threads)
+                    const uint32_t b1 = (1u << tk1) - 1u, b2 = (1u << tk2) - 1u;
+                    if (tag_suffix_of(P, g_first + tc1 - 1u, tm1, o + w + uint32_t(__popc(vm & b1)) + uint32_t(__popc(spm & b1)) + uint32_t(__popc(em & b1)), tl1) != tl1) err |= kErrBadOffsets;
+                    if (tl2 && tag_suffix_of(P, g_first + tc2 - 1u, tm2, o + w + tl1 + uint32_t(__popc(vm & b2)) + uint32_t(__popc(spm & b2)) + uint32_t(__popc(em & b2)), tl2) != tl2) err |= kErrBadOffsets;
+                }
+            }
+            uint32_t rem = sm;   // the sentences that start in the thread's bytes (few threads, one as a rule)
+            while (rem) {
+                const uint32_t k = uint32_t(__ffs(int(rem))) - 1u, below = (1u << k) - 1u;
+                rem &= rem - 1u;
+                const uint64_t s = sb + s_in + uint32_t(__popc(sm & below));
+                if (s < ns) {
+                    P.out_offsets[i0 + s] = at_out + w + uint32_t(__popc(vm & below)) + uint32_t(__popc(spm & below)) + uint32_t(__popc(em & below)) +
+                                            (kTags ? (tk1 <= k ? tl1 : 0u) + (tk2 <= k ? tl2 : 0u) : 0u);
+                    if (cb + c_in + uint32_t(__popc(lm & below)) != uint64_t(L.so[s]) + s) err |= kErrBadOffsets;   // not the char its offset names
+                } else err |= kErrBadOffsets;
+            }
+        } else {
+            // [tags] [' '] | sentence offset | ['\\'] byte, char by char (o: LDS or the output itself)
+            uint8_t* const o = !store_ok ? nullptr : staged ? sbytes + head : dst + 0;
+            uint32_t pos = w, ci = 0;
+#pragma unroll 1
             for (uint32_t k = 0; k < 16; ++k) {
-                const uint32_t v = (vm >> k) & 1u, sp = (spm >> k) & 1u, es = (em >> k) & 1u;
-                *(sp ? o + pos : dump) = 0x20u; pos += sp;
-                *(es ? o + pos : dump) = 0x5Cu; pos += es;
-                *(v ? o + pos : dump) = uint8_t(byte_of(x, k)); pos += v;
+                if (!((vm >> k) & 1u)) continue;
+                if ((tmask >> k) & 1u) pos += tag_suffix(P, g_first + ci - 1u, o ? o + pos : nullptr);
+                if ((spm >> k) & 1u) { if (o) o[pos] = 0x20u; ++pos; }
+                if ((sm >> k) & 1u) {
+                    const uint64_t s = sb + s_in + uint32_t(__popc(sm & ((1u << k) - 1u)));
+                    if (s < ns) {
+                        P.out_offsets[i0 + s] = at_out + pos;
+                        if (cb + c_in + ci != uint64_t(L.so[s]) + s) err |= kErrBadOffsets;
+                    } else err |= kErrBadOffsets;
+                }
+                if ((em >> k) & 1u) { if (o) o[pos] = 0x5Cu; ++pos; }
+                if (o) o[pos] = uint8_t(byte_of_rt(x, k));
+                ++pos;
+                ci += (lm >> k) & 1u;
             }
         }
-        uint32_t rem = sm;   // the sentences that start in the thread's bytes (few threads, one as a rule)
-        while (rem) {
-            const uint32_t k = uint32_t(__ffs(int(rem))) - 1u, below = (1u << k) - 1u;
-            rem &= rem - 1u;
-            const uint64_t s = sb + s_in + uint32_t(__popc(sm & below));
-            if (s < ns) {
-                P.out_offsets[i0 + s] = at_out + w + uint32_t(__popc(vm & below)) + uint32_t(__popc(spm & below)) + uint32_t(__popc(em & below));
-                if (cb + c_in + uint32_t(__popc(lm & below)) != uint64_t(L.so[s]) + s) err |= kErrBadOffsets;   // not the char its offset names
-            } else err |= kErrBadOffsets;
-        }
         __syncthreads();
-        if (store_ok) {   // LDS byte j is output byte j - head: whole 16-byte chunks leave aligned, the two edges byte by byte
+        if (store_ok && staged) {   // LDS byte j is output byte j - head: whole 16-byte chunks leave aligned, the two edges byte by byte
             uint8_t* const abase = dst - head;
             const uint32_t nd = (head + total + 15u) >> 4;
             for (uint32_t d = tid; d < nd; d += kEmitThreads) {
@@ -786,7 +879,14 @@ __global__ __launch_bounds__(kEmitThreads) void emit_flat_kernel(const EmitParam
         cb += tot & 0xFFFFu;
         sb += tot >> 16;
     }
-    // (what was written is what the size pass said: anything else means chars, labels and offsets do not belong together)
+    if (kTags && fits) {   // the tags of the run's last token
+        const uint64_t g_last = O1 + i0 + ns - 1;
+        const uint32_t sl = tag_suffix(P, g_last, nullptr);   // (every thread computes the same)
+        if (sl && store_ok && at_out + sl <= end && tid == 0) tag_suffix(P, g_last, P.out_text + at_out);
+        at_out += sl;
+    }
+    // (what was written is what the size pass said: anything else means chars, labels, offsets -- or the tags' token words and the labels,
+    // which must be the ones fill_tags saw -- do not belong together)
     if (!fits || at_out != end || cb != (O1 - O0) + ns || sb != ns) err |= kErrBadOffsets;
     if (err) atomicOr(P.status, err);
 }
@@ -911,8 +1011,9 @@ hipError_t launch_count_boundaries(const uint8_t* text, const uint64_t* boff, ui
 }
 
 hipError_t launch_emit_tokenized(const EmitParams& P, const EmitFuse& F, hipStream_t stream) {
-    if (F.flat) {   // (no tags, no timing ablations: capi.cpp) a workgroup per run of sentences
-        hipLaunchKernelGGL(emit_flat_kernel, dim3(uint32_t(F.n_blocks)), dim3(kEmitThreads), 0, stream, P, F);
+    if (F.flat) {   // (no timing ablations: capi.cpp) a workgroup per run of sentences
+        if (P.tags) hipLaunchKernelGGL(emit_flat_kernel<true>, dim3(uint32_t(F.n_blocks)), dim3(kEmitThreads), 0, stream, P, F);
+        else hipLaunchKernelGGL(emit_flat_kernel<false>, dim3(uint32_t(F.n_blocks)), dim3(kEmitThreads), 0, stream, P, F);
         return hipGetLastError();
     }
     const dim3 grid(uint32_t((F.n_blocks + kEmitWaves - 1) / kEmitWaves));
