@@ -37,7 +37,7 @@ with open(os.path.join(out,"summary.txt"),"w") as w:
         w.write("== kernel stats (%s)\n" % os.path.basename(f)); w.write(open(f).read()+"\n")
     w.write("== PMC per-dispatch averages\n")
     for k,v in agg.items():
-        if not any(x in k for x in ("score", "tag_tokens", "decode_chars", "emit", "count")): continue
+        if not any(x in k for x in ("score", "tag_tokens", "tag_front", "tag_pass", "decode_chars", "emit", "count", "cut_", "assign_tiles")): continue
         for c,vals in sorted(v.items()):
             w.write("%-98s %-34s n=%d avg=%.1f\n" % (k,c,len(vals),sum(vals)/len(vals)))
     if os.path.exists(os.path.join(out,"failed.txt")):
