@@ -164,7 +164,11 @@ int tc_score(const tc_model* t, const uint32_t* cps, size_t n, int32_t* y_out, u
             const uint32_t* w = ch + pk_tri_w_dw(wl);
             for (int j = 0; j < nt; ++j) add(y, S - wl + 2 + j, (j & 1) ? hi16(w[j >> 1]) : lo16(w[j >> 1]));
         }
-        uint32_t ref = ch[pk_tri_kids_dw(wl)], depth = 3;
+        uint32_t ref = ch[pk_tri_kids_dw(wl)] & kTriKidsRefMask, depth = 3;
+        if (ref != 0) {   // the node's child filter (layout.h, "tri"), as the kernel applies it
+            const uint32_t c4 = sym[s + 3 < n ? s + 3 : n];
+            if (c4 == 0 || c4 == kNoId || !((tri_kid_filter(ch[0], ch[pk_tri_kids_dw(wl)]) >> packed_kid_filter_bit(c4)) & 1u)) ref = 0;
+        }
         while (ref != 0) {
             const size_t at = s + depth;
             const uint32_t c = sym[at < n ? at : n];

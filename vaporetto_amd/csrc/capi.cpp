@@ -122,7 +122,7 @@ struct TableGeom {
     int32_t window, lo[3], len[3];
 };
 constexpr char kCompiledMagic[16] = "VaporettoHIP-C\x01";   // 15 chars + NUL
-constexpr uint32_t kCompiledVersion = 11;                    // bump whenever layout.h or a kernel's reading of it changes
+constexpr uint32_t kCompiledVersion = 12;                    // bump whenever layout.h or a kernel's reading of it changes
 struct PredictorMeta {                                      // plain data: written and read as is (little-endian hosts)
     char magic[16];
     uint32_t version, meta_bytes;

@@ -722,7 +722,13 @@ __global__ __launch_bounds__(kThreads, fast_wg(WL)) void score_tiles_fast_kernel
                 }
             }
             if (hit && (td[0] & (kPkWide << kTriFlagShift))) wide_kinds |= kWideTri;
-            uint32_t kids = hit ? td[pk_tri_kids_dw(WL)] : 0u;
+            // the node's kids, unless its child filter says that the char behind the trigram is none of them (layout.h, "tri": the queued trie
+            // step that this saves is two 64-byte entry reads)
+            uint32_t kids = 0;
+            if (hit && (td[pk_tri_kids_dw(WL)] & kTriKidsRefMask) != 0) {
+                const uint32_t c4 = L.sym[s_t + 3] & kCpMask;   // (zero past the tile; s_t + 3 < kSymSlots)
+                if (uint32_t(c4 - 1u) < kNoId - 1u && ((tri_kid_filter(td[0], td[pk_tri_kids_dw(WL)]) >> packed_kid_filter_bit(c4)) & 1u)) kids = td[pk_tri_kids_dw(WL)] & kTriKidsRefMask;
+            }
             VPT_PIN(kids);
             drain_w<WL>(P, K, L, Q, lane, kQHigh, prof);           // room for one more round of pushes
             Q.push_w(kids != 0 && !(dbg & 8u), s_t | (3u << 11), kids);

@@ -66,7 +66,10 @@
 //            wl > 3: dword 0 key, 1 B2, 2..3 filter, 4.. row  (the first 16 bytes decide, the rest is the row)
 //   tri    trigram nodes of pk_tri_dw(wl) dwords: (slot of the parent bigram node + 1) | cflags << 28 (0 = free; cflags: kPkWide),
 //          2 wl - 2 weights of 16 bits (boundaries s-wl+2 .. s+wl-1), `kids`: mini-table ref of its depth-4 children in `deep`
-//          (0: none).  A node = a 3-char pattern and/or the 3-char prefix of longer ones.
+//          (0: none) in the low 27 bits.  A node = a 3-char pattern and/or the 3-char prefix of longer ones.  An 8-bit FILTER over
+//          packed_kid_filter_bit(id) of those children (round 5) sits in what the two words leave free -- bits 27..31 of `kids`, bits 28..30
+//          of dword 0 --: most trigram prefixes have a child or two, the char behind most trigrams in a text is none of them, and a trie step
+//          that the filter turns away costs the kernel nothing where a queued one costs two 64-byte entry reads.
 //            wl = 3: dword 0 parent, 1..2 weights, 3 kids          wl > 3: dword 0 parent, 1 kids, 2.. weights
 //   deep   64-byte entries for the trie below depth 3.  An entry stands for a child symbol PLUS the chain of up to 8
 //          further symbols that must follow it (nodes with a single child and no row of their own are compressed
@@ -131,6 +134,8 @@ constexpr int kBiFieldBits = 19;               // bigram node: 2 wl - 1 fields
 constexpr int kUniBaseBits = 19;
 constexpr uint32_t kUniBaseMask = 0x7FFFFu;    // B1 of a unigram node: 19 bits behind its fields, the wide flag behind that
 constexpr uint32_t kTriParentMask = 0x0FFFFFFFu, kTriFlagShift = 28;   // dword 0 of a trigram node: parent slot + 1; cflags above
+constexpr uint32_t kTriKidsRefMask = 0x07FFFFFFu;                     // its kids word: the mini-table ref (base < 2^22); above it 5 bits of the child filter
+constexpr uint32_t kTriKidsMaxBase = 1u << 22;
 constexpr uint32_t kCinfoLinebreak = 1u << 29; // cid word: the (scored) char is '\n' or '\r' (where the kernel's symbol word keeps it)
 
 #if defined(__HIPCC__)
@@ -172,6 +177,9 @@ VPT_HD uint32_t packed_filter_bit(uint32_t sym) { return (mul_u16(sym & 0xFFFFu,
 VPT_HD uint32_t packed_mini_slot(uint32_t sym, uint32_t ref) { return (mul_u16(sym & 0xFFFFu, 0x9E3779u) & 0xFFFFFFu) >> (24u - (ref & 31u)); }   // mini-tables have at most 2^17 entries
 VPT_HD uint32_t packed_filter_bit(uint32_t sym) { return (mul_u16(sym & 0xFFFFu, 0x9E3779u) >> 18) & 63u; }   // 0..63
 #endif
+// the child filter of a trigram node (header comment, "tri"): 8 bits, bits 0..4 above the kids ref, bits 5..7 in dword 0's bits 28..30
+VPT_HD uint32_t packed_kid_filter_bit(uint32_t sym) { return (mul_u16(sym & 0xFFFFu, 0x9E3779u) >> 21) & 7u; }   // 0..7
+VPT_HD uint32_t tri_kid_filter(uint32_t dword0, uint32_t kids_word) { return (kids_word >> 27) | (((dword0 >> 28) & 7u) << 5); }
 // the alphabet outside the BMP (header comment, "xcid"): `tab` = the section's first dword
 VPT_HD uint32_t xcid_slot(uint32_t cp, uint32_t bits) { return (cp * kHashMulLo) >> (32u - bits); }   // bits in 1..31
 VPT_HD uint32_t xcid_find(const uint32_t* tab, uint32_t cp) {

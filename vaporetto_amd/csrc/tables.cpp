@@ -625,8 +625,12 @@ HostPackedTable build_packed(const PatSet& S_in, int wl) {
                 const int32_t* w = S.row(*k.pat);
                 for (int q = 0; q < nt; q += 2) e[pk_tri_w_dw(wl) + q / 2] = pack16(w[q], w[q + 1]);
             }
-            e[0] = (pf.slot + 1) | (fl << kTriFlagShift);
-            e[pk_tri_kids_dw(wl)] = k.ref;
+            // the child filter (layout.h, "tri"): a mini-table entry is looked up by the FIRST symbol of a compressed chain, the child's own
+            uint32_t filt = 0;
+            for (uint32_t q = 0; q < n_kids(pkid[j]); ++q) filt |= 1u << packed_kid_filter_bit(nodes[kid(pkid[j], q)].sym);
+            if ((k.ref >> 5) >= kTriKidsMaxBase) throw ModelError("InvalidModelError: too many patterns for the packed tables");
+            e[0] = (pf.slot + 1) | (fl << kTriFlagShift) | ((filt >> 5) << 28);
+            e[pk_tri_kids_dw(wl)] = k.ref | ((filt & 31u) << 27);
             ++t.n_tri;
         }
         r[pk_bi_base_dw(wl)] = b2[pi]; r[pk_bi_filter_dw(wl)] = uint32_t(mask); r[pk_bi_filter_dw(wl) + 1] = uint32_t(mask >> 32);
