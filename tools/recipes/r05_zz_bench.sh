@@ -1,9 +1,9 @@
 # round 5, second half of the evidence run (after profiles/traffic.json holds the entries of r05_z): the whole bench, the dry runs of the scaling jobs
-O=gpurun_out/r05_zz; mkdir -p $O
+O=gpurun_out/r05_zz2; mkdir -p $O
 python bench.py --detail-out $O/bench_detail.json > $O/bench.json 2> $O/bench.err; tail -c 300 $O/bench.err; wc -c $O/bench.json
 python - <<'PY'
 import json
-l = json.loads(open("gpurun_out/r05_zz/bench.json").read().strip().splitlines()[-1])
+l = json.loads(open("gpurun_out/r05_zz2/bench.json").read().strip().splitlines()[-1])
 print(l["value"], l["roofline"]["frac"], l["roofline"]["traffic"], l["parity"])
 for w in l["workloads"]: print({k: w[k] for k in ("name", "value_G", "kernel_ms", "frac", "traffic_ratio", "parity", "emit_ms") if k in w})
 PY
