@@ -949,7 +949,18 @@ def main():
             raise SystemExit(0)
         raise SystemExit(run_in_process(args, "torch.distributed could not be used by the %d ranks the caller launched (%s)" % (R.world, R.dist_failed)))
     primary_id = args.config or 2          # ONE workload over the whole 1 -> 8 curve (module docstring)
-    prim = R.run(primary_id, primary=True, e2e_leg=(primary_id == 1))
+    try:
+        prim = R.run(primary_id, primary=True, e2e_leg=(primary_id == 1))
+    except Exception as e:   # noqa: BLE001
+        # A collective that fails AFTER the process group came up (a fabric error in the tables' broadcast, a rank that died: the others time out
+        # after 300 s) must not cost the line either: same way out as a failed init.  One rank alone (N = 1) has nothing to fall back to.
+        if R.world == 1 or os.environ.get("VPT_BENCH_NO_FALLBACK"):
+            raise
+        import traceback
+        sys.stderr.write("bench.py: rank %d: the %d-rank job failed: %s\n%s" % (R.rank, R.world, e, traceback.format_exc()))
+        if R.rank != 0:
+            raise SystemExit(0)
+        raise SystemExit(run_in_process(args, "the %d-rank torch.distributed job failed on rank 0: %s: %s" % (R.world, type(e).__name__, str(e).replace("\n", " ")[:200])))
     extra = []
     if not args.config and not args.quick and R.world == 1:
         for cid in (1, 3, 4, 5, 6, 7, 8):
