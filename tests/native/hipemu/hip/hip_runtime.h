@@ -43,6 +43,10 @@
 
 struct uint2 { uint32_t x, y; };
 struct uint4 { uint32_t x, y, z, w; } __attribute__((aligned(16)));
+struct int2 { int32_t x, y; } __attribute__((aligned(8)));
+struct int4 { int32_t x, y, z, w; } __attribute__((aligned(16)));
+static inline int2 make_int2(int32_t x, int32_t y) { return int2{x, y}; }
+static inline int4 make_int4(int32_t x, int32_t y, int32_t z, int32_t w) { return int4{x, y, z, w}; }
 static inline uint2 make_uint2(uint32_t x, uint32_t y) { return uint2{x, y}; }
 static inline uint4 make_uint4(uint32_t x, uint32_t y, uint32_t z, uint32_t w) { return uint4{x, y, z, w}; }
 struct dim3 {
@@ -156,6 +160,7 @@ template <typename T, typename V> static inline void __hip_atomic_store(T* p, V 
 #define __builtin_amdgcn_s_memtime() ::hipemu::clock()
 #define __builtin_amdgcn_s_sleep(n) ((void)0)
 #define __builtin_amdgcn_s_setprio(n) ((void)0)
+#define __builtin_amdgcn_sched_barrier(m) ((void)0)
 static inline uint32_t hipemu_mbcnt_lo(uint32_t mask, uint32_t base) {
     const unsigned l = ::hipemu::lane();
     return base + uint32_t(__builtin_popcount(l >= 32 ? mask : mask & ((1u << l) - 1u)));
@@ -174,3 +179,5 @@ static inline uint32_t hipemu_alignbit(uint32_t hi, uint32_t lo, uint32_t sh) {
 }
 #define __builtin_amdgcn_alignbyte(hi, lo, sh) hipemu_alignbyte((hi), (lo), (sh))
 #define __builtin_amdgcn_alignbit(hi, lo, sh) hipemu_alignbit((hi), (lo), (sh))
+// a wave-uniform 64-bit mask as a lane predicate (the mask goes to EXEC / VCC as it is)
+#define __builtin_amdgcn_inverse_ballot_w64(m) (((uint64_t(m) >> ::hipemu::lane()) & 1u) != 0)

@@ -1,0 +1,34 @@
+# round 5: the flat front end of fill_tags storing a full step's None entries unconditionally, behind the step's loads (t6u / t8u: 6 / 8 waves per SIMD; t6ur4 / t6ur8:
+# runs of 4 K / 8 K chars; WGS_PER_CU: the grid) against the same kernel storing them where no candidate is, at the step's end (t6) and the round-4 kernel (t0):
+# kernel stats of configs[4]'s step (rocprofv3 --kernel-trace --stats), then the tags of the built library against the oracle (bench parity + the GPU tag tests)
+O=gpurun_out/r05_v; mkdir -p $O; export TMPDIR=/tmp; REPO=$(pwd)
+cp vaporetto_amd/lib/libvaporetto_hip.so /tmp/lib_built.so
+one() {   # tag, library, env...
+  T=$1; V=$2; shift 2
+  cp tools/prebuilt/libvaporetto_$V.so vaporetto_amd/lib/libvaporetto_hip.so
+  (cd /tmp && env "$@" rocprofv3 --kernel-trace --stats --output-format csv -d $REPO/$O/trace_$T -- python $REPO/bench.py --config 4 --quick --steps 10 --warmup 2 --no-cpu-baseline --no-e2e --no-emit > $REPO/$O/trace_$T.log 2>&1)
+  python - "$T" $(find $O/trace_$T -name "*kernel_stats.csv") <<'PY' | tee -a $O/tag_kernel_stats.txt
+import csv, sys
+tag = sys.argv[1]
+for row in csv.DictReader(open(sys.argv[2])):
+    n = row["Name"]
+    if "tag_" in n or "emit_flat" in n:
+        print("%-8s %-44s calls %3s  avg %9.1f us" % (tag, n.replace("vpt::(anonymous namespace)::", "")[:44], row["Calls"], float(row["AverageNs"]) / 1e3))
+PY
+  rm -rf $O/trace_$T
+}
+one t0 t0 A=1
+one t6 t6 A=1
+one t6u t6u A=1
+one t8u t8u A=1
+one t6ur4 t6ur4 A=1
+one t6ur8 t6ur8 A=1
+one t6u_wg8 t6u VPT_TAG_WGS_PER_CU=8
+one t6u_wg16 t6u VPT_TAG_WGS_PER_CU=16
+one t6u_wg64 t6u VPT_TAG_WGS_PER_CU=64
+one t0b t0 A=1
+one t6ub t6u A=1
+cp /tmp/lib_built.so vaporetto_amd/lib/libvaporetto_hip.so
+python bench.py --config 4 --quick --steps 5 --warmup 2 --no-e2e > $O/bench_c4.json 2> $O/bench_c4.err; python -c "
+import json; l=json.loads(open('$O/bench_c4.json').read().strip().splitlines()[-1]); print('configs[4]', l['ms_per_step'], l['parity'], l['tags']['ms_per_step'], l['tags']['parity'], l['emit']['ms_per_step'], l['emit']['parity'])"
+timeout 600 python -m pytest tests/test_gpu_parity.py -m gpu -x -q -k "tag or fill or tokenize" 2>&1 | tail -3 | tee $O/pytest_tags.txt

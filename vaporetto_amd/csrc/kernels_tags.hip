@@ -58,7 +58,9 @@
 #include "device_common.h"
 #include "kernels.hpp"
 #include <algorithm>
+#include <type_traits>
 #include <cstdlib>
+#include <cstdio>
 
 namespace vpt {
 namespace {
@@ -205,8 +207,8 @@ struct TagWaveLds {
         } f;
     };
 };
-struct TagFrontLds {                         // what the step loop keeps per wave
-    uint32_t txt[kRing];
+struct alignas(16) TagFrontLds {             // what the step loop keeps per wave
+    uint32_t txt[kRing + 4];                 // (the flat front end keeps words 0 .. 2 once more at kRing ..: a token's first four chars are consecutive words)
     uint32_t cand[kTagCand][4];              // tokens the filter let through, waiting for the token table: flat index of the last char (2),
                                              // chars, chars before | after << 8 inside the sentence (clipped to the context)
 };
@@ -868,170 +870,328 @@ __global__ __launch_bounds__(kTagThreads, kSplit ? kTagFrontOcc : VPT_TAG_OCC) v
 // the chars that end one -- a sentence's last char ends a token (predictor.rs:563-570), the label of any other char q of sentence i is
 // labels[flat(q) - i], and a candidate's context stops at its sentence's ends.  The token logic (ends, Unknown, filter, candidates,
 // lookups, queue in HBM) is tag_tokens_kernel's, in run-relative positions.
-// 6 workgroups per CU: 78 VGPRs, nothing spilled (7: 72 + 5 spilled, 8: 64 + 12; the same 1.77 / 1.78 / 1.87 ms).
-__global__ __launch_bounds__(kTagThreads, 6) void tag_front_flat_kernel(const TagParams P, const uint32_t per) {
+//
+// Round 5: the same steps in fewer vector instructions (the kernel spent 358 of them per step, two thirds of its SIMDs' issue slots:
+// profiles/r05_z2_c4_summary.txt) --
+//   * every global access of a step is a wave-uniform pointer (advanced per step in scalar registers) plus a lane offset that does
+//     not change: no 64-bit address arithmetic in the lanes;
+//   * ONE bitmap of marks per step (sentence starts and the run's end; EM is SM shifted down by one), set by a scalar loop over the few
+//     window entries that fall into the step (LDS atomics only when there are more than six);
+//   * which token ends are valid (no Unknown label inside, predictor.rs:566-567) is scalar bit arithmetic: adding the positions just
+//     above the Unknown labels to the mask of unlabelled positions carries each one up to the next label -- the token ends reached
+//     that way are the tainted ones;
+//   * counts of mask bits below a lane through v_mbcnt, lane predicates straight from scalar masks;
+//   * the ring keeps its first three words again behind its end, so a token's first four chars are four consecutive LDS words;
+//   * a candidate's context clip from two funnel shifts over the bitmaps' words instead of four 64-bit scans;
+//   * the None entries of a char as ONE store for 1, 2 or 4 tags per token.
+#ifndef VPT_TAG_FLAT_OCC
+#define VPT_TAG_FLAT_OCC 6     // waves per SIMD the flat front end is compiled for (A/B builds: -D); 62 VGPRs either way, the scalar registers decide
+#endif
+#ifndef VPT_TAG_RUN_CHARS
+#define VPT_TAG_RUN_CHARS 2048 // chars of a run of sentences
+#endif
+// -DVPT_TAG_PROFILE (diagnostic builds, tools/build_variants.sh): where a wave of the flat front end spends its time -- shader-clock ticks per
+// part of a step, summed over the waves (printed by the NEXT launch: g_tag_prof is read back before it is cleared)
+#ifndef VPT_TAG_ABLATE
+#define VPT_TAG_ABLATE 0   // timing ablations of the flat front end (wrong results): 1 no filter loads, 2 no candidates, 4 no None stores, 8 no label loads, 16 no ring / keys, 32 filter words loaded but no candidates, 64 candidates queued but never looked up
+#endif
+#ifdef VPT_TAG_PROFILE
+__device__ unsigned long long g_tag_prof[16];
+#define VPT_TP_DECL unsigned long long tp_[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}; unsigned long long tp_t = __builtin_amdgcn_s_memtime(); const unsigned long long tp_t00 = tp_t
+#define VPT_TP(k) do { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); tp_[k] += t_ - tp_t; tp_t = t_; } while (0)
+#define VPT_TP_COUNT(k) (tp_[k] += 1)
+#define VPT_TP_FLUSH() do { tp_[11] = __builtin_amdgcn_s_memtime() - tp_t00; if (lane == 0) for (int k_ = 0; k_ < 12; ++k_) atomicAdd(&g_tag_prof[k_], tp_[k_]); } while (0)
+#else
+#define VPT_TP_DECL ((void)0)
+#define VPT_TP(k) ((void)0)
+#define VPT_TP_COUNT(k) ((void)0)
+#define VPT_TP_FLUSH() ((void)0)
+#endif
+__device__ __forceinline__ void read_tag_params(TagParams& Q, VPT_KARG(TagParams) R) { __builtin_memcpy(&Q, R, sizeof(Q)); }   // (for the lookups: the whole block)
+__device__ __forceinline__ uint32_t mask_bits_below_lane(uint64_t mask, uint32_t plus) {   // of a wave-uniform mask: v_mbcnt_lo / _hi
+    return __builtin_amdgcn_mbcnt_hi(uint32_t(mask >> 32), __builtin_amdgcn_mbcnt_lo(uint32_t(mask), plus));
+}
+// kFill = 1, 2, 4: the batch has a tok_model array, no model_out, and that many tags per token with an array aligned for one store of them --
+// then every char of a full step gets its None entries UNCONDITIONALLY, right behind the step's loads (a char whose token turns out to
+// have a tag model is written again by tag_pass_kernel, the launch behind this one; everything this kernel itself writes is a None entry,
+// so writing one twice changes nothing).  Why: the counter a wave waits on counts loads and stores alike, in order; entries stored at the
+// end of a step -- they depended on the filter words -- made the next step's wait for ITS filter words a wait for their write
+// acknowledgements as well, and that, not the instruction count, was most of a step's time.  Stores that depend on nothing sit between the
+// loads and the wait, with no branch for the wait to be merged over.  kFill = 0: anything else, entries stored where no candidate is.
+template <int kFill>
+__global__ __launch_bounds__(kTagThreads, VPT_TAG_FLAT_OCC) void tag_front_flat_kernel(const TagParams P_in, const uint32_t per) {
+    VPT_KARG(TagParams) P = VPT_KARG_PTR(TagParams, P_in);   // (read where it is used, like the scoring kernel's block: device_common.h)
     __shared__ TagKernelLds<true> LDS;
-    __shared__ uint32_t BITS[kTagWaves][8];   // per wave: SM (4 words), EM (4 words) of the step being prepared
-    const int lane = threadIdx.x & 63;
+    __shared__ uint32_t BITS[kTagWaves][8];   // per wave: the marks of the step being prepared, when there are many (5 words)
+    const uint32_t lane = threadIdx.x & 63;
     const uint32_t wid = wave_uniform(threadIdx.x >> 6);
     TagFrontLds& L = LDS.fr[wid];
     uint32_t* const bits = BITS[wid];
     const uint64_t wave = uint64_t(blockIdx.x) * kTagWaves + wid, n_waves = uint64_t(gridDim.x) * kTagWaves;
-    const uint32_t nt = P.n_tags;
-    const uint64_t below_me = (uint64_t(1) << lane) - 1, upto_me = below_me | (uint64_t(1) << lane);
-    const uint64_t total_b = P.total_chars - P.n_sent;   // labels of the batch
-    const uint64_t n_runs = (P.n_sent + per - 1) / per;
+    const uint32_t nt = P->n_tags;
+    const uint64_t below_me = (uint64_t(1) << lane) - 1;
+    const uint64_t total_b = P->total_chars - P->n_sent;   // labels of the batch
+    const uint64_t n_runs = (P->n_sent + per - 1) / per;
     uint32_t nq = 0, nc = 0;   // (queued tokens: unused by the front end), waiting candidates (wave-uniform)
+    VPT_TP_DECL;
     for (uint64_t run = wave; run < n_runs; run += n_waves) {
-        const uint64_t i_a = run * per, i_b = i_a + per < P.n_sent ? i_a + per : P.n_sent;
-        const uint64_t run0 = wave_uniform64(P.ooff[i_a]) + i_a, run1 = wave_uniform64(P.ooff[i_b]) + i_b;   // flat chars [run0, run1)
+        VPT_TP(0);
+        VPT_KARG_FENCE(P);
+        const uint64_t i_a = run * per, i_b = i_a + per < P->n_sent ? i_a + per : P->n_sent;
+        const uint64_t o_a = wave_uniform64(P->ooff[i_a]);
+        const uint64_t run0 = o_a + i_a, run1 = wave_uniform64(P->ooff[i_b]) + i_b;   // flat chars [run0, run1)
         // offsets that do not fit the batch are reported by decode_chars_kernel / the scoring kernel; such a run (and one of 2^31 chars:
         // not in this kernel's index width) is left alone
-        if (run1 < run0 || run1 > P.total_chars || run1 - run0 >= 0x7FFFFF00ull) continue;
-        const int n = int(run1 - run0);
-        const uint32_t* const cps = P.cps + run0;
+        if (run1 < run0 || run1 > P->total_chars || run1 - run0 >= 0x7FFFFF00ull) continue;
+        const uint32_t n = uint32_t(run1 - run0);
+        // the run's arrays (kept in scalar registers, or spilled to a lane: either is cheaper in a step than asking the constant cache again --
+        // a step is a chain of waits, not of instructions)
+        const uint32_t* const cps = P->cps + run0;
+        const uint8_t* const lab_run = P->labels + o_a;
+        int32_t* const tok_model = P->tok_model, * const model_out = P->model_out;
+        int32_t* const tm_run = tok_model + run0;   // (nullptr stays a pointer that is not used)
+        int32_t* const mo_run = model_out + run0;
+        int32_t* const tg_run = P->tags + run0 * nt;
+        const uint32_t tok_bits = P->tok_bits, fshift = 32u - tok_bits - kTagFilterLog2;
+        const uint32_t* const filt = P->tok_tab + (size_t(4) << tok_bits);
+        // the label of char q of the run, in sentence i_a + k: labels[o_a + q - k]; nothing past the batch's last label is read whatever
+        // the offsets say (d_max: the furthest q - k may go)
+        const bool labels_here = total_b != 0 && o_a < total_b;
+        const uint64_t d_max = labels_here ? total_b - 1 - o_a : 0;
         // ---- the run's sentence starts, run-relative, 64 at a time in the lanes: entry k of the window is sentence i_load + k; the entry of
-        // i_b is the run's end (it marks the last char's EM bit); entries past it are "never"
-        constexpr int kNever = 0x7FFFFFFF;
+        // i_b is the run's end; entries past it are "never"
+        constexpr uint32_t kNever = 0x7FFFFFFFu;
         uint64_t i_load = i_a;
-        auto load_window = [&]() -> int {
+        auto load_window = [&]() -> uint32_t {
             const uint64_t i = i_load + uint64_t(lane);
             if (i > i_b) return kNever;
-            const uint64_t f = P.ooff[i] + i;
-            return (f >= run0 && f <= run1) ? int(f - run0) : kNever;   // (offsets out of order: reported elsewhere; nothing is marked)
+            const uint64_t f = P->ooff[i] + i;
+            return (f >= run0 && f <= run1) ? uint32_t(f - run0) : kNever;   // (offsets out of order: reported elsewhere; nothing is marked)
         };
-        int win = load_window();
-        uint64_t sm_n[2], em_n[2];   // the bitmaps of the step that is being prepared
-        auto prepare = [&](int base) {   // SM / EM of the chars [base, base + 128)
-            if (lane < 8) bits[lane] = 0;
-            __builtin_amdgcn_wave_barrier();
+        uint32_t win = load_window();
+        // MARKS of the chars [base, base + 128]: a sentence starts there, or the run ends there.  (base + 128 is the next step's first
+        // char: its mark is the end of this step's last one.)
+        uint64_t mk0 = 0, mk1 = 0;
+        uint32_t mk2 = 0;
+        auto prepare = [&](uint32_t base) {
+            mk0 = 0; mk1 = 0; mk2 = 0;
             for (;;) {
-                if (win != kNever) {
-                    const int s = win - base, e = win - 1 - base;
-                    if (s >= 0 && s < 128 && i_load + uint64_t(lane) < i_b) atomicOr(&bits[s >> 5], 1u << (s & 31));
-                    if (e >= 0 && e < 128) atomicOr(&bits[4 + (e >> 5)], 1u << (e & 31));
+                const uint32_t d = win - base;   // an entry in front of the step, or "never": far above 128
+                uint64_t hit = __ballot(d <= 128u);
+                if (hit != 0) {
+                    if (__popcll(hit) <= 6) {
+                        do {
+                            const int k = __ffsll((long long)hit) - 1;
+                            hit &= hit - 1;
+                            const uint32_t dk = uint32_t(__builtin_amdgcn_readlane(int(d), k));
+                            if (dk < 64u) mk0 |= uint64_t(1) << dk;
+                            else if (dk < 128u) mk1 |= uint64_t(1) << (dk - 64u);
+                            else mk2 = 1u;
+                        } while (hit != 0);
+                    } else {
+                        if (lane < 5) bits[lane] = 0;
+                        __builtin_amdgcn_wave_barrier();
+                        if (d <= 128u) atomicOr(&bits[d >> 5], 1u << (d & 31u));
+                        __builtin_amdgcn_wave_barrier();
+                        mk0 |= uint64_t(wave_uniform(bits[0])) | (uint64_t(wave_uniform(bits[1])) << 32);
+                        mk1 |= uint64_t(wave_uniform(bits[2])) | (uint64_t(wave_uniform(bits[3])) << 32);
+                        mk2 |= wave_uniform(bits[4]) & 1u;
+                        __builtin_amdgcn_wave_barrier();
+                    }
                 }
                 // the window is used up when its last entry lies in front of the next step (an entry AT the next step's first char has
                 // marked the end in front of it here and marks its start there) -- as long as sentences are left
-                const int last = __builtin_amdgcn_readlane(win, 63);
-                if (last == kNever || last >= base + 128 || i_load + 64 > i_b) break;
+                const uint32_t last = uint32_t(__builtin_amdgcn_readlane(int(win), 63));
+                if (last == kNever || last >= base + 128u || i_load + 64 > i_b) break;
                 i_load += 64;
                 win = load_window();
             }
-            __builtin_amdgcn_wave_barrier();
-            sm_n[0] = uint64_t(wave_uniform(bits[0])) | (uint64_t(wave_uniform(bits[1])) << 32);
-            sm_n[1] = uint64_t(wave_uniform(bits[2])) | (uint64_t(wave_uniform(bits[3])) << 32);
-            em_n[0] = uint64_t(wave_uniform(bits[4])) | (uint64_t(wave_uniform(bits[5])) << 32);
-            em_n[1] = uint64_t(wave_uniform(bits[6])) | (uint64_t(wave_uniform(bits[7])) << 32);
-            __builtin_amdgcn_wave_barrier();
         };
-        uint32_t cs_n = 0;   // sentence starts of the run in front of the step being prepared
+        uint32_t cs = 0;   // marks of the run in front of the step being prepared (= sentence starts: the end's mark is the last one)
         uint32_t c_next[2], b_next[2];
-        auto fetch = [&](int base) {   // the prepared step's chars and labels (1 where a sentence ends, 0 past the run)
+        auto fetch = [&](uint32_t base) {   // the prepared step's chars and labels (1 where a sentence ends, 0 past the run)
+            // SM, the chars that start a sentence (and the run's end), are the marks; EM, the chars that end one, the marks one down
+            const uint64_t sm_n[2] = {mk0, mk1}, em_n[2] = {(mk0 >> 1) | (mk1 << 63), (mk1 >> 1) | (uint64_t(mk2) << 63)};
+            const uint32_t rem = n - base;
+            const uint32_t* const cstep = cps + base;
+            // char q of the step sits in sentence i_a + cs - 1 + (marks of the step at or in front of q): its label is
+            // labels[o_a + (base - cs) + q + 1 - those]
+            const uint64_t ahead = uint64_t(base - cs);   // (every mark in front of the step is a char in front of it: cs <= base)
+            const bool lab = labels_here && d_max >= ahead;
+            const uint64_t room = lab ? d_max - ahead : 0;
+            const uint32_t lim = room < 255u ? uint32_t(room) : 255u;
+            const uint8_t* const lstep = lab_run + ahead;
 #pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                const int q = base + 64 * h + lane;
-                const bool in_run = q < n;
-                const uint32_t before = cs_n + (h ? uint32_t(__popcll(sm_n[0])) : 0u);
-                const uint64_t i = i_a + before + uint32_t(__popcll(sm_n[h] & upto_me)) - 1u;   // the char's sentence (the run starts with one: >= i_a)
-                uint64_t li = run0 + uint64_t(q) - i;
-                if (total_b != 0 && li >= total_b) li = total_b - 1;
-                const bool last = ((em_n[h] >> lane) & 1u) != 0;
-                c_next[h] = in_run ? cps[q] : 0u;
-                b_next[h] = !in_run ? 0u : (last || total_b == 0) ? 1u : uint32_t(P.labels[li]);
+            for (uint32_t h = 0; h < 2; ++h) {
+                const uint32_t q = lane + 64u * h;
+                const bool in_run = q < rem;
+                // marks at or in front of the lane = bit 0 + the bits of (mask >> 1) below the lane
+                const uint32_t u = 64u * h + 1u - uint32_t(sm_n[h] & 1u) - (h ? uint32_t(__popcll(sm_n[0])) : 0u);
+                uint32_t voff = lane + u - mask_bits_below_lane(sm_n[h] >> 1, 0u);
+                voff = voff < lim ? voff : lim;
+                const bool last = __builtin_amdgcn_inverse_ballot_w64(em_n[h]);
+                c_next[h] = in_run ? cstep[q] : 0u;
+                b_next[h] = !in_run ? 0u : (last || !lab) ? 1u : (VPT_TAG_ABLATE & 8) ? (voff & 3u) == 0 : uint32_t(lstep[voff]);
             }
+            cs += uint32_t(__popcll(mk0)) + uint32_t(__popcll(mk1));
         };
         prepare(0);
         fetch(0);
-        int start = 0;              // where the token that is open at the beginning of this step started
-        bool have_start = true;     // ... and no Unknown boundary has been seen inside it (predictor.rs:566-567)
-        uint64_t sm_prev = 0;       // SM of the half-step in front of the current one
-        for (int base = 0; base < n; base += 128) {
-            uint32_t c[2], b[2];
-            const uint64_t sm[2] = {sm_n[0], sm_n[1]}, em[2] = {em_n[0], em_n[1]};
-#pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                c[h] = c_next[h]; b[h] = b_next[h];
-                L.txt[(base + 64 * h + lane) & (kRing - 1)] = c[h];
+        // (the first step's chars and labels are waited for HERE: at the loop's head the wait would be merged with the back edge's, where
+        // only stores are outstanding, into a wait for everything -- a step would start with a wait for the write acknowledgements)
+        VPT_PIN(c_next[0]); VPT_PIN(c_next[1]); VPT_PIN(b_next[0]); VPT_PIN(b_next[1]);
+        VPT_TP(1);   // a run's start: its offsets, the first window, the first step's chars and labels
+        VPT_TP_COUNT(9);
+        int start = 0;              // where the token that is open at the beginning of this half-step started
+        uint32_t tainted = 0;       // 1: an Unknown boundary has been seen inside it (predictor.rs:566-567)
+        uint64_t sm_prev = 0;       // SM of the half-step in front of the current step
+        uint32_t base = 0;
+        auto step = [&](auto full_step) {   // the chars [base, base + 128) of the run; full_step: all of them are (every step but a run's last)
+            constexpr bool kFull = decltype(full_step)::value;
+            const uint32_t c[2] = {c_next[0], c_next[1]}, b[2] = {b_next[0], b_next[1]};
+            const uint64_t sm[2] = {mk0, mk1};   // this step's marks (the next step's are prepared below)
+            const uint32_t sm_top = mk2;         // ... and the mark of the char behind it
+            const uint32_t rem = n - base;
+            {   // the ring: char x at txt[x & 255], and chars = 0, 1, 2 (mod 256) once more behind its end
+                const uint32_t r = (base & 128u) + lane;
+                L.txt[r] = c[0];
+                L.txt[r + 64u] = c[1];
+                if ((base & 128u) == 0 && lane < 3u) L.txt[kRing + lane] = c[0];
             }
-            cs_n += uint32_t(__popcll(sm[0])) + uint32_t(__popcll(sm[1]));
-            if (base + 128 < n) { prepare(base + 128); fetch(base + 128); }
-            else { sm_n[0] = 0; }
-            uint64_t ends[2], unk[2];
-#pragma unroll
-            for (int h = 0; h < 2; ++h) { ends[h] = __ballot(b[h] == 1u); unk[h] = __ballot(b[h] == 2u); }
+            const bool more = kFull && base + 128u < n;
+            VPT_TP(2);   // (what is left of the step before, the ring)
+            if (more) { prepare(base + 128u); fetch(base + 128u); }
+            VPT_TP(3);   // the next step's marks; its loads issued
             __builtin_amdgcn_wave_barrier();
             // ---- (1) this lane's tokens, if its chars end one: [s0, p], valid when no Unknown lies inside.  Could they have a tag model?
-            int s0[2];
-            bool valid[2];
-            uint32_t fbit[2], fword[2];
+            uint32_t len[2], fbit[2], fword[2];
+            uint64_t valid[2];
 #pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                const int hb = base + 64 * h;
-                const uint64_t prev_ends = ends[h] & below_me;
-                const int prev = prev_ends ? 63 - __clzll((long long)prev_ends) : -1;
-                s0[h] = prev >= 0 ? hb + prev + 1 : start;
-                const uint64_t after_prev = prev >= 0 ? ~((uint64_t(2) << prev) - 1) : ~uint64_t(0);
-                valid[h] = b[h] == 1u && (unk[h] & below_me & after_prev) == 0 && (prev >= 0 || have_start);
-                fbit[h] = valid[h] ? tag_filter_bit(P, cps, L.txt, base - 128, s0[h], hb + lane) : 0u;
+            for (uint32_t h = 0; h < 2; ++h) {
+                const uint32_t hb = base + 64u * h;
+                const uint64_t E = __ballot(b[h] == 1u), U = __ballot(b[h] == 2u);
+                // a carry started just above an Unknown label (and at the half-step's first char when the open token has one already)
+                // runs up the unlabelled positions into the next label: the token ends reached are the tainted ones
+                const uint64_t M = ~(E | U), seed = (U << 1) | tainted;
+                valid[h] = E & ~((M + seed) ^ M);
+                const uint64_t prev_ends = E & below_me;
+                const int s0 = prev_ends ? int(hb) + 64 - __clzll((long long)prev_ends) : start;
+                len[h] = hb + lane + 1u - uint32_t(s0);
+                const uint32_t* const r = &L.txt[uint32_t(s0) & (kRing - 1)];
+                uint32_t c0 = r[0], c1 = r[1], c2 = r[2], c3 = r[3];   // always an LDS read ...
+                if (VPT_TAG_ABLATE & 16) { c0 = c[h]; c1 = c2 = c3 = uint32_t(s0); }
+                const bool mine = __builtin_amdgcn_inverse_ballot_w64(valid[h]);
+                if (mine && s0 < int(base) - 128) {   // ... and for a token that began before the ring (rare) the chars themselves
+                    c0 = cps[s0];
+                    c1 = len[h] > 1u ? cps[s0 + 1] : 0u; c2 = len[h] > 2u ? cps[s0 + 2] : 0u; c3 = len[h] > 3u ? cps[s0 + 3] : 0u;
+                }
+                uint32_t lo = (c0 & 0xFFFFu) | (c1 << 16), hi = (c2 & 0xFFFFu) | (c3 << 16);
+                if (len[h] < 2u) lo &= 0xFFFFu;
+                if (len[h] < 4u) hi &= 0xFFFFu;
+                if (len[h] < 3u) hi = 0u;
+                fbit[h] = tag_token_hash_key(lo, hi, len[h]) >> fshift;
                 // the token that stays open into the next half-step
-                if (ends[h]) {
-                    const int last = 63 - __clzll((long long)ends[h]);
-                    start = hb + last + 1;
-                    have_start = last == 63 || (unk[h] >> (last + 1)) == 0;
-                } else if (unk[h]) {
-                    have_start = false;
+                if (E) {
+                    const int last = 63 - __clzll((long long)E);
+                    start = int(hb) + last + 1;
+                    tainted = ((U >> last) >> 1) != 0 ? 1u : 0u;   // (an Unknown label above the last end)
+                } else if (U) {
+                    tainted = 1u;
                 }
             }
 #pragma unroll
-            for (int h = 0; h < 2; ++h) fword[h] = valid[h] ? P.tok_tab[(size_t(4) << P.tok_bits) + (fbit[h] >> 5)] : 0u;
+            for (uint32_t h = 0; h < 2; ++h) fword[h] = (!(VPT_TAG_ABLATE & 1) && __builtin_amdgcn_inverse_ballot_w64(valid[h])) ? filt[fbit[h] >> 5] : 0u;
+            VPT_TP(4);   // token ends, keys, filter loads issued
+            constexpr bool kStoreAll = kFull && kFill != 0;
+            if constexpr (kStoreAll && !(VPT_TAG_ABLATE & 4)) {   // (see above: nothing between the loads and these stores that the wait would have to be merged over)
+                __builtin_amdgcn_sched_barrier(0);   // behind the filter loads ...
+                int32_t* const tm = tm_run + base;
+                int32_t* const tg = tg_run + size_t(base) * uint32_t(kFill);
 #pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                const int p = base + 64 * h + lane;
-                const bool cand = valid[h] && ((fword[h] >> (fbit[h] & 31u)) & 1u) != 0;
+                for (uint32_t h = 0; h < 2; ++h) {
+                    const uint32_t q = lane + 64u * h;
+                    tm[q] = 0;
+                    if constexpr (kFill == 1) tg[q] = -1;
+                    else if constexpr (kFill == 2) reinterpret_cast<int2*>(tg)[q] = make_int2(-1, -1);
+                    else reinterpret_cast<int4*>(tg)[q] = make_int4(-1, -1, -1, -1);
+                }
+                __builtin_amdgcn_sched_barrier(0);   // ... and in front of the wait for them
+            }
+#ifdef VPT_TAG_PROFILE
+            VPT_TP(5);   // stores issued
+            VPT_PIN(fword[0]); VPT_PIN(fword[1]);
+            VPT_TP(6);   // the wait for the filter words (and everything older)
+            VPT_TP_COUNT(10);
+#endif
+#pragma unroll
+            for (uint32_t h = 0; h < 2; ++h) {
+                const uint32_t q = lane + 64u * h;
+                const bool cand = ((fword[h] >> (fbit[h] & 31u)) & 1u) != 0;   // (no filter word where no valid token ends)
                 // every char of the run gets its entries here or when its token has been looked up (nothing is cleared beforehand):
                 // 0 / None where no token with a tag model ends
-                if (p < n && !cand) {
-                    const uint64_t g = run0 + uint64_t(p);
-                    if (P.tok_model) P.tok_model[g] = 0;
-                    if (P.model_out) P.model_out[g] = -1;
-                    for (uint32_t j = 0; j < nt; ++j) P.tags[g * nt + j] = -1;
-                }
-                // ---- (2) the candidates wait for the token table together: 64 of them are a lookup with every lane busy
-                const uint64_t cmask = __ballot(cand);
-                if (cmask != 0) {
-                    // chars of the token's sentence in front of / behind its last char, clipped to the context: up to the nearest sentence
-                    // start at or in front of the char, up to the nearest sentence end at or behind it
-                    const uint64_t at_or_before = sm[h] & upto_me, pm = h ? sm[0] : sm_prev;
-                    const uint32_t back_full = at_or_before ? uint32_t(lane - (63 - __clzll((long long)at_or_before)))
-                                                            : pm ? uint32_t(lane + 1 + __clzll((long long)pm)) : 0xFFu;
-                    const uint64_t at_or_after = em[h] & ~below_me, nm = h ? (base + 128 < n ? em_n[0] : 0) : em[1];
-                    const uint32_t fwd_full = at_or_after ? uint32_t(__builtin_ctzll(at_or_after) - lane)
-                                                          : nm ? uint32_t(64 - lane + __builtin_ctzll(nm)) : 0xFFu;
-                    const uint32_t back = back_full < uint32_t(kCtxBack) ? back_full : uint32_t(kCtxBack);
-                    const uint32_t fwd = fwd_full < uint32_t(kCtx - 1 - kCtxBack) ? fwd_full : uint32_t(kCtx - 1 - kCtxBack);
-                    const uint32_t rank = uint32_t(__popcll(cmask & below_me));
-                    uint32_t remaining = uint32_t(__popcll(cmask)), done = 0;
-                    for (;;) {
-                        const uint32_t room = uint32_t(kTagCand) - nc, take = remaining < room ? remaining : room;
-                        if (cand && rank >= done && rank < done + take) {
-                            const uint32_t row = nc + rank - done;
-                            const uint64_t gp = run0 + uint64_t(p);
-                            L.cand[row][0] = uint32_t(gp); L.cand[row][1] = uint32_t(gp >> 32); L.cand[row][2] = uint32_t(p - s0[h] + 1); L.cand[row][3] = back | (fwd << 8);
-                        }
-                        nc += take; done += take; remaining -= take;
-                        if (nc != uint32_t(kTagCand)) break;
-                        tag_resolve<true>(P, L, nullptr, nc, nq, false, lane, 0u);
-                        nc = 0;
-                        if (!remaining) break;
+                if constexpr (!kStoreAll) {
+                    if (q < rem && !cand) {
+                        int32_t* const tm = tok_model ? tm_run + base : nullptr;
+                        int32_t* const mo = model_out ? mo_run + base : nullptr;
+                        int32_t* const tg = tg_run + size_t(base) * nt;
+                        if (tm) tm[q] = 0;
+                        if (mo) mo[q] = -1;
+                        if constexpr (kFill == 1) tg[q] = -1;
+                        else if constexpr (kFill == 2) reinterpret_cast<int2*>(tg)[q] = make_int2(-1, -1);
+                        else if constexpr (kFill == 4) reinterpret_cast<int4*>(tg)[q] = make_int4(-1, -1, -1, -1);
+                        else for (uint32_t j = 0; j < nt; ++j) tg[q * nt + j] = -1;
                     }
+                }
+                // ---- (2) the candidates wait for the token table together: 64 of them are a lookup with every lane busy.  There are one or
+                // two in a half-step (BASELINE's configs[4]): each is put into its row by scalar code -- its context clip from the bitmaps
+                // (chars of the token's sentence in front of / behind its last char: up to the nearest sentence start at or in front of
+                // the char, up to the nearest sentence end at or behind it), its length from the lane that owns it
+                uint64_t cmask = (VPT_TAG_ABLATE & 2) ? 0 : __ballot(cand);
+                if (VPT_TAG_ABLATE & 32) { if (cmask == 0x123456789ABCDEFull) L.txt[lane] = 1; cmask = 0; }
+                if (cmask != 0) {
+                    // EM: the marks one down
+                    const uint64_t em_h = h ? (sm[1] >> 1) | (uint64_t(sm_top) << 63) : (sm[0] >> 1) | (sm[1] << 63);
+                    const uint64_t pm = h ? sm[0] : sm_prev;
+                    const uint64_t nm = h ? (more ? (mk0 >> 1) | (mk1 << 63) : 0) : (sm[1] >> 1) | (uint64_t(sm_top) << 63);
+                    do {
+                        const int k = __ffsll((long long)cmask) - 1;
+                        cmask &= cmask - 1;
+                        const uint64_t upto = (uint64_t(2) << k) - 1;   // bits 0 .. k
+                        const uint64_t at_or_before = sm[h] & upto, at_or_after = em_h & ~(upto >> 1);
+                        const uint32_t back_full = at_or_before ? uint32_t(k - (63 - __clzll((long long)at_or_before)))
+                                                                : pm ? uint32_t(k + 1 + __clzll((long long)pm)) : 0xFFu;
+                        const uint32_t fwd_full = at_or_after ? uint32_t(__ffsll((long long)at_or_after) - 1 - k)
+                                                              : nm ? uint32_t(64 - k + __ffsll((long long)nm) - 1) : 0xFFu;
+                        const uint32_t back = back_full < uint32_t(kCtxBack) ? back_full : uint32_t(kCtxBack);
+                        const uint32_t fwd = fwd_full < uint32_t(kCtx - 1 - kCtxBack) ? fwd_full : uint32_t(kCtx - 1 - kCtxBack);
+                        const uint32_t ln = uint32_t(__builtin_amdgcn_readlane(int(len[h]), k));
+                        const uint64_t gp = run0 + uint64_t(base + 64u * h + uint32_t(k));
+                        if (lane == 0) *reinterpret_cast<uint4*>(L.cand[nc]) = make_uint4(uint32_t(gp), uint32_t(gp >> 32), ln, back | (fwd << 8));
+                        if ((VPT_TAG_ABLATE & 64) && nc == uint32_t(kTagCand) - 1u) nc = 0;
+                        if (++nc == uint32_t(kTagCand)) {
+                            VPT_TP(7);   // candidates into their rows (and a last step's entries)
+                            VPT_KARG(TagParams) R = P;
+                            VPT_KARG_FENCE(R);
+                            TagParams Q;
+                            read_tag_params(Q, R);
+                            tag_resolve<true>(Q, L, nullptr, nc, nq, false, int(lane), 0u);
+                            nc = 0;
+                            VPT_TP(8);   // a lookup of 64 candidates
+                        }
+                    } while (cmask != 0);
                 }
             }
             sm_prev = sm[1];
             __builtin_amdgcn_wave_barrier();   // the ring is written by the next step
-        }
+            VPT_TP(7);
+        };
+        for (; n - base >= 128u; base += 128u) step(std::true_type{});
+        if (base < n) step(std::false_type{});
     }
-    if (nc != 0) tag_resolve<true>(P, L, nullptr, nc, nq, true, lane, 0u);
+    VPT_TP(0);
+    if (nc != 0 && !(VPT_TAG_ABLATE & 64)) { TagParams Q; read_tag_params(Q, P); tag_resolve<true>(Q, L, nullptr, nc, nq, true, int(lane), 0u); }
+    VPT_TP(8);
+    VPT_TP_FLUSH();
 }
 
 }  // namespace
@@ -1061,10 +1221,32 @@ hipError_t launch_tag_tokens(const TagParams& P, hipStream_t stream) {
         else {
             // runs of about 2 K chars (16 steps), at least a sentence: enough runs for every wave of the grid to even out, a window of offsets every
             // few steps (measured on configs[4], profiles/r04_o_tag_front.jsonl: runs of 2 K / 4 K / 16 K chars 1.761 / 1.781 / 1.970 ms stand-alone)
-            const uint64_t per = std::max<uint64_t>(1, (uint64_t(2048) * P.n_sent + P.total_chars / 2) / std::max<uint64_t>(P.total_chars, 1));
+            const uint64_t per = std::max<uint64_t>(1, (uint64_t(VPT_TAG_RUN_CHARS) * P.n_sent + P.total_chars / 2) / std::max<uint64_t>(P.total_chars, 1));
             const uint64_t runs = (P.n_sent + per - 1) / per, want_f = (runs + kTagWaves - 1) / kTagWaves;
             const uint32_t blocks_f = uint32_t(want_f < 1 ? 1 : want_f > cap ? cap : want_f);
-            hipLaunchKernelGGL(tag_front_flat_kernel, dim3(blocks_f), dim3(kTagThreads), 0, stream, P, uint32_t(std::min<uint64_t>(per, 0x7FFFFFFFull)));
+            // a char's None entries as ONE store of 1, 2 or 4 tags (the array's alignment allowing), with the writer's tok_model array and no model_out:
+            // the instances that store them behind a step's loads, unconditionally
+            const uint32_t per32 = uint32_t(std::min<uint64_t>(per, 0x7FFFFFFFull));
+#ifdef VPT_TAG_PROFILE
+            {
+                unsigned long long h[16] = {0};
+                (void)hipStreamSynchronize(stream);
+                (void)hipMemcpyFromSymbol(h, HIP_SYMBOL(g_tag_prof), sizeof(h));
+                if (h[11]) {
+                    static const char* names[9] = {"between runs", "run start", "step: ring", "step: prepare + fetch", "step: ends, keys", "step: stores", "step: WAIT filter words", "step: candidates", "lookups"};
+                    std::fprintf(stderr, "[tag front profile] %llu runs, %llu steps, wave ticks %llu:", h[9], h[10], h[11]);
+                    for (int k = 0; k < 9; ++k) std::fprintf(stderr, " %s %.1f%%", names[k], 100.0 * double(h[k]) / double(h[11]));
+                    std::fprintf(stderr, "\n");
+                }
+                unsigned long long z[16] = {0};
+                (void)hipMemcpyToSymbol(HIP_SYMBOL(g_tag_prof), z, sizeof(z));
+            }
+#endif
+            const bool plain = P.tok_model && !P.model_out && (reinterpret_cast<uintptr_t>(P.tags) & 15u) == 0;
+            if (plain && P.n_tags == 1) hipLaunchKernelGGL(tag_front_flat_kernel<1>, dim3(blocks_f), dim3(kTagThreads), 0, stream, P, per32);
+            else if (plain && P.n_tags == 2) hipLaunchKernelGGL(tag_front_flat_kernel<2>, dim3(blocks_f), dim3(kTagThreads), 0, stream, P, per32);
+            else if (plain && P.n_tags == 4) hipLaunchKernelGGL(tag_front_flat_kernel<4>, dim3(blocks_f), dim3(kTagThreads), 0, stream, P, per32);
+            else hipLaunchKernelGGL(tag_front_flat_kernel<0>, dim3(blocks_f), dim3(kTagThreads), 0, stream, P, per32);
         }
         hipLaunchKernelGGL(tag_pass_kernel, dim3(blocks), dim3(kTagThreads), 0, stream, P);
         hipLaunchKernelGGL((tag_tokens_kernel<false, false>), dim3(blocks), dim3(kTagThreads), 0, stream, P, 0u);
