@@ -67,6 +67,7 @@ struct hipDeviceProp_t { int multiProcessorCount; };
 
 hipError_t hipGetDeviceCount(int* n);
 hipError_t hipSetDevice(int dev);
+hipError_t hipGetDevice(int* dev);
 hipError_t hipGetDeviceProperties(hipDeviceProp_t* prop, int dev);
 hipError_t hipMalloc(void** p, size_t bytes);
 hipError_t hipFree(void* p);

@@ -290,7 +290,9 @@ struct hipemu_event { int unused; };
 
 // two pretend devices (one address space), so that the multi-device entry points run on the emulator too
 hipError_t hipGetDeviceCount(int* n) { *n = 2; return hipSuccess; }
-hipError_t hipSetDevice(int dev) { return (dev == 0 || dev == 1) ? hipSuccess : hipErrorInvalidValue; }
+static thread_local int g_current_device = 0;
+hipError_t hipSetDevice(int dev) { if (dev != 0 && dev != 1) return hipErrorInvalidValue; g_current_device = dev; return hipSuccess; }
+hipError_t hipGetDevice(int* dev) { *dev = g_current_device; return hipSuccess; }
 hipError_t hipGetDeviceProperties(hipDeviceProp_t* prop, int) { prop->multiProcessorCount = 2; return hipSuccess; }
 
 hipError_t hipMalloc(void** p, size_t bytes) {

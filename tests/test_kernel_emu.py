@@ -118,7 +118,8 @@ def test_halves_and_permutation_sized_down():
     assert np.array_equal(ps.reshape(n, 63), scores.reshape(n, 63)[perm])
 
 
-@pytest.mark.parametrize("env", [{}, {"VPT_TAG_SPLIT": "1", "VPT_TOKENIZE_CHUNK_BYTES": "700"}], ids=["default", "two-launch tags, small tokenize chunks"])
+@pytest.mark.parametrize("env", [{}, {"VPT_TAG_SPLIT": "1", "VPT_TOKENIZE_CHUNK_BYTES": "700"}, {"VPT_TAG_SPLIT": "1", "VPT_EMU_DEFINES": "-DVPT_TAG_SUM_LOG2=7"}],
+                         ids=["default", "two-launch tags, small tokenize chunks", "two-launch tags, a 128-bit summary of the token filter (a bit for many of the filter's)"])
 def test_short_fuzz_of_the_kernel_sources(env):
     """tools/fuzz_gpu.py for a quarter of a minute on the emulator: random models (every window, tag models, wide weights) x ragged batches x
     flags against the oracle -- boundaries, tags, writers, vpt_tokenize_batch.  The seeds are fixed: a failure names the one to rerun."""

@@ -58,6 +58,7 @@
 #include "device_common.h"
 #include "kernels.hpp"
 #include <algorithm>
+#include <atomic>
 #include <type_traits>
 #include <cstdlib>
 #include <cstdio>
@@ -918,16 +919,54 @@ __device__ __forceinline__ uint32_t mask_bits_below_lane(uint64_t mask, uint32_t
 // end of a step -- they depended on the filter words -- made the next step's wait for ITS filter words a wait for their write
 // acknowledgements as well, and that, not the instruction count, was most of a step's time.  Stores that depend on nothing sit between the
 // loads and the wait, with no branch for the wait to be merged over.  kFill = 0: anything else, entries stored where no candidate is.
-template <int kFill>
-__global__ __launch_bounds__(kTagThreads, VPT_TAG_FLAT_OCC) void tag_front_flat_kernel(const TagParams P_in, const uint32_t per) {
+// kSum: a SUMMARY of the token table's filter sits in LDS (2^18 bits, one for every 2^(tok_bits + 5 - 18) of the filter's: set when any of
+// them is; built by tag_filter_summary_kernel in front of this launch, into the tail of the queue's slow part).  The filter word of a token
+// end is a random 4-byte load that hits the L2 -- 25 of them per half-step, 52 M per launch of configs[4], a third of the kernel's time at the
+// rate the vector L1 takes random lanes (profiles/r05_y_tag_front_ablations.txt: keys + filter loads 0.32 ms, None stores 0.30 ms, the rest
+// 0.09 + 0.09, and they ADD) -- and 96 of 100 answers are "no".  With 50 000 tag models the summary is a sixth full: five of six of those
+// loads are not issued.  Workgroups of 8 waves share one copy (32 KB; 3 workgroups per CU).
+constexpr int kFlatThreads = 512, kFlatWaves = kFlatThreads / 64;
+#ifndef VPT_TAG_SUM_LOG2
+#define VPT_TAG_SUM_LOG2 18   // (tests build a small one: a summary bit then stands for many filter bits with the test models' small tables, too)
+#endif
+constexpr uint32_t kSumLog2 = VPT_TAG_SUM_LOG2;
+static_assert(kSumLog2 >= 5 && kSumLog2 <= 18, "the summary's words in LDS");
+__global__ __launch_bounds__(256) void tag_filter_summary_kernel(const uint32_t* __restrict__ filt, const uint32_t big_log2, const uint32_t sum_log2,
+                                                                   uint32_t* __restrict__ out) {
+    const uint32_t w = blockIdx.x * blockDim.x + threadIdx.x;   // a word of the summary
+    if (w >= (1u << (sum_log2 - 5u))) return;
+    const uint32_t c = big_log2 - sum_log2;   // a summary bit stands for 2^c filter bits
+    uint32_t r = 0;
+    for (uint32_t j = 0; j < 32u; ++j) {
+        const uint32_t sb = 32u * w + j;
+        bool any = false;
+        if (c >= 5u) {
+            for (uint32_t k = sb << (c - 5u); k < (sb + 1u) << (c - 5u); ++k) any = any || filt[k] != 0;
+        } else {
+            const uint32_t b0 = sb << c;   // (2^c <= 16 bits that start at a multiple of 2^c: inside one word)
+            any = ((filt[b0 >> 5] >> (b0 & 31u)) & ((1u << (1u << c)) - 1u)) != 0;
+        }
+        r |= uint32_t(any) << j;
+    }
+    out[w] = r;
+}
+template <int kFill, bool kSum>
+__global__ __launch_bounds__(kFlatThreads, VPT_TAG_FLAT_OCC) void tag_front_flat_kernel(const TagParams P_in, const uint32_t per, const uint32_t* __restrict__ summary,
+                                                                                         const uint32_t sum_log2) {
     VPT_KARG(TagParams) P = VPT_KARG_PTR(TagParams, P_in);   // (read where it is used, like the scoring kernel's block: device_common.h)
-    __shared__ TagKernelLds<true> LDS;
-    __shared__ uint32_t BITS[kTagWaves][8];   // per wave: the marks of the step being prepared, when there are many (5 words)
+    __shared__ TagFrontLds FR[kFlatWaves];
+    __shared__ uint32_t BITS[kFlatWaves][8];   // per wave: the marks of the step being prepared, when there are many (5 words)
+    __shared__ uint32_t SUM[kSum ? (1u << (kSumLog2 - 5u)) : 1u];
     const uint32_t lane = threadIdx.x & 63;
     const uint32_t wid = wave_uniform(threadIdx.x >> 6);
-    TagFrontLds& L = LDS.fr[wid];
+    TagFrontLds& L = FR[wid];
     uint32_t* const bits = BITS[wid];
-    const uint64_t wave = uint64_t(blockIdx.x) * kTagWaves + wid, n_waves = uint64_t(gridDim.x) * kTagWaves;
+    const uint64_t wave = uint64_t(blockIdx.x) * kFlatWaves + wid, n_waves = uint64_t(gridDim.x) * kFlatWaves;
+    if constexpr (kSum) {
+        for (uint32_t i = threadIdx.x; i < (1u << (sum_log2 - 5u)); i += uint32_t(kFlatThreads)) SUM[i] = summary[i];
+        __syncthreads();
+    }
+    const uint32_t sshift = 32u - sum_log2;
     const uint32_t nt = P->n_tags;
     const uint64_t below_me = (uint64_t(1) << lane) - 1;
     const uint64_t total_b = P->total_chars - P->n_sent;   // labels of the batch
@@ -1066,6 +1105,7 @@ __global__ __launch_bounds__(kTagThreads, VPT_TAG_FLAT_OCC) void tag_front_flat_
             // ---- (1) this lane's tokens, if its chars end one: [s0, p], valid when no Unknown lies inside.  Could they have a tag model?
             uint32_t len[2], fbit[2], fword[2];
             uint64_t valid[2];
+            bool want[2];
 #pragma unroll
             for (uint32_t h = 0; h < 2; ++h) {
                 const uint32_t hb = base + 64u * h;
@@ -1089,7 +1129,14 @@ __global__ __launch_bounds__(kTagThreads, VPT_TAG_FLAT_OCC) void tag_front_flat_
                 if (len[h] < 2u) lo &= 0xFFFFu;
                 if (len[h] < 4u) hi &= 0xFFFFu;
                 if (len[h] < 3u) hi = 0u;
-                fbit[h] = tag_token_hash_key(lo, hi, len[h]) >> fshift;
+                const uint32_t key = tag_token_hash_key(lo, hi, len[h]);
+                fbit[h] = key >> fshift;
+                bool ask = mine;   // is the filter word asked for?  Only where the summary does not say no already
+                if constexpr (kSum) {
+                    const uint32_t sb = key >> sshift;
+                    ask = ask && ((SUM[sb >> 5] >> (sb & 31u)) & 1u) != 0;
+                }
+                want[h] = ask;
                 // the token that stays open into the next half-step
                 if (E) {
                     const int last = 63 - __clzll((long long)E);
@@ -1100,7 +1147,7 @@ __global__ __launch_bounds__(kTagThreads, VPT_TAG_FLAT_OCC) void tag_front_flat_
                 }
             }
 #pragma unroll
-            for (uint32_t h = 0; h < 2; ++h) fword[h] = (!(VPT_TAG_ABLATE & 1) && __builtin_amdgcn_inverse_ballot_w64(valid[h])) ? filt[fbit[h] >> 5] : 0u;
+            for (uint32_t h = 0; h < 2; ++h) fword[h] = (!(VPT_TAG_ABLATE & 1) && want[h]) ? filt[fbit[h] >> 5] : 0u;
             VPT_TP(4);   // token ends, keys, filter loads issued
             constexpr bool kStoreAll = kFull && kFill != 0;
             if constexpr (kStoreAll && !(VPT_TAG_ABLATE & 4)) {   // (see above: nothing between the loads and these stores that the wait would have to be merged over)
@@ -1207,6 +1254,22 @@ hipError_t launch_decode_chars(const uint8_t* text, const uint64_t* boff, const 
     return hipGetLastError();
 }
 
+// CUs of the current device (capi.cpp has set it), asked for once per device
+static uint32_t device_cus() {
+    static std::atomic<uint32_t> cache[64];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 0;
+    uint32_t c = cache[dev].load(std::memory_order_relaxed);
+    if (c == 0) {
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) {
+            c = uint32_t(prop.multiProcessorCount);
+            cache[dev].store(c, std::memory_order_relaxed);
+        }
+    }
+    return c;
+}
+
 hipError_t launch_tag_tokens(const TagParams& P, hipStream_t stream) {
     // sentences differ in length (8..512 chars in BASELINE's configs[4]): a grid of one wave per sentence leaves the waves of a
     // workgroup waiting for its longest one, so the waves stay (P.max_blocks = what the device runs at a time) and stride over the batch
@@ -1222,8 +1285,7 @@ hipError_t launch_tag_tokens(const TagParams& P, hipStream_t stream) {
             // runs of about 2 K chars (16 steps), at least a sentence: enough runs for every wave of the grid to even out, a window of offsets every
             // few steps (measured on configs[4], profiles/r04_o_tag_front.jsonl: runs of 2 K / 4 K / 16 K chars 1.761 / 1.781 / 1.970 ms stand-alone)
             const uint64_t per = std::max<uint64_t>(1, (uint64_t(VPT_TAG_RUN_CHARS) * P.n_sent + P.total_chars / 2) / std::max<uint64_t>(P.total_chars, 1));
-            const uint64_t runs = (P.n_sent + per - 1) / per, want_f = (runs + kTagWaves - 1) / kTagWaves;
-            const uint32_t blocks_f = uint32_t(want_f < 1 ? 1 : want_f > cap ? cap : want_f);
+            const uint64_t runs = (P.n_sent + per - 1) / per;
             // a char's None entries as ONE store of 1, 2 or 4 tags (the array's alignment allowing), with the writer's tok_model array and no model_out:
             // the instances that store them behind a step's loads, unconditionally
             const uint32_t per32 = uint32_t(std::min<uint64_t>(per, 0x7FFFFFFFull));
@@ -1243,10 +1305,33 @@ hipError_t launch_tag_tokens(const TagParams& P, hipStream_t stream) {
             }
 #endif
             const bool plain = P.tok_model && !P.model_out && (reinterpret_cast<uintptr_t>(P.tags) & 15u) == 0;
-            if (plain && P.n_tags == 1) hipLaunchKernelGGL(tag_front_flat_kernel<1>, dim3(blocks_f), dim3(kTagThreads), 0, stream, P, per32);
-            else if (plain && P.n_tags == 2) hipLaunchKernelGGL(tag_front_flat_kernel<2>, dim3(blocks_f), dim3(kTagThreads), 0, stream, P, per32);
-            else if (plain && P.n_tags == 4) hipLaunchKernelGGL(tag_front_flat_kernel<4>, dim3(blocks_f), dim3(kTagThreads), 0, stream, P, per32);
-            else hipLaunchKernelGGL(tag_front_flat_kernel<0>, dim3(blocks_f), dim3(kTagThreads), 0, stream, P, per32);
+            const int fill = !plain ? 0 : P.n_tags == 1 ? 1 : P.n_tags == 2 ? 2 : P.n_tags == 4 ? 4 : 0;
+            // the filter's summary for the workgroups' LDS: built into the last entries of the queue's slow part, which the front end then
+            // does not fill (a queue too small for that -- VPT_TAG_QUEUE in tests -- goes without)
+            const uint32_t big_log2 = P.tok_bits + kTagFilterLog2, sum_log2 = std::min(big_log2, kSumLog2);
+            const uint32_t sum_words = 1u << (sum_log2 - 5u), sum_entries = (sum_words + 3u) / 4u;
+            static const bool no_sum = [] { const char* e = std::getenv("VPT_TAG_NO_SUMMARY"); return e && std::atoi(e) != 0; }();   // (A/B; read once per process)
+            const bool sum = !no_sum && P.queue_slow >= 2u * sum_entries + 64u;
+            TagParams F = P;
+            const uint32_t* summary = nullptr;
+            if (sum) {
+                F.queue_slow = P.queue_slow - sum_entries;
+                uint32_t* const out = reinterpret_cast<uint32_t*>(P.queue + P.queue_fast + F.queue_slow);
+                hipLaunchKernelGGL(tag_filter_summary_kernel, dim3((sum_words + 255u) / 256u), dim3(256), 0, stream, P.tok_tab + (size_t(4) << P.tok_bits), big_log2, sum_log2, out);
+                summary = out;
+            }
+            // the grid: what the device holds at a time and no more -- 3 workgroups per CU (6 waves per SIMD; the summary's 32 KB each), their waves
+            // striding over the runs.  A workgroup loads its summary once; a second generation of workgroups would load it again and leave the
+            // CUs unevenly filled at the end (measured on configs[4]: 768 / 1024 / 1536 / 2048 / 4096 workgroups 0.69 / 0.83 / 0.74 / 0.76 /
+            // 0.80 ms, profiles/r05_zc_tag_front_grid.txt).  P.max_blocks (VPT_TAG_WGS_PER_CU) still caps it.
+            const uint32_t cus = device_cus();
+            const uint64_t want_w = (runs + kFlatWaves - 1) / kFlatWaves;
+            const uint64_t cap_w = std::min<uint64_t>(std::max<uint64_t>(1, cap * kTagWaves / kFlatWaves), cus ? uint64_t(cus) * (VPT_TAG_FLAT_OCC / 2) : ~uint64_t(0));
+            const dim3 grid(uint32_t(want_w < 1 ? 1 : want_w > cap_w ? cap_w : want_w)), block(kFlatThreads);
+#define VPT_LAUNCH_FLAT(f, s) hipLaunchKernelGGL((tag_front_flat_kernel<f, s>), grid, block, 0, stream, F, per32, summary, sum_log2)
+            if (sum) { if (fill == 1) VPT_LAUNCH_FLAT(1, true); else if (fill == 2) VPT_LAUNCH_FLAT(2, true); else if (fill == 4) VPT_LAUNCH_FLAT(4, true); else VPT_LAUNCH_FLAT(0, true); }
+            else { if (fill == 1) VPT_LAUNCH_FLAT(1, false); else if (fill == 2) VPT_LAUNCH_FLAT(2, false); else if (fill == 4) VPT_LAUNCH_FLAT(4, false); else VPT_LAUNCH_FLAT(0, false); }
+#undef VPT_LAUNCH_FLAT
         }
         hipLaunchKernelGGL(tag_pass_kernel, dim3(blocks), dim3(kTagThreads), 0, stream, P);
         hipLaunchKernelGGL((tag_tokens_kernel<false, false>), dim3(blocks), dim3(kTagThreads), 0, stream, P, 0u);
