@@ -908,6 +908,64 @@ def test_tag_front_end_over_runs_of_sentences(front, monkeypatch):
             assert np.array_equal(got[g0:g0 + len(t)], want), (edit, i, len(t))
 
 
+@pytest.mark.parametrize("n_slots", [1, 2, 3, 4, 5])
+def test_fill_tags_front_end_stores_for_any_tag_count_and_alignment(n_slots, monkeypatch):
+    """The flat front end of fill_tags has an instance per way of storing a char's None entries: 1, 2 or 4 tags per token as ONE store, for every
+    char of a full step whether a token with a model ends there or not (the passes behind it write those again) -- when the tags array is 16-byte
+    aligned and no tag scores are asked for -- and the general one (any count, any alignment, entries only where no candidate is).  Models with
+    exactly `n_slots` tag slots, sentences of many steps: tags against the oracle through the host path; through the device path with the array
+    16-byte aligned and 4 bytes off, the words around it untouched; with the models' indices asked for (vpt_fill_tags_scores_batch_device)."""
+    import random
+    from vaporetto_amd.modelfmt import TagModel, TagNgramData, TagWeight
+    monkeypatch.setenv("VPT_TAG_SPLIT", "1")
+    m = randmodel.rand_model(9300 + n_slots, alphabet="tiny", n_tag_models=0, max_word=4, n_char=40, n_dict=30)
+    rng = random.Random(77 + n_slots)
+    alpha = randmodel.ALPHABETS["tiny"]
+    seen = set()
+    while len(m.tag_models) < 24:
+        tok = "".join(rng.choice(alpha) for _ in range(rng.randint(1, 3)))
+        if tok in seen:
+            continue
+        seen.add(tok)
+        k = n_slots if len(m.tag_models) < 6 else rng.randint(1, n_slots)
+        slots = [["t%d" % j for j in range(rng.randint(0, 4))] for _ in range(k)]
+        zlen = sum(len(x) for x in slots if len(x) >= 2)
+        tm = TagModel(tok, slots, bias=randmodel.rand_weights(rng, zlen))
+        for _ in range(rng.randint(0, 3)):
+            g = "".join(rng.choice(alpha) for _ in range(rng.randint(0, 2))) + tok + "".join(rng.choice(alpha) for _ in range(rng.randint(0, 2)))
+            tm.char_ngram_model.append(TagNgramData(g, [TagWeight(r, randmodel.rand_weights(rng, zlen)) for r in sorted({rng.randint(0, m.char_window_size) for _ in range(2)})]))
+        m.tag_models.append(tm)
+    raw = encode_model(m)
+    pred = api.Predictor(api.Model.read_slice(raw)[0], True)
+    orc = cbind.OraclePredictor(raw, True)
+    nt = pred.n_tags()
+    assert nt == n_slots
+    toks = [t.token for t in m.tag_models]
+    def text(n):
+        return "".join(rng.choice(toks) if rng.random() < 0.3 else rng.choice(alpha) for _ in range(n))
+    texts = [text(n) for n in [1, 2, 63, 64, 65, 128, 129, 300, 700, 1500] + [rng.randint(1, 200) for _ in range(120)]]
+    utf8, boff = api.pack_texts([t.encode("utf-8") for t in texts])
+    _, labels, ooff = pred.predict_packed(utf8, boff)
+    got = pred.fill_tags_packed(utf8, boff, ooff, labels)
+    nb, S = int(ooff[-1]), len(texts)
+    for i, t in enumerate(texts):
+        a, b = int(ooff[i]), int(ooff[i + 1])
+        want, _ = orc.predict_tags(t, labels=labels[a:b])
+        assert np.array_equal(got[a + i:a + i + (b - a + 1)], want), (i, len(t))
+    d_text = devmem.put(np.concatenate([utf8, np.zeros(16, np.uint8)]))
+    d_boff, d_ooff = devmem.put(boff.astype(np.uint64)), devmem.put(ooff.astype(np.uint64))
+    d_labels = devmem.put(np.concatenate([labels, np.zeros(1, np.uint8)]))
+    n_words = (nb + S) * nt
+    for off_words in (4, 1, 5):   # 16 bytes into the allocation (aligned), 4 and 20 bytes (not)
+        d_tags = devmem.put(np.full(n_words + 16, 777, np.int32))
+        batch = api.DeviceBatch(pred)
+        batch.fill_tags(d_text.ptr, d_boff.ptr, d_ooff.ptr, S, nb, d_labels.ptr, d_tags.ptr + 4 * off_words, devmem.stream())
+        batch.sync()
+        w = d_tags.get(n_words + 16)
+        assert np.array_equal(w[off_words:off_words + n_words].reshape(nb + S, nt), got), off_words
+        assert np.all(w[:off_words] == 777) and np.all(w[off_words + n_words:] == 777), off_words
+
+
 @pytest.mark.parametrize("wc,wt", [(3, 6), (5, 5), (8, 8), (4, 2), (2, 7)])
 def test_tag_models_under_wide_windows(wc, wt):
     """Tag n-grams end up to `window` chars past their token (tag_trainer.rs:79-103).  The fast pass keeps p - 11 .. p + 4 of a token's context:

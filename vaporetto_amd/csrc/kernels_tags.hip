@@ -50,7 +50,9 @@
 //                        Round 4: the front-end launch of the pair, flat over the batch's chars -- a wave takes a run of consecutive sentences
 //                        (about 2 K chars) and walks it in the same 128-char steps with every lane busy; sentence starts and ends come from
 //                        two bitmaps per step built from the run's offsets.  configs[4]: 1.08 -> 1.00 ms (tag_tokens_kernel<.., kSplit> stays
-//                        as the A/B: VPT_TAG_FRONT_BY_SENTENCE).
+//                        as the A/B: VPT_TAG_FRONT_BY_SENTENCE).  Round 5: rewritten (see at the kernel) -- 43 % of the vector instructions,
+//                        None entries stored behind a step's loads, a summary of the token filter in LDS (tag_filter_summary_kernel builds it),
+//                        workgroups of 8 waves, a grid of what the device holds: 0.69 - 0.77 ms.
 //   With predict_tags the scoring kernel of the preceding vpt_predict_batch_device call leaves the decoded chars behind and
 //   decode_chars_kernel is skipped (capi.cpp).
 #include <hip/hip_runtime.h>
@@ -872,8 +874,9 @@ __global__ __launch_bounds__(kTagThreads, kSplit ? kTagFrontOcc : VPT_TAG_OCC) v
 // labels[flat(q) - i], and a candidate's context stops at its sentence's ends.  The token logic (ends, Unknown, filter, candidates,
 // lookups, queue in HBM) is tag_tokens_kernel's, in run-relative positions.
 //
-// Round 5: the same steps in fewer vector instructions (the kernel spent 358 of them per step, two thirds of its SIMDs' issue slots:
-// profiles/r05_z2_c4_summary.txt) --
+// Round 5, first the same steps in fewer vector instructions (358 of them per step, two thirds of the SIMDs' issue slots by the counters:
+// profiles/r05_z2_c4_summary.txt; SQ_INSTS_VALU 372 M -> 162 M per launch of configs[4] -- which bought 4 %: the instructions were not the
+// bound, see kSum below) --
 //   * every global access of a step is a wave-uniform pointer (advanced per step in scalar registers) plus a lane offset that does
 //     not change: no 64-bit address arithmetic in the lanes;
 //   * ONE bitmap of marks per step (sentence starts and the run's end; EM is SM shifted down by one), set by a scalar loop over the few
@@ -883,7 +886,7 @@ __global__ __launch_bounds__(kTagThreads, kSplit ? kTagFrontOcc : VPT_TAG_OCC) v
 //     that way are the tainted ones;
 //   * counts of mask bits below a lane through v_mbcnt, lane predicates straight from scalar masks;
 //   * the ring keeps its first three words again behind its end, so a token's first four chars are four consecutive LDS words;
-//   * a candidate's context clip from two funnel shifts over the bitmaps' words instead of four 64-bit scans;
+//   * the one or two candidates of a half-step are put into their rows by scalar code (context clip from the bitmaps, length from the lane);
 //   * the None entries of a char as ONE store for 1, 2 or 4 tags per token.
 #ifndef VPT_TAG_FLAT_OCC
 #define VPT_TAG_FLAT_OCC 6     // waves per SIMD the flat front end is compiled for (A/B builds: -D); 62 VGPRs either way, the scalar registers decide
