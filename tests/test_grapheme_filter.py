@@ -68,6 +68,20 @@ def test_packed_form_equals_per_sentence_form():
     assert (packed[changed] == B.NotWordBoundary).all()
 
 
+def test_generated_tables_name_the_regex_module_they_came_from():
+    """the C++ mirror's class tables are a snapshot of the `regex` module's Unicode data, the Python path uses the installed module's \\X
+    directly -- the two agree only while the snapshot is of the installed version.  The generated file names its source; a newer `regex` (another
+    Unicode version) fails here with what to do, instead of in the random-string comparison below with a code point nobody recognises.  (The
+    reference pins unicode-segmentation 1.12.0; neither side can be checked against that crate here -- no GraphemeBreakTest.txt in this image.)"""
+    import re
+    import regex
+    head = open(os.path.join(ROOT, "include", "vaporetto_grapheme_tables.inc"), encoding="utf-8").readline()
+    m = re.search(r"`regex` module (\S+) --", head)
+    assert m, head
+    assert m.group(1) == regex.__version__, ("include/vaporetto_grapheme_tables.inc was generated from regex %s, the installed module is %s: "
+                                             "rerun tools/gen_grapheme_tables.py and commit the file" % (m.group(1), regex.__version__))
+
+
 def test_cpp_mirror_segments_like_the_regex_module(tmp_path):
     """include/vaporetto_grapheme.hpp (UAX #29's rules over generated class tables) against \\X of the `regex` module: the reference's four
     cases, hand-picked rule cases (Hangul jamo, Indic conjuncts, prepend, flags, ZWJ sequences, CR LF, controls) and 4 000 random strings over
