@@ -908,6 +908,37 @@ def test_tag_front_end_over_runs_of_sentences(front, monkeypatch):
             assert np.array_equal(got[g0:g0 + len(t)], want), (edit, i, len(t))
 
 
+@pytest.mark.parametrize("shape", ["only one-char sentences", "one-char sentences at the end", "one sentence of many steps, then one-char ones"])
+def test_fill_tags_front_end_where_the_labels_run_out(shape, monkeypatch):
+    """A one-char sentence has no label, so a batch (or its tail) of them has none: the front end's runs there have nothing to read in `labels`
+    (an empty array for the first shape) and every char ends a token.  Tags against the oracle, fill_tags as two launches."""
+    monkeypatch.setenv("VPT_TAG_SPLIT", "1")
+    m = randmodel.rand_model(9410, alphabet="tiny", n_tag_models=30, max_word=4, n_char=40, n_dict=30)
+    raw = encode_model(m)
+    pred = api.Predictor(api.Model.read_slice(raw)[0], True)
+    orc = cbind.OraclePredictor(raw, True)
+    rng = np.random.RandomState(11)
+    alpha = randmodel.ALPHABETS["tiny"]
+    ones = [t.token[:1] for t in m.tag_models] + [alpha[k] for k in rng.randint(0, len(alpha), size=40)]
+    def text(n):
+        return "".join(alpha[k] for k in rng.randint(0, len(alpha), size=n))
+    singles = [ones[k % len(ones)] for k in range(700)]
+    if shape == "only one-char sentences":
+        texts = singles
+    elif shape == "one-char sentences at the end":
+        texts = [text(int(n)) for n in rng.randint(1, 90, size=60)] + singles
+    else:
+        texts = [text(1000)] + singles[:300]
+    utf8, boff = api.pack_texts([t.encode("utf-8") for t in texts])
+    _, labels, ooff = pred.predict_packed(utf8, boff)
+    got = pred.fill_tags_packed(utf8, boff, ooff, labels)
+    assert got.shape == (int(ooff[-1]) + len(texts), pred.n_tags())
+    for i, t in enumerate(texts):
+        a, b = int(ooff[i]), int(ooff[i + 1])
+        want, _ = orc.predict_tags(t, labels=labels[a:b])
+        assert np.array_equal(got[a + i:a + i + len(t)], want), (i, len(t))
+
+
 @pytest.mark.parametrize("n_slots", [1, 2, 3, 4, 5])
 def test_fill_tags_front_end_stores_for_any_tag_count_and_alignment(n_slots, monkeypatch):
     """The flat front end of fill_tags has an instance per way of storing a char's None entries: 1, 2 or 4 tags per token as ONE store, for every

@@ -46,7 +46,7 @@ _AS_IS = [
     "test_type_rows_and_window_table_agree_with_oracle", "test_type_weights_no_window_reads_and_padding_ngrams", "test_understated_length_bounds_are_reported",
     "test_tag_enabled_model_with_duplicate_type_ngrams_runs_on_the_packed_path", "test_predict_tags_like_reference",
     "test_fill_tags_requires_predict_tags_gpu", "test_fixture_tags_gpu", "test_random_tag_models_match_oracle",
-    "test_tag_models_inside_and_outside_the_record_form", "test_fill_tags_front_end_stores_for_any_tag_count_and_alignment", "test_tag_models_under_wide_windows", "test_fill_tags_as_two_launches", "test_tag_front_end_over_runs_of_sentences", "test_tokenize_with_the_grapheme_cluster_filter", "test_stored_tag_scores_reproduce_the_scorer_kats", "test_stored_tag_scores_match_oracle_on_random_models", "test_tag_token_table_keys_and_queue",
+    "test_tag_models_inside_and_outside_the_record_form", "test_fill_tags_front_end_stores_for_any_tag_count_and_alignment", "test_fill_tags_front_end_where_the_labels_run_out", "test_tag_models_under_wide_windows", "test_fill_tags_as_two_launches", "test_tag_front_end_over_runs_of_sentences", "test_tokenize_with_the_grapheme_cluster_filter", "test_stored_tag_scores_reproduce_the_scorer_kats", "test_stored_tag_scores_match_oracle_on_random_models", "test_tag_token_table_keys_and_queue",
     "test_converted_kytea_fixture_on_gpu", "test_fullwidth_filter_on_device", "test_label_post_filters_on_device",
     "test_device_resident_predict_then_fill_tags", "test_chars_left_by_predict_are_never_another_batchs", "test_fill_tags_with_offsets_that_do_not_match_the_text",
     "test_write_tokenized_text_on_device", "test_writer_blocks_of_any_size", "test_concurrent_host_threads_share_a_predictor",
