@@ -1313,8 +1313,11 @@ hipError_t launch_tag_tokens(const TagParams& P, hipStream_t stream) {
             // does not fill (a queue too small for that -- VPT_TAG_QUEUE in tests -- goes without)
             const uint32_t big_log2 = P.tok_bits + kTagFilterLog2, sum_log2 = std::min(big_log2, kSumLog2);
             const uint32_t sum_words = 1u << (sum_log2 - 5u), sum_entries = (sum_words + 3u) / 4u;
-            static const bool no_sum = [] { const char* e = std::getenv("VPT_TAG_NO_SUMMARY"); return e && std::atoi(e) != 0; }();   // (A/B; read once per process)
-            const bool sum = !no_sum && P.queue_slow >= 2u * sum_entries + 64u;
+#ifdef VPT_TAG_NO_SUMMARY   // (A/B builds: the same geometry without the summary.  A build switch, not an environment variable: nothing on the launch path calls getenv)
+            const bool sum = false;
+#else
+            const bool sum = P.queue_slow >= 2u * sum_entries + 64u;
+#endif
             TagParams F = P;
             const uint32_t* summary = nullptr;
             if (sum) {
