@@ -227,7 +227,7 @@ class Runner:
         p0 = api.Predictor(api.Model.read_slice(raw)[0], tags, device=self.local_rank) if self.rank == 0 else None
         create_s = time.perf_counter() - t
         t = time.perf_counter()
-        pred = vdist.broadcast_predictor(p0, src=0, device=self.dev, model_bytes=raw, predict_tags=tags)
+        pred = vdist.broadcast_predictor(p0, src=0, device=self.dev, model_bytes=raw)
         self.tables_broadcast = getattr(pred, "tables_broadcast", None)   # view / staged / compile: which way the tables took (dist.py)
         if self.world > 1:
             self.torch.cuda.synchronize()
@@ -862,6 +862,7 @@ def run_in_process(args, reason: str) -> int:
                    "launch": "in-process fallback: one process, vpt_predictor_clone_to_device (hipMemcpyPeer) to %d device(s), one host thread + stream "
                              "per device (%s)%s" % (N, reason, "; VPT_BENCH_ONE_DEVICE: every shard on device 0" if one_dev else "")},
         "parity": parity, "roofline": roof, "cpu_baseline": cpu,
+        "dist_failure": reason,      # top level: this line is NOT the N-rank RCCL job the caller asked for
     }
     print(json.dumps(line))
     sys.stdout.flush()
@@ -937,6 +938,29 @@ def scale_sweep(args) -> int:
     return 1 if failures else 0
 
 
+def is_dist_error(e: BaseException) -> bool:
+    """A failure of the collective layer (RCCL / gloo / the store), as opposed to a failure of the job itself."""
+    import torch.distributed as dist
+    kinds = tuple(k for k in (getattr(dist, "DistError", None), getattr(dist, "DistBackendError", None), getattr(dist, "DistNetworkError", None),
+                              getattr(dist, "DistStoreError", None)) if k is not None) + (TimeoutError, ConnectionError)
+    if isinstance(e, kinds):
+        return True
+    text = str(e)
+    return isinstance(e, RuntimeError) and any(w in text for w in ("NCCL", "RCCL", "ProcessGroup", "c10d", "Gloo", "gloo", "collective", "Timed out", "timed out"))
+
+
+def teardown_process_group(dist) -> None:
+    """Leave the process group without waiting for collectives that will never finish (abort where torch has it, destroy otherwise)."""
+    try:
+        abort = getattr(dist.distributed_c10d, "_abort_process_group", None)
+        if abort is not None:
+            abort()
+        else:
+            dist.destroy_process_group()
+    except Exception as e2:   # noqa: BLE001 -- already on the way out
+        sys.stderr.write("bench.py: leaving the process group: %s\n" % e2)
+
+
 def main():
     args = parse_args()
     if args.scale_sweep or args.dry_scale:
@@ -953,11 +977,13 @@ def main():
         prim = R.run(primary_id, primary=True, e2e_leg=(primary_id == 1))
     except Exception as e:   # noqa: BLE001
         # A collective that fails AFTER the process group came up (a fabric error in the tables' broadcast, a rank that died: the others time out
-        # after 300 s) must not cost the line either: same way out as a failed init.  One rank alone (N = 1) has nothing to fall back to.
-        if R.world == 1 or os.environ.get("VPT_BENCH_NO_FALLBACK"):
+        # after 300 s) must not cost the line either: same way out as a failed init -- but ONLY for a failure of torch.distributed.  Anything
+        # else (out of memory, an API error, a bug in this file) is a failure of the job: every rank exits non-zero and no line is printed.
+        if R.world == 1 or os.environ.get("VPT_BENCH_NO_FALLBACK") or not is_dist_error(e):
             raise
         import traceback
         sys.stderr.write("bench.py: rank %d: the %d-rank job failed: %s\n%s" % (R.rank, R.world, e, traceback.format_exc()))
+        teardown_process_group(R.dist)       # ranks still inside a collective let go of their devices before rank 0 times kernels on them
         if R.rank != 0:
             raise SystemExit(0)
         raise SystemExit(run_in_process(args, "the %d-rank torch.distributed job failed on rank 0: %s: %s" % (R.world, type(e).__name__, str(e).replace("\n", " ")[:200])))

@@ -31,15 +31,23 @@ devmem.EMULATED = True
 rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
 os.environ["VPT_CHUNK_CHARS"] = "4000"                              # the pipelined host path, several chunks per shard (read when a predictor is made)
 dist.init_process_group("gloo", rank=rank, world_size=world)
-m = randmodel.rand_model(31, alphabet="kana", wc=3, wt=3, n_char=150, n_dict=150, max_word=9)
+m = randmodel.rand_model(31, alphabet="kana", wc=3, wt=3, n_char=150, n_dict=150, max_word=9, n_tag_models=12)
 raw0 = encode_model(m) if rank == 0 else None
 raw = vdist.broadcast_model_bytes(raw0, src=0)                      # the model file (kept: checked below)
-pred0 = api.Predictor(api.Model.read_slice(raw)[0], False) if rank == 0 else None
+pred0 = api.Predictor(api.Model.read_slice(raw)[0], True) if rank == 0 else None     # predict_tags: only src knows (it travels in the header)
 if os.environ.get("VPT_TEST_BREAK_VIEW") and rank == 0:                    # as if torch could not view the library's device memory
     vdist._DeviceBytes = None
     import numpy.ctypeslib as _ncl
     _ncl.as_array = lambda *a, **k: (_ for _ in ()).throw(RuntimeError("no view of foreign memory"))
+if os.environ.get("VPT_TEST_BREAK_ADOPT") and rank == 1:                   # a failure only ONE rank sees, after the collectives of the view path
+    _real = _lib.load()
+    class _NoAdopt:
+        def __getattr__(self, k):
+            return (lambda *a: _lib.VPT_RUNTIME_ERROR) if k == "vpt_predictor_adopt_device" else getattr(_real, k)
+    _lib._lib = _NoAdopt()
 pred = vdist.broadcast_predictor(pred0, src=0, device=torch.device("cpu"), model_bytes=raw)   # the COMPILED tables; rank 1 compiles nothing (but on the last path)
+if os.environ.get("VPT_TEST_BREAK_ADOPT") and rank == 1:
+    _lib._lib = _real
 open(os.path.join({out!r}, "path%d.txt" % rank), "w").write(str(pred.tables_broadcast))
 texts = randmodel.rand_sentences(9, m, 900, alphabet="kana", max_len=150)    # every rank builds the same batch
 texts = [t if i % 3 else "abc de" * (1 + i % 20) for i, t in enumerate(texts)]   # mixed 1- and 3-byte chars
@@ -83,11 +91,13 @@ def test_shard_bounds_balance_and_cover():
 import pytest
 
 
-@pytest.mark.parametrize("path", ["view", "staged", "compile", "view-breaks"])
+@pytest.mark.parametrize("path", ["view", "staged", "compile", "view-breaks", "adopt-breaks"])
 def test_two_rank_gloo_broadcast_shard_and_reduce(tmp_path, path):
     """... over every way the compiled tables can travel (dist.broadcast_predictor; VERDICT r4 item 5: the first 8-GPU run must not trip):
     the zero-copy view of the library's memory, the compiled form staged through torch-owned memory, every rank compiling for itself --
-    each forced by VPT_TABLES_BROADCAST -- and a view that fails on rank 0, which every rank then answers with the staged path."""
+    each forced by VPT_TABLES_BROADCAST -- a view that fails on rank 0, which every rank then answers with the staged path, and an adopt
+    that fails on rank 1 ALONE: the ranks agree (all_reduce MIN) before leaving the view path, so rank 0 goes to the staged
+    path with it instead of returning.  The compile path builds rank 1's predictor with rank 0's predict_tags, which only the header carries."""
     from tests import emu
     emu.build_emulated()        # once, before the ranks race for it
     port = _free_port()
@@ -99,18 +109,20 @@ def test_two_rank_gloo_broadcast_shard_and_reduce(tmp_path, path):
                    LOCAL_RANK=str(rank))
         if path == "view-breaks":
             env["VPT_TEST_BREAK_VIEW"] = "1"
+        elif path == "adopt-breaks":
+            env["VPT_TEST_BREAK_ADOPT"] = "1"
         else:
             env["VPT_TABLES_BROADCAST"] = path
         procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
     outs = [p.communicate(timeout=600)[0].decode() for p in procs]
     assert all(p.returncode == 0 for p in procs), "\n".join(outs)
     paths = [open(tmp_path / ("path%d.txt" % k)).read() for k in range(2)]
-    if path == "view-breaks":
+    if path in ("view-breaks", "adopt-breaks"):
         assert all(x.startswith("staged (after: view:") for x in paths), paths
     else:
         assert paths == [path, path], paths
 
-    m = randmodel.rand_model(31, alphabet="kana", wc=3, wt=3, n_char=150, n_dict=150, max_word=9)
+    m = randmodel.rand_model(31, alphabet="kana", wc=3, wt=3, n_char=150, n_dict=150, max_word=9, n_tag_models=12)
     raw = encode_model(m)
     texts = randmodel.rand_sentences(9, m, 900, alphabet="kana", max_len=150)
     texts = [t if i % 3 else "abc de" * (1 + i % 20) for i, t in enumerate(texts)]
@@ -121,6 +133,7 @@ def test_two_rank_gloo_broadcast_shard_and_reduce(tmp_path, path):
     want = np.frombuffer(hashlib.sha256(raw).digest(), dtype=np.uint8)
     assert np.array_equal(r[0]["sha"], want) and np.array_equal(r[1]["sha"], want)      # broadcast delivered the model
     assert r[0]["info"].tolist() == r[1]["info"].tolist()                                # ... and the compiled predictor
+    assert dict(r[1]["info"].tolist())["predict_tags"] == 1                               # ... with src's predict_tags, on the compile path too
     assert int(r[0]["first"]) == 0 and int(r[1]["first"]) == int(r[0]["n"]) and int(r[0]["n"]) + int(r[1]["n"]) == 900
     assert abs(int(r[0]["chars"]) - int(r[1]["chars"])) <= 2 * 150                       # balanced by characters
     assert np.array_equal(np.concatenate([r[0]["scores"], r[1]["scores"]]), full_scores)   # shards tile the batch

@@ -420,6 +420,19 @@ def test_non_bmp_pattern_models_use_the_general_tables():
     check_batch(pred, orc, randmodel.rand_sentences(3, m, 600, alphabet="mixed", max_len=70))
 
 
+def test_deep_arena_limit_falls_to_the_general_kernels(monkeypatch):
+    """a deep arena past the 22 bits the trigram node's child filter leaves a mini-table base is no InvalidModel error: the
+    general tables and kernels score the model (the reference accepts any dictionary, dict_model.rs:18-50)."""
+    m = randmodel.rand_model(5, alphabet="kana", wc=3, wt=3, n_char=60, n_dict=200, max_word=9)
+    monkeypatch.setenv("VPT_DEBUG_KIDS_MAX_BASE", "1")
+    pred, orc = make_predictor(m)
+    assert pred.info()["packed"] == 0
+    check_batch(pred, orc, randmodel.rand_sentences(8, m, 500, alphabet="kana", max_len=80))
+    monkeypatch.delenv("VPT_DEBUG_KIDS_MAX_BASE")
+    pred, orc = make_predictor(m)
+    assert pred.info()["packed"] == 1
+
+
 def test_non_bmp_and_ffff_alphabets_on_the_packed_path(monkeypatch):
     """Patterns made of chars outside the BMP only, U+FFFF / U+FFFE as pattern chars, a wide (outside-its-fields) unigram, bigram and
     trigram row that start with a non-BMP char (the replay from the general tables, which keep such a unigram with the short strings),

@@ -139,6 +139,18 @@ def test_packed_walk_sparse_rows_and_filters(tc):
     assert probes[3] > 0 and probes[1] > 0          # the filters rejected lookups, and admitted some
 
 
+def test_a_deep_arena_past_the_kid_filters_reach_is_refused_not_an_error(tc, monkeypatch):
+    """the 8-bit child filter leaves a mini-table base 22 bits; a model whose deep arena outgrows them (a NEologd-size dictionary
+    of long words) used to be an InvalidModel error -- the reference loads any such model (dict_model.rs:18-50).  It now falls to the
+    general tables (present = false) like the other limits of the format.  VPT_DEBUG_KIDS_MAX_BASE lowers the limit for the test."""
+    m = randmodel.rand_model(5, alphabet="kana", wc=3, wt=3, n_char=60, n_dict=200, max_word=9)
+    raw = encode_model(m)
+    assert Walker(tc, raw).packed and Walker(tc, raw).stats()["n_deep"] > 4
+    monkeypatch.setenv("VPT_DEBUG_KIDS_MAX_BASE", "1")
+    wk = Walker(tc, raw)            # no error ...
+    assert not wk.packed            # ... the general tables serve it (GPU parity: test_gpu_parity.py::test_deep_arena_limit_falls_to_the_general_kernels)
+
+
 def test_packed_eligibility(tc):
     base = dict(bias=3, char_window_size=3, type_window_size=3)
     # chars outside the BMP, U+FFFF and U+FFFE are pattern chars like any other (round 5): ids through the side table `xcid`

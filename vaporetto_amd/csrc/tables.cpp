@@ -321,6 +321,9 @@ HostPackedTable build_packed(const PatSet& S_in, int wl) {
     HostPackedTable t;
     t.wl = wl;
     const size_t udw = size_t(pk_uni_dw(wl)), bdw = size_t(pk_bi_dw(wl)), tdw = size_t(pk_tri_dw(wl));
+    // (tests lower the limit to reach the refusal without a 256 MB deep arena)
+    const char* kmb = std::getenv("VPT_DEBUG_KIDS_MAX_BASE");
+    const uint32_t kids_max_base = kmb ? std::min<uint32_t>(kTriKidsMaxBase, uint32_t(std::strtoul(kmb, nullptr, 10))) : kTriKidsMaxBase;
     // A pattern that holds U+0000 matches no text (a sentence with a NUL is an error, sentence.rs:174-179): it takes no part here (0 is
     // the tables' "outside the sentence").  `S` = the patterns that can match; the copy is made for such a model only.
     PatSet filtered;
@@ -628,7 +631,12 @@ HostPackedTable build_packed(const PatSet& S_in, int wl) {
             // the child filter (layout.h, "tri"): a mini-table entry is looked up by the FIRST symbol of a compressed chain, the child's own
             uint32_t filt = 0;
             for (uint32_t q = 0; q < n_kids(pkid[j]); ++q) filt |= 1u << packed_kid_filter_bit(nodes[kid(pkid[j], q)].sym);
-            if ((k.ref >> 5) >= kTriKidsMaxBase) throw ModelError("InvalidModelError: too many patterns for the packed tables");
+            if ((k.ref >> 5) >= kids_max_base) {   // the deep arena outgrew the 22 bits the child filter leaves its bases: the general tables serve the model
+                if (tm.on) std::fprintf(stderr, "[vpt compile] packed tables refused: a mini-table base past %u deep entries\n", kids_max_base);
+                HostPackedTable none;
+                none.wl = wl;
+                return none;
+            }
             e[0] = (pf.slot + 1) | (fl << kTriFlagShift) | ((filt >> 5) << 28);
             e[pk_tri_kids_dw(wl)] = k.ref | ((filt & 31u) << 27);
             ++t.n_tri;
