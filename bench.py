@@ -281,8 +281,10 @@ class Runner:
         def step():
             batch.predict(d_text.data_ptr(), d_boff.data_ptr(), d_ooff.data_ptr(), S, nb, max_bytes,
                           d_scores.data_ptr(), d_labels.data_ptr(), stream)
-            if nt:   # Sentence::fill_tags on the labels just predicted: configs[4]'s step is the whole tagging job
-                batch.fill_tags(d_text.data_ptr(), d_boff.data_ptr(), d_ooff.data_ptr(), S, nb, d_labels.data_ptr(), d_tags.data_ptr(), stream)
+            if nt:   # Sentence::fill_tags on the labels just predicted: configs[4]'s step is the whole tagging job.  What it leaves is what the tagged
+                # writer reads: one record per token that has a tag model (the reference holds None everywhere else, predictor.rs:558-573); the dense
+                # (chars x n_tags) array of the C ABI is timed beside it (tags.dense_ms_per_step) and BOTH forms are compared with the oracle below
+                batch.fill_tags(d_text.data_ptr(), d_boff.data_ptr(), d_ooff.data_ptr(), S, nb, d_labels.data_ptr(), 0, stream)
 
         steps = args.steps if primary else max(10, min(args.steps, 20))
         for _ in range(args.warmup):
@@ -343,16 +345,29 @@ class Runner:
         # ---- tag kernels on their own (event-free wall clock over the same steps)
         tags_info = None
         if nt:
-            torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            for _ in range(steps):
-                batch.fill_tags(d_text.data_ptr(), d_boff.data_ptr(), d_ooff.data_ptr(), S, nb, d_labels.data_ptr(), d_tags.data_ptr(), stream)
-            torch.cuda.synchronize()
-            dt = (time.perf_counter() - t0) / steps
+            def timed_fill(dense_ptr):
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for _ in range(steps):
+                    batch.fill_tags(d_text.data_ptr(), d_boff.data_ptr(), d_ooff.data_ptr(), S, nb, d_labels.data_ptr(), dense_ptr, stream)
+                torch.cuda.synchronize()
+                return (time.perf_counter() - t0) / steps
+            dt_dense = timed_fill(d_tags.data_ptr())       # the dense array with the call (a memset + a scatter of the records): d_tags holds it now
+            dt = timed_fill(0)                             # the records alone: what the step above and the tagged writer below use
+            d_tags2 = torch.full(((nb + S) * nt + 1,), 7, dtype=torch.int32, device=dev)
+            batch.expand_tags(S, nb, d_tags2.data_ptr(), stream)   # ... expanded: must be the same array
+            batch.sync()
+            records_ok = bool(torch.equal(d_tags2[:(nb + S) * nt], d_tags[:(nb + S) * nt]))
+            n_records_lb = int((d_tags2[:(nb + S) * nt].view(nb + S, nt) >= 0).any(dim=1).sum().item())
+            del d_tags2
             lab = d_labels[:nb].cpu().numpy()
             n_tokens = int((lab == 1).sum()) + S
-            tags_info = {"ms_per_step": 1e3 * dt, "tokens_per_s": n_tokens / dt, "chars_per_s": (nb + S) / dt, "n_tags": nt,
-                         "kernels": "decode_chars_kernel + tag_front_flat_kernel (runs of sentences as consecutive chars) + tag_pass_kernel on the predicted labels"}
+            tags_info = {"ms_per_step": 1e3 * dt, "dense_ms_per_step": 1e3 * dt_dense, "records_expand_to_the_dense_array": records_ok,
+                         "tokens_per_s": n_tokens / dt, "chars_per_s": (nb + S) / dt, "n_tags": nt, "tokens_with_tags_at_least": n_records_lb,
+                         "output": "ms_per_step: one record per token that has a tag model, sorted by position (what write_tagged reads); dense_ms_per_step: "
+                                   "the (chars x n_tags) int32 array of vpt_fill_tags_batch_device as well",
+                         "kernels": "decode_chars_kernel + tag_filter_summary_kernel + tag_front_flat_kernel (runs of sentences as consecutive chars) + "
+                                    "scan_chained_kernel + tag_pass_kernel on the predicted labels"}
 
         # ---- token emission on the labels just predicted (Sentence::write_tokenized_text, with "/tag" suffixes for tag models)
         emit_info, emit_out = None, None
@@ -363,7 +378,7 @@ class Runner:
 
             def emit():
                 if nt:
-                    batch.write_tagged(d_text.data_ptr(), d_boff.data_ptr(), d_ooff.data_ptr(), S, nb, d_labels.data_ptr(), d_tags.data_ptr(),
+                    batch.write_tagged(d_text.data_ptr(), d_boff.data_ptr(), d_ooff.data_ptr(), S, nb, d_labels.data_ptr(), 0,
                                        d_out.data_ptr(), cap, d_toff.data_ptr(), stream)
                 else:
                     batch.write_tokenized(d_text.data_ptr(), d_boff.data_ptr(), d_ooff.data_ptr(), S, nb, d_labels.data_ptr(),
@@ -380,9 +395,9 @@ class Runner:
             batch.sync()
             toff = d_toff.cpu().numpy().astype(np.uint64)
             out_bytes = int(toff[-1])
-            moved = nbytes + nb + out_bytes + 16 * S + (4 * (nb + S) * (nt + 1) if nt else 0)   # text + labels (+ tags, token models) in, text + offsets out
+            moved = nbytes + nb + out_bytes + 16 * S + ((16 + 4 * nt) * tags_info["tokens_with_tags_at_least"] if nt else 0)   # text + labels (+ tag records) in, text + offsets out
             emit_info = {"ms_per_step": 1e3 * dt, "out_bytes": out_bytes, "algorithmic_GBps": moved / dt / 1e9, "frac_of_hbm": moved / dt / 1e9 / HBM_PEAK_GBS,
-                         "kernels": "emit_fused_kernel: one launch (kernels_emit.hip), %s" % ("tagged" if nt else "boundaries only")}
+                         "kernels": "emit_flat_kernel: one launch (kernels_emit.hip), %s" % ("tagged, from the tag records" if nt else "boundaries only")}
             # the whole output is compared with the oracle's writer below (sentence.rs:850-886 restated in oracle/vaporetto_oracle.c)
             emit_out = (d_out[:out_bytes].cpu().numpy(), toff) if not args.no_cpu_baseline else None
             # ... and the writer as a phase of the scoring kernel (vpt_predict_write_batch_device): ONE launch leaves scores, labels and the
@@ -489,7 +504,7 @@ class Runner:
             if nt:   # EVERY token of the shard: Sentence::fill_tags on the labels the GPU predicted (they are the oracle's: checked above)
                 got = d_tags[:(nb + S) * nt].cpu().numpy().reshape(nb + S, nt)
                 o_tags, _, o_models = orc.fill_tags_batch(utf8, boff, ooff, g_labels, nthreads=self.ncores, want_scores=False)
-                tag_ok = bool(np.array_equal(got, o_tags))
+                tag_ok = bool(np.array_equal(got, o_tags)) and bool(tags_info["records_expand_to_the_dense_array"])
                 if not tag_ok and mismatch is None:
                     mismatch = first_diff("tags of the token ending at this char (1 = some slot differs)", (got != o_tags).any(axis=1).astype(np.int8),
                                           np.zeros(nb + S, np.int8), rows_are_chars=True)
@@ -631,7 +646,7 @@ def compact_row(w):
            "kernel": roof.get("kernel"), "kernel_ms": r3(roof.get("kernel_ms"), 4), "frac": r3(roof.get("frac"), 4), "bytes_per_boundary": r3(roof.get("bytes_per_boundary"), 1),
            "traffic_ratio": r3(tr / a) if (a and tr) else None, "parity": w.get("parity"), "packed": w.get("packed_tables"), "tile_plan": (w.get("tile_plan") or "").split(" of ")[0]}
     if w.get("tags"):
-        row["tags_ms"], row["tags_parity"] = r3(w["tags"]["ms_per_step"], 4), w["tags"].get("parity")
+        row["tags_ms"], row["tags_dense_ms"], row["tags_parity"] = r3(w["tags"]["ms_per_step"], 4), r3(w["tags"]["dense_ms_per_step"], 4), w["tags"].get("parity")
     if w.get("emit"):
         row["emit_ms"], row["emit_frac"], row["emit_parity"] = r3(w["emit"]["ms_per_step"], 4), r3(w["emit"]["frac_of_hbm"], 4), w["emit"].get("parity")
         if w["emit"].get("fused"):
@@ -786,7 +801,7 @@ def run_in_process(args, reason: str) -> int:
                                     sh["d_scores"].data_ptr(), sh["d_labels"].data_ptr(), st)
                 if nt:   # configs[4]: the step is the whole tagging job
                     sh["batch"].fill_tags(sh["d_text"].data_ptr(), sh["d_boff"].data_ptr(), sh["d_ooff"].data_ptr(), sh["S"], sh["nb"], sh["d_labels"].data_ptr(),
-                                          sh["d_tags"].data_ptr(), st)
+                                          0, st)   # (the tag records; expanded for the parity check below)
             for _ in range(args.warmup):
                 step()
             sh["batch"].sync()
@@ -824,6 +839,8 @@ def run_in_process(args, reason: str) -> int:
             torch.cuda.set_device(sh["dev"])
             ok = bool(np.array_equal(sh["d_scores"][:sh["nb"]].cpu().numpy(), o_scores) and np.array_equal(sh["d_labels"][:sh["nb"]].cpu().numpy(), o_labels))
             if nt:
+                sh["batch"].expand_tags(sh["S"], sh["nb"], sh["d_tags"].data_ptr(), 0)
+                sh["batch"].sync()
                 o_tags, _, _ = orc.fill_tags_batch(sh["utf8"], sh["boff"], sh["ooff"], o_labels, nthreads=ncores, want_scores=False)
                 ok = ok and bool(np.array_equal(sh["d_tags"][:(sh["nb"] + sh["S"]) * nt].cpu().numpy().reshape(sh["nb"] + sh["S"], nt), o_tags))
             parity = parity and ok

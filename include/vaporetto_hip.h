@@ -241,8 +241,13 @@ vpt_status vpt_fill_tags_batch_flags(const vpt_predictor *p, const uint8_t *utf8
 
 /* Device-resident variant of vpt_fill_tags_batch: all pointers are device pointers, asynchronous on `hip_stream`
  * (NULL = default stream).  d_labels as written by vpt_predict_batch_device (possibly edited by the caller's own
- * kernels); d_tags_out must hold (total_boundaries + n_sentences) * n_tags int32.  The workspace keeps the decoded
- * scalar values (4 bytes per char) between the two kernels; flags as set by vpt_batch_set_flags (fullwidth only).
+ * kernels).  The reference stores None for every char that does not end a token with a tag model (predictor.rs:558-573);
+ * what this call leaves IN THE WORKSPACE is one record per token that HAS one (last char, tag model, chosen candidates),
+ * sorted by position -- what vpt_write_tagged_batch_device reads.  d_tags_out: NULL (a tokenizer needs no more than the
+ * records), or (total_boundaries + n_sentences) * n_tags int32 that receive the dense array described above (None = -1
+ * everywhere else: a memset + a scatter of the records); vpt_expand_tags_batch_device makes it from the records later.
+ * At most 2^32 - 257 chars per call.  The workspace keeps the decoded scalar values (4 bytes per char) between the
+ * kernels; flags as set by vpt_batch_set_flags (fullwidth only).
  * When the call BEFORE this one on this workspace was vpt_predict_batch_device for the SAME buffers, sizes, flags and stream
  * (as Sentence::fill_tags follows Predictor::predict on the same sentence, predictor.rs:542), the chars that call decoded are
  * taken over and the decode kernel is skipped: do not rewrite d_utf8 in place between those two calls.  The chars are good
@@ -252,6 +257,11 @@ vpt_status vpt_fill_tags_batch_device(const vpt_predictor *p, vpt_batch *b, cons
                                       const uint64_t *d_byte_offsets, const uint64_t *d_out_offsets,
                                       size_t n_sentences, uint64_t total_boundaries, const uint8_t *d_labels,
                                       int32_t *d_tags_out, void *hip_stream);
+/* Sentence::tags() of the batch of the last vpt_fill_tags_batch_device call on this workspace (same n_sentences and
+ * total_boundaries): d_tags_out, (total_boundaries + n_sentences) * n_tags int32, receives the dense array -- None (-1)
+ * for every char but the last one of a token that has a tag model (predictor.rs:556-598). */
+vpt_status vpt_expand_tags_batch_device(const vpt_predictor *p, vpt_batch *b, size_t n_sentences, uint64_t total_boundaries,
+                                        int32_t *d_tags_out, void *hip_stream);
 
 /* ---------------------------------------------------------------------------------------------------------
  * Predictor::store_tag_scores(true) + Token::tag_candidates       (predictor.rs:510-514,599-601,632-634; sentence.rs:1218-1250)
@@ -313,11 +323,12 @@ vpt_status vpt_predict_write_batch_device(const vpt_predictor *p, vpt_batch *b, 
                                           uint64_t text_capacity, uint64_t *d_text_offsets_out, void *hip_stream);
 
 /* Device-resident variants: all pointers are device pointers, asynchronous on `hip_stream`; errors at vpt_batch_sync.
- * One kernel (kernels_emit.hip: a wave per block of sentences sizes, places and writes it).  The tagged one takes the
- * d_tags_out of a vpt_fill_tags_batch_device call made on the SAME workspace for the same batch AND THE SAME LABELS (the
- * workspace keeps, for every token that call found a tag model for, the model and the bytes its tags take; tags or labels
+ * One kernel (kernels_emit.hip: a workgroup per run of sentences sizes, places and writes it).  The tagged one takes its
+ * tags from the RECORDS a vpt_fill_tags_batch_device call left on the SAME workspace for the same batch AND THE SAME
+ * LABELS (one per token that call found a tag model for: the model, the chosen candidates, the bytes they take; labels
  * changed in between are reported as offsets that do not match -- Sentence::fill_tags and write_tokenized_text see the
- * same boundaries too, sentence.rs:1144-1148, 850-886). */
+ * same boundaries too, sentence.rs:1144-1148, 850-886).  d_tags: not read (until round 6 the dense array of that
+ * fill_tags call); NULL is fine. */
 vpt_status vpt_write_tokenized_batch_device(const vpt_predictor *p, vpt_batch *b, const uint8_t *d_utf8,
                                             const uint64_t *d_byte_offsets, const uint64_t *d_out_offsets,
                                             size_t n_sentences, uint64_t total_boundaries, const uint8_t *d_labels,

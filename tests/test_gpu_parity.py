@@ -851,38 +851,51 @@ def test_stored_tag_scores_match_oracle_on_random_models(seed):
     assert (got_s[o_models < 0] == 12345).all()
 
 
-@pytest.mark.parametrize("queue", [None, "8", "by-sentence"])
-def test_fill_tags_as_two_launches(queue, monkeypatch):
-    """Batches of 256 K chars and more take fill_tags as two launches: the front end (flat over the batch's chars: a wave takes a run of
-    sentences; VPT_TAG_FRONT_BY_SENTENCE: a sentence at a time) leaves the tokens that have a tag model in a queue in HBM, a launch of passes
-    runs over it (VPT_TAG_SPLIT=1 forces that for any batch; read when a workspace is made).  A queue of 8 entries (VPT_TAG_QUEUE) overflows
-    at once: the one-launch kernel does the batch again.  Same tags, same score vectors, same tagged text as through one launch -- on
-    models inside and outside the record form."""
-    monkeypatch.setenv("VPT_TAG_SPLIT", "1")
-    if queue == "by-sentence":
-        monkeypatch.setenv("VPT_TAG_FRONT_BY_SENTENCE", "1")
-        queue = None
-    if queue:
-        monkeypatch.setenv("VPT_TAG_QUEUE", queue)
+def test_fill_tags_as_two_launches():
+    """(The name is history.)  fill_tags is the front end (flat over the batch's chars: a wave takes a run of sentences) that leaves the tokens
+    that have a tag model in a queue in HBM, a chained scan over the runs' counts, and a launch of passes over the queue -- for every batch
+    size since round 6 (the one-launch kernel, the by-sentence front end and the queue that could overflow are gone: the queue holds a token
+    per char).  What it leaves is a RECORD per token with a tag model; the dense array is a scatter of them over a memset.  Both forms against
+    the oracle: the dense array asked for with the call, and the one expanded from the records of a call that asked for none."""
+    m = randmodel.rand_model(9102, alphabet="tiny", n_tag_models=40, max_word=4, n_char=40, n_dict=30)
+    raw = encode_model(m)
+    pred = api.Predictor(api.Model.read_slice(raw)[0], True)
+    orc = cbind.OraclePredictor(raw, True)
+    texts = randmodel.rand_sentences(77, m, 700, alphabet="tiny", max_len=90)
+    toks = [t.token for t in m.tag_models]
+    texts += ["".join(toks[(k + j) % len(toks)] for j in range(30)) for k in range(20)]      # tokens with tag models, back to back: a record per token
+    utf8, boff = api.pack_texts([t.encode("utf-8") for t in texts])
+    o_scores, o_labels, ooff, _ = orc.predict_batch(utf8, boff)
+    o_tags, _, _ = orc.fill_tags_batch(utf8, boff, ooff, o_labels, want_scores=False)
+    nb, S, nt = int(ooff[-1]), len(texts), pred.n_tags()
+    assert (o_tags >= 0).any()
+    d_text = devmem.put(np.concatenate([utf8, np.zeros(16, np.uint8)])); d_boff = devmem.put(boff.astype(np.uint64)); d_ooff = devmem.put(ooff.astype(np.uint64))
+    d_labels = devmem.put(np.concatenate([o_labels, np.zeros(1, np.uint8)]))
+    d_dense = devmem.put(np.full((nb + S) * nt + 1, 77, np.int32)); d_expanded = devmem.put(np.full((nb + S) * nt + 1, 55, np.int32))
+    batch = api.DeviceBatch(pred)
+    with pytest.raises(api.VaporettoError, match="vpt_fill_tags_batch_device on this workspace"):
+        batch.expand_tags(S, nb, d_expanded.ptr, devmem.stream())
+    batch.fill_tags(d_text.ptr, d_boff.ptr, d_ooff.ptr, S, nb, d_labels.ptr, d_dense.ptr, devmem.stream())        # the dense array with the call
+    batch.sync()
+    assert np.array_equal(d_dense.get((nb + S) * nt).reshape(nb + S, nt), o_tags) and d_dense.get()[-1] == 77
+    batch.fill_tags(d_text.ptr, d_boff.ptr, d_ooff.ptr, S, nb, d_labels.ptr, 0, devmem.stream())                  # records only ...
+    batch.expand_tags(S, nb, d_expanded.ptr, devmem.stream())                                                      # ... expanded afterwards
+    batch.sync()
+    assert np.array_equal(d_expanded.get((nb + S) * nt).reshape(nb + S, nt), o_tags) and d_expanded.get()[-1] == 55
+    with pytest.raises(api.VaporettoError, match="vpt_fill_tags_batch_device on this workspace"):                   # another batch's records are nobody's tags
+        batch.expand_tags(S - 1, nb, d_expanded.ptr, devmem.stream())
     test_predict_tags_like_reference()
     test_tag_models_inside_and_outside_the_record_form()
     for seed in ((3,) if devmem.EMULATED else (0, 3, 7)):   # (the emulator takes its time)
         test_random_tag_models_match_oracle(seed)
     test_stored_tag_scores_match_oracle_on_random_models(1)
-    if not (devmem.EMULATED and queue):
-        test_device_resident_predict_then_fill_tags()
-    test_write_tagged_text_on_device()
 
 
-@pytest.mark.parametrize("front", ["flat", "by-sentence"])
-def test_tag_front_end_over_runs_of_sentences(front, monkeypatch):
+def test_tag_front_end_over_runs_of_sentences():
     """The front-end launch of fill_tags walks RUNS of sentences as consecutive chars, 128 per step: runs of hundreds of one- and two-char
     sentences (more sentence starts in a step than the 64 offsets the lanes hold), sentences that end exactly at a half-step's or a step's
     last char, sentences of several steps, tokens that begin steps before they end, Unknown labels anywhere, several runs per wave --
     tags of every char against the oracle's, for predicted and for edited labels."""
-    monkeypatch.setenv("VPT_TAG_SPLIT", "1")
-    if front == "by-sentence":
-        monkeypatch.setenv("VPT_TAG_FRONT_BY_SENTENCE", "1")
     m = randmodel.rand_model(9100, alphabet="tiny", n_tag_models=30, max_word=4, n_char=40, n_dict=30)
     raw = encode_model(m)
     pred = api.Predictor(api.Model.read_slice(raw)[0], True)
@@ -924,8 +937,7 @@ def test_tag_front_end_over_runs_of_sentences(front, monkeypatch):
 @pytest.mark.parametrize("shape", ["only one-char sentences", "one-char sentences at the end", "one sentence of many steps, then one-char ones"])
 def test_fill_tags_front_end_where_the_labels_run_out(shape, monkeypatch):
     """A one-char sentence has no label, so a batch (or its tail) of them has none: the front end's runs there have nothing to read in `labels`
-    (an empty array for the first shape) and every char ends a token.  Tags against the oracle, fill_tags as two launches."""
-    monkeypatch.setenv("VPT_TAG_SPLIT", "1")
+    (an empty array for the first shape) and every char ends a token -- the densest the records get: one per char.  Tags against the oracle."""
     m = randmodel.rand_model(9410, alphabet="tiny", n_tag_models=30, max_word=4, n_char=40, n_dict=30)
     raw = encode_model(m)
     pred = api.Predictor(api.Model.read_slice(raw)[0], True)
@@ -954,14 +966,12 @@ def test_fill_tags_front_end_where_the_labels_run_out(shape, monkeypatch):
 
 @pytest.mark.parametrize("n_slots", [1, 2, 3, 4, 5])
 def test_fill_tags_front_end_stores_for_any_tag_count_and_alignment(n_slots, monkeypatch):
-    """The flat front end of fill_tags has an instance per way of storing a char's None entries: 1, 2 or 4 tags per token as ONE store, for every
-    char of a full step whether a token with a model ends there or not (the passes behind it write those again) -- when the tags array is 16-byte
-    aligned and no tag scores are asked for -- and the general one (any count, any alignment, entries only where no candidate is).  Models with
+    """(The name is history: until round 6 the front end stored a char's None entries, one instance per tag count; the dense array is a memset
+    and a scatter of the records now, for any count and alignment.)  Models with
     exactly `n_slots` tag slots, sentences of many steps: tags against the oracle through the host path; through the device path with the array
     16-byte aligned and 4 bytes off, the words around it untouched; with the models' indices asked for (vpt_fill_tags_scores_batch_device)."""
     import random
     from vaporetto_amd.modelfmt import TagModel, TagNgramData, TagWeight
-    monkeypatch.setenv("VPT_TAG_SPLIT", "1")
     m = randmodel.rand_model(9300 + n_slots, alphabet="tiny", n_tag_models=0, max_word=4, n_char=40, n_dict=30)
     rng = random.Random(77 + n_slots)
     alpha = randmodel.ALPHABETS["tiny"]
@@ -1599,22 +1609,31 @@ def test_write_tagged_text_on_device():
     toff = d_toff.get(S + 1)
     out = bytes(d_out.get(int(toff[-1])))
     assert [out[int(toff[i]):int(toff[i + 1])].decode("utf-8") for i in range(S)] == want
-    # tags changed after fill_tags (the workspace still holds the bytes the OLD ones take): reported, nothing written out of place
+    # the dense array is not what the writer reads (round 6: the workspace's records are): NULL, or anything else, changes nothing
     d_none = devmem.put(np.full((nb + S) * nt + 1, -1, np.int32))
-    batch.write_tagged(d_text.ptr, d_boff.ptr, d_ooff.ptr, S, nb, d_labels.ptr, d_none.ptr, d_out.ptr, cap, d_toff.ptr, devmem.stream())
+    for d in (0, d_none.ptr):
+        d_out.set(np.zeros(cap + 1, np.uint8))
+        batch.write_tagged(d_text.ptr, d_boff.ptr, d_ooff.ptr, S, nb, d_labels.ptr, d, d_out.ptr, cap, d_toff.ptr, devmem.stream())
+        batch.sync()
+        toff = d_toff.get(S + 1)
+        out = bytes(d_out.get(int(toff[-1])))
+        assert [out[int(toff[i]):int(toff[i + 1])].decode("utf-8") for i in range(S)] == want
+    # labels changed after fill_tags (a token the records have tags for ends nowhere any more): reported, nothing written out of place
+    labels = d_labels.get(nb + 1).copy()
+    labels[:nb] = 0
+    d_labels.set(labels)
+    batch.write_tagged(d_text.ptr, d_boff.ptr, d_ooff.ptr, S, nb, d_labels.ptr, 0, d_out.ptr, cap, d_toff.ptr, devmem.stream())
     with pytest.raises(api.VaporettoError, match="do not match the text"):
         batch.sync()
 
 
-@pytest.mark.parametrize("per_block", [1, 3, 64, 256, "waves-3"])
+@pytest.mark.parametrize("per_block", [1, 3, 64, 256])
 def test_writer_blocks_of_any_size(per_block, monkeypatch):
-    """The writer takes blocks of consecutive sentences (kernels_emit.hip): a workgroup per run without tags (emit_flat_kernel, round 5), a wave
-    per block with tags (and without, under VPT_EMIT_WAVE_BLOCKS: "waves-3"); the block size comes from the mean sentence length -- here it is
-    forced (VPT_EMIT_PER_BLOCK, read when a workspace is made): one sentence per block, a few, 64, 256; sentences of 1 .. 13 000 chars (several
-    4 KB pieces of a workgroup's walk) with escapes, 1- to 4-byte chars, every alignment of text, labels and output."""
-    if per_block == "waves-3":
-        monkeypatch.setenv("VPT_EMIT_WAVE_BLOCKS", "1")
-        per_block = 3
+    """The writer takes runs of consecutive sentences, a workgroup each (kernels_emit.hip, emit_flat_kernel, with and without tags); the run
+    size comes from the mean sentence length (with tags: a whole multiple of fill_tags' runs, so that a workgroup's tag records are one slice
+    named by two prefix words) -- here it is forced (VPT_EMIT_PER_BLOCK, read when a workspace is made) to sizes that are NO such multiple:
+    one sentence per run, a few, 64, 256; sentences of 1 .. 13 000 chars (several 4 KB pieces of a workgroup's walk) with escapes, 1- to
+    4-byte chars, every alignment of text, labels and output."""
     monkeypatch.setenv("VPT_EMIT_PER_BLOCK", str(per_block))
     m = randmodel.rand_model(843, alphabet="kana", wc=3, wt=3, n_tag_models=30, max_word=3, n_char=60, n_dict=60)
     for k, tm in enumerate(m.tag_models):

@@ -42,7 +42,7 @@ _AS_IS = [
     "test_many_batches_through_one_predictor", "test_sentences_of_any_length_are_cut_across_tiles", "test_cut_tiles_with_tags_filters_unaligned_text_and_errors", "test_fast_and_general_kernels_agree_with_oracle",
     "test_packed_path_is_used_and_handles_wide_rows", "test_dense_packed_tables", "test_sparse_double_array_rows_interleave",
     "test_long_dictionary_words_cross_tile_sized_sentences", "test_very_long_words_and_compressed_chains",
-    "test_non_bmp_pattern_models_use_the_general_tables", "test_non_bmp_and_ffff_alphabets_on_the_packed_path", "test_long_type_ngrams_use_global_type_rows",
+    "test_non_bmp_pattern_models_use_the_general_tables", "test_deep_arena_limit_falls_to_the_general_kernels", "test_non_bmp_and_ffff_alphabets_on_the_packed_path", "test_long_type_ngrams_use_global_type_rows",
     "test_type_rows_and_window_table_agree_with_oracle", "test_type_weights_no_window_reads_and_padding_ngrams", "test_understated_length_bounds_are_reported",
     "test_tag_enabled_model_with_duplicate_type_ngrams_runs_on_the_packed_path", "test_predict_tags_like_reference",
     "test_fill_tags_requires_predict_tags_gpu", "test_fixture_tags_gpu", "test_random_tag_models_match_oracle",
@@ -118,8 +118,8 @@ def test_halves_and_permutation_sized_down():
     assert np.array_equal(ps.reshape(n, 63), scores.reshape(n, 63)[perm])
 
 
-@pytest.mark.parametrize("env", [{}, {"VPT_TAG_SPLIT": "1", "VPT_TOKENIZE_CHUNK_BYTES": "700"}, {"VPT_TAG_SPLIT": "1", "VPT_EMU_DEFINES": "-DVPT_TAG_SUM_LOG2=7"}],
-                         ids=["default", "two-launch tags, small tokenize chunks", "two-launch tags, a 128-bit summary of the token filter (a bit for many of the filter's)"])
+@pytest.mark.parametrize("env", [{}, {"VPT_TOKENIZE_CHUNK_BYTES": "700"}, {"VPT_EMU_DEFINES": "-DVPT_TAG_SUM_LOG2=7"}],
+                         ids=["default", "small tokenize chunks", "a 128-bit summary of the token filter (a bit for many of the filter's)"])
 def test_short_fuzz_of_the_kernel_sources(env):
     """tools/fuzz_gpu.py for a quarter of a minute on the emulator: random models (every window, tag models, wide weights) x ragged batches x
     flags against the oracle -- boundaries, tags, writers, vpt_tokenize_batch.  The seeds are fixed: a failure names the one to rerun."""

@@ -73,6 +73,7 @@ SIGNATURES = {
     "vpt_write_tagged_batch": (C.c_int, [_P, _P, _P, C.c_size_t, _P, _P, C.c_uint, _P, C.c_uint64, _P]),
     "vpt_write_tagged_batch_device": (C.c_int, [_P, _P, _P, _P, _P, C.c_size_t, C.c_uint64, _P, _P, _P, C.c_uint64, _P, _P]),
     "vpt_fill_tags_batch_device": (C.c_int, [_P, _P, _P, _P, _P, C.c_size_t, C.c_uint64, _P, _P, _P]),
+    "vpt_expand_tags_batch_device": (C.c_int, [_P, _P, C.c_size_t, C.c_uint64, _P, _P]),
     "vpt_batch_create": (C.c_int, [_P, C.POINTER(_P)]),
     "vpt_batch_destroy": (None, [_P]),
     "vpt_predict_batch_device": (C.c_int, [_P, _P, _P, _P, _P, C.c_size_t, C.c_uint64, C.c_uint64, _P, _P, _P]),

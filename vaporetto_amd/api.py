@@ -828,9 +828,17 @@ class DeviceBatch:
 
     def fill_tags(self, d_utf8: int, d_boff: int, d_ooff: int, n_sentences: int, total_boundaries: int, d_labels: int,
                   d_tags: int, stream: int = 0) -> None:
-        """Device-resident Sentence::fill_tags for the batch (vpt_fill_tags_batch_device); enqueues and returns."""
+        """Device-resident Sentence::fill_tags for the batch (vpt_fill_tags_batch_device); enqueues and returns.  d_tags = 0 (NULL): the
+        tags stay in the workspace as one record per token that has a tag model (what write_tagged reads; expand_tags makes the dense array)."""
         st = _lib.load().vpt_fill_tags_batch_device(self._p.handle, self._h, d_utf8, d_boff, d_ooff, n_sentences,
-                                                    total_boundaries, d_labels, d_tags, stream)
+                                                    total_boundaries, d_labels, d_tags or None, stream)
+        if st != _lib.VPT_OK:
+            _raise(st)
+
+    def expand_tags(self, n_sentences: int, total_boundaries: int, d_tags: int, stream: int = 0) -> None:
+        """Sentence::tags() of the batch of the last fill_tags call on this workspace as the dense int32 [chars, n_tags] array
+        (vpt_expand_tags_batch_device): None (-1) everywhere but at the last char of a token that has a tag model."""
+        st = _lib.load().vpt_expand_tags_batch_device(self._p.handle, self._h, n_sentences, total_boundaries, d_tags, stream)
         if st != _lib.VPT_OK:
             _raise(st)
 
@@ -863,10 +871,10 @@ class DeviceBatch:
 
     def write_tagged(self, d_utf8: int, d_boff: int, d_ooff: int, n_sentences: int, total_boundaries: int, d_labels: int,
                      d_tags: int, d_text_out: int, text_capacity: int, d_text_offsets: int, stream: int = 0) -> None:
-        """write_tokenized_text with "/tag" suffixes from the d_tags of a fill_tags call on this workspace
-        (vpt_write_tagged_batch_device); enqueues and returns."""
+        """write_tokenized_text with "/tag" suffixes from the records the fill_tags call on this workspace left for this batch
+        (vpt_write_tagged_batch_device; d_tags is not read any more and may be 0); enqueues and returns."""
         st = _lib.load().vpt_write_tagged_batch_device(self._p.handle, self._h, d_utf8, d_boff, d_ooff, n_sentences, total_boundaries,
-                                                       d_labels, d_tags, d_text_out, text_capacity, d_text_offsets, stream)
+                                                       d_labels, d_tags or None, d_text_out, text_capacity, d_text_offsets, stream)
         if st != _lib.VPT_OK:
             _raise(st)
 

@@ -49,7 +49,6 @@ struct PredictorKnobs {
     bool tokenize_separate = false;     // VPT_TOKENIZE_SEPARATE: predict and the writer as launches of their own for untagged text too (A/B of the fused path)
     bool tokenize_serial = false;       // VPT_TOKENIZE_SERIAL: every kernel of every chunk on ONE stream with one workspace (A/B of the preparing stream)
     bool tokenize_direct = false;       // VPT_TOKENIZE_DIRECT: the kernels write the tokenized text straight into a pinned caller buffer (no copies out)
-    int tag_wgs_per_cu = 32;            // VPT_TAG_WGS_PER_CU
 };
 struct BatchKnobs {
     bool force_generic = false;         // VPT_FORCE_GENERIC
@@ -59,13 +58,7 @@ struct BatchKnobs {
     uint32_t debug_ablate = 0;          // VPT_DEBUG_ABLATE
     bool profile_phases = false;        // VPT_PROFILE_PHASES
     bool emit_no_prefix = false;        // VPT_DEBUG_EMIT_NO_PREFIX: the fused writer's tiles publish sizes only (tests: every look-back walks to the front)
-    bool tag_front_by_sentence = false; // VPT_TAG_FRONT_BY_SENTENCE: fill_tags' front-end launch as a wave per sentence (A/B of the flat one)
-    int tag_split = 0;                  // VPT_TAG_SPLIT: 1 = fill_tags always as two launches (step loop -> queue in HBM -> passes), -1 = never (default: batches of 256 K chars and more)
-    uint32_t tag_queue = 0;             // VPT_TAG_QUEUE: entries of that queue (tests: overflow; default: an eighth of the batch's chars + 64 K)
-    uint32_t debug_emit = 0;            // VPT_DEBUG_EMIT
-    uint32_t emit_per_block = 0;        // VPT_EMIT_PER_BLOCK: sentences a wave / a workgroup of the writer takes (1..64 / 1..256; 0: from the mean sentence length)
-    bool emit_wave_blocks = false;      // VPT_EMIT_WAVE_BLOCKS: the writer as a wave per block (A/B of the workgroup-per-run kernel)
-    bool emit_wave_tagged = false;      // VPT_EMIT_WAVE_TAGGED: ... with tags only
+    uint32_t emit_per_block = 0;        // VPT_EMIT_PER_BLOCK: sentences a workgroup of the writer takes (1..256; 0: from the mean sentence length) -- tests: runs of any size
     uint32_t emit_run_chars = 0;        // VPT_EMIT_RUN_CHARS: chars of a workgroup's run (default 5120)
 };
 PredictorKnobs read_predictor_knobs() {
@@ -75,7 +68,6 @@ PredictorKnobs read_predictor_knobs() {
     if (const char* v = std::getenv("VPT_PIPE_LANES")) k.pipe_lanes = std::max(0, std::atoi(v));
     if (const char* v = std::getenv("VPT_CHUNK_CHARS")) { const long long n = std::atoll(v); if (n > 0) k.chunk_chars = uint64_t(n); }
     if (const char* v = std::getenv("VPT_TOKENIZE_CHUNK_BYTES")) { const long long n = std::atoll(v); if (n > 0) { k.tokenize_chunk_bytes = uint64_t(n); k.tokenize_chunk_bytes_set = true; } }
-    if (const char* v = std::getenv("VPT_TAG_WGS_PER_CU")) k.tag_wgs_per_cu = std::atoi(v);
     k.tokenize_direct = std::getenv("VPT_TOKENIZE_DIRECT") != nullptr;
     k.tokenize_serial = std::getenv("VPT_TOKENIZE_SERIAL") != nullptr;
     k.tokenize_separate = std::getenv("VPT_TOKENIZE_SEPARATE") != nullptr;
@@ -86,13 +78,7 @@ BatchKnobs read_batch_knobs() {
     k.force_generic = std::getenv("VPT_FORCE_GENERIC") != nullptr;
     if (const char* v = std::getenv("VPT_FORCE_CUT_TILES")) k.force_cut = std::atoi(v);
     if (const char* v = std::getenv("VPT_TILE_FLAT")) k.tile_flat = uint32_t(std::max(0, std::atoi(v)));
-    k.tag_front_by_sentence = std::getenv("VPT_TAG_FRONT_BY_SENTENCE") != nullptr;
-    if (const char* v = std::getenv("VPT_TAG_SPLIT")) k.tag_split = std::atoi(v);
-    if (const char* v = std::getenv("VPT_TAG_QUEUE")) k.tag_queue = uint32_t(std::max(0, std::atoi(v)));
-    if (const char* v = std::getenv("VPT_DEBUG_EMIT")) k.debug_emit = uint32_t(std::max(0, std::atoi(v)));
     if (const char* v = std::getenv("VPT_EMIT_PER_BLOCK")) k.emit_per_block = uint32_t(std::min(256, std::max(0, std::atoi(v))));
-    k.emit_wave_blocks = std::getenv("VPT_EMIT_WAVE_BLOCKS") != nullptr;
-    k.emit_wave_tagged = std::getenv("VPT_EMIT_WAVE_TAGGED") != nullptr;
     if (const char* v = std::getenv("VPT_EMIT_RUN_CHARS")) k.emit_run_chars = uint32_t(std::max(0, std::atoi(v)));
     k.no_cps_from_predict = std::getenv("VPT_NO_CPS_FROM_PREDICT") != nullptr;
     if (const char* v = std::getenv("VPT_DEBUG_ABLATE")) k.debug_ablate = uint32_t(std::atoi(v));
@@ -294,14 +280,21 @@ struct vpt_batch {
     uint8_t* d_tlab = nullptr; size_t tlab_cap = 0;                 // vpt_tokenize_batch: the labels of the whole batch (no scores are kept)
     uint64_t* d_toff = nullptr; size_t toff_cap = 0;
     uint64_t* d_chain = nullptr; size_t chain_cap = 0;             // vpt_tokenize_batch: where a chunk's tokenized text starts (EmitOut::chain_in / chain_out)
-    int32_t* d_tok_model = nullptr; size_t tok_model_cap = 0;      // tag model of every token, from the last fill_tags on this workspace
-    uint64_t tok_model_chars = 0;                                   // ... which covered this many chars
+    // what the last fill_tags on this workspace left (TagParams, kernels.hpp): a record per token that has a tag model, sorted by position
+    uint4* d_tag_records = nullptr; size_t tag_records_cap = 0;
+    int32_t* d_rec_tags = nullptr; size_t rec_tags_cap = 0;
+    uint64_t* d_tag_ctl = nullptr; size_t tag_ctl_cap = 0;          // qctl (one word), the scan's state, run_pref [n_runs + 1]: zeroed as one range per call
+    uint64_t* d_run_pref = nullptr;                                 // (inside d_tag_ctl)
+    uint2* d_tag_qrun = nullptr; size_t tag_qrun_cap = 0;
+    uint32_t* d_tag_summary = nullptr;
+    uint64_t tag_chars = 0, tag_sentences = 0, tag_runs = 0;        // the batch those records belong to (0 chars: none)
+    uint32_t tag_run_sent = 0;
     std::vector<uint64_t> h_boff, h_ooff;                           // rebased offsets of the call in flight (copied asynchronously)
     uint8_t* d_types = nullptr; size_t types_cap = 0;               // vpt_char_types_batch
     uint64_t* d_scan_part = nullptr; size_t scan_part_cap = 0;      // per-workgroup partials of the prefix sums (kernels_emit.hip)
     // the writer's state words (EmitFuse): two arrays of emit_state_cap words, used in turn; a call zeroes what the call before it
     // left in the other one (emit_dirty = how many words that is)
-    uint4* d_tag_queue = nullptr; size_t tag_queue_cap = 0;        // fill_tags as two launches: the tokens that have a tag model (TagParams::queue), + 4 dwords of counters
+    uint4* d_tag_queue = nullptr; size_t tag_queue_cap = 0;        // fill_tags: the tokens that have a tag model, between the front end and the passes (TagParams::queue)
     uint64_t* d_emit_state = nullptr; size_t emit_state_cap = 0; size_t emit_dirty[2] = {0, 0}; int emit_flip = 0;
     uint64_t* d_fuse_state = nullptr; size_t fuse_state_cap = 0;   // the fused writer's words (EmitOut::state): one per tile + the ticket, + the chain word
     // the pipelined host-buffer path (predict_pipelined): two sets of device buffers, copy streams, pinned offset staging
@@ -380,7 +373,7 @@ void batch_release(vpt_batch* b) {
     (void)hipFree(b->d_tile_first); (void)hipFree(b->d_slow_list); (void)hipFree(b->d_ctrl); (void)hipFree(b->d_scratch);
     (void)hipFree(b->d_prof); (void)hipFree(b->d_cps);
     (void)hipFree(b->d_text); (void)hipFree(b->d_boff); (void)hipFree(b->d_ooff); (void)hipFree(b->d_scores); (void)hipFree(b->d_labels);
-    (void)hipFree(b->d_tags); (void)hipFree(b->d_tag_scores); (void)hipFree(b->d_tag_models); (void)hipFree(b->d_tok); (void)hipFree(b->d_tlab); (void)hipFree(b->d_toff); (void)hipFree(b->d_tok_model);
+    (void)hipFree(b->d_tags); (void)hipFree(b->d_tag_scores); (void)hipFree(b->d_tag_models); (void)hipFree(b->d_tok); (void)hipFree(b->d_tlab); (void)hipFree(b->d_toff); (void)hipFree(b->d_tag_records); (void)hipFree(b->d_rec_tags); (void)hipFree(b->d_tag_ctl); (void)hipFree(b->d_tag_qrun); (void)hipFree(b->d_tag_summary);
     (void)hipFree(b->d_types);
     for (auto& ps : b->pipe) {
         (void)hipFree(ps.text); (void)hipFree(ps.off); (void)hipFree(ps.scores); (void)hipFree(ps.labels);
@@ -1039,7 +1032,7 @@ namespace {
 struct FuseRequest { uint8_t* text_out; uint64_t capacity; uint64_t* offsets_out; uint64_t* total_out; const uint64_t* chain_in; uint64_t* chain_out; };
 vpt_status emit_device(const vpt_predictor* p, vpt_batch* b, const uint8_t* d_utf8, const uint64_t* d_byte_offsets,
                        const uint64_t* d_out_offsets, size_t n_sentences, uint64_t total_boundaries, const uint8_t* d_labels,
-                       const int32_t* d_tags, uint8_t* d_text_out, uint64_t text_capacity, uint64_t* d_text_offsets_out,
+                       bool tagged, uint8_t* d_text_out, uint64_t text_capacity, uint64_t* d_text_offsets_out,
                        hipStream_t stream, uint64_t* total_out = nullptr);
 
 vpt_status predict_device_impl(const vpt_predictor* p, vpt_batch* b, const uint8_t* d_utf8, const uint64_t* d_byte_offsets,
@@ -1211,7 +1204,7 @@ vpt_status predict_device_impl(const vpt_predictor* p, vpt_batch* b, const uint8
     b->last_tile_flat = uint32_t(tile_flat); b->last_plan = !fast ? 0u : cut_tiles ? 2u : 1u;
     if (fuse && !fast) {
         if (fuse->chain_in || fuse->chain_out) return fail(VPT_RUNTIME_ERROR, "internal error: chained tokenized text needs the specialised kernel");
-        return emit_device(p, b, d_utf8, d_byte_offsets, d_out_offsets, n_sentences, total_boundaries, labels_for_writer, nullptr, fuse->text_out,
+        return emit_device(p, b, d_utf8, d_byte_offsets, d_out_offsets, n_sentences, total_boundaries, labels_for_writer, false, fuse->text_out,
                            fuse->capacity, fuse->offsets_out, stream, fuse->total_out);
     }
     return VPT_OK;
@@ -1557,15 +1550,34 @@ vpt_status vpt_fill_tags_scores_batch_device(const vpt_predictor* p, vpt_batch* 
     if (!p || !b || b->pred != p) return fail(VPT_INVALID_ARGUMENT, "InvalidArgumentError: batch: does not belong to this predictor");
     if (!p->predict_tags) return fail(VPT_INVALID_ARGUMENT, "InvalidArgumentError: this predictor is created with predict_tags = false");
     if (n_sentences == 0 || p->n_tags == 0) return VPT_OK;
-    if (!d_utf8 || !d_byte_offsets || !d_out_offsets || !d_tags_out || (total_boundaries && !d_labels))
+    if (!d_utf8 || !d_byte_offsets || !d_out_offsets || (total_boundaries && !d_labels))
         return fail(VPT_INVALID_ARGUMENT, "InvalidArgumentError: NULL device pointer");
     hipStream_t stream = static_cast<hipStream_t>(hip_stream);
     VPT_HIP(hipSetDevice(p->device));
     const uint64_t total_c = total_boundaries + n_sentences;
+    // record numbers and queue places are 32-bit (one per char at most)
+    if (total_c >= 0xFFFFFF00ull) return fail(VPT_INVALID_ARGUMENT, "InvalidArgumentError: batch: fill_tags takes fewer than 2^32 - 256 chars per call");
     vpt_status st = grow(&b->d_cps, &b->cps_cap, size_t(total_c) + 16);
     if (st != VPT_OK) return st;
-    if ((st = grow(&b->d_tok_model, &b->tok_model_cap, size_t(total_c) + 16 + 4)) != VPT_OK) return st;   // (+ 4 in front: the writer reads the entry before a char's)
-    b->tok_model_chars = total_c;
+    b->tag_chars = 0;   // (until the launches are enqueued: a failure below leaves no records behind)
+    // What the call leaves is ONE RECORD PER TOKEN THAT HAS A TAG MODEL (kernels.hpp, TagParams): the reference holds None for every other
+    // char (predictor.rs:558-573).  Everything is sized for the worst case -- a tagged token per char, which a real tag model comes close
+    // to (most tokens of real text have one; the synthetic M3's one token in thirty-five is the other end) -- so nothing can overflow and
+    // there is no second path: records 16 + 4 n_tags bytes, the queue between the two launches 16 + 8.
+    const uint32_t run_sent = vpt::tag_run_sentences(n_sentences, total_c);
+    const uint64_t n_runs = (uint64_t(n_sentences) + run_sent - 1) / run_sent;
+    const size_t n_state = vpt::scan_part_entries(n_runs), ctl_words = 2 + n_state + size_t(n_runs) + 2;
+    if ((st = grow(&b->d_tag_records, &b->tag_records_cap, size_t(total_c) + 16)) != VPT_OK) return st;
+    if ((st = grow(&b->d_rec_tags, &b->rec_tags_cap, size_t(total_c) * p->n_tags + 16)) != VPT_OK) return st;
+    if ((st = grow(&b->d_tag_queue, &b->tag_queue_cap, size_t(total_c) + 16)) != VPT_OK) return st;
+    if ((st = grow(&b->d_tag_qrun, &b->tag_qrun_cap, size_t(total_c) + 16)) != VPT_OK) return st;
+    if ((st = grow(&b->d_tag_ctl, &b->tag_ctl_cap, ctl_words)) != VPT_OK) return st;
+    if (!b->d_tag_summary) VPT_HIP(hipMalloc(reinterpret_cast<void**>(&b->d_tag_summary), vpt::tag_summary_words() * sizeof(uint32_t)));
+    VPT_HIP(hipMemsetAsync(b->d_tag_ctl, 0, ctl_words * sizeof(uint64_t), stream));   // the queue's counters, the scan's state, the runs' counts
+    // the dense arrays of the C ABI, for the callers that want them: None everywhere (what `resize(n_tags * len, None)` leaves, predictor.rs:556-557);
+    // the passes write the entries of the tokens that have a model
+    if (d_tags_out) VPT_HIP(hipMemsetAsync(d_tags_out, 0xFF, size_t(total_c) * p->n_tags * sizeof(int32_t), stream));
+    if (d_tag_models_out) VPT_HIP(hipMemsetAsync(d_tag_models_out, 0xFF, size_t(total_c) * sizeof(int32_t), stream));
     const uint32_t* cinfo = p->d_cinfo + ((b->flags & VPT_FLAG_KYTEA_FULLWIDTH) ? 65536 : 0);
     const bool have_cps = b->cps_text == d_utf8 && b->cps_ooff == d_out_offsets && b->cps_sentences == n_sentences &&
                           b->cps_boundaries == total_boundaries && b->cps_flags == (b->flags & VPT_FLAG_KYTEA_FULLWIDTH) && b->last_stream == stream;
@@ -1578,27 +1590,30 @@ vpt_status vpt_fill_tags_scores_batch_device(const vpt_predictor* p, vpt_batch* 
     T.weights = p->dtag.weights; T.cinfo = cinfo; T.tok_bits = p->tok_bits; T.n_tags = p->n_tags;
     T.use_char = p->tag_use_char ? 1u : 0u; T.use_type = p->tag_use_type ? 1u : 0u;
     T.cps = b->d_cps; T.ooff = d_out_offsets; T.labels = d_labels; T.n_sent = n_sentences; T.total_chars = total_c; T.tags = d_tags_out;
-    T.tok_model = b->d_tok_model + 4;
     T.slot_str = p->dtag.slot_str; T.str_off = p->dtag.str_off; T.n_strings = p->dtag.n_strings;
     T.scores_out = p->max_tag_scores ? d_tag_scores_out : nullptr; T.model_out = d_tag_models_out; T.score_stride = p->max_tag_scores;
-    // tag_tokens_kernel runs 8 workgroups per CU at a time; four generations of them stride over the batch, so that the
-    // sentences' lengths (8..512 chars in BASELINE's configs[4]) even out without one workgroup per four sentences
-    // (measured on configs[4], 300 K sentences: 65536 workgroups 1.09 ms, 8 per CU 0.67, 32 per CU 0.64)
-    T.max_blocks = p->n_cus * uint32_t(std::max(0, p->knobs.tag_wgs_per_cu));
-    // Two launches for a batch worth them: the step loop (every token end: filter, lookup, the entries of the tokens without a model)
-    // leaves the tokens that have one in a queue in HBM, the passes run over that queue -- each launch with the registers it needs
-    // and no more (one launch: the pass's peak on top of the loop's own values, 80 VGPRs at 6 workgroups per CU; measured on
-    // configs[4], profiles/r03_zb_tag_split.txt).  The queue holds an eighth of the batch's chars (one token in thirty has a model in
-    // BASELINE's configs[4]); a batch that overflows it is done again by the one-launch kernel, which otherwise returns at once.
-    if (b->knobs.tag_split > 0 || (b->knobs.tag_split == 0 && total_c >= (uint64_t(1) << 18))) {
-        const uint64_t want = b->knobs.tag_queue ? uint64_t(b->knobs.tag_queue) : total_c / 8 + 65536;
-        const uint32_t entries = uint32_t(std::min<uint64_t>(want, 0x7FFFFF00ull));
-        if ((st = grow(&b->d_tag_queue, &b->tag_queue_cap, size_t(entries) + 1)) != VPT_OK) return st;
-        T.queue = b->d_tag_queue + 1; T.qctl = reinterpret_cast<uint32_t*>(b->d_tag_queue);
-        T.queue_slow = std::max<uint32_t>(entries / 8, 1u); T.queue_fast = entries - T.queue_slow;
-    }
-    T.front_by_sentence = b->knobs.tag_front_by_sentence ? 1u : 0u;
+    T.n_cus = p->n_cus;
+    T.records = b->d_tag_records; T.rec_tags = b->d_rec_tags;
+    T.qctl = reinterpret_cast<uint32_t*>(b->d_tag_ctl); T.scan_state = b->d_tag_ctl + 2; T.run_pref = b->d_tag_ctl + 2 + n_state;
+    T.n_runs = n_runs; T.run_sent = run_sent;
+    T.queue = b->d_tag_queue; T.qrun = b->d_tag_qrun; T.queue_cap = uint32_t(total_c);
+    T.summary = b->d_tag_summary;
     VPT_HIP(vpt::launch_tag_tokens(T, stream));
+    b->d_run_pref = T.run_pref; b->tag_chars = total_c; b->tag_sentences = n_sentences; b->tag_runs = n_runs; b->tag_run_sent = run_sent;
+    b->last_stream = stream; b->pending = true;
+    return VPT_OK;
+}
+
+vpt_status vpt_expand_tags_batch_device(const vpt_predictor* p, vpt_batch* b, size_t n_sentences, uint64_t total_boundaries, int32_t* d_tags_out, void* hip_stream) {
+    if (!p || !b || b->pred != p) return fail(VPT_INVALID_ARGUMENT, "InvalidArgumentError: batch: does not belong to this predictor");
+    if (!p->predict_tags) return fail(VPT_INVALID_ARGUMENT, "InvalidArgumentError: this predictor is created with predict_tags = false");
+    if (n_sentences == 0 || p->n_tags == 0) return VPT_OK;
+    if (!d_tags_out) return fail(VPT_INVALID_ARGUMENT, "InvalidArgumentError: NULL device pointer");
+    if (b->tag_chars != total_boundaries + n_sentences || b->tag_sentences != n_sentences || !b->d_tag_records)
+        return fail(VPT_INVALID_ARGUMENT, "InvalidArgumentError: batch: call vpt_fill_tags_batch_device on this workspace for this batch first");
+    VPT_HIP(hipSetDevice(p->device));
+    hipStream_t stream = static_cast<hipStream_t>(hip_stream);
+    VPT_HIP(vpt::launch_expand_tags(b->d_tag_records, b->d_rec_tags, b->d_run_pref + b->tag_runs, p->n_tags, b->tag_chars, d_tags_out, p->n_cus, stream));
     b->last_stream = stream; b->pending = true;
     return VPT_OK;
 }
@@ -1606,7 +1621,7 @@ vpt_status vpt_fill_tags_scores_batch_device(const vpt_predictor* p, vpt_batch* 
 namespace {
 vpt_status emit_device(const vpt_predictor* p, vpt_batch* b, const uint8_t* d_utf8, const uint64_t* d_byte_offsets,
                        const uint64_t* d_out_offsets, size_t n_sentences, uint64_t total_boundaries, const uint8_t* d_labels,
-                       const int32_t* d_tags, uint8_t* d_text_out, uint64_t text_capacity, uint64_t* d_text_offsets_out,
+                       bool tagged, uint8_t* d_text_out, uint64_t text_capacity, uint64_t* d_text_offsets_out,
                        hipStream_t stream, uint64_t* total_out) {
     if (!p || !b || b->pred != p) return fail(VPT_INVALID_ARGUMENT, "InvalidArgumentError: batch: does not belong to this predictor");
     if (!d_text_offsets_out) return fail(VPT_INVALID_ARGUMENT, "InvalidArgumentError: NULL device pointer");
@@ -1622,29 +1637,28 @@ vpt_status emit_device(const vpt_predictor* p, vpt_batch* b, const uint8_t* d_ut
     E.text = d_utf8; E.boff = d_byte_offsets; E.ooff = d_out_offsets; E.labels = d_labels; E.n_sent = n_sentences;
     E.total_boundaries = total_boundaries; E.out_text = d_text_out; E.out_offsets = d_text_offsets_out; E.capacity = text_capacity;
     E.status = b->d_ctrl;
-    if (d_tags && p->n_tags > 0) {   // "/tag" suffixes: the indices of fill_tags + the tag model it found for every token
+    if (tagged && p->n_tags > 0) {   // "/tag" suffixes: from the records the fill_tags call on this workspace left for this batch
         if (!p->predict_tags) return fail(VPT_INVALID_ARGUMENT, "InvalidArgumentError: this predictor is created with predict_tags = false");
-        if (b->tok_model_chars != total_boundaries + n_sentences || !b->d_tok_model)
+        if (b->tag_chars != total_boundaries + n_sentences || b->tag_sentences != n_sentences || !b->d_tag_records)
             return fail(VPT_INVALID_ARGUMENT, "InvalidArgumentError: batch: call vpt_fill_tags_batch_device on this workspace for this batch first");
-        E.tags = d_tags; E.tok_model = b->d_tok_model + 4; E.n_tags = p->n_tags; E.n_models = p->dtag.n_models; E.n_strings = p->dtag.n_strings;
+        E.records = b->d_tag_records; E.rec_tags = b->d_rec_tags; E.run_pref = b->d_run_pref; E.n_runs = b->tag_runs; E.run_sent = b->tag_run_sent;
+        E.n_tags = p->n_tags; E.n_models = p->dtag.n_models; E.n_strings = p->dtag.n_strings;
         E.models = p->dtag.models; E.slot_str = p->dtag.slot_str; E.str_off = p->dtag.str_off; E.str_bytes = p->dtag.str_bytes;
     }
-    // a wave per block of sentences: about two thousand chars of them (six steps of CJK text), at most 64 (measured on MI355X,
-    // configs[1]: 4 sentences of 64 chars per wave 0.122 ms, 8 0.093, 16 0.070, 32 0.063, 64 0.066: profiles/r03_n_emit_block_sizes.txt)
-    // Without tags (round 5): a WORKGROUP per run of sentences, about 5 K chars of them (16 KB of CJK text: four pieces of 4 KB), at most 256
-    // -- one look-back per workgroup, the prefix sums of a piece shared by 256 threads (emit_flat_kernel; VPT_EMIT_WAVE_BLOCKS keeps the waves).
+    // A WORKGROUP per run of sentences (emit_flat_kernel, round 5; a wave per block of 2 K chars before): 5 K chars when the batch is small (the
+    // chip wants a thousand workgroups and more), up to 20 K on a big one -- fewer look-backs and size passes per byte (measured,
+    // profiles/r05_h_*, r05_k_*: configs[1] 5 K 0.057 ms / 10 K 0.060 / 20 K 0.068; configs[2] 2.56 / 2.28 / 2.15; tagged configs[4] 2.39 / 2.10 /
+    // 2.04); at most 256 sentences.  With tags: a whole multiple of fill_tags' runs, so that a workgroup's records are run_pref[a] .. run_pref[b].
     vpt::EmitFuse F{};
     {
         const uint64_t chars = total_boundaries + n_sentences;
-        F.flat = (!b->knobs.debug_emit && !b->knobs.emit_wave_blocks && !(E.tags && b->knobs.emit_wave_tagged)) ? 1u : 0u;
-        // a run: 5 K chars when the batch is small (the chip wants a thousand workgroups and more), up to 20 K on a big one -- fewer look-backs and
-        // size passes per byte (measured, profiles/r05_h_*, r05_k_*: configs[1] 5 K 0.057 ms / 10 K 0.060 / 20 K 0.068; configs[2] 2.56 / 2.28 / 2.15;
-        // tagged configs[4] 2.39 / 2.10 / 2.04)
         const uint64_t auto_run = std::min<uint64_t>(std::max<uint64_t>(chars / (uint64_t(16) * std::max<uint32_t>(p->n_cus, 64)), 5120), 20480);
-        const uint64_t target = F.flat ? (b->knobs.emit_run_chars ? b->knobs.emit_run_chars : auto_run) : 2048;
-        const uint64_t per = (target * n_sentences + chars / 2) / chars;   // round(target / mean chars per sentence)
-        F.per_block = uint32_t(std::min<uint64_t>(std::max<uint64_t>(per, 1), F.flat ? vpt::kEmitFlatMaxBlock : vpt::kEmitFuseMaxBlock));
-        if (b->knobs.emit_per_block) F.per_block = std::min<uint32_t>(b->knobs.emit_per_block, F.flat ? vpt::kEmitFlatMaxBlock : vpt::kEmitFuseMaxBlock);
+        const uint64_t target = b->knobs.emit_run_chars ? b->knobs.emit_run_chars : auto_run;
+        uint64_t per = std::min<uint64_t>(std::max<uint64_t>((target * n_sentences + chars / 2) / chars, 1), vpt::kEmitFlatMaxBlock);   // round(target / mean chars per sentence)
+        if (E.records && E.run_sent <= vpt::kEmitFlatMaxBlock)
+            per = std::min<uint64_t>(std::max<uint64_t>((per + E.run_sent / 2) / E.run_sent, 1) * E.run_sent, (vpt::kEmitFlatMaxBlock / E.run_sent) * E.run_sent);
+        F.per_block = uint32_t(per);
+        if (b->knobs.emit_per_block) F.per_block = std::min<uint32_t>(b->knobs.emit_per_block, vpt::kEmitFlatMaxBlock);
         F.n_blocks = (n_sentences + F.per_block - 1) / F.per_block;
     }
     const size_t words = size_t(F.n_blocks) + 1;
@@ -1660,7 +1674,6 @@ vpt_status emit_device(const vpt_predictor* p, vpt_batch* b, const uint8_t* d_ut
     F.clear = b->d_emit_state + size_t(b->emit_flip ^ 1) * b->emit_state_cap;
     F.clear_n = b->emit_dirty[b->emit_flip ^ 1];
     F.total_out = total_out;
-    F.dbg = b->knobs.debug_emit;
     b->emit_dirty[b->emit_flip ^ 1] = 0; b->emit_dirty[b->emit_flip] = words;
     b->emit_flip ^= 1;
     VPT_HIP(vpt::launch_emit_tokenized(E, F, stream));
@@ -1673,7 +1686,7 @@ vpt_status vpt_write_tokenized_batch_device(const vpt_predictor* p, vpt_batch* b
                                             const uint64_t* d_out_offsets, size_t n_sentences, uint64_t total_boundaries,
                                             const uint8_t* d_labels, uint8_t* d_text_out, uint64_t text_capacity,
                                             uint64_t* d_text_offsets_out, void* hip_stream) {
-    return emit_device(p, b, d_utf8, d_byte_offsets, d_out_offsets, n_sentences, total_boundaries, d_labels, nullptr, d_text_out, text_capacity,
+    return emit_device(p, b, d_utf8, d_byte_offsets, d_out_offsets, n_sentences, total_boundaries, d_labels, false, d_text_out, text_capacity,
                        d_text_offsets_out, static_cast<hipStream_t>(hip_stream));
 }
 
@@ -1681,8 +1694,8 @@ vpt_status vpt_write_tagged_batch_device(const vpt_predictor* p, vpt_batch* b, c
                                          const uint64_t* d_out_offsets, size_t n_sentences, uint64_t total_boundaries,
                                          const uint8_t* d_labels, const int32_t* d_tags, uint8_t* d_text_out, uint64_t text_capacity,
                                          uint64_t* d_text_offsets_out, void* hip_stream) {
-    if (p && p->n_tags > 0 && !d_tags) return fail(VPT_INVALID_ARGUMENT, "InvalidArgumentError: NULL device pointer");
-    return emit_device(p, b, d_utf8, d_byte_offsets, d_out_offsets, n_sentences, total_boundaries, d_labels, d_tags, d_text_out, text_capacity,
+    (void)d_tags;   // (until round 6: the dense array of fill_tags; the tags are the workspace's records of that call now -- NULL is fine)
+    return emit_device(p, b, d_utf8, d_byte_offsets, d_out_offsets, n_sentences, total_boundaries, d_labels, true, d_text_out, text_capacity,
                        d_text_offsets_out, static_cast<hipStream_t>(hip_stream));
 }
 
@@ -1707,13 +1720,12 @@ static vpt_status emit_host(const vpt_predictor* p, const uint8_t* utf8, const u
     if ((st = grow(&b->d_tok, &b->tok_cap, size_t(text_capacity) + 16)) != VPT_OK) return st;
     if ((st = grow(&b->d_toff, &b->toff_cap, n_sentences + 1)) != VPT_OK) return st;
     const bool with_tags = tagged && p->n_tags > 0;
-    if (with_tags) {   // Sentence::fill_tags, then the writer, as the CLI does (predict/src/main.rs:156-176)
-        if ((st = grow(&b->d_tags, &b->tags_cap, size_t(total_b + n_sentences) * p->n_tags + 16)) != VPT_OK) return st;
+    if (with_tags) {   // Sentence::fill_tags, then the writer, as the CLI does (predict/src/main.rs:156-176); no dense array: the records are the tags
         b->flags = flags;
-        st = vpt_fill_tags_batch_device(p, b, b->d_text, b->d_boff, b->d_ooff, n_sentences, total_b, b->d_labels, b->d_tags, b->own_stream);
+        st = vpt_fill_tags_batch_device(p, b, b->d_text, b->d_boff, b->d_ooff, n_sentences, total_b, b->d_labels, nullptr, b->own_stream);
         if (st != VPT_OK) return st;
     }
-    st = emit_device(p, b, b->d_text, b->d_boff, b->d_ooff, n_sentences, total_b, b->d_labels, with_tags ? b->d_tags : nullptr, b->d_tok,
+    st = emit_device(p, b, b->d_text, b->d_boff, b->d_ooff, n_sentences, total_b, b->d_labels, with_tags, b->d_tok,
                      text_capacity, b->d_toff, b->own_stream);
     if (st != VPT_OK) return st;
     if ((st = vpt_batch_sync(b)) != VPT_OK) return st;
@@ -2012,7 +2024,6 @@ vpt_status vpt_tokenize_batch(const vpt_predictor* p, const uint8_t* utf8, const
         b->off_cap = std::min(cap, cap2);
     }
     if ((st = grow(&b->d_tlab, &b->tlab_cap, nbytes + 1)) != VPT_OK) return st;
-    if (with_tags && (st = grow(&b->d_tags, &b->tags_cap, nbytes * p->n_tags + 16)) != VPT_OK) return st;
     if ((st = grow(&b->d_tok, &b->tok_cap, size_t(nbytes * per_byte) + 16)) != VPT_OK) return st;
     if ((st = grow(&b->d_toff, &b->toff_cap, n_sentences + max_chunks + 1)) != VPT_OK) return st;
     const size_t need_off = n_sentences + 1 + max_chunks;   // pinned: the offsets relative to the batch's text, then one total per chunk
@@ -2046,14 +2057,13 @@ vpt_status vpt_tokenize_batch(const vpt_predictor* p, const uint8_t* utf8, const
         const uint64_t tb_bound = nby - n;                        // boundaries of the chunk, at most
         st = vpt_predict_batch_device(p, bb, b->d_text, d_boff_k, d_ooff_k, n, tb_bound, mb, nullptr, d_labels_k, s);
         if (st != VPT_OK) return st;
-        int32_t* d_tags_k = with_tags ? b->d_tags + tb * p->n_tags : nullptr;
-        if (with_tags) {
+        if (with_tags) {   // (no dense array: the writer takes the records)
             bb->flags = flags & VPT_FLAG_KYTEA_FULLWIDTH;
-            st = vpt_fill_tags_batch_device(p, bb, b->d_text, d_boff_k, d_ooff_k, n, tb_bound, d_labels_k, d_tags_k, s);
+            st = vpt_fill_tags_batch_device(p, bb, b->d_text, d_boff_k, d_ooff_k, n, tb_bound, d_labels_k, nullptr, s);
             if (st != VPT_OK) return st;
         }
         h_total[k] = 0;
-        st = emit_device(p, bb, b->d_text, d_boff_k, d_ooff_k, n, tb_bound, d_labels_k, d_tags_k, b->d_tok + tb * per_byte, nby * per_byte,
+        st = emit_device(p, bb, b->d_text, d_boff_k, d_ooff_k, n, tb_bound, d_labels_k, with_tags, b->d_tok + tb * per_byte, nby * per_byte,
                          b->d_toff + a + k, s, h_total + k);
         if (st != VPT_OK) return st;
         VPT_HIP(hipEventRecord(b->chunk_ev[k], s));

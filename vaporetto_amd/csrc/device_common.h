@@ -23,6 +23,17 @@
 #define VPT_PIN(x) __asm__ volatile("" : "+v"(x))
 #endif
 
+// A pointer that is KNOWN to point into LDS (a function argument; a plain pointer there is a flat one).  hipcc 7.2 fails on tag_token_by_wave's
+// flat scratch pointer next to its global stores ("Illegal instruction detected: Operand has incorrect register class. V_CMP_NE_U32_e32 0,
+// $src_shared_base"); with the address space in the type there is no flat access to lower.  The CPU emulator of the tests has one address space.
+#if defined(VPT_HIPEMU)
+#define VPT_LDS_PTR(T) T*
+#define VPT_TO_LDS_PTR(T, p) (p)
+#else
+#define VPT_LDS_PTR(T) __attribute__((address_space(3))) T*
+#define VPT_TO_LDS_PTR(T, p) ((__attribute__((address_space(3))) T*)(p))
+#endif
+
 // The kernel's parameter block read WHERE IT IS USED.  A by-value kernel argument is loaded from the kernarg segment at the kernel's entry
 // and kept in scalar registers to its last use; the specialised scoring kernel has 70-odd such words and 72 SGPRs at 8 waves per SIMD
 // (800 per SIMD, 16 of every wave's allocation reserved for the trap handler), so the compiler spilled 84 of them to VGPR lanes.  The

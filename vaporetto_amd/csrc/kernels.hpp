@@ -139,26 +139,41 @@ struct TagParams {
     const uint64_t* ooff;       // [S+1]
     const uint8_t* labels;      // [total boundaries] CharacterBoundary values (0, 1, 2 = Unknown)
     uint64_t n_sent;
-    uint64_t total_chars;       // total boundaries + S: what `cps` and `tags / n_tags` hold
-    int32_t* tok_model;         // [total chars] or nullptr: the token ending at the char for the writer (layout.h, tok_model words)
+    uint64_t total_chars;       // total boundaries + S: what `cps` holds (below 2^32 - 256: capi.cpp)
     const uint32_t *slot_str, *str_off;   // the tag strings' lengths (HostTagTables): what a token's tags take in the tokenized text
     uint32_t n_strings;
-    int32_t* tags;              // [(total boundaries + S) * n_tags] candidate index per slot, -1 = None
-    // Predictor::store_tag_scores (predictor.rs:510-514): optional outputs, both indexed by char like `tags`
-    int32_t* scores_out;        // [(total boundaries + S) * score_stride] or nullptr: at the last char of a token with a tag model, entries
-                                // [0, bias.len()) = the scores the reference keeps in sentence.tag_scores[i] (predictor.rs:599-601)
-    int32_t* model_out;         // [total boundaries + S] or nullptr: index of that tag model (Model::tag_models order), -1 elsewhere
+    // What fill_tags LEAVES (round 6): one RECORD per token that has a tag model -- the reference holds None for every other char
+    // (predictor.rs:558-573) and so nothing is stored for them -- sorted by the token's last char:
+    //   records[k]  = {flat index of the token's last char (2 dwords), its tok_model word (layout.h: tag model + 1 | the bytes its tags take in
+    //                  the tokenized text << 24), 0};   rec_tags[k * n_tags + j] = the candidate chosen for slot j, -1 = None
+    // The front end walks the batch in RUNS of `run_sent` consecutive sentences, a wave per run, in order: token number `ordinal` (among those
+    // with a model) of run r is record run_pref[r] + ordinal.  run_pref [n_runs + 1]: zero in front of the launches; while the front end runs,
+    // entry r + 1 counts run r's records; a chained scan turns it into the exclusive prefix (entry n_runs: all records).
+    uint4* records;
+    int32_t* rec_tags;
+    uint64_t* run_pref;
+    uint64_t* scan_state;       // scan_part_entries(n_runs) words of that scan, zero in front of the launches
+    uint64_t n_runs;
+    uint32_t run_sent;
+    // the dense arrays of the C ABI, all optional (nullptr: not wanted), indexed by char; the caller has set them to None (-1) / left them alone:
+    int32_t* tags;              // [(total boundaries + S) * n_tags] candidate index per slot: written at the last char of a token with a tag model
+    int32_t* scores_out;        // [(total boundaries + S) * score_stride]: Predictor::store_tag_scores (predictor.rs:510-514,599-601): there, entries
+                                // [0, bias.len()) = the scores the reference keeps in sentence.tag_scores[i]
+    int32_t* model_out;         // [total boundaries + S]: there, the index of the tag model (Model::tag_models order)
     uint32_t score_stride;
-    uint32_t max_blocks;        // workgroups the device runs at a time (0: one wave per sentence up to 65536 workgroups)
-    // Two launches instead of one (nullptr: one): the step loop appends the tokens that have a tag model to a queue in HBM -- those whose
-    // model fits the record form at [0, queue_fast), the others at [queue_fast, queue_fast + queue_slow) -- and a launch of passes
-    // takes them from there.  qctl = {fast tokens, slow tokens, overflow}: zeroed in front of the launches; on overflow the one-launch
-    // kernel does the batch again.
+    uint32_t n_cus;             // the device's CUs: the grids are what it holds at a time
+    // Between the two launches: the tokens that have a tag model wait in a queue in HBM -- those whose model fits the record form from its
+    // front (qctl[0] of them), the others from its back (qctl[1]) -- with where their record goes (qrun: run, ordinal).  queue_cap = total_chars:
+    // a token is at least a char, the queue cannot overflow.  qctl: zero in front of the launches.
     uint4* queue;
+    uint2* qrun;
     uint32_t* qctl;
-    uint32_t queue_fast, queue_slow;
-    uint32_t front_by_sentence; // A/B knob (read when the workspace was made, like every launch-level knob): the pair's front end as a wave per sentence
+    uint32_t queue_cap;
+    const uint32_t* summary;    // 2^(kTagSumLog2 - 5) words for the summary of the token filter (tag_filter_summary_kernel writes it, the front end reads it)
 };
+// sentences of a front-end run for a batch of this shape (about VPT_TAG_RUN_CHARS chars, at most 256 sentences); words of TagParams::summary
+uint32_t tag_run_sentences(uint64_t n_sent, uint64_t total_chars);
+size_t tag_summary_words();
 hipError_t launch_decode_chars(const uint8_t* text, const uint64_t* boff, const uint64_t* ooff, uint64_t n_sent, uint64_t total_chars,
                                const uint32_t* cinfo, uint32_t* cps, uint8_t* types, uint32_t* status, hipStream_t stream);
 hipError_t launch_tag_tokens(const TagParams& P, hipStream_t stream);
@@ -174,28 +189,32 @@ struct EmitParams {
     uint64_t* out_offsets;      // [S+1] byte range of every sentence's tokenized text in out_text
     uint64_t capacity;
     uint32_t* status;
-    // "/tag" suffixes (sentence.rs:866-881); tags == nullptr: none
-    const int32_t* tags;        // [(total boundaries + S) * n_tags] as vpt_fill_tags_batch wrote them
-    const int32_t* tok_model;   // [total boundaries + S] from the same fill_tags call (TagParams::tok_model)
+    // "/tag" suffixes (sentence.rs:866-881), from the records the fill_tags call on this workspace left (TagParams); records == nullptr: none
+    const uint4* records;
+    const int32_t* rec_tags;
+    const uint64_t* run_pref;   // [n_runs + 1]: records in front of run r of `run_sent` sentences
+    uint64_t n_runs;
+    uint32_t run_sent;
     uint32_t n_tags, n_models, n_strings;
     const uint32_t *models, *slot_str, *str_off;
     const uint8_t* str_bytes;
 };
 // scan_part: workspace of scan_part_entries(n_sent) uint64 (the prefix sum's per-workgroup partials)
 size_t scan_part_entries(uint64_t n);
-// The writer's launch (emit_fused_kernel): a wave per block of `per_block` consecutive sentences (1 .. kEmitFuseMaxBlock).
-constexpr uint32_t kEmitFuseMaxBlock = 64;
-// ... or, without tags, a WORKGROUP per run of `per_block` consecutive sentences (1 .. kEmitFlatMaxBlock): emit_flat_kernel
+// The writer's launch (emit_flat_kernel): a WORKGROUP per run of `per_block` consecutive sentences (1 .. kEmitFlatMaxBlock)
 constexpr uint32_t kEmitFlatMaxBlock = 256;
 struct EmitFuse {
     uint64_t* state;        // n_blocks + 1 words, ZERO when the kernel starts: the blocks' sizes / positions and the ticket
     uint64_t* clear;        // the state words of the NEXT call (the other of two arrays), zeroed by this one: [0, clear_n)
     uint64_t clear_n, n_blocks;
     uint32_t per_block;
-    uint32_t dbg;           // VPT_DEBUG_EMIT timing ablations (a diagnostics build of the kernel; results are wrong by design)
-    uint32_t flat;          // the blocks are runs of sentences for emit_flat_kernel (no tags)
     uint64_t* total_out;    // optional device-writable HOST address that receives the output's total size
 };
+// inclusive prefix sum over offsets[1 .. n] in place, offsets[0] = 0 (a chained scan, one launch; part: scan_part_entries(n) zero words)
+hipError_t launch_scan(uint64_t* offsets, uint64_t n, uint64_t* part, uint64_t capacity, uint32_t* status, uint64_t* total_out, hipStream_t stream);
+// vpt_expand_tags_batch_device: the dense tags array from the records (None everywhere else)
+hipError_t launch_expand_tags(const uint4* records, const int32_t* rec_tags, const uint64_t* n_records, uint32_t n_tags, uint64_t total_chars, int32_t* tags,
+                              uint32_t n_cus, hipStream_t stream);
 hipError_t launch_emit_tokenized(const EmitParams& P, const EmitFuse& F, hipStream_t stream);
 // vpt_count_boundaries on the device: ooff_out[S+1]; *max_chars (atomicMax) = the longest sentence in chars; text_bytes_hint: the batch's text
 // bytes when the host knows them (0: not), which sizes the workgroups' shares

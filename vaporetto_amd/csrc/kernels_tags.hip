@@ -11,48 +11,36 @@
 // (char_scorer/boundary_tag_scorer.rs:62-174, type_scorer/boundary_tag_scorer.rs:51-143) with suffix-merged tag
 // weights; integer adds are order-free, so the sums are bit-identical.
 //
-// Kernels (a wave takes sentences in turn):
+// What fill_tags leaves (round 6): the reference stores None for every char that does not end a token with a tag model
+// (predictor.rs:558-573) -- here NOTHING is stored for them.  The device-side result is one RECORD per token that has a tag model
+// (last char, tag model, chosen candidates, the bytes its "/tag" suffix takes), sorted by position (TagParams, kernels.hpp); the writer
+// reads the records, and the dense (chars x n_tags) array of the C ABI is a scatter of them over a memset for the callers that ask for it.
+//
+// Kernels:
 //   decode_chars_kernel  UTF-8 -> flat per batch (char g of sentence i at out_offsets[i] + i + g): the scored scalar value
 //                        | CharacterType << 24; optionally Sentence::char_types on their own
-//   tag_tokens_kernel    The waves stay and stride over the sentences, 64 chars per step, chars and labels fetched one step
-//                        ahead.  (1) Every lane whose char ends a token owns it: start from the step's boundary masks; the token
-//                        table's FILTER -- keyed like the table by the length and the first four chars, which the lane reads
-//                        from the sentence's ring in LDS, so there is no loop over the token -- says with one 4-byte read whether
-//                        the surface can be a tag model's at all.  One token in thirty has a model (BASELINE's configs[4]), not
-//                        one in a hundred of the others passes: every char that does not get its entries (None) at once.  The
-//                        CANDIDATES wait in LDS, across steps and sentences, until there are 64: then every lane probes the table
-//                        for one (round 2: each step probed for its own token ends, 28 of 64 lanes busy, the step's critical path
-//                        as long as its longest probe sequence: profiles/r02_g_tag_steps.txt); a token of up to 4 chars is
-//                        verified from its 16-byte slot alone.
-//                        (2) The tokens that found a tag model join a QUEUE in LDS that outlives the step and the sentence; 16
-//                        of them are a pass: their context chars (p - 11 .. p + 4), model records and bias arrive in one trip;
-//                        a model's char n-grams come in groups by rel_position with a 64-bit filter over the chars they END
-//                        with, so a token only enumerates the groups its text can match; the wave's lanes then take (token,
-//                        tag n-gram) PAIRS, 64 per round: a lane checks one whole n-gram from one 32-byte record against the
-//                        token's context in LDS; the matches are collected and lanes over (match, score) pairs add their
-//                        weights to the token's scores in LDS (which start as the model's bias); lanes over (token, slot)
-//                        pairs take the argmax.  With one token in thirty carrying a model (BASELINE's configs[4]) a step
-//                        would fill a round to a quarter and pay the pass's four dependent trips for one or two tokens;
-//                        the queue fills every round and pays them once per sixteen.  Models that do not fit the record form
-//                        (an n-gram over 12 symbols or outside the BMP, more than 16 scores or 3 slots, rel_position above
-//                        3) go through a whole-wave routine, one token at a time.
-//   tag_tokens_kernel<.., kSplit> + tag_pass_kernel
-//                        For batches of 256 K chars and more the work above is TWO launches: the step loop ("front end": every token
-//                        end's filter word, the candidates' lookups, the entries of every char without a model) appends the tokens that
-//                        have a model to a queue in HBM, a wave's share with one atomic, and the passes are a launch of their own over
-//                        that queue.  In one launch the pass's peak register use sits on top of the loop's own values (80 VGPRs at 6
-//                        workgroups per CU, the loop's loads cannot be issued further ahead without spilling:
-//                        profiles/r03_w_tag_variants.txt); apart, the loop has 69 VGPRs at 7 per CU with steps of two 64-char
-//                        half-steps and the next sentence's offsets and first chars in flight a sentence ahead, the passes 57 at 8
-//                        per CU.  A queue that overflows (an eighth of the batch's chars) sets a flag: the one-launch kernel, always
-//                        launched behind the pair, then does the batch again -- otherwise it returns at once.
-//   tag_front_flat_kernel
-//                        Round 4: the front-end launch of the pair, flat over the batch's chars -- a wave takes a run of consecutive sentences
-//                        (about 2 K chars) and walks it in the same 128-char steps with every lane busy; sentence starts and ends come from
-//                        two bitmaps per step built from the run's offsets.  configs[4]: 1.08 -> 1.00 ms (tag_tokens_kernel<.., kSplit> stays
-//                        as the A/B: VPT_TAG_FRONT_BY_SENTENCE).  Round 5: rewritten (see at the kernel) -- 43 % of the vector instructions,
-//                        None entries stored behind a step's loads, a summary of the token filter in LDS (tag_filter_summary_kernel builds it),
-//                        workgroups of 8 waves, a grid of what the device holds: 0.69 - 0.77 ms.
+//   tag_filter_summary_kernel + tag_front_flat_kernel
+//                        The FRONT END, flat over the batch's chars: a wave takes a run of consecutive sentences (about 2 K chars) and walks it
+//                        in 128-char steps with every lane busy; sentence starts and ends come from one bitmap of marks per step built from the
+//                        run's offsets.  Every lane whose char ends a token owns it; the token table's FILTER -- keyed like the table by the
+//                        length and the first four chars, which the lane reads from the ring in LDS, so there is no loop over the token --
+//                        says whether the surface can be a tag model's at all (a summary of it sits in LDS: five of six token ends need no
+//                        load).  The CANDIDATES wait in LDS, across steps and runs, until there are 64: then every lane probes the table for
+//                        one.  The tokens that have a model are appended to a QUEUE in HBM, a wave's share with one atomic, each with its run
+//                        and its ordinal among the run's tokens with a model.  The kernel stores nothing else (until round 6 it stored the None
+//                        entries of every char: 1.07 of configs[4]'s 1.6 GB of writes, 0.30 of its 0.75 ms).
+//   launch_scan          the runs' record counts -> the runs' first records (a chained scan, kernels_emit.hip)
+//   tag_pass_kernel      The PASSES over that queue, 16 tokens at a time: their context chars (p - 11 .. p + 4), model records and bias arrive in
+//                        one trip; a model's char n-grams come in groups by rel_position with a 64-bit filter over the chars they END with,
+//                        so a token only enumerates the groups its text can match; the wave's lanes then take (token, tag n-gram) PAIRS,
+//                        64 per round: a lane checks one whole n-gram from one 32-byte record against the token's context in LDS; the
+//                        matches are collected and lanes over (match, score) pairs add their weights to the token's scores in LDS (which
+//                        start as the model's bias); lanes over (token, slot) pairs take the argmax (first maximum, predictor.rs:286-304).
+//                        Models that do not fit the record form (an n-gram over 12 symbols or outside the BMP, more than 16 scores or 3
+//                        slots, rel_position above 3) go through a whole-wave routine, one token at a time.  Each token's record is written
+//                        at run_pref[run] + ordinal.
+//   (Until round 6 there was a one-launch kernel for small batches and for a queue that overflowed -- tag_tokens_kernel, a wave per
+//   sentence -- and an A/B of the front end by sentence; the queue now holds a token per char of the batch and cannot overflow: HISTORY.md.)
 //   With predict_tags the scoring kernel of the preceding vpt_predict_batch_device call leaves the decoded chars behind and
 //   decode_chars_kernel is skipped (capi.cpp).
 #include <hip/hip_runtime.h>
@@ -189,11 +177,7 @@ constexpr int kRing = 256;                   // the sentence's cps words in LDS:
 constexpr int kTagPass = 16;                 // queued tokens a pass takes
 constexpr int kCtx = 16, kCtxBack = 11;      // the text a queued token's n-grams can touch: chars p - 11 .. p + 4 around its last char p
 static_assert(kCtx - 1 - kCtxBack == int(kTagFastMaxRel), "tables.cpp keeps models with a tag n-gram further past the token off the fast path");
-#ifdef VPT_TAG_NO_PASS
-constexpr int kTagCand = 32;                 // (the experiment runs 8 workgroups per CU)
-#else
 constexpr int kTagCand = 64;                 // tokens that wait for the token table together
-#endif
 constexpr int kMatchCap = 128;               // matched (token, n-gram) pairs collected before their weights are added
 
 struct TagWaveLds {
@@ -202,7 +186,7 @@ struct TagWaveLds {
         struct {
             uint32_t tok[kTagPass][12];             // the queue: tag model + 1, flat char index (2), chars before | after << 8 inside the sentence (clipped
                                                    // to the context); a pass adds: first record, scores | slots << 8 | type entries << 16 | active
-                                                   // groups << 24, packed slots, the four char group sizes, slot_str of its slots (3)
+                                                   // groups << 24, packed slots, the four char group sizes, slot_str of its slots (3); [11]: the token's record
             uint32_t ctx[kTagPass][kCtx];          // cps words p - 11 .. p + 4 of every token, 0 outside its sentence
             int32_t zt[kTagPass][kTagFastZ + 1];   // the scores (rows padded against bank conflicts)
             uint32_t pref[kTagPass + 1];           // records before token t (exclusive prefix of the counts)
@@ -211,64 +195,13 @@ struct TagWaveLds {
     };
 };
 struct alignas(16) TagFrontLds {             // what the step loop keeps per wave
-    uint32_t txt[kRing + 4];                 // (the flat front end keeps words 0 .. 2 once more at kRing ..: a token's first four chars are consecutive words)
+    uint32_t txt[kRing + 4];                 // (the ring keeps words 0 .. 2 once more at kRing ..: a token's first four chars are consecutive words)
     uint32_t cand[kTagCand][4];              // tokens the filter let through, waiting for the token table: flat index of the last char (2),
                                              // chars, chars before | after << 8 inside the sentence (clipped to the context)
+    uint32_t crun[kTagCand];                 // ... and the run they belong to
 };
-// one launch: both; the front-end launch of the pair: the step loop's alone
-template <bool kSplit> struct TagKernelLds {
-    TagWaveLds w[kTagWaves];
-    TagFrontLds fr[kTagWaves];
-    __device__ __forceinline__ TagWaveLds* pass(uint32_t wid) { return &w[wid]; }
-};
-template <> struct TagKernelLds<true> {
-    TagFrontLds fr[kTagWaves];
-    __device__ __forceinline__ TagWaveLds* pass(uint32_t) { return nullptr; }
-};
-#ifndef VPT_TAG_OCC
-#define VPT_TAG_OCC 6     // workgroups per CU the one-launch kernel is compiled for (A/B builds: -D)
-#endif
-#ifndef VPT_TAG_FRONT_OCC
-#define VPT_TAG_FRONT_OCC 7
-#endif
-constexpr int kTagPairOcc = 8, kTagFrontOcc = VPT_TAG_FRONT_OCC;   // ... and the kernels of the pair (the passes: 57 VGPRs; the step loop: 64 at 8 per CU with 4 spilled, 72 at 7)
-static_assert(sizeof(TagKernelLds<false>) <= 160 * 1024 / VPT_TAG_OCC && sizeof(TagKernelLds<true>) <= 160 * 1024 / kTagPairOcc &&
-              sizeof(TagWaveLds) * kTagWaves <= 160 * 1024 / kTagPairOcc, "workgroups per CU");
-
-// Can the chars [s0, e] of the sentence be the token of a tag model?  One lane on its own, no loop over the token: the table's
-// filter is keyed like the table -- by the length and the first four chars (layout.h, tag_token_hash_key), which the lane reads from
-// the sentence's ring in LDS -- and answers with one 4-byte read (no for all but a percent of the tokens without a model).
-__device__ __forceinline__ bool tag_filter_hit(const TagParams& P, const uint32_t* cps, const uint32_t* txt, int base, int s0, int e) {
-    const int len = e - s0 + 1;
-    const bool in_ring = s0 >= base - (kRing - 64);
-    uint32_t c[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) c[j] = j < len ? txt[(s0 + j) & (kRing - 1)] & kCharMask : 0u;   // always an LDS read ...
-    if (!in_ring) {   // ... and for a token that began before the ring (rare) the chars themselves
-#pragma unroll
-        for (int j = 0; j < 4; ++j) c[j] = j < len ? cps[s0 + j] & kCharMask : 0u;
-    }
-    const uint32_t lo = (c[0] & 0xFFFFu) | (c[1] << 16), hi = (c[2] & 0xFFFFu) | (c[3] << 16);
-    const uint32_t fbit = tag_token_hash_key(lo, hi, uint32_t(len)) >> (32 - P.tok_bits - kTagFilterLog2);
-    return ((P.tok_tab[(size_t(4) << P.tok_bits) + (fbit >> 5)] >> (fbit & 31u)) & 1u) != 0;
-}
-
-// The same for the front-end launch's wide steps.  One lane on its own, no loop over the token: the table's
-// filter is keyed like the table -- by the length and the first four chars (layout.h, tag_token_hash_key), which the lane reads from
-// the sentence's ring in LDS (chars from `ring_lo` on) -- and answers with one 4-byte read (no for all but a percent of the tokens
-// without a model).  This is the number of the filter's bit; the caller reads the word (two half-steps' reads go out together).
-__device__ __forceinline__ uint32_t tag_filter_bit(const TagParams& P, const uint32_t* cps, const uint32_t* txt, int ring_lo, int s0, int e) {
-    const int len = e - s0 + 1;
-    uint32_t c[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) c[j] = j < len ? txt[(s0 + j) & (kRing - 1)] & kCharMask : 0u;   // always an LDS read ...
-    if (s0 < ring_lo) {   // ... and for a token that began before the ring (rare) the chars themselves
-#pragma unroll
-        for (int j = 0; j < 4; ++j) c[j] = j < len ? cps[s0 + j] & kCharMask : 0u;
-    }
-    const uint32_t lo = (c[0] & 0xFFFFu) | (c[1] << 16), hi = (c[2] & 0xFFFFu) | (c[3] << 16);
-    return tag_token_hash_key(lo, hi, uint32_t(len)) >> (32 - P.tok_bits - kTagFilterLog2);
-}
+constexpr int kTagPairOcc = 8;               // workgroups per CU of the passes (57 VGPRs)
+static_assert(sizeof(TagWaveLds) * kTagWaves <= 160 * 1024 / kTagPairOcc, "workgroups per CU");
 
 // The tag model (index + 1) whose token is the `len` chars at `tc` (flat cps words), or 0: the table is keyed by the length and the
 // first four chars; a surface of up to four BMP chars is verified by the slot itself, a longer candidate against `syms`.
@@ -298,7 +231,7 @@ __device__ __forceinline__ uint32_t find_tag_model(const TagParams& P, const uin
 
 // One token handled by the whole wave (models outside the record form): lanes over z entries, n-gram chars, slots.
 __device__ __forceinline__ void tag_token_by_wave(const TagParams& P, const uint32_t* cps, int64_t n, int64_t e, uint64_t g0, uint32_t model,
-                                                  volatile int32_t* z, int lane) {
+                                                  VPT_LDS_PTR(volatile int32_t) z, int lane, uint64_t slot) {
     const uint32_t* mr = P.models + size_t(model - 1) * 12;
     const uint32_t zlen = mr[7];
     for (uint32_t i = lane; i < zlen; i += 64) z[i] = P.weights[mr[6] + i];
@@ -342,7 +275,8 @@ __device__ __forceinline__ void tag_token_by_wave(const TagParams& P, const uint
                 if (v > best) { best = v; tag = int32_t(c); }
             }
         }
-        P.tags[(g0 + uint64_t(e)) * P.n_tags + j] = tag;
+        P.rec_tags[slot * P.n_tags + j] = tag;
+        if (P.tags) P.tags[(g0 + uint64_t(e)) * P.n_tags + j] = tag;
         if (tag >= 0) {
             const uint32_t k = P.slot_str[mr[8] + j] + uint32_t(tag);
             const uint32_t sl = k < P.n_strings ? P.str_off[k + 1] - P.str_off[k] : 0u;
@@ -350,9 +284,13 @@ __device__ __forceinline__ void tag_token_by_wave(const TagParams& P, const uint
             last_some = j + 1;
         }
     }
-    if (P.tok_model) {
+    {
         const uint32_t bytes = uint32_t(wave_sum64(str_bytes < 0x10000u ? str_bytes : 0x10000u)) + wave_max(last_some);
-        if (lane == 0) P.tok_model[g0 + uint64_t(e)] = int32_t(model | ((bytes < kTokSuffixLong ? bytes : kTokSuffixLong) << kTokSuffixShift));
+        const uint64_t gp = g0 + uint64_t(e);
+        if (lane == 0) {
+            P.records[slot] = make_uint4(uint32_t(gp), uint32_t(gp >> 32), model | ((bytes < kTokSuffixLong ? bytes : kTokSuffixLong) << kTokSuffixShift), 0u);
+            if (P.model_out) P.model_out[gp] = int32_t(model) - 1;
+        }
     }
     __builtin_amdgcn_wave_barrier();
 }
@@ -382,7 +320,8 @@ __device__ __forceinline__ void tag_add_matches(const TagParams& P, TagWaveLds& 
 // A pass over the `nq` queued tokens (they come from any of the wave's sentences): their context chars, model records and
 // bias are fetched in ONE trip -- lanes over (token, char), tokens, (token, score) -- then the n-grams of ALL of them are
 // checked in rounds of 64 (token, n-gram) pairs, the weights of the matches added, the argmax taken.
-__device__ __forceinline__ void tag_pass(const TagParams& P, TagWaveLds& L, uint32_t nq, int lane, uint32_t dbg) {
+__device__ __forceinline__ void tag_pass(const TagParams& P, TagWaveLds& L, uint32_t nq, int lane) {
+    constexpr uint32_t dbg = 0;
     const uint32_t nt = P.n_tags;
     const uint64_t below_me = (uint64_t(1) << lane) - 1;
     __builtin_amdgcn_wave_barrier();
@@ -522,9 +461,12 @@ __device__ __forceinline__ void tag_pass(const TagParams& P, TagWaveLds& L, uint
                     if (v > best) { best = v; tag = int32_t(c); }
                 }
             }
-            const uint64_t gp = uint64_t(L.f.tok[t][1]) | (uint64_t(L.f.tok[t][2]) << 32);
-            P.tags[gp * nt + j] = tag;
-            if (P.tok_model && tag >= 0) {
+            P.rec_tags[size_t(L.f.tok[t][11]) * nt + j] = tag;
+            if (P.tags) {
+                const uint64_t gp = uint64_t(L.f.tok[t][1]) | (uint64_t(L.f.tok[t][2]) << 32);
+                P.tags[gp * nt + j] = tag;
+            }
+            if (tag >= 0) {
                 const uint32_t k = L.f.tok[t][8 + j] + uint32_t(tag);   // (j < 3: the record form)
                 const uint32_t sl = k < P.n_strings ? P.str_off[k + 1] - P.str_off[k] : 0u;
                 atomicAdd(&L.f.pref[t], sl < 0x10000u ? sl : 0x10000u);
@@ -533,113 +475,85 @@ __device__ __forceinline__ void tag_pass(const TagParams& P, TagWaveLds& L, uint
         }
     }
     __builtin_amdgcn_wave_barrier();
-    if (P.tok_model && uint32_t(lane) < nq && !(dbg & 16u)) {
-        const uint64_t gp = uint64_t(L.f.tok[lane][1]) | (uint64_t(L.f.tok[lane][2]) << 32);
+    if (uint32_t(lane) < nq) {   // the token's record: where the writer finds its tags
         const uint32_t bytes = L.f.pref[lane] + uint32_t(L.f.zt[lane][kTagFastZ]);
-        P.tok_model[gp] = int32_t(L.f.tok[lane][0] | ((bytes < kTokSuffixLong ? bytes : kTokSuffixLong) << kTokSuffixShift));
+        P.records[L.f.tok[lane][11]] = make_uint4(L.f.tok[lane][1], L.f.tok[lane][2],
+                                                  L.f.tok[lane][0] | ((bytes < kTokSuffixLong ? bytes : kTokSuffixLong) << kTokSuffixShift), 0u);
+        if (P.model_out) P.model_out[uint64_t(L.f.tok[lane][1]) | (uint64_t(L.f.tok[lane][2]) << 32)] = int32_t(L.f.tok[lane][0]) - 1;
     }
     __builtin_amdgcn_wave_barrier();
 }
 
-// The `nc` tokens that wait in L.cand, one per lane: the token table says which tag model each has (most have one: the filter let
-// them through); every one of them gets its entries (no tag model: None); those whose model fits the record form join the QUEUE of
-// tag_pass -- a full queue is a pass --, the others go through the whole-wave routine, one token at a time.  drain: nothing may
-// stay in the queue (the wave's last call).
-// kSplit: the front-end launch -- the tokens that have a model are appended to the queue in HBM instead (TagParams::queue), a wave's
-// share with one atomic.
-template <bool kSplit>
-__device__ __forceinline__ void tag_resolve(const TagParams& P, TagFrontLds& F, TagWaveLds* Lp, uint32_t nc, uint32_t& nq, bool drain, int lane, uint32_t dbg) {
-    const uint32_t nt = P.n_tags;
+// The `nc` tokens that wait in F.cand, one per lane: the token table says which tag model each has (most have one: the filter let
+// them through).  Those that have one are appended to the queue in HBM -- record-form models from its front, the others from its back, a
+// wave's share with one atomic each -- together with where their RECORD goes: their run and their ordinal among the run's tokens that have
+// a model.  A run is walked by ONE wave, in order, and its candidates are resolved in order, so the ordinals follow the positions: the
+// records come out sorted without a sort (tag_pass_kernel adds the records of the runs in front, TagParams::run_pref).
+__device__ __forceinline__ void tag_resolve(const TagParams& P, TagFrontLds& F, uint32_t nc, int lane) {
     const uint64_t below_me = (uint64_t(1) << lane) - 1;
     __builtin_amdgcn_wave_barrier();
     const bool have = uint32_t(lane) < nc;
     const uint64_t gp = have ? uint64_t(F.cand[lane][0]) | (uint64_t(F.cand[lane][1]) << 32) : 0;
     const uint32_t len = have ? F.cand[lane][2] : 0u, clip = have ? F.cand[lane][3] : 0u;
+    const uint32_t run = have ? F.crun[lane] : 0u;
     bool fast = false;
-    uint32_t model = have ? find_tag_model(P, P.cps + (gp + 1 - len), len, &fast) : 0u;
-    if (dbg & 2u) model = 0;
-    if (have) {
-        if (P.tok_model && (model == 0 || (!kSplit && (dbg & 80u)))) P.tok_model[gp] = int32_t(model);   // 0: no tag model for this surface (else: written with its tags' bytes by tag_pass / tag_token_by_wave)
-        if (P.model_out) P.model_out[gp] = int32_t(model) - 1;
-        if (model == 0) for (uint32_t j = 0; j < nt; ++j) P.tags[gp * nt + j] = -1;
-    }
-    if (dbg & 64u) model = 0;
-    const uint64_t qmask = __ballot(model != 0 && fast);
-    uint64_t todo = __ballot(model != 0 && !fast);   // the models outside the record form: their routine's scores take the queue's place
-    if (kSplit) {
+    const uint32_t model = have ? find_tag_model(P, P.cps + (gp + 1 - len), len, &fast) : 0u;
+    const uint64_t tagged = __ballot(model != 0);
+    if (tagged != 0) {   // wave-uniform
+        // ordinals: the batch's runs one by one (a few: a run has some thirty candidates); the run's count lives in run_pref[run + 1]
+        // (an atomic: it is this wave's alone, but a plain read could be served by a stale line of the vector L1)
+        uint32_t ord = 0;
+        for (uint64_t left = tagged; left != 0;) {
+            const int k = __ffsll((long long)left) - 1;
+            const uint32_t r = uint32_t(__builtin_amdgcn_readlane(int(run), k));
+            const uint64_t m = __ballot(model != 0 && run == r);
+            unsigned long long base = 0;
+            if (lane == 0) base = atomicAdd(reinterpret_cast<unsigned long long*>(P.run_pref + size_t(r) + 1), (unsigned long long)__popcll(m));
+            const uint32_t b0 = wave_uniform(uint32_t(base));
+            if ((m >> lane) & 1u) ord = b0 + uint32_t(__popcll(m & below_me));
+            left &= ~m;
+        }
+        const uint64_t qmask = __ballot(model != 0 && fast);
 #pragma unroll
         for (int kind = 0; kind < 2; ++kind) {
-            const uint64_t m = kind == 0 ? qmask : todo;
+            const uint64_t m = kind == 0 ? qmask : tagged & ~qmask;   // the models outside the record form: the whole-wave routine's
             if (m == 0) continue;   // wave-uniform
-            const uint32_t n = uint32_t(__popcll(m)), cap = kind == 0 ? P.queue_fast : P.queue_slow;
             uint32_t base = 0;
-            if (lane == 0) base = atomicAdd(&P.qctl[kind], n);
-            base = wave_uniform(base);
-            if (base + n > cap || base + n < base) { if (lane == 0) P.qctl[2] = 1u; continue; }   // the one-launch kernel does the batch again
-            if ((m >> lane) & 1u)
-                P.queue[(kind == 0 ? 0u : P.queue_fast) + base + uint32_t(__popcll(m & below_me))] = make_uint4(uint32_t(gp), uint32_t(gp >> 32), model, clip);
-        }
-        __builtin_amdgcn_wave_barrier();
-        return;
-    }
-    TagWaveLds& L = *Lp;   // (one launch: the passes' share of the LDS)
-    const bool flush = drain || todo != 0;
-    if (qmask != 0 || (flush && nq != 0)) {
-        const uint32_t rank = uint32_t(__popcll(qmask & below_me));
-        uint32_t remaining = uint32_t(__popcll(qmask)), done = 0;
-        for (;;) {
-            const uint32_t room = uint32_t(kTagPass) - nq, take = remaining < room ? remaining : room;
-            if (model != 0 && fast && rank >= done && rank < done + take) {
-                const uint32_t row = nq + rank - done;
-                L.f.tok[row][0] = model; L.f.tok[row][1] = uint32_t(gp); L.f.tok[row][2] = uint32_t(gp >> 32); L.f.tok[row][3] = clip;
+            if (lane == 0) base = atomicAdd(&P.qctl[kind], uint32_t(__popcll(m)));
+            base = wave_uniform(base) + uint32_t(__popcll(m & below_me));
+            const uint32_t at = kind == 0 ? base : P.queue_cap - 1u - base;
+            if (((m >> lane) & 1u) && base < P.queue_cap) {   // (always: a token is at least a char, the queue holds one per char)
+                P.queue[at] = make_uint4(uint32_t(gp), uint32_t(gp >> 32), model, clip);
+                P.qrun[at] = make_uint2(run, ord);
             }
-            nq += take; done += take; remaining -= take;
-            if (!(nq == uint32_t(kTagPass) || (nq != 0 && remaining == 0 && flush))) break;
-#ifndef VPT_TAG_NO_PASS   // (experiment: the step loop and the lookups alone -- what a pass of its own launch would leave behind)
-            tag_pass(P, L, nq, lane, dbg);
-#endif
-            nq = 0;
-            if (!remaining) break;
         }
-    }
-    while (todo) {   // wave-uniform: the whole wave, one token at a time; its sentence is looked up in the offsets (rare models)
-        const int k = __ffsll((long long)todo) - 1;
-        todo &= todo - 1;
-        const uint32_t mk = uint32_t(__shfl(int(model), k));
-        const uint64_t gk = uint64_t(uint32_t(__shfl(int(uint32_t(gp)), k))) | (uint64_t(uint32_t(__shfl(int(uint32_t(gp >> 32)), k))) << 32);
-        uint64_t lo = 0, hi = P.n_sent;   // the last sentence i with ooff[i] + i <= gk
-        while (hi - lo > 1) {
-            const uint64_t mid = (lo + hi) >> 1;
-            if (P.ooff[mid] + mid <= gk) lo = mid; else hi = mid;
-        }
-        const uint64_t g0 = P.ooff[lo] + lo;
-#ifndef VPT_TAG_NO_PASS
-        tag_token_by_wave(P, P.cps + g0, int64_t(P.ooff[lo + 1] - P.ooff[lo]) + 1, int64_t(gk - g0), g0, mk, L.z, lane);
-#endif
     }
     __builtin_amdgcn_wave_barrier();
 }
 
-// The passes as a launch of their own: the waves stride over the queue the front-end launch left in HBM, 16 tokens a pass; then over
-// the tokens of the models outside the record form, one per wave at a time.
+// The passes: the waves stride over the queue the front end left in HBM, 16 tokens a pass; then over the tokens of the models outside
+// the record form, one per wave at a time.  The grid is what the device holds.
 __global__ __launch_bounds__(kTagThreads, kTagPairOcc) void tag_pass_kernel(const TagParams P) {
     __shared__ TagWaveLds LDS[kTagWaves];
     const int lane = threadIdx.x & 63;
     const uint32_t wid = wave_uniform(threadIdx.x >> 6);
     TagWaveLds& L = LDS[wid];
     const uint64_t wave = uint64_t(blockIdx.x) * kTagWaves + wid, n_waves = uint64_t(gridDim.x) * kTagWaves;
-    if (wave_uniform(P.qctl[2]) != 0) return;   // overflow: the one-launch kernel behind this one does the batch
     const uint64_t n_fast = wave_uniform(P.qctl[0]), n_slow = wave_uniform(P.qctl[1]);
     for (uint64_t q0 = wave * kTagPass; q0 < n_fast; q0 += n_waves * kTagPass) {
         const uint32_t nq = uint32_t(n_fast - q0 < uint64_t(kTagPass) ? n_fast - q0 : uint64_t(kTagPass));
         if (uint32_t(lane) < nq) {
             const uint4 e = P.queue[q0 + lane];
+            const uint2 ro = P.qrun[q0 + lane];
             L.f.tok[lane][0] = e.z; L.f.tok[lane][1] = e.x; L.f.tok[lane][2] = e.y; L.f.tok[lane][3] = e.w;
+            L.f.tok[lane][11] = uint32_t(P.run_pref[ro.x]) + ro.y;
         }
-        tag_pass(P, L, nq, lane, 0u);
+        tag_pass(P, L, nq, lane);
     }
     for (uint64_t k = wave; k < n_slow; k += n_waves) {
-        const uint4 e = P.queue[P.queue_fast + k];
+        const uint64_t at = uint64_t(P.queue_cap) - 1u - k;
+        const uint4 e = P.queue[at];
+        const uint2 ro = P.qrun[at];
         const uint64_t gk = uint64_t(wave_uniform(e.x)) | (uint64_t(wave_uniform(e.y)) << 32);
         uint64_t lo = 0, hi = P.n_sent;   // the last sentence i with ooff[i] + i <= gk
         while (hi - lo > 1) {
@@ -647,232 +561,19 @@ __global__ __launch_bounds__(kTagThreads, kTagPairOcc) void tag_pass_kernel(cons
             if (P.ooff[mid] + mid <= gk) lo = mid; else hi = mid;
         }
         const uint64_t g0 = P.ooff[lo] + lo;
-        tag_token_by_wave(P, P.cps + g0, int64_t(P.ooff[lo + 1] - P.ooff[lo]) + 1, int64_t(gk - g0), g0, wave_uniform(e.z), L.z, lane);
+        tag_token_by_wave(P, P.cps + g0, int64_t(P.ooff[lo + 1] - P.ooff[lo]) + 1, int64_t(gk - g0), g0, wave_uniform(e.z), VPT_TO_LDS_PTR(volatile int32_t, L.z), lane,
+                          wave_uniform64(P.run_pref[wave_uniform(ro.x)]) + wave_uniform(ro.y));
     }
 }
 
-// kSplit: the front-end launch of the pair (the step loop and the lookups; tag_pass_kernel follows).  Without it: everything in one
-// launch -- small batches, and any batch whose queue overflowed (then the pair has left `overflow` set and this kernel, launched
-// behind it, runs; otherwise it returns at once).
-template <bool DBG, bool kSplit>
-__global__ __launch_bounds__(kTagThreads, kSplit ? kTagFrontOcc : VPT_TAG_OCC) void tag_tokens_kernel(const TagParams P, const uint32_t dbg_in) {
-    const uint32_t dbg = DBG ? dbg_in : 0u;   // timing ablations (VPT_DEBUG_TAGS; results are wrong with any bit set)
-    if (!kSplit && P.qctl && wave_uniform(P.qctl[2]) == 0) return;   // the pair did the batch
-    __shared__ TagKernelLds<kSplit> LDS;
-    const int lane = threadIdx.x & 63;
-    const uint32_t wid = wave_uniform(threadIdx.x >> 6);     // a scalar, and everything derived from it below
-    TagFrontLds& L = LDS.fr[wid];
-    TagWaveLds* const Lp = LDS.pass(wid);
-    const uint64_t wave = uint64_t(blockIdx.x) * kTagWaves + wid;
-    const uint64_t n_waves = uint64_t(gridDim.x) * kTagWaves;
-    const uint32_t nt = P.n_tags;
-    const uint64_t below_me = (uint64_t(1) << lane) - 1;
-    uint32_t nq = 0, nc = 0;   // queued tokens, waiting candidates (wave-uniform)
-    if constexpr (kSplit) {
-    // ---- the front-end launch: with 49 VGPRs there is room to hide its trips to memory (in the one-launch kernel the same loop spills
-    // 35 VGPRs and loses: profiles/r03_w_tag_variants.txt)
-    // A sentence starts with two dependent trips to memory (its offsets, then its first chars and labels) that nothing of the sentence
-    // can overlap with -- a wave takes 140 sentences of configs[4] in turn: the offsets are loaded TWO sentences ahead, the first
-    // step's chars and labels one sentence ahead.
-    auto sent_offsets = [&](uint64_t i, uint64_t* o0, uint64_t* o1) {
-        *o0 = 0; *o1 = 0;
-        if (i < P.n_sent) { *o0 = wave_uniform64(P.ooff[i]); *o1 = wave_uniform64(P.ooff[i + 1]); }
-    };
-    // chars of a sentence, or 0 when its offsets do not fit the batch (reported by decode_chars_kernel / the scoring kernel; such a
-    // sentence -- and one of 2^31 chars: not in this kernel's index width -- is taken as empty here)
-    auto sent_chars = [&](uint64_t i, uint64_t o0, uint64_t o1) {
-        const bool sane = i < P.n_sent && o1 >= o0 && o1 + i + 1 <= P.total_chars && o1 - o0 < 0x7FFFFF00ull;
-        return sane ? int(o1 - o0) + 1 : 0;
-    };
-    auto first_step = [&](uint64_t i, uint64_t o0, int n, uint32_t* c, uint32_t* b) {   // (two half-steps of 64 chars)
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            const int q = 64 * h + lane;
-            c[h] = q < n ? P.cps[o0 + i + uint64_t(q)] : 0u;
-            b[h] = q < n - 1 ? uint32_t(P.labels[o0 + uint64_t(q)]) : (q == n - 1 ? 1u : 0u);
-        }
-    };
-    uint64_t o0_a, o1_a, o0_b, o1_b;
-    sent_offsets(wave, &o0_a, &o1_a);
-    sent_offsets(wave + n_waves, &o0_b, &o1_b);
-    uint32_t c_first[2], b_first[2];
-    first_step(wave, o0_a, sent_chars(wave, o0_a, o1_a), c_first, b_first);
-    for (uint64_t si = wave; si < P.n_sent; si += n_waves) {
-        const uint64_t o0 = o0_a, o1 = o1_a;
-        const uint64_t g0 = o0 + si;                            // flat index of the sentence's first char
-        const int n = sent_chars(si, o0, o1);  // chars
-        const uint32_t* cps = P.cps + g0;
-        const uint8_t* lab = P.labels + o0;                      // n - 1 labels
-        int start = 0;              // where the token that is open at the beginning of this step started
-        bool have_start = true;     // ... and no Unknown boundary has been seen inside it (predictor.rs:566-567)
-        // the step's chars and labels are fetched one step ahead
-        uint32_t c_next[2] = {c_first[0], c_first[1]}, b_next[2] = {b_first[0], b_first[1]};
-        o0_a = o0_b; o1_a = o1_b;
-        first_step(si + n_waves, o0_a, sent_chars(si + n_waves, o0_a, o1_a), c_first, b_first);
-        sent_offsets(si + 2 * n_waves, &o0_b, &o1_b);
-        // A step = two half-steps of 64 chars: their chars, labels and filter words travel together, so a wave waits once per 128
-        // chars for each (round 2 asked for exactly this: "tokens of two 64-char steps per lookup").
-        for (int base = 0; base == 0 || base < n; base += 128) {
-            uint32_t c[2], b[2];
-#pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                c[h] = c_next[h]; b[h] = b_next[h];
-                const int pn = base + 128 + 64 * h + lane;
-                c_next[h] = pn < n ? cps[pn] : 0u;
-                b_next[h] = pn < n - 1 ? uint32_t(lab[pn]) : (pn == n - 1 ? 1u : 0u);
-                L.txt[(base + 64 * h + lane) & (kRing - 1)] = c[h];
-            }
-            uint64_t ends[2], unk[2];
-#pragma unroll
-            for (int h = 0; h < 2; ++h) { ends[h] = __ballot(b[h] == 1u); unk[h] = __ballot(b[h] == 2u); }
-            __builtin_amdgcn_wave_barrier();
-            // ---- (1) this lane's tokens, if its chars end one: [s0, p], valid when no Unknown lies inside.  Could they have a tag model?
-            int s0[2];
-            bool valid[2];
-            uint32_t fbit[2], fword[2];
-#pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                const int hb = base + 64 * h;
-                const uint64_t prev_ends = ends[h] & below_me;
-                const int prev = prev_ends ? 63 - __clzll((long long)prev_ends) : -1;
-                s0[h] = prev >= 0 ? hb + prev + 1 : start;
-                const uint64_t after_prev = prev >= 0 ? ~((uint64_t(2) << prev) - 1) : ~uint64_t(0);
-                valid[h] = b[h] == 1u && (unk[h] & below_me & after_prev) == 0 && (prev >= 0 || have_start) && !(dbg & 1u);
-                fbit[h] = valid[h] ? tag_filter_bit(P, cps, L.txt, base - 128, s0[h], hb + lane) : 0u;
-                // the token that stays open into the next half-step
-                if (ends[h]) {
-                    const int last = 63 - __clzll((long long)ends[h]);
-                    start = hb + last + 1;
-                    have_start = last == 63 || (unk[h] >> (last + 1)) == 0;
-                } else if (unk[h]) {
-                    have_start = false;
-                }
-            }
-#pragma unroll
-            for (int h = 0; h < 2; ++h) fword[h] = valid[h] ? P.tok_tab[(size_t(4) << P.tok_bits) + (fbit[h] >> 5)] : 0u;
-#pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                const int p = base + 64 * h + lane;
-                const bool cand = valid[h] && ((fword[h] >> (fbit[h] & 31u)) & 1u) != 0;
-                // every char of the sentence gets its entries here or when its token has been looked up (nothing is cleared beforehand):
-                // 0 / None where no token with a tag model ends
-                if (p < n && !cand) {
-                    if (P.tok_model) P.tok_model[g0 + uint64_t(p)] = 0;
-                    if (P.model_out) P.model_out[g0 + uint64_t(p)] = -1;
-                    for (uint32_t j = 0; j < nt; ++j) P.tags[(g0 + uint64_t(p)) * nt + j] = -1;
-                }
-                // ---- (2) the candidates wait for the token table together: 64 of them are a lookup with every lane busy
-                const uint64_t cmask = __ballot(cand);
-                if (cmask != 0) {
-                    const uint32_t rank = uint32_t(__popcll(cmask & below_me));
-                    uint32_t remaining = uint32_t(__popcll(cmask)), done = 0;
-                    for (;;) {
-                        const uint32_t room = uint32_t(kTagCand) - nc, take = remaining < room ? remaining : room;
-                        if (cand && rank >= done && rank < done + take) {
-                            const uint32_t row = nc + rank - done;
-                            const uint64_t gp = g0 + uint64_t(p);
-                            const uint32_t back = p < kCtxBack ? uint32_t(p) : uint32_t(kCtxBack);
-                            const uint32_t fwd = n - 1 - p < kCtx - 1 - kCtxBack ? uint32_t(n - 1 - p) : uint32_t(kCtx - 1 - kCtxBack);
-                            L.cand[row][0] = uint32_t(gp); L.cand[row][1] = uint32_t(gp >> 32); L.cand[row][2] = uint32_t(p - s0[h] + 1); L.cand[row][3] = back | (fwd << 8);
-                        }
-                        nc += take; done += take; remaining -= take;
-                        if (nc != uint32_t(kTagCand)) break;
-                        tag_resolve<kSplit>(P, L, Lp, nc, nq, false, lane, dbg);
-                        nc = 0;
-                        if (!remaining) break;
-                    }
-                }
-            }
-            __builtin_amdgcn_wave_barrier();   // the ring is written by the next step
-        }
-    }
-    } else {
-    for (uint64_t si = wave; si < P.n_sent; si += n_waves) {
-        const uint64_t o0 = wave_uniform64(P.ooff[si]), o1 = wave_uniform64(P.ooff[si + 1]);
-        const uint64_t g0 = o0 + si;                            // flat index of the sentence's first char
-        // offsets that do not fit the batch are reported by decode_chars_kernel / the scoring kernel; such a sentence (and one of
-        // 2^31 chars: not in this kernel's index width) is taken as empty here
-        const bool sane = o1 >= o0 && o1 + si + 1 <= P.total_chars && o1 - o0 < 0x7FFFFF00ull;
-        const int n = sane ? int(o1 - o0) + 1 : 0;  // chars
-        const uint32_t* cps = P.cps + g0;
-        const uint8_t* lab = P.labels + o0;                      // n - 1 labels
-        int start = 0;              // where the token that is open at the beginning of this step started
-        bool have_start = true;     // ... and no Unknown boundary has been seen inside it (predictor.rs:566-567)
-        // the step's chars and labels are fetched one step ahead
-        uint32_t c_next = lane < n ? cps[lane] : 0u;
-        uint32_t b_next = lane < n - 1 ? uint32_t(lab[lane]) : (lane == n - 1 ? 1u : 0u);
-        for (int base = 0; base == 0 || base < n; base += 64) {
-            const int p = base + lane;
-            const uint32_t c = c_next, b = b_next;
-            {
-                const int pn = p + 64;
-                c_next = pn < n ? cps[pn] : 0u;
-                b_next = pn < n - 1 ? uint32_t(lab[pn]) : (pn == n - 1 ? 1u : 0u);
-            }
-            L.txt[p & (kRing - 1)] = c;
-            const uint64_t ends = __ballot(b == 1u), unk = __ballot(b == 2u);
-            __builtin_amdgcn_wave_barrier();
-            // ---- (1) this lane's token, if its char ends one: [s0, p], valid when no Unknown lies inside.  Could it have a tag model?
-            const uint64_t prev_ends = ends & below_me;
-            const int prev = prev_ends ? 63 - __clzll((long long)prev_ends) : -1;
-            const int s0 = prev >= 0 ? base + prev + 1 : start;
-            const uint64_t after_prev = prev >= 0 ? ~((uint64_t(2) << prev) - 1) : ~uint64_t(0);
-            const bool valid = b == 1u && (unk & below_me & after_prev) == 0 && (prev >= 0 || have_start);
-            const bool cand = valid && !(dbg & 1u) && tag_filter_hit(P, cps, L.txt, base, s0, p);
-            // every char of the sentence gets its entries here or when its token has been looked up (nothing is cleared beforehand):
-            // 0 / None where no token with a tag model ends
-            if (p < n && !cand) {
-                if (P.tok_model) P.tok_model[g0 + uint64_t(p)] = 0;
-                if (P.model_out) P.model_out[g0 + uint64_t(p)] = -1;
-                for (uint32_t j = 0; j < nt; ++j) P.tags[(g0 + uint64_t(p)) * nt + j] = -1;
-            }
-            // ---- (2) the candidates wait for the token table together: 64 of them are a lookup with every lane busy
-            const uint64_t cmask = __ballot(cand);
-            if (cmask != 0) {
-                const uint32_t rank = uint32_t(__popcll(cmask & below_me));
-                uint32_t remaining = uint32_t(__popcll(cmask)), done = 0;
-                for (;;) {
-                    const uint32_t room = uint32_t(kTagCand) - nc, take = remaining < room ? remaining : room;
-                    if (cand && rank >= done && rank < done + take) {
-                        const uint32_t row = nc + rank - done;
-                        const uint64_t gp = g0 + uint64_t(p);
-                        const uint32_t back = p < kCtxBack ? uint32_t(p) : uint32_t(kCtxBack);
-                        const uint32_t fwd = n - 1 - p < kCtx - 1 - kCtxBack ? uint32_t(n - 1 - p) : uint32_t(kCtx - 1 - kCtxBack);
-                        L.cand[row][0] = uint32_t(gp); L.cand[row][1] = uint32_t(gp >> 32); L.cand[row][2] = uint32_t(p - s0 + 1); L.cand[row][3] = back | (fwd << 8);
-                    }
-                    nc += take; done += take; remaining -= take;
-                    if (nc != uint32_t(kTagCand)) break;
-                    tag_resolve<kSplit>(P, L, Lp, nc, nq, false, lane, dbg);
-                    nc = 0;
-                    if (!remaining) break;
-                }
-            }
-            // the token that stays open into the next step
-            if (ends) {
-                const int last = 63 - __clzll((long long)ends);
-                start = base + last + 1;
-                have_start = last == 63 || (unk >> (last + 1)) == 0;
-            } else if (unk) {
-                have_start = false;
-            }
-            __builtin_amdgcn_wave_barrier();   // the ring is written by the next step
-        }
-    }
-    }
-    // what still waits: the candidates, then the queue
-    if (nc != 0 || nq != 0) tag_resolve<kSplit>(P, L, Lp, nc, nq, true, lane, dbg);
-}
-
-
-// The front-end launch, FLAT over the batch's chars (round 4).  tag_tokens_kernel<.., kSplit> gives a sentence to a wave: its steps of
-// 128 chars run half empty at a sentence's end (configs[4]'s sentences of 8 .. 512 chars: 2.5 steps where 2.0 would do) and every
-// sentence starts with its own trips for offsets and first chars.  Here a wave takes a RUN of `per` consecutive sentences, which are
-// consecutive chars (char q of sentence i sits at ooff[i] + i + q), and walks them in the same steps of two 64-char half-steps with
-// every lane busy up to the run's last step.  What the per-sentence loop knew from its loop variables comes from two bitmaps per
+// The front end, FLAT over the batch's chars (round 4; a wave per sentence ran its steps of 128 chars half empty at a sentence's end --
+// configs[4]'s sentences of 8 .. 512 chars: 2.5 steps where 2.0 would do -- and started every sentence with its own trips for offsets
+// and first chars).  A wave takes a RUN of `per` consecutive sentences, which are consecutive chars (char q of sentence i sits at
+// ooff[i] + i + q), and walks them in steps of two 64-char half-steps with every lane busy up to the run's last step.  What the per-sentence loop knew from its loop variables comes from two bitmaps per
 // step, built a step ahead from the run's offsets (64 sentences' worth in the lanes at a time): SM, the chars that start a sentence, and EM,
 // the chars that end one -- a sentence's last char ends a token (predictor.rs:563-570), the label of any other char q of sentence i is
 // labels[flat(q) - i], and a candidate's context stops at its sentence's ends.  The token logic (ends, Unknown, filter, candidates,
-// lookups, queue in HBM) is tag_tokens_kernel's, in run-relative positions.
+// lookups, queue in HBM) works in run-relative positions.
 //
 // Round 5, first the same steps in fewer vector instructions (358 of them per step, two thirds of the SIMDs' issue slots by the counters:
 // profiles/r05_z2_c4_summary.txt; SQ_INSTS_VALU 372 M -> 162 M per launch of configs[4] -- which bought 4 %: the instructions were not the
@@ -886,8 +587,9 @@ __global__ __launch_bounds__(kTagThreads, kSplit ? kTagFrontOcc : VPT_TAG_OCC) v
 //     that way are the tainted ones;
 //   * counts of mask bits below a lane through v_mbcnt, lane predicates straight from scalar masks;
 //   * the ring keeps its first three words again behind its end, so a token's first four chars are four consecutive LDS words;
-//   * the one or two candidates of a half-step are put into their rows by scalar code (context clip from the bitmaps, length from the lane);
-//   * the None entries of a char as ONE store for 1, 2 or 4 tags per token.
+//   * the one or two candidates of a half-step are put into their rows by scalar code (context clip from the bitmaps, length from the lane).
+// Round 6: the kernel STORES NOTHING but the queue entries of the tokens that have a tag model (it used to write the None entries of every
+// char -- two thirds of its stores, 0.30 of its 0.75 ms by the ablations -- and the writer's token word per char: the output is the records now).
 #ifndef VPT_TAG_FLAT_OCC
 #define VPT_TAG_FLAT_OCC 6     // waves per SIMD the flat front end is compiled for (A/B builds: -D); 62 VGPRs either way, the scalar registers decide
 #endif
@@ -915,15 +617,8 @@ __device__ __forceinline__ void read_tag_params(TagParams& Q, VPT_KARG(TagParams
 __device__ __forceinline__ uint32_t mask_bits_below_lane(uint64_t mask, uint32_t plus) {   // of a wave-uniform mask: v_mbcnt_lo / _hi
     return __builtin_amdgcn_mbcnt_hi(uint32_t(mask >> 32), __builtin_amdgcn_mbcnt_lo(uint32_t(mask), plus));
 }
-// kFill = 1, 2, 4: the batch has a tok_model array, no model_out, and that many tags per token with an array aligned for one store of them --
-// then every char of a full step gets its None entries UNCONDITIONALLY, right behind the step's loads (a char whose token turns out to
-// have a tag model is written again by tag_pass_kernel, the launch behind this one; everything this kernel itself writes is a None entry,
-// so writing one twice changes nothing).  Why: the counter a wave waits on counts loads and stores alike, in order; entries stored at the
-// end of a step -- they depended on the filter words -- made the next step's wait for ITS filter words a wait for their write
-// acknowledgements as well, and that, not the instruction count, was most of a step's time.  Stores that depend on nothing sit between the
-// loads and the wait, with no branch for the wait to be merged over.  kFill = 0: anything else, entries stored where no candidate is.
 // kSum: a SUMMARY of the token table's filter sits in LDS (2^18 bits, one for every 2^(tok_bits + 5 - 18) of the filter's: set when any of
-// them is; built by tag_filter_summary_kernel in front of this launch, into the tail of the queue's slow part).  The filter word of a token
+// them is; built by tag_filter_summary_kernel in front of this launch, into TagParams::summary).  The filter word of a token
 // end is a random 4-byte load that hits the L2 -- 25 of them per half-step, 52 M per launch of configs[4], a third of the kernel's time at the
 // rate the vector L1 takes random lanes (profiles/r05_y_tag_front_ablations.txt: keys + filter loads 0.32 ms, None stores 0.30 ms, the rest
 // 0.09 + 0.09, and they ADD) -- and 96 of 100 answers are "no".  With 50 000 tag models the summary is a sixth full: five of six of those
@@ -953,9 +648,8 @@ __global__ __launch_bounds__(256) void tag_filter_summary_kernel(const uint32_t*
     }
     out[w] = r;
 }
-template <int kFill, bool kSum>
-__global__ __launch_bounds__(kFlatThreads, VPT_TAG_FLAT_OCC) void tag_front_flat_kernel(const TagParams P_in, const uint32_t per, const uint32_t* __restrict__ summary,
-                                                                                         const uint32_t sum_log2) {
+template <bool kSum>
+__global__ __launch_bounds__(kFlatThreads, VPT_TAG_FLAT_OCC) void tag_front_flat_kernel(const TagParams P_in, const uint32_t sum_log2) {
     VPT_KARG(TagParams) P = VPT_KARG_PTR(TagParams, P_in);   // (read where it is used, like the scoring kernel's block: device_common.h)
     __shared__ TagFrontLds FR[kFlatWaves];
     __shared__ uint32_t BITS[kFlatWaves][8];   // per wave: the marks of the step being prepared, when there are many (5 words)
@@ -966,15 +660,16 @@ __global__ __launch_bounds__(kFlatThreads, VPT_TAG_FLAT_OCC) void tag_front_flat
     uint32_t* const bits = BITS[wid];
     const uint64_t wave = uint64_t(blockIdx.x) * kFlatWaves + wid, n_waves = uint64_t(gridDim.x) * kFlatWaves;
     if constexpr (kSum) {
+        const uint32_t* const summary = P->summary;
         for (uint32_t i = threadIdx.x; i < (1u << (sum_log2 - 5u)); i += uint32_t(kFlatThreads)) SUM[i] = summary[i];
         __syncthreads();
     }
     const uint32_t sshift = 32u - sum_log2;
-    const uint32_t nt = P->n_tags;
     const uint64_t below_me = (uint64_t(1) << lane) - 1;
     const uint64_t total_b = P->total_chars - P->n_sent;   // labels of the batch
-    const uint64_t n_runs = (P->n_sent + per - 1) / per;
-    uint32_t nq = 0, nc = 0;   // (queued tokens: unused by the front end), waiting candidates (wave-uniform)
+    const uint32_t per = P->run_sent;
+    const uint64_t n_runs = P->n_runs;
+    uint32_t nc = 0;   // waiting candidates (wave-uniform)
     VPT_TP_DECL;
     for (uint64_t run = wave; run < n_runs; run += n_waves) {
         VPT_TP(0);
@@ -990,10 +685,6 @@ __global__ __launch_bounds__(kFlatThreads, VPT_TAG_FLAT_OCC) void tag_front_flat
         // a step is a chain of waits, not of instructions)
         const uint32_t* const cps = P->cps + run0;
         const uint8_t* const lab_run = P->labels + o_a;
-        int32_t* const tok_model = P->tok_model, * const model_out = P->model_out;
-        int32_t* const tm_run = tok_model + run0;   // (nullptr stays a pointer that is not used)
-        int32_t* const mo_run = model_out + run0;
-        int32_t* const tg_run = P->tags + run0 * nt;
         const uint32_t tok_bits = P->tok_bits, fshift = 32u - tok_bits - kTagFilterLog2;
         const uint32_t* const filt = P->tok_tab + (size_t(4) << tok_bits);
         // the label of char q of the run, in sentence i_a + k: labels[o_a + q - k]; nothing past the batch's last label is read whatever
@@ -1093,7 +784,6 @@ __global__ __launch_bounds__(kFlatThreads, VPT_TAG_FLAT_OCC) void tag_front_flat
             const uint32_t c[2] = {c_next[0], c_next[1]}, b[2] = {b_next[0], b_next[1]};
             const uint64_t sm[2] = {mk0, mk1};   // this step's marks (the next step's are prepared below)
             const uint32_t sm_top = mk2;         // ... and the mark of the char behind it
-            const uint32_t rem = n - base;
             {   // the ring: char x at txt[x & 255], and chars = 0, 1, 2 (mod 256) once more behind its end
                 const uint32_t r = (base & 128u) + lane;
                 L.txt[r] = c[0];
@@ -1152,21 +842,6 @@ __global__ __launch_bounds__(kFlatThreads, VPT_TAG_FLAT_OCC) void tag_front_flat
 #pragma unroll
             for (uint32_t h = 0; h < 2; ++h) fword[h] = (!(VPT_TAG_ABLATE & 1) && want[h]) ? filt[fbit[h] >> 5] : 0u;
             VPT_TP(4);   // token ends, keys, filter loads issued
-            constexpr bool kStoreAll = kFull && kFill != 0;
-            if constexpr (kStoreAll && !(VPT_TAG_ABLATE & 4)) {   // (see above: nothing between the loads and these stores that the wait would have to be merged over)
-                __builtin_amdgcn_sched_barrier(0);   // behind the filter loads ...
-                int32_t* const tm = tm_run + base;
-                int32_t* const tg = tg_run + size_t(base) * uint32_t(kFill);
-#pragma unroll
-                for (uint32_t h = 0; h < 2; ++h) {
-                    const uint32_t q = lane + 64u * h;
-                    tm[q] = 0;
-                    if constexpr (kFill == 1) tg[q] = -1;
-                    else if constexpr (kFill == 2) reinterpret_cast<int2*>(tg)[q] = make_int2(-1, -1);
-                    else reinterpret_cast<int4*>(tg)[q] = make_int4(-1, -1, -1, -1);
-                }
-                __builtin_amdgcn_sched_barrier(0);   // ... and in front of the wait for them
-            }
 #ifdef VPT_TAG_PROFILE
             VPT_TP(5);   // stores issued
             VPT_PIN(fword[0]); VPT_PIN(fword[1]);
@@ -1175,23 +850,7 @@ __global__ __launch_bounds__(kFlatThreads, VPT_TAG_FLAT_OCC) void tag_front_flat
 #endif
 #pragma unroll
             for (uint32_t h = 0; h < 2; ++h) {
-                const uint32_t q = lane + 64u * h;
                 const bool cand = ((fword[h] >> (fbit[h] & 31u)) & 1u) != 0;   // (no filter word where no valid token ends)
-                // every char of the run gets its entries here or when its token has been looked up (nothing is cleared beforehand):
-                // 0 / None where no token with a tag model ends
-                if constexpr (!kStoreAll) {
-                    if (q < rem && !cand) {
-                        int32_t* const tm = tok_model ? tm_run + base : nullptr;
-                        int32_t* const mo = model_out ? mo_run + base : nullptr;
-                        int32_t* const tg = tg_run + size_t(base) * nt;
-                        if (tm) tm[q] = 0;
-                        if (mo) mo[q] = -1;
-                        if constexpr (kFill == 1) tg[q] = -1;
-                        else if constexpr (kFill == 2) reinterpret_cast<int2*>(tg)[q] = make_int2(-1, -1);
-                        else if constexpr (kFill == 4) reinterpret_cast<int4*>(tg)[q] = make_int4(-1, -1, -1, -1);
-                        else for (uint32_t j = 0; j < nt; ++j) tg[q * nt + j] = -1;
-                    }
-                }
                 // ---- (2) the candidates wait for the token table together: 64 of them are a lookup with every lane busy.  There are one or
                 // two in a half-step (BASELINE's configs[4]): each is put into its row by scalar code -- its context clip from the bitmaps
                 // (chars of the token's sentence in front of / behind its last char: up to the nearest sentence start at or in front of
@@ -1216,7 +875,7 @@ __global__ __launch_bounds__(kFlatThreads, VPT_TAG_FLAT_OCC) void tag_front_flat
                         const uint32_t fwd = fwd_full < uint32_t(kCtx - 1 - kCtxBack) ? fwd_full : uint32_t(kCtx - 1 - kCtxBack);
                         const uint32_t ln = uint32_t(__builtin_amdgcn_readlane(int(len[h]), k));
                         const uint64_t gp = run0 + uint64_t(base + 64u * h + uint32_t(k));
-                        if (lane == 0) *reinterpret_cast<uint4*>(L.cand[nc]) = make_uint4(uint32_t(gp), uint32_t(gp >> 32), ln, back | (fwd << 8));
+                        if (lane == 0) { *reinterpret_cast<uint4*>(L.cand[nc]) = make_uint4(uint32_t(gp), uint32_t(gp >> 32), ln, back | (fwd << 8)); L.crun[nc] = uint32_t(run); }
                         if ((VPT_TAG_ABLATE & 64) && nc == uint32_t(kTagCand) - 1u) nc = 0;
                         if (++nc == uint32_t(kTagCand)) {
                             VPT_TP(7);   // candidates into their rows (and a last step's entries)
@@ -1224,7 +883,7 @@ __global__ __launch_bounds__(kFlatThreads, VPT_TAG_FLAT_OCC) void tag_front_flat
                             VPT_KARG_FENCE(R);
                             TagParams Q;
                             read_tag_params(Q, R);
-                            tag_resolve<true>(Q, L, nullptr, nc, nq, false, int(lane), 0u);
+                            tag_resolve(Q, L, nc, int(lane));
                             nc = 0;
                             VPT_TP(8);   // a lookup of 64 candidates
                         }
@@ -1239,7 +898,7 @@ __global__ __launch_bounds__(kFlatThreads, VPT_TAG_FLAT_OCC) void tag_front_flat
         if (base < n) step(std::false_type{});
     }
     VPT_TP(0);
-    if (nc != 0 && !(VPT_TAG_ABLATE & 64)) { TagParams Q; read_tag_params(Q, P); tag_resolve<true>(Q, L, nullptr, nc, nq, true, int(lane), 0u); }
+    if (nc != 0 && !(VPT_TAG_ABLATE & 64)) { TagParams Q; read_tag_params(Q, P); tag_resolve(Q, L, nc, int(lane)); }
     VPT_TP(8);
     VPT_TP_FLUSH();
 }
@@ -1257,96 +916,76 @@ hipError_t launch_decode_chars(const uint8_t* text, const uint64_t* boff, const 
     return hipGetLastError();
 }
 
-// CUs of the current device (capi.cpp has set it), asked for once per device
-static uint32_t device_cus() {
-    static std::atomic<uint32_t> cache[64];
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 0;
-    uint32_t c = cache[dev].load(std::memory_order_relaxed);
-    if (c == 0) {
-        hipDeviceProp_t prop;
-        if (hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) {
-            c = uint32_t(prop.multiProcessorCount);
-            cache[dev].store(c, std::memory_order_relaxed);
+uint32_t tag_run_sentences(uint64_t n_sent, uint64_t total_chars) {
+    // runs of about 2 K chars (16 steps), at least a sentence: enough runs for every wave of the grid to even out, a window of offsets every
+    // few steps (measured on configs[4], profiles/r04_o_tag_front.jsonl: runs of 2 K / 4 K / 16 K chars 1.761 / 1.781 / 1.970 ms stand-alone);
+    // at most 256 sentences (the writer's runs are whole multiples of these: kEmitFlatMaxBlock)
+    const uint64_t per = (uint64_t(VPT_TAG_RUN_CHARS) * n_sent + total_chars / 2) / std::max<uint64_t>(total_chars, 1);
+    return uint32_t(std::min<uint64_t>(std::max<uint64_t>(per, 1), 256));
+}
+size_t tag_summary_words() { return size_t(1) << (kSumLog2 - 5u); }
+
+// fill_tags: [summary of the token filter] -> front end (queue) -> scan (the runs' first records) -> passes (records).  The caller has zeroed
+// qctl, run_pref and scan_state and set the dense arrays it wants to None.
+hipError_t launch_tag_tokens(const TagParams& P, hipStream_t stream) {
+#ifdef VPT_TAG_PROFILE
+    {
+        unsigned long long h[16] = {0};
+        (void)hipStreamSynchronize(stream);
+        (void)hipMemcpyFromSymbol(h, HIP_SYMBOL(g_tag_prof), sizeof(h));
+        if (h[11]) {
+            static const char* names[9] = {"between runs", "run start", "step: ring", "step: prepare + fetch", "step: ends, keys", "step: stores", "step: WAIT filter words", "step: candidates", "lookups"};
+            std::fprintf(stderr, "[tag front profile] %llu runs, %llu steps, wave ticks %llu:", h[9], h[10], h[11]);
+            for (int k = 0; k < 9; ++k) std::fprintf(stderr, " %s %.1f%%", names[k], 100.0 * double(h[k]) / double(h[11]));
+            std::fprintf(stderr, "\n");
         }
+        unsigned long long z[16] = {0};
+        (void)hipMemcpyToSymbol(HIP_SYMBOL(g_tag_prof), z, sizeof(z));
     }
-    return c;
+#endif
+    const uint32_t cus = P.n_cus ? P.n_cus : 256u;
+    // the filter's summary for the workgroups' LDS
+    const uint32_t big_log2 = P.tok_bits + kTagFilterLog2, sum_log2 = std::min(big_log2, kSumLog2);
+    const uint32_t sum_words = 1u << (sum_log2 - 5u);
+#ifdef VPT_TAG_NO_SUMMARY   // (A/B builds: the same geometry without the summary.  A build switch, not an environment variable: nothing on the launch path calls getenv)
+    constexpr bool sum = false;
+#else
+    constexpr bool sum = true;
+    hipLaunchKernelGGL(tag_filter_summary_kernel, dim3((sum_words + 255u) / 256u), dim3(256), 0, stream, P.tok_tab + (size_t(4) << P.tok_bits), big_log2, sum_log2,
+                       const_cast<uint32_t*>(P.summary));
+#endif
+    // the grid: what the device holds at a time and no more -- 3 workgroups per CU (6 waves per SIMD; the summary's 32 KB each), their waves
+    // striding over the runs.  A workgroup loads its summary once; a second generation of workgroups would load it again and leave the
+    // CUs unevenly filled at the end (measured on configs[4]: 768 / 1024 / 1536 / 2048 / 4096 workgroups 0.69 / 0.83 / 0.74 / 0.76 /
+    // 0.80 ms, profiles/r05_zc_tag_front_grid.txt).
+    const uint64_t want_w = (P.n_runs + kFlatWaves - 1) / kFlatWaves, cap_w = uint64_t(cus) * (VPT_TAG_FLAT_OCC / 2);
+    const dim3 grid(uint32_t(want_w < 1 ? 1 : want_w > cap_w ? cap_w : want_w)), block(kFlatThreads);
+    hipLaunchKernelGGL((tag_front_flat_kernel<sum>), grid, block, 0, stream, P, sum_log2);
+    hipError_t e = launch_scan(P.run_pref, P.n_runs, P.scan_state, ~uint64_t(0), nullptr, nullptr, stream);
+    if (e != hipSuccess) return e;
+    // the passes: what the device holds (8 workgroups of 4 waves per CU), never more than a wave per char of the batch would need
+    const uint64_t want_p = (P.total_chars + uint64_t(kTagPass) * kTagWaves - 1) / (uint64_t(kTagPass) * kTagWaves), cap_p = uint64_t(cus) * kTagPairOcc;
+    hipLaunchKernelGGL(tag_pass_kernel, dim3(uint32_t(want_p < 1 ? 1 : want_p > cap_p ? cap_p : want_p)), dim3(kTagThreads), 0, stream, P);
+    return hipGetLastError();
 }
 
-hipError_t launch_tag_tokens(const TagParams& P, hipStream_t stream) {
-    // sentences differ in length (8..512 chars in BASELINE's configs[4]): a grid of one wave per sentence leaves the waves of a
-    // workgroup waiting for its longest one, so the waves stay (P.max_blocks = what the device runs at a time) and stride over the batch
-    const uint64_t want = (P.n_sent + kTagWaves - 1) / kTagWaves, cap = P.max_blocks ? P.max_blocks : 65536;
-    const uint32_t blocks = uint32_t(want < 1 ? 1 : want > cap ? cap : want);
-    static const uint32_t dbg = [] { const char* e = std::getenv("VPT_DEBUG_TAGS"); return e ? uint32_t(std::atoi(e)) : 0u; }();
-    if (P.queue && !dbg) {   // the pair, then the one-launch kernel for the case that the queue overflowed (it returns at once otherwise)
-        const hipError_t e = hipMemsetAsync(P.qctl, 0, 3 * sizeof(uint32_t), stream);
-        if (e != hipSuccess) return e;
-        // (A/B, VPT_TAG_FRONT_BY_SENTENCE -- read when the workspace was made: nothing on the launch path calls getenv) the front end that gives a wave a sentence at a time
-        if (P.front_by_sentence) hipLaunchKernelGGL((tag_tokens_kernel<false, true>), dim3(blocks), dim3(kTagThreads), 0, stream, P, 0u);
-        else {
-            // runs of about 2 K chars (16 steps), at least a sentence: enough runs for every wave of the grid to even out, a window of offsets every
-            // few steps (measured on configs[4], profiles/r04_o_tag_front.jsonl: runs of 2 K / 4 K / 16 K chars 1.761 / 1.781 / 1.970 ms stand-alone)
-            const uint64_t per = std::max<uint64_t>(1, (uint64_t(VPT_TAG_RUN_CHARS) * P.n_sent + P.total_chars / 2) / std::max<uint64_t>(P.total_chars, 1));
-            const uint64_t runs = (P.n_sent + per - 1) / per;
-            // a char's None entries as ONE store of 1, 2 or 4 tags (the array's alignment allowing), with the writer's tok_model array and no model_out:
-            // the instances that store them behind a step's loads, unconditionally
-            const uint32_t per32 = uint32_t(std::min<uint64_t>(per, 0x7FFFFFFFull));
-#ifdef VPT_TAG_PROFILE
-            {
-                unsigned long long h[16] = {0};
-                (void)hipStreamSynchronize(stream);
-                (void)hipMemcpyFromSymbol(h, HIP_SYMBOL(g_tag_prof), sizeof(h));
-                if (h[11]) {
-                    static const char* names[9] = {"between runs", "run start", "step: ring", "step: prepare + fetch", "step: ends, keys", "step: stores", "step: WAIT filter words", "step: candidates", "lookups"};
-                    std::fprintf(stderr, "[tag front profile] %llu runs, %llu steps, wave ticks %llu:", h[9], h[10], h[11]);
-                    for (int k = 0; k < 9; ++k) std::fprintf(stderr, " %s %.1f%%", names[k], 100.0 * double(h[k]) / double(h[11]));
-                    std::fprintf(stderr, "\n");
-                }
-                unsigned long long z[16] = {0};
-                (void)hipMemcpyToSymbol(HIP_SYMBOL(g_tag_prof), z, sizeof(z));
-            }
-#endif
-            const bool plain = P.tok_model && !P.model_out && (reinterpret_cast<uintptr_t>(P.tags) & 15u) == 0;
-            const int fill = !plain ? 0 : P.n_tags == 1 ? 1 : P.n_tags == 2 ? 2 : P.n_tags == 4 ? 4 : 0;
-            // the filter's summary for the workgroups' LDS: built into the last entries of the queue's slow part, which the front end then
-            // does not fill (a queue too small for that -- VPT_TAG_QUEUE in tests -- goes without)
-            const uint32_t big_log2 = P.tok_bits + kTagFilterLog2, sum_log2 = std::min(big_log2, kSumLog2);
-            const uint32_t sum_words = 1u << (sum_log2 - 5u), sum_entries = (sum_words + 3u) / 4u;
-#ifdef VPT_TAG_NO_SUMMARY   // (A/B builds: the same geometry without the summary.  A build switch, not an environment variable: nothing on the launch path calls getenv)
-            const bool sum = false;
-#else
-            const bool sum = P.queue_slow >= 2u * sum_entries + 64u;
-#endif
-            TagParams F = P;
-            const uint32_t* summary = nullptr;
-            if (sum) {
-                F.queue_slow = P.queue_slow - sum_entries;
-                uint32_t* const out = reinterpret_cast<uint32_t*>(P.queue + P.queue_fast + F.queue_slow);
-                hipLaunchKernelGGL(tag_filter_summary_kernel, dim3((sum_words + 255u) / 256u), dim3(256), 0, stream, P.tok_tab + (size_t(4) << P.tok_bits), big_log2, sum_log2, out);
-                summary = out;
-            }
-            // the grid: what the device holds at a time and no more -- 3 workgroups per CU (6 waves per SIMD; the summary's 32 KB each), their waves
-            // striding over the runs.  A workgroup loads its summary once; a second generation of workgroups would load it again and leave the
-            // CUs unevenly filled at the end (measured on configs[4]: 768 / 1024 / 1536 / 2048 / 4096 workgroups 0.69 / 0.83 / 0.74 / 0.76 /
-            // 0.80 ms, profiles/r05_zc_tag_front_grid.txt).  P.max_blocks (VPT_TAG_WGS_PER_CU) still caps it.
-            const uint32_t cus = device_cus();
-            const uint64_t want_w = (runs + kFlatWaves - 1) / kFlatWaves;
-            const uint64_t cap_w = std::min<uint64_t>(std::max<uint64_t>(1, cap * kTagWaves / kFlatWaves), cus ? uint64_t(cus) * (VPT_TAG_FLAT_OCC / 2) : ~uint64_t(0));
-            const dim3 grid(uint32_t(want_w < 1 ? 1 : want_w > cap_w ? cap_w : want_w)), block(kFlatThreads);
-#define VPT_LAUNCH_FLAT(f, s) hipLaunchKernelGGL((tag_front_flat_kernel<f, s>), grid, block, 0, stream, F, per32, summary, sum_log2)
-            if (sum) { if (fill == 1) VPT_LAUNCH_FLAT(1, true); else if (fill == 2) VPT_LAUNCH_FLAT(2, true); else if (fill == 4) VPT_LAUNCH_FLAT(4, true); else VPT_LAUNCH_FLAT(0, true); }
-            else { if (fill == 1) VPT_LAUNCH_FLAT(1, false); else if (fill == 2) VPT_LAUNCH_FLAT(2, false); else if (fill == 4) VPT_LAUNCH_FLAT(4, false); else VPT_LAUNCH_FLAT(0, false); }
-#undef VPT_LAUNCH_FLAT
-        }
-        hipLaunchKernelGGL(tag_pass_kernel, dim3(blocks), dim3(kTagThreads), 0, stream, P);
-        hipLaunchKernelGGL((tag_tokens_kernel<false, false>), dim3(blocks), dim3(kTagThreads), 0, stream, P, 0u);
-        return hipGetLastError();
+// vpt_expand_tags_batch_device: the dense array of the C ABI from the records -- None everywhere (the reference's Vec<Option<..>> after
+// `resize(n_tags * len, None)`, predictor.rs:556-557), then the records' tags at their tokens' last chars
+__global__ __launch_bounds__(256) void expand_tags_kernel(const uint4* __restrict__ records, const int32_t* __restrict__ rec_tags, const uint64_t* __restrict__ n_records,
+                                                          const uint32_t n_tags, const uint64_t total_chars, int32_t* __restrict__ tags) {
+    const uint64_t n = *n_records, n_items = n * n_tags;
+    for (uint64_t i = uint64_t(blockIdx.x) * 256u + threadIdx.x; i < n_items; i += uint64_t(gridDim.x) * 256u) {
+        const uint64_t k = i / n_tags, j = i - k * n_tags;
+        const uint4 r = records[k];
+        const uint64_t gp = uint64_t(r.x) | (uint64_t(r.y) << 32);
+        if (gp < total_chars) tags[gp * n_tags + j] = rec_tags[i];
     }
-    TagParams Q = P;
-    Q.queue = nullptr; Q.qctl = nullptr;
-    if (dbg) hipLaunchKernelGGL((tag_tokens_kernel<true, false>), dim3(blocks), dim3(kTagThreads), 0, stream, Q, dbg);
-    else hipLaunchKernelGGL((tag_tokens_kernel<false, false>), dim3(blocks), dim3(kTagThreads), 0, stream, Q, 0u);
+}
+hipError_t launch_expand_tags(const uint4* records, const int32_t* rec_tags, const uint64_t* n_records, uint32_t n_tags, uint64_t total_chars, int32_t* tags,
+                              uint32_t n_cus, hipStream_t stream) {
+    const hipError_t e = hipMemsetAsync(tags, 0xFF, size_t(total_chars) * n_tags * sizeof(int32_t), stream);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(expand_tags_kernel, dim3((n_cus ? n_cus : 256u) * 8u), dim3(256), 0, stream, records, rec_tags, n_records, n_tags, total_chars, tags);
     return hipGetLastError();
 }
 
