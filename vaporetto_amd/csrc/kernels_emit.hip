@@ -205,6 +205,9 @@ struct alignas(16) FlatLds {
 // with tags: which record (its number in the piece's records + 1; 0: none; kMarkCarry: the record carried over from the piece before) ends a
 // token at the piece's char k - 1, in marks[k]; marks[0]: the last char of the piece before
 constexpr uint32_t kMarkCarry = 0xFFFFu;
+#ifndef VPT_EMIT_ABLATE
+#define VPT_EMIT_ABLATE 0   // timing ablations of the tagged writer (A/B builds, wrong output): 1 the suffixes' bytes are not written, 2 no suffixes at all (the marks stay), 4 no marks either
+#endif
 struct alignas(16) FlatMarks { uint16_t m[kFlatPiece + 16]; };
 
 // exclusive prefix sum of x over the workgroup's threads (two packed 16-bit counts or one 32-bit one); *total = the sum
@@ -307,7 +310,7 @@ __global__ __launch_bounds__(kEmitThreads) void emit_flat_kernel(const EmitParam
             for (uint64_t r = r_lo + tid; r < r_hi; r += kEmitThreads) {
                 const uint4 rec = P.records[r];
                 const uint64_t pos = uint64_t(rec.x) | (uint64_t(rec.y) << 32);
-                if (pos >= g0 && pos < g1) added += tag_suffix_bytes(P, r, rec.z);
+                if (pos >= g0 && pos < g1 && !(VPT_EMIT_ABLATE & 6)) added += tag_suffix_bytes(P, r, rec.z);
             }
         }
         const uint64_t ws = wave_sum64(added);
@@ -422,7 +425,7 @@ __global__ __launch_bounds__(kEmitThreads) void emit_flat_kernel(const EmitParam
         if (kTags) {
             // mark the piece's records: sorted, so they are the next ones -- one coalesced read of their positions, a trip as a rule
             const uint64_t p_lo = g0 + cb, p_hi = p_lo + piece_chars;
-            for (;;) {
+            for (; !(VPT_EMIT_ABLATE & 4);) {
                 const uint64_t r = rp + n_rec + tid;
                 bool in = false;
                 if (r < r_hi) {
@@ -438,7 +441,7 @@ __global__ __launch_bounds__(kEmitThreads) void emit_flat_kernel(const EmitParam
             }
             tmask = spm | sm;
             if (sb + s_in == 0 && sm) tmask &= ~(sm & (0u - sm));
-            if (tmask) {
+            if (tmask && !(VPT_EMIT_ABLATE & 6)) {
                 // the records of the chars in front of the thread's chars: marks[c_in + j] for its j-th char; which of them are there at all
                 uint32_t pm = 0;
                 for (uint32_t j = 0; j < nl; ++j) pm |= (marks[c_in + j] != 0 ? 1u : 0u) << j;
@@ -493,7 +496,7 @@ __global__ __launch_bounds__(kEmitThreads) void emit_flat_kernel(const EmitParam
                     *(es ? o + pos : dump) = 0x5Cu; pos += es;
                     *(v ? o + pos : dump) = uint8_t(byte_of(x, k)); pos += v;
                 }
-                if (kTags && tl1) {   // the tags themselves (few threads)
+                if (kTags && tl1 && !(VPT_EMIT_ABLATE & 1)) {   // the tags themselves (few threads)
                     const uint32_t b1 = (1u << tk1) - 1u, b2 = (1u << tk2) - 1u;
                     if (tag_suffix_of(P, tr1, tm1, o + w + uint32_t(__popc(vm & b1)) + uint32_t(__popc(spm & b1)) + uint32_t(__popc(em & b1)), tl1) != tl1) err |= kErrBadOffsets;
                     if (tl2 && tag_suffix_of(P, tr2, tm2, o + w + tl1 + uint32_t(__popc(vm & b2)) + uint32_t(__popc(spm & b2)) + uint32_t(__popc(em & b2)), tl2) != tl2) err |= kErrBadOffsets;
@@ -561,7 +564,7 @@ __global__ __launch_bounds__(kEmitThreads) void emit_flat_kernel(const EmitParam
         cb += tot & 0xFFFFu;
         sb += tot >> 16;
     }
-    if (kTags && fits && carry_rec != ~uint64_t(0)) {   // the tags of the run's last token: the record, if any, of its last char
+    if (kTags && fits && carry_rec != ~uint64_t(0) && !(VPT_EMIT_ABLATE & 6)) {   // the tags of the run's last token: the record, if any, of its last char
         const uint4 rec = P.records[carry_rec];
         const uint32_t sl = (uint64_t(rec.x) | (uint64_t(rec.y) << 32)) == g1 - 1 ? tag_suffix(P, carry_rec, nullptr) : 0u;   // (every thread computes the same)
         if (sl && store_ok && at_out + sl <= end && tid == 0) tag_suffix(P, carry_rec, P.out_text + at_out);
