@@ -283,9 +283,10 @@ struct vpt_batch {
     // what the last fill_tags on this workspace left (TagParams, kernels.hpp): a record per token that has a tag model, sorted by position
     uint4* d_tag_records = nullptr; size_t tag_records_cap = 0;
     int32_t* d_rec_tags = nullptr; size_t rec_tags_cap = 0;
-    uint64_t* d_tag_ctl = nullptr; size_t tag_ctl_cap = 0;          // qctl (one word), the scan's state, run_pref [n_runs + 1]: zeroed as one range per call
+    uint64_t* d_tag_ctl = nullptr; size_t tag_ctl_cap = 0;          // the scan's state, run_pref [n_runs + 1]: zeroed as one range per call
     uint64_t* d_run_pref = nullptr;                                 // (inside d_tag_ctl)
-    uint2* d_tag_qrun = nullptr; size_t tag_qrun_cap = 0;
+    uint2* d_rec_str = nullptr; size_t rec_str_cap = 0;
+    uint4* d_tag_cands = nullptr; size_t tag_cands_cap = 0;
     uint32_t* d_tag_summary = nullptr;
     uint64_t tag_chars = 0, tag_sentences = 0, tag_runs = 0;        // the batch those records belong to (0 chars: none)
     uint32_t tag_run_sent = 0;
@@ -294,7 +295,6 @@ struct vpt_batch {
     uint64_t* d_scan_part = nullptr; size_t scan_part_cap = 0;      // per-workgroup partials of the prefix sums (kernels_emit.hip)
     // the writer's state words (EmitFuse): two arrays of emit_state_cap words, used in turn; a call zeroes what the call before it
     // left in the other one (emit_dirty = how many words that is)
-    uint4* d_tag_queue = nullptr; size_t tag_queue_cap = 0;        // fill_tags: the tokens that have a tag model, between the front end and the passes (TagParams::queue)
     uint64_t* d_emit_state = nullptr; size_t emit_state_cap = 0; size_t emit_dirty[2] = {0, 0}; int emit_flip = 0;
     uint64_t* d_fuse_state = nullptr; size_t fuse_state_cap = 0;   // the fused writer's words (EmitOut::state): one per tile + the ticket, + the chain word
     // the pipelined host-buffer path (predict_pipelined): two sets of device buffers, copy streams, pinned offset staging
@@ -368,12 +368,11 @@ void batch_release(vpt_batch* b) {
     (void)hipFree(b->d_scan_part);
     (void)hipFree(b->d_emit_state);
     (void)hipFree(b->d_fuse_state); (void)hipFree(b->d_chain);
-    (void)hipFree(b->d_tag_queue);
     (void)hipFree(b->d_tiles); (void)hipFree(b->d_cut_local); (void)hipFree(b->d_cut_super);
     (void)hipFree(b->d_tile_first); (void)hipFree(b->d_slow_list); (void)hipFree(b->d_ctrl); (void)hipFree(b->d_scratch);
     (void)hipFree(b->d_prof); (void)hipFree(b->d_cps);
     (void)hipFree(b->d_text); (void)hipFree(b->d_boff); (void)hipFree(b->d_ooff); (void)hipFree(b->d_scores); (void)hipFree(b->d_labels);
-    (void)hipFree(b->d_tags); (void)hipFree(b->d_tag_scores); (void)hipFree(b->d_tag_models); (void)hipFree(b->d_tok); (void)hipFree(b->d_tlab); (void)hipFree(b->d_toff); (void)hipFree(b->d_tag_records); (void)hipFree(b->d_rec_tags); (void)hipFree(b->d_tag_ctl); (void)hipFree(b->d_tag_qrun); (void)hipFree(b->d_tag_summary);
+    (void)hipFree(b->d_tags); (void)hipFree(b->d_tag_scores); (void)hipFree(b->d_tag_models); (void)hipFree(b->d_tok); (void)hipFree(b->d_tlab); (void)hipFree(b->d_toff); (void)hipFree(b->d_tag_records); (void)hipFree(b->d_rec_tags); (void)hipFree(b->d_tag_ctl); (void)hipFree(b->d_rec_str); (void)hipFree(b->d_tag_cands); (void)hipFree(b->d_tag_summary);
     (void)hipFree(b->d_types);
     for (auto& ps : b->pipe) {
         (void)hipFree(ps.text); (void)hipFree(ps.off); (void)hipFree(ps.scores); (void)hipFree(ps.labels);
@@ -1563,17 +1562,17 @@ vpt_status vpt_fill_tags_scores_batch_device(const vpt_predictor* p, vpt_batch* 
     // What the call leaves is ONE RECORD PER TOKEN THAT HAS A TAG MODEL (kernels.hpp, TagParams): the reference holds None for every other
     // char (predictor.rs:558-573).  Everything is sized for the worst case -- a tagged token per char, which a real tag model comes close
     // to (most tokens of real text have one; the synthetic M3's one token in thirty-five is the other end) -- so nothing can overflow and
-    // there is no second path: records 16 + 4 n_tags bytes, the queue between the two launches 16 + 8.
+    // there is no second path: records 16 + 12 n_tags bytes, the candidates between the launches 16.
     const uint32_t run_sent = vpt::tag_run_sentences(n_sentences, total_c);
     const uint64_t n_runs = (uint64_t(n_sentences) + run_sent - 1) / run_sent;
-    const size_t n_state = vpt::scan_part_entries(n_runs), ctl_words = 2 + n_state + size_t(n_runs) + 2;
+    const size_t n_state = vpt::scan_part_entries(n_runs), ctl_words = n_state + size_t(n_runs) + 2;
     if ((st = grow(&b->d_tag_records, &b->tag_records_cap, size_t(total_c) + 16)) != VPT_OK) return st;
     if ((st = grow(&b->d_rec_tags, &b->rec_tags_cap, size_t(total_c) * p->n_tags + 16)) != VPT_OK) return st;
-    if ((st = grow(&b->d_tag_queue, &b->tag_queue_cap, size_t(total_c) + 16)) != VPT_OK) return st;
-    if ((st = grow(&b->d_tag_qrun, &b->tag_qrun_cap, size_t(total_c) + 16)) != VPT_OK) return st;
+    if ((st = grow(&b->d_rec_str, &b->rec_str_cap, size_t(total_c) * p->n_tags + 16)) != VPT_OK) return st;
+    if ((st = grow(&b->d_tag_cands, &b->tag_cands_cap, size_t(total_c) + 16)) != VPT_OK) return st;
     if ((st = grow(&b->d_tag_ctl, &b->tag_ctl_cap, ctl_words)) != VPT_OK) return st;
     if (!b->d_tag_summary) VPT_HIP(hipMalloc(reinterpret_cast<void**>(&b->d_tag_summary), vpt::tag_summary_words() * sizeof(uint32_t)));
-    VPT_HIP(hipMemsetAsync(b->d_tag_ctl, 0, ctl_words * sizeof(uint64_t), stream));   // the queue's counters, the scan's state, the runs' counts
+    VPT_HIP(hipMemsetAsync(b->d_tag_ctl, 0, ctl_words * sizeof(uint64_t), stream));   // the scan's state, the runs' counts
     // the dense arrays of the C ABI, for the callers that want them: None everywhere (what `resize(n_tags * len, None)` leaves, predictor.rs:556-557);
     // the passes write the entries of the tokens that have a model
     if (d_tags_out) VPT_HIP(hipMemsetAsync(d_tags_out, 0xFF, size_t(total_c) * p->n_tags * sizeof(int32_t), stream));
@@ -1593,10 +1592,9 @@ vpt_status vpt_fill_tags_scores_batch_device(const vpt_predictor* p, vpt_batch* 
     T.slot_str = p->dtag.slot_str; T.str_off = p->dtag.str_off; T.n_strings = p->dtag.n_strings;
     T.scores_out = p->max_tag_scores ? d_tag_scores_out : nullptr; T.model_out = d_tag_models_out; T.score_stride = p->max_tag_scores;
     T.n_cus = p->n_cus;
-    T.records = b->d_tag_records; T.rec_tags = b->d_rec_tags;
-    T.qctl = reinterpret_cast<uint32_t*>(b->d_tag_ctl); T.scan_state = b->d_tag_ctl + 2; T.run_pref = b->d_tag_ctl + 2 + n_state;
+    T.records = b->d_tag_records; T.rec_tags = b->d_rec_tags; T.rec_str = b->d_rec_str; T.cands = b->d_tag_cands;
+    T.scan_state = b->d_tag_ctl; T.run_pref = b->d_tag_ctl + n_state;
     T.n_runs = n_runs; T.run_sent = run_sent;
-    T.queue = b->d_tag_queue; T.qrun = b->d_tag_qrun; T.queue_cap = uint32_t(total_c);
     T.summary = b->d_tag_summary;
     VPT_HIP(vpt::launch_tag_tokens(T, stream));
     b->d_run_pref = T.run_pref; b->tag_chars = total_c; b->tag_sentences = n_sentences; b->tag_runs = n_runs; b->tag_run_sent = run_sent;
@@ -1641,9 +1639,8 @@ vpt_status emit_device(const vpt_predictor* p, vpt_batch* b, const uint8_t* d_ut
         if (!p->predict_tags) return fail(VPT_INVALID_ARGUMENT, "InvalidArgumentError: this predictor is created with predict_tags = false");
         if (b->tag_chars != total_boundaries + n_sentences || b->tag_sentences != n_sentences || !b->d_tag_records)
             return fail(VPT_INVALID_ARGUMENT, "InvalidArgumentError: batch: call vpt_fill_tags_batch_device on this workspace for this batch first");
-        E.records = b->d_tag_records; E.rec_tags = b->d_rec_tags; E.run_pref = b->d_run_pref; E.n_runs = b->tag_runs; E.run_sent = b->tag_run_sent;
-        E.n_tags = p->n_tags; E.n_models = p->dtag.n_models; E.n_strings = p->dtag.n_strings;
-        E.models = p->dtag.models; E.slot_str = p->dtag.slot_str; E.str_off = p->dtag.str_off; E.str_bytes = p->dtag.str_bytes;
+        E.records = b->d_tag_records; E.rec_str = b->d_rec_str; E.run_pref = b->d_run_pref; E.n_runs = b->tag_runs; E.run_sent = b->tag_run_sent;
+        E.n_tags = p->n_tags; E.str_bytes = p->dtag.str_bytes;
     }
     // A WORKGROUP per run of sentences (emit_flat_kernel, round 5; a wave per block of 2 K chars before): 5 K chars when the batch is small (the
     // chip wants a thousand workgroups and more), up to 20 K on a big one -- fewer look-backs and size passes per byte (measured,

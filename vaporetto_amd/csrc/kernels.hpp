@@ -142,19 +142,27 @@ struct TagParams {
     uint64_t total_chars;       // total boundaries + S: what `cps` holds (below 2^32 - 256: capi.cpp)
     const uint32_t *slot_str, *str_off;   // the tag strings' lengths (HostTagTables): what a token's tags take in the tokenized text
     uint32_t n_strings;
-    // What fill_tags LEAVES (round 6): one RECORD per token that has a tag model -- the reference holds None for every other char
+    // What fill_tags LEAVES (round 6): one RECORD per token that can have a tag model -- the reference holds None for every other char
     // (predictor.rs:558-573) and so nothing is stored for them -- sorted by the token's last char:
     //   records[k]  = {flat index of the token's last char (2 dwords), its tok_model word (layout.h: tag model + 1 | the bytes its tags take in
-    //                  the tokenized text << 24), 0};   rec_tags[k * n_tags + j] = the candidate chosen for slot j, -1 = None
-    // The front end walks the batch in RUNS of `run_sent` consecutive sentences, a wave per run, in order: token number `ordinal` (among those
-    // with a model) of run r is record run_pref[r] + ordinal.  run_pref [n_runs + 1]: zero in front of the launches; while the front end runs,
-    // entry r + 1 counts run r's records; a chained scan turns it into the exclusive prefix (entry n_runs: all records).
+    //                  the tokenized text << 24; 0: the token table's filter let the token through but it has no tag model: an empty record),
+    //                  slots of its "/tag" suffix (up to the last Some)}
+    //                  (between the lookups and the passes: {last char, context clip, tag model + 1 | record form << 31, 0});
+    //   rec_tags[k * n_tags + j] = the candidate chosen for slot j, -1 = None;   rec_str[k * n_tags + j] = {where that candidate's string starts in
+    //                  the predictor's str_bytes, its length}: the writer copies bytes, it looks nothing up
+    // The front end walks the batch in RUNS of `run_sent` consecutive sentences, a wave per run, in order, and numbers the run's CANDIDATES (the
+    // token ends the filter lets through) as it meets them: candidate i of run r is record run_pref[r] + i.  run_pref [n_runs + 1]: zero in front of
+    // the launches; the front end leaves run r's candidate count in entry r + 1; a chained scan turns it into the exclusive prefix (entry
+    // n_runs: all records).  cands [total_chars]: run r's candidates at [first char of r, + count): {char in the run, token length, chars
+    // before | after << 8 inside the sentence (clipped to the context), 0} -- plain stores, nothing the front end waits for.
     uint4* records;
     int32_t* rec_tags;
+    uint2* rec_str;
     uint64_t* run_pref;
     uint64_t* scan_state;       // scan_part_entries(n_runs) words of that scan, zero in front of the launches
     uint64_t n_runs;
     uint32_t run_sent;
+    uint4* cands;
     // the dense arrays of the C ABI, all optional (nullptr: not wanted), indexed by char; the caller has set them to None (-1) / left them alone:
     int32_t* tags;              // [(total boundaries + S) * n_tags] candidate index per slot: written at the last char of a token with a tag model
     int32_t* scores_out;        // [(total boundaries + S) * score_stride]: Predictor::store_tag_scores (predictor.rs:510-514,599-601): there, entries
@@ -162,13 +170,6 @@ struct TagParams {
     int32_t* model_out;         // [total boundaries + S]: there, the index of the tag model (Model::tag_models order)
     uint32_t score_stride;
     uint32_t n_cus;             // the device's CUs: the grids are what it holds at a time
-    // Between the two launches: the tokens that have a tag model wait in a queue in HBM -- those whose model fits the record form from its
-    // front (qctl[0] of them), the others from its back (qctl[1]) -- with where their record goes (qrun: run, ordinal).  queue_cap = total_chars:
-    // a token is at least a char, the queue cannot overflow.  qctl: zero in front of the launches.
-    uint4* queue;
-    uint2* qrun;
-    uint32_t* qctl;
-    uint32_t queue_cap;
     const uint32_t* summary;    // 2^(kTagSumLog2 - 5) words for the summary of the token filter (tag_filter_summary_kernel writes it, the front end reads it)
 };
 // sentences of a front-end run for a batch of this shape (about VPT_TAG_RUN_CHARS chars, at most 256 sentences); words of TagParams::summary
@@ -191,12 +192,11 @@ struct EmitParams {
     uint32_t* status;
     // "/tag" suffixes (sentence.rs:866-881), from the records the fill_tags call on this workspace left (TagParams); records == nullptr: none
     const uint4* records;
-    const int32_t* rec_tags;
+    const uint2* rec_str;       // [records * n_tags]: the strings of a record's suffix
     const uint64_t* run_pref;   // [n_runs + 1]: records in front of run r of `run_sent` sentences
     uint64_t n_runs;
     uint32_t run_sent;
-    uint32_t n_tags, n_models, n_strings;
-    const uint32_t *models, *slot_str, *str_off;
+    uint32_t n_tags;
     const uint8_t* str_bytes;
 };
 // scan_part: workspace of scan_part_entries(n_sent) uint64 (the prefix sum's per-workgroup partials)

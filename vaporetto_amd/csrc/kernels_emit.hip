@@ -25,36 +25,32 @@ constexpr int kEmitWaves = kEmitThreads / 64;
 constexpr int kScanThreads = 256, kScanPer = 16;
 constexpr uint64_t kScanBlock = uint64_t(kScanThreads) * kScanPer;   // offsets one workgroup of the scan takes
 
-// "/tag/tag.." of the token of record `ri` (its tags: rec_tags[ri * n_tags ..]) whose tag model (index + 1) is `model`: bytes it takes;
-// written to `dst` when given -- never more than `limit` of them (what was reserved for it)
-__device__ __noinline__ uint32_t tag_suffix_of(const EmitParams& P, uint64_t ri, int32_t model, uint8_t* dst, uint32_t limit = 0xFFFFFFFFu) {
-    if (model <= 0 || uint32_t(model) > P.n_models) return 0;   // (not a record of ours)
-    const uint32_t* mr = P.models + size_t(model - 1) * 12;
-    const int32_t* tg = P.rec_tags + ri * P.n_tags;
-    const uint32_t slot0 = mr[8], n_slots = mr[9] < P.n_tags ? mr[9] : P.n_tags;
-    uint32_t last = 0;   // slots to write: up to the last Some (the tags are fetched with the model record, not after it)
-    for (uint32_t j = 0; j < P.n_tags; ++j)
-        if (tg[j] >= 0 && j < n_slots) last = j + 1;
+// "/tag/tag.." of the token of record `ri`: `last` slots (up to the last Some, sentence.rs:866-881), each a '/' and the chosen candidate's
+// string -- rec_str says where it starts in str_bytes and how long it is (an empty one for a None in between); `pre`: the first two slots'
+// entries when the caller has them at hand already (LDS), else nullptr.  Returns the bytes it takes; written to `dst` when given -- never more
+// than `limit` of them (what was reserved for it).
+__device__ __forceinline__ uint32_t tag_suffix_write(const EmitParams& P, uint64_t ri, uint32_t last, const uint2* pre, uint8_t* dst, uint32_t limit = 0xFFFFFFFFu) {
+    const uint2* rs = P.rec_str + ri * P.n_tags;
+    if (last > P.n_tags) last = P.n_tags;
     uint32_t n = 0;
     for (uint32_t j = 0; j < last; ++j) {
+        const uint2 e = (pre && j < 2) ? pre[j] : rs[j];
         if (dst && n < limit) dst[n] = 0x2Fu;
         ++n;
-        if (tg[j] < 0) continue;
-        const uint32_t k = P.slot_str[slot0 + j] + uint32_t(tg[j]);
-        if (k >= P.n_strings) continue;                            // an index fill_tags cannot have written
-        const uint32_t a = P.str_off[k], b = P.str_off[k + 1];
-        if (dst) for (uint32_t q = a; q < b && n + (q - a) < limit; ++q) dst[n + (q - a)] = P.str_bytes[q];
-        n += b - a;
+        if (dst) for (uint32_t q = 0; q < e.y && n + q < limit; ++q) dst[n + q] = P.str_bytes[e.x + q];
+        n += e.y;
     }
     return n;
 }
-// the bytes of the suffix of the token of record ri, whose tok_model word is w (layout.h): carried from fill_tags unless it is a long one
-__device__ __forceinline__ uint32_t tag_suffix_bytes(const EmitParams& P, uint64_t ri, uint32_t w) {
+// the bytes of the suffix of the token of record ri, whose token word is w (layout.h) and whose suffix has `last` slots: carried from fill_tags
+// unless it is a long one
+__device__ __forceinline__ uint32_t tag_suffix_bytes(const EmitParams& P, uint64_t ri, uint32_t w, uint32_t last) {
     const uint32_t code = w >> kTokSuffixShift;
-    return (w & kTokModelMask) == 0 ? 0u : code != kTokSuffixLong ? code : tag_suffix_of(P, ri, int32_t(w & kTokModelMask), nullptr);
+    return (w & kTokModelMask) == 0 ? 0u : code != kTokSuffixLong ? code : tag_suffix_write(P, ri, last, nullptr, nullptr);
 }
-__device__ __forceinline__ uint32_t tag_suffix(const EmitParams& P, uint64_t ri, uint8_t* dst) {
-    return tag_suffix_of(P, ri, int32_t(P.records[ri].z & kTokModelMask), dst);
+__device__ __noinline__ uint32_t tag_suffix(const EmitParams& P, uint64_t ri, uint8_t* dst, uint32_t limit = 0xFFFFFFFFu) {   // (the rare paths: everything from HBM)
+    const uint4 rec = P.records[ri];
+    return (rec.z & kTokModelMask) == 0 ? 0u : tag_suffix_write(P, ri, rec.w, nullptr, dst, limit);
 }
 __device__ __forceinline__ uint64_t wave_sum64(uint64_t x) {   // total over the 64 lanes, in every lane
 #pragma unroll
@@ -208,7 +204,12 @@ constexpr uint32_t kMarkCarry = 0xFFFFu;
 #ifndef VPT_EMIT_ABLATE
 #define VPT_EMIT_ABLATE 0   // timing ablations of the tagged writer (A/B builds, wrong output): 1 the suffixes' bytes are not written, 2 no suffixes at all (the marks stay), 4 no marks either
 #endif
-struct alignas(16) FlatMarks { uint16_t m[kFlatPiece + 16]; };
+constexpr uint32_t kStash = 256;             // records of a piece whose words and first strings wait in LDS (entry kStash: the carried record's)
+struct alignas(16) FlatMarks {
+    uint16_t m[kFlatPiece + 16];
+    uint32_t word[kStash + 1], last[kStash + 1];
+    uint2 str[kStash + 1][2];
+};
 
 // exclusive prefix sum of x over the workgroup's threads (two packed 16-bit counts or one 32-bit one); *total = the sum
 __device__ __forceinline__ uint32_t flat_block_scan(uint32_t x, uint32_t* wtot, uint32_t lane, uint32_t wave, uint32_t* total) {
@@ -310,7 +311,7 @@ __global__ __launch_bounds__(kEmitThreads) void emit_flat_kernel(const EmitParam
             for (uint64_t r = r_lo + tid; r < r_hi; r += kEmitThreads) {
                 const uint4 rec = P.records[r];
                 const uint64_t pos = uint64_t(rec.x) | (uint64_t(rec.y) << 32);
-                if (pos >= g0 && pos < g1 && !(VPT_EMIT_ABLATE & 6)) added += tag_suffix_bytes(P, r, rec.z);
+                if (pos >= g0 && pos < g1 && !(VPT_EMIT_ABLATE & 6)) added += tag_suffix_bytes(P, r, rec.z, rec.w);
             }
         }
         const uint64_t ws = wave_sum64(added);
@@ -410,34 +411,45 @@ __global__ __launch_bounds__(kEmitThreads) void emit_flat_kernel(const EmitParam
         // the run's first (the run before this one wrote that one behind its last byte).  The thread that holds the byte in FRONT of which
         // a suffix goes owns it; at most two per thread are carried in registers (tk: the byte, tl: the length, tc: the token's last
         // char), a third sends the thread's WAVE through its chars one by one (emit_fused_kernel's scheme).
-        uint32_t tmask = 0, tk1 = 16, tl1 = 0, tk2 = 16, tl2 = 0;
+        uint32_t tmask = 0, tk1 = 16, tl1 = 0, tk2 = 16, tl2 = 0, ts1 = 0, ts2 = 0;   // (ts: the record's place in LDS)
         uint64_t tr1 = 0, tr2 = 0;
-        int32_t tm1 = 0, tm2 = 0;
         bool many = false;
         const uint32_t piece_chars = tot & 0xFFFFu;
         uint32_t n_rec = 0;                       // records of the piece (the same in every thread)
         uint16_t* const marks = kTags ? MK[0].m : nullptr;
-        // the record that ends a token at the piece's char k - 1 (k = 0: the char in front of the piece); ~0: none
-        auto rec_at = [&](uint32_t k) -> uint64_t {
+        FlatMarks& SK = MK[0];
+        // the record that ends a token at the piece's char k - 1 (k = 0: the char in front of the piece), ~0: none; *si: where its word and
+        // strings wait in LDS (kStash: the carried record's), ~0: nowhere
+        auto rec_at = [&](uint32_t k, uint32_t* si) -> uint64_t {
             const uint32_t m = marks[k];
+            *si = m == 0 ? ~0u : m == kMarkCarry ? kStash : m - 1u < kStash ? m - 1u : ~0u;
             return m == 0 ? ~uint64_t(0) : m == kMarkCarry ? carry_rec : rp + (m - 1u);
         };
         if (kTags) {
-            // mark the piece's records: sorted, so they are the next ones -- one coalesced read of their positions, a trip as a rule
+            // mark the piece's records: sorted, so they are the next ones -- one coalesced read of their positions (a quarter of the workgroup
+            // first: a piece of CJK text has some twenty), their words and first strings on the same trip into LDS
             const uint64_t p_lo = g0 + cb, p_hi = p_lo + piece_chars;
+            uint32_t width = 64;
             for (; !(VPT_EMIT_ABLATE & 4);) {
                 const uint64_t r = rp + n_rec + tid;
                 bool in = false;
-                if (r < r_hi) {
+                if (tid < width && r < r_hi) {
                     const uint4 rec = P.records[r];
+                    const uint32_t si = n_rec + tid;
+                    uint2 s0 = make_uint2(0u, 0u), s1 = s0;
+                    if (si < kStash) { s0 = P.rec_str[r * P.n_tags]; if (P.n_tags > 1) s1 = P.rec_str[r * P.n_tags + 1]; }
                     const uint64_t pos = uint64_t(rec.x) | (uint64_t(rec.y) << 32);
                     in = pos < p_hi;
-                    if (in && pos >= p_lo) marks[uint32_t(pos - p_lo) + 1u] = uint16_t(n_rec + tid + 1u);
+                    if (in && pos >= p_lo) {
+                        marks[uint32_t(pos - p_lo) + 1u] = uint16_t(si + 1u);
+                        if (si < kStash) { SK.word[si] = rec.z; SK.last[si] = rec.w; SK.str[si][0] = s0; SK.str[si][1] = s1; }
+                    }
                 }
                 uint32_t n_in;
                 flat_block_scan(in ? 1u : 0u, L.wtot, lane, wave, &n_in);   // (its barriers: the marks are written)
                 n_rec += n_in;
-                if (n_in < uint32_t(kEmitThreads)) break;
+                if (n_in < width) break;
+                width = uint32_t(kEmitThreads);
             }
             tmask = spm | sm;
             if (sb + s_in == 0 && sm) tmask &= ~(sm & (0u - sm));
@@ -452,14 +464,16 @@ __global__ __launch_bounds__(kEmitThreads) void emit_flat_kernel(const EmitParam
                     for (uint32_t q = 0; q < j; ++q) remj &= remj - 1u;
                     const uint32_t k = uint32_t(__ffs(int(remj))) - 1u;          // the byte of the thread's j-th char
                     if (!((tmask >> k) & 1u)) continue;                          // no token ends in front of it
-                    const uint64_t ri = rec_at(c_in + j);
+                    uint32_t si;
+                    const uint64_t ri = rec_at(c_in + j, &si);
                     if (ri == ~uint64_t(0)) continue;
-                    const uint32_t word = P.records[ri].z;
-                    const int32_t mdl = int32_t(word & kTokModelMask);
-                    const uint32_t len = tag_suffix_bytes(P, ri, word);   // (carried from fill_tags)
+                    uint32_t word, last;
+                    if (si != ~0u) { word = SK.word[si]; last = SK.last[si]; }
+                    else { const uint4 rec = P.records[ri]; word = rec.z; last = rec.w; }
+                    const uint32_t len = tag_suffix_bytes(P, ri, word, last);   // (carried from fill_tags)
                     if (!len) continue;
-                    if (tk1 == 16) { tk1 = k; tl1 = len; tr1 = ri; tm1 = mdl; }
-                    else if (tk2 == 16) { tk2 = k; tl2 = len; tr2 = ri; tm2 = mdl; }
+                    if (tk1 == 16) { tk1 = k; tl1 = len; tr1 = ri; ts1 = si; }
+                    else if (tk2 == 16) { tk2 = k; tl2 = len; tr2 = ri; ts2 = si; }
                     else many = true;
                 }
             }
@@ -472,7 +486,8 @@ __global__ __launch_bounds__(kEmitThreads) void emit_flat_kernel(const EmitParam
             while (todo) {
                 const uint32_t low = todo & (0u - todo);
                 todo &= todo - 1u;
-                const uint64_t ri = rec_at(c_in + uint32_t(__popc(lm & (low - 1u))));
+                uint32_t si;
+                const uint64_t ri = rec_at(c_in + uint32_t(__popc(lm & (low - 1u))), &si);
                 if (ri != ~uint64_t(0)) sfx_total += tag_suffix(P, ri, nullptr);
             }
         }
@@ -498,8 +513,12 @@ __global__ __launch_bounds__(kEmitThreads) void emit_flat_kernel(const EmitParam
                 }
                 if (kTags && tl1 && !(VPT_EMIT_ABLATE & 1)) {   // the tags themselves (few threads)
                     const uint32_t b1 = (1u << tk1) - 1u, b2 = (1u << tk2) - 1u;
-                    if (tag_suffix_of(P, tr1, tm1, o + w + uint32_t(__popc(vm & b1)) + uint32_t(__popc(spm & b1)) + uint32_t(__popc(em & b1)), tl1) != tl1) err |= kErrBadOffsets;
-                    if (tl2 && tag_suffix_of(P, tr2, tm2, o + w + tl1 + uint32_t(__popc(vm & b2)) + uint32_t(__popc(spm & b2)) + uint32_t(__popc(em & b2)), tl2) != tl2) err |= kErrBadOffsets;
+                    // (their strings' places wait in LDS as a rule: the bytes are one trip away)
+                    const auto put = [&](uint64_t ri, uint32_t si, uint8_t* at, uint32_t len) -> bool {
+                        return si != ~0u ? tag_suffix_write(P, ri, SK.last[si], SK.str[si], at, len) == len : tag_suffix(P, ri, at, len) == len;
+                    };
+                    if (!put(tr1, ts1, o + w + uint32_t(__popc(vm & b1)) + uint32_t(__popc(spm & b1)) + uint32_t(__popc(em & b1)), tl1)) err |= kErrBadOffsets;
+                    if (tl2 && !put(tr2, ts2, o + w + tl1 + uint32_t(__popc(vm & b2)) + uint32_t(__popc(spm & b2)) + uint32_t(__popc(em & b2)), tl2)) err |= kErrBadOffsets;
                 }
             }
             uint32_t rem = sm;   // the sentences that start in the thread's bytes (few threads, one as a rule)
@@ -520,7 +539,7 @@ __global__ __launch_bounds__(kEmitThreads) void emit_flat_kernel(const EmitParam
 #pragma unroll 1
             for (uint32_t k = 0; k < 16; ++k) {
                 if (!((vm >> k) & 1u)) continue;
-                if ((tmask >> k) & 1u) { const uint64_t ri = rec_at(c_in + ci); if (ri != ~uint64_t(0)) pos += tag_suffix(P, ri, o ? o + pos : nullptr); }
+                if ((tmask >> k) & 1u) { uint32_t si; const uint64_t ri = rec_at(c_in + ci, &si); if (ri != ~uint64_t(0)) pos += tag_suffix(P, ri, o ? o + pos : nullptr); }
                 if ((spm >> k) & 1u) { if (o) o[pos] = 0x20u; ++pos; }
                 if ((sm >> k) & 1u) {
                     const uint64_t s = sb + s_in + uint32_t(__popc(sm & ((1u << k) - 1u)));
@@ -536,7 +555,8 @@ __global__ __launch_bounds__(kEmitThreads) void emit_flat_kernel(const EmitParam
             }
         }
         uint64_t next_carry = carry_rec;   // the record of the piece's last char goes on to the next piece (every thread reads the same mark)
-        if (kTags && piece_chars) next_carry = rec_at(piece_chars);
+        uint32_t next_si = kStash;
+        if (kTags && piece_chars) next_carry = rec_at(piece_chars, &next_si);
         __syncthreads();
         if (kTags) {   // the marks are done with: clear them for the next piece, whose marks[0] is this piece's last char
             reinterpret_cast<uint4*>(marks)[tid] = make_uint4(0, 0, 0, 0);
@@ -544,7 +564,17 @@ __global__ __launch_bounds__(kEmitThreads) void emit_flat_kernel(const EmitParam
             if (tid < 2) reinterpret_cast<uint4*>(marks)[2 * kEmitThreads + tid] = make_uint4(0, 0, 0, 0);
             carry_rec = next_carry;
             rp += n_rec;
-            if (tid == 0 && carry_rec != ~uint64_t(0)) marks[0] = uint16_t(kMarkCarry);
+            if (tid == 0 && carry_rec != ~uint64_t(0)) {   // ... with its word and strings in the carried record's place
+                marks[0] = uint16_t(kMarkCarry);
+                if (next_si != kStash) {
+                    if (next_si != ~0u) { SK.word[kStash] = SK.word[next_si]; SK.last[kStash] = SK.last[next_si]; SK.str[kStash][0] = SK.str[next_si][0]; SK.str[kStash][1] = SK.str[next_si][1]; }
+                    else {
+                        const uint4 rec = P.records[carry_rec];
+                        SK.word[kStash] = rec.z; SK.last[kStash] = rec.w;
+                        SK.str[kStash][0] = P.rec_str[carry_rec * P.n_tags]; SK.str[kStash][1] = P.n_tags > 1 ? P.rec_str[carry_rec * P.n_tags + 1] : make_uint2(0u, 0u);
+                    }
+                }
+            }
         }
         if (store_ok && staged) {   // LDS byte j is output byte j - head: whole 16-byte chunks leave aligned, the two edges byte by byte
             uint8_t* const abase = dst - head;

@@ -12,8 +12,8 @@
 // weights; integer adds are order-free, so the sums are bit-identical.
 //
 // What fill_tags leaves (round 6): the reference stores None for every char that does not end a token with a tag model
-// (predictor.rs:558-573) -- here NOTHING is stored for them.  The device-side result is one RECORD per token that has a tag model
-// (last char, tag model, chosen candidates, the bytes its "/tag" suffix takes), sorted by position (TagParams, kernels.hpp); the writer
+// (predictor.rs:558-573) -- here NOTHING is stored for them.  The device-side result is one RECORD per token that can have a tag model
+// (last char, tag model, chosen candidates, where the strings of its "/tag" suffix are), sorted by position (TagParams, kernels.hpp); the writer
 // reads the records, and the dense (chars x n_tags) array of the C ABI is a scatter of them over a memset for the callers that ask for it.
 //
 // Kernels:
@@ -25,20 +25,21 @@
 //                        run's offsets.  Every lane whose char ends a token owns it; the token table's FILTER -- keyed like the table by the
 //                        length and the first four chars, which the lane reads from the ring in LDS, so there is no loop over the token --
 //                        says whether the surface can be a tag model's at all (a summary of it sits in LDS: five of six token ends need no
-//                        load).  The CANDIDATES wait in LDS, across steps and runs, until there are 64: then every lane probes the table for
-//                        one.  The tokens that have a model are appended to a QUEUE in HBM, a wave's share with one atomic, each with its run
-//                        and its ordinal among the run's tokens with a model.  The kernel stores nothing else (until round 6 it stored the None
-//                        entries of every char: 1.07 of configs[4]'s 1.6 GB of writes, 0.30 of its 0.75 ms).
-//   launch_scan          the runs' record counts -> the runs' first records (a chained scan, kernels_emit.hip)
-//   tag_pass_kernel      The PASSES over that queue, 16 tokens at a time: their context chars (p - 11 .. p + 4), model records and bias arrive in
+//                        load).  The CANDIDATES it lets through are stored, in order, at the run's own places in HBM and counted: a candidate's
+//                        number in its run names its record.  The kernel stores nothing else and waits for nothing it stores (until round 6 it
+//                        stored the None entries of every char -- 1.07 of configs[4]'s 1.6 GB of writes -- and did the lookups itself, a wave
+//                        waiting on each chain of trips: 0.53 of its 0.65 ms).
+//   launch_scan          the runs' candidate counts -> the runs' first records (a chained scan, kernels_emit.hip)
+//   tag_resolve_kernel   The LOOKUPS, a lane per candidate, as many waves as the device holds: which tag model has this surface?  The answer goes
+//                        into the candidate's record (none: an empty record).
+//   tag_pass_kernel      The PASSES over the records whose token has a model, 16 tokens at a time: their context chars (p - 11 .. p + 4), model records and bias arrive in
 //                        one trip; a model's char n-grams come in groups by rel_position with a 64-bit filter over the chars they END with,
 //                        so a token only enumerates the groups its text can match; the wave's lanes then take (token, tag n-gram) PAIRS,
 //                        64 per round: a lane checks one whole n-gram from one 32-byte record against the token's context in LDS; the
 //                        matches are collected and lanes over (match, score) pairs add their weights to the token's scores in LDS (which
 //                        start as the model's bias); lanes over (token, slot) pairs take the argmax (first maximum, predictor.rs:286-304).
 //                        Models that do not fit the record form (an n-gram over 12 symbols or outside the BMP, more than 16 scores or 3
-//                        slots, rel_position above 3) go through a whole-wave routine, one token at a time.  Each token's record is written
-//                        at run_pref[run] + ordinal.
+//                        slots, rel_position above 3) go through a whole-wave routine, one token at a time.
 //   (Until round 6 there was a one-launch kernel for small batches and for a queue that overflowed -- tag_tokens_kernel, a wave per
 //   sentence -- and an A/B of the front end by sentence; the queue now holds a token per char of the batch and cannot overflow: HISTORY.md.)
 //   With predict_tags the scoring kernel of the preceding vpt_predict_batch_device call leaves the decoded chars behind and
@@ -177,7 +178,6 @@ constexpr int kRing = 256;                   // the sentence's cps words in LDS:
 constexpr int kTagPass = 16;                 // queued tokens a pass takes
 constexpr int kCtx = 16, kCtxBack = 11;      // the text a queued token's n-grams can touch: chars p - 11 .. p + 4 around its last char p
 static_assert(kCtx - 1 - kCtxBack == int(kTagFastMaxRel), "tables.cpp keeps models with a tag n-gram further past the token off the fast path");
-constexpr int kTagCand = 64;                 // tokens that wait for the token table together
 constexpr int kMatchCap = 128;               // matched (token, n-gram) pairs collected before their weights are added
 
 struct TagWaveLds {
@@ -196,9 +196,6 @@ struct TagWaveLds {
 };
 struct alignas(16) TagFrontLds {             // what the step loop keeps per wave
     uint32_t txt[kRing + 4];                 // (the ring keeps words 0 .. 2 once more at kRing ..: a token's first four chars are consecutive words)
-    uint32_t cand[kTagCand][4];              // tokens the filter let through, waiting for the token table: flat index of the last char (2),
-                                             // chars, chars before | after << 8 inside the sentence (clipped to the context)
-    uint32_t crun[kTagCand];                 // ... and the run they belong to
 };
 constexpr int kTagPairOcc = 8;               // workgroups per CU of the passes (57 VGPRs)
 static_assert(sizeof(TagWaveLds) * kTagWaves <= 160 * 1024 / kTagPairOcc, "workgroups per CU");
@@ -218,10 +215,15 @@ __device__ __forceinline__ uint32_t find_tag_model(const TagParams& P, const uin
         if (t.x == 0) return 0;
         if ((t.y & kTagTokLenMask) == len && t.z == lo && t.w == hi) {
             bool same = bmp;
-            if (!(t.y & kTagTokInline)) {
+            if (!(t.y & kTagTokInline)) {   // a longer token (or one outside the BMP): its symbols, four to a trip
                 const uint32_t so = P.models[size_t(t.x - 1) * 12];
                 same = true;
-                for (uint32_t j = 0; j < len && same; ++j) same = P.syms[so + j] == (tc[j] & kCharMask);
+                for (uint32_t j = 0; j < len && same; j += 4) {
+                    uint32_t a[4], b[4];
+#pragma unroll
+                    for (uint32_t q = 0; q < 4; ++q) { const bool in = j + q < len; a[q] = in ? P.syms[so + j + q] : 0u; b[q] = in ? tc[j + q] & kCharMask : 0u; }
+                    same = a[0] == b[0] && a[1] == b[1] && a[2] == b[2] && a[3] == b[3];
+                }
             }
             if (same) { *fast = (t.y & kTagTokFast) != 0; return t.x; }
         }
@@ -277,18 +279,22 @@ __device__ __forceinline__ void tag_token_by_wave(const TagParams& P, const uint
         }
         P.rec_tags[slot * P.n_tags + j] = tag;
         if (P.tags) P.tags[(g0 + uint64_t(e)) * P.n_tags + j] = tag;
+        uint2 str = make_uint2(0u, 0u);
         if (tag >= 0) {
             const uint32_t k = P.slot_str[mr[8] + j] + uint32_t(tag);
-            const uint32_t sl = k < P.n_strings ? P.str_off[k + 1] - P.str_off[k] : 0u;
+            if (k < P.n_strings) str = make_uint2(P.str_off[k], P.str_off[k + 1] - P.str_off[k]);
+            const uint32_t sl = str.y;
             str_bytes += sl < 0x10000u ? sl : 0x10000u;
             last_some = j + 1;
         }
+        P.rec_str[slot * P.n_tags + j] = str;
     }
     {
-        const uint32_t bytes = uint32_t(wave_sum64(str_bytes < 0x10000u ? str_bytes : 0x10000u)) + wave_max(last_some);
+        const uint32_t last = wave_max(last_some);
+        const uint32_t bytes = uint32_t(wave_sum64(str_bytes < 0x10000u ? str_bytes : 0x10000u)) + last;
         const uint64_t gp = g0 + uint64_t(e);
         if (lane == 0) {
-            P.records[slot] = make_uint4(uint32_t(gp), uint32_t(gp >> 32), model | ((bytes < kTokSuffixLong ? bytes : kTokSuffixLong) << kTokSuffixShift), 0u);
+            P.records[slot] = make_uint4(uint32_t(gp), uint32_t(gp >> 32), model | ((bytes < kTokSuffixLong ? bytes : kTokSuffixLong) << kTokSuffixShift), last);
             if (P.model_out) P.model_out[gp] = int32_t(model) - 1;
         }
     }
@@ -466,104 +472,118 @@ __device__ __forceinline__ void tag_pass(const TagParams& P, TagWaveLds& L, uint
                 const uint64_t gp = uint64_t(L.f.tok[t][1]) | (uint64_t(L.f.tok[t][2]) << 32);
                 P.tags[gp * nt + j] = tag;
             }
+            uint2 str = make_uint2(0u, 0u);
             if (tag >= 0) {
                 const uint32_t k = L.f.tok[t][8 + j] + uint32_t(tag);   // (j < 3: the record form)
-                const uint32_t sl = k < P.n_strings ? P.str_off[k + 1] - P.str_off[k] : 0u;
-                atomicAdd(&L.f.pref[t], sl < 0x10000u ? sl : 0x10000u);
+                if (k < P.n_strings) str = make_uint2(P.str_off[k], P.str_off[k + 1] - P.str_off[k]);
+                atomicAdd(&L.f.pref[t], str.y < 0x10000u ? str.y : 0x10000u);
                 atomicMax(reinterpret_cast<uint32_t*>(&L.f.zt[t][kTagFastZ]), j + 1u);
             }
+            P.rec_str[size_t(L.f.tok[t][11]) * nt + j] = str;
         }
     }
     __builtin_amdgcn_wave_barrier();
     if (uint32_t(lane) < nq) {   // the token's record: where the writer finds its tags
         const uint32_t bytes = L.f.pref[lane] + uint32_t(L.f.zt[lane][kTagFastZ]);
         P.records[L.f.tok[lane][11]] = make_uint4(L.f.tok[lane][1], L.f.tok[lane][2],
-                                                  L.f.tok[lane][0] | ((bytes < kTokSuffixLong ? bytes : kTokSuffixLong) << kTokSuffixShift), 0u);
+                                                  L.f.tok[lane][0] | ((bytes < kTokSuffixLong ? bytes : kTokSuffixLong) << kTokSuffixShift), uint32_t(L.f.zt[lane][kTagFastZ]));
         if (P.model_out) P.model_out[uint64_t(L.f.tok[lane][1]) | (uint64_t(L.f.tok[lane][2]) << 32)] = int32_t(L.f.tok[lane][0]) - 1;
     }
     __builtin_amdgcn_wave_barrier();
 }
 
-// The `nc` tokens that wait in F.cand, one per lane: the token table says which tag model each has (most have one: the filter let
-// them through).  Those that have one are appended to the queue in HBM -- record-form models from its front, the others from its back, a
-// wave's share with one atomic each -- together with where their RECORD goes: their run and their ordinal among the run's tokens that have
-// a model.  A run is walked by ONE wave, in order, and its candidates are resolved in order, so the ordinals follow the positions: the
-// records come out sorted without a sort (tag_pass_kernel adds the records of the runs in front, TagParams::run_pref).
-__device__ __forceinline__ void tag_resolve(const TagParams& P, TagFrontLds& F, uint32_t nc, int lane) {
-    const uint64_t below_me = (uint64_t(1) << lane) - 1;
-    __builtin_amdgcn_wave_barrier();
-    const bool have = uint32_t(lane) < nc;
-    const uint64_t gp = have ? uint64_t(F.cand[lane][0]) | (uint64_t(F.cand[lane][1]) << 32) : 0;
-    const uint32_t len = have ? F.cand[lane][2] : 0u, clip = have ? F.cand[lane][3] : 0u;
-    const uint32_t run = have ? F.crun[lane] : 0u;
-    bool fast = false;
-    const uint32_t model = have ? find_tag_model(P, P.cps + (gp + 1 - len), len, &fast) : 0u;
-    const uint64_t tagged = __ballot(model != 0);
-    if (tagged != 0) {   // wave-uniform
-        // ordinals: the batch's runs one by one (a few: a run has some thirty candidates); the run's count lives in run_pref[run + 1]
-        // (an atomic: it is this wave's alone, but a plain read could be served by a stale line of the vector L1)
-        uint32_t ord = 0;
-        for (uint64_t left = tagged; left != 0;) {
-            const int k = __ffsll((long long)left) - 1;
-            const uint32_t r = uint32_t(__builtin_amdgcn_readlane(int(run), k));
-            const uint64_t m = __ballot(model != 0 && run == r);
-            unsigned long long base = 0;
-            if (lane == 0) base = atomicAdd(reinterpret_cast<unsigned long long*>(P.run_pref + size_t(r) + 1), (unsigned long long)__popcll(m));
-            const uint32_t b0 = wave_uniform(uint32_t(base));
-            if ((m >> lane) & 1u) ord = b0 + uint32_t(__popcll(m & below_me));
-            left &= ~m;
-        }
-        const uint64_t qmask = __ballot(model != 0 && fast);
+// The LOOKUPS, a launch of their own (round 6; the front end used to do them itself, 64 candidates at a time, and spent most of its time
+// waiting for them: a lookup is a chain of dependent trips -- the token's chars, the table slot, a longer token's symbols -- in ONE wave
+// with nothing else to run; profiles/r06_c_tag_ablations.jsonl: the front end without its candidates took 0.12 of its 0.65 ms).  Here a
+// wave takes a run's candidates, a lane each, and there are as many waves as the device holds: the trips overlap.  A candidate that has a
+// tag model joins the queue of the passes -- record-form models from its front, the others from its back, a wave's share with ONE 64-bit
+// atomic -- with the record it will fill; one that has none gets its (empty) record here.
+constexpr uint32_t kResolveRuns = 8;   // runs a wave takes together: their candidates, back to back, keep its lanes busy (a run has some forty)
+__global__ __launch_bounds__(kTagThreads) void tag_resolve_kernel(const TagParams P) {
+    __shared__ uint64_t PREF[kTagWaves][kResolveRuns + 1], RUN0[kTagWaves][kResolveRuns];
+    const int lane = threadIdx.x & 63;
+    const uint32_t wid = wave_uniform(threadIdx.x >> 6);
+    const uint64_t wave = uint64_t(blockIdx.x) * kTagWaves + wid, n_waves = uint64_t(gridDim.x) * kTagWaves;
+    for (uint64_t r_first = wave * kResolveRuns; r_first < P.n_runs; r_first += n_waves * kResolveRuns) {
+        const uint32_t nr = uint32_t(P.n_runs - r_first < kResolveRuns ? P.n_runs - r_first : kResolveRuns);
+        __builtin_amdgcn_wave_barrier();
+        // the runs' first records (= their candidates' numbers: candidate c IS record c) and first chars, one trip for all of them
+        if (uint32_t(lane) <= nr) PREF[wid][lane] = P.run_pref[r_first + uint32_t(lane)];
+        if (uint32_t(lane) < nr) { const uint64_t i_a = (r_first + uint32_t(lane)) * P.run_sent; RUN0[wid][lane] = P.ooff[i_a] + i_a; }
+        __builtin_amdgcn_wave_barrier();
+        const uint64_t c_lo = PREF[wid][0], c_hi = PREF[wid][nr];
+        for (uint64_t c0 = c_lo; c0 < c_hi; c0 += 64) {
+            const uint64_t c = c0 + uint32_t(lane);
+            const bool have = c < c_hi;
+            uint32_t j = 0;   // the candidate's run: the last one whose first record is not behind it
 #pragma unroll
-        for (int kind = 0; kind < 2; ++kind) {
-            const uint64_t m = kind == 0 ? qmask : tagged & ~qmask;   // the models outside the record form: the whole-wave routine's
-            if (m == 0) continue;   // wave-uniform
-            uint32_t base = 0;
-            if (lane == 0) base = atomicAdd(&P.qctl[kind], uint32_t(__popcll(m)));
-            base = wave_uniform(base) + uint32_t(__popcll(m & below_me));
-            const uint32_t at = kind == 0 ? base : P.queue_cap - 1u - base;
-            if (((m >> lane) & 1u) && base < P.queue_cap) {   // (always: a token is at least a char, the queue holds one per char)
-                P.queue[at] = make_uint4(uint32_t(gp), uint32_t(gp >> 32), model, clip);
-                P.qrun[at] = make_uint2(run, ord);
-            }
+            for (uint32_t q = 1; q < kResolveRuns; ++q) j += (q < nr && PREF[wid][q] <= c) ? 1u : 0u;
+            const uint64_t run0 = RUN0[wid][j];
+            const uint4 e = have ? P.cands[run0 + (c - PREF[wid][j])] : make_uint4(0, 1, 0, 0);
+            const uint64_t gp = run0 + e.x;
+            bool fast = false;
+            const uint32_t model = have ? find_tag_model(P, P.cps + (gp + 1 - e.y), e.y, &fast) : 0u;
+            // the record, for now: {last char, context clip, tag model + 1 | record form << 31, 0}; the passes make it the token's record.
+            // No tag model: that IS the (empty) record.  (A queue of the tokens that have one, filled with an atomic per 64 candidates,
+            // stood here first: 44 K atomics on one word took most of the launch's 0.48 ms, profiles/r06_e_*.)
+            if (have) P.records[c] = make_uint4(uint32_t(gp), model ? e.z : 0u, model | (fast ? 0x80000000u : 0u), 0u);
         }
     }
-    __builtin_amdgcn_wave_barrier();
 }
 
-// The passes: the waves stride over the queue the front end left in HBM, 16 tokens a pass; then over the tokens of the models outside
-// the record form, one per wave at a time.  The grid is what the device holds.
+// The passes: the waves stride over the RECORDS the lookups left, 64 at a time; those whose token has a tag model of the record form are
+// gathered, in order, into the wave's queue in LDS -- 16 of them are a pass --, the others' tokens go through the whole-wave routine one at a
+// time.  Nothing is allocated, nothing is counted: a record is overwritten in place by what its token's tags turn out to be.  The grid
+// is what the device holds.
 __global__ __launch_bounds__(kTagThreads, kTagPairOcc) void tag_pass_kernel(const TagParams P) {
     __shared__ TagWaveLds LDS[kTagWaves];
     const int lane = threadIdx.x & 63;
     const uint32_t wid = wave_uniform(threadIdx.x >> 6);
     TagWaveLds& L = LDS[wid];
+    const uint64_t below_me = (uint64_t(1) << lane) - 1;
     const uint64_t wave = uint64_t(blockIdx.x) * kTagWaves + wid, n_waves = uint64_t(gridDim.x) * kTagWaves;
-    const uint64_t n_fast = wave_uniform(P.qctl[0]), n_slow = wave_uniform(P.qctl[1]);
-    for (uint64_t q0 = wave * kTagPass; q0 < n_fast; q0 += n_waves * kTagPass) {
-        const uint32_t nq = uint32_t(n_fast - q0 < uint64_t(kTagPass) ? n_fast - q0 : uint64_t(kTagPass));
-        if (uint32_t(lane) < nq) {
-            const uint4 e = P.queue[q0 + lane];
-            const uint2 ro = P.qrun[q0 + lane];
-            L.f.tok[lane][0] = e.z; L.f.tok[lane][1] = e.x; L.f.tok[lane][2] = e.y; L.f.tok[lane][3] = e.w;
-            L.f.tok[lane][11] = uint32_t(P.run_pref[ro.x]) + ro.y;
+    const uint64_t n_rec = wave_uniform64(P.run_pref[P.n_runs]);
+    uint32_t nq = 0;
+    for (uint64_t c0 = wave * 64; c0 < n_rec; c0 += n_waves * 64) {
+        const uint64_t c = c0 + uint32_t(lane);
+        const uint4 e = c < n_rec ? P.records[c] : make_uint4(0, 0, 0, 0);
+        const uint32_t model = e.z & 0x7FFFFFFFu;
+        const bool fast = (e.z >> 31) != 0;
+        const uint64_t qmask = __ballot(model != 0 && fast);
+        uint64_t todo = __ballot(model != 0 && !fast);
+        if (qmask != 0) {
+            const uint32_t rank = uint32_t(__popcll(qmask & below_me));
+            uint32_t remaining = uint32_t(__popcll(qmask)), done = 0;
+            for (;;) {
+                const uint32_t room = uint32_t(kTagPass) - nq, take = remaining < room ? remaining : room;
+                if (model != 0 && fast && rank >= done && rank < done + take) {
+                    const uint32_t row = nq + rank - done;
+                    L.f.tok[row][0] = model; L.f.tok[row][1] = e.x; L.f.tok[row][2] = 0u; L.f.tok[row][3] = e.y; L.f.tok[row][11] = uint32_t(c);
+                }
+                nq += take; done += take; remaining -= take;
+                if (nq < uint32_t(kTagPass)) break;
+                tag_pass(P, L, nq, lane);
+                nq = 0;
+                if (!remaining) break;
+            }
         }
-        tag_pass(P, L, nq, lane);
-    }
-    for (uint64_t k = wave; k < n_slow; k += n_waves) {
-        const uint64_t at = uint64_t(P.queue_cap) - 1u - k;
-        const uint4 e = P.queue[at];
-        const uint2 ro = P.qrun[at];
-        const uint64_t gk = uint64_t(wave_uniform(e.x)) | (uint64_t(wave_uniform(e.y)) << 32);
-        uint64_t lo = 0, hi = P.n_sent;   // the last sentence i with ooff[i] + i <= gk
-        while (hi - lo > 1) {
-            const uint64_t mid = (lo + hi) >> 1;
-            if (P.ooff[mid] + mid <= gk) lo = mid; else hi = mid;
+        while (todo) {   // wave-uniform: the whole wave, one token at a time; its sentence is looked up in the offsets (rare models)
+            const int k = __ffsll((long long)todo) - 1;
+            todo &= todo - 1;
+            const uint32_t mk = uint32_t(__builtin_amdgcn_readlane(int(model), k));
+            const uint64_t gk = uint64_t(uint32_t(__builtin_amdgcn_readlane(int(e.x), k)));
+            uint64_t lo = 0, hi = P.n_sent;   // the last sentence i with ooff[i] + i <= gk
+            while (hi - lo > 1) {
+                const uint64_t mid = (lo + hi) >> 1;
+                if (P.ooff[mid] + mid <= gk) lo = mid; else hi = mid;
+            }
+            const uint64_t g0 = P.ooff[lo] + lo;
+            // (the routine's scratch is the union's other member: the queue's rows stay as they are only while it is empty -- so run the waiting pass first)
+            if (nq != 0) { tag_pass(P, L, nq, lane); nq = 0; }
+            tag_token_by_wave(P, P.cps + g0, int64_t(P.ooff[lo + 1] - P.ooff[lo]) + 1, int64_t(gk - g0), g0, mk, VPT_TO_LDS_PTR(volatile int32_t, L.z), lane, c0 + uint32_t(k));
         }
-        const uint64_t g0 = P.ooff[lo] + lo;
-        tag_token_by_wave(P, P.cps + g0, int64_t(P.ooff[lo + 1] - P.ooff[lo]) + 1, int64_t(gk - g0), g0, wave_uniform(e.z), VPT_TO_LDS_PTR(volatile int32_t, L.z), lane,
-                          wave_uniform64(P.run_pref[wave_uniform(ro.x)]) + wave_uniform(ro.y));
     }
+    if (nq != 0) tag_pass(P, L, nq, lane);
 }
 
 // The front end, FLAT over the batch's chars (round 4; a wave per sentence ran its steps of 128 chars half empty at a sentence's end --
@@ -669,7 +689,6 @@ __global__ __launch_bounds__(kFlatThreads, VPT_TAG_FLAT_OCC) void tag_front_flat
     const uint64_t total_b = P->total_chars - P->n_sent;   // labels of the batch
     const uint32_t per = P->run_sent;
     const uint64_t n_runs = P->n_runs;
-    uint32_t nc = 0;   // waiting candidates (wave-uniform)
     VPT_TP_DECL;
     for (uint64_t run = wave; run < n_runs; run += n_waves) {
         VPT_TP(0);
@@ -684,6 +703,8 @@ __global__ __launch_bounds__(kFlatThreads, VPT_TAG_FLAT_OCC) void tag_front_flat
         // the run's arrays (kept in scalar registers, or spilled to a lane: either is cheaper in a step than asking the constant cache again --
         // a step is a chain of waits, not of instructions)
         const uint32_t* const cps = P->cps + run0;
+        uint4* const cands = P->cands + run0;   // the run's candidates: as many places as it has chars
+        uint32_t n_cand = 0;                    // (wave-uniform)
         const uint8_t* const lab_run = P->labels + o_a;
         const uint32_t tok_bits = P->tok_bits, fshift = 32u - tok_bits - kTagFilterLog2;
         const uint32_t* const filt = P->tok_tab + (size_t(4) << tok_bits);
@@ -842,52 +863,31 @@ __global__ __launch_bounds__(kFlatThreads, VPT_TAG_FLAT_OCC) void tag_front_flat
 #pragma unroll
             for (uint32_t h = 0; h < 2; ++h) fword[h] = (!(VPT_TAG_ABLATE & 1) && want[h]) ? filt[fbit[h] >> 5] : 0u;
             VPT_TP(4);   // token ends, keys, filter loads issued
-#ifdef VPT_TAG_PROFILE
-            VPT_TP(5);   // stores issued
-            VPT_PIN(fword[0]); VPT_PIN(fword[1]);
-            VPT_TP(6);   // the wait for the filter words (and everything older)
-            VPT_TP_COUNT(10);
-#endif
+            // ---- (2) the candidates -- one or two in a half-step (BASELINE's configs[4]) -- go to the run's places in HBM, in order, for the
+            // lookups' launch: the char, the token's length, and its context clip from the bitmaps (chars of the token's sentence in front
+            // of / behind its last char: up to the nearest sentence start at or in front of the char, up to the nearest sentence end at
+            // or behind it).  Plain stores: nothing here waits for them.  (Finding a step's candidates a step later, so that one wait serves
+            // the filter words and the next chars, changed nothing -- 0.479 / 0.487 ms, profiles/r06_e_*: the kernel is bound by the scalar
+            // instructions of its mask arithmetic, 235 a step.)
 #pragma unroll
             for (uint32_t h = 0; h < 2; ++h) {
                 const bool cand = ((fword[h] >> (fbit[h] & 31u)) & 1u) != 0;   // (no filter word where no valid token ends)
-                // ---- (2) the candidates wait for the token table together: 64 of them are a lookup with every lane busy.  There are one or
-                // two in a half-step (BASELINE's configs[4]): each is put into its row by scalar code -- its context clip from the bitmaps
-                // (chars of the token's sentence in front of / behind its last char: up to the nearest sentence start at or in front of
-                // the char, up to the nearest sentence end at or behind it), its length from the lane that owns it
-                uint64_t cmask = (VPT_TAG_ABLATE & 2) ? 0 : __ballot(cand);
-                if (VPT_TAG_ABLATE & 32) { if (cmask == 0x123456789ABCDEFull) L.txt[lane] = 1; cmask = 0; }
+                const uint64_t cmask = (VPT_TAG_ABLATE & 2) ? 0 : __ballot(cand);
                 if (cmask != 0) {
                     // EM: the marks one down
                     const uint64_t em_h = h ? (sm[1] >> 1) | (uint64_t(sm_top) << 63) : (sm[0] >> 1) | (sm[1] << 63);
                     const uint64_t pm = h ? sm[0] : sm_prev;
                     const uint64_t nm = h ? (more ? (mk0 >> 1) | (mk1 << 63) : 0) : (sm[1] >> 1) | (uint64_t(sm_top) << 63);
-                    do {
-                        const int k = __ffsll((long long)cmask) - 1;
-                        cmask &= cmask - 1;
-                        const uint64_t upto = (uint64_t(2) << k) - 1;   // bits 0 .. k
-                        const uint64_t at_or_before = sm[h] & upto, at_or_after = em_h & ~(upto >> 1);
-                        const uint32_t back_full = at_or_before ? uint32_t(k - (63 - __clzll((long long)at_or_before)))
-                                                                : pm ? uint32_t(k + 1 + __clzll((long long)pm)) : 0xFFu;
-                        const uint32_t fwd_full = at_or_after ? uint32_t(__ffsll((long long)at_or_after) - 1 - k)
-                                                              : nm ? uint32_t(64 - k + __ffsll((long long)nm) - 1) : 0xFFu;
-                        const uint32_t back = back_full < uint32_t(kCtxBack) ? back_full : uint32_t(kCtxBack);
-                        const uint32_t fwd = fwd_full < uint32_t(kCtx - 1 - kCtxBack) ? fwd_full : uint32_t(kCtx - 1 - kCtxBack);
-                        const uint32_t ln = uint32_t(__builtin_amdgcn_readlane(int(len[h]), k));
-                        const uint64_t gp = run0 + uint64_t(base + 64u * h + uint32_t(k));
-                        if (lane == 0) { *reinterpret_cast<uint4*>(L.cand[nc]) = make_uint4(uint32_t(gp), uint32_t(gp >> 32), ln, back | (fwd << 8)); L.crun[nc] = uint32_t(run); }
-                        if ((VPT_TAG_ABLATE & 64) && nc == uint32_t(kTagCand) - 1u) nc = 0;
-                        if (++nc == uint32_t(kTagCand)) {
-                            VPT_TP(7);   // candidates into their rows (and a last step's entries)
-                            VPT_KARG(TagParams) R = P;
-                            VPT_KARG_FENCE(R);
-                            TagParams Q;
-                            read_tag_params(Q, R);
-                            tag_resolve(Q, L, nc, int(lane));
-                            nc = 0;
-                            VPT_TP(8);   // a lookup of 64 candidates
-                        }
-                    } while (cmask != 0);
+                    const uint64_t upto = (uint64_t(2) << lane) - 1;   // bits 0 .. lane
+                    const uint64_t at_or_before = sm[h] & upto, at_or_after = em_h & ~(upto >> 1);
+                    const uint32_t back_full = at_or_before ? lane - uint32_t(63 - __clzll((long long)at_or_before))
+                                                            : pm ? lane + 1u + uint32_t(__clzll((long long)pm)) : 0xFFu;
+                    const uint32_t fwd_full = at_or_after ? uint32_t(__ffsll((long long)at_or_after)) - 1u - lane
+                                                          : nm ? 64u - lane + uint32_t(__ffsll((long long)nm)) - 1u : 0xFFu;
+                    const uint32_t back = back_full < uint32_t(kCtxBack) ? back_full : uint32_t(kCtxBack);
+                    const uint32_t fwd = fwd_full < uint32_t(kCtx - 1 - kCtxBack) ? fwd_full : uint32_t(kCtx - 1 - kCtxBack);
+                    if (cand) cands[n_cand + uint32_t(__popcll(cmask & below_me))] = make_uint4(base + 64u * h + lane, len[h], back | (fwd << 8), 0u);
+                    n_cand += uint32_t(__popcll(cmask));
                 }
             }
             sm_prev = sm[1];
@@ -896,10 +896,9 @@ __global__ __launch_bounds__(kFlatThreads, VPT_TAG_FLAT_OCC) void tag_front_flat
         };
         for (; n - base >= 128u; base += 128u) step(std::true_type{});
         if (base < n) step(std::false_type{});
+        if (lane == 0) P->run_pref[run + 1] = n_cand;   // (this wave's word alone; the scan behind this launch reads it)
     }
     VPT_TP(0);
-    if (nc != 0 && !(VPT_TAG_ABLATE & 64)) { TagParams Q; read_tag_params(Q, P); tag_resolve(Q, L, nc, int(lane)); }
-    VPT_TP(8);
     VPT_TP_FLUSH();
 }
 
@@ -925,8 +924,8 @@ uint32_t tag_run_sentences(uint64_t n_sent, uint64_t total_chars) {
 }
 size_t tag_summary_words() { return size_t(1) << (kSumLog2 - 5u); }
 
-// fill_tags: [summary of the token filter] -> front end (queue) -> scan (the runs' first records) -> passes (records).  The caller has zeroed
-// qctl, run_pref and scan_state and set the dense arrays it wants to None.
+// fill_tags: [summary of the token filter] -> front end (candidates) -> scan (the runs' first records) -> lookups (the records' models) ->
+// passes (the records).  The caller has zeroed run_pref and scan_state and set the dense arrays it wants to None.
 hipError_t launch_tag_tokens(const TagParams& P, hipStream_t stream) {
 #ifdef VPT_TAG_PROFILE
     {
@@ -963,8 +962,12 @@ hipError_t launch_tag_tokens(const TagParams& P, hipStream_t stream) {
     hipLaunchKernelGGL((tag_front_flat_kernel<sum>), grid, block, 0, stream, P, sum_log2);
     hipError_t e = launch_scan(P.run_pref, P.n_runs, P.scan_state, ~uint64_t(0), nullptr, nullptr, stream);
     if (e != hipSuccess) return e;
-    // the passes: what the device holds (8 workgroups of 4 waves per CU), never more than a wave per char of the batch would need
-    const uint64_t want_p = (P.total_chars + uint64_t(kTagPass) * kTagWaves - 1) / (uint64_t(kTagPass) * kTagWaves), cap_p = uint64_t(cus) * kTagPairOcc;
+    // the lookups and the passes: what the device holds (8 workgroups of 4 waves per CU), never more waves than there are runs / than a
+    // wave per 16 chars of the batch would need
+    const uint64_t cap_p = uint64_t(cus) * kTagPairOcc;
+    const uint64_t want_r = (P.n_runs + uint64_t(kTagWaves) * kResolveRuns - 1) / (uint64_t(kTagWaves) * kResolveRuns);
+    hipLaunchKernelGGL(tag_resolve_kernel, dim3(uint32_t(want_r < 1 ? 1 : want_r > cap_p ? cap_p : want_r)), dim3(kTagThreads), 0, stream, P);
+    const uint64_t want_p = (P.total_chars + uint64_t(64) * kTagWaves - 1) / (uint64_t(64) * kTagWaves);
     hipLaunchKernelGGL(tag_pass_kernel, dim3(uint32_t(want_p < 1 ? 1 : want_p > cap_p ? cap_p : want_p)), dim3(kTagThreads), 0, stream, P);
     return hipGetLastError();
 }
@@ -978,7 +981,7 @@ __global__ __launch_bounds__(256) void expand_tags_kernel(const uint4* __restric
         const uint64_t k = i / n_tags, j = i - k * n_tags;
         const uint4 r = records[k];
         const uint64_t gp = uint64_t(r.x) | (uint64_t(r.y) << 32);
-        if (gp < total_chars) tags[gp * n_tags + j] = rec_tags[i];
+        if (gp < total_chars && (r.z & kTokModelMask) != 0) tags[gp * n_tags + j] = rec_tags[i];   // (an empty record: a candidate without a tag model)
     }
 }
 hipError_t launch_expand_tags(const uint4* records, const int32_t* rec_tags, const uint64_t* n_records, uint32_t n_tags, uint64_t total_chars, int32_t* tags,
