@@ -37,6 +37,8 @@ __device__ __forceinline__ uint32_t tag_suffix_write(const EmitParams& P, uint64
         const uint2 e = (pre && j < 2) ? pre[j] : rs[j];
         if (dst && n < limit) dst[n] = 0x2Fu;
         ++n;
+        // (copied byte by byte: sixteen bytes a trip -- through registers, or through five dwords of LDS of the thread's own -- measured no
+        // faster, 1.43 - 1.70 against 1.37 ms on configs[4], profiles/r06_h_*, r06_i_*: the strings are a few bytes and sit in the L2)
         if (dst) for (uint32_t q = 0; q < e.y && n + q < limit; ++q) dst[n + q] = P.str_bytes[e.x + q];
         n += e.y;
     }
@@ -228,8 +230,11 @@ __device__ __forceinline__ uint32_t flat_block_scan(uint32_t x, uint32_t* wtot, 
     return woff + incl - x;
 }
 
+#ifndef VPT_EMIT_TAG_OCC
+#define VPT_EMIT_TAG_OCC 4   // waves per SIMD the tagged instance is compiled for at least (A/B builds: -D; 1: what the compiler takes by itself -- 140 VGPRs, 3 waves: 1.54 ms on configs[4] against 1.37 at 4, profiles/r06_g_*)
+#endif
 template <bool kTags>
-__global__ __launch_bounds__(kEmitThreads) void emit_flat_kernel(const EmitParams P, const EmitFuse F) {
+__global__ __launch_bounds__(kEmitThreads, kTags ? VPT_EMIT_TAG_OCC : 1) void emit_flat_kernel(const EmitParams P, const EmitFuse F) {
     __shared__ FlatLds L;
     __shared__ FlatMarks MK[1];   // (with tags; the instance without never touches it and the compiler drops it)
     // the other array of state words, for the call after this one
