@@ -400,32 +400,6 @@ class Runner:
                          "kernels": "emit_flat_kernel: one launch (kernels_emit.hip), %s" % ("tagged, from the tag records" if nt else "boundaries only")}
             # the whole output is compared with the oracle's writer below (sentence.rs:850-886 restated in oracle/vaporetto_oracle.c)
             emit_out = (d_out[:out_bytes].cpu().numpy(), toff) if not args.no_cpu_baseline else None
-            # ... and the writer as a phase of the scoring kernel (vpt_predict_write_batch_device): ONE launch leaves scores, labels and the
-            # tokenized text; compared with predict + emit above (kernel time by the same HIP events), its text with the writer's
-            if not nt:
-                d_out2 = torch.empty(cap + 1, dtype=torch.uint8, device=dev)
-
-                def fused():
-                    batch.predict_write(d_text.data_ptr(), d_boff.data_ptr(), d_ooff.data_ptr(), S, nb, max_bytes, d_scores.data_ptr(), d_labels.data_ptr(),
-                                        d_out2.data_ptr(), cap, d_toff.data_ptr(), stream)
-                for _ in range(3):
-                    fused()
-                batch.sync()
-                batch.kernel_ms()
-                torch.cuda.synchronize()
-                t0 = time.perf_counter()
-                for _ in range(steps):
-                    fused()
-                torch.cuda.synchronize()
-                dtf = (time.perf_counter() - t0) / steps
-                batch.sync()
-                kt = batch.kernel_times()
-                toff2 = d_toff.cpu().numpy().astype(np.uint64)
-                same = bool(np.array_equal(toff2, toff) and torch.equal(d_out2[:out_bytes], d_out[:out_bytes]))
-                emit_info["fused"] = {"ms_per_step": 1e3 * dtf, "kernel_ms": float(np.median(kt)) if len(kt) else None, "same_text_as_the_writer": same,
-                                      "separate_ms_per_step": 1e3 * elapsed / steps + emit_info["ms_per_step"],
-                                      "kernels": "score_tiles_fast_kernel<.., EMIT>: phases A-C + D (tokenized text from the tile's LDS, look-back over the tiles' sizes)"}
-                del d_out2
             del d_out, d_toff
 
         # ---- parity against the oracle (this rank's whole shard, bit for bit) and the algorithmic bytes it counts
@@ -646,11 +620,9 @@ def compact_row(w):
            "kernel": roof.get("kernel"), "kernel_ms": r3(roof.get("kernel_ms"), 4), "frac": r3(roof.get("frac"), 4), "bytes_per_boundary": r3(roof.get("bytes_per_boundary"), 1),
            "traffic_ratio": r3(tr / a) if (a and tr) else None, "parity": w.get("parity"), "packed": w.get("packed_tables"), "tile_plan": (w.get("tile_plan") or "").split(" of ")[0]}
     if w.get("tags"):
-        row["tags_ms"], row["tags_dense_ms"], row["tags_parity"] = r3(w["tags"]["ms_per_step"], 4), r3(w["tags"]["dense_ms_per_step"], 4), w["tags"].get("parity")
+        row["tags_ms"], row["tags_dense_ms"], row["tags_parity"] = r3(w["tags"]["ms_per_step"], 4), r3(w["tags"].get("dense_ms_per_step"), 4), w["tags"].get("parity")
     if w.get("emit"):
         row["emit_ms"], row["emit_frac"], row["emit_parity"] = r3(w["emit"]["ms_per_step"], 4), r3(w["emit"]["frac_of_hbm"], 4), w["emit"].get("parity")
-        if w["emit"].get("fused"):
-            row["fused_ms"] = r3(w["emit"]["fused"]["ms_per_step"], 4)
     if w.get("e2e"):
         row["e2e_ms"], row["e2e_frac_both_ways"] = r3(w["e2e"]["ms_per_batch"], 4), r3(w["e2e"]["frac_of_both_ways"])
         row["tokenize_ms"], row["tokenize_Gchars"] = r3(w["e2e"]["tokenize"]["ms_per_batch"], 4), r3(w["e2e"]["tokenize"]["chars_per_s"] / 1e9)
@@ -1034,8 +1006,8 @@ def main():
         if extra:
             line["workloads"] = [compact_row(w) for w in [prim] + extra]
             line["workloads_columns"] = "G boundaries/s; kernel_ms = HIP-event median of the scoring kernel; frac = algorithmic bytes / kernel_ms / 8 TB/s; " \
-                                        "traffic_ratio = PMC bytes / algorithmic bytes (null: no PMC pass on these sources); tags_ms / emit_ms / fused_ms = fill_tags, " \
-                                        "the writer's launch, predict + writer in one launch, wall clock per call"
+                                        "traffic_ratio = PMC bytes / algorithmic bytes (null: no PMC pass on these sources); tags_ms / emit_ms = fill_tags, " \
+                                        "the writer's launch, wall clock per call"
         detail = dict(line, workloads=[prim] + extra) if extra else line
         try:
             os.makedirs(os.path.dirname(os.path.abspath(args.detail_out)), exist_ok=True)

@@ -1196,9 +1196,11 @@ def _fused_write(pred, texts, flags=0, want_scores=True, cap=None):
 
 @pytest.mark.parametrize("case", ["rows", "window-table", "no-types", "window-5", "window-8", "general"])
 def test_predict_and_write_in_one_launch(case, monkeypatch):
-    """vpt_predict_write_batch_device: the tokenized text comes out of the scoring kernel's tiles (phase D) -- byte for byte what the
-    oracle's Sentence::write_tokenized_text (sentence.rs:850-886) makes of the oracle's labels, for whole-sentence and cut tiles, every
-    UTF-8 length, the escaped bytes, 1-char sentences, sentences longer than a tile, with and without the score / label outputs."""
+    """(The name is history: rounds 4 - 5 fused the writer into the scoring kernel; since round 6 the call is the scoring launch and the
+    writer's, back to back.)  vpt_predict_write_batch_device: the tokenized text is byte for byte what the oracle's
+    Sentence::write_tokenized_text (sentence.rs:850-886) makes of the oracle's labels, for whole-sentence and cut tiles, every UTF-8 length,
+    the escaped bytes, 1-char sentences, sentences longer than a tile, with and without the score / label outputs (without: the labels stay
+    in the workspace)."""
     wc, wt = {"window-5": (5, 2), "window-8": (8, 8)}.get(case, (3, 3))
     if case == "window-table":
         monkeypatch.setenv("VPT_FORCE_WINDOW_TABLE", "1")
@@ -1246,24 +1248,15 @@ def test_predict_and_write_in_one_launch(case, monkeypatch):
         _fused_write(pred, texts, cap=100)
 
 
-@pytest.mark.parametrize("chunk_bytes", ["", "900", "20000", "20000:no-prefix", "direct", "900:direct", "20000:direct:no-prefix", "serial", "900:serial", "20000:serial",
-                                         "20000:serial:no-prefix", "300"])
+@pytest.mark.parametrize("chunk_bytes", ["", "900", "20000", "20000:small-runs", "300"])
 def test_tokenize_batch_into_pinned_buffers(chunk_bytes, monkeypatch):
-    """vpt_tokenize_batch without tags: the scoring kernel's tiles write the tokenized text themselves, chunk after chunk into one contiguous
-    text (the chunks hand the position on through device words), copied out chunk by chunk while the next one is scored and the one after
-    it has its chars counted and its tiles found on another stream; with
-    VPT_TOKENIZE_DIRECT into caller buffers in PINNED memory (vpt_host_alloc) the kernels write it over PCIe themselves -- no copy out.
-    Too small a buffer is an error either way."""
-    if "serial" in chunk_bytes:    # every kernel on one stream, one workspace (default: char count and tile search on a stream of their own)
-        monkeypatch.setenv("VPT_TOKENIZE_SERIAL", "1")
-        chunk_bytes = chunk_bytes.replace(":serial", "").replace("serial", "")
-    if "direct" in chunk_bytes:   # the kernels write into the pinned caller buffers themselves
-        monkeypatch.setenv("VPT_TOKENIZE_DIRECT", "1")
-        chunk_bytes = chunk_bytes.replace(":direct", "").replace("direct", "")
-    if chunk_bytes.endswith(":no-prefix"):   # tiles publish sizes only: every look-back walks back to the launch's start (and, in a chunk behind the
-        chunk_bytes = chunk_bytes.split(":")[0]   # first, adds where that is) -- the path a tile takes when none in front of it has its position yet
-        monkeypatch.setenv("VPT_DEBUG_EMIT_NO_PREFIX", "1")
-        monkeypatch.setenv("VPT_TILE_FLAT", "64")   # many tiles per chunk: tile numbers that are multiples of 64 among them
+    """vpt_tokenize_batch without tags: chunk after chunk -- scoring launch, then the writer's -- into one contiguous text (the writers hand
+    the position on through device words), copied out chunk by chunk while the next one is scored and the one after it has its chars counted
+    and its tiles found on another stream; pinned (vpt_host_alloc) and pageable caller buffers.  Too small a buffer is an error."""
+    if chunk_bytes.endswith(":small-runs"):   # many runs per chunk for the writer's look-back (run numbers that are multiples of 64 among them), cut tiles
+        chunk_bytes = chunk_bytes.split(":")[0]
+        monkeypatch.setenv("VPT_EMIT_PER_BLOCK", "1")
+        monkeypatch.setenv("VPT_TILE_FLAT", "64")
         monkeypatch.setenv("VPT_FORCE_CUT_TILES", "1")
     if chunk_bytes:
         monkeypatch.setenv("VPT_TOKENIZE_CHUNK_BYTES", chunk_bytes)

@@ -87,7 +87,7 @@ while time.time() < t_end:
         if pred.tokenize(sub, fullwidth=fw) != pred.write_tokenized_batch(sents):
             print("MISMATCH tokenize: seed", seed)
             sys.exit(1)
-    if not fw and seed % 2 == 1:   # the writer fused into the scoring kernel, the WHOLE batch against the oracle's writer (round 4):
+    if not fw and seed % 2 == 1:   # predict + the writer for the WHOLE batch against the oracle's writer:
         o_text, o_toff = orc.write_tokenized_batch(n_utf8, n_boff, o_ooff, o_labels, None, None)
         t_text, t_toff = pred.tokenize_packed(utf8, boff)       # ... through vpt_tokenize_batch (chunks chained into one text)
         if not (np.array_equal(t_toff, o_toff) and np.array_equal(t_text, o_text)):

@@ -46,9 +46,6 @@ struct PredictorKnobs {
     uint64_t chunk_chars = 0;           // VPT_CHUNK_CHARS (0: the size rule)
     uint64_t tokenize_chunk_bytes = uint64_t(256) << 20;   // VPT_TOKENIZE_CHUNK_BYTES (the tagged pipeline's default; the fused one: an eighth of the batch, at least 4 MB)
     bool tokenize_chunk_bytes_set = false;
-    bool tokenize_separate = false;     // VPT_TOKENIZE_SEPARATE: predict and the writer as launches of their own for untagged text too (A/B of the fused path)
-    bool tokenize_serial = false;       // VPT_TOKENIZE_SERIAL: every kernel of every chunk on ONE stream with one workspace (A/B of the preparing stream)
-    bool tokenize_direct = false;       // VPT_TOKENIZE_DIRECT: the kernels write the tokenized text straight into a pinned caller buffer (no copies out)
 };
 struct BatchKnobs {
     bool force_generic = false;         // VPT_FORCE_GENERIC
@@ -57,7 +54,6 @@ struct BatchKnobs {
     bool no_cps_from_predict = false;   // VPT_NO_CPS_FROM_PREDICT
     uint32_t debug_ablate = 0;          // VPT_DEBUG_ABLATE
     bool profile_phases = false;        // VPT_PROFILE_PHASES
-    bool emit_no_prefix = false;        // VPT_DEBUG_EMIT_NO_PREFIX: the fused writer's tiles publish sizes only (tests: every look-back walks to the front)
     uint32_t emit_per_block = 0;        // VPT_EMIT_PER_BLOCK: sentences a workgroup of the writer takes (1..256; 0: from the mean sentence length) -- tests: runs of any size
     uint32_t emit_run_chars = 0;        // VPT_EMIT_RUN_CHARS: chars of a workgroup's run (default 5120)
 };
@@ -68,9 +64,6 @@ PredictorKnobs read_predictor_knobs() {
     if (const char* v = std::getenv("VPT_PIPE_LANES")) k.pipe_lanes = std::max(0, std::atoi(v));
     if (const char* v = std::getenv("VPT_CHUNK_CHARS")) { const long long n = std::atoll(v); if (n > 0) k.chunk_chars = uint64_t(n); }
     if (const char* v = std::getenv("VPT_TOKENIZE_CHUNK_BYTES")) { const long long n = std::atoll(v); if (n > 0) { k.tokenize_chunk_bytes = uint64_t(n); k.tokenize_chunk_bytes_set = true; } }
-    k.tokenize_direct = std::getenv("VPT_TOKENIZE_DIRECT") != nullptr;
-    k.tokenize_serial = std::getenv("VPT_TOKENIZE_SERIAL") != nullptr;
-    k.tokenize_separate = std::getenv("VPT_TOKENIZE_SEPARATE") != nullptr;
     return k;
 }
 BatchKnobs read_batch_knobs() {
@@ -83,7 +76,6 @@ BatchKnobs read_batch_knobs() {
     k.no_cps_from_predict = std::getenv("VPT_NO_CPS_FROM_PREDICT") != nullptr;
     if (const char* v = std::getenv("VPT_DEBUG_ABLATE")) k.debug_ablate = uint32_t(std::atoi(v));
     k.profile_phases = std::getenv("VPT_PROFILE_PHASES") != nullptr;
-    k.emit_no_prefix = std::getenv("VPT_DEBUG_EMIT_NO_PREFIX") != nullptr;
     return k;
 }
 
@@ -296,7 +288,6 @@ struct vpt_batch {
     // the writer's state words (EmitFuse): two arrays of emit_state_cap words, used in turn; a call zeroes what the call before it
     // left in the other one (emit_dirty = how many words that is)
     uint64_t* d_emit_state = nullptr; size_t emit_state_cap = 0; size_t emit_dirty[2] = {0, 0}; int emit_flip = 0;
-    uint64_t* d_fuse_state = nullptr; size_t fuse_state_cap = 0;   // the fused writer's words (EmitOut::state): one per tile + the ticket, + the chain word
     // the pipelined host-buffer path (predict_pipelined): two sets of device buffers, copy streams, pinned offset staging
     struct PipeSet {
         uint8_t* text = nullptr; size_t text_cap = 0;
@@ -335,8 +326,6 @@ struct vpt_predictor {
     int32_t bias = 0; int pad = 1; int type_kind = 0; int type_window = 0; int chunks = 2;
     uint32_t tile_slots = 0;           // workgroups of the scoring kernel the device runs at a time (0 = unknown)
     uint32_t n_cus = 0;                // compute units of the device (0 = unknown)
-    bool fused_writer_ok = false;      // the specialised kernel scores ANY batch of this predictor (tiles cut anywhere fit beside its longest pattern):
-                                       // vpt_tokenize_batch can count on the writer fused into it
     vpt::PackedView pk{};
     const int32_t* d_type_table = nullptr;
     const uint8_t* d_ctype = nullptr;
@@ -367,7 +356,7 @@ void batch_release(vpt_batch* b) {
     (void)hipSetDevice(b->device);
     (void)hipFree(b->d_scan_part);
     (void)hipFree(b->d_emit_state);
-    (void)hipFree(b->d_fuse_state); (void)hipFree(b->d_chain);
+    (void)hipFree(b->d_chain);
     (void)hipFree(b->d_tiles); (void)hipFree(b->d_cut_local); (void)hipFree(b->d_cut_super);
     (void)hipFree(b->d_tile_first); (void)hipFree(b->d_slow_list); (void)hipFree(b->d_ctrl); (void)hipFree(b->d_scratch);
     (void)hipFree(b->d_prof); (void)hipFree(b->d_cps);
@@ -612,13 +601,6 @@ void bind_predictor(vpt_predictor* p) {
         probe.ct = p->ct; probe.pk = p->pk; probe.pad = p->pad; probe.ctype = p->d_ctype; probe.cid = p->d_cid; probe.type_kind = p->type_kind;
         probe.type_window = p->type_window; probe.force_window_table = p->knobs.force_window_table ? 1u : 0u;
         const bool fast = vpt::fast_path_supported(probe);
-        if (fast) {   // (the same room as vpt_predict_batch_device's plan: a cut tile between its halos)
-            const uint32_t lmax = std::max<uint32_t>(p->info.max_pattern_chars, 3), wl = p->pk.wl;
-            const uint32_t levels = p->pk.trow_mode == vpt::kTypeRowsGlobal ? p->pk.trow_levels : 3u;
-            const int64_t room = int64_t(vpt::fast_path_cap(probe)) - vpt::kFastStageSlack - int64_t(p->pad) - int64_t(std::max<uint32_t>(lmax - 1, wl)) -
-                                 int64_t(wl + std::max<uint32_t>(std::max<uint32_t>(lmax - 1, wl), levels));
-            p->fused_writer_ok = room >= 256;
-        }
         auto slots_for = [&](size_t lds, size_t built_for) {
             lds += p->knobs.lds_pad;   // occupancy experiments (kernels_fast.hip)
             const size_t granules = (lds + 1279) / 1280;   // gfx950 hands out its 160 KB of LDS in 1280-byte granules
@@ -1025,18 +1007,14 @@ vpt_status vpt_batch_node_reads(vpt_batch* b, uint64_t reads[8]) {
 }
 
 namespace {
-// What a fused-writer call asks of predict_device_impl: where the tokenized text goes.  chain: a device word that holds the output
-// position in front of this call's text / receives the position behind it (calls enqueued one after the other on one stream
-// write one contiguous text: vpt_tokenize_batch's chunks); nullptr: the text starts at 0.
-struct FuseRequest { uint8_t* text_out; uint64_t capacity; uint64_t* offsets_out; uint64_t* total_out; const uint64_t* chain_in; uint64_t* chain_out; };
 vpt_status emit_device(const vpt_predictor* p, vpt_batch* b, const uint8_t* d_utf8, const uint64_t* d_byte_offsets,
                        const uint64_t* d_out_offsets, size_t n_sentences, uint64_t total_boundaries, const uint8_t* d_labels,
                        bool tagged, uint8_t* d_text_out, uint64_t text_capacity, uint64_t* d_text_offsets_out,
-                       hipStream_t stream, uint64_t* total_out = nullptr);
+                       hipStream_t stream, uint64_t* total_out = nullptr, const uint64_t* chain_in = nullptr, uint64_t* chain_out = nullptr);
 
 vpt_status predict_device_impl(const vpt_predictor* p, vpt_batch* b, const uint8_t* d_utf8, const uint64_t* d_byte_offsets,
                                const uint64_t* d_out_offsets, size_t n_sentences, uint64_t total_boundaries,
-                               uint64_t max_sentence_bytes, int32_t* d_scores, uint8_t* d_labels, void* hip_stream, const FuseRequest* fuse) {
+                               uint64_t max_sentence_bytes, int32_t* d_scores, uint8_t* d_labels, void* hip_stream) {
     if (!p || !b || b->pred != p) return fail(VPT_INVALID_ARGUMENT, "InvalidArgumentError: batch: does not belong to this predictor");
     if (n_sentences == 0) { b->last_tiles = 0; return VPT_OK; }   // nothing enqueued; earlier work stays pending
     if (!d_utf8 || !d_byte_offsets || !d_out_offsets) return fail(VPT_INVALID_ARGUMENT, "InvalidArgumentError: NULL device pointer");
@@ -1165,29 +1143,10 @@ vpt_status predict_device_impl(const vpt_predictor* p, vpt_batch* b, const uint8
     if (b->knobs.debug_ablate) { P.debug = b->knobs.debug_ablate; P.ct.debug = P.debug; P.tt.debug = P.debug; }
 
     P.n_sent = n_sentences; P.tile_flat = uint32_t(tile_flat); P.n_tiles = n_tiles;
-    // The writer fused into the specialised kernel: its words (one per tile + the ticket) are cleared by the assign kernel in front
-    // of it.  The general kernels have no such phase: labels into the workspace, then the writer's own launch.
-    uint64_t* fuse_state = nullptr;
-    uint8_t* labels_for_writer = d_labels;
-    if (fuse) {
-        if (fast) {
-            const size_t words = size_t(n_tiles) + 2;
-            if ((st = grow(&b->d_fuse_state, &b->fuse_state_cap, words)) != VPT_OK) return st;
-            fuse_state = b->d_fuse_state;
-            P.emit.out_text = fuse->text_out; P.emit.capacity = fuse->capacity; P.emit.out_offsets = fuse->offsets_out;
-            P.emit.state = fuse_state; P.emit.total_out = fuse->total_out; P.emit.chain_in = fuse->chain_in; P.emit.chain_out = fuse->chain_out;
-            P.emit.no_prefix = b->knobs.emit_no_prefix ? 1u : 0u;
-            if (!P.emit.out_text) P.emit.out_text = reinterpret_cast<uint8_t*>(b->d_ctrl);   // capacity 0: nothing is stored, the sizes still are
-        } else if (!labels_for_writer) {
-            if ((st = grow(&b->d_tlab, &b->tlab_cap, size_t(total_boundaries) + 1)) != VPT_OK) return st;
-            labels_for_writer = b->d_tlab;
-            P.labels = labels_for_writer;
-        }
-    }
     // the tiles (a kernel of its own: finding them at the head of every workgroup measured slower, profiles/r02_c1_ab.jsonl); for
     // cut tiles preceded by the lead-byte index of the text
-    if (fast && cut_tiles) VPT_HIP(vpt::launch_assign_tiles_cut(P, cut, n_tiles, total_chars, b->d_cut_local, b->d_cut_super, b->d_tiles, b->d_ctrl, stream, fuse_state));
-    else VPT_HIP(vpt::launch_assign_tiles(d_out_offsets, n_sentences, p->pad, uint32_t(tile_flat), n_tiles, b->d_tile_first, b->d_ctrl, stream, fuse_state));
+    if (fast && cut_tiles) VPT_HIP(vpt::launch_assign_tiles_cut(P, cut, n_tiles, total_chars, b->d_cut_local, b->d_cut_super, b->d_tiles, b->d_ctrl, stream));
+    else VPT_HIP(vpt::launch_assign_tiles(d_out_offsets, n_sentences, p->pad, uint32_t(tile_flat), n_tiles, b->d_tile_first, b->d_ctrl, stream));
     if (b->split_stream) {
         VPT_HIP(hipEventRecord(b->split_event, stream));
         VPT_HIP(hipStreamWaitEvent(b->split_stream, b->split_event, 0));
@@ -1201,11 +1160,6 @@ vpt_status predict_device_impl(const vpt_predictor* p, vpt_batch* b, const uint8
     if (b->timing) { VPT_HIP(hipEventRecord(b->ev[2 * slot + 1], stream)); ++b->ev_calls; }
     b->last_tiles = n_tiles; b->last_stream = stream; b->pending = true;
     b->last_tile_flat = uint32_t(tile_flat); b->last_plan = !fast ? 0u : cut_tiles ? 2u : 1u;
-    if (fuse && !fast) {
-        if (fuse->chain_in || fuse->chain_out) return fail(VPT_RUNTIME_ERROR, "internal error: chained tokenized text needs the specialised kernel");
-        return emit_device(p, b, d_utf8, d_byte_offsets, d_out_offsets, n_sentences, total_boundaries, labels_for_writer, false, fuse->text_out,
-                           fuse->capacity, fuse->offsets_out, stream, fuse->total_out);
-    }
     return VPT_OK;
 }
 }  // namespace
@@ -1213,11 +1167,12 @@ vpt_status predict_device_impl(const vpt_predictor* p, vpt_batch* b, const uint8
 vpt_status vpt_predict_batch_device(const vpt_predictor* p, vpt_batch* b, const uint8_t* d_utf8, const uint64_t* d_byte_offsets,
                                     const uint64_t* d_out_offsets, size_t n_sentences, uint64_t total_boundaries,
                                     uint64_t max_sentence_bytes, int32_t* d_scores, uint8_t* d_labels, void* hip_stream) {
-    return predict_device_impl(p, b, d_utf8, d_byte_offsets, d_out_offsets, n_sentences, total_boundaries, max_sentence_bytes, d_scores, d_labels, hip_stream, nullptr);
+    return predict_device_impl(p, b, d_utf8, d_byte_offsets, d_out_offsets, n_sentences, total_boundaries, max_sentence_bytes, d_scores, d_labels, hip_stream);
 }
 
-// Predictor::predict + Sentence::write_tokenized_text (no tags) for a batch in ONE scoring launch: the tiles of the specialised kernel write
-// the tokenized text of their own chars straight from LDS (kernels_fast.hip, phase D); scores and labels are optional outputs.
+// Predictor::predict + Sentence::write_tokenized_text (no tags) for a batch as ONE call: the scoring launch and the writer's, back to back on the
+// stream; scores and labels are optional outputs (no d_labels: the labels stay in the workspace).  (Rounds 4 - 5 fused the writer into the scoring
+// kernel as a fourth phase: slower than the two launches on every batch size and, chunk by chunk, in vpt_tokenize_batch too -- HISTORY.md.)
 vpt_status vpt_predict_write_batch_device(const vpt_predictor* p, vpt_batch* b, const uint8_t* d_utf8, const uint64_t* d_byte_offsets,
                                           const uint64_t* d_out_offsets, size_t n_sentences, uint64_t total_boundaries,
                                           uint64_t max_sentence_bytes, int32_t* d_scores, uint8_t* d_labels, uint8_t* d_text_out,
@@ -1230,8 +1185,17 @@ vpt_status vpt_predict_write_batch_device(const vpt_predictor* p, vpt_batch* b, 
         b->last_stream = static_cast<hipStream_t>(hip_stream); b->pending = true; b->cps_text = nullptr;
         return VPT_OK;
     }
-    const FuseRequest fuse{d_text_out, text_capacity, d_text_offsets_out, nullptr, nullptr, nullptr};
-    return predict_device_impl(p, b, d_utf8, d_byte_offsets, d_out_offsets, n_sentences, total_boundaries, max_sentence_bytes, d_scores, d_labels, hip_stream, &fuse);
+    if (!d_utf8 || !d_byte_offsets || !d_out_offsets) return fail(VPT_INVALID_ARGUMENT, "InvalidArgumentError: NULL device pointer");
+    uint8_t* labels = d_labels;
+    if (!labels) {
+        const vpt_status st = grow(&b->d_tlab, &b->tlab_cap, size_t(total_boundaries) + 16);
+        if (st != VPT_OK) return st;
+        labels = b->d_tlab;
+    }
+    const vpt_status st = predict_device_impl(p, b, d_utf8, d_byte_offsets, d_out_offsets, n_sentences, total_boundaries, max_sentence_bytes, d_scores, labels, hip_stream);
+    if (st != VPT_OK) return st;
+    return emit_device(p, b, d_utf8, d_byte_offsets, d_out_offsets, n_sentences, total_boundaries, labels, false, d_text_out, text_capacity, d_text_offsets_out,
+                       static_cast<hipStream_t>(hip_stream));
 }
 
 vpt_status vpt_batch_last_plan(const vpt_batch* b, uint32_t* n_tiles, uint32_t* tile_flat, uint32_t* kind) {
@@ -1620,7 +1584,7 @@ namespace {
 vpt_status emit_device(const vpt_predictor* p, vpt_batch* b, const uint8_t* d_utf8, const uint64_t* d_byte_offsets,
                        const uint64_t* d_out_offsets, size_t n_sentences, uint64_t total_boundaries, const uint8_t* d_labels,
                        bool tagged, uint8_t* d_text_out, uint64_t text_capacity, uint64_t* d_text_offsets_out,
-                       hipStream_t stream, uint64_t* total_out) {
+                       hipStream_t stream, uint64_t* total_out, const uint64_t* chain_in, uint64_t* chain_out) {
     if (!p || !b || b->pred != p) return fail(VPT_INVALID_ARGUMENT, "InvalidArgumentError: batch: does not belong to this predictor");
     if (!d_text_offsets_out) return fail(VPT_INVALID_ARGUMENT, "InvalidArgumentError: NULL device pointer");
     VPT_HIP(hipSetDevice(p->device));
@@ -1670,7 +1634,7 @@ vpt_status emit_device(const vpt_predictor* p, vpt_batch* b, const uint8_t* d_ut
     F.state = b->d_emit_state + size_t(b->emit_flip) * b->emit_state_cap;
     F.clear = b->d_emit_state + size_t(b->emit_flip ^ 1) * b->emit_state_cap;
     F.clear_n = b->emit_dirty[b->emit_flip ^ 1];
-    F.total_out = total_out;
+    F.total_out = total_out; F.chain_in = chain_in; F.chain_out = chain_out;
     b->emit_dirty[b->emit_flip ^ 1] = 0; b->emit_dirty[b->emit_flip] = words;
     b->emit_flip ^= 1;
     VPT_HIP(vpt::launch_emit_tokenized(E, F, stream));
@@ -1768,37 +1732,26 @@ vpt_status vpt_count_boundaries_device(const vpt_predictor* p, vpt_batch* b, con
 }
 
 namespace {
-// memory a kernel can write: pinned host memory (vpt_host_alloc / hipHostMalloc / hipHostRegister) as the device sees it, else nullptr
-void* device_view_of_host(void* host_ptr) {
-    if (!host_ptr) return nullptr;
-    hipPointerAttribute_t attr;
-    if (hipPointerGetAttributes(&attr, host_ptr) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
-    if (attr.type != hipMemoryTypeHost) return nullptr;
-    void* d = nullptr;
-    if (hipHostGetDevicePointer(&d, host_ptr, 0) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
-    return d;
-}
-
-// vpt_tokenize_batch without tags, on the scoring kernel with the writer fused in (vpt_predict_write_batch_device's path): a chunk of lines
-// is a copy in (text, offsets), the char count, the tile search and ONE scoring launch that leaves tokenized text.  Every chunk's text
-// follows the one before it -- the kernels hand the output position on through a chain of device words -- so the batch's output is one
-// piece however it is cut.  Four stages overlap:
+// vpt_tokenize_batch without tags, in chunks: a chunk of lines is a copy in (text, offsets), the char count, the tile search, the scoring
+// launch (labels into the workspace) and the writer's launch.  Every chunk's text follows the one before it -- the writers hand the output
+// position on through a chain of device words (EmitFuse::chain_in / chain_out) -- so the batch's output is one piece however it is cut.
+// Four stages overlap:
 //   copy in of chunk k + 2            its own stream
 //   char count + tile search of k + 1 the PREPARING stream, with the scratch of one of two workspaces (k + 1 & 1)
-//   scoring launch of chunk k         the SCORING stream: the launches follow each other with an event wait that has long fired in between
+//   scoring + writer of chunk k       the SCORING stream: the launches follow each other with an event wait that has long fired in between
 //                                     (profiles/r04_e_tokenize_timeline.txt: 33 us of small launches in front of every scoring launch before)
 //   copy out of chunk k - 1           issued by the host as soon as the chunk's event has fired; a pinned word says where its text ends
 // and the host is a fifth: a chunk is some fifteen runtime calls, and with everything enqueued before the first wait the copies out only
 // started when the LAST chunk was enqueued (r04_i_tokenize_timeline.txt).  So the loop cuts and rebases a chunk's offsets when its copy in
 // is due, keeps the copies in two chunks ahead of the kernels, and after every chunk looks whether an earlier one can leave.
-// Measured and dropped (profiles/r04_{k,m,n}_tokenize*): a small first and last chunk (what is in front of the first scored chunk and behind
-// the last one overlaps with nothing; host timestamps of the equal cut, 100 K lines: first chunk scored at 250 us, one every 100 us after it,
-// 94 us behind the last) -- 0.96 ms against 0.88; two independent lanes, each chunk's text placed by an upper bound and closed up by
-// the copies out -- two scoring launches at a time take twice as long each, 1.07 ms against 0.88; scoring and writer as launches of their
-// own per chunk (28 + 28 us against 88 fused, r04_l_fused_by_batch_size.jsonl) -- the five launches per chunk cost the host more than the
-// device gains, 1.07 ms; kernels storing STRAIGHT into a pinned caller buffer (VPT_TOKENIZE_DIRECT=1, kept): their stores cross PCIe at 27 ..
-// 34 GB/s against the copy engine's 56.  `text` = the batch's first byte; byte_offsets are the caller's (relative to byte_offsets[0]).
-vpt_status tokenize_fused(const vpt_predictor* p, vpt_batch* b, const uint8_t* text, const uint64_t* byte_offsets, size_t n_sentences, unsigned flags,
+// Round 6: rounds 4 - 5 scored a chunk with the writer FUSED into the scoring kernel (one launch, 88 us of device time per 3.2 MB chunk); with
+// the flat writer (round 5) the two launches take 28 + 12 us and the whole call 0.83 ms per 100 K lines against 0.88, 5.75 against 5.83 per
+// million (profiles/r06_k_tokenize.jsonl) -- the fused phase, a second instance of every scoring kernel, is gone.
+// Measured and dropped earlier (profiles/r04_{e,g,k,m,n}_tokenize*): a small first and last chunk (0.96 ms against 0.88); two independent lanes,
+// each chunk's text placed by an upper bound and closed up by the copies out (1.07); kernels storing STRAIGHT into a pinned caller buffer
+// (their stores cross PCIe at 27 .. 34 GB/s against the copy engine's 56: 1.15 - 1.29); every kernel of every chunk on one stream (0.97).
+// `text` = the batch's first byte; byte_offsets are the caller's (relative to byte_offsets[0]).
+vpt_status tokenize_chunked(const vpt_predictor* p, vpt_batch* b, const uint8_t* text, const uint64_t* byte_offsets, size_t n_sentences, unsigned flags,
                           uint64_t max_bytes, uint8_t* text_out, uint64_t text_capacity, uint64_t* text_offsets_out) {
     (void)max_bytes;
     const uint64_t t0 = byte_offsets[0];
@@ -1810,9 +1763,8 @@ vpt_status tokenize_fused(const vpt_predictor* p, vpt_batch* b, const uint8_t* t
     const size_t max_chunks = std::min<size_t>(n_sentences, n_cuts) + 1;
     auto cut_end = [&](size_t k) -> uint64_t { return std::min<uint64_t>(uint64_t(nbytes), (k + 1) * chunk_bytes); };   // where chunk k of n_cuts should end
     vpt_status st;
-    const bool serial = p->knobs.tokenize_serial;
-    Workspace second;   // the scratch (tiles, partial sums, the writer's words, status) of every other chunk
-    if (!serial && (st = acquire(p, &second)) != VPT_OK) return st;
+    Workspace second;   // the scratch (tiles, partial sums, the writer's words, labels, status) of every other chunk
+    if ((st = acquire(p, &second)) != VPT_OK) return st;
     // Kernels enqueued on THIS workspace's streams look back over the second one's scratch (its writer words, its status): on any return --
     // an error one in the middle of the chunks included -- those streams are drained BEFORE `second` goes back to the pool (a guard declared
     // behind it is destroyed in front of it), or another host thread could take and clear what a chunk in flight still reads
@@ -1824,7 +1776,7 @@ vpt_status tokenize_fused(const vpt_predictor* p, vpt_batch* b, const uint8_t* t
             if (b->s_tok_out) (void)hipStreamSynchronize(b->s_tok_out);
         }
     } drain_first{b};
-    vpt_batch* const ws[2] = {b, serial ? b : second.b};
+    vpt_batch* const ws[2] = {b, second.b};
     if (!b->s_tok_in) VPT_HIP(hipStreamCreateWithFlags(&b->s_tok_in, hipStreamNonBlocking));
     if (!b->s_tok_out) VPT_HIP(hipStreamCreateWithFlags(&b->s_tok_out, hipStreamNonBlocking));
     while (b->chunk_ev.size() < 3 * max_chunks) {   // per chunk: copied in, tiles found, scored
@@ -1841,21 +1793,11 @@ vpt_status tokenize_fused(const vpt_predictor* p, vpt_batch* b, const uint8_t* t
         b->off_cap = std::min(cap, cap2);
     }
     if ((st = grow(&b->d_chain, &b->chain_cap, max_chunks + 2)) != VPT_OK) return st;
-    uint8_t* d_out = nullptr;
-    uint64_t* d_off_out = nullptr;
-    bool direct = false;
-    if (p->knobs.tokenize_direct) {
-        d_out = static_cast<uint8_t*>(device_view_of_host(text_out));
-        d_off_out = static_cast<uint64_t*>(device_view_of_host(text_offsets_out));
-        direct = (d_out || text_capacity == 0) && d_off_out;
-    }
-    uint64_t out_cap = text_capacity;
-    if (!direct) {
-        out_cap = uint64_t(nbytes) * 3 + 16;
-        if ((st = grow(&b->d_tok, &b->tok_cap, size_t(out_cap) + 16)) != VPT_OK) return st;
-        if ((st = grow(&b->d_toff, &b->toff_cap, n_sentences + 2)) != VPT_OK) return st;
-        d_out = b->d_tok; d_off_out = b->d_toff;
-    }
+    const uint64_t out_cap = uint64_t(nbytes) * 3 + 16;
+    if ((st = grow(&b->d_tok, &b->tok_cap, size_t(out_cap) + 16)) != VPT_OK) return st;
+    if ((st = grow(&b->d_toff, &b->toff_cap, n_sentences + 2)) != VPT_OK) return st;
+    uint8_t* const d_out = b->d_tok;
+    uint64_t* const d_off_out = b->d_toff;
     const size_t need_off = n_sentences + 1 + max_chunks + 1 + 2;   // pinned: the offsets relative to the batch's text, where every chunk's text ends, the workspaces' status words
     if (need_off > b->h_off_cap) {
         if (b->h_off) (void)hipHostFree(b->h_off);
@@ -1867,7 +1809,7 @@ vpt_status tokenize_fused(const vpt_predictor* p, vpt_batch* b, const uint8_t* t
     uint64_t* const h_end = b->h_off + n_sentences + 1;
     uint64_t* const h_ctrl = h_end + max_chunks + 1;
     hipStream_t s = b->own_stream, s_in = b->s_tok_in, s_out = b->s_tok_out;
-    hipStream_t s_prep = serial ? s : second.b->own_stream;
+    hipStream_t s_prep = second.b->own_stream;
     for (vpt_batch* w : ws) {
         w->flags = flags;
         w->max_chars = 0;   // unknown on the host (no round trip for it): the scoring kernel takes the geometry that fits any sentence
@@ -1918,21 +1860,23 @@ vpt_status tokenize_fused(const vpt_predictor* p, vpt_batch* b, const uint8_t* t
         uint64_t* d_boff_k = b->d_boff + c.a + k;
         uint64_t* d_ooff_k = b->d_ooff + c.a + k;   // n + 1 entries per chunk, chunk-relative
         VPT_HIP(hipStreamWaitEvent(s_prep, b->chunk_ev[3 * k], 0));
-        if (!serial && k >= 2) VPT_HIP(hipStreamWaitEvent(s_prep, b->chunk_ev[3 * (k - 2) + 2], 0));   // this workspace's scratch: the chunk before the last is through with it
+        if (k >= 2) VPT_HIP(hipStreamWaitEvent(s_prep, b->chunk_ev[3 * (k - 2) + 2], 0));   // this workspace's scratch: the chunk before the last is through with it
         if ((st = count_boundaries_impl(p, w, b->d_text, d_boff_k, c.n, d_ooff_k, s_prep, c.nby)) != VPT_OK) return st;
         h_end[k] = ~uint64_t(0);
-        const FuseRequest fuse{d_out, out_cap, d_off_out + c.a, h_end + k, b->d_chain + k, b->d_chain + k + 1};
-        if (!serial) { w->split_stream = s; w->split_event = b->chunk_ev[3 * k + 1]; }
-        st = predict_device_impl(p, w, b->d_text, d_boff_k, d_ooff_k, c.n, c.nby - c.n /* boundaries of the chunk, at most */, c.mb, nullptr, nullptr, s_prep, &fuse);
+        if ((st = grow(&w->d_tlab, &w->tlab_cap, size_t(c.nby) + 16)) != VPT_OK) return st;
+        w->split_stream = s; w->split_event = b->chunk_ev[3 * k + 1];   // the scoring launch: on the scoring stream, behind the tile search
+        st = predict_device_impl(p, w, b->d_text, d_boff_k, d_ooff_k, c.n, c.nby - c.n /* boundaries of the chunk, at most */, c.mb, nullptr, w->d_tlab, s_prep);
         w->split_stream = nullptr; w->split_event = nullptr;
+        if (st != VPT_OK) return st;
+        st = emit_device(p, w, b->d_text, d_boff_k, d_ooff_k, c.n, c.nby - c.n, w->d_tlab, false, d_out, out_cap, d_off_out + c.a, s, h_end + k, b->d_chain + k, b->d_chain + k + 1);
         if (st != VPT_OK) return st;
         VPT_HIP(hipEventRecord(b->chunk_ev[3 * k + 2], s));
         if ((st = copy_in_next()) != VPT_OK) return st;
-        while (!direct && !out_of_range && !too_small && next_out < k && hipEventQuery(b->chunk_ev[3 * next_out + 2]) == hipSuccess)
+        while (!out_of_range && !too_small && next_out < k && hipEventQuery(b->chunk_ev[3 * next_out + 2]) == hipSuccess)
             if ((st = copy_out(next_out++)) != VPT_OK) return st;
     }
     // ---- collect what is still on the device
-    for (; next_out < chunks.size() && !direct && !out_of_range && !too_small; ++next_out) {
+    for (; next_out < chunks.size() && !out_of_range && !too_small; ++next_out) {
         VPT_HIP(hipEventSynchronize(b->chunk_ev[3 * next_out + 2]));
         if ((st = copy_out(next_out)) != VPT_OK) return st;
     }
@@ -1940,7 +1884,7 @@ vpt_status tokenize_fused(const vpt_predictor* p, vpt_batch* b, const uint8_t* t
     h_ctrl[0] = h_ctrl[1] = 0;
     VPT_HIP(hipStreamSynchronize(s_prep));
     VPT_HIP(hipMemcpyAsync(h_ctrl, b->d_ctrl, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
-    if (!serial) VPT_HIP(hipMemcpyAsync(h_ctrl + 1, second.b->d_ctrl, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+    VPT_HIP(hipMemcpyAsync(h_ctrl + 1, second.b->d_ctrl, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
     VPT_HIP(hipStreamSynchronize(s));
     VPT_HIP(hipStreamSynchronize(s_out));
     for (vpt_batch* w : ws) w->pending = false;
@@ -1982,8 +1926,7 @@ vpt_status vpt_tokenize_batch(const vpt_predictor* p, const uint8_t* utf8, const
     vpt_batch* b = w.b;
     const size_t nbytes = size_t(t1 - t0);
     const bool with_tags = tagged && p->n_tags > 0;
-    if (!with_tags && p->fused_writer_ok && !b->knobs.force_generic && !p->knobs.tokenize_separate)
-        return tokenize_fused(p, b, utf8 + t0, byte_offsets, n_sentences, flags, max_bytes, text_out, text_capacity, text_offsets_out);
+    if (!with_tags) return tokenize_chunked(p, b, utf8 + t0, byte_offsets, n_sentences, flags, max_bytes, text_out, text_capacity, text_offsets_out);
     // NOTHING on the way needs a number from the device: the device buffers hold the whole batch and a slice of an output starts
     // where an upper bound puts it (a char is at least one byte: boundaries and chars in front of a slice <= text bytes in front
     // of it; tokenized text <= 3 bytes per text byte + the longest tag suffix per char), so copy in, char count, scoring, tagging

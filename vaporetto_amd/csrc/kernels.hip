@@ -308,11 +308,10 @@ __device__ __forceinline__ void process_tile(const ScoreParams& P, const TileMem
 // less than a separate memset.  The status word (ctrl[0]) is NOT cleared here: it accumulates over every call
 // enqueued on the workspace until vpt_batch_sync reads and clears it, so an error of any of them is reported.
 __global__ void assign_tiles_kernel(const uint64_t* __restrict__ ooff, uint64_t n_sent, int pad, uint32_t tile_flat,
-                                    uint32_t n_tiles, uint32_t* __restrict__ tile_first, uint32_t* __restrict__ ctrl, uint64_t* __restrict__ emit_state) {
+                                    uint32_t n_tiles, uint32_t* __restrict__ tile_first, uint32_t* __restrict__ ctrl) {
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t == 1) ctrl[1] = 0;
     if (t > n_tiles) return;
-    if (emit_state) emit_state[t] = 0;   // the fused writer's words (one per tile + the ticket)
     const uint64_t lo = first_sentence_at(ooff, n_sent, uint64_t(1 + pad), uint64_t(t) * tile_flat);
     tile_first[t] = t == n_tiles ? uint32_t(n_sent) : uint32_t(lo);
 }
@@ -379,9 +378,9 @@ size_t score_tiles_lds_bytes() {
 }
 
 hipError_t launch_assign_tiles(const uint64_t* ooff, uint64_t n_sent, int pad, uint32_t tile_flat, uint32_t n_tiles,
-                               uint32_t* tile_first, uint32_t* ctrl, hipStream_t stream, uint64_t* emit_state) {
+                               uint32_t* tile_first, uint32_t* ctrl, hipStream_t stream) {
     const uint32_t threads = 256, blocks = (n_tiles + 1 + threads - 1) / threads;
-    hipLaunchKernelGGL(assign_tiles_kernel, dim3(blocks), dim3(threads), 0, stream, ooff, n_sent, pad, tile_flat, n_tiles, tile_first, ctrl, emit_state);
+    hipLaunchKernelGGL(assign_tiles_kernel, dim3(blocks), dim3(threads), 0, stream, ooff, n_sent, pad, tile_flat, n_tiles, tile_first, ctrl);
     return hipGetLastError();
 }
 

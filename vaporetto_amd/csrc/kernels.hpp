@@ -56,20 +56,6 @@ constexpr uint32_t kErrScratchTooSmall = 8u;  // max_sentence_bytes was understa
 constexpr uint32_t kErrUnknownLabel = 16u;    // token emission: a label that is neither 0 nor 1
 constexpr uint32_t kErrOutputTooSmall = 32u;  // token emission: text_capacity is smaller than the tokenized text
 
-// The writer fused into the specialised scoring kernel (vpt_predict_write_batch_device): a tile writes the tokenized text of the
-// chars it owns -- Sentence::write_tokenized_text without tags (sentence.rs:850-886) -- straight from its LDS, placed by a decoupled
-// look-back over the tiles' sizes.  out_text == nullptr: off.
-struct EmitOut {
-    uint8_t* out_text;          // [capacity]
-    uint64_t* out_offsets;      // [S+1] byte range of every sentence's tokenized text in out_text
-    uint64_t capacity;
-    uint64_t* state;            // n_tiles words + the ticket, ZERO when the kernel starts (the assign kernel in front of it clears them):
-                                // flag << 62 | value -- 1: the tile's size, 2: the output position behind the tile
-    uint64_t* total_out;        // optional device-writable HOST address that receives the output's total size
-    const uint64_t* chain_in;   // optional device word: the output position in front of this launch's text (what the launch before it left
-    uint64_t* chain_out;        // in ITS chain_out: one text over several launches on one stream); optional: receives the position behind it
-    uint32_t no_prefix;         // test knob (VPT_DEBUG_EMIT_NO_PREFIX): tiles publish their sizes only, so every look-back walks to the launch's start
-};
 
 struct ScoreParams {
     PatternTableView ct;        // characters: n-grams + dictionary words
@@ -108,7 +94,6 @@ struct ScoreParams {
     uint32_t lds_pad;           // experiment knob: extra dynamic LDS per workgroup (occupancy sweeps)
     uint32_t debug;             // profiling ablation bits (VPT_DEBUG_ABLATE env, 0 in production)
     uint64_t* prof;             // per-phase shader-cycle counters (VPT_PROFILE_PHASES env), else nullptr
-    EmitOut emit;               // the fused writer (specialised kernel only)
 };
 
 // What a workgroup of the specialised kernel needs to know of its tile, made by the assign kernels (kernels_fast.hip).  The tile's
@@ -209,6 +194,10 @@ struct EmitFuse {
     uint64_t clear_n, n_blocks;
     uint32_t per_block;
     uint64_t* total_out;    // optional device-writable HOST address that receives the output's total size
+    // calls enqueued one after the other on one stream write ONE contiguous text (vpt_tokenize_batch's chunks): a device word that holds the
+    // output position in front of this call's text / receives the position behind it; nullptr: the text starts at 0
+    const uint64_t* chain_in;
+    uint64_t* chain_out;
 };
 // inclusive prefix sum over offsets[1 .. n] in place, offsets[0] = 0 (a chained scan, one launch; part: scan_part_entries(n) zero words)
 hipError_t launch_scan(uint64_t* offsets, uint64_t n, uint64_t* part, uint64_t capacity, uint32_t* status, uint64_t* total_out, hipStream_t stream);
@@ -222,9 +211,8 @@ hipError_t launch_count_boundaries(const uint8_t* text, const uint64_t* boff, ui
                                    uint32_t* max_chars, uint64_t text_bytes_hint, hipStream_t stream);
 
 size_t score_tiles_lds_bytes();
-// `emit_state` (optional): the n_tiles + 1 words of EmitOut::state, cleared here for the scoring kernel behind this launch
 hipError_t launch_assign_tiles(const uint64_t* ooff, uint64_t n_sent, int pad, uint32_t tile_flat, uint32_t n_tiles,
-                               uint32_t* tile_first, uint32_t* ctrl, hipStream_t stream, uint64_t* emit_state = nullptr);
+                               uint32_t* tile_first, uint32_t* ctrl, hipStream_t stream);
 // specialised kernel (kernels_fast.hip): packed tables (windows up to 8, BMP, i16), type rows, the type window table (row window 3) or none
 bool fast_path_supported(const ScoreParams& P);
 int fast_path_cap(const ScoreParams& P);   // flat positions per tile / workgroups per CU of the instance that scores P
@@ -236,7 +224,7 @@ hipError_t launch_score_tiles_fast(const ScoreParams& P, uint32_t n_tiles, hipSt
 struct CutGeometry { uint32_t tile_flat, halo_left, halo_right, cap_eff, mis /* text pointer & 15 */, pad /* separator slots */, cap /* the kernel's tile */; };
 void cut_index_entries(uint64_t total_chars_bound, size_t* n_local, size_t* n_super);
 hipError_t launch_assign_tiles_cut(const ScoreParams& P, const CutGeometry& G, uint32_t n_tiles, uint64_t total_chars_bound, uint32_t* cut_local,
-                                   uint64_t* cut_super, TileDesc* tiles, uint32_t* ctrl, hipStream_t stream, uint64_t* emit_state = nullptr);
+                                   uint64_t* cut_super, TileDesc* tiles, uint32_t* ctrl, hipStream_t stream);
 hipError_t launch_score_tiles(const ScoreParams& P, int chunks, uint32_t n_tiles, hipStream_t stream);
 hipError_t launch_score_slow(const ScoreParams& P, int chunks, uint32_t n_blocks, hipStream_t stream);
 

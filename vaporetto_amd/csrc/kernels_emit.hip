@@ -330,10 +330,11 @@ __global__ __launch_bounds__(kEmitThreads, kTags ? VPT_EMIT_TAG_OCC : 1) void em
     if (wave == 0) {
         constexpr uint64_t kVal = (uint64_t(1) << 62) - 1;
         if (lane == 0) __hip_atomic_store(F.state + blk, (uint64_t(1) << 62) | size, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        uint64_t base = 0;
+        const uint64_t start = (F.chain_in ? *F.chain_in : 0ull) & kVal;   // where the call's text starts (a call chained behind another: EmitFuse)
+        uint64_t base = blk == 0 ? start : 0;
         for (uint64_t p = blk; p > 0;) {
             const bool have = uint64_t(lane) < p;
-            uint64_t w = uint64_t(2) << 62;   // in front of run 0: position 0
+            uint64_t w = (uint64_t(2) << 62) | start;   // in front of run 0
             if (have) w = __hip_atomic_load(F.state + (p - 1 - uint64_t(lane)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             const uint64_t pending = __ballot((w >> 62) == 0), prefixed = __ballot((w >> 62) == 2);
             const int first = prefixed ? __ffsll((long long)prefixed) - 1 : 64;   // the nearest run whose position is known
@@ -355,6 +356,7 @@ __global__ __launch_bounds__(kEmitThreads, kTags ? VPT_EMIT_TAG_OCC : 1) void em
         P.out_offsets[P.n_sent] = end;
         if (end > P.capacity) err |= kErrOutputTooSmall;
         if (F.total_out) *F.total_out = end;
+        if (F.chain_out) *F.chain_out = end;
     }
     if (!sane) {
         if (mine) P.out_offsets[i0 + tid] = base;

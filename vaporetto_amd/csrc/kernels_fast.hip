@@ -350,42 +350,9 @@ __device__ __forceinline__ uint64_t phase_mark(uint64_t* prof, int slot, uint64_
     return now;
 }
 
-// The fused writer's decoupled look-back (one wave; `state`: EmitOut::state): publishes the tile's size, sums the sizes of the tiles
-// in front of it -- 64 words per trip, stopping at the nearest tile whose position is known -- publishes the position behind the tile
-// and returns the one in front of it (in every lane); `front`: where the launch's text starts.  Every tile with a smaller number is running or done (tickets), so the wait ends.
-__device__ __forceinline__ uint64_t emit_lookback(uint64_t* state, uint32_t tile, uint32_t size, int lane, uint64_t front, bool no_prefix = false) {
-    constexpr uint64_t kVal = (uint64_t(1) << 62) - 1;
-    if (lane == 0) __hip_atomic_store(state + tile, (uint64_t(1) << 62) | uint64_t(size), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    uint64_t base = tile == 0 ? front : 0;
-    for (uint64_t pz = tile; pz > 0;) {
-        const bool have = uint64_t(lane) < pz;
-        uint64_t w = (uint64_t(2) << 62) | (front & kVal);   // in front of tile 0: where the launch's text starts
-        if (have) w = __hip_atomic_load(state + (pz - 1 - uint64_t(lane)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const uint64_t pending = __ballot((w >> 62) == 0), prefixed = __ballot((w >> 62) == 2);
-        const int first = prefixed ? __ffsll((long long)prefixed) - 1 : 64;   // the nearest tile whose position is known
-        const uint64_t need = first < 63 ? (uint64_t(2) << first) - 1 : ~uint64_t(0);
-        if (pending & need) { __builtin_amdgcn_s_sleep(2); continue; }         // not all published yet: look again
-        uint64_t part = lane <= first ? (w & kVal) : 0;
-#pragma unroll
-        for (int d = 32; d >= 1; d >>= 1) {
-            const uint32_t plo = uint32_t(__shfl_xor(int(uint32_t(part)), d)), phi = uint32_t(__shfl_xor(int(uint32_t(part >> 32)), d));
-            part += uint64_t(plo) | (uint64_t(phi) << 32);
-        }
-        base += part;
-        if (first < 64) break;
-        pz -= 64;
-        if (pz == 0) base += front;   // 64 sizes and the launch's first tile behind them: what lies in front of it is the launch's start
-    }
-    if (lane == 0 && !no_prefix) __hip_atomic_store(state + tile, (uint64_t(2) << 62) | ((base + size) & kVal), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    return base;
-}
-
-// DBG: the diagnostics build (VPT_DEBUG_ABLATE timing ablations, VPT_PROFILE_PHASES) -- compiled out of the kernel
-// production launches use.  WL: the row window of the packed tables (layout.h); TM: where the type scores come from.
-// EMIT: the writer fused in (EmitOut) -- a fourth phase that writes the tokenized text of the tile's own chars.
 // The parameter block is read through a pointer, phase by phase (device_common.h, VPT_KARG); what phase C needs of the tile's geometry
 // waits in LDS (FastLdsT::geo) instead of in registers over the pattern phase.
-template <int WL, int TM, bool DBG, bool EMIT>
+template <int WL, int TM, bool DBG>
 __global__ __launch_bounds__(kThreads, fast_wg(WL)) void score_tiles_fast_kernel(const ScoreParams P_in) {
     using G = FastGeom<WL>;
     constexpr uint32_t kPad = G::kPadG, kDump = G::kDump;
@@ -404,27 +371,7 @@ __global__ __launch_bounds__(kThreads, fast_wg(WL)) void score_tiles_fast_kernel
     // Cut tiles come with a description (kernels.hpp, TileDesc: four scalar loads).  A whole-sentence tile is described by its
     // first sentence and its neighbour's (the general kernel's assign_tiles_kernel: the cheapest thing in front of this launch); the
     // rest follows from the offsets of the two -- a second trip of scalar loads that other tiles' work hides.
-    // With the writer fused in, a tile's number is a TICKET: every tile with a smaller number is then running or done, so the
-    // look-back over their sizes (phase D) cannot wait for one that has not started.
-    uint32_t tile = blockIdx.x;
-    if (EMIT) {
-        if (tid == 0) M.wtot[7] = uint32_t(atomicAdd(reinterpret_cast<unsigned long long*>(P->emit.state + P->n_tiles), 1ull));
-        __syncthreads();
-        tile = wave_uniform(M.wtot[7]);
-    }
-    auto publish_nothing = [&]() {   // a tile without output still has a word the later tiles look at; the last one leaves the total
-        if (!EMIT) return;
-        if (tile != P->n_tiles - 1) {
-            if (tid == 0) __hip_atomic_store(P->emit.state + tile, uint64_t(1) << 62, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        } else if (wave == 0) {
-            const uint64_t end = emit_lookback(P->emit.state, tile, 0u, lane, P->emit.chain_in ? *P->emit.chain_in : 0ull, P->emit.no_prefix != 0);
-            if (lane == 0) {
-                P->emit.out_offsets[P->n_sent] = end;
-                if (P->emit.total_out) *P->emit.total_out = end;
-                if (P->emit.chain_out) *P->emit.chain_out = end;
-            }
-        }
-    };
+    const uint32_t tile = blockIdx.x;
     uint64_t i0, byte0, g0;
     uint32_t nbytes, nsent, flat_len, own_lo, own_hi, expect_chars, strict_end;
     int32_t c_off, sib0;
@@ -433,7 +380,7 @@ __global__ __launch_bounds__(kThreads, fast_wg(WL)) void score_tiles_fast_kernel
     if (P->tiles) {
         const TileDesc* const dp = P->tiles + tile;
         nbytes = dp->nbytes;
-        if (nbytes == 0) { publish_nothing(); return; }   // an empty tile (past the batch's end; reported as not fitting)
+        if (nbytes == 0) return;   // an empty tile (past the batch's end; reported as not fitting)
         i0 = dp->i0; nsent = dp->nsent; flat_len = dp->flat_len; own_lo = dp->own_lo; own_hi = dp->own_hi;
         c_off = dp->c_off; sib0 = dp->sib0;
         byte0 = uint64_t(dp->byte0_lo) | (uint64_t(dp->byte0_hi) << 32); g0 = uint64_t(dp->g0_lo) | (uint64_t(dp->g0_hi) << 32);
@@ -441,12 +388,11 @@ __global__ __launch_bounds__(kThreads, fast_wg(WL)) void score_tiles_fast_kernel
     } else {
         i0 = P->tile_first[tile];
         const uint64_t i1 = P->tile_first[tile + 1];
-        if (i0 >= i1) { publish_nothing(); return; }      // no sentence starts in this tile's range
+        if (i0 >= i1) return;      // no sentence starts in this tile's range
         const uint64_t O0 = p_ooff[i0], O1 = p_ooff[i1], B0 = p_boff[i0], B1 = p_boff[i1];
         const uint64_t fl = uint64_t(kPad) + (O1 + i1 * (kPad + 1)) - (O0 + i0 * (kPad + 1));
         if (O1 < O0 || B1 <= B0 || fl > uint64_t(kFastCap) || B1 - B0 > uint64_t(kFastCap) * 4 + 15 || i1 - i0 > 1023) {
             if (tid == 0) atomicOr(P->status, kErrScratchTooSmall);   // a sentence longer than the caller's bound (or offsets that are no offsets)
-            publish_nothing();
             return;
         }
         nsent = uint32_t(i1 - i0); byte0 = B0; nbytes = uint32_t(B1 - B0); c_off = int32_t(kPad); sib0 = -1;
@@ -507,7 +453,6 @@ __global__ __launch_bounds__(kThreads, fast_wg(WL)) void score_tiles_fast_kernel
     __syncthreads();
     tmark = phase_mark(prof, 1, tmark);   // sentence starts
     uint32_t base_leads = 0, base_starts = 0;
-    uint32_t keep_masks = 0, keep_idx = 0;   // (fused writer) this thread's first chunk: lead | sentence-start masks, char index | sentence + 1 in front of it
     uint32_t min_lead = 0xFFu;     // over this thread's chars that are not three-byte sequences: the smallest lead byte (a NUL char is the byte 0; a
                                    // cut tile's last staged char may miss its continuation bytes, so the decoded value is not what is looked at)
     int32_t max_p = -1;            // ... and the last flat position (a char past the tile)
@@ -540,7 +485,6 @@ __global__ __launch_bounds__(kThreads, fast_wg(WL)) void score_tiles_fast_kernel
         const int32_t sib = sib0 + int32_t(base_starts + (excl >> 16));   // sentence of a char = sib + starts up to it in this chunk
         base_leads += total & 0xFFFFu;
         base_starts += total >> 16;
-        if (EMIT && c0 == 0) { keep_masks = lm | (sm << 16); keep_idx = ci | (uint32_t(sib + 1) << 16); }   // phase D numbers the same chars again
         __syncthreads();   // wtot is rewritten by the next pass
         uint32_t m = lm;
         int32_t fb = c_off + int32_t(ci) + int32_t(kPad) * sib;   // flat = c_off + char index + kPad * sentence
@@ -821,39 +765,22 @@ __global__ __launch_bounds__(kThreads, fast_wg(WL)) void score_tiles_fast_kernel
     // Its output index is (g0 - i0) + (p - c_off) - (kPad + 1) * (sentence in tile): a 32-bit offset from a scalar base.
     // (The tile's geometry comes back from LDS, the outputs' addresses from the parameter block: none of it waited in registers.)
     VPT_KARG_FENCE(P);
-    const uint64_t obase = EMIT ? g0 - i0 : (uint64_t(wave_uniform(M.geo[0])) | (uint64_t(wave_uniform(M.geo[1])) << 32));
-    const int32_t c_off_c = EMIT ? c_off : int32_t(wave_uniform(M.geo[2]));
-    const uint32_t own_lo_c = EMIT ? own_lo : wave_uniform(M.geo[3]), own_hi_c = EMIT ? own_hi : wave_uniform(M.geo[4]);
+    const uint64_t obase = uint64_t(wave_uniform(M.geo[0])) | (uint64_t(wave_uniform(M.geo[1])) << 32);
+    const int32_t c_off_c = int32_t(wave_uniform(M.geo[2]));
+    const uint32_t own_lo_c = wave_uniform(M.geo[3]), own_hi_c = wave_uniform(M.geo[4]);
     const uint64_t total_b = P->total_chars - P->n_sent;         // boundaries of the call (or the caller's upper bound of them)
     const uint32_t o_lim = obase >= total_b ? 0u : (total_b - obase > 0xFFFFFFFFull ? 0xFFFFFFFFu : uint32_t(total_b - obase));
     int32_t* const sc = P->scores ? P->scores + obase : nullptr;
     uint8_t* const lb = P->labels ? P->labels + obase : nullptr;
     const int32_t bias = P->bias;
     const uint32_t post = P->post;
-    // the fused writer's scratch behind what phase C still reads of the union (the type codes of the window-table modes; the type rows
-    // are dead): a label byte per flat position, the sentence-start bitmap of the tile's text, a few words
-    constexpr uint32_t kEmitOff = (TM >= 1 && TM <= 3) ? uint32_t((kSymSlots + 15) & ~15) : 0u;
-    uint8_t* const labb = reinterpret_cast<uint8_t*>(M.typ) + kEmitOff;
-    uint4 etx[2];   // ... whose text is asked for again now (the L2 has it) and arrives while the boundaries are written
-    if (EMIT) {
-#pragma unroll
-        for (int r = 0; r < 2; ++r) {
-            const uint32_t c = uint32_t(tid) + uint32_t(r) * kThreads;
-            etx[r] = c < nchunks ? reinterpret_cast<const uint4*>(a0)[c] : make_uint4(0, 0, 0, 0);
-        }
-        if (uint32_t(tid) < kPad) labb[tid] = 0;
-    }
 #pragma unroll
     for (int k = 0; k < kPerThread; ++k) {
         const uint32_t p = kPad + uint32_t(tid) + uint32_t(k) * kThreads;   // p + 1 < kSymSlots; zero past the tile
-        if (wbase + uint32_t(k) * kThreads + kPad + 1 >= flat_len) {        // wave-uniform
-            if (!EMIT) break;
-            labb[p] = 0;
-            continue;
-        }
+        if (wbase + uint32_t(k) * kThreads + kPad + 1 >= flat_len) break;   // wave-uniform
         const uint32_t x = L.sym[p], x2 = L.sym[p + 1];
         int32_t y = bias + L.score[p];
-        if ((x & kCpMask) == 0 || (x2 & kCpMask) == 0 || p < own_lo_c || p >= own_hi_c) { if (EMIT) labb[p] = 0; continue; }
+        if ((x & kCpMask) == 0 || (x2 & kCpMask) == 0 || p < own_lo_c || p >= own_hi_c) continue;
         if (TM >= 1 && TM <= 3) {
             uint32_t id = 0;  // window t[b-W+1 .. b+W], 3 bits each (boundary_scorer_cache.rs:59-81)
 #pragma unroll
@@ -861,227 +788,22 @@ __global__ __launch_bounds__(kThreads, fast_wg(WL)) void score_tiles_fast_kernel
             y += P->type_table[id];
         }
         const uint32_t o = uint32_t(int32_t(p) - c_off_c) - (kPad + 1) * ((x >> 19) & 1023u);
-        if (o >= o_lim) { err |= kErrBadOffsets; if (EMIT) labb[p] = 0; continue; }  // only with offsets that do not match the text
+        if (o >= o_lim) { err |= kErrBadOffsets; continue; }  // only with offsets that do not match the text
         if (sc) sc[o] = y;
         uint32_t label = y > 0 ? 1u : 0u;
-        if (lb || EMIT) {
+        if (lb) {
             if (post) {   // wave-uniform: KyteaWsConstFilter / SplitLinebreaksFilter on the label
                 const uint32_t t1 = (x >> 16) & 7u, t2 = (x2 >> 16) & 7u;
                 if (t1 == t2 && ((post >> t1) & 1u) && t1 != 0 && t1 != 7) label = 0;
                 if ((post & 0x80u) && ((x | x2) & kSymLinebreak)) label = 1;
             }
-            if (lb) lb[o] = uint8_t(label);
-            if (EMIT) labb[p] = uint8_t(label);
+            lb[o] = uint8_t(label);
         }
     }
     tmark = phase_mark(prof, 6, tmark);           // boundaries out
 
-    // ---------------------------------------------------------------- D. tokenized text (the fused writer)
-    // Sentence::write_tokenized_text without tags (sentence.rs:850-886) for the chars the tile OWNS (flat positions [own_lo, own_hi)):
-    // every byte of theirs, a '\' in front of ' ', '\' and '/', and a ' ' behind a char whose boundary is a WordBoundary -- that is,
-    // in front of the lead byte of the char at p + 1 for an own boundary p, so that a tile's output depends on nothing another tile
-    // computes.  The output of the batch is the tiles' outputs one after the other; a sentence's offset is the output position of its
-    // first byte.  Worked in BYTE space like phase A: every thread holds its 16 bytes of the text again (asked for before phase C) and the
-    // numbers phase A's chunk scan gave them, turns them into at most 48 bytes, and a block-wide prefix sum places them; the bytes
-    // are assembled in LDS (the score array and the queues: dead) while wave 0 looks back over the earlier tiles' sizes for the
-    // tile's position, and leave as aligned 16-byte stores.
-    if (EMIT) {
-        uint32_t* const raw2 = reinterpret_cast<uint32_t*>(&L.sym[0]);
-        uint32_t* const bm2 = reinterpret_cast<uint32_t*>(labb + ((kSymSlots + 15) & ~15));
-        constexpr uint32_t kBm2Words = (uint32_t(kFastCap) * 4 + 31 + 31) / 32 + 2;
-        uint32_t* const ew = bm2 + kBm2Words;          // [0] first own byte, [1] first byte behind the own chars, [2..3] the tile's position, [4..7] wave totals
-        uint8_t* const outb = reinterpret_cast<uint8_t*>(&L.score[0]);   // score + queue + mqueue: contiguous
-        constexpr uint32_t kOutCap = uint32_t(sizeof(int32_t) * kSymSlots + sizeof(uint2) * kWavesF * kQCap + sizeof(uint32_t) * kWavesF * kMCap);
-        static_assert(kOutCap >= 5u * uint32_t(kFastCap) + 64u, "a tile's tokenized text: at most 4 bytes + a space (or 1 + '\\' + a space) per char");
-        static_assert(offsetof(FastLdsT<WL>, queue) == offsetof(FastLdsT<WL>, score) + sizeof(int32_t) * kSymSlots &&
-                      offsetof(FastLdsT<WL>, mqueue) == offsetof(FastLdsT<WL>, queue) + sizeof(uint2) * kWavesF * kQCap, "the assembly area is one piece");
-        __syncthreads();   // the symbols and scores have been read, the labels written
-        const bool one_round = nchunks <= uint32_t(kThreads);   // (block-uniform) the usual tile: a chunk per thread at most, its scan kept from phase A
-        if (tid == 0) { ew[0] = 0xFFFFFFFFu; ew[1] = 0xFFFFFFFFu; }
-        if (!one_round) {   // (more than 4 KB of text: 1- and 2-byte chars) the text is staged again, the sentence starts marked again
-#pragma unroll
-            for (int r = 0; r < 2; ++r) {
-                const uint32_t c = uint32_t(tid) + uint32_t(r) * kThreads;
-                if (c < nchunks) reinterpret_cast<uint4*>(raw2)[c] = etx[r];
-            }
-            for (uint32_t i = tid; i < ((nbytes_al + 31) >> 5) + 1; i += kThreads) bm2[i] = 0;
-            if (tid == 0) raw2[nchunks * 4] = 0;
-            __syncthreads();
-            for (uint32_t j = tid; j < nsent; j += kThreads) {
-                const uint64_t b = P->boff[i0 + j];
-                if (b >= byte0 && b - byte0 < nbytes) {
-                    const uint32_t pos = head + uint32_t(b - byte0);
-                    atomicOr(&bm2[pos >> 5], 1u << (pos & 31));
-                }
-            }
-        }
-        __syncthreads();
-        // ---- pass 1: per chunk the masks of its bytes; where the own chars' bytes begin and end
-        uint32_t e_sm[2], e_em[2], e_sp[2], e_so[2], e_sib[2], e_vm[2];
-        {
-            uint32_t bl = 0, bs = 0, lo_pos = 0xFFFFFFFFu, hi_pos = 0xFFFFFFFFu;
-#pragma unroll
-            for (int r = 0; r < 2; ++r) {
-                const uint32_t c = uint32_t(tid) + uint32_t(r) * kThreads;
-                e_sm[r] = e_em[r] = e_sp[r] = e_so[r] = e_sib[r] = e_vm[r] = 0;
-                if (uint32_t(r) * kThreads >= nchunks) continue;   // (block-uniform)
-                const uint32_t pos0 = c < nchunks ? c * 16 : 0u;
-                uint32_t lm = 0, sm = 0, em = 0, vm = 0;
-                if (c < nchunks) {
-                    const uint4 v = etx[r];
-                    const uint32_t lo = pos0 < head ? head - pos0 : 0u;
-                    const uint32_t rem = nbytes_al - pos0;
-                    const uint32_t hi = rem < 16 ? rem : 16u;
-                    vm = ((1u << hi) - 1u) & ~((1u << lo) - 1u);
-                    em = (esc_nibble(v.x) | (esc_nibble(v.y) << 4) | (esc_nibble(v.z) << 8) | (esc_nibble(v.w) << 12)) & vm;
-                    if (one_round) { lm = keep_masks & 0xFFFFu; sm = (keep_masks >> 16) & lm; }
-                    else {
-                        lm = lead_mask16(v) & vm;
-                        sm = (bm2[pos0 >> 5] >> (pos0 & 31)) & 0xFFFFu & lm;
-                    }
-                }
-                uint32_t ci;
-                int32_t sib;
-                if (one_round) { ci = keep_idx & 0xFFFFu; sib = int32_t(keep_idx >> 16) - 1; }
-                else {
-                    const uint32_t mine = __popc(lm) | (__popc(sm) << 16);
-                    const uint32_t incl = wave_inclusive_scan(mine);
-                    if (lane == 63) ew[4 + wave] = incl;
-                    __syncthreads();
-                    uint32_t woff = 0, total = 0;
-#pragma unroll
-                    for (int k = 0; k < kWavesF; ++k) {
-                        const uint32_t u = wave_uniform(ew[4 + k]);
-                        if (k < wave) woff += u;
-                        total += u;
-                    }
-                    const uint32_t excl = woff + incl - mine;
-                    ci = bl + (excl & 0xFFFFu);
-                    sib = sib0 + int32_t(bs + (excl >> 16));
-                    bl += total & 0xFFFFu;
-                    bs += total >> 16;
-                    __syncthreads();   // the wave totals are rewritten by the next round
-                }
-                int32_t fb = c_off + int32_t(ci) + int32_t(kPad) * sib;
-                uint32_t m = lm, spm = 0, som = 0;
-                while (m != 0) {
-                    const uint32_t k = uint32_t(__builtin_ctz(m));
-                    m &= m - 1;
-                    const uint32_t rr = uint32_t(__popc(sm & ((2u << k) - 1u)));
-                    const int32_t p = fb + int32_t(kPad) * int32_t(rr);
-                    ++fb;
-                    const bool starts = ((sm >> k) & 1u) != 0;
-                    // a ' ' goes in front of this char when the boundary in front of it is the tile's own and a WordBoundary
-                    if (p > int32_t(own_lo) && p <= int32_t(own_hi) && !starts && labb[p - 1] != 0) spm |= 1u << k;
-                    if (p >= int32_t(own_lo) && p < int32_t(own_hi) && starts) som |= 1u << k;   // an own sentence starts here
-                    if (p >= int32_t(own_lo)) lo_pos = lo_pos < pos0 + k ? lo_pos : pos0 + k;
-                    if (p >= int32_t(own_hi)) hi_pos = hi_pos < pos0 + k ? hi_pos : pos0 + k;
-                }
-                e_sm[r] = sm; e_em[r] = em; e_sp[r] = spm; e_so[r] = som; e_sib[r] = uint32_t(sib); e_vm[r] = vm;
-            }
-            if (lo_pos != 0xFFFFFFFFu) atomicMin(&ew[0], lo_pos);
-            if (hi_pos != 0xFFFFFFFFu) atomicMin(&ew[1], hi_pos);
-        }
-        __syncthreads();
-        const uint32_t byte_hi = ew[1] < nbytes_al ? ew[1] : nbytes_al;
-        const uint32_t byte_lo = ew[0] < byte_hi ? ew[0] : byte_hi;
-        // ---- pass 2: what every chunk writes, placed by a block-wide prefix sum
-        uint32_t e_w[2], run = 0;
-#pragma unroll
-        for (int r = 0; r < 2; ++r) {
-            e_w[r] = 0;
-            if (uint32_t(r) * kThreads >= nchunks) continue;   // (block-uniform)
-            const uint32_t pos0 = (uint32_t(tid) + uint32_t(r) * kThreads) * 16u;
-            const uint32_t a = byte_lo > pos0 ? (byte_lo - pos0 < 16 ? byte_lo - pos0 : 16u) : 0u;
-            const uint32_t bnd = byte_hi > pos0 ? (byte_hi - pos0 < 16 ? byte_hi - pos0 : 16u) : 0u;
-            const uint32_t om = bnd > a ? (((1u << bnd) - 1u) & ~((1u << a) - 1u)) : 0u;   // the chunk's bytes of own chars
-            e_vm[r] &= om;
-            e_em[r] &= om;
-            const uint32_t t = uint32_t(__popc(e_vm[r])) + uint32_t(__popc(e_em[r])) + uint32_t(__popc(e_sp[r]));
-            const uint32_t incl = wave_inclusive_scan(t);
-            if (lane == 63) ew[4 + wave] = incl;
-            __syncthreads();
-            uint32_t woff = 0, total = 0;
-#pragma unroll
-            for (int k = 0; k < kWavesF; ++k) {
-                const uint32_t u = wave_uniform(ew[4 + k]);
-                if (k < wave) woff += u;
-                total += u;
-            }
-            e_w[r] = run + woff + incl - t;
-            run += total;
-            __syncthreads();
-        }
-        const uint32_t size = run;   // (the same in every thread)
-        // ---- the tile's position: wave 0 publishes the size and looks back over the earlier tiles' words, 64 per trip
-        if (wave == 0) {
-            const uint64_t base = emit_lookback(P->emit.state, tile, size, lane, P->emit.chain_in ? *P->emit.chain_in : 0ull, P->emit.no_prefix != 0);
-            if (lane == 0) { ew[2] = uint32_t(base); ew[3] = uint32_t(base >> 32); }
-        }
-        // ---- assembly (every wave; needs no position): [' '] ['\\'] byte for the chunk's bytes, in order
-#pragma unroll
-        for (int r = 0; r < 2; ++r) {
-            if (uint32_t(r) * kThreads >= nchunks) continue;   // (block-uniform)
-            const uint32_t c = uint32_t(tid) + uint32_t(r) * kThreads;
-            if (c >= nchunks) continue;
-            const uint4 v = etx[r];
-            const uint32_t vm = e_vm[r], spm = e_sp[r], em = e_em[r];
-            uint32_t pos = e_w[r];
-            if ((vm | spm) == 0) continue;
-#pragma unroll
-            for (uint32_t k = 0; k < 16; ++k) {
-                const uint32_t d = k < 4 ? v.x : k < 8 ? v.y : k < 12 ? v.z : v.w;
-                if ((spm >> k) & 1u) outb[pos++] = 0x20u;
-                if ((em >> k) & 1u) outb[pos++] = 0x5Cu;
-                if ((vm >> k) & 1u) outb[pos++] = uint8_t((d >> (8 * (k & 3u))) & 0xFFu);
-            }
-        }
-        __syncthreads();
-        const uint64_t base = uint64_t(ew[2]) | (uint64_t(ew[3]) << 32);
-        const uint64_t end = base + size;
-        const bool store_ok = end <= P->emit.capacity;
-        if (!store_ok) err |= kErrOutputTooSmall;
-        if (tile == P->n_tiles - 1 && tid == 0) {
-            P->emit.out_offsets[P->n_sent] = end;
-            if (P->emit.total_out) *P->emit.total_out = end;
-            if (P->emit.chain_out) *P->emit.chain_out = end;
-        }
-        // ---- the own sentences' offsets: the output position of their first byte (its ' ' never exists, its '\' belongs to it)
-#pragma unroll
-        for (int r = 0; r < 2; ++r) {
-            uint32_t rem = e_so[r];
-            while (rem) {
-                const uint32_t k = uint32_t(__builtin_ctz(rem)), below = (1u << k) - 1u;
-                rem &= rem - 1u;
-                const uint32_t s_in_tile = e_sib[r] + uint32_t(__popc(e_sm[r] & ((2u << k) - 1u)));   // the sentence this lead starts
-                const uint64_t at = base + e_w[r] + uint32_t(__popc(e_vm[r] & below)) + uint32_t(__popc(e_em[r] & below)) + uint32_t(__popc(e_sp[r] & below));
-                if (s_in_tile < nsent) P->emit.out_offsets[i0 + s_in_tile] = at;
-                else err |= kErrBadOffsets;
-            }
-        }
-        // ---- out: LDS byte j is output byte base + j; whole 16-byte chunks leave aligned (an LDS funnel shift), the two edges byte by byte
-        if (store_ok && size != 0) {
-            uint8_t* const dst = P->emit.out_text + base;
-            const uint32_t hd = uint32_t(reinterpret_cast<uintptr_t>(dst) & 15u);   // dst - hd is aligned
-            const uint32_t nd = (hd + size + 15u) >> 4;
-            const uint32_t* const ow = reinterpret_cast<const uint32_t*>(outb);
-            for (uint32_t d = uint32_t(tid); d < nd; d += kThreads) {
-                const uint32_t lo = d * 16u, hi = lo + 16u;             // output bytes [lo, hi) relative to dst - hd = LDS bytes [lo - hd, hi - hd)
-                if (lo >= hd && hi <= hd + size) {
-                    const uint32_t j = lo - hd, q = j >> 2, sh = j & 3u;
-                    uint4 o4;
-                    o4.x = __builtin_amdgcn_alignbyte(ow[q + 1], ow[q], sh); o4.y = __builtin_amdgcn_alignbyte(ow[q + 2], ow[q + 1], sh);
-                    o4.z = __builtin_amdgcn_alignbyte(ow[q + 3], ow[q + 2], sh); o4.w = __builtin_amdgcn_alignbyte(ow[q + 4], ow[q + 3], sh);
-                    *reinterpret_cast<uint4*>(dst - hd + lo) = o4;
-                } else {
-                    const uint32_t a = lo > hd ? lo : hd, bnd = hi < hd + size ? hi : hd + size;
-                    for (uint32_t j = a; j < bnd; ++j) (dst - hd)[j] = outb[j - hd];
-                }
-            }
-        }
-    }
     if (err) atomicOr(P->status, err);
-    phase_mark(prof, 7, tmark);           // (with the fused writer: tokenized text out)
+    phase_mark(prof, 7, tmark);
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -1195,10 +917,9 @@ __device__ __forceinline__ uint64_t last_block_le(const CutIndex& X, uint64_t lo
 __global__ __launch_bounds__(256) void assign_tiles_cut_kernel(const uint64_t* __restrict__ boff, const uint64_t* __restrict__ ooff, uint64_t n_sent,
                                                                CutGeometry Gm, uint32_t n_tiles, const uint32_t* __restrict__ cut_local,
                                                                const uint64_t* __restrict__ cut_super, uint64_t n_super_max, TileDesc* __restrict__ tiles,
-                                                               uint32_t* __restrict__ ctrl, uint64_t* __restrict__ emit_state) {
+                                                               uint32_t* __restrict__ ctrl) {
     const uint32_t t = blockIdx.x * 256u + threadIdx.x;
     if (t == 1) ctrl[1] = 0;
-    if (emit_state && t <= n_tiles) emit_state[t] = 0;   // the fused writer's words (one per tile + the ticket); the grid covers n_tiles + 1 threads
     if (t >= n_tiles) return;
     TileDesc d{};
     const uint64_t kPad = Gm.pad;
@@ -1286,40 +1007,31 @@ int fast_path_cap(const ScoreParams& P) { return fast_cap(int(P.pk.wl)); }
 int fast_path_wg(const ScoreParams& P) { return fast_wg(int(P.pk.wl)); }
 
 template <int WL>
-static size_t lds_bytes_for(int tm, uint32_t trow_mode, bool emit) {
+static size_t lds_bytes_for(int tm, uint32_t trow_mode) {
     using T = FastLdsT<WL>;
     constexpr size_t kSlots16 = size_t((FastGeom<WL>::kSymSlots + 15) & ~15);
-    // the fused writer's scratch (phase D): label bytes, the sentence-start bitmap, eight words -- behind the type codes, over the type rows
-    const size_t emit_bytes = emit ? kSlots16 + 4 * ((size_t(FastGeom<WL>::kCapG) * 4 + 31 + 31) / 32 + 2) + 32 : 0;
-    if (tm == kTypeRows) return offsetof(T, typ) + std::max(trow_mode == kTypeRowsLds ? sizeof(uint4) * kTrowCount * FastGeom<WL>::kTrowQ : size_t(16), emit_bytes);
-    return offsetof(T, typ) + (tm == 0 ? std::max(size_t(16), emit_bytes) : kSlots16 + emit_bytes);
+    if (tm == kTypeRows) return offsetof(T, typ) + (trow_mode == kTypeRowsLds ? sizeof(uint4) * kTrowCount * FastGeom<WL>::kTrowQ : size_t(16));
+    return offsetof(T, typ) + (tm == 0 ? size_t(16) : kSlots16);
 }
 size_t score_tiles_fast_lds_bytes(const ScoreParams& P) {
     int wl = 3, tm = 0;
     if (!fast_instance(P, &wl, &tm)) return 0;
-    const bool emit = P.emit.out_text != nullptr;
     switch (wl) {
-        case 3: return lds_bytes_for<3>(tm, P.pk.trow_mode, emit);
-        case 4: return lds_bytes_for<4>(tm, P.pk.trow_mode, emit);
-        case 5: return lds_bytes_for<5>(tm, P.pk.trow_mode, emit);
-        case 6: return lds_bytes_for<6>(tm, P.pk.trow_mode, emit);
-        case 7: return lds_bytes_for<7>(tm, P.pk.trow_mode, emit);
-        default: return lds_bytes_for<8>(tm, P.pk.trow_mode, emit);
+        case 3: return lds_bytes_for<3>(tm, P.pk.trow_mode);
+        case 4: return lds_bytes_for<4>(tm, P.pk.trow_mode);
+        case 5: return lds_bytes_for<5>(tm, P.pk.trow_mode);
+        case 6: return lds_bytes_for<6>(tm, P.pk.trow_mode);
+        case 7: return lds_bytes_for<7>(tm, P.pk.trow_mode);
+        default: return lds_bytes_for<8>(tm, P.pk.trow_mode);
     }
 }
 
-// The instances: row window 3 with every type source, the diagnostics build and the fused writer; the wider windows with type rows or
-// none, with and without the writer.
+// The instances: row window 3 with every type source and the diagnostics build; the wider windows with type rows or none.
 template <int WL>
-static hipError_t launch_wide(const ScoreParams& P, int tm, bool emit, uint32_t n_tiles, size_t lds, hipStream_t stream) {
+static hipError_t launch_wide(const ScoreParams& P, int tm, uint32_t n_tiles, size_t lds, hipStream_t stream) {
     if (tm != kTypeRows && tm != 0) return hipErrorInvalidValue;
-    if (tm == kTypeRows) {
-        if (emit) hipLaunchKernelGGL((score_tiles_fast_kernel<WL, kTypeRows, false, true>), dim3(n_tiles), dim3(kThreads), lds, stream, P);
-        else hipLaunchKernelGGL((score_tiles_fast_kernel<WL, kTypeRows, false, false>), dim3(n_tiles), dim3(kThreads), lds, stream, P);
-    } else {
-        if (emit) hipLaunchKernelGGL((score_tiles_fast_kernel<WL, 0, false, true>), dim3(n_tiles), dim3(kThreads), lds, stream, P);
-        else hipLaunchKernelGGL((score_tiles_fast_kernel<WL, 0, false, false>), dim3(n_tiles), dim3(kThreads), lds, stream, P);
-    }
+    if (tm == kTypeRows) hipLaunchKernelGGL((score_tiles_fast_kernel<WL, kTypeRows, false>), dim3(n_tiles), dim3(kThreads), lds, stream, P);
+    else hipLaunchKernelGGL((score_tiles_fast_kernel<WL, 0, false>), dim3(n_tiles), dim3(kThreads), lds, stream, P);
     return hipGetLastError();
 }
 
@@ -1327,20 +1039,18 @@ hipError_t launch_score_tiles_fast(const ScoreParams& P, uint32_t n_tiles, hipSt
     int wl = 3, tm = 0;
     if (!fast_instance(P, &wl, &tm)) return hipErrorInvalidValue;
     const size_t lds = score_tiles_fast_lds_bytes(P) + P.lds_pad;  // (the pad: occupancy experiments)
-    const bool emit = P.emit.out_text != nullptr;
-    const bool dbg = !emit && (P.debug != 0 || P.prof != nullptr);
+    const bool dbg = P.debug != 0 || P.prof != nullptr;
     switch (wl) {
-        case 4: return launch_wide<4>(P, tm, emit, n_tiles, lds, stream);
-        case 5: return launch_wide<5>(P, tm, emit, n_tiles, lds, stream);
-        case 6: return launch_wide<6>(P, tm, emit, n_tiles, lds, stream);
-        case 7: return launch_wide<7>(P, tm, emit, n_tiles, lds, stream);
-        case 8: return launch_wide<8>(P, tm, emit, n_tiles, lds, stream);
+        case 4: return launch_wide<4>(P, tm, n_tiles, lds, stream);
+        case 5: return launch_wide<5>(P, tm, n_tiles, lds, stream);
+        case 6: return launch_wide<6>(P, tm, n_tiles, lds, stream);
+        case 7: return launch_wide<7>(P, tm, n_tiles, lds, stream);
+        case 8: return launch_wide<8>(P, tm, n_tiles, lds, stream);
         default: break;
     }
 #define VPT_LAUNCH_FAST(TM_)                                                                                                                  \
-    if (emit) hipLaunchKernelGGL((score_tiles_fast_kernel<3, TM_, false, true>), dim3(n_tiles), dim3(kThreads), lds, stream, P);           \
-    else if (dbg) hipLaunchKernelGGL((score_tiles_fast_kernel<3, TM_, true, false>), dim3(n_tiles), dim3(kThreads), lds, stream, P);        \
-    else hipLaunchKernelGGL((score_tiles_fast_kernel<3, TM_, false, false>), dim3(n_tiles), dim3(kThreads), lds, stream, P);                \
+    if (dbg) hipLaunchKernelGGL((score_tiles_fast_kernel<3, TM_, true>), dim3(n_tiles), dim3(kThreads), lds, stream, P);                      \
+    else hipLaunchKernelGGL((score_tiles_fast_kernel<3, TM_, false>), dim3(n_tiles), dim3(kThreads), lds, stream, P);                         \
     break;
     switch (tm) {
         case 0: VPT_LAUNCH_FAST(0)
@@ -1362,14 +1072,14 @@ void cut_index_entries(uint64_t total_chars_bound, size_t* n_local, size_t* n_su
 }
 
 hipError_t launch_assign_tiles_cut(const ScoreParams& P, const CutGeometry& G, uint32_t n_tiles, uint64_t total_chars_bound, uint32_t* cut_local,
-                                   uint64_t* cut_super, TileDesc* tiles, uint32_t* ctrl, hipStream_t stream, uint64_t* emit_state) {
+                                   uint64_t* cut_super, TileDesc* tiles, uint32_t* ctrl, hipStream_t stream) {
     size_t n_local = 0, n_super = 0;
     cut_index_entries(total_chars_bound, &n_local, &n_super);
     const uint64_t supers = uint64_t(n_super - 1);
     hipLaunchKernelGGL(cut_count_kernel, dim3(uint32_t(supers)), dim3(256), 0, stream, P.text, G.mis, P.boff, P.n_sent, cut_local, cut_super);
     hipLaunchKernelGGL(cut_scan_kernel, dim3(1), dim3(256), 0, stream, G.mis, P.boff, P.n_sent, cut_super, supers);
     hipLaunchKernelGGL(assign_tiles_cut_kernel, dim3((n_tiles + 1 + 255) / 256), dim3(256), 0, stream, P.boff, P.ooff, P.n_sent, G, n_tiles, cut_local, cut_super,
-                       supers, tiles, ctrl, emit_state);
+                       supers, tiles, ctrl);
     return hipGetLastError();
 }
 
