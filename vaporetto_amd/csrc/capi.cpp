@@ -41,7 +41,6 @@ vpt_status fail(vpt_status st, const std::string& msg) {
 // path: getenv is not thread-safe against setenv, and a drop-in library must not change behaviour under a running host.
 struct PredictorKnobs {
     bool force_window_table = false;    // VPT_FORCE_WINDOW_TABLE: the 8^(2W) type table instead of the type rows
-    uint32_t lds_pad = 0;               // VPT_DEBUG_LDS_PAD: occupancy experiments
     int pipe_lanes = -1;                // VPT_PIPE_LANES (-1: the size rule)
     uint64_t chunk_chars = 0;           // VPT_CHUNK_CHARS (0: the size rule)
     uint64_t tokenize_chunk_bytes = uint64_t(256) << 20;   // VPT_TOKENIZE_CHUNK_BYTES (the tagged pipeline's default; the fused one: an eighth of the batch, at least 4 MB)
@@ -51,16 +50,13 @@ struct BatchKnobs {
     bool force_generic = false;         // VPT_FORCE_GENERIC
     int force_cut = 0;                  // VPT_FORCE_CUT_TILES: 1 = cut tiles for every batch, -1 = whole-sentence tiles whenever they fit (tests, A/B)
     uint32_t tile_flat = 0;             // VPT_TILE_FLAT: flat positions per tile (tests: cuts at many places; never above what fits)
-    bool no_cps_from_predict = false;   // VPT_NO_CPS_FROM_PREDICT
     uint32_t debug_ablate = 0;          // VPT_DEBUG_ABLATE
     bool profile_phases = false;        // VPT_PROFILE_PHASES
     uint32_t emit_per_block = 0;        // VPT_EMIT_PER_BLOCK: sentences a workgroup of the writer takes (1..256; 0: from the mean sentence length) -- tests: runs of any size
-    uint32_t emit_run_chars = 0;        // VPT_EMIT_RUN_CHARS: chars of a workgroup's run (default 5120)
 };
 PredictorKnobs read_predictor_knobs() {
     PredictorKnobs k;
     k.force_window_table = std::getenv("VPT_FORCE_WINDOW_TABLE") != nullptr;
-    if (const char* v = std::getenv("VPT_DEBUG_LDS_PAD")) k.lds_pad = uint32_t(std::max(0, std::atoi(v)));
     if (const char* v = std::getenv("VPT_PIPE_LANES")) k.pipe_lanes = std::max(0, std::atoi(v));
     if (const char* v = std::getenv("VPT_CHUNK_CHARS")) { const long long n = std::atoll(v); if (n > 0) k.chunk_chars = uint64_t(n); }
     if (const char* v = std::getenv("VPT_TOKENIZE_CHUNK_BYTES")) { const long long n = std::atoll(v); if (n > 0) { k.tokenize_chunk_bytes = uint64_t(n); k.tokenize_chunk_bytes_set = true; } }
@@ -72,8 +68,6 @@ BatchKnobs read_batch_knobs() {
     if (const char* v = std::getenv("VPT_FORCE_CUT_TILES")) k.force_cut = std::atoi(v);
     if (const char* v = std::getenv("VPT_TILE_FLAT")) k.tile_flat = uint32_t(std::max(0, std::atoi(v)));
     if (const char* v = std::getenv("VPT_EMIT_PER_BLOCK")) k.emit_per_block = uint32_t(std::min(256, std::max(0, std::atoi(v))));
-    if (const char* v = std::getenv("VPT_EMIT_RUN_CHARS")) k.emit_run_chars = uint32_t(std::max(0, std::atoi(v)));
-    k.no_cps_from_predict = std::getenv("VPT_NO_CPS_FROM_PREDICT") != nullptr;
     if (const char* v = std::getenv("VPT_DEBUG_ABLATE")) k.debug_ablate = uint32_t(std::atoi(v));
     k.profile_phases = std::getenv("VPT_PROFILE_PHASES") != nullptr;
     return k;
@@ -602,7 +596,6 @@ void bind_predictor(vpt_predictor* p) {
         probe.type_window = p->type_window; probe.force_window_table = p->knobs.force_window_table ? 1u : 0u;
         const bool fast = vpt::fast_path_supported(probe);
         auto slots_for = [&](size_t lds, size_t built_for) {
-            lds += p->knobs.lds_pad;   // occupancy experiments (kernels_fast.hip)
             const size_t granules = (lds + 1279) / 1280;   // gfx950 hands out its 160 KB of LDS in 1280-byte granules
             return uint32_t(prop.multiProcessorCount) * uint32_t(std::min<size_t>(built_for, std::max<size_t>(1, 128 / std::max<size_t>(granules, 1))));
         };
@@ -1028,7 +1021,7 @@ vpt_status predict_device_impl(const vpt_predictor* p, vpt_batch* b, const uint8
     P.cid = p->d_cid ? p->d_cid + ((b->flags & VPT_FLAG_KYTEA_FULLWIDTH) ? 65536 : 0) : nullptr;
     P.post = b->flags & 0xFEu;
     P.type_window = p->type_window; P.type_kind = p->type_kind; P.bias = p->bias; P.pad = p->pad;
-    P.force_window_table = p->knobs.force_window_table ? 1u : 0u; P.lds_pad = p->knobs.lds_pad;
+    P.force_window_table = p->knobs.force_window_table ? 1u : 0u;
     // flat positions of the longest sentence: its chars, bounded by the caller's hint or else by its bytes
     const uint64_t max_chars = (b->max_chars && b->max_chars < max_sentence_bytes) ? b->max_chars : max_sentence_bytes;
     const uint64_t total_flat = total_boundaries + uint64_t(n_sentences) * uint64_t(1 + p->pad);
@@ -1133,7 +1126,7 @@ vpt_status predict_device_impl(const vpt_predictor* p, vpt_batch* b, const uint8
     // call for the same buffers on this workspace (Sentence::fill_tags follows Predictor::predict on the same sentence,
     // predictor.rs:542) skips its own decode pass.
     b->cps_text = nullptr;
-    if (p->has_tags && p->predict_tags && fast && !b->knobs.no_cps_from_predict) {
+    if (p->has_tags && p->predict_tags && fast) {
         vpt_status st2 = grow(&b->d_cps, &b->cps_cap, size_t(total_chars) + 16);
         if (st2 != VPT_OK) return st2;
         P.cps_out = b->d_cps;
@@ -1614,7 +1607,7 @@ vpt_status emit_device(const vpt_predictor* p, vpt_batch* b, const uint8_t* d_ut
     {
         const uint64_t chars = total_boundaries + n_sentences;
         const uint64_t auto_run = std::min<uint64_t>(std::max<uint64_t>(chars / (uint64_t(16) * std::max<uint32_t>(p->n_cus, 64)), 5120), 20480);
-        const uint64_t target = b->knobs.emit_run_chars ? b->knobs.emit_run_chars : auto_run;
+        const uint64_t target = auto_run;
         uint64_t per = std::min<uint64_t>(std::max<uint64_t>((target * n_sentences + chars / 2) / chars, 1), vpt::kEmitFlatMaxBlock);   // round(target / mean chars per sentence)
         if (E.records && E.run_sent <= vpt::kEmitFlatMaxBlock)
             per = std::min<uint64_t>(std::max<uint64_t>((per + E.run_sent / 2) / E.run_sent, 1) * E.run_sent, (vpt::kEmitFlatMaxBlock / E.run_sent) * E.run_sent);

@@ -91,7 +91,6 @@ struct ScoreParams {
     uint64_t total_chars;       // what cps_out holds: total boundaries + sentences of the call
     uint32_t post;              // label post-filters: bits 1..6 KyteaWsConstFilter per CharacterType, bit 7 SplitLinebreaksFilter
     uint32_t force_window_table;// experiment knob (read when the predictor is made): the 8^(2W) type table although type rows exist
-    uint32_t lds_pad;           // experiment knob: extra dynamic LDS per workgroup (occupancy sweeps)
     uint32_t debug;             // profiling ablation bits (VPT_DEBUG_ABLATE env, 0 in production)
     uint64_t* prof;             // per-phase shader-cycle counters (VPT_PROFILE_PHASES env), else nullptr
 };

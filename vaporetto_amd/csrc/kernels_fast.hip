@@ -1038,7 +1038,7 @@ static hipError_t launch_wide(const ScoreParams& P, int tm, uint32_t n_tiles, si
 hipError_t launch_score_tiles_fast(const ScoreParams& P, uint32_t n_tiles, hipStream_t stream) {
     int wl = 3, tm = 0;
     if (!fast_instance(P, &wl, &tm)) return hipErrorInvalidValue;
-    const size_t lds = score_tiles_fast_lds_bytes(P) + P.lds_pad;  // (the pad: occupancy experiments)
+    const size_t lds = score_tiles_fast_lds_bytes(P);
     const bool dbg = P.debug != 0 || P.prof != nullptr;
     switch (wl) {
         case 4: return launch_wide<4>(P, tm, n_tiles, lds, stream);
