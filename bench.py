@@ -105,6 +105,66 @@ def kernel_source_hash() -> str:
     return h.hexdigest()[:16]
 
 
+def measured_entry(kernel: str, model: str, workload: str):
+    """The whole entry of profiles/traffic.json for `kernel` on THESE sources (see measured_traffic), or None."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "traffic.json")) as fh:
+            entries = json.load(fh)["entries"]
+    except (OSError, ValueError, KeyError):
+        return None
+    sha = kernel_source_hash()
+    for e in reversed(entries):
+        if e.get("kernel") == kernel and e.get("model") == model and e.get("workload") == workload and e.get("source_hash") == sha:
+            return e
+    return None
+
+
+def gather_rates():
+    """tools/tcp_bench on MI355X (profiles/r06_j_tcp_bench.jsonl): random 16-byte loads per second from a table that fits the vector L1, the
+    L2, neither -- what each level of the memory system serves when it is the only one asked."""
+    rates = {}
+    try:
+        with open(os.path.join(ROOT, "profiles", "r06_j_tcp_bench.jsonl")) as fh:
+            for l in fh:
+                r = json.loads(l)
+                if r.get("shape") == "b16":
+                    rates[{"L1": "l1", "L2": "l2", "HB": "hbm"}[r["table"][:2]]] = r["G_items_s"]
+    except (OSError, ValueError, KeyError):
+        return None
+    return rates if len(rates) == 3 else None
+
+
+def gather_block(entry, node_reads, chars, wl, kernel_ms):
+    """roofline.gather: what the scoring kernel asks of the memory system per launch, in 16-byte lane loads, against what
+    tools/tcp_bench measured each level to serve.  lane_loads_per_launch: counted by a diagnostics launch of the same batch (vpt_batch_node_reads:
+    unigram / bigram / trigram nodes, deep entries and rows) + one char-table word per char.  With a PMC pass on these sources (tools/profile.sh):
+    the vector L1's lookups, how many of them went to the L2 and how many of those to the fabric; each level's load against its microbench rate --
+    the largest is the level that binds, and `frac` is how close the kernel runs to it."""
+    if kernel_ms is None or kernel_ms <= 0:
+        return None
+    out = {"unit": "16-byte lane loads"}
+    if node_reads:
+        q = {"unigram_nodes": {3: 1, 4: 2, 5: 2, 6: 2, 7: 4, 8: 4}[wl], "bigram_nodes": 2 if wl == 3 else 4, "trigram_nodes": {3: 1, 4: 2, 5: 2, 6: 2, 7: 2, 8: 4}[wl],
+             "deep_entries": 1, "deep_rows": 1, "global_type_rows": ((2 * wl + 3) & ~3) // 4}
+        loads = int(sum(node_reads.get(k, 0) * q[k] for k in q) + chars)
+        out.update({"lane_loads_per_launch": loads, "achieved_Glanes_s": loads / (kernel_ms * 1e-3) / 1e9, "node_reads_per_launch": node_reads})
+    rates = gather_rates()
+    if rates:
+        out["microbench_Glanes_s"] = rates
+        out["microbench_source"] = "profiles/r06_j_tcp_bench.jsonl (tools/tcp_bench: random 16-byte loads from a 16 KB / 2 MB / 256 MB table)"
+    if entry and rates and entry.get("tcp_lookups"):
+        look, l2req, l2miss = float(entry["tcp_lookups"]), float(entry.get("tcp_tcc_read_req") or 0), float(entry.get("tcc_miss") or 0)
+        t = kernel_ms * 1e-3
+        levels = {"l1": look / t / 1e9 / rates["l1"], "l2": l2req / t / 1e9 / rates["l2"], "hbm": l2miss / t / 1e9 / rates["hbm"]}
+        bound = max(levels, key=levels.get)
+        out.update({"pmc": {"tcp_lookups_per_launch": int(look), "of_them_to_the_l2": int(l2req), "of_those_to_the_fabric": int(l2miss),
+                            "tcp_busy_share": (float(entry["tcp_busy_cycles"]) / float(entry["tcp_cycles"])) if entry.get("tcp_cycles") else None},
+                    "load_by_level": {k: round(v, 4) for k, v in levels.items()}, "bound": bound, "frac": round(levels[bound], 4),
+                    "reading": "each level's requests per second over what tools/tcp_bench measured that level to serve alone; the levels work in parallel, the "
+                               "largest share is the one that binds"})
+    return out
+
+
 def measured_traffic(kernel: str, model: str, workload: str):
     """HBM-side bytes per launch of `kernel` from the rocprofv3 PMC passes tools/profile.sh ran on THESE sources
     (profiles/traffic.json: reads = 128 B x TCC_EA0_RDREQ_128B + 64 B x .._64B + 32 B x .._32B, writes = WRITE_SIZE; both
@@ -418,42 +478,36 @@ class Runner:
                 # (char_scorer/boundary_scorer.rs:76-99); the checker's hash-table automaton, which the parity pass below uses, is timed beside
                 # it (`hash_automaton_value`): same scores (tests/test_oracle_c_kat.py), 16 bytes per state instead of 32+ per transition
                 sub = (utf8[:int(boff[n1])], boff[:n1 + 1])
-                orc.predict_batch(utf8[:int(boff[min(S, 64)])], boff[:min(S, 64) + 1], nthreads=1, double_array=True)   # builds the double array (untimed)
-                t = time.perf_counter()
-                orc.predict_batch(*sub, nthreads=1, double_array=True)
-                t1 = time.perf_counter() - t
                 nb1 = int(ooff[n1])
                 # the first pass over the shard is the parity check's reference; its outputs are fresh arrays, so it also pays their
                 # page faults (3 GB for configs[2], first touched from every thread) -- it is NOT timed.  The timed passes write the same
-                # arrays again with the workers pinned: what they measure is the algorithm at memory-resident size.
+                # arrays again: what they measure is the algorithm at memory-resident size.
                 o_scores, o_labels, o_ooff, a_char = orc.predict_batch(utf8, boff, nthreads=self.ncores)
                 t = time.perf_counter()
                 orc.predict_batch(utf8, boff, nthreads=self.ncores, out=(o_scores, o_labels, o_ooff), pin=True)
                 t_hash = time.perf_counter() - t
-                tn, reps, spent = None, 0, 0.0
-                while reps < 20 and (reps == 0 or spent + (spent / reps) < 10.0):
-                    t = time.perf_counter()
-                    orc.predict_batch(utf8, boff, nthreads=self.ncores, out=(o_scores, o_labels, o_ooff), pin=True, double_array=True)
-                    dt = time.perf_counter() - t
-                    tn = dt if tn is None else min(tn, dt)
-                    spent += dt
-                    reps += 1
-                # ... and at cache-resident size: the first 100 K sentences (what configs[1] is), best of a few passes on every thread
-                c_out = orc.predict_batch(*sub, nthreads=self.ncores)[:3]
-                tc = None
-                for _ in range(10):
-                    t = time.perf_counter()
-                    orc.predict_batch(*sub, nthreads=self.ncores, out=c_out, pin=True, double_array=True)
-                    dt = time.perf_counter() - t
-                    tc = dt if tc is None else min(tc, dt)
+                # (round 6) the timed passes run on a POOL of pinned workers that lives for all of them -- a pass is timed from
+                # the first worker's start to the last one's end, thread start-up is in none -- with the data every char walks (automaton, codes,
+                # weight records and vectors, type table) REPLICATED per NUMA node; the same pool without the replicas is timed beside it
+                reps_n = 3 if S > 2_000_000 else 6
+                secs_n, _, nodes = orc.baseline_timed(utf8, boff, (o_scores, o_labels, o_ooff), nthreads=self.ncores, reps=reps_n, replicate=True)
+                secs_shared, _, _ = orc.baseline_timed(utf8, boff, (o_scores, o_labels, o_ooff), nthreads=self.ncores, reps=2, replicate=False)
+                tn = min(secs_n[1:]) if len(secs_n) > 1 else secs_n[0]
+                c_out = orc.predict_batch(*sub, nthreads=1)[:3]
+                secs_1, _, _ = orc.baseline_timed(*sub, c_out, nthreads=1, reps=3, replicate=False)       # ONE thread: the reference is single-threaded
+                t1 = min(secs_1[1:])
+                secs_c, _, _ = orc.baseline_timed(*sub, c_out, nthreads=self.ncores, reps=12, replicate=True)   # cache-resident: configs[1]'s size on every thread
+                tc = min(secs_c[1:])
                 del c_out
-                cpu = {"value": nb / tn, "unit": "boundaries/s", "cores": self.ncores, "kind": "port",
-                       "single_thread_value": nb1 / t1, "cache_resident_value": nb1 / tc, "hash_automaton_value": nb / t_hash, "cpu": cpu_model_name(),
-                       "sample": "rank 0's shard of this workload (%d sentences): best of %d pass(es) on %d pinned threads into pre-faulted outputs, the char scorer's "
-                                 "automaton as a double array (what the reference's matcher is); `hash_automaton_value`: one such pass with the checker's hash-table "
-                                 "automaton; `cache_resident_value`: the first %d sentences, best of 10 passes; `single_thread_value`: those once on 1 thread "
-                                 "(C restatement of the reference algorithm, not the Rust binary)"
-                                 % (S, reps, self.ncores, n1, )}
+                cpu = {"value": nb / tn, "unit": "boundaries/s", "cores": self.ncores, "kind": "port", "numa_nodes": nodes,
+                       "single_thread_value": nb1 / t1, "scaling_vs_one_thread": (nb / tn) / (nb1 / t1), "cache_resident_value": nb1 / tc,
+                       "shared_tables_value": nb / min(secs_shared), "hash_automaton_value": nb / t_hash, "pass_seconds": [round(x, 4) for x in secs_n], "cpu": cpu_model_name(),
+                       "sample": "rank 0's shard of this workload (%d sentences): best of %d passes (the first one apart) on a pool of %d pinned threads that lives for all "
+                                 "of them -- a pass is timed from its first worker's start to its last one's end -- into pre-faulted outputs, the char scorer's automaton as a "
+                                 "double array (what the reference's matcher is), the tables replicated per NUMA node (%d); `shared_tables_value`: the same pool, one copy "
+                                 "of the tables; `hash_automaton_value`: one pass with the checker's hash-table automaton, a thread per call; `cache_resident_value`: the "
+                                 "first %d sentences, best of 11 passes; `single_thread_value`: those on 1 thread, best of 2 (C restatement of the reference "
+                                 "algorithm, not the Rust binary)" % (S, len(secs_n) - 1, self.ncores, nodes, n1)}
             else:
                 o_scores, o_labels, _, a_char = orc.predict_batch(utf8, boff, nthreads=self.ncores)
             g_scores = d_scores[:nb].cpu().numpy()
@@ -594,6 +648,24 @@ class Runner:
                          "traffic": measured_traffic(kernel_name, model_name, cfg["name"]) if self.world == 1 and not self.args.sentences else None,
                          "algorithmic_bytes_per_launch": a, "bytes_per_boundary": a / max(nb, 1),
                          "a_stream": a_stream, "a_char": a_char, "a_type": a_type})
+        if self.world == 1 and kernel_name == "score_tiles_fast_kernel":
+            node_reads = None
+            try:   # a diagnostics launch of the same batch counts the node reads (untimed; the instance that counts is slower)
+                os.environ["VPT_PROFILE_PHASES"] = "1"
+                counted = api.DeviceBatch(pred)
+                os.environ.pop("VPT_PROFILE_PHASES", None)
+                counted.set_max_sentence_chars(max_chars)
+                counted.predict(d_text.data_ptr(), d_boff.data_ptr(), d_ooff.data_ptr(), S, nb, max_bytes, d_scores.data_ptr(), d_labels.data_ptr(), stream)
+                counted.sync()
+                node_reads = counted.node_reads()
+                del counted
+            except Exception as e:   # noqa: BLE001 -- a diagnostic: the line does not depend on it
+                sys.stderr.write("bench.py: node reads not counted: %s\n" % e)
+            finally:
+                os.environ.pop("VPT_PROFILE_PHASES", None)
+            wl = max(3, int(info["char_window"]), int(info["type_window"]))
+            entry = measured_entry(kernel_name, model_name, cfg["name"]) if not self.args.sentences else None
+            roof["gather"] = gather_block(entry, node_reads, nb + S, wl, kernel_ms)
         out["roofline"] = roof
         out["parity"] = parity
         if not args.no_cpu_baseline:

@@ -38,6 +38,8 @@ def lib():
                                        C.c_void_p, C.c_int, C.POINTER(C.c_uint64)]
         L.vo_predict_batch_ex.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p,
                                           C.c_void_p, C.c_int, C.POINTER(C.c_uint64), C.c_int]
+        L.vo_baseline_timed.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,
+                                        C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_int)]
         L.vo_predict_tags.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t, C.c_void_p, C.c_void_p, C.POINTER(C.c_uint32)]
         L.vo_n_tags.argtypes = [C.c_void_p]
         L.vo_n_tags.restype = C.c_uint32
@@ -116,6 +118,23 @@ class OraclePredictor:
         if st != 0:
             raise OracleError(st, "predict_batch failed")
         return scores, labels, ooff, ab.value
+
+    def baseline_timed(self, utf8: np.ndarray, byte_offsets: np.ndarray, out, nthreads: int = 1, reps: int = 3, double_array: bool = True, replicate: bool = True):
+        """bench.py's cpu_baseline leg (vo_baseline_timed): `reps` passes of the reference's loop over the batch on a pool of `nthreads` pinned workers
+        that lives for the whole call -- the passes are timed between barriers, thread start-up is in none -- with the data every char walks
+        replicated per NUMA node.  `out` = (scores, labels, out_offsets) of an earlier call on this batch (written in place).  Returns
+        (seconds per pass, A_char bytes, NUMA nodes used)."""
+        S = len(byte_offsets) - 1
+        utf8 = np.ascontiguousarray(utf8, dtype=np.uint8)
+        byte_offsets = np.ascontiguousarray(byte_offsets, dtype=np.uint64)
+        scores, labels, ooff = out
+        secs = np.zeros(max(reps, 1), dtype=np.float64)
+        ab, nodes = C.c_uint64(), C.c_int()
+        st = lib().vo_baseline_timed(self._h, utf8.ctypes.data, byte_offsets.ctypes.data, S, scores.ctypes.data, labels.ctypes.data, ooff.ctypes.data, nthreads,
+                                     (2 if double_array else 0) | (4 if replicate else 0), reps, secs.ctypes.data, C.byref(ab), C.byref(nodes))
+        if st != 0:
+            raise OracleError(st, "baseline_timed failed")
+        return secs.tolist(), ab.value, nodes.value
 
     def predict_tags(self, text: str, labels=None):
         raw = text.encode("utf-8")

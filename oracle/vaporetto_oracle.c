@@ -36,6 +36,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <time.h>
 
 #define VO_OK 0
 #define VO_INVALID_MODEL 1
@@ -1082,6 +1083,135 @@ int vo_predict_batch_ex(const vo_predictor *p, const uint8_t *utf8, const uint64
     int status = VO_OK; uint64_t ab = 0;
     for (int t = 0; t < nthreads; t++) { if (jobs[t].status && !status) status = jobs[t].status; ab += jobs[t].abytes; }
     if (char_bytes_out) *char_bytes_out = ab;
+    free(jobs); free(th); free(cpus);
+    return status;
+}
+/* ---- the TIMED baseline (bench.py's cpu_baseline leg; VERDICT r5 item 9: "a CPU baseline that scales").
+ * The reference's loop (predict/src/main.rs:126-148) on a POOL of pinned workers that lives for the whole run -- `reps` passes over the batch
+ * with a barrier on either side of each, timed by the calling thread between the barriers, so that thread start-up is in no pass -- and with
+ * the read-only data every char walks (the double-array automaton, the chars' codes, the weight records and vectors, the type window table)
+ * REPLICATED per NUMA node: the first worker of a node copies them (first touch: the pages land on its node), the node's workers read that
+ * copy.  (One copy made by the main thread serves both sockets of the box from one node's memory: 256 threads were 10.7 x one.)
+ * flags: bit 1 = double array (as vo_predict_batch_ex), bit 2 = replicate per node.  seconds_out[reps]; *nodes_out = NUMA nodes used. */
+typedef struct {
+    const vo_predictor *p; vo_predictor *view;   /* what this worker reads: p, or its node's replica */
+    const uint8_t *utf8; const uint64_t *boff, *ooff; size_t lo, hi; int32_t *scores; uint8_t *labels;
+    int cpu, node, first_of_node, use_da, reps, status; uint64_t abytes;
+    pthread_barrier_t *bar; vo_predictor **replicas; int replicate;
+    double *t_start, *t_end;   /* [reps]: this worker's own clock readings around its share of a pass (the caller may not run while the workers do) */
+} pool_job;
+static double now_s(void) { struct timespec t; clock_gettime(CLOCK_MONOTONIC, &t); return (double)t.tv_sec + 1e-9 * (double)t.tv_nsec; }
+static int node_of_cpu(int cpu) {   /* /sys/devices/system/node/nodeN/cpulist; 0 when the machine does not say */
+    for (int n = 0; n < 64; n++) {
+        char path[96]; snprintf(path, sizeof(path), "/sys/devices/system/node/node%d/cpulist", n);
+        FILE *f = fopen(path, "r");
+        if (!f) { if (n == 0) return 0; break; }
+        char buf[4096]; size_t len = fread(buf, 1, sizeof(buf) - 1, f); buf[len] = 0; fclose(f);
+        const char *q = buf;
+        while (*q) {
+            char *e; long a = strtol(q, &e, 10), b = a;
+            if (e == q) break;
+            if (*e == '-') { q = e + 1; b = strtol(q, &e, 10); }
+            if (cpu >= a && cpu <= b) return n;
+            q = (*e == ',') ? e + 1 : e;
+            if (*q == '\n') break;
+        }
+    }
+    return 0;
+}
+static void *dup_bytes(const void *src, size_t n) { if (!src || !n) return NULL; void *d = xmalloc(n); memcpy(d, src, n); return d; }
+static vo_predictor *replicate_hot(const vo_predictor *p) {   /* a view of p whose hot read-only arrays are fresh copies (made by the calling thread) */
+    vo_predictor *v = (vo_predictor *)xmalloc(sizeof(*v));
+    *v = *p;
+    if (p->has_char) {
+        v->chr.pw = (pw_rec *)dup_bytes(p->chr.pw, sizeof(pw_rec) * p->chr.n_pat);
+        v->chr.wdata = (int32_t *)dup_bytes(p->chr.wdata, sizeof(int32_t) * p->chr.n_wdata);
+        if (p->chr.da) {
+            da_t *d = (da_t *)xmalloc(sizeof(*d));
+            *d = *p->chr.da;
+            d->st = (da_state *)dup_bytes(p->chr.da->st, sizeof(da_state) * p->chr.da->n);
+            d->code_of = (uint32_t *)dup_bytes(p->chr.da->code_of, sizeof(uint32_t) * p->chr.da->n_codes_map);
+            v->chr.da = d;
+        }
+    }
+    if (p->type_kind == 1 && p->tcache.scores) v->tcache.scores = (int32_t *)dup_bytes(p->tcache.scores, sizeof(int32_t) * (size_t)(p->tcache.mask + 1));
+    return v;
+}
+static void replica_free(const vo_predictor *p, vo_predictor *v) {
+    if (!v) return;
+    if (p->has_char) { free(v->chr.pw); free(v->chr.wdata); if (p->chr.da) { free(v->chr.da->st); free(v->chr.da->code_of); free(v->chr.da); } }
+    if (p->type_kind == 1 && p->tcache.scores) free(v->tcache.scores);
+    free(v);
+}
+static void *pool_run(void *arg) {
+    pool_job *j = (pool_job *)arg;
+    if (j->cpu >= 0) { cpu_set_t set; CPU_ZERO(&set); CPU_SET(j->cpu, &set); (void)pthread_setaffinity_np(pthread_self(), sizeof(set), &set); }
+    if (j->replicate && j->first_of_node) j->replicas[j->node] = replicate_hot(j->p);
+    pthread_barrier_wait(j->bar);                                   /* every worker pinned, every node's copy made */
+    const vo_predictor *view = (j->replicate && j->replicas[j->node]) ? j->replicas[j->node] : j->p;
+    scratch_t s; memset(&s, 0, sizeof(s));
+    for (int r = 0; r < j->reps; r++) {
+        pthread_barrier_wait(j->bar);                               /* the pass starts */
+        j->t_start[r] = now_s();
+        uint64_t ab = 0;
+        for (size_t i = j->lo; i < j->hi && !j->status; i++) {
+            long n = predict_one_ex(view, j->utf8 + j->boff[i], (size_t)(j->boff[i + 1] - j->boff[i]), &s,
+                                    j->scores ? j->scores + j->ooff[i] : NULL, j->labels ? j->labels + j->ooff[i] : NULL, &ab, j->use_da);
+            if (n < 0) j->status = (int)-n;
+            else if ((uint64_t)(n - 1) != j->ooff[i + 1] - j->ooff[i]) j->status = VO_INVALID_ARGUMENT;
+        }
+        j->abytes = ab;
+        j->t_end[r] = now_s();
+        pthread_barrier_wait(j->bar);                               /* the pass is over */
+    }
+    scratch_free(&s);
+    return NULL;
+}
+int vo_baseline_timed(const vo_predictor *p, const uint8_t *utf8, const uint64_t *byte_offsets, size_t S, int32_t *scores, uint8_t *labels,
+                      const uint64_t *out_offsets, int nthreads, int flags, int reps, double *seconds_out, uint64_t *char_bytes_out, int *nodes_out) {
+    if ((flags & 2) && p->has_char && !p->chr.da) ((vo_predictor *)p)->chr.da = da_build(&p->chr.pma);
+    if (nthreads < 1) nthreads = 1;
+    if ((size_t)nthreads > S) nthreads = S ? (int)S : 1;
+    if (reps < 1) reps = 1;
+    int *cpus = (int *)xcalloc(CPU_SETSIZE, sizeof(int)); int ncpus = 0;
+    cpu_set_t allowed; CPU_ZERO(&allowed);
+    if (sched_getaffinity(0, sizeof(allowed), &allowed) == 0)
+        for (int c = 0; c < CPU_SETSIZE; c++) if (CPU_ISSET(c, &allowed)) cpus[ncpus++] = c;
+    pool_job *jobs = (pool_job *)xcalloc((size_t)nthreads, sizeof(pool_job));
+    pthread_t *th = (pthread_t *)xcalloc((size_t)nthreads, sizeof(pthread_t));
+    vo_predictor *replicas[64]; memset(replicas, 0, sizeof(replicas));
+    int seen[64]; memset(seen, 0, sizeof(seen));
+    pthread_barrier_t bar; pthread_barrier_init(&bar, NULL, (unsigned)nthreads + 1);
+    uint64_t total = S ? byte_offsets[S] - byte_offsets[0] : 0;
+    size_t lo = 0; int n_nodes = 0;
+    for (int t = 0; t < nthreads; t++) {
+        size_t hi = lo;
+        uint64_t target = byte_offsets[0] + total * (uint64_t)(t + 1) / (uint64_t)nthreads;
+        if (t == nthreads - 1) hi = S; else while (hi < S && byte_offsets[hi + 1] <= target) hi++;
+        pool_job *j = &jobs[t];
+        j->p = p; j->utf8 = utf8; j->boff = byte_offsets; j->ooff = out_offsets; j->lo = lo; j->hi = hi; j->scores = scores; j->labels = labels;
+        j->cpu = (ncpus >= nthreads) ? cpus[t] : -1;
+        j->node = j->cpu >= 0 ? node_of_cpu(j->cpu) & 63 : 0;
+        j->first_of_node = !seen[j->node]; if (!seen[j->node]) { seen[j->node] = 1; n_nodes++; }
+        j->use_da = (flags & 2) ? 1 : 0; j->reps = reps; j->bar = &bar; j->replicas = replicas; j->replicate = (flags & 4) ? 1 : 0;
+        j->t_start = (double *)xcalloc((size_t)reps, sizeof(double)); j->t_end = (double *)xcalloc((size_t)reps, sizeof(double));
+        lo = hi;
+    }
+    for (int t = 0; t < nthreads; t++) pthread_create(&th[t], NULL, pool_run, &jobs[t]);
+    pthread_barrier_wait(&bar);
+    for (int r = 0; r < reps; r++) { pthread_barrier_wait(&bar); pthread_barrier_wait(&bar); }
+    int status = VO_OK; uint64_t ab = 0;
+    for (int t = 0; t < nthreads; t++) { pthread_join(th[t], NULL); if (jobs[t].status && !status) status = jobs[t].status; ab += jobs[t].abytes; }
+    for (int r = 0; r < reps && seconds_out; r++) {   /* a pass: from the first worker's start to the last one's end */
+        double a = jobs[0].t_start[r], b = jobs[0].t_end[r];
+        for (int t = 1; t < nthreads; t++) { if (jobs[t].t_start[r] < a) a = jobs[t].t_start[r]; if (jobs[t].t_end[r] > b) b = jobs[t].t_end[r]; }
+        seconds_out[r] = b - a;
+    }
+    for (int t = 0; t < nthreads; t++) { free(jobs[t].t_start); free(jobs[t].t_end); }
+    for (int n = 0; n < 64; n++) replica_free(p, replicas[n]);
+    pthread_barrier_destroy(&bar);
+    if (char_bytes_out) *char_bytes_out = ab;
+    if (nodes_out) *nodes_out = n_nodes;
     free(jobs); free(th); free(cpus);
     return status;
 }

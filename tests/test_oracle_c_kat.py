@@ -254,3 +254,22 @@ def test_double_array_automaton_of_the_baseline_leg_equals_the_checker():
         for nthreads in (1, 3):
             got = orc.predict_batch(utf8, boff, nthreads=nthreads, double_array=True)
             assert np.array_equal(got[0], want[0]) and np.array_equal(got[1], want[1]) and got[3] == want[3]
+
+
+def test_timed_baseline_pool_equals_the_plain_batch():
+    """bench.py's cpu_baseline leg (vo_baseline_timed): a pool of pinned workers that lives for all the passes, the tables
+    replicated per NUMA node or shared -- the same scores, labels and algorithmic bytes as the plain batch call, a positive time per pass."""
+    from tests import randmodel
+    from vaporetto_amd import api
+    from vaporetto_amd.modelfmt import encode_model
+    m = randmodel.rand_model(55, alphabet="kana", wc=3, wt=3, n_char=200, n_dict=200, max_word=8)
+    raw = encode_model(m)
+    texts = randmodel.rand_sentences(8, m, 3000, alphabet="kana", max_len=80)
+    utf8, boff = api.pack_texts([t.encode("utf-8") for t in texts])
+    o = cbind.OraclePredictor(raw)
+    s0, l0, ooff, ab0 = o.predict_batch(utf8, boff)
+    for nthreads, replicate, da in ((1, False, True), (3, True, True), (4, False, False), (64, True, True)):
+        s1, l1 = np.zeros_like(s0), np.zeros_like(l0)
+        secs, ab, nodes = o.baseline_timed(utf8, boff, (s1, l1, ooff), nthreads=nthreads, reps=3, double_array=da, replicate=replicate)
+        assert np.array_equal(s0, s1) and np.array_equal(l0, l1) and ab == ab0, (nthreads, replicate, da)
+        assert len(secs) == 3 and all(x > 0 for x in secs) and nodes >= 1

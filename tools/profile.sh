@@ -13,7 +13,7 @@ export TMPDIR=/tmp
 CMD="python $REPO/bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-e2e --no-emit --quick $*"   # (--no-emit: no writer and no fused-writer instance of the scoring kernel, whose launches would be averaged in)
 cd /tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- $CMD > $OUT/trace.log 2>&1
-DEFAULT_GROUPS="TCC_EA0_RDREQ_128B_sum TCC_EA0_RDREQ_64B_sum TCC_EA0_RDREQ_32B_sum|WRITE_SIZE|TCP_TCC_READ_REQ_sum TCP_TCC_READ_REQ_LATENCY_sum TCP_TOTAL_ACCESSES_sum TCP_PENDING_STALL_CYCLES_sum|TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum|SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_SALU|SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_SMEM SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_LDS GRBM_GUI_ACTIVE"
+DEFAULT_GROUPS="TCC_EA0_RDREQ_128B_sum TCC_EA0_RDREQ_64B_sum TCC_EA0_RDREQ_32B_sum|WRITE_SIZE|TCP_TCC_READ_REQ_sum TCP_TCC_READ_REQ_LATENCY_sum TCP_TOTAL_ACCESSES_sum TCP_PENDING_STALL_CYCLES_sum|TCP_TOTAL_CACHE_ACCESSES_sum TCP_GATE_EN1_sum|TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum|SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_SALU|SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_SMEM SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_LDS GRBM_GUI_ACTIVE"
 GROUPS_STR="${VPT_PMC_GROUPS:-$DEFAULT_GROUPS}"
 IFS='|' read -ra GRPS <<< "$GROUPS_STR"
 for C in "${GRPS[@]}"; do
@@ -55,6 +55,9 @@ for k, v in agg.items():
              "source_hash": bench.kernel_source_hash(),
              "read_bytes": int(128 * avg("TCC_EA0_RDREQ_128B_sum") + 64 * avg("TCC_EA0_RDREQ_64B_sum") + 32 * avg("TCC_EA0_RDREQ_32B_sum")),
              "write_bytes": int(1024 * avg("WRITE_SIZE")),
+             # the gather side (bench.py, roofline.gather): the vector L1's lookups, its requests to the L2, the L2's misses, the L1s' busy cycles
+             "tcp_lookups": int(avg("TCP_TOTAL_CACHE_ACCESSES_sum")), "tcp_tcc_read_req": int(avg("TCP_TCC_READ_REQ_sum")), "tcc_miss": int(avg("TCC_MISS_sum")),
+             "tcc_hit": int(avg("TCC_HIT_sum")), "tcp_busy_cycles": int(avg("TCP_GATE_EN1_sum")), "tcp_cycles": int(avg("GRBM_GUI_ACTIVE") / 8 * 256),
              "source": "gpurun_out/prof_%s (rocprofv3 --pmc, separate passes: read-request size classes, WRITE_SIZE), bench args: %s" % (sys.argv[1], sys.argv[2])}
     json.dump(entry, open(os.path.join(out, "traffic_entry.json"), "w"), indent=1)
     print("traffic entry:", json.dumps(entry))
