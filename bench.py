@@ -490,22 +490,23 @@ class Runner:
                 # the first worker's start to the last one's end, thread start-up is in none -- with the data every char walks (automaton, codes,
                 # weight records and vectors, type table) REPLICATED per NUMA node; the same pool without the replicas is timed beside it
                 reps_n = 3 if S > 2_000_000 else 6
-                secs_n, _, nodes = orc.baseline_timed(utf8, boff, (o_scores, o_labels, o_ooff), nthreads=self.ncores, reps=reps_n, replicate=True)
+                secs_n, _, nodes = orc.baseline_timed(utf8, boff, (o_scores, o_labels, o_ooff), nthreads=self.ncores, reps=reps_n, replicate=True, huge_pages=True)
+                secs_4k, _, _ = orc.baseline_timed(utf8, boff, (o_scores, o_labels, o_ooff), nthreads=self.ncores, reps=2, replicate=True)
                 secs_shared, _, _ = orc.baseline_timed(utf8, boff, (o_scores, o_labels, o_ooff), nthreads=self.ncores, reps=2, replicate=False)
                 tn = min(secs_n[1:]) if len(secs_n) > 1 else secs_n[0]
                 c_out = orc.predict_batch(*sub, nthreads=1)[:3]
                 secs_1, _, _ = orc.baseline_timed(*sub, c_out, nthreads=1, reps=3, replicate=False)       # ONE thread: the reference is single-threaded
                 t1 = min(secs_1[1:])
-                secs_c, _, _ = orc.baseline_timed(*sub, c_out, nthreads=self.ncores, reps=12, replicate=True)   # cache-resident: configs[1]'s size on every thread
+                secs_c, _, _ = orc.baseline_timed(*sub, c_out, nthreads=self.ncores, reps=12, replicate=True, huge_pages=True)   # cache-resident: configs[1]'s size on every thread
                 tc = min(secs_c[1:])
                 del c_out
                 cpu = {"value": nb / tn, "unit": "boundaries/s", "cores": self.ncores, "kind": "port", "numa_nodes": nodes,
                        "single_thread_value": nb1 / t1, "scaling_vs_one_thread": (nb / tn) / (nb1 / t1), "cache_resident_value": nb1 / tc,
-                       "shared_tables_value": nb / min(secs_shared), "hash_automaton_value": nb / t_hash, "pass_seconds": [round(x, 4) for x in secs_n], "cpu": cpu_model_name(),
+                       "shared_tables_value": nb / min(secs_shared), "small_pages_value": nb / min(secs_4k), "hash_automaton_value": nb / t_hash, "pass_seconds": [round(x, 4) for x in secs_n], "cpu": cpu_model_name(),
                        "sample": "rank 0's shard of this workload (%d sentences): best of %d passes (the first one apart) on a pool of %d pinned threads that lives for all "
                                  "of them -- a pass is timed from its first worker's start to its last one's end -- into pre-faulted outputs, the char scorer's automaton as a "
-                                 "double array (what the reference's matcher is), the tables replicated per NUMA node (%d); `shared_tables_value`: the same pool, one copy "
-                                 "of the tables; `hash_automaton_value`: one pass with the checker's hash-table automaton, a thread per call; `cache_resident_value`: the "
+                                 "double array (what the reference's matcher is), the tables replicated per NUMA node (%d) on 2 MB pages (madvise); `small_pages_value`: the "
+                                 "replicas on 4 KB pages; `shared_tables_value`: the same pool, one copy of the tables; `hash_automaton_value`: one pass with the checker's hash-table automaton, a thread per call; `cache_resident_value`: the "
                                  "first %d sentences, best of 11 passes; `single_thread_value`: those on 1 thread, best of 2 (C restatement of the reference "
                                  "algorithm, not the Rust binary)" % (S, len(secs_n) - 1, self.ncores, nodes, n1)}
             else:

@@ -119,10 +119,11 @@ class OraclePredictor:
             raise OracleError(st, "predict_batch failed")
         return scores, labels, ooff, ab.value
 
-    def baseline_timed(self, utf8: np.ndarray, byte_offsets: np.ndarray, out, nthreads: int = 1, reps: int = 3, double_array: bool = True, replicate: bool = True):
+    def baseline_timed(self, utf8: np.ndarray, byte_offsets: np.ndarray, out, nthreads: int = 1, reps: int = 3, double_array: bool = True, replicate: bool = True,
+                       huge_pages: bool = False):
         """bench.py's cpu_baseline leg (vo_baseline_timed): `reps` passes of the reference's loop over the batch on a pool of `nthreads` pinned workers
         that lives for the whole call -- the passes are timed between barriers, thread start-up is in none -- with the data every char walks
-        replicated per NUMA node.  `out` = (scores, labels, out_offsets) of an earlier call on this batch (written in place).  Returns
+        replicated per NUMA node (`huge_pages`: those copies on 2 MB pages).  `out` = (scores, labels, out_offsets) of an earlier call on this batch (written in place).  Returns
         (seconds per pass, A_char bytes, NUMA nodes used)."""
         S = len(byte_offsets) - 1
         utf8 = np.ascontiguousarray(utf8, dtype=np.uint8)
@@ -131,7 +132,7 @@ class OraclePredictor:
         secs = np.zeros(max(reps, 1), dtype=np.float64)
         ab, nodes = C.c_uint64(), C.c_int()
         st = lib().vo_baseline_timed(self._h, utf8.ctypes.data, byte_offsets.ctypes.data, S, scores.ctypes.data, labels.ctypes.data, ooff.ctypes.data, nthreads,
-                                     (2 if double_array else 0) | (4 if replicate else 0), reps, secs.ctypes.data, C.byref(ab), C.byref(nodes))
+                                     (2 if double_array else 0) | (4 if replicate else 0) | (8 if huge_pages else 0), reps, secs.ctypes.data, C.byref(ab), C.byref(nodes))
         if st != 0:
             raise OracleError(st, "baseline_timed failed")
         return secs.tolist(), ab.value, nodes.value

@@ -37,6 +37,7 @@
 #include <stdlib.h>
 #include <string.h>
 #include <time.h>
+#include <sys/mman.h>
 
 #define VO_OK 0
 #define VO_INVALID_MODEL 1
@@ -1092,7 +1093,8 @@ int vo_predict_batch_ex(const vo_predictor *p, const uint8_t *utf8, const uint64
  * the read-only data every char walks (the double-array automaton, the chars' codes, the weight records and vectors, the type window table)
  * REPLICATED per NUMA node: the first worker of a node copies them (first touch: the pages land on its node), the node's workers read that
  * copy.  (One copy made by the main thread serves both sockets of the box from one node's memory: 256 threads were 10.7 x one.)
- * flags: bit 1 = double array (as vo_predict_batch_ex), bit 2 = replicate per node.  seconds_out[reps]; *nodes_out = NUMA nodes used. */
+ * flags: bit 1 = double array (as vo_predict_batch_ex), bit 2 = replicate per node, bit 3 = the replicas on 2 MB pages (transparent huge
+ * pages by madvise, where the host allows them).  seconds_out[reps]; *nodes_out = NUMA nodes used. */
 typedef struct {
     const vo_predictor *p; vo_predictor *view;   /* what this worker reads: p, or its node's replica */
     const uint8_t *utf8; const uint64_t *boff, *ooff; size_t lo, hi; int32_t *scores; uint8_t *labels;
@@ -1119,7 +1121,19 @@ static int node_of_cpu(int cpu) {   /* /sys/devices/system/node/nodeN/cpulist; 0
     }
     return 0;
 }
-static void *dup_bytes(const void *src, size_t n) { if (!src || !n) return NULL; void *d = xmalloc(n); memcpy(d, src, n); return d; }
+static int g_dup_huge = 0;   /* the copies on 2 MB pages (madvise: a random walk over 200 MB of tables otherwise misses the TLB at every step) */
+static void *dup_bytes(const void *src, size_t n) {
+    if (!src || !n) return NULL;
+    void *d = NULL;
+    if (g_dup_huge && n >= ((size_t)1 << 21)) {
+        const size_t al = (size_t)1 << 21, len = (n + al - 1) & ~(al - 1);
+        if (posix_memalign(&d, al, len) != 0) d = NULL;
+        else (void)madvise(d, len, MADV_HUGEPAGE);
+    }
+    if (!d) d = xmalloc(n);
+    memcpy(d, src, n);
+    return d;
+}
 static vo_predictor *replicate_hot(const vo_predictor *p) {   /* a view of p whose hot read-only arrays are fresh copies (made by the calling thread) */
     vo_predictor *v = (vo_predictor *)xmalloc(sizeof(*v));
     *v = *p;
@@ -1173,6 +1187,7 @@ int vo_baseline_timed(const vo_predictor *p, const uint8_t *utf8, const uint64_t
     if (nthreads < 1) nthreads = 1;
     if ((size_t)nthreads > S) nthreads = S ? (int)S : 1;
     if (reps < 1) reps = 1;
+    g_dup_huge = (flags & 8) ? 1 : 0;
     int *cpus = (int *)xcalloc(CPU_SETSIZE, sizeof(int)); int ncpus = 0;
     cpu_set_t allowed; CPU_ZERO(&allowed);
     if (sched_getaffinity(0, sizeof(allowed), &allowed) == 0)
@@ -1190,7 +1205,7 @@ int vo_baseline_timed(const vo_predictor *p, const uint8_t *utf8, const uint64_t
         if (t == nthreads - 1) hi = S; else while (hi < S && byte_offsets[hi + 1] <= target) hi++;
         pool_job *j = &jobs[t];
         j->p = p; j->utf8 = utf8; j->boff = byte_offsets; j->ooff = out_offsets; j->lo = lo; j->hi = hi; j->scores = scores; j->labels = labels;
-        j->cpu = (ncpus >= nthreads) ? cpus[t] : -1;
+        j->cpu = (ncpus >= nthreads && nthreads > 1) ? cpus[t] : -1;   /* (one worker: wherever the scheduler puts it, like the reference's one thread) */
         j->node = j->cpu >= 0 ? node_of_cpu(j->cpu) & 63 : 0;
         j->first_of_node = !seen[j->node]; if (!seen[j->node]) { seen[j->node] = 1; n_nodes++; }
         j->use_da = (flags & 2) ? 1 : 0; j->reps = reps; j->bar = &bar; j->replicas = replicas; j->replicate = (flags & 4) ? 1 : 0;

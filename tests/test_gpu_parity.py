@@ -1273,6 +1273,7 @@ def test_tokenize_batch_into_pinned_buffers(chunk_bytes, monkeypatch):
     pin_text, pin_off = api.PinnedArray((cap,), np.uint8), api.PinnedArray((S + 1,), np.uint64)
     pin_text.array[:] = 0xEE
     for _ in range(2):   # the workspace, its chain words and the ticket are reused
+        pin_text.array[:] = 0xEE   # (poisoned every time: a run written to another run's place must not find the right bytes there from the call before)
         text, toff = pred.tokenize_packed(utf8, boff, text_out=pin_text.array, offsets_out=pin_off.array)
         assert np.array_equal(toff, o_toff) and np.array_equal(text, o_text)
         assert (pin_text.array[int(o_toff[-1]):] == 0xEE).all()          # nothing behind the text was touched
@@ -1282,8 +1283,10 @@ def test_tokenize_batch_into_pinned_buffers(chunk_bytes, monkeypatch):
     for out in (pin_text.array, np.zeros(cap, np.uint8)):
         st = L.vpt_tokenize_batch(pred.handle, utf8.ctypes.data, boff.ctypes.data, S, 0, 0, out.ctypes.data, 64, pin_off.array.ctypes.data)
         assert st == api._lib.VPT_INVALID_ARGUMENT and "text_capacity" in api._lib.last_error()
-    text, toff = pred.tokenize_packed(utf8, boff, text_out=pin_text.array, offsets_out=pin_off.array)   # and the workspace is clean again
-    assert np.array_equal(toff, o_toff) and np.array_equal(text, o_text)
+    for _ in range(4):
+        pin_text.array[:] = 0xEE
+        text, toff = pred.tokenize_packed(utf8, boff, text_out=pin_text.array, offsets_out=pin_off.array)   # and the workspace is clean again
+        assert np.array_equal(toff, o_toff) and np.array_equal(text, o_text)
 
 
 def test_converted_kytea_fixture_on_gpu():

@@ -331,7 +331,8 @@ __global__ __launch_bounds__(kEmitThreads, kTags ? VPT_EMIT_TAG_OCC : 1) void em
         constexpr uint64_t kVal = (uint64_t(1) << 62) - 1;
         if (lane == 0) __hip_atomic_store(F.state + blk, (uint64_t(1) << 62) | size, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         const uint64_t start = (F.chain_in ? *F.chain_in : 0ull) & kVal;   // where the call's text starts (a call chained behind another: EmitFuse)
-        uint64_t base = blk == 0 ? start : 0;
+        uint64_t base = 0;
+        bool anchored = false;   // the sum has reached a run whose position is known (or the front's sentinel): it holds `start`
         for (uint64_t p = blk; p > 0;) {
             const bool have = uint64_t(lane) < p;
             uint64_t w = (uint64_t(2) << 62) | start;   // in front of run 0
@@ -341,11 +342,16 @@ __global__ __launch_bounds__(kEmitThreads, kTags ? VPT_EMIT_TAG_OCC : 1) void em
             const uint64_t need = first < 63 ? (uint64_t(2) << first) - 1 : ~uint64_t(0);
             if (pending & need) { __builtin_amdgcn_s_sleep(2); continue; }         // not all published yet: look again
             base += wave_sum64(int(lane) <= first ? (w & kVal) : 0);
-            if (first < 64) break;
+            if (first < 64) { anchored = true; break; }
             p -= 64;
         }
+        // run 0, or a walk that ran off the front exactly at a multiple of 64 runs with none of them placed yet (then no lane held the sentinel:
+        // found on MI355X by the chained chunks of vpt_tokenize_batch with one-sentence runs -- a misplaced run's text landed in an earlier chunk's)
+        if (!anchored) base += start;
         if (lane == 0) {
+#ifndef VPT_EMIT_NO_PREFIX   // (test builds, tests/test_kernel_emu.py: the runs publish their sizes only, so every look-back walks to the launch's front)
             __hip_atomic_store(F.state + blk, (uint64_t(2) << 62) | ((base + size) & kVal), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#endif
             L.bcast[3] = base;
         }
     }
