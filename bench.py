@@ -482,6 +482,10 @@ class Runner:
                 # the first pass over the shard is the parity check's reference; its outputs are fresh arrays, so it also pays their
                 # page faults (3 GB for configs[2], first touched from every thread) -- it is NOT timed.  The timed passes write the same
                 # arrays again: what they measure is the algorithm at memory-resident size.
+                # ONE thread first (the reference is single-threaded), before the all-core passes take the cores' boost clocks away
+                c_out = orc.predict_batch(*sub, nthreads=1)[:3]
+                secs_1, _, _ = orc.baseline_timed(*sub, c_out, nthreads=1, reps=3, replicate=False)
+                t1 = min(secs_1[1:])
                 o_scores, o_labels, o_ooff, a_char = orc.predict_batch(utf8, boff, nthreads=self.ncores)
                 t = time.perf_counter()
                 orc.predict_batch(utf8, boff, nthreads=self.ncores, out=(o_scores, o_labels, o_ooff), pin=True)
@@ -494,21 +498,30 @@ class Runner:
                 secs_4k, _, _ = orc.baseline_timed(utf8, boff, (o_scores, o_labels, o_ooff), nthreads=self.ncores, reps=2, replicate=True)
                 secs_shared, _, _ = orc.baseline_timed(utf8, boff, (o_scores, o_labels, o_ooff), nthreads=self.ncores, reps=2, replicate=False)
                 tn = min(secs_n[1:]) if len(secs_n) > 1 else secs_n[0]
-                c_out = orc.predict_batch(*sub, nthreads=1)[:3]
-                secs_1, _, _ = orc.baseline_timed(*sub, c_out, nthreads=1, reps=3, replicate=False)       # ONE thread: the reference is single-threaded
-                t1 = min(secs_1[1:])
                 secs_c, _, _ = orc.baseline_timed(*sub, c_out, nthreads=self.ncores, reps=12, replicate=True, huge_pages=True)   # cache-resident: configs[1]'s size on every thread
                 tc = min(secs_c[1:])
                 del c_out
+                # what stops the pool from scaling: the same pool over growing prefixes of the batch -- the walk is a chain of dependent loads, and
+                # once the sentences' share of the automaton no longer fits the cores' caches every char waits for DRAM
+                by_size = []
+                for n_k in (100_000, 300_000, 1_000_000, 3_000_000):
+                    if n_k >= S:
+                        break
+                    sub_k = (utf8[:int(boff[n_k])], boff[:n_k + 1])
+                    k_out = (o_scores[:int(ooff[n_k])], o_labels[:int(ooff[n_k])], ooff[:n_k + 1].copy())
+                    secs_k, _, _ = orc.baseline_timed(*sub_k, k_out, nthreads=self.ncores, reps=4, replicate=True, huge_pages=True)
+                    by_size.append({"sentences": n_k, "value": int(ooff[n_k]) / min(secs_k[1:])})
+                by_size.append({"sentences": S, "value": nb / tn})
                 cpu = {"value": nb / tn, "unit": "boundaries/s", "cores": self.ncores, "kind": "port", "numa_nodes": nodes,
                        "single_thread_value": nb1 / t1, "scaling_vs_one_thread": (nb / tn) / (nb1 / t1), "cache_resident_value": nb1 / tc,
-                       "shared_tables_value": nb / min(secs_shared), "small_pages_value": nb / min(secs_4k), "hash_automaton_value": nb / t_hash, "pass_seconds": [round(x, 4) for x in secs_n], "cpu": cpu_model_name(),
+                       "shared_tables_value": nb / min(secs_shared), "small_pages_value": nb / min(secs_4k), "hash_automaton_value": nb / t_hash, "pass_seconds": [round(x, 4) for x in secs_n], "by_batch_size": by_size, "cpu": cpu_model_name(),
                        "sample": "rank 0's shard of this workload (%d sentences): best of %d passes (the first one apart) on a pool of %d pinned threads that lives for all "
                                  "of them -- a pass is timed from its first worker's start to its last one's end -- into pre-faulted outputs, the char scorer's automaton as a "
                                  "double array (what the reference's matcher is), the tables replicated per NUMA node (%d) on 2 MB pages (madvise); `small_pages_value`: the "
                                  "replicas on 4 KB pages; `shared_tables_value`: the same pool, one copy of the tables; `hash_automaton_value`: one pass with the checker's hash-table automaton, a thread per call; `cache_resident_value`: the "
-                                 "first %d sentences, best of 11 passes; `single_thread_value`: those on 1 thread, best of 2 (C restatement of the reference "
-                                 "algorithm, not the Rust binary)" % (S, len(secs_n) - 1, self.ncores, nodes, n1)}
+                                 "first %d sentences, best of 11 passes; `by_batch_size`: the pool over growing prefixes of the batch; `single_thread_value`: the first %d sentences on 1 thread, "
+                                 "best of 2, before any all-core pass (C restatement of the reference "
+                                 "algorithm, not the Rust binary)" % (S, len(secs_n) - 1, self.ncores, nodes, n1, n1)}
             else:
                 o_scores, o_labels, _, a_char = orc.predict_batch(utf8, boff, nthreads=self.ncores)
             g_scores = d_scores[:nb].cpu().numpy()

@@ -4,7 +4,7 @@
 set -e
 cd "$(dirname "$0")/.."
 mkdir -p tools/prebuilt
-SRC="model.cpp tables.cpp capi.cpp kernels.hip kernels_fast.hip kernels_tags.hip kernels_emit.hip"
+SRC="model.cpp tables.cpp capi.cpp capi_device.cpp capi_host.cpp kernels.hip kernels_fast.hip kernels_tags.hip kernels_emit.hip"
 for V in "$@"; do
   NAME="${V%%:*}"; DEFS="${V#*:}"
   ( cd vaporetto_amd/csrc && /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -Wall -Wno-unused-function $DEFS -o ../../tools/prebuilt/libvaporetto_$NAME.so $SRC ) &

@@ -13,8 +13,8 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB_DIR = os.path.join(HERE, "lib")
 LIB_PATH = os.path.join(LIB_DIR, "libvaporetto_hip.so")
-SOURCES = ["model.cpp", "tables.cpp", "capi.cpp", "kernels.hip", "kernels_fast.hip", "kernels_tags.hip", "kernels_emit.hip"]
-HEADERS = ["model.hpp", "tables.hpp", "layout.h", "kernels.hpp", "device_common.h", os.path.join("..", "..", "include", "vaporetto_hip.h")]
+SOURCES = ["model.cpp", "tables.cpp", "capi.cpp", "capi_device.cpp", "capi_host.cpp", "kernels.hip", "kernels_fast.hip", "kernels_tags.hip", "kernels_emit.hip"]
+HEADERS = ["model.hpp", "tables.hpp", "layout.h", "kernels.hpp", "device_common.h", "capi_internal.hpp", "patset.hpp", os.path.join("..", "..", "include", "vaporetto_hip.h")]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wall", "-Wno-unused-function"]
 
