@@ -36,6 +36,9 @@
 namespace vpt {
 namespace {
 
+#ifndef VPT_FAST_PAIR_BI
+#define VPT_FAST_PAIR_BI 1                   // the bigram node's halves fetched by lane pairs (A/B builds: -DVPT_FAST_PAIR_BI=0)
+#endif
 constexpr int kQCap = 128;                   // W items per wave
 constexpr uint32_t kQHigh = kQCap - 64;      // replay until one more round of pushes (<= 64) fits
 constexpr int kMCap = 64;                    // M items per wave: one round of pushes (<= 64) always fits an empty stack
@@ -358,6 +361,7 @@ __global__ __launch_bounds__(kThreads, fast_wg(WL)) void score_tiles_fast_kernel
     constexpr uint32_t kPad = G::kPadG, kDump = G::kDump;
     constexpr int kFastCap = G::kCapG, kSymSlots = G::kSymSlots, kPerThread = G::kPerThread;
     constexpr int kNU = pk_uni_fields(WL), kNB = pk_bi_fields(WL), kNT = pk_tri_fields(WL);
+    constexpr bool kPairBi = VPT_FAST_PAIR_BI != 0 && G::kBiQ == 2;   // (row window 3: the 32-byte bigram node)
     VPT_KARG(ScoreParams) P = VPT_KARG_PTR(ScoreParams, P_in);
     const uint32_t dbg = DBG ? P->debug : 0u;
     uint64_t* const prof = DBG ? P->prof : nullptr;
@@ -619,6 +623,8 @@ __global__ __launch_bounds__(kThreads, fast_wg(WL)) void score_tiles_fast_kernel
         for (int q = 0; q < G::kBiQ; ++q) VPT_UNDEF4(nn[q]);
 #pragma unroll
         for (int q = 0; q < G::kUniQ; ++q) un[q] = make_uint4(0, 0, 0, 0);   // (a char of no pattern has a zero row)
+        uint4 pa, pb;   // (kPairBi) the halves of the lane pair's two bigram nodes this lane fetches
+        VPT_UNDEF4(pa); VPT_UNDEF4(pb);
         uint32_t x1 = 0, x2 = 0, x3 = 0;
         uint32_t wide_kinds = 0;   // what this lane's three stages find outside their fields this trip
         if (DBG && do_t) count_reads(prof, 2, t_slot != ~0u);
@@ -631,7 +637,21 @@ __global__ __launch_bounds__(kThreads, fast_wg(WL)) void score_tiles_fast_kernel
             }
         }
         if (do_b) {
-            if (b_key != 0) {
+            if constexpr (kPairBi) {
+                // The two halves of a 32-byte node as ONE request each way: two loads of one lane that miss the vector L1 are two requests to the
+                // L2 -- nothing merges them, and the L1's outstanding misses (some 200 a CU) over their latency are what this phase runs at
+                // (tools/tcp_bench, profiles/r06_j_*: adjacent pairs of 16-byte loads 132 G nodes/s where single ones make 264) -- while two LANES
+                // of one instruction that ask for one line are one request.  So a pair of lanes fetches the even lane's node (a half each), then
+                // the odd lane's, and they swap what they fetched for each other (four DPP moves a half).
+                const uint32_t p_slot = uint32_t(__builtin_amdgcn_mov_dpp(int(b_slot), 0xB1, 0xF, 0xF, true));   // quad_perm [1, 0, 3, 2]: the partner's
+                const bool p_on = __builtin_amdgcn_mov_dpp(int(b_key != 0 ? 1u : 0u), 0xB1, 0xF, 0xF, true) != 0;
+                const bool odd = (lane & 1) != 0;
+                const uint32_t slot_a = odd ? p_slot : b_slot, slot_b = odd ? b_slot : p_slot;
+                const bool on_a = odd ? p_on : b_key != 0, on_b = odd ? b_key != 0 : p_on;
+                const uint32_t half = odd ? 16u : 0u;
+                if (on_a) pa = ld16(kbase, (off_bi + (((dbg & 1u) ? 0u : slot_a) * uint32_t(4 * pk_bi_dw(WL)))) | half);
+                if (on_b) pb = ld16(kbase, (off_bi + (((dbg & 1u) ? 0u : slot_b) * uint32_t(4 * pk_bi_dw(WL)))) | half);
+            } else if (b_key != 0) {
                 const uint32_t a = off_bi + (((dbg & 1u) ? 0u : b_slot) * uint32_t(4 * pk_bi_dw(WL)));
 #pragma unroll
                 for (int q = 0; q < G::kBiQ; ++q) nn[q] = ld16(kbase, a | (16u * uint32_t(q)));
@@ -680,6 +700,15 @@ __global__ __launch_bounds__(kThreads, fast_wg(WL)) void score_tiles_fast_kernel
         // ---- bigram stage of positions s_b: key check, the row, and the address of the trigram node
         t_slot = ~0u;
         if (do_b) {
+            if constexpr (kPairBi) {   // pa: a half of the pair's even node, pb: of its odd node -- the lane's own node is its half and the partner's
+                const bool odd = (lane & 1) != 0;
+                const auto sel = [&](uint32_t a, uint32_t b) { return odd ? b : a; };
+                const auto swp = [&](uint32_t v) { return uint32_t(__builtin_amdgcn_mov_dpp(int(v), 0xB1, 0xF, 0xF, true)); };
+                // the half I fetched for my partner (even: of pb, odd: of pa) goes over; what comes back is the other half of my node
+                const uint32_t ox = swp(sel(pb.x, pa.x)), oy = swp(sel(pb.y, pa.y)), oz = swp(sel(pb.z, pa.z)), ow = swp(sel(pb.w, pa.w));
+                nn[0] = make_uint4(sel(pa.x, ox), sel(pa.y, oy), sel(pa.z, oz), sel(pa.w, ow));   // first half: the even lane's own, the odd lane's from its partner
+                nn[1] = make_uint4(sel(ox, pb.x), sel(oy, pb.y), sel(oz, pb.z), sel(ow, pb.w));
+            }
             uint32_t nd[4 * G::kBiQ + 1];
             unpack4(nn, nd);
             const bool keyok = b_key != 0 && nd[pk_bi_key_dw(WL)] == b_key;
