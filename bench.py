@@ -486,6 +486,19 @@ class Runner:
                 c_out = orc.predict_batch(*sub, nthreads=1)[:3]
                 secs_1, _, _ = orc.baseline_timed(*sub, c_out, nthreads=1, reps=3, replicate=False)
                 t1 = min(secs_1[1:])
+                # ... and on a sample that is NOT cache-resident (the first million sentences, one pass after a warm-up over a tenth of them): the
+                # regime the whole batch runs in -- the automaton walk is a chain of dependent loads, and past a few hundred thousand sentences the
+                # states they visit no longer fit the caches (by_batch_size below)
+                single_big = None
+                if S >= 2_000_000:
+                    n_big = 1_000_000
+                    sub_b = (utf8[:int(boff[n_big])], boff[:n_big + 1])
+                    b_out = orc.predict_batch(utf8[:int(boff[n_big // 10])], boff[:n_big // 10 + 1], nthreads=1)[:3]
+                    del b_out
+                    b_out = (np.zeros(int(ooff[n_big]), np.int32), np.zeros(int(ooff[n_big]), np.uint8), ooff[:n_big + 1].copy())
+                    secs_b, _, _ = orc.baseline_timed(*sub_b, b_out, nthreads=1, reps=1, replicate=False)
+                    single_big = int(ooff[n_big]) / secs_b[0]
+                    del b_out
                 o_scores, o_labels, o_ooff, a_char = orc.predict_batch(utf8, boff, nthreads=self.ncores)
                 t = time.perf_counter()
                 orc.predict_batch(utf8, boff, nthreads=self.ncores, out=(o_scores, o_labels, o_ooff), pin=True)
@@ -513,14 +526,15 @@ class Runner:
                     by_size.append({"sentences": n_k, "value": int(ooff[n_k]) / min(secs_k[1:])})
                 by_size.append({"sentences": S, "value": nb / tn})
                 cpu = {"value": nb / tn, "unit": "boundaries/s", "cores": self.ncores, "kind": "port", "numa_nodes": nodes,
-                       "single_thread_value": nb1 / t1, "scaling_vs_one_thread": (nb / tn) / (nb1 / t1), "cache_resident_value": nb1 / tc,
+                       "single_thread_value": nb1 / t1, "scaling_vs_one_thread": (nb / tn) / (nb1 / t1),
+                       "single_thread_memory_resident_value": single_big, "scaling_vs_one_thread_memory_resident": ((nb / tn) / single_big) if single_big else None, "cache_resident_value": nb1 / tc,
                        "shared_tables_value": nb / min(secs_shared), "small_pages_value": nb / min(secs_4k), "hash_automaton_value": nb / t_hash, "pass_seconds": [round(x, 4) for x in secs_n], "by_batch_size": by_size, "cpu": cpu_model_name(),
                        "sample": "rank 0's shard of this workload (%d sentences): best of %d passes (the first one apart) on a pool of %d pinned threads that lives for all "
                                  "of them -- a pass is timed from its first worker's start to its last one's end -- into pre-faulted outputs, the char scorer's automaton as a "
                                  "double array (what the reference's matcher is), the tables replicated per NUMA node (%d) on 2 MB pages (madvise); `small_pages_value`: the "
                                  "replicas on 4 KB pages; `shared_tables_value`: the same pool, one copy of the tables; `hash_automaton_value`: one pass with the checker's hash-table automaton, a thread per call; `cache_resident_value`: the "
                                  "first %d sentences, best of 11 passes; `by_batch_size`: the pool over growing prefixes of the batch; `single_thread_value`: the first %d sentences on 1 thread, "
-                                 "best of 2, before any all-core pass (C restatement of the reference "
+                                 "best of 2, before any all-core pass; `single_thread_memory_resident_value`: the first million sentences once on 1 thread (C restatement of the reference "
                                  "algorithm, not the Rust binary)" % (S, len(secs_n) - 1, self.ncores, nodes, n1, n1)}
             else:
                 o_scores, o_labels, _, a_char = orc.predict_batch(utf8, boff, nthreads=self.ncores)
@@ -662,7 +676,7 @@ class Runner:
                          "traffic": measured_traffic(kernel_name, model_name, cfg["name"]) if self.world == 1 and not self.args.sentences else None,
                          "algorithmic_bytes_per_launch": a, "bytes_per_boundary": a / max(nb, 1),
                          "a_stream": a_stream, "a_char": a_char, "a_type": a_type})
-        if self.world == 1 and kernel_name == "score_tiles_fast_kernel":
+        if self.world == 1 and kernel_name == "score_tiles_fast_kernel" and not args.no_cpu_baseline:   # (profiling runs: no second instance of the kernel in the counters)
             node_reads = None
             try:   # a diagnostics launch of the same batch counts the node reads (untimed; the instance that counts is slower)
                 os.environ["VPT_PROFILE_PHASES"] = "1"

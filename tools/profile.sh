@@ -48,7 +48,7 @@ line = None
 for l in open(os.path.join(out, "trace.log")):
     if l.startswith("{"): line = json.loads(l)
 for k, v in agg.items():
-    if "score_tiles" not in k or "TCC_EA0_RDREQ_128B_sum" not in v or "WRITE_SIZE" not in v: continue
+    if "score_tiles" not in k or ", true>" in k or "TCC_EA0_RDREQ_128B_sum" not in v or "WRITE_SIZE" not in v: continue   # (", true>": the diagnostics instance that counts node reads)
     avg = lambda c: sum(v[c]) / len(v[c]) if c in v else 0.0
     entry = {"round": sys.argv[1], "kernel": line["roofline"]["kernel"] if line else "score_tiles_fast_kernel",
              "model": line["config"]["tokenizer_model"] if line else None, "workload": line["config"]["workload"].split(":")[0] if line else None,
