@@ -361,7 +361,9 @@ __global__ __launch_bounds__(kThreads, fast_wg(WL)) void score_tiles_fast_kernel
     constexpr uint32_t kPad = G::kPadG, kDump = G::kDump;
     constexpr int kFastCap = G::kCapG, kSymSlots = G::kSymSlots, kPerThread = G::kPerThread;
     constexpr int kNU = pk_uni_fields(WL), kNB = pk_bi_fields(WL), kNT = pk_tri_fields(WL);
-    constexpr bool kPairBi = VPT_FAST_PAIR_BI != 0 && G::kBiQ == 2;   // (row window 3: the 32-byte bigram node)
+    // (row window 3: the 32-byte bigram node.  The same for the 64-byte nodes of windows 4 .. 8 -- two requests a node instead of three or four, at the
+    // price of a fourth load instruction per lane -- measured equal on charw4, 0.1250 against 0.1247 ms, profiles/r06_n_*: not kept)
+    constexpr bool kPairBi = VPT_FAST_PAIR_BI != 0 && G::kBiQ == 2;
     VPT_KARG(ScoreParams) P = VPT_KARG_PTR(ScoreParams, P_in);
     const uint32_t dbg = DBG ? P->debug : 0u;
     uint64_t* const prof = DBG ? P->prof : nullptr;
