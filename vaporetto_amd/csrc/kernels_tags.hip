@@ -383,6 +383,8 @@ __device__ __forceinline__ void tag_pass(const TagParams& P, TagWaveLds& L, uint
     if (uint32_t(lane) == nq) L.f.pref[nq] = total;
     __builtin_amdgcn_wave_barrier();
     uint32_t n_acc = 0;   // matches waiting in mlist
+    // (the rounds software-pipelined -- the records of round r + 1 asked for before round r is compared -- changed nothing: 0.2551 against 0.2569 ms
+    // on configs[4], profiles/r06_p_*; by its instruction counts the launch is nearer its vector ALUs' limit than its trips')
     for (uint32_t r0 = 0; r0 < total; r0 += 64) {
         const uint32_t pi = r0 + uint32_t(lane);
         const bool have = pi < total;
@@ -908,6 +910,7 @@ hipError_t launch_decode_chars(const uint8_t* text, const uint64_t* boff, const 
                                const uint32_t* cinfo, uint32_t* cps, uint8_t* types, uint32_t* status, hipStream_t stream) {
     // sentences per workgroup: about 16 K chars (4 pieces of CJK text and more; a char is at least a byte, so the chars bound the bytes from
     // below), at most one per thread
+    // (4 K / 8 K / 32 K chars measured the same, profiles/r06_o_*: the launch runs at the rate of its char-table gathers, one L1 miss a char)
     const uint64_t per = std::min<uint64_t>(std::max<uint64_t>((uint64_t(16384) * n_sent + total_chars / 2) / std::max<uint64_t>(total_chars, 1), 1), kTagThreads);
     const uint64_t blocks = (n_sent + per - 1) / per;
     hipLaunchKernelGGL(decode_chars_kernel, dim3(uint32_t(blocks)), dim3(kTagThreads), 0, stream, text, boff, ooff, n_sent, total_chars, cinfo, cps,
