@@ -131,3 +131,24 @@ def test_dry_scale_of_the_tagged_ragged_workload_at_four_ranks():
     assert all("configs[4]" in l["config"]["workload"] for l in lines) and lines[1]["tags"]["parity"] is True
     chars = [pr["chars"] for pr in lines[1]["per_rank"]]
     assert len(chars) == 4 and max(chars) - min(chars) <= 2 * 512, chars
+
+
+def test_the_gather_block_of_the_line():
+    """roofline.gather: lane loads from the node reads of a diagnostics launch, tools/tcp_bench's rates from profiles/, and -- with a
+    PMC entry for the sources -- every level's requests per second over the rate the microbenchmark measured for it; the largest share binds."""
+    sys.path.insert(0, ROOT)
+    import bench
+    rates = bench.gather_rates()
+    assert rates and set(rates) == {"l1", "l2", "hbm"} and rates["l1"] > rates["l2"] > rates["hbm"] > 0      # profiles/r06_j_tcp_bench.jsonl
+    reads = {"unigram_nodes": 1000, "bigram_nodes": 900, "trigram_nodes": 400, "deep_entries": 200, "deep_rows": 50, "global_type_rows": 0}
+    g = bench.gather_block(None, reads, chars=1100, wl=3, kernel_ms=0.001)
+    assert g["lane_loads_per_launch"] == 1000 + 2 * 900 + 400 + 200 + 50 + 1100 and "frac" not in g and g["microbench_Glanes_s"] == rates
+    assert abs(g["achieved_Glanes_s"] - g["lane_loads_per_launch"] / 1e-6 / 1e9) < 1e-9
+    wide = bench.gather_block(None, reads, chars=0, wl=4, kernel_ms=0.001)
+    assert wide["lane_loads_per_launch"] == 2 * 1000 + 4 * 900 + 2 * 400 + 200 + 50                               # 32- / 64- / 32-byte nodes at row window 4
+    entry = {"tcp_lookups": 3.0e9, "tcp_tcc_read_req": 1.1e9, "tcc_miss": 3.3e8, "tcp_busy_cycles": 9.0e8, "tcp_cycles": 1.0e9}
+    g = bench.gather_block(entry, reads, chars=0, wl=3, kernel_ms=9.0)
+    t = 9.0e-3
+    want = {"l1": 3.0e9 / t / 1e9 / rates["l1"], "l2": 1.1e9 / t / 1e9 / rates["l2"], "hbm": 3.3e8 / t / 1e9 / rates["hbm"]}
+    assert g["bound"] == max(want, key=want.get) and abs(g["frac"] - max(want.values())) < 1e-3 and abs(g["pmc"]["tcp_busy_share"] - 0.9) < 1e-9
+    assert bench.gather_block(entry, reads, 0, 3, None) is None

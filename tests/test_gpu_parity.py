@@ -2015,3 +2015,14 @@ def test_char_types_from_the_device():
     fw = api.KyteaFullwidthFilter()
     want_fw = np.concatenate([api.Sentence.from_raw(fw.filter(t)).char_types() for t in texts])
     assert np.array_equal(got_fw, want_fw)
+    # every scalar value of the BMP (and a few planes above): the decode kernel computes a char's type itself and asks the char table only where
+    # KyteaFullwidthFilter can rewrite it (round 6) -- both against CharacterType::get_type (sentence.rs:50-67) of the plain / the filtered char
+    cps = [c for c in range(1, 0x10000) if not 0xD800 <= c <= 0xDFFF] + [0x10000, 0x1F600, 0x20000, 0x2A6DF, 0x2A6E0, 0x2B740, 0x2CEAF, 0x2F800, 0x2FA1F, 0x2FA20, 0x10FFFF]
+    texts = ["".join(chr(c) for c in cps[i:i + 500]) for i in range(0, len(cps), 500)]
+    utf8, boff = api.pack_texts([t.encode("utf-8") for t in texts])
+    ooff = api.count_boundaries(utf8, boff)
+    want = np.array([int(api.CharacterType.get_type(chr(c))) for c in cps], dtype=np.uint8)
+    assert np.array_equal(pred.char_types_packed(utf8, boff, ooff), want)
+    table = fw.table()
+    want_fw = np.array([int(api.CharacterType.get_type(chr(table.get(c, c)))) for c in cps], dtype=np.uint8)
+    assert np.array_equal(pred.char_types_packed(utf8, boff, ooff, fullwidth=True), want_fw)

@@ -139,6 +139,9 @@ vpt_status vpt_predictor_create(const uint8_t* model_bytes, size_t len, int pred
     for (uint32_t cp = 0; cp < 65536; ++cp) {
         cinfo[cp] = cp | (uint32_t(vpt::char_type_host(cp)) << 16);
         const uint32_t fw = vpt::kytea_fullwidth_host(cp);
+        // (decode_chars_kernel reads the table only where the filter can differ from the identity: every char it rewrites lies in these ranges)
+        if (fw != cp && !(cp < 0x80u || (cp - 0x2000u) < 0x600u || (cp - 0xFF00u) < 0xF0u))
+            return fail(VPT_RUNTIME_ERROR, "internal error: KyteaFullwidthFilter rewrites a char outside the ranges the decode kernel looks up");
         cinfo[65536 + cp] = fw | (uint32_t(vpt::char_type_host(fw)) << 16);
         ctype[cp] = vpt::char_type_host(cp);
     }

@@ -262,7 +262,7 @@ vpt_status vpt_fill_tags_scores_batch_device(const vpt_predictor* p, vpt_batch* 
                           b->cps_boundaries == total_boundaries && b->cps_flags == (b->flags & VPT_FLAG_KYTEA_FULLWIDTH) && b->last_stream == stream;
     b->cps_text = nullptr;   // one shot: only the fill_tags call that FOLLOWS the predict call takes its chars (predictor.rs:542)
     if (!have_cps) {
-        VPT_HIP(vpt::launch_decode_chars(d_utf8, d_byte_offsets, d_out_offsets, n_sentences, total_c, cinfo, b->d_cps, nullptr, b->d_ctrl, stream));
+        VPT_HIP(vpt::launch_decode_chars(d_utf8, d_byte_offsets, d_out_offsets, n_sentences, total_c, cinfo, b->d_cps, nullptr, b->d_ctrl, stream, (b->flags & VPT_FLAG_KYTEA_FULLWIDTH) != 0));
     }
     vpt::TagParams T{};
     T.tok_tab = p->dtag.tok_tab; T.models = p->dtag.models; T.mfilt = p->dtag.mfilt; T.ngrams = p->dtag.ngrams; T.nrec = p->dtag.nrec; T.syms = p->dtag.syms; T.slots = p->dtag.slots;
@@ -412,7 +412,7 @@ vpt_status vpt_char_types_batch_device(const vpt_predictor* p, vpt_batch* b, con
     VPT_HIP(hipSetDevice(p->device));
     const uint32_t* cinfo = p->d_cinfo + ((b->flags & VPT_FLAG_KYTEA_FULLWIDTH) ? 65536 : 0);
     VPT_HIP(vpt::launch_decode_chars(d_utf8, d_byte_offsets, d_out_offsets, n_sentences, total_boundaries + n_sentences, cinfo, nullptr, d_types_out,
-                                     b->d_ctrl, stream));
+                                     b->d_ctrl, stream, (b->flags & VPT_FLAG_KYTEA_FULLWIDTH) != 0));
     b->last_stream = stream; b->pending = true; b->cps_text = nullptr;
     return VPT_OK;
 }

@@ -159,8 +159,9 @@ struct TagParams {
 // sentences of a front-end run for a batch of this shape (about VPT_TAG_RUN_CHARS chars, at most 256 sentences); words of TagParams::summary
 uint32_t tag_run_sentences(uint64_t n_sent, uint64_t total_chars);
 size_t tag_summary_words();
+// `fullwidth`: cinfo is the table that looks through KyteaFullwidthFilter (else the identity: no word of it is read)
 hipError_t launch_decode_chars(const uint8_t* text, const uint64_t* boff, const uint64_t* ooff, uint64_t n_sent, uint64_t total_chars,
-                               const uint32_t* cinfo, uint32_t* cps, uint8_t* types, uint32_t* status, hipStream_t stream);
+                               const uint32_t* cinfo, uint32_t* cps, uint8_t* types, uint32_t* status, hipStream_t stream, bool fullwidth);
 hipError_t launch_tag_tokens(const TagParams& P, hipStream_t stream);
 
 // token emission (kernels_emit.hip): Sentence::write_tokenized_text, boundary part

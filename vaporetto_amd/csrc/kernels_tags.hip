@@ -84,7 +84,7 @@ constexpr uint32_t kDecodePiece = kTagThreads * 16;
 __global__ __launch_bounds__(kTagThreads) void decode_chars_kernel(const uint8_t* __restrict__ text, const uint64_t* __restrict__ boff,
                                                                    const uint64_t* __restrict__ ooff, uint64_t n_sent, uint64_t total_chars,
                                                                    const uint32_t* __restrict__ cinfo, uint32_t* __restrict__ cps,
-                                                                   uint8_t* __restrict__ types, uint32_t* __restrict__ status, uint32_t per_block) {
+                                                                   uint8_t* __restrict__ types, uint32_t* __restrict__ status, uint32_t per_block, uint32_t fullwidth) {
     __shared__ uint16_t masks[kTagThreads];   // lead mask of every 16-byte chunk of the piece
     __shared__ uint32_t pfx[kTagThreads];     // leads of the piece in front of the chunk
     __shared__ uint32_t wtot[kTagWaves];
@@ -145,10 +145,16 @@ __global__ __launch_bounds__(kTagThreads) void decode_chars_kernel(const uint8_t
                 m &= m - 1u;
                 const uint32_t w = __builtin_amdgcn_alignbyte(d[q + 1], d[q], k);
                 const uint32_t cp = utf8_scalar(w);
-                const uint32_t info = cp < 0x10000u ? cinfo[cp] : 0u;   // the scored char | its CharacterType << 16 (BMP only)
-                const uint32_t ty = cp < 0x10000u ? info >> 16 : char_type(cp);
+                // the char it is scored as | its CharacterType: a word of the char table -- asked for only where the table can differ from the
+                // identity (with KyteaFullwidthFilter: ASCII, U+2000 .. 25FF, U+FF00 .. FFEF hold every char the filter rewrites,
+                // kytea_fullwidth.rs:13-117); anything else is itself and its type is arithmetic.  A gather per char -- one miss of the vector
+                // L1 each -- was what the launch ran at (0.47 ms on configs[4], profiles/r06_o_*).
+                const bool mapped = fullwidth && cp < 0x10000u && (cp < 0x80u || (cp - 0x2000u) < 0x600u || (cp - 0xFF00u) < 0xF0u);
+                uint32_t scored = cp, ty;
+                if (mapped) { const uint32_t info = cinfo[cp]; scored = info & 0xFFFFu; ty = info >> 16; }
+                else ty = char_type(cp);
                 if (dest < total_chars) {
-                    if (cps) cps[dest] = (cp < 0x10000u ? info & 0xFFFFu : cp) | (ty << 24);
+                    if (cps) cps[dest] = scored | (ty << 24);
                     if (types) types[dest] = uint8_t(ty);   // Sentence::char_types (sentence.rs:1016)
                 }
                 ++dest;
@@ -907,14 +913,14 @@ __global__ __launch_bounds__(kFlatThreads, VPT_TAG_FLAT_OCC) void tag_front_flat
 }  // namespace
 
 hipError_t launch_decode_chars(const uint8_t* text, const uint64_t* boff, const uint64_t* ooff, uint64_t n_sent, uint64_t total_chars,
-                               const uint32_t* cinfo, uint32_t* cps, uint8_t* types, uint32_t* status, hipStream_t stream) {
+                               const uint32_t* cinfo, uint32_t* cps, uint8_t* types, uint32_t* status, hipStream_t stream, bool fullwidth) {
     // sentences per workgroup: about 16 K chars (4 pieces of CJK text and more; a char is at least a byte, so the chars bound the bytes from
     // below), at most one per thread
     // (4 K / 8 K / 32 K chars measured the same, profiles/r06_o_*: the launch runs at the rate of its char-table gathers, one L1 miss a char)
     const uint64_t per = std::min<uint64_t>(std::max<uint64_t>((uint64_t(16384) * n_sent + total_chars / 2) / std::max<uint64_t>(total_chars, 1), 1), kTagThreads);
     const uint64_t blocks = (n_sent + per - 1) / per;
     hipLaunchKernelGGL(decode_chars_kernel, dim3(uint32_t(blocks)), dim3(kTagThreads), 0, stream, text, boff, ooff, n_sent, total_chars, cinfo, cps,
-                       types, status, uint32_t(per));
+                       types, status, uint32_t(per), fullwidth ? 1u : 0u);
     return hipGetLastError();
 }
 
