@@ -178,6 +178,11 @@ static inline uint32_t hipemu_alignbyte(uint32_t hi, uint32_t lo, uint32_t sh) {
 static inline uint32_t hipemu_alignbit(uint32_t hi, uint32_t lo, uint32_t sh) {
     return uint32_t(((uint64_t(hi) << 32) | lo) >> (sh & 31u));
 }
+static inline uint32_t hipemu_udot4(uint32_t a, uint32_t b, uint32_t c) {   // v_dot4_u32_u8 (no clamp)
+    for (int k = 0; k < 4; ++k) c += ((a >> (8 * k)) & 0xFFu) * ((b >> (8 * k)) & 0xFFu);
+    return c;
+}
+#define __builtin_amdgcn_udot4(a, b, c, clamp) hipemu_udot4((a), (b), (c))
 #define __builtin_amdgcn_alignbyte(hi, lo, sh) hipemu_alignbyte((hi), (lo), (sh))
 #define __builtin_amdgcn_alignbit(hi, lo, sh) hipemu_alignbit((hi), (lo), (sh))
 // a wave-uniform 64-bit mask as a lane predicate (the mask goes to EXEC / VCC as it is)

@@ -25,6 +25,7 @@ def main():
     ap.add_argument("--configs", default="1,2")
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--no-parity", action="store_true")
+    ap.add_argument("--per-block", default="0", help="comma list: sentences per run (VPT_EMIT_PER_BLOCK; 0: what the library takes)")
     args = ap.parse_args()
     import torch
     import bench
@@ -45,7 +46,8 @@ def main():
         max_bytes = int(np.max(np.diff(boff.astype(np.int64))))
         max_chars = int(np.max(np.diff(ooff.astype(np.int64)))) + 1
         want = None
-        for v in args.variants.split(","):
+        for v, pb in [(v, pb) for v in args.variants.split(",") for pb in args.per_block.split(",")]:
+            os.environ["VPT_EMIT_PER_BLOCK"] = pb
             L = C.CDLL(lib_path(v))
             for fn, (res, a) in _lib.SIGNATURES.items():
                 f = getattr(L, fn)
@@ -77,7 +79,7 @@ def main():
             toff = d_toff.cpu().numpy().astype(np.uint64)
             out_bytes = int(toff[-1])
             moved = nbytes + nb + out_bytes + 16 * S
-            row = {"variant": v, "workload": cfg["name"], "model": name, "ms": round(ms, 4), "GBps": round(moved / ms / 1e6, 1), "frac_of_hbm": round(moved / ms / 1e6 / 8000.0, 4),
+            row = {"variant": v, "per_block": int(pb), "workload": cfg["name"], "model": name, "ms": round(ms, 4), "GBps": round(moved / ms / 1e6, 1), "frac_of_hbm": round(moved / ms / 1e6 / 8000.0, 4),
                    "bytes_moved": moved, "out_bytes": out_bytes}
             if not args.no_parity:
                 if want is None:   # (the labels are the same for every library: the scoring kernel is checked elsewhere)

@@ -155,6 +155,13 @@ __device__ __forceinline__ uint32_t load4(const uint8_t* __restrict__ p, uint64_
     return nv == 4u ? x : x & ((1u << (8u * nv)) - 1u);
 }
 
+// values the compiler must take as new at this point (no common subexpressions with what was computed from them before, nothing hoisted across)
+#ifdef VPT_HIPEMU
+#define VPT_OPAQUE3(a, b, c) ((void)0)
+#else
+#define VPT_OPAQUE3(a, b, c) asm volatile("" : "+v"(a), "+v"(b), "+v"(c))
+#endif
+
 // bits 7, 15, 23, 31 -> bits 0..3.  Bits 7, 15, 23 travel to bits 21, 22, 23 of a 24-bit product (0x4081 = bits 0, 7, 14: the nine
 // partial products fall on nine different bits) -- a full-rate v_mul_u32_u24, where the 32-bit multiply this used to be (v_mul_lo_u32)
 // takes four issue slots and every chunk of text needs eight of them -- and bit 31 is placed by hand.
@@ -162,16 +169,32 @@ __device__ __forceinline__ uint32_t byte_flags_to_nibble(uint32_t m) {
     return ((((m & 0x00808080u) * 0x4081u) >> 21) & 7u) | ((m >> 31) << 3);
 }
 // 4-bit mask of the bytes of x that are NOT UTF-8 continuation bytes (10xxxxxx): bit 7 clear or bit 6 set
-__device__ __forceinline__ uint32_t lead_nibble(uint32_t x) { return byte_flags_to_nibble((~x | (x << 1)) & 0x80808080u); }
+__device__ __forceinline__ uint32_t lead_flags(uint32_t x) { return (~x | (x << 1)) & 0x80808080u; }   // 0x80 in every such byte
+__device__ __forceinline__ uint32_t lead_nibble(uint32_t x) { return byte_flags_to_nibble(lead_flags(x)); }
+// Sixteen byte flags (0x80 or 0 in every byte of four dwords) -> a 16-bit mask, byte k of the sixteen -> bit k.  v_dot4_u32_u8 weighs a dword's four
+// bytes in one issue slot (round 6: the writer was found to run at the vector ALU's issue rate, and a third of its instructions gathered flag bits
+// nibble by nibble -- byte_flags_to_nibble above, five slots a dword and three more to join the nibbles); a flag byte adds 0x80 x its weight.
+__device__ __forceinline__ uint32_t flag_bytes_to_mask16(uint32_t f0, uint32_t f1, uint32_t f2, uint32_t f3) {
+    uint32_t lo = __builtin_amdgcn_udot4(f0, 0x08040201u, 0u, false), hi = __builtin_amdgcn_udot4(f2, 0x08040201u, 0u, false);
+    lo = __builtin_amdgcn_udot4(f1, 0x80402010u, lo, false);
+    hi = __builtin_amdgcn_udot4(f3, 0x80402010u, hi, false);
+    return (lo + (hi << 8)) >> 7;
+}
 // 16-bit mask over the 16 bytes of v
-__device__ __forceinline__ uint32_t lead_mask16(const uint4& v) { return lead_nibble(v.x) | (lead_nibble(v.y) << 4) | (lead_nibble(v.z) << 8) | (lead_nibble(v.w) << 12); }
+__device__ __forceinline__ uint32_t lead_mask16(const uint4& v) { return flag_bytes_to_mask16(lead_flags(v.x), lead_flags(v.y), lead_flags(v.z), lead_flags(v.w)); }
 
 // 0x80 in every byte of v that is zero (exact: no carries between the bytes)
 __device__ __forceinline__ uint32_t zero_bytes(uint32_t v) { return ~(((v & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | v | 0x7F7F7F7Fu); }
-// 4-bit mask of the bytes of x that Sentence::write_tokenized_text escapes: ' ', '\', '/' (sentence.rs:850-886)
-__device__ __forceinline__ uint32_t esc_nibble(uint32_t x) {
-    return byte_flags_to_nibble(zero_bytes(x ^ 0x20202020u) | zero_bytes(x ^ 0x5C5C5C5Cu) | zero_bytes(x ^ 0x2F2F2F2Fu));
+__device__ __forceinline__ uint32_t zero_mask16(const uint4& v) { return flag_bytes_to_mask16(zero_bytes(v.x), zero_bytes(v.y), zero_bytes(v.z), zero_bytes(v.w)); }
+// 0x80 in the bytes of x that Sentence::write_tokenized_text escapes: ' ', '\', '/' (sentence.rs:850-886).  All three are below 0x80: the low
+// seven bits are compared (x7 ^ c is at most 0x7F: adding 0x7F sets bit 7 unless it is zero, and carries nowhere), bit 7 of x itself must be clear
+__device__ __forceinline__ uint32_t esc_flags(uint32_t x) {
+    const uint32_t x7 = x & 0x7F7F7F7Fu;
+    const uint32_t a = (x7 ^ 0x20202020u) + 0x7F7F7F7Fu, b = (x7 ^ 0x5C5C5C5Cu) + 0x7F7F7F7Fu, c = (x7 ^ 0x2F2F2F2Fu) + 0x7F7F7F7Fu;
+    return ~((a & b & c) | x) & 0x80808080u;
 }
+__device__ __forceinline__ uint32_t esc_nibble(uint32_t x) { return byte_flags_to_nibble(esc_flags(x)); }
+__device__ __forceinline__ uint32_t esc_mask16(const uint4& v) { return flag_bytes_to_mask16(esc_flags(v.x), esc_flags(v.y), esc_flags(v.z), esc_flags(v.w)); }
 
 // scalar value of the UTF-8 sequence whose four bytes (lead first) are packed little-endian in b4
 __device__ __forceinline__ uint32_t utf8_scalar(uint32_t b4) {

@@ -209,7 +209,7 @@ __device__ __forceinline__ void process_tile(const ScoreParams& P, const TileMem
             const uint64_t rem = nbytes_al - pos0;
             const uint32_t hi = rem < 16 ? uint32_t(rem) : 16u;
             const uint32_t vm = ((1u << hi) - 1u) & ~((1u << lo) - 1u);
-            lm = (lead_nibble(w[0]) | (lead_nibble(w[1]) << 4) | (lead_nibble(w[2]) << 8) | (lead_nibble(w[3]) << 12)) & vm;
+            lm = flag_bytes_to_mask16(lead_flags(w[0]), lead_flags(w[1]), lead_flags(w[2]), lead_flags(w[3])) & vm;
             if (kLds) sm = (bitmap[pos0 >> 5] >> (pos0 & 31)) & 0xFFFFu;
             else sm = (pos0 <= head && head < pos0 + 16) ? (1u << (head - uint32_t(pos0))) : 0u;
         }

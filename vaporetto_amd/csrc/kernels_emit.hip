@@ -16,6 +16,7 @@
 
 #include "device_common.h"
 #include "kernels.hpp"
+#include <type_traits>
 
 namespace vpt {
 namespace {
@@ -166,12 +167,12 @@ namespace {
 // read, and a thread asks the marks of its chars -- where rounds 4 - 5 read a dense token word per char from HBM, twice, for one
 // token in thirty-five that had tags.
 // ------------------------------------------------------------------------------------------------------------
-__device__ __forceinline__ uint32_t lead16(const uint4& x) { return lead_nibble(x.x) | (lead_nibble(x.y) << 4) | (lead_nibble(x.z) << 8) | (lead_nibble(x.w) << 12); }
-__device__ __forceinline__ uint32_t esc16(const uint4& x) { return esc_nibble(x.x) | (esc_nibble(x.y) << 4) | (esc_nibble(x.z) << 8) | (esc_nibble(x.w) << 12); }
-__device__ __forceinline__ uint32_t one_nibble(uint32_t y) { return byte_flags_to_nibble(zero_bytes(y ^ 0x01010101u)); }   // bytes equal to 1
-__device__ __forceinline__ uint32_t one16(const uint4& y) { return one_nibble(y.x) | (one_nibble(y.y) << 4) | (one_nibble(y.z) << 8) | (one_nibble(y.w) << 12); }
-__device__ __forceinline__ uint32_t unk_nibble(uint32_t y) { return byte_flags_to_nibble(~zero_bytes(y & 0xFEFEFEFEu) & 0x80808080u); }   // bytes above 1
-__device__ __forceinline__ uint32_t unk16(const uint4& y) { return unk_nibble(y.x) | (unk_nibble(y.y) << 4) | (unk_nibble(y.z) << 8) | (unk_nibble(y.w) << 12); }
+__device__ __forceinline__ uint32_t lead16(const uint4& x) { return lead_mask16(x); }
+__device__ __forceinline__ uint32_t esc16(const uint4& x) { return esc_mask16(x); }
+__device__ __forceinline__ uint32_t one_flags(uint32_t y) { return zero_bytes(y ^ 0x01010101u); }   // bytes equal to 1
+__device__ __forceinline__ uint32_t one16(const uint4& y) { return flag_bytes_to_mask16(one_flags(y.x), one_flags(y.y), one_flags(y.z), one_flags(y.w)); }
+__device__ __forceinline__ uint32_t unk_flags(uint32_t y) { return ~zero_bytes(y & 0xFEFEFEFEu) & 0x80808080u; }   // bytes above 1
+__device__ __forceinline__ uint32_t unk16(const uint4& y) { return flag_bytes_to_mask16(unk_flags(y.x), unk_flags(y.y), unk_flags(y.z), unk_flags(y.w)); }
 // which of the 16 bytes at `addr` lie in [lo, hi)
 __device__ __forceinline__ uint32_t in_range16(uintptr_t addr, uintptr_t lo, uintptr_t hi) {
     const uint32_t a = lo > addr ? (lo - addr < 16 ? uint32_t(lo - addr) : 16u) : 0u;
@@ -230,11 +231,48 @@ __device__ __forceinline__ uint32_t flat_block_scan(uint32_t x, uint32_t* wtot, 
     return woff + incl - x;
 }
 
+// The chain of the runs' positions (one word per run: flag << 62 | value; 1: the run's size, 2: the position behind it).  A run's size is
+// published as soon as it is known; the WAVE that calls place_run walks back over the earlier runs' words, 64 per trip, until one holds a
+// position, publishes the run's own and returns where the run starts.
+__device__ __forceinline__ void publish_run_size(const EmitFuse& F, uint64_t blk, uint64_t size) {
+    __hip_atomic_store(F.state + blk, (uint64_t(1) << 62) | size, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ uint64_t place_run(const EmitFuse& F, uint64_t blk, uint64_t size, uint32_t lane) {
+    constexpr uint64_t kVal = (uint64_t(1) << 62) - 1;
+    const uint64_t start = (F.chain_in ? *F.chain_in : 0ull) & kVal;   // where the call's text starts (a call chained behind another: EmitFuse)
+    uint64_t base = 0;
+    bool anchored = false;   // the sum has reached a run whose position is known (or the front's sentinel): it holds `start`
+    for (uint64_t p = blk; p > 0;) {
+        const bool have = uint64_t(lane) < p;
+        uint64_t w = (uint64_t(2) << 62) | start;   // in front of run 0
+        if (have) w = __hip_atomic_load(F.state + (p - 1 - uint64_t(lane)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const uint64_t pending = __ballot((w >> 62) == 0), prefixed = __ballot((w >> 62) == 2);
+        const int first = prefixed ? __ffsll((long long)prefixed) - 1 : 64;   // the nearest run whose position is known
+        const uint64_t need = first < 63 ? (uint64_t(2) << first) - 1 : ~uint64_t(0);
+        if (pending & need) { __builtin_amdgcn_s_sleep(2); continue; }         // not all published yet: look again
+        base += wave_sum64(int(lane) <= first ? (w & kVal) : 0);
+        if (first < 64) { anchored = true; break; }
+        p -= 64;
+    }
+    // run 0, or a walk that ran off the front exactly at a multiple of 64 runs with none of them placed yet (then no lane held the sentinel:
+    // found on MI355X by the chained chunks of vpt_tokenize_batch with one-sentence runs -- a misplaced run's text landed in an earlier chunk's)
+    if (!anchored) base += start;
+    if (lane == 0) {
+#ifndef VPT_EMIT_NO_PREFIX   // (test builds, tests/test_kernel_emu.py: the runs publish their sizes only, so every look-back walks to the launch's front)
+        __hip_atomic_store(F.state + blk, (uint64_t(2) << 62) | ((base + size) & kVal), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#endif
+    }
+    return base;
+}
+
 #ifndef VPT_EMIT_TAG_OCC
 #define VPT_EMIT_TAG_OCC 4   // waves per SIMD the tagged instance is compiled for at least (A/B builds: -D; 1: what the compiler takes by itself -- 140 VGPRs, 3 waves: 1.54 ms on configs[4] against 1.37 at 4, profiles/r06_g_*)
 #endif
+#ifndef VPT_EMIT_OCC
+#define VPT_EMIT_OCC 8    // ... and the instance without tags
+#endif
 template <bool kTags>
-__global__ __launch_bounds__(kEmitThreads, kTags ? VPT_EMIT_TAG_OCC : 1) void emit_flat_kernel(const EmitParams P, const EmitFuse F) {
+__global__ __launch_bounds__(kEmitThreads, kTags ? VPT_EMIT_TAG_OCC : VPT_EMIT_OCC) void emit_flat_kernel(const EmitParams P, const EmitFuse F) {
     __shared__ FlatLds L;
     __shared__ FlatMarks MK[1];   // (with tags; the instance without never touches it and the compiler drops it)
     // the other array of state words, for the call after this one
@@ -328,32 +366,9 @@ __global__ __launch_bounds__(kEmitThreads, kTags ? VPT_EMIT_TAG_OCC : 1) void em
     }
     // ---- the run's position: wave 0 looks back over the earlier runs' words, 64 per trip
     if (wave == 0) {
-        constexpr uint64_t kVal = (uint64_t(1) << 62) - 1;
-        if (lane == 0) __hip_atomic_store(F.state + blk, (uint64_t(1) << 62) | size, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const uint64_t start = (F.chain_in ? *F.chain_in : 0ull) & kVal;   // where the call's text starts (a call chained behind another: EmitFuse)
-        uint64_t base = 0;
-        bool anchored = false;   // the sum has reached a run whose position is known (or the front's sentinel): it holds `start`
-        for (uint64_t p = blk; p > 0;) {
-            const bool have = uint64_t(lane) < p;
-            uint64_t w = (uint64_t(2) << 62) | start;   // in front of run 0
-            if (have) w = __hip_atomic_load(F.state + (p - 1 - uint64_t(lane)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            const uint64_t pending = __ballot((w >> 62) == 0), prefixed = __ballot((w >> 62) == 2);
-            const int first = prefixed ? __ffsll((long long)prefixed) - 1 : 64;   // the nearest run whose position is known
-            const uint64_t need = first < 63 ? (uint64_t(2) << first) - 1 : ~uint64_t(0);
-            if (pending & need) { __builtin_amdgcn_s_sleep(2); continue; }         // not all published yet: look again
-            base += wave_sum64(int(lane) <= first ? (w & kVal) : 0);
-            if (first < 64) { anchored = true; break; }
-            p -= 64;
-        }
-        // run 0, or a walk that ran off the front exactly at a multiple of 64 runs with none of them placed yet (then no lane held the sentinel:
-        // found on MI355X by the chained chunks of vpt_tokenize_batch with one-sentence runs -- a misplaced run's text landed in an earlier chunk's)
-        if (!anchored) base += start;
-        if (lane == 0) {
-#ifndef VPT_EMIT_NO_PREFIX   // (test builds, tests/test_kernel_emu.py: the runs publish their sizes only, so every look-back walks to the launch's front)
-            __hip_atomic_store(F.state + blk, (uint64_t(2) << 62) | ((base + size) & kVal), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-#endif
-            L.bcast[3] = base;
-        }
+        if (lane == 0) publish_run_size(F, blk, size);
+        const uint64_t base = place_run(F, blk, size, lane);
+        if (lane == 0) L.bcast[3] = base;
     }
     __syncthreads();
     const uint64_t base = L.bcast[3], end = base + size;
@@ -403,23 +418,35 @@ __global__ __launch_bounds__(kEmitThreads, kTags ? VPT_EMIT_TAG_OCC : 1) void em
         const uint32_t excl = flat_block_scan(nl | (nst << 16), L.wtot, lane, wave, &tot);   // (its barriers: every thread has read its starts)
         if (tid < kFlatPiece / 32) L.starts[tid] = 0;
         const uint32_t c_in = excl & 0xFFFFu, s_in = excl >> 16;   // chars / starts of the piece in front of this thread
-        // the thread's chars that have a label in front take consecutive labels from (c_in - s_in) of the window on
+        // the thread's chars that have a label in front take consecutive labels from (c_in - s_in) of the window on: label q of the thread = bit q of lab
         const uint32_t nm = lm & ~sm;
-        uint32_t spm = 0;
+        uint32_t spm = 0, lab, n_sp;
         {
             const uint32_t loff = lab_head + (c_in - s_in);           // byte offset in labs: <= 15 + 4096
             const uint32_t d = loff >> 2, r = loff & 3u;
             uint4 y;
             y.x = __builtin_amdgcn_alignbyte(L.labs[d + 1], L.labs[d], r); y.y = __builtin_amdgcn_alignbyte(L.labs[d + 2], L.labs[d + 1], r);
             y.z = __builtin_amdgcn_alignbyte(L.labs[d + 3], L.labs[d + 2], r); y.w = __builtin_amdgcn_alignbyte(L.labs[d + 4], L.labs[d + 3], r);
-            uint32_t bits = one16(y), rem = nm;
-            while (rem) {   // label q of the thread onto its q-th labelled char
-                const uint32_t low = rem & (0u - rem);
-                if (bits & 1u) spm |= low;
-                bits >>= 1;
-                rem &= rem - 1u;
+            lab = one16(y);
+            if (kTags) {   // (the tags' owners ask for the spaces byte by byte)
+                uint32_t bits = lab, rem = nm;
+                while (rem) {   // label q of the thread onto its q-th labelled char
+                    const uint32_t low = rem & (0u - rem);
+                    if (bits & 1u) spm |= low;
+                    bits >>= 1;
+                    rem &= rem - 1u;
+                }
+                n_sp = uint32_t(__popc(spm));
+            } else {
+                // without tags nothing asks where the spaces are before the bytes go out, one after the other, each labelled char taking the next
+                // label (below): their number is enough here -- no loop over the chars, which ran as long as the longest of the wave's lanes said
+                n_sp = uint32_t(__popc(lab & ((1u << uint32_t(__popc(nm))) - 1u)));
             }
         }
+        // spaces in front of the thread's byte k (below = the bits under k)
+        const auto spaces_below = [&](uint32_t below) -> uint32_t {
+            return kTags ? uint32_t(__popc(spm & below)) : uint32_t(__popc(lab & ((1u << uint32_t(__popc(nm & below))) - 1u)));
+        };
         // Tag suffixes go in front of a space and in front of a sentence's first byte (the last token of the sentence before it), except
         // the run's first (the run before this one wrote that one behind its last byte).  The thread that holds the byte in FRONT of which
         // a suffix goes owns it; at most two per thread are carried in registers (tk: the byte, tl: the length, tc: the token's last
@@ -504,7 +531,7 @@ __global__ __launch_bounds__(kEmitThreads, kTags ? VPT_EMIT_TAG_OCC : 1) void em
                 if (ri != ~uint64_t(0)) sfx_total += tag_suffix(P, ri, nullptr);
             }
         }
-        const uint32_t t = uint32_t(__popc(vm)) + uint32_t(__popc(spm)) + uint32_t(__popc(em)) + sfx_total;
+        const uint32_t t = uint32_t(__popc(vm)) + n_sp + uint32_t(__popc(em)) + sfx_total;
         uint32_t total;
         const uint32_t w = flat_block_scan(t, L.wtot, lane, wave, &total);
         if (at_out + total > end) { fits = false; break; }   // (the same in every thread)
@@ -512,27 +539,60 @@ __global__ __launch_bounds__(kEmitThreads, kTags ? VPT_EMIT_TAG_OCC : 1) void em
         const uint32_t head = uint32_t(reinterpret_cast<uintptr_t>(dst) & 15u);
         const bool staged = !kTags || head + total <= kFlatStageBytes;   // (the same in every thread) else: byte stores straight to the output
         if (!slow) {
-            if (store_ok) {   // the thread's bytes in order: [tags] [' '] ['\\'] byte.  No branches: what is not there goes to a slot of the thread's own
-                uint8_t* const o = !kTags || staged ? sbytes + head : dst + 0;   // (with tags: a generic pointer)
+            // (wave-uniform) every lane's sixteen bytes are the run's and the piece is assembled in LDS: the bytes go out unconditionally
+            const bool whole = (!kTags || staged) && __ballot(vm != 0xFFFFu) == 0;
+            uint8_t* const o = !kTags || staged ? sbytes + head : dst + 0;   // (with tags: a generic pointer)
+            if (store_ok && whole) {
+                // The thread's bytes in order, [tags] [' '] ['\\'] byte, with no selects: a ' ' (and a '\\') is written where it WOULD stand and the
+                // position moves on only if it does -- what follows overwrites it otherwise (the LDS takes a wave's stores in the order they were
+                // issued, and the last store of a thread is a byte of its text; the tags' bytes, written below, lie where none of these stores
+                // goes).  Four issue slots a byte where the selects of the general loop below took fifteen: the writer runs at the vector ALU's
+                // issue rate (profiles/r06_r_*).  The variants are the wave's: no '\\' stores without an escaped byte, no tag lengths without a tag.
+                uint8_t* const ob = sbytes + head + w;
+                const auto bytes_out = [&](auto esc_c, auto tag_c) {
+                    constexpr bool kEsc = decltype(esc_c)::value, kTag = decltype(tag_c)::value;
+                    uint32_t ins = 0, bits = lab, mk = kTags ? spm : nm, ek = em;
+#pragma unroll
+                    for (uint32_t k = 0; k < 16; ++k) {
+                        // (a dword at a time, its masks taken from copies nothing else reads: computed for all sixteen bytes ahead of the branch, as the
+                        // compiler would, the bits and the bytes hold thirty registers and the kernel runs five waves per SIMD where it had eight)
+                        if ((k & 3u) == 0) VPT_OPAQUE3(mk, ek, ins);
+                        uint32_t sp;
+                        if (kTags) sp = (mk >> k) & 1u;
+                        else { const uint32_t nmk = (mk >> k) & 1u; sp = nmk & bits; bits >>= nmk; }   // (a labelled char takes the next label)
+                        if (kTag) ins += (k == tk1 ? tl1 : 0u) + (k == tk2 ? tl2 : 0u);
+                        ob[ins + k] = 0x20u; ins += sp;
+                        if (kEsc) { ob[ins + k] = 0x5Cu; ins += (ek >> k) & 1u; }
+                        ob[ins + k] = uint8_t(byte_of(x, k));
+                    }
+                };
+                const bool any_esc = __ballot(em != 0) != 0, any_tag = kTags && __ballot(tl1 != 0) != 0;
+                if (!any_esc && !any_tag) bytes_out(std::false_type{}, std::false_type{});
+                else if (!any_tag) bytes_out(std::true_type{}, std::false_type{});
+                else if (!any_esc) bytes_out(std::false_type{}, std::true_type{});
+                else bytes_out(std::true_type{}, std::true_type{});
+            } else if (store_ok && __ballot(vm != 0) != 0) {   // the same with a select per store: what is not there goes to a slot of the thread's own
                 uint8_t* const dump = reinterpret_cast<uint8_t*>(L.dump + tid);
-                uint32_t pos = w;
+                uint32_t pos = w, bits = lab;
 #pragma unroll
                 for (uint32_t k = 0; k < 16; ++k) {
-                    const uint32_t v = (vm >> k) & 1u, sp = (spm >> k) & 1u, es = (em >> k) & 1u;
+                    const uint32_t nmk = (nm >> k) & 1u;
+                    const uint32_t v = (vm >> k) & 1u, sp = kTags ? (spm >> k) & 1u : nmk & bits, es = (em >> k) & 1u;
+                    bits >>= nmk;
                     if (kTags) pos += (k == tk1 ? tl1 : 0u) + (k == tk2 ? tl2 : 0u);
                     *(sp ? o + pos : dump) = 0x20u; pos += sp;
                     *(es ? o + pos : dump) = 0x5Cu; pos += es;
                     *(v ? o + pos : dump) = uint8_t(byte_of(x, k)); pos += v;
                 }
-                if (kTags && tl1 && !(VPT_EMIT_ABLATE & 1)) {   // the tags themselves (few threads)
-                    const uint32_t b1 = (1u << tk1) - 1u, b2 = (1u << tk2) - 1u;
-                    // (their strings' places wait in LDS as a rule: the bytes are one trip away)
-                    const auto put = [&](uint64_t ri, uint32_t si, uint8_t* at, uint32_t len) -> bool {
-                        return si != ~0u ? tag_suffix_write(P, ri, SK.last[si], SK.str[si], at, len) == len : tag_suffix(P, ri, at, len) == len;
-                    };
-                    if (!put(tr1, ts1, o + w + uint32_t(__popc(vm & b1)) + uint32_t(__popc(spm & b1)) + uint32_t(__popc(em & b1)), tl1)) err |= kErrBadOffsets;
-                    if (tl2 && !put(tr2, ts2, o + w + tl1 + uint32_t(__popc(vm & b2)) + uint32_t(__popc(spm & b2)) + uint32_t(__popc(em & b2)), tl2)) err |= kErrBadOffsets;
-                }
+            }
+            if (kTags && store_ok && tl1 && !(VPT_EMIT_ABLATE & 1)) {   // the tags themselves (few threads)
+                const uint32_t b1 = (1u << tk1) - 1u, b2 = (1u << tk2) - 1u;
+                // (their strings' places wait in LDS as a rule: the bytes are one trip away)
+                const auto put = [&](uint64_t ri, uint32_t si, uint8_t* at, uint32_t len) -> bool {
+                    return si != ~0u ? tag_suffix_write(P, ri, SK.last[si], SK.str[si], at, len) == len : tag_suffix(P, ri, at, len) == len;
+                };
+                if (!put(tr1, ts1, o + w + uint32_t(__popc(vm & b1)) + uint32_t(__popc(spm & b1)) + uint32_t(__popc(em & b1)), tl1)) err |= kErrBadOffsets;
+                if (tl2 && !put(tr2, ts2, o + w + tl1 + uint32_t(__popc(vm & b2)) + uint32_t(__popc(spm & b2)) + uint32_t(__popc(em & b2)), tl2)) err |= kErrBadOffsets;
             }
             uint32_t rem = sm;   // the sentences that start in the thread's bytes (few threads, one as a rule)
             while (rem) {
@@ -540,7 +600,7 @@ __global__ __launch_bounds__(kEmitThreads, kTags ? VPT_EMIT_TAG_OCC : 1) void em
                 rem &= rem - 1u;
                 const uint64_t s = sb + s_in + uint32_t(__popc(sm & below));
                 if (s < ns) {
-                    P.out_offsets[i0 + s] = at_out + w + uint32_t(__popc(vm & below)) + uint32_t(__popc(spm & below)) + uint32_t(__popc(em & below)) +
+                    P.out_offsets[i0 + s] = at_out + w + uint32_t(__popc(vm & below)) + spaces_below(below) + uint32_t(__popc(em & below)) +
                                             (kTags ? (tk1 <= k ? tl1 : 0u) + (tk2 <= k ? tl2 : 0u) : 0u);
                     if (cb + c_in + uint32_t(__popc(lm & below)) != uint64_t(L.so[s]) + s) err |= kErrBadOffsets;   // not the char its offset names
                 } else err |= kErrBadOffsets;
@@ -619,6 +679,336 @@ __global__ __launch_bounds__(kEmitThreads, kTags ? VPT_EMIT_TAG_OCC : 1) void em
     if (err) atomicOr(P.status, err);
 }
 
+// ------------------------------------------------------------------------------------------------------------
+// emit_tile_kernel (round 6): the writer without tags, a run's text read ONCE.
+//
+// What the counters said about emit_flat_kernel<false> (profiles/r06_r_*): 1.44 G vector instructions per launch on configs[2] -- the kernel ran at the
+// vector ALU's issue rate -- and, with those cut to 0.85 G (flag gathers as v_dot4_u32_u8, bytes written unconditionally), the waves wait: seven barriers
+// and a trip to memory per 4 KB piece, the text read twice (once for the run's size, once to write it).  Here a workgroup's run is a TILE of 16 KB of text
+// as a rule (capi_device.cpp sizes the runs for that), held in registers from the size pass on -- four 16-byte chunks per thread, piece-major, so every
+// load is contiguous over the workgroup; their lead / escape masks are taken once; the run's labels become a BIT per label in LDS while they are counted;
+// the block prefix sums of the four pieces (chars and sentence starts, then output bytes) are two barriers for the tile, not four per piece; the
+// look-back comes after them, when the earlier runs have had time to publish.  A piece then costs two barriers: its bytes assembled in LDS, and gone.
+// A run longer than a tile (ragged input) walks its tiles one after the other and reads them again, as emit_flat_kernel did.
+// ------------------------------------------------------------------------------------------------------------
+constexpr uint32_t kTilePieces = 4;
+constexpr uint32_t kTileBytes = kTilePieces * kFlatPiece;   // text a workgroup holds in registers (64 bytes per thread)
+constexpr uint32_t kTileLabChunks = kTileBytes / 16 + 2;    // 16-byte chunks of labels a tile's chars can ask for: a label per char at most, and the two ragged ends
+struct alignas(16) TileLds {
+    uint32_t stage[kFlatStageBytes / 4];
+    uint32_t lbits[(kTileLabChunks + 1) / 2 + 3];   // a bit per label: the chunks' 16-bit masks side by side (+ the dword behind a window's last)
+    uint32_t starts[kTileBytes / 32];               // a bit per byte of the tile: a sentence starts here
+    uint32_t so[kEmitFlatMaxBlock + 1];             // the run's boundary offsets, relative to its first
+    uint32_t dump[kEmitThreads];                    // where a thread's stores of bytes that are not there go
+    uint32_t wt1[kTilePieces][kEmitWaves];          // the waves' sums of the two block prefix sums, every piece of the tile at once
+    uint32_t wt2[kTilePieces / 2][kEmitWaves];
+    uint32_t flags;
+    uint64_t red[kEmitWaves];
+    uint64_t bcast[4];                              // ticket, B0, O0, base
+};
+// which of the 16 bytes at offset `off` lie in [lo, hi) (offsets from the same base)
+__device__ __forceinline__ uint32_t in_range16_rel(uint32_t off, uint32_t lo, uint32_t hi) {
+    const uint32_t a = lo > off ? (lo - off < 16u ? lo - off : 16u) : 0u;
+    const uint32_t b = hi > off ? (hi - off < 16u ? hi - off : 16u) : 0u;
+    return ((1u << b) - 1u) & ~((1u << a) - 1u);   // (b < a: nothing)
+}
+
+__global__ __launch_bounds__(kEmitThreads, VPT_EMIT_OCC) void emit_tile_kernel(const EmitParams P, const EmitFuse F) {
+    __shared__ TileLds L;
+    // the other array of state words, for the call after this one
+    for (uint64_t k = uint64_t(blockIdx.x) * kEmitThreads + threadIdx.x; k < F.clear_n; k += uint64_t(gridDim.x) * kEmitThreads) F.clear[k] = 0;
+    const uint32_t tid = threadIdx.x, lane = tid & 63, wave = wave_uniform(tid >> 6);
+    if (tid == 0) { L.bcast[0] = atomicAdd(reinterpret_cast<unsigned long long*>(F.state + F.n_blocks), 1ull); L.flags = 0; }
+    L.starts[tid] = 0; L.starts[kEmitThreads + tid] = 0;
+    static_assert(kTileBytes / 32 == 2 * kEmitThreads, "two words of the starts per thread");
+    __syncthreads();
+    const uint64_t blk = wave_uniform64(L.bcast[0]);   // (what every thread reads from LDS is the wave's: scalar registers)
+    if (blk >= F.n_blocks) return;
+    const uint64_t i0 = blk * F.per_block;
+    const uint32_t ns = uint32_t(P.n_sent - i0 < F.per_block ? P.n_sent - i0 : F.per_block);
+    // the run's offsets: thread j holds sentence i0 + j's and its successor's
+    uint64_t my_b = ~uint64_t(0), my_o = 0, nx_b = 0, nx_o = 0;
+    const bool mine = tid < ns;
+    if (mine) { my_b = P.boff[i0 + tid]; my_o = P.ooff[i0 + tid]; nx_b = P.boff[i0 + tid + 1]; nx_o = P.ooff[i0 + tid + 1]; }
+    if (tid == 0) { L.bcast[1] = my_b; L.bcast[2] = my_o; }
+    if (tid == ns - 1) { L.red[0] = nx_b; L.red[1] = nx_o; }
+    uint32_t err = 0;
+    {
+        const bool empty = mine && nx_b <= my_b, bad = mine && (nx_o < my_o || nx_o > P.total_boundaries);
+        if (empty) err |= kErrEmptySentence;
+        if (bad) err |= kErrBadOffsets;
+        if (empty || bad) atomicOr(&L.flags, 1u);
+    }
+    __syncthreads();
+    const uint64_t B0 = wave_uniform64(L.bcast[1]), O0 = wave_uniform64(L.bcast[2]), B1 = wave_uniform64(L.red[0]), O1 = wave_uniform64(L.red[1]);
+    const bool sane = wave_uniform(L.flags) == 0 && O1 - O0 < 0xFFFF0000ull && B1 - B0 < 0xFFFF0000ull;
+    if (!sane) err |= kErrBadOffsets;
+    if (mine) L.so[tid] = uint32_t(my_o - O0);
+    if (tid == 0) L.so[ns] = uint32_t(O1 - O0);
+    __syncthreads();   // (red[] is used again below)
+    if (!sane) {   // nothing of the run is read: it takes its place in the chain with no bytes
+        if (wave == 0) {
+            if (lane == 0) publish_run_size(F, blk, 0);
+            const uint64_t base = place_run(F, blk, 0, lane);
+            if (lane == 0) L.bcast[3] = base;
+        }
+        __syncthreads();
+        const uint64_t base = wave_uniform64(L.bcast[3]);
+        if (blk == F.n_blocks - 1 && tid == 0) {
+            P.out_offsets[P.n_sent] = base;
+            if (base > P.capacity) err |= kErrOutputTooSmall;
+            if (F.total_out) *F.total_out = base;
+            if (F.chain_out) *F.chain_out = base;
+        }
+        if (mine) P.out_offsets[i0 + tid] = base;
+        atomicOr(P.status, err);
+        return;
+    }
+
+    const uintptr_t t_lo = reinterpret_cast<uintptr_t>(P.text) + B0, t_hi = reinterpret_cast<uintptr_t>(P.text) + B1;
+    const uintptr_t l_all = reinterpret_cast<uintptr_t>(P.labels), l_lo = l_all + O0, l_hi = l_all + O1;
+    const uintptr_t tb = t_lo & ~uintptr_t(15);            // the tiles' base: every chunk is a 16-byte aligned load
+    const uint32_t lo_rel = uint32_t(t_lo - tb), span = uint32_t(t_hi - tb);
+    const uint32_t n_tiles = (span + kTileBytes - 1u) / kTileBytes;   // (at least one: the run has bytes)
+    const uint32_t my_rel = mine ? uint32_t(my_b - B0) + lo_rel : 0u;   // where the thread's sentence starts, from tb
+    uint8_t* const sbytes = reinterpret_cast<uint8_t*>(L.stage);
+
+    uint4 x[kTilePieces];
+    uint32_t me[kTilePieces];   // the chunks' masks: chars' first bytes | escaped bytes << 16
+    // the chunks of the tile at byte `first` of the run's span: loads, then masks; returns the escaped bytes of the thread's chunks
+    const auto load_tile = [&](uint32_t first) -> uint32_t {
+#pragma unroll
+        for (uint32_t q = 0; q < kTilePieces; ++q) {
+            const uint32_t off = first + q * kFlatPiece + 16u * tid;
+            x[q] = off < span ? *reinterpret_cast<const uint4*>(tb + off) : make_uint4(0, 0, 0, 0);
+        }
+        uint32_t n_esc = 0;
+#pragma unroll
+        for (uint32_t q = 0; q < kTilePieces; ++q) {
+            const uint32_t vm = in_range16_rel(first + q * kFlatPiece + 16u * tid, lo_rel, span);
+            const uint32_t lm = lead16(x[q]) & vm, em = esc16(x[q]) & vm;
+            me[q] = lm | (em << 16);
+            n_esc += uint32_t(__popc(em));
+        }
+        return n_esc;
+    };
+    // label bits of the window that starts at label `first` of the run (a tile's chars ask for labels from there on): a bit per label, bit lab_head first
+    const auto stage_labels = [&](uint64_t first) -> uint32_t {
+        const uintptr_t la = l_lo + first, lbt = la & ~uintptr_t(15);
+        if (la < l_hi) {
+            const uint64_t n_all = (l_hi - lbt + 15) >> 4;
+            const uint32_t n = n_all < kTileLabChunks ? uint32_t(n_all) : kTileLabChunks;
+            for (uint32_t c = tid; c < n; c += kEmitThreads) {
+                const uintptr_t a = lbt + 16u * c;
+                const uint4 y = *reinterpret_cast<const uint4*>(a);
+                reinterpret_cast<uint16_t*>(L.lbits)[c] = uint16_t(one16(y) & in_range16(a, l_lo, l_hi));
+            }
+        }
+        return uint32_t(la - lbt);
+    };
+
+    // ---- the run's size = its bytes + the escaped bytes + the boundary labels of its label range; tile 0 stays in the registers, its labels' bits
+    // and its sentences' starts in LDS
+    uint64_t size;
+    uint32_t lab_head = uint32_t(l_lo & 15u);
+    {
+        uint32_t added = 0;
+        for (uint32_t t = n_tiles; t-- > 0;) added += load_tile(t * kTileBytes);   // (tile 0 last)
+        if (l_hi > l_lo) {
+            const uintptr_t lb = l_lo & ~uintptr_t(15);
+            const uint32_t n = uint32_t((l_hi - lb + 15) >> 4);
+            for (uint32_t c = tid; c < n; c += kEmitThreads) {
+                const uintptr_t a = lb + 16u * c;
+                const uint4 y = *reinterpret_cast<const uint4*>(a);
+                const uint32_t m = in_range16(a, l_lo, l_hi), ones = one16(y) & m;
+                added += uint32_t(__popc(ones));
+                if (unk16(y) & m) err |= kErrUnknownLabel;
+                if (c < kTileLabChunks) reinterpret_cast<uint16_t*>(L.lbits)[c] = uint16_t(ones);
+            }
+        }
+        if (mine && my_rel < kTileBytes) atomicOr(&L.starts[my_rel >> 5], 1u << (my_rel & 31u));
+        const uint64_t ws = wave_sum64(added);
+        if (lane == 0) L.red[wave] = ws;
+        __syncthreads();
+        size = B1 - B0;
+#pragma unroll
+        for (uint32_t k = 0; k < uint32_t(kEmitWaves); ++k) size += wave_uniform64(L.red[k]);
+    }
+    if (tid == 0) publish_run_size(F, blk, size);   // (as early as it is known: the runs behind this one add it up)
+
+    uint64_t at_out = 0, end = 0, cb = 0, sb = 0;   // output position, the run's end, chars and sentence starts in front of the tile
+    bool fits = true, store_ok = false;
+    for (uint32_t t = 0; t < n_tiles; ++t) {
+        const uint32_t first = t * kTileBytes;
+        if (t) {   // (a run of several tiles) the tile's starts and label bits replace the last one's
+            __syncthreads();
+            L.starts[tid] = 0; L.starts[kEmitThreads + tid] = 0;
+            __syncthreads();
+            (void)load_tile(first);
+            lab_head = stage_labels(cb - sb);
+            if (mine && my_rel >= first && my_rel - first < kTileBytes) atomicOr(&L.starts[(my_rel - first) >> 5], 1u << ((my_rel - first) & 31u));
+            __syncthreads();
+        } else if (n_tiles > 1) (void)load_tile(0);
+        // chars and sentence starts in front of every chunk: one block prefix sum for the tile's pieces
+        uint32_t vs[kTilePieces], pk[kTilePieces], in[kTilePieces];   // in range | starts << 16; the chunks' chars | starts << 16; those in front
+#pragma unroll
+        for (uint32_t q = 0; q < kTilePieces; ++q) {
+            const uint32_t vm = in_range16_rel(first + q * kFlatPiece + 16u * tid, lo_rel, span), lm = me[q] & 0xFFFFu;
+            uint32_t sm = reinterpret_cast<const uint16_t*>(L.starts)[q * kEmitThreads + tid];
+            if (sm & ~lm) err |= kErrBadOffsets;   // a sentence that starts inside a char (or outside the run)
+            sm &= lm;
+            vs[q] = vm | (sm << 16);
+            pk[q] = uint32_t(__popc(lm)) | (uint32_t(__popc(sm)) << 16);
+            in[q] = wave_inclusive_scan(pk[q]);
+            if (lane == 63) L.wt1[q][wave] = in[q];
+        }
+        __syncthreads();
+        uint32_t tile_tot = 0;
+#pragma unroll
+        for (uint32_t q = 0; q < kTilePieces; ++q) {
+            uint32_t woff = 0, tot = 0;
+#pragma unroll
+            for (uint32_t k = 0; k < uint32_t(kEmitWaves); ++k) {
+                const uint32_t u = wave_uniform(L.wt1[q][k]);
+                if (k < wave) woff += u;
+                tot += u;
+            }
+            in[q] = tile_tot + woff + in[q] - pk[q];
+            tile_tot += tot;
+        }
+        // the labels of every chunk's chars and with them its output bytes; the second prefix sum, two pieces to a dword
+        uint32_t lw[kTilePieces], tq[kTilePieces];   // label bits | place in the piece's output << 16
+#pragma unroll
+        for (uint32_t q = 0; q < kTilePieces; ++q) {
+            const uint32_t lm = me[q] & 0xFFFFu, em = me[q] >> 16, vm = vs[q] & 0xFFFFu, sm = vs[q] >> 16;
+            const uint32_t loff = lab_head + (in[q] & 0xFFFFu) - (in[q] >> 16);   // the chunk's first label: a bit of lbits
+            const uint32_t lab = __builtin_amdgcn_alignbit(L.lbits[(loff >> 5) + 1], L.lbits[loff >> 5], loff & 31u) & 0xFFFFu;
+            const uint32_t n_sp = uint32_t(__popc(lab & ((1u << uint32_t(__popc(lm & ~sm))) - 1u)));
+            lw[q] = lab;
+            tq[q] = uint32_t(__popc(vm)) + n_sp + uint32_t(__popc(em));
+        }
+        uint32_t totals[kTilePieces];
+#pragma unroll
+        for (uint32_t j = 0; j < kTilePieces / 2; ++j) {
+            const uint32_t p = tq[2 * j] | (tq[2 * j + 1] << 16), inc = wave_inclusive_scan(p);
+            if (lane == 63) L.wt2[j][wave] = inc;
+            tq[2 * j] = inc - p;   // (the wave's part; the rest behind the barrier)
+        }
+        __syncthreads();
+#pragma unroll
+        for (uint32_t j = 0; j < kTilePieces / 2; ++j) {
+            uint32_t woff = 0, tot = 0;
+#pragma unroll
+            for (uint32_t k = 0; k < uint32_t(kEmitWaves); ++k) {
+                const uint32_t u = wave_uniform(L.wt2[j][k]);
+                if (k < wave) woff += u;
+                tot += u;
+            }
+            const uint32_t e = woff + tq[2 * j];
+            lw[2 * j] |= (e & 0xFFFFu) << 16; lw[2 * j + 1] |= (e >> 16) << 16;
+            totals[2 * j] = tot & 0xFFFFu; totals[2 * j + 1] = tot >> 16;
+        }
+        if (t == 0) {   // ---- the run's position: wave 0 looks back over the earlier runs' words (they have had the prefix sums' time to publish)
+            if (wave == 0) {
+                const uint64_t base = place_run(F, blk, size, lane);
+                if (lane == 0) L.bcast[3] = base;
+            }
+            __syncthreads();
+            at_out = wave_uniform64(L.bcast[3]);
+            end = at_out + size;
+            store_ok = end <= P.capacity;
+            if (blk == F.n_blocks - 1 && tid == 0) {
+                P.out_offsets[P.n_sent] = end;
+                if (end > P.capacity) err |= kErrOutputTooSmall;
+                if (F.total_out) *F.total_out = end;
+                if (F.chain_out) *F.chain_out = end;
+            }
+        }
+        // ---- the pieces: every byte of the tile to its place
+        // (one copy of the piece's code, its registers picked by selects: unrolled, the compiler computes the four pieces' bits and bytes ahead -- 163 VGPRs)
+        const auto pick = [](const uint32_t (&a)[kTilePieces], uint32_t q) -> uint32_t { return q == 0 ? a[0] : q == 1 ? a[1] : q == 2 ? a[2] : a[3]; };
+#pragma unroll 1
+        for (uint32_t q = 0; q < kTilePieces; ++q) {
+            if (first + q * kFlatPiece >= span) break;   // (the same in every thread) the run ends in front of this piece
+            const uint32_t total = pick(totals, q);
+            if (at_out + total > end) { fits = false; break; }   // (the same in every thread)
+            const uint32_t me_q = pick(me, q), vs_q = pick(vs, q), lw_q = pick(lw, q), in_q = pick(in, q);
+            uint4 xq;
+            xq.x = q == 0 ? x[0].x : q == 1 ? x[1].x : q == 2 ? x[2].x : x[3].x; xq.y = q == 0 ? x[0].y : q == 1 ? x[1].y : q == 2 ? x[2].y : x[3].y;
+            xq.z = q == 0 ? x[0].z : q == 1 ? x[1].z : q == 2 ? x[2].z : x[3].z; xq.w = q == 0 ? x[0].w : q == 1 ? x[1].w : q == 2 ? x[2].w : x[3].w;
+            const uint32_t lm = me_q & 0xFFFFu, em = me_q >> 16, vm = vs_q & 0xFFFFu, sm = vs_q >> 16, lab = lw_q & 0xFFFFu, w = lw_q >> 16;
+            const uint32_t c_in = in_q & 0xFFFFu, s_in = in_q >> 16, nm = lm & ~sm;
+            uint8_t* const dst = P.out_text + at_out;
+            const uint32_t head = uint32_t(reinterpret_cast<uintptr_t>(dst) & 15u);
+            if (store_ok) {
+                if (__ballot(vm != 0xFFFFu) == 0) {
+                    // (wave-uniform) every lane's sixteen bytes are the run's.  The thread's bytes in order, [' '] ['\\'] byte, with no selects: a ' ' (and a
+                    // '\\') is written where it WOULD stand and the position moves on only if it does -- what follows overwrites it otherwise (the LDS
+                    // takes a wave's stores in the order they were issued, and the last store of a thread is a byte of its text)
+                    uint8_t* const ob = sbytes + head + w;
+                    const auto bytes_out = [&](auto esc_c) {
+                        constexpr bool kEsc = decltype(esc_c)::value;
+                        uint32_t ins = 0, bits = lab, mk = nm, ek = em;
+#pragma unroll
+                        for (uint32_t k = 0; k < 16; ++k) {
+                            if ((k & 3u) == 0) VPT_OPAQUE3(mk, ek, ins);   // (a dword at a time: see emit_flat_kernel)
+                            const uint32_t nmk = (mk >> k) & 1u, sp = nmk & bits;   // a labelled char takes the next label
+                            bits >>= nmk;
+                            ob[ins + k] = 0x20u; ins += sp;
+                            if (kEsc) { ob[ins + k] = 0x5Cu; ins += (ek >> k) & 1u; }
+                            ob[ins + k] = uint8_t(byte_of(xq, k));
+                        }
+                    };
+                    if (__ballot(em != 0) == 0) bytes_out(std::false_type{});
+                    else bytes_out(std::true_type{});
+                } else if (__ballot(vm != 0) != 0) {   // the run's ends: byte by byte, only what is there (two waves of a run at most)
+                    uint8_t* const o = sbytes + head;
+                    uint32_t pos = w, bits = lab;
+#pragma unroll 1
+                    for (uint32_t k = 0; k < 16; ++k) {
+                        if (!((vm >> k) & 1u)) continue;
+                        if ((nm >> k) & 1u) { if (bits & 1u) o[pos++] = 0x20u; bits >>= 1; }
+                        if ((em >> k) & 1u) o[pos++] = 0x5Cu;
+                        o[pos++] = uint8_t(byte_of_rt(xq, k));
+                    }
+                }
+            }
+            uint32_t rem = sm;   // the sentences that start in the thread's bytes (few threads, one as a rule)
+            while (rem) {
+                const uint32_t k = uint32_t(__ffs(int(rem))) - 1u, below = (1u << k) - 1u;
+                rem &= rem - 1u;
+                const uint64_t s = sb + s_in + uint32_t(__popc(sm & below));
+                if (s < ns) {
+                    P.out_offsets[i0 + s] = at_out + w + uint32_t(__popc(vm & below)) + uint32_t(__popc(lab & ((1u << uint32_t(__popc(nm & below))) - 1u))) + uint32_t(__popc(em & below));
+                    if (cb + c_in + uint32_t(__popc(lm & below)) != uint64_t(L.so[s]) + s) err |= kErrBadOffsets;   // not the char its offset names
+                } else err |= kErrBadOffsets;
+            }
+            __syncthreads();
+            if (store_ok) {   // LDS byte j is output byte j - head: whole 16-byte chunks leave aligned, the two edges byte by byte
+                uint8_t* const abase = dst - head;
+                const uint32_t nd = (head + total + 15u) >> 4;
+                for (uint32_t d = tid; d < nd; d += kEmitThreads) {
+                    const uint32_t lo = d * 16u, hi = lo + 16u;
+                    if (lo >= head && hi <= head + total) {
+                        *reinterpret_cast<uint4*>(abase + lo) = reinterpret_cast<const uint4*>(L.stage)[d];
+                    } else {
+                        const uint32_t a = lo > head ? lo : head, b = hi < head + total ? hi : head + total;
+                        for (uint32_t j = a; j < b; ++j) abase[j] = sbytes[j];
+                    }
+                }
+            }
+            __syncthreads();   // the next piece rewrites the stage
+            at_out += total;
+        }
+        if (!fits) break;
+        cb += tile_tot & 0xFFFFu;
+        sb += tile_tot >> 16;
+    }
+    // (what was written is what the size pass said: anything else means chars, labels and offsets do not belong together)
+    if (!fits || at_out != end || cb != (O1 - O0) + ns || sb != ns) err |= kErrBadOffsets;
+    if (err) atomicOr(P.status, err);
+}
+
 // vpt_count_boundaries on the device: chars - 1 of every sentence -> offsets[i + 1] (the scan follows), the same
 // validation as Sentence::from_raw (sentence.rs:160-196), the longest sentence (in chars) -> *max_chars.
 //
@@ -664,9 +1054,8 @@ __global__ __launch_bounds__(kEmitThreads) void count_chars_kernel(const uint8_t
             const uint32_t lo = t_lo > a ? (t_lo - a < 16 ? uint32_t(t_lo - a) : 16u) : 0u;
             const uint32_t hi = t_hi > a ? (t_hi - a < 16 ? uint32_t(t_hi - a) : 16u) : 0u;
             const uint32_t vm = hi > lo ? ((1u << hi) - 1u) & ~((1u << lo) - 1u) : 0u;
-            const uint32_t lm = (lead_nibble(v[q].x) | (lead_nibble(v[q].y) << 4) | (lead_nibble(v[q].z) << 8) | (lead_nibble(v[q].w) << 12)) & vm;
-            const uint32_t zm = (byte_flags_to_nibble(zero_bytes(v[q].x)) | (byte_flags_to_nibble(zero_bytes(v[q].y)) << 4) |
-                                 (byte_flags_to_nibble(zero_bytes(v[q].z)) << 8) | (byte_flags_to_nibble(zero_bytes(v[q].w)) << 12)) & vm;
+            const uint32_t lm = lead_mask16(v[q]) & vm;
+            const uint32_t zm = zero_mask16(v[q]) & vm;
             nul = nul || zm != 0;
             masks[tid * 4 + q] = uint16_t(lm);
             cnt += uint32_t(__popc(lm));
@@ -733,7 +1122,11 @@ hipError_t launch_count_boundaries(const uint8_t* text, const uint64_t* boff, ui
 
 hipError_t launch_emit_tokenized(const EmitParams& P, const EmitFuse& F, hipStream_t stream) {   // a workgroup per run of sentences
     if (P.records) hipLaunchKernelGGL(emit_flat_kernel<true>, dim3(uint32_t(F.n_blocks)), dim3(kEmitThreads), 0, stream, P, F);
+#ifdef VPT_EMIT_FLAT_UNTAGGED   // (A/B builds: round 5's kernel without tags)
     else hipLaunchKernelGGL(emit_flat_kernel<false>, dim3(uint32_t(F.n_blocks)), dim3(kEmitThreads), 0, stream, P, F);
+#else
+    else hipLaunchKernelGGL(emit_tile_kernel, dim3(uint32_t(F.n_blocks)), dim3(kEmitThreads), 0, stream, P, F);
+#endif
     return hipGetLastError();
 }
 

@@ -119,7 +119,7 @@ __global__ __launch_bounds__(kTagThreads) void decode_chars_kernel(const uint8_t
         const uint32_t lo = t_lo > a ? (t_lo - a < 16 ? uint32_t(t_lo - a) : 16u) : 0u;
         const uint32_t hi = t_hi > a ? (t_hi - a < 16 ? uint32_t(t_hi - a) : 16u) : 0u;
         const uint32_t vm = hi > lo ? ((1u << hi) - 1u) & ~((1u << lo) - 1u) : 0u;
-        const uint32_t lm = (lead_nibble(d[0]) | (lead_nibble(d[1]) << 4) | (lead_nibble(d[2]) << 8) | (lead_nibble(d[3]) << 12)) & vm;
+        const uint32_t lm = flag_bytes_to_mask16(lead_flags(d[0]), lead_flags(d[1]), lead_flags(d[2]), lead_flags(d[3])) & vm;
         const uint32_t cnt = uint32_t(__popc(lm));
         masks[tid] = uint16_t(lm);
         const uint32_t incl = wave_inclusive_scan(cnt);
