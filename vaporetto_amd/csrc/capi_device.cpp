@@ -322,16 +322,15 @@ vpt_status emit_device(const vpt_predictor* p, vpt_batch* b, const uint8_t* d_ut
         E.records = b->d_tag_records; E.rec_str = b->d_rec_str; E.run_pref = b->d_run_pref; E.n_runs = b->tag_runs; E.run_sent = b->tag_run_sent;
         E.n_tags = p->n_tags; E.str_bytes = p->dtag.str_bytes;
     }
-    // A WORKGROUP per run of sentences.  With tags (emit_flat_kernel, round 5): 5 K chars when the batch is small (the chip wants a thousand workgroups
-    // and more), up to 20 K on a big one -- fewer look-backs and size passes per byte (measured, profiles/r05_h_*, r05_k_*: tagged configs[4] 2.39 / 2.10 /
-    // 2.04 ms at 5 K / 10 K / 20 K) -- and a whole multiple of fill_tags' runs, so that a workgroup's records are run_pref[a] .. run_pref[b].  Without
-    // (emit_tile_kernel, round 6): what the kernel holds in registers and reads once, 16 KB of text -- 4.5 K chars of three bytes leave room for a
-    // ragged run (one that is longer is read twice, nothing else).  At most 256 sentences.
+    // A WORKGROUP per run of sentences (emit_flat_kernel, round 5; a wave per block of 2 K chars before): 5 K chars when the batch is small (the
+    // chip wants a thousand workgroups and more), up to 20 K on a big one -- fewer look-backs and size passes per byte (measured,
+    // profiles/r05_h_*, r05_k_*, r06_t_*: configs[2] 2.03 ms at 128 sentences, 1.80 at 256; tagged configs[4] 2.39 / 2.10 / 2.04 at 5 K / 10 K / 20 K
+    // chars); at most 256 sentences.  With tags: a whole multiple of fill_tags' runs, so that a workgroup's records are run_pref[a] .. run_pref[b].
     vpt::EmitFuse F{};
     {
         const uint64_t chars = total_boundaries + n_sentences;
         const uint64_t auto_run = std::min<uint64_t>(std::max<uint64_t>(chars / (uint64_t(16) * std::max<uint32_t>(p->n_cus, 64)), 5120), 20480);
-        const uint64_t target = E.records ? auto_run : 4608;
+        const uint64_t target = auto_run;
         uint64_t per = std::min<uint64_t>(std::max<uint64_t>((target * n_sentences + chars / 2) / chars, 1), vpt::kEmitFlatMaxBlock);   // round(target / mean chars per sentence)
         if (E.records && E.run_sent <= vpt::kEmitFlatMaxBlock)
             per = std::min<uint64_t>(std::max<uint64_t>((per + E.run_sent / 2) / E.run_sent, 1) * E.run_sent, (vpt::kEmitFlatMaxBlock / E.run_sent) * E.run_sent);

@@ -188,6 +188,12 @@ __device__ __forceinline__ uint32_t byte_of_rt(const uint4& x, uint32_t k) {   /
     const uint32_t d = q == 0 ? x.x : q == 1 ? x.y : q == 2 ? x.z : x.w;
     return (d >> (8 * (k & 3u))) & 0xFFu;
 }
+// which of the 16 bytes at offset `off` lie in [lo, hi) (offsets from the same base)
+__device__ __forceinline__ uint32_t in_range16_rel(uint32_t off, uint32_t lo, uint32_t hi) {
+    const uint32_t a = lo > off ? (lo - off < 16u ? lo - off : 16u) : 0u;
+    const uint32_t b = hi > off ? (hi - off < 16u ? hi - off : 16u) : 0u;
+    return ((1u << b) - 1u) & ~((1u << a) - 1u);   // (b < a: nothing)
+}
 constexpr uint32_t kFlatPiece = kEmitThreads * 16;                 // text bytes of a workgroup's step
 constexpr uint32_t kFlatStageBytes = 3 * kFlatPiece + 32;          // its output at most (every byte escaped, a space per char) + the alignment head
 struct alignas(16) FlatLds {
@@ -195,7 +201,7 @@ struct alignas(16) FlatLds {
     uint32_t labs[(kFlatPiece + 64) / 4];     // the labels a piece's chars can ask for, from a 16-byte aligned address
     uint32_t starts[kFlatPiece / 32];         // one bit per byte of the piece: a sentence starts here
     uint32_t so[kEmitFlatMaxBlock + 1];       // the run's boundary offsets, relative to its first
-    uint32_t dump[kEmitThreads];              // where a thread's stores of bytes that are not there go
+    uint32_t dump[kEmitWaves];                // where a wave's stores of bytes that are not there go (nobody reads it)
     uint32_t wtot[kEmitWaves];
     uint32_t flags;                           // OR of the threads' "my offsets are no offsets"
     uint64_t red[kEmitWaves];
@@ -314,6 +320,9 @@ __global__ __launch_bounds__(kEmitThreads, kTags ? VPT_EMIT_TAG_OCC : VPT_EMIT_O
     // ---- the run's size = its bytes + the escaped bytes + the boundary labels of its label range
     const uintptr_t t_lo = reinterpret_cast<uintptr_t>(P.text) + B0, t_hi = reinterpret_cast<uintptr_t>(P.text) + B1;
     const uintptr_t l_all = reinterpret_cast<uintptr_t>(P.labels), l_end = l_all + P.total_boundaries;
+    // (the run's bytes from a 16-byte aligned base, in 32 bits: the run is shorter than 4 GB -- `sane`)
+    const uintptr_t tb = t_lo & ~uintptr_t(15);
+    const uint32_t lo_rel = uint32_t(t_lo - tb), span = sane ? uint32_t(t_hi - tb) : 0u;
     // with tags: the records of the run's chars [g0, g1) are the slice [r_lo, r_hi) of the sorted records
     const uint64_t g0 = O0 + i0, g1 = O1 + i0 + ns;
     uint64_t r_lo = 0, r_hi = 0;
@@ -337,12 +346,12 @@ __global__ __launch_bounds__(kEmitThreads, kTags ? VPT_EMIT_TAG_OCC : VPT_EMIT_O
     if (sane) {
         uint32_t added = 0;
         const uintptr_t l_lo = l_all + O0, l_hi = l_all + O1;
-        for (uintptr_t a = (t_lo & ~uintptr_t(15)) + 16u * tid; a < t_hi; a += 4 * kFlatPiece) {   // four loads in flight
+        for (uint32_t off = 16u * tid; off < span; off += 4 * kFlatPiece) {   // four loads in flight
             uint4 x[4];
 #pragma unroll
-            for (uint32_t q = 0; q < 4; ++q) x[q] = a + q * kFlatPiece < t_hi ? *reinterpret_cast<const uint4*>(a + q * kFlatPiece) : make_uint4(0, 0, 0, 0);
+            for (uint32_t q = 0; q < 4; ++q) x[q] = off + q * kFlatPiece < span ? *reinterpret_cast<const uint4*>(tb + off + q * kFlatPiece) : make_uint4(0, 0, 0, 0);
 #pragma unroll
-            for (uint32_t q = 0; q < 4; ++q) added += uint32_t(__popc(esc16(x[q]) & in_range16(a + q * kFlatPiece, t_lo, t_hi)));
+            for (uint32_t q = 0; q < 4; ++q) added += uint32_t(__popc(esc16(x[q]) & in_range16_rel(off + q * kFlatPiece, lo_rel, span)));
         }
         for (uintptr_t a = (l_lo & ~uintptr_t(15)) + 16u * tid; a < l_hi; a += kFlatPiece) {
             const uint4 y = *reinterpret_cast<const uint4*>(a);
@@ -387,25 +396,26 @@ __global__ __launch_bounds__(kEmitThreads, kTags ? VPT_EMIT_TAG_OCC : VPT_EMIT_O
 
     // ---- the pieces: every byte of the run to its place
     uint8_t* const sbytes = reinterpret_cast<uint8_t*>(L.stage);
-    const uintptr_t my_start = reinterpret_cast<uintptr_t>(P.text) + my_b;
+    const uint32_t my_rel = mine ? uint32_t(my_b - B0) + lo_rel : 0u;   // where the thread's sentence starts, from tb
     uint64_t at_out = base, cb = 0, sb = 0;   // output position, chars and sentence starts of the run in front of the piece
     bool fits = true;
     uint64_t rp = r_lo;                       // with tags: the first record not yet behind the pieces done (the same in every thread) ...
     uint64_t carry_rec = ~uint64_t(0);        // ... and the record, if any, of the last char in front of the piece
-    for (uintptr_t piece = t_lo & ~uintptr_t(15); piece < t_hi; piece += kFlatPiece) {
-        const uintptr_t addr = piece + 16u * tid;
-        const uint32_t vm = in_range16(addr, t_lo, t_hi);
-        const uint4 x = vm ? *reinterpret_cast<const uint4*>(addr) : make_uint4(0, 0, 0, 0);
+    for (uint32_t p_off = 0; p_off < span; p_off += kFlatPiece) {
+        const uint32_t vm = in_range16_rel(p_off + 16u * tid, lo_rel, span);
+        const uint4 x = vm ? *reinterpret_cast<const uint4*>(tb + p_off + 16u * tid) : make_uint4(0, 0, 0, 0);
         // the labels the piece's chars can ask for: label (O0 + cb - sb) onwards (every char but a sentence's first has one in front)
         const uintptr_t lab_at = l_all + O0 + (cb - sb), lab_al = lab_at & ~uintptr_t(15);
         const uint32_t lab_head = uint32_t(lab_at - lab_al);
         {
-            const uintptr_t a = lab_al + 16u * tid, a2 = lab_al + 16u * (uint32_t(kEmitThreads) + tid);
-            reinterpret_cast<uint4*>(L.labs)[tid] = (a + 16 > l_all && a < l_end) ? *reinterpret_cast<const uint4*>(a) : make_uint4(0, 0, 0, 0);
-            if (tid < 4) reinterpret_cast<uint4*>(L.labs)[kEmitThreads + tid] = (a2 + 16 > l_all && a2 < l_end) ? *reinterpret_cast<const uint4*>(a2) : make_uint4(0, 0, 0, 0);
+            // (lab_al + 16 > l_all: the window begins at a label of the run; how much of it there is, in 32 bits -- the workgroup's value)
+            const uint32_t lim = l_end > lab_al ? (l_end - lab_al < 0xFFFFFFFFull ? uint32_t(l_end - lab_al) : 0xFFFFFFFFu) : 0u;
+            const uint32_t a = 16u * tid, a2 = 16u * (uint32_t(kEmitThreads) + tid);
+            reinterpret_cast<uint4*>(L.labs)[tid] = a < lim ? *reinterpret_cast<const uint4*>(lab_al + a) : make_uint4(0, 0, 0, 0);
+            if (tid < 4) reinterpret_cast<uint4*>(L.labs)[kEmitThreads + tid] = a2 < lim ? *reinterpret_cast<const uint4*>(lab_al + a2) : make_uint4(0, 0, 0, 0);
         }
-        if (mine && my_start >= piece && my_start - piece < kFlatPiece) {
-            const uint32_t r = uint32_t(my_start - piece);
+        if (mine && my_rel - p_off < kFlatPiece) {   // (unsigned: a start in front of the piece is far behind it)
+            const uint32_t r = my_rel - p_off;
             atomicOr(&L.starts[r >> 5], 1u << (r & 31u));
         }
         __syncthreads();
@@ -548,6 +558,8 @@ __global__ __launch_bounds__(kEmitThreads, kTags ? VPT_EMIT_TAG_OCC : VPT_EMIT_O
                 // issued, and the last store of a thread is a byte of its text; the tags' bytes, written below, lie where none of these stores
                 // goes).  Four issue slots a byte where the selects of the general loop below took fifteen: the writer runs at the vector ALU's
                 // issue rate (profiles/r06_r_*).  The variants are the wave's: no '\\' stores without an escaped byte, no tag lengths without a tag.
+                // (Measured and not kept, profiles/r06_v_*: a dword's bytes and spaces picked by two v_perm_b32 with selectors from a table in LDS and stored as
+                // one unaligned ds_write_b64 -- 10 % fewer vector instructions, 7 % slower: the LDS splits the unaligned stores.)
                 uint8_t* const ob = sbytes + head + w;
                 const auto bytes_out = [&](auto esc_c, auto tag_c) {
                     constexpr bool kEsc = decltype(esc_c)::value, kTag = decltype(tag_c)::value;
@@ -572,7 +584,7 @@ __global__ __launch_bounds__(kEmitThreads, kTags ? VPT_EMIT_TAG_OCC : VPT_EMIT_O
                 else if (!any_esc) bytes_out(std::false_type{}, std::true_type{});
                 else bytes_out(std::true_type{}, std::true_type{});
             } else if (store_ok && __ballot(vm != 0) != 0) {   // the same with a select per store: what is not there goes to a slot of the thread's own
-                uint8_t* const dump = reinterpret_cast<uint8_t*>(L.dump + tid);
+                uint8_t* const dump = reinterpret_cast<uint8_t*>(L.dump + wave);
                 uint32_t pos = w, bits = lab;
 #pragma unroll
                 for (uint32_t k = 0; k < 16; ++k) {
@@ -675,336 +687,6 @@ __global__ __launch_bounds__(kEmitThreads, kTags ? VPT_EMIT_TAG_OCC : VPT_EMIT_O
     }
     // (what was written is what the size pass said: anything else means chars, labels, offsets -- or the tags' token words and the labels,
     // which must be the ones fill_tags saw -- do not belong together)
-    if (!fits || at_out != end || cb != (O1 - O0) + ns || sb != ns) err |= kErrBadOffsets;
-    if (err) atomicOr(P.status, err);
-}
-
-// ------------------------------------------------------------------------------------------------------------
-// emit_tile_kernel (round 6): the writer without tags, a run's text read ONCE.
-//
-// What the counters said about emit_flat_kernel<false> (profiles/r06_r_*): 1.44 G vector instructions per launch on configs[2] -- the kernel ran at the
-// vector ALU's issue rate -- and, with those cut to 0.85 G (flag gathers as v_dot4_u32_u8, bytes written unconditionally), the waves wait: seven barriers
-// and a trip to memory per 4 KB piece, the text read twice (once for the run's size, once to write it).  Here a workgroup's run is a TILE of 16 KB of text
-// as a rule (capi_device.cpp sizes the runs for that), held in registers from the size pass on -- four 16-byte chunks per thread, piece-major, so every
-// load is contiguous over the workgroup; their lead / escape masks are taken once; the run's labels become a BIT per label in LDS while they are counted;
-// the block prefix sums of the four pieces (chars and sentence starts, then output bytes) are two barriers for the tile, not four per piece; the
-// look-back comes after them, when the earlier runs have had time to publish.  A piece then costs two barriers: its bytes assembled in LDS, and gone.
-// A run longer than a tile (ragged input) walks its tiles one after the other and reads them again, as emit_flat_kernel did.
-// ------------------------------------------------------------------------------------------------------------
-constexpr uint32_t kTilePieces = 4;
-constexpr uint32_t kTileBytes = kTilePieces * kFlatPiece;   // text a workgroup holds in registers (64 bytes per thread)
-constexpr uint32_t kTileLabChunks = kTileBytes / 16 + 2;    // 16-byte chunks of labels a tile's chars can ask for: a label per char at most, and the two ragged ends
-struct alignas(16) TileLds {
-    uint32_t stage[kFlatStageBytes / 4];
-    uint32_t lbits[(kTileLabChunks + 1) / 2 + 3];   // a bit per label: the chunks' 16-bit masks side by side (+ the dword behind a window's last)
-    uint32_t starts[kTileBytes / 32];               // a bit per byte of the tile: a sentence starts here
-    uint32_t so[kEmitFlatMaxBlock + 1];             // the run's boundary offsets, relative to its first
-    uint32_t dump[kEmitThreads];                    // where a thread's stores of bytes that are not there go
-    uint32_t wt1[kTilePieces][kEmitWaves];          // the waves' sums of the two block prefix sums, every piece of the tile at once
-    uint32_t wt2[kTilePieces / 2][kEmitWaves];
-    uint32_t flags;
-    uint64_t red[kEmitWaves];
-    uint64_t bcast[4];                              // ticket, B0, O0, base
-};
-// which of the 16 bytes at offset `off` lie in [lo, hi) (offsets from the same base)
-__device__ __forceinline__ uint32_t in_range16_rel(uint32_t off, uint32_t lo, uint32_t hi) {
-    const uint32_t a = lo > off ? (lo - off < 16u ? lo - off : 16u) : 0u;
-    const uint32_t b = hi > off ? (hi - off < 16u ? hi - off : 16u) : 0u;
-    return ((1u << b) - 1u) & ~((1u << a) - 1u);   // (b < a: nothing)
-}
-
-__global__ __launch_bounds__(kEmitThreads, VPT_EMIT_OCC) void emit_tile_kernel(const EmitParams P, const EmitFuse F) {
-    __shared__ TileLds L;
-    // the other array of state words, for the call after this one
-    for (uint64_t k = uint64_t(blockIdx.x) * kEmitThreads + threadIdx.x; k < F.clear_n; k += uint64_t(gridDim.x) * kEmitThreads) F.clear[k] = 0;
-    const uint32_t tid = threadIdx.x, lane = tid & 63, wave = wave_uniform(tid >> 6);
-    if (tid == 0) { L.bcast[0] = atomicAdd(reinterpret_cast<unsigned long long*>(F.state + F.n_blocks), 1ull); L.flags = 0; }
-    L.starts[tid] = 0; L.starts[kEmitThreads + tid] = 0;
-    static_assert(kTileBytes / 32 == 2 * kEmitThreads, "two words of the starts per thread");
-    __syncthreads();
-    const uint64_t blk = wave_uniform64(L.bcast[0]);   // (what every thread reads from LDS is the wave's: scalar registers)
-    if (blk >= F.n_blocks) return;
-    const uint64_t i0 = blk * F.per_block;
-    const uint32_t ns = uint32_t(P.n_sent - i0 < F.per_block ? P.n_sent - i0 : F.per_block);
-    // the run's offsets: thread j holds sentence i0 + j's and its successor's
-    uint64_t my_b = ~uint64_t(0), my_o = 0, nx_b = 0, nx_o = 0;
-    const bool mine = tid < ns;
-    if (mine) { my_b = P.boff[i0 + tid]; my_o = P.ooff[i0 + tid]; nx_b = P.boff[i0 + tid + 1]; nx_o = P.ooff[i0 + tid + 1]; }
-    if (tid == 0) { L.bcast[1] = my_b; L.bcast[2] = my_o; }
-    if (tid == ns - 1) { L.red[0] = nx_b; L.red[1] = nx_o; }
-    uint32_t err = 0;
-    {
-        const bool empty = mine && nx_b <= my_b, bad = mine && (nx_o < my_o || nx_o > P.total_boundaries);
-        if (empty) err |= kErrEmptySentence;
-        if (bad) err |= kErrBadOffsets;
-        if (empty || bad) atomicOr(&L.flags, 1u);
-    }
-    __syncthreads();
-    const uint64_t B0 = wave_uniform64(L.bcast[1]), O0 = wave_uniform64(L.bcast[2]), B1 = wave_uniform64(L.red[0]), O1 = wave_uniform64(L.red[1]);
-    const bool sane = wave_uniform(L.flags) == 0 && O1 - O0 < 0xFFFF0000ull && B1 - B0 < 0xFFFF0000ull;
-    if (!sane) err |= kErrBadOffsets;
-    if (mine) L.so[tid] = uint32_t(my_o - O0);
-    if (tid == 0) L.so[ns] = uint32_t(O1 - O0);
-    __syncthreads();   // (red[] is used again below)
-    if (!sane) {   // nothing of the run is read: it takes its place in the chain with no bytes
-        if (wave == 0) {
-            if (lane == 0) publish_run_size(F, blk, 0);
-            const uint64_t base = place_run(F, blk, 0, lane);
-            if (lane == 0) L.bcast[3] = base;
-        }
-        __syncthreads();
-        const uint64_t base = wave_uniform64(L.bcast[3]);
-        if (blk == F.n_blocks - 1 && tid == 0) {
-            P.out_offsets[P.n_sent] = base;
-            if (base > P.capacity) err |= kErrOutputTooSmall;
-            if (F.total_out) *F.total_out = base;
-            if (F.chain_out) *F.chain_out = base;
-        }
-        if (mine) P.out_offsets[i0 + tid] = base;
-        atomicOr(P.status, err);
-        return;
-    }
-
-    const uintptr_t t_lo = reinterpret_cast<uintptr_t>(P.text) + B0, t_hi = reinterpret_cast<uintptr_t>(P.text) + B1;
-    const uintptr_t l_all = reinterpret_cast<uintptr_t>(P.labels), l_lo = l_all + O0, l_hi = l_all + O1;
-    const uintptr_t tb = t_lo & ~uintptr_t(15);            // the tiles' base: every chunk is a 16-byte aligned load
-    const uint32_t lo_rel = uint32_t(t_lo - tb), span = uint32_t(t_hi - tb);
-    const uint32_t n_tiles = (span + kTileBytes - 1u) / kTileBytes;   // (at least one: the run has bytes)
-    const uint32_t my_rel = mine ? uint32_t(my_b - B0) + lo_rel : 0u;   // where the thread's sentence starts, from tb
-    uint8_t* const sbytes = reinterpret_cast<uint8_t*>(L.stage);
-
-    uint4 x[kTilePieces];
-    uint32_t me[kTilePieces];   // the chunks' masks: chars' first bytes | escaped bytes << 16
-    // the chunks of the tile at byte `first` of the run's span: loads, then masks; returns the escaped bytes of the thread's chunks
-    const auto load_tile = [&](uint32_t first) -> uint32_t {
-#pragma unroll
-        for (uint32_t q = 0; q < kTilePieces; ++q) {
-            const uint32_t off = first + q * kFlatPiece + 16u * tid;
-            x[q] = off < span ? *reinterpret_cast<const uint4*>(tb + off) : make_uint4(0, 0, 0, 0);
-        }
-        uint32_t n_esc = 0;
-#pragma unroll
-        for (uint32_t q = 0; q < kTilePieces; ++q) {
-            const uint32_t vm = in_range16_rel(first + q * kFlatPiece + 16u * tid, lo_rel, span);
-            const uint32_t lm = lead16(x[q]) & vm, em = esc16(x[q]) & vm;
-            me[q] = lm | (em << 16);
-            n_esc += uint32_t(__popc(em));
-        }
-        return n_esc;
-    };
-    // label bits of the window that starts at label `first` of the run (a tile's chars ask for labels from there on): a bit per label, bit lab_head first
-    const auto stage_labels = [&](uint64_t first) -> uint32_t {
-        const uintptr_t la = l_lo + first, lbt = la & ~uintptr_t(15);
-        if (la < l_hi) {
-            const uint64_t n_all = (l_hi - lbt + 15) >> 4;
-            const uint32_t n = n_all < kTileLabChunks ? uint32_t(n_all) : kTileLabChunks;
-            for (uint32_t c = tid; c < n; c += kEmitThreads) {
-                const uintptr_t a = lbt + 16u * c;
-                const uint4 y = *reinterpret_cast<const uint4*>(a);
-                reinterpret_cast<uint16_t*>(L.lbits)[c] = uint16_t(one16(y) & in_range16(a, l_lo, l_hi));
-            }
-        }
-        return uint32_t(la - lbt);
-    };
-
-    // ---- the run's size = its bytes + the escaped bytes + the boundary labels of its label range; tile 0 stays in the registers, its labels' bits
-    // and its sentences' starts in LDS
-    uint64_t size;
-    uint32_t lab_head = uint32_t(l_lo & 15u);
-    {
-        uint32_t added = 0;
-        for (uint32_t t = n_tiles; t-- > 0;) added += load_tile(t * kTileBytes);   // (tile 0 last)
-        if (l_hi > l_lo) {
-            const uintptr_t lb = l_lo & ~uintptr_t(15);
-            const uint32_t n = uint32_t((l_hi - lb + 15) >> 4);
-            for (uint32_t c = tid; c < n; c += kEmitThreads) {
-                const uintptr_t a = lb + 16u * c;
-                const uint4 y = *reinterpret_cast<const uint4*>(a);
-                const uint32_t m = in_range16(a, l_lo, l_hi), ones = one16(y) & m;
-                added += uint32_t(__popc(ones));
-                if (unk16(y) & m) err |= kErrUnknownLabel;
-                if (c < kTileLabChunks) reinterpret_cast<uint16_t*>(L.lbits)[c] = uint16_t(ones);
-            }
-        }
-        if (mine && my_rel < kTileBytes) atomicOr(&L.starts[my_rel >> 5], 1u << (my_rel & 31u));
-        const uint64_t ws = wave_sum64(added);
-        if (lane == 0) L.red[wave] = ws;
-        __syncthreads();
-        size = B1 - B0;
-#pragma unroll
-        for (uint32_t k = 0; k < uint32_t(kEmitWaves); ++k) size += wave_uniform64(L.red[k]);
-    }
-    if (tid == 0) publish_run_size(F, blk, size);   // (as early as it is known: the runs behind this one add it up)
-
-    uint64_t at_out = 0, end = 0, cb = 0, sb = 0;   // output position, the run's end, chars and sentence starts in front of the tile
-    bool fits = true, store_ok = false;
-    for (uint32_t t = 0; t < n_tiles; ++t) {
-        const uint32_t first = t * kTileBytes;
-        if (t) {   // (a run of several tiles) the tile's starts and label bits replace the last one's
-            __syncthreads();
-            L.starts[tid] = 0; L.starts[kEmitThreads + tid] = 0;
-            __syncthreads();
-            (void)load_tile(first);
-            lab_head = stage_labels(cb - sb);
-            if (mine && my_rel >= first && my_rel - first < kTileBytes) atomicOr(&L.starts[(my_rel - first) >> 5], 1u << ((my_rel - first) & 31u));
-            __syncthreads();
-        } else if (n_tiles > 1) (void)load_tile(0);
-        // chars and sentence starts in front of every chunk: one block prefix sum for the tile's pieces
-        uint32_t vs[kTilePieces], pk[kTilePieces], in[kTilePieces];   // in range | starts << 16; the chunks' chars | starts << 16; those in front
-#pragma unroll
-        for (uint32_t q = 0; q < kTilePieces; ++q) {
-            const uint32_t vm = in_range16_rel(first + q * kFlatPiece + 16u * tid, lo_rel, span), lm = me[q] & 0xFFFFu;
-            uint32_t sm = reinterpret_cast<const uint16_t*>(L.starts)[q * kEmitThreads + tid];
-            if (sm & ~lm) err |= kErrBadOffsets;   // a sentence that starts inside a char (or outside the run)
-            sm &= lm;
-            vs[q] = vm | (sm << 16);
-            pk[q] = uint32_t(__popc(lm)) | (uint32_t(__popc(sm)) << 16);
-            in[q] = wave_inclusive_scan(pk[q]);
-            if (lane == 63) L.wt1[q][wave] = in[q];
-        }
-        __syncthreads();
-        uint32_t tile_tot = 0;
-#pragma unroll
-        for (uint32_t q = 0; q < kTilePieces; ++q) {
-            uint32_t woff = 0, tot = 0;
-#pragma unroll
-            for (uint32_t k = 0; k < uint32_t(kEmitWaves); ++k) {
-                const uint32_t u = wave_uniform(L.wt1[q][k]);
-                if (k < wave) woff += u;
-                tot += u;
-            }
-            in[q] = tile_tot + woff + in[q] - pk[q];
-            tile_tot += tot;
-        }
-        // the labels of every chunk's chars and with them its output bytes; the second prefix sum, two pieces to a dword
-        uint32_t lw[kTilePieces], tq[kTilePieces];   // label bits | place in the piece's output << 16
-#pragma unroll
-        for (uint32_t q = 0; q < kTilePieces; ++q) {
-            const uint32_t lm = me[q] & 0xFFFFu, em = me[q] >> 16, vm = vs[q] & 0xFFFFu, sm = vs[q] >> 16;
-            const uint32_t loff = lab_head + (in[q] & 0xFFFFu) - (in[q] >> 16);   // the chunk's first label: a bit of lbits
-            const uint32_t lab = __builtin_amdgcn_alignbit(L.lbits[(loff >> 5) + 1], L.lbits[loff >> 5], loff & 31u) & 0xFFFFu;
-            const uint32_t n_sp = uint32_t(__popc(lab & ((1u << uint32_t(__popc(lm & ~sm))) - 1u)));
-            lw[q] = lab;
-            tq[q] = uint32_t(__popc(vm)) + n_sp + uint32_t(__popc(em));
-        }
-        uint32_t totals[kTilePieces];
-#pragma unroll
-        for (uint32_t j = 0; j < kTilePieces / 2; ++j) {
-            const uint32_t p = tq[2 * j] | (tq[2 * j + 1] << 16), inc = wave_inclusive_scan(p);
-            if (lane == 63) L.wt2[j][wave] = inc;
-            tq[2 * j] = inc - p;   // (the wave's part; the rest behind the barrier)
-        }
-        __syncthreads();
-#pragma unroll
-        for (uint32_t j = 0; j < kTilePieces / 2; ++j) {
-            uint32_t woff = 0, tot = 0;
-#pragma unroll
-            for (uint32_t k = 0; k < uint32_t(kEmitWaves); ++k) {
-                const uint32_t u = wave_uniform(L.wt2[j][k]);
-                if (k < wave) woff += u;
-                tot += u;
-            }
-            const uint32_t e = woff + tq[2 * j];
-            lw[2 * j] |= (e & 0xFFFFu) << 16; lw[2 * j + 1] |= (e >> 16) << 16;
-            totals[2 * j] = tot & 0xFFFFu; totals[2 * j + 1] = tot >> 16;
-        }
-        if (t == 0) {   // ---- the run's position: wave 0 looks back over the earlier runs' words (they have had the prefix sums' time to publish)
-            if (wave == 0) {
-                const uint64_t base = place_run(F, blk, size, lane);
-                if (lane == 0) L.bcast[3] = base;
-            }
-            __syncthreads();
-            at_out = wave_uniform64(L.bcast[3]);
-            end = at_out + size;
-            store_ok = end <= P.capacity;
-            if (blk == F.n_blocks - 1 && tid == 0) {
-                P.out_offsets[P.n_sent] = end;
-                if (end > P.capacity) err |= kErrOutputTooSmall;
-                if (F.total_out) *F.total_out = end;
-                if (F.chain_out) *F.chain_out = end;
-            }
-        }
-        // ---- the pieces: every byte of the tile to its place
-        // (one copy of the piece's code, its registers picked by selects: unrolled, the compiler computes the four pieces' bits and bytes ahead -- 163 VGPRs)
-        const auto pick = [](const uint32_t (&a)[kTilePieces], uint32_t q) -> uint32_t { return q == 0 ? a[0] : q == 1 ? a[1] : q == 2 ? a[2] : a[3]; };
-#pragma unroll 1
-        for (uint32_t q = 0; q < kTilePieces; ++q) {
-            if (first + q * kFlatPiece >= span) break;   // (the same in every thread) the run ends in front of this piece
-            const uint32_t total = pick(totals, q);
-            if (at_out + total > end) { fits = false; break; }   // (the same in every thread)
-            const uint32_t me_q = pick(me, q), vs_q = pick(vs, q), lw_q = pick(lw, q), in_q = pick(in, q);
-            uint4 xq;
-            xq.x = q == 0 ? x[0].x : q == 1 ? x[1].x : q == 2 ? x[2].x : x[3].x; xq.y = q == 0 ? x[0].y : q == 1 ? x[1].y : q == 2 ? x[2].y : x[3].y;
-            xq.z = q == 0 ? x[0].z : q == 1 ? x[1].z : q == 2 ? x[2].z : x[3].z; xq.w = q == 0 ? x[0].w : q == 1 ? x[1].w : q == 2 ? x[2].w : x[3].w;
-            const uint32_t lm = me_q & 0xFFFFu, em = me_q >> 16, vm = vs_q & 0xFFFFu, sm = vs_q >> 16, lab = lw_q & 0xFFFFu, w = lw_q >> 16;
-            const uint32_t c_in = in_q & 0xFFFFu, s_in = in_q >> 16, nm = lm & ~sm;
-            uint8_t* const dst = P.out_text + at_out;
-            const uint32_t head = uint32_t(reinterpret_cast<uintptr_t>(dst) & 15u);
-            if (store_ok) {
-                if (__ballot(vm != 0xFFFFu) == 0) {
-                    // (wave-uniform) every lane's sixteen bytes are the run's.  The thread's bytes in order, [' '] ['\\'] byte, with no selects: a ' ' (and a
-                    // '\\') is written where it WOULD stand and the position moves on only if it does -- what follows overwrites it otherwise (the LDS
-                    // takes a wave's stores in the order they were issued, and the last store of a thread is a byte of its text)
-                    uint8_t* const ob = sbytes + head + w;
-                    const auto bytes_out = [&](auto esc_c) {
-                        constexpr bool kEsc = decltype(esc_c)::value;
-                        uint32_t ins = 0, bits = lab, mk = nm, ek = em;
-#pragma unroll
-                        for (uint32_t k = 0; k < 16; ++k) {
-                            if ((k & 3u) == 0) VPT_OPAQUE3(mk, ek, ins);   // (a dword at a time: see emit_flat_kernel)
-                            const uint32_t nmk = (mk >> k) & 1u, sp = nmk & bits;   // a labelled char takes the next label
-                            bits >>= nmk;
-                            ob[ins + k] = 0x20u; ins += sp;
-                            if (kEsc) { ob[ins + k] = 0x5Cu; ins += (ek >> k) & 1u; }
-                            ob[ins + k] = uint8_t(byte_of(xq, k));
-                        }
-                    };
-                    if (__ballot(em != 0) == 0) bytes_out(std::false_type{});
-                    else bytes_out(std::true_type{});
-                } else if (__ballot(vm != 0) != 0) {   // the run's ends: byte by byte, only what is there (two waves of a run at most)
-                    uint8_t* const o = sbytes + head;
-                    uint32_t pos = w, bits = lab;
-#pragma unroll 1
-                    for (uint32_t k = 0; k < 16; ++k) {
-                        if (!((vm >> k) & 1u)) continue;
-                        if ((nm >> k) & 1u) { if (bits & 1u) o[pos++] = 0x20u; bits >>= 1; }
-                        if ((em >> k) & 1u) o[pos++] = 0x5Cu;
-                        o[pos++] = uint8_t(byte_of_rt(xq, k));
-                    }
-                }
-            }
-            uint32_t rem = sm;   // the sentences that start in the thread's bytes (few threads, one as a rule)
-            while (rem) {
-                const uint32_t k = uint32_t(__ffs(int(rem))) - 1u, below = (1u << k) - 1u;
-                rem &= rem - 1u;
-                const uint64_t s = sb + s_in + uint32_t(__popc(sm & below));
-                if (s < ns) {
-                    P.out_offsets[i0 + s] = at_out + w + uint32_t(__popc(vm & below)) + uint32_t(__popc(lab & ((1u << uint32_t(__popc(nm & below))) - 1u))) + uint32_t(__popc(em & below));
-                    if (cb + c_in + uint32_t(__popc(lm & below)) != uint64_t(L.so[s]) + s) err |= kErrBadOffsets;   // not the char its offset names
-                } else err |= kErrBadOffsets;
-            }
-            __syncthreads();
-            if (store_ok) {   // LDS byte j is output byte j - head: whole 16-byte chunks leave aligned, the two edges byte by byte
-                uint8_t* const abase = dst - head;
-                const uint32_t nd = (head + total + 15u) >> 4;
-                for (uint32_t d = tid; d < nd; d += kEmitThreads) {
-                    const uint32_t lo = d * 16u, hi = lo + 16u;
-                    if (lo >= head && hi <= head + total) {
-                        *reinterpret_cast<uint4*>(abase + lo) = reinterpret_cast<const uint4*>(L.stage)[d];
-                    } else {
-                        const uint32_t a = lo > head ? lo : head, b = hi < head + total ? hi : head + total;
-                        for (uint32_t j = a; j < b; ++j) abase[j] = sbytes[j];
-                    }
-                }
-            }
-            __syncthreads();   // the next piece rewrites the stage
-            at_out += total;
-        }
-        if (!fits) break;
-        cb += tile_tot & 0xFFFFu;
-        sb += tile_tot >> 16;
-    }
-    // (what was written is what the size pass said: anything else means chars, labels and offsets do not belong together)
     if (!fits || at_out != end || cb != (O1 - O0) + ns || sb != ns) err |= kErrBadOffsets;
     if (err) atomicOr(P.status, err);
 }
@@ -1122,11 +804,7 @@ hipError_t launch_count_boundaries(const uint8_t* text, const uint64_t* boff, ui
 
 hipError_t launch_emit_tokenized(const EmitParams& P, const EmitFuse& F, hipStream_t stream) {   // a workgroup per run of sentences
     if (P.records) hipLaunchKernelGGL(emit_flat_kernel<true>, dim3(uint32_t(F.n_blocks)), dim3(kEmitThreads), 0, stream, P, F);
-#ifdef VPT_EMIT_FLAT_UNTAGGED   // (A/B builds: round 5's kernel without tags)
     else hipLaunchKernelGGL(emit_flat_kernel<false>, dim3(uint32_t(F.n_blocks)), dim3(kEmitThreads), 0, stream, P, F);
-#else
-    else hipLaunchKernelGGL(emit_tile_kernel, dim3(uint32_t(F.n_blocks)), dim3(kEmitThreads), 0, stream, P, F);
-#endif
     return hipGetLastError();
 }
 
