@@ -202,7 +202,7 @@ struct alignas(16) FlatLds {
     uint32_t starts[kFlatPiece / 32];         // one bit per byte of the piece: a sentence starts here
     uint32_t so[kEmitFlatMaxBlock + 1];       // the run's boundary offsets, relative to its first
     uint32_t dump[kEmitWaves];                // where a wave's stores of bytes that are not there go (nobody reads it)
-    uint32_t wtot[kEmitWaves];
+    uint32_t wtot[kEmitWaves], wtot1[kEmitWaves], wtot2[kEmitWaves];   // the waves' sums: of the sums that come in loops, of a piece's first and of its second
     uint32_t flags;                           // OR of the threads' "my offsets are no offsets"
     uint64_t red[kEmitWaves];
     uint64_t bcast[4];                        // ticket, B0, O0, base
@@ -220,7 +220,9 @@ struct alignas(16) FlatMarks {
     uint2 str[kStash + 1][2];
 };
 
-// exclusive prefix sum of x over the workgroup's threads (two packed 16-bit counts or one 32-bit one); *total = the sum
+// exclusive prefix sum of x over the workgroup's threads (two packed 16-bit counts or one 32-bit one); *total = the sum.  kAgain: the same wtot
+// serves the next sum at once (a loop of sums) -- a second barrier; the sums of a piece that come once have words of their own and take one
+template <bool kAgain = true>
 __device__ __forceinline__ uint32_t flat_block_scan(uint32_t x, uint32_t* wtot, uint32_t lane, uint32_t wave, uint32_t* total) {
     const uint32_t incl = wave_inclusive_scan(x);
     if (lane == 63) wtot[wave] = incl;
@@ -232,7 +234,7 @@ __device__ __forceinline__ uint32_t flat_block_scan(uint32_t x, uint32_t* wtot, 
         if (k < wave) woff += u;
         tot += u;
     }
-    __syncthreads();   // wtot is written again by the next sum
+    if (kAgain) __syncthreads();   // wtot is written again by the next sum
     *total = tot;
     return woff + incl - x;
 }
@@ -346,18 +348,25 @@ __global__ __launch_bounds__(kEmitThreads, kTags ? VPT_EMIT_TAG_OCC : VPT_EMIT_O
     if (sane) {
         uint32_t added = 0;
         const uintptr_t l_lo = l_all + O0, l_hi = l_all + O1;
-        for (uint32_t off = 16u * tid; off < span; off += 4 * kFlatPiece) {   // four loads in flight
-            uint4 x[4];
+        // (one loop for text and labels, six loads in flight: a run of 48 KB and its 16 KB of labels are three trips to memory -- as two loops of
+        // four and one loads they were seven, and the workgroup does nothing else while it waits for its size: profiles/r06_w_*)
+        constexpr uint32_t kT = 4, kY = 2;
+        const uintptr_t lb = l_lo & ~uintptr_t(15);
+        const uint32_t llo = uint32_t(l_lo - lb), lspan = l_hi > l_lo ? uint32_t(l_hi - lb) : 0u;   // (O1 - O0 < 4 GB: `sane`)
+        for (uint32_t toff = 16u * tid, loff = 16u * tid; toff < span || loff < lspan; toff += kT * kFlatPiece, loff += kY * kFlatPiece) {
+            uint4 x[kT], y[kY];
 #pragma unroll
-            for (uint32_t q = 0; q < 4; ++q) x[q] = off + q * kFlatPiece < span ? *reinterpret_cast<const uint4*>(tb + off + q * kFlatPiece) : make_uint4(0, 0, 0, 0);
+            for (uint32_t q = 0; q < kT; ++q) x[q] = toff + q * kFlatPiece < span ? *reinterpret_cast<const uint4*>(tb + toff + q * kFlatPiece) : make_uint4(0, 0, 0, 0);
 #pragma unroll
-            for (uint32_t q = 0; q < 4; ++q) added += uint32_t(__popc(esc16(x[q]) & in_range16_rel(off + q * kFlatPiece, lo_rel, span)));
-        }
-        for (uintptr_t a = (l_lo & ~uintptr_t(15)) + 16u * tid; a < l_hi; a += kFlatPiece) {
-            const uint4 y = *reinterpret_cast<const uint4*>(a);
-            const uint32_t m = in_range16(a, l_lo, l_hi);
-            added += uint32_t(__popc(one16(y) & m));
-            if (unk16(y) & m) err |= kErrUnknownLabel;
+            for (uint32_t q = 0; q < kY; ++q) y[q] = loff + q * kFlatPiece < lspan ? *reinterpret_cast<const uint4*>(lb + loff + q * kFlatPiece) : make_uint4(0, 0, 0, 0);
+#pragma unroll
+            for (uint32_t q = 0; q < kT; ++q) added += uint32_t(__popc(esc16(x[q]) & in_range16_rel(toff + q * kFlatPiece, lo_rel, span)));
+#pragma unroll
+            for (uint32_t q = 0; q < kY; ++q) {
+                const uint32_t m = in_range16_rel(loff + q * kFlatPiece, llo, lspan);
+                added += uint32_t(__popc(one16(y[q]) & m));
+                if (unk16(y[q]) & m) err |= kErrUnknownLabel;
+            }
         }
         if (kTags) {   // the bytes of the run's tag suffixes: fill_tags left them in the records' token words (layout.h)
             for (uint64_t r = r_lo + tid; r < r_hi; r += kEmitThreads) {
@@ -425,7 +434,7 @@ __global__ __launch_bounds__(kEmitThreads, kTags ? VPT_EMIT_TAG_OCC : VPT_EMIT_O
         sm &= lm;
         const uint32_t nl = uint32_t(__popc(lm)), nst = uint32_t(__popc(sm));
         uint32_t tot;
-        const uint32_t excl = flat_block_scan(nl | (nst << 16), L.wtot, lane, wave, &tot);   // (its barriers: every thread has read its starts)
+        const uint32_t excl = flat_block_scan<false>(nl | (nst << 16), L.wtot1, lane, wave, &tot);   // (its barrier: every thread has read its starts)
         if (tid < kFlatPiece / 32) L.starts[tid] = 0;
         const uint32_t c_in = excl & 0xFFFFu, s_in = excl >> 16;   // chars / starts of the piece in front of this thread
         // the thread's chars that have a label in front take consecutive labels from (c_in - s_in) of the window on: label q of the thread = bit q of lab
@@ -543,7 +552,7 @@ __global__ __launch_bounds__(kEmitThreads, kTags ? VPT_EMIT_TAG_OCC : VPT_EMIT_O
         }
         const uint32_t t = uint32_t(__popc(vm)) + n_sp + uint32_t(__popc(em)) + sfx_total;
         uint32_t total;
-        const uint32_t w = flat_block_scan(t, L.wtot, lane, wave, &total);
+        const uint32_t w = flat_block_scan<false>(t, L.wtot2, lane, wave, &total);
         if (at_out + total > end) { fits = false; break; }   // (the same in every thread)
         uint8_t* const dst = P.out_text + at_out;
         const uint32_t head = uint32_t(reinterpret_cast<uintptr_t>(dst) & 15u);
