@@ -1561,6 +1561,32 @@ def test_write_tokenized_text_on_device():
     assert np.array_equal(d_toff.get(S + 1), want_off) and np.array_equal(d_out.get(int(want_off[-1])), want_text)
 
 
+def test_writer_every_byte_value_at_every_alignment():
+    """The writer's masks (which bytes begin a char, which are escaped: sentence.rs:850-886 escapes ' ', '\\' and '/') come from byte flags gathered
+    sixteen at a time (device_common.h, flag_bytes_to_mask16 / esc_flags, round 6): every byte value a text can hold -- every ASCII char but NUL, lead
+    and continuation bytes of two-, three- and four-byte chars -- at every offset of a 16-byte chunk, with and without a space in front; waves whose
+    chunks hold no escaped byte take another loop than those that do, and a run's ragged ends a third."""
+    raw, _ = kat.load_fixture("model.bin")
+    pred = api.Predictor(api.Model.read_slice(raw)[0], False)
+    rng = np.random.default_rng(23)
+    chars = [chr(c) for c in range(1, 128)] + ["\u00e9", "\u07ff", "\u3042", "\u6f22", "\uffee", "\U0001f90c", "\U0010ffff"]
+    texts = []
+    for shift in range(16):
+        for c in chars:
+            texts.append("a" * shift + c + "\u3042" * 3)                      # the byte at offset `shift` of its chunk
+    texts += ["\u6f22\u5b57" * 700, "x" * 5000, "/ \\" * 900]                # long runs without and with escaped bytes (whole waves of either kind)
+    texts += ["".join(rng.choice(chars, size=int(n))) for n in rng.integers(1, 200, 200)]
+    utf8, boff = api.pack_texts([t.encode("utf-8") for t in texts])
+    ooff = api.count_boundaries(utf8, boff)
+    for p_one in (0.0, 0.35, 1.0):
+        labels = (rng.random(int(ooff[-1])) < p_one).astype(np.uint8)
+        text, toff = pred.write_tokenized_packed(utf8, boff, ooff, labels)
+        got = bytes(text)
+        for i, t in enumerate(texts):
+            want = _tokenized_reference(t, labels[int(ooff[i]):int(ooff[i + 1])])
+            assert got[int(toff[i]):int(toff[i + 1])].decode("utf-8") == want, (p_one, i, t[:40])
+
+
 def test_write_tagged_text_on_device():
     """vpt_write_tagged_batch = fill_tags + write_tokenized_text with "/tag" suffixes (sentence.rs:850-886) on the device."""
     # the reference's own tagged outputs (resources/docs.tok lines, kat.FIXTURE_TAGGED)

@@ -51,7 +51,7 @@ _AS_IS = [
     "test_tag_models_inside_and_outside_the_record_form", "test_fill_tags_front_end_stores_for_any_tag_count_and_alignment", "test_fill_tags_front_end_where_the_labels_run_out", "test_tag_models_under_wide_windows", "test_fill_tags_as_two_launches", "test_tag_front_end_over_runs_of_sentences", "test_tokenize_with_the_grapheme_cluster_filter", "test_stored_tag_scores_reproduce_the_scorer_kats", "test_stored_tag_scores_match_oracle_on_random_models", "test_tag_token_table_keys_and_queue",
     "test_converted_kytea_fixture_on_gpu", "test_fullwidth_filter_on_device", "test_label_post_filters_on_device",
     "test_device_resident_predict_then_fill_tags", "test_chars_left_by_predict_are_never_another_batchs", "test_fill_tags_with_offsets_that_do_not_match_the_text",
-    "test_write_tokenized_text_on_device", "test_writer_blocks_of_any_size", "test_concurrent_host_threads_share_a_predictor",
+    "test_write_tokenized_text_on_device", "test_writer_every_byte_value_at_every_alignment", "test_writer_blocks_of_any_size", "test_concurrent_host_threads_share_a_predictor",
     "test_write_tagged_text_on_device", "test_predict_and_write_in_one_launch", "test_count_boundaries_on_the_device_flat_kernel", "test_tokenize_batch_into_pinned_buffers", "test_tokenize_batch_is_the_whole_pipeline",
     "test_tokenize_batch_in_chunks", "test_device_calls_accept_an_upper_bound_of_the_boundaries",
     "test_compiled_predictor_round_trip_and_clone", "test_compiled_predictor_rejects_damaged_blobs",

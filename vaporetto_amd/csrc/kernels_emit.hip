@@ -30,7 +30,16 @@ constexpr uint64_t kScanBlock = uint64_t(kScanThreads) * kScanPer;   // offsets 
 // string -- rec_str says where it starts in str_bytes and how long it is (an empty one for a None in between); `pre`: the first two slots'
 // entries when the caller has them at hand already (LDS), else nullptr.  Returns the bytes it takes; written to `dst` when given -- never more
 // than `limit` of them (what was reserved for it).
-__device__ __forceinline__ uint32_t tag_suffix_write(const EmitParams& P, uint64_t ri, uint32_t last, const uint2* pre, uint8_t* dst, uint32_t limit = 0xFFFFFFFFu) {
+// (What the suffix routines read of the kernel's parameters, BY VALUE: tag_suffix is a call, and a reference to the parameter block made the
+// compiler keep the whole block in scratch memory -- 128 bytes a lane written at the kernel's start, every P.field of the kernel a scratch load;
+// found in round 6 by reading the ISA.)
+struct TagStrings {
+    const uint4* records;
+    const uint2* rec_str;
+    const uint8_t* str_bytes;
+    uint32_t n_tags;
+};
+__device__ __forceinline__ uint32_t tag_suffix_write(const TagStrings P, uint64_t ri, uint32_t last, const uint2* pre, uint8_t* dst, uint32_t limit = 0xFFFFFFFFu) {
     const uint2* rs = P.rec_str + ri * P.n_tags;
     if (last > P.n_tags) last = P.n_tags;
     uint32_t n = 0;
@@ -47,11 +56,11 @@ __device__ __forceinline__ uint32_t tag_suffix_write(const EmitParams& P, uint64
 }
 // the bytes of the suffix of the token of record ri, whose token word is w (layout.h) and whose suffix has `last` slots: carried from fill_tags
 // unless it is a long one
-__device__ __forceinline__ uint32_t tag_suffix_bytes(const EmitParams& P, uint64_t ri, uint32_t w, uint32_t last) {
+__device__ __forceinline__ uint32_t tag_suffix_bytes(const TagStrings P, uint64_t ri, uint32_t w, uint32_t last) {
     const uint32_t code = w >> kTokSuffixShift;
     return (w & kTokModelMask) == 0 ? 0u : code != kTokSuffixLong ? code : tag_suffix_write(P, ri, last, nullptr, nullptr);
 }
-__device__ __noinline__ uint32_t tag_suffix(const EmitParams& P, uint64_t ri, uint8_t* dst, uint32_t limit = 0xFFFFFFFFu) {   // (the rare paths: everything from HBM)
+__device__ __noinline__ uint32_t tag_suffix(const TagStrings P, uint64_t ri, uint8_t* dst, uint32_t limit = 0xFFFFFFFFu) {   // (the rare paths: everything from HBM)
     const uint4 rec = P.records[ri];
     return (rec.z & kTokModelMask) == 0 ? 0u : tag_suffix_write(P, ri, rec.w, nullptr, dst, limit);
 }
@@ -283,6 +292,7 @@ template <bool kTags>
 __global__ __launch_bounds__(kEmitThreads, kTags ? VPT_EMIT_TAG_OCC : VPT_EMIT_OCC) void emit_flat_kernel(const EmitParams P, const EmitFuse F) {
     __shared__ FlatLds L;
     __shared__ FlatMarks MK[1];   // (with tags; the instance without never touches it and the compiler drops it)
+    const TagStrings TS{P.records, P.rec_str, P.str_bytes, P.n_tags};
     // the other array of state words, for the call after this one
     for (uint64_t k = uint64_t(blockIdx.x) * kEmitThreads + threadIdx.x; k < F.clear_n; k += uint64_t(gridDim.x) * kEmitThreads) F.clear[k] = 0;
     const uint32_t tid = threadIdx.x, lane = tid & 63, wave = wave_uniform(tid >> 6);
@@ -372,7 +382,7 @@ __global__ __launch_bounds__(kEmitThreads, kTags ? VPT_EMIT_TAG_OCC : VPT_EMIT_O
             for (uint64_t r = r_lo + tid; r < r_hi; r += kEmitThreads) {
                 const uint4 rec = P.records[r];
                 const uint64_t pos = uint64_t(rec.x) | (uint64_t(rec.y) << 32);
-                if (pos >= g0 && pos < g1 && !(VPT_EMIT_ABLATE & 6)) added += tag_suffix_bytes(P, r, rec.z, rec.w);
+                if (pos >= g0 && pos < g1 && !(VPT_EMIT_ABLATE & 6)) added += tag_suffix_bytes(TS, r, rec.z, rec.w);
             }
         }
         const uint64_t ws = wave_sum64(added);
@@ -529,7 +539,7 @@ __global__ __launch_bounds__(kEmitThreads, kTags ? VPT_EMIT_TAG_OCC : VPT_EMIT_O
                     uint32_t word, last;
                     if (si != ~0u) { word = SK.word[si]; last = SK.last[si]; }
                     else { const uint4 rec = P.records[ri]; word = rec.z; last = rec.w; }
-                    const uint32_t len = tag_suffix_bytes(P, ri, word, last);   // (carried from fill_tags)
+                    const uint32_t len = tag_suffix_bytes(TS, ri, word, last);   // (carried from fill_tags)
                     if (!len) continue;
                     if (tk1 == 16) { tk1 = k; tl1 = len; tr1 = ri; ts1 = si; }
                     else if (tk2 == 16) { tk2 = k; tl2 = len; tr2 = ri; ts2 = si; }
@@ -547,7 +557,7 @@ __global__ __launch_bounds__(kEmitThreads, kTags ? VPT_EMIT_TAG_OCC : VPT_EMIT_O
                 todo &= todo - 1u;
                 uint32_t si;
                 const uint64_t ri = rec_at(c_in + uint32_t(__popc(lm & (low - 1u))), &si);
-                if (ri != ~uint64_t(0)) sfx_total += tag_suffix(P, ri, nullptr);
+                if (ri != ~uint64_t(0)) sfx_total += tag_suffix(TS, ri, nullptr);
             }
         }
         const uint32_t t = uint32_t(__popc(vm)) + n_sp + uint32_t(__popc(em)) + sfx_total;
@@ -610,7 +620,7 @@ __global__ __launch_bounds__(kEmitThreads, kTags ? VPT_EMIT_TAG_OCC : VPT_EMIT_O
                 const uint32_t b1 = (1u << tk1) - 1u, b2 = (1u << tk2) - 1u;
                 // (their strings' places wait in LDS as a rule: the bytes are one trip away)
                 const auto put = [&](uint64_t ri, uint32_t si, uint8_t* at, uint32_t len) -> bool {
-                    return si != ~0u ? tag_suffix_write(P, ri, SK.last[si], SK.str[si], at, len) == len : tag_suffix(P, ri, at, len) == len;
+                    return si != ~0u ? tag_suffix_write(TS, ri, SK.last[si], SK.str[si], at, len) == len : tag_suffix(TS, ri, at, len) == len;
                 };
                 if (!put(tr1, ts1, o + w + uint32_t(__popc(vm & b1)) + uint32_t(__popc(spm & b1)) + uint32_t(__popc(em & b1)), tl1)) err |= kErrBadOffsets;
                 if (tl2 && !put(tr2, ts2, o + w + tl1 + uint32_t(__popc(vm & b2)) + uint32_t(__popc(spm & b2)) + uint32_t(__popc(em & b2)), tl2)) err |= kErrBadOffsets;
@@ -633,7 +643,7 @@ __global__ __launch_bounds__(kEmitThreads, kTags ? VPT_EMIT_TAG_OCC : VPT_EMIT_O
 #pragma unroll 1
             for (uint32_t k = 0; k < 16; ++k) {
                 if (!((vm >> k) & 1u)) continue;
-                if ((tmask >> k) & 1u) { uint32_t si; const uint64_t ri = rec_at(c_in + ci, &si); if (ri != ~uint64_t(0)) pos += tag_suffix(P, ri, o ? o + pos : nullptr); }
+                if ((tmask >> k) & 1u) { uint32_t si; const uint64_t ri = rec_at(c_in + ci, &si); if (ri != ~uint64_t(0)) pos += tag_suffix(TS, ri, o ? o + pos : nullptr); }
                 if ((spm >> k) & 1u) { if (o) o[pos] = 0x20u; ++pos; }
                 if ((sm >> k) & 1u) {
                     const uint64_t s = sb + s_in + uint32_t(__popc(sm & ((1u << k) - 1u)));
@@ -690,8 +700,8 @@ __global__ __launch_bounds__(kEmitThreads, kTags ? VPT_EMIT_TAG_OCC : VPT_EMIT_O
     }
     if (kTags && fits && carry_rec != ~uint64_t(0) && !(VPT_EMIT_ABLATE & 6)) {   // the tags of the run's last token: the record, if any, of its last char
         const uint4 rec = P.records[carry_rec];
-        const uint32_t sl = (uint64_t(rec.x) | (uint64_t(rec.y) << 32)) == g1 - 1 ? tag_suffix(P, carry_rec, nullptr) : 0u;   // (every thread computes the same)
-        if (sl && store_ok && at_out + sl <= end && tid == 0) tag_suffix(P, carry_rec, P.out_text + at_out);
+        const uint32_t sl = (uint64_t(rec.x) | (uint64_t(rec.y) << 32)) == g1 - 1 ? tag_suffix(TS, carry_rec, nullptr) : 0u;   // (every thread computes the same)
+        if (sl && store_ok && at_out + sl <= end && tid == 0) tag_suffix(TS, carry_rec, P.out_text + at_out);
         at_out += sl;
     }
     // (what was written is what the size pass said: anything else means chars, labels, offsets -- or the tags' token words and the labels,
