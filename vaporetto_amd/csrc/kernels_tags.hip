@@ -88,6 +88,7 @@ __global__ __launch_bounds__(kTagThreads) void decode_chars_kernel(const uint8_t
     __shared__ uint16_t masks[kTagThreads];   // lead mask of every 16-byte chunk of the piece
     __shared__ uint32_t pfx[kTagThreads];     // leads of the piece in front of the chunk
     __shared__ uint32_t wtot[kTagWaves];
+    __shared__ uint32_t tlut[80];             // CharacterType nibbles of ASCII, U+30xx and U+FFxx (below)
     const uint32_t tid = threadIdx.x, lane = tid & 63, wave = wave_uniform(tid >> 6);
     const uint64_t s0 = uint64_t(blockIdx.x) * per_block;
     if (s0 >= n_sent) return;
@@ -105,9 +106,23 @@ __global__ __launch_bounds__(kTagThreads) void decode_chars_kernel(const uint8_t
         my_want = sane ? o1 - o0 + 1 : 0;
     }
     uint32_t err = (mine && !sane) ? kErrBadOffsets : 0u;
-    if (B1 <= B0 || G0 > total_chars) { if (tid == 0) atomicOr(status, kErrBadOffsets); return; }
+    if (B1 <= B0 || G0 > total_chars || B1 - B0 >= 0xFFFFFF00ull) { if (tid == 0) atomicOr(status, kErrBadOffsets); return; }   // (a run of 4 GB: not in the chars' index width below)
+    // CharacterType of the chars a Japanese text is made of, as nibbles in LDS: ASCII, U+3000 .. 30FF (punctuation, hiragana, katakana), U+FF00 .. FFFF
+    // (fullwidth and halfwidth forms); the main block of kanji is one compare; anything else is rare and takes char_type's twenty range tests -- which
+    // every char of a wave took before: 45 of the 80 vector instructions a char cost, in a kernel that ran at the vector ALU's issue rate (round 6)
+    if (tid < 80u) {
+        const uint32_t c0 = tid < 16u ? 8u * tid : tid < 48u ? 0x3000u + 8u * (tid - 16u) : 0xFF00u + 8u * (tid - 48u);
+        uint32_t w = 0;
+        for (uint32_t j = 0; j < 8u; ++j) w |= char_type(c0 + j) << (4u * j);
+        tlut[tid] = w;
+    }
+    __syncthreads();
     uint64_t p_start = 0, p_end = 0, carry = 0;
     const uintptr_t t_lo = reinterpret_cast<uintptr_t>(text) + B0, t_hi = reinterpret_cast<uintptr_t>(text) + B1;
+    // (the run's chars from its first: 32 bits -- a run is a few sentences -- against what the batch's arrays hold behind it)
+    const uint32_t room = total_chars - G0 < 0xFFFFFFFFull ? uint32_t(total_chars - G0) : 0xFFFFFFFFu;
+    uint32_t* const cps_run = cps ? cps + G0 : nullptr;
+    uint8_t* const types_run = types ? types + G0 : nullptr;
     for (uintptr_t piece = t_lo & ~uintptr_t(15); piece < t_hi; piece += kDecodePiece) {
         const uintptr_t a = piece + 16u * tid;
         uint32_t d[5] = {0, 0, 0, 0, 0};
@@ -135,30 +150,31 @@ __global__ __launch_bounds__(kTagThreads) void decode_chars_kernel(const uint8_t
         const uint32_t excl = woff + incl - cnt;
         pfx[tid] = excl;
         __syncthreads();
-        // ---- this chunk's chars: decoded from registers, a dword of the chunk at a time
-        uint64_t dest = G0 + carry + excl;
-#pragma unroll
-        for (uint32_t q = 0; q < 4; ++q) {
-            uint32_t m = (lm >> (4 * q)) & 15u;
-            while (m) {
-                const uint32_t k = uint32_t(__builtin_ctz(m));
-                m &= m - 1u;
-                const uint32_t w = __builtin_amdgcn_alignbyte(d[q + 1], d[q], k);
-                const uint32_t cp = utf8_scalar(w);
-                // the char it is scored as | its CharacterType: a word of the char table -- asked for only where the table can differ from the
-                // identity (with KyteaFullwidthFilter: ASCII, U+2000 .. 25FF, U+FF00 .. FFEF hold every char the filter rewrites,
-                // kytea_fullwidth.rs:13-117); anything else is itself and its type is arithmetic.  A gather per char -- one miss of the vector
-                // L1 each -- was what the launch ran at (0.47 ms on configs[4], profiles/r06_o_*).
-                const bool mapped = fullwidth && cp < 0x10000u && (cp < 0x80u || (cp - 0x2000u) < 0x600u || (cp - 0xFF00u) < 0xF0u);
-                uint32_t scored = cp, ty;
-                if (mapped) { const uint32_t info = cinfo[cp]; scored = info & 0xFFFFu; ty = info >> 16; }
+        // ---- this chunk's chars, one after the other (a wave walks as many as its fullest chunk holds: six of CJK text), decoded from registers
+        uint32_t dest = uint32_t(carry) + excl;   // (carry < 2^32: the run's chars so far)
+        for (uint32_t rem = lm; rem != 0; rem &= rem - 1u) {
+            const uint32_t k = uint32_t(__builtin_ctz(rem)), q = k >> 2;
+            const uint32_t w0 = q == 0 ? d[0] : q == 1 ? d[1] : q == 2 ? d[2] : d[3], w1 = q == 0 ? d[1] : q == 1 ? d[2] : q == 2 ? d[3] : d[4];
+            const uint32_t cp = utf8_scalar(__builtin_amdgcn_alignbyte(w1, w0, k));
+            // the char it is scored as | its CharacterType: a word of the char table -- asked for only where the table can differ from the
+            // identity (with KyteaFullwidthFilter: ASCII, U+2000 .. 25FF, U+FF00 .. FFEF hold every char the filter rewrites,
+            // kytea_fullwidth.rs:13-117); anything else is itself and its type is arithmetic.  A gather per char -- one miss of the vector
+            // L1 each -- was what the launch ran at (0.47 ms on configs[4], profiles/r06_o_*).
+            const bool mapped = fullwidth && cp < 0x10000u && (cp < 0x80u || (cp - 0x2000u) < 0x600u || (cp - 0xFF00u) < 0xF0u);
+            uint32_t scored = cp, ty;
+            if (mapped) { const uint32_t info = cinfo[cp]; scored = info & 0xFFFFu; ty = info >> 16; }
+            else if (cp - 0x4E00u <= 0x9FFFu - 0x4E00u) ty = 5u;
+            else {
+                const uint32_t page = cp >> 8;
+                const uint32_t idx = cp < 0x80u ? cp : page == 0x30u ? 128u + (cp & 0xFFu) : page == 0xFFu ? 384u + (cp & 0xFFu) : ~0u;
+                if (idx != ~0u) ty = (tlut[idx >> 3] >> (4u * (idx & 7u))) & 15u;
                 else ty = char_type(cp);
-                if (dest < total_chars) {
-                    if (cps) cps[dest] = scored | (ty << 24);
-                    if (types) types[dest] = uint8_t(ty);   // Sentence::char_types (sentence.rs:1016)
-                }
-                ++dest;
             }
+            if (dest < room) {
+                if (cps_run) cps_run[dest] = scored | (ty << 24);
+                if (types_run) types_run[dest] = uint8_t(ty);   // Sentence::char_types (sentence.rs:1016)
+            }
+            ++dest;
         }
         // ---- the sentences' char counts against their offsets
         auto before = [&](uintptr_t x) -> uint32_t {   // leads of the piece in front of byte x (piece <= x <= piece + kDecodePiece)
