@@ -1649,12 +1649,12 @@ def test_write_tagged_text_on_device():
         batch.sync()
 
 
-@pytest.mark.parametrize("per_block", [1, 3, 64, 256])
+@pytest.mark.parametrize("per_block", [1, 3, 64, 256, 300, 512])
 def test_writer_blocks_of_any_size(per_block, monkeypatch):
     """The writer takes runs of consecutive sentences, a workgroup each (kernels_emit.hip, emit_flat_kernel, with and without tags); the run
     size comes from the mean sentence length (with tags: a whole multiple of fill_tags' runs, so that a workgroup's tag records are one slice
     named by two prefix words) -- here it is forced (VPT_EMIT_PER_BLOCK, read when a workspace is made) to sizes that are NO such multiple:
-    one sentence per run, a few, 64, 256; sentences of 1 .. 13 000 chars (several 4 KB pieces of a workgroup's walk) with escapes, 1- to
+    one sentence per run, a few, 64, 256, more than a thread each (300, 512: two sentences a thread); sentences of 1 .. 13 000 chars (several 4 KB pieces of a workgroup's walk) with escapes, 1- to
     4-byte chars, every alignment of text, labels and output."""
     monkeypatch.setenv("VPT_EMIT_PER_BLOCK", str(per_block))
     m = randmodel.rand_model(843, alphabet="kana", wc=3, wt=3, n_tag_models=30, max_word=3, n_char=60, n_dict=60)

@@ -325,11 +325,11 @@ vpt_status emit_device(const vpt_predictor* p, vpt_batch* b, const uint8_t* d_ut
     // A WORKGROUP per run of sentences (emit_flat_kernel, round 5; a wave per block of 2 K chars before): 5 K chars when the batch is small (the
     // chip wants a thousand workgroups and more), up to 20 K on a big one -- fewer look-backs and size passes per byte (measured,
     // profiles/r05_h_*, r05_k_*, r06_t_*: configs[2] 2.03 ms at 128 sentences, 1.80 at 256; tagged configs[4] 2.39 / 2.10 / 2.04 at 5 K / 10 K / 20 K
-    // chars); at most 256 sentences.  With tags: a whole multiple of fill_tags' runs, so that a workgroup's records are run_pref[a] .. run_pref[b].
+    // chars; without tags up to 32 K chars: 512 sentences of 64, `r06_zv_*`); at most 512 sentences (two a thread).  With tags: a whole multiple of fill_tags' runs, so that a workgroup's records are run_pref[a] .. run_pref[b].
     vpt::EmitFuse F{};
     {
         const uint64_t chars = total_boundaries + n_sentences;
-        const uint64_t auto_run = std::min<uint64_t>(std::max<uint64_t>(chars / (uint64_t(16) * std::max<uint32_t>(p->n_cus, 64)), 5120), 20480);
+        const uint64_t auto_run = std::min<uint64_t>(std::max<uint64_t>(chars / (uint64_t(16) * std::max<uint32_t>(p->n_cus, 64)), 5120), E.records ? 20480 : 32768);
         const uint64_t target = auto_run;
         uint64_t per = std::min<uint64_t>(std::max<uint64_t>((target * n_sentences + chars / 2) / chars, 1), vpt::kEmitFlatMaxBlock);   // round(target / mean chars per sentence)
         if (E.records && E.run_sent <= vpt::kEmitFlatMaxBlock)

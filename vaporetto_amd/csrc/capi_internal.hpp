@@ -53,7 +53,7 @@ struct BatchKnobs {
     uint32_t tile_flat = 0;             // VPT_TILE_FLAT: flat positions per tile (tests: cuts at many places; never above what fits)
     uint32_t debug_ablate = 0;          // VPT_DEBUG_ABLATE
     bool profile_phases = false;        // VPT_PROFILE_PHASES
-    uint32_t emit_per_block = 0;        // VPT_EMIT_PER_BLOCK: sentences a workgroup of the writer takes (1..256; 0: from the mean sentence length) -- tests: runs of any size
+    uint32_t emit_per_block = 0;        // VPT_EMIT_PER_BLOCK: sentences a workgroup of the writer takes (1..512; 0: from the mean sentence length) -- tests: runs of any size
 };
 PredictorKnobs read_predictor_knobs() {
     PredictorKnobs k;
@@ -68,7 +68,7 @@ BatchKnobs read_batch_knobs() {
     k.force_generic = std::getenv("VPT_FORCE_GENERIC") != nullptr;
     if (const char* v = std::getenv("VPT_FORCE_CUT_TILES")) k.force_cut = std::atoi(v);
     if (const char* v = std::getenv("VPT_TILE_FLAT")) k.tile_flat = uint32_t(std::max(0, std::atoi(v)));
-    if (const char* v = std::getenv("VPT_EMIT_PER_BLOCK")) k.emit_per_block = uint32_t(std::min(256, std::max(0, std::atoi(v))));
+    if (const char* v = std::getenv("VPT_EMIT_PER_BLOCK")) k.emit_per_block = uint32_t(std::min(512, std::max(0, std::atoi(v))));
     if (const char* v = std::getenv("VPT_DEBUG_ABLATE")) k.debug_ablate = uint32_t(std::atoi(v));
     k.profile_phases = std::getenv("VPT_PROFILE_PHASES") != nullptr;
     return k;

@@ -187,7 +187,7 @@ struct EmitParams {
 // scan_part: workspace of scan_part_entries(n_sent) uint64 (the prefix sum's per-workgroup partials)
 size_t scan_part_entries(uint64_t n);
 // The writer's launch (emit_flat_kernel): a WORKGROUP per run of `per_block` consecutive sentences (1 .. kEmitFlatMaxBlock)
-constexpr uint32_t kEmitFlatMaxBlock = 256;
+constexpr uint32_t kEmitFlatMaxBlock = 512;   // (two sentences a thread)
 struct EmitFuse {
     uint64_t* state;        // n_blocks + 1 words, ZERO when the kernel starts: the blocks' sizes / positions and the ticket
     uint64_t* clear;        // the state words of the NEXT call (the other of two arrays), zeroed by this one: [0, clear_n)

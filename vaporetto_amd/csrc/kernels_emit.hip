@@ -308,15 +308,22 @@ __global__ __launch_bounds__(kEmitThreads, kTags ? VPT_EMIT_TAG_OCC : VPT_EMIT_O
     if (blk >= F.n_blocks) return;
     const uint64_t i0 = blk * F.per_block;
     const uint32_t ns = uint32_t(P.n_sent - i0 < F.per_block ? P.n_sent - i0 : F.per_block);
-    // the run's offsets: thread j holds sentence i0 + j's and its successor's
-    uint64_t my_b = ~uint64_t(0), my_o = 0, nx_b = 0, nx_o = 0;
-    const bool mine = tid < ns;
-    if (mine) { my_b = P.boff[i0 + tid]; my_o = P.ooff[i0 + tid]; nx_b = P.boff[i0 + tid + 1]; nx_o = P.ooff[i0 + tid + 1]; }
-    if (tid == 0) { L.bcast[1] = my_b; L.bcast[2] = my_o; }
-    if (tid == ns - 1) { L.red[0] = nx_b; L.red[1] = nx_o; }
+    // the run's offsets: thread j holds sentences i0 + j and i0 + kEmitThreads + j (and their successors')
+    constexpr uint32_t kMine = kEmitFlatMaxBlock / kEmitThreads;
+    static_assert(kMine * kEmitThreads == kEmitFlatMaxBlock, "sentences per thread");
+    uint64_t my_b[kMine], my_o[kMine];
+    bool mine[kMine];
     uint32_t err = 0;
-    {
-        const bool empty = mine && nx_b <= my_b, bad = mine && (nx_o < my_o || nx_o > P.total_boundaries);
+#pragma unroll
+    for (uint32_t j = 0; j < kMine; ++j) {
+        const uint32_t s = tid + j * kEmitThreads;
+        mine[j] = s < ns;
+        uint64_t nx_b = 0, nx_o = 0;
+        my_b[j] = ~uint64_t(0); my_o[j] = 0;
+        if (mine[j]) { my_b[j] = P.boff[i0 + s]; my_o[j] = P.ooff[i0 + s]; nx_b = P.boff[i0 + s + 1]; nx_o = P.ooff[i0 + s + 1]; }
+        if (s == 0) { L.bcast[1] = my_b[j]; L.bcast[2] = my_o[j]; }
+        if (s == ns - 1) { L.red[0] = nx_b; L.red[1] = nx_o; }
+        const bool empty = mine[j] && nx_b <= my_b[j], bad = mine[j] && (nx_o < my_o[j] || nx_o > P.total_boundaries);
         if (empty) err |= kErrEmptySentence;
         if (bad) err |= kErrBadOffsets;
         if (empty || bad) atomicOr(&L.flags, 1u);
@@ -325,7 +332,8 @@ __global__ __launch_bounds__(kEmitThreads, kTags ? VPT_EMIT_TAG_OCC : VPT_EMIT_O
     const uint64_t B0 = L.bcast[1], O0 = L.bcast[2], B1 = L.red[0], O1 = L.red[1];
     const bool sane = L.flags == 0 && O1 - O0 < 0xFFFF0000ull && B1 - B0 < 0xFFFF0000ull;
     if (!sane) err |= kErrBadOffsets;
-    if (mine) L.so[tid] = uint32_t(my_o - O0);
+#pragma unroll
+    for (uint32_t j = 0; j < kMine; ++j) if (mine[j]) L.so[tid + j * kEmitThreads] = uint32_t(my_o[j] - O0);
     if (tid == 0) L.so[ns] = uint32_t(O1 - O0);
     __syncthreads();   // (red[] is used again below)
 
@@ -408,14 +416,17 @@ __global__ __launch_bounds__(kEmitThreads, kTags ? VPT_EMIT_TAG_OCC : VPT_EMIT_O
         if (F.chain_out) *F.chain_out = end;
     }
     if (!sane) {
-        if (mine) P.out_offsets[i0 + tid] = base;
+#pragma unroll
+        for (uint32_t j = 0; j < kMine; ++j) if (mine[j]) P.out_offsets[i0 + tid + j * kEmitThreads] = base;
         if (err) atomicOr(P.status, err);
         return;
     }
 
     // ---- the pieces: every byte of the run to its place
     uint8_t* const sbytes = reinterpret_cast<uint8_t*>(L.stage);
-    const uint32_t my_rel = mine ? uint32_t(my_b - B0) + lo_rel : 0u;   // where the thread's sentence starts, from tb
+    uint32_t my_rel[kMine];   // where the thread's sentences start, from tb (far away: none)
+#pragma unroll
+    for (uint32_t j = 0; j < kMine; ++j) my_rel[j] = mine[j] ? uint32_t(my_b[j] - B0) + lo_rel : 0xFFFFFFFFu;
     uint64_t at_out = base, cb = 0, sb = 0;   // output position, chars and sentence starts of the run in front of the piece
     bool fits = true;
     uint64_t rp = r_lo;                       // with tags: the first record not yet behind the pieces done (the same in every thread) ...
@@ -433,9 +444,12 @@ __global__ __launch_bounds__(kEmitThreads, kTags ? VPT_EMIT_TAG_OCC : VPT_EMIT_O
             reinterpret_cast<uint4*>(L.labs)[tid] = a < lim ? *reinterpret_cast<const uint4*>(lab_al + a) : make_uint4(0, 0, 0, 0);
             if (tid < 4) reinterpret_cast<uint4*>(L.labs)[kEmitThreads + tid] = a2 < lim ? *reinterpret_cast<const uint4*>(lab_al + a2) : make_uint4(0, 0, 0, 0);
         }
-        if (mine && my_rel - p_off < kFlatPiece) {   // (unsigned: a start in front of the piece is far behind it)
-            const uint32_t r = my_rel - p_off;
-            atomicOr(&L.starts[r >> 5], 1u << (r & 31u));
+#pragma unroll
+        for (uint32_t j = 0; j < kMine; ++j) {
+            if (mine[j] && my_rel[j] - p_off < kFlatPiece) {   // (unsigned: a start in front of the piece is far behind it)
+                const uint32_t r = my_rel[j] - p_off;
+                atomicOr(&L.starts[r >> 5], 1u << (r & 31u));
+            }
         }
         __syncthreads();
         uint32_t sm = (L.starts[tid >> 1] >> (16 * (tid & 1))) & 0xFFFFu;
